@@ -1,0 +1,59 @@
+#!/usr/bin/env bash
+# build_ref.sh -- TEST INFRASTRUCTURE. Compiles the reference's own LibTorch CPU path
+# (from the sources where they lie under /root/reference/src) together with
+# oracle/ref/ref_driver.cpp into oracle/_ref/ref_driver.
+#
+#   * No reference source is copied into this repository; outputs go only to oracle/_ref/
+#     (git-ignored; travels to the GPU box like the repo's own built .so files).
+#   * No stand-in headers or libraries are written.  Two reference files cannot be fed to
+#     g++ on Linux verbatim, so they are FILTERED ON THE FLY into a mktemp dir that is
+#     deleted at exit:
+#       - NeRF.cpp:236  `torch::tensor({(1ll << ...) - 1ll}, kLong)` is ambiguous where
+#         int64_t is `long` (the reference is MSVC-flavoured); the literal gets an
+#         int64_t cast.  Arithmetic unchanged.
+#       - NeRFRenderer.h:7-9,46-68  three <opencv2/...> includes and the two cv::Mat <->
+#         Tensor image helpers (CVMatToTorchTensor / TorchTensorToCVMat) are deleted.
+#         They are image I/O for the caller (NeRFExecutor::RenderPath), not on the
+#         render path; OpenCV is absent from this image.  Every line of
+#         Render/BatchifyRays/RenderRays/RunNetwork/RawToOutputs compiles unmodified.
+#   * CUDA-only units (CuHashEmbedder.cu, CuSHEncoder.cu) and units that need RuCLIP /
+#     COLMAP / OpenCV proper (NeRFExecutor.h, LeRFRenderer.cpp, loaders) are NOT built:
+#     unbuildable here.
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+REF="${NRF_REFERENCE_DIR:-/root/reference}/src"
+if [ ! -d "$REF" ]; then
+  echo "build_ref.sh: $REF not present (GPU box?) -- keeping prebuilt oracle/_ref if any" >&2
+  exit 0
+fi
+T="$(python3 -c 'import torch,os;print(os.path.dirname(torch.__file__))')"
+out="$here/_ref"
+mkdir -p "$out"
+tmp="$(mktemp -d)"
+trap 'rm -rf "$tmp"' EXIT
+
+# filtered header (see above); everything else is included straight from $REF
+sed -e '/^#include <opencv2\//d' \
+    -e '/^inline torch::Tensor CVMatToTorchTensor/,/^}/d' \
+    -e '/^inline cv::Mat TorchTensorToCVMat/,/^}/d' \
+    "$REF/NeRFRenderer.h" > "$tmp/NeRFRenderer.h"
+if grep -q 'cv::' "$tmp/NeRFRenderer.h"; then echo "filter failed: cv:: still referenced" >&2; exit 1; fi
+
+CXX="${CXX:-g++}"
+FLAGS="-std=c++17 -O2 -fPIC -D_GLIBCXX_USE_CXX11_ABI=1 -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -w"
+INC="-I$tmp -I$REF -I$REF/LibTorchTraining -I$REF/Common -I$here/../include -I$T/include -I$T/include/torch/csrc/api/include -I/opt/rocm/include"
+LIBS="-L$T/lib -Wl,-rpath,$T/lib -ltorch -ltorch_cpu -lc10"
+
+# objects are cached in oracle/_ref/obj (object code only); rebuilt when the source is newer
+mkdir -p "$out/obj"
+stale() { [ ! -f "$1" ] || [ "$2" -nt "$1" ] || [ "$0" -nt "$1" ]; }
+if stale "$out/obj/NeRF.o" "$REF/NeRF.cpp"; then
+  sed -e 's/torch::tensor({(1ll << static_cast<long long>(log2_hashmap_size)) - 1ll}, torch::kLong)/torch::tensor({static_cast<int64_t>((1ll << static_cast<long long>(log2_hashmap_size)) - 1ll)}, torch::kLong)/' \
+      "$REF/NeRF.cpp" | $CXX $FLAGS $INC -x c++ -c - -o "$out/obj/NeRF.o" &
+fi
+if stale "$out/obj/CustomOps.o" "$REF/CustomOps.cpp"; then $CXX $FLAGS $INC -c "$REF/CustomOps.cpp" -o "$out/obj/CustomOps.o" & fi
+if stale "$out/obj/LeRF.o" "$REF/LeRF.cpp"; then $CXX $FLAGS $INC -c "$REF/LeRF.cpp" -o "$out/obj/LeRF.o" & fi
+if stale "$out/obj/ref_driver.o" "$here/ref/ref_driver.cpp"; then $CXX $FLAGS $INC -c "$here/ref/ref_driver.cpp" -o "$out/obj/ref_driver.o" & fi
+wait
+$CXX -o "$out/ref_driver" "$out/obj/ref_driver.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" "$out/obj/LeRF.o" $LIBS
+echo "built $out/ref_driver"

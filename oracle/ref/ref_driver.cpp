@@ -1,0 +1,603 @@
+// ref_driver.cpp -- TEST INFRASTRUCTURE (not product code).
+//
+// Drives the *reference's own* LibTorch CPU path (compiled from the sources where
+// they lie under /root/reference/src by oracle/build_ref.sh) to
+//   (1) emit golden input/output vectors for every hot-path stage  ("golden <dir>")
+//   (2) time the reference CPU renderer for bench.py's cpu_baseline  ("bench ...").
+//
+// Nothing in here restates reference arithmetic: every number written to a golden
+// file is produced by a function or class of the reference (RayUtils.h, Sampler.h,
+// NeRF.{h,cpp}, CustomOps.{h,cpp}, LeRF.{h,cpp}, NeRFRenderer.h), except the few
+// arrays explicitly prefixed "aux_" which are derived with the same ATen ops in the
+// same order as the cited reference lines, to expose values the reference keeps local.
+//
+// Model parameters are NOT random: they are filled from include/nrf_synth.h so the
+// tests can regenerate them on the GPU box without shipping multi-megabyte blobs.
+
+#include "NeRF.h"
+#include "LeRF.h"
+#include "Sampler.h"
+#include "CustomOps.h"
+#include "NeRFRenderer.h"   // filtered copy (OpenCV image helpers removed), see build_ref.sh
+
+#include "nrf_synth.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <iostream>
+#include <map>
+
+using torch::indexing::Slice;
+using torch::indexing::None;
+
+// ----------------------------------------------------------------------------------------------
+// .npy writer (v1.0, C order)
+// ----------------------------------------------------------------------------------------------
+static std::string g_outdir;
+static std::ofstream g_manifest;
+
+static void save_npy(const std::string &name, torch::Tensor t)
+{
+	t = t.detach().cpu().contiguous();
+	std::string descr;
+	if (t.scalar_type() == torch::kFloat32) descr = "<f4";
+	else if (t.scalar_type() == torch::kFloat64) descr = "<f8";
+	else if (t.scalar_type() == torch::kInt64) descr = "<i8";
+	else if (t.scalar_type() == torch::kInt32) descr = "<i4";
+	else if (t.scalar_type() == torch::kBool) descr = "|b1";
+	else if (t.scalar_type() == torch::kUInt8) descr = "|u1";
+	else { std::cerr << "save_npy: unsupported dtype for " << name << std::endl; std::exit(2); }
+	std::ostringstream shape;
+	shape << "(";
+	for (int64_t i = 0; i < t.dim(); i++) { shape << t.size(i) << ","; }
+	shape << ")";
+	std::string hdr = "{'descr': '" + descr + "', 'fortran_order': False, 'shape': " + shape.str() + ", }";
+	size_t total = 10 + hdr.size() + 1;
+	size_t pad = (64 - total % 64) % 64;
+	hdr += std::string(pad, ' ');
+	hdr += "\n";
+	std::ofstream f(g_outdir + "/" + name + ".npy", std::ios::binary);
+	const char magic[] = "\x93NUMPY";
+	f.write(magic, 6);
+	char ver[2] = {1, 0};
+	f.write(ver, 2);
+	uint16_t hl = (uint16_t)hdr.size();
+	f.write(reinterpret_cast<char*>(&hl), 2);
+	f.write(hdr.data(), hdr.size());
+	f.write(reinterpret_cast<const char*>(t.data_ptr()), t.numel() * t.element_size());
+}
+
+static void save_scalar(const std::string &name, double v) { save_npy(name, torch::tensor({(float)v})); }
+
+// ----------------------------------------------------------------------------------------------
+// synthetic parameters (include/nrf_synth.h); a manifest line per tensor lets the tests
+// rebuild exactly the same tensors in numpy.
+// ----------------------------------------------------------------------------------------------
+static void fill_synth(torch::Tensor p, uint32_t seed, float amp)
+{
+	torch::NoGradGuard ng;
+	auto flat = torch::empty({p.numel()}, torch::kFloat32);
+	float *d = flat.data_ptr<float>();
+	for (int64_t i = 0; i < p.numel(); i++)
+		d[i] = nrf_synth_sym(seed, (uint32_t)i, amp);
+	p.copy_(flat.view(p.sizes()));
+}
+
+// gain<0 : absolute amplitude |gain|;  else xavier-uniform-like amplitude gain*sqrt(6/(fan_in+fan_out))
+template <class M>
+static void fill_module(const std::string &model_tag, M &module, uint32_t base_seed, float w_gain, float bias_amp,
+	const std::map<std::string, float> &per_tensor_scale = {})
+{
+	int k = 0;
+	for (auto &p : module->named_parameters())
+	{
+		auto t = p.value();
+		float amp;
+		if (t.dim() == 2 && p.key().find("embeddings") == std::string::npos)
+			amp = w_gain * std::sqrt(6.0f / float(t.size(0) + t.size(1)));
+		else if (t.dim() == 2)
+			amp = w_gain;		//embedding tables: w_gain is the absolute amplitude
+		else
+			amp = bias_amp;
+		for (auto &kv : per_tensor_scale)
+			if (p.key().find(kv.first) != std::string::npos)
+				amp *= kv.second;
+		uint32_t seed = base_seed + 1000u * (uint32_t)k;
+		fill_synth(t, seed, amp);
+		g_manifest << model_tag << " " << p.key() << " " << seed << " " << std::setprecision(9) << amp;
+		for (int64_t i = 0; i < t.dim(); i++) g_manifest << " " << t.size(i);
+		g_manifest << "\n";
+		k++;
+	}
+}
+
+static torch::Tensor synth_tensor(std::vector<int64_t> shape, uint32_t seed, float amp, float offset = 0.f)
+{
+	int64_t n = 1; for (auto s : shape) n *= s;
+	auto t = torch::empty({n}, torch::kFloat32);
+	float *d = t.data_ptr<float>();
+	for (int64_t i = 0; i < n; i++) d[i] = nrf_synth_sym(seed, (uint32_t)i, amp) + offset;
+	return t.view(shape);
+}
+
+// ----------------------------------------------------------------------------------------------
+// inputs: Lego-shaped camera. Input generators only -- nothing here is graded.
+// ----------------------------------------------------------------------------------------------
+static torch::Tensor lego_K(int h, int w)
+{
+	const float cax = 0.6911112f;
+	float focal = 0.5f * w / std::tan(0.5f * cax);
+	float kdata[] = { focal, 0, 0.5f * w, 0, focal, 0.5f * h, 0, 0, 1 };
+	return torch::from_blob(kdata, {3, 3}).clone();
+}
+
+static torch::Tensor orbit_pose(float theta_deg, float phi_deg, float radius)
+{
+	// camera on a sphere looking at the origin, blender convention; an input generator
+	const float PI_ = std::acos(-1.0f);
+	float th = theta_deg / 180.f * PI_, ph = phi_deg / 180.f * PI_;
+	float t_[] = {1,0,0,0, 0,1,0,0, 0,0,1,radius, 0,0,0,1};
+	float rp[] = {1,0,0,0, 0,std::cos(ph),-std::sin(ph),0, 0,std::sin(ph),std::cos(ph),0, 0,0,0,1};
+	float rt[] = {std::cos(th),0,-std::sin(th),0, 0,1,0,0, std::sin(th),0,std::cos(th),0, 0,0,0,1};
+	float fl[] = {-1,0,0,0, 0,0,1,0, 0,1,0,0, 0,0,0,1};
+	auto c2w = torch::from_blob(t_, {4,4}).clone();
+	c2w = torch::matmul(torch::from_blob(rp, {4,4}).clone(), c2w);
+	c2w = torch::matmul(torch::from_blob(rt, {4,4}).clone(), c2w);
+	c2w = torch::matmul(torch::from_blob(fl, {4,4}).clone(), c2w);
+	return c2w.index({Slice(None, 3), Slice(None, 4)}).contiguous();
+}
+
+// ----------------------------------------------------------------------------------------------
+// Spy: the reference renderer with its protected virtuals opened up and every
+// intermediate recorded. All arithmetic is Base::.
+// ----------------------------------------------------------------------------------------------
+template <class E, class D, class M>
+struct Spy : public NeRFRenderer<E, D, M>
+{
+	using Base = NeRFRenderer<E, D, M>;
+	Spy(E e, D d, M m) : Base(e, d, m) {}
+	std::vector<torch::Tensor> net_pts, net_raw, r2o_raw, r2o_z, r2o_d, batch_rays;
+	std::vector<NeRFRendererOutputs> r2o_out;
+
+	torch::Tensor RunNetwork(torch::Tensor inputs, torch::Tensor view_dirs, M fn, E embed_fn, D embeddirs_fn) override
+	{
+		auto out = Base::RunNetwork(inputs, view_dirs, fn, embed_fn, embeddirs_fn);
+		net_pts.push_back(inputs.detach().clone());
+		net_raw.push_back(out.detach().clone());
+		return out;
+	}
+	NeRFRendererOutputs RawToOutputs(torch::Tensor raw, torch::Tensor cone_angle, torch::Tensor z_vals, torch::Tensor rays_d,
+		const float raw_noise_std = 0.f, const bool white_bkgr = false) override
+	{
+		auto out = Base::RawToOutputs(raw, cone_angle, z_vals, rays_d, raw_noise_std, white_bkgr);
+		r2o_raw.push_back(raw.detach().clone());
+		r2o_z.push_back(z_vals.detach().clone());
+		r2o_d.push_back(rays_d.detach().clone());
+		r2o_out.push_back(out);
+		return out;
+	}
+	NeRFRenderResult BatchifyRays(torch::Tensor rays_flat, torch::Tensor cone_angle, const int n_samples, const int chunk = 1024 * 32,
+		const bool return_raw = false, const bool lin_disp = false, const float perturb = 0.f, const int n_importance = 0,
+		const bool white_bkgr = false, const float raw_noise_std = 0., const float spa = 0.f,
+		torch::Tensor bounding_box = torch::Tensor(), const bool return_weights = true) override
+	{
+		batch_rays.push_back(rays_flat.detach().clone());
+		return Base::BatchifyRays(rays_flat, cone_angle, n_samples, chunk, return_raw, lin_disp, perturb, n_importance, white_bkgr,
+			raw_noise_std, spa, bounding_box, return_weights);
+	}
+	NeRFRendererOutputs OpenRawToOutputs(torch::Tensor raw, torch::Tensor z_vals, torch::Tensor rays_d, bool white)
+	{
+		return Base::RawToOutputs(raw, torch::Tensor(), z_vals, rays_d, 0.f, white);
+	}
+};
+
+static void save_outputs(const std::string &prefix, const NeRFRendererOutputs &o)
+{
+	if (o.RGBMap.defined()) save_npy(prefix + "rgb", o.RGBMap);
+	if (o.DispMap.defined()) save_npy(prefix + "disp", o.DispMap);
+	if (o.AccMap.defined()) save_npy(prefix + "acc", o.AccMap);
+	if (o.Weights.defined()) save_npy(prefix + "weights", o.Weights);
+	if (o.DepthMap.defined()) save_npy(prefix + "depth", o.DepthMap);
+}
+
+static torch::Tensor lego_bbox() { return torch::tensor({-1.5f, -1.5f, -1.5f, 1.5f, 1.5f, 1.5f}); }
+
+static NeRFRenderParams lego_params(int ns, int ni, int chunk)
+{
+	NeRFRenderParams rp;
+	rp.NSamples = ns; rp.NImportance = ni; rp.Chunk = chunk;
+	rp.ReturnRaw = true; rp.LinDisp = false; rp.Perturb = 0.f; rp.WhiteBkgr = true; rp.RawNoiseStd = 0.f;
+	rp.Ndc = false; rp.UseViewdirs = true; rp.ReturnWeights = true; rp.ThinRay = true; rp.RenderFactor = 0;
+	rp.BoundingBox = lego_bbox();
+	rp.StochasticPreconditioningAlpha = 0.f;
+	return rp;
+}
+
+// ----------------------------------------------------------------------------------------------
+// golden groups
+// ----------------------------------------------------------------------------------------------
+static void g_rays()
+{
+	// R1: GetDirections + GetRays (RayUtils.h:5-46), non-square to pin row-major (y outer, x inner)
+	const int h = 6, w = 10;
+	auto k = lego_K(h, w);
+	auto c2w = orbit_pose(30.f, -30.f, 4.f);
+	auto [o, d, cone] = GetRays(h, w, k, c2w);
+	save_npy("rays.k", k); save_npy("rays.c2w", c2w);
+	save_npy("rays.hw", torch::tensor({h, w}, torch::kInt32));
+	save_npy("rays.o", o.contiguous()); save_npy("rays.d", d); save_npy("rays.cone", cone.reshape({1}));
+	// R2: NDCRays (RayUtils.h:49-83) on the same rays
+	auto [no, nd, nc] = NDCRays(h, w, k[0][0].item<float>(), 1.f, o, d, cone);
+	save_npy("rays.ndc_o", no); save_npy("rays.ndc_d", nd); save_npy("rays.ndc_cone", nc);
+	// second camera: 8x8 Lego view used by the render goldens
+	const int h2 = 8, w2 = 8;
+	auto k2 = lego_K(h2, w2);
+	auto c2 = orbit_pose(-63.f, -30.f, 4.f);
+	auto [o2, d2, cone2] = GetRays(h2, w2, k2, c2);
+	save_npy("rays.k2", k2); save_npy("rays.c2w2", c2);
+	save_npy("rays.o2", o2.contiguous()); save_npy("rays.d2", d2); save_npy("rays.cone2", cone2.reshape({1}));
+}
+
+static void g_aabb()
+{
+	// R3: IntersectWithAABB (RayUtils.h:87-126)
+	auto bbox = lego_bbox();
+	auto o = synth_tensor({48, 3}, 11u, 4.0f);
+	auto d = synth_tensor({48, 3}, 12u, 1.0f);
+	{
+		// hand-placed edge cases: axis-parallel, zero and -1e-6 components, origin inside the box, rays pointing away
+		auto oa = o.accessor<float, 2>(); auto da = d.accessor<float, 2>();
+		oa[0][0] = 0; oa[0][1] = 0; oa[0][2] = 4;  da[0][0] = 0; da[0][1] = 0; da[0][2] = -1;
+		oa[1][0] = 0; oa[1][1] = 0; oa[1][2] = 4;  da[1][0] = 0; da[1][1] = 0; da[1][2] = 1;		//points away
+		oa[2][0] = 0.2f; oa[2][1] = -0.3f; oa[2][2] = 0.1f;  da[2][0] = 0.3f; da[2][1] = 0.5f; da[2][2] = -0.2f;	//inside
+		oa[3][0] = 5; oa[3][1] = 5; oa[3][2] = 5;  da[3][0] = 1; da[3][1] = 0; da[3][2] = 0;			//misses
+		oa[4][0] = -4; oa[4][1] = 0.5f; oa[4][2] = 0.5f;  da[4][0] = 1; da[4][1] = -1e-6f; da[4][2] = 0;	//d+1e-6 == 0
+		oa[5][0] = 1.5f; oa[5][1] = 1.5f; oa[5][2] = 4;  da[5][0] = 0; da[5][1] = 0; da[5][2] = -1;		//grazes an edge
+	}
+	auto [nears, fars] = IntersectWithAABB(o, d, bbox, 0.f);
+	save_npy("aabb.bbox", bbox); save_npy("aabb.o", o); save_npy("aabb.d", d);
+	save_npy("aabb.near", nears); save_npy("aabb.far", fars);
+}
+
+static void g_sample_pdf()
+{
+	// R8: SamplePDF (Sampler.h:6-43), deterministic (det=true <=> Perturb==0, NeRFRenderer.h:428)
+	const int n = 16, nb = 63;
+	auto near = synth_tensor({n, 1}, 21u, 0.5f, 2.5f);
+	auto far = near + synth_tensor({n, 1}, 22u, 1.0f, 2.5f);
+	auto t = torch::linspace(0.f, 1.f, 64, torch::kFloat);
+	auto z = near * (1.f - t) + far * t;
+	auto bins = .5 * (z.index({"...", Slice(1, None)}) + z.index({"...", Slice(None, -1)}));
+	auto w = torch::abs(synth_tensor({n, nb - 1}, 23u, 1.0f));
+	{
+		auto wa = w.accessor<float, 2>();
+		for (int j = 0; j < nb - 1; j++) { wa[0][j] = 0.f; wa[1][j] = 1.f; wa[2][j] = (j == 30) ? 1.f : 0.f; wa[3][j] = (j == 0) ? 5.f : 0.f; wa[4][j] = (j == nb - 2) ? 0.25f : 0.f; }
+		for (int j = 0; j < nb - 1; j++) { wa[5][j] = std::exp(-0.5f * (j - 20.f) * (j - 20.f) / 4.f); wa[6][j] = 1e-9f * j; wa[7][j] = (j % 7 == 0) ? 0.3f : 1e-6f; }
+	}
+	save_npy("sample_pdf.bins", bins.contiguous()); save_npy("sample_pdf.weights", w);
+	for (int ns : {128, 192, 5})
+	{
+		auto s = SamplePDF(bins, w, ns, true);
+		save_npy("sample_pdf.samples_" + std::to_string(ns), s);
+		// aux_: same ATen ops, same order as Sampler.h:10-13,21-22,28-30 to expose the local index tensors
+		auto w2 = w + 1e-8;
+		auto pdf = w2 / torch::sum(w2, -1, true);
+		auto cdf = torch::cumsum(pdf, -1);
+		cdf = torch::cat({torch::zeros_like(cdf.index({"...", Slice(None, 1)})), cdf}, -1);
+		auto u = torch::linspace(0.f, 1.f, ns, torch::kFloat).expand({n, ns}).contiguous();
+		auto inds = torch::searchsorted(cdf, u, false, true);
+		if (ns == 128) { save_npy("sample_pdf.aux_pdf", pdf); save_npy("sample_pdf.aux_cdf", cdf); }
+		save_npy("sample_pdf.aux_u_" + std::to_string(ns), u.index({0}));
+		save_npy("sample_pdf.aux_inds_" + std::to_string(ns), inds);
+	}
+	save_npy("sample_pdf.aux_t64", t);
+	save_npy("sample_pdf.aux_t192", torch::linspace(0.f, 1.f, 192, torch::kFloat));
+}
+
+static void g_pe()
+{
+	// E1: EmbedderImpl (NeRF.cpp:4-39)
+	auto x = synth_tensor({40, 3}, 31u, 1.5f);
+	x[0][0] = 0.f; x[0][1] = 1.5f; x[0][2] = -1.5f;
+	save_npy("pe.x", x);
+	for (int nf : {10, 4, 1 + 1})
+	{
+		Embedder e("pe", nf);
+		auto [out, m] = e->forward(x);
+		save_npy("pe.out_" + std::to_string(nf), out);
+	}
+}
+
+static void g_sh()
+{
+	// S2: SHEncoderImpl (NeRF.cpp:131-201)
+	auto d = synth_tensor({40, 3}, 41u, 1.0f);
+	d = d / torch::norm(d, 2, -1, true);
+	d[0][0] = 0.f; d[0][1] = 0.f; d[0][2] = 1.f;
+	d[1][0] = 1.f; d[1][1] = 0.f; d[1][2] = 0.f;
+	save_npy("sh.dirs", d.contiguous());
+	for (int deg = 1; deg <= 5; deg++)
+	{
+		SHEncoder e("sh", 3, deg);
+		auto [out, m] = e->forward(d);
+		save_npy("sh.out_" + std::to_string(deg), out);
+	}
+}
+
+static void g_hash()
+{
+	// H1: HashEmbedderImpl (NeRF.cpp:208-318)
+	auto bbox = lego_bbox();
+	struct Cfg { const char *tag; int L, F, T, base, fine; int npts; float amp; };
+	for (Cfg c : { Cfg{"small", 4, 2, 10, 4, 32, 96, 1e-4f}, Cfg{"f4", 3, 4, 8, 2, 20, 64, 0.5f}, Cfg{"f8", 2, 8, 12, 16, 128, 32, 0.5f},
+		Cfg{"full", 16, 2, 19, 16, 512, 256, 0.5f}, Cfg{"full1024", 16, 2, 19, 16, 1024, 64, 1e-4f} })
+	{
+		std::string tag = std::string("hash_") + c.tag;
+		HashEmbedder e("embedder", bbox, c.L, c.F, c.T, c.base, c.fine);
+		fill_module(tag, e, 5000u, c.amp, 0.f);
+		auto x = synth_tensor({c.npts, 3}, 51u, 1.6f);		//some points fall outside the [-1.5,1.5] box
+		{
+			auto xa = x.accessor<float, 2>();
+			xa[0][0] = 1.5f; xa[0][1] = 1.5f; xa[0][2] = 1.5f;		//max corner: idx == res
+			xa[1][0] = -1.5f; xa[1][1] = -1.5f; xa[1][2] = -1.5f;	//min corner
+			xa[2][0] = 0.f; xa[2][1] = 0.f; xa[2][2] = 0.f;			//exact lattice point at even resolutions
+			xa[3][0] = 1.5f; xa[3][1] = 0.1f; xa[3][2] = -1.5f;
+			xa[4][0] = 2.0f; xa[4][1] = 0.1f; xa[4][2] = 0.2f;		//outside -> clamped, mask false
+			xa[5][0] = 0.75f; xa[5][1] = -0.75f; xa[5][2] = 0.375f;
+		}
+		auto [emb, mask] = e->forward(x);
+		save_npy(tag + ".cfg", torch::tensor({c.L, c.F, c.T, c.base, c.fine}, torch::kInt32));
+		save_npy(tag + ".bbox", bbox);
+		save_npy(tag + ".x", x); save_npy(tag + ".emb", emb); save_npy(tag + ".mask", mask);
+	}
+}
+
+static void g_mlp()
+{
+	// M2: NeRFSmallImpl (NeRF.cpp:322-412), executor construction NeRFExecutor.h:479-493
+	for (int nlc : {4, 3})
+	{
+		std::string tag = "mlp_small_c" + std::to_string(nlc);
+		NeRFSmall m(3, 64, 15, nlc, 64, false, 3, 64, 32, 16, "model");
+		fill_module(tag, m, 6000u, 1.6f, 0.f);
+		auto x = synth_tensor({96, 48}, 61u, 1.0f);
+		auto y = m->forward(x);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", y);
+	}
+	{
+		// SH degree 8 direction input (main.cpp:188) -> 64-d views
+		std::string tag = "mlp_small_v64";
+		NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 32, 64, "model");
+		fill_module(tag, m, 6100u, 1.6f, 0.f);
+		auto x = synth_tensor({64, 96}, 62u, 1.0f);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", m->forward(x));
+	}
+	{
+		// M1: NeRFImpl (NeRF.cpp:41-126) with view directions
+		std::string tag = "mlp_nerf";
+		NeRF m(8, 256, 63, 27, 5, std::set<int>{4}, true, "model");
+		fill_module(tag, m, 7000u, 1.4f, 0.1f);
+		auto x = synth_tensor({64, 90}, 71u, 1.0f);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", m->forward(x));
+	}
+	{
+		// M1 without view directions (output_linear branch, NeRF.cpp:121-124)
+		std::string tag = "mlp_nerf_noview";
+		NeRF m(8, 256, 63, 0, 4, std::set<int>{4}, false, "model");
+		fill_module(tag, m, 7100u, 1.4f, 0.1f);
+		auto x = synth_tensor({32, 63}, 72u, 1.0f);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", m->forward(x));
+	}
+	{
+		// L1: LeRFImpl (LeRF.cpp:28-111), main.cpp:203-213 dims
+		std::string tag = "lerf";
+		LeRF m(32, 2, 256, 768, 128, "lang_model");
+		fill_module(tag, m, 8000u, 1.4f, 0.f);
+		auto x = synth_tensor({12, 128}, 81u, 0.5f);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", m->forward(x));
+	}
+}
+
+static void g_truncexp()
+{
+	// C1 helper: TruncExp forward/backward (CustomOps.cpp:5-15)
+	auto x = torch::tensor({-120.f, -100.f, -5.f, -1e-3f, 0.f, 0.5f, 4.9f, 5.f, 5.1f, 20.f}).set_requires_grad(true);
+	auto y = torch::autograd::TruncExp::apply(x)[0];
+	y.sum().backward();
+	save_npy("truncexp.x", x); save_npy("truncexp.y", y); save_npy("truncexp.grad", x.grad());
+}
+
+static void g_raw2out()
+{
+	// C1: RawToOutputs (NeRFRenderer.h:199-282)
+	Embedder e("e", 2), ed("ed", 2);
+	NeRF m(2, 8, 15, 15, 4, std::set<int>{}, true, "model");
+	Spy<Embedder, Embedder, NeRF> spy(e, ed, m);
+	for (int S : {64, 192})
+	{
+		const int n = 12;
+		auto raw = synth_tensor({n, S, 4}, 91u + S, 3.0f);
+		auto near = synth_tensor({n, 1}, 92u, 0.5f, 2.5f);
+		auto far = near + synth_tensor({n, 1}, 93u, 1.0f, 2.5f);
+		auto z = near * (1.f - torch::linspace(0.f, 1.f, S, torch::kFloat)) + far * torch::linspace(0.f, 1.f, S, torch::kFloat);
+		auto d = synth_tensor({n, 3}, 94u, 1.0f);
+		{
+			// density scaled so rays span transparent..opaque; ray 0 zero sigma, ray 1 saturated, ray 2 negative sigma
+			auto s = raw.index({"...", 3});
+			raw.index_put_({"...", 3}, s * 20.f);
+			raw.index_put_({0, "...", 3}, 0.f);
+			raw.index_put_({1, "...", 3}, 1e4f);
+			raw.index_put_({2, "...", 3}, -5.f);
+			raw.index_put_({3, Slice(0, S / 2), 3}, 0.f);
+			raw.index_put_({3, Slice(S / 2, None), 3}, 50.f);
+			z.index_put_({4, Slice()}, z.index({4, 0}).item<float>());		//degenerate ray: all samples at one depth
+		}
+		std::string tag = "raw2out_" + std::to_string(S);
+		save_npy(tag + ".raw", raw); save_npy(tag + ".z", z.contiguous()); save_npy(tag + ".d", d);
+		save_outputs(tag + ".black_", spy.OpenRawToOutputs(raw, z, d, false));
+		save_outputs(tag + ".white_", spy.OpenRawToOutputs(raw, z, d, true));
+	}
+}
+
+template <class SpyT>
+static void dump_spy(const std::string &tag, SpyT &spy, const NeRFRenderResult &res)
+{
+	save_npy(tag + ".rays_flat", spy.batch_rays[0]);
+	// chunks concatenated; pass 0 = coarse, pass 1 = fine per chunk
+	std::vector<torch::Tensor> cp, cr, fp, fr, cz, fz, cw;
+	for (size_t i = 0; i + 1 < spy.net_pts.size(); i += 2)
+	{
+		cp.push_back(spy.net_pts[i]); cr.push_back(spy.net_raw[i]); fp.push_back(spy.net_pts[i + 1]); fr.push_back(spy.net_raw[i + 1]);
+		cz.push_back(spy.r2o_z[i]); fz.push_back(spy.r2o_z[i + 1]); cw.push_back(spy.r2o_out[i].Weights);
+	}
+	save_npy(tag + ".coarse_pts", torch::cat(cp, 0)); save_npy(tag + ".coarse_raw", torch::cat(cr, 0));
+	save_npy(tag + ".coarse_z", torch::cat(cz, 0)); save_npy(tag + ".coarse_weights", torch::cat(cw, 0));
+	save_npy(tag + ".fine_pts", torch::cat(fp, 0)); save_npy(tag + ".fine_raw", torch::cat(fr, 0));
+	save_npy(tag + ".fine_z", torch::cat(fz, 0));
+	save_outputs(tag + ".out_", res.Outputs);
+	save_npy(tag + ".near_far", torch::tensor({res.Near, res.Far}));
+}
+
+static void g_render()
+{
+	const int h = 8, w = 8;
+	auto k = lego_K(h, w);
+	auto c2w = orbit_pose(-63.f, -30.f, 4.f);
+	// a tighter view so most rays hit the box: scale focal down (wider fov)
+	k[0][0] = k[0][0] * 0.8f; k[1][1] = k[1][1] * 0.8f;
+	auto bbox = lego_bbox();
+	{
+		// C3 shape: HashEmbedder(L16,T19,F2,16..512) + SHEncoder(4) + NeRFSmall (NeRFExecutor.h:427-493 construction)
+		std::string tag = "render_hash";
+		HashEmbedder e("embedder", bbox, 16, 2, 19, 16, 512);
+		SHEncoder ed("embeddirs", 3, 4);
+		NeRFSmall m(3, 64, 15, 4, 64, false, 3, 64, 32, 16, "model");
+		fill_module(tag, e, 5000u, 0.5f, 0.f);
+		fill_module(tag, m, 6000u, 1.6f, 0.f, {{"sigma_net_2", 30.0f}});
+		save_npy(tag + ".k", k); save_npy(tag + ".c2w", c2w); save_npy(tag + ".bbox", bbox);
+		for (int chunk : {64, 24})
+		{
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+			auto res = spy.Render(h, w, k, lego_params(64, 128, chunk), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+			if (chunk == 64) dump_spy(tag, spy, res);
+			else { save_npy(tag + ".chunk24_rgb", res.Outputs.RGBMap); save_npy(tag + ".chunk24_depth", res.Outputs.DepthMap); }
+		}
+		{
+			// LinDisp + black background + explicit ray batch (training-style call, NeRFExecutor.h:876)
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+			auto [o, d, cone] = GetRays(h, w, k, c2w);
+			auto rp = lego_params(64, 128, 64);
+			rp.LinDisp = true; rp.WhiteBkgr = false;
+			auto res = spy.Render(0, 0, torch::Tensor(), rp, {o.reshape({-1, 3}).index({Slice(0, 40)}), d.reshape({-1, 3}).index({Slice(0, 40)}), cone});
+			dump_spy("render_hash_lindisp", spy, res);
+		}
+	}
+	{
+		// C2 shape: PE(10)/PE(4) + NeRF 8x256 with viewdirs
+		std::string tag = "render_classic";
+		Embedder e("embedder", 10), ed("embeddirs", 4);
+		NeRF m(8, 256, 63, 27, 5, std::set<int>{4}, true, "model");
+		fill_module(tag, m, 7000u, 1.4f, 0.1f, {{"alpha_linear.weight", 40.0f}});
+		save_npy(tag + ".k", k); save_npy(tag + ".c2w", c2w); save_npy(tag + ".bbox", bbox);
+		Spy<Embedder, Embedder, NeRF> spy(e, ed, m);
+		auto res = spy.Render(h, w, k, lego_params(64, 128, 64), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+		dump_spy(tag, spy, res);
+	}
+	{
+		// C1 shape: coarse only, N_importance = 0 -> Render() leaves Outputs undefined (NeRFRenderer.h:423 vs :448);
+		// the coarse half is taken from the spy's RawToOutputs record.
+		std::string tag = "render_classic_coarse";
+		Embedder e("embedder", 10), ed("embeddirs", 4);
+		NeRF m(8, 256, 63, 27, 4, std::set<int>{4}, true, "model");
+		fill_module(tag, m, 7000u, 1.4f, 0.1f, {{"alpha_linear.weight", 40.0f}});
+		Spy<Embedder, Embedder, NeRF> spy(e, ed, m);
+		auto res = spy.Render(h, w, k, lego_params(64, 0, 1024), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+		save_npy(tag + ".rgb_defined", torch::tensor({res.Outputs.RGBMap.defined() ? 1 : 0}, torch::kInt32));
+		save_npy(tag + ".coarse_z", spy.r2o_z[0]); save_npy(tag + ".coarse_raw", spy.r2o_raw[0]);
+		save_outputs(tag + ".out_", spy.r2o_out[0]);
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// bench: the reference CPU renderer timed on synthetic Lego-shaped rays (cpu_baseline kind "reference")
+// ----------------------------------------------------------------------------------------------
+static int run_bench(int argc, const char **argv)
+{
+	std::string family = argc > 2 ? argv[2] : "hash";
+	int h = argc > 3 ? atoi(argv[3]) : 800, w = h;
+	int rows = argc > 4 ? atoi(argv[4]) : 4;		//image rows rendered (bounded sample)
+	int ns = argc > 5 ? atoi(argv[5]) : 64, ni = argc > 6 ? atoi(argv[6]) : 128;
+	int chunk = argc > 7 ? atoi(argv[7]) : 4096;
+	int reps = argc > 8 ? atoi(argv[8]) : 1;
+	std::ofstream devnull("/dev/null");
+	g_manifest.swap(devnull);
+	torch::NoGradGuard ng;
+	auto k = lego_K(h, w);
+	auto c2w = orbit_pose(30.f, -30.f, 4.f);
+	auto bbox = lego_bbox();
+	auto [o, d, cone] = GetRays(h, w, k, c2w);
+	int r0 = h / 2 - rows / 2;
+	auto ro = o.index({Slice(r0, r0 + rows)}).reshape({-1, 3}).contiguous();
+	auto rd = d.index({Slice(r0, r0 + rows)}).reshape({-1, 3}).contiguous();
+	auto rp = lego_params(ns, ni, chunk);
+	rp.ReturnRaw = false; rp.ReturnWeights = false;
+	double best = 1e30;
+	int64_t nrays = ro.size(0);
+	auto run = [&](auto &renderer) {
+		for (int r = 0; r < reps + 1; r++)
+		{
+			auto t0 = std::chrono::steady_clock::now();
+			auto res = renderer.Render(0, 0, torch::Tensor(), rp, {ro, rd, cone});
+			auto t1 = std::chrono::steady_clock::now();
+			double s = std::chrono::duration<double>(t1 - t0).count();
+			if (r > 0 || reps == 0) best = std::min(best, s);
+		}
+	};
+	if (family == "hash")
+	{
+		HashEmbedder e("embedder", bbox, 16, 2, 19, 16, 512);
+		SHEncoder ed("embeddirs", 3, 4);
+		NeRFSmall m(3, 64, 15, 4, 64, false, 3, 64, 32, 16, "model");
+		fill_module("b", e, 5000u, 0.5f, 0.f);
+		fill_module("b", m, 6000u, 1.6f, 0.f, {{"sigma_net_2", 30.0f}});
+		NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> r(e, ed, m);
+		run(r);
+	} else {
+		Embedder e("embedder", 10), ed("embeddirs", 4);
+		NeRF m(8, 256, 63, 27, 5, std::set<int>{4}, true, "model");
+		fill_module("b", m, 7000u, 1.4f, 0.1f, {{"alpha_linear.weight", 40.0f}});
+		NeRFRenderer<Embedder, Embedder, NeRF> r(e, ed, m);
+		run(r);
+	}
+	int64_t units = nrays * (ni > 0 ? (ns + ns + ni) : ns);
+	printf("{\"family\": \"%s\", \"rays\": %ld, \"units\": %ld, \"seconds\": %.6f, \"units_per_s\": %.1f, \"threads\": %d}\n",
+		family.c_str(), (long)nrays, (long)units, best, units / best, at::get_num_threads());
+	return 0;
+}
+
+int main(int argc, const char **argv)
+{
+	if (argc < 2) { std::cerr << "usage: ref_driver golden <outdir> | bench <hash|classic> [h rows ns ni chunk reps]" << std::endl; return 1; }
+	std::string cmd = argv[1];
+	if (cmd == "bench") return run_bench(argc, argv);
+	if (cmd != "golden" || argc < 3) return 1;
+	g_outdir = argv[2];
+	g_manifest.open(g_outdir + "/manifest.txt");
+	torch::manual_seed(42);
+	g_rays();
+	g_aabb();
+	g_sample_pdf();
+	g_pe();
+	g_sh();
+	g_hash();
+	g_mlp();
+	g_truncexp();
+	g_raw2out();
+	g_render();
+	g_manifest.close();
+	std::cout << "golden vectors written to " << g_outdir << std::endl;
+	return 0;
+}
