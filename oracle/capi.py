@@ -1,0 +1,277 @@
+"""ctypes binding of oracle/_build/liboracle.so -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (nerfpp_amd) must never import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "liboracle.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "nerf_oracle.c")):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_mlp_small_param_count.restype = C.c_int64
+        _LIB.orc_mlp_nerf_param_count.restype = C.c_int64
+        _LIB.orc_aten_row_sum.restype = C.c_float
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+ATEN_VEC = 8  # fp32 lanes of ATen's sum kernel on any AVX2-or-newer x86 host (see nerf_oracle.c)
+
+
+def linspace(start, end, steps):
+    out = np.empty(steps, np.float32)
+    lib().orc_linspace(C.c_float(start), C.c_float(end), C.c_int(steps), _p(out))
+    return out
+
+
+def get_rays(h, w, K, c2w, row0=0, rows=None):
+    rows = h - row0 if rows is None else rows
+    K = _f(K); c2w = _f(c2w)
+    o = np.empty((rows, w, 3), np.float32); d = np.empty((rows, w, 3), np.float32)
+    cone = C.c_float(0)
+    lib().orc_get_rays(C.c_int(h), C.c_int(w), _p(K), _p(c2w), C.c_int(row0), C.c_int(rows), _p(o), _p(d), C.byref(cone))
+    return o, d, np.float32(cone.value)
+
+
+def ndc_rays(h, w, focal, near, o, d):
+    o = _f(o).reshape(-1, 3); d = _f(d).reshape(-1, 3)
+    oo = np.empty_like(o); od = np.empty_like(d)
+    lib().orc_ndc_rays(C.c_int(h), C.c_int(w), C.c_float(focal), C.c_float(near), _p(o), _p(d), C.c_int64(o.shape[0]), _p(oo), _p(od))
+    return oo, od
+
+
+def aabb(o, d, bbox, near_plane=0.0):
+    o = _f(o).reshape(-1, 3); d = _f(d).reshape(-1, 3); bbox = _f(bbox)
+    n = o.shape[0]
+    nr = np.empty(n, np.float32); fr = np.empty(n, np.float32)
+    lib().orc_aabb(_p(o), _p(d), _p(bbox), C.c_int64(n), C.c_float(near_plane), _p(nr), _p(fr))
+    return nr, fr
+
+
+def z_vals(nears, fars, t, lindisp=False):
+    nears = _f(nears).reshape(-1); fars = _f(fars).reshape(-1); t = _f(t)
+    z = np.empty((nears.shape[0], t.shape[0]), np.float32)
+    lib().orc_z_vals(_p(nears), _p(fars), _p(t), C.c_int64(nears.shape[0]), C.c_int(t.shape[0]), C.c_int(int(lindisp)), _p(z))
+    return z
+
+
+def points(o, d, z):
+    o = _f(o); d = _f(d); z = _f(z)
+    n, s = z.shape
+    pts = np.empty((n, s, 3), np.float32)
+    lib().orc_points(_p(o), _p(d), _p(z), C.c_int64(n), C.c_int(s), _p(pts))
+    return pts
+
+
+def pe(x, nfreq):
+    x = _f(x).reshape(-1, 3)
+    out = np.empty((x.shape[0], 3 + 6 * nfreq), np.float32)
+    lib().orc_pe(_p(x), C.c_int64(x.shape[0]), C.c_int(nfreq), _p(out))
+    return out
+
+
+def sh_libtorch(dirs, degree):
+    dirs = _f(dirs).reshape(-1, 3)
+    out = np.empty((dirs.shape[0], degree * degree), np.float32)
+    lib().orc_sh_libtorch(_p(dirs), C.c_int64(dirs.shape[0]), C.c_int(degree), _p(out))
+    return out
+
+
+def sh_cu(dirs, degree):
+    dirs = _f(dirs).reshape(-1, 3)
+    out = np.empty((dirs.shape[0], degree * degree), np.float32)
+    lib().orc_sh_cu(_p(dirs), C.c_int64(dirs.shape[0]), C.c_int(degree), _p(out))
+    return out
+
+
+def hash_ngp_resolutions(L, base, finest):
+    out = np.empty(L, np.float32)
+    lib().orc_hash_ngp_resolutions(C.c_int(L), C.c_int(base), C.c_int(finest), _p(out))
+    return out
+
+
+def hash_ngp(x, table, bbox, L, F, log2_t, base, finest):
+    x = _f(x).reshape(-1, 3); table = _f(table); bbox = _f(bbox)
+    assert table.size == L * (1 << log2_t) * F
+    out = np.empty((x.shape[0], L * F), np.float32); mask = np.empty(x.shape[0], np.uint8)
+    lib().orc_hash_ngp(_p(x), C.c_int64(x.shape[0]), _p(table), _p(bbox), C.c_int(L), C.c_int(F), C.c_int(log2_t),
+                       C.c_int(base), C.c_int(finest), _p(out), _p(mask))
+    return out, mask.astype(bool)
+
+
+def hash_cu_scales(L, base, finest):
+    out = np.empty(L, np.float32)
+    lib().orc_hash_cu_scales(C.c_int(L), C.c_int(base), C.c_int(finest), _p(out))
+    return out
+
+
+def f32_to_f16(a):
+    a = _f(a)
+    out = np.empty(a.shape, np.uint16)
+    lib().orc_f32_to_f16(_p(a), _p(out), C.c_int64(a.size))
+    return out
+
+
+def hash_cu(x, table_f16, primes, local_idx, local_size, bias, bbox, mul, L, F):
+    x = _f(x).reshape(-1, 3)
+    table_f16 = np.ascontiguousarray(table_f16, dtype=np.uint16)
+    primes = np.ascontiguousarray(primes, dtype=np.int32); local_idx = np.ascontiguousarray(local_idx, dtype=np.int32)
+    local_size = np.ascontiguousarray(local_size, dtype=np.int32)
+    bias = _f(bias); bbox = _f(bbox); mul = _f(mul)
+    out = np.empty((x.shape[0], L * F), np.float32); mask = np.empty(x.shape[0], np.uint8)
+    lib().orc_hash_cu(_p(x), C.c_int64(x.shape[0]), _p(table_f16), _p(primes), _p(local_idx), _p(local_size), _p(bias), _p(bbox),
+                      _p(mul), C.c_int(L), C.c_int(F), _p(out), _p(mask))
+    return out, mask.astype(bool)
+
+
+def mlp_small(params, x, in_ch, in_views, n_layers=3, hidden=64, geo=15, n_layers_c=4, hidden_c=64):
+    params = _f(params); x = _f(x)
+    n = lib().orc_mlp_small_param_count(C.c_int(in_ch), C.c_int(in_views), C.c_int(n_layers), C.c_int(hidden), C.c_int(geo), C.c_int(n_layers_c), C.c_int(hidden_c))
+    assert params.size == n, (params.size, n)
+    out = np.empty((x.shape[0], 4), np.float32)
+    lib().orc_mlp_small(_p(params), _p(x), C.c_int64(x.shape[0]), C.c_int(in_ch), C.c_int(in_views), C.c_int(n_layers), C.c_int(hidden),
+                        C.c_int(geo), C.c_int(n_layers_c), C.c_int(hidden_c), _p(out))
+    return out
+
+
+def mlp_nerf(params, x, d=8, w=256, in_ch=63, in_views=27, out_ch=4, skip=4, use_viewdirs=True):
+    params = _f(params); x = _f(x)
+    n = lib().orc_mlp_nerf_param_count(C.c_int(d), C.c_int(w), C.c_int(in_ch), C.c_int(in_views), C.c_int(out_ch), C.c_int(skip), C.c_int(int(use_viewdirs)))
+    assert params.size == n, (params.size, n)
+    od = 4 if use_viewdirs else out_ch
+    out = np.empty((x.shape[0], od), np.float32)
+    lib().orc_mlp_nerf(_p(params), _p(x), C.c_int64(x.shape[0]), C.c_int(d), C.c_int(w), C.c_int(in_ch), C.c_int(in_views), C.c_int(out_ch),
+                       C.c_int(skip), C.c_int(int(use_viewdirs)), _p(out))
+    return out
+
+
+def lerf(params, x, in_ch=128, n_layers=2, hidden=256, geo=32, embed=768):
+    params = _f(params); x = _f(x)
+    out = np.empty((x.shape[0], embed + 1), np.float32)
+    lib().orc_lerf(_p(params), _p(x), C.c_int64(x.shape[0]), C.c_int(in_ch), C.c_int(n_layers), C.c_int(hidden), C.c_int(geo), C.c_int(embed), _p(out))
+    return out
+
+
+def raw2outputs(raw, z, d, white_bkgr=False):
+    raw = _f(raw); z = _f(z); d = _f(d)
+    n, s, c = raw.shape
+    rgb = np.empty((n, 3), np.float32); disp = np.empty(n, np.float32); acc = np.empty(n, np.float32)
+    w = np.empty((n, s), np.float32); depth = np.empty(n, np.float32)
+    lib().orc_raw2outputs(_p(raw), _p(z), _p(d), C.c_int64(n), C.c_int(s), C.c_int(c), C.c_int(int(white_bkgr)), _p(rgb), _p(disp), _p(acc), _p(w), _p(depth))
+    return dict(rgb=rgb, disp=disp, acc=acc, weights=w, depth=depth)
+
+
+def sample_pdf(bins, weights, u, sum_vec=ATEN_VEC):
+    bins = _f(bins); weights = _f(weights); u = _f(u)
+    n, nb = bins.shape
+    assert weights.shape == (n, nb - 1)
+    ns = u.shape[0]
+    samples = np.empty((n, ns), np.float32); inds = np.empty((n, ns), np.int64); cdf = np.empty((n, nb), np.float32)
+    lib().orc_sample_pdf(_p(bins), _p(weights), C.c_int64(n), C.c_int(nb), _p(u), C.c_int(ns), C.c_int(sum_vec), _p(samples), _p(inds), _p(cdf))
+    return samples, inds, cdf
+
+
+def z_mid(z):
+    z = _f(z)
+    n, s = z.shape
+    out = np.empty((n, s - 1), np.float32)
+    lib().orc_z_mid(_p(z), C.c_int64(n), C.c_int(s), _p(out))
+    return out
+
+
+def merge_sorted(z, zs):
+    z = _f(z); zs = _f(zs)
+    n, s = z.shape
+    ns = zs.shape[1]
+    out = np.empty((n, s + ns), np.float32)
+    lib().orc_merge_sorted(_p(z), C.c_int(s), _p(zs), C.c_int(ns), C.c_int64(n), _p(out))
+    return out
+
+
+def pack_rays(o, d, bbox):
+    o = _f(o).reshape(-1, 3); d = _f(d).reshape(-1, 3); bbox = _f(bbox)
+    rays = np.empty((o.shape[0], 11), np.float32)
+    lib().orc_pack_rays(_p(o), _p(d), _p(bbox), C.c_int64(o.shape[0]), _p(rays))
+    return rays
+
+
+class OrcModel(C.Structure):
+    _fields_ = [
+        ("family", C.c_int),
+        ("bbox", C.c_void_p),
+        ("n_levels", C.c_int), ("n_feat", C.c_int), ("log2_t", C.c_int), ("base", C.c_int), ("finest", C.c_int),
+        ("table_f32", C.c_void_p), ("table_f16", C.c_void_p),
+        ("primes", C.c_void_p), ("local_idx", C.c_void_p), ("local_size", C.c_void_p),
+        ("bias", C.c_void_p), ("mul", C.c_void_p),
+        ("sh_degree", C.c_int), ("pe_freqs", C.c_int), ("pe_freqs_views", C.c_int),
+        ("params", C.c_void_p),
+        ("n_layers", C.c_int), ("hidden", C.c_int), ("geo", C.c_int), ("n_layers_c", C.c_int), ("hidden_c", C.c_int),
+        ("depth", C.c_int), ("width", C.c_int), ("skip", C.c_int),
+    ]
+
+
+class Model:
+    """Keeps the numpy buffers alive next to the C struct."""
+
+    def __init__(self, family, params, bbox=None, table_f32=None, table_f16=None, L=16, F=2, log2_t=19, base=16, finest=512,
+                 primes=None, local_idx=None, local_size=None, bias=None, mul=None, sh_degree=4, pe_freqs=10, pe_freqs_views=4,
+                 n_layers=3, hidden=64, geo=15, n_layers_c=4, hidden_c=64, depth=8, width=256, skip=4):
+        self.keep = dict(
+            params=_f(params), bbox=_f(bbox) if bbox is not None else None,
+            table_f32=_f(table_f32) if table_f32 is not None else None,
+            table_f16=np.ascontiguousarray(table_f16, np.uint16) if table_f16 is not None else None,
+            primes=np.ascontiguousarray(primes, np.int32) if primes is not None else None,
+            local_idx=np.ascontiguousarray(local_idx, np.int32) if local_idx is not None else None,
+            local_size=np.ascontiguousarray(local_size, np.int32) if local_size is not None else None,
+            bias=_f(bias) if bias is not None else None, mul=_f(mul) if mul is not None else None)
+        k = self.keep
+        self.c = OrcModel(family, _p(k["bbox"]), L, F, log2_t, base, finest, _p(k["table_f32"]), _p(k["table_f16"]), _p(k["primes"]),
+                          _p(k["local_idx"]), _p(k["local_size"]), _p(k["bias"]), _p(k["mul"]), sh_degree, pe_freqs, pe_freqs_views,
+                          _p(k["params"]), n_layers, hidden, geo, n_layers_c, hidden_c, depth, width, skip)
+
+
+def render_rays(model: Model, rays, n_samples, n_importance, t_coarse, u_fine, lindisp=False, white_bkgr=True, want_intermediates=False,
+                sum_vec=ATEN_VEC):
+    rays = _f(rays)
+    n = rays.shape[0]
+    s, sf = n_samples, n_samples + n_importance
+    t_coarse = _f(t_coarse); u_fine = _f(u_fine) if u_fine is not None else None
+    out = dict(rgb=np.empty((n, 3), np.float32), disp=np.empty(n, np.float32), acc=np.empty(n, np.float32), depth=np.empty(n, np.float32),
+               weights=np.empty((n, sf if n_importance > 0 else s), np.float32))
+    inter = {}
+    if want_intermediates:
+        inter = dict(z_coarse=np.empty((n, s), np.float32), z_fine=np.empty((n, sf), np.float32), raw_coarse=np.empty((n, s, 4), np.float32),
+                     raw_fine=np.empty((n, sf, 4), np.float32), weights_coarse=np.empty((n, s), np.float32))
+    lib().orc_render_rays(C.byref(model.c), _p(rays), C.c_int64(n), C.c_int(n_samples), C.c_int(n_importance), _p(t_coarse), _p(u_fine),
+                          C.c_int(int(lindisp)), C.c_int(int(white_bkgr)), C.c_int(sum_vec), _p(out["rgb"]), _p(out["disp"]), _p(out["acc"]), _p(out["depth"]),
+                          _p(out["weights"]), _p(inter.get("z_coarse")), _p(inter.get("z_fine")), _p(inter.get("raw_coarse")),
+                          _p(inter.get("raw_fine")), _p(inter.get("weights_coarse")))
+    out.update(inter)
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

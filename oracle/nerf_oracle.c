@@ -1,0 +1,951 @@
+/*
+ * nerf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C (C99 + optional OpenMP) restatement of the reference's volume-rendering hot
+ * path (DeliriumV01D/NeRFpp).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (nerfpp_amd/, libnerfpp_hip.so)
+ * never links, imports or calls it and has no CPU fallback.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).  Evaluation rule: fp32, one IEEE rounding per source-level
+ * operation, in source order -- the way LibTorch's CPU eager ops evaluate a chain of
+ * tensor ops.  Build with -ffp-contract=off (oracle/Makefile does) so the compiler never
+ * fuses a*b+c.  Where ATen itself is not sequential-fp32 it is stated:
+ *   - cumsum(float) on CPU accumulates in double and rounds each prefix to float
+ *     (ATen/native/cpu/ReduceOpsKernel.cpp cumsum -> acc_type<float,false> == double);
+ *   - sum(float) on CPU is a vectorised multi-lane cascade whose order depends on the
+ *     host ISA (AVX2 vs AVX-512): it has no machine-independent bit pattern.  The oracle
+ *     accumulates such sums in double and rounds once, which is within 1 ulp of any of
+ *     ATen's orders;
+ *   - sin/cos/exp/log/sigmoid on CPU are SLEEF u10 vector kernels, not libm: <= 1-2 ulp.
+ *
+ * PINNING: oracle/_ref (the reference's own sources compiled against LibTorch here) emits
+ * tests/golden/ (npz files); tests/test_oracle_golden.py checks every function below against
+ * them (bit-exact for integer/index outputs and for stages made only of + - * / floor;
+ * tolerance stated per test otherwise).  The two CUDA-only units (CuHashEmbedder.cu,
+ * CuSHEncoder.cu) cannot be compiled here: orc_hash_cu / orc_sh_cu are
+ * RESTATEMENT-PINNED (hand-computed known answers + cross-checks), parity unpinned by
+ * any reference run.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define OMP_FOR
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * helpers
+ * ------------------------------------------------------------------------------------------ */
+static inline float f_min(float a, float b) { return a < b ? a : b; }
+static inline float f_max(float a, float b) { return a > b ? a : b; }
+
+/* fp32 -> fp16 bits, round-to-nearest-even (what tensor.to(kFloat16) and CUDA (__half)x do) */
+static uint16_t f32_to_f16_bits(float f)
+{
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x007fffffu;
+    int32_t exp = (int32_t)((x >> 23) & 0xff);
+    if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u : 0u));
+    int32_t e = exp - 127 + 15;
+    if (e >= 0x1f) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t half = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half & 1u))) half++;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;
+    return (uint16_t)(sign | half);
+}
+
+static float f16_bits_to_f32(uint16_t h)
+{
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t mant = h & 0x3ffu;
+    uint32_t x;
+    if (exp == 0) {
+        if (mant == 0) x = sign;
+        else {
+            int e = -1;
+            do { e++; mant <<= 1; } while (!(mant & 0x400u));
+            x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((mant & 0x3ffu) << 13);
+        }
+    } else if (exp == 0x1f) x = sign | 0x7f800000u | (mant << 13);
+    else x = sign | ((exp - 15 + 127) << 23) | (mant << 13);
+    float f; memcpy(&f, &x, 4);
+    return f;
+}
+
+ORC_API void orc_f32_to_f16(const float *in, uint16_t *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = f32_to_f16_bits(in[i]);
+}
+ORC_API void orc_f16_to_f32(const uint16_t *in, float *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; i++) out[i] = f16_bits_to_f32(in[i]);
+}
+
+/* torch::linspace(start, end, steps, kFloat) as ATen's CPU kernel evaluates it
+ * (ATen/native/cpu/RangeFactoriesKernel.cpp linspace_kernel): step = (end-start)/(steps-1) in
+ * fp32; element i is start + step*i in the first half and end - step*(steps-1-i) in the second,
+ * and the kernel is built with FMA contraction, so each element is ONE fused rounding:
+ * fma(step, i, start) / fma(-step, steps-1-i, end).  Verified bit for bit against torch 2.10
+ * (tests/golden sample_pdf aux_t64 / aux_u_128 / aux_t192).  The renderer takes its t / u tables
+ * as INPUTS (the LibTorch / PyTorch host passes torch::linspace output); this is for hosts that
+ * have no torch at hand and for the oracle's own drivers. */
+ORC_API void orc_linspace(float start, float end, int steps, float *out)
+{
+    if (steps == 1) { out[0] = start; return; }
+    float step = (end - start) / (float)(steps - 1);
+    int halfway = steps / 2;
+    for (int i = 0; i < steps; i++)
+        out[i] = (i < halfway) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - i - 1), end);
+}
+
+/* torch::sum(x, -1) over a contiguous fp32 row of n < 1024 elements as ATen's CPU kernel evaluates
+ * it (ATen/native/cpu/SumKernel.cpp: vectorized_inner_sum -> row_sum -> multi_row_sum, ilp 4):
+ *   nv = n / vec full vectors; lane-wise: four interleaved vector accumulators P_k = sum_i V[4i+k]
+ *   (i < nv/4, sequential), then P_0 += V[j] for the nv%4 left-over vectors, then P_0 += P_1,P_2,P_3;
+ *   scalar: acc = sum of the n%vec tail elements (sequential), then acc += lane[0..vec-1] of P_0.
+ * vec = 8: ATen registers the AVX2 build of this kernel for AVX-512 hosts too (REGISTER_DISPATCH
+ * without ALSO_REGISTER_AVX512_DISPATCH), so 8 fp32 lanes is what any AVX2-or-newer x86 host runs;
+ * verified bit for bit against torch 2.10 on an AVX-512 machine.  vec = 0 selects the
+ * order-free definition: accumulate in double, round once.  Used where a sum feeds an integer
+ * decision (SamplePDF's pdf normaliser -> searchsorted indices). */
+static float aten_row_sum_f32(const float *x, int n, int vec)
+{
+    if (vec <= 0 || n < vec) {
+        if (vec <= 0) { double s = 0.0; for (int i = 0; i < n; i++) s += (double)x[i]; return (float)s; }
+        /* n < vec: scalar_inner_sum -> row_sum over scalars with ilp 4 */
+        float ps[4] = {0, 0, 0, 0};
+        int q = n / 4;
+        for (int i = 0; i < q; i++) for (int k = 0; k < 4; k++) ps[k] += x[i * 4 + k];
+        for (int i = q * 4; i < n; i++) ps[0] += x[i];
+        for (int k = 1; k < 4; k++) ps[0] += ps[k];
+        return ps[0];
+    }
+    float P[4][64];
+    memset(P, 0, sizeof(P));
+    int nv = n / vec, q = nv / 4;
+    for (int i = 0; i < q; i++)
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < vec; l++) P[k][l] += x[(i * 4 + k) * vec + l];
+    for (int j = q * 4; j < nv; j++)
+        for (int l = 0; l < vec; l++) P[0][l] += x[j * vec + l];
+    for (int k = 1; k < 4; k++)
+        for (int l = 0; l < vec; l++) P[0][l] += P[k][l];
+    float acc = 0.0f;
+    for (int i = nv * vec; i < n; i++) acc += x[i];
+    for (int l = 0; l < vec; l++) acc += P[0][l];
+    return acc;
+}
+ORC_API float orc_aten_row_sum(const float *x, int n, int vec) { return aten_row_sum_f32(x, n, vec); }
+
+/* ------------------------------------------------------------------------------------------
+ * R1  GetDirections + GetRays            RayUtils.h:5-46
+ *     dir = ((x-cx)/fx, -(y-cy)/fy, -1);  d_i = sum_j dir_j * c2w[i][j] (torch::sum over 3,
+ *     left to right);  o = c2w[:3,3];  cone_angle = ((1/fx + 1/fy)/2) * 1.1
+ *     Pixel <-> ray index is row-major, y outer, x inner.  Pixel coordinates come from
+ *     linspace(0, n-1, n) whose values are exact integers in fp32.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_get_rays(int h, int w, const float *K, const float *c2w /*[3,4]*/, int row0, int rows,
+                          float *o, float *d, float *cone_angle)
+{
+    const float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    OMP_FOR
+    for (int y = row0; y < row0 + rows; y++)
+        for (int x = 0; x < w; x++) {
+            float dir[3];
+            dir[0] = ((float)x - cx) / fx;
+            dir[1] = -((float)y - cy) / fy;
+            dir[2] = -1.0f;
+            int64_t r = (int64_t)(y - row0) * w + x;
+            for (int i = 0; i < 3; i++) {
+                float acc = dir[0] * c2w[i * 4 + 0];
+                acc = acc + dir[1] * c2w[i * 4 + 1];
+                acc = acc + dir[2] * c2w[i * 4 + 2];
+                d[r * 3 + i] = acc;
+                o[r * 3 + i] = c2w[i * 4 + 3];
+            }
+        }
+    if (cone_angle) {
+        /* RayUtils.h:35-43: tensors stay fp32 (a 0-dim fp32 tensor times a double scalar stays fp32) */
+        float px = 1.0f / fx, py = 1.0f / fy;
+        float avg = (px + py) / 2.0f;
+        *cone_angle = avg * 1.1f;
+    }
+}
+
+/* R2  NDCRays                              RayUtils.h:49-83  (near = 1 in Render(), NeRFRenderer.h:567) */
+ORC_API void orc_ndc_rays(int h, int w, float focal, float near_, const float *o, const float *d, int64_t n,
+                          float *oo, float *od)
+{
+    /* the python-double constants (-1./(w/(2.*focal)), 2.*near ...) are evaluated in double and
+       applied to fp32 tensors as scalars: the tensor op rounds the double scalar to fp32 first. */
+    const float sx = (float)(-1. / ((double)w / (2. * (double)focal)));
+    const float sy = (float)(-1. / ((double)h / (2. * (double)focal)));
+    const float two_near = (float)(2. * (double)near_);
+    const float m_two_near = (float)(-2. * (double)near_);
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        float ox = o[i * 3], oy = o[i * 3 + 1], oz = o[i * 3 + 2];
+        float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+        float t = -(near_ + oz) / dz;
+        ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+        oo[i * 3 + 0] = sx * ox / oz;
+        oo[i * 3 + 1] = sy * oy / oz;
+        oo[i * 3 + 2] = 1.0f + two_near / oz;
+        od[i * 3 + 0] = sx * (dx / dz - ox / oz);
+        od[i * 3 + 1] = sy * (dy / dz - oy / oz);
+        od[i * 3 + 2] = m_two_near / oz;
+    }
+}
+
+/* R3  IntersectWithAABB                    RayUtils.h:87-126
+ *     inv = 1/(d + 1e-6)  (1e-6 is a double scalar -> rounded to fp32 by the tensor op) */
+ORC_API void orc_aabb(const float *o, const float *d, const float *bbox, int64_t n, float near_plane,
+                      float *nears, float *fars)
+{
+    const float eps = (float)1e-6;
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        float tmin[3], tmax[3];
+        for (int a = 0; a < 3; a++) {
+            float inv = 1.0f / (d[i * 3 + a] + eps);
+            float t1 = (bbox[a] - o[i * 3 + a]) * inv;
+            float t2 = (bbox[3 + a] - o[i * 3 + a]) * inv;
+            tmin[a] = f_min(t1, t2);
+            tmax[a] = f_max(t1, t2);
+        }
+        float nr = f_max(f_max(tmin[0], tmin[1]), tmin[2]);
+        float fr = f_min(f_min(tmax[0], tmax[1]), tmax[2]);
+        nr = f_max(nr, near_plane);             /* clamp_min */
+        fr = f_max(fr, nr + 1e-6f);
+        nears[i] = nr; fars[i] = fr;
+    }
+}
+
+/* R6  stratified depths (Perturb == 0)     NeRFRenderer.h:393-402
+ *     z = near*(1-t) + far*t ; lindisp: safe_inv(safe_inv(near)*(1-t) + safe_inv(far)*t) */
+static inline float safe_inv(float x) { return (fabsf(x) < 1e-8f) ? (1.0f / 1e-8f) : (1.0f / x); }
+
+ORC_API void orc_z_vals(const float *nears, const float *fars, const float *t, int64_t n, int s, int lindisp, float *z)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < s; j++) {
+            float omt = 1.0f - t[j];
+            if (!lindisp) z[i * s + j] = nears[i] * omt + fars[i] * t[j];
+            else z[i * s + j] = safe_inv(safe_inv(nears[i]) * omt + safe_inv(fars[i]) * t[j]);
+        }
+}
+
+/* pts = o + d*z                            NeRFRenderer.h:419 */
+ORC_API void orc_points(const float *o, const float *d, const float *z, int64_t n, int s, float *pts)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < s; j++)
+            for (int a = 0; a < 3; a++)
+                pts[(i * s + j) * 3 + a] = o[i * 3 + a] + d[i * 3 + a] * z[i * s + j];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * E1  sinusoidal positional encoding       NeRF.cpp:4-39
+ *     freq_i = powf(2, maxlog2/(n-1)*i) with maxlog2 = n-1 (NeRF.h:22-23);
+ *     out = [x, sin(x f0), cos(x f0), sin(x f1), ...], each block 3 wide.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_pe(const float *x, int64_t p, int nfreq, float *out)
+{
+    const int od = 3 + 6 * nfreq;
+    float freqs[64];
+    const float maxf = (float)(nfreq - 1);
+    for (int i = 0; i < nfreq; i++) freqs[i] = powf(2.0f, maxf / (float)(nfreq - 1) * (float)i);
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float *o = out + i * od;
+        for (int a = 0; a < 3; a++) o[a] = x[i * 3 + a];
+        for (int f = 0; f < nfreq; f++)
+            for (int a = 0; a < 3; a++) {
+                float v = x[i * 3 + a] * freqs[f];
+                o[3 + f * 6 + a] = sinf(v);
+                o[3 + f * 6 + 3 + a] = cosf(v);
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * S2  LibTorch spherical harmonics, degree <= 5     NeRF.cpp:131-201, constants NeRF.h:83-111
+ *     Python-style literals (2.0, 3, 4, 7, 35 ...) are scalars applied to fp32 tensors, each
+ *     tensor-scalar op rounds once; products are evaluated left to right.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_sh_libtorch(const float *dirs, int64_t p, int degree, float *out)
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f,
+                         1.445305721320277f, -0.5900435899266435f};
+    const float C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f, -0.6690465435572892f, 0.10578554691520431f,
+                         -0.6690465435572892f, 0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
+    const int od = degree * degree;
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        const float x = dirs[i * 3], y = dirs[i * 3 + 1], z = dirs[i * 3 + 2];
+        float *r = out + i * od;
+        r[0] = C0;
+        if (degree <= 1) continue;
+        r[1] = -C1 * y; r[2] = C1 * z; r[3] = -C1 * x;
+        if (degree <= 2) continue;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r[4] = C2[0] * xy;
+        r[5] = C2[1] * yz;
+        r[6] = C2[2] * (2.0f * zz - xx - yy);
+        r[7] = C2[3] * xz;
+        r[8] = C2[4] * (xx - yy);
+        if (degree <= 3) continue;
+        r[9] = C3[0] * y * (3.0f * xx - yy);
+        r[10] = C3[1] * xy * z;
+        r[11] = C3[2] * y * (4.0f * zz - xx - yy);
+        r[12] = C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        r[13] = C3[4] * x * (4.0f * zz - xx - yy);
+        r[14] = C3[5] * z * (xx - yy);
+        r[15] = C3[6] * x * (xx - 3.0f * yy);
+        if (degree <= 4) continue;
+        r[16] = C4[0] * xy * (xx - yy);
+        r[17] = C4[1] * yz * (3.0f * xx - yy);
+        r[18] = C4[2] * xy * (7.0f * zz - 1.0f);
+        r[19] = C4[3] * yz * (7.0f * zz - 3.0f);
+        r[20] = C4[4] * (zz * (35.0f * zz - 30.0f) + 3.0f);
+        r[21] = C4[5] * xz * (7.0f * zz - 3.0f);
+        r[22] = C4[6] * (xx - yy) * (7.0f * zz - 1.0f);
+        r[23] = C4[7] * xz * (xx - 3.0f * yy);
+        r[24] = C4[8] * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * S1  CUDA spherical harmonics, degree <= 8         CuSHEncoder.cu:15-104 (restatement-pinned)
+ *     Closed-form polynomials for UNIT directions.  Coefficient tables are laid out per band;
+ *     the evaluation order of every expression follows the kernel text.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_sh_cu(const float *dirs, int64_t p, int degree, float *out)
+{
+    const int od = degree * degree;
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        const float x = dirs[i * 3], y = dirs[i * 3 + 1], z = dirs[i * 3 + 2];
+        const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+        const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+        const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
+        float *r = out + i * od;
+        r[0] = 0.28209479177387814f;
+        if (degree <= 1) continue;
+        r[1] = -0.48860251190291987f * y;
+        r[2] = 0.48860251190291987f * z;
+        r[3] = -0.48860251190291987f * x;
+        if (degree <= 2) continue;
+        r[4] = 1.0925484305920792f * xy;
+        r[5] = -1.0925484305920792f * yz;
+        r[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+        r[7] = -1.0925484305920792f * xz;
+        r[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+        if (degree <= 3) continue;
+        r[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+        r[10] = 2.8906114426405538f * xy * z;
+        r[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+        r[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+        r[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+        r[14] = 1.4453057213202769f * z * (x2 - y2);
+        r[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+        if (degree <= 4) continue;
+        r[16] = 2.5033429417967046f * xy * (x2 - y2);
+        r[17] = 1.7701307697799304f * yz * (-3.0f * x2 + y2);
+        r[18] = 0.94617469575756008f * xy * (7.0f * z2 - 1.0f);
+        r[19] = 0.66904654355728921f * yz * (3.0f - 7.0f * z2);
+        r[20] = -3.1735664074561294f * z2 + 3.7024941420321507f * z4 + 0.31735664074561293f;
+        r[21] = 0.66904654355728921f * xz * (3.0f - 7.0f * z2);
+        r[22] = 0.47308734787878004f * (x2 - y2) * (7.0f * z2 - 1.0f);
+        r[23] = 1.7701307697799304f * xz * (-x2 + 3.0f * y2);
+        r[24] = -3.7550144126950569f * x2 * y2 + 0.62583573544917614f * x4 + 0.62583573544917614f * y4;
+        if (degree <= 5) continue;
+        r[25] = 0.65638205684017015f * y * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+        r[26] = 8.3026492595241645f * xy * z * (x2 - y2);
+        r[27] = -0.48923829943525038f * y * (3.0f * x2 - y2) * (9.0f * z2 - 1.0f);
+        r[28] = 4.7935367849733241f * xy * z * (3.0f * z2 - 1.0f);
+        r[29] = 0.45294665119569694f * y * (14.0f * z2 - 21.0f * z4 - 1.0f);
+        r[30] = 0.1169503224534236f * z * (-70.0f * z2 + 63.0f * z4 + 15.0f);
+        r[31] = 0.45294665119569694f * x * (14.0f * z2 - 21.0f * z4 - 1.0f);
+        r[32] = 2.3967683924866621f * z * (x2 - y2) * (3.0f * z2 - 1.0f);
+        r[33] = -0.48923829943525038f * x * (x2 - 3.0f * y2) * (9.0f * z2 - 1.0f);
+        r[34] = 2.0756623148810411f * z * (-6.0f * x2 * y2 + x4 + y4);
+        r[35] = 0.65638205684017015f * x * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+        if (degree <= 6) continue;
+        r[36] = 1.3663682103838286f * xy * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
+        r[37] = 2.3666191622317521f * yz * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+        r[38] = 2.0182596029148963f * xy * (x2 - y2) * (11.0f * z2 - 1.0f);
+        r[39] = -0.92120525951492349f * yz * (3.0f * x2 - y2) * (11.0f * z2 - 3.0f);
+        r[40] = 0.92120525951492349f * xy * (-18.0f * z2 + 33.0f * z4 + 1.0f);
+        r[41] = 0.58262136251873131f * yz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+        r[42] = 6.6747662381009842f * z2 - 20.024298714302954f * z4 + 14.684485723822165f * z6 - 0.31784601133814211f;
+        r[43] = 0.58262136251873131f * xz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+        r[44] = 0.46060262975746175f * (x2 - y2) * (11.0f * z2 * (3.0f * z2 - 1.0f) - 7.0f * z2 + 1.0f);
+        r[45] = -0.92120525951492349f * xz * (x2 - 3.0f * y2) * (11.0f * z2 - 3.0f);
+        r[46] = 0.50456490072872406f * (11.0f * z2 - 1.0f) * (-6.0f * x2 * y2 + x4 + y4);
+        r[47] = 2.3666191622317521f * xz * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+        r[48] = 10.247761577878714f * x2 * y4 - 10.247761577878714f * x4 * y2 + 0.6831841051919143f * x6 - 0.6831841051919143f * y6;
+        if (degree <= 7) continue;
+        r[49] = 0.70716273252459627f * y * (-21.0f * x2 * y4 + 35.0f * x4 * y2 - 7.0f * x6 + y6);
+        r[50] = 5.2919213236038001f * xy * z * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
+        r[51] = -0.51891557872026028f * y * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + 5.0f * x4 + y4);
+        r[52] = 4.1513246297620823f * xy * z * (x2 - y2) * (13.0f * z2 - 3.0f);
+        r[53] = -0.15645893386229404f * y * (3.0f * x2 - y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
+        r[54] = 0.44253269244498261f * xy * z * (-110.0f * z2 + 143.0f * z4 + 15.0f);
+        r[55] = 0.090331607582517306f * y * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
+        r[56] = 0.068284276912004949f * z * (315.0f * z2 - 693.0f * z4 + 429.0f * z6 - 35.0f);
+        r[57] = 0.090331607582517306f * x * (-135.0f * z2 + 495.0f * z4 - 429.0f * z6 + 5.0f);
+        r[58] = 0.07375544874083044f * z * (x2 - y2) * (143.0f * z2 * (3.0f * z2 - 1.0f) - 187.0f * z2 + 45.0f);
+        r[59] = -0.15645893386229404f * x * (x2 - 3.0f * y2) * (13.0f * z2 * (11.0f * z2 - 3.0f) - 27.0f * z2 + 3.0f);
+        r[60] = 1.0378311574405206f * z * (13.0f * z2 - 3.0f) * (-6.0f * x2 * y2 + x4 + y4);
+        r[61] = -0.51891557872026028f * x * (13.0f * z2 - 1.0f) * (-10.0f * x2 * y2 + x4 + 5.0f * y4);
+        r[62] = 2.6459606618019f * z * (15.0f * x2 * y4 - 15.0f * x4 * y2 + x6 - y6);
+        r[63] = 0.70716273252459627f * x * (-35.0f * x2 * y4 + 21.0f * x4 * y2 - x6 + 7.0f * y6);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * H1  LibTorch hash-grid encoder           NeRF.cpp:208-318, NeRF.h:137-147
+ *     resolution_l = floor(float(base * pow(b, l)))  with b = float(exp((ln finest - ln base)/(L-1)))
+ *       (NeRF.cpp:251,309: the product is a double, torch::tensor(double) makes an fp32 tensor)
+ *     grid = (max-min)/res ; idx = floor((clamp(x) - min)/grid) as int64 ; vmin = idx*grid + min ;
+ *     vmax = vmin + grid ; hash = (ix*1 ^ iy*2654435761 ^ iz*805459861) & (2^T - 1) in int64 ;
+ *     corner order z fastest ; trilinear weights use the UNCLAMPED x (NeRF.cpp:311 passes x) ;
+ *     keep_mask = all(x == clamp(x)) (NeRF.cpp:213,316).
+ *     table layout: [L][2^T][F] fp32 (L independent nn::Embedding, NeRF.cpp:255-256)
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_hash_ngp_resolutions(int n_levels, int base, int finest, float *res_out)
+{
+    float b = (float)exp((log((double)finest) - log((double)base)) / (double)(n_levels - 1));
+    for (int l = 0; l < n_levels; l++) {
+        double prod = (double)base * pow((double)b, (double)l);
+        res_out[l] = floorf((float)prod);
+    }
+}
+
+ORC_API void orc_hash_ngp(const float *x, int64_t p, const float *table, const float *bbox,
+                          int n_levels, int n_feat, int log2_t, int base, int finest,
+                          float *out /*[p, L*F]*/, uint8_t *mask /*[p]*/)
+{
+    float res[64];
+    orc_hash_ngp_resolutions(n_levels, base, finest, res);
+    const int64_t tsize = (int64_t)1 << log2_t;
+    const int64_t hmask = tsize - 1;
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float xc[3];
+        int keep = 1;
+        for (int a = 0; a < 3; a++) {
+            float v = x[i * 3 + a];
+            float c = f_max(f_min(v, bbox[3 + a]), bbox[a]);
+            if (!(v == c)) keep = 0;
+            xc[a] = c;
+        }
+        if (mask) mask[i] = (uint8_t)keep;
+        for (int l = 0; l < n_levels; l++) {
+            float w[3];
+            int64_t idx[3];
+            for (int a = 0; a < 3; a++) {
+                float grid = (bbox[3 + a] - bbox[a]) / res[l];
+                idx[a] = (int64_t)floorf((xc[a] - bbox[a]) / grid);
+                float vmin = (float)idx[a] * grid + bbox[a];
+                float vmax = vmin + grid;           /* vmin + 1.0*grid */
+                w[a] = (x[i * 3 + a] - vmin) / (vmax - vmin);
+            }
+            const float *tl = table + (int64_t)l * tsize * n_feat;
+            const float *e[8];
+            for (int c = 0; c < 8; c++) {
+                int64_t cx = idx[0] + ((c >> 2) & 1), cy = idx[1] + ((c >> 1) & 1), cz = idx[2] + (c & 1);
+                int64_t hsh = ((cx * 1LL) ^ (cy * 2654435761LL) ^ (cz * 805459861LL)) & hmask;
+                e[c] = tl + hsh * n_feat;
+            }
+            const float omx = 1.0f - w[0], omy = 1.0f - w[1], omz = 1.0f - w[2];
+            for (int f = 0; f < n_feat; f++) {
+                float c00 = e[0][f] * omx + e[4][f] * w[0];
+                float c01 = e[1][f] * omx + e[5][f] * w[0];
+                float c10 = e[2][f] * omx + e[6][f] * w[0];
+                float c11 = e[3][f] * omx + e[7][f] * w[0];
+                float c0 = c00 * omy + c10 * w[1];
+                float c1 = c01 * omy + c11 * w[1];
+                out[i * n_levels * n_feat + l * n_feat + f] = c0 * omz + c1 * w[2];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * H2  CUDA hash-grid encoder               CuHashEmbedder.cpp:85-103 (host: mask + clamp),
+ *                                          CuHashEmbedder.cu:27-101 (kernel), :221-275 (launch)
+ *     RESTATEMENT-PINNED (CUDA-only unit).  fp16 table (fp32 master cast per call, .cu:257),
+ *     uint32 hash with per-level random primes, position scale mul_l = exp2f(...) NOT floored,
+ *     level base offset in ELEMENTS = feat_local_idx[l] while rows are F wide (the overlap
+ *     quirk, .cu:54 vs :96), fp32 blend rounded once to fp16 (.cu:95), returned as fp32 (.cu:274).
+ *     mul_l is computed on the host in fp32 libm (orc_hash_cu_scales) and handed to both this
+ *     oracle and the HIP kernel, so the two agree bit for bit on voxel indices.
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_hash_cu_scales(int n_levels, int base, int finest, float *mul_out)
+{
+    for (int l = 0; l < n_levels; l++)
+        mul_out[l] = exp2f((log2f((float)finest) - log2f((float)base)) * (float)l / (float)(n_levels - 1) + log2f((float)base));
+}
+
+ORC_API void orc_hash_cu(const float *x, int64_t p, const uint16_t *table_f16, const int32_t *primes /*[L,1,3]*/,
+                         const int32_t *local_idx /*[L]*/, const int32_t *local_size /*[L]*/,
+                         const float *bias /*[L,3]*/, const float *bbox, const float *mul /*[L]*/,
+                         int n_levels, int n_feat,
+                         float *out /*[p, L*F] fp32 holding fp16-rounded values*/, uint8_t *mask)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float xc[3];
+        int keep = 1;
+        for (int a = 0; a < 3; a++) {
+            float v = x[i * 3 + a];
+            float c = f_max(f_min(v, bbox[3 + a]), bbox[a]);
+            if (!(v == c)) keep = 0;
+            xc[a] = c;
+        }
+        if (mask) mask[i] = (uint8_t)keep;
+        for (int l = 0; l < n_levels; l++) {
+            float pt[3], fl[3];
+            uint32_t pos[3];
+            for (int a = 0; a < 3; a++) {
+                pt[a] = (xc[a] - bbox[a]) / (bbox[3 + a] - bbox[a]) * mul[l];
+                pt[a] = pt[a] + bias[l * 3 + a];
+                fl[a] = floorf(pt[a]);
+                pos[a] = (uint32_t)fl[a];
+            }
+            const uint32_t pa = (uint32_t)primes[l * 3 + 0], pb = (uint32_t)primes[l * 3 + 1], pc = (uint32_t)primes[l * 3 + 2];
+            const uint32_t lsz = (uint32_t)local_size[l];
+            const uint16_t *fp = table_f16 + local_idx[l];
+            const float a = pt[0] - fl[0], b = pt[1] - fl[1], c = pt[2] - fl[2];
+            float ws[8];
+            uint32_t ps[8];
+            for (int k = 0; k < 8; k++) {        /* k = (dx dy dz) bits, same order as pos_000..pos_111 */
+                uint32_t dx = (k >> 2) & 1u, dy = (k >> 1) & 1u, dz = k & 1u;
+                ps[k] = (((pos[0] + dx) * pa) ^ ((pos[1] + dy) * pb) ^ ((pos[2] + dz) * pc)) % lsz;
+                float wx = dx ? a : (1.0f - a), wy = dy ? b : (1.0f - b), wz = dz ? c : (1.0f - c);
+                ws[k] = wx * wy * wz;
+            }
+            for (int f = 0; f < n_feat; f++) {
+                float acc = ws[0] * f16_bits_to_f32(fp[ps[0] * n_feat + f]);
+                for (int k = 1; k < 8; k++)
+                    acc = acc + ws[k] * f16_bits_to_f32(fp[ps[k] * n_feat + f]);
+                out[i * n_levels * n_feat + l * n_feat + f] = f16_bits_to_f32(f32_to_f16_bits(acc));
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * MLPs.  Parameters arrive as ONE fp32 blob in the reference's named_parameters() order
+ * (== checkpoint order, NeRFExecutor.h:1055-1070), Linear weights [out, in] row-major.
+ * Dot products: fp32, ascending k.  (LibTorch uses MKL sgemm whose blocking/FMA order is
+ * unknowable; agreement is to ~1e-6 relative, tolerance stated in the tests.)
+ * ------------------------------------------------------------------------------------------ */
+static void linear(const float *w, const float *b, const float *x, int in, int out, float *y, int relu)
+{
+    for (int o = 0; o < out; o++) {
+        float acc = 0.0f;
+        const float *wr = w + (int64_t)o * in;
+        for (int k = 0; k < in; k++) acc += wr[k] * x[k];
+        if (b) acc += b[o];
+        y[o] = (relu && acc < 0.0f) ? 0.0f : acc;
+    }
+}
+
+/* M2  NeRFSmallImpl::forward               NeRF.cpp:322-412 (bias-free; use_pred_normal=false)
+ *     sigma net: in -> H .. -> 1+geo (ReLU between); colour net: cat[views, geo] -> Hc .. -> 3;
+ *     out = cat[colour, sigma] */
+ORC_API int64_t orc_mlp_small_param_count(int in_ch, int in_views, int n_layers, int hidden, int geo, int n_layers_c, int hidden_c)
+{
+    int64_t n = 0;
+    for (int l = 0; l < n_layers; l++) n += (int64_t)((l == 0) ? in_ch : hidden) * ((l == n_layers - 1) ? (1 + geo) : hidden);
+    for (int l = 0; l < n_layers_c; l++) n += (int64_t)((l == 0) ? in_views + geo : hidden_c) * ((l == n_layers_c - 1) ? 3 : hidden_c);
+    return n;
+}
+
+ORC_API void orc_mlp_small(const float *params, const float *x /*[p, in_ch+in_views]*/, int64_t p,
+                           int in_ch, int in_views, int n_layers, int hidden, int geo, int n_layers_c, int hidden_c,
+                           float *out /*[p,4]*/)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float a[512], b2[512];
+        const float *xi = x + i * (in_ch + in_views);
+        const float *w = params;
+        const float *cur = xi;
+        float *bufs[2] = {a, b2};
+        int cur_dim = in_ch;
+        for (int l = 0; l < n_layers; l++) {
+            int od = (l == n_layers - 1) ? (1 + geo) : hidden;
+            linear(w, NULL, cur, cur_dim, od, bufs[l & 1], l != n_layers - 1);
+            w += (int64_t)cur_dim * od;
+            cur = bufs[l & 1]; cur_dim = od;
+        }
+        float sigma = cur[0];
+        float cin[512];
+        for (int k = 0; k < in_views; k++) cin[k] = xi[in_ch + k];
+        for (int k = 0; k < geo; k++) cin[in_views + k] = cur[1 + k];
+        cur = cin; cur_dim = in_views + geo;
+        for (int l = 0; l < n_layers_c; l++) {
+            int od = (l == n_layers_c - 1) ? 3 : hidden_c;
+            linear(w, NULL, cur, cur_dim, od, bufs[l & 1], l != n_layers_c - 1);
+            w += (int64_t)cur_dim * od;
+            cur = bufs[l & 1]; cur_dim = od;
+        }
+        out[i * 4 + 0] = cur[0]; out[i * 4 + 1] = cur[1]; out[i * 4 + 2] = cur[2]; out[i * 4 + 3] = sigma;
+    }
+}
+
+/* M1  NeRFImpl::forward                    NeRF.cpp:41-126
+ *     D Linear(+bias)+ReLU; after layer index `skip` h = cat[input_pts, h] (NeRF.cpp:103-104);
+ *     viewdirs: alpha = Linear(W,1)(h); feat = Linear(W,W)(h) (no ReLU); h = cat[feat, views];
+ *     ReLU(Linear(W+views, W/2)); rgb = Linear(W/2,3); out = cat[rgb, alpha]
+ *     no viewdirs: out = Linear(W+in, out_ch)(cat[h, input_pts]) (NeRF.cpp:121-124)
+ *     blob order: pts_linears_i.{weight,bias}..., then (viewdirs) views_linears_0.{w,b},
+ *     feature_linear.{w,b}, alpha_linear.{w,b}, rgb_linear.{w,b}  |  (else) output_linear.{w,b} */
+ORC_API int64_t orc_mlp_nerf_param_count(int d, int w, int in_ch, int in_views, int out_ch, int skip, int use_viewdirs)
+{
+    int64_t n = (int64_t)in_ch * w + w;
+    for (int i = 0; i < d - 1; i++) n += (int64_t)((i == skip) ? (w + in_ch) : w) * w + w;
+    if (use_viewdirs) n += (int64_t)(in_views + w) * (w / 2) + w / 2 + (int64_t)w * w + w + w + 1 + (int64_t)(w / 2) * 3 + 3;
+    else n += (int64_t)(w + in_ch) * out_ch + out_ch;
+    return n;
+}
+
+ORC_API void orc_mlp_nerf(const float *params, const float *x, int64_t p, int d, int w, int in_ch, int in_views,
+                          int out_ch, int skip, int use_viewdirs, float *out)
+{
+    const int xd = in_ch + (use_viewdirs ? in_views : 0);
+    const int od = use_viewdirs ? 4 : out_ch;
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float h0[1024], h1[1024];
+        const float *xi = x + i * xd;
+        const float *wp = params;
+        float *bufs[2] = {h0, h1};
+        const float *cur = xi;
+        int cur_dim = in_ch;
+        int which = 0;
+        for (int l = 0; l < d; l++) {
+            float *dst = bufs[which];
+            int off = (l == skip) ? in_ch : 0;       /* after layer `skip`: cat[input_pts, h] */
+            linear(wp, wp + (int64_t)cur_dim * w, cur, cur_dim, w, dst + off, 1);
+            wp += (int64_t)cur_dim * w + w;
+            if (off) memcpy(dst, xi, sizeof(float) * in_ch);
+            cur = dst; cur_dim = w + off; which ^= 1;
+        }
+        if (use_viewdirs) {
+            const float *vw = wp; wp += (int64_t)(in_views + w) * (w / 2) + w / 2;
+            const float *fw = wp; wp += (int64_t)w * w + w;
+            const float *aw = wp; wp += w + 1;
+            const float *rw = wp;
+            float alpha;
+            linear(aw, aw + w, cur, w, 1, &alpha, 0);
+            float *feat = bufs[which];
+            linear(fw, fw + (int64_t)w * w, cur, w, w, feat, 0);
+            memcpy(feat + w, xi + in_ch, sizeof(float) * in_views);
+            float *hv = bufs[which ^ 1];
+            linear(vw, vw + (int64_t)(in_views + w) * (w / 2), feat, w + in_views, w / 2, hv, 1);
+            linear(rw, rw + (int64_t)(w / 2) * 3, hv, w / 2, 3, out + i * od, 0);
+            out[i * od + 3] = alpha;
+        } else {
+            float *hc = bufs[which];
+            memcpy(hc, cur, sizeof(float) * w);
+            memcpy(hc + w, xi, sizeof(float) * in_ch);
+            linear(wp, wp + (int64_t)(w + in_ch) * out_ch, hc, w + in_ch, out_ch, out + i * od, 0);
+        }
+    }
+}
+
+/* L1  LeRFImpl::forward                    LeRF.cpp:28-111 (bias-free)
+ *     sigma net: in -> H.. -> 1+geo ; LE net: cat[geo, in] -> H.. -> E ; L2-normalise (eps 1e-8:
+ *     x / max(||x||, eps)) ; out = cat[le, sigma] */
+ORC_API void orc_lerf(const float *params, const float *x, int64_t p, int in_ch, int n_layers, int hidden, int geo, int embed,
+                      float *out /*[p, embed+1]*/)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float *a = (float *)malloc(sizeof(float) * 4096), *b2 = (float *)malloc(sizeof(float) * 4096), *cin = (float *)malloc(sizeof(float) * 4096);
+        float *bufs[2] = {a, b2};
+        const float *xi = x + i * in_ch;
+        const float *w = params;
+        const float *cur = xi;
+        int cur_dim = in_ch;
+        for (int l = 0; l < n_layers; l++) {
+            int od = (l == n_layers - 1) ? (1 + geo) : hidden;
+            linear(w, NULL, cur, cur_dim, od, bufs[l & 1], l != n_layers - 1);
+            w += (int64_t)cur_dim * od; cur = bufs[l & 1]; cur_dim = od;
+        }
+        float sigma = cur[0];
+        for (int k = 0; k < geo; k++) cin[k] = cur[1 + k];
+        for (int k = 0; k < in_ch; k++) cin[geo + k] = xi[k];
+        cur = cin; cur_dim = geo + in_ch;
+        for (int l = 0; l < n_layers; l++) {
+            int od = (l == n_layers - 1) ? embed : hidden;
+            linear(w, NULL, cur, cur_dim, od, bufs[l & 1], l != n_layers - 1);
+            w += (int64_t)cur_dim * od; cur = bufs[l & 1]; cur_dim = od;
+        }
+        double ss = 0.0;
+        for (int k = 0; k < embed; k++) ss += (double)cur[k] * (double)cur[k];
+        float nrm = f_max((float)sqrt(ss), 1e-8f);
+        for (int k = 0; k < embed; k++) out[i * (embed + 1) + k] = cur[k] / nrm;
+        out[i * (embed + 1) + embed] = sigma;
+        free(a); free(b2); free(cin);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * C1  RawToOutputs                         NeRFRenderer.h:199-282, TruncExp fwd CustomOps.cpp:5-9
+ *     dists = [z[i+1]-z[i], 1e10] * ||d|| ; rgb = sigmoid(raw[:3]) ;
+ *     alpha = -exp(-relu(sigma)*dists) + 1 ;
+ *     T_i = exp(sum_{j<i} log(max(1-alpha_j, 1e-10)))  -- cumsum accumulates in DOUBLE, each prefix
+ *     rounded to fp32 (ATen CPU cumsum) ; w = alpha*T ; rgb_map = sum w*rgb ;
+ *     depth = sum(w*z)/max(sum w, 1e-10) ; disp = 1/max(1e-10, depth) ; acc = sum w ;
+ *     white: rgb_map + (1 - acc).   Reductions over samples: double accumulate, one rounding.
+ *     raw has `c` channels per sample with rgb at 0..2 and sigma at 3 (c = 4 or 5).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        const float *dv = d + i * 3;
+        float nrm = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        double logt = 0.0;        /* running double prefix */
+        float tprev = 0.0f;       /* exclusive prefix rounded to fp32 */
+        double sr = 0, sg = 0, sb = 0, sw = 0, swz = 0;
+        for (int j = 0; j < s; j++) {
+            const float *r = raw + (i * s + j) * c;
+            float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
+            dist = dist * nrm;
+            float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            float alpha = -expf(-sig * dist) + 1.0f;
+            float trans = expf(tprev);
+            float w = alpha * trans;
+            float one_m = 1.0f - alpha;
+            float lg = logf(one_m > 1e-10f ? one_m : 1e-10f);
+            logt += (double)lg;
+            tprev = (float)logt;
+            if (weights) weights[i * s + j] = w;
+            float cr = 1.0f / (1.0f + expf(-r[0])), cg = 1.0f / (1.0f + expf(-r[1])), cb = 1.0f / (1.0f + expf(-r[2]));
+            sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);
+            sw += (double)w; swz += (double)(w * z[i * s + j]);
+        }
+        float acc = (float)sw;
+        float dep = (float)swz / (acc > 1e-10f ? acc : 1e-10f);
+        float rr = (float)sr, gg = (float)sg, bb = (float)sb;
+        if (white_bkgr) { float bg = 1.0f - acc; rr = rr + bg; gg = gg + bg; bb = bb + bg; }
+        rgb_map[i * 3] = rr; rgb_map[i * 3 + 1] = gg; rgb_map[i * 3 + 2] = bb;
+        if (depth) depth[i] = dep;
+        if (disp) disp[i] = 1.0f / (dep > 1e-10f ? dep : 1e-10f);
+        if (acc_map) acc_map[i] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R8  SamplePDF (det)                      Sampler.h:6-43
+ *     w += 1e-8 ; pdf = w / sum(w) (sum in ATen's order for a `sum_vec`-wide host, see
+ *     aten_row_sum_f32; 0 = double accumulate) ; cdf = [0, cumsum(pdf)] (double accumulate, fp32 prefixes) ;
+ *     inds = searchsorted(cdf, u, right=True) = #{cdf_k <= u} ; below = max(0, inds-1) ;
+ *     above = min(nb-1, inds) ; denom = cdf[above]-cdf[below], <1e-5 -> 1 ;
+ *     t = (u - cdf[below]) / denom ; sample = bins[below] + t*(bins[above]-bins[below])
+ *     bins: [n, nb], weights: [n, nb-1], u: [ns] (torch::linspace(0,1,ns) supplied by the host).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_sample_pdf(const float *bins, const float *weights, int64_t n, int nb, const float *u, int ns, int sum_vec,
+                            float *samples, int64_t *inds_out, float *cdf_out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        float cdf[1024], wv[1024];
+        const int nw = nb - 1;
+        for (int k = 0; k < nw; k++) wv[k] = weights[i * nw + k] + (float)1e-8;
+        float fsum = aten_row_sum_f32(wv, nw, sum_vec);
+        cdf[0] = 0.0f;
+        double run = 0.0;
+        for (int k = 0; k < nw; k++) { float pdf = wv[k] / fsum; run += (double)pdf; cdf[k + 1] = (float)run; }
+        if (cdf_out) memcpy(cdf_out + i * nb, cdf, sizeof(float) * nb);
+        const float *b = bins + i * nb;
+        for (int j = 0; j < ns; j++) {
+            int lo = 0, hi = nb;                 /* first index with cdf[idx] > u */
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u[j]) lo = mid + 1; else hi = mid; }
+            int ind = lo;
+            int below = ind - 1 > 0 ? ind - 1 : 0;
+            int above = ind < nb - 1 ? ind : nb - 1;
+            float denom = cdf[above] - cdf[below];
+            if (denom < 1e-5f) denom = 1.0f;
+            float t = (u[j] - cdf[below]) / denom;
+            samples[i * ns + j] = b[below] + t * (b[above] - b[below]);
+            if (inds_out) inds_out[i * ns + j] = ind;
+        }
+    }
+}
+
+/* z_mid = .5*(z[1:] + z[:-1])              NeRFRenderer.h:427 */
+ORC_API void orc_z_mid(const float *z, int64_t n, int s, float *mid)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j + 1 < s; j++) mid[i * (s - 1) + j] = 0.5f * (z[i * s + j + 1] + z[i * s + j]);
+}
+
+/* sort(cat(z_vals, z_samples))             NeRFRenderer.h:431  (stable ascending; values only are used) */
+static int cmp_float(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+ORC_API void orc_merge_sorted(const float *z, int s, const float *zs, int ns, int64_t n, float *out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        float *o = out + i * (s + ns);
+        memcpy(o, z + i * s, sizeof(float) * s);
+        memcpy(o + s, zs + i * ns, sizeof(float) * ns);
+        qsort(o, s + ns, sizeof(float), cmp_float);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R4/R5/R6/R9  RenderRays end to end       NeRFRenderer.h:366-459 (+RunNetwork :164-194)
+ *     ThinRay (no TangentScatter), Perturb = 0, RawNoiseStd = 0.  One network for both passes.
+ *     family 0 = HashEmbedder(H1) + SHEncoder(S2) + NeRFSmall ; family 1 = PE + PE + NeRF ;
+ *     family 2 = CuHashEmbedder(H2) + CuSHEncoder(S1) + NeRFSmall.
+ *     rays: [n, 11] = o, d, near, far, viewdir  (NeRFRenderer.h:580-583).
+ *     Used by the tests as the end-to-end checker and by bench.py's cpu_baseline ("port").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int family;
+    /* encoders */
+    const float *bbox;
+    int n_levels, n_feat, log2_t, base, finest;
+    const float *table_f32;            /* family 0 */
+    const uint16_t *table_f16;         /* family 2 */
+    const int32_t *primes, *local_idx, *local_size;
+    const float *bias, *mul;
+    int sh_degree;
+    int pe_freqs, pe_freqs_views;
+    /* MLP */
+    const float *params;
+    int n_layers, hidden, geo, n_layers_c, hidden_c;   /* small */
+    int depth, width, skip;                             /* classic */
+} orc_model;
+
+static void run_network(const orc_model *m, const float *pts, const float *viewdirs, int64_t n, int s, float *raw)
+{
+    const int64_t p = n * s;
+    int in_ch, in_views;
+    float *emb, *embd;
+    uint8_t *mask = NULL;
+    if (m->family == 1) { in_ch = 3 + 6 * m->pe_freqs; in_views = 3 + 6 * m->pe_freqs_views; }
+    else { in_ch = m->n_levels * m->n_feat; in_views = m->sh_degree * m->sh_degree; }
+    emb = (float *)malloc(sizeof(float) * p * in_ch);
+    embd = (float *)malloc(sizeof(float) * n * in_views);
+    if (m->family == 0) { mask = (uint8_t *)malloc(p); orc_hash_ngp(pts, p, m->table_f32, m->bbox, m->n_levels, m->n_feat, m->log2_t, m->base, m->finest, emb, mask); orc_sh_libtorch(viewdirs, n, m->sh_degree, embd); }
+    else if (m->family == 2) { mask = (uint8_t *)malloc(p); orc_hash_cu(pts, p, m->table_f16, m->primes, m->local_idx, m->local_size, m->bias, m->bbox, m->mul, m->n_levels, m->n_feat, emb, mask); orc_sh_cu(viewdirs, n, m->sh_degree, embd); }
+    else { orc_pe(pts, p, m->pe_freqs, emb); orc_pe(viewdirs, n, m->pe_freqs_views, embd); }
+    /* view-direction features are identical for every sample of a ray (NeRFRenderer.h:179 expands them) */
+    float *xin = (float *)malloc(sizeof(float) * p * (in_ch + in_views));
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        memcpy(xin + i * (in_ch + in_views), emb + i * in_ch, sizeof(float) * in_ch);
+        memcpy(xin + i * (in_ch + in_views) + in_ch, embd + (i / s) * in_views, sizeof(float) * in_views);
+    }
+    if (m->family == 1) orc_mlp_nerf(m->params, xin, p, m->depth, m->width, in_ch, in_views, 4, m->skip, 1, raw);
+    else orc_mlp_small(m->params, xin, p, in_ch, in_views, m->n_layers, m->hidden, m->geo, m->n_layers_c, m->hidden_c, raw);
+    if (mask) {
+        for (int64_t i = 0; i < p; i++) if (!mask[i]) raw[i * 4 + 3] = 0.0f;      /* NeRFRenderer.h:187-188 */
+        free(mask);
+    }
+    free(emb); free(embd); free(xin);
+}
+
+ORC_API void orc_render_rays(const orc_model *m, const float *rays, int64_t n, int n_samples, int n_importance,
+                             const float *t_coarse, const float *u_fine, int lindisp, int white_bkgr, int sum_vec,
+                             float *rgb, float *disp, float *acc, float *depth, float *weights_fine,
+                             float *z_coarse_out, float *z_fine_out, float *raw_coarse_out, float *raw_fine_out,
+                             float *weights_coarse_out)
+{
+    const int s = n_samples, sf = n_samples + n_importance;
+    float *o = (float *)malloc(sizeof(float) * n * 3), *d = (float *)malloc(sizeof(float) * n * 3), *vd = (float *)malloc(sizeof(float) * n * 3);
+    float *nears = (float *)malloc(sizeof(float) * n), *fars = (float *)malloc(sizeof(float) * n);
+    for (int64_t i = 0; i < n; i++) {
+        memcpy(o + i * 3, rays + i * 11, 12); memcpy(d + i * 3, rays + i * 11 + 3, 12); memcpy(vd + i * 3, rays + i * 11 + 8, 12);
+        nears[i] = rays[i * 11 + 6]; fars[i] = rays[i * 11 + 7];
+    }
+    float *z = (float *)malloc(sizeof(float) * n * s), *pts = (float *)malloc(sizeof(float) * n * sf * 3);
+    float *raw = (float *)malloc(sizeof(float) * n * sf * 4), *wc = (float *)malloc(sizeof(float) * n * s);
+    float *c_rgb = (float *)malloc(sizeof(float) * n * 3);
+    orc_z_vals(nears, fars, t_coarse, n, s, lindisp, z);
+    orc_points(o, d, z, n, s, pts);
+    run_network(m, pts, vd, n, s, raw);
+    if (n_importance <= 0) {
+        orc_raw2outputs(raw, z, d, n, s, 4, white_bkgr, rgb, disp, acc, weights_fine, depth);
+    } else {
+        orc_raw2outputs(raw, z, d, n, s, 4, white_bkgr, c_rgb, NULL, NULL, wc, NULL);
+    }
+    if (z_coarse_out) memcpy(z_coarse_out, z, sizeof(float) * n * s);
+    if (raw_coarse_out) memcpy(raw_coarse_out, raw, sizeof(float) * n * s * 4);
+    if (weights_coarse_out && n_importance > 0) memcpy(weights_coarse_out, wc, sizeof(float) * n * s);
+    if (n_importance > 0) {
+        float *mid = (float *)malloc(sizeof(float) * n * (s - 1)), *wmid = (float *)malloc(sizeof(float) * n * (s - 2));
+        float *zs = (float *)malloc(sizeof(float) * n * n_importance), *zf = (float *)malloc(sizeof(float) * n * sf);
+        orc_z_mid(z, n, s, mid);
+        for (int64_t i = 0; i < n; i++) memcpy(wmid + i * (s - 2), wc + i * s + 1, sizeof(float) * (s - 2));   /* weights[..., 1:-1] */
+        orc_sample_pdf(mid, wmid, n, s - 1, u_fine, n_importance, sum_vec, zs, NULL, NULL);
+        orc_merge_sorted(z, s, zs, n_importance, n, zf);
+        orc_points(o, d, zf, n, sf, pts);
+        run_network(m, pts, vd, n, sf, raw);
+        orc_raw2outputs(raw, zf, d, n, sf, 4, white_bkgr, rgb, disp, acc, weights_fine, depth);
+        if (z_fine_out) memcpy(z_fine_out, zf, sizeof(float) * n * sf);
+        if (raw_fine_out) memcpy(raw_fine_out, raw, sizeof(float) * n * sf * 4);
+        free(mid); free(wmid); free(zs); free(zf);
+    }
+    free(o); free(d); free(vd); free(nears); free(fars); free(z); free(pts); free(raw); free(wc); free(c_rgb);
+}
+
+/* viewdirs = d / ||d||                     NeRFRenderer.h:559 ; rays_ = cat[o, d, near, far, viewdirs] :580-583 */
+ORC_API void orc_pack_rays(const float *o, const float *d, const float *bbox, int64_t n, float *rays /*[n,11]*/)
+{
+    float *nears = (float *)malloc(sizeof(float) * n), *fars = (float *)malloc(sizeof(float) * n);
+    orc_aabb(o, d, bbox, n, 0.0f, nears, fars);
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        const float *dv = d + i * 3;
+        float nrm = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        float *r = rays + i * 11;
+        for (int a = 0; a < 3; a++) { r[a] = o[i * 3 + a]; r[3 + a] = dv[a]; r[8 + a] = dv[a] / nrm; }
+        r[6] = nears[i]; r[7] = fars[i];
+    }
+    free(nears); free(fars);
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

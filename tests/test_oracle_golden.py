@@ -1,0 +1,243 @@
+"""CPU tests: the C oracle (oracle/nerf_oracle.c) against golden vectors emitted by the
+reference's own LibTorch CPU path (oracle/_ref/ref_driver -> tests/golden/*.npz).
+
+Bars (stated per test):
+  * bit-exact   -- integer / index outputs and every stage made only of + - * / floor / compare
+  * <= 2 ulp    -- stages whose only difference is ATen's SLEEF sin/cos/exp/log vs libm, or ATen's
+                   vectorised sum order
+  * 1e-4 rel    -- MLPs (MKL sgemm blocking / FMA order is unknowable)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from nerfpp_amd import synth
+from oracle import capi as O
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1); b = np.ascontiguousarray(b, np.float32).reshape(-1)
+    ia = a.view(np.int32).astype(np.int64); ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia); ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def assert_exact(a, b, what=""):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape or a.size == b.size, (what, a.shape, b.shape)
+    bad = np.nonzero(a.reshape(-1) != b.reshape(-1))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}"
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    np.testing.assert_allclose(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1), rtol=rtol, atol=atol, err_msg=what)
+
+
+# ------------------------------------------------------------------------------------------- rays
+def test_get_rays_bit_exact():
+    g = load_golden("rays")
+    h, w = g["hw"]
+    o, d, cone = O.get_rays(h, w, g["k"], g["c2w"])
+    assert_exact(o, g["o"], "rays_o"); assert_exact(d, g["d"], "rays_d"); assert_exact(cone, g["cone"][0], "cone_angle")
+    o2, d2, _ = O.get_rays(8, 8, g["k2"], g["c2w2"])
+    assert_exact(o2, g["o2"]); assert_exact(d2, g["d2"])
+    # row-tile form (multi-GPU sharding): rows [2,5) of the image equal the slice of the full image
+    ot, dt, _ = O.get_rays(h, w, g["k"], g["c2w"], row0=2, rows=3)
+    assert_exact(ot, g["o"][2:5]); assert_exact(dt, g["d"][2:5])
+
+
+def test_ndc_rays_bit_exact():
+    g = load_golden("rays")
+    h, w = g["hw"]
+    oo, od = O.ndc_rays(h, w, g["k"][0, 0], 1.0, g["o"], g["d"])
+    assert_exact(oo, g["ndc_o"]); assert_exact(od, g["ndc_d"])
+
+
+def test_aabb_bit_exact_including_misses():
+    g = load_golden("aabb")
+    nr, fr = O.aabb(g["o"], g["d"], g["bbox"])
+    assert_exact(nr, g["near"]); assert_exact(fr, g["far"])
+    assert (g["far"] - g["near"] <= 2e-6).sum() >= 2, "fixture must contain rays that miss the box"
+
+
+def test_linspace_matches_aten_bit_exact():
+    g = load_golden("sample_pdf")
+    assert_exact(O.linspace(0, 1, 64), g["aux_t64"]); assert_exact(O.linspace(0, 1, 128), g["aux_u_128"])
+    assert_exact(O.linspace(0, 1, 192), g["aux_t192"]); assert_exact(O.linspace(0, 1, 5), g["aux_u_5"])
+
+
+# ---------------------------------------------------------------------------------------- sampler
+@pytest.mark.parametrize("ns", [128, 192, 5])
+def test_sample_pdf_indices_and_samples_bit_exact(ns):
+    g = load_golden("sample_pdf")
+    s, inds, cdf = O.sample_pdf(g["bins"], g["weights"], g[f"aux_u_{ns}"])
+    assert_exact(inds, g[f"aux_inds_{ns}"], "searchsorted indices")
+    assert_exact(s, g[f"samples_{ns}"], "samples")
+    if ns == 128:
+        assert_exact(cdf, g["aux_cdf"], "cdf")
+
+
+def test_sample_pdf_double_sum_variant_close():
+    """sum_vec=0 (order-free double accumulation) differs from ATen only at ulp-level CDF ties."""
+    g = load_golden("sample_pdf")
+    s, inds, _ = O.sample_pdf(g["bins"], g["weights"], g["aux_u_128"], sum_vec=0)
+    assert (inds == g["aux_inds_128"]).mean() > 0.995
+
+
+# --------------------------------------------------------------------------------------- encoders
+@pytest.mark.parametrize("nf", [10, 4, 2])
+def test_pe_within_2ulp_of_sleef(nf):
+    g = load_golden("pe")
+    out = O.pe(g["x"], nf)
+    assert_exact(out[:, :3], g[f"out_{nf}"][:, :3])
+    # sin/cos of arguments up to 2^9 * 1.5: libm vs SLEEF u10
+    assert_close(out, g[f"out_{nf}"], rtol=0, atol=2.5e-7, what="PE")
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5])
+def test_sh_libtorch_bit_exact(deg):
+    g = load_golden("sh")
+    assert_exact(O.sh_libtorch(g["dirs"], deg), g[f"out_{deg}"])
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5])
+def test_sh_cu_restatement_agrees_with_libtorch_on_unit_vectors(deg):
+    """S1 (CUDA, restatement-pinned) vs S2 (LibTorch, reference-pinned): same basis, different
+    algebraic form (S1 assumes |d| = 1); equal to fp32 rounding on unit vectors."""
+    g = load_golden("sh")
+    assert_close(O.sh_cu(g["dirs"], deg), g[f"out_{deg}"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["hash_small", "hash_f4", "hash_f8", "hash_full", "hash_full1024"])
+def test_hash_ngp_bit_exact(tag, manifest):
+    g = load_golden(tag)
+    L, F, T, base, fine = (int(v) for v in g["cfg"])
+    table = synth.blob_from_manifest(manifest[tag])
+    emb, mask = O.hash_ngp(g["x"], table, g["bbox"], L, F, T, base, fine)
+    assert_exact(mask, g["mask"], "keep_mask"); assert_exact(emb, g["emb"], "embedding")
+    assert (~g["mask"]).sum() > 0, "fixture must contain out-of-box points"
+
+
+# ------------------------------------------------------------------------------------------- MLPs
+@pytest.mark.parametrize("tag,kw", [
+    ("mlp_small_c4", dict(in_ch=32, in_views=16, n_layers_c=4)),
+    ("mlp_small_c3", dict(in_ch=32, in_views=16, n_layers_c=3)),
+    ("mlp_small_v64", dict(in_ch=32, in_views=64, n_layers_c=3)),
+])
+def test_mlp_small(tag, kw, manifest):
+    g = load_golden(tag)
+    y = O.mlp_small(synth.blob_from_manifest(manifest[tag]), g["x"], **kw)
+    assert_close(y, g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_mlp_nerf(manifest):
+    g = load_golden("mlp_nerf")
+    assert_close(O.mlp_nerf(synth.blob_from_manifest(manifest["mlp_nerf"]), g["x"], out_ch=5), g["y"], rtol=1e-4, atol=1e-5)
+    g = load_golden("mlp_nerf_noview")
+    y = O.mlp_nerf(synth.blob_from_manifest(manifest["mlp_nerf_noview"]), g["x"], in_views=0, out_ch=4, use_viewdirs=False)
+    assert_close(y, g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_lerf_head(manifest):
+    g = load_golden("lerf")
+    y = O.lerf(synth.blob_from_manifest(manifest["lerf"]), g["x"])
+    assert_close(y, g["y"], rtol=1e-3, atol=2e-7)
+    assert_close(np.linalg.norm(y[:, :768], axis=1), np.ones(y.shape[0]), rtol=1e-5, atol=0)
+
+
+# ------------------------------------------------------------------------------------ compositing
+@pytest.mark.parametrize("S", [64, 192])
+@pytest.mark.parametrize("bg", ["black", "white"])
+def test_raw2outputs(S, bg):
+    g = load_golden(f"raw2out_{S}")
+    r = O.raw2outputs(g["raw"], g["z"], g["d"], bg == "white")
+    for k in ("rgb", "disp", "acc", "weights", "depth"):
+        ref = g[f"{bg}_{k}"]
+        # exp/log/sigmoid are SLEEF in ATen; sums are vectorised: a few ulp.  disp = 1/max(1e-10, depth) is huge
+        # (1e10) for empty rays, so it is compared relatively.
+        assert_close(r[k], ref, rtol=3e-6, atol=3e-7, what=f"{k} S={S} {bg}")
+    assert r["acc"][0] == 0.0 and abs(r["acc"][1] - 1.0) < 1e-6      # zero-sigma ray, saturated ray
+
+
+# ------------------------------------------------------------------------------------- end to end
+def _hash_model(manifest, bbox):
+    ent = manifest["render_hash"]
+    table = synth.blob_from_manifest([e for e in ent if "embeddings" in e[0]])
+    params = synth.blob_from_manifest([e for e in ent if "embeddings" not in e[0]])
+    return O.Model(0, params, bbox=bbox, table_f32=table)
+
+
+def test_pack_rays_matches_render_prologue():
+    g = load_golden("render_hash")
+    o, d, _ = O.get_rays(8, 8, g["k"], g["c2w"])
+    rays = O.pack_rays(o, d, g["bbox"])
+    assert_exact(rays[:, :8], g["rays_flat"][:, :8], "o, d, near, far")
+    assert ulp_diff(rays[:, 8:], g["rays_flat"][:, 8:]).max() <= 2, "viewdirs = d/||d|| (torch::norm order)"
+
+
+@pytest.mark.parametrize("tag,family", [("render_hash", 0), ("render_hash_lindisp", 0), ("render_classic", 1)])
+def test_render_rays_end_to_end(tag, family, manifest):
+    g = load_golden(tag)
+    bbox = load_golden("render_hash")["bbox"]
+    model = _hash_model(manifest, bbox) if family == 0 else O.Model(1, synth.blob_from_manifest(manifest["render_classic"]), bbox=bbox)
+    lind = tag.endswith("lindisp")
+    out = O.render_rays(model, g["rays_flat"], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), lindisp=lind,
+                        white_bkgr=not lind, want_intermediates=True)
+    assert_exact(out["z_coarse"], g["coarse_z"], "coarse z_vals")
+    raw_scale = np.abs(g["coarse_raw"]).max()
+    assert_close(out["raw_coarse"], g["coarse_raw"], rtol=0, atol=1e-4 * raw_scale, what="coarse raw")
+    assert_close(out["weights_coarse"], g["coarse_weights"], rtol=0, atol=5e-6)
+    # the fine depths are a discontinuous function of the coarse weights (searchsorted on plateaus of
+    # the CDF): ulp-level MLP differences move a few samples that carry ~zero weight.
+    assert (out["z_fine"] == g["fine_z"]).mean() > 0.85
+    # pixels: north_star tolerance 1e-4
+    assert_close(out["rgb"], g["out_rgb"], rtol=0, atol=1e-4, what="rgb")
+    assert_close(out["acc"], g["out_acc"], rtol=0, atol=1e-4, what="acc")
+    assert_close(out["depth"], g["out_depth"], rtol=0, atol=3e-4, what="depth")
+    mse = np.mean((out["rgb"].reshape(-1) - g["out_rgb"].reshape(-1)) ** 2)
+    assert -10 * np.log10(max(mse, 1e-20)) > 80, "PSNR(oracle render, reference render) > 80 dB"
+
+
+def test_stage_chained_fine_sampling_bit_exact(manifest):
+    """Feed the REFERENCE's own coarse weights / z to the oracle's sampler stages: the fine depths
+    (sample indices included) must then match the reference bit for bit."""
+    for tag in ("render_hash", "render_classic", "render_hash_lindisp"):
+        g = load_golden(tag)
+        mid = O.z_mid(g["coarse_z"])
+        samples, _, _ = O.sample_pdf(mid, g["coarse_weights"][:, 1:-1], O.linspace(0, 1, 128))
+        zf = O.merge_sorted(g["coarse_z"], samples)
+        assert_exact(zf, g["fine_z"], f"{tag}: fine z_vals from reference coarse weights")
+        pts = O.points(g["rays_flat"][:, 0:3], g["rays_flat"][:, 3:6], zf)
+        assert_exact(pts, g["fine_pts"], f"{tag}: fine sample points")
+
+
+def test_chunk_invariance_of_reference():
+    g = load_golden("render_hash")
+    assert_close(g["chunk24_rgb"], g["out_rgb"], rtol=0, atol=2e-6)
+
+
+def test_coarse_only_reference_quirk(manifest):
+    """NImportance == 0: Render() returns UNDEFINED maps in the reference (NeRFRenderer.h:423 vs :448)."""
+    g = load_golden("render_classic_coarse")
+    assert int(g["rgb_defined"][0]) == 0
+    r = O.raw2outputs(g["coarse_raw"], g["coarse_z"], load_golden("render_classic")["rays_flat"][:, 3:6], True)
+    assert_close(r["rgb"], g["out_rgb"], rtol=0, atol=2e-6)
+
+
+def test_truncexp_forward_is_plain_exp():
+    g = load_golden("truncexp")
+    assert_close(np.exp(g["x"].astype(np.float32)), g["y"], rtol=3e-7, atol=0)
+    assert_close(np.exp(np.clip(g["x"], -100, 5)), g["grad"], rtol=3e-7, atol=0)
+
+
+def test_synth_generator_matches_c_header():
+    """nerfpp_amd/synth.py == include/nrf_synth.h (via the reference driver's fill): hash tables regenerate
+    to tensors that reproduce the golden embeddings bit for bit (test_hash_ngp_bit_exact) -- here just
+    the closed form on a few hand values."""
+    u = synth.synth_u32(5000, 4)
+    x = (np.arange(4, dtype=np.uint64) * 0x9E3779B9 + 5000) & 0xFFFFFFFF
+
+    def mix(v):
+        v ^= v >> 16; v = (v * 0x7FEB352D) & 0xFFFFFFFF; v ^= v >> 15; v = (v * 0x846CA68B) & 0xFFFFFFFF; v ^= v >> 16
+        return v
+    assert [int(mix(int(v))) for v in x] == [int(v) for v in u]
