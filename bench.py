@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-samples/s of the HIP volume-rendering path on synthetic Blender-Lego-shaped frames.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched under torch.distributed.run)
+
+A "step" renders `N` 800x800 frames (64 + 128 samples per ray, 256 network evaluations per ray).  Every frame is split
+into N contiguous row tiles, rank r renders tile r of every frame, and one RCCL all-gather per step hands every rank all
+N complete frames -- so each GPU traces 640 000 rays (163.84 M ray-samples) per step at any N: weak scaling.  At N = 1
+this is one frame and no collective.  Inputs (rays, tables, weights) are resident in HBM before the timed region.
+
+Workloads (BASELINE.json configs):  --workload hash    HashNeRF: CuHashEmbedder L16 T2^19 F2 + CuSHEncoder(4) + NeRFSmall
+                                     --workload classic PE(10)/PE(4) + NeRF 8x256
+One JSON line is printed by rank 0 (see the keys at the bottom).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+NS, NI = 64, 128
+UNITS_PER_RAY = NS + NS + NI          # one shared network, fine pass re-evaluates all depths (NeRFRenderer.h:422,447)
+
+# algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)
+HASH_BYTES_PER_UNIT = 16 * 8 * 2 * 2 + 12 + 64      # table gathers + point in + fp16 features out (standalone encode kernel)
+SMALL_FLOP_PER_UNIT = 35072
+NERF_FLOP_PER_UNIT = 1186816
+HBM_PEAK = 8.0e12
+MFMA_F16_PEAK = 2.5e15
+F32_PEAK = 157.3e12
+
+
+def cpu_baseline(workload, seconds_target=15.0):
+    """The reference's own CPU renderer (oracle/_ref/ref_driver, kind 'reference') when that binary travelled with the
+    repo, else the C oracle ('port'), on a bounded sample of the same workload: a few image rows of the same camera."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    fam = "hash" if workload == "hash" else "classic"
+    if os.path.exists(drv):
+        try:
+            def run(rows):
+                out = subprocess.run([drv, "bench", fam, str(H), str(rows), str(NS), str(NI), "4096", "1"], capture_output=True, text=True, timeout=600)
+                return json.loads(out.stdout.strip().splitlines()[-1])
+            probe = run(1)
+            rows = int(max(1, min(64, seconds_target / max(probe["seconds"], 1e-3))))
+            r = run(rows) if rows > 1 else probe
+            return dict(value=r["units_per_s"], unit="ray-samples/s", cores=r["threads"], kind="reference",
+                        sample=f"{r['rays']} rays ({rows} rows of the {H}x{W} frame), {NS}+{NI} samples, LibTorch CPU "
+                               f"{'HashEmbedder+SHEncoder+NeRFSmall' if fam == 'hash' else 'PE+NeRF 8x256'}, {r['seconds']:.1f} s")
+        except Exception as e:  # fall through to the port
+            print(f"[bench] reference driver failed ({e}); timing the oracle port instead", file=sys.stderr)
+    from oracle import capi as O
+    from nerfpp_amd import scene, synth
+    bbox = scene.LEGO_BBOX
+    if workload == "hash":
+        table = scene.synth_hash_table(16, 19, 2, 5000, 0.5)
+        blob = np.concatenate([a.reshape(-1) for _, a in scene.synth_linear_stack(scene.small_shapes(), 6000, 1.6, 0.0, {"sigma_net_2": 30.0})])
+        model = O.Model(0, blob, bbox=bbox, table_f32=table)
+    else:
+        blob = np.concatenate([a.reshape(-1) for _, a in scene.synth_linear_stack(scene.nerf_shapes(), 7000, 1.4, 0.1, {"alpha_linear.weight": 40.0})])
+        model = O.Model(1, blob, bbox=bbox)
+    K = scene.lego_K(H, W); c2w = scene.pose_spherical(30.0, -30.0, 4.0)
+
+    def run(rows):
+        o, d, _ = O.get_rays(H, W, K, c2w, row0=H // 2 - rows // 2, rows=rows)
+        rays = O.pack_rays(o, d, bbox)
+        t0 = time.time()
+        O.render_rays(model, rays, NS, NI, O.linspace(0, 1, NS), O.linspace(0, 1, NI), white_bkgr=True)
+        return rays.shape[0], time.time() - t0
+    n, t = run(1)
+    rows = int(max(1, min(64, seconds_target / max(t, 1e-3))))
+    if rows > 1:
+        n, t = run(rows)
+    return dict(value=n * UNITS_PER_RAY / t, unit="ray-samples/s", cores=O.num_threads(), kind="port",
+                sample=f"{n} rays ({rows} rows of the {H}x{W} frame), {NS}+{NI} samples, C oracle with OpenMP, {t:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="hash", choices=["hash", "classic"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
+    ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload)        # before the GPU is initialised (it may spawn a child process)
+
+    import torch
+    import torch.distributed as dist
+    from nerfpp_amd import _lib as L, scene
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from nerfpp_amd.dist import TileShard
+
+    prec = L.NRF_PREC_F16_MFMA if args.precision == "f16" else L.NRF_PREC_F32
+    if args.workload == "hash":
+        sc = scene.make_hash_scene(mode=args.hash_mode)
+        chunk = args.chunk or 32768
+    else:
+        sc = scene.make_classic_scene()
+        chunk = args.chunk or 8192
+    renderer = sc["renderer"]
+    rp = scene.lego_render_params(sc["bbox"], NS, NI, chunk, prec)
+    K = scene.lego_K(H, W)
+    # frames of one step: N poses on the reference's test orbit (pose_spherical(theta, -30, 4), theta step 9 degrees)
+    poses = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(world)]
+    shard = TileShard(H, W, rank, world)
+
+    def step():
+        tiles = [renderer.Render(H, W, K, rp, c2w=c2w, row0=shard.row0, rows=shard.rows).Outputs.RGBMap for c2w in poses]
+        return shard.all_gather_frames(tiles)     # [N frames, H, W, 3] on every rank; identity at N = 1
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L.lib().nrf_profile_enable(1)
+    import ctypes as C
+    ms = (C.c_double * 5)(); cnt = (C.c_int64 * 5)()
+    L.lib().nrf_profile_read(ms, cnt, 1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frames = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.lib().nrf_profile_read(ms, cnt, 1)
+    L.lib().nrf_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    units_per_step = world * H * W * UNITS_PER_RAY
+    value = units_per_step * args.steps / elapsed
+
+    if rank == 0:
+        prof = {n: dict(ms=ms[i], launches=int(cnt[i])) for i, n in enumerate(L.NRF_PROF_NAMES)}
+        # dominant kernel: hash encode (hash workload) / MLP (classic); per-launch figures from HIP events on the launch stream
+        if args.workload == "hash":
+            k = prof["hash"]
+            units_per_launch = (H * W // world) * world * UNITS_PER_RAY * args.steps / max(k["launches"], 1)
+            dur = k["ms"] * 1e-3 / max(k["launches"], 1)
+            achieved = units_per_launch * HASH_BYTES_PER_UNIT / max(dur, 1e-12)
+            roof = dict(bound="hbm", kernel="hash_encode", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
+                        traffic=None, launches=k["launches"], avg_launch_ms=dur * 1e3, units_per_launch=units_per_launch,
+                        bytes_per_unit=HASH_BYTES_PER_UNIT)
+            mk = prof["mlp"]
+            mdur = mk["ms"] * 1e-3
+            mlp_peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
+            roof["mlp"] = dict(bound="mfma", achieved=units_per_step * args.steps * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
+                               unit="TFLOP/s", frac=units_per_step * args.steps * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / mlp_peak)
+        else:
+            k = prof["mlp"]
+            dur_total = k["ms"] * 1e-3
+            flops = units_per_step * args.steps * NERF_FLOP_PER_UNIT
+            peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
+            roof = dict(bound="mfma", kernel="mlp_nerf", achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                        frac=flops / max(dur_total, 1e-12) / peak, traffic=None, launches=k["launches"],
+                        avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT)
+        line = {
+            "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f16 MFMA (fp32 accumulate) MLP; " if args.precision == "f16" else "f32 MLP; ") +
+                     ("fp16 hash table, fp32 blend" if (args.workload == "hash" and args.hash_mode == "cu") else "f32 encoders") + "; f32/f64 compositing",
+            "data": "synthetic",
+            "config": {"workload": ("hashnerf_lego800_64+128" if args.workload == "hash" else "classic_nerf_lego800_64+128"),
+                       "baseline_config": (2 if args.workload == "hash" else 1),
+                       "encoder": (("CuHashEmbedder" if args.hash_mode == "cu" else "HashEmbedder") + " L16 T2^19 F2 16..512 + " +
+                                   ("CuSHEncoder" if args.hash_mode == "cu" else "SHEncoder") + " deg4 + NeRFSmall 3x64/4x64") if args.workload == "hash"
+                       else "PE(10)/PE(4) + NeRF 8x256 skip4 viewdirs",
+                       "frames_per_step": world, "rays_per_gpu_per_step": H * W, "ray_samples_per_ray": UNITS_PER_RAY, "chunk": chunk,
+                       "parallelism": f"row-tile x{world}" + (" + RCCL all_gather" if world > 1 else "")},
+            "rays_per_s": value / UNITS_PER_RAY, "s_per_frame_per_gpu": elapsed / args.steps,
+            "roofline": roof, "kernel_ms": prof,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        # quality: GPU render vs the CPU oracle on identical weights/pose, a bounded ray sample (render-vs-render PSNR)
+        try:
+            line["psnr_vs_oracle_db"] = quality_check(sc, renderer, rp, K, poses[0], args)
+        except Exception as e:
+            line["psnr_vs_oracle_db"] = f"unavailable: {e}"
+        assert frames.shape[0] == world and bool(torch.isfinite(frames).all())
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def quality_check(sc, renderer, rp, K, c2w, args, nrays=256):
+    import torch
+    from oracle import capi as O
+    from nerfpp_amd import scene
+    res = renderer.Render(H, W, K, rp, c2w=c2w, row0=H // 2, rows=1)
+    rays = res.Extras["rays_flat"].cpu().numpy()[::W // nrays][:nrays]
+    rgb = res.Outputs.RGBMap.cpu().numpy().reshape(-1, 3)[::W // nrays][:nrays]
+    if args.workload == "hash":
+        cfg = sc["cfg"]
+        if sc["mode"] == "cu":
+            ls = ((1 << cfg["log2_t"]) >> 4) << 4
+            Lv = cfg["n_levels"]
+            model = O.Model(2, sc["mlp_blob"], bbox=sc["bbox"], table_f16=O.f32_to_f16(sc["table"]), primes=sc["primes"],
+                            local_idx=np.arange(Lv, dtype=np.int32) * ls, local_size=np.full(Lv, ls, np.int32), bias=np.zeros((Lv, 3), np.float32),
+                            mul=O.hash_cu_scales(Lv, cfg["base"], cfg["finest"]))
+        else:
+            model = O.Model(0, sc["mlp_blob"], bbox=sc["bbox"], table_f32=sc["table"])
+    else:
+        model = O.Model(1, sc["mlp_blob"], bbox=sc["bbox"])
+    ref = O.render_rays(model, rays, NS, NI, O.linspace(0, 1, NS), O.linspace(0, 1, NI), white_bkgr=True)
+    return dict(psnr=scene.psnr(rgb, ref["rgb"]), max_abs_err=float(np.abs(rgb - ref["rgb"]).max()), rays=int(rays.shape[0]))
+
+
+if __name__ == "__main__":
+    main()

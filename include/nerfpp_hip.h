@@ -1,0 +1,259 @@
+/*
+ * nerfpp_hip.h -- C ABI of the MI355X-native (gfx950) NeRF / HashNeRF volume-rendering path.
+ *
+ * The reference (DeliriumV01D/NeRFpp) has no C ABI: its hot path sits behind C++ templates and
+ * virtuals (BaseEmbedderImpl, BaseNeRFImpl, NeRFRenderer<...>).  This header is the boundary a
+ * host binds instead: `extern "C"`, plain pointers and sizes, no torch types.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference's src/).  The
+ * LibTorch adapter classes (include/nerfpp_torch.h) and the Python mirror (nerfpp_amd/) are thin
+ * callers of exactly these functions.
+ *
+ * Conventions
+ *   - every `d_` pointer is DEVICE memory (hipMalloc / a torch tensor's data_ptr on the same GPU),
+ *     fp32 row-major unless stated; every other pointer is HOST memory read during the call;
+ *   - every launch goes to the caller's stream (`void *stream` is a hipStream_t; NULL = the
+ *     per-process default stream).  No call synchronises the device, allocates device memory
+ *     (handles own theirs; scratch comes from the caller through *_workspace_bytes) or throws;
+ *   - return value: NRF_OK or an NRF_ERR_* code; nrf_last_error() gives the text (thread-local);
+ *   - the caller owns all buffers; handles are created/destroyed explicitly and are immutable
+ *     during a call (re-entrant: no per-call state is kept on a handle, unlike
+ *     CuHashEmbedderImpl::QueryPoints, CuHashEmbedder.h:26-27).
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry returns NRF_ERR_HIP.
+ */
+#ifndef NERFPP_HIP_H
+#define NERFPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRF_API __attribute__((visibility("default")))
+
+enum {
+    NRF_OK = 0,
+    NRF_ERR_INVALID_ARG = 1,
+    NRF_ERR_HIP = 2,          /* a HIP runtime call / kernel launch failed (no device, OOM, ...) */
+    NRF_ERR_UNSUPPORTED = 3,  /* valid in the reference, not built here (message says what) */
+    NRF_ERR_WORKSPACE = 4     /* caller's workspace too small */
+};
+
+NRF_API int nrf_version(void);
+NRF_API const char *nrf_last_error(void);
+NRF_API const char *nrf_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rays                                                         RayUtils.h
+ * ------------------------------------------------------------------------------------------- */
+
+/* GetDirections + GetRays (RayUtils.h:5-46) for image rows [row0, row0+rows) of an h x w image.
+ * K: host [9] row-major 3x3, c2w: host [12] row-major 3x4.  d_o, d_d: [rows*w, 3].
+ * Ray r = (y-row0)*w + x (row-major, y outer) -- the reference's pixel<->ray mapping.
+ * cone_angle (host, optional) receives ((1/fx + 1/fy)/2)*1.1 (RayUtils.h:35-43). */
+NRF_API int nrf_get_rays(int h, int w, const float *K, const float *c2w, int row0, int rows,
+                         float *d_o, float *d_d, float *cone_angle, void *stream);
+
+/* NDCRays (RayUtils.h:49-83); in place allowed. */
+NRF_API int nrf_ndc_rays(int h, int w, float focal, float near_plane, const float *d_o, const float *d_d, int64_t n,
+                         float *d_o_out, float *d_d_out, void *stream);
+
+/* IntersectWithAABB (RayUtils.h:87-126). bbox: host [6] = min xyz, max xyz. */
+NRF_API int nrf_aabb(const float *d_o, const float *d_d, const float *bbox, int64_t n, float near_plane,
+                     float *d_near, float *d_far, void *stream);
+
+/* The ray-batch assembly of NeRFRenderer::Render (NeRFRenderer.h:549-583):
+ * viewdirs = d/||d||, near/far from the AABB, rays = cat[o, d, near, far, (viewdirs)].
+ * d_rays: [n, 11] when use_viewdirs else [n, 8]. */
+NRF_API int nrf_pack_rays(const float *d_o, const float *d_d, const float *bbox, int64_t n, int use_viewdirs,
+                          float *d_rays, void *stream);
+
+/* min(near), max(far) over a packed ray batch (NeRFRenderer.h:602-603); results to host, synchronises `stream`. */
+NRF_API int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *near_min, float *far_max, void *stream);
+
+/* torch::linspace(start, end, steps) as ATen's CPU kernel rounds it (one fused rounding per
+ * element) -- for hosts without torch; the LibTorch / PyTorch callers pass torch::linspace itself. */
+NRF_API int nrf_linspace(float start, float end, int steps, float *out_host);
+
+/* z_vals (NeRFRenderer.h:393-402) and sample points pts = o + d*z (:419). d_t: [s] = linspace(0,1,s). */
+NRF_API int nrf_z_vals(const float *d_rays, int ray_stride, int64_t n, const float *d_t, int s, int lindisp,
+                       float *d_z, void *stream);
+NRF_API int nrf_points(const float *d_rays, int ray_stride, const float *d_z, int64_t n, int s, float *d_pts, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoders                                                     BaseEmbedder.h:6-15 (plugin iface)
+ * ------------------------------------------------------------------------------------------- */
+
+/* EmbedderImpl::forward, sinusoidal PE (NeRF.cpp:4-39): [p,3] -> [p, 3+6*nfreq]. */
+NRF_API int nrf_pe_encode(const float *d_x, int64_t p, int nfreq, float *d_out, void *stream);
+
+/* Spherical harmonics: variant 0 = SHEncoderImpl (NeRF.cpp:131-201, degree 1..5),
+ *                      variant 1 = CuSHEncoderImpl / CuSHKernel (CuSHEncoder.cu:4-118, degree 1..8).
+ * [p,3] -> [p, degree^2]. */
+enum { NRF_SH_LIBTORCH = 0, NRF_SH_CUDA = 1 };
+NRF_API int nrf_sh_encode(const float *d_dirs, int64_t p, int degree, int variant, float *d_out, void *stream);
+
+/* Multiresolution hash grid.
+ *   NRF_HASH_NGP : HashEmbedderImpl  (NeRF.cpp:208-318)  fp32 table [L][2^T][F], int64 hash with the
+ *                  Instant-NGP primes, floor()ed per-level resolution.
+ *   NRF_HASH_CU  : CuHashEmbedderImpl (CuHashEmbedder.cpp:85-103 + CuHashEmbedder.cu:8-102) fp16 table
+ *                  [L*2^T, F] (cast ONCE at upload, not per forward as .cu:257 does), uint32 hash with
+ *                  per-level primes, un-floored scale, the level-offset overlap quirk (.cu:54),
+ *                  blend in fp32 rounded once to fp16 (.cu:95). */
+enum { NRF_HASH_NGP = 0, NRF_HASH_CU = 1 };
+
+typedef struct nrf_hash_desc {
+    int mode;                 /* NRF_HASH_NGP | NRF_HASH_CU */
+    int n_levels;             /* L  (ctor arg n_levels, NeRFExecutor.h:430-432) */
+    int n_features;           /* F  */
+    int log2_hashmap_size;    /* T  */
+    int base_resolution;
+    int finest_resolution;
+    float bbox[6];            /* min xyz, max xyz */
+} nrf_hash_desc;
+
+typedef struct nrf_hash nrf_hash;
+
+NRF_API int nrf_hash_create(const nrf_hash_desc *desc, nrf_hash **out);
+NRF_API void nrf_hash_destroy(nrf_hash *h);
+NRF_API int nrf_hash_output_dims(const nrf_hash *h);              /* GetOutputDims() */
+NRF_API int64_t nrf_hash_table_elems(const nrf_hash *h);          /* L * 2^T * F */
+
+/* Upload the embedding table from an fp32 array in the reference's parameter layout
+ * (NGP: embeddings_0..L-1 concatenated, each [2^T, F], NeRF.cpp:255-258;  CU: `embedder_embeddings`
+ * [L*2^T, F], CuHashEmbedder.cpp:24).  `src` may be host or device memory (src_on_device). */
+NRF_API int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *stream);
+
+/* NRF_HASH_CU only: per-level primes [L*3] (buffer `embedder_primes`, CuHashEmbedder.cpp:51-52) and
+ * biases [L*3] (`embedder_biases`, :54-59; NULL = zeros).  Host pointers. */
+NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases);
+
+/* BaseEmbedderImpl::forward for the hash grid: x [p,3] -> (embedding [p, L*F] fp32, keep_mask [p] u8).
+ * d_keep_mask may be NULL. */
+NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, float *d_out, uint8_t *d_keep_mask, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MLPs                                                         BaseNeRFImpl::forward (NeRF.h:33-42)
+ * Parameters: ONE fp32 blob in the reference's named_parameters() == checkpoint order
+ * (NeRFExecutor.h:1055-1070), Linear weights [out, in] row-major.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    NRF_PREC_F32 = 0,      /* fp32 FMA chains in ascending k: the parity mode (== oracle bit for bit) */
+    NRF_PREC_F16_MFMA = 1  /* fp16 operands on the matrix cores, fp32 accumulate: the fast mode */
+};
+
+typedef struct nrf_mlp_small_desc {      /* NeRFSmallImpl ctor (NeRF.cpp:322-360) */
+    int input_ch, input_ch_views;
+    int num_layers, hidden_dim, geo_feat_dim;
+    int num_layers_color, hidden_dim_color;
+} nrf_mlp_small_desc;
+
+typedef struct nrf_mlp_nerf_desc {       /* NeRFImpl ctor (NeRF.cpp:41-90) */
+    int depth, width, input_ch, input_ch_views, output_ch, skip, use_viewdirs;
+} nrf_mlp_nerf_desc;
+
+typedef struct nrf_mlp nrf_mlp;
+
+NRF_API int64_t nrf_mlp_small_param_count(const nrf_mlp_small_desc *d);
+NRF_API int64_t nrf_mlp_nerf_param_count(const nrf_mlp_nerf_desc *d);
+NRF_API int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out);
+NRF_API int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out);
+NRF_API void nrf_mlp_destroy(nrf_mlp *m);
+NRF_API int nrf_mlp_output_dims(const nrf_mlp *m);
+/* forward: x [p, input_ch + input_ch_views] -> out [p, output_dims] */
+NRF_API int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int precision, float *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Compositing and hierarchical sampling
+ * ------------------------------------------------------------------------------------------- */
+
+/* NeRFRenderer::RawToOutputs (NeRFRenderer.h:199-282) + TruncExp::forward (CustomOps.cpp:5-9).
+ * raw [n,s,c] (rgb at 0..2, sigma at 3), z [n,s], d [n,3] (stride d_stride floats).
+ * Any output pointer may be NULL. */
+NRF_API int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c,
+                            int white_bkgr, float *d_rgb, float *d_disp, float *d_acc, float *d_weights, float *d_depth,
+                            void *stream);
+
+/* SamplePDF, deterministic branch (Sampler.h:6-43).  bins [n,nb], weights [n,nb-1], u [ns] device
+ * (= linspace(0,1,ns)).  sum_vec: fp32 lanes of the host whose torch::sum order is reproduced for the
+ * pdf normaliser (8 = any AVX2+/AVX-512 x86 build of ATen; 0 = order-free double accumulation).
+ * d_inds (optional): the searchsorted indices, int64 like the reference's. */
+NRF_API int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
+                           float *d_samples, int64_t *d_inds, void *stream);
+
+/* The fine-pass depth set of RenderRays (NeRFRenderer.h:427-431): z_mid, SamplePDF on weights[1:-1],
+ * sort(cat(z, samples)).  z [n,s], weights [n,s] -> z_fine [n, s+ns]. */
+NRF_API int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec,
+                            float *d_z_fine, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Renderer                                    NeRFRenderer<TEmbedder,TEmbedDirs,TNeRF> (NeRFRenderer.h:88-159)
+ * ------------------------------------------------------------------------------------------- */
+enum { NRF_DIRS_NONE = 0, NRF_DIRS_PE = 1, NRF_DIRS_SH_LIBTORCH = 2, NRF_DIRS_SH_CUDA = 3 };
+
+typedef struct nrf_renderer_desc {
+    const nrf_hash *hash;     /* position encoder: hash grid, or NULL for sinusoidal PE */
+    int pe_freqs;             /* used when hash == NULL (Embedder multires, NeRFExecutor.h:427) */
+    int dirs_encoder;         /* NRF_DIRS_* */
+    int dirs_param;           /* PE: multires_views;  SH: degree */
+    const nrf_mlp *mlp;
+} nrf_renderer_desc;
+
+/* NeRFRenderParams (NeRFRenderer.h:28-44) restricted to the deterministic render path
+ * (Perturb = 0, RawNoiseStd = 0, ThinRay = true: what FillRenderParams sets at test time,
+ * NeRFExecutor.h:379-415, plus ThinRay). */
+typedef struct nrf_render_params {
+    int n_samples;            /* NSamples */
+    int n_importance;         /* NImportance */
+    int lindisp;              /* LinDisp */
+    int white_bkgr;           /* WhiteBkgr */
+    int precision;            /* NRF_PREC_* for the MLP */
+    int sum_vec;              /* see nrf_sample_pdf */
+} nrf_render_params;
+
+typedef struct nrf_render_outputs {   /* NeRFRendererOutputs / NeRFRenderResult (NeRFRenderer.h:12-26); NULL = not wanted */
+    float *d_rgb;             /* [n,3] */
+    float *d_disp;            /* [n]   */
+    float *d_acc;             /* [n]   */
+    float *d_depth;           /* [n]   */
+    float *d_weights;         /* [n, S_out]  S_out = n_samples + n_importance (or n_samples if n_importance == 0) */
+    float *d_raw;             /* [n, S_out, 4] */
+    /* intermediates for stage-chained parity tests (optional) */
+    float *d_z_coarse;        /* [n, n_samples] */
+    float *d_raw_coarse;      /* [n, n_samples, 4] */
+    float *d_weights_coarse;  /* [n, n_samples] */
+    float *d_z_fine;          /* [n, n_samples + n_importance] */
+} nrf_render_outputs;
+
+typedef struct nrf_renderer nrf_renderer;
+
+NRF_API int nrf_renderer_create(const nrf_renderer_desc *desc, nrf_renderer **out);
+NRF_API void nrf_renderer_destroy(nrf_renderer *r);
+
+/* RunNetwork (NeRFRenderer.h:164-194): pts [n,s,3], viewdirs [n,3] (or NULL) -> raw [n,s,4]
+ * with sigma forced to 0 where the embedder's keep_mask is false (:187-188). */
+NRF_API size_t nrf_run_network_workspace_bytes(const nrf_renderer *r, int64_t n, int s);
+NRF_API int nrf_run_network(const nrf_renderer *r, const float *d_pts, const float *d_viewdirs, int64_t n, int s, int precision,
+                            float *d_raw, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* RenderRays (NeRFRenderer.h:366-459) over one chunk of n packed rays [n, 8 | 11].
+ * d_t: [n_samples] linspace(0,1,n_samples); d_u: [n_importance] linspace(0,1,n_importance). */
+NRF_API size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const nrf_render_params *p);
+NRF_API int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
+                            const float *d_t, const float *d_u, const nrf_render_outputs *out,
+                            void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instrumentation (bench / tests)
+ * ------------------------------------------------------------------------------------------- */
+/* When enabled, nrf_render_rays brackets its dominant kernels with HIP events on the caller's stream;
+ * nrf_profile_read synchronises them and returns accumulated milliseconds and launch counts. */
+enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAMPLE = 3, NRF_PROF_OTHER = 4, NRF_PROF_COUNT = 5 };
+NRF_API int nrf_profile_enable(int on);
+NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFPP_HIP_H */

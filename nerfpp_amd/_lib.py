@@ -1,0 +1,93 @@
+"""ctypes loader for libnerfpp_hip.so (the C ABI declared in include/nerfpp_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C nerfpp_amd/csrc`.  There is no CPU
+fallback: if the shared object is missing, importing the compute API raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerfpp_hip.so")
+
+NRF_OK = 0
+NRF_HASH_NGP, NRF_HASH_CU = 0, 1
+NRF_SH_LIBTORCH, NRF_SH_CUDA = 0, 1
+NRF_PREC_F32, NRF_PREC_F16_MFMA = 0, 1
+NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
+NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other")
+
+
+class HashDesc(C.Structure):
+    _fields_ = [("mode", C.c_int), ("n_levels", C.c_int), ("n_features", C.c_int), ("log2_hashmap_size", C.c_int),
+                ("base_resolution", C.c_int), ("finest_resolution", C.c_int), ("bbox", C.c_float * 6)]
+
+
+class MlpSmallDesc(C.Structure):
+    _fields_ = [("input_ch", C.c_int), ("input_ch_views", C.c_int), ("num_layers", C.c_int), ("hidden_dim", C.c_int),
+                ("geo_feat_dim", C.c_int), ("num_layers_color", C.c_int), ("hidden_dim_color", C.c_int)]
+
+
+class MlpNerfDesc(C.Structure):
+    _fields_ = [("depth", C.c_int), ("width", C.c_int), ("input_ch", C.c_int), ("input_ch_views", C.c_int),
+                ("output_ch", C.c_int), ("skip", C.c_int), ("use_viewdirs", C.c_int)]
+
+
+class RendererDesc(C.Structure):
+    _fields_ = [("hash", C.c_void_p), ("pe_freqs", C.c_int), ("dirs_encoder", C.c_int), ("dirs_param", C.c_int), ("mlp", C.c_void_p)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("n_samples", C.c_int), ("n_importance", C.c_int), ("lindisp", C.c_int), ("white_bkgr", C.c_int),
+                ("precision", C.c_int), ("sum_vec", C.c_int)]
+
+
+class RenderOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_rgb", "d_disp", "d_acc", "d_depth", "d_weights", "d_raw",
+                                          "d_z_coarse", "d_raw_coarse", "d_weights_coarse", "d_z_fine")]
+
+
+# every symbol include/nerfpp_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "nrf_version", "nrf_last_error", "nrf_status_string",
+    "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_near_far_range", "nrf_linspace", "nrf_z_vals", "nrf_points",
+    "nrf_pe_encode", "nrf_sh_encode",
+    "nrf_hash_create", "nrf_hash_destroy", "nrf_hash_output_dims", "nrf_hash_table_elems", "nrf_hash_set_table", "nrf_hash_set_primes",
+    "nrf_hash_encode",
+    "nrf_mlp_small_param_count", "nrf_mlp_nerf_param_count", "nrf_mlp_small_create", "nrf_mlp_nerf_create", "nrf_mlp_destroy",
+    "nrf_mlp_output_dims", "nrf_mlp_forward",
+    "nrf_raw2outputs", "nrf_sample_pdf", "nrf_fine_depths",
+    "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
+    "nrf_render_rays_workspace_bytes", "nrf_render_rays",
+    "nrf_profile_enable", "nrf_profile_read",
+]
+
+_lib = None
+
+
+class NrfError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NrfError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.nrf_last_error.restype = C.c_char_p
+        L.nrf_status_string.restype = C.c_char_p
+        L.nrf_hash_table_elems.restype = C.c_int64
+        L.nrf_mlp_small_param_count.restype = C.c_int64
+        L.nrf_mlp_nerf_param_count.restype = C.c_int64
+        L.nrf_mlp_lerf_param_count.restype = C.c_int64
+        L.nrf_run_network_workspace_bytes.restype = C.c_size_t
+        L.nrf_render_rays_workspace_bytes.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != NRF_OK:
+        L = lib()
+        raise NrfError(f"{L.nrf_status_string(status).decode()}: {L.nrf_last_error().decode()}")

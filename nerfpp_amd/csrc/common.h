@@ -1,0 +1,114 @@
+// common.h -- internal helpers of libnerfpp_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "nerfpp_hip.h"
+
+namespace nrf {
+
+void set_error(const char *fmt, ...);
+
+#define NRF_CHECK_ARG(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ::nrf::set_error(__VA_ARGS__);                         \
+            return NRF_ERR_INVALID_ARG;                            \
+        }                                                          \
+    } while (0)
+
+#define NRF_HIP(call)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            ::nrf::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NRF_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define NRF_LAUNCH_CHECK()                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) {                                                                   \
+            ::nrf::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NRF_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define NRF_TRY(expr)                  \
+    do {                               \
+        int s_ = (expr);               \
+        if (s_ != NRF_OK) return s_;   \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- profiling (nrf_profile_*): HIP events on the caller's stream around the dominant kernels ----
+struct ProfScope {
+    int slot;
+    hipStream_t stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool active;
+    ProfScope(int slot, hipStream_t stream);
+    ~ProfScope();
+};
+
+// ---- small device helpers ----
+
+// Orders LDS traffic between the lanes of ONE wavefront (hardware executes a wave's DS ops in order; the fences
+// stop the compiler from moving accesses across, the barrier pins the schedule).  No instruction is emitted beyond
+// the waits the compiler derives.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Bbox {
+    float mn[3];
+    float mx[3];
+};
+
+struct F3 {
+    float x, y, z;
+};
+
+// A sample point is either read from an explicit [p,3] array or formed as o + d*z from a packed ray
+// batch and a depth table (NeRFRenderer.h:419) -- the fused pipeline never materialises pts.
+struct PointSource {
+    const float *pts;     // explicit points, or nullptr
+    const float *rays;    // [n, ray_stride] packed rays
+    const float *z;       // [n, s]
+    int ray_stride;
+    int s;
+};
+
+__device__ __forceinline__ F3 load_point(const PointSource &ps, int64_t i)
+{
+    F3 r;
+    if (ps.pts) {
+        r.x = ps.pts[i * 3 + 0];
+        r.y = ps.pts[i * 3 + 1];
+        r.z = ps.pts[i * 3 + 2];
+    } else {
+        const int64_t ray = i / ps.s;
+        const float *rp = ps.rays + ray * ps.ray_stride;
+        const float zz = ps.z[i];
+        r.x = rp[0] + rp[3] * zz;
+        r.y = rp[1] + rp[4] * zz;
+        r.z = rp[2] + rp[5] * zz;
+    }
+    return r;
+}
+
+}  // namespace nrf

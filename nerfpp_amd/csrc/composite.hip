@@ -1,0 +1,302 @@
+// composite.hip -- per-ray stages: sigma->alpha compositing and hierarchical (inverse-CDF) sampling.
+//   RawToOutputs   NeRFRenderer.h:199-282 (+ TruncExp::forward, CustomOps.cpp:5-9)
+//   SamplePDF      Sampler.h:6-43 ;  z_mid / sort(cat(z, samples))  NeRFRenderer.h:427-431
+//
+// One 64-lane wavefront per ray, lane = sample.  The two prefix sums the reference computes with
+// torch::cumsum (log-transmittance, CDF) are wave scans in DOUBLE: ATen's CPU cumsum accumulates fp32 in double
+// and rounds every prefix to fp32, and a double scan's reassociation error (1e-16) disappears in that rounding,
+// so the scan reproduces the sequential result.  The pdf normaliser sum(w) is evaluated in ATen's own lane
+// order (sum_vec) because it feeds searchsorted: the sample INDICES are bit-exact against the oracle.
+#include "common.h"
+
+namespace nrf {
+
+constexpr int MAX_S = 256;        // samples per ray per pass (coarse) / importance samples
+constexpr int RAYS_PER_BLOCK = 4; // waves per block
+
+__device__ __forceinline__ double wave_incl_scan(double v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C1  RawToOutputs
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
+k_raw2outputs(int64_t n, int s, int c, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
+              int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
+              float *__restrict__ depth)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float *dv = dirs + ray * d_stride;
+    float nn = dv[0] * dv[0]; nn = nn + dv[1] * dv[1]; nn = nn + dv[2] * dv[2];
+    const float nrm = sqrtf(nn);                                   // torch::norm(rays_d, 2, -1)
+    const float *zr = z + ray * s;
+    double carry = 0.0;                                            // sum of log(1-alpha) over previous 64-sample blocks
+    double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0, swz = 0.0;
+    for (int base = 0; base < s; base += 64) {
+        const int j = base + lane;
+        const bool live = j < s;
+        float w = 0.0f, zj = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, lg = 0.0f;
+        float alpha = 0.0f;
+        if (live) {
+            const float *r = raw + (ray * s + j) * c;
+            zj = zr[j];
+            float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
+            dist = dist * nrm;                                      // :241
+            const float sig = r[3] > 0.0f ? r[3] : 0.0f;            // relu
+            alpha = -expf(-sig * dist) + 1.0f;                      // :234
+            const float om = 1.0f - alpha;
+            lg = logf(om > 1e-10f ? om : 1e-10f);                   // :265
+            cr = 1.0f / (1.0f + expf(-r[0]));                       // sigmoid, :250
+            cg = 1.0f / (1.0f + expf(-r[1]));
+            cb = 1.0f / (1.0f + expf(-r[2]));
+        }
+        const double incl = wave_incl_scan((double)lg, lane);
+        const double excl = carry + (incl - (double)lg);            // exclusive prefix: cat[0, cumsum][:-1] (:263-266)
+        carry += __shfl(incl, 63);
+        if (live) {
+            const float trans = expf((float)excl);                  // TruncExp forward = exp (:267)
+            w = alpha * trans;
+            if (weights) weights[ray * s + j] = w;
+            sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);
+            sw += (double)w; swz += (double)(w * zj);
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sw = wave_sum(sw); swz = wave_sum(swz);
+    if (lane == 0) {
+        const float a = (float)sw;
+        const float dep = (float)swz / (a > 1e-10f ? a : 1e-10f);  // :272
+        float rr = (float)sr, gg = (float)sg, bb = (float)sb;
+        if (white) { const float bg = 1.0f - a; rr = rr + bg; gg = gg + bg; bb = bb + bg; }   // :276-277
+        if (rgb) { rgb[ray * 3] = rr; rgb[ray * 3 + 1] = gg; rgb[ray * 3 + 2] = bb; }
+        if (depth) depth[ray] = dep;
+        if (disp) disp[ray] = 1.0f / (dep > 1e-10f ? dep : 1e-10f);                           // :273
+        if (acc) acc[ray] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch::sum over a contiguous fp32 row, in ATen's CPU order for a `vec`-lane build (see the oracle's
+// aten_row_sum_f32 for the derivation from SumKernel.cpp).  x lives in LDS; called by the whole wave,
+// result valid in every lane.  vec == 0: double accumulation (order-free definition).
+// ------------------------------------------------------------------------------------------------
+__device__ float aten_row_sum(const float *x, int n, int vec, float *scratch /*>= 64 floats LDS*/, int lane)
+{
+    if (vec <= 0) {
+        double sacc = 0.0;
+        for (int i = lane; i < n; i += 64) sacc += (double)x[i];
+        return (float)wave_sum(sacc);
+    }
+    float result = 0.0f;
+    if (n < vec) {
+        if (lane == 0) {
+            float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int q = n / 4;
+            for (int i = 0; i < q; i++)
+                for (int k = 0; k < 4; k++) ps[k] += x[i * 4 + k];
+            for (int i = q * 4; i < n; i++) ps[0] += x[i];
+            for (int k = 1; k < 4; k++) ps[0] += ps[k];
+            result = ps[0];
+        }
+        return __shfl(result, 0);
+    }
+    // vec <= 16 so the 4 x vec interleaved accumulators fit one wave: lane = k*vec + l
+    const int nv = n / vec, q = nv / 4;
+    if (lane < 4 * vec) {
+        const int k = lane / vec, l = lane - k * vec;
+        float p = 0.0f;
+        for (int i = 0; i < q; i++) p += x[(i * 4 + k) * vec + l];
+        if (k == 0)
+            for (int j = q * 4; j < nv; j++) p += x[j * vec + l];
+        scratch[lane] = p;
+    }
+    wave_sync();
+    if (lane == 0) {
+        float a = 0.0f;
+        for (int i = nv * vec; i < n; i++) a += x[i];
+        for (int l = 0; l < vec; l++) {
+            float p0 = scratch[l];
+            for (int k = 1; k < 4; k++) p0 += scratch[k * vec + l];
+            a += p0;
+        }
+        result = a;
+    }
+    return __shfl(result, 0);
+}
+
+// Shared body of SamplePDF for one ray handled by one wave.  bins[nb], wts[nb-1] and the outputs live in LDS.
+//   cdf[nb] (out), samples[ns] (out), inds (optional global int64 out)
+__device__ void sample_pdf_wave(const float *bins, float *wts, int nb, const float *__restrict__ u, int ns, int sum_vec,
+                                float *cdf, float *samples, float *scratch, int64_t *inds, int lane)
+{
+    const int nw = nb - 1;
+    for (int k = lane; k < nw; k += 64) wts[k] = wts[k] + 1e-8f;                 // Sampler.h:10
+    wave_sync();
+    const float fsum = aten_row_sum(wts, nw, sum_vec, scratch, lane);            // :11 sum(weights, -1, true)
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.0f;                                                // :13
+    for (int base = 0; base < nw; base += 64) {
+        const int k = base + lane;
+        const float pdf = (k < nw) ? (wts[k] / fsum) : 0.0f;                     // :11
+        const double incl = carry + wave_incl_scan((double)pdf, lane);           // :12 cumsum (double accumulate)
+        if (k < nw) cdf[k + 1] = (float)incl;
+        carry = __shfl(incl, 63);
+    }
+    wave_sync();
+    for (int j = lane; j < ns; j += 64) {
+        const float uj = u[j];
+        int lo = 0, hi = nb;                                                     // searchsorted(cdf, u, right=True) (:28)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+        }
+        const int ind = lo;
+        const int below = ind - 1 > 0 ? ind - 1 : 0;                             // :29
+        const int above = ind < nb - 1 ? ind : nb - 1;                           // :30
+        float denom = cdf[above] - cdf[below];                                   // :37
+        if (denom < 1e-5f) denom = 1.0f;                                         // :38
+        const float t = (uj - cdf[below]) / denom;                               // :39
+        samples[j] = bins[below] + t * (bins[above] - bins[below]);              // :40
+        if (inds) inds[j] = ind;
+    }
+    wave_sync();
+}
+
+struct PdfLds {
+    float bins[MAX_S];
+    float wts[MAX_S];
+    float cdf[MAX_S + 4];
+    float merged[2 * MAX_S];
+    float scratch[64];
+};
+
+__global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
+k_sample_pdf(int64_t n, int nb, int ns, int sum_vec, const float *__restrict__ bins, const float *__restrict__ weights,
+             const float *__restrict__ u, float *__restrict__ samples, int64_t *__restrict__ inds)
+{
+    __shared__ PdfLds lds[RAYS_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= n) return;
+    PdfLds &L = lds[wv];
+    for (int k = lane; k < nb; k += 64) L.bins[k] = bins[ray * nb + k];
+    for (int k = lane; k < nb - 1; k += 64) L.wts[k] = weights[ray * (nb - 1) + k];
+    wave_sync();
+    sample_pdf_wave(L.bins, L.wts, nb, u, ns, sum_vec, L.cdf, L.merged, L.scratch, inds ? inds + ray * ns : nullptr, lane);
+    for (int j = lane; j < ns; j += 64) samples[ray * ns + j] = L.merged[j];
+}
+
+// NeRFRenderer.h:427-431: z_mid -> SamplePDF(weights[1:-1]) -> sort(cat(z, samples)).
+__global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
+k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z, const float *__restrict__ weights,
+              const float *__restrict__ u, float *__restrict__ zf)
+{
+    __shared__ PdfLds lds[RAYS_PER_BLOCK];
+    __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (ray >= n) return;
+    PdfLds &L = lds[wv];
+    float *zl = zs[wv];
+    for (int k = lane; k < s; k += 64) zl[k] = z[ray * s + k];
+    wave_sync();
+    const int nb = s - 1;
+    for (int k = lane; k < nb; k += 64) L.bins[k] = 0.5f * (zl[k + 1] + zl[k]);                  // :427
+    for (int k = lane; k < nb - 1; k += 64) L.wts[k] = weights[ray * s + 1 + k];                 // weights[..., 1:-1] (:428)
+    wave_sync();
+    float *smp = L.merged;                  // samples [ns]
+    sample_pdf_wave(L.bins, L.wts, nb, u, ns, sum_vec, L.cdf, smp, L.scratch, nullptr, lane);
+    // ---- stable ascending sort of cat(z[0..s), samples[0..ns)) by merge ranks (both runs are sorted unless
+    //      fp32 rounding broke monotonicity by an ulp: detected, then ranked by exhaustive counting) ----
+    bool bad = false;
+    for (int k = lane; k + 1 < s; k += 64) bad |= zl[k] > zl[k + 1];
+    for (int k = lane; k + 1 < ns; k += 64) bad |= smp[k] > smp[k + 1];
+    float *outp = zf + ray * (s + ns);
+    if (!__any(bad)) {
+        for (int i = lane; i < s; i += 64) {             // rank(z_i) = i + #{samples < z_i}   (z precedes samples on ties)
+            const float v = zl[i];
+            int lo = 0, hi = ns;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (smp[mid] < v) lo = mid + 1; else hi = mid; }
+            outp[i + lo] = v;
+        }
+        for (int j = lane; j < ns; j += 64) {            // rank(sample_j) = j + #{z <= sample_j}
+            const float v = smp[j];
+            int lo = 0, hi = s;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (zl[mid] <= v) lo = mid + 1; else hi = mid; }
+            outp[j + lo] = v;
+        }
+    } else {
+        const int tot = s + ns;
+        for (int i = lane; i < tot; i += 64) {
+            const float v = i < s ? zl[i] : smp[i - s];
+            int rank = 0;
+            for (int k = 0; k < tot; k++) {
+                const float o = k < s ? zl[k] : smp[k - s];
+                rank += (o < v) || (o == v && k < i);
+            }
+            outp[rank] = v;
+        }
+    }
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                    float *d_rgb, float *d_disp, float *d_acc, float *d_weights, float *d_depth, void *stream)
+{
+    NRF_CHECK_ARG(d_raw && d_z && d_dirs && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs: bad argument");
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_COMPOSITE, as_stream(stream));
+    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, white_bkgr,
+                       d_raw, d_z, d_dirs, d_stride, d_rgb, d_disp, d_acc, d_weights, d_depth);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
+                   float *d_samples, int64_t *d_inds, void *stream)
+{
+    NRF_CHECK_ARG(d_bins && d_weights && d_u && d_samples && n >= 0, "nrf_sample_pdf: bad argument");
+    NRF_CHECK_ARG(nb >= 2 && nb <= MAX_S && ns >= 1 && ns <= 2 * MAX_S, "nrf_sample_pdf: nb %d / ns %d outside the built range (<= %d bins, <= %d samples)", nb, ns, MAX_S, 2 * MAX_S);
+    NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_sample_pdf: sum_vec must be 0, 4, 8 or 16");
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_SAMPLE, as_stream(stream));
+    hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, nb, ns, sum_vec,
+                       d_bins, d_weights, d_u, d_samples, d_inds);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec, float *d_z_fine, void *stream)
+{
+    NRF_CHECK_ARG(d_z && d_weights && d_u && d_z_fine && n >= 0, "nrf_fine_depths: bad argument");
+    NRF_CHECK_ARG(s >= 4 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [4,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
+    NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_fine_depths: sum_vec must be 0, 4, 8 or 16");
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_SAMPLE, as_stream(stream));
+    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, ns, sum_vec,
+                       d_z, d_weights, d_u, d_z_fine);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,344 @@
+// encode.hip -- position / direction encoders behind the BaseEmbedder plugin surface (BaseEmbedder.h:6-15):
+//   sinusoidal PE            EmbedderImpl          NeRF.cpp:4-39
+//   spherical harmonics      SHEncoderImpl         NeRF.cpp:131-201      (variant NRF_SH_LIBTORCH)
+//                            CuSHKernel            CuSHEncoder.cu:4-107  (variant NRF_SH_CUDA)
+//   multiresolution hash     HashEmbedderImpl      NeRF.cpp:208-318      (mode NRF_HASH_NGP)
+//                            CuHashEmbedder kernel CuHashEmbedder.cu:8-102 + CuHashEmbedder.cpp:85-103 (mode NRF_HASH_CU)
+//
+// Generic row-major kernels (any caller, fp32 [p, D] outputs with a row stride so the renderer can write the
+// concatenated MLP input in place).  The level-major fp16 fast path used by the fused renderer lives in
+// hash_fast.hip.  Built with -ffp-contract=off: every value equals the oracle's bit for bit except sin/cos.
+#include "encode.h"
+
+namespace nrf {
+
+// ------------------------------------------------------------------------------------------------
+// E1 sinusoidal PE.  One thread per (row, frequency slot); slot 0 copies x.
+// out row = [x, sin(x f0), cos(x f0), sin(x f1), ...]; f_i = 2^i exactly (powf(2, (n-1)/(n-1)*i), NeRF.cpp:15).
+// `rep`: row i encodes x[i / rep] (view directions are shared by the `rep` samples of a ray, NeRFRenderer.h:179).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pe(int64_t rows, int nfreq, int rep, const float *__restrict__ x, int x_stride, float *__restrict__ out, int out_stride)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int slots = nfreq + 1;
+    if (gid >= rows * slots) return;
+    const int64_t row = gid / slots;
+    const int slot = (int)(gid - row * slots);
+    const float *xp = x + (row / rep) * x_stride;
+    float *o = out + row * out_stride;
+    if (slot == 0) {
+        o[0] = xp[0]; o[1] = xp[1]; o[2] = xp[2];
+        return;
+    }
+    const int f = slot - 1;
+    const float freq = __builtin_ldexpf(1.0f, f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float v = xp[a] * freq;
+        o[3 + f * 6 + a] = sinf(v);
+        o[3 + f * 6 + 3 + a] = cosf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S2 LibTorch SH (degree <= 5).  Expression order follows NeRF.cpp:158-196 (tensor-scalar ops, left to right).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sh_libtorch(float x, float y, float z, int degree, float *r)
+{
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    r[0] = C0;
+    if (degree <= 1) return;
+    r[1] = -C1 * y; r[2] = C1 * z; r[3] = -C1 * x;
+    if (degree <= 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    r[4] = 1.0925484305920792f * xy;
+    r[5] = -1.0925484305920792f * yz;
+    r[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    r[7] = -1.0925484305920792f * xz;
+    r[8] = 0.5462742152960396f * (xx - yy);
+    if (degree <= 3) return;
+    r[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+    r[10] = 2.890611442640554f * xy * z;
+    r[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+    r[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    r[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+    r[14] = 1.445305721320277f * z * (xx - yy);
+    r[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+    if (degree <= 4) return;
+    r[16] = 2.5033429417967046f * xy * (xx - yy);
+    r[17] = -1.7701307697799304f * yz * (3.0f * xx - yy);
+    r[18] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
+    r[19] = -0.6690465435572892f * yz * (7.0f * zz - 3.0f);
+    r[20] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
+    r[21] = -0.6690465435572892f * xz * (7.0f * zz - 3.0f);
+    r[22] = 0.47308734787878004f * (xx - yy) * (7.0f * zz - 1.0f);
+    r[23] = -1.7701307697799304f * xz * (xx - 3.0f * yy);
+    r[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+}
+
+__global__ void k_sh(int64_t rows, int degree, int variant, int rep, const float *__restrict__ dirs, int dir_stride,
+                     float *__restrict__ out, int out_stride)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float *dp = dirs + (i / rep) * dir_stride;
+    float r[64];
+    if (variant == NRF_SH_LIBTORCH) sh_libtorch(dp[0], dp[1], dp[2], degree, r);
+    else sh_cuda(dp[0], dp[1], dp[2], degree, r);
+    float *o = out + i * out_stride;
+    const int od = degree * degree;
+    for (int k = 0; k < od; k++) o[k] = r[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// H1  LibTorch hash grid, generic row-major kernel.  One thread per (point, level).
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void k_hash_ngp(HashParams hp, PointSource ps, int64_t p, float *__restrict__ out, int out_stride, uint8_t *__restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= p) return;
+    const F3 pt = load_point(ps, i);
+    const float x[3] = {pt.x, pt.y, pt.z};
+    float w[3];
+    int32_t idx[3];
+    bool kp = true;
+    const float res = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);
+        kp = kp && (x[a] == c);
+        const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / res;
+        const float fl = floorf((c - hp.bbox.mn[a]) / grid);
+        idx[a] = (int32_t)fl;
+        const float vmin = fl * grid + hp.bbox.mn[a];       // (float)int64 idx * grid + min
+        const float vmax = vmin + grid;
+        w[a] = (x[a] - vmin) / (vmax - vmin);               // UNCLAMPED x (NeRF.cpp:311)
+    }
+    if (l == 0 && keep) keep[i] = kp ? 1 : 0;
+    const float *tl = reinterpret_cast<const float *>(hp.table) + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
+    const uint32_t hmask = (1u << hp.log2_t) - 1u;
+    // low T bits of the int64 hash (NeRF.cpp:230-237) == the same expression in uint32 arithmetic
+    const float *e[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t cx = (uint32_t)idx[0] + ((c >> 2) & 1), cy = (uint32_t)idx[1] + ((c >> 1) & 1), cz = (uint32_t)idx[2] + (c & 1);
+        const uint32_t h = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
+        e[c] = tl + (int64_t)h * F;
+    }
+    const float omx = 1.0f - w[0], omy = 1.0f - w[1], omz = 1.0f - w[2];
+    float *o = out + i * out_stride + l * F;
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        const float c00 = e[0][f] * omx + e[4][f] * w[0];
+        const float c01 = e[1][f] * omx + e[5][f] * w[0];
+        const float c10 = e[2][f] * omx + e[6][f] * w[0];
+        const float c11 = e[3][f] * omx + e[7][f] * w[0];
+        const float c0 = c00 * omy + c10 * w[1];
+        const float c1 = c01 * omy + c11 * w[1];
+        o[f] = c0 * omz + c1 * w[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// H2  CUDA-semantics hash grid, generic row-major kernel.  One thread per (point, level).
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void k_hash_cu(HashParams hp, PointSource ps, int64_t p, float *__restrict__ out, int out_stride, uint8_t *__restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= p) return;
+    const F3 pt = load_point(ps, i);
+    const float x[3] = {pt.x, pt.y, pt.z};
+    bool kp = true;
+    float fr[3];
+    uint32_t pos[3];
+    const float mul = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);      // CuHashEmbedder.cpp:92-94
+        kp = kp && (x[a] == c);
+        float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * mul;  // .cu:44-46
+        q = q + hp.bias[l * 3 + a];                                              // .cu:61-63
+        const float fl = floorf(q);
+        pos[a] = (uint32_t)fl;                                                   // .cu:66-68
+        fr[a] = q - fl;                                                          // .cu:79-81
+    }
+    if (l == 0 && keep) keep[i] = kp ? 1 : 0;
+    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+    const uint32_t lsz = hp.local_size[l];
+    const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];   // the overlap quirk (.cu:54)
+    float acc[F];
+    cu_blend<F>(fp, pos, fr, pa, pb, pc, lsz, acc);
+    float *o = out + i * out_stride + l * F;
+#pragma unroll
+    for (int f = 0; f < F; f++) o[f] = __half2float(__float2half_rn(acc[f]));     // one fp16 rounding (.cu:95), returned as fp32 (.cu:274)
+}
+
+__global__ void k_f32_to_f16(int64_t n, const float *__restrict__ in, __half *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __float2half_rn(in[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int launch_pe(const float *x, int x_stride, int64_t rows, int nfreq, int rep, float *out, int out_stride, hipStream_t st)
+{
+    if (rows == 0) return NRF_OK;
+    const int64_t total = rows * (nfreq + 1);
+    hipLaunchKernelGGL(k_pe, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, rows, nfreq, rep, x, x_stride, out, out_stride);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int launch_sh(const float *dirs, int dir_stride, int64_t rows, int degree, int variant, int rep, float *out, int out_stride, hipStream_t st)
+{
+    if (rows == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_sh, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, st, rows, degree, variant, rep, dirs, dir_stride, out, out_stride);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+template <int F>
+static int launch_hash_f(const nrf_hash *h, const PointSource &ps, int64_t p, float *out, int out_stride, uint8_t *keep, hipStream_t st)
+{
+    const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)h->desc.n_levels);
+    if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL(k_hash_ngp<F>, grid, dim3(256), 0, st, h->params, ps, p, out, out_stride, keep);
+    else hipLaunchKernelGGL(k_hash_cu<F>, grid, dim3(256), 0, st, h->params, ps, p, out, out_stride, keep);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int launch_hash(const nrf_hash *h, const PointSource &ps, int64_t p, float *out, int out_stride, uint8_t *keep, hipStream_t st)
+{
+    if (p == 0) return NRF_OK;
+    if (!h->table_set) { set_error("hash grid: table not uploaded (nrf_hash_set_table)"); return NRF_ERR_INVALID_ARG; }
+    if (h->desc.mode == NRF_HASH_CU && !h->primes_set) { set_error("hash grid (CU mode): primes not set (nrf_hash_set_primes)"); return NRF_ERR_INVALID_ARG; }
+    ProfScope prof(NRF_PROF_HASH, st);
+    switch (h->desc.n_features) {
+        case 1: return launch_hash_f<1>(h, ps, p, out, out_stride, keep, st);
+        case 2: return launch_hash_f<2>(h, ps, p, out, out_stride, keep, st);
+        case 4: return launch_hash_f<4>(h, ps, p, out, out_stride, keep, st);
+        case 8: return launch_hash_f<8>(h, ps, p, out, out_stride, keep, st);
+        default: set_error("hash grid: n_features %d not built (1, 2, 4, 8)", h->desc.n_features); return NRF_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_pe_encode(const float *d_x, int64_t p, int nfreq, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_x && d_out && p >= 0 && nfreq >= 1 && nfreq <= 32, "nrf_pe_encode: bad argument");
+    return launch_pe(d_x, 3, p, nfreq, 1, d_out, 3 + 6 * nfreq, as_stream(stream));
+}
+
+int nrf_sh_encode(const float *d_dirs, int64_t p, int degree, int variant, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_dirs && d_out && p >= 0, "nrf_sh_encode: bad argument");
+    NRF_CHECK_ARG(variant == NRF_SH_LIBTORCH || variant == NRF_SH_CUDA, "nrf_sh_encode: unknown variant %d", variant);
+    NRF_CHECK_ARG(degree >= 1 && degree <= (variant == NRF_SH_LIBTORCH ? 5 : 8), "nrf_sh_encode: degree %d out of range for variant %d", degree, variant);
+    return launch_sh(d_dirs, 3, p, degree, variant, 1, d_out, degree * degree, as_stream(stream));
+}
+
+int nrf_hash_create(const nrf_hash_desc *desc, nrf_hash **out)
+{
+    NRF_CHECK_ARG(desc && out, "nrf_hash_create: null pointer");
+    NRF_CHECK_ARG(desc->mode == NRF_HASH_NGP || desc->mode == NRF_HASH_CU, "nrf_hash_create: unknown mode %d", desc->mode);
+    NRF_CHECK_ARG(desc->n_levels >= 2 && desc->n_levels <= NRF_MAX_LEVELS, "nrf_hash_create: n_levels %d outside [2,%d]", desc->n_levels, NRF_MAX_LEVELS);
+    NRF_CHECK_ARG(desc->log2_hashmap_size >= 4 && desc->log2_hashmap_size <= 24, "nrf_hash_create: log2_hashmap_size %d outside [4,24]", desc->log2_hashmap_size);
+    NRF_CHECK_ARG(desc->n_features == 1 || desc->n_features == 2 || desc->n_features == 4 || desc->n_features == 8, "nrf_hash_create: n_features %d not in {1,2,4,8}", desc->n_features);
+    NRF_CHECK_ARG(desc->base_resolution >= 1 && desc->finest_resolution >= desc->base_resolution, "nrf_hash_create: bad resolutions");
+    for (int a = 0; a < 3; a++) NRF_CHECK_ARG(desc->bbox[3 + a] > desc->bbox[a], "nrf_hash_create: empty bounding box on axis %d", a);
+    nrf_hash *h = new nrf_hash();
+    h->desc = *desc;
+    const int L = desc->n_levels;
+    HashParams &hp = h->params;
+    memset(&hp, 0, sizeof(hp));
+    for (int a = 0; a < 3; a++) { hp.bbox.mn[a] = desc->bbox[a]; hp.bbox.mx[a] = desc->bbox[3 + a]; }
+    hp.n_levels = L; hp.log2_t = desc->log2_hashmap_size;
+    if (desc->mode == NRF_HASH_NGP) {
+        // NeRF.cpp:251: b = float(exp((ln finest - ln base)/(L-1)));  :309: res_l = floor(float(base * pow(b, l)))
+        const float b = (float)exp((log((double)desc->finest_resolution) - log((double)desc->base_resolution)) / (double)(L - 1));
+        for (int l = 0; l < L; l++) hp.level_scale[l] = floorf((float)((double)desc->base_resolution * pow((double)b, (double)l)));
+    } else {
+        // CuHashEmbedder.cu:40: mul_l = exp2f((log2f(finest) - log2f(base)) * l / (L-1) + log2f(base)), fp32 libm on the host
+        for (int l = 0; l < L; l++)
+            hp.level_scale[l] = exp2f((log2f((float)desc->finest_resolution) - log2f((float)desc->base_resolution)) * (float)l / (float)(L - 1) + log2f((float)desc->base_resolution));
+        // CuHashEmbedder.cpp:62-68: local_size = (2^T >> 4) << 4; local_idx = cumsum - local_size
+        const int32_t ls = (int32_t)((((int64_t)1 << desc->log2_hashmap_size) >> 4) << 4);
+        for (int l = 0; l < L; l++) { hp.local_size[l] = (uint32_t)ls; hp.local_idx[l] = (int32_t)((int64_t)l * ls); }
+    }
+    const int64_t elems = (int64_t)L * ((int64_t)1 << desc->log2_hashmap_size) * desc->n_features;
+    const size_t bytes = (size_t)elems * (desc->mode == NRF_HASH_NGP ? 4 : 2);
+    hipError_t e = hipMalloc(&h->d_table, bytes);
+    if (e != hipSuccess) { set_error("nrf_hash_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); delete h; return NRF_ERR_HIP; }
+    hp.table = h->d_table;
+    *out = h;
+    return NRF_OK;
+}
+
+void nrf_hash_destroy(nrf_hash *h)
+{
+    if (!h) return;
+    if (h->d_table) (void)hipFree(h->d_table);
+    if (h->d_fast) (void)hipFree(h->d_fast);
+    delete h;
+}
+
+int nrf_hash_output_dims(const nrf_hash *h) { return h ? h->desc.n_levels * h->desc.n_features : 0; }
+int64_t nrf_hash_table_elems(const nrf_hash *h) { return h ? (int64_t)h->desc.n_levels * ((int64_t)1 << h->desc.log2_hashmap_size) * h->desc.n_features : 0; }
+
+int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *stream)
+{
+    NRF_CHECK_ARG(h && src, "nrf_hash_set_table: null pointer");
+    const int64_t elems = nrf_hash_table_elems(h);
+    hipStream_t st = as_stream(stream);
+    if (h->desc.mode == NRF_HASH_NGP) {
+        NRF_HIP(hipMemcpyAsync(h->d_table, src, (size_t)elems * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    } else {
+        // fp32 master -> fp16 once (the reference re-casts on every forward, CuHashEmbedder.cu:257)
+        const float *d_src = src;
+        float *tmp = nullptr;
+        if (!src_on_device) {
+            NRF_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)elems * 4));
+            NRF_HIP(hipMemcpyAsync(tmp, src, (size_t)elems * 4, hipMemcpyHostToDevice, st));
+            d_src = tmp;
+        }
+        hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, elems, d_src, reinterpret_cast<__half *>(h->d_table));
+        NRF_LAUNCH_CHECK();
+        if (tmp) { NRF_HIP(hipStreamSynchronize(st)); NRF_HIP(hipFree(tmp)); }
+    }
+    h->table_set = true;
+    h->fast_valid = false;
+    return NRF_OK;
+}
+
+int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
+{
+    NRF_CHECK_ARG(h && primes, "nrf_hash_set_primes: null pointer");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_CU, "nrf_hash_set_primes: only the CuHashEmbedder mode has per-level primes");
+    for (int i = 0; i < h->desc.n_levels * 3; i++) {
+        h->params.primes[i] = (uint32_t)primes[i];
+        h->params.bias[i] = biases ? biases[i] : 0.0f;
+    }
+    h->primes_set = true;
+    h->fast_valid = false;
+    return NRF_OK;
+}
+
+int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, float *d_out, uint8_t *d_keep_mask, void *stream)
+{
+    NRF_CHECK_ARG(h && d_x && d_out && p >= 0, "nrf_hash_encode: bad argument");
+    PointSource ps{d_x, nullptr, nullptr, 0, 1};
+    return launch_hash(h, ps, p, d_out, nrf_hash_output_dims(h), d_keep_mask, as_stream(stream));
+}
+
+}  // extern "C"

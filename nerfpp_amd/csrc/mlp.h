@@ -1,0 +1,47 @@
+// mlp.h -- MLP handle shared by mlp.hip (generic fp32 path), mlp_small_mfma.hip and mlp_nerf_mfma.hip.
+#pragma once
+#include "common.h"
+
+#include <vector>
+
+namespace nrf {
+
+enum { MLP_SMALL = 0, MLP_NERF = 1, MLP_LERF = 2 };
+
+struct LinearLayer {
+    int in = 0, out = 0;
+    float *d_wt = nullptr;      // W^T [in][out] fp32 (lane = output neuron reads coalesced)
+    float *d_bias = nullptr;    // [out] or nullptr
+    size_t w_off = 0;           // offset of W [out][in] in the parameter blob (floats)
+};
+
+}  // namespace nrf
+
+struct nrf_mlp {
+    int family = 0;
+    nrf_mlp_small_desc small{};
+    nrf_mlp_nerf_desc nerf{};
+    int in_dims = 0, out_dims = 0;
+    int max_width = 0;                       // widest activation row (for workspace sizing)
+    std::vector<nrf::LinearLayer> layers;    // in forward order (see mlp.hip for the per-family order)
+    float *d_params = nullptr;               // the fp32 blob, checkpoint order, on device
+    int64_t n_params = 0;
+    // packed operands of the matrix-core paths (built at create time)
+    void *d_packed_f16 = nullptr;
+    size_t packed_f16_bytes = 0;
+};
+
+namespace nrf {
+
+// bytes of scratch nrf_mlp forward needs for `p` points in precision `prec`
+size_t mlp_workspace_bytes(const nrf_mlp *m, int64_t p, int prec);
+
+// x: [p, x_stride] rows holding [input_ch | input_ch_views]; out: [p, out_stride]
+int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int prec, float *d_out, int out_stride,
+                void *d_ws, size_t ws_bytes, hipStream_t st);
+
+// matrix-core paths (separate translation units)
+int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+
+}  // namespace nrf

@@ -1,0 +1,390 @@
+// mlp.hip -- the radiance-field MLPs behind BaseNeRFImpl::forward (NeRF.h:33-42):
+//   NeRFSmallImpl  NeRF.cpp:322-412      NeRFImpl  NeRF.cpp:41-126      LeRFImpl  LeRF.cpp:28-111
+//
+// This file holds the handle (parameter blob in the reference's checkpoint order) and the NRF_PREC_F32 path:
+// a generic fused Linear(+bias)(+ReLU) kernel whose dot product is an fp32 FMA chain in ascending k starting
+// from 0 -- the exact order the oracle restates, so NRF_PREC_F32 output equals the oracle bit for bit.
+// The matrix-core paths (NRF_PREC_F16_MFMA) are in mlp_small_mfma.hip / mlp_nerf_mfma.hip.
+#include "mlp.h"
+
+namespace nrf {
+
+struct Seg {
+    const float *p;   // rows
+    int stride;       // floats between rows
+    int off;          // first column
+    int n;            // columns taken
+};
+
+constexpr int LIN_TP = 16;   // points per block
+
+// y[pt][y_off + o] = act( sum_k W[o][k] * concat(a,b)[pt][k] + bias[o] ),  W given transposed ([in][out]).
+__global__ void __launch_bounds__(256) k_linear(int64_t npts, Seg a, Seg b, const float *__restrict__ wt, const float *__restrict__ bias,
+                                                int out, int relu, float *__restrict__ y, int y_stride, int y_off)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [in][LIN_TP]
+    const int in = a.n + b.n;
+    const int64_t p0 = (int64_t)blockIdx.x * LIN_TP;
+    for (int e = threadIdx.x; e < in * LIN_TP; e += blockDim.x) {
+        const int j = e / in, k = e - j * in;                     // consecutive threads walk a row: coalesced
+        const int64_t pt = p0 + j;
+        float v = 0.0f;
+        if (pt < npts) v = (k < a.n) ? a.p[pt * a.stride + a.off + k] : b.p[pt * b.stride + b.off + (k - a.n)];
+        xs[k * LIN_TP + j] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < out; o += blockDim.x) {
+        float acc[LIN_TP];
+#pragma unroll
+        for (int j = 0; j < LIN_TP; j++) acc[j] = 0.0f;
+        for (int k = 0; k < in; k++) {
+            const float w = wt[(size_t)k * out + o];
+            const float4 *xv = reinterpret_cast<const float4 *>(xs + k * LIN_TP);
+#pragma unroll
+            for (int q = 0; q < LIN_TP / 4; q++) {
+                const float4 v = xv[q];
+                acc[q * 4 + 0] = __builtin_fmaf(w, v.x, acc[q * 4 + 0]);
+                acc[q * 4 + 1] = __builtin_fmaf(w, v.y, acc[q * 4 + 1]);
+                acc[q * 4 + 2] = __builtin_fmaf(w, v.z, acc[q * 4 + 2]);
+                acc[q * 4 + 3] = __builtin_fmaf(w, v.w, acc[q * 4 + 3]);
+            }
+        }
+        const float bo = bias ? bias[o] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < LIN_TP; j++) {
+            const int64_t pt = p0 + j;
+            if (pt < npts) {
+                float v = acc[j];
+                if (bias) v = v + bo;
+                if (relu) v = v < 0.0f ? 0.0f : v;
+                y[pt * y_stride + y_off + o] = v;
+            }
+        }
+    }
+}
+
+// LeRFImpl: le = normalize(h, eps=1e-8) = h / max(||h||, eps); one wave per point.
+__global__ void k_l2_normalize(int64_t npts, int n, const float *__restrict__ x, int x_stride, float *__restrict__ y, int y_stride)
+{
+    const int64_t pt = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (pt >= npts) return;
+    const int lane = threadIdx.x & 63;
+    double ss = 0.0;
+    for (int k = lane; k < n; k += 64) { const float v = x[pt * x_stride + k]; ss += (double)v * (double)v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-8f);
+    for (int k = lane; k < n; k += 64) y[pt * y_stride + k] = x[pt * x_stride + k] / nrm;
+}
+
+__global__ void k_copy_col(int64_t npts, const float *__restrict__ x, int x_stride, int x_col, float *__restrict__ y, int y_stride, int y_col)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npts) y[i * y_stride + y_col] = x[i * x_stride + x_col];
+}
+
+static int run_linear(int64_t npts, Seg a, Seg b, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
+{
+    const int in = a.n + b.n;
+    if (in != L.in) { set_error("internal: linear layer expects %d inputs, got %d", L.in, in); return NRF_ERR_INVALID_ARG; }
+    const int threads = L.out >= 256 ? 256 : (int)ceil_div(L.out, 64) * 64;
+    const size_t lds = (size_t)in * LIN_TP * sizeof(float);
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)ceil_div(npts, LIN_TP)), dim3(threads), lds, st, npts, a, b, L.d_wt, L.d_bias, L.out, relu, y, y_stride, y_off);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+static const int64_t F32_CHUNK = 1 << 18;   // points per pass of the generic path (bounds the scratch)
+
+size_t mlp_workspace_bytes(const nrf_mlp *m, int64_t p, int prec)
+{
+    if (prec == NRF_PREC_F32) {
+        const int64_t c = p < F32_CHUNK ? p : F32_CHUNK;
+        return align_up((size_t)c * m->max_width * sizeof(float), 256) * 3;
+    }
+    return 256;
+}
+
+static int forward_f32(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, float *ws, hipStream_t st)
+{
+    const size_t buf_elems = align_up((size_t)(p < F32_CHUNK ? p : F32_CHUNK) * m->max_width * sizeof(float), 256) / sizeof(float);
+    float *A = ws, *B = ws + buf_elems, *C = ws + 2 * buf_elems;
+    const int W = m->max_width;
+    const Seg none{nullptr, 0, 0, 0};
+    if (m->family == MLP_SMALL) {
+        const auto &d = m->small;
+        // sigma net (NeRF.cpp:372-381)
+        Seg cur{x, xs, 0, d.input_ch};
+        float *bufs[2] = {A, B};
+        int li = 0;
+        for (int l = 0; l < d.num_layers; l++, li++) {
+            NRF_TRY(run_linear(p, cur, none, m->layers[li], l != d.num_layers - 1, bufs[l & 1], W, 0, st));
+            cur = Seg{bufs[l & 1], W, 0, m->layers[li].out};
+        }
+        const float *sig = cur.p;   // column 0 = sigma, 1.. = geo features
+        // colour net on cat[views, geo] (NeRF.cpp:384-391)
+        Seg cv{x, xs, d.input_ch, d.input_ch_views};
+        Seg cg{sig, W, 1, d.geo_feat_dim};
+        float *cb[2] = {C, (sig == A) ? B : A};
+        for (int l = 0; l < d.num_layers_color; l++, li++) {
+            const bool last = (l == d.num_layers_color - 1);
+            float *dst = last ? out : cb[l & 1];
+            NRF_TRY(run_linear(p, l == 0 ? cv : cur, l == 0 ? cg : none, m->layers[li], !last, dst, last ? os : W, 0, st));
+            cur = Seg{dst, last ? os : W, 0, m->layers[li].out};
+        }
+        // out = cat[colour, sigma] (NeRF.cpp:408)
+        hipLaunchKernelGGL(k_copy_col, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, st, p, sig, W, 0, out, os, 3);
+        NRF_LAUNCH_CHECK();
+        return NRF_OK;
+    }
+    if (m->family == MLP_NERF) {
+        const auto &d = m->nerf;
+        const Seg xin{x, xs, 0, d.input_ch};
+        Seg cur = xin;
+        bool cat_in = false;
+        float *bufs[2] = {A, B};
+        int li = 0;
+        for (int l = 0; l < d.depth; l++, li++) {
+            // after layer `skip`, h = cat[input_pts, h] (NeRF.cpp:103-104)
+            NRF_TRY(run_linear(p, cat_in ? xin : cur, cat_in ? cur : none, m->layers[li], 1, bufs[l & 1], W, 0, st));
+            cur = Seg{bufs[l & 1], W, 0, d.width};
+            cat_in = (l == d.skip);
+        }
+        float *other = (cur.p == A) ? B : A;
+        if (d.use_viewdirs) {
+            const LinearLayer &views = m->layers[li], &feat = m->layers[li + 1], &alpha = m->layers[li + 2], &rgb = m->layers[li + 3];
+            NRF_TRY(run_linear(p, cur, none, alpha, 0, out, os, 3, st));                                   // alpha -> out[:,3]
+            NRF_TRY(run_linear(p, cur, none, feat, 0, other, W, 0, st));                                   // feature (no ReLU)
+            NRF_TRY(run_linear(p, Seg{other, W, 0, d.width}, Seg{x, xs, d.input_ch, d.input_ch_views}, views, 1, C, W, 0, st));
+            NRF_TRY(run_linear(p, Seg{C, W, 0, d.width / 2}, none, rgb, 0, out, os, 0, st));               // rgb -> out[:,0:3]
+        } else {
+            // output_linear(cat[h, input_pts]) (NeRF.cpp:121-124); cat_in can only be set if skip == depth-1
+            NRF_TRY(run_linear(p, cur, xin, m->layers[li], 0, out, os, 0, st));
+        }
+        return NRF_OK;
+    }
+    // MLP_LERF (LeRF.cpp:86-108)
+    {
+        const auto &d = m->small;   // reuses: input_ch, num_layers, hidden_dim, geo_feat_dim; hidden_dim_color = embed dim
+        const Seg xin{x, xs, 0, d.input_ch};
+        Seg cur = xin;
+        float *bufs[2] = {A, B};
+        int li = 0;
+        for (int l = 0; l < d.num_layers; l++, li++) {
+            NRF_TRY(run_linear(p, cur, none, m->layers[li], l != d.num_layers - 1, bufs[l & 1], W, 0, st));
+            cur = Seg{bufs[l & 1], W, 0, m->layers[li].out};
+        }
+        const float *sig = cur.p;
+        float *cb[2] = {C, (sig == A) ? B : A};
+        Seg g{sig, W, 1, d.geo_feat_dim};
+        for (int l = 0; l < d.num_layers; l++, li++) {
+            NRF_TRY(run_linear(p, l == 0 ? g : cur, l == 0 ? xin : none, m->layers[li], l != d.num_layers - 1, cb[l & 1], W, 0, st));
+            cur = Seg{cb[l & 1], W, 0, m->layers[li].out};
+        }
+        const int E = d.hidden_dim_color;
+        hipLaunchKernelGGL(k_l2_normalize, dim3((unsigned)ceil_div(p, 4)), dim3(256), 0, st, p, E, cur.p, W, out, os);
+        NRF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_copy_col, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, st, p, sig, W, 0, out, os, E);
+        NRF_LAUNCH_CHECK();
+        return NRF_OK;
+    }
+}
+
+int mlp_small_forward_mfma(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, float *d_out, int out_stride, hipStream_t st);
+int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, float *d_out, int out_stride, hipStream_t st);
+
+int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int prec, float *d_out, int out_stride,
+                void *d_ws, size_t ws_bytes, hipStream_t st)
+{
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_MLP, st);
+    if (prec == NRF_PREC_F32) {
+        if (ws_bytes < mlp_workspace_bytes(m, p, prec)) { set_error("mlp_forward: workspace %zu < %zu bytes", ws_bytes, mlp_workspace_bytes(m, p, prec)); return NRF_ERR_WORKSPACE; }
+        for (int64_t p0 = 0; p0 < p; p0 += F32_CHUNK) {
+            const int64_t c = (p - p0) < F32_CHUNK ? (p - p0) : F32_CHUNK;
+            NRF_TRY(forward_f32(m, d_x + p0 * x_stride, x_stride, c, d_out + p0 * out_stride, out_stride, reinterpret_cast<float *>(d_ws), st));
+        }
+        return NRF_OK;
+    }
+    if (prec == NRF_PREC_F16_MFMA) {
+        if (m->family == MLP_SMALL) return mlp_small_forward_mfma(m, d_x, x_stride, p, d_out, out_stride, st);
+        if (m->family == MLP_NERF) return mlp_nerf_forward_mfma(m, d_x, x_stride, p, d_out, out_stride, st);
+        set_error("NRF_PREC_F16_MFMA is not built for this MLP family; use NRF_PREC_F32");
+        return NRF_ERR_UNSUPPORTED;
+    }
+    set_error("unknown precision %d", prec);
+    return NRF_ERR_INVALID_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// handle construction
+// ---------------------------------------------------------------------------------------------------
+static int add_layer(nrf_mlp *m, const std::vector<float> &hp, size_t &off, int in, int out, bool bias)
+{
+    LinearLayer L;
+    L.in = in; L.out = out; L.w_off = off;
+    std::vector<float> wt((size_t)in * out);
+    for (int o = 0; o < out; o++)
+        for (int k = 0; k < in; k++) wt[(size_t)k * out + o] = hp[off + (size_t)o * in + k];
+    off += (size_t)in * out;
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&L.d_wt), wt.size() * sizeof(float)));
+    NRF_HIP(hipMemcpy(L.d_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (bias) {
+        NRF_HIP(hipMalloc(reinterpret_cast<void **>(&L.d_bias), (size_t)out * sizeof(float)));
+        NRF_HIP(hipMemcpy(L.d_bias, hp.data() + off, (size_t)out * sizeof(float), hipMemcpyHostToDevice));
+        off += out;
+    }
+    m->layers.push_back(L);
+    if (in > m->max_width) m->max_width = in;
+    if (out > m->max_width) m->max_width = out;
+    return NRF_OK;
+}
+
+static int fetch_params(const float *params, int on_device, int64_t n, hipStream_t st, std::vector<float> &host, nrf_mlp *m)
+{
+    host.resize((size_t)n);
+    if (on_device) {
+        NRF_HIP(hipMemcpyAsync(host.data(), params, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        NRF_HIP(hipStreamSynchronize(st));
+    } else memcpy(host.data(), params, (size_t)n * 4);
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_params), (size_t)n * 4));
+    NRF_HIP(hipMemcpy(m->d_params, host.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    m->n_params = n;
+    return NRF_OK;
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int64_t nrf_mlp_small_param_count(const nrf_mlp_small_desc *d)
+{
+    if (!d) return 0;
+    int64_t n = 0;
+    for (int l = 0; l < d->num_layers; l++) n += (int64_t)((l == 0) ? d->input_ch : d->hidden_dim) * ((l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim);
+    for (int l = 0; l < d->num_layers_color; l++)
+        n += (int64_t)((l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color) * ((l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color);
+    return n;
+}
+
+int64_t nrf_mlp_nerf_param_count(const nrf_mlp_nerf_desc *d)
+{
+    if (!d) return 0;
+    const int w = d->width;
+    int64_t n = (int64_t)d->input_ch * w + w;
+    for (int i = 0; i < d->depth - 1; i++) n += (int64_t)((i == d->skip) ? (w + d->input_ch) : w) * w + w;
+    if (d->use_viewdirs) n += (int64_t)(d->input_ch_views + w) * (w / 2) + w / 2 + (int64_t)w * w + w + w + 1 + (int64_t)(w / 2) * 3 + 3;
+    else n += (int64_t)(w + d->input_ch) * d->output_ch + d->output_ch;
+    return n;
+}
+
+int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out)
+{
+    NRF_CHECK_ARG(d && params && out, "nrf_mlp_small_create: null pointer");
+    NRF_CHECK_ARG(d->input_ch > 0 && d->input_ch_views >= 0 && d->num_layers >= 1 && d->hidden_dim > 0 && d->geo_feat_dim >= 0 &&
+                  d->num_layers_color >= 1 && d->hidden_dim_color > 0, "nrf_mlp_small_create: bad dimensions");
+    nrf_mlp *m = new nrf_mlp();
+    m->family = MLP_SMALL; m->small = *d;
+    m->in_dims = d->input_ch + d->input_ch_views; m->out_dims = 4;
+    std::vector<float> hp;
+    int s = fetch_params(params, params_on_device, nrf_mlp_small_param_count(d), as_stream(stream), hp, m);
+    size_t off = 0;
+    for (int l = 0; l < d->num_layers && s == NRF_OK; l++)
+        s = add_layer(m, hp, off, (l == 0) ? d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim, false);
+    for (int l = 0; l < d->num_layers_color && s == NRF_OK; l++)
+        s = add_layer(m, hp, off, (l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color, (l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color, false);
+    if (s == NRF_OK) s = mlp_small_pack_f16(m, hp);
+    if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
+    *out = m;
+    return NRF_OK;
+}
+
+int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out)
+{
+    NRF_CHECK_ARG(d && params && out, "nrf_mlp_nerf_create: null pointer");
+    NRF_CHECK_ARG(d->depth >= 2 && d->width >= 2 && d->input_ch > 0 && d->skip >= -1 && d->skip < d->depth - 1, "nrf_mlp_nerf_create: bad dimensions");
+    NRF_CHECK_ARG(d->use_viewdirs ? d->input_ch_views > 0 : d->output_ch > 0, "nrf_mlp_nerf_create: bad head dimensions");
+    nrf_mlp *m = new nrf_mlp();
+    m->family = MLP_NERF; m->nerf = *d;
+    m->in_dims = d->input_ch + (d->use_viewdirs ? d->input_ch_views : 0);
+    m->out_dims = d->use_viewdirs ? 4 : d->output_ch;
+    std::vector<float> hp;
+    int s = fetch_params(params, params_on_device, nrf_mlp_nerf_param_count(d), as_stream(stream), hp, m);
+    size_t off = 0;
+    const int w = d->width;
+    if (s == NRF_OK) s = add_layer(m, hp, off, d->input_ch, w, true);
+    for (int i = 0; i < d->depth - 1 && s == NRF_OK; i++) s = add_layer(m, hp, off, (i == d->skip) ? (w + d->input_ch) : w, w, true);
+    if (d->use_viewdirs) {
+        // blob order: views_linears_0, feature_linear, alpha_linear, rgb_linear (NeRF.cpp:78-88)
+        if (s == NRF_OK) s = add_layer(m, hp, off, d->input_ch_views + w, w / 2, true);
+        if (s == NRF_OK) s = add_layer(m, hp, off, w, w, true);
+        if (s == NRF_OK) s = add_layer(m, hp, off, w, 1, true);
+        if (s == NRF_OK) s = add_layer(m, hp, off, w / 2, 3, true);
+    } else if (s == NRF_OK) s = add_layer(m, hp, off, w + d->input_ch, d->output_ch, true);
+    if (w + d->input_ch_views > m->max_width) m->max_width = w + d->input_ch_views;
+    if (s == NRF_OK) s = mlp_nerf_pack_f16(m, hp);
+    if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
+    *out = m;
+    return NRF_OK;
+}
+
+/* LeRFImpl ctor (LeRF.cpp:3-26): sigma net in->H..->1+geo, LE net (geo+in)->H..->embed, both `num_layers` deep, bias-free.
+ * Described with nrf_mlp_small_desc: input_ch, num_layers, hidden_dim, geo_feat_dim, hidden_dim_color = lang_embed_dim. */
+NRF_API int64_t nrf_mlp_lerf_param_count(const nrf_mlp_small_desc *d)
+{
+    if (!d) return 0;
+    int64_t n = 0;
+    for (int l = 0; l < d->num_layers; l++) n += (int64_t)((l == 0) ? d->input_ch : d->hidden_dim) * ((l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim);
+    for (int l = 0; l < d->num_layers; l++) n += (int64_t)((l == 0) ? d->geo_feat_dim + d->input_ch : d->hidden_dim) * ((l == d->num_layers - 1) ? d->hidden_dim_color : d->hidden_dim);
+    return n;
+}
+
+NRF_API int nrf_mlp_lerf_create(const nrf_mlp_small_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out)
+{
+    NRF_CHECK_ARG(d && params && out, "nrf_mlp_lerf_create: null pointer");
+    NRF_CHECK_ARG(d->input_ch > 0 && d->num_layers >= 1 && d->hidden_dim > 0 && d->geo_feat_dim >= 0 && d->hidden_dim_color > 0, "nrf_mlp_lerf_create: bad dimensions");
+    nrf_mlp *m = new nrf_mlp();
+    m->family = MLP_LERF; m->small = *d;
+    m->in_dims = d->input_ch; m->out_dims = d->hidden_dim_color + 1;
+    std::vector<float> hp;
+    int s = fetch_params(params, params_on_device, nrf_mlp_lerf_param_count(d), as_stream(stream), hp, m);
+    size_t off = 0;
+    for (int l = 0; l < d->num_layers && s == NRF_OK; l++)
+        s = add_layer(m, hp, off, (l == 0) ? d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim, false);
+    for (int l = 0; l < d->num_layers && s == NRF_OK; l++)
+        s = add_layer(m, hp, off, (l == 0) ? d->geo_feat_dim + d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? d->hidden_dim_color : d->hidden_dim, false);
+    if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
+    *out = m;
+    return NRF_OK;
+}
+
+void nrf_mlp_destroy(nrf_mlp *m)
+{
+    if (!m) return;
+    for (auto &L : m->layers) {
+        if (L.d_wt) (void)hipFree(L.d_wt);
+        if (L.d_bias) (void)hipFree(L.d_bias);
+    }
+    if (m->d_params) (void)hipFree(m->d_params);
+    if (m->d_packed_f16) (void)hipFree(m->d_packed_f16);
+    delete m;
+}
+
+int nrf_mlp_output_dims(const nrf_mlp *m) { return m ? m->out_dims : 0; }
+
+int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int precision, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(m && d_x && d_out && p >= 0, "nrf_mlp_forward: bad argument");
+    if (p == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    const size_t wsb = mlp_workspace_bytes(m, p, precision);
+    void *ws = nullptr;
+    NRF_HIP(hipMallocAsync(&ws, wsb, st));          // stream-ordered scratch for the standalone entry point
+    const int s = mlp_forward(m, d_x, m->in_dims, p, precision, d_out, m->out_dims, ws, wsb, st);
+    NRF_HIP(hipFreeAsync(ws, st));
+    return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,270 @@
+// rays.hip -- ray generation, AABB clipping, ray-batch packing, stratified depths.
+// Reference: RayUtils.h (GetDirections/GetRays/NDCRays/IntersectWithAABB), NeRFRenderer.h:393-419, :549-603.
+// fp32, one rounding per source-level op (the library is built with -ffp-contract=off) so that every
+// value here equals the LibTorch CPU result bit for bit.
+#include "common.h"
+
+namespace nrf {
+
+// ------------------------------------------------------------------------------------------------
+// RayUtils.h:5-46.  One thread per pixel; ray index = (y-row0)*w + x.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_get_rays(int w, int row0, int64_t n, float fx, float cx, float fy, float cy,
+                           float r00, float r01, float r02, float r10, float r11, float r12, float r20, float r21, float r22,
+                           float t0, float t1, float t2, float *__restrict__ o, float *__restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int y = row0 + (int)(i / w);
+    const int x = (int)(i % w);
+    const float dx = ((float)x - cx) / fx;
+    const float dy = -((float)y - cy) / fy;
+    const float dz = -1.0f;
+    // torch::sum(dirs[..., None, :] * c2w[:3,:3], -1): three products summed left to right
+    float a0 = dx * r00; a0 = a0 + dy * r01; a0 = a0 + dz * r02;
+    float a1 = dx * r10; a1 = a1 + dy * r11; a1 = a1 + dz * r12;
+    float a2 = dx * r20; a2 = a2 + dy * r21; a2 = a2 + dz * r22;
+    d[i * 3 + 0] = a0; d[i * 3 + 1] = a1; d[i * 3 + 2] = a2;
+    o[i * 3 + 0] = t0; o[i * 3 + 1] = t1; o[i * 3 + 2] = t2;
+}
+
+// RayUtils.h:49-83
+__global__ void k_ndc_rays(int64_t n, float sx, float sy, float near_, float two_near, float m_two_near,
+                           const float *__restrict__ o, const float *__restrict__ d, float *__restrict__ oo, float *__restrict__ od)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ox = o[i * 3], oy = o[i * 3 + 1], oz = o[i * 3 + 2];
+    const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+    const float t = -(near_ + oz) / dz;
+    ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+    oo[i * 3 + 0] = sx * ox / oz;
+    oo[i * 3 + 1] = sy * oy / oz;
+    oo[i * 3 + 2] = 1.0f + two_near / oz;
+    od[i * 3 + 0] = sx * (dx / dz - ox / oz);
+    od[i * 3 + 1] = sy * (dy / dz - oy / oz);
+    od[i * 3 + 2] = m_two_near / oz;
+}
+
+// RayUtils.h:87-126
+__device__ __forceinline__ void aabb_one(const float *o, const float *d, const Bbox &bb, float near_plane, float &nr, float &fr)
+{
+    float tmin[3], tmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float inv = 1.0f / (d[a] + 1e-6f);
+        const float t1 = (bb.mn[a] - o[a]) * inv;
+        const float t2 = (bb.mx[a] - o[a]) * inv;
+        tmin[a] = fminf(t1, t2);
+        tmax[a] = fmaxf(t1, t2);
+    }
+    nr = fmaxf(fmaxf(tmin[0], tmin[1]), tmin[2]);
+    fr = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+    nr = fmaxf(nr, near_plane);
+    fr = fmaxf(fr, nr + 1e-6f);
+}
+
+__global__ void k_aabb(int64_t n, Bbox bb, float near_plane, const float *__restrict__ o, const float *__restrict__ d,
+                       float *__restrict__ nears, float *__restrict__ fars)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float oo[3] = {o[i * 3], o[i * 3 + 1], o[i * 3 + 2]};
+    float dd[3] = {d[i * 3], d[i * 3 + 1], d[i * 3 + 2]};
+    float nr, fr;
+    aabb_one(oo, dd, bb, near_plane, nr, fr);
+    nears[i] = nr; fars[i] = fr;
+}
+
+// NeRFRenderer.h:549-583
+__global__ void k_pack_rays(int64_t n, Bbox bb, int use_viewdirs, const float *__restrict__ o, const float *__restrict__ d,
+                            float *__restrict__ rays)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int stride = use_viewdirs ? 11 : 8;
+    float oo[3] = {o[i * 3], o[i * 3 + 1], o[i * 3 + 2]};
+    float dd[3] = {d[i * 3], d[i * 3 + 1], d[i * 3 + 2]};
+    float nr, fr;
+    aabb_one(oo, dd, bb, 0.0f, nr, fr);
+    float *r = rays + i * stride;
+    r[0] = oo[0]; r[1] = oo[1]; r[2] = oo[2];
+    r[3] = dd[0]; r[4] = dd[1]; r[5] = dd[2];
+    r[6] = nr; r[7] = fr;
+    if (use_viewdirs) {
+        float s = dd[0] * dd[0]; s = s + dd[1] * dd[1]; s = s + dd[2] * dd[2];
+        const float nrm = sqrtf(s);
+        r[8] = dd[0] / nrm; r[9] = dd[1] / nrm; r[10] = dd[2] / nrm;
+    }
+}
+
+// NeRFRenderer.h:602-603: near.min(), far.max().  Exact (min/max are order independent).
+__global__ void k_near_far_range(int64_t n, int stride, const float *__restrict__ rays, float *__restrict__ out /*[2], pre-set to +inf,-inf*/)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        mn = fminf(mn, rays[i * stride + 6]);
+        mx = fmaxf(mx, rays[i * stride + 7]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // floats >= 0 order like their bit patterns; near >= 0 by construction (clamp_min(0)), far may be
+        // anything, so use the order-preserving int transform for both.
+        auto enc = [](float f) { int v = __float_as_int(f); return v >= 0 ? v : (v ^ 0x7fffffff); };
+        atomicMin(reinterpret_cast<int *>(out), enc(mn));
+        atomicMax(reinterpret_cast<int *>(out) + 1, enc(mx));
+    }
+}
+
+__device__ __forceinline__ float safe_inv(float x) { return (fabsf(x) < 1e-8f) ? (1.0f / 1e-8f) : (1.0f / x); }
+
+// NeRFRenderer.h:393-402
+__global__ void k_z_vals(int64_t total, int s, int stride, int lindisp, const float *__restrict__ rays, const float *__restrict__ t,
+                         float *__restrict__ z)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t ray = i / s;
+    const int j = (int)(i - ray * s);
+    const float nr = rays[ray * stride + 6], fr = rays[ray * stride + 7];
+    const float tj = t[j];
+    const float omt = 1.0f - tj;
+    float v;
+    if (!lindisp) v = nr * omt + fr * tj;
+    else v = safe_inv(safe_inv(nr) * omt + safe_inv(fr) * tj);
+    z[i] = v;
+}
+
+// NeRFRenderer.h:419
+__global__ void k_points(int64_t total, int s, int stride, const float *__restrict__ rays, const float *__restrict__ z, float *__restrict__ pts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t ray = i / s;
+    const float *r = rays + ray * stride;
+    const float zz = z[i];
+    pts[i * 3 + 0] = r[0] + r[3] * zz;
+    pts[i * 3 + 1] = r[1] + r[4] * zz;
+    pts[i * 3 + 2] = r[2] + r[5] * zz;
+}
+
+static inline Bbox make_bbox(const float *b)
+{
+    Bbox bb;
+    for (int a = 0; a < 3; a++) { bb.mn[a] = b[a]; bb.mx[a] = b[3 + a]; }
+    return bb;
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_get_rays(int h, int w, const float *K, const float *c2w, int row0, int rows, float *d_o, float *d_d, float *cone_angle, void *stream)
+{
+    NRF_CHECK_ARG(K && c2w && d_o && d_d, "nrf_get_rays: null pointer");
+    NRF_CHECK_ARG(h > 0 && w > 0 && row0 >= 0 && rows >= 0 && row0 + rows <= h, "nrf_get_rays: rows [%d,%d) outside image of height %d", row0, row0 + rows, h);
+    const int64_t n = (int64_t)rows * w;
+    if (cone_angle) {
+        const float px = 1.0f / K[0], py = 1.0f / K[4];
+        const float avg = (px + py) / 2.0f;
+        *cone_angle = avg * 1.1f;
+    }
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), w, row0, n, K[0], K[2], K[4], K[5],
+                       c2w[0], c2w[1], c2w[2], c2w[4], c2w[5], c2w[6], c2w[8], c2w[9], c2w[10], c2w[3], c2w[7], c2w[11], d_o, d_d);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_ndc_rays(int h, int w, float focal, float near_plane, const float *d_o, const float *d_d, int64_t n, float *d_o_out, float *d_d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_o && d_d && d_o_out && d_d_out && n >= 0, "nrf_ndc_rays: bad argument");
+    if (n == 0) return NRF_OK;
+    // RayUtils.h:63-71: the double-precision python-style constants are rounded to fp32 when applied to fp32 tensors
+    const float sx = (float)(-1. / ((double)w / (2. * (double)focal)));
+    const float sy = (float)(-1. / ((double)h / (2. * (double)focal)));
+    const float two_near = (float)(2. * (double)near_plane);
+    const float m_two_near = (float)(-2. * (double)near_plane);
+    hipLaunchKernelGGL(k_ndc_rays, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, sx, sy, near_plane, two_near, m_two_near,
+                       d_o, d_d, d_o_out, d_d_out);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_aabb(const float *d_o, const float *d_d, const float *bbox, int64_t n, float near_plane, float *d_near, float *d_far, void *stream)
+{
+    NRF_CHECK_ARG(d_o && d_d && bbox && d_near && d_far && n >= 0, "nrf_aabb: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_aabb, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, make_bbox(bbox), near_plane, d_o, d_d, d_near, d_far);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_pack_rays(const float *d_o, const float *d_d, const float *bbox, int64_t n, int use_viewdirs, float *d_rays, void *stream)
+{
+    NRF_CHECK_ARG(d_o && d_d && bbox && d_rays && n >= 0, "nrf_pack_rays: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_pack_rays, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, make_bbox(bbox), use_viewdirs, d_o, d_d, d_rays);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *near_min, float *far_max, void *stream)
+{
+    NRF_CHECK_ARG(d_rays && n > 0 && ray_stride >= 8 && near_min && far_max, "nrf_near_far_range: bad argument");
+    int *d_out = nullptr;
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_out), 2 * sizeof(int), as_stream(stream)));
+    const int init[2] = {0x7f800000 /* +inf */, (int)(0xff800000u ^ 0x7fffffffu) /* enc(-inf) */};
+    NRF_HIP(hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, as_stream(stream)));
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024);
+    hipLaunchKernelGGL(k_near_far_range, dim3(grid), dim3(256), 0, as_stream(stream), n, ray_stride, d_rays, reinterpret_cast<float *>(d_out));
+    NRF_LAUNCH_CHECK();
+    int res[2];
+    NRF_HIP(hipMemcpyAsync(res, d_out, sizeof(res), hipMemcpyDeviceToHost, as_stream(stream)));
+    NRF_HIP(hipStreamSynchronize(as_stream(stream)));
+    NRF_HIP(hipFreeAsync(d_out, as_stream(stream)));
+    auto dec = [](int v) { int b = v >= 0 ? v : (v ^ 0x7fffffff); float f; memcpy(&f, &b, 4); return f; };
+    *near_min = dec(res[0]);
+    *far_max = dec(res[1]);
+    return NRF_OK;
+}
+
+int nrf_linspace(float start, float end, int steps, float *out)
+{
+    NRF_CHECK_ARG(out && steps >= 1, "nrf_linspace: bad argument");
+    if (steps == 1) { out[0] = start; return NRF_OK; }
+    // ATen linspace_kernel: fp32 step, halves mirrored, one FUSED rounding per element (see oracle/nerf_oracle.c orc_linspace)
+    const float step = (end - start) / (float)(steps - 1);
+    const int halfway = steps / 2;
+    for (int i = 0; i < steps; i++)
+        out[i] = (i < halfway) ? __builtin_fmaf(step, (float)i, start) : __builtin_fmaf(-step, (float)(steps - i - 1), end);
+    return NRF_OK;
+}
+
+int nrf_z_vals(const float *d_rays, int ray_stride, int64_t n, const float *d_t, int s, int lindisp, float *d_z, void *stream)
+{
+    NRF_CHECK_ARG(d_rays && d_t && d_z && ray_stride >= 8 && n >= 0 && s > 0, "nrf_z_vals: bad argument");
+    const int64_t total = n * s;
+    if (total == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_z_vals, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), total, s, ray_stride, lindisp, d_rays, d_t, d_z);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_points(const float *d_rays, int ray_stride, const float *d_z, int64_t n, int s, float *d_pts, void *stream)
+{
+    NRF_CHECK_ARG(d_rays && d_z && d_pts && ray_stride >= 8 && n >= 0 && s > 0, "nrf_points: bad argument");
+    const int64_t total = n * s;
+    if (total == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_points, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), total, s, ray_stride, d_rays, d_z, d_pts);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // extern "C"

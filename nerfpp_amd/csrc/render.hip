@@ -1,0 +1,281 @@
+// render.hip -- the renderer behind NeRFRenderer<TEmbedder,TEmbedDirs,TNeRF> (NeRFRenderer.h:88-159):
+//   RunNetwork  :164-194     RenderRays  :366-459
+// plus library-wide bookkeeping (error text, profiling events).
+//
+// Deterministic render path only (Perturb = 0, RawNoiseStd = 0, ThinRay): what FillRenderParams configures for
+// test-time rendering (NeRFExecutor.h:379-415).  One network serves both passes and the fine pass re-evaluates all
+// S + N_importance depths (NeRFRenderer.h:422,447).
+#include "encode.h"
+#include "mlp.h"
+
+#include <mutex>
+
+struct nrf_renderer {
+    nrf_renderer_desc desc;
+    int in_ch = 0, in_views = 0;
+};
+
+namespace nrf {
+
+// ---------------------------------------------------------------------------------------------------
+// error text
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// profiling: HIP events around the dominant kernels, recorded on the caller's stream
+// ---------------------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+struct ProfRec { int slot; hipEvent_t e0, e1; };
+static std::vector<ProfRec> g_prof_pending;
+static double g_prof_ms[NRF_PROF_COUNT];
+static int64_t g_prof_n[NRF_PROF_COUNT];
+
+ProfScope::ProfScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_), active(g_prof_on)
+{
+    if (!active) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { active = false; return; }
+    (void)hipEventRecord(e0, stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!active) return;
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_pending.push_back({slot, e0, e1});
+}
+
+// raw[i][3] = 0 where the embedder's keep_mask is false (NeRFRenderer.h:187-188)
+__global__ void k_mask_sigma(int64_t p, int c, const uint8_t *__restrict__ keep, float *__restrict__ raw)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p && !keep[i]) raw[i * c + (c - 1)] = 0.0f;
+}
+
+struct Bump {
+    char *base;
+    size_t off = 0, cap;
+    Bump(void *b, size_t c) : base(static_cast<char *>(b)), cap(c) {}
+    template <class T> T *take(size_t count)
+    {
+        off = align_up(off, 256);
+        T *p = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+static size_t network_ws_bytes(const nrf_renderer *r, int64_t p, int prec)
+{
+    size_t b = 0;
+    b += align_up((size_t)p * (r->in_ch + r->in_views) * sizeof(float), 256);    // concatenated MLP input
+    b += align_up((size_t)p, 256);                                               // keep mask
+    b += align_up((size_t)p * 3 * sizeof(float), 256);                           // explicit points (PE path)
+    b += align_up(mlp_workspace_bytes(r->desc.mlp, p, prec), 256) + 1024;
+    return b;
+}
+
+// RunNetwork over p = n*s points given either explicit points or (rays, z).
+static int run_network(const nrf_renderer *r, const PointSource &ps, const float *viewdirs, int vd_stride, int64_t n, int s, int prec,
+                       float *raw, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    const int64_t p = n * s;
+    if (p == 0) return NRF_OK;
+    if (ws_bytes < network_ws_bytes(r, p, prec)) { set_error("run_network: workspace %zu < %zu bytes", ws_bytes, network_ws_bytes(r, p, prec)); return NRF_ERR_WORKSPACE; }
+    Bump bump(ws, ws_bytes);
+    const int xd = r->in_ch + r->in_views;
+    float *x = bump.take<float>((size_t)p * xd);
+    uint8_t *keep = bump.take<uint8_t>((size_t)p);
+    float *pts = bump.take<float>((size_t)p * 3);
+    void *mws = bump.take<char>(0);
+    const size_t mws_bytes = ws_bytes - bump.off;
+    // embed_fn->forward(inputs_flat)                                            (NeRFRenderer.h:175)
+    if (r->desc.hash) {
+        NRF_TRY(launch_hash(r->desc.hash, ps, p, x, xd, keep, st));
+    } else {
+        const float *px = ps.pts;
+        if (!px) {
+            NRF_TRY(nrf_points(ps.rays, ps.ray_stride, ps.z, n, s, pts, st));
+            px = pts;
+        }
+        NRF_TRY(launch_pe(px, 3, p, r->desc.pe_freqs, 1, x, xd, st));
+    }
+    // embeddirs_fn(view_dirs expanded per sample)                               (NeRFRenderer.h:177-183)
+    if (r->in_views > 0) {
+        if (!viewdirs) { set_error("run_network: the renderer was built with a direction encoder but no view directions were given"); return NRF_ERR_INVALID_ARG; }
+        if (r->desc.dirs_encoder == NRF_DIRS_PE) NRF_TRY(launch_pe(viewdirs, vd_stride, p, r->desc.dirs_param, s, x + r->in_ch, xd, st));
+        else NRF_TRY(launch_sh(viewdirs, vd_stride, p, r->desc.dirs_param, r->desc.dirs_encoder == NRF_DIRS_SH_CUDA ? NRF_SH_CUDA : NRF_SH_LIBTORCH, s, x + r->in_ch, xd, st));
+    }
+    // fn->forward(embedded)                                                     (NeRFRenderer.h:184)
+    NRF_TRY(mlp_forward(r->desc.mlp, x, xd, p, prec, raw, r->desc.mlp->out_dims, mws, mws_bytes, st));
+    // outputs_flat[~keep_mask, -1] = 0                                          (NeRFRenderer.h:187-188)
+    if (r->desc.hash) {
+        hipLaunchKernelGGL(k_mask_sigma, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, st, p, r->desc.mlp->out_dims, keep, raw);
+        NRF_LAUNCH_CHECK();
+    }
+    return NRF_OK;
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_version(void) { return 100; }
+const char *nrf_last_error(void) { return g_err; }
+
+const char *nrf_status_string(int status)
+{
+    switch (status) {
+        case NRF_OK: return "ok";
+        case NRF_ERR_INVALID_ARG: return "invalid argument";
+        case NRF_ERR_HIP: return "HIP runtime error";
+        case NRF_ERR_UNSUPPORTED: return "unsupported configuration";
+        case NRF_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int nrf_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return NRF_OK;
+}
+
+int nrf_profile_read(double *ms, int64_t *launches, int reset)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &rec : g_prof_pending) {
+        float t = 0.0f;
+        if (hipEventSynchronize(rec.e1) == hipSuccess && hipEventElapsedTime(&t, rec.e0, rec.e1) == hipSuccess) {
+            g_prof_ms[rec.slot] += (double)t;
+            g_prof_n[rec.slot] += 1;
+        }
+        (void)hipEventDestroy(rec.e0);
+        (void)hipEventDestroy(rec.e1);
+    }
+    g_prof_pending.clear();
+    for (int i = 0; i < NRF_PROF_COUNT; i++) {
+        if (ms) ms[i] = g_prof_ms[i];
+        if (launches) launches[i] = g_prof_n[i];
+        if (reset) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
+    }
+    return NRF_OK;
+}
+
+int nrf_renderer_create(const nrf_renderer_desc *desc, nrf_renderer **out)
+{
+    NRF_CHECK_ARG(desc && out && desc->mlp, "nrf_renderer_create: null pointer");
+    nrf_renderer *r = new nrf_renderer();
+    r->desc = *desc;
+    r->in_ch = desc->hash ? nrf_hash_output_dims(desc->hash) : 3 + 6 * desc->pe_freqs;
+    switch (desc->dirs_encoder) {
+        case NRF_DIRS_NONE: r->in_views = 0; break;
+        case NRF_DIRS_PE: r->in_views = 3 + 6 * desc->dirs_param; break;
+        case NRF_DIRS_SH_LIBTORCH:
+        case NRF_DIRS_SH_CUDA: r->in_views = desc->dirs_param * desc->dirs_param; break;
+        default: delete r; set_error("nrf_renderer_create: unknown direction encoder %d", desc->dirs_encoder); return NRF_ERR_INVALID_ARG;
+    }
+    const int max_deg = desc->dirs_encoder == NRF_DIRS_SH_LIBTORCH ? 5 : 8;
+    if ((desc->dirs_encoder == NRF_DIRS_SH_LIBTORCH || desc->dirs_encoder == NRF_DIRS_SH_CUDA) && (desc->dirs_param < 1 || desc->dirs_param > max_deg)) {
+        delete r; set_error("nrf_renderer_create: SH degree %d outside [1,%d]", desc->dirs_param, max_deg); return NRF_ERR_INVALID_ARG;
+    }
+    if (!desc->hash && (desc->pe_freqs < 1 || desc->pe_freqs > 32)) { delete r; set_error("nrf_renderer_create: pe_freqs %d outside [1,32]", desc->pe_freqs); return NRF_ERR_INVALID_ARG; }
+    if (r->in_ch + r->in_views != desc->mlp->in_dims) {
+        set_error("nrf_renderer_create: encoders produce %d + %d features but the MLP expects %d", r->in_ch, r->in_views, desc->mlp->in_dims);
+        delete r;
+        return NRF_ERR_INVALID_ARG;
+    }
+    if (desc->mlp->out_dims < 4) { delete r; set_error("nrf_renderer_create: the MLP must output at least rgb + sigma"); return NRF_ERR_INVALID_ARG; }
+    *out = r;
+    return NRF_OK;
+}
+
+void nrf_renderer_destroy(nrf_renderer *r) { delete r; }
+
+size_t nrf_run_network_workspace_bytes(const nrf_renderer *r, int64_t n, int s)
+{
+    return r ? network_ws_bytes(r, n * s, NRF_PREC_F32) : 0;
+}
+
+int nrf_run_network(const nrf_renderer *r, const float *d_pts, const float *d_viewdirs, int64_t n, int s, int precision,
+                    float *d_raw, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && d_pts && d_raw && n >= 0 && s >= 1, "nrf_run_network: bad argument");
+    PointSource ps{d_pts, nullptr, nullptr, 0, s};
+    return run_network(r, ps, d_viewdirs, 3, n, s, precision, d_raw, d_workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const nrf_render_params *p)
+{
+    if (!r || !p) return 0;
+    const int s = p->n_samples, sf = p->n_samples + p->n_importance;
+    const int c = r->desc.mlp->out_dims;
+    size_t b = 0;
+    b += align_up((size_t)n * s * 4, 256) * 2;            // z_coarse, weights_coarse
+    b += align_up((size_t)n * s * c * 4, 256);            // raw_coarse
+    b += align_up((size_t)n * sf * 4, 256);               // z_fine
+    b += align_up((size_t)n * sf * c * 4, 256);           // raw_fine
+    b += network_ws_bytes(r, n * sf, p->precision) + 4096;
+    return b;
+}
+
+int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
+                    const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && d_rays && p && d_t && out, "nrf_render_rays: null pointer");
+    NRF_CHECK_ARG(n >= 0 && (ray_stride == 8 || ray_stride == 11), "nrf_render_rays: ray_stride must be 8 or 11 (NeRFRenderer.h:580-583)");
+    NRF_CHECK_ARG(p->n_samples >= 1 && p->n_importance >= 0, "nrf_render_rays: bad sample counts");
+    NRF_CHECK_ARG(p->n_importance == 0 || d_u, "nrf_render_rays: n_importance > 0 needs the u table");
+    NRF_CHECK_ARG(r->in_views == 0 || ray_stride == 11, "nrf_render_rays: the renderer encodes view directions but the ray batch has none");
+    if (n == 0) return NRF_OK;
+    if (workspace_bytes < nrf_render_rays_workspace_bytes(r, n, p)) {
+        set_error("nrf_render_rays: workspace %zu < %zu bytes", workspace_bytes, nrf_render_rays_workspace_bytes(r, n, p));
+        return NRF_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    const int s = p->n_samples, ni = p->n_importance, sf = s + ni;
+    const int c = r->desc.mlp->out_dims;
+    Bump bump(d_workspace, workspace_bytes);
+    float *z_c = out->d_z_coarse ? out->d_z_coarse : bump.take<float>((size_t)n * s);
+    float *w_c = out->d_weights_coarse ? out->d_weights_coarse : bump.take<float>((size_t)n * s);
+    float *raw_c = out->d_raw_coarse ? out->d_raw_coarse : ((ni == 0 && out->d_raw) ? out->d_raw : bump.take<float>((size_t)n * s * c));
+    float *z_f = nullptr, *raw_f = nullptr;
+    if (ni > 0) {
+        z_f = out->d_z_fine ? out->d_z_fine : bump.take<float>((size_t)n * sf);
+        raw_f = out->d_raw ? out->d_raw : bump.take<float>((size_t)n * sf * c);
+    }
+    void *nws = bump.take<char>(0);
+    const size_t nws_bytes = workspace_bytes - bump.off;
+    const float *viewdirs = r->in_views > 0 ? d_rays + 8 : nullptr;
+
+    // z_vals; pts = o + d*z formed inside the encoder                           (NeRFRenderer.h:393-419)
+    NRF_TRY(nrf_z_vals(d_rays, ray_stride, n, d_t, s, p->lindisp, z_c, st));
+    PointSource ps{nullptr, d_rays, z_c, ray_stride, s};
+    NRF_TRY(run_network(r, ps, viewdirs, ray_stride, n, s, p->precision, raw_c, nws, nws_bytes, st));              // :422
+    if (ni == 0) {
+        // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
+        return nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
+                               out->d_weights ? out->d_weights : w_c, out->d_depth, st);
+    }
+    NRF_TRY(nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, st));   // :423
+    NRF_TRY(nrf_fine_depths(z_c, w_c, n, s, d_u, ni, p->sum_vec, z_f, st));                                                           // :427-431
+    PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
+    NRF_TRY(run_network(r, psf, viewdirs, ray_stride, n, sf, p->precision, raw_f, nws, nws_bytes, st));            // :447
+    return nrf_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
+                           out->d_weights, out->d_depth, st);                                                      // :448
+}
+
+}  // extern "C"

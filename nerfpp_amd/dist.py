@@ -1,0 +1,38 @@
+"""Multi-GPU sharding of the render path: whole-image batches are partitioned by ray (contiguous row tiles), the model
+(hash table 32-64 MiB + MLP <= 1.2 MB) is replicated read-only on every GPU, and one all-gather per step returns the
+per-tile pixels to every rank (RCCL over xGMI on the GPU box; the same code runs on gloo for the CPU tests).
+
+The reference is single-process / single-GPU; this is new work with no reference counterpart.
+Row-contiguous tiles keep the reference's row-major pixel <-> ray index mapping (RayUtils.h:5-21) trivially intact: ray
+r of tile t is pixel (row0_t + r // W, r % W).  The payload is tiny (800x800x3 fp32 = 7.7 MB per frame across all ranks),
+so the collective is latency-bound; it is issued once per step for all frames of the step, not per chunk.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TileShard:
+    def __init__(self, h, w, rank=0, world=1):
+        self.h, self.w, self.rank, self.world = h, w, rank, world
+        base, rem = divmod(h, world)
+        self.rows_of = [base + (1 if r < rem else 0) for r in range(world)]
+        self.row0_of = [sum(self.rows_of[:r]) for r in range(world)]
+        self.rows, self.row0 = self.rows_of[rank], self.row0_of[rank]
+        self.max_rows = max(self.rows_of)
+
+    def all_gather_frames(self, tiles):
+        """tiles: list (one per frame of the step) of this rank's [rows, W, C] pixel tiles.
+        Returns [frames, H, W, C] on every rank.  world == 1: a stack, no collective."""
+        local = torch.stack([t.reshape(self.rows, self.w, -1) for t in tiles], 0)       # [F, rows, W, C]
+        if self.world == 1:
+            return local
+        f, _, w, c = local.shape
+        if self.rows != self.max_rows:                                                    # uneven split: pad to the tallest tile
+            pad = torch.zeros((f, self.max_rows - self.rows, w, c), device=local.device, dtype=local.dtype)
+            local = torch.cat([local, pad], 1)
+        local = local.contiguous()
+        out = torch.empty((self.world * f,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local)                                           # ncclAllGather over xGMI (dim-0 concatenation)
+        out = out.view((self.world, f) + tuple(local.shape[1:]))
+        parts = [out[r, :, :self.rows_of[r]] for r in range(self.world)]
+        return torch.cat(parts, 1)                                                        # [F, H, W, C]

@@ -1,0 +1,277 @@
+"""Host-side mirror of RayUtils.h / Sampler.h / NeRFRenderer.h over the C ABI.
+
+Same names, argument meaning and quirks as the reference so the parity tests read like the reference's own calls:
+GetRays, NDCRays, IntersectWithAABB, SamplePDF, NeRFRenderParams, NeRFRendererOutputs, NeRFRenderResult and
+NeRFRenderer.{Render, BatchifyRays, RenderRays, RunNetwork, RawToOutputs}.  All arithmetic happens in
+libnerfpp_hip.so on the current HIP stream; torch only owns the buffers.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .modules import Embedder, SHEncoder, CuSHEncoder, _HashBase, _ptr, _stream, _dev_f32
+
+ATEN_SUM_VEC = 8   # fp32 lanes of ATen's CPU sum kernel on any AVX2+/AVX-512 x86 host (REGISTER_DISPATCH registers the AVX2 build)
+
+
+def _host_f32(t, n):
+    a = np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, np.float32).reshape(-1)
+    assert a.size == n
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+# RayUtils.h
+# ------------------------------------------------------------------------------------------------
+def GetRays(h, w, k, c2w, device="cuda", row0=0, rows=None):
+    """RayUtils.h:23-46 -> (rays_o [rows,w,3], rays_d [rows,w,3], cone_angle 0-dim).  row0/rows select an image row tile
+    (multi-GPU sharding); ray index stays row-major, y outer."""
+    rows = h - row0 if rows is None else rows
+    K = _host_f32(k, 9); M = _host_f32(torch.as_tensor(c2w)[:3, :4] if torch.is_tensor(c2w) else np.asarray(c2w)[:3, :4], 12)
+    o = torch.empty((rows, w, 3), device=device, dtype=torch.float32)
+    d = torch.empty((rows, w, 3), device=device, dtype=torch.float32)
+    cone = C.c_float(0)
+    L.check(L.lib().nrf_get_rays(h, w, K.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p), row0, rows, _ptr(o), _ptr(d), C.byref(cone), _stream()))
+    return o, d, torch.tensor(cone.value, dtype=torch.float32)
+
+
+def NDCRays(h, w, focal, near, rays_o, rays_d, cone_angle=None):
+    """RayUtils.h:49-83 (cone_angle rescaling only matters when ThinRay is false; not on the deterministic path)."""
+    o = _dev_f32(rays_o); d = _dev_f32(rays_d)
+    oo = torch.empty_like(o); od = torch.empty_like(d)
+    L.check(L.lib().nrf_ndc_rays(h, w, C.c_float(focal), C.c_float(near), _ptr(o), _ptr(d), C.c_int64(o.numel() // 3), _ptr(oo), _ptr(od), _stream()))
+    return oo, od, cone_angle
+
+
+def IntersectWithAABB(rays_o, rays_d, bounding_box, near_plane=0.0):
+    """RayUtils.h:87-126 -> (nears [N], fars [N])."""
+    o = _dev_f32(rays_o).reshape(-1, 3); d = _dev_f32(rays_d).reshape(-1, 3)
+    bb = _host_f32(bounding_box, 6)
+    nr = torch.empty((o.shape[0],), device=o.device, dtype=torch.float32); fr = torch.empty_like(nr)
+    L.check(L.lib().nrf_aabb(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(o.shape[0]), C.c_float(near_plane), _ptr(nr), _ptr(fr), _stream()))
+    return nr, fr
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampler.h
+# ------------------------------------------------------------------------------------------------
+def SamplePDF(bins, weights, nsamples, det=True, return_inds=False, sum_vec=ATEN_SUM_VEC):
+    """Sampler.h:6-43, deterministic branch (det == (Perturb == 0), NeRFRenderer.h:428)."""
+    if not det:
+        raise L.NrfError("SamplePDF(det=False) draws torch::rand: training-time stochastic path, not built")
+    bins = _dev_f32(bins); weights = _dev_f32(weights)
+    n, nb = bins.shape
+    assert weights.shape == (n, nb - 1)
+    u = torch.linspace(0.0, 1.0, nsamples, dtype=torch.float32).to(bins.device)     # Sampler.h:21, ATen's own rounding
+    samples = torch.empty((n, nsamples), device=bins.device, dtype=torch.float32)
+    inds = torch.empty((n, nsamples), device=bins.device, dtype=torch.int64) if return_inds else None
+    L.check(L.lib().nrf_sample_pdf(_ptr(bins), _ptr(weights), C.c_int64(n), nb, _ptr(u), nsamples, sum_vec, _ptr(samples), _ptr(inds), _stream()))
+    return (samples, inds) if return_inds else samples
+
+
+# ------------------------------------------------------------------------------------------------
+# NeRFRenderer.h
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class NeRFRendererOutputs:            # NeRFRenderer.h:12-18
+    RGBMap: Optional[torch.Tensor] = None
+    DispMap: Optional[torch.Tensor] = None
+    AccMap: Optional[torch.Tensor] = None
+    Weights: Optional[torch.Tensor] = None
+    DepthMap: Optional[torch.Tensor] = None
+
+
+@dataclass
+class NeRFRenderResult:               # NeRFRenderer.h:20-26
+    Outputs: NeRFRendererOutputs = field(default_factory=NeRFRendererOutputs)
+    Raw: Optional[torch.Tensor] = None
+    Near: float = 0.0
+    Far: float = 0.0
+    # intermediates exposed for stage-chained parity tests (not in the reference struct)
+    Extras: dict = field(default_factory=dict)
+
+
+@dataclass
+class NeRFRenderParams:               # NeRFRenderer.h:28-44 (same defaults)
+    NSamples: int = 64
+    NImportance: int = 192
+    Chunk: int = 1024 * 32
+    ReturnRaw: bool = False
+    LinDisp: bool = False
+    Perturb: float = 0.0
+    WhiteBkgr: bool = False
+    RawNoiseStd: float = 0.0
+    Ndc: bool = True
+    UseViewdirs: bool = False
+    ReturnWeights: bool = False
+    ThinRay: bool = False
+    RenderFactor: float = 0
+    BoundingBox: Optional[object] = None
+    StochasticPreconditioningAlpha: float = 0.0
+    # not in the reference: MLP arithmetic (L.NRF_PREC_F32 parity mode / L.NRF_PREC_F16_MFMA fast mode)
+    Precision: int = L.NRF_PREC_F32
+    KeepIntermediates: bool = False
+
+
+class NeRFRenderer:
+    """NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> (NeRFRenderer.h:88-159)."""
+
+    def __init__(self, embed_fn, embeddirs_fn, nerf):
+        self.EmbedFn, self.EmbeddirsFn, self.NeRF = embed_fn, embeddirs_fn, nerf
+        desc = L.RendererDesc()
+        if isinstance(embed_fn, _HashBase):
+            desc.hash = embed_fn._h; desc.pe_freqs = 0
+        elif isinstance(embed_fn, Embedder):
+            desc.hash = None; desc.pe_freqs = embed_fn.multires
+        else:
+            raise L.NrfError(f"unsupported position embedder {type(embed_fn).__name__}")
+        if embeddirs_fn is None:
+            desc.dirs_encoder, desc.dirs_param = L.NRF_DIRS_NONE, 0
+        elif isinstance(embeddirs_fn, Embedder):
+            desc.dirs_encoder, desc.dirs_param = L.NRF_DIRS_PE, embeddirs_fn.multires
+        elif isinstance(embeddirs_fn, CuSHEncoder):
+            desc.dirs_encoder, desc.dirs_param = L.NRF_DIRS_SH_CUDA, embeddirs_fn.degree
+        elif isinstance(embeddirs_fn, SHEncoder):
+            desc.dirs_encoder, desc.dirs_param = L.NRF_DIRS_SH_LIBTORCH, embeddirs_fn.degree
+        else:
+            raise L.NrfError(f"unsupported direction embedder {type(embeddirs_fn).__name__}")
+        desc.mlp = nerf._m
+        self._r = C.c_void_p()
+        L.check(L.lib().nrf_renderer_create(C.byref(desc), C.byref(self._r)))
+        self._ws = None
+
+    def __del__(self):
+        r = getattr(self, "_r", None)
+        if r:
+            L.lib().nrf_renderer_destroy(r)
+            self._r = None
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty((int(nbytes),), device=device, dtype=torch.uint8)
+        return self._ws
+
+    # ---- protected virtuals of the reference ----
+    def RunNetwork(self, inputs, view_dirs, precision=L.NRF_PREC_F32):
+        """NeRFRenderer.h:164-194: inputs [N,S,3], view_dirs [N,3] or None -> raw [N,S,C]."""
+        pts = _dev_f32(inputs)
+        n, s = pts.shape[0], pts.shape[1]
+        vd = _dev_f32(view_dirs) if view_dirs is not None and view_dirs.numel() else None
+        c = self.NeRF.GetOutputDims()
+        raw = torch.empty((n, s, c), device=pts.device, dtype=torch.float32)
+        nb = L.lib().nrf_run_network_workspace_bytes(self._r, C.c_int64(n), s)
+        ws = self._workspace(nb, pts.device)
+        L.check(L.lib().nrf_run_network(self._r, _ptr(pts), _ptr(vd), C.c_int64(n), s, precision, _ptr(raw), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+        return raw
+
+    def RawToOutputs(self, raw, cone_angle, z_vals, rays_d, raw_noise_std=0.0, white_bkgr=False):
+        """NeRFRenderer.h:199-282 (raw_noise_std must be 0: randn is a training-time branch)."""
+        if raw_noise_std > 0:
+            raise L.NrfError("RawToOutputs(raw_noise_std > 0) is the training-time noise branch; not built")
+        raw = _dev_f32(raw); z = _dev_f32(z_vals); d = _dev_f32(rays_d)
+        n, s, c = raw.shape
+        o = NeRFRendererOutputs(RGBMap=torch.empty((n, 3), device=raw.device), DispMap=torch.empty((n,), device=raw.device),
+                                AccMap=torch.empty((n,), device=raw.device), Weights=torch.empty((n, s), device=raw.device),
+                                DepthMap=torch.empty((n,), device=raw.device))
+        L.check(L.lib().nrf_raw2outputs(_ptr(raw), _ptr(z), _ptr(d), 3, C.c_int64(n), s, c, int(white_bkgr), _ptr(o.RGBMap), _ptr(o.DispMap),
+                                        _ptr(o.AccMap), _ptr(o.Weights), _ptr(o.DepthMap), _stream()))
+        return o
+
+    # ---- public surface ----
+    def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
+                   raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True,
+                   precision=L.NRF_PREC_F32, keep_intermediates=False):
+        """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11]."""
+        if perturb > 0 or raw_noise_std > 0 or stochastic_preconditioning_alpha > 0:
+            raise L.NrfError("perturb / raw_noise_std / stochastic preconditioning draw torch RNG: training-time branches, not built")
+        if cone_angle is not None and torch.is_tensor(cone_angle) and cone_angle.numel():
+            raise L.NrfError("a defined cone_angle selects TangentScatter (random in-cone offsets, NeRFRenderer.h:307-362); "
+                             "render with ThinRay=True for the deterministic path")
+        rays = _dev_f32(ray_batch)
+        n, stride = rays.shape
+        dev = rays.device
+        s, ni = int(n_samples), int(n_importance)
+        sf = s + ni
+        c = self.NeRF.GetOutputDims()
+        t = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)                      # NeRFRenderer.h:393
+        u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev) if ni > 0 else None   # Sampler.h:21
+        rp = L.RenderParams(s, ni, int(lin_disp), int(white_bkgr), precision, ATEN_SUM_VEC)
+        res = NeRFRenderResult()
+        so = sf if ni > 0 else s
+        o = res.Outputs
+        o.RGBMap = torch.empty((n, 3), device=dev); o.DispMap = torch.empty((n,), device=dev); o.AccMap = torch.empty((n,), device=dev)
+        o.DepthMap = torch.empty((n,), device=dev)
+        o.Weights = torch.empty((n, so), device=dev) if return_weights else None
+        if return_raw:
+            res.Raw = torch.empty((n, so, c), device=dev)
+        ro = L.RenderOutputs(_ptr(o.RGBMap), _ptr(o.DispMap), _ptr(o.AccMap), _ptr(o.DepthMap), _ptr(o.Weights), _ptr(res.Raw), None, None, None, None)
+        if keep_intermediates:
+            ex = res.Extras
+            ex["z_coarse"] = torch.empty((n, s), device=dev); ex["raw_coarse"] = torch.empty((n, s, c), device=dev)
+            ex["weights_coarse"] = torch.empty((n, s), device=dev)
+            ro.d_z_coarse, ro.d_raw_coarse, ro.d_weights_coarse = _ptr(ex["z_coarse"]), _ptr(ex["raw_coarse"]), _ptr(ex["weights_coarse"])
+            if ni > 0:
+                ex["z_fine"] = torch.empty((n, sf), device=dev)
+                ro.d_z_fine = _ptr(ex["z_fine"])
+        nb = L.lib().nrf_render_rays_workspace_bytes(self._r, C.c_int64(n), C.byref(rp))
+        ws = self._workspace(nb, dev)
+        L.check(L.lib().nrf_render_rays(self._r, _ptr(rays), stride, C.c_int64(n), C.byref(rp), _ptr(t), _ptr(u), C.byref(ro), _ptr(ws),
+                                        C.c_size_t(ws.numel()), _stream()))
+        return res
+
+    def BatchifyRays(self, rays_flat, cone_angle, n_samples, chunk=1024 * 32, **kw):
+        """NeRFRenderer.h:465-525: host loop over Chunk-sized slices, torch.cat of every defined field."""
+        results = [self.RenderRays(rays_flat[i:i + chunk], cone_angle, n_samples, **kw) for i in range(0, rays_flat.shape[0], chunk)]
+        res = NeRFRenderResult()
+
+        def cat(get):
+            parts = [get(r) for r in results if get(r) is not None]
+            return torch.cat(parts, 0) if parts else None
+        o = res.Outputs
+        o.RGBMap = cat(lambda r: r.Outputs.RGBMap); o.DispMap = cat(lambda r: r.Outputs.DispMap); o.AccMap = cat(lambda r: r.Outputs.AccMap)
+        o.Weights = cat(lambda r: r.Outputs.Weights); o.DepthMap = cat(lambda r: r.Outputs.DepthMap)
+        res.Raw = cat(lambda r: r.Raw)
+        for k in (results[0].Extras if results else {}):
+            res.Extras[k] = torch.cat([r.Extras[k] for r in results], 0)
+        return res
+
+    def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, c2w_staticcam=None, row0=0, rows=None):
+        """NeRFRenderer.h:530-605.  Either a pose (c2w, full image or the row tile [row0, row0+rows)) or an explicit ray batch."""
+        p = render_params
+        if c2w is not None:
+            rays_o, rays_d, cone_angle = GetRays(h, w, k, c2w, row0=row0, rows=rows)                  # :543
+        else:
+            rays_o, rays_d, cone_angle = rays
+            rays_o, rays_d = _dev_f32(rays_o), _dev_f32(rays_d)
+        if c2w_staticcam is not None:
+            raise L.NrfError("c2w_staticcam (NeRFRenderer.h:554-558, a visualisation aid) is not built")
+        sh = tuple(rays_d.shape)
+        bb = _host_f32(p.BoundingBox, 6)
+        if p.Ndc:
+            kk = _host_f32(k, 9)
+            rays_o, rays_d, cone_angle = NDCRays(h, w, float(kk[0]), 1.0, rays_o, rays_d, None if p.ThinRay else cone_angle)   # :567
+            if p.UseViewdirs:
+                raise L.NrfError("Ndc together with UseViewdirs needs the pre-NDC directions as viewdirs; use the stage functions")
+        o = rays_o.reshape(-1, 3).contiguous(); d = rays_d.reshape(-1, 3).contiguous()
+        n = o.shape[0]
+        stride = 11 if p.UseViewdirs else 8
+        rays_ = torch.empty((n, stride), device=o.device, dtype=torch.float32)
+        L.check(L.lib().nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))   # :549-583
+        all_ret = self.BatchifyRays(rays_, None if p.ThinRay else cone_angle, p.NSamples, p.Chunk, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
+                                    perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
+                                    stochastic_preconditioning_alpha=p.StochasticPreconditioningAlpha, bounding_box=p.BoundingBox,
+                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates)
+        out = all_ret.Outputs
+        if out.RGBMap is not None:
+            out.RGBMap = out.RGBMap.reshape(sh)                                                       # :591-592
+        if len(sh) > 2:
+            out.DispMap = out.DispMap.reshape(sh[0], sh[1]); out.DepthMap = out.DepthMap.reshape(sh[0], sh[1])   # :594-600
+        nr, fr = C.c_float(0), C.c_float(0)
+        L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))   # :602-603
+        all_ret.Near, all_ret.Far = nr.value, fr.value
+        all_ret.Extras["rays_flat"] = rays_
+        return all_ret

@@ -564,15 +564,16 @@ ORC_API void orc_hash_cu(const float *x, int64_t p, const uint16_t *table_f16, c
 /* ------------------------------------------------------------------------------------------
  * MLPs.  Parameters arrive as ONE fp32 blob in the reference's named_parameters() order
  * (== checkpoint order, NeRFExecutor.h:1055-1070), Linear weights [out, in] row-major.
- * Dot products: fp32, ascending k.  (LibTorch uses MKL sgemm whose blocking/FMA order is
- * unknowable; agreement is to ~1e-6 relative, tolerance stated in the tests.)
+ * Dot products: an fp32 FMA chain in ascending k starting from 0, bias added last -- the order the
+ * HIP path's NRF_PREC_F32 mode reproduces bit for bit.  (LibTorch uses MKL sgemm whose blocking /
+ * FMA order is unknowable; agreement is to ~1e-6 relative, tolerance stated in the tests.)
  * ------------------------------------------------------------------------------------------ */
 static void linear(const float *w, const float *b, const float *x, int in, int out, float *y, int relu)
 {
     for (int o = 0; o < out; o++) {
         float acc = 0.0f;
         const float *wr = w + (int64_t)o * in;
-        for (int k = 0; k < in; k++) acc += wr[k] * x[k];
+        for (int k = 0; k < in; k++) acc = fmaf(wr[k], x[k], acc);     /* one rounding per MAC, ascending k */
         if (b) acc += b[o];
         y[o] = (relu && acc < 0.0f) ? 0.0f : acc;
     }

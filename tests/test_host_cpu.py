@@ -1,0 +1,136 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, host-side logic (synthetic scenes,
+row-tile sharding, argument validation that happens before any device call), and the 2-rank gloo path of the
+multi-GPU gather."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from nerfpp_amd import synth
+
+
+def test_library_builds_loads_and_exports_every_header_symbol():
+    import __graft_entry__ as g
+    from nerfpp_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    lib = C.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "nerfpp_hip.h")).read()
+    declared = set(re.findall(r"NRF_API\s+[\w\s\*]+?\b(nrf_\w+)\s*\(", hdr))
+    assert len(declared) >= 35
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), f"libnerfpp_hip.so does not export {s}"
+    lib.nrf_status_string.restype = C.c_char_p
+    assert lib.nrf_status_string(0) == b"ok" and lib.nrf_version() >= 100
+
+
+def test_argument_validation_needs_no_gpu():
+    from nerfpp_amd import _lib
+    lib = _lib.lib()
+    assert lib.nrf_pe_encode(None, C.c_int64(4), 10, None, None) == 1          # NRF_ERR_INVALID_ARG
+    assert b"nrf_pe_encode" in lib.nrf_last_error()
+    d = _lib.HashDesc(7, 16, 2, 19, 16, 512, (C.c_float * 6)(-1, -1, -1, 1, 1, 1))
+    h = C.c_void_p()
+    assert lib.nrf_hash_create(C.byref(d), C.byref(h)) == 1 and b"unknown mode" in lib.nrf_last_error()
+    d.mode = 0; d.n_features = 3
+    assert lib.nrf_hash_create(C.byref(d), C.byref(h)) == 1
+    out = np.empty(64, np.float32)
+    assert lib.nrf_linspace(C.c_float(0), C.c_float(1), 64, out.ctypes.data_as(C.c_void_p)) == 0
+    assert (out == load_golden("sample_pdf")["aux_t64"]).all()                  # host helper == ATen bit for bit
+    sd = _lib.MlpSmallDesc(32, 16, 3, 64, 15, 4, 64)
+    assert lib.nrf_mlp_small_param_count(C.byref(sd)) == 17536                 # 17 536 MAC / point
+    nd = _lib.MlpNerfDesc(8, 256, 63, 27, 4, 4, 1)
+    assert lib.nrf_mlp_nerf_param_count(C.byref(nd)) == 593408 + 8 * 256 + 128 + 256 + 1 + 3   # 593 408 weights + biases
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the compute entry points must FAIL (NRF_ERR_HIP), never compute on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    from nerfpp_amd import _lib
+    lib = _lib.lib()
+    d = _lib.HashDesc(0, 4, 2, 10, 4, 32, (C.c_float * 6)(-1, -1, -1, 1, 1, 1))
+    h = C.c_void_p()
+    assert lib.nrf_hash_create(C.byref(d), C.byref(h)) == 2                     # NRF_ERR_HIP: hipMalloc fails
+    assert b"hipMalloc" in lib.nrf_last_error()
+
+
+def test_scene_synth_reproduces_golden_manifest(manifest):
+    from nerfpp_amd import scene
+    ent = manifest["render_hash"]
+    mlp = [e for e in ent if "embeddings" not in e[0]]
+    mine = scene.synth_linear_stack(scene.small_shapes(), 6000, 1.6, 0.0, {"sigma_net_2": 30.0})
+    ref = synth.params_from_manifest(mlp)
+    assert [n for n, _ in mine] == [n for n, _ in ref]
+    for (_, a), (_, b) in zip(mine, ref):
+        assert a.shape == b.shape and (a == b).all()
+    table = scene.synth_hash_table(16, 19, 2, 5000, 0.5)
+    assert (table[:1024] == synth.blob_from_manifest(ent[:1])[:1024]).all()
+    cl = scene.synth_linear_stack(scene.nerf_shapes(), 7000, 1.4, 0.1, {"alpha_linear.weight": 40.0})
+    ref = synth.params_from_manifest(manifest["render_classic"])
+    assert [n for n, _ in cl] == [n for n, _ in ref]
+    assert all((a == b).all() for (_, a), (_, b) in zip(cl, ref))
+
+
+def test_pose_spherical_and_camera():
+    from nerfpp_amd import scene
+    c2w = scene.pose_spherical(30.0, -30.0, 4.0)
+    assert c2w.shape == (3, 4)
+    assert abs(np.linalg.norm(c2w[:, 3]) - 4.0) < 1e-5                           # camera on the radius-4 sphere
+    assert np.allclose(c2w[:, :3] @ c2w[:, :3].T, np.eye(3), atol=1e-6)          # rotation
+    fwd = -c2w[:, 2]                                                             # looks at the origin
+    assert np.allclose(fwd, -c2w[:, 3] / 4.0, atol=1e-5)
+    K = scene.lego_K(800, 800)
+    assert abs(K[0, 0] - 1111.111) < 1e-2 and K[0, 2] == 400
+    assert abs(scene.lego_K(400, 400)[0, 0] - 555.5555) < 1e-2
+    assert len(set(scene.CU_PRIMES)) == 96 and all((1 << 28) <= p < (1 << 30) for p in scene.CU_PRIMES)
+    assert all(all(p % q for q in range(2, int(p ** 0.5) + 1)) for p in scene.CU_PRIMES[:6])
+
+
+def test_tile_shard_partition():
+    from nerfpp_amd.dist import TileShard
+    for h, n in ((800, 1), (800, 2), (800, 8), (10, 4), (7, 3)):
+        shards = [TileShard(h, 5, r, n) for r in range(n)]
+        assert sum(s.rows for s in shards) == h
+        assert [s.row0 for s in shards] == [sum(s2.rows for s2 in shards[:i]) for i in range(n)]
+    s = TileShard(6, 4)
+    t = torch.arange(6 * 4 * 3, dtype=torch.float32).reshape(6, 4, 3)
+    assert torch.equal(s.all_gather_frames([t, t + 1])[1], t + 1)
+
+
+GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["NRF_ROOT"])
+from nerfpp_amd.dist import TileShard
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+H, W, F = 7, 5, 3                       # uneven split: 4 + 3 rows
+full = torch.arange(F * H * W * 3, dtype=torch.float32).reshape(F, H, W, 3)
+sh = TileShard(H, W, rank, world)
+tiles = [full[f, sh.row0:sh.row0 + sh.rows].clone() for f in range(F)]
+out = sh.all_gather_frames(tiles)
+assert out.shape == full.shape and torch.equal(out, full), "gathered frames differ"
+dist.barrier()
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() == world
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_tile_all_gather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, NRF_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
