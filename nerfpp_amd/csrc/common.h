@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "nerfpp_hip.h"
+#include "nrf_math.h"
 
 namespace nrf {
 

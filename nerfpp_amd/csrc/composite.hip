@@ -5,7 +5,8 @@
 // One 64-lane wavefront per ray, lane = sample.  The two prefix sums the reference computes with
 // torch::cumsum (log-transmittance, CDF) are wave scans in DOUBLE: ATen's CPU cumsum accumulates fp32 in double
 // and rounds every prefix to fp32, and a double scan's reassociation error (1e-16) disappears in that rounding,
-// so the scan reproduces the sequential result.  The pdf normaliser sum(w) is evaluated in ATen's own lane
+// so the scan reproduces the sequential result.  exp/log/sigmoid come from include/nrf_math.h (the same bits on
+// the CPU oracle and here), which makes the whole stage -- and with it the fine-pass sample set -- reproducible.  The pdf normaliser sum(w) is evaluated in ATen's own lane
 // order (sum_vec) because it feeds searchsorted: the sample INDICES are bit-exact against the oracle.
 #include "common.h"
 
@@ -59,18 +60,18 @@ k_raw2outputs(int64_t n, int s, int c, int white, const float *__restrict__ raw,
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
             const float sig = r[3] > 0.0f ? r[3] : 0.0f;            // relu
-            alpha = -expf(-sig * dist) + 1.0f;                      // :234
+            alpha = -nrf_expf(-sig * dist) + 1.0f;                      // :234
             const float om = 1.0f - alpha;
-            lg = logf(om > 1e-10f ? om : 1e-10f);                   // :265
-            cr = 1.0f / (1.0f + expf(-r[0]));                       // sigmoid, :250
-            cg = 1.0f / (1.0f + expf(-r[1]));
-            cb = 1.0f / (1.0f + expf(-r[2]));
+            lg = nrf_logf(om > 1e-10f ? om : 1e-10f);                   // :265
+            cr = nrf_sigmoidf(r[0]);                                // sigmoid, :250
+            cg = nrf_sigmoidf(r[1]);
+            cb = nrf_sigmoidf(r[2]);
         }
         const double incl = wave_incl_scan((double)lg, lane);
         const double excl = carry + (incl - (double)lg);            // exclusive prefix: cat[0, cumsum][:-1] (:263-266)
         carry += __shfl(incl, 63);
         if (live) {
-            const float trans = expf((float)excl);                  // TruncExp forward = exp (:267)
+            const float trans = nrf_expf((float)excl);                  // TruncExp forward = exp (:267)
             w = alpha * trans;
             if (weights) weights[ray * s + j] = w;
             sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);

@@ -7,7 +7,7 @@
 //
 // Generic row-major kernels (any caller, fp32 [p, D] outputs with a row stride so the renderer can write the
 // concatenated MLP input in place).  The level-major fp16 fast path used by the fused renderer lives in
-// hash_fast.hip.  Built with -ffp-contract=off: every value equals the oracle's bit for bit except sin/cos.
+// hash_fast.hip.  Built with -ffp-contract=off; sin/cos from include/nrf_math.h: every value equals the oracle's bit for bit.
 #include "encode.h"
 
 namespace nrf {
@@ -35,8 +35,10 @@ __global__ void k_pe(int64_t rows, int nfreq, int rep, const float *__restrict__
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float v = xp[a] * freq;
-        o[3 + f * 6 + a] = sinf(v);
-        o[3 + f * 6 + 3 + a] = cosf(v);
+        float sn, cs;
+        nrf_sincosf(v, &sn, &cs);
+        o[3 + f * 6 + a] = sn;
+        o[3 + f * 6 + 3 + a] = cs;
     }
 }
 

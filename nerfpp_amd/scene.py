@@ -52,9 +52,11 @@ def pose_spherical(theta, phi, radius):
 
 def lego_render_params(bbox=LEGO_BBOX, n_samples=64, n_importance=128, chunk=32768, precision=L.NRF_PREC_F32, white_bkgr=True, **kw):
     """The deterministic test-time parameter set (FillRenderParams, NeRFExecutor.h:379-415, + ThinRay)."""
-    return NeRFRenderParams(NSamples=n_samples, NImportance=n_importance, Chunk=chunk, ReturnRaw=False, LinDisp=False, Perturb=0.0,
-                            WhiteBkgr=white_bkgr, RawNoiseStd=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=False, ThinRay=True,
-                            BoundingBox=np.asarray(bbox, np.float32), Precision=precision, **kw)
+    args = dict(NSamples=n_samples, NImportance=n_importance, Chunk=chunk, ReturnRaw=False, LinDisp=False, Perturb=0.0,
+                WhiteBkgr=white_bkgr, RawNoiseStd=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=False, ThinRay=True,
+                BoundingBox=np.asarray(bbox, np.float32), Precision=precision)
+    args.update(kw)
+    return NeRFRenderParams(**args)
 
 
 def _amp(gain, fan_in, fan_out):

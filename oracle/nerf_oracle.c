@@ -17,7 +17,10 @@
  *     host ISA (AVX2 vs AVX-512): it has no machine-independent bit pattern.  The oracle
  *     accumulates such sums in double and rounds once, which is within 1 ulp of any of
  *     ATen's orders;
- *   - sin/cos/exp/log/sigmoid on CPU are SLEEF u10 vector kernels, not libm: <= 1-2 ulp.
+ *   - sin/cos/exp/log/sigmoid on CPU are SLEEF u10 vector kernels; libm and the GPU's OCML each differ
+ *     from it (and from each other) in the last ulp.  The oracle and the HIP path therefore share ONE
+ *     portable definition, include/nrf_math.h (FMA/mul/add/div + bit casts only, <= 1.5 ulp), so that
+ *     they agree bit for bit; against the reference these stages are checked to a few ulp.
  *
  * PINNING: oracle/_ref (the reference's own sources compiled against LibTorch here) emits
  * tests/golden/ (npz files); tests/test_oracle_golden.py checks every function below against
@@ -29,6 +32,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include "nrf_math.h"   /* portable exp/log/sin/cos: identical bits on CPU and GPU (see the header) */
 #include <stdlib.h>
 #include <string.h>
 
@@ -284,8 +288,8 @@ ORC_API void orc_pe(const float *x, int64_t p, int nfreq, float *out)
         for (int f = 0; f < nfreq; f++)
             for (int a = 0; a < 3; a++) {
                 float v = x[i * 3 + a] * freqs[f];
-                o[3 + f * 6 + a] = sinf(v);
-                o[3 + f * 6 + 3 + a] = cosf(v);
+                o[3 + f * 6 + a] = nrf_sinf(v);
+                o[3 + f * 6 + 3 + a] = nrf_cosf(v);
             }
     }
 }
@@ -746,15 +750,15 @@ ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, i
             float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
             dist = dist * nrm;
             float sig = r[3] > 0.0f ? r[3] : 0.0f;
-            float alpha = -expf(-sig * dist) + 1.0f;
-            float trans = expf(tprev);
+            float alpha = -nrf_expf(-sig * dist) + 1.0f;
+            float trans = nrf_expf(tprev);
             float w = alpha * trans;
             float one_m = 1.0f - alpha;
-            float lg = logf(one_m > 1e-10f ? one_m : 1e-10f);
+            float lg = nrf_logf(one_m > 1e-10f ? one_m : 1e-10f);
             logt += (double)lg;
             tprev = (float)logt;
             if (weights) weights[i * s + j] = w;
-            float cr = 1.0f / (1.0f + expf(-r[0])), cg = 1.0f / (1.0f + expf(-r[1])), cb = 1.0f / (1.0f + expf(-r[2]));
+            float cr = nrf_sigmoidf(r[0]), cg = nrf_sigmoidf(r[1]), cb = nrf_sigmoidf(r[2]);
             sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);
             sw += (double)w; swz += (double)(w * z[i * s + j]);
         }

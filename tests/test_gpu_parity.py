@@ -87,7 +87,9 @@ def test_pe(api, nf):
     assert mask is None
     out = host(out)
     assert_exact(out[:, :3], g[f"out_{nf}"][:, :3])
-    assert_close(out, g[f"out_{nf}"], rtol=0, atol=5e-7, what="sin/cos: device libm vs SLEEF, arguments up to 2^9*1.5")
+    assert_close(out, g[f"out_{nf}"], rtol=0, atol=5e-7, what="sin/cos: nrf_math vs SLEEF, arguments up to 2^9*1.5")
+    from oracle import capi as O
+    assert_exact(out, O.pe(g["x"], nf), "PE == oracle bit for bit (shared portable sin/cos)")
 
 
 @pytest.mark.parametrize("deg", [1, 2, 3, 4, 5])
@@ -220,7 +222,7 @@ def test_raw2outputs(api, O, S, bg):
     ref = O.raw2outputs(g["raw"], g["z"], g["d"], bg == "white")
     for k, v in (("rgb", o.RGBMap), ("disp", o.DispMap), ("acc", o.AccMap), ("weights", o.Weights), ("depth", o.DepthMap)):
         assert_close(host(v), g[f"{bg}_{k}"], rtol=4e-6, atol=4e-7, what=f"{k} vs reference")
-        assert_close(host(v), ref[k], rtol=4e-6, atol=4e-7, what=f"{k} vs oracle")
+        assert_exact(host(v), ref[k], f"{k} == oracle bit for bit (double scans/sums + shared exp/log)")
 
 
 # ---------------------------------------------------------------------------------------- sampler
@@ -304,15 +306,18 @@ def test_render_hash_vs_reference(api, O, manifest):
     samples, _, _ = O.sample_pdf(mid, ex["weights_coarse"][:, 1:-1], O.linspace(0, 1, 128))
     assert_exact(ex["z_fine"], O.merge_sorted(ex["z_coarse"], samples), "fine depths given the GPU's coarse weights: bit-exact sample indices")
     wc = O.raw2outputs(ex["raw_coarse"], ex["z_coarse"], ex["rays_flat"][:, 3:6], True)["weights"]
-    assert_close(ex["weights_coarse"], wc, rtol=4e-6, atol=4e-7)
+    assert_exact(ex["weights_coarse"], wc, "coarse weights == oracle on the GPU's raw")
     fin = O.raw2outputs(host(res.Raw), ex["z_fine"], ex["rays_flat"][:, 3:6], True)
-    assert_close(host(res.Outputs.RGBMap).reshape(-1, 3), fin["rgb"], rtol=4e-6, atol=4e-7)
+    assert_exact(host(res.Outputs.RGBMap).reshape(-1, 3), fin["rgb"], "pixels == oracle compositing of the GPU's raw")
     # fp32 parity mode: the network output equals the oracle's bit for bit on the same points
     model = O.Model(0, blob, bbox=g["bbox"], table_f32=synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" in x[0]]))
     oc = O.render_rays(model, ex["rays_flat"], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True, want_intermediates=True)
-    same_vd = (ex["rays_flat"][:, 8:] == O.pack_rays(ex["rays_flat"][:, :3], ex["rays_flat"][:, 3:6], g["bbox"])[:, 8:]).all(axis=1)
-    assert same_vd.mean() > 0.5
-    assert_exact(ex["raw_coarse"][same_vd], oc["raw_coarse"][same_vd], "NRF_PREC_F32 coarse raw == oracle")
+    assert_exact(ex["rays_flat"], O.pack_rays(ex["rays_flat"][:, :3], ex["rays_flat"][:, 3:6], g["bbox"]), "packed rays == oracle")
+    assert_exact(ex["raw_coarse"], oc["raw_coarse"], "NRF_PREC_F32 coarse raw == oracle")
+    assert_exact(ex["z_fine"], oc["z_fine"], "END-TO-END sample set == oracle (indices bit-exact through both passes)")
+    assert_exact(host(res.Raw), oc["raw_fine"], "fine raw == oracle")
+    assert_exact(host(res.Outputs.RGBMap).reshape(-1, 3), oc["rgb"], "END-TO-END pixels == oracle bit for bit")
+    assert_exact(host(res.Outputs.DepthMap).reshape(-1), oc["depth"]); assert_exact(host(res.Outputs.AccMap), oc["acc"])
 
 
 def test_render_hash_chunk_invariance_and_ray_batch(api, manifest):
@@ -331,7 +336,7 @@ def test_render_hash_chunk_invariance_and_ray_batch(api, manifest):
     assert_close(host(res.Outputs.RGBMap), gl["out_rgb"], rtol=0, atol=1e-4)
 
 
-def test_render_classic_vs_reference(api, manifest):
+def test_render_classic_vs_reference(api, O, manifest):
     g = load_golden("render_classic")
     blob = synth.blob_from_manifest(manifest["render_classic"])
     m = api.M.NeRF(8, 256, 63, 27, 5, (4,), True, "model", params=blob)
@@ -342,6 +347,11 @@ def test_render_classic_vs_reference(api, manifest):
     assert_close(host(res.Extras["raw_coarse"]), g["coarse_raw"], rtol=0, atol=2e-4 * scale)
     assert_close(host(res.Outputs.RGBMap), g["out_rgb"], rtol=0, atol=2e-4, what="classic pixels (PE sin/cos + 10-layer fp32 MLP)")
     assert api.S.psnr(host(res.Outputs.RGBMap), g["out_rgb"]) > 75
+    model = O.Model(1, blob, bbox=g["bbox"])
+    rays = host(res.Extras["rays_flat"])
+    oc = O.render_rays(model, rays, 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True, want_intermediates=True)
+    assert_exact(host(res.Extras["z_fine"]), oc["z_fine"], "classic: end-to-end sample set == oracle")
+    assert_exact(host(res.Outputs.RGBMap).reshape(-1, 3), oc["rgb"], "classic: end-to-end pixels == oracle bit for bit")
     # coarse only (N_importance = 0): the reference returns undefined maps; here the coarse maps, equal to RawToOutputs of the coarse pass
     gc = load_golden("render_classic_coarse")
     p = _params(api, g["bbox"], 1024); p.NImportance = 0
@@ -387,4 +397,4 @@ def test_full_size_row_tile_properties(api, O):
                     local_idx=np.arange(16, dtype=np.int32) * ls, local_size=np.full(16, ls, np.int32), bias=np.zeros((16, 3), np.float32),
                     mul=O.hash_cu_scales(16, 16, 512))
     ref = O.render_rays(model, rays[idx], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
-    assert_close(rgb[idx], ref["rgb"], rtol=0, atol=1e-4, what="800x800 sample vs oracle")
+    assert_exact(rgb[idx], ref["rgb"], "800x800 sample == oracle bit for bit (CuHash mode, fp32 parity precision)")
