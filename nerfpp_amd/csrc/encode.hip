@@ -42,42 +42,6 @@ __global__ void k_pe(int64_t rows, int nfreq, int rep, const float *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// S2 LibTorch SH (degree <= 5).  Expression order follows NeRF.cpp:158-196 (tensor-scalar ops, left to right).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sh_libtorch(float x, float y, float z, int degree, float *r)
-{
-    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-    r[0] = C0;
-    if (degree <= 1) return;
-    r[1] = -C1 * y; r[2] = C1 * z; r[3] = -C1 * x;
-    if (degree <= 2) return;
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    r[4] = 1.0925484305920792f * xy;
-    r[5] = -1.0925484305920792f * yz;
-    r[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
-    r[7] = -1.0925484305920792f * xz;
-    r[8] = 0.5462742152960396f * (xx - yy);
-    if (degree <= 3) return;
-    r[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
-    r[10] = 2.890611442640554f * xy * z;
-    r[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
-    r[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-    r[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
-    r[14] = 1.445305721320277f * z * (xx - yy);
-    r[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
-    if (degree <= 4) return;
-    r[16] = 2.5033429417967046f * xy * (xx - yy);
-    r[17] = -1.7701307697799304f * yz * (3.0f * xx - yy);
-    r[18] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
-    r[19] = -0.6690465435572892f * yz * (7.0f * zz - 3.0f);
-    r[20] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
-    r[21] = -0.6690465435572892f * xz * (7.0f * zz - 3.0f);
-    r[22] = 0.47308734787878004f * (xx - yy) * (7.0f * zz - 1.0f);
-    r[23] = -1.7701307697799304f * xz * (xx - 3.0f * yy);
-    r[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
-}
-
 __global__ void k_sh(int64_t rows, int degree, int variant, int rep, const float *__restrict__ dirs, int dir_stride,
                      float *__restrict__ out, int out_stride)
 {

@@ -41,6 +41,9 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
                 void *d_ws, size_t ws_bytes, hipStream_t st);
 
 // matrix-core paths (separate translation units)
+int mlp_small_mfma_available(const nrf_mlp *m);
+int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, int s, const uint8_t *keep,
+                              int64_t p, float *out, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 

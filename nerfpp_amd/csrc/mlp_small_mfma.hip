@@ -77,9 +77,20 @@ struct SmallPlan {
     }
 };
 
-template <int IN_KS, int V_KS, int NL, int NLC>
+// Input of the fused kernel: either fp32 rows [p, in_ch + in_views] (the generic BaseNeRF::forward boundary) or the
+// renderer's fast-path layout: level-major fp16 hash features feats[level][p] (half2), per-RAY direction features
+// dirs[ray][V] (fp16) shared by the `s` samples of a ray (NeRFRenderer.h:179), and the embedder's keep mask, which is
+// applied to sigma in the epilogue (NeRFRenderer.h:187-188).
+struct SmallInput {
+    const float *x; int x_stride; int in_ch;          // row-major fp32 input
+    const __half2 *feats; int64_t pstride;            // level-major fp16 input
+    const __half *dirs; int s;
+    const uint8_t *keep;
+};
+
+template <int IN_KS, int V_KS, int NL, int NLC, bool LM>
 __global__ void __launch_bounds__(64 * WAVES)
-k_mlp_small_mfma(int64_t npts, const float *__restrict__ x, int x_stride, int in_ch, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
+k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
     using Plan = SmallPlan<IN_KS, V_KS, NL, NLC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -100,18 +111,31 @@ k_mlp_small_mfma(int64_t npts, const float *__restrict__ x, int x_stride, int in
         for (int pt = 0; pt < PT; pt++) {
             int64_t p = p0 + pt * 32 + r;
             if (p >= npts) p = npts - 1;                 // clamp loads; stores are guarded
-            const float *row = x + p * x_stride;
+            if constexpr (LM) {
 #pragma unroll
-            for (int s = 0; s < IN_KS; s++) {
-                const float4 lo = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h);
-                const float4 hi = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h + 4);
-                bx[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
-            }
+                for (int s = 0; s < IN_KS; s++) {
+                    union { half8 v; __half2 q[4]; } u;
 #pragma unroll
-            for (int s = 0; s < V_KS; s++) {
-                const float4 lo = *reinterpret_cast<const float4 *>(row + in_ch + 16 * s + 8 * h);
-                const float4 hi = *reinterpret_cast<const float4 *>(row + in_ch + 16 * s + 8 * h + 4);
-                bv[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+                    for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];   // features 16s+8h+2q, +1
+                    bx[pt][s] = u.v;
+                }
+                const __half *drow = in.dirs + (p / in.s) * (int64_t)(16 * V_KS);
+#pragma unroll
+                for (int s = 0; s < V_KS; s++) bv[pt][s] = *reinterpret_cast<const half8 *>(drow + 16 * s + 8 * h);
+            } else {
+                const float *row = in.x + p * in.x_stride;
+#pragma unroll
+                for (int s = 0; s < IN_KS; s++) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h);
+                    const float4 hi = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h + 4);
+                    bx[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+                }
+#pragma unroll
+                for (int s = 0; s < V_KS; s++) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(row + in.in_ch + 16 * s + 8 * h);
+                    const float4 hi = *reinterpret_cast<const float4 *>(row + in.in_ch + 16 * s + 8 * h + 4);
+                    bv[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+                }
             }
         }
         const half8 *fr = wl;
@@ -164,8 +188,10 @@ k_mlp_small_mfma(int64_t npts, const float *__restrict__ x, int x_stride, int in
             for (int pt = 0; pt < PT; pt++) {
                 const int64_t p = p0 + pt * 32 + r;
                 if (p < npts) {
-                    float *o = out + p * out_stride;
-                    o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sig[pt][0][0];
+                    float sg = sig[pt][0][0];
+                    if constexpr (LM) { if (in.keep && !in.keep[p]) sg = 0.0f; }
+                    if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
+                    else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
                 }
             }
         }
@@ -238,18 +264,31 @@ int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 }
 
 template <int V_KS, int NL, int NLC>
-static int launch_small(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
+static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st)
 {
     using Plan = SmallPlan<2, V_KS, NL, NLC>;
     const size_t lds = (size_t)Plan::total() * 1024;
     if (lds != m->packed_f16_bytes) { set_error("internal: packed weight image is %zu bytes, kernel expects %zu", m->packed_f16_bytes, lds); return NRF_ERR_INVALID_ARG; }
     const int64_t nblocks = ceil_div(p, BLOCK_PTS);
     const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);      // persistent: 256 CUs x up to 4 resident workgroups
-    auto kern = k_mlp_small_mfma<2, V_KS, NL, NLC>;
-    if (lds > 48 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds, st, p, x, xs, m->small.input_ch, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
+    if (lm) hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, true>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
+    else hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, false>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
+}
+
+static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st);
+
+int mlp_small_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_SMALL && m->d_packed_f16 != nullptr; }
+
+// renderer fast path: level-major fp16 features + per-ray fp16 direction features + keep mask -> raw [p,4] (sigma masked)
+int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, int s, const uint8_t *keep,
+                              int64_t p, float *out, hipStream_t st)
+{
+    if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
+    ProfScope prof(NRF_PROF_MLP, st);
+    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep};
+    return dispatch_small(m, in, true, p, out, 4, st);
 }
 
 int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
@@ -261,8 +300,15 @@ int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, 
         return NRF_ERR_UNSUPPORTED;
     }
     if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("NRF_PREC_F16_MFMA: input rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
+    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr};
+    return dispatch_small(m, in, false, p, out, os, st);
+}
+
+static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st)
+{
+    const auto &d = m->small;
     const int v = d.input_ch_views / 16;
-#define NRF_CASE(V, NL, NLC) if (v == V && d.num_layers == NL && d.num_layers_color == NLC) return launch_small<V, NL, NLC>(m, x, xs, p, out, os, st);
+#define NRF_CASE(V, NL, NLC) if (v == V && d.num_layers == NL && d.num_layers_color == NLC) return launch_small<V, NL, NLC>(m, in, lm, p, out, os, st);
     NRF_CASE(1, 3, 4) NRF_CASE(1, 3, 3) NRF_CASE(1, 3, 2) NRF_CASE(1, 2, 4) NRF_CASE(1, 2, 3) NRF_CASE(1, 2, 2)
     NRF_CASE(4, 3, 4) NRF_CASE(4, 3, 3) NRF_CASE(4, 3, 2) NRF_CASE(4, 2, 4) NRF_CASE(4, 2, 3) NRF_CASE(4, 2, 2)
 #undef NRF_CASE

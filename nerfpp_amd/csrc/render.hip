@@ -6,6 +6,7 @@
 // test-time rendering (NeRFExecutor.h:379-415).  One network serves both passes and the fine pass re-evaluates all
 // S + N_importance depths (NeRFRenderer.h:422,447).
 #include "encode.h"
+#include "hash_fast.h"
 #include "mlp.h"
 
 #include <mutex>
@@ -83,6 +84,34 @@ static size_t network_ws_bytes(const nrf_renderer *r, int64_t p, int prec)
     b += align_up((size_t)p * 3 * sizeof(float), 256);                           // explicit points (PE path)
     b += align_up(mlp_workspace_bytes(r->desc.mlp, p, prec), 256) + 1024;
     return b;
+}
+
+// The fused fast path (NRF_PREC_F16_MFMA, CuHashEmbedder-mode grid with F = 2 and 16 levels, SH directions, NeRFSmall in the
+// built matrix-core family): level-major fp16 features -> fused MFMA MLP, two launches per pass, no concatenated input.
+static bool fast_path(const nrf_renderer *r, int prec)
+{
+    return prec == NRF_PREC_F16_MFMA && r->desc.hash && hash_fast_supported(r->desc.hash) && r->in_ch == 32 &&
+           (r->desc.dirs_encoder == NRF_DIRS_SH_CUDA || r->desc.dirs_encoder == NRF_DIRS_SH_LIBTORCH) && (r->in_views == 16 || r->in_views == 64) &&
+           mlp_small_mfma_available(r->desc.mlp);
+}
+
+static size_t fast_ws_bytes(const nrf_renderer *r, int64_t n, int64_t p)
+{
+    return align_up((size_t)p * 16 * sizeof(__half2), 256) + align_up((size_t)p, 256) + align_up((size_t)n * r->in_views * sizeof(__half), 256) + 1024;
+}
+
+// dirs_f16: per-ray direction features [n, V] prepared once per chunk (nullptr: computed here from `viewdirs`)
+static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const __half *dirs_f16, int64_t n, int s, float *raw, void *ws,
+                            size_t ws_bytes, hipStream_t st)
+{
+    const int64_t p = n * s;
+    if (p == 0) return NRF_OK;
+    Bump bump(ws, ws_bytes);
+    __half2 *feats = bump.take<__half2>((size_t)p * 16);
+    uint8_t *keep = bump.take<uint8_t>((size_t)p);
+    if (bump.off > ws_bytes) { set_error("run_network_fast: workspace too small"); return NRF_ERR_WORKSPACE; }
+    NRF_TRY(launch_hash_lm(r->desc.hash, ps, p, feats, p, keep, HASH_LM_DEFAULT_VARIANT, st));
+    return mlp_small_forward_mfma_lm(r->desc.mlp, feats, p, dirs_f16, s, keep, p, raw, st);
 }
 
 // RunNetwork over p = n*s points given either explicit points or (rays, z).
@@ -215,7 +244,7 @@ int nrf_run_network(const nrf_renderer *r, const float *d_pts, const float *d_vi
 {
     NRF_CHECK_ARG(r && d_pts && d_raw && n >= 0 && s >= 1, "nrf_run_network: bad argument");
     PointSource ps{d_pts, nullptr, nullptr, 0, s};
-    return run_network(r, ps, d_viewdirs, 3, n, s, precision, d_raw, d_workspace, workspace_bytes, as_stream(stream));
+    return run_network(r, ps, d_viewdirs, 3, n, s, precision, d_raw, d_workspace, workspace_bytes, as_stream(stream));   // generic boundary: row-major path
 }
 
 size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const nrf_render_params *p)
@@ -229,6 +258,7 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += align_up((size_t)n * sf * 4, 256);               // z_fine
     b += align_up((size_t)n * sf * c * 4, 256);           // raw_fine
     b += network_ws_bytes(r, n * sf, p->precision) + 4096;
+    b += align_up((size_t)n * 64 * sizeof(__half), 256);  // per-ray direction features of the fast path
     return b;
 }
 
@@ -257,14 +287,22 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         z_f = out->d_z_fine ? out->d_z_fine : bump.take<float>((size_t)n * sf);
         raw_f = out->d_raw ? out->d_raw : bump.take<float>((size_t)n * sf * c);
     }
+    const bool fast = fast_path(r, p->precision);
+    __half *dirs16 = nullptr;
+    if (fast) dirs16 = bump.take<__half>((size_t)n * r->in_views);
     void *nws = bump.take<char>(0);
     const size_t nws_bytes = workspace_bytes - bump.off;
     const float *viewdirs = r->in_views > 0 ? d_rays + 8 : nullptr;
+    if (fast) NRF_TRY(launch_dirs_f16(d_rays, ray_stride, n, r->desc.dirs_param, r->desc.dirs_encoder == NRF_DIRS_SH_CUDA ? NRF_SH_CUDA : NRF_SH_LIBTORCH, dirs16, st));
+    auto network = [&](const PointSource &src, int ns_, float *raw_out) -> int {
+        if (fast) return run_network_fast(r, src, dirs16, n, ns_, raw_out, nws, nws_bytes, st);
+        return run_network(r, src, viewdirs, ray_stride, n, ns_, p->precision, raw_out, nws, nws_bytes, st);
+    };
 
     // z_vals; pts = o + d*z formed inside the encoder                           (NeRFRenderer.h:393-419)
     NRF_TRY(nrf_z_vals(d_rays, ray_stride, n, d_t, s, p->lindisp, z_c, st));
     PointSource ps{nullptr, d_rays, z_c, ray_stride, s};
-    NRF_TRY(run_network(r, ps, viewdirs, ray_stride, n, s, p->precision, raw_c, nws, nws_bytes, st));              // :422
+    NRF_TRY(network(ps, s, raw_c));                                                                                // :422
     if (ni == 0) {
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
         return nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
@@ -273,7 +311,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     NRF_TRY(nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, st));   // :423
     NRF_TRY(nrf_fine_depths(z_c, w_c, n, s, d_u, ni, p->sum_vec, z_f, st));                                                           // :427-431
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
-    NRF_TRY(run_network(r, psf, viewdirs, ray_stride, n, sf, p->precision, raw_f, nws, nws_bytes, st));            // :447
+    NRF_TRY(network(psf, sf, raw_f));                                                                              // :447
     return nrf_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
                            out->d_weights, out->d_depth, st);                                                      // :448
 }

@@ -398,3 +398,35 @@ def test_full_size_row_tile_properties(api, O):
                     mul=O.hash_cu_scales(16, 16, 512))
     ref = O.render_rays(model, rays[idx], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
     assert_exact(rgb[idx], ref["rgb"], "800x800 sample == oracle bit for bit (CuHash mode, fp32 parity precision)")
+
+
+# ------------------------------------------------------------------ fused fast path (NRF_PREC_F16_MFMA)
+def test_fast_path_equals_stagewise_f16(api):
+    """The renderer's fused path (level-major fp16 hash features -> fused MFMA MLP, CuHash mode) must produce the same raw
+    network outputs, bit for bit, as composing the public stage functions on the same points:
+    CuHashEmbedder.forward -> CuSHEncoder.forward -> cat -> NeRFSmall.forward(NRF_PREC_F16_MFMA) -> sigma mask."""
+    sc = api.S.make_hash_scene(mode="cu")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F16_MFMA, ReturnRaw=True, KeepIntermediates=True)
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=2)          # 1600 rays, two ragged chunks
+    rays = res.Extras["rays_flat"]; zc = res.Extras["z_coarse"]; zf = res.Extras["z_fine"]
+    for z, raw in ((zc, res.Extras["raw_coarse"]), (zf, res.Raw)):
+        n, s = z.shape
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        # o + d*z must be formed with the same two roundings as the kernel (mul, add): torch does exactly that
+        emb, keep = sc["embedder"].forward(pts)
+        dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+        x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+        ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_MFMA)
+        ref[~keep, 3] = 0
+        assert_exact(host(raw).reshape(-1, 4), host(ref), "fused fast path raw == stage-wise F16 raw")
+    assert np.isfinite(host(res.Outputs.RGBMap)).all()
+
+
+def test_fast_path_pixels_close_to_parity_mode(api):
+    sc = api.S.make_hash_scene(mode="cu", sigma_scale=4.0)      # a smoother density field than the adversarial default
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    a = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=4096, precision=api.L.NRF_PREC_F16_MFMA), c2w=c2w, row0=396, rows=8)
+    b = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=4096, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=396, rows=8)
+    ps = api.S.psnr(host(a.Outputs.RGBMap), host(b.Outputs.RGBMap))
+    assert ps > 45, ps
