@@ -1,19 +1,372 @@
-// mlp_nerf_mfma.hip -- NeRFImpl::forward (NeRF.cpp:41-126) on the gfx950 matrix cores (NRF_PREC_F16_MFMA).
+// mlp_nerf_mfma.hip -- NeRFImpl::forward (NeRF.cpp:41-126), the classic 8 x 256 MLP with view directions, on the gfx950
+// matrix cores (NRF_PREC_F16_MFMA: fp16 operands, fp32 accumulate).
+//
+// Same transposed formulation as mlp_small_mfma.hip: H_{l+1}^T [neurons x points] = W_{l+1} . H_l^T with
+// v_mfma_f32_32x32x16_f16, A = weights (32 neurons x 16 k), B = activations (16 k x 32 points).  A layer's 32 x 32 fp32
+// output tiles become, after bias + ReLU + fp16 conversion, the B fragments of the next layer IN PLACE (registers 8s..8s+7
+// of a tile = k-step s; the k permutation inside a k-step is folded into the weight image), so activations never leave
+// the register file: one wavefront carries 64 points (two 32-point tiles sharing every weight fragment) through all 11 GEMMs.
+//
+// What does not fit on chip is the weights: 1.16 MB of fp16 against 160 KB of LDS per CU.  The weight image
+// is therefore cut into 40 CHUNKS (two 32-neuron tiles x all k-steps of a layer, <= 40 KB) laid out in consumption
+// order; a 256-thread workgroup (4 waves x 64 points = 256 points, one workgroup per CU, one wave per SIMD owning the whole
+// 512-entry register file, persistent) streams chunk i+1 from L2 into registers while its waves run the MFMAs of chunk i
+// out of LDS, and writes it to the other LDS buffer before the
+// barrier that ends the chunk (issue-early / write-late staging).  Every A fragment is one conflict-free ds_read_b128.
+// L2 -> LDS weight traffic is 1.16 MB per 256 points, ~4.6 KB per point.
+//
+// Layer plan (D = 8, W = 256, skip 4, PE(10) positions = 63 -> 4 k-steps, PE(4) directions = 27 -> 2 k-steps):
+//   0      : pts_linears_0   [nat 4]              -> 8 tiles  ReLU
+//   1-4,6,7: pts_linears_i   [chained 16]         -> 8 tiles  ReLU
+//   5      : pts_linears_5   [nat 4 | chained 16]    cat[input_pts, h] after layer 4 (NeRF.cpp:103-104)
+//   8      : feature_linear (8 tiles, no ReLU) + alpha_linear (tile 8, row 0)   (NeRF.cpp:110-111)
+//   9      : views_linears_0 [chained 16 | nat 2] -> 4 tiles  ReLU              cat[feature, views] (NeRF.cpp:112-117)
+//   10     : rgb_linear      [chained 8]          -> 1 tile (rows 0..2)         out = cat[rgb, alpha] (NeRF.cpp:119)
 #include "mlp.h"
+
+#include <utility>
 
 namespace nrf {
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NW = 4;                  // waves per workgroup: one per SIMD, each owning the whole 512-entry register file
+constexpr int NPT = 2;                 // 32-point tiles per wave (every weight fragment read from LDS feeds NPT MFMAs)
+constexpr int NBLK = 32 * NPT * NW;    // points per workgroup iteration
+constexpr int MAXF = 40;               // fragments (1 KB each) in the largest chunk
+constexpr int NBIAS = 8 * 256 + 288 + 128 + 32;
+
+__host__ __device__ inline int nerf_perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+struct NerfNet {
+    static constexpr int NLAYER = 11;
+    static constexpr int tiles(int l) { return l < 8 ? 8 : l == 8 ? 9 : l == 9 ? 4 : 1; }
+    static constexpr int ks_nat(int l) { return (l == 0 || l == 5) ? 4 : l == 9 ? 2 : 0; }
+    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 10 ? 8 : 16; }
+    static constexpr bool nat_first(int l) { return l != 9; }
+    static constexpr int ks(int l) { return ks_nat(l) + ks_ch(l); }
+    static constexpr int chunks(int l) { return (tiles(l) + 1) / 2; }
+    static constexpr int chunk_tiles(int l, int c) { return (2 * c + 2 <= tiles(l)) ? 2 : 1; }
+    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += chunks(i); return n; }
+    static constexpr int total_chunks() { return first_chunk(NLAYER); }
+    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
+    static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
+    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
+    static constexpr int total_frags() { return chunk_off(total_chunks()); }
+    static constexpr int bias_off(int l) { int n = 0; for (int i = 0; i < l; i++) n += (i == 8 ? 288 : tiles(i) * 32); return n; }
+};
+static_assert(NerfNet::total_chunks() == 40, "chunk count");
+static_assert(NerfNet::total_chunks() % 2 == 0, "double-buffer parity must repeat per point block");
+
+// Staging registers for the NEXT chunk: each thread carries up to NPIECE 16-byte pieces.
+constexpr int NPIECE = (MAXF * 64 + 64 * NW - 1) / (64 * NW);
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Stage {
+    u32x4 r[NPIECE];
+};
+
+// The chunk's byte offset travels in the SCALAR offset of a buffer load and the per-lane part is the single VGPR tid*16, so
+// no per-chunk address ever occupies a vector register (40 chunks x up to 10 pieces of 64-bit lane addresses, hoisted out
+// of the persistent loop as loop invariants, is what spilled the first version of this kernel).
+template <int CI>
+__device__ __forceinline__ void stage_load(Stage &st, __amdgpu_buffer_rsrc_t rsrc, int tid)
+{
+    constexpr int ci = CI % NerfNet::total_chunks();
+    constexpr int n = NerfNet::chunk_frags(ci) * 64;          // 16-byte pieces in the chunk
+    constexpr int base = NerfNet::chunk_off(ci) * 1024;       // byte offset of the chunk in the image
+#pragma unroll
+    for (int q = 0; q < NPIECE; q++) {
+        const int i = q * (64 * NW) + tid;
+        if (q * (64 * NW) < n) { if (i < n) st.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, base + q * (64 * NW * 16), 0); }
+    }
+}
+
+template <int CI>
+__device__ __forceinline__ void stage_store(const Stage &st, half8 *__restrict__ dst, int tid)
+{
+    constexpr int ci = CI % NerfNet::total_chunks();
+    constexpr int n = NerfNet::chunk_frags(ci) * 64;
+#pragma unroll
+    for (int q = 0; q < NPIECE; q++) {
+        const int i = q * (64 * NW) + tid;
+        if (q * (64 * NW) < n) { if (i < n) reinterpret_cast<u32x4 *>(dst)[i] = st.r[q]; }
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ half8 nerf_tile_to_frag(const f32x16 &acc, int s)
+{
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float v = acc[8 * s + j];
+        if (RELU) v = v > 0.0f ? v : 0.0f;
+        r[j] = (_Float16)v;
+    }
+    return r;
+}
+
+struct Ctx {
+    half8 *wbuf;            // [2][MAXF*64]
+    const float *bias_s;    // LDS
+    __amdgpu_buffer_rsrc_t packed;   // buffer descriptor of the weight image (wave-uniform)
+    int tid, lane, h;
+    bool last_block;
+};
+
+// One chunk (<= 2 neuron tiles of layer L): start fetching the following chunk, run this chunk's MFMAs out of LDS, turn the
+// finished tiles into next-layer fragments, then publish the fetched chunk.  Every index is a template constant (the
+// constexpr table functions of NerfNet must be evaluated at compile time: called with a loop variable they become runtime
+// loops).  `last` receives the layer's final tile (alpha row / rgb rows are read from it).
+template <int L, int C, bool RELU, int NN, int NC, int NOUT>
+__device__ __forceinline__ void nerf_chunk(const Ctx &cx, const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT])
+{
+    constexpr int KSN = NerfNet::ks_nat(L), KSC = NerfNet::ks_ch(L), KS = KSN + KSC;
+    constexpr int CI = NerfNet::first_chunk(L) + C;
+    constexpr bool FINAL = (CI == NerfNet::total_chunks() - 1);
+    constexpr int NT = NerfNet::chunk_tiles(L, C);
+    constexpr int BOFF = NerfNet::bias_off(L);
+    constexpr int NTILES = NerfNet::tiles(L);
+    constexpr bool NATF = NerfNet::nat_first(L);
+    static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
+    Stage st;
+    const bool fetch = !(FINAL && cx.last_block);
+    if (fetch) stage_load<CI + 1>(st, cx.packed, cx.tid);
+    const half8 *w = cx.wbuf + (CI & 1) * (MAXF * 64);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int tile = 2 * C + t;
+        f32x16 acc[NPT];
+        const float *bp = cx.bias_s + BOFF + tile * 32 + 4 * cx.h;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bp + 8 * g);
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++) { acc[pt][4 * g + 0] = bv.x; acc[pt][4 * g + 1] = bv.y; acc[pt][4 * g + 2] = bv.z; acc[pt][4 * g + 3] = bv.w; }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const half8 a = w[(t * KS + k) * 64 + cx.lane];
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++) {
+                half8 b;
+                if (NATF) b = (k < KSN) ? bn[pt][k < KSN ? k : 0] : bc[pt][k >= KSN ? k - KSN : 0];
+                else b = (k < KSC) ? bc[pt][k < KSC ? k : 0] : bn[pt][k >= KSC ? k - KSC : 0];
+                acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[pt], 0, 0, 0);
+            }
+            // keep the weight-fragment reads at most a group of 4 ahead of their MFMAs: without the fence the scheduler
+            // hoists all 16-20 ds_read_b128 of a tile (64-80 VGPRs)
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) {
+            if (2 * tile + 1 < NOUT) {
+                bout[pt][2 * tile] = nerf_tile_to_frag<RELU>(acc[pt], 0);
+                bout[pt][2 * tile + 1] = nerf_tile_to_frag<RELU>(acc[pt], 1);
+            }
+            if (tile == NTILES - 1) last[pt] = acc[pt];
+        }
+    }
+    if (fetch) stage_store<CI + 1>(st, cx.wbuf + ((CI + 1) & 1) * (MAXF * 64), cx.tid);
+    __syncthreads();
+}
+
+template <int L, bool RELU, int NN, int NC, int NOUT, int... Cs>
+__device__ __forceinline__ void nerf_layer_seq(const Ctx &cx, const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT],
+                                               std::integer_sequence<int, Cs...>)
+{
+    (nerf_chunk<L, Cs, RELU>(cx, bn, bc, bout, last), ...);
+}
+
+template <int L, bool RELU, int NN, int NC, int NOUT>
+__device__ __forceinline__ void nerf_layer(const Ctx &cx, const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT])
+{
+    nerf_layer_seq<L, RELU>(cx, bn, bc, bout, last, std::make_integer_sequence<int, NerfNet::chunks(L)>{});
+}
+
+__global__ void __launch_bounds__(64 * NW)
+k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const half8 *__restrict__ packed, const float *__restrict__ biases,
+                float *__restrict__ out, int out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // biases FIRST: their LDS addresses then fit the 16-bit immediate offset of ds_read (one base VGPR for all 76 tiles)
+    constexpr int BIAS_BYTES = (NBIAS * 4 + 1023) / 1024 * 1024;
+    float *bias_s = reinterpret_cast<float *>(smem);
+    half8 *wbuf = reinterpret_cast<half8 *>(smem + BIAS_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < NBIAS; i += 64 * NW) bias_s[i] = biases[i];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, NerfNet::total_frags() * 1024, 0x00020000);
+    {   // chunk 0 into buffer 0
+        Stage st;
+        stage_load<0>(st, rsrc, tid);
+        stage_store<0>(st, wbuf, tid);
+    }
+    __syncthreads();
+    const int64_t nblocks = (npts + NBLK - 1) / NBLK;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        Ctx cx{wbuf, bias_s, rsrc, tid, lane, h, blk + gridDim.x >= nblocks};
+        int64_t p[NPT];
+        bool live[NPT];
+        const float *row[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) {
+            p[pt] = blk * NBLK + (wave * NPT + pt) * 32 + r;
+            live[pt] = p[pt] < npts;
+            if (!live[pt]) p[pt] = npts - 1;
+            row[pt] = x + p[pt] * x_stride;
+        }
+        // natural-order operand fragments: element j of k-step s is input 16s + 8h + j.  They are (re)loaded right where a
+        // layer consumes them (L0, L5: positions; L9: directions) instead of being kept live across the whole network.
+        auto load_pe = [&](half8 (&pe)[NPT][4]) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) pe[pt][s][j] = (_Float16)row[pt][16 * s + 8 * h + j];  // index 63 is the first view feature: its weight column is zero
+        };
+        half8 ba[NPT][16], bb[NPT][16], none[NPT][1];
+        f32x16 last[NPT];
+        {
+            half8 pe[NPT][4];
+            load_pe(pe);
+            nerf_layer<0, true>(cx, pe, none, ba, last);
+        }
+        nerf_layer<1, true>(cx, none, ba, bb, last);
+        nerf_layer<2, true>(cx, none, bb, ba, last);
+        nerf_layer<3, true>(cx, none, ba, bb, last);
+        nerf_layer<4, true>(cx, none, bb, ba, last);
+        {
+            half8 pe[NPT][4];
+            load_pe(pe);
+            nerf_layer<5, true>(cx, pe, ba, bb, last);
+        }
+        nerf_layer<6, true>(cx, none, bb, ba, last);
+        nerf_layer<7, true>(cx, none, ba, bb, last);
+        nerf_layer<8, false>(cx, none, bb, ba, last);          // feature tiles -> ba (no ReLU); tile 8 row 0 = alpha
+        float alpha[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) alpha[pt] = last[pt][0];
+        {
+            half8 vw[NPT][2];
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { const int k = 16 * s + 8 * h + j; vw[pt][s][j] = (k < 27) ? (_Float16)row[pt][63 + k] : (_Float16)0.0f; }
+            nerf_layer<9, true>(cx, vw, ba, bb, last);          // 4 tiles -> bb[..][0..7]
+        }
+        nerf_layer<10, false>(cx, none, bb, ba, last);
+        if (h == 0) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++)
+                if (live[pt]) {
+                    float *o = out + p[pt] * out_stride;
+                    o[0] = last[pt][0]; o[1] = last[pt][1]; o[2] = last[pt][2]; o[3] = alpha[pt];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight image
+// ---------------------------------------------------------------------------------------------------
+static bool nerf_mfma_supported(const nrf_mlp_nerf_desc &d)
+{
+    return d.depth == 8 && d.width == 256 && d.input_ch == 63 && d.input_ch_views == 27 && d.skip == 4 && d.use_viewdirs;
+}
+
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 {
-    (void)m; (void)hp;
+    const auto &d = m->nerf;
+    if (!nerf_mfma_supported(d)) return NRF_OK;
+    const int W = 256, IN = 63, V = 27;
+    // blob offsets (NeRF.cpp:75-89 order)
+    std::vector<size_t> w_off(12), b_off(12);
+    std::vector<int> in_dim(12), out_dim(12);
+    size_t off = 0;
+    for (int l = 0; l < 8; l++) {
+        in_dim[l] = l == 0 ? IN : (l == 5 ? W + IN : W); out_dim[l] = W;
+        w_off[l] = off; off += (size_t)in_dim[l] * W; b_off[l] = off; off += W;
+    }
+    const int VIEWS = 8, FEAT = 9, ALPHA = 10, RGB = 11;
+    in_dim[VIEWS] = V + W; out_dim[VIEWS] = W / 2; w_off[VIEWS] = off; off += (size_t)(V + W) * (W / 2); b_off[VIEWS] = off; off += W / 2;
+    in_dim[FEAT] = W; out_dim[FEAT] = W; w_off[FEAT] = off; off += (size_t)W * W; b_off[FEAT] = off; off += W;
+    in_dim[ALPHA] = W; out_dim[ALPHA] = 1; w_off[ALPHA] = off; off += W; b_off[ALPHA] = off; off += 1;
+    in_dim[RGB] = W / 2; out_dim[RGB] = 3; w_off[RGB] = off; off += (size_t)(W / 2) * 3; b_off[RGB] = off; off += 3;
+
+    std::vector<_Float16> img;
+    img.reserve((size_t)NerfNet::total_frags() * 512);
+    std::vector<float> bias(NBIAS, 0.0f);
+    auto chained = [](int k, int h, int j) { return 32 * (k >> 1) + nerf_perm_row(k & 1, h, j); };
+    auto natural = [](int k, int h, int j) { return 16 * k + 8 * h + j; };
+    // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel-layer L (-> 0 if padding)
+    auto wval = [&](int L, int row, int kstep, int h, int j) -> float {
+        const int ksn = NerfNet::ks_nat(L), ksc = NerfNet::ks_ch(L);
+        const bool nat = NerfNet::nat_first(L) ? (kstep < ksn) : (kstep >= ksc);
+        const int kk = NerfNet::nat_first(L) ? (nat ? kstep : kstep - ksn) : (nat ? kstep - ksc : kstep);
+        const int idx = nat ? natural(kk, h, j) : chained(kk, h, j);
+        if (L < 8) {
+            const float *w = hp.data() + w_off[L];
+            if (L == 0) return (idx < IN) ? w[(size_t)row * IN + idx] : 0.0f;
+            if (L == 5) return nat ? ((idx < IN) ? w[(size_t)row * (W + IN) + idx] : 0.0f) : w[(size_t)row * (W + IN) + IN + idx];
+            return w[(size_t)row * W + idx];
+        }
+        if (L == 8) {
+            if (row < W) return hp[w_off[FEAT] + (size_t)row * W + idx];
+            return row == W ? hp[w_off[ALPHA] + idx] : 0.0f;
+        }
+        if (L == 9) {
+            if (row >= W / 2) return 0.0f;
+            const float *w = hp.data() + w_off[VIEWS];
+            return nat ? ((idx < V) ? w[(size_t)row * (V + W) + W + idx] : 0.0f) : w[(size_t)row * (V + W) + idx];
+        }
+        return row < 3 ? hp[w_off[RGB] + (size_t)row * (W / 2) + idx] : 0.0f;
+    };
+    for (int L = 0; L < NerfNet::NLAYER; L++) {
+        const int KS = NerfNet::ks(L);
+        for (int tile = 0; tile < NerfNet::tiles(L); tile++)
+            for (int k = 0; k < KS; k++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(L, tile * 32 + (lane & 31), k, lane >> 5, j));
+        float *bp = bias.data() + NerfNet::bias_off(L);
+        if (L < 8) for (int i = 0; i < W; i++) bp[i] = hp[b_off[L] + i];
+        else if (L == 8) { for (int i = 0; i < W; i++) bp[i] = hp[b_off[FEAT] + i]; bp[W] = hp[b_off[ALPHA]]; }
+        else if (L == 9) for (int i = 0; i < W / 2; i++) bp[i] = hp[b_off[VIEWS] + i];
+        else for (int i = 0; i < 3; i++) bp[i] = hp[b_off[RGB] + i];
+    }
+    if (img.size() != (size_t)NerfNet::total_frags() * 512) { set_error("internal: classic NeRF weight image has %zu halves, expected %zu", img.size(), (size_t)NerfNet::total_frags() * 512); return NRF_ERR_INVALID_ARG; }
+    m->packed_f16_bytes = img.size() * sizeof(_Float16) + bias.size() * sizeof(float);
+    NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
+    NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_f16) + img.size() * sizeof(_Float16), bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     return NRF_OK;
 }
 
 int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
 {
-    (void)m; (void)x; (void)xs; (void)p; (void)out; (void)os; (void)st;
-    set_error("NRF_PREC_F16_MFMA for the 8x256 NeRF MLP is not built yet; use NRF_PREC_F32");
-    return NRF_ERR_UNSUPPORTED;
+    if (!m->d_packed_f16) {
+        set_error("NRF_PREC_F16_MFMA: this NeRF shape is outside the built matrix-core family (8 x 256, skip 4, PE(10)/PE(4), view directions); use NRF_PREC_F32");
+        return NRF_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)2 * MAXF * 1024 + ((size_t)NBIAS * sizeof(float) + 1023) / 1024 * 1024;
+    const int64_t nblocks = ceil_div(p, NBLK);
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent 8-wave workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const half8 *packed = reinterpret_cast<const half8 *>(m->d_packed_f16);
+    const float *biases = reinterpret_cast<const float *>(static_cast<const char *>(m->d_packed_f16) + (size_t)NerfNet::total_frags() * 1024);
+    hipLaunchKernelGGL(k_mlp_nerf_mfma, dim3(grid), dim3(64 * NW), lds, st, p, x, xs, packed, biases, out, os);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
 }
 
 }  // namespace nrf

@@ -430,3 +430,27 @@ def test_fast_path_pixels_close_to_parity_mode(api):
     b = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=4096, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=396, rows=8)
     ps = api.S.psnr(host(a.Outputs.RGBMap), host(b.Outputs.RGBMap))
     assert ps > 45, ps
+
+
+def test_mlp_nerf_f16_mfma(api, manifest):
+    g = load_golden("mlp_nerf")
+    blob = synth.blob_from_manifest(manifest["mlp_nerf"])
+    m = api.M.NeRF(8, 256, 63, 27, 5, (4,), True, "model", params=blob)
+    x = np.tile(g["x"], (12, 1))[:700]                 # 700 points: two full 256-point blocks + a ragged one
+    y = host(m.forward(dev(x), api.L.NRF_PREC_F16_MFMA))
+    ref = np.tile(g["y"], (12, 1))[:700]
+    scale = np.abs(ref).max()
+    assert_close(y, ref, rtol=0, atol=4e-3 * scale, what="classic NeRF fp16 MFMA vs reference")
+    assert np.abs(y - ref).mean() < 6e-4 * scale
+    f32 = host(m.forward(dev(x), api.L.NRF_PREC_F32))
+    assert np.abs(y - f32).mean() < 6e-4 * scale
+
+
+def test_render_classic_f16_mfma_pixels(api, manifest):
+    g = load_golden("render_classic")
+    blob = synth.blob_from_manifest(manifest["render_classic"])
+    m = api.M.NeRF(8, 256, 63, 27, 5, (4,), True, "model", params=blob)
+    r = api.R.NeRFRenderer(api.M.Embedder("embedder", 10), api.M.Embedder("embeddirs", 4), m)
+    res = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64, Precision=api.L.NRF_PREC_F16_MFMA), c2w=g["c2w"])
+    rgb = host(res.Outputs.RGBMap)
+    assert np.isfinite(rgb).all() and api.S.psnr(rgb, g["out_rgb"]) > 35
