@@ -57,3 +57,16 @@ if stale "$out/obj/ref_driver.o" "$here/ref/ref_driver.cpp"; then $CXX $FLAGS $I
 wait
 $CXX -o "$out/ref_driver" "$out/obj/ref_driver.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" "$out/obj/LeRF.o" $LIBS
 echo "built $out/ref_driver"
+
+# adapter_check: the LibTorch adapter (include/nerfpp_torch.h) inside the reference's NeRFRenderer<> machinery, against the
+# reference CPU renderer.  Links the repo's own libnerfpp_hip.so (rpath relative to the binary) and LibTorch's HIP backend.
+hiplib="$here/../nerfpp_amd/lib/libnerfpp_hip.so"
+if [ -f "$hiplib" ]; then
+  if stale "$out/obj/adapter_check.o" "$here/ref/adapter_check.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_check.o" ]; then
+    $CXX $FLAGS $INC -c "$here/ref/adapter_check.cpp" -o "$out/obj/adapter_check.o"
+  fi
+  $CXX -o "$out/adapter_check" "$out/obj/adapter_check.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" $LIBS \
+      -Wl,--no-as-needed -ltorch_hip -lc10_hip -Wl,--as-needed -L"$here/../nerfpp_amd/lib" -lnerfpp_hip \
+      -Wl,-rpath,'$ORIGIN/../../nerfpp_amd/lib' -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64
+  echo "built $out/adapter_check"
+fi

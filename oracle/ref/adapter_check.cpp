@@ -1,0 +1,133 @@
+// adapter_check.cpp -- TEST INFRASTRUCTURE (built only where /root/reference exists; the binary travels in oracle/_ref/).
+//
+// The drop-in demonstration, inside the reference's own template machinery:
+//   reference   NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall>             on LibTorch CPU          (the oracle)
+//   this repo   nrfpp::HipNeRFRenderer<HipHashEmbedder, HipSHEncoder, NeRFSmall> : NeRFRenderer<...>  on the MI355X
+// Both are driven through the reference's unmodified Render() -> BatchifyRays() -> (virtual) RenderRays() and given the same
+// synthetic weights.  >= 90 % of the pixels must agree within 1e-4 and the render-vs-render PSNR must exceed 55 dB (fp32
+// parity precision): the reference's fine-pass sample set is a discontinuous function of the coarse weights, and the
+// reference differs from ITSELF by this much between CPU dispatch settings ("How exact can parity be").
+// Also checks the BaseEmbedder surface
+// (GetOutputDims / forward) of the hash and SH encoders against the reference modules.
+//
+// usage: adapter_check [h w]      prints one JSON line, exit code 0 iff every check passed
+#define NRFPP_WITH_REFERENCE
+#include "nerfpp_torch.h"
+#include "nrf_synth.h"
+
+#include <cstdio>
+#include <iostream>
+
+using torch::indexing::Slice;
+using torch::indexing::None;
+
+static void fill_synth(torch::Tensor p, uint32_t seed, float amp)
+{
+	torch::NoGradGuard ng;
+	auto flat = torch::empty({p.numel()}, torch::kFloat32);
+	float *d = flat.data_ptr<float>();
+	for (int64_t i = 0; i < p.numel(); i++) d[i] = nrf_synth_sym(seed, (uint32_t)i, amp);
+	p.copy_(flat.view(p.sizes()));
+}
+
+static torch::Tensor lego_K(int h, int w)
+{
+	float focal = 0.5f * w / std::tan(0.5f * 0.6911112f);
+	float kdata[] = {focal, 0, 0.5f * w, 0, focal, 0.5f * h, 0, 0, 1};
+	return torch::from_blob(kdata, {3, 3}).clone();
+}
+
+static torch::Tensor orbit_pose(float theta_deg, float phi_deg, float radius)
+{
+	const float PI_ = std::acos(-1.0f);
+	float th = theta_deg / 180.f * PI_, ph = phi_deg / 180.f * PI_;
+	float t_[] = {1,0,0,0, 0,1,0,0, 0,0,1,radius, 0,0,0,1};
+	float rp[] = {1,0,0,0, 0,std::cos(ph),-std::sin(ph),0, 0,std::sin(ph),std::cos(ph),0, 0,0,0,1};
+	float rt[] = {std::cos(th),0,-std::sin(th),0, 0,1,0,0, std::sin(th),0,std::cos(th),0, 0,0,0,1};
+	float fl[] = {-1,0,0,0, 0,0,1,0, 0,1,0,0, 0,0,0,1};
+	auto c2w = torch::from_blob(t_, {4,4}).clone();
+	c2w = torch::matmul(torch::from_blob(rp, {4,4}).clone(), c2w);
+	c2w = torch::matmul(torch::from_blob(rt, {4,4}).clone(), c2w);
+	c2w = torch::matmul(torch::from_blob(fl, {4,4}).clone(), c2w);
+	return c2w.index({Slice(None, 3), Slice(None, 4)}).contiguous();
+}
+
+int main(int argc, const char **argv)
+{
+	const int h = argc > 1 ? atoi(argv[1]) : 16, w = argc > 2 ? atoi(argv[2]) : 16;
+	if (!torch::cuda::is_available()) { printf("{\"ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
+	std::streambuf *cout_buf = std::cout.rdbuf();
+	torch::NoGradGuard ng;
+	const int L = 16, F = 2, T = 17;      // 2^17 rows per level keeps the CPU table small; semantics identical
+	auto bbox = torch::tensor({-1.5f, -1.5f, -1.5f, 1.5f, 1.5f, 1.5f});
+	// ---- the reference's modules (CPU) with synthetic weights ----
+	HashEmbedder e("embedder", bbox, L, F, T, 16, 512);
+	SHEncoder ed("embeddirs", 3, 4);
+	NeRFSmall m(3, 64, 15, 4, 64, false, 3, 64, L * F, 16, "model");
+	int k = 0;
+	for (auto &p : e->named_parameters()) fill_synth(p.value(), 5000u + 1000u * (k++), 0.5f);
+	k = 0;
+	for (auto &p : m->named_parameters()) {
+		auto t = p.value();
+		float amp = 1.6f * std::sqrt(6.0f / float(t.size(0) + t.size(1)));
+		if (p.key().find("sigma_net_2") != std::string::npos) amp *= 8.0f;
+		fill_synth(t, 6000u + 1000u * (k++), amp);
+	}
+	// ---- the same model behind the HIP adapters ----
+	nrfpp::HipHashEmbedder he("embedder", bbox, L, F, T, 16, 512, NRF_HASH_NGP);
+	{
+		std::vector<torch::Tensor> tabs;
+		for (auto &p : e->named_parameters()) tabs.push_back(p.value());
+		he->Embeddings.copy_(torch::cat(tabs, 0));
+		he->Initialize();
+	}
+	nrfpp::HipSHEncoder hd("embeddirs", 3, 4, NRF_SH_LIBTORCH);
+	nrfpp::HipNeRFRenderer<nrfpp::HipHashEmbedder, nrfpp::HipSHEncoder, NeRFSmall> hip(he, hd, m, NRF_PREC_F32);
+	nrf_mlp_small_desc sd{L * F, 16, 3, 64, 15, 4, 64};
+	hip.SyncWeights(&sd, nullptr);
+
+	bool ok = true;
+	// ---- BaseEmbedder surface ----
+	auto x = (torch::rand({4096, 3}) * 3.2f - 1.6f);
+	auto [emb_ref, mask_ref] = e->forward(x);
+	auto [emb_hip, mask_hip] = he->forward(x.cuda());
+	const bool emb_exact = torch::equal(emb_hip.cpu(), emb_ref) && torch::equal(mask_hip.cpu(), mask_ref);
+	ok = ok && emb_exact && he->GetOutputDims() == e->GetOutputDims();
+	auto dirs = torch::nn::functional::normalize(torch::randn({1024, 3}), torch::nn::functional::NormalizeFuncOptions().dim(-1));
+	const bool sh_exact = torch::equal(hd->forward(dirs.cuda()).first.cpu(), ed->forward(dirs).first);
+	ok = ok && sh_exact;
+
+	// ---- Render(): reference CPU vs HIP, through the reference's own Render/BatchifyRays ----
+	NeRFRenderParams rp;
+	rp.NSamples = 64; rp.NImportance = 128; rp.Chunk = 100; rp.ReturnRaw = false; rp.LinDisp = false; rp.Perturb = 0.f; rp.WhiteBkgr = true;
+	rp.RawNoiseStd = 0.f; rp.Ndc = false; rp.UseViewdirs = true; rp.ReturnWeights = true; rp.ThinRay = true; rp.BoundingBox = bbox;
+	auto K = lego_K(h, w);
+	auto c2w = orbit_pose(30.f, -30.f, 4.f);
+	NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> ref(e, ed, m);
+	auto r_ref = ref.Render(h, w, K, rp, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+	auto rp_gpu = rp; rp_gpu.BoundingBox = bbox.cuda();
+	auto r_hip = hip.Render(h, w, K.cuda(), rp_gpu, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w.cuda());
+	const float rgb_err = (r_hip.Outputs.RGBMap.cpu() - r_ref.Outputs.RGBMap).abs().max().item<float>();
+	const float acc_err = (r_hip.Outputs.AccMap.cpu() - r_ref.Outputs.AccMap).abs().max().item<float>();
+	const float dep_err = (r_hip.Outputs.DepthMap.cpu() - r_ref.Outputs.DepthMap).abs().max().item<float>();
+	// The fine-pass sample set is a discontinuous function of the coarse weights (searchsorted on CDF plateaus): ulp-level
+	// differences between MKL/SLEEF on the CPU and the HIP path move a few samples, so a few pixels differ by more than the
+	// typical 1e-5.  Reported: the share of pixels within 1e-4 and the PSNR, next to the max.
+	const float frac_1e4 = ((r_hip.Outputs.RGBMap.cpu() - r_ref.Outputs.RGBMap).abs().amax(-1) < 1e-4f).to(torch::kFloat32).mean().item<float>();
+	const double mse = (r_hip.Outputs.RGBMap.cpu() - r_ref.Outputs.RGBMap).pow(2).mean().item<double>();
+	const double psnr = mse > 0 ? -10.0 * std::log10(mse) : 999.0;
+	const bool shape_ok = r_hip.Outputs.RGBMap.sizes() == r_ref.Outputs.RGBMap.sizes() && r_hip.Outputs.DepthMap.sizes() == r_ref.Outputs.DepthMap.sizes() &&
+		r_hip.Near == r_ref.Near && r_hip.Far == r_ref.Far;
+	ok = ok && frac_1e4 >= 0.90f && psnr > 55.0 && shape_ok;
+	// fast precision through the same surface
+	hip.SetPrecision(NRF_PREC_F16_MFMA);
+	auto r_f16 = hip.Render(h, w, K.cuda(), rp_gpu, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w.cuda());
+	const bool f16_finite = torch::isfinite(r_f16.Outputs.RGBMap).all().item<bool>();
+	ok = ok && f16_finite;
+	std::cout.rdbuf(cout_buf);
+	printf("{\"ok\": %s, \"image\": [%d, %d], \"hash_embedding_bit_exact\": %s, \"sh_bit_exact\": %s, \"rgb_max_abs_err\": %.3e, \"pixels_within_1e-4\": %.4f, \"acc_max_abs_err\": %.3e, "
+		"\"depth_max_abs_err\": %.3e, \"psnr_db\": %.2f, \"shapes_near_far_equal\": %s, \"f16_render_finite\": %s}\n",
+		ok ? "true" : "false", h, w, emb_exact ? "true" : "false", sh_exact ? "true" : "false", rgb_err, frac_1e4, acc_err, dep_err, psnr, shape_ok ? "true" : "false",
+		f16_finite ? "true" : "false");
+	return ok ? 0 : 1;
+}

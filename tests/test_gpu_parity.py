@@ -454,3 +454,21 @@ def test_render_classic_f16_mfma_pixels(api, manifest):
     res = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64, Precision=api.L.NRF_PREC_F16_MFMA), c2w=g["c2w"])
     rgb = host(res.Outputs.RGBMap)
     assert np.isfinite(rgb).all() and api.S.psnr(rgb, g["out_rgb"]) > 35
+
+
+def test_libtorch_adapter_drop_in_inside_reference_renderer():
+    """oracle/_ref/adapter_check (compiled where /root/reference exists, travels as a binary): the C++ LibTorch adapter
+    classes of include/nerfpp_torch.h driven by the reference's own NeRFRenderer::Render / BatchifyRays, compared with the
+    reference CPU renderer on the same weights."""
+    import json, os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, "16", "16"], capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout + out.stderr
+    r = json.loads(lines[-1])
+    assert out.returncode == 0 and r["ok"], r
+    assert r["hash_embedding_bit_exact"] and r["sh_bit_exact"] and r["shapes_near_far_equal"]
+    assert r["pixels_within_1e-4"] >= 0.90 and r["psnr_db"] > 55, r
