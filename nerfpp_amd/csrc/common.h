@@ -102,7 +102,8 @@ __device__ __forceinline__ F3 load_point(const PointSource &ps, int64_t i)
         r.y = ps.pts[i * 3 + 1];
         r.z = ps.pts[i * 3 + 2];
     } else {
-        const int64_t ray = i / ps.s;
+        // 32-bit division when the index fits (always, for a chunk): the 64-bit one is a ~60-instruction sequence
+        const int64_t ray = (i >> 31) == 0 ? (int64_t)((uint32_t)i / (uint32_t)ps.s) : i / ps.s;
         const float *rp = ps.rays + ray * ps.ray_stride;
         const float zz = ps.z[i];
         r.x = rp[0] + rp[3] * zz;

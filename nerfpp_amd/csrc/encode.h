@@ -54,10 +54,14 @@ __device__ __forceinline__ void cu_blend(const __half *fp, const uint32_t pos[3]
     const uint32_t hz0 = pos[2] * pc, hz1 = (pos[2] + 1u) * pc;
     uint32_t ps[8];
     float ws[8];
+    // `% local_size` (CuHashEmbedder.cu:70-77): local_size = (2^T >> 4) << 4 is a power of two for every T >= 4, where the
+    // modulo is a mask; the general remainder (a ~25-instruction sequence, 8 times per point and level) is kept for other sizes.
+    const bool pow2 = (lsz & (lsz - 1u)) == 0u;          // wave-uniform (lsz comes from the kernel arguments)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const uint32_t hx = (k & 4) ? hx1 : hx0, hy = (k & 2) ? hy1 : hy0, hz = (k & 1) ? hz1 : hz0;
-        ps[k] = (hx ^ hy ^ hz) % lsz;
+        const uint32_t hv = hx ^ hy ^ hz;
+        ps[k] = pow2 ? (hv & (lsz - 1u)) : (hv % lsz);
         const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
         ws[k] = wx * wy * wz;
     }
