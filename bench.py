@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
     ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,6 +117,8 @@ def main():
     prec = L.NRF_PREC_F16_MFMA if args.precision == "f16" else L.NRF_PREC_F32
     if args.workload == "hash":
         sc = scene.make_hash_scene(mode=args.hash_mode)
+        if args.dense_mb >= 0 and args.hash_mode == "cu":
+            sc["embedder"].set_dense_budget(int(args.dense_mb * (1 << 20)))
         chunk = args.chunk or 32768
     else:
         sc = scene.make_classic_scene()

@@ -19,6 +19,10 @@ struct HashParams {
     float bias[NRF_MAX_LEVELS * 3];         // CU
     int32_t local_idx[NRF_MAX_LEVELS];      // CU: level base offset in ELEMENTS (the reference's overlap quirk)
     uint32_t local_size[NRF_MAX_LEVELS];    // CU
+    // baked dense image of the coarse levels (hash_fast.hip): entry offset into `dense` (-1: level stays hashed) and block grid
+    const void *dense;
+    int64_t dense_off[NRF_MAX_LEVELS];
+    int32_t dense_nby[NRF_MAX_LEVELS], dense_nbz[NRF_MAX_LEVELS];
 };
 
 }  // namespace nrf
@@ -32,7 +36,9 @@ struct nrf_hash {
     // fast-path image of the table (hash_fast.hip), rebuilt lazily after the table or primes change
     void *d_fast = nullptr;
     size_t fast_bytes = 0;
-    mutable bool fast_valid = false;
+    bool fast_valid = false;
+    int dense_levels = 0;
+    size_t dense_budget = (size_t)12 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 1.1 GB at 16..512, 8.6 GB at 16..1024 -- HBM is 288 GB
 };
 
 namespace nrf {
@@ -43,9 +49,11 @@ int launch_hash(const nrf_hash *h, const PointSource &ps, int64_t p, float *out,
 
 // CuHashEmbedder.cu:70-100: 8 hashed corners, trilinear weights as three-factor products, fp32 sum of
 // products in the order 000,001,010,011,100,101,110,111 (bit 2 = x, bit 1 = y, bit 0 = z).
-template <int F>
+// GATHER: 0 = plain global loads; 1..3 = buffer loads through a descriptor of the table (voffset = byte offset of the row) with
+// cache policy aux 0 / nt / sc1 (tuning experiments, hash_fast.hip)
+template <int F, int GATHER = 0>
 __device__ __forceinline__ void cu_blend(const __half *fp, const uint32_t pos[3], const float fr[3], uint32_t pa, uint32_t pb, uint32_t pc,
-                                         uint32_t lsz, float acc[F])
+                                         uint32_t lsz, float acc[F], __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), uint32_t base_bytes = 0)
 {
     const float a = fr[0], b = fr[1], c = fr[2];
     const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
@@ -68,7 +76,15 @@ __device__ __forceinline__ void cu_blend(const __half *fp, const uint32_t pos[3]
     if constexpr (F == 2) {
         float2 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = __half22float2(*reinterpret_cast<const __half2 *>(fp + (size_t)ps[k] * 2));
+        for (int k = 0; k < 8; k++) {
+            if constexpr (GATHER == 0) v[k] = __half22float2(*reinterpret_cast<const __half2 *>(fp + (size_t)ps[k] * 2));
+            else {
+                constexpr int aux = GATHER == 1 ? 0 : GATHER == 2 ? 2 : 16;
+                const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ps[k] * 4u, base_bytes, aux);
+                __half2 hv; __builtin_memcpy(&hv, &w, 4);
+                v[k] = __half22float2(hv);
+            }
+        }
         float a0 = ws[0] * v[0].x, a1 = ws[0] * v[0].y;
 #pragma unroll
         for (int k = 1; k < 8; k++) { a0 = a0 + ws[k] * v[k].x; a1 = a1 + ws[k] * v[k].y; }

@@ -9,6 +9,7 @@
 // concatenated MLP input in place).  The level-major fp16 fast path used by the fused renderer lives in
 // hash_fast.hip.  Built with -ffp-contract=off; sin/cos from include/nrf_math.h: every value equals the oracle's bit for bit.
 #include "encode.h"
+#include "hash_fast.h"
 
 namespace nrf {
 
@@ -230,6 +231,7 @@ int nrf_hash_create(const nrf_hash_desc *desc, nrf_hash **out)
     memset(&hp, 0, sizeof(hp));
     for (int a = 0; a < 3; a++) { hp.bbox.mn[a] = desc->bbox[a]; hp.bbox.mx[a] = desc->bbox[3 + a]; }
     hp.n_levels = L; hp.log2_t = desc->log2_hashmap_size;
+    for (int l = 0; l < NRF_MAX_LEVELS; l++) hp.dense_off[l] = -1;
     if (desc->mode == NRF_HASH_NGP) {
         // NeRF.cpp:251: b = float(exp((ln finest - ln base)/(L-1)));  :309: res_l = floor(float(base * pow(b, l)))
         const float b = (float)exp((log((double)desc->finest_resolution) - log((double)desc->base_resolution)) / (double)(L - 1));
@@ -284,6 +286,7 @@ int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *s
     }
     h->table_set = true;
     h->fast_valid = false;
+    if (hash_fast_supported(h)) NRF_TRY(hash_fast_prepare(h, h->dense_budget, st));
     return NRF_OK;
 }
 
@@ -297,6 +300,7 @@ int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
     }
     h->primes_set = true;
     h->fast_valid = false;
+    if (hash_fast_supported(h)) NRF_TRY(hash_fast_prepare(h, h->dense_budget, nullptr));
     return NRF_OK;
 }
 

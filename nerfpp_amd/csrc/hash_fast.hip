@@ -34,7 +34,18 @@ __device__ __forceinline__ PointPrep prep_point(const HashParams &hp, const F3 &
 }
 
 // One (point, level): 8 half2 gathers issued back to back, then the fp32 blend in the reference's order.
-__device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, int l)
+// Dense ("baked") image of a level: the value of every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, copied out of the
+// hashed table once at model load.  Vertices are stored in 4x4x2 bricks of 32 half2 = one 128-B line, so the 8 corners of a
+// voxel fall into 2.3 lines on average (8 for the hashed table) and consecutive samples along a ray share lines.  The lookup
+// result is the same table entry the hash would have selected: outputs are bit-identical.
+__device__ __forceinline__ uint32_t dense_index(uint32_t x, uint32_t y, uint32_t z, uint32_t nby, uint32_t nbz)
+{
+    const uint32_t blk = ((x >> 2) * nby + (y >> 2)) * nbz + (z >> 1);
+    return blk * 32u + (((x & 3u) << 3) | ((y & 3u) << 1) | (z & 1u));
+}
+
+template <int GATHER>
+__device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, int l, __amdgpu_buffer_rsrc_t rsrc)
 {
     float fr[3];
     uint32_t pos[3];
@@ -47,15 +58,95 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
         pos[a] = (uint32_t)fl;
         fr[a] = q - fl;
     }
-    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
-    const uint32_t lsz = hp.local_size[l];
-    const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
     float acc[2];
-    cu_blend<2>(fp, pos, fr, pa, pb, pc, lsz, acc);
+    if (hp.dense_off[l] >= 0) {                 // wave-uniform
+        const __half2 *dp = reinterpret_cast<const __half2 *>(hp.dense) + hp.dense_off[l];
+        const uint32_t nby = (uint32_t)hp.dense_nby[l], nbz = (uint32_t)hp.dense_nbz[l];
+        const float a = fr[0], b = fr[1], c = fr[2];
+        const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
+        float2 v[8];
+        float ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v[k] = __half22float2(dp[dense_index(pos[0] + ((k >> 2) & 1), pos[1] + ((k >> 1) & 1), pos[2] + (k & 1), nby, nbz)]);
+            const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
+            ws[k] = wx * wy * wz;
+        }
+        float a0 = ws[0] * v[0].x, a1 = ws[0] * v[0].y;
+#pragma unroll
+        for (int k = 1; k < 8; k++) { a0 = a0 + ws[k] * v[k].x; a1 = a1 + ws[k] * v[k].y; }
+        acc[0] = a0; acc[1] = a1;
+    } else {
+        const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+        const uint32_t lsz = hp.local_size[l];
+        const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
+        cu_blend<2, GATHER>(fp, pos, fr, pa, pb, pc, lsz, acc, rsrc, (uint32_t)hp.local_idx[l] * 2u);
+    }
     return __halves2half2(__float2half_rn(acc[0]), __float2half_rn(acc[1]));
 }
 
-template <int PPT>
+__global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries, __half2 *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= entries) return;
+    const uint32_t nby = (uint32_t)hp.dense_nby[l], nbz = (uint32_t)hp.dense_nbz[l];
+    const uint32_t w = (uint32_t)(i & 31), blk = (uint32_t)(i >> 5);
+    const uint32_t bz = blk % nbz, by = (blk / nbz) % nby, bx = blk / (nbz * nby);
+    const uint32_t x = bx * 4 + (w >> 3), y = by * 4 + ((w >> 1) & 3), z = bz * 2 + (w & 1);
+    __half2 v = __halves2half2(__float2half_rn(0.0f), __float2half_rn(0.0f));
+    if (x < dim && y < dim && z < dim) {
+        const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+        const uint32_t hv = ((x * pa) ^ (y * pb) ^ (z * pc)) % hp.local_size[l];
+        v = *reinterpret_cast<const __half2 *>(reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l] + (size_t)hv * 2);
+    }
+    dst[i] = v;
+}
+
+// (Re)build the dense image of levels [0, nb) after the table or the primes changed.  nb is chosen by a byte budget.
+int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
+{
+    if (h->fast_valid) return NRF_OK;
+    HashParams &hp = h->params;
+    const int L = h->desc.n_levels;
+    for (int l = 0; l < L; l++) hp.dense_off[l] = -1;
+    hp.dense = nullptr;
+    bool zero_bias = true;
+    for (int i = 0; i < L * 3; i++) zero_bias = zero_bias && hp.bias[i] == 0.0f;
+    int64_t total = 0;
+    int nb = 0;
+    if (zero_bias && h->desc.mode == NRF_HASH_CU && h->desc.n_features == 2) {
+        for (int l = 0; l < L; l++) {
+            const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
+            const int64_t nbx = (dim + 3) / 4, nby = (dim + 3) / 4, nbz = (dim + 1) / 2;
+            const int64_t entries = nbx * nby * nbz * 32;
+            if ((size_t)(total + entries) * 4 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
+            hp.dense_off[l] = total; hp.dense_nby[l] = (int32_t)nby; hp.dense_nbz[l] = (int32_t)nbz;
+            total += entries; nb = l + 1;
+        }
+    }
+    if (nb > 0) {
+        if (h->fast_bytes < (size_t)total * 4) {
+            if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
+            h->d_fast = nullptr; h->fast_bytes = 0;
+            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 4));
+            h->fast_bytes = (size_t)total * 4;
+        }
+        hp.dense = h->d_fast;
+        for (int l = 0; l < nb; l++) {
+            const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
+            const int64_t entries = (l + 1 < nb ? hp.dense_off[l + 1] : total) - hp.dense_off[l];
+            hipLaunchKernelGGL(k_bake_dense, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
+                               reinterpret_cast<__half2 *>(h->d_fast) + hp.dense_off[l]);
+            NRF_LAUNCH_CHECK();
+        }
+    }
+    NRF_HIP(hipStreamSynchronize(st));          // model-load time: later launches may come from any stream
+    h->fast_valid = true;
+    h->dense_levels = nb;
+    return NRF_OK;
+}
+
+template <int PPT, int GATHER>
 __global__ void __launch_bounds__(256)
 k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep, int lpg, int xcd_map,
              int level0)
@@ -83,9 +174,12 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
         const int64_t i = idx[q] < p ? idx[q] : p - 1;
         pp[q] = prep_point(hp, load_point(ps, i));
     }
+    __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t();
+    if constexpr (GATHER != 0)
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(hp.table), 0, (int)(((size_t)hp.n_levels << hp.log2_t) * 4), 0x00020000);
     __half2 out[PPT];
 #pragma unroll
-    for (int q = 0; q < PPT; q++) out[q] = encode_level(hp, pp[q], level);
+    for (int q = 0; q < PPT; q++) out[q] = encode_level<GATHER>(hp, pp[q], level, rsrc);
 #pragma unroll
     for (int q = 0; q < PPT; q++) {
         if (idx[q] < p) {
@@ -125,8 +219,13 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     if (level_hi < 0) level_hi = L;
     const int64_t ntiles = ceil_div(p, 256 * ppt);
     dim3 grid = xcd ? dim3((unsigned)(ntiles * lpg * 8)) : dim3((unsigned)ntiles, (unsigned)(level_hi - level_lo));
-    if (ppt == 1) hipLaunchKernelGGL(k_hash_cu_lm<1>, grid, dim3(256), 0, st, h->params, ps, p, feats, pstride, keep, lpg, xcd, level_lo);
-    else hipLaunchKernelGGL(k_hash_cu_lm<2>, grid, dim3(256), 0, st, h->params, ps, p, feats, pstride, keep, lpg, xcd, level_lo);
+    const int gather = (variant >> 3) & 3;
+    HashParams hpar = h->params;
+    if (variant & 32) { for (int l = 0; l < L; l++) hpar.dense_off[l] = -1; }       // tuning: force the hashed lookup everywhere
+#define NRF_LM(P, G) hipLaunchKernelGGL((k_hash_cu_lm<P, G>), grid, dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, xcd, level_lo)
+    if (ppt == 1) { if (gather == 0) NRF_LM(1, 0); else if (gather == 1) NRF_LM(1, 1); else if (gather == 2) NRF_LM(1, 2); else NRF_LM(1, 3); }
+    else { if (gather == 0) NRF_LM(2, 0); else if (gather == 1) NRF_LM(2, 1); else if (gather == 2) NRF_LM(2, 2); else NRF_LM(2, 3); }
+#undef NRF_LM
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
@@ -144,6 +243,15 @@ int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int va
 using namespace nrf;
 
 // Debug / tuning entry (not part of the public header): level-major encode of explicit points with a kernel variant.
+// Debug / tuning entry: set the dense-image byte budget (0 disables baking) and rebuild.
+extern "C" NRF_API int nrf_dbg_hash_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
+{
+    NRF_CHECK_ARG(h, "nrf_dbg_hash_dense_budget: null handle");
+    h->dense_budget = (size_t)budget_bytes;
+    h->fast_valid = false;
+    return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
+}
+
 extern "C" NRF_API int nrf_dbg_hash_lm(const nrf_hash *h, const float *d_x, int64_t p, int variant, int level_lo, int level_hi, void *d_feats, uint8_t *d_keep, void *stream)
 {
     NRF_CHECK_ARG(h && d_x && d_feats && p >= 0, "nrf_dbg_hash_lm: bad argument");

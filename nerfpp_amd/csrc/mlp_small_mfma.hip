@@ -58,6 +58,9 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
             const half8 a = frags[(mt * KS + ks) * 64 + lane];
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks], acc[pt][mt], 0, 0, 0);
+            // fence the scheduler every two k-steps: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments =
+            // 160 VGPRs), which costs the occupancy that hides the feature-load latency
+            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -89,7 +92,7 @@ struct SmallInput {
 };
 
 template <int IN_KS, int V_KS, int NL, int NLC, bool LM>
-__global__ void __launch_bounds__(64 * WAVES)
+__global__ void __launch_bounds__(64 * WAVES, 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
     using Plan = SmallPlan<IN_KS, V_KS, NL, NLC>;
@@ -270,7 +273,7 @@ static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t
     const size_t lds = (size_t)Plan::total() * 1024;
     if (lds != m->packed_f16_bytes) { set_error("internal: packed weight image is %zu bytes, kernel expects %zu", m->packed_f16_bytes, lds); return NRF_ERR_INVALID_ARG; }
     const int64_t nblocks = ceil_div(p, BLOCK_PTS);
-    const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);      // persistent: 256 CUs x up to 4 resident workgroups
+    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);        // persistent: 256 CUs x 3 resident workgroups (146 VGPRs, 40-46 KB LDS)
     if (lm) hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, true>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
     else hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, false>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
     NRF_LAUNCH_CHECK();

@@ -139,6 +139,11 @@ class CuHashEmbedder(_HashBase):
     Table `embedder_embeddings` [L*2^T, F] fp32 master (cast to fp16 once at upload); per-level primes/biases."""
     mode = L.NRF_HASH_CU
 
+    def set_dense_budget(self, nbytes):
+        """Tuning knob: bytes of baked dense image for the coarse levels of the fast path (0 = all levels hashed)."""
+        lib = L.lib()
+        L.check(lib.nrf_dbg_hash_dense_budget(self._h, C.c_int64(int(nbytes)), _stream()))
+
     def set_primes(self, primes, biases=None):
         p = np.ascontiguousarray(primes, np.int32).reshape(-1)
         assert p.size == self.NLevels * 3

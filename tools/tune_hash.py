@@ -50,11 +50,11 @@ def main():
         for lv in range(16):
             med, mn = timeit(lambda: L.check(lib.nrf_dbg_hash_lm(h, P(pts), C.c_int64(npts), 0, lv, lv + 1, P(feats), P(keep), None)), n=5)
             print(f"      level {lv:2d} alone: {med*1e3:7.1f} us", end="" if lv % 4 != 3 else "\n")
-        for variant in (0, 1, 2, 4, 5):
+        for variant in (0, 1, 8, 16, 24, 9, 17):
             feats.zero_()
             med, mn = timeit(lambda: L.check(lib.nrf_dbg_hash_lm(h, P(pts), C.c_int64(npts), variant, 0, -1, P(feats), P(keep), None)))
             same = bool((feats.permute(1, 0, 2).reshape(npts, 32).float() == ref).all())
-            print(f"    variant {variant} (ppt={1 + (variant & 1)}, xcd={(variant >> 1) & 3}): {med:.3f} ms (min {mn:.3f})  {npts/med/1e6:.2f} Gpts/s  "
+            print(f"    variant {variant} (ppt={1 + (variant & 1)}, xcd={(variant >> 1) & 3}, gather={(variant >> 3) & 3}): {med:.3f} ms (min {mn:.3f})  {npts/med/1e6:.2f} Gpts/s  "
                   f"alg {npts*588/med/1e6:.0f} GB/s ({npts*588/med/1e6/8000*100:.1f}% of 8 TB/s)  bit-identical={same}")
 
 
