@@ -22,7 +22,7 @@ struct HashParams {
     // baked dense image of the coarse levels (hash_fast.hip): entry offset into `dense` (-1: level stays hashed) and block grid
     const void *dense;
     int64_t dense_off[NRF_MAX_LEVELS];
-    int32_t dense_nby[NRF_MAX_LEVELS], dense_nbz[NRF_MAX_LEVELS];
+    int32_t dense_nby[NRF_MAX_LEVELS], dense_nbz[NRF_MAX_LEVELS];   // (x,y) tiles per row; z extent
 };
 
 }  // namespace nrf
@@ -38,7 +38,7 @@ struct nrf_hash {
     size_t fast_bytes = 0;
     bool fast_valid = false;
     int dense_levels = 0;
-    size_t dense_budget = (size_t)12 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 1.1 GB at 16..512, 8.6 GB at 16..1024 -- HBM is 288 GB
+    size_t dense_budget = (size_t)24 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 2.2 GB at 16..512, 17 GB at 16..1024 -- HBM is 288 GB
 };
 
 namespace nrf {

@@ -34,15 +34,16 @@ __device__ __forceinline__ PointPrep prep_point(const HashParams &hp, const F3 &
 }
 
 // One (point, level): 8 half2 gathers issued back to back, then the fp32 blend in the reference's order.
-// Dense ("baked") image of a level: the value of every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, copied out of the
-// hashed table once at model load.  Vertices are stored in 4x4x2 bricks of 32 half2 = one 128-B line, so the 8 corners of a
-// voxel fall into 2.3 lines on average (8 for the hashed table) and consecutive samples along a ray share lines.  The lookup
-// result is the same table entry the hash would have selected: outputs are bit-identical.
-__device__ __forceinline__ uint32_t dense_index(uint32_t x, uint32_t y, uint32_t z, uint32_t nby, uint32_t nbz)
-{
-    const uint32_t blk = ((x >> 2) * nby + (y >> 2)) * nbz + (z >> 1);
-    return blk * 32u + (((x & 3u) << 3) | ((y & 3u) << 1) | (z & 1u));
-}
+// Dense ("baked") image of a level: for every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, the PAIR of table
+// values of (x,y,z) and (x,y,z+1), copied out of the hashed table once at model load (8 bytes: two half2).  A voxel's 8
+// corners are then 4 eight-byte loads instead of 8 four-byte gathers.  Vertices are grouped in 4x4 (x,y) tiles of 16 pairs
+// = one 128-B line, tiles of one (x,y) column stacked along z, so the 4 loads of a lookup fall into 1.56 lines on average
+// (8 for the hashed table) and consecutive samples along a ray share lines / walk adjacent ones.  Each lookup returns the
+// same table entries the hash would have selected: outputs are bit-identical.  Costs 2x the vertices in memory (2.2 GB at
+// 16..512) -- HBM is 288 GB.
+struct DensePair { __half2 lo, hi; };
+
+__device__ __forceinline__ uint32_t dense_tile(uint32_t x, uint32_t y, uint32_t nby) { return (x >> 2) * nby + (y >> 2); }
 
 template <int GATHER>
 __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, int l, __amdgpu_buffer_rsrc_t rsrc)
@@ -60,15 +61,25 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
     }
     float acc[2];
     if (hp.dense_off[l] >= 0) {                 // wave-uniform
-        const __half2 *dp = reinterpret_cast<const __half2 *>(hp.dense) + hp.dense_off[l];
-        const uint32_t nby = (uint32_t)hp.dense_nby[l], nbz = (uint32_t)hp.dense_nbz[l];
+        const uint2 *dp = reinterpret_cast<const uint2 *>(hp.dense) + hp.dense_off[l];
+        const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
         const float a = fr[0], b = fr[1], c = fr[2];
         const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
+        const uint32_t x0 = pos[0], x1 = pos[0] + 1u, y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
+        const uint32_t tx0 = (x0 >> 2) * nby, tx1 = (x1 >> 2) * nby, ty0 = y0 >> 2, ty1 = y1 >> 2;
+        const uint32_t ix0 = (x0 & 3u) << 2, ix1 = (x1 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
+        uint2 pr[4];
+        pr[0] = dp[(((tx0 + ty0) * dz + z) << 4) | ix0 | iy0];
+        pr[1] = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];
+        pr[2] = dp[(((tx1 + ty0) * dz + z) << 4) | ix1 | iy0];
+        pr[3] = dp[(((tx1 + ty1) * dz + z) << 4) | ix1 | iy1];
         float2 v[8];
         float ws[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            v[k] = __half22float2(dp[dense_index(pos[0] + ((k >> 2) & 1), pos[1] + ((k >> 1) & 1), pos[2] + (k & 1), nby, nbz)]);
+            const uint32_t w = (k & 1) ? pr[k >> 1].y : pr[k >> 1].x;
+            __half2 hv; __builtin_memcpy(&hv, &w, 4);
+            v[k] = __half22float2(hv);
             const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
             ws[k] = wx * wy * wz;
         }
@@ -85,19 +96,21 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
     return __halves2half2(__float2half_rn(acc[0]), __float2half_rn(acc[1]));
 }
 
-__global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries, __half2 *__restrict__ dst)
+__global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries, uint2 *__restrict__ dst)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= entries) return;
-    const uint32_t nby = (uint32_t)hp.dense_nby[l], nbz = (uint32_t)hp.dense_nbz[l];
-    const uint32_t w = (uint32_t)(i & 31), blk = (uint32_t)(i >> 5);
-    const uint32_t bz = blk % nbz, by = (blk / nbz) % nby, bx = blk / (nbz * nby);
-    const uint32_t x = bx * 4 + (w >> 3), y = by * 4 + ((w >> 1) & 3), z = bz * 2 + (w & 1);
-    __half2 v = __halves2half2(__float2half_rn(0.0f), __float2half_rn(0.0f));
-    if (x < dim && y < dim && z < dim) {
-        const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
-        const uint32_t hv = ((x * pa) ^ (y * pb) ^ (z * pc)) % hp.local_size[l];
-        v = *reinterpret_cast<const __half2 *>(reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l] + (size_t)hv * 2);
+    const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
+    const uint32_t w = (uint32_t)(i & 15);
+    const int64_t col = i >> 4;                       // (tile * dz + z)
+    const uint32_t z = (uint32_t)(col % dz), tile = (uint32_t)(col / dz);
+    const uint32_t x = (tile / nby) * 4 + (w >> 2), y = (tile % nby) * 4 + (w & 3);
+    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+    const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
+    uint2 v{0u, 0u};
+    if (x < dim && y < dim) {
+        if (z < dim) { const uint32_t hv = ((x * pa) ^ (y * pb) ^ (z * pc)) % hp.local_size[l]; v.x = *reinterpret_cast<const uint32_t *>(fp + (size_t)hv * 2); }
+        if (z + 1 < dim) { const uint32_t hv = ((x * pa) ^ (y * pb) ^ ((z + 1) * pc)) % hp.local_size[l]; v.y = *reinterpret_cast<const uint32_t *>(fp + (size_t)hv * 2); }
     }
     dst[i] = v;
 }
@@ -117,26 +130,26 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
     if (zero_bias && h->desc.mode == NRF_HASH_CU && h->desc.n_features == 2) {
         for (int l = 0; l < L; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
-            const int64_t nbx = (dim + 3) / 4, nby = (dim + 3) / 4, nbz = (dim + 1) / 2;
-            const int64_t entries = nbx * nby * nbz * 32;
-            if ((size_t)(total + entries) * 4 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
-            hp.dense_off[l] = total; hp.dense_nby[l] = (int32_t)nby; hp.dense_nbz[l] = (int32_t)nbz;
+            const int64_t nbx = (dim + 3) / 4, nby = (dim + 3) / 4;
+            const int64_t entries = nbx * nby * dim * 16;                 // 8-byte (z, z+1) pairs
+            if ((size_t)(total + entries) * 8 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
+            hp.dense_off[l] = total; hp.dense_nby[l] = (int32_t)nby; hp.dense_nbz[l] = (int32_t)dim;
             total += entries; nb = l + 1;
         }
     }
     if (nb > 0) {
-        if (h->fast_bytes < (size_t)total * 4) {
+        if (h->fast_bytes < (size_t)total * 8) {
             if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
             h->d_fast = nullptr; h->fast_bytes = 0;
-            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 4));
-            h->fast_bytes = (size_t)total * 4;
+            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 8));
+            h->fast_bytes = (size_t)total * 8;
         }
         hp.dense = h->d_fast;
         for (int l = 0; l < nb; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
             const int64_t entries = (l + 1 < nb ? hp.dense_off[l + 1] : total) - hp.dense_off[l];
             hipLaunchKernelGGL(k_bake_dense, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
-                               reinterpret_cast<__half2 *>(h->d_fast) + hp.dense_off[l]);
+                               reinterpret_cast<uint2 *>(h->d_fast) + hp.dense_off[l]);
             NRF_LAUNCH_CHECK();
         }
     }
