@@ -119,7 +119,7 @@ def main():
         sc = scene.make_hash_scene(mode=args.hash_mode)
         if args.dense_mb >= 0 and args.hash_mode == "cu":
             sc["embedder"].set_dense_budget(int(args.dense_mb * (1 << 20)))
-        chunk = args.chunk or 32768
+        chunk = args.chunk or 131072
     else:
         sc = scene.make_classic_scene()
         chunk = args.chunk or 8192
@@ -169,9 +169,10 @@ def main():
             units_per_launch = (H * W // world) * world * UNITS_PER_RAY * args.steps / max(k["launches"], 1)
             dur = k["ms"] * 1e-3 / max(k["launches"], 1)
             achieved = units_per_launch * HASH_BYTES_PER_UNIT / max(dur, 1e-12)
+            traffic, traffic_src = pmc_traffic("hash_encode (k_hash_cu_lm)", units_per_launch)
             roof = dict(bound="hbm", kernel="hash_encode", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=achieved / HBM_PEAK,
-                        traffic=None, launches=k["launches"], avg_launch_ms=dur * 1e3, units_per_launch=units_per_launch,
-                        bytes_per_unit=HASH_BYTES_PER_UNIT)
+                        traffic=traffic, traffic_source=traffic_src, launches=k["launches"], avg_launch_ms=dur * 1e3,
+                        units_per_launch=units_per_launch, bytes_per_unit=HASH_BYTES_PER_UNIT)
             mk = prof["mlp"]
             mdur = mk["ms"] * 1e-3
             mlp_peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
@@ -213,6 +214,22 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, units_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
+    by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench), rescaled to this run's
+    units per launch.  None if no PMC summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        k = d[kernel]
+        per_unit = k["hbm_bytes_per_launch"] / d["_meta"]["units_per_launch"]
+        return per_unit * units_per_launch, f"profiles/pmc_latest.json ({d['_meta']['source']}): (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, gfx950 x2 read correction"
+    except Exception:
+        return None, None
 
 
 def quality_check(sc, renderer, rp, K, c2w, args, nrays=256):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnerfpp_hip.so")
+LIB_PATH = os.environ.get("NRF_LIB_PATH") or os.path.join(_HERE, "lib", "libnerfpp_hip.so")   # NRF_LIB_PATH: tuning builds only
 
 NRF_OK = 0
 NRF_HASH_NGP, NRF_HASH_CU = 0, 1

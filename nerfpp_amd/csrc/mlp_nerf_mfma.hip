@@ -5,12 +5,11 @@
 // v_mfma_f32_32x32x16_f16, A = weights (32 neurons x 16 k), B = activations (16 k x 32 points).  A layer's 32 x 32 fp32
 // output tiles become, after bias + ReLU + fp16 conversion, the B fragments of the next layer IN PLACE (registers 8s..8s+7
 // of a tile = k-step s; the k permutation inside a k-step is folded into the weight image), so activations never leave
-// the register file: one wavefront carries 64 points (two 32-point tiles sharing every weight fragment) through all 11 GEMMs.
+// the register file: one wavefront carries 32 points through all 11 GEMMs.
 //
 // What does not fit on chip is the weights: 1.16 MB of fp16 against 160 KB of LDS per CU.  The weight image
 // is therefore cut into 40 CHUNKS (two 32-neuron tiles x all k-steps of a layer, <= 40 KB) laid out in consumption
-// order; a 256-thread workgroup (4 waves x 64 points = 256 points, one workgroup per CU, one wave per SIMD owning the whole
-// 512-entry register file, persistent) streams chunk i+1 from L2 into registers while its waves run the MFMAs of chunk i
+// order; a 512-thread workgroup (8 waves x 32 points = 256 points, one workgroup per CU, two waves per SIMD, persistent) streams chunk i+1 from L2 into registers while its waves run the MFMAs of chunk i
 // out of LDS, and writes it to the other LDS buffer before the
 // barrier that ends the chunk (issue-early / write-late staging).  Every A fragment is one conflict-free ds_read_b128.
 // L2 -> LDS weight traffic is 1.16 MB per 256 points, ~4.6 KB per point.
@@ -31,8 +30,15 @@ namespace nrf {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NW = 4;                  // waves per workgroup: one per SIMD, each owning the whole 512-entry register file
-constexpr int NPT = 2;                 // 32-point tiles per wave (every weight fragment read from LDS feeds NPT MFMAs)
+// Measured on MI355X (bench --workload classic): 8 waves x 1 point tile = 1021 TFLOP/s (40.9 % of the 2.5 PF dense fp16 peak);
+// 4 waves x 2 tiles (one wave per SIMD, half the LDS fragment reads) = 779 TFLOP/s: with a single wave per SIMD nothing
+// covers the bias/ReLU/convert epilogue between tiles, with two the other wave's MFMAs do.
+#ifndef NRF_NERF_NW
+#define NRF_NERF_NW 8
+#define NRF_NERF_NPT 1
+#endif
+constexpr int NW = NRF_NERF_NW;        // waves per workgroup
+constexpr int NPT = NRF_NERF_NPT;      // 32-point tiles per wave (every weight fragment read from LDS feeds NPT MFMAs)
 constexpr int NBLK = 32 * NPT * NW;    // points per workgroup iteration
 constexpr int MAXF = 40;               // fragments (1 KB each) in the largest chunk
 constexpr int NBIAS = 8 * 256 + 288 + 128 + 32;
@@ -187,8 +193,18 @@ __device__ __forceinline__ void nerf_layer(const Ctx &cx, const half8 (&bn)[NPT]
     nerf_layer_seq<L, RELU>(cx, bn, bc, bout, last, std::make_integer_sequence<int, NerfNet::chunks(L)>{});
 }
 
+// Input: fp32 rows [p, 90] = [PE(10)(x) | PE(4)(dir)] (the generic BaseNeRF::forward boundary), or -- FUSED, the renderer's
+// fast path -- the packed rays, the depth table and per-RAY fp16 direction encodings: the kernel forms x = o + d*z
+// (NeRFRenderer.h:419) and its 63 sinusoidal features (NeRF.cpp:33-37, same nrf_sincosf as the stand-alone encoder, so the
+// operand fragments are bit-identical to the unfused path) in registers; no [P, 90] input is ever written.
+struct NerfInput {
+    const float *x; int x_stride;
+    const float *rays; int ray_stride; const float *z; int s; const __half *dirs;    // dirs: [n, 32] fp16, PE(4) of the view direction, zero padded
+};
+
+template <bool FUSED>
 __global__ void __launch_bounds__(64 * NW)
-k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const half8 *__restrict__ packed, const float *__restrict__ biases,
+k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, const float *__restrict__ biases,
                 float *__restrict__ out, int out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -196,6 +212,8 @@ k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const h
     constexpr int BIAS_BYTES = (NBIAS * 4 + 1023) / 1024 * 1024;
     float *bias_s = reinterpret_cast<float *>(smem);
     half8 *wbuf = reinterpret_cast<half8 *>(smem + BIAS_BYTES);
+    // the position fragments are needed twice (layer 0 and the skip layer 5): parked in LDS in between (4 KB per wave per tile)
+    half8 *pe_park = reinterpret_cast<half8 *>(smem + BIAS_BYTES + 2 * MAXF * 1024) + (size_t)(threadIdx.x >> 6) * (NPT * 4 * 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     for (int i = tid; i < NBIAS; i += 64 * NW) bias_s[i] = biases[i];
@@ -209,31 +227,55 @@ k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const h
     const int64_t nblocks = (npts + NBLK - 1) / NBLK;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         Ctx cx{wbuf, bias_s, rsrc, tid, lane, h, blk + gridDim.x >= nblocks};
-        int64_t p[NPT];
-        bool live[NPT];
-        const float *row[NPT];
-#pragma unroll
-        for (int pt = 0; pt < NPT; pt++) {
-            p[pt] = blk * NBLK + (wave * NPT + pt) * 32 + r;
-            live[pt] = p[pt] < npts;
-            if (!live[pt]) p[pt] = npts - 1;
-            row[pt] = x + p[pt] * x_stride;
-        }
+        // point index of this lane's column in tile pt (recomputed where needed: nothing per-point stays live across the network)
+        auto point_of = [&](int pt) -> int64_t { return blk * NBLK + (wave * NPT + pt) * 32 + r; };
+        auto clamped = [&](int pt) -> int64_t { const int64_t q = point_of(pt); return q < npts ? q : npts - 1; };
         // natural-order operand fragments: element j of k-step s is input 16s + 8h + j.  They are (re)loaded right where a
         // layer consumes them (L0, L5: positions; L9: directions) instead of being kept live across the whole network.
         auto load_pe = [&](half8 (&pe)[NPT][4]) {
 #pragma unroll
-            for (int pt = 0; pt < NPT; pt++)
+            for (int pt = 0; pt < NPT; pt++) {
+                const int64_t q = clamped(pt);
+                float px[3] = {0.0f, 0.0f, 0.0f};
+                const float *row = nullptr;
+                if constexpr (FUSED) {
+                    const float *rp = in.rays + (int64_t)((uint32_t)q / (uint32_t)in.s) * in.ray_stride;
+                    const float zz = in.z[q];
+                    px[0] = rp[0] + rp[3] * zz; px[1] = rp[1] + rp[4] * zz; px[2] = rp[2] + rp[5] * zz;
+                } else row = in.x + q * in.x_stride;
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) pe[pt][s][j] = (_Float16)row[pt][16 * s + 8 * h + j];  // index 63 is the first view feature: its weight column is zero
+                    for (int j = 0; j < 8; j++) {
+                        if constexpr (FUSED) {
+                            // feature index k = 16s + 8h + j: [x(3) | per frequency f: sin(x 2^f)(3), cos(x 2^f)(3)].  Both lane halves'
+                            // indices are COMPILE-TIME constants and h only selects between them: index arithmetic on h would be
+                            // hoisted out of the persistent loop as ~90 loop-invariant VGPRs and spilled.
+                            constexpr auto arg_axis = [](int k) { return k < 3 ? k : ((k - 3) % 6) % 3; };
+                            constexpr auto arg_freq = [](int k) { return k < 3 ? 0 : (k - 3) / 6; };
+                            constexpr auto kind = [](int k) { return k < 3 ? 0 : k >= 63 ? 3 : (((k - 3) % 6) < 3 ? 1 : 2); };   // 0 raw, 1 sin, 2 cos, 3 pad
+                            const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+                            const float a0 = px[arg_axis(k0)] * __builtin_ldexpf(1.0f, arg_freq(k0));
+                            const float a1 = px[arg_axis(k1 < 63 ? k1 : 0)] * __builtin_ldexpf(1.0f, arg_freq(k1 < 63 ? k1 : 0));
+                            float sn, cs;
+                            nrf_sincosf(h ? a1 : a0, &sn, &cs);
+                            const int kd0 = kind(k0), kd1 = kind(k1);
+                            const float v0 = kd0 == 0 ? px[arg_axis(k0)] : kd0 == 1 ? sn : kd0 == 2 ? cs : 0.0f;
+                            const float v1 = kd1 == 0 ? px[arg_axis(k1 < 63 ? k1 : 0)] : kd1 == 1 ? sn : kd1 == 2 ? cs : 0.0f;
+                            pe[pt][s][j] = (_Float16)(h ? v1 : v0);
+                        } else pe[pt][s][j] = (_Float16)row[16 * s + 8 * h + j];  // index 63 is the first view feature: its weight column is zero
+                    }
+            }
         };
         half8 ba[NPT][16], bb[NPT][16], none[NPT][1];
         f32x16 last[NPT];
         {
             half8 pe[NPT][4];
             load_pe(pe);
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) pe_park[(pt * 4 + s) * 64 + lane] = pe[pt][s];
             nerf_layer<0, true>(cx, pe, none, ba, last);
         }
         nerf_layer<1, true>(cx, none, ba, bb, last);
@@ -242,7 +284,10 @@ k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const h
         nerf_layer<4, true>(cx, none, bb, ba, last);
         {
             half8 pe[NPT][4];
-            load_pe(pe);
+#pragma unroll
+            for (int pt = 0; pt < NPT; pt++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) pe[pt][s] = pe_park[(pt * 4 + s) * 64 + lane];     // own lane's data: no barrier needed
             nerf_layer<5, true>(cx, pe, ba, bb, last);
         }
         nerf_layer<6, true>(cx, none, bb, ba, last);
@@ -254,21 +299,30 @@ k_mlp_nerf_mfma(int64_t npts, const float *__restrict__ x, int x_stride, const h
         {
             half8 vw[NPT][2];
 #pragma unroll
-            for (int pt = 0; pt < NPT; pt++)
+            for (int pt = 0; pt < NPT; pt++) {
+                const int64_t q = clamped(pt);
 #pragma unroll
-                for (int s = 0; s < 2; s++)
+                for (int s = 0; s < 2; s++) {
+                    if constexpr (FUSED) vw[pt][s] = *reinterpret_cast<const half8 *>(in.dirs + (int64_t)((uint32_t)q / (uint32_t)in.s) * 32 + 16 * s + 8 * h);
+                    else {
+                        const float *row = in.x + q * in.x_stride;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { const int k = 16 * s + 8 * h + j; vw[pt][s][j] = (k < 27) ? (_Float16)row[pt][63 + k] : (_Float16)0.0f; }
+                        for (int j = 0; j < 8; j++) { const int k = 16 * s + 8 * h + j; vw[pt][s][j] = (k < 27) ? (_Float16)row[63 + k] : (_Float16)0.0f; }
+                    }
+                }
+            }
             nerf_layer<9, true>(cx, vw, ba, bb, last);          // 4 tiles -> bb[..][0..7]
         }
         nerf_layer<10, false>(cx, none, bb, ba, last);
         if (h == 0) {
 #pragma unroll
-            for (int pt = 0; pt < NPT; pt++)
-                if (live[pt]) {
-                    float *o = out + p[pt] * out_stride;
+            for (int pt = 0; pt < NPT; pt++) {
+                const int64_t q = point_of(pt);
+                if (q < npts) {
+                    float *o = out + q * out_stride;
                     o[0] = last[pt][0]; o[1] = last[pt][1]; o[2] = last[pt][2]; o[3] = alpha[pt];
                 }
+            }
         }
     }
 }
@@ -348,23 +402,68 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     return NRF_OK;
 }
 
-int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
+static int launch_nerf(const nrf_mlp *m, const NerfInput &in, bool fused, int64_t p, float *out, int os, hipStream_t st)
 {
     if (!m->d_packed_f16) {
         set_error("NRF_PREC_F16_MFMA: this NeRF shape is outside the built matrix-core family (8 x 256, skip 4, PE(10)/PE(4), view directions); use NRF_PREC_F32");
         return NRF_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)2 * MAXF * 1024 + ((size_t)NBIAS * sizeof(float) + 1023) / 1024 * 1024;
+    const size_t lds = (size_t)2 * MAXF * 1024 + ((size_t)NBIAS * sizeof(float) + 1023) / 1024 * 1024 + (size_t)NW * NPT * 4 * 1024;
     const int64_t nblocks = ceil_div(p, NBLK);
-    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent 8-wave workgroup per CU
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent workgroup per CU
     static bool attr_set = false;
     if (!attr_set) {
-        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const half8 *packed = reinterpret_cast<const half8 *>(m->d_packed_f16);
     const float *biases = reinterpret_cast<const float *>(static_cast<const char *>(m->d_packed_f16) + (size_t)NerfNet::total_frags() * 1024);
-    hipLaunchKernelGGL(k_mlp_nerf_mfma, dim3(grid), dim3(64 * NW), lds, st, p, x, xs, packed, biases, out, os);
+    if (fused) hipLaunchKernelGGL(k_mlp_nerf_mfma<true>, dim3(grid), dim3(64 * NW), lds, st, p, in, packed, biases, out, os);
+    else hipLaunchKernelGGL(k_mlp_nerf_mfma<false>, dim3(grid), dim3(64 * NW), lds, st, p, in, packed, biases, out, os);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
+{
+    NerfInput in{x, xs, nullptr, 0, nullptr, 1, nullptr};
+    return launch_nerf(m, in, false, p, out, os, st);
+}
+
+int mlp_nerf_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_NERF && m->d_packed_f16 != nullptr; }
+
+// renderer fast path: points from (rays, z), PE in registers, per-ray fp16 direction encodings -> raw [p,4]
+int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st)
+{
+    ProfScope prof(NRF_PROF_MLP, st);
+    NerfInput in{nullptr, 0, rays, ray_stride, z, s, dirs};
+    return launch_nerf(m, in, true, p, out, 4, st);
+}
+
+// per-ray PE(4) of the view direction as fp16 rows [n, 32] (27 features, zero padded): the L9 operand of the fused path
+__global__ void k_dirs_pe_f16(int64_t n, const float *__restrict__ rays, int stride, __half *__restrict__ out)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * 32) return;
+    const int64_t i = gid >> 5;
+    const int k = (int)(gid & 31);
+    const float *dp = rays + i * stride + 8;
+    float v = 0.0f;
+    if (k < 3) v = dp[k];
+    else if (k < 27) {
+        const int f = (k - 3) / 6, q = (k - 3) - 6 * f;
+        float sn, cs;
+        nrf_sincosf(dp[q < 3 ? q : q - 3] * __builtin_ldexpf(1.0f, f), &sn, &cs);
+        v = q < 3 ? sn : cs;
+    }
+    out[gid] = __float2half_rn(v);
+}
+
+int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st)
+{
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_dirs_pe_f16, dim3((unsigned)ceil_div(n * 32, 256)), dim3(256), 0, st, n, rays, stride, out);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

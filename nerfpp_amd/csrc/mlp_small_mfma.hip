@@ -22,7 +22,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PT = 2;            // 32-point tiles per wave
+#ifndef NRF_SMALL_PT
+#define NRF_SMALL_PT 2
+#endif
+constexpr int PT = NRF_SMALL_PT; // 32-point tiles per wave
 constexpr int WAVES = 4;
 constexpr int BLOCK_PTS = 32 * PT * WAVES;
 

@@ -472,3 +472,20 @@ def test_libtorch_adapter_drop_in_inside_reference_renderer():
     assert out.returncode == 0 and r["ok"], r
     assert r["hash_embedding_bit_exact"] and r["sh_bit_exact"] and r["shapes_near_far_equal"]
     assert r["pixels_within_1e-4"] >= 0.90 and r["psnr_db"] > 55, r
+
+
+def test_classic_fused_path_equals_stagewise_f16(api):
+    """Classic NeRF fast path (points + PE formed inside the 8x256 matrix-core kernel) == Embedder.forward -> cat -> NeRF.forward(F16)."""
+    sc = api.S.make_classic_scene()
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=api.L.NRF_PREC_F16_MFMA, ReturnRaw=True, KeepIntermediates=True)
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=1)           # 800 rays, two ragged chunks
+    rays = res.Extras["rays_flat"]
+    for z, raw in ((res.Extras["z_coarse"], res.Extras["raw_coarse"]), (res.Extras["z_fine"], res.Raw)):
+        n, s = z.shape
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        emb, _ = sc["embedder"].forward(pts)
+        dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+        x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+        ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_MFMA)
+        assert_exact(host(raw).reshape(-1, 4), host(ref), "fused classic raw == stage-wise F16 raw")

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc counter CSVs written by tools/gpu_pmc.sh into one JSON of per-kernel averages per dispatch.
+
+usage: tools/pmc_summary.py gpurun_out/<tag> profiles/round1/<name>.json
+FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived metrics).  `hbm_bytes_per_launch` applies the gfx950 correction of
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B fabric read requests at 64 B -> x2 on the read side."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+tag, out = sys.argv[1], sys.argv[2]
+res = {}
+for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}_*/*/*_counter_collection.csv"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        short = k.split("(")[0].replace("void ", "").strip()
+        if "k_hash_cu_lm" in k: short = "hash_encode (k_hash_cu_lm)"
+        elif "k_mlp_small_mfma" in k: short = "mlp_small (k_mlp_small_mfma)"
+        elif "k_mlp_nerf_mfma" in k: short = "mlp_nerf (k_mlp_nerf_mfma)"
+        for c, x in v.items():
+            res.setdefault(short, {})[c] = sum(x) / len(x)
+            res[short]["dispatches"] = len(x)
+for k, v in res.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+    if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
+        v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+res = {k: v for k, v in res.items() if k.startswith(("hash_encode", "mlp_", "nrf::"))}
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(f"wrote {out}: {len(res)} kernels")
