@@ -107,11 +107,9 @@ __device__ __forceinline__ half8 nerf_tile_to_frag(const f32x16 &acc, int s)
 {
     half8 r;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        float v = acc[8 * s + j];
-        if (RELU) v = v > 0.0f ? v : 0.0f;
-        r[j] = (_Float16)v;
-    }
+    for (int j = 0; j < 8; j++) r[j] = (_Float16)acc[8 * s + j];
+    // ReLU after the (monotonic) rounding: max(round(x), 0) == round(max(x, 0)); packed, 4 v_pk_max_f16 instead of 8 v_max_f32
+    if (RELU) r = __builtin_elementwise_max(r, half8{0, 0, 0, 0, 0, 0, 0, 0});
     return r;
 }
 
