@@ -183,8 +183,10 @@ def main():
             dur_total = k["ms"] * 1e-3
             flops = units_per_step * args.steps * NERF_FLOP_PER_UNIT
             peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
+            upl = units_per_step * args.steps / max(k["launches"], 1)
+            traffic, traffic_src = pmc_traffic("mlp_nerf (k_mlp_nerf_mfma)", upl, "classic_units_per_launch")
             roof = dict(bound="mfma", kernel="mlp_nerf", achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                        frac=flops / max(dur_total, 1e-12) / peak, traffic=None, launches=k["launches"],
+                        frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
                         avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT)
         line = {
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
@@ -216,7 +218,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, units_per_launch):
+def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
     by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench), rescaled to this run's
     units per launch.  None if no PMC summary is committed."""
@@ -226,7 +228,7 @@ def pmc_traffic(kernel, units_per_launch):
     try:
         d = json.load(open(path))
         k = d[kernel]
-        per_unit = k["hbm_bytes_per_launch"] / d["_meta"]["units_per_launch"]
+        per_unit = k["hbm_bytes_per_launch"] / d["_meta"][meta_key]
         return per_unit * units_per_launch, f"profiles/pmc_latest.json ({d['_meta']['source']}): (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, gfx950 x2 read correction"
     except Exception:
         return None, None
