@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
     ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (self-test of the N > 1 code path)")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
     args = ap.parse_args()
 
@@ -109,8 +110,10 @@ def main():
     from nerfpp_amd import _lib as L, scene
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from nerfpp_amd.dist import TileShard
 
@@ -128,14 +131,14 @@ def main():
     K = scene.lego_K(H, W)
     # frames of one step: N poses on the reference's test orbit (pose_spherical(theta, -30, 4), theta step 9 degrees)
     poses = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(world)]
-    shard = TileShard(H, W, rank, world)
+    shard = TileShard(H, W, rank, world, force_collective=args.force_dist)
 
     def step():
         tiles = [renderer.Render(H, W, K, rp, c2w=c2w, row0=shard.row0, rows=shard.rows).Outputs.RGBMap for c2w in poses]
         return shard.all_gather_frames(tiles)     # [N frames, H, W, 3] on every rank; identity at N = 1
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +156,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.lib().nrf_profile_read(ms, cnt, 1)
     L.lib().nrf_profile_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -213,9 +216,16 @@ def main():
         except Exception as e:
             line["psnr_vs_oracle_db"] = f"unavailable: {e}"
         assert frames.shape[0] == world and bool(torch.isfinite(frames).all())
-        print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio when the process exits; the contract is ONE JSON line, so drain what is
+        # buffered, print the line, flush, and leave without running exit-time printers (the process group is already destroyed).
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
+        if use_dist:
+            os._exit(0)
 
 
 def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):

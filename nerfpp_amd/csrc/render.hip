@@ -265,7 +265,9 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
 int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
                     const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream)
 {
-    NRF_CHECK_ARG(r && d_rays && p && d_t && out, "nrf_render_rays: null pointer");
+    NRF_CHECK_ARG(r && p && out, "nrf_render_rays: null pointer");
+    if (n == 0) return NRF_OK;
+    NRF_CHECK_ARG(d_rays && d_t, "nrf_render_rays: null pointer");
     NRF_CHECK_ARG(n >= 0 && (ray_stride == 8 || ray_stride == 11), "nrf_render_rays: ray_stride must be 8 or 11 (NeRFRenderer.h:580-583)");
     NRF_CHECK_ARG(p->n_samples >= 1 && p->n_importance >= 0, "nrf_render_rays: bad sample counts");
     NRF_CHECK_ARG(p->n_importance == 0 || d_u, "nrf_render_rays: n_importance > 0 needs the u table");

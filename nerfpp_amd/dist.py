@@ -12,8 +12,9 @@ import torch.distributed as dist
 
 
 class TileShard:
-    def __init__(self, h, w, rank=0, world=1):
+    def __init__(self, h, w, rank=0, world=1, force_collective=False):
         self.h, self.w, self.rank, self.world = h, w, rank, world
+        self.force_collective = force_collective
         base, rem = divmod(h, world)
         self.rows_of = [base + (1 if r < rem else 0) for r in range(world)]
         self.row0_of = [sum(self.rows_of[:r]) for r in range(world)]
@@ -24,7 +25,7 @@ class TileShard:
         """tiles: list (one per frame of the step) of this rank's [rows, W, C] pixel tiles.
         Returns [frames, H, W, C] on every rank.  world == 1: a stack, no collective."""
         local = torch.stack([t.reshape(self.rows, self.w, -1) for t in tiles], 0)       # [F, rows, W, C]
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return local
         f, _, w, c = local.shape
         if self.rows != self.max_rows:                                                    # uneven split: pad to the tallest tile

@@ -489,3 +489,57 @@ def test_classic_fused_path_equals_stagewise_f16(api):
         x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
         ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_MFMA)
         assert_exact(host(raw).reshape(-1, 4), host(ref), "fused classic raw == stage-wise F16 raw")
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_cases_empty_ragged_and_limits(api):
+    import ctypes as C
+    sc = api.S.make_hash_scene(mode="cu", log2_t=14)
+    r = sc["renderer"]
+    K = api.S.lego_K(64, 64); c2w = api.S.pose_spherical(10.0, -30.0, 4.0)
+    o, d, cone = api.R.GetRays(64, 64, K, c2w)
+    o = o.reshape(-1, 3); d = d.reshape(-1, 3)
+    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA):
+        # ragged sample counts (not multiples of 64), n = 1 ray, n = 0 rays
+        p = api.S.lego_render_params(sc["bbox"], n_samples=37, n_importance=53, chunk=97, precision=prec, ReturnWeights=True)
+        full = r.Render(0, 0, None, p, rays=(o[:301], d[:301], None))
+        assert host(full.Outputs.Weights).shape == (301, 90) and np.isfinite(host(full.Outputs.RGBMap)).all()
+        one = r.Render(0, 0, None, p, rays=(o[5:6], d[5:6], None))
+        assert_exact(host(one.Outputs.RGBMap), host(full.Outputs.RGBMap)[5:6], "a single ray renders like the same ray inside a batch")
+        # coarse only
+        p0 = api.S.lego_render_params(sc["bbox"], n_samples=64, n_importance=0, chunk=128, precision=prec, ReturnWeights=True)
+        c = r.Render(0, 0, None, p0, rays=(o[:200], d[:200], None))
+        assert host(c.Outputs.Weights).shape == (200, 64)
+    empty = r.RenderRays(torch.empty((0, 11), device="cuda"), None, 64, n_importance=128)
+    assert empty.Outputs.RGBMap.shape == (0, 3)
+    # limits are reported, not silently mis-rendered
+    with pytest.raises(api.L.NrfError, match="outside the built range"):
+        r.RenderRays(torch.zeros((4, 11), device="cuda"), None, 300, n_importance=128)
+    with pytest.raises(api.L.NrfError, match="TangentScatter"):
+        r.RenderRays(torch.zeros((4, 11), device="cuda"), torch.tensor(0.001), 64, n_importance=128)
+    with pytest.raises(api.L.NrfError):
+        api.R.SamplePDF(torch.zeros((2, 63), device="cuda"), torch.zeros((2, 62), device="cuda"), 128, det=False)
+    # rays that miss the box entirely: transparent, white background, finite depth
+    far_o = torch.tensor([[10.0, 10.0, 10.0]], device="cuda").repeat(8, 1); away = torch.tensor([[1.0, 0.2, 0.1]], device="cuda").repeat(8, 1)
+    miss = r.Render(0, 0, None, api.S.lego_render_params(sc["bbox"], chunk=8), rays=(far_o, away, None))
+    assert_exact(host(miss.Outputs.AccMap), np.zeros(8, np.float32)); assert_exact(host(miss.Outputs.RGBMap), np.ones((8, 3), np.float32))
+
+
+def test_hash_fast_path_fallbacks_bit_exact(api, O):
+    """Dense pyramid off (budget 0), biased grids (dense disabled) and the default all-dense image give identical features."""
+    import ctypes as C
+    lib = api.L.lib()
+    sc = api.S.make_hash_scene(mode="cu")
+    e = sc["embedder"]
+    x = synth.synth_sym(99, (20000, 3), np.float32(1.6))
+    xd = dev(x)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    feats = torch.empty((16, x.shape[0], 2), device="cuda", dtype=torch.float16); keep = torch.empty((x.shape[0],), device="cuda", dtype=torch.uint8)
+    ref, _ = e.forward(xd)                                             # generic hashed kernel
+    outs = []
+    for budget in (1 << 34, 50 << 20, 0):
+        e.set_dense_budget(budget)
+        api.L.check(lib.nrf_dbg_hash_lm(e._h, P(xd), C.c_int64(x.shape[0]), 0, 0, -1, P(feats), P(keep), None))
+        outs.append(host(feats.permute(1, 0, 2).reshape(x.shape[0], 32).float()))
+        assert_exact(outs[-1], host(ref), f"dense budget {budget}")
+    e.set_dense_budget(1 << 34)
