@@ -157,6 +157,10 @@ typedef struct nrf_mlp nrf_mlp;
 
 NRF_API int64_t nrf_mlp_small_param_count(const nrf_mlp_small_desc *d);
 NRF_API int64_t nrf_mlp_nerf_param_count(const nrf_mlp_nerf_desc *d);
+/* LeRFImpl (LeRF.cpp:3-26) described with nrf_mlp_small_desc: input_ch = input_ch_le, num_layers = num_layers_le, hidden_dim =
+ * hidden_dim_le, geo_feat_dim = geo_feat_dim_le, hidden_dim_color = lang_embed_dim (other fields ignored). Output [p, lang_embed_dim + 1]. */
+NRF_API int64_t nrf_mlp_lerf_param_count(const nrf_mlp_small_desc *d);
+NRF_API int nrf_mlp_lerf_create(const nrf_mlp_small_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out);
 NRF_API int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out);
 NRF_API int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int params_on_device, void *stream, nrf_mlp **out);
 NRF_API void nrf_mlp_destroy(nrf_mlp *m);
@@ -174,6 +178,17 @@ NRF_API int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int p
 NRF_API int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c,
                             int white_bkgr, float *d_rgb, float *d_disp, float *d_acc, float *d_weights, float *d_depth,
                             void *stream);
+
+/* LeRF: the weights / depth part of LeRFRenderer::RawToLEOutputs (LeRFRenderer.cpp:27-76): the same sigma -> alpha -> weights
+ * arithmetic as RawToOutputs with sigma at channel `sigma_ch` of a c-wide raw tensor and no colour. */
+NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                            float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream);
+
+/* RenderCLIPEmbedding (LeRFRenderer.h:45-54): out[n, embed_dim] = normalize(sum_s weights[n,s] * embeds[n,s,:embed_dim], eps 1e-8).
+ * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]).  Relevancy(...) (LeRFRenderer.cpp:79) lives
+ * in the external RuCLIP module and is not part of this library. */
+NRF_API int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed_dim, const float *d_weights, int64_t n, int s,
+                                      float *d_out, void *stream);
 
 /* SamplePDF, deterministic branch (Sampler.h:6-43).  bins [n,nb], weights [n,nb-1], u [ns] device
  * (= linspace(0,1,ns)).  sum_vec: fp32 lanes of the host whose torch::sum order is reproduced for the

@@ -55,7 +55,8 @@ SYMBOLS = [
     "nrf_hash_encode",
     "nrf_mlp_small_param_count", "nrf_mlp_nerf_param_count", "nrf_mlp_small_create", "nrf_mlp_nerf_create", "nrf_mlp_destroy",
     "nrf_mlp_output_dims", "nrf_mlp_forward",
-    "nrf_raw2outputs", "nrf_sample_pdf", "nrf_fine_depths",
+    "nrf_mlp_lerf_param_count", "nrf_mlp_lerf_create",
+    "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays",
     "nrf_profile_enable", "nrf_profile_read",

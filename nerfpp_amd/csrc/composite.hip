@@ -36,7 +36,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // C1  RawToOutputs
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
-k_raw2outputs(int64_t n, int s, int c, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
+k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
               float *__restrict__ depth)
 {
@@ -59,13 +59,16 @@ k_raw2outputs(int64_t n, int s, int c, int white, const float *__restrict__ raw,
             zj = zr[j];
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
-            const float sig = r[3] > 0.0f ? r[3] : 0.0f;            // relu
+            const float sg = r[sigma_ch];
+            const float sig = sg > 0.0f ? sg : 0.0f;                // relu
             alpha = -nrf_expf(-sig * dist) + 1.0f;                      // :234
             const float om = 1.0f - alpha;
             lg = nrf_logf(om > 1e-10f ? om : 1e-10f);                   // :265
-            cr = nrf_sigmoidf(r[0]);                                // sigmoid, :250
-            cg = nrf_sigmoidf(r[1]);
-            cb = nrf_sigmoidf(r[2]);
+            if (rgb) {
+                cr = nrf_sigmoidf(r[0]);                            // sigmoid, :250
+                cg = nrf_sigmoidf(r[1]);
+                cb = nrf_sigmoidf(r[2]);
+            }
         }
         const double incl = wave_incl_scan((double)lg, lane);
         const double excl = carry + (incl - (double)lg);            // exclusive prefix: cat[0, cumsum][:-1] (:263-266)
@@ -255,6 +258,30 @@ k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z
     }
 }
 
+// RenderCLIPEmbedding (LeRFRenderer.h:45-54): out = normalize(sum_s w_s * e_s, eps 1e-8).  One workgroup per ray; thread = embedding
+// channel(s); the sum over samples and the squared norm accumulate in double (order-free, same definition as the oracle).
+__global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int dim, const float *__restrict__ e, const float *__restrict__ w, float *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int64_t ray = blockIdx.x;
+    const float *er = e + ray * (int64_t)s * stride;
+    const float *wr = w + ray * s;
+    double ss = 0.0;
+    for (int k = threadIdx.x; k < dim; k += 256) {
+        double acc = 0.0;
+        for (int j = 0; j < s; j++) acc += (double)(wr[j] * er[(int64_t)j * stride + k]);
+        const float v = (float)acc;
+        out[ray * dim + k] = v;
+        ss += (double)v * (double)v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = fmaxf((float)sqrt(red[0] + red[1] + red[2] + red[3]), 1e-8f);
+    for (int k = threadIdx.x; k < dim; k += 256) out[ray * dim + k] = out[ray * dim + k] / nrm;
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -267,8 +294,29 @@ int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d_dirs, i
     NRF_CHECK_ARG(d_raw && d_z && d_dirs && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs: bad argument");
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_COMPOSITE, as_stream(stream));
-    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, white_bkgr,
+    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, 3, white_bkgr,
                        d_raw, d_z, d_dirs, d_stride, d_rgb, d_disp, d_acc, d_weights, d_depth);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                    float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream)
+{
+    NRF_CHECK_ARG(d_raw && d_z && d_dirs && n >= 0 && s >= 1 && c >= 1 && sigma_ch >= 0 && sigma_ch < c && d_stride >= 3, "nrf_raw2weights: bad argument");
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_COMPOSITE, as_stream(stream));
+    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, sigma_ch, 0,
+                       d_raw, d_z, d_dirs, d_stride, (float *)nullptr, d_disp, d_acc, d_weights, d_depth);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed_dim, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_embeds && d_weights && d_out && n >= 0 && s >= 1 && embed_dim >= 1 && embed_stride >= embed_dim, "nrf_render_clip_embedding: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_clip_embedding, dim3((unsigned)n), dim3(256), 0, as_stream(stream), s, embed_stride, embed_dim, d_embeds, d_weights, d_out);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

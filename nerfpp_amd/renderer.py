@@ -275,3 +275,139 @@ class NeRFRenderer:
         all_ret.Near, all_ret.Far = nr.value, fr.value
         all_ret.Extras["rays_flat"] = rays_
         return all_ret
+
+
+# ------------------------------------------------------------------------------------------------
+# LeRFRenderer.h / LeRFRenderer.cpp  (BASELINE config 4: language-embedded radiance field render pass)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LeRFRendererOutputs:            # LeRFRenderer.h:9-18
+    LangEmbedding: Optional[torch.Tensor] = None            # [N, S, E]
+    RenderedLangEmbedding: Optional[torch.Tensor] = None    # [N, E]
+    DispMapLE: Optional[torch.Tensor] = None
+    AccMapLE: Optional[torch.Tensor] = None
+    WeightsLE: Optional[torch.Tensor] = None
+    DepthMapLE: Optional[torch.Tensor] = None
+    Relevancy: Optional[torch.Tensor] = None                # external RuCLIP `Relevancy(...)` (LeRFRenderer.cpp:79): NOT built
+
+
+@dataclass
+class LeRFRenderResult:               # LeRFRenderer.h:20-26
+    Outputs: LeRFRendererOutputs = field(default_factory=LeRFRendererOutputs)
+    Raw: Optional[torch.Tensor] = None
+    Near: float = 0.0
+    Far: float = 0.0
+    Extras: dict = field(default_factory=dict)
+
+
+def RenderCLIPEmbedding(embeds, weights):
+    """LeRFRenderer.h:45-54: embeds [N,S,>=E] (row stride may exceed E), weights [N,S] or [N,S,1] -> normalize(sum_s w*e) [N,E]."""
+    e = _dev_f32(embeds); w = _dev_f32(weights).reshape(e.shape[0], e.shape[1])
+    n, s, stride = e.shape
+    return _clip_embedding(e, stride, stride, w)
+
+
+def _clip_embedding(e, stride, dim, w):
+    n, s = w.shape
+    out = torch.empty((n, dim), device=e.device, dtype=torch.float32)
+    L.check(L.lib().nrf_render_clip_embedding(_ptr(e), stride, dim, _ptr(w), C.c_int64(n), s, _ptr(out), _stream()))
+    return out
+
+
+class LeRFRenderer:
+    """LeRFRenderer (LeRFRenderer.h:57-132, LeRFRenderer.cpp): CuHashEmbedder -> LeRF head -> sigma_le weights -> rendered CLIP
+    embedding.  Stage-composed over the C ABI (generic fp32 kernels); `Relevancy` needs the external RuCLIP text encoder and is
+    left to the caller."""
+
+    def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16):
+        self.LangEmbedFn, self.Lerf = lang_embed_fn, lerf
+        self.LerfPositives, self.LerfNegatives = lerf_positives, lerf_negatives
+        self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
+
+    def RunLENetwork(self, inputs):
+        """LeRFRenderer.cpp:5-25: [N,S,3] -> [N,S,E+1], sigma_le zeroed where the embedder's keep_mask is false."""
+        pts = _dev_f32(inputs)
+        flat = pts.reshape(-1, 3)
+        outs = []
+        for i in range(0, flat.shape[0], self.point_chunk):
+            emb, keep = self.LangEmbedFn.forward(flat[i:i + self.point_chunk])
+            o = self.Lerf.forward(emb, L.NRF_PREC_F32)
+            o[~keep, -1] = 0
+            outs.append(o)
+        out = torch.cat(outs, 0) if outs else torch.empty((0, self.Lerf.GetOutputDims()), device=pts.device)
+        return out.reshape(pts.shape[0], pts.shape[1], -1)
+
+    def RawToLEOutputs(self, raw_le, z_vals_le, rays_d, lang_embed_dim=768, raw_noise_std=0.0):
+        """LeRFRenderer.cpp:27-82 without Relevancy."""
+        if raw_noise_std > 0:
+            raise L.NrfError("raw_noise_std > 0 is the training-time noise branch; not built")
+        raw = _dev_f32(raw_le); z = _dev_f32(z_vals_le); d = _dev_f32(rays_d)
+        n, s, c = raw.shape
+        o = LeRFRendererOutputs(LangEmbedding=raw[..., :lang_embed_dim], WeightsLE=torch.empty((n, s), device=raw.device),
+                                DepthMapLE=torch.empty((n,), device=raw.device), DispMapLE=torch.empty((n,), device=raw.device),
+                                AccMapLE=torch.empty((n,), device=raw.device))
+        L.check(L.lib().nrf_raw2weights(_ptr(raw), c, lang_embed_dim, _ptr(z), _ptr(d), 3, C.c_int64(n), s, _ptr(o.WeightsLE), _ptr(o.DepthMapLE),
+                                        _ptr(o.DispMapLE), _ptr(o.AccMapLE), _stream()))
+        o.RenderedLangEmbedding = _clip_embedding(raw, c, lang_embed_dim, o.WeightsLE)
+        return o
+
+    def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
+                   raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True):
+        """LeRFRenderer.cpp:85-187 (deterministic path)."""
+        if perturb > 0 or raw_noise_std > 0 or stochastic_preconditioning_alpha > 0 or (cone_angle is not None and torch.is_tensor(cone_angle) and cone_angle.numel()):
+            raise L.NrfError("perturb / noise / preconditioning / TangentScatter are RNG branches; render with ThinRay=True, Perturb=0")
+        rays = _dev_f32(ray_batch)
+        n, stride = rays.shape
+        dev = rays.device
+        s, ni = int(n_samples), int(n_importance)
+        E = self.Lerf.GetLangEmbedDim()
+        t = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)
+        z = torch.empty((n, s), device=dev); pts = torch.empty((n, s, 3), device=dev)
+        L.check(L.lib().nrf_z_vals(_ptr(rays), stride, C.c_int64(n), _ptr(t), s, int(lin_disp), _ptr(z), _stream()))
+        L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
+        rays_d = rays[:, 3:6].contiguous()
+        raw = self.RunLENetwork(pts)
+        out1 = self.RawToLEOutputs(raw, z, rays_d, E)
+        res = LeRFRenderResult()
+        res.Outputs = out1 if ni == 0 else None        # (the reference leaves Outputs undefined when n_importance == 0; the coarse ones are returned here)
+        if ni > 0:
+            u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
+            zf = torch.empty((n, s + ni), device=dev)
+            L.check(L.lib().nrf_fine_depths(_ptr(z), _ptr(out1.WeightsLE), C.c_int64(n), s, _ptr(u), ni, ATEN_SUM_VEC, _ptr(zf), _stream()))
+            ptsf = torch.empty((n, s + ni, 3), device=dev)
+            L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(zf), C.c_int64(n), s + ni, _ptr(ptsf), _stream()))
+            raw = self.RunLENetwork(ptsf)
+            res.Outputs = self.RawToLEOutputs(raw, zf, rays_d, E)
+            res.Extras["z_fine"] = zf
+        res.Extras["z_coarse"] = z
+        if return_raw:
+            res.Raw = raw
+        if not return_weights:
+            res.Outputs.WeightsLE = None; res.Outputs.LangEmbedding = None; res.Outputs.RenderedLangEmbedding = None   # LeRFRenderer.cpp:180-185
+        return res
+
+    def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, row0=0, rows=None):
+        """LeRFRenderer.cpp:265-330."""
+        p = render_params
+        if c2w is not None:
+            rays_o, rays_d, cone_angle = GetRays(h, w, k, c2w, row0=row0, rows=rows)
+        else:
+            rays_o, rays_d, cone_angle = rays
+        bb = _host_f32(p.BoundingBox, 6)
+        o = _dev_f32(rays_o).reshape(-1, 3).contiguous(); d = _dev_f32(rays_d).reshape(-1, 3).contiguous()
+        n = o.shape[0]
+        stride = 11 if p.UseViewdirs else 8
+        rays_ = torch.empty((n, stride), device=o.device, dtype=torch.float32)
+        L.check(L.lib().nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))
+        parts = [self.RenderRays(rays_[i:i + p.Chunk], None if p.ThinRay else cone_angle, p.NSamples, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
+                                 perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
+                                 return_weights=p.ReturnWeights) for i in range(0, n, p.Chunk)]
+        res = LeRFRenderResult()
+        for name in ("RenderedLangEmbedding", "DispMapLE", "AccMapLE", "WeightsLE", "DepthMapLE"):
+            vals = [getattr(q.Outputs, name) for q in parts if getattr(q.Outputs, name) is not None]
+            setattr(res.Outputs, name, torch.cat(vals, 0) if vals else None)
+        nr, fr = C.c_float(0), C.c_float(0)
+        L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
+        res.Near, res.Far = nr.value, fr.value
+        res.Extras["rays_flat"] = rays_
+        return res

@@ -184,6 +184,22 @@ def raw2outputs(raw, z, d, white_bkgr=False):
     return dict(rgb=rgb, disp=disp, acc=acc, weights=w, depth=depth)
 
 
+def raw2weights(raw, sigma_ch, z, d):
+    raw = _f(raw); z = _f(z); d = _f(d)
+    n, s, c = raw.shape
+    w = np.empty((n, s), np.float32); depth = np.empty(n, np.float32); disp = np.empty(n, np.float32); acc = np.empty(n, np.float32)
+    lib().orc_raw2weights(_p(raw), C.c_int(c), C.c_int(sigma_ch), _p(z), _p(d), C.c_int64(n), C.c_int(s), _p(w), _p(depth), _p(disp), _p(acc))
+    return dict(weights=w, depth=depth, disp=disp, acc=acc)
+
+
+def render_clip_embedding(embeds, dim, w):
+    embeds = _f(embeds); w = _f(w)
+    n, s, stride = embeds.shape
+    out = np.empty((n, dim), np.float32)
+    lib().orc_render_clip_embedding(_p(embeds), C.c_int(stride), C.c_int(dim), _p(w), C.c_int64(n), C.c_int(s), _p(out))
+    return out
+
+
 def sample_pdf(bins, weights, u, sum_vec=ATEN_VEC):
     bins = _f(bins); weights = _f(weights); u = _f(u)
     n, nb = bins.shape

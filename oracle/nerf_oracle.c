@@ -735,7 +735,40 @@ ORC_API void orc_lerf(const float *params, const float *x, int64_t p, int in_ch,
  *     white: rgb_map + (1 - acc).   Reductions over samples: double accumulate, one rounding.
  *     raw has `c` channels per sample with rgb at 0..2 and sigma at 3 (c = 4 or 5).
  * ------------------------------------------------------------------------------------------ */
+static void raw2outputs_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int sigma_ch, int white_bkgr,
+                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth);
+
 ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
+{
+    raw2outputs_impl(raw, z, d, n, s, c, 3, white_bkgr, rgb_map, disp, acc_map, weights, depth);
+}
+
+/* L2  LeRFRenderer::RawToLEOutputs, weights part   LeRFRenderer.cpp:27-76 (sigma_le at channel lang_embed_dim, no colour) */
+ORC_API void orc_raw2weights(const float *raw, int c, int sigma_ch, const float *z, const float *d, int64_t n, int s,
+                             float *weights, float *depth, float *disp, float *acc_map)
+{
+    raw2outputs_impl(raw, z, d, n, s, c, sigma_ch, 0, NULL, disp, acc_map, weights, depth);
+}
+
+/* L2  RenderCLIPEmbedding                          LeRFRenderer.h:45-54: normalize(sum_s w*e, eps 1e-8) */
+ORC_API void orc_render_clip_embedding(const float *embeds, int stride, int dim, const float *w, int64_t n, int s, float *out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        double ss = 0.0;
+        for (int k = 0; k < dim; k++) {
+            double acc = 0.0;
+            for (int j = 0; j < s; j++) acc += (double)(w[i * s + j] * embeds[(i * s + j) * (int64_t)stride + k]);
+            out[i * dim + k] = (float)acc;
+            ss += (double)out[i * dim + k] * (double)out[i * dim + k];
+        }
+        float nrm = f_max((float)sqrt(ss), 1e-8f);
+        for (int k = 0; k < dim; k++) out[i * dim + k] = out[i * dim + k] / nrm;
+    }
+}
+
+static void raw2outputs_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int sigma_ch, int white_bkgr,
                              float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
 {
     OMP_FOR
@@ -749,7 +782,7 @@ ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, i
             const float *r = raw + (i * s + j) * c;
             float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
             dist = dist * nrm;
-            float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            float sig = r[sigma_ch] > 0.0f ? r[sigma_ch] : 0.0f;
             float alpha = -nrf_expf(-sig * dist) + 1.0f;
             float trans = nrf_expf(tprev);
             float w = alpha * trans;
@@ -758,7 +791,8 @@ ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, i
             logt += (double)lg;
             tprev = (float)logt;
             if (weights) weights[i * s + j] = w;
-            float cr = nrf_sigmoidf(r[0]), cg = nrf_sigmoidf(r[1]), cb = nrf_sigmoidf(r[2]);
+            float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            if (rgb_map) { cr = nrf_sigmoidf(r[0]); cg = nrf_sigmoidf(r[1]); cb = nrf_sigmoidf(r[2]); }
             sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);
             sw += (double)w; swz += (double)(w * z[i * s + j]);
         }
@@ -766,7 +800,7 @@ ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, i
         float dep = (float)swz / (acc > 1e-10f ? acc : 1e-10f);
         float rr = (float)sr, gg = (float)sg, bb = (float)sb;
         if (white_bkgr) { float bg = 1.0f - acc; rr = rr + bg; gg = gg + bg; bb = bb + bg; }
-        rgb_map[i * 3] = rr; rgb_map[i * 3 + 1] = gg; rgb_map[i * 3 + 2] = bb;
+        if (rgb_map) { rgb_map[i * 3] = rr; rgb_map[i * 3 + 1] = gg; rgb_map[i * 3 + 2] = bb; }
         if (depth) depth[i] = dep;
         if (disp) disp[i] = 1.0f / (dep > 1e-10f ? dep : 1e-10f);
         if (acc_map) acc_map[i] = acc;

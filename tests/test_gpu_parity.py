@@ -543,3 +543,50 @@ def test_hash_fast_path_fallbacks_bit_exact(api, O):
         outs.append(host(feats.permute(1, 0, 2).reshape(x.shape[0], 32).float()))
         assert_exact(outs[-1], host(ref), f"dense budget {budget}")
     e.set_dense_budget(1 << 34)
+
+
+# ------------------------------------------------------------------ LeRF (BASELINE config 4)
+def test_lerf_render_pass_vs_oracle(api, O, manifest):
+    """LeRFRenderer::RenderRays minus the external Relevancy: CuHashEmbedder(F=8) -> LeRF head -> sigma_le weights ->
+    RenderCLIPEmbedding, against the oracle composed stage by stage on the same rays."""
+    Lv, F, T = 16, 8, 12
+    bbox = api.S.LEGO_BBOX
+    e = api.M.CuHashEmbedder("lang_embedder", bbox, Lv, F, T, 16, 128)
+    table = synth.synth_sym(311, (Lv * (1 << T) * F,), np.float32(0.5))
+    primes = np.array(api.S.CU_PRIMES[:3 * Lv], np.int32)
+    e.set_table(table); e.set_primes(primes)
+    blob = synth.blob_from_manifest(manifest["lerf"])
+    blob = blob.copy(); blob[128 * 256:128 * 256 + 256] *= 20.0            # row 0 of sigma_le_net_1: a density that is not ~0
+    lerf = api.M.LeRF(32, 2, 256, 768, 128, "lang_model", params=blob)
+    r = api.R.LeRFRenderer(e, lerf)
+    K = api.S.lego_K(6, 6); c2w = api.S.pose_spherical(40.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=16, NImportance=16, Chunk=20, ReturnRaw=True, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True,
+                               ThinRay=True, BoundingBox=bbox)
+    res = r.Render(6, 6, K, p, c2w=c2w)
+    rays = host(res.Extras["rays_flat"])
+    # oracle, stage by stage
+    ls = ((1 << T) >> 4) << 4
+    def net(pts):
+        emb, keep = O.hash_cu(pts.reshape(-1, 3), O.f32_to_f16(table), primes, np.arange(Lv, dtype=np.int32) * ls, np.full(Lv, ls, np.int32),
+                              np.zeros((Lv, 3), np.float32), bbox, O.hash_cu_scales(Lv, 16, 128), Lv, F)
+        o = O.lerf(blob, emb)
+        o[~keep, -1] = 0
+        return o.reshape(pts.shape[0], pts.shape[1], -1)
+    z = O.z_vals(rays[:, 6], rays[:, 7], O.linspace(0, 1, 16))
+    raw = net(O.points(rays[:, :3], rays[:, 3:6], z))
+    w1 = O.raw2weights(raw, 768, z, rays[:, 3:6])["weights"]
+    samples, _, _ = O.sample_pdf(O.z_mid(z), w1[:, 1:-1], O.linspace(0, 1, 16))
+    zf = O.merge_sorted(z, samples)
+    rawf = net(O.points(rays[:, :3], rays[:, 3:6], zf))
+    fin = O.raw2weights(rawf, 768, zf, rays[:, 3:6])
+    emb_ref = O.render_clip_embedding(rawf, 768, fin["weights"])
+    assert fin["acc"].max() > 0.05, "fixture must have non-trivial language density"
+    assert_close(host(res.Outputs.WeightsLE), fin["weights"], rtol=2e-4, atol=2e-6, what="WeightsLE")
+    assert_close(host(res.Outputs.DepthMapLE), fin["depth"], rtol=2e-4, atol=2e-5)
+    hit = fin["acc"] > 1e-3
+    assert_close(host(res.Outputs.RenderedLangEmbedding)[hit], emb_ref[hit], rtol=0, atol=2e-4, what="rendered CLIP embedding")
+    assert_close(np.linalg.norm(host(res.Outputs.RenderedLangEmbedding)[hit], axis=1), np.ones(hit.sum()), rtol=1e-5, atol=0)
+    # the stage functions on the oracle's own inputs are exact
+    w_gpu = api.R.LeRFRenderer.RawToLEOutputs(r, dev(rawf), dev(zf), dev(rays[:, 3:6]), 768)
+    assert_exact(host(w_gpu.WeightsLE), fin["weights"], "nrf_raw2weights == oracle")
+    assert_close(host(w_gpu.RenderedLangEmbedding)[hit], emb_ref[hit], rtol=1e-6, atol=1e-7, what="nrf_render_clip_embedding")
