@@ -203,6 +203,37 @@ NRF_API int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n,
                             float *d_z_fine, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stochastic branches of RenderRays (Perturb > 0, cone rays, training-time noise).  The stage functions take the random
+ * draws as explicit device arrays -- hand them the reference's own torch::rand / randn tensors and the results can be
+ * compared value for value.  nrf_render_rays itself generates draws in-kernel from (seed, stream, GLOBAL element index)
+ * with include/nrf_rng.h (streams NRF_RNG_*), so a render does not depend on Chunk or on the ray sharding;
+ * nrf_rng_fill materialises the same draws: element k = draw(seed, rng_stream, index0 + k), uniform [0,1) or normal.
+ * ------------------------------------------------------------------------------------------- */
+NRF_API int nrf_rng_fill(uint64_t seed, uint32_t rng_stream, uint64_t index0, int64_t count, int normal, float *d_out, void *stream);
+
+/* Stratified jitter (NeRFRenderer.h:404-417): z [n,s], t_rand [n,s] uniform -> out [n,s] (must not alias z). */
+NRF_API int nrf_jitter_z(const float *d_z, const float *d_t_rand, int64_t n, int s, float *d_out, void *stream);
+
+/* TangentScatter (NeRFRenderer.h:307-362).  d_pts [n,s,3] or NULL (= o + d*z from the packed rays); rays_d is read from the
+ * packed rays (columns 3..5); u_r / u_theta [n,s] uniform draws; bbox: host [6] or NULL (no clamp). */
+NRF_API int nrf_tangent_scatter(const float *d_pts, const float *d_rays, int ray_stride, const float *d_z, int64_t n, int s, float cone_angle,
+                                const float *d_u_r, const float *d_u_theta, const float *bbox, float *d_out, void *stream);
+
+/* Stochastic preconditioning + ReflectBoundary (NeRFRenderer.h:433-443, :285-304): pts [p,3] + noise [p,3]*alpha, reflected. */
+NRF_API int nrf_precondition(const float *d_pts, const float *d_noise, float alpha, const float *bbox, int64_t p, float *d_out, void *stream);
+
+/* RawToOutputs with raw_noise_std > 0 (NeRFRenderer.h:251-252): noise [n,s] normal draws. */
+NRF_API int nrf_raw2outputs_noise(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                                  const float *d_noise, float noise_std, float *d_rgb, float *d_disp, float *d_acc, float *d_weights,
+                                  float *d_depth, void *stream);
+
+/* SamplePDF with det = false (Sampler.h:22-24) and the fine depth set built on it: u is [n, ns], one unsorted row per ray. */
+NRF_API int nrf_sample_pdf_rand(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
+                                float *d_samples, int64_t *d_inds, void *stream);
+NRF_API int nrf_fine_depths_rand(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec,
+                                 float *d_z_fine, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Renderer                                    NeRFRenderer<TEmbedder,TEmbedDirs,TNeRF> (NeRFRenderer.h:88-159)
  * ------------------------------------------------------------------------------------------- */
 enum { NRF_DIRS_NONE = 0, NRF_DIRS_PE = 1, NRF_DIRS_SH_LIBTORCH = 2, NRF_DIRS_SH_CUDA = 3 };
@@ -215,9 +246,9 @@ typedef struct nrf_renderer_desc {
     const nrf_mlp *mlp;
 } nrf_renderer_desc;
 
-/* NeRFRenderParams (NeRFRenderer.h:28-44) restricted to the deterministic render path
- * (Perturb = 0, RawNoiseStd = 0, ThinRay = true: what FillRenderParams sets at test time,
- * NeRFExecutor.h:379-415, plus ThinRay). */
+/* NeRFRenderParams (NeRFRenderer.h:28-44) as RenderRays consumes them.  Zero-initialise the struct: all stochastic
+ * fields 0 is the deterministic render path (Perturb = 0, RawNoiseStd = 0, ThinRay = true -- what FillRenderParams sets
+ * at test time, NeRFExecutor.h:379-415, plus ThinRay). */
 typedef struct nrf_render_params {
     int n_samples;            /* NSamples */
     int n_importance;         /* NImportance */
@@ -225,6 +256,16 @@ typedef struct nrf_render_params {
     int white_bkgr;           /* WhiteBkgr */
     int precision;            /* NRF_PREC_* for the MLP */
     int sum_vec;              /* see nrf_sample_pdf */
+    /* stochastic branches; draws come from include/nrf_rng.h keyed by (seed, stream, (ray_base + ray)*S + sample) */
+    float perturb;            /* Perturb > 0: stratified jitter + SamplePDF(det = false) */
+    int has_cone;             /* !ThinRay: TangentScatter on both passes with `cone_angle` (GetRays, RayUtils.h:43-44) */
+    float cone_angle;
+    float raw_noise_std;      /* RawNoiseStd */
+    float precond_alpha;      /* StochasticPreconditioningAlpha (fine pass only, as in the reference) */
+    int has_bbox;             /* BoundingBox given: TangentScatter clamps to it; required by precond_alpha > 0 */
+    float bbox[6];
+    uint64_t seed;
+    int64_t ray_base;         /* index of d_rays[0] within the whole image / ray batch */
 } nrf_render_params;
 
 typedef struct nrf_render_outputs {   /* NeRFRendererOutputs / NeRFRenderResult (NeRFRenderer.h:12-26); NULL = not wanted */

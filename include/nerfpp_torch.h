@@ -186,6 +186,8 @@ class HipNeRFRenderer : public NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> {
 	nrf_renderer *Renderer = nullptr;
 	torch::Tensor Workspace;
 	int Precision;
+	uint64_t Seed = 0;        ///seed of the counter-based draws of the stochastic branches (include/nrf_rng.h)
+	int64_t RayCursor = 0;    ///rays already rendered by the current Render() call: makes the draws independent of Chunk
 
 	void *workspace(size_t bytes, torch::Device dev)
 	{
@@ -199,6 +201,7 @@ public:
 	~HipNeRFRenderer() override { nrf_renderer_destroy(Renderer); }
 
 	void SetPrecision(int precision) { Precision = precision; }
+	void SetSeed(uint64_t seed) { Seed = seed; }
 
 	/// (Re)read the network's parameters and rebuild the device-side images; call after construction, load or an optimizer step.
 	void SyncWeights(const nrf_mlp_small_desc *small, const nrf_mlp_nerf_desc *classic)
@@ -236,7 +239,7 @@ protected:
 	NeRFRendererOutputs RawToOutputs(torch::Tensor raw, torch::Tensor cone_angle, torch::Tensor z_vals, torch::Tensor rays_d,
 		const float raw_noise_std = 0.f, const bool white_bkgr = false) override
 	{
-		TORCH_CHECK(raw_noise_std == 0.f, "RawToOutputs: raw_noise_std > 0 is the training-time noise branch; not built");
+		TORCH_CHECK(raw_noise_std == 0.f, "RawToOutputs: raw_noise_std > 0 draws inside RenderRays (nrf_render_rays) or takes explicit draws (nrf_raw2outputs_noise)");
 		raw = dev_f32(raw); z_vals = dev_f32(z_vals); rays_d = dev_f32(rays_d);
 		const int64_t n = raw.size(0); const int s = (int)raw.size(1), c = (int)raw.size(2);
 		NeRFRendererOutputs o;
@@ -275,6 +278,7 @@ public:
 		auto bb = host_floats(render_params.BoundingBox);
 		auto rays_ = torch::empty({n, stride}, o.options());
 		check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, render_params.UseViewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
+		RayCursor = 0;
 		NeRFRenderResult all_ret = this->BatchifyRays(rays_, render_params.ThinRay ? torch::Tensor() : cone_angle, render_params.NSamples, render_params.Chunk,
 			render_params.ReturnRaw, render_params.LinDisp, render_params.Perturb, render_params.NImportance, render_params.WhiteBkgr, render_params.RawNoiseStd,
 			render_params.StochasticPreconditioningAlpha, render_params.BoundingBox, render_params.ReturnWeights);
@@ -293,9 +297,6 @@ public:
 		const float raw_noise_std = 0.f, const float stochastic_preconditioning_alpha = 0.f, torch::Tensor bounding_box = torch::Tensor(),
 		const bool return_weights = true) override
 	{
-		TORCH_CHECK(perturb == 0.f && raw_noise_std == 0.f && stochastic_preconditioning_alpha == 0.f,
-			"HipNeRFRenderer renders the deterministic path; perturb / noise / preconditioning are training-time RNG branches");
-		TORCH_CHECK(!(cone_angle.defined() && cone_angle.numel()), "a defined cone_angle selects TangentScatter (NeRFRenderer.h:307-362): render with ThinRay = true");
 		auto rays = dev_f32(ray_batch);
 		const int64_t n = rays.size(0); const int stride = (int)rays.size(1);
 		const int sf = n_samples + n_importance, so = n_importance > 0 ? sf : n_samples;
@@ -308,6 +309,11 @@ public:
 		if (return_weights) res.Outputs.Weights = torch::empty({n, so}, opt);
 		if (return_raw) res.Raw = torch::empty({n, so, 4}, opt);
 		nrf_render_params p{n_samples, n_importance, lin_disp, white_bkgr, Precision, 8};
+		// stochastic branches: the library draws from its counter RNG keyed by (Seed, position of the ray in this Render call, sample)
+		p.perturb = perturb; p.raw_noise_std = raw_noise_std; p.precond_alpha = stochastic_preconditioning_alpha;
+		if (cone_angle.defined() && cone_angle.numel()) { p.has_cone = 1; p.cone_angle = cone_angle.cpu().template item<float>(); }
+		if (bounding_box.defined() && bounding_box.numel() == 6) { auto bb = host_floats(bounding_box); p.has_bbox = 1; for (int a = 0; a < 6; a++) p.bbox[a] = bb[a]; }
+		p.seed = Seed; p.ray_base = RayCursor; RayCursor += n;
 		nrf_render_outputs o{};
 		o.d_rgb = res.Outputs.RGBMap.data_ptr<float>(); o.d_disp = res.Outputs.DispMap.data_ptr<float>(); o.d_acc = res.Outputs.AccMap.data_ptr<float>();
 		o.d_depth = res.Outputs.DepthMap.data_ptr<float>();

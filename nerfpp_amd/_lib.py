@@ -14,6 +14,8 @@ NRF_HASH_NGP, NRF_HASH_CU = 0, 1
 NRF_SH_LIBTORCH, NRF_SH_CUDA = 0, 1
 NRF_PREC_F32, NRF_PREC_F16_MFMA = 0, 1
 NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
+(NRF_RNG_T_RAND, NRF_RNG_R_COARSE, NRF_RNG_THETA_COARSE, NRF_RNG_NOISE_COARSE, NRF_RNG_U_PDF, NRF_RNG_PRECOND, NRF_RNG_R_FINE, NRF_RNG_THETA_FINE,
+ NRF_RNG_NOISE_FINE) = range(1, 10)       # include/nrf_rng.h
 NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other")
 
 
@@ -38,7 +40,9 @@ class RendererDesc(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("n_samples", C.c_int), ("n_importance", C.c_int), ("lindisp", C.c_int), ("white_bkgr", C.c_int),
-                ("precision", C.c_int), ("sum_vec", C.c_int)]
+                ("precision", C.c_int), ("sum_vec", C.c_int),
+                ("perturb", C.c_float), ("has_cone", C.c_int), ("cone_angle", C.c_float), ("raw_noise_std", C.c_float), ("precond_alpha", C.c_float),
+                ("has_bbox", C.c_int), ("bbox", C.c_float * 6), ("seed", C.c_uint64), ("ray_base", C.c_int64)]
 
 
 class RenderOutputs(C.Structure):
@@ -57,6 +61,7 @@ SYMBOLS = [
     "nrf_mlp_output_dims", "nrf_mlp_forward",
     "nrf_mlp_lerf_param_count", "nrf_mlp_lerf_create",
     "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths",
+    "nrf_rng_fill", "nrf_jitter_z", "nrf_tangent_scatter", "nrf_precondition", "nrf_raw2outputs_noise", "nrf_sample_pdf_rand", "nrf_fine_depths_rand",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays",
     "nrf_profile_enable", "nrf_profile_read",

@@ -9,6 +9,7 @@
 // the CPU oracle and here), which makes the whole stage -- and with it the fine-pass sample set -- reproducible.  The pdf normaliser sum(w) is evaluated in ATen's own lane
 // order (sum_vec) because it feeds searchsorted: the sample INDICES are bit-exact against the oracle.
 #include "common.h"
+#include "stoch.h"
 
 namespace nrf {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ double wave_sum(double v)
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-              float *__restrict__ depth)
+              float *__restrict__ depth, SigmaNoise nz)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
@@ -59,7 +60,9 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
             zj = zr[j];
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
-            const float sg = r[sigma_ch];
+            float sg = r[sigma_ch];
+            if (nz.on)                                              // raw_noise_std > 0 (:251-252)
+                sg = sg + (nz.arr ? nz.arr[ray * s + j] : nrf_rng_normal(nz.g.seed, nz.stream, (uint64_t)((nz.g.ray_base + ray) * s + j))) * nz.std;
             const float sig = sg > 0.0f ? sg : 0.0f;                // relu
             alpha = -nrf_expf(-sig * dist) + 1.0f;                      // :234
             const float om = 1.0f - alpha;
@@ -145,7 +148,9 @@ __device__ float aten_row_sum(const float *x, int n, int vec, float *scratch /*>
 
 // Shared body of SamplePDF for one ray handled by one wave.  bins[nb], wts[nb-1] and the outputs live in LDS.
 //   cdf[nb] (out), samples[ns] (out), inds (optional global int64 out)
-__device__ void sample_pdf_wave(const float *bins, float *wts, int nb, const float *__restrict__ u, int ns, int sum_vec,
+// u: this ray's draw row (the shared linspace table when det, Sampler.h:21; a row of torch::rand when not, :23), or NULL ->
+// generated: element j is nrf_rng_uniform(seed, NRF_RNG_U_PDF, u_base + j)
+__device__ void sample_pdf_wave(const float *bins, float *wts, int nb, const float *__restrict__ u, uint64_t u_seed, uint64_t u_base, int ns, int sum_vec,
                                 float *cdf, float *samples, float *scratch, int64_t *inds, int lane)
 {
     const int nw = nb - 1;
@@ -163,7 +168,7 @@ __device__ void sample_pdf_wave(const float *bins, float *wts, int nb, const flo
     }
     wave_sync();
     for (int j = lane; j < ns; j += 64) {
-        const float uj = u[j];
+        const float uj = u ? u[j] : nrf_rng_uniform(u_seed, NRF_RNG_U_PDF, u_base + (uint64_t)j);
         int lo = 0, hi = nb;                                                     // searchsorted(cdf, u, right=True) (:28)
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -191,7 +196,7 @@ struct PdfLds {
 
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_sample_pdf(int64_t n, int nb, int ns, int sum_vec, const float *__restrict__ bins, const float *__restrict__ weights,
-             const float *__restrict__ u, float *__restrict__ samples, int64_t *__restrict__ inds)
+             const float *__restrict__ u, int64_t u_stride, float *__restrict__ samples, int64_t *__restrict__ inds)
 {
     __shared__ PdfLds lds[RAYS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -201,14 +206,14 @@ k_sample_pdf(int64_t n, int nb, int ns, int sum_vec, const float *__restrict__ b
     for (int k = lane; k < nb; k += 64) L.bins[k] = bins[ray * nb + k];
     for (int k = lane; k < nb - 1; k += 64) L.wts[k] = weights[ray * (nb - 1) + k];
     wave_sync();
-    sample_pdf_wave(L.bins, L.wts, nb, u, ns, sum_vec, L.cdf, L.merged, L.scratch, inds ? inds + ray * ns : nullptr, lane);
+    sample_pdf_wave(L.bins, L.wts, nb, u + ray * u_stride, 0, 0, ns, sum_vec, L.cdf, L.merged, L.scratch, inds ? inds + ray * ns : nullptr, lane);
     for (int j = lane; j < ns; j += 64) samples[ray * ns + j] = L.merged[j];
 }
 
 // NeRFRenderer.h:427-431: z_mid -> SamplePDF(weights[1:-1]) -> sort(cat(z, samples)).
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z, const float *__restrict__ weights,
-              const float *__restrict__ u, float *__restrict__ zf)
+              const float *__restrict__ u, int64_t u_stride, RngRef g, float *__restrict__ zf)
 {
     __shared__ PdfLds lds[RAYS_PER_BLOCK];
     __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
@@ -224,7 +229,7 @@ k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z
     for (int k = lane; k < nb - 1; k += 64) L.wts[k] = weights[ray * s + 1 + k];                 // weights[..., 1:-1] (:428)
     wave_sync();
     float *smp = L.merged;                  // samples [ns]
-    sample_pdf_wave(L.bins, L.wts, nb, u, ns, sum_vec, L.cdf, smp, L.scratch, nullptr, lane);
+    sample_pdf_wave(L.bins, L.wts, nb, u ? u + ray * u_stride : nullptr, g.seed, (uint64_t)((g.ray_base + ray) * ns), ns, sum_vec, L.cdf, smp, L.scratch, nullptr, lane);
     // ---- stable ascending sort of cat(z[0..s), samples[0..ns)) by merge ranks (both runs are sorted unless
     //      fp32 rounding broke monotonicity by an ulp: detected, then ranked by exhaustive counting) ----
     bool bad = false;
@@ -282,6 +287,30 @@ __global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int d
     for (int k = threadIdx.x; k < dim; k += 256) out[ray * dim + k] = out[ray * dim + k] / nrm;
 }
 
+int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
+                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st)
+{
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_COMPOSITE, st);
+    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
+                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+// u == NULL: per-ray uniform draws generated from g (SamplePDF det = false with the library's counter RNG)
+int launch_fine_depths(const float *z, const float *weights, int64_t n, int s, const float *u, int64_t u_stride, const RngRef &g, int ns, int sum_vec,
+                       float *zf, hipStream_t st)
+{
+    NRF_CHECK_ARG(s >= 4 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [4,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
+    NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_fine_depths: sum_vec must be 0, 4, 8 or 16");
+    if (n == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_SAMPLE, st);
+    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, ns, sum_vec, z, weights, u, u_stride, g, zf);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -292,24 +321,23 @@ int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d_dirs, i
                     float *d_rgb, float *d_disp, float *d_acc, float *d_weights, float *d_depth, void *stream)
 {
     NRF_CHECK_ARG(d_raw && d_z && d_dirs && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs: bad argument");
-    if (n == 0) return NRF_OK;
-    ProfScope prof(NRF_PROF_COMPOSITE, as_stream(stream));
-    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, 3, white_bkgr,
-                       d_raw, d_z, d_dirs, d_stride, d_rgb, d_disp, d_acc, d_weights, d_depth);
-    NRF_LAUNCH_CHECK();
-    return NRF_OK;
+    return launch_raw2outputs(d_raw, d_z, d_dirs, d_stride, n, s, c, 3, white_bkgr, d_rgb, d_disp, d_acc, d_weights, d_depth, SigmaNoise{}, as_stream(stream));
+}
+
+int nrf_raw2outputs_noise(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                          const float *d_noise, float noise_std, float *d_rgb, float *d_disp, float *d_acc, float *d_weights, float *d_depth, void *stream)
+{
+    NRF_CHECK_ARG(d_raw && d_z && d_dirs && d_noise && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs_noise: bad argument");
+    SigmaNoise nz{};
+    nz.on = 1; nz.arr = d_noise; nz.std = noise_std;
+    return launch_raw2outputs(d_raw, d_z, d_dirs, d_stride, n, s, c, 3, white_bkgr, d_rgb, d_disp, d_acc, d_weights, d_depth, nz, as_stream(stream));
 }
 
 int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
                     float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream)
 {
     NRF_CHECK_ARG(d_raw && d_z && d_dirs && n >= 0 && s >= 1 && c >= 1 && sigma_ch >= 0 && sigma_ch < c && d_stride >= 3, "nrf_raw2weights: bad argument");
-    if (n == 0) return NRF_OK;
-    ProfScope prof(NRF_PROF_COMPOSITE, as_stream(stream));
-    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, c, sigma_ch, 0,
-                       d_raw, d_z, d_dirs, d_stride, (float *)nullptr, d_disp, d_acc, d_weights, d_depth);
-    NRF_LAUNCH_CHECK();
-    return NRF_OK;
+    return launch_raw2outputs(d_raw, d_z, d_dirs, d_stride, n, s, c, sigma_ch, 0, nullptr, d_disp, d_acc, d_weights, d_depth, SigmaNoise{}, as_stream(stream));
 }
 
 int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed_dim, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
@@ -321,8 +349,8 @@ int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed
     return NRF_OK;
 }
 
-int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
-                   float *d_samples, int64_t *d_inds, void *stream)
+static int sample_pdf_entry(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int64_t u_stride, int ns, int sum_vec,
+                            float *d_samples, int64_t *d_inds, void *stream)
 {
     NRF_CHECK_ARG(d_bins && d_weights && d_u && d_samples && n >= 0, "nrf_sample_pdf: bad argument");
     NRF_CHECK_ARG(nb >= 2 && nb <= MAX_S && ns >= 1 && ns <= 2 * MAX_S, "nrf_sample_pdf: nb %d / ns %d outside the built range (<= %d bins, <= %d samples)", nb, ns, MAX_S, 2 * MAX_S);
@@ -330,22 +358,33 @@ int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t n, int n
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_SAMPLE, as_stream(stream));
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, nb, ns, sum_vec,
-                       d_bins, d_weights, d_u, d_samples, d_inds);
+                       d_bins, d_weights, d_u, u_stride, d_samples, d_inds);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
+}
+
+int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
+                   float *d_samples, int64_t *d_inds, void *stream)
+{
+    return sample_pdf_entry(d_bins, d_weights, n, nb, d_u, 0, ns, sum_vec, d_samples, d_inds, stream);
+}
+
+int nrf_sample_pdf_rand(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int ns, int sum_vec,
+                        float *d_samples, int64_t *d_inds, void *stream)
+{
+    return sample_pdf_entry(d_bins, d_weights, n, nb, d_u, ns, ns, sum_vec, d_samples, d_inds, stream);
 }
 
 int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec, float *d_z_fine, void *stream)
 {
     NRF_CHECK_ARG(d_z && d_weights && d_u && d_z_fine && n >= 0, "nrf_fine_depths: bad argument");
-    NRF_CHECK_ARG(s >= 4 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [4,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
-    NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_fine_depths: sum_vec must be 0, 4, 8 or 16");
-    if (n == 0) return NRF_OK;
-    ProfScope prof(NRF_PROF_SAMPLE, as_stream(stream));
-    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, as_stream(stream), n, s, ns, sum_vec,
-                       d_z, d_weights, d_u, d_z_fine);
-    NRF_LAUNCH_CHECK();
-    return NRF_OK;
+    return launch_fine_depths(d_z, d_weights, n, s, d_u, 0, RngRef{0, 0}, ns, sum_vec, d_z_fine, as_stream(stream));
+}
+
+int nrf_fine_depths_rand(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec, float *d_z_fine, void *stream)
+{
+    NRF_CHECK_ARG(d_z && d_weights && d_u && d_z_fine && n >= 0, "nrf_fine_depths_rand: bad argument");
+    return launch_fine_depths(d_z, d_weights, n, s, d_u, ns, RngRef{0, 0}, ns, sum_vec, d_z_fine, as_stream(stream));
 }
 
 }  // extern "C"

@@ -45,7 +45,7 @@ int mlp_small_mfma_available(const nrf_mlp *m);
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, int s, const uint8_t *keep,
                               int64_t p, float *out, hipStream_t st);
 int mlp_nerf_mfma_available(const nrf_mlp *m);
-int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);
+int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);
 int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);

@@ -237,9 +237,13 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
                 float px[3] = {0.0f, 0.0f, 0.0f};
                 const float *row = nullptr;
                 if constexpr (FUSED) {
-                    const float *rp = in.rays + (int64_t)((uint32_t)q / (uint32_t)in.s) * in.ray_stride;
-                    const float zz = in.z[q];
-                    px[0] = rp[0] + rp[3] * zz; px[1] = rp[1] + rp[4] * zz; px[2] = rp[2] + rp[5] * zz;
+                    if (in.x) {        // explicit sample points [p,3] (stochastic branches: scattered / preconditioned points)
+                        px[0] = in.x[q * 3]; px[1] = in.x[q * 3 + 1]; px[2] = in.x[q * 3 + 2];
+                    } else {
+                        const float *rp = in.rays + (int64_t)((uint32_t)q / (uint32_t)in.s) * in.ray_stride;
+                        const float zz = in.z[q];
+                        px[0] = rp[0] + rp[3] * zz; px[1] = rp[1] + rp[4] * zz; px[2] = rp[2] + rp[5] * zz;
+                    }
                 } else row = in.x + q * in.x_stride;
 #pragma unroll
                 for (int s = 0; s < 4; s++)
@@ -431,11 +435,11 @@ int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, f
 
 int mlp_nerf_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_NERF && m->d_packed_f16 != nullptr; }
 
-// renderer fast path: points from (rays, z), PE in registers, per-ray fp16 direction encodings -> raw [p,4]
-int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st)
+// renderer fast path: points from (rays, z) -- or explicit `pts` [p,3] when not NULL --, PE in registers, per-ray fp16 direction encodings -> raw [p,4]
+int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st)
 {
     ProfScope prof(NRF_PROF_MLP, st);
-    NerfInput in{nullptr, 0, rays, ray_stride, z, s, dirs};
+    NerfInput in{pts, 3, rays, ray_stride, z, s, dirs};
     return launch_nerf(m, in, true, p, out, 4, st);
 }
 

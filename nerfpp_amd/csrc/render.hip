@@ -2,12 +2,15 @@
 //   RunNetwork  :164-194     RenderRays  :366-459
 // plus library-wide bookkeeping (error text, profiling events).
 //
-// Deterministic render path only (Perturb = 0, RawNoiseStd = 0, ThinRay): what FillRenderParams configures for
-// test-time rendering (NeRFExecutor.h:379-415).  One network serves both passes and the fine pass re-evaluates all
-// S + N_importance depths (NeRFRenderer.h:422,447).
+// The deterministic render path (Perturb = 0, RawNoiseStd = 0, ThinRay: what FillRenderParams configures for test-time
+// rendering, NeRFExecutor.h:379-415) forms sample points inside the encoders and never materialises them.  The stochastic
+// branches (jitter, cone rays / TangentScatter, sigma noise, preconditioning) add one point-generation launch per pass
+// (stoch.hip) whose draws are counter-based, and then run the same network kernels on explicit points.  One network
+// serves both passes and the fine pass re-evaluates all S + N_importance depths (NeRFRenderer.h:422,447).
 #include "encode.h"
 #include "hash_fast.h"
 #include "mlp.h"
+#include "stoch.h"
 
 #include <mutex>
 
@@ -259,6 +262,8 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += align_up((size_t)n * sf * c * 4, 256);           // raw_fine
     b += network_ws_bytes(r, n * sf, p->precision) + 4096;
     b += align_up((size_t)n * 64 * sizeof(__half), 256);  // per-ray direction features of the fast path
+    if (p->perturb > 0.0f) b += align_up((size_t)n * s * 4, 256);                             // un-jittered depths
+    if (p->has_cone || p->precond_alpha > 0.0f) b += align_up((size_t)n * sf * 12, 256);     // explicit sample points
     return b;
 }
 
@@ -270,9 +275,11 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     NRF_CHECK_ARG(d_rays && d_t, "nrf_render_rays: null pointer");
     NRF_CHECK_ARG(n >= 0 && (ray_stride == 8 || ray_stride == 11), "nrf_render_rays: ray_stride must be 8 or 11 (NeRFRenderer.h:580-583)");
     NRF_CHECK_ARG(p->n_samples >= 1 && p->n_importance >= 0, "nrf_render_rays: bad sample counts");
-    NRF_CHECK_ARG(p->n_importance == 0 || d_u, "nrf_render_rays: n_importance > 0 needs the u table");
+    NRF_CHECK_ARG(p->n_importance == 0 || d_u || p->perturb > 0.0f, "nrf_render_rays: n_importance > 0 needs the u table");
     NRF_CHECK_ARG(r->in_views == 0 || ray_stride == 11, "nrf_render_rays: the renderer encodes view directions but the ray batch has none");
-    if (n == 0) return NRF_OK;
+    NRF_CHECK_ARG(p->perturb >= 0.0f && p->raw_noise_std >= 0.0f && p->precond_alpha >= 0.0f, "nrf_render_rays: negative perturb / raw_noise_std / precond_alpha");
+    NRF_CHECK_ARG(p->precond_alpha == 0.0f || p->has_bbox, "nrf_render_rays: stochastic preconditioning reflects at the bounding box (NeRFRenderer.h:436-442): bbox required");
+    NRF_CHECK_ARG(p->perturb == 0.0f || p->n_samples >= 2, "nrf_render_rays: Perturb > 0 needs n_samples >= 2");
     if (workspace_bytes < nrf_render_rays_workspace_bytes(r, n, p)) {
         set_error("nrf_render_rays: workspace %zu < %zu bytes", workspace_bytes, nrf_render_rays_workspace_bytes(r, n, p));
         return NRF_ERR_WORKSPACE;
@@ -296,6 +303,8 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     __half *dirs16 = nullptr;
     if (fast) dirs16 = bump.take<__half>((size_t)n * r->in_views);
     if (fast_classic) dirs16 = bump.take<__half>((size_t)n * 32);
+    float *z_plain = p->perturb > 0.0f ? bump.take<float>((size_t)n * s) : nullptr;
+    float *bump_pts = (p->has_cone || p->precond_alpha > 0.0f) ? bump.take<float>((size_t)n * sf * 3) : nullptr;
     void *nws = bump.take<char>(0);
     const size_t nws_bytes = workspace_bytes - bump.off;
     const float *viewdirs = r->in_views > 0 ? d_rays + 8 : nullptr;
@@ -303,25 +312,49 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     if (fast_classic) NRF_TRY(launch_dirs_pe_f16(d_rays, ray_stride, n, dirs16, st));
     auto network = [&](const PointSource &src, int ns_, float *raw_out) -> int {
         if (fast) return run_network_fast(r, src, dirs16, n, ns_, raw_out, nws, nws_bytes, st);
-        if (fast_classic) return mlp_nerf_forward_mfma_fused(r->desc.mlp, src.rays, src.ray_stride, src.z, ns_, dirs16, n * (int64_t)ns_, raw_out, st);
+        if (fast_classic) return mlp_nerf_forward_mfma_fused(r->desc.mlp, src.pts, src.rays, src.ray_stride, src.z, ns_, dirs16, n * (int64_t)ns_, raw_out, st);
         return run_network(r, src, viewdirs, ray_stride, n, ns_, p->precision, raw_out, nws, nws_bytes, st);
     };
+    // ---- stochastic branches: all off on the render path ----
+    const RngRef rng{p->seed, p->ray_base};
+    const bool jitter = p->perturb > 0.0f, cone = p->has_cone != 0, precond = p->precond_alpha > 0.0f;
+    float *pts = (cone || precond) ? bump_pts : nullptr;
+    SigmaNoise nz{};
+    nz.on = p->raw_noise_std > 0.0f; nz.std = p->raw_noise_std; nz.g = rng;
+    StochPoints sp{};
+    sp.cone = cone; sp.cone_angle = p->cone_angle; sp.clamp = cone && p->has_bbox; sp.alpha = p->precond_alpha;
+    for (int a = 0; a < 3; a++) { sp.box.mn[a] = p->bbox[a]; sp.box.mx[a] = p->bbox[3 + a]; }
 
     // z_vals; pts = o + d*z formed inside the encoder                           (NeRFRenderer.h:393-419)
-    NRF_TRY(nrf_z_vals(d_rays, ray_stride, n, d_t, s, p->lindisp, z_c, st));
+    if (jitter) {
+        NRF_TRY(nrf_z_vals(d_rays, ray_stride, n, d_t, s, p->lindisp, z_plain, st));
+        NRF_TRY(launch_jitter_z(z_plain, nullptr, rng, n, s, z_c, st));                                             // :404-417
+    } else NRF_TRY(nrf_z_vals(d_rays, ray_stride, n, d_t, s, p->lindisp, z_c, st));
     PointSource ps{nullptr, d_rays, z_c, ray_stride, s};
+    if (cone) {                                                                                                    // :420
+        sp.precond = 0; sp.stream_r = NRF_RNG_R_COARSE; sp.stream_theta = NRF_RNG_THETA_COARSE;
+        NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_c, n, s, sp, rng, pts, st));
+        ps.pts = pts;
+    }
     NRF_TRY(network(ps, s, raw_c));                                                                                // :422
+    nz.stream = NRF_RNG_NOISE_COARSE;
     if (ni == 0) {
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
-        return nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                               out->d_weights ? out->d_weights : w_c, out->d_depth, st);
+        return launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
+                                  out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st);
     }
-    NRF_TRY(nrf_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, st));   // :423
-    NRF_TRY(nrf_fine_depths(z_c, w_c, n, s, d_u, ni, p->sum_vec, z_f, st));                                                           // :427-431
+    NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz, st));   // :423
+    NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st));          // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
+    if (cone || precond) {                                                                                         // :433-445
+        sp.precond = precond; sp.stream_r = NRF_RNG_R_FINE; sp.stream_theta = NRF_RNG_THETA_FINE;
+        NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_f, n, sf, sp, rng, pts, st));
+        psf.pts = pts;
+    }
     NRF_TRY(network(psf, sf, raw_f));                                                                              // :447
-    return nrf_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                           out->d_weights, out->d_depth, st);                                                      // :448
+    nz.stream = NRF_RNG_NOISE_FINE;
+    return launch_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
+                              out->d_weights, out->d_depth, nz, st);                                               // :448
 }
 
 }  // extern "C"

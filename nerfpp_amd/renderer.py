@@ -59,18 +59,58 @@ def IntersectWithAABB(rays_o, rays_d, bounding_box, near_plane=0.0):
 # ------------------------------------------------------------------------------------------------
 # Sampler.h
 # ------------------------------------------------------------------------------------------------
-def SamplePDF(bins, weights, nsamples, det=True, return_inds=False, sum_vec=ATEN_SUM_VEC):
-    """Sampler.h:6-43, deterministic branch (det == (Perturb == 0), NeRFRenderer.h:428)."""
-    if not det:
-        raise L.NrfError("SamplePDF(det=False) draws torch::rand: training-time stochastic path, not built")
+def SamplePDF(bins, weights, nsamples, det=True, return_inds=False, sum_vec=ATEN_SUM_VEC, u=None, seed=0, ray_base=0):
+    """Sampler.h:6-43 (det == (Perturb == 0), NeRFRenderer.h:428).  det=False: `u` [N, nsamples] are the uniform draws (the reference's
+    torch::rand tensor); when None they come from the library's counter RNG (seed, NRF_RNG_U_PDF, global element index)."""
     bins = _dev_f32(bins); weights = _dev_f32(weights)
     n, nb = bins.shape
     assert weights.shape == (n, nb - 1)
-    u = torch.linspace(0.0, 1.0, nsamples, dtype=torch.float32).to(bins.device)     # Sampler.h:21, ATen's own rounding
     samples = torch.empty((n, nsamples), device=bins.device, dtype=torch.float32)
     inds = torch.empty((n, nsamples), device=bins.device, dtype=torch.int64) if return_inds else None
-    L.check(L.lib().nrf_sample_pdf(_ptr(bins), _ptr(weights), C.c_int64(n), nb, _ptr(u), nsamples, sum_vec, _ptr(samples), _ptr(inds), _stream()))
+    if det:
+        u = torch.linspace(0.0, 1.0, nsamples, dtype=torch.float32).to(bins.device)     # Sampler.h:21, ATen's own rounding
+        L.check(L.lib().nrf_sample_pdf(_ptr(bins), _ptr(weights), C.c_int64(n), nb, _ptr(u), nsamples, sum_vec, _ptr(samples), _ptr(inds), _stream()))
+    else:
+        u = RngFill(seed, L.NRF_RNG_U_PDF, ray_base * nsamples, n * nsamples, device=bins.device).reshape(n, nsamples) if u is None else _dev_f32(u)
+        assert u.shape == (n, nsamples)
+        L.check(L.lib().nrf_sample_pdf_rand(_ptr(bins), _ptr(weights), C.c_int64(n), nb, _ptr(u), nsamples, sum_vec, _ptr(samples), _ptr(inds), _stream()))
     return (samples, inds) if return_inds else samples
+
+
+def RngFill(seed, rng_stream, index0, count, normal=False, device="cuda"):
+    """include/nrf_rng.h: element k = draw(seed, rng_stream, index0 + k); uniform on [0,1) or standard normal."""
+    out = torch.empty((int(count),), device=device, dtype=torch.float32)
+    L.check(L.lib().nrf_rng_fill(C.c_uint64(int(seed)), C.c_uint32(int(rng_stream)), C.c_uint64(int(index0)), C.c_int64(int(count)), int(normal), _ptr(out), _stream()))
+    return out
+
+
+def JitterZ(z_vals, t_rand):
+    """NeRFRenderer.h:404-417 with explicit uniform draws t_rand [N,S]."""
+    z = _dev_f32(z_vals); t = _dev_f32(t_rand)
+    out = torch.empty_like(z)
+    L.check(L.lib().nrf_jitter_z(_ptr(z), _ptr(t), C.c_int64(z.shape[0]), z.shape[1], _ptr(out), _stream()))
+    return out
+
+
+def TangentScatter(pts, z_vals, cone_angle, rays_d, bounding_box=None, u_r=None, u_theta=None):
+    """NeRFRenderer.h:307-362 with explicit uniform draws u_r, u_theta [N,S(,1)] (the reference's two torch::rand tensors)."""
+    pts = _dev_f32(pts); z = _dev_f32(z_vals); d = _dev_f32(rays_d).reshape(-1, 3)
+    n, s = z.shape
+    rays = torch.cat([torch.zeros_like(d), d], -1).contiguous()          # only columns 3..5 (rays_d) are read when pts are explicit
+    bb = _host_f32(bounding_box, 6) if bounding_box is not None else None
+    out = torch.empty_like(pts)
+    L.check(L.lib().nrf_tangent_scatter(_ptr(pts), _ptr(rays), 6, _ptr(z), C.c_int64(n), s, C.c_float(float(cone_angle)), _ptr(_dev_f32(u_r).reshape(n, s)),
+                                        _ptr(_dev_f32(u_theta).reshape(n, s)), bb.ctypes.data_as(C.c_void_p) if bb is not None else None, _ptr(out), _stream()))
+    return out
+
+
+def StochasticPrecondition(pts, noise, alpha, bounding_box):
+    """NeRFRenderer.h:433-443 + ReflectBoundary :285-304: reflect(pts + noise*alpha)."""
+    pts = _dev_f32(pts); nz = _dev_f32(noise)
+    bb = _host_f32(bounding_box, 6)
+    out = torch.empty_like(pts)
+    L.check(L.lib().nrf_precondition(_ptr(pts), _ptr(nz), C.c_float(alpha), bb.ctypes.data_as(C.c_void_p), C.c_int64(pts.numel() // 3), _ptr(out), _stream()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -115,6 +155,8 @@ class NeRFRenderParams:               # NeRFRenderer.h:28-44 (same defaults)
     # not in the reference: MLP arithmetic (L.NRF_PREC_F32 parity mode / L.NRF_PREC_F16_MFMA fast mode)
     Precision: int = L.NRF_PREC_F32
     KeepIntermediates: bool = False
+    # not in the reference (it draws from torch's global RNG): seed of the counter-based draws of the stochastic branches
+    Seed: int = 0
 
 
 class NeRFRenderer:
@@ -168,11 +210,19 @@ class NeRFRenderer:
         L.check(L.lib().nrf_run_network(self._r, _ptr(pts), _ptr(vd), C.c_int64(n), s, precision, _ptr(raw), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
         return raw
 
-    def RawToOutputs(self, raw, cone_angle, z_vals, rays_d, raw_noise_std=0.0, white_bkgr=False):
-        """NeRFRenderer.h:199-282 (raw_noise_std must be 0: randn is a training-time branch)."""
-        if raw_noise_std > 0:
-            raise L.NrfError("RawToOutputs(raw_noise_std > 0) is the training-time noise branch; not built")
+    def RawToOutputs(self, raw, cone_angle, z_vals, rays_d, raw_noise_std=0.0, white_bkgr=False, noise=None):
+        """NeRFRenderer.h:199-282.  raw_noise_std > 0 needs `noise` [N,S], the normal draws the reference takes from torch::randn_like."""
         raw = _dev_f32(raw); z = _dev_f32(z_vals); d = _dev_f32(rays_d)
+        if raw_noise_std > 0:
+            if noise is None:
+                raise L.NrfError("RawToOutputs(raw_noise_std > 0): pass the normal draws as `noise` (RngFill(..., normal=True) or your own)")
+            n, s, c = raw.shape
+            o = NeRFRendererOutputs(RGBMap=torch.empty((n, 3), device=raw.device), DispMap=torch.empty((n,), device=raw.device),
+                                    AccMap=torch.empty((n,), device=raw.device), Weights=torch.empty((n, s), device=raw.device),
+                                    DepthMap=torch.empty((n,), device=raw.device))
+            L.check(L.lib().nrf_raw2outputs_noise(_ptr(raw), _ptr(z), _ptr(d), 3, C.c_int64(n), s, c, int(white_bkgr), _ptr(_dev_f32(noise)),
+                                                  C.c_float(raw_noise_std), _ptr(o.RGBMap), _ptr(o.DispMap), _ptr(o.AccMap), _ptr(o.Weights), _ptr(o.DepthMap), _stream()))
+            return o
         n, s, c = raw.shape
         o = NeRFRendererOutputs(RGBMap=torch.empty((n, 3), device=raw.device), DispMap=torch.empty((n,), device=raw.device),
                                 AccMap=torch.empty((n,), device=raw.device), Weights=torch.empty((n, s), device=raw.device),
@@ -184,13 +234,9 @@ class NeRFRenderer:
     # ---- public surface ----
     def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
                    raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True,
-                   precision=L.NRF_PREC_F32, keep_intermediates=False):
-        """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11]."""
-        if perturb > 0 or raw_noise_std > 0 or stochastic_preconditioning_alpha > 0:
-            raise L.NrfError("perturb / raw_noise_std / stochastic preconditioning draw torch RNG: training-time branches, not built")
-        if cone_angle is not None and torch.is_tensor(cone_angle) and cone_angle.numel():
-            raise L.NrfError("a defined cone_angle selects TangentScatter (random in-cone offsets, NeRFRenderer.h:307-362); "
-                             "render with ThinRay=True for the deterministic path")
+                   precision=L.NRF_PREC_F32, keep_intermediates=False, seed=0, ray_base=0):
+        """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11].  The stochastic branches (perturb, a defined cone_angle,
+        raw_noise_std, stochastic preconditioning) draw from the library's counter RNG keyed by (seed, ray_base + ray, sample)."""
         rays = _dev_f32(ray_batch)
         n, stride = rays.shape
         dev = rays.device
@@ -200,6 +246,13 @@ class NeRFRenderer:
         t = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)                      # NeRFRenderer.h:393
         u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev) if ni > 0 else None   # Sampler.h:21
         rp = L.RenderParams(s, ni, int(lin_disp), int(white_bkgr), precision, ATEN_SUM_VEC)
+        rp.perturb, rp.raw_noise_std, rp.precond_alpha = float(perturb), float(raw_noise_std), float(stochastic_preconditioning_alpha)
+        if cone_angle is not None and (not torch.is_tensor(cone_angle) or cone_angle.numel()):
+            rp.has_cone, rp.cone_angle = 1, float(cone_angle)
+        if bounding_box is not None:
+            rp.has_bbox = 1
+            rp.bbox = (C.c_float * 6)(*_host_f32(bounding_box, 6).tolist())
+        rp.seed, rp.ray_base = int(seed), int(ray_base)
         res = NeRFRenderResult()
         so = sf if ni > 0 else s
         o = res.Outputs
@@ -225,7 +278,8 @@ class NeRFRenderer:
 
     def BatchifyRays(self, rays_flat, cone_angle, n_samples, chunk=1024 * 32, **kw):
         """NeRFRenderer.h:465-525: host loop over Chunk-sized slices, torch.cat of every defined field."""
-        results = [self.RenderRays(rays_flat[i:i + chunk], cone_angle, n_samples, **kw) for i in range(0, rays_flat.shape[0], chunk)]
+        base = kw.pop("ray_base", 0)
+        results = [self.RenderRays(rays_flat[i:i + chunk], cone_angle, n_samples, ray_base=base + i, **kw) for i in range(0, rays_flat.shape[0], chunk)]
         res = NeRFRenderResult()
 
         def cat(get):
@@ -264,7 +318,8 @@ class NeRFRenderer:
         all_ret = self.BatchifyRays(rays_, None if p.ThinRay else cone_angle, p.NSamples, p.Chunk, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
                                     perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
                                     stochastic_preconditioning_alpha=p.StochasticPreconditioningAlpha, bounding_box=p.BoundingBox,
-                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates)
+                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates, seed=p.Seed,
+                                    ray_base=row0 * w if c2w is not None else 0)
         out = all_ret.Outputs
         if out.RGBMap is not None:
             out.RGBMap = out.RGBMap.reshape(sh)                                                       # :591-592

@@ -269,8 +269,16 @@ class Model:
                           _p(k["params"]), n_layers, hidden, geo, n_layers_c, hidden_c, depth, width, skip)
 
 
+class OrcStoch(C.Structure):
+    _fields_ = [("perturb", C.c_float), ("has_cone", C.c_int), ("cone_angle", C.c_float), ("raw_noise_std", C.c_float), ("precond_alpha", C.c_float),
+                ("seed", C.c_uint64), ("ray_base", C.c_int64)] + [(k, C.c_void_p) for k in
+                ("t_rand", "u_r1", "u_theta1", "noise1", "u_pdf", "precond", "u_r2", "u_theta2", "noise2")]
+
+
 def render_rays(model: Model, rays, n_samples, n_importance, t_coarse, u_fine, lindisp=False, white_bkgr=True, want_intermediates=False,
-                sum_vec=ATEN_VEC):
+                sum_vec=ATEN_VEC, stoch=None):
+    """stoch: None (deterministic render path) or a dict with perturb / cone_angle (None = thin rays) / raw_noise_std / precond_alpha /
+    seed / ray_base and, optionally, explicit draw arrays t_rand, u_r1, u_theta1, noise1, u_pdf, precond, u_r2, u_theta2, noise2."""
     rays = _f(rays)
     n = rays.shape[0]
     s, sf = n_samples, n_samples + n_importance
@@ -280,12 +288,75 @@ def render_rays(model: Model, rays, n_samples, n_importance, t_coarse, u_fine, l
     inter = {}
     if want_intermediates:
         inter = dict(z_coarse=np.empty((n, s), np.float32), z_fine=np.empty((n, sf), np.float32), raw_coarse=np.empty((n, s, 4), np.float32),
-                     raw_fine=np.empty((n, sf, 4), np.float32), weights_coarse=np.empty((n, s), np.float32))
-    lib().orc_render_rays(C.byref(model.c), _p(rays), C.c_int64(n), C.c_int(n_samples), C.c_int(n_importance), _p(t_coarse), _p(u_fine),
-                          C.c_int(int(lindisp)), C.c_int(int(white_bkgr)), C.c_int(sum_vec), _p(out["rgb"]), _p(out["disp"]), _p(out["acc"]), _p(out["depth"]),
-                          _p(out["weights"]), _p(inter.get("z_coarse")), _p(inter.get("z_fine")), _p(inter.get("raw_coarse")),
-                          _p(inter.get("raw_fine")), _p(inter.get("weights_coarse")))
+                     raw_fine=np.empty((n, sf, 4), np.float32), weights_coarse=np.empty((n, s), np.float32),
+                     pts_coarse=np.empty((n, s, 3), np.float32), pts_fine=np.empty((n, sf, 3), np.float32))
+    st, keep = None, []
+    if stoch is not None:
+        cone = stoch.get("cone_angle")
+        st = OrcStoch(float(stoch.get("perturb", 0.0)), int(cone is not None), float(cone or 0.0), float(stoch.get("raw_noise_std", 0.0)),
+                      float(stoch.get("precond_alpha", 0.0)), int(stoch.get("seed", 0)), int(stoch.get("ray_base", 0)))
+        for k in ("t_rand", "u_r1", "u_theta1", "noise1", "u_pdf", "precond", "u_r2", "u_theta2", "noise2"):
+            if stoch.get(k) is not None:
+                a = _f(stoch[k]); keep.append(a)
+                setattr(st, k, a.ctypes.data)
+    lib().orc_render_rays_stoch(C.byref(model.c), _p(rays), C.c_int64(n), C.c_int(n_samples), C.c_int(n_importance), _p(t_coarse), _p(u_fine),
+                                C.c_int(int(lindisp)), C.c_int(int(white_bkgr)), C.c_int(sum_vec), C.byref(st) if st is not None else None,
+                                _p(out["rgb"]), _p(out["disp"]), _p(out["acc"]), _p(out["depth"]),
+                                _p(out["weights"]), _p(inter.get("z_coarse")), _p(inter.get("z_fine")), _p(inter.get("raw_coarse")),
+                                _p(inter.get("raw_fine")), _p(inter.get("weights_coarse")), _p(inter.get("pts_coarse")), _p(inter.get("pts_fine")))
     out.update(inter)
+    return out
+
+
+def rng_uniform(seed, stream, idx0, count):
+    out = np.empty(count, np.float32)
+    lib().orc_rng_uniform(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(idx0), C.c_int64(count), _p(out))
+    return out
+
+
+def rng_normal(seed, stream, idx0, count):
+    out = np.empty(count, np.float32)
+    lib().orc_rng_normal(C.c_uint64(seed), C.c_uint32(stream), C.c_uint64(idx0), C.c_int64(count), _p(out))
+    return out
+
+
+def jitter_z(z, t_rand):
+    z = _f(z); t_rand = _f(t_rand)
+    out = np.empty_like(z)
+    lib().orc_jitter_z(_p(z), _p(t_rand), C.c_int64(z.shape[0]), C.c_int(z.shape[1]), _p(out))
+    return out
+
+
+def tangent_scatter(pts, z, cone_angle, rays_d, u_r, u_theta, bbox=None):
+    pts = _f(pts); z = _f(z); rays_d = _f(rays_d); u_r = _f(u_r); u_theta = _f(u_theta); bb = _f(bbox) if bbox is not None else None
+    out = np.empty_like(pts)
+    lib().orc_tangent_scatter(_p(pts), _p(z), C.c_float(cone_angle), _p(rays_d), _p(u_r), _p(u_theta), _p(bb), C.c_int64(z.shape[0]), C.c_int(z.shape[1]), _p(out))
+    return out
+
+
+def precondition(pts, noise, alpha, bbox):
+    pts = _f(pts); noise = _f(noise); bb = _f(bbox)
+    out = np.empty_like(pts)
+    lib().orc_precondition(_p(pts), _p(noise), C.c_float(alpha), _p(bb), C.c_int64(pts.size // 3), _p(out))
+    return out
+
+
+def sample_pdf_rand(bins, weights, u, sum_vec=ATEN_VEC):
+    bins = _f(bins); weights = _f(weights); u = _f(u)
+    n, nb = bins.shape
+    ns = u.shape[1]
+    samples = np.empty((n, ns), np.float32); inds = np.empty((n, ns), np.int64)
+    lib().orc_sample_pdf_rand(_p(bins), _p(weights), C.c_int64(n), C.c_int(nb), _p(u), C.c_int(ns), C.c_int(sum_vec), _p(samples), _p(inds))
+    return samples, inds
+
+
+def raw2outputs_noise(raw, z, d, noise, noise_std, white_bkgr=False):
+    raw = _f(raw); z = _f(z); d = _f(d); noise = _f(noise)
+    n, s, c = raw.shape
+    out = dict(rgb=np.empty((n, 3), np.float32), disp=np.empty(n, np.float32), acc=np.empty(n, np.float32), weights=np.empty((n, s), np.float32),
+               depth=np.empty(n, np.float32))
+    lib().orc_raw2outputs_noise(_p(raw), _p(z), _p(d), C.c_int64(n), C.c_int(s), C.c_int(c), C.c_int(int(white_bkgr)), _p(noise), C.c_float(noise_std),
+                                _p(out["rgb"]), _p(out["disp"]), _p(out["acc"]), _p(out["weights"]), _p(out["depth"]))
     return out
 
 

@@ -32,7 +32,8 @@
  */
 #include <math.h>
 #include <stdint.h>
-#include "nrf_math.h"   /* portable exp/log/sin/cos: identical bits on CPU and GPU (see the header) */
+#include "nrf_math.h"
+#include "nrf_rng.h"   /* portable exp/log/sin/cos: identical bits on CPU and GPU (see the header) */
 #include <stdlib.h>
 #include <string.h>
 
@@ -268,6 +269,105 @@ ORC_API void orc_points(const float *o, const float *d, const float *z, int64_t 
         for (int j = 0; j < s; j++)
             for (int a = 0; a < 3; a++)
                 pts[(i * s + j) * 3 + a] = o[i * 3 + a] + d[i * 3 + a] * z[i * s + j];
+}
+
+/* Counter-based draws (include/nrf_rng.h): element k of the array gets index idx0 + k. */
+ORC_API void orc_rng_uniform(uint64_t seed, uint32_t stream, uint64_t idx0, int64_t count, float *out)
+{
+    OMP_FOR
+    for (int64_t k = 0; k < count; k++) out[k] = nrf_rng_uniform(seed, stream, idx0 + (uint64_t)k);
+}
+
+ORC_API void orc_rng_normal(uint64_t seed, uint32_t stream, uint64_t idx0, int64_t count, float *out)
+{
+    OMP_FOR
+    for (int64_t k = 0; k < count; k++) out[k] = nrf_rng_normal(seed, stream, idx0 + (uint64_t)k);
+}
+
+/* R6  stratified jitter (Perturb > 0)      NeRFRenderer.h:404-417
+ *     mids = .5*(z[1:]+z[:-1]) ; upper = [mids, z[-1]] ; lower = [z[0], mids] ; interval = upper-lower ;
+ *     z' = lower + (interval > 1e-8 ? interval*t_rand : 0)           t_rand: the [n,s] uniform draws */
+ORC_API void orc_jitter_z(const float *z, const float *t_rand, int64_t n, int s, float *out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        const float *zi = z + i * s;
+        for (int k = 0; k < s; k++) {
+            float upper = (k < s - 1) ? 0.5f * (zi[k + 1] + zi[k]) : zi[s - 1];
+            float lower = (k > 0) ? 0.5f * (zi[k] + zi[k - 1]) : zi[0];
+            float interval = upper - lower;
+            out[i * s + k] = lower + ((interval > 1e-8f) ? interval * t_rand[i * s + k] : 0.0f);
+        }
+    }
+}
+
+/* R7  TangentScatter                       NeRFRenderer.h:307-362
+ *     dn = d / max(|d|, 1e-8) ; up = the axis dn is least aligned with (x if |dx| strictly smallest, else y if |dy|
+ *     strictly smallest, else z) ; tangent = normalize(dn x up) ; bitangent = normalize(dn x tangent) ;
+ *     r = sqrt(clamp(U1, 1e-8, 1-1e-8)) ; theta = fmod(U2*2*pi, 2*pi) ; offset = tangent*r*cos + bitangent*r*sin ;
+ *     pts += offset * (cone_angle*z) ; clamp to the bounding box when one is given.
+ *     u_r, u_theta: the [n,s] uniform draws (torch::rand at :342-343). */
+static inline void normalize3(float *v)
+{
+    float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    nrm = f_max(nrm, 1e-8f);
+    v[0] = v[0] / nrm; v[1] = v[1] / nrm; v[2] = v[2] / nrm;
+}
+
+static inline void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+ORC_API void orc_tangent_scatter(const float *pts, const float *z, float cone_angle, const float *rays_d, const float *u_r,
+                                 const float *u_theta, const float *bbox /* [6] or NULL */, int64_t n, int s, float *out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        float dn[3] = {rays_d[i * 3], rays_d[i * 3 + 1], rays_d[i * 3 + 2]};
+        normalize3(dn);
+        const float ax = fabsf(dn[0]), ay = fabsf(dn[1]), az = fabsf(dn[2]);
+        const int mx = (ax < ay) && (ax < az), my = (ay < ax) && (ay < az);
+        float up[3] = {mx ? 1.0f : 0.0f, (!mx && my) ? 1.0f : 0.0f, (!mx && !my) ? 1.0f : 0.0f};
+        float tg[3], bt[3];
+        cross3(dn, up, tg); normalize3(tg);
+        cross3(dn, tg, bt); normalize3(bt);
+        for (int k = 0; k < s; k++) {
+            const int64_t q = i * s + k;
+            float u1 = u_r[q];
+            u1 = f_min(f_max(u1, 1e-8f), 1.0f - 1e-8f);
+            const float r = sqrtf(u1);
+            const float theta = fmodf(u_theta[q] * 2.0f * (float)M_PI, (float)(2.0f * M_PI));
+            float sn, cs;
+            nrf_sincosf(theta, &sn, &cs);
+            const float ox = r * cs, oy = r * sn;
+            const float radius = cone_angle * z[q];
+            for (int a = 0; a < 3; a++) {
+                float v = pts[q * 3 + a] + (tg[a] * ox + bt[a] * oy) * radius;
+                if (bbox) v = f_min(f_max(v, bbox[a]), bbox[3 + a]);
+                out[q * 3 + a] = v;
+            }
+        }
+    }
+}
+
+/* Stochastic preconditioning + ReflectBoundary      NeRFRenderer.h:433-443, :285-304
+ *     pts += noise*alpha ; x = (pts-min)/(max-min) ; x = fmod(x, 2) ; x > 1 -> 2 - x ; pts = x*(max-min)+min
+ *     (fmod keeps the sign, so points pushed below the box minimum stay outside: reference behaviour). */
+ORC_API void orc_precondition(const float *pts, const float *noise, float alpha, const float *bbox, int64_t p, float *out)
+{
+    OMP_FOR
+    for (int64_t q = 0; q < p; q++)
+        for (int a = 0; a < 3; a++) {
+            const float ext = bbox[3 + a] - bbox[a];
+            float v = pts[q * 3 + a] + noise[q * 3 + a] * alpha;
+            float x = (v - bbox[a]) / ext;
+            x = fmodf(x, 2.0f);
+            if (x > 1.0f) x = 2.0f - x;
+            out[q * 3 + a] = x * ext + bbox[a];
+        }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -736,19 +836,26 @@ ORC_API void orc_lerf(const float *params, const float *x, int64_t p, int in_ch,
  *     raw has `c` channels per sample with rgb at 0..2 and sigma at 3 (c = 4 or 5).
  * ------------------------------------------------------------------------------------------ */
 static void raw2outputs_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int sigma_ch, int white_bkgr,
-                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth);
+                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth, const float *noise, float noise_std);
 
 ORC_API void orc_raw2outputs(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
                              float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
 {
-    raw2outputs_impl(raw, z, d, n, s, c, 3, white_bkgr, rgb_map, disp, acc_map, weights, depth);
+    raw2outputs_impl(raw, z, d, n, s, c, 3, white_bkgr, rgb_map, disp, acc_map, weights, depth, NULL, 0.0f);
+}
+
+/* RawNoiseStd > 0 (training): sigma + noise*std before the relu (NeRFRenderer.h:251-252); noise: the [n,s] normal draws */
+ORC_API void orc_raw2outputs_noise(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr, const float *noise,
+                                   float noise_std, float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
+{
+    raw2outputs_impl(raw, z, d, n, s, c, 3, white_bkgr, rgb_map, disp, acc_map, weights, depth, noise, noise_std);
 }
 
 /* L2  LeRFRenderer::RawToLEOutputs, weights part   LeRFRenderer.cpp:27-76 (sigma_le at channel lang_embed_dim, no colour) */
 ORC_API void orc_raw2weights(const float *raw, int c, int sigma_ch, const float *z, const float *d, int64_t n, int s,
                              float *weights, float *depth, float *disp, float *acc_map)
 {
-    raw2outputs_impl(raw, z, d, n, s, c, sigma_ch, 0, NULL, disp, acc_map, weights, depth);
+    raw2outputs_impl(raw, z, d, n, s, c, sigma_ch, 0, NULL, disp, acc_map, weights, depth, NULL, 0.0f);
 }
 
 /* L2  RenderCLIPEmbedding                          LeRFRenderer.h:45-54: normalize(sum_s w*e, eps 1e-8) */
@@ -769,7 +876,7 @@ ORC_API void orc_render_clip_embedding(const float *embeds, int stride, int dim,
 }
 
 static void raw2outputs_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int sigma_ch, int white_bkgr,
-                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth)
+                             float *rgb_map, float *disp, float *acc_map, float *weights, float *depth, const float *noise, float noise_std)
 {
     OMP_FOR
     for (int64_t i = 0; i < n; i++) {
@@ -782,7 +889,9 @@ static void raw2outputs_impl(const float *raw, const float *z, const float *d, i
             const float *r = raw + (i * s + j) * c;
             float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
             dist = dist * nrm;
-            float sig = r[sigma_ch] > 0.0f ? r[sigma_ch] : 0.0f;
+            float sraw = r[sigma_ch];
+            if (noise) sraw = sraw + noise[i * s + j] * noise_std;
+            float sig = sraw > 0.0f ? sraw : 0.0f;
             float alpha = -nrf_expf(-sig * dist) + 1.0f;
             float trans = nrf_expf(tprev);
             float w = alpha * trans;
@@ -816,7 +925,23 @@ static void raw2outputs_impl(const float *raw, const float *z, const float *d, i
  *     t = (u - cdf[below]) / denom ; sample = bins[below] + t*(bins[above]-bins[below])
  *     bins: [n, nb], weights: [n, nb-1], u: [ns] (torch::linspace(0,1,ns) supplied by the host).
  * ------------------------------------------------------------------------------------------ */
+static void sample_pdf_impl(const float *bins, const float *weights, int64_t n, int nb, const float *u_all, int64_t u_stride, int ns, int sum_vec,
+                            float *samples, int64_t *inds_out, float *cdf_out);
+
 ORC_API void orc_sample_pdf(const float *bins, const float *weights, int64_t n, int nb, const float *u, int ns, int sum_vec,
+                            float *samples, int64_t *inds_out, float *cdf_out)
+{
+    sample_pdf_impl(bins, weights, n, nb, u, 0, ns, sum_vec, samples, inds_out, cdf_out);
+}
+
+/* det = false (Sampler.h:22-24): u = torch::rand([n, ns]), one row per ray, NOT sorted; everything else is unchanged */
+ORC_API void orc_sample_pdf_rand(const float *bins, const float *weights, int64_t n, int nb, const float *u /* [n,ns] */, int ns, int sum_vec,
+                                 float *samples, int64_t *inds_out)
+{
+    sample_pdf_impl(bins, weights, n, nb, u, ns, ns, sum_vec, samples, inds_out, NULL);
+}
+
+static void sample_pdf_impl(const float *bins, const float *weights, int64_t n, int nb, const float *u_all, int64_t u_stride, int ns, int sum_vec,
                             float *samples, int64_t *inds_out, float *cdf_out)
 {
     OMP_FOR
@@ -830,6 +955,7 @@ ORC_API void orc_sample_pdf(const float *bins, const float *weights, int64_t n, 
         for (int k = 0; k < nw; k++) { float pdf = wv[k] / fsum; run += (double)pdf; cdf[k + 1] = (float)run; }
         if (cdf_out) memcpy(cdf_out + i * nb, cdf, sizeof(float) * nb);
         const float *b = bins + i * nb;
+        const float *u = u_all + i * u_stride;
         for (int j = 0; j < ns; j++) {
             int lo = 0, hi = nb;                 /* first index with cdf[idx] > u */
             while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u[j]) lo = mid + 1; else hi = mid; }
@@ -920,12 +1046,52 @@ static void run_network(const orc_model *m, const float *pts, const float *viewd
     free(emb); free(embd); free(xin);
 }
 
+/* The stochastic branches of RenderRays.  Every draw array may be given explicitly (the reference's own torch::rand / randn draws,
+ * replayed: that is how tests pin this code against the reference) or left NULL, in which case it is generated from
+ * (seed, stream, global element index) with include/nrf_rng.h -- the definition the HIP renderer uses. */
+typedef struct {
+    float perturb;                 /* > 0: stratified jitter + SamplePDF(det = false) */
+    int has_cone; float cone_angle;/* cone rays (ThinRay = false): TangentScatter on both passes */
+    float raw_noise_std, precond_alpha;
+    uint64_t seed; int64_t ray_base;   /* index of rays[0] in the whole image (Chunk / shard independence) */
+    const float *t_rand, *u_r1, *u_theta1, *noise1, *u_pdf, *precond, *u_r2, *u_theta2, *noise2;
+} orc_stoch;
+
+static float *draws(const float *given, int normal, uint64_t seed, uint32_t stream, int64_t idx0, int64_t count)
+{
+    float *a = (float *)malloc(sizeof(float) * (count > 0 ? count : 1));
+    if (given) memcpy(a, given, sizeof(float) * count);
+    else if (normal) orc_rng_normal(seed, stream, (uint64_t)idx0, count, a);
+    else orc_rng_uniform(seed, stream, (uint64_t)idx0, count, a);
+    return a;
+}
+
+ORC_API void orc_render_rays_stoch(const orc_model *m, const float *rays, int64_t n, int n_samples, int n_importance,
+                             const float *t_coarse, const float *u_fine, int lindisp, int white_bkgr, int sum_vec, const orc_stoch *st,
+                             float *rgb, float *disp, float *acc, float *depth, float *weights_fine,
+                             float *z_coarse_out, float *z_fine_out, float *raw_coarse_out, float *raw_fine_out,
+                             float *weights_coarse_out, float *pts_coarse_out, float *pts_fine_out);
+
 ORC_API void orc_render_rays(const orc_model *m, const float *rays, int64_t n, int n_samples, int n_importance,
                              const float *t_coarse, const float *u_fine, int lindisp, int white_bkgr, int sum_vec,
                              float *rgb, float *disp, float *acc, float *depth, float *weights_fine,
                              float *z_coarse_out, float *z_fine_out, float *raw_coarse_out, float *raw_fine_out,
                              float *weights_coarse_out)
 {
+    orc_render_rays_stoch(m, rays, n, n_samples, n_importance, t_coarse, u_fine, lindisp, white_bkgr, sum_vec, NULL, rgb, disp, acc, depth,
+                          weights_fine, z_coarse_out, z_fine_out, raw_coarse_out, raw_fine_out, weights_coarse_out, NULL, NULL);
+}
+
+ORC_API void orc_render_rays_stoch(const orc_model *m, const float *rays, int64_t n, int n_samples, int n_importance,
+                             const float *t_coarse, const float *u_fine, int lindisp, int white_bkgr, int sum_vec, const orc_stoch *st,
+                             float *rgb, float *disp, float *acc, float *depth, float *weights_fine,
+                             float *z_coarse_out, float *z_fine_out, float *raw_coarse_out, float *raw_fine_out,
+                             float *weights_coarse_out, float *pts_coarse_out, float *pts_fine_out)
+{
+    const int jitter = st && st->perturb > 0.0f, cone = st && st->has_cone;
+    const float nstd = st ? st->raw_noise_std : 0.0f, palpha = st ? st->precond_alpha : 0.0f;
+    const int64_t rb = st ? st->ray_base : 0;
+    const uint64_t seed = st ? st->seed : 0;
     const int s = n_samples, sf = n_samples + n_importance;
     float *o = (float *)malloc(sizeof(float) * n * 3), *d = (float *)malloc(sizeof(float) * n * 3), *vd = (float *)malloc(sizeof(float) * n * 3);
     float *nears = (float *)malloc(sizeof(float) * n), *fars = (float *)malloc(sizeof(float) * n);
@@ -937,12 +1103,25 @@ ORC_API void orc_render_rays(const orc_model *m, const float *rays, int64_t n, i
     float *raw = (float *)malloc(sizeof(float) * n * sf * 4), *wc = (float *)malloc(sizeof(float) * n * s);
     float *c_rgb = (float *)malloc(sizeof(float) * n * 3);
     orc_z_vals(nears, fars, t_coarse, n, s, lindisp, z);
+    if (jitter) {                                                                       /* :404-417 */
+        float *tr = draws(st->t_rand, 0, seed, NRF_RNG_T_RAND, rb * s, n * s), *zj = (float *)malloc(sizeof(float) * n * s);
+        orc_jitter_z(z, tr, n, s, zj);
+        memcpy(z, zj, sizeof(float) * n * s);
+        free(tr); free(zj);
+    }
     orc_points(o, d, z, n, s, pts);
+    if (cone) {                                                                         /* :420 */
+        float *ur = draws(st->u_r1, 0, seed, NRF_RNG_R_COARSE, rb * s, n * s), *ut = draws(st->u_theta1, 0, seed, NRF_RNG_THETA_COARSE, rb * s, n * s);
+        orc_tangent_scatter(pts, z, st->cone_angle, d, ur, ut, m->bbox, n, s, pts);
+        free(ur); free(ut);
+    }
+    if (pts_coarse_out) memcpy(pts_coarse_out, pts, sizeof(float) * n * s * 3);
     run_network(m, pts, vd, n, s, raw);
-    if (n_importance <= 0) {
-        orc_raw2outputs(raw, z, d, n, s, 4, white_bkgr, rgb, disp, acc, weights_fine, depth);
-    } else {
-        orc_raw2outputs(raw, z, d, n, s, 4, white_bkgr, c_rgb, NULL, NULL, wc, NULL);
+    {
+        float *nz = nstd > 0.0f ? draws(st->noise1, 1, seed, NRF_RNG_NOISE_COARSE, rb * s, n * s) : NULL;
+        if (n_importance <= 0) raw2outputs_impl(raw, z, d, n, s, 4, 3, white_bkgr, rgb, disp, acc, weights_fine, depth, nz, nstd);
+        else raw2outputs_impl(raw, z, d, n, s, 4, 3, white_bkgr, c_rgb, NULL, NULL, wc, NULL, nz, nstd);
+        free(nz);
     }
     if (z_coarse_out) memcpy(z_coarse_out, z, sizeof(float) * n * s);
     if (raw_coarse_out) memcpy(raw_coarse_out, raw, sizeof(float) * n * s * 4);
@@ -952,11 +1131,30 @@ ORC_API void orc_render_rays(const orc_model *m, const float *rays, int64_t n, i
         float *zs = (float *)malloc(sizeof(float) * n * n_importance), *zf = (float *)malloc(sizeof(float) * n * sf);
         orc_z_mid(z, n, s, mid);
         for (int64_t i = 0; i < n; i++) memcpy(wmid + i * (s - 2), wc + i * s + 1, sizeof(float) * (s - 2));   /* weights[..., 1:-1] */
-        orc_sample_pdf(mid, wmid, n, s - 1, u_fine, n_importance, sum_vec, zs, NULL, NULL);
+        if (jitter) {                                                                   /* SamplePDF(det = (perturb == 0)) :428 */
+            float *up = draws(st->u_pdf, 0, seed, NRF_RNG_U_PDF, rb * n_importance, n * n_importance);
+            orc_sample_pdf_rand(mid, wmid, n, s - 1, up, n_importance, sum_vec, zs, NULL);
+            free(up);
+        } else orc_sample_pdf(mid, wmid, n, s - 1, u_fine, n_importance, sum_vec, zs, NULL, NULL);
         orc_merge_sorted(z, s, zs, n_importance, n, zf);
         orc_points(o, d, zf, n, sf, pts);
+        if (palpha > 0.0f) {                                                            /* :433-443 */
+            float *pn = draws(st->precond, 1, seed, NRF_RNG_PRECOND, rb * sf * 3, n * sf * 3);
+            orc_precondition(pts, pn, palpha, m->bbox, n * sf, pts);
+            free(pn);
+        }
+        if (cone) {                                                                     /* :445 */
+            float *ur = draws(st->u_r2, 0, seed, NRF_RNG_R_FINE, rb * sf, n * sf), *ut = draws(st->u_theta2, 0, seed, NRF_RNG_THETA_FINE, rb * sf, n * sf);
+            orc_tangent_scatter(pts, zf, st->cone_angle, d, ur, ut, m->bbox, n, sf, pts);
+            free(ur); free(ut);
+        }
+        if (pts_fine_out) memcpy(pts_fine_out, pts, sizeof(float) * n * sf * 3);
         run_network(m, pts, vd, n, sf, raw);
-        orc_raw2outputs(raw, zf, d, n, sf, 4, white_bkgr, rgb, disp, acc, weights_fine, depth);
+        {
+            float *nz = nstd > 0.0f ? draws(st->noise2, 1, seed, NRF_RNG_NOISE_FINE, rb * sf, n * sf) : NULL;
+            raw2outputs_impl(raw, zf, d, n, sf, 4, 3, white_bkgr, rgb, disp, acc, weights_fine, depth, nz, nstd);
+            free(nz);
+        }
         if (z_fine_out) memcpy(z_fine_out, zf, sizeof(float) * n * sf);
         if (raw_fine_out) memcpy(raw_fine_out, raw, sizeof(float) * n * sf * 4);
         free(mid); free(wmid); free(zs); free(zf);

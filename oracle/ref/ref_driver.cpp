@@ -494,6 +494,32 @@ static void g_render()
 			auto res = spy.Render(0, 0, torch::Tensor(), rp, {o.reshape({-1, 3}).index({Slice(0, 40)}), d.reshape({-1, 3}).index({Slice(0, 40)}), cone});
 			dump_spy("render_hash_lindisp", spy, res);
 		}
+		// Stochastic branches (Perturb > 0, cone rays with TangentScatter, training-time noise / preconditioning).  The torch::rand /
+		// randn draws the reference makes are replayed after re-seeding (same shapes, same order) and saved next to its outputs, so
+		// a restatement fed the SAME draws can be compared value for value.
+		for (int variant = 0; variant < 2; variant++)
+		{
+			std::string stag = variant == 0 ? "render_stoch" : "render_stoch_train";
+			const int ns = 32, ni = 48, nr = h * w;
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+			auto rp = lego_params(ns, ni, nr);
+			rp.ThinRay = false; rp.Perturb = 1.f;
+			if (variant == 1) { rp.RawNoiseStd = 0.5f; rp.StochasticPreconditioningAlpha = 0.01f; }
+			torch::manual_seed(777);
+			auto res = spy.Render(h, w, k, rp, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+			dump_spy(stag, spy, res);
+			save_npy(stag + ".cone_angle", std::get<2>(GetRays(h, w, k, c2w)).reshape({1}));
+			torch::manual_seed(777);
+			save_npy(stag + ".t_rand", torch::rand({nr, ns}));					//NeRFRenderer.h:415
+			save_npy(stag + ".u_r1", torch::rand({nr, ns, 1}));				//:342
+			save_npy(stag + ".u_theta1", torch::rand({nr, ns, 1}));		//:343
+			if (variant == 1) save_npy(stag + ".noise1", torch::randn({nr, ns}));		//:252
+			save_npy(stag + ".u_pdf", torch::rand({nr, ni}));					//Sampler.h:23
+			if (variant == 1) save_npy(stag + ".precond", torch::randn({nr, ns + ni, 3}));		//:439
+			save_npy(stag + ".u_r2", torch::rand({nr, ns + ni, 1}));
+			save_npy(stag + ".u_theta2", torch::rand({nr, ns + ni, 1}));
+			if (variant == 1) save_npy(stag + ".noise2", torch::randn({nr, ns + ni}));
+		}
 	}
 	{
 		// C2 shape: PE(10)/PE(4) + NeRF 8x256 with viewdirs

@@ -515,10 +515,13 @@ def test_edge_cases_empty_ragged_and_limits(api):
     # limits are reported, not silently mis-rendered
     with pytest.raises(api.L.NrfError, match="outside the built range"):
         r.RenderRays(torch.zeros((4, 11), device="cuda"), None, 300, n_importance=128)
-    with pytest.raises(api.L.NrfError, match="TangentScatter"):
-        r.RenderRays(torch.zeros((4, 11), device="cuda"), torch.tensor(0.001), 64, n_importance=128)
-    with pytest.raises(api.L.NrfError):
-        api.R.SamplePDF(torch.zeros((2, 63), device="cuda"), torch.zeros((2, 62), device="cuda"), 128, det=False)
+    with pytest.raises(api.L.NrfError, match="bbox required"):
+        r.RenderRays(torch.zeros((4, 11), device="cuda"), None, 64, n_importance=128, stochastic_preconditioning_alpha=0.01)
+    # degenerate stochastic inputs: zero-length rays with a cone, all-zero weights with random u -> finite results
+    deg = r.RenderRays(torch.zeros((4, 11), device="cuda"), torch.tensor(0.001), 64, n_importance=128, perturb=1.0)
+    assert np.isfinite(host(deg.Outputs.RGBMap)).all()
+    smp = api.R.SamplePDF(torch.zeros((2, 63), device="cuda"), torch.zeros((2, 62), device="cuda"), 128, det=False, seed=3)
+    assert smp.shape == (2, 128) and np.isfinite(host(smp)).all()
     # rays that miss the box entirely: transparent, white background, finite depth
     far_o = torch.tensor([[10.0, 10.0, 10.0]], device="cuda").repeat(8, 1); away = torch.tensor([[1.0, 0.2, 0.1]], device="cuda").repeat(8, 1)
     miss = r.Render(0, 0, None, api.S.lego_render_params(sc["bbox"], chunk=8), rays=(far_o, away, None))
@@ -590,3 +593,98 @@ def test_lerf_render_pass_vs_oracle(api, O, manifest):
     w_gpu = api.R.LeRFRenderer.RawToLEOutputs(r, dev(rawf), dev(zf), dev(rays[:, 3:6]), 768)
     assert_exact(host(w_gpu.WeightsLE), fin["weights"], "nrf_raw2weights == oracle")
     assert_close(host(w_gpu.RenderedLangEmbedding)[hit], emb_ref[hit], rtol=1e-6, atol=1e-7, what="nrf_render_clip_embedding")
+
+
+# ------------------------------------------------------------------ stochastic branches (R6 jitter, R7 TangentScatter, det=false, noise)
+def test_counter_rng_matches_oracle(api, O):
+    for stream, normal in ((api.L.NRF_RNG_T_RAND, False), (api.L.NRF_RNG_U_PDF, False), (api.L.NRF_RNG_PRECOND, True)):
+        got = host(api.R.RngFill(1234567, stream, 1000003, 70001, normal=normal))
+        ref = O.rng_normal(1234567, stream, 1000003, 70001) if normal else O.rng_uniform(1234567, stream, 1000003, 70001)
+        assert_exact(got, ref, f"nrf_rng_fill stream {stream}")
+    big = host(api.R.RngFill(5, 2, (1 << 40) + 17, 4096))               # 64-bit element indices
+    assert_exact(big, O.rng_uniform(5, 2, (1 << 40) + 17, 4096))
+
+
+@pytest.mark.parametrize("tag", ["render_stoch", "render_stoch_train"])
+def test_stochastic_stages_with_reference_draws(api, O, tag):
+    """Every stochastic stage fed the reference's inputs and its replayed torch::rand / randn draws: == oracle bit for bit, and within
+    the sin/cos ulp of the reference's LibTorch values."""
+    g = load_golden(tag)
+    train = tag.endswith("train")
+    rays, bbox, cone = g["rays_flat"], load_golden("render_hash")["bbox"], float(g["cone_angle"][0])
+    ns, ni = 32, 48
+    z0 = O.z_vals(rays[:, 6], rays[:, 7], O.linspace(0, 1, ns))
+    zj = host(api.R.JitterZ(dev(z0), dev(g["t_rand"])))
+    assert_exact(zj, g["coarse_z"], "stratified jitter == reference")
+    p0 = O.points(rays[:, :3], rays[:, 3:6], zj)
+    pts = host(api.R.TangentScatter(dev(p0), dev(zj), cone, dev(rays[:, 3:6]), bbox, dev(g["u_r1"]), dev(g["u_theta1"])))
+    assert_exact(pts, O.tangent_scatter(p0, zj, cone, rays[:, 3:6], g["u_r1"], g["u_theta1"], bbox), "TangentScatter == oracle")
+    assert_close(pts, g["coarse_pts"], rtol=0, atol=2e-7, what="TangentScatter vs reference")
+    samples, inds = api.R.SamplePDF(dev(O.z_mid(g["coarse_z"])), dev(g["coarse_weights"][:, 1:-1]), ni, det=False, return_inds=True, u=dev(g["u_pdf"]))
+    s_ref, i_ref = O.sample_pdf_rand(O.z_mid(g["coarse_z"]), g["coarse_weights"][:, 1:-1], g["u_pdf"])
+    assert_exact(host(inds), i_ref, "det=false searchsorted indices"); assert_exact(host(samples), s_ref)
+    import ctypes as C
+    zf = torch.empty((rays.shape[0], ns + ni), device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    zc, wc, up = dev(g["coarse_z"]), dev(g["coarse_weights"]), dev(g["u_pdf"])
+    api.L.check(api.L.lib().nrf_fine_depths_rand(P(zc), P(wc), C.c_int64(rays.shape[0]), ns, P(up), ni, 8, P(zf), None))
+    assert_exact(host(zf), g["fine_z"], "fine depth set (unsorted draws -> sort) == reference")
+    pf = O.points(rays[:, :3], rays[:, 3:6], g["fine_z"])
+    if train:
+        pre = host(api.R.StochasticPrecondition(dev(pf), dev(g["precond"]), 0.01, bbox))
+        assert_exact(pre, O.precondition(pf, g["precond"], 0.01, bbox), "preconditioning + ReflectBoundary == oracle")
+        pf = pre
+    pf2 = host(api.R.TangentScatter(dev(pf), dev(g["fine_z"]), cone, dev(rays[:, 3:6]), bbox, dev(g["u_r2"]), dev(g["u_theta2"])))
+    assert_close(pf2, g["fine_pts"], rtol=0, atol=5e-7, what="fine points vs reference")
+    if train:
+        r = api.R.NeRFRenderer.RawToOutputs(None, dev(g["fine_raw"]), None, dev(g["fine_z"]), dev(rays[:, 3:6]), 0.5, True, noise=dev(g["noise2"]))
+        ref = O.raw2outputs_noise(g["fine_raw"], g["fine_z"], rays[:, 3:6], g["noise2"], 0.5, True)
+        assert_exact(host(r.RGBMap), ref["rgb"], "RawToOutputs(raw_noise_std) == oracle"); assert_exact(host(r.Weights), ref["weights"])
+        assert_close(host(r.RGBMap), g["out_rgb"], rtol=0, atol=2e-6, what="vs reference")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_stochastic_render_bit_exact_vs_oracle_and_chunk_independent(api, O, manifest, train):
+    """nrf_render_rays with its in-kernel counter RNG == the oracle generating the same draws; Chunk does not matter."""
+    g = load_golden("render_hash")
+    bbox = g["bbox"]
+    r, blob = _golden_hash_scene(api, manifest)
+    kw = dict(RawNoiseStd=0.5, StochasticPreconditioningAlpha=0.01) if train else {}
+    def params(chunk):
+        p = _params(api, bbox, chunk, Seed=4242, **{k: v for k, v in kw.items() if k != "RawNoiseStd"})
+        p.NSamples, p.NImportance, p.ThinRay, p.Perturb = 32, 48, False, 1.0
+        p.RawNoiseStd = kw.get("RawNoiseStd", 0.0)
+        return p
+    a = r.Render(8, 8, g["k"], params(64), c2w=g["c2w"])
+    b = r.Render(8, 8, g["k"], params(24), c2w=g["c2w"])
+    assert_exact(host(a.Outputs.RGBMap), host(b.Outputs.RGBMap), "stochastic render independent of Chunk")
+    _, _, cone = api.R.GetRays(8, 8, g["k"], g["c2w"])
+    model = O.Model(0, blob, bbox=bbox, table_f32=synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" in x[0]]))
+    st = dict(perturb=1.0, cone_angle=float(cone), seed=4242, raw_noise_std=kw.get("RawNoiseStd", 0.0), precond_alpha=kw.get("StochasticPreconditioningAlpha", 0.0))
+    oc = O.render_rays(model, host(a.Extras["rays_flat"]), 32, 48, O.linspace(0, 1, 32), None, white_bkgr=True, want_intermediates=True, stoch=st)
+    assert_exact(host(a.Extras["z_coarse"]), oc["z_coarse"], "jittered depths"); assert_exact(host(a.Extras["z_fine"]), oc["z_fine"], "fine sample set")
+    assert_exact(host(a.Raw), oc["raw_fine"], "fine raw (scattered points through the network)")
+    assert_exact(host(a.Outputs.RGBMap).reshape(-1, 3), oc["rgb"], "stochastic pixels == oracle bit for bit")
+    # a different seed is a different sample of the estimator; the same seed reproduces
+    p2 = params(64); p2.Seed = 4243
+    c = r.Render(8, 8, g["k"], p2, c2w=g["c2w"])
+    assert np.abs(host(c.Outputs.RGBMap) - host(a.Outputs.RGBMap)).max() > 1e-3
+    assert_exact(host(r.Render(8, 8, g["k"], params(64), c2w=g["c2w"]).Outputs.RGBMap), host(a.Outputs.RGBMap), "same seed reproduces")
+    # row-tile sharding (multi-GPU) draws the same numbers as the whole image
+    t = r.Render(8, 8, g["k"], params(64), c2w=g["c2w"], row0=3, rows=2)
+    assert_exact(host(t.Outputs.RGBMap), host(a.Outputs.RGBMap)[3:5], "row tile == slice of the full stochastic render")
+
+
+def test_stochastic_fast_paths_use_same_points(api, manifest):
+    """The matrix-core fast paths (CuHash + NeRFSmall, PE + NeRF) take the scattered points as explicit inputs: cone renders in F16 mode
+    stay close to the F32 mode (same draws; the sample set differs where fp16 weights move a random u across a CDF bin)."""
+    bbox = api.S.LEGO_BBOX
+    for make, chunk, floor in ((api.S.make_hash_scene, 4096, 35.0), (api.S.make_classic_scene, 2048, 35.0)):
+        r = make()["renderer"]
+        K = api.S.lego_K(24, 24); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+        outs = {}
+        for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA):
+            p = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=chunk, Perturb=1.0, WhiteBkgr=True, Ndc=False, UseViewdirs=True, ThinRay=False,
+                                       BoundingBox=bbox, Precision=prec, Seed=11)
+            outs[prec] = host(r.Render(24, 24, K, p, c2w=c2w).Outputs.RGBMap)
+        assert api.S.psnr(outs[api.L.NRF_PREC_F16_MFMA], outs[api.L.NRF_PREC_F32]) > floor

@@ -241,3 +241,90 @@ def test_synth_generator_matches_c_header():
         v ^= v >> 16; v = (v * 0x7FEB352D) & 0xFFFFFFFF; v ^= v >> 15; v = (v * 0x846CA68B) & 0xFFFFFFFF; v ^= v >> 16
         return v
     assert [int(mix(int(v))) for v in x] == [int(v) for v in u]
+
+
+# ------------------------------------------------------------------ stochastic branches (R6 jitter, R7 TangentScatter, det=false, noise)
+def _stoch_dict(g, train):
+    d = dict(perturb=1.0, cone_angle=float(g["cone_angle"][0]), t_rand=g["t_rand"], u_r1=g["u_r1"], u_theta1=g["u_theta1"], u_pdf=g["u_pdf"],
+             u_r2=g["u_r2"], u_theta2=g["u_theta2"])
+    if train:
+        d.update(raw_noise_std=0.5, precond_alpha=0.01, noise1=g["noise1"], precond=g["precond"], noise2=g["noise2"])
+    return d
+
+
+@pytest.mark.parametrize("tag", ["render_stoch", "render_stoch_train"])
+def test_stochastic_stages_with_replayed_draws(tag):
+    """Each stochastic stage, fed the reference's own inputs and its replayed torch::rand / randn draws."""
+    g = load_golden(tag)
+    train = tag.endswith("train")
+    rays, bbox, cone = g["rays_flat"], load_golden("render_hash")["bbox"], float(g["cone_angle"][0])
+    ns, ni = 32, 48
+    z0 = O.z_vals(rays[:, 6], rays[:, 7], O.linspace(0, 1, ns))
+    zj = O.jitter_z(z0, g["t_rand"])
+    assert_exact(zj, g["coarse_z"], "stratified jitter (NeRFRenderer.h:404-417)")
+    pts = O.tangent_scatter(O.points(rays[:, :3], rays[:, 3:6], zj), zj, cone, rays[:, 3:6], g["u_r1"], g["u_theta1"], bbox)
+    # the offsets are ~cone_angle*z ~ 1e-3..1e-2; sin/cos differ from SLEEF by an ulp -> 1e-9 absolute
+    assert_close(pts, g["coarse_pts"], rtol=0, atol=2e-7, what="TangentScatter (coarse)")
+    assert np.abs(g["coarse_pts"] - O.points(rays[:, :3], rays[:, 3:6], zj)).max() > 1e-4, "fixture must actually scatter"
+    # SamplePDF(det=false) on the reference's coarse weights: unsorted per-ray u
+    samples, _ = O.sample_pdf_rand(O.z_mid(g["coarse_z"]), g["coarse_weights"][:, 1:-1], g["u_pdf"])
+    zf = O.merge_sorted(g["coarse_z"], samples)
+    assert_exact(zf, g["fine_z"], "fine depths from det=false SamplePDF")
+    ptsf = O.points(rays[:, :3], rays[:, 3:6], zf)
+    if train:
+        ptsf = O.precondition(ptsf, g["precond"], 0.01, bbox)
+    ptsf = O.tangent_scatter(ptsf, zf, cone, rays[:, 3:6], g["u_r2"], g["u_theta2"], bbox)
+    assert_close(ptsf, g["fine_pts"], rtol=0, atol=5e-7, what="fine points (preconditioning + TangentScatter)")
+    if train:
+        r = O.raw2outputs_noise(g["fine_raw"], g["fine_z"], rays[:, 3:6], g["noise2"], 0.5, True)
+        assert_close(r["rgb"], g["out_rgb"], rtol=0, atol=2e-6, what="RawToOutputs with raw_noise_std")
+        assert_close(r["weights"], g["out_weights"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["render_stoch", "render_stoch_train"])
+def test_stochastic_render_end_to_end(tag, manifest):
+    g = load_golden(tag)
+    bbox = load_golden("render_hash")["bbox"]
+    out = O.render_rays(_hash_model(manifest, bbox), g["rays_flat"], 32, 48, O.linspace(0, 1, 32), None, white_bkgr=True, want_intermediates=True,
+                        stoch=_stoch_dict(g, tag.endswith("train")))
+    assert_exact(out["z_coarse"], g["coarse_z"], "jittered coarse z")
+    assert_close(out["pts_coarse"], g["coarse_pts"], rtol=0, atol=2e-7)
+    # scattered points differ from the reference's by ~1e-7 (SLEEF vs nrf_math sin/cos); the finest grid level (cell 6e-3, features
+    # +-0.5, sigma head x30) turns that into ~1e-4 relative on a weight
+    assert_close(out["weights_coarse"], g["coarse_weights"], rtol=0, atol=2e-4)
+    assert (out["z_fine"] == g["fine_z"]).mean() > 0.85
+    # end to end the chain is only as continuous as searchsorted: a fine sample that lands in a different CDF bin is a different
+    # Monte-Carlo sample (32+48 samples per ray here), so pixels agree to the estimator's noise, not to 1e-4.  The stage-wise test above,
+    # which feeds every stage the reference's own inputs, is the tight one.
+    assert_close(out["rgb"], g["out_rgb"], rtol=0, atol=2e-3, what="rgb")
+    assert_close(out["acc"], g["out_acc"], rtol=0, atol=2e-3, what="acc")
+    assert np.abs(out["rgb"] - g["out_rgb"].reshape(-1, 3)).mean() < 5e-5
+
+
+def test_counter_rng_properties():
+    """include/nrf_rng.h: uniform on the 24-bit grid in [0,1), streams independent, index-addressable (chunk independence)."""
+    u = O.rng_uniform(42, 2, 0, 1 << 18)
+    assert u.min() >= 0 and u.max() < 1 and np.all(u * 16777216 == np.round(u * 16777216))
+    assert abs(u.mean() - 0.5) < 3e-3 and abs(u.var() - 1 / 12) < 1e-3
+    hist = np.histogram(u, bins=64, range=(0, 1))[0]
+    assert np.abs(hist - u.size / 64).max() < 6 * np.sqrt(u.size / 64)
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.01
+    assert abs(np.corrcoef(u, O.rng_uniform(42, 3, 0, 1 << 18))[0, 1]) < 0.01
+    assert_exact(O.rng_uniform(42, 2, 1000, 500), u[1000:1500], "index-addressable")
+    nrm = O.rng_normal(7, 4, 0, 1 << 18)
+    assert abs(nrm.mean()) < 6e-3 and abs(nrm.std() - 1) < 6e-3 and abs((nrm ** 4).mean() - 3) < 0.1
+
+
+def test_stochastic_render_own_rng_is_chunk_independent(manifest):
+    """With draws generated from (seed, stream, global index) a render does not depend on how rays are chunked."""
+    g = load_golden("render_stoch")
+    bbox = load_golden("render_hash")["bbox"]
+    model = _hash_model(manifest, bbox)
+    st = dict(perturb=1.0, cone_angle=float(g["cone_angle"][0]), seed=99)
+    full = O.render_rays(model, g["rays_flat"], 32, 48, O.linspace(0, 1, 32), None, stoch=st)
+    a = O.render_rays(model, g["rays_flat"][:24], 32, 48, O.linspace(0, 1, 32), None, stoch=dict(st, ray_base=0))
+    b = O.render_rays(model, g["rays_flat"][24:], 32, 48, O.linspace(0, 1, 32), None, stoch=dict(st, ray_base=24))
+    assert_exact(np.concatenate([a["rgb"], b["rgb"]]), full["rgb"], "chunked == whole")
+    # and it is a Monte-Carlo render of the same (deliberately high-frequency) field as the reference's torch-RNG render: same image mean
+    assert abs(full["acc"].mean() - g["out_acc"].mean()) < 0.1 and abs(full["rgb"].mean() - g["out_rgb"].mean()) < 0.1
+    assert np.abs(full["rgb"] - g["out_rgb"].reshape(-1, 3)).max() > 1e-3, "different draws -> a different sample of the estimator"
