@@ -31,6 +31,8 @@ UNITS_PER_RAY = NS + NS + NI          # one shared network, fine pass re-evaluat
 # algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)
 HASH_BYTES_PER_UNIT = 16 * 8 * 2 * 2 + 12 + 64      # table gathers + point in + fp16 features out (standalone encode kernel)
 SMALL_FLOP_PER_UNIT = 35072
+# matrix-core work the NeRFSmall kernel actually issues per point (32-row / 16-k padded tiles; x3 products in split mode, x2 on layer 0)
+SMALL_MFMA_FLOP_PER_UNIT = {"f16": 40 * 32768 // 32, "f16x3": 116 * 32768 // 32}
 NERF_FLOP_PER_UNIT = 1186816
 HBM_PEAK = 8.0e12
 MFMA_F16_PEAK = 2.5e15
@@ -87,7 +89,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hash", choices=["hash", "classic"])
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default=None, choices=["f16", "f16x3", "f32"],
+                    help="MLP arithmetic: f16 = matrix cores, fp16 operands; f16x3 = matrix cores, hi+lo fp16 operand pairs (fp32-grade); f32 = FMA chains "
+                         "(== oracle bitwise).  Default: f16x3 for the hash workload (pixels within 1e-4 of the fp32 path), f16 for classic")
+    ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (other precision, classic workload) at N = 1")
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
     ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +100,8 @@ def main():
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
     args = ap.parse_args()
 
+    if args.precision is None:
+        args.precision = "f16x3" if args.workload == "hash" else "f16"
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -117,7 +124,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from nerfpp_amd.dist import TileShard
 
-    prec = L.NRF_PREC_F16_MFMA if args.precision == "f16" else L.NRF_PREC_F32
+    prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[args.precision]
     if args.workload == "hash":
         sc = scene.make_hash_scene(mode=args.hash_mode)
         if args.dense_mb >= 0 and args.hash_mode == "cu":
@@ -178,14 +185,16 @@ def main():
                         units_per_launch=units_per_launch, bytes_per_unit=HASH_BYTES_PER_UNIT)
             mk = prof["mlp"]
             mdur = mk["ms"] * 1e-3
-            mlp_peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
+            mlp_peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             roof["mlp"] = dict(bound="mfma", achieved=units_per_step * args.steps * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
                                unit="TFLOP/s", frac=units_per_step * args.steps * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / mlp_peak)
+            if args.precision in SMALL_MFMA_FLOP_PER_UNIT:     # issued matrix-core flops (padding + the 3 products of the split mode) / peak
+                roof["mlp"]["mfma_issued_frac"] = units_per_step * args.steps * SMALL_MFMA_FLOP_PER_UNIT[args.precision] / max(mdur, 1e-12) / mlp_peak
         else:
             k = prof["mlp"]
             dur_total = k["ms"] * 1e-3
             flops = units_per_step * args.steps * NERF_FLOP_PER_UNIT
-            peak = MFMA_F16_PEAK if args.precision == "f16" else F32_PEAK
+            peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             upl = units_per_step * args.steps / max(k["launches"], 1)
             traffic, traffic_src = pmc_traffic("mlp_nerf (k_mlp_nerf_mfma)", upl, "classic_units_per_launch")
             roof = dict(bound="mfma", kernel="mlp_nerf", achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
@@ -195,7 +204,8 @@ def main():
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f16 MFMA (fp32 accumulate) MLP; " if args.precision == "f16" else "f32 MLP; ") +
+            "dtype": {"f16": "f16 MFMA (fp32 accumulate) MLP; ", "f16x3": "split-f16 MFMA (hi+lo operand pairs, 3 products, fp32 accumulate) MLP; ",
+                      "f32": "f32 MLP; "}[args.precision] +
                      ("fp16 hash table, fp32 blend" if (args.workload == "hash" and args.hash_mode == "cu") else "f32 encoders") + "; f32/f64 compositing",
             "data": "synthetic",
             "config": {"workload": ("hashnerf_lego800_64+128" if args.workload == "hash" else "classic_nerf_lego800_64+128"),
@@ -216,6 +226,8 @@ def main():
         except Exception as e:
             line["psnr_vs_oracle_db"] = f"unavailable: {e}"
         assert frames.shape[0] == world and bool(torch.isfinite(frames).all())
+        if world == 1 and not use_dist and not args.no_also:
+            line["also"] = secondary_measurements(args, scene, L, K, poses[0], sc)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -226,6 +238,37 @@ def main():
         print(json.dumps(line), flush=True)
         if use_dist:
             os._exit(0)
+
+
+def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
+    """Short extra timings at N = 1 (not part of `value`): the other matrix-core precision of this workload and the other
+    BASELINE workload, each with its render-vs-oracle quality on the same 256-ray sample."""
+    import torch
+    out = []
+    todo = [("hash", "f16" if args.precision != "f16" else "f16x3"), ("classic", "f16")] if args.workload == "hash" else [("hash", "f16x3"), ("hash", "f16")]
+    scenes = {args.workload: sc_main}
+    for wl, pname in todo:
+        try:
+            if wl not in scenes:
+                scenes[wl] = scene.make_hash_scene(mode=args.hash_mode) if wl == "hash" else scene.make_classic_scene()
+            sc = scenes[wl]
+            prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[pname]
+            rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072 if wl == "hash" else 8192, prec)
+            for _ in range(2):
+                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            a2 = argparse.Namespace(**{**vars(args), "workload": wl, "precision": pname})
+            out.append(dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
+                            precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps,
+                            psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
+        except Exception as e:
+            out.append(dict(workload=wl, precision=pname, error=str(e)))
+    return out
 
 
 def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
@@ -264,7 +307,9 @@ def quality_check(sc, renderer, rp, K, c2w, args, nrays=256):
     else:
         model = O.Model(1, sc["mlp_blob"], bbox=sc["bbox"])
     ref = O.render_rays(model, rays, NS, NI, O.linspace(0, 1, NS), O.linspace(0, 1, NI), white_bkgr=True)
-    return dict(psnr=scene.psnr(rgb, ref["rgb"]), max_abs_err=float(np.abs(rgb - ref["rgb"]).max()), rays=int(rays.shape[0]))
+    d = np.abs(rgb - ref["rgb"])
+    return dict(psnr=scene.psnr(rgb, ref["rgb"]), max_abs_err=float(d.max()), median_abs_err=float(np.median(d)), frac_within_1e4=float((d < 1e-4).mean()),
+                rays=int(rays.shape[0]))
 
 
 if __name__ == "__main__":

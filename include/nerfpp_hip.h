@@ -140,7 +140,9 @@ NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, floa
  * ------------------------------------------------------------------------------------------- */
 enum {
     NRF_PREC_F32 = 0,      /* fp32 FMA chains in ascending k: the parity mode (== oracle bit for bit) */
-    NRF_PREC_F16_MFMA = 1  /* fp16 operands on the matrix cores, fp32 accumulate: the fast mode */
+    NRF_PREC_F16_MFMA = 1, /* fp16 operands on the matrix cores, fp32 accumulate: the fast mode */
+    NRF_PREC_F16_SPLIT = 2 /* matrix cores with every operand carried as hi + lo fp16 pairs (22 significant bits, three MFMAs per
+                              product): fp32-grade results at matrix-core speed.  Built for the NeRFSmall family. */
 };
 
 typedef struct nrf_mlp_small_desc {      /* NeRFSmallImpl ctor (NeRF.cpp:322-360) */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NRF_LIB_PATH") or os.path.join(_HERE, "lib", "libnerf
 NRF_OK = 0
 NRF_HASH_NGP, NRF_HASH_CU = 0, 1
 NRF_SH_LIBTORCH, NRF_SH_CUDA = 0, 1
-NRF_PREC_F32, NRF_PREC_F16_MFMA = 0, 1
+NRF_PREC_F32, NRF_PREC_F16_MFMA, NRF_PREC_F16_SPLIT = 0, 1, 2
 NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
 (NRF_RNG_T_RAND, NRF_RNG_R_COARSE, NRF_RNG_THETA_COARSE, NRF_RNG_NOISE_COARSE, NRF_RNG_U_PDF, NRF_RNG_PRECOND, NRF_RNG_R_FINE, NRF_RNG_THETA_FINE,
  NRF_RNG_NOISE_FINE) = range(1, 10)       # include/nrf_rng.h

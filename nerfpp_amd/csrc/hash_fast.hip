@@ -203,7 +203,7 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
 }
 
 // per-ray direction features as fp16 rows [n, V] (the MLP kernel's colour-net operand): SH of the ray's view direction
-__global__ void k_dirs_f16(int64_t n, int degree, int variant, const float *__restrict__ rays, int stride, __half *__restrict__ out)
+__global__ void k_dirs_f16(int64_t n, int degree, int variant, const float *__restrict__ rays, int stride, __half *__restrict__ out, __half *__restrict__ out_lo)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -212,7 +212,11 @@ __global__ void k_dirs_f16(int64_t n, int degree, int variant, const float *__re
     if (variant == NRF_SH_CUDA) sh_cuda(dp[0], dp[1], dp[2], degree, r);
     else sh_libtorch(dp[0], dp[1], dp[2], degree, r);
     const int od = degree * degree;
-    for (int k = 0; k < od; k++) out[i * od + k] = __float2half_rn(r[k]);
+    for (int k = 0; k < od; k++) {
+        const __half hv = __float2half_rn(r[k]);
+        out[i * od + k] = hv;
+        if (out_lo) out_lo[i * od + k] = __float2half_rn(r[k] - __half2float(hv));
+    }
 }
 
 int hash_fast_supported(const nrf_hash *h)
@@ -243,10 +247,10 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     return NRF_OK;
 }
 
-int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int variant, __half *out, hipStream_t st)
+int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int variant, __half *out, __half *out_lo, hipStream_t st)
 {
     if (n == 0) return NRF_OK;
-    hipLaunchKernelGGL(k_dirs_f16, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, degree, variant, rays, stride, out);
+    hipLaunchKernelGGL(k_dirs_f16, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, degree, variant, rays, stride, out, out_lo);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

@@ -29,6 +29,8 @@ struct nrf_mlp {
     // packed operands of the matrix-core paths (built at create time)
     void *d_packed_f16 = nullptr;
     size_t packed_f16_bytes = 0;
+    void *d_packed_split = nullptr;          // NRF_PREC_F16_SPLIT: (hi, lo) fragment pairs
+    size_t packed_split_bytes = 0;
 };
 
 namespace nrf {
@@ -42,7 +44,7 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
 
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);
-int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, int s, const uint8_t *keep,
+int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s, const uint8_t *keep,
                               int64_t p, float *out, hipStream_t st);
 int mlp_nerf_mfma_available(const nrf_mlp *m);
 int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);

@@ -190,7 +190,7 @@ static int forward_f32(const nrf_mlp *m, const float *x, int xs, int64_t p, floa
     }
 }
 
-int mlp_small_forward_mfma(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, float *d_out, int out_stride, hipStream_t st);
+int mlp_small_forward_mfma(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int split, float *d_out, int out_stride, hipStream_t st);
 int mlp_nerf_forward_mfma(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, float *d_out, int out_stride, hipStream_t st);
 
 int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int prec, float *d_out, int out_stride,
@@ -207,9 +207,14 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
         return NRF_OK;
     }
     if (prec == NRF_PREC_F16_MFMA) {
-        if (m->family == MLP_SMALL) return mlp_small_forward_mfma(m, d_x, x_stride, p, d_out, out_stride, st);
+        if (m->family == MLP_SMALL) return mlp_small_forward_mfma(m, d_x, x_stride, p, 0, d_out, out_stride, st);
         if (m->family == MLP_NERF) return mlp_nerf_forward_mfma(m, d_x, x_stride, p, d_out, out_stride, st);
         set_error("NRF_PREC_F16_MFMA is not built for this MLP family; use NRF_PREC_F32");
+        return NRF_ERR_UNSUPPORTED;
+    }
+    if (prec == NRF_PREC_F16_SPLIT) {
+        if (m->family == MLP_SMALL) return mlp_small_forward_mfma(m, d_x, x_stride, p, 1, d_out, out_stride, st);
+        set_error("NRF_PREC_F16_SPLIT is built for the NeRFSmall family; use NRF_PREC_F32 or NRF_PREC_F16_MFMA");
         return NRF_ERR_UNSUPPORTED;
     }
     set_error("unknown precision %d", prec);
@@ -369,6 +374,7 @@ void nrf_mlp_destroy(nrf_mlp *m)
     }
     if (m->d_params) (void)hipFree(m->d_params);
     if (m->d_packed_f16) (void)hipFree(m->d_packed_f16);
+    if (m->d_packed_split) (void)hipFree(m->d_packed_split);
     delete m;
 }
 

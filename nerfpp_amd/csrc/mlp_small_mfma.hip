@@ -14,6 +14,14 @@
 //   sigma net : x[in] -> 64 -> ... -> (1+geo)        ReLU between, none at the end          (NeRF.cpp:372-381)
 //   colour net: cat[views, geo] -> 64 -> ... -> 3     the geo rows come straight from the sigma net's last D tile
 //   out = (rgb, sigma)                                                                       (NeRF.cpp:408)
+//
+// NRF_PREC_F16_SPLIT (template SPLIT): every fp32 quantity v is carried as an UNEVALUATED SUM of two fp16 numbers,
+// v = hi + lo with hi = f16(v), lo = f16(v - hi) (22 significant bits), weights split once at pack time, activations split
+// when a D tile becomes the next B fragment.  A product W.x is then three matrix-core instructions accumulating into the same
+// fp32 tile:  Wh.xh + Wl.xh + Wh.xl  (the dropped Wl.xl term is 2^-22 relative).  The CuHashEmbedder features are exactly
+// fp16 in the reference itself (CuHashEmbedder.cu:95), so the first layer needs only two.  Result: fp32-grade pixels
+// (render-vs-oracle PSNR > 90 dB where the plain fp16 mode gives ~45 dB on the adversarial synthetic scene) at 3x the MFMA
+// work of a kernel that was not MFMA-bound to begin with.  The doubled weight image (80 KB) is shared by 8 waves per workgroup.
 #include "mlp.h"
 
 namespace nrf {
@@ -26,8 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NRF_SMALL_PT 2
 #endif
 constexpr int PT = NRF_SMALL_PT; // 32-point tiles per wave
-constexpr int WAVES = 4;
-constexpr int BLOCK_PTS = 32 * PT * WAVES;
+constexpr int waves_of(bool split) { return split ? 8 : 4; }
+constexpr int block_pts_of(bool split) { return 32 * PT * waves_of(split); }
 
 // neuron (row of a D tile / k of the next layer) held by element j of lane-half h in k-step s of a 32-row tile
 __host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
@@ -44,9 +52,24 @@ __device__ __forceinline__ half8 tile_to_frag(const f32x16 &acc, int s)
     return r;
 }
 
+// D tile registers 8s..8s+7 -> (hi, lo) fp16 pair of B fragments: v = hi + lo to 22 bits
+template <bool RELU>
+__device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &hi, half8 &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float v = acc[8 * s + j];
+        if (RELU) v = fmaxf(v, 0.0f);
+        const _Float16 hv = (_Float16)v;
+        hi[j] = hv;
+        lo[j] = (_Float16)(v - (float)hv);
+    }
+}
+
 // acc[pt][mt] += A[mt][ks] . B[pt][ks] over all k-steps; A fragments stream from LDS in consumption order.
-template <int MT, int KS>
-__device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS], f32x16 (&acc)[PT][MT])
+// NP = 1: plain fp16 operands.  NP = 2: split operands, fragments stored (hi, lo) adjacent; BLO = the B operand has a non-zero lo part.
+template <int MT, int KS, int NP, bool BLO>
+__device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT])
 {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
@@ -56,12 +79,22 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
             for (int i = 0; i < 16; i++) acc[pt][mt][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const half8 a = frags[(mt * KS + ks) * 64 + lane];
+            const half8 a = frags[((mt * KS + ks) * NP) * 64 + lane];
+            if constexpr (NP == 2) {
+                const half8 al = frags[((mt * KS + ks) * NP + 1) * 64 + lane];
+                // small terms first, the leading product last
 #pragma unroll
-            for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks], acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
+                if constexpr (BLO) {
+#pragma unroll
+                    for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], acc[pt][mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
             // fence the scheduler every two k-steps: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments =
             // 160 VGPRs), which costs the occupancy that hides the feature-load latency
-            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            if (NP == 2 || (ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -90,27 +123,36 @@ struct SmallInput {
     const __half2 *feats; int64_t pstride;            // level-major fp16 input
     const __half *dirs; int s;
     const uint8_t *keep;
+    const __half *dirs_lo;                            // split mode: lo parts of the direction features, same layout
 };
 
-template <int IN_KS, int V_KS, int NL, int NLC, bool LM>
-__global__ void __launch_bounds__(64 * WAVES, 2)
+template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT>
+__global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? 1 : 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
     using Plan = SmallPlan<IN_KS, V_KS, NL, NLC>;
+    constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int BLOCK_PTS = block_pts_of(SPLIT);
+    constexpr bool IN_LO = SPLIT && !LM;        // level-major hash features are exact fp16 numbers: no lo part
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wl = reinterpret_cast<half8 *>(smem);
-    constexpr int NFRAG = Plan::total();
+    constexpr int NFRAG = Plan::total() * NP;
     for (int i = threadIdx.x; i < NFRAG * 64; i += blockDim.x) wl[i] = packed[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t nblocks = (npts + BLOCK_PTS - 1) / BLOCK_PTS;
+    auto split8 = [](const float4 &lo4, const float4 &hi4, half8 &hv, half8 &lv) {
+        const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; hv[j] = t; lv[j] = (_Float16)(v[j] - (float)t); }
+    };
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int64_t p0 = blk * BLOCK_PTS + wave * (32 * PT);
         // ---- layer-0 B fragments straight from the fp32 input rows: element j of k-step s is x[pt][16s + 8h + j] ----
-        half8 bx[PT][IN_KS];
-        half8 bv[PT][V_KS];
+        half8 bx[PT][IN_KS][NP];
+        half8 bv[PT][V_KS][NP];
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
             int64_t p = p0 + pt * 32 + r;
@@ -121,69 +163,85 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                     union { half8 v; __half2 q[4]; } u;
 #pragma unroll
                     for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];   // features 16s+8h+2q, +1
-                    bx[pt][s] = u.v;
+                    bx[pt][s][0] = u.v;
+                    if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
-                const __half *drow = in.dirs + (p / in.s) * (int64_t)(16 * V_KS);
+                const int64_t doff = (p / in.s) * (int64_t)(16 * V_KS);
 #pragma unroll
-                for (int s = 0; s < V_KS; s++) bv[pt][s] = *reinterpret_cast<const half8 *>(drow + 16 * s + 8 * h);
+                for (int s = 0; s < V_KS; s++) {
+                    bv[pt][s][0] = *reinterpret_cast<const half8 *>(in.dirs + doff + 16 * s + 8 * h);
+                    if constexpr (SPLIT) bv[pt][s][NP - 1] = *reinterpret_cast<const half8 *>(in.dirs_lo + doff + 16 * s + 8 * h);
+                }
             } else {
                 const float *row = in.x + p * in.x_stride;
 #pragma unroll
                 for (int s = 0; s < IN_KS; s++) {
                     const float4 lo = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h);
                     const float4 hi = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h + 4);
-                    bx[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+                    if constexpr (SPLIT) split8(lo, hi, bx[pt][s][0], bx[pt][s][NP - 1]);
+                    else bx[pt][s][0] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
                 }
 #pragma unroll
                 for (int s = 0; s < V_KS; s++) {
                     const float4 lo = *reinterpret_cast<const float4 *>(row + in.in_ch + 16 * s + 8 * h);
                     const float4 hi = *reinterpret_cast<const float4 *>(row + in.in_ch + 16 * s + 8 * h + 4);
-                    bv[pt][s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+                    if constexpr (SPLIT) split8(lo, hi, bv[pt][s][0], bv[pt][s][NP - 1]);
+                    else bv[pt][s][0] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
                 }
             }
         }
         const half8 *fr = wl;
-        // ---- sigma net ----
-        half8 bh[PT][4];
+        // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer
+        half8 bh[PT][4][NP];
         f32x16 acc2[PT][2];
+        auto hidden_to_b = [&]() {
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        if constexpr (SPLIT) tile_to_frag2<true>(acc2[pt][t], s, bh[pt][2 * t + s][0], bh[pt][2 * t + s][NP - 1]);
+                        else bh[pt][2 * t + s][0] = tile_to_frag<true>(acc2[pt][t], s);
+                    }
+        };
+        // ---- sigma net ----
         f32x16 sig[PT][1];
         if constexpr (NL == 1) {
-            gemm_layer<1, IN_KS>(fr, lane, bx, sig); fr += Plan::sigma_frags(0) * 64;
+            gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
-            gemm_layer<2, IN_KS>(fr, lane, bx, acc2); fr += Plan::sigma_frags(0) * 64;
+            gemm_layer<2, IN_KS, NP, IN_LO>(fr, lane, bx, acc2); fr += Plan::sigma_frags(0) * 64 * NP;
 #pragma unroll
             for (int l = 1; l < NL; l++) {
-#pragma unroll
-                for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-                    for (int t = 0; t < 2; t++) { bh[pt][2 * t] = tile_to_frag<true>(acc2[pt][t], 0); bh[pt][2 * t + 1] = tile_to_frag<true>(acc2[pt][t], 1); }
-                if (l < NL - 1) gemm_layer<2, 4>(fr, lane, bh, acc2);
-                else gemm_layer<1, 4>(fr, lane, bh, sig);
-                fr += Plan::sigma_frags(l) * 64;
+                hidden_to_b();
+                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh, acc2);
+                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh, sig);
+                fr += Plan::sigma_frags(l) * 64 * NP;
             }
         }
         // ---- colour net: k-steps = [views..., geo] ----
-        half8 bc[PT][V_KS + 1];
+        half8 bc[PT][V_KS + 1][NP];
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
 #pragma unroll
-            for (int s = 0; s < V_KS; s++) bc[pt][s] = bv[pt][s];
-            bc[pt][V_KS] = tile_to_frag<false>(sig[pt][0], 0);        // rows 0..15 of the sigma tile: sigma (zero weight) + geo
+            for (int s = 0; s < V_KS; s++)
+#pragma unroll
+                for (int q = 0; q < NP; q++) bc[pt][s][q] = bv[pt][s][q];
+            // rows 0..15 of the sigma tile: sigma (zero weight) + geo
+            if constexpr (SPLIT) tile_to_frag2<false>(sig[pt][0], 0, bc[pt][V_KS][0], bc[pt][V_KS][NP - 1]);
+            else bc[pt][V_KS][0] = tile_to_frag<false>(sig[pt][0], 0);
         }
         f32x16 rgb[PT][1];
         if constexpr (NLC == 1) {
-            gemm_layer<1, V_KS + 1>(fr, lane, bc, rgb);
+            gemm_layer<1, V_KS + 1, NP, SPLIT>(fr, lane, bc, rgb);
         } else {
-            gemm_layer<2, V_KS + 1>(fr, lane, bc, acc2); fr += Plan::color_frags(0) * 64;
+            gemm_layer<2, V_KS + 1, NP, SPLIT>(fr, lane, bc, acc2); fr += Plan::color_frags(0) * 64 * NP;
 #pragma unroll
             for (int l = 1; l < NLC; l++) {
-#pragma unroll
-                for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-                    for (int t = 0; t < 2; t++) { bh[pt][2 * t] = tile_to_frag<true>(acc2[pt][t], 0); bh[pt][2 * t + 1] = tile_to_frag<true>(acc2[pt][t], 1); }
-                if (l < NLC - 1) gemm_layer<2, 4>(fr, lane, bh, acc2);
-                else gemm_layer<1, 4>(fr, lane, bh, rgb);
-                fr += Plan::color_frags(l) * 64;
+                hidden_to_b();
+                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh, acc2);
+                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh, rgb);
+                fr += Plan::color_frags(l) * 64 * NP;
             }
         }
         // ---- out = (rgb, sigma): rows 0..2 of the colour tile and row 0 of the sigma tile live in registers 0..2 / 0 of lane-half 0 ----
@@ -208,19 +266,22 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 struct Packer {
     std::vector<_Float16> img;
     // one layer: W [out][in] row-major at `w`; krow(ks, h, j) -> input index or -1 (zero)
+    bool split = false;     // each 1-KB fragment followed by the fragment of the rounding residuals w - f16(w)
     template <class KMap>
     void layer(const float *w, int in, int out, int mtiles, int ksteps, KMap kmap)
     {
         for (int mt = 0; mt < mtiles; mt++)
             for (int ks = 0; ks < ksteps; ks++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++) {
-                        const int row = mt * 32 + (lane & 31);
-                        const int k = kmap(ks, lane >> 5, j);
-                        float v = 0.0f;
-                        if (row < out && k >= 0 && k < in) v = w[(size_t)row * in + k];
-                        img.push_back((_Float16)v);
-                    }
+                for (int part = 0; part < (split ? 2 : 1); part++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int row = mt * 32 + (lane & 31);
+                            const int k = kmap(ks, lane >> 5, j);
+                            float v = 0.0f;
+                            if (row < out && k >= 0 && k < in) v = w[(size_t)row * in + k];
+                            const _Float16 hv = (_Float16)v;
+                            img.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                        }
     }
 };
 
@@ -230,11 +291,8 @@ static bool small_mfma_supported(const nrf_mlp_small_desc &d)
            d.geo_feat_dim >= 0 && d.geo_feat_dim <= 15 && d.num_layers >= 2 && d.num_layers <= 3 && d.num_layers_color >= 2 && d.num_layers_color <= 4;
 }
 
-int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+static void pack_small(const nrf_mlp_small_desc &d, const std::vector<float> &hp, Packer &pk)
 {
-    const auto &d = m->small;
-    if (!small_mfma_supported(d)) return NRF_OK;      // NRF_PREC_F16_MFMA then reports NRF_ERR_UNSUPPORTED at forward time
-    Packer pk;
     const int in_ks = d.input_ch / 16, v_ks = d.input_ch_views / 16;
     auto natural = [](int ks, int h, int j) { return 16 * ks + 8 * h + j; };                       // operand loaded from memory
     auto chained = [](int ks, int h, int j) { return 32 * (ks >> 1) + perm_row(ks & 1, h, j); };  // operand = previous D tiles
@@ -261,58 +319,83 @@ int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         } else pk.layer(hp.data() + off, in, out, mt, 4, chained);
         off += (size_t)in * out;
     }
+}
+
+int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->small;
+    if (!small_mfma_supported(d)) return NRF_OK;      // the matrix-core precisions then report NRF_ERR_UNSUPPORTED at forward time
+    Packer pk, pk2;
+    pk2.split = true;
+    pack_small(d, hp, pk);
+    pack_small(d, hp, pk2);
     m->packed_f16_bytes = pk.img.size() * sizeof(_Float16);
     NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_f16, pk.img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));
+    m->packed_split_bytes = pk2.img.size() * sizeof(_Float16);
+    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
+    NRF_HIP(hipMemcpy(m->d_packed_split, pk2.img.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
     return NRF_OK;
 }
 
 template <int V_KS, int NL, int NLC>
-static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st)
+static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool split, int64_t p, float *out, int os, hipStream_t st)
 {
     using Plan = SmallPlan<2, V_KS, NL, NLC>;
-    const size_t lds = (size_t)Plan::total() * 1024;
-    if (lds != m->packed_f16_bytes) { set_error("internal: packed weight image is %zu bytes, kernel expects %zu", m->packed_f16_bytes, lds); return NRF_ERR_INVALID_ARG; }
-    const int64_t nblocks = ceil_div(p, BLOCK_PTS);
-    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);        // persistent: 256 CUs x 3 resident workgroups (146 VGPRs, 40-46 KB LDS)
-    if (lm) hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, true>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
-    else hipLaunchKernelGGL((k_mlp_small_mfma<2, V_KS, NL, NLC, false>), dim3(grid), dim3(64 * WAVES), lds, st, p, in, reinterpret_cast<const half8 *>(m->d_packed_f16), out, os);
+    const size_t lds = (size_t)Plan::total() * 1024 * (split ? 2 : 1);
+    const size_t have = split ? m->packed_split_bytes : m->packed_f16_bytes;
+    if (lds != have) { set_error("internal: packed weight image is %zu bytes, kernel expects %zu", have, lds); return NRF_ERR_INVALID_ARG; }
+    const int64_t nblocks = ceil_div(p, block_pts_of(split));
+    // persistent: 256 CUs x 3 resident 4-wave workgroups (146 VGPRs, 40-46 KB LDS), or x 1 resident 8-wave workgroup with the 80-92 KB split image
+    const int64_t cap = split ? 256 : 768;
+    const unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
+    const half8 *img = reinterpret_cast<const half8 *>(split ? m->d_packed_split : m->d_packed_f16);
+#define NRF_GO(LM_, SP_)                                                                                                                      \
+    do {                                                                                                                                      \
+        auto kfn = k_mlp_small_mfma<2, V_KS, NL, NLC, LM_, SP_>;                                                                              \
+        if (lds > 64 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * waves_of(SP_)), lds, st, p, in, img, out, os);                                          \
+    } while (0)
+    if (lm) { if (split) NRF_GO(true, true); else NRF_GO(true, false); }
+    else { if (split) NRF_GO(false, true); else NRF_GO(false, false); }
+#undef NRF_GO
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 
-static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st);
+static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool split, int64_t p, float *out, int os, hipStream_t st);
 
-int mlp_small_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_SMALL && m->d_packed_f16 != nullptr; }
+int mlp_small_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_SMALL && m->d_packed_f16 != nullptr && m->d_packed_split != nullptr; }
 
-// renderer fast path: level-major fp16 features + per-ray fp16 direction features + keep mask -> raw [p,4] (sigma masked)
-int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, int s, const uint8_t *keep,
+// renderer fast path: level-major fp16 features + per-ray fp16 direction features + keep mask -> raw [p,4] (sigma masked).
+// dirs_lo != NULL selects the split-precision kernel (NRF_PREC_F16_SPLIT).
+int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s, const uint8_t *keep,
                               int64_t p, float *out, hipStream_t st)
 {
     if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
     ProfScope prof(NRF_PROF_MLP, st);
-    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep};
-    return dispatch_small(m, in, true, p, out, 4, st);
+    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo};
+    return dispatch_small(m, in, true, dirs_lo != nullptr, p, out, 4, st);
 }
 
-int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st)
+int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, int split, float *out, int os, hipStream_t st)
 {
     const auto &d = m->small;
     if (!m->d_packed_f16) {
-        set_error("NRF_PREC_F16_MFMA: NeRFSmall shape (in %d, views %d, %dx%d, geo %d, colour %dx%d) is outside the built matrix-core family; use NRF_PREC_F32",
+        set_error("NRF_PREC_F16_MFMA / NRF_PREC_F16_SPLIT: NeRFSmall shape (in %d, views %d, %dx%d, geo %d, colour %dx%d) is outside the built matrix-core family; use NRF_PREC_F32",
                   d.input_ch, d.input_ch_views, d.num_layers, d.hidden_dim, d.geo_feat_dim, d.num_layers_color, d.hidden_dim_color);
         return NRF_ERR_UNSUPPORTED;
     }
     if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("NRF_PREC_F16_MFMA: input rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
-    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr};
-    return dispatch_small(m, in, false, p, out, os, st);
+    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr};
+    return dispatch_small(m, in, false, split != 0, p, out, os, st);
 }
 
-static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, int64_t p, float *out, int os, hipStream_t st)
+static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool split, int64_t p, float *out, int os, hipStream_t st)
 {
     const auto &d = m->small;
     const int v = d.input_ch_views / 16;
-#define NRF_CASE(V, NL, NLC) if (v == V && d.num_layers == NL && d.num_layers_color == NLC) return launch_small<V, NL, NLC>(m, in, lm, p, out, os, st);
+#define NRF_CASE(V, NL, NLC) if (v == V && d.num_layers == NL && d.num_layers_color == NLC) return launch_small<V, NL, NLC>(m, in, lm, split, p, out, os, st);
     NRF_CASE(1, 3, 4) NRF_CASE(1, 3, 3) NRF_CASE(1, 3, 2) NRF_CASE(1, 2, 4) NRF_CASE(1, 2, 3) NRF_CASE(1, 2, 2)
     NRF_CASE(4, 3, 4) NRF_CASE(4, 3, 3) NRF_CASE(4, 3, 2) NRF_CASE(4, 2, 4) NRF_CASE(4, 2, 3) NRF_CASE(4, 2, 2)
 #undef NRF_CASE

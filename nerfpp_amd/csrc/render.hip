@@ -93,7 +93,7 @@ static size_t network_ws_bytes(const nrf_renderer *r, int64_t p, int prec)
 // built matrix-core family): level-major fp16 features -> fused MFMA MLP, two launches per pass, no concatenated input.
 static bool fast_path(const nrf_renderer *r, int prec)
 {
-    return prec == NRF_PREC_F16_MFMA && r->desc.hash && hash_fast_supported(r->desc.hash) && r->in_ch == 32 &&
+    return (prec == NRF_PREC_F16_MFMA || prec == NRF_PREC_F16_SPLIT) && r->desc.hash && hash_fast_supported(r->desc.hash) && r->in_ch == 32 &&
            (r->desc.dirs_encoder == NRF_DIRS_SH_CUDA || r->desc.dirs_encoder == NRF_DIRS_SH_LIBTORCH) && (r->in_views == 16 || r->in_views == 64) &&
            mlp_small_mfma_available(r->desc.mlp);
 }
@@ -104,7 +104,7 @@ static size_t fast_ws_bytes(const nrf_renderer *r, int64_t n, int64_t p)
 }
 
 // dirs_f16: per-ray direction features [n, V] prepared once per chunk (nullptr: computed here from `viewdirs`)
-static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const __half *dirs_f16, int64_t n, int s, float *raw, void *ws,
+static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const __half *dirs_f16, const __half *dirs_lo, int64_t n, int s, float *raw, void *ws,
                             size_t ws_bytes, hipStream_t st)
 {
     const int64_t p = n * s;
@@ -114,7 +114,7 @@ static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const 
     uint8_t *keep = bump.take<uint8_t>((size_t)p);
     if (bump.off > ws_bytes) { set_error("run_network_fast: workspace too small"); return NRF_ERR_WORKSPACE; }
     NRF_TRY(launch_hash_lm(r->desc.hash, ps, p, feats, p, keep, HASH_LM_DEFAULT_VARIANT, st));
-    return mlp_small_forward_mfma_lm(r->desc.mlp, feats, p, dirs_f16, s, keep, p, raw, st);
+    return mlp_small_forward_mfma_lm(r->desc.mlp, feats, p, dirs_f16, dirs_lo, s, keep, p, raw, st);
 }
 
 // RunNetwork over p = n*s points given either explicit points or (rays, z).
@@ -261,7 +261,7 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += align_up((size_t)n * sf * 4, 256);               // z_fine
     b += align_up((size_t)n * sf * c * 4, 256);           // raw_fine
     b += network_ws_bytes(r, n * sf, p->precision) + 4096;
-    b += align_up((size_t)n * 64 * sizeof(__half), 256);  // per-ray direction features of the fast path
+    b += align_up((size_t)n * 64 * sizeof(__half), 256) * 2;  // per-ray direction features of the fast path (hi, lo)
     if (p->perturb > 0.0f) b += align_up((size_t)n * s * 4, 256);                             // un-jittered depths
     if (p->has_cone || p->precond_alpha > 0.0f) b += align_up((size_t)n * sf * 12, 256);     // explicit sample points
     return b;
@@ -301,17 +301,19 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     const bool fast_classic = p->precision == NRF_PREC_F16_MFMA && !r->desc.hash && r->desc.pe_freqs == 10 && r->desc.dirs_encoder == NRF_DIRS_PE &&
                               r->desc.dirs_param == 4 && mlp_nerf_mfma_available(r->desc.mlp);
     __half *dirs16 = nullptr;
+    __half *dirs_lo = nullptr;
     if (fast) dirs16 = bump.take<__half>((size_t)n * r->in_views);
+    if (fast && p->precision == NRF_PREC_F16_SPLIT) dirs_lo = bump.take<__half>((size_t)n * r->in_views);
     if (fast_classic) dirs16 = bump.take<__half>((size_t)n * 32);
     float *z_plain = p->perturb > 0.0f ? bump.take<float>((size_t)n * s) : nullptr;
     float *bump_pts = (p->has_cone || p->precond_alpha > 0.0f) ? bump.take<float>((size_t)n * sf * 3) : nullptr;
     void *nws = bump.take<char>(0);
     const size_t nws_bytes = workspace_bytes - bump.off;
     const float *viewdirs = r->in_views > 0 ? d_rays + 8 : nullptr;
-    if (fast) NRF_TRY(launch_dirs_f16(d_rays, ray_stride, n, r->desc.dirs_param, r->desc.dirs_encoder == NRF_DIRS_SH_CUDA ? NRF_SH_CUDA : NRF_SH_LIBTORCH, dirs16, st));
+    if (fast) NRF_TRY(launch_dirs_f16(d_rays, ray_stride, n, r->desc.dirs_param, r->desc.dirs_encoder == NRF_DIRS_SH_CUDA ? NRF_SH_CUDA : NRF_SH_LIBTORCH, dirs16, dirs_lo, st));
     if (fast_classic) NRF_TRY(launch_dirs_pe_f16(d_rays, ray_stride, n, dirs16, st));
     auto network = [&](const PointSource &src, int ns_, float *raw_out) -> int {
-        if (fast) return run_network_fast(r, src, dirs16, n, ns_, raw_out, nws, nws_bytes, st);
+        if (fast) return run_network_fast(r, src, dirs16, dirs_lo, n, ns_, raw_out, nws, nws_bytes, st);
         if (fast_classic) return mlp_nerf_forward_mfma_fused(r->desc.mlp, src.pts, src.rays, src.ray_stride, src.z, ns_, dirs16, n * (int64_t)ns_, raw_out, st);
         return run_network(r, src, viewdirs, ray_stride, n, ns_, p->precision, raw_out, nws, nws_bytes, st);
     };

@@ -96,7 +96,10 @@ class _HashBase(BaseEmbedder):
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            L.lib().nrf_hash_destroy(h)
+            try:
+                L.lib().nrf_hash_destroy(h)
+            except Exception:       # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def GetOutputDims(self):
@@ -165,7 +168,10 @@ class BaseNeRF:
     def __del__(self):
         m = getattr(self, "_m", None)
         if m:
-            L.lib().nrf_mlp_destroy(m)
+            try:
+                L.lib().nrf_mlp_destroy(m)
+            except Exception:       # interpreter shutdown: module globals may already be gone
+                pass
             self._m = None
 
     def _blob(self, params):

@@ -189,7 +189,10 @@ class NeRFRenderer:
     def __del__(self):
         r = getattr(self, "_r", None)
         if r:
-            L.lib().nrf_renderer_destroy(r)
+            try:
+                L.lib().nrf_renderer_destroy(r)
+            except Exception:       # interpreter shutdown: module globals may already be gone
+                pass
             self._r = None
 
     def _workspace(self, nbytes, device):

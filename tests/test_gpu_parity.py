@@ -688,3 +688,43 @@ def test_stochastic_fast_paths_use_same_points(api, manifest):
                                        BoundingBox=bbox, Precision=prec, Seed=11)
             outs[prec] = host(r.Render(24, 24, K, p, c2w=c2w).Outputs.RGBMap)
         assert api.S.psnr(outs[api.L.NRF_PREC_F16_MFMA], outs[api.L.NRF_PREC_F32]) > floor
+
+
+# ------------------------------------------------------------------ NRF_PREC_F16_SPLIT: matrix cores at fp32-grade accuracy
+def test_mlp_small_split_precision_vs_oracle(api, O, manifest):
+    """hi + lo fp16 operand pairs (three MFMAs per product): the NeRFSmall output agrees with the fp32 oracle to ~1e-6 of its scale,
+    three orders of magnitude tighter than the plain fp16 mode."""
+    ent = [x for x in manifest["render_hash"] if "embeddings" not in x[0]]
+    blob = synth.blob_from_manifest(ent)
+    m = api.M.NeRFSmall(3, 64, 15, 4, 64, False, 3, 64, 32, 16, "model", params=blob)
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.uniform(-1, 1, (3000, 32)), rng.uniform(-1, 1, (3000, 16))], 1).astype(np.float32)
+    x[:, :32] = x[:, :32].astype(np.float16).astype(np.float32) * rng.choice([1.0, 1e-2, 1e-4], (3000, 1))     # incl. tiny (freshly initialised) features
+    ref = O.mlp_small(blob, x, 32, 16)
+    scale = np.abs(ref).max()
+    y3 = host(m.forward(dev(x), api.L.NRF_PREC_F16_SPLIT))
+    y1 = host(m.forward(dev(x), api.L.NRF_PREC_F16_MFMA))
+    e3, e1 = np.abs(y3 - ref).max() / scale, np.abs(y1 - ref).max() / scale
+    assert e3 < 3e-6, (e3, e1)
+    assert e1 > 50 * e3, "the plain fp16 mode is the loose one"
+
+
+def test_split_precision_render_matches_parity_mode(api, O):
+    """BASELINE config 2 shape, CuHash fast path in NRF_PREC_F16_SPLIT vs the bit-exact NRF_PREC_F32 mode on the adversarial scene."""
+    sc = api.S.make_hash_scene(mode="cu")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    out = {}
+    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_SPLIT, api.L.NRF_PREC_F16_MFMA):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=4096, precision=prec, KeepIntermediates=True, ReturnRaw=True)
+        out[prec] = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=396, rows=8)
+    a, b, c = (out[k] for k in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_SPLIT, api.L.NRF_PREC_F16_MFMA))
+    raw_scale = np.abs(host(a.Extras["raw_coarse"])).max()
+    assert_close(host(b.Extras["raw_coarse"]), host(a.Extras["raw_coarse"]), rtol=0, atol=3e-6 * raw_scale, what="coarse raw, same points")
+    # the fine sample set is a discontinuous function of the coarse weights (searchsorted on CDF plateaus), so ~1e-6 weight differences
+    # move a few near-zero-weight samples, exactly as between two hosts running the reference (oracle/ref_self_consistency.sh);
+    # on this adversarial field (finest cell 6e-3, sigma head x30) a moved sample is worth up to ~5e-4 of a pixel
+    rgb_a, rgb_b = host(a.Outputs.RGBMap).reshape(-1, 3), host(b.Outputs.RGBMap).reshape(-1, 3)
+    d = np.abs(rgb_b - rgb_a)
+    assert (d < 1e-4).mean() > 0.98 and np.median(d) < 1e-5 and d.max() < 2e-2, ((d < 1e-4).mean(), np.median(d), d.max())
+    ps_split, ps_f16 = api.S.psnr(rgb_b, rgb_a), api.S.psnr(host(c.Outputs.RGBMap).reshape(-1, 3), rgb_a)
+    assert ps_split > 70 and ps_split > ps_f16 + 20, (ps_split, ps_f16)
