@@ -52,17 +52,36 @@ __device__ __forceinline__ half8 tile_to_frag(const f32x16 &acc, int s)
     return r;
 }
 
-// D tile registers 8s..8s+7 -> (hi, lo) fp16 pair of B fragments: v = hi + lo to 22 bits
+// D tile registers 8s..8s+7 -> (hi, lo) fp16 pair of B fragments: v = hi + lo to 22 bits.
+// VALU cost matters here (the split kernel converts as many values as it multiplies tiles), so the hidden-layer form is 2.5
+// instructions per value: one v_max_f32 (this file is built with -fno-honor-nans, otherwise fmaxf first canonicalises the MFMA
+// result), half a v_cvt_pk_f16_f32 (RNE), and lo = f16(v - hi) as ONE mixed-precision FMA that reads hi as a half and writes a
+// half (v_fma_mixlo/mixhi_f16: fma(f32(hi), -1, v), exact difference, rounded once) -- which the compiler does not select by
+// itself (it emits cvt + sub + cvt).  The asm only ever reads compiler-produced VALU results, never an MFMA result directly,
+// so the MFMA -> VALU hazard handling stays with the compiler.
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+}
+
 template <bool RELU>
 __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &hi, half8 &lo)
 {
+    if constexpr (RELU) {
+        union { half8 v; uint32_t u[4]; } h, l;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        float v = acc[8 * s + j];
-        if (RELU) v = fmaxf(v, 0.0f);
-        const _Float16 hv = (_Float16)v;
-        hi[j] = hv;
-        lo[j] = (_Float16)(v - (float)hv);
+        for (int j = 0; j < 4; j++) split_pair(fmaxf(acc[8 * s + 2 * j], 0.0f), fmaxf(acc[8 * s + 2 * j + 1], 0.0f), h.u[j], l.u[j]);
+        hi = h.v; lo = l.v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float v = acc[8 * s + j];
+            const _Float16 hv = (_Float16)v;
+            hi[j] = hv;
+            lo[j] = (_Float16)(v - (float)hv);
+        }
     }
 }
 
@@ -166,7 +185,9 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                     bx[pt][s][0] = u.v;
                     if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
-                const int64_t doff = (p / in.s) * (int64_t)(16 * V_KS);
+                // 32-bit division when the index fits (always, for a chunk): the 64-bit one is a ~60-instruction sequence
+                const int64_t ray = (p >> 31) == 0 ? (int64_t)((uint32_t)p / (uint32_t)in.s) : p / in.s;
+                const int64_t doff = ray * (int64_t)(16 * V_KS);
 #pragma unroll
                 for (int s = 0; s < V_KS; s++) {
                     bv[pt][s][0] = *reinterpret_cast<const half8 *>(in.dirs + doff + 16 * s + 8 * h);
