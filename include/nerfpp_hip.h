@@ -303,6 +303,14 @@ NRF_API int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_
                             void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image-space tail of NeRFExecutor::RenderPath (NeRFExecutor.h:690, :698-700; TorchTensorToCVMat, NeRFRenderer.h:58-68)
+ * ------------------------------------------------------------------------------------------- */
+/* depth' = (depth - near) / (far - near) with the frame's scalar Near / Far (nrf_near_far_range).  In place allowed. */
+NRF_API int nrf_normalize_depth(const float *d_depth, int64_t n, float near_, float far_, float *d_out, void *stream);
+/* u8 = (uint8)clamp(x * 255, 0, 255): what cv::imwrite receives for RGB / disparity / normalised depth. */
+NRF_API int nrf_to_u8(const float *d_x, int64_t n, uint8_t *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)
  * ------------------------------------------------------------------------------------------- */
 /* When enabled, nrf_render_rays brackets its dominant kernels with HIP events on the caller's stream;

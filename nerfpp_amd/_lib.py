@@ -64,6 +64,7 @@ SYMBOLS = [
     "nrf_rng_fill", "nrf_jitter_z", "nrf_tangent_scatter", "nrf_precondition", "nrf_raw2outputs_noise", "nrf_sample_pdf_rand", "nrf_fine_depths_rand",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays",
+    "nrf_normalize_depth", "nrf_to_u8",
     "nrf_profile_enable", "nrf_profile_read",
 ]
 

@@ -159,6 +159,29 @@ static inline Bbox make_bbox(const float *b)
     return bb;
 }
 
+// N4: (depth - near) / span (NeRFExecutor.h:690)
+__global__ void k_normalize_depth(int64_t n, float near_, float span, const float *__restrict__ depth, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (depth[i] - near_) / span;
+}
+
+// N4: t.mul(255).clamp(0, 255).to(kU8) (NeRFRenderer.h:62); 4 values per thread, one packed 32-bit store when aligned
+__global__ void k_to_u8(int64_t n, const float *__restrict__ x, uint8_t *__restrict__ out)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    uint32_t pk = 0;
+    const int cnt = (n - i0) < 4 ? (int)(n - i0) : 4;
+    for (int k = 0; k < cnt; k++) {
+        float v = x[i0 + k] * 255.0f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        pk |= (uint32_t)(uint8_t)v << (8 * k);
+    }
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(out) & 3) == 0)) *reinterpret_cast<uint32_t *>(out + i0) = pk;
+    else for (int k = 0; k < cnt; k++) out[i0 + k] = (uint8_t)(pk >> (8 * k));
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -232,6 +255,24 @@ int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *ne
     auto dec = [](int v) { int b = v >= 0 ? v : (v ^ 0x7fffffff); float f; memcpy(&f, &b, 4); return f; };
     *near_min = dec(res[0]);
     *far_max = dec(res[1]);
+    return NRF_OK;
+}
+
+int nrf_normalize_depth(const float *d_depth, int64_t n, float near_, float far_, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_depth && d_out && n >= 0, "nrf_normalize_depth: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_normalize_depth, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, near_, far_ - near_, d_depth, d_out);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_to_u8(const float *d_x, int64_t n, uint8_t *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_x && d_out && n >= 0, "nrf_to_u8: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_to_u8, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, as_stream(stream), n, d_x, d_out);
+    NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 

@@ -336,6 +336,31 @@ class NeRFRenderer:
 
 
 # ------------------------------------------------------------------------------------------------
+# Image-space tail of NeRFExecutor::RenderPath (NeRFExecutor.h:690, :698-700; TorchTensorToCVMat, NeRFRenderer.h:58-68)
+# ------------------------------------------------------------------------------------------------
+def NormalizeDepth(depth_map, near, far):
+    """(DepthMap - Near) / (Far - Near), NeRFExecutor.h:690."""
+    d = _dev_f32(depth_map)
+    out = torch.empty_like(d)
+    L.check(L.lib().nrf_normalize_depth(_ptr(d), C.c_int64(d.numel()), C.c_float(near), C.c_float(far), _ptr(out), _stream()))
+    return out
+
+
+def TorchTensorToCVMat(tensor_image):
+    """NeRFRenderer.h:58-68 up to the cv::Mat wrap: squeeze, mul(255).clamp(0,255).to(u8); returns the uint8 tensor (on the GPU)."""
+    t = _dev_f32(tensor_image).squeeze()
+    out = torch.empty(t.shape, device=t.device, dtype=torch.uint8)
+    L.check(L.lib().nrf_to_u8(_ptr(t), C.c_int64(t.numel()), _ptr(out), _stream()))
+    return out
+
+
+def RenderViewBuffers(result):
+    """The three 8-bit images RenderPath writes for a pose (NeRFExecutor.h:690-700): rgb, disparity, Near/Far-normalised depth."""
+    o = result.Outputs
+    return TorchTensorToCVMat(o.RGBMap), TorchTensorToCVMat(o.DispMap), TorchTensorToCVMat(NormalizeDepth(o.DepthMap, result.Near, result.Far))
+
+
+# ------------------------------------------------------------------------------------------------
 # LeRFRenderer.h / LeRFRenderer.cpp  (BASELINE config 4: language-embedded radiance field render pass)
 # ------------------------------------------------------------------------------------------------
 @dataclass

@@ -360,5 +360,17 @@ def raw2outputs_noise(raw, z, d, noise, noise_std, white_bkgr=False):
     return out
 
 
+def normalize_depth(depth, near, far):
+    d = _f(depth); out = np.empty_like(d)
+    lib().orc_normalize_depth(_p(d), C.c_int64(d.size), C.c_float(near), C.c_float(far), _p(out))
+    return out
+
+
+def to_u8(x):
+    x = _f(x); out = np.empty(x.shape, np.uint8)
+    lib().orc_to_u8(_p(x), C.c_int64(x.size), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -1178,6 +1178,25 @@ ORC_API void orc_pack_rays(const float *o, const float *d, const float *bbox, in
     free(nears); free(fars);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * N4  image-space tail of RenderPath       NeRFExecutor.h:690,698-700 ; TorchTensorToCVMat NeRFRenderer.h:58-68
+ *     depth' = (depth - Near) / (Far - Near) ; u8 = (uint8)clamp(x*255, 0, 255)   (float -> u8 conversion truncates)
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_normalize_depth(const float *depth, int64_t n, float near_, float far_, float *out)
+{
+    const float span = far_ - near_;
+    for (int64_t i = 0; i < n; i++) out[i] = (depth[i] - near_) / span;
+}
+
+ORC_API void orc_to_u8(const float *x, int64_t n, uint8_t *out)
+{
+    for (int64_t i = 0; i < n; i++) {
+        float v = x[i] * 255.0f;
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        out[i] = (uint8_t)v;
+    }
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -461,6 +461,22 @@ static void dump_spy(const std::string &tag, SpyT &spy, const NeRFRenderResult &
 	save_npy(tag + ".near_far", torch::tensor({res.Near, res.Far}));
 }
 
+// N4: the image-space tail of NeRFExecutor::RenderPath (NeRFExecutor.h:690, :698-700 + TorchTensorToCVMat, NeRFRenderer.h:58-68):
+// depth normalisation by the frame's Near/Far, then mul(255).clamp(0,255).to(kU8).  TorchTensorToCVMat itself needs OpenCV (absent);
+// its tensor expression is evaluated here verbatim.
+static void g_post(const NeRFRenderResult &res)
+{
+	auto to_u8 = [](torch::Tensor t) { return t.detach().squeeze().cpu().mul(255).clamp(0, 255).to(torch::kU8).contiguous(); };		//NeRFRenderer.h:60-63
+	auto depth_n = (res.Outputs.DepthMap - res.Near) / (res.Far - res.Near);		//NeRFExecutor.h:690
+	save_npy("post.rgb", res.Outputs.RGBMap); save_npy("post.disp", res.Outputs.DispMap); save_npy("post.depth", res.Outputs.DepthMap);
+	save_npy("post.near_far", torch::tensor({res.Near, res.Far}));
+	save_npy("post.depth_norm", depth_n);
+	save_npy("post.rgb_u8", to_u8(res.Outputs.RGBMap)); save_npy("post.disp_u8", to_u8(res.Outputs.DispMap)); save_npy("post.depth_u8", to_u8(depth_n));
+	// edge values: negatives, > 1, exact .5/255 steps
+	auto edge = torch::tensor({-0.5f, 0.f, 0.00195f, 0.00392156886f, 0.00392157f, 0.5f, 0.99999994f, 1.f, 1.2f, 300.f, 0.0039215684f * 37.f});
+	save_npy("post.edge", edge); save_npy("post.edge_u8", to_u8(edge));
+}
+
 static void g_render()
 {
 	const int h = 8, w = 8;
@@ -482,7 +498,7 @@ static void g_render()
 		{
 			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
 			auto res = spy.Render(h, w, k, lego_params(64, 128, chunk), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
-			if (chunk == 64) dump_spy(tag, spy, res);
+			if (chunk == 64) { dump_spy(tag, spy, res); g_post(res); }
 			else { save_npy(tag + ".chunk24_rgb", res.Outputs.RGBMap); save_npy(tag + ".chunk24_depth", res.Outputs.DepthMap); }
 		}
 		{

@@ -728,3 +728,15 @@ def test_split_precision_render_matches_parity_mode(api, O):
     assert (d < 1e-4).mean() > 0.98 and np.median(d) < 1e-5 and d.max() < 2e-2, ((d < 1e-4).mean(), np.median(d), d.max())
     ps_split, ps_f16 = api.S.psnr(rgb_b, rgb_a), api.S.psnr(host(c.Outputs.RGBMap).reshape(-1, 3), rgb_a)
     assert ps_split > 70 and ps_split > ps_f16 + 20, (ps_split, ps_f16)
+
+
+def test_image_post_bit_exact_vs_reference(api, O):
+    """N4: the 8-bit buffers RenderPath hands to cv::imwrite (NeRFExecutor.h:690-700)."""
+    g = load_golden("post")
+    dn = api.R.NormalizeDepth(dev(g["depth"]), float(g["near_far"][0]), float(g["near_far"][1]))
+    assert_exact(host(dn), g["depth_norm"])
+    for k in ("rgb", "disp", "edge"):
+        assert_exact(host(api.R.TorchTensorToCVMat(dev(g[k]))), g[k + "_u8"], k)
+    assert_exact(host(api.R.TorchTensorToCVMat(dn)), g["depth_u8"])
+    big = np.random.RandomState(0).uniform(-0.2, 1.3, 1000003).astype(np.float32)         # ragged length, unaligned tail
+    assert_exact(host(api.R.TorchTensorToCVMat(dev(big))), O.to_u8(big))

@@ -328,3 +328,12 @@ def test_stochastic_render_own_rng_is_chunk_independent(manifest):
     # and it is a Monte-Carlo render of the same (deliberately high-frequency) field as the reference's torch-RNG render: same image mean
     assert abs(full["acc"].mean() - g["out_acc"].mean()) < 0.1 and abs(full["rgb"].mean() - g["out_rgb"].mean()) < 0.1
     assert np.abs(full["rgb"] - g["out_rgb"].reshape(-1, 3)).max() > 1e-3, "different draws -> a different sample of the estimator"
+
+
+def test_image_post_vs_reference():
+    """N4: depth normalisation and 8-bit quantisation of RenderPath."""
+    g = load_golden("post")
+    dn = O.normalize_depth(g["depth"], g["near_far"][0], g["near_far"][1])
+    assert_exact(dn, g["depth_norm"], "(depth - Near) / (Far - Near)")
+    assert_exact(O.to_u8(g["rgb"]), g["rgb_u8"]); assert_exact(O.to_u8(g["disp"]), g["disp_u8"]); assert_exact(O.to_u8(dn), g["depth_u8"])
+    assert_exact(O.to_u8(g["edge"]), g["edge_u8"], "clamp + truncation edge cases")
