@@ -372,5 +372,42 @@ def to_u8(x):
     return out
 
 
+def huber_loss(pred, target):
+    pred = _f(pred); target = _f(target)
+    loss = C.c_float(0); mse = C.c_float(0); grad = np.empty_like(pred)
+    lib().orc_huber_loss(_p(pred), _p(target), C.c_int64(pred.size), C.byref(loss), C.byref(mse), _p(grad))
+    return loss.value, mse.value, grad
+
+
+def raw2outputs_backward(raw, z, d, g_rgb, white_bkgr=False):
+    raw = _f(raw); z = _f(z); d = _f(d); g_rgb = _f(g_rgb)
+    n, s, c = raw.shape
+    out = np.empty_like(raw)
+    lib().orc_raw2outputs_backward(_p(raw), _p(z), _p(d), C.c_int64(n), C.c_int(s), C.c_int(c), C.c_int(int(white_bkgr)), _p(g_rgb), _p(out))
+    return out
+
+
+def mlp_small_backward(params, x, g_out, in_ch, in_views, n_layers=3, hidden=64, geo=15, n_layers_c=4, hidden_c=64):
+    params = _f(params); x = _f(x); g_out = _f(g_out)
+    g_params = np.zeros_like(params); g_x = np.empty((x.shape[0], in_ch), np.float32)
+    lib().orc_mlp_small_backward(_p(params), _p(x), _p(g_out), C.c_int64(x.shape[0]), C.c_int(in_ch), C.c_int(in_views), C.c_int(n_layers), C.c_int(hidden),
+                                 C.c_int(geo), C.c_int(n_layers_c), C.c_int(hidden_c), _p(g_params), _p(g_x))
+    return g_params, g_x
+
+
+def hash_ngp_backward(x, bbox, L, F, log2_t, base, finest, g_emb):
+    x = _f(x); g_emb = _f(g_emb); bb = _f(bbox)
+    g_table = np.zeros((L, 1 << log2_t, F), np.float32)
+    lib().orc_hash_ngp_backward(_p(x), C.c_int64(x.shape[0]), _p(bb), C.c_int(L), C.c_int(F), C.c_int(log2_t), C.c_int(base), C.c_int(finest), _p(g_emb), _p(g_table))
+    return g_table
+
+
+def adam_step(p, g, m, v, lr, t, b1=0.9, b2=0.99, eps=1e-15):
+    """in place on p, m, v (float32 arrays)"""
+    assert p.dtype == np.float32 and m.dtype == np.float32 and v.dtype == np.float32
+    g = _f(g)
+    lib().orc_adam_step(_p(p), _p(g), _p(m), _p(v), C.c_int64(p.size), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_int(t))
+
+
 def num_threads():
     return lib().orc_num_threads()

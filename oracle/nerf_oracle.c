@@ -1178,6 +1178,198 @@ ORC_API void orc_pack_rays(const float *o, const float *d, const float *bbox, in
     free(nears); free(fars);
 }
 
+/* ==========================================================================================
+ * N1  training step: backward of the render path + loss + Adam.   NeRFExecutor.h:862-995, :539
+ *     Gradients flow only through the FINE pass: z_samples are detached (NeRFRenderer.h:429), rays and depths carry no
+ *     parameters, so d loss / d raw of the coarse pass is identically zero (golden train_hash.s1_coarse_raw_has_grad).
+ *     Autograd's own summation orders are not reproduced (the GPU accumulates with atomics anyway): tests compare with a
+ *     relative tolerance.  Accumulations here are in double.
+ * ========================================================================================== */
+
+/* torch::nn::functional::huber_loss (delta = 1, mean) and mse_loss; grad = d huber / d pred     NeRFExecutor.h:882-887 */
+ORC_API void orc_huber_loss(const float *pred, const float *target, int64_t count, float *loss, float *mse, float *grad)
+{
+    double acc = 0.0, acc2 = 0.0;
+    const float norm = 1.0f / (float)count;
+    for (int64_t i = 0; i < count; i++) {
+        const float d = pred[i] - target[i];
+        const float z = fabsf(d);
+        acc += (z < 1.0f) ? 0.5 * (double)z * (double)z : (double)z - 0.5;
+        acc2 += (double)d * (double)d;
+        if (grad) grad[i] = (d < -1.0f) ? -norm : (d > 1.0f ? norm : norm * d);
+    }
+    if (loss) *loss = (float)(acc / (double)count);
+    if (mse) *mse = (float)(acc2 / (double)count);
+}
+
+/* Backward of RawToOutputs (NeRFRenderer.h:199-282) w.r.t. raw, given d loss / d rgb_map [n,3] (the only output the
+ * training loss reads).  TruncExp::backward = grad * exp(clamp(x, -100, 5)) (CustomOps.cpp:11-15); clamp_min passes the
+ * gradient where 1 - alpha >= 1e-10; relu where sigma > 0. */
+ORC_API void orc_raw2outputs_backward(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                                      const float *g_rgb /*[n,3]*/, float *g_raw /*[n,s,c]*/)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        const float *dv = d + i * 3;
+        const float nrm = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        float alpha[1024], trans[1024], x_[1024], lt[1024], col[1024][3];
+        double logt = 0.0;
+        float tprev = 0.0f;
+        for (int j = 0; j < s; j++) {            /* forward, as orc_raw2outputs */
+            const float *r = raw + (i * s + j) * c;
+            float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
+            dist = dist * nrm;
+            const float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            x_[j] = -sig * dist;
+            alpha[j] = -nrf_expf(x_[j]) + 1.0f;
+            lt[j] = tprev;
+            trans[j] = nrf_expf(tprev);
+            const float om = 1.0f - alpha[j];
+            logt += (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
+            tprev = (float)logt;
+            for (int k = 0; k < 3; k++) col[j][k] = nrf_sigmoidf(r[k]);
+        }
+        const float gsum = g_rgb[i * 3] + g_rgb[i * 3 + 1] + g_rgb[i * 3 + 2];
+        double suffix = 0.0;                      /* sum_{j > k} g_L[j] */
+        for (int j = s - 1; j >= 0; j--) {
+            const float *r = raw + (i * s + j) * c;
+            float *g = g_raw + (i * s + j) * c;
+            for (int k = 0; k < c; k++) g[k] = 0.0f;
+            float gw = g_rgb[i * 3] * col[j][0] + g_rgb[i * 3 + 1] * col[j][1] + g_rgb[i * 3 + 2] * col[j][2];
+            if (white_bkgr) gw -= gsum;           /* rgb += 1 - acc */
+            const float w = alpha[j] * trans[j];
+            for (int k = 0; k < 3; k++) g[k] = g_rgb[i * 3 + k] * w * (col[j][k] * (1.0f - col[j][k]));
+            float g_alpha = gw * trans[j];
+            const float om = 1.0f - alpha[j];
+            if (om >= 1e-10f) g_alpha -= (float)suffix / om;                                   /* l_j = log(clamp_min(1 - alpha_j)) feeds every later T */
+            const float cl = lt[j] < -100.0f ? -100.0f : (lt[j] > 5.0f ? 5.0f : lt[j]);
+            suffix += (double)(gw * alpha[j] * nrf_expf(cl));                                   /* g_L[j] = g_T[j] * exp(clamp(L_j)) */
+            const float cx = x_[j] < -100.0f ? -100.0f : (x_[j] > 5.0f ? 5.0f : x_[j]);
+            const float g_x = -g_alpha * nrf_expf(cx);
+            float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
+            dist = dist * nrm;
+            g[3] = (r[3] > 0.0f) ? -g_x * dist : 0.0f;
+        }
+    }
+}
+
+/* Backward of NeRFSmallImpl::forward (bias-free).  g_out [p,4] = d loss / d (rgb, sigma).  Accumulates d loss / d params into
+ * g_params (same blob layout; caller zeroes) and writes d loss / d x[:, :in_ch] (the position features) to g_x [p, in_ch]. */
+ORC_API void orc_mlp_small_backward(const float *params, const float *x, const float *g_out, int64_t p, int in_ch, int in_views, int n_layers,
+                                    int hidden, int geo, int n_layers_c, int hidden_c, float *g_params, float *g_x)
+{
+    const int64_t np_ = orc_mlp_small_param_count(in_ch, in_views, n_layers, hidden, geo, n_layers_c, hidden_c);
+    double *gacc = (double *)calloc((size_t)np_, sizeof(double));
+    /* sequential over points: a deterministic double accumulation (the oracle is a checker, not a fast path) */
+    for (int64_t i = 0; i < p; i++) {
+        float act[16][512];                 /* inputs of every layer */
+        int dims[17];
+        const float *xi = x + i * (in_ch + in_views);
+        const float *w = params;
+        const float *wl[16];
+        int nl = 0;
+        memcpy(act[0], xi, sizeof(float) * in_ch); dims[0] = in_ch;
+        for (int l = 0; l < n_layers; l++) {
+            const int od = (l == n_layers - 1) ? (1 + geo) : hidden;
+            wl[nl] = w;
+            linear(w, NULL, act[nl], dims[nl], od, act[nl + 1], l != n_layers - 1);
+            w += (int64_t)dims[nl] * od; dims[nl + 1] = od; nl++;
+        }
+        const int sig_layer_out = nl;       /* act[nl] = h (1 + geo) */
+        float cin[512];
+        for (int k = 0; k < in_views; k++) cin[k] = xi[in_ch + k];
+        for (int k = 0; k < geo; k++) cin[in_views + k] = act[sig_layer_out][1 + k];
+        const int c0 = nl + 1;              /* colour layers use act[c0 ...] */
+        memcpy(act[c0], cin, sizeof(float) * (in_views + geo)); dims[c0] = in_views + geo;
+        int cl = c0;
+        for (int l = 0; l < n_layers_c; l++) {
+            const int od = (l == n_layers_c - 1) ? 3 : hidden_c;
+            wl[cl] = w;
+            linear(w, NULL, act[cl], dims[cl], od, act[cl + 1], l != n_layers_c - 1);
+            w += (int64_t)dims[cl] * od; dims[cl + 1] = od; cl++;
+        }
+        /* ---- backward ---- */
+        float g[512], gin[512];
+        g[0] = g_out[i * 4]; g[1] = g_out[i * 4 + 1]; g[2] = g_out[i * 4 + 2];
+        for (int l = cl - 1; l >= c0; l--) {                 /* colour net, last layer first */
+            const int id = dims[l], od = dims[l + 1];
+            if (l != cl - 1) for (int o = 0; o < od; o++) if (!(act[l + 1][o] > 0.0f)) g[o] = 0.0f;     /* ReLU */
+            double *ga = gacc + (wl[l] - params);
+            for (int o = 0; o < od; o++) for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)g[o] * (double)act[l][k];
+            for (int k = 0; k < id; k++) { float a = 0.0f; for (int o = 0; o < od; o++) a += wl[l][(int64_t)o * id + k] * g[o]; gin[k] = a; }
+            memcpy(g, gin, sizeof(float) * id);
+        }
+        /* g now holds d / d cat[views, geo]; the sigma net's output gradient = (g_sigma, g_geo) */
+        float gh[512];
+        gh[0] = g_out[i * 4 + 3];
+        for (int k = 0; k < geo; k++) gh[1 + k] = g[in_views + k];
+        memcpy(g, gh, sizeof(float) * (1 + geo));
+        for (int l = sig_layer_out - 1; l >= 0; l--) {
+            const int id = dims[l], od = dims[l + 1];
+            if (l != sig_layer_out - 1) for (int o = 0; o < od; o++) if (!(act[l + 1][o] > 0.0f)) g[o] = 0.0f;
+            double *ga = gacc + (wl[l] - params);
+            for (int o = 0; o < od; o++) for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)g[o] * (double)act[l][k];
+            for (int k = 0; k < id; k++) { float a = 0.0f; for (int o = 0; o < od; o++) a += wl[l][(int64_t)o * id + k] * g[o]; gin[k] = a; }
+            memcpy(g, gin, sizeof(float) * id);
+        }
+        if (g_x) memcpy(g_x + i * in_ch, g, sizeof(float) * in_ch);
+    }
+    for (int64_t k = 0; k < np_; k++) g_params[k] += (float)gacc[k];
+    free(gacc);
+}
+
+/* Backward of HashEmbedderImpl::forward w.r.t. the embedding tables (NeRF.cpp:279-298 trilinear blend; nn::Embedding backward =
+ * index_add of the row gradients).  g_emb [p, L*F]; g_table [L][2^T][F] accumulated (caller zeroes). */
+ORC_API void orc_hash_ngp_backward(const float *x, int64_t p, const float *bbox, int n_levels, int n_feat, int log2_t, int base, int finest,
+                                   const float *g_emb, float *g_table)
+{
+    float res[64];
+    orc_hash_ngp_resolutions(n_levels, base, finest, res);
+    const int64_t tsize = (int64_t)1 << log2_t, hmask = tsize - 1;
+    double *acc = (double *)calloc((size_t)(n_levels * tsize * n_feat), sizeof(double));
+    for (int64_t i = 0; i < p; i++) {
+        float xc[3];
+        for (int a = 0; a < 3; a++) xc[a] = f_max(f_min(x[i * 3 + a], bbox[3 + a]), bbox[a]);
+        for (int l = 0; l < n_levels; l++) {
+            float w[3];
+            int64_t idx[3];
+            for (int a = 0; a < 3; a++) {
+                float grid = (bbox[3 + a] - bbox[a]) / res[l];
+                idx[a] = (int64_t)floorf((xc[a] - bbox[a]) / grid);
+                float vmin = (float)idx[a] * grid + bbox[a];
+                float vmax = vmin + grid;
+                w[a] = (x[i * 3 + a] - vmin) / (vmax - vmin);
+            }
+            for (int c = 0; c < 8; c++) {
+                int64_t cx = idx[0] + ((c >> 2) & 1), cy = idx[1] + ((c >> 1) & 1), cz = idx[2] + (c & 1);
+                int64_t hsh = ((cx * 1LL) ^ (cy * 2654435761LL) ^ (cz * 805459861LL)) & hmask;
+                const float wx = ((c >> 2) & 1) ? w[0] : 1.0f - w[0], wy = ((c >> 1) & 1) ? w[1] : 1.0f - w[1], wz = (c & 1) ? w[2] : 1.0f - w[2];
+                for (int f = 0; f < n_feat; f++) {
+                    const float g = g_emb[i * n_levels * n_feat + l * n_feat + f];
+                    acc[((int64_t)l * tsize + hsh) * n_feat + f] += (double)(((g * wz) * wy) * wx);     /* autograd's chain: c -> c0/c1 -> c00.. -> e */
+                }
+            }
+        }
+    }
+    for (int64_t k = 0; k < (int64_t)n_levels * tsize * n_feat; k++) g_table[k] += (float)acc[k];
+    free(acc);
+}
+
+/* torch::optim::Adam::step (no weight decay, no amsgrad), step count t >= 1:
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) */
+ORC_API void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps, int t)
+{
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const double step_size = (double)lr / bc1, bc2s = sqrt(bc2);
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        m[i] = m[i] * b1 + g[i] * (1.0f - b1);                /* exp_avg.lerp_(grad, 1 - beta1) == this up to 1 ulp */
+        v[i] = v[i] * b2 + (g[i] * g[i]) * (1.0f - b2);       /* exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2) */
+        const float denom = (float)((double)sqrtf(v[i]) / bc2s) + eps;
+        p[i] = p[i] - (float)step_size * (m[i] / denom);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * N4  image-space tail of RenderPath       NeRFExecutor.h:690,698-700 ; TorchTensorToCVMat NeRFRenderer.h:58-68
  *     depth' = (depth - Near) / (Far - Near) ; u8 = (uint8)clamp(x*255, 0, 255)   (float -> u8 conversion truncates)

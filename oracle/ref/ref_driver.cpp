@@ -161,6 +161,7 @@ struct Spy : public NeRFRenderer<E, D, M>
 	Spy(E e, D d, M m) : Base(e, d, m) {}
 	std::vector<torch::Tensor> net_pts, net_raw, r2o_raw, r2o_z, r2o_d, batch_rays;
 	std::vector<NeRFRendererOutputs> r2o_out;
+	std::vector<torch::Tensor> raw_live;		//the graph tensors themselves (retain_grad), for the training-step goldens
 
 	torch::Tensor RunNetwork(torch::Tensor inputs, torch::Tensor view_dirs, M fn, E embed_fn, D embeddirs_fn) override
 	{
@@ -172,6 +173,7 @@ struct Spy : public NeRFRenderer<E, D, M>
 	NeRFRendererOutputs RawToOutputs(torch::Tensor raw, torch::Tensor cone_angle, torch::Tensor z_vals, torch::Tensor rays_d,
 		const float raw_noise_std = 0.f, const bool white_bkgr = false) override
 	{
+		if (raw.requires_grad()) { raw.retain_grad(); raw_live.push_back(raw); }
 		auto out = Base::RawToOutputs(raw, cone_angle, z_vals, rays_d, raw_noise_std, white_bkgr);
 		r2o_raw.push_back(raw.detach().clone());
 		r2o_z.push_back(z_vals.detach().clone());
@@ -564,6 +566,61 @@ static void g_render()
 }
 
 // ----------------------------------------------------------------------------------------------
+// N1: one (and a second) optimisation step of NeRFExecutor::Train (NeRFExecutor.h:862-995) on a tiny HashNeRF:
+// Render(ray batch) -> huber_loss(RGBMap, target) -> backward -> Adam(lr, betas (0.9, 0.99), eps 1e-15) (:539).
+// Dumps the loss, d loss / d raw of the fine pass, every parameter gradient, and the parameters after each step.
+// ----------------------------------------------------------------------------------------------
+static void g_train()
+{
+	const std::string tag = "train_hash";
+	const int h = 8, w = 8, ns = 32, ni = 32;
+	auto k = lego_K(h, w);
+	k[0][0] = k[0][0] * 0.8f; k[1][1] = k[1][1] * 0.8f;
+	auto c2w = orbit_pose(-63.f, -30.f, 4.f);
+	auto bbox = lego_bbox();
+	HashEmbedder e("embedder", bbox, 4, 2, 12, 16, 128);
+	SHEncoder ed("embeddirs", 3, 4);
+	NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 8, 16, "model");
+	fill_module(tag, e, 5000u, 0.5f, 0.f);
+	fill_module(tag, m, 6000u, 1.6f, 0.f, {{"sigma_net_2", 8.0f}});
+	auto [o, d, cone] = GetRays(h, w, k, c2w);
+	o = o.reshape({-1, 3}); d = d.reshape({-1, 3});
+	auto target = synth_tensor({h * w, 3}, 9100u, 0.5f, 0.5f);
+	save_npy(tag + ".rays_o", o); save_npy(tag + ".rays_d", d); save_npy(tag + ".target", target); save_npy(tag + ".bbox", bbox);
+	std::vector<torch::Tensor> grad_vars;
+	for (auto &p : e->parameters()) grad_vars.push_back(p);
+	for (auto &p : m->parameters()) grad_vars.push_back(p);
+	const float lr = 5e-3f;
+	torch::optim::Adam opt(grad_vars, torch::optim::AdamOptions(lr).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));		//NeRFExecutor.h:539
+	save_npy(tag + ".lr", torch::tensor({lr}));
+	auto rp = lego_params(ns, ni, h * w);
+	rp.WhiteBkgr = false;		//training default
+	for (int step = 1; step <= 2; step++)
+	{
+		const std::string st = tag + ".s" + std::to_string(step) + "_";
+		Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+		opt.zero_grad();
+		auto res = spy.Render(0, 0, torch::Tensor(), rp, {o, d, cone});
+		auto mse = torch::mse_loss(res.Outputs.RGBMap, target.detach());
+		auto loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, target.detach());		//:883
+		loss.backward();
+		save_npy(st + "loss", loss.detach().reshape({1})); save_npy(st + "mse", mse.detach().reshape({1}));
+		save_npy(st + "rgb", res.Outputs.RGBMap.detach());
+		if (step == 1)
+		{
+			save_npy(st + "fine_z", spy.r2o_z[1]); save_npy(st + "fine_raw", spy.r2o_raw[1]); save_npy(st + "fine_pts", spy.net_pts[1]);
+			save_npy(st + "grad_fine_raw", spy.raw_live[1].grad());
+			save_npy(st + "coarse_raw_has_grad", torch::tensor({spy.raw_live[0].grad().defined() ? spy.raw_live[0].grad().abs().max().item<float>() : -1.f}));
+			for (auto &p : e->named_parameters()) save_npy(st + "grad_" + p.key(), p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value()));
+			for (auto &p : m->named_parameters()) save_npy(st + "grad_" + p.key(), p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value()));
+		}
+		opt.step();
+		for (auto &p : e->named_parameters()) save_npy(st + "param_" + p.key(), p.value().detach());
+		for (auto &p : m->named_parameters()) save_npy(st + "param_" + p.key(), p.value().detach());
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
 // bench: the reference CPU renderer timed on synthetic Lego-shaped rays (cpu_baseline kind "reference")
 // ----------------------------------------------------------------------------------------------
 static int run_bench(int argc, const char **argv)
@@ -639,6 +696,7 @@ int main(int argc, const char **argv)
 	g_truncexp();
 	g_raw2out();
 	g_render();
+	g_train();
 	g_manifest.close();
 	std::cout << "golden vectors written to " << g_outdir << std::endl;
 	return 0;

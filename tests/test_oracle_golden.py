@@ -337,3 +337,82 @@ def test_image_post_vs_reference():
     assert_exact(dn, g["depth_norm"], "(depth - Near) / (Far - Near)")
     assert_exact(O.to_u8(g["rgb"]), g["rgb_u8"]); assert_exact(O.to_u8(g["disp"]), g["disp_u8"]); assert_exact(O.to_u8(dn), g["depth_u8"])
     assert_exact(O.to_u8(g["edge"]), g["edge_u8"], "clamp + truncation edge cases")
+
+
+# ------------------------------------------------------------------ N1: training step (backward + huber + Adam)
+def _train_setup(manifest):
+    g = load_golden("train_hash")
+    ent = manifest["train_hash"]
+    table = synth.blob_from_manifest([e for e in ent if "embeddings" in e[0]]).reshape(4, 4096, 2)
+    blob = synth.blob_from_manifest([e for e in ent if "embeddings" not in e[0]])
+    rays = O.pack_rays(g["rays_o"], g["rays_d"], g["bbox"])
+    return g, table, blob, rays
+
+
+def _mlp_grad_blob(g, step="s1"):
+    names = ["sigma_net_0", "sigma_net_1", "sigma_net_2", "color_net_0", "color_net_1", "color_net_2"]
+    return np.concatenate([g[f"{step}_grad_model_{n}.weight"].reshape(-1) for n in names])
+
+
+def test_training_backward_chain_vs_reference_autograd(manifest):
+    """d loss/d raw, d loss/d MLP weights and d loss/d hash tables of one NeRFExecutor::Train step, stage by stage on the
+    reference's own forward intermediates, against the gradients LibTorch autograd produced."""
+    g, table, blob, rays = _train_setup(manifest)
+    loss, mse, g_rgb = O.huber_loss(g["s1_rgb"], g["target"])
+    assert abs(loss - g["s1_loss"][0]) < 2e-7 and abs(mse - g["s1_mse"][0]) < 2e-7
+    assert g["s1_coarse_raw_has_grad"][0] == -1.0, "the coarse pass receives no gradient in the reference"
+    g_raw = O.raw2outputs_backward(g["s1_fine_raw"], g["s1_fine_z"], rays[:, 3:6], g_rgb, white_bkgr=False)
+    ref = g["s1_grad_fine_raw"]
+    assert_close(g_raw, ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max(), what="RawToOutputs backward (TruncExp, log-space transmittance, clamp_min, relu)")
+    # network backward on the reference's fine-pass points
+    pts = g["s1_fine_pts"].reshape(-1, 3)
+    emb, keep = O.hash_ngp(pts, table, g["bbox"], 4, 2, 12, 16, 128)
+    dirs = O.sh_libtorch(rays[:, 8:11], 4)
+    x = np.concatenate([emb, np.repeat(dirs, 64, axis=0)], 1)
+    g_raw_m = ref.reshape(-1, 4).copy()
+    g_raw_m[~keep, 3] = 0                                       # outputs_flat[~keep_mask, -1] = 0 (NeRFRenderer.h:187-188)
+    g_params, g_x = O.mlp_small_backward(blob, x, g_raw_m, 8, 16, 3, 64, 15, 3, 64)
+    refb = _mlp_grad_blob(g)
+    assert_close(g_params, refb, rtol=1e-3, atol=2e-5 * np.abs(refb).max(), what="NeRFSmall weight gradients")
+    g_table = O.hash_ngp_backward(pts, g["bbox"], 4, 2, 12, 16, 128, g_x)
+    reft = np.stack([g[f"s1_grad_embedder_embeddings_{l}.weight"] for l in range(4)])
+    assert_close(g_table, reft, rtol=1e-3, atol=2e-5 * np.abs(reft).max(), what="hash table gradients")
+    assert (reft != 0).mean() > 0.02
+
+
+def test_adam_two_steps_vs_reference(manifest):
+    """Adam(lr, betas (0.9, 0.99), eps 1e-15) fed the reference's step-1 gradients reproduces its parameters after step 1; a full
+    second step through the oracle's own forward/backward lands on the reference's step-2 parameters and loss."""
+    g, table, blob, rays = _train_setup(manifest)
+    lr = float(g["lr"][0])
+    names = ["sigma_net_0", "sigma_net_1", "sigma_net_2", "color_net_0", "color_net_1", "color_net_2"]
+    p = blob.copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    O.adam_step(p, _mlp_grad_blob(g), m, v, lr, 1)
+    ref1 = np.concatenate([g[f"s1_param_model_{n}.weight"].reshape(-1) for n in names])
+    assert_close(p, ref1, rtol=0, atol=2e-7, what="MLP params after step 1")
+    t = table.copy(); mt = np.zeros_like(t); vt = np.zeros_like(t)
+    O.adam_step(t.reshape(-1), np.stack([g[f"s1_grad_embedder_embeddings_{l}.weight"] for l in range(4)]).reshape(-1), mt.reshape(-1), vt.reshape(-1), lr, 1)
+    assert_close(t, np.stack([g[f"s1_param_embedder_embeddings_{l}.weight"] for l in range(4)]), rtol=0, atol=2e-7, what="tables after step 1")
+    # step 2, end to end in the oracle
+    model = O.Model(0, p, bbox=g["bbox"], table_f32=t, L=4, F=2, log2_t=12, base=16, finest=128, n_layers_c=3)
+    out = O.render_rays(model, rays, 32, 32, O.linspace(0, 1, 32), O.linspace(0, 1, 32), white_bkgr=False, want_intermediates=True)
+    loss2, _, g_rgb = O.huber_loss(out["rgb"], g["target"])
+    assert abs(loss2 - g["s2_loss"][0]) < 2e-5, (loss2, g["s2_loss"][0])
+    g_raw = O.raw2outputs_backward(out["raw_fine"], out["z_fine"], rays[:, 3:6], g_rgb, white_bkgr=False)
+    pts = O.points(rays[:, :3], rays[:, 3:6], out["z_fine"]).reshape(-1, 3)
+    emb, keep = O.hash_ngp(pts, t, g["bbox"], 4, 2, 12, 16, 128)
+    x = np.concatenate([emb, np.repeat(O.sh_libtorch(rays[:, 8:11], 4), 64, axis=0)], 1)
+    gr = g_raw.reshape(-1, 4); gr[~keep, 3] = 0
+    g_params, g_x = O.mlp_small_backward(p, x, gr, 8, 16, 3, 64, 15, 3, 64)
+    g_table = O.hash_ngp_backward(pts, g["bbox"], 4, 2, 12, 16, 128, g_x)
+    O.adam_step(p, g_params, m, v, lr, 2)
+    O.adam_step(t.reshape(-1), g_table.reshape(-1), mt.reshape(-1), vt.reshape(-1), lr, 2)
+    ref2 = np.concatenate([g[f"s2_param_model_{n}.weight"].reshape(-1) for n in names])
+    # Adam's update is lr * m/sqrt(v): ~lr per step whatever the gradient scale (a weight whose step-2 gradient is rounding-level
+    # noise still moves by a sizeable fraction of lr), so compare against the step size: the bulk to 1e-3 lr, outliers below lr/3
+    assert np.abs(p - ref2).max() < 0.3 * lr and np.abs(p - ref2).mean() < 2e-3 * lr, (np.abs(p - ref2).max() / lr, np.abs(p - ref2).mean() / lr)
+    reft2 = np.stack([g[f"s2_param_embedder_embeddings_{l}.weight"] for l in range(4)])
+    # table rows touched only by a fine sample that sits in a different CDF bin than the reference's get a whole Adam step (~lr) in one
+    # run and none in the other: bound their share, not their size
+    dt = np.abs(t - reft2) / lr
+    assert dt.mean() < 5e-3 and (dt > 0.01).mean() < 0.05, (dt.max(), dt.mean(), (dt > 0.01).mean())
