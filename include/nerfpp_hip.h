@@ -303,6 +303,41 @@ NRF_API int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_
                             void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training step: NeRFExecutor::Train, NeRFExecutor.h:862-995.
+ *   render (nrf_render_rays) -> huber loss -> backward of the FINE pass only (z_samples are detached, NeRFRenderer.h:429):
+ *   RawToOutputs -> sigma mask -> MLP -> hash grid -> Adam(lr, betas (0.9, 0.99), eps 1e-15) (:539).
+ * All gradients fp32; accumulations use hardware fp32 atomics (order-free definition: compare with a tolerance).
+ * ------------------------------------------------------------------------------------------- */
+/* torch::nn::functional::huber_loss (delta 1, mean) and torch::mse_loss (:882-887).  d_loss_mse: device [2] = (huber, mse);
+ * d_grad (optional): d huber / d pred, same shape as pred. */
+NRF_API int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t count, float *d_loss_mse, float *d_grad, void *stream);
+
+/* Backward of RawToOutputs (NeRFRenderer.h:199-282) w.r.t. raw given d loss / d RGBMap [n,3]; TruncExp::backward clamps its
+ * argument to [-100, 5] (CustomOps.cpp:11-15). */
+NRF_API int nrf_raw2outputs_backward(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                                     const float *d_g_rgb, float *d_g_raw, void *stream);
+/* d/d sigma = 0 where keep is false: the backward of `outputs_flat[~keep_mask, -1] = 0` (NeRFRenderer.h:187-188). */
+NRF_API int nrf_mask_sigma_grad(const uint8_t *d_keep, int64_t p, int c, float *d_g_raw, void *stream);
+
+/* Backward of the MLP (NeRFSmall family): x [p, in_dims] as given to nrf_mlp_forward, g_out [p, 4].  d_g_params (blob layout)
+ * is ACCUMULATED into; d_g_x (optional) receives d loss / d x[:, :input_ch] as [p, input_ch]. */
+NRF_API size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p);
+NRF_API int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
+                             void *d_workspace, size_t workspace_bytes, void *stream);
+/* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images). */
+NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
+
+/* Backward of the hash grid w.r.t. its table: d_g_emb [p, L*F] -> d_g_table, fp32 in the table's own layout, ACCUMULATED into.
+ * NRF_HASH_NGP: nn::Embedding's index_add of the trilinear weights (NeRF.cpp:279-298).  NRF_HASH_CU: CuHashEmbedderBackwardKernel
+ * (CuHashEmbedder.cu:105-216) -- contributions rounded to fp16 after the x128 gradient scaling exactly as there, but accumulated
+ * in fp32 instead of with fp16 atomics. */
+NRF_API int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, const float *d_g_emb, float *d_g_table, void *stream);
+
+/* torch::optim::Adam::step without weight decay / amsgrad; t = 1, 2, ... */
+NRF_API int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Image-space tail of NeRFExecutor::RenderPath (NeRFExecutor.h:690, :698-700; TorchTensorToCVMat, NeRFRenderer.h:58-68)
  * ------------------------------------------------------------------------------------------- */
 /* depth' = (depth - near) / (far - near) with the frame's scalar Near / Far (nrf_near_far_range).  In place allowed. */

@@ -222,6 +222,162 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// N1  backward of NeRFSmallImpl::forward (training step, NeRFExecutor.h:923 loss.backward()).  fp32, layer by layer:
+//   forward with every layer output kept  ->  for each layer, last to first:  g *= (out > 0) ;  dW += g^T . in ;  g_in = g . W
+// g . W is the same k_linear kernel run on the checkpoint-order blob (W [out][in] row-major IS the transposed operand of the
+// backward product); dW is a TN GEMM over the points with one atomic add per output element and workgroup.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_relu_mask(int64_t total, int n, float *__restrict__ g, int g_stride, const float *__restrict__ act, int act_stride)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int64_t pt = e / n; const int k = (int)(e - pt * n);
+    if (!(act[pt * act_stride + k] > 0.0f)) g[pt * g_stride + k] = 0.0f;
+}
+
+constexpr int GW_PTS = 32;      // points staged per iteration
+// dW[o][i] += sum_pt g[pt][o] * concat(a, b)[pt][i]   (out, in <= 64 per launch tile; 256 threads, a 4x4 register tile each)
+__global__ void __launch_bounds__(256) k_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *__restrict__ dw)
+{
+    __shared__ float gs[GW_PTS][64 + 1], xs[GW_PTS][64 + 1];
+    const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
+    const int to = (threadIdx.x >> 4) * 4, ti = (threadIdx.x & 15) * 4;
+    float acc[4][4] = {};
+    for (int64_t base = (int64_t)blockIdx.x * GW_PTS; base < npts; base += (int64_t)gridDim.x * GW_PTS) {
+        for (int e = threadIdx.x; e < GW_PTS * 64; e += 256) {
+            const int j = e >> 6, k = e & 63;
+            const int64_t pt = base + j;
+            float gv = 0.0f, xv = 0.0f;
+            if (pt < npts) {
+                if (o0 + k < out) gv = g.p[pt * g.stride + g.off + o0 + k];
+                const int col = i0 + k;
+                if (col < in) xv = (col < a.n) ? a.p[pt * a.stride + a.off + col] : b.p[pt * b.stride + b.off + (col - a.n)];
+            }
+            gs[j][k] = gv; xs[j][k] = xv;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < GW_PTS; j++) {
+            float gv[4], xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { gv[q] = gs[j][to + q]; xv[q] = xs[j][ti + q]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[q][r] = __builtin_fmaf(gv[q], xv[r], acc[q][r]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int o = o0 + to + q, i = i0 + ti + r;
+            if (o < out && i < in && acc[q][r] != 0.0f) unsafeAtomicAdd(dw + (size_t)o * in + i, acc[q][r]);
+        }
+}
+
+static int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st)
+{
+    const int64_t nb = ceil_div(npts, GW_PTS);
+    dim3 grid((unsigned)(nb < 256 ? nb : 256), (unsigned)ceil_div(out, 64), (unsigned)ceil_div(in, 64));
+    hipLaunchKernelGGL(k_grad_w, grid, dim3(256), 0, st, npts, g, a, b, out, in, dw);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+// g_in[pt][k] = sum_o g[pt][o] * W[o][k]: k_linear with the blob matrix as its [in' = out][out' = in] operand
+static int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st)
+{
+    const Seg none{nullptr, 0, 0, 0};
+    const int threads = L.in >= 256 ? 256 : (int)ceil_div(L.in, 64) * 64;
+    const size_t lds = (size_t)L.out * LIN_TP * sizeof(float);
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)ceil_div(npts, LIN_TP)), dim3(threads), lds, st, npts, g, none, m->d_params + L.w_off, (const float *)nullptr, L.in, 0, y,
+                       y_stride, 0);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+static const int64_t BWD_CHUNK = 1 << 17;
+
+size_t mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
+{
+    const int64_t c = p < BWD_CHUNK ? p : BWD_CHUNK;
+    return align_up((size_t)c * m->max_width * sizeof(float), 256) * (m->layers.size() + 3);
+}
+
+int mlp_small_backward(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs,
+                       void *ws, size_t ws_bytes, hipStream_t st)
+{
+    if (m->family != MLP_SMALL) { set_error("nrf_mlp_backward: built for the NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
+    if (ws_bytes < mlp_backward_workspace_bytes(m, p)) { set_error("nrf_mlp_backward: workspace %zu < %zu bytes", ws_bytes, mlp_backward_workspace_bytes(m, p)); return NRF_ERR_WORKSPACE; }
+    const auto &d = m->small;
+    const int W = m->max_width, nl = (int)m->layers.size();
+    const size_t buf = align_up((size_t)(p < BWD_CHUNK ? p : BWD_CHUNK) * W * sizeof(float), 256) / sizeof(float);
+    float *base = reinterpret_cast<float *>(ws);
+    std::vector<float *> H(nl);
+    for (int l = 0; l < nl; l++) H[l] = base + (size_t)l * buf;
+    float *G[3] = {base + (size_t)nl * buf, base + (size_t)(nl + 1) * buf, base + (size_t)(nl + 2) * buf};
+    const Seg none{nullptr, 0, 0, 0};
+    for (int64_t p0 = 0; p0 < p; p0 += BWD_CHUNK) {
+        const int64_t c = (p - p0) < BWD_CHUNK ? (p - p0) : BWD_CHUNK;
+        const float *xc = x + p0 * xs;
+        const float *gc = g_out + p0 * gos;
+        // ---- forward, keeping every layer output (post-ReLU for hidden layers) ----
+        Seg cur{xc, xs, 0, d.input_ch};
+        int li = 0;
+        for (int l = 0; l < d.num_layers; l++, li++) {
+            NRF_TRY(run_linear(c, cur, none, m->layers[li], l != d.num_layers - 1, H[li], W, 0, st));
+            cur = Seg{H[li], W, 0, m->layers[li].out};
+        }
+        const int sig_l = li - 1;                             // H[sig_l]: column 0 = sigma, 1.. = geo
+        const Seg cv{xc, xs, d.input_ch, d.input_ch_views}, cg{H[sig_l], W, 1, d.geo_feat_dim};
+        for (int l = 0; l < d.num_layers_color; l++, li++) {
+            NRF_TRY(run_linear(c, l == 0 ? cv : cur, l == 0 ? cg : none, m->layers[li], l != d.num_layers_color - 1, H[li], W, 0, st));
+            cur = Seg{H[li], W, 0, m->layers[li].out};
+        }
+        // ---- colour net backward ----
+        Seg g{gc, gos, 0, 3};
+        int gi = 0;
+        for (int l = nl - 1; l > sig_l; l--) {
+            const LinearLayer &L = m->layers[l];
+            if (l != nl - 1) {
+                hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)ceil_div(c * L.out, 256)), dim3(256), 0, st, c * L.out, L.out, const_cast<float *>(g.p), g.stride, H[l], W);
+                NRF_LAUNCH_CHECK();
+            }
+            const bool first = (l == sig_l + 1);
+            NRF_TRY(run_grad_w(c, g, first ? cv : Seg{H[l - 1], W, 0, L.in}, first ? cg : none, L.out, L.in, g_params + L.w_off, st));
+            float *dst = G[gi]; gi = (gi + 1) % 3;
+            NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+            g = Seg{dst, W, 0, L.in};
+        }
+        // sigma-net output gradient: column 0 = d/d sigma (g_out[:,3]), 1..geo = d/d geo (columns views.. of the colour input gradient)
+        float *gh = G[gi]; gi = (gi + 1) % 3;
+        hipLaunchKernelGGL(k_copy_col, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, st, c, gc, gos, 3, gh, W, 0);
+        NRF_LAUNCH_CHECK();
+        for (int k = 0; k < d.geo_feat_dim; k++) {
+            hipLaunchKernelGGL(k_copy_col, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, st, c, g.p, g.stride, d.input_ch_views + k, gh, W, 1 + k);
+            NRF_LAUNCH_CHECK();
+        }
+        g = Seg{gh, W, 0, 1 + d.geo_feat_dim};
+        for (int l = sig_l; l >= 0; l--) {
+            const LinearLayer &L = m->layers[l];
+            if (l != sig_l) {
+                hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)ceil_div(c * L.out, 256)), dim3(256), 0, st, c * L.out, L.out, const_cast<float *>(g.p), g.stride, H[l], W);
+                NRF_LAUNCH_CHECK();
+            }
+            NRF_TRY(run_grad_w(c, g, l == 0 ? Seg{xc, xs, 0, d.input_ch} : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
+            if (l == 0 && !g_x) break;
+            float *dst = (l == 0) ? g_x + p0 * gxs : G[gi];
+            gi = (gi + 1) % 3;
+            NRF_TRY(run_backprop(c, g, m, L, dst, l == 0 ? gxs : W, st));
+            g = Seg{dst, l == 0 ? gxs : W, 0, L.in};
+        }
+    }
+    return NRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // handle construction
 // ---------------------------------------------------------------------------------------------------
 static int add_layer(nrf_mlp *m, const std::vector<float> &hp, size_t &off, int in, int out, bool bias)
@@ -363,6 +519,41 @@ NRF_API int nrf_mlp_lerf_create(const nrf_mlp_small_desc *d, const float *params
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
+}
+
+/* Training: replace the parameter blob (same layout) and refresh every derived operand (transposed fp32 layers, matrix-core images). */
+int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream)
+{
+    NRF_CHECK_ARG(m && params, "nrf_mlp_set_params: null pointer");
+    hipStream_t st = as_stream(stream);
+    std::vector<float> hp((size_t)m->n_params);
+    if (params_on_device) {
+        NRF_HIP(hipMemcpyAsync(hp.data(), params, hp.size() * 4, hipMemcpyDeviceToHost, st));
+        NRF_HIP(hipStreamSynchronize(st));
+    } else memcpy(hp.data(), params, hp.size() * 4);
+    NRF_HIP(hipMemcpyAsync(m->d_params, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
+    std::vector<float> wt;
+    for (auto &L : m->layers) {
+        wt.resize((size_t)L.in * L.out);
+        for (int o = 0; o < L.out; o++)
+            for (int k = 0; k < L.in; k++) wt[(size_t)k * L.out + o] = hp[L.w_off + (size_t)o * L.in + k];
+        NRF_HIP(hipMemcpyAsync(L.d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
+        if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, hp.data() + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyHostToDevice, st));
+        NRF_HIP(hipStreamSynchronize(st));            // wt is reused by the next layer
+    }
+    if (m->family == MLP_SMALL) return mlp_small_pack_f16(m, hp);
+    if (m->family == MLP_NERF) return mlp_nerf_pack_f16(m, hp);
+    return NRF_OK;
+}
+
+size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p) { return m ? mlp_backward_workspace_bytes(m, p) : 0; }
+
+int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x, void *d_workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(m && d_x && d_g_out && d_g_params && d_workspace && p >= 0, "nrf_mlp_backward: bad argument");
+    if (p == 0) return NRF_OK;
+    return mlp_small_backward(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
 }
 
 void nrf_mlp_destroy(nrf_mlp *m)

@@ -397,6 +397,7 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         else for (int i = 0; i < 3; i++) bp[i] = hp[b_off[RGB] + i];
     }
     if (img.size() != (size_t)NerfNet::total_frags() * 512) { set_error("internal: classic NeRF weight image has %zu halves, expected %zu", img.size(), (size_t)NerfNet::total_frags() * 512); return NRF_ERR_INVALID_ARG; }
+    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // re-pack after nrf_mlp_set_params
     m->packed_f16_bytes = img.size() * sizeof(_Float16) + bias.size() * sizeof(float);
     NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));

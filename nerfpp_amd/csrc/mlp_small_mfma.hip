@@ -350,6 +350,8 @@ int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     pk2.split = true;
     pack_small(d, hp, pk);
     pack_small(d, hp, pk2);
+    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // re-pack after nrf_mlp_set_params
+    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
     m->packed_f16_bytes = pk.img.size() * sizeof(_Float16);
     NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_f16, pk.img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));

@@ -1,0 +1,312 @@
+// train.hip -- N1: the pieces of one optimisation step of NeRFExecutor::Train (NeRFExecutor.h:862-995) that are not the MLP:
+//   huber_loss / mse_loss                       :882-887          nrf_huber_loss
+//   RawToOutputs backward (+ TruncExp::backward) NeRFRenderer.h:199-282, CustomOps.cpp:11-15   nrf_raw2outputs_backward
+//   hash-grid backward                          HashEmbedder: nn::Embedding index_add of the trilinear weights (NeRF.cpp:279-298)
+//                                               CuHashEmbedder: CuHashEmbedder.cu:105-216, host :277-325   nrf_hash_backward
+//   Adam(lr, betas (0.9, 0.99), eps 1e-15)      :539               nrf_adam_step
+// Gradients flow only through the fine pass (z_samples are detached, NeRFRenderer.h:429).
+#include "encode.h"
+
+namespace nrf {
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// out[0] += sum huber, out[1] += sum squared error (both divided by count on the host side of the call)
+__global__ void k_huber(int64_t count, float norm, const float *__restrict__ pred, const float *__restrict__ target, double *__restrict__ out, float *__restrict__ grad)
+{
+    double h = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        const float z = fabsf(d);
+        h += (z < 1.0f) ? 0.5 * (double)z * (double)z : (double)z - 0.5;
+        q += (double)d * (double)d;
+        if (grad) grad[i] = (d < -1.0f) ? -norm : (d > 1.0f ? norm : norm * d);
+    }
+    h = wsum(h); q = wsum(q);
+    if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(out, h); unsafeAtomicAdd(out + 1, q); }
+}
+
+__global__ void k_finish_loss(int64_t count, const double *__restrict__ acc, float *__restrict__ loss_mse)
+{
+    loss_mse[0] = (float)(acc[0] / (double)count);
+    loss_mse[1] = (float)(acc[1] / (double)count);
+}
+
+// One wave per ray.  Forward quantities are recomputed exactly as k_raw2outputs does (same double scan for the log-transmittance);
+// the reverse pass needs suffix sums of g_L over later samples: a reverse wave scan per 64-sample block, blocks walked last to first.
+constexpr int BW_RAYS = 4;
+__device__ __forceinline__ double wave_incl_scan_d(double v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * BW_RAYS)
+k_raw2outputs_bwd(int64_t n, int s, int c, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int d_stride,
+                  const float *__restrict__ g_rgb, float *__restrict__ g_raw, float *__restrict__ lt_scratch /* [n, s] exclusive log-transmittance */)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * BW_RAYS + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const float *dv = dirs + ray * d_stride;
+    float nn = dv[0] * dv[0]; nn = nn + dv[1] * dv[1]; nn = nn + dv[2] * dv[2];
+    const float nrm = sqrtf(nn);
+    const float *zr = z + ray * s;
+    float *lt = lt_scratch + ray * s;
+    // pass 1 (forward order): exclusive prefix of log(clamp_min(1 - alpha, 1e-10)), rounded to fp32 like torch::cumsum's output
+    double carry = 0.0;
+    for (int base = 0; base < s; base += 64) {
+        const int j = base + lane;
+        float lg = 0.0f;
+        if (j < s) {
+            const float *r = raw + (ray * s + j) * c;
+            float dist = (j + 1 < s) ? (zr[j + 1] - zr[j]) : 1e10f;
+            dist = dist * nrm;
+            const float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            const float alpha = -nrf_expf(-sig * dist) + 1.0f;
+            const float om = 1.0f - alpha;
+            lg = nrf_logf(om > 1e-10f ? om : 1e-10f);
+        }
+        const double incl = wave_incl_scan_d((double)lg, lane);
+        if (j < s) lt[j] = (float)(carry + (incl - (double)lg));
+        carry += __shfl(incl, 63);
+    }
+    wave_sync();
+    // pass 2 (reverse order)
+    const float gr = g_rgb[ray * 3], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+    const float gsum = gr + gg + gb;
+    double suffix = 0.0;                                   // sum of g_L over samples in later blocks
+    const int nblk = (s + 63) / 64;
+    for (int blk = nblk - 1; blk >= 0; blk--) {
+        const int j = blk * 64 + lane;
+        const bool live = j < s;
+        float gL = 0.0f, gw = 0.0f, alpha = 0.0f, trans = 0.0f, x = 0.0f, dist = 0.0f, sraw = 0.0f;
+        float col[3] = {0.0f, 0.0f, 0.0f};
+        if (live) {
+            const float *r = raw + (ray * s + j) * c;
+            dist = (j + 1 < s) ? (zr[j + 1] - zr[j]) : 1e10f;
+            dist = dist * nrm;
+            sraw = r[3];
+            const float sig = sraw > 0.0f ? sraw : 0.0f;
+            x = -sig * dist;
+            alpha = -nrf_expf(x) + 1.0f;
+            const float l = lt[j];
+            trans = nrf_expf(l);
+            col[0] = nrf_sigmoidf(r[0]); col[1] = nrf_sigmoidf(r[1]); col[2] = nrf_sigmoidf(r[2]);
+            gw = gr * col[0] + gg * col[1] + gb * col[2];
+            if (white) gw -= gsum;
+            const float cl = fminf(fmaxf(l, -100.0f), 5.0f);
+            gL = gw * alpha * nrf_expf(cl);                // g_T * dT/dL with TruncExp's clamped derivative
+        }
+        // suffix over LATER samples: total of this block minus the inclusive prefix, plus later blocks
+        const double incl = wave_incl_scan_d((double)gL, lane);
+        const double total = __shfl(incl, 63);
+        const double later = suffix + (total - incl);
+        suffix += total;
+        if (live) {
+            float *g = g_raw + (ray * s + j) * c;
+            const float w = alpha * trans;
+            g[0] = gr * w * (col[0] * (1.0f - col[0]));
+            g[1] = gg * w * (col[1] * (1.0f - col[1]));
+            g[2] = gb * w * (col[2] * (1.0f - col[2]));
+            float g_alpha = gw * trans;
+            const float om = 1.0f - alpha;
+            if (om >= 1e-10f) g_alpha -= (float)later / om;
+            const float cx = fminf(fmaxf(x, -100.0f), 5.0f);
+            const float g_x = -g_alpha * nrf_expf(cx);
+            g[3] = (sraw > 0.0f) ? -g_x * dist : 0.0f;
+            for (int k = 4; k < c; k++) g[k] = 0.0f;
+        }
+    }
+}
+
+// d loss / d sigma = 0 where the embedder's keep mask is false (raw[~keep, -1] = 0 is an in-place overwrite in the forward)
+__global__ void k_mask_grad(int64_t p, int c, const uint8_t *__restrict__ keep, float *__restrict__ g_raw)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p && !keep[i]) g_raw[i * c + (c - 1)] = 0.0f;
+}
+
+// HashEmbedder (fp32 tables [L][2^T][F]): row gradient = g * wz * wy * wx in autograd's chain order
+template <int F>
+__global__ void k_hash_ngp_bwd(HashParams hp, const float *__restrict__ pts, int64_t p, const float *__restrict__ g_emb, int g_stride, float *__restrict__ g_table)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= p) return;
+    const float x[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    float w[3];
+    int32_t idx[3];
+    const float res = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);
+        const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / res;
+        const float fl = floorf((c - hp.bbox.mn[a]) / grid);
+        idx[a] = (int32_t)fl;
+        const float vmin = fl * grid + hp.bbox.mn[a];
+        const float vmax = vmin + grid;
+        w[a] = (x[a] - vmin) / (vmax - vmin);
+    }
+    float g[F];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; f++) { g[f] = g_emb[i * g_stride + l * F + f]; any |= g[f] != 0.0f; }
+    if (!any) return;
+    float *tl = g_table + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
+    const uint32_t hmask = (1u << hp.log2_t) - 1u;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t cx = (uint32_t)idx[0] + ((c >> 2) & 1), cy = (uint32_t)idx[1] + ((c >> 1) & 1), cz = (uint32_t)idx[2] + (c & 1);
+        const uint32_t h = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
+        const float wx = ((c >> 2) & 1) ? w[0] : 1.0f - w[0], wy = ((c >> 1) & 1) ? w[1] : 1.0f - w[1], wz = (c & 1) ? w[2] : 1.0f - w[2];
+#pragma unroll
+        for (int f = 0; f < F; f++) unsafeAtomicAdd(tl + (int64_t)h * F + f, ((g[f] * wz) * wy) * wx);
+    }
+}
+
+// CuHashEmbedder (CuHashEmbedder.cu:105-216): grad_in = fp16(g * 128) (:297), each corner adds fp16(grad_in * w) (:196-197) into the
+// level's slice of the pool at the forward's (quirky) element offset, result / 128 (:323).  The reference accumulates with fp16
+// atomics (order-dependent, saturating); here the per-corner contributions are rounded exactly as there but ACCUMULATED IN FP32.
+template <int F>
+__global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int64_t p, const float *__restrict__ g_emb, int g_stride, float *__restrict__ g_table)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= p) return;
+    float fr[3];
+    uint32_t pos[3];
+    const float mul = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(pts[i * 3 + a], hp.bbox.mx[a]), hp.bbox.mn[a]);      // QueryPoints = the clamped points (CuHashEmbedder.cpp:92-96)
+        float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * mul;
+        q = q + hp.bias[l * 3 + a];
+        const float fl = floorf(q);
+        pos[a] = (uint32_t)fl;
+        fr[a] = q - fl;
+    }
+    float g[F];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; f++) { g[f] = __half2float(__float2half_rn(g_emb[i * g_stride + l * F + f] * 128.0f)); any |= g[f] != 0.0f; }
+    if (!any) return;
+    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+    const uint32_t lsz = hp.local_size[l];
+    float *tl = g_table + hp.local_idx[l];
+    const float a = fr[0], b = fr[1], c = fr[2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t hx = (pos[0] + ((k >> 2) & 1)) * pa, hy = (pos[1] + ((k >> 1) & 1)) * pb, hz = (pos[2] + (k & 1)) * pc;
+        const uint32_t ps = (hx ^ hy ^ hz) % lsz;
+        const float w = ((k & 4) ? a : 1.0f - a) * ((k & 2) ? b : 1.0f - b) * ((k & 1) ? c : 1.0f - c);
+#pragma unroll
+        for (int f = 0; f < F; f++) unsafeAtomicAdd(tl + (size_t)ps * F + f, __half2float(__float2half_rn(g[f] * w)) * (1.0f / 128.0f));
+    }
+}
+
+__global__ void k_adam(int64_t n, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps, float *__restrict__ p, const float *__restrict__ g,
+                       float *__restrict__ m, float *__restrict__ v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.0f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - lr_over_bc1 * (mi / denom);
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t count, float *d_loss_mse, float *d_grad, void *stream)
+{
+    NRF_CHECK_ARG(d_pred && d_target && d_loss_mse && count > 0, "nrf_huber_loss: bad argument");
+    hipStream_t st = as_stream(stream);
+    double *acc = nullptr;
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&acc), 2 * sizeof(double), st));
+    NRF_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
+    const unsigned grid = (unsigned)(ceil_div(count, 256) < 512 ? ceil_div(count, 256) : 512);
+    hipLaunchKernelGGL(k_huber, dim3(grid), dim3(256), 0, st, count, 1.0f / (float)count, d_pred, d_target, acc, d_grad);
+    NRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finish_loss, dim3(1), dim3(1), 0, st, count, acc, d_loss_mse);
+    NRF_LAUNCH_CHECK();
+    NRF_HIP(hipFreeAsync(acc, st));
+    return NRF_OK;
+}
+
+int nrf_raw2outputs_backward(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                             const float *d_g_rgb, float *d_g_raw, void *stream)
+{
+    NRF_CHECK_ARG(d_raw && d_z && d_dirs && d_g_rgb && d_g_raw && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs_backward: bad argument");
+    if (n == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    float *lt = nullptr;
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&lt), (size_t)n * s * sizeof(float), st));
+    hipLaunchKernelGGL(k_raw2outputs_bwd, dim3((unsigned)ceil_div(n, BW_RAYS)), dim3(64 * BW_RAYS), 0, st, n, s, c, white_bkgr, d_raw, d_z, d_dirs, d_stride, d_g_rgb,
+                       d_g_raw, lt);
+    NRF_LAUNCH_CHECK();
+    NRF_HIP(hipFreeAsync(lt, st));
+    return NRF_OK;
+}
+
+int nrf_mask_sigma_grad(const uint8_t *d_keep, int64_t p, int c, float *d_g_raw, void *stream)
+{
+    NRF_CHECK_ARG(d_keep && d_g_raw && p >= 0 && c >= 1, "nrf_mask_sigma_grad: bad argument");
+    if (p == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, as_stream(stream), p, c, d_keep, d_g_raw);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, const float *d_g_emb, float *d_g_table, void *stream)
+{
+    NRF_CHECK_ARG(h && d_x && d_g_emb && d_g_table && p >= 0, "nrf_hash_backward: bad argument");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_NGP || h->primes_set, "nrf_hash_backward: CuHashEmbedder-mode grid without primes");
+    if (p == 0) return NRF_OK;
+    const int F = h->desc.n_features, L = h->desc.n_levels;
+    dim3 grid((unsigned)ceil_div(p, 256), (unsigned)L);
+    hipStream_t st = as_stream(stream);
+#define NRF_BWD(FF)                                                                                                                        \
+    do {                                                                                                                                   \
+        if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL(k_hash_ngp_bwd<FF>, grid, dim3(256), 0, st, h->params, d_x, p, d_g_emb, L * F, d_g_table); \
+        else hipLaunchKernelGGL(k_hash_cu_bwd<FF>, grid, dim3(256), 0, st, h->params, d_x, p, d_g_emb, L * F, d_g_table);                 \
+    } while (0)
+    switch (F) {
+        case 1: NRF_BWD(1); break;
+        case 2: NRF_BWD(2); break;
+        case 4: NRF_BWD(4); break;
+        case 8: NRF_BWD(8); break;
+        default: set_error("nrf_hash_backward: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
+    }
+#undef NRF_BWD
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t, void *stream)
+{
+    NRF_CHECK_ARG(d_p && d_g && d_m && d_v && n >= 0 && t >= 1, "nrf_adam_step: bad argument");
+    if (n == 0) return NRF_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps,
+                       d_p, d_g, d_m, d_v);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // extern "C"

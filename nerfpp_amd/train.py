@@ -1,0 +1,100 @@
+"""One optimisation step of NeRFExecutor::Train (NeRFExecutor.h:862-995) over the C ABI -- SURVEY section 8f, row N1.
+
+    render the ray batch (NeRFRenderer::Render with an explicit ray batch, :876) -> huber_loss(RGBMap, target) (:883)
+    -> loss.backward() (:923) -> Adam(lr, betas (0.9, 0.99), eps 1e-15).step() (:539, :985)
+
+Gradients flow through the FINE pass only (z_samples are detached, NeRFRenderer.h:429; rays and depths carry no parameters).
+PyTorch owns the buffers (fp32 master parameters, Adam moments) and nothing else: every arithmetic step is a call into
+libnerfpp_hip.so on the current HIP stream.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .modules import _HashBase, CuHashEmbedder, NeRFSmall, _ptr, _stream, _dev_f32
+from .renderer import NeRFRenderer, NeRFRenderParams
+
+
+class Trainer:
+    def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15):
+        if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
+            raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
+        self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
+        self.renderer = NeRFRenderer(embedder, embeddirs, mlp)
+        dev = "cuda"
+        self.table = torch.as_tensor(np.ascontiguousarray(table, np.float32).reshape(-1) if not torch.is_tensor(table) else table.reshape(-1)).to(dev).contiguous()
+        self.blob = torch.as_tensor(np.ascontiguousarray(mlp_blob, np.float32).reshape(-1) if not torch.is_tensor(mlp_blob) else mlp_blob.reshape(-1)).to(dev).contiguous()
+        assert self.table.numel() == embedder.table_elems() and self.blob.numel() == mlp.n_params
+        self.m_table, self.v_table = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
+        self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
+        self.lr, self.betas, self.eps, self.t = float(learning_rate), betas, float(eps), 0
+        self._ws = None
+        if isinstance(embedder, CuHashEmbedder):
+            embedder.set_dense_budget(0)        # the baked dense pyramid of the render fast path would be re-baked after every step
+        self._push_params()
+
+    def _push_params(self):
+        self.embedder.set_table(self.table)
+        L.check(L.lib().nrf_mlp_set_params(self.mlp._m, _ptr(self.blob), 1, _stream()))
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty((int(nbytes),), device="cuda", dtype=torch.uint8)
+        return self._ws
+
+    def backward(self, res, target, n_samples_out, white_bkgr):
+        """loss + gradients of one rendered batch (fills self.g_table / self.g_blob); returns device tensor [huber, mse]."""
+        lib = L.lib()
+        rays = res.Extras["rays_flat"]
+        n, stride = rays.shape
+        rgb = res.Outputs.RGBMap.reshape(n, 3).contiguous()
+        tgt = _dev_f32(target).reshape(n, 3)
+        loss_mse = torch.empty((2,), device=rgb.device); g_rgb = torch.empty_like(rgb)
+        L.check(lib.nrf_huber_loss(_ptr(rgb), _ptr(tgt), C.c_int64(rgb.numel()), _ptr(loss_mse), _ptr(g_rgb), _stream()))
+        raw = res.Raw; s = n_samples_out
+        z = res.Extras["z_fine"] if "z_fine" in res.Extras else res.Extras["z_coarse"]
+        assert raw.shape == (n, s, 4) and z.shape == (n, s)
+        g_raw = torch.empty_like(raw)
+        L.check(lib.nrf_raw2outputs_backward(_ptr(raw), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), s, 4, int(white_bkgr), _ptr(g_rgb), _ptr(g_raw),
+                                             _stream()))
+        pts = torch.empty((n * s, 3), device=rays.device)
+        L.check(lib.nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
+        emb, keep = self.embedder.forward(pts)
+        dirs, _ = self.embeddirs.forward(rays[:, 8:11].contiguous())
+        x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+        keep_u8 = keep.to(torch.uint8)
+        L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
+        self.g_blob.zero_(); self.g_table.zero_()
+        in_ch = self.embedder.GetOutputDims()
+        g_x = torch.empty((n * s, in_ch), device=rays.device)
+        nb = lib.nrf_mlp_backward_workspace_bytes(self.mlp._m, C.c_int64(n * s))
+        ws = self._workspace(nb)
+        L.check(lib.nrf_mlp_backward(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+        L.check(lib.nrf_hash_backward(self.embedder._h, _ptr(pts), C.c_int64(n * s), _ptr(g_x), _ptr(self.g_table), _stream()))
+        self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
+        return loss_mse
+
+    def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams):
+        """Optimizer->zero_grad(); Render; huber; backward; Optimizer->step() (NeRFExecutor.h:866-985)."""
+        p = render_params
+        if p.RawNoiseStd > 0 or p.StochasticPreconditioningAlpha > 0 or not p.ThinRay or p.Perturb > 0:
+            raise L.NrfError("Trainer.step: the backward pass is built for the deterministic sample set (RawNoiseStd = 0, no preconditioning, ThinRay)")
+        p.ReturnRaw, p.KeepIntermediates = True, True
+        res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, None))
+        s_out = p.NSamples + p.NImportance
+        loss_mse = self.backward(res, target, s_out, p.WhiteBkgr)
+        self.t += 1
+        b1, b2 = self.betas
+        for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):
+            L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                          C.c_float(self.eps), self.t, _stream()))
+        self._push_params()
+        return loss_mse, res
+
+    @staticmethod
+    def psnr(mse):
+        return -10.0 * math.log(max(float(mse), 1e-30)) / math.log(10.0)       # NeRFExecutor.h:893

@@ -1365,7 +1365,7 @@ ORC_API void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t
     for (int64_t i = 0; i < n; i++) {
         m[i] = m[i] * b1 + g[i] * (1.0f - b1);                /* exp_avg.lerp_(grad, 1 - beta1) == this up to 1 ulp */
         v[i] = v[i] * b2 + (g[i] * g[i]) * (1.0f - b2);       /* exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2) */
-        const float denom = (float)((double)sqrtf(v[i]) / bc2s) + eps;
+        const float denom = sqrtf(v[i]) / (float)bc2s + eps;   /* (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps), fp32 tensor ops */
         p[i] = p[i] - (float)step_size * (m[i] / denom);
     }
 }

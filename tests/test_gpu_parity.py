@@ -740,3 +740,125 @@ def test_image_post_bit_exact_vs_reference(api, O):
     assert_exact(host(api.R.TorchTensorToCVMat(dn)), g["depth_u8"])
     big = np.random.RandomState(0).uniform(-0.2, 1.3, 1000003).astype(np.float32)         # ragged length, unaligned tail
     assert_exact(host(api.R.TorchTensorToCVMat(dev(big))), O.to_u8(big))
+
+
+# ------------------------------------------------------------------ N1: training step (backward + huber + Adam)
+def _train_golden(api, manifest):
+    g = load_golden("train_hash")
+    ent = manifest["train_hash"]
+    table = synth.blob_from_manifest([e for e in ent if "embeddings" in e[0]])
+    blob = synth.blob_from_manifest([e for e in ent if "embeddings" not in e[0]])
+    e = api.M.HashEmbedder("embedder", g["bbox"], 4, 2, 12, 16, 128)
+    m = api.M.NeRFSmall(3, 64, 15, 3, 64, False, 3, 64, 8, 16, "model", params=blob)
+    return g, table, blob, e, api.M.SHEncoder("embeddirs", 3, 4), m
+
+
+def _mlp_names():
+    return ["sigma_net_0", "sigma_net_1", "sigma_net_2", "color_net_0", "color_net_1", "color_net_2"]
+
+
+def test_training_backward_stages_vs_reference_autograd(api, O, manifest):
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    g, table, blob, e, ed, m = _train_golden(api, manifest)
+    e.set_table(table)
+    lib = api.L.lib()
+    # huber / mse and d huber / d rgb
+    rgb, tgt = dev(g["s1_rgb"]), dev(g["target"])
+    lm = torch.empty(2, device="cuda"); g_rgb = torch.empty_like(rgb)
+    api.L.check(lib.nrf_huber_loss(P(rgb), P(tgt), C.c_int64(rgb.numel()), P(lm), P(g_rgb), None))
+    assert abs(host(lm)[0] - g["s1_loss"][0]) < 2e-7 and abs(host(lm)[1] - g["s1_mse"][0]) < 2e-7
+    ol, om, og = O.huber_loss(g["s1_rgb"], g["target"])
+    assert_exact(host(g_rgb), og, "d huber / d rgb == oracle")
+    # RawToOutputs backward on the reference's fine raw / z
+    rays = O.pack_rays(g["rays_o"], g["rays_d"], g["bbox"])
+    raw, z, d = dev(g["s1_fine_raw"]), dev(g["s1_fine_z"]), dev(rays[:, 3:6])
+    g_raw = torch.empty_like(raw)
+    api.L.check(lib.nrf_raw2outputs_backward(P(raw), P(z), P(d), 3, C.c_int64(64), 64, 4, 0, P(g_rgb), P(g_raw), None))
+    ref = g["s1_grad_fine_raw"]
+    assert_close(host(g_raw), ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max(), what="RawToOutputs backward vs autograd")
+    assert_close(host(g_raw), O.raw2outputs_backward(g["s1_fine_raw"], g["s1_fine_z"], rays[:, 3:6], og), rtol=1e-5, atol=1e-7 * np.abs(ref).max(), what="vs oracle")
+    # network backward on the reference's points
+    pts = dev(g["s1_fine_pts"].reshape(-1, 3))
+    emb, keep = e.forward(pts)
+    dirs, _ = ed.forward(dev(rays[:, 8:11]))
+    x = torch.cat([emb, dirs[:, None, :].expand(64, 64, 16).reshape(4096, 16)], 1).contiguous()
+    gr = dev(ref.reshape(-1, 4).copy())
+    ku8 = keep.to(torch.uint8)
+    api.L.check(lib.nrf_mask_sigma_grad(P(ku8), C.c_int64(4096), 4, P(gr), None))
+    g_blob = torch.zeros(blob.size, device="cuda"); g_x = torch.empty((4096, 8), device="cuda")
+    nb = lib.nrf_mlp_backward_workspace_bytes(m._m, C.c_int64(4096))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    api.L.check(lib.nrf_mlp_backward(m._m, P(x), P(gr), C.c_int64(4096), P(g_blob), P(g_x), P(ws), C.c_size_t(nb), None))
+    refb = np.concatenate([g[f"s1_grad_model_{n}.weight"].reshape(-1) for n in _mlp_names()])
+    assert_close(host(g_blob), refb, rtol=1e-3, atol=2e-5 * np.abs(refb).max(), what="NeRFSmall weight gradients vs autograd")
+    gp_o, gx_o = O.mlp_small_backward(blob, host(x), host(gr), 8, 16, 3, 64, 15, 3, 64)
+    assert_close(host(g_x), gx_o, rtol=1e-4, atol=1e-6 * np.abs(gx_o).max(), what="d loss / d features vs oracle")
+    g_table = torch.zeros(table.size, device="cuda")
+    api.L.check(lib.nrf_hash_backward(e._h, P(pts), C.c_int64(4096), P(g_x), P(g_table), None))
+    reft = np.stack([g[f"s1_grad_embedder_embeddings_{l}.weight"] for l in range(4)]).reshape(-1)
+    assert_close(host(g_table), reft, rtol=1e-3, atol=2e-5 * np.abs(reft).max(), what="hash table gradients vs autograd")
+    # Adam on the reference's gradients -> the reference's parameters after step 1
+    p = dev(blob.copy()); mm = torch.zeros_like(p); vv = torch.zeros_like(p); gg = dev(refb)
+    api.L.check(lib.nrf_adam_step(P(p), P(gg), P(mm), P(vv), C.c_int64(p.numel()), C.c_float(float(g["lr"][0])), C.c_float(0.9), C.c_float(0.99), C.c_float(1e-15), 1, None))
+    ref1 = np.concatenate([g[f"s1_param_model_{n}.weight"].reshape(-1) for n in _mlp_names()])
+    assert_close(host(p), ref1, rtol=0, atol=2e-7, what="Adam step 1")
+
+
+def test_trainer_two_steps_vs_reference(api, manifest):
+    from nerfpp_amd.train import Trainer
+    g, table, blob, e, ed, m = _train_golden(api, manifest)
+    lr = float(g["lr"][0])
+    tr = Trainer(e, ed, m, table, blob, learning_rate=lr)
+    rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=64, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                                BoundingBox=g["bbox"], Precision=api.L.NRF_PREC_F32)
+    o, d, tgt = dev(g["rays_o"]), dev(g["rays_d"]), dev(g["target"])
+    lm1, _ = tr.step(o, d, tgt, rp)
+    # end to end the loss inherits the render's own distance to the reference (a few fine samples in other CDF bins, 64 rays only)
+    assert abs(host(lm1)[0] - g["s1_loss"][0]) < 2e-4 and abs(host(lm1)[1] - g["s1_mse"][0]) < 4e-4, (host(lm1), g["s1_loss"], g["s1_mse"])
+    ref1 = np.concatenate([g[f"s1_param_model_{n}.weight"].reshape(-1) for n in _mlp_names()])
+    # Adam's first step is lr * sign(g) (m/sqrt(v) = g/|g|, eps 1e-15): a weight whose gradient is rounding-level noise moves by +-lr either
+    # way, so the comparison bounds the SHARE of such weights, not their distance
+    d1 = np.abs(host(tr.blob) - ref1) / lr
+    assert d1.mean() < 0.02 and (d1 > 0.05).mean() < 0.03, (d1.mean(), (d1 > 0.05).mean())
+    # second step from the REFERENCE's state after step 1 (its parameters; moments rebuilt from its step-1 gradients), so that the
+    # comparison is not dominated by the sign-descent noise of step 1
+    g1b = np.concatenate([g[f"s1_grad_model_{n}.weight"].reshape(-1) for n in _mlp_names()])
+    g1t = np.stack([g[f"s1_grad_embedder_embeddings_{l}.weight"] for l in range(4)]).reshape(-1)
+    tr.blob.copy_(dev(ref1)); tr.table.copy_(dev(np.stack([g[f"s1_param_embedder_embeddings_{l}.weight"] for l in range(4)]).reshape(-1)))
+    tr.m_blob.copy_(dev(0.1 * g1b)); tr.v_blob.copy_(dev(np.float32(0.01) * g1b * g1b))
+    tr.m_table.copy_(dev(0.1 * g1t)); tr.v_table.copy_(dev(np.float32(0.01) * g1t * g1t))
+    tr._push_params()
+    lm2, _ = tr.step(o, d, tgt, rp)
+    assert abs(host(lm2)[0] - g["s2_loss"][0]) < 2e-4, (host(lm2), g["s2_loss"])
+    ref2 = np.concatenate([g[f"s2_param_model_{n}.weight"].reshape(-1) for n in _mlp_names()])
+    d2 = np.abs(host(tr.blob) - ref2) / lr
+    assert d2.mean() < 5e-3 and (d2 > 0.05).mean() < 0.03, (d2.mean(), (d2 > 0.05).mean())
+    reft2 = np.stack([g[f"s2_param_embedder_embeddings_{l}.weight"] for l in range(4)]).reshape(-1)
+    dt = np.abs(host(tr.table) - reft2) / lr
+    assert dt.mean() < 8e-3 and (dt > 0.05).mean() < 0.05, (dt.mean(), (dt > 0.05).mean())
+
+
+def test_trainer_learns_a_teacher_scene(api):
+    """Fit a freshly initialised CuHash + NeRFSmall student to the renders of a teacher: the loss must fall steadily
+    (CuHashEmbedder backward, fp32 accumulation; the render the loss is computed on runs on the matrix cores)."""
+    from nerfpp_amd.train import Trainer
+    teacher = api.S.make_hash_scene(mode="cu", log2_t=14, sigma_scale=6.0)
+    student = api.S.make_hash_scene(mode="cu", log2_t=14, seed=777, table_amp=1e-4, sigma_scale=1.0)
+    K = api.S.lego_K(48, 48); bbox = api.S.LEGO_BBOX
+    rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=4096, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                                BoundingBox=bbox, Precision=api.L.NRF_PREC_F16_SPLIT)
+    views = []
+    for th in (-120.0, -30.0, 60.0, 150.0):
+        c2w = api.S.pose_spherical(th, -30.0, 4.0)
+        o, d, _ = api.R.GetRays(48, 48, K, c2w)
+        tgt = teacher["renderer"].Render(48, 48, K, rp, c2w=c2w).Outputs.RGBMap.reshape(-1, 3).clone()
+        views.append((o.reshape(-1, 3), d.reshape(-1, 3), tgt))
+    tr = Trainer(student["embedder"], student["embeddirs"], student["mlp"], student["table"], student["mlp_blob"], learning_rate=1e-2)
+    losses = []
+    for it in range(60):
+        o, d, tgt = views[it % 4]
+        lm, _ = tr.step(o, d, tgt, rp)
+        losses.append(float(host(lm)[0]))
+    first, last = np.mean(losses[:4]), np.mean(losses[-4:])
+    assert np.isfinite(losses).all() and last < 0.5 * first, (first, last)
