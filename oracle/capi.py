@@ -402,6 +402,15 @@ def hash_ngp_backward(x, bbox, L, F, log2_t, base, finest, g_emb):
     return g_table
 
 
+def hash_cu_backward(x, primes, local_idx, local_size, bias, bbox, mul, L, F, pool_elems, g_emb):
+    x = _f(x); g_emb = _f(g_emb); bb = _f(bbox); bias = _f(bias); mul = _f(mul)
+    pr = np.ascontiguousarray(primes, np.int32); li = np.ascontiguousarray(local_idx, np.int32); ls = np.ascontiguousarray(local_size, np.int32)
+    out = np.zeros(pool_elems, np.float32)
+    lib().orc_hash_cu_backward(_p(x), C.c_int64(x.shape[0]), pr.ctypes.data_as(C.c_void_p), li.ctypes.data_as(C.c_void_p), ls.ctypes.data_as(C.c_void_p),
+                               _p(bias), _p(bb), _p(mul), C.c_int(L), C.c_int(F), C.c_int64(pool_elems), _p(g_emb), _p(out))
+    return out
+
+
 def adam_step(p, g, m, v, lr, t, b1=0.9, b2=0.99, eps=1e-15):
     """in place on p, m, v (float32 arrays)"""
     assert p.dtype == np.float32 and m.dtype == np.float32 and v.dtype == np.float32

@@ -1355,6 +1355,48 @@ ORC_API void orc_hash_ngp_backward(const float *x, int64_t p, const float *bbox,
     free(acc);
 }
 
+/* H3  CuHashEmbedderBackwardKernel         CuHashEmbedder.cu:105-216, host :277-325   RESTATEMENT-PINNED (CUDA-only unit)
+ *     grad_in = fp16(g * 128) (:297) ; corner contribution = fp16(grad_in * w) (:196-197) added to the pool at the forward's
+ *     element offset (the overlap quirk again, :154) ; result = pool / 128 (:323).
+ *     The reference adds with fp16 atomics into an fp16 pool (order-dependent, loses small addends); the restatement keeps its
+ *     per-contribution roundings and accumulates exactly (double), which is the definition the HIP kernel implements in fp32. */
+ORC_API void orc_hash_cu_backward(const float *x, int64_t p, const int32_t *primes, const int32_t *local_idx, const int32_t *local_size,
+                                  const float *bias, const float *bbox, const float *mul, int n_levels, int n_feat, int64_t pool_elems,
+                                  const float *g_emb /*[p, L*F]*/, float *g_table /*[pool_elems] accumulated*/)
+{
+    double *acc = (double *)calloc((size_t)pool_elems, sizeof(double));
+    for (int64_t i = 0; i < p; i++) {
+        float xc[3];
+        for (int a = 0; a < 3; a++) xc[a] = f_max(f_min(x[i * 3 + a], bbox[3 + a]), bbox[a]);
+        for (int l = 0; l < n_levels; l++) {
+            float pt[3], fl[3];
+            uint32_t pos[3];
+            for (int a = 0; a < 3; a++) {
+                pt[a] = (xc[a] - bbox[a]) / (bbox[3 + a] - bbox[a]) * mul[l];
+                pt[a] = pt[a] + bias[l * 3 + a];
+                fl[a] = floorf(pt[a]);
+                pos[a] = (uint32_t)fl[a];
+            }
+            const uint32_t pa = (uint32_t)primes[l * 3 + 0], pb = (uint32_t)primes[l * 3 + 1], pc = (uint32_t)primes[l * 3 + 2];
+            const uint32_t lsz = (uint32_t)local_size[l];
+            const float a = pt[0] - fl[0], b = pt[1] - fl[1], c = pt[2] - fl[2];
+            for (int k = 0; k < 8; k++) {
+                uint32_t dx = (k >> 2) & 1u, dy = (k >> 1) & 1u, dz = k & 1u;
+                uint32_t ps = (((pos[0] + dx) * pa) ^ ((pos[1] + dy) * pb) ^ ((pos[2] + dz) * pc)) % lsz;
+                float w = (dx ? a : (1.0f - a)) * (dy ? b : (1.0f - b)) * (dz ? c : (1.0f - c));
+                for (int f = 0; f < n_feat; f++) {
+                    const float gin = f16_bits_to_f32(f32_to_f16_bits(g_emb[i * n_levels * n_feat + l * n_feat + f] * 128.0f));
+                    if (gin == 0.0f) continue;
+                    const float contrib = f16_bits_to_f32(f32_to_f16_bits(gin * w));
+                    acc[(int64_t)local_idx[l] + (int64_t)ps * n_feat + f] += (double)(contrib * (1.0f / 128.0f));
+                }
+            }
+        }
+    }
+    for (int64_t k = 0; k < pool_elems; k++) g_table[k] += (float)acc[k];
+    free(acc);
+}
+
 /* torch::optim::Adam::step (no weight decay, no amsgrad), step count t >= 1:
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) */
 ORC_API void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps, int t)

@@ -862,3 +862,26 @@ def test_trainer_learns_a_teacher_scene(api):
         losses.append(float(host(lm)[0]))
     first, last = np.mean(losses[:4]), np.mean(losses[-4:])
     assert np.isfinite(losses).all() and last < 0.5 * first, (first, last)
+
+
+@pytest.mark.parametrize("F,T", [(2, 12), (8, 10)])
+def test_hash_cu_backward_vs_oracle(api, O, F, T):
+    """CuHashEmbedderBackwardKernel (CuHashEmbedder.cu:105-216): same corner set, same fp16-rounded contributions (x128 scaling), the
+    overlap quirk of the level offsets included; fp32 accumulation vs the oracle's exact one."""
+    import ctypes as C
+    Lv = 6
+    bbox = api.S.LEGO_BBOX
+    e = api.M.CuHashEmbedder("embedder", bbox, Lv, F, T, 16, 256)
+    primes = np.array(api.S.CU_PRIMES[:3 * Lv], np.int32)
+    e.set_primes(primes); e.set_table(np.zeros(e.table_elems(), np.float32))
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-1.6, 1.6, (5000, 3)).astype(np.float32)            # some points outside the box (clamped, like QueryPoints)
+    g_emb = (rng.standard_normal((5000, Lv * F)) * rng.choice([1e-2, 1e-4, 0.0], (5000, 1))).astype(np.float32)
+    gt = torch.zeros(e.table_elems(), device="cuda")
+    xd, gd = dev(x), dev(g_emb)
+    api.L.check(api.L.lib().nrf_hash_backward(e._h, C.c_void_p(xd.data_ptr()), C.c_int64(5000), C.c_void_p(gd.data_ptr()), C.c_void_p(gt.data_ptr()), None))
+    ls = ((1 << T) >> 4) << 4
+    ref = O.hash_cu_backward(x, primes, np.arange(Lv, dtype=np.int32) * ls, np.full(Lv, ls, np.int32), np.zeros((Lv, 3), np.float32), bbox,
+                             O.hash_cu_scales(Lv, 16, 256), Lv, F, e.table_elems(), g_emb)
+    assert (ref != 0).mean() > 0.05
+    assert_close(host(gt), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max(), what="CuHash table gradient (fp32 atomics vs exact accumulation)")
