@@ -333,6 +333,10 @@ NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_de
  * in fp32 instead of with fp16 atomics. */
 NRF_API int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, const float *d_g_emb, float *d_g_table, void *stream);
 
+/* The same gradient for points that are the samples of rays, pts [n, s, 3] ray-major (what a training step has): consecutive samples
+ * of a ray that share a voxel are summed in registers before the atomic add -- the count of scattered float atomics is the cost. */
+NRF_API int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *stream);
+
 /* torch::optim::Adam::step without weight decay / amsgrad; t = 1, 2, ... */
 NRF_API int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
                           void *stream);

@@ -214,6 +214,100 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
     }
 }
 
+// Ray-coherent variants: float atomics run at the memory side and scattered ones (one row per lane) at ~1/17 of the shaped rate
+// (0.08 vs 1.3 TB/s of added bytes), so the count of atomics IS the cost of the table gradient.  Consecutive samples of a ray
+// (importance sampling packs them densely) mostly sit in the same voxel of a level: one thread walks SEG consecutive samples of one ray
+// at one level, sums the eight corner contributions in registers while the voxel does not change and issues the atomics only when it
+// does.  Same addends as the per-point kernels, summed in a different order (fp32).
+constexpr int BWD_SEG = 16;
+
+template <int F, bool CU>
+__global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+                               float *__restrict__ g_table)
+{
+    const int nseg = (s + BWD_SEG - 1) / BWD_SEG;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (t >= n * nseg) return;
+    const int64_t ray = t / nseg;
+    const int j0 = (int)(t - ray * nseg) * BWD_SEG;
+    const int j1 = (j0 + BWD_SEG < s) ? j0 + BWD_SEG : s;
+    float acc[8][F];
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    bool have = false;
+    const float scale = hp.level_scale[l];
+    float *tl;
+    uint32_t pa = 0, pb = 0, pc = 0, lsz = 1, hmask = 0;
+    if constexpr (CU) {
+        tl = g_table + hp.local_idx[l];
+        pa = hp.primes[l * 3 + 0]; pb = hp.primes[l * 3 + 1]; pc = hp.primes[l * 3 + 2]; lsz = hp.local_size[l];
+    } else {
+        tl = g_table + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
+        hmask = (1u << hp.log2_t) - 1u;
+    }
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t cx = cur[0] + ((k >> 2) & 1), cy = cur[1] + ((k >> 1) & 1), cz = cur[2] + (k & 1);
+            const uint32_t row = CU ? (((cx * pa) ^ (cy * pb) ^ (cz * pc)) % lsz) : ((cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask);
+#pragma unroll
+            for (int f = 0; f < F; f++)
+                if (acc[k][f] != 0.0f) unsafeAtomicAdd(tl + (size_t)row * F + f, acc[k][f]);
+        }
+    };
+    for (int j = j0; j < j1; j++) {
+        const int64_t i = ray * s + j;
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            g[f] = g_emb[i * g_stride + l * F + f];
+            if constexpr (CU) g[f] = __half2float(__float2half_rn(g[f] * 128.0f));
+            any |= g[f] != 0.0f;
+        }
+        if (!any) continue;
+        uint32_t pos[3];
+        float w[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float x = pts[i * 3 + a];
+            const float c = fmaxf(fminf(x, hp.bbox.mx[a]), hp.bbox.mn[a]);
+            if constexpr (CU) {
+                float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * scale;
+                q = q + hp.bias[l * 3 + a];
+                const float fl = floorf(q);
+                pos[a] = (uint32_t)fl; w[a] = q - fl;
+            } else {
+                const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / scale;
+                const float fl = floorf((c - hp.bbox.mn[a]) / grid);
+                pos[a] = (uint32_t)(int32_t)fl;
+                const float vmin = fl * grid + hp.bbox.mn[a];
+                const float vmax = vmin + grid;
+                w[a] = (x - vmin) / (vmax - vmin);
+            }
+        }
+        if (!have || pos[0] != cur[0] || pos[1] != cur[1] || pos[2] != cur[2]) {
+            if (have) flush();
+            have = true;
+            cur[0] = pos[0]; cur[1] = pos[1]; cur[2] = pos[2];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int f = 0; f < F; f++) acc[k][f] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float wx = ((k >> 2) & 1) ? w[0] : 1.0f - w[0], wy = ((k >> 1) & 1) ? w[1] : 1.0f - w[1], wz = (k & 1) ? w[2] : 1.0f - w[2];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                if constexpr (CU) acc[k][f] += __half2float(__float2half_rn(g[f] * (wx * wy * wz))) * (1.0f / 128.0f);
+                else acc[k][f] += ((g[f] * wz) * wy) * wx;
+            }
+        }
+    }
+    if (have) flush();
+}
+
 __global__ void k_adam(int64_t n, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps, float *__restrict__ p, const float *__restrict__ g,
                        float *__restrict__ m, float *__restrict__ v)
 {
@@ -292,6 +386,32 @@ int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, const floa
         case 4: NRF_BWD(4); break;
         case 8: NRF_BWD(8); break;
         default: set_error("nrf_hash_backward: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
+    }
+#undef NRF_BWD
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *stream)
+{
+    NRF_CHECK_ARG(h && d_pts && d_g_emb && d_g_table && n >= 0 && s >= 1, "nrf_hash_backward_rays: bad argument");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_NGP || h->primes_set, "nrf_hash_backward_rays: CuHashEmbedder-mode grid without primes");
+    if (n == 0) return NRF_OK;
+    const int F = h->desc.n_features, L = h->desc.n_levels;
+    const int64_t threads = n * ((s + BWD_SEG - 1) / BWD_SEG);
+    dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
+    hipStream_t st = as_stream(stream);
+#define NRF_BWD(FF)                                                                                                                                     \
+    do {                                                                                                                                                \
+        if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL((k_hash_bwd_ray<FF, false>), grid, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table); \
+        else hipLaunchKernelGGL((k_hash_bwd_ray<FF, true>), grid, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table);               \
+    } while (0)
+    switch (F) {
+        case 1: NRF_BWD(1); break;
+        case 2: NRF_BWD(2); break;
+        case 4: NRF_BWD(4); break;
+        case 8: NRF_BWD(8); break;
+        default: set_error("nrf_hash_backward_rays: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
     }
 #undef NRF_BWD
     NRF_LAUNCH_CHECK();

@@ -74,7 +74,7 @@ class Trainer:
         nb = lib.nrf_mlp_backward_workspace_bytes(self.mlp._m, C.c_int64(n * s))
         ws = self._workspace(nb)
         L.check(lib.nrf_mlp_backward(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
-        L.check(lib.nrf_hash_backward(self.embedder._h, _ptr(pts), C.c_int64(n * s), _ptr(g_x), _ptr(self.g_table), _stream()))
+        L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
         return loss_mse
 

@@ -677,11 +677,63 @@ static int run_bench(int argc, const char **argv)
 	return 0;
 }
 
+// ----------------------------------------------------------------------------------------------
+// bench_train: the reference's optimisation step (NeRFExecutor.h:862-995: Render(ray batch) -> huber -> backward -> Adam) on LibTorch CPU
+// ----------------------------------------------------------------------------------------------
+static int run_bench_train(int argc, const char **argv)
+{
+	int nrays = argc > 2 ? atoi(argv[2]) : 1024;
+	int ns = argc > 3 ? atoi(argv[3]) : 64, ni = argc > 4 ? atoi(argv[4]) : 128;
+	int chunk = argc > 5 ? atoi(argv[5]) : 4096;
+	int steps = argc > 6 ? atoi(argv[6]) : 1;
+	std::ofstream devnull("/dev/null");
+	g_manifest.swap(devnull);
+	const int h = 800, w = 800;
+	auto k = lego_K(h, w);
+	auto c2w = orbit_pose(30.f, -30.f, 4.f);
+	auto bbox = lego_bbox();
+	auto [o, d, cone] = GetRays(h, w, k, c2w);
+	auto idx = torch::arange(0, nrays, torch::kLong) * ((int64_t)h * w / nrays);		//a strided sample of the frame's rays
+	auto ro = o.reshape({-1, 3}).index_select(0, idx).contiguous(), rd = d.reshape({-1, 3}).index_select(0, idx).contiguous();
+	auto target = synth_tensor({nrays, 3}, 9100u, 0.5f, 0.5f);
+	HashEmbedder e("embedder", bbox, 16, 2, 19, 16, 512);
+	SHEncoder ed("embeddirs", 3, 4);
+	NeRFSmall m(3, 64, 15, 4, 64, false, 3, 64, 32, 16, "model");
+	fill_module("b", e, 5000u, 0.5f, 0.f);
+	fill_module("b", m, 6000u, 1.6f, 0.f, {{"sigma_net_2", 30.0f}});
+	NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> r(e, ed, m);
+	std::vector<torch::Tensor> grad_vars;
+	for (auto &p : e->parameters()) grad_vars.push_back(p);
+	for (auto &p : m->parameters()) grad_vars.push_back(p);
+	torch::optim::Adam opt(grad_vars, torch::optim::AdamOptions(5e-4).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));
+	auto rp = lego_params(ns, ni, chunk);
+	rp.ReturnRaw = false; rp.ReturnWeights = false; rp.WhiteBkgr = false;
+	double best = 1e30; float last_loss = 0.f;
+	for (int it = 0; it < steps + 1; it++)
+	{
+		auto t0 = std::chrono::steady_clock::now();
+		opt.zero_grad();
+		auto res = r.Render(0, 0, torch::Tensor(), rp, {ro, rd, cone});
+		auto loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, target);
+		loss.backward();
+		opt.step();
+		auto t1 = std::chrono::steady_clock::now();
+		double sec = std::chrono::duration<double>(t1 - t0).count();
+		if (it > 0 || steps == 0) best = std::min(best, sec);
+		last_loss = loss.item<float>();
+	}
+	int64_t units = (int64_t)nrays * (ns + ns + ni);
+	printf("{\"family\": \"hash_train\", \"rays\": %d, \"units\": %ld, \"seconds\": %.6f, \"units_per_s\": %.1f, \"rays_per_s\": %.1f, \"threads\": %d, \"loss\": %.6f}\n",
+		nrays, (long)units, best, units / best, nrays / best, at::get_num_threads(), last_loss);
+	return 0;
+}
+
 int main(int argc, const char **argv)
 {
 	if (argc < 2) { std::cerr << "usage: ref_driver golden <outdir> | bench <hash|classic> [h rows ns ni chunk reps]" << std::endl; return 1; }
 	std::string cmd = argv[1];
 	if (cmd == "bench") return run_bench(argc, argv);
+	if (cmd == "bench_train") return run_bench_train(argc, argv);
 	if (cmd != "golden" || argc < 3) return 1;
 	g_outdir = argv[2];
 	g_manifest.open(g_outdir + "/manifest.txt");

@@ -885,3 +885,26 @@ def test_hash_cu_backward_vs_oracle(api, O, F, T):
                              O.hash_cu_scales(Lv, 16, 256), Lv, F, e.table_elems(), g_emb)
     assert (ref != 0).mean() > 0.05
     assert_close(host(gt), ref, rtol=2e-5, atol=1e-4 * np.abs(ref).max(), what="CuHash table gradient (fp32 atomics vs exact accumulation; a handful of entries differ by one fp16 ulp of a single contribution)")
+
+
+@pytest.mark.parametrize("mode", ["ngp", "cu"])
+def test_hash_backward_ray_coherent_equals_per_point(api, mode):
+    """nrf_hash_backward_rays (voxel-run pre-summation along each ray) == nrf_hash_backward up to fp32 summation order."""
+    import ctypes as C
+    sc = api.S.make_hash_scene(mode=mode, log2_t=15)
+    e = sc["embedder"]
+    n, s = 700, 37                                                        # ragged: s not a multiple of the segment length
+    K = api.S.lego_K(64, 64); c2w = api.S.pose_spherical(20.0, -30.0, 4.0)
+    o, d, _ = api.R.GetRays(64, 64, K, c2w)
+    o = o.reshape(-1, 3)[:n]; d = d.reshape(-1, 3)[:n]
+    z = torch.sort(torch.rand((n, s), device="cuda") * 3.0 + 2.0, dim=1).values
+    z[:, 5:20] = z[:, 5:6] + torch.linspace(0, 0.01, 15, device="cuda")   # a dense cluster, as importance sampling produces
+    pts = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
+    g = (torch.randn((n * s, 32), device="cuda") * 1e-3).contiguous()
+    a = torch.zeros(e.table_elems(), device="cuda"); b = torch.zeros_like(a)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    api.L.check(api.L.lib().nrf_hash_backward(e._h, P(pts), C.c_int64(n * s), P(g), P(a), None))
+    api.L.check(api.L.lib().nrf_hash_backward_rays(e._h, P(pts), C.c_int64(n), s, P(g), P(b), None))
+    ha, hb = host(a), host(b)
+    assert (ha != 0).mean() > 0.01
+    assert_close(hb, ha, rtol=1e-4, atol=1e-4 * np.abs(ha).max())        # signed addends cancel: order-dependent to ~1e-7 of the sum of magnitudes
