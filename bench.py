@@ -268,7 +268,52 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
                             psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
         except Exception as e:
             out.append(dict(workload=wl, precision=pname, error=str(e)))
+    try:
+        out.append(train_step_measurement(args, scene, L))
+    except Exception as e:
+        out.append(dict(workload="hashnerf_train_step", error=str(e)))
     return out
+
+
+def train_step_measurement(args, scene, L, n_rand=16384, steps=5):
+    """SURVEY section 8f row N1: one optimisation step of NeRFExecutor::Train (render the ray batch, huber loss, backward of the fine pass,
+    Adam) on the HashNeRF configuration, N_rand = 32*32*16 rays per step as in the reference's main.cpp:232, next to the reference's own
+    LibTorch CPU step (oracle/_ref/ref_driver bench_train) on a bounded ray batch."""
+    import torch
+    from nerfpp_amd import renderer as R
+    from nerfpp_amd.train import Trainer
+    sc = scene.make_hash_scene(mode="cu", table_amp=1e-2, sigma_scale=4.0)
+    K = scene.lego_K(H, W); c2w = scene.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(H, W, K, c2w)
+    idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
+    o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
+    tgt = torch.rand((n_rand, 3), device="cuda")
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4)
+    rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                            BoundingBox=scene.LEGO_BBOX, Precision=L.NRF_PREC_F16_SPLIT)
+    for _ in range(2):
+        tr.step(o, d, tgt, rp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(steps):
+        lm, _ = tr.step(o, d, tgt, rp)
+        losses.append(lm)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rec = dict(workload="hashnerf_train_step", rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt,
+               value=n_rand * UNITS_PER_RAY / dt, unit="ray-samples/s", steps=steps, loss_first_last=[float(losses[0][0]), float(losses[-1][0])],
+               arithmetic="render: split-f16 MFMA; backward: fp32 (layer-wise kernels, float atomics for dW and the table gradient); Adam fp32")
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(drv) and not args.no_cpu_baseline:
+        try:
+            outp = subprocess.run([drv, "bench_train", "1024", str(NS), str(NI), "4096", "1"], capture_output=True, text=True, timeout=600)
+            r = json.loads(outp.stdout.strip().splitlines()[-1])
+            rec["cpu_reference"] = dict(rays_per_s=r["rays_per_s"], value=r["units_per_s"], unit="ray-samples/s", cores=r["threads"], kind="reference",
+                                        sample=f"{r['rays']} rays per step, LibTorch CPU HashEmbedder+SHEncoder+NeRFSmall forward+backward+Adam, {r['seconds']:.1f} s per step")
+        except Exception as e:
+            rec["cpu_reference"] = f"unavailable: {e}"
+    return rec
 
 
 def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
