@@ -59,6 +59,20 @@ NRF_API int nrf_get_rays(int h, int w, const float *K, const float *c2w, int row
 NRF_API int nrf_ndc_rays(int h, int w, float focal, float near_plane, const float *d_o, const float *d_d, int64_t n,
                          float *d_o_out, float *d_d_out, void *stream);
 
+/* ---- ray-batch producer of the training loop: NeRFDataset::get_batch / GetRayBatch (NeRFDataset.cpp:109-208), SURVEY 8f row N2 ----
+ * nrf_precrop_bounds : CalculateBounds (:44-65), host only; out = {h_start, h_end, w_start, w_end}, inclusive.
+ * nrf_rand_pixels    : the batch's pixel coordinates (:154-155 draws torch::randint): counter-based, element k of iteration `iter` is
+ *                      lo + floor(u32(seed, stream, iter*n + k) * range / 2^32), streams 16 (rows) / 17 (columns) of include/nrf_rng.h.
+ * nrf_ray_batch      : GetRayBatch (:109-145): rays through pixels (rand_h[k], rand_w[k]); cone_angle = (1/fx + 1/fy)/2 to host.
+ * nrf_gather_pixels  : target_s = CurrentImage.index({rand_h, rand_w}) (:156); image [h, w, c] fp32 on the device. */
+NRF_API int nrf_precrop_bounds(int h, int w, int iter, int precrop_iters, float precrop_frac, int *out);
+NRF_API int nrf_rand_pixels(uint64_t seed, int64_t iter, int h_start, int h_end, int w_start, int w_end, int64_t n, int64_t *d_rand_h,
+                            int64_t *d_rand_w, void *stream);
+NRF_API int nrf_ray_batch(const float *K, const float *c2w, const int64_t *d_rand_h, const int64_t *d_rand_w, int64_t n, float *d_o, float *d_d,
+                          float *cone_angle, void *stream);
+NRF_API int nrf_gather_pixels(const float *d_image, int h, int w, int c, const int64_t *d_rand_h, const int64_t *d_rand_w, int64_t n, float *d_out,
+                              void *stream);
+
 /* IntersectWithAABB (RayUtils.h:87-126). bbox: host [6] = min xyz, max xyz. */
 NRF_API int nrf_aabb(const float *d_o, const float *d_d, const float *bbox, int64_t n, float near_plane,
                      float *d_near, float *d_far, void *stream);

@@ -3,6 +3,7 @@
 // fp32, one rounding per source-level op (the library is built with -ffp-contract=off) so that every
 // value here equals the LibTorch CPU result bit for bit.
 #include "common.h"
+#include "nrf_rng.h"
 
 namespace nrf {
 
@@ -159,6 +160,41 @@ static inline Bbox make_bbox(const float *b)
     return bb;
 }
 
+// N2: GetRayBatch (NeRFDataset.cpp:109-145): the arithmetic of k_get_rays at arbitrary integer pixel coordinates
+__global__ void k_ray_batch(int64_t n, const int64_t *__restrict__ rh, const int64_t *__restrict__ rw, float fx, float cx, float fy, float cy,
+                            float r00, float r01, float r02, float r10, float r11, float r12, float r20, float r21, float r22,
+                            float t0, float t1, float t2, float *__restrict__ o, float *__restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = ((float)rw[i] - cx) / fx;
+    const float dy = -((float)rh[i] - cy) / fy;
+    const float dz = -1.0f;
+    float a0 = dx * r00; a0 = a0 + dy * r01; a0 = a0 + dz * r02;
+    float a1 = dx * r10; a1 = a1 + dy * r11; a1 = a1 + dz * r12;
+    float a2 = dx * r20; a2 = a2 + dy * r21; a2 = a2 + dz * r22;
+    d[i * 3 + 0] = a0; d[i * 3 + 1] = a1; d[i * 3 + 2] = a2;
+    o[i * 3 + 0] = t0; o[i * 3 + 1] = t1; o[i * 3 + 2] = t2;
+}
+
+__global__ void k_gather_pixels(int64_t total, int w, int c, const float *__restrict__ img, const int64_t *__restrict__ rh, const int64_t *__restrict__ rw,
+                                float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int64_t r = e / c; const int k = (int)(e - r * c);
+    out[e] = img[(rh[r] * w + rw[r]) * c + k];
+}
+
+__global__ void k_rand_pixels(int64_t n, uint64_t seed, uint64_t idx0, int h0, uint64_t rh_range, int w0, uint64_t rw_range, int64_t *__restrict__ rh,
+                              int64_t *__restrict__ rw)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    rh[k] = h0 + (int64_t)(((uint64_t)nrf_rng_u32(seed, 16u, idx0 + (uint64_t)k) * rh_range) >> 32);
+    rw[k] = w0 + (int64_t)(((uint64_t)nrf_rng_u32(seed, 17u, idx0 + (uint64_t)k) * rw_range) >> 32);
+}
+
 // N4: (depth - near) / span (NeRFExecutor.h:690)
 __global__ void k_normalize_depth(int64_t n, float near_, float span, const float *__restrict__ depth, float *__restrict__ out)
 {
@@ -255,6 +291,47 @@ int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *ne
     auto dec = [](int v) { int b = v >= 0 ? v : (v ^ 0x7fffffff); float f; memcpy(&f, &b, 4); return f; };
     *near_min = dec(res[0]);
     *far_max = dec(res[1]);
+    return NRF_OK;
+}
+
+int nrf_precrop_bounds(int h, int w, int iter, int precrop_iters, float precrop_frac, int *out)
+{
+    NRF_CHECK_ARG(out && h > 0 && w > 0, "nrf_precrop_bounds: bad argument");
+    if (iter < precrop_iters) {
+        const int dh = (int)(h / 2 * precrop_frac), dw = (int)(w / 2 * precrop_frac);
+        out[0] = h / 2 - dh; out[1] = h / 2 + dh - 1; out[2] = w / 2 - dw; out[3] = w / 2 + dw - 1;
+    } else { out[0] = 0; out[1] = h - 1; out[2] = 0; out[3] = w - 1; }
+    return NRF_OK;
+}
+
+int nrf_rand_pixels(uint64_t seed, int64_t iter, int h_start, int h_end, int w_start, int w_end, int64_t n, int64_t *d_rand_h, int64_t *d_rand_w, void *stream)
+{
+    NRF_CHECK_ARG(d_rand_h && d_rand_w && n >= 0 && iter >= 0 && h_end >= h_start && w_end >= w_start, "nrf_rand_pixels: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_rand_pixels, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, seed, (uint64_t)iter * (uint64_t)n, h_start,
+                       (uint64_t)(h_end - h_start + 1), w_start, (uint64_t)(w_end - w_start + 1), d_rand_h, d_rand_w);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_ray_batch(const float *K, const float *c2w, const int64_t *d_rand_h, const int64_t *d_rand_w, int64_t n, float *d_o, float *d_d, float *cone_angle,
+                  void *stream)
+{
+    NRF_CHECK_ARG(K && c2w && d_rand_h && d_rand_w && d_o && d_d && n >= 0, "nrf_ray_batch: bad argument");
+    if (cone_angle) { const float px = 1.0f / K[0], py = 1.0f / K[4]; *cone_angle = (px + py) / 2.0f; }
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_ray_batch, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, d_rand_h, d_rand_w, K[0], K[2], K[4], K[5],
+                       c2w[0], c2w[1], c2w[2], c2w[4], c2w[5], c2w[6], c2w[8], c2w[9], c2w[10], c2w[3], c2w[7], c2w[11], d_o, d_d);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_gather_pixels(const float *d_image, int h, int w, int c, const int64_t *d_rand_h, const int64_t *d_rand_w, int64_t n, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(d_image && d_rand_h && d_rand_w && d_out && h > 0 && w > 0 && c > 0 && n >= 0, "nrf_gather_pixels: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_gather_pixels, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, as_stream(stream), n * c, w, c, d_image, d_rand_h, d_rand_w, d_out);
+    NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 

@@ -418,5 +418,35 @@ def adam_step(p, g, m, v, lr, t, b1=0.9, b2=0.99, eps=1e-15):
     lib().orc_adam_step(_p(p), _p(g), _p(m), _p(v), C.c_int64(p.size), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_int(t))
 
 
+def ray_batch(K, c2w, rand_h, rand_w):
+    K = _f(K).reshape(-1); M = _f(np.asarray(c2w)[:3, :4]).reshape(-1)
+    rh = np.ascontiguousarray(rand_h, np.int64); rw = np.ascontiguousarray(rand_w, np.int64)
+    n = rh.size
+    o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32); cone = C.c_float(0)
+    lib().orc_ray_batch(_p(K), _p(M), rh.ctypes.data_as(C.c_void_p), rw.ctypes.data_as(C.c_void_p), C.c_int64(n), _p(o), _p(d), C.byref(cone))
+    return o, d, cone.value
+
+
+def gather_pixels(image, rand_h, rand_w):
+    img = _f(image); h, w, c = img.shape
+    rh = np.ascontiguousarray(rand_h, np.int64); rw = np.ascontiguousarray(rand_w, np.int64)
+    out = np.empty((rh.size, c), np.float32)
+    lib().orc_gather_pixels(_p(img), C.c_int(h), C.c_int(w), C.c_int(c), rh.ctypes.data_as(C.c_void_p), rw.ctypes.data_as(C.c_void_p), C.c_int64(rh.size), _p(out))
+    return out
+
+
+def precrop_bounds(h, w, it, precrop_iters, precrop_frac):
+    out = (C.c_int * 4)()
+    lib().orc_precrop_bounds(C.c_int(h), C.c_int(w), C.c_int(it), C.c_int(precrop_iters), C.c_float(precrop_frac), out)
+    return tuple(out)
+
+
+def rand_pixels(seed, it, bounds, n):
+    rh = np.empty(n, np.int64); rw = np.empty(n, np.int64)
+    lib().orc_rand_pixels(C.c_uint64(seed), C.c_int64(it), C.c_int(bounds[0]), C.c_int(bounds[1]), C.c_int(bounds[2]), C.c_int(bounds[3]), C.c_int64(n),
+                          rh.ctypes.data_as(C.c_void_p), rw.ctypes.data_as(C.c_void_p))
+    return rh, rw
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -197,6 +197,63 @@ ORC_API void orc_get_rays(int h, int w, const float *K, const float *c2w /*[3,4]
     }
 }
 
+/* N2  NeRFDataset::GetRayBatch             NeRFDataset.cpp:109-145 -- rays through the pixels (rand_h, rand_w) of one view.
+ *     The same direction arithmetic as GetRays (pixel coordinates converted to fp32, (w - cx)/fx, -(h - cy)/fy, -1, three products
+ *     summed left to right), so a batch drawn at grid coordinates equals the rows of GetRays bit for bit; cone_angle here is the plain
+ *     mean pixel size (1/fx + 1/fy)/2 (no x1.1 factor, unlike RayUtils.h:43).  RESTATEMENT-PINNED via GetRays (NeRFDataset.cpp needs
+ *     OpenCV loaders and does not build here). */
+ORC_API void orc_ray_batch(const float *K, const float *c2w, const int64_t *rand_h, const int64_t *rand_w, int64_t n, float *o, float *d, float *cone_angle)
+{
+    const float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    OMP_FOR
+    for (int64_t r = 0; r < n; r++) {
+        float dir[3];
+        dir[0] = ((float)rand_w[r] - cx) / fx;
+        dir[1] = -((float)rand_h[r] - cy) / fy;
+        dir[2] = -1.0f;
+        for (int i = 0; i < 3; i++) {
+            float acc = dir[0] * c2w[i * 4 + 0];
+            acc = acc + dir[1] * c2w[i * 4 + 1];
+            acc = acc + dir[2] * c2w[i * 4 + 2];
+            d[r * 3 + i] = acc;
+            o[r * 3 + i] = c2w[i * 4 + 3];
+        }
+    }
+    if (cone_angle) {
+        /* 1.0 / fx with fx a 0-dim fp32 tensor: fp32 */
+        float px = 1.0f / fx, py = 1.0f / fy;
+        *cone_angle = (px + py) / 2.0f;
+    }
+}
+
+/* target_s = CurrentImage.index({rand_h, rand_w})        NeRFDataset.cpp:156 ; image [H, W, C] */
+ORC_API void orc_gather_pixels(const float *image, int h, int w, int c, const int64_t *rand_h, const int64_t *rand_w, int64_t n, float *out)
+{
+    for (int64_t r = 0; r < n; r++)
+        memcpy(out + r * c, image + ((int64_t)rand_h[r] * w + rand_w[r]) * c, sizeof(float) * c);
+}
+
+/* CalculateBounds (NeRFDataset.cpp:44-65): the centre crop used for the first PrecorpIters iterations; inclusive bounds */
+ORC_API void orc_precrop_bounds(int h, int w, int iter, int precrop_iters, float precrop_frac, int *out /* h_start, h_end, w_start, w_end */)
+{
+    if (iter < precrop_iters) {
+        int dh = (int)(h / 2 * precrop_frac), dw = (int)(w / 2 * precrop_frac);
+        out[0] = h / 2 - dh; out[1] = h / 2 + dh - 1; out[2] = w / 2 - dw; out[3] = w / 2 + dw - 1;
+    } else { out[0] = 0; out[1] = h - 1; out[2] = 0; out[3] = w - 1; }
+}
+
+/* Random pixel coordinates of a batch (NeRFDataset.cpp:154-155 draws torch::randint): here a pure function of (seed, iter, element):
+ * lo + floor(u32 * (hi - lo + 1) / 2^32) with the counter generator of include/nrf_rng.h, streams 16 (rows) and 17 (columns). */
+ORC_API void orc_rand_pixels(uint64_t seed, int64_t iter, int h_start, int h_end, int w_start, int w_end, int64_t n, int64_t *rand_h, int64_t *rand_w)
+{
+    const uint64_t rh = (uint64_t)(h_end - h_start + 1), rw = (uint64_t)(w_end - w_start + 1);
+    for (int64_t k = 0; k < n; k++) {
+        const uint64_t idx = (uint64_t)iter * (uint64_t)n + (uint64_t)k;
+        rand_h[k] = h_start + (int64_t)(((uint64_t)nrf_rng_u32(seed, 16u, idx) * rh) >> 32);
+        rand_w[k] = w_start + (int64_t)(((uint64_t)nrf_rng_u32(seed, 17u, idx) * rw) >> 32);
+    }
+}
+
 /* R2  NDCRays                              RayUtils.h:49-83  (near = 1 in Render(), NeRFRenderer.h:567) */
 ORC_API void orc_ndc_rays(int h, int w, float focal, float near_, const float *o, const float *d, int64_t n,
                           float *oo, float *od)

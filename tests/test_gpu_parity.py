@@ -908,3 +908,30 @@ def test_hash_backward_ray_coherent_equals_per_point(api, mode):
     ha, hb = host(a), host(b)
     assert (ha != 0).mean() > 0.01
     assert_close(hb, ha, rtol=1e-4, atol=1e-4 * np.abs(ha).max())        # signed addends cancel: order-dependent to ~1e-7 of the sum of magnitudes
+
+
+# ------------------------------------------------------------------ N2: ray-batch producer
+def test_ray_batch_producer(api, O):
+    from nerfpp_amd import dataset as D
+    g = load_golden("rays")
+    h, w = (int(v) for v in g["hw"])
+    rng = np.random.RandomState(1)
+    img = rng.rand(h, w, 3).astype(np.float32)
+    v = D.View(H=h, W=w, K=g["k"], Pose=g["c2w"], Image=dev(img), Near=2.0, Far=6.0)
+    ds = D.NeRFDataset([v], batch_size=500, precorp_iters=0, seed=11)
+    ds.SetCurrentIter(5)
+    b = ds.get_batch()
+    rh, rw = host(b["rand_h"]), host(b["rand_w"])
+    rh_o, rw_o = O.rand_pixels(11, 5, (0, h - 1, 0, w - 1), 500)
+    assert_exact(rh, rh_o, "pixel rows == oracle"); assert_exact(rw, rw_o, "pixel columns == oracle")
+    assert_exact(host(b["rays_d"]), g["d"][rh, rw], "rays_d == the reference's GetRays at those pixels")
+    assert_exact(host(b["rays_o"]), g["o"][rh, rw]); assert_exact(host(b["target_s"]), img[rh, rw], "target colours")
+    o_o, d_o, cone_o = O.ray_batch(g["k"], g["c2w"], rh, rw)
+    assert float(b["cone_angle"]) == cone_o
+    assert D.CalculateBounds(800, 800, 0, 500, 0.5) == (200, 599, 200, 599)
+    # Blender bounds helpers on the reference's test orbit
+    views = [D.View(H=800, W=800, K=api.S.lego_K(800, 800), Pose=api.S.pose_spherical(th, -30.0, 4.0), Near=2.0, Far=6.0) for th in (-180.0, -90.0, 0.0, 90.0)]
+    near, far = D.GetBoundsForObj(views)
+    assert 0 < near < far and abs(far / near - 4.0) < 1e-5
+    bb = D.GetBbox3dForObj(views)
+    assert (bb[:3] < -1.5).all() and (bb[3:] > 1.5).all(), "the frusta of four orbit cameras between Near and Far enclose the Lego box"

@@ -416,3 +416,31 @@ def test_adam_two_steps_vs_reference(manifest):
     # run and none in the other: bound their share, not their size
     dt = np.abs(t - reft2) / lr
     assert dt.mean() < 5e-3 and (dt > 0.01).mean() < 0.05, (dt.max(), dt.mean(), (dt > 0.01).mean())
+
+
+# ------------------------------------------------------------------ N2: ray-batch producer
+def test_ray_batch_equals_get_rays_rows():
+    """GetRayBatch (NeRFDataset.cpp:109-145) at grid coordinates == the reference's GetRays output (golden), bit for bit."""
+    g = load_golden("rays")
+    h, w = (int(v) for v in g["hw"])
+    rng = np.random.RandomState(0)
+    rh = rng.randint(0, h, 200); rw = rng.randint(0, w, 200)
+    o, d, cone = O.ray_batch(g["k"], g["c2w"], rh, rw)
+    assert_exact(d, g["d"][rh, rw], "rays_d"); assert_exact(o, g["o"][rh, rw], "rays_o")
+    assert np.float32(np.float32(cone) * np.float32(1.1)) == g["cone"].reshape(-1)[0], "mean pixel size; GetRays applies an extra x1.1 (RayUtils.h:43)"
+    img = rng.rand(h, w, 3).astype(np.float32)
+    assert_exact(O.gather_pixels(img, rh, rw), img[rh, rw])
+
+
+def test_precrop_bounds_and_random_pixels():
+    assert O.precrop_bounds(800, 800, 0, 500, 0.5) == (200, 599, 200, 599)          # NeRFDataset.cpp:51-56
+    assert O.precrop_bounds(800, 600, 500, 500, 0.5) == (0, 799, 0, 599)
+    assert O.precrop_bounds(401, 401, 3, 10, 0.3) == (200 - 60, 200 + 59, 200 - 60, 200 + 59)
+    b = O.precrop_bounds(800, 800, 0, 500, 0.5)
+    rh, rw = O.rand_pixels(7, 3, b, 1 << 16)
+    assert rh.min() >= 200 and rh.max() <= 599 and rw.min() >= 200 and rw.max() <= 599
+    hist = np.bincount(rh - 200, minlength=400)
+    assert np.abs(hist - rh.size / 400).max() < 6 * np.sqrt(rh.size / 400)
+    assert abs(np.corrcoef(rh, rw)[0, 1]) < 0.02
+    rh2, _ = O.rand_pixels(7, 4, b, 1 << 16)
+    assert (rh2 != rh).mean() > 0.9, "another iteration draws other pixels"
