@@ -40,6 +40,10 @@ def main():
             print(f"{g}: {len(arrs)} arrays, {sum(a.nbytes for a in arrs.values())} bytes raw")
         with open(os.path.join(tmp, "manifest.txt")) as f, open(os.path.join(out, "manifest.txt"), "w") as g:
             g.write(f.read())
+    # checkpoint archives written by the reference's own torch::save calls (SaveCheckpoint, NeRFExecutor.h:1055-1070): format fixtures
+    ck = os.path.join(out, "ckpt")
+    os.makedirs(ck, exist_ok=True)
+    subprocess.check_call([drv, "ckpt_save", ck])
     return 0
 
 

@@ -728,12 +728,71 @@ static int run_bench_train(int argc, const char **argv)
 	return 0;
 }
 
+// ----------------------------------------------------------------------------------------------
+// N3: checkpoint interchange (NeRFExecutor::SaveCheckpoint / LoadCheckpoint, NeRFExecutor.h:540-566, :1055-1070).
+//   ckpt_save <dir> : torch::save the train_hash-sized HashEmbedder / NeRFSmall (+ start step) exactly as SaveCheckpoint does, plus a
+//                     module carrying CuHashEmbedder's registered names (CuHashEmbedder.cpp:24,73-76; the class itself needs CUDA)
+//   ckpt_load <dir> <outdir> : torch::load checkpoints (e.g. written by nerfpp_amd/checkpoint.py) INTO the reference's modules and
+//                     dump every parameter as .npy -- proves a file written by this repo restores a reference model
+// ----------------------------------------------------------------------------------------------
+struct CuHashNamesImpl : torch::nn::Module
+{
+	torch::Tensor Embeddings, Primes, Biases, FeatLocalSize, FeatLocalIdx;
+	CuHashNamesImpl(const std::string &name, int n_levels, int n_feat, int log2_t)
+	{
+		const int64_t t = 1ll << log2_t;
+		Embeddings = register_parameter(name + "_embeddings", torch::zeros({t * n_levels, n_feat}));
+		Primes = register_buffer(name + "_primes", torch::zeros({n_levels, 1, 3}, torch::kInt32));
+		Biases = register_buffer(name + "_biases", torch::zeros({n_levels, 3}));
+		int local_size = (int)((t >> 4) << 4);
+		FeatLocalSize = register_buffer(name + "_feat_local_size", torch::full({n_levels}, local_size, torch::kInt32));
+		FeatLocalIdx = register_buffer(name + "_feat_local_idx", (torch::cumsum(FeatLocalSize, 0) - local_size).to(torch::kInt32));
+	}
+};
+TORCH_MODULE(CuHashNames);
+
+static int run_ckpt(int argc, const char **argv, bool save)
+{
+	std::ofstream devnull("/dev/null");
+	g_manifest.swap(devnull);
+	std::string dir = argv[2];
+	auto bbox = lego_bbox();
+	HashEmbedder e("embedder", bbox, 4, 2, 12, 16, 128);
+	NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 8, 16, "model");
+	CuHashNames cu("embedder", 4, 2, 12);
+	if (save)
+	{
+		fill_module("ckpt", e, 5000u, 0.5f, 0.f);
+		fill_module("ckpt", m, 6000u, 1.6f, 0.f, {{"sigma_net_2", 8.0f}});
+		fill_synth(cu->Embeddings, 4242u, 1e-4f);
+		{ torch::NoGradGuard ng; auto p = cu->Primes.view({-1}); for (int i = 0; i < p.size(0); i++) p[i] = 268435459 + 2 * i; cu->Biases.fill_(0.25f); }
+		torch::save(e, dir + "/embedder_checkpoint.pt");			//NeRFExecutor.h:1058
+		torch::save(m, dir + "/model_checkpoint.pt");				//:1059
+		torch::save(torch::full({1}, /*value=*/1234), dir + "/start_checkpoint.pt");		//:1066
+		torch::save(cu, dir + "/cu_embedder_checkpoint.pt");
+		return 0;
+	}
+	g_outdir = argv[3];
+	torch::load(e, dir + "/embedder_checkpoint.pt");				//:552
+	torch::load(m, dir + "/model_checkpoint.pt");					//:553
+	torch::load(cu, dir + "/cu_embedder_checkpoint.pt");
+	torch::Tensor start; torch::load(start, dir + "/start_checkpoint.pt");
+	for (auto &p : e->named_parameters()) save_npy("e." + p.key(), p.value().detach());
+	for (auto &p : m->named_parameters()) save_npy("m." + p.key(), p.value().detach());
+	for (auto &p : cu->named_parameters()) save_npy("cu." + p.key(), p.value().detach());
+	for (auto &p : cu->named_buffers()) save_npy("cu." + p.key(), p.value().detach());
+	save_npy("start", start.to(torch::kFloat32));
+	return 0;
+}
+
 int main(int argc, const char **argv)
 {
 	if (argc < 2) { std::cerr << "usage: ref_driver golden <outdir> | bench <hash|classic> [h rows ns ni chunk reps]" << std::endl; return 1; }
 	std::string cmd = argv[1];
 	if (cmd == "bench") return run_bench(argc, argv);
 	if (cmd == "bench_train") return run_bench_train(argc, argv);
+	if (cmd == "ckpt_save" && argc >= 3) return run_ckpt(argc, argv, true);
+	if (cmd == "ckpt_load" && argc >= 4) return run_ckpt(argc, argv, false);
 	if (cmd != "golden" || argc < 3) return 1;
 	g_outdir = argv[2];
 	g_manifest.open(g_outdir + "/manifest.txt");

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("filterwarnings", "ignore:.*torch.jit.*:DeprecationWarning")        # the reference's checkpoints ARE TorchScript archives
 
 
 def load_golden(group):

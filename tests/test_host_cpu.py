@@ -134,3 +134,47 @@ def test_tile_all_gather_two_ranks_gloo(tmp_path):
                           "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+# ------------------------------------------------------------------ N3: checkpoint interchange with the reference
+def test_read_reference_checkpoints(manifest):
+    """tests/golden/ckpt/*.pt were written by the reference's own torch::save calls (oracle/_ref/ref_driver ckpt_save, NeRFExecutor.h:1058-1066)."""
+    from nerfpp_amd import checkpoint as CK, synth
+    d = os.path.join(ROOT, "tests", "golden", "ckpt")
+    ck = CK.LoadCheckpoint(d)
+    assert ck["start"] == 1234
+    assert list(ck["model"].keys()) == [f"model_{n}.weight" for n in ("sigma_net_0", "sigma_net_1", "sigma_net_2", "color_net_0", "color_net_1", "color_net_2")]
+    ent = manifest["train_hash"]          # ckpt_save fills the modules with the train_hash seeds
+    np.testing.assert_array_equal(CK.blob(ck["model"]), synth.blob_from_manifest([e for e in ent if "embeddings" not in e[0]]))
+    np.testing.assert_array_equal(CK.blob(ck["embedder"]), synth.blob_from_manifest([e for e in ent if "embeddings" in e[0]]))
+    p, b = CK.load_module(os.path.join(d, "cu_embedder_checkpoint.pt"))
+    table, primes, biases = CK.cu_hash_state(p, b)
+    assert table.shape == (4 * 4096, 2) and primes.shape == (12,) and primes[0] == 268435459 and primes[5] == 268435469 and (biases == 0.25).all()
+    assert list(b["embedder_feat_local_idx"]) == [0, 4096, 8192, 12288]
+
+
+def test_written_checkpoints_restore_a_reference_model(tmp_path):
+    """SaveCheckpoint -> the reference's torch::load into ITS HashEmbedder / NeRFSmall (oracle/_ref/ref_driver ckpt_load) -> same numbers."""
+    import subprocess
+    from nerfpp_amd import checkpoint as CK
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        pytest.skip("oracle/_ref/ref_driver not built (needs /root/reference)")
+    rng = np.random.RandomState(4)
+    model = {f"model_{n}.weight": rng.randn(*s).astype(np.float32) for n, s in (("sigma_net_0", (64, 8)), ("sigma_net_1", (64, 64)), ("sigma_net_2", (16, 64)),
+                                                                              ("color_net_0", (64, 31)), ("color_net_1", (64, 64)), ("color_net_2", (3, 64)))}
+    emb = {f"embedder_embeddings_{l}.weight": rng.randn(4096, 2).astype(np.float32) for l in range(4)}
+    d = str(tmp_path / "ck"); out = str(tmp_path / "out"); os.makedirs(out)
+    CK.SaveCheckpoint(d, embedder=emb, model=model, global_step=77)
+    cu_p = {"embedder_embeddings": rng.randn(4 * 4096, 2).astype(np.float32)}
+    cu_b = {"embedder_primes": (268435459 + np.arange(12, dtype=np.int32) * 4).reshape(4, 1, 3), "embedder_biases": np.full((4, 3), 0.5, np.float32),
+            "embedder_feat_local_size": np.full(4, 4096, np.int32), "embedder_feat_local_idx": (np.arange(4) * 4096).astype(np.int32)}
+    CK.save_module(os.path.join(d, "cu_embedder_checkpoint.pt"), cu_p, cu_b)
+    subprocess.check_call([drv, "ckpt_load", d, out], stdout=subprocess.DEVNULL)
+    for k, v in model.items():
+        np.testing.assert_array_equal(np.load(os.path.join(out, "m." + k + ".npy")), v)
+    for k, v in emb.items():
+        np.testing.assert_array_equal(np.load(os.path.join(out, "e." + k + ".npy")), v)
+    np.testing.assert_array_equal(np.load(os.path.join(out, "cu.embedder_embeddings.npy")), cu_p["embedder_embeddings"])
+    np.testing.assert_array_equal(np.load(os.path.join(out, "cu.embedder_primes.npy")), cu_b["embedder_primes"])
+    assert int(np.load(os.path.join(out, "start.npy"))[0]) == 77
