@@ -34,7 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NRF_SMALL_PT 2
 #endif
 constexpr int PT = NRF_SMALL_PT; // 32-point tiles per wave
-constexpr int waves_of(bool split) { return split ? 8 : 4; }
+#ifndef NRF_SPLIT_WAVES
+#define NRF_SPLIT_WAVES 8
+#endif
+constexpr int waves_of(bool split) { return split ? NRF_SPLIT_WAVES : 4; }
 constexpr int block_pts_of(bool split) { return 32 * PT * waves_of(split); }
 
 // neuron (row of a D tile / k of the next layer) held by element j of lane-half h in k-step s of a 32-row tile
@@ -90,12 +93,11 @@ __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &h
 template <int MT, int KS, int NP, bool BLO>
 __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT])
 {
+    // the first product of every accumulator takes the literal zero as its C operand (an inline constant of the MFMA encoding):
+    // clearing the tiles with v_mov first costs 16 VALU issues per tile -- 384 per block iteration, more than all conversions together
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[pt][mt][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const half8 a = frags[((mt * KS + ks) * NP) * 64 + lane];
@@ -103,14 +105,17 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
                 const half8 al = frags[((mt * KS + ks) * NP + 1) * 64 + lane];
                 // small terms first, the leading product last
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
                 if constexpr (BLO) {
 #pragma unroll
                     for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], acc[pt][mt], 0, 0, 0);
                 }
-            }
 #pragma unroll
-            for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
+            }
             // fence the scheduler every two k-steps: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments =
             // 160 VGPRs), which costs the occupancy that hides the feature-load latency
             if (NP == 2 || (ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);

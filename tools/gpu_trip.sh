@@ -5,10 +5,13 @@ tag=${1:-t}
 mkdir -p gpurun_out
 (timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/${tag}_tests.log 2>&1
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5) > gpurun_out/${tag}_smoke.log 2>&1
-(timeout 600 python bench.py --steps 5 --warmup 2 2>&1 | tail -3) > gpurun_out/${tag}_bench_f16.log 2>&1
-(timeout 600 python bench.py --steps 3 --warmup 1 --precision f32 --no-cpu-baseline 2>&1 | tail -3) > gpurun_out/${tag}_bench_f32.log 2>&1
+(timeout 900 python bench.py 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_default.json
+(timeout 600 python bench.py --precision f16 --no-cpu-baseline --no-also 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_hashnerf_f16.json
+(timeout 600 python bench.py --steps 3 --warmup 1 --precision f32 --no-cpu-baseline --no-also 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_hashnerf_f32.json
+(timeout 600 python bench.py --workload classic --steps 5 --warmup 1 --no-also 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_classic_f16.json
 ROOTD=$PWD
 cd /tmp && export TMPDIR=/tmp
-(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_classic -- python3 $ROOTD/bench.py --workload classic --steps 3 --warmup 1 --no-cpu-baseline --no-also 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof_classic.log 2>&1
 cd $ROOTD
 tail -4 gpurun_out/${tag}_tests.log
