@@ -90,19 +90,31 @@ __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &h
 
 // acc[pt][mt] += A[mt][ks] . B[pt][ks] over all k-steps; A fragments stream from LDS in consumption order.
 // NP = 1: plain fp16 operands.  NP = 2: split operands, fragments stored (hi, lo) adjacent; BLO = the B operand has a non-zero lo part.
-template <int MT, int KS, int NP, bool BLO>
-__device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT])
+struct NoJob { __device__ __forceinline__ void operator()(int, int) const {} };
+
+// job(mt, ks): extra work issued right after the products of step (mt, ks) -- the software pipeline of the kernel puts the
+// conversion of the PREVIOUS tile there, so that its VALU instructions execute while this step's MFMAs occupy the matrix pipe.
+// The A fragments of the whole network lie in LDS in consumption order, so the fragment(s) of step i + 1 -- the next k-step, m-tile or
+// LAYER -- are simply the next 1 (2) KB: they are fetched at the top of step i and arrive while its products run.  `pre` carries them
+// from step to step and from layer to layer (fetched = false only for the very last step of the network).
+template <int MT, int KS, int NP, bool BLO, bool LAST = false, class Job = NoJob>
+__device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT], half8 (&pre)[NP],
+                                           Job job = Job())
 {
-    // the first product of every accumulator takes the literal zero as its C operand (an inline constant of the MFMA encoding):
-    // clearing the tiles with v_mov first costs 16 VALU issues per tile -- 384 per block iteration, more than all conversions together
+    // the first product of every accumulator takes the literal zero as its C operand (an inline constant of the MFMA encoding)
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const half8 a = frags[((mt * KS + ks) * NP) * 64 + lane];
+            const half8 a = pre[0];
+            half8 al = a;
+            if constexpr (NP == 2) al = pre[NP - 1];
+            if (!(LAST && mt == MT - 1 && ks == KS - 1)) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) pre[q] = frags[((mt * KS + ks + 1) * NP + q) * 64 + lane];
+            }
             if constexpr (NP == 2) {
-                const half8 al = frags[((mt * KS + ks) * NP + 1) * 64 + lane];
                 // small terms first, the leading product last
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
@@ -116,9 +128,10 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
             }
-            // fence the scheduler every two k-steps: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments =
-            // 160 VGPRs), which costs the occupancy that hides the feature-load latency
-            if (NP == 2 || (ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            job(mt, ks);
+            // fence the scheduler: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments = 160 VGPRs), which costs
+            // the occupancy that hides the feature-load latency
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -149,6 +162,13 @@ struct SmallInput {
     const uint8_t *keep;
     const __half *dirs_lo;                            // split mode: lo parts of the direction features, same layout
 };
+
+#ifndef NRF_SMALL_PIPE_SPLIT
+#define NRF_SMALL_PIPE_SPLIT 1
+#endif
+#ifndef NRF_SMALL_PIPE_F16
+#define NRF_SMALL_PIPE_F16 0
+#endif
 
 template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT>
 __global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? 1 : 2)
@@ -217,31 +237,55 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             }
         }
         const half8 *fr = wl;
-        // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer
-        half8 bh[PT][4][NP];
+        // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer (two buffers: the software pipeline writes the
+        // next layer's operands while the current layer still reads its own)
+        constexpr bool PIPE = SPLIT ? (NRF_SMALL_PIPE_SPLIT != 0) : (NRF_SMALL_PIPE_F16 != 0);
+        constexpr int NBUF = PIPE ? 2 : 1;
+        half8 bh[NBUF][PT][4][NP];
         f32x16 acc2[PT][2];
-        auto hidden_to_b = [&]() {
+        // item i in 0..3 of tile t: point tile i >> 1, register half i & 1 -> operand fragment 2t + (i & 1) of buffer `buf`
+        auto conv_item = [&](int buf, int t, int i) {
+            const int pt = i >> 1, sh = i & 1;
+            if constexpr (SPLIT) tile_to_frag2<true>(acc2[pt][t], sh, bh[buf][pt][2 * t + sh][0], bh[buf][pt][2 * t + sh][NP - 1]);
+            else bh[buf][pt][2 * t + sh][0] = tile_to_frag<true>(acc2[pt][t], sh);
+        };
+        static_assert(PT == 2, "the conversion schedule below is written for two point tiles per wave");
+        auto hidden_to_b = [&](int buf) {
 #pragma unroll
-            for (int pt = 0; pt < PT; pt++)
+            for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int s = 0; s < 2; s++) {
-                        if constexpr (SPLIT) tile_to_frag2<true>(acc2[pt][t], s, bh[pt][2 * t + s][0], bh[pt][2 * t + s][NP - 1]);
-                        else bh[pt][2 * t + s][0] = tile_to_frag<true>(acc2[pt][t], s);
+                for (int i = 0; i < 4; i++) conv_item(buf, t, i);
+        };
+        // Software pipeline (PIPE): while the matrix pipe works on tile 1 of a layer, tile 0 -- already complete -- is converted into the next
+        // layer's first two operand fragments; tile 1 is converted during the first two k-steps of the next layer, which only need those.
+        //   job of a layer with input buffer `bi` and KS k-steps:  mt == 0, ks < 2 : previous layer's tile 1 -> bh[bi][.][2..3]
+        //                                                           mt == 1         : this layer's tile 0      -> bh[bi ^ 1][.][0..1]
+        auto make_job = [&](int bi, bool conv_prev_tile1, bool conv_this_tile0, int ks_count) {
+            return [=, &conv_item](int mt, int ks) {
+                if constexpr (PIPE) {
+                    if (conv_prev_tile1 && mt == 0 && ks < 2) { conv_item(bi, 1, 2 * ks); conv_item(bi, 1, 2 * ks + 1); }
+                    if (conv_this_tile0 && mt == 1) {
+                        const int per = (4 + ks_count - 1) / ks_count;
+                        for (int i = ks * per; i < (ks + 1) * per && i < 4; i++) conv_item(bi ^ 1, 0, i);
                     }
+                }
+            };
         };
         // ---- sigma net ----
+        half8 pre[NP];
+#pragma unroll
+        for (int q = 0; q < NP; q++) pre[q] = fr[q * 64 + lane];
         f32x16 sig[PT][1];
         if constexpr (NL == 1) {
-            gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig); fr += Plan::sigma_frags(0) * 64 * NP;
+            gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
-            gemm_layer<2, IN_KS, NP, IN_LO>(fr, lane, bx, acc2); fr += Plan::sigma_frags(0) * 64 * NP;
+            gemm_layer<2, IN_KS, NP, IN_LO>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
 #pragma unroll
             for (int l = 1; l < NL; l++) {
-                hidden_to_b();
-                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh, acc2);
-                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh, sig);
+                const int bi = PIPE ? ((l - 1) & 1) : 0;
+                if constexpr (!PIPE) hidden_to_b(0);
+                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
+                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4));
                 fr += Plan::sigma_frags(l) * 64 * NP;
             }
         }
@@ -259,14 +303,15 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         }
         f32x16 rgb[PT][1];
         if constexpr (NLC == 1) {
-            gemm_layer<1, V_KS + 1, NP, SPLIT>(fr, lane, bc, rgb);
+            gemm_layer<1, V_KS + 1, NP, SPLIT, true>(fr, lane, bc, rgb, pre);
         } else {
-            gemm_layer<2, V_KS + 1, NP, SPLIT>(fr, lane, bc, acc2); fr += Plan::color_frags(0) * 64 * NP;
+            gemm_layer<2, V_KS + 1, NP, SPLIT>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
 #pragma unroll
             for (int l = 1; l < NLC; l++) {
-                hidden_to_b();
-                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh, acc2);
-                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh, rgb);
+                const int bi = PIPE ? ((l - 1) & 1) : 0;
+                if constexpr (!PIPE) hidden_to_b(0);
+                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
+                else gemm_layer<1, 4, NP, SPLIT, true>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4));
                 fr += Plan::color_frags(l) * 64 * NP;
             }
         }
