@@ -220,7 +220,7 @@ def main():
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        # quality: GPU render vs the CPU oracle on identical weights/pose, a bounded ray sample (render-vs-render PSNR)
+        # parity of what was just timed (cpu_baseline leg, checker use of oracle/): GPU render vs the CPU oracle on identical weights/pose
         try:
             line["psnr_vs_oracle_db"] = quality_check(sc, renderer, rp, K, poses[0], args)
         except Exception as e:
@@ -333,6 +333,8 @@ def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
 
 
 def quality_check(sc, renderer, rp, K, c2w, args, nrays=256):
+    """Second half of the cpu_baseline leg (outside every timed region): the CPU oracle renders 256 rays of the frame with the same weights
+    and the GPU pixels are compared with it -- oracle/ is used as the checker only, never as part of what is measured or shipped."""
     import torch
     from oracle import capi as O
     from nerfpp_amd import scene
