@@ -38,7 +38,7 @@ struct nrf_hash {
     size_t fast_bytes = 0;
     bool fast_valid = false;
     int dense_levels = 0;
-    size_t dense_budget = (size_t)24 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 2.2 GB at 16..512, 17 GB at 16..1024 -- HBM is 288 GB
+    size_t dense_budget = (size_t)24 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 4.4 GB at 16..512; at 16..1024 the finest level (35 GB) stays hashed -- HBM is 288 GB
 };
 
 namespace nrf {

@@ -33,14 +33,16 @@ __device__ __forceinline__ PointPrep prep_point(const HashParams &hp, const F3 &
     return r;
 }
 
-// One (point, level): 8 half2 gathers issued back to back, then the fp32 blend in the reference's order.
-// Dense ("baked") image of a level: for every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, the PAIR of table
-// values of (x,y,z) and (x,y,z+1), copied out of the hashed table once at model load (8 bytes: two half2).  A voxel's 8
-// corners are then 4 eight-byte loads instead of 8 four-byte gathers.  Vertices are grouped in 4x4 (x,y) tiles of 16 pairs
-// = one 128-B line, tiles of one (x,y) column stacked along z, so the 4 loads of a lookup fall into 1.56 lines on average
-// (8 for the hashed table) and consecutive samples along a ray share lines / walk adjacent ones.  Each lookup returns the
-// same table entries the hash would have selected: outputs are bit-identical.  Costs 2x the vertices in memory (2.2 GB at
-// 16..512) -- HBM is 288 GB.
+// One (point, level): the voxel's 8 table values, then the fp32 blend in the reference's order.
+// Dense ("baked") image of a level: for every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, the QUAD of table values of
+// (x,y,z), (x,y,z+1), (x+1,y,z), (x+1,y,z+1), copied out of the hashed table once at model load (16 bytes: four half2).  A voxel's
+// 8 corners are then 2 sixteen-byte loads (rows y and y+1) instead of 8 four-byte gathers into 8 lines.  Vertices are grouped in
+// 4x4 (x,y) tiles (256 B at one z), tiles of one (x,y) column stacked along z, so the two loads of a lookup mostly share a line
+// and consecutive samples along a ray walk adjacent ones.  Each lookup returns the same table entries the hash would have selected:
+// outputs are bit-identical.  Costs 4x the vertices in memory (4.4 GB at 16..512) -- HBM is 288 GB.
+// Measured ladder (ms per 800x800x256 frame, same kernel otherwise): hashed table 30.6 -> (z,z+1) pairs, 4 x 8-B loads 14.8 ->
+// quads, 2 x 16-B loads 13.6 -> all 8 corners in one 32-B entry 22.2 (REJECTED: 8.8 GB of image, every lookup its own line, the kernel
+// turns HBM-bound).  The kernel sits where the vector-memory request rate and the line traffic balance.
 struct DensePair { __half2 lo, hi; };
 
 __device__ __forceinline__ uint32_t dense_tile(uint32_t x, uint32_t y, uint32_t nby) { return (x >> 2) * nby + (y >> 2); }
@@ -61,24 +63,22 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
     }
     float acc[2];
     if (hp.dense_off[l] >= 0) {                 // wave-uniform
-        const uint2 *dp = reinterpret_cast<const uint2 *>(hp.dense) + hp.dense_off[l];
+        const uint4 *dp = reinterpret_cast<const uint4 *>(hp.dense) + hp.dense_off[l];
         const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
         const float a = fr[0], b = fr[1], c = fr[2];
         const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
-        const uint32_t x0 = pos[0], x1 = pos[0] + 1u, y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
-        const uint32_t tx0 = (x0 >> 2) * nby, tx1 = (x1 >> 2) * nby, ty0 = y0 >> 2, ty1 = y1 >> 2;
-        const uint32_t ix0 = (x0 & 3u) << 2, ix1 = (x1 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
-        uint2 pr[4];
-        pr[0] = dp[(((tx0 + ty0) * dz + z) << 4) | ix0 | iy0];
-        pr[1] = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];
-        pr[2] = dp[(((tx1 + ty0) * dz + z) << 4) | ix1 | iy0];
-        pr[3] = dp[(((tx1 + ty1) * dz + z) << 4) | ix1 | iy1];
+        const uint32_t x0 = pos[0], y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
+        const uint32_t tx0 = (x0 >> 2) * nby, ty0 = y0 >> 2, ty1 = y1 >> 2;
+        const uint32_t ix0 = (x0 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
+        const uint4 q0 = dp[(((tx0 + ty0) * dz + z) << 4) | ix0 | iy0];      // corners (x..x+1, y0, z..z+1)
+        const uint4 q1 = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];      // corners (x..x+1, y1, z..z+1)
+        // blend order k = 4dx + 2dy + dz; a quad holds (dx,dz) = (0,0),(0,1),(1,0),(1,1)
+        const uint32_t wv[8] = {q0.x, q0.y, q1.x, q1.y, q0.z, q0.w, q1.z, q1.w};
         float2 v[8];
         float ws[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint32_t w = (k & 1) ? pr[k >> 1].y : pr[k >> 1].x;
-            __half2 hv; __builtin_memcpy(&hv, &w, 4);
+            __half2 hv; __builtin_memcpy(&hv, &wv[k], 4);
             v[k] = __half22float2(hv);
             const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
             ws[k] = wx * wy * wz;
@@ -96,7 +96,7 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
     return __halves2half2(__float2half_rn(acc[0]), __float2half_rn(acc[1]));
 }
 
-__global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries, uint2 *__restrict__ dst)
+__global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries, uint4 *__restrict__ dst)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= entries) return;
@@ -107,12 +107,12 @@ __global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries
     const uint32_t x = (tile / nby) * 4 + (w >> 2), y = (tile % nby) * 4 + (w & 3);
     const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
     const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
-    uint2 v{0u, 0u};
-    if (x < dim && y < dim) {
-        if (z < dim) { const uint32_t hv = ((x * pa) ^ (y * pb) ^ (z * pc)) % hp.local_size[l]; v.x = *reinterpret_cast<const uint32_t *>(fp + (size_t)hv * 2); }
-        if (z + 1 < dim) { const uint32_t hv = ((x * pa) ^ (y * pb) ^ ((z + 1) * pc)) % hp.local_size[l]; v.y = *reinterpret_cast<const uint32_t *>(fp + (size_t)hv * 2); }
-    }
-    dst[i] = v;
+    auto row = [&](uint32_t xx, uint32_t zz) -> uint32_t {
+        if (xx >= dim || y >= dim || zz >= dim) return 0u;
+        const uint32_t hv = ((xx * pa) ^ (y * pb) ^ (zz * pc)) % hp.local_size[l];
+        return *reinterpret_cast<const uint32_t *>(fp + (size_t)hv * 2);
+    };
+    dst[i] = uint4{row(x, z), row(x, z + 1), row(x + 1, z), row(x + 1, z + 1)};
 }
 
 // (Re)build the dense image of levels [0, nb) after the table or the primes changed.  nb is chosen by a byte budget.
@@ -131,25 +131,25 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
         for (int l = 0; l < L; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
             const int64_t nbx = (dim + 3) / 4, nby = (dim + 3) / 4;
-            const int64_t entries = nbx * nby * dim * 16;                 // 8-byte (z, z+1) pairs
-            if ((size_t)(total + entries) * 8 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
+            const int64_t entries = nbx * nby * dim * 16;                 // 16-byte (x..x+1, z..z+1) quads
+            if ((size_t)(total + entries) * 16 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
             hp.dense_off[l] = total; hp.dense_nby[l] = (int32_t)nby; hp.dense_nbz[l] = (int32_t)dim;
             total += entries; nb = l + 1;
         }
     }
     if (nb > 0) {
-        if (h->fast_bytes < (size_t)total * 8) {
+        if (h->fast_bytes < (size_t)total * 16) {
             if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
             h->d_fast = nullptr; h->fast_bytes = 0;
-            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 8));
-            h->fast_bytes = (size_t)total * 8;
+            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 16));
+            h->fast_bytes = (size_t)total * 16;
         }
         hp.dense = h->d_fast;
         for (int l = 0; l < nb; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
             const int64_t entries = (l + 1 < nb ? hp.dense_off[l + 1] : total) - hp.dense_off[l];
             hipLaunchKernelGGL(k_bake_dense, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
-                               reinterpret_cast<uint2 *>(h->d_fast) + hp.dense_off[l]);
+                               reinterpret_cast<uint4 *>(h->d_fast) + hp.dense_off[l]);
             NRF_LAUNCH_CHECK();
         }
     }
