@@ -74,19 +74,23 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
         const uint4 q1 = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];      // corners (x..x+1, y1, z..z+1)
         // blend order k = 4dx + 2dy + dz; a quad holds (dx,dz) = (0,0),(0,1),(1,0),(1,1)
         const uint32_t wv[8] = {q0.x, q0.y, q1.x, q1.y, q0.z, q0.w, q1.z, q1.w};
-        float2 v[8];
+        // both features of a corner go through the same multiply and the same add: float2 vector arithmetic lets the compiler use the
+        // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, one rounding per lane and op: bit-identical to the scalar form)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v[8];
         float ws[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             __half2 hv; __builtin_memcpy(&hv, &wv[k], 4);
-            v[k] = __half22float2(hv);
+            const float2 t = __half22float2(hv);
+            v[k] = f32x2{t.x, t.y};
             const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
             ws[k] = wx * wy * wz;
         }
-        float a0 = ws[0] * v[0].x, a1 = ws[0] * v[0].y;
+        f32x2 s2 = v[0] * ws[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) { a0 = a0 + ws[k] * v[k].x; a1 = a1 + ws[k] * v[k].y; }
-        acc[0] = a0; acc[1] = a1;
+        for (int k = 1; k < 8; k++) s2 = s2 + v[k] * ws[k];
+        acc[0] = s2.x; acc[1] = s2.y;
     } else {
         const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
         const uint32_t lsz = hp.local_size[l];
@@ -159,7 +163,9 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
     return NRF_OK;
 }
 
-template <int PPT, int GATHER>
+// LPT levels per thread (blockIdx.y indexes groups of LPT levels): the coarse levels run at a fixed per-(point, level) instruction
+// cost (their lines are cached), a good part of which is forming the point and its box coordinates -- done once for LPT levels.
+template <int PPT, int GATHER, int LPT = 1>
 __global__ void __launch_bounds__(256)
 k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep, int lpg, int xcd_map,
              int level0)
@@ -176,7 +182,7 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
         else { const int k = sub * 8 + g; level = (sub & 1) ? (hp.n_levels - 1 - (k - 8 * sub) - 8 * (sub >> 1)) : (k - 8 * sub) + 8 * (sub >> 1); }
         if (level >= hp.n_levels || level < 0) return;
     } else {
-        level = level0 + blockIdx.y;
+        level = level0 + blockIdx.y * LPT;
         tile = blockIdx.x;
     }
     PointPrep pp[PPT];
@@ -190,16 +196,20 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
     __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t();
     if constexpr (GATHER != 0)
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(hp.table), 0, (int)(((size_t)hp.n_levels << hp.log2_t) * 4), 0x00020000);
-    __half2 out[PPT];
+    __half2 out[LPT][PPT];
 #pragma unroll
-    for (int q = 0; q < PPT; q++) out[q] = encode_level<GATHER>(hp, pp[q], level, rsrc);
+    for (int j = 0; j < LPT; j++)
 #pragma unroll
-    for (int q = 0; q < PPT; q++) {
-        if (idx[q] < p) {
-            feats[(int64_t)level * pstride + idx[q]] = out[q];
-            if (level == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
+        for (int q = 0; q < PPT; q++) out[j][q] = encode_level<GATHER>(hp, pp[q], level + j, rsrc);
+#pragma unroll
+    for (int j = 0; j < LPT; j++)
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            if (idx[q] < p) {
+                feats[(int64_t)(level + j) * pstride + idx[q]] = out[j][q];
+                if (level + j == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
+            }
         }
-    }
 }
 
 // per-ray direction features as fp16 rows [n, V] (the MLP kernel's colour-net operand): SH of the ray's view direction
@@ -239,6 +249,16 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     const int gather = (variant >> 3) & 3;
     HashParams hpar = h->params;
     if (variant & 32) { for (int l = 0; l < L; l++) hpar.dense_off[l] = -1; }       // tuning: force the hashed lookup everywhere
+    // default variant, all levels: the lower three quarters of the pyramid in groups of four levels per thread, the (memory-bound) finest
+    // levels one level per thread
+    if (variant == 0 && level_lo == 0 && level_hi == L && L >= 8) {
+        const int lc = (L * 3 / 4) & ~3;       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
+        if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+        NRF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+        NRF_LAUNCH_CHECK();
+        return NRF_OK;
+    }
 #define NRF_LM(P, G) hipLaunchKernelGGL((k_hash_cu_lm<P, G>), grid, dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, xcd, level_lo)
     if (ppt == 1) { if (gather == 0) NRF_LM(1, 0); else if (gather == 1) NRF_LM(1, 1); else if (gather == 2) NRF_LM(1, 2); else NRF_LM(1, 3); }
     else { if (gather == 0) NRF_LM(2, 0); else if (gather == 1) NRF_LM(2, 1); else if (gather == 2) NRF_LM(2, 2); else NRF_LM(2, 3); }
