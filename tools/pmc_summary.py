@@ -14,16 +14,25 @@ tag, out = sys.argv[1], sys.argv[2]
 res = {}
 for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}_*/*/*_counter_collection.csv"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    launches = collections.Counter()
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
+        k = r["Kernel_Name"]
         short = k.split("(")[0].replace("void ", "").strip()
         if "k_hash_cu_lm" in k: short = "hash_encode (k_hash_cu_lm)"
         elif "k_mlp_small_mfma" in k: short = "mlp_small (k_mlp_small_mfma)"
         elif "k_mlp_nerf_mfma" in k: short = "mlp_nerf (k_mlp_nerf_mfma)"
+        agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # one logical hash-encode launch is TWO dispatches (four-levels-per-thread group + single-level group): count the latter
+        if short.startswith("hash_encode"):
+            if "ELi1ELi0ELi1E" in k or "<1, 0, 1>" in k: launches[(short, r["Counter_Name"])] += 1
+        else:
+            launches[(short, r["Counter_Name"])] += 1
+    for short, v in agg.items():
         for c, x in v.items():
-            res.setdefault(short, {})[c] = sum(x) / len(x)
+            n = max(launches[(short, c)], 1)
+            res.setdefault(short, {})[c] = sum(x) / n
             res[short]["dispatches"] = len(x)
+            res[short]["launches"] = n
 for k, v in res.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
