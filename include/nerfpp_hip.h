@@ -200,6 +200,15 @@ NRF_API int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d
 NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
                             float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream);
 
+/* The LeRF head fused with its render pass on the matrix cores (fp16 operands, fp32 accumulate), for the reference's LeRF shape
+ * (main.cpp:203-213: in 128, hidden 256, 2 + 2 layers, geo 32, embedding 768) -- the [N, S, 769] raw tensor is never formed.
+ *   nrf_lerf_sigma            : sigma_le = LeRFImpl::forward(x)[..., -1] (LeRF.cpp:86-95), zeroed where keep is false (LeRFRenderer.cpp:22-23)
+ *   nrf_lerf_render_embedding : out[n, 768] = sum_s weights[n,s] * normalize(le(x[n,s]))  (LeRF.cpp:96-108 + the sum of LeRFRenderer.h:45-54);
+ *                               s must be a multiple of 32.  L2-normalise `out` afterwards (nrf_render_clip_embedding's last step). */
+NRF_API int nrf_lerf_mfma_available(const nrf_mlp *m);
+NRF_API int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
+NRF_API int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
+
 /* RenderCLIPEmbedding (LeRFRenderer.h:45-54): out[n, embed_dim] = normalize(sum_s weights[n,s] * embeds[n,s,:embed_dim], eps 1e-8).
  * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]).  Relevancy(...) (LeRFRenderer.cpp:79) lives
  * in the external RuCLIP module and is not part of this library. */

@@ -51,5 +51,6 @@ int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float 
 int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 
 }  // namespace nrf

@@ -1,0 +1,384 @@
+// mlp_lerf_mfma.hip -- the LeRF language head (LeRFImpl::forward, LeRF.cpp:28-111) FUSED with its render pass
+// (LeRFRenderer::RawToLEOutputs / RenderCLIPEmbedding, LeRFRenderer.cpp:27-76, LeRFRenderer.h:45-54) on the gfx950 matrix cores.
+//
+// The reference materialises raw_le [N, S, 769] (3 KB per sample point: 500 GB per 800x800 frame at 64+128 samples) only to
+// reduce it to one 768-vector per ray.  Here the 768-wide output never leaves the register file:
+//
+//   kernel A  nrf_lerf_sigma             sigma net only  (in 128 -> 256 -> 33):  sigma_le per point, for the compositing weights
+//   kernel B  nrf_lerf_render_embedding  sigma net (for the 32 geo features) -> LE net (cat[geo, in] 160 -> 256 -> 768) TWICE:
+//               pass 1 accumulates ||h||^2 per point, pass 2 recomputes the 24 output tiles, scales each point's column by
+//               w_s / max(||h||, 1e-8) and sums the 32 points (= 32 consecutive samples of ONE ray) of the tile across lanes;
+//               each wave adds its 768 partial sums to out[ray] with one 128-byte-contiguous float atomic per tile.
+//             out[ray] = normalize(sum_s w_s * normalize(h_s))  is finished by the caller's L2-normalise.
+//
+// Same transposed MFMA formulation and the same L2 -> LDS weight streaming as mlp_nerf_mfma.hip (8 waves x 32 points per workgroup,
+// chunks of <= 2 neuron tiles x all k-steps, double buffered, issue-early / write-late); fp16 operands, fp32 accumulate.
+// Built for the reference's LeRF shape (main.cpp:203-213): in 16 x 8 = 128, hidden 256, 2 + 2 layers, geo 32, embedding 768.
+#include "mlp.h"
+
+#include <utility>
+
+namespace nrf {
+namespace lerf {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 8;              // waves per workgroup
+constexpr int NBLK = 32 * NW;      // points per workgroup iteration (one 32-point tile per wave)
+constexpr int MAXF = 32;           // fragments (1 KB each) in the largest chunk
+constexpr int IN = 128, HID = 256, GEO = 32, EMB = 768;
+
+__host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// Layers: 0 sigma0 [nat 8] -> 8 tiles ReLU | 1 sigma1 [chained 16] -> 2 tiles (row 0 = sigma, rows 1..32 = geo) | 2 LE0 [chained 4 | nat 8]
+// -> 8 tiles ReLU (cat[geo, in], LeRF.cpp) | 3 LE1 [chained 16] -> 24 tiles (norm pass) | 4 = layer 3 again (weighted-sum pass).
+// NL = 2: the sigma net alone (kernel A); NL = 5: everything (kernel B).  Both walk the same weight image.
+template <int NL>
+struct Net {
+    static constexpr int NLAYER = NL;
+    static constexpr int tiles(int l) { return l == 0 ? 8 : l == 1 ? 2 : l == 2 ? 8 : 24; }
+    static constexpr int ks_nat(int l) { return (l == 0 || l == 2) ? 8 : 0; }
+    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 2 ? 4 : 16; }
+    static constexpr bool nat_first(int l) { return l != 2; }
+    static constexpr int ks(int l) { return ks_nat(l) + ks_ch(l); }
+    static constexpr int chunk_tiles(int l, int) { return l == 1 ? 1 : 2; }            // sigma1: 1 + 1 keeps the chunk count even
+    static constexpr int chunks(int l) { return l == 1 ? 2 : tiles(l) / 2; }
+    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += chunks(i); return n; }
+    static constexpr int total_chunks() { return first_chunk(NLAYER); }
+    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
+    static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
+    // byte-offset bookkeeping in the IMAGE: layer 4 re-reads layer 3's chunks
+    static constexpr int image_chunk(int ci) { return ci >= first_chunk(4) && NLAYER > 4 ? ci - chunks(3) : ci; }
+    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < image_chunk(ci); i++) n += chunk_frags(i); return n; }
+};
+static_assert(Net<2>::total_chunks() == 6 && Net<5>::total_chunks() == 34, "chunk counts");
+static_assert(Net<5>::total_chunks() % 2 == 0 && Net<2>::total_chunks() % 2 == 0, "double-buffer parity must repeat per point block");
+constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 24 * 16;       // 576 KB
+static_assert(Net<5>::chunk_off(Net<5>::first_chunk(3)) + 24 * 16 == IMAGE_FRAGS, "image size");
+static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) == Net<5>::chunk_off(Net<5>::first_chunk(3)), "pass 2 re-reads pass 1's weights");
+
+constexpr int NPIECE = (MAXF * 64 + 64 * NW - 1) / (64 * NW);
+struct Stage { u32x4 r[NPIECE]; };
+
+template <class N, int CI>
+__device__ __forceinline__ void stage_load(Stage &st, __amdgpu_buffer_rsrc_t rsrc, int tid)
+{
+    constexpr int ci = CI % N::total_chunks();
+    constexpr int n = N::chunk_frags(ci) * 64;
+    constexpr int base = N::chunk_off(ci) * 1024;
+#pragma unroll
+    for (int q = 0; q < NPIECE; q++) {
+        const int i = q * (64 * NW) + tid;
+        if (q * (64 * NW) < n) {
+            // the chunk's byte offset is a compile-time constant in the SCALAR offset operand; the empty volatile asm pins its s_mov here
+            // -- hoisted out of the persistent loop, the 34 x 4 constants (plus the hooks' lane masks) overflow the SGPR file and spill
+            int soff = base + q * (64 * NW * 16);
+            asm volatile("" : "+s"(soff));
+            if (i < n) st.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, soff, 0);
+        }
+    }
+}
+
+template <class N, int CI>
+__device__ __forceinline__ void stage_store(const Stage &st, half8 *__restrict__ dst, int tid)
+{
+    constexpr int ci = CI % N::total_chunks();
+    constexpr int n = N::chunk_frags(ci) * 64;
+#pragma unroll
+    for (int q = 0; q < NPIECE; q++) {
+        const int i = q * (64 * NW) + tid;
+        if (q * (64 * NW) < n) { if (i < n) reinterpret_cast<u32x4 *>(dst)[i] = st.r[q]; }
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ half8 tile_to_frag(const f32x16 &acc, int s)
+{
+    half8 r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = (_Float16)acc[8 * s + j];
+    if (RELU) r = __builtin_elementwise_max(r, half8{0, 0, 0, 0, 0, 0, 0, 0});
+    return r;
+}
+
+struct Ctx {
+    half8 *wbuf;                       // [2][MAXF*64]
+    __amdgpu_buffer_rsrc_t packed;
+    int tid, lane, h;
+    bool last_block;
+};
+
+// One chunk: fetch the following chunk, run this chunk's MFMAs out of LDS, hand each finished tile to `hook(tile, acc)`, publish the
+// fetched chunk.  All indices are template constants.
+template <class N, int L, int C, int NN, int NC, class Hook>
+__device__ __forceinline__ void chunk(const Ctx &cx, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook)
+{
+    constexpr int KSN = N::ks_nat(L), KSC = N::ks_ch(L), KS = KSN + KSC;
+    constexpr int CI = N::first_chunk(L) + C;
+    constexpr bool FINAL = (CI == N::total_chunks() - 1);
+    constexpr int NT = N::chunk_tiles(L, C);
+    constexpr int TILE0 = (L == 1) ? C : 2 * C;
+    constexpr bool NATF = N::nat_first(L);
+    static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
+    Stage st;
+    const bool fetch = !(FINAL && cx.last_block);
+    if (fetch) stage_load<N, CI + 1>(st, cx.packed, cx.tid);
+    const half8 *w = cx.wbuf + (CI & 1) * (MAXF * 64);
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        f32x16 acc = zero;
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const half8 a = w[(t * KS + k) * 64 + cx.lane];
+            half8 b;
+            if (NATF) b = (k < KSN) ? bn[k < KSN ? k : 0] : bc[k >= KSN ? k - KSN : 0];
+            else b = (k < KSC) ? bc[k < KSC ? k : 0] : bn[k >= KSC ? k - KSC : 0];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        hook(TILE0 + t, acc);
+        // the tile is consumed HERE: without the fence the scheduler runs ahead with the next tiles' MFMAs and parks finished accumulators
+        // (16 VGPRs each) until it gets round to their epilogues -- hundreds of spills on the 24-tile layers
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (fetch) stage_store<N, CI + 1>(st, cx.wbuf + ((CI + 1) & 1) * (MAXF * 64), cx.tid);
+    __syncthreads();
+}
+
+template <class N, int L, int NN, int NC, class Hook, int... Cs>
+__device__ __forceinline__ void layer_seq(const Ctx &cx, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook, std::integer_sequence<int, Cs...>)
+{
+    (chunk<N, L, Cs>(cx, bn, bc, hook), ...);
+}
+
+template <class N, int L, int NN, int NC, class Hook>
+__device__ __forceinline__ void layer(const Ctx &cx, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook)
+{
+    layer_seq<N, L>(cx, bn, bc, hook, std::make_integer_sequence<int, N::chunks(L)>{});
+}
+
+// tile -> the two operand fragments it contributes to the next layer
+template <bool RELU, int NOUT, bool KEEP0 = false>
+struct ConvHook {
+    half8 (&bout)[NOUT];
+    float row0;                                // KEEP0: row 0 of tile 0 as it came out of the accumulator (sigma_le of the sigma net's last layer)
+    __device__ __forceinline__ void operator()(int tile, const f32x16 &acc)
+    {
+        if (2 * tile + 1 < NOUT) { bout[2 * tile] = tile_to_frag<RELU>(acc, 0); bout[2 * tile + 1] = tile_to_frag<RELU>(acc, 1); }
+        if (KEEP0 && tile == 0) row0 = acc[0];
+    }
+};
+
+struct SumsqHook {
+    float ss = 0.0f;
+    __device__ __forceinline__ void operator()(int, const f32x16 &acc)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++) ss = __builtin_fmaf(acc[i], acc[i], ss);
+        // pin the partial sum here: its only real use is after the 24th tile, and the IR-level code sinking would otherwise move all 384
+        // FMAs down there -- keeping every finished accumulator alive (12 tiles in registers, 12 spilled)
+        asm volatile("" : "+v"(ss));
+    }
+};
+
+// Scale the point's column by f and sum the 32 points of the tile (the lanes of one half) with a reduce-scatter: at the step with
+// partner lane ^ m a lane keeps the half of its registers selected by its own bit m and adds the partner's copy of that half, so after
+// m = 16, 8, 4, 2 a lane holds ONE register, index r >> 1, summed over 16 lanes; the last exchange (m = 1) completes it.  62 VALU per
+// tile instead of 160 for sixteen full butterflies, and the sums land one per lane -- the shape the 128-byte atomic wants.
+struct ReduceHook {
+    float f;
+    float *out_row;        // nullptr: this wave's points lie beyond the batch
+    int r, h;
+    template <int NKEEP>      // partner = lane ^ (2 * NKEEP): keep NKEEP of 2 * NKEEP registers
+    __device__ __forceinline__ void step(float (&v)[16]) const
+    {
+        const bool up = (r & (2 * NKEEP)) != 0;
+#pragma unroll
+        for (int i = 0; i < NKEEP; i++) {
+            const float keep = up ? v[i + NKEEP] : v[i], send = up ? v[i] : v[i + NKEEP];
+            v[i] = keep + __shfl_xor(send, 2 * NKEEP);
+        }
+    }
+    __device__ __forceinline__ void operator()(int tile, const f32x16 &acc)
+    {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = acc[i] * f;
+        step<8>(v); step<4>(v); step<2>(v); step<1>(v);
+        v[0] += __shfl_xor(v[0], 1);
+        // lane r (even) of half h owns accumulator register i = r >> 1 = row 16(i>>3) + 8((i&7)>>2) + 4h + (i&3) of the tile
+        const int i = r >> 1;
+        if (out_row && (r & 1) == 0) unsafeAtomicAdd(out_row + tile * 32 + 16 * (i >> 3) + 8 * ((i & 7) >> 2) + 4 * h + (i & 3), v[0]);
+    }
+};
+
+struct Args {
+    const float *x; int x_stride;           // hash features [p, 128] fp32
+    const float *weights;                   // [p] render weights (kernel B)
+    const uint8_t *keep;                    // optional: sigma forced to 0 where false (kernel A)
+    float *sigma;                           // [p] (kernel A)
+    float *out;                             // [n, 768] accumulated (kernel B)
+    int s;                                  // samples per ray, a multiple of 32
+};
+
+template <int NL>
+__global__ void __launch_bounds__(64 * NW)
+k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
+{
+    using N = Net<NL>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *wbuf = reinterpret_cast<half8 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, IMAGE_FRAGS * 1024, 0x00020000);
+    {
+        Stage st;
+        stage_load<N, 0>(st, rsrc, tid);
+        stage_store<N, 0>(st, wbuf, tid);
+    }
+    __syncthreads();
+    const int64_t nblocks = (npts + NBLK - 1) / NBLK;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        Ctx cx{wbuf, rsrc, tid, lane, h, blk + gridDim.x >= nblocks};
+        const int64_t p0 = blk * NBLK + wave * 32;
+        const int64_t q = p0 + r;
+        const bool live = q < npts;
+        const int64_t qc = live ? q : npts - 1;
+        // input operand: element j of k-step s is x[q][16 s + 8 h + j].  Needed by layer 0 and again by layer 2 (cat[geo, in]): read twice
+        // (512 B per point from L2) rather than kept in 32 VGPRs across the sigma net
+        half8 none[1];
+        auto load_x = [&](half8 (&xin)[8]) {
+            const float *row = in.x + qc * in.x_stride;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const float4 lo = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h);
+                const float4 hi = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h + 4);
+                xin[s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+            }
+        };
+        half8 ba[16], bb[4];
+        ConvHook<true, 16> c0{ba, 0.0f};
+        {
+            half8 xin[8];
+            load_x(xin);
+            layer<N, 0>(cx, xin, none, c0);                   // sigma0: 128 -> 256, ReLU
+        }
+        ConvHook<false, 4, NL == 2> c1{bb, 0.0f};
+        layer<N, 1>(cx, none, ba, c1);                        // sigma1: 256 -> (sigma, geo32), tiles -> bb[0..3]
+        if constexpr (NL == 2) {
+            if (h == 0 && live) {
+                float sg = c1.row0;
+                if (in.keep && !in.keep[q]) sg = 0.0f;        // raw_le[~keep, -1] = 0 (LeRFRenderer.cpp:22-23)
+                in.sigma[q] = sg;
+            }
+        } else {
+            ConvHook<true, 16> c2{ba, 0.0f};
+            {
+                half8 xin[8];
+                load_x(xin);
+                layer<N, 2>(cx, xin, bb, c2);                 // LE0: cat[geo, in] -> 256, ReLU
+            }
+            SumsqHook ssq;
+            layer<N, 3>(cx, none, ba, ssq);                   // LE1, pass 1: ||h||^2
+            const float tot = ssq.ss + __shfl_xor(ssq.ss, 32);
+            const float wgt = live ? in.weights[q] : 0.0f;
+            ReduceHook red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)EMB : nullptr, r, h};
+            layer<N, 4>(cx, none, ba, red);                   // LE1, pass 2: sum_s w_s h_s / ||h_s||
+        }
+    }
+}
+
+// value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L
+static float wval(const std::vector<float> &hp, int L, int row, int kstep, int h, int j)
+{
+    const size_t off0 = 0, off1 = off0 + (size_t)HID * IN, off2 = off1 + (size_t)(1 + GEO) * HID, off3 = off2 + (size_t)HID * (GEO + IN);
+    auto chained = [](int k, int hh, int jj) { return 32 * (k >> 1) + perm_row(k & 1, hh, jj); };
+    auto natural = [](int k, int hh, int jj) { return 16 * k + 8 * hh + jj; };
+    if (L == 0) return hp[off0 + (size_t)row * IN + natural(kstep, h, j)];
+    if (L == 1) return row < 1 + GEO ? hp[off1 + (size_t)row * HID + chained(kstep, h, j)] : 0.0f;
+    if (L == 2) {
+        if (kstep < 4) {                                   // the two sigma1 tiles: row 0 = sigma (no weight), rows 1..32 = geo
+            const int src = chained(kstep, h, j);
+            return (src >= 1 && src <= GEO) ? hp[off2 + (size_t)row * (GEO + IN) + (src - 1)] : 0.0f;
+        }
+        return hp[off2 + (size_t)row * (GEO + IN) + GEO + natural(kstep - 4, h, j)];
+    }
+    return hp[off3 + (size_t)row * HID + chained(kstep, h, j)];
+}
+
+}  // namespace lerf
+
+using namespace lerf;
+
+static bool lerf_mfma_supported(const nrf_mlp_small_desc &d)
+{
+    return d.input_ch == IN && d.num_layers == 2 && d.hidden_dim == HID && d.geo_feat_dim == GEO && d.hidden_dim_color == EMB;
+}
+
+int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+{
+    if (!lerf_mfma_supported(m->small)) return NRF_OK;
+    std::vector<_Float16> img;
+    img.reserve((size_t)IMAGE_FRAGS * 512);
+    using N = Net<5>;
+    for (int L = 0; L < 4; L++)
+        for (int tile = 0; tile < N::tiles(L); tile++)
+            for (int k = 0; k < N::ks(L); k++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(hp, L, tile * 32 + (lane & 31), k, lane >> 5, j));
+    if (img.size() != (size_t)IMAGE_FRAGS * 512) { set_error("internal: LeRF weight image has %zu halves, expected %zu", img.size(), (size_t)IMAGE_FRAGS * 512); return NRF_ERR_INVALID_ARG; }
+    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }
+    m->packed_f16_bytes = img.size() * sizeof(_Float16);
+    NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
+    NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));
+    return NRF_OK;
+}
+
+template <int NL>
+static int launch_lerf(const nrf_mlp *m, const Args &a, int64_t p, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * MAXF * 1024;
+    const int64_t nblocks = ceil_div(p, NBLK);
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 8-wave workgroup per CU (216 VGPRs: two waves per SIMD)
+    hipLaunchKernelGGL((k_lerf_mfma<NL>), dim3(grid), dim3(64 * NW), lds, st, p, a, reinterpret_cast<const lerf::half8 *>(m->d_packed_f16));
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_lerf_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_LERF && m->d_packed_f16 != nullptr; }
+
+int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream)
+{
+    NRF_CHECK_ARG(m && d_x && d_sigma && p >= 0, "nrf_lerf_sigma: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_sigma: feature rows must be 16-byte aligned");
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
+    lerf::Args a{d_x, lerf::IN, nullptr, d_keep, d_sigma, nullptr, 32};
+    return launch_lerf<2>(m, a, p, as_stream(stream));
+}
+
+int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(m && d_x && d_weights && d_out && n >= 0 && s >= 1, "nrf_lerf_render_embedding: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_render_embedding: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_render_embedding: feature rows must be 16-byte aligned");
+    if (n == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    NRF_HIP(hipMemsetAsync(d_out, 0, (size_t)n * lerf::EMB * sizeof(float), st));
+    ProfScope prof(NRF_PROF_MLP, st);
+    lerf::Args a{d_x, lerf::IN, d_weights, nullptr, nullptr, d_out, s};
+    return launch_lerf<5>(m, a, n * (int64_t)s, st);
+}
+
+}  // extern "C"

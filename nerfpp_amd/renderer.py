@@ -402,10 +402,41 @@ class LeRFRenderer:
     embedding.  Stage-composed over the C ABI (generic fp32 kernels); `Relevancy` needs the external RuCLIP text encoder and is
     left to the caller."""
 
-    def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16):
+    def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16, fused=True):
         self.LangEmbedFn, self.Lerf = lang_embed_fn, lerf
         self.LerfPositives, self.LerfNegatives = lerf_positives, lerf_negatives
         self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
+        # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
+        self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
+
+    def _sigma_fused(self, pts):
+        """sigma_le [N,S] (keep-masked) and the hash features [N*S, in] of the sample points, sigma net on the matrix cores."""
+        n, s = pts.shape[0], pts.shape[1]
+        x, keep = self.LangEmbedFn.forward(pts.reshape(-1, 3))
+        ku8 = keep.to(torch.uint8)
+        sig = torch.empty((n, s), device=pts.device, dtype=torch.float32)
+        L.check(L.lib().nrf_lerf_sigma(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
+        return sig, x
+
+    def _weights_from_sigma(self, sig, z, rays_d):
+        n, s = sig.shape
+        o = LeRFRendererOutputs(WeightsLE=torch.empty((n, s), device=sig.device), DepthMapLE=torch.empty((n,), device=sig.device),
+                                DispMapLE=torch.empty((n,), device=sig.device), AccMapLE=torch.empty((n,), device=sig.device))
+        L.check(L.lib().nrf_raw2weights(_ptr(sig), 1, 0, _ptr(z), _ptr(rays_d), 3, C.c_int64(n), s, _ptr(o.WeightsLE), _ptr(o.DepthMapLE), _ptr(o.DispMapLE),
+                                        _ptr(o.AccMapLE), _stream()))
+        return o
+
+    def _render_fused(self, pts, z, rays_d, want_embedding):
+        sig, x = self._sigma_fused(pts)
+        o = self._weights_from_sigma(sig, z, rays_d)
+        if want_embedding:
+            n, s = sig.shape
+            E = self.Lerf.GetLangEmbedDim()
+            acc = torch.empty((n, E), device=pts.device, dtype=torch.float32)
+            L.check(L.lib().nrf_lerf_render_embedding(self.Lerf._m, _ptr(x), _ptr(o.WeightsLE), C.c_int64(n), s, _ptr(acc), _stream()))
+            ones = torch.ones((n, 1), device=pts.device, dtype=torch.float32)
+            o.RenderedLangEmbedding = _clip_embedding(acc, E, E, ones)          # the final normalize of RenderCLIPEmbedding (LeRFRenderer.h:53)
+        return o
 
     def RunLENetwork(self, inputs):
         """LeRFRenderer.cpp:5-25: [N,S,3] -> [N,S,E+1], sigma_le zeroed where the embedder's keep_mask is false."""
@@ -449,9 +480,25 @@ class LeRFRenderer:
         L.check(L.lib().nrf_z_vals(_ptr(rays), stride, C.c_int64(n), _ptr(t), s, int(lin_disp), _ptr(z), _stream()))
         L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
         rays_d = rays[:, 3:6].contiguous()
+        res = LeRFRenderResult()
+        if self.fused and not return_raw and s % 32 == 0 and (ni == 0 or (s + ni) % 32 == 0):
+            # coarse pass: only sigma_le is consumed (the reference also renders a coarse embedding, LeRFRenderer.cpp:139, and drops it)
+            out1 = self._render_fused(pts, z, rays_d, want_embedding=(ni == 0))
+            res.Outputs = out1
+            if ni > 0:
+                u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
+                zf = torch.empty((n, s + ni), device=dev)
+                L.check(L.lib().nrf_fine_depths(_ptr(z), _ptr(out1.WeightsLE), C.c_int64(n), s, _ptr(u), ni, ATEN_SUM_VEC, _ptr(zf), _stream()))
+                ptsf = torch.empty((n, s + ni, 3), device=dev)
+                L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(zf), C.c_int64(n), s + ni, _ptr(ptsf), _stream()))
+                res.Outputs = self._render_fused(ptsf, zf, rays_d, want_embedding=True)
+                res.Extras["z_fine"] = zf
+            res.Extras["z_coarse"] = z
+            if not return_weights:
+                res.Outputs.WeightsLE = None; res.Outputs.RenderedLangEmbedding = None      # LeRFRenderer.cpp:180-185
+            return res
         raw = self.RunLENetwork(pts)
         out1 = self.RawToLEOutputs(raw, z, rays_d, E)
-        res = LeRFRenderResult()
         res.Outputs = out1 if ni == 0 else None        # (the reference leaves Outputs undefined when n_importance == 0; the coarse ones are returned here)
         if ni > 0:
             u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)

@@ -13,7 +13,7 @@ lerf = M.LeRF(32, 2, 256, 768, 128, "lang_model", params=blob)
 r = R.LeRFRenderer(e, lerf)
 K = S.lego_K(800, 800); c2w = S.pose_spherical(40.0, -30.0, 4.0)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-p = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=1600, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=False, ThinRay=True, BoundingBox=bbox)
+p = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=32768, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=False, ThinRay=True, BoundingBox=bbox)
 r.Render(800, 800, K, p, c2w=c2w, row0=400, rows=1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 res = r.Render(800, 800, K, p, c2w=c2w, row0=400, rows=rows)
