@@ -274,7 +274,33 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
         out.append(train_step_measurement(args, scene, L))
     except Exception as e:
         out.append(dict(workload="hashnerf_train_step", error=str(e)))
+    try:
+        out.append(lerf_measurement(scene, K, c2w))
+    except Exception as e:
+        out.append(dict(workload="lerf_lego800_64+128", error=str(e)))
     return out
+
+
+def lerf_measurement(scene, K, c2w, rows=200):
+    """BASELINE config 4: the LeRF language-embedding render pass (CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768, main.cpp:203-213)
+    on a 200-row band of the 800x800 frame (the 8-feature fp32 hash features of a chunk are 512 B per sample point), 64+128 samples."""
+    import torch
+    from nerfpp_amd import renderer as R
+    sc = scene.make_lerf_scene()
+    p = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=32768, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True,
+                           BoundingBox=sc["bbox"])
+    r = sc["renderer"]
+    r.Render(H, W, K, p, c2w=c2w, row0=0, rows=41)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = r.Render(H, W, K, p, c2w=c2w, row0=(H - rows) // 2, rows=rows)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = rows * W
+    emb = res.Outputs.RenderedLangEmbedding
+    return dict(workload="lerf_lego800_64+128", baseline_config=4, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt * H / rows,
+                fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
+                arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; generic CuHash F=8 encode (fp32 features)")
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5):

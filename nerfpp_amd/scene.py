@@ -137,6 +137,29 @@ def make_classic_scene(multires=10, multires_views=4, seed=7000, alpha_scale=40.
     return dict(renderer=NeRFRenderer(emb, dirs, mlp), embedder=emb, embeddirs=dirs, mlp=mlp, mlp_blob=blob, bbox=np.asarray(bbox, np.float32))
 
 
+def make_lerf_scene(n_levels=16, n_feat=8, log2_t=19, base=16, finest=1024, num_layers=2, hidden=256, geo=32, embed=768, seed=311, table_amp=0.5,
+                    sigma_scale=20.0, bbox=LEGO_BBOX):
+    """LeRF render pass (BASELINE config 4, the dimensions of main.cpp:203-213): CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768."""
+    from .modules import LeRF
+    from .renderer import LeRFRenderer
+    from . import synth
+    emb = CuHashEmbedder("lang_embedder", bbox, n_levels, n_feat, log2_t, base, finest)
+    primes = np.array(CU_PRIMES[:3 * n_levels], np.int32)
+    emb.set_primes(primes)
+    table = synth.synth_sym(seed, (n_levels * (1 << log2_t) * n_feat,), np.float32(table_amp))
+    emb.set_table(table)
+    in_ch = n_levels * n_feat
+    shapes = []
+    for l in range(num_layers):
+        shapes.append((f"sigma_le_net_{l}", (1 + geo) if l == num_layers - 1 else hidden, in_ch if l == 0 else hidden, False))
+    for l in range(num_layers):
+        shapes.append((f"le_net_{l}", embed if l == num_layers - 1 else hidden, (geo + in_ch) if l == 0 else hidden, False))
+    params = synth_linear_stack(shapes, seed + 1000, 1.6, 0.0, {f"sigma_le_net_{num_layers - 1}": sigma_scale})
+    blob = np.concatenate([a.reshape(-1) for _, a in params])
+    lerf = LeRF(geo, num_layers, hidden, embed, in_ch, "lang_model", params=blob)
+    return dict(renderer=LeRFRenderer(emb, lerf), embedder=emb, lerf=lerf, table=table, blob=blob, primes=primes, bbox=np.asarray(bbox, np.float32))
+
+
 def psnr(a, b):
     """-10*log10(mse) (NeRFExecutor.h:893)."""
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
