@@ -14,4 +14,132 @@ int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int va
 
 constexpr int HASH_LM_DEFAULT_VARIANT = 0;
 
+// ---------------------------------------------------------------------------------------------------
+// device-side lookup of the level-major encode kernel (hash_fast.hip).  The level parameters travel in a struct so that a kernel whose
+// lanes work on DIFFERENT levels can use the same code: that was tried as a fused hash + NeRFSmall kernel (each lane looks up exactly the
+// 8 levels its layer-0 MFMA fragment holds; no feature buffer) and REJECTED -- at the 2-3 waves per SIMD the MLP's registers allow, the
+// gathers lose the memory-level parallelism the stand-alone kernel gets from 8 waves per SIMD: 30.9 ms per frame against 11.5 + 5.5.
+// ---------------------------------------------------------------------------------------------------
+struct PointPrep {
+    float q[3];     // (clamp(x) - min) / (max - min), level independent (CuHashEmbedder.cu:44-46 before * mul)
+    bool keep;
+};
+
+__device__ __forceinline__ PointPrep prep_point(const HashParams &hp, const F3 &pt)
+{
+    PointPrep r;
+    const float x[3] = {pt.x, pt.y, pt.z};
+    r.keep = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);
+        r.keep = r.keep && (x[a] == c);
+        r.q[a] = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]);
+    }
+    return r;
+}
+
+// Everything a lookup needs to know about its level (wave-uniform in the encode kernel: scalar registers).
+struct LevelParams {
+    float mul, bias[3];
+    int64_t dense_off;          // >= 0: baked dense image (offset in 16-byte quads), -1: hashed table
+    uint32_t nby, dz;
+    uint32_t pa, pb, pc, lsz;
+    int32_t local_idx;
+};
+
+__device__ __forceinline__ LevelParams level_params(const HashParams &hp, int l)
+{
+    LevelParams p;
+    p.mul = hp.level_scale[l];
+    p.bias[0] = hp.bias[l * 3]; p.bias[1] = hp.bias[l * 3 + 1]; p.bias[2] = hp.bias[l * 3 + 2];
+    p.dense_off = hp.dense_off[l];
+    p.nby = (uint32_t)hp.dense_nby[l]; p.dz = (uint32_t)hp.dense_nbz[l];
+    p.pa = hp.primes[l * 3 + 0]; p.pb = hp.primes[l * 3 + 1]; p.pc = hp.primes[l * 3 + 2];
+    p.lsz = hp.local_size[l];
+    p.local_idx = hp.local_idx[l];
+    return p;
+}
+
+__device__ __forceinline__ LevelParams select_params(bool second, const LevelParams &a, const LevelParams &b)
+{
+    LevelParams p;
+    p.mul = second ? b.mul : a.mul;
+#pragma unroll
+    for (int i = 0; i < 3; i++) p.bias[i] = second ? b.bias[i] : a.bias[i];
+    p.dense_off = second ? b.dense_off : a.dense_off;
+    p.nby = second ? b.nby : a.nby; p.dz = second ? b.dz : a.dz;
+    p.pa = second ? b.pa : a.pa; p.pb = second ? b.pb : a.pb; p.pc = second ? b.pc : a.pc;
+    p.lsz = second ? b.lsz : a.lsz;
+    p.local_idx = second ? b.local_idx : a.local_idx;
+    return p;
+}
+
+// One (point, level): the voxel's 8 table values, then the fp32 blend in the reference's order.
+// Dense ("baked") image of a level: for every lattice vertex (x,y,z), 0 <= x,y,z < D = floor(mul)+2, the QUAD of table values of
+// (x,y,z), (x,y,z+1), (x+1,y,z), (x+1,y,z+1), copied out of the hashed table once at model load (16 bytes: four half2).  A voxel's
+// 8 corners are then 2 sixteen-byte loads (rows y and y+1) instead of 8 four-byte gathers into 8 lines.  Vertices are grouped in
+// 4x4 (x,y) tiles (256 B at one z), tiles of one (x,y) column stacked along z, so the two loads of a lookup mostly share a line
+// and consecutive samples along a ray walk adjacent ones.  Each lookup returns the same table entries the hash would have selected:
+// outputs are bit-identical.  Costs 4x the vertices in memory (4.4 GB at 16..512) -- HBM is 288 GB.
+// Measured ladder (ms per 800x800x256 frame, same kernel otherwise): hashed table 30.6 -> (z,z+1) pairs, 4 x 8-B loads 14.8 ->
+// quads, 2 x 16-B loads 13.6 -> all 8 corners in one 32-B entry 22.2 (REJECTED: 8.8 GB of image, every lookup its own line, the kernel
+// turns HBM-bound).  The kernel sits where the vector-memory request rate and the line traffic balance.
+template <int GATHER>
+__device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, const LevelParams &lp, __amdgpu_buffer_rsrc_t rsrc)
+{
+    float fr[3];
+    uint32_t pos[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float q = pp.q[a] * lp.mul;
+        q = q + lp.bias[a];
+        const float fl = floorf(q);
+        pos[a] = (uint32_t)fl;
+        fr[a] = q - fl;
+    }
+    float acc[2];
+    if (lp.dense_off >= 0) {
+        const uint4 *dp = reinterpret_cast<const uint4 *>(hp.dense) + lp.dense_off;
+        const uint32_t nby = lp.nby, dz = lp.dz;
+        const float a = fr[0], b = fr[1], c = fr[2];
+        const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
+        const uint32_t x0 = pos[0], y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
+        const uint32_t tx0 = (x0 >> 2) * nby, ty0 = y0 >> 2, ty1 = y1 >> 2;
+        const uint32_t ix0 = (x0 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
+        const uint4 q0 = dp[(((tx0 + ty0) * dz + z) << 4) | ix0 | iy0];      // corners (x..x+1, y0, z..z+1)
+        const uint4 q1 = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];      // corners (x..x+1, y1, z..z+1)
+        // blend order k = 4dx + 2dy + dz; a quad holds (dx,dz) = (0,0),(0,1),(1,0),(1,1)
+        const uint32_t wv[8] = {q0.x, q0.y, q1.x, q1.y, q0.z, q0.w, q1.z, q1.w};
+        // both features of a corner go through the same multiply and the same add: float2 vector arithmetic lets the compiler use the
+        // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, one rounding per lane and op: bit-identical to the scalar form)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v[8];
+        float ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            __half2 hv; __builtin_memcpy(&hv, &wv[k], 4);
+            const float2 t = __half22float2(hv);
+            v[k] = f32x2{t.x, t.y};
+            const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
+            ws[k] = wx * wy * wz;
+        }
+        f32x2 s2 = v[0] * ws[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) s2 = s2 + v[k] * ws[k];
+        acc[0] = s2.x; acc[1] = s2.y;
+    } else {
+        const __half *fp = reinterpret_cast<const __half *>(hp.table) + lp.local_idx;
+        cu_blend<2, GATHER>(fp, pos, fr, lp.pa, lp.pb, lp.pc, lp.lsz, acc, rsrc, (uint32_t)lp.local_idx * 2u);
+    }
+    return __halves2half2(__float2half_rn(acc[0]), __float2half_rn(acc[1]));
+}
+
+template <int GATHER>
+__device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, int l, __amdgpu_buffer_rsrc_t rsrc)
+{
+    return encode_level<GATHER>(hp, pp, level_params(hp, l), rsrc);
+}
+
+
 }  // namespace nrf
