@@ -339,6 +339,9 @@ NRF_API int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t c
  * argument to [-100, 5] (CustomOps.cpp:11-15). */
 NRF_API int nrf_raw2outputs_backward(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
                                      const float *d_g_rgb, float *d_g_raw, void *stream);
+/* ... of a forward that ran with raw_noise_std > 0: d_noise [n,s] are the same normal draws (nrf_rng_fill(seed, NRF_RNG_NOISE_FINE, ...)). */
+NRF_API int nrf_raw2outputs_backward_noise(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c,
+                                           int white_bkgr, const float *d_noise, float noise_std, const float *d_g_rgb, float *d_g_raw, void *stream);
 /* d/d sigma = 0 where keep is false: the backward of `outputs_flat[~keep_mask, -1] = 0` (NeRFRenderer.h:187-188). */
 NRF_API int nrf_mask_sigma_grad(const uint8_t *d_keep, int64_t p, int c, float *d_g_raw, void *stream);
 

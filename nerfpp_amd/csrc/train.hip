@@ -52,7 +52,8 @@ __device__ __forceinline__ double wave_incl_scan_d(double v, int lane)
 
 __global__ void __launch_bounds__(64 * BW_RAYS)
 k_raw2outputs_bwd(int64_t n, int s, int c, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs, int d_stride,
-                  const float *__restrict__ g_rgb, float *__restrict__ g_raw, float *__restrict__ lt_scratch /* [n, s] exclusive log-transmittance */)
+                  const float *__restrict__ g_rgb, float *__restrict__ g_raw, float *__restrict__ lt_scratch /* [n, s] exclusive log-transmittance */,
+                  const float *__restrict__ noise, float noise_std)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * BW_RAYS + (threadIdx.x >> 6);
@@ -71,7 +72,9 @@ k_raw2outputs_bwd(int64_t n, int s, int c, int white, const float *__restrict__ 
             const float *r = raw + (ray * s + j) * c;
             float dist = (j + 1 < s) ? (zr[j + 1] - zr[j]) : 1e10f;
             dist = dist * nrm;
-            const float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            float sr = r[3];
+            if (noise) sr = sr + noise[ray * s + j] * noise_std;     // the forward's sigma + randn * raw_noise_std (NeRFRenderer.h:251-252)
+            const float sig = sr > 0.0f ? sr : 0.0f;
             const float alpha = -nrf_expf(-sig * dist) + 1.0f;
             const float om = 1.0f - alpha;
             lg = nrf_logf(om > 1e-10f ? om : 1e-10f);
@@ -96,6 +99,7 @@ k_raw2outputs_bwd(int64_t n, int s, int c, int white, const float *__restrict__ 
             dist = (j + 1 < s) ? (zr[j + 1] - zr[j]) : 1e10f;
             dist = dist * nrm;
             sraw = r[3];
+            if (noise) sraw = sraw + noise[ray * s + j] * noise_std;
             const float sig = sraw > 0.0f ? sraw : 0.0f;
             x = -sig * dist;
             alpha = -nrf_expf(x) + 1.0f;
@@ -346,13 +350,19 @@ int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t count, fl
 int nrf_raw2outputs_backward(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
                              const float *d_g_rgb, float *d_g_raw, void *stream)
 {
+    return nrf_raw2outputs_backward_noise(d_raw, d_z, d_dirs, d_stride, n, s, c, white_bkgr, nullptr, 0.0f, d_g_rgb, d_g_raw, stream);
+}
+
+int nrf_raw2outputs_backward_noise(const float *d_raw, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, int c, int white_bkgr,
+                                   const float *d_noise, float noise_std, const float *d_g_rgb, float *d_g_raw, void *stream)
+{
     NRF_CHECK_ARG(d_raw && d_z && d_dirs && d_g_rgb && d_g_raw && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs_backward: bad argument");
     if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
     float *lt = nullptr;
     NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&lt), (size_t)n * s * sizeof(float), st));
     hipLaunchKernelGGL(k_raw2outputs_bwd, dim3((unsigned)ceil_div(n, BW_RAYS)), dim3(64 * BW_RAYS), 0, st, n, s, c, white_bkgr, d_raw, d_z, d_dirs, d_stride, d_g_rgb,
-                       d_g_raw, lt);
+                       d_g_raw, lt, d_noise, noise_std);
     NRF_LAUNCH_CHECK();
     NRF_HIP(hipFreeAsync(lt, st));
     return NRF_OK;

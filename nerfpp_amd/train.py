@@ -15,7 +15,7 @@ import torch
 
 from . import _lib as L
 from .modules import _HashBase, CuHashEmbedder, NeRFSmall, _ptr, _stream, _dev_f32
-from .renderer import NeRFRenderer, NeRFRenderParams
+from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecondition, TangentScatter
 
 
 class Trainer:
@@ -46,8 +46,10 @@ class Trainer:
             self._ws = torch.empty((int(nbytes),), device="cuda", dtype=torch.uint8)
         return self._ws
 
-    def backward(self, res, target, n_samples_out, white_bkgr):
-        """loss + gradients of one rendered batch (fills self.g_table / self.g_blob); returns device tensor [huber, mse]."""
+    def backward(self, res, target, n_samples_out, white_bkgr, params=None, cone_angle=None):
+        """loss + gradients of one rendered batch (fills self.g_table / self.g_blob); returns device tensor [huber, mse].
+        `params` (the NeRFRenderParams of the forward) tells which stochastic branches ran: their counter-based draws are regenerated here
+        (same seed, stream and element index, include/nrf_rng.h), so the backward sees exactly the forward's sample points and densities."""
         lib = L.lib()
         rays = res.Extras["rays_flat"]
         n, stride = rays.shape
@@ -59,10 +61,22 @@ class Trainer:
         z = res.Extras["z_fine"] if "z_fine" in res.Extras else res.Extras["z_coarse"]
         assert raw.shape == (n, s, 4) and z.shape == (n, s)
         g_raw = torch.empty_like(raw)
-        L.check(lib.nrf_raw2outputs_backward(_ptr(raw), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), s, 4, int(white_bkgr), _ptr(g_rgb), _ptr(g_raw),
-                                             _stream()))
+        p = params
+        seed = int(p.Seed) if p is not None else 0
+        fine = "z_fine" in res.Extras
+        noise_std = float(p.RawNoiseStd) if p is not None else 0.0
+        noise = RngFill(seed, L.NRF_RNG_NOISE_FINE if fine else L.NRF_RNG_NOISE_COARSE, 0, n * s, normal=True, device=rays.device) if noise_std > 0 else None
+        L.check(lib.nrf_raw2outputs_backward_noise(_ptr(raw), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), s, 4, int(white_bkgr), _ptr(noise),
+                                                   C.c_float(noise_std), _ptr(g_rgb), _ptr(g_raw), _stream()))
         pts = torch.empty((n * s, 3), device=rays.device)
         L.check(lib.nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
+        if p is not None and fine and p.StochasticPreconditioningAlpha > 0:          # NeRFRenderer.h:433-443 (fine pass only)
+            pn = RngFill(seed, L.NRF_RNG_PRECOND, 0, n * s * 3, normal=True, device=rays.device)
+            pts = StochasticPrecondition(pts, pn, float(p.StochasticPreconditioningAlpha), p.BoundingBox)
+        if cone_angle is not None:                                                  # TangentScatter, NeRFRenderer.h:307-362
+            ur = RngFill(seed, L.NRF_RNG_R_FINE if fine else L.NRF_RNG_R_COARSE, 0, n * s, device=rays.device)
+            ut = RngFill(seed, L.NRF_RNG_THETA_FINE if fine else L.NRF_RNG_THETA_COARSE, 0, n * s, device=rays.device)
+            pts = TangentScatter(pts.reshape(n, s, 3), z, float(cone_angle), rays[:, 3:6].contiguous(), p.BoundingBox if p is not None else None, ur, ut).reshape(n * s, 3)
         emb, keep = self.embedder.forward(pts)
         dirs, _ = self.embeddirs.forward(rays[:, 8:11].contiguous())
         x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
@@ -78,15 +92,16 @@ class Trainer:
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
         return loss_mse
 
-    def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams):
+    def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams, cone_angle=None):
         """Optimizer->zero_grad(); Render; huber; backward; Optimizer->step() (NeRFExecutor.h:866-985)."""
         p = render_params
-        if p.RawNoiseStd > 0 or p.StochasticPreconditioningAlpha > 0 or not p.ThinRay or p.Perturb > 0:
-            raise L.NrfError("Trainer.step: the backward pass is built for the deterministic sample set (RawNoiseStd = 0, no preconditioning, ThinRay)")
+        if not p.ThinRay and cone_angle is None:
+            raise L.NrfError("Trainer.step: ThinRay = False needs the batch's cone_angle (GetRayBatch / GetRays)")
         p.ReturnRaw, p.KeepIntermediates = True, True
-        res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, None))
+        cone = None if p.ThinRay else cone_angle
+        res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))
         s_out = p.NSamples + p.NImportance
-        loss_mse = self.backward(res, target, s_out, p.WhiteBkgr)
+        loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
         self.t += 1
         b1, b2 = self.betas
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):

@@ -387,6 +387,15 @@ def raw2outputs_backward(raw, z, d, g_rgb, white_bkgr=False):
     return out
 
 
+def raw2outputs_backward_noise(raw, z, d, g_rgb, noise, noise_std, white_bkgr=False):
+    raw = _f(raw); z = _f(z); d = _f(d); g_rgb = _f(g_rgb); noise = _f(noise)
+    n, s, c = raw.shape
+    out = np.empty_like(raw)
+    lib().orc_raw2outputs_backward_noise(_p(raw), _p(z), _p(d), C.c_int64(n), C.c_int(s), C.c_int(c), C.c_int(int(white_bkgr)), _p(noise), C.c_float(noise_std),
+                                         _p(g_rgb), _p(out))
+    return out
+
+
 def mlp_small_backward(params, x, g_out, in_ch, in_views, n_layers=3, hidden=64, geo=15, n_layers_c=4, hidden_c=64):
     params = _f(params); x = _f(x); g_out = _f(g_out)
     g_params = np.zeros_like(params); g_x = np.empty((x.shape[0], in_ch), np.float32)

@@ -1262,8 +1262,24 @@ ORC_API void orc_huber_loss(const float *pred, const float *target, int64_t coun
 /* Backward of RawToOutputs (NeRFRenderer.h:199-282) w.r.t. raw, given d loss / d rgb_map [n,3] (the only output the
  * training loss reads).  TruncExp::backward = grad * exp(clamp(x, -100, 5)) (CustomOps.cpp:11-15); clamp_min passes the
  * gradient where 1 - alpha >= 1e-10; relu where sigma > 0. */
+static void raw2outputs_backward_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                                       const float *noise, float noise_std, const float *g_rgb, float *g_raw);
+
 ORC_API void orc_raw2outputs_backward(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
                                       const float *g_rgb /*[n,3]*/, float *g_raw /*[n,s,c]*/)
+{
+    raw2outputs_backward_impl(raw, z, d, n, s, c, white_bkgr, NULL, 0.0f, g_rgb, g_raw);
+}
+
+/* ... of a forward with raw_noise_std > 0: the density that went through relu / alpha was sigma + noise*std (NeRFRenderer.h:251-252) */
+ORC_API void orc_raw2outputs_backward_noise(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                                            const float *noise, float noise_std, const float *g_rgb, float *g_raw)
+{
+    raw2outputs_backward_impl(raw, z, d, n, s, c, white_bkgr, noise, noise_std, g_rgb, g_raw);
+}
+
+static void raw2outputs_backward_impl(const float *raw, const float *z, const float *d, int64_t n, int s, int c, int white_bkgr,
+                                       const float *noise, float noise_std, const float *g_rgb, float *g_raw)
 {
     OMP_FOR
     for (int64_t i = 0; i < n; i++) {
@@ -1276,7 +1292,9 @@ ORC_API void orc_raw2outputs_backward(const float *raw, const float *z, const fl
             const float *r = raw + (i * s + j) * c;
             float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
             dist = dist * nrm;
-            const float sig = r[3] > 0.0f ? r[3] : 0.0f;
+            float sraw = r[3];
+            if (noise) sraw = sraw + noise[i * s + j] * noise_std;
+            const float sig = sraw > 0.0f ? sraw : 0.0f;
             x_[j] = -sig * dist;
             alpha[j] = -nrf_expf(x_[j]) + 1.0f;
             lt[j] = tprev;
@@ -1305,7 +1323,9 @@ ORC_API void orc_raw2outputs_backward(const float *raw, const float *z, const fl
             const float g_x = -g_alpha * nrf_expf(cx);
             float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
             dist = dist * nrm;
-            g[3] = (r[3] > 0.0f) ? -g_x * dist : 0.0f;
+            float sraw = r[3];
+            if (noise) sraw = sraw + noise[i * s + j] * noise_std;
+            g[3] = (sraw > 0.0f) ? -g_x * dist : 0.0f;
         }
     }
 }

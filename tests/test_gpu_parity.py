@@ -983,3 +983,47 @@ def test_lerf_fused_matrix_core_path(api, O, manifest):
     assert np.median(cos) > 0.99999 and (cos > 0.999).mean() > 0.85 and cos.min() > 0.9, (np.median(cos), (cos > 0.999).mean(), cos.min())
     da = np.abs(host(a.Outputs.AccMapLE) - host(b.Outputs.AccMapLE))
     assert np.median(da) < 1e-3 and (da < 5e-3).mean() > 0.9, (np.median(da), (da < 5e-3).mean())
+
+
+def test_raw2outputs_backward_with_noise_vs_oracle(api, O):
+    import ctypes as C
+    g = load_golden("train_hash")
+    rays = O.pack_rays(g["rays_o"], g["rays_d"], g["bbox"])
+    rng = np.random.RandomState(2)
+    noise = rng.standard_normal((64, 64)).astype(np.float32); g_rgb = (rng.standard_normal((64, 3)) * 1e-2).astype(np.float32)
+    raw, z, d, nz, gr = dev(g["s1_fine_raw"]), dev(g["s1_fine_z"]), dev(rays[:, 3:6]), dev(noise), dev(g_rgb)
+    out = torch.empty_like(raw)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    api.L.check(api.L.lib().nrf_raw2outputs_backward_noise(P(raw), P(z), P(d), 3, C.c_int64(64), 64, 4, 1, P(nz), C.c_float(0.7), P(gr), P(out), None))
+    ref = O.raw2outputs_backward_noise(g["s1_fine_raw"], g["s1_fine_z"], rays[:, 3:6], g_rgb, noise, 0.7, white_bkgr=True)
+    assert_close(host(out), ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max())
+    plain = O.raw2outputs_backward(g["s1_fine_raw"], g["s1_fine_z"], rays[:, 3:6], g_rgb, white_bkgr=True)
+    assert np.abs(ref - plain).max() > 1e-3 * np.abs(plain).max(), "the noise must matter"
+
+
+def test_trainer_with_stochastic_branches_sees_the_forwards_samples(api):
+    """RawNoiseStd, stochastic preconditioning and cone rays during training (FillRenderParams, NeRFExecutor.h:405-411): the backward
+    regenerates the forward's counter-based draws.  Check: the features recomputed for the backward reproduce the forward's raw output
+    exactly (fp32 mode), and a few steps reduce the loss."""
+    from nerfpp_amd.train import Trainer
+    sc = api.S.make_hash_scene(mode="cu", log2_t=14, seed=777, table_amp=1e-2, sigma_scale=2.0)
+    K = api.S.lego_K(32, 32); c2w = api.S.pose_spherical(20.0, -30.0, 4.0)
+    o, d, cone = api.R.GetRays(32, 32, K, c2w)
+    o = o.reshape(-1, 3); d = d.reshape(-1, 3)
+    tgt = torch.rand((1024, 3), device="cuda") * 0.2 + 0.4
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-3)
+    rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=400, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=False, RawNoiseStd=0.5,
+                                StochasticPreconditioningAlpha=0.01, BoundingBox=api.S.LEGO_BBOX, Precision=api.L.NRF_PREC_F32, Seed=123)
+    rp.ReturnRaw, rp.KeepIntermediates = True, True
+    res = tr.renderer.Render(0, 0, None, rp, rays=(o, d, cone))
+    tr.backward(res, tgt, 64, False, params=rp, cone_angle=cone)
+    raw_again = tr.mlp.forward(tr.last["x"], api.L.NRF_PREC_F32)
+    keep = tr.embedder.forward(tr.last["pts"])[1]
+    raw_again[~keep, 3] = 0
+    assert_exact(host(raw_again), host(res.Raw).reshape(-1, 4), "backward's recomputed points/features == the forward's (cone + preconditioning draws regenerated)")
+    losses = []
+    for it in range(12):
+        rp.Seed = 1000 + it
+        lm, _ = tr.step(o, d, tgt, rp, cone_angle=cone)
+        losses.append(float(host(lm)[0]))
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.8 * np.mean(losses[:3]), losses
