@@ -1027,3 +1027,41 @@ def test_trainer_with_stochastic_branches_sees_the_forwards_samples(api):
         lm, _ = tr.step(o, d, tgt, rp, cone_angle=cone)
         losses.append(float(host(lm)[0]))
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < 0.8 * np.mean(losses[:3]), losses
+
+
+def test_render_from_reference_checkpoint(api, O, manifest):
+    """N3 end to end: a checkpoint written by the reference's torch::save (tests/golden/ckpt) is loaded, its tensors handed to the C ABI in
+    checkpoint order, and the render equals the oracle render of the same weights bit for bit (fp32 mode)."""
+    import os
+    from conftest import GOLDEN
+    from nerfpp_amd import checkpoint as CK
+    ck = CK.LoadCheckpoint(os.path.join(GOLDEN, "ckpt"))
+    g = load_golden("train_hash")
+    e = api.M.HashEmbedder("embedder", g["bbox"], 4, 2, 12, 16, 128)
+    e.set_table(CK.blob(ck["embedder"]))
+    m = api.M.NeRFSmall(3, 64, 15, 3, 64, False, 3, 64, 8, 16, "model", params=CK.blob(ck["model"]))
+    r = api.R.NeRFRenderer(e, api.M.SHEncoder("embeddirs", 3, 4), m)
+    rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=64, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                                BoundingBox=g["bbox"], Precision=api.L.NRF_PREC_F32)
+    res = r.Render(0, 0, None, rp, rays=(dev(g["rays_o"]), dev(g["rays_d"]), None))
+    dref = np.abs(host(res.Outputs.RGBMap) - g["s1_rgb"])      # vs the reference's own render of these weights (32+32 samples: a fine sample in another
+    assert np.median(dref) < 1e-5 and (dref < 1e-4).mean() > 0.9, (np.median(dref), (dref < 1e-4).mean())      # CDF bin is worth a few 1e-2 of a pixel)
+    model = O.Model(0, CK.blob(ck["model"]), bbox=g["bbox"], table_f32=CK.blob(ck["embedder"]), L=4, F=2, log2_t=12, base=16, finest=128, n_layers_c=3)
+    oc = O.render_rays(model, host(res.Extras["rays_flat"]), 32, 32, O.linspace(0, 1, 32), O.linspace(0, 1, 32), white_bkgr=False)
+    assert_exact(host(res.Outputs.RGBMap), oc["rgb"], "== oracle on the checkpoint's tensors")
+
+
+def test_lerf_renderer_falls_back_when_samples_are_not_multiples_of_32(api, manifest):
+    Lv, F, T = 16, 8, 12
+    e = api.M.CuHashEmbedder("lang_embedder", api.S.LEGO_BBOX, Lv, F, T, 16, 128)
+    e.set_table(synth.synth_sym(311, (Lv * (1 << T) * F,), np.float32(0.5))); e.set_primes(np.array(api.S.CU_PRIMES[:3 * Lv], np.int32))
+    lerf = api.M.LeRF(32, 2, 256, 768, 128, "lang_model", params=synth.blob_from_manifest(manifest["lerf"]))
+    r = api.R.LeRFRenderer(e, lerf)
+    K = api.S.lego_K(6, 6); c2w = api.S.pose_spherical(40.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=20, NImportance=17, Chunk=36, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=api.S.LEGO_BBOX)
+    res = r.Render(6, 6, K, p, c2w=c2w)               # 37 samples per ray: the stage-composed path
+    assert host(res.Outputs.WeightsLE).shape == (36, 37) and np.isfinite(host(res.Outputs.RenderedLangEmbedding)).all()
+    with pytest.raises(api.L.NrfError, match="multiple of 32"):
+        import ctypes as C
+        x = torch.zeros((37, 128), device="cuda"); w = torch.zeros((37,), device="cuda"); out = torch.zeros((1, 768), device="cuda")
+        api.L.check(api.L.lib().nrf_lerf_render_embedding(lerf._m, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_int64(1), 37, C.c_void_p(out.data_ptr()), None))
