@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(256) k_linear(int64_t npts, Seg a, Seg b, cons
         float acc[LIN_TP];
 #pragma unroll
         for (int j = 0; j < LIN_TP; j++) acc[j] = 0.0f;
-        for (int k = 0; k < in; k++) {
-            const float w = wt[(size_t)k * out + o];
+        // k ascending, one FMA per (k, point): the order the oracle restates.  Eight k-steps per trip so that their weight loads (one
+        // 4-byte global load per thread and k, the only vector-memory traffic of the loop) are in flight together instead of one at a time.
+        auto kstep = [&](int k, float w) {
             const float4 *xv = reinterpret_cast<const float4 *>(xs + k * LIN_TP);
 #pragma unroll
             for (int q = 0; q < LIN_TP / 4; q++) {
@@ -48,7 +49,16 @@ __global__ void __launch_bounds__(256) k_linear(int64_t npts, Seg a, Seg b, cons
                 acc[q * 4 + 2] = __builtin_fmaf(w, v.z, acc[q * 4 + 2]);
                 acc[q * 4 + 3] = __builtin_fmaf(w, v.w, acc[q * 4 + 3]);
             }
+        };
+        int k = 0;
+        for (; k + 8 <= in; k += 8) {
+            float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w8[u] = wt[(size_t)(k + u) * out + o];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kstep(k + u, w8[u]);
         }
+        for (; k < in; k++) kstep(k, wt[(size_t)k * out + o]);
         const float bo = bias ? bias[o] : 0.0f;
 #pragma unroll
         for (int j = 0; j < LIN_TP; j++) {
@@ -239,7 +249,7 @@ constexpr int GW_PTS = 32;      // points staged per iteration
 // dW[o][i] += sum_pt g[pt][o] * concat(a, b)[pt][i]   (out, in <= 64 per launch tile; 256 threads, a 4x4 register tile each)
 __global__ void __launch_bounds__(256) k_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *__restrict__ dw)
 {
-    __shared__ float gs[GW_PTS][64 + 1], xs[GW_PTS][64 + 1];
+    __shared__ __attribute__((aligned(16))) float gs[GW_PTS][64 + 4], xs[GW_PTS][64 + 4];      // +4: rows stay 16-byte aligned for b128 reads
     const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
     const int to = (threadIdx.x >> 4) * 4, ti = (threadIdx.x & 15) * 4;
     float acc[4][4] = {};
@@ -256,11 +266,10 @@ __global__ void __launch_bounds__(256) k_grad_w(int64_t npts, Seg g, Seg a, Seg 
             gs[j][k] = gv; xs[j][k] = xv;
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll 8
         for (int j = 0; j < GW_PTS; j++) {
-            float gv[4], xv[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { gv[q] = gs[j][to + q]; xv[q] = xs[j][ti + q]; }
+            const float4 g4 = *reinterpret_cast<const float4 *>(&gs[j][to]), x4 = *reinterpret_cast<const float4 *>(&xs[j][ti]);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
