@@ -33,6 +33,116 @@ __global__ void k_bake_dense(HashParams hp, int l, uint32_t dim, int64_t entries
     dst[i] = uint4{row(x, z), row(x, z + 1), row(x + 1, z), row(x + 1, z + 1)};
 }
 
+// ------------------------------------------------------------------------------------------------
+// HashEmbedder (LibTorch) semantics, NeRF.cpp:208-318: fp32 tables [L][2^T][F], floor()ed resolution, int64 hash with the Instant-NGP
+// primes, nested-lerp blend with weights from the UNCLAMPED point.  Same arithmetic, bit for bit, as k_hash_ngp in encode.hip.
+// Dense image: per vertex (x,y,z), 0 <= x,y,z < res + 2, the fp32 feature pairs of (x,y,z), (x,y,z+1), (x+1,y,z), (x+1,y,z+1): 32 bytes,
+// same 4x4 (x,y) tiling as the CuHash image.  Output: level-major fp16 in TWO planes, hi = f16(v) and lo = f16(v - hi): the split-precision
+// MLP consumes both (22 significant bits of the fp32 feature), the plain fp16 MLP only the first.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bake_dense_ngp(HashParams hp, int l, uint32_t dim, int64_t entries, uint4 *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= entries) return;
+    const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
+    const uint32_t w = (uint32_t)(i & 15);
+    const int64_t col = i >> 4;
+    const uint32_t z = (uint32_t)(col % dz), tile = (uint32_t)(col / dz);
+    const uint32_t x = (tile / nby) * 4 + (w >> 2), y = (tile % nby) * 4 + (w & 3);
+    const float *tl = reinterpret_cast<const float *>(hp.table) + (int64_t)l * ((int64_t)1 << hp.log2_t) * 2;
+    const uint32_t hmask = (1u << hp.log2_t) - 1u;
+    auto row = [&](uint32_t xx, uint32_t zz) -> uint2 {
+        if (xx >= dim || y >= dim || zz >= dim) return uint2{0u, 0u};
+        const uint32_t hv = (xx ^ (y * 2654435761u) ^ (zz * 805459861u)) & hmask;
+        return *reinterpret_cast<const uint2 *>(tl + (size_t)hv * 2);
+    };
+    const uint2 a = row(x, z), b = row(x, z + 1), c = row(x + 1, z), d = row(x + 1, z + 1);
+    dst[i * 2] = uint4{a.x, a.y, b.x, b.y};
+    dst[i * 2 + 1] = uint4{c.x, c.y, d.x, d.y};
+}
+
+__device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const float (&x)[3], const float (&xc)[3], int l, float (&acc)[2])
+{
+    float w[3];
+    uint32_t idx[3];
+    const float res = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / res;
+        const float fl = floorf((xc[a] - hp.bbox.mn[a]) / grid);
+        idx[a] = (uint32_t)(int32_t)fl;
+        const float vmin = fl * grid + hp.bbox.mn[a];
+        const float vmax = vmin + grid;
+        w[a] = (x[a] - vmin) / (vmax - vmin);
+    }
+    float2 e[8];
+    if (hp.dense_off[l] >= 0) {                 // wave-uniform
+        const uint4 *dp = reinterpret_cast<const uint4 *>(hp.dense) + hp.dense_off[l] * 2;
+        const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
+        const uint32_t x0 = idx[0], y0 = idx[1], y1 = idx[1] + 1u, z = idx[2];
+        const uint32_t tx0 = (x0 >> 2) * nby, ix0 = (x0 & 3u) << 2;
+        const size_t e0 = (size_t)((((tx0 + (y0 >> 2)) * dz + z) << 4) | ix0 | (y0 & 3u)) * 2;
+        const size_t e1 = (size_t)((((tx0 + (y1 >> 2)) * dz + z) << 4) | ix0 | (y1 & 3u)) * 2;
+        const uint4 q0a = dp[e0], q0b = dp[e0 + 1], q1a = dp[e1], q1b = dp[e1 + 1];
+        auto f2 = [](uint32_t u, uint32_t v) { float2 r; __builtin_memcpy(&r.x, &u, 4); __builtin_memcpy(&r.y, &v, 4); return r; };
+        // corner index c = 4dx + 2dy + dz; a quad holds (dx,dz) = (0,0),(0,1) | (1,0),(1,1)
+        e[0] = f2(q0a.x, q0a.y); e[1] = f2(q0a.z, q0a.w); e[4] = f2(q0b.x, q0b.y); e[5] = f2(q0b.z, q0b.w);
+        e[2] = f2(q1a.x, q1a.y); e[3] = f2(q1a.z, q1a.w); e[6] = f2(q1b.x, q1b.y); e[7] = f2(q1b.z, q1b.w);
+    } else {
+        const float *tl = reinterpret_cast<const float *>(hp.table) + (int64_t)l * ((int64_t)1 << hp.log2_t) * 2;
+        const uint32_t hmask = (1u << hp.log2_t) - 1u;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t cx = idx[0] + ((c >> 2) & 1), cy = idx[1] + ((c >> 1) & 1), cz = idx[2] + (c & 1);
+            const uint32_t hv = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask;
+            e[c] = *reinterpret_cast<const float2 *>(tl + (size_t)hv * 2);
+        }
+    }
+    const float omx = 1.0f - w[0], omy = 1.0f - w[1], omz = 1.0f - w[2];
+    // NeRF.cpp:279-298, per feature: mul, mul, add -- one rounding each (the x and y component are independent chains)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto v2 = [](const float2 &t) { return f32x2{t.x, t.y}; };
+    const f32x2 c00 = v2(e[0]) * omx + v2(e[4]) * w[0];
+    const f32x2 c01 = v2(e[1]) * omx + v2(e[5]) * w[0];
+    const f32x2 c10 = v2(e[2]) * omx + v2(e[6]) * w[0];
+    const f32x2 c11 = v2(e[3]) * omx + v2(e[7]) * w[0];
+    const f32x2 c0 = c00 * omy + c10 * w[1];
+    const f32x2 c1 = c01 * omy + c11 * w[1];
+    const f32x2 o = c0 * omz + c1 * w[2];
+    acc[0] = o.x; acc[1] = o.y;
+}
+
+// feats: plane 0 (hi) at feats, plane 1 (lo) at feats + lo_off (0: not wanted); both [L][pstride] half2
+template <int LPT>
+__global__ void __launch_bounds__(256)
+k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, int64_t lo_off, uint8_t *__restrict__ keep, int level0)
+{
+    const int level = level0 + blockIdx.y * LPT;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const F3 pt = load_point(ps, i < p ? i : p - 1);
+    const float x[3] = {pt.x, pt.y, pt.z};
+    float xc[3];
+    bool kp = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { xc[a] = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]); kp = kp && (x[a] == xc[a]); }
+    __half2 hi[LPT], lo[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; j++) {
+        float acc[2];
+        encode_level_ngp(hp, x, xc, level + j, acc);
+        const __half h0 = __float2half_rn(acc[0]), h1 = __float2half_rn(acc[1]);
+        hi[j] = __halves2half2(h0, h1);
+        lo[j] = __halves2half2(__float2half_rn(acc[0] - __half2float(h0)), __float2half_rn(acc[1] - __half2float(h1)));
+    }
+    if (i >= p) return;
+#pragma unroll
+    for (int j = 0; j < LPT; j++) {
+        feats[(int64_t)(level + j) * pstride + i] = hi[j];
+        if (lo_off) feats[lo_off + (int64_t)(level + j) * pstride + i] = lo[j];
+    }
+    if (level == 0 && keep) keep[i] = kp ? 1 : 0;
+}
+
 // (Re)build the dense image of levels [0, nb) after the table or the primes changed.  nb is chosen by a byte budget.
 int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
 {
@@ -45,29 +155,33 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
     for (int i = 0; i < L * 3; i++) zero_bias = zero_bias && hp.bias[i] == 0.0f;
     int64_t total = 0;
     int nb = 0;
-    if (zero_bias && h->desc.mode == NRF_HASH_CU && h->desc.n_features == 2) {
+    const bool ngp = h->desc.mode == NRF_HASH_NGP;
+    const size_t entry_bytes = ngp ? 32 : 16;
+    if (h->desc.n_features == 2 && (ngp || zero_bias)) {
         for (int l = 0; l < L; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
             const int64_t nbx = (dim + 3) / 4, nby = (dim + 3) / 4;
-            const int64_t entries = nbx * nby * dim * 16;                 // 16-byte (x..x+1, z..z+1) quads
-            if ((size_t)(total + entries) * 16 > budget_bytes || entries >= ((int64_t)1 << 31)) break;
+            const int64_t entries = nbx * nby * dim * 16;                 // (x..x+1, z..z+1) quads: 16 bytes (fp16 pairs) / 32 bytes (fp32 pairs)
+            if ((size_t)(total + entries) * entry_bytes > budget_bytes || entries >= ((int64_t)1 << 30)) break;
             hp.dense_off[l] = total; hp.dense_nby[l] = (int32_t)nby; hp.dense_nbz[l] = (int32_t)dim;
             total += entries; nb = l + 1;
         }
     }
     if (nb > 0) {
-        if (h->fast_bytes < (size_t)total * 16) {
+        if (h->fast_bytes < (size_t)total * entry_bytes) {
             if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
             h->d_fast = nullptr; h->fast_bytes = 0;
-            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * 16));
-            h->fast_bytes = (size_t)total * 16;
+            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * entry_bytes));
+            h->fast_bytes = (size_t)total * entry_bytes;
         }
         hp.dense = h->d_fast;
         for (int l = 0; l < nb; l++) {
             const int64_t dim = (int64_t)floorf(hp.level_scale[l]) + 2;
             const int64_t entries = (l + 1 < nb ? hp.dense_off[l + 1] : total) - hp.dense_off[l];
-            hipLaunchKernelGGL(k_bake_dense, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
-                               reinterpret_cast<uint4 *>(h->d_fast) + hp.dense_off[l]);
+            if (ngp) hipLaunchKernelGGL(k_bake_dense_ngp, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
+                                        reinterpret_cast<uint4 *>(h->d_fast) + hp.dense_off[l] * 2);
+            else hipLaunchKernelGGL(k_bake_dense, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, hp, l, (uint32_t)dim, entries,
+                                    reinterpret_cast<uint4 *>(h->d_fast) + hp.dense_off[l]);
             NRF_LAUNCH_CHECK();
         }
     }
@@ -145,7 +259,23 @@ __global__ void k_dirs_f16(int64_t n, int degree, int variant, const float *__re
 
 int hash_fast_supported(const nrf_hash *h)
 {
-    return h && h->desc.mode == NRF_HASH_CU && h->desc.n_features == 2 && h->table_set && h->primes_set;
+    if (!h || h->desc.n_features != 2 || !h->table_set) return 0;
+    return h->desc.mode == NRF_HASH_NGP ? 1 : (h->primes_set ? 1 : 0);
+}
+
+// HashEmbedder-mode level-major encode: hi plane at feats, lo plane at feats + lo_off (0 = none)
+int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st)
+{
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_HASH, st);
+    const int L = h->desc.n_levels;
+    const int64_t ntiles = ceil_div(p, 256);
+    const int lc = (L * 3 / 4) & ~3;
+    if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0);
+    NRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_hash_ngp_lm<1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
 }
 
 int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, uint8_t *keep, int variant, hipStream_t st,
@@ -206,7 +336,7 @@ extern "C" NRF_API int nrf_dbg_hash_dense_budget(nrf_hash *h, int64_t budget_byt
 extern "C" NRF_API int nrf_dbg_hash_lm(const nrf_hash *h, const float *d_x, int64_t p, int variant, int level_lo, int level_hi, void *d_feats, uint8_t *d_keep, void *stream)
 {
     NRF_CHECK_ARG(h && d_x && d_feats && p >= 0, "nrf_dbg_hash_lm: bad argument");
-    NRF_CHECK_ARG(hash_fast_supported(h), "nrf_dbg_hash_lm: needs a CuHashEmbedder-mode grid with F = 2, table and primes set");
+    NRF_CHECK_ARG(hash_fast_supported(h) && h->desc.mode == NRF_HASH_CU, "nrf_dbg_hash_lm: needs a CuHashEmbedder-mode grid with F = 2, table and primes set");
     PointSource ps{d_x, nullptr, nullptr, 0, 1};
     return launch_hash_lm(h, ps, p, reinterpret_cast<__half2 *>(d_feats), p, d_keep, variant, as_stream(stream), level_lo, level_hi);
 }

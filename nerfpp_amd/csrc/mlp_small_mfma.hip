@@ -161,6 +161,7 @@ struct SmallInput {
     const __half *dirs; int s;
     const uint8_t *keep;
     const __half *dirs_lo;                            // split mode: lo parts of the direction features, same layout
+    const __half2 *feats_lo;                          // split mode, fp32-valued features (HashEmbedder): lo plane, same layout as feats
 };
 
 #ifndef NRF_SMALL_PIPE_SPLIT
@@ -170,14 +171,16 @@ struct SmallInput {
 #define NRF_SMALL_PIPE_F16 0
 #endif
 
-template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT>
+// LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
+// fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
+template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false>
 __global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? 1 : 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
     using Plan = SmallPlan<IN_KS, V_KS, NL, NLC>;
     constexpr int NP = SPLIT ? 2 : 1;
     constexpr int BLOCK_PTS = block_pts_of(SPLIT);
-    constexpr bool IN_LO = SPLIT && !LM;        // level-major hash features are exact fp16 numbers: no lo part
+    constexpr bool IN_LO = SPLIT && (!LM || LMLO);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wl = reinterpret_cast<half8 *>(smem);
     constexpr int NFRAG = Plan::total() * NP;
@@ -208,7 +211,11 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 #pragma unroll
                     for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];   // features 16s+8h+2q, +1
                     bx[pt][s][0] = u.v;
-                    if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (SPLIT && LMLO) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) u.q[q] = in.feats_lo[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];
+                        bx[pt][s][NP - 1] = u.v;
+                    } else if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
                 // 32-bit division when the index fits (always, for a chunk): the 64-bit one is a ~60-instruction sequence
                 const int64_t ray = (p >> 31) == 0 ? (int64_t)((uint32_t)p / (uint32_t)in.s) : p / in.s;
@@ -423,14 +430,14 @@ static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool sp
     const int64_t cap = split ? 256 : 768;
     const unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
     const half8 *img = reinterpret_cast<const half8 *>(split ? m->d_packed_split : m->d_packed_f16);
-#define NRF_GO(LM_, SP_)                                                                                                                      \
+#define NRF_GO(LM_, SP_, LO_)                                                                                                                 \
     do {                                                                                                                                      \
-        auto kfn = k_mlp_small_mfma<2, V_KS, NL, NLC, LM_, SP_>;                                                                              \
+        auto kfn = k_mlp_small_mfma<2, V_KS, NL, NLC, LM_, SP_, LO_>;                                                                         \
         if (lds > 64 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * waves_of(SP_)), lds, st, p, in, img, out, os);                                          \
     } while (0)
-    if (lm) { if (split) NRF_GO(true, true); else NRF_GO(true, false); }
-    else { if (split) NRF_GO(false, true); else NRF_GO(false, false); }
+    if (lm) { if (split) { if (in.feats_lo) NRF_GO(true, true, true); else NRF_GO(true, true, false); } else NRF_GO(true, false, false); }
+    else { if (split) NRF_GO(false, true, false); else NRF_GO(false, false, false); }
 #undef NRF_GO
     NRF_LAUNCH_CHECK();
     return NRF_OK;
@@ -442,12 +449,12 @@ int mlp_small_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_SM
 
 // renderer fast path: level-major fp16 features + per-ray fp16 direction features + keep mask -> raw [p,4] (sigma masked).
 // dirs_lo != NULL selects the split-precision kernel (NRF_PREC_F16_SPLIT).
-int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s, const uint8_t *keep,
-                              int64_t p, float *out, hipStream_t st)
+int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,
+                              const uint8_t *keep, int64_t p, float *out, hipStream_t st)
 {
     if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
     ProfScope prof(NRF_PROF_MLP, st);
-    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo};
+    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo, dirs_lo ? feats_lo : nullptr};
     return dispatch_small(m, in, true, dirs_lo != nullptr, p, out, 4, st);
 }
 
@@ -460,7 +467,7 @@ int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, 
         return NRF_ERR_UNSUPPORTED;
     }
     if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("NRF_PREC_F16_MFMA: input rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
-    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr};
+    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr};
     return dispatch_small(m, in, false, split != 0, p, out, os, st);
 }
 

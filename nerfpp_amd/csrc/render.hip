@@ -89,8 +89,9 @@ static size_t network_ws_bytes(const nrf_renderer *r, int64_t p, int prec)
     return b;
 }
 
-// The fused fast path (NRF_PREC_F16_MFMA, CuHashEmbedder-mode grid with F = 2 and 16 levels, SH directions, NeRFSmall in the
-// built matrix-core family): level-major fp16 features -> fused MFMA MLP, two launches per pass, no concatenated input.
+// The fast path (matrix-core precisions, a hash grid of either encoder with F = 2 and 16 levels, SH directions, NeRFSmall in the built
+// matrix-core family): level-major fp16 features -> MFMA MLP, no concatenated input.  CuHashEmbedder features are exact fp16 numbers;
+// HashEmbedder (LibTorch, fp32) features travel as hi + lo planes in the split-precision mode.
 static bool fast_path(const nrf_renderer *r, int prec)
 {
     return (prec == NRF_PREC_F16_MFMA || prec == NRF_PREC_F16_SPLIT) && r->desc.hash && hash_fast_supported(r->desc.hash) && r->in_ch == 32 &&
@@ -100,7 +101,7 @@ static bool fast_path(const nrf_renderer *r, int prec)
 
 static size_t fast_ws_bytes(const nrf_renderer *r, int64_t n, int64_t p)
 {
-    return align_up((size_t)p * 16 * sizeof(__half2), 256) + align_up((size_t)p, 256) + align_up((size_t)n * r->in_views * sizeof(__half), 256) + 1024;
+    return align_up((size_t)p * 16 * sizeof(__half2), 256) * 2 + align_up((size_t)p, 256) + align_up((size_t)n * r->in_views * sizeof(__half), 256) + 1024;
 }
 
 // dirs_f16: per-ray direction features [n, V] prepared once per chunk (nullptr: computed here from `viewdirs`)
@@ -110,11 +111,14 @@ static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const 
     const int64_t p = n * s;
     if (p == 0) return NRF_OK;
     Bump bump(ws, ws_bytes);
-    __half2 *feats = bump.take<__half2>((size_t)p * 16);
+    const bool ngp = r->desc.hash->desc.mode == NRF_HASH_NGP;
+    const bool want_lo = ngp && dirs_lo != nullptr;                       // split precision on fp32-valued features
+    __half2 *feats = bump.take<__half2>((size_t)p * 16 * (want_lo ? 2 : 1));
     uint8_t *keep = bump.take<uint8_t>((size_t)p);
     if (bump.off > ws_bytes) { set_error("run_network_fast: workspace too small"); return NRF_ERR_WORKSPACE; }
-    NRF_TRY(launch_hash_lm(r->desc.hash, ps, p, feats, p, keep, HASH_LM_DEFAULT_VARIANT, st));
-    return mlp_small_forward_mfma_lm(r->desc.mlp, feats, p, dirs_f16, dirs_lo, s, keep, p, raw, st);
+    if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, p, feats, p, want_lo ? p * 16 : 0, keep, st));
+    else NRF_TRY(launch_hash_lm(r->desc.hash, ps, p, feats, p, keep, HASH_LM_DEFAULT_VARIANT, st));
+    return mlp_small_forward_mfma_lm(r->desc.mlp, feats, want_lo ? feats + p * 16 : nullptr, p, dirs_f16, dirs_lo, s, keep, p, raw, st);
 }
 
 // RunNetwork over p = n*s points given either explicit points or (rays, z).

@@ -1065,3 +1065,38 @@ def test_lerf_renderer_falls_back_when_samples_are_not_multiples_of_32(api, mani
         import ctypes as C
         x = torch.zeros((37, 128), device="cuda"); w = torch.zeros((37,), device="cuda"); out = torch.zeros((1, 768), device="cuda")
         api.L.check(api.L.lib().nrf_lerf_render_embedding(lerf._m, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_int64(1), 37, C.c_void_p(out.data_ptr()), None))
+
+
+# ------------------------------------------------------------------ HashEmbedder (LibTorch semantics) on the fast path
+def test_ngp_fast_path_vs_reference_render(api, manifest):
+    """The reference's own LibTorch CPU render (golden render_hash: HashEmbedder + SHEncoder + NeRFSmall) against the fast path -- dense fp32
+    pyramid, level-major hi/lo fp16 features, split-precision matrix-core MLP: pixels within the north star's 1e-4."""
+    g = load_golden("render_hash")
+    r, _ = _golden_hash_scene(api, manifest)
+    res = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64, Precision=api.L.NRF_PREC_F16_SPLIT), c2w=g["c2w"])
+    ref32 = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64, Precision=api.L.NRF_PREC_F32), c2w=g["c2w"])
+    rgb = host(res.Outputs.RGBMap)
+    scale = np.abs(g["coarse_raw"]).max()
+    assert_close(host(res.Extras["raw_coarse"]), host(ref32.Extras["raw_coarse"]), rtol=0, atol=3e-6 * scale, what="coarse raw: split fast path vs fp32 parity mode")
+    assert_close(rgb, g["out_rgb"], rtol=0, atol=1e-4, what="fast path pixels within 1e-4 of the reference's LibTorch CPU render")
+    assert api.S.psnr(rgb, g["out_rgb"]) > 80
+
+
+def test_ngp_fast_path_features_equal_generic_encoder(api):
+    """k_hash_ngp_lm (dense fp32 pyramid) == k_hash_ngp (hashed fp32 tables): hi plane = f16(feature), hi + lo = feature to 2^-22."""
+    import ctypes as C
+    sc = api.S.make_hash_scene(mode="ngp")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates=True)
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=2)
+    rays = res.Extras["rays_flat"]; zf = res.Extras["z_fine"]
+    n, s = zf.shape
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
+    emb, keep = sc["embedder"].forward(pts)
+    dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+    x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+    ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)                 # fp32 rows -> the kernel splits them itself: same hi/lo operands
+    ref[~keep, 3] = 0
+    assert_exact(host(res.Raw).reshape(-1, 4), host(ref), "fast path raw == stage-wise split raw (identical hi/lo operands, identical lookups)")
+    f32 = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=400, rows=2)
+    assert api.S.psnr(host(res.Outputs.RGBMap), host(f32.Outputs.RGBMap)) > 85
