@@ -472,6 +472,7 @@ def test_libtorch_adapter_drop_in_inside_reference_renderer():
     assert out.returncode == 0 and r["ok"], r
     assert r["hash_embedding_bit_exact"] and r["sh_bit_exact"] and r["shapes_near_far_equal"]
     assert r["pixels_within_1e-4"] >= 0.90 and r["psnr_db"] > 55, r
+    assert r["split_pixels_within_1e-4"] >= 0.90 and r["split_psnr_db"] > 55, r      # the matrix-core fast path behind the reference's own Render()
 
 
 def test_classic_fused_path_equals_stagewise_f16(api):
