@@ -60,7 +60,11 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
             zj = zr[j];
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
-            float sg = r[sigma_ch];
+            // c == 4 (rgb, sigma): one 16-byte load per sample instead of four dword loads
+            float4 r4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            const bool vec = (c == 4) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+            if (vec) r4 = *reinterpret_cast<const float4 *>(r);
+            float sg = vec ? (sigma_ch == 3 ? r4.w : sigma_ch == 0 ? r4.x : sigma_ch == 1 ? r4.y : r4.z) : r[sigma_ch];
             if (nz.on)                                              // raw_noise_std > 0 (:251-252)
                 sg = sg + (nz.arr ? nz.arr[ray * s + j] : nrf_rng_normal(nz.g.seed, nz.stream, (uint64_t)((nz.g.ray_base + ray) * s + j))) * nz.std;
             const float sig = sg > 0.0f ? sg : 0.0f;                // relu
@@ -68,9 +72,9 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
             const float om = 1.0f - alpha;
             lg = nrf_logf(om > 1e-10f ? om : 1e-10f);                   // :265
             if (rgb) {
-                cr = nrf_sigmoidf(r[0]);                            // sigmoid, :250
-                cg = nrf_sigmoidf(r[1]);
-                cb = nrf_sigmoidf(r[2]);
+                cr = nrf_sigmoidf(vec ? r4.x : r[0]);               // sigmoid, :250
+                cg = nrf_sigmoidf(vec ? r4.y : r[1]);
+                cb = nrf_sigmoidf(vec ? r4.z : r[2]);
             }
         }
         const double incl = wave_incl_scan((double)lg, lane);
