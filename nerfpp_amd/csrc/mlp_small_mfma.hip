@@ -170,6 +170,12 @@ struct SmallInput {
 #ifndef NRF_SMALL_PIPE_F16
 #define NRF_SMALL_PIPE_F16 0
 #endif
+#ifndef NRF_SMALL_PREFETCH_SPLIT
+#define NRF_SMALL_PREFETCH_SPLIT 1
+#endif
+#ifndef NRF_SMALL_PREFETCH_F16
+#define NRF_SMALL_PREFETCH_F16 0
+#endif
 
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
@@ -195,14 +201,12 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 #pragma unroll
         for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; hv[j] = t; lv[j] = (_Float16)(v[j] - (float)t); }
     };
-    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        const int64_t p0 = blk * BLOCK_PTS + wave * (32 * PT);
-        // ---- layer-0 B fragments straight from the fp32 input rows: element j of k-step s is x[pt][16s + 8h + j] ----
-        half8 bx[PT][IN_KS][NP];
-        half8 bv[PT][V_KS][NP];
+    // ---- layer-0 / colour-layer-0 B fragments of one block iteration: element j of k-step s is x[pt][16s + 8h + j] ----
+    auto load_inputs = [&](int64_t blk_, half8 (&bx)[PT][IN_KS][NP], half8 (&bv)[PT][V_KS][NP]) {
+        const int64_t p0_ = blk_ * BLOCK_PTS + wave * (32 * PT);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
-            int64_t p = p0 + pt * 32 + r;
+            int64_t p = p0_ + pt * 32 + r;
             if (p >= npts) p = npts - 1;                 // clamp loads; stores are guarded
             if constexpr (LM) {
 #pragma unroll
@@ -243,6 +247,19 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 }
             }
         }
+    };
+    // PREFETCH: the operands of the NEXT block iteration are requested right after this iteration's first layer has consumed its own, and
+    // arrive while the rest of the network runs (the loads' latency, ~2 us under load, is otherwise exposed once per ~10 us iteration)
+    constexpr bool PREFETCH = LM && (SPLIT ? (NRF_SMALL_PREFETCH_SPLIT != 0) : (NRF_SMALL_PREFETCH_F16 != 0));
+    half8 bx[PT][IN_KS][NP];
+    half8 bv[PT][V_KS][NP];
+    half8 bxn[PREFETCH ? PT : 1][IN_KS][NP];
+    half8 bvn[PREFETCH ? PT : 1][V_KS][NP];
+    if constexpr (PREFETCH) { if ((int64_t)blockIdx.x < nblocks) load_inputs(blockIdx.x, bx, bv); }
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t p0 = blk * BLOCK_PTS + wave * (32 * PT);
+        if constexpr (!PREFETCH) load_inputs(blk, bx, bv);
+        const bool more = blk + gridDim.x < nblocks;
         const half8 *fr = wl;
         // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer (two buffers: the software pipeline writes the
         // next layer's operands while the current layer still reads its own)
@@ -287,6 +304,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
             gemm_layer<2, IN_KS, NP, IN_LO>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
+            if constexpr (PREFETCH) { if (more) load_inputs(blk + gridDim.x, bxn, bvn); }
 #pragma unroll
             for (int l = 1; l < NL; l++) {
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
@@ -332,6 +350,21 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                     if constexpr (LM) { if (in.keep && !in.keep[p]) sg = 0.0f; }
                     if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
                     else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+            if (more) {
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) {
+#pragma unroll
+                    for (int s = 0; s < IN_KS; s++)
+#pragma unroll
+                        for (int q = 0; q < NP; q++) bx[pt][s][q] = bxn[pt][s][q];
+#pragma unroll
+                    for (int s = 0; s < V_KS; s++)
+#pragma unroll
+                        for (int q = 0; q < NP; q++) bv[pt][s][q] = bvn[pt][s][q];
                 }
             }
         }
