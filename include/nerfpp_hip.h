@@ -363,6 +363,12 @@ NRF_API int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, co
  * of a ray that share a voxel are summed in registers before the atomic add -- the count of scattered float atomics is the cost. */
 NRF_API int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *stream);
 
+/* TotalVariationLoss of the LibTorch HashEmbedder (NeRF.h:255-300, NeRFExecutor.h:896-913; NRF_HASH_NGP grids): the cube of
+ * (cube_size + 1)^3 lattice vertices at min_vertex (host [3]; the reference draws it with torch::randint) of `level`.
+ * d_loss (device, 1 float) += weight * loss;  d_g_table (optional, table layout) += weight * d loss / d table. */
+NRF_API int nrf_hash_tv_loss(const nrf_hash *h, const float *d_table, int level, const int *min_vertex, int cube_size, float weight, float *d_loss,
+                             float *d_g_table, void *stream);
+
 /* torch::optim::Adam::step without weight decay / amsgrad; t = 1, 2, ... */
 NRF_API int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
                           void *stream);

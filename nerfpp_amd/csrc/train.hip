@@ -312,6 +312,38 @@ __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int
     if (have) flush();
 }
 
+// TotalVariationLoss (NeRF.h:255-300): one thread per cube vertex owns the three forward differences starting at it
+template <int F>
+__global__ void k_tv_loss(int n, int cube, int log2_t, int vx, int vy, int vz, float weight, const float *__restrict__ tl, float *__restrict__ loss, float *__restrict__ g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double tv = 0.0;
+    if (t < n * n * n) {
+        const int z = t % n, y = (t / n) % n, x = t / (n * n);
+        const uint32_t hmask = (1u << log2_t) - 1u;
+        auto row = [&](int xx, int yy, int zz) { return (size_t)((((uint32_t)(vx + xx)) ^ ((uint32_t)(vy + yy) * 2654435761u) ^ ((uint32_t)(vz + zz) * 805459861u)) & hmask); };
+        const size_t v = row(x, y, z);
+        const int c[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (c[a] + 1 >= n) continue;
+            const size_t u = row(x + (a == 0), y + (a == 1), z + (a == 2));
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const float d = tl[u * F + f] - tl[v * F + f];
+                tv += (double)(d * d);
+                if (g) {
+                    const float gr = weight * (2.0f * d) / (float)cube;
+                    unsafeAtomicAdd(g + u * F + f, gr);
+                    unsafeAtomicAdd(g + v * F + f, -gr);
+                }
+            }
+        }
+    }
+    tv = wsum(tv);
+    if ((threadIdx.x & 63) == 0 && tv != 0.0) unsafeAtomicAdd(loss, (float)(tv * (double)weight / (double)cube));
+}
+
 __global__ void k_adam(int64_t n, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps, float *__restrict__ p, const float *__restrict__ g,
                        float *__restrict__ m, float *__restrict__ v)
 {
@@ -424,6 +456,30 @@ int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int
         default: set_error("nrf_hash_backward_rays: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
     }
 #undef NRF_BWD
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_hash_tv_loss(const nrf_hash *h, const float *d_table, int level, const int *min_vertex, int cube_size, float weight, float *d_loss, float *d_g_table,
+                     void *stream)
+{
+    NRF_CHECK_ARG(h && d_table && min_vertex && d_loss && cube_size >= 1 && cube_size <= 511, "nrf_hash_tv_loss: bad argument");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_NGP, "nrf_hash_tv_loss: the reference defines this regulariser for the LibTorch HashEmbedder only (NeRFExecutor.h:896-913)");
+    NRF_CHECK_ARG(level >= 0 && level < h->desc.n_levels, "nrf_hash_tv_loss: level %d outside [0,%d)", level, h->desc.n_levels);
+    const int n = cube_size + 1, F = h->desc.n_features, T = h->desc.log2_hashmap_size;
+    const size_t off = (size_t)level * ((size_t)1 << T) * F;
+    const unsigned grid = (unsigned)ceil_div((int64_t)n * n * n, 256);
+    hipStream_t st = as_stream(stream);
+    float *g = d_g_table ? d_g_table + off : nullptr;
+#define NRF_TV(FF) hipLaunchKernelGGL(k_tv_loss<FF>, dim3(grid), dim3(256), 0, st, n, cube_size, T, min_vertex[0], min_vertex[1], min_vertex[2], weight, d_table + off, d_loss, g)
+    switch (F) {
+        case 1: NRF_TV(1); break;
+        case 2: NRF_TV(2); break;
+        case 4: NRF_TV(4); break;
+        case 8: NRF_TV(8); break;
+        default: set_error("nrf_hash_tv_loss: n_features %d not built", F); return NRF_ERR_UNSUPPORTED;
+    }
+#undef NRF_TV
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

@@ -19,7 +19,8 @@ from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecond
 
 
 class Trainer:
-    def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15):
+    def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
+                 tv_loss_weight=0.0, seed=0):
         if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
             raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
@@ -32,6 +33,9 @@ class Trainer:
         self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
         self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
         self.lr, self.betas, self.eps, self.t = float(learning_rate), betas, float(eps), 0
+        # TotalVariationLoss of the LibTorch HashEmbedder, weight 1e-6 in the reference for the first half of training (NeRFExecutor.h:896-913)
+        self.tv_loss_weight, self.seed = float(tv_loss_weight), int(seed)
+        self.tv_loss = torch.zeros((1,), device=dev)
         self._ws = None
         if isinstance(embedder, CuHashEmbedder):
             embedder.set_dense_budget(0)        # the baked dense pyramid of the render fast path would be re-baked after every step
@@ -92,6 +96,32 @@ class Trainer:
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
         return loss_mse
 
+    @staticmethod
+    def _rng_u32(seed, stream, idx):
+        """include/nrf_rng.h's nrf_rng_u32 on the host (three draws per level and step do not need a kernel)."""
+        m = (1 << 64) - 1
+        x = (seed + idx * 0x9E3779B97F4A7C15) & m
+        x ^= (stream * 0xD1B54A32D192ED03) & m
+        x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & m
+        x ^= x >> 27; x = (x * 0x94D049BB133111EB) & m
+        x ^= x >> 31
+        return x >> 32
+
+    def add_tv_loss(self):
+        """loss += w * TotalVariationLoss(level) for every level (NeRF.h:255-300): accumulates into self.g_table and self.tv_loss."""
+        e = self.embedder
+        if self.tv_loss_weight <= 0 or e.mode != L.NRF_HASH_NGP:
+            return
+        self.tv_loss.zero_()
+        b = math.exp((math.log(e.FinestResolution) - math.log(e.BaseResolution)) / (e.NLevels - 1))          # NeRF.h:265
+        for level in range(e.NLevels):
+            res = int(math.floor(b ** level * e.BaseResolution))
+            cube = int(math.floor(min(max(float(np.float32(res) / np.float32(10.0)), e.BaseResolution - 1), e.FinestResolution - 1)))      # :269-273
+            span = max(res - cube, 1)
+            mv = np.array([self._rng_u32(self.seed, 18, (self.t * e.NLevels + level) * 3 + a) * span >> 32 for a in range(3)], np.int32)   # randint(0, res - cube), :276
+            L.check(L.lib().nrf_hash_tv_loss(e._h, _ptr(self.table), level, mv.ctypes.data_as(C.c_void_p), cube, C.c_float(self.tv_loss_weight), _ptr(self.tv_loss),
+                                             _ptr(self.g_table), _stream()))
+
     def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams, cone_angle=None):
         """Optimizer->zero_grad(); Render; huber; backward; Optimizer->step() (NeRFExecutor.h:866-985)."""
         p = render_params
@@ -102,6 +132,7 @@ class Trainer:
         res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))
         s_out = p.NSamples + p.NImportance
         loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
+        self.add_tv_loss()
         self.t += 1
         b1, b2 = self.betas
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):

@@ -420,6 +420,14 @@ def hash_cu_backward(x, primes, local_idx, local_size, bias, bbox, mul, L, F, po
     return out
 
 
+def tv_loss(table_level, log2_t, min_vertex, cube, weight=1.0, want_grad=True):
+    t = _f(table_level); F = t.shape[-1]
+    mv = np.ascontiguousarray(min_vertex, np.int32)
+    loss = C.c_float(0); grad = np.zeros_like(t) if want_grad else None
+    lib().orc_tv_loss(_p(t), C.c_int(log2_t), C.c_int(F), mv.ctypes.data_as(C.c_void_p), C.c_int(cube), C.c_float(weight), C.byref(loss), _p(grad))
+    return loss.value, grad
+
+
 def adam_step(p, g, m, v, lr, t, b1=0.9, b2=0.99, eps=1e-15):
     """in place on p, m, v (float32 arrays)"""
     assert p.dtype == np.float32 and m.dtype == np.float32 and v.dtype == np.float32

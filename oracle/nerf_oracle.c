@@ -1474,6 +1474,41 @@ ORC_API void orc_hash_cu_backward(const float *x, int64_t p, const int32_t *prim
     free(acc);
 }
 
+/* TotalVariationLoss of the LibTorch HashEmbedder (NeRF.h:255-300; added to the training loss for the first half of the iterations,
+ * NeRFExecutor.h:896-913): a cube of (cube+1)^3 lattice vertices starting at min_vertex, the level's table rows at their hashes,
+ * loss = (sum of squared forward differences along x, y, z) / cube.  grad (optional) accumulates weight * d loss / d table. */
+ORC_API void orc_tv_loss(const float *table_level, int log2_t, int n_feat, const int32_t *min_vertex, int cube, float weight, float *loss, float *grad)
+{
+    const int n = cube + 1;
+    const int64_t hmask = ((int64_t)1 << log2_t) - 1;
+    int64_t *rows = (int64_t *)malloc(sizeof(int64_t) * n * n * n);
+    for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) for (int z = 0; z < n; z++) {
+        const int64_t cx = min_vertex[0] + x, cy = min_vertex[1] + y, cz = min_vertex[2] + z;
+        rows[((int64_t)x * n + y) * n + z] = ((cx * 1LL) ^ (cy * 2654435761LL) ^ (cz * 805459861LL)) & hmask;
+    }
+    double tv = 0.0;
+    const int64_t stride[3] = {(int64_t)n * n, n, 1};
+    for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) for (int z = 0; z < n; z++) {
+        const int64_t v = ((int64_t)x * n + y) * n + z;
+        const int c[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) {
+            if (c[a] + 1 >= n) continue;
+            const int64_t u = v + stride[a];
+            for (int f = 0; f < n_feat; f++) {
+                const float d = table_level[rows[u] * n_feat + f] - table_level[rows[v] * n_feat + f];
+                tv += (double)(d * d);
+                if (grad) {
+                    const float g = weight * (2.0f * d) / (float)cube;
+                    grad[rows[u] * n_feat + f] += g;
+                    grad[rows[v] * n_feat + f] -= g;
+                }
+            }
+        }
+    }
+    if (loss) *loss = (float)(tv / (double)cube);
+    free(rows);
+}
+
 /* torch::optim::Adam::step (no weight decay, no amsgrad), step count t >= 1:
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) */
 ORC_API void orc_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float b1, float b2, float eps, int t)

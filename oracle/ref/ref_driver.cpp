@@ -570,6 +570,34 @@ static void g_render()
 // Render(ray batch) -> huber_loss(RGBMap, target) -> backward -> Adam(lr, betas (0.9, 0.99), eps 1e-15) (:539).
 // Dumps the loss, d loss / d raw of the fine pass, every parameter gradient, and the parameters after each step.
 // ----------------------------------------------------------------------------------------------
+// The total-variation regulariser of the LibTorch HashEmbedder (NeRF.h:255-300), added to the loss for the first half of training
+// (NeRFExecutor.h:896-913): value and gradient w.r.t. the level's table, with the cube's random min vertex replayed.
+static void g_tv()
+{
+	const std::string tag = "tv_loss";
+	auto bbox = lego_bbox();
+	HashEmbedder e("embedder", bbox, 6, 2, 14, 16, 256);
+	fill_module(tag, e, 5000u, 0.5f, 0.f);
+	for (int level : {0, 3, 5})
+	{
+		const std::string st = tag + ".l" + std::to_string(level) + "_";
+		for (auto &p : e->parameters()) if (p.grad().defined()) p.grad().zero_();
+		torch::manual_seed(4000 + level);
+		auto loss = TotalVariationLoss(e, torch::kCPU, 16, 256, level, 14, 6);
+		loss.backward();
+		double b = exp((log(256.) - log(16.)) / (6 - 1));
+		int64_t res = (int64_t)floor(pow(b, level) * 16);
+		int64_t cube = std::min<int64_t>(255, std::max<int64_t>(15, (int64_t)floor(res / 10.f)));
+		torch::manual_seed(4000 + level);
+		auto min_vertex = torch::randint(0, res - cube, {3}, torch::kLong);		//NeRF.h:276
+		save_npy(st + "loss", loss.detach().reshape({1}).to(torch::kFloat32));
+		save_npy(st + "min_vertex", min_vertex.to(torch::kInt32));
+		save_npy(st + "res_cube", torch::tensor({(int)res, (int)cube}, torch::kInt32));
+		int li = 0;
+		for (auto &p : e->named_parameters()) { if (li == level) save_npy(st + "grad", p.value().grad()); li++; }
+	}
+}
+
 static void g_train()
 {
 	const std::string tag = "train_hash";
@@ -808,6 +836,7 @@ int main(int argc, const char **argv)
 	g_raw2out();
 	g_render();
 	g_train();
+	g_tv();
 	g_manifest.close();
 	std::cout << "golden vectors written to " << g_outdir << std::endl;
 	return 0;

@@ -444,3 +444,16 @@ def test_precrop_bounds_and_random_pixels():
     assert abs(np.corrcoef(rh, rw)[0, 1]) < 0.02
     rh2, _ = O.rand_pixels(7, 4, b, 1 << 16)
     assert (rh2 != rh).mean() > 0.9, "another iteration draws other pixels"
+
+
+def test_tv_loss_vs_reference_autograd(manifest):
+    """TotalVariationLoss of the LibTorch HashEmbedder (NeRF.h:255-300): value and table gradient against the reference's autograd."""
+    g = load_golden("tv_loss")
+    ent = manifest["tv_loss"]
+    for level in (0, 3, 5):
+        table = synth.blob_from_manifest([ent[level]]).reshape(1 << 14, 2)
+        loss, grad = O.tv_loss(table, 14, g[f"l{level}_min_vertex"], int(g[f"l{level}_res_cube"][1]))
+        assert abs(loss - g[f"l{level}_loss"][0]) < 2e-5 * g[f"l{level}_loss"][0]
+        ref = g[f"l{level}_grad"]
+        assert_close(grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"level {level}")
+        assert (ref != 0).sum() >= (int(g[f"l{level}_res_cube"][1]) + 1) ** 3 * 0.9
