@@ -303,7 +303,7 @@ def lerf_measurement(scene, K, c2w, rows=200):
                 arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; generic CuHash F=8 encode (fp32 features)")
 
 
-def train_step_measurement(args, scene, L, n_rand=16384, steps=5):
+def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):
     """SURVEY section 8f row N1: one optimisation step of NeRFExecutor::Train (render the ray batch, huber loss, backward of the fine pass,
     Adam) on the HashNeRF configuration, N_rand = 32*32*16 rays per step as in the reference's main.cpp:232, next to the reference's own
     LibTorch CPU step (oracle/_ref/ref_driver bench_train) on a bounded ray batch."""
@@ -316,7 +316,7 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5):
     idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
     o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
     tgt = torch.rand((n_rand, 3), device="cuda")
-    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4)
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=mlp_backward)
     rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                             BoundingBox=scene.LEGO_BBOX, Precision=L.NRF_PREC_F16_SPLIT)
     for _ in range(2):
@@ -331,7 +331,14 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5):
     dt = (time.perf_counter() - t0) / steps
     rec = dict(workload="hashnerf_train_step", rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt,
                value=n_rand * UNITS_PER_RAY / dt, unit="ray-samples/s", steps=steps, loss_first_last=[float(losses[0][0]), float(losses[-1][0])],
-               arithmetic="render: split-f16 MFMA; backward: fp32 (layer-wise kernels, float atomics for dW and the table gradient); Adam fp32")
+               arithmetic="render: split-f16 MFMA; NeRFSmall backward: " + ("one fused matrix-core kernel, fp16 operands / fp32 accumulation / device-side loss scale" if mlp_backward == "f16"
+                                                                            else "fp32 layer-wise kernels") + "; hash backward: fp32 ray-coherent pre-sum + float atomics; Adam fp32")
+    if mlp_backward == "f16":
+        try:
+            r32 = train_step_measurement(argparse.Namespace(**{**vars(args), "no_cpu_baseline": True}), scene, L, n_rand, steps, "f32")
+            rec["fp32_backward"] = dict(ms_per_step=r32["ms_per_step"], rays_per_s=r32["rays_per_s"], loss_first_last=r32["loss_first_last"])
+        except Exception as e:
+            rec["fp32_backward"] = f"unavailable: {e}"
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(drv) and not args.no_cpu_baseline:
         try:

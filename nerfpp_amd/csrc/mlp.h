@@ -31,6 +31,8 @@ struct nrf_mlp {
     size_t packed_f16_bytes = 0;
     void *d_packed_split = nullptr;          // NRF_PREC_F16_SPLIT: (hi, lo) fragment pairs
     size_t packed_split_bytes = 0;
+    void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
+    size_t packed_bwd_bytes = 0;
 };
 
 namespace nrf {
@@ -50,6 +52,10 @@ int mlp_nerf_mfma_available(const nrf_mlp *m);
 int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);
 int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &host_params);
+size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p);
+int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
+                            size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 

@@ -567,6 +567,16 @@ int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, i
     return mlp_small_backward(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
 }
 
+size_t nrf_mlp_backward_f16_workspace_bytes(const nrf_mlp *m, int64_t p) { return (m && m->family == MLP_SMALL) ? mlp_small_backward_mfma_workspace_bytes(m, p) : 0; }
+
+int nrf_mlp_backward_f16(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x, void *d_workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(m && d_x && d_g_out && d_g_params && d_workspace && p >= 0, "nrf_mlp_backward_f16: bad argument");
+    if (p == 0) return NRF_OK;
+    return mlp_small_backward_mfma(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
+}
+
 void nrf_mlp_destroy(nrf_mlp *m)
 {
     if (!m) return;
@@ -577,6 +587,7 @@ void nrf_mlp_destroy(nrf_mlp *m)
     if (m->d_params) (void)hipFree(m->d_params);
     if (m->d_packed_f16) (void)hipFree(m->d_packed_f16);
     if (m->d_packed_split) (void)hipFree(m->d_packed_split);
+    if (m->d_packed_bwd) (void)hipFree(m->d_packed_bwd);
     delete m;
 }
 

@@ -448,7 +448,7 @@ int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     m->packed_split_bytes = pk2.img.size() * sizeof(_Float16);
     NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_split, pk2.img.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
-    return NRF_OK;
+    return mlp_small_pack_bwd(m, hp);
 }
 
 template <int V_KS, int NL, int NLC>

@@ -20,7 +20,7 @@ from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecond
 
 class Trainer:
     def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
-                 tv_loss_weight=0.0, seed=0):
+                 tv_loss_weight=0.0, seed=0, mlp_backward="f32"):
         if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
             raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
@@ -36,6 +36,11 @@ class Trainer:
         # TotalVariationLoss of the LibTorch HashEmbedder, weight 1e-6 in the reference for the first half of training (NeRFExecutor.h:896-913)
         self.tv_loss_weight, self.seed = float(tv_loss_weight), int(seed)
         self.tv_loss = torch.zeros((1,), device=dev)
+        # "f32": layer-wise fp32 kernels (the parity path, pinned to the reference's autograd); "f16": one fused matrix-core kernel
+        # (fp16 operands, fp32 accumulation, device-side loss scaling -- mlp_small_bwd_mfma.hip)
+        if mlp_backward not in ("f32", "f16"):
+            raise L.NrfError("mlp_backward must be 'f32' or 'f16'")
+        self.mlp_backward = mlp_backward
         self._ws = None
         if isinstance(embedder, CuHashEmbedder):
             embedder.set_dense_budget(0)        # the baked dense pyramid of the render fast path would be re-baked after every step
@@ -89,9 +94,10 @@ class Trainer:
         self.g_blob.zero_(); self.g_table.zero_()
         in_ch = self.embedder.GetOutputDims()
         g_x = torch.empty((n * s, in_ch), device=rays.device)
-        nb = lib.nrf_mlp_backward_workspace_bytes(self.mlp._m, C.c_int64(n * s))
+        ws_fn, bw_fn = (lib.nrf_mlp_backward_f16_workspace_bytes, lib.nrf_mlp_backward_f16) if self.mlp_backward == "f16" else (lib.nrf_mlp_backward_workspace_bytes, lib.nrf_mlp_backward)
+        nb = ws_fn(self.mlp._m, C.c_int64(n * s))
         ws = self._workspace(nb)
-        L.check(lib.nrf_mlp_backward(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+        L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
         L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
         return loss_mse

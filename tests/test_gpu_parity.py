@@ -806,6 +806,106 @@ def test_training_backward_stages_vs_reference_autograd(api, O, manifest):
     assert_close(host(p), ref1, rtol=0, atol=2e-7, what="Adam step 1")
 
 
+def _small_backward_both(api, nl, nlc, blob, x_h, gr_h):
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    p = x_h.shape[0]
+    m = api.M.NeRFSmall(nl, 64, 15, nlc, 64, False, 3, 64, 32, 16, "model", params=blob)
+    x, gr = dev(x_h), dev(gr_h)
+    lib = api.L.lib()
+    out = {}
+    for name, fn, wsfn in (("f32", lib.nrf_mlp_backward, lib.nrf_mlp_backward_workspace_bytes), ("f16", lib.nrf_mlp_backward_f16, lib.nrf_mlp_backward_f16_workspace_bytes)):
+        nb = wsfn(m._m, C.c_int64(p))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        g_blob = torch.zeros(blob.size, device="cuda"); g_x = torch.zeros((p, 32), device="cuda")
+        api.L.check(fn(m._m, P(x), P(gr), C.c_int64(p), P(g_blob), P(g_x), P(ws), C.c_size_t(nb), None))
+        torch.cuda.synchronize()
+        out[name] = (host(g_blob), host(g_x))
+    return out["f32"], out["f16"]
+
+
+def _small_dims(nl, nlc):
+    return [(32, 64)] + [(64, 64)] * (nl - 2) + [(64, 16)] + [(31, 64)] + [(64, 64)] * (nlc - 2) + [(64, 3)]
+
+
+@pytest.mark.parametrize("nl,nlc,p", [(3, 4, 1000), (3, 3, 333), (2, 4, 128), (2, 3, 4100)])
+def test_mlp_backward_matrix_core_exact_on_integer_network(api, nl, nlc, p):
+    """nrf_mlp_backward_f16 (one fused MFMA kernel: forward, gradient chain through W^T images, weight gradients through MFMA transposition)
+    against the fp32 backward, which test_training_backward_stages_vs_reference_autograd pins to the reference's autograd.  Sparse -1/0/+1
+    weights and small-integer inputs / output gradients: every activation and every chained gradient is an integer fp16 holds exactly
+    (checked below in float64), no pre-activation sits next to the ReLU kink, so the two paths may differ by fp32 summation order only --
+    any wrong fragment index, mask bit or blob offset shows up at full size."""
+    rng = np.random.default_rng(100 * nl + nlc)
+    dims = _small_dims(nl, nlc)
+    mats = []
+    for (i, o) in dims:
+        w = np.zeros((o, i), np.float32)
+        nz = rng.random((o, i)) < 3.0 / i
+        w[nz] = rng.choice([-1.0, 1.0], size=int(nz.sum()))
+        mats.append(w)
+    blob = np.concatenate([w.reshape(-1) for w in mats])
+    x = np.concatenate([rng.integers(-2, 3, (p, 32)), rng.integers(-1, 2, (p, 16))], 1).astype(np.float32)
+    gk = rng.integers(-2, 3, (p, 4)).astype(np.float64)
+    gk[0, 0] = 2.0                                              # the device picks the loss scale from max |g_out|
+    gr = (gk * 2.0 ** -22).astype(np.float32)
+    # float64 model of the pass: every value the kernel rounds to fp16 must be an integer below 2048 (in units of the scaled gradient)
+    h, acts = x[:, :32].astype(np.float64), []
+    for l in range(nl):
+        acts.append(h); h = h @ mats[l].T.astype(np.float64)
+        if l < nl - 1: h = np.maximum(h, 0)
+    sig = h
+    c = np.concatenate([x[:, 32:].astype(np.float64), sig[:, 1:]], 1)
+    for l in range(nlc - 1):
+        acts.append(c); c = np.maximum(c @ mats[nl + l].T.astype(np.float64), 0)
+    acts.append(c)
+    assert max(np.abs(a).max() for a in acts) < 2048 and np.abs(sig).max() < 2048
+    g = gk[:, :3] @ mats[-1].astype(np.float64); gmax = 0.0
+    for l in range(nlc - 1, 0, -1):
+        g = g * (acts[nl + l] > 0); gmax = max(gmax, np.abs(g).max()); g = g @ mats[nl + l - 1].astype(np.float64)
+    g = np.concatenate([gk[:, 3:4], g[:, 16:]], 1)
+    for l in range(nl - 1, 0, -1):
+        gmax = max(gmax, np.abs(g).max()); g = (g @ mats[l].astype(np.float64)) * (acts[l] > 0)
+    assert max(gmax, np.abs(g).max()) < 256                     # x 8 (the loss scale puts max |g_out| = 2 at 16) < 2048
+    (gb32, gx32), (gb16, gx16) = _small_backward_both(api, nl, nlc, blob, x, gr)
+    off = 0
+    for li, (i, o) in enumerate(dims):
+        a, b = gb16[off:off + i * o], gb32[off:off + i * o]
+        assert np.abs(b).max() > 0
+        assert_close(a, b, rtol=1e-5, atol=1e-6 * np.abs(b).max(), what=f"dW of layer {li}")
+        off += i * o
+    assert_close(gx16, gx32, rtol=1e-5, atol=1e-6 * np.abs(gx32).max(), what="d loss / d features")
+    assert np.abs(gx32).max() > 0
+
+
+@pytest.mark.parametrize("nl,nlc,p", [(3, 4, 50000), (3, 3, 20001)])
+def test_mlp_backward_matrix_core_vs_fp32_random_network(api, nl, nlc, p):
+    """Same comparison on a dense random network.  The fused kernel's own forward is fp16, so a pre-activation within ~1e-3 of zero can land on
+    the other side of the ReLU than in the fp32 pass and that point's gradient through that neuron flips on/off: a handful of points differ at
+    full size, everything else by fp16 rounding.  With this test's random-SIGN output gradients signal and flip noise both grow as sqrt(points)
+    (relative error ~ sqrt(share of flipped units), ~1 %); a training batch's coherent gradient grows as `points`.  Hence statistical bounds."""
+    rng = np.random.default_rng(nl * 10 + nlc)
+    dims = _small_dims(nl, nlc)
+    blob = (rng.standard_normal(sum(i * o for i, o in dims)) * 0.18).astype(np.float32)
+    x = rng.uniform(-1, 1, (p, 48)).astype(np.float32)
+    gr = (rng.standard_normal((p, 4)) * 3e-6).astype(np.float32)
+    gr[rng.random(p) < 0.2, 3] = 0.0                        # masked sigma gradients (keep == false)
+    (gb32, gx32), (gb16, gx16) = _small_backward_both(api, nl, nlc, blob, x, gr)
+    assert np.isfinite(gb16).all() and np.isfinite(gx16).all()
+    off = 0
+    for li, (i, o) in enumerate(dims):
+        a, b = gb16[off:off + i * o], gb32[off:off + i * o]
+        scale = np.abs(b).max()
+        assert np.corrcoef(a, b)[0, 1] > 0.998, (li, np.corrcoef(a, b)[0, 1])
+        assert np.sqrt(np.mean((a - b) ** 2)) < 2e-2 * scale, (li, np.sqrt(np.mean((a - b) ** 2)) / scale)
+        assert np.abs(a - b).max() < 0.12 * scale, (li, np.abs(a - b).max() / scale)
+        off += i * o
+    sx = np.abs(gx32).max()
+    row_err = np.abs(gx16 - gx32).max(1) / sx
+    assert np.median(row_err) < 2e-3, np.median(row_err)
+    assert np.mean(row_err > 2e-2) < 0.05, np.mean(row_err > 2e-2)
+    assert np.sqrt(np.mean((gx16 - gx32) ** 2)) < 1e-2 * sx
+
+
 def test_trainer_two_steps_vs_reference(api, manifest):
     from nerfpp_amd.train import Trainer
     g, table, blob, e, ed, m = _train_golden(api, manifest)
@@ -1121,6 +1221,48 @@ def test_tv_loss_vs_oracle_and_reference(api, O, manifest):
         ref = g[f"l{level}_grad"]
         assert_close(got[level], ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"TV gradient, level {level}")
         assert np.abs(np.delete(got, level, axis=0)).max() == 0, "only the level's own table receives gradient"
+
+
+def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
+    """Trainer(mlp_backward="f16") vs the fp32 trainer on the same rendered batch of a HashNeRF scene: gradients of the MLP and of the hash table
+    (which sees the MLP backward through d loss / d features), then three optimisation steps with the same loss trajectory."""
+    from nerfpp_amd.train import Trainer
+    sc = api.S.make_hash_scene(mode="cu", log2_t=15, seed=4242, table_amp=0.3, sigma_scale=3.0)
+    K = api.S.lego_K(32, 32); c2w = api.S.pose_spherical(20.0, -30.0, 4.0)
+    o, d, _ = api.R.GetRays(32, 32, K, c2w)
+    o = o.reshape(-1, 3); d = d.reshape(-1, 3)
+    tgt = torch.rand((1024, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=1024, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                                BoundingBox=api.S.LEGO_BBOX, Precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates=True)
+    grads = {}
+    for mode in ("f32", "f16"):
+        tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-3, mlp_backward=mode)
+        res = tr.renderer.Render(0, 0, None, rp, rays=(o, d, None))
+        lm = tr.backward(res, tgt, 64, False, rp)
+        grads[mode] = (host(tr.g_blob).copy(), host(tr.g_table).copy(), host(lm).copy())
+    (gb32, gt32, l32), (gb16, gt16, l16) = grads["f32"], grads["f16"]
+    assert np.array_equal(l32, l16)
+    assert np.isfinite(gb16).all() and np.isfinite(gt16).all()
+    off = 0
+    for li, (i, o_) in enumerate(_small_dims(3, 4)):
+        a, b = gb16[off:off + i * o_], gb32[off:off + i * o_]
+        scale = np.abs(b).max()
+        assert np.sqrt(np.mean((a - b) ** 2)) < 1e-2 * scale and np.abs(a - b).max() < 5e-2 * scale, (li, np.sqrt(np.mean((a - b) ** 2)) / scale, np.abs(a - b).max() / scale)
+        off += i * o_
+    nz = gt32 != 0
+    assert nz.sum() > 1000 and np.array_equal(nz, gt16 != 0) or np.mean(nz != (gt16 != 0)) < 1e-3
+    st = np.abs(gt32).max()
+    assert np.sqrt(np.mean((gt16[nz] - gt32[nz]) ** 2)) < 1e-2 * st, np.sqrt(np.mean((gt16[nz] - gt32[nz]) ** 2)) / st
+    assert np.corrcoef(gt16[nz], gt32[nz])[0, 1] > 0.999
+    # a few steps: same descent
+    losses = {}
+    for mode in ("f32", "f16"):
+        tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-3, mlp_backward=mode)
+        losses[mode] = [float(host(tr.step(o, d, tgt, rp)[0])[0]) for _ in range(4)]
+    assert losses["f16"][-1] < losses["f16"][0]
+    assert np.allclose(losses["f16"], losses["f32"], rtol=2e-2), losses
+    with pytest.raises(api.L.NrfError):
+        Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], mlp_backward="bf16")
 
 
 def test_trainer_tv_regulariser_smooths_the_table(api):
