@@ -316,7 +316,7 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
     o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
     tgt = torch.rand((n_rand, 3), device="cuda")
-    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=mlp_backward)
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=mlp_backward, hash_backward="packed" if mlp_backward == "f16" else "f32")
     rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                             BoundingBox=scene.LEGO_BBOX, Precision=L.NRF_PREC_F16_SPLIT)
     for _ in range(2):
@@ -332,7 +332,9 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     rec = dict(workload="hashnerf_train_step", rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt,
                value=n_rand * UNITS_PER_RAY / dt, unit="ray-samples/s", steps=steps, loss_first_last=[float(losses[0][0]), float(losses[-1][0])],
                arithmetic="render: split-f16 MFMA; NeRFSmall backward: " + ("one fused matrix-core kernel, fp16 operands / fp32 accumulation / device-side loss scale" if mlp_backward == "f16"
-                                                                            else "fp32 layer-wise kernels") + "; hash backward: fp32 ray-coherent pre-sum + float atomics; Adam fp32")
+                                                                            else "fp32 layer-wise kernels") +
+                          "; hash backward: ray-coherent fp32 pre-sum, then " + ("one 64-bit fixed-point atomic per entry (both features)" if mlp_backward == "f16" else "one float atomic per feature") +
+                          "; Adam fp32")
     if mlp_backward == "f16":
         try:
             r32 = train_step_measurement(argparse.Namespace(**{**vars(args), "no_cpu_baseline": True}), scene, L, n_rand, steps, "f32")

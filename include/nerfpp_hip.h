@@ -368,6 +368,14 @@ NRF_API int nrf_hash_backward(const nrf_hash *h, const float *d_x, int64_t p, co
 /* The same gradient for points that are the samples of rays, pts [n, s, 3] ray-major (what a training step has): consecutive samples
  * of a ray that share a voxel are summed in registers before the atomic add -- the count of scattered float atomics is the cost. */
 NRF_API int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *stream);
+/* ... with both features of an entry (n_features == 2) in ONE 64-bit integer atomic: two 32-bit fixed-point fields, scaled by a power of
+ * two that a device-side pass derives from a rigorous bound on any entry's total (sum over the points of max_f |g|, per level), so the fields
+ * cannot overflow; decoded and ACCUMULATED into d_g_table (fp32) at the end.  Half the atomics of nrf_hash_backward_rays -- the L2 atomic
+ * rate, not bytes, bounds this pass.  Resolution: (bound / 2^30) per addend, i.e. ~(active entries of a level) * 2^-30 relative to a typical
+ * entry.  d_workspace: nrf_hash_backward_packed_workspace_bytes(h), 256-byte aligned; no host synchronisation. */
+NRF_API size_t nrf_hash_backward_packed_workspace_bytes(const nrf_hash *h);
+NRF_API int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table,
+                                          void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* TotalVariationLoss of the LibTorch HashEmbedder (NeRF.h:255-300, NeRFExecutor.h:896-913; NRF_HASH_NGP grids): the cube of
  * (cube_size + 1)^3 lattice vertices at min_vertex (host [3]; the reference draws it with torch::randint) of `level`.

@@ -224,10 +224,17 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 // at one level, sums the eight corner contributions in registers while the voxel does not change and issues the atomics only when it
 // does.  Same addends as the per-point kernels, summed in a different order (fp32).
 constexpr int BWD_SEG = 16;
+constexpr int64_t PACKED_GROUP_PTS = 1 << 18;      // points per fixed-point pass of nrf_hash_backward_rays_packed
 
-template <int F, bool CU>
+// Q (F == 2 only): both features of a table entry leave in ONE 64-bit integer atomic.  The L2 atomic units retire ~21-24 G operations/s
+// whatever the operand type (tools/scratch/atomic_bench.hip: fp32, f64, u32, u64 and packed-f16 adds all land there), so the table gradient
+// is bound by the NUMBER of atomics and the packed form halves it.  Each feature is a 32-bit fixed-point field, value * qscale rounded to
+// nearest, packed as hi * 2^32 + lo in two's complement: integer addition of such words adds the fields exactly as long as neither field's
+// total leaves int32 (the low field's borrows are undone by the sign-extending decode in k_unpack_q).  qscale is a power of two chosen on the
+// device from a rigorous bound on any entry's total (k_level_mass), so the fields cannot overflow.
+template <int F, bool CU, bool Q = false>
 __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
-                               float *__restrict__ g_table)
+                               float *__restrict__ g_table, const float *__restrict__ qscale_p = nullptr)
 {
     const int nseg = (s + BWD_SEG - 1) / BWD_SEG;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,14 +256,22 @@ __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int
         tl = g_table + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
         hmask = (1u << hp.log2_t) - 1u;
     }
+    float qscale = 1.0f;
+    if constexpr (Q) qscale = qscale_p[0];
     auto flush = [&]() {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t cx = cur[0] + ((k >> 2) & 1), cy = cur[1] + ((k >> 1) & 1), cz = cur[2] + (k & 1);
             const uint32_t row = CU ? (((cx * pa) ^ (cy * pb) ^ (cz * pc)) % lsz) : ((cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask);
+            if constexpr (Q) {
+                static_assert(!Q || F == 2, "packed atomics carry exactly two features");
+                const int32_t q0 = __float2int_rn(acc[k][0] * qscale), q1 = __float2int_rn(acc[k][F - 1] * qscale);
+                if (q0 | q1) atomicAdd(reinterpret_cast<unsigned long long *>(tl) + row, (unsigned long long)(((int64_t)q1 << 32) + (int64_t)q0));
+            } else {
 #pragma unroll
-            for (int f = 0; f < F; f++)
-                if (acc[k][f] != 0.0f) unsafeAtomicAdd(tl + (size_t)row * F + f, acc[k][f]);
+                for (int f = 0; f < F; f++)
+                    if (acc[k][f] != 0.0f) unsafeAtomicAdd(tl + (size_t)row * F + f, acc[k][f]);
+            }
         }
     };
     for (int j = j0; j < j1; j++) {
@@ -310,6 +325,73 @@ __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int
         }
     }
     if (have) flush();
+}
+
+// mass[l] = sum over the points of max_f |g[pt][l][f]|: no table entry of level l can receive more than that (corner weights are in [0,1]
+// and sum to one per point), whatever the hash collisions and however the samples cluster.  Accumulated in double.
+// HashEmbedder mode only: its interpolation weights are computed from the UNCLAMPED coordinate (NeRF.cpp:265-277), so a point outside the box
+// has weights beyond [0,1]; `pts` != NULL multiplies the point's mass by prod_a (1 + excess_a / finest cell size), a bound for every level.
+__global__ void __launch_bounds__(256) k_level_mass(int64_t p, int L, int F, const float *__restrict__ g, double *__restrict__ mass, const float *__restrict__ pts,
+                                                    Bbox bbox, float finest_res)
+{
+    __shared__ double red[4][NRF_MAX_LEVELS];
+    const int l = threadIdx.x % 16, sub = threadIdx.x / 16;          // 16 threads share a row: coalesced for the L = 16 default
+    double m[(NRF_MAX_LEVELS + 15) / 16] = {};
+    for (int64_t i = (int64_t)blockIdx.x * 16 + sub; i < p; i += (int64_t)gridDim.x * 16)
+    {
+        float wb = 1.0f;
+        if (pts) {
+            for (int a = 0; a < 3; a++) {
+                const float x = pts[i * 3 + a], ex = fmaxf(fmaxf(bbox.mn[a] - x, x - bbox.mx[a]), 0.0f);
+                wb *= 1.0f + ex * finest_res / (bbox.mx[a] - bbox.mn[a]) * 1.001f;
+            }
+        }
+        for (int ll = l, q = 0; ll < L; ll += 16, q++) {
+            float a = 0.0f;
+            for (int f = 0; f < F; f++) a = fmaxf(a, fabsf(g[i * (int64_t)(L * F) + ll * F + f]));
+            m[q] += (double)a * (double)wb;
+        }
+    }
+    for (int ll = l, q = 0; ll < L; ll += 16, q++) {
+        double v = m[q];
+        // lanes l, l+16, l+32, l+48 of a wave hold the same level
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][ll] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < L) unsafeAtomicAdd(mass + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// qs[0] = 2^k with bound * 2^k <= 2^30 (k clamped to +-96), qs[1] = 2^-k.  bound = the largest mass any memory word can collect: one level's
+// in the HashEmbedder layout, two adjacent levels' in the CuHashEmbedder layout (whose level blocks overlap by half, CuHashEmbedder.cpp:62-68),
+// times 1.01 for the fp16 rounding of the CuHashEmbedder addends.  The 2^30 leaves 2^30 units for the round-to-nearest of the individual addends.
+__global__ void k_qscale(int L, int overlap, const double *__restrict__ mass, float *__restrict__ qs)
+{
+    double b = 0.0;
+    for (int l = 0; l < L; l++) {
+        const double v = mass[l] + ((overlap && l + 1 < L) ? mass[l + 1] : 0.0);
+        b = v > b ? v : b;
+    }
+    int k = 0;
+    if (b > 0.0) { int e; (void)frexp(b * 1.01, &e); k = 30 - e; }      // b * 1.01 < 2^e
+    k = k < -96 ? -96 : (k > 96 ? 96 : k);
+    qs[0] = ldexpf(1.0f, k); qs[1] = ldexpf(1.0f, -k);
+}
+
+// g_table[2e], [2e+1] += the two fixed-point fields of word e
+__global__ void k_unpack_q(int64_t entries, unsigned long long *__restrict__ q, const float *__restrict__ qs, float *__restrict__ g_table)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    const int64_t w = (int64_t)q[e];
+    if (w == 0) return;
+    q[e] = 0;                         // leaves the word table zero for the next group / call
+    const int32_t lo = (int32_t)(uint32_t)(w & 0xffffffffll);
+    const int32_t hi = (int32_t)((w - (int64_t)lo) >> 32);
+    float2 *gp = reinterpret_cast<float2 *>(g_table) + e;
+    float2 v = *gp;
+    v.x += (float)lo * qs[1]; v.y += (float)hi * qs[1];
+    *gp = v;
 }
 
 // TotalVariationLoss (NeRF.h:255-300): one thread per cube vertex owns the three forward differences starting at it
@@ -456,6 +538,48 @@ int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int
         default: set_error("nrf_hash_backward_rays: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
     }
 #undef NRF_BWD
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+size_t nrf_hash_backward_packed_workspace_bytes(const nrf_hash *h) { return h ? 1024 + (size_t)nrf_hash_table_elems(h) / 2 * 8 : 0; }
+
+int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *d_workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(h && d_pts && d_g_emb && d_g_table && d_workspace && n >= 0 && s >= 1, "nrf_hash_backward_rays_packed: bad argument");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_NGP || h->primes_set, "nrf_hash_backward_rays_packed: CuHashEmbedder-mode grid without primes");
+    if (h->desc.n_features != 2) { set_error("nrf_hash_backward_rays_packed: built for 2 features per level (a table entry = one 64-bit word); use nrf_hash_backward_rays"); return NRF_ERR_UNSUPPORTED; }
+    if (workspace_bytes < nrf_hash_backward_packed_workspace_bytes(h)) { set_error("nrf_hash_backward_rays_packed: workspace %zu < %zu bytes", workspace_bytes, nrf_hash_backward_packed_workspace_bytes(h)); return NRF_ERR_WORKSPACE; }
+    if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) || (reinterpret_cast<uintptr_t>(d_g_table) & 7)) { set_error("nrf_hash_backward_rays_packed: workspace must be 256-byte, g_table 8-byte aligned"); return NRF_ERR_INVALID_ARG; }
+    if (n == 0) return NRF_OK;
+    const int L = h->desc.n_levels;
+    hipStream_t st = as_stream(stream);
+    double *mass = reinterpret_cast<double *>(d_workspace);                                         // [L] (<= 64 levels = 512 bytes)
+    float *qs = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(d_workspace) + 768);
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(d_workspace) + 1024);
+    const int64_t entries = nrf_hash_table_elems(h) / 2;
+    NRF_HIP(hipMemsetAsync(d_workspace, 0, 1024 + (size_t)entries * 8, st));
+    float *qt = reinterpret_cast<float *>(q);                        // the kernel indexes its table in floats: entry e = floats 2e, 2e+1 = word e
+    const bool ngp = h->desc.mode == NRF_HASH_NGP;
+    // The bound behind the scale is a sum over ALL points of a pass while a typical entry sees a handful, so the resolution relative to one addend
+    // is ~2 * points * 2^-30.  Groups of <= 2^18 points keep that at 5e-4 (the float atomics' own summation order moves entries by ~1e-6); each
+    // group costs one sweep over the word table (k_unpack_q, ~25 us at 2^23 words) on top of its atomics.
+    const int64_t rays_per_group = (PACKED_GROUP_PTS / s) > 0 ? (PACKED_GROUP_PTS / s) : 1;
+    for (int64_t r0 = 0; r0 < n; r0 += rays_per_group) {
+        const int64_t nr = (n - r0) < rays_per_group ? (n - r0) : rays_per_group;
+        const int64_t p = nr * s;
+        const float *gp = d_g_emb + r0 * s * (int64_t)(L * 2), *pp = d_pts + r0 * s * 3;
+        if (r0) NRF_HIP(hipMemsetAsync(mass, 0, 512, st));
+        hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(ceil_div(p, 16) < 2048 ? ceil_div(p, 16) : 2048)), dim3(256), 0, st, p, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
+                           h->params.bbox, (float)h->desc.finest_resolution);
+        hipLaunchKernelGGL(k_qscale, dim3(1), dim3(1), 0, st, L, ngp ? 0 : 1, mass, qs);
+        const int64_t threads = nr * ((s + BWD_SEG - 1) / BWD_SEG);
+        dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
+        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, qt, (const float *)qs);
+        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, qt, (const float *)qs);
+        hipLaunchKernelGGL(k_unpack_q, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, entries, q, (const float *)qs, d_g_table);
+    }
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

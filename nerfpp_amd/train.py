@@ -20,7 +20,7 @@ from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecond
 
 class Trainer:
     def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
-                 tv_loss_weight=0.0, seed=0, mlp_backward="f32"):
+                 tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32"):
         if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
             raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
@@ -41,6 +41,13 @@ class Trainer:
         if mlp_backward not in ("f32", "f16"):
             raise L.NrfError("mlp_backward must be 'f32' or 'f16'")
         self.mlp_backward = mlp_backward
+        # "f32": one float atomic per feature; "packed": both features of an entry in one 64-bit fixed-point atomic (nrf_hash_backward_rays_packed)
+        if hash_backward not in ("f32", "packed"):
+            raise L.NrfError("hash_backward must be 'f32' or 'packed'")
+        if hash_backward == "packed" and embedder.NFeaturesPerLevel != 2:
+            raise L.NrfError("hash_backward='packed' needs 2 features per level")
+        self.hash_backward = hash_backward
+        self._hws = None
         self._ws = None
         if isinstance(embedder, CuHashEmbedder):
             embedder.set_dense_budget(0)        # the baked dense pyramid of the render fast path would be re-baked after every step
@@ -98,7 +105,13 @@ class Trainer:
         nb = ws_fn(self.mlp._m, C.c_int64(n * s))
         ws = self._workspace(nb)
         L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
-        L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
+        if self.hash_backward == "packed":
+            nbh = lib.nrf_hash_backward_packed_workspace_bytes(self.embedder._h)
+            if self._hws is None or self._hws.numel() < nbh:
+                self._hws = torch.empty((int(nbh),), device="cuda", dtype=torch.uint8)
+            L.check(lib.nrf_hash_backward_rays_packed(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _ptr(self._hws), C.c_size_t(self._hws.numel()), _stream()))
+        else:
+            L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
         return loss_mse
 

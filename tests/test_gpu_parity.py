@@ -1223,6 +1223,56 @@ def test_tv_loss_vs_oracle_and_reference(api, O, manifest):
         assert np.abs(np.delete(got, level, axis=0)).max() == 0, "only the level's own table receives gradient"
 
 
+@pytest.mark.parametrize("mode", ["cu", "ngp"])
+def test_hash_backward_packed_fixed_point_vs_float_atomics(api, mode):
+    """nrf_hash_backward_rays_packed (one 64-bit fixed-point atomic per entry) against nrf_hash_backward_rays (one float atomic per feature,
+    pinned to the reference's autograd by test_training_backward_stages_vs_reference_autograd): same addends, so the difference is the
+    round-to-nearest of each addend to (mass bound) * 2^-30, with the bound computed on the device.  Includes samples piled onto one voxel
+    (the overflow-relevant case) and accumulation into a non-zero g_table."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    sc = api.S.make_hash_scene(mode=mode, log2_t=14, seed=99, table_amp=0.3)
+    e = sc["embedder"]
+    rng = np.random.default_rng(5)
+    n, s = 600, 48
+    bb = api.S.LEGO_BBOX
+    o = rng.uniform(bb[:3], bb[3:], (n, 1, 3)); dd = rng.standard_normal((n, 1, 3)) * 0.02
+    pts = (o + dd * np.arange(s)[None, :, None]).astype(np.float32)
+    pts[:50] = pts[0, 0]                                  # 2400 samples in one voxel of every level
+    pts[50:60] += np.float32(3.0 if mode == "cu" else 2e-3)     # outside the box: the HashEmbedder's weights leave [0,1] there and the bound has to know (it grows with the distance)
+    g = (rng.standard_normal((n * s, 32)) * 1e-4).astype(np.float32)
+    g[:50 * s] = np.abs(g[:50 * s])                       # coherent: the pile adds up
+    g[rng.random(n * s) < 0.1] = 0.0
+    dp, dg = dev(pts.reshape(-1, 3)), dev(g)
+    lib = api.L.lib()
+    base = (rng.standard_normal(e.table_elems()) * 1e-3).astype(np.float32)
+    gt_f, gt_q = dev(base.copy()), dev(base.copy())
+    api.L.check(lib.nrf_hash_backward_rays(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_f), None))
+    nb = lib.nrf_hash_backward_packed_workspace_bytes(e._h)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                    # second call: the workspace is reusable as is
+        gt_q.copy_(dev(base))
+        api.L.check(lib.nrf_hash_backward_rays_packed(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_q), P(ws), C.c_size_t(nb), None))
+    a, b = host(gt_q) - base, host(gt_f) - base
+    assert np.abs(b).max() > 1e-2                         # the pile
+    unit = float(ws[768 + 4:768 + 8].view(torch.float32).cpu()[0])          # 1 / scale of the (only) pass, as the device chose it
+    mass = np.abs(g).reshape(-1, 16, 2).max(2).sum(0)     # per level
+    bound = (mass[:-1] + mass[1:]).max() if mode == "cu" else mass.max()
+    assert unit >= bound * 2.0 ** -30                     # never finer than the rigorous bound allows ...
+    if mode == "cu":
+        assert unit <= bound * 1.01 * 2.0 ** -29          # ... and no coarser than the next power of two (the outside points only matter in ngp mode)
+    # an entry collects at most n*s*8 addends (in practice tens, 2400 on the pile), each off by <= unit/2, plus the float path's own fp32 summation noise
+    tol = 64 * unit + 3e-6 * np.abs(b)
+    assert (np.abs(a - b) <= tol).all(), (np.abs(a - b).max(), unit)
+    nz = b != 0
+    assert np.sqrt(np.mean((a[nz] - b[nz]) ** 2)) < 4 * unit + 1e-6 * np.sqrt(np.mean(b[nz] ** 2))
+    if mode == "cu":
+        h4 = api.M.CuHashEmbedder("e4", bb, 8, 4, 14, 16, 256)
+        h4.set_primes(np.array(api.S.CU_PRIMES[:24], np.int32))
+        with pytest.raises(api.L.NrfError):
+            api.L.check(lib.nrf_hash_backward_rays_packed(h4._h, P(dp), C.c_int64(n), s, P(dg), P(gt_q), P(ws), C.c_size_t(nb), None))
+
+
 def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
     """Trainer(mlp_backward="f16") vs the fp32 trainer on the same rendered batch of a HashNeRF scene: gradients of the MLP and of the hash table
     (which sees the MLP backward through d loss / d features), then three optimisation steps with the same loss trajectory."""
@@ -1256,13 +1306,21 @@ def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
     assert np.corrcoef(gt16[nz], gt32[nz])[0, 1] > 0.999
     # a few steps: same descent
     losses = {}
-    for mode in ("f32", "f16"):
-        tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-3, mlp_backward=mode)
-        losses[mode] = [float(host(tr.step(o, d, tgt, rp)[0])[0]) for _ in range(4)]
-    assert losses["f16"][-1] < losses["f16"][0]
-    assert np.allclose(losses["f16"], losses["f32"], rtol=2e-2), losses
+    for mode, hmode in (("f32", "f32"), ("f16", "f32"), ("f16", "packed")):
+        tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-3, mlp_backward=mode, hash_backward=hmode)
+        losses[mode + hmode] = [float(host(tr.step(o, d, tgt, rp)[0])[0]) for _ in range(4)]
+        if hmode == "packed":                                  # table gradient of the last step vs the float-atomic trainer's (same parameters up to step noise)
+            gq = host(tr.g_table)
+        elif mode == "f16":
+            gf = host(tr.g_table)
+    assert losses["f16f32"][-1] < losses["f16f32"][0]
+    assert np.allclose(losses["f16f32"], losses["f32f32"], rtol=2e-2), losses
+    assert np.allclose(losses["f16packed"], losses["f32f32"], rtol=2e-2), losses
+    assert np.corrcoef(gq, gf)[0, 1] > 0.99
     with pytest.raises(api.L.NrfError):
         Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], mlp_backward="bf16")
+    with pytest.raises(api.L.NrfError):
+        Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], hash_backward="f16")
 
 
 def test_trainer_tv_regulariser_smooths_the_table(api):

@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from nerfpp_amd import _lib as L, scene as S, renderer as R
 from nerfpp_amd.train import Trainer
 H = W = 800
@@ -11,7 +11,8 @@ o, d, _ = R.GetRays(H, W, K, c2w)
 idx = torch.arange(0, N, device="cuda") * (H * W // N)
 o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
 tgt = torch.rand((N, 3), device="cuda")
-tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4)
+MB = sys.argv[2] if len(sys.argv) > 2 else "f32"; HB = sys.argv[3] if len(sys.argv) > 3 else "f32"
+tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=MB, hash_backward=HB)
 for prec, name in ((L.NRF_PREC_F16_SPLIT, "f16x3"), (L.NRF_PREC_F32, "f32")):
     rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=N, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                             BoundingBox=S.LEGO_BBOX, Precision=prec)
