@@ -540,17 +540,22 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
     if (params_on_device) {
         NRF_HIP(hipMemcpyAsync(hp.data(), params, hp.size() * 4, hipMemcpyDeviceToHost, st));
         NRF_HIP(hipStreamSynchronize(st));
-    } else memcpy(hp.data(), params, hp.size() * 4);
+    } else {
+        memcpy(hp.data(), params, hp.size() * 4);
+        NRF_HIP(hipStreamSynchronize(st));             // the derived images are overwritten in place: nothing may still be reading them
+    }
     NRF_HIP(hipMemcpyAsync(m->d_params, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
-    std::vector<float> wt;
-    for (auto &L : m->layers) {
+    std::vector<std::vector<float>> wts(m->layers.size());          // alive until the one synchronisation below
+    for (size_t li = 0; li < m->layers.size(); li++) {
+        auto &L = m->layers[li];
+        auto &wt = wts[li];
         wt.resize((size_t)L.in * L.out);
         for (int o = 0; o < L.out; o++)
             for (int k = 0; k < L.in; k++) wt[(size_t)k * L.out + o] = hp[L.w_off + (size_t)o * L.in + k];
         NRF_HIP(hipMemcpyAsync(L.d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
         if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, hp.data() + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyHostToDevice, st));
-        NRF_HIP(hipStreamSynchronize(st));            // wt is reused by the next layer
     }
+    NRF_HIP(hipStreamSynchronize(st));
     if (m->family == MLP_SMALL) return mlp_small_pack_f16(m, hp);
     if (m->family == MLP_NERF) return mlp_nerf_pack_f16(m, hp);
     if (m->family == MLP_LERF) return mlp_lerf_pack_f16(m, hp);

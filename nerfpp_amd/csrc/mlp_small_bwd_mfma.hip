@@ -428,9 +428,12 @@ LayerOffs layer_offsets(const nrf_mlp *m)
 int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
 {
     const auto &d = m->small;
-    if (m->d_packed_bwd) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; m->packed_bwd_bytes = 0; }
-    if (!bwd_supported(d)) return NRF_OK;
-    for (auto &L : m->layers) if (L.d_bias) return NRF_OK;
+    bool ok = bwd_supported(d);
+    for (auto &L : m->layers) if (L.d_bias) ok = false;
+    if (!ok) {
+        if (m->d_packed_bwd) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; m->packed_bwd_bytes = 0; }
+        return NRF_OK;
+    }
     const int G = d.geo_feat_dim;
     auto natural = [](int ks, int h, int j) { return 16 * ks + 8 * h + j; };
     auto chained = [](int ks, int h, int j) { return 32 * (ks >> 1) + prow(ks & 1, h, j); };
@@ -458,9 +461,11 @@ int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
         else if (l > 0) pk.layer(transposed(L), 64, 64, 2, 4, chained);
         else pk.layer(transposed(L), 32, 64, 1, 4, chained);
     }
-    m->packed_bwd_bytes = pk.img.size() * sizeof(_Float16);
-    NRF_HIP(hipMalloc(&m->d_packed_bwd, m->packed_bwd_bytes));
-    NRF_HIP(hipMemcpy(m->d_packed_bwd, pk.img.data(), m->packed_bwd_bytes, hipMemcpyHostToDevice));
+    const size_t bytes = pk.img.size() * sizeof(_Float16);
+    if (m->d_packed_bwd && m->packed_bwd_bytes != bytes) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; }
+    if (!m->d_packed_bwd) NRF_HIP(hipMalloc(&m->d_packed_bwd, bytes));        // re-packed every optimisation step: overwritten in place
+    m->packed_bwd_bytes = bytes;
+    NRF_HIP(hipMemcpy(m->d_packed_bwd, pk.img.data(), bytes, hipMemcpyHostToDevice));
     return NRF_OK;
 }
 

@@ -440,14 +440,17 @@ int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     pk2.split = true;
     pack_small(d, hp, pk);
     pack_small(d, hp, pk2);
-    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // re-pack after nrf_mlp_set_params
-    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
-    m->packed_f16_bytes = pk.img.size() * sizeof(_Float16);
-    NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
-    NRF_HIP(hipMemcpy(m->d_packed_f16, pk.img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));
-    m->packed_split_bytes = pk2.img.size() * sizeof(_Float16);
-    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
-    NRF_HIP(hipMemcpy(m->d_packed_split, pk2.img.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
+    // re-pack after nrf_mlp_set_params (every optimisation step): same sizes, so the device images are overwritten in place
+    auto upload = [](void *&dst, size_t &have, const std::vector<_Float16> &img) -> int {
+        const size_t bytes = img.size() * sizeof(_Float16);
+        if (dst && have != bytes) { (void)hipFree(dst); dst = nullptr; }
+        if (!dst) NRF_HIP(hipMalloc(&dst, bytes));
+        have = bytes;
+        NRF_HIP(hipMemcpy(dst, img.data(), bytes, hipMemcpyHostToDevice));
+        return NRF_OK;
+    };
+    NRF_TRY(upload(m->d_packed_f16, m->packed_f16_bytes, pk.img));
+    NRF_TRY(upload(m->d_packed_split, m->packed_split_bytes, pk2.img));
     return mlp_small_pack_bwd(m, hp);
 }
 
