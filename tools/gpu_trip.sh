@@ -13,5 +13,6 @@ ROOTD=$PWD
 cd /tmp && export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_classic -- python3 $ROOTD/bench.py --workload classic --steps 3 --warmup 1 --no-cpu-baseline --no-also 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof_classic.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_train -- python3 $ROOTD/tools/scratch/train_prof.py 16384 f16 packed --fast-only 2>&1 | tail -8) > $ROOTD/gpurun_out/${tag}_prof_train.log 2>&1
 cd $ROOTD
 tail -4 gpurun_out/${tag}_tests.log

@@ -13,7 +13,7 @@ o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
 tgt = torch.rand((N, 3), device="cuda")
 MB = sys.argv[2] if len(sys.argv) > 2 else "f32"; HB = sys.argv[3] if len(sys.argv) > 3 else "f32"
 tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=MB, hash_backward=HB)
-for prec, name in ((L.NRF_PREC_F16_SPLIT, "f16x3"), (L.NRF_PREC_F32, "f32")):
+for prec, name in ((L.NRF_PREC_F16_SPLIT, "f16x3"), (L.NRF_PREC_F32, "f32"))[:1 if "--fast-only" in sys.argv else 2]:
     rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=N, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                             BoundingBox=S.LEGO_BBOX, Precision=prec)
     for _ in range(2): tr.step(o, d, tgt, rp)
