@@ -198,6 +198,10 @@ def main():
                 mroof["note"] = ("achieved / frac price the ALGORITHMIC 35 072 flop per unit; the split-precision mode issues three fp16 products per algorithmic one "
                                  "to deliver fp32-grade pixels (north_star: within 1e-4), mfma_issued_frac is the matrix pipe's own utilisation") if args.precision == "f16x3" else \
                                 "achieved / frac price the algorithmic 35 072 flop per unit; mfma_issued_frac includes the zero padding of the 16- and 3-wide layers"
+                busy = pmc_mfma_busy("mlp_small (k_mlp_small_mfma)", args.precision)
+                if busy:
+                    mroof["mfma_busy_frac_of_active_cycles"] = busy
+                    mroof["clock_held_ghz"] = 2.4 * mroof["mfma_issued_frac"] / busy
             # the roofline object describes the kernel that took the most time in THIS run (split precision: the MLP; plain fp16: the hash encode);
             # the other one rides along under its own key
             hroof = roof
@@ -380,6 +384,16 @@ def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
         return per_unit * units_per_launch, f"profiles/pmc_latest.json ({d['_meta']['source']}): (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, gfx950 x2 read correction"
     except Exception:
         return None, None
+
+
+def pmc_mfma_busy(kernel, precision):
+    """Share of GPU-active cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD), from the committed PMC
+    passes; with the issued fraction at the nominal 2.4 GHz it gives the clock the chip held: clock = 2.4 GHz * issued_frac / busy_frac."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        return float(d[kernel]["mfma_busy_frac_of_active_cycles"][precision])
+    except Exception:
+        return None
 
 
 def quality_check(sc, renderer, rp, K, c2w, args, nrays=256):

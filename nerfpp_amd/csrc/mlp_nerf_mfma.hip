@@ -78,8 +78,13 @@ struct Stage {
 // no per-chunk address ever occupies a vector register (40 chunks x up to 10 pieces of 64-bit lane addresses, hoisted out
 // of the persistent loop as loop invariants, is what spilled the first version of this kernel).
 template <int CI>
-__device__ __forceinline__ void stage_load(Stage &st, __amdgpu_buffer_rsrc_t rsrc, int tid)
+__device__ __forceinline__ void stage_load(Stage &st, const half8 *packed, int tid)
 {
+    // The descriptor is rebuilt from the (pinned) scalar pointer at every use.  Carried across the persistent loop it ends up in VGPRs -- the 100+
+    // SGPRs of this kernel are spoken for -- and every buffer_load is then wrapped in a readfirstlane / compare / branch "waterfall" loop.
+    asm volatile("" : "+s"(packed));
+    constexpr int image_bytes = NerfNet::total_frags() * 1024;      // constexpr: the table functions must fold at compile time
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, image_bytes, 0x00020000);
     constexpr int ci = CI % NerfNet::total_chunks();
     constexpr int n = NerfNet::chunk_frags(ci) * 64;          // 16-byte pieces in the chunk
     constexpr int base = NerfNet::chunk_off(ci) * 1024;       // byte offset of the chunk in the image
@@ -116,7 +121,7 @@ __device__ __forceinline__ half8 nerf_tile_to_frag(const f32x16 &acc, int s)
 struct Ctx {
     half8 *wbuf;            // [2][MAXF*64]
     const float *bias_s;    // LDS
-    __amdgpu_buffer_rsrc_t packed;   // buffer descriptor of the weight image (wave-uniform)
+    const half8 *packed;    // the weight image (wave-uniform)
     int tid, lane, h;
     bool last_block;
 };
@@ -215,16 +220,15 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     for (int i = tid; i < NBIAS; i += 64 * NW) bias_s[i] = biases[i];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, NerfNet::total_frags() * 1024, 0x00020000);
     {   // chunk 0 into buffer 0
         Stage st;
-        stage_load<0>(st, rsrc, tid);
+        stage_load<0>(st, packed, tid);
         stage_store<0>(st, wbuf, tid);
     }
     __syncthreads();
     const int64_t nblocks = (npts + NBLK - 1) / NBLK;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        Ctx cx{wbuf, bias_s, rsrc, tid, lane, h, blk + gridDim.x >= nblocks};
+        Ctx cx{wbuf, bias_s, packed, tid, lane, h, blk + gridDim.x >= nblocks};
         // point index of this lane's column in tile pt (recomputed where needed: nothing per-point stays live across the network)
         auto point_of = [&](int pt) -> int64_t { return blk * NBLK + (wave * NPT + pt) * 32 + r; };
         auto clamped = [&](int pt) -> int64_t { const int64_t q = point_of(pt); return q < npts ? q : npts - 1; };
