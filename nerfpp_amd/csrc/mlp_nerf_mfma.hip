@@ -9,10 +9,20 @@
 //
 // What does not fit on chip is the weights: 1.16 MB of fp16 against 160 KB of LDS per CU.  The weight image
 // is therefore cut into 40 CHUNKS (two 32-neuron tiles x all k-steps of a layer, <= 40 KB) laid out in consumption
-// order; a 512-thread workgroup (8 waves x 32 points = 256 points, one workgroup per CU, two waves per SIMD, persistent) streams chunk i+1 from L2 into registers while its waves run the MFMAs of chunk i
-// out of LDS, and writes it to the other LDS buffer before the
-// barrier that ends the chunk (issue-early / write-late staging).  Every A fragment is one conflict-free ds_read_b128.
-// L2 -> LDS weight traffic is 1.16 MB per 256 points, ~4.6 KB per point.
+// order and streamed through THREE LDS buffers by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write
+// pass): a 512-thread workgroup (8 waves x 32 points = 256 points, one workgroup per CU, two waves per SIMD, persistent)
+// requests chunk i+2 at the top of chunk i, runs the MFMAs of chunk i out of LDS, and ends the chunk with a counted
+// s_waitcnt vmcnt (chunk i+1 landed, i+2 may stay in flight) and a raw s_barrier.  Every A fragment is one conflict-free
+// ds_read_b128.  L2 -> LDS weight traffic is 1.16 MB per 256 points, ~4.6 KB per point.
+//
+// Measured on MI355X (800x800, 64+128; same box for every row): register-staged double buffer whose buffer_loads sat in
+// waterfall loops (the descriptor had ended up in VGPRs) 187 ms -> descriptor rebuilt from the pinned scalar pointer 179 ->
+// LDS-DMA, two buffers 169 -> three buffers, two chunks ahead 166.  Ablations of the final kernel: no barriers 162; the DMA
+// reading the same 1 KB every time (L2 out of the picture) 160; a quarter of the DMA instructions 133; no DMA at all 122.
+// So what the stream costs is neither its L2 bandwidth (4.5 TB/s aggregate) nor its latency but the LDS-side write of
+// 1.16 MB per 256 points, ~35 clocks per 1-KB instruction during which the workgroup's fragment reads make no progress;
+// the lever that remains is more points per weight pass, which at 64 VGPRs of activations per 32 points and buffer is a
+// register-file problem (two tiles per wave = 256 VGPRs for the two activation buffers alone).
 //
 // Layer plan (D = 8, W = 256, skip 4, PE(10) positions = 63 -> 4 k-steps, PE(4) directions = 27 -> 2 k-steps):
 //   0      : pts_linears_0   [nat 4]              -> 8 tiles  ReLU
@@ -63,47 +73,25 @@ struct NerfNet {
     static constexpr int bias_off(int l) { int n = 0; for (int i = 0; i < l; i++) n += (i == 8 ? 288 : tiles(i) * 32); return n; }
 };
 static_assert(NerfNet::total_chunks() == 40, "chunk count");
-static_assert(NerfNet::total_chunks() % 2 == 0, "double-buffer parity must repeat per point block");
 
-// Staging registers for the NEXT chunk: each thread carries up to NPIECE 16-byte pieces.
-constexpr int NPIECE = (MAXF * 64 + 64 * NW - 1) / (64 * NW);
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct Stage {
-    u32x4 r[NPIECE];
-};
-
-// The chunk's byte offset travels in the SCALAR offset of a buffer load and the per-lane part is the single VGPR tid*16, so
-// no per-chunk address ever occupies a vector register (40 chunks x up to 10 pieces of 64-bit lane addresses, hoisted out
-// of the persistent loop as loop invariants, is what spilled the first version of this kernel).
+// Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves one 1-KB fragment
+// (64 lanes x 16 B, lane-linear on both sides -- exactly the fragment layout), wave w takes fragments w, w + NW, ...  No staging registers
+// (the register-staged version carried 20 VGPRs per thread in a kernel at the 256-VGPR cap) and no ds_write pass; the data is in flight
+// while the chunk's MFMAs run and is retired by the vmcnt(0) that __syncthreads() emits at the end of the chunk.
+// The fragment's address is a pinned SGPR base + lane * 16: left to itself the compiler hoists 40 chunks x 5 lane addresses out of the
+// persistent loop as 64-bit VGPR pairs.
 template <int CI>
-__device__ __forceinline__ void stage_load(Stage &st, const half8 *packed, int tid)
-{
-    // The descriptor is rebuilt from the (pinned) scalar pointer at every use.  Carried across the persistent loop it ends up in VGPRs -- the 100+
-    // SGPRs of this kernel are spoken for -- and every buffer_load is then wrapped in a readfirstlane / compare / branch "waterfall" loop.
-    asm volatile("" : "+s"(packed));
-    constexpr int image_bytes = NerfNet::total_frags() * 1024;      // constexpr: the table functions must fold at compile time
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, image_bytes, 0x00020000);
-    constexpr int ci = CI % NerfNet::total_chunks();
-    constexpr int n = NerfNet::chunk_frags(ci) * 64;          // 16-byte pieces in the chunk
-    constexpr int base = NerfNet::chunk_off(ci) * 1024;       // byte offset of the chunk in the image
-#pragma unroll
-    for (int q = 0; q < NPIECE; q++) {
-        const int i = q * (64 * NW) + tid;
-        if (q * (64 * NW) < n) { if (i < n) st.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, base + q * (64 * NW * 16), 0); }
-    }
-}
-
-template <int CI>
-__device__ __forceinline__ void stage_store(const Stage &st, half8 *__restrict__ dst, int tid)
+__device__ __forceinline__ void stage_dma(half8 *__restrict__ dst, const half8 *__restrict__ packed, int wave, int lane)
 {
     constexpr int ci = CI % NerfNet::total_chunks();
-    constexpr int n = NerfNet::chunk_frags(ci) * 64;
+    constexpr int nf = NerfNet::chunk_frags(ci);
+    constexpr int base = NerfNet::chunk_off(ci);
+    const half8 *pk = packed + (size_t)wave * 64;
+    asm volatile("" : "+s"(pk));                          // opaque here: what is derived from it below cannot be hoisted
 #pragma unroll
-    for (int q = 0; q < NPIECE; q++) {
-        const int i = q * (64 * NW) + tid;
-        if (q * (64 * NW) < n) { if (i < n) reinterpret_cast<u32x4 *>(dst)[i] = st.r[q]; }
+    for (int q = 0; q < (nf + NW - 1) / NW; q++) {
+        if (q * NW + wave < nf)                          // wave-uniform
+            __builtin_amdgcn_global_load_lds(pk + (size_t)(base + q * NW) * 64 + lane, (__attribute__((address_space(3))) void *)(dst + (q * NW + wave) * 64), 16, 0, 0);
     }
 }
 
@@ -122,8 +110,8 @@ struct Ctx {
     half8 *wbuf;            // [2][MAXF*64]
     const float *bias_s;    // LDS
     const half8 *packed;    // the weight image (wave-uniform)
-    int tid, lane, h;
-    bool last_block;
+    int tid, lane, h, wave;
+    int *cur;               // LDS buffer (0..2) holding the chunk being consumed; wave-uniform, advanced by every chunk
 };
 
 // One chunk (<= 2 neuron tiles of layer L): start fetching the following chunk, run this chunk's MFMAs out of LDS, turn the
@@ -131,25 +119,25 @@ struct Ctx {
 // constexpr table functions of NerfNet must be evaluated at compile time: called with a loop variable they become runtime
 // loops).  `last` receives the layer's final tile (alpha row / rgb rows are read from it).
 template <int L, int C, bool RELU, int NN, int NC, int NOUT>
-__device__ __forceinline__ void nerf_chunk(const Ctx &cx, const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT])
+__device__ __forceinline__ void nerf_chunk_body(const Ctx &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const float *__restrict__ bias_s,
+                                                const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT])
 {
+    // w / dma_dst / bias_s are __restrict__ PARAMETERS on purpose: inlining turns that into alias-scope metadata on the LDS reads and on the DMA's LDS
+    // write, which is what lets the compiler see that this chunk's reads do not touch the look-ahead's destination.  Without it every LDS read issued
+    // while an LDS-DMA is pending is preceded by s_waitcnt vmcnt(0) and the look-ahead is drained at the top of the chunk.
     constexpr int KSN = NerfNet::ks_nat(L), KSC = NerfNet::ks_ch(L), KS = KSN + KSC;
     constexpr int CI = NerfNet::first_chunk(L) + C;
-    constexpr bool FINAL = (CI == NerfNet::total_chunks() - 1);
     constexpr int NT = NerfNet::chunk_tiles(L, C);
     constexpr int BOFF = NerfNet::bias_off(L);
     constexpr int NTILES = NerfNet::tiles(L);
     constexpr bool NATF = NerfNet::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
-    Stage st;
-    const bool fetch = !(FINAL && cx.last_block);
-    if (fetch) stage_load<CI + 1>(st, cx.packed, cx.tid);
-    const half8 *w = cx.wbuf + (CI & 1) * (MAXF * 64);
+    stage_dma<CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const int tile = 2 * C + t;
         f32x16 acc[NPT];
-        const float *bp = cx.bias_s + BOFF + tile * 32 + 4 * cx.h;
+        const float *bp = bias_s + BOFF + tile * 32 + 4 * cx.h;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const float4 bv = *reinterpret_cast<const float4 *>(bp + 8 * g);
@@ -166,8 +154,8 @@ __device__ __forceinline__ void nerf_chunk(const Ctx &cx, const half8 (&bn)[NPT]
                 else b = (k < KSC) ? bc[pt][k < KSC ? k : 0] : bn[pt][k >= KSC ? k - KSC : 0];
                 acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[pt], 0, 0, 0);
             }
-            // keep the weight-fragment reads at most a group of 4 ahead of their MFMAs: without the fence the scheduler
-            // hoists all 16-20 ds_read_b128 of a tile (64-80 VGPRs)
+            // keep the weight-fragment reads at most a group of 4 ahead of their MFMAs: without the fence the scheduler hoists all 16-20 ds_read_b128 of a
+            // tile (64-80 VGPRs).  (Fetching a whole group ahead of the previous group's MFMAs was measured: no gain, two waves per SIMD already cover it.)
             if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -179,8 +167,20 @@ __device__ __forceinline__ void nerf_chunk(const Ctx &cx, const half8 (&bn)[NPT]
             if (tile == NTILES - 1) last[pt] = acc[pt];
         }
     }
-    if (fetch) stage_store<CI + 1>(st, cx.wbuf + ((CI + 1) & 1) * (MAXF * 64), cx.tid);
-    __syncthreads();
+    // End of the chunk: chunk CI + 1 (requested one whole chunk ago) must have landed, chunk CI + 2 (requested at the top of this one) may stay in
+    // flight -- a counted vmcnt and a RAW barrier (__syncthreads() would drain the DMA with vmcnt(0)).  KEEP = the fewest DMA instructions any wave
+    // issued for chunk CI + 2.  The "memory" clobber keeps the compiler from moving LDS reads across it.
+    constexpr int KEEP = NerfNet::chunk_frags((CI + 2) % NerfNet::total_chunks()) / NW;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
+template <int L, int C, bool RELU, int NN, int NC, int NOUT>
+__device__ __forceinline__ void nerf_chunk(const Ctx &cx, const half8 (&bn)[NPT][NN], const half8 (&bc)[NPT][NC], half8 (&bout)[NPT][NOUT], f32x16 (&last)[NPT])
+{
+    // chunk CI + 2 -> the buffer chunk CI - 1 was consumed from (every wave is past the barrier that ended it)
+    const int cur = *cx.cur;
+    nerf_chunk_body<L, C, RELU>(cx, cx.wbuf + cur * (MAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (MAXF * 64), cx.bias_s, bn, bc, bout, last);
+    *cx.cur = cur == 2 ? 0 : cur + 1;
 }
 
 template <int L, bool RELU, int NN, int NC, int NOUT, int... Cs>
@@ -211,24 +211,21 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
                 float *__restrict__ out, int out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // biases FIRST: their LDS addresses then fit the 16-bit immediate offset of ds_read (one base VGPR for all 76 tiles)
-    constexpr int BIAS_BYTES = (NBIAS * 4 + 1023) / 1024 * 1024;
-    float *bias_s = reinterpret_cast<float *>(smem);
-    half8 *wbuf = reinterpret_cast<half8 *>(smem + BIAS_BYTES);
-    // the position fragments are needed twice (layer 0 and the skip layer 5): parked in LDS in between (4 KB per wave per tile)
-    half8 *pe_park = reinterpret_cast<half8 *>(smem + BIAS_BYTES + 2 * MAXF * 1024) + (size_t)(threadIdx.x >> 6) * (NPT * 4 * 64);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The biases live in their OWN LDS object: the compiler makes every LDS read that may alias a pending LDS-DMA wait for vmcnt(0), which would drain the
+    // look-ahead at the first bias read of a chunk; reads of a distinct object are provably clear of the DMA destinations in `smem`.
+    __shared__ __attribute__((aligned(16))) float bias_s[NBIAS];
+    half8 *wbuf = reinterpret_cast<half8 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     for (int i = tid; i < NBIAS; i += 64 * NW) bias_s[i] = biases[i];
-    {   // chunk 0 into buffer 0
-        Stage st;
-        stage_load<0>(st, packed, tid);
-        stage_store<0>(st, wbuf, tid);
-    }
-    __syncthreads();
+    // three LDS buffers, weights requested TWO chunks ahead of their use: a chunk's MFMAs take 1-2 us, an L2 round trip under this load about as long
+    stage_dma<0>(wbuf, packed, wave, lane);
+    stage_dma<1>(wbuf + MAXF * 64, packed, wave, lane);
+    __syncthreads();                               // vmcnt(0): chunks 0 and 1 are in place
+    int cur = 0;
     const int64_t nblocks = (npts + NBLK - 1) / NBLK;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        Ctx cx{wbuf, bias_s, packed, tid, lane, h, blk + gridDim.x >= nblocks};
+        Ctx cx{wbuf, bias_s, packed, tid, lane, h, wave, &cur};
         // point index of this lane's column in tile pt (recomputed where needed: nothing per-point stays live across the network)
         auto point_of = [&](int pt) -> int64_t { return blk * NBLK + (wave * NPT + pt) * 32 + r; };
         auto clamped = [&](int pt) -> int64_t { const int64_t q = point_of(pt); return q < npts ? q : npts - 1; };
@@ -275,27 +272,14 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
         };
         half8 ba[NPT][16], bb[NPT][16], none[NPT][1];
         f32x16 last[NPT];
-        {
-            half8 pe[NPT][4];
-            load_pe(pe);
-#pragma unroll
-            for (int pt = 0; pt < NPT; pt++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) pe_park[(pt * 4 + s) * 64 + lane] = pe[pt][s];
-            nerf_layer<0, true>(cx, pe, none, ba, last);
-        }
+        half8 pe[NPT][4];                                      // needed twice (layer 0 and the skip layer 5): 16 registers, freed by the DMA staging
+        load_pe(pe);
+        nerf_layer<0, true>(cx, pe, none, ba, last);
         nerf_layer<1, true>(cx, none, ba, bb, last);
         nerf_layer<2, true>(cx, none, bb, ba, last);
         nerf_layer<3, true>(cx, none, ba, bb, last);
         nerf_layer<4, true>(cx, none, bb, ba, last);
-        {
-            half8 pe[NPT][4];
-#pragma unroll
-            for (int pt = 0; pt < NPT; pt++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) pe[pt][s] = pe_park[(pt * 4 + s) * 64 + lane];     // own lane's data: no barrier needed
-            nerf_layer<5, true>(cx, pe, ba, bb, last);
-        }
+        nerf_layer<5, true>(cx, pe, ba, bb, last);
         nerf_layer<6, true>(cx, none, bb, ba, last);
         nerf_layer<7, true>(cx, none, ba, bb, last);
         nerf_layer<8, false>(cx, none, bb, ba, last);          // feature tiles -> ba (no ReLU); tile 8 row 0 = alpha
@@ -331,6 +315,7 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two chunks' look-ahead requests are still in flight
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -415,7 +400,7 @@ static int launch_nerf(const nrf_mlp *m, const NerfInput &in, bool fused, int64_
         set_error("NRF_PREC_F16_MFMA: this NeRF shape is outside the built matrix-core family (8 x 256, skip 4, PE(10)/PE(4), view directions); use NRF_PREC_F32");
         return NRF_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)2 * MAXF * 1024 + ((size_t)NBIAS * sizeof(float) + 1023) / 1024 * 1024 + (size_t)NW * NPT * 4 * 1024;
+    const size_t lds = (size_t)3 * MAXF * 1024;          // + the static bias array
     const int64_t nblocks = ceil_div(p, NBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent workgroup per CU
     static bool attr_set = false;
