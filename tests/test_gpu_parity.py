@@ -877,6 +877,47 @@ def test_mlp_backward_matrix_core_exact_on_integer_network(api, nl, nlc, p):
     assert np.abs(gx32).max() > 0
 
 
+def test_mlp_backward_matrix_core_edges(api):
+    """Boundary behaviour of nrf_mlp_backward_f16: empty batch, optional d_g_x, all-zero output gradient (loss scale of nothing), accumulation into a
+    non-zero gradient blob, a workspace that is too small, a NeRFSmall shape outside the built family, more points than one 2^22-point pass."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    rng = np.random.default_rng(3)
+    dims = _small_dims(3, 4)
+    blob = (rng.standard_normal(sum(i * o for i, o in dims)) * 0.2).astype(np.float32)
+    m = api.M.NeRFSmall(3, 64, 15, 4, 64, False, 3, 64, 32, 16, "model", params=blob)
+    lib = api.L.lib()
+    p = 777
+    x = dev(rng.uniform(-1, 1, (p, 48)).astype(np.float32)); gr = dev((rng.standard_normal((p, 4)) * 1e-3).astype(np.float32))
+    nb = lib.nrf_mlp_backward_f16_workspace_bytes(m._m, C.c_int64(p))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    g0 = torch.zeros(blob.size, device="cuda"); gx = torch.zeros((p, 32), device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(0), P(g0), P(gx), P(ws), C.c_size_t(nb), None))          # p = 0
+    assert float(g0.abs().max()) == 0.0
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(g0), P(gx), P(ws), C.c_size_t(nb), None))
+    g1 = torch.full((blob.size,), 0.5, device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(g1), None, P(ws), C.c_size_t(nb), None))            # no d_g_x; accumulates
+    assert_close(host(g1) - 0.5, host(g0), rtol=1e-4, atol=1e-6 * float(g0.abs().max()), what="accumulation into a non-zero blob")
+    gz = torch.zeros_like(gr); g2 = torch.zeros(blob.size, device="cuda"); gx2 = torch.ones((p, 32), device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gz), C.c_int64(p), P(g2), P(gx2), P(ws), C.c_size_t(nb), None))          # zero gradient in
+    assert float(g2.abs().max()) == 0.0 and float(gx2.abs().max()) == 0.0
+    with pytest.raises(api.L.NrfError):
+        api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(g0), P(gx), P(ws), C.c_size_t(1024), None))
+    m8 = api.M.NeRFSmall(3, 64, 15, 3, 64, False, 3, 64, 8, 16, "model", params=(rng.standard_normal(8 * 64 + 64 * 64 + 64 * 16 + 31 * 64 + 64 * 64 + 64 * 3) * 0.1).astype(np.float32))
+    x8 = torch.zeros((p, 24), device="cuda")
+    with pytest.raises(api.L.NrfError):
+        api.L.check(lib.nrf_mlp_backward_f16(m8._m, P(x8), P(gr), C.c_int64(p), P(g0), P(gx), P(ws), C.c_size_t(nb), None))
+    # two passes (2^22 points each): the second pass's points must land in the same gradient
+    pbig = (1 << 22) + 1000
+    xb = x[:1].expand(pbig, 48).contiguous(); gb = gr[:1].expand(pbig, 4).contiguous()
+    nbb = lib.nrf_mlp_backward_f16_workspace_bytes(m._m, C.c_int64(pbig))
+    wsb = torch.empty(nbb, dtype=torch.uint8, device="cuda")
+    g3 = torch.zeros(blob.size, device="cuda"); g4 = torch.zeros(blob.size, device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(xb), P(gb), C.c_int64(pbig), P(g3), None, P(wsb), C.c_size_t(nbb), None))
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(xb), P(gb), C.c_int64(1000), P(g4), None, P(wsb), C.c_size_t(nbb), None))
+    assert_close(host(g3), host(g4) * (pbig / 1000.0), rtol=2e-3, atol=1e-5 * float(g3.abs().max()), what="identical points: gradient scales with their count")
+
+
 @pytest.mark.parametrize("nl,nlc,p", [(3, 4, 50000), (3, 3, 20001)])
 def test_mlp_backward_matrix_core_vs_fp32_random_network(api, nl, nlc, p):
     """Same comparison on a dense random network.  The fused kernel's own forward is fp16, so a pre-activation within ~1e-3 of zero can land on
