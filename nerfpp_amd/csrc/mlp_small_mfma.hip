@@ -371,6 +371,11 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     }
 }
 
+// Tried and measured (same box): the last colour layer (64 -> 3, one 32-row tile with 3 useful rows = 12 of the split mode's 116 matrix instructions per tile)
+// moved to the vector ALUs in fp32, straight from the last hidden layer's D tiles.  Split mode: 13.63 vs 13.65 ms per frame -- nothing, although
+// 11 % of the matrix work is gone: the chip is holding its clock down under this load, so cycles taken off the matrix pipe and put on the
+// vector ALUs come back as clock, not as time.  Plain fp16 mode: 7.1 vs 5.5 ms (194 VGPRs instead of 146 cost the third wave per SIMD).  Not kept.
+
 // ---------------------------------------------------------------------------------------------------
 // weight image
 // ---------------------------------------------------------------------------------------------------
