@@ -300,7 +300,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
 
 def lerf_measurement(scene, K, c2w, rows=200):
     """BASELINE config 4: the LeRF language-embedding render pass (CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768, main.cpp:203-213)
-    on a 200-row band of the 800x800 frame (the 8-feature fp32 hash features of a chunk are 512 B per sample point), 64+128 samples."""
+    on a 200-row band of the 800x800 frame, 64+128 samples."""
     import torch
     from nerfpp_amd import renderer as R
     sc = scene.make_lerf_scene()
@@ -317,7 +317,9 @@ def lerf_measurement(scene, K, c2w, rows=200):
     emb = res.Outputs.RenderedLangEmbedding
     return dict(workload="lerf_lego800_64+128", baseline_config=4, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt * H / rows,
                 fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
-                arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; generic CuHash F=8 encode (fp32 features)")
+                level_major_features=bool(getattr(r, "level_major", False)),
+                arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
+                           "read by the kernels as operand fragments")
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):

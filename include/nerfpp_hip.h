@@ -146,6 +146,9 @@ NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float 
 /* BaseEmbedderImpl::forward for the hash grid: x [p,3] -> (embedding [p, L*F] fp32, keep_mask [p] u8).
  * d_keep_mask may be NULL. */
 NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, float *d_out, uint8_t *d_keep_mask, void *stream);
+/* CuHashEmbedder mode: the same features level-major in fp16, d_feats [n_levels][p][n_features] halfs (16-byte aligned) -- the values the row-major call
+ * returns (they are fp16-rounded there too, CuHashEmbedder.cu:95) in the layout a matrix-core consumer loads as operand fragments. */
+NRF_API int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MLPs                                                         BaseNeRFImpl::forward (NeRF.h:33-42)
@@ -208,6 +211,9 @@ NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float
 NRF_API int nrf_lerf_mfma_available(const nrf_mlp *m);
 NRF_API int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
 NRF_API int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
+/* ... reading the level-major fp16 features of nrf_hash_encode_lm_f16 (16 levels x 8 features: [16][p][8] halfs) instead of fp32 rows. */
+NRF_API int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
+NRF_API int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
 
 /* RenderCLIPEmbedding (LeRFRenderer.h:45-54): out[n, embed_dim] = normalize(sum_s weights[n,s] * embeds[n,s,:embed_dim], eps 1e-8).
  * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]).  Relevancy(...) (LeRFRenderer.cpp:79) lives

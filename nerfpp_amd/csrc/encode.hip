@@ -144,6 +144,46 @@ __global__ void k_hash_cu(HashParams hp, PointSource ps, int64_t p, float *__res
     for (int f = 0; f < F; f++) o[f] = __half2float(__float2half_rn(acc[f]));     // one fp16 rounding (.cu:95), returned as fp32 (.cu:274)
 }
 
+// The same lookup, written level-major in fp16: feats[level][point][F] (2F bytes per thread, contiguous across the points of a wave).  For F = 8 that is one
+// 16-byte store per thread and exactly the operand fragment of a matrix-core consumer: k-step s, lane half h = level 2s + h (mlp_lerf_mfma.hip).
+// The values are the row-major kernel's (one fp16 rounding of the fp32 blend, .cu:95), so consumers see identical inputs.
+template <int F>
+__global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *__restrict__ feats, uint8_t *__restrict__ keep)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= p) return;
+    const F3 pt = load_point(ps, i);
+    const float x[3] = {pt.x, pt.y, pt.z};
+    bool kp = true;
+    float fr[3];
+    uint32_t pos[3];
+    const float mul = hp.level_scale[l];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);
+        kp = kp && (x[a] == c);
+        float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * mul;
+        q = q + hp.bias[l * 3 + a];
+        const float fl = floorf(q);
+        pos[a] = (uint32_t)fl;
+        fr[a] = q - fl;
+    }
+    if (l == 0 && keep) keep[i] = kp ? 1 : 0;
+    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+    const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
+    float acc[F];
+    cu_blend<F>(fp, pos, fr, pa, pb, pc, hp.local_size[l], acc);
+    __half o[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) o[f] = __float2half_rn(acc[f]);
+    __half *dst = feats + ((int64_t)l * p + i) * F;
+    if constexpr (F == 8) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
+    else if constexpr (F == 4) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+    else if constexpr (F == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(o);
+    else dst[0] = o[0];
+}
+
 __global__ void k_f32_to_f16(int64_t n, const float *__restrict__ in, __half *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,6 +341,29 @@ int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
     h->primes_set = true;
     h->fast_valid = false;
     if (hash_fast_supported(h)) NRF_TRY(hash_fast_prepare(h, h->dense_budget, nullptr));
+    return NRF_OK;
+}
+
+int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream)
+{
+    NRF_CHECK_ARG(h && d_x && d_feats && p >= 0, "nrf_hash_encode_lm_f16: bad argument");
+    if (h->desc.mode != NRF_HASH_CU) { set_error("nrf_hash_encode_lm_f16: built for the CuHashEmbedder (its features ARE fp16, CuHashEmbedder.cu:95); the HashEmbedder's are fp32"); return NRF_ERR_UNSUPPORTED; }
+    if (!h->table_set || !h->primes_set) { set_error("nrf_hash_encode_lm_f16: table / primes not set"); return NRF_ERR_INVALID_ARG; }
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats) & 15) == 0, "nrf_hash_encode_lm_f16: feature buffer must be 16-byte aligned");
+    if (p == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(NRF_PROF_HASH, st);
+    PointSource ps{d_x, nullptr, nullptr, 0, 1};
+    const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)h->desc.n_levels);
+    __half *f = reinterpret_cast<__half *>(d_feats);
+    switch (h->desc.n_features) {
+        case 1: hipLaunchKernelGGL(k_hash_cu_lmf<1>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
+        case 2: hipLaunchKernelGGL(k_hash_cu_lmf<2>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
+        case 4: hipLaunchKernelGGL(k_hash_cu_lmf<4>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
+        case 8: hipLaunchKernelGGL(k_hash_cu_lmf<8>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
+        default: set_error("nrf_hash_encode_lm_f16: n_features %d not built (1, 2, 4, 8)", h->desc.n_features); return NRF_ERR_UNSUPPORTED;
+    }
+    NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 

@@ -216,7 +216,8 @@ struct ReduceHook {
 };
 
 struct Args {
-    const float *x; int x_stride;           // hash features [p, 128] fp32
+    const float *x; int x_stride;           // hash features [p, 128] fp32 ...
+    const __half *x_lm; int64_t pstride;    // ... or level-major fp16 [16][pstride][8] (nrf_hash_encode_lm_f16): k-step s, lane half h = level 2s + h, one 16-byte load
     const float *weights;                   // [p] render weights (kernel B)
     const uint8_t *keep;                    // optional: sigma forced to 0 where false (kernel A)
     float *sigma;                           // [p] (kernel A)
@@ -251,6 +252,11 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
         // (512 B per point from L2) rather than kept in 32 VGPRs across the sigma net
         half8 none[1];
         auto load_x = [&](half8 (&xin)[8]) {
+            if (in.x_lm) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) xin[s] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + qc) * 8);
+                return;
+            }
             const float *row = in.x + qc * in.x_stride;
 #pragma unroll
             for (int s = 0; s < 8; s++) {
@@ -363,7 +369,7 @@ int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, in
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_sigma: feature rows must be 16-byte aligned");
     if (p == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_MLP, as_stream(stream));
-    lerf::Args a{d_x, lerf::IN, nullptr, d_keep, d_sigma, nullptr, 32};
+    lerf::Args a{d_x, lerf::IN, nullptr, 0, nullptr, d_keep, d_sigma, nullptr, 32};
     return launch_lerf<2>(m, a, p, as_stream(stream));
 }
 
@@ -377,7 +383,33 @@ int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d
     hipStream_t st = as_stream(stream);
     NRF_HIP(hipMemsetAsync(d_out, 0, (size_t)n * lerf::EMB * sizeof(float), st));
     ProfScope prof(NRF_PROF_MLP, st);
-    lerf::Args a{d_x, lerf::IN, d_weights, nullptr, nullptr, d_out, s};
+    lerf::Args a{d_x, lerf::IN, nullptr, 0, d_weights, nullptr, nullptr, d_out, s};
+    return launch_lerf<5>(m, a, n * (int64_t)s, st);
+}
+
+// the same two passes reading level-major fp16 features (nrf_hash_encode_lm_f16 of a 16-level, 8-feature CuHashEmbedder): [16][p][8] halfs
+int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_sigma && p >= 0, "nrf_lerf_sigma_lm: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma_lm: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_sigma_lm: features must be 16-byte aligned");
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), p, nullptr, d_keep, d_sigma, nullptr, 32};
+    return launch_lerf<2>(m, a, p, as_stream(stream));
+}
+
+int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_weights && d_out && n >= 0 && s >= 1, "nrf_lerf_render_embedding_lm: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_render_embedding_lm: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding_lm: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_render_embedding_lm: features must be 16-byte aligned");
+    if (n == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    NRF_HIP(hipMemsetAsync(d_out, 0, (size_t)n * lerf::EMB * sizeof(float), st));
+    ProfScope prof(NRF_PROF_MLP, st);
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), n * (int64_t)s, d_weights, nullptr, nullptr, d_out, s};
     return launch_lerf<5>(m, a, n * (int64_t)s, st);
 }
 

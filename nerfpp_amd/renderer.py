@@ -408,13 +408,22 @@ class LeRFRenderer:
         self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
         # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
         self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
+        # level-major fp16 features straight into the matrix-core kernels' operand fragments (CuHashEmbedder, 16 levels x 8 features); False = fp32 rows
+        self.level_major = self.fused and getattr(lang_embed_fn, "mode", None) == L.NRF_HASH_CU and lang_embed_fn.NLevels == 16 and lang_embed_fn.NFeaturesPerLevel == 8
 
     def _sigma_fused(self, pts):
         """sigma_le [N,S] (keep-masked) and the hash features [N*S, in] of the sample points, sigma net on the matrix cores."""
         n, s = pts.shape[0], pts.shape[1]
+        sig = torch.empty((n, s), device=pts.device, dtype=torch.float32)
+        if self.level_major:
+            flat = pts.reshape(-1, 3).contiguous()
+            x = torch.empty((16, n * s, 8), device=pts.device, dtype=torch.float16)
+            ku8 = torch.empty((n * s,), device=pts.device, dtype=torch.uint8)
+            L.check(L.lib().nrf_hash_encode_lm_f16(self.LangEmbedFn._h, _ptr(flat), C.c_int64(n * s), _ptr(x), _ptr(ku8), _stream()))
+            L.check(L.lib().nrf_lerf_sigma_lm(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
+            return sig, x
         x, keep = self.LangEmbedFn.forward(pts.reshape(-1, 3))
         ku8 = keep.to(torch.uint8)
-        sig = torch.empty((n, s), device=pts.device, dtype=torch.float32)
         L.check(L.lib().nrf_lerf_sigma(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
         return sig, x
 
@@ -433,7 +442,8 @@ class LeRFRenderer:
             n, s = sig.shape
             E = self.Lerf.GetLangEmbedDim()
             acc = torch.empty((n, E), device=pts.device, dtype=torch.float32)
-            L.check(L.lib().nrf_lerf_render_embedding(self.Lerf._m, _ptr(x), _ptr(o.WeightsLE), C.c_int64(n), s, _ptr(acc), _stream()))
+            fn = L.lib().nrf_lerf_render_embedding_lm if self.level_major else L.lib().nrf_lerf_render_embedding
+            L.check(fn(self.Lerf._m, _ptr(x), _ptr(o.WeightsLE), C.c_int64(n), s, _ptr(acc), _stream()))
             ones = torch.ones((n, 1), device=pts.device, dtype=torch.float32)
             o.RenderedLangEmbedding = _clip_embedding(acc, E, E, ones)          # the final normalize of RenderCLIPEmbedding (LeRFRenderer.h:53)
         return o

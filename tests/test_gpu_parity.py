@@ -1111,9 +1111,19 @@ def test_lerf_fused_matrix_core_path(api, O, manifest):
     w = np.random.RandomState(0).rand(144, 32).astype(np.float32)
     acc = torch.empty((144, 768), device="cuda")
     wd = dev(w)
-    api.L.check(api.L.lib().nrf_lerf_render_embedding(lerf._m, C.c_void_p(x_gpu.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc.data_ptr()), None))
+    assert fused.level_major and x_gpu.dtype == torch.float16 and tuple(x_gpu.shape) == (16, 144 * 32, 8)
+    api.L.check(api.L.lib().nrf_lerf_render_embedding_lm(lerf._m, C.c_void_p(x_gpu.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc.data_ptr()), None))
     ref = (w[:, :, None] * raw[:, :768].reshape(144, 32, 768)).sum(1)
     assert_close(host(acc), ref, rtol=0, atol=4e-3 * np.abs(ref).max(), what="sum_s w_s normalize(le_s)")
+    # the level-major fp16 feature path against the fp32-row path: the same fp16 values reach the same kernels
+    rowm = api.R.LeRFRenderer(e, lerf); rowm.level_major = False
+    sig_r, x_r = rowm._sigma_fused(dev(pts))
+    assert x_r.dtype == torch.float32
+    assert_exact(host(x_gpu).astype(np.float32).transpose(1, 0, 2).reshape(144 * 32, 128), host(x_r), "level-major fp16 features == row-major features")
+    assert_exact(host(sig_gpu), host(sig_r), "sigma_le: level-major == row-major input")
+    acc_r = torch.empty((144, 768), device="cuda")
+    api.L.check(api.L.lib().nrf_lerf_render_embedding(lerf._m, C.c_void_p(x_r.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc_r.data_ptr()), None))
+    assert_close(host(acc), host(acc_r), rtol=0, atol=1e-5 * np.abs(ref).max(), what="embedding sums differ by the order of the float atomics only")
     # end to end: same rays, fused vs stage-composed fp32
     hit = host(b.Outputs.AccMapLE) > 1e-2
     assert hit.sum() > 20
