@@ -362,6 +362,10 @@ NRF_API int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_
 NRF_API size_t nrf_mlp_backward_f16_workspace_bytes(const nrf_mlp *m, int64_t p);
 NRF_API int nrf_mlp_backward_f16(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* ... with the network input given the way the renderer's fast path has it instead of as [p, 48] fp32 rows: d_feats_lm = the level-major fp16 hash features of
+ * nrf_hash_encode_lm_f16 ([16][p][2] halfs), d_dirs_f16 = [p / s][16] fp16 direction features, one row per RAY (point i belongs to ray i / s). */
+NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, const void *d_dirs_f16, int s, const float *d_g_out, int64_t p, float *d_g_params,
+                                    float *d_g_x, void *d_workspace, size_t workspace_bytes, void *stream);
 /* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images). */
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
 

@@ -54,6 +54,8 @@ int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hi
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &host_params);
 size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p);
+int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p, float *g_params,
+                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st);
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);

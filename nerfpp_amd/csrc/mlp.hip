@@ -582,6 +582,16 @@ int nrf_mlp_backward_f16(const nrf_mlp *m, const float *d_x, const float *d_g_ou
     return mlp_small_backward_mfma(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
 }
 
+int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, const void *d_dirs_f16, int s, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
+                            void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_dirs_f16 && d_g_out && d_g_params && d_workspace && p >= 0 && s >= 1, "nrf_mlp_backward_f16_lm: bad argument");
+    if (p == 0) return NRF_OK;
+    if (m->family != MLP_SMALL) { set_error("nrf_mlp_backward_f16_lm: built for the NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
+    return mlp_small_backward_mfma_lm(m, reinterpret_cast<const __half2 *>(d_feats_lm), reinterpret_cast<const __half *>(d_dirs_f16), s, d_g_out, m->out_dims, p, d_g_params, d_g_x,
+                                      m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
+}
+
 void nrf_mlp_destroy(nrf_mlp *m)
 {
     if (!m) return;

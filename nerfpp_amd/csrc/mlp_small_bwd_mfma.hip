@@ -65,6 +65,10 @@ struct BwdPlan {
 
 struct LayerOffs { int s[4]; int c[4]; };       // offsets (floats) of every W in the parameter blob
 
+// Alternative input (feats != NULL): the level-major fp16 hash features of nrf_hash_encode_lm_f16 ([16 levels][pstride] half2, already offset to this launch's
+// first point) and per-RAY fp16 direction features [n][16]; point p of the launch belongs to ray (p_base + p) / s.  No [p, 48] fp32 row is ever formed.
+struct LmInput { const __half2 *feats; int64_t pstride; const __half *dirs; int s; int64_t p_base; };
+
 __device__ __forceinline__ f32x16 mfma(const half8 &a, const half8 &b, const f32x16 &c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <bool RELU>
@@ -150,7 +154,7 @@ template <int NL, int NLC>
 __global__ void __launch_bounds__(64 * BW, 1)
 k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__restrict__ g_out, int gos, const half8 *__restrict__ fimg,
             const half8 *__restrict__ bimg, half8 *__restrict__ scratch, float *__restrict__ g_params, float *__restrict__ g_x, int gxs,
-            const uint32_t *__restrict__ absmax_bits, int n_params, LayerOffs lo)
+            const uint32_t *__restrict__ absmax_bits, int n_params, LayerOffs lo, LmInput lm)
 {
     using P = BwdPlan<NL, NLC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -229,6 +233,19 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
             for (int pt = 0; pt < BPT; pt++) {
                 int64_t p = p0 + pt * 32 + r;
                 if (p >= npts) p = npts - 1;
+                if (lm.feats) {
+#pragma unroll
+                    for (int s = 0; s < IN_KS; s++) {
+                        union { half8 v; __half2 q[4]; } u;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) u.q[q] = lm.feats[(int64_t)(8 * s + 4 * h + q) * lm.pstride + p];      // features 16s + 8h + 2q, +1
+                        bx[pt][s] = u.v; hstore(pt, P::h_sigma(0) + s, u.v);
+                    }
+                    const int64_t ray = (lm.p_base + p) / lm.s;
+                    bc[pt][0] = *reinterpret_cast<const half8 *>(lm.dirs + ray * V + 8 * h);
+                    hstore(pt, P::h_color(0), bc[pt][0]);
+                    continue;
+                }
                 const float *row = x + p * xs;
 #pragma unroll
                 for (int s = 0; s < IN_KS + 1; s++) {
@@ -480,8 +497,25 @@ size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p)
     return 256 + (size_t)tiles * h_frags_of(m->small) * 1024;
 }
 
+static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p,
+                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st);
+
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st)
+{
+    if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("nrf_mlp_backward_f16: rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
+    return backward_mfma_impl(m, x, xs, nullptr, nullptr, 1, g_out, gos, p, g_params, g_x, gxs, ws, ws_bytes, st);
+}
+
+int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p, float *g_params,
+                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    if ((reinterpret_cast<uintptr_t>(feats_lm) & 3) || (reinterpret_cast<uintptr_t>(dirs) & 15) || s_per_ray < 1) { set_error("nrf_mlp_backward_f16_lm: bad feature / direction buffers"); return NRF_ERR_INVALID_ARG; }
+    return backward_mfma_impl(m, nullptr, 0, feats_lm, dirs, s_per_ray, g_out, gos, p, g_params, g_x, gxs, ws, ws_bytes, st);
+}
+
+static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p,
+                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st)
 {
     const auto &d = m->small;
     if (m->family != MLP_SMALL || !m->d_packed_bwd || !m->d_packed_f16) {
@@ -489,9 +523,7 @@ int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const floa
         return NRF_ERR_UNSUPPORTED;
     }
     if (ws_bytes < mlp_small_backward_mfma_workspace_bytes(m, p)) { set_error("nrf_mlp_backward_f16: workspace %zu < %zu bytes", ws_bytes, mlp_small_backward_mfma_workspace_bytes(m, p)); return NRF_ERR_WORKSPACE; }
-    if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (g_x && ((gxs % 4) != 0 || (reinterpret_cast<uintptr_t>(g_x) & 15)))) {
-        set_error("nrf_mlp_backward_f16: rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG;
-    }
+    if (g_x && ((gxs % 4) != 0 || (reinterpret_cast<uintptr_t>(g_x) & 15))) { set_error("nrf_mlp_backward_f16: d_g_x rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
     uint32_t *absmax = reinterpret_cast<uint32_t *>(ws);
     half8 *scratch = reinterpret_cast<half8 *>(reinterpret_cast<unsigned char *>(ws) + 256);
     NRF_HIP(hipMemsetAsync(absmax, 0, 4, st));
@@ -515,8 +547,9 @@ int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const floa
                 set_error("internal: NeRFSmall backward image sizes do not match the kernel plan"); return NRF_ERR_UNSUPPORTED;                            \
             }                                                                                                                                             \
             NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * BW), lds, st, c, x + p0 * xs, xs, g_out + p0 * gos, gos, reinterpret_cast<const half8 *>(m->d_packed_f16), \
-                               reinterpret_cast<const half8 *>(m->d_packed_bwd), scratch, g_params, g_x ? g_x + p0 * gxs : nullptr, gxs, absmax, (int)m->n_params, lo); \
+            const LmInput lmi{feats_lm ? feats_lm + p0 : nullptr, p, dirs, s_per_ray, p0};                                                                   \
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * BW), lds, st, c, x ? x + p0 * xs : nullptr, xs, g_out + p0 * gos, gos, reinterpret_cast<const half8 *>(m->d_packed_f16), \
+                               reinterpret_cast<const half8 *>(m->d_packed_bwd), scratch, g_params, g_x ? g_x + p0 * gxs : nullptr, gxs, absmax, (int)m->n_params, lo, lmi); \
                                                                                                      \
         }
         NRF_BW(3, 4) NRF_BW(3, 3) NRF_BW(2, 4) NRF_BW(2, 3)

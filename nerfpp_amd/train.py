@@ -93,18 +93,34 @@ class Trainer:
             ur = RngFill(seed, L.NRF_RNG_R_FINE if fine else L.NRF_RNG_R_COARSE, 0, n * s, device=rays.device)
             ut = RngFill(seed, L.NRF_RNG_THETA_FINE if fine else L.NRF_RNG_THETA_COARSE, 0, n * s, device=rays.device)
             pts = TangentScatter(pts.reshape(n, s, 3), z, float(cone_angle), rays[:, 3:6].contiguous(), p.BoundingBox if p is not None else None, ur, ut).reshape(n * s, 3)
-        emb, keep = self.embedder.forward(pts)
         dirs, _ = self.embeddirs.forward(rays[:, 8:11].contiguous())
-        x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
-        keep_u8 = keep.to(torch.uint8)
-        L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
-        self.g_blob.zero_(); self.g_table.zero_()
         in_ch = self.embedder.GetOutputDims()
         g_x = torch.empty((n * s, in_ch), device=rays.device)
-        ws_fn, bw_fn = (lib.nrf_mlp_backward_f16_workspace_bytes, lib.nrf_mlp_backward_f16) if self.mlp_backward == "f16" else (lib.nrf_mlp_backward_workspace_bytes, lib.nrf_mlp_backward)
-        nb = ws_fn(self.mlp._m, C.c_int64(n * s))
-        ws = self._workspace(nb)
-        L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+        self.g_blob.zero_(); self.g_table.zero_()
+        lm = (self.mlp_backward == "f16" and isinstance(self.embedder, CuHashEmbedder) and self.embedder.NLevels == 16 and self.embedder.NFeaturesPerLevel == 2
+              and dirs.shape[1] == 16)
+        if lm:
+            # the fast path's own layout: level-major fp16 hash features + one fp16 direction row per ray; no [p, 48] fp32 input is formed
+            feats = torch.empty((16, n * s, 2), device=rays.device, dtype=torch.float16)
+            keep_u8 = torch.empty((n * s,), device=rays.device, dtype=torch.uint8)
+            ptsc = pts.contiguous()
+            L.check(lib.nrf_hash_encode_lm_f16(self.embedder._h, _ptr(ptsc), C.c_int64(n * s), _ptr(feats), _ptr(keep_u8), _stream()))
+            dirs16 = dirs.to(torch.float16).contiguous()
+            L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
+            nb = lib.nrf_mlp_backward_f16_workspace_bytes(self.mlp._m, C.c_int64(n * s))
+            ws = self._workspace(nb)
+            L.check(lib.nrf_mlp_backward_f16_lm(self.mlp._m, _ptr(feats), _ptr(dirs16), s, _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws),
+                                                C.c_size_t(ws.numel()), _stream()))
+            x = None
+        else:
+            emb, keep = self.embedder.forward(pts)
+            x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+            keep_u8 = keep.to(torch.uint8)
+            L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
+            ws_fn, bw_fn = (lib.nrf_mlp_backward_f16_workspace_bytes, lib.nrf_mlp_backward_f16) if self.mlp_backward == "f16" else (lib.nrf_mlp_backward_workspace_bytes, lib.nrf_mlp_backward)
+            nb = ws_fn(self.mlp._m, C.c_int64(n * s))
+            ws = self._workspace(nb)
+            L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
         if self.hash_backward == "packed":
             nbh = lib.nrf_hash_backward_packed_workspace_bytes(self.embedder._h)
             if self._hws is None or self._hws.numel() < nbh:

@@ -877,6 +877,41 @@ def test_mlp_backward_matrix_core_exact_on_integer_network(api, nl, nlc, p):
     assert np.abs(gx32).max() > 0
 
 
+def test_mlp_backward_matrix_core_level_major_input(api):
+    """nrf_mlp_backward_f16_lm (level-major fp16 hash features of nrf_hash_encode_lm_f16 + one fp16 direction row per ray) against nrf_mlp_backward_f16 on the
+    [p, 48] fp32 rows built from the same encoders: the operand fragments are the same fp16 values, so the gradients agree to summation order.
+    p is not a multiple of the kernel's 128-point block and s does not divide it."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    sc = api.S.make_hash_scene(mode="cu", log2_t=14, seed=31, table_amp=0.4)
+    e, ed, m = sc["embedder"], sc["embeddirs"], sc["mlp"]
+    rng = np.random.default_rng(8)
+    n, s = 37, 24
+    p = n * s
+    bb = api.S.LEGO_BBOX
+    pts = dev(rng.uniform(bb[:3] - 0.1, bb[3:] + 0.1, (p, 3)).astype(np.float32))            # a few outside the box (keep == false)
+    vd = rng.standard_normal((n, 3)); vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+    dirs, _ = ed.forward(dev(vd.astype(np.float32)))
+    emb, keep = e.forward(pts)
+    x = torch.cat([emb, dirs[:, None, :].expand(n, s, 16).reshape(p, 16)], 1).contiguous()
+    gr = dev((rng.standard_normal((p, 4)) * 1e-4).astype(np.float32))
+    lib = api.L.lib()
+    feats = torch.empty((16, p, 2), device="cuda", dtype=torch.float16); k8 = torch.empty((p,), device="cuda", dtype=torch.uint8)
+    api.L.check(lib.nrf_hash_encode_lm_f16(e._h, P(pts), C.c_int64(p), P(feats), P(k8), None))
+    assert_exact(host(feats).astype(np.float32).transpose(1, 0, 2).reshape(p, 32), host(emb), "level-major fp16 features == CuHashEmbedder.forward")
+    assert_exact(host(k8).astype(bool), host(keep), "keep mask")
+    assert (~host(keep)).sum() > 0
+    d16 = dirs.to(torch.float16).contiguous()
+    nb = lib.nrf_mlp_backward_f16_workspace_bytes(m._m, C.c_int64(p)); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    ga = torch.zeros(m.n_params, device="cuda"); gxa = torch.zeros((p, 32), device="cuda")
+    gb = torch.zeros(m.n_params, device="cuda"); gxb = torch.zeros((p, 32), device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(ga), P(gxa), P(ws), C.c_size_t(nb), None))
+    api.L.check(lib.nrf_mlp_backward_f16_lm(m._m, P(feats), P(d16), s, P(gr), C.c_int64(p), P(gb), P(gxb), P(ws), C.c_size_t(nb), None))
+    assert float(ga.abs().max()) > 0
+    assert_exact(host(gxb), host(gxa), "d loss / d features: level-major input == row input")
+    assert_close(host(gb), host(ga), rtol=1e-5, atol=1e-6 * float(ga.abs().max()), what="weight gradients (LDS float-atomic order only)")
+
+
 def test_mlp_backward_matrix_core_edges(api):
     """Boundary behaviour of nrf_mlp_backward_f16: empty batch, optional d_g_x, all-zero output gradient (loss scale of nothing), accumulation into a
     non-zero gradient blob, a workspace that is too small, a NeRFSmall shape outside the built family, more points than one 2^22-point pass."""
