@@ -12,7 +12,7 @@
 //             out[ray] = normalize(sum_s w_s * normalize(h_s))  is finished by the caller's L2-normalise.
 //
 // Same transposed MFMA formulation and the same L2 -> LDS weight streaming as mlp_nerf_mfma.hip (8 waves x 32 points per workgroup,
-// chunks of <= 2 neuron tiles x all k-steps, double buffered, issue-early / write-late); fp16 operands, fp32 accumulate.
+// chunks of <= 2 neuron tiles x all k-steps, LDS-DMA through three buffers two chunks ahead); fp16 operands, fp32 accumulate.
 // Built for the reference's LeRF shape (main.cpp:203-213): in 16 x 8 = 128, hidden 256, 2 + 2 layers, geo 32, embedding 768.
 #include "mlp.h"
 
@@ -54,42 +54,24 @@ struct Net {
     static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < image_chunk(ci); i++) n += chunk_frags(i); return n; }
 };
 static_assert(Net<2>::total_chunks() == 6 && Net<5>::total_chunks() == 34, "chunk counts");
-static_assert(Net<5>::total_chunks() % 2 == 0 && Net<2>::total_chunks() % 2 == 0, "double-buffer parity must repeat per point block");
 constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 24 * 16;       // 576 KB
 static_assert(Net<5>::chunk_off(Net<5>::first_chunk(3)) + 24 * 16 == IMAGE_FRAGS, "image size");
 static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) == Net<5>::chunk_off(Net<5>::first_chunk(3)), "pass 2 re-reads pass 1's weights");
 
-constexpr int NPIECE = (MAXF * 64 + 64 * NW - 1) / (64 * NW);
-struct Stage { u32x4 r[NPIECE]; };
-
+// Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4, one 1-KB fragment per wave-instruction, wave w takes fragments
+// w, w + NW, ...): same scheme as mlp_nerf_mfma.hip -- three LDS buffers, requested two chunks ahead, no staging registers.
 template <class N, int CI>
-__device__ __forceinline__ void stage_load(Stage &st, __amdgpu_buffer_rsrc_t rsrc, int tid)
+__device__ __forceinline__ void stage_dma(half8 *__restrict__ dst, const half8 *__restrict__ packed, int wave, int lane)
 {
     constexpr int ci = CI % N::total_chunks();
-    constexpr int n = N::chunk_frags(ci) * 64;
-    constexpr int base = N::chunk_off(ci) * 1024;
+    constexpr int nf = N::chunk_frags(ci);
+    constexpr int base = N::chunk_off(ci);
+    const half8 *pk = packed + (size_t)wave * 64;
+    asm volatile("" : "+s"(pk));                          // opaque here: the addresses derived from it cannot be hoisted out of the persistent loop
 #pragma unroll
-    for (int q = 0; q < NPIECE; q++) {
-        const int i = q * (64 * NW) + tid;
-        if (q * (64 * NW) < n) {
-            // the chunk's byte offset is a compile-time constant in the SCALAR offset operand; the empty volatile asm pins its s_mov here
-            // -- hoisted out of the persistent loop, the 34 x 4 constants (plus the hooks' lane masks) overflow the SGPR file and spill
-            int soff = base + q * (64 * NW * 16);
-            asm volatile("" : "+s"(soff));
-            if (i < n) st.r[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, soff, 0);
-        }
-    }
-}
-
-template <class N, int CI>
-__device__ __forceinline__ void stage_store(const Stage &st, half8 *__restrict__ dst, int tid)
-{
-    constexpr int ci = CI % N::total_chunks();
-    constexpr int n = N::chunk_frags(ci) * 64;
-#pragma unroll
-    for (int q = 0; q < NPIECE; q++) {
-        const int i = q * (64 * NW) + tid;
-        if (q * (64 * NW) < n) { if (i < n) reinterpret_cast<u32x4 *>(dst)[i] = st.r[q]; }
+    for (int q = 0; q < (nf + NW - 1) / NW; q++) {
+        if (q * NW + wave < nf)                          // wave-uniform
+            __builtin_amdgcn_global_load_lds(pk + (size_t)(base + q * NW) * 64 + lane, (__attribute__((address_space(3))) void *)(dst + (q * NW + wave) * 64), 16, 0, 0);
     }
 }
 
@@ -104,28 +86,26 @@ __device__ __forceinline__ half8 tile_to_frag(const f32x16 &acc, int s)
 }
 
 struct Ctx {
-    half8 *wbuf;                       // [2][MAXF*64]
-    __amdgpu_buffer_rsrc_t packed;
-    int tid, lane, h;
-    bool last_block;
+    half8 *wbuf;                       // [3][MAXF*64]
+    const half8 *packed;
+    int tid, lane, h, wave;
+    int *cur;                          // LDS buffer (0..2) of the chunk being consumed; wave-uniform
 };
 
 // One chunk: fetch the following chunk, run this chunk's MFMAs out of LDS, hand each finished tile to `hook(tile, acc)`, publish the
 // fetched chunk.  All indices are template constants.
+// w / dma_dst are __restrict__ parameters so that, inlined, the LDS reads and the DMA's LDS write carry alias scopes: otherwise every LDS read issued
+// while an LDS-DMA is pending waits for vmcnt(0) (see mlp_nerf_mfma.hip).
 template <class N, int L, int C, int NN, int NC, class Hook>
-__device__ __forceinline__ void chunk(const Ctx &cx, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook)
+__device__ __forceinline__ void chunk_body(const Ctx &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook)
 {
     constexpr int KSN = N::ks_nat(L), KSC = N::ks_ch(L), KS = KSN + KSC;
     constexpr int CI = N::first_chunk(L) + C;
-    constexpr bool FINAL = (CI == N::total_chunks() - 1);
     constexpr int NT = N::chunk_tiles(L, C);
     constexpr int TILE0 = (L == 1) ? C : 2 * C;
     constexpr bool NATF = N::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
-    Stage st;
-    const bool fetch = !(FINAL && cx.last_block);
-    if (fetch) stage_load<N, CI + 1>(st, cx.packed, cx.tid);
-    const half8 *w = cx.wbuf + (CI & 1) * (MAXF * 64);
+    stage_dma<N, CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane);
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -144,8 +124,18 @@ __device__ __forceinline__ void chunk(const Ctx &cx, const half8 (&bn)[NN], cons
         // (16 VGPRs each) until it gets round to their epilogues -- hundreds of spills on the 24-tile layers
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (fetch) stage_store<N, CI + 1>(st, cx.wbuf + ((CI + 1) & 1) * (MAXF * 64), cx.tid);
-    __syncthreads();
+    // chunk CI + 1 (requested a whole chunk ago) must have landed; chunk CI + 2 -- and any float atomics the hook issued after it -- may stay in flight:
+    // vector-memory operations retire in issue order, so "at most KEEP outstanding" leaves only operations younger than chunk CI + 1's loads
+    constexpr int KEEP = N::chunk_frags((CI + 2) % N::total_chunks()) / NW;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
+template <class N, int L, int C, int NN, int NC, class Hook>
+__device__ __forceinline__ void chunk(const Ctx &cx, const half8 (&bn)[NN], const half8 (&bc)[NC], Hook &hook)
+{
+    const int cur = *cx.cur;
+    chunk_body<N, L, C>(cx, cx.wbuf + cur * (MAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (MAXF * 64), bn, bc, hook);
+    *cx.cur = cur == 2 ? 0 : cur + 1;
 }
 
 template <class N, int L, int NN, int NC, class Hook, int... Cs>
@@ -232,18 +222,15 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
     using N = Net<NL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wbuf = reinterpret_cast<half8 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(packed), 0, IMAGE_FRAGS * 1024, 0x00020000);
-    {
-        Stage st;
-        stage_load<N, 0>(st, rsrc, tid);
-        stage_store<N, 0>(st, wbuf, tid);
-    }
-    __syncthreads();
+    stage_dma<N, 0>(wbuf, packed, wave, lane);
+    stage_dma<N, 1>(wbuf + MAXF * 64, packed, wave, lane);
+    __syncthreads();                               // vmcnt(0): chunks 0 and 1 are in place
+    int cur = 0;
     const int64_t nblocks = (npts + NBLK - 1) / NBLK;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        Ctx cx{wbuf, rsrc, tid, lane, h, blk + gridDim.x >= nblocks};
+        Ctx cx{wbuf, packed, tid, lane, h, wave, &cur};
         const int64_t p0 = blk * NBLK + wave * 32;
         const int64_t q = p0 + r;
         const bool live = q < npts;
@@ -295,6 +282,7 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
             layer<N, 4>(cx, none, ba, red);                   // LE1, pass 2: sum_s w_s h_s / ||h_s||
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two chunks' look-ahead requests are still in flight
 }
 
 // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L
@@ -346,7 +334,7 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 template <int NL>
 static int launch_lerf(const nrf_mlp *m, const Args &a, int64_t p, hipStream_t st)
 {
-    const size_t lds = (size_t)2 * MAXF * 1024;
+    const size_t lds = (size_t)3 * MAXF * 1024;
     const int64_t nblocks = ceil_div(p, NBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 8-wave workgroup per CU (216 VGPRs: two waves per SIMD)
     hipLaunchKernelGGL((k_lerf_mfma<NL>), dim3(grid), dim3(64 * NW), lds, st, p, a, reinterpret_cast<const lerf::half8 *>(m->d_packed_f16));
