@@ -33,12 +33,16 @@ constexpr int IN = 128, HID = 256, GEO = 32, EMB = 768;
 __host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 // Layers: 0 sigma0 [nat 8] -> 8 tiles ReLU | 1 sigma1 [chained 16] -> 2 tiles (row 0 = sigma, rows 1..32 = geo) | 2 LE0 [chained 4 | nat 8]
-// -> 8 tiles ReLU (cat[geo, in], LeRF.cpp) | 3 LE1 [chained 16] -> 24 tiles (norm pass) | 4 = layer 3 again (weighted-sum pass).
-// NL = 2: the sigma net alone (kernel A); NL = 5: everything (kernel B).  Both walk the same weight image.
+// -> 8 tiles ReLU (cat[geo, in], LeRF.cpp) | 3 GRAM [chained 16] -> 8 tiles: t = (W^T W) a, ||LE1(a)||^2 = a . t | 4 LE1 [chained 16] -> 24 tiles
+// (weighted-sum pass).  NL = 2: the sigma net alone (kernel A); NL = 5: everything (kernel B).  Both walk the same weight image.
+//
+// The norm: LE1 is bias-free (LeRF.cpp:21-24), so ||W a||^2 = a^T (W^T W) a.  The 256 x 256 Gram matrix is formed once per weight set (in double, at pack
+// time) and costs 8 tiles x 16 k-steps per point tile instead of the 24 x 16 of a first full pass through the 256 -> 768 layer: 704 matrix instructions
+// per 32 points instead of 960.
 template <int NL>
 struct Net {
     static constexpr int NLAYER = NL;
-    static constexpr int tiles(int l) { return l == 0 ? 8 : l == 1 ? 2 : l == 2 ? 8 : 24; }
+    static constexpr int tiles(int l) { return l == 0 ? 8 : l == 1 ? 2 : l == 2 ? 8 : l == 3 ? 8 : 24; }
     static constexpr int ks_nat(int l) { return (l == 0 || l == 2) ? 8 : 0; }
     static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 2 ? 4 : 16; }
     static constexpr bool nat_first(int l) { return l != 2; }
@@ -49,14 +53,11 @@ struct Net {
     static constexpr int total_chunks() { return first_chunk(NLAYER); }
     static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
     static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
-    // byte-offset bookkeeping in the IMAGE: layer 4 re-reads layer 3's chunks
-    static constexpr int image_chunk(int ci) { return ci >= first_chunk(4) && NLAYER > 4 ? ci - chunks(3) : ci; }
-    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < image_chunk(ci); i++) n += chunk_frags(i); return n; }
+    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
 };
-static_assert(Net<2>::total_chunks() == 6 && Net<5>::total_chunks() == 34, "chunk counts");
-constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 24 * 16;       // 576 KB
-static_assert(Net<5>::chunk_off(Net<5>::first_chunk(3)) + 24 * 16 == IMAGE_FRAGS, "image size");
-static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) == Net<5>::chunk_off(Net<5>::first_chunk(3)), "pass 2 re-reads pass 1's weights");
+static_assert(Net<2>::total_chunks() == 6 && Net<5>::total_chunks() == 26, "chunk counts");
+constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16 + 24 * 16;       // 704 KB
+static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) + 24 * 16 == IMAGE_FRAGS, "image size");
 
 // Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4, one 1-KB fragment per wave-instruction, wave w takes fragments
 // w, w + NW, ...): same scheme as mlp_nerf_mfma.hip -- three LDS buffers, requested two chunks ahead, no staging registers.
@@ -162,12 +163,15 @@ struct ConvHook {
     }
 };
 
-struct SumsqHook {
+// a . (G a): tile t of G a against the operand fragments 2t, 2t+1 of a -- registers 8s..8s+7 of a D tile and the elements of fragment 2t+s are the
+// same neurons on the same lane (that identity is what the whole transposed formulation rests on)
+struct DotHook {
+    const half8 (&a)[16];
     float ss = 0.0f;
-    __device__ __forceinline__ void operator()(int, const f32x16 &acc)
+    __device__ __forceinline__ void operator()(int tile, const f32x16 &acc)
     {
 #pragma unroll
-        for (int i = 0; i < 16; i++) ss = __builtin_fmaf(acc[i], acc[i], ss);
+        for (int i = 0; i < 16; i++) ss = __builtin_fmaf(acc[i], (float)a[2 * tile + (i >> 3)][i & 7], ss);
         // pin the partial sum here: its only real use is after the 24th tile, and the IR-level code sinking would otherwise move all 384
         // FMAs down there -- keeping every finished accumulator alive (12 tiles in registers, 12 spilled)
         asm volatile("" : "+v"(ss));
@@ -274,19 +278,19 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
                 load_x(xin);
                 layer<N, 2>(cx, xin, bb, c2);                 // LE0: cat[geo, in] -> 256, ReLU
             }
-            SumsqHook ssq;
-            layer<N, 3>(cx, none, ba, ssq);                   // LE1, pass 1: ||h||^2
-            const float tot = ssq.ss + __shfl_xor(ssq.ss, 32);
+            DotHook ssq{ba};
+            layer<N, 3>(cx, none, ba, ssq);                   // ||LE1(a)||^2 = a . (W^T W) a
+            const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f);
             const float wgt = live ? in.weights[q] : 0.0f;
             ReduceHook red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)EMB : nullptr, r, h};
-            layer<N, 4>(cx, none, ba, red);                   // LE1, pass 2: sum_s w_s h_s / ||h_s||
+            layer<N, 4>(cx, none, ba, red);                   // LE1: sum_s w_s h_s / ||h_s||
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two chunks' look-ahead requests are still in flight
 }
 
 // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L
-static float wval(const std::vector<float> &hp, int L, int row, int kstep, int h, int j)
+static float wval(const std::vector<float> &hp, const std::vector<float> &gram, int L, int row, int kstep, int h, int j)
 {
     const size_t off0 = 0, off1 = off0 + (size_t)HID * IN, off2 = off1 + (size_t)(1 + GEO) * HID, off3 = off2 + (size_t)HID * (GEO + IN);
     auto chained = [](int k, int hh, int jj) { return 32 * (k >> 1) + perm_row(k & 1, hh, jj); };
@@ -300,6 +304,7 @@ static float wval(const std::vector<float> &hp, int L, int row, int kstep, int h
         }
         return hp[off2 + (size_t)row * (GEO + IN) + GEO + natural(kstep - 4, h, j)];
     }
+    if (L == 3) return gram[(size_t)row * HID + chained(kstep, h, j)];
     return hp[off3 + (size_t)row * HID + chained(kstep, h, j)];
 }
 
@@ -318,11 +323,26 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     std::vector<_Float16> img;
     img.reserve((size_t)IMAGE_FRAGS * 512);
     using N = Net<5>;
-    for (int L = 0; L < 4; L++)
+    // Gram matrix of the embedding layer W [768][256] (bias-free): G = W^T W, accumulated in double
+    std::vector<float> gram((size_t)HID * HID);
+    {
+        const float *w3 = hp.data() + (size_t)HID * IN + (size_t)(1 + GEO) * HID + (size_t)HID * (GEO + IN);
+        std::vector<double> wt((size_t)HID * EMB);                    // W^T [256][768]: contiguous dot products
+        for (int o = 0; o < EMB; o++)
+            for (int k = 0; k < HID; k++) wt[(size_t)k * EMB + o] = (double)w3[(size_t)o * HID + k];
+        for (int a = 0; a < HID; a++)
+            for (int b = a; b < HID; b++) {
+                double acc = 0.0;
+                const double *pa = wt.data() + (size_t)a * EMB, *pb = wt.data() + (size_t)b * EMB;
+                for (int o = 0; o < EMB; o++) acc += pa[o] * pb[o];
+                gram[(size_t)a * HID + b] = gram[(size_t)b * HID + a] = (float)acc;
+            }
+    }
+    for (int L = 0; L < 5; L++)
         for (int tile = 0; tile < N::tiles(L); tile++)
             for (int k = 0; k < N::ks(L); k++)
                 for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(hp, L, tile * 32 + (lane & 31), k, lane >> 5, j));
+                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(hp, gram, L, tile * 32 + (lane & 31), k, lane >> 5, j));
     if (img.size() != (size_t)IMAGE_FRAGS * 512) { set_error("internal: LeRF weight image has %zu halves, expected %zu", img.size(), (size_t)IMAGE_FRAGS * 512); return NRF_ERR_INVALID_ARG; }
     if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }
     m->packed_f16_bytes = img.size() * sizeof(_Float16);
