@@ -28,9 +28,11 @@
 //   0      : pts_linears_0   [nat 4]              -> 8 tiles  ReLU
 //   1-4,6,7: pts_linears_i   [chained 16]         -> 8 tiles  ReLU
 //   5      : pts_linears_5   [nat 4 | chained 16]    cat[input_pts, h] after layer 4 (NeRF.cpp:103-104)
-//   8      : feature_linear (8 tiles, no ReLU) + alpha_linear (tile 8, row 0)   (NeRF.cpp:110-111)
-//   9      : views_linears_0 [chained 16 | nat 2] -> 4 tiles  ReLU              cat[feature, views] (NeRF.cpp:112-117)
-//   10     : rgb_linear      [chained 8]          -> 1 tile (rows 0..2)         out = cat[rgb, alpha] (NeRF.cpp:119)
+//   8      : views_linears_0 o feature_linear [chained 16 | nat 2] -> 4 tiles ReLU, + alpha_linear (tile 4, row 0)
+//            feature_linear has no activation (NeRF.cpp:110-113), so views_linears_0(cat[feature_linear(h), views]) is ONE affine map of
+//            cat[h, views]: W_v[:, :256] . F (128 x 256, formed in double at pack time) on h, W_v[:, 256:] on the views, bias W_v[:, :256] . b_f + b_v.
+//            90 matrix instructions per 32 points instead of the 216 of the two layers run one after the other (and 126 KB less weight stream).
+//   9      : rgb_linear      [chained 8]          -> 1 tile (rows 0..2)         out = cat[rgb, alpha] (NeRF.cpp:119)
 #include "mlp.h"
 
 #include <utility>
@@ -51,16 +53,16 @@ constexpr int NW = NRF_NERF_NW;        // waves per workgroup
 constexpr int NPT = NRF_NERF_NPT;      // 32-point tiles per wave (every weight fragment read from LDS feeds NPT MFMAs)
 constexpr int NBLK = 32 * NPT * NW;    // points per workgroup iteration
 constexpr int MAXF = 40;               // fragments (1 KB each) in the largest chunk
-constexpr int NBIAS = 8 * 256 + 288 + 128 + 32;
+constexpr int NBIAS = 8 * 256 + 160 + 32;
 
 __host__ __device__ inline int nerf_perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 struct NerfNet {
-    static constexpr int NLAYER = 11;
-    static constexpr int tiles(int l) { return l < 8 ? 8 : l == 8 ? 9 : l == 9 ? 4 : 1; }
-    static constexpr int ks_nat(int l) { return (l == 0 || l == 5) ? 4 : l == 9 ? 2 : 0; }
-    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 10 ? 8 : 16; }
-    static constexpr bool nat_first(int l) { return l != 9; }
+    static constexpr int NLAYER = 10;
+    static constexpr int tiles(int l) { return l < 8 ? 8 : l == 8 ? 5 : 1; }
+    static constexpr int ks_nat(int l) { return (l == 0 || l == 5) ? 4 : l == 8 ? 2 : 0; }
+    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 9 ? 8 : 16; }
+    static constexpr bool nat_first(int l) { return l != 8; }
     static constexpr int ks(int l) { return ks_nat(l) + ks_ch(l); }
     static constexpr int chunks(int l) { return (tiles(l) + 1) / 2; }
     static constexpr int chunk_tiles(int l, int c) { return (2 * c + 2 <= tiles(l)) ? 2 : 1; }
@@ -70,9 +72,9 @@ struct NerfNet {
     static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
     static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
     static constexpr int total_frags() { return chunk_off(total_chunks()); }
-    static constexpr int bias_off(int l) { int n = 0; for (int i = 0; i < l; i++) n += (i == 8 ? 288 : tiles(i) * 32); return n; }
+    static constexpr int bias_off(int l) { int n = 0; for (int i = 0; i < l; i++) n += tiles(i) * 32; return n; }
 };
-static_assert(NerfNet::total_chunks() == 40, "chunk count");
+static_assert(NerfNet::total_chunks() == 36, "chunk count");
 
 // Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves one 1-KB fragment
 // (64 lanes x 16 B, lane-linear on both sides -- exactly the fragment layout), wave w takes fragments w, w + NW, ...  No staging registers
@@ -282,10 +284,7 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
         nerf_layer<5, true>(cx, pe, ba, bb, last);
         nerf_layer<6, true>(cx, none, bb, ba, last);
         nerf_layer<7, true>(cx, none, ba, bb, last);
-        nerf_layer<8, false>(cx, none, bb, ba, last);          // feature tiles -> ba (no ReLU); tile 8 row 0 = alpha
         float alpha[NPT];
-#pragma unroll
-        for (int pt = 0; pt < NPT; pt++) alpha[pt] = last[pt][0];
         {
             half8 vw[NPT][2];
 #pragma unroll
@@ -301,9 +300,11 @@ k_mlp_nerf_mfma(int64_t npts, NerfInput in, const half8 *__restrict__ packed, co
                     }
                 }
             }
-            nerf_layer<9, true>(cx, vw, ba, bb, last);          // 4 tiles -> bb[..][0..7]
+            nerf_layer<8, true>(cx, vw, bb, ba, last);          // views_linears_0 o feature_linear -> ba[..][0..7] (ReLU); tile 4 row 0 = alpha (from the accumulator)
         }
-        nerf_layer<10, false>(cx, none, bb, ba, last);
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) alpha[pt] = last[pt][0];
+        nerf_layer<9, false>(cx, none, ba, bb, last);
         if (h == 0) {
 #pragma unroll
             for (int pt = 0; pt < NPT; pt++) {
@@ -350,6 +351,24 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     std::vector<float> bias(NBIAS, 0.0f);
     auto chained = [](int k, int h, int j) { return 32 * (k >> 1) + nerf_perm_row(k & 1, h, j); };
     auto natural = [](int k, int h, int j) { return 16 * k + 8 * h + j; };
+    // views_linears_0 o feature_linear: merged[r][k] = sum_f W_v[r][f] F[f][k], merged_b[r] = sum_f W_v[r][f] b_f[f] + b_v[r]   (double accumulation)
+    std::vector<float> merged((size_t)(W / 2) * W), merged_b(W / 2);
+    {
+        const float *wv = hp.data() + w_off[VIEWS], *wf = hp.data() + w_off[FEAT], *bf = hp.data() + b_off[FEAT], *bv = hp.data() + b_off[VIEWS];
+        std::vector<double> acc(W);
+        for (int r = 0; r < W / 2; r++) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            double b = (double)bv[r];
+            for (int f = 0; f < W; f++) {
+                const double c = (double)wv[(size_t)r * (V + W) + f];
+                b += c * (double)bf[f];
+                const float *frow = wf + (size_t)f * W;
+                for (int k = 0; k < W; k++) acc[k] += c * (double)frow[k];
+            }
+            for (int k = 0; k < W; k++) merged[(size_t)r * W + k] = (float)acc[k];
+            merged_b[r] = (float)b;
+        }
+    }
     // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel-layer L (-> 0 if padding)
     auto wval = [&](int L, int row, int kstep, int h, int j) -> float {
         const int ksn = NerfNet::ks_nat(L), ksc = NerfNet::ks_ch(L);
@@ -363,13 +382,8 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
             return w[(size_t)row * W + idx];
         }
         if (L == 8) {
-            if (row < W) return hp[w_off[FEAT] + (size_t)row * W + idx];
-            return row == W ? hp[w_off[ALPHA] + idx] : 0.0f;
-        }
-        if (L == 9) {
-            if (row >= W / 2) return 0.0f;
-            const float *w = hp.data() + w_off[VIEWS];
-            return nat ? ((idx < V) ? w[(size_t)row * (V + W) + W + idx] : 0.0f) : w[(size_t)row * (V + W) + idx];
+            if (row < W / 2) return nat ? ((idx < V) ? hp[w_off[VIEWS] + (size_t)row * (V + W) + W + idx] : 0.0f) : merged[(size_t)row * W + idx];
+            return (row == W / 2 && !nat) ? hp[w_off[ALPHA] + idx] : 0.0f;
         }
         return row < 3 ? hp[w_off[RGB] + (size_t)row * (W / 2) + idx] : 0.0f;
     };
@@ -381,8 +395,7 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
                     for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(L, tile * 32 + (lane & 31), k, lane >> 5, j));
         float *bp = bias.data() + NerfNet::bias_off(L);
         if (L < 8) for (int i = 0; i < W; i++) bp[i] = hp[b_off[L] + i];
-        else if (L == 8) { for (int i = 0; i < W; i++) bp[i] = hp[b_off[FEAT] + i]; bp[W] = hp[b_off[ALPHA]]; }
-        else if (L == 9) for (int i = 0; i < W / 2; i++) bp[i] = hp[b_off[VIEWS] + i];
+        else if (L == 8) { for (int i = 0; i < W / 2; i++) bp[i] = merged_b[i]; bp[W / 2] = hp[b_off[ALPHA]]; }
         else for (int i = 0; i < 3; i++) bp[i] = hp[b_off[RGB] + i];
     }
     if (img.size() != (size_t)NerfNet::total_frags() * 512) { set_error("internal: classic NeRF weight image has %zu halves, expected %zu", img.size(), (size_t)NerfNet::total_frags() * 512); return NRF_ERR_INVALID_ARG; }
