@@ -201,7 +201,10 @@ def main():
                 busy = pmc_mfma_busy("mlp_small (k_mlp_small_mfma)", args.precision)
                 if busy:
                     mroof["mfma_busy_frac_of_active_cycles"] = busy
-                    mroof["clock_held_ghz"] = 2.4 * mroof["mfma_issued_frac"] / busy
+                try:
+                    mroof["clock_ghz_measured"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["mlp_small (k_mlp_small_mfma)"]["clock_ghz_measured"][args.precision]
+                except Exception:
+                    pass
             # the roofline object describes the kernel that took the most time in THIS run (split precision: the MLP; plain fp16: the hash encode);
             # the other one rides along under its own key
             hroof = roof
