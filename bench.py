@@ -295,6 +295,28 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
                             psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
         except Exception as e:
             out.append(dict(workload=wl, precision=pname, error=str(e)))
+    if args.workload == "hash" and args.hash_mode == "cu":
+        # the same configuration on the LibTorch HashEmbedder + SHEncoder (the encoders whose reference implementation runs on the CPU and
+        # pins the oracle) -- fp32 table, hi + lo fp16 feature planes
+        try:
+            sc = scene.make_hash_scene(mode="ngp")
+            rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072, L.NRF_PREC_F16_SPLIT)
+            for _ in range(2):
+                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            a2 = argparse.Namespace(**{**vars(args), "workload": "hash", "precision": "f16x3", "hash_mode": "ngp"})
+            out.append(dict(workload="hashnerf_lego800_64+128", baseline_config=2, encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3",
+                            value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=3,
+                            psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
+            del sc
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out.append(dict(workload="hashnerf (HashEmbedder twin)", error=str(e)))
     try:
         out.append(train_step_measurement(args, scene, L))
     except Exception as e:
