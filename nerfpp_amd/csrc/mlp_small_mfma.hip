@@ -78,13 +78,16 @@ __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &h
         for (int j = 0; j < 4; j++) split_pair(fmaxf(acc[8 * s + 2 * j], 0.0f), fmaxf(acc[8 * s + 2 * j + 1], 0.0f), h.u[j], l.u[j]);
         hi = h.v; lo = l.v;
     } else {
+        // same two roundings (hi = RNE(v), lo = RNE(v - hi)) through the 1.5-instruction-per-value path
+        union { half8 v; uint32_t u[4]; } h, l;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float v = acc[8 * s + j];
-            const _Float16 hv = (_Float16)v;
-            hi[j] = hv;
-            lo[j] = (_Float16)(v - (float)hv);
+        for (int j = 0; j < 4; j++) {
+            // split_pair's asm must read VALU results, never the matrix instruction's destination directly (the MFMA -> VALU hazard handling is the compiler's and
+            // does not look into asm): a max with -FLT_MAX is the cheapest instruction that is the identity on every finite value
+            const float v0 = fmaxf(acc[8 * s + 2 * j], -3.402823466e38f), v1 = fmaxf(acc[8 * s + 2 * j + 1], -3.402823466e38f);
+            split_pair(v0, v1, h.u[j], l.u[j]);
         }
+        hi = h.v; lo = l.v;
     }
 }
 
