@@ -289,6 +289,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         //                                                           mt == 1         : this layer's tile 0      -> bh[bi ^ 1][.][0..1]
         auto make_job = [&](int bi, bool conv_prev_tile1, bool conv_this_tile0, int ks_count) {
             return [=, &conv_item](int mt, int ks) {
+                (void)conv_item;           // not referenced when PIPE is off for this instantiation
                 if constexpr (PIPE) {
                     if (conv_prev_tile1 && mt == 0 && ks < 2) { conv_item(bi, 1, 2 * ks); conv_item(bi, 1, 2 * ks + 1); }
                     if (conv_this_tile0 && mt == 1) {
