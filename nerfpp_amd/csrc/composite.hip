@@ -11,10 +11,31 @@
 #include "common.h"
 #include "stoch.h"
 
+#include <type_traits>
+
 namespace nrf {
 
 constexpr int MAX_S = 256;        // samples per ray per pass (coarse) / importance samples
 constexpr int RAYS_PER_BLOCK = 4; // waves per block
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan_t(T v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+template <class T>
+__device__ __forceinline__ T wave_sum_t(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 __device__ __forceinline__ double wave_incl_scan(double v, int lane)
 {
@@ -36,6 +57,10 @@ __device__ __forceinline__ double wave_sum(double v)
 // ------------------------------------------------------------------------------------------------
 // C1  RawToOutputs
 // ------------------------------------------------------------------------------------------------
+// FAST (the matrix-core precisions of the fused renderer, whose network outputs carry fp16-class error anyway): fp32 scan and sums, hardware exp / log /
+// reciprocal (v_exp_f32, v_log_f32, v_rcp_f32) instead of the ATen-reproducing routines of nrf_math.h and the double scan -- the exact form is ~180 vector
+// instructions per sample, this one ~25.  !FAST is the parity path and every stand-alone nrf_raw2outputs* entry.
+template <bool FAST>
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
@@ -48,8 +73,9 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
     float nn = dv[0] * dv[0]; nn = nn + dv[1] * dv[1]; nn = nn + dv[2] * dv[2];
     const float nrm = sqrtf(nn);                                   // torch::norm(rays_d, 2, -1)
     const float *zr = z + ray * s;
-    double carry = 0.0;                                            // sum of log(1-alpha) over previous 64-sample blocks
-    double sr = 0.0, sg = 0.0, sb = 0.0, sw = 0.0, swz = 0.0;
+    using acc_t = typename std::conditional<FAST, float, double>::type;
+    acc_t carry = 0;                                               // sum of log(1-alpha) over previous 64-sample blocks
+    acc_t sr = 0, sg = 0, sb = 0, sw = 0, swz = 0;
     for (int base = 0; base < s; base += 64) {
         const int j = base + lane;
         const bool live = j < s;
@@ -68,27 +94,28 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
             if (nz.on)                                              // raw_noise_std > 0 (:251-252)
                 sg = sg + (nz.arr ? nz.arr[ray * s + j] : nrf_rng_normal(nz.g.seed, nz.stream, (uint64_t)((nz.g.ray_base + ray) * s + j))) * nz.std;
             const float sig = sg > 0.0f ? sg : 0.0f;                // relu
-            alpha = -nrf_expf(-sig * dist) + 1.0f;                      // :234
+            alpha = -(FAST ? __expf(-sig * dist) : nrf_expf(-sig * dist)) + 1.0f;      // :234
             const float om = 1.0f - alpha;
-            lg = nrf_logf(om > 1e-10f ? om : 1e-10f);                   // :265
+            lg = FAST ? __logf(om > 1e-10f ? om : 1e-10f) : nrf_logf(om > 1e-10f ? om : 1e-10f);      // :265
             if (rgb) {
-                cr = nrf_sigmoidf(vec ? r4.x : r[0]);               // sigmoid, :250
-                cg = nrf_sigmoidf(vec ? r4.y : r[1]);
-                cb = nrf_sigmoidf(vec ? r4.z : r[2]);
+                auto sigm = [](float x) { return FAST ? __frcp_rn(1.0f + __expf(-x)) : nrf_sigmoidf(x); };
+                cr = sigm(vec ? r4.x : r[0]);                       // sigmoid, :250
+                cg = sigm(vec ? r4.y : r[1]);
+                cb = sigm(vec ? r4.z : r[2]);
             }
         }
-        const double incl = wave_incl_scan((double)lg, lane);
-        const double excl = carry + (incl - (double)lg);            // exclusive prefix: cat[0, cumsum][:-1] (:263-266)
+        const acc_t incl = wave_incl_scan_t<acc_t>((acc_t)lg, lane);
+        const acc_t excl = carry + (incl - (acc_t)lg);              // exclusive prefix: cat[0, cumsum][:-1] (:263-266)
         carry += __shfl(incl, 63);
         if (live) {
-            const float trans = nrf_expf((float)excl);                  // TruncExp forward = exp (:267)
+            const float trans = FAST ? __expf((float)excl) : nrf_expf((float)excl);      // TruncExp forward = exp (:267)
             w = alpha * trans;
             if (weights) weights[ray * s + j] = w;
-            sr += (double)(w * cr); sg += (double)(w * cg); sb += (double)(w * cb);
-            sw += (double)w; swz += (double)(w * zj);
+            sr += (acc_t)(w * cr); sg += (acc_t)(w * cg); sb += (acc_t)(w * cb);
+            sw += (acc_t)w; swz += (acc_t)(w * zj);
         }
     }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sw = wave_sum(sw); swz = wave_sum(swz);
+    sr = wave_sum_t<acc_t>(sr); sg = wave_sum_t<acc_t>(sg); sb = wave_sum_t<acc_t>(sb); sw = wave_sum_t<acc_t>(sw); swz = wave_sum_t<acc_t>(swz);
     if (lane == 0) {
         const float a = (float)sw;
         const float dep = (float)swz / (a > 1e-10f ? a : 1e-10f);  // :272
@@ -292,11 +319,13 @@ __global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int d
 }
 
 int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
-                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st)
+                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast)
 {
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_COMPOSITE, st);
-    hipLaunchKernelGGL(k_raw2outputs, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
+    if (fast) hipLaunchKernelGGL(k_raw2outputs<true>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
+                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz);
+    else hipLaunchKernelGGL(k_raw2outputs<false>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
                        raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz);
     NRF_LAUNCH_CHECK();
     return NRF_OK;

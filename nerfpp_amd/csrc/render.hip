@@ -291,6 +291,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     hipStream_t st = as_stream(stream);
     const int s = p->n_samples, ni = p->n_importance, sf = s + ni;
     const int c = r->desc.mlp->out_dims;
+    // the FINAL compositing of the matrix-core precisions uses hardware exp / log / rcp and fp32 scans (composite.hip); NRF_PREC_F32, and the coarse pass whose
+    // weights feed SamplePDF (a moved CDF bin is a visibly different sample set), keep the oracle's arithmetic
+    const bool fastc = p->precision != NRF_PREC_F32;
     Bump bump(d_workspace, workspace_bytes);
     float *z_c = out->d_z_coarse ? out->d_z_coarse : bump.take<float>((size_t)n * s);
     float *w_c = out->d_weights_coarse ? out->d_weights_coarse : bump.take<float>((size_t)n * s);
@@ -347,9 +350,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     if (ni == 0) {
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
         return launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                                  out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st);
+                                  out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st, fastc);
     }
-    NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz, st));   // :423
+    NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz, st, false));   // :423  always the exact arithmetic: these weights choose the fine samples
     NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st));          // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
     if (cone || precond) {                                                                                         // :433-445
@@ -360,7 +363,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     NRF_TRY(network(psf, sf, raw_f));                                                                              // :447
     nz.stream = NRF_RNG_NOISE_FINE;
     return launch_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                              out->d_weights, out->d_depth, nz, st);                                               // :448
+                              out->d_weights, out->d_depth, nz, st, fastc);                                        // :448
 }
 
 }  // extern "C"
