@@ -1,14 +1,14 @@
 """Experiment: do the hash-encode (vector-memory bound) and MLP (MFMA bound) kernels of independent ray tiles overlap when issued on two HIP streams?"""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from nerfpp_amd import _lib as L, scene as S
 from nerfpp_amd.renderer import NeRFRenderer
 H = W = 800
-for precname, prec in (("f16", L.NRF_PREC_F16_MFMA), ("f16x3", L.NRF_PREC_F16_SPLIT)):
+for precname, prec in (("f16x3", L.NRF_PREC_F16_SPLIT),):
     sc = S.make_hash_scene(mode="cu")
     K = S.lego_K(H, W); c2w = S.pose_spherical(30.0, -30.0, 4.0)
-    for nstreams, chunk in ((1, 131072), (2, 131072), (2, 65536), (2, 32768), (4, 65536), (1, 65536), (3, 65536)):
+    for nstreams, chunk in ((1, 131072), (2, 131072), (2, 65536), (3, 65536), (4, 65536)):
         rs = [NeRFRenderer(sc["embedder"], sc["embeddirs"], sc["mlp"]) for _ in range(nstreams)]
         streams = [torch.cuda.Stream() for _ in range(nstreams)]
         rp = S.lego_render_params(sc["bbox"], 64, 128, chunk, prec)
