@@ -37,3 +37,31 @@ class TileShard:
         out = out.view((self.world, f) + tuple(local.shape[1:]))
         parts = [out[r, :, :self.rows_of[r]] for r in range(self.world)]
         return torch.cat(parts, 1)                                                        # [F, H, W, C]
+
+
+class GradSync:
+    """Data-parallel training step (SURVEY section 8f row N1 across GPUs): every rank renders and back-propagates its own ray batch against the replicated model,
+    the gradients (hash table: 67 MB of fp32 at L16 T2^19 F2; MLP blob: 70 KB) are summed with ONE all-reduce per bucket and divided by the world size before Adam, so
+    all replicas take the same step.  xGMI is point-to-point (7 links per GPU), so a ring all-reduce moves 2 (N-1)/N of the payload per link: the table gradient is
+    sent in `bucket_bytes` slices to keep several links busy while the previous slice is being reduced; the blob rides in the last one.  No reference counterpart
+    (the reference trains on one device)."""
+
+    def __init__(self, world=None, bucket_bytes=32 << 20):
+        self.world = (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1) if world is None else int(world)
+        self.bucket_elems = max(int(bucket_bytes) // 4, 1)
+
+    def __call__(self, *grads):
+        """grads: fp32 gradient tensors, reduced IN PLACE to their mean over the ranks."""
+        if self.world == 1:
+            return grads
+        handles = []
+        for g in grads:
+            flat = g.view(-1)
+            for i in range(0, flat.numel(), self.bucket_elems):
+                handles.append(dist.all_reduce(flat[i:i + self.bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+        inv = 1.0 / self.world
+        for g in grads:
+            g.mul_(inv)
+        return grads

@@ -20,7 +20,7 @@ from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecond
 
 class Trainer:
     def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
-                 tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32"):
+                 tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32", grad_sync=None):
         if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
             raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
@@ -47,6 +47,7 @@ class Trainer:
         if hash_backward == "packed" and embedder.NFeaturesPerLevel != 2:
             raise L.NrfError("hash_backward='packed' needs 2 features per level")
         self.hash_backward = hash_backward
+        self.grad_sync = grad_sync          # callable(g_table, g_blob) reducing the gradients across data-parallel ranks in place, or None
         self._hws = None
         self._ws = None
         if isinstance(embedder, CuHashEmbedder):
@@ -168,6 +169,8 @@ class Trainer:
         s_out = p.NSamples + p.NImportance
         loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
         self.add_tv_loss()
+        if self.grad_sync is not None:                     # data-parallel replicas: mean of the ranks' gradients (nerfpp_amd/dist.py::GradSync)
+            self.grad_sync(self.g_table, self.g_blob)
         self.t += 1
         b1, b2 = self.betas
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):

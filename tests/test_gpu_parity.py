@@ -1407,6 +1407,14 @@ def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
         Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], mlp_backward="bf16")
     with pytest.raises(api.L.NrfError):
         Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], hash_backward="f16")
+    # the data-parallel hook sees both gradients after the backward and before Adam (world size 1 here: the 2-rank reduction itself is a CPU gloo test)
+    from nerfpp_amd.dist import GradSync
+    seen = []
+    def hook(gt, gb):
+        seen.append((float(gt.abs().sum()), float(gb.abs().sum()))); return GradSync(world=1)(gt, gb)
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-3, grad_sync=hook)
+    tr.step(o, d, tgt, rp)
+    assert len(seen) == 1 and seen[0][0] > 0 and seen[0][1] > 0
 
 
 def test_trainer_tv_regulariser_smooths_the_table(api):

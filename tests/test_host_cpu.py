@@ -121,6 +121,11 @@ dist.barrier()
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert t.item() == world
+# data-parallel gradient mean (GradSync): bucketed all-reduce, in place, uneven last bucket
+from nerfpp_amd.dist import GradSync
+g_table = torch.arange(1000, dtype=torch.float32) * (rank + 1); g_blob = torch.full((7,), float(rank), dtype=torch.float32)
+GradSync(bucket_bytes=4 * 300)(g_table, g_blob)
+assert torch.allclose(g_table, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)) and torch.allclose(g_blob, torch.full((7,), (world - 1) / 2.0))
 dist.destroy_process_group()
 print("ok", rank)
 """
