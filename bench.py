@@ -349,7 +349,7 @@ def lerf_measurement(scene, K, c2w, rows=200):
                 fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
                 level_major_features=bool(getattr(r, "level_major", False)),
                 arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
-                           "read by the kernels as operand fragments; embedding norm via the Gram matrix of the bias-free output layer")
+                           "read by the kernels as operand fragments; embedding norm via the Gram matrix of the bias-free output layer, which is applied once per ray to the weighted sum of its inputs")
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):

@@ -5,11 +5,14 @@
 // reduce it to one 768-vector per ray.  Here the 768-wide output never leaves the register file:
 //
 //   kernel A  nrf_lerf_sigma             sigma net only  (in 128 -> 256 -> 33):  sigma_le per point, for the compositing weights
-//   kernel B  nrf_lerf_render_embedding  sigma net (for the 32 geo features) -> LE net (cat[geo, in] 160 -> 256 -> 768) TWICE:
-//               pass 1 accumulates ||h||^2 per point, pass 2 recomputes the 24 output tiles, scales each point's column by
-//               w_s / max(||h||, 1e-8) and sums the 32 points (= 32 consecutive samples of ONE ray) of the tile across lanes;
-//               each wave adds its 768 partial sums to out[ray] with one 128-byte-contiguous float atomic per tile.
-//             out[ray] = normalize(sum_s w_s * normalize(h_s))  is finished by the caller's L2-normalise.
+//   kernel B  nrf_lerf_render_embedding  sigma net (for the 32 geo features) -> LE0 (cat[geo, in] 160 -> 256, ReLU) = a_s; the embedding layer LE1
+//               (256 -> 768) is bias-free and LINEAR, and so is the ray's weighted sum, hence
+//                   sum_s w_s normalize(W a_s) = W . sum_s (w_s / max(||W a_s||, 1e-8)) a_s        with ||W a||^2 = a^T (W^T W) a:
+//               per SAMPLE only the 256 x 256 Gram product (8 tiles) is evaluated, the scaled a_s of the 32 points of a tile (= 32 consecutive
+//               samples of ONE ray) are summed across lanes and added to asum[ray][256] with one 128-byte float atomic per 32 neurons;
+//   kernel C  W is applied ONCE PER RAY to asum (384 matrix instructions per 32 rays instead of per 32 samples): out[ray][768].
+//             out[ray] = normalize(...) is finished by the caller's L2-normalise.  320 matrix instructions per 32 sample points instead of 960 (704 with
+//             the Gram norm but the layer still run per sample).
 //
 // Same transposed MFMA formulation and the same L2 -> LDS weight streaming as mlp_nerf_mfma.hip (8 waves x 32 points per workgroup,
 // chunks of <= 2 neuron tiles x all k-steps, LDS-DMA through three buffers two chunks ahead); fp16 operands, fp32 accumulate.
@@ -55,8 +58,9 @@ struct Net {
     static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
     static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
 };
-static_assert(Net<2>::total_chunks() == 6 && Net<5>::total_chunks() == 26, "chunk counts");
-constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16 + 24 * 16;       // 704 KB
+static_assert(Net<2>::total_chunks() == 6 && Net<4>::total_chunks() == 14 && Net<5>::total_chunks() == 26, "chunk counts");
+constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16 + 24 * 16;       // 704 KB: sigma0, sigma1, LE0, Gram (chained operands) + LE1 in NATURAL operand order (kernel C)
+constexpr int LE1_FRAG0 = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16;
 static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) + 24 * 16 == IMAGE_FRAGS, "image size");
 
 // Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4, one 1-KB fragment per wave-instruction, wave w takes fragments
@@ -282,11 +286,49 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
             layer<N, 3>(cx, none, ba, ssq);                   // ||LE1(a)||^2 = a . (W^T W) a
             const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f);
             const float wgt = live ? in.weights[q] : 0.0f;
-            ReduceHook red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)EMB : nullptr, r, h};
-            layer<N, 4>(cx, none, ba, red);                   // LE1: sum_s w_s h_s / ||h_s||
+            // sum over the tile's 32 samples of (w_s / ||h_s||) a_s: fragments 2t, 2t+1 of a hold, on each lane, the neurons of D-tile t's 16 registers
+            ReduceHook red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)HID : nullptr, r, h};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                f32x16 v;
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = (float)ba[2 * t + (i >> 3)][i & 7];
+                red(t, v);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two chunks' look-ahead requests are still in flight
+}
+
+// kernel C: out[ray][768] = W . asum[ray][256] -- the embedding layer applied once per ray.  One wave per 32 rays; the operand (16 k-steps, natural order) is read
+// from asum in fp32 and rounded to fp16 once; the 384 weight fragments (384 KB, L2-resident) are read straight from global memory, coalesced 1 KB per wave
+// instruction -- at 1/192 of the per-sample work this kernel is 2 % of the pass and needs no staging.
+__global__ void __launch_bounds__(256)
+k_lerf_embed(int64_t nrays, const float *__restrict__ asum, const half8 *__restrict__ packed, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t ray = tile * 32 + r;
+    if (tile * 32 >= nrays) return;
+    const int64_t rc = ray < nrays ? ray : nrays - 1;
+    half8 b[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const float4 lo = *reinterpret_cast<const float4 *>(asum + rc * HID + 16 * s + 8 * h), hi = *reinterpret_cast<const float4 *>(asum + rc * HID + 16 * s + 8 * h + 4);
+        b[s] = half8{(_Float16)lo.x, (_Float16)lo.y, (_Float16)lo.z, (_Float16)lo.w, (_Float16)hi.x, (_Float16)hi.y, (_Float16)hi.z, (_Float16)hi.w};
+    }
+    const half8 *w = packed + (size_t)LE1_FRAG0 * 64 + lane;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < 24; t++) {
+        f32x16 acc = zero;
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(size_t)(t * 16 + k) * 64], b[k], acc, 0, 0, 0);
+        if (ray < nrays) {
+            float *o = out + ray * EMB + 32 * t + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(o + 8 * g) = float4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};      // rows 8g + 4h + 0..3
+        }
+    }
 }
 
 // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L
@@ -305,7 +347,7 @@ static float wval(const std::vector<float> &hp, const std::vector<float> &gram, 
         return hp[off2 + (size_t)row * (GEO + IN) + GEO + natural(kstep - 4, h, j)];
     }
     if (L == 3) return gram[(size_t)row * HID + chained(kstep, h, j)];
-    return hp[off3 + (size_t)row * HID + chained(kstep, h, j)];
+    return hp[off3 + (size_t)row * HID + natural(kstep, h, j)];          // LE1 for kernel C: its operand comes from memory, natural order
 }
 
 }  // namespace lerf
@@ -362,6 +404,28 @@ static int launch_lerf(const nrf_mlp *m, const Args &a, int64_t p, hipStream_t s
     return NRF_OK;
 }
 
+// kernel B into a stream-ordered scratch asum [n][256] (zeroed), then kernel C
+static int lerf_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int s, float *d_out, hipStream_t st)
+{
+    float *asum = nullptr;
+    const size_t bytes = (size_t)n * lerf::HID * sizeof(float);
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&asum), bytes, st));
+    NRF_HIP(hipMemsetAsync(asum, 0, bytes, st));
+    int rc;
+    {
+        ProfScope prof(NRF_PROF_MLP, st);
+        a.out = asum;
+        rc = launch_lerf<4>(m, a, n * (int64_t)s, st);
+        if (rc == NRF_OK) {
+            hipLaunchKernelGGL(lerf::k_lerf_embed, dim3((unsigned)ceil_div(ceil_div(n, (int64_t)32), (int64_t)4)), dim3(256), 0, st, n, (const float *)asum,
+                               reinterpret_cast<const lerf::half8 *>(m->d_packed_f16), d_out);
+            if (hipGetLastError() != hipSuccess) { set_error("k_lerf_embed launch failed"); rc = NRF_ERR_HIP; }
+        }
+    }
+    (void)hipFreeAsync(asum, st);
+    return rc;
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -388,11 +452,8 @@ int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d
     NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_render_embedding: feature rows must be 16-byte aligned");
     if (n == 0) return NRF_OK;
-    hipStream_t st = as_stream(stream);
-    NRF_HIP(hipMemsetAsync(d_out, 0, (size_t)n * lerf::EMB * sizeof(float), st));
-    ProfScope prof(NRF_PROF_MLP, st);
-    lerf::Args a{d_x, lerf::IN, nullptr, 0, d_weights, nullptr, nullptr, d_out, s};
-    return launch_lerf<5>(m, a, n * (int64_t)s, st);
+    lerf::Args a{d_x, lerf::IN, nullptr, 0, d_weights, nullptr, nullptr, nullptr, s};
+    return lerf_embedding_passes(m, a, n, s, d_out, as_stream(stream));
 }
 
 // the same two passes reading level-major fp16 features (nrf_hash_encode_lm_f16 of a 16-level, 8-feature CuHashEmbedder): [16][p][8] halfs
@@ -414,11 +475,8 @@ int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const
     NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding_lm: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_render_embedding_lm: features must be 16-byte aligned");
     if (n == 0) return NRF_OK;
-    hipStream_t st = as_stream(stream);
-    NRF_HIP(hipMemsetAsync(d_out, 0, (size_t)n * lerf::EMB * sizeof(float), st));
-    ProfScope prof(NRF_PROF_MLP, st);
-    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), n * (int64_t)s, d_weights, nullptr, nullptr, d_out, s};
-    return launch_lerf<5>(m, a, n * (int64_t)s, st);
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), n * (int64_t)s, d_weights, nullptr, nullptr, nullptr, s};
+    return lerf_embedding_passes(m, a, n, s, d_out, as_stream(stream));
 }
 
 }  // extern "C"
