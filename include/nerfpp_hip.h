@@ -207,7 +207,9 @@ NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float
  * (main.cpp:203-213: in 128, hidden 256, 2 + 2 layers, geo 32, embedding 768) -- the [N, S, 769] raw tensor is never formed.
  *   nrf_lerf_sigma            : sigma_le = LeRFImpl::forward(x)[..., -1] (LeRF.cpp:86-95), zeroed where keep is false (LeRFRenderer.cpp:22-23)
  *   nrf_lerf_render_embedding : out[n, 768] = sum_s weights[n,s] * normalize(le(x[n,s]))  (LeRF.cpp:96-108 + the sum of LeRFRenderer.h:45-54);
- *                               s must be a multiple of 32.  L2-normalise `out` afterwards (nrf_render_clip_embedding's last step). */
+ *                               s must be a multiple of 32.  L2-normalise `out` afterwards (nrf_render_clip_embedding's last step).
+ *                               Evaluated as W . sum_s (weights / ||W a||) a with ||W a||^2 = a^T (W^T W) a (the output layer is bias-free, hence linear): the
+ *                               256 -> 768 layer runs once per ray.  Takes n * 256 floats of stream-ordered scratch (hipMallocAsync / hipFreeAsync). */
 NRF_API int nrf_lerf_mfma_available(const nrf_mlp *m);
 NRF_API int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
 NRF_API int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
