@@ -282,6 +282,14 @@ typedef struct nrf_renderer_desc {
 /* NeRFRenderParams (NeRFRenderer.h:28-44) as RenderRays consumes them.  Zero-initialise the struct: all stochastic
  * fields 0 is the deterministic render path (Perturb = 0, RawNoiseStd = 0, ThinRay = true -- what FillRenderParams sets
  * at test time, NeRFExecutor.h:379-415, plus ThinRay). */
+/* The coarse pass of a hierarchical render contributes only its compositing weights (NeRFRenderer.h:422-428), i.e. sigma, and those
+ * weights choose the fine samples through searchsorted -- a discontinuous function.  NRF_COARSE_AUTO: with NRF_PREC_F16_SPLIT on the
+ * HashNeRF fast path the coarse pass evaluates the sigma net ONLY, in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32 ==
+ * the ascending-k fma chain of NRF_PREC_F32, bit for bit), so the fine sample set equals the parity mode's; every other case runs
+ * the whole network in `precision`.  NRF_COARSE_FULL forces the latter, NRF_COARSE_SIGMA_F32 asks for the former in
+ * NRF_PREC_F16_MFMA too.  A caller that wants d_raw_coarse always gets the whole network. */
+enum { NRF_COARSE_AUTO = 0, NRF_COARSE_FULL = 1, NRF_COARSE_SIGMA_F32 = 2 };
+
 typedef struct nrf_render_params {
     int n_samples;            /* NSamples */
     int n_importance;         /* NImportance */
@@ -299,6 +307,7 @@ typedef struct nrf_render_params {
     float bbox[6];
     uint64_t seed;
     int64_t ray_base;         /* index of d_rays[0] within the whole image / ray batch */
+    int coarse_mode;          /* NRF_COARSE_*: how the coarse pass is evaluated when n_importance > 0 (it only supplies SamplePDF's weights) */
 } nrf_render_params;
 
 typedef struct nrf_render_outputs {   /* NeRFRendererOutputs / NeRFRenderResult (NeRFRenderer.h:12-26); NULL = not wanted */
@@ -412,7 +421,7 @@ NRF_API int nrf_to_u8(const float *d_x, int64_t n, uint8_t *d_out, void *stream)
  * ------------------------------------------------------------------------------------------- */
 /* When enabled, nrf_render_rays brackets its dominant kernels with HIP events on the caller's stream;
  * nrf_profile_read synchronises them and returns accumulated milliseconds and launch counts. */
-enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAMPLE = 3, NRF_PROF_OTHER = 4, NRF_PROF_COUNT = 5 };
+enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAMPLE = 3, NRF_PROF_OTHER = 4, NRF_PROF_SIGMA = 5, NRF_PROF_COUNT = 6 };
 NRF_API int nrf_profile_enable(int on);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
 

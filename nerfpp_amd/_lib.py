@@ -16,7 +16,8 @@ NRF_PREC_F32, NRF_PREC_F16_MFMA, NRF_PREC_F16_SPLIT = 0, 1, 2
 NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
 (NRF_RNG_T_RAND, NRF_RNG_R_COARSE, NRF_RNG_THETA_COARSE, NRF_RNG_NOISE_COARSE, NRF_RNG_U_PDF, NRF_RNG_PRECOND, NRF_RNG_R_FINE, NRF_RNG_THETA_FINE,
  NRF_RNG_NOISE_FINE) = range(1, 10)       # include/nrf_rng.h
-NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other")
+NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other", "sigma")
+NRF_COARSE_AUTO, NRF_COARSE_FULL, NRF_COARSE_SIGMA_F32 = 0, 1, 2
 
 
 class HashDesc(C.Structure):
@@ -42,7 +43,7 @@ class RenderParams(C.Structure):
     _fields_ = [("n_samples", C.c_int), ("n_importance", C.c_int), ("lindisp", C.c_int), ("white_bkgr", C.c_int),
                 ("precision", C.c_int), ("sum_vec", C.c_int),
                 ("perturb", C.c_float), ("has_cone", C.c_int), ("cone_angle", C.c_float), ("raw_noise_std", C.c_float), ("precond_alpha", C.c_float),
-                ("has_bbox", C.c_int), ("bbox", C.c_float * 6), ("seed", C.c_uint64), ("ray_base", C.c_int64)]
+                ("has_bbox", C.c_int), ("bbox", C.c_float * 6), ("seed", C.c_uint64), ("ray_base", C.c_int64), ("coarse_mode", C.c_int)]
 
 
 class RenderOutputs(C.Structure):

@@ -10,7 +10,8 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st);
 int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, uint8_t *keep, int variant, hipStream_t st,
                    int level_lo = 0, int level_hi = -1);
 // out_lo (optional): the rounding residuals r - f16(r), for the split-precision MLP
-int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st);
+// f32_out: ONE float2 plane [L][pstride] of the unrounded fp32 features at feats instead (lo_off ignored)
+int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out = false);
 int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int variant, __half *out, __half *out_lo, hipStream_t st);
 
 constexpr int HASH_LM_DEFAULT_VARIANT = 0;

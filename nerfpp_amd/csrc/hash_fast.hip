@@ -112,8 +112,9 @@ __device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const flo
     acc[0] = o.x; acc[1] = o.y;
 }
 
-// feats: plane 0 (hi) at feats, plane 1 (lo) at feats + lo_off (0: not wanted); both [L][pstride] half2
-template <int LPT>
+// feats: plane 0 (hi) at feats, plane 1 (lo) at feats + lo_off (0: not wanted); both [L][pstride] half2.
+// F32OUT: the unrounded fp32 features instead, as ONE level-major float2 plane at feats (the exact-fp32 coarse pass, sigma_small_f32.hip).
+template <int LPT, bool F32OUT = false>
 __global__ void __launch_bounds__(256)
 k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, int64_t lo_off, uint8_t *__restrict__ keep, int level0)
 {
@@ -126,6 +127,7 @@ k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fe
 #pragma unroll
     for (int a = 0; a < 3; a++) { xc[a] = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]); kp = kp && (x[a] == xc[a]); }
     __half2 hi[LPT], lo[LPT];
+    float2 full[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; j++) {
         float acc[2];
@@ -133,12 +135,16 @@ k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fe
         const __half h0 = __float2half_rn(acc[0]), h1 = __float2half_rn(acc[1]);
         hi[j] = __halves2half2(h0, h1);
         lo[j] = __halves2half2(__float2half_rn(acc[0] - __half2float(h0)), __float2half_rn(acc[1] - __half2float(h1)));
+        full[j] = float2{acc[0], acc[1]};
     }
     if (i >= p) return;
 #pragma unroll
     for (int j = 0; j < LPT; j++) {
-        feats[(int64_t)(level + j) * pstride + i] = hi[j];
-        if (lo_off) feats[lo_off + (int64_t)(level + j) * pstride + i] = lo[j];
+        if constexpr (F32OUT) reinterpret_cast<float2 *>(feats)[(int64_t)(level + j) * pstride + i] = full[j];
+        else {
+            feats[(int64_t)(level + j) * pstride + i] = hi[j];
+            if (lo_off) feats[lo_off + (int64_t)(level + j) * pstride + i] = lo[j];
+        }
     }
     if (level == 0 && keep) keep[i] = kp ? 1 : 0;
 }
@@ -264,13 +270,20 @@ int hash_fast_supported(const nrf_hash *h)
 }
 
 // HashEmbedder-mode level-major encode: hi plane at feats, lo plane at feats + lo_off (0 = none)
-int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st)
+int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out)
 {
     if (p == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_HASH, st);
     const int L = h->desc.n_levels;
     const int64_t ntiles = ceil_div(p, 256);
     const int lc = (L * 3 / 4) & ~3;
+    if (f32_out) {
+        if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4, true>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0);
+        NRF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_hash_ngp_lm<1, true>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc);
+        NRF_LAUNCH_CHECK();
+        return NRF_OK;
+    }
     if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0);
     NRF_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_hash_ngp_lm<1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc);

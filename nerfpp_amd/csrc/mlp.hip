@@ -466,6 +466,7 @@ int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int p
     for (int l = 0; l < d->num_layers_color && s == NRF_OK; l++)
         s = add_layer(m, hp, off, (l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color, (l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color, false);
     if (s == NRF_OK) s = mlp_small_pack_f16(m, hp);
+    if (s == NRF_OK) s = mlp_small_pack_sigma_f32(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -556,7 +557,7 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
         if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, hp.data() + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyHostToDevice, st));
     }
     NRF_HIP(hipStreamSynchronize(st));
-    if (m->family == MLP_SMALL) return mlp_small_pack_f16(m, hp);
+    if (m->family == MLP_SMALL) { NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }
     if (m->family == MLP_NERF) return mlp_nerf_pack_f16(m, hp);
     if (m->family == MLP_LERF) return mlp_lerf_pack_f16(m, hp);
     return NRF_OK;
@@ -603,6 +604,7 @@ void nrf_mlp_destroy(nrf_mlp *m)
     if (m->d_packed_f16) (void)hipFree(m->d_packed_f16);
     if (m->d_packed_split) (void)hipFree(m->d_packed_split);
     if (m->d_packed_bwd) (void)hipFree(m->d_packed_bwd);
+    if (m->d_packed_sigma_f32) (void)hipFree(m->d_packed_sigma_f32);
     delete m;
 }
 

@@ -121,6 +121,22 @@ static int run_network_fast(const nrf_renderer *r, const PointSource &ps, const 
     return mlp_small_forward_mfma_lm(r->desc.mlp, feats, want_lo ? feats + p * 16 : nullptr, p, dirs_f16, dirs_lo, s, keep, p, raw, st);
 }
 
+// Coarse pass of a hierarchical render on the fast path: sigma only, exact fp32 on the matrix cores (sigma_small_f32.hip).  The features are the
+// fast path's own (CuHashEmbedder: level-major fp16, exact; HashEmbedder: one level-major fp32 plane), so sigma equals NRF_PREC_F32's bit for bit.
+static int run_sigma_fast(const nrf_renderer *r, const PointSource &ps, int64_t n, int s, float *sigma, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    const int64_t p = n * s;
+    if (p == 0) return NRF_OK;
+    Bump bump(ws, ws_bytes);
+    const bool ngp = r->desc.hash->desc.mode == NRF_HASH_NGP;
+    __half2 *feats = bump.take<__half2>((size_t)p * 16 * (ngp ? 2 : 1));
+    uint8_t *keep = bump.take<uint8_t>((size_t)p);
+    if (bump.off > ws_bytes) { set_error("run_sigma_fast: workspace too small"); return NRF_ERR_WORKSPACE; }
+    if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, p, feats, p, 0, keep, st, true));
+    else NRF_TRY(launch_hash_lm(r->desc.hash, ps, p, feats, p, keep, HASH_LM_DEFAULT_VARIANT, st));
+    return mlp_small_sigma_f32_lm(r->desc.mlp, feats, ngp ? 1 : 0, p, keep, p, sigma, st);
+}
+
 // RunNetwork over p = n*s points given either explicit points or (rays, z).
 static int run_network(const nrf_renderer *r, const PointSource &ps, const float *viewdirs, int vd_stride, int64_t n, int s, int prec,
                        float *raw, void *ws, size_t ws_bytes, hipStream_t st)
@@ -284,6 +300,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     NRF_CHECK_ARG(p->perturb >= 0.0f && p->raw_noise_std >= 0.0f && p->precond_alpha >= 0.0f, "nrf_render_rays: negative perturb / raw_noise_std / precond_alpha");
     NRF_CHECK_ARG(p->precond_alpha == 0.0f || p->has_bbox, "nrf_render_rays: stochastic preconditioning reflects at the bounding box (NeRFRenderer.h:436-442): bbox required");
     NRF_CHECK_ARG(p->perturb == 0.0f || p->n_samples >= 2, "nrf_render_rays: Perturb > 0 needs n_samples >= 2");
+    NRF_CHECK_ARG(p->coarse_mode >= NRF_COARSE_AUTO && p->coarse_mode <= NRF_COARSE_SIGMA_F32, "nrf_render_rays: coarse_mode %d is not an NRF_COARSE_* value", p->coarse_mode);
     if (workspace_bytes < nrf_render_rays_workspace_bytes(r, n, p)) {
         set_error("nrf_render_rays: workspace %zu < %zu bytes", workspace_bytes, nrf_render_rays_workspace_bytes(r, n, p));
         return NRF_ERR_WORKSPACE;
@@ -304,6 +321,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         raw_f = out->d_raw ? out->d_raw : bump.take<float>((size_t)n * sf * c);
     }
     const bool fast = fast_path(r, p->precision);
+    // the coarse pass only supplies SamplePDF's weights: sigma net alone, in the parity arithmetic (see nrf_render_params.coarse_mode)
+    const bool sigma_only = ni > 0 && fast && !out->d_raw_coarse && mlp_small_sigma_f32_available(r->desc.mlp) &&
+                            (p->coarse_mode == NRF_COARSE_SIGMA_F32 || (p->coarse_mode == NRF_COARSE_AUTO && p->precision == NRF_PREC_F16_SPLIT));
     // classic NeRF fast path: PE(10) positions / PE(4) directions + the 8x256 matrix-core kernel with the PE fused in
     const bool fast_classic = p->precision == NRF_PREC_F16_MFMA && !r->desc.hash && r->desc.pe_freqs == 10 && r->desc.dirs_encoder == NRF_DIRS_PE &&
                               r->desc.dirs_param == 4 && mlp_nerf_mfma_available(r->desc.mlp);
@@ -345,14 +365,16 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_c, n, s, sp, rng, pts, st));
         ps.pts = pts;
     }
-    NRF_TRY(network(ps, s, raw_c));                                                                                // :422
+    if (sigma_only) NRF_TRY(run_sigma_fast(r, ps, n, s, raw_c, nws, nws_bytes, st));                               // raw_c holds sigma [n,s] only
+    else NRF_TRY(network(ps, s, raw_c));                                                                           // :422
     nz.stream = NRF_RNG_NOISE_COARSE;
     if (ni == 0) {
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
         return launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
                                   out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st, fastc);
     }
-    NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz, st, false));   // :423  always the exact arithmetic: these weights choose the fine samples
+    NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, sigma_only ? 1 : c, sigma_only ? 0 : 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz,
+                               st, false));   // :423  always the exact arithmetic: these weights choose the fine samples
     NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st));          // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
     if (cone || precond) {                                                                                         // :433-445

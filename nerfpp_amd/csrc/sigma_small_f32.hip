@@ -1,0 +1,199 @@
+// sigma_small_f32.hip -- the density head of NeRFSmallImpl::forward (NeRF.cpp:372-381, sigma = h[..., 0]) in EXACT fp32 on the matrix
+// cores, for the renderer's coarse pass.
+//
+// Why it exists.  With N_importance > 0 the coarse pass contributes nothing but its compositing weights (NeRFRenderer.h:422-428:
+// outputs1.Weights -> SamplePDF), i.e. only sigma: the colour net (59 % of the network's MACs) is dead work there.  And those weights pick the
+// fine pass's sample set through searchsorted on CDF plateaus, a DISCONTINUOUS function: a sigma that differs in the last bits moves
+// a few samples into another bin and a pixel by up to ~5e-4, however accurate the fine pass is.  So the coarse sigma is evaluated in the
+// parity arithmetic itself: v_mfma_f32_32x32x2_f32 is, bit for bit, the ascending-k fmaf chain of NRF_PREC_F32 / the oracle
+// (tools/scratch/mfma_f32_probe.hip: 1024 of 1024 outputs identical, denormals included) at the fp32 vector rate without its operand traffic.
+// The coarse weights, hence z_fine, then EQUAL the parity mode's, and the matrix-core precisions differ from it only by the fine pass's
+// smooth rounding error.
+//
+// Formulation (transposed, as the fp16 kernels):  H_{l+1}^T [neurons x points] = W [neurons x k] . H_l^T [k x points],
+// A = 32 neurons x 2 k (lane (i, hh): W[row i][2 ks + hh]), B = 2 k x 32 points (lane (r, hh): act[2 ks + hh] of point r), one k-step = 2 k
+// in ascending order inside the instruction and ascending k-steps through the accumulator.  A D tile holds row 8(q/4) + 4 hh + (q%4) in
+// register q of lane half hh; the OUTPUT neurons are free to permute (a neuron's own sum keeps its order), so row i of an m-tile carries
+// neuron 2(4(i/8) + i%4) + (i/4)%2: register q of lane half hh is then neuron 2q + hh -- after the ReLU, register q of a D tile IS the B
+// operand of k-step q of the next layer, in natural ascending k.  No lane movement, no LDS round trip, no permutation of any sum.
+//
+// The last layer needs one output (sigma; the geo features feed only the colour net): a 64-term chain per point, on the vector ALUs.  A
+// point's hidden values sit in two lanes (even k in lane r, odd k in lane r + 32); one v_permlane32_swap per register PAIR of the wave's
+// two point tiles hands lane l both parities of point l (lanes 0-31: tile 0, lanes 32-63: tile 1), and every lane runs the ascending chain
+// for its own point: 64 fma + 32 swaps per 64 points instead of 64 matrix instructions with one useful row.
+#include "mlp.h"
+
+namespace nrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SIG_WAVES = 8;                     // 2 per SIMD: one's vector work (ReLU, swaps, the last layer) under the other's matrix chain
+constexpr int SIG_BLOCK_PTS = 64 * SIG_WAVES;    // two 32-point tiles per wave
+
+// neuron carried by row i of an m-tile (see above)
+__host__ __device__ inline int sigma_row_neuron(int i) { return 2 * (4 * (i >> 3) + (i & 3)) + ((i >> 2) & 1); }
+
+// acc[pt][mt] = sum over KS k-steps; A fragments from LDS as [mt][ks / 4][lane][4] floats (one ds_read_b128 per four k-steps, shared by
+// both point tiles); bfn(pt, ks) yields the B operand
+template <int KS, class BFn>
+__device__ __forceinline__ void sigma_layer(const f32x4 *__restrict__ img, int lane, f32x16 (&acc)[2][2], BFn bfn)
+{
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+        for (int g = 0; g < KS / 4; g++) {
+            const f32x4 a4 = img[(mt * (KS / 4) + g) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ks = 4 * g + j;
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bfn(pt, ks), ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
+            }
+            // fence the scheduler: unfenced it hoists every ds_read_b128 of the layer to its top (96 VGPRs) and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[2][2])
+{
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[pt][mt][q] = fmaxf(acc[pt][mt][q], 0.0f);    // one v_max_f32 (this file is built with -fno-honor-nans); equals the oracle's
+                                                                                          // x < 0 ? 0 : x on every value (a -0 becomes +0: no sum can tell)
+}
+
+// feats: level-major [16][pstride], half2 (CuHashEmbedder: exactly the fp16 numbers the reference's kernel outputs, CuHashEmbedder.cu:95) or
+// float2 (HashEmbedder, fp32 features).  image: W0 [2][4][64][4] | (NL == 3: W1 [2][8][64][4]) | w_last [64] floats.
+template <int NL, bool F32IN>
+__global__ void __launch_bounds__(64 * SIG_WAVES)
+k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride, const uint8_t *__restrict__ keep, const float *__restrict__ image,
+                  float *__restrict__ sigma)
+{
+    constexpr int W0_F4 = 2 * 4 * 64, W1_F4 = NL == 3 ? 2 * 8 * 64 : 0;
+    __shared__ f32x4 wl[W0_F4 + W1_F4];
+    __shared__ float wlast[64];
+    for (int i = threadIdx.x; i < W0_F4 + W1_F4; i += blockDim.x) wl[i] = reinterpret_cast<const f32x4 *>(image)[i];
+    if (threadIdx.x < 64) wlast[threadIdx.x] = image[(W0_F4 + W1_F4) * 4 + threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t nblocks = (npts + SIG_BLOCK_PTS - 1) / SIG_BLOCK_PTS;
+    // raw operand words of one block iteration: level ks of point (pt, r); lane half hh consumes feature hh
+    auto load_inputs = [&](int64_t blk, uint32_t (&x)[2][16]) {
+        const int64_t p0 = blk * SIG_BLOCK_PTS + wave * 64;
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+            int64_t p = p0 + pt * 32 + r;
+            if (p >= npts) p = npts - 1;             // clamp loads; the store is guarded
+#pragma unroll
+            for (int ks = 0; ks < 16; ks++) {
+                if constexpr (F32IN) x[pt][ks] = reinterpret_cast<const uint32_t *>(feats)[((int64_t)ks * pstride + p) * 2 + hh];
+                else x[pt][ks] = reinterpret_cast<const uint32_t *>(feats)[(int64_t)ks * pstride + p];
+            }
+        }
+    };
+    uint32_t x[2][16];
+    if ((int64_t)blockIdx.x < nblocks) load_inputs(blockIdx.x, x);
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const bool more = blk + gridDim.x < nblocks;
+        f32x16 h0[2][2];
+        sigma_layer<16>(wl, lane, h0, [&](int pt, int ks) -> float {
+            if constexpr (F32IN) return __uint_as_float(x[pt][ks]);
+            else {
+                const uint32_t w = x[pt][ks];
+                const uint16_t bits = (uint16_t)(hh ? (w >> 16) : (w & 0xffffu));
+                _Float16 hv; __builtin_memcpy(&hv, &bits, 2);
+                return (float)hv;                    // exact
+            }
+        });
+        if (more) load_inputs(blk + gridDim.x, x);   // the next iteration's operands, into the registers layer 0 has just finished with: they land under the rest of the network
+        relu_tiles(h0);
+        // ---- last layer, output 0 only: lane l takes over point l of the wave's 64 ----
+        auto last = [&](const f32x16 (&hl)[2][2]) -> float {
+            float a = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    // vdst = tile-0 register, src = tile-1 register: lanes 32-63 of vdst <-> lanes 0-31 of src
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hl[0][t][q]), __float_as_uint(hl[1][t][q]), false, false);
+                    const float ev = __uint_as_float(sw[0]), od = __uint_as_float(sw[1]);     // k = 32t + 2q, 32t + 2q + 1 of this lane's point
+                    a = __builtin_fmaf(wlast[32 * t + 2 * q], ev, a);
+                    a = __builtin_fmaf(wlast[32 * t + 2 * q + 1], od, a);
+                }
+            }
+            return a;
+        };
+        float acc;
+        if constexpr (NL == 3) {
+            f32x16 h1[2][2];
+            sigma_layer<32>(wl + W0_F4, lane, h1, [&](int pt, int ks) -> float { return h0[pt][ks >> 4][ks & 15]; });
+            relu_tiles(h1);
+            acc = last(h1);
+        } else acc = last(h0);
+        const int64_t p = blk * SIG_BLOCK_PTS + wave * 64 + lane;
+        if (p < npts) sigma[p] = (keep && !keep[p]) ? 0.0f : acc;                               // NeRFRenderer.h:187-188
+    }
+}
+
+static bool sigma_f32_supported(const nrf_mlp_small_desc &d)
+{
+    return d.input_ch == 32 && d.hidden_dim == 64 && (d.num_layers == 2 || d.num_layers == 3);
+}
+
+int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->small;
+    if (!sigma_f32_supported(d)) return NRF_OK;
+    std::vector<float> img;
+    size_t off = 0;
+    for (int l = 0; l + 1 < d.num_layers; l++) {
+        const int in = l == 0 ? d.input_ch : d.hidden_dim, out = d.hidden_dim;
+        const float *w = hp.data() + off;
+        const int ks_count = in / 2;
+        for (int mt = 0; mt < 2; mt++)
+            for (int g = 0; g < ks_count / 4; g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 4; j++) {
+                        const int row = 32 * mt + sigma_row_neuron(lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+                        img.push_back(w[(size_t)row * in + k]);
+                    }
+        off += (size_t)in * out;
+    }
+    for (int k = 0; k < d.hidden_dim; k++) img.push_back(hp[off + k]);       // row 0 (sigma) of the last sigma-net layer [1 + geo][hidden]
+    const size_t bytes = img.size() * sizeof(float);
+    if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
+    if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));
+    m->packed_sigma_f32_bytes = bytes;
+    NRF_HIP(hipMemcpy(m->d_packed_sigma_f32, img.data(), bytes, hipMemcpyHostToDevice));
+    return NRF_OK;
+}
+
+int mlp_small_sigma_f32_available(const nrf_mlp *m) { return m && m->family == MLP_SMALL && m->d_packed_sigma_f32 != nullptr; }
+
+// sigma [p] = keep ? NeRFSmall sigma-net output 0 : 0, bit-identical to NRF_PREC_F32.  feats: level-major [16][pstride] half2, or float2 when f32_in.
+int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st)
+{
+    if (!mlp_small_sigma_f32_available(m)) { set_error("internal: fp32 matrix-core sigma image missing"); return NRF_ERR_UNSUPPORTED; }
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_SIGMA, st);
+    const int64_t nblocks = ceil_div(p, SIG_BLOCK_PTS);
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);          // persistent: one 8-wave workgroup per CU
+    const float *img = reinterpret_cast<const float *>(m->d_packed_sigma_f32);
+    const int nl = m->small.num_layers;
+#define NRF_GO(NL_, F_) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma)
+    if (nl == 3) { if (f32_in) NRF_GO(3, true); else NRF_GO(3, false); }
+    else { if (f32_in) NRF_GO(2, true); else NRF_GO(2, false); }
+#undef NRF_GO
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // namespace nrf

@@ -154,7 +154,10 @@ class NeRFRenderParams:               # NeRFRenderer.h:28-44 (same defaults)
     StochasticPreconditioningAlpha: float = 0.0
     # not in the reference: MLP arithmetic (L.NRF_PREC_F32 parity mode / L.NRF_PREC_F16_MFMA fast mode)
     Precision: int = L.NRF_PREC_F32
-    KeepIntermediates: bool = False
+    KeepIntermediates: object = False     # True: z / raw / weights of the coarse pass + z_fine in Extras; "depths": the same without raw_coarse
+    # not in the reference: how the coarse pass is evaluated when NImportance > 0 (L.NRF_COARSE_*, include/nerfpp_hip.h).  AUTO: with
+    # NRF_PREC_F16_SPLIT on the HashNeRF fast path, sigma net only in exact fp32 on the matrix cores -> the fine sample set of NRF_PREC_F32
+    CoarseMode: int = L.NRF_COARSE_AUTO
     # not in the reference (it draws from torch's global RNG): seed of the counter-based draws of the stochastic branches
     Seed: int = 0
 
@@ -237,7 +240,7 @@ class NeRFRenderer:
     # ---- public surface ----
     def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
                    raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True,
-                   precision=L.NRF_PREC_F32, keep_intermediates=False, seed=0, ray_base=0):
+                   precision=L.NRF_PREC_F32, keep_intermediates=False, seed=0, ray_base=0, coarse_mode=L.NRF_COARSE_AUTO):
         """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11].  The stochastic branches (perturb, a defined cone_angle,
         raw_noise_std, stochastic preconditioning) draw from the library's counter RNG keyed by (seed, ray_base + ray, sample)."""
         rays = _dev_f32(ray_batch)
@@ -256,6 +259,7 @@ class NeRFRenderer:
             rp.has_bbox = 1
             rp.bbox = (C.c_float * 6)(*_host_f32(bounding_box, 6).tolist())
         rp.seed, rp.ray_base = int(seed), int(ray_base)
+        rp.coarse_mode = int(coarse_mode)
         res = NeRFRenderResult()
         so = sf if ni > 0 else s
         o = res.Outputs
@@ -267,9 +271,12 @@ class NeRFRenderer:
         ro = L.RenderOutputs(_ptr(o.RGBMap), _ptr(o.DispMap), _ptr(o.AccMap), _ptr(o.DepthMap), _ptr(o.Weights), _ptr(res.Raw), None, None, None, None)
         if keep_intermediates:
             ex = res.Extras
-            ex["z_coarse"] = torch.empty((n, s), device=dev); ex["raw_coarse"] = torch.empty((n, s, c), device=dev)
+            ex["z_coarse"] = torch.empty((n, s), device=dev)
             ex["weights_coarse"] = torch.empty((n, s), device=dev)
-            ro.d_z_coarse, ro.d_raw_coarse, ro.d_weights_coarse = _ptr(ex["z_coarse"]), _ptr(ex["raw_coarse"]), _ptr(ex["weights_coarse"])
+            ro.d_z_coarse, ro.d_weights_coarse = _ptr(ex["z_coarse"]), _ptr(ex["weights_coarse"])
+            if keep_intermediates != "depths":       # asking for the coarse raw forces the whole network on the coarse pass (nrf_render_params.coarse_mode)
+                ex["raw_coarse"] = torch.empty((n, s, c), device=dev)
+                ro.d_raw_coarse = _ptr(ex["raw_coarse"])
             if ni > 0:
                 ex["z_fine"] = torch.empty((n, sf), device=dev)
                 ro.d_z_fine = _ptr(ex["z_fine"])
@@ -321,7 +328,7 @@ class NeRFRenderer:
         all_ret = self.BatchifyRays(rays_, None if p.ThinRay else cone_angle, p.NSamples, p.Chunk, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
                                     perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
                                     stochastic_preconditioning_alpha=p.StochasticPreconditioningAlpha, bounding_box=p.BoundingBox,
-                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates, seed=p.Seed,
+                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates, seed=p.Seed, coarse_mode=p.CoarseMode,
                                     ray_base=row0 * w if c2w is not None else 0)
         out = all_ret.Outputs
         if out.RGBMap is not None:

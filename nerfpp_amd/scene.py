@@ -103,7 +103,7 @@ def synth_hash_table(n_levels, log2_t, n_feat, base_seed=5000, amp=0.5):
 
 
 def make_hash_scene(mode="cu", n_levels=16, n_feat=2, log2_t=19, base=16, finest=512, sh_degree=4, num_layers_color=4, seed=5000,
-                    table_amp=0.5, sigma_scale=30.0, bbox=LEGO_BBOX):
+                    table_amp=0.5, sigma_scale=30.0, bbox=LEGO_BBOX, num_layers=3):
     """HashNeRF (BASELINE config 2/3): hash grid + SH + NeRFSmall.  mode 'cu' = CuHashEmbedder + CuSHEncoder (the named
     plugin), 'ngp' = HashEmbedder + SHEncoder (the LibTorch CPU twin the oracle/_ref pins)."""
     table = synth_hash_table(n_levels, log2_t, n_feat, seed, table_amp)
@@ -118,10 +118,10 @@ def make_hash_scene(mode="cu", n_levels=16, n_feat=2, log2_t=19, base=16, finest
         dirs = SHEncoder("embeddirs", 3, sh_degree)
     emb.set_table(table)
     in_ch, in_views = n_levels * n_feat, sh_degree * sh_degree
-    params = synth_linear_stack(small_shapes(in_ch, in_views, 3, 64, 15, num_layers_color, 64), seed + 1000, 1.6, 0.0,
-                                {"sigma_net_2": sigma_scale})
+    params = synth_linear_stack(small_shapes(in_ch, in_views, num_layers, 64, 15, num_layers_color, 64), seed + 1000, 1.6, 0.0,
+                                {f"sigma_net_{num_layers - 1}": sigma_scale})
     blob = np.concatenate([a.reshape(-1) for _, a in params])
-    mlp = NeRFSmall(3, 64, 15, num_layers_color, 64, False, 3, 64, in_ch, in_views, "model", params=blob)
+    mlp = NeRFSmall(num_layers, 64, 15, num_layers_color, 64, False, 3, 64, in_ch, in_views, "model", params=blob)
     return dict(renderer=NeRFRenderer(emb, dirs, mlp), embedder=emb, embeddirs=dirs, mlp=mlp, table=table, mlp_blob=blob, primes=primes,
                 bbox=np.asarray(bbox, np.float32), mode=mode, cfg=dict(n_levels=n_levels, n_feat=n_feat, log2_t=log2_t, base=base, finest=finest,
                                                                       sh_degree=sh_degree, num_layers_color=num_layers_color))

@@ -731,6 +731,62 @@ def test_split_precision_render_matches_parity_mode(api, O):
     assert ps_split > 70 and ps_split > ps_f16 + 20, (ps_split, ps_f16)
 
 
+@pytest.mark.parametrize("mode", ["cu", "ngp"])
+def test_exact_coarse_sigma_pass_reproduces_the_parity_sample_set(api, mode):
+    """The timed precision (NRF_PREC_F16_SPLIT, coarse pass = sigma net alone in exact fp32 on the matrix cores, sigma_small_f32.hip) against
+    the bit-exact NRF_PREC_F32 mode on a 16-row tile of the 800x800 frame (12 800 rays, 3.3 M network evaluations):
+    coarse weights and the fine sample set z_fine are IDENTICAL (bit for bit), and every pixel value is within the north star's 1e-4 --
+    strictly, not for a fraction of them."""
+    sc = api.S.make_hash_scene(mode=mode)
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    def render(prec, keep, **kw):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=4096, precision=prec, KeepIntermediates=keep, **kw)
+        return sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=392, rows=16)
+    a = render(api.L.NRF_PREC_F32, True)
+    b = render(api.L.NRF_PREC_F16_SPLIT, "depths")
+    assert "raw_coarse" not in b.Extras
+    assert_exact(host(b.Extras["z_coarse"]), host(a.Extras["z_coarse"]), "z_coarse")
+    assert_exact(host(b.Extras["weights_coarse"]), host(a.Extras["weights_coarse"]), "coarse weights: fp32 MFMA sigma == NRF_PREC_F32")
+    assert_exact(host(b.Extras["z_fine"]), host(a.Extras["z_fine"]), "fine sample set")
+    rgb_a, rgb_b = host(a.Outputs.RGBMap).reshape(-1, 3), host(b.Outputs.RGBMap).reshape(-1, 3)
+    d = np.abs(rgb_b - rgb_a)
+    assert d.max() < 1e-4 and np.median(d) < 1e-5, (d.max(), np.median(d))
+    for k in ("DepthMap", "AccMap"):
+        dd = np.abs(host(getattr(b.Outputs, k)).reshape(-1) - host(getattr(a.Outputs, k)).reshape(-1))
+        assert dd.max() < 1e-4, (k, dd.max())
+    # the plain fp16 mode can ask for the same coarse pass
+    c = render(api.L.NRF_PREC_F16_MFMA, "depths", CoarseMode=api.L.NRF_COARSE_SIGMA_F32)
+    assert_exact(host(c.Extras["z_fine"]), host(a.Extras["z_fine"]), "fine sample set, fp16 fine pass")
+    # NRF_COARSE_FULL is the whole network in the chosen precision (what a caller asking for raw_coarse gets): close, not identical
+    e = render(api.L.NRF_PREC_F16_SPLIT, "depths", CoarseMode=api.L.NRF_COARSE_FULL)
+    we, wa = host(e.Extras["weights_coarse"]), host(a.Extras["weights_coarse"])
+    assert np.abs(we - wa).max() < 1e-4 and (we != wa).any()
+    # stochastic branches (jitter + SamplePDF(det=false), cone rays, sigma noise, preconditioning) go through the same coarse pass
+    kw = dict(Perturb=1.0, RawNoiseStd=0.5, ThinRay=False, StochasticPreconditioningAlpha=0.01, Seed=77)
+    sa = render(api.L.NRF_PREC_F32, True, **kw)
+    sb = render(api.L.NRF_PREC_F16_SPLIT, "depths", **kw)
+    assert_exact(host(sb.Extras["weights_coarse"]), host(sa.Extras["weights_coarse"]), "stochastic: coarse weights")
+    assert_exact(host(sb.Extras["z_fine"]), host(sa.Extras["z_fine"]), "stochastic: fine sample set")
+
+
+def test_sigma_f32_kernel_shapes_and_ragged_sizes(api):
+    """sigma_small_f32.hip over every built shape (2 or 3 sigma layers; fp16 / fp32 features) and ragged point counts (1 ray, a non-multiple of the
+    512-point block, one block + 1): coarse weights == NRF_PREC_F32, bit for bit."""
+    for mode, nl in (("cu", 3), ("cu", 2), ("ngp", 2), ("ngp", 3)):
+        sc = api.S.make_hash_scene(mode=mode, log2_t=14, num_layers=nl)
+        K = api.S.lego_K(40, 40); c2w = api.S.pose_spherical(10.0, -30.0, 4.0)
+        for rows, cols, ns in ((1, 1, 64), (3, 7, 64), (1, 9, 57), (5, 40, 64)):
+            out = {}
+            for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_SPLIT):
+                rp = api.S.lego_render_params(sc["bbox"], ns, 32, 4096, prec, KeepIntermediates="depths" if prec else True)
+                o, d, _ = api.R.GetRays(40, 40, K, c2w, row0=17, rows=rows)
+                out[prec] = sc["renderer"].Render(0, 0, None, rp, rays=(o.reshape(-1, 3)[:rows * cols].contiguous(), d.reshape(-1, 3)[:rows * cols].contiguous(), None))
+            a, b = out[api.L.NRF_PREC_F32], out[api.L.NRF_PREC_F16_SPLIT]
+            assert host(a.Extras["weights_coarse"]).max() > 0
+            assert_exact(host(b.Extras["weights_coarse"]), host(a.Extras["weights_coarse"]), f"{mode} nl={nl} n={rows * cols} s={ns}")
+            assert_exact(host(b.Extras["z_fine"]), host(a.Extras["z_fine"]), f"{mode} nl={nl} n={rows * cols} s={ns} z_fine")
+
+
 def test_image_post_bit_exact_vs_reference(api, O):
     """N4: the 8-bit buffers RenderPath hands to cv::imwrite (NeRFExecutor.h:690-700)."""
     g = load_golden("post")
