@@ -416,6 +416,39 @@ NRF_API int nrf_normalize_depth(const float *d_depth, int64_t n, float near_, fl
 /* u8 = (uint8)clamp(x * 255, 0, 255): what cv::imwrite receives for RGB / disparity / normalised depth. */
 NRF_API int nrf_to_u8(const float *d_x, int64_t n, uint8_t *d_out, void *stream);
 
+/* The render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627), host only: with render_factor != 0 the frame is rendered
+ * downsampled, h1 = (int)(h / render_factor), w1 = (int)(w / render_factor) (int / float -> float -> int, as the reference's
+ * `h = h / rparams.RenderFactor` does with its float field) and fx, fy, cx, cy of K (host [9], row-major) are divided by it in fp32;
+ * render_factor == 0 copies.  NeRFExecutor::RenderPath (:657-662) scales h, w and a local focal but hands Render() the ORIGINAL k --
+ * callers that mirror RenderPath pass k unchanged and only use h1 / w1 (K1 may be NULL). */
+NRF_API int nrf_render_view_dims(int h, int w, const float *K, float render_factor, int *h1, int *w1, float *K1);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: whole-image render batches partitioned by ray into contiguous row tiles, one process per GPU, the model replicated
+ * read-only; per-tile pixels return to every rank with ONE RCCL collective per step over xGMI (north_star).  The reference
+ * is single-GPU (no counterpart).  RCCL is resolved with dlopen at first use -- the copy already mapped into the process (LibTorch's)
+ * if there is one -- so this library has no link-time RCCL dependency; without RCCL the nrf_comm_* calls return NRF_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------- */
+/* Rank `rank` of `world` renders image rows [row0, row0 + rows): contiguous, the first h % world ranks one row taller.  Host only. */
+NRF_API int nrf_tile_partition(int h, int world, int rank, int *row0, int *rows);
+
+#define NRF_COMM_ID_BYTES 128
+typedef struct nrf_comm nrf_comm;
+/* Rendezvous as in NCCL: rank 0 calls nrf_comm_unique_id (id_out: host [NRF_COMM_ID_BYTES]) and hands the bytes to every rank by any
+ * out-of-band means (a file, a socket, torch.distributed, MPI); every rank then calls nrf_comm_create on ITS device
+ * (hipSetDevice first; blocks until all `world` ranks arrive).  nrf_comm_wrap adopts a live ncclComm_t the host already owns
+ * (it is not destroyed by nrf_comm_destroy). */
+NRF_API int nrf_comm_unique_id(void *id_out);
+NRF_API int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out);
+NRF_API int nrf_comm_wrap(void *nccl_comm, nrf_comm **out);
+NRF_API void nrf_comm_destroy(nrf_comm *c);
+NRF_API int nrf_comm_world(const nrf_comm *c);
+NRF_API int nrf_comm_rank(const nrf_comm *c);
+/* d_tiles: this rank's [frames, rows_rank, w, c] fp32 tiles of `frames` images (rows_rank from nrf_tile_partition);
+ * d_frames: [frames, h, w, c] on every rank.  One fused launch on `stream` (ncclAllGather per frame when h % world == 0, grouped
+ * ncclBroadcast per tile otherwise); asynchronous like every other call.  d_tiles and d_frames must not overlap. */
+NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int h, int w, int c_channels, float *d_frames, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)
  * ------------------------------------------------------------------------------------------- */

@@ -23,8 +23,12 @@
 #include <torch/torch.h>
 #include <c10/hip/HIPStream.h>
 
+#include <chrono>
+#include <cstdio>
+#include <fstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nerfpp_hip.h"
@@ -156,6 +160,59 @@ public:
 TORCH_MODULE(HipHashEmbedder);
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Multi-GPU: one process per GPU, frames partitioned into contiguous row tiles (nrf_tile_partition), one RCCL all-gather per
+// frame over xGMI (nrf_allgather_tiles).  No reference counterpart (the reference is single-GPU).
+// ---------------------------------------------------------------------------------------------------------------------
+class TileComm {
+	nrf_comm *Comm = nullptr;
+	int World = 1, Rank = 0;
+public:
+	/// Rendezvous through the filesystem (launchers that give every rank WORLD_SIZE / RANK and a shared directory need nothing else): rank 0 asks the
+	/// library for the RCCL unique id and publishes it at `id_path` (written to a temporary name, then renamed: readers never see a partial file); the other
+	/// ranks wait for it.  Call after hipSetDevice / c10::hip::set_device: the communicator binds to the calling thread's current device.
+	TileComm(int world, int rank, const std::string &id_path, double timeout_s = 120.0) : World(world), Rank(rank)
+	{
+		unsigned char id[NRF_COMM_ID_BYTES];
+		if (rank == 0) {
+			check(nrf_comm_unique_id(id), "nrf_comm_unique_id");
+			if (world > 1) {
+				const std::string tmp = id_path + ".tmp";
+				{ std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id), sizeof(id)); }
+				if (std::rename(tmp.c_str(), id_path.c_str()) != 0) throw std::runtime_error("TileComm: cannot publish the communicator id at " + id_path);
+			}
+		} else {
+			const auto t0 = std::chrono::steady_clock::now();
+			for (;;) {
+				std::ifstream f(id_path, std::ios::binary);
+				if (f && f.read(reinterpret_cast<char *>(id), sizeof(id)) && f.gcount() == (std::streamsize)sizeof(id)) break;
+				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) throw std::runtime_error("TileComm: no communicator id at " + id_path);
+				std::this_thread::sleep_for(std::chrono::milliseconds(20));
+			}
+		}
+		check(nrf_comm_create(id, world, rank, &Comm), "nrf_comm_create");
+	}
+	/// Adopt a live ncclComm_t the host already owns (not destroyed here).
+	explicit TileComm(void *nccl_comm) { check(nrf_comm_wrap(nccl_comm, &Comm), "nrf_comm_wrap"); World = nrf_comm_world(Comm); Rank = nrf_comm_rank(Comm); }
+	TileComm(const TileComm &) = delete;
+	TileComm &operator=(const TileComm &) = delete;
+	~TileComm() { nrf_comm_destroy(Comm); }
+
+	int GetWorld() const { return World; }
+	int GetRank() const { return Rank; }
+	/// rows [row0, row0 + rows) of an h-row frame belong to this rank
+	std::pair<int, int> Rows(int h) const { int row0 = 0, rows = 0; check(nrf_tile_partition(h, World, Rank, &row0, &rows), "nrf_tile_partition"); return {row0, rows}; }
+	/// tiles [F, rows_rank, W, C] (this rank's rows of F frames) -> [F, h, W, C] on every rank; one fused RCCL launch on the current stream
+	torch::Tensor AllGatherFrames(torch::Tensor tiles, int h) const
+	{
+		tiles = dev_f32(tiles);
+		TORCH_CHECK(tiles.dim() == 4 && tiles.size(1) == Rows(h).second, "AllGatherFrames: tiles must be [frames, rows of this rank, w, c]");
+		auto out = torch::empty({tiles.size(0), (int64_t)h, tiles.size(2), tiles.size(3)}, tiles.options());
+		check(nrf_allgather_tiles(Comm, tiles.data_ptr<float>(), (int)tiles.size(0), h, (int)tiles.size(2), (int)tiles.size(3), out.data_ptr<float>(), current_stream()), "nrf_allgather_tiles");
+		return out;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
 // MLP handle built from a reference module's parameters (named_parameters() order == the blob order of nerfpp_hip.h)
 // ---------------------------------------------------------------------------------------------------------------------
 template <class TModule>
@@ -259,13 +316,60 @@ public:
 		torch::Tensor c2w = torch::Tensor(), torch::Tensor c2w_staticcam = torch::Tensor()) override
 	{
 		if (render_params.Ndc || (c2w_staticcam.defined() && c2w_staticcam.numel() != 0)) return Base::Render(h, w, k, render_params, rays, c2w, c2w_staticcam);
+		return RenderRows(h, w, k, render_params, rays, c2w, 0, h);
+	}
+
+	/// Rows [row0, row0 + rows) of the h x w frame seen from c2w: one rank's share of a frame (multi-GPU row tiles).  Ray r of the tile is pixel
+	/// (row0 + r / w, r % w); the counter-based draws of the stochastic branches are keyed by the ray's position in the WHOLE frame, so a tile equals
+	/// the corresponding slice of the full render bit for bit.  Outputs are [rows, w, ...]; Near / Far are the tile's.
+	NeRFRenderResult RenderTile(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params, torch::Tensor c2w, const int row0, const int rows)
+	{
+		TORCH_CHECK(!render_params.Ndc, "RenderTile: NDC scenes are rendered whole (Render)");
+		TORCH_CHECK(row0 >= 0 && rows >= 0 && row0 + rows <= h, "RenderTile: rows outside the frame");
+		return RenderRows(h, w, k, render_params, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w, row0, rows);
+	}
+
+	/// One frame over all ranks of `comm`: this rank renders its row tile, ONE all-gather (rgb, disparity, accumulation, depth packed per pixel) returns the
+	/// whole frame to every rank.  Near / Far are the whole frame's (rays are cheap: every rank generates the full ray batch for that reduction).
+	NeRFRenderResult RenderSharded(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params, torch::Tensor c2w, const TileComm &comm)
+	{
+		const auto [row0, rows] = comm.Rows(h);
+		NeRFRenderParams rp = render_params;
+		rp.ReturnRaw = false; rp.ReturnWeights = false;                 // per-sample tensors stay on the rank that made them
+		NeRFRenderResult tile = RenderTile(h, w, k, rp, c2w, row0, rows);
+		auto &o = tile.Outputs;
+		auto packed = torch::cat({o.RGBMap.reshape({rows, w, 3}), o.DispMap.reshape({rows, w, 1}), o.AccMap.reshape({rows, w, 1}), o.DepthMap.reshape({rows, w, 1})}, -1).unsqueeze(0);
+		auto frame = comm.AllGatherFrames(packed, h).squeeze(0);        // [h, w, 6]
+		using torch::indexing::Slice;
+		NeRFRenderResult res;
+		res.Outputs.RGBMap = frame.index({Slice(), Slice(), Slice(0, 3)}).contiguous();
+		res.Outputs.DispMap = frame.index({Slice(), Slice(), 3}).contiguous();
+		res.Outputs.AccMap = frame.index({Slice(), Slice(), 4}).contiguous().reshape({-1});
+		res.Outputs.DepthMap = frame.index({Slice(), Slice(), 5}).contiguous();
+		// Near / Far of the whole frame (NeRFRenderer.h:602-603)
+		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
+		auto K = host_floats(k), M = host_floats(c2w.index({Slice(torch::indexing::None, 3), Slice(torch::indexing::None, 4)}));
+		auto ro = torch::empty({(int64_t)h * w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), rd = torch::empty_like(ro);
+		check(nrf_get_rays(h, w, K.data(), M.data(), 0, h, ro.data_ptr<float>(), rd.data_ptr<float>(), nullptr, current_stream()), "nrf_get_rays");
+		auto bb = host_floats(render_params.BoundingBox);
+		auto rays_ = torch::empty({(int64_t)h * w, 8}, ro.options());
+		check(nrf_pack_rays(ro.data_ptr<float>(), rd.data_ptr<float>(), bb.data(), (int64_t)h * w, 0, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
+		check(nrf_near_far_range(rays_.data_ptr<float>(), (int64_t)h * w, 8, &res.Near, &res.Far, current_stream()), "nrf_near_far_range");
+		return res;
+	}
+
+private:
+	NeRFRenderResult RenderRows(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params,
+		std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays, torch::Tensor c2w, const int row0, const int rows)
+	{
 		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
 		torch::Tensor rays_o, rays_d, cone_angle;
-		if (c2w.defined() && c2w.numel() != 0) {
+		const bool from_pose = c2w.defined() && c2w.numel() != 0;
+		if (from_pose) {
 			auto K = host_floats(k), M = host_floats(c2w.index({torch::indexing::Slice(torch::indexing::None, 3), torch::indexing::Slice(torch::indexing::None, 4)}));
-			rays_o = torch::empty({h, w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)); rays_d = torch::empty_like(rays_o);
+			rays_o = torch::empty({rows, w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)); rays_d = torch::empty_like(rays_o);
 			float cone = 0.f;
-			check(nrf_get_rays(h, w, K.data(), M.data(), 0, h, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), &cone, current_stream()), "nrf_get_rays");
+			check(nrf_get_rays(h, w, K.data(), M.data(), row0, rows, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), &cone, current_stream()), "nrf_get_rays");
 			cone_angle = torch::tensor(cone);
 		} else {
 			std::tie(rays_o, rays_d, cone_angle) = rays;
@@ -278,7 +382,7 @@ public:
 		auto bb = host_floats(render_params.BoundingBox);
 		auto rays_ = torch::empty({n, stride}, o.options());
 		check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, render_params.UseViewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
-		RayCursor = 0;
+		RayCursor = from_pose ? (int64_t)row0 * w : 0;
 		NeRFRenderResult all_ret = this->BatchifyRays(rays_, render_params.ThinRay ? torch::Tensor() : cone_angle, render_params.NSamples, render_params.Chunk,
 			render_params.ReturnRaw, render_params.LinDisp, render_params.Perturb, render_params.NImportance, render_params.WhiteBkgr, render_params.RawNoiseStd,
 			render_params.StochasticPreconditioningAlpha, render_params.BoundingBox, render_params.ReturnWeights);
@@ -291,6 +395,7 @@ public:
 		return all_ret;
 	}
 
+public:
 	/// NeRFRenderer.h:366-459, one fused call per chunk of packed rays
 	NeRFRenderResult RenderRays(torch::Tensor ray_batch, torch::Tensor cone_angle, const int n_samples, const bool return_raw = false,
 		const bool lin_disp = false, const float perturb = 0.f, const int n_importance = 0, const bool white_bkgr = false,

@@ -70,8 +70,11 @@ SYMBOLS = [
     "nrf_normalize_depth", "nrf_to_u8",
     "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_hash_encode_lm_f16", "nrf_lerf_sigma_lm", "nrf_lerf_render_embedding_lm", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_mlp_set_params",
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
+    "nrf_render_view_dims",
+    "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",
     "nrf_profile_enable", "nrf_profile_read",
 ]
+NRF_COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -1,0 +1,187 @@
+// comm.hip -- multi-GPU sharding of the render path behind the C ABI (SURVEY 8e / 8b `nrf_allgather_tiles`).
+//
+// Whole-image render batches are partitioned by ray into contiguous ROW TILES (rank r of R renders rows [row0_r, row0_r + rows_r) of the
+// frame; the row-major pixel <-> ray mapping of RayUtils.h:5-21 is untouched), the model is replicated read-only, and ONE collective per
+// step returns the per-tile pixels to every rank: ncclAllGather (RCCL over xGMI) straight into the frame when the tiles are equal, a
+// grouped set of ncclBroadcast (the all-gather-v idiom, still one fused launch) when H does not divide by the world size.  Payload:
+// 800 x 800 x 3 fp32 = 7.7 MB per frame over all ranks -- latency-bound on the 7 x 153 GB/s point-to-point links.
+// The reference is single-process / single-GPU: no counterpart.
+//
+// RCCL is resolved at first use with dlopen (the copy already mapped into the process -- LibTorch's -- if there is one, so that a
+// communicator handed over by the host and the calls made here belong to the same library), so libnerfpp_hip.so itself carries no RCCL
+// dependency and loads on a box without it.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+struct nrf_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    bool owned = false;
+};
+
+namespace nrf {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static Rccl g_rccl;
+static std::once_flag g_rccl_once;
+static char g_rccl_err[256] = "";
+
+static void rccl_load()
+{
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the host process already uses
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { snprintf(g_rccl_err, sizeof(g_rccl_err), "RCCL not found: %s", dlerror()); return; }
+    Rccl r;
+    r.handle = h;
+    bool ok = true;
+#define NRF_SYM(field, name) do { r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name)); if (!r.field) { ok = false; snprintf(g_rccl_err, sizeof(g_rccl_err), "RCCL lacks %s", name); } } while (0)
+    NRF_SYM(GetUniqueId, "ncclGetUniqueId"); NRF_SYM(CommInitRank, "ncclCommInitRank"); NRF_SYM(CommDestroy, "ncclCommDestroy");
+    NRF_SYM(CommCount, "ncclCommCount"); NRF_SYM(CommUserRank, "ncclCommUserRank"); NRF_SYM(AllGather, "ncclAllGather");
+    NRF_SYM(Broadcast, "ncclBroadcast"); NRF_SYM(GroupStart, "ncclGroupStart"); NRF_SYM(GroupEnd, "ncclGroupEnd");
+    NRF_SYM(GetErrorString, "ncclGetErrorString");
+#undef NRF_SYM
+    if (ok) g_rccl = r;
+}
+
+static const Rccl *rccl()
+{
+    std::call_once(g_rccl_once, rccl_load);
+    if (!g_rccl.handle) { set_error("%s", g_rccl_err); return nullptr; }
+    return &g_rccl;
+}
+
+#define NRF_NCCL(R, call)                                                                                \
+    do {                                                                                                 \
+        ncclResult_t e_ = (call);                                                                        \
+        if (e_ != ncclSuccess) {                                                                         \
+            ::nrf::set_error("%s failed: %s (%s:%d)", #call, (R)->GetErrorString(e_), __FILE__, __LINE__); \
+            return NRF_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+static void partition(int h, int world, int rank, int *row0, int *rows)
+{
+    const int base = h / world, rem = h % world;            // the first `rem` ranks take one row more
+    *rows = base + (rank < rem ? 1 : 0);
+    *row0 = rank * base + (rank < rem ? rank : rem);
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_tile_partition(int h, int world, int rank, int *row0, int *rows)
+{
+    NRF_CHECK_ARG(row0 && rows, "nrf_tile_partition: null pointer");
+    NRF_CHECK_ARG(h >= 0 && world >= 1 && rank >= 0 && rank < world, "nrf_tile_partition: need h >= 0 and 0 <= rank < world (h %d, world %d, rank %d)", h, world, rank);
+    partition(h, world, rank, row0, rows);
+    return NRF_OK;
+}
+
+int nrf_comm_unique_id(void *id_out)
+{
+    NRF_CHECK_ARG(id_out, "nrf_comm_unique_id: null pointer");
+    const Rccl *R = rccl();
+    if (!R) return NRF_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    NRF_NCCL(R, R->GetUniqueId(&id));
+    static_assert(sizeof(id) == NRF_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return NRF_OK;
+}
+
+int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out)
+{
+    NRF_CHECK_ARG(id && out, "nrf_comm_create: null pointer");
+    NRF_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "nrf_comm_create: need 0 <= rank < world (world %d, rank %d)", world, rank);
+    const Rccl *R = rccl();
+    if (!R) return NRF_ERR_UNSUPPORTED;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t c = nullptr;
+    NRF_NCCL(R, R->CommInitRank(&c, world, uid, rank));     // on the calling thread's current HIP device; blocks until all ranks arrive
+    nrf_comm *cm = new nrf_comm();
+    cm->comm = c; cm->world = world; cm->rank = rank; cm->owned = true;
+    *out = cm;
+    return NRF_OK;
+}
+
+int nrf_comm_wrap(void *nccl_comm, nrf_comm **out)
+{
+    NRF_CHECK_ARG(nccl_comm && out, "nrf_comm_wrap: null pointer");
+    const Rccl *R = rccl();
+    if (!R) return NRF_ERR_UNSUPPORTED;
+    nrf_comm *cm = new nrf_comm();
+    cm->comm = static_cast<ncclComm_t>(nccl_comm);
+    ncclResult_t e1 = R->CommCount(cm->comm, &cm->world), e2 = R->CommUserRank(cm->comm, &cm->rank);
+    if (e1 != ncclSuccess || e2 != ncclSuccess) { delete cm; set_error("nrf_comm_wrap: not a live ncclComm_t of the RCCL mapped into this process"); return NRF_ERR_INVALID_ARG; }
+    *out = cm;
+    return NRF_OK;
+}
+
+void nrf_comm_destroy(nrf_comm *c)
+{
+    if (!c) return;
+    if (c->owned && c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+int nrf_comm_world(const nrf_comm *c) { return c ? c->world : 0; }
+int nrf_comm_rank(const nrf_comm *c) { return c ? c->rank : -1; }
+
+int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int h, int w, int ch, float *d_frames, void *stream)
+{
+    NRF_CHECK_ARG(c && c->comm, "nrf_allgather_tiles: null communicator");
+    NRF_CHECK_ARG(frames >= 0 && h >= 0 && w >= 0 && ch >= 1, "nrf_allgather_tiles: bad sizes");
+    if (frames == 0 || h == 0 || w == 0) return NRF_OK;
+    NRF_CHECK_ARG(d_tiles && d_frames, "nrf_allgather_tiles: null pointer");
+    const Rccl *R = rccl();
+    if (!R) return NRF_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    int row0, rows;
+    partition(h, c->world, c->rank, &row0, &rows);
+    const size_t px = (size_t)w * ch, tile = (size_t)rows * px, frame = (size_t)h * px;
+    const bool even = (h % c->world) == 0;
+    // one fused launch for all frames of the step (ncclGroupStart / End aggregates the operations)
+    NRF_NCCL(R, R->GroupStart());
+    for (int f = 0; f < frames; f++) {
+        const float *src = d_tiles + (size_t)f * tile;
+        float *dst = d_frames + (size_t)f * frame;
+        if (even) {
+            NRF_NCCL(R, R->AllGather(src, dst, tile, ncclFloat, c->comm, st));
+        } else {
+            for (int r = 0; r < c->world; r++) {
+                int r0, rr;
+                partition(h, c->world, r, &r0, &rr);
+                if (rr == 0) continue;
+                NRF_NCCL(R, R->Broadcast(src, dst + (size_t)r0 * px, (size_t)rr * px, ncclFloat, r, c->comm, st));   // sendbuff is read on the root only
+            }
+        }
+    }
+    NRF_NCCL(R, R->GroupEnd());
+    return NRF_OK;
+}
+
+}  // extern "C"

@@ -304,6 +304,21 @@ int nrf_precrop_bounds(int h, int w, int iter, int precrop_iters, float precrop_
     return NRF_OK;
 }
 
+// the render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627): h, w and K's fx, fy, cx, cy divided by the (float) factor
+int nrf_render_view_dims(int h, int w, const float *K, float render_factor, int *h1, int *w1, float *K1)
+{
+    NRF_CHECK_ARG(h1 && w1 && h >= 0 && w >= 0 && render_factor >= 0.0f, "nrf_render_view_dims: bad argument");
+    NRF_CHECK_ARG(K || !K1, "nrf_render_view_dims: K1 wanted but K is NULL");
+    if (K1) for (int i = 0; i < 9; i++) K1[i] = K[i];
+    *h1 = h; *w1 = w;
+    if (render_factor != 0.0f) {
+        *h1 = (int)((float)h / render_factor);              // int = int / float, as `h = h / rparams.RenderFactor`
+        *w1 = (int)((float)w / render_factor);
+        if (K1) { K1[0] = K[0] / render_factor; K1[4] = K[4] / render_factor; K1[2] = K[2] / render_factor; K1[5] = K[5] / render_factor; }
+    }
+    return NRF_OK;
+}
+
 int nrf_rand_pixels(uint64_t seed, int64_t iter, int h_start, int h_end, int w_start, int w_end, int64_t n, int64_t *d_rand_h, int64_t *d_rand_w, void *stream)
 {
     NRF_CHECK_ARG(d_rand_h && d_rand_w && n >= 0 && iter >= 0 && h_end >= h_start && w_end >= w_start, "nrf_rand_pixels: bad argument");

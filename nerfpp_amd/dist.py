@@ -7,17 +7,28 @@ Row-contiguous tiles keep the reference's row-major pixel <-> ray index mapping 
 r of tile t is pixel (row0_t + r // W, r % W).  The payload is tiny (800x800x3 fp32 = 7.7 MB per frame across all ranks),
 so the collective is latency-bound; it is issued once per step for all frames of the step, not per chunk.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
+
+
+def tile_partition(h, world, rank):
+    """(row0, rows) of rank's contiguous row tile: nrf_tile_partition, the one definition both hosts (C++ adapter, this mirror) use."""
+    r0, rr = C.c_int(0), C.c_int(0)
+    L.check(L.lib().nrf_tile_partition(int(h), int(world), int(rank), C.byref(r0), C.byref(rr)))
+    return r0.value, rr.value
 
 
 class TileShard:
     def __init__(self, h, w, rank=0, world=1, force_collective=False):
         self.h, self.w, self.rank, self.world = h, w, rank, world
         self.force_collective = force_collective
-        base, rem = divmod(h, world)
-        self.rows_of = [base + (1 if r < rem else 0) for r in range(world)]
-        self.row0_of = [sum(self.rows_of[:r]) for r in range(world)]
+        parts = [tile_partition(h, world, r) for r in range(world)]
+        self.row0_of = [p[0] for p in parts]
+        self.rows_of = [p[1] for p in parts]
         self.rows, self.row0 = self.rows_of[rank], self.row0_of[rank]
         self.max_rows = max(self.rows_of)
 
@@ -37,6 +48,43 @@ class TileShard:
         out = out.view((self.world, f) + tuple(local.shape[1:]))
         parts = [out[r, :, :self.rows_of[r]] for r in range(self.world)]
         return torch.cat(parts, 1)                                                        # [F, H, W, C]
+
+
+class TileComm:
+    """The collective behind the C ABI (nrf_comm_* / nrf_allgather_tiles, include/nerfpp_hip.h): what the C++ / LibTorch host calls.  The RCCL unique id is
+    created on rank 0 by the library and handed to the other ranks through torch.distributed (any backend; a file or a socket serves a host without it)."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        self.rank, self.world = int(rank), int(world)
+        buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES)()
+        if self.rank == 0:
+            L.check(L.lib().nrf_comm_unique_id(buf))
+        if self.world > 1:
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES).from_buffer_copy(box[0])
+        self._c = C.c_void_p()
+        L.check(L.lib().nrf_comm_create(buf, self.world, self.rank, C.byref(self._c)))
+
+    def all_gather_frames(self, tiles, h):
+        """tiles: [F, rows_rank, W, C] fp32 (contiguous) -> [F, h, W, C] on every rank; one fused RCCL launch on the current stream."""
+        tiles = tiles.contiguous()
+        f, _, w, c = tiles.shape
+        out = torch.empty((f, h, w, c), device=tiles.device, dtype=torch.float32)
+        L.check(L.lib().nrf_allgather_tiles(self._c, C.c_void_p(tiles.data_ptr()), int(f), int(h), int(w), int(c), C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def close(self):
+        if getattr(self, "_c", None):
+            L.lib().nrf_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GradSync:

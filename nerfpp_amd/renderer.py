@@ -367,6 +367,33 @@ def RenderViewBuffers(result):
     return TorchTensorToCVMat(o.RGBMap), TorchTensorToCVMat(o.DispMap), TorchTensorToCVMat(NormalizeDepth(o.DepthMap, result.Near, result.Far))
 
 
+def RenderViewDims(h, w, k, render_factor):
+    """The render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627) -> (h1, w1, K1 [3,3] float32)."""
+    K = _host_f32(k, 9)
+    K1 = np.empty(9, np.float32)
+    h1, w1 = C.c_int(0), C.c_int(0)
+    L.check(L.lib().nrf_render_view_dims(int(h), int(w), K.ctypes.data_as(C.c_void_p), C.c_float(float(render_factor)), C.byref(h1), C.byref(w1),
+                                         K1.ctypes.data_as(C.c_void_p)))
+    return h1.value, w1.value, K1.reshape(3, 3)
+
+
+def RenderView(renderer, render_pose, w, h, k, rparams: NeRFRenderParams, **kw):
+    """NeRFExecutor::RenderView (NeRFExecutor.h:609-650), argument order (pose, w, h, k, params) as there: with RenderFactor != 0 the
+    frame is rendered at (h, w) / RenderFactor with fx, fy, cx, cy divided by it.  `renderer` is a NeRFRenderer or a LeRFRenderer mirror;
+    row0 / rows (multi-GPU tiles) refer to the downsampled frame."""
+    h1, w1, k1 = RenderViewDims(h, w, k, rparams.RenderFactor)
+    pose = torch.as_tensor(render_pose)[:3, :4] if torch.is_tensor(render_pose) else np.asarray(render_pose)[:3, :4]
+    return renderer.Render(h1, w1, k1, rparams, c2w=pose, **kw)
+
+
+def RenderPath(renderer, render_poses, h, w, focal, k, rparams: NeRFRenderParams):
+    """NeRFExecutor::RenderPath (NeRFExecutor.h:653-737) up to cv::imwrite: per pose the three 8-bit buffers (rgb, disparity, Near/Far-normalised
+    depth).  Reproduced quirk: RenderFactor scales h, w and the local `focal` (:657-662) but Render() receives the ORIGINAL k (:668)."""
+    h1, w1, _ = RenderViewDims(h, w, k, rparams.RenderFactor)
+    return [RenderViewBuffers(renderer.Render(h1, w1, k, rparams, c2w=(torch.as_tensor(p)[:3, :4] if torch.is_tensor(p) else np.asarray(p)[:3, :4])))
+            for p in render_poses]
+
+
 # ------------------------------------------------------------------------------------------------
 # LeRFRenderer.h / LeRFRenderer.cpp  (BASELINE config 4: language-embedded radiance field render pass)
 # ------------------------------------------------------------------------------------------------
@@ -553,6 +580,8 @@ class LeRFRenderer:
         for name in ("RenderedLangEmbedding", "DispMapLE", "AccMapLE", "WeightsLE", "DepthMapLE"):
             vals = [getattr(q.Outputs, name) for q in parts if getattr(q.Outputs, name) is not None]
             setattr(res.Outputs, name, torch.cat(vals, 0) if vals else None)
+        for k_ in (parts[0].Extras if parts else {}):
+            res.Extras[k_] = torch.cat([q.Extras[k_] for q in parts], 0)
         nr, fr = C.c_float(0), C.c_float(0)
         L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
         res.Near, res.Far = nr.value, fr.value

@@ -4,9 +4,11 @@
 //   reference   NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall>             on LibTorch CPU          (the oracle)
 //   this repo   nrfpp::HipNeRFRenderer<HipHashEmbedder, HipSHEncoder, NeRFSmall> : NeRFRenderer<...>  on the MI355X
 // Both are driven through the reference's unmodified Render() -> BatchifyRays() -> (virtual) RenderRays() and given the same
-// synthetic weights.  >= 90 % of the pixels must agree within 1e-4 and the render-vs-render PSNR must exceed 55 dB (fp32
-// parity precision): the reference's fine-pass sample set is a discontinuous function of the coarse weights, and the
-// reference differs from ITSELF by this much between CPU dispatch settings ("How exact can parity be").
+// synthetic weights.  Against the LibTorch CPU render >= 90 % of the pixels must agree within 1e-4 and the render-vs-render PSNR must
+// exceed 55 dB: the reference's fine-pass sample set is a discontinuous function of the coarse weights, and the reference differs
+// from ITSELF by this much between CPU dispatch settings ("How exact can parity be").  The adapter's matrix-core precision
+// (NRF_PREC_F16_SPLIT) against its own NRF_PREC_F32 render -- which equals the CPU oracle bit for bit -- is held to the strict bar:
+// every pixel value within 1e-4.  The multi-GPU surface (RenderTile, RenderSharded over a TileComm) is exercised on a world of one.
 // Also checks the BaseEmbedder surface
 // (GetOutputDims / forward) of the hash and SH encoders against the reference modules.
 //
@@ -17,6 +19,7 @@
 
 #include <cstdio>
 #include <iostream>
+#include <unistd.h>
 
 using torch::indexing::Slice;
 using torch::indexing::None;
@@ -131,10 +134,30 @@ int main(int argc, const char **argv)
 	const double split_mse = (r_sp.Outputs.RGBMap.cpu() - r_ref.Outputs.RGBMap).pow(2).mean().item<double>();
 	const double split_psnr = split_mse > 0 ? -10.0 * std::log10(split_mse) : 999.0;
 	ok = ok && split_frac_1e4 >= 0.90f && split_psnr > 55.0;
+	// ... and against the adapter's OWN NRF_PREC_F32 render (== the CPU oracle bit for bit): the split mode's coarse pass evaluates the sigma net in exact fp32,
+	// so the sample sets coincide and EVERY pixel value is within 1e-4 (strict; the comparison with the LibTorch CPU render above carries MKL's summation order)
+	const float split_vs_f32 = (r_sp.Outputs.RGBMap - r_hip.Outputs.RGBMap).abs().max().item<float>();
+	ok = ok && split_vs_f32 < 1e-4f;
+	// ---- multi-GPU surface: RenderTile == the slice of Render, RenderSharded over a world of one == Render (the box has one GPU) ----
+	const int row0 = h / 3, rows = h / 2;
+	auto r_tile = hip.RenderTile(h, w, K.cuda(), rp_gpu, c2w.cuda(), row0, rows);
+	const bool tile_exact = torch::equal(r_tile.Outputs.RGBMap, r_sp.Outputs.RGBMap.index({Slice(row0, row0 + rows)})) &&
+		torch::equal(r_tile.Outputs.DepthMap, r_sp.Outputs.DepthMap.index({Slice(row0, row0 + rows)}));
+	bool sharded_exact = false;
+	std::string comm_note = "ok";
+	try {
+		const std::string id_path = std::string("/tmp/nrf_adapter_check_comm_") + std::to_string((long)getpid());
+		nrfpp::TileComm comm(1, 0, id_path);
+		auto r_sh = hip.RenderSharded(h, w, K.cuda(), rp_gpu, c2w.cuda(), comm);
+		sharded_exact = torch::equal(r_sh.Outputs.RGBMap, r_sp.Outputs.RGBMap) && torch::equal(r_sh.Outputs.DepthMap, r_sp.Outputs.DepthMap) &&
+			torch::equal(r_sh.Outputs.AccMap.reshape({-1}), r_sp.Outputs.AccMap.reshape({-1})) && r_sh.Near == r_sp.Near && r_sh.Far == r_sp.Far;
+	} catch (const std::exception &ex) { comm_note = ex.what(); }
+	ok = ok && tile_exact && sharded_exact;
 	std::cout.rdbuf(cout_buf);
 	printf("{\"ok\": %s, \"image\": [%d, %d], \"hash_embedding_bit_exact\": %s, \"sh_bit_exact\": %s, \"rgb_max_abs_err\": %.3e, \"pixels_within_1e-4\": %.4f, \"acc_max_abs_err\": %.3e, "
-		"\"depth_max_abs_err\": %.3e, \"psnr_db\": %.2f, \"shapes_near_far_equal\": %s, \"f16_render_finite\": %s, \"split_pixels_within_1e-4\": %.4f, \"split_psnr_db\": %.2f}\n",
+		"\"depth_max_abs_err\": %.3e, \"psnr_db\": %.2f, \"shapes_near_far_equal\": %s, \"f16_render_finite\": %s, \"split_pixels_within_1e-4\": %.4f, \"split_psnr_db\": %.2f, "
+		"\"split_vs_own_f32_max_abs_err\": %.3e, \"render_tile_equals_slice\": %s, \"render_sharded_world1_equals_render\": %s, \"comm\": \"%s\"}\n",
 		ok ? "true" : "false", h, w, emb_exact ? "true" : "false", sh_exact ? "true" : "false", rgb_err, frac_1e4, acc_err, dep_err, psnr, shape_ok ? "true" : "false",
-		f16_finite ? "true" : "false", split_frac_1e4, split_psnr);
+		f16_finite ? "true" : "false", split_frac_1e4, split_psnr, split_vs_f32, tile_exact ? "true" : "false", sharded_exact ? "true" : "false", comm_note.c_str());
 	return ok ? 0 : 1;
 }

@@ -538,6 +538,29 @@ static void g_render()
 			save_npy(stag + ".u_theta2", torch::rand({nr, ns + ni, 1}));
 			if (variant == 1) save_npy(stag + ".noise2", torch::randn({nr, ns + ni}));
 		}
+		{
+			// X1: the render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627).  NeRFExecutor.h is unbuildable here (NeRFactor / RuCLIP
+			// headers), so its statements on h, w and k1 are evaluated below with the same types (int / float field, torch::Tensor element division),
+			// followed by the reference's own Render -- an "aux_" derivation in the sense of this file's header.
+			std::string rtag = "render_factor";
+			int hh = 26, ww = 26;
+			float RenderFactor = 3;
+			auto kk = lego_K(hh, ww);
+			kk[0][0] = kk[0][0] * 0.8f; kk[1][1] = kk[1][1] * 0.8f;
+			save_npy(rtag + ".k", kk); save_npy(rtag + ".hw", torch::tensor({hh, ww}, torch::kInt32)); save_scalar(rtag + ".render_factor", RenderFactor);
+			torch::Tensor k1 = kk.clone().detach();
+			hh = hh / RenderFactor;
+			ww = ww / RenderFactor;
+			k1[0][0] = k1[0][0] / RenderFactor;
+			k1[1][1] = k1[1][1] / RenderFactor;
+			k1[0][2] = k1[0][2] / RenderFactor;
+			k1[1][2] = k1[1][2] / RenderFactor;
+			save_npy(rtag + ".aux_k1", k1); save_npy(rtag + ".aux_hw1", torch::tensor({hh, ww}, torch::kInt32)); save_npy(rtag + ".c2w", c2w);
+			NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> r(e, ed, m);
+			auto res = r.Render(hh, ww, k1, lego_params(64, 128, 64), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+			save_outputs(rtag + ".out_", res.Outputs);
+			save_npy(rtag + ".near_far", torch::tensor({res.Near, res.Far}));
+		}
 	}
 	{
 		// C2 shape: PE(10)/PE(4) + NeRF 8x256 with viewdirs

@@ -711,24 +711,28 @@ def test_mlp_small_split_precision_vs_oracle(api, O, manifest):
 
 
 def test_split_precision_render_matches_parity_mode(api, O):
-    """BASELINE config 2 shape, CuHash fast path in NRF_PREC_F16_SPLIT vs the bit-exact NRF_PREC_F32 mode on the adversarial scene."""
+    """BASELINE config 2 shape, CuHash fast path in NRF_PREC_F16_SPLIT vs the bit-exact NRF_PREC_F32 mode on the adversarial scene.  The default coarse pass
+    (sigma net in exact fp32) reproduces the parity mode's sample set, so EVERY pixel value is within 1e-4; with the whole network forced onto the coarse pass
+    in split precision (NRF_COARSE_FULL, what round 1 timed) ~1e-6 weight differences move a few samples across CDF plateaus and only the statistical bound holds."""
     sc = api.S.make_hash_scene(mode="cu")
     K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
     out = {}
-    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_SPLIT, api.L.NRF_PREC_F16_MFMA):
-        rp = api.S.lego_render_params(sc["bbox"], chunk=4096, precision=prec, KeepIntermediates=True, ReturnRaw=True)
-        out[prec] = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=396, rows=8)
-    a, b, c = (out[k] for k in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_SPLIT, api.L.NRF_PREC_F16_MFMA))
+    for name, prec, kw in (("f32", api.L.NRF_PREC_F32, {}), ("split", api.L.NRF_PREC_F16_SPLIT, {}), ("split_full", api.L.NRF_PREC_F16_SPLIT, dict(CoarseMode=api.L.NRF_COARSE_FULL)),
+                           ("f16", api.L.NRF_PREC_F16_MFMA, {})):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=4096, precision=prec, KeepIntermediates=(True if name in ("f32", "split_full") else "depths"), ReturnRaw=True, **kw)
+        out[name] = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=396, rows=8)
+    a, b, bf, c = (out[k] for k in ("f32", "split", "split_full", "f16"))
     raw_scale = np.abs(host(a.Extras["raw_coarse"])).max()
-    assert_close(host(b.Extras["raw_coarse"]), host(a.Extras["raw_coarse"]), rtol=0, atol=3e-6 * raw_scale, what="coarse raw, same points")
-    # the fine sample set is a discontinuous function of the coarse weights (searchsorted on CDF plateaus), so ~1e-6 weight differences
-    # move a few near-zero-weight samples, exactly as between two hosts running the reference (oracle/ref_self_consistency.sh);
-    # on this adversarial field (finest cell 6e-3, sigma head x30) a moved sample is worth up to ~5e-4 of a pixel
+    assert_close(host(bf.Extras["raw_coarse"]), host(a.Extras["raw_coarse"]), rtol=0, atol=3e-6 * raw_scale, what="coarse raw, same points")
     rgb_a, rgb_b = host(a.Outputs.RGBMap).reshape(-1, 3), host(b.Outputs.RGBMap).reshape(-1, 3)
+    assert_exact(host(b.Extras["z_fine"]), host(a.Extras["z_fine"]), "default coarse pass: the parity mode's sample set")
     d = np.abs(rgb_b - rgb_a)
-    assert (d < 1e-4).mean() > 0.98 and np.median(d) < 1e-5 and d.max() < 2e-2, ((d < 1e-4).mean(), np.median(d), d.max())
+    assert d.max() < 1e-4 and np.median(d) < 1e-5, (d.max(), np.median(d))                      # strict: north_star's pixel bar
+    assert np.abs(host(b.Raw) - host(a.Raw)).max() < 1e-5 * np.abs(host(a.Raw)).max()           # fine raw on identical points: 22-bit operands
+    df = np.abs(host(bf.Outputs.RGBMap).reshape(-1, 3) - rgb_a)
+    assert (df < 1e-4).mean() > 0.98 and np.median(df) < 1e-5 and df.max() < 2e-2, ((df < 1e-4).mean(), np.median(df), df.max())
     ps_split, ps_f16 = api.S.psnr(rgb_b, rgb_a), api.S.psnr(host(c.Outputs.RGBMap).reshape(-1, 3), rgb_a)
-    assert ps_split > 70 and ps_split > ps_f16 + 20, (ps_split, ps_f16)
+    assert ps_split > 95 and ps_split > ps_f16 + 20, (ps_split, ps_f16)
 
 
 @pytest.mark.parametrize("mode", ["cu", "ngp"])
@@ -1496,3 +1500,129 @@ def test_trainer_tv_regulariser_smooths_the_table(api):
     tr2 = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=1e-2, tv_loss_weight=0.0)
     tr2.step(o, d, tgt, rp)
     assert float(tr2.tv_loss) == 0.0
+
+
+# ------------------------------------------------------------------ X1: render factor, multi-GPU collective behind the C ABI, whole frames
+def test_render_view_render_factor_vs_reference(api, manifest):
+    """NeRFExecutor::RenderView with RenderFactor = 3 (NeRFExecutor.h:609-650): 26x26 -> 8x8 with K's fx, fy, cx, cy divided, then Render --
+    against the reference's own render of the downsampled view."""
+    g = load_golden("render_factor")
+    r, _ = _golden_hash_scene(api, manifest)
+    h, w = (int(v) for v in g["hw"])
+    p = _params(api, load_golden("render_hash")["bbox"], 64, RenderFactor=float(g["render_factor"][0]))
+    res = api.R.RenderView(r, g["c2w"], w, h, g["k"], p)
+    assert tuple(res.Outputs.RGBMap.shape) == (8, 8, 3) and tuple(res.Outputs.DepthMap.shape) == (8, 8)
+    assert_close(host(res.Outputs.RGBMap), g["out_rgb"], rtol=0, atol=1e-4, what="downsampled view within 1e-4 of the reference")
+    assert_close(host(res.Outputs.AccMap), g["out_acc"], rtol=0, atol=1e-4)
+    assert res.Near == g["near_far"][0] and res.Far == g["near_far"][1]
+    # RenderFactor == 0 is the plain Render; RenderPath scales the size only (the reference hands Render() the original k, NeRFExecutor.h:668)
+    p0 = _params(api, load_golden("render_hash")["bbox"], 64)
+    g0 = load_golden("render_hash")
+    full = api.R.RenderView(r, g0["c2w"], 8, 8, g0["k"], p0)
+    assert_exact(host(full.Outputs.RGBMap), host(r.Render(8, 8, g0["k"], p0, c2w=g0["c2w"]).Outputs.RGBMap), "RenderFactor 0")
+    bufs = api.R.RenderPath(r, [g["c2w"]], h, w, float(g["k"][0, 0]), g["k"], p)
+    assert len(bufs) == 1 and tuple(bufs[0][0].shape) == (8, 8, 3) and bufs[0][0].dtype == torch.uint8
+    same_k = r.Render(8, 8, g["k"], p, c2w=g["c2w"])
+    assert_exact(host(bufs[0][0]), host(api.R.TorchTensorToCVMat(same_k.Outputs.RGBMap)), "RenderPath: size / factor, k unchanged")
+
+
+def test_allgather_tiles_c_abi_single_rank(api):
+    """nrf_comm_* / nrf_allgather_tiles on a world of one (the box has one GPU): RCCL is found, the communicator comes up from the library's own unique id,
+    and the gathered frames equal the tiles -- equal split (ncclAllGather) and the uneven-split code path's bookkeeping are the same at world 1, so the N > 1
+    offsets are covered by the CPU partition tests and the 2-rank gloo test; N > 1 on RCCL runs in the driver's SCALE job (bench.py reports a cross-check there)."""
+    from nerfpp_amd.dist import TileComm, tile_partition
+    cm = TileComm(0, 1)
+    assert api.L.lib().nrf_comm_world(cm._c) == 1 and api.L.lib().nrf_comm_rank(cm._c) == 0
+    tiles = torch.rand((3, 37, 20, 3), device="cuda")
+    out = cm.all_gather_frames(tiles, 37)
+    torch.cuda.synchronize()
+    assert_exact(host(out), host(tiles), "world-1 all-gather through RCCL")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                   # launches go to the caller's stream
+        out2 = cm.all_gather_frames(tiles[:1], 37)
+    s.synchronize()
+    assert_exact(host(out2), host(tiles[:1]))
+    assert tile_partition(37, 1, 0) == (0, 37)
+    cm.close()
+
+
+def test_whole_frame_800x800_bench_configuration(api, O):
+    """The bench configuration itself (BASELINE config 2: CuHashEmbedder L16 T2^19 F2 + CuSHEncoder(4) + NeRFSmall, 640 000 rays, 64 + 128 samples,
+    Chunk 131 072, NRF_PREC_F16_SPLIT) rendered whole: properties over every pixel, the bit-exact NRF_PREC_F32 mode on the same frame as the yardstick
+    (every pixel value within 1e-4), 1 024 random rays of the F32 frame equal to the CPU oracle bit for bit, and row tiles == slices of the frame."""
+    sc = api.S.make_hash_scene(mode="cu")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=131072, precision=api.L.NRF_PREC_F16_SPLIT)
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w)
+    rgb = host(res.Outputs.RGBMap).reshape(-1, 3); acc = host(res.Outputs.AccMap).reshape(-1); dep = host(res.Outputs.DepthMap).reshape(-1)
+    rays = host(res.Extras["rays_flat"])
+    assert rgb.shape == (640000, 3) and np.isfinite(rgb).all() and np.isfinite(dep).all() and np.isfinite(acc).all()
+    assert acc.min() >= 0 and acc.max() <= 1 + 1e-5 and rgb.min() >= -1e-5 and rgb.max() <= 1 + 1e-5
+    hit = acc > 1e-3
+    assert 0.2 < hit.mean() < 1.0                                # the orbit camera sees the box in the middle of the frame, background around it
+    assert (dep[hit] >= rays[hit, 6] - 1e-4).all() and (dep[hit] <= rays[hit, 7] + 1e-4).all()
+    miss = rays[:, 7] <= rays[:, 6] + 2e-6                       # rays that miss the AABB (far clamped to near + 1e-6, RayUtils.h:123)
+    assert miss.any() and np.abs(rgb[miss & (acc < 1e-6)] - 1.0).max() < 1e-5      # white background
+    # the parity mode on the same frame
+    rp32 = api.S.lego_render_params(sc["bbox"], chunk=32768, precision=api.L.NRF_PREC_F32)
+    ref = sc["renderer"].Render(800, 800, K, rp32, c2w=c2w)
+    rgb32 = host(ref.Outputs.RGBMap).reshape(-1, 3)
+    d = np.abs(rgb - rgb32)
+    assert d.max() < 1e-4 and np.median(d) < 1e-5, (d.max(), np.median(d), (d >= 1e-4).sum())
+    assert api.S.psnr(rgb, rgb32) > 95
+    assert np.abs(dep - host(ref.Outputs.DepthMap).reshape(-1)).max() < 2e-4 and np.abs(acc - host(ref.Outputs.AccMap).reshape(-1)).max() < 1e-4
+    # 1 024 random rays of the parity frame against the CPU oracle
+    idx = np.sort(np.random.RandomState(7).choice(640000, 1024, replace=False))
+    cfg = sc["cfg"]
+    ls = ((1 << cfg["log2_t"]) >> 4) << 4
+    model = O.Model(2, sc["mlp_blob"], bbox=sc["bbox"], table_f16=O.f32_to_f16(sc["table"]), primes=sc["primes"],
+                    local_idx=np.arange(16, dtype=np.int32) * ls, local_size=np.full(16, ls, np.int32), bias=np.zeros((16, 3), np.float32),
+                    mul=O.hash_cu_scales(16, 16, 512))
+    orc = O.render_rays(model, rays[idx], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
+    assert_exact(rgb32[idx], orc["rgb"], "whole frame, NRF_PREC_F32: 1024 random rays == oracle bit for bit")
+    assert np.abs(rgb[idx] - orc["rgb"]).max() < 1e-4
+    # multi-GPU partition: rank 5 of 8's row tile equals the slice of the frame, bit for bit
+    from nerfpp_amd.dist import tile_partition
+    row0, rows = tile_partition(800, 8, 5)
+    tile = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=row0, rows=rows)
+    assert_exact(host(tile.Outputs.RGBMap).reshape(-1, 3), rgb[row0 * 800:(row0 + rows) * 800], "row tile == slice of the frame")
+
+
+def test_lerf_render_pass_at_main_cpp_table_size(api, O):
+    """BASELINE config 4 at the reference's own sizes (main.cpp:203-213: CuHashEmbedder L16 F8 T2^19 16..1024, LeRF 2 x 256 -> 768) on a 4-row tile of the
+    800x800 frame, 64 + 128 samples, fused matrix-core path: sigma_le and the rendered embedding of 48 sampled rays against the oracle composed stage by
+    stage; unit norm, finite, Chunk-independent."""
+    sc = api.S.make_lerf_scene()
+    r = sc["renderer"]
+    assert r.fused and r.level_major
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=2048, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    res = r.Render(800, 800, K, p, c2w=c2w, row0=398, rows=4)
+    emb = host(res.Outputs.RenderedLangEmbedding); accm = host(res.Outputs.AccMapLE)
+    assert emb.shape == (3200, 768) and np.isfinite(emb).all()
+    hit = accm > 1e-2
+    assert hit.sum() > 500
+    assert_close(np.linalg.norm(emb[hit], axis=1), np.ones(hit.sum()), rtol=1e-5, atol=0)
+    p2 = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=800, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    res2 = r.Render(800, 800, K, p2, c2w=c2w, row0=398, rows=4)
+    cosc = (host(res2.Outputs.RenderedLangEmbedding)[hit] * emb[hit]).sum(1)
+    assert cosc.min() > 1 - 1e-5, cosc.min()                                   # Chunk only changes the order of the float atomics of the per-ray sums
+    # oracle on a sample of the rays: the fp32 stage path of the oracle on the GPU's own fine depths (the fine sample set depends on fp16 sigma)
+    rays = host(res.Extras["rays_flat"])
+    idx = np.nonzero(hit)[0][::max(1, hit.sum() // 48)][:48]
+    Lv, F, T = 16, 8, 19
+    ls = ((1 << T) >> 4) << 4
+    primes = sc["primes"]
+    def net(pts):
+        e_, keep = O.hash_cu(pts.reshape(-1, 3), O.f32_to_f16(sc["table"]), primes, np.arange(Lv, dtype=np.int32) * ls, np.full(Lv, ls, np.int32),
+                             np.zeros((Lv, 3), np.float32), sc["bbox"], O.hash_cu_scales(Lv, 16, 1024), Lv, F)
+        o = O.lerf(sc["blob"], e_)
+        o[~keep, -1] = 0
+        return o.reshape(pts.shape[0], pts.shape[1], -1)
+    zf = host(res.Extras["z_fine"])[idx]
+    rawf = net(O.points(rays[idx, :3], rays[idx, 3:6], zf))
+    fin = O.raw2weights(rawf, 768, zf, rays[idx, 3:6])
+    ref = O.render_clip_embedding(rawf, 768, fin["weights"])
+    assert_close(host(res.Outputs.WeightsLE)[idx], fin["weights"], rtol=0, atol=5e-3 * fin["weights"].max(), what="WeightsLE (fp16 sigma net) on the same depths")
+    cos = (emb[idx] * ref).sum(1)
+    assert np.median(cos) > 0.9999 and cos.min() > 0.995, (np.median(cos), cos.min())

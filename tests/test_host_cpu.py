@@ -105,6 +105,40 @@ def test_tile_shard_partition():
     assert torch.equal(s.all_gather_frames([t, t + 1])[1], t + 1)
 
 
+def test_tile_partition_c_abi():
+    """nrf_tile_partition: the tile bookkeeping of the C++ / LibTorch host (HipNeRFRenderer::RenderSharded) -- contiguous, covering, balanced to one row."""
+    from nerfpp_amd import _lib
+    from nerfpp_amd.dist import tile_partition
+    for h, n in ((800, 1), (800, 2), (800, 3), (800, 7), (800, 8), (10, 4), (7, 3), (3, 8), (0, 2)):
+        parts = [tile_partition(h, n, r) for r in range(n)]
+        assert parts[0][0] == 0 and sum(p[1] for p in parts) == h
+        assert all(parts[r + 1][0] == parts[r][0] + parts[r][1] for r in range(n - 1))
+        assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+    assert tile_partition(800, 8, 3) == (300, 100)            # SURVEY 8e: 800 / 8 = 100 rows = 80 000 rays per rank
+    r0, rr = C.c_int(), C.c_int()
+    lib = _lib.lib()
+    assert lib.nrf_tile_partition(800, 8, 8, C.byref(r0), C.byref(rr)) == 1 and b"rank" in lib.nrf_last_error()
+    assert lib.nrf_tile_partition(800, 0, 0, C.byref(r0), C.byref(rr)) == 1
+    assert lib.nrf_allgather_tiles(None, None, 1, 8, 8, 3, None, None) == 1 and b"communicator" in lib.nrf_last_error()
+
+
+def test_render_view_dims_vs_reference():
+    """The render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627) against the golden from its own statements."""
+    from nerfpp_amd import _lib
+    g = load_golden("render_factor")
+    h, w = (int(v) for v in g["hw"])
+    K = np.ascontiguousarray(g["k"], np.float32)
+    K1 = np.empty(9, np.float32)
+    h1, w1 = C.c_int(), C.c_int()
+    lib = _lib.lib()
+    assert lib.nrf_render_view_dims(h, w, K.ctypes.data_as(C.c_void_p), C.c_float(float(g["render_factor"][0])), C.byref(h1), C.byref(w1), K1.ctypes.data_as(C.c_void_p)) == 0
+    assert [h1.value, w1.value] == list(g["aux_hw1"]) == [8, 8]
+    assert (K1.reshape(3, 3) == g["aux_k1"]).all()
+    assert lib.nrf_render_view_dims(h, w, K.ctypes.data_as(C.c_void_p), C.c_float(0.0), C.byref(h1), C.byref(w1), K1.ctypes.data_as(C.c_void_p)) == 0
+    assert (h1.value, w1.value) == (h, w) and (K1 == K.reshape(-1)).all()       # RenderFactor == 0: untouched
+    assert lib.nrf_render_view_dims(h, w, K.ctypes.data_as(C.c_void_p), C.c_float(2.0), C.byref(h1), C.byref(w1), None) == 0 and h1.value == 13   # RenderPath's use: dims only
+
+
 GLOO_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["NRF_ROOT"])

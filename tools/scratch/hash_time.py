@@ -11,7 +11,7 @@ r = sc["renderer"]
 for _ in range(3): r.Render(H, W, K, rp, c2w=c2w)
 torch.cuda.synchronize()
 lib = L.lib(); lib.nrf_profile_enable(1)
-ms = (C.c_double * 5)(); cnt = (C.c_int64 * 5)(); lib.nrf_profile_read(ms, cnt, 1)
+ms = (C.c_double * len(L.NRF_PROF_NAMES))(); cnt = (C.c_int64 * len(L.NRF_PROF_NAMES))(); lib.nrf_profile_read(ms, cnt, 1)
 ts = []
 for _ in range(8):
     t0 = time.perf_counter(); out = r.Render(H, W, K, rp, c2w=c2w); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
