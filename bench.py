@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--workload", default="hash", choices=["hash", "classic"])
     ap.add_argument("--precision", default=None, choices=["f16", "f16x3", "f32"],
                     help="MLP arithmetic: f16 = matrix cores, fp16 operands; f16x3 = matrix cores, hi+lo fp16 operand pairs (fp32-grade); f32 = FMA chains "
-                         "(== oracle bitwise).  Default: f16x3 for the hash workload (pixels within 1e-4 of the fp32 path), f16 for classic")
+                         "(== oracle bitwise).  Default: f16x3 (fp32-grade pixels; the reference computes in fp32)")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (other precision, classic workload) at N = 1")
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
     ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
@@ -124,7 +124,7 @@ def main():
     args = ap.parse_args()
 
     if args.precision is None:
-        args.precision = "f16x3" if args.workload == "hash" else "f16"
+        args.precision = "f16x3"
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -291,11 +291,14 @@ def main():
             peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             upl = units_per_step * args.steps / world / max(k["launches"], 1)
             traffic, traffic_src = pmc_traffic("mlp_nerf (k_mlp_nerf_mfma)", upl, "classic_units_per_launch")
-            roof = dict(bound="mfma", kernel="mlp_nerf", achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel="mlp_nerf" + ("_split" if args.precision == "f16x3" else ""), achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
                         frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
                         avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT,
                         note="achieved / frac price the ALGORITHMIC 1 186 816 flop per unit of NeRFImpl::forward as written (11 linear layers); the kernel runs "
                              "feature_linear and views_linears_0 (no activation in between) as one pre-multiplied affine layer, 10.6 % fewer matrix instructions")
+            if args.precision == "f16x3":      # three fp16 products per algorithmic one (hi + lo operand pairs)
+                roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * (units_per_step * args.steps / world) / max(dur_total, 1e-12) / peak
+                roof["note"] += "; split precision issues 3 x 1 058 matrix instructions per 32 points (mfma_issued_frac) to deliver fp32-grade pixels"
             busy = pmc_mfma_busy("mlp_nerf (k_mlp_nerf_mfma)", args.precision)
             if busy:
                 roof["mfma_busy_frac_of_active_cycles_before_restaging"] = busy
@@ -303,7 +306,7 @@ def main():
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f16": "f16 MFMA (fp32 accumulate) MLP; ", "f16x3": "split-f16 MFMA (hi+lo operand pairs, 3 products, fp32 accumulate) MLP; ",
+            "dtype": {"f16": "f16 MFMA (fp32 accumulate) MLP; ", "f16x3": "split-f16 MFMA (hi+lo operand pairs, 3 products, fp32 accumulate: fp32-grade) MLP; ",
                       "f32": "f32 MLP; "}[args.precision] +
                      ("fp16 hash table, fp32 blend" if (args.workload == "hash" and args.hash_mode == "cu") else "f32 encoders") + "; f32/f64 compositing",
             "data": "synthetic",
@@ -352,7 +355,8 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
     BASELINE workload, each with its render-vs-oracle quality on the same 256-ray sample."""
     import torch
     out = []
-    todo = [("hash", "f16" if args.precision != "f16" else "f16x3"), ("classic", "f16")] if args.workload == "hash" else [("hash", "f16x3"), ("hash", "f16")]
+    todo = [("hash", "f16" if args.precision != "f16" else "f16x3"), ("classic", "f16x3"), ("classic", "f16")] if args.workload == "hash" else \
+           [("classic", "f16" if args.precision != "f16" else "f16x3"), ("hash", "f16x3")]
     scenes = {args.workload: sc_main}
     for wl, pname in todo:
         try:
@@ -401,14 +405,15 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
         out.append(train_step_measurement(args, scene, L))
     except Exception as e:
         out.append(dict(workload="hashnerf_train_step", error=str(e)))
-    try:
-        out.append(lerf_measurement(scene, K, c2w))
-    except Exception as e:
-        out.append(dict(workload="lerf_lego800_64+128", error=str(e)))
+    for lp in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA):
+        try:
+            out.append(lerf_measurement(scene, K, c2w, lp))
+        except Exception as e:
+            out.append(dict(workload="lerf_lego800_64+128", error=str(e)))
     return out
 
 
-def lerf_measurement(scene, K, c2w, repeats=3):
+def lerf_measurement(scene, K, c2w, precision, repeats=3):
     """BASELINE config 4: the LeRF language-embedding render pass (CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768, main.cpp:203-213)
     on the WHOLE 800x800 frame, 64+128 samples: one warm-up frame, then `repeats` timed frames."""
     import torch
@@ -417,6 +422,7 @@ def lerf_measurement(scene, K, c2w, repeats=3):
     p = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=32768, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True,
                            BoundingBox=sc["bbox"])
     r = sc["renderer"]
+    r.set_precision(precision)
     r.Render(H, W, K, p, c2w=c2w)
     torch.cuda.synchronize()
     times = []
@@ -434,7 +440,8 @@ def lerf_measurement(scene, K, c2w, repeats=3):
                 s_per_frame_min_max=[min(times), max(times)], fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
                 rays_with_language_density=int(hit.sum()), embedding_norm_min_max=[float(nrm.min()), float(nrm.max())] if int(hit.sum()) else None,
                 level_major_features=bool(getattr(r, "level_major", False)), precision=getattr(r, "precision_name", "f16"),
-                arithmetic="fp16 MFMA (fp32 accumulate) LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
+                arithmetic=("split-f16 MFMA (hi + lo operand pairs, three products, fp32 accumulate: fp32-grade)" if r.precision_name == "f16x3" else "fp16 MFMA (fp32 accumulate)") +
+                           " LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
                            "read by the kernels as operand fragments; embedding norm via the Gram matrix of the bias-free output layer, which is applied once per ray to the weighted sum of its inputs")
 
 

@@ -159,7 +159,8 @@ enum {
     NRF_PREC_F32 = 0,      /* fp32 FMA chains in ascending k: the parity mode (== oracle bit for bit) */
     NRF_PREC_F16_MFMA = 1, /* fp16 operands on the matrix cores, fp32 accumulate: the fast mode */
     NRF_PREC_F16_SPLIT = 2 /* matrix cores with every operand carried as hi + lo fp16 pairs (22 significant bits, three MFMAs per
-                              product): fp32-grade results at matrix-core speed.  Built for the NeRFSmall family. */
+                              product): fp32-grade results at matrix-core speed.  Built for NeRFSmall, the classic 8 x 256 NeRF and
+                              the fused LeRF passes (nrf_lerf_set_precision). */
 };
 
 typedef struct nrf_mlp_small_desc {      /* NeRFSmallImpl ctor (NeRF.cpp:322-360) */
@@ -211,6 +212,9 @@ NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float
  *                               Evaluated as W . sum_s (weights / ||W a||) a with ||W a||^2 = a^T (W^T W) a (the output layer is bias-free, hence linear): the
  *                               256 -> 768 layer runs once per ray.  Takes n * 256 floats of stream-ordered scratch (hipMallocAsync / hipFreeAsync). */
 NRF_API int nrf_lerf_mfma_available(const nrf_mlp *m);
+/* Arithmetic of the four fused entries below, per handle: NRF_PREC_F16_MFMA (default: fp16 operands, fp32 accumulate) or NRF_PREC_F16_SPLIT (hi + lo fp16
+ * operand pairs, three products: fp32-grade, as LeRFImpl::forward computes -- mlp_lerf_split_mfma.hip).  Call between, not during, passes. */
+NRF_API int nrf_lerf_set_precision(nrf_mlp *m, int precision);
 NRF_API int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
 NRF_API int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
 /* ... reading the level-major fp16 features of nrf_hash_encode_lm_f16 (16 levels x 8 features: [16][p][8] halfs) instead of fp32 rows. */

@@ -1,4 +1,4 @@
-// mlp.h -- MLP handle shared by mlp.hip (generic fp32 path), mlp_small_mfma.hip and mlp_nerf_mfma.hip.
+// mlp.h -- MLP handle shared by mlp.hip (generic fp32 path) and the matrix-core translation units (mlp_small_*, mlp_nerf_*, mlp_lerf_*).
 #pragma once
 #include "common.h"
 
@@ -33,6 +33,8 @@ struct nrf_mlp {
     size_t packed_split_bytes = 0;
     void *d_packed_sigma_f32 = nullptr;      // fp32 MFMA fragments of the sigma net (sigma_small_f32.hip)
     size_t packed_sigma_f32_bytes = 0;
+    int lerf_precision = NRF_PREC_F16_MFMA;  // arithmetic of the fused LeRF passes (nrf_lerf_set_precision)
+    float lerf_gram_scale = 1.0f;            // LeRF: the Gram matrix of the embedding layer is stored divided by this power of two (fp16 range), see mlp_lerf_mfma.hip
     void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
     size_t packed_bwd_bytes = 0;
 };
@@ -56,6 +58,12 @@ int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int6
 int mlp_nerf_mfma_available(const nrf_mlp *m);
 int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);
 int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st);
+// NRF_PREC_F16_SPLIT for the classic NeRF (mlp_nerf_split_mfma.hip)
+int mlp_nerf_split_available(const nrf_mlp *m);
+int mlp_nerf_forward_split_rows(const nrf_mlp *m, const float *x, int xs, int64_t p, float *out, int os, hipStream_t st);
+int mlp_nerf_forward_split_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, const __half *dirs_lo,
+                                 int64_t p, float *out, hipStream_t st);
+int launch_dirs_pe_split(const float *rays, int stride, int64_t n, __half *out_hi, __half *out_lo, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &host_params);
 size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p);

@@ -224,7 +224,8 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
     }
     if (prec == NRF_PREC_F16_SPLIT) {
         if (m->family == MLP_SMALL) return mlp_small_forward_mfma(m, d_x, x_stride, p, 1, d_out, out_stride, st);
-        set_error("NRF_PREC_F16_SPLIT is built for the NeRFSmall family; use NRF_PREC_F32 or NRF_PREC_F16_MFMA");
+        if (m->family == MLP_NERF) return mlp_nerf_forward_split_rows(m, d_x, x_stride, p, d_out, out_stride, st);
+        set_error("NRF_PREC_F16_SPLIT is built for the NeRFSmall and NeRF families; use NRF_PREC_F32 or NRF_PREC_F16_MFMA");
         return NRF_ERR_UNSUPPORTED;
     }
     set_error("unknown precision %d", prec);

@@ -17,51 +17,12 @@
 // Same transposed MFMA formulation and the same L2 -> LDS weight streaming as mlp_nerf_mfma.hip (8 waves x 32 points per workgroup,
 // chunks of <= 2 neuron tiles x all k-steps, LDS-DMA through three buffers two chunks ahead); fp16 operands, fp32 accumulate.
 // Built for the reference's LeRF shape (main.cpp:203-213): in 16 x 8 = 128, hidden 256, 2 + 2 layers, geo 32, embedding 768.
-#include "mlp.h"
+#include "mlp_lerf_net.h"
 
 #include <utility>
 
 namespace nrf {
 namespace lerf {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int NW = 8;              // waves per workgroup
-constexpr int NBLK = 32 * NW;      // points per workgroup iteration (one 32-point tile per wave)
-constexpr int MAXF = 32;           // fragments (1 KB each) in the largest chunk
-constexpr int IN = 128, HID = 256, GEO = 32, EMB = 768;
-
-__host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
-
-// Layers: 0 sigma0 [nat 8] -> 8 tiles ReLU | 1 sigma1 [chained 16] -> 2 tiles (row 0 = sigma, rows 1..32 = geo) | 2 LE0 [chained 4 | nat 8]
-// -> 8 tiles ReLU (cat[geo, in], LeRF.cpp) | 3 GRAM [chained 16] -> 8 tiles: t = (W^T W) a, ||LE1(a)||^2 = a . t | 4 LE1 [chained 16] -> 24 tiles
-// (weighted-sum pass).  NL = 2: the sigma net alone (kernel A); NL = 5: everything (kernel B).  Both walk the same weight image.
-//
-// The norm: LE1 is bias-free (LeRF.cpp:21-24), so ||W a||^2 = a^T (W^T W) a.  The 256 x 256 Gram matrix is formed once per weight set (in double, at pack
-// time) and costs 8 tiles x 16 k-steps per point tile instead of the 24 x 16 of a first full pass through the 256 -> 768 layer: 704 matrix instructions
-// per 32 points instead of 960.
-template <int NL>
-struct Net {
-    static constexpr int NLAYER = NL;
-    static constexpr int tiles(int l) { return l == 0 ? 8 : l == 1 ? 2 : l == 2 ? 8 : l == 3 ? 8 : 24; }
-    static constexpr int ks_nat(int l) { return (l == 0 || l == 2) ? 8 : 0; }
-    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 2 ? 4 : 16; }
-    static constexpr bool nat_first(int l) { return l != 2; }
-    static constexpr int ks(int l) { return ks_nat(l) + ks_ch(l); }
-    static constexpr int chunk_tiles(int l, int) { return l == 1 ? 1 : 2; }            // sigma1: 1 + 1 keeps the chunk count even
-    static constexpr int chunks(int l) { return l == 1 ? 2 : tiles(l) / 2; }
-    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += chunks(i); return n; }
-    static constexpr int total_chunks() { return first_chunk(NLAYER); }
-    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
-    static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
-    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
-};
-static_assert(Net<2>::total_chunks() == 6 && Net<4>::total_chunks() == 14 && Net<5>::total_chunks() == 26, "chunk counts");
-constexpr int IMAGE_FRAGS = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16 + 24 * 16;       // 704 KB: sigma0, sigma1, LE0, Gram (chained operands) + LE1 in NATURAL operand order (kernel C)
-constexpr int LE1_FRAG0 = 8 * 8 + 2 * 16 + 8 * 12 + 8 * 16;
-static_assert(Net<5>::chunk_off(Net<5>::first_chunk(4)) + 24 * 16 == IMAGE_FRAGS, "image size");
 
 // Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4, one 1-KB fragment per wave-instruction, wave w takes fragments
 // w, w + NW, ...): same scheme as mlp_nerf_mfma.hip -- three LDS buffers, requested two chunks ahead, no staging registers.
@@ -213,16 +174,6 @@ struct ReduceHook {
     }
 };
 
-struct Args {
-    const float *x; int x_stride;           // hash features [p, 128] fp32 ...
-    const __half *x_lm; int64_t pstride;    // ... or level-major fp16 [16][pstride][8] (nrf_hash_encode_lm_f16): k-step s, lane half h = level 2s + h, one 16-byte load
-    const float *weights;                   // [p] render weights (kernel B)
-    const uint8_t *keep;                    // optional: sigma forced to 0 where false (kernel A)
-    float *sigma;                           // [p] (kernel A)
-    float *out;                             // [n, 768] accumulated (kernel B)
-    int s;                                  // samples per ray, a multiple of 32
-};
-
 template <int NL>
 __global__ void __launch_bounds__(64 * NW)
 k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
@@ -284,7 +235,8 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
             }
             DotHook ssq{ba};
             layer<N, 3>(cx, none, ba, ssq);                   // ||LE1(a)||^2 = a . (W^T W) a
-            const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f);
+            // G rounded to fp16 is not guaranteed positive semi-definite: a tiny negative a^T G a is clamped to 0 (-> the 1e-8 floor of normalize, LeRF.cpp:106-107)
+            const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
             const float wgt = live ? in.weights[q] : 0.0f;
             // sum over the tile's 32 samples of (w_s / ||h_s||) a_s: fragments 2t, 2t+1 of a hold, on each lane, the neurons of D-tile t's 16 registers
             ReduceHook red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)HID : nullptr, r, h};
@@ -380,6 +332,16 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
                 gram[(size_t)a * HID + b] = gram[(size_t)b * HID + a] = (float)acc;
             }
     }
+    // fp16 range: entries of G are sums of 768 products and pass 65504 for weights of moderate size; G is stored divided by a power of two that brings
+    // max|G| to <= 1024 (exact scaling; the kernels multiply a^T G a back), so neither the entries nor the fp16 rounding of large ones can overflow
+    {
+        float gmax = 0.0f;
+        for (float g : gram) gmax = fmaxf(gmax, fabsf(g));
+        int e = 0;
+        if (gmax > 1024.0f) (void)frexpf(gmax / 1024.0f, &e);
+        m->lerf_gram_scale = ldexpf(1.0f, e);
+        if (e != 0) for (float &g : gram) g = ldexpf(g, -e);
+    }
     for (int L = 0; L < 5; L++)
         for (int tile = 0; tile < N::tiles(L); tile++)
             for (int k = 0; k < N::ks(L); k++)
@@ -390,12 +352,31 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     m->packed_f16_bytes = img.size() * sizeof(_Float16);
     NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));
+    // split-precision image (mlp_lerf_split_mfma.hip): every fragment followed by the fragment of the rounding residuals w - f16(w)
+    std::vector<_Float16> img2;
+    img2.reserve(img.size() * 2);
+    for (int L = 0; L < 5; L++)
+        for (int tile = 0; tile < N::tiles(L); tile++)
+            for (int k = 0; k < N::ks(L); k++)
+                for (int part = 0; part < 2; part++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const float v = wval(hp, gram, L, tile * 32 + (lane & 31), k, lane >> 5, j);
+                            const _Float16 hv = (_Float16)v;
+                            img2.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                        }
+    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
+    m->packed_split_bytes = img2.size() * sizeof(_Float16);
+    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
+    NRF_HIP(hipMemcpy(m->d_packed_split, img2.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
     return NRF_OK;
 }
 
 template <int NL>
-static int launch_lerf(const nrf_mlp *m, const Args &a, int64_t p, hipStream_t st)
+static int launch_lerf(const nrf_mlp *m, const Args &a_in, int64_t p, hipStream_t st)
 {
+    Args a = a_in;
+    a.gram_scale = m->lerf_gram_scale;
     const size_t lds = (size_t)3 * MAXF * 1024;
     const int64_t nblocks = ceil_div(p, NBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 8-wave workgroup per CU (216 VGPRs: two waves per SIMD)
@@ -410,9 +391,9 @@ static int lerf_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int 
     float *asum = nullptr;
     const size_t bytes = (size_t)n * lerf::HID * sizeof(float);
     NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&asum), bytes, st));
-    NRF_HIP(hipMemsetAsync(asum, 0, bytes, st));
-    int rc;
-    {
+    int rc = hipMemsetAsync(asum, 0, bytes, st) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
+    if (rc != NRF_OK) set_error("hipMemsetAsync failed");
+    else {
         ProfScope prof(NRF_PROF_MLP, st);
         a.out = asum;
         rc = launch_lerf<4>(m, a, n * (int64_t)s, st);
@@ -434,14 +415,24 @@ extern "C" {
 
 int nrf_lerf_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_LERF && m->d_packed_f16 != nullptr; }
 
+int nrf_lerf_set_precision(nrf_mlp *m, int precision)
+{
+    NRF_CHECK_ARG(m && m->family == MLP_LERF, "nrf_lerf_set_precision: not a LeRF handle");
+    NRF_CHECK_ARG(precision == NRF_PREC_F16_MFMA || precision == NRF_PREC_F16_SPLIT, "nrf_lerf_set_precision: the fused passes run in NRF_PREC_F16_MFMA or NRF_PREC_F16_SPLIT (NRF_PREC_F32: nrf_mlp_forward + the stage functions)");
+    if (precision == NRF_PREC_F16_SPLIT && !lerf_split_available(m)) { set_error("nrf_lerf_set_precision: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    m->lerf_precision = precision;
+    return NRF_OK;
+}
+
 int nrf_lerf_sigma(const nrf_mlp *m, const float *d_x, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream)
 {
     NRF_CHECK_ARG(m && d_x && d_sigma && p >= 0, "nrf_lerf_sigma: bad argument");
     if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_sigma: feature rows must be 16-byte aligned");
     if (p == 0) return NRF_OK;
-    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
     lerf::Args a{d_x, lerf::IN, nullptr, 0, nullptr, d_keep, d_sigma, nullptr, 32};
+    if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_sigma(m, a, p, as_stream(stream));
+    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
     return launch_lerf<2>(m, a, p, as_stream(stream));
 }
 
@@ -453,6 +444,7 @@ int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "nrf_lerf_render_embedding: feature rows must be 16-byte aligned");
     if (n == 0) return NRF_OK;
     lerf::Args a{d_x, lerf::IN, nullptr, 0, d_weights, nullptr, nullptr, nullptr, s};
+    if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_embedding_passes(m, a, n, s, d_out, as_stream(stream));
     return lerf_embedding_passes(m, a, n, s, d_out, as_stream(stream));
 }
 
@@ -463,8 +455,9 @@ int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d
     if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma_lm: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_sigma_lm: features must be 16-byte aligned");
     if (p == 0) return NRF_OK;
-    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
     lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), p, nullptr, d_keep, d_sigma, nullptr, 32};
+    if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_sigma(m, a, p, as_stream(stream));
+    ProfScope prof(NRF_PROF_MLP, as_stream(stream));
     return launch_lerf<2>(m, a, p, as_stream(stream));
 }
 
@@ -476,6 +469,7 @@ int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_render_embedding_lm: features must be 16-byte aligned");
     if (n == 0) return NRF_OK;
     lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), n * (int64_t)s, d_weights, nullptr, nullptr, nullptr, s};
+    if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_embedding_passes(m, a, n, s, d_out, as_stream(stream));
     return lerf_embedding_passes(m, a, n, s, d_out, as_stream(stream));
 }
 

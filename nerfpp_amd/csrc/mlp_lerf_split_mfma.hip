@@ -1,0 +1,379 @@
+// mlp_lerf_split_mfma.hip -- the LeRF language head fused with its render pass (see mlp_lerf_mfma.hip) at fp32-grade precision: NRF_PREC_F16_SPLIT.
+//
+// The reference runs LeRFImpl::forward (LeRF.cpp:28-111) in fp32.  Here, as in mlp_nerf_split_mfma.hip, every fp32 quantity travels as an unevaluated sum
+// of two fp16 numbers (hi = f16(v), lo = f16(v - hi): 22 significant bits); weights -- the Gram matrix of the embedding layer included -- are split at pack
+// time, activations when a D tile becomes the next operand, and a product is three matrix instructions (Wh.xh into the main accumulator, Wl.xh + Wh.xl into
+// a second one).  CuHashEmbedder features are exact fp16 numbers (CuHashEmbedder.cu:95), so the layers fed by them need two.
+//
+//   kernel A  sigma net (128 -> 256 -> 33): sigma_le per point
+//   kernel B  sigma net -> LE0 (cat[geo, in] -> 256, ReLU) = a;  ||W a||^2 = a^T (W^T W) a from the Gram product (8 tiles);  the ray's
+//             sum_s (w_s / ||W a_s||) a_s by reduce-scatter + one 128-byte float atomic per 32 neurons
+//   kernel C  W applied once per ray to that sum, operand and weights as (hi, lo) pairs
+//
+// One wave per SIMD (4 waves, 128 points per workgroup pass): the (hi, lo) activations of a 256-wide layer are 128 registers, input and output of a layer 256.
+// Weight stream: chunks of ONE neuron tile (<= 32 fragments: 16 k-steps x (hi, lo)), LDS-DMA through three buffers two chunks ahead, the DMA pieces issued
+// between the matrix instructions of the running chunk.
+#include "mlp_lerf_net.h"
+
+#include <utility>
+
+namespace nrf {
+namespace lerf {
+
+constexpr int SNW = 4;                 // waves per workgroup: one per SIMD
+constexpr int SNBLK = 32 * SNW;
+constexpr int SMAXF = 32;              // fragments in the largest chunk: 16 k-steps x (hi, lo)
+
+// one neuron tile per chunk; per (layer, tile, k-step) the hi fragment then the lo fragment
+template <int NL>
+struct NetS {
+    using F = Net<NL>;
+    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += F::tiles(i); return n; }
+    static constexpr int total_chunks() { return first_chunk(NL); }
+    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
+    static constexpr int chunk_frags(int ci) { return 2 * F::ks(layer_of(ci)); }
+    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
+};
+static_assert(NetS<2>::total_chunks() == 10 && NetS<4>::total_chunks() == 26, "chunk counts");
+static_assert(NetS<4>::chunk_off(26) == 2 * LE1_FRAG0, "the split image doubles the fp16 image");
+
+template <class N, int CI, int Q>
+__device__ __forceinline__ void stage_piece(half8 *__restrict__ dst, const half8 *__restrict__ packed, int wave, int lane)
+{
+    constexpr int ci = CI % N::total_chunks();
+    constexpr int nf = N::chunk_frags(ci);
+    static_assert(nf % SNW == 0, "fragments per chunk must divide by the wave count");
+    if constexpr (Q * SNW < nf) {
+        constexpr int base = N::chunk_off(ci);
+        const half8 *pk = packed + (size_t)wave * 64;
+        asm volatile("" : "+s"(pk));                          // opaque: the addresses derived from it cannot be hoisted out of the persistent loop
+        __builtin_amdgcn_global_load_lds(pk + (size_t)(base + Q * SNW) * 64 + lane, (__attribute__((address_space(3))) void *)(dst + (Q * SNW + wave) * 64), 16, 0, 0);
+    }
+}
+
+template <class N, int CI, int... Qs>
+__device__ __forceinline__ void stage_all(half8 *__restrict__ dst, const half8 *__restrict__ packed, int wave, int lane, std::integer_sequence<int, Qs...>)
+{
+    (stage_piece<N, CI, Qs>(dst, packed, wave, lane), ...);
+}
+
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+}
+
+// registers 8s..8s+7 of a finished tile -> the (hi, lo) operand fragments of k-step s.  The asm reads VALU results only (the max / the add).
+template <bool RELU>
+__device__ __forceinline__ void tile_to_frag2(const f32x16 &t, int s, half8 &hi, half8 &lo)
+{
+    union { half8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float lim = RELU ? 0.0f : -3.402823466e38f;          // max with -FLT_MAX: the identity on every finite value, and a VALU result for the asm to read
+        split_pair(fmaxf(t[8 * s + 2 * j], lim), fmaxf(t[8 * s + 2 * j + 1], lim), h.u[j], l.u[j]);
+    }
+    hi = h.v; lo = l.v;
+}
+
+struct CtxS {
+    half8 *wbuf;
+    const half8 *packed;
+    int lane, h, wave;
+    int *cur;
+};
+
+// One chunk = neuron tile T of layer L; the finished tile (main + correction accumulator) goes to hook(T, tile).  BNLO / BCLO: the natural / chained operand has a lo part.
+template <class N, int L, int T, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+__device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
+{
+    using F = typename N::F;
+    constexpr int KSN = F::ks_nat(L), KSC = F::ks_ch(L), KS = KSN + KSC;
+    constexpr int CI = N::first_chunk(L) + T;
+    constexpr bool NATF = F::nat_first(L);
+    static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
+    constexpr int NQ = N::chunk_frags((CI + 2) % N::total_chunks()) / SNW;
+    constexpr int EVERY = (KS / NQ) > 0 ? (KS / NQ) : 1;
+    constexpr int LEAD = NQ > KS / EVERY ? NQ - KS / EVERY : 0;
+    static_assert(NQ <= 8, "piece switch covers 8 pieces per wave");
+    stage_all<N, CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane, std::make_integer_sequence<int, LEAD>{});
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc = zero, cor = zero;
+    int q = LEAD;
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        const half8 ah = w[(2 * k) * 64 + cx.lane], al = w[(2 * k + 1) * 64 + cx.lane];
+        const bool nat = NATF ? (k < KSN) : (k >= KSC);
+        const int kk = NATF ? (nat ? k : k - KSN) : (nat ? k - KSC : k);
+        const half8 bh = nat ? bn[nat ? kk : 0][0] : bc[nat ? 0 : kk][0];
+        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cor, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        if (nat ? BNLO : BCLO) {
+            const half8 bl = nat ? bn[nat ? kk : 0][1] : bc[nat ? 0 : kk][1];
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cor, 0, 0, 0);
+        }
+        if ((k % EVERY) == EVERY - 1 && q < NQ) {
+            const int qq = q;
+            switch (qq) {
+#define NRF_PIECE(Q) case Q: stage_piece<N, CI + 2, Q>(dma_dst, cx.packed, cx.wave, cx.lane); break;
+                NRF_PIECE(0) NRF_PIECE(1) NRF_PIECE(2) NRF_PIECE(3) NRF_PIECE(4) NRF_PIECE(5) NRF_PIECE(6) NRF_PIECE(7)
+#undef NRF_PIECE
+            }
+            q++;
+        }
+        if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x16 tile;
+#pragma unroll
+    for (int i = 0; i < 16; i++) tile[i] = acc[i] + cor[i];
+    hook(T, tile);
+    __builtin_amdgcn_sched_barrier(0);          // the tile is consumed here (see mlp_lerf_mfma.hip)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ) : "memory");
+}
+
+template <class N, int L, int T, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+__device__ __forceinline__ void chunk_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
+{
+    const int cur = *cx.cur;
+    chunk_body_s<N, L, T, BNLO, BCLO>(cx, cx.wbuf + cur * (SMAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (SMAXF * 64), bn, bc, hook);
+    *cx.cur = cur == 2 ? 0 : cur + 1;
+}
+
+template <class N, int L, bool BNLO, bool BCLO, int NN, int NC, class Hook, int... Ts>
+__device__ __forceinline__ void layer_seq_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, std::integer_sequence<int, Ts...>)
+{
+    (chunk_s<N, L, Ts, BNLO, BCLO>(cx, bn, bc, hook), ...);
+}
+
+template <class N, int L, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+__device__ __forceinline__ void layer_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
+{
+    layer_seq_s<N, L, BNLO, BCLO>(cx, bn, bc, hook, std::make_integer_sequence<int, N::F::tiles(L)>{});
+}
+
+template <bool RELU, int NOUT, bool KEEP0 = false>
+struct ConvHookS {
+    half8 (&bout)[NOUT][2];
+    float row0;
+    __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
+    {
+        if (2 * tile + 1 < NOUT) {
+            tile_to_frag2<RELU>(t, 0, bout[2 * tile][0], bout[2 * tile][1]);
+            tile_to_frag2<RELU>(t, 1, bout[2 * tile + 1][0], bout[2 * tile + 1][1]);
+        }
+        if (KEEP0 && tile == 0) row0 = t[0];
+    }
+};
+
+// a . (G a) with a = hi + lo
+struct DotHookS {
+    const half8 (&a)[16][2];
+    float ss = 0.0f;
+    __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++) ss = __builtin_fmaf(t[i], (float)a[2 * tile + (i >> 3)][0][i & 7] + (float)a[2 * tile + (i >> 3)][1][i & 7], ss);
+        asm volatile("" : "+v"(ss));          // pin the partial sum (see mlp_lerf_mfma.hip)
+    }
+};
+
+// the reduce-scatter over the tile's 32 samples and the float atomics of mlp_lerf_mfma.hip's ReduceHook
+struct ReduceS {
+    float f;
+    float *out_row;
+    int r, h;
+    template <int NKEEP>
+    __device__ __forceinline__ void step(float (&v)[16]) const
+    {
+        const bool up = (r & (2 * NKEEP)) != 0;
+#pragma unroll
+        for (int i = 0; i < NKEEP; i++) {
+            const float keep = up ? v[i + NKEEP] : v[i], send = up ? v[i] : v[i + NKEEP];
+            v[i] = keep + __shfl_xor(send, 2 * NKEEP);
+        }
+    }
+    __device__ __forceinline__ void operator()(int tile, float (&v)[16]) const
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] *= f;
+        step<8>(v); step<4>(v); step<2>(v); step<1>(v);
+        v[0] += __shfl_xor(v[0], 1);
+        const int i = r >> 1;
+        if (out_row && (r & 1) == 0) unsafeAtomicAdd(out_row + tile * 32 + 16 * (i >> 3) + 8 * ((i & 7) >> 2) + 4 * h + (i & 3), v[0]);
+    }
+};
+
+// XLO: the input features carry a lo part (fp32 rows); level-major CuHashEmbedder features are exact fp16
+template <int NL, bool XLO>
+__global__ void __launch_bounds__(64 * SNW, 1)
+k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
+{
+    using N = NetS<NL>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *wbuf = reinterpret_cast<half8 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(0) / SNW>{});
+    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(1) / SNW>{});
+    __syncthreads();
+    int cur = 0;
+    const int64_t nblocks = (npts + SNBLK - 1) / SNBLK;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        CtxS cx{wbuf, packed, lane, h, wave, &cur};
+        const int64_t p0 = blk * SNBLK + wave * 32;
+        const int64_t q = p0 + r;
+        const bool live = q < npts;
+        const int64_t qc = live ? q : npts - 1;
+        half8 none[1][2];
+        // input operand: element j of k-step s is x[q][16 s + 8 h + j]; needed by layer 0 and again by layer 2 (cat[geo, in]): read twice
+        auto load_x = [&](half8 (&xin)[8][2]) {
+            if (in.x_lm) {
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    xin[s][0] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + qc) * 8);
+                    xin[s][1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+                return;
+            }
+            const float *row = in.x + qc * in.x_stride;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const float4 lo4 = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h);
+                const float4 hi4 = *reinterpret_cast<const float4 *>(row + 16 * s + 8 * h + 4);
+                const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; xin[s][0][j] = t; xin[s][1][j] = (_Float16)(v[j] - (float)t); }
+            }
+        };
+        half8 ba[16][2], bb[4][2];
+        ConvHookS<true, 16> c0{ba, 0.0f};
+        {
+            half8 xin[8][2];
+            load_x(xin);
+            layer_s<N, 0, XLO, false>(cx, xin, none, c0);                 // sigma0: 128 -> 256, ReLU
+        }
+        ConvHookS<false, 4, NL == 2> c1{bb, 0.0f};
+        layer_s<N, 1, false, true>(cx, none, ba, c1);                     // sigma1: 256 -> (sigma, geo32)
+        if constexpr (NL == 2) {
+            if (h == 0 && live) {
+                float sg = c1.row0;
+                if (in.keep && !in.keep[q]) sg = 0.0f;                    // raw_le[~keep, -1] = 0 (LeRFRenderer.cpp:22-23)
+                in.sigma[q] = sg;
+            }
+        } else {
+            ConvHookS<true, 16> c2{ba, 0.0f};
+            {
+                half8 xin[8][2];
+                load_x(xin);
+                layer_s<N, 2, XLO, true>(cx, xin, bb, c2);                // LE0: cat[geo, in] -> 256, ReLU
+            }
+            DotHookS ssq{ba};
+            layer_s<N, 3, false, true>(cx, none, ba, ssq);                // ||LE1(a)||^2 = a . (W^T W) a
+            const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
+            const float wgt = live ? in.weights[q] : 0.0f;
+            ReduceS red{wgt / fmaxf(sqrtf(tot), 1e-8f), (p0 < npts) ? in.out + (p0 / in.s) * (int64_t)HID : nullptr, r, h};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = (float)ba[2 * t + (i >> 3)][0][i & 7] + (float)ba[2 * t + (i >> 3)][1][i & 7];
+                red(t, v);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// kernel C: out[ray][768] = W . asum[ray][256], operand and weights as (hi, lo) pairs: three matrix instructions per fragment pair.  One wave per 32 rays;
+// the 768 split fragments (768 KB, L2-resident) are read straight from global memory.
+__global__ void __launch_bounds__(256)
+k_lerf_embed_split(int64_t nrays, const float *__restrict__ asum, const half8 *__restrict__ packed, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t ray = tile * 32 + r;
+    if (tile * 32 >= nrays) return;
+    const int64_t rc = ray < nrays ? ray : nrays - 1;
+    half8 bh[16], bl[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const float4 lo4 = *reinterpret_cast<const float4 *>(asum + rc * HID + 16 * s + 8 * h), hi4 = *reinterpret_cast<const float4 *>(asum + rc * HID + 16 * s + 8 * h + 4);
+        const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; bh[s][j] = t; bl[s][j] = (_Float16)(v[j] - (float)t); }
+    }
+    const half8 *w = packed + (size_t)(2 * LE1_FRAG0) * 64 + lane;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < 24; t++) {
+        f32x16 acc = zero, cor = zero;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const half8 ah = w[(size_t)(2 * (t * 16 + k)) * 64], al = w[(size_t)(2 * (t * 16 + k) + 1) * 64];
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[k], cor, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[k], acc, 0, 0, 0);
+            cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[k], cor, 0, 0, 0);
+        }
+        if (ray < nrays) {
+            float *o = out + ray * EMB + 32 * t + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(o + 8 * g) = float4{acc[4 * g] + cor[4 * g], acc[4 * g + 1] + cor[4 * g + 1], acc[4 * g + 2] + cor[4 * g + 2], acc[4 * g + 3] + cor[4 * g + 3]};
+        }
+    }
+}
+
+template <int NL>
+static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipStream_t st)
+{
+    Args a = a_in;
+    a.gram_scale = m->lerf_gram_scale;
+    const size_t lds = (size_t)3 * SMAXF * 1024;
+    const int64_t nblocks = ceil_div(p, SNBLK);
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 4-wave workgroup per CU
+    const half8 *img = reinterpret_cast<const half8 *>(m->d_packed_split);
+    static bool attr_set = false;
+    if (!attr_set) {
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (a.x_lm) hipLaunchKernelGGL((k_lerf_split<NL, false>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
+    else hipLaunchKernelGGL((k_lerf_split<NL, true>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // namespace lerf
+
+int lerf_split_available(const nrf_mlp *m) { return m && m->family == MLP_LERF && m->d_packed_split != nullptr && m->packed_split_bytes == (size_t)2 * lerf::IMAGE_FRAGS * 1024; }
+
+int lerf_split_sigma(const nrf_mlp *m, const lerf::Args &a, int64_t p, hipStream_t st)
+{
+    ProfScope prof(NRF_PROF_MLP, st);
+    return lerf::launch_lerf_split<2>(m, a, p, st);
+}
+
+// kernel B into a stream-ordered scratch asum [n][256] (zeroed), then kernel C
+int lerf_split_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int s, float *d_out, hipStream_t st)
+{
+    float *asum = nullptr;
+    const size_t bytes = (size_t)n * lerf::HID * sizeof(float);
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&asum), bytes, st));
+    int rc = hipMemsetAsync(asum, 0, bytes, st) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
+    if (rc == NRF_OK) {
+        ProfScope prof(NRF_PROF_MLP, st);
+        a.out = asum;
+        rc = lerf::launch_lerf_split<4>(m, a, n * (int64_t)s, st);
+        if (rc == NRF_OK) {
+            hipLaunchKernelGGL(lerf::k_lerf_embed_split, dim3((unsigned)ceil_div(ceil_div(n, (int64_t)32), (int64_t)4)), dim3(256), 0, st, n, (const float *)asum,
+                               reinterpret_cast<const lerf::half8 *>(m->d_packed_split), d_out);
+            if (hipGetLastError() != hipSuccess) { set_error("k_lerf_embed_split launch failed"); rc = NRF_ERR_HIP; }
+        }
+    } else set_error("hipMemsetAsync failed");
+    (void)hipFreeAsync(asum, st);          // stream-ordered: also on the error paths
+    return rc;
+}
+
+}  // namespace nrf

@@ -33,48 +33,11 @@
 //            cat[h, views]: W_v[:, :256] . F (128 x 256, formed in double at pack time) on h, W_v[:, 256:] on the views, bias W_v[:, :256] . b_f + b_v.
 //            90 matrix instructions per 32 points instead of the 216 of the two layers run one after the other (and 126 KB less weight stream).
 //   9      : rgb_linear      [chained 8]          -> 1 tile (rows 0..2)         out = cat[rgb, alpha] (NeRF.cpp:119)
-#include "mlp.h"
+#include "mlp_nerf_net.h"
 
 #include <utility>
 
 namespace nrf {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// Measured on MI355X (bench --workload classic): 8 waves x 1 point tile = 1021 TFLOP/s (40.9 % of the 2.5 PF dense fp16 peak);
-// 4 waves x 2 tiles (one wave per SIMD, half the LDS fragment reads) = 779 TFLOP/s: with a single wave per SIMD nothing
-// covers the bias/ReLU/convert epilogue between tiles, with two the other wave's MFMAs do.
-#ifndef NRF_NERF_NW
-#define NRF_NERF_NW 8
-#define NRF_NERF_NPT 1
-#endif
-constexpr int NW = NRF_NERF_NW;        // waves per workgroup
-constexpr int NPT = NRF_NERF_NPT;      // 32-point tiles per wave (every weight fragment read from LDS feeds NPT MFMAs)
-constexpr int NBLK = 32 * NPT * NW;    // points per workgroup iteration
-constexpr int MAXF = 40;               // fragments (1 KB each) in the largest chunk
-constexpr int NBIAS = 8 * 256 + 160 + 32;
-
-__host__ __device__ inline int nerf_perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
-
-struct NerfNet {
-    static constexpr int NLAYER = 10;
-    static constexpr int tiles(int l) { return l < 8 ? 8 : l == 8 ? 5 : 1; }
-    static constexpr int ks_nat(int l) { return (l == 0 || l == 5) ? 4 : l == 8 ? 2 : 0; }
-    static constexpr int ks_ch(int l) { return l == 0 ? 0 : l == 9 ? 8 : 16; }
-    static constexpr bool nat_first(int l) { return l != 8; }
-    static constexpr int ks(int l) { return ks_nat(l) + ks_ch(l); }
-    static constexpr int chunks(int l) { return (tiles(l) + 1) / 2; }
-    static constexpr int chunk_tiles(int l, int c) { return (2 * c + 2 <= tiles(l)) ? 2 : 1; }
-    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += chunks(i); return n; }
-    static constexpr int total_chunks() { return first_chunk(NLAYER); }
-    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
-    static constexpr int chunk_frags(int ci) { const int l = layer_of(ci); return chunk_tiles(l, ci - first_chunk(l)) * ks(l); }
-    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
-    static constexpr int total_frags() { return chunk_off(total_chunks()); }
-    static constexpr int bias_off(int l) { int n = 0; for (int i = 0; i < l; i++) n += tiles(i) * 32; return n; }
-};
-static_assert(NerfNet::total_chunks() == 36, "chunk count");
 
 // Chunk CI of the weight image -> LDS buffer `dst` by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves one 1-KB fragment
 // (64 lanes x 16 B, lane-linear on both sides -- exactly the fragment layout), wave w takes fragments w, w + NW, ...  No staging registers
@@ -197,15 +160,6 @@ __device__ __forceinline__ void nerf_layer(const Ctx &cx, const half8 (&bn)[NPT]
 {
     nerf_layer_seq<L, RELU>(cx, bn, bc, bout, last, std::make_integer_sequence<int, NerfNet::chunks(L)>{});
 }
-
-// Input: fp32 rows [p, 90] = [PE(10)(x) | PE(4)(dir)] (the generic BaseNeRF::forward boundary), or -- FUSED, the renderer's
-// fast path -- the packed rays, the depth table and per-RAY fp16 direction encodings: the kernel forms x = o + d*z
-// (NeRFRenderer.h:419) and its 63 sinusoidal features (NeRF.cpp:33-37, same nrf_sincosf as the stand-alone encoder, so the
-// operand fragments are bit-identical to the unfused path) in registers; no [P, 90] input is ever written.
-struct NerfInput {
-    const float *x; int x_stride;
-    const float *rays; int ray_stride; const float *z; int s; const __half *dirs;    // dirs: [n, 32] fp16, PE(4) of the view direction, zero padded
-};
 
 template <bool FUSED>
 __global__ void __launch_bounds__(64 * NW)
@@ -404,6 +358,26 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_f16) + img.size() * sizeof(_Float16), bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    // NRF_PREC_F16_SPLIT image (mlp_nerf_split_mfma.hip): every fragment followed by the fragment of the rounding residuals w - f16(w); same biases behind it
+    std::vector<_Float16> img2;
+    img2.reserve(img.size() * 2);
+    for (int L = 0; L < NerfNet::NLAYER; L++) {
+        const int KS = NerfNet::ks(L);
+        for (int tile = 0; tile < NerfNet::tiles(L); tile++)
+            for (int k = 0; k < KS; k++)
+                for (int part = 0; part < 2; part++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const float v = wval(L, tile * 32 + (lane & 31), k, lane >> 5, j);
+                            const _Float16 hv = (_Float16)v;
+                            img2.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                        }
+    }
+    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
+    m->packed_split_bytes = img2.size() * sizeof(_Float16) + bias.size() * sizeof(float);
+    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
+    NRF_HIP(hipMemcpy(m->d_packed_split, img2.data(), img2.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_split) + img2.size() * sizeof(_Float16), bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     return NRF_OK;
 }
 

@@ -37,6 +37,9 @@ constexpr int PT = NRF_SMALL_PT; // 32-point tiles per wave
 #ifndef NRF_SPLIT_WAVES
 #define NRF_SPLIT_WAVES 8
 #endif
+#ifndef NRF_SPLIT_MINWAVES
+#define NRF_SPLIT_MINWAVES 1           // waves per SIMD the register budget is sized for (2 with NRF_SPLIT_WAVES = 4: half the register file is left to other kernels)
+#endif
 constexpr int waves_of(bool split) { return split ? NRF_SPLIT_WAVES : 4; }
 constexpr int block_pts_of(bool split) { return 32 * PT * waves_of(split); }
 
@@ -183,7 +186,7 @@ struct SmallInput {
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
 template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false>
-__global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? 1 : 2)
+__global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? NRF_SPLIT_MINWAVES : 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
     using Plan = SmallPlan<IN_KS, V_KS, NL, NLC>;

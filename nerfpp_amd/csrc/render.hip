@@ -325,22 +325,26 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     const bool sigma_only = ni > 0 && fast && !out->d_raw_coarse && mlp_small_sigma_f32_available(r->desc.mlp) &&
                             (p->coarse_mode == NRF_COARSE_SIGMA_F32 || (p->coarse_mode == NRF_COARSE_AUTO && p->precision == NRF_PREC_F16_SPLIT));
     // classic NeRF fast path: PE(10) positions / PE(4) directions + the 8x256 matrix-core kernel with the PE fused in
-    const bool fast_classic = p->precision == NRF_PREC_F16_MFMA && !r->desc.hash && r->desc.pe_freqs == 10 && r->desc.dirs_encoder == NRF_DIRS_PE &&
-                              r->desc.dirs_param == 4 && mlp_nerf_mfma_available(r->desc.mlp);
+    const bool classic_split = p->precision == NRF_PREC_F16_SPLIT;
+    const bool fast_classic = (p->precision == NRF_PREC_F16_MFMA || classic_split) && !r->desc.hash && r->desc.pe_freqs == 10 && r->desc.dirs_encoder == NRF_DIRS_PE &&
+                              r->desc.dirs_param == 4 && (classic_split ? mlp_nerf_split_available(r->desc.mlp) : mlp_nerf_mfma_available(r->desc.mlp));
     __half *dirs16 = nullptr;
     __half *dirs_lo = nullptr;
     if (fast) dirs16 = bump.take<__half>((size_t)n * r->in_views);
     if (fast && p->precision == NRF_PREC_F16_SPLIT) dirs_lo = bump.take<__half>((size_t)n * r->in_views);
     if (fast_classic) dirs16 = bump.take<__half>((size_t)n * 32);
+    if (fast_classic && classic_split) dirs_lo = bump.take<__half>((size_t)n * 32);
     float *z_plain = p->perturb > 0.0f ? bump.take<float>((size_t)n * s) : nullptr;
     float *bump_pts = (p->has_cone || p->precond_alpha > 0.0f) ? bump.take<float>((size_t)n * sf * 3) : nullptr;
     void *nws = bump.take<char>(0);
     const size_t nws_bytes = workspace_bytes - bump.off;
     const float *viewdirs = r->in_views > 0 ? d_rays + 8 : nullptr;
     if (fast) NRF_TRY(launch_dirs_f16(d_rays, ray_stride, n, r->desc.dirs_param, r->desc.dirs_encoder == NRF_DIRS_SH_CUDA ? NRF_SH_CUDA : NRF_SH_LIBTORCH, dirs16, dirs_lo, st));
-    if (fast_classic) NRF_TRY(launch_dirs_pe_f16(d_rays, ray_stride, n, dirs16, st));
+    if (fast_classic && classic_split) NRF_TRY(launch_dirs_pe_split(d_rays, ray_stride, n, dirs16, dirs_lo, st));
+    else if (fast_classic) NRF_TRY(launch_dirs_pe_f16(d_rays, ray_stride, n, dirs16, st));
     auto network = [&](const PointSource &src, int ns_, float *raw_out) -> int {
         if (fast) return run_network_fast(r, src, dirs16, dirs_lo, n, ns_, raw_out, nws, nws_bytes, st);
+        if (fast_classic && classic_split) return mlp_nerf_forward_split_fused(r->desc.mlp, src.pts, src.rays, src.ray_stride, src.z, ns_, dirs16, dirs_lo, n * (int64_t)ns_, raw_out, st);
         if (fast_classic) return mlp_nerf_forward_mfma_fused(r->desc.mlp, src.pts, src.rays, src.ray_stride, src.z, ns_, dirs16, n * (int64_t)ns_, raw_out, st);
         return run_network(r, src, viewdirs, ray_stride, n, ns_, p->precision, raw_out, nws, nws_bytes, st);
     };

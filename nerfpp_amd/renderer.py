@@ -436,14 +436,27 @@ class LeRFRenderer:
     embedding.  Stage-composed over the C ABI (generic fp32 kernels); `Relevancy` needs the external RuCLIP text encoder and is
     left to the caller."""
 
-    def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16, fused=True):
+    def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16, fused=True, precision=L.NRF_PREC_F16_SPLIT):
+        """precision: arithmetic of the fused matrix-core passes, L.NRF_PREC_F16_SPLIT (default: hi + lo fp16 operand pairs, fp32-grade like LeRFImpl::forward)
+        or L.NRF_PREC_F16_MFMA (plain fp16 operands, ~2x faster network, ~1e-3 relative)."""
         self.LangEmbedFn, self.Lerf = lang_embed_fn, lerf
         self.LerfPositives, self.LerfNegatives = lerf_positives, lerf_negatives
         self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
         # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
         self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
+        self.precision = int(precision)
+        if self.fused:
+            self.set_precision(precision)
         # level-major fp16 features straight into the matrix-core kernels' operand fragments (CuHashEmbedder, 16 levels x 8 features); False = fp32 rows
         self.level_major = self.fused and getattr(lang_embed_fn, "mode", None) == L.NRF_HASH_CU and lang_embed_fn.NLevels == 16 and lang_embed_fn.NFeaturesPerLevel == 8
+
+    def set_precision(self, precision):
+        L.check(L.lib().nrf_lerf_set_precision(self.Lerf._m, int(precision)))
+        self.precision = int(precision)
+
+    @property
+    def precision_name(self):
+        return {L.NRF_PREC_F16_MFMA: "f16", L.NRF_PREC_F16_SPLIT: "f16x3"}.get(self.precision, "f32")
 
     def _sigma_fused(self, pts):
         """sigma_le [N,S] (keep-masked) and the hash features [N*S, in] of the sample points, sigma net on the matrix cores."""

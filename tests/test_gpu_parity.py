@@ -1187,7 +1187,7 @@ def test_lerf_fused_matrix_core_path(api, O, manifest):
     blob[128 * 256:128 * 256 + 256] *= 20.0
     lerf = api.M.LeRF(32, 2, 256, 768, 128, "lang_model", params=blob)
     assert api.L.lib().nrf_lerf_mfma_available(lerf._m)
-    fused = api.R.LeRFRenderer(e, lerf); plain = api.R.LeRFRenderer(e, lerf, fused=False)
+    fused = api.R.LeRFRenderer(e, lerf, precision=api.L.NRF_PREC_F16_MFMA); plain = api.R.LeRFRenderer(e, lerf, fused=False)
     assert fused.fused and not plain.fused
     K = api.S.lego_K(12, 12); c2w = api.S.pose_spherical(40.0, -30.0, 4.0)
     p = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=50, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=bbox)
@@ -1211,7 +1211,7 @@ def test_lerf_fused_matrix_core_path(api, O, manifest):
     ref = (w[:, :, None] * raw[:, :768].reshape(144, 32, 768)).sum(1)
     assert_close(host(acc), ref, rtol=0, atol=4e-3 * np.abs(ref).max(), what="sum_s w_s normalize(le_s)")
     # the level-major fp16 feature path against the fp32-row path: the same fp16 values reach the same kernels
-    rowm = api.R.LeRFRenderer(e, lerf); rowm.level_major = False
+    rowm = api.R.LeRFRenderer(e, lerf, precision=api.L.NRF_PREC_F16_MFMA); rowm.level_major = False
     sig_r, x_r = rowm._sigma_fused(dev(pts))
     assert x_r.dtype == torch.float32
     assert_exact(host(x_gpu).astype(np.float32).transpose(1, 0, 2).reshape(144 * 32, 128), host(x_r), "level-major fp16 features == row-major features")
@@ -1626,3 +1626,115 @@ def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     assert_close(host(res.Outputs.WeightsLE)[idx], fin["weights"], rtol=0, atol=5e-3 * fin["weights"].max(), what="WeightsLE (fp16 sigma net) on the same depths")
     cos = (emb[idx] * ref).sum(1)
     assert np.median(cos) > 0.9999 and cos.min() > 0.995, (np.median(cos), cos.min())
+
+
+# ------------------------------------------------------------------ classic NeRF at fp32-grade precision on the matrix cores (NRF_PREC_F16_SPLIT)
+def test_mlp_nerf_split_precision_vs_oracle_and_reference(api, O, manifest):
+    """NeRFImpl::forward (8 x 256, skip, view branch) with hi + lo fp16 operand pairs: against the reference's own output (golden, MKL sgemm order) and against
+    the fp32 FMA-chain oracle on a larger batch incl. ragged sizes (one point, a block + 1, several blocks); three orders tighter than the plain fp16 mode."""
+    g = load_golden("mlp_nerf")
+    blob = synth.blob_from_manifest(manifest["mlp_nerf"])
+    m = api.M.NeRF(8, 256, 63, 27, 5, (4,), True, "model", params=blob)
+    y = host(m.forward(dev(g["x"]), api.L.NRF_PREC_F16_SPLIT))
+    scale = np.abs(g["y"]).max()
+    assert_close(y, g["y"], rtol=0, atol=2e-5 * scale, what="classic NeRF, split precision vs the reference")
+    rng = np.random.RandomState(5)
+    for n in (1, 129, 1000):
+        x = rng.uniform(-1, 1, (n, 90)).astype(np.float32)
+        ref = host(m.forward(dev(x), api.L.NRF_PREC_F32))                      # == oracle bit for bit (test_mlp_nerf_f32_bit_exact_vs_oracle)
+        y3 = host(m.forward(dev(x), api.L.NRF_PREC_F16_SPLIT))
+        y1 = host(m.forward(dev(x), api.L.NRF_PREC_F16_MFMA))
+        sc_ = np.abs(ref).max()
+        e3, e1 = np.abs(y3 - ref).max() / sc_, np.abs(y1 - ref).max() / sc_
+        assert e3 < 5e-6, (n, e3, e1)
+        assert n == 1 or e1 > 50 * e3, "the plain fp16 mode is the loose one"
+    oref = O.mlp_nerf(blob, x)
+    assert np.abs(y3 - oref).max() / np.abs(oref).max() < 5e-6
+
+
+def test_classic_split_render_vs_parity_mode_and_stagewise(api, O):
+    """BASELINE config 1 shape (PE(10)/PE(4) + NeRF 8x256, 800x800 camera, 64 + 128) on a 2-row tile: the fused split-precision path (points and PE formed in
+    the kernel, per-ray (hi, lo) direction rows) equals the stage-wise split path bit for bit, and its pixels are within 2e-4 of the bit-exact NRF_PREC_F32 render
+    (>= 99 %; the coarse pass runs in split precision too, so a handful of fine samples may sit in another CDF bin), PSNR > 80 dB -- where the plain fp16 mode gives ~58."""
+    sc = api.S.make_classic_scene()
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    out = {}
+    for name, prec in (("f32", api.L.NRF_PREC_F32), ("split", api.L.NRF_PREC_F16_SPLIT), ("f16", api.L.NRF_PREC_F16_MFMA)):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=prec, ReturnRaw=True, KeepIntermediates=True)
+        out[name] = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=2)
+    a, b, c = out["f32"], out["split"], out["f16"]
+    rays = b.Extras["rays_flat"]
+    for z, raw in ((b.Extras["z_coarse"], b.Extras["raw_coarse"]), (b.Extras["z_fine"], b.Raw)):
+        n, s = z.shape
+        pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).reshape(-1, 3)
+        emb, _ = sc["embedder"].forward(pts)
+        dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+        x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+        ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)
+        assert_exact(host(raw).reshape(-1, 4), host(ref), "fused classic split raw == stage-wise split raw")
+    raw_scale = np.abs(host(a.Extras["raw_coarse"])).max()
+    assert_close(host(b.Extras["raw_coarse"]), host(a.Extras["raw_coarse"]), rtol=0, atol=5e-6 * raw_scale, what="coarse raw on identical points")
+    rgb_a, rgb_b, rgb_c = (host(o.Outputs.RGBMap).reshape(-1, 3) for o in (a, b, c))
+    d = np.abs(rgb_b - rgb_a)
+    assert (d < 2e-4).mean() >= 0.99 and np.median(d) < 1e-5, ((d < 2e-4).mean(), np.median(d), d.max())
+    ps_split, ps_f16 = api.S.psnr(rgb_b, rgb_a), api.S.psnr(rgb_c, rgb_a)
+    assert ps_split > 80 and ps_split > ps_f16 + 15, (ps_split, ps_f16)
+
+
+def test_lerf_fused_split_precision_vs_fp32_stage_path(api, O, manifest):
+    """The fused LeRF passes in NRF_PREC_F16_SPLIT (mlp_lerf_split_mfma.hip) against the oracle-pinned fp32 stage path on identical points: sigma_le to 1e-5 of
+    its scale (the plain fp16 mode: 3e-3), the per-ray weighted sum of normalised embeddings to 2e-5 (4e-3), level-major == row-major input, and end to end against the
+    stage-composed fp32 renderer: embeddings parallel to 1e-6 where both see the same samples."""
+    import ctypes as C
+    Lv, F, T = 16, 8, 12
+    bbox = api.S.LEGO_BBOX
+    e = api.M.CuHashEmbedder("lang_embedder", bbox, Lv, F, T, 16, 128)
+    table = synth.synth_sym(311, (Lv * (1 << T) * F,), np.float32(0.5))
+    e.set_table(table); e.set_primes(np.array(api.S.CU_PRIMES[:3 * Lv], np.int32))
+    blob = synth.blob_from_manifest(manifest["lerf"]).copy()
+    blob[128 * 256:128 * 256 + 256] *= 20.0
+    lerf = api.M.LeRF(32, 2, 256, 768, 128, "lang_model", params=blob)
+    fused = api.R.LeRFRenderer(e, lerf, precision=api.L.NRF_PREC_F16_SPLIT); plain = api.R.LeRFRenderer(e, lerf, fused=False)
+    assert fused.fused and fused.precision_name == "f16x3"
+    K = api.S.lego_K(12, 12); c2w = api.S.pose_spherical(40.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=50, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=bbox)
+    a = fused.Render(12, 12, K, p, c2w=c2w); b = plain.Render(12, 12, K, p, c2w=c2w)
+    rays = host(a.Extras["rays_flat"])
+    z = O.z_vals(rays[:, 6], rays[:, 7], O.linspace(0, 1, 32))
+    pts = O.points(rays[:, :3], rays[:, 3:6], z)
+    ls = ((1 << T) >> 4) << 4
+    emb, keep = O.hash_cu(pts.reshape(-1, 3), O.f32_to_f16(table), np.array(api.S.CU_PRIMES[:3 * Lv], np.int32), np.arange(Lv, dtype=np.int32) * ls,
+                          np.full(Lv, ls, np.int32), np.zeros((Lv, 3), np.float32), bbox, O.hash_cu_scales(Lv, 16, 128), Lv, F)
+    raw = O.lerf(blob, emb); raw[~keep, -1] = 0
+    sig_gpu, x_gpu = fused._sigma_fused(dev(pts))
+    scale = np.abs(raw[:, -1]).max()
+    assert_close(host(sig_gpu).reshape(-1), raw[:, -1], rtol=0, atol=1e-5 * scale, what="sigma_le, split precision")
+    w = np.random.RandomState(0).rand(144, 32).astype(np.float32)
+    acc = torch.empty((144, 768), device="cuda")
+    wd = dev(w)
+    api.L.check(api.L.lib().nrf_lerf_render_embedding_lm(lerf._m, C.c_void_p(x_gpu.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc.data_ptr()), None))
+    ref = (w[:, :, None] * raw[:, :768].reshape(144, 32, 768)).sum(1)
+    assert_close(host(acc), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), what="sum_s w_s normalize(le_s), split precision")
+    # fp32 feature rows (values are fp16 numbers here, so hi + lo carries them exactly): same result as the level-major input
+    x_rows = dev(host(x_gpu).astype(np.float32).transpose(1, 0, 2).reshape(144 * 32, 128))
+    sig_r = torch.empty((144 * 32,), device="cuda")
+    ku8 = dev(keep.astype(np.uint8))
+    api.L.check(api.L.lib().nrf_lerf_sigma(lerf._m, C.c_void_p(x_rows.data_ptr()), C.c_void_p(ku8.data_ptr()), C.c_int64(144 * 32), C.c_void_p(sig_r.data_ptr()), None))
+    assert_exact(host(sig_r), host(sig_gpu).reshape(-1), "sigma_le: row-major == level-major input (split)")
+    acc_r = torch.empty((144, 768), device="cuda")
+    api.L.check(api.L.lib().nrf_lerf_render_embedding(lerf._m, C.c_void_p(x_rows.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc_r.data_ptr()), None))
+    assert_close(host(acc), host(acc_r), rtol=0, atol=1e-5 * np.abs(ref).max(), what="embedding sums differ by the order of the float atomics only")
+    # end to end against the stage-composed fp32 renderer
+    hit = host(b.Outputs.AccMapLE) > 1e-2
+    assert hit.sum() > 20
+    ea, eb = host(a.Outputs.RenderedLangEmbedding)[hit], host(b.Outputs.RenderedLangEmbedding)[hit]
+    assert_close(np.linalg.norm(ea, axis=1), np.ones(hit.sum()), rtol=1e-5, atol=0)
+    # rays whose fine samples fall in the same CDF bins (a 1e-6 sigma difference can move a sample to a neighbouring bin; inside a bin it moves it by ~1e-7)
+    same = (np.abs(host(a.Extras["z_fine"]) - host(b.Extras["z_fine"])).max(1) < 1e-5)[hit]
+    assert same.mean() > 0.8, same.mean()
+    cos = (ea * eb).sum(1)
+    assert cos[same].min() > 1 - 1e-6 and np.median(cos) > 1 - 1e-7, (cos[same].min(), np.median(cos))
+    assert np.abs(host(a.Outputs.AccMapLE) - host(b.Outputs.AccMapLE))[hit][same].max() < 1e-5
+    fused.set_precision(api.L.NRF_PREC_F16_MFMA)                                       # a handle-level switch: the plain mode is the loose one
+    sig16, _ = fused._sigma_fused(dev(pts))
+    assert np.abs(host(sig16).reshape(-1) - raw[:, -1]).max() > 30 * np.abs(host(sig_gpu).reshape(-1) - raw[:, -1]).max()

@@ -8,7 +8,7 @@ H = W = 800
 for precname, prec in (("f16x3", L.NRF_PREC_F16_SPLIT),):
     sc = S.make_hash_scene(mode="cu")
     K = S.lego_K(H, W); c2w = S.pose_spherical(30.0, -30.0, 4.0)
-    for nstreams, chunk in ((1, 131072), (2, 131072), (2, 65536), (3, 65536), (4, 65536)):
+    for nstreams, chunk in ((1, 131072), (2, 131072), (2, 32768), (3, 32768), (4, 32768), (4, 16384)):
         rs = [NeRFRenderer(sc["embedder"], sc["embeddirs"], sc["mlp"]) for _ in range(nstreams)]
         streams = [torch.cuda.Stream() for _ in range(nstreams)]
         rp = S.lego_render_params(sc["bbox"], 64, 128, chunk, prec)
