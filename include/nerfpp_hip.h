@@ -143,6 +143,12 @@ NRF_API int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device,
  * biases [L*3] (`embedder_biases`, :54-59; NULL = zeros).  Host pointers. */
 NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases);
 
+/* The renderer's fast path reads a DENSE image of the grid's coarse levels (every lattice vertex's table entries copied next to each other, baked from the
+ * table at upload; outputs identical to the hashed lookup): `budget_bytes` of it are built, coarse to fine, default 24 GiB of the 288 GB (all 16 levels at
+ * finest 512 take 4.4 GiB).  A training loop re-uploads the table every step and sets 0 (no bake); a renderer leaves the default.  Re-bakes immediately when a
+ * table is present; synchronises `stream`. */
+NRF_API int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream);
+
 /* BaseEmbedderImpl::forward for the hash grid: x [p,3] -> (embedding [p, L*F] fp32, keep_mask [p] u8).
  * d_keep_mask may be NULL. */
 NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, float *d_out, uint8_t *d_keep_mask, void *stream);

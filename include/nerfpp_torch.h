@@ -10,6 +10,8 @@
 //                                                `<name>_biases` (CuHashEmbedder.cpp:24,73-76) so checkpoints round-trip.
 //   HipSHEncoderImpl     : BaseEmbedderImpl      replaces CuSHEncoderImpl (CuSHEncoder.h:6-29) / SHEncoderImpl (NeRF.h:80-132)
 //   HipEmbedderImpl      : BaseEmbedderImpl      replaces EmbedderImpl (NeRF.h:12-31)
+//   TileComm                                     multi-GPU row tiles: RCCL all-gather of per-tile pixels behind the C ABI (no reference counterpart)
+//   HipLeRFPass / HipLeRFRenderer : LeRFRenderer  the LeRF render pass (LeRFRenderer.h:56-132); the subclass needs -DNRFPP_WITH_LERF_RENDERER
 //   HipNeRFRenderer<E, D, TNeRF> : NeRFRenderer<E, D, TNeRF>   overrides the virtuals Render / RenderRays / RunNetwork /
 //                                                RawToOutputs (NeRFRenderer.h:96-158); BatchifyRays (the chunk loop) is inherited.
 //                                                TNeRF is the reference's own NeRFSmall / NeRF module: its parameters are
@@ -232,6 +234,190 @@ struct MlpHandle {
 	void reset(nrf_mlp *n) { nrf_mlp_destroy(m); m = n; }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LeRF render pass (LeRFRenderer.h:56-132, LeRFRenderer.cpp): CuHashEmbedder features -> LeRF head -> sigma_le weights -> rendered CLIP embedding.
+// HipLeRFPass holds everything that does not need the reference's headers (so it links and runs without LeRFRenderer.cpp, which pulls in the external
+// RuCLIP module for `Relevancy`); HipLeRFRenderer below subclasses the reference's LeRFRenderer onto it.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LeRFPassOutputs {                 // LeRFRendererOutputs (LeRFRenderer.h:9-18) without Relevancy (external) -- same member names
+	torch::Tensor LangEmbedding, RenderedLangEmbedding, DispMapLE, AccMapLE, WeightsLE, DepthMapLE;
+};
+
+/// nrf_mlp_small_desc of a LeRF module (LeRF.cpp:3-26) from its parameter shapes, named_parameters() order: sigma_le_net_0..L-1, le_net_0..L-1
+template <class TLeRF>
+inline nrf_mlp_small_desc lerf_desc_of(TLeRF &lerf)
+{
+	std::vector<torch::Tensor> w;
+	for (auto &p : lerf->named_parameters()) w.push_back(p.value());
+	TORCH_CHECK(w.size() >= 2 && w.size() % 2 == 0, "LeRF: expected 2 x num_layers_le bias-free Linear weights");
+	const int nl = (int)w.size() / 2;
+	nrf_mlp_small_desc d{};
+	d.input_ch = (int)w[0].size(1); d.input_ch_views = 0; d.num_layers = nl; d.hidden_dim = (int)w[0].size(0);
+	d.geo_feat_dim = (int)w[nl - 1].size(0) - 1; d.num_layers_color = nl; d.hidden_dim_color = (int)w[2 * nl - 1].size(0);
+	return d;
+}
+
+class HipLeRFPass {
+	HipHashEmbedder LangEmbedFn = nullptr;
+	MlpHandle Mlp;
+	nrf_mlp_small_desc Desc{};
+	int Precision;
+	bool Fused = false, LevelMajor = false;
+public:
+	/// precision of the fused matrix-core passes: NRF_PREC_F16_SPLIT (fp32-grade, as LeRFImpl::forward computes) or NRF_PREC_F16_MFMA
+	explicit HipLeRFPass(HipHashEmbedder lang_embed_fn, int precision = NRF_PREC_F16_SPLIT) : LangEmbedFn(lang_embed_fn), Precision(precision) {}
+
+	int GetLangEmbedDim() const { return Desc.hidden_dim_color; }
+	bool IsFused() const { return Fused; }
+
+	/// (Re)read the LeRF head's parameters; call after construction, checkpoint load or an optimizer step.
+	void SyncWeights(const nrf_mlp_small_desc &d, const std::vector<float> &blob)
+	{
+		TORCH_CHECK((int64_t)blob.size() == nrf_mlp_lerf_param_count(&d), "LeRF parameter count mismatch");
+		nrf_mlp *m = nullptr;
+		check(nrf_mlp_lerf_create(&d, blob.data(), 0, current_stream(), &m), "nrf_mlp_lerf_create");
+		Mlp.reset(m); Desc = d;
+		LangEmbedFn->Sync();
+		Fused = nrf_lerf_mfma_available(m) != 0;
+		if (Fused) check(nrf_lerf_set_precision(m, Precision), "nrf_lerf_set_precision");
+		LevelMajor = Fused && LangEmbedFn->Mode == NRF_HASH_CU && LangEmbedFn->NLevels == 16 && LangEmbedFn->NFeaturesPerLevel == 8;
+	}
+	template <class TLeRF> void SyncWeights(TLeRF &lerf) { SyncWeights(lerf_desc_of(lerf), parameter_blob(lerf)); }
+
+	/// LeRFRenderer::RunLENetwork (LeRFRenderer.cpp:5-25): [N,S,3] -> [N,S,E+1] in fp32, sigma_le zeroed where the embedder's keep_mask is false
+	torch::Tensor RunLENetwork(torch::Tensor inputs)
+	{
+		auto pts = dev_f32(inputs);
+		auto flat = pts.view({-1, 3});
+		auto [emb, keep] = LangEmbedFn->forward(flat);
+		auto out = torch::empty({flat.size(0), (int64_t)nrf_mlp_output_dims(Mlp.m)}, emb.options());
+		check(nrf_mlp_forward(Mlp.m, emb.data_ptr<float>(), flat.size(0), NRF_PREC_F32, out.data_ptr<float>(), current_stream()), "nrf_mlp_forward");
+		out.index_put_({~keep, -1}, 0);
+		auto sz = pts.sizes().vec(); sz.back() = out.size(1);
+		return out.view(sz);
+	}
+
+	/// LeRFRenderer::RawToLEOutputs (LeRFRenderer.cpp:27-82) without Relevancy
+	LeRFPassOutputs RawToLEOutputs(torch::Tensor raw_le, torch::Tensor z_vals_le, torch::Tensor rays_d, const int lang_embed_dim = 768, const float raw_noise_std = 0.f)
+	{
+		TORCH_CHECK(raw_noise_std == 0.f, "RawToLEOutputs: raw_noise_std > 0 is the training-time noise branch (torch::randn_like); not built");
+		auto raw = dev_f32(raw_le); auto z = dev_f32(z_vals_le); auto d = dev_f32(rays_d);
+		const int64_t n = raw.size(0); const int s = (int)raw.size(1), c = (int)raw.size(2);
+		LeRFPassOutputs o;
+		using torch::indexing::Slice;
+		o.LangEmbedding = raw.index({"...", Slice(0, lang_embed_dim)});
+		o.WeightsLE = torch::empty({n, s}, raw.options()); o.DepthMapLE = torch::empty({n}, raw.options()); o.DispMapLE = torch::empty({n}, raw.options()); o.AccMapLE = torch::empty({n}, raw.options());
+		check(nrf_raw2weights(raw.data_ptr<float>(), c, lang_embed_dim, z.data_ptr<float>(), d.data_ptr<float>(), 3, n, s, o.WeightsLE.data_ptr<float>(), o.DepthMapLE.data_ptr<float>(),
+			o.DispMapLE.data_ptr<float>(), o.AccMapLE.data_ptr<float>(), current_stream()), "nrf_raw2weights");
+		o.RenderedLangEmbedding = torch::empty({n, (int64_t)lang_embed_dim}, raw.options());
+		check(nrf_render_clip_embedding(raw.data_ptr<float>(), c, lang_embed_dim, o.WeightsLE.data_ptr<float>(), n, s, o.RenderedLangEmbedding.data_ptr<float>(), current_stream()), "nrf_render_clip_embedding");
+		return o;
+	}
+
+private:
+	/// one pass of the fused path over [n, s] depths: sigma_le -> weights (-> rendered embedding)
+	LeRFPassOutputs FusedPass(torch::Tensor rays, torch::Tensor z, torch::Tensor rays_d, bool want_embedding)
+	{
+		const int64_t n = z.size(0); const int s = (int)z.size(1); const int stride = (int)rays.size(1);
+		auto opt = rays.options();
+		auto pts = torch::empty({n * s, 3}, opt);
+		check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
+		auto sig = torch::empty({n, s}, opt);
+		torch::Tensor x, keep;
+		if (LevelMajor) {
+			x = torch::empty({16, n * s, 8}, opt.dtype(torch::kFloat16)); keep = torch::empty({n * s}, opt.dtype(torch::kUInt8));
+			check(nrf_hash_encode_lm_f16(LangEmbedFn->GetHandle(), pts.data_ptr<float>(), n * s, x.data_ptr(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16");
+			check(nrf_lerf_sigma_lm(Mlp.m, x.data_ptr(), keep.data_ptr<uint8_t>(), n * s, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma_lm");
+		} else {
+			torch::Tensor kb;
+			std::tie(x, kb) = LangEmbedFn->forward(pts);
+			keep = kb.to(torch::kUInt8);
+			check(nrf_lerf_sigma(Mlp.m, x.data_ptr<float>(), keep.data_ptr<uint8_t>(), n * s, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma");
+		}
+		LeRFPassOutputs o;
+		o.WeightsLE = torch::empty({n, s}, opt); o.DepthMapLE = torch::empty({n}, opt); o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt);
+		check(nrf_raw2weights(sig.data_ptr<float>(), 1, 0, z.data_ptr<float>(), rays_d.data_ptr<float>(), 3, n, s, o.WeightsLE.data_ptr<float>(), o.DepthMapLE.data_ptr<float>(),
+			o.DispMapLE.data_ptr<float>(), o.AccMapLE.data_ptr<float>(), current_stream()), "nrf_raw2weights");
+		if (want_embedding) {
+			const int E = GetLangEmbedDim();
+			auto acc = torch::empty({n, (int64_t)E}, opt);
+			if (LevelMajor) check(nrf_lerf_render_embedding_lm(Mlp.m, x.data_ptr(), o.WeightsLE.data_ptr<float>(), n, s, acc.data_ptr<float>(), current_stream()), "nrf_lerf_render_embedding_lm");
+			else check(nrf_lerf_render_embedding(Mlp.m, x.data_ptr<float>(), o.WeightsLE.data_ptr<float>(), n, s, acc.data_ptr<float>(), current_stream()), "nrf_lerf_render_embedding");
+			auto ones = torch::ones({n, 1}, opt);
+			o.RenderedLangEmbedding = torch::empty({n, (int64_t)E}, opt);          // the final normalize of RenderCLIPEmbedding (LeRFRenderer.h:53)
+			check(nrf_render_clip_embedding(acc.data_ptr<float>(), E, E, ones.data_ptr<float>(), n, 1, o.RenderedLangEmbedding.data_ptr<float>(), current_stream()), "nrf_render_clip_embedding");
+		}
+		return o;
+	}
+
+public:
+	/// LeRFRenderer::RenderRays (LeRFRenderer.cpp:85-187), deterministic path (Perturb = 0, RawNoiseStd = 0, ThinRay): the fused matrix-core passes when the
+	/// sample counts are multiples of 32 (a wave's 32-point tile lies inside one ray), the fp32 stage path otherwise.  z_fine (optional) receives the fine depths.
+	LeRFPassOutputs RenderRays(torch::Tensor ray_batch, const int n_samples, const bool lin_disp = false, const int n_importance = 0, const bool return_weights = true,
+		torch::Tensor *z_fine = nullptr)
+	{
+		auto rays = dev_f32(ray_batch);
+		const int64_t n = rays.size(0); const int stride = (int)rays.size(1);
+		const int s = n_samples, ni = n_importance;
+		using torch::indexing::Slice;
+		auto opt = rays.options();
+		auto t = torch::linspace(0.f, 1.f, s, torch::kFloat).to(rays.device());
+		auto z = torch::empty({n, s}, opt);
+		check(nrf_z_vals(rays.data_ptr<float>(), stride, n, t.data_ptr<float>(), s, lin_disp, z.data_ptr<float>(), current_stream()), "nrf_z_vals");
+		auto rays_d = rays.index({Slice(), Slice(3, 6)}).contiguous();
+		const bool fused = Fused && s % 32 == 0 && (ni == 0 || (s + ni) % 32 == 0);
+		auto stage = [&](torch::Tensor zz) {
+			auto pts = torch::empty({n, zz.size(1), 3}, opt);
+			check(nrf_points(rays.data_ptr<float>(), stride, zz.data_ptr<float>(), n, (int)zz.size(1), pts.data_ptr<float>(), current_stream()), "nrf_points");
+			return RawToLEOutputs(RunLENetwork(pts), zz, rays_d, GetLangEmbedDim());
+		};
+		LeRFPassOutputs out = fused ? FusedPass(rays, z, rays_d, ni == 0) : stage(z);
+		if (ni > 0) {
+			auto u = torch::linspace(0.f, 1.f, ni, torch::kFloat).to(rays.device());
+			auto zf = torch::empty({n, (int64_t)(s + ni)}, opt);
+			check(nrf_fine_depths(z.data_ptr<float>(), out.WeightsLE.data_ptr<float>(), n, s, u.data_ptr<float>(), ni, 8, zf.data_ptr<float>(), current_stream()), "nrf_fine_depths");
+			out = fused ? FusedPass(rays, zf, rays_d, true) : stage(zf);
+			if (z_fine) *z_fine = zf;
+		}
+		if (!return_weights) { out.WeightsLE = torch::Tensor(); out.LangEmbedding = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }      // LeRFRenderer.cpp:180-185
+		return out;
+	}
+
+	/// LeRFRenderer::Render (LeRFRenderer.cpp:265-330) for a pose or an explicit ray batch: rays, AABB clipping, the chunk loop, Near / Far.  row0 / rows:
+	/// a row tile of the frame (multi-GPU sharding).  Returns the concatenated per-ray outputs (the reference does not reshape them either).
+	LeRFPassOutputs Render(const int h, const int w, torch::Tensor k, torch::Tensor bounding_box, const int n_samples, const int n_importance, const int chunk,
+		torch::Tensor c2w, const bool use_viewdirs = true, const bool lin_disp = false, const bool return_weights = true, float *near_out = nullptr, float *far_out = nullptr,
+		int row0 = 0, int rows = -1)
+	{
+		if (rows < 0) rows = h - row0;
+		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
+		auto K = host_floats(k), M = host_floats(c2w.index({torch::indexing::Slice(torch::indexing::None, 3), torch::indexing::Slice(torch::indexing::None, 4)}));
+		auto o = torch::empty({(int64_t)rows * w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), d = torch::empty_like(o);
+		check(nrf_get_rays(h, w, K.data(), M.data(), row0, rows, o.data_ptr<float>(), d.data_ptr<float>(), nullptr, current_stream()), "nrf_get_rays");
+		const int64_t n = o.size(0);
+		const int stride = use_viewdirs ? 11 : 8;
+		auto bb = host_floats(bounding_box);
+		auto rays_ = torch::empty({n, stride}, o.options());
+		check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, use_viewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
+		std::vector<torch::Tensor> e, w_, dep, disp, acc;
+		for (int64_t i = 0; i < n; i += chunk) {
+			auto part = RenderRays(rays_.index({torch::indexing::Slice(i, std::min<int64_t>(i + chunk, n))}), n_samples, lin_disp, n_importance, return_weights);
+			if (part.RenderedLangEmbedding.defined()) e.push_back(part.RenderedLangEmbedding);
+			if (part.WeightsLE.defined()) w_.push_back(part.WeightsLE);
+			dep.push_back(part.DepthMapLE); disp.push_back(part.DispMapLE); acc.push_back(part.AccMapLE);
+		}
+		LeRFPassOutputs out;
+		if (!e.empty()) out.RenderedLangEmbedding = torch::cat(e, 0);
+		if (!w_.empty()) out.WeightsLE = torch::cat(w_, 0);
+		out.DepthMapLE = torch::cat(dep, 0); out.DispMapLE = torch::cat(disp, 0); out.AccMapLE = torch::cat(acc, 0);
+		float nr = 0.f, fr = 0.f;
+		check(nrf_near_far_range(rays_.data_ptr<float>(), n, stride, &nr, &fr, current_stream()), "nrf_near_far_range");
+		if (near_out) *near_out = nr;
+		if (far_out) *far_out = fr;
+		return out;
+	}
+};
+
 #ifdef NRFPP_WITH_REFERENCE
 // ---------------------------------------------------------------------------------------------------------------------
 // The renderer: NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> with its virtuals routed to the HIP path.
@@ -433,3 +619,57 @@ public:
 #endif  // NRFPP_WITH_REFERENCE
 
 }  // namespace nrfpp
+
+#ifdef NRFPP_WITH_LERF_RENDERER
+// ---------------------------------------------------------------------------------------------------------------------
+// HipLeRFRenderer : LeRFRenderer (LeRFRenderer.h:56-132).  Needs the reference's LeRFRenderer.h on the include path and LeRFRenderer.cpp in the link (the
+// base class's vtable and its Render / BatchifyRays live there; that unit includes RuCLIPProcessor.h, LeRFRenderer.cpp:2, for `Relevancy`, :79 -- the external
+// RuCLIP module, which is why this class can only be COMPILED, not linked, where RuCLIP is absent).  The base keeps a null CuHashEmbedder: every path that would
+// touch it (RunLENetwork) is overridden.  Outputs.Relevancy is left undefined here; callers that want it apply RuCLIP's Relevancy(RenderedLangEmbedding,
+// positives, negatives) to the result, as LeRFRenderer.cpp:79 does.
+// ---------------------------------------------------------------------------------------------------------------------
+#include "LeRFRenderer.h"
+
+namespace nrfpp {
+
+class HipLeRFRenderer : public LeRFRenderer {
+	HipLeRFPass Pass;
+
+	static LeRFRendererOutputs to_ref(const LeRFPassOutputs &p)
+	{
+		LeRFRendererOutputs o;
+		o.LangEmbedding = p.LangEmbedding; o.RenderedLangEmbedding = p.RenderedLangEmbedding; o.DispMapLE = p.DispMapLE; o.AccMapLE = p.AccMapLE;
+		o.WeightsLE = p.WeightsLE; o.DepthMapLE = p.DepthMapLE;
+		return o;
+	}
+protected:
+	torch::Tensor RunLENetwork(torch::Tensor inputs, LeRF lerf, CuHashEmbedder lang_embed_fn) override { return Pass.RunLENetwork(inputs); }
+	LeRFRendererOutputs RawToLEOutputs(torch::Tensor raw_le, torch::Tensor z_vals_le, torch::Tensor rays_d, const int lang_embed_dim = 768, const float raw_noise_std = 0.f) override
+	{
+		return to_ref(Pass.RawToLEOutputs(raw_le, z_vals_le, rays_d, lang_embed_dim, raw_noise_std));
+	}
+public:
+	HipLeRFRenderer(HipHashEmbedder lang_embed_fn, LeRF lerf, torch::Tensor lerf_positives = torch::Tensor(), torch::Tensor lerf_negatives = torch::Tensor(),
+		int precision = NRF_PREC_F16_SPLIT) : LeRFRenderer(CuHashEmbedder(nullptr), lerf, lerf_positives, lerf_negatives), Pass(lang_embed_fn, precision) { Pass.SyncWeights(Lerf); }
+
+	/// after a checkpoint load or an optimizer step on the LeRF head / the language hash grid
+	void SyncWeights() { Pass.SyncWeights(Lerf); }
+
+	/// LeRFRenderer.cpp:85-187.  The deterministic render path goes to the fused matrix-core passes; the RNG branches (Perturb, RawNoiseStd, cone rays,
+	/// stochastic preconditioning) take the inherited torch-op path, whose RunLENetwork / RawToLEOutputs calls land on the overrides above.
+	LeRFRenderResult RenderRays(torch::Tensor ray_batch, torch::Tensor cone_angle, const int n_samples, const bool return_raw = false, const bool lin_disp = false,
+		const float perturb = 0.f, const int n_importance = 0, const bool white_bkgr = false, const float raw_noise_std = 0.f, const float stochastic_preconditioning_alpha = 0.f,
+		torch::Tensor bounding_box = torch::Tensor(), const bool return_weights = true) override
+	{
+		const bool rng = perturb > 0.f || raw_noise_std > 0.f || stochastic_preconditioning_alpha > 0.f || (cone_angle.defined() && cone_angle.numel() != 0);
+		if (rng || return_raw)
+			return LeRFRenderer::RenderRays(ray_batch, cone_angle, n_samples, return_raw, lin_disp, perturb, n_importance, white_bkgr, raw_noise_std,
+				stochastic_preconditioning_alpha, bounding_box, return_weights);
+		LeRFRenderResult res;
+		res.Outputs = to_ref(Pass.RenderRays(ray_batch, n_samples, lin_disp, n_importance, return_weights));
+		return res;
+	}
+};
+
+}  // namespace nrfpp
+#endif  // NRFPP_WITH_LERF_RENDERER

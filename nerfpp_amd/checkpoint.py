@@ -39,7 +39,8 @@ def blob(params):
 
 
 def LoadCheckpoint(path):
-    """NeRFExecutor.h:540-566: whichever of the four module files exist + the start step."""
+    """NeRFExecutor.h:540-566: whichever of the four module files exist + the start step + the Adam state; `would_restore` is the reference's own
+    existence condition (:541-546) -- when False its executor ignores the directory and calls Initialize()."""
     out = {}
     for key, fn in (("embedder", "embedder_checkpoint.pt"), ("model", "model_checkpoint.pt"), ("lang_embedder", "lang_embedder_checkpoint.pt"),
                     ("lang_model", "lang_model_checkpoint.pt")):
@@ -49,6 +50,10 @@ def LoadCheckpoint(path):
     f = os.path.join(path, "start_checkpoint.pt")
     if os.path.exists(f):
         out["start"] = int(load_tensor(f).reshape(-1)[0])
+    f = os.path.join(path, "optimizer_checkpoint.pt")
+    if os.path.exists(f):
+        out["optimizer"] = load_adam(f)
+    out["would_restore"] = WouldRestore(path, use_nerf=True, use_lerf=("lang_model" in out))
     return out
 
 
@@ -96,11 +101,90 @@ def save_tensor(path, value):
     torch.jit.script(m).save(path)
 
 
-def SaveCheckpoint(path, embedder=None, embedder_buffers=None, model=None, global_step=0):
-    """NeRFExecutor.h:1055-1070 (embedder + model + start step; the optimizer state is not interchanged)."""
+# ------------------------------------------------------------------------------------------------
+# torch::optim::Adam archives (torch::save(*Optimizer, "optimizer_checkpoint.pt"), NeRFExecutor.h:1067; restored at :565)
+#
+# LibTorch's optimizer serialisation (torch/csrc/api/include/torch/optim/serialize.h) writes a module archive
+#     pytorch_version = "1.5.0"
+#     state/<key>/{step (int), exp_avg, exp_avg_sq}              one sub-archive per parameter THAT HAS STATE, <key> = a decimal number
+#     param_groups/{param_groups/size, param_groups/<g>/{params/size, params/<i> = <key>, options/{lr, betas, eps, weight_decay, amsgrad}}}
+# and on load hands state <key> to the optimizer's i-th parameter of group g -- the keys themselves (addresses in the writing process)
+# only have to be distinct numbers.  The attribute names are not Python identifiers, so the archive is assembled with the same low-level
+# module builder TorchScript uses instead of torch.jit.script.
+# ------------------------------------------------------------------------------------------------
+class _Archive(torch.nn.Module):
+    pass
+
+
+def _archive(attrs, subs=()):
+    """OutputArchive::write for a list of (name, tensor | int | float | bool | str | tuple) and sub-archives (name, archive)."""
+    b = torch._C.ConcreteModuleTypeBuilder(_Archive)
+    for name, v in attrs:
+        if torch.is_tensor(v):
+            b.add_attribute(name, torch._C.TensorType.get(), True, False)
+        else:
+            b.add_attribute(name, torch._C._jit_try_infer_type(v).type(), False, False)
+    for name, (ct, _) in subs:
+        b.add_module(name, ct)
+    ct = b.build()
+    cm = torch._C._create_module_with_type(ct.jit_type)
+    for name, v in attrs:
+        cm.setattr(name, v)
+    for name, (_, sub) in subs:
+        cm.setattr(name, sub)
+    return ct, cm
+
+
+def save_adam(path, moments, step, lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, amsgrad=False):
+    """Write an archive torch::load(torch::optim::Adam&) accepts.  moments: per parameter, in the optimizer's parameter order (NeRFExecutor.h:508-535:
+    embedder parameters, then the model's), a pair (exp_avg, exp_avg_sq) of arrays shaped like the parameter, or None for a parameter without state."""
+    keys = [str(1000 + i) for i in range(len(moments))]
+    states = []
+    for k, mv in zip(keys, moments):
+        if mv is None:
+            continue
+        m, v = (torch.as_tensor(np.ascontiguousarray(a, np.float32)) for a in mv)
+        states.append((k, _archive([("step", int(step)), ("exp_avg", m), ("exp_avg_sq", v)])))
+    opts = _archive([("lr", float(lr)), ("betas", (float(betas[0]), float(betas[1]))), ("eps", float(eps)), ("weight_decay", float(weight_decay)), ("amsgrad", bool(amsgrad))])
+    g0 = _archive([("params/size", torch.tensor(len(keys)))] + [(f"params/{i}", k) for i, k in enumerate(keys)], [("options", opts)])
+    groups = _archive([("param_groups/size", torch.tensor(1))], [("param_groups/0", g0)])
+    top = _archive([("pytorch_version", "1.5.0")], [("state", _archive([], states)), ("param_groups", groups)])
+    top[1].save(path)
+
+
+def load_adam(path):
+    """-> dict(step, lr, betas, eps, moments = [(exp_avg, exp_avg_sq) | None per parameter of group 0, in order])."""
+    c = torch.jit.load(path, map_location="cpu")._c
+    state, g0 = c.getattr("state"), c.getattr("param_groups").getattr("param_groups/0")
+    n = int(g0.getattr("params/size"))
+    moments, step = [], 0
+    for i in range(n):
+        k = g0.getattr(f"params/{i}")
+        if state.hasattr(k):
+            st = state.getattr(k)
+            moments.append((st.getattr("exp_avg").detach().numpy().copy(), st.getattr("exp_avg_sq").detach().numpy().copy()))
+            step = int(st.getattr("step"))
+        else:
+            moments.append(None)
+    o = g0.getattr("options")
+    return dict(step=step, lr=float(o.getattr("lr")), betas=tuple(o.getattr("betas")), eps=float(o.getattr("eps")), moments=moments)
+
+
+def WouldRestore(path, use_nerf=True, use_lerf=False):
+    """The existence condition under which NeRFExecutor::Initialize restores instead of initialising (NeRFExecutor.h:541-546)."""
+    ex = lambda f: os.path.exists(os.path.join(path, f))
+    return (ex("start_checkpoint.pt") and ex("optimizer_checkpoint.pt") and (ex("model_checkpoint.pt") or not use_nerf) and
+            (ex("lang_embedder_checkpoint.pt") or not use_lerf))
+
+
+def SaveCheckpoint(path, embedder=None, embedder_buffers=None, model=None, global_step=0, optimizer=None):
+    """NeRFExecutor.h:1055-1070: embedder + model + start step + optimizer.  `optimizer`: dict(moments, step, lr[, betas, eps]) for save_adam -- without
+    optimizer_checkpoint.pt the reference's executor ignores the directory and initialises afresh (:541-546)."""
     os.makedirs(path, exist_ok=True)
     if embedder is not None:
         save_module(os.path.join(path, "embedder_checkpoint.pt"), embedder, embedder_buffers)
     if model is not None:
         save_module(os.path.join(path, "model_checkpoint.pt"), model)
     save_tensor(os.path.join(path, "start_checkpoint.pt"), np.full((1,), int(global_step), np.int64))
+    if optimizer is not None:
+        save_adam(os.path.join(path, "optimizer_checkpoint.pt"), **optimizer)

@@ -340,8 +340,19 @@ int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
     }
     h->primes_set = true;
     h->fast_valid = false;
+    // model-load time: the table upload may still be in flight on a caller's (non-blocking) stream, and the bake below runs on the default one
+    NRF_HIP(hipDeviceSynchronize());
     if (hash_fast_supported(h)) NRF_TRY(hash_fast_prepare(h, h->dense_budget, nullptr));
     return NRF_OK;
+}
+
+int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
+{
+    NRF_CHECK_ARG(h && budget_bytes >= 0, "nrf_hash_set_dense_budget: bad argument");
+    h->dense_budget = (size_t)budget_bytes;
+    h->fast_valid = false;
+    if (!hash_fast_supported(h)) return NRF_OK;           // takes effect at the next table / primes upload
+    return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
 }
 
 int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream)

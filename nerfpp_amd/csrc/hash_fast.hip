@@ -173,6 +173,11 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
             total += entries; nb = l + 1;
         }
     }
+    if (nb == 0 && h->d_fast) {          // budget 0 (a training loop): give the image back
+        NRF_HIP(hipStreamSynchronize(st));
+        NRF_HIP(hipFree(h->d_fast));
+        h->d_fast = nullptr; h->fast_bytes = 0;
+    }
     if (nb > 0) {
         if (h->fast_bytes < (size_t)total * entry_bytes) {
             if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
@@ -337,14 +342,6 @@ int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int va
 using namespace nrf;
 
 // Debug / tuning entry (not part of the public header): level-major encode of explicit points with a kernel variant.
-// Debug / tuning entry: set the dense-image byte budget (0 disables baking) and rebuild.
-extern "C" NRF_API int nrf_dbg_hash_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
-{
-    NRF_CHECK_ARG(h, "nrf_dbg_hash_dense_budget: null handle");
-    h->dense_budget = (size_t)budget_bytes;
-    h->fast_valid = false;
-    return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
-}
 
 extern "C" NRF_API int nrf_dbg_hash_lm(const nrf_hash *h, const float *d_x, int64_t p, int variant, int level_lo, int level_hi, void *d_feats, uint8_t *d_keep, void *stream)
 {

@@ -111,6 +111,11 @@ class _HashBase(BaseEmbedder):
     def table_elems(self):
         return self.NLevels * (1 << self.Log2HashmapSize) * self.NFeaturesPerLevel
 
+    def set_dense_budget(self, nbytes):
+        """Bytes of baked dense image for the coarse levels of the renderer's fast path (nrf_hash_set_dense_budget; 0 = every level hashed: what a
+        training loop, which re-uploads the table every step, wants)."""
+        L.check(L.lib().nrf_hash_set_dense_budget(self._h, C.c_int64(int(nbytes)), _stream()))
+
     def set_table(self, table):
         """fp32 embedding table in the reference's parameter layout (numpy or torch, host or device)."""
         if torch.is_tensor(table) and table.is_cuda:
@@ -141,11 +146,6 @@ class CuHashEmbedder(_HashBase):
     """CUDA hash grid, CuHashEmbedderImpl (CuHashEmbedder.h:8-63, CuHashEmbedder.cpp, CuHashEmbedder.cu).
     Table `embedder_embeddings` [L*2^T, F] fp32 master (cast to fp16 once at upload); per-level primes/biases."""
     mode = L.NRF_HASH_CU
-
-    def set_dense_budget(self, nbytes):
-        """Tuning knob: bytes of baked dense image for the coarse levels of the fast path (0 = all levels hashed)."""
-        lib = L.lib()
-        L.check(lib.nrf_dbg_hash_dense_budget(self._h, C.c_int64(int(nbytes)), _stream()))
 
     def set_primes(self, primes, biases=None):
         p = np.ascontiguousarray(primes, np.int32).reshape(-1)

@@ -7,6 +7,7 @@ Gradients flow through the FINE pass only (z_samples are detached, NeRFRenderer.
 PyTorch owns the buffers (fp32 master parameters, Adam moments) and nothing else: every arithmetic step is a call into
 libnerfpp_hip.so on the current HIP stream.
 """
+import copy
 import ctypes as C
 import math
 
@@ -33,6 +34,7 @@ class Trainer:
         self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
         self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
         self.lr, self.betas, self.eps, self.t = float(learning_rate), betas, float(eps), 0
+        self.learning_rate0 = float(learning_rate)          # Params.LearningRate: the base of the exponential decay (NeRFExecutor.h:992-996)
         # TotalVariationLoss of the LibTorch HashEmbedder, weight 1e-6 in the reference for the first half of training (NeRFExecutor.h:896-913)
         self.tv_loss_weight, self.seed = float(tv_loss_weight), int(seed)
         self.tv_loss = torch.zeros((1,), device=dev)
@@ -50,8 +52,9 @@ class Trainer:
         self.grad_sync = grad_sync          # callable(g_table, g_blob) reducing the gradients across data-parallel ranks in place, or None
         self._hws = None
         self._ws = None
-        if isinstance(embedder, CuHashEmbedder):
-            embedder.set_dense_budget(0)        # the baked dense pyramid of the render fast path would be re-baked after every step
+        # the baked dense pyramid of the render fast path would be re-baked (GBs, with a stream synchronisation) after every step's table upload:
+        # off for ANY hash embedder -- the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
+        embedder.set_dense_budget(0)
         self._push_params()
 
     def _push_params(self):
@@ -158,17 +161,23 @@ class Trainer:
             L.check(L.lib().nrf_hash_tv_loss(e._h, _ptr(self.table), level, mv.ctypes.data_as(C.c_void_p), cube, C.c_float(self.tv_loss_weight), _ptr(self.tv_loss),
                                              _ptr(self.g_table), _stream()))
 
-    def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams, cone_angle=None):
-        """Optimizer->zero_grad(); Render; huber; backward; Optimizer->step() (NeRFExecutor.h:866-985)."""
-        p = render_params
-        if not p.ThinRay and cone_angle is None:
+    def step(self, rays_o, rays_d, target, render_params: NeRFRenderParams, cone_angle=None, global_step=None, n_iters=None, lrate_decay=None):
+        """Optimizer->zero_grad(); Render; huber; backward; Optimizer->step(); learning-rate decay (NeRFExecutor.h:866-996).
+        global_step / n_iters / lrate_decay (the executor's loop counter, Params.NIters and Params.LRateDecay): when given, the TV regulariser is added only
+        for global_step < n_iters / 2 (:896-913) and after the step lr = learning_rate * 0.1^(global_step / (lrate_decay * 1000)) (:992-996).
+        The counter-based draws of the stochastic branches are keyed by (Seed, step): every iteration draws afresh, as the reference does from torch's global
+        generator.  The caller's render_params object is not modified."""
+        if not render_params.ThinRay and cone_angle is None:
             raise L.NrfError("Trainer.step: ThinRay = False needs the batch's cone_angle (GetRayBatch / GetRays)")
+        p = copy.copy(render_params)
         p.ReturnRaw, p.KeepIntermediates = True, True
+        p.Seed = (int(render_params.Seed) + 0x9E3779B97F4A7C15 * self.t) & ((1 << 64) - 1)
         cone = None if p.ThinRay else cone_angle
         res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))
         s_out = p.NSamples + p.NImportance
         loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
-        self.add_tv_loss()
+        if global_step is None or n_iters is None or global_step < n_iters / 2:
+            self.add_tv_loss()
         if self.grad_sync is not None:                     # data-parallel replicas: mean of the ranks' gradients (nerfpp_amd/dist.py::GradSync)
             self.grad_sync(self.g_table, self.g_blob)
         self.t += 1
@@ -177,7 +186,78 @@ class Trainer:
             L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
                                           C.c_float(self.eps), self.t, _stream()))
         self._push_params()
+        if global_step is not None and lrate_decay:
+            self.lr = self.learning_rate0 * math.pow(0.1, float(global_step) / (float(lrate_decay) * 1000.0))      # :992-996
         return loss_mse, res
+
+    # ---- checkpoint interchange (NeRFExecutor::SaveCheckpoint / the restore branch of Initialize, NeRFExecutor.h:1055-1070, :540-566) ----
+    def _param_layout(self):
+        """[(name, offset, shape)] of the embedder's and the model's parameters in the reference's optimizer order (embedder first, :508-535)."""
+        e, out = self.embedder, []
+        rows, F = 1 << e.Log2HashmapSize, e.NFeaturesPerLevel
+        if e.mode == L.NRF_HASH_NGP:
+            emb = [(f"{e.name}_embeddings_{l}.weight", l * rows * F, (rows, F)) for l in range(e.NLevels)]
+        else:
+            emb = [(f"{e.name}_embeddings", 0, (rows * e.NLevels, F))]
+        d, off, mlp = self.mlp.desc, 0, []
+        for l in range(d.num_layers):
+            o, i = ((1 + d.geo_feat_dim) if l == d.num_layers - 1 else d.hidden_dim), (d.input_ch if l == 0 else d.hidden_dim)
+            mlp.append((f"model_sigma_net_{l}.weight", off, (o, i))); off += o * i
+        for l in range(d.num_layers_color):
+            o, i = (3 if l == d.num_layers_color - 1 else d.hidden_dim_color), ((d.input_ch_views + d.geo_feat_dim) if l == 0 else d.hidden_dim_color)
+            mlp.append((f"model_color_net_{l}.weight", off, (o, i))); off += o * i
+        assert off == self.blob.numel()
+        return emb, mlp
+
+    def SaveCheckpoint(self, path, global_step=0):
+        """embedder_checkpoint.pt, model_checkpoint.pt, start_checkpoint.pt and optimizer_checkpoint.pt as the reference writes them: its executor restores
+        from such a directory (all four must exist, :541-546), Adam moments and step included."""
+        from . import checkpoint as CK
+        from collections import OrderedDict
+        emb, mlp = self._param_layout()
+        cut = lambda t, off, shape: t[off:off + int(np.prod(shape))].reshape(shape).detach().cpu().numpy()
+        bufs = None
+        if self.embedder.mode == L.NRF_HASH_CU:
+            e = self.embedder
+            ls = ((1 << e.Log2HashmapSize) >> 4) << 4
+            bufs = OrderedDict([(f"{e.name}_primes", np.asarray(e.Primes, np.int32).reshape(e.NLevels, 1, 3)),
+                                (f"{e.name}_biases", (np.zeros((e.NLevels, 3), np.float32) if e.Biases is None else np.asarray(e.Biases, np.float32).reshape(e.NLevels, 3))),
+                                (f"{e.name}_feat_local_size", np.full(e.NLevels, ls, np.int32)), (f"{e.name}_feat_local_idx", (np.arange(e.NLevels) * ls).astype(np.int32))])
+        moments = None if self.t == 0 else \
+            [(cut(self.m_table, o, sh), cut(self.v_table, o, sh)) for _, o, sh in emb] + [(cut(self.m_blob, o, sh), cut(self.v_blob, o, sh)) for _, o, sh in mlp]
+        if moments is None:
+            moments = [None] * (len(emb) + len(mlp))
+        CK.SaveCheckpoint(path, embedder=OrderedDict((n, cut(self.table, o, sh)) for n, o, sh in emb), embedder_buffers=bufs,
+                          model=OrderedDict((n, cut(self.blob, o, sh)) for n, o, sh in mlp), global_step=global_step,
+                          optimizer=dict(moments=moments, step=self.t, lr=self.lr, betas=self.betas, eps=self.eps))
+
+    def LoadCheckpoint(self, path):
+        """Restore parameters, Adam moments / step / lr and return the start step -- only under the reference's own condition (:541-546: start, optimizer and
+        model files all present); otherwise nothing is touched and None is returned (the reference then initialises afresh)."""
+        from . import checkpoint as CK
+        if not CK.WouldRestore(path):
+            return None
+        ck = CK.LoadCheckpoint(path)
+        emb, mlp = self._param_layout()
+        dev = self.table.device
+        put = lambda dst, off, a: dst[off:off + a.size].copy_(torch.as_tensor(np.ascontiguousarray(a, np.float32).reshape(-1)).to(dev))
+        if "embedder" in ck:
+            for n, o, sh in emb:
+                put(self.table, o, ck["embedder"][n])
+        for n, o, sh in mlp:
+            put(self.blob, o, ck["model"][n])
+        opt = ck["optimizer"]
+        assert len(opt["moments"]) == len(emb) + len(mlp), "optimizer_checkpoint.pt does not match this model's parameter list"
+        for (n, o, sh), mv in zip(emb + mlp, opt["moments"]):
+            m_dst, v_dst = (self.m_table, self.v_table) if (n, o, sh) in emb else (self.m_blob, self.v_blob)
+            if mv is None:
+                m_dst[o:o + int(np.prod(sh))].zero_(); v_dst[o:o + int(np.prod(sh))].zero_()
+            else:
+                put(m_dst, o, mv[0]); put(v_dst, o, mv[1])
+        self.t, self.lr = int(opt["step"]), float(opt["lr"])
+        self.betas, self.eps = tuple(opt["betas"]), float(opt["eps"])
+        self._push_params()
+        return ck.get("start", 0)
 
     @staticmethod
     def psnr(mse):

@@ -16,6 +16,8 @@
 #         They are image I/O for the caller (NeRFExecutor::RenderPath), not on the
 #         render path; OpenCV is absent from this image.  Every line of
 #         Render/BatchifyRays/RenderRays/RunNetwork/RawToOutputs compiles unmodified.
+#       - LeRFRenderer.h goes through the same temp dir UNCHANGED, only so that its
+#         #include "NeRFRenderer.h" resolves to the filtered header.
 #   * CUDA-only units (CuHashEmbedder.cu, CuSHEncoder.cu) and units that need RuCLIP /
 #     COLMAP / OpenCV proper (NeRFExecutor.h, LeRFRenderer.cpp, loaders) are NOT built:
 #     unbuildable here.
@@ -38,6 +40,9 @@ sed -e '/^#include <opencv2\//d' \
     -e '/^inline cv::Mat TorchTensorToCVMat/,/^}/d' \
     "$REF/NeRFRenderer.h" > "$tmp/NeRFRenderer.h"
 if grep -q 'cv::' "$tmp/NeRFRenderer.h"; then echo "filter failed: cv:: still referenced" >&2; exit 1; fi
+# LeRFRenderer.h says #include "NeRFRenderer.h", which a compiler resolves next to the including file first: passed through the same temp dir (unchanged),
+# it picks up the filtered header above instead of the OpenCV-including one beside it
+cat "$REF/LeRFRenderer.h" > "$tmp/LeRFRenderer.h"
 
 CXX="${CXX:-g++}"
 FLAGS="-std=c++17 -O2 -fPIC -D_GLIBCXX_USE_CXX11_ABI=1 -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -w"
@@ -65,7 +70,12 @@ if [ -f "$hiplib" ]; then
   if stale "$out/obj/adapter_check.o" "$here/ref/adapter_check.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_check.o" ]; then
     $CXX $FLAGS $INC -c "$here/ref/adapter_check.cpp" -o "$out/obj/adapter_check.o"
   fi
-  $CXX -o "$out/adapter_check" "$out/obj/adapter_check.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" $LIBS \
+  # the LeRFRenderer subclass: compile-only (its base class's unit needs the external RuCLIP module; see the file's header)
+  if stale "$out/obj/adapter_lerf_compile.o" "$here/ref/adapter_lerf_compile.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_lerf_compile.o" ]; then
+    $CXX $FLAGS $INC -c "$here/ref/adapter_lerf_compile.cpp" -o "$out/obj/adapter_lerf_compile.o"
+    echo "compiled HipLeRFRenderer : LeRFRenderer against the reference header (not linkable without RuCLIP)"
+  fi
+  $CXX -o "$out/adapter_check" "$out/obj/adapter_check.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" "$out/obj/LeRF.o" $LIBS \
       -Wl,--no-as-needed -ltorch_hip -lc10_hip -Wl,--as-needed -L"$here/../nerfpp_amd/lib" -lnerfpp_hip \
       -Wl,-rpath,'$ORIGIN/../../nerfpp_amd/lib' -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64
   echo "built $out/adapter_check"

@@ -821,6 +821,17 @@ static int run_ckpt(int argc, const char **argv, bool save)
 		torch::save(m, dir + "/model_checkpoint.pt");				//:1059
 		torch::save(torch::full({1}, /*value=*/1234), dir + "/start_checkpoint.pt");		//:1066
 		torch::save(cu, dir + "/cu_embedder_checkpoint.pt");
+		{
+			// optimizer_checkpoint.pt (:1067): the reference's Adam (:539) over the embedder's and the model's parameters after one step on a synthetic gradient
+			std::vector<torch::Tensor> gv;
+			for (auto &p : e->parameters()) gv.push_back(p);
+			for (auto &p : m->parameters()) gv.push_back(p);
+			torch::optim::Adam opt(gv, torch::optim::AdamOptions(5e-4).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));
+			uint32_t k = 0;
+			for (auto &p : gv) { p.mutable_grad() = torch::zeros_like(p); fill_synth(p.mutable_grad(), 9000u + 1000u * (k++), 1e-2f); }
+			opt.step();
+			torch::save(opt, dir + "/optimizer_checkpoint.pt");		//:1067 (a format fixture: the module files above hold the parameters BEFORE this step)
+		}
 		return 0;
 	}
 	g_outdir = argv[3];
@@ -828,6 +839,32 @@ static int run_ckpt(int argc, const char **argv, bool save)
 	torch::load(m, dir + "/model_checkpoint.pt");					//:553
 	torch::load(cu, dir + "/cu_embedder_checkpoint.pt");
 	torch::Tensor start; torch::load(start, dir + "/start_checkpoint.pt");
+	{
+		// NeRFExecutor.h:541-546: the executor restores only when start_checkpoint.pt AND optimizer_checkpoint.pt exist; load the optimizer as it does (:565) and dump its state
+		std::vector<torch::Tensor> gv;
+		for (auto &p : e->parameters()) gv.push_back(p);
+		for (auto &p : m->parameters()) gv.push_back(p);
+		torch::optim::Adam opt(gv, torch::optim::AdamOptions(5e-4).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));
+		const bool have = std::ifstream(dir + "/optimizer_checkpoint.pt").good();
+		save_npy("opt.would_restore", torch::tensor({have ? 1 : 0}, torch::kInt32));
+		if (have)
+		{
+			torch::load(opt, dir + "/optimizer_checkpoint.pt");
+			int i = 0;
+			for (auto &p : gv)
+			{
+				auto it = opt.state().find(p.unsafeGetTensorImpl());
+				if (it != opt.state().end())
+				{
+					auto &st = static_cast<torch::optim::AdamParamState &>(*it->second);
+					save_npy("opt." + std::to_string(i) + ".exp_avg", st.exp_avg()); save_npy("opt." + std::to_string(i) + ".exp_avg_sq", st.exp_avg_sq());
+					save_npy("opt." + std::to_string(i) + ".step", torch::tensor({(float)st.step()}));
+				}
+				i++;
+			}
+			save_npy("opt.lr", torch::tensor({(float)static_cast<torch::optim::AdamOptions &>(opt.param_groups()[0].options()).lr()}));
+		}
+	}
 	for (auto &p : e->named_parameters()) save_npy("e." + p.key(), p.value().detach());
 	for (auto &p : m->named_parameters()) save_npy("m." + p.key(), p.value().detach());
 	for (auto &p : cu->named_parameters()) save_npy("cu." + p.key(), p.value().detach());

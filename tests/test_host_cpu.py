@@ -190,6 +190,13 @@ def test_read_reference_checkpoints(manifest):
     table, primes, biases = CK.cu_hash_state(p, b)
     assert table.shape == (4 * 4096, 2) and primes.shape == (12,) and primes[0] == 268435459 and primes[5] == 268435469 and (biases == 0.25).all()
     assert list(b["embedder_feat_local_idx"]) == [0, 4096, 8192, 12288]
+    # the reference's own torch::save(*Optimizer) (NeRFExecutor.h:1067): Adam(lr 5e-4, betas (0.9, 0.99), eps 1e-15) after one step
+    assert ck["would_restore"]
+    opt = ck["optimizer"]
+    assert opt["step"] == 1 and abs(opt["lr"] - 5e-4) < 1e-12 and opt["betas"] == (0.9, 0.99) and opt["eps"] == 1e-15 and len(opt["moments"]) == 10
+    g0 = synth.synth_sym(9000, (4096, 2), np.float32(1e-2))               # the driver's synthetic gradient of parameter 0: after one step m = 0.1 g, v = 0.01 g^2
+    np.testing.assert_allclose(opt["moments"][0][0], np.float32(0.1) * g0, rtol=1e-6)
+    np.testing.assert_allclose(opt["moments"][0][1], np.float32(0.01) * g0 * g0, rtol=2e-6)
 
 
 def test_written_checkpoints_restore_a_reference_model(tmp_path):
@@ -204,7 +211,13 @@ def test_written_checkpoints_restore_a_reference_model(tmp_path):
                                                                               ("color_net_0", (64, 31)), ("color_net_1", (64, 64)), ("color_net_2", (3, 64)))}
     emb = {f"embedder_embeddings_{l}.weight": rng.randn(4096, 2).astype(np.float32) for l in range(4)}
     d = str(tmp_path / "ck"); out = str(tmp_path / "out"); os.makedirs(out)
-    CK.SaveCheckpoint(d, embedder=emb, model=model, global_step=77)
+    # Adam state in the optimizer's parameter order (NeRFExecutor.h:508-535: the embedder's parameters, then the model's)
+    shapes = [v.shape for v in emb.values()] + [v.shape for v in model.values()]
+    mom = [(rng.randn(*s_).astype(np.float32), rng.rand(*s_).astype(np.float32)) for s_ in shapes]
+    mom[2] = None                                                      # a parameter that has not been stepped yet has no state
+    assert not CK.WouldRestore(str(tmp_path))
+    CK.SaveCheckpoint(d, embedder=emb, model=model, global_step=77, optimizer=dict(moments=mom, step=41, lr=3e-4))
+    assert CK.WouldRestore(d)                                           # the reference's own condition (NeRFExecutor.h:541-546): start + optimizer + model files
     cu_p = {"embedder_embeddings": rng.randn(4 * 4096, 2).astype(np.float32)}
     cu_b = {"embedder_primes": (268435459 + np.arange(12, dtype=np.int32) * 4).reshape(4, 1, 3), "embedder_biases": np.full((4, 3), 0.5, np.float32),
             "embedder_feat_local_size": np.full(4, 4096, np.int32), "embedder_feat_local_idx": (np.arange(4) * 4096).astype(np.int32)}
@@ -217,3 +230,17 @@ def test_written_checkpoints_restore_a_reference_model(tmp_path):
     np.testing.assert_array_equal(np.load(os.path.join(out, "cu.embedder_embeddings.npy")), cu_p["embedder_embeddings"])
     np.testing.assert_array_equal(np.load(os.path.join(out, "cu.embedder_primes.npy")), cu_b["embedder_primes"])
     assert int(np.load(os.path.join(out, "start.npy"))[0]) == 77
+    # torch::load(*Optimizer, "optimizer_checkpoint.pt") (:565) into the reference's Adam: moments, step and lr arrive value for value
+    assert int(np.load(os.path.join(out, "opt.would_restore.npy"))[0]) == 1
+    assert np.load(os.path.join(out, "opt.lr.npy"))[0] == np.float32(3e-4)
+    for i, mv in enumerate(mom):
+        f = os.path.join(out, f"opt.{i}.exp_avg.npy")
+        if mv is None:
+            assert not os.path.exists(f)
+            continue
+        np.testing.assert_array_equal(np.load(f), mv[0])
+        np.testing.assert_array_equal(np.load(os.path.join(out, f"opt.{i}.exp_avg_sq.npy")), mv[1])
+        assert np.load(os.path.join(out, f"opt.{i}.step.npy"))[0] == 41
+    back = CK.LoadCheckpoint(d)
+    assert back["would_restore"] and back["optimizer"]["step"] == 41 and back["optimizer"]["moments"][2] is None
+    np.testing.assert_array_equal(back["optimizer"]["moments"][5][1], mom[5][1])
