@@ -96,19 +96,22 @@ __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &h
 
 // acc[pt][mt] += A[mt][ks] . B[pt][ks] over all k-steps; A fragments stream from LDS in consumption order.
 // NP = 1: plain fp16 operands.  NP = 2: split operands, fragments stored (hi, lo) adjacent; BLO = the B operand has a non-zero lo part.
-struct NoJob { __device__ __forceinline__ void operator()(int, int) const {} };
+struct NoJob { __device__ __forceinline__ void operator()(int, int, int, int) const {} };
 
-// job(mt, ks): extra work issued right after the products of step (mt, ks) -- the software pipeline of the kernel puts the
-// conversion of the PREVIOUS tile there, so that its VALU instructions execute while this step's MFMAs occupy the matrix pipe.
+// job(mt, ks, g, ng): extra work issued right after matrix instruction g of the ng of step (mt, ks) -- the software pipeline of the kernel puts the
+// conversion of the PREVIOUS tile there, so that its VALU instructions execute while the MFMAs occupy the matrix pipe.  A 32x32x16 MFMA holds the SIMD's
+// vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md): ~6 four-cycle vector instructions per gap are free, so the conversion work is dealt out in
+// half-quad units (4-6 instructions) gap by gap instead of in one block per step (FINE: a scheduling fence after every matrix instruction keeps it there).
 // The A fragments of the whole network lie in LDS in consumption order, so the fragment(s) of step i + 1 -- the next k-step, m-tile or
 // LAYER -- are simply the next 1 (2) KB: they are fetched at the top of step i and arrive while its products run.  `pre` carries them
 // from step to step and from layer to layer (fetched = false only for the very last step of the network).
-template <int MT, int KS, int NP, bool BLO, bool LAST = false, class Job = NoJob>
+template <int MT, int KS, int NP, bool BLO, bool LAST = false, bool FINE = false, class Job = NoJob>
 __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT], half8 (&pre)[NP],
                                            Job job = Job())
 {
     // the first product of every accumulator takes the literal zero as its C operand (an inline constant of the MFMA encoding)
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NG = (NP == 2 ? (BLO ? 3 : 2) : 1) * PT;          // matrix instructions per step
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -120,21 +123,26 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
 #pragma unroll
                 for (int q = 0; q < NP; q++) pre[q] = frags[((mt * KS + ks + 1) * NP + q) * 64 + lane];
             }
+            int g = 0;
+            auto after = [&]() {
+                job(mt, ks, g, NG);
+                g++;
+                if constexpr (FINE) __builtin_amdgcn_sched_barrier(0);
+            };
             if constexpr (NP == 2) {
                 // small terms first, the leading product last
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0); after(); }
                 if constexpr (BLO) {
 #pragma unroll
-                    for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], acc[pt][mt], 0, 0, 0);
+                    for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], acc[pt][mt], 0, 0, 0); after(); }
                 }
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0); after(); }
             } else {
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0);
+                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0); after(); }
             }
-            job(mt, ks);
             // fence the scheduler: unfenced it hoists every ds_read_b128 of the network to the top (40 fragments = 160 VGPRs), which costs
             // the occupancy that hides the feature-load latency
             __builtin_amdgcn_sched_barrier(0);
@@ -182,6 +190,12 @@ struct SmallInput {
 #ifndef NRF_SMALL_PREFETCH_F16
 #define NRF_SMALL_PREFETCH_F16 0
 #endif
+#ifndef NRF_SMALL_STAGGER
+#define NRF_SMALL_STAGGER 0         // split mode: waves 4-7 start this many x 8 128 cycles late
+#endif
+#ifndef NRF_SMALL_FINE
+#define NRF_SMALL_FINE 1            // split mode: conversion work dealt out per matrix instruction (0: one block per step)
+#endif
 
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
@@ -202,6 +216,14 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t nblocks = (npts + BLOCK_PTS - 1) / BLOCK_PTS;
+#if NRF_SMALL_STAGGER
+    // SIMD partners (waves w and w + 4) run the same program and fall into lockstep -- both in their matrix phases, then both in their vector phases.
+    // Waves 4-7 start a fraction of an iteration late (MI355X_MICROARCH.md, "two waves that run the SAME program: try a stagger").
+    if (SPLIT && wave >= 4) {
+#pragma unroll
+        for (int i = 0; i < NRF_SMALL_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     auto split8 = [](const float4 &lo4, const float4 &hi4, half8 &hv, half8 &lv) {
         const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
@@ -279,6 +301,33 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             if constexpr (SPLIT) tile_to_frag2<true>(acc2[pt][t], sh, bh[buf][pt][2 * t + sh][0], bh[buf][pt][2 * t + sh][NP - 1]);
             else bh[buf][pt][2 * t + sh][0] = tile_to_frag<true>(acc2[pt][t], sh);
         };
+        // The same conversion in HALF-QUAD units for the fine-grained schedule (split mode): quad q of item i = values 4q..4q+3 of the 8-register half tile.
+        // Part 0: four ReLUs and the two packed roundings to fp16 (hi); part 1: the four residuals lo = f16(v - hi).  Two value pairs advance together so that
+        // no instruction reads the result of the one right before it (a v_cvt_pk followed by the v_fma_mix that reads it costs an s_nop).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        float qm[4];
+        uint32_t qc[2];
+        auto conv_half = [&](int buf, int t, int i, int q, int part) {
+            (void)qm; (void)qc;
+            if constexpr (SPLIT) {
+                const int pt = i >> 1, sh = i & 1;
+                if (part == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qm[e] = fmaxf(acc2[pt][t][8 * sh + 4 * q + e], 0.0f);
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(qc[0]) : "v"(qm[0]), "v"(qm[1]));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(qc[1]) : "v"(qm[2]), "v"(qm[3]));
+                } else {
+                    uint32_t l0, l1;
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(qc[0]), "v"(qm[0]));
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(qc[1]), "v"(qm[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(qc[0]), "v"(qm[1]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(qc[1]), "v"(qm[3]));
+                    u32x4 hv = __builtin_bit_cast(u32x4, bh[buf][pt][2 * t + sh][0]), lv = __builtin_bit_cast(u32x4, bh[buf][pt][2 * t + sh][NP - 1]);
+                    hv[2 * q] = qc[0]; hv[2 * q + 1] = qc[1]; lv[2 * q] = l0; lv[2 * q + 1] = l1;
+                    bh[buf][pt][2 * t + sh][0] = __builtin_bit_cast(half8, hv); bh[buf][pt][2 * t + sh][NP - 1] = __builtin_bit_cast(half8, lv);
+                }
+            }
+        };
         static_assert(PT == 2, "the conversion schedule below is written for two point tiles per wave");
         auto hidden_to_b = [&](int buf) {
 #pragma unroll
@@ -290,14 +339,31 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         // layer's first two operand fragments; tile 1 is converted during the first two k-steps of the next layer, which only need those.
         //   job of a layer with input buffer `bi` and KS k-steps:  mt == 0, ks < 2 : previous layer's tile 1 -> bh[bi][.][2..3]
         //                                                           mt == 1         : this layer's tile 0      -> bh[bi ^ 1][.][0..1]
+        // FINE (split mode): the items of a step are cut into half-quad units (4 per item) and dealt out over the step's ng matrix instructions, unit u after
+        // instruction floor(u * ng / units); otherwise the step's items follow its last matrix instruction as one block.
+        constexpr bool FINE = SPLIT && PIPE && (NRF_SMALL_FINE != 0) && V_KS == 1;      // the 64-wide direction encodings (SH degree 8) are at the register limit already
         auto make_job = [&](int bi, bool conv_prev_tile1, bool conv_this_tile0, int ks_count) {
-            return [=, &conv_item](int mt, int ks) {
-                (void)conv_item;           // not referenced when PIPE is off for this instantiation
+            return [=, &conv_item, &conv_half](int mt, int ks, int g, int ng) {
+                (void)conv_item; (void)conv_half;           // not referenced when PIPE is off for this instantiation
                 if constexpr (PIPE) {
-                    if (conv_prev_tile1 && mt == 0 && ks < 2) { conv_item(bi, 1, 2 * ks); conv_item(bi, 1, 2 * ks + 1); }
+                    // items of this step: [i0, i1) of tile tt into buffer bb
+                    int i0 = 0, i1 = 0, tt = 0, bb = bi;
+                    if (conv_prev_tile1 && mt == 0 && ks < 2) { i0 = 2 * ks; i1 = 2 * ks + 2; tt = 1; bb = bi; }
                     if (conv_this_tile0 && mt == 1) {
                         const int per = (4 + ks_count - 1) / ks_count;
-                        for (int i = ks * per; i < (ks + 1) * per && i < 4; i++) conv_item(bi ^ 1, 0, i);
+                        i0 = ks * per; i1 = (ks + 1) * per < 4 ? (ks + 1) * per : 4; tt = 0; bb = bi ^ 1;
+                    }
+                    if constexpr (FINE) {
+                        const int units = (i1 - i0) * 4;
+#pragma unroll
+                        for (int u = 0; u < 16; u++)            // fixed bound: every index below must fold to a constant (register arrays)
+                            if (u < units && (u * ng) / units == g) conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1);
+                    } else {
+                        if (g == ng - 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (i >= i0 && i < i1) conv_item(bb, tt, i);
+                        }
                     }
                 }
             };
@@ -310,14 +376,14 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         if constexpr (NL == 1) {
             gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
-            gemm_layer<2, IN_KS, NP, IN_LO>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
+            gemm_layer<2, IN_KS, NP, IN_LO, false, FINE>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
             if constexpr (PREFETCH) { if (more) load_inputs(blk + gridDim.x, bxn, bvn); }
 #pragma unroll
             for (int l = 1; l < NL; l++) {
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
                 if constexpr (!PIPE) hidden_to_b(0);
-                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
-                else gemm_layer<1, 4, NP, SPLIT>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4));
+                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
+                else gemm_layer<1, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4));
                 fr += Plan::sigma_frags(l) * 64 * NP;
             }
         }
@@ -337,13 +403,13 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         if constexpr (NLC == 1) {
             gemm_layer<1, V_KS + 1, NP, SPLIT, true>(fr, lane, bc, rgb, pre);
         } else {
-            gemm_layer<2, V_KS + 1, NP, SPLIT>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
+            gemm_layer<2, V_KS + 1, NP, SPLIT, false, FINE>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
 #pragma unroll
             for (int l = 1; l < NLC; l++) {
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
                 if constexpr (!PIPE) hidden_to_b(0);
-                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
-                else gemm_layer<1, 4, NP, SPLIT, true>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4));
+                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
+                else gemm_layer<1, 4, NP, SPLIT, true, FINE>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4));
                 fr += Plan::color_frags(l) * 64 * NP;
             }
         }
@@ -378,6 +444,14 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     }
 }
 
+// Tried and measured in round 2 (same box, A/B builds of this file, split mode, ms of this kernel per 800x800 frame's fine pass):
+//   * NRF_SMALL_FINE (kept): the conversions dealt out over the matrix instructions of a step (4-6 vector instructions per MFMA gap, a fence after every MFMA,
+//     value pairs interleaved so that no v_fma_mix reads the v_cvt_pk right before it) instead of one block per step: 10.88 vs 10.94, 10.61 vs 10.71 -- under 1 %.
+//   * NRF_SMALL_STAGGER = 1, 2, 3 (waves 4-7 start 8 / 16 / 24 k cycles late, so that SIMD partners are not in the same phase): 11.06 / 11.15 / 11.05 vs 11.13.
+//   Together with the first round's results (scheduler strategies, 16x16x32, register-resident weights, 11 % of the matrix work moved to the vector ALUs: all
+//   within 1 %) the kernel's time does not respond to how its instructions are ordered or split between the pipes: per wave and iteration it issues ~6.9 k cycles
+//   of instructions (MFMA 1.9 k, conversions 3.4 k, address arithmetic 1.1 k), two waves per SIMD make 13.9 k of the 24.9 k cycles an iteration takes, the matrix
+//   pipe is busy 14.1 k.
 // Tried and measured (same box): the last colour layer (64 -> 3, one 32-row tile with 3 useful rows = 12 of the split mode's 116 matrix instructions per tile)
 // moved to the vector ALUs in fp32, straight from the last hidden layer's D tiles.  Split mode: 13.63 vs 13.65 ms per frame -- nothing, although
 // 11 % of the matrix work is gone: the chip is holding its clock down under this load, so cycles taken off the matrix pipe and put on the
