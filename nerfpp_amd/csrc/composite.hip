@@ -244,8 +244,10 @@ k_sample_pdf(int64_t n, int nb, int ns, int sum_vec, const float *__restrict__ b
 // NeRFRenderer.h:427-431: z_mid -> SamplePDF(weights[1:-1]) -> sort(cat(z, samples)).
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z, const float *__restrict__ weights,
-              const float *__restrict__ u, int64_t u_stride, RngRef g, float *__restrict__ zf)
+              const float *__restrict__ u, int64_t u_stride, RngRef g, float *__restrict__ zf, int32_t *__restrict__ src, float *__restrict__ z_new)
 {
+    // src / z_new (optional, the renderer's feature reuse): src[ray][slot] = where slot's depth came from -- ray * s + i for coarse sample i, n * s + ray * ns + j for
+    // new sample j (a column of a feature table that holds the coarse pass's columns first, then the new samples'); z_new[ray][j] = the new samples, unsorted
     __shared__ PdfLds lds[RAYS_PER_BLOCK];
     __shared__ float zs[RAYS_PER_BLOCK][MAX_S];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -267,18 +269,23 @@ k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z
     for (int k = lane; k + 1 < s; k += 64) bad |= zl[k] > zl[k + 1];
     for (int k = lane; k + 1 < ns; k += 64) bad |= smp[k] > smp[k + 1];
     float *outp = zf + ray * (s + ns);
+    int32_t *srcp = src ? src + ray * (s + ns) : nullptr;
+    const int32_t src_z = (int32_t)(ray * s), src_new = (int32_t)(n * s + ray * ns);
+    if (z_new) for (int j = lane; j < ns; j += 64) z_new[ray * ns + j] = smp[j];
     if (!__any(bad)) {
         for (int i = lane; i < s; i += 64) {             // rank(z_i) = i + #{samples < z_i}   (z precedes samples on ties)
             const float v = zl[i];
             int lo = 0, hi = ns;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (smp[mid] < v) lo = mid + 1; else hi = mid; }
             outp[i + lo] = v;
+            if (srcp) srcp[i + lo] = src_z + i;
         }
         for (int j = lane; j < ns; j += 64) {            // rank(sample_j) = j + #{z <= sample_j}
             const float v = smp[j];
             int lo = 0, hi = s;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (zl[mid] <= v) lo = mid + 1; else hi = mid; }
             outp[j + lo] = v;
+            if (srcp) srcp[j + lo] = src_new + j;
         }
     } else {
         const int tot = s + ns;
@@ -290,6 +297,7 @@ k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z
                 rank += (o < v) || (o == v && k < i);
             }
             outp[rank] = v;
+            if (srcp) srcp[rank] = i < s ? src_z + i : src_new + (i - s);
         }
     }
 }
@@ -333,13 +341,13 @@ int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int 
 
 // u == NULL: per-ray uniform draws generated from g (SamplePDF det = false with the library's counter RNG)
 int launch_fine_depths(const float *z, const float *weights, int64_t n, int s, const float *u, int64_t u_stride, const RngRef &g, int ns, int sum_vec,
-                       float *zf, hipStream_t st)
+                       float *zf, hipStream_t st, int32_t *src, float *z_new)
 {
     NRF_CHECK_ARG(s >= 4 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [4,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
     NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_fine_depths: sum_vec must be 0, 4, 8 or 16");
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_SAMPLE, st);
-    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, ns, sum_vec, z, weights, u, u_stride, g, zf);
+    hipLaunchKernelGGL(k_fine_depths, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, ns, sum_vec, z, weights, u, u_stride, g, zf, src, z_new);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

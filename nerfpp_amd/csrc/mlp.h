@@ -51,7 +51,7 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,
-                              const uint8_t *keep, int64_t p, float *out, hipStream_t st);
+                              const uint8_t *keep, int64_t p, float *out, hipStream_t st, const int32_t *src = nullptr);
 int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_small_sigma_f32_available(const nrf_mlp *m);
 int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st);

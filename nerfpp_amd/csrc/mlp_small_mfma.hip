@@ -176,6 +176,8 @@ struct SmallInput {
     const uint8_t *keep;
     const __half *dirs_lo;                            // split mode: lo parts of the direction features, same layout
     const __half2 *feats_lo;                          // split mode, fp32-valued features (HashEmbedder): lo plane, same layout as feats
+    const int32_t *src;                               // optional: point i reads column src[i] of feats / keep (the renderer's feature reuse: the fine pass's coarse depths
+                                                      // point at the coarse pass's columns); NULL: column i
 };
 
 #ifndef NRF_SMALL_PIPE_SPLIT
@@ -237,15 +239,16 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             int64_t p = p0_ + pt * 32 + r;
             if (p >= npts) p = npts - 1;                 // clamp loads; stores are guarded
             if constexpr (LM) {
+                const int64_t col = in.src ? (int64_t)in.src[p] : p;
 #pragma unroll
                 for (int s = 0; s < IN_KS; s++) {
                     union { half8 v; __half2 q[4]; } u;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];   // features 16s+8h+2q, +1
+                    for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + col];   // features 16s+8h+2q, +1
                     bx[pt][s][0] = u.v;
                     if constexpr (SPLIT && LMLO) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) u.q[q] = in.feats_lo[(int64_t)(8 * s + 4 * h + q) * in.pstride + p];
+                        for (int q = 0; q < 4; q++) u.q[q] = in.feats_lo[(int64_t)(8 * s + 4 * h + q) * in.pstride + col];
                         bx[pt][s][NP - 1] = u.v;
                     } else if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
@@ -420,7 +423,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 const int64_t p = p0 + pt * 32 + r;
                 if (p < npts) {
                     float sg = sig[pt][0][0];
-                    if constexpr (LM) { if (in.keep && !in.keep[p]) sg = 0.0f; }
+                    if constexpr (LM) { if (in.keep && !in.keep[in.src ? (int64_t)in.src[p] : p]) sg = 0.0f; }
                     if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
                     else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
                 }
@@ -572,11 +575,11 @@ int mlp_small_mfma_available(const nrf_mlp *m) { return m && m->family == MLP_SM
 // renderer fast path: level-major fp16 features + per-ray fp16 direction features + keep mask -> raw [p,4] (sigma masked).
 // dirs_lo != NULL selects the split-precision kernel (NRF_PREC_F16_SPLIT).
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,
-                              const uint8_t *keep, int64_t p, float *out, hipStream_t st)
+                              const uint8_t *keep, int64_t p, float *out, hipStream_t st, const int32_t *src)
 {
     if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
     ProfScope prof(NRF_PROF_MLP, st);
-    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo, dirs_lo ? feats_lo : nullptr};
+    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo, dirs_lo ? feats_lo : nullptr, src};
     return dispatch_small(m, in, true, dirs_lo != nullptr, p, out, 4, st);
 }
 
@@ -589,7 +592,7 @@ int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, 
         return NRF_ERR_UNSUPPORTED;
     }
     if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("NRF_PREC_F16_MFMA: input rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
-    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr};
+    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr};
     return dispatch_small(m, in, false, split != 0, p, out, os, st);
 }
 
