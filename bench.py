@@ -28,7 +28,21 @@ sys.path.insert(0, ROOT)
 
 H = W = 800
 NS, NI = 64, 128
-UNITS_PER_RAY = NS + NS + NI          # one shared network, fine pass re-evaluates all depths (NeRFRenderer.h:422,447)
+UNITS_PER_RAY = NS + NS + NI          # one shared network, fine pass re-evaluates all depths (NeRFRenderer.h:422,447): the metric's unit count per ray
+# What the kernels actually execute per ray on the matrix-core paths: the S coarse depths of the fine set are the coarse pass's own sample points, so their hash
+# features (default split mode) or their whole network outputs (coarse pass = whole network in the same arithmetic) are reused -- results unchanged.  `value` keeps
+# counting the reference's 256 evaluations per ray (the work the frame stands for); the rooflines below price what each kernel really processed.
+
+
+def executed_per_ray(workload, precision, hash_mode):
+    """(hash-encode points, fused-MLP points, sigma-only points) per ray."""
+    if precision == "f32":
+        return UNITS_PER_RAY, UNITS_PER_RAY, 0
+    if workload == "classic":
+        return 0, NS + NI, 0
+    if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32)
+        return (NS + NI) if hash_mode == "cu" else UNITS_PER_RAY, NS + NI, NS
+    return NS + NI, NS + NI, 0                                # plain fp16: coarse outputs reused by the fine pass
 
 # algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)
 HASH_BYTES_PER_UNIT = 16 * 8 * 2 * 2 + 12 + 64      # table gathers + point in + fp16 features out (standalone encode kernel)
@@ -234,8 +248,9 @@ def main():
         # per-launch figures from HIP events on the launch stream; hash workload: the two candidates for `dominant` are the hash encode (HBM) and the fused MLP (MFMA)
         if args.workload == "hash":
             k = prof["hash"]
-            units_total = units_per_step * args.steps / world                     # this rank's units over the timed region
-            units_per_launch = units_total / max(k["launches"], 1)
+            units_total = units_per_step * args.steps / world                     # this rank's units over the timed region (256 per ray)
+            ex_hash, ex_mlp, ex_sigma = executed_per_ray(args.workload, args.precision, args.hash_mode)
+            units_per_launch = units_total * ex_hash / UNITS_PER_RAY / max(k["launches"], 1)          # points the hash kernel really encoded
             dur = k["ms"] * 1e-3 / max(k["launches"], 1)
             achieved = units_per_launch * HASH_BYTES_PER_UNIT / max(dur, 1e-12)
             traffic, traffic_src = pmc_traffic("hash_encode (k_hash_cu_lm)", units_per_launch)
@@ -252,8 +267,8 @@ def main():
             mdur = mk["ms"] * 1e-3
             mlp_peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             sk = prof["sigma"]
-            # units the fused MLP kernel processed: all 256 per ray, or the 192 fine-pass ones when the coarse pass ran the sigma net alone
-            mlp_units = units_total * ((NS + NI) / UNITS_PER_RAY if sk["launches"] else 1.0)
+            # points the fused MLP kernel really processed (see executed_per_ray)
+            mlp_units = units_total * ex_mlp / UNITS_PER_RAY
             mupl = mlp_units / max(mk["launches"], 1)
             mtraffic, mtraffic_src = pmc_traffic("mlp_small (k_mlp_small_mfma)", mupl)
             mroof = dict(bound="mfma", kernel="mlp_small", achieved=mlp_units * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
@@ -274,7 +289,7 @@ def main():
             sroof = None
             if sk["launches"]:
                 sdur = sk["ms"] * 1e-3
-                s_units = units_total * NS / UNITS_PER_RAY
+                s_units = units_total * ex_sigma / UNITS_PER_RAY
                 sroof = dict(bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
                              peak=F32_PEAK / 1e12, unit="TFLOP/s", frac=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / F32_PEAK, launches=sk["launches"],
                              avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT)
@@ -287,9 +302,11 @@ def main():
         else:
             k = prof["mlp"]
             dur_total = k["ms"] * 1e-3
-            flops = units_per_step * args.steps / world * NERF_FLOP_PER_UNIT          # this rank's
+            ex_mlp = executed_per_ray(args.workload, args.precision, args.hash_mode)[1]
+            exec_units = units_per_step * args.steps / world * ex_mlp / UNITS_PER_RAY          # network evaluations this rank's kernel really ran
+            flops = exec_units * NERF_FLOP_PER_UNIT
             peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
-            upl = units_per_step * args.steps / world / max(k["launches"], 1)
+            upl = exec_units / max(k["launches"], 1)
             traffic, traffic_src = pmc_traffic("mlp_nerf (k_mlp_nerf_mfma)", upl, "classic_units_per_launch")
             roof = dict(bound="mfma", kernel="mlp_nerf" + ("_split" if args.precision == "f16x3" else ""), achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
                         frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
@@ -297,7 +314,7 @@ def main():
                         note="achieved / frac price the ALGORITHMIC 1 186 816 flop per unit of NeRFImpl::forward as written (11 linear layers); the kernel runs "
                              "feature_linear and views_linears_0 (no activation in between) as one pre-multiplied affine layer, 10.6 % fewer matrix instructions")
             if args.precision == "f16x3":      # three fp16 products per algorithmic one (hi + lo operand pairs)
-                roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * (units_per_step * args.steps / world) / max(dur_total, 1e-12) / peak
+                roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / peak
                 roof["note"] += "; split precision issues 3 x 1 058 matrix instructions per 32 points (mfma_issued_frac) to deliver fp32-grade pixels"
             busy = pmc_mfma_busy("mlp_nerf (k_mlp_nerf_mfma)", args.precision)
             if busy:
@@ -317,6 +334,9 @@ def main():
                        else "PE(10)/PE(4) + NeRF 8x256 skip4 viewdirs",
                        "frames_per_step": nframes, "rays_per_gpu_per_step": nframes * H * W // world, "ray_samples_per_ray": UNITS_PER_RAY, "chunk": chunk,
                        "parallelism": f"row-tile x{world}" + ((" + RCCL all_gather (" + ("nrf_allgather_tiles, C ABI" if args.collective == "cabi" else "torch.distributed") + ")") if use_dist else "")},
+            "executed_evaluations_per_ray": dict(zip(("hash_encode", "fused_mlp", "sigma_only"), executed_per_ray(args.workload, args.precision, args.hash_mode)),
+                                                 note="value counts the reference's 256 network evaluations per ray; the fine pass's 64 coarse depths reuse the coarse pass's "
+                                                      "hash features / outputs (identical results), so the kernels process fewer"),
             "rays_per_s": value / UNITS_PER_RAY, "s_per_frame": elapsed / args.steps / nframes * (world if args.scaling == "weak" else 1),
             "roofline": roof, "kernel_ms": prof,
         }

@@ -66,6 +66,16 @@ __global__ void k_mask_sigma(int64_t p, int c, const uint8_t *__restrict__ keep,
     if (i < p && !keep[i]) raw[i * c + (c - 1)] = 0.0f;
 }
 
+// raw_f[i] = the network output of fine depth i: computed in the coarse pass (columns [0, n_coarse) of the merge map) or in the fine pass's evaluation of the new samples
+__global__ void k_gather_raw(int64_t p, const int32_t *__restrict__ src, const float4 *__restrict__ raw_coarse, const float4 *__restrict__ raw_new, int64_t n_coarse,
+                             float4 *__restrict__ raw_f)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p) return;
+    const int64_t c = src[i];
+    raw_f[i] = c < n_coarse ? raw_coarse[c] : raw_new[c - n_coarse];
+}
+
 struct Bump {
     char *base;
     size_t off = 0, cap;
@@ -308,6 +318,7 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += network_ws_bytes(r, n * sf, p->precision) + 4096;
     b += align_up((size_t)n * 64 * sizeof(__half), 256) * 2;  // per-ray direction features of the fast path (hi, lo)
     b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + 1024;   // feature reuse: merge map + new-sample depths
+    b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + align_up((size_t)n * (sf - s) * 16, 256);   // raw reuse: map, depths, outputs of the new samples
     if (p->perturb > 0.0f) b += align_up((size_t)n * s * 4, 256);                             // un-jittered depths
     if (p->has_cone || p->precond_alpha > 0.0f) b += align_up((size_t)n * sf * 12, 256);     // explicit sample points
     return b;
@@ -360,6 +371,10 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     if (fast && p->precision == NRF_PREC_F16_SPLIT) dirs_lo = bump.take<__half>((size_t)n * r->in_views);
     if (fast_classic) dirs16 = bump.take<__half>((size_t)n * 32);
     if (fast_classic && classic_split) dirs_lo = bump.take<__half>((size_t)n * 32);
+    // merge map, new-sample depths and their network outputs of the raw-reuse fine pass (see reuse_raw below)
+    int32_t *rr_src = ni > 0 ? bump.take<int32_t>((size_t)n * sf) : nullptr;
+    float *rr_znew = ni > 0 ? bump.take<float>((size_t)n * ni) : nullptr;
+    float *rr_rawnew = ni > 0 ? bump.take<float>((size_t)n * ni * 4) : nullptr;
     float *z_plain = p->perturb > 0.0f ? bump.take<float>((size_t)n * s) : nullptr;
     float *bump_pts = (p->has_cone || p->precond_alpha > 0.0f) ? bump.take<float>((size_t)n * sf * 3) : nullptr;
     void *nws = bump.take<char>(0);
@@ -395,8 +410,13 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_c, n, s, sp, rng, pts, st));
         ps.pts = pts;
     }
-    // coarse features kept for the fine pass (see ReuseWs): CuHashEmbedder fast path, sample points formed from (rays, z) in both passes
-    const bool reuse = fast && ni > 0 && r->desc.hash->desc.mode == NRF_HASH_CU && !cone && !precond && n * (int64_t)sf < ((int64_t)1 << 31);
+    // Where the coarse pass runs the WHOLE network in the fine pass's own arithmetic (the classic NeRF fast path in either matrix-core precision; HashNeRF with
+    // NRF_COARSE_FULL), the fine pass's S coarse depths need no evaluation at all: their outputs exist.  The network then runs on the N_importance new samples and
+    // k_gather_raw assembles raw_f through the merge map: a quarter of the frame's network evaluations (64 of 256 per ray) is not done; same kernel on the same
+    // inputs, so the result is unchanged bit for bit.
+    const bool reuse_raw = (fast || fast_classic) && ni > 0 && !sigma_only && !cone && !precond && c == 4 && n * (int64_t)sf < ((int64_t)1 << 31);
+    // otherwise (the default split mode: coarse pass = sigma net alone) the coarse hash features are kept for the fine pass (see ReuseWs)
+    const bool reuse = !reuse_raw && fast && ni > 0 && r->desc.hash->desc.mode == NRF_HASH_CU && !cone && !precond && n * (int64_t)sf < ((int64_t)1 << 31);
     ReuseWs rw{};
     if (reuse) {
         NRF_TRY(reuse_layout(nws, nws_bytes, n, s, ni, rw));
@@ -413,14 +433,22 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     }
     NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, sigma_only ? 1 : c, sigma_only ? 0 : 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz,
                                st, false));   // :423  always the exact arithmetic: these weights choose the fine samples
-    NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st, reuse ? rw.src : nullptr, reuse ? rw.z_new : nullptr));   // :427-431 (det = perturb == 0)
+    NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st, reuse_raw ? rr_src : (reuse ? rw.src : nullptr),
+                               reuse_raw ? rr_znew : (reuse ? rw.z_new : nullptr)));                                // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
     if (cone || precond) {                                                                                         // :433-445
         sp.precond = precond; sp.stream_r = NRF_RNG_R_FINE; sp.stream_theta = NRF_RNG_THETA_FINE;
         NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_f, n, sf, sp, rng, pts, st));
         psf.pts = pts;
     }
-    if (reuse) {
+    if (reuse_raw) {
+        // the network on the N_importance new samples only; the S coarse depths take the coarse pass's outputs (same kernel, same inputs: same bits)
+        PointSource psn{nullptr, d_rays, rr_znew, ray_stride, ni};
+        NRF_TRY(network(psn, ni, rr_rawnew));
+        hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)ceil_div(n * (int64_t)sf, 256)), dim3(256), 0, st, n * (int64_t)sf, rr_src, reinterpret_cast<const float4 *>(raw_c),
+                           reinterpret_cast<const float4 *>(rr_rawnew), n * (int64_t)s, reinterpret_cast<float4 *>(raw_f));
+        NRF_LAUNCH_CHECK();
+    } else if (reuse) {
         // the hash encode of the N_importance new samples only; the MLP gathers every depth's column through the merge map
         PointSource psn{nullptr, d_rays, rw.z_new, ray_stride, ni};
         NRF_TRY(launch_hash_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.keep + n * (int64_t)s, HASH_LM_DEFAULT_VARIANT, st));
