@@ -20,6 +20,8 @@ for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}
         short = k.split("(")[0].replace("void ", "").strip()
         if "k_hash_cu_lm" in k: short = "hash_encode (k_hash_cu_lm)"
         elif "k_mlp_small_mfma" in k: short = "mlp_small (k_mlp_small_mfma)"
+        elif "k_sigma_small_f32" in k: short = "sigma_small_f32 (k_sigma_small_f32)"
+        elif "k_mlp_nerf_split" in k: short = "mlp_nerf_split (k_mlp_nerf_split)"
         elif "k_mlp_nerf_mfma" in k: short = "mlp_nerf (k_mlp_nerf_mfma)"
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
         # one logical hash-encode launch is TWO dispatches (four-levels-per-thread group + single-level group): count the latter
@@ -38,6 +40,6 @@ for k, v in res.items():
         v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v:
         v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
-res = {k: v for k, v in res.items() if k.startswith(("hash_encode", "mlp_", "nrf::"))}
+res = {k: v for k, v in res.items() if k.startswith(("hash_encode", "mlp_", "sigma_", "nrf::"))}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(f"wrote {out}: {len(res)} kernels")
