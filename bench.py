@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the whole-frame render in the NRF_PREC_F32 parity mode after the timed region (profiling runs: keeps the kernel summary to the timed kernels)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (self-test of the N > 1 code path)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets N ranks SHARE one GPU (a rehearsal of the N > 1 code path on a one-GPU box: RCCL refuses two ranks on a device)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): N frames per step, every GPU traces a whole frame's worth of rays; strong: ONE frame per step split over the N ranks")
     ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
@@ -154,12 +156,12 @@ def main():
     import torch.distributed as dist
     from nerfpp_amd import _lib as L, scene
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if args.backend == "nccl" else local % max(torch.cuda.device_count(), 1))
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     from nerfpp_amd.dist import TileShard, TileComm
 
     prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[args.precision]
@@ -178,6 +180,8 @@ def main():
     nframes = 1 if args.scaling == "strong" else world
     poses = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(nframes)]
     shard = TileShard(H, W, rank, world, force_collective=args.force_dist)
+    if args.backend == "gloo" and args.collective == "cabi":
+        sys.exit("--collective cabi is RCCL: one rank per GPU (--backend nccl)")
     comm = TileComm(rank, world) if (use_dist and args.collective == "cabi") else None
 
     def render_tiles():
@@ -210,14 +214,14 @@ def main():
     L.lib().nrf_profile_read(ms, cnt, 1)
     L.lib().nrf_profile_enable(0)
     if use_dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # untimed cross-check of the other collective implementation on the same tiles (N > 1: the C-ABI all-gather a C++ host calls vs torch.distributed's).
     # It runs on a helper thread with a deadline so that nothing it does can cost the run its result line.
     collective_check = None
     stuck = False
-    if use_dist:
+    if use_dist and args.backend == "nccl":
         import threading
         box = {}
 
@@ -293,7 +297,9 @@ def main():
             if sk["launches"]:
                 sdur = sk["ms"] * 1e-3
                 s_units = units_total * ex_sigma / UNITS_PER_RAY
-                sroof = dict(bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
+                straffic, straffic_src = pmc_traffic("sigma_small_f32 (k_sigma_small_f32)", s_units / sk["launches"])
+                sroof = dict(traffic=straffic, traffic_source=straffic_src, mfma_busy_frac_of_active_cycles=pmc_mfma_busy("sigma_small_f32 (k_sigma_small_f32)", "f16x3"),
+                             bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
                              peak=F32_PEAK / 1e12, unit="TFLOP/s", frac=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / F32_PEAK, launches=sk["launches"],
                              avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT)
             # the roofline object describes the kernel that took the most time in THIS run; the others ride along under their own keys
@@ -310,7 +316,7 @@ def main():
             flops = exec_units * NERF_FLOP_PER_UNIT
             peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             upl = exec_units / max(k["launches"], 1)
-            traffic, traffic_src = pmc_traffic("mlp_nerf (k_mlp_nerf_mfma)", upl, "classic_units_per_launch")
+            traffic, traffic_src = pmc_traffic("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", upl)
             roof = dict(bound="mfma", kernel="mlp_nerf" + ("_split" if args.precision == "f16x3" else ""), achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
                         frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
                         avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT,
@@ -319,9 +325,9 @@ def main():
             if args.precision == "f16x3":      # three fp16 products per algorithmic one (hi + lo operand pairs)
                 roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / peak
                 roof["note"] += "; split precision issues 3 x 1 058 matrix instructions per 32 points (mfma_issued_frac) to deliver fp32-grade pixels"
-            busy = pmc_mfma_busy("mlp_nerf (k_mlp_nerf_mfma)", args.precision)
+            busy = pmc_mfma_busy("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", args.precision)
             if busy:
-                roof["mfma_busy_frac_of_active_cycles_before_restaging"] = busy
+                roof["mfma_busy_frac_of_active_cycles"] = busy
         line = {
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,7 +345,8 @@ def main():
                                       "reference run (nvcc's FMA contraction is not modelled); the reference-pinned encoders are the LibTorch twin in `also`")
                        if (args.workload == "hash" and args.hash_mode == "cu") else "reference-pinned (goldens from the compiled reference)",
                        "frames_per_step": nframes, "rays_per_gpu_per_step": nframes * H * W // world, "ray_samples_per_ray": UNITS_PER_RAY, "chunk": chunk,
-                       "parallelism": f"row-tile x{world}" + ((" + RCCL all_gather (" + ("nrf_allgather_tiles, C ABI" if args.collective == "cabi" else "torch.distributed") + ")") if use_dist else "")},
+                       "parallelism": f"row-tile x{world}" + ((" + " + ("RCCL" if args.backend == "nccl" else "gloo (ranks SHARING one GPU: a rehearsal of the N > 1 code path)") +
+                                                               " all_gather (" + ("nrf_allgather_tiles, C ABI" if args.collective == "cabi" else "torch.distributed") + ")") if use_dist else "")},
             "executed_evaluations_per_ray": dict(zip(("hash_encode", "fused_mlp", "sigma_only"), executed_per_ray(args.workload, args.precision, args.hash_mode)),
                                                  note="value counts the reference's 256 network evaluations per ray; the fine pass's 64 coarse depths reuse the coarse pass's "
                                                       "hash features / outputs (identical results), so the kernels process fewer"),
@@ -522,18 +529,16 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     return rec
 
 
-def pmc_traffic(kernel, units_per_launch, meta_key="units_per_launch"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
-    by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench), rescaled to this run's
-    units per launch.  None if no PMC summary is committed."""
+def pmc_traffic(kernel, units_per_launch, meta_key=None):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written from separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of this same bench: bytes per point the kernel processed), times this run's points per launch.  None if no PMC summary is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
-        k = d[kernel]
-        per_unit = k["hbm_bytes_per_launch"] / d["_meta"][meta_key]
-        return per_unit * units_per_launch, f"profiles/pmc_latest.json ({d['_meta']['source']}): (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, gfx950 x2 read correction"
+        return d[kernel]["hbm_bytes_per_point"] * units_per_launch, ("profiles/pmc_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch (gfx950 x2 read correction) summed over "
+                                                                    "`bench.py --steps 1 --warmup 1` and divided by the points processed; " + d["_meta"]["source"])
     except Exception:
         return None, None
 

@@ -387,6 +387,10 @@ NRF_API int nrf_mlp_backward_f16(const nrf_mlp *m, const float *d_x, const float
  * nrf_hash_encode_lm_f16 ([16][p][2] halfs), d_dirs_f16 = [p / s][16] fp16 direction features, one row per RAY (point i belongs to ray i / s). */
 NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, const void *d_dirs_f16, int s, const float *d_g_out, int64_t p, float *d_g_params,
                                     float *d_g_x, void *d_workspace, size_t workspace_bytes, void *stream);
+/* Overflow report of the last nrf_mlp_backward_f16(_lm) that used `d_workspace` (the chain runs on fp16 operands behind a loss scale taken from max |g_out|):
+ * flags_out[0] != 0: the incoming gradient held an inf / NaN; flags_out[1] != 0: an accumulated parameter gradient is not finite.  Host array of 2; synchronises
+ * `stream`.  A caller skips (or rescales) the optimizer step when either is set. */
+NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream);
 /* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images). */
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
 

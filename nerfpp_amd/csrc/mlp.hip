@@ -624,4 +624,14 @@ int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int precision
     return s;
 }
 
+int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream)
+{
+    NRF_CHECK_ARG(d_workspace && flags_out, "nrf_mlp_backward_f16_flags: null pointer");
+    uint32_t w[4] = {0, 0, 0, 0};
+    NRF_HIP(hipMemcpyAsync(w, d_workspace, sizeof(w), hipMemcpyDeviceToHost, as_stream(stream)));
+    NRF_HIP(hipStreamSynchronize(as_stream(stream)));
+    flags_out[0] = w[1]; flags_out[1] = w[2];
+    return NRF_OK;
+}
+
 }  // extern "C"

@@ -401,11 +401,19 @@ __global__ void k_absmax(int64_t n, const float *__restrict__ g, uint32_t *__res
     uint32_t m = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t b = __float_as_uint(g[i]) & 0x7fffffffu;
-        if (b < 0x7f800000u && b > m) m = b;            // finite values only
+        if (b < 0x7f800000u) { if (b > m) m = b; }      // the scale comes from the finite values ...
+        else out[1] = 1u;                                // ... and an inf / NaN in the incoming gradient is flagged (nrf_mlp_backward_f16_flags)
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, o); m = t > m ? t : m; }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// flags[2] = 1 if any accumulated parameter gradient is not finite (an fp16 operand or product of the chain overflowed)
+__global__ void k_flag_nonfinite(int64_t n, const float *__restrict__ g, uint32_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if ((__float_as_uint(g[i]) & 0x7fffffffu) >= 0x7f800000u) flags[2] = 1u;
 }
 
 struct BPacker {
@@ -526,7 +534,7 @@ static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __
     if (g_x && ((gxs % 4) != 0 || (reinterpret_cast<uintptr_t>(g_x) & 15))) { set_error("nrf_mlp_backward_f16: d_g_x rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
     uint32_t *absmax = reinterpret_cast<uint32_t *>(ws);
     half8 *scratch = reinterpret_cast<half8 *>(reinterpret_cast<unsigned char *>(ws) + 256);
-    NRF_HIP(hipMemsetAsync(absmax, 0, 4, st));
+    NRF_HIP(hipMemsetAsync(absmax, 0, 16, st));           // [0] max |g_out| bits, [1] non-finite input flag, [2] non-finite result flag
     {
         const int64_t n = p * gos;
         hipLaunchKernelGGL(k_absmax, dim3((unsigned)(ceil_div(n, (int64_t)256) < 1024 ? ceil_div(n, (int64_t)256) : 1024)), dim3(256), 0, st, n, g_out, absmax);
@@ -556,6 +564,8 @@ static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __
 #undef NRF_BW
         NRF_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(k_flag_nonfinite, dim3(64), dim3(256), 0, st, (int64_t)m->n_params, (const float *)g_params, absmax);
+    NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 

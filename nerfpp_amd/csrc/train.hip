@@ -443,21 +443,31 @@ __global__ void k_adam(int64_t n, float lr_over_bc1, float bc2_sqrt, float b1, f
 
 using namespace nrf;
 
+// stream-ordered scratch that is given back on every path out of its scope, the error returns included
+struct AsyncBuf {
+    void *p = nullptr;
+    hipStream_t st;
+    explicit AsyncBuf(hipStream_t s) : st(s) {}
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+    AsyncBuf(const AsyncBuf &) = delete;
+    AsyncBuf &operator=(const AsyncBuf &) = delete;
+};
+
 extern "C" {
 
 int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t count, float *d_loss_mse, float *d_grad, void *stream)
 {
     NRF_CHECK_ARG(d_pred && d_target && d_loss_mse && count > 0, "nrf_huber_loss: bad argument");
     hipStream_t st = as_stream(stream);
-    double *acc = nullptr;
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&acc), 2 * sizeof(double), st));
+    AsyncBuf buf(st);
+    NRF_HIP(hipMallocAsync(&buf.p, 2 * sizeof(double), st));
+    double *acc = static_cast<double *>(buf.p);
     NRF_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
     const unsigned grid = (unsigned)(ceil_div(count, 256) < 512 ? ceil_div(count, 256) : 512);
     hipLaunchKernelGGL(k_huber, dim3(grid), dim3(256), 0, st, count, 1.0f / (float)count, d_pred, d_target, acc, d_grad);
     NRF_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_finish_loss, dim3(1), dim3(1), 0, st, count, acc, d_loss_mse);
     NRF_LAUNCH_CHECK();
-    NRF_HIP(hipFreeAsync(acc, st));
     return NRF_OK;
 }
 
@@ -473,12 +483,12 @@ int nrf_raw2outputs_backward_noise(const float *d_raw, const float *d_z, const f
     NRF_CHECK_ARG(d_raw && d_z && d_dirs && d_g_rgb && d_g_raw && n >= 0 && s >= 1 && c >= 4 && d_stride >= 3, "nrf_raw2outputs_backward: bad argument");
     if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
-    float *lt = nullptr;
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&lt), (size_t)n * s * sizeof(float), st));
+    AsyncBuf buf(st);
+    NRF_HIP(hipMallocAsync(&buf.p, (size_t)n * s * sizeof(float), st));
+    float *lt = static_cast<float *>(buf.p);
     hipLaunchKernelGGL(k_raw2outputs_bwd, dim3((unsigned)ceil_div(n, BW_RAYS)), dim3(64 * BW_RAYS), 0, st, n, s, c, white_bkgr, d_raw, d_z, d_dirs, d_stride, d_g_rgb,
                        d_g_raw, lt, d_noise, noise_std);
     NRF_LAUNCH_CHECK();
-    NRF_HIP(hipFreeAsync(lt, st));
     return NRF_OK;
 }
 

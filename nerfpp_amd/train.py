@@ -133,6 +133,12 @@ class Trainer:
         else:
             L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
+        # fp16 gradient chain: was anything in it, or anything it produced, not finite?  (nrf_mlp_backward_f16_flags; the caller skips the step then)
+        self.overflow = False
+        if self.mlp_backward == "f16":
+            fl = (C.c_uint32 * 2)()
+            L.check(lib.nrf_mlp_backward_f16_flags(_ptr(self._ws), fl, _stream()))
+            self.overflow = bool(fl[0] or fl[1])
         return loss_mse
 
     @staticmethod
@@ -180,6 +186,9 @@ class Trainer:
             self.add_tv_loss()
         if self.grad_sync is not None:                     # data-parallel replicas: mean of the ranks' gradients (nerfpp_amd/dist.py::GradSync)
             self.grad_sync(self.g_table, self.g_blob)
+        if self.overflow:                                  # a non-finite gradient in the fp16 chain: no optimizer step (the moments would be poisoned for good)
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+            return loss_mse, res
         self.t += 1
         b1, b2 = self.betas
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):

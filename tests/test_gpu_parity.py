@@ -998,6 +998,19 @@ def test_mlp_backward_matrix_core_edges(api):
     g1 = torch.full((blob.size,), 0.5, device="cuda")
     api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(g1), None, P(ws), C.c_size_t(nb), None))            # no d_g_x; accumulates
     assert_close(host(g1) - 0.5, host(g0), rtol=1e-4, atol=1e-6 * float(g0.abs().max()), what="accumulation into a non-zero blob")
+    # overflow report (nrf_mlp_backward_f16_flags): clean after a normal call; an inf / NaN in the incoming gradient or a non-finite accumulated gradient is flagged
+    fl = (C.c_uint32 * 2)()
+    api.L.check(lib.nrf_mlp_backward_f16_flags(P(ws), fl, None))
+    assert (fl[0], fl[1]) == (0, 0)
+    gr_bad = gr.clone(); gr_bad[5, 2] = float("inf"); gr_bad[9, 0] = float("nan")
+    g2 = torch.zeros(blob.size, device="cuda")
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr_bad), C.c_int64(p), P(g2), None, P(ws), C.c_size_t(nb), None))
+    api.L.check(lib.nrf_mlp_backward_f16_flags(P(ws), fl, None))
+    assert fl[0] == 1 and fl[1] == 1, (fl[0], fl[1])
+    g3 = torch.zeros(blob.size, device="cuda"); g3[7] = float("inf")                         # a poisoned accumulator is reported too
+    api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gr), C.c_int64(p), P(g3), None, P(ws), C.c_size_t(nb), None))
+    api.L.check(lib.nrf_mlp_backward_f16_flags(P(ws), fl, None))
+    assert fl[0] == 0 and fl[1] == 1
     gz = torch.zeros_like(gr); g2 = torch.zeros(blob.size, device="cuda"); gx2 = torch.ones((p, 32), device="cuda")
     api.L.check(lib.nrf_mlp_backward_f16(m._m, P(x), P(gz), C.c_int64(p), P(g2), P(gx2), P(ws), C.c_size_t(nb), None))          # zero gradient in
     assert float(g2.abs().max()) == 0.0 and float(gx2.abs().max()) == 0.0
