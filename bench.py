@@ -370,17 +370,15 @@ def main():
         assert frames.shape[0] == nframes and bool(torch.isfinite(frames).all())
         if world == 1 and not use_dist and not args.no_also:
             line["also"] = secondary_measurements(args, scene, L, K, poses[0], sc)
-    if use_dist and not stuck:
-        dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints a version banner through C stdio when the process exits; the contract is ONE JSON line, so drain what is
-        # buffered, print the line, flush, and leave without running exit-time printers (the process group is already destroyed).
+        # The contract is ONE JSON line.  RCCL prints a version banner through C stdio when the process exits, and tearing the process group down is a collective
+        # that a slow or already-gone peer can stall: drain what is buffered, print the line, flush -- and in the distributed case every rank then leaves without
+        # running tear-down or exit-time printers (everything that was to be measured and checked is in the line).
         sys.stdout.flush()
         C.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
-        if use_dist:
-            os._exit(0)
-    elif stuck:
+    if use_dist:
+        sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
 
 
