@@ -455,6 +455,9 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 //   within 1 %) the kernel's time does not respond to how its instructions are ordered or split between the pipes: per wave and iteration it issues ~6.9 k cycles
 //   of instructions (MFMA 1.9 k, conversions 3.4 k, address arithmetic 1.1 k), two waves per SIMD make 13.9 k of the 24.9 k cycles an iteration takes, the matrix
 //   pipe is busy 14.1 k.
+//   * Ablation builds (results wrong on purpose; full kernel 11.1-11.8 ms on that box): one instruction instead of the ten conversions of a half-quad 8.9 ms;
+//     one A-fragment ds_read_b128 per layer instead of one per step 11.5 ms; one matrix product per step instead of three (40 of 116 MFMAs per tile) 5.2 ms.
+//     The time follows the SUM of the matrix and the vector work, not their maximum; LDS reads are free.
 // Tried and measured (same box): the last colour layer (64 -> 3, one 32-row tile with 3 useful rows = 12 of the split mode's 116 matrix instructions per tile)
 // moved to the vector ALUs in fp32, straight from the last hidden layer's D tiles.  Split mode: 13.63 vs 13.65 ms per frame -- nothing, although
 // 11 % of the matrix work is gone: the chip is holding its clock down under this load, so cycles taken off the matrix pipe and put on the
