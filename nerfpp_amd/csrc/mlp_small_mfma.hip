@@ -46,6 +46,11 @@ constexpr int block_pts_of(bool split) { return 32 * PT * waves_of(split); }
 // neuron (row of a D tile / k of the next layer) held by element j of lane-half h in k-step s of a 32-row tile
 __host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
+#ifndef NRF_SPLIT_RTZ
+#define NRF_SPLIT_RTZ 0             // split mode, hidden layers: 1 = ReLU folded into a truncating (hi, lo) split (2 instructions per value instead of 2.5);
+                                    // measured 11.65 vs 11.79 ms (same box, warm) with the frame's max error vs fp32 5.2e-6 instead of 3.5e-6: off
+#endif
+
 // D tile registers 8s..8s+7 -> fp16 B fragment (round to nearest even), optional ReLU
 template <bool RELU>
 __device__ __forceinline__ half8 tile_to_frag(const f32x16 &acc, int s)
@@ -72,13 +77,35 @@ __device__ __forceinline__ void split_pair(float v0, float v1, uint32_t &hi, uin
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
 }
 
+// ReLU folded into the split, 2 instructions per value: hi' = f16(v) rounded TOWARD ZERO (v_cvt_pkrtz_f16_f32, two values per instruction), so that the
+// residual v - hi' is zero or has the sign of v; then relu(v) = max(hi', 0) + max(v - hi', 0) exactly: the first max is one packed v_pk_max_f16 per pair,
+// the second is the clamp bit of the mixed-precision FMA that forms the residual (clamp = [0, 1]; the residual of a finite half is below 32).  hi keeps
+// 11 bits, lo 11 more starting at most one ulp(hi) down: v = hi + lo to 21 bits (22 with the round-to-nearest split).
+// The cvt is the compiler's (builtin), reads the MFMA result first and so carries the MFMA -> VALU hazard handling; the asm FMAs depend on its result.
+__device__ __forceinline__ void split_pair_relu(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 pre2 = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    const uint32_t pre = __builtin_bit_cast(uint32_t, pre2);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(lo) : "v"(pre), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(lo) : "v"(pre), "v"(v1));
+    hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, pre), f16x2{0, 0}));
+}
+
 template <bool RELU>
 __device__ __forceinline__ void tile_to_frag2(const f32x16 &acc, int s, half8 &hi, half8 &lo)
 {
     if constexpr (RELU) {
         union { half8 v; uint32_t u[4]; } h, l;
 #pragma unroll
-        for (int j = 0; j < 4; j++) split_pair(fmaxf(acc[8 * s + 2 * j], 0.0f), fmaxf(acc[8 * s + 2 * j + 1], 0.0f), h.u[j], l.u[j]);
+        for (int j = 0; j < 4; j++) {
+#if NRF_SPLIT_RTZ
+            split_pair_relu(acc[8 * s + 2 * j], acc[8 * s + 2 * j + 1], h.u[j], l.u[j]);
+#else
+            split_pair(fmaxf(acc[8 * s + 2 * j], 0.0f), fmaxf(acc[8 * s + 2 * j + 1], 0.0f), h.u[j], l.u[j]);
+#endif
+        }
         hi = h.v; lo = l.v;
     } else {
         // same two roundings (hi = RNE(v), lo = RNE(v - hi)) through the 1.5-instruction-per-value path
@@ -314,6 +341,28 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             (void)qm; (void)qc;
             if constexpr (SPLIT) {
                 const int pt = i >> 1, sh = i & 1;
+#if NRF_SPLIT_RTZ
+                // (see split_pair_relu) part 0: the two truncating packed conversions; part 1: four clamped residuals and the two packed ReLUs of hi
+                typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                const int b0 = 8 * sh + 4 * q;
+                if (part == 0) {
+                    qc[0] = __builtin_bit_cast(uint32_t, (fp16x2)__builtin_amdgcn_cvt_pkrtz(acc2[pt][t][b0], acc2[pt][t][b0 + 1]));
+                    qc[1] = __builtin_bit_cast(uint32_t, (fp16x2)__builtin_amdgcn_cvt_pkrtz(acc2[pt][t][b0 + 2], acc2[pt][t][b0 + 3]));
+                } else {
+                    uint32_t l0, l1;
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(l0) : "v"(qc[0]), "v"(acc2[pt][t][b0]));
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(l1) : "v"(qc[1]), "v"(acc2[pt][t][b0 + 2]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l0) : "v"(qc[0]), "v"(acc2[pt][t][b0 + 1]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l1) : "v"(qc[1]), "v"(acc2[pt][t][b0 + 3]));
+                    const uint32_t h0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, qc[0]), f16x2{0, 0}));
+                    const uint32_t h1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, qc[1]), f16x2{0, 0}));
+                    u32x4 hv = __builtin_bit_cast(u32x4, bh[buf][pt][2 * t + sh][0]), lv = __builtin_bit_cast(u32x4, bh[buf][pt][2 * t + sh][NP - 1]);
+                    hv[2 * q] = h0; hv[2 * q + 1] = h1; lv[2 * q] = l0; lv[2 * q + 1] = l1;
+                    bh[buf][pt][2 * t + sh][0] = __builtin_bit_cast(half8, hv); bh[buf][pt][2 * t + sh][NP - 1] = __builtin_bit_cast(half8, lv);
+                }
+                return;
+#endif
                 if (part == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) qm[e] = fmaxf(acc2[pt][t][8 * sh + 4 * q + e], 0.0f);
