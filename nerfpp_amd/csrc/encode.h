@@ -16,7 +16,7 @@ struct HashParams {
     const void *table;                      // NGP: fp32 [L][2^T][F];  CU: fp16 [L*2^T, F]
     float level_scale[NRF_MAX_LEVELS];      // NGP: floor()ed resolution;  CU: un-floored scale mul_l
     uint32_t primes[NRF_MAX_LEVELS * 3];    // CU
-    float bias[NRF_MAX_LEVELS * 3];         // CU
+    float bias[NRF_MAX_LEVELS * 3];         // CU: the level's offset;  NGP: the level's cell size (max - min) / res per axis
     int32_t local_idx[NRF_MAX_LEVELS];      // CU: level base offset in ELEMENTS (the reference's overlap quirk)
     uint32_t local_size[NRF_MAX_LEVELS];    // CU
     // baked dense image of the coarse levels (hash_fast.hip): entry offset into `dense` (-1: level stays hashed) and block grid

@@ -276,6 +276,10 @@ int nrf_hash_create(const nrf_hash_desc *desc, nrf_hash **out)
         // NeRF.cpp:251: b = float(exp((ln finest - ln base)/(L-1)));  :309: res_l = floor(float(base * pow(b, l)))
         const float b = (float)exp((log((double)desc->finest_resolution) - log((double)desc->base_resolution)) / (double)(L - 1));
         for (int l = 0; l < L; l++) hp.level_scale[l] = floorf((float)((double)desc->base_resolution * pow((double)b, (double)l)));
+        // NeRF.cpp:262: grid_size = (max - min) / resolution, one correctly rounded fp32 division per level and axis: formed here once, read by the
+        // level-major encode as a scalar (hash_fast.hip; the generic kernels divide on the device, same IEEE result)
+        for (int l = 0; l < L; l++)
+            for (int a = 0; a < 3; a++) hp.bias[l * 3 + a] = (hp.bbox.mx[a] - hp.bbox.mn[a]) / hp.level_scale[l];
     } else {
         // CuHashEmbedder.cu:40: mul_l = exp2f((log2f(finest) - log2f(base)) * l / (L-1) + log2f(base)), fp32 libm on the host
         for (int l = 0; l < L; l++)

@@ -11,7 +11,9 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
                    int level_lo = 0, int level_hi = -1);
 // out_lo (optional): the rounding residuals r - f16(r), for the split-precision MLP
 // f32_out: ONE float2 plane [L][pstride] of the unrounded fp32 features at feats instead (lo_off ignored)
-int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out = false);
+// f32_also (with the (hi, lo) form only): the fp32 features as well, as a level-major float2 plane [L][f32_stride]
+int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out = false,
+                       float2 *f32_also = nullptr, int64_t f32_stride = 0);
 int launch_dirs_f16(const float *rays, int stride, int64_t n, int degree, int variant, __half *out, __half *out_lo, hipStream_t st);
 
 constexpr int HASH_LM_DEFAULT_VARIANT = 0;

@@ -65,10 +65,9 @@ __device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const flo
 {
     float w[3];
     uint32_t idx[3];
-    const float res = hp.level_scale[l];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / res;
+        const float grid = hp.bias[l * 3 + a];          // (max - min) / res, divided once on the host (wave-uniform: a scalar load instead of a vector division)
         const float fl = floorf((xc[a] - hp.bbox.mn[a]) / grid);
         idx[a] = (uint32_t)(int32_t)fl;
         const float vmin = fl * grid + hp.bbox.mn[a];
@@ -116,7 +115,8 @@ __device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const flo
 // F32OUT: the unrounded fp32 features instead, as ONE level-major float2 plane at feats (the exact-fp32 coarse pass, sigma_small_f32.hip).
 template <int LPT, bool F32OUT = false>
 __global__ void __launch_bounds__(256)
-k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, int64_t lo_off, uint8_t *__restrict__ keep, int level0)
+k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, int64_t lo_off, uint8_t *__restrict__ keep, int level0,
+              float2 *__restrict__ f32_also = nullptr, int64_t f32_stride = 0)
 {
     const int level = level0 + blockIdx.y * LPT;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -144,6 +144,7 @@ k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fe
         else {
             feats[(int64_t)(level + j) * pstride + i] = hi[j];
             if (lo_off) feats[lo_off + (int64_t)(level + j) * pstride + i] = lo[j];
+            if (f32_also) f32_also[(int64_t)(level + j) * f32_stride + i] = full[j];       // the coarse pass of a feature-reusing render: both forms in one encode
         }
     }
     if (level == 0 && keep) keep[i] = kp ? 1 : 0;
@@ -279,7 +280,8 @@ int hash_fast_supported(const nrf_hash *h)
 }
 
 // HashEmbedder-mode level-major encode: hi plane at feats, lo plane at feats + lo_off (0 = none)
-int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out)
+int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 *feats, int64_t pstride, int64_t lo_off, uint8_t *keep, hipStream_t st, bool f32_out,
+                       float2 *f32_also, int64_t f32_stride)
 {
     if (p == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_HASH, st);
@@ -287,15 +289,15 @@ int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __ha
     const int64_t ntiles = ceil_div(p, 256);
     const int lc = (L * 3 / 4) & ~3;
     if (f32_out) {
-        if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4, true>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0);
+        if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4, true>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0, nullptr, 0);
         NRF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_hash_ngp_lm<1, true>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc);
+        hipLaunchKernelGGL((k_hash_ngp_lm<1, true>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc, nullptr, 0);
         NRF_LAUNCH_CHECK();
         return NRF_OK;
     }
-    if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0);
+    if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0, f32_also, f32_stride);
     NRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_hash_ngp_lm<1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc);
+    hipLaunchKernelGGL((k_hash_ngp_lm<1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc, f32_also, f32_stride);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

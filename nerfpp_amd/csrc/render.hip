@@ -147,24 +147,28 @@ static int run_sigma_fast(const nrf_renderer *r, const PointSource &ps, int64_t 
     return mlp_small_sigma_f32_lm(r->desc.mlp, feats, ngp ? 1 : 0, p, keep, p, sigma, st);
 }
 
-// Feature reuse across the two passes of a hierarchical render (CuHashEmbedder fast path, deterministic sample points): the fine pass evaluates the network at
+// Feature reuse across the two passes of a hierarchical render (both hash encoders' fast paths, deterministic sample points): the fine pass evaluates the network at
 // all S + N_importance depths (NeRFRenderer.h:431,447), S of which ARE the coarse pass's sample points -- same o + d z, same hash features, bit for bit.  The
 // feature table of a chunk therefore keeps the coarse pass's columns [0, n S), the hash encode of the fine pass runs on the N_importance NEW samples only
 // (columns [n S, n (S + N_importance))), and the MLP reads column src[i] for point i (k_fine_depths emits the map while it merges the two sorted runs).
 // A third of the fine pass's gathers (2.9 of 11.7 ms per 800x800 frame) is not issued; results are unchanged.
 struct ReuseWs {
     __half2 *feats;      // [16][cols] level-major
+    __half2 *feats_lo;   // HashEmbedder (fp32-valued features) in split precision: the plane of the rounding residuals, else null
+    float2 *f32;         // HashEmbedder, sigma-only coarse pass: the fp32 features of the coarse columns [16][n S] (sigma_small_f32.hip reads these), else null
     uint8_t *keep;       // [cols]
     int32_t *src;        // [n, sf]
     float *z_new;        // [n, ni]
     int64_t cols;
 };
 
-static int reuse_layout(void *ws, size_t ws_bytes, int64_t n, int s, int ni, ReuseWs &w)
+static int reuse_layout(void *ws, size_t ws_bytes, int64_t n, int s, int ni, bool want_lo, bool want_f32, ReuseWs &w)
 {
     Bump bump(ws, ws_bytes);
     w.cols = n * (int64_t)(s + ni);
     w.feats = bump.take<__half2>((size_t)w.cols * 16);
+    w.feats_lo = want_lo ? bump.take<__half2>((size_t)w.cols * 16) : nullptr;
+    w.f32 = want_f32 ? bump.take<float2>((size_t)n * s * 16) : nullptr;
     w.keep = bump.take<uint8_t>((size_t)w.cols);
     w.src = bump.take<int32_t>((size_t)w.cols);
     w.z_new = bump.take<float>((size_t)n * ni);
@@ -416,13 +420,15 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     // inputs, so the result is unchanged bit for bit.
     const bool reuse_raw = (fast || fast_classic) && ni > 0 && !sigma_only && !cone && !precond && c == 4 && n * (int64_t)sf < ((int64_t)1 << 31);
     // otherwise (the default split mode: coarse pass = sigma net alone) the coarse hash features are kept for the fine pass (see ReuseWs)
-    const bool reuse = !reuse_raw && fast && ni > 0 && r->desc.hash->desc.mode == NRF_HASH_CU && !cone && !precond && n * (int64_t)sf < ((int64_t)1 << 31);
+    const bool reuse = !reuse_raw && fast && ni > 0 && !cone && !precond && n * (int64_t)sf < ((int64_t)1 << 31);
+    const bool ngp = fast && r->desc.hash->desc.mode == NRF_HASH_NGP;       // HashEmbedder: fp32-valued features, (hi, lo) planes in split precision
     ReuseWs rw{};
     if (reuse) {
-        NRF_TRY(reuse_layout(nws, nws_bytes, n, s, ni, rw));
-        NRF_TRY(launch_hash_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.keep, HASH_LM_DEFAULT_VARIANT, st));
-        if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, rw.feats, 0, rw.cols, rw.keep, n * (int64_t)s, raw_c, st));
-        else NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, nullptr, rw.cols, dirs16, dirs_lo, s, rw.keep, n * (int64_t)s, raw_c, st));
+        NRF_TRY(reuse_layout(nws, nws_bytes, n, s, ni, ngp && dirs_lo, ngp && sigma_only, rw));
+        if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep, st, false, rw.f32, n * (int64_t)s));
+        else NRF_TRY(launch_hash_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.keep, HASH_LM_DEFAULT_VARIANT, st));
+        if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, ngp ? static_cast<const void *>(rw.f32) : rw.feats, ngp ? 1 : 0, ngp ? n * (int64_t)s : rw.cols, rw.keep, n * (int64_t)s, raw_c, st));
+        else NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, s, rw.keep, n * (int64_t)s, raw_c, st));
     } else if (sigma_only) NRF_TRY(run_sigma_fast(r, ps, n, s, raw_c, nws, nws_bytes, st));                       // raw_c holds sigma [n,s] only
     else NRF_TRY(network(ps, s, raw_c));                                                                           // :422
     nz.stream = NRF_RNG_NOISE_COARSE;
@@ -451,8 +457,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     } else if (reuse) {
         // the hash encode of the N_importance new samples only; the MLP gathers every depth's column through the merge map
         PointSource psn{nullptr, d_rays, rw.z_new, ray_stride, ni};
-        NRF_TRY(launch_hash_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.keep + n * (int64_t)s, HASH_LM_DEFAULT_VARIANT, st));
-        NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, nullptr, rw.cols, dirs16, dirs_lo, sf, rw.keep, n * (int64_t)sf, raw_f, st, rw.src));
+        if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep + n * (int64_t)s, st));
+        else NRF_TRY(launch_hash_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.keep + n * (int64_t)s, HASH_LM_DEFAULT_VARIANT, st));
+        NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, sf, rw.keep, n * (int64_t)sf, raw_f, st, rw.src));
     } else NRF_TRY(network(psf, sf, raw_f));                                                                       // :447
     nz.stream = NRF_RNG_NOISE_FINE;
     return launch_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,

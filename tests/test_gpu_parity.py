@@ -1363,8 +1363,38 @@ def test_ngp_fast_path_features_equal_generic_encoder(api):
     ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)                 # fp32 rows -> the kernel splits them itself: same hi/lo operands
     ref[~keep, 3] = 0
     assert_exact(host(res.Raw).reshape(-1, 4), host(ref), "fast path raw == stage-wise split raw (identical hi/lo operands, identical lookups)")
+    # the default split render (sigma-only fp32 coarse pass; the fine pass keeps the coarse columns of both feature planes and encodes the new samples only)
+    rp2 = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates="depths")
+    res2 = sc["renderer"].Render(800, 800, K, rp2, c2w=c2w, row0=400, rows=2)
+    zf2 = res2.Extras["z_fine"]
+    pts2 = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf2[..., None]).reshape(-1, 3)
+    emb2, keep2 = sc["embedder"].forward(pts2)
+    x2 = torch.cat([emb2, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+    ref2 = sc["mlp"].forward(x2, api.L.NRF_PREC_F16_SPLIT)
+    ref2[~keep2, 3] = 0
+    assert_exact(host(res2.Raw).reshape(-1, 4), host(ref2), "feature-reusing fine pass == stage-wise evaluation of all S + N_importance points")
     f32 = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=400, rows=2)
     assert api.S.psnr(host(res.Outputs.RGBMap), host(f32.Outputs.RGBMap)) > 85
+
+
+def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
+    """Default split render of the CuHashEmbedder scene (sigma-only coarse pass; the fine pass keeps the coarse pass's feature columns, encodes the N_importance
+    new samples only and reads every depth's column through the merge map of k_fine_depths): the network outputs at all S + N_importance depths equal the
+    stage-wise evaluation (encoder, SH, split MLP on explicit points) bit for bit -- ragged chunk sizes included."""
+    sc = api.S.make_hash_scene(mode="cu")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates="depths")
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=399, rows=2)
+    rays = res.Extras["rays_flat"]; zf = res.Extras["z_fine"]
+    n, s = zf.shape
+    assert s == 192
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
+    emb, keep = sc["embedder"].forward(pts)
+    dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+    x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+    ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)
+    ref[~keep, 3] = 0
+    assert_exact(host(res.Raw).reshape(-1, 4), host(ref), "feature-reusing fine pass == stage-wise evaluation of all S + N_importance points")
 
 
 def test_tv_loss_vs_oracle_and_reference(api, O, manifest):

@@ -1,10 +1,10 @@
-"""frame time + per-kernel ms of the HashNeRF render for tuning builds (NRF_LIB_PATH); arg: f16x3 | f16"""
+"""frame time + per-kernel ms of the HashNeRF render for tuning builds (NRF_LIB_PATH); args: f16x3 | f16 [cu | ngp]"""
 import sys, os, time, ctypes as C, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from nerfpp_amd import _lib as L, scene as S, renderer as R
 H = W = 800
 prec = {"f16x3": L.NRF_PREC_F16_SPLIT, "f16": L.NRF_PREC_F16_MFMA}[sys.argv[1] if len(sys.argv) > 1 else "f16x3"]
-sc = S.make_hash_scene(mode="cu", table_amp=0.5, sigma_scale=30.0)
+sc = S.make_hash_scene(mode=sys.argv[2] if len(sys.argv) > 2 else "cu", table_amp=0.5, sigma_scale=30.0)
 K = S.lego_K(H, W); c2w = S.pose_spherical(30.0, -30.0, 4.0)
 rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=131072, Perturb=0.0, WhiteBkgr=True, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX, Precision=prec)
 r = sc["renderer"]
