@@ -41,7 +41,7 @@ def executed_per_ray(workload, precision, hash_mode):
     if workload == "classic":
         return 0, NS + NI, 0
     if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32)
-        return (NS + NI) if hash_mode == "cu" else UNITS_PER_RAY, NS + NI, NS
+        return NS + NI, NS + NI, NS                           # both encoders: the fine pass keeps the coarse pass's feature columns
     return NS + NI, NS + NI, 0                                # plain fp16: coarse outputs reused by the fine pass
 
 # algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)

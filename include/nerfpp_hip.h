@@ -155,6 +155,9 @@ NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, floa
 /* CuHashEmbedder mode: the same features level-major in fp16, d_feats [n_levels][p][n_features] halfs (16-byte aligned) -- the values the row-major call
  * returns (they are fp16-rounded there too, CuHashEmbedder.cu:95) in the layout a matrix-core consumer loads as operand fragments. */
 NRF_API int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream);
+/* ... into p columns of a wider table: level l of point i at d_feats + (l * pstride + i) * n_features halfs (d_feats = the first column to write, aligned to one
+ * point's n_features * 2 bytes).  A renderer that keeps the coarse pass's columns next to the fine pass's new ones (see nrf_fine_depths_merge) encodes each once. */
+NRF_API int nrf_hash_encode_lm_f16_strided(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, int64_t pstride, uint8_t *d_keep_mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MLPs                                                         BaseNeRFImpl::forward (NeRF.h:33-42)
@@ -226,6 +229,11 @@ NRF_API int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const 
 /* ... reading the level-major fp16 features of nrf_hash_encode_lm_f16 (16 levels x 8 features: [16][p][8] halfs) instead of fp32 rows. */
 NRF_API int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
 NRF_API int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
+/* ... on columns of a wider level-major table ([16][pstride][8] halfs): _strided evaluates p consecutive columns starting at d_feats_lm; _gather reads column
+ * d_src[i] for sample i of the n * s sorted depths (d_src = the merge map of nrf_fine_depths_merge; NULL = column i).  Same arithmetic, same results. */
+NRF_API int nrf_lerf_sigma_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
+NRF_API int nrf_lerf_render_embedding_lm_gather(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const float *d_weights, int64_t n,
+                                                int s, float *d_out, void *stream);
 
 /* RenderCLIPEmbedding (LeRFRenderer.h:45-54): out[n, embed_dim] = normalize(sum_s weights[n,s] * embeds[n,s,:embed_dim], eps 1e-8).
  * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]).  Relevancy(...) (LeRFRenderer.cpp:79) lives
@@ -244,6 +252,14 @@ NRF_API int nrf_sample_pdf(const float *d_bins, const float *d_weights, int64_t 
  * sort(cat(z, samples)).  z [n,s], weights [n,s] -> z_fine [n, s+ns]. */
 NRF_API int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec,
                             float *d_z_fine, void *stream);
+/* ... and where each sorted depth came from.  s of the s + ns depths of a ray ARE its coarse depths (same z, hence the same sample point and the same
+ * encoder features, bit for bit), so a fine pass need only encode the ns new ones:
+ *   d_src [n, s+ns] int32 : column of sorted depth (ray, i) in a table holding the coarse pass's n*s points first (ray-major) and the n*ns new points after
+ *                           them: ray*s + j for coarse depth j, n*s + ray*ns + j for new sample j
+ *   d_z_new [n, ns]       : the new samples' depths in SamplePDF order (ascending)
+ * nrf_render_rays does this internally; the entry serves hosts that drive the passes themselves (the LeRF render pass).  n (s + ns) < 2^31. */
+NRF_API int nrf_fine_depths_merge(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec,
+                                  float *d_z_fine, int32_t *d_src, float *d_z_new, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stochastic branches of RenderRays (Perturb > 0, cone rays, training-time noise).  The stage functions take the random

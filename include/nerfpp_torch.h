@@ -350,7 +350,56 @@ private:
 		return o;
 	}
 
+	/// Both passes with every sample point encoded ONCE (level-major fused path): the fine pass's S + N_importance depths contain the S coarse ones, whose
+	/// features and sigma_le exist -- the hash encode and the sigma net run on the N_importance new samples only, the embedding pass reads every depth's feature
+	/// column through the merge map of nrf_fine_depths_merge.  Same kernels on the same inputs: equal to two FusedPass calls bit for bit (weights, maps).
+	LeRFPassOutputs FusedPassesReusing(torch::Tensor rays, torch::Tensor z, torch::Tensor rays_d, const int ni, torch::Tensor *z_fine)
+	{
+		const int64_t n = z.size(0); const int s = (int)z.size(1), sf = s + ni; const int stride = (int)rays.size(1);
+		const int64_t cols = n * sf, nc = n * s, nn = n * (int64_t)ni;
+		auto opt = rays.options();
+		const nrf_hash *h = LangEmbedFn->GetHandle();
+		auto x = torch::empty({16, cols, 8}, opt.dtype(torch::kFloat16));
+		auto keep = torch::empty({cols}, opt.dtype(torch::kUInt8));
+		auto sig = torch::empty({cols}, opt);                                      // [coarse n*s | new n*ni]: the table's column order
+		auto pts = torch::empty({nc, 3}, opt);
+		check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
+		check(nrf_hash_encode_lm_f16_strided(h, pts.data_ptr<float>(), nc, x.data_ptr(), cols, keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16_strided");
+		check(nrf_lerf_sigma_lm_strided(Mlp.m, x.data_ptr(), cols, keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma_lm_strided");
+		auto weights = [&](const float *sg, torch::Tensor zz, int ss) {
+			LeRFPassOutputs o;
+			o.WeightsLE = torch::empty({n, (int64_t)ss}, opt); o.DepthMapLE = torch::empty({n}, opt); o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt);
+			check(nrf_raw2weights(sg, 1, 0, zz.data_ptr<float>(), rays_d.data_ptr<float>(), 3, n, ss, o.WeightsLE.data_ptr<float>(), o.DepthMapLE.data_ptr<float>(),
+				o.DispMapLE.data_ptr<float>(), o.AccMapLE.data_ptr<float>(), current_stream()), "nrf_raw2weights");
+			return o;
+		};
+		LeRFPassOutputs coarse = weights(sig.data_ptr<float>(), z, s);
+		auto u = torch::linspace(0.f, 1.f, ni, torch::kFloat).to(rays.device());
+		auto zf = torch::empty({n, (int64_t)sf}, opt), z_new = torch::empty({n, (int64_t)ni}, opt);
+		auto src = torch::empty({n, (int64_t)sf}, opt.dtype(torch::kInt32));
+		check(nrf_fine_depths_merge(z.data_ptr<float>(), coarse.WeightsLE.data_ptr<float>(), n, s, u.data_ptr<float>(), ni, 8, zf.data_ptr<float>(), src.data_ptr<int32_t>(),
+			z_new.data_ptr<float>(), current_stream()), "nrf_fine_depths_merge");
+		auto pts_new = torch::empty({nn, 3}, opt);
+		check(nrf_points(rays.data_ptr<float>(), stride, z_new.data_ptr<float>(), n, ni, pts_new.data_ptr<float>(), current_stream()), "nrf_points");
+		void *x_new = static_cast<char *>(x.data_ptr()) + nc * 8 * 2;             // column n*s of level 0
+		check(nrf_hash_encode_lm_f16_strided(h, pts_new.data_ptr<float>(), nn, x_new, cols, keep.data_ptr<uint8_t>() + nc, current_stream()), "nrf_hash_encode_lm_f16_strided");
+		check(nrf_lerf_sigma_lm_strided(Mlp.m, x_new, cols, keep.data_ptr<uint8_t>() + nc, nn, sig.data_ptr<float>() + nc, current_stream()), "nrf_lerf_sigma_lm_strided");
+		auto sig_f = sig.index_select(0, src.reshape({-1}).to(torch::kLong));      // sigma_le of the sorted depths
+		LeRFPassOutputs o = weights(sig_f.data_ptr<float>(), zf, sf);
+		const int E = GetLangEmbedDim();
+		auto acc = torch::empty({n, (int64_t)E}, opt);
+		check(nrf_lerf_render_embedding_lm_gather(Mlp.m, x.data_ptr(), cols, src.data_ptr<int32_t>(), o.WeightsLE.data_ptr<float>(), n, sf, acc.data_ptr<float>(), current_stream()),
+			"nrf_lerf_render_embedding_lm_gather");
+		auto ones = torch::ones({n, 1}, opt);
+		o.RenderedLangEmbedding = torch::empty({n, (int64_t)E}, opt);
+		check(nrf_render_clip_embedding(acc.data_ptr<float>(), E, E, ones.data_ptr<float>(), n, 1, o.RenderedLangEmbedding.data_ptr<float>(), current_stream()), "nrf_render_clip_embedding");
+		if (z_fine) *z_fine = zf;
+		return o;
+	}
+
 public:
+	bool ReuseFeatures = true;          ///< level-major fused path: encode every sample point once per render (false: two plain passes)
+
 	/// LeRFRenderer::RenderRays (LeRFRenderer.cpp:85-187), deterministic path (Perturb = 0, RawNoiseStd = 0, ThinRay): the fused matrix-core passes when the
 	/// sample counts are multiples of 32 (a wave's 32-point tile lies inside one ray), the fp32 stage path otherwise.  z_fine (optional) receives the fine depths.
 	LeRFPassOutputs RenderRays(torch::Tensor ray_batch, const int n_samples, const bool lin_disp = false, const int n_importance = 0, const bool return_weights = true,
@@ -371,6 +420,11 @@ public:
 			check(nrf_points(rays.data_ptr<float>(), stride, zz.data_ptr<float>(), n, (int)zz.size(1), pts.data_ptr<float>(), current_stream()), "nrf_points");
 			return RawToLEOutputs(RunLENetwork(pts), zz, rays_d, GetLangEmbedDim());
 		};
+		if (fused && LevelMajor && ReuseFeatures && ni > 0 && n * (int64_t)(s + ni) < ((int64_t)1 << 31)) {
+			LeRFPassOutputs out = FusedPassesReusing(rays, z, rays_d, ni, z_fine);
+			if (!return_weights) { out.WeightsLE = torch::Tensor(); out.LangEmbedding = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }
+			return out;
+		}
 		LeRFPassOutputs out = fused ? FusedPass(rays, z, rays_d, ni == 0) : stage(z);
 		if (ni > 0) {
 			auto u = torch::linspace(0.f, 1.f, ni, torch::kFloat).to(rays.device());

@@ -63,12 +63,12 @@ SYMBOLS = [
     "nrf_mlp_output_dims", "nrf_mlp_forward",
     "nrf_mlp_lerf_param_count", "nrf_mlp_lerf_create",
     "nrf_lerf_mfma_available", "nrf_lerf_set_precision", "nrf_lerf_sigma", "nrf_lerf_render_embedding",
-    "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths",
+    "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths", "nrf_fine_depths_merge",
     "nrf_rng_fill", "nrf_jitter_z", "nrf_tangent_scatter", "nrf_precondition", "nrf_raw2outputs_noise", "nrf_sample_pdf_rand", "nrf_fine_depths_rand",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays",
     "nrf_normalize_depth", "nrf_to_u8",
-    "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_lerf_sigma_lm", "nrf_lerf_render_embedding_lm", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_mlp_set_params",
+    "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_hash_encode_lm_f16_strided", "nrf_lerf_sigma_lm", "nrf_lerf_sigma_lm_strided", "nrf_lerf_render_embedding_lm", "nrf_lerf_render_embedding_lm_gather", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_mlp_set_params",
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",

@@ -422,6 +422,14 @@ int nrf_fine_depths(const float *d_z, const float *d_weights, int64_t n, int s, 
     return launch_fine_depths(d_z, d_weights, n, s, d_u, 0, RngRef{0, 0}, ns, sum_vec, d_z_fine, as_stream(stream));
 }
 
+int nrf_fine_depths_merge(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec, float *d_z_fine, int32_t *d_src,
+                          float *d_z_new, void *stream)
+{
+    NRF_CHECK_ARG(d_z && d_weights && d_u && d_z_fine && d_src && d_z_new && n >= 0, "nrf_fine_depths_merge: bad argument");
+    NRF_CHECK_ARG(n * (int64_t)(s + ns) < ((int64_t)1 << 31), "nrf_fine_depths_merge: n (s + ns) must fit the int32 column map");
+    return launch_fine_depths(d_z, d_weights, n, s, d_u, 0, RngRef{0, 0}, ns, sum_vec, d_z_fine, as_stream(stream), d_src, d_z_new);
+}
+
 int nrf_fine_depths_rand(const float *d_z, const float *d_weights, int64_t n, int s, const float *d_u, int ns, int sum_vec, float *d_z_fine, void *stream)
 {
     NRF_CHECK_ARG(d_z && d_weights && d_u && d_z_fine && n >= 0, "nrf_fine_depths_rand: bad argument");

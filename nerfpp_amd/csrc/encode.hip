@@ -148,7 +148,7 @@ __global__ void k_hash_cu(HashParams hp, PointSource ps, int64_t p, float *__res
 // 16-byte store per thread and exactly the operand fragment of a matrix-core consumer: k-step s, lane half h = level 2s + h (mlp_lerf_mfma.hip).
 // The values are the row-major kernel's (one fp16 rounding of the fp32 blend, .cu:95), so consumers see identical inputs.
 template <int F>
-__global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *__restrict__ feats, uint8_t *__restrict__ keep)
+__global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = blockIdx.y;
@@ -177,7 +177,7 @@ __global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *
     __half o[F];
 #pragma unroll
     for (int f = 0; f < F; f++) o[f] = __float2half_rn(acc[f]);
-    __half *dst = feats + ((int64_t)l * p + i) * F;
+    __half *dst = feats + ((int64_t)l * pstride + i) * F;
     if constexpr (F == 8) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
     else if constexpr (F == 4) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
     else if constexpr (F == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(o);
@@ -361,10 +361,15 @@ int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
 
 int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream)
 {
-    NRF_CHECK_ARG(h && d_x && d_feats && p >= 0, "nrf_hash_encode_lm_f16: bad argument");
+    return nrf_hash_encode_lm_f16_strided(h, d_x, p, d_feats, p, d_keep_mask, stream);
+}
+
+int nrf_hash_encode_lm_f16_strided(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, int64_t pstride, uint8_t *d_keep_mask, void *stream)
+{
+    NRF_CHECK_ARG(h && d_x && d_feats && p >= 0 && pstride >= p, "nrf_hash_encode_lm_f16: bad argument");
     if (h->desc.mode != NRF_HASH_CU) { set_error("nrf_hash_encode_lm_f16: built for the CuHashEmbedder (its features ARE fp16, CuHashEmbedder.cu:95); the HashEmbedder's are fp32"); return NRF_ERR_UNSUPPORTED; }
     if (!h->table_set || !h->primes_set) { set_error("nrf_hash_encode_lm_f16: table / primes not set"); return NRF_ERR_INVALID_ARG; }
-    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats) & 15) == 0, "nrf_hash_encode_lm_f16: feature buffer must be 16-byte aligned");
+    NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats) & (size_t)(h->desc.n_features * 2 - 1)) == 0, "nrf_hash_encode_lm_f16: feature buffer must be aligned to one point's %d bytes", h->desc.n_features * 2);
     if (p == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(NRF_PROF_HASH, st);
@@ -372,10 +377,10 @@ int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void 
     const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)h->desc.n_levels);
     __half *f = reinterpret_cast<__half *>(d_feats);
     switch (h->desc.n_features) {
-        case 1: hipLaunchKernelGGL(k_hash_cu_lmf<1>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
-        case 2: hipLaunchKernelGGL(k_hash_cu_lmf<2>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
-        case 4: hipLaunchKernelGGL(k_hash_cu_lmf<4>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
-        case 8: hipLaunchKernelGGL(k_hash_cu_lmf<8>, grid, dim3(256), 0, st, h->params, ps, p, f, d_keep_mask); break;
+        case 1: hipLaunchKernelGGL(k_hash_cu_lmf<1>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
+        case 2: hipLaunchKernelGGL(k_hash_cu_lmf<2>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
+        case 4: hipLaunchKernelGGL(k_hash_cu_lmf<4>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
+        case 8: hipLaunchKernelGGL(k_hash_cu_lmf<8>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
         default: set_error("nrf_hash_encode_lm_f16: n_features %d not built (1, 2, 4, 8)", h->desc.n_features); return NRF_ERR_UNSUPPORTED;
     }
     NRF_LAUNCH_CHECK();

@@ -199,8 +199,9 @@ k_lerf_mfma(int64_t npts, Args in, const half8 *__restrict__ packed)
         half8 none[1];
         auto load_x = [&](half8 (&xin)[8]) {
             if (in.x_lm) {
+                const int64_t col = in.src ? (int64_t)in.src[qc] : qc;
 #pragma unroll
-                for (int s = 0; s < 8; s++) xin[s] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + qc) * 8);
+                for (int s = 0; s < 8; s++) xin[s] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + col) * 8);
                 return;
             }
             const float *row = in.x + qc * in.x_stride;
@@ -451,11 +452,16 @@ int nrf_lerf_render_embedding(const nrf_mlp *m, const float *d_x, const float *d
 // the same two passes reading level-major fp16 features (nrf_hash_encode_lm_f16 of a 16-level, 8-feature CuHashEmbedder): [16][p][8] halfs
 int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream)
 {
-    NRF_CHECK_ARG(m && d_feats_lm && d_sigma && p >= 0, "nrf_lerf_sigma_lm: bad argument");
+    return nrf_lerf_sigma_lm_strided(m, d_feats_lm, p, d_keep, p, d_sigma, stream);
+}
+
+int nrf_lerf_sigma_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_sigma && p >= 0 && pstride >= p, "nrf_lerf_sigma_lm: bad argument");
     if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma_lm: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_sigma_lm: features must be 16-byte aligned");
     if (p == 0) return NRF_OK;
-    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), p, nullptr, d_keep, d_sigma, nullptr, 32};
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), pstride, nullptr, d_keep, d_sigma, nullptr, 32};
     if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_sigma(m, a, p, as_stream(stream));
     ProfScope prof(NRF_PROF_MLP, as_stream(stream));
     return launch_lerf<2>(m, a, p, as_stream(stream));
@@ -463,12 +469,20 @@ int nrf_lerf_sigma_lm(const nrf_mlp *m, const void *d_feats_lm, const uint8_t *d
 
 int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
 {
+    return nrf_lerf_render_embedding_lm_gather(m, d_feats_lm, n * (int64_t)s, nullptr, d_weights, n, s, d_out, stream);
+}
+
+int nrf_lerf_render_embedding_lm_gather(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const float *d_weights, int64_t n, int s,
+                                        float *d_out, void *stream)
+{
     NRF_CHECK_ARG(m && d_feats_lm && d_weights && d_out && n >= 0 && s >= 1, "nrf_lerf_render_embedding_lm: bad argument");
+    NRF_CHECK_ARG(d_src ? pstride >= 1 : pstride >= n * (int64_t)s, "nrf_lerf_render_embedding_lm: column stride %lld too small", (long long)pstride);
     if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_render_embedding_lm: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
     NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding_lm: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats_lm) & 15) == 0, "nrf_lerf_render_embedding_lm: features must be 16-byte aligned");
     if (n == 0) return NRF_OK;
-    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), n * (int64_t)s, d_weights, nullptr, nullptr, nullptr, s};
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), pstride, d_weights, nullptr, nullptr, nullptr, s};
+    a.src = d_src;
     if (m->lerf_precision == NRF_PREC_F16_SPLIT) return lerf_split_embedding_passes(m, a, n, s, d_out, as_stream(stream));
     return lerf_embedding_passes(m, a, n, s, d_out, as_stream(stream));
 }

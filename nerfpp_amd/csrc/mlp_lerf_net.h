@@ -54,6 +54,7 @@ struct Args {
     float *out;                             // [n, 768] accumulated (kernel B)
     int s;                                  // samples per ray, a multiple of 32
     float gram_scale;                       // the image's Gram matrix is (W^T W) / gram_scale (a power of two keeping it inside fp16 range); set by the launchers
+    const int32_t *src;                     // optional (x_lm): point q reads feature column src[q] -- the merge map of a feature-reusing fine pass (nrf_fine_depths_merge)
 };
 
 }  // namespace lerf

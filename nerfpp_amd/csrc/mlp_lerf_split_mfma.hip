@@ -229,9 +229,10 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
         // input operand: element j of k-step s is x[q][16 s + 8 h + j]; needed by layer 0 and again by layer 2 (cat[geo, in]): read twice
         auto load_x = [&](half8 (&xin)[8][2]) {
             if (in.x_lm) {
+                const int64_t col = in.src ? (int64_t)in.src[qc] : qc;
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
-                    xin[s][0] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + qc) * 8);
+                    xin[s][0] = *reinterpret_cast<const half8 *>(in.x_lm + ((int64_t)(2 * s + h) * in.pstride + col) * 8);
                     xin[s][1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
                 return;

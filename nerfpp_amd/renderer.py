@@ -444,6 +444,7 @@ class LeRFRenderer:
         self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
         # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
         self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
+        self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
         if self.fused:
             self.set_precision(precision)
@@ -473,6 +474,38 @@ class LeRFRenderer:
         ku8 = keep.to(torch.uint8)
         L.check(L.lib().nrf_lerf_sigma(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
         return sig, x
+
+    def _render_fine_reusing(self, rays, stride, z, pts, rays_d, ni):
+        """Both passes of a hierarchical render with every sample point encoded ONCE (level-major fused path): the fine pass's S + N_importance depths contain the
+        S coarse ones, whose features and sigma_le exist already -- the hash encode and the sigma net run on the N_importance new samples only, the embedding pass
+        reads every depth's feature column through the merge map (nrf_fine_depths_merge).  Same kernels on the same inputs: results equal the plain two-pass
+        evaluation bit for bit.  Returns (coarse outputs, fine outputs, z_fine)."""
+        n, s = z.shape
+        sf, dev = s + ni, z.device
+        cols = n * sf
+        lib, h, m = L.lib(), self.LangEmbedFn._h, self.Lerf._m
+        x = torch.empty((16, cols, 8), device=dev, dtype=torch.float16)
+        keep = torch.empty((cols,), device=dev, dtype=torch.uint8)
+        sig = torch.empty((cols,), device=dev, dtype=torch.float32)           # [coarse n*s | new n*ni], the table's column order
+        L.check(lib.nrf_hash_encode_lm_f16_strided(h, _ptr(pts), C.c_int64(n * s), _ptr(x), C.c_int64(cols), _ptr(keep), _stream()))
+        L.check(lib.nrf_lerf_sigma_lm_strided(m, _ptr(x), C.c_int64(cols), _ptr(keep), C.c_int64(n * s), _ptr(sig), _stream()))
+        out1 = self._weights_from_sigma(sig[:n * s].view(n, s), z, rays_d)
+        u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
+        zf = torch.empty((n, sf), device=dev); src = torch.empty((n, sf), device=dev, dtype=torch.int32); z_new = torch.empty((n, ni), device=dev)
+        L.check(lib.nrf_fine_depths_merge(_ptr(z), _ptr(out1.WeightsLE), C.c_int64(n), s, _ptr(u), ni, ATEN_SUM_VEC, _ptr(zf), _ptr(src), _ptr(z_new), _stream()))
+        pts_new = torch.empty((n, ni, 3), device=dev)
+        L.check(lib.nrf_points(_ptr(rays), stride, _ptr(z_new), C.c_int64(n), ni, _ptr(pts_new), _stream()))
+        x_new = C.c_void_p(x.data_ptr() + n * s * 8 * 2)                      # column n*s of level 0
+        L.check(lib.nrf_hash_encode_lm_f16_strided(h, _ptr(pts_new), C.c_int64(n * ni), x_new, C.c_int64(cols), _ptr(keep[n * s:]), _stream()))
+        L.check(lib.nrf_lerf_sigma_lm_strided(m, x_new, C.c_int64(cols), _ptr(keep[n * s:]), C.c_int64(n * ni), _ptr(sig[n * s:]), _stream()))
+        sig_f = sig[src.reshape(-1).long()].view(n, sf)
+        o = self._weights_from_sigma(sig_f, zf, rays_d)
+        E = self.Lerf.GetLangEmbedDim()
+        acc = torch.empty((n, E), device=dev, dtype=torch.float32)
+        L.check(lib.nrf_lerf_render_embedding_lm_gather(m, _ptr(x), C.c_int64(cols), _ptr(src), _ptr(o.WeightsLE), C.c_int64(n), sf, _ptr(acc), _stream()))
+        ones = torch.ones((n, 1), device=dev, dtype=torch.float32)
+        o.RenderedLangEmbedding = _clip_embedding(acc, E, E, ones)
+        return out1, o, zf
 
     def _weights_from_sigma(self, sig, z, rays_d):
         n, s = sig.shape
@@ -538,6 +571,12 @@ class LeRFRenderer:
         L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
         rays_d = rays[:, 3:6].contiguous()
         res = LeRFRenderResult()
+        if self.fused and self.level_major and self.reuse_features and not return_raw and ni > 0 and s % 32 == 0 and (s + ni) % 32 == 0 and n * (s + ni) < (1 << 31):
+            out1, res.Outputs, zf = self._render_fine_reusing(rays, stride, z, pts, rays_d, ni)
+            res.Extras["z_fine"] = zf; res.Extras["z_coarse"] = z; res.Extras["weights_coarse"] = out1.WeightsLE
+            if not return_weights:
+                res.Outputs.WeightsLE = None; res.Outputs.RenderedLangEmbedding = None      # LeRFRenderer.cpp:180-185
+            return res
         if self.fused and not return_raw and s % 32 == 0 and (ni == 0 or (s + ni) % 32 == 0):
             # coarse pass: only sigma_le is consumed (the reference also renders a coarse embedding, LeRFRenderer.cpp:139, and drops it)
             out1 = self._render_fused(pts, z, rays_d, want_embedding=(ni == 0))

@@ -164,7 +164,7 @@ int main(int argc, const char **argv)
 	// ---- LeRF render pass (BASELINE config 4): nrfpp::HipLeRFPass -- what HipLeRFRenderer : LeRFRenderer forwards to -- against the reference's own LeRF module
 	// (LeRF.cpp, LibTorch CPU) and RenderCLIPEmbedding (LeRFRenderer.h:45-54) on the same sample points.  The language hash grid is CUDA-only in the
 	// reference (CuHashEmbedder), so its features come from the HIP encoder on both sides.
-	bool lerf_ok = false, lerf_fused = false;
+	bool lerf_ok = false, lerf_fused = false, lerf_reuse_same = false;
 	double lerf_cos_min = 0.0, lerf_w_err = 1.0, lerf_f16_cos_min = 0.0;
 	std::string lerf_note = "ok";
 	try {
@@ -200,6 +200,13 @@ int main(int argc, const char **argv)
 		torch::Tensor zf;
 		auto got = pass.RenderRays(rays_, 64, false, 128, true, &zf);
 		stage("LeRF fused RenderRays done");
+		// the feature-reusing passes (default) against the two plain passes: same kernels on the same inputs
+		pass.ReuseFeatures = false;
+		torch::Tensor zf2;
+		auto plain = pass.RenderRays(rays_, 64, false, 128, true, &zf2);
+		pass.ReuseFeatures = true;
+		lerf_reuse_same = torch::equal(zf, zf2) && torch::equal(got.WeightsLE, plain.WeightsLE) && torch::equal(got.DepthMapLE, plain.DepthMapLE) &&
+			(got.RenderedLangEmbedding - plain.RenderedLangEmbedding).abs().max().item<double>() < 2e-5;
 		// the reference side, on the fused pass's own fine depths
 		auto rc = rays_.cpu(); auto zc = zf.cpu();
 		auto pts = rc.index({Slice(), None, Slice(0, 3)}) + rc.index({Slice(), None, Slice(3, 6)}) * zc.index({Slice(), Slice(), None});
@@ -219,13 +226,13 @@ int main(int argc, const char **argv)
 		auto got16 = pass16.RenderRays(rays_, 64, false, 128, true);
 		auto cos16 = (got16.RenderedLangEmbedding.cpu() * emb_ref).sum(-1).index({hit});
 		lerf_f16_cos_min = cos16.numel() ? cos16.min().item<double>() : 0.0;
-		lerf_ok = lerf_fused && hit.sum().item<int64_t>() > (int64_t)h * w / 8 && lerf_cos_min > 1.0 - 2e-6 && lerf_w_err < 1e-5 && torch::isfinite(got.RenderedLangEmbedding).all().item<bool>();
+		lerf_ok = lerf_fused && lerf_reuse_same && hit.sum().item<int64_t>() > (int64_t)h * w / 8 && lerf_cos_min > 1.0 - 2e-6 && lerf_w_err < 1e-5 && torch::isfinite(got.RenderedLangEmbedding).all().item<bool>();
 	} catch (const std::exception &ex) { lerf_note = ex.what(); for (auto &ch : lerf_note) if (ch == '"' || ch == '\n') ch = ' '; }
 	stage("LeRF section done");
 	ok = ok && lerf_ok;
 	std::cout.rdbuf(cout_buf);
-	printf("{\"lerf_pass_ok\": %s, \"lerf_fused\": %s, \"lerf_split_cos_min_vs_reference_head\": %.9f, \"lerf_split_weights_max_abs_err\": %.3e, \"lerf_f16_cos_min\": %.6f, \"lerf_note\": \"%s\"}\n",
-		lerf_ok ? "true" : "false", lerf_fused ? "true" : "false", lerf_cos_min, lerf_w_err, lerf_f16_cos_min, lerf_note.c_str());
+	printf("{\"lerf_pass_ok\": %s, \"lerf_fused\": %s, \"lerf_feature_reuse_equals_two_passes\": %s, \"lerf_split_cos_min_vs_reference_head\": %.9f, \"lerf_split_weights_max_abs_err\": %.3e, \"lerf_f16_cos_min\": %.6f, \"lerf_note\": \"%s\"}\n",
+		lerf_ok ? "true" : "false", lerf_fused ? "true" : "false", lerf_reuse_same ? "true" : "false", lerf_cos_min, lerf_w_err, lerf_f16_cos_min, lerf_note.c_str());
 	printf("{\"ok\": %s, \"image\": [%d, %d], \"hash_embedding_bit_exact\": %s, \"sh_bit_exact\": %s, \"rgb_max_abs_err\": %.3e, \"pixels_within_1e-4\": %.4f, \"acc_max_abs_err\": %.3e, "
 		"\"depth_max_abs_err\": %.3e, \"psnr_db\": %.2f, \"shapes_near_far_equal\": %s, \"f16_render_finite\": %s, \"split_pixels_within_1e-4\": %.4f, \"split_psnr_db\": %.2f, "
 		"\"split_vs_own_f32_max_abs_err\": %.3e, \"render_tile_equals_slice\": %s, \"render_sharded_world1_equals_render\": %s, \"comm\": \"%s\"}\n",

@@ -1676,6 +1676,33 @@ def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     assert np.median(cos) > 0.9999 and cos.min() > 0.995, (np.median(cos), cos.min())
 
 
+def test_lerf_feature_reusing_render_equals_two_pass_render(api):
+    """The LeRF render pass that encodes every sample point once (coarse columns kept, nrf_fine_depths_merge map, hash encode + sigma net on the new samples,
+    embedding pass gathering columns) against the plain two-pass evaluation of the same kernels, main.cpp sizes, both precisions, ragged chunks: depth set,
+    weights and maps identical bit for bit; the rendered embedding identical up to the order of the per-ray float atomics."""
+    sc = api.S.make_lerf_scene()
+    r = sc["renderer"]
+    assert r.fused and r.level_major and r.reuse_features
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=1100, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    try:
+        for prec in (api.L.NRF_PREC_F16_SPLIT, api.L.NRF_PREC_F16_MFMA):
+            r.set_precision(prec)
+            r.reuse_features = True
+            a = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
+            r.reuse_features = False
+            b = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
+            assert_exact(host(a.Extras["z_fine"]), host(b.Extras["z_fine"]), "fine depth set")
+            for f in ("WeightsLE", "DepthMapLE", "DispMapLE", "AccMapLE"):
+                assert_exact(host(getattr(a.Outputs, f)), host(getattr(b.Outputs, f)), f)
+            ea, eb = host(a.Outputs.RenderedLangEmbedding), host(b.Outputs.RenderedLangEmbedding)
+            assert np.isfinite(ea).all()
+            assert_close(ea, eb, rtol=0, atol=2e-5, what="rendered embedding (unit vectors; the float atomics of the per-ray sums are unordered in either render)")
+    finally:
+        r.reuse_features = True
+        r.set_precision(api.L.NRF_PREC_F16_SPLIT)
+
+
 # ------------------------------------------------------------------ classic NeRF at fp32-grade precision on the matrix cores (NRF_PREC_F16_SPLIT)
 def test_mlp_nerf_split_precision_vs_oracle_and_reference(api, O, manifest):
     """NeRFImpl::forward (8 x 256, skip, view branch) with hi + lo fp16 operand pairs: against the reference's own output (golden, MKL sgemm order) and against
