@@ -68,18 +68,12 @@ __device__ __forceinline__ void nerf_split_pair(float v0, float v1, uint32_t &hi
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
 }
 
-// registers 8s..8s+7 of a finished tile (main + correction accumulators) -> the (hi, lo) B fragments of k-step s, ReLU applied.
-// The asm reads VALU results only (the add), never a matrix instruction's destination: the MFMA -> VALU hazard handling stays with the compiler.
-__device__ __forceinline__ void nerf_tile_to_frag2(const f32x16 &acc, const f32x16 &cor, int s, half8 &hi, half8 &lo)
-{
-    union { half8 v; uint32_t u[4]; } h, l;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float v0 = fmaxf(acc[8 * s + 2 * j] + cor[8 * s + 2 * j], 0.0f), v1 = fmaxf(acc[8 * s + 2 * j + 1] + cor[8 * s + 2 * j + 1], 0.0f);
-        nerf_split_pair(v0, v1, h.u[j], l.u[j]);
-    }
-    hi = h.v; lo = l.v;
-}
+#ifdef NRF_NERF_TRACE
+// diagnostic build only (tools/scratch/classic_trace.py): cycle stamps of wave 0 of every workgroup, summed per section: [0] tile loops, [2] end-of-chunk wait +
+// barrier, [3] input encoding, [4] whole iterations, [5] iterations, [6] / [7] the 4-step / 16-step tile loops alone
+__device__ unsigned long long g_nerf_trace[256 * 8];
+#define NRF_STAMP() __builtin_readcyclecounter()
+#endif
 
 struct CtxS {
     half8 *wbuf;            // [3][SMAXF*64]
@@ -87,13 +81,43 @@ struct CtxS {
     const half8 *packed;    // the weight image (wave-uniform)
     int lane, h, wave;
     int *cur;               // LDS buffer (0..2) holding the chunk being consumed; wave-uniform, advanced by every chunk
+    f32x16 *accs;           // two accumulator tiles: chunk CI accumulates into accs[CI & 1] while accs[(CI & 1) ^ 1], the previous tile, is being converted
+#ifdef NRF_NERF_TRACE
+    unsigned long long *tr;
+#endif
 };
+
+typedef uint32_t nerf_u32x4 __attribute__((ext_vector_type(4)));
+
+// One conversion unit of a finished tile: values 8s + 2j, 8s + 2j + 1 (s = u >> 2, j = u & 3) of its accumulator -> ReLU -> the (hi, lo) words j of the next layer's
+// B fragments 2 PT + s.  Seven vector instructions (two AGPR reads, two v_max, one v_cvt_pk, two v_fma_mix).
+template <int PT, int NB>
+__device__ __forceinline__ void nerf_conv_unit(const f32x16 &tile, int u, half8 (&tgt)[NB][2])
+{
+    const int s = u >> 2, j = u & 3;
+    uint32_t hi, lo;
+    nerf_split_pair(fmaxf(tile[8 * s + 2 * j], 0.0f), fmaxf(tile[8 * s + 2 * j + 1], 0.0f), hi, lo);
+    nerf_u32x4 hv = __builtin_bit_cast(nerf_u32x4, tgt[2 * PT + s][0]), lv = __builtin_bit_cast(nerf_u32x4, tgt[2 * PT + s][1]);
+    hv[j] = hi; lv[j] = lo;
+    tgt[2 * PT + s][0] = __builtin_bit_cast(half8, hv); tgt[2 * PT + s][1] = __builtin_bit_cast(half8, lv);
+}
 
 // One chunk = neuron tile T of layer L.  w / dma_dst / bias_s are __restrict__ PARAMETERS on purpose (alias-scope metadata after inlining: this chunk's
 // LDS reads do not touch the look-ahead's destination, so no vmcnt(0) is inserted before them -- see mlp_nerf_mfma.hip).
+//
+// What a single wave per SIMD has to hide by itself (cycle stamps of a diagnostic build, per 16-step tile = 1536 matrix-pipe cycles; numbers in DESIGN section 9):
+//   * the conversion of a finished tile into the next layer's operands -- ~180 vector instructions = ~700 cycles during which the pipe sat idle when the
+//     conversion followed its own tile.  Now the tile of chunk CI - 1 is converted DURING chunk CI: two accumulator tiles alternate, and the eight conversion
+//     units of the previous tile are dealt out one per k-step behind this tile's matrix instructions (two per step on layer 0's four-step tiles).  The operands
+//     it writes (fragments 2 PT, 2 PT + 1 of the next layer's input; for a layer's last tile, fragments 14 and 15 of THIS layer's input) are first read at
+//     chained k-step >= 14, after the last unit;
+//   * the LDS latency of the weight fragments: read two k-steps ahead through three register slots, with counted waits (the reads and waits are written out:
+//     left alone the compiler puts a step's reads 32 pipe cycles before their use, or -- given the order -- waits for ALL outstanding reads, lgkmcnt(0));
+//   * one accumulator per tile: the three products of a k-step go into the same tile, small terms first (a dependent chain of this instruction issues
+//     back to back, MI355X_MICROARCH.md), which halves the AGPR reads and drops the additions of the former main + correction pair.
 template <int L, int T, int NN, int NC, int NOUT>
 __device__ __forceinline__ void nerf_chunk_body_s(const CtxS &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const float *__restrict__ bias_s,
-                                                  const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
+                                                  half8 (&bn)[NN][2], half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
 {
     constexpr int KSN = NerfNet::ks_nat(L), KSC = NerfNet::ks_ch(L), KS = KSN + KSC;
     constexpr int CI = NerfNetS::first_chunk(L) + T;
@@ -101,29 +125,65 @@ __device__ __forceinline__ void nerf_chunk_body_s(const CtxS &cx, const half8 *_
     constexpr int NTILES = NerfNet::tiles(L);
     constexpr bool NATF = NerfNet::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
+    // the previous chunk's tile, still unconverted in the other accumulator
+    constexpr int PL = T > 0 ? L : L - 1;                                          // its layer (L = 0, T = 0: none -- the last layer's tile is never converted)
+    constexpr int PT = T > 0 ? T - 1 : (L > 0 ? NerfNet::tiles(L > 0 ? L - 1 : 0) - 1 : 0);
+    constexpr bool PEND = (T > 0 || L > 0) && PL < NerfNet::NLAYER - 1 && 2 * PT + 1 < 16;
+    constexpr int UPS = KS >= 8 ? 1 : 2;                                            // conversion units per k-step
+    static_assert(!PEND || 8 <= UPS * KS, "the previous tile's eight conversion units must fit this tile's k-steps");
+    static_assert(!PEND || T > 0 || NC == 16, "a layer's last tile becomes fragments 14, 15 of the next layer's chained input");
+    // chained fragments 2 PT, 2 PT + 1 must not be read before the last unit has written them: first chained k-step that reads them vs last unit's step
+    static_assert(!PEND || T > 0 || (NATF ? KSN : 0) + 14 >= (8 + UPS - 1) / UPS, "conversion finishes too late for this layer's chained operands");
+    f32x16 &acc = cx.accs[CI & 1];
+    const f32x16 &prev = cx.accs[(CI & 1) ^ 1];
     // pieces of chunk CI + 2 this wave issues, spread over this chunk's k-steps
     constexpr int NQ = NerfNetS::chunk_frags((CI + 2) % NerfNetS::total_chunks()) / SNW;
     constexpr int EVERY = (KS / NQ) > 0 ? (KS / NQ) : 1;          // one piece every EVERY k-steps ...
     constexpr int LEAD = NQ > KS / EVERY ? NQ - KS / EVERY : 0;   // ... and what does not fit that way, at the top
+#ifdef NRF_NERF_TRACE
+    const unsigned long long t0_ = NRF_STAMP();
+#endif
     stage_all<CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane, std::make_integer_sequence<int, LEAD>{});
-    f32x16 acc, cor;
+    half8 fa[3][2];
+    const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+    auto read_pair = [&](int kk, int slot) {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr + (uint32_t)kk * 2048u));
+    };
+    read_pair(0, 0);
+    if (KS > 1) read_pair(1, 1);
     const float *bp = bias_s + BOFF + T * 32 + 4 * cx.h;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float4 bv = *reinterpret_cast<const float4 *>(bp + 8 * g);
         acc[4 * g + 0] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
     }
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int q = LEAD;
 #pragma unroll
     for (int k = 0; k < KS; k++) {
-        const half8 ah = w[(2 * k) * 64 + cx.lane], al = w[(2 * k + 1) * 64 + cx.lane];
+        // counted waits: conservative against LDS / scalar loads the compiler issues itself (they only add to the number outstanding)
+        if (k + 2 < KS) {
+            read_pair(k + 2, (k + 2) % 3);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        } else if (k + 1 < KS) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 ah = fa[k % 3][0], al = fa[k % 3][1];
         half8 bh, bl;
         if (NATF) { bh = (k < KSN) ? bn[k < KSN ? k : 0][0] : bc[k >= KSN ? k - KSN : 0][0]; bl = (k < KSN) ? bn[k < KSN ? k : 0][1] : bc[k >= KSN ? k - KSN : 0][1]; }
         else { bh = (k < KSC) ? bc[k < KSC ? k : 0][0] : bn[k >= KSC ? k - KSC : 0][0]; bl = (k < KSC) ? bc[k < KSC ? k : 0][1] : bn[k >= KSC ? k - KSC : 0][1]; }
-        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, k == 0 ? zero : cor, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cor, 0, 0, 0);
+        if constexpr (PEND) {
+#pragma unroll
+            for (int uu = 0; uu < UPS; uu++) {
+                const int u = k * UPS + uu;
+                if (u < 8) {
+                    if constexpr (T > 0) nerf_conv_unit<PT>(prev, u, bout);
+                    else if constexpr (NC == 16) nerf_conv_unit<PT>(prev, u, bc);
+                }
+            }
+        }
         if ((k % EVERY) == EVERY - 1 && q < NQ) {
             // the next piece of the look-ahead chunk, in the shadow of this k-step's matrix instructions (q is a compile-time value after unrolling)
             const int qq = q;
@@ -134,24 +194,24 @@ __device__ __forceinline__ void nerf_chunk_body_s(const CtxS &cx, const half8 *_
             }
             q++;
         }
-        // keep the weight-fragment reads at most two k-steps ahead of their matrix instructions (unfenced, the scheduler hoists a tile's 40 ds_read_b128)
-        if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     static_assert(NQ <= 10, "piece switch covers 10 pieces per wave");
-    if (L < NerfNet::NLAYER - 1 && 2 * T + 1 < NOUT) {          // the last layer's tile is only read through `last`
-        nerf_tile_to_frag2(acc, cor, 0, bout[2 * T][0], bout[2 * T][1]);
-        nerf_tile_to_frag2(acc, cor, 1, bout[2 * T + 1][0], bout[2 * T + 1][1]);
-    }
-    if (T == NTILES - 1) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) last[i] = acc[i] + cor[i];
-    }
+    if (T == NTILES - 1 && L >= 8) last = acc;          // alpha (layer 8) and rgb (layer 9) are read from the accumulators
+#ifdef NRF_NERF_TRACE
+    const unsigned long long t1_ = NRF_STAMP();
+#endif
     // End of the chunk: chunk CI + 1 (requested during chunk CI - 1) must have landed, chunk CI + 2 (requested during this one) may stay in flight.
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ) : "memory");
+#ifdef NRF_NERF_TRACE
+    cx.tr[0] += t1_ - t0_; cx.tr[2] += NRF_STAMP() - t1_;
+    if (KS == 4) cx.tr[6] += t1_ - t0_;
+    if (KS == 16) cx.tr[7] += t1_ - t0_;
+#endif
 }
 
 template <int L, int T, int NN, int NC, int NOUT>
-__device__ __forceinline__ void nerf_chunk_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
+__device__ __forceinline__ void nerf_chunk_s(const CtxS &cx, half8 (&bn)[NN][2], half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
 {
     // chunk CI + 2 -> the buffer chunk CI - 1 was consumed from (every wave is past the barrier that ended it)
     const int cur = *cx.cur;
@@ -160,14 +220,14 @@ __device__ __forceinline__ void nerf_chunk_s(const CtxS &cx, const half8 (&bn)[N
 }
 
 template <int L, int NN, int NC, int NOUT, int... Ts>
-__device__ __forceinline__ void nerf_layer_seq_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last,
+__device__ __forceinline__ void nerf_layer_seq_s(const CtxS &cx, half8 (&bn)[NN][2], half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last,
                                                  std::integer_sequence<int, Ts...>)
 {
     (nerf_chunk_s<L, Ts>(cx, bn, bc, bout, last), ...);
 }
 
 template <int L, int NN, int NC, int NOUT>
-__device__ __forceinline__ void nerf_layer_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
+__device__ __forceinline__ void nerf_layer_s(const CtxS &cx, half8 (&bn)[NN][2], half8 (&bc)[NC][2], half8 (&bout)[NOUT][2], f32x16 &last)
 {
     nerf_layer_seq_s<L>(cx, bn, bc, bout, last, std::make_integer_sequence<int, NerfNet::tiles(L)>{});
 }
@@ -193,8 +253,17 @@ k_mlp_nerf_split(int64_t npts, NerfInput in, const half8 *__restrict__ packed, c
     __syncthreads();                               // vmcnt(0): chunks 0 and 1 are in place
     int cur = 0;
     const int64_t nblocks = (npts + SNBLK - 1) / SNBLK;
+    f32x16 accs[2];
+#ifdef NRF_NERF_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        CtxS cx{wbuf, bias_s, packed, lane, h, wave, &cur};
+#ifdef NRF_NERF_TRACE
+        CtxS cx{wbuf, bias_s, packed, lane, h, wave, &cur, accs, tr};
+        const unsigned long long ti0_ = NRF_STAMP();
+#else
+        CtxS cx{wbuf, bias_s, packed, lane, h, wave, &cur, accs};
+#endif
         const int64_t q_raw = blk * SNBLK + wave * 32 + r;
         const int64_t q = q_raw < npts ? q_raw : npts - 1;          // clamp loads; the store is guarded
         half8 pe[4][2];                                             // positions: layer 0 and the skip layer 5
@@ -236,6 +305,10 @@ k_mlp_nerf_split(int64_t npts, NerfInput in, const half8 *__restrict__ packed, c
         }
         half8 ba[16][2], bb[16][2], none[1][2];
         f32x16 last;
+#ifdef NRF_NERF_TRACE
+        asm volatile("s_nop 0" : "+v"(pe[3][1]));
+        tr[3] += NRF_STAMP() - ti0_;
+#endif
         nerf_layer_s<0>(cx, pe, none, ba, last);
         nerf_layer_s<1>(cx, none, ba, bb, last);
         nerf_layer_s<2>(cx, none, bb, ba, last);
@@ -271,9 +344,24 @@ k_mlp_nerf_split(int64_t npts, NerfInput in, const half8 *__restrict__ packed, c
             float *o = out + q_raw * out_stride;
             o[0] = last[0]; o[1] = last[1]; o[2] = last[2]; o[3] = alpha;
         }
+#ifdef NRF_NERF_TRACE
+        tr[4] += NRF_STAMP() - ti0_; tr[5] += 1;
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last two chunks' look-ahead requests are still in flight
+#ifdef NRF_NERF_TRACE
+    if (tid == 0 && FUSED) for (int i = 0; i < 8; i++) g_nerf_trace[blockIdx.x * 8 + i] += tr[i];      // no other code reads this buffer
+#endif
 }
+
+#ifdef NRF_NERF_TRACE
+extern "C" NRF_API int nrf_dbg_nerf_trace(unsigned long long *host_out, int reset)
+{
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nerf_trace), sizeof(unsigned long long) * 256 * 8) != hipSuccess) return NRF_ERR_HIP;
+    if (reset) { static unsigned long long z[256 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_trace), z, sizeof(z)) != hipSuccess) return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+#endif
 
 // per-ray PE(4) of the view direction as (hi, lo) fp16 rows [n, 32] (27 features, zero padded): the layer-8 operand of the fused path
 __global__ void k_dirs_pe_split(int64_t n, const float *__restrict__ rays, int stride, __half *__restrict__ out_hi, __half *__restrict__ out_lo)
