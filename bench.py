@@ -288,7 +288,7 @@ def main():
                 mroof["mfma_issued_frac"] = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] / max(mdur, 1e-12) / mlp_peak
                 mroof["mfma_issued_vs_sustained_gemm"] = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
                 mroof["sustained_note"] = ("mfma_issued_vs_sustained_gemm = issued matrix-core flop/s over the 1 247 TFLOP/s a tuned bf16 GEMM holds on random data (guide, DVFS give-back: "
-                                           "the chip lowers its clock under matrix load); this kernel's cycle count does not change on all-zero weights while its clock does (DESIGN section 9)")
+                                           "the chip lowers its clock under matrix load); measured on the classic split kernel: its cycle count does not change on all-zero weights while its clock does (DESIGN section 9)")
                 mroof["note"] = ("achieved / frac price the ALGORITHMIC 35 072 flop per unit; the split-precision mode issues three fp16 products per algorithmic one "
                                  "to deliver fp32-grade pixels (north_star: within 1e-4), mfma_issued_frac is the matrix pipe's own utilisation") if args.precision == "f16x3" else \
                                 "achieved / frac price the algorithmic 35 072 flop per unit; mfma_issued_frac includes the zero padding of the 16- and 3-wide layers"
