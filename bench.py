@@ -497,7 +497,7 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
     o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
     tgt = torch.rand((n_rand, 3), device="cuda")
-    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=mlp_backward, hash_backward="packed" if mlp_backward == "f16" else "f32")
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward=mlp_backward, hash_backward="binned" if mlp_backward == "f16" else "f32")
     rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                             BoundingBox=scene.LEGO_BBOX, Precision=L.NRF_PREC_F16_SPLIT)
     for _ in range(2):

@@ -427,6 +427,13 @@ NRF_API int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_
 NRF_API size_t nrf_hash_backward_packed_workspace_bytes(const nrf_hash *h);
 NRF_API int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table,
                                           void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same gradient with the contributions MERGED before they reach memory: records {word, fixed-point fields} are binned by ranges of 2^14 table words
+ * (count pass, scan, emit pass), each bin is summed in one workgroup's LDS and added to d_g_table without atomics.  Same groups, same scale, integer sums:
+ * the result equals nrf_hash_backward_rays_packed bit for bit.  log2_hashmap_size <= 19.  Workspace: nrf_hash_backward_binned_workspace_bytes(h, s)
+ * (~0.5 GB at s = 192: 2^18 points x 8 corners x levels x 16 bytes), 256-byte aligned. */
+NRF_API size_t nrf_hash_backward_binned_workspace_bytes(const nrf_hash *h, int s);
+NRF_API int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table,
+                                          void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* TotalVariationLoss of the LibTorch HashEmbedder (NeRF.h:255-300, NeRFExecutor.h:896-913; NRF_HASH_NGP grids): the cube of
  * (cube_size + 1)^3 lattice vertices at min_vertex (host [3]; the reference draws it with torch::randint) of `level`.

@@ -232,9 +232,61 @@ constexpr int64_t PACKED_GROUP_PTS = 1 << 18;      // points per fixed-point pas
 // nearest, packed as hi * 2^32 + lo in two's complement: integer addition of such words adds the fields exactly as long as neither field's
 // total leaves int32 (the low field's borrows are undone by the sign-extending decode in k_unpack_q).  qscale is a power of two chosen on the
 // device from a rigorous bound on any entry's total (k_level_mass), so the fields cannot overflow.
-template <int F, bool CU, bool Q = false>
+// BINNED (MODE 1 = count, 2 = emit; Q only): the same walk, but a flushed contribution becomes a RECORD instead of an atomic.  The table's 64-bit words are cut
+// into bins of 2^14 consecutive words (128 KB of packed accumulators: one workgroup's LDS); a count pass sizes the bins, an exclusive scan places them, an
+// emit pass writes {word, q0, q1} records bin by bin, and k_bin_accumulate sums each bin in LDS (ds_add_u64 on the packed word) and adds the decoded fields to
+// the fp32 gradient: the ~48 contributions an entry of a fine level receives per step merge in LDS instead of serialising in the L2 atomic units.  Integer
+// sums do not depend on order: the result equals the atomic path's bit for bit.
+constexpr int BIN_SHIFT = 14;
+constexpr int BIN_WORDS = 1 << BIN_SHIFT;
+constexpr int BIN_MAX_PER_LEVEL = 40;        // bins one level's words can touch: 2^19 / 2^14 = 32, + 1 for an unaligned base (+ margin)
+struct BinSink {
+    uint32_t *wg_hist;       // [levels][workgroups][BIN_MAX_PER_LEVEL] records of a workgroup per bin (count pass writes, emit pass reads)
+    uint32_t *gcount;        // [nbins + 1] records per bin (count pass), then left as is
+    uint32_t *cursor;        // [nbins] next free record slot of a bin (scan initialises to the bin's start)
+    uint4 *rec;              // records
+};
+
+template <int F, bool CU, bool Q, int MODE>
+__device__ __forceinline__ void hash_bwd_walk(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+                                              float *__restrict__ g_table, const float *__restrict__ qscale_p, const BinSink &sink, uint32_t *bin_cnt, const uint32_t *bin_base);
+
+template <int F, bool CU, bool Q = false, int MODE = 0>
 __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
-                               float *__restrict__ g_table, const float *__restrict__ qscale_p = nullptr)
+                               float *__restrict__ g_table, const float *__restrict__ qscale_p = nullptr, BinSink sink = BinSink{})
+{
+    __shared__ uint32_t bin_cnt[MODE ? BIN_MAX_PER_LEVEL : 1];
+    __shared__ uint32_t bin_base[MODE ? BIN_MAX_PER_LEVEL : 1];
+    if constexpr (MODE != 0) {
+        static_assert(MODE == 0 || Q, "binning carries the packed fixed-point fields");
+        uint32_t *mine = sink.wg_hist + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BIN_MAX_PER_LEVEL;
+        if (threadIdx.x < BIN_MAX_PER_LEVEL) {
+            if (MODE == 1) bin_cnt[threadIdx.x] = 0;
+            else {          // reserve this workgroup's slots in every bin it feeds; bin_cnt becomes the running rank inside the reservation
+                const uint32_t c = mine[threadIdx.x];
+                const uint32_t wb0 = (uint32_t)((CU ? (int64_t)hp.local_idx[blockIdx.y] : (int64_t)blockIdx.y * ((int64_t)1 << hp.log2_t) * F) / 2) >> BIN_SHIFT;
+                bin_base[threadIdx.x] = c ? atomicAdd(sink.cursor + wb0 + threadIdx.x, c) : 0u;
+                bin_cnt[threadIdx.x] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    hash_bwd_walk<F, CU, Q, MODE>(hp, pts, n, s, g_emb, g_stride, g_table, qscale_p, sink, bin_cnt, bin_base);
+    if constexpr (MODE == 1) {
+        __syncthreads();
+        if (threadIdx.x < BIN_MAX_PER_LEVEL) {
+            uint32_t *mine = sink.wg_hist + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BIN_MAX_PER_LEVEL;
+            const uint32_t c = bin_cnt[threadIdx.x];
+            mine[threadIdx.x] = c;
+            const uint32_t wb0 = (uint32_t)((CU ? (int64_t)hp.local_idx[blockIdx.y] : (int64_t)blockIdx.y * ((int64_t)1 << hp.log2_t) * F) / 2) >> BIN_SHIFT;
+            if (c) atomicAdd(sink.gcount + wb0 + threadIdx.x, c);
+        }
+    }
+}
+
+template <int F, bool CU, bool Q, int MODE>
+__device__ __forceinline__ void hash_bwd_walk(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+                                              float *__restrict__ g_table, const float *__restrict__ qscale_p, const BinSink &sink, uint32_t *bin_cnt, const uint32_t *bin_base)
 {
     const int nseg = (s + BWD_SEG - 1) / BWD_SEG;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,7 +318,17 @@ __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int
             if constexpr (Q) {
                 static_assert(!Q || F == 2, "packed atomics carry exactly two features");
                 const int32_t q0 = __float2int_rn(acc[k][0] * qscale), q1 = __float2int_rn(acc[k][F - 1] * qscale);
-                if (q0 | q1) atomicAdd(reinterpret_cast<unsigned long long *>(tl) + row, (unsigned long long)(((int64_t)q1 << 32) + (int64_t)q0));
+                if constexpr (MODE == 0) {
+                    if (q0 | q1) atomicAdd(reinterpret_cast<unsigned long long *>(tl) + row, (unsigned long long)(((int64_t)q1 << 32) + (int64_t)q0));
+                } else if (q0 | q1) {
+                    const uint32_t wbase = (uint32_t)((tl - g_table) / 2);                 // the level's first 64-bit word
+                    const uint32_t word = wbase + row, b = (word >> BIN_SHIFT) - (wbase >> BIN_SHIFT);
+                    if constexpr (MODE == 1) atomicAdd(bin_cnt + b, 1u);
+                    else {
+                        const uint32_t rank = atomicAdd(bin_cnt + b, 1u);
+                        sink.rec[(size_t)bin_base[b] + rank] = make_uint4(word, (uint32_t)q0, (uint32_t)q1, 0u);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int f = 0; f < F; f++)
@@ -392,6 +454,51 @@ __global__ void k_unpack_q(int64_t entries, unsigned long long *__restrict__ q, 
     float2 v = *gp;
     v.x += (float)lo * qs[1]; v.y += (float)hi * qs[1];
     *gp = v;
+}
+
+// start[b] = records of the bins before b (exclusive scan; start[nbins] = total), cursor[b] = start[b]
+__global__ void k_bin_scan(int nbins, const uint32_t *__restrict__ gcount, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t part[256];
+    const int per = (nbins + 255) / 256, b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (int i = b0; i < b0 + per && i < nbins; i++) sum += gcount[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { const uint32_t v = part[i]; part[i] = run; run += v; } start[nbins] = run; }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int i = b0; i < b0 + per && i < nbins; i++) { start[i] = run; cursor[i] = run; run += gcount[i]; }
+}
+
+// One workgroup per bin: its records summed in LDS (packed 64-bit words, integer addition: exact and order-free), then the two fixed-point fields of every touched
+// word decoded and added to the fp32 gradient -- words of a bin belong to this workgroup alone, so the read-modify-write needs no atomic.
+__global__ void __launch_bounds__(256) k_bin_accumulate(const uint32_t *__restrict__ start, const uint4 *__restrict__ rec, const float *__restrict__ qs, int64_t entries,
+                                                        float *__restrict__ g_table)
+{
+    extern __shared__ unsigned long long bin_acc[];
+    const uint32_t r0 = start[blockIdx.x], r1 = start[blockIdx.x + 1];
+    if (r0 == r1) return;
+    for (int e = threadIdx.x; e < BIN_WORDS; e += 256) bin_acc[e] = 0ull;
+    __syncthreads();
+    for (uint32_t i = r0 + threadIdx.x; i < r1; i += 256) {
+        const uint4 r = rec[i];
+        atomicAdd(bin_acc + (r.x & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)(((int64_t)(int32_t)r.z << 32) + (int64_t)(int32_t)r.y));
+    }
+    __syncthreads();
+    const float inv = qs[1];
+    for (int e = threadIdx.x; e < BIN_WORDS; e += 256) {
+        const int64_t w = (int64_t)bin_acc[e];
+        if (w == 0) continue;
+        const int64_t word = (int64_t)blockIdx.x * BIN_WORDS + e;
+        if (word >= entries) continue;
+        const int32_t lo = (int32_t)(uint32_t)(w & 0xffffffffll);
+        const int32_t hi = (int32_t)((w - (int64_t)lo) >> 32);
+        float2 *gp = reinterpret_cast<float2 *>(g_table) + word;
+        float2 v = *gp;
+        v.x += (float)lo * inv; v.y += (float)hi * inv;
+        *gp = v;
+    }
 }
 
 // TotalVariationLoss (NeRF.h:255-300): one thread per cube vertex owns the three forward differences starting at it
@@ -589,6 +696,78 @@ int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t
         if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, qt, (const float *)qs);
         else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, qt, (const float *)qs);
         hipLaunchKernelGGL(k_unpack_q, dim3((unsigned)ceil_div(entries, 256)), dim3(256), 0, st, entries, q, (const float *)qs, d_g_table);
+    }
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+// workspace of the binned form: header (1 KB: mass, scale) | gcount [nbins + 1] | start [nbins + 1] | cursor [nbins] | wg_hist | records
+static void binned_layout(const nrf_hash *h, int s, int64_t *nbins, int64_t *rays_per_group, int64_t *nwg, size_t *off_hist, size_t *off_rec, size_t *total)
+{
+    const int L = h->desc.n_levels;
+    const int64_t entries = nrf_hash_table_elems(h) / 2;
+    *nbins = ceil_div(entries, (int64_t)BIN_WORDS);
+    *rays_per_group = (PACKED_GROUP_PTS / s) > 0 ? (PACKED_GROUP_PTS / s) : 1;
+    const int64_t threads = *rays_per_group * ((s + BWD_SEG - 1) / BWD_SEG);
+    *nwg = ceil_div(threads, (int64_t)256);
+    size_t o = 1024 + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
+    *off_hist = o;
+    o += align_up((size_t)L * *nwg * BIN_MAX_PER_LEVEL * 4, 256);
+    *off_rec = o;
+    o += (size_t)*rays_per_group * s * 8 * L * sizeof(uint4);          // every sample may flush eight records per level
+    *total = o;
+}
+
+size_t nrf_hash_backward_binned_workspace_bytes(const nrf_hash *h, int s)
+{
+    if (!h || s < 1) return 0;
+    int64_t nbins, rpg, nwg; size_t oh, orr, total;
+    binned_layout(h, s, &nbins, &rpg, &nwg, &oh, &orr, &total);
+    return total;
+}
+
+int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table, void *d_workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(h && d_pts && d_g_emb && d_g_table && d_workspace && n >= 0 && s >= 1, "nrf_hash_backward_rays_binned: bad argument");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_NGP || h->primes_set, "nrf_hash_backward_rays_binned: CuHashEmbedder-mode grid without primes");
+    if (h->desc.n_features != 2) { set_error("nrf_hash_backward_rays_binned: built for 2 features per level (a table entry = one 64-bit word); use nrf_hash_backward_rays"); return NRF_ERR_UNSUPPORTED; }
+    if (h->desc.log2_hashmap_size > 19) { set_error("nrf_hash_backward_rays_binned: a level of 2^%d words touches more than %d bins; use nrf_hash_backward_rays_packed", h->desc.log2_hashmap_size, BIN_MAX_PER_LEVEL); return NRF_ERR_UNSUPPORTED; }
+    int64_t nbins, rays_per_group, nwg; size_t off_hist, off_rec, total;
+    binned_layout(h, s, &nbins, &rays_per_group, &nwg, &off_hist, &off_rec, &total);
+    if (workspace_bytes < total) { set_error("nrf_hash_backward_rays_binned: workspace %zu < %zu bytes", workspace_bytes, total); return NRF_ERR_WORKSPACE; }
+    if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) || (reinterpret_cast<uintptr_t>(d_g_table) & 7)) { set_error("nrf_hash_backward_rays_binned: workspace must be 256-byte, g_table 8-byte aligned"); return NRF_ERR_INVALID_ARG; }
+    if (n == 0) return NRF_OK;
+    const int L = h->desc.n_levels;
+    hipStream_t st = as_stream(stream);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(d_workspace);
+    double *mass = reinterpret_cast<double *>(ws);
+    float *qs = reinterpret_cast<float *>(ws + 768);
+    const size_t cnt_bytes = align_up((size_t)(nbins + 1) * 4, 256);
+    uint32_t *gcount = reinterpret_cast<uint32_t *>(ws + 1024), *start = reinterpret_cast<uint32_t *>(ws + 1024 + cnt_bytes), *cursor = reinterpret_cast<uint32_t *>(ws + 1024 + 2 * cnt_bytes);
+    BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<uint4 *>(ws + off_rec)};
+    const int64_t entries = nrf_hash_table_elems(h) / 2;
+    const bool ngp = h->desc.mode == NRF_HASH_NGP;
+    static bool attr_set = false;
+    const size_t lds = (size_t)BIN_WORDS * 8;
+    if (!attr_set) { NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    // same groups and the same scale as the packed form: the integer fields are identical, so is the result
+    for (int64_t r0 = 0; r0 < n; r0 += rays_per_group) {
+        const int64_t nr = (n - r0) < rays_per_group ? (n - r0) : rays_per_group;
+        const int64_t p = nr * s;
+        const float *gp = d_g_emb + r0 * s * (int64_t)(L * 2), *pp = d_pts + r0 * s * 3;
+        NRF_HIP(hipMemsetAsync(ws, 0, 1024 + cnt_bytes, st));                        // mass, scale, bin counts
+        hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(ceil_div(p, 16) < 2048 ? ceil_div(p, 16) : 2048)), dim3(256), 0, st, p, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
+                           h->params.bbox, (float)h->desc.finest_resolution);
+        hipLaunchKernelGGL(k_qscale, dim3(1), dim3(1), 0, st, L, ngp ? 0 : 1, mass, qs);
+        const int64_t threads = nr * ((s + BWD_SEG - 1) / BWD_SEG);
+        dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
+        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
+        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, (const uint32_t *)gcount, start, cursor);
+        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
+        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
+        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(256), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, (const float *)qs, entries, d_g_table);
     }
     NRF_LAUNCH_CHECK();
     return NRF_OK;

@@ -43,11 +43,12 @@ class Trainer:
         if mlp_backward not in ("f32", "f16"):
             raise L.NrfError("mlp_backward must be 'f32' or 'f16'")
         self.mlp_backward = mlp_backward
-        # "f32": one float atomic per feature; "packed": both features of an entry in one 64-bit fixed-point atomic (nrf_hash_backward_rays_packed)
-        if hash_backward not in ("f32", "packed"):
-            raise L.NrfError("hash_backward must be 'f32' or 'packed'")
-        if hash_backward == "packed" and embedder.NFeaturesPerLevel != 2:
-            raise L.NrfError("hash_backward='packed' needs 2 features per level")
+        # "f32": one float atomic per feature; "packed": both features of an entry in one 64-bit fixed-point atomic (nrf_hash_backward_rays_packed);
+        # "binned": the same fixed-point contributions merged per table range in LDS before they reach memory (nrf_hash_backward_rays_binned; equals "packed" bit for bit)
+        if hash_backward not in ("f32", "packed", "binned"):
+            raise L.NrfError("hash_backward must be 'f32', 'packed' or 'binned'")
+        if hash_backward in ("packed", "binned") and embedder.NFeaturesPerLevel != 2:
+            raise L.NrfError("hash_backward='%s' needs 2 features per level" % hash_backward)
         self.hash_backward = hash_backward
         self.grad_sync = grad_sync          # callable(g_table, g_blob) reducing the gradients across data-parallel ranks in place, or None
         self._hws = None
@@ -125,7 +126,12 @@ class Trainer:
             nb = ws_fn(self.mlp._m, C.c_int64(n * s))
             ws = self._workspace(nb)
             L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
-        if self.hash_backward == "packed":
+        if self.hash_backward == "binned":
+            nbh = lib.nrf_hash_backward_binned_workspace_bytes(self.embedder._h, s)
+            if self._hws is None or self._hws.numel() < nbh:
+                self._hws = torch.empty((int(nbh),), device="cuda", dtype=torch.uint8)
+            L.check(lib.nrf_hash_backward_rays_binned(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _ptr(self._hws), C.c_size_t(self._hws.numel()), _stream()))
+        elif self.hash_backward == "packed":
             nbh = lib.nrf_hash_backward_packed_workspace_bytes(self.embedder._h)
             if self._hws is None or self._hws.numel() < nbh:
                 self._hws = torch.empty((int(nbh),), device="cuda", dtype=torch.uint8)

@@ -1467,6 +1467,43 @@ def test_hash_backward_packed_fixed_point_vs_float_atomics(api, mode):
             api.L.check(lib.nrf_hash_backward_rays_packed(h4._h, P(dp), C.c_int64(n), s, P(dg), P(gt_q), P(ws), C.c_size_t(nb), None))
 
 
+@pytest.mark.parametrize("mode,log2_t", [("cu", 14), ("ngp", 14), ("cu", 19)])
+def test_hash_backward_binned_equals_packed_bit_for_bit(api, mode, log2_t):
+    """nrf_hash_backward_rays_binned (records binned by table range, summed in LDS, added without atomics) against nrf_hash_backward_rays_packed (one 64-bit
+    fixed-point atomic per contribution): same groups of points, same device-side scale, integer sums -- the gradient tables must be IDENTICAL.  Several groups
+    (n * s > 2^18), a pile of samples on one voxel, points outside the box, zero gradients, accumulation into a non-zero table, workspace reuse."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    sc = api.S.make_hash_scene(mode=mode, log2_t=log2_t, seed=77, table_amp=0.3)
+    e = sc["embedder"]
+    rng = np.random.default_rng(11)
+    n, s = 3000, 192                                      # 576 000 points: three groups of <= 2^18
+    bb = api.S.LEGO_BBOX
+    o = rng.uniform(bb[:3], bb[3:], (n, 1, 3)); dd = rng.standard_normal((n, 1, 3)) * 0.004
+    pts = (o + dd * np.arange(s)[None, :, None]).astype(np.float32)
+    pts[:20] = pts[0, 0]                                  # 3 840 samples in one voxel of every level
+    pts[20:30] += np.float32(3.0 if mode == "cu" else 2e-3)
+    g = (rng.standard_normal((n * s, 32)) * 1e-4).astype(np.float32)
+    g[rng.random(n * s) < 0.1] = 0.0
+    dp, dg = dev(pts.reshape(-1, 3)), dev(g)
+    lib = api.L.lib()
+    base = (rng.standard_normal(e.table_elems()) * 1e-3).astype(np.float32)
+    gt_q, gt_b = dev(base.copy()), dev(base.copy())
+    nb = lib.nrf_hash_backward_packed_workspace_bytes(e._h)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    api.L.check(lib.nrf_hash_backward_rays_packed(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_q), P(ws), C.c_size_t(nb), None))
+    nbb = lib.nrf_hash_backward_binned_workspace_bytes(e._h, s)
+    wsb = torch.empty(nbb, dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.L.NrfError):
+        api.L.check(lib.nrf_hash_backward_rays_binned(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_b), P(wsb), C.c_size_t(nbb - 1), None))
+    for _ in range(2):                                    # second call: the workspace is reusable as is
+        gt_b.copy_(dev(base))
+        api.L.check(lib.nrf_hash_backward_rays_binned(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_b), P(wsb), C.c_size_t(nbb), None))
+    a, b = host(gt_b), host(gt_q)
+    assert np.abs(b - base).max() > 0
+    assert_exact(a, b, f"{mode} T=2^{log2_t}: binned table gradient == packed-atomic table gradient")
+
+
 def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
     """Trainer(mlp_backward="f16") vs the fp32 trainer on the same rendered batch of a HashNeRF scene: gradients of the MLP and of the hash table
     (which sees the MLP backward through d loss / d features), then three optimisation steps with the same loss trajectory."""
