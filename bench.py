@@ -514,7 +514,7 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
                value=n_rand * UNITS_PER_RAY / dt, unit="ray-samples/s", steps=steps, loss_first_last=[float(losses[0][0]), float(losses[-1][0])],
                arithmetic="render: split-f16 MFMA; NeRFSmall backward: " + ("one fused matrix-core kernel, fp16 operands / fp32 accumulation / device-side loss scale" if mlp_backward == "f16"
                                                                             else "fp32 layer-wise kernels") +
-                          "; hash backward: ray-coherent fp32 pre-sum, then " + ("one 64-bit fixed-point atomic per entry (both features)" if mlp_backward == "f16" else "one float atomic per feature") +
+                          "; hash backward: ray-coherent fp32 pre-sum, then " + ("fixed-point records binned by table range and summed in LDS (no atomics to memory; equals the packed-atomic path bit for bit)" if mlp_backward == "f16" else "one float atomic per feature") +
                           "; Adam fp32")
     if mlp_backward == "f16":
         try:

@@ -473,21 +473,25 @@ __global__ void k_bin_scan(int nbins, const uint32_t *__restrict__ gcount, uint3
 
 // One workgroup per bin: its records summed in LDS (packed 64-bit words, integer addition: exact and order-free), then the two fixed-point fields of every touched
 // word decoded and added to the fp32 gradient -- words of a bin belong to this workgroup alone, so the read-modify-write needs no atomic.
-__global__ void __launch_bounds__(256) k_bin_accumulate(const uint32_t *__restrict__ start, const uint4 *__restrict__ rec, const float *__restrict__ qs, int64_t entries,
-                                                        float *__restrict__ g_table)
+constexpr int BIN_THREADS = 1024;          // one workgroup per CU (128 KB of LDS): sixteen waves, four record loads in flight per lane, to cover the loads' latency
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_accumulate(const uint32_t *__restrict__ start, const uint4 *__restrict__ rec, const float *__restrict__ qs, int64_t entries,
+                                                                float *__restrict__ g_table)
 {
     extern __shared__ unsigned long long bin_acc[];
     const uint32_t r0 = start[blockIdx.x], r1 = start[blockIdx.x + 1];
     if (r0 == r1) return;
-    for (int e = threadIdx.x; e < BIN_WORDS; e += 256) bin_acc[e] = 0ull;
+    for (int e = threadIdx.x; e < BIN_WORDS; e += BIN_THREADS) bin_acc[e] = 0ull;
     __syncthreads();
-    for (uint32_t i = r0 + threadIdx.x; i < r1; i += 256) {
-        const uint4 r = rec[i];
-        atomicAdd(bin_acc + (r.x & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)(((int64_t)(int32_t)r.z << 32) + (int64_t)(int32_t)r.y));
+    auto add = [&](const uint4 &r) { atomicAdd(bin_acc + (r.x & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)(((int64_t)(int32_t)r.z << 32) + (int64_t)(int32_t)r.y)); };
+    uint32_t i = r0 + threadIdx.x;
+    for (; i + 3u * BIN_THREADS < r1; i += 4u * BIN_THREADS) {
+        const uint4 a = rec[i], b = rec[i + BIN_THREADS], c = rec[i + 2u * BIN_THREADS], d = rec[i + 3u * BIN_THREADS];
+        add(a); add(b); add(c); add(d);
     }
+    for (; i < r1; i += BIN_THREADS) add(rec[i]);
     __syncthreads();
     const float inv = qs[1];
-    for (int e = threadIdx.x; e < BIN_WORDS; e += 256) {
+    for (int e = threadIdx.x; e < BIN_WORDS; e += BIN_THREADS) {
         const int64_t w = (int64_t)bin_acc[e];
         if (w == 0) continue;
         const int64_t word = (int64_t)blockIdx.x * BIN_WORDS + e;
@@ -767,7 +771,7 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, (const uint32_t *)gcount, start, cursor);
         if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
         else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
-        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(256), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, (const float *)qs, entries, d_g_table);
+        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(BIN_THREADS), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, (const float *)qs, entries, d_g_table);
     }
     NRF_LAUNCH_CHECK();
     return NRF_OK;

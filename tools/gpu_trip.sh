@@ -15,7 +15,7 @@ ROOTD=$PWD
 cd /tmp && export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_classic -- python3 $ROOTD/bench.py --workload classic --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof_classic.log 2>&1
-(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_train -- python3 $ROOTD/tools/scratch/train_prof.py 16384 f16 packed --fast-only 2>&1 | tail -8) > $ROOTD/gpurun_out/${tag}_prof_train.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_train -- python3 $ROOTD/tools/scratch/train_prof.py 16384 f16 binned --fast-only 2>&1 | tail -8) > $ROOTD/gpurun_out/${tag}_prof_train.log 2>&1
 cd $ROOTD
 for d in prof prof_classic prof_train; do f=$(ls gpurun_out/${tag}_$d/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_${d}_kernel_stats.csv; rm -rf gpurun_out/${tag}_$d; done
 tail -4 gpurun_out/${tag}_tests.log
