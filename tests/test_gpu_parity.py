@@ -1713,6 +1713,33 @@ def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     assert np.median(cos) > 0.9999 and cos.min() > 0.995, (np.median(cos), cos.min())
 
 
+def test_fine_depths_merge_map(api):
+    """nrf_fine_depths_merge: the same depth set as nrf_fine_depths, plus where every sorted depth came from -- src indexes a table holding the n*s coarse points
+    first and the n*ns new samples after them, z_new are the new samples in SamplePDF order.  Ragged n, plateaus (zero weights), duplicates."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    lib = api.L.lib()
+    rng = np.random.default_rng(3)
+    for n, s, ns in ((1, 64, 128), (37, 64, 128), (130, 32, 32), (5, 8, 200)):
+        z = np.sort(rng.uniform(2.0, 6.0, (n, s)).astype(np.float32), axis=1)
+        w = rng.uniform(0.0, 1.0, (n, s)).astype(np.float32)
+        w[: max(1, n // 3), s // 4: s // 2] = 0.0                       # CDF plateaus
+        if n > 2: z[2, 5] = z[2, 4]                                     # a duplicate coarse depth
+        dz, dw = dev(z), dev(w)
+        u = torch.linspace(0.0, 1.0, ns, dtype=torch.float32).cuda()
+        zf0 = torch.empty((n, s + ns), device="cuda"); zf1 = torch.empty_like(zf0)
+        src = torch.empty((n, s + ns), device="cuda", dtype=torch.int32); zn = torch.empty((n, ns), device="cuda")
+        api.L.check(lib.nrf_fine_depths(P(dz), P(dw), C.c_int64(n), s, P(u), ns, 8, P(zf0), None))
+        api.L.check(lib.nrf_fine_depths_merge(P(dz), P(dw), C.c_int64(n), s, P(u), ns, 8, P(zf1), P(src), P(zn), None))
+        assert_exact(host(zf1), host(zf0), "depth set")
+        table = np.concatenate([z.reshape(-1), host(zn).reshape(-1)])
+        sv = host(src).astype(np.int64)
+        assert_exact(table[sv], host(zf1), "z_fine == table[src]")
+        assert (np.sort(sv, axis=1) == np.sort(np.concatenate([np.arange(n)[:, None] * s + np.arange(s)[None], n * s + np.arange(n)[:, None] * ns + np.arange(ns)[None]], 1), axis=1)).all(), \
+            "every column of the ray appears exactly once"
+        assert (np.diff(host(zn), axis=1) >= 0).all()
+
+
 def test_lerf_feature_reusing_render_equals_two_pass_render(api):
     """The LeRF render pass that encodes every sample point once (coarse columns kept, nrf_fine_depths_merge map, hash encode + sigma net on the new samples,
     embedding pass gathering columns) against the plain two-pass evaluation of the same kernels, main.cpp sizes, both precisions, ragged chunks: depth set,

@@ -6,7 +6,7 @@ H = W = 800
 prec = {"f16x3": L.NRF_PREC_F16_SPLIT, "f16": L.NRF_PREC_F16_MFMA}[sys.argv[1] if len(sys.argv) > 1 else "f16x3"]
 sc = S.make_hash_scene(mode=sys.argv[2] if len(sys.argv) > 2 else "cu", table_amp=0.5, sigma_scale=30.0)
 K = S.lego_K(H, W); c2w = S.pose_spherical(30.0, -30.0, 4.0)
-rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=131072, Perturb=0.0, WhiteBkgr=True, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX, Precision=prec)
+rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=int(os.environ.get("NRF_CHUNK", "131072")), Perturb=0.0, WhiteBkgr=True, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX, Precision=prec)
 r = sc["renderer"]
 for _ in range(3): r.Render(H, W, K, rp, c2w=c2w)
 torch.cuda.synchronize()
