@@ -149,6 +149,14 @@ NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float 
  * table is present; synchronises `stream`. */
 NRF_API int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream);
 
+/* CuHashEmbedder mode: the per-level position scales mul_l (host arrays of n_levels floats).  The reference computes them ON THE DEVICE, per thread, as
+ * exp2f((log2f(finest) - log2f(base)) * l / (L - 1) + log2f(base)) (CuHashEmbedder.cu:40); nrf_hash_create evaluates the same expression with the host's
+ * libm.  CUDA's exp2f / log2f are not libm's, and the features are fp16-ROUNDED blends: one ulp of mul_l flips the fp16 rounding of ~10 % of the features
+ * of the Lego-sized grid and moves a rendered pixel by a few 1e-4 (tests/test_oracle_golden.py, sensitivity study).  A host that needs parity with a
+ * particular CUDA build at the 1e-4 level reads the 16 values once from that build and sets them here; everything downstream then sees its voxels. */
+NRF_API int nrf_hash_get_level_scales(const nrf_hash *h, float *scales_out);
+NRF_API int nrf_hash_set_level_scales(nrf_hash *h, const float *scales, void *stream);
+
 /* BaseEmbedderImpl::forward for the hash grid: x [p,3] -> (embedding [p, L*F] fp32, keep_mask [p] u8).
  * d_keep_mask may be NULL. */
 NRF_API int nrf_hash_encode(const nrf_hash *h, const float *d_x, int64_t p, float *d_out, uint8_t *d_keep_mask, void *stream);

@@ -359,6 +359,25 @@ int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
     return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
 }
 
+int nrf_hash_get_level_scales(const nrf_hash *h, float *scales_out)
+{
+    NRF_CHECK_ARG(h && scales_out, "nrf_hash_get_level_scales: null pointer");
+    for (int l = 0; l < h->desc.n_levels; l++) scales_out[l] = h->params.level_scale[l];
+    return NRF_OK;
+}
+
+int nrf_hash_set_level_scales(nrf_hash *h, const float *scales, void *stream)
+{
+    NRF_CHECK_ARG(h && scales, "nrf_hash_set_level_scales: null pointer");
+    NRF_CHECK_ARG(h->desc.mode == NRF_HASH_CU, "nrf_hash_set_level_scales: the CuHashEmbedder mode computes mul_l with exp2f / log2f on the device (CuHashEmbedder.cu:40); the HashEmbedder's resolutions are floor()ed integers");
+    for (int l = 0; l < h->desc.n_levels; l++) NRF_CHECK_ARG(scales[l] >= 1.0f && scales[l] < 65536.0f, "nrf_hash_set_level_scales: scale %d = %g outside [1, 65536)", l, (double)scales[l]);
+    for (int l = 0; l < h->desc.n_levels; l++) h->params.level_scale[l] = scales[l];
+    h->fast_valid = false;                                   // the dense image's extents follow floor(mul_l)
+    if (!hash_fast_supported(h)) return NRF_OK;
+    NRF_HIP(hipDeviceSynchronize());
+    return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
+}
+
 int nrf_hash_encode_lm_f16(const nrf_hash *h, const float *d_x, int64_t p, void *d_feats, uint8_t *d_keep_mask, void *stream)
 {
     return nrf_hash_encode_lm_f16_strided(h, d_x, p, d_feats, p, d_keep_mask, stream);

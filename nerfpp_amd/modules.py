@@ -116,6 +116,18 @@ class _HashBase(BaseEmbedder):
         training loop, which re-uploads the table every step, wants)."""
         L.check(L.lib().nrf_hash_set_dense_budget(self._h, C.c_int64(int(nbytes)), _stream()))
 
+    def level_scales(self):
+        """The per-level position scales in use (CuHashEmbedder: mul_l of CuHashEmbedder.cu:40; HashEmbedder: the floor()ed resolutions)."""
+        out = np.empty(self.NLevels, np.float32)
+        L.check(L.lib().nrf_hash_get_level_scales(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_level_scales(self, scales):
+        """CuHashEmbedder only: replace the host-libm mul_l by the values a particular CUDA build computes on its device (nrf_hash_set_level_scales)."""
+        a = np.ascontiguousarray(scales, np.float32)
+        assert a.shape == (self.NLevels,)
+        L.check(L.lib().nrf_hash_set_level_scales(self._h, a.ctypes.data_as(C.c_void_p), _stream()))
+
     def set_table(self, table):
         """fp32 embedding table in the reference's parameter layout (numpy or torch, host or device)."""
         if torch.is_tensor(table) and table.is_cuda:

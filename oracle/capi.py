@@ -135,6 +135,11 @@ def f32_to_f16(a):
     return out
 
 
+def set_cuda_fma_model(flags):
+    """0 (default): CuHashEmbedder.cu's expressions as written; bit 0 / bit 1: model nvcc's FMA contraction of the blend / of scale + bias (sensitivity study only)."""
+    lib().orc_set_cuda_fma_model(C.c_int(int(flags)))
+
+
 def hash_cu(x, table_f16, primes, local_idx, local_size, bias, bbox, mul, L, F):
     x = _f(x).reshape(-1, 3)
     table_f16 = np.ascontiguousarray(table_f16, dtype=np.uint16)

@@ -674,6 +674,15 @@ ORC_API void orc_hash_cu_scales(int n_levels, int base, int finest, float *mul_o
         mul_out[l] = exp2f((log2f((float)finest) - log2f((float)base)) * (float)l / (float)(n_levels - 1) + log2f((float)base));
 }
 
+/* What a real CUDA build could do differently, as a switchable MODEL (test infrastructure for the sensitivity study in
+ * tests/test_oracle_golden.py; default 0 = the expressions as written, one rounding per operation):
+ *   bit 0: nvcc's default -fmad=true contracts the blend  w000*f000 + w001*f001 + ...  (.cu:95-100) into a chain of FMAs
+ *          (first product rounded, every following product fused into its addition);
+ *   bit 1: the same contraction of  pt * mul  followed by  pt += bias  (.cu:44-46, :61-63).
+ * Which contractions ptxas really performs cannot be observed here (no nvcc); the study bounds their effect. */
+static int g_cuda_fma_model = 0;
+ORC_API void orc_set_cuda_fma_model(int flags) { g_cuda_fma_model = flags; }
+
 ORC_API void orc_hash_cu(const float *x, int64_t p, const uint16_t *table_f16, const int32_t *primes /*[L,1,3]*/,
                          const int32_t *local_idx /*[L]*/, const int32_t *local_size /*[L]*/,
                          const float *bias /*[L,3]*/, const float *bbox, const float *mul /*[L]*/,
@@ -695,8 +704,11 @@ ORC_API void orc_hash_cu(const float *x, int64_t p, const uint16_t *table_f16, c
             float pt[3], fl[3];
             uint32_t pos[3];
             for (int a = 0; a < 3; a++) {
-                pt[a] = (xc[a] - bbox[a]) / (bbox[3 + a] - bbox[a]) * mul[l];
-                pt[a] = pt[a] + bias[l * 3 + a];
+                if (g_cuda_fma_model & 2) pt[a] = fmaf((xc[a] - bbox[a]) / (bbox[3 + a] - bbox[a]), mul[l], bias[l * 3 + a]);
+                else {
+                    pt[a] = (xc[a] - bbox[a]) / (bbox[3 + a] - bbox[a]) * mul[l];
+                    pt[a] = pt[a] + bias[l * 3 + a];
+                }
                 fl[a] = floorf(pt[a]);
                 pos[a] = (uint32_t)fl[a];
             }
@@ -714,8 +726,10 @@ ORC_API void orc_hash_cu(const float *x, int64_t p, const uint16_t *table_f16, c
             }
             for (int f = 0; f < n_feat; f++) {
                 float acc = ws[0] * f16_bits_to_f32(fp[ps[0] * n_feat + f]);
-                for (int k = 1; k < 8; k++)
-                    acc = acc + ws[k] * f16_bits_to_f32(fp[ps[k] * n_feat + f]);
+                for (int k = 1; k < 8; k++) {
+                    if (g_cuda_fma_model & 1) acc = fmaf(ws[k], f16_bits_to_f32(fp[ps[k] * n_feat + f]), acc);
+                    else acc = acc + ws[k] * f16_bits_to_f32(fp[ps[k] * n_feat + f]);
+                }
                 out[i * n_levels * n_feat + l * n_feat + f] = f16_bits_to_f32(f32_to_f16_bits(acc));
             }
         }

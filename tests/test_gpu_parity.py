@@ -1713,6 +1713,38 @@ def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     assert np.median(cos) > 0.9999 and cos.min() > 0.995, (np.median(cos), cos.min())
 
 
+def test_level_scales_of_a_cuda_build_can_be_injected(api, O):
+    """nrf_hash_set_level_scales: the CuHashEmbedder's mul_l are computed by the reference ON THE DEVICE with CUDA's exp2f / log2f; one ulp of them flips the
+    fp16 rounding of ~10 % of the features (sensitivity study in tests/test_oracle_golden.py), so a host that needs parity with a particular CUDA build hands
+    its 16 values over.  With scales one ulp up, the HIP render (generic kernels AND the dense-image fast path, which is re-baked) equals the oracle fed the
+    same scales bit for bit, and differs from the render with the libm scales."""
+    sc = api.S.make_hash_scene(mode="cu")
+    e, r = sc["embedder"], sc["renderer"]
+    mul0 = O.hash_cu_scales(16, 16, 512)
+    assert_exact(e.level_scales(), mul0, "scales of nrf_hash_create == the oracle's libm evaluation of CuHashEmbedder.cu:40")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp32 = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F32, KeepIntermediates=True)
+    rps = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F16_SPLIT)
+    before = host(r.Render(800, 800, K, rp32, c2w=c2w, row0=400, rows=1).Outputs.RGBMap).reshape(-1, 3)
+    mul1 = np.nextafter(mul0, np.float32(np.inf)).astype(np.float32)
+    try:
+        e.set_level_scales(mul1)
+        res = r.Render(800, 800, K, rp32, c2w=c2w, row0=400, rows=1)
+        rgb = host(res.Outputs.RGBMap).reshape(-1, 3); rays = host(res.Extras["rays_flat"])
+        ls = ((1 << 19) >> 4) << 4
+        model = O.Model(2, sc["mlp_blob"], bbox=sc["bbox"], table_f16=O.f32_to_f16(sc["table"]), primes=sc["primes"], local_idx=np.arange(16, dtype=np.int32) * ls,
+                        local_size=np.full(16, ls, np.int32), bias=np.zeros((16, 3), np.float32), mul=mul1)
+        idx = np.arange(0, 800, 13)
+        ref = O.render_rays(model, rays[idx], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
+        assert_exact(rgb[idx], ref["rgb"], "F32 render with injected scales == oracle with the same scales")
+        assert np.abs(rgb - before).max() > 1e-4, "one ulp of the level scales is visible in the pixels (why the knob exists)"
+        fast = host(r.Render(800, 800, K, rps, c2w=c2w, row0=400, rows=1).Outputs.RGBMap).reshape(-1, 3)
+        assert_close(fast, rgb, rtol=0, atol=1e-4, what="fast path (re-baked dense image) with injected scales vs its own parity mode")
+    finally:
+        e.set_level_scales(mul0)
+    assert_exact(host(r.Render(800, 800, K, rp32, c2w=c2w, row0=400, rows=1).Outputs.RGBMap).reshape(-1, 3), before, "restored")
+
+
 def test_fine_depths_merge_map(api):
     """nrf_fine_depths_merge: the same depth set as nrf_fine_depths, plus where every sorted depth came from -- src indexes a table holding the n*s coarse points
     first and the n*ns new samples after them, z_new are the new samples in SamplePDF order.  Ragged n, plateaus (zero weights), duplicates."""

@@ -457,3 +457,63 @@ def test_tv_loss_vs_reference_autograd(manifest):
         ref = g[f"l{level}_grad"]
         assert_close(grad, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), what=f"level {level}")
         assert (ref != 0).sum() >= (int(g[f"l{level}_res_cube"][1]) + 1) ** 3 * 0.9
+
+
+def test_cuda_only_encoder_sensitivity_to_what_cannot_be_pinned():
+    """CuHashEmbedder.cu cannot be compiled here (no nvcc), so its restatement is pinned by hand-computed answers only.  Three things a real CUDA build may
+    do differently are MODELLED and their effect measured on the bench scene (L16 T2^19 F2 16..512, 64 + 128 samples, 96 rays of the 800x800 frame):
+      (1) nvcc's default FMA contraction of the 8-term blend (.cu:95-100);   (2) the same for scale * x + bias (.cu:44-46, :61-63);
+      (3) CUDA's exp2f / log2f (not libm's) yielding level scales mul_l (.cu:40, evaluated per thread on the device) one ulp away from the host's.
+    The features are fp16-ROUNDED blends (.cu:95), so any last-bit change of the fp32 blend flips the rounding of some features by one fp16 ulp (5e-4).
+    Measured: (1), (2) flip 0.02 % of the features and move no pixel by more than 2e-5 -- harmless.  (3) flips ~10 % of the features (the scale multiplies
+    coordinates of up to 512 voxels) and moves the MEDIAN pixel by 3-4e-4: parity with a particular CUDA build at the north star's 1e-4 requires that build's
+    16 scale values, whatever the implementation -- hence nrf_hash_set_level_scales (test_level_scales_of_a_cuda_build_can_be_injected)."""
+    from nerfpp_amd import scene as S
+    L_, F_, T_ = 16, 2, 19
+    table = S.synth_hash_table(L_, T_, F_, 5000, 0.5)
+    params = S.synth_linear_stack(S.small_shapes(32, 16, 3, 64, 15, 4, 64), 6000, 1.6, 0.0, {"sigma_net_2": 30.0})
+    blob = np.concatenate([a.reshape(-1) for _, a in params])
+    primes = np.array(S.CU_PRIMES[:3 * L_], np.int32)
+    ls = ((1 << T_) >> 4) << 4
+    mul = O.hash_cu_scales(L_, 16, 512)
+    def model(m):
+        return O.Model(2, blob, bbox=S.LEGO_BBOX, table_f16=O.f32_to_f16(table), primes=primes, local_idx=np.arange(L_, dtype=np.int32) * ls,
+                       local_size=np.full(L_, ls, np.int32), bias=np.zeros((L_, 3), np.float32), mul=m)
+    K = S.lego_K(800, 800); c2w = S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = O.get_rays(800, 800, K, c2w, row0=400, rows=1)
+    rays = O.pack_rays(o.reshape(-1, 3)[::8][:96], d.reshape(-1, 3)[::8][:96], S.LEGO_BBOX)
+    t, u = O.linspace(0, 1, 64), O.linspace(0, 1, 128)
+    base = O.render_rays(model(mul), rays, 64, 128, t, u, white_bkgr=True, want_intermediates=True)
+    pts = base["pts_fine"].reshape(-1, 3)
+    args = (O.f32_to_f16(table), primes, np.arange(L_, dtype=np.int32) * ls, np.full(L_, ls, np.int32), np.zeros((L_, 3), np.float32), S.LEGO_BBOX)
+    f0, _ = O.hash_cu(pts, *args, mul, L_, F_)
+    worst = 0.0
+    report = {}
+    variants = {"fma blend": (1, mul), "fma blend + scale": (3, mul), "mul + 1 ulp": (0, np.nextafter(mul, np.float32(np.inf)).astype(np.float32)),
+                "mul - 1 ulp": (0, np.nextafter(mul, np.float32(-np.inf)).astype(np.float32)),
+                "all, mul + 1 ulp": (3, np.nextafter(mul, np.float32(np.inf)).astype(np.float32))}
+    try:
+        for name, (flags, m) in variants.items():
+            O.set_cuda_fma_model(flags)
+            f1, _ = O.hash_cu(pts, *args, m, L_, F_)
+            r = O.render_rays(model(m), rays, 64, 128, t, u, white_bkgr=True, want_intermediates=True)
+            changed = float((f1 != f0).mean())
+            step = float(np.abs(f1 - f0).max() / np.abs(f0).max())
+            dp = np.abs(r["rgb"] - base["rgb"]).max(axis=1)                        # per ray
+            same_set = (r["z_fine"] == base["z_fine"]).all(axis=1)                 # rays whose fine sample set did not move
+            report[name] = dict(features_changed=changed, largest_feature_step=step, max_pixel_change=float(dp.max()), median_pixel_change=float(np.median(dp)),
+                                rays_within_1e4=float((dp < 1e-4).mean()), rays_with_same_sample_set=float(same_set.mean()),
+                                max_pixel_change_same_sample_set=float(dp[same_set].max()) if same_set.any() else 0.0)
+            worst = max(worst, float(dp.max()))
+            assert step < 2e-3, (name, step)                 # a feature moves by fp16 ulps, not more
+            if "mul" not in name:                            # FMA contraction alone: harmless
+                assert changed < 2e-3 and dp.max() < 1e-4, (name, report[name])
+            else:                                            # one ulp of the level scales: visible -- the finding this test records
+                assert 0.02 < changed < 0.3, (name, report[name])
+                assert 1e-5 < np.median(dp) < 5e-3, (name, report[name])
+    finally:
+        O.set_cuda_fma_model(0)
+    import json
+    print("CuHashEmbedder sensitivity:", json.dumps(report, indent=1))
+    assert base["rgb"].std() > 0.05                          # a scene with structure, not a constant image
+    assert any(v["features_changed"] > 0 for v in report.values())            # the variants do change features: not a vacuous study
