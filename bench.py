@@ -354,7 +354,9 @@ def main():
                                    ("CuSHEncoder" if args.hash_mode == "cu" else "SHEncoder") + " deg4 + NeRFSmall 3x64/4x64") if args.workload == "hash"
                        else "PE(10)/PE(4) + NeRF 8x256 skip4 viewdirs",
                        "oracle_pin": ("CuHashEmbedder / CuSHEncoder are CUDA-only units: the oracle for them is a line-by-line restatement pinned by hand-computed known answers, not by a "
-                                      "reference run (nvcc's FMA contraction is not modelled); the reference-pinned encoders are the LibTorch twin in `also`")
+                                      "reference run.  What a real CUDA build could change was measured by modelling it in the oracle (tests/test_oracle_golden.py, sensitivity study): nvcc's FMA "
+                                      "contraction moves no pixel by more than 2e-5; one ulp of the level scales, which the reference computes on the device with CUDA's exp2f / log2f, moves the "
+                                      "median pixel by 3-4e-4 -- nrf_hash_set_level_scales takes a CUDA build's values.  The reference-pinned encoders are the LibTorch twin in `also`")
                        if (args.workload == "hash" and args.hash_mode == "cu") else "reference-pinned (goldens from the compiled reference)",
                        "frames_per_step": nframes, "rays_per_gpu_per_step": nframes * H * W // world, "ray_samples_per_ray": UNITS_PER_RAY, "chunk": chunk,
                        "parallelism": f"row-tile x{world}" + ((" + " + ("RCCL" if args.backend == "nccl" else "gloo (ranks SHARING one GPU: a rehearsal of the N > 1 code path)") +
