@@ -240,6 +240,15 @@ NRF_API int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_l
 /* ... on columns of a wider level-major table ([16][pstride][8] halfs): _strided evaluates p consecutive columns starting at d_feats_lm; _gather reads column
  * d_src[i] for sample i of the n * s sorted depths (d_src = the merge map of nrf_fine_depths_merge; NULL = column i).  Same arithmetic, same results. */
 NRF_API int nrf_lerf_sigma_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma, void *stream);
+/* Split precision only: kernel A also leaves the sigma net's second output (sigma, geo32: LE0's chained operand, 192 bytes per column as fragment planes,
+ * nrf_lerf_geo_bytes(columns)) in d_geo, and the embedding pass starts at LE0 from it instead of re-evaluating the sigma net (224 of its 832 matrix
+ * instructions per 32 points).  d_geo / d_feats_lm of a _strided call point at the call's first column; geo_stride = columns of the whole table.
+ * Same values in the same order as the recomputation: results unchanged.  NRF_ERR_UNSUPPORTED in NRF_PREC_F16_MFMA. */
+NRF_API size_t nrf_lerf_geo_bytes(int64_t columns);
+NRF_API int nrf_lerf_sigma_geo_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma,
+                                          void *d_geo, int64_t geo_stride, void *stream);
+NRF_API int nrf_lerf_render_embedding_lm_geo(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const void *d_geo,
+                                             int64_t geo_stride, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
 NRF_API int nrf_lerf_render_embedding_lm_gather(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const float *d_weights, int64_t n,
                                                 int s, float *d_out, void *stream);
 

@@ -365,7 +365,15 @@ private:
 		auto pts = torch::empty({nc, 3}, opt);
 		check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
 		check(nrf_hash_encode_lm_f16_strided(h, pts.data_ptr<float>(), nc, x.data_ptr(), cols, keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16_strided");
-		check(nrf_lerf_sigma_lm_strided(Mlp.m, x.data_ptr(), cols, keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma_lm_strided");
+		// split precision: the sigma pass also leaves (sigma, geo32) per column and the embedding pass starts at LE0 from it
+		const bool hand_over = Precision == NRF_PREC_F16_SPLIT && HandOverGeo;
+		torch::Tensor geo;
+		if (hand_over) geo = torch::empty({(int64_t)nrf_lerf_geo_bytes(cols)}, opt.dtype(torch::kUInt8));
+		auto sigma_pass = [&](void *xp, uint8_t *kp, int64_t count, float *sp, int64_t col0) {
+			if (hand_over) check(nrf_lerf_sigma_geo_lm_strided(Mlp.m, xp, cols, kp, count, sp, static_cast<char *>(geo.data_ptr()) + col0 * 32, cols, current_stream()), "nrf_lerf_sigma_geo_lm_strided");
+			else check(nrf_lerf_sigma_lm_strided(Mlp.m, xp, cols, kp, count, sp, current_stream()), "nrf_lerf_sigma_lm_strided");
+		};
+		sigma_pass(x.data_ptr(), keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), 0);
 		auto weights = [&](const float *sg, torch::Tensor zz, int ss) {
 			LeRFPassOutputs o;
 			o.WeightsLE = torch::empty({n, (int64_t)ss}, opt); o.DepthMapLE = torch::empty({n}, opt); o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt);
@@ -383,12 +391,14 @@ private:
 		check(nrf_points(rays.data_ptr<float>(), stride, z_new.data_ptr<float>(), n, ni, pts_new.data_ptr<float>(), current_stream()), "nrf_points");
 		void *x_new = static_cast<char *>(x.data_ptr()) + nc * 8 * 2;             // column n*s of level 0
 		check(nrf_hash_encode_lm_f16_strided(h, pts_new.data_ptr<float>(), nn, x_new, cols, keep.data_ptr<uint8_t>() + nc, current_stream()), "nrf_hash_encode_lm_f16_strided");
-		check(nrf_lerf_sigma_lm_strided(Mlp.m, x_new, cols, keep.data_ptr<uint8_t>() + nc, nn, sig.data_ptr<float>() + nc, current_stream()), "nrf_lerf_sigma_lm_strided");
+		sigma_pass(x_new, keep.data_ptr<uint8_t>() + nc, nn, sig.data_ptr<float>() + nc, nc);
 		auto sig_f = sig.index_select(0, src.reshape({-1}).to(torch::kLong));      // sigma_le of the sorted depths
 		LeRFPassOutputs o = weights(sig_f.data_ptr<float>(), zf, sf);
 		const int E = GetLangEmbedDim();
 		auto acc = torch::empty({n, (int64_t)E}, opt);
-		check(nrf_lerf_render_embedding_lm_gather(Mlp.m, x.data_ptr(), cols, src.data_ptr<int32_t>(), o.WeightsLE.data_ptr<float>(), n, sf, acc.data_ptr<float>(), current_stream()),
+		if (hand_over) check(nrf_lerf_render_embedding_lm_geo(Mlp.m, x.data_ptr(), cols, src.data_ptr<int32_t>(), geo.data_ptr(), cols, o.WeightsLE.data_ptr<float>(), n, sf, acc.data_ptr<float>(),
+			current_stream()), "nrf_lerf_render_embedding_lm_geo");
+		else check(nrf_lerf_render_embedding_lm_gather(Mlp.m, x.data_ptr(), cols, src.data_ptr<int32_t>(), o.WeightsLE.data_ptr<float>(), n, sf, acc.data_ptr<float>(), current_stream()),
 			"nrf_lerf_render_embedding_lm_gather");
 		auto ones = torch::ones({n, 1}, opt);
 		o.RenderedLangEmbedding = torch::empty({n, (int64_t)E}, opt);
@@ -399,6 +409,7 @@ private:
 
 public:
 	bool ReuseFeatures = true;          ///< level-major fused path: encode every sample point once per render (false: two plain passes)
+	bool HandOverGeo = true;            ///< split precision, reuse path: the embedding pass takes the sigma net's output from the sigma pass (false: re-evaluates it)
 
 	/// LeRFRenderer::RenderRays (LeRFRenderer.cpp:85-187), deterministic path (Perturb = 0, RawNoiseStd = 0, ThinRay): the fused matrix-core passes when the
 	/// sample counts are multiples of 32 (a wave's 32-point tile lies inside one ray), the fp32 stage path otherwise.  z_fine (optional) receives the fine depths.

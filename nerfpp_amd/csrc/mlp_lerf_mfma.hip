@@ -467,6 +467,35 @@ int nrf_lerf_sigma_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t 
     return launch_lerf<2>(m, a, p, as_stream(stream));
 }
 
+size_t nrf_lerf_geo_bytes(int64_t columns) { return columns > 0 ? (size_t)columns * (size_t)lerf::GEO_BYTES_PER_COLUMN : 0; }
+
+int nrf_lerf_sigma_geo_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma, void *d_geo,
+                                  int64_t geo_stride, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_sigma && d_geo && p >= 0 && pstride >= p && geo_stride >= p, "nrf_lerf_sigma_geo_lm_strided: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_sigma_geo_lm_strided: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    if (m->lerf_precision != NRF_PREC_F16_SPLIT) { set_error("nrf_lerf_sigma_geo_lm_strided: built for NRF_PREC_F16_SPLIT (nrf_lerf_set_precision); the fp16 passes re-evaluate the sigma net"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG(((reinterpret_cast<uintptr_t>(d_feats_lm) | reinterpret_cast<uintptr_t>(d_geo)) & 15) == 0, "nrf_lerf_sigma_geo_lm_strided: features / geo must be 16-byte aligned");
+    if (p == 0) return NRF_OK;
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), pstride, nullptr, d_keep, d_sigma, nullptr, 32};
+    a.geo = d_geo; a.geo_stride = geo_stride;
+    return lerf_split_sigma(m, a, p, as_stream(stream));
+}
+
+int nrf_lerf_render_embedding_lm_geo(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const void *d_geo, int64_t geo_stride,
+                                     const float *d_weights, int64_t n, int s, float *d_out, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_geo && d_weights && d_out && n >= 0 && s >= 1 && pstride >= 1 && geo_stride >= 1, "nrf_lerf_render_embedding_lm_geo: bad argument");
+    if (!nrf_lerf_mfma_available(m)) { set_error("nrf_lerf_render_embedding_lm_geo: the matrix-core LeRF path is built for in 128 / hidden 256 / 2+2 layers / geo 32 / embedding 768"); return NRF_ERR_UNSUPPORTED; }
+    if (m->lerf_precision != NRF_PREC_F16_SPLIT) { set_error("nrf_lerf_render_embedding_lm_geo: built for NRF_PREC_F16_SPLIT (nrf_lerf_set_precision)"); return NRF_ERR_UNSUPPORTED; }
+    NRF_CHECK_ARG(s % 32 == 0, "nrf_lerf_render_embedding_lm_geo: samples per ray (%d) must be a multiple of 32 (a wave's 32-point tile lies inside one ray)", s);
+    NRF_CHECK_ARG(((reinterpret_cast<uintptr_t>(d_feats_lm) | reinterpret_cast<uintptr_t>(d_geo)) & 15) == 0, "nrf_lerf_render_embedding_lm_geo: features / geo must be 16-byte aligned");
+    if (n == 0) return NRF_OK;
+    lerf::Args a{nullptr, 0, reinterpret_cast<const __half *>(d_feats_lm), pstride, d_weights, nullptr, nullptr, nullptr, s};
+    a.src = d_src; a.geo = const_cast<void *>(d_geo); a.geo_stride = geo_stride;
+    return lerf_split_embedding_passes(m, a, n, s, d_out, as_stream(stream));
+}
+
 int nrf_lerf_render_embedding_lm(const nrf_mlp *m, const void *d_feats_lm, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
 {
     return nrf_lerf_render_embedding_lm_gather(m, d_feats_lm, n * (int64_t)s, nullptr, d_weights, n, s, d_out, stream);

@@ -55,7 +55,14 @@ struct Args {
     int s;                                  // samples per ray, a multiple of 32
     float gram_scale;                       // the image's Gram matrix is (W^T W) / gram_scale (a power of two keeping it inside fp16 range); set by the launchers
     const int32_t *src;                     // optional (x_lm): point q reads feature column src[q] -- the merge map of a feature-reusing fine pass (nrf_fine_depths_merge)
+    // Split precision, level-major input: the sigma net's second output (sigma, geo32 = LE0's chained operand: three (hi, lo) fragment pairs per point) handed
+    // from kernel A to kernel B through memory, so that B starts at LE0 instead of re-evaluating the sigma net (224 of its 832 matrix instructions per tile).
+    // Layout: plane (f, part), f = 0..2, part = hi / lo: half8 [geo_stride columns][2 lane halves]; kernel A writes column q, kernel B reads column src[q] (or q).
+    void *geo;
+    int64_t geo_stride;
 };
+constexpr int GEO_FRAGS = 3;                                        // fragments 0, 1: sigma + geo[0..30]; fragment 2: geo[31] (the fourth is all zero)
+constexpr int64_t GEO_BYTES_PER_COLUMN = GEO_FRAGS * 2 * 2 * 16;    // 192
 
 }  // namespace lerf
 

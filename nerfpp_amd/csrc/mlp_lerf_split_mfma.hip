@@ -25,15 +25,18 @@ constexpr int SNBLK = 32 * SNW;
 constexpr int SMAXF = 32;              // fragments in the largest chunk: 16 k-steps x (hi, lo)
 
 // one neuron tile per chunk; per (layer, tile, k-step) the hi fragment then the lo fragment
-template <int NL>
+// L0: first layer the kernel runs (2: kernel B fed the sigma net's output by kernel A, see Args::geo); chunks are numbered from that layer's first tile
+template <int NL, int L0 = 0>
 struct NetS {
     using F = Net<NL>;
-    static constexpr int first_chunk(int l) { int n = 0; for (int i = 0; i < l; i++) n += F::tiles(i); return n; }
+    static constexpr int first_chunk(int l) { int n = 0; for (int i = L0; i < l; i++) n += F::tiles(i); return n; }
     static constexpr int total_chunks() { return first_chunk(NL); }
-    static constexpr int layer_of(int ci) { int l = 0; while (first_chunk(l + 1) <= ci) l++; return l; }
+    static constexpr int layer_of(int ci) { int l = L0; while (first_chunk(l + 1) <= ci) l++; return l; }
     static constexpr int chunk_frags(int ci) { return 2 * F::ks(layer_of(ci)); }
-    static constexpr int chunk_off(int ci) { int n = 0; for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
+    static constexpr int image_off() { int n = 0; for (int i = 0; i < L0; i++) n += F::tiles(i) * 2 * F::ks(i); return n; }      // fragments of the skipped layers
+    static constexpr int chunk_off(int ci) { int n = image_off(); for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
 };
+static_assert(NetS<4, 2>::total_chunks() == 16 && NetS<4, 2>::chunk_off(0) == 2 * (8 * 8 + 2 * 16), "kernel B from LE0 on");
 static_assert(NetS<2>::total_chunks() == 10 && NetS<4>::total_chunks() == 26, "chunk counts");
 static_assert(NetS<4>::chunk_off(26) == 2 * LE1_FRAG0, "the split image doubles the fp16 image");
 
@@ -205,11 +208,12 @@ struct ReduceS {
 };
 
 // XLO: the input features carry a lo part (fp32 rows); level-major CuHashEmbedder features are exact fp16
-template <int NL, bool XLO>
+template <int NL, bool XLO, bool GEOIN = false>
 __global__ void __launch_bounds__(64 * SNW, 1)
 k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
 {
-    using N = NetS<NL>;
+    using N = NetS<NL, GEOIN ? 2 : 0>;
+    static_assert(!GEOIN || NL == 4, "only kernel B can start from the sigma net's output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wbuf = reinterpret_cast<half8 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,21 +252,39 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
             }
         };
         half8 ba[16][2], bb[4][2];
-        ConvHookS<true, 16> c0{ba, 0.0f};
-        {
-            half8 xin[8][2];
-            load_x(xin);
-            layer_s<N, 0, XLO, false>(cx, xin, none, c0);                 // sigma0: 128 -> 256, ReLU
-        }
-        ConvHookS<false, 4, NL == 2> c1{bb, 0.0f};
-        layer_s<N, 1, false, true>(cx, none, ba, c1);                     // sigma1: 256 -> (sigma, geo32)
-        if constexpr (NL == 2) {
-            if (h == 0 && live) {
-                float sg = c1.row0;
-                if (in.keep && !in.keep[q]) sg = 0.0f;                    // raw_le[~keep, -1] = 0 (LeRFRenderer.cpp:22-23)
-                in.sigma[q] = sg;
-            }
+        half8 *geo = reinterpret_cast<half8 *>(in.geo);
+        if constexpr (GEOIN) {
+            // (sigma, geo32) as kernel A left them: the operand fragments themselves, column src[q]
+            const int64_t col = in.src ? (int64_t)in.src[qc] : qc;
+#pragma unroll
+            for (int f = 0; f < GEO_FRAGS; f++)
+#pragma unroll
+                for (int part = 0; part < 2; part++) bb[f][part] = geo[(((int64_t)(f * 2 + part) * in.geo_stride + col) << 1) + h];
+            bb[3][0] = half8{0, 0, 0, 0, 0, 0, 0, 0}; bb[3][1] = bb[3][0];
         } else {
+            ConvHookS<true, 16> c0{ba, 0.0f};
+            {
+                half8 xin[8][2];
+                load_x(xin);
+                layer_s<N, 0, XLO, false>(cx, xin, none, c0);                 // sigma0: 128 -> 256, ReLU
+            }
+            ConvHookS<false, 4, NL == 2> c1{bb, 0.0f};
+            layer_s<N, 1, false, true>(cx, none, ba, c1);                     // sigma1: 256 -> (sigma, geo32)
+            if constexpr (NL == 2) {
+                if (h == 0 && live) {
+                    float sg = c1.row0;
+                    if (in.keep && !in.keep[q]) sg = 0.0f;                    // raw_le[~keep, -1] = 0 (LeRFRenderer.cpp:22-23)
+                    in.sigma[q] = sg;
+                }
+                if (geo && live) {
+#pragma unroll
+                    for (int f = 0; f < GEO_FRAGS; f++)
+#pragma unroll
+                        for (int part = 0; part < 2; part++) geo[(((int64_t)(f * 2 + part) * in.geo_stride + q) << 1) + h] = bb[f][part];
+                }
+            }
+        }
+        if constexpr (NL != 2) {
             ConvHookS<true, 16> c2{ba, 0.0f};
             {
                 half8 xin[8][2];
@@ -338,9 +360,13 @@ static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipS
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (a.x_lm) hipLaunchKernelGGL((k_lerf_split<NL, false>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
+    if (NL == 4 && a.geo) {
+        if (!a.x_lm) { set_error("LeRF passes: the sigma net's output is handed over on the level-major input path only"); return NRF_ERR_INVALID_ARG; }
+        hipLaunchKernelGGL((k_lerf_split<4, false, true>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
+    } else if (a.x_lm) hipLaunchKernelGGL((k_lerf_split<NL, false>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
     else hipLaunchKernelGGL((k_lerf_split<NL, true>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
     NRF_LAUNCH_CHECK();
     return NRF_OK;

@@ -444,6 +444,7 @@ class LeRFRenderer:
         self.point_chunk = point_chunk          # bounds the [P, E+1] raw tensor (3 KB per point at E = 768)
         # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
         self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
+        self.hand_over_geo = True           # split precision, reuse path: the embedding pass takes the sigma net's output from the sigma pass (False: re-evaluates it)
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
         if self.fused:
@@ -488,7 +489,15 @@ class LeRFRenderer:
         keep = torch.empty((cols,), device=dev, dtype=torch.uint8)
         sig = torch.empty((cols,), device=dev, dtype=torch.float32)           # [coarse n*s | new n*ni], the table's column order
         L.check(lib.nrf_hash_encode_lm_f16_strided(h, _ptr(pts), C.c_int64(n * s), _ptr(x), C.c_int64(cols), _ptr(keep), _stream()))
-        L.check(lib.nrf_lerf_sigma_lm_strided(m, _ptr(x), C.c_int64(cols), _ptr(keep), C.c_int64(n * s), _ptr(sig), _stream()))
+        # split precision: the sigma pass also leaves (sigma, geo32) per column, and the embedding pass starts at LE0 from it (nrf_lerf_*_geo)
+        geo = torch.empty((int(lib.nrf_lerf_geo_bytes(C.c_int64(cols))),), device=dev, dtype=torch.uint8) if self.precision == L.NRF_PREC_F16_SPLIT and self.hand_over_geo else None
+        def sigma_pass(x_ptr, keep_t, count, sig_t, col0):
+            if geo is None:
+                L.check(lib.nrf_lerf_sigma_lm_strided(m, x_ptr, C.c_int64(cols), _ptr(keep_t), C.c_int64(count), _ptr(sig_t), _stream()))
+            else:
+                L.check(lib.nrf_lerf_sigma_geo_lm_strided(m, x_ptr, C.c_int64(cols), _ptr(keep_t), C.c_int64(count), _ptr(sig_t), C.c_void_p(geo.data_ptr() + col0 * 32),
+                                                          C.c_int64(cols), _stream()))
+        sigma_pass(_ptr(x), keep, n * s, sig, 0)
         out1 = self._weights_from_sigma(sig[:n * s].view(n, s), z, rays_d)
         u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
         zf = torch.empty((n, sf), device=dev); src = torch.empty((n, sf), device=dev, dtype=torch.int32); z_new = torch.empty((n, ni), device=dev)
@@ -497,12 +506,15 @@ class LeRFRenderer:
         L.check(lib.nrf_points(_ptr(rays), stride, _ptr(z_new), C.c_int64(n), ni, _ptr(pts_new), _stream()))
         x_new = C.c_void_p(x.data_ptr() + n * s * 8 * 2)                      # column n*s of level 0
         L.check(lib.nrf_hash_encode_lm_f16_strided(h, _ptr(pts_new), C.c_int64(n * ni), x_new, C.c_int64(cols), _ptr(keep[n * s:]), _stream()))
-        L.check(lib.nrf_lerf_sigma_lm_strided(m, x_new, C.c_int64(cols), _ptr(keep[n * s:]), C.c_int64(n * ni), _ptr(sig[n * s:]), _stream()))
+        sigma_pass(x_new, keep[n * s:], n * ni, sig[n * s:], n * s)
         sig_f = sig[src.reshape(-1).long()].view(n, sf)
         o = self._weights_from_sigma(sig_f, zf, rays_d)
         E = self.Lerf.GetLangEmbedDim()
         acc = torch.empty((n, E), device=dev, dtype=torch.float32)
-        L.check(lib.nrf_lerf_render_embedding_lm_gather(m, _ptr(x), C.c_int64(cols), _ptr(src), _ptr(o.WeightsLE), C.c_int64(n), sf, _ptr(acc), _stream()))
+        if geo is None:
+            L.check(lib.nrf_lerf_render_embedding_lm_gather(m, _ptr(x), C.c_int64(cols), _ptr(src), _ptr(o.WeightsLE), C.c_int64(n), sf, _ptr(acc), _stream()))
+        else:
+            L.check(lib.nrf_lerf_render_embedding_lm_geo(m, _ptr(x), C.c_int64(cols), _ptr(src), _ptr(geo), C.c_int64(cols), _ptr(o.WeightsLE), C.c_int64(n), sf, _ptr(acc), _stream()))
         ones = torch.ones((n, 1), device=dev, dtype=torch.float32)
         o.RenderedLangEmbedding = _clip_embedding(acc, E, E, ones)
         return out1, o, zf

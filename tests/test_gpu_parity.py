@@ -1786,6 +1786,11 @@ def test_lerf_feature_reusing_render_equals_two_pass_render(api):
             r.set_precision(prec)
             r.reuse_features = True
             a = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
+            r.hand_over_geo = False           # split precision: the embedding pass re-evaluating the sigma net instead of taking its output from the sigma pass
+            a2 = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
+            r.hand_over_geo = True
+            assert_exact(host(a2.Outputs.WeightsLE), host(a.Outputs.WeightsLE), "WeightsLE with / without the sigma net's output handed over")
+            assert_close(host(a2.Outputs.RenderedLangEmbedding), host(a.Outputs.RenderedLangEmbedding), rtol=0, atol=2e-5, what="embedding with / without the hand-over")
             r.reuse_features = False
             b = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
             assert_exact(host(a.Extras["z_fine"]), host(b.Extras["z_fine"]), "fine depth set")
@@ -1795,7 +1800,7 @@ def test_lerf_feature_reusing_render_equals_two_pass_render(api):
             assert np.isfinite(ea).all()
             assert_close(ea, eb, rtol=0, atol=2e-5, what="rendered embedding (unit vectors; the float atomics of the per-ray sums are unordered in either render)")
     finally:
-        r.reuse_features = True
+        r.reuse_features = True; r.hand_over_geo = True
         r.set_precision(api.L.NRF_PREC_F16_SPLIT)
 
 
