@@ -85,6 +85,7 @@ struct CtxS {
     const half8 *packed;
     int lane, h, wave;
     int *cur;
+    f32x16 *accs;           // two accumulator tiles: tile T of a layer accumulates into accs[T & 1] while tile T - 1 (in the other) is being converted
 };
 
 // One chunk = neuron tile T of layer L; the finished tile (main + correction accumulator) goes to hook(T, tile).  BNLO / BCLO: the natural / chained operand has a lo part.
@@ -102,20 +103,46 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     static_assert(NQ <= 8, "piece switch covers 8 pieces per wave");
     stage_all<N, CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane, std::make_integer_sequence<int, LEAD>{});
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 acc = zero, cor = zero;
+    // One accumulator per tile, small terms first within a k-step (a dependent chain of this instruction issues back to back).  Hooks that convert a tile into
+    // the next layer's operands (UNITS > 0) are DEFERRED within a layer: tile T - 1, finished in the other accumulator, is converted one unit per k-step behind
+    // tile T's matrix instructions instead of after its own (at one wave per SIMD nothing else overlaps those ~180 vector instructions); a layer's last tile is
+    // converted at once.
+    constexpr int NT = F::tiles(L);
+    constexpr bool DEFER = Hook::UNITS > 0;
+    constexpr bool PEND = DEFER && T > 0;
+    static_assert(!DEFER || Hook::UNITS <= KS, "a deferred tile's units must fit the next tile's k-steps");
+    f32x16 &acc = cx.accs[T & 1];
+    const f32x16 &prev = cx.accs[(T & 1) ^ 1];
+    acc = zero;
     int q = LEAD;
+    // weight fragments two k-steps ahead of their matrix instructions through three register slots, with counted waits (see mlp_nerf_split_mfma.hip: left to
+    // the compiler the reads sit 32 pipe cycles before their use, or it waits for ALL outstanding reads)
+    half8 fa[3][2];
+    const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+    auto read_pair = [&](int kk_, int slot) {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr + (uint32_t)kk_ * 2048u));
+    };
+    read_pair(0, 0);
+    if (KS > 1) read_pair(1, 1);
 #pragma unroll
     for (int k = 0; k < KS; k++) {
-        const half8 ah = w[(2 * k) * 64 + cx.lane], al = w[(2 * k + 1) * 64 + cx.lane];
+        if (k + 2 < KS) {
+            read_pair(k + 2, (k + 2) % 3);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        } else if (k + 1 < KS) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 ah = fa[k % 3][0], al = fa[k % 3][1];
         const bool nat = NATF ? (k < KSN) : (k >= KSC);
         const int kk = NATF ? (nat ? k : k - KSN) : (nat ? k - KSC : k);
         const half8 bh = nat ? bn[nat ? kk : 0][0] : bc[nat ? 0 : kk][0];
-        cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cor, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
         if (nat ? BNLO : BCLO) {
             const half8 bl = nat ? bn[nat ? kk : 0][1] : bc[nat ? 0 : kk][1];
-            cor = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cor, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
         }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        if constexpr (PEND) { if (k < Hook::UNITS) hook.unit(T - 1, prev, k); }
         if ((k % EVERY) == EVERY - 1 && q < NQ) {
             const int qq = q;
             switch (qq) {
@@ -125,12 +152,9 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
             }
             q++;
         }
-        if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    f32x16 tile;
-#pragma unroll
-    for (int i = 0; i < 16; i++) tile[i] = acc[i] + cor[i];
-    hook(T, tile);
+    if constexpr (!DEFER || T == NT - 1) hook(T, acc);
     __builtin_amdgcn_sched_barrier(0);          // the tile is consumed here (see mlp_lerf_mfma.hip)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ) : "memory");
 }
@@ -159,6 +183,7 @@ template <bool RELU, int NOUT, bool KEEP0 = false>
 struct ConvHookS {
     half8 (&bout)[NOUT][2];
     float row0;
+    static constexpr int UNITS = 8;          // deferrable: unit u = values 8s + 2j, 8s + 2j + 1 (s = u >> 2, j = u & 3) -> words j of fragments 2 tile + s
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
         if (2 * tile + 1 < NOUT) {
@@ -167,12 +192,27 @@ struct ConvHookS {
         }
         if (KEEP0 && tile == 0) row0 = t[0];
     }
+    __device__ __forceinline__ void unit(int tile, const f32x16 &t, int u)
+    {
+        if (2 * tile + 1 < NOUT) {
+            const int s = u >> 2, j = u & 3;
+            const float lim = RELU ? 0.0f : -3.402823466e38f;
+            uint32_t hi, lo;
+            split_pair(fmaxf(t[8 * s + 2 * j], lim), fmaxf(t[8 * s + 2 * j + 1], lim), hi, lo);
+            u32x4 hv = __builtin_bit_cast(u32x4, bout[2 * tile + s][0]), lv = __builtin_bit_cast(u32x4, bout[2 * tile + s][1]);
+            hv[j] = hi; lv[j] = lo;
+            bout[2 * tile + s][0] = __builtin_bit_cast(half8, hv); bout[2 * tile + s][1] = __builtin_bit_cast(half8, lv);
+        }
+        if (KEEP0 && tile == 0 && u == 0) row0 = t[0];
+    }
 };
 
 // a . (G a) with a = hi + lo
 struct DotHookS {
     const half8 (&a)[16][2];
     float ss = 0.0f;
+    static constexpr int UNITS = 0;          // consumed at once (16 FMAs)
+    __device__ __forceinline__ void unit(int, const f32x16 &, int) {}
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
 #pragma unroll
@@ -222,9 +262,10 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
     stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(1) / SNW>{});
     __syncthreads();
     int cur = 0;
+    f32x16 accs[2];
     const int64_t nblocks = (npts + SNBLK - 1) / SNBLK;
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-        CtxS cx{wbuf, packed, lane, h, wave, &cur};
+        CtxS cx{wbuf, packed, lane, h, wave, &cur, accs};
         const int64_t p0 = blk * SNBLK + wave * 32;
         const int64_t q = p0 + r;
         const bool live = q < npts;
