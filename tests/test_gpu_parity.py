@@ -1790,7 +1790,8 @@ def test_lerf_feature_reusing_render_equals_two_pass_render(api):
             a2 = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
             r.hand_over_geo = True
             assert_exact(host(a2.Outputs.WeightsLE), host(a.Outputs.WeightsLE), "WeightsLE with / without the sigma net's output handed over")
-            assert_close(host(a2.Outputs.RenderedLangEmbedding), host(a.Outputs.RenderedLangEmbedding), rtol=0, atol=2e-5, what="embedding with / without the hand-over")
+            if prec == api.L.NRF_PREC_F16_SPLIT:
+                assert_exact(host(a2.Outputs.RenderedLangEmbedding), host(a.Outputs.RenderedLangEmbedding), "embedding with / without the hand-over")
             r.reuse_features = False
             b = r.Render(800, 800, K, p, c2w=c2w, row0=397, rows=3)
             assert_exact(host(a.Extras["z_fine"]), host(b.Extras["z_fine"]), "fine depth set")
@@ -1798,7 +1799,10 @@ def test_lerf_feature_reusing_render_equals_two_pass_render(api):
                 assert_exact(host(getattr(a.Outputs, f)), host(getattr(b.Outputs, f)), f)
             ea, eb = host(a.Outputs.RenderedLangEmbedding), host(b.Outputs.RenderedLangEmbedding)
             assert np.isfinite(ea).all()
-            assert_close(ea, eb, rtol=0, atol=2e-5, what="rendered embedding (unit vectors; the float atomics of the per-ray sums are unordered in either render)")
+            if prec == api.L.NRF_PREC_F16_SPLIT:      # the split passes own a ray per wave: plain stores, a deterministic sum
+                assert_exact(ea, eb, "rendered embedding (split precision: no atomics)")
+            else:
+                assert_close(ea, eb, rtol=0, atol=2e-5, what="rendered embedding (unit vectors; the float atomics of the per-ray sums are unordered in either render)")
     finally:
         r.reuse_features = True; r.hand_over_geo = True
         r.set_precision(api.L.NRF_PREC_F16_SPLIT)
