@@ -1,6 +1,7 @@
 // common.h -- internal helpers of libnerfpp_hip (gfx950 only).
 #pragma once
 
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 

@@ -414,7 +414,7 @@ static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipS
     const int64_t nblocks = NL == 2 ? ceil_div(p, SNBLK) : ceil_div(p / a.s, (int64_t)SNW);       // kernel B: one ray per wave
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 4-wave workgroup per CU
     const half8 *img = reinterpret_cast<const half8 *>(m->d_packed_split);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
     if (!attr_set) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -390,7 +390,7 @@ static int launch_nerf(const nrf_mlp *m, const NerfInput &in, bool fused, int64_
     const size_t lds = (size_t)3 * MAXF * 1024;          // + the static bias array
     const int64_t nblocks = ceil_div(p, NBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent workgroup per CU
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
     if (!attr_set) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_mfma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

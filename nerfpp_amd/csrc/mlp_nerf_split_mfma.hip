@@ -405,7 +405,7 @@ int mlp_nerf_forward_split(const nrf_mlp *m, const NerfInput &in, bool fused, in
     const size_t lds = (size_t)3 * SMAXF * 1024;          // + the static bias array
     const int64_t nblocks = ceil_div(p, SNBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent workgroup per CU
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
     if (!attr_set) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_split<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

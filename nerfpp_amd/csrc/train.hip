@@ -752,7 +752,7 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<uint4 *>(ws + off_rec)};
     const int64_t entries = nrf_hash_table_elems(h) / 2;
     const bool ngp = h->desc.mode == NRF_HASH_NGP;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
     const size_t lds = (size_t)BIN_WORDS * 8;
     if (!attr_set) { NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     // same groups and the same scale as the packed form: the integer fields are identical, so is the result
