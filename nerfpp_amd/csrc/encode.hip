@@ -391,8 +391,11 @@ int nrf_hash_encode_lm_f16_strided(const nrf_hash *h, const float *d_x, int64_t 
     NRF_CHECK_ARG((reinterpret_cast<uintptr_t>(d_feats) & (size_t)(h->desc.n_features * 2 - 1)) == 0, "nrf_hash_encode_lm_f16: feature buffer must be aligned to one point's %d bytes", h->desc.n_features * 2);
     if (p == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
-    ProfScope prof(NRF_PROF_HASH, st);
     PointSource ps{d_x, nullptr, nullptr, 0, 1};
+    // F = 2: the renderer's own encode kernel (four coarse levels per thread, the dense image where one is baked, the hashed table otherwise): same values
+    if (h->desc.n_features == 2 && h->desc.n_levels >= 8 && hash_fast_supported(h) && (reinterpret_cast<uintptr_t>(d_feats) & 3) == 0)
+        return launch_hash_lm(h, ps, p, reinterpret_cast<__half2 *>(d_feats), pstride, d_keep_mask, HASH_LM_DEFAULT_VARIANT, st);
+    ProfScope prof(NRF_PROF_HASH, st);
     const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)h->desc.n_levels);
     __half *f = reinterpret_cast<__half *>(d_feats);
     switch (h->desc.n_features) {
