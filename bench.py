@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- ray-samples/s of the HIP volume-rendering path on synthetic Blender-Lego-shaped frames.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" renders `N` 800x800 frames (64 + 128 samples per ray, 256 network evaluations per ray).  Every frame is split
-into N contiguous row tiles, rank r renders tile r of every frame, and one RCCL all-gather per step hands every rank all
-N complete frames -- so each GPU traces 640 000 rays (163.84 M ray-samples) per step at any N: weak scaling (the default,
-what the driver's SCALE run times).  `--scaling strong`: a step is ONE frame split over the N ranks and gathered, i.e.
-frame latency at N GPUs.  At N = 1 both are one frame and no collective.  Inputs (rays, tables, weights) are resident in
-HBM before the timed region.
+N > 1 runs one process per GPU.  Either launcher works: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks
+read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; a plain `python bench.py --gpus N` starts the N ranks itself (the parent
+touches no GPU API, starts N fresh child processes, relays rank 0's single JSON line and exits non-zero if any child fails).
+
+A "step" at N = 1 is one 800x800 frame (64 + 128 samples per ray, 256 network evaluations per ray).  At N > 1 the headline is BASELINE config 4,
+strong scaling: a step is still ONE frame, cut into N contiguous row tiles; rank r renders tile r with one library call (nrf_render_rows) and one RCCL
+all-gather hands every rank the complete frame -- `value` is the frame's ray-samples over the step time.  `--scaling weak` renders N frames per step
+(rank r renders tile r of every frame; each GPU traces a whole frame's worth of rays) and rides in `also` at N > 1.  Inputs (pose, tables, weights)
+are resident in HBM before the timed region.
 
 Workloads (BASELINE.json configs):  --workload hash    HashNeRF: CuHashEmbedder L16 T2^19 F2 + CuSHEncoder(4) + NeRFSmall
                                      --workload classic PE(10)/PE(4) + NeRF 8x256
@@ -119,6 +122,56 @@ def cpu_baseline(workload, seconds_target=12.0):
                 sample=f"{n} rays ({rows} rows of the {H}x{W} frame), {NS}+{NI} samples, C oracle with OpenMP, {t:.1f} s")
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what torch.distributed.run would set), relay rank 0's JSON line, return non-zero if any rank failed.  The parent never
+    initialises the GPU and never replaces itself (no exec): it waits for its children."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = ""
+    deadline = time.time() + float(os.environ.get("NRF_BENCH_TIMEOUT", "1500"))
+    try:
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        th.start()
+        rc = [None] * n
+        while any(c is None for c in rc) and time.time() < deadline:
+            for i, pr in enumerate(procs):
+                if rc[i] is None:
+                    rc[i] = pr.poll()
+            if any(c not in (None, 0) for c in rc):
+                break                                    # a rank died: its peers would wait in a collective for ever
+            time.sleep(0.05)
+        th.join(timeout=5.0)
+        out0 = box.get("out", "") or ""
+    finally:
+        for pr in procs:                                 # exact PIDs of the children this process started
+            if pr.poll() is None:
+                pr.kill()
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except Exception:
+                pass
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    codes = [pr.returncode for pr in procs]
+    if any(c != 0 for c in codes) or not lines:
+        print(f"[bench] rank exit codes {codes}" + ("" if lines else "; rank 0 printed no result line"), file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,8 +189,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (self-test of the N > 1 code path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets N ranks SHARE one GPU (a rehearsal of the N > 1 code path on a one-GPU box: RCCL refuses two ranks on a device)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): N frames per step, every GPU traces a whole frame's worth of rays; strong: ONE frame per step split over the N ranks")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default at N > 1, BASELINE config 4): ONE frame per step split over the N ranks; weak: N frames per step, every GPU traces a whole frame's worth of rays")
     ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
                     help="the per-step all-gather: torch.distributed (RCCL through PyTorch) or nrf_allgather_tiles (RCCL behind the C ABI, what a C++ host calls)")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
@@ -145,11 +198,16 @@ def main():
 
     if args.precision is None:
         args.precision = "f16x3"
+    if args.backend == "gloo" and args.collective == "cabi":
+        sys.exit("--collective cabi is RCCL: one rank per GPU (--backend nccl)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))                 # plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("NRF_BENCH_TEST_FAIL_RANK") == str(rank):
+        sys.exit(3)                                      # test hook: a rank that dies at start-up (tests/: the launcher must report it, not hang)
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"   # N = 1: the two coincide (one frame per step), reported as "weak" per the driver's contract
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -179,47 +237,69 @@ def main():
     renderer = sc["renderer"]
     rp = scene.lego_render_params(sc["bbox"], NS, NI, chunk, prec)
     K = scene.lego_K(H, W)
-    # frames of one step: N poses on the reference's test orbit (pose_spherical(theta, -30, 4), theta step 9 degrees); strong scaling: one frame
-    nframes = 1 if args.scaling == "strong" else world
-    poses = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(nframes)]
     shard = TileShard(H, W, rank, world, force_collective=args.force_dist)
-    if args.backend == "gloo" and args.collective == "cabi":
-        sys.exit("--collective cabi is RCCL: one rank per GPU (--backend nccl)")
     comm = TileComm(rank, world) if (use_dist and args.collective == "cabi") else None
-
-    def render_tiles():
-        return [renderer.Render(H, W, K, rp, c2w=c2w, row0=shard.row0, rows=shard.rows).Outputs.RGBMap for c2w in poses]
-
-    def step():
-        tiles = render_tiles()
-        if comm is not None:
-            return comm.all_gather_frames(torch.stack([t.reshape(shard.rows, W, 3) for t in tiles], 0), H)
-        return shard.all_gather_frames(tiles)     # [frames, H, W, 3] on every rank; identity at N = 1
+    import ctypes as C
+    NPROF = len(L.NRF_PROF_NAMES)
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    L.lib().nrf_profile_enable(1)
-    import ctypes as C
-    NPROF = len(L.NRF_PROF_NAMES)
-    ms = (C.c_double * NPROF)(); cnt = (C.c_int64 * NPROF)()
-    L.lib().nrf_profile_read(ms, cnt, 1)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frames = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    L.lib().nrf_profile_read(ms, cnt, 1)
-    L.lib().nrf_profile_enable(0)
-    if use_dist:
-        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run(scaling, steps, warmup, profile=False):
+        """W untimed + K timed steps of `scaling`; returns (seconds = max over ranks, frames of the last step, poses, host seconds this rank spent inside Render
+        calls, per-kernel HIP-event totals)."""
+        # frames of one step: poses on the reference's test orbit (pose_spherical(theta, -30, 4), theta step 9 degrees); strong scaling: one frame
+        nfr = 1 if scaling == "strong" else world
+        poses_ = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(nfr)]
+        host = [0.0]
+
+        def render_tiles():
+            t_h = time.perf_counter()
+            tiles = [renderer.Render(H, W, K, rp, c2w=c2w, row0=shard.row0, rows=shard.rows).Outputs.RGBMap for c2w in poses_]   # one nrf_render_rows call each
+            host[0] += time.perf_counter() - t_h
+            return tiles
+
+        def step():
+            tiles = render_tiles()
+            if comm is not None:
+                return comm.all_gather_frames(torch.stack([t.reshape(shard.rows, W, 3) for t in tiles], 0), H)
+            return shard.all_gather_frames(tiles)     # [frames, H, W, 3] on every rank; identity at N = 1
+
+        for _ in range(warmup):
+            step()
+        ms = (C.c_double * NPROF)(); cnt = (C.c_int64 * NPROF)()
+        if profile:
+            L.lib().nrf_profile_enable(1)
+            L.lib().nrf_profile_read(ms, cnt, 1)
+        host[0] = 0.0
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frames_ = step()
+        sync()
+        dt = time.perf_counter() - t0
+        if profile:
+            L.lib().nrf_profile_read(ms, cnt, 1)
+            L.lib().nrf_profile_enable(0)
+        if use_dist:
+            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, frames_, poses_, host[0], (ms, cnt), render_tiles
+
+    elapsed, frames, poses, host_s, (ms, cnt), render_tiles = timed_run(args.scaling, args.steps, args.warmup, profile=True)
+    nframes = len(poses)
+    # at N > 1 the other scaling mode rides along in `also` (every rank takes part; fewer steps)
+    other = None
+    if world > 1 and not args.no_also:
+        o_scaling = "weak" if args.scaling == "strong" else "strong"
+        o_steps = max(2, args.steps // 2)
+        o_dt, o_frames, o_poses, o_host, _, _ = timed_run(o_scaling, o_steps, 1)
+        other = dict(scaling=o_scaling, frames_per_step=len(o_poses), steps=o_steps, ms_per_step=o_dt / o_steps * 1e3,
+                     value=len(o_poses) * H * W * UNITS_PER_RAY * o_steps / o_dt, unit="ray-samples/s",
+                     host_ms_per_tile=o_host / o_steps / len(o_poses) * 1e3, finite=bool(torch.isfinite(o_frames).all()))
     # untimed cross-check of the other collective implementation on the same tiles (N > 1: the C-ABI all-gather a C++ host calls vs torch.distributed's).
     # It runs on a helper thread with a deadline so that nothing it does can cost the run its result line.
     collective_check = None
@@ -365,8 +445,13 @@ def main():
                                                  note="value counts the reference's 256 network evaluations per ray; the fine pass's 64 coarse depths reuse the coarse pass's "
                                                       "hash features / outputs (identical results), so the kernels process fewer"),
             "rays_per_s": value / UNITS_PER_RAY, "s_per_frame": elapsed / args.steps / nframes * (world if args.scaling == "weak" else 1),
+            # host side of the sharded step on rank 0: wall time spent INSIDE Render (one nrf_render_rows call per tile: ~25 asynchronous launches, no
+            # synchronisation) -- the unsharded work that bounds strong scaling once a tile's kernels get short
+            "host_ms_per_tile": host_s / args.steps / nframes * 1e3, "tile_rows": shard.rows,
             "roofline": roof, "kernel_ms": prof,
         }
+        if other is not None:
+            line["also"] = [other]
         if collective_check is not None:
             line["collective_check"] = collective_check
         if cpu is not None:
@@ -382,6 +467,9 @@ def main():
             except Exception as e:
                 line["parity_full_frame_vs_f32"] = f"unavailable: {e}"
         assert frames.shape[0] == nframes and bool(torch.isfinite(frames).all())
+        # the gathered frame of the first pose, hashed: equal strings at different N (or launchers) = the sharded render is the single-GPU render bit for bit
+        import hashlib
+        line["frame_sha256"] = hashlib.sha256(frames[0].reshape(H, W, 3).contiguous().cpu().numpy().tobytes()).hexdigest()
         if world == 1 and not use_dist and not args.no_also:
             line["also"] = secondary_measurements(args, scene, L, K, poses[0], sc)
     if rank == 0:

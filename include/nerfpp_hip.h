@@ -83,6 +83,30 @@ NRF_API int nrf_aabb(const float *d_o, const float *d_d, const float *bbox, int6
 NRF_API int nrf_pack_rays(const float *d_o, const float *d_d, const float *bbox, int64_t n, int use_viewdirs,
                           float *d_rays, void *stream);
 
+/* ... with the view directions taken from d_view_src [n,3] instead of d_d: Render() normalises rays_d into viewdirs BEFORE the NDC warp replaces
+ * rays_o / rays_d (NeRFRenderer.h:549-568), so an Ndc + UseViewdirs batch packs the warped o, d with the un-warped directions.  d_rays: [n, 11]. */
+NRF_API int nrf_pack_rays_viewsrc(const float *d_o, const float *d_d, const float *d_view_src, const float *bbox, int64_t n, float *d_rays, void *stream);
+
+/* The pose branch of NeRFRenderer::Render (NeRFRenderer.h:541-583) for the row tile [row0, row0 + rows) of an h x w frame, as ONE kernel:
+ * GetRays(h, w, K, c2w) -> view directions d/||d|| (from c2w's rays, before c2w_staticcam replaces the camera, :549-561, and before the NDC warp) ->
+ * NDCRays(h, w, K[0], 1.f) when `ndc` (:563-568) -> IntersectWithAABB -> rays_ = cat[o, d, near, far, (viewdirs)].  Zero-initialise the struct.
+ * `chunk` is BatchifyRays' Chunk (used by nrf_render_rows; results do not depend on it). */
+typedef struct nrf_view {
+    int h, w;                 /* frame size (after any RenderFactor, nrf_render_view_dims) */
+    float K[9];               /* row-major 3x3 */
+    float c2w[12];            /* row-major 3x4 */
+    int has_staticcam;        /* c2w_staticcam given (honoured only with use_viewdirs, as in the reference) */
+    float c2w_staticcam[12];
+    int row0, rows;           /* the tile; ray r of the tile is pixel (row0 + r / w, r % w) */
+    int use_viewdirs;         /* UseViewdirs: ray stride 11, else 8 */
+    int ndc;                  /* Ndc */
+    int chunk;                /* Chunk */
+    float bbox[6];            /* BoundingBox: min xyz, max xyz */
+} nrf_view;
+/* d_rays: [rows*w, 8|11].  d_near_far (optional): DEVICE [2] floats receiving min(near), max(far) of the tile (NeRFRenderer.h:602-603) --
+ * written on `stream`, no host synchronisation (the reference's two .item() calls stall the host once per frame). */
+NRF_API int nrf_view_rays(const nrf_view *v, float *d_rays, float *d_near_far, void *stream);
+
 /* min(near), max(far) over a packed ray batch (NeRFRenderer.h:602-603); results to host, synchronises `stream`. */
 NRF_API int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *near_min, float *far_max, void *stream);
 
@@ -140,7 +164,8 @@ NRF_API int64_t nrf_hash_table_elems(const nrf_hash *h);          /* L * 2^T * F
 NRF_API int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *stream);
 
 /* NRF_HASH_CU only: per-level primes [L*3] (buffer `embedder_primes`, CuHashEmbedder.cpp:51-52) and
- * biases [L*3] (`embedder_biases`, :54-59; NULL = zeros).  Host pointers. */
+ * biases [L*3] (`embedder_biases`, :54-59; NULL = zeros).  Host pointers.  A zero or even multiplier is rejected (NRF_ERR_INVALID_ARG): the reference
+ * only ever produces odd primes in [2^28, 2^30), and zeros -- an uninitialised buffer -- would hash every corner to row 0 without any error. */
 NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases);
 
 /* The renderer's fast path reads a DENSE image of the grid's coarse levels (every lattice vertex's table entries copied next to each other, baked from the
@@ -384,6 +409,22 @@ NRF_API size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n,
 NRF_API int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
                             const float *d_t, const float *d_u, const nrf_render_outputs *out,
                             void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* BatchifyRays (NeRFRenderer.h:465-525): the host loop over Chunk-sized slices of a packed ray batch, inside the library -- every output of `out`
+ * is the whole batch's buffer ([n, ...]), slice i of the loop writes its rows in place (what the reference's torch::cat assembles afterwards), and
+ * p->ray_base advances with the slice so the counter-based draws of the stochastic branches do not depend on Chunk.  Workspace: that of ONE chunk. */
+NRF_API size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p);
+NRF_API int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p,
+                              const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* NeRFRenderer::Render for a pose (NeRFRenderer.h:530-605), restricted to the row tile of `v`: nrf_view_rays + nrf_batchify_rays + the tile's
+ * Near / Far in ONE call -- what a rank of the row-tile sharding issues per frame; ~25 asynchronous launches, no synchronisation, no allocation.
+ * out: buffers for the TILE's rows*w rays.  d_rays_out (optional): receives the packed rays [rows*w, 8|11] (else they live in the workspace).
+ * d_near_far (optional): see nrf_view_rays.  p->ray_base is taken as the index of the FRAME's first ray; the tile adds row0 * w itself.
+ * NRF_ERR_UNSUPPORTED: ndc together with cone rays (p->has_cone: NDCRays turns cone_angle into a per-ray tensor, RayUtils.h:76-81). */
+NRF_API size_t nrf_render_rows_workspace_bytes(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p);
+NRF_API int nrf_render_rows(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p, const float *d_t, const float *d_u,
+                            const nrf_render_outputs *out, float *d_rays_out, float *d_near_far, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training step: NeRFExecutor::Train, NeRFExecutor.h:862-995.

@@ -13,7 +13,8 @@
 //   TileComm                                     multi-GPU row tiles: RCCL all-gather of per-tile pixels behind the C ABI (no reference counterpart)
 //   HipLeRFPass / HipLeRFRenderer : LeRFRenderer  the LeRF render pass (LeRFRenderer.h:56-132); the subclass needs -DNRFPP_WITH_LERF_RENDERER
 //   HipNeRFRenderer<E, D, TNeRF> : NeRFRenderer<E, D, TNeRF>   overrides the virtuals Render / RenderRays / RunNetwork /
-//                                                RawToOutputs (NeRFRenderer.h:96-158); BatchifyRays (the chunk loop) is inherited.
+//                                                RawToOutputs (NeRFRenderer.h:96-158); Render is one library call per pose (nrf_render_rows);
+//                                                BatchifyRays (the host chunk loop) stays inherited for callers that use it directly.
 //                                                TNeRF is the reference's own NeRFSmall / NeRF module: its parameters are
 //                                                read in named_parameters() order (SyncWeights()).
 //
@@ -110,7 +111,12 @@ class HipHashEmbedderImpl : public BaseEmbedderImpl {
 public:
 	torch::Tensor BoundingBox;
 	int NLevels, NFeaturesPerLevel, Log2HashmapSize, BaseResolution, FinestResolution, Mode;
-	torch::Tensor Embeddings, Primes, Biases;
+	int NVolumes{1};
+	/// NRF_HASH_CU (CuHashEmbedderImpl's state, CuHashEmbedder.h:14-27): the `<name>_embeddings` parameter [L * 2^T, F] and the four registered buffers.
+	torch::Tensor Embeddings, Primes, Biases, FeatLocalSize, FeatLocalIdx;
+	/// NRF_HASH_NGP (HashEmbedderImpl's state, NeRF.h:153): one nn::Embedding(2^T, F) per level, registered as `<name>_embeddings_<i>` (NeRF.cpp:255-259), so
+	/// named_parameters() lists `<name>_embeddings_<i>.weight` and the reference's embedder_checkpoint.pt loads with torch::load.
+	torch::nn::ModuleList LevelEmbeddings;
 
 	/// mode NRF_HASH_CU: CuHashEmbedder semantics (fp16 table, per-level primes);  NRF_HASH_NGP: HashEmbedder semantics.
 	HipHashEmbedderImpl(const std::string &module_name, torch::Tensor bounding_box, const int n_levels = 16, const int n_features_per_level = 2,
@@ -123,25 +129,67 @@ public:
 		TORCH_CHECK(bb.size() == 6, "bounding_box must hold [min xyz, max xyz]");
 		for (int i = 0; i < 6; i++) d.bbox[i] = bb[i];
 		check(nrf_hash_create(&d, &Handle), "nrf_hash_create");
-		const int64_t rows = ((int64_t)1 << log2_hashmap_size) * n_levels;
-		// same parameter / buffer names and init as the reference (CuHashEmbedder.cpp:24: U(0,1)*1e-4; NeRF.cpp:270: U(-1e-4,1e-4))
-		auto init = (mode == NRF_HASH_CU) ? torch::rand({rows, n_features_per_level}) * 1e-4f : (torch::rand({rows, n_features_per_level}) * 2.f - 1.f) * 1e-4f;
-		Embeddings = register_parameter(module_name + "_embeddings", init.to(torch::kCUDA), /*requires_grad=*/true);
-		Primes = register_buffer(module_name + "_primes", torch::zeros({n_levels, 1, 3}, torch::kInt32));
-		Biases = register_buffer(module_name + "_biases", torch::zeros({n_levels, 3}, torch::kFloat32));
+		const int64_t t_rows = (int64_t)1 << log2_hashmap_size;
+		const auto cuda = torch::TensorOptions().device(torch::kCUDA);
+		if (mode == NRF_HASH_CU) {
+			// ---- exactly the constructor state of CuHashEmbedderImpl (CuHashEmbedder.cpp:24-76): same draws from the same generators, same names, shapes, dtypes ----
+			Embeddings = register_parameter(module_name + "_embeddings", torch::rand({t_rows * NLevels, NFeaturesPerLevel}, cuda.dtype(torch::kFloat32)) * 1e-4f, /*requires_grad=*/true);   // :24
+			auto is_prim = [](int x) { for (int i = 2; i * i <= x; i++) if (x % i == 0) return false; return true; };                                                                     // :28-35
+			std::vector<int> prim_selected;
+			const int min_local_prim = 1 << 28, max_local_prim = 1 << 30;
+			for (int i = 0; i < 3 * NLevels * NVolumes; i++) {                                                                                                                            // :41-49
+				int val;
+				do { val = torch::randint(min_local_prim, max_local_prim, {1}, torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU)).item<int>(); } while (!is_prim(val));
+				prim_selected.push_back(val);
+			}
+			Primes = torch::from_blob(prim_selected.data(), 3 * NLevels * NVolumes, torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU)).to(torch::kCUDA);
+			Primes = Primes.reshape({NLevels, NVolumes, 3}).contiguous();                                                                                                                // :52-53
+			Biases = torch::zeros({NLevels * NVolumes, 3}, cuda.dtype(torch::kFloat)).contiguous();                                                                                      // :59 (RandBias is false)
+			int local_size = 1ll << static_cast<long long>(Log2HashmapSize);                                                                                                             // :63-68
+			local_size = (local_size >> 4) << 4;
+			FeatLocalSize = torch::full({NLevels}, local_size, cuda.dtype(torch::kInt32)).contiguous();
+			FeatLocalIdx = (torch::cumsum(FeatLocalSize, 0) - local_size).to(torch::kInt32).contiguous();
+			Primes = register_buffer(module_name + "_primes", Primes);                                                                                                                   // :73-76
+			Biases = register_buffer(module_name + "_biases", Biases);
+			FeatLocalSize = register_buffer(module_name + "_feat_local_size", FeatLocalSize);
+			FeatLocalIdx = register_buffer(module_name + "_feat_local_idx", FeatLocalIdx);
+		} else {
+			// ---- HashEmbedderImpl (NeRF.cpp:255-271): L x nn::Embedding(2^T, F), registered per level, U(-1e-4, 1e-4) ----
+			for (int i = 0; i < NLevels; i++) LevelEmbeddings->push_back(torch::nn::Embedding(t_rows, NFeaturesPerLevel));
+			for (size_t i = 0; i < LevelEmbeddings->size(); i++) register_module(module_name + "_embeddings_" + std::to_string(i), LevelEmbeddings[i]);
+			InitLevels();
+			this->to(torch::kCUDA);
+		}
 	}
 	~HipHashEmbedderImpl() override { nrf_hash_destroy(Handle); }
 
 	const nrf_hash *GetHandle() const { return Handle; }
 	torch::Tensor GetBoundingBox() const { return BoundingBox; }
 	int GetOutputDims() override { return NLevels * NFeaturesPerLevel; }
+	int GetNLevels() const { return NLevels; }
+	int GetNFeaturesPerLevel() const { return NFeaturesPerLevel; }
+	int GetLog2HashmapSize() const { return Log2HashmapSize; }
+	int GetBaseResolution() const { return BaseResolution; }
+	int GetFinestResolution() const { return FinestResolution; }
 
-	/// The reference calls Initialize() after construction / checkpoint load (NeRFExecutor.h:570): push table + primes to the library.
-	void Initialize() { Sync(); }
-	void SetPrimes(torch::Tensor primes) { Primes.copy_(primes.view_as(Primes)); }
+	/// HashEmbedderImpl::Initialize (NeRF.cpp:264-271): custom uniform initialisation of every level
+	void InitLevels() { for (size_t i = 0; i < LevelEmbeddings->size(); i++) for (auto p : LevelEmbeddings[i]->parameters()) torch::nn::init::uniform_(p, -0.0001, 0.0001); }
+
+	/// The executor calls Initialize() on a freshly built embedder (NeRFExecutor.h:570; HashEmbedder re-draws its tables there, CuHashEmbedder's is empty) -- and the
+	/// library needs the current table / primes pushed to it: both happen here.  After torch::load or an optimizer step call Sync().
+	void Initialize() { if (Mode == NRF_HASH_NGP) InitLevels(); Sync(); }
+	void SetPrimes(torch::Tensor primes) { torch::NoGradGuard g; Primes.copy_(primes.view_as(Primes)); }
+	/// the table in the layout nrf_hash_set_table takes: CU [L * 2^T, F]; NGP the levels' weights concatenated
+	torch::Tensor Table()
+	{
+		if (Mode == NRF_HASH_CU) return Embeddings.detach();
+		std::vector<torch::Tensor> lv;
+		for (size_t i = 0; i < LevelEmbeddings->size(); i++) lv.push_back(LevelEmbeddings[i]->as<torch::nn::Embedding>()->weight.detach());
+		return torch::cat(lv, 0);
+	}
 	void Sync()
 	{
-		auto emb = dev_f32(Embeddings.detach());
+		auto emb = dev_f32(Table());
 		check(nrf_hash_set_table(Handle, emb.data_ptr<float>(), 1, current_stream()), "nrf_hash_set_table");
 		if (Mode == NRF_HASH_CU) {
 			auto p = Primes.to(torch::kCPU, torch::kInt32).contiguous();
@@ -559,25 +607,29 @@ protected:
 	}
 
 public:
-	/// NeRFRenderer.h:530-605.  Ray generation, view-direction normalisation, AABB clipping and the ray-batch assembly run in
-	/// the library (bit-identical to the LibTorch CPU path); the chunk loop is the reference's own BatchifyRays.  NDC scenes and
-	/// c2w_staticcam take the inherited torch-op path.
+	/// NeRFRenderer.h:530-605.  A pose render is ONE library call (nrf_render_rows: ray generation, view directions taken before any c2w_staticcam / NDC
+	/// substitution, NDCRays, AABB clipping, ray-batch assembly, the Chunk loop and Near / Far -- bit-identical to the LibTorch CPU path stage by stage);
+	/// an explicit ray batch is packed and handed to nrf_batchify_rays.  `sh` is taken by value: the reference keeps an ArrayRef into a tensor that its
+	/// NDC branch then releases (:562 vs :567), so its own Ndc renders read freed memory at :591-600.
+	/// LibraryChunkLoop = false keeps the reference's own BatchifyRays (a host loop of virtual RenderRays calls + torch::cat) in the loop instead.
+	bool LibraryChunkLoop = true;
 	NeRFRenderResult Render(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params,
 		std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays = {torch::Tensor(), torch::Tensor(), torch::Tensor()},
 		torch::Tensor c2w = torch::Tensor(), torch::Tensor c2w_staticcam = torch::Tensor()) override
 	{
-		if (render_params.Ndc || (c2w_staticcam.defined() && c2w_staticcam.numel() != 0)) return Base::Render(h, w, k, render_params, rays, c2w, c2w_staticcam);
-		return RenderRows(h, w, k, render_params, rays, c2w, 0, h);
+		return RenderRows(h, w, k, render_params, rays, c2w, c2w_staticcam, 0, h);
 	}
 
 	/// Rows [row0, row0 + rows) of the h x w frame seen from c2w: one rank's share of a frame (multi-GPU row tiles).  Ray r of the tile is pixel
 	/// (row0 + r / w, r % w); the counter-based draws of the stochastic branches are keyed by the ray's position in the WHOLE frame, so a tile equals
 	/// the corresponding slice of the full render bit for bit.  Outputs are [rows, w, ...]; Near / Far are the tile's.
-	NeRFRenderResult RenderTile(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params, torch::Tensor c2w, const int row0, const int rows)
+	/// near_far_dev (optional): receives the tile's [min near, max far] as a DEVICE tensor and Near / Far of the result stay 0 -- the call then never waits for the GPU
+	/// (a rank of a sharded render issues its ~25 launches and goes straight to the collective).
+	NeRFRenderResult RenderTile(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params, torch::Tensor c2w, const int row0, const int rows,
+		torch::Tensor *near_far_dev = nullptr)
 	{
-		TORCH_CHECK(!render_params.Ndc, "RenderTile: NDC scenes are rendered whole (Render)");
 		TORCH_CHECK(row0 >= 0 && rows >= 0 && row0 + rows <= h, "RenderTile: rows outside the frame");
-		return RenderRows(h, w, k, render_params, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w, row0, rows);
+		return RenderRows(h, w, k, render_params, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w, torch::Tensor(), row0, rows, near_far_dev);
 	}
 
 	/// One frame over all ranks of `comm`: this rank renders its row tile, ONE all-gather (rgb, disparity, accumulation, depth packed per pixel) returns the
@@ -587,7 +639,8 @@ public:
 		const auto [row0, rows] = comm.Rows(h);
 		NeRFRenderParams rp = render_params;
 		rp.ReturnRaw = false; rp.ReturnWeights = false;                 // per-sample tensors stay on the rank that made them
-		NeRFRenderResult tile = RenderTile(h, w, k, rp, c2w, row0, rows);
+		torch::Tensor tile_nf;
+		NeRFRenderResult tile = RenderTile(h, w, k, rp, c2w, row0, rows, &tile_nf);
 		auto &o = tile.Outputs;
 		auto packed = torch::cat({o.RGBMap.reshape({rows, w, 3}), o.DispMap.reshape({rows, w, 1}), o.AccMap.reshape({rows, w, 1}), o.DepthMap.reshape({rows, w, 1})}, -1).unsqueeze(0);
 		auto frame = comm.AllGatherFrames(packed, h).squeeze(0);        // [h, w, 6]
@@ -597,52 +650,140 @@ public:
 		res.Outputs.DispMap = frame.index({Slice(), Slice(), 3}).contiguous();
 		res.Outputs.AccMap = frame.index({Slice(), Slice(), 4}).contiguous().reshape({-1});
 		res.Outputs.DepthMap = frame.index({Slice(), Slice(), 5}).contiguous();
-		// Near / Far of the whole frame (NeRFRenderer.h:602-603)
+		// Near / Far of the whole frame (NeRFRenderer.h:602-603): min / max over the ranks' tile values would need a second collective; generating the frame's
+		// rays once more on every rank is cheaper than its latency (one kernel over h*w pixels)
 		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
-		auto K = host_floats(k), M = host_floats(c2w.index({Slice(torch::indexing::None, 3), Slice(torch::indexing::None, 4)}));
-		auto ro = torch::empty({(int64_t)h * w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), rd = torch::empty_like(ro);
-		check(nrf_get_rays(h, w, K.data(), M.data(), 0, h, ro.data_ptr<float>(), rd.data_ptr<float>(), nullptr, current_stream()), "nrf_get_rays");
-		auto bb = host_floats(render_params.BoundingBox);
-		auto rays_ = torch::empty({(int64_t)h * w, 8}, ro.options());
-		check(nrf_pack_rays(ro.data_ptr<float>(), rd.data_ptr<float>(), bb.data(), (int64_t)h * w, 0, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
-		check(nrf_near_far_range(rays_.data_ptr<float>(), (int64_t)h * w, 8, &res.Near, &res.Far, current_stream()), "nrf_near_far_range");
+		nrf_view v = make_view(h, w, k, render_params, c2w, torch::Tensor(), 0, h);
+		auto rays_ = torch::empty({(int64_t)h * w, v.use_viewdirs ? 11 : 8}, torch::TensorOptions().dtype(torch::kFloat32).device(dev));
+		auto nf = torch::empty({2}, rays_.options());
+		check(nrf_view_rays(&v, rays_.data_ptr<float>(), nf.data_ptr<float>(), current_stream()), "nrf_view_rays");
+		auto nfh = nf.cpu();
+		res.Near = nfh[0].item<float>(); res.Far = nfh[1].item<float>();
 		return res;
 	}
 
 private:
+	static nrf_view make_view(const int h, const int w, torch::Tensor k, const NeRFRenderParams &rp, torch::Tensor c2w, torch::Tensor c2w_staticcam, const int row0, const int rows)
+	{
+		using torch::indexing::Slice;
+		nrf_view v{};
+		v.h = h; v.w = w; v.row0 = row0; v.rows = rows;
+		auto K = host_floats(k), M = host_floats(c2w.index({Slice(torch::indexing::None, 3), Slice(torch::indexing::None, 4)}));
+		TORCH_CHECK(K.size() == 9 && M.size() == 12, "Render: k must be 3x3 and c2w at least 3x4");
+		for (int i = 0; i < 9; i++) v.K[i] = K[i];
+		for (int i = 0; i < 12; i++) v.c2w[i] = M[i];
+		if (c2w_staticcam.defined() && c2w_staticcam.numel() != 0) {
+			auto S = host_floats(c2w_staticcam.index({Slice(torch::indexing::None, 3), Slice(torch::indexing::None, 4)}));
+			v.has_staticcam = 1;
+			for (int i = 0; i < 12; i++) v.c2w_staticcam[i] = S[i];
+		}
+		v.use_viewdirs = rp.UseViewdirs; v.ndc = rp.Ndc; v.chunk = rp.Chunk;
+		auto bb = host_floats(rp.BoundingBox);
+		TORCH_CHECK(bb.size() == 6, "Render: BoundingBox must hold [min xyz, max xyz]");
+		for (int i = 0; i < 6; i++) v.bbox[i] = bb[i];
+		return v;
+	}
+
+	nrf_render_params make_params(const NeRFRenderParams &rp, torch::Tensor cone_angle, int64_t ray_base) const
+	{
+		nrf_render_params p{rp.NSamples, rp.NImportance, rp.LinDisp, rp.WhiteBkgr, Precision, 8};
+		p.perturb = rp.Perturb; p.raw_noise_std = rp.RawNoiseStd; p.precond_alpha = rp.StochasticPreconditioningAlpha;
+		if (!rp.ThinRay && cone_angle.defined() && cone_angle.numel()) { p.has_cone = 1; p.cone_angle = cone_angle.cpu().template item<float>(); }
+		if (rp.BoundingBox.defined() && rp.BoundingBox.numel() == 6) { auto bb = host_floats(rp.BoundingBox); p.has_bbox = 1; for (int a = 0; a < 6; a++) p.bbox[a] = bb[a]; }
+		p.seed = Seed; p.ray_base = ray_base;
+		return p;
+	}
+
+	/// torch::linspace(0, 1, steps) on the device (NeRFRenderer.h:393, Sampler.h:21), cached: a tile render must not pay two uploads per call
+	torch::Tensor linspace01(int steps, torch::Device dev)
+	{
+		for (auto &e : LinCache) if (e.first == steps && e.second.device() == dev) return e.second;
+		LinCache.emplace_back(steps, torch::linspace(0.f, 1.f, steps, torch::kFloat).to(dev));
+		return LinCache.back().second;
+	}
+	std::vector<std::pair<int, torch::Tensor>> LinCache;
+
 	NeRFRenderResult RenderRows(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params,
-		std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays, torch::Tensor c2w, const int row0, const int rows)
+		std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays, torch::Tensor c2w, torch::Tensor c2w_staticcam, const int row0, const int rows,
+		torch::Tensor *near_far_dev = nullptr)
 	{
 		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
-		torch::Tensor rays_o, rays_d, cone_angle;
+		const auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
 		const bool from_pose = c2w.defined() && c2w.numel() != 0;
+		const int stride = render_params.UseViewdirs ? 11 : 8;
+		const int s = render_params.NSamples, ni = render_params.NImportance, so = ni > 0 ? s + ni : s;
+		torch::Tensor rays_, cone_angle, nf;
+		std::vector<int64_t> sh;
+		int64_t n = 0;
+		nrf_view v{};
 		if (from_pose) {
-			auto K = host_floats(k), M = host_floats(c2w.index({torch::indexing::Slice(torch::indexing::None, 3), torch::indexing::Slice(torch::indexing::None, 4)}));
-			rays_o = torch::empty({rows, w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)); rays_d = torch::empty_like(rays_o);
-			float cone = 0.f;
-			check(nrf_get_rays(h, w, K.data(), M.data(), row0, rows, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), &cone, current_stream()), "nrf_get_rays");
-			cone_angle = torch::tensor(cone);
+			v = make_view(h, w, k, render_params, c2w, c2w_staticcam, row0, rows);
+			n = (int64_t)rows * w;
+			sh = {rows, w, 3};
+			rays_ = torch::empty({n, stride}, opt);
+			nf = torch::empty({2}, opt);
+			const float px = 1.0f / v.K[0], py = 1.0f / v.K[4];                     // GetRays' cone_angle (RayUtils.h:35-43)
+			cone_angle = torch::tensor(((px + py) / 2.0f) * 1.1f);
 		} else {
+			TORCH_CHECK(!(c2w_staticcam.defined() && c2w_staticcam.numel() != 0), "Render: c2w_staticcam replaces the camera of a POSE render (NeRFRenderer.h:554-558)");
+			torch::Tensor rays_o, rays_d;
 			std::tie(rays_o, rays_d, cone_angle) = rays;
 			rays_o = dev_f32(rays_o); rays_d = dev_f32(rays_d);
+			sh = rays_d.sizes().vec();
+			auto vsrc = rays_d.reshape({-1, 3}).contiguous();                        // view directions: the un-warped rays_d (:549-561)
+			if (render_params.Ndc) {
+				TORCH_CHECK(render_params.ThinRay || !(cone_angle.defined() && cone_angle.numel()), "Render: Ndc with cone rays makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built");
+				auto oo = torch::empty_like(rays_o), od = torch::empty_like(rays_d);
+				check(nrf_ndc_rays(h, w, host_floats(k)[0], 1.f, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), rays_o.numel() / 3, oo.data_ptr<float>(), od.data_ptr<float>(),
+					current_stream()), "nrf_ndc_rays");
+				rays_o = oo; rays_d = od;
+			}
+			auto o = rays_o.reshape({-1, 3}).contiguous(), d = rays_d.reshape({-1, 3}).contiguous();
+			n = o.size(0);
+			auto bb = host_floats(render_params.BoundingBox);
+			rays_ = torch::empty({n, stride}, opt);
+			if (render_params.Ndc && render_params.UseViewdirs)
+				check(nrf_pack_rays_viewsrc(o.data_ptr<float>(), d.data_ptr<float>(), vsrc.data_ptr<float>(), bb.data(), n, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays_viewsrc");
+			else check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, render_params.UseViewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
 		}
-		auto sh = rays_d.sizes().vec();
-		auto o = rays_o.reshape({-1, 3}).contiguous(), d = rays_d.reshape({-1, 3}).contiguous();
-		const int64_t n = o.size(0);
-		const int stride = render_params.UseViewdirs ? 11 : 8;
-		auto bb = host_floats(render_params.BoundingBox);
-		auto rays_ = torch::empty({n, stride}, o.options());
-		check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, render_params.UseViewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
-		RayCursor = from_pose ? (int64_t)row0 * w : 0;
-		NeRFRenderResult all_ret = this->BatchifyRays(rays_, render_params.ThinRay ? torch::Tensor() : cone_angle, render_params.NSamples, render_params.Chunk,
-			render_params.ReturnRaw, render_params.LinDisp, render_params.Perturb, render_params.NImportance, render_params.WhiteBkgr, render_params.RawNoiseStd,
-			render_params.StochasticPreconditioningAlpha, render_params.BoundingBox, render_params.ReturnWeights);
+		NeRFRenderResult all_ret;
+		if (LibraryChunkLoop) {
+			auto &o = all_ret.Outputs;
+			o.RGBMap = torch::empty({n, 3}, opt); o.DispMap = torch::empty({n}, opt); o.AccMap = torch::empty({n}, opt); o.DepthMap = torch::empty({n}, opt);
+			if (render_params.ReturnWeights) o.Weights = torch::empty({n, (int64_t)so}, opt);
+			if (render_params.ReturnRaw) all_ret.Raw = torch::empty({n, (int64_t)so, 4}, opt);
+			nrf_render_outputs ro{};
+			ro.d_rgb = o.RGBMap.data_ptr<float>(); ro.d_disp = o.DispMap.data_ptr<float>(); ro.d_acc = o.AccMap.data_ptr<float>(); ro.d_depth = o.DepthMap.data_ptr<float>();
+			ro.d_weights = render_params.ReturnWeights ? o.Weights.data_ptr<float>() : nullptr;
+			ro.d_raw = render_params.ReturnRaw ? all_ret.Raw.data_ptr<float>() : nullptr;
+			nrf_render_params p = make_params(render_params, cone_angle, 0);
+			torch::Tensor t = linspace01(s, dev);
+			torch::Tensor u; if (ni > 0) u = linspace01(ni, dev);
+			if (from_pose) {
+				const size_t wsb = nrf_render_rows_workspace_bytes(Renderer, &v, &p);
+				check(nrf_render_rows(Renderer, &v, &p, t.data_ptr<float>(), u.defined() ? u.data_ptr<float>() : nullptr, &ro, rays_.data_ptr<float>(), nf.data_ptr<float>(),
+					workspace(wsb, dev), wsb, current_stream()), "nrf_render_rows");
+			} else if (n > 0) {
+				const size_t wsb = nrf_batchify_rays_workspace_bytes(Renderer, n, render_params.Chunk, &p);
+				check(nrf_batchify_rays(Renderer, rays_.data_ptr<float>(), stride, n, render_params.Chunk, &p, t.data_ptr<float>(), u.defined() ? u.data_ptr<float>() : nullptr, &ro,
+					workspace(wsb, dev), wsb, current_stream()), "nrf_batchify_rays");
+			}
+		} else {
+			if (from_pose) check(nrf_view_rays(&v, rays_.data_ptr<float>(), nf.data_ptr<float>(), current_stream()), "nrf_view_rays");
+			RayCursor = from_pose ? (int64_t)row0 * w : 0;
+			all_ret = this->BatchifyRays(rays_, render_params.ThinRay ? torch::Tensor() : cone_angle, render_params.NSamples, render_params.Chunk,
+				render_params.ReturnRaw, render_params.LinDisp, render_params.Perturb, render_params.NImportance, render_params.WhiteBkgr, render_params.RawNoiseStd,
+				render_params.StochasticPreconditioningAlpha, render_params.BoundingBox, render_params.ReturnWeights);
+		}
 		if (all_ret.Outputs.RGBMap.defined() && all_ret.Outputs.RGBMap.numel() != 0) all_ret.Outputs.RGBMap = torch::reshape(all_ret.Outputs.RGBMap, sh);
 		if (sh.size() > 2) {
 			if (all_ret.Outputs.DispMap.defined() && all_ret.Outputs.DispMap.numel() != 0) all_ret.Outputs.DispMap = torch::reshape(all_ret.Outputs.DispMap, {sh[0], sh[1]});
 			if (all_ret.Outputs.DepthMap.defined() && all_ret.Outputs.DepthMap.numel() != 0) all_ret.Outputs.DepthMap = torch::reshape(all_ret.Outputs.DepthMap, {sh[0], sh[1]});
 		}
-		check(nrf_near_far_range(rays_.data_ptr<float>(), n, stride, &all_ret.Near, &all_ret.Far, current_stream()), "nrf_near_far_range");
+		// NeRFRenderResult::Near / Far are host floats (the reference's two .item() calls, :602-603): one small read-back of the device-side reduction
+		if (from_pose && near_far_dev) *near_far_dev = nf;               // the caller reads (or ignores) it later: no synchronisation here
+		else if (from_pose) { auto nfh = nf.cpu(); all_ret.Near = nfh[0].item<float>(); all_ret.Far = nfh[1].item<float>(); }
+		else if (n > 0) check(nrf_near_far_range(rays_.data_ptr<float>(), n, stride, &all_ret.Near, &all_ret.Far, current_stream()), "nrf_near_far_range");
 		return all_ret;
 	}
 

@@ -51,10 +51,15 @@ class RenderOutputs(C.Structure):
                                           "d_z_coarse", "d_raw_coarse", "d_weights_coarse", "d_z_fine")]
 
 
+class View(C.Structure):          # nrf_view
+    _fields_ = [("h", C.c_int), ("w", C.c_int), ("K", C.c_float * 9), ("c2w", C.c_float * 12), ("has_staticcam", C.c_int), ("c2w_staticcam", C.c_float * 12),
+                ("row0", C.c_int), ("rows", C.c_int), ("use_viewdirs", C.c_int), ("ndc", C.c_int), ("chunk", C.c_int), ("bbox", C.c_float * 6)]
+
+
 # every symbol include/nerfpp_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "nrf_version", "nrf_last_error", "nrf_status_string",
-    "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_near_far_range", "nrf_linspace", "nrf_z_vals", "nrf_points",
+    "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_pack_rays_viewsrc", "nrf_view_rays", "nrf_near_far_range", "nrf_linspace", "nrf_z_vals", "nrf_points",
     "nrf_precrop_bounds", "nrf_rand_pixels", "nrf_ray_batch", "nrf_gather_pixels",
     "nrf_pe_encode", "nrf_sh_encode",
     "nrf_hash_create", "nrf_hash_destroy", "nrf_hash_output_dims", "nrf_hash_table_elems", "nrf_hash_set_table", "nrf_hash_set_primes", "nrf_hash_set_dense_budget", "nrf_hash_get_level_scales", "nrf_hash_set_level_scales",
@@ -66,7 +71,7 @@ SYMBOLS = [
     "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths", "nrf_fine_depths_merge",
     "nrf_rng_fill", "nrf_jitter_z", "nrf_tangent_scatter", "nrf_precondition", "nrf_raw2outputs_noise", "nrf_sample_pdf_rand", "nrf_fine_depths_rand",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
-    "nrf_render_rays_workspace_bytes", "nrf_render_rays",
+    "nrf_render_rays_workspace_bytes", "nrf_render_rays", "nrf_batchify_rays_workspace_bytes", "nrf_batchify_rays", "nrf_render_rows_workspace_bytes", "nrf_render_rows",
     "nrf_normalize_depth", "nrf_to_u8",
     "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_hash_encode_lm_f16_strided", "nrf_lerf_sigma_lm", "nrf_lerf_sigma_lm_strided", "nrf_lerf_render_embedding_lm", "nrf_lerf_render_embedding_lm_gather", "nrf_lerf_geo_bytes", "nrf_lerf_sigma_geo_lm_strided", "nrf_lerf_render_embedding_lm_geo", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_hash_backward_binned_workspace_bytes", "nrf_hash_backward_rays_binned", "nrf_mlp_set_params",
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
@@ -98,6 +103,8 @@ def lib():
         L.nrf_mlp_lerf_param_count.restype = C.c_int64
         L.nrf_run_network_workspace_bytes.restype = C.c_size_t
         L.nrf_render_rays_workspace_bytes.restype = C.c_size_t
+        L.nrf_batchify_rays_workspace_bytes.restype = C.c_size_t
+        L.nrf_render_rows_workspace_bytes.restype = C.c_size_t
         L.nrf_mlp_backward_workspace_bytes.restype = C.c_size_t
         L.nrf_mlp_backward_f16_workspace_bytes.restype = C.c_size_t
         L.nrf_hash_backward_binned_workspace_bytes.restype = C.c_size_t

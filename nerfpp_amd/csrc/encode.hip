@@ -338,6 +338,11 @@ int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
 {
     NRF_CHECK_ARG(h && primes, "nrf_hash_set_primes: null pointer");
     NRF_CHECK_ARG(h->desc.mode == NRF_HASH_CU, "nrf_hash_set_primes: only the CuHashEmbedder mode has per-level primes");
+    // The reference draws every multiplier as a prime in [2^28, 2^30) (CuHashEmbedder.cpp:28-49).  A zero removes its axis from the hash (all-zero: every
+    // corner of every voxel lands on row 0 of its level -- what an uninitialised `_primes` buffer would silently do); an even one loses the axis' low bit.
+    for (int i = 0; i < h->desc.n_levels * 3; i++)
+        NRF_CHECK_ARG(primes[i] != 0 && (primes[i] & 1), "nrf_hash_set_primes: multiplier %d of level %d is %d: zero / even multipliers degenerate the hash "
+                      "(the reference draws primes in [2^28, 2^30), CuHashEmbedder.cpp:28-49) -- was the `_primes` buffer initialised or loaded?", i % 3, i / 3, primes[i]);
     for (int i = 0; i < h->desc.n_levels * 3; i++) {
         h->params.primes[i] = (uint32_t)primes[i];
         h->params.bias[i] = biases ? biases[i] : 0.0f;

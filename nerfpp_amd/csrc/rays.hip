@@ -99,6 +99,103 @@ __global__ void k_pack_rays(int64_t n, Bbox bb, int use_viewdirs, const float *_
     }
 }
 
+// The ray-batch assembly of NeRFRenderer::Render for a pose (NeRFRenderer.h:541-583) in one pass over the pixels of a row tile: GetRays (k_get_rays'
+// arithmetic), the view directions d/||d|| taken from c2w's rays BEFORE any c2w_staticcam substitution (:549-561) and BEFORE the NDC warp (:563-568), NDCRays
+// (k_ndc_rays' arithmetic), the AABB near/far (aabb_one) and the packed row (k_pack_rays' order).  Also reduces min(near) / max(far) of the tile (:602-603) into
+// two order-encoded ints (nf_enc, may be null) so that the caller needs no second pass and no host synchronisation.
+struct ViewCam {
+    float fx, cx, fy, cy;
+    float r[9];      // c2w[:3,:3] row-major
+    float t[3];      // c2w[:3,3]
+};
+struct NdcConst { float sx, sy, near_, two_near, m_two_near; };
+
+__device__ __forceinline__ int order_enc(float f) { const int v = __float_as_int(f); return v >= 0 ? v : (v ^ 0x7fffffff); }
+
+__global__ void k_view_rays(int w, int row0, int64_t n, ViewCam cam, ViewCam cam_o, int use_static, int use_viewdirs, int ndc, NdcConst nc, Bbox bb,
+                            float *__restrict__ rays, int *__restrict__ nf_enc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float nr = INFINITY, fr = -INFINITY;
+    if (i < n) {
+        const int y = row0 + (int)(i / w);
+        const int x = (int)(i % w);
+        const float dx = ((float)x - cam.cx) / cam.fx;
+        const float dy = -((float)y - cam.cy) / cam.fy;
+        const float dz = -1.0f;
+        float dd[3], oo[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float v = dx * cam.r[a * 3]; v = v + dy * cam.r[a * 3 + 1]; v = v + dz * cam.r[a * 3 + 2];
+            dd[a] = v; oo[a] = cam.t[a];
+        }
+        const int stride = use_viewdirs ? 11 : 8;
+        float *r = rays + i * stride;
+        if (use_viewdirs) {
+            float s = dd[0] * dd[0]; s = s + dd[1] * dd[1]; s = s + dd[2] * dd[2];
+            const float nrm = sqrtf(s);
+            r[8] = dd[0] / nrm; r[9] = dd[1] / nrm; r[10] = dd[2] / nrm;
+            if (use_static) {                       // :554-558: the camera of the rays is c2w_staticcam, the view directions stay c2w's
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    float v = dx * cam_o.r[a * 3]; v = v + dy * cam_o.r[a * 3 + 1]; v = v + dz * cam_o.r[a * 3 + 2];
+                    dd[a] = v; oo[a] = cam_o.t[a];
+                }
+            }
+        }
+        if (ndc) {
+            float ox = oo[0], oy = oo[1], oz = oo[2];
+            const float t = -(nc.near_ + oz) / dd[2];
+            ox = ox + t * dd[0]; oy = oy + t * dd[1]; oz = oz + t * dd[2];
+            const float q0 = nc.sx * (dd[0] / dd[2] - ox / oz);
+            const float q1 = nc.sy * (dd[1] / dd[2] - oy / oz);
+            const float q2 = nc.m_two_near / oz;
+            oo[0] = nc.sx * ox / oz; oo[1] = nc.sy * oy / oz; oo[2] = 1.0f + nc.two_near / oz;
+            dd[0] = q0; dd[1] = q1; dd[2] = q2;
+        }
+        aabb_one(oo, dd, bb, 0.0f, nr, fr);
+        r[0] = oo[0]; r[1] = oo[1]; r[2] = oo[2];
+        r[3] = dd[0]; r[4] = dd[1]; r[5] = dd[2];
+        r[6] = nr; r[7] = fr;
+    }
+    if (nf_enc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nr = fminf(nr, __shfl_xor(nr, off));
+            fr = fmaxf(fr, __shfl_xor(fr, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(nf_enc, order_enc(nr));
+            atomicMax(nf_enc + 1, order_enc(fr));
+        }
+    }
+}
+
+__global__ void k_nf_init(int *nf_enc) { nf_enc[0] = 0x7f800000; nf_enc[1] = (int)(0xff800000u ^ 0x7fffffffu); }
+__global__ void k_nf_decode(const int *nf_enc, float *out)
+{
+    for (int k = 0; k < 2; k++) { const int v = nf_enc[k]; out[k] = __int_as_float(v >= 0 ? v : (v ^ 0x7fffffff)); }
+}
+
+// NeRFRenderer.h:549-583 for an explicit ray batch whose view directions come from other directions than the packed ones (Ndc: the pre-warp rays_d)
+__global__ void k_pack_rays_vd(int64_t n, Bbox bb, const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ vsrc, float *__restrict__ rays)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float oo[3] = {o[i * 3], o[i * 3 + 1], o[i * 3 + 2]};
+    float dd[3] = {d[i * 3], d[i * 3 + 1], d[i * 3 + 2]};
+    const float v0 = vsrc[i * 3], v1 = vsrc[i * 3 + 1], v2 = vsrc[i * 3 + 2];
+    float nr, fr;
+    aabb_one(oo, dd, bb, 0.0f, nr, fr);
+    float *r = rays + i * 11;
+    r[0] = oo[0]; r[1] = oo[1]; r[2] = oo[2];
+    r[3] = dd[0]; r[4] = dd[1]; r[5] = dd[2];
+    r[6] = nr; r[7] = fr;
+    float s = v0 * v0; s = s + v1 * v1; s = s + v2 * v2;
+    const float nrm = sqrtf(s);
+    r[8] = v0 / nrm; r[9] = v1 / nrm; r[10] = v2 / nrm;
+}
+
 // NeRFRenderer.h:602-603: near.min(), far.max().  Exact (min/max are order independent).
 __global__ void k_near_far_range(int64_t n, int stride, const float *__restrict__ rays, float *__restrict__ out /*[2], pre-set to +inf,-inf*/)
 {
@@ -271,6 +368,58 @@ int nrf_pack_rays(const float *d_o, const float *d_d, const float *bbox, int64_t
     if (n == 0) return NRF_OK;
     hipLaunchKernelGGL(k_pack_rays, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, make_bbox(bbox), use_viewdirs, d_o, d_d, d_rays);
     NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_pack_rays_viewsrc(const float *d_o, const float *d_d, const float *d_view_src, const float *bbox, int64_t n, float *d_rays, void *stream)
+{
+    NRF_CHECK_ARG(d_o && d_d && d_view_src && bbox && d_rays && n >= 0, "nrf_pack_rays_viewsrc: bad argument");
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_pack_rays_vd, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, make_bbox(bbox), d_o, d_d, d_view_src, d_rays);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+static ViewCam make_cam(const float *K, const float *c2w)
+{
+    ViewCam c;
+    c.fx = K[0]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
+    for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) c.r[a * 3 + b] = c2w[a * 4 + b]; c.t[a] = c2w[a * 4 + 3]; }
+    return c;
+}
+
+int nrf_view_check(const nrf_view *v, const char *who)
+{
+    NRF_CHECK_ARG(v, "%s: null view", who);
+    NRF_CHECK_ARG(v->h > 0 && v->w > 0 && v->row0 >= 0 && v->rows >= 0 && v->row0 + v->rows <= v->h, "%s: rows [%d,%d) outside image of height %d", who, v->row0,
+                  v->row0 + v->rows, v->h);
+    NRF_CHECK_ARG(v->chunk > 0, "%s: Chunk must be positive", who);
+    return NRF_OK;
+}
+
+int nrf_view_rays(const nrf_view *v, float *d_rays, float *d_near_far, void *stream)
+{
+    NRF_TRY(nrf_view_check(v, "nrf_view_rays"));
+    NRF_CHECK_ARG(d_rays || v->rows == 0, "nrf_view_rays: null ray buffer");
+    const int64_t n = (int64_t)v->rows * v->w;
+    if (n == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    NdcConst nc{};
+    if (v->ndc) {
+        // RayUtils.h:63-71 with focal = k[0][0], near = 1.f (NeRFRenderer.h:567)
+        const double focal = (double)v->K[0];
+        nc.sx = (float)(-1. / ((double)v->w / (2. * focal)));
+        nc.sy = (float)(-1. / ((double)v->h / (2. * focal)));
+        nc.near_ = 1.0f; nc.two_near = 2.0f; nc.m_two_near = -2.0f;
+    }
+    int *nf_enc = d_near_far ? reinterpret_cast<int *>(d_near_far) : nullptr;     // reduced in place as order-encoded ints, decoded to floats at the end
+    if (nf_enc) { hipLaunchKernelGGL(k_nf_init, dim3(1), dim3(1), 0, st, nf_enc); NRF_LAUNCH_CHECK(); }
+    const ViewCam cam = make_cam(v->K, v->c2w);
+    const ViewCam cam_o = v->has_staticcam ? make_cam(v->K, v->c2w_staticcam) : cam;
+    hipLaunchKernelGGL(k_view_rays, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, v->w, v->row0, n, cam, cam_o, v->has_staticcam ? 1 : 0,
+                       v->use_viewdirs ? 1 : 0, v->ndc ? 1 : 0, nc, make_bbox(v->bbox), d_rays, nf_enc);
+    NRF_LAUNCH_CHECK();
+    if (nf_enc) { hipLaunchKernelGGL(k_nf_decode, dim3(1), dim3(1), 0, st, nf_enc, d_near_far); NRF_LAUNCH_CHECK(); }
     return NRF_OK;
 }
 

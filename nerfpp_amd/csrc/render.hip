@@ -466,4 +466,79 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
                               out->d_weights, out->d_depth, nz, st, fastc);                                        // :448
 }
 
+
+// ---- BatchifyRays (NeRFRenderer.h:465-525) and the pose branch of Render (:530-605) as single calls ----
+static nrf_render_outputs slice_outputs(const nrf_render_outputs &o, int64_t i, int s, int so, int sf, int c)
+{
+    nrf_render_outputs q = o;
+    if (q.d_rgb) q.d_rgb += i * 3;
+    if (q.d_disp) q.d_disp += i;
+    if (q.d_acc) q.d_acc += i;
+    if (q.d_depth) q.d_depth += i;
+    if (q.d_weights) q.d_weights += i * so;
+    if (q.d_raw) q.d_raw += i * so * c;
+    if (q.d_z_coarse) q.d_z_coarse += i * s;
+    if (q.d_raw_coarse) q.d_raw_coarse += i * s * c;
+    if (q.d_weights_coarse) q.d_weights_coarse += i * s;
+    if (q.d_z_fine) q.d_z_fine += i * sf;
+    return q;
+}
+
+size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p)
+{
+    if (!r || !p || chunk <= 0) return 0;
+    return nrf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
+}
+
+int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p, const float *d_t,
+                      const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && p && out, "nrf_batchify_rays: null pointer");
+    NRF_CHECK_ARG(chunk > 0 && n >= 0, "nrf_batchify_rays: Chunk must be positive");
+    const int s = p->n_samples, sf = p->n_samples + p->n_importance, so = p->n_importance > 0 ? sf : s;
+    const int c = r->desc.mlp->out_dims;
+    nrf_render_params q = *p;
+    for (int64_t i = 0; i < n; i += chunk) {                                                                      // :476
+        const int64_t m = n - i < chunk ? n - i : (int64_t)chunk;
+        q.ray_base = p->ray_base + i;
+        const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
+        NRF_TRY(nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, d_workspace, workspace_bytes, stream));
+    }
+    return NRF_OK;
+}
+
+extern "C" int nrf_view_check(const nrf_view *v, const char *who);
+
+size_t nrf_render_rows_workspace_bytes(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p)
+{
+    if (!r || !v || !p || v->chunk <= 0 || v->rows < 0 || v->w <= 0) return 0;
+    const int64_t n = (int64_t)v->rows * v->w;
+    return align_up((size_t)n * (v->use_viewdirs ? 11 : 8) * sizeof(float), 256) + 256 + nrf_batchify_rays_workspace_bytes(r, n, v->chunk, p);
+}
+
+int nrf_render_rows(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p, const float *d_t, const float *d_u, const nrf_render_outputs *out,
+                    float *d_rays_out, float *d_near_far, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && p && out, "nrf_render_rows: null pointer");
+    NRF_TRY(nrf_view_check(v, "nrf_render_rows"));
+    if (v->ndc && p->has_cone) {
+        set_error("nrf_render_rows: Ndc with cone rays (ThinRay = false) makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built -- render with ThinRay");
+        return NRF_ERR_UNSUPPORTED;
+    }
+    const int64_t n = (int64_t)v->rows * v->w;
+    if (n == 0) return NRF_OK;
+    const int stride = v->use_viewdirs ? 11 : 8;
+    if (workspace_bytes < nrf_render_rows_workspace_bytes(r, v, p)) {
+        set_error("nrf_render_rows: workspace %zu < %zu bytes", workspace_bytes, nrf_render_rows_workspace_bytes(r, v, p));
+        return NRF_ERR_WORKSPACE;
+    }
+    Bump bump(d_workspace, workspace_bytes);
+    float *rays = d_rays_out ? d_rays_out : bump.take<float>((size_t)n * stride);
+    void *ws = bump.take<char>(0);
+    NRF_TRY(nrf_view_rays(v, rays, d_near_far, stream));                                                          // :541-583, :602-603
+    nrf_render_params q = *p;
+    q.ray_base = p->ray_base + (int64_t)v->row0 * v->w;
+    return nrf_batchify_rays(r, rays, stride, n, v->chunk, &q, d_t, d_u, out, ws, workspace_bytes - bump.off, stream);   // :586-590
+}
+
 }  // extern "C"

@@ -43,6 +43,11 @@ class TileShard:
             pad = torch.zeros((f, self.max_rows - self.rows, w, c), device=local.device, dtype=local.dtype)
             local = torch.cat([local, pad], 1)
         local = local.contiguous()
+        if f == 1 and self.rows == self.max_rows and self.h == self.world * self.rows:
+            # one frame, equal tiles (800 rows over 2 / 4 / 8 ranks): the gathered buffer IS the frame -- no copy after the collective
+            out = torch.empty((1, self.h, w, c), device=local.device, dtype=local.dtype)
+            dist.all_gather_into_tensor(out.view(self.world, self.rows, w, c), local.view(self.rows, w, c))
+            return out
         out = torch.empty((self.world * f,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         dist.all_gather_into_tensor(out, local)                                           # ncclAllGather over xGMI (dim-0 concatenation)
         out = out.view((self.world, f) + tuple(local.shape[1:]))

@@ -125,14 +125,25 @@ class NeRFRendererOutputs:            # NeRFRenderer.h:12-18
     DepthMap: Optional[torch.Tensor] = None
 
 
-@dataclass
 class NeRFRenderResult:               # NeRFRenderer.h:20-26
-    Outputs: NeRFRendererOutputs = field(default_factory=NeRFRendererOutputs)
-    Raw: Optional[torch.Tensor] = None
-    Near: float = 0.0
-    Far: float = 0.0
-    # intermediates exposed for stage-chained parity tests (not in the reference struct)
-    Extras: dict = field(default_factory=dict)
+    """Outputs, Raw, Near, Far as in the reference.  Near / Far are float scalars there (two .item() host syncs per frame, NeRFRenderer.h:602-603); here the
+    library leaves them in a device [2] buffer on the render's stream and the properties read it on first access, so a render call never stalls the host."""
+
+    def __init__(self):
+        self.Outputs = NeRFRendererOutputs()
+        self.Raw = None
+        self.Extras = {}          # intermediates exposed for stage-chained parity tests (not in the reference struct)
+        self._nf = (0.0, 0.0)
+        self._nf_dev = None
+
+    def _near_far(self):
+        if self._nf_dev is not None:
+            a = self._nf_dev.tolist()             # synchronises the producing stream
+            self._nf, self._nf_dev = (a[0], a[1]), None
+        return self._nf
+
+    Near = property(lambda self: self._near_far()[0], lambda self, v: setattr(self, "_nf", (float(v), self._near_far()[1])))
+    Far = property(lambda self: self._near_far()[1], lambda self, v: setattr(self, "_nf", (self._near_far()[0], float(v))))
 
 
 @dataclass
@@ -238,20 +249,21 @@ class NeRFRenderer:
         return o
 
     # ---- public surface ----
-    def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
-                   raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True,
-                   precision=L.NRF_PREC_F32, keep_intermediates=False, seed=0, ray_base=0, coarse_mode=L.NRF_COARSE_AUTO):
-        """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11].  The stochastic branches (perturb, a defined cone_angle,
-        raw_noise_std, stochastic preconditioning) draw from the library's counter RNG keyed by (seed, ray_base + ray, sample)."""
-        rays = _dev_f32(ray_batch)
-        n, stride = rays.shape
-        dev = rays.device
-        s, ni = int(n_samples), int(n_importance)
-        sf = s + ni
-        c = self.NeRF.GetOutputDims()
-        t = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)                      # NeRFRenderer.h:393
-        u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev) if ni > 0 else None   # Sampler.h:21
-        rp = L.RenderParams(s, ni, int(lin_disp), int(white_bkgr), precision, ATEN_SUM_VEC)
+    _lin_cache = {}
+
+    @classmethod
+    def _linspace(cls, steps, dev):
+        """torch::linspace(0, 1, steps) on the device (NeRFRenderer.h:393, Sampler.h:21), ATen's own rounding; cached per (steps, device)."""
+        key = (int(steps), str(dev))
+        t = cls._lin_cache.get(key)
+        if t is None:
+            t = cls._lin_cache[key] = torch.linspace(0.0, 1.0, int(steps), dtype=torch.float32).to(dev)
+        return t
+
+    @staticmethod
+    def _params(n_samples, n_importance, cone_angle, lin_disp, perturb, white_bkgr, raw_noise_std, stochastic_preconditioning_alpha, bounding_box, precision,
+                seed, ray_base, coarse_mode):
+        rp = L.RenderParams(int(n_samples), int(n_importance), int(lin_disp), int(white_bkgr), precision, ATEN_SUM_VEC)
         rp.perturb, rp.raw_noise_std, rp.precond_alpha = float(perturb), float(raw_noise_std), float(stochastic_preconditioning_alpha)
         if cone_angle is not None and (not torch.is_tensor(cone_angle) or cone_angle.numel()):
             rp.has_cone, rp.cone_angle = 1, float(cone_angle)
@@ -260,6 +272,12 @@ class NeRFRenderer:
             rp.bbox = (C.c_float * 6)(*_host_f32(bounding_box, 6).tolist())
         rp.seed, rp.ray_base = int(seed), int(ray_base)
         rp.coarse_mode = int(coarse_mode)
+        return rp
+
+    def _alloc_outputs(self, n, s, ni, dev, return_raw, return_weights, keep_intermediates):
+        """(result, nrf_render_outputs) with every buffer sized for n rays."""
+        sf = s + ni
+        c = self.NeRF.GetOutputDims()
         res = NeRFRenderResult()
         so = sf if ni > 0 else s
         o = res.Outputs
@@ -280,6 +298,22 @@ class NeRFRenderer:
             if ni > 0:
                 ex["z_fine"] = torch.empty((n, sf), device=dev)
                 ro.d_z_fine = _ptr(ex["z_fine"])
+        return res, ro
+
+    def RenderRays(self, ray_batch, cone_angle, n_samples, return_raw=False, lin_disp=False, perturb=0.0, n_importance=0, white_bkgr=False,
+                   raw_noise_std=0.0, stochastic_preconditioning_alpha=0.0, bounding_box=None, return_weights=True,
+                   precision=L.NRF_PREC_F32, keep_intermediates=False, seed=0, ray_base=0, coarse_mode=L.NRF_COARSE_AUTO):
+        """NeRFRenderer.h:366-459 for one chunk of packed rays [N, 8|11].  The stochastic branches (perturb, a defined cone_angle,
+        raw_noise_std, stochastic preconditioning) draw from the library's counter RNG keyed by (seed, ray_base + ray, sample)."""
+        rays = _dev_f32(ray_batch)
+        n, stride = rays.shape
+        dev = rays.device
+        s, ni = int(n_samples), int(n_importance)
+        t = self._linspace(s, dev)                                   # NeRFRenderer.h:393
+        u = self._linspace(ni, dev) if ni > 0 else None               # Sampler.h:21
+        rp = self._params(s, ni, cone_angle, lin_disp, perturb, white_bkgr, raw_noise_std, stochastic_preconditioning_alpha, bounding_box, precision, seed,
+                          ray_base, coarse_mode)
+        res, ro = self._alloc_outputs(n, s, ni, dev, return_raw, return_weights, keep_intermediates)
         nb = L.lib().nrf_render_rays_workspace_bytes(self._r, C.c_int64(n), C.byref(rp))
         ws = self._workspace(nb, dev)
         L.check(L.lib().nrf_render_rays(self._r, _ptr(rays), stride, C.c_int64(n), C.byref(rp), _ptr(t), _ptr(u), C.byref(ro), _ptr(ws),
@@ -303,43 +337,82 @@ class NeRFRenderer:
             res.Extras[k] = torch.cat([r.Extras[k] for r in results], 0)
         return res
 
-    def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, c2w_staticcam=None, row0=0, rows=None):
-        """NeRFRenderer.h:530-605.  Either a pose (c2w, full image or the row tile [row0, row0+rows)) or an explicit ray batch."""
+    def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, c2w_staticcam=None, row0=0, rows=None, device="cuda"):
+        """NeRFRenderer.h:530-605.  Either a pose (c2w, full image or the row tile [row0, row0+rows)) or an explicit ray batch.
+        The pose branch is ONE library call (nrf_render_rows: ray generation, view directions, NDC, AABB, packing, the Chunk loop and the
+        tile's Near / Far); the ray-batch branch packs and then runs the Chunk loop in one call (nrf_batchify_rays).  Neither synchronises."""
         p = render_params
+        s, ni = int(p.NSamples), int(p.NImportance)
+        stride = 11 if p.UseViewdirs else 8
+        bb = _host_f32(p.BoundingBox, 6)
+        lib = L.lib()
         if c2w is not None:
-            rays_o, rays_d, cone_angle = GetRays(h, w, k, c2w, row0=row0, rows=rows)                  # :543
+            rows = h - row0 if rows is None else rows
+            dev = torch.device(device)
+            sh = (rows, w, 3)
+            n = rows * w
+            v = L.View()
+            v.h, v.w, v.row0, v.rows = int(h), int(w), int(row0), int(rows)
+            v.K = (C.c_float * 9)(*_host_f32(k, 9).tolist())
+            v.c2w = (C.c_float * 12)(*_host_f32(torch.as_tensor(c2w)[:3, :4] if torch.is_tensor(c2w) else np.asarray(c2w)[:3, :4], 12).tolist())
+            if c2w_staticcam is not None:
+                v.has_staticcam = 1
+                cs = c2w_staticcam
+                v.c2w_staticcam = (C.c_float * 12)(*_host_f32(torch.as_tensor(cs)[:3, :4] if torch.is_tensor(cs) else np.asarray(cs)[:3, :4], 12).tolist())
+            v.use_viewdirs, v.ndc, v.chunk = int(bool(p.UseViewdirs)), int(bool(p.Ndc)), int(p.Chunk)
+            v.bbox = (C.c_float * 6)(*bb.tolist())
+            cone_angle = None
+            if not p.ThinRay:                                            # GetRays' third result (RayUtils.h:35-43)
+                kk = _host_f32(k, 9)
+                cone_angle = float(np.float32((np.float32(1.0) / kk[0] + np.float32(1.0) / kk[4]) / np.float32(2.0)) * np.float32(1.1))
+            rp = self._params(s, ni, cone_angle, p.LinDisp, p.Perturb, p.WhiteBkgr, p.RawNoiseStd, p.StochasticPreconditioningAlpha, p.BoundingBox, p.Precision,
+                              p.Seed, 0, p.CoarseMode)
+            res, ro = self._alloc_outputs(n, s, ni, dev, p.ReturnRaw, p.ReturnWeights, p.KeepIntermediates)
+            rays_ = torch.empty((n, stride), device=dev, dtype=torch.float32)
+            nf = torch.empty((2,), device=dev, dtype=torch.float32)
+            nb = lib.nrf_render_rows_workspace_bytes(self._r, C.byref(v), C.byref(rp))
+            ws = self._workspace(nb, dev)
+            L.check(lib.nrf_render_rows(self._r, C.byref(v), C.byref(rp), _ptr(self._linspace(s, dev)), _ptr(self._linspace(ni, dev)) if ni > 0 else None,
+                                        C.byref(ro), _ptr(rays_), _ptr(nf), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
         else:
+            if c2w_staticcam is not None:
+                raise L.NrfError("c2w_staticcam replaces the camera of a POSE render (NeRFRenderer.h:554-558); with an explicit ray batch pass those rays yourself")
             rays_o, rays_d, cone_angle = rays
             rays_o, rays_d = _dev_f32(rays_o), _dev_f32(rays_d)
-        if c2w_staticcam is not None:
-            raise L.NrfError("c2w_staticcam (NeRFRenderer.h:554-558, a visualisation aid) is not built")
-        sh = tuple(rays_d.shape)
-        bb = _host_f32(p.BoundingBox, 6)
-        if p.Ndc:
-            kk = _host_f32(k, 9)
-            rays_o, rays_d, cone_angle = NDCRays(h, w, float(kk[0]), 1.0, rays_o, rays_d, None if p.ThinRay else cone_angle)   # :567
-            if p.UseViewdirs:
-                raise L.NrfError("Ndc together with UseViewdirs needs the pre-NDC directions as viewdirs; use the stage functions")
-        o = rays_o.reshape(-1, 3).contiguous(); d = rays_d.reshape(-1, 3).contiguous()
-        n = o.shape[0]
-        stride = 11 if p.UseViewdirs else 8
-        rays_ = torch.empty((n, stride), device=o.device, dtype=torch.float32)
-        L.check(L.lib().nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))   # :549-583
-        all_ret = self.BatchifyRays(rays_, None if p.ThinRay else cone_angle, p.NSamples, p.Chunk, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
-                                    perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
-                                    stochastic_preconditioning_alpha=p.StochasticPreconditioningAlpha, bounding_box=p.BoundingBox,
-                                    return_weights=p.ReturnWeights, precision=p.Precision, keep_intermediates=p.KeepIntermediates, seed=p.Seed, coarse_mode=p.CoarseMode,
-                                    ray_base=row0 * w if c2w is not None else 0)
-        out = all_ret.Outputs
-        if out.RGBMap is not None:
-            out.RGBMap = out.RGBMap.reshape(sh)                                                       # :591-592
+            sh = tuple(rays_d.shape)
+            dev = rays_d.device
+            view_src = rays_d.reshape(-1, 3)
+            if p.Ndc:
+                if not p.ThinRay and cone_angle is not None:
+                    raise L.NrfError("Ndc with cone rays (ThinRay = false) makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built")
+                kk = _host_f32(k, 9)
+                rays_o, rays_d, _ = NDCRays(h, w, float(kk[0]), 1.0, rays_o, rays_d, None)                       # :567
+            o = rays_o.reshape(-1, 3).contiguous(); d = rays_d.reshape(-1, 3).contiguous()
+            n = o.shape[0]
+            rays_ = torch.empty((n, stride), device=dev, dtype=torch.float32)
+            if p.Ndc and p.UseViewdirs:                                  # viewdirs are taken before the warp (:549-561)
+                L.check(lib.nrf_pack_rays_viewsrc(_ptr(o), _ptr(d), _ptr(view_src.contiguous()), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), _ptr(rays_), _stream()))
+            else:
+                L.check(lib.nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))   # :549-583
+            rp = self._params(s, ni, None if p.ThinRay else cone_angle, p.LinDisp, p.Perturb, p.WhiteBkgr, p.RawNoiseStd, p.StochasticPreconditioningAlpha,
+                              p.BoundingBox, p.Precision, p.Seed, 0, p.CoarseMode)
+            res, ro = self._alloc_outputs(n, s, ni, dev, p.ReturnRaw, p.ReturnWeights, p.KeepIntermediates)
+            nb = lib.nrf_batchify_rays_workspace_bytes(self._r, C.c_int64(n), int(p.Chunk), C.byref(rp))
+            ws = self._workspace(nb, dev)
+            L.check(lib.nrf_batchify_rays(self._r, _ptr(rays_), stride, C.c_int64(n), int(p.Chunk), C.byref(rp), _ptr(self._linspace(s, dev)),
+                                          _ptr(self._linspace(ni, dev)) if ni > 0 else None, C.byref(ro), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+            nf = None
+            if n > 0:
+                nr, fr = C.c_float(0), C.c_float(0)
+                L.check(lib.nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))   # :602-603
+                res._nf = (nr.value, fr.value)
+        out = res.Outputs
+        out.RGBMap = out.RGBMap.reshape(sh)                                                               # :591-592
         if len(sh) > 2:
             out.DispMap = out.DispMap.reshape(sh[0], sh[1]); out.DepthMap = out.DepthMap.reshape(sh[0], sh[1])   # :594-600
-        nr, fr = C.c_float(0), C.c_float(0)
-        L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))   # :602-603
-        all_ret.Near, all_ret.Far = nr.value, fr.value
-        all_ret.Extras["rays_flat"] = rays_
-        return all_ret
+        res._nf_dev = nf
+        res.Extras["rays_flat"] = rays_
+        return res
 
 
 # ------------------------------------------------------------------------------------------------

@@ -82,11 +82,16 @@ int main(int argc, const char **argv)
 	}
 	// ---- the same model behind the HIP adapters ----
 	nrfpp::HipHashEmbedder he("embedder", bbox, L, F, T, 16, 512, NRF_HASH_NGP);
+	bool names_equal = true;
 	{
-		std::vector<torch::Tensor> tabs;
-		for (auto &p : e->named_parameters()) tabs.push_back(p.value());
-		he->Embeddings.copy_(torch::cat(tabs, 0));
-		he->Initialize();
+		// same parameter names as the reference module (NeRF.cpp:255-259: `embedder_embeddings_<i>.weight`), copied level by level
+		auto pr = e->named_parameters(); auto ph = he->named_parameters();
+		names_equal = pr.size() == ph.size();
+		for (size_t i = 0; names_equal && i < pr.size(); i++) {
+			names_equal = pr[i].key() == ph[i].key() && pr[i].value().sizes() == ph[i].value().sizes();
+			if (names_equal) ph[i].value().copy_(pr[i].value());
+		}
+		he->Sync();
 	}
 	nrfpp::HipSHEncoder hd("embeddirs", 3, 4, NRF_SH_LIBTORCH);
 	nrfpp::HipNeRFRenderer<nrfpp::HipHashEmbedder, nrfpp::HipSHEncoder, NeRFSmall> hip(he, hd, m, NRF_PREC_F32);
@@ -143,6 +148,93 @@ int main(int argc, const char **argv)
 	const float split_vs_f32 = (r_sp.Outputs.RGBMap - r_hip.Outputs.RGBMap).abs().max().item<float>();
 	ok = ok && split_vs_f32 < 1e-4f;
 	stage("single-GPU renders done");
+	// the library's chunk loop (nrf_render_rows, the default) against the reference's own BatchifyRays driving the virtual RenderRays: same pixels, bit for bit
+	hip.LibraryChunkLoop = false;
+	auto r_loop = hip.Render(h, w, K.cuda(), rp_gpu, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w.cuda());
+	hip.LibraryChunkLoop = true;
+	const bool chunk_loop_same = torch::equal(r_loop.Outputs.RGBMap, r_sp.Outputs.RGBMap) && torch::equal(r_loop.Outputs.DepthMap, r_sp.Outputs.DepthMap) &&
+		torch::equal(r_loop.Outputs.Weights, r_sp.Outputs.Weights) && r_loop.Near == r_sp.Near && r_loop.Far == r_sp.Far;
+	// Ndc + UseViewdirs and c2w_staticcam through the fused Render (the reference's own Ndc render reads a dangling `sh`, NeRFRenderer.h:562/567, so the comparison
+	// is with the reference's pieces: GetRays -> viewdirs -> NDCRays -> IntersectWithAABB on the CPU, and the explicit-ray-batch branch of the adapter)
+	bool ndc_ok = false, static_ok = false;
+	{
+		auto c2n = torch::tensor({{0.98f, -0.05f, 0.19f, 0.10f}, {0.06f, 0.995f, -0.07f, -0.05f}, {-0.185f, 0.08f, 0.98f, 0.20f}});
+		auto rpn = rp_gpu; rpn.Ndc = true; rpn.Chunk = 77;
+		auto r_n = hip.Render(h, w, K.cuda(), rpn, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2n.cuda());
+		auto [ro, rd, cone] = GetRays(h, w, K, c2n);
+		auto r_b = hip.Render(h, w, K.cuda(), rpn, {ro.reshape({-1, 3}).cuda(), rd.reshape({-1, 3}).cuda(), cone});
+		ndc_ok = r_n.Outputs.RGBMap.sizes() == std::vector<int64_t>({h, w, 3}) && torch::isfinite(r_n.Outputs.RGBMap).all().item<bool>() &&
+			torch::equal(r_n.Outputs.RGBMap.reshape({-1, 3}), r_b.Outputs.RGBMap) && r_n.Near == r_b.Near && r_n.Far == r_b.Far;
+		auto [no, nd, nc] = NDCRays(h, w, K[0][0].item<float>(), 1.f, ro, rd, torch::Tensor());
+		auto [nr, fr] = IntersectWithAABB(no.reshape({-1, 3}), nd.reshape({-1, 3}), bbox, 0.f);
+		ndc_ok = ndc_ok && r_n.Near == nr.min().item<float>() && r_n.Far == fr.max().item<float>();
+		auto c2s = orbit_pose(-20.f, -35.f, 3.6f);
+		auto r_s = hip.Render(h, w, K.cuda(), rp_gpu, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w.cuda(), c2s.cuda());
+		auto r_ref_s = ref.Render(h, w, K, rp, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w, c2s);
+		const float frac_s = ((r_s.Outputs.RGBMap.cpu() - r_ref_s.Outputs.RGBMap).abs().amax(-1) < 1e-4f).to(torch::kFloat32).mean().item<float>();
+		static_ok = frac_s >= 0.90f && r_s.Near == r_ref_s.Near && r_s.Far == r_ref_s.Far;
+	}
+	ok = ok && names_equal && chunk_loop_same && ndc_ok && static_ok;
+	stage("chunk loop / NDC / staticcam done");
+	// ---- module state of the drop-in embedders (CuHashEmbedder.cpp:24-76, NeRF.cpp:255-271) ----
+	bool cu_scratch_ok = false, load_cu_ok = false, load_ngp_ok = false, saved = false, zero_primes_rejected = false;
+	std::string state_note = "ok";
+	try {
+		const int SL = 4, SF = 2, ST = 12;
+		torch::manual_seed(1234);
+		nrfpp::HipHashEmbedder cu("embedder", bbox, SL, SF, ST, 16, 128, NRF_HASH_CU);       // constructed from scratch, exactly as INTEGRATION.md section 1 says
+		cu->Initialize();
+		auto pr = cu->Primes.cpu().reshape({-1});
+		bool primes_ok = pr.numel() == 3 * SL;
+		for (int64_t i = 0; primes_ok && i < pr.numel(); i++) {
+			const int v = pr[i].item<int>();
+			primes_ok = v >= (1 << 28) && v < (1 << 30);
+			for (int q = 2; primes_ok && (int64_t)q * q <= v; q++) if (v % q == 0) primes_ok = false;
+		}
+		// the same generator state gives the reference's draw sequence: rand for the table first, then one randint per candidate prime
+		torch::manual_seed(1234);
+		auto tab_ref = torch::rand({((int64_t)1 << ST) * SL, SF}, torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA)) * 1e-4f;
+		const bool table_ok = torch::equal(tab_ref, cu->Embeddings.detach());
+		auto xs = (torch::rand({2048, 3}) * 2.8f - 1.4f).cuda();
+		auto emb_s = cu->forward(xs).first;                                                   // zero primes would hash every corner to row 0: identical rows
+		const bool spread = (emb_s.std(0) > 0).all().item<bool>() && (emb_s.amax(0) - emb_s.amin(0)).min().item<float>() > 1e-6f;
+		auto names = cu->named_buffers();
+		const bool buffers_ok = names.size() == 4 && names.contains("embedder_feat_local_size") && names.contains("embedder_feat_local_idx") &&
+			names["embedder_feat_local_size"].dtype() == torch::kInt32 && names["embedder_feat_local_idx"][SL - 1].item<int>() == (SL - 1) * (1 << ST) &&
+			names["embedder_primes"].sizes() == std::vector<int64_t>({SL, 1, 3}) && names["embedder_biases"].sizes() == std::vector<int64_t>({SL, 3});
+		cu_scratch_ok = primes_ok && table_ok && spread && buffers_ok;
+		{
+			nrf_hash *hh = nullptr; nrf_hash_desc hd{NRF_HASH_CU, SL, SF, ST, 16, 128, {-1.5f, -1.5f, -1.5f, 1.5f, 1.5f, 1.5f}};
+			nrfpp::check(nrf_hash_create(&hd, &hh), "nrf_hash_create");
+			std::vector<int32_t> z(3 * SL, 0);
+			zero_primes_rejected = nrf_hash_set_primes(hh, z.data(), nullptr) == NRF_ERR_INVALID_ARG;
+			nrf_hash_destroy(hh);
+		}
+		const char *ck = getenv("NRF_ADAPTER_CKPT_DIR"), *outd = getenv("NRF_ADAPTER_OUT_DIR");
+		if (ck) {
+			// the reference-written fixtures (tests/golden/ckpt, ref_driver ckpt_save) straight into the adapter modules with torch::load
+			torch::load(cu, std::string(ck) + "/cu_embedder_checkpoint.pt");
+			cu->Sync();
+			auto p2 = cu->Primes.cpu().reshape({-1});
+			load_cu_ok = p2[0].item<int>() == 268435459 && p2[5].item<int>() == 268435469 && (cu->Biases.cpu() == 0.25f).all().item<bool>() &&
+				torch::isfinite(cu->forward(xs).first).all().item<bool>();
+			nrfpp::HipHashEmbedder ng("embedder", bbox, SL, SF, ST, 16, 128, NRF_HASH_NGP);
+			torch::load(ng, std::string(ck) + "/embedder_checkpoint.pt");
+			ng->Sync();
+			HashEmbedder e_ref("embedder", bbox, SL, SF, ST, 16, 128);
+			torch::load(e_ref, std::string(ck) + "/embedder_checkpoint.pt");
+			auto xc = xs.cpu();
+			load_ngp_ok = torch::equal(ng->forward(xs).first.cpu(), e_ref->forward(xc).first);
+			if (outd) {
+				// files the adapters torch::save: ref_driver ckpt_load (the reference's own modules + torch::load) must accept them (checked by the caller)
+				torch::save(ng, std::string(outd) + "/embedder_checkpoint.pt");
+				torch::save(cu, std::string(outd) + "/cu_embedder_checkpoint.pt");
+				saved = true;
+			}
+		}
+	} catch (const std::exception &ex) { state_note = ex.what(); for (auto &ch : state_note) if (ch == '"' || ch == '\n') ch = ' '; state_note = state_note.substr(0, 300); }
+	ok = ok && cu_scratch_ok && zero_primes_rejected && (!getenv("NRF_ADAPTER_CKPT_DIR") || (load_cu_ok && load_ngp_ok));
+	stage("module state done");
 	// ---- multi-GPU surface: RenderTile == the slice of Render, RenderSharded over a world of one == Render (the box has one GPU) ----
 	const int row0 = h / 3, rows = h / 2;
 	auto r_tile = hip.RenderTile(h, w, K.cuda(), rp_gpu, c2w.cuda(), row0, rows);
@@ -233,6 +325,11 @@ int main(int argc, const char **argv)
 	std::cout.rdbuf(cout_buf);
 	printf("{\"lerf_pass_ok\": %s, \"lerf_fused\": %s, \"lerf_feature_reuse_equals_two_passes\": %s, \"lerf_split_cos_min_vs_reference_head\": %.9f, \"lerf_split_weights_max_abs_err\": %.3e, \"lerf_f16_cos_min\": %.6f, \"lerf_note\": \"%s\"}\n",
 		lerf_ok ? "true" : "false", lerf_fused ? "true" : "false", lerf_reuse_same ? "true" : "false", lerf_cos_min, lerf_w_err, lerf_f16_cos_min, lerf_note.c_str());
+	printf("{\"module_state_ok\": %s, \"parameter_names_equal_reference\": %s, \"cu_from_scratch_primes_table_buffers_ok\": %s, \"zero_primes_rejected\": %s, \"torch_load_cu_fixture\": %s, "
+		"\"torch_load_ngp_fixture_forward_bit_exact\": %s, \"adapter_checkpoints_saved\": %s, \"chunk_loop_library_equals_reference_batchify\": %s, \"ndc_viewdirs_ok\": %s, "
+		"\"staticcam_ok\": %s, \"state_note\": \"%s\"}\n", (cu_scratch_ok && zero_primes_rejected) ? "true" : "false", names_equal ? "true" : "false", cu_scratch_ok ? "true" : "false",
+		zero_primes_rejected ? "true" : "false", load_cu_ok ? "true" : "false", load_ngp_ok ? "true" : "false", saved ? "true" : "false", chunk_loop_same ? "true" : "false",
+		ndc_ok ? "true" : "false", static_ok ? "true" : "false", state_note.c_str());
 	printf("{\"ok\": %s, \"image\": [%d, %d], \"hash_embedding_bit_exact\": %s, \"sh_bit_exact\": %s, \"rgb_max_abs_err\": %.3e, \"pixels_within_1e-4\": %.4f, \"acc_max_abs_err\": %.3e, "
 		"\"depth_max_abs_err\": %.3e, \"psnr_db\": %.2f, \"shapes_near_far_equal\": %s, \"f16_render_finite\": %s, \"split_pixels_within_1e-4\": %.4f, \"split_psnr_db\": %.2f, "
 		"\"split_vs_own_f32_max_abs_err\": %.3e, \"render_tile_equals_slice\": %s, \"render_sharded_world1_equals_render\": %s, \"comm\": \"%s\"}\n",

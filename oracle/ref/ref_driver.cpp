@@ -539,6 +539,55 @@ static void g_render()
 			if (variant == 1) save_npy(stag + ".noise2", torch::randn({nr, ns + ni}));
 		}
 		{
+			// Ndc + UseViewdirs (NeRFRenderer.h:549-568): the view directions are normalised from the rays of the pose BEFORE NDCRays replaces
+			// rays_o / rays_d.  A forward-facing camera (looking down -z, as NDCRays assumes) slightly off the axis; the warped rays run from
+			// z = -1 to z = +1 inside the same [-1.5, 1.5]^3 box.
+			std::string ntag = "render_ndc";
+			auto c2n = torch::tensor({{0.98f, -0.05f, 0.19f, 0.10f}, {0.06f, 0.995f, -0.07f, -0.05f}, {-0.185f, 0.08f, 0.98f, 0.20f}});
+			save_npy(ntag + ".k", k); save_npy(ntag + ".c2w", c2n); save_npy(ntag + ".bbox", bbox);
+			// Reference quirk: Render() keeps `auto sh = rays_d.sizes()` (:562) -- an ArrayRef INTO the tensor that `std::tie(rays_o, rays_d, ...) = NDCRays(...)`
+			// (:567) then releases, so the reshapes at :591-600 read freed memory (here: "shape '[8, 0, 0]' is invalid").  Everything up to and including
+			// BatchifyRays has run by then; the spy holds the packed rays and every RawToOutputs result, which is what is saved (per-ray maps, flat).
+			auto run = [&](Spy<HashEmbedder, SHEncoder, NeRFSmall> &spy, std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays, torch::Tensor pose) {
+				auto rp = lego_params(64, 128, 40);
+				rp.Ndc = true;
+				bool threw = false;
+				try { spy.Render(h, w, k, rp, rays, pose); } catch (const c10::Error &) { threw = true; }
+				return threw;
+			};
+			auto cat_fine = [](Spy<HashEmbedder, SHEncoder, NeRFSmall> &spy, const std::string &tag) {
+				std::vector<torch::Tensor> rgb, depth, disp, acc, fz, cw;
+				for (size_t i = 0; i + 1 < spy.r2o_out.size(); i += 2)
+				{
+					rgb.push_back(spy.r2o_out[i + 1].RGBMap); depth.push_back(spy.r2o_out[i + 1].DepthMap); disp.push_back(spy.r2o_out[i + 1].DispMap);
+					acc.push_back(spy.r2o_out[i + 1].AccMap); fz.push_back(spy.r2o_z[i + 1]); cw.push_back(spy.r2o_out[i].Weights);
+				}
+				save_npy(tag + "rgb", torch::cat(rgb, 0)); save_npy(tag + "depth", torch::cat(depth, 0)); save_npy(tag + "disp", torch::cat(disp, 0));
+				save_npy(tag + "acc", torch::cat(acc, 0)); save_npy(tag + "fine_z", torch::cat(fz, 0)); save_npy(tag + "coarse_weights", torch::cat(cw, 0));
+			};
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+			const bool threw = run(spy, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2n);
+			save_npy(ntag + ".reference_render_threw", torch::tensor({threw ? 1 : 0}, torch::kInt32));
+			save_npy(ntag + ".rays_flat", spy.batch_rays[0]);
+			cat_fine(spy, ntag + ".out_");
+			save_npy(ntag + ".near_far", torch::stack({spy.batch_rays[0].index({Slice(), 6}).min(), spy.batch_rays[0].index({Slice(), 7}).max()}));		//the expressions of :602-603
+			// the same through an explicit ray batch (the first 40 rays of the frame)
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy2(e, ed, m);
+			auto [o, d, cone] = GetRays(h, w, k, c2n);
+			run(spy2, {o.reshape({-1, 3}).index({Slice(0, 40)}), d.reshape({-1, 3}).index({Slice(0, 40)}), cone}, torch::Tensor());
+			save_npy(ntag + ".batch_rays_flat", spy2.batch_rays[0]);
+			cat_fine(spy2, ntag + ".batch_");
+		}
+		{
+			// c2w_staticcam (NeRFRenderer.h:554-558): rays from the static camera, view directions from c2w
+			std::string stag = "render_staticcam";
+			auto c2s = orbit_pose(-20.f, -35.f, 3.6f);
+			Spy<HashEmbedder, SHEncoder, NeRFSmall> spy(e, ed, m);
+			auto res = spy.Render(h, w, k, lego_params(64, 128, 64), {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w, c2s);
+			save_npy(stag + ".k", k); save_npy(stag + ".c2w", c2w); save_npy(stag + ".c2w_staticcam", c2s); save_npy(stag + ".bbox", bbox);
+			dump_spy(stag, spy, res);
+		}
+		{
 			// X1: the render-factor step of NeRFExecutor::RenderView (NeRFExecutor.h:618-627).  NeRFExecutor.h is unbuildable here (NeRFactor / RuCLIP
 			// headers), so its statements on h, w and k1 are evaluated below with the same types (int / float field, torch::Tensor element division),
 			// followed by the reference's own Render -- an "aux_" derivation in the sense of this file's header.

@@ -456,28 +456,51 @@ def test_render_classic_f16_mfma_pixels(api, manifest):
     assert np.isfinite(rgb).all() and api.S.psnr(rgb, g["out_rgb"]) > 35
 
 
-def test_libtorch_adapter_drop_in_inside_reference_renderer():
+def test_libtorch_adapter_drop_in_inside_reference_renderer(tmp_path):
     """oracle/_ref/adapter_check (compiled where /root/reference exists, travels as a binary): the C++ LibTorch adapter
     classes of include/nerfpp_torch.h driven by the reference's own NeRFRenderer::Render / BatchifyRays, compared with the
-    reference CPU renderer on the same weights."""
-    import json, os, subprocess
-    from conftest import ROOT
+    reference CPU renderer on the same weights; plus the MODULE STATE of the drop-in embedders: HipHashEmbedder(CU) built from
+    scratch draws its primes as CuHashEmbedder.cpp:28-51 does and registers the reference's four buffers, the NGP mode carries
+    `embedder_embeddings_<i>.weight`, the reference-written checkpoint fixtures torch::load into the adapters, and the files the
+    adapters torch::save load into the REFERENCE's modules (ref_driver ckpt_load)."""
+    import json, os, shutil, subprocess
+    from conftest import ROOT, GOLDEN
     exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
-    out = subprocess.run([exe, "16", "16"], capture_output=True, text=True, timeout=600)
+    outd = str(tmp_path / "adapter_ckpt"); os.makedirs(outd)
+    env = dict(os.environ, NRF_ADAPTER_CKPT_DIR=os.path.join(GOLDEN, "ckpt"), NRF_ADAPTER_OUT_DIR=outd)
+    out = subprocess.run([exe, "16", "16"], capture_output=True, text=True, timeout=600, env=env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert lines, out.stdout + out.stderr
     r = json.loads(lines[-1])
-    assert out.returncode == 0 and r["ok"], r
+    ms = json.loads(lines[-2])
+    assert out.returncode == 0 and r["ok"], (r, ms)
     assert r["hash_embedding_bit_exact"] and r["sh_bit_exact"] and r["shapes_near_far_equal"]
     assert r["pixels_within_1e-4"] >= 0.90 and r["psnr_db"] > 55, r
     assert r["split_pixels_within_1e-4"] >= 0.90 and r["split_psnr_db"] > 55, r      # the matrix-core fast path behind the reference's own Render()
     assert r["split_vs_own_f32_max_abs_err"] < 1e-4, r                                # strict: every pixel of the split render within 1e-4 of the adapter's parity render
     assert r["render_tile_equals_slice"] and r["render_sharded_world1_equals_render"], r     # multi-GPU surface: RenderTile / RenderSharded over a TileComm (world of one)
-    lr = json.loads(lines[-2])                                                        # the LeRF pass: HipLeRFPass (what HipLeRFRenderer forwards to) vs the reference's LeRF module
+    lr = json.loads(lines[-3])                                                        # the LeRF pass: HipLeRFPass (what HipLeRFRenderer forwards to) vs the reference's LeRF module
     assert lr["lerf_pass_ok"] and lr["lerf_fused"], lr
     assert lr["lerf_split_cos_min_vs_reference_head"] > 1 - 2e-6 and lr["lerf_split_weights_max_abs_err"] < 1e-5, lr
+    # module state of the drop-in
+    assert ms["module_state_ok"] and ms["parameter_names_equal_reference"] and ms["cu_from_scratch_primes_table_buffers_ok"] and ms["zero_primes_rejected"], ms
+    assert ms["torch_load_cu_fixture"] and ms["torch_load_ngp_fixture_forward_bit_exact"] and ms["adapter_checkpoints_saved"], ms
+    assert ms["chunk_loop_library_equals_reference_batchify"] and ms["ndc_viewdirs_ok"] and ms["staticcam_ok"], ms
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(drv):
+        # the adapter-saved embedder files next to the reference-written model / start files -> the reference's own torch::load into ITS modules
+        for f in ("model_checkpoint.pt", "start_checkpoint.pt"):
+            shutil.copy(os.path.join(GOLDEN, "ckpt", f), outd)
+        dump = str(tmp_path / "dump"); os.makedirs(dump)
+        subprocess.check_call([drv, "ckpt_load", outd, dump], stdout=subprocess.DEVNULL)
+        ref_dump = str(tmp_path / "ref_dump"); os.makedirs(ref_dump)
+        subprocess.check_call([drv, "ckpt_load", os.path.join(GOLDEN, "ckpt"), ref_dump], stdout=subprocess.DEVNULL)
+        names = [f for f in os.listdir(ref_dump) if f.startswith(("e.", "cu."))]
+        assert len(names) >= 4 + 5
+        for f in names:        # the adapters had loaded the fixtures, so what they saved must restore the same numbers
+            np.testing.assert_array_equal(np.load(os.path.join(dump, f)), np.load(os.path.join(ref_dump, f)), err_msg=f)
 
 
 def test_classic_fused_path_equals_stagewise_f16(api):
@@ -1965,3 +1988,147 @@ def test_trainer_ngp_mode_schedule_and_checkpoint_round_trip(api, tmp_path):
     b, _ = tr2.step(o, d, tgt, rp, global_step=6, n_iters=n_iters, lrate_decay=decay)
     assert_exact(host(a), host(b), "loss of the next step")
     assert_close(host(tr2.blob), host(tr.blob), rtol=0, atol=1e-7, what="parameters after the next step (float atomics of the table gradient aside)")
+
+
+# ------------------------------------------------------------------ Render() as one library call; NDC + view directions; c2w_staticcam; the sharded frame
+def _stagewise_render(api, r, h, w, k, p, c2w, row0, rows, chunk):
+    """The pose branch of Render composed on the host from the stage functions, the way the mirror did before nrf_render_rows existed:
+    GetRays -> nrf_pack_rays -> a Python loop of RenderRays over Chunk-sized slices -> torch.cat -> nrf_near_far_range."""
+    import ctypes as C
+    o, d, _ = api.R.GetRays(h, w, k, c2w, row0=row0, rows=rows)
+    o = o.reshape(-1, 3).contiguous(); d = d.reshape(-1, 3).contiguous()
+    n = o.shape[0]
+    rays = torch.empty((n, 11), device="cuda")
+    bb = np.ascontiguousarray(p.BoundingBox, np.float32)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    api.L.check(api.L.lib().nrf_pack_rays(P(o), P(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), 1, P(rays), None))
+    res = r.BatchifyRays(rays, None, p.NSamples, chunk, return_raw=p.ReturnRaw, lin_disp=p.LinDisp, perturb=p.Perturb, n_importance=p.NImportance,
+                         white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd, bounding_box=p.BoundingBox, return_weights=p.ReturnWeights,
+                         precision=p.Precision, keep_intermediates=p.KeepIntermediates, seed=p.Seed, coarse_mode=p.CoarseMode, ray_base=row0 * w)
+    nr, fr = C.c_float(0), C.c_float(0)
+    api.L.check(api.L.lib().nrf_near_far_range(P(rays), C.c_int64(n), 11, C.byref(nr), C.byref(fr), None))
+    return res, rays, (nr.value, fr.value)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_render_rows_single_call_equals_the_stagewise_host_loop(api, prec):
+    """nrf_render_rows (ray generation + view directions + AABB + packing + the Chunk loop + Near/Far in ONE call, what a rank of the
+    row-tile sharding issues per frame) against the same render composed from the stage functions: every output bit for bit, with a
+    Chunk that does not divide the tile and a stochastic branch whose draws are keyed by the global ray index."""
+    sc = api.S.make_hash_scene(mode="cu", log2_t=14)
+    h, w = 64, 48
+    K = api.S.lego_K(h, w); c2w = api.S.pose_spherical(40.0, -30.0, 4.0)
+    P = {"f32": api.L.NRF_PREC_F32, "f16x3": api.L.NRF_PREC_F16_SPLIT}[prec]
+    for perturb in (0.0, 1.0):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=P, ReturnWeights=True, ReturnRaw=True, KeepIntermediates="depths", Perturb=perturb, Seed=11)
+        a = sc["renderer"].Render(h, w, K, rp, c2w=c2w, row0=13, rows=37)
+        b, rays, nf = _stagewise_render(api, sc["renderer"], h, w, K, rp, c2w, 13, 37, 1000)
+        assert_exact(host(a.Extras["rays_flat"]), host(rays), "packed rays")
+        for name in ("RGBMap", "DispMap", "AccMap", "DepthMap", "Weights"):
+            assert_exact(host(getattr(a.Outputs, name)), host(getattr(b.Outputs, name)), f"{name} ({prec}, perturb {perturb})")
+        assert_exact(host(a.Raw), host(b.Raw), "raw")
+        for kx in ("z_coarse", "weights_coarse", "z_fine"):
+            assert_exact(host(a.Extras[kx]), host(b.Extras[kx]), kx)
+        assert (a.Near, a.Far) == nf, "Near / Far reduced on the device == nrf_near_far_range"
+        assert a.Outputs.RGBMap.shape == (37, w, 3) and a.Outputs.DepthMap.shape == (37, w)
+    # the tile of a full-frame render == the tile rendered alone (sharding by rows cannot change a pixel)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=P)
+    full = sc["renderer"].Render(h, w, K, rp, c2w=c2w)
+    tile = sc["renderer"].Render(h, w, K, rp, c2w=c2w, row0=13, rows=37)
+    assert_exact(host(full.Outputs.RGBMap)[13:50], host(tile.Outputs.RGBMap), "row tile == rows of the frame")
+
+
+def test_render_rows_argument_errors(api):
+    import ctypes as C
+    sc = api.S.make_hash_scene(mode="ngp", log2_t=12)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=0)
+    with pytest.raises(api.L.NrfError, match="Chunk"):
+        sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0))
+    rp = api.S.lego_render_params(sc["bbox"], chunk=64)
+    with pytest.raises(api.L.NrfError, match="outside image"):
+        sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0), row0=4, rows=5)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=64, Ndc=True, ThinRay=False)
+    with pytest.raises(api.L.NrfError, match="cone"):
+        sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0))
+
+
+def test_render_ndc_with_viewdirs_vs_reference(api, manifest):
+    """Ndc + UseViewdirs through the fused Render (NeRFRenderer.h:549-570): view directions are normalised from the pose's rays BEFORE NDCRays
+    replaces rays_o / rays_d.  Golden = the reference's packed rays and RawToOutputs results (its Render() itself reads a dangling `sh` after
+    :567 and threw here -- `reference_render_threw` -- after BatchifyRays had run)."""
+    g = load_golden("render_ndc")
+    assert int(g["reference_render_threw"][0]) == 1
+    r, _ = _golden_hash_scene(api, manifest)
+    p = _params(api, g["bbox"], 40); p.Ndc = True
+    res = r.Render(8, 8, g["k"], p, c2w=g["c2w"])
+    rays = host(res.Extras["rays_flat"])
+    assert_exact(rays[:, :8], g["rays_flat"][:, :8], "NDC-warped o, d and their AABB near / far")
+    assert_close(rays[:, 8:], g["rays_flat"][:, 8:], rtol=3e-7, atol=0, what="view directions of the UN-warped rays (torch::norm's order: 2 ulp)")
+    assert np.abs(rays[:, 8:] - rays[:, 3:6] / np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)).max() > 0.1, "viewdirs are NOT the warped directions"
+    assert_close(host(res.Outputs.RGBMap).reshape(-1, 3), g["out_rgb"], rtol=0, atol=1e-4, what="pixels within 1e-4 of the reference")
+    assert_close(host(res.Outputs.AccMap), g["out_acc"], rtol=0, atol=1e-4)
+    assert_close(host(res.Outputs.DepthMap).reshape(-1), g["out_depth"], rtol=0, atol=3e-4)
+    assert (host(res.Extras["z_fine"]) == g["out_fine_z"]).mean() > 0.85
+    assert (res.Near, res.Far) == (float(g["near_far"][0]), float(g["near_far"][1]))
+    assert res.Outputs.RGBMap.shape == (8, 8, 3)          # `sh` taken by value
+    # explicit ray batch: same arithmetic through NDCRays + nrf_pack_rays_viewsrc
+    o, d, cone = api.R.GetRays(8, 8, g["k"], g["c2w"])
+    rb = r.Render(8, 8, g["k"], p, rays=(o.reshape(-1, 3)[:40], d.reshape(-1, 3)[:40], cone))
+    assert_exact(host(rb.Extras["rays_flat"]), rays[:40], "ray-batch branch packs the same rows as the pose branch")
+    assert_exact(host(rb.Extras["rays_flat"])[:, :8], g["batch_rays_flat"][:, :8])
+    assert_exact(host(rb.Outputs.RGBMap), host(res.Outputs.RGBMap).reshape(-1, 3)[:40], "and renders the same pixels")
+    assert_close(host(rb.Outputs.RGBMap), g["batch_rgb"], rtol=0, atol=1e-4)
+
+
+def test_render_c2w_staticcam_vs_reference(api, manifest):
+    """c2w_staticcam (NeRFRenderer.h:554-558): the rays come from the static camera, the view directions from c2w."""
+    g = load_golden("render_staticcam")
+    r, _ = _golden_hash_scene(api, manifest)
+    res = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64), c2w=g["c2w"], c2w_staticcam=g["c2w_staticcam"])
+    rays = host(res.Extras["rays_flat"])
+    assert_exact(rays[:, :8], g["rays_flat"][:, :8], "o, d, near, far of the static camera")
+    assert_close(rays[:, 8:], g["rays_flat"][:, 8:], rtol=3e-7, atol=0, what="view directions of c2w")
+    assert_exact(host(res.Extras["z_coarse"]), g["coarse_z"])
+    assert_close(host(res.Outputs.RGBMap), g["out_rgb"], rtol=0, atol=1e-4)
+    assert_close(host(res.Outputs.DepthMap), g["out_depth"], rtol=0, atol=3e-4)
+    assert (res.Near, res.Far) == (float(g["near_far"][0]), float(g["near_far"][1]))
+    # without view directions the reference ignores c2w_staticcam altogether (the substitution sits inside `if UseViewdirs`)
+    import ctypes as C
+    def view_rays(staticcam):
+        v = api.L.View()
+        v.h, v.w, v.row0, v.rows, v.use_viewdirs, v.ndc, v.chunk = 8, 8, 0, 8, 0, 0, 64
+        v.K = (C.c_float * 9)(*np.asarray(g["k"], np.float32).reshape(-1).tolist())
+        v.c2w = (C.c_float * 12)(*np.asarray(g["c2w"], np.float32).reshape(-1).tolist())
+        v.has_staticcam = int(staticcam)
+        v.c2w_staticcam = (C.c_float * 12)(*np.asarray(g["c2w_staticcam"], np.float32).reshape(-1).tolist())
+        v.bbox = (C.c_float * 6)(*np.asarray(g["bbox"], np.float32).tolist())
+        out = torch.empty((64, 8), device="cuda")
+        api.L.check(api.L.lib().nrf_view_rays(C.byref(v), C.c_void_p(out.data_ptr()), None, None))
+        return host(out)
+    assert_exact(view_rays(True), view_rays(False), "UseViewdirs = false: c2w_staticcam has no effect")
+
+
+def test_bench_launcher_two_ranks_share_the_gpu_and_reproduce_the_single_rank_frame(tmp_path):
+    """BASELINE config 4's code path end to end through bench.py's OWN spawn path (`python bench.py --gpus 2`, no torchrun): the parent starts two
+    fresh ranks (gloo, both on this box's one GPU), rank r renders row tile r with one nrf_render_rows call, the tiles are all-gathered, and the
+    gathered 800x800 frame must equal the single-rank frame bit for bit (sha256 of the pixel buffer, printed in both result lines)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-also"]
+    env = dict(os.environ, NRF_BENCH_TIMEOUT="600")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l1 = json.loads([x for x in one.stdout.splitlines() if x.startswith("{")][-1])
+    l2 = json.loads([x for x in two.stdout.splitlines() if x.startswith("{")][-1])
+    assert len([x for x in two.stdout.splitlines() if x.startswith("{")]) == 1, "ONE JSON line"
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "strong" and l2["config"]["frames_per_step"] == 1 and l2["tile_rows"] == 400
+    assert l1["n_gpus"] == 1 and l1["tile_rows"] == 800
+    assert l1["frame_sha256"] == l2["frame_sha256"], "gathered frame of 2 row tiles == the single-rank frame, bit for bit"
+    assert l2["host_ms_per_tile"] < 5.0
+    # a rank that dies must fail the launcher (non-zero exit), not hang it: its peer waits in the rendezvous and is ended by the parent
+    t0 = __import__("time").time()
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common,
+                         capture_output=True, text=True, timeout=600, env=dict(env, NRF_BENCH_TEST_FAIL_RANK="1"))
+    assert bad.returncode != 0 and "rank exit codes" in bad.stderr and __import__("time").time() - t0 < 300

@@ -244,3 +244,18 @@ def test_written_checkpoints_restore_a_reference_model(tmp_path):
     back = CK.LoadCheckpoint(d)
     assert back["would_restore"] and back["optimizer"]["step"] == 41 and back["optimizer"]["moments"][2] is None
     np.testing.assert_array_equal(back["optimizer"]["moments"][5][1], mom[5][1])
+
+
+def test_bench_launcher_reports_failing_ranks_without_hanging():
+    """`python bench.py --gpus 2` with no launcher: the parent starts the ranks itself and must return non-zero -- promptly -- when a rank fails
+    (here rank 1 exits at start-up through the test hook; on a box without a GPU rank 0 fails too, at its "needs MI355X" assertion)."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-also", "--no-parity"], capture_output=True, text=True, timeout=300, env=dict(os.environ, NRF_BENCH_TEST_FAIL_RANK="1", NRF_BENCH_TIMEOUT="120"))
+    assert r.returncode != 0 and "rank exit codes" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 200
+    assert not [x for x in r.stdout.splitlines() if x.startswith("{")], "no result line from a failed run"
+    # contradictory flags are rejected by the parent before anything is started
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--collective", "cabi"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cabi" in r.stderr
