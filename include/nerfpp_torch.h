@@ -187,9 +187,11 @@ public:
 		for (size_t i = 0; i < LevelEmbeddings->size(); i++) lv.push_back(LevelEmbeddings[i]->as<torch::nn::Embedding>()->weight.detach());
 		return torch::cat(lv, 0);
 	}
+	/// torch::load re-homes parameters on the device they were SAVED from (a CPU-written checkpoint leaves them on the CPU; the executor follows its loads with
+	/// ->to(device), NeRFExecutor.h:552-556): the upload below takes them from wherever they are.
 	void Sync()
 	{
-		auto emb = dev_f32(Table());
+		auto emb = dev_f32(Table().to(torch::kCUDA));
 		check(nrf_hash_set_table(Handle, emb.data_ptr<float>(), 1, current_stream()), "nrf_hash_set_table");
 		if (Mode == NRF_HASH_CU) {
 			auto p = Primes.to(torch::kCPU, torch::kInt32).contiguous();

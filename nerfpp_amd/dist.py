@@ -46,7 +46,7 @@ class TileShard:
         if f == 1 and self.rows == self.max_rows and self.h == self.world * self.rows:
             # one frame, equal tiles (800 rows over 2 / 4 / 8 ranks): the gathered buffer IS the frame -- no copy after the collective
             out = torch.empty((1, self.h, w, c), device=local.device, dtype=local.dtype)
-            dist.all_gather_into_tensor(out.view(self.world, self.rows, w, c), local.view(self.rows, w, c))
+            dist.all_gather_into_tensor(out.view(self.h, w, c), local.view(self.rows, w, c))         # dim-0 concatenation of the tiles = the frame's rows
             return out
         out = torch.empty((self.world * f,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         dist.all_gather_into_tensor(out, local)                                           # ncclAllGather over xGMI (dim-0 concatenation)

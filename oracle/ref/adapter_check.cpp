@@ -214,13 +214,14 @@ int main(int argc, const char **argv)
 		if (ck) {
 			// the reference-written fixtures (tests/golden/ckpt, ref_driver ckpt_save) straight into the adapter modules with torch::load
 			torch::load(cu, std::string(ck) + "/cu_embedder_checkpoint.pt");
+			cu->to(torch::kCUDA);                                                               // as the executor does after its loads (NeRFExecutor.h:552-556)
 			cu->Sync();
 			auto p2 = cu->Primes.cpu().reshape({-1});
 			load_cu_ok = p2[0].item<int>() == 268435459 && p2[5].item<int>() == 268435469 && (cu->Biases.cpu() == 0.25f).all().item<bool>() &&
 				torch::isfinite(cu->forward(xs).first).all().item<bool>();
 			nrfpp::HipHashEmbedder ng("embedder", bbox, SL, SF, ST, 16, 128, NRF_HASH_NGP);
 			torch::load(ng, std::string(ck) + "/embedder_checkpoint.pt");
-			ng->Sync();
+			ng->Sync();                                                                         // (left on the CPU on purpose: Sync uploads from wherever the parameters are)
 			HashEmbedder e_ref("embedder", bbox, SL, SF, ST, 16, 128);
 			torch::load(e_ref, std::string(ck) + "/embedder_checkpoint.pt");
 			auto xc = xs.cpu();

