@@ -55,6 +55,14 @@ SMALL_MFMA_FLOP_PER_UNIT = {"f16": 40 * 32768 // 32, "f16x3": 116 * 32768 // 32}
 NERF_FLOP_PER_UNIT = 1186816
 # the coarse pass of the default mode needs sigma only (NeRFRenderer.h:422-428): in 32 -> 64 -> 64 -> 1
 SIGMA_FLOP_PER_UNIT = 2 * (32 * 64 + 64 * 64 + 64)
+# LeRF head at main.cpp:203-213 sizes: 128 -> 256 -> 33 ; cat[geo32, in128] -> 256 -> 768, bias-free
+LERF_FLOP_PER_UNIT = 557568
+LERF_SIGMA_FLOP_PER_UNIT = 2 * (128 * 256 + 256 * 33)                        # the density net alone (the coarse pass's exact-fp32 kernel, geo rows included)
+# matrix instructions (32x32x16 fp16 = 32 768 flop) the split-precision LeRF passes issue per 32 points: the sigma pass on the new samples (layer 0 on exact-fp16
+# features: 2 products, layer 1: 3) and the embedding pass from LE0 on (LE0: 8 tiles x (8 x 2 + 4 x 3), Gram: 8 x 16 x 3); the 256 -> 768 layer runs once per RAY
+LERF_SPLIT_MFMA_SIGMA = 8 * 8 * 2 + 2 * 16 * 3
+LERF_SPLIT_MFMA_EMBED = 8 * (8 * 2 + 4 * 3) + 8 * 16 * 3
+LERF_HASH_BYTES_PER_UNIT = 16 * 8 * 8 * 2 + 12 + 16 * 8 * 2                    # CuHash F = 8: 2 048 B of table reads + the point + 256 B of level-major fp16 features
 HBM_PEAK = 8.0e12
 MFMA_F16_PEAK = 2.5e15
 # MI355X_MICROARCH.md, "DVFS give-back" item 1: the chip lowers its clock under matrix load; a tuned bf16 GEMM on random data holds 1.90-1.95 GHz and
@@ -345,12 +353,15 @@ def main():
             # The baked pyramid is read through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), so the bound is the vector-memory GATHER
             # path, not HBM: `achieved` prices the algorithmic bytes (588 B per unit) against the guide's measured ceiling for cache-resident
             # gathers; hbm_frac is what the HBM counters saw, against the 8 TB/s SURVEY 8d names.
-            roof = dict(bound="gather (L2 / Infinity Cache; table reads are cache-resident)", kernel="hash_encode", achieved=achieved / 1e9, peak=GATHER_PEAK_L2 / 1e9,
-                        unit="GB/s", frac=achieved / GATHER_PEAK_L2, over_infinity_cache_gather_rate=achieved / GATHER_PEAK,
+            # achieved = algorithmic bytes (588 B per point the kernel encoded) / kernel time, against the 8 TB/s HBM peak.  The baked pyramid is read
+            # through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), which is how `frac` can exceed 1; the ceilings of the vector-memory
+            # gather path the kernel really runs on ride along (frac_of_l2_gather_ceiling / over_infinity_cache_gather_rate), and hbm_frac is what the HBM counters saw.
+            roof = dict(bound="hbm", kernel="hash_encode", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9,
+                        unit="GB/s", frac=achieved / HBM_PEAK, frac_of_l2_gather_ceiling=achieved / GATHER_PEAK_L2, over_infinity_cache_gather_rate=achieved / GATHER_PEAK,
                         hbm_frac=(traffic / max(dur, 1e-12) / HBM_PEAK) if traffic else None, algorithmic_over_hbm_peak=achieved / HBM_PEAK,
                         traffic=traffic, traffic_source=traffic_src, launches=k["launches"], avg_launch_ms=dur * 1e3,
                         units_per_launch=units_per_launch, bytes_per_unit=HASH_BYTES_PER_UNIT,
-                        peak_source="MI355X_MICROARCH.md 'Indexed rows: gather': the gather path tops out at 16.8-18.8 TB/s (rows resident in the XCD's L2) = `peak`; "
+                        peak_source="peak = HBM3E 8 TB/s (MI355X_MICROARCH.md; SURVEY 8d).  Gather path, same guide, 'Indexed rows: gather': 16.8-18.8 TB/s with the rows resident in the XCD's L2 (frac_of_l2_gather_ceiling); "
                                     "8.6 TB/s when the rows come from the Infinity Cache (38 MB table), 6.0 TB/s swept from HBM.  The 1.1 GB pyramid's coarse levels are L2-resident, "
                                     "its fine levels are not: the kernel runs between the two rates (over_infinity_cache_gather_rate)")
             # a model that fits the ablations, not a documented figure: a gather whose 64 lanes fall into 64 different lines holds the CU's vector L1 for ~64 clocks; a hash lookup is
@@ -484,9 +495,43 @@ def main():
         os._exit(0)
 
 
-def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
-    """Short extra timings at N = 1 (not part of `value`): the other matrix-core precision of this workload and the other
-    BASELINE workload, each with its render-vs-oracle quality on the same 256-ray sample."""
+def timed_frames(L, render, frames, warm=2):
+    """warm untimed + `frames` timed calls of render() -> (seconds per frame, per-kernel HIP-event ms per frame and launches per frame)."""
+    import ctypes as C
+    import torch
+    for _ in range(warm):
+        render()
+    torch.cuda.synchronize()
+    n = len(L.NRF_PROF_NAMES)
+    ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+    L.lib().nrf_profile_enable(1)
+    L.lib().nrf_profile_read(ms, cnt, 1)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        out = render()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    L.lib().nrf_profile_read(ms, cnt, 1)
+    L.lib().nrf_profile_enable(0)
+    return dt, {nm: dict(ms_per_frame=ms[i] / frames, launches_per_frame=cnt[i] / frames) for i, nm in enumerate(L.NRF_PROF_NAMES)}, out
+
+
+def mfma_roofline(kernel, units, flop_per_unit, seconds, launches, issued_flop_per_unit=None, peak=MFMA_F16_PEAK, note=None):
+    r = dict(bound="mfma", kernel=kernel, achieved=units * flop_per_unit / max(seconds, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+             frac=units * flop_per_unit / max(seconds, 1e-12) / peak, launches=launches, avg_launch_ms=seconds * 1e3 / max(launches, 1),
+             units_per_launch=units / max(launches, 1), flop_per_unit=flop_per_unit)
+    if issued_flop_per_unit:
+        r["mfma_issued_frac"] = units * issued_flop_per_unit / max(seconds, 1e-12) / peak
+        r["mfma_issued_vs_sustained_gemm"] = units * issued_flop_per_unit / max(seconds, 1e-12) / MFMA_F16_SUSTAINED_GEMM
+    if note:
+        r["note"] = note
+    return r
+
+
+def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
+    """Extra timings at N = 1 (not part of `value`): the other matrix-core precision of this workload and the other BASELINE workloads -- each with its own
+    per-kernel HIP-event times, the roofline of its dominant kernel (algorithmic flops of the network as written x the evaluations the kernel executed) and its
+    render-vs-oracle quality on a 256-ray sample."""
     import torch
     out = []
     todo = [("hash", "f16" if args.precision != "f16" else "f16x3"), ("classic", "f16x3"), ("classic", "f16")] if args.workload == "hash" else \
@@ -499,18 +544,28 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
             sc = scenes[wl]
             prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[pname]
             rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072 if wl == "hash" else 8192, prec)
-            for _ in range(2):
-                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), steps)
             a2 = argparse.Namespace(**{**vars(args), "workload": wl, "precision": pname})
-            out.append(dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
-                            precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps,
-                            psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
+            ex_hash, ex_mlp, ex_sigma = executed_per_ray(wl, pname, args.hash_mode)
+            rec = dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
+                       precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=kms,
+                       executed_evaluations_per_ray=dict(hash_encode=ex_hash, fused_mlp=ex_mlp, sigma_only=ex_sigma))
+            mk = kms["mlp"]
+            if wl == "classic":
+                rec["roofline"] = mfma_roofline("mlp_nerf" + ("_split" if pname == "f16x3" else ""), H * W * ex_mlp, NERF_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3,
+                                                mk["launches_per_frame"], issued_flop_per_unit=(3.0 if pname == "f16x3" else 1.0) * 1058 * 32768 / 32,
+                                                note="algorithmic 1 186 816 flop of NeRFImpl::forward as written x the network evaluations the kernel executed "
+                                                     "(192 per ray: the fine pass's 64 coarse depths take the coarse pass's outputs); issued: 1 058 matrix instructions per 32 points"
+                                                     + (" x 3 products (hi + lo operand pairs)" if pname == "f16x3" else ""))
+            else:
+                rec["roofline"] = mfma_roofline("mlp_small", H * W * ex_mlp, SMALL_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
+                                                issued_flop_per_unit=SMALL_MFMA_FLOP_PER_UNIT.get(pname))
+                hk = kms["hash"]
+                rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode", unit="GB/s", peak=HBM_PEAK / 1e9,
+                                               achieved=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / 1e9,
+                                               frac=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / HBM_PEAK)
+            rec["psnr_vs_oracle_db"] = quality_check(sc, sc["renderer"], rp, K, c2w, a2)
+            out.append(rec)
         except Exception as e:
             out.append(dict(workload=wl, precision=pname, error=str(e)))
     if args.workload == "hash" and args.hash_mode == "cu":
@@ -519,17 +574,10 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
         try:
             sc = scene.make_hash_scene(mode="ngp")
             rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072, L.NRF_PREC_F16_SPLIT)
-            for _ in range(2):
-                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                sc["renderer"].Render(H, W, K, rp, c2w=c2w)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 3
+            dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), steps)
             a2 = argparse.Namespace(**{**vars(args), "workload": "hash", "precision": "f16x3", "hash_mode": "ngp"})
             out.append(dict(workload="hashnerf_lego800_64+128", baseline_config=2, encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3",
-                            value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=3,
+                            value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=kms,
                             psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
             del sc
             torch.cuda.empty_cache()
@@ -541,15 +589,52 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=5):
         out.append(dict(workload="hashnerf_train_step", error=str(e)))
     for lp in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA):
         try:
-            out.append(lerf_measurement(scene, K, c2w, lp))
+            out.append(lerf_measurement(scene, L, K, c2w, lp))
         except Exception as e:
             out.append(dict(workload="lerf_lego800_64+128", error=str(e)))
     return out
 
 
-def lerf_measurement(scene, K, c2w, precision, repeats=3):
-    """BASELINE config 4: the LeRF language-embedding render pass (CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768, main.cpp:203-213)
-    on the WHOLE 800x800 frame, 64+128 samples: one warm-up frame, then `repeats` timed frames."""
+def lerf_oracle_check(sc, res, nrays=256):
+    """`nrays` rays of the LeRF frame end to end through the CPU oracle's fp32 stage path (CuHash F = 8 encode -> LeRFImpl::forward -> RawToLEOutputs weights ->
+    SamplePDF -> fine pass -> RenderCLIPEmbedding): sample set, weights and rendered embedding of the GPU pass against it.  Checker use of oracle/ only."""
+    import torch
+    from oracle import capi as O
+    from nerfpp_amd import scene
+    acc = res.Outputs.AccMapLE.cpu().numpy()
+    hit = np.nonzero(acc > 1e-2)[0]
+    idx = hit[::max(1, hit.size // nrays)][:nrays]
+    rays = res.Extras["rays_flat"].cpu().numpy()[idx]
+    Lv, F, T = 16, 8, 19
+    ls = ((1 << T) >> 4) << 4
+    tab16 = O.f32_to_f16(sc["table"])
+    mul = O.hash_cu_scales(Lv, 16, 1024)
+
+    def net(pts):
+        e_, keep = O.hash_cu(pts.reshape(-1, 3), tab16, sc["primes"], np.arange(Lv, dtype=np.int32) * ls, np.full(Lv, ls, np.int32), np.zeros((Lv, 3), np.float32), sc["bbox"], mul, Lv, F)
+        o = O.lerf(sc["blob"], e_)
+        o[~keep, -1] = 0
+        return o.reshape(pts.shape[0], pts.shape[1], -1)
+    zc = O.z_vals(rays[:, 6], rays[:, 7], O.linspace(0, 1, NS))
+    wc = O.raw2weights(net(O.points(rays[:, :3], rays[:, 3:6], zc)), 768, zc, rays[:, 3:6])["weights"]
+    samples, _, _ = O.sample_pdf(O.z_mid(zc), wc[:, 1:-1], O.linspace(0, 1, NI))
+    zf = O.merge_sorted(zc, samples)
+    rawf = net(O.points(rays[:, :3], rays[:, 3:6], zf))
+    fin = O.raw2weights(rawf, 768, zf, rays[:, 3:6])
+    ref = O.render_clip_embedding(rawf, 768, fin["weights"])
+    zg = res.Extras["z_fine"].cpu().numpy()[idx]
+    wg = res.Outputs.WeightsLE.cpu().numpy()[idx]
+    eg = res.Outputs.RenderedLangEmbedding.cpu().numpy()[idx]
+    cos = (eg * ref).sum(1)
+    same = (zg == zf).all(1)
+    return dict(rays=int(idx.size), fine_sample_set_bit_identical_rays=float(same.mean()), weights_max_abs_err_over_max=float(np.abs(wg - fin["weights"])[same].max() / fin["weights"].max()) if same.any() else None,
+                embedding_cos_min=float(cos.min()), embedding_cos_min_same_samples=float(cos[same].min()) if same.any() else None, embedding_cos_median=float(np.median(cos)),
+                against="CPU oracle, fp32 stage path end to end (its own coarse pass and fine sample set)")
+
+
+def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
+    """BASELINE config 5: the LeRF language-embedding render pass (CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768, main.cpp:203-213)
+    on the WHOLE 800x800 frame, 64+128 samples: warm-up, then `repeats` timed frames with per-kernel HIP-event times, rooflines and an oracle check of 256 rays."""
     import torch
     from nerfpp_amd import renderer as R
     sc = scene.make_lerf_scene()
@@ -557,26 +642,49 @@ def lerf_measurement(scene, K, c2w, precision, repeats=3):
                            BoundingBox=sc["bbox"])
     r = sc["renderer"]
     r.set_precision(precision)
-    r.Render(H, W, K, p, c2w=c2w)
-    torch.cuda.synchronize()
-    times = []
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        res = r.Render(H, W, K, p, c2w=c2w)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    dt = sum(times) / len(times)
+    dt, kms, res = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1)
     n = H * W
     emb = res.Outputs.RenderedLangEmbedding
     hit = res.Outputs.AccMapLE > 1e-2
     nrm = emb[hit].norm(dim=1)
-    return dict(workload="lerf_lego800_64+128", baseline_config=4, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt, frames_timed=repeats,
-                s_per_frame_min_max=[min(times), max(times)], fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
-                rays_with_language_density=int(hit.sum()), embedding_norm_min_max=[float(nrm.min()), float(nrm.max())] if int(hit.sum()) else None,
-                level_major_features=bool(getattr(r, "level_major", False)), precision=getattr(r, "precision_name", "f16"),
-                arithmetic=("split-f16 MFMA (hi + lo operand pairs, three products, fp32 accumulate: fp32-grade)" if r.precision_name == "f16x3" else "fp16 MFMA (fp32 accumulate)") +
-                           " LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
-                           "read by the kernels as operand fragments; embedding norm via the Gram matrix of the bias-free output layer, which is applied once per ray to the weighted sum of its inputs")
+    split = r.precision_name == "f16x3"
+    exact = bool(split and r._exact_coarse_on())
+    rec = dict(workload="lerf_lego800_64+128", baseline_config=5, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt, frames_timed=repeats, kernel_ms=kms,
+               fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
+               rays_with_language_density=int(hit.sum()), embedding_norm_min_max=[float(nrm.min()), float(nrm.max())] if int(hit.sum()) else None,
+               level_major_features=bool(getattr(r, "level_major", False)), precision=getattr(r, "precision_name", "f16"),
+               coarse_pass="sigma_le in exact fp32 on the matrix cores (sigma_lerf_f32.hip): the fp32 path's fine sample set" if exact else "the timed arithmetic",
+               executed_evaluations_per_ray=dict(hash_encode=NS + NI, density_net=NS + NI, embedding_net=NS + NI,
+                                                 note="every sample point is encoded once and its density net evaluated once (the fine pass's 64 coarse depths reuse the coarse pass's columns)"),
+               arithmetic=("split-f16 MFMA (hi + lo operand pairs, three products, fp32 accumulate: fp32-grade)" if split else "fp16 MFMA (fp32 accumulate)") +
+                          " LeRF head fused with the render pass; CuHash F=8 features level-major fp16 (256 B per sample point), "
+                          "read by the kernels as operand fragments; embedding norm via the Gram matrix of the bias-free output layer, which is applied once per ray to the weighted sum of its inputs")
+    # rooflines: algorithmic flops of LeRFImpl::forward as written (557 568 per sample, the 256 -> 768 layer per SAMPLE) x the 192 evaluations per ray the passes execute
+    mk, sk, hk = kms["mlp"], kms["sigma"], kms["hash"]
+    units = n * (NS + NI)
+    t_mlp = (mk["ms_per_frame"] + sk["ms_per_frame"]) * 1e-3
+    issued = None
+    if split:
+        new_pts, all_pts = n * NI, n * (NS + NI)
+        issued_f16 = ((new_pts if exact else all_pts) * LERF_SPLIT_MFMA_SIGMA + all_pts * LERF_SPLIT_MFMA_EMBED) * 32768 / 32 + n * 24 * 16 * 3 * 32768 / 32
+        issued = issued_f16 / units
+    rec["roofline"] = mfma_roofline("lerf passes (density net + embedding net + per-ray output layer" + ("; coarse density net: exact-fp32 kernel, in `sigma_exact`" if exact else "") + ")",
+                                    units, LERF_FLOP_PER_UNIT, t_mlp, mk["launches_per_frame"] + sk["launches_per_frame"], issued_flop_per_unit=issued,
+                                    note="achieved / frac price the ALGORITHMIC 557 568 flop per sample of LeRFImpl::forward as written over the time of ALL LeRF network kernels; the kernels "
+                                         "execute far fewer (Gram-matrix norm, output layer once per ray): mfma_issued_frac is the fp16 matrix pipe's own share")
+    if exact and sk["launches_per_frame"]:
+        rec["roofline"]["sigma_exact"] = mfma_roofline("lerf_sigma_f32 (coarse pass: density net in exact fp32, v_mfma_f32_32x32x2_f32)", n * NS, LERF_SIGMA_FLOP_PER_UNIT, sk["ms_per_frame"] * 1e-3,
+                                                       sk["launches_per_frame"], peak=F32_PEAK)
+    if hk["launches_per_frame"]:
+        b = units * LERF_HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12)
+        rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode F=8 (k_hash_cu, level-major fp16 out)", unit="GB/s", achieved=b / 1e9, peak=HBM_PEAK / 1e9, frac=b / HBM_PEAK,
+                                       frac_of_infinity_cache_gather_rate=b / GATHER_PEAK, bytes_per_unit=LERF_HASH_BYTES_PER_UNIT, units_per_frame=units,
+                                       note="the 134 MB hashed table is Infinity-Cache resident: the gather path's ceiling for such tables is 8.6 TB/s (MI355X_MICROARCH.md)")
+    try:
+        rec["oracle_check"] = lerf_oracle_check(sc, res)
+    except Exception as e:
+        rec["oracle_check"] = f"unavailable: {e}"
+    return rec
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):
@@ -629,16 +737,41 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     return rec
 
 
+# source files whose contents decide a kernel's HBM traffic: the PMC summary records their hashes, and a summary taken from other sources is not reported
+PMC_KERNEL_SOURCES = {
+    "hash_encode (k_hash_cu_lm)": ["hash_fast.hip", "hash_fast.h", "encode.h"],
+    "mlp_small (k_mlp_small_mfma)": ["mlp_small_mfma.hip"],
+    "sigma_small_f32 (k_sigma_small_f32)": ["sigma_small_f32.hip"],
+    "mlp_nerf_split (k_mlp_nerf_split)": ["mlp_nerf_split_mfma.hip", "mlp_nerf_net.h"],
+    "mlp_nerf (k_mlp_nerf_mfma)": ["mlp_nerf_mfma.hip", "mlp_nerf_net.h"],
+}
+
+
+def kernel_source_hash(kernel):
+    import hashlib
+    h = hashlib.sha256()
+    for f in PMC_KERNEL_SOURCES.get(kernel, []):
+        with open(os.path.join(ROOT, "nerfpp_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, units_per_launch, meta_key=None):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written from separate --pmc FETCH_SIZE / WRITE_SIZE
-    runs of this same bench: bytes per point the kernel processed), times this run's points per launch.  None if no PMC summary is committed."""
+    runs of this same bench: bytes per point the kernel processed), times this run's points per launch.  The summary is stamped with the commit it was taken at
+    and with a hash of each kernel's sources: if the kernel's source differs from what was profiled, NO traffic is reported (None) and the reason is given."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
-        return d[kernel]["hbm_bytes_per_point"] * units_per_launch, ("profiles/pmc_latest.json: (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch (gfx950 x2 read correction) summed over "
-                                                                    "`bench.py --steps 1 --warmup 1` and divided by the points processed; " + d["_meta"]["source"])
+        meta = d["_meta"]
+        stamp = "PMC pass at commit " + str(meta.get("commit", "unrecorded (round 2)"))
+        want = (meta.get("kernel_source_sha256_16") or {}).get(kernel)
+        if want is None or want != kernel_source_hash(kernel):
+            return None, f"not reported: the kernel's sources changed since the {stamp} (profiles/pmc_latest.json); re-run tools/gpu_pmc_round.sh"
+        return d[kernel]["hbm_bytes_per_point"] * units_per_launch, ("profiles/pmc_latest.json, " + stamp + ", kernel sources unchanged since: (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch "
+                                                                    "(gfx950 x2 read correction) summed over `bench.py --steps 1 --warmup 1` and divided by the points processed; " + meta["source"])
     except Exception:
         return None, None
 

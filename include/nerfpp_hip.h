@@ -272,6 +272,14 @@ NRF_API int nrf_lerf_sigma_lm_strided(const nrf_mlp *m, const void *d_feats_lm, 
 NRF_API size_t nrf_lerf_geo_bytes(int64_t columns);
 NRF_API int nrf_lerf_sigma_geo_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma,
                                           void *d_geo, int64_t geo_stride, void *stream);
+/* The LeRF density net in EXACT fp32 on the matrix cores (sigma_lerf_f32.hip): d_sigma equals nrf_mlp_forward(..., NRF_PREC_F32)[..., -1] -- and the CPU oracle --
+ * bit for bit (v_mfma_f32_32x32x2_f32 == the ascending-k fmaf chain), at ~0.8 of the 157 TFLOP/s fp32 matrix peak.  The coarse pass of a hierarchical LeRF render
+ * consumes nothing but sigma_le (LeRFRenderer.cpp:139-170) and its weights choose the fine samples through a discontinuous function, so the split-precision render
+ * runs its coarse pass through this entry: the fine sample set is then the fp32 path's own.  d_geo (optional): also leaves (sigma, geo32) as the (hi, lo) operand
+ * planes of nrf_lerf_render_embedding_lm_geo, split from the exact values.  Level-major CuHashEmbedder features, same column conventions as the _strided entries. */
+NRF_API int nrf_lerf_sigma_exact_available(const nrf_mlp *m);
+NRF_API int nrf_lerf_sigma_exact_lm_strided(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const uint8_t *d_keep, int64_t p, float *d_sigma,
+                                            void *d_geo, int64_t geo_stride, void *stream);
 NRF_API int nrf_lerf_render_embedding_lm_geo(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const void *d_geo,
                                              int64_t geo_stride, const float *d_weights, int64_t n, int s, float *d_out, void *stream);
 NRF_API int nrf_lerf_render_embedding_lm_gather(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const float *d_weights, int64_t n,
@@ -535,11 +543,15 @@ typedef struct nrf_comm nrf_comm;
  * (it is not destroyed by nrf_comm_destroy). */
 NRF_API int nrf_comm_unique_id(void *id_out);
 NRF_API int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out);
+/* ... with a bounded rendezvous: the communicator is initialised non-blocking and polled; after timeout_s seconds without all `world` ranks it is aborted and
+ * NRF_ERR_HIP returned (a peer that never started, or an id of another launch).  timeout_s <= 0 waits for ever.  nrf_comm_create itself uses
+ * NRF_COMM_TIMEOUT_S from the environment (default 300). */
+NRF_API int nrf_comm_create_timeout(const void *id, int world, int rank, double timeout_s, nrf_comm **out);
 NRF_API int nrf_comm_wrap(void *nccl_comm, nrf_comm **out);
 NRF_API void nrf_comm_destroy(nrf_comm *c);
 NRF_API int nrf_comm_world(const nrf_comm *c);
 NRF_API int nrf_comm_rank(const nrf_comm *c);
-/* d_tiles: this rank's [frames, rows_rank, w, c] fp32 tiles of `frames` images (rows_rank from nrf_tile_partition);
+/* d_tiles: this rank's [frames, rows_rank, w, c] fp32 tiles of `frames` images (rows_rank from nrf_tile_partition; may be NULL on a rank that owns no rows, h < world);
  * d_frames: [frames, h, w, c] on every rank.  One fused launch on `stream` (ncclAllGather per frame when h % world == 0, grouped
  * ncclBroadcast per tile otherwise); asynchronous like every other call.  d_tiles and d_frames must not overlap. */
 NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int h, int w, int c_channels, float *d_frames, void *stream);

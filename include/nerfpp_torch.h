@@ -28,6 +28,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -222,26 +223,38 @@ public:
 	/// Rendezvous through the filesystem (launchers that give every rank WORLD_SIZE / RANK and a shared directory need nothing else): rank 0 asks the
 	/// library for the RCCL unique id and publishes it at `id_path` (written to a temporary name, then renamed: readers never see a partial file); the other
 	/// ranks wait for it.  Call after hipSetDevice / c10::hip::set_device: the communicator binds to the calling thread's current device.
-	TileComm(int world, int rank, const std::string &id_path, double timeout_s = 120.0) : World(world), Rank(rank)
+	/// `launch_tag` must be the SAME string on every rank of one launch and DIFFERENT between launches that share `id_path` (a job id, the launcher's start
+	/// time, MASTER_PORT): the file carries it in its header and a reader ignores a file with another tag -- so a file left behind by an earlier run is never
+	/// taken for this run's id (with an empty tag, `id_path` itself must be unique per launch; rank 0 then removes any existing file first).  Rank 0 unlinks the
+	/// file once the communicator exists (every rank has read it by then).  Both the wait for the file and the communicator's own rendezvous are bounded by
+	/// `timeout_s` (nrf_comm_create_timeout): a peer that never arrives raises instead of parking this rank for ever.
+	TileComm(int world, int rank, const std::string &id_path, double timeout_s = 120.0, const std::string &launch_tag = "") : World(world), Rank(rank)
 	{
 		unsigned char id[NRF_COMM_ID_BYTES];
+		char tag[64] = {0};
+		std::snprintf(tag, sizeof(tag), "%s", launch_tag.c_str());
 		if (rank == 0) {
 			check(nrf_comm_unique_id(id), "nrf_comm_unique_id");
 			if (world > 1) {
+				std::remove(id_path.c_str());                            // a stale file of an earlier launch
 				const std::string tmp = id_path + ".tmp";
-				{ std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id), sizeof(id)); }
+				{ std::ofstream f(tmp, std::ios::binary); f.write(tag, sizeof(tag)); f.write(reinterpret_cast<const char *>(id), sizeof(id)); }
 				if (std::rename(tmp.c_str(), id_path.c_str()) != 0) throw std::runtime_error("TileComm: cannot publish the communicator id at " + id_path);
 			}
 		} else {
 			const auto t0 = std::chrono::steady_clock::now();
 			for (;;) {
 				std::ifstream f(id_path, std::ios::binary);
-				if (f && f.read(reinterpret_cast<char *>(id), sizeof(id)) && f.gcount() == (std::streamsize)sizeof(id)) break;
-				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) throw std::runtime_error("TileComm: no communicator id at " + id_path);
+				char got[64];
+				if (f && f.read(got, sizeof(got)) && f.read(reinterpret_cast<char *>(id), sizeof(id)) && f.gcount() == (std::streamsize)sizeof(id) &&
+					std::memcmp(got, tag, sizeof(tag)) == 0) break;
+				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+					throw std::runtime_error("TileComm: no communicator id of this launch at " + id_path);
 				std::this_thread::sleep_for(std::chrono::milliseconds(20));
 			}
 		}
-		check(nrf_comm_create(id, world, rank, &Comm), "nrf_comm_create");
+		check(nrf_comm_create_timeout(id, world, rank, timeout_s, &Comm), "nrf_comm_create");
+		if (rank == 0 && world > 1) std::remove(id_path.c_str());
 	}
 	/// Adopt a live ncclComm_t the host already owns (not destroyed here).
 	explicit TileComm(void *nccl_comm) { check(nrf_comm_wrap(nccl_comm, &Comm), "nrf_comm_wrap"); World = nrf_comm_world(Comm); Rank = nrf_comm_rank(Comm); }
@@ -366,7 +379,9 @@ public:
 
 private:
 	/// one pass of the fused path over [n, s] depths: sigma_le -> weights (-> rendered embedding)
-	LeRFPassOutputs FusedPass(torch::Tensor rays, torch::Tensor z, torch::Tensor rays_d, bool want_embedding)
+	bool ExactCoarseOn() const { return ExactCoarse && Precision == NRF_PREC_F16_SPLIT && nrf_lerf_sigma_exact_available(Mlp.m) != 0; }
+
+	LeRFPassOutputs FusedPass(torch::Tensor rays, torch::Tensor z, torch::Tensor rays_d, bool want_embedding, bool exact = false)
 	{
 		const int64_t n = z.size(0); const int s = (int)z.size(1); const int stride = (int)rays.size(1);
 		auto opt = rays.options();
@@ -377,7 +392,8 @@ private:
 		if (LevelMajor) {
 			x = torch::empty({16, n * s, 8}, opt.dtype(torch::kFloat16)); keep = torch::empty({n * s}, opt.dtype(torch::kUInt8));
 			check(nrf_hash_encode_lm_f16(LangEmbedFn->GetHandle(), pts.data_ptr<float>(), n * s, x.data_ptr(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16");
-			check(nrf_lerf_sigma_lm(Mlp.m, x.data_ptr(), keep.data_ptr<uint8_t>(), n * s, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma_lm");
+			if (exact) check(nrf_lerf_sigma_exact_lm_strided(Mlp.m, x.data_ptr(), n * s, keep.data_ptr<uint8_t>(), n * s, sig.data_ptr<float>(), nullptr, 0, current_stream()), "nrf_lerf_sigma_exact_lm_strided");
+			else check(nrf_lerf_sigma_lm(Mlp.m, x.data_ptr(), keep.data_ptr<uint8_t>(), n * s, sig.data_ptr<float>(), current_stream()), "nrf_lerf_sigma_lm");
 		} else {
 			torch::Tensor kb;
 			std::tie(x, kb) = LangEmbedFn->forward(pts);
@@ -423,7 +439,11 @@ private:
 			if (hand_over) check(nrf_lerf_sigma_geo_lm_strided(Mlp.m, xp, cols, kp, count, sp, static_cast<char *>(geo.data_ptr()) + col0 * 32, cols, current_stream()), "nrf_lerf_sigma_geo_lm_strided");
 			else check(nrf_lerf_sigma_lm_strided(Mlp.m, xp, cols, kp, count, sp, current_stream()), "nrf_lerf_sigma_lm_strided");
 		};
-		sigma_pass(x.data_ptr(), keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), 0);
+		// split precision: the COARSE columns' sigma_le in exact fp32 on the matrix cores (its weights choose the fine samples through a discontinuous function, so the
+		// sample set is then the fp32 path's own, bit for bit) -- and, with the hand-over, the sigma net's geo output split from the exact values
+		if (ExactCoarseOn()) check(nrf_lerf_sigma_exact_lm_strided(Mlp.m, x.data_ptr(), cols, keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), hand_over ? geo.data_ptr() : nullptr, cols,
+			current_stream()), "nrf_lerf_sigma_exact_lm_strided");
+		else sigma_pass(x.data_ptr(), keep.data_ptr<uint8_t>(), nc, sig.data_ptr<float>(), 0);
 		auto weights = [&](const float *sg, torch::Tensor zz, int ss) {
 			LeRFPassOutputs o;
 			o.WeightsLE = torch::empty({n, (int64_t)ss}, opt); o.DepthMapLE = torch::empty({n}, opt); o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt);
@@ -460,6 +480,7 @@ private:
 public:
 	bool ReuseFeatures = true;          ///< level-major fused path: encode every sample point once per render (false: two plain passes)
 	bool HandOverGeo = true;            ///< split precision, reuse path: the embedding pass takes the sigma net's output from the sigma pass (false: re-evaluates it)
+	bool ExactCoarse = true;            ///< split precision: the coarse pass's sigma_le in exact fp32 on the matrix cores (sigma_lerf_f32.hip): the fp32 path's sample set
 
 	/// LeRFRenderer::RenderRays (LeRFRenderer.cpp:85-187), deterministic path (Perturb = 0, RawNoiseStd = 0, ThinRay): the fused matrix-core passes when the
 	/// sample counts are multiples of 32 (a wave's 32-point tile lies inside one ray), the fp32 stage path otherwise.  z_fine (optional) receives the fine depths.
@@ -486,7 +507,7 @@ public:
 			if (!return_weights) { out.WeightsLE = torch::Tensor(); out.LangEmbedding = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }
 			return out;
 		}
-		LeRFPassOutputs out = fused ? FusedPass(rays, z, rays_d, ni == 0) : stage(z);
+		LeRFPassOutputs out = fused ? FusedPass(rays, z, rays_d, ni == 0, ni > 0 && LevelMajor && ExactCoarseOn()) : stage(z);
 		if (ni > 0) {
 			auto u = torch::linspace(0.f, 1.f, ni, torch::kFloat).to(rays.device());
 			auto zf = torch::empty({n, (int64_t)(s + ni)}, opt);

@@ -15,7 +15,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 struct nrf_comm {
     ncclComm_t comm = nullptr;
@@ -37,6 +39,10 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    // optional (bounded rendezvous): a non-blocking communicator init that can be polled and aborted
+    decltype(&ncclCommInitRankConfig) CommInitRankConfig = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
 };
 
 static Rccl g_rccl;
@@ -60,6 +66,9 @@ static void rccl_load()
     NRF_SYM(Broadcast, "ncclBroadcast"); NRF_SYM(GroupStart, "ncclGroupStart"); NRF_SYM(GroupEnd, "ncclGroupEnd");
     NRF_SYM(GetErrorString, "ncclGetErrorString");
 #undef NRF_SYM
+    r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(dlsym(h, "ncclCommInitRankConfig"));
+    r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
     if (ok) g_rccl = r;
 }
 
@@ -112,7 +121,7 @@ int nrf_comm_unique_id(void *id_out)
     return NRF_OK;
 }
 
-int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out)
+int nrf_comm_create_timeout(const void *id, int world, int rank, double timeout_s, nrf_comm **out)
 {
     NRF_CHECK_ARG(id && out, "nrf_comm_create: null pointer");
     NRF_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "nrf_comm_create: need 0 <= rank < world (world %d, rank %d)", world, rank);
@@ -121,11 +130,43 @@ int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclComm_t c = nullptr;
-    NRF_NCCL(R, R->CommInitRank(&c, world, uid, rank));     // on the calling thread's current HIP device; blocks until all ranks arrive
+    if (timeout_s > 0.0 && R->CommInitRankConfig && R->CommGetAsyncError && R->CommAbort) {
+        // bounded rendezvous: non-blocking init, polled until every rank has arrived or the deadline passes (a peer that never starts -- or one that was
+        // handed a stale id -- would otherwise park this rank in ncclCommInitRank for ever); on timeout the half-built communicator is aborted
+        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+        cfg.blocking = 0;
+        ncclResult_t e = R->CommInitRankConfig(&c, world, uid, rank, &cfg);
+        if (e != ncclSuccess && e != ncclInProgress) { set_error("ncclCommInitRankConfig failed: %s", R->GetErrorString(e)); return NRF_ERR_HIP; }
+        const auto t0 = std::chrono::steady_clock::now();
+        ncclResult_t st = ncclInProgress;
+        for (;;) {
+            e = R->CommGetAsyncError(c, &st);
+            if (e != ncclSuccess) { set_error("ncclCommGetAsyncError failed: %s", R->GetErrorString(e)); (void)R->CommAbort(c); return NRF_ERR_HIP; }
+            if (st != ncclInProgress) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                (void)R->CommAbort(c);
+                set_error("nrf_comm_create: rank %d of %d waited %.0f s for its peers (a rank that never started, or a communicator id of another launch); aborted",
+                          rank, world, timeout_s);
+                return NRF_ERR_HIP;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        if (st != ncclSuccess) { set_error("communicator init failed: %s", R->GetErrorString(st)); (void)R->CommAbort(c); return NRF_ERR_HIP; }
+    } else {
+        NRF_NCCL(R, R->CommInitRank(&c, world, uid, rank));     // on the calling thread's current HIP device; blocks until all ranks arrive
+    }
     nrf_comm *cm = new nrf_comm();
     cm->comm = c; cm->world = world; cm->rank = rank; cm->owned = true;
     *out = cm;
     return NRF_OK;
+}
+
+int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out)
+{
+    // default bound: NRF_COMM_TIMEOUT_S seconds (300; 0 = wait for ever, the plain blocking ncclCommInitRank)
+    double t = 300.0;
+    if (const char *e = getenv("NRF_COMM_TIMEOUT_S")) t = atof(e);
+    return nrf_comm_create_timeout(id, world, rank, t, out);
 }
 
 int nrf_comm_wrap(void *nccl_comm, nrf_comm **out)
@@ -156,31 +197,39 @@ int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int
     NRF_CHECK_ARG(c && c->comm, "nrf_allgather_tiles: null communicator");
     NRF_CHECK_ARG(frames >= 0 && h >= 0 && w >= 0 && ch >= 1, "nrf_allgather_tiles: bad sizes");
     if (frames == 0 || h == 0 || w == 0) return NRF_OK;
-    NRF_CHECK_ARG(d_tiles && d_frames, "nrf_allgather_tiles: null pointer");
+    NRF_CHECK_ARG(d_frames, "nrf_allgather_tiles: null pointer");
     const Rccl *R = rccl();
     if (!R) return NRF_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     int row0, rows;
     partition(h, c->world, c->rank, &row0, &rows);
+    // a rank that owns no rows (h < world) has nothing to send: its d_tiles may be NULL -- it still takes part in the collective, or its peers would hang
+    NRF_CHECK_ARG(d_tiles || rows == 0, "nrf_allgather_tiles: null tile buffer on a rank that owns %d rows", rows);
     const size_t px = (size_t)w * ch, tile = (size_t)rows * px, frame = (size_t)h * px;
     const bool even = (h % c->world) == 0;
-    // one fused launch for all frames of the step (ncclGroupStart / End aggregates the operations)
+    // one fused launch for all frames of the step (ncclGroupStart / End aggregates the operations).  The group is closed on EVERY path: the first failure is
+    // remembered, the remaining operations are skipped, GroupEnd runs, and only then is the error returned -- a dangling group would swallow every later
+    // collective of this thread.
     NRF_NCCL(R, R->GroupStart());
-    for (int f = 0; f < frames; f++) {
-        const float *src = d_tiles + (size_t)f * tile;
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (int f = 0; f < frames && first == ncclSuccess; f++) {
+        const float *src = d_tiles ? d_tiles + (size_t)f * tile : d_frames;      // never dereferenced when rows == 0 (this rank is the root of no broadcast)
         float *dst = d_frames + (size_t)f * frame;
         if (even) {
-            NRF_NCCL(R, R->AllGather(src, dst, tile, ncclFloat, c->comm, st));
+            first = R->AllGather(src, dst, tile, ncclFloat, c->comm, st); what = "ncclAllGather";
         } else {
-            for (int r = 0; r < c->world; r++) {
+            for (int r = 0; r < c->world && first == ncclSuccess; r++) {
                 int r0, rr;
                 partition(h, c->world, r, &r0, &rr);
                 if (rr == 0) continue;
-                NRF_NCCL(R, R->Broadcast(src, dst + (size_t)r0 * px, (size_t)rr * px, ncclFloat, r, c->comm, st));   // sendbuff is read on the root only
+                first = R->Broadcast(src, dst + (size_t)r0 * px, (size_t)rr * px, ncclFloat, r, c->comm, st); what = "ncclBroadcast";   // sendbuff is read on the root only
             }
         }
     }
-    NRF_NCCL(R, R->GroupEnd());
+    const ncclResult_t end = R->GroupEnd();
+    if (first != ncclSuccess) { set_error("nrf_allgather_tiles: %s failed: %s", what, R->GetErrorString(first)); return NRF_ERR_HIP; }
+    if (end != ncclSuccess) { set_error("nrf_allgather_tiles: ncclGroupEnd failed: %s", R->GetErrorString(end)); return NRF_ERR_HIP; }
     return NRF_OK;
 }
 

@@ -197,7 +197,8 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
             NRF_LAUNCH_CHECK();
         }
     }
-    NRF_HIP(hipStreamSynchronize(st));          // model-load time: later launches may come from any stream
+    if (nb > 0) NRF_HIP(hipStreamSynchronize(st));          // model-load time: the bake must be complete before launches from any other stream read it.
+                                                            // Nothing baked (budget 0: a training loop's per-step table upload): nothing to wait for
     h->fast_valid = true;
     h->dense_levels = nb;
     return NRF_OK;

@@ -73,5 +73,6 @@ int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const floa
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_lerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);      // sigma_lerf_f32.hip
 
 }  // namespace nrf

@@ -528,6 +528,7 @@ NRF_API int nrf_mlp_lerf_create(const nrf_mlp_small_desc *d, const float *params
     for (int l = 0; l < d->num_layers && s == NRF_OK; l++)
         s = add_layer(m, hp, off, (l == 0) ? d->geo_feat_dim + d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? d->hidden_dim_color : d->hidden_dim, false);
     if (s == NRF_OK) s = mlp_lerf_pack_f16(m, hp);
+    if (s == NRF_OK) s = mlp_lerf_pack_sigma_f32(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -560,7 +561,7 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
     NRF_HIP(hipStreamSynchronize(st));
     if (m->family == MLP_SMALL) { NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }
     if (m->family == MLP_NERF) return mlp_nerf_pack_f16(m, hp);
-    if (m->family == MLP_LERF) return mlp_lerf_pack_f16(m, hp);
+    if (m->family == MLP_LERF) { NRF_TRY(mlp_lerf_pack_f16(m, hp)); return mlp_lerf_pack_sigma_f32(m, hp); }
     return NRF_OK;
 }
 

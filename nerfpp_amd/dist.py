@@ -59,7 +59,8 @@ class TileComm:
     """The collective behind the C ABI (nrf_comm_* / nrf_allgather_tiles, include/nerfpp_hip.h): what the C++ / LibTorch host calls.  The RCCL unique id is
     created on rank 0 by the library and handed to the other ranks through torch.distributed (any backend; a file or a socket serves a host without it)."""
 
-    def __init__(self, rank=0, world=1, group=None):
+    def __init__(self, rank=0, world=1, group=None, timeout_s=300.0):
+        """timeout_s bounds the communicator's own rendezvous (nrf_comm_create_timeout): a peer that never arrives raises instead of parking this rank for ever."""
         self.rank, self.world = int(rank), int(world)
         buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES)()
         if self.rank == 0:
@@ -69,7 +70,7 @@ class TileComm:
             dist.broadcast_object_list(box, src=0, group=group)
             buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES).from_buffer_copy(box[0])
         self._c = C.c_void_p()
-        L.check(L.lib().nrf_comm_create(buf, self.world, self.rank, C.byref(self._c)))
+        L.check(L.lib().nrf_comm_create_timeout(buf, self.world, self.rank, C.c_double(float(timeout_s)), C.byref(self._c)))
 
     def all_gather_frames(self, tiles, h):
         """tiles: [F, rows_rank, W, C] fp32 (contiguous) -> [F, h, W, C] on every rank; one fused RCCL launch on the current stream."""
@@ -102,6 +103,24 @@ class GradSync:
     def __init__(self, world=None, bucket_bytes=32 << 20):
         self.world = (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1) if world is None else int(world)
         self.bucket_elems = max(int(bucket_bytes) // 4, 1)
+
+    def any_overflow(self, flag, device=None):
+        """True on EVERY rank iff any rank passes True: the fp16 backward's overflow report is per rank, the decision to skip the optimizer step must not be --
+        a replica that steps while another skips (or that steps on the sum of a peer's inf) leaves the replicas with different parameters, moments and step counts."""
+        if self.world == 1:
+            return bool(flag)
+        dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
+    def reduce_or_skip(self, overflow, *grads):
+        """The data-parallel step's exchange: agree on the overflow flag FIRST, then average the gradients only if nobody overflowed (a non-finite gradient is never
+        summed into the peers').  Returns True when the step must be skipped -- on all ranks alike."""
+        if self.any_overflow(overflow):
+            return True
+        self(*grads)
+        return False
 
     def __call__(self, *grads):
         """grads: fp32 gradient tensors, reduced IN PLACE to their mean over the ranks."""

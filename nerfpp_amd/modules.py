@@ -92,6 +92,7 @@ class _HashBase(BaseEmbedder):
                           (C.c_float * 6)(*bb.tolist()))
         self._h = C.c_void_p()
         L.check(L.lib().nrf_hash_create(C.byref(desc), C.byref(self._h)))
+        self.dense_budget = 24 << 30          # the library's default bake budget (encode.h); set_dense_budget keeps this in step
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -115,6 +116,7 @@ class _HashBase(BaseEmbedder):
         """Bytes of baked dense image for the coarse levels of the renderer's fast path (nrf_hash_set_dense_budget; 0 = every level hashed: what a
         training loop, which re-uploads the table every step, wants)."""
         L.check(L.lib().nrf_hash_set_dense_budget(self._h, C.c_int64(int(nbytes)), _stream()))
+        self.dense_budget = int(nbytes)
 
     def level_scales(self):
         """The per-level position scales in use (CuHashEmbedder: mul_l of CuHashEmbedder.cu:40; HashEmbedder: the floor()ed resolutions)."""

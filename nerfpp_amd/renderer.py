@@ -518,6 +518,9 @@ class LeRFRenderer:
         # matrix-core path: the LeRF head fused with its render pass (mlp_lerf_mfma.hip); raw_le [N, S, E+1] is never formed
         self.fused = bool(fused) and bool(L.lib().nrf_lerf_mfma_available(lerf._m))
         self.hand_over_geo = True           # split precision, reuse path: the embedding pass takes the sigma net's output from the sigma pass (False: re-evaluates it)
+        # split precision: the COARSE pass's sigma_le in exact fp32 on the matrix cores (sigma_lerf_f32.hip) -- its weights choose the fine samples through a
+        # discontinuous function, so the fine sample set of the timed mode is then the fp32 stage path's own, bit for bit (False: split arithmetic, for A/B tests)
+        self.exact_coarse = True
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
         if self.fused:
@@ -533,8 +536,11 @@ class LeRFRenderer:
     def precision_name(self):
         return {L.NRF_PREC_F16_MFMA: "f16", L.NRF_PREC_F16_SPLIT: "f16x3"}.get(self.precision, "f32")
 
-    def _sigma_fused(self, pts):
-        """sigma_le [N,S] (keep-masked) and the hash features [N*S, in] of the sample points, sigma net on the matrix cores."""
+    def _exact_coarse_on(self):
+        return bool(self.exact_coarse) and self.precision == L.NRF_PREC_F16_SPLIT and bool(L.lib().nrf_lerf_sigma_exact_available(self.Lerf._m))
+
+    def _sigma_fused(self, pts, exact=False):
+        """sigma_le [N,S] (keep-masked) and the hash features [N*S, in] of the sample points, sigma net on the matrix cores (exact: in exact fp32, the coarse pass)."""
         n, s = pts.shape[0], pts.shape[1]
         sig = torch.empty((n, s), device=pts.device, dtype=torch.float32)
         if self.level_major:
@@ -542,7 +548,10 @@ class LeRFRenderer:
             x = torch.empty((16, n * s, 8), device=pts.device, dtype=torch.float16)
             ku8 = torch.empty((n * s,), device=pts.device, dtype=torch.uint8)
             L.check(L.lib().nrf_hash_encode_lm_f16(self.LangEmbedFn._h, _ptr(flat), C.c_int64(n * s), _ptr(x), _ptr(ku8), _stream()))
-            L.check(L.lib().nrf_lerf_sigma_lm(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
+            if exact:
+                L.check(L.lib().nrf_lerf_sigma_exact_lm_strided(self.Lerf._m, _ptr(x), C.c_int64(n * s), _ptr(ku8), C.c_int64(n * s), _ptr(sig), None, C.c_int64(0), _stream()))
+            else:
+                L.check(L.lib().nrf_lerf_sigma_lm(self.Lerf._m, _ptr(x), _ptr(ku8), C.c_int64(n * s), _ptr(sig), _stream()))
             return sig, x
         x, keep = self.LangEmbedFn.forward(pts.reshape(-1, 3))
         ku8 = keep.to(torch.uint8)
@@ -570,7 +579,11 @@ class LeRFRenderer:
             else:
                 L.check(lib.nrf_lerf_sigma_geo_lm_strided(m, x_ptr, C.c_int64(cols), _ptr(keep_t), C.c_int64(count), _ptr(sig_t), C.c_void_p(geo.data_ptr() + col0 * 32),
                                                           C.c_int64(cols), _stream()))
-        sigma_pass(_ptr(x), keep, n * s, sig, 0)
+        if self._exact_coarse_on():
+            # coarse columns: sigma_le in exact fp32 (== the fp32 stage path bit for bit), and -- with the hand-over -- the sigma net's geo output split from the exact values
+            L.check(lib.nrf_lerf_sigma_exact_lm_strided(m, _ptr(x), C.c_int64(cols), _ptr(keep), C.c_int64(n * s), _ptr(sig), _ptr(geo), C.c_int64(cols), _stream()))
+        else:
+            sigma_pass(_ptr(x), keep, n * s, sig, 0)
         out1 = self._weights_from_sigma(sig[:n * s].view(n, s), z, rays_d)
         u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
         zf = torch.empty((n, sf), device=dev); src = torch.empty((n, sf), device=dev, dtype=torch.int32); z_new = torch.empty((n, ni), device=dev)
@@ -600,8 +613,8 @@ class LeRFRenderer:
                                         _ptr(o.AccMapLE), _stream()))
         return o
 
-    def _render_fused(self, pts, z, rays_d, want_embedding):
-        sig, x = self._sigma_fused(pts)
+    def _render_fused(self, pts, z, rays_d, want_embedding, exact=False):
+        sig, x = self._sigma_fused(pts, exact)
         o = self._weights_from_sigma(sig, z, rays_d)
         if want_embedding:
             n, s = sig.shape
@@ -664,7 +677,7 @@ class LeRFRenderer:
             return res
         if self.fused and not return_raw and s % 32 == 0 and (ni == 0 or (s + ni) % 32 == 0):
             # coarse pass: only sigma_le is consumed (the reference also renders a coarse embedding, LeRFRenderer.cpp:139, and drops it)
-            out1 = self._render_fused(pts, z, rays_d, want_embedding=(ni == 0))
+            out1 = self._render_fused(pts, z, rays_d, want_embedding=(ni == 0), exact=(ni > 0 and self.level_major and self._exact_coarse_on()))
             res.Outputs = out1
             if ni > 0:
                 u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)

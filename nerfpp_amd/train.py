@@ -55,8 +55,22 @@ class Trainer:
         self._ws = None
         # the baked dense pyramid of the render fast path would be re-baked (GBs, with a stream synchronisation) after every step's table upload:
         # off for ANY hash embedder -- the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
+        self._dense_budget_before = getattr(embedder, "dense_budget", None)
         embedder.set_dense_budget(0)
         self._push_params()
+
+    def close(self):
+        """Give the embedder its baked dense image back (the budget it had before this Trainer switched it off): renders after training -- evaluation frames, a
+        bench measurement -- then take the fast path again.  Idempotent."""
+        if getattr(self, "_dense_budget_before", None) is not None:
+            self.embedder.set_dense_budget(self._dense_budget_before)
+            self._dense_budget_before = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _push_params(self):
         self.embedder.set_table(self.table)
@@ -190,9 +204,15 @@ class Trainer:
         loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
         if global_step is None or n_iters is None or global_step < n_iters / 2:
             self.add_tv_loss()
-        if self.grad_sync is not None:                     # data-parallel replicas: mean of the ranks' gradients (nerfpp_amd/dist.py::GradSync)
-            self.grad_sync(self.g_table, self.g_blob)
-        if self.overflow:                                  # a non-finite gradient in the fp16 chain: no optimizer step (the moments would be poisoned for good)
+        # A non-finite gradient in the fp16 chain: no optimizer step (the moments would be poisoned for good).  With data-parallel replicas the flag is made
+        # collective BEFORE any gradient is exchanged (GradSync.reduce_or_skip): every rank skips, none sums a peer's inf, all keep the same t / seed / lr.
+        skip = bool(self.overflow)
+        if self.grad_sync is not None:                     # mean of the ranks' gradients (nerfpp_amd/dist.py::GradSync)
+            if hasattr(self.grad_sync, "reduce_or_skip"):
+                skip = self.grad_sync.reduce_or_skip(skip, self.g_table, self.g_blob)
+            elif not skip:
+                self.grad_sync(self.g_table, self.g_blob)   # a plain callable: single-process hooks
+        if skip:
             self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
             return loss_mse, res
         self.t += 1

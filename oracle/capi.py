@@ -180,6 +180,14 @@ def lerf(params, x, in_ch=128, n_layers=2, hidden=256, geo=32, embed=768):
     return out
 
 
+def lerf_sigma_net(params, x, in_ch=128, n_layers=2, hidden=256, geo=32):
+    """SigmaLENet(x) of LeRFImpl::forward (LeRF.cpp:86-95) -> [p, 1 + geo]: column 0 = sigma_le, columns 1.. = geo_feat_le."""
+    params = _f(params); x = _f(x)
+    out = np.empty((x.shape[0], 1 + geo), np.float32)
+    lib().orc_lerf_sigma_net(_p(params), _p(x), C.c_int64(x.shape[0]), C.c_int(in_ch), C.c_int(n_layers), C.c_int(hidden), C.c_int(geo), _p(out))
+    return out
+
+
 def raw2outputs(raw, z, d, white_bkgr=False):
     raw = _f(raw); z = _f(z); d = _f(d)
     n, s, c = raw.shape

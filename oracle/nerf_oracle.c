@@ -896,6 +896,26 @@ ORC_API void orc_lerf(const float *params, const float *x, int64_t p, int in_ch,
     }
 }
 
+/* the density net of LeRFImpl::forward alone (LeRF.cpp:86-95): h = SigmaLENet(x) -> out [p, 1+geo] (row 0 = sigma_le, rows 1.. = geo_feat_le) */
+ORC_API void orc_lerf_sigma_net(const float *params, const float *x, int64_t p, int in_ch, int n_layers, int hidden, int geo, float *out /*[p, 1+geo]*/)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float *a = (float *)malloc(sizeof(float) * 4096), *b2 = (float *)malloc(sizeof(float) * 4096);
+        float *bufs[2] = {a, b2};
+        const float *w = params;
+        const float *cur = x + i * in_ch;
+        int cur_dim = in_ch;
+        for (int l = 0; l < n_layers; l++) {
+            int od = (l == n_layers - 1) ? (1 + geo) : hidden;
+            linear(w, NULL, cur, cur_dim, od, bufs[l & 1], l != n_layers - 1);
+            w += (int64_t)cur_dim * od; cur = bufs[l & 1]; cur_dim = od;
+        }
+        memcpy(out + i * (1 + geo), cur, sizeof(float) * (1 + geo));
+        free(a); free(b2);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * C1  RawToOutputs                         NeRFRenderer.h:199-282, TruncExp fwd CustomOps.cpp:5-9
  *     dists = [z[i+1]-z[i], 1e10] * ||d|| ; rgb = sigmoid(raw[:3]) ;

@@ -160,6 +160,22 @@ from nerfpp_amd.dist import GradSync
 g_table = torch.arange(1000, dtype=torch.float32) * (rank + 1); g_blob = torch.full((7,), float(rank), dtype=torch.float32)
 GradSync(bucket_bytes=4 * 300)(g_table, g_blob)
 assert torch.allclose(g_table, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)) and torch.allclose(g_blob, torch.full((7,), (world - 1) / 2.0))
+# one frame, equal tiles: the gathered buffer is the frame itself (the strong-scaling step of bench.py)
+H2 = 8
+full2 = torch.arange(H2 * W * 3, dtype=torch.float32).reshape(1, H2, W, 3)
+sh2 = TileShard(H2, W, rank, world)
+out2 = sh2.all_gather_frames([full2[0, sh2.row0:sh2.row0 + sh2.rows].clone()])
+assert out2.shape == full2.shape and torch.equal(out2, full2)
+# the fp16 backward's overflow flag is per rank; the decision to skip the optimizer step is collective and comes BEFORE any gradient is exchanged
+gs = GradSync()
+g1 = torch.ones(10); g2 = torch.ones(3)
+if rank == 1:
+    g1[4] = float("inf")
+skip = gs.reduce_or_skip(rank == 1, g1, g2)
+assert skip is True, "every rank skips when any rank overflowed"
+assert torch.isfinite(g1).all() == (rank == 0) and torch.equal(g2, torch.ones(3)), "no gradient was summed: rank 0 keeps its finite one, the inf stays where it arose"
+skip = gs.reduce_or_skip(False, g2)
+assert skip is False and torch.equal(g2, torch.ones(3))
 dist.destroy_process_group()
 print("ok", rank)
 """
