@@ -37,12 +37,14 @@ UNITS_PER_RAY = NS + NS + NI          # one shared network, fine pass re-evaluat
 # counting the reference's 256 evaluations per ray (the work the frame stands for); the rooflines below price what each kernel really processed.
 
 
-def executed_per_ray(workload, precision, hash_mode):
+def executed_per_ray(workload, precision, hash_mode, coarse_full=False):
     """(hash-encode points, fused-MLP points, sigma-only points) per ray."""
     if precision == "f32":
         return UNITS_PER_RAY, UNITS_PER_RAY, 0
     if workload == "classic":
-        return 0, NS + NI, 0
+        if precision == "f16x3" and coarse_full is False:
+            return 0, NS + NI, NS                                 # coarse pass: the density branch alone in exact fp32 (sigma_nerf_f32.hip); the fine pass evaluates all 192 depths
+        return 0, NS + NI, 0                                      # whole network on the coarse pass, its outputs reused by the fine pass: 64 + 128 evaluations
     if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32)
         return NS + NI, NS + NI, NS                           # both encoders: the fine pass keeps the coarse pass's feature columns
     return NS + NI, NS + NI, 0                                # plain fp16: coarse outputs reused by the fine pass
@@ -53,6 +55,8 @@ SMALL_FLOP_PER_UNIT = 35072
 # matrix-core work the NeRFSmall kernel actually issues per point (32-row / 16-k padded tiles; x3 products in split mode, x2 on layer 0)
 SMALL_MFMA_FLOP_PER_UNIT = {"f16": 40 * 32768 // 32, "f16x3": 116 * 32768 // 32}
 NERF_FLOP_PER_UNIT = 1186816
+# the density branch alone (NeRF.cpp:92-108: pts_linears 0..7 with the skip-concat, alpha_linear): 491 264 MAC
+NERF_SIGMA_FLOP_PER_UNIT = 2 * (63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256)
 # the coarse pass of the default mode needs sigma only (NeRFRenderer.h:422-428): in 32 -> 64 -> 64 -> 1
 SIGMA_FLOP_PER_UNIT = 2 * (32 * 64 + 64 * 64 + 64)
 # LeRF head at main.cpp:203-213 sizes: 128 -> 256 -> 33 ; cat[geo32, in128] -> 256 -> 768, bias-free
@@ -413,7 +417,7 @@ def main():
         else:
             k = prof["mlp"]
             dur_total = k["ms"] * 1e-3
-            ex_mlp = executed_per_ray(args.workload, args.precision, args.hash_mode)[1]
+            ex_mlp = executed_per_ray(args.workload, args.precision, args.hash_mode, coarse_full=False)[1]
             exec_units = units_per_step * args.steps / world * ex_mlp / UNITS_PER_RAY          # network evaluations this rank's kernel really ran
             flops = exec_units * NERF_FLOP_PER_UNIT
             peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
@@ -534,21 +538,28 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
     render-vs-oracle quality on a 256-ray sample."""
     import torch
     out = []
-    todo = [("hash", "f16" if args.precision != "f16" else "f16x3"), ("classic", "f16x3"), ("classic", "f16")] if args.workload == "hash" else \
-           [("classic", "f16" if args.precision != "f16" else "f16x3"), ("hash", "f16x3")]
+    # (workload, precision, coarse pass); classic split precision is timed in both coarse modes: "exact" (NRF_COARSE_AUTO: density branch in exact fp32 on the
+    # matrix cores, the fp32 path's sample set bit for bit) and "full" (NRF_COARSE_FULL: whole network in split arithmetic, outputs reused: 99.9 % of pixels within 1e-4)
+    todo = [("hash", "f16" if args.precision != "f16" else "f16x3", None), ("classic", "f16x3", "exact"), ("classic", "f16x3", "full"), ("classic", "f16", None)] if args.workload == "hash" else \
+           [("classic", "f16x3", "full"), ("classic", "f16" if args.precision != "f16" else "f16x3", None), ("hash", "f16x3", None)]
     scenes = {args.workload: sc_main}
-    for wl, pname in todo:
+    for wl, pname, coarse in todo:
         try:
             if wl not in scenes:
                 scenes[wl] = scene.make_hash_scene(mode=args.hash_mode) if wl == "hash" else scene.make_classic_scene()
             sc = scenes[wl]
             prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[pname]
             rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072 if wl == "hash" else 8192, prec)
-            dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), steps)
-            a2 = argparse.Namespace(**{**vars(args), "workload": wl, "precision": pname})
-            ex_hash, ex_mlp, ex_sigma = executed_per_ray(wl, pname, args.hash_mode)
+            if coarse == "full":
+                rp.CoarseMode = L.NRF_COARSE_FULL
+            n_fr = steps if not (wl == "classic" and pname == "f16x3") else max(3, steps // 2)
+            dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), n_fr)
+            a2 = argparse.Namespace(**{**vars(args), "workload": wl, "precision": pname, "coarse_full": coarse == "full"})
+            ex_hash, ex_mlp, ex_sigma = executed_per_ray(wl, pname, args.hash_mode, coarse_full=(coarse != "exact") if wl == "classic" else False)
             rec = dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
-                       precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=kms,
+                       precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=n_fr, kernel_ms=kms,
+                       **({"coarse_pass": "density branch in exact fp32 on the matrix cores (sigma_nerf_f32.hip): the fp32 path's sample set" if coarse == "exact"
+                           else "whole network in the timed arithmetic, outputs reused by the fine pass (NRF_COARSE_FULL)"} if coarse else {}),
                        executed_evaluations_per_ray=dict(hash_encode=ex_hash, fused_mlp=ex_mlp, sigma_only=ex_sigma))
             mk = kms["mlp"]
             if wl == "classic":
@@ -557,6 +568,10 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                                                 note="algorithmic 1 186 816 flop of NeRFImpl::forward as written x the network evaluations the kernel executed "
                                                      "(192 per ray: the fine pass's 64 coarse depths take the coarse pass's outputs); issued: 1 058 matrix instructions per 32 points"
                                                      + (" x 3 products (hi + lo operand pairs)" if pname == "f16x3" else ""))
+                sk = kms["sigma"]
+                if sk["launches_per_frame"]:
+                    rec["roofline"]["sigma_exact"] = mfma_roofline("sigma_nerf_f32 (coarse pass: density branch in exact fp32, v_mfma_f32_32x32x2_f32)", H * W * ex_sigma, NERF_SIGMA_FLOP_PER_UNIT,
+                                                                   sk["ms_per_frame"] * 1e-3, sk["launches_per_frame"], peak=F32_PEAK)
             else:
                 rec["roofline"] = mfma_roofline("mlp_small", H * W * ex_mlp, SMALL_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
                                                 issued_flop_per_unit=SMALL_MFMA_FLOP_PER_UNIT.get(pname))

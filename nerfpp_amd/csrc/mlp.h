@@ -72,6 +72,10 @@ int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const 
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+// sigma_nerf_f32.hip: the classic network's density branch in exact fp32 on the matrix cores (coarse pass)
+int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_nerf_sigma_f32_available(const nrf_mlp *m);
+int mlp_nerf_sigma_f32(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, int64_t p, float *sigma, hipStream_t st);
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_lerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);      // sigma_lerf_f32.hip
 

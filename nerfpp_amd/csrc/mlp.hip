@@ -497,6 +497,7 @@ int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int par
     } else if (s == NRF_OK) s = add_layer(m, hp, off, w + d->input_ch, d->output_ch, true);
     if (w + d->input_ch_views > m->max_width) m->max_width = w + d->input_ch_views;
     if (s == NRF_OK) s = mlp_nerf_pack_f16(m, hp);
+    if (s == NRF_OK) s = mlp_nerf_pack_sigma_f32(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -560,7 +561,7 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
     }
     NRF_HIP(hipStreamSynchronize(st));
     if (m->family == MLP_SMALL) { NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }
-    if (m->family == MLP_NERF) return mlp_nerf_pack_f16(m, hp);
+    if (m->family == MLP_NERF) { NRF_TRY(mlp_nerf_pack_f16(m, hp)); return mlp_nerf_pack_sigma_f32(m, hp); }
     if (m->family == MLP_LERF) { NRF_TRY(mlp_lerf_pack_f16(m, hp)); return mlp_lerf_pack_sigma_f32(m, hp); }
     return NRF_OK;
 }

@@ -1,0 +1,281 @@
+// sigma_nerf_f32.hip -- the density branch of NeRFImpl::forward (NeRF.cpp:92-108: eight Linear(+bias)+ReLU layers of width 256 with the skip-concat
+// h = cat[input_pts, h] after layer 4, then alpha_linear) in EXACT fp32 on the matrix cores, for the coarse pass of the classic renderer.
+//
+// Why.  With N_importance > 0 the coarse pass contributes only its compositing weights (NeRFRenderer.h:422-428), i.e. only sigma, and those weights choose the
+// fine samples through searchsorted (Sampler.h:6-43) -- a discontinuous function.  In the split (hi + lo fp16) arithmetic of the timed mode 99.93 % of the pixel
+// values came out within 1e-4 of the fp32 render and the rest did not: a moved sample.  "Certified sampling" (re-evaluating only the rays whose u values come
+// within an error bound of a CDF edge) cannot close that gap: u_127 = 1.0 is compared with the CDF's top plateau, whose entries sit within 1e-7 of 1.0 on every
+// ray that saturates, so whether cdf_i <= 1.0 holds depends on the last bit of the weight sum -- nearly every ray would be flagged
+// (profiles/round3/r3c_classic_cdf_stats.log).  So the coarse sigma is evaluated in the parity arithmetic itself: v_mfma_f32_32x32x2_f32 is, bit for bit, the
+// ascending-k fmaf chain of NRF_PREC_F32 / the oracle (sigma_small_f32.hip).  The view branch (feature_linear, views_linears, rgb_linear: 17 % of the MACs) is
+// dead work in this pass and is not run.
+//
+// Formulation (as sigma_small_f32.hip / sigma_lerf_f32.hip): layers transposed, H^T [256 x points] = W [256 x K] . X^T, A = 32 neurons x 2 k, B = 2 k x 32 points,
+// K / 2 ascending k-steps through ONE accumulator per neuron tile (a dependent chain of this instruction issues back to back, MI355X_MICROARCH.md).  Row i of a
+// neuron tile carries neuron 2(4(i/8) + i%4) + (i/4)%2, so register q of lane half hh of a finished tile is neuron 2q + hh: after bias and ReLU it IS the B operand
+// of k-step 16 tile + q of the next layer.  Padding: K = 63 runs as 64 with a zero product at the end, and the skip layer's cat[input(63), h(256)] runs as
+// [input(63), 0, h(256)] -- fmaf(0, 0, acc) returns acc exactly (an accumulator that started at +0 is never -0), so both chains equal the oracle's.
+// alpha_linear (256 -> 1) is a 256-term chain per point on the vector ALUs.
+//
+// Resources: one wave per SIMD (4 waves, 128 points per workgroup pass).  A wave holds a layer's input and output for its 32 points in registers (2 x 128, the
+// unified VGPR + AGPR file); the 1.9 MB of fp32 weight fragments stream L2 -> LDS by LDS-DMA in chunks of one neuron tile (8 / 32 / 40 KB), one chunk ahead,
+// shared by the four waves.  Layers 1-4 and 6-7 have the same shape and run the same unrolled code (1 024 matrix instructions) in a loop.
+#include "mlp.h"
+
+namespace nrf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace nsig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NW = 4;
+constexpr int BLK = 32 * NW;
+constexpr int NL = 8;
+__host__ __device__ constexpr int kdim(int l) { return l == 0 ? 64 : l == 5 ? 320 : 256; }
+__host__ __device__ constexpr int groups(int l) { return kdim(l) / 8; }                    // float4 fragment groups (4 k-steps each) per neuron tile
+__host__ __device__ constexpr int chunk_first_group(int l, int mt)                          // offset of chunk (l, mt) in the image, in groups
+{
+    int n = 0;
+    for (int i = 0; i < l; i++) n += 8 * groups(i);
+    return n + mt * groups(l);
+}
+constexpr int TOTAL_GROUPS = chunk_first_group(NL, 0);
+constexpr int MAXG = 40;
+constexpr int BIAS_FLOATS = NL * 256;                 // [layer][tile][lane half][16]
+constexpr int ALPHA_FLOATS = 256 + 4;                 // alpha_linear.weight [256] | bias | pad
+constexpr size_t LDS_BYTES = (size_t)2 * MAXG * 1024 + (BIAS_FLOATS + ALPHA_FLOATS) * 4;
+static_assert(TOTAL_GROUPS == 8 * (8 + 6 * 32 + 40), "image size");
+
+__host__ __device__ inline int row_neuron(int i) { return 2 * (4 * (i >> 3) + (i & 3)) + ((i >> 2) & 1); }
+
+struct Ctx {
+    f32x4 *wbuf;                 // [2][MAXG * 64]
+    const float *bias_s;         // LDS
+    const f32x4 *image;          // global
+    int lane, hh, wave;
+    int cur;                     // LDS buffer holding the chunk being consumed
+    int next_group;              // image offset (groups) of the chunk after the one being consumed
+};
+
+// the DMA of one chunk (ng groups starting at image group g0) into LDS buffer `dst`: wave w moves groups w, w + 4, ...; 1 KB per instruction
+__device__ __forceinline__ void stage_chunk(const Ctx &cx, f32x4 *dst, int g0, int ng)
+{
+    const f32x4 *src = cx.image + (size_t)g0 * 64 + cx.lane;
+    for (int q = cx.wave; q < ng; q += NW)
+        __builtin_amdgcn_global_load_lds(src + (size_t)q * 64, (__attribute__((address_space(3))) void *)(dst + q * 64), 16, 0, 0);
+}
+
+// One neuron tile: G groups of four k-steps, A fragments from LDS (read through asm so that the compiler does not order them against the look-ahead DMA into the
+// OTHER buffer), B operand bfn(ks); returns the finished tile with bias and ReLU applied.  NEXT_G: groups of the chunk to prefetch.
+template <int G, class BFn>
+__device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, BFn bfn)
+{
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 *w = cx.wbuf + cx.cur * (MAXG * 64);
+    f32x4 *nxt = cx.wbuf + (cx.cur ^ 1) * (MAXG * 64);
+    // The look-ahead DMA of the next chunk, issued in one burst ahead of the tile's matrix instructions (8-10 pieces per wave).  Dealing the pieces out over the
+    // tile's groups instead -- what pays in the fp16 split kernels -- made THIS kernel slower (417 vs 362 ms per frame's coarse pass, same box).
+    stage_chunk(cx, nxt, cx.next_group, next_ng);
+    cx.next_group += next_ng;
+    if (cx.next_group >= TOTAL_GROUPS) cx.next_group = 0;
+    const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+    f32x4 fa[3];
+    // fragments two groups ahead through three register slots, counted waits
+#define NRF_RD(g_, slot_) asm volatile("ds_read_b128 %0, %1" : "=&v"(fa[slot_]) : "v"(waddr + (uint32_t)(g_) * 1024u))
+    NRF_RD(0, 0);
+    if (G > 1) NRF_RD(1, 1);
+    f32x16 acc = zero;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g + 2 < G) {
+            NRF_RD(g + 2, (g + 2) % 3);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[g % 3]));
+        } else if (g + 1 < G) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[g % 3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[g % 3]));
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a4 = fa[g % 3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bfn(4 * g + j), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef NRF_RD
+    // bias (one rounding, after the chain: the oracle's `acc += b`) and ReLU; [layer][tile][lane half][16] so that a lane reads 16 consecutive floats
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(cx.bias_s + ((layer * 8 + mt) * 2 + cx.hh) * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+        const f32x4 bv = b4[q4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float v = acc[4 * q4 + e] + bv[e];
+            acc[4 * q4 + e] = fmaxf(v, 0.0f);
+        }
+    }
+    // the next chunk has landed (this wave's pieces) and every wave is done with this buffer
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    cx.cur ^= 1;
+    return acc;
+}
+
+// image: fragments of the 64 chunks | bias [8][8][2][16] | alpha weight [256], alpha bias, pad
+__global__ void __launch_bounds__(64 * NW, 1)
+k_sigma_nerf_f32(int64_t npts, const float *__restrict__ pts, const float *__restrict__ rays, int ray_stride, const float *__restrict__ z, int s,
+                 const float *__restrict__ image, float *__restrict__ sigma)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);
+    float *bias_s = reinterpret_cast<float *>(smem + (size_t)2 * MAXG * 1024);
+    float *alpha_s = bias_s + BIAS_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const float *tail = image + (size_t)TOTAL_GROUPS * 256;
+    for (int i = tid; i < BIAS_FLOATS + ALPHA_FLOATS; i += blockDim.x) bias_s[i] = tail[i];
+    Ctx cx{wbuf, bias_s, reinterpret_cast<const f32x4 *>(image), lane, hh, wave, 0, 0};
+    stage_chunk(cx, wbuf, 0, groups(0));                           // chunk (0, 0) into buffer 0
+    cx.next_group = groups(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int64_t nblocks = (npts + BLK - 1) / BLK;
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t p0 = blk * BLK + wave * 32;
+        int64_t q = p0 + r;
+        if (q >= npts) q = npts - 1;                               // clamp loads; the store is guarded
+        // ---- the 63 sinusoidal features of this lane's point (NeRF.cpp:33-37; the stand-alone encoder's arithmetic): k-step ks takes entries 2 ks + hh ----
+        float px[3];
+        if (pts) { px[0] = pts[q * 3]; px[1] = pts[q * 3 + 1]; px[2] = pts[q * 3 + 2]; }
+        else {
+            const float *rp = rays + (int64_t)((uint32_t)q / (uint32_t)s) * ray_stride;
+            const float zz = z[q];
+            px[0] = rp[0] + rp[3] * zz; px[1] = rp[1] + rp[4] * zz; px[2] = rp[2] + rp[5] * zz;
+        }
+        float xin[32];
+#pragma unroll
+        for (int ks = 0; ks < 32; ks++) {
+            constexpr auto arg_axis = [](int k) { return k < 3 ? k : ((k - 3) % 6) % 3; };
+            constexpr auto arg_freq = [](int k) { return k < 3 ? 0 : (k - 3) / 6; };
+            constexpr auto kind = [](int k) { return k < 3 ? 0 : k >= 63 ? 3 : (((k - 3) % 6) < 3 ? 1 : 2); };   // 0 raw, 1 sin, 2 cos, 3 pad
+            const int k0 = 2 * ks, k1 = 2 * ks + 1;
+            const float a0 = px[arg_axis(k0)] * __builtin_ldexpf(1.0f, arg_freq(k0));
+            const float a1 = px[arg_axis(k1 < 63 ? k1 : 0)] * __builtin_ldexpf(1.0f, arg_freq(k1 < 63 ? k1 : 0));
+            float sn, cs;
+            nrf_sincosf(hh ? a1 : a0, &sn, &cs);
+            const int kd0 = kind(k0), kd1 = kind(k1);
+            const float v0 = kd0 == 0 ? px[arg_axis(k0)] : kd0 == 1 ? sn : kd0 == 2 ? cs : 0.0f;
+            const float v1 = kd1 == 0 ? px[arg_axis(k1 < 63 ? k1 : 0)] : kd1 == 1 ? sn : kd1 == 2 ? cs : 0.0f;
+            xin[ks] = hh ? v1 : v0;
+        }
+        f32x16 hin[8], hout[8];
+        // ---- layer 0: 63 (+ 1) -> 256 ----
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) hout[mt] = tile<groups(0)>(cx, 0, mt, mt < 7 ? groups(0) : groups(1), [&](int ks) { return xin[ks]; });
+#pragma unroll
+        for (int t = 0; t < 8; t++) hin[t] = hout[t];
+        // ---- layers 1..7: 256 -> 256, layer 5 with the skip-concat in front (k-steps 0..31: the input features, then the 128 of h) ----
+        for (int l = 1; l < NL; l++) {
+            if (l == 5) {
+#pragma unroll
+                for (int mt = 0; mt < 8; mt++)
+                    hout[mt] = tile<groups(5)>(cx, 5, mt, mt < 7 ? groups(5) : groups(6), [&](int ks) { return ks < 32 ? xin[ks < 32 ? ks : 0] : hin[ks >= 32 ? (ks - 32) >> 4 : 0][(ks - 32) & 15]; });
+            } else {
+                const int ng_after = l == 4 ? groups(5) : l == 7 ? groups(0) : groups(1);
+#pragma unroll
+                for (int mt = 0; mt < 8; mt++) hout[mt] = tile<groups(1)>(cx, l, mt, mt < 7 ? groups(1) : ng_after, [&](int ks) { return hin[ks >> 4][ks & 15]; });
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) hin[t] = hout[t];
+        }
+        // ---- alpha_linear: a 256-term ascending chain per point; lanes 0-31 run it (even k is their own register, odd k comes from lane + 32) ----
+        float a = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const f32x4 *wa = reinterpret_cast<const f32x4 *>(alpha_s + 32 * t);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; q4++) {
+                const f32x4 w4 = wa[q4];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int qq = 2 * q4 + e;
+                    const uint32_t v = __float_as_uint(hin[t][qq]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // [1]: lanes 0-31 receive lanes 32-63 (the odd neuron of the same point)
+                    a = __builtin_fmaf(w4[2 * e], hin[t][qq], a);
+                    a = __builtin_fmaf(w4[2 * e + 1], __uint_as_float(sw[1]), a);
+                }
+            }
+        }
+        a = a + alpha_s[256];
+        const int64_t p = p0 + r;
+        if (hh == 0 && p < npts) sigma[p] = a;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last tile
+}
+
+}  // namespace nsig
+
+static bool sigma_nerf_f32_supported(const nrf_mlp_nerf_desc &d)
+{
+    return d.depth == 8 && d.width == 256 && d.input_ch == 63 && d.skip == 4 && d.use_viewdirs;
+}
+
+int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->nerf;
+    if (!sigma_nerf_f32_supported(d)) return NRF_OK;
+    using namespace nsig;
+    std::vector<float> img;
+    img.reserve((size_t)TOTAL_GROUPS * 256 + BIAS_FLOATS + ALPHA_FLOATS);
+    std::vector<float> bias((size_t)BIAS_FLOATS, 0.0f);
+    size_t off = 0;
+    for (int l = 0; l < NL; l++) {
+        const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
+        const float *w = hp.data() + off, *b = w + (size_t)in * 256;
+        // padded k -> column of W: layer 0: k < 63; layer 5: [input 0..62 | pad | h 0..255] -> columns [0..62 | - | 63..318]
+        auto col = [&](int k) { return l == 0 ? (k < 63 ? k : -1) : l == 5 ? (k < 63 ? k : k == 63 ? -1 : k - 1) : k; };
+        for (int mt = 0; mt < 8; mt++)
+            for (int g = 0; g < groups(l); g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 4; j++) {
+                        const int row = 32 * mt + row_neuron(lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+                        const int c = col(k);
+                        img.push_back(c >= 0 ? w[(size_t)row * in + c] : 0.0f);
+                    }
+        for (int mt = 0; mt < 8; mt++)
+            for (int h = 0; h < 2; h++)
+                for (int q = 0; q < 16; q++) bias[((size_t)(l * 8 + mt) * 2 + h) * 16 + q] = b[32 * mt + 2 * q + h];
+        off += (size_t)in * 256 + 256;
+    }
+    // blob order after pts_linears: views_linears_0 (w, b), feature_linear (w, b), alpha_linear (w, b), rgb_linear (w, b)
+    off += (size_t)(d.input_ch_views + 256) * 128 + 128;
+    off += (size_t)256 * 256 + 256;
+    const float *aw = hp.data() + off;
+    img.insert(img.end(), bias.begin(), bias.end());
+    for (int k = 0; k < 256; k++) img.push_back(aw[k]);
+    img.push_back(aw[256]);
+    for (int k = 0; k < 3; k++) img.push_back(0.0f);
+    const size_t bytes = img.size() * sizeof(float);
+    if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
+    if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));
+    m->packed_sigma_f32_bytes = bytes;
+    NRF_HIP(hipMemcpy(m->d_packed_sigma_f32, img.data(), bytes, hipMemcpyHostToDevice));
+    return NRF_OK;
+}
+
+int mlp_nerf_sigma_f32_available(const nrf_mlp *m) { return m && m->family == MLP_NERF && m->d_packed_sigma_f32 != nullptr; }
+
+// sigma [p] of the classic network, bit-identical to NRF_PREC_F32: points explicit (pts [p,3]) or formed from (rays, z) as o + d z
+int mlp_nerf_sigma_f32(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, int64_t p, float *sigma, hipStream_t st)
+{
+    if (!mlp_nerf_sigma_f32_available(m)) { set_error("internal: fp32 matrix-core sigma image of the classic network missing"); return NRF_ERR_UNSUPPORTED; }
+    if (p == 0) return NRF_OK;
+    ProfScope prof(NRF_PROF_SIGMA, st);
+    NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nsig::k_sigma_nerf_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nsig::LDS_BYTES));
+    const int64_t nblocks = ceil_div(p, nsig::BLK);
+    const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);          // persistent: one 4-wave workgroup per CU
+    hipLaunchKernelGGL(nsig::k_sigma_nerf_f32, dim3(grid), dim3(64 * nsig::NW), nsig::LDS_BYTES, st, p, pts, rays, ray_stride, z, s,
+                       reinterpret_cast<const float *>(m->d_packed_sigma_f32), sigma);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+}  // namespace nrf

@@ -2216,3 +2216,34 @@ def test_baseline_config_1_shape_coarse_only_batch_of_1024_rays(api, O):
     rps = api.S.lego_render_params(sc["bbox"], n_samples=64, n_importance=0, chunk=1024 * 32, precision=api.L.NRF_PREC_F16_SPLIT, white_bkgr=False)
     sp = sc["renderer"].Render(h, w, K, rps, rays=(ro, rd, cone))
     assert_close(host(sp.Outputs.RGBMap), oc["rgb"], rtol=0, atol=1e-4, what="config 1 in split precision: every pixel within 1e-4 of the oracle")
+
+
+def test_classic_exact_coarse_sigma_pass_reproduces_the_parity_sample_set(api, O):
+    """The classic renderer's timed mode (NRF_PREC_F16_SPLIT, NRF_COARSE_AUTO): the coarse pass is the density branch alone -- eight 256-wide layers with the
+    skip-concat, then alpha_linear -- in exact fp32 on the matrix cores (sigma_nerf_f32.hip).  Its sigma, hence the coarse weights and the fine sample set, must
+    EQUAL the NRF_PREC_F32 render's bit for bit (which equals the CPU oracle), on a 16-row band of the 800x800 frame with ragged chunks; every pixel value is then
+    within 1e-4 (strict).  NRF_COARSE_FULL (coarse pass in split arithmetic, 2.2 x faster) stays available and is looser, as documented."""
+    sc = api.S.make_classic_scene()
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    kw = dict(chunk=333, KeepIntermediates="depths", ReturnWeights=True)
+    a = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], precision=api.L.NRF_PREC_F32, **kw), c2w=c2w, row0=392, rows=16)
+    b = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], precision=api.L.NRF_PREC_F16_SPLIT, **kw), c2w=c2w, row0=392, rows=16)
+    assert_exact(host(b.Extras["z_coarse"]), host(a.Extras["z_coarse"]))
+    assert_exact(host(b.Extras["weights_coarse"]), host(a.Extras["weights_coarse"]), "coarse weights: exact-fp32 matrix-core density branch == the fp32 FMA chains")
+    assert_exact(host(b.Extras["z_fine"]), host(a.Extras["z_fine"]), "fine sample set of the timed classic mode == NRF_PREC_F32's, bit for bit (12 800 rays)")
+    d = np.abs(host(b.Outputs.RGBMap) - host(a.Outputs.RGBMap))
+    assert d.max() < 1e-4, d.max()                                   # strict: every pixel value
+    wa, wb = host(a.Outputs.Weights), host(b.Outputs.Weights)
+    assert_close(wb, wa, rtol=0, atol=2e-5, what="fine weights: split-precision network on the same samples")
+    # a sample of the band against the CPU oracle itself
+    rays = host(a.Extras["rays_flat"])[::50]
+    oc = O.render_rays(O.Model(1, sc["mlp_blob"], bbox=sc["bbox"]), rays, 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True, want_intermediates=True)
+    assert_exact(host(b.Extras["z_fine"])[::50], oc["z_fine"], "== the CPU oracle's sample set")
+    assert np.abs(host(b.Outputs.RGBMap).reshape(-1, 3)[::50] - oc["rgb"]).max() < 1e-4
+    # the cheaper mode: whole network in split arithmetic on the coarse pass (its outputs reused by the fine pass)
+    c = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], precision=api.L.NRF_PREC_F16_SPLIT, CoarseMode=api.L.NRF_COARSE_FULL, **kw), c2w=c2w, row0=392, rows=16)
+    dc = np.abs(host(c.Outputs.RGBMap) - host(a.Outputs.RGBMap))
+    assert (dc < 1e-4).mean() > 0.99 and api.S.psnr(host(c.Outputs.RGBMap), host(a.Outputs.RGBMap)) > 70
+    # plain fp16 precision may ask for the exact coarse pass too (NRF_COARSE_SIGMA_F32)
+    e = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], precision=api.L.NRF_PREC_F16_MFMA, CoarseMode=api.L.NRF_COARSE_SIGMA_F32, **kw), c2w=c2w, row0=392, rows=2)
+    assert_exact(host(e.Extras["z_fine"]), host(a.Extras["z_fine"])[:1600], "fp16 fine pass on the fp32 sample set")
