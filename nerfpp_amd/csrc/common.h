@@ -49,6 +49,16 @@ void set_error(const char *fmt, ...);
         if (s_ != NRF_OK) return s_;   \
     } while (0)
 
+// One-time kernel attribute setup (the dynamic-LDS window of a kernel) is per DEVICE, not per process: a process that drives several GPUs (the nrf_comm_* C ABI
+// allows one communicator per device) must set it on each.  needed() is true until done() has been called for the calling thread's current device; the setup
+// itself is idempotent, so two first callers racing on the same device both run it.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static uint64_t bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool needed() const { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -414,14 +414,14 @@ static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipS
     const int64_t nblocks = NL == 2 ? ceil_div(p, SNBLK) : ceil_div(p / a.s, (int64_t)SNW);       // kernel B: one ray per wave
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 4-wave workgroup per CU
     const half8 *img = reinterpret_cast<const half8 *>(m->d_packed_split);
-    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;          // idempotent one-time setup per device (common.h)
+    if (attr_set.needed()) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     if (NL == 4 && a.geo) {
         if (!a.x_lm) { set_error("LeRF passes: the sigma net's output is handed over on the level-major input path only"); return NRF_ERR_INVALID_ARG; }

@@ -405,11 +405,11 @@ int mlp_nerf_forward_split(const nrf_mlp *m, const NerfInput &in, bool fused, in
     const size_t lds = (size_t)3 * SMAXF * 1024;          // + the static bias array
     const int64_t nblocks = ceil_div(p, SNBLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // one persistent workgroup per CU
-    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;          // idempotent one-time setup per device (common.h)
+    if (attr_set.needed()) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_nerf_split<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     const half8 *packed = reinterpret_cast<const half8 *>(m->d_packed_split);
     const float *biases = reinterpret_cast<const float *>(static_cast<const char *>(m->d_packed_split) + img_bytes);

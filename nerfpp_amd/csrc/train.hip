@@ -752,9 +752,9 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<uint4 *>(ws + off_rec)};
     const int64_t entries = nrf_hash_table_elems(h) / 2;
     const bool ngp = h->desc.mode == NRF_HASH_NGP;
-    static std::atomic<bool> attr_set{false};          // idempotent one-time setup; atomic so that concurrent first calls do not race on the flag
+    static PerDeviceOnce attr_set;          // idempotent one-time setup per device (common.h)
     const size_t lds = (size_t)BIN_WORDS * 8;
-    if (!attr_set) { NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    if (attr_set.needed()) { NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.done(); }
     // same groups and the same scale as the packed form: the integer fields are identical, so is the result
     for (int64_t r0 = 0; r0 < n; r0 += rays_per_group) {
         const int64_t nr = (n - r0) < rays_per_group ? (n - r0) : rays_per_group;
