@@ -11,6 +11,7 @@ mkdir -p gpurun_out
 (timeout -k 10 600 python bench.py --steps 3 --warmup 1 --precision f32 --no-cpu-baseline --no-also 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_hashnerf_f32.json
 (timeout -k 10 600 python bench.py --workload classic --steps 5 --warmup 1 --no-also 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_classic_f16x3.json
 (timeout -k 10 600 python bench.py --gpus 2 --backend gloo --no-cpu-baseline --no-parity 2>gpurun_out/${tag}_rehearsal.err | tail -1) > gpurun_out/${tag}_rehearsal_2ranks_one_gpu_gloo.json
+(timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --backend gloo --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-also 2>gpurun_out/${tag}_rehearsal_torchrun.err | tail -1) > gpurun_out/${tag}_rehearsal_2ranks_one_gpu_gloo_torchrun.json
 (timeout -k 10 300 python bench.py --force-dist --collective cabi --scaling strong --no-also --no-cpu-baseline 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_strong_cabi_world1.json
 ROOTD=$PWD
 cd /tmp && export TMPDIR=/tmp
