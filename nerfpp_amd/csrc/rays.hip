@@ -402,8 +402,14 @@ int nrf_view_rays(const nrf_view *v, float *d_rays, float *d_near_far, void *str
     NRF_TRY(nrf_view_check(v, "nrf_view_rays"));
     NRF_CHECK_ARG(d_rays || v->rows == 0, "nrf_view_rays: null ray buffer");
     const int64_t n = (int64_t)v->rows * v->w;
-    if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
+    if (n == 0) {                                  // an empty tile (h < world): Near / Far of no rays = (+inf, -inf), the identities of min / max
+        if (d_near_far) {
+            hipLaunchKernelGGL(k_nf_init, dim3(1), dim3(1), 0, st, reinterpret_cast<int *>(d_near_far)); NRF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_nf_decode, dim3(1), dim3(1), 0, st, reinterpret_cast<const int *>(d_near_far), d_near_far); NRF_LAUNCH_CHECK();
+        }
+        return NRF_OK;
+    }
     NdcConst nc{};
     if (v->ndc) {
         // RayUtils.h:63-71 with focal = k[0][0], near = 1.f (NeRFRenderer.h:567)

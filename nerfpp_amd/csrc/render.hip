@@ -532,7 +532,7 @@ int nrf_render_rows(const nrf_renderer *r, const nrf_view *v, const nrf_render_p
         return NRF_ERR_UNSUPPORTED;
     }
     const int64_t n = (int64_t)v->rows * v->w;
-    if (n == 0) return NRF_OK;
+    if (n == 0) return nrf_view_rays(v, nullptr, d_near_far, stream);        // an empty tile: only Near / Far (= +inf / -inf) are defined
     const int stride = v->use_viewdirs ? 11 : 8;
     if (workspace_bytes < nrf_render_rows_workspace_bytes(r, v, p)) {
         set_error("nrf_render_rows: workspace %zu < %zu bytes", workspace_bytes, nrf_render_rows_workspace_bytes(r, v, p));

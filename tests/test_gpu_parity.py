@@ -2084,6 +2084,15 @@ def test_render_rows_single_call_equals_the_stagewise_host_loop(api, prec):
     assert_exact(host(full.Outputs.RGBMap)[13:50], host(tile.Outputs.RGBMap), "row tile == rows of the frame")
 
 
+def test_render_rows_empty_tile(api):
+    """A rank that owns no rows (h < world) renders an empty tile: no launch but the Near / Far identities, outputs of zero rays."""
+    sc = api.S.make_hash_scene(mode="ngp", log2_t=12)
+    rp = api.S.lego_render_params(sc["bbox"], chunk=64)
+    res = sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0), row0=8, rows=0)
+    assert res.Outputs.RGBMap.shape == (0, 8, 3) and res.Extras["rays_flat"].shape == (0, 11)
+    assert res.Near == float("inf") and res.Far == float("-inf")
+
+
 def test_render_rows_argument_errors(api):
     import ctypes as C
     sc = api.S.make_hash_scene(mode="ngp", log2_t=12)
