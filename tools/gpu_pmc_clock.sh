@@ -22,8 +22,8 @@ for d in sorted(glob.glob(f"gpurun_out/{tag}_*/")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not any(s in k for s in ("k_mlp_small_mfma", "k_mlp_nerf_mfma", "k_mlp_nerf_split", "k_sigma_small_f32", "k_hash_cu_lm")): continue
-            short = "mlp_small" if "k_mlp_small" in k else ("mlp_nerf_split" if "k_mlp_nerf_split" in k else ("mlp_nerf" if "k_mlp_nerf" in k else ("sigma_small_f32" if "k_sigma" in k else "hash_encode")))
+            if not any(s in k for s in ("k_mlp_small_mfma", "k_mlp_nerf_mfma", "k_mlp_nerf_split", "k_sigma_small_f32", "k_sigma_nerf_f32", "k_hash_cu_lm")): continue
+            short = "mlp_small" if "k_mlp_small" in k else ("mlp_nerf_split" if "k_mlp_nerf_split" in k else ("mlp_nerf" if "k_mlp_nerf" in k else ("sigma_nerf_f32" if "k_sigma_nerf" in k else ("sigma_small_f32" if "k_sigma" in k else "hash_encode"))))
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
         run = d.rstrip("/").split(tag + "_")[1].split("_GRBM")[0].split("_SQ_")[0]
         for short, v in agg.items():

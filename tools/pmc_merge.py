@@ -36,7 +36,7 @@ for k, v in res.items():
 if os.path.exists(clk):
     c = json.load(open(clk))
     names = {"mlp_small": "mlp_small (k_mlp_small_mfma)", "mlp_nerf_split": "mlp_nerf_split (k_mlp_nerf_split)", "mlp_nerf": "mlp_nerf (k_mlp_nerf_mfma)",
-             "sigma_small_f32": "sigma_small_f32 (k_sigma_small_f32)", "hash_encode": "hash_encode (k_hash_cu_lm)"}
+             "sigma_small_f32": "sigma_small_f32 (k_sigma_small_f32)", "sigma_nerf_f32": "sigma_nerf_f32 (k_sigma_nerf_f32)", "hash_encode": "hash_encode (k_hash_cu_lm)"}
     for run, kernels in c.items():            # run = "<workload>_<precision>"
         prec = run.split("_")[-1]
         for short, ctr in kernels.items():
@@ -46,8 +46,8 @@ if os.path.exists(clk):
             e = res.setdefault(key, {})
             if "SQ_VALU_MFMA_BUSY_CYCLES" in ctr and "GRBM_GUI_ACTIVE" in ctr and ctr["GRBM_GUI_ACTIVE"] > 0:
                 e.setdefault("mfma_busy_frac_of_active_cycles", {})[prec] = (ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (ctr["GRBM_GUI_ACTIVE"] / 8.0)
-            if "SQ_VALU_MFMA_COEXEC_CYCLES" in ctr and "SQ_BUSY_CYCLES" in ctr and ctr["SQ_BUSY_CYCLES"] > 0:
-                e.setdefault("mfma_valu_coexec_frac_of_sq_busy_cycles", {})[prec] = ctr["SQ_VALU_MFMA_COEXEC_CYCLES"] / ctr["SQ_BUSY_CYCLES"]
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in ctr and "GRBM_GUI_ACTIVE" in ctr and ctr["GRBM_GUI_ACTIVE"] > 0:       # same normalisation as the busy share: per SIMD over per XCD
+                e.setdefault("mfma_valu_coexec_frac_of_active_cycles", {})[prec] = (ctr["SQ_VALU_MFMA_COEXEC_CYCLES"] / 1024.0) / (ctr["GRBM_GUI_ACTIVE"] / 8.0)
 res["_meta"] = {
     "commit": commit,
     "kernel_source_sha256_16": {k: bench.kernel_source_hash(k) for k in bench.PMC_KERNEL_SOURCES},

@@ -21,6 +21,7 @@ for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}
         if "k_hash_cu_lm" in k: short = "hash_encode (k_hash_cu_lm)"
         elif "k_mlp_small_mfma" in k: short = "mlp_small (k_mlp_small_mfma)"
         elif "k_sigma_small_f32" in k: short = "sigma_small_f32 (k_sigma_small_f32)"
+        elif "k_sigma_nerf_f32" in k: short = "sigma_nerf_f32 (k_sigma_nerf_f32)"
         elif "k_mlp_nerf_split" in k: short = "mlp_nerf_split (k_mlp_nerf_split)"
         elif "k_mlp_nerf_mfma" in k: short = "mlp_nerf (k_mlp_nerf_mfma)"
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
