@@ -63,9 +63,9 @@ SIGMA_FLOP_PER_UNIT = 2 * (32 * 64 + 64 * 64 + 64)
 LERF_FLOP_PER_UNIT = 557568
 LERF_SIGMA_FLOP_PER_UNIT = 2 * (128 * 256 + 256 * 33)                        # the density net alone (the coarse pass's exact-fp32 kernel, geo rows included)
 # matrix instructions (32x32x16 fp16 = 32 768 flop) the split-precision LeRF passes issue per 32 points: the sigma pass on the new samples (layer 0 on exact-fp16
-# features: 2 products, layer 1: 3) and the embedding pass from LE0 on (LE0: 8 tiles x (8 x 2 + 4 x 3), Gram: 8 x 16 x 3); the 256 -> 768 layer runs once per RAY
+# features: 2 products, layer 1: 3) and the embedding pass from LE0 on (LE0: 8 tiles x (8 x 2 + 4 x 3), Gram: 8 x 16 x 1); the 256 -> 768 layer runs once per RAY
 LERF_SPLIT_MFMA_SIGMA = 8 * 8 * 2 + 2 * 16 * 3
-LERF_SPLIT_MFMA_EMBED = 8 * (8 * 2 + 4 * 3) + 8 * 16 * 3
+LERF_SPLIT_MFMA_EMBED = 8 * (8 * 2 + 4 * 3) + 8 * 16 * 1                       # LE0 in split precision; the Gram product (a scalar norm per sample) on the hi parts only
 LERF_HASH_BYTES_PER_UNIT = 16 * 8 * 8 * 2 + 12 + 16 * 8 * 2                    # CuHash F = 8: 2 048 B of table reads + the point + 256 B of level-major fp16 features
 HBM_PEAK = 8.0e12
 MFMA_F16_PEAK = 2.5e15
@@ -643,7 +643,8 @@ def lerf_oracle_check(sc, res, nrays=256):
     eg = res.Outputs.RenderedLangEmbedding.cpu().numpy()[idx]
     cos = (eg * ref).sum(1)
     same = (zg == zf).all(1)
-    return dict(rays=int(idx.size), fine_sample_set_bit_identical_rays=float(same.mean()), weights_max_abs_err_over_max=float(np.abs(wg - fin["weights"])[same].max() / fin["weights"].max()) if same.any() else None,
+    return dict(rays=int(idx.size), embedding_max_abs_err=float(np.abs(eg - ref).max()), embedding_rms_err=float(np.sqrt(((eg - ref).astype(np.float64) ** 2).mean())),
+                fine_sample_set_bit_identical_rays=float(same.mean()), weights_max_abs_err_over_max=float(np.abs(wg - fin["weights"])[same].max() / fin["weights"].max()) if same.any() else None,
                 embedding_cos_min=float(cos.min()), embedding_cos_min_same_samples=float(cos[same].min()) if same.any() else None, embedding_cos_median=float(np.median(cos)),
                 against="CPU oracle, fp32 stage path end to end (its own coarse pass and fine sample set)")
 

@@ -89,7 +89,7 @@ struct CtxS {
 };
 
 // One chunk = neuron tile T of layer L; the finished tile (main + correction accumulator) goes to hook(T, tile).  BNLO / BCLO: the natural / chained operand has a lo part.
-template <class N, int L, int T, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook>
 __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
 {
     using F = typename N::F;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         const bool nat = NATF ? (k < KSN) : (k >= KSC);
         const int kk = NATF ? (nat ? k : k - KSN) : (nat ? k - KSC : k);
         const half8 bh = nat ? bn[nat ? kk : 0][0] : bc[nat ? 0 : kk][0];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        if constexpr (WLO) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);      // WLO = false: the weights' lo fragments are not applied (see the Gram layer)
         if (nat ? BNLO : BCLO) {
             const half8 bl = nat ? bn[nat ? kk : 0][1] : bc[nat ? 0 : kk][1];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
@@ -159,24 +159,24 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ) : "memory");
 }
 
-template <class N, int L, int T, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook>
 __device__ __forceinline__ void chunk_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
 {
     const int cur = *cx.cur;
-    chunk_body_s<N, L, T, BNLO, BCLO>(cx, cx.wbuf + cur * (SMAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (SMAXF * 64), bn, bc, hook);
+    chunk_body_s<N, L, T, BNLO, BCLO, WLO>(cx, cx.wbuf + cur * (SMAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (SMAXF * 64), bn, bc, hook);
     *cx.cur = cur == 2 ? 0 : cur + 1;
 }
 
-template <class N, int L, bool BNLO, bool BCLO, int NN, int NC, class Hook, int... Ts>
+template <class N, int L, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, int... Ts>
 __device__ __forceinline__ void layer_seq_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, std::integer_sequence<int, Ts...>)
 {
-    (chunk_s<N, L, Ts, BNLO, BCLO>(cx, bn, bc, hook), ...);
+    (chunk_s<N, L, Ts, BNLO, BCLO, WLO>(cx, bn, bc, hook), ...);
 }
 
-template <class N, int L, bool BNLO, bool BCLO, int NN, int NC, class Hook>
+template <class N, int L, bool BNLO, bool BCLO, bool WLO = true, int NN, int NC, class Hook>
 __device__ __forceinline__ void layer_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
 {
-    layer_seq_s<N, L, BNLO, BCLO>(cx, bn, bc, hook, std::make_integer_sequence<int, N::F::tiles(L)>{});
+    layer_seq_s<N, L, BNLO, BCLO, WLO>(cx, bn, bc, hook, std::make_integer_sequence<int, N::F::tiles(L)>{});
 }
 
 template <bool RELU, int NOUT, bool KEEP0 = false>
@@ -348,7 +348,18 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
                 layer_s<N, 2, XLO, true>(cx, xin, bb, c2);                // LE0: cat[geo, in] -> 256, ReLU
             }
             DotHookS ssq{ba};
-            layer_s<N, 3, false, true>(cx, none, ba, ssq);                // ||LE1(a)||^2 = a . (W^T W) a
+            // The Gram product supplies ONE scalar per sample, the norm ||W a|| that scales the sample's share of the ray's sum; the embedding's DIRECTION comes from
+            // the split-precision sum of a and kernel C.  An fp16-grade norm (relative error ~1e-4: rounding of a and of G, no lo parts) perturbs the shares by as much
+            // and the rendered unit embedding by < 1e-6 per component -- measured against the CPU oracle on 256 rays of the bench frame (max abs error, rms):
+            //   three products (Gh.ah + Gl.ah + Gh.al) 3.6e-7 / 3.4e-8, 97.1 ms of LeRF passes per frame;  two (a's hi part) 7.6e-7 / 9.1e-8, 87.4 ms;
+            //   ONE (Gh.ah) 8.8e-7 / 1.2e-7, 77.5 ms -- the default.  cos >= 1 - 1.2e-7 in all three (profiles/round3/r3i_lerf_gram_products.log).
+#ifndef NRF_LERF_GRAM_ALO
+#define NRF_LERF_GRAM_ALO 0              // 1: the lo part of a enters the Gram product
+#endif
+#ifndef NRF_LERF_GRAM_GLO
+#define NRF_LERF_GRAM_GLO 0              // 1: the lo part of the Gram matrix enters it
+#endif
+            layer_s<N, 3, false, NRF_LERF_GRAM_ALO != 0, NRF_LERF_GRAM_GLO != 0>(cx, none, ba, ssq);   // ||LE1(a)||^2 = a . (W^T W) a
             const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
             const float wgt = live ? in.weights[q] : 0.0f;
             const float f = wgt / fmaxf(sqrtf(tot), 1e-8f);

@@ -1963,7 +1963,11 @@ def test_lerf_fused_split_precision_vs_fp32_stage_path(api, O, manifest):
     wd = dev(w)
     api.L.check(api.L.lib().nrf_lerf_render_embedding_lm(lerf._m, C.c_void_p(x_gpu.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_int64(144), 32, C.c_void_p(acc.data_ptr()), None))
     ref = (w[:, :, None] * raw[:, :768].reshape(144, 32, 768)).sum(1)
-    assert_close(host(acc), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), what="sum_s w_s normalize(le_s), split precision")
+    # the per-sample norm ||W a|| comes from the Gram product on the hi parts only (one scalar per sample, fp16-grade: ~1e-4 relative, mlp_lerf_split_mfma.hip): the
+    # un-normalised sum carries that as a common-mode scale error of a few 1e-5; its DIRECTION -- what RenderCLIPEmbedding returns -- stays fp32-grade
+    assert_close(host(acc), ref, rtol=0, atol=6e-5 * np.abs(ref).max(), what="sum_s w_s normalize(le_s), split precision")
+    unit = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    assert np.abs(unit(host(acc).astype(np.float64)) - unit(ref.astype(np.float64))).max() < 2e-6, "direction of the per-ray sum"
     # fp32 feature rows (values are fp16 numbers here, so hi + lo carries them exactly): same result as the level-major input
     x_rows = dev(host(x_gpu).astype(np.float32).transpose(1, 0, 2).reshape(144 * 32, 128))
     sig_r = torch.empty((144 * 32,), device="cuda")
