@@ -69,15 +69,27 @@ __device__ __forceinline__ void stage_chunk(const Ctx &cx, f32x4 *dst, int g0, i
 
 // One neuron tile: G groups of four k-steps, A fragments from LDS (read through asm so that the compiler does not order them against the look-ahead DMA into the
 // OTHER buffer), B operand bfn(ks); returns the finished tile with bias and ReLU applied.  NEXT_G: groups of the chunk to prefetch.
+// Tried: accumulating tile mt straight into the caller's output tile while the PREVIOUS tile's bias / ReLU epilogue runs behind this tile's first matrix
+// instructions (one wave per SIMD: nothing else overlaps those ~40 vector instructions).  The extra live ranges cost 141 spilled registers on top of the
+// 499 in use, the build was no faster (342 ms per frame's coarse pass, inside this kernel's 328-357 ms run-to-run spread) and it failed the bit-exactness test
+// (not chased further) -- not kept.
 template <int G, class BFn>
 __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, BFn bfn)
 {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 *w = cx.wbuf + cx.cur * (MAXG * 64);
     f32x4 *nxt = cx.wbuf + (cx.cur ^ 1) * (MAXG * 64);
-    // The look-ahead DMA of the next chunk, issued in one burst ahead of the tile's matrix instructions (8-10 pieces per wave).  Dealing the pieces out over the
-    // tile's groups instead -- what pays in the fp16 split kernels -- made THIS kernel slower (417 vs 362 ms per frame's coarse pass, same box).
-    stage_chunk(cx, nxt, cx.next_group, next_ng);
+    // The look-ahead DMA of the next chunk: this wave's pieces (groups wave, wave + 4, ...: 2-10 of them) go out one per group behind the tile's FIRST matrix
+    // instructions -- a piece costs its issuing wave ~60 cycles (MI355X_MICROARCH.md), which overlap the 256 pipe cycles of the group in flight instead of standing in
+    // front of the tile's first matrix instruction -- and have the remaining >= 20 groups (~5 000 cycles) to land before the end-of-tile wait.  Worth ~1 %: same
+    // box, alternating runs, this / one burst per tile: 355.6 / 357.0 and 328.3 / 332.1 ms per frame's coarse pass (the kernel's time moves 8 % from run to run with
+    // the clock; a first comparison across two gpurun calls had suggested 9 %).
+#ifndef NRF_NSIG_DMA_SPREAD
+#define NRF_NSIG_DMA_SPREAD 1
+#endif
+    const f32x4 *dsrc = cx.image + (size_t)cx.next_group * 64 + cx.lane;
+    const int npieces = (next_ng - cx.wave + NW - 1) / NW;
+    if (!NRF_NSIG_DMA_SPREAD) stage_chunk(cx, nxt, cx.next_group, next_ng);
     cx.next_group += next_ng;
     if (cx.next_group >= TOTAL_GROUPS) cx.next_group = 0;
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
@@ -98,9 +110,20 @@ __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, 
         const f32x4 a4 = fa[g % 3];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bfn(4 * g + j), acc, 0, 0, 0);
+        if (NRF_NSIG_DMA_SPREAD && g < 10 && g < npieces) {
+            const int q = cx.wave + NW * g;
+            __builtin_amdgcn_global_load_lds(dsrc + (size_t)q * 64, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (NRF_NSIG_DMA_SPREAD) {
+        for (int g = G < 10 ? G : 10; g < npieces; g++) {          // layer 0's 8-group tiles ahead of a 10-piece chunk
+            const int q = cx.wave + NW * g;
+            __builtin_amdgcn_global_load_lds(dsrc + (size_t)q * 64, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
+        }
+    }
 #undef NRF_RD
+    // the next chunk has landed (this wave's pieces) and every wave is done with this buffer
     // bias (one rounding, after the chain: the oracle's `acc += b`) and ReLU; [layer][tile][lane half][16] so that a lane reads 16 consecutive floats
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(cx.bias_s + ((layer * 8 + mt) * 2 + cx.hh) * 16);
 #pragma unroll
