@@ -43,7 +43,7 @@ def executed_per_ray(workload, precision, hash_mode, coarse_full=False):
         return UNITS_PER_RAY, UNITS_PER_RAY, 0
     if workload == "classic":
         if precision == "f16x3" and coarse_full is False:
-            return 0, NS + NI, NS                                 # coarse pass: the density branch alone in exact fp32 (sigma_nerf_f32.hip); the fine pass evaluates all 192 depths
+            return 0, NI, NS                                      # coarse pass: density branch in exact fp32 + colour branch on the exact h8 (sigma_nerf_f32.hip); the fine pass evaluates the 128 new depths
         return 0, NS + NI, 0                                      # whole network on the coarse pass, its outputs reused by the fine pass: 64 + 128 evaluations
     if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32)
         return NS + NI, NS + NI, NS                           # both encoders: the fine pass keeps the coarse pass's feature columns
@@ -559,7 +559,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
             ex_hash, ex_mlp, ex_sigma = executed_per_ray(wl, pname, args.hash_mode, coarse_full=(coarse != "exact") if wl == "classic" else False)
             rec = dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
                        precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=n_fr, kernel_ms=kms,
-                       **({"coarse_pass": "density branch in exact fp32 on the matrix cores (sigma_nerf_f32.hip): the fp32 path's sample set" if coarse == "exact"
+                       **({"coarse_pass": "density branch in exact fp32 on the matrix cores + colour branch on the exact h8 (sigma_nerf_f32.hip): the fp32 path's sample set, outputs reused by the fine pass" if coarse == "exact"
                            else "whole network in the timed arithmetic, outputs reused by the fine pass (NRF_COARSE_FULL)"} if coarse else {}),
                        executed_evaluations_per_ray=dict(hash_encode=ex_hash, fused_mlp=ex_mlp, sigma_only=ex_sigma))
             mk = kms["mlp"]
@@ -567,11 +567,11 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                 rec["roofline"] = mfma_roofline("mlp_nerf" + ("_split" if pname == "f16x3" else ""), H * W * ex_mlp, NERF_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3,
                                                 mk["launches_per_frame"], issued_flop_per_unit=(3.0 if pname == "f16x3" else 1.0) * 1058 * 32768 / 32,
                                                 note="algorithmic 1 186 816 flop of NeRFImpl::forward as written x the network evaluations the kernel executed "
-                                                     "(192 per ray: the fine pass's 64 coarse depths take the coarse pass's outputs); issued: 1 058 matrix instructions per 32 points"
+                                                     "(the fine pass's 64 coarse depths take the coarse pass's outputs); issued: 1 058 matrix instructions per 32 points"
                                                      + (" x 3 products (hi + lo operand pairs)" if pname == "f16x3" else ""))
                 sk = kms["sigma"]
                 if sk["launches_per_frame"]:
-                    rec["roofline"]["sigma_exact"] = mfma_roofline("sigma_nerf_f32 (coarse pass: density branch in exact fp32, v_mfma_f32_32x32x2_f32)", H * W * ex_sigma, NERF_SIGMA_FLOP_PER_UNIT,
+                    rec["roofline"]["sigma_exact"] = mfma_roofline("sigma_nerf_f32 (coarse pass: density branch in exact fp32, v_mfma_f32_32x32x2_f32; + the colour branch in split fp16, 2 % of its matrix time)", H * W * ex_sigma, NERF_SIGMA_FLOP_PER_UNIT,
                                                                    sk["ms_per_frame"] * 1e-3, sk["launches_per_frame"], peak=F32_PEAK)
             else:
                 rec["roofline"] = mfma_roofline("mlp_small", H * W * ex_mlp, SMALL_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],

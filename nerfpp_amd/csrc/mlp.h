@@ -75,7 +75,8 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 // sigma_nerf_f32.hip: the classic network's density branch in exact fp32 on the matrix cores (coarse pass)
 int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_nerf_sigma_f32_available(const nrf_mlp *m);
-int mlp_nerf_sigma_f32(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, int64_t p, float *sigma, hipStream_t st);
+int mlp_nerf_exact_coarse(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, const __half *dirs_lo, int64_t p,
+                          float *raw, hipStream_t st);
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_lerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);      // sigma_lerf_f32.hip
 

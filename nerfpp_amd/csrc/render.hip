@@ -369,11 +369,12 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     const bool classic_split = p->precision == NRF_PREC_F16_SPLIT;
     const bool fast_classic = (p->precision == NRF_PREC_F16_MFMA || classic_split) && !r->desc.hash && r->desc.pe_freqs == 10 && r->desc.dirs_encoder == NRF_DIRS_PE &&
                               r->desc.dirs_param == 4 && (classic_split ? mlp_nerf_split_available(r->desc.mlp) : mlp_nerf_mfma_available(r->desc.mlp));
-    // ... and its coarse pass: the density branch alone (eight 256-wide layers + alpha_linear) in exact fp32 on the matrix cores (sigma_nerf_f32.hip).  The fine
-    // pass then evaluates all S + N_importance depths (the coarse pass leaves no colours to reuse): 2.2 x the time of NRF_COARSE_FULL for the fp32 path's sample set
-    const bool sigma_only_classic = ni > 0 && fast_classic && !out->d_raw_coarse && mlp_nerf_sigma_f32_available(r->desc.mlp) &&
-                                    (p->coarse_mode == NRF_COARSE_SIGMA_F32 || (p->coarse_mode == NRF_COARSE_AUTO && classic_split));
-    const bool sigma_only = sigma_only_hash || sigma_only_classic;
+    // ... and its coarse pass: the density branch (eight 256-wide layers + alpha_linear) in exact fp32 on the matrix cores, followed in the same kernel by the colour
+    // branch on the exact h8 in split precision (sigma_nerf_f32.hip).  Sigma -- hence the coarse weights and the fine sample set -- equals NRF_PREC_F32's bit for bit, and
+    // the coarse pass still leaves whole (rgb, sigma) rows for the fine pass to reuse at its S coarse depths.  2 x the time of NRF_COARSE_FULL.
+    const bool exact_classic = ni > 0 && fast_classic && mlp_nerf_sigma_f32_available(r->desc.mlp) && c == 4 &&
+                               (p->coarse_mode == NRF_COARSE_SIGMA_F32 || (p->coarse_mode == NRF_COARSE_AUTO && classic_split));
+    const bool sigma_only = sigma_only_hash;
     __half *dirs16 = nullptr;
     __half *dirs_lo = nullptr;
     if (fast) dirs16 = bump.take<__half>((size_t)n * r->in_views);
@@ -434,7 +435,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         else NRF_TRY(launch_hash_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.keep, HASH_LM_DEFAULT_VARIANT, st));
         if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, ngp ? static_cast<const void *>(rw.f32) : rw.feats, ngp ? 1 : 0, ngp ? n * (int64_t)s : rw.cols, rw.keep, n * (int64_t)s, raw_c, st));
         else NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, s, rw.keep, n * (int64_t)s, raw_c, st));
-    } else if (sigma_only_classic) NRF_TRY(mlp_nerf_sigma_f32(r->desc.mlp, ps.pts, ps.rays, ps.ray_stride, ps.z, s, n * (int64_t)s, raw_c, st));   // raw_c holds sigma [n,s] only
+    } else if (exact_classic) NRF_TRY(mlp_nerf_exact_coarse(r->desc.mlp, ps.pts, ps.rays, ps.ray_stride, ps.z, s, dirs16, dirs_lo, n * (int64_t)s, raw_c, st));
     else if (sigma_only) NRF_TRY(run_sigma_fast(r, ps, n, s, raw_c, nws, nws_bytes, st));                         // raw_c holds sigma [n,s] only
     else NRF_TRY(network(ps, s, raw_c));                                                                           // :422
     nz.stream = NRF_RNG_NOISE_COARSE;

@@ -7,8 +7,10 @@
 // within an error bound of a CDF edge) cannot close that gap: u_127 = 1.0 is compared with the CDF's top plateau, whose entries sit within 1e-7 of 1.0 on every
 // ray that saturates, so whether cdf_i <= 1.0 holds depends on the last bit of the weight sum -- nearly every ray would be flagged
 // (profiles/round3/r3c_classic_cdf_stats.log).  So the coarse sigma is evaluated in the parity arithmetic itself: v_mfma_f32_32x32x2_f32 is, bit for bit, the
-// ascending-k fmaf chain of NRF_PREC_F32 / the oracle (sigma_small_f32.hip).  The view branch (feature_linear, views_linears, rgb_linear: 17 % of the MACs) is
-// dead work in this pass and is not run.
+// ascending-k fmaf chain of NRF_PREC_F32 / the oracle (sigma_small_f32.hip).  The colour branch (feature_linear, views_linears, rgb_linear: 17 % of the MACs) is
+// dead work for the coarse pass's own result -- but the fine pass re-evaluates the network at the S coarse depths unless the coarse pass leaves whole (rgb, sigma)
+// rows to reuse.  So the kernel's tail runs it on the exact h8 in SPLIT precision on the fp16 matrix instructions (240 of them per 32 points next to 7 680 fp32
+// ones): the renderer's raw-reuse path then evaluates the split-precision network on the N_importance new samples only (frame 645-690 -> 587 ms).
 //
 // Formulation (as sigma_small_f32.hip / sigma_lerf_f32.hip): layers transposed, H^T [256 x points] = W [256 x K] . X^T, A = 32 neurons x 2 k, B = 2 k x 32 points,
 // K / 2 ascending k-steps through ONE accumulator per neuron tile (a dependent chain of this instruction issues back to back, MI355X_MICROARCH.md).  Row i of a
@@ -41,12 +43,23 @@ __host__ __device__ constexpr int chunk_first_group(int l, int mt)              
     for (int i = 0; i < l; i++) n += 8 * groups(i);
     return n + mt * groups(l);
 }
-constexpr int TOTAL_GROUPS = chunk_first_group(NL, 0);
+constexpr int SIGMA_GROUPS = chunk_first_group(NL, 0);
+// the colour branch behind it, as fp16 (hi, lo) fragment pairs (1 KB each, same DMA units): four tiles of views_linears_0 o feature_linear (16 chained k-steps of
+// h8 + 2 natural ones of the direction encoding) and the rgb tile (8 chained k-steps)
+// The views layer runs K-OUTER: a chunk holds four k-steps of ALL four neuron tiles ([tile][k][hi | lo]), so that each operand fragment of h8 is converted once, on the
+// fly from its fp32 tile, and used by the four tiles' matrix instructions at once -- h8 is never held as 128 registers of fragments next to its 128 of fp32.
+constexpr int RGB_KS = 8;                             // (the views layer has 16 chained + 2 natural k-steps)
+constexpr int VIEW_CHUNK_KS = 4;
+constexpr int VIEW_GROUPS = 4 * VIEW_CHUNK_KS * 2, VIEW_LAST_GROUPS = 4 * 2 * 2, RGB_GROUPS = 2 * RGB_KS;      // 32, 16 (the two direction k-steps), 16
+constexpr int TOTAL_GROUPS = SIGMA_GROUPS + 4 * VIEW_GROUPS + VIEW_LAST_GROUPS + RGB_GROUPS;
 constexpr int MAXG = 40;
 constexpr int BIAS_FLOATS = NL * 256;                 // [layer][tile][lane half][16]
 constexpr int ALPHA_FLOATS = 256 + 4;                 // alpha_linear.weight [256] | bias | pad
-constexpr size_t LDS_BYTES = (size_t)2 * MAXG * 1024 + (BIAS_FLOATS + ALPHA_FLOATS) * 4;
-static_assert(TOTAL_GROUPS == 8 * (8 + 6 * 32 + 40), "image size");
+constexpr int VIEW_BIAS_FLOATS = 128 + 4;             // merged bias [tile 4][lane half 2][16] | rgb bias [3] | pad
+constexpr size_t LDS_BYTES = (size_t)2 * MAXG * 1024 + (BIAS_FLOATS + ALPHA_FLOATS + VIEW_BIAS_FLOATS) * 4;
+static_assert(SIGMA_GROUPS == 8 * (8 + 6 * 32 + 40) && VIEW_GROUPS <= MAXG, "image size");
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+__host__ __device__ inline int perm_row(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }      // row of a 32x32 D tile in register 8s + j of lane half h
 
 __host__ __device__ inline int row_neuron(int i) { return 2 * (4 * (i >> 3) + (i & 3)) + ((i >> 2) & 1); }
 
@@ -141,10 +154,96 @@ __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, 
     return acc;
 }
 
-// image: fragments of the 64 chunks | bias [8][8][2][16] | alpha weight [256], alpha bias, pad
+__device__ __forceinline__ void split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+}
+
+// registers 8s..8s+7 of an fp32 tile -> the (hi, lo) fp16 operand fragments of one k-step (v = hi + lo to 22 bits).  The asm reads VALU results only (the max).
+__device__ __forceinline__ void tile_to_frag2(const f32x16 &t, int s, float lim, half8 &hi, half8 &lo)
+{
+    union { half8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) split_pair(fmaxf(t[8 * s + 2 * j], lim), fmaxf(t[8 * s + 2 * j + 1], lim), h.u[j], l.u[j]);
+    hi = h.v; lo = l.v;
+}
+
+// One tile of the colour branch in split precision (mlp_nerf_split_mfma.hip's arithmetic: Wl.xh + Wh.xl + Wh.xh per k-step into one fp32 accumulator): KS k-steps,
+// fragments (hi, lo) adjacent in the LDS chunk, B operand pairs from bfn(ks, part).  Same chunk / look-ahead protocol as tile().
+template <int KS, class BFn>
+__device__ __forceinline__ f32x16 tile16(Ctx &cx, int next_ng, BFn bfn)
+{
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 *w = cx.wbuf + cx.cur * (MAXG * 64);
+    f32x4 *nxt = cx.wbuf + (cx.cur ^ 1) * (MAXG * 64);
+    stage_chunk(cx, nxt, cx.next_group, next_ng);
+    cx.next_group += next_ng;
+    if (cx.next_group >= TOTAL_GROUPS) cx.next_group = 0;
+    const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+    half8 fa[2][2];
+#define NRF_RD2(k_, slot_) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot_][0]), "=&v"(fa[slot_][1]) : "v"(waddr + (uint32_t)(k_) * 2048u))
+    NRF_RD2(0, 0);
+    f32x16 acc = zero;
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        if (k + 1 < KS) {
+            NRF_RD2(k + 1, (k + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k & 1][0]), "+v"(fa[k & 1][1]));
+        } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k & 1][0]), "+v"(fa[k & 1][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 ah = fa[k & 1][0], al = fa[k & 1][1];
+        const half8 bh = bfn(k, 0), bl = bfn(k, 1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef NRF_RD2
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    cx.cur ^= 1;
+    return acc;
+}
+
+// K (<= 4) k-steps of the views layer for all four neuron tiles: acc[t] += (Wl.xh + Wh.xl + Wh.xh)(k) with the chunk laid out [tile][k][hi | lo].  The eight
+// fragments of a k-step are read together; bfn(k, hi, lo) yields the operand pair.
+template <int K, class BFn>
+__device__ __forceinline__ void views_chunk(Ctx &cx, int next_ng, bool first, BFn bfn, f32x16 (&acc)[4])
+{
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 *w = cx.wbuf + cx.cur * (MAXG * 64);
+    f32x4 *nxt = cx.wbuf + (cx.cur ^ 1) * (MAXG * 64);
+    stage_chunk(cx, nxt, cx.next_group, next_ng);
+    cx.next_group += next_ng;
+    if (cx.next_group >= TOTAL_GROUPS) cx.next_group = 0;
+    const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        half8 fa[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[t][0]), "=&v"(fa[t][1]) : "v"(waddr + (uint32_t)((t * K + k) * 2) * 1024u));
+        half8 bh, bl;
+        bfn(k, bh, bl);                                     // the conversion runs while the reads are in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][1], bh, (first && k == 0) ? zero : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], bh, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    cx.cur ^= 1;
+}
+
+// image: fragments of the 64 + 6 chunks | bias [8][8][2][16] | alpha weight [256], alpha bias, pad | merged bias [4][2][16], rgb bias [3], pad
 __global__ void __launch_bounds__(64 * NW, 1)
 k_sigma_nerf_f32(int64_t npts, const float *__restrict__ pts, const float *__restrict__ rays, int ray_stride, const float *__restrict__ z, int s,
-                 const float *__restrict__ image, float *__restrict__ sigma)
+                 const _Float16 *__restrict__ dirs, const _Float16 *__restrict__ dirs_lo, const float *__restrict__ image, float *__restrict__ raw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4 *wbuf = reinterpret_cast<f32x4 *>(smem);
@@ -153,7 +252,8 @@ k_sigma_nerf_f32(int64_t npts, const float *__restrict__ pts, const float *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const float *tail = image + (size_t)TOTAL_GROUPS * 256;
-    for (int i = tid; i < BIAS_FLOATS + ALPHA_FLOATS; i += blockDim.x) bias_s[i] = tail[i];
+    for (int i = tid; i < BIAS_FLOATS + ALPHA_FLOATS + VIEW_BIAS_FLOATS; i += blockDim.x) bias_s[i] = tail[i];
+    const float *vbias_s = alpha_s + ALPHA_FLOATS;
     Ctx cx{wbuf, bias_s, reinterpret_cast<const f32x4 *>(image), lane, hh, wave, 0, 0};
     stage_chunk(cx, wbuf, 0, groups(0));                           // chunk (0, 0) into buffer 0
     cx.next_group = groups(0);
@@ -202,7 +302,7 @@ k_sigma_nerf_f32(int64_t npts, const float *__restrict__ pts, const float *__res
                 for (int mt = 0; mt < 8; mt++)
                     hout[mt] = tile<groups(5)>(cx, 5, mt, mt < 7 ? groups(5) : groups(6), [&](int ks) { return ks < 32 ? xin[ks < 32 ? ks : 0] : hin[ks >= 32 ? (ks - 32) >> 4 : 0][(ks - 32) & 15]; });
             } else {
-                const int ng_after = l == 4 ? groups(5) : l == 7 ? groups(0) : groups(1);
+                const int ng_after = l == 4 ? groups(5) : l == 7 ? VIEW_GROUPS : groups(1);
 #pragma unroll
                 for (int mt = 0; mt < 8; mt++) hout[mt] = tile<groups(1)>(cx, l, mt, mt < 7 ? groups(1) : ng_after, [&](int ks) { return hin[ks >> 4][ks & 15]; });
             }
@@ -228,8 +328,44 @@ k_sigma_nerf_f32(int64_t npts, const float *__restrict__ pts, const float *__res
             }
         }
         a = a + alpha_s[256];
+        // ---- the colour branch on the exact h8, in split precision on the fp16 matrix instructions (2 % of this kernel's matrix instructions' time): the coarse pass
+        // then leaves whole (rgb, sigma) rows and the fine pass need not evaluate the network at its 64 coarse depths again.
+        //   rgb = rgb_linear(relu(views_linears_0(cat[feature_linear(h8), views])))        (NeRF.cpp:108-120), feature_linear folded into views_linears_0 at pack time
+        // h8 is the chained operand: k-step 2 t + s' = registers 8 s'..8 s'+7 of tile t (neuron 32 t + 2 (8 s' + j) + h), split into (hi, lo) when its k-step comes up
+        // (h8 >= 0 already: the max inside the split is the identity -- and a VALU result for the asm to read).
+        f32x16 vacc[4];
+#pragma unroll
+        for (int ck = 0; ck < 4; ck++)
+            views_chunk<VIEW_CHUNK_KS>(cx, ck < 3 ? VIEW_GROUPS : VIEW_LAST_GROUPS, ck == 0, [&](int k, half8 &bh, half8 &bl) {
+                const int c = 4 * ck + k;                        // chained k-step 0..15
+                tile_to_frag2(hin[c >> 1], c & 1, 0.0f, bh, bl);
+            }, vacc);
+        {
+            // PE(4) of the view direction, one row per ray: natural order, element j of k-step s = dirs[16 s + 8 h + j]
+            const int64_t doff = (int64_t)((uint32_t)q / (uint32_t)s) * 32;              // point q belongs to ray q / s, explicit points included ([n, s, 3])
+            views_chunk<2>(cx, RGB_GROUPS, false, [&](int k, half8 &bh, half8 &bl) {
+                bh = *reinterpret_cast<const half8 *>(dirs + doff + 16 * k + 8 * hh);
+                bl = dirs_lo ? *reinterpret_cast<const half8 *>(dirs_lo + doff + 16 * k + 8 * hh) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }, vacc);
+        }
+        half8 bb[8][2];                                         // relu(views layer), 128 wide: k-step 2 t + s' of the rgb tile
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x16 v = vacc[t];
+            const f32x4 *b4 = reinterpret_cast<const f32x4 *>(vbias_s + (t * 2 + hh) * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const f32x4 bv = b4[q4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[4 * q4 + e] = v[4 * q4 + e] + bv[e];
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; sp++) tile_to_frag2(v, sp, 0.0f, bb[2 * t + sp][0], bb[2 * t + sp][1]);           // ReLU inside the split
+        }
+        const f32x16 c = tile16<RGB_KS>(cx, groups(0), [&](int k, int part) { return bb[k][part]; });
         const int64_t p = p0 + r;
-        if (hh == 0 && p < npts) sigma[p] = a;
+        if (hh == 0 && p < npts)                                // rows 0..2 of the rgb tile sit in registers 0..2 of lane half 0
+            *reinterpret_cast<float4 *>(raw + p * 4) = float4{c[0] + vbias_s[128], c[1] + vbias_s[129], c[2] + vbias_s[130], a};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead DMA of the last tile
 }
@@ -247,7 +383,7 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     if (!sigma_nerf_f32_supported(d)) return NRF_OK;
     using namespace nsig;
     std::vector<float> img;
-    img.reserve((size_t)TOTAL_GROUPS * 256 + BIAS_FLOATS + ALPHA_FLOATS);
+    img.reserve((size_t)TOTAL_GROUPS * 256 + BIAS_FLOATS + ALPHA_FLOATS + VIEW_BIAS_FLOATS);
     std::vector<float> bias((size_t)BIAS_FLOATS, 0.0f);
     size_t off = 0;
     for (int l = 0; l < NL; l++) {
@@ -269,13 +405,74 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
         off += (size_t)in * 256 + 256;
     }
     // blob order after pts_linears: views_linears_0 (w, b), feature_linear (w, b), alpha_linear (w, b), rgb_linear (w, b)
-    off += (size_t)(d.input_ch_views + 256) * 128 + 128;
+    const int V = d.input_ch_views;                                  // 27
+    const float *wv = hp.data() + off, *bv = wv + (size_t)(V + 256) * 128;
+    off += (size_t)(V + 256) * 128 + 128;
+    const float *wf = hp.data() + off, *bf = wf + (size_t)256 * 256;
     off += (size_t)256 * 256 + 256;
     const float *aw = hp.data() + off;
+    off += 256 + 1;
+    const float *wr = hp.data() + off, *br = wr + (size_t)128 * 3;
+    // views_linears_0 o feature_linear (no activation between them, NeRF.cpp:112-115): merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r], in double
+    std::vector<float> merged((size_t)128 * 256), merged_b(128);
+    {
+        std::vector<double> acc(256);
+        for (int r = 0; r < 128; r++) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            double b = (double)bv[r];
+            for (int f = 0; f < 256; f++) {
+                const double c = (double)wv[(size_t)r * (V + 256) + f];
+                b += c * (double)bf[f];
+                const float *frow = wf + (size_t)f * 256;
+                for (int k = 0; k < 256; k++) acc[k] += c * (double)frow[k];
+            }
+            for (int k = 0; k < 256; k++) merged[(size_t)r * 256 + k] = (float)acc[k];
+            merged_b[r] = (float)b;
+        }
+    }
+    // (hi, lo) fp16 fragments of the colour branch: per k-step the hi fragment then the fragment of the rounding residuals
+    std::vector<_Float16> himg;
+    himg.reserve((size_t)(4 * VIEW_GROUPS + VIEW_LAST_GROUPS + RGB_GROUPS) * 512);
+    auto push_frag = [&](auto value_of /* (lane, j) -> float */) {
+        for (int part = 0; part < 2; part++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const float v = value_of(lane, j);
+                    const _Float16 hv = (_Float16)v;
+                    himg.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                }
+    };
+    auto view_value = [&](int t, int k, int lane, int j) -> float {
+        const int row = 32 * t + (lane & 31), h = lane >> 5;
+        if (k < 16) return merged[(size_t)row * 256 + 32 * (k >> 1) + 2 * (8 * (k & 1) + j) + h];       // h8 as this kernel's fp32 tiles hold it: neuron 2 q + h in register q
+        const int idx = 16 * (k - 16) + 8 * h + j;                                                       // direction encoding, natural order
+        return idx < V ? wv[(size_t)row * (V + 256) + 256 + idx] : 0.0f;
+    };
+    for (int ck = 0; ck < 5; ck++) {                             // chunks of four k-steps (the last: the two direction k-steps), [tile][k][hi | lo] inside
+        const int k0 = 4 * ck, kn = ck < 4 ? VIEW_CHUNK_KS : 2;
+        for (int t = 0; t < 4; t++)
+            for (int k = 0; k < kn; k++)
+                push_frag([&](int lane, int j) -> float { return view_value(t, k0 + k, lane, j); });
+    }
+    for (int k = 0; k < RGB_KS; k++)
+        push_frag([&](int lane, int j) -> float {
+            const int row = lane & 31, h = lane >> 5;
+            return row < 3 ? wr[(size_t)row * 128 + 32 * (k >> 1) + perm_row(k & 1, h, j)] : 0.0f;                // the views tiles are plain 32x32x16 D tiles: row 16 s + 8 (j >> 2) + 4 h + (j & 3)
+        });
+    {
+        const size_t nf = himg.size() / 2, at = img.size();
+        img.resize(at + nf);
+        memcpy(img.data() + at, himg.data(), nf * sizeof(float));
+    }
     img.insert(img.end(), bias.begin(), bias.end());
     for (int k = 0; k < 256; k++) img.push_back(aw[k]);
     img.push_back(aw[256]);
     for (int k = 0; k < 3; k++) img.push_back(0.0f);
+    for (int t = 0; t < 4; t++)
+        for (int h = 0; h < 2; h++)
+            for (int q = 0; q < 16; q++) img.push_back(merged_b[32 * t + 8 * (q >> 2) + 4 * h + (q & 3)]);
+    for (int k = 0; k < 3; k++) img.push_back(br[k]);
+    img.push_back(0.0f);
     const size_t bytes = img.size() * sizeof(float);
     if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
     if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));
@@ -286,8 +483,11 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
 
 int mlp_nerf_sigma_f32_available(const nrf_mlp *m) { return m && m->family == MLP_NERF && m->d_packed_sigma_f32 != nullptr; }
 
-// sigma [p] of the classic network, bit-identical to NRF_PREC_F32: points explicit (pts [p,3]) or formed from (rays, z) as o + d z
-int mlp_nerf_sigma_f32(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, int64_t p, float *sigma, hipStream_t st)
+// The classic network's coarse pass: raw [p, 4] = (rgb, sigma) with sigma bit-identical to NRF_PREC_F32 (exact fp32 on the matrix cores) and rgb from the exact h8 in
+// split precision.  Points explicit (pts [p, 3]) or formed from (rays, z) as o + d z; dirs / dirs_lo: PE(4) of the view direction as fp16 (hi, lo) rows [n, 32]
+// (launch_dirs_pe_split; dirs_lo may be null), one row per ray (point i belongs to ray i / s).
+int mlp_nerf_exact_coarse(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, const __half *dirs_lo,
+                          int64_t p, float *raw, hipStream_t st)
 {
     if (!mlp_nerf_sigma_f32_available(m)) { set_error("internal: fp32 matrix-core sigma image of the classic network missing"); return NRF_ERR_UNSUPPORTED; }
     if (p == 0) return NRF_OK;
@@ -296,7 +496,7 @@ int mlp_nerf_sigma_f32(const nrf_mlp *m, const float *pts, const float *rays, in
     const int64_t nblocks = ceil_div(p, nsig::BLK);
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);          // persistent: one 4-wave workgroup per CU
     hipLaunchKernelGGL(nsig::k_sigma_nerf_f32, dim3(grid), dim3(64 * nsig::NW), nsig::LDS_BYTES, st, p, pts, rays, ray_stride, z, s,
-                       reinterpret_cast<const float *>(m->d_packed_sigma_f32), sigma);
+                       reinterpret_cast<const _Float16 *>(dirs), reinterpret_cast<const _Float16 *>(dirs_lo), reinterpret_cast<const float *>(m->d_packed_sigma_f32), raw);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

@@ -1887,10 +1887,18 @@ def test_classic_split_render_vs_parity_mode_and_stagewise(api, O):
     sc = api.S.make_classic_scene()
     K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
     out = {}
-    for name, prec in (("f32", api.L.NRF_PREC_F32), ("split", api.L.NRF_PREC_F16_SPLIT), ("f16", api.L.NRF_PREC_F16_MFMA)):
-        rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=prec, ReturnRaw=True, KeepIntermediates=True)
+    for name, prec, cm in (("f32", api.L.NRF_PREC_F32, api.L.NRF_COARSE_AUTO), ("split", api.L.NRF_PREC_F16_SPLIT, api.L.NRF_COARSE_FULL),
+                           ("f16", api.L.NRF_PREC_F16_MFMA, api.L.NRF_COARSE_AUTO), ("exact", api.L.NRF_PREC_F16_SPLIT, api.L.NRF_COARSE_AUTO)):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=prec, ReturnRaw=True, KeepIntermediates=True, CoarseMode=cm)
         out[name] = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=2)
-    a, b, c = out["f32"], out["split"], out["f16"]
+    a, b, c = out["f32"], out["split"], out["f16"]          # b: NRF_COARSE_FULL, the whole network in split arithmetic on both passes (same kernel as the stage-wise forward)
+    # the default coarse pass (sigma_nerf_f32.hip): sigma in exact fp32 == the parity mode's bit for bit; rgb from the exact h8 through the split-precision colour branch
+    e = out["exact"]
+    assert_exact(host(e.Extras["raw_coarse"])[..., 3], host(a.Extras["raw_coarse"])[..., 3], "coarse sigma: exact fp32 on the matrix cores == NRF_PREC_F32")
+    assert_close(host(e.Extras["raw_coarse"])[..., :3], host(a.Extras["raw_coarse"])[..., :3], rtol=0, atol=1e-5 * np.abs(host(a.Extras["raw_coarse"])[..., :3]).max(),
+                 what="coarse rgb: colour branch in split precision on the exact h8")
+    assert_exact(host(e.Extras["z_fine"]), host(a.Extras["z_fine"]), "fine sample set")
+    assert np.abs(host(e.Outputs.RGBMap) - host(a.Outputs.RGBMap)).max() < 1e-4
     rays = b.Extras["rays_flat"]
     for z, raw in ((b.Extras["z_coarse"], b.Extras["raw_coarse"]), (b.Extras["z_fine"], b.Raw)):
         n, s = z.shape
