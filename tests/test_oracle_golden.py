@@ -143,6 +143,10 @@ def test_lerf_head(manifest):
     y = O.lerf(synth.blob_from_manifest(manifest["lerf"]), g["x"])
     assert_close(y, g["y"], rtol=1e-3, atol=2e-7)
     assert_close(np.linalg.norm(y[:, :768], axis=1), np.ones(y.shape[0]), rtol=1e-5, atol=0)
+    # the density net alone (what the exact-fp32 matrix-core coarse pass of the LeRF renderer is checked against): column 0 IS the head's sigma_le, bit for bit
+    h = O.lerf_sigma_net(synth.blob_from_manifest(manifest["lerf"]), g["x"])
+    assert h.shape == (g["x"].shape[0], 33) and (h[:, 0] == y[:, 768]).all()
+    assert_close(h[:, 0], g["y"][:, 768], rtol=1e-3, atol=2e-7)
 
 
 # ------------------------------------------------------------------------------------ compositing
@@ -517,3 +521,37 @@ def test_cuda_only_encoder_sensitivity_to_what_cannot_be_pinned():
     print("CuHashEmbedder sensitivity:", json.dumps(report, indent=1))
     assert base["rgb"].std() > 0.05                          # a scene with structure, not a constant image
     assert any(v["features_changed"] > 0 for v in report.values())            # the variants do change features: not a vacuous study
+
+
+# ------------------------------------------------------------------------------------- Ndc + UseViewdirs, c2w_staticcam (goldens of round 3)
+def test_oracle_ndc_with_viewdirs_and_staticcam_vs_reference(manifest):
+    """The oracle composed as NeRFRenderer::Render composes it (NeRFRenderer.h:541-583): GetRays -> view directions from the pose's rays BEFORE NDCRays / c2w_staticcam
+    replace them -> IntersectWithAABB -> packed rows; then the render of those rows.  Against the compiled reference's own packed rays and RawToOutputs records
+    (its NDC Render() itself reads a dangling `sh` after :567 and threw in the generator: `reference_render_threw`)."""
+    g = load_golden("render_ndc")
+    assert int(g["reference_render_threw"][0]) == 1
+    h = w = 8
+    o, d, _ = O.get_rays(h, w, g["k"], g["c2w"])
+    no, nd = O.ndc_rays(h, w, float(g["k"][0, 0]), 1.0, o, d)
+    rays = O.pack_rays(no.reshape(-1, 3), nd.reshape(-1, 3), g["bbox"])                 # o, d, near, far of the warped rays (+ THEIR normalised directions)
+    dd = d.reshape(-1, 3)
+    rays[:, 8:11] = dd / np.sqrt((dd * dd).sum(1, keepdims=True, dtype=np.float32))     # view directions: the un-warped rays_d
+    assert (rays[:, :8] == g["rays_flat"][:, :8]).all(), "NDC-warped o, d, near, far bit-exact"
+    assert_close(rays[:, 8:], g["rays_flat"][:, 8:], rtol=3e-7, atol=0)
+    model = _hash_model(manifest, g["bbox"])
+    out = O.render_rays(model, g["rays_flat"], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True, want_intermediates=True)
+    assert (np.abs(out["rgb"] - g["out_rgb"]).max(axis=1) < 1e-4).mean() >= 0.95 and -10.0 * np.log10(np.mean((out["rgb"].astype(np.float64) - g["out_rgb"]) ** 2)) > 60
+    assert_close(out["weights_coarse"], g["out_coarse_weights"], rtol=0, atol=2e-4)
+    assert (out["z_fine"] == g["out_fine_z"]).mean() > 0.85
+    assert float(rays[:, 6].min()) == float(g["near_far"][0]) and float(rays[:, 7].max()) == float(g["near_far"][1])
+    # c2w_staticcam: rays of the static camera, view directions of c2w
+    gs = load_golden("render_staticcam")
+    os_, ds_, _ = O.get_rays(h, w, gs["k"], gs["c2w_staticcam"])
+    _, dv, _ = O.get_rays(h, w, gs["k"], gs["c2w"])
+    rs = O.pack_rays(os_.reshape(-1, 3), ds_.reshape(-1, 3), gs["bbox"])
+    dv = dv.reshape(-1, 3)
+    rs[:, 8:11] = dv / np.sqrt((dv * dv).sum(1, keepdims=True, dtype=np.float32))
+    assert (rs[:, :8] == gs["rays_flat"][:, :8]).all()
+    assert_close(rs[:, 8:], gs["rays_flat"][:, 8:], rtol=3e-7, atol=0)
+    outs = O.render_rays(model, gs["rays_flat"], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
+    assert_close(outs["rgb"], gs["out_rgb"].reshape(-1, 3), rtol=0, atol=1e-4)
