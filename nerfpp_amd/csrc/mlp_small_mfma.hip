@@ -30,6 +30,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef NRF_SMALL_TRACE
+// diagnostic build only (tools/scratch/small_trace.py): cycle stamps of wave 0 of every workgroup of the split kernel, summed per section:
+// [0..2] sigma layers, [3] colour-net operand (geo split), [4..7] colour layers, [8] epilogue + store + operand hand-over, [9] whole iterations, [10] iterations
+__device__ unsigned long long g_small_trace[256 * 12];
+#define NRF_TSTAMP(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define NRF_TSTAMP(i) do { } while (0)
+#endif
 #ifndef NRF_SMALL_PT
 #define NRF_SMALL_PT 2
 #endif
@@ -259,14 +267,29 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; hv[j] = t; lv[j] = (_Float16)(v[j] - (float)t); }
     };
     // ---- layer-0 / colour-layer-0 B fragments of one block iteration: element j of k-step s is x[pt][16s + 8h + j] ----
-    auto load_inputs = [&](int64_t blk_, half8 (&bx)[PT][IN_KS][NP], half8 (&bv)[PT][V_KS][NP]) {
+    // The feature column of a point is src[p] when the renderer reuses the coarse pass's columns (the fine pass: ALWAYS): a load whose result is the ADDRESS of the
+    // feature loads, and of the keep-mask load in the epilogue.  Cycle stamps (tools/scratch/small_trace.py, one wave per SIMD) showed the wave waiting ~3 300 cycles for
+    // src[p] before it could even issue its operand prefetch, and ~2 000-3 500 more at the end of the iteration for src[p] -> keep[src[p]]: a third of the iteration.
+    // So the columns travel one iteration AHEAD of the operands (load_cols for block i + 2 while block i computes), and the keep byte is fetched with the operands.
+    auto load_cols = [&](int64_t blk_, int32_t (&cols)[PT]) {
+        const int64_t p0_ = blk_ * BLOCK_PTS + wave * (32 * PT);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            int64_t p = p0_ + pt * 32 + r;
+            if (p >= npts) p = npts - 1;
+            cols[pt] = (LM && in.src) ? in.src[p] : (int32_t)0;       // without a merge map the column is the point itself (formed where it is used)
+        }
+    };
+    auto load_inputs = [&](int64_t blk_, const int32_t (&cols)[PT], half8 (&bx)[PT][IN_KS][NP], half8 (&bv)[PT][V_KS][NP], uint8_t (&kpv)[PT]) {
         const int64_t p0_ = blk_ * BLOCK_PTS + wave * (32 * PT);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
             int64_t p = p0_ + pt * 32 + r;
             if (p >= npts) p = npts - 1;                 // clamp loads; stores are guarded
+            kpv[pt] = 1;
             if constexpr (LM) {
-                const int64_t col = in.src ? (int64_t)in.src[p] : p;
+                const int64_t col = in.src ? (int64_t)cols[pt] : p;
+                if (in.keep) kpv[pt] = in.keep[col];
 #pragma unroll
                 for (int s = 0; s < IN_KS; s++) {
                     union { half8 v; __half2 q[4]; } u;
@@ -313,10 +336,28 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     half8 bv[PT][V_KS][NP];
     half8 bxn[PREFETCH ? PT : 1][IN_KS][NP];
     half8 bvn[PREFETCH ? PT : 1][V_KS][NP];
-    if constexpr (PREFETCH) { if ((int64_t)blockIdx.x < nblocks) load_inputs(blockIdx.x, bx, bv); }
+    uint8_t kp[PT], kpn[PT];
+    int32_t cols_next[PT];                                   // columns of the block after the one whose operands are being prefetched
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) { kp[pt] = 1; kpn[pt] = 1; cols_next[pt] = 0; }
+    if constexpr (PREFETCH) {
+        if ((int64_t)blockIdx.x < nblocks) {
+            int32_t c0[PT];
+            load_cols(blockIdx.x, c0);
+            if ((int64_t)blockIdx.x + gridDim.x < nblocks) load_cols((int64_t)blockIdx.x + gridDim.x, cols_next);
+            load_inputs(blockIdx.x, c0, bx, bv, kp);
+        }
+    }
+#ifdef NRF_SMALL_TRACE
+    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+#ifdef NRF_SMALL_TRACE
+        const unsigned long long titer = __builtin_readcyclecounter();
+        unsigned long long tprev = titer;
+#endif
         const int64_t p0 = blk * BLOCK_PTS + wave * (32 * PT);
-        if constexpr (!PREFETCH) load_inputs(blk, bx, bv);
+        if constexpr (!PREFETCH) { int32_t c0[PT]; load_cols(blk, c0); load_inputs(blk, c0, bx, bv, kp); }
         const bool more = blk + gridDim.x < nblocks;
         const half8 *fr = wl;
         // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer (two buffers: the software pipeline writes the
@@ -429,7 +470,13 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
             gemm_layer<2, IN_KS, NP, IN_LO, false, FINE>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
-            if constexpr (PREFETCH) { if (more) load_inputs(blk + gridDim.x, bxn, bvn); }
+            if constexpr (PREFETCH) {
+                if (more) {
+                    load_inputs(blk + gridDim.x, cols_next, bxn, bvn, kpn);                       // cols_next arrived an iteration ago
+                    if (blk + 2 * (int64_t)gridDim.x < nblocks) load_cols(blk + 2 * (int64_t)gridDim.x, cols_next);
+                }
+            }
+            NRF_TSTAMP(0);
 #pragma unroll
             for (int l = 1; l < NL; l++) {
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
@@ -437,6 +484,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
                 else gemm_layer<1, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4));
                 fr += Plan::sigma_frags(l) * 64 * NP;
+                NRF_TSTAMP(l);
             }
         }
         // ---- colour net: k-steps = [views..., geo] ----
@@ -451,11 +499,13 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             if constexpr (SPLIT) tile_to_frag2<false>(sig[pt][0], 0, bc[pt][V_KS][0], bc[pt][V_KS][NP - 1]);
             else bc[pt][V_KS][0] = tile_to_frag<false>(sig[pt][0], 0);
         }
+        NRF_TSTAMP(3);
         f32x16 rgb[PT][1];
         if constexpr (NLC == 1) {
             gemm_layer<1, V_KS + 1, NP, SPLIT, true>(fr, lane, bc, rgb, pre);
         } else {
             gemm_layer<2, V_KS + 1, NP, SPLIT, false, FINE>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
+            NRF_TSTAMP(4);
 #pragma unroll
             for (int l = 1; l < NLC; l++) {
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
@@ -463,6 +513,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
                 else gemm_layer<1, 4, NP, SPLIT, true, FINE>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4));
                 fr += Plan::color_frags(l) * 64 * NP;
+                NRF_TSTAMP(4 + l);
             }
         }
         // ---- out = (rgb, sigma): rows 0..2 of the colour tile and row 0 of the sigma tile live in registers 0..2 / 0 of lane-half 0 ----
@@ -472,7 +523,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 const int64_t p = p0 + pt * 32 + r;
                 if (p < npts) {
                     float sg = sig[pt][0][0];
-                    if constexpr (LM) { if (in.keep && !in.keep[in.src ? (int64_t)in.src[p] : p]) sg = 0.0f; }
+                    if constexpr (LM) { if (!kp[pt]) sg = 0.0f; }                                    // the embedder's keep mask (NeRFRenderer.h:187-188), fetched with the operands
                     if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
                     else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
                 }
@@ -490,11 +541,28 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                     for (int s = 0; s < V_KS; s++)
 #pragma unroll
                         for (int q = 0; q < NP; q++) bv[pt][s][q] = bvn[pt][s][q];
+                    kp[pt] = kpn[pt];
                 }
             }
         }
+#ifdef NRF_SMALL_TRACE
+        NRF_TSTAMP(8);
+        tr[9] += __builtin_readcyclecounter() - titer; tr[10] += 1;
+#endif
     }
+#ifdef NRF_SMALL_TRACE
+    if (threadIdx.x == 0 && SPLIT && LM) for (int i = 0; i < 12; i++) g_small_trace[blockIdx.x * 12 + i] += tr[i];      // no other code reads this buffer
+#endif
 }
+
+#ifdef NRF_SMALL_TRACE
+extern "C" NRF_API int nrf_dbg_small_trace(unsigned long long *host_out, int reset)
+{
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_small_trace), sizeof(unsigned long long) * 256 * 12) != hipSuccess) return NRF_ERR_HIP;
+    if (reset) { static unsigned long long z[256 * 12]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_small_trace), z, sizeof(z)) != hipSuccess) return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+#endif
 
 // Tried and measured in round 2 (same box, A/B builds of this file, split mode, ms of this kernel per 800x800 frame's fine pass):
 //   * NRF_SMALL_FINE (kept): the conversions dealt out over the matrix instructions of a step (4-6 vector instructions per MFMA gap, a fence after every MFMA,

@@ -1,0 +1,6 @@
+for i in 1 2 3; do
+  for v in new old; do
+    if [ $v = old ]; then export NRF_LIB_PATH=$PWD/tune/old/libnerfpp_hip.so; else unset NRF_LIB_PATH; fi
+    timeout -k 10 300 python bench.py --no-cpu-baseline --no-also --no-parity --steps 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],3), {k:round(v['ms']/20,3) for k,v in d['kernel_ms'].items()}, d['frame_sha256'][:8])"
+  done
+done
