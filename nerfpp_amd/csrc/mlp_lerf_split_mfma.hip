@@ -88,9 +88,19 @@ struct CtxS {
     f32x16 *accs;           // two accumulator tiles: tile T of a layer accumulates into accs[T & 1] while tile T - 1 (in the other) is being converted
 };
 
+// Prefetch policy of a kernel's tile loop: loads issued at the TAIL of chunk ci (after its DMA pieces, before its end-of-chunk wait) into registers the
+// running layers do not read.  The end-of-chunk wait counts vector memory operations in issue order ("all but the youngest n have landed" must cover chunk
+// ci + 1's weights, issued during chunk ci - 1), so the count(ci) loads of a tail stay in flight across TWO chunks: the wait of chunk ci and that of chunk
+// ci + 1 allow count(ci) more, the wait of chunk ci + 2 retires them.  count() is a compile-time constant per chunk: every load of a tail is unconditional.
+struct NoPF {
+    static constexpr int count(int) { return 0; }
+    template <int CI> __device__ __forceinline__ void issue() {}
+    template <int CI> __device__ __forceinline__ void kstep(int) {}          // vector work a kernel hides behind chunk CI's k-step k (see GeoPF)
+};
+
 // One chunk = neuron tile T of layer L; the finished tile (main + correction accumulator) goes to hook(T, tile).  BNLO / BCLO: the natural / chained operand has a lo part.
-template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook>
-__device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
+template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, class PF>
+__device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__restrict__ w, half8 *__restrict__ dma_dst, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, PF &pf)
 {
     using F = typename N::F;
     constexpr int KSN = F::ks_nat(L), KSC = F::ks_ch(L), KS = KSN + KSC;
@@ -143,6 +153,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
         if constexpr (PEND) { if (k < Hook::UNITS) hook.unit(T - 1, prev, k); }
+        pf.template kstep<CI>(k);
         if ((k % EVERY) == EVERY - 1 && q < NQ) {
             const int qq = q;
             switch (qq) {
@@ -154,29 +165,43 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    constexpr int TOT = N::total_chunks();
+    constexpr int EXTRA = PF::count(CI) + PF::count((CI + TOT - 1) % TOT);
+    static_assert(NQ + EXTRA < 64, "vmcnt is a 6-bit counter");
+    if constexpr (PF::count(CI) > 0) {
+        pf.template issue<CI>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (!DEFER || T == NT - 1) hook(T, acc);
     __builtin_amdgcn_sched_barrier(0);          // the tile is consumed here (see mlp_lerf_mfma.hip)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ + EXTRA) : "memory");
 }
 
-template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook>
-__device__ __forceinline__ void chunk_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
+template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, class PF>
+__device__ __forceinline__ void chunk_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, PF &pf)
 {
     const int cur = *cx.cur;
-    chunk_body_s<N, L, T, BNLO, BCLO, WLO>(cx, cx.wbuf + cur * (SMAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (SMAXF * 64), bn, bc, hook);
+    chunk_body_s<N, L, T, BNLO, BCLO, WLO>(cx, cx.wbuf + cur * (SMAXF * 64), cx.wbuf + (cur == 0 ? 2 : cur - 1) * (SMAXF * 64), bn, bc, hook, pf);
     *cx.cur = cur == 2 ? 0 : cur + 1;
 }
 
-template <class N, int L, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, int... Ts>
-__device__ __forceinline__ void layer_seq_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, std::integer_sequence<int, Ts...>)
+template <class N, int L, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, class PF, int... Ts>
+__device__ __forceinline__ void layer_seq_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, PF &pf, std::integer_sequence<int, Ts...>)
 {
-    (chunk_s<N, L, Ts, BNLO, BCLO, WLO>(cx, bn, bc, hook), ...);
+    (chunk_s<N, L, Ts, BNLO, BCLO, WLO>(cx, bn, bc, hook, pf), ...);
+}
+
+template <class N, int L, bool BNLO, bool BCLO, bool WLO = true, int NN, int NC, class Hook, class PF>
+__device__ __forceinline__ void layer_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook, PF &pf)
+{
+    layer_seq_s<N, L, BNLO, BCLO, WLO>(cx, bn, bc, hook, pf, std::make_integer_sequence<int, N::F::tiles(L)>{});
 }
 
 template <class N, int L, bool BNLO, bool BCLO, bool WLO = true, int NN, int NC, class Hook>
 __device__ __forceinline__ void layer_s(const CtxS &cx, const half8 (&bn)[NN][2], const half8 (&bc)[NC][2], Hook &hook)
 {
-    layer_seq_s<N, L, BNLO, BCLO, WLO>(cx, bn, bc, hook, std::make_integer_sequence<int, N::F::tiles(L)>{});
+    NoPF pf;
+    layer_s<N, L, BNLO, BCLO, WLO>(cx, bn, bc, hook, pf);
 }
 
 template <bool RELU, int NOUT, bool KEEP0 = false>
@@ -207,17 +232,32 @@ struct ConvHookS {
     }
 };
 
-// a . (G a) with a = hi + lo
+// Two ways of hiding kernel B's open vector work behind matrix instructions, both measured on the LeRF frame in one call against the build without them
+// (profiles/round3/r3u_lerf_defer_ab.log; 74.1-74.5 ms of LeRF passes per frame): DOT, the Gram tiles' dot products one per k-step behind the next tile --
+// 74.1-75.3 ms, nothing; SUM, a tile's share of the ray's sum behind the next tile's LE0 -- 77.5-79.5 ms, slower (the conversions it interleaves with already
+// fill those k-steps).  The matrix pipe is this kernel's clock-limited resource; cycles freed beside it buy nothing.  Both off.
+#ifndef NRF_LERF_DEFER_DOT
+#define NRF_LERF_DEFER_DOT 0
+#endif
+#ifndef NRF_LERF_DEFER_SUM
+#define NRF_LERF_DEFER_SUM 0
+#endif
+// a . (G a) with a = hi + lo.  NRF_LERF_DEFER_DOT: deferred like the conversions, tile T - 1's sixteen products one per k-step behind tile T's matrix instructions
+// (same order of additions as consuming each tile at once), the layer's last tile in the open.
 struct DotHookS {
     const half8 (&a)[16][2];
     float ss = 0.0f;
-    static constexpr int UNITS = 0;          // consumed at once (16 FMAs)
-    __device__ __forceinline__ void unit(int, const f32x16 &, int) {}
+    static constexpr int UNITS = NRF_LERF_DEFER_DOT ? 16 : 0;
+    __device__ __forceinline__ void unit(int tile, const f32x16 &t, int i)
+    {
+        ss = __builtin_fmaf(t[i], (float)a[2 * tile + (i >> 3)][0][i & 7] + (float)a[2 * tile + (i >> 3)][1][i & 7], ss);
+        asm volatile("" : "+v"(ss));          // pin the partial sum (see mlp_lerf_mfma.hip)
+    }
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
 #pragma unroll
         for (int i = 0; i < 16; i++) ss = __builtin_fmaf(t[i], (float)a[2 * tile + (i >> 3)][0][i & 7] + (float)a[2 * tile + (i >> 3)][1][i & 7], ss);
-        asm volatile("" : "+v"(ss));          // pin the partial sum (see mlp_lerf_mfma.hip)
+        asm volatile("" : "+v"(ss));
     }
 };
 
@@ -246,13 +286,19 @@ struct ReduceS {
     }
 };
 
+#ifndef NRF_LERF_GRAM_ALO
+#define NRF_LERF_GRAM_ALO 0              // 1: the lo part of a enters the Gram product
+#endif
+#ifndef NRF_LERF_GRAM_GLO
+#define NRF_LERF_GRAM_GLO 0              // 1: the lo part of the Gram matrix enters it
+#endif
+
 // XLO: the input features carry a lo part (fp32 rows); level-major CuHashEmbedder features are exact fp16
-template <int NL, bool XLO, bool GEOIN = false>
+template <int NL, bool XLO>
 __global__ void __launch_bounds__(64 * SNW, 1)
 k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
 {
-    using N = NetS<NL, GEOIN ? 2 : 0>;
-    static_assert(!GEOIN || NL == 4, "only kernel B can start from the sigma net's output");
+    using N = NetS<NL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wbuf = reinterpret_cast<half8 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,15 +355,7 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
         };
         half8 ba[16][2], bb[4][2];
         half8 *geo = reinterpret_cast<half8 *>(in.geo);
-        if constexpr (GEOIN) {
-            // (sigma, geo32) as kernel A left them: the operand fragments themselves, column src[q]
-            const int64_t col = in.src ? (int64_t)in.src[qc] : qc;
-#pragma unroll
-            for (int f = 0; f < GEO_FRAGS; f++)
-#pragma unroll
-                for (int part = 0; part < 2; part++) bb[f][part] = geo[(((int64_t)(f * 2 + part) * in.geo_stride + col) << 1) + h];
-            bb[3][0] = half8{0, 0, 0, 0, 0, 0, 0, 0}; bb[3][1] = bb[3][0];
-        } else {
+        {
             ConvHookS<true, 16> c0{ba, 0.0f};
             {
                 half8 xin[8][2];
@@ -348,18 +386,7 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
                 layer_s<N, 2, XLO, true>(cx, xin, bb, c2);                // LE0: cat[geo, in] -> 256, ReLU
             }
             DotHookS ssq{ba};
-            // The Gram product supplies ONE scalar per sample, the norm ||W a|| that scales the sample's share of the ray's sum; the embedding's DIRECTION comes from
-            // the split-precision sum of a and kernel C.  An fp16-grade norm (relative error ~1e-4: rounding of a and of G, no lo parts) perturbs the shares by as much
-            // and the rendered unit embedding by < 1e-6 per component -- measured against the CPU oracle on 256 rays of the bench frame (max abs error, rms):
-            //   three products (Gh.ah + Gl.ah + Gh.al) 3.6e-7 / 3.4e-8, 97.1 ms of LeRF passes per frame;  two (a's hi part) 7.6e-7 / 9.1e-8, 87.4 ms;
-            //   ONE (Gh.ah) 8.8e-7 / 1.2e-7, 77.5 ms -- the default.  cos >= 1 - 1.2e-7 in all three (profiles/round3/r3i_lerf_gram_products.log).
-#ifndef NRF_LERF_GRAM_ALO
-#define NRF_LERF_GRAM_ALO 0              // 1: the lo part of a enters the Gram product
-#endif
-#ifndef NRF_LERF_GRAM_GLO
-#define NRF_LERF_GRAM_GLO 0              // 1: the lo part of the Gram matrix enters it
-#endif
-            layer_s<N, 3, false, NRF_LERF_GRAM_ALO != 0, NRF_LERF_GRAM_GLO != 0>(cx, none, ba, ssq);   // ||LE1(a)||^2 = a . (W^T W) a
+            layer_s<N, 3, false, NRF_LERF_GRAM_ALO != 0, NRF_LERF_GRAM_GLO != 0>(cx, none, ba, ssq);   // ||LE1(a)||^2 = a . (W^T W) a  (see k_lerf_split_geo)
             const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
             const float wgt = live ? in.weights[q] : 0.0f;
             const float f = wgt / fmaxf(sqrtf(tot), 1e-8f);
@@ -375,6 +402,181 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
 #pragma unroll
           for (int t = 0; t < 8; t++) red(t, vsum[t]);
       }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Kernel B started from the sigma net's output (Args::geo, level-major features): LE0 and the Gram product only, 16 chunks per tile of 32 samples.  At one wave
+// per SIMD nothing hides a tile's operand loads, and they hang on a dependent chain (merge map src[q] -> column -> six geo fragments and eight feature
+// fragments, then the matrix instructions): the tile loop is therefore a software pipeline over the wave's whole tile sequence (ray after ray), and everything
+// it prefetches travels by LDS-DMA into the wave's private 15 KB behind the weight buffers -- the kernel has no registers to spare (ONE more value live across
+// the tile costs ~200 spills), and a DMA leaves the compiler nothing to wait for.  During tile t:
+//   chunk 0's tail   src[q] of tile t + 1's sample -> column slot
+//   chunk 4's tail   the column back (one LDS read), then tile t + 1's 14 operand fragments, each lane from its own column, and the sample's render weight
+// and tile t + 1 starts with 14 LDS reads.  Waits: the counted scheme described at NoPF.
+constexpr int GEO_OPER_FRAGS = 2 * GEO_FRAGS + 8;          // per tile and lane: geo (hi, lo) x 3, features x 8
+struct GeoPF {
+    const Args &in;
+    half8 *oper;               // the wave's slots: [GEO_OPER_FRAGS][64 lanes] fragments, then 64 floats x 2 (weights, by tile parity), then 64 columns
+    int h;
+    int64_t q1;                // tile t + 1: sample index of this lane (clamped to the launch)
+    int par;                   // weight slot of the tile whose operands were issued last
+    static constexpr int count(int ci) { return ci == 0 ? 1 : ci == 4 ? GEO_OPER_FRAGS + 1 : 0; }
+    __device__ __forceinline__ float *wslot(int p) const { return reinterpret_cast<float *>(oper + GEO_OPER_FRAGS * 64) + p * 64; }
+    __device__ __forceinline__ int32_t *cslot() const { return reinterpret_cast<int32_t *>(oper + GEO_OPER_FRAGS * 64) + 128; }
+    // one DMA either way (the count is a constant): without a merge map the slot receives a dummy word and the column is the sample index
+    __device__ __forceinline__ void load_col()
+    {
+        __builtin_amdgcn_global_load_lds(in.src ? in.src + q1 : reinterpret_cast<const int32_t *>(in.weights) + q1, (__attribute__((address_space(3))) void *)cslot(), 4, 0, 0);
+    }
+    __device__ __forceinline__ void load_operands(int lane)
+    {
+        int c;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(cslot() + lane)) : "memory");
+        // per-lane part of the addresses (column, lane half) formed HERE, plane offsets uniform: nothing the compiler could precompute per lane and carry (or
+        // spill) across the tile
+        const int64_t col = in.src ? (int64_t)c : q1;
+        const half8 *gb = reinterpret_cast<const half8 *>(in.geo) + ((col << 1) + h);
+        const __half *xb = in.x_lm + ((int64_t)h * in.pstride + col) * 8;
+#pragma unroll
+        for (int f = 0; f < 2 * GEO_FRAGS; f++)
+            __builtin_amdgcn_global_load_lds(gb + (int64_t)f * in.geo_stride * 2, (__attribute__((address_space(3))) void *)(oper + f * 64), 16, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            __builtin_amdgcn_global_load_lds(xb + (int64_t)(2 * s) * in.pstride * 8, (__attribute__((address_space(3))) void *)(oper + (2 * GEO_FRAGS + s) * 64), 16, 0, 0);
+        par ^= 1;                   // the weight is read at the END of its tile, after this tail has run for the next one: two slots
+        __builtin_amdgcn_global_load_lds(in.weights + q1, (__attribute__((address_space(3))) void *)wslot(par), 4, 0, 0);
+    }
+    int lane_;
+    template <int CI>
+    __device__ __forceinline__ void issue()
+    {
+        if constexpr (CI == 0) load_col();
+        else load_operands(lane_);
+    }
+    // NRF_LERF_DEFER_SUM: the PREVIOUS tile's share of the ray's sum, vsum[t][.] += f_prev a_prev[.], taken behind LE0's matrix instructions: chunk t (neuron tile t of LE0) adds the
+    // sixteen values of fragments 2t, 2t + 1 of a_prev, two per k-step, BEFORE the running tile's conversion overwrites them (tile t - 1's deferred units write
+    // fragments 2t - 2, 2t - 1 during chunk t; tile 7 is converted after its k-loop).  f_prev = 0 on a ray's first tile; a ray's last tile is added in the open.
+    float (&vsum)[8][16];
+    const half8 (&ba)[16][2];
+    float f_prev;
+    template <int CI>
+    __device__ __forceinline__ void kstep(int k)
+    {
+        if constexpr (NRF_LERF_DEFER_SUM && CI < 8) {
+            if (k < 8) {
+#pragma unroll
+                for (int i = 2 * k; i < 2 * k + 2; i++) vsum[CI][i] = __builtin_fmaf(f_prev, (float)ba[2 * CI + (i >> 3)][0][i & 7] + (float)ba[2 * CI + (i >> 3)][1][i & 7], vsum[CI][i]);
+            }
+        }
+    }
+    // weight of the RUNNING tile's sample (call after the tile's chunk 4: par already points at the next tile's slot)
+    __device__ __forceinline__ float weight(int lane) const
+    {
+        float w;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(wslot(par ^ 1) + lane)) : "memory");
+        return w;
+    }
+    // the tile's operands out of the slots (they landed chunks ago: the counted waits retire the DMA by the end of chunk 6)
+    __device__ __forceinline__ void take(half8 (&bb)[4][2], half8 (&xin)[8][2], int lane) const
+    {
+        const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(oper + lane);
+#pragma unroll
+        for (int f = 0; f < GEO_FRAGS; f++)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(bb[f][0]), "=&v"(bb[f][1]) : "v"(a + (uint32_t)f * 2048u));
+#pragma unroll
+        for (int s = 0; s < 8; s += 2)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(xin[s][0]), "=&v"(xin[s + 1][0]) : "v"(a + (uint32_t)(2 * GEO_FRAGS + s) * 1024u));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the asm reads are opaque to the compiler: tie the registers to the wait
+#pragma unroll
+        for (int f = 0; f < GEO_FRAGS; f++) asm volatile("" : "+v"(bb[f][0]), "+v"(bb[f][1]));
+#pragma unroll
+        for (int s = 0; s < 8; s++) asm volatile("" : "+v"(xin[s][0]));
+    }
+};
+
+__global__ void __launch_bounds__(64 * SNW, 1)
+k_lerf_split_geo(int64_t npts, Args in, const half8 *__restrict__ packed)
+{
+    using N = NetS<4, 2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8 *wbuf = reinterpret_cast<half8 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    half8 *oper = wbuf + 3 * SMAXF * 64 + wave * ((GEO_OPER_FRAGS + 1) * 64);
+    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(0) / SNW>{});
+    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(1) / SNW>{});
+    __syncthreads();
+    int cur = 0;
+    f32x16 accs[2];
+    const int tpr = in.s / 32;                                     // tiles per ray
+    const int64_t nrays = npts / in.s;
+    const int64_t nblocks = (nrays + SNW - 1) / SNW;               // the four waves of a workgroup walk four rays in step (see k_lerf_split)
+    // this lane's sample of tile (blk, jt) of the wave's sequence; rays past the end repeat the last one (loaded, computed, never stored)
+    auto sample_of = [&](int64_t blk, int jt) -> int64_t {
+        const int64_t ray = blk * SNW + wave;
+        return (ray < nrays ? ray : nrays - 1) * in.s + jt * 32 + r;
+    };
+    // cursor over the tile sequence, one tile ahead of the running one
+    int64_t nb = blockIdx.x; int nj = 0;
+    auto advance = [&]() { if (++nj == tpr) { nj = 0; nb += gridDim.x; } };
+    float vsum[8][16];
+    half8 ba[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { ba[i][0] = half8{0, 0, 0, 0, 0, 0, 0, 0}; ba[i][1] = ba[i][0]; }          // read (times f_prev = 0) by the first tile
+    GeoPF pf{in, oper, h, 0, 0, lane, vsum, ba, 0.0f};
+    // prologue: tile 0's column, then its operands
+    pf.q1 = sample_of(nb, nj);
+    pf.load_col();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pf.load_operands(lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+#pragma unroll
+      for (int t = 0; t < 8; t++)
+#pragma unroll
+          for (int i = 0; i < 16; i++) vsum[t][i] = 0.0f;
+      const int64_t ray = blk * SNW + wave;
+      const bool rlive = ray < nrays;
+#pragma unroll 1
+      for (int jt = 0; jt < tpr; jt++) {
+        CtxS cx{wbuf, packed, lane, h, wave, &cur, accs};
+        half8 bb[4][2], xin[8][2], none[1][2];
+        // tile t: its operands and its weight wait in the wave's slots; the cursor moves on to tile t + 1
+        pf.take(bb, xin, lane);
+        bb[3][0] = half8{0, 0, 0, 0, 0, 0, 0, 0}; bb[3][1] = bb[3][0];
+#pragma unroll
+        for (int s = 0; s < 8; s++) xin[s][1] = bb[3][0];
+        advance();
+        pf.q1 = sample_of(nb, nj);
+        ConvHookS<true, 16> c2{ba, 0.0f};
+        layer_s<N, 2, false, true>(cx, xin, bb, c2, pf);                  // LE0: cat[geo, in] -> 256, ReLU      (chunk 0's tail: column of tile t + 1; chunk 4's: its operands)
+        DotHookS ssq{ba};
+        // The Gram product supplies ONE scalar per sample, the norm ||W a|| that scales the sample's share of the ray's sum; the embedding's DIRECTION comes from
+        // the split-precision sum of a and kernel C.  An fp16-grade norm (relative error ~1e-4: rounding of a and of G, no lo parts) perturbs the shares by as much
+        // and the rendered unit embedding by < 1e-6 per component -- measured against the CPU oracle on 256 rays of the bench frame (max abs error, rms):
+        //   three products (Gh.ah + Gl.ah + Gh.al) 3.6e-7 / 3.4e-8, 97.1 ms of LeRF passes per frame;  two (a's hi part) 7.6e-7 / 9.1e-8, 87.4 ms;
+        //   ONE (Gh.ah) 8.8e-7 / 1.2e-7, 77.5 ms -- the default.  cos >= 1 - 1.2e-7 in all three (profiles/round3/r3i_lerf_gram_products.log).
+        layer_s<N, 3, false, NRF_LERF_GRAM_ALO != 0, NRF_LERF_GRAM_GLO != 0>(cx, none, ba, ssq, pf);   // ||LE1(a)||^2 = a . (W^T W) a
+        const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
+        const float wgt = rlive ? pf.weight(lane) : 0.0f;
+        const float f = wgt / fmaxf(sqrtf(tot), 1e-8f);
+        // fragments 2t, 2t+1 of a hold, on each lane, the neurons of D-tile t's 16 registers.  The tile's share is added behind the next tile's LE0 (GeoPF::kstep),
+        // except a ray's last one
+        if (NRF_LERF_DEFER_SUM && jt + 1 < tpr) pf.f_prev = f;
+        else {
+            pf.f_prev = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) vsum[t][i] = __builtin_fmaf(f, (float)ba[2 * t + (i >> 3)][0][i & 7] + (float)ba[2 * t + (i >> 3)][1][i & 7], vsum[t][i]);
+        }
+      }
+      ReduceS red{rlive ? in.out + ray * (int64_t)HID : nullptr, r, h};
+#pragma unroll
+      for (int t = 0; t < 8; t++) red(t, vsum[t]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -422,6 +624,7 @@ static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipS
     Args a = a_in;
     a.gram_scale = m->lerf_gram_scale;
     const size_t lds = (size_t)3 * SMAXF * 1024;
+    const size_t lds_geo = lds + (size_t)SNW * (GEO_OPER_FRAGS + 1) * 1024;          // + the waves' operand slots (k_lerf_split_geo)
     const int64_t nblocks = NL == 2 ? ceil_div(p, SNBLK) : ceil_div(p / a.s, (int64_t)SNW);       // kernel B: one ray per wave
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);       // persistent: one 4-wave workgroup per CU
     const half8 *img = reinterpret_cast<const half8 *>(m->d_packed_split);
@@ -431,12 +634,12 @@ static int launch_lerf_split(const nrf_mlp *m, const Args &a_in, int64_t p, hipS
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lerf_split_geo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_geo));
         attr_set.done();
     }
     if (NL == 4 && a.geo) {
         if (!a.x_lm) { set_error("LeRF passes: the sigma net's output is handed over on the level-major input path only"); return NRF_ERR_INVALID_ARG; }
-        hipLaunchKernelGGL((k_lerf_split<4, false, true>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
+        hipLaunchKernelGGL(k_lerf_split_geo, dim3(grid), dim3(64 * SNW), lds_geo, st, p, a, img);
     } else if (a.x_lm) hipLaunchKernelGGL((k_lerf_split<NL, false>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
     else hipLaunchKernelGGL((k_lerf_split<NL, true>), dim3(grid), dim3(64 * SNW), lds, st, p, a, img);
     NRF_LAUNCH_CHECK();
