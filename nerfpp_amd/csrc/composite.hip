@@ -64,8 +64,9 @@ template <bool FAST>
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-              float *__restrict__ depth, SigmaNoise nz)
+              float *__restrict__ depth, SigmaNoise nz, const int32_t *__restrict__ src)
 {
+    // src: sample i's network output is row src[i] of raw (the renderer's column-ordered fine pass: a ray's samples are two contiguous runs of rows, merged by depth)
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n) return;
@@ -82,7 +83,7 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
         float w = 0.0f, zj = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, lg = 0.0f;
         float alpha = 0.0f;
         if (live) {
-            const float *r = raw + (ray * s + j) * c;
+            const float *r = raw + (src ? (int64_t)src[ray * s + j] : ray * s + j) * c;
             zj = zr[j];
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
@@ -327,14 +328,14 @@ __global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int d
 }
 
 int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
-                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast)
+                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast, const int32_t *src)
 {
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_COMPOSITE, st);
     if (fast) hipLaunchKernelGGL(k_raw2outputs<true>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz);
+                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src);
     else hipLaunchKernelGGL(k_raw2outputs<false>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz);
+                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

@@ -52,9 +52,12 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
 int mlp_small_mfma_available(const nrf_mlp *m);
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,
                               const uint8_t *keep, int64_t p, float *out, hipStream_t st, const int32_t *src = nullptr);
+int mlp_small_color_from_geo_lm(const nrf_mlp *m, const void *geo, int64_t geo_stride, const float *sigma, const __half *dirs, const __half *dirs_lo, int s,
+                                const uint8_t *keep, int64_t p, float *out, hipStream_t st);
 int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_small_sigma_f32_available(const nrf_mlp *m);
-int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st);
+int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st, void *geo = nullptr,
+                           int64_t geo_stride = 0);
 int mlp_nerf_mfma_available(const nrf_mlp *m);
 int mlp_nerf_forward_mfma_fused(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, int64_t p, float *out, hipStream_t st);
 int launch_dirs_pe_f16(const float *rays, int stride, int64_t n, __half *out, hipStream_t st);

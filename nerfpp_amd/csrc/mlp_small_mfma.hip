@@ -191,6 +191,7 @@ struct SmallPlan {
     static constexpr int GEO_KS = 1;
     static constexpr int sigma_frags(int l) { return (l == NL - 1 ? 1 : 2) * (l == 0 ? IN_KS : 4); }
     static constexpr int color_frags(int l) { return (l == NLC - 1 ? 1 : 2) * (l == 0 ? (V_KS + GEO_KS) : 4); }
+    static constexpr int sigma_total() { int t = 0; for (int l = 0; l < NL; l++) t += sigma_frags(l); return t; }
     static constexpr int total()
     {
         int t = 0;
@@ -213,6 +214,10 @@ struct SmallInput {
     const __half2 *feats_lo;                          // split mode, fp32-valued features (HashEmbedder): lo plane, same layout as feats
     const int32_t *src;                               // optional: point i reads column src[i] of feats / keep (the renderer's feature reuse: the fine pass's coarse depths
                                                       // point at the coarse pass's columns); NULL: column i
+    // GEOIN (colour net only): the sigma net's output comes from the coarse pass's exact kernel (sigma_small_f32.hip, GEO) -- the (sigma, geo_feat) operand fragment of
+    // point i as planes [hi | lo][geo_stride][2 lane halves] of 16 bytes, and sigma itself (keep mask applied) as [p] floats.  feats is not read.
+    const half8 *geo; int64_t geo_stride;
+    const float *sigma;
 };
 
 #ifndef NRF_SMALL_PIPE_SPLIT
@@ -236,7 +241,7 @@ struct SmallInput {
 
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
-template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false>
+template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false, bool GEOIN = false>
 __global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? NRF_SPLIT_MINWAVES : 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
@@ -244,6 +249,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     constexpr int NP = SPLIT ? 2 : 1;
     constexpr int BLOCK_PTS = block_pts_of(SPLIT);
     constexpr bool IN_LO = SPLIT && (!LM || LMLO);
+    static_assert(!GEOIN || (LM && SPLIT && !LMLO), "the colour-only kernel exists in split precision on the level-major path");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8 *wl = reinterpret_cast<half8 *>(smem);
     constexpr int NFRAG = Plan::total() * NP;
@@ -280,7 +286,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             cols[pt] = (LM && in.src) ? in.src[p] : (int32_t)0;       // without a merge map the column is the point itself (formed where it is used)
         }
     };
-    auto load_inputs = [&](int64_t blk_, const int32_t (&cols)[PT], half8 (&bx)[PT][IN_KS][NP], half8 (&bv)[PT][V_KS][NP], uint8_t (&kpv)[PT]) {
+    auto load_inputs = [&](int64_t blk_, const int32_t (&cols)[PT], half8 (&bx)[PT][IN_KS][NP], half8 (&bv)[PT][V_KS][NP], uint8_t (&kpv)[PT], half8 (&bg)[PT][NP], float (&sgv)[PT]) {
         const int64_t p0_ = blk_ * BLOCK_PTS + wave * (32 * PT);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
@@ -290,8 +296,13 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             if constexpr (LM) {
                 const int64_t col = in.src ? (int64_t)cols[pt] : p;
                 if (in.keep) kpv[pt] = in.keep[col];
+                if constexpr (GEOIN) {
+                    bg[pt][0] = in.geo[(col << 1) + h];
+                    bg[pt][NP - 1] = in.geo[((in.geo_stride + col) << 1) + h];
+                    sgv[pt] = in.sigma[col];
+                }
 #pragma unroll
-                for (int s = 0; s < IN_KS; s++) {
+                for (int s = 0; s < (GEOIN ? 0 : IN_KS); s++) {
                     union { half8 v; __half2 q[4]; } u;
 #pragma unroll
                     for (int q = 0; q < 4; q++) u.q[q] = in.feats[(int64_t)(8 * s + 4 * h + q) * in.pstride + col];   // features 16s+8h+2q, +1
@@ -336,6 +347,9 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     half8 bv[PT][V_KS][NP];
     half8 bxn[PREFETCH ? PT : 1][IN_KS][NP];
     half8 bvn[PREFETCH ? PT : 1][V_KS][NP];
+    half8 bg[PT][NP], bgn[PT][NP];                           // GEOIN: the geo operand fragment, and the sigma that goes with it
+    float sgv[PT], sgn[PT];
+    (void)bg; (void)bgn; (void)sgv; (void)sgn;
     uint8_t kp[PT], kpn[PT];
     int32_t cols_next[PT];                                   // columns of the block after the one whose operands are being prefetched
 #pragma unroll
@@ -345,7 +359,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             int32_t c0[PT];
             load_cols(blockIdx.x, c0);
             if ((int64_t)blockIdx.x + gridDim.x < nblocks) load_cols((int64_t)blockIdx.x + gridDim.x, cols_next);
-            load_inputs(blockIdx.x, c0, bx, bv, kp);
+            load_inputs(blockIdx.x, c0, bx, bv, kp, bg, sgv);
         }
     }
 #ifdef NRF_SMALL_TRACE
@@ -357,7 +371,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         unsigned long long tprev = titer;
 #endif
         const int64_t p0 = blk * BLOCK_PTS + wave * (32 * PT);
-        if constexpr (!PREFETCH) { int32_t c0[PT]; load_cols(blk, c0); load_inputs(blk, c0, bx, bv, kp); }
+        if constexpr (!PREFETCH) { int32_t c0[PT]; load_cols(blk, c0); load_inputs(blk, c0, bx, bv, kp, bg, sgv); }
         const bool more = blk + gridDim.x < nblocks;
         const half8 *fr = wl;
         // D tiles of a 64-wide hidden layer -> the four k-step operands of the next layer (two buffers: the software pipeline writes the
@@ -462,20 +476,25 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             };
         };
         // ---- sigma net ----
+        if constexpr (GEOIN) fr += Plan::sigma_total() * 64 * NP;          // colour net only: its fragments follow the sigma net's in the image
         half8 pre[NP];
 #pragma unroll
         for (int q = 0; q < NP; q++) pre[q] = fr[q * 64 + lane];
         f32x16 sig[PT][1];
-        if constexpr (NL == 1) {
-            gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
-        } else {
-            gemm_layer<2, IN_KS, NP, IN_LO, false, FINE>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
+        auto prefetch_next = [&]() {
             if constexpr (PREFETCH) {
                 if (more) {
-                    load_inputs(blk + gridDim.x, cols_next, bxn, bvn, kpn);                       // cols_next arrived an iteration ago
+                    load_inputs(blk + gridDim.x, cols_next, bxn, bvn, kpn, bgn, sgn);             // cols_next arrived an iteration ago
                     if (blk + 2 * (int64_t)gridDim.x < nblocks) load_cols(blk + 2 * (int64_t)gridDim.x, cols_next);
                 }
             }
+        };
+        if constexpr (GEOIN) {
+        } else if constexpr (NL == 1) {
+            gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
+        } else {
+            gemm_layer<2, IN_KS, NP, IN_LO, false, FINE>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
+            prefetch_next();
             NRF_TSTAMP(0);
 #pragma unroll
             for (int l = 1; l < NL; l++) {
@@ -496,15 +515,18 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 #pragma unroll
                 for (int q = 0; q < NP; q++) bc[pt][s][q] = bv[pt][s][q];
             // rows 0..15 of the sigma tile: sigma (zero weight) + geo
-            if constexpr (SPLIT) tile_to_frag2<false>(sig[pt][0], 0, bc[pt][V_KS][0], bc[pt][V_KS][NP - 1]);
+            if constexpr (GEOIN) { bc[pt][V_KS][0] = bg[pt][0]; bc[pt][V_KS][NP - 1] = bg[pt][NP - 1]; }
+            else if constexpr (SPLIT) tile_to_frag2<false>(sig[pt][0], 0, bc[pt][V_KS][0], bc[pt][V_KS][NP - 1]);
             else bc[pt][V_KS][0] = tile_to_frag<false>(sig[pt][0], 0);
         }
         NRF_TSTAMP(3);
         f32x16 rgb[PT][1];
         if constexpr (NLC == 1) {
             gemm_layer<1, V_KS + 1, NP, SPLIT, true>(fr, lane, bc, rgb, pre);
+            if constexpr (GEOIN) prefetch_next();
         } else {
             gemm_layer<2, V_KS + 1, NP, SPLIT, false, FINE>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
+            if constexpr (GEOIN) prefetch_next();          // the colour-only kernel's operands of the next iteration, behind its first layer
             NRF_TSTAMP(4);
 #pragma unroll
             for (int l = 1; l < NLC; l++) {
@@ -522,7 +544,8 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             for (int pt = 0; pt < PT; pt++) {
                 const int64_t p = p0 + pt * 32 + r;
                 if (p < npts) {
-                    float sg = sig[pt][0][0];
+                    float sg;
+                    if constexpr (GEOIN) sg = sgv[pt]; else sg = sig[pt][0][0];
                     if constexpr (LM) { if (!kp[pt]) sg = 0.0f; }                                    // the embedder's keep mask (NeRFRenderer.h:187-188), fetched with the operands
                     if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
                     else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
@@ -542,6 +565,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
 #pragma unroll
                         for (int q = 0; q < NP; q++) bv[pt][s][q] = bvn[pt][s][q];
                     kp[pt] = kpn[pt];
+                    if constexpr (GEOIN) { bg[pt][0] = bgn[pt][0]; bg[pt][NP - 1] = bgn[pt][NP - 1]; sgv[pt] = sgn[pt]; }
                 }
             }
         }
@@ -675,13 +699,14 @@ static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool sp
     const int64_t cap = split ? 256 : 768;
     const unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
     const half8 *img = reinterpret_cast<const half8 *>(split ? m->d_packed_split : m->d_packed_f16);
-#define NRF_GO(LM_, SP_, LO_)                                                                                                                 \
+#define NRF_GO(LM_, SP_, LO_, ...)                                                                                                            \
     do {                                                                                                                                      \
-        auto kfn = k_mlp_small_mfma<2, V_KS, NL, NLC, LM_, SP_, LO_>;                                                                         \
+        auto kfn = k_mlp_small_mfma<2, V_KS, NL, NLC, LM_, SP_, LO_, ##__VA_ARGS__>;                                                          \
         if (lds > 64 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * waves_of(SP_)), lds, st, p, in, img, out, os);                                          \
     } while (0)
-    if (lm) { if (split) { if (in.feats_lo) NRF_GO(true, true, true); else NRF_GO(true, true, false); } else NRF_GO(true, false, false); }
+    if (in.geo) { if (!lm || !split) { set_error("internal: the colour-only NeRFSmall kernel is split precision, level-major"); return NRF_ERR_INVALID_ARG; } NRF_GO(true, true, false, true); }
+    else if (lm) { if (split) { if (in.feats_lo) NRF_GO(true, true, true); else NRF_GO(true, true, false); } else NRF_GO(true, false, false); }
     else { if (split) NRF_GO(false, true, false); else NRF_GO(false, false, false); }
 #undef NRF_GO
     NRF_LAUNCH_CHECK();
@@ -699,8 +724,20 @@ int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __ha
 {
     if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
     ProfScope prof(NRF_PROF_MLP, st);
-    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo, dirs_lo ? feats_lo : nullptr, src};
+    SmallInput in{nullptr, 0, m->small.input_ch, feats, pstride, dirs, s, keep, dirs_lo, dirs_lo ? feats_lo : nullptr, src, nullptr, 0, nullptr};
     return dispatch_small(m, in, true, dirs_lo != nullptr, p, out, 4, st);
+}
+
+// The colour net alone, split precision: point i takes the sigma net's output from the exact coarse kernel (mlp_small_sigma_f32_lm with geo) -- column i of the geo
+// planes, sigma[i] -- and the direction features of ray i / s.  out [p, 4] = (rgb, sigma).
+int mlp_small_color_from_geo_lm(const nrf_mlp *m, const void *geo, int64_t geo_stride, const float *sigma, const __half *dirs, const __half *dirs_lo, int s,
+                                const uint8_t *keep, int64_t p, float *out, hipStream_t st)
+{
+    if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
+    if (!geo || !sigma || !dirs_lo) { set_error("internal: colour-only pass without geo planes / sigma / split direction features"); return NRF_ERR_INVALID_ARG; }
+    ProfScope prof(NRF_PROF_MLP, st);
+    SmallInput in{nullptr, 0, m->small.input_ch, nullptr, 0, dirs, s, keep, dirs_lo, nullptr, nullptr, static_cast<const half8 *>(geo), geo_stride, sigma};
+    return dispatch_small(m, in, true, true, p, out, 4, st);
 }
 
 int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, int split, float *out, int os, hipStream_t st)
@@ -712,7 +749,7 @@ int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, 
         return NRF_ERR_UNSUPPORTED;
     }
     if ((xs % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15)) { set_error("NRF_PREC_F16_MFMA: input rows must be 16-byte aligned"); return NRF_ERR_INVALID_ARG; }
-    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr};
+    SmallInput in{x, xs, d.input_ch, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     return dispatch_small(m, in, false, split != 0, p, out, os, st);
 }
 

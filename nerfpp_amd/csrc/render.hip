@@ -323,6 +323,7 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += align_up((size_t)n * 64 * sizeof(__half), 256) * 2;  // per-ray direction features of the fast path (hi, lo)
     b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + 1024;   // feature reuse: merge map + new-sample depths
     b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + align_up((size_t)n * (sf - s) * 16, 256);   // raw reuse: map, depths, outputs of the new samples
+    b += align_up((size_t)n * s * 64, 256) + align_up((size_t)n * sf * 16, 256);                 // geo hand-over: operand fragments of the coarse columns, outputs by column
     if (p->perturb > 0.0f) b += align_up((size_t)n * s * 4, 256);                             // un-jittered depths
     if (p->has_cone || p->precond_alpha > 0.0f) b += align_up((size_t)n * sf * 12, 256);     // explicit sample points
     return b;
@@ -385,6 +386,8 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     int32_t *rr_src = ni > 0 ? bump.take<int32_t>((size_t)n * sf) : nullptr;
     float *rr_znew = ni > 0 ? bump.take<float>((size_t)n * ni) : nullptr;
     float *rr_rawnew = ni > 0 ? bump.take<float>((size_t)n * ni * 4) : nullptr;
+    void *geo_planes = ni > 0 ? static_cast<void *>(bump.take<char>((size_t)n * s * 64)) : nullptr;      // see geo_reuse below
+    float *raw_cols = ni > 0 ? bump.take<float>((size_t)n * sf * 4) : nullptr;
     float *z_plain = p->perturb > 0.0f ? bump.take<float>((size_t)n * s) : nullptr;
     float *bump_pts = (p->has_cone || p->precond_alpha > 0.0f) ? bump.take<float>((size_t)n * sf * 3) : nullptr;
     void *nws = bump.take<char>(0);
@@ -428,12 +431,19 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     // otherwise (the default split mode: coarse pass = sigma net alone) the coarse hash features are kept for the fine pass (see ReuseWs)
     const bool reuse = !reuse_raw && fast && ni > 0 && !cone && !precond && n * (int64_t)sf < ((int64_t)1 << 31);
     const bool ngp = fast && r->desc.hash->desc.mode == NRF_HASH_NGP;       // HashEmbedder: fp32-valued features, (hi, lo) planes in split precision
+    // The default HashNeRF mode (split precision, exact sigma-only coarse pass): the coarse kernel also leaves the sigma net's whole output (sigma, geo_feat) as the colour
+    // net's operand fragment, so the fine pass runs the colour net alone at its S coarse depths -- 44 of the 116 matrix instructions per 32 points and 144 of the 336
+    // conversions per point are not repeated there, and what it uses is the EXACT sigma-net output instead of a split-precision repeat.  Both network launches of the
+    // fine pass then walk feature COLUMNS in order (coarse columns, new columns: coalesced loads, no merge-map indirection) and write by column; the compositing
+    // kernel reads through the merge map (one ray's samples lie in two contiguous runs).
+    const bool geo_reuse = reuse && sigma_only && dirs_lo != nullptr && r->desc.mlp->small.geo_feat_dim <= 15;
     ReuseWs rw{};
     if (reuse) {
         NRF_TRY(reuse_layout(nws, nws_bytes, n, s, ni, ngp && dirs_lo, ngp && sigma_only, rw));
         if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep, st, false, rw.f32, n * (int64_t)s));
         else NRF_TRY(launch_hash_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.keep, HASH_LM_DEFAULT_VARIANT, st));
-        if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, ngp ? static_cast<const void *>(rw.f32) : rw.feats, ngp ? 1 : 0, ngp ? n * (int64_t)s : rw.cols, rw.keep, n * (int64_t)s, raw_c, st));
+        if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, ngp ? static_cast<const void *>(rw.f32) : rw.feats, ngp ? 1 : 0, ngp ? n * (int64_t)s : rw.cols, rw.keep, n * (int64_t)s, raw_c, st,
+                                                       geo_reuse ? geo_planes : nullptr, n * (int64_t)s));
         else NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, s, rw.keep, n * (int64_t)s, raw_c, st));
     } else if (exact_classic) NRF_TRY(mlp_nerf_exact_coarse(r->desc.mlp, ps.pts, ps.rays, ps.ray_stride, ps.z, s, dirs16, dirs_lo, n * (int64_t)s, raw_c, st));
     else if (sigma_only) NRF_TRY(run_sigma_fast(r, ps, n, s, raw_c, nws, nws_bytes, st));                         // raw_c holds sigma [n,s] only
@@ -449,6 +459,8 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     NRF_TRY(launch_fine_depths(z_c, w_c, n, s, jitter ? nullptr : d_u, 0, rng, ni, p->sum_vec, z_f, st, reuse_raw ? rr_src : (reuse ? rw.src : nullptr),
                                reuse_raw ? rr_znew : (reuse ? rw.z_new : nullptr)));                                // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
+    const float *raw_final = raw_f;
+    const int32_t *src_final = nullptr;          // compositing reads sample i's network output at raw_final[src_final[i]] (NULL: i)
     if (cone || precond) {                                                                                         // :433-445
         sp.precond = precond; sp.stream_r = NRF_RNG_R_FINE; sp.stream_theta = NRF_RNG_THETA_FINE;
         NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_f, n, sf, sp, rng, pts, st));
@@ -466,11 +478,21 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         PointSource psn{nullptr, d_rays, rw.z_new, ray_stride, ni};
         if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep + n * (int64_t)s, st));
         else NRF_TRY(launch_hash_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.keep + n * (int64_t)s, HASH_LM_DEFAULT_VARIANT, st));
-        NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, sf, rw.keep, n * (int64_t)sf, raw_f, st, rw.src));
+        if (geo_reuse) {
+            const int64_t nc = n * (int64_t)s;
+            NRF_TRY(mlp_small_color_from_geo_lm(r->desc.mlp, geo_planes, nc, raw_c, dirs16, dirs_lo, s, rw.keep, nc, raw_cols, st));
+            NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats + nc, rw.feats_lo ? rw.feats_lo + nc : nullptr, rw.cols, dirs16, dirs_lo, ni, rw.keep + nc, n * (int64_t)ni,
+                                              raw_cols + nc * 4, st));
+            if (out->d_raw) {          // the caller wants raw in depth order
+                hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)ceil_div(n * (int64_t)sf, 256)), dim3(256), 0, st, n * (int64_t)sf, rw.src, reinterpret_cast<const float4 *>(raw_cols),
+                                   reinterpret_cast<const float4 *>(raw_cols) + nc, nc, reinterpret_cast<float4 *>(raw_f));
+                NRF_LAUNCH_CHECK();
+            } else { raw_final = raw_cols; src_final = rw.src; }
+        } else NRF_TRY(mlp_small_forward_mfma_lm(r->desc.mlp, rw.feats, rw.feats_lo, rw.cols, dirs16, dirs_lo, sf, rw.keep, n * (int64_t)sf, raw_f, st, rw.src));
     } else NRF_TRY(network(psf, sf, raw_f));                                                                       // :447
     nz.stream = NRF_RNG_NOISE_FINE;
-    return launch_raw2outputs(raw_f, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                              out->d_weights, out->d_depth, nz, st, fastc);                                        // :448
+    return launch_raw2outputs(raw_final, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
+                              out->d_weights, out->d_depth, nz, st, fastc, src_final);                             // :448
 }
 
 

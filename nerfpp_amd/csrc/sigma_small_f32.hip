@@ -21,12 +21,36 @@
 // point's hidden values sit in two lanes (even k in lane r, odd k in lane r + 32); one v_permlane32_swap per register PAIR of the wave's
 // two point tiles hands lane l both parities of point l (lanes 0-31: tile 0, lanes 32-63: tile 1), and every lane runs the ascending chain
 // for its own point: 64 fma + 32 swaps per 64 points instead of 64 matrix instructions with one useful row.
+//
+// GEO (the renderer's default HashNeRF mode): the kernel also leaves the sigma net's WHOLE last row block -- (sigma, geo_feat) -- for the fine pass, which then runs
+// only the colour net at its S coarse depths (mlp_small_mfma.hip, GEOIN) instead of repeating the sigma net there.  The geo features feed a split-precision layer,
+// so they are formed the same way: the exact hidden values split into (hi, lo) fp16 fragments, registers 8u..8u+7 of tile t = k-step (t, u) of a 32x32x16 product
+// (any assignment of k inside a k-step is fine as long as the weight fragment uses the same one), three matrix instructions per k-step, 12 per 32 points beside the
+// 192 fp32 ones.  Natural row order: register q of lane half h of the result is row 8(q/4) + 4h + q%4, which IS element q of the colour net's geo operand fragment
+// (perm_row(0, h, q) in mlp_small_mfma.hip) -- split once more and stored as that fragment, planes [hi | lo][column][lane half] of 16 bytes.
 #include "mlp.h"
 
 namespace nrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sg_half8 __attribute__((ext_vector_type(8)));
+
+// two fp32 values -> packed (hi, lo) fp16 pairs, v = hi + lo to 22 bits (see split_pair in mlp_small_mfma.hip)
+__device__ __forceinline__ void sg_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+}
+// registers q0..q0+7 of a tile -> one (hi, lo) operand fragment.  The asm reads VALU results only (the max / a copy), never a matrix result directly.
+__device__ __forceinline__ void sg_frag(const f32x16 &t, int q0, sg_half8 &hi, sg_half8 &lo)
+{
+    union { sg_half8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) sg_split_pair(fmaxf(t[q0 + 2 * j], -3.402823466e38f), fmaxf(t[q0 + 2 * j + 1], -3.402823466e38f), h.u[j], l.u[j]);
+    hi = h.v; lo = l.v;
+}
 
 constexpr int SIG_WAVES = 8;                     // 2 per SIMD: one's vector work (ReLU, swaps, the last layer) under the other's matrix chain
 constexpr int SIG_BLOCK_PTS = 64 * SIG_WAVES;    // two 32-point tiles per wave
@@ -69,17 +93,23 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[2][2])
 }
 
 // feats: level-major [16][pstride], half2 (CuHashEmbedder: exactly the fp16 numbers the reference's kernel outputs, CuHashEmbedder.cu:95) or
-// float2 (HashEmbedder, fp32 features).  image: W0 [2][4][64][4] | (NL == 3: W1 [2][8][64][4]) | w_last [64] floats.
-template <int NL, bool F32IN>
+// float2 (HashEmbedder, fp32 features).  image: W0 [2][4][64][4] | (NL == 3: W1 [2][8][64][4]) | w_last [64] floats | geo fragments [4 k-steps][hi, lo][64 lanes] half8.
+// GEO: geo [2][geo_stride][2] half8 receives the (sigma, geo_feat) operand fragment of every point (column = point index).
+template <int NL, bool F32IN, bool GEO>
 __global__ void __launch_bounds__(64 * SIG_WAVES)
 k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride, const uint8_t *__restrict__ keep, const float *__restrict__ image,
-                  float *__restrict__ sigma)
+                  float *__restrict__ sigma, sg_half8 *__restrict__ geo, int64_t geo_stride)
 {
     constexpr int W0_F4 = 2 * 4 * 64, W1_F4 = NL == 3 ? 2 * 8 * 64 : 0;
     __shared__ f32x4 wl[W0_F4 + W1_F4];
     __shared__ float wlast[64];
+    __shared__ sg_half8 wg[GEO ? 4 * 2 * 64 : 1];
     for (int i = threadIdx.x; i < W0_F4 + W1_F4; i += blockDim.x) wl[i] = reinterpret_cast<const f32x4 *>(image)[i];
     if (threadIdx.x < 64) wlast[threadIdx.x] = image[(W0_F4 + W1_F4) * 4 + threadIdx.x];
+    if constexpr (GEO) {
+        const sg_half8 *gi = reinterpret_cast<const sg_half8 *>(image + (W0_F4 + W1_F4) * 4 + 64);
+        for (int i = threadIdx.x; i < 4 * 2 * 64; i += blockDim.x) wg[i] = gi[i];
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,13 +161,40 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
             }
             return a;
         };
+        // ---- GEO: rows 0..15 of the last layer for both point tiles, in split precision, stored as the colour net's operand fragment ----
+        auto geo_out = [&](const f32x16 (&hl)[2][2]) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                f32x16 g = zero;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        sg_half8 xh, xl;
+                        sg_frag(hl[pt][t], 8 * u, xh, xl);
+                        const sg_half8 ah = wg[((2 * t + u) * 2 + 0) * 64 + lane], al = wg[((2 * t + u) * 2 + 1) * 64 + lane];
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, g, 0, 0, 0);
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, g, 0, 0, 0);
+                        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, g, 0, 0, 0);
+                    }
+                sg_half8 gh, gl;
+                sg_frag(g, 0, gh, gl);
+                const int64_t pp = blk * SIG_BLOCK_PTS + wave * 64 + pt * 32 + r;
+                if (pp < npts) { geo[(pp << 1) + hh] = gh; geo[((geo_stride + pp) << 1) + hh] = gl; }
+            }
+        };
         float acc;
         if constexpr (NL == 3) {
             f32x16 h1[2][2];
             sigma_layer<32>(wl + W0_F4, lane, h1, [&](int pt, int ks) -> float { return h0[pt][ks >> 4][ks & 15]; });
             relu_tiles(h1);
+            if constexpr (GEO) geo_out(h1);
             acc = last(h1);
-        } else acc = last(h0);
+        } else {
+            if constexpr (GEO) geo_out(h0);
+            acc = last(h0);
+        }
         const int64_t p = blk * SIG_BLOCK_PTS + wave * 64 + lane;
         if (p < npts) sigma[p] = (keep && !keep[p]) ? 0.0f : acc;                               // NeRFRenderer.h:187-188
     }
@@ -168,6 +225,24 @@ int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
         off += (size_t)in * out;
     }
     for (int k = 0; k < d.hidden_dim; k++) img.push_back(hp[off + k]);       // row 0 (sigma) of the last sigma-net layer [1 + geo][hidden]
+    // the whole last layer (rows 0 .. geo) as split fp16 fragments of the GEO product: k-step (t, u), lane (row i, half hh), element j = W[i][32t + 16u + 2j + hh]
+    {
+        const int rows = 1 + d.geo_feat_dim;
+        std::vector<_Float16> frag;
+        for (int ks = 0; ks < 4; ks++)
+            for (int part = 0; part < 2; part++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int i = lane & 31, k = 32 * (ks >> 1) + 16 * (ks & 1) + 2 * j + (lane >> 5);
+                        const float v = i < rows ? hp[off + (size_t)i * d.hidden_dim + k] : 0.0f;
+                        const _Float16 hv = (_Float16)v;
+                        frag.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                    }
+        const size_t nf = frag.size() * sizeof(_Float16) / sizeof(float);
+        const size_t at = img.size();
+        img.resize(at + nf);
+        std::memcpy(img.data() + at, frag.data(), nf * sizeof(float));
+    }
     const size_t bytes = img.size() * sizeof(float);
     if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
     if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));
@@ -179,7 +254,9 @@ int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
 int mlp_small_sigma_f32_available(const nrf_mlp *m) { return m && m->family == MLP_SMALL && m->d_packed_sigma_f32 != nullptr; }
 
 // sigma [p] = keep ? NeRFSmall sigma-net output 0 : 0, bit-identical to NRF_PREC_F32.  feats: level-major [16][pstride] half2, or float2 when f32_in.
-int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st)
+// geo != NULL: also the (sigma, geo_feat) operand fragments of the colour net, planes [hi | lo][geo_stride columns][2 lane halves] of 16 bytes, column = point index
+int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int64_t pstride, const uint8_t *keep, int64_t p, float *sigma, hipStream_t st, void *geo,
+                           int64_t geo_stride)
 {
     if (!mlp_small_sigma_f32_available(m)) { set_error("internal: fp32 matrix-core sigma image missing"); return NRF_ERR_UNSUPPORTED; }
     if (p == 0) return NRF_OK;
@@ -188,7 +265,13 @@ int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int6
     const unsigned grid = (unsigned)(nblocks < 256 ? nblocks : 256);          // persistent: one 8-wave workgroup per CU
     const float *img = reinterpret_cast<const float *>(m->d_packed_sigma_f32);
     const int nl = m->small.num_layers;
-#define NRF_GO(NL_, F_) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma)
+    if (geo && (m->small.geo_feat_dim > 15 || m->small.hidden_dim != 64)) { set_error("internal: geo hand-over outside the built NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
+    sg_half8 *g = static_cast<sg_half8 *>(geo);
+#define NRF_GO(NL_, F_)                                                                                                                                              \
+    do {                                                                                                                                                             \
+        if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);    \
+        else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);    \
+    } while (0)
     if (nl == 3) { if (f32_in) NRF_GO(3, true); else NRF_GO(3, false); }
     else { if (f32_in) NRF_GO(2, true); else NRF_GO(2, false); }
 #undef NRF_GO

@@ -1370,6 +1370,38 @@ def test_ngp_fast_path_vs_reference_render(api, manifest):
     assert api.S.psnr(rgb, g["out_rgb"]) > 80
 
 
+def check_default_split_fine_pass(api, sc, res, rays, what):
+    """The default HashNeRF split render: sigma-only exact coarse pass that hands the sigma net's output (sigma, geo_feat) to the fine pass; the fine pass runs the
+    whole network on the N_importance NEW samples and the colour net alone on its S coarse depths.  Against the stage-wise evaluation (encoder, SH, MLP on explicit
+    points) of all S + N_importance depths:
+      new samples     == the split-precision MLP, bit for bit (same kernel arithmetic on the same operands);
+      coarse depths   sigma == the NRF_PREC_F32 MLP's, bit for bit (the exact fp32 matrix-core chain); rgb within split-precision distance of it."""
+    zf = res.Extras["z_fine"]; zc = res.Extras["z_coarse"]
+    n, s = zf.shape
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
+    emb, keep = sc["embedder"].forward(pts)
+    dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+    x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+    ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)
+    ref32 = sc["mlp"].forward(x, api.L.NRF_PREC_F32)
+    ref[~keep, 3] = 0; ref32[~keep, 3] = 0
+    got = host(res.Raw).reshape(-1, 4); ref = host(ref); ref32 = host(ref32)
+    coarse = host((zf[:, :, None] == zc[:, None, :]).any(-1))
+    # a new sample that lands exactly on a coarse depth cannot be told from it by its depth: leave such pairs out (a handful per tile at most)
+    tie = np.zeros_like(coarse)
+    eq = host(zf[:, 1:] == zf[:, :-1])
+    tie[:, 1:] |= eq; tie[:, :-1] |= eq
+    assert tie.sum() <= 1e-4 * tie.size
+    assert (coarse & ~tie).sum() + tie.sum() // 2 == n * zc.shape[1], "every coarse depth is among the fine depths"
+    tie = tie.reshape(-1); new = ~coarse.reshape(-1) & ~tie; coarse = coarse.reshape(-1) & ~tie
+    assert_exact(got[new], ref[new], what + ": new samples == stage-wise split-precision MLP")
+    assert_exact(got[coarse, 3], ref32[coarse, 3], what + ": sigma at the coarse depths == NRF_PREC_F32")
+    scale = np.abs(ref32[:, :3]).max()
+    assert_close(got[coarse, :3], ref32[coarse, :3], rtol=0, atol=2e-5 * scale, what=what + ": rgb at the coarse depths vs the fp32 MLP")
+    # ... and not further from fp32 than the full split-precision network is
+    assert np.abs(got[coarse, :3] - ref32[coarse, :3]).max() <= 1.5 * np.abs(ref[coarse, :3] - ref32[coarse, :3]).max() + 1e-7 * scale
+
+
 def test_ngp_fast_path_features_equal_generic_encoder(api):
     """k_hash_ngp_lm (dense fp32 pyramid) == k_hash_ngp (hashed fp32 tables): hi plane = f16(feature), hi + lo = feature to 2^-22."""
     import ctypes as C
@@ -1389,35 +1421,24 @@ def test_ngp_fast_path_features_equal_generic_encoder(api):
     # the default split render (sigma-only fp32 coarse pass; the fine pass keeps the coarse columns of both feature planes and encodes the new samples only)
     rp2 = api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates="depths")
     res2 = sc["renderer"].Render(800, 800, K, rp2, c2w=c2w, row0=400, rows=2)
-    zf2 = res2.Extras["z_fine"]
-    pts2 = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf2[..., None]).reshape(-1, 3)
-    emb2, keep2 = sc["embedder"].forward(pts2)
-    x2 = torch.cat([emb2, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
-    ref2 = sc["mlp"].forward(x2, api.L.NRF_PREC_F16_SPLIT)
-    ref2[~keep2, 3] = 0
-    assert_exact(host(res2.Raw).reshape(-1, 4), host(ref2), "feature-reusing fine pass == stage-wise evaluation of all S + N_importance points")
+    check_default_split_fine_pass(api, sc, res2, rays, "HashEmbedder, default split render")
     f32 = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=400, rows=2)
     assert api.S.psnr(host(res.Outputs.RGBMap), host(f32.Outputs.RGBMap)) > 85
 
 
 def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
-    """Default split render of the CuHashEmbedder scene (sigma-only coarse pass; the fine pass keeps the coarse pass's feature columns, encodes the N_importance
-    new samples only and reads every depth's column through the merge map of k_fine_depths): the network outputs at all S + N_importance depths equal the
-    stage-wise evaluation (encoder, SH, split MLP on explicit points) bit for bit -- ragged chunk sizes included."""
+    """Default split render of the CuHashEmbedder scene (see check_default_split_fine_pass) -- ragged chunk sizes included."""
     sc = api.S.make_hash_scene(mode="cu")
     K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
     rp = api.S.lego_render_params(sc["bbox"], chunk=700, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates="depths")
     res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=399, rows=2)
-    rays = res.Extras["rays_flat"]; zf = res.Extras["z_fine"]
-    n, s = zf.shape
-    assert s == 192
-    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
-    emb, keep = sc["embedder"].forward(pts)
-    dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
-    x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
-    ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)
-    ref[~keep, 3] = 0
-    assert_exact(host(res.Raw).reshape(-1, 4), host(ref), "feature-reusing fine pass == stage-wise evaluation of all S + N_importance points")
+    assert res.Extras["z_fine"].shape[1] == 192
+    check_default_split_fine_pass(api, sc, res, res.Extras["rays_flat"], "CuHashEmbedder, default split render")
+    # without ReturnRaw the compositing kernel reads the column-ordered outputs through the merge map: same pixels as composing the gathered rows
+    rp_n = api.S.lego_render_params(sc["bbox"], chunk=700, precision=api.L.NRF_PREC_F16_SPLIT)
+    res_n = sc["renderer"].Render(800, 800, K, rp_n, c2w=c2w, row0=399, rows=2)
+    for f in ("RGBMap", "DepthMap", "AccMap", "DispMap"):
+        assert_exact(host(getattr(res_n.Outputs, f)), host(getattr(res.Outputs, f)), f"{f}: merge-map read in the compositing kernel == gathered rows")
 
 
 def test_tv_loss_vs_oracle_and_reference(api, O, manifest):
