@@ -45,13 +45,21 @@ def executed_per_ray(workload, precision, hash_mode, coarse_full=False):
         if precision == "f16x3" and coarse_full is False:
             return 0, NI, NS                                      # coarse pass: density branch in exact fp32 + colour branch on the exact h8 (sigma_nerf_f32.hip); the fine pass evaluates the 128 new depths
         return 0, NS + NI, 0                                      # whole network on the coarse pass, its outputs reused by the fine pass: 64 + 128 evaluations
-    if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32)
-        return NS + NI, NS + NI, NS                           # both encoders: the fine pass keeps the coarse pass's feature columns
+    if precision == "f16x3":                                  # coarse pass: sigma net alone (exact fp32), which hands (sigma, geo_feat) to the fine pass
+        return NS + NI, NI, NS                                # both encoders: the fine pass keeps the coarse pass's feature columns; whole network on the new samples only
     return NS + NI, NS + NI, 0                                # plain fp16: coarse outputs reused by the fine pass
+
+
+def colour_only_per_ray(workload, precision):
+    """Points per ray at which the fused-MLP kernel runs the colour net alone (HashNeRF default mode: the fine pass's S coarse depths, whose sigma-net output comes
+    from the exact coarse kernel)."""
+    return NS if (workload == "hash" and precision == "f16x3") else 0
 
 # algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)
 HASH_BYTES_PER_UNIT = 16 * 8 * 2 * 2 + 12 + 64      # table gathers + point in + fp16 features out (standalone encode kernel)
 SMALL_FLOP_PER_UNIT = 35072
+SMALL_COLOUR_FLOP_PER_UNIT = 2 * ((16 + 15) * 64 + 64 * 64 + 64 * 64 + 64 * 3)      # the colour net alone (NeRF.cpp:383-406): 20 736
+SMALL_COLOUR_MFMA_FLOP_PER_UNIT = 72 * 32768 // 32                                   # its 72 of the split kernel's 116 matrix instructions per 32 points
 # matrix-core work the NeRFSmall kernel actually issues per point (32-row / 16-k padded tiles; x3 products in split mode, x2 on layer 0)
 SMALL_MFMA_FLOP_PER_UNIT = {"f16": 40 * 32768 // 32, "f16x3": 116 * 32768 // 32}
 NERF_FLOP_PER_UNIT = 1186816
@@ -380,14 +388,21 @@ def main():
             sk = prof["sigma"]
             # points the fused MLP kernel really processed (see executed_per_ray)
             mlp_units = units_total * ex_mlp / UNITS_PER_RAY
-            mupl = mlp_units / max(mk["launches"], 1)
+            col_units = units_total * colour_only_per_ray(args.workload, args.precision) / UNITS_PER_RAY      # colour net alone (second launch per chunk, same kernel family and slot)
+            mupl = (mlp_units + col_units) / max(mk["launches"], 1)
             mtraffic, mtraffic_src = pmc_traffic("mlp_small (k_mlp_small_mfma)", mupl)
-            mroof = dict(bound="mfma", kernel="mlp_small", achieved=mlp_units * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
-                         unit="TFLOP/s", frac=mlp_units * SMALL_FLOP_PER_UNIT / max(mdur, 1e-12) / mlp_peak, traffic=mtraffic, traffic_source=mtraffic_src,
+            mflop = mlp_units * SMALL_FLOP_PER_UNIT + col_units * SMALL_COLOUR_FLOP_PER_UNIT
+            mroof = dict(bound="mfma", kernel="mlp_small", achieved=mflop / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
+                         unit="TFLOP/s", frac=mflop / max(mdur, 1e-12) / mlp_peak, traffic=mtraffic, traffic_source=mtraffic_src,
                          launches=mk["launches"], avg_launch_ms=mdur * 1e3 / max(mk["launches"], 1), units_per_launch=mupl, flop_per_unit=SMALL_FLOP_PER_UNIT)
+            if col_units:
+                mroof["colour_only"] = dict(units_per_ray=colour_only_per_ray(args.workload, args.precision), flop_per_unit=SMALL_COLOUR_FLOP_PER_UNIT,
+                                            note="two launches per chunk share the slot: the whole network on the N_importance new samples (35 072 flop) and the colour net alone on the "
+                                                 "fine pass's S coarse depths (20 736 flop; sigma and geo_feat come from the exact coarse kernel); achieved = the sum of both over the slot's time")
             if args.precision in SMALL_MFMA_FLOP_PER_UNIT:     # issued matrix-core flops (padding + the 3 products of the split mode) / peak
-                mroof["mfma_issued_frac"] = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] / max(mdur, 1e-12) / mlp_peak
-                mroof["mfma_issued_vs_sustained_gemm"] = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
+                missued = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] + col_units * SMALL_COLOUR_MFMA_FLOP_PER_UNIT
+                mroof["mfma_issued_frac"] = missued / max(mdur, 1e-12) / mlp_peak
+                mroof["mfma_issued_vs_sustained_gemm"] = missued / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
                 mroof["sustained_note"] = ("mfma_issued_vs_sustained_gemm = issued matrix-core flop/s over the 1 247 TFLOP/s a tuned bf16 GEMM holds on random data (guide, DVFS give-back: "
                                            "the chip lowers its clock under matrix load); measured on the classic split kernel: its cycle count does not change on all-zero weights while its clock does (DESIGN section 9)")
                 mroof["note"] = ("achieved / frac price the ALGORITHMIC 35 072 flop per unit; the split-precision mode issues three fp16 products per algorithmic one "
@@ -408,7 +423,9 @@ def main():
                 sroof = dict(traffic=straffic, traffic_source=straffic_src, mfma_busy_frac_of_active_cycles=pmc_mfma_busy("sigma_small_f32 (k_sigma_small_f32)", "f16x3"),
                              bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
                              peak=F32_PEAK / 1e12, unit="TFLOP/s", frac=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / F32_PEAK, launches=sk["launches"],
-                             avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT)
+                             avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT,
+                             note="flop_per_unit prices the exact-fp32 sigma chain (32 -> 64 -> 64 -> 1); the kernel also forms the 15 geo_feat rows of the last layer for the fine pass "
+                                  "in split fp16 (12 of its 204 matrix instructions per 32 points) and stores them as the colour net's operand fragment (64 B per point)")
             # the roofline object describes the kernel that took the most time in THIS run; the others ride along under their own keys
             cands = [(k["ms"], "hash", roof), (mk["ms"], "mlp", mroof)] + ([(sk["ms"], "sigma", sroof)] if sroof else [])
             cands.sort(key=lambda c: -c[0])
@@ -458,6 +475,7 @@ def main():
                        "parallelism": f"row-tile x{world}" + ((" + " + ("RCCL" if args.backend == "nccl" else "gloo (ranks SHARING one GPU: a rehearsal of the N > 1 code path)") +
                                                                " all_gather (" + ("nrf_allgather_tiles, C ABI" if args.collective == "cabi" else "torch.distributed") + ")") if use_dist else "")},
             "executed_evaluations_per_ray": dict(zip(("hash_encode", "fused_mlp", "sigma_only"), executed_per_ray(args.workload, args.precision, args.hash_mode)),
+                                                 colour_net_only=colour_only_per_ray(args.workload, args.precision),
                                                  note="value counts the reference's 256 network evaluations per ray; the fine pass's 64 coarse depths reuse the coarse pass's "
                                                       "hash features / outputs (identical results), so the kernels process fewer"),
             "rays_per_s": value / UNITS_PER_RAY, "s_per_frame": elapsed / args.steps / nframes * (world if args.scaling == "weak" else 1),
@@ -561,7 +579,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                        precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=n_fr, kernel_ms=kms,
                        **({"coarse_pass": "density branch in exact fp32 on the matrix cores + colour branch on the exact h8 (sigma_nerf_f32.hip): the fp32 path's sample set, outputs reused by the fine pass" if coarse == "exact"
                            else "whole network in the timed arithmetic, outputs reused by the fine pass (NRF_COARSE_FULL)"} if coarse else {}),
-                       executed_evaluations_per_ray=dict(hash_encode=ex_hash, fused_mlp=ex_mlp, sigma_only=ex_sigma))
+                       executed_evaluations_per_ray=dict(hash_encode=ex_hash, fused_mlp=ex_mlp, sigma_only=ex_sigma, colour_net_only=colour_only_per_ray(wl, pname)))
             mk = kms["mlp"]
             if wl == "classic":
                 rec["roofline"] = mfma_roofline("mlp_nerf" + ("_split" if pname == "f16x3" else ""), H * W * ex_mlp, NERF_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3,
@@ -574,8 +592,11 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                     rec["roofline"]["sigma_exact"] = mfma_roofline("sigma_nerf_f32 (coarse pass: density branch in exact fp32, v_mfma_f32_32x32x2_f32; + the colour branch in split fp16, 2 % of its matrix time)", H * W * ex_sigma, NERF_SIGMA_FLOP_PER_UNIT,
                                                                    sk["ms_per_frame"] * 1e-3, sk["launches_per_frame"], peak=F32_PEAK)
             else:
-                rec["roofline"] = mfma_roofline("mlp_small", H * W * ex_mlp, SMALL_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
-                                                issued_flop_per_unit=SMALL_MFMA_FLOP_PER_UNIT.get(pname))
+                excol = colour_only_per_ray(wl, pname)
+                # the whole network on ex_mlp points per ray + the colour net alone on excol: priced per ray
+                rec["roofline"] = mfma_roofline("mlp_small", H * W, ex_mlp * SMALL_FLOP_PER_UNIT + excol * SMALL_COLOUR_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
+                                                issued_flop_per_unit=(ex_mlp * SMALL_MFMA_FLOP_PER_UNIT[pname] + excol * SMALL_COLOUR_MFMA_FLOP_PER_UNIT) if pname in SMALL_MFMA_FLOP_PER_UNIT else None,
+                                                note="unit = one ray: the whole network at fused_mlp points + the colour net alone at colour_net_only points")
                 hk = kms["hash"]
                 rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode", unit="GB/s", peak=HBM_PEAK / 1e9,
                                                achieved=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / 1e9,

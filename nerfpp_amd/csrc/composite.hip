@@ -64,9 +64,10 @@ template <bool FAST>
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-              float *__restrict__ depth, SigmaNoise nz, const int32_t *__restrict__ src)
+              float *__restrict__ depth, SigmaNoise nz, const int32_t *__restrict__ src, const float *__restrict__ raw2, int64_t n_split)
 {
-    // src: sample i's network output is row src[i] of raw (the renderer's column-ordered fine pass: a ray's samples are two contiguous runs of rows, merged by depth)
+    // src: sample i's network output is row src[i] -- of raw when src[i] < n_split, else row src[i] - n_split of raw2 (the renderer's fine passes keep the outputs of the
+    // coarse depths and of the new samples where they were computed: a ray's samples are two contiguous runs of rows, merged by depth)
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n) return;
@@ -83,7 +84,11 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
         float w = 0.0f, zj = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, lg = 0.0f;
         float alpha = 0.0f;
         if (live) {
-            const float *r = raw + (src ? (int64_t)src[ray * s + j] : ray * s + j) * c;
+            const float *r = raw + (ray * s + j) * c;
+            if (src) {
+                const int64_t row = src[ray * s + j];
+                r = row < n_split ? raw + row * c : raw2 + (row - n_split) * c;
+            }
             zj = zr[j];
             float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
             dist = dist * nrm;                                      // :241
@@ -328,14 +333,15 @@ __global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int d
 }
 
 int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
-                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast, const int32_t *src)
+                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast, const int32_t *src, const float *raw2, int64_t n_split)
 {
+    if (src && !raw2) { raw2 = raw; n_split = 0; }          // one array of rows
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_COMPOSITE, st);
     if (fast) hipLaunchKernelGGL(k_raw2outputs<true>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src);
+                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split);
     else hipLaunchKernelGGL(k_raw2outputs<false>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src);
+                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

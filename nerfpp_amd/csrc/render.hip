@@ -460,7 +460,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
                                reuse_raw ? rr_znew : (reuse ? rw.z_new : nullptr)));                                // :427-431 (det = perturb == 0)
     PointSource psf{nullptr, d_rays, z_f, ray_stride, sf};
     const float *raw_final = raw_f;
-    const int32_t *src_final = nullptr;          // compositing reads sample i's network output at raw_final[src_final[i]] (NULL: i)
+    const int32_t *src_final = nullptr;          // compositing reads sample i's network output at row src_final[i] (NULL: i) of raw_final | raw2_final (launch_raw2outputs)
+    const float *raw2_final = nullptr;
+    int64_t split_final = 0;
     if (cone || precond) {                                                                                         // :433-445
         sp.precond = precond; sp.stream_r = NRF_RNG_R_FINE; sp.stream_theta = NRF_RNG_THETA_FINE;
         NRF_TRY(launch_stoch_points(nullptr, d_rays, ray_stride, z_f, n, sf, sp, rng, pts, st));
@@ -470,9 +472,11 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         // the network on the N_importance new samples only; the S coarse depths take the coarse pass's outputs (same kernel, same inputs: same bits)
         PointSource psn{nullptr, d_rays, rr_znew, ray_stride, ni};
         NRF_TRY(network(psn, ni, rr_rawnew));
-        hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)ceil_div(n * (int64_t)sf, 256)), dim3(256), 0, st, n * (int64_t)sf, rr_src, reinterpret_cast<const float4 *>(raw_c),
-                           reinterpret_cast<const float4 *>(rr_rawnew), n * (int64_t)s, reinterpret_cast<float4 *>(raw_f));
-        NRF_LAUNCH_CHECK();
+        if (out->d_raw) {          // the caller wants raw in depth order
+            hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)ceil_div(n * (int64_t)sf, 256)), dim3(256), 0, st, n * (int64_t)sf, rr_src, reinterpret_cast<const float4 *>(raw_c),
+                               reinterpret_cast<const float4 *>(rr_rawnew), n * (int64_t)s, reinterpret_cast<float4 *>(raw_f));
+            NRF_LAUNCH_CHECK();
+        } else { raw_final = raw_c; raw2_final = rr_rawnew; split_final = n * (int64_t)s; src_final = rr_src; }          // the compositing kernel reads through the merge map
     } else if (reuse) {
         // the hash encode of the N_importance new samples only; the MLP gathers every depth's column through the merge map
         PointSource psn{nullptr, d_rays, rw.z_new, ray_stride, ni};
@@ -492,7 +496,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     } else NRF_TRY(network(psf, sf, raw_f));                                                                       // :447
     nz.stream = NRF_RNG_NOISE_FINE;
     return launch_raw2outputs(raw_final, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                              out->d_weights, out->d_depth, nz, st, fastc, src_final);                             // :448
+                              out->d_weights, out->d_depth, nz, st, fastc, src_final, raw2_final, split_final);     // :448
 }
 
 

@@ -1441,6 +1441,22 @@ def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
         assert_exact(host(getattr(res_n.Outputs, f)), host(getattr(res.Outputs, f)), f"{f}: merge-map read in the compositing kernel == gathered rows")
 
 
+@pytest.mark.parametrize("workload,coarse", [("hash", "full"), ("classic", "full"), ("classic", "exact")])
+def test_composite_through_merge_map_equals_gathered_rows(api, workload, coarse):
+    """Fine passes that keep the coarse pass's network outputs (NRF_COARSE_FULL of either network, the classic network's exact coarse pass): without ReturnRaw the
+    compositing kernel reads each sample's row through the merge map (coarse rows | new-sample rows); with it the rows are first gathered into depth order.
+    Same rows, same order of the per-ray scan: identical maps."""
+    sc = api.S.make_hash_scene(mode="cu") if workload == "hash" else api.S.make_classic_scene()
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    kw = dict(CoarseMode=api.L.NRF_COARSE_FULL) if coarse == "full" else {}
+    outs = []
+    for raw in (False, True):
+        rp = api.S.lego_render_params(sc["bbox"], chunk=900, precision=api.L.NRF_PREC_F16_SPLIT, ReturnRaw=raw, ReturnWeights=True, **kw)
+        outs.append(sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=401, rows=2))
+    for f in ("RGBMap", "DepthMap", "AccMap", "DispMap", "Weights"):
+        assert_exact(host(getattr(outs[0].Outputs, f)), host(getattr(outs[1].Outputs, f)), f"{workload}/{coarse} {f}")
+
+
 def test_tv_loss_vs_oracle_and_reference(api, O, manifest):
     import ctypes as C
     g = load_golden("tv_loss")
