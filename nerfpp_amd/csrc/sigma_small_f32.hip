@@ -34,7 +34,9 @@
 // were given the same chains as v_pk_fma_f32 code (lane = point, weights broadcast from LDS, units of 64 points handed out by a ticket counter; both crews
 // bit-identical by construction, geo rows as exact fp32 chains).  Per frame, same call: all waves matrix 7.54 ms, all waves vector 8.7 ms, half and half 7.59 ms
 // -- the two formulations do not add up, they share what limits them -- against 4.8 ms for this file (whose geo rows cost 12 fp16 matrix instructions per 32
-// points instead of 512 packed FMAs per 64).  Not kept.
+// points instead of 512 packed FMAs per 64).  Not kept.  A registers-only probe settles why (tools/scratch/coexec_probe.hip, profiles/round3/
+// r3z_fp32_mfma_vs_pk_fma_coexec_probe.log): four matrix waves alone 3.4 ms, four packed-FMA waves alone 4.7 ms, the eight together 8.2 ms -- on this chip the fp32
+// matrix instruction and the packed fp32 FMA execute on the same lanes; 157 TFLOP/s is the ceiling of their SUM.
 #include "mlp.h"
 
 namespace nrf {
