@@ -208,6 +208,32 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
 // reciprocal multiply + two FMA corrections (bit-identical: compared exhaustively on the host for 8 extents over all normal numerators), the point -> ray index
 // division by a magic multiply, the tile-index multiplies by 24-bit ones: ~18 % fewer vector-ALU cycles -- changed NOTHING: 11.76 vs 11.76 ms, 11.58 vs 11.56 ms per
 // frame.  The kernel is not bound by instruction issue (although SQ_INSTS_VALU x 4 cycles is 78 % of its duration) but by the gather path; not kept.
+// Which point a thread encodes.  Linear (thread t -> point t) puts 64 consecutive samples of ONE ray on a wave: a segment as long as the scene, 20-64 different
+// lines per gather instruction at every level but the coarsest.  NRF_HASH_LANE_TILE = R > 1: a wave takes 64 / R consecutive samples of R consecutive rays --
+// neighbouring pixels at neighbouring depths, a handful of lines per gather -- while the features still go to column = point index (R runs of 256 / R bytes per
+// store instruction), so nothing downstream changes and the features are the same bits.  Measured on the bench frame, same call, ms of hash encode per frame
+// (profiles/round3/r4a_hash_lane_tile_ab.log): linear 8.54 / 8.20, R = 2: 8.39 / 8.05, R = 4: 8.14 / 8.19, R = 8: 8.81 / 8.44 (9.0 vs 8.7 in another call),
+// R = 16: 10.8 -- the gather path does not pay for fewer distinct lines per instruction, the stores pay for more.  Linear stays.
+#ifndef NRF_HASH_LANE_TILE
+#define NRF_HASH_LANE_TILE 1
+#endif
+__device__ __forceinline__ int64_t lane_tile_index(const PointSource &ps, int64_t p, int64_t t)
+{
+#if NRF_HASH_LANE_TILE > 1
+    constexpr uint32_t R = NRF_HASH_LANE_TILE, SPW = 64 / R;              // rays and samples per wave
+    if (ps.pts || (ps.s % SPW) || (p >> 31)) return t;
+    const uint32_t s = (uint32_t)ps.s, span = R * s;                       // points of a group of R rays
+    const uint32_t whole = ((uint32_t)p / span) * span;                   // points in whole groups
+    if ((uint32_t)t >= whole) return t;
+    const uint32_t w = (uint32_t)t >> 6, lane = (uint32_t)t & 63u;         // wave of the launch, lane
+    const uint32_t wpg = s / SPW;                                         // waves per group: one per run of SPW samples
+    const uint32_t grp = w / wpg, jo = w - grp * wpg;
+    return (int64_t)((grp * R + lane / SPW) * s + jo * SPW + (lane % SPW));
+#else
+    return t;
+#endif
+}
+
 // LPT levels per thread (blockIdx.y indexes groups of LPT levels): the coarse levels run at a fixed per-(point, level) instruction
 // cost (their lines are cached), a good part of which is forming the point and its box coordinates -- done once for LPT levels.
 template <int PPT, int GATHER, int LPT = 1>
@@ -234,7 +260,7 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
     int64_t idx[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; q++) {
-        idx[q] = (tile * PPT + q) * 256 + threadIdx.x;
+        idx[q] = lane_tile_index(ps, p, (tile * PPT + q) * 256 + threadIdx.x);
         const int64_t i = idx[q] < p ? idx[q] : p - 1;
         pp[q] = prep_point(hp, load_point(ps, i));
     }
