@@ -387,20 +387,24 @@ def main():
             mlp_peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
             sk = prof["sigma"]
             # points the fused MLP kernel really processed (see executed_per_ray)
-            mlp_units = units_total * ex_mlp / UNITS_PER_RAY
-            col_units = units_total * colour_only_per_ray(args.workload, args.precision) / UNITS_PER_RAY      # colour net alone (second launch per chunk, same kernel family and slot)
-            mupl = (mlp_units + col_units) / max(mk["launches"], 1)
+            mlp_units = units_total * ex_mlp / UNITS_PER_RAY                       # whole-network launches (the kernel instance rocprofv3 lists as k_mlp_small_mfma<..., GEOIN = false>)
+            mupl = mlp_units / max(mk["launches"], 1)
             mtraffic, mtraffic_src = pmc_traffic("mlp_small (k_mlp_small_mfma)", mupl)
-            mflop = mlp_units * SMALL_FLOP_PER_UNIT + col_units * SMALL_COLOUR_FLOP_PER_UNIT
+            mflop = mlp_units * SMALL_FLOP_PER_UNIT
             mroof = dict(bound="mfma", kernel="mlp_small", achieved=mflop / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
                          unit="TFLOP/s", frac=mflop / max(mdur, 1e-12) / mlp_peak, traffic=mtraffic, traffic_source=mtraffic_src,
                          launches=mk["launches"], avg_launch_ms=mdur * 1e3 / max(mk["launches"], 1), units_per_launch=mupl, flop_per_unit=SMALL_FLOP_PER_UNIT)
-            if col_units:
-                mroof["colour_only"] = dict(units_per_ray=colour_only_per_ray(args.workload, args.precision), flop_per_unit=SMALL_COLOUR_FLOP_PER_UNIT,
-                                            note="two launches per chunk share the slot: the whole network on the N_importance new samples (35 072 flop) and the colour net alone on the "
-                                                 "fine pass's S coarse depths (20 736 flop; sigma and geo_feat come from the exact coarse kernel); achieved = the sum of both over the slot's time")
+            ck = prof["mlp_colour"]
+            if ck["launches"]:
+                # the colour-net-only launches of the fine pass (its S coarse depths; sigma and geo_feat come from the exact coarse kernel): own slot, own kernel instance (GEOIN = true)
+                cdur = ck["ms"] * 1e-3
+                col_units = units_total * colour_only_per_ray(args.workload, args.precision) / UNITS_PER_RAY
+                mroof["colour_only"] = dict(bound="mfma", kernel="mlp_small, colour net alone", achieved=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
+                                            unit="TFLOP/s", frac=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak, launches=ck["launches"],
+                                            avg_launch_ms=cdur * 1e3 / ck["launches"], units_per_launch=col_units / ck["launches"], flop_per_unit=SMALL_COLOUR_FLOP_PER_UNIT,
+                                            mfma_issued_frac=col_units * SMALL_COLOUR_MFMA_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak)
             if args.precision in SMALL_MFMA_FLOP_PER_UNIT:     # issued matrix-core flops (padding + the 3 products of the split mode) / peak
-                missued = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision] + col_units * SMALL_COLOUR_MFMA_FLOP_PER_UNIT
+                missued = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision]
                 mroof["mfma_issued_frac"] = missued / max(mdur, 1e-12) / mlp_peak
                 mroof["mfma_issued_vs_sustained_gemm"] = missued / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
                 mroof["sustained_note"] = ("mfma_issued_vs_sustained_gemm = issued matrix-core flop/s over the 1 247 TFLOP/s a tuned bf16 GEMM holds on random data (guide, DVFS give-back: "
@@ -592,11 +596,12 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                     rec["roofline"]["sigma_exact"] = mfma_roofline("sigma_nerf_f32 (coarse pass: density branch in exact fp32, v_mfma_f32_32x32x2_f32; + the colour branch in split fp16, 2 % of its matrix time)", H * W * ex_sigma, NERF_SIGMA_FLOP_PER_UNIT,
                                                                    sk["ms_per_frame"] * 1e-3, sk["launches_per_frame"], peak=F32_PEAK)
             else:
-                excol = colour_only_per_ray(wl, pname)
-                # the whole network on ex_mlp points per ray + the colour net alone on excol: priced per ray
-                rec["roofline"] = mfma_roofline("mlp_small", H * W, ex_mlp * SMALL_FLOP_PER_UNIT + excol * SMALL_COLOUR_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
-                                                issued_flop_per_unit=(ex_mlp * SMALL_MFMA_FLOP_PER_UNIT[pname] + excol * SMALL_COLOUR_MFMA_FLOP_PER_UNIT) if pname in SMALL_MFMA_FLOP_PER_UNIT else None,
-                                                note="unit = one ray: the whole network at fused_mlp points + the colour net alone at colour_net_only points")
+                rec["roofline"] = mfma_roofline("mlp_small", H * W * ex_mlp, SMALL_FLOP_PER_UNIT, mk["ms_per_frame"] * 1e-3, mk["launches_per_frame"],
+                                                issued_flop_per_unit=SMALL_MFMA_FLOP_PER_UNIT.get(pname))
+                ck = kms["mlp_colour"]
+                if ck["launches_per_frame"]:
+                    rec["roofline"]["colour_only"] = mfma_roofline("mlp_small, colour net alone", H * W * colour_only_per_ray(wl, pname), SMALL_COLOUR_FLOP_PER_UNIT, ck["ms_per_frame"] * 1e-3,
+                                                                   ck["launches_per_frame"], issued_flop_per_unit=SMALL_COLOUR_MFMA_FLOP_PER_UNIT)
                 hk = kms["hash"]
                 rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode", unit="GB/s", peak=HBM_PEAK / 1e9,
                                                achieved=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / 1e9,

@@ -16,7 +16,7 @@ NRF_PREC_F32, NRF_PREC_F16_MFMA, NRF_PREC_F16_SPLIT = 0, 1, 2
 NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
 (NRF_RNG_T_RAND, NRF_RNG_R_COARSE, NRF_RNG_THETA_COARSE, NRF_RNG_NOISE_COARSE, NRF_RNG_U_PDF, NRF_RNG_PRECOND, NRF_RNG_R_FINE, NRF_RNG_THETA_FINE,
  NRF_RNG_NOISE_FINE) = range(1, 10)       # include/nrf_rng.h
-NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other", "sigma")
+NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other", "sigma", "mlp_colour")
 NRF_COARSE_AUTO, NRF_COARSE_FULL, NRF_COARSE_SIGMA_F32 = 0, 1, 2
 
 

@@ -735,7 +735,7 @@ int mlp_small_color_from_geo_lm(const nrf_mlp *m, const void *geo, int64_t geo_s
 {
     if (!mlp_small_mfma_available(m)) { set_error("internal: matrix-core NeRFSmall image missing"); return NRF_ERR_UNSUPPORTED; }
     if (!geo || !sigma || !dirs_lo) { set_error("internal: colour-only pass without geo planes / sigma / split direction features"); return NRF_ERR_INVALID_ARG; }
-    ProfScope prof(NRF_PROF_MLP, st);
+    ProfScope prof(NRF_PROF_MLP_COLOUR, st);
     SmallInput in{nullptr, 0, m->small.input_ch, nullptr, 0, dirs, s, keep, dirs_lo, nullptr, nullptr, static_cast<const half8 *>(geo), geo_stride, sigma};
     return dispatch_small(m, in, true, true, p, out, 4, st);
 }

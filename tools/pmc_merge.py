@@ -23,7 +23,7 @@ for f in (hn, cl):
 FRAMES = 2                      # --steps 1 --warmup 1
 RAYS = bench.H * bench.W
 per_ray = {"hash_encode (k_hash_cu_lm)": bench.executed_per_ray("hash", "f16x3", "cu")[0],
-           "mlp_small (k_mlp_small_mfma)": bench.executed_per_ray("hash", "f16x3", "cu")[1] + bench.colour_only_per_ray("hash", "f16x3"),      # both launches of the fine pass
+           "mlp_small (k_mlp_small_mfma)": bench.executed_per_ray("hash", "f16x3", "cu")[1] + bench.colour_only_per_ray("hash", "f16x3"),      # both instances (whole network / colour net alone) are summed under this name
            "sigma_small_f32 (k_sigma_small_f32)": bench.executed_per_ray("hash", "f16x3", "cu")[2],
            "mlp_nerf_split (k_mlp_nerf_split)": bench.executed_per_ray("classic", "f16x3", "cu")[1]}
 points = {}
