@@ -528,17 +528,22 @@ def test_edge_cases_empty_ragged_and_limits(api):
     K = api.S.lego_K(64, 64); c2w = api.S.pose_spherical(10.0, -30.0, 4.0)
     o, d, cone = api.R.GetRays(64, 64, K, c2w)
     o = o.reshape(-1, 3); d = d.reshape(-1, 3)
-    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA):
+    ragged = {}
+    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA, api.L.NRF_PREC_F16_SPLIT):
         # ragged sample counts (not multiples of 64), n = 1 ray, n = 0 rays
         p = api.S.lego_render_params(sc["bbox"], n_samples=37, n_importance=53, chunk=97, precision=prec, ReturnWeights=True)
         full = r.Render(0, 0, None, p, rays=(o[:301], d[:301], None))
         assert host(full.Outputs.Weights).shape == (301, 90) and np.isfinite(host(full.Outputs.RGBMap)).all()
+        ragged[prec] = full
         one = r.Render(0, 0, None, p, rays=(o[5:6], d[5:6], None))
         assert_exact(host(one.Outputs.RGBMap), host(full.Outputs.RGBMap)[5:6], "a single ray renders like the same ray inside a batch")
         # coarse only
         p0 = api.S.lego_render_params(sc["bbox"], n_samples=64, n_importance=0, chunk=128, precision=prec, ReturnWeights=True)
         c = r.Render(0, 0, None, p0, rays=(o[:200], d[:200], None))
         assert host(c.Outputs.Weights).shape == (200, 64)
+    # the default split mode at ragged sizes (exact coarse pass with the geo hand-over, colour net alone at the 37 coarse depths, partial 64-point blocks everywhere)
+    assert_close(host(ragged[api.L.NRF_PREC_F16_SPLIT].Outputs.RGBMap), host(ragged[api.L.NRF_PREC_F32].Outputs.RGBMap), rtol=0, atol=1e-4, what="ragged split render vs fp32")
+    assert_close(host(ragged[api.L.NRF_PREC_F16_SPLIT].Outputs.Weights), host(ragged[api.L.NRF_PREC_F32].Outputs.Weights), rtol=0, atol=2e-5, what="ragged split weights vs fp32")
     empty = r.RenderRays(torch.empty((0, 11), device="cuda"), None, 64, n_importance=128)
     assert empty.Outputs.RGBMap.shape == (0, 3)
     # limits are reported, not silently mis-rendered
