@@ -213,7 +213,9 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
 // neighbouring pixels at neighbouring depths, a handful of lines per gather -- while the features still go to column = point index (R runs of 256 / R bytes per
 // store instruction), so nothing downstream changes and the features are the same bits.  Measured on the bench frame, same call, ms of hash encode per frame
 // (profiles/round3/r4a_hash_lane_tile_ab.log): linear 8.54 / 8.20, R = 2: 8.39 / 8.05, R = 4: 8.14 / 8.19, R = 8: 8.81 / 8.44 (9.0 vs 8.7 in another call),
-// R = 16: 10.8 -- the gather path does not pay for fewer distinct lines per instruction, the stores pay for more.  Linear stays.
+// R = 16: 10.8 -- the gather path does not pay for fewer distinct lines per instruction, the stores pay for more.  Even with the features stored at the thread's own
+// (linear) column -- a wrong image, but the cost a layout that followed the tiling would have -- R = 8 takes 8.8-9.1 against 8.4, R = 16 10.4, R = 64 15.8: a wave
+// that spans R rays loads R rays' origins and directions instead of one broadcast row.  Linear stays.
 #ifndef NRF_HASH_LANE_TILE
 #define NRF_HASH_LANE_TILE 1
 #endif
