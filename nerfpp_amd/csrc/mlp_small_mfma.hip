@@ -218,6 +218,8 @@ struct SmallInput {
     // point i as planes [hi | lo][geo_stride][2 lane halves] of 16 bytes, and sigma itself (keep mask applied) as [p] floats.  feats is not read.
     const half8 *geo; int64_t geo_stride;
     const float *sigma;
+    // point -> ray without a division: ray = (p * ray_mul) >> (31 + ray_shift) for p < 2^31 (ray_mul = ceil(2^(31 + L) / s), L = ceil(log2 s); set by the launchers)
+    uint32_t ray_mul; int ray_shift;
 };
 
 #ifndef NRF_SMALL_PIPE_SPLIT
@@ -241,7 +243,8 @@ struct SmallInput {
 
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
-template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false, bool GEOIN = false>
+// A32 (level-major input without a merge map, < 2^26 points, planes < 2^27 columns: every launch of the renderer's default mode): 32-bit addressing, see load_inputs
+template <int IN_KS, int V_KS, int NL, int NLC, bool LM, bool SPLIT, bool LMLO = false, bool GEOIN = false, bool A32 = false>
 __global__ void __launch_bounds__(64 * waves_of(SPLIT), SPLIT ? NRF_SPLIT_MINWAVES : 2)
 k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, float *__restrict__ out, int out_stride)
 {
@@ -277,7 +280,9 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     // feature loads, and of the keep-mask load in the epilogue.  Cycle stamps (tools/scratch/small_trace.py, one wave per SIMD) showed the wave waiting ~3 300 cycles for
     // src[p] before it could even issue its operand prefetch, and ~2 000-3 500 more at the end of the iteration for src[p] -> keep[src[p]]: a third of the iteration.
     // So the columns travel one iteration AHEAD of the operands (load_cols for block i + 2 while block i computes), and the keep byte is fetched with the operands.
+    static_assert(!A32 || (LM && SPLIT), "32-bit addressing is instantiated for the split-precision level-major kernels");
     auto load_cols = [&](int64_t blk_, int32_t (&cols)[PT]) {
+        if (A32 || !(LM && in.src)) return;
         const int64_t p0_ = blk_ * BLOCK_PTS + wave * (32 * PT);
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
@@ -294,6 +299,41 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             if (p >= npts) p = npts - 1;                 // clamp loads; stores are guarded
             kpv[pt] = 1;
             if constexpr (LM) {
+                if constexpr (A32) {
+                    // 32-bit addressing (the renderer's launches: no merge map, < 2^26 points, planes < 2^27 columns): per-lane byte offsets next to uniform plane bases,
+                    // the ray index by a multiply -- the generic path below spends ~150 vector instructions per iteration on 64-bit indices and two divisions
+                    uint32_t pu = (uint32_t)p0_ + (uint32_t)(pt * 32 + r);
+                    pu = pu < (uint32_t)npts ? pu : (uint32_t)npts - 1u;
+                    if (in.keep) kpv[pt] = in.keep[pu];
+                    if constexpr (GEOIN) {
+                        const uint32_t goff = (pu * 2u + (uint32_t)h) * 16u;
+                        bg[pt][0] = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(in.geo) + goff);
+                        bg[pt][NP - 1] = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(in.geo + in.geo_stride * 2) + goff);
+                        sgv[pt] = in.sigma[pu];
+                    } else {
+                        const uint32_t voff = ((uint32_t)(4 * h) * (uint32_t)in.pstride + pu) * 4u;
+#pragma unroll
+                        for (int s = 0; s < IN_KS; s++) {
+                            union { half8 v; __half2 q[4]; } u;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) u.q[q] = *reinterpret_cast<const __half2 *>(reinterpret_cast<const char *>(in.feats + (int64_t)(8 * s + q) * in.pstride) + voff);
+                            bx[pt][s][0] = u.v;
+                            if constexpr (SPLIT && LMLO) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) u.q[q] = *reinterpret_cast<const __half2 *>(reinterpret_cast<const char *>(in.feats_lo + (int64_t)(8 * s + q) * in.pstride) + voff);
+                                bx[pt][s][NP - 1] = u.v;
+                            } else if constexpr (SPLIT) bx[pt][s][NP - 1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                        }
+                    }
+                    const uint32_t ray = in.ray_shift < 0 ? pu : (__umulhi(pu, in.ray_mul) >> in.ray_shift);
+                    const uint32_t doff = ray * (uint32_t)(32 * V_KS) + (uint32_t)(16 * h);          // bytes; rays < 2^26
+#pragma unroll
+                    for (int s = 0; s < V_KS; s++) {
+                        bv[pt][s][0] = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(in.dirs) + doff + 32 * s);
+                        if constexpr (SPLIT) bv[pt][s][NP - 1] = *reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(in.dirs_lo) + doff + 32 * s);
+                    }
+                    continue;
+                }
                 const int64_t col = in.src ? (int64_t)cols[pt] : p;
                 if (in.keep) kpv[pt] = in.keep[col];
                 if constexpr (GEOIN) {
@@ -705,8 +745,16 @@ static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool sp
         if (lds > 64 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * waves_of(SP_)), lds, st, p, in, img, out, os);                                          \
     } while (0)
-    if (in.geo) { if (!lm || !split) { set_error("internal: the colour-only NeRFSmall kernel is split precision, level-major"); return NRF_ERR_INVALID_ARG; } NRF_GO(true, true, false, true); }
-    else if (lm) { if (split) { if (in.feats_lo) NRF_GO(true, true, true); else NRF_GO(true, true, false); } else NRF_GO(true, false, false); }
+    const bool a32 = lm && split && !in.src && (p >> 26) == 0 && (in.pstride >> 27) == 0 && (in.geo_stride >> 26) == 0 && in.ray_mul != 0;
+    if (in.geo) {
+        if (!lm || !split) { set_error("internal: the colour-only NeRFSmall kernel is split precision, level-major"); return NRF_ERR_INVALID_ARG; }
+        if (a32) NRF_GO(true, true, false, true, true); else NRF_GO(true, true, false, true);
+    } else if (lm) {
+        if (split) {
+            if (in.feats_lo) { if (a32) NRF_GO(true, true, true, false, true); else NRF_GO(true, true, true); }
+            else { if (a32) NRF_GO(true, true, false, false, true); else NRF_GO(true, true, false); }
+        } else NRF_GO(true, false, false);
+    }
     else { if (split) NRF_GO(false, true, false); else NRF_GO(false, false, false); }
 #undef NRF_GO
     NRF_LAUNCH_CHECK();
@@ -753,9 +801,19 @@ int mlp_small_forward_mfma(const nrf_mlp *m, const float *x, int xs, int64_t p, 
     return dispatch_small(m, in, false, split != 0, p, out, os, st);
 }
 
-static int dispatch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool split, int64_t p, float *out, int os, hipStream_t st)
+static int dispatch_small(const nrf_mlp *m, const SmallInput &in_, bool lm, bool split, int64_t p, float *out, int os, hipStream_t st)
 {
     const auto &d = m->small;
+    SmallInput in = in_;
+    in.ray_mul = 0; in.ray_shift = 0;
+    if (lm && in.s >= 1) {
+        // ray = floor(p / s) for p < 2^31 as (p * M) >> (31 + L), L = ceil(log2 s), M = ceil(2^(31 + L) / s) < 2^32 (Granlund-Montgomery round-up); the kernel takes the
+        // high word of the product and shifts by L - 1 (s = 1: ray = p, flagged by a negative shift)
+        int L = 0;
+        while ((1 << L) < in.s) L++;
+        if (L == 0) { in.ray_mul = 1; in.ray_shift = -1; }
+        else { in.ray_mul = (uint32_t)((((uint64_t)1 << (31 + L)) + (uint64_t)in.s - 1) / (uint64_t)in.s); in.ray_shift = L - 1; }
+    }
     const int v = d.input_ch_views / 16;
 #define NRF_CASE(V, NL, NLC) if (v == V && d.num_layers == NL && d.num_layers_color == NLC) return launch_small<V, NL, NLC>(m, in, lm, split, p, out, os, st);
     NRF_CASE(1, 3, 4) NRF_CASE(1, 3, 3) NRF_CASE(1, 3, 2) NRF_CASE(1, 2, 4) NRF_CASE(1, 2, 3) NRF_CASE(1, 2, 2)
