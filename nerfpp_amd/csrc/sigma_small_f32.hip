@@ -104,7 +104,7 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[2][2])
 // feats: level-major [16][pstride], half2 (CuHashEmbedder: exactly the fp16 numbers the reference's kernel outputs, CuHashEmbedder.cu:95) or
 // float2 (HashEmbedder, fp32 features).  image: W0 [2][4][64][4] | (NL == 3: W1 [2][8][64][4]) | w_last [64] floats | geo fragments [4 k-steps][hi, lo][64 lanes] half8.
 // GEO: geo [2][geo_stride][2] half8 receives the (sigma, geo_feat) operand fragment of every point (column = point index).
-template <int NL, bool F32IN, bool GEO>
+template <int NL, bool F32IN, bool GEO, bool A32>
 __global__ void __launch_bounds__(64 * SIG_WAVES)
 k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride, const uint8_t *__restrict__ keep, const float *__restrict__ image,
                   float *__restrict__ sigma, sg_half8 *__restrict__ geo, int64_t geo_stride)
@@ -125,16 +125,33 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
     const int r = lane & 31, hh = lane >> 5;
     const int64_t nblocks = (npts + SIG_BLOCK_PTS - 1) / SIG_BLOCK_PTS;
     // raw operand words of one block iteration: level ks of point (pt, r); lane half hh consumes feature hh
+    // On this chip the fp32 matrix instruction runs on the vector ALUs' lanes (header), so every vector instruction of this kernel is time taken from the matrix pipe.
+    // fp16 features: each lane half loads ITS 16-bit feature (a 2-byte load at byte offset 2 hh) instead of the packed word plus a shift and a select per value; and
+    // with < 2^28 points / columns the addresses are a per-lane 32-bit byte offset beside 16 uniform level bases instead of a 64-bit sum per load.
+    static_assert(!A32 || !F32IN, "the 2-byte feature loads are the fp16 input's");
+    // A32: the feature planes as ONE buffer resource -- a load is a per-lane 32-bit byte offset plus the level's uniform byte offset in a scalar register, no vector
+    // instruction per address (the launcher guarantees 16 planes < 4 GB)
+    __amdgpu_buffer_rsrc_t frsrc = __amdgpu_buffer_rsrc_t();
+    if constexpr (A32) frsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(feats), 0, (int)(uint32_t)((uint64_t)16 * (uint64_t)pstride * 4u), 0x00020000);
     auto load_inputs = [&](int64_t blk, uint32_t (&x)[2][16]) {
         const int64_t p0 = blk * SIG_BLOCK_PTS + wave * 64;
 #pragma unroll
         for (int pt = 0; pt < 2; pt++) {
             int64_t p = p0 + pt * 32 + r;
             if (p >= npts) p = npts - 1;             // clamp loads; the store is guarded
+            if constexpr (A32) {
+                uint32_t pu = (uint32_t)p0 + (uint32_t)(pt * 32 + r);
+                pu = pu < (uint32_t)npts ? pu : (uint32_t)npts - 1u;
+                const uint32_t voff = pu * 4u + 2u * (uint32_t)hh;
+#pragma unroll
+                for (int ks = 0; ks < 16; ks++)
+                    x[pt][ks] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(frsrc, (int)voff, (int)(uint32_t)((uint64_t)ks * (uint64_t)pstride * 4u), 0);
+                continue;
+            }
 #pragma unroll
             for (int ks = 0; ks < 16; ks++) {
                 if constexpr (F32IN) x[pt][ks] = reinterpret_cast<const uint32_t *>(feats)[((int64_t)ks * pstride + p) * 2 + hh];
-                else x[pt][ks] = reinterpret_cast<const uint32_t *>(feats)[(int64_t)ks * pstride + p];
+                else { const uint32_t w = reinterpret_cast<const uint32_t *>(feats)[(int64_t)ks * pstride + p]; x[pt][ks] = hh ? (w >> 16) : (w & 0xffffu); }
             }
         }
     };
@@ -146,8 +163,7 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
         sigma_layer<16>(wl, lane, h0, [&](int pt, int ks) -> float {
             if constexpr (F32IN) return __uint_as_float(x[pt][ks]);
             else {
-                const uint32_t w = x[pt][ks];
-                const uint16_t bits = (uint16_t)(hh ? (w >> 16) : (w & 0xffffu));
+                const uint16_t bits = (uint16_t)x[pt][ks];          // the lane half's own feature (load_inputs)
                 _Float16 hv; __builtin_memcpy(&hv, &bits, 2);
                 return (float)hv;                    // exact
             }
@@ -276,10 +292,15 @@ int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int6
     const int nl = m->small.num_layers;
     if (geo && (m->small.geo_feat_dim > 15 || m->small.hidden_dim != 64)) { set_error("internal: geo hand-over outside the built NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
     sg_half8 *g = static_cast<sg_half8 *>(geo);
+    const bool a32 = (p >> 26) == 0 && (pstride >> 26) == 0;          // the 16 level planes within 4 GB: 32-bit byte offsets
 #define NRF_GO(NL_, F_)                                                                                                                                              \
     do {                                                                                                                                                             \
-        if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);    \
-        else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);    \
+        constexpr bool A_ = !F_;                                                                                                                                     \
+        if (A_ && a32) {                                                                                                                                             \
+            if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
+            else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
+        } else if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
+        else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);   \
     } while (0)
     if (nl == 3) { if (f32_in) NRF_GO(3, true); else NRF_GO(3, false); }
     else { if (f32_in) NRF_GO(2, true); else NRF_GO(2, false); }
