@@ -745,7 +745,9 @@ static int launch_small(const nrf_mlp *m, const SmallInput &in, bool lm, bool sp
         if (lds > 64 * 1024) NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * waves_of(SP_)), lds, st, p, in, img, out, os);                                          \
     } while (0)
-    const bool a32 = lm && split && !in.src && (p >> 26) == 0 && (in.pstride >> 27) == 0 && (in.geo_stride >> 26) == 0 && in.ray_mul != 0;
+    // 32-bit byte offsets: points, feature planes (4 levels apart), geo fragments and the per-ray direction rows all below 4 GB
+    const bool a32 = lm && split && !in.src && (p >> 26) == 0 && (in.pstride >> 27) == 0 && (in.geo_stride >> 26) == 0 && in.ray_mul != 0 &&
+                     (((uint64_t)(p / (in.s > 0 ? in.s : 1)) + 1) * (uint64_t)(32 * V_KS)) >> 32 == 0;
     if (in.geo) {
         if (!lm || !split) { set_error("internal: the colour-only NeRFSmall kernel is split precision, level-major"); return NRF_ERR_INVALID_ARG; }
         if (a32) NRF_GO(true, true, false, true, true); else NRF_GO(true, true, false, true);
