@@ -276,8 +276,8 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         for (int j = 0; j < 8; j++) { const _Float16 t = (_Float16)v[j]; hv[j] = t; lv[j] = (_Float16)(v[j] - (float)t); }
     };
     // ---- layer-0 / colour-layer-0 B fragments of one block iteration: element j of k-step s is x[pt][16s + 8h + j] ----
-    // The feature column of a point is src[p] when the renderer reuses the coarse pass's columns (the fine pass: ALWAYS): a load whose result is the ADDRESS of the
-    // feature loads, and of the keep-mask load in the epilogue.  Cycle stamps (tools/scratch/small_trace.py, one wave per SIMD) showed the wave waiting ~3 300 cycles for
+    // The feature column of a point is src[p] when a caller passes a merge map (the renderer's feature-reusing fine pass outside the default mode -- plain fp16 with an
+    // exact coarse pass; the default mode walks columns in order, A32 below): a load whose result is the ADDRESS of the feature loads, and of the keep-mask load in the epilogue.  Cycle stamps (tools/scratch/small_trace.py, one wave per SIMD) showed the wave waiting ~3 300 cycles for
     // src[p] before it could even issue its operand prefetch, and ~2 000-3 500 more at the end of the iteration for src[p] -> keep[src[p]]: a third of the iteration.
     // So the columns travel one iteration AHEAD of the operands (load_cols for block i + 2 while block i computes), and the keep byte is fetched with the operands.
     static_assert(!A32 || (LM && SPLIT), "32-bit addressing is instantiated for the split-precision level-major kernels");
