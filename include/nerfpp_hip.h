@@ -361,7 +361,9 @@ typedef struct nrf_renderer_desc {
 /* The coarse pass of a hierarchical render contributes only its compositing weights (NeRFRenderer.h:422-428), i.e. sigma, and those
  * weights choose the fine samples through searchsorted -- a discontinuous function.  NRF_COARSE_AUTO: with NRF_PREC_F16_SPLIT on the
  * HashNeRF fast path the coarse pass evaluates the sigma net ONLY, in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32 ==
- * the ascending-k fma chain of NRF_PREC_F32, bit for bit), so the fine sample set equals the parity mode's; every other case runs
+ * the ascending-k fma chain of NRF_PREC_F32, bit for bit), so the fine sample set equals the parity mode's; that kernel also hands the
+ * sigma net's output (sigma, geo_feat) of the coarse points to the fine pass, which evaluates the colour net alone at its n_samples coarse
+ * depths (their sigma is then NRF_PREC_F32's bit for bit) and the whole network at the n_importance new ones; every other case runs
  * the whole network in `precision`.  NRF_COARSE_FULL forces the latter, NRF_COARSE_SIGMA_F32 asks for the former in
  * NRF_PREC_F16_MFMA too.  A caller that wants d_raw_coarse always gets the whole network. */
 enum { NRF_COARSE_AUTO = 0, NRF_COARSE_FULL = 1, NRF_COARSE_SIGMA_F32 = 2 };
@@ -392,7 +394,8 @@ typedef struct nrf_render_outputs {   /* NeRFRendererOutputs / NeRFRenderResult 
     float *d_acc;             /* [n]   */
     float *d_depth;           /* [n]   */
     float *d_weights;         /* [n, S_out]  S_out = n_samples + n_importance (or n_samples if n_importance == 0) */
-    float *d_raw;             /* [n, S_out, 4] */
+    float *d_raw;             /* [n, S_out, 4] in depth order.  The fast paths keep the network outputs where they were computed (coarse depths | new samples) and the
+                               * compositing kernel reads through the merge map; asking for d_raw adds one gather pass (16 B read + written per sample) */
     /* intermediates for stage-chained parity tests (optional) */
     float *d_z_coarse;        /* [n, n_samples] */
     float *d_raw_coarse;      /* [n, n_samples, 4] */
