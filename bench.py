@@ -282,14 +282,33 @@ def main():
             host[0] += time.perf_counter() - t_h
             return tiles
 
+        pending = [None]
+
         def step():
+            # the all-gather of step k is issued asynchronously and completed (stream order, no host wait) at step k + 1: the next frame's kernels are not held behind
+            # a latency-bound collective -- what a renderer of consecutive frames does
+            # (RCCL only: gloo moves the tiles through the host on a helper thread and is slower issued that way -- 38.8 vs 29.4 ms per step in the 2-rank rehearsal)
             tiles = render_tiles()
+            ov = args.backend == "nccl"
             if comm is not None:
-                return comm.all_gather_frames(torch.stack([t.reshape(shard.rows, W, 3) for t in tiles], 0), H)
-            return shard.all_gather_frames(tiles)     # [frames, H, W, 3] on every rank; identity at N = 1
+                out, work = comm.all_gather_frames(torch.stack([t.reshape(shard.rows, W, 3) for t in tiles], 0), H, overlap=True)
+            elif ov:
+                out, work = shard.all_gather_frames(tiles, overlap=True)     # [frames, H, W, 3] on every rank; identity at N = 1
+            else:
+                out, work = shard.all_gather_frames(tiles), None
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = work
+            return out
+
+        def drain():
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
 
         for _ in range(warmup):
             step()
+        drain()
         ms = (C.c_double * NPROF)(); cnt = (C.c_int64 * NPROF)()
         if profile:
             L.lib().nrf_profile_enable(1)
@@ -299,6 +318,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             frames_ = step()
+        drain()                                   # the last frame's collective, inside the timed region
         sync()
         dt = time.perf_counter() - t0
         if profile:

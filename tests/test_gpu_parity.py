@@ -1692,6 +1692,12 @@ def test_allgather_tiles_c_abi_single_rank(api):
         out2 = cm.all_gather_frames(tiles[:1], 37)
     s.synchronize()
     assert_exact(host(out2), host(tiles[:1]))
+    # overlap = True: issued on a side stream behind the current one; the result is ordered into the current stream by pending.wait()
+    tiles3 = tiles * 2.0
+    out3, pending = cm.all_gather_frames(tiles3, 37, overlap=True)
+    pending.wait()
+    torch.cuda.synchronize()
+    assert_exact(host(out3), host(tiles3), "world-1 all-gather issued on the side stream")
     assert tile_partition(37, 1, 0) == (0, 37)
     cm.close()
 

@@ -166,6 +166,13 @@ full2 = torch.arange(H2 * W * 3, dtype=torch.float32).reshape(1, H2, W, 3)
 sh2 = TileShard(H2, W, rank, world)
 out2 = sh2.all_gather_frames([full2[0, sh2.row0:sh2.row0 + sh2.rows].clone()])
 assert out2.shape == full2.shape and torch.equal(out2, full2)
+# ... issued asynchronously (bench.py's step: the next frame's render is not held behind the collective); the frame may be read after work.wait()
+out3, work = sh2.all_gather_frames([full2[0, sh2.row0:sh2.row0 + sh2.rows].clone()], overlap=True)
+assert work is not None
+work.wait()
+assert torch.equal(out3, full2)
+out4, work4 = sh.all_gather_frames(tiles, overlap=True)          # uneven tiles: re-assembled behind the collective, nothing pending
+assert work4 is None and torch.equal(out4, full)
 # the fp16 backward's overflow flag is per rank; the decision to skip the optimizer step is collective and comes BEFORE any gradient is exchanged
 gs = GradSync()
 g1 = torch.ones(10); g2 = torch.ones(3)
