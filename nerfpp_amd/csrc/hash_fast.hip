@@ -236,28 +236,10 @@ __device__ __forceinline__ int64_t lane_tile_index(const PointSource &ps, int64_
 #endif
 }
 
-// LPT levels per thread (blockIdx.y indexes groups of LPT levels): the coarse levels run at a fixed per-(point, level) instruction
-// cost (their lines are cached), a good part of which is forming the point and its box coordinates -- done once for LPT levels.
-template <int PPT, int GATHER, int LPT = 1>
-__global__ void __launch_bounds__(256)
-k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep, int lpg, int xcd_map,
-             int level0)
+template <int PPT, int GATHER, int LPT>
+__device__ __forceinline__ void hash_lm_body(const HashParams &hp, const PointSource &ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep,
+                                             int level, int64_t tile)
 {
-    int level;
-    int64_t tile;
-    if (xcd_map) {
-        const int g = blockIdx.x & 7;
-        const int64_t j = blockIdx.x >> 3;
-        const int sub = (int)(j % lpg);
-        tile = j / lpg;
-        // xcd_map 1: XCD g owns levels [g*lpg, (g+1)*lpg);  2: mirrored pairing (cheap coarse level with an expensive fine one)
-        if (xcd_map == 1) level = g * lpg + sub;
-        else { const int k = sub * 8 + g; level = (sub & 1) ? (hp.n_levels - 1 - (k - 8 * sub) - 8 * (sub >> 1)) : (k - 8 * sub) + 8 * (sub >> 1); }
-        if (level >= hp.n_levels || level < 0) return;
-    } else {
-        level = level0 + blockIdx.y * LPT;
-        tile = blockIdx.x;
-    }
     PointPrep pp[PPT];
     int64_t idx[PPT];
 #pragma unroll
@@ -283,6 +265,31 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
                 if (level + j == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
             }
         }
+}
+
+// LPT levels per thread (blockIdx.y indexes groups of LPT levels): the coarse levels run at a fixed per-(point, level) instruction
+// cost (their lines are cached), a good part of which is forming the point and its box coordinates -- done once for LPT levels.
+template <int PPT, int GATHER, int LPT = 1>
+__global__ void __launch_bounds__(256)
+k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep, int lpg, int xcd_map,
+             int level0)
+{
+    int level;
+    int64_t tile;
+    if (xcd_map) {
+        const int g = blockIdx.x & 7;
+        const int64_t j = blockIdx.x >> 3;
+        const int sub = (int)(j % lpg);
+        tile = j / lpg;
+        // xcd_map 1: XCD g owns levels [g*lpg, (g+1)*lpg);  2: mirrored pairing (cheap coarse level with an expensive fine one)
+        if (xcd_map == 1) level = g * lpg + sub;
+        else { const int k = sub * 8 + g; level = (sub & 1) ? (hp.n_levels - 1 - (k - 8 * sub) - 8 * (sub >> 1)) : (k - 8 * sub) + 8 * (sub >> 1); }
+        if (level >= hp.n_levels || level < 0) return;
+    } else {
+        level = level0 + blockIdx.y * LPT;
+        tile = blockIdx.x;
+    }
+    hash_lm_body<PPT, GATHER, LPT>(hp, ps, p, feats, pstride, keep, level, tile);
 }
 
 // per-ray direction features as fp16 rows [n, V] (the MLP kernel's colour-net operand): SH of the ray's view direction
@@ -350,6 +357,9 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     // levels one level per thread
     if (variant == 0 && level_lo == 0 && level_hi == L && L >= 8) {
         const int lc = (L * 3 / 4) & ~3;       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
+        // Both launches as ONE (consecutive workgroups alternating between a four-coarse-levels kind and a one-fine-level kind, so that a CU holds vector-bound and
+        // latency-bound waves together) was built and measured, same call: 8.71-8.74 ms per frame against 8.61-8.62 for the two launches
+        // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.
         if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
         NRF_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
