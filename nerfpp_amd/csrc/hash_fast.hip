@@ -356,12 +356,24 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     // default variant, all levels: the lower three quarters of the pyramid in groups of four levels per thread, the (memory-bound) finest
     // levels one level per thread
     if (variant == 0 && level_lo == 0 && level_hi == L && L >= 8) {
-        const int lc = (L * 3 / 4) & ~3;       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
+#ifdef NRF_HASH_LC
+        const int lc = NRF_HASH_LC;
+#else
+        const int lc = (L * 3 / 4) & ~3;
+#endif       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
         // Both launches as ONE (consecutive workgroups alternating between a four-coarse-levels kind and a one-fine-level kind, so that a CU holds vector-bound and
         // latency-bound waves together) was built and measured, same call: 8.71-8.74 ms per frame against 8.61-8.62 for the two launches
         // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.
         if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
         NRF_LAUNCH_CHECK();
+        // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
+        // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
+#ifndef NRF_HASH_FINE_LPT
+#define NRF_HASH_FINE_LPT 2
+#endif
+        if (NRF_HASH_FINE_LPT == 2 && ((L - lc) % 2) == 0)
+            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 2>), dim3((unsigned)ntiles, (unsigned)((L - lc) / 2)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+        else
         hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         NRF_LAUNCH_CHECK();
         return NRF_OK;
