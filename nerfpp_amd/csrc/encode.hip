@@ -147,41 +147,51 @@ __global__ void k_hash_cu(HashParams hp, PointSource ps, int64_t p, float *__res
 // The same lookup, written level-major in fp16: feats[level][point][F] (2F bytes per thread, contiguous across the points of a wave).  For F = 8 that is one
 // 16-byte store per thread and exactly the operand fragment of a matrix-core consumer: k-step s, lane half h = level 2s + h (mlp_lerf_mfma.hip).
 // The values are the row-major kernel's (one fp16 rounding of the fp32 blend, .cu:95), so consumers see identical inputs.
-template <int F>
+// LPT levels per thread (blockIdx.y indexes groups of LPT levels): the point, its clamp and its three box-coordinate divisions are level-independent and formed once
+template <int F, int LPT>
 __global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = blockIdx.y;
+    const int l0 = blockIdx.y * LPT;
     if (i >= p) return;
     const F3 pt = load_point(ps, i);
     const float x[3] = {pt.x, pt.y, pt.z};
     bool kp = true;
-    float fr[3];
-    uint32_t pos[3];
-    const float mul = hp.level_scale[l];
+    float t[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float c = fmaxf(fminf(x[a], hp.bbox.mx[a]), hp.bbox.mn[a]);
         kp = kp && (x[a] == c);
-        float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * mul;
-        q = q + hp.bias[l * 3 + a];
-        const float fl = floorf(q);
-        pos[a] = (uint32_t)fl;
-        fr[a] = q - fl;
+        t[a] = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]);
     }
-    if (l == 0 && keep) keep[i] = kp ? 1 : 0;
-    const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
-    const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
-    float acc[F];
-    cu_blend<F>(fp, pos, fr, pa, pb, pc, hp.local_size[l], acc);
-    __half o[F];
+    if (l0 == 0 && keep) keep[i] = kp ? 1 : 0;
 #pragma unroll
-    for (int f = 0; f < F; f++) o[f] = __float2half_rn(acc[f]);
-    __half *dst = feats + ((int64_t)l * pstride + i) * F;
-    if constexpr (F == 8) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
-    else if constexpr (F == 4) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
-    else if constexpr (F == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(o);
-    else dst[0] = o[0];
+    for (int j = 0; j < LPT; j++) {
+        const int l = l0 + j;
+        float fr[3];
+        uint32_t pos[3];
+        const float mul = hp.level_scale[l];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float q = t[a] * mul;
+            q = q + hp.bias[l * 3 + a];
+            const float fl = floorf(q);
+            pos[a] = (uint32_t)fl;
+            fr[a] = q - fl;
+        }
+        const uint32_t pa = hp.primes[l * 3 + 0], pb = hp.primes[l * 3 + 1], pc = hp.primes[l * 3 + 2];
+        const __half *fp = reinterpret_cast<const __half *>(hp.table) + hp.local_idx[l];
+        float acc[F];
+        cu_blend<F>(fp, pos, fr, pa, pb, pc, hp.local_size[l], acc);
+        __half o[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) o[f] = __float2half_rn(acc[f]);
+        __half *dst = feats + ((int64_t)l * pstride + i) * F;
+        if constexpr (F == 8) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(o);
+        else if constexpr (F == 4) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+        else if constexpr (F == 2) *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(o);
+        else dst[0] = o[0];
+    }
 }
 
 __global__ void k_f32_to_f16(int64_t n, const float *__restrict__ in, __half *__restrict__ out)
@@ -401,13 +411,22 @@ int nrf_hash_encode_lm_f16_strided(const nrf_hash *h, const float *d_x, int64_t 
     if (h->desc.n_features == 2 && h->desc.n_levels >= 8 && hash_fast_supported(h) && (reinterpret_cast<uintptr_t>(d_feats) & 3) == 0)
         return launch_hash_lm(h, ps, p, reinterpret_cast<__half2 *>(d_feats), pstride, d_keep_mask, HASH_LM_DEFAULT_VARIANT, st);
     ProfScope prof(NRF_PROF_HASH, st);
-    const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)h->desc.n_levels);
+    // levels per thread: ONE.  This kernel's lookups are eight 16-byte gathers per level out of the hashed table (F = 8: 128 B per point and level); it lives on the number
+    // of gathers in flight, and sharing the point preparation between levels costs more than it saves -- LeRF frame, same call, ms of hash encode: 1 per thread 40.4-41.1,
+    // 2: 43.8-43.9, 4: 50.2-50.3, 8: 59.5-59.6 (profiles/round3/r6h_lerf_hash_levels_per_thread_ab.log).  (The F = 2 fast path is the opposite case: hash_fast.hip.)
+#ifndef NRF_HASH_LMF_LPT
+#define NRF_HASH_LMF_LPT 1
+#endif
+    const int lpt = (h->desc.n_levels % NRF_HASH_LMF_LPT) == 0 ? NRF_HASH_LMF_LPT : 1;
+    const dim3 grid((unsigned)ceil_div(p, 256), (unsigned)(h->desc.n_levels / lpt));
     __half *f = reinterpret_cast<__half *>(d_feats);
+#define NRF_LMF(F_) do { if (lpt == 1) hipLaunchKernelGGL((k_hash_cu_lmf<F_, 1>), grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); \
+                         else hipLaunchKernelGGL((k_hash_cu_lmf<F_, NRF_HASH_LMF_LPT>), grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); } while (0)
     switch (h->desc.n_features) {
-        case 1: hipLaunchKernelGGL(k_hash_cu_lmf<1>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
-        case 2: hipLaunchKernelGGL(k_hash_cu_lmf<2>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
-        case 4: hipLaunchKernelGGL(k_hash_cu_lmf<4>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
-        case 8: hipLaunchKernelGGL(k_hash_cu_lmf<8>, grid, dim3(256), 0, st, h->params, ps, p, f, pstride, d_keep_mask); break;
+        case 1: NRF_LMF(1); break;
+        case 2: NRF_LMF(2); break;
+        case 4: NRF_LMF(4); break;
+        case 8: NRF_LMF(8); break;
         default: set_error("nrf_hash_encode_lm_f16: n_features %d not built (1, 2, 4, 8)", h->desc.n_features); return NRF_ERR_UNSUPPORTED;
     }
     NRF_LAUNCH_CHECK();

@@ -324,16 +324,31 @@ int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __ha
     const int L = h->desc.n_levels;
     const int64_t ntiles = ceil_div(p, 256);
     const int lc = (L * 3 / 4) & ~3;
+    // levels per thread of the coarse / fine launch (see launch_hash_lm).  This encoder's lookups are four 16-byte gathers per level out of an 8.7 GB fp32 image: no grouping
+    // moves it -- bench frame of the LibTorch-twin scene, same call, ms of hash encode: 4 + 1 per thread 23.7-23.8, 12 + 2: 24.0-24.1, 6 + 2: 23.6, 4 + 2: 23.8
+    // (profiles/round3/r6i_ngp_levels_per_thread_ab.log)
+#ifndef NRF_NGP_COARSE_LPT
+#define NRF_NGP_COARSE_LPT 4
+#endif
+#ifndef NRF_NGP_FINE_LPT
+#define NRF_NGP_FINE_LPT 1
+#endif
+    const bool cg = lc > 0 && (lc % NRF_NGP_COARSE_LPT) == 0, fg = ((L - lc) % NRF_NGP_FINE_LPT) == 0;
+    const dim3 gc((unsigned)ntiles, (unsigned)(cg ? lc / NRF_NGP_COARSE_LPT : lc / 4)), gf((unsigned)ntiles, (unsigned)(fg ? (L - lc) / NRF_NGP_FINE_LPT : L - lc));
     if (f32_out) {
-        if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4, true>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0, nullptr, 0);
+        if (cg) hipLaunchKernelGGL((k_hash_ngp_lm<NRF_NGP_COARSE_LPT, true>), gc, dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0, nullptr, 0);
+        else if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4, true>), gc, dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, 0, nullptr, 0);
         NRF_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_hash_ngp_lm<1, true>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc, nullptr, 0);
+        if (fg) hipLaunchKernelGGL((k_hash_ngp_lm<NRF_NGP_FINE_LPT, true>), gf, dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc, nullptr, 0);
+        else hipLaunchKernelGGL((k_hash_ngp_lm<1, true>), gf, dim3(256), 0, st, h->params, ps, p, feats, pstride, 0, keep, lc, nullptr, 0);
         NRF_LAUNCH_CHECK();
         return NRF_OK;
     }
-    if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0, f32_also, f32_stride);
+    if (cg) hipLaunchKernelGGL((k_hash_ngp_lm<NRF_NGP_COARSE_LPT>), gc, dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0, f32_also, f32_stride);
+    else if (lc > 0) hipLaunchKernelGGL((k_hash_ngp_lm<4>), gc, dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, 0, f32_also, f32_stride);
     NRF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_hash_ngp_lm<1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc, f32_also, f32_stride);
+    if (fg) hipLaunchKernelGGL((k_hash_ngp_lm<NRF_NGP_FINE_LPT>), gf, dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc, f32_also, f32_stride);
+    else hipLaunchKernelGGL((k_hash_ngp_lm<1>), gf, dim3(256), 0, st, h->params, ps, p, feats, pstride, lo_off, keep, lc, f32_also, f32_stride);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
@@ -353,8 +368,8 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
     const int gather = (variant >> 3) & 3;
     HashParams hpar = h->params;
     if (variant & 32) { for (int l = 0; l < L; l++) hpar.dense_off[l] = -1; }       // tuning: force the hashed lookup everywhere
-    // default variant, all levels: the lower three quarters of the pyramid in groups of four levels per thread, the (memory-bound) finest
-    // levels one level per thread
+    // default variant, all levels: the lower three quarters of the pyramid (instruction-bound: their lines are cached) in ONE thread per point, the (gather-bound) finest
+    // levels two per thread
     if (variant == 0 && level_lo == 0 && level_hi == L && L >= 8) {
 #ifdef NRF_HASH_LC
         const int lc = NRF_HASH_LC;
@@ -364,15 +379,23 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
         // Both launches as ONE (consecutive workgroups alternating between a four-coarse-levels kind and a one-fine-level kind, so that a CU holds vector-bound and
         // latency-bound waves together) was built and measured, same call: 8.71-8.74 ms per frame against 8.61-8.62 for the two launches
         // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.
-        if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+        // ... and the coarse levels ALL in one thread when there are twelve of them (16-level grids): the point and its box coordinates are formed once, and a coarse level
+        // costs instructions, not gather latency.  Round 3, same call, ms of hash encode per frame: 4 per thread 8.34-8.42, 6: 7.88-8.11, 12: 7.79-7.86; 14 + 2: 7.95-8.01,
+        // 10 + 6: 7.89-7.96 (profiles/round3/r6g_hash_levels_per_thread_ab.log)
+#ifndef NRF_HASH_COARSE_LPT
+#define NRF_HASH_COARSE_LPT 12
+#endif
+        if (lc > 0 && (lc % NRF_HASH_COARSE_LPT) == 0)
+            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_COARSE_LPT>), dim3((unsigned)ntiles, (unsigned)(lc / NRF_HASH_COARSE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+        else if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
         NRF_LAUNCH_CHECK();
         // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
         // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
 #ifndef NRF_HASH_FINE_LPT
 #define NRF_HASH_FINE_LPT 2
 #endif
-        if (NRF_HASH_FINE_LPT == 2 && ((L - lc) % 2) == 0)
-            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 2>), dim3((unsigned)ntiles, (unsigned)((L - lc) / 2)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+        if (NRF_HASH_FINE_LPT > 1 && ((L - lc) % NRF_HASH_FINE_LPT) == 0)
+            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_FINE_LPT>), dim3((unsigned)ntiles, (unsigned)((L - lc) / NRF_HASH_FINE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         else
         hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         NRF_LAUNCH_CHECK();
