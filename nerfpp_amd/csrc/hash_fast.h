@@ -118,19 +118,26 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
         // both features of a corner go through the same multiply and the same add: float2 vector arithmetic lets the compiler use the
         // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, one rounding per lane and op: bit-identical to the scalar form)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 v[8];
         float ws[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            __half2 hv; __builtin_memcpy(&hv, &wv[k], 4);
-            const float2 t = __half22float2(hv);
-            v[k] = f32x2{t.x, t.y};
             const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
             ws[k] = wx * wy * wz;
         }
-        f32x2 s2 = v[0] * ws[0];
+        // product of a corner's fp16 feature and its weight: v_fma_mix_f32 converts and multiplies in one instruction (fma(f32(h), w, -0) = RN(f32(h) * w), sign of a zero
+        // product included) at the issue cost of a plain multiply, where v_cvt_f32_f16 alone costs 1.6 of them (tools/scratch/valu_cost_probe.hip) -- 16 per level
+        f32x2 pr[8];
+        const float negzero = -0.0f;
 #pragma unroll
-        for (int k = 1; k < 8; k++) s2 = s2 + v[k] * ws[k];
+        for (int k = 0; k < 8; k++) {
+            float p0, p1;
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p0) : "v"(wv[k]), "v"(ws[k]), "s"(negzero));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(wv[k]), "v"(ws[k]), "s"(negzero));
+            pr[k] = f32x2{p0, p1};
+        }
+        f32x2 s2 = pr[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) s2 = s2 + pr[k];
         acc[0] = s2.x; acc[1] = s2.y;
     } else {
         const __half *fp = reinterpret_cast<const __half *>(hp.table) + lp.local_idx;
