@@ -385,19 +385,24 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
 #ifndef NRF_HASH_COARSE_LPT
 #define NRF_HASH_COARSE_LPT 12
 #endif
-        if (lc > 0 && (lc % NRF_HASH_COARSE_LPT) == 0)
-            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_COARSE_LPT>), dim3((unsigned)ntiles, (unsigned)(lc / NRF_HASH_COARSE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
-        else if (lc > 0) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
-        NRF_LAUNCH_CHECK();
-        // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
-        // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
 #ifndef NRF_HASH_FINE_LPT
 #define NRF_HASH_FINE_LPT 2
 #endif
-        if (NRF_HASH_FINE_LPT > 1 && ((L - lc) % NRF_HASH_FINE_LPT) == 0)
-            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_FINE_LPT>), dim3((unsigned)ntiles, (unsigned)((L - lc) / NRF_HASH_FINE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
-        else
-        hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+        // ... where those levels are baked.  With the hashed lookups (a training step uploads a new table every step and bakes nothing: 8 four-byte gathers per level into 8
+        // lines) the old grouping stays: training step 9.2-9.35 ms with 4 + 1 levels per thread against 9.83-9.87 with 12 + 2 (profiles/round3/r7c_train_step_hash_grouping_ab.log)
+        bool baked = !(variant & 32);
+        for (int l = 0; l < lc && baked; l++) baked = hpar.dense_off[l] >= 0;
+        const int clpt = (baked && (lc % NRF_HASH_COARSE_LPT) == 0) ? NRF_HASH_COARSE_LPT : 4;
+        const int flpt = (baked && ((L - lc) % NRF_HASH_FINE_LPT) == 0) ? NRF_HASH_FINE_LPT : 1;
+        if (lc > 0) {
+            if (clpt == 4) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+            else hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_COARSE_LPT>), dim3((unsigned)ntiles, (unsigned)(lc / NRF_HASH_COARSE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+        }
+        NRF_LAUNCH_CHECK();
+        // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
+        // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
+        if (flpt == 1) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+        else hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_FINE_LPT>), dim3((unsigned)ntiles, (unsigned)((L - lc) / NRF_HASH_FINE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         NRF_LAUNCH_CHECK();
         return NRF_OK;
     }
