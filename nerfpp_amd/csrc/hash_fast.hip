@@ -378,7 +378,8 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
 #endif       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
         // Both launches as ONE (consecutive workgroups alternating between a four-coarse-levels kind and a one-fine-level kind, so that a CU holds vector-bound and
         // latency-bound waves together) was built and measured, same call: 8.71-8.74 ms per frame against 8.61-8.62 for the two launches
-        // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.
+        // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.  Again with the 12-level coarse kind and two 2-level fine kinds:
+        // 7.78-7.79 against 7.65-7.68.
         // ... and the coarse levels ALL in one thread when there are twelve of them (16-level grids): the point and its box coordinates are formed once, and a coarse level
         // costs instructions, not gather latency.  Round 3, same call, ms of hash encode per frame: 4 per thread 8.34-8.42, 6: 7.88-8.11, 12: 7.79-7.86; 14 + 2: 7.95-8.01,
         // 10 + 6: 7.89-7.96 (profiles/round3/r6g_hash_levels_per_thread_ab.log)
