@@ -706,19 +706,21 @@ int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t
 }
 
 // workspace of the binned form: header (1 KB: mass, scale) | gcount [nbins + 1] | start [nbins + 1] | cursor [nbins] | wg_hist | records
-static void binned_layout(const nrf_hash *h, int s, int64_t *nbins, int64_t *rays_per_group, int64_t *nwg, size_t *off_hist, size_t *off_rec, size_t *total)
+// n_rays < 0: the worst case (a whole group of 2^18 points per pass); otherwise the pass never holds more than n_rays rays and the record buffer is sized for that
+static void binned_layout(const nrf_hash *h, int s, int64_t n_rays, int64_t *nbins, int64_t *rays_per_group, int64_t *nwg, size_t *off_hist, size_t *off_rec, size_t *total)
 {
     const int L = h->desc.n_levels;
     const int64_t entries = nrf_hash_table_elems(h) / 2;
     *nbins = ceil_div(entries, (int64_t)BIN_WORDS);
     *rays_per_group = (PACKED_GROUP_PTS / s) > 0 ? (PACKED_GROUP_PTS / s) : 1;
-    const int64_t threads = *rays_per_group * ((s + BWD_SEG - 1) / BWD_SEG);
+    const int64_t held = (n_rays >= 0 && n_rays < *rays_per_group) ? (n_rays > 0 ? n_rays : 1) : *rays_per_group;      // rays a pass can hold at most
+    const int64_t threads = held * ((s + BWD_SEG - 1) / BWD_SEG);
     *nwg = ceil_div(threads, (int64_t)256);
     size_t o = 1024 + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
     *off_hist = o;
     o += align_up((size_t)L * *nwg * BIN_MAX_PER_LEVEL * 4, 256);
     *off_rec = o;
-    o += (size_t)*rays_per_group * s * 8 * L * sizeof(uint4);          // every sample may flush eight records per level
+    o += (size_t)held * s * 8 * L * sizeof(uint4);                     // every sample may flush eight records per level
     *total = o;
 }
 
@@ -726,7 +728,15 @@ size_t nrf_hash_backward_binned_workspace_bytes(const nrf_hash *h, int s)
 {
     if (!h || s < 1) return 0;
     int64_t nbins, rpg, nwg; size_t oh, orr, total;
-    binned_layout(h, s, &nbins, &rpg, &nwg, &oh, &orr, &total);
+    binned_layout(h, s, -1, &nbins, &rpg, &nwg, &oh, &orr, &total);
+    return total;
+}
+
+size_t nrf_hash_backward_binned_workspace_bytes_for(const nrf_hash *h, int64_t n, int s)
+{
+    if (!h || s < 1 || n < 0) return 0;
+    int64_t nbins, rpg, nwg; size_t oh, orr, total;
+    binned_layout(h, s, n, &nbins, &rpg, &nwg, &oh, &orr, &total);
     return total;
 }
 
@@ -738,7 +748,7 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     if (h->desc.n_features != 2) { set_error("nrf_hash_backward_rays_binned: built for 2 features per level (a table entry = one 64-bit word); use nrf_hash_backward_rays"); return NRF_ERR_UNSUPPORTED; }
     if (h->desc.log2_hashmap_size > 19) { set_error("nrf_hash_backward_rays_binned: a level of 2^%d words touches more than %d bins; use nrf_hash_backward_rays_packed", h->desc.log2_hashmap_size, BIN_MAX_PER_LEVEL); return NRF_ERR_UNSUPPORTED; }
     int64_t nbins, rays_per_group, nwg; size_t off_hist, off_rec, total;
-    binned_layout(h, s, &nbins, &rays_per_group, &nwg, &off_hist, &off_rec, &total);
+    binned_layout(h, s, n, &nbins, &rays_per_group, &nwg, &off_hist, &off_rec, &total);       // sized for THIS call's rays: any workspace of nrf_hash_backward_binned_workspace_bytes[_for] fits
     if (workspace_bytes < total) { set_error("nrf_hash_backward_rays_binned: workspace %zu < %zu bytes", workspace_bytes, total); return NRF_ERR_WORKSPACE; }
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 255) || (reinterpret_cast<uintptr_t>(d_g_table) & 7)) { set_error("nrf_hash_backward_rays_binned: workspace must be 256-byte, g_table 8-byte aligned"); return NRF_ERR_INVALID_ARG; }
     if (n == 0) return NRF_OK;

@@ -141,7 +141,7 @@ class Trainer:
             ws = self._workspace(nb)
             L.check(bw_fn(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
         if self.hash_backward == "binned":
-            nbh = lib.nrf_hash_backward_binned_workspace_bytes(self.embedder._h, s)
+            nbh = lib.nrf_hash_backward_binned_workspace_bytes_for(self.embedder._h, C.c_int64(n), s)      # records for this batch, not for a whole 2^18-point pass
             if self._hws is None or self._hws.numel() < nbh:
                 self._hws = torch.empty((int(nbh),), device="cuda", dtype=torch.uint8)
             L.check(lib.nrf_hash_backward_rays_binned(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _ptr(self._hws), C.c_size_t(self._hws.numel()), _stream()))

@@ -1567,6 +1567,14 @@ def test_hash_backward_binned_equals_packed_bit_for_bit(api, mode, log2_t):
     a, b = host(gt_b), host(gt_q)
     assert np.abs(b - base).max() > 0
     assert_exact(a, b, f"{mode} T=2^{log2_t}: binned table gradient == packed-atomic table gradient")
+    # a workspace sized for THIS batch (records for n rays instead of a whole 2^18-point pass) serves the same call
+    lib.nrf_hash_backward_binned_workspace_bytes_for.restype = C.c_size_t
+    nbf = lib.nrf_hash_backward_binned_workspace_bytes_for(e._h, C.c_int64(n), s)
+    assert 0 < nbf <= nbb
+    wsf = torch.empty(nbf, dtype=torch.uint8, device="cuda")
+    gt_f = dev(base.copy())
+    api.L.check(lib.nrf_hash_backward_rays_binned(e._h, P(dp), C.c_int64(n), s, P(dg), P(gt_f), P(wsf), C.c_size_t(nbf), None))
+    assert_exact(host(gt_f), b, "batch-sized workspace: same table gradient")
 
 
 def test_trainer_matrix_core_backward_matches_fp32_trainer(api):
