@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16", "f16x3", "f32"],
                     help="MLP arithmetic: f16 = matrix cores, fp16 operands; f16x3 = matrix cores, hi+lo fp16 operand pairs (fp32-grade); f32 = FMA chains "
                          "(== oracle bitwise).  Default: f16x3 (fp32-grade pixels; the reference computes in fp32)")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the single-lane pass behind roofline.isolated")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (other precision, classic workload) at N = 1")
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
     ap.add_argument("--chunk", type=int, default=0, help="rays per RenderRays call (0 = workload default)")
@@ -245,6 +246,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     from nerfpp_amd.dist import TileShard, TileComm
+    if use_dist and args.backend != "nccl" and world > 1:
+        # a rehearsal: the ranks SHARE one GPU.  Two processes with two lanes each is four streams' worth of kernels time-sliced between two contexts (102 ms per step
+        # against 29 with one lane per process): one lane per process there
+        L.check(L.lib().nrf_set_render_lanes(1))
+        os.environ["NRF_RENDER_LANES"] = "1"
 
     prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[args.precision]
     if args.workload == "hash":
@@ -369,115 +375,139 @@ def main():
         collective_check = box.get("r", "nrf_allgather_tiles cross-check did not finish within 90 s")
         stuck = th.is_alive()                                        # a stuck collective: report what was timed and leave without tearing the group down
 
+    # rooflines of the kernels one at a time: a short single-lane pass (every rank takes part), see `roofline.isolated`
+    isolated = None
+    if not args.no_isolated and not stuck and os.environ.get("NRF_RENDER_LANES", "2") != "1":
+        L.check(L.lib().nrf_set_render_lanes(1))
+        i_steps = max(3, min(5, args.steps))
+        i_dt, _, _, _, (i_ms, i_cnt), _ = timed_run(args.scaling, i_steps, 1, profile=True)
+        L.check(L.lib().nrf_set_render_lanes(2))
+        isolated = dict(dt=i_dt, ms=i_ms, cnt=i_cnt, steps=i_steps)
     units_per_step = nframes * H * W * UNITS_PER_RAY          # over all ranks
     value = units_per_step * args.steps / elapsed
 
     if rank == 0:
-        prof = {n: dict(ms=ms[i], launches=int(cnt[i])) for i, n in enumerate(L.NRF_PROF_NAMES)}
-        # per-launch figures from HIP events on the launch stream; hash workload: the two candidates for `dominant` are the hash encode (HBM) and the fused MLP (MFMA)
-        if args.workload == "hash":
-            k = prof["hash"]
-            units_total = units_per_step * args.steps / world                     # this rank's units over the timed region (256 per ray)
-            ex_hash, ex_mlp, ex_sigma = executed_per_ray(args.workload, args.precision, args.hash_mode)
-            units_per_launch = units_total * ex_hash / UNITS_PER_RAY / max(k["launches"], 1)          # points the hash kernel really encoded
-            dur = k["ms"] * 1e-3 / max(k["launches"], 1)
-            achieved = units_per_launch * HASH_BYTES_PER_UNIT / max(dur, 1e-12)
-            traffic, traffic_src = pmc_traffic("hash_encode (k_hash_cu_lm)", units_per_launch)
-            # The baked pyramid is read through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), so the bound is the vector-memory GATHER
-            # path, not HBM: `achieved` prices the algorithmic bytes (588 B per unit) against the guide's measured ceiling for cache-resident
-            # gathers; hbm_frac is what the HBM counters saw, against the 8 TB/s SURVEY 8d names.
-            # achieved = algorithmic bytes (588 B per point the kernel encoded) / kernel time, against the 8 TB/s HBM peak.  The baked pyramid is read
-            # through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), which is how `frac` can exceed 1; the ceilings of the vector-memory
-            # gather path the kernel really runs on ride along (frac_of_l2_gather_ceiling / over_infinity_cache_gather_rate), and hbm_frac is what the HBM counters saw.
-            roof = dict(bound="hbm", kernel="hash_encode", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9,
-                        unit="GB/s", frac=achieved / HBM_PEAK, frac_of_l2_gather_ceiling=achieved / GATHER_PEAK_L2, over_infinity_cache_gather_rate=achieved / GATHER_PEAK,
-                        hbm_frac=(traffic / max(dur, 1e-12) / HBM_PEAK) if traffic else None, algorithmic_over_hbm_peak=achieved / HBM_PEAK,
-                        traffic=traffic, traffic_source=traffic_src, launches=k["launches"], avg_launch_ms=dur * 1e3,
-                        units_per_launch=units_per_launch, bytes_per_unit=HASH_BYTES_PER_UNIT,
-                        peak_source="peak = HBM3E 8 TB/s (MI355X_MICROARCH.md; SURVEY 8d).  Gather path, same guide, 'Indexed rows: gather': 16.8-18.8 TB/s with the rows resident in the XCD's L2 (frac_of_l2_gather_ceiling); "
-                                    "8.6 TB/s when the rows come from the Infinity Cache (38 MB table), 6.0 TB/s swept from HBM.  The 1.1 GB pyramid's coarse levels are L2-resident, "
-                                    "its fine levels are not: the kernel runs between the two rates (over_infinity_cache_gather_rate)")
-            # a model that fits the ablations, not a documented figure: a gather whose 64 lanes fall into 64 different lines holds the CU's vector L1 for ~64 clocks; a hash lookup is
-            # two 16-byte gathers per point and level (8 corners = two quads), so a launch cannot finish before units x 32 lookups / (256 CUs x clock)
-            roof["l1_tag_lookup_model"] = dict(line_lookups_per_unit=32, floor_ms_per_launch=[units_per_launch * 32 / (256 * 2.4e9) * 1e3, units_per_launch * 32 / (256 * 2.1e9) * 1e3],
-                                                floor_clock_ghz=[2.4, 2.1], frac_of_floor_at_2p1_ghz=units_per_launch * 32 / (256 * 2.1e9) / max(dur, 1e-12),
-                                                note="ablation builds (DESIGN section 9): gathers alone 7.8 ms, vector work alone 5.6 ms, whole kernel 8.2-8.3 ms per frame")
-            mk = prof["mlp"]
-            mdur = mk["ms"] * 1e-3
-            mlp_peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
-            sk = prof["sigma"]
-            # points the fused MLP kernel really processed (see executed_per_ray)
-            mlp_units = units_total * ex_mlp / UNITS_PER_RAY                       # whole-network launches (the kernel instance rocprofv3 lists as k_mlp_small_mfma<..., GEOIN = false>)
-            mupl = mlp_units / max(mk["launches"], 1)
-            mtraffic, mtraffic_src = pmc_traffic("mlp_small (k_mlp_small_mfma)", mupl)
-            mflop = mlp_units * SMALL_FLOP_PER_UNIT
-            mroof = dict(bound="mfma", kernel="mlp_small", achieved=mflop / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
-                         unit="TFLOP/s", frac=mflop / max(mdur, 1e-12) / mlp_peak, traffic=mtraffic, traffic_source=mtraffic_src,
-                         launches=mk["launches"], avg_launch_ms=mdur * 1e3 / max(mk["launches"], 1), units_per_launch=mupl, flop_per_unit=SMALL_FLOP_PER_UNIT)
-            ck = prof["mlp_colour"]
-            if ck["launches"]:
-                # the colour-net-only launches of the fine pass (its S coarse depths; sigma and geo_feat come from the exact coarse kernel): own slot, own kernel instance (GEOIN = true)
-                cdur = ck["ms"] * 1e-3
-                col_units = units_total * colour_only_per_ray(args.workload, args.precision) / UNITS_PER_RAY
-                mroof["colour_only"] = dict(bound="mfma", kernel="mlp_small, colour net alone", achieved=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
-                                            unit="TFLOP/s", frac=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak, launches=ck["launches"],
-                                            avg_launch_ms=cdur * 1e3 / ck["launches"], units_per_launch=col_units / ck["launches"], flop_per_unit=SMALL_COLOUR_FLOP_PER_UNIT,
-                                            mfma_issued_frac=col_units * SMALL_COLOUR_MFMA_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak)
-            if args.precision in SMALL_MFMA_FLOP_PER_UNIT:     # issued matrix-core flops (padding + the 3 products of the split mode) / peak
-                missued = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision]
-                mroof["mfma_issued_frac"] = missued / max(mdur, 1e-12) / mlp_peak
-                mroof["mfma_issued_vs_sustained_gemm"] = missued / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
-                mroof["sustained_note"] = ("mfma_issued_vs_sustained_gemm = issued matrix-core flop/s over the 1 247 TFLOP/s a tuned bf16 GEMM holds on random data (guide, DVFS give-back: "
-                                           "the chip lowers its clock under matrix load); measured on the classic split kernel: its cycle count does not change on all-zero weights while its clock does (DESIGN section 9)")
-                mroof["note"] = ("achieved / frac price the ALGORITHMIC 35 072 flop per unit; the split-precision mode issues three fp16 products per algorithmic one "
-                                 "to deliver fp32-grade pixels (north_star: within 1e-4), mfma_issued_frac is the matrix pipe's own utilisation") if args.precision == "f16x3" else \
-                                "achieved / frac price the algorithmic 35 072 flop per unit; mfma_issued_frac includes the zero padding of the 16- and 3-wide layers"
-                busy = pmc_mfma_busy("mlp_small (k_mlp_small_mfma)", args.precision)
+        def rooflines(ms, cnt, steps_):
+            """(kernel_ms, roofline) from the HIP-event totals of `steps_` timed steps."""
+            prof = {n: dict(ms=ms[i], launches=int(cnt[i])) for i, n in enumerate(L.NRF_PROF_NAMES)}
+            # per-launch figures from HIP events on the launch stream; hash workload: the two candidates for `dominant` are the hash encode (HBM) and the fused MLP (MFMA)
+            if args.workload == "hash":
+                k = prof["hash"]
+                units_total = units_per_step * steps_ / world                     # this rank's units over the timed region (256 per ray)
+                ex_hash, ex_mlp, ex_sigma = executed_per_ray(args.workload, args.precision, args.hash_mode)
+                units_per_launch = units_total * ex_hash / UNITS_PER_RAY / max(k["launches"], 1)          # points the hash kernel really encoded
+                dur = k["ms"] * 1e-3 / max(k["launches"], 1)
+                achieved = units_per_launch * HASH_BYTES_PER_UNIT / max(dur, 1e-12)
+                traffic, traffic_src = pmc_traffic("hash_encode (k_hash_cu_lm)", units_per_launch)
+                # The baked pyramid is read through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), so the bound is the vector-memory GATHER
+                # path, not HBM: `achieved` prices the algorithmic bytes (SURVEY 8d: 588 B per unit) against the guide's measured ceiling for cache-resident
+                # gathers; hbm_frac is what the HBM counters saw, against the 8 TB/s SURVEY 8d names.
+                # SURVEY 8(d): achieved = algorithmic bytes (588 B per point the kernel encoded) / kernel time, against the 8 TB/s HBM peak.  The baked pyramid is read
+                # through L2 / Infinity Cache (PMC: a third of the requested bytes reach HBM), which is how `frac` can exceed 1; the ceilings of the vector-memory
+                # gather path the kernel really runs on ride along (frac_of_l2_gather_ceiling / over_infinity_cache_gather_rate), and hbm_frac is what the HBM counters saw.
+                roof = dict(bound="hbm", kernel="hash_encode", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9,
+                            unit="GB/s", frac=achieved / HBM_PEAK, frac_of_l2_gather_ceiling=achieved / GATHER_PEAK_L2, over_infinity_cache_gather_rate=achieved / GATHER_PEAK,
+                            hbm_frac=(traffic / max(dur, 1e-12) / HBM_PEAK) if traffic else None, algorithmic_over_hbm_peak=achieved / HBM_PEAK,
+                            traffic=traffic, traffic_source=traffic_src, launches=k["launches"], avg_launch_ms=dur * 1e3,
+                            units_per_launch=units_per_launch, bytes_per_unit=HASH_BYTES_PER_UNIT,
+                            peak_source="peak = HBM3E 8 TB/s (MI355X_MICROARCH.md; SURVEY 8d).  Gather path, same guide, 'Indexed rows: gather': 16.8-18.8 TB/s with the rows resident in the XCD's L2 (frac_of_l2_gather_ceiling); "
+                                        "8.6 TB/s when the rows come from the Infinity Cache (38 MB table), 6.0 TB/s swept from HBM.  The 1.1 GB pyramid's coarse levels are L2-resident, "
+                                        "its fine levels are not: the kernel runs between the two rates (over_infinity_cache_gather_rate)")
+                # a model that fits the ablations (DESIGN section 9), not a documented figure: a gather whose 64 lanes fall into 64 different lines holds the CU's vector L1 for ~64 clocks; a hash lookup is
+                # two 16-byte gathers per point and level (8 corners = two quads), so a launch cannot finish before units x 32 lookups / (256 CUs x clock)
+                roof["l1_tag_lookup_model"] = dict(line_lookups_per_unit=32, floor_ms_per_launch=[units_per_launch * 32 / (256 * 2.4e9) * 1e3, units_per_launch * 32 / (256 * 2.1e9) * 1e3],
+                                                    floor_clock_ghz=[2.4, 2.1], frac_of_floor_at_2p1_ghz=units_per_launch * 32 / (256 * 2.1e9) / max(dur, 1e-12),
+                                                    note="ablation builds (DESIGN section 9): gathers alone 7.8 ms, vector work alone 5.6 ms, whole kernel 8.2-8.3 ms per frame")
+                mk = prof["mlp"]
+                mdur = mk["ms"] * 1e-3
+                mlp_peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
+                sk = prof["sigma"]
+                # points the fused MLP kernel really processed (see executed_per_ray)
+                mlp_units = units_total * ex_mlp / UNITS_PER_RAY                       # whole-network launches (the kernel instance rocprofv3 lists as k_mlp_small_mfma<..., GEOIN = false>)
+                mupl = mlp_units / max(mk["launches"], 1)
+                mtraffic, mtraffic_src = pmc_traffic("mlp_small (k_mlp_small_mfma)", mupl)
+                mflop = mlp_units * SMALL_FLOP_PER_UNIT
+                mroof = dict(bound="mfma", kernel="mlp_small", achieved=mflop / max(mdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
+                             unit="TFLOP/s", frac=mflop / max(mdur, 1e-12) / mlp_peak, traffic=mtraffic, traffic_source=mtraffic_src,
+                             launches=mk["launches"], avg_launch_ms=mdur * 1e3 / max(mk["launches"], 1), units_per_launch=mupl, flop_per_unit=SMALL_FLOP_PER_UNIT)
+                ck = prof["mlp_colour"]
+                if ck["launches"]:
+                    # the colour-net-only launches of the fine pass (its S coarse depths; sigma and geo_feat come from the exact coarse kernel): own slot, own kernel instance (GEOIN = true)
+                    cdur = ck["ms"] * 1e-3
+                    col_units = units_total * colour_only_per_ray(args.workload, args.precision) / UNITS_PER_RAY
+                    mroof["colour_only"] = dict(bound="mfma", kernel="mlp_small, colour net alone", achieved=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / 1e12, peak=mlp_peak / 1e12,
+                                                unit="TFLOP/s", frac=col_units * SMALL_COLOUR_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak, launches=ck["launches"],
+                                                avg_launch_ms=cdur * 1e3 / ck["launches"], units_per_launch=col_units / ck["launches"], flop_per_unit=SMALL_COLOUR_FLOP_PER_UNIT,
+                                                mfma_issued_frac=col_units * SMALL_COLOUR_MFMA_FLOP_PER_UNIT / max(cdur, 1e-12) / mlp_peak)
+                if args.precision in SMALL_MFMA_FLOP_PER_UNIT:     # issued matrix-core flops (padding + the 3 products of the split mode) / peak
+                    missued = mlp_units * SMALL_MFMA_FLOP_PER_UNIT[args.precision]
+                    mroof["mfma_issued_frac"] = missued / max(mdur, 1e-12) / mlp_peak
+                    mroof["mfma_issued_vs_sustained_gemm"] = missued / max(mdur, 1e-12) / MFMA_F16_SUSTAINED_GEMM
+                    mroof["sustained_note"] = ("mfma_issued_vs_sustained_gemm = issued matrix-core flop/s over the 1 247 TFLOP/s a tuned bf16 GEMM holds on random data (guide, DVFS give-back: "
+                                               "the chip lowers its clock under matrix load); measured on the classic split kernel: its cycle count does not change on all-zero weights while its clock does (DESIGN section 9)")
+                    mroof["note"] = ("achieved / frac price the ALGORITHMIC 35 072 flop per unit; the split-precision mode issues three fp16 products per algorithmic one "
+                                     "to deliver fp32-grade pixels (north_star: within 1e-4), mfma_issued_frac is the matrix pipe's own utilisation") if args.precision == "f16x3" else \
+                                    "achieved / frac price the algorithmic 35 072 flop per unit; mfma_issued_frac includes the zero padding of the 16- and 3-wide layers"
+                    busy = pmc_mfma_busy("mlp_small (k_mlp_small_mfma)", args.precision)
+                    if busy:
+                        mroof["mfma_busy_frac_of_active_cycles"] = busy
+                    try:
+                        mroof["clock_ghz_measured"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["mlp_small (k_mlp_small_mfma)"]["clock_ghz_measured"][args.precision]
+                    except Exception:
+                        pass
+                sroof = None
+                if sk["launches"]:
+                    sdur = sk["ms"] * 1e-3
+                    s_units = units_total * ex_sigma / UNITS_PER_RAY
+                    straffic, straffic_src = pmc_traffic("sigma_small_f32 (k_sigma_small_f32)", s_units / sk["launches"])
+                    sroof = dict(traffic=straffic, traffic_source=straffic_src, mfma_busy_frac_of_active_cycles=pmc_mfma_busy("sigma_small_f32 (k_sigma_small_f32)", "f16x3"),
+                                 bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
+                                 peak=F32_PEAK / 1e12, unit="TFLOP/s", frac=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / F32_PEAK, launches=sk["launches"],
+                                 avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT,
+                                 note="flop_per_unit prices the exact-fp32 sigma chain (32 -> 64 -> 64 -> 1); the kernel also forms the 15 geo_feat rows of the last layer for the fine pass "
+                                      "in split fp16 (12 of its 204 matrix instructions per 32 points) and stores them as the colour net's operand fragment (64 B per point)")
+                # the roofline object describes the kernel that took the most time in THIS run; the others ride along under their own keys
+                # (the NeRFSmall kernel's two instances -- whole network / colour net alone -- count as one kernel here; each keeps its own flops and launch time in the object)
+                cands = [(k["ms"], "hash", roof), (mk["ms"] + prof["mlp_colour"]["ms"], "mlp", mroof)] + ([(sk["ms"], "sigma", sroof)] if sroof else [])
+                cands.sort(key=lambda c: -c[0])
+                roof = dict(cands[0][2])
+                for _, name, r_ in cands[1:]:
+                    roof[name] = r_
+            else:
+                k = prof["mlp"]
+                dur_total = k["ms"] * 1e-3
+                ex_mlp = executed_per_ray(args.workload, args.precision, args.hash_mode, coarse_full=False)[1]
+                exec_units = units_per_step * steps_ / world * ex_mlp / UNITS_PER_RAY          # network evaluations this rank's kernel really ran
+                flops = exec_units * NERF_FLOP_PER_UNIT
+                peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
+                upl = exec_units / max(k["launches"], 1)
+                traffic, traffic_src = pmc_traffic("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", upl)
+                roof = dict(bound="mfma", kernel="mlp_nerf" + ("_split" if args.precision == "f16x3" else ""), achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
+                            frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
+                            avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT,
+                            note="achieved / frac price the ALGORITHMIC 1 186 816 flop per unit of NeRFImpl::forward as written (11 linear layers); the kernel runs "
+                                 "feature_linear and views_linears_0 (no activation in between) as one pre-multiplied affine layer, 10.6 % fewer matrix instructions")
+                if args.precision == "f16x3":      # three fp16 products per algorithmic one (hi + lo operand pairs)
+                    roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / peak
+                    roof["mfma_issued_vs_sustained_gemm"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / MFMA_F16_SUSTAINED_GEMM
+                    roof["note"] += "; split precision issues 3 x 1 058 matrix instructions per 32 points (mfma_issued_frac) to deliver fp32-grade pixels"
+                busy = pmc_mfma_busy("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", args.precision)
                 if busy:
-                    mroof["mfma_busy_frac_of_active_cycles"] = busy
-                try:
-                    mroof["clock_ghz_measured"] = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["mlp_small (k_mlp_small_mfma)"]["clock_ghz_measured"][args.precision]
-                except Exception:
-                    pass
-            sroof = None
-            if sk["launches"]:
-                sdur = sk["ms"] * 1e-3
-                s_units = units_total * ex_sigma / UNITS_PER_RAY
-                straffic, straffic_src = pmc_traffic("sigma_small_f32 (k_sigma_small_f32)", s_units / sk["launches"])
-                sroof = dict(traffic=straffic, traffic_source=straffic_src, mfma_busy_frac_of_active_cycles=pmc_mfma_busy("sigma_small_f32 (k_sigma_small_f32)", "f16x3"),
-                             bound="mfma (fp32, v_mfma_f32_32x32x2_f32)", kernel="sigma_small_f32 (coarse pass: sigma net alone, exact fp32)", achieved=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / 1e12,
-                             peak=F32_PEAK / 1e12, unit="TFLOP/s", frac=s_units * SIGMA_FLOP_PER_UNIT / max(sdur, 1e-12) / F32_PEAK, launches=sk["launches"],
-                             avg_launch_ms=sdur * 1e3 / sk["launches"], units_per_launch=s_units / sk["launches"], flop_per_unit=SIGMA_FLOP_PER_UNIT,
-                             note="flop_per_unit prices the exact-fp32 sigma chain (32 -> 64 -> 64 -> 1); the kernel also forms the 15 geo_feat rows of the last layer for the fine pass "
-                                  "in split fp16 (12 of its 204 matrix instructions per 32 points) and stores them as the colour net's operand fragment (64 B per point)")
-            # the roofline object describes the kernel that took the most time in THIS run; the others ride along under their own keys
-            # (the NeRFSmall kernel's two instances -- whole network / colour net alone -- count as one kernel here; each keeps its own flops and launch time in the object)
-            cands = [(k["ms"], "hash", roof), (mk["ms"] + prof["mlp_colour"]["ms"], "mlp", mroof)] + ([(sk["ms"], "sigma", sroof)] if sroof else [])
-            cands.sort(key=lambda c: -c[0])
-            roof = dict(cands[0][2])
-            for _, name, r_ in cands[1:]:
-                roof[name] = r_
-        else:
-            k = prof["mlp"]
-            dur_total = k["ms"] * 1e-3
-            ex_mlp = executed_per_ray(args.workload, args.precision, args.hash_mode, coarse_full=False)[1]
-            exec_units = units_per_step * args.steps / world * ex_mlp / UNITS_PER_RAY          # network evaluations this rank's kernel really ran
-            flops = exec_units * NERF_FLOP_PER_UNIT
-            peak = MFMA_F16_PEAK if args.precision != "f32" else F32_PEAK
-            upl = exec_units / max(k["launches"], 1)
-            traffic, traffic_src = pmc_traffic("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", upl)
-            roof = dict(bound="mfma", kernel="mlp_nerf" + ("_split" if args.precision == "f16x3" else ""), achieved=flops / max(dur_total, 1e-12) / 1e12, peak=peak / 1e12, unit="TFLOP/s",
-                        frac=flops / max(dur_total, 1e-12) / peak, traffic=traffic, traffic_source=traffic_src, launches=k["launches"], units_per_launch=upl,
-                        avg_launch_ms=dur_total * 1e3 / max(k["launches"], 1), flop_per_unit=NERF_FLOP_PER_UNIT,
-                        note="achieved / frac price the ALGORITHMIC 1 186 816 flop per unit of NeRFImpl::forward as written (11 linear layers); the kernel runs "
-                             "feature_linear and views_linears_0 (no activation in between) as one pre-multiplied affine layer, 10.6 % fewer matrix instructions")
-            if args.precision == "f16x3":      # three fp16 products per algorithmic one (hi + lo operand pairs)
-                roof["mfma_issued_frac"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / peak
-                roof["mfma_issued_vs_sustained_gemm"] = 3.0 * (1058 * 32768 / 32) * exec_units / max(dur_total, 1e-12) / MFMA_F16_SUSTAINED_GEMM
-                roof["note"] += "; split precision issues 3 x 1 058 matrix instructions per 32 points (mfma_issued_frac) to deliver fp32-grade pixels"
-            busy = pmc_mfma_busy("mlp_nerf_split (k_mlp_nerf_split)" if args.precision == "f16x3" else "mlp_nerf (k_mlp_nerf_mfma)", args.precision)
-            if busy:
-                roof["mfma_busy_frac_of_active_cycles"] = busy
+                    roof["mfma_busy_frac_of_active_cycles"] = busy
+            return prof, roof
+
+        prof, roof = rooflines(ms, cnt, args.steps)
+        if isolated is not None:
+            # the same quantities with the Chunk loop on ONE stream (a short pass after the timed region): there each kernel has the GPU to itself, so launch time is the
+            # kernel's own and the fractions are the kernels' -- in the timed region two chunks' kernels share the CUs and a launch's duration includes the sharing
+            iprof, iroof = rooflines(isolated["ms"], isolated["cnt"], isolated["steps"])
+            iroof["kernel_ms"] = iprof
+            iroof["ms_per_step"] = isolated["dt"] / isolated["steps"] * 1e3
+            iroof["note_isolated"] = ("nrf_set_render_lanes(1): chunks one after another on the caller's stream, %d steps right after the timed region; the headline's timed region runs "
+                                      "consecutive chunks on two streams (one chunk's gather-bound encode beside another's matrix-bound network)" % isolated["steps"])
+            roof["isolated"] = iroof
+            roof["note_overlap"] = ("timed region: two lanes -- kernels of two chunks share the CUs, so avg_launch_ms (and every fraction derived from it) includes the sharing; "
+                                    "`isolated` holds the same figures measured one kernel at a time")
         line = {
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -550,16 +580,29 @@ def timed_frames(L, render, frames, warm=2):
     for _ in range(warm):
         render()
     torch.cuda.synchronize()
-    n = len(L.NRF_PROF_NAMES)
-    ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
-    L.lib().nrf_profile_enable(1)
-    L.lib().nrf_profile_read(ms, cnt, 1)
     t0 = time.perf_counter()
     for _ in range(frames):
         out = render()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames
+    # the per-kernel times come from a second, single-lane pass (nrf_set_render_lanes(1): a kernel has the GPU to itself, its launch time is its own); the frame time
+    # above is the default two-lane Chunk loop's
+    n = len(L.NRF_PROF_NAMES)
+    ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+    single = os.environ.get("NRF_RENDER_LANES", "2") != "1"
+    if single:
+        L.lib().nrf_set_render_lanes(1)
+    frames = max(2, min(frames, 4))
+    render()
+    torch.cuda.synchronize()
+    L.lib().nrf_profile_enable(1)
     L.lib().nrf_profile_read(ms, cnt, 1)
+    for _ in range(frames):
+        out = render()
+    torch.cuda.synchronize()
+    L.lib().nrf_profile_read(ms, cnt, 1)
+    if single:
+        L.lib().nrf_set_render_lanes(2)
     L.lib().nrf_profile_enable(0)
     return dt, {nm: dict(ms_per_frame=ms[i] / frames, launches_per_frame=cnt[i] / frames) for i, nm in enumerate(L.NRF_PROF_NAMES)}, out
 

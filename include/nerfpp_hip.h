@@ -569,6 +569,9 @@ NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int fra
 /* NRF_PROF_MLP_COLOUR: the NeRFSmall kernel's colour-net-only launch of a hierarchical render's fine pass (its S coarse depths; see nrf_render_params.coarse_mode) --
  * a different amount of work per point than NRF_PROF_MLP's whole-network launches, so it has its own slot. */
 enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAMPLE = 3, NRF_PROF_OTHER = 4, NRF_PROF_SIGMA = 5, NRF_PROF_MLP_COLOUR = 6, NRF_PROF_COUNT = 7 };
+/* The Chunk loop of nrf_batchify_rays / nrf_render_rows runs consecutive chunks on two internal streams (forked from and joined to the caller's stream) so that one
+ * chunk's gather-bound kernels overlap another's matrix-bound ones; results do not depend on it.  lanes = 1 restores the single-stream loop (also: NRF_RENDER_LANES=1). */
+NRF_API int nrf_set_render_lanes(int lanes);
 NRF_API int nrf_profile_enable(int on);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
 

@@ -77,7 +77,7 @@ SYMBOLS = [
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_create_timeout", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",
-    "nrf_profile_enable", "nrf_profile_read",
+    "nrf_profile_enable", "nrf_profile_read", "nrf_set_render_lanes",
 ]
 NRF_COMM_ID_BYTES = 128
 

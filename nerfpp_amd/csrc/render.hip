@@ -12,11 +12,18 @@
 #include "mlp.h"
 #include "stoch.h"
 
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 struct nrf_renderer {
     nrf_renderer_desc desc;
     int in_ch = 0, in_views = 0;
+    // the two lanes of the Chunk loop (nrf_batchify_rays): auxiliary streams, created on first use on the device that is current then
+    mutable std::mutex lane_mu;
+    mutable hipStream_t lane[2] = {nullptr, nullptr};
+    mutable int lane_device = -1;
+    ~nrf_renderer() { for (auto &st : lane) if (st) (void)hipStreamDestroy(st); }
 };
 
 namespace nrf {
@@ -517,10 +524,63 @@ static nrf_render_outputs slice_outputs(const nrf_render_outputs &o, int64_t i, 
     return q;
 }
 
+// ---- the Chunk loop on two lanes ----
+// Consecutive chunks are independent, and their kernels are bound by different things: the hash encode's fine levels by gather latency, the network kernels by the
+// matrix / vector issue of the SIMDs.  Issued on two streams, the chunks' kernels share the CUs (the NeRFSmall kernels hold 206-218 of a SIMD's 512 registers per wave,
+// two waves per SIMD: a wave of the 44-66-register encode fits beside them -- it did not in round 2, when those kernels held 255 and the same experiment gained nothing):
+// 24.8 -> 22.7 ms per frame (tools/scratch/overlap.py).  Chunk i runs on lane i % 2 with its own half of the workspace; the lanes fork from the caller's stream and join
+// it again, so the call is as asynchronous and as ordered as before, and the results do not depend on it (same kernels on the same slices).  A batch that is one chunk is
+// cut in two.  NRF_RENDER_LANES=1 (or nrf_set_render_lanes(1)) restores the single-stream loop.
+static std::atomic<int> g_render_lanes{0};          // 0: not decided yet (environment, default 2)
+static int render_lanes()
+{
+    int v = g_render_lanes.load(std::memory_order_relaxed);
+    if (v == 0) {
+        const char *e = getenv("NRF_RENDER_LANES");
+        v = (e && atoi(e) == 1) ? 1 : 2;
+        g_render_lanes.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+#ifndef NRF_LANE_STAGGER
+#define NRF_LANE_STAGGER 1
+#endif
+constexpr int64_t LANE_MIN_RAYS = 16384;           // below this a batch stays on the caller's stream
+
+// rays per chunk of the two-lane loop; 0: single-stream loop
+static int64_t lane_chunk(int64_t n, int chunk)
+{
+    if (render_lanes() < 2 || n < LANE_MIN_RAYS) return 0;
+    if (n > chunk) return chunk;
+    return ((n + 1) / 2 + 63) / 64 * 64;            // one chunk: two halves
+}
+
 size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p)
 {
     if (!r || !p || chunk <= 0) return 0;
+    const int64_t lc = lane_chunk(n, chunk);
+    if (lc > 0 && lc < n) return 2 * align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256);
     return nrf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
+}
+
+int nrf_set_render_lanes(int lanes)
+{
+    NRF_CHECK_ARG(lanes == 1 || lanes == 2, "nrf_set_render_lanes: 1 (single stream) or 2");
+    g_render_lanes.store(lanes, std::memory_order_relaxed);
+    return NRF_OK;
+}
+
+static int lanes_of(const nrf_renderer *r, hipStream_t (&st)[2])
+{
+    std::lock_guard<std::mutex> lk(r->lane_mu);
+    int dev = 0;
+    NRF_HIP(hipGetDevice(&dev));
+    if (r->lane[0] && r->lane_device != dev) { set_error("nrf_batchify_rays: the renderer's lanes live on device %d, the call came on device %d", r->lane_device, dev); return NRF_ERR_INVALID_ARG; }
+    for (int i = 0; i < 2; i++)
+        if (!r->lane[i]) NRF_HIP(hipStreamCreateWithFlags(&r->lane[i], hipStreamNonBlocking));
+    r->lane_device = dev;
+    st[0] = r->lane[0]; st[1] = r->lane[1];
+    return NRF_OK;
 }
 
 int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p, const float *d_t,
@@ -531,6 +591,46 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
     const int s = p->n_samples, sf = p->n_samples + p->n_importance, so = p->n_importance > 0 ? sf : s;
     const int c = r->desc.mlp->out_dims;
     nrf_render_params q = *p;
+    const int64_t lc = lane_chunk(n, chunk);
+    const size_t half = lc > 0 && lc < n ? align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256) : 0;
+    if (half > 0 && 2 * half <= workspace_bytes && d_workspace) {
+        // two lanes: fork from the caller's stream, chunk i on lane i % 2 in its own half of the workspace, join
+        hipStream_t st = as_stream(stream), lane[2];
+        NRF_TRY(lanes_of(r, lane));
+        hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+        NRF_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        int rc = NRF_OK;
+        if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(lane[0], fork, 0) != hipSuccess || hipStreamWaitEvent(lane[1], fork, 0) != hipSuccess) {
+            set_error("nrf_batchify_rays: forking the lanes failed"); rc = NRF_ERR_HIP;
+        }
+        // lane 1 starts with a half chunk: the lanes then run out of phase (one in its encode while the other is in its network) instead of doing the same thing at
+        // the same time, which is what makes them share the CUs well
+        int k = 0;
+        bool first1 = true;
+        for (int64_t i = 0; i < n && rc == NRF_OK; k ^= 1) {                                                      // :476
+            int64_t m = lc;
+#if NRF_LANE_STAGGER
+            if (k == 1 && first1) { m = (lc / 2 + 63) / 64 * 64; first1 = false; }
+#endif
+            (void)first1;
+            if (m > n - i) m = n - i;
+            q.ray_base = p->ray_base + i;
+            const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
+            rc = nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * half, half, lane[k]);
+            i += m;
+        }
+        // join on every path: whatever was launched is ordered before the caller's next operation
+        for (int j = 0; j < 2; j++) {
+            if (hipEventCreateWithFlags(&done[j], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[j], lane[j]) != hipSuccess ||
+                hipStreamWaitEvent(st, done[j], 0) != hipSuccess) {
+                if (rc == NRF_OK) { set_error("nrf_batchify_rays: joining the lanes failed"); rc = NRF_ERR_HIP; }
+                (void)hipStreamSynchronize(lane[j]);
+            }
+        }
+        (void)hipEventDestroy(fork);
+        for (int j = 0; j < 2; j++) if (done[j]) (void)hipEventDestroy(done[j]);
+        return rc;
+    }
     for (int64_t i = 0; i < n; i += chunk) {                                                                      // :476
         const int64_t m = n - i < chunk ? n - i : (int64_t)chunk;
         q.ray_base = p->ray_base + i;

@@ -1,6 +1,8 @@
 #!/bin/bash
 # clock held under load + matrix-pipe busy cycles of the dominant kernels (separate --pmc passes, kernel dispatch only)
 set -u
+# counters are per dispatch: the Chunk loop on ONE stream, so that no two kernels run at the same time (the variable is inherited; nothing stands between rocprofv3's -- and python3)
+export NRF_RENDER_LANES=1
 tag=${1:-pmcclk}
 ROOTD=$PWD
 mkdir -p gpurun_out

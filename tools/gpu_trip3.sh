@@ -15,10 +15,11 @@ mkdir -p gpurun_out
 (timeout -k 10 300 python bench.py --force-dist --collective cabi --scaling strong --no-also --no-cpu-baseline 2>/dev/null | tail -1) > gpurun_out/${tag}_bench_strong_cabi_world1.json
 ROOTD=$PWD
 cd /tmp && export TMPDIR=/tmp
-(timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
+(timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity --no-isolated 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof.log 2>&1
+(export NRF_RENDER_LANES=1; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_single_lane -- python3 $ROOTD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof_single_lane.log 2>&1
 (timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_classic -- python3 $ROOTD/bench.py --workload classic --steps 3 --warmup 1 --no-cpu-baseline --no-also --no-parity 2>&1 | tail -5) > $ROOTD/gpurun_out/${tag}_prof_classic.log 2>&1
 (timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_lerf -- python3 $ROOTD/tools/scratch/lerf_time.py 2>&1 | tail -8) > $ROOTD/gpurun_out/${tag}_prof_lerf.log 2>&1
 (timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTD/gpurun_out/${tag}_prof_train -- python3 $ROOTD/tools/scratch/train_prof.py 16384 f16 binned --fast-only 2>&1 | tail -8) > $ROOTD/gpurun_out/${tag}_prof_train.log 2>&1
 cd $ROOTD
-for d in prof prof_classic prof_lerf prof_train; do f=$(ls gpurun_out/${tag}_$d/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_${d}_kernel_stats.csv; rm -rf gpurun_out/${tag}_$d; done
+for d in prof prof_single_lane prof_classic prof_lerf prof_train; do f=$(ls gpurun_out/${tag}_$d/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_${d}_kernel_stats.csv; rm -rf gpurun_out/${tag}_$d; done
 tail -4 gpurun_out/${tag}_tests.log
