@@ -545,6 +545,9 @@ static int render_lanes()
 #ifndef NRF_LANE_STAGGER
 #define NRF_LANE_STAGGER 1
 #endif
+#ifndef NRF_LANE_STAGGER_PCT
+#define NRF_LANE_STAGGER_PCT 50          // lane 1's first chunk, in per cent of a chunk
+#endif
 constexpr int64_t LANE_MIN_RAYS = 16384;           // below this a batch stays on the caller's stream
 
 // rays per chunk of the two-lane loop; 0: single-stream loop
@@ -610,7 +613,7 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
         for (int64_t i = 0; i < n && rc == NRF_OK; k ^= 1) {                                                      // :476
             int64_t m = lc;
 #if NRF_LANE_STAGGER
-            if (k == 1 && first1) { m = (lc / 2 + 63) / 64 * 64; first1 = false; }
+            if (k == 1 && first1) { m = (lc * NRF_LANE_STAGGER_PCT / 100 + 63) / 64 * 64; first1 = false; }
 #endif
             (void)first1;
             if (m > n - i) m = n - i;
