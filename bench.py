@@ -573,7 +573,7 @@ def main():
         os._exit(0)
 
 
-def timed_frames(L, render, frames, warm=2):
+def timed_frames(L, render, frames, warm=2, lanes_hook=None):
     """warm untimed + `frames` timed calls of render() -> (seconds per frame, per-kernel HIP-event ms per frame and launches per frame)."""
     import ctypes as C
     import torch
@@ -592,6 +592,8 @@ def timed_frames(L, render, frames, warm=2):
     single = os.environ.get("NRF_RENDER_LANES", "2") != "1"
     if single:
         L.lib().nrf_set_render_lanes(1)
+        if lanes_hook:
+            lanes_hook(1)                        # a host whose own Chunk loop has lanes (LeRFRenderer)
     frames = max(2, min(frames, 4))
     render()
     torch.cuda.synchronize()
@@ -603,6 +605,8 @@ def timed_frames(L, render, frames, warm=2):
     L.lib().nrf_profile_read(ms, cnt, 1)
     if single:
         L.lib().nrf_set_render_lanes(2)
+        if lanes_hook:
+            lanes_hook(2)
     L.lib().nrf_profile_enable(0)
     return dt, {nm: dict(ms_per_frame=ms[i] / frames, launches_per_frame=cnt[i] / frames) for i, nm in enumerate(L.NRF_PROF_NAMES)}, out
 
@@ -749,7 +753,7 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
                            BoundingBox=sc["bbox"])
     r = sc["renderer"]
     r.set_precision(precision)
-    dt, kms, res = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1)
+    dt, kms, res = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1, lanes_hook=lambda k: setattr(r, "lanes", k))
     n = H * W
     emb = res.Outputs.RenderedLangEmbedding
     hit = res.Outputs.AccMapLE > 1e-2

@@ -6,6 +6,7 @@ NeRFRenderer.{Render, BatchifyRays, RenderRays, RunNetwork, RawToOutputs}.  All 
 libnerfpp_hip.so on the current HIP stream; torch only owns the buffers.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -523,6 +524,8 @@ class LeRFRenderer:
         self.exact_coarse = True
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
+        self.lanes = 1 if os.environ.get("NRF_RENDER_LANES", "2") == "1" else 2      # streams of Render's Chunk loop (see Render)
+        self._lane_streams = None
         if self.fused:
             self.set_precision(precision)
         # level-major fp16 features straight into the matrix-core kernels' operand fragments (CuHashEmbedder, 16 levels x 8 features); False = fp32 rows
@@ -723,9 +726,31 @@ class LeRFRenderer:
         stride = 11 if p.UseViewdirs else 8
         rays_ = torch.empty((n, stride), device=o.device, dtype=torch.float32)
         L.check(L.lib().nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))
-        parts = [self.RenderRays(rays_[i:i + p.Chunk], None if p.ThinRay else cone_angle, p.NSamples, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
-                                 perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
-                                 return_weights=p.ReturnWeights) for i in range(0, n, p.Chunk)]
+        def one(i):
+            return self.RenderRays(rays_[i:i + p.Chunk], None if p.ThinRay else cone_angle, p.NSamples, return_raw=p.ReturnRaw, lin_disp=p.LinDisp,
+                                   perturb=p.Perturb, n_importance=p.NImportance, white_bkgr=p.WhiteBkgr, raw_noise_std=p.RawNoiseStd,
+                                   return_weights=p.ReturnWeights)
+        starts = list(range(0, n, p.Chunk))
+        if self.lanes >= 2 and len(starts) >= 2 and rays_.is_cuda:
+            # the Chunk loop on two lanes (as nrf_batchify_rays does for the NeRF renderers): consecutive chunks on two streams forked from and joined to the current one, so that
+            # one chunk's gather-bound F = 8 hash encode shares the CUs with another's matrix-bound passes.  Same kernels on the same slices: same results.
+            cur = torch.cuda.current_stream()
+            if self._lane_streams is None:
+                self._lane_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for st in self._lane_streams:
+                st.wait_stream(cur)
+            parts = []
+            for j, i in enumerate(starts):
+                with torch.cuda.stream(self._lane_streams[j & 1]):
+                    parts.append(one(i))
+            for st in self._lane_streams:
+                cur.wait_stream(st)
+            for q in parts:            # the results are read (concatenated) on the current stream: tell the allocator before the lanes may reuse their memory
+                for t in list(vars(q.Outputs).values()) + list(q.Extras.values()) + [q.Raw]:
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
+        else:
+            parts = [one(i) for i in starts]
         res = LeRFRenderResult()
         for name in ("RenderedLangEmbedding", "DispMapLE", "AccMapLE", "WeightsLE", "DepthMapLE"):
             vals = [getattr(q.Outputs, name) for q in parts if getattr(q.Outputs, name) is not None]
