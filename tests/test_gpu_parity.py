@@ -1752,6 +1752,43 @@ def test_whole_frame_800x800_bench_configuration(api, O):
     assert_exact(host(tile.Outputs.RGBMap).reshape(-1, 3), rgb[row0 * 800:(row0 + rows) * 800], "row tile == slice of the frame")
 
 
+def test_chunk_loop_lanes_reproduce_the_single_stream_loop(api):
+    """nrf_batchify_rays runs consecutive chunks on two internal streams (render.hip: forked from / joined to the caller's stream, lane 1 staggered by half a
+    chunk, a one-chunk batch cut in two).  Same kernels on the same slices: every output equals the single-stream loop's bit for bit -- several chunks, an odd
+    count, one chunk, a batch below the two-lane threshold, a ragged last chunk, and a caller on a side stream whose next kernel reads the result."""
+    import torch
+    sc = api.S.make_hash_scene(mode="cu")
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    lib = api.L.lib()
+    cases = [(300, 200, 40000), (300, 200, 65536), (300, 200, 131072), (300, 200, 1 << 20), (390, 20, 131072), (390, 21, 5000), (300, 37, 9999)]
+    try:
+        for row0, rows, chunk in cases:
+            rp = api.S.lego_render_params(sc["bbox"], chunk=chunk, precision=api.L.NRF_PREC_F16_SPLIT)
+            outs = []
+            for lanes in (1, 2):
+                api.L.check(lib.nrf_set_render_lanes(lanes))
+                res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=row0, rows=rows)
+                outs.append([host(res.Outputs.RGBMap), host(res.Outputs.DepthMap), host(res.Outputs.AccMap), host(res.Outputs.DispMap)])
+            for x, y, nm in zip(outs[0], outs[1], ("rgb", "depth", "acc", "disp")):
+                assert_exact(y, x, "two lanes == one stream: %s, rows %d chunk %d" % (nm, rows, chunk))
+        # the caller's stream order holds across the fork / join: a side stream renders, then reduces the pixels on the same stream, no host sync in between
+        rp = api.S.lego_render_params(sc["bbox"], chunk=40000, precision=api.L.NRF_PREC_F16_SPLIT)
+        api.L.check(lib.nrf_set_render_lanes(2))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        sums = []
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=300, rows=200)
+                sums.append(res.Outputs.RGBMap.double().sum())
+        side.synchronize()
+        api.L.check(lib.nrf_set_render_lanes(1))
+        ref = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=300, rows=200).Outputs.RGBMap.double().sum().item()
+        assert [v.item() for v in sums] == [ref] * 3
+    finally:
+        api.L.check(lib.nrf_set_render_lanes(2))
+
+
 def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     """BASELINE config 4 at the reference's own sizes (main.cpp:203-213: CuHashEmbedder L16 F8 T2^19 16..1024, LeRF 2 x 256 -> 768) on a 4-row tile of the
     800x800 frame, 64 + 128 samples, fused matrix-core path: sigma_le and the rendered embedding of 48 sampled rays against the oracle composed stage by
