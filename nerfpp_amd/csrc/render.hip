@@ -548,6 +548,9 @@ static int render_lanes()
 #ifndef NRF_LANE_STAGGER_PCT
 #define NRF_LANE_STAGGER_PCT 50          // lane 1's first chunk, in per cent of a chunk
 #endif
+#ifndef NRF_LANE_BALANCE
+#define NRF_LANE_BALANCE 1               // the tail of the batch is cut so that both lanes end together (0: full chunks to the end)
+#endif
 constexpr int64_t LANE_MIN_RAYS = 16384;           // below this a batch stays on the caller's stream
 
 // rays per chunk of the two-lane loop; 0: single-stream loop
@@ -608,18 +611,30 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
         }
         // lane 1 starts with a half chunk: the lanes then run out of phase (one in its encode while the other is in its network) instead of doing the same thing at
         // the same time, which is what makes them share the CUs well
-        int k = 0;
+        // The next chunk goes to the lane that has been given fewer rays so far (strict alternation would leave lane 1, which started with half a chunk, a chunk and
+        // a half behind at the end of a five-chunk frame: the last quarter of the frame on one lane), and the last < 2 chunks are cut so that both lanes end together.
+        int64_t given[2] = {0, 0};
         bool first1 = true;
-        for (int64_t i = 0; i < n && rc == NRF_OK; k ^= 1) {                                                      // :476
+        for (int64_t i = 0; i < n && rc == NRF_OK;) {                                                             // :476
+            const int k = given[1] < given[0] ? 1 : 0;
+            const int64_t rem = n - i;
             int64_t m = lc;
 #if NRF_LANE_STAGGER
-            if (k == 1 && first1) { m = (lc * NRF_LANE_STAGGER_PCT / 100 + 63) / 64 * 64; first1 = false; }
+            if (k == 1 && first1) m = (lc * NRF_LANE_STAGGER_PCT / 100 + 63) / 64 * 64;
 #endif
-            (void)first1;
-            if (m > n - i) m = n - i;
+            if (k == 1) first1 = false;
+#if NRF_LANE_BALANCE
+            if (rem < 2 * lc) {
+                m = ((rem + given[k ^ 1] - given[k]) / 2 + 63) / 64 * 64;       // lane k's share of the rest that evens the lanes out
+                if (m > lc) m = lc;
+                if (rem - m < 1024 && rem <= lc) m = rem;                       // no crumbs
+            }
+#endif
+            if (m > rem) m = rem;
             q.ray_base = p->ray_base + i;
             const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
             rc = nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * half, half, lane[k]);
+            given[k] += m;
             i += m;
         }
         // join on every path: whatever was launched is ordered before the caller's next operation
