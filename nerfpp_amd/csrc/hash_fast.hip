@@ -328,9 +328,9 @@ int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __ha
     const int L = h->desc.n_levels;
     const int64_t ntiles = ceil_div(p, 256);
     const int lc = (L * 3 / 4) & ~3;
-    // levels per thread of the coarse / fine launch (see launch_hash_lm).  This encoder's lookups are four 16-byte gathers per level out of an 8.7 GB fp32 image: no grouping
-    // moves it -- bench frame of the LibTorch-twin scene, same call, ms of hash encode: 4 + 1 per thread 23.7-23.8, 12 + 2: 24.0-24.1, 6 + 2: 23.6, 4 + 2: 23.8
-    // (profiles/round3/r6i_ngp_levels_per_thread_ab.log)
+    // levels per thread of the coarse / fine launch (see launch_hash_lm).  This encoder's lookups are four 16-byte gathers per level out of an 8.7 GB fp32 image -- bench
+    // frame of the LibTorch-twin scene, same call, ms of hash encode: 4 + 1 per thread 14.0-14.1, 12 + 2: 15.3, 6 + 2: 14.2, 4 + 2: 14.2, 2 + 1: 14.1
+    // (profiles/round3/r9e_ngp_levels_per_thread_ab.log; before the dense lookup's loads were repaired -- see encode_level_ngp -- every grouping took 23.6-24.1)
 #ifndef NRF_NGP_COARSE_LPT
 #define NRF_NGP_COARSE_LPT 4
 #endif
