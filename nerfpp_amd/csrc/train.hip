@@ -248,7 +248,7 @@ struct BinSink {
 };
 
 template <int F, bool CU, bool Q, int MODE>
-__device__ __forceinline__ void hash_bwd_walk(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+__device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
                                               float *__restrict__ g_table, const float *__restrict__ qscale_p, const BinSink &sink, uint32_t *bin_cnt, const uint32_t *bin_base);
 
 template <int F, bool CU, bool Q = false, int MODE = 0>
@@ -285,7 +285,7 @@ __global__ void k_hash_bwd_ray(HashParams hp, const float *__restrict__ pts, int
 }
 
 template <int F, bool CU, bool Q, int MODE>
-__device__ __forceinline__ void hash_bwd_walk(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+__device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
                                               float *__restrict__ g_table, const float *__restrict__ qscale_p, const BinSink &sink, uint32_t *bin_cnt, const uint32_t *bin_base)
 {
     const int nseg = (s + BWD_SEG - 1) / BWD_SEG;
