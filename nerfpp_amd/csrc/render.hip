@@ -447,7 +447,10 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     ReuseWs rw{};
     if (reuse) {
         NRF_TRY(reuse_layout(nws, nws_bytes, n, s, ni, ngp && dirs_lo, ngp && sigma_only, rw));
-        if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep, st, false, rw.f32, n * (int64_t)s));
+        // HashEmbedder mode: the exact coarse kernel reads the unrounded fp32 features; the (hi, lo) planes of the coarse columns are read only by a fine pass that
+        // runs the whole network there -- not when the coarse kernel hands (sigma, geo_feat) over
+        if (ngp && geo_reuse) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, n * (int64_t)s, reinterpret_cast<__half2 *>(rw.f32), n * (int64_t)s, 0, rw.keep, st, true, nullptr, 0));
+        else if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep, st, false, rw.f32, n * (int64_t)s));
         else NRF_TRY(launch_hash_lm(r->desc.hash, ps, n * (int64_t)s, rw.feats, rw.cols, rw.keep, HASH_LM_DEFAULT_VARIANT, st));
         if (sigma_only) NRF_TRY(mlp_small_sigma_f32_lm(r->desc.mlp, ngp ? static_cast<const void *>(rw.f32) : rw.feats, ngp ? 1 : 0, ngp ? n * (int64_t)s : rw.cols, rw.keep, n * (int64_t)s, raw_c, st,
                                                        geo_reuse ? geo_planes : nullptr, n * (int64_t)s));
