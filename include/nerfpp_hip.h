@@ -246,6 +246,11 @@ NRF_API int nrf_raw2outputs(const float *d_raw, const float *d_z, const float *d
 NRF_API int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
                             float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream);
 
+/* The same with sample (ray, j)'s raw row read at row d_src[ray * s + j] (int32) of d_raw: the feature-reusing LeRF pass keeps sigma_le in feature-COLUMN order
+ * (coarse columns, then the new samples') and composes through the merge map of nrf_fine_depths_merge instead of gathering first. */
+NRF_API int nrf_raw2weights_gather(const float *d_raw, int c, int sigma_ch, const int32_t *d_src, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                                   float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream);
+
 /* The LeRF head fused with its render pass on the matrix cores (fp16 operands, fp32 accumulate), for the reference's LeRF shape
  * (main.cpp:203-213: in 128, hidden 256, 2 + 2 layers, geo 32, embedding 768) -- the [N, S, 769] raw tensor is never formed.
  *   nrf_lerf_sigma            : sigma_le = LeRFImpl::forward(x)[..., -1] (LeRF.cpp:86-95), zeroed where keep is false (LeRFRenderer.cpp:22-23)

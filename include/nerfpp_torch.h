@@ -462,8 +462,11 @@ private:
 		void *x_new = static_cast<char *>(x.data_ptr()) + nc * 8 * 2;             // column n*s of level 0
 		check(nrf_hash_encode_lm_f16_strided(h, pts_new.data_ptr<float>(), nn, x_new, cols, keep.data_ptr<uint8_t>() + nc, current_stream()), "nrf_hash_encode_lm_f16_strided");
 		sigma_pass(x_new, keep.data_ptr<uint8_t>() + nc, nn, sig.data_ptr<float>() + nc, nc);
-		auto sig_f = sig.index_select(0, src.reshape({-1}).to(torch::kLong));      // sigma_le of the sorted depths
-		LeRFPassOutputs o = weights(sig_f.data_ptr<float>(), zf, sf);
+		// sigma_le stays in column order: the compositing kernel reads the sorted depths' values through the merge map
+		LeRFPassOutputs o;
+		o.WeightsLE = torch::empty({n, (int64_t)sf}, opt); o.DepthMapLE = torch::empty({n}, opt); o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt);
+		check(nrf_raw2weights_gather(sig.data_ptr<float>(), 1, 0, src.data_ptr<int32_t>(), zf.data_ptr<float>(), rays_d.data_ptr<float>(), 3, n, sf, o.WeightsLE.data_ptr<float>(),
+			o.DepthMapLE.data_ptr<float>(), o.DispMapLE.data_ptr<float>(), o.AccMapLE.data_ptr<float>(), current_stream()), "nrf_raw2weights_gather");
 		const int E = GetLangEmbedDim();
 		auto acc = torch::empty({n, (int64_t)E}, opt);
 		if (hand_over) check(nrf_lerf_render_embedding_lm_geo(Mlp.m, x.data_ptr(), cols, src.data_ptr<int32_t>(), geo.data_ptr(), cols, o.WeightsLE.data_ptr<float>(), n, sf, acc.data_ptr<float>(),

@@ -68,7 +68,7 @@ SYMBOLS = [
     "nrf_mlp_output_dims", "nrf_mlp_forward",
     "nrf_mlp_lerf_param_count", "nrf_mlp_lerf_create",
     "nrf_lerf_mfma_available", "nrf_lerf_set_precision", "nrf_lerf_sigma", "nrf_lerf_render_embedding",
-    "nrf_raw2outputs", "nrf_raw2weights", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths", "nrf_fine_depths_merge",
+    "nrf_raw2outputs", "nrf_raw2weights", "nrf_raw2weights_gather", "nrf_render_clip_embedding", "nrf_sample_pdf", "nrf_fine_depths", "nrf_fine_depths_merge",
     "nrf_rng_fill", "nrf_jitter_z", "nrf_tangent_scatter", "nrf_precondition", "nrf_raw2outputs_noise", "nrf_sample_pdf_rand", "nrf_fine_depths_rand",
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays", "nrf_batchify_rays_workspace_bytes", "nrf_batchify_rays", "nrf_render_rows_workspace_bytes", "nrf_render_rows",

@@ -388,6 +388,13 @@ int nrf_raw2weights(const float *d_raw, int c, int sigma_ch, const float *d_z, c
     return launch_raw2outputs(d_raw, d_z, d_dirs, d_stride, n, s, c, sigma_ch, 0, nullptr, d_disp, d_acc, d_weights, d_depth, SigmaNoise{}, as_stream(stream));
 }
 
+int nrf_raw2weights_gather(const float *d_raw, int c, int sigma_ch, const int32_t *d_src, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                           float *d_weights, float *d_depth, float *d_disp, float *d_acc, void *stream)
+{
+    NRF_CHECK_ARG(d_raw && d_src && d_z && d_dirs && n >= 0 && s >= 1 && c >= 1 && sigma_ch >= 0 && sigma_ch < c && d_stride >= 3, "nrf_raw2weights_gather: bad argument");
+    return launch_raw2outputs(d_raw, d_z, d_dirs, d_stride, n, s, c, sigma_ch, 0, nullptr, d_disp, d_acc, d_weights, d_depth, SigmaNoise{}, as_stream(stream), false, d_src, nullptr, 0);
+}
+
 int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed_dim, const float *d_weights, int64_t n, int s, float *d_out, void *stream)
 {
     NRF_CHECK_ARG(d_embeds && d_weights && d_out && n >= 0 && s >= 1 && embed_dim >= 1 && embed_stride >= embed_dim, "nrf_render_clip_embedding: bad argument");

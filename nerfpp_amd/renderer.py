@@ -522,6 +522,7 @@ class LeRFRenderer:
         # split precision: the COARSE pass's sigma_le in exact fp32 on the matrix cores (sigma_lerf_f32.hip) -- its weights choose the fine samples through a
         # discontinuous function, so the fine sample set of the timed mode is then the fp32 stage path's own, bit for bit (False: split arithmetic, for A/B tests)
         self.exact_coarse = True
+        self.compose_through_map = True     # reuse path: sigma_le of the sorted depths read through the merge map by the compositing kernel (False: gathered by torch first, A/B)
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
         self.lanes = 1 if os.environ.get("NRF_RENDER_LANES", "2") == "1" else 2      # streams of Render's Chunk loop (see Render)
@@ -588,7 +589,7 @@ class LeRFRenderer:
         else:
             sigma_pass(_ptr(x), keep, n * s, sig, 0)
         out1 = self._weights_from_sigma(sig[:n * s].view(n, s), z, rays_d)
-        u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
+        u = NeRFRenderer._linspace(ni, dev)                                   # cached: a fresh host tensor's .to(device) is a synchronous copy per chunk
         zf = torch.empty((n, sf), device=dev); src = torch.empty((n, sf), device=dev, dtype=torch.int32); z_new = torch.empty((n, ni), device=dev)
         L.check(lib.nrf_fine_depths_merge(_ptr(z), _ptr(out1.WeightsLE), C.c_int64(n), s, _ptr(u), ni, ATEN_SUM_VEC, _ptr(zf), _ptr(src), _ptr(z_new), _stream()))
         pts_new = torch.empty((n, ni, 3), device=dev)
@@ -596,8 +597,10 @@ class LeRFRenderer:
         x_new = C.c_void_p(x.data_ptr() + n * s * 8 * 2)                      # column n*s of level 0
         L.check(lib.nrf_hash_encode_lm_f16_strided(h, _ptr(pts_new), C.c_int64(n * ni), x_new, C.c_int64(cols), _ptr(keep[n * s:]), _stream()))
         sigma_pass(x_new, keep[n * s:], n * ni, sig[n * s:], n * s)
-        sig_f = sig[src.reshape(-1).long()].view(n, sf)
-        o = self._weights_from_sigma(sig_f, zf, rays_d)
+        if self.compose_through_map:
+            o = self._weights_from_sigma(sig, zf, rays_d, src)                 # sigma_le stays in column order; the compositing kernel reads through the merge map
+        else:
+            o = self._weights_from_sigma(sig[src.reshape(-1).long()].view(n, sf), zf, rays_d)
         E = self.Lerf.GetLangEmbedDim()
         acc = torch.empty((n, E), device=dev, dtype=torch.float32)
         if geo is None:
@@ -608,12 +611,17 @@ class LeRFRenderer:
         o.RenderedLangEmbedding = _clip_embedding(acc, E, E, ones)
         return out1, o, zf
 
-    def _weights_from_sigma(self, sig, z, rays_d):
-        n, s = sig.shape
+    def _weights_from_sigma(self, sig, z, rays_d, src=None):
+        """sigma_le -> weights / depth / disp / acc (nrf_raw2weights); src: sample (ray, j)'s sigma_le is sig[src[ray, j]] (the merge map), else sig[ray, j]."""
+        n, s = z.shape
         o = LeRFRendererOutputs(WeightsLE=torch.empty((n, s), device=sig.device), DepthMapLE=torch.empty((n,), device=sig.device),
                                 DispMapLE=torch.empty((n,), device=sig.device), AccMapLE=torch.empty((n,), device=sig.device))
-        L.check(L.lib().nrf_raw2weights(_ptr(sig), 1, 0, _ptr(z), _ptr(rays_d), 3, C.c_int64(n), s, _ptr(o.WeightsLE), _ptr(o.DepthMapLE), _ptr(o.DispMapLE),
-                                        _ptr(o.AccMapLE), _stream()))
+        if src is None:
+            L.check(L.lib().nrf_raw2weights(_ptr(sig), 1, 0, _ptr(z), _ptr(rays_d), 3, C.c_int64(n), s, _ptr(o.WeightsLE), _ptr(o.DepthMapLE), _ptr(o.DispMapLE),
+                                            _ptr(o.AccMapLE), _stream()))
+        else:
+            L.check(L.lib().nrf_raw2weights_gather(_ptr(sig), 1, 0, _ptr(src), _ptr(z), _ptr(rays_d), 3, C.c_int64(n), s, _ptr(o.WeightsLE), _ptr(o.DepthMapLE),
+                                                   _ptr(o.DispMapLE), _ptr(o.AccMapLE), _stream()))
         return o
 
     def _render_fused(self, pts, z, rays_d, want_embedding, exact=False):
@@ -666,7 +674,7 @@ class LeRFRenderer:
         dev = rays.device
         s, ni = int(n_samples), int(n_importance)
         E = self.Lerf.GetLangEmbedDim()
-        t = torch.linspace(0.0, 1.0, s, dtype=torch.float32).to(dev)
+        t = NeRFRenderer._linspace(s, dev)
         z = torch.empty((n, s), device=dev); pts = torch.empty((n, s, 3), device=dev)
         L.check(L.lib().nrf_z_vals(_ptr(rays), stride, C.c_int64(n), _ptr(t), s, int(lin_disp), _ptr(z), _stream()))
         L.check(L.lib().nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
@@ -683,7 +691,7 @@ class LeRFRenderer:
             out1 = self._render_fused(pts, z, rays_d, want_embedding=(ni == 0), exact=(ni > 0 and self.level_major and self._exact_coarse_on()))
             res.Outputs = out1
             if ni > 0:
-                u = torch.linspace(0.0, 1.0, ni, dtype=torch.float32).to(dev)
+                u = NeRFRenderer._linspace(ni, dev)
                 zf = torch.empty((n, s + ni), device=dev)
                 L.check(L.lib().nrf_fine_depths(_ptr(z), _ptr(out1.WeightsLE), C.c_int64(n), s, _ptr(u), ni, ATEN_SUM_VEC, _ptr(zf), _stream()))
                 ptsf = torch.empty((n, s + ni, 3), device=dev)
