@@ -244,19 +244,52 @@ struct ConvHookS {
 #endif
 // a . (G a) with a = hi + lo.  NRF_LERF_DEFER_DOT: deferred like the conversions, tile T - 1's sixteen products one per k-step behind tile T's matrix instructions
 // (same order of additions as consuming each tile at once), the layer's last tile in the open.
+// acc + x * (hi + lo) with the (hi, lo) pair's halves entering as fp16 operands of two mixed-precision FMAs (v_fma_mix_f32 converts in the instruction): two vector
+// instructions per value where convert, convert, add, fma took four -- kernel B reconstructs its 128 activations per lane twice per tile (Gram dot product, ray sum)
+#ifndef NRF_LERF_MIX_FMA
+#define NRF_LERF_MIX_FMA 1
+#endif
+__device__ __forceinline__ float mix_dot(float x, const half8 (&pair)[2], int k, float acc)
+{
+#if NRF_LERF_MIX_FMA
+    acc = __builtin_fmaf(x, (float)pair[1][k], acc);          // the small term first
+    return __builtin_fmaf(x, (float)pair[0][k], acc);
+#else
+    return __builtin_fmaf(x, (float)pair[0][k] + (float)pair[1][k], acc);
+#endif
+}
+// the same where the compiler does not fold the conversions by itself (the ray sums: it converts both halves and issues two v_fmac).  Only for operands that vector
+// instructions produced: x, the pair and acc here are -- the asm hides its reads from the MFMA -> VALU hazard handling, so it must never read a matrix result.
+__device__ __forceinline__ float mix_dot_asm(float x, const half8 (&pair)[2], int k, float acc)
+{
+#if NRF_LERF_MIX_FMA
+    const uint32_t wh = __builtin_bit_cast(u32x4, pair[0])[k >> 1], wl = __builtin_bit_cast(u32x4, pair[1])[k >> 1];
+    if (k & 1) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(wl));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(wh));
+    } else {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(wl));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(wh));
+    }
+    return acc;
+#else
+    return mix_dot(x, pair, k, acc);
+#endif
+}
+
 struct DotHookS {
     const half8 (&a)[16][2];
     float ss = 0.0f;
     static constexpr int UNITS = NRF_LERF_DEFER_DOT ? 16 : 0;
     __device__ __forceinline__ void unit(int tile, const f32x16 &t, int i)
     {
-        ss = __builtin_fmaf(t[i], (float)a[2 * tile + (i >> 3)][0][i & 7] + (float)a[2 * tile + (i >> 3)][1][i & 7], ss);
+        ss = mix_dot(t[i], a[2 * tile + (i >> 3)], i & 7, ss);
         asm volatile("" : "+v"(ss));          // pin the partial sum (see mlp_lerf_mfma.hip)
     }
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
 #pragma unroll
-        for (int i = 0; i < 16; i++) ss = __builtin_fmaf(t[i], (float)a[2 * tile + (i >> 3)][0][i & 7] + (float)a[2 * tile + (i >> 3)][1][i & 7], ss);
+        for (int i = 0; i < 16; i++) ss = mix_dot(t[i], a[2 * tile + (i >> 3)], i & 7, ss);
         asm volatile("" : "+v"(ss));
     }
 };
@@ -394,7 +427,7 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
 #pragma unroll
             for (int t = 0; t < 8; t++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) vsum[t][i] = __builtin_fmaf(f, (float)ba[2 * t + (i >> 3)][0][i & 7] + (float)ba[2 * t + (i >> 3)][1][i & 7], vsum[t][i]);
+                for (int i = 0; i < 16; i++) vsum[t][i] = mix_dot_asm(f, ba[2 * t + (i >> 3)], i & 7, vsum[t][i]);
         }
       }
       if constexpr (RAYS) {
@@ -466,7 +499,7 @@ struct GeoPF {
         if constexpr (NRF_LERF_DEFER_SUM && CI < 8) {
             if (k < 8) {
 #pragma unroll
-                for (int i = 2 * k; i < 2 * k + 2; i++) vsum[CI][i] = __builtin_fmaf(f_prev, (float)ba[2 * CI + (i >> 3)][0][i & 7] + (float)ba[2 * CI + (i >> 3)][1][i & 7], vsum[CI][i]);
+                for (int i = 2 * k; i < 2 * k + 2; i++) vsum[CI][i] = mix_dot(f_prev, ba[2 * CI + (i >> 3)], i & 7, vsum[CI][i]);
             }
         }
     }
@@ -571,7 +604,7 @@ k_lerf_split_geo(int64_t npts, Args in, const half8 *__restrict__ packed)
 #pragma unroll
             for (int t = 0; t < 8; t++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) vsum[t][i] = __builtin_fmaf(f, (float)ba[2 * t + (i >> 3)][0][i & 7] + (float)ba[2 * t + (i >> 3)][1][i & 7], vsum[t][i]);
+                for (int i = 0; i < 16; i++) vsum[t][i] = mix_dot_asm(f, ba[2 * t + (i >> 3)], i & 7, vsum[t][i]);
         }
       }
       ReduceS red{rlive ? in.out + ray * (int64_t)HID : nullptr, r, h};
