@@ -72,9 +72,15 @@ k_lerf_sigma_f32(int64_t npts, const _Float16 *__restrict__ x_lm, int64_t pstrid
             if (p >= npts) p = npts - 1;             // clamp loads; the stores are guarded
 #pragma unroll
             for (int lv = 0; lv < 16; lv++) {
-                const half8 v = *reinterpret_cast<const half8 *>(x_lm + ((int64_t)lv * pstride + p) * 8);
+                // word j of the 16 bytes holds features 2 j (low half) and 2 j + 1 (high half): the lane half's one is shifted down and converted -- two instructions per
+                // value.  Written as `hh ? v[2 j + 1] : v[2 j]` the compiler builds a dynamic vector-element extract: seven v_cndmask per value, 870 per iteration.
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = *reinterpret_cast<const u32x4_t *>(x_lm + ((int64_t)lv * pstride + p) * 8);
 #pragma unroll
-                for (int j = 0; j < 4; j++) x[pt][4 * lv + j] = (float)(hh ? v[2 * j + 1] : v[2 * j]);      // exact
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t bits = v[j] >> (16 * hh);
+                    x[pt][4 * lv + j] = (float)__builtin_bit_cast(_Float16, (uint16_t)bits);                  // exact
+                }
             }
         }
         float a = 0.0f;
