@@ -554,7 +554,7 @@ static int render_lanes()
 #ifndef NRF_LANE_BALANCE
 #define NRF_LANE_BALANCE 1               // the tail of the batch is cut so that both lanes end together (0: full chunks to the end)
 #endif
-constexpr int64_t LANE_MIN_RAYS = 16384;           // below this a batch stays on the caller's stream
+constexpr int64_t LANE_MIN_RAYS = 32768;           // below this a batch stays on the caller's stream (a 16 384-ray training batch: 9.39 ms per step on one stream, 9.49 cut in two)
 
 // rays per chunk of the two-lane loop; 0: single-stream loop
 static int64_t lane_chunk(int64_t n, int chunk)
