@@ -32,12 +32,16 @@ __device__ __forceinline__ void stage_dma(half8 *__restrict__ dst, const half8 *
     constexpr int ci = CI % N::total_chunks();
     constexpr int nf = N::chunk_frags(ci);
     constexpr int base = N::chunk_off(ci);
-    const half8 *pk = packed + (size_t)wave * 64;
-    asm volatile("" : "+s"(pk));                          // opaque here: the addresses derived from it cannot be hoisted out of the persistent loop
 #pragma unroll
     for (int q = 0; q < (nf + NW - 1) / NW; q++) {
+        // SGPR base with the fragment's constant offset added on the scalar side, then made opaque (not hoistable out of the persistent loop), + lane * 16: the
+        // saddr form of the DMA; with the offset added behind the opaque point the compiler forms a 64-bit per-lane address (two v_lshl_add_u64 per DMA)
+        const half8 *pk = packed + (size_t)wave * 64;
+        asm volatile("" : "+s"(pk));                     // not hoistable out of the persistent loop ...
+        pk += (size_t)(base + q * NW) * 64;
+        asm volatile("" : "+s"(pk));                     // ... and the offset added here, on the scalar side
         if (q * NW + wave < nf)                          // wave-uniform
-            __builtin_amdgcn_global_load_lds(pk + (size_t)(base + q * NW) * 64 + lane, (__attribute__((address_space(3))) void *)(dst + (q * NW + wave) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + (q * NW + wave) * 64), 16, 0, 0);
     }
 }
 

@@ -48,9 +48,13 @@ __device__ __forceinline__ void stage_piece(half8 *__restrict__ dst, const half8
     static_assert(nf % SNW == 0, "fragments per chunk must divide by the wave count");
     if constexpr (Q * SNW < nf) {
         constexpr int base = NerfNetS::chunk_off(ci);
+        // the fragment's address = SGPR base (its constant offset added on the scalar side, then made opaque) + lane * 16: the saddr form of the DMA.  With the offset
+        // added after the opaque point the compiler forms a 64-bit per-lane address instead -- two v_lshl_add_u64 per DMA, ~1 070 per iteration of the classic kernel
         const half8 *pk = packed + (size_t)wave * 64;
-        asm volatile("" : "+s"(pk));                          // opaque here: what is derived from it below cannot be hoisted out of the persistent loop
-        __builtin_amdgcn_global_load_lds(pk + (size_t)(base + Q * SNW) * 64 + lane, (__attribute__((address_space(3))) void *)(dst + (Q * SNW + wave) * 64), 16, 0, 0);
+        asm volatile("" : "+s"(pk));                          // opaque: the addresses derived from it cannot be hoisted out of the persistent loop (533 SGPR pairs would spill)
+        pk += (size_t)(base + Q * SNW) * 64;
+        asm volatile("" : "+s"(pk));                          // the offset is added HERE, on the scalar side (s_add_u32 / s_addc_u32)
+        __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + (Q * SNW + wave) * 64), 16, 0, 0);
     }
 }
 

@@ -75,9 +75,12 @@ struct Ctx {
 // the DMA of one chunk (ng groups starting at image group g0) into LDS buffer `dst`: wave w moves groups w, w + 4, ...; 1 KB per instruction
 __device__ __forceinline__ void stage_chunk(const Ctx &cx, f32x4 *dst, int g0, int ng)
 {
-    const f32x4 *src = cx.image + (size_t)g0 * 64 + cx.lane;
-    for (int q = cx.wave; q < ng; q += NW)
-        __builtin_amdgcn_global_load_lds(src + (size_t)q * 64, (__attribute__((address_space(3))) void *)(dst + q * 64), 16, 0, 0);
+    // address = SGPR base (the group's offset added on the scalar side, then opaque) + lane * 16: the saddr form of the DMA, no per-lane 64-bit add
+    for (int q = cx.wave; q < ng; q += NW) {
+        const f32x4 *sb = cx.image + (size_t)(g0 + q) * 64;
+        asm volatile("" : "+s"(sb));
+        __builtin_amdgcn_global_load_lds(sb + cx.lane, (__attribute__((address_space(3))) void *)(dst + q * 64), 16, 0, 0);
+    }
 }
 
 // One neuron tile: G groups of four k-steps, A fragments from LDS (read through asm so that the compiler does not order them against the look-ahead DMA into the
@@ -100,7 +103,7 @@ __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, 
 #ifndef NRF_NSIG_DMA_SPREAD
 #define NRF_NSIG_DMA_SPREAD 1
 #endif
-    const f32x4 *dsrc = cx.image + (size_t)cx.next_group * 64 + cx.lane;
+    const f32x4 *dsrc_s = cx.image + (size_t)cx.next_group * 64;             // uniform: the per-lane part (lane * 16) is the DMA's vector offset
     const int npieces = (next_ng - cx.wave + NW - 1) / NW;
     if (!NRF_NSIG_DMA_SPREAD) stage_chunk(cx, nxt, cx.next_group, next_ng);
     cx.next_group += next_ng;
@@ -125,14 +128,18 @@ __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, 
         for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], bfn(4 * g + j), acc, 0, 0, 0);
         if (NRF_NSIG_DMA_SPREAD && g < 10 && g < npieces) {
             const int q = cx.wave + NW * g;
-            __builtin_amdgcn_global_load_lds(dsrc + (size_t)q * 64, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
+            const f32x4 *sb = dsrc_s + (size_t)q * 64;
+            asm volatile("" : "+s"(sb));
+            __builtin_amdgcn_global_load_lds(sb + cx.lane, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (NRF_NSIG_DMA_SPREAD) {
         for (int g = G < 10 ? G : 10; g < npieces; g++) {          // layer 0's 8-group tiles ahead of a 10-piece chunk
             const int q = cx.wave + NW * g;
-            __builtin_amdgcn_global_load_lds(dsrc + (size_t)q * 64, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
+            const f32x4 *sb = dsrc_s + (size_t)q * 64;
+            asm volatile("" : "+s"(sb));
+            __builtin_amdgcn_global_load_lds(sb + cx.lane, (__attribute__((address_space(3))) void *)(nxt + q * 64), 16, 0, 0);
         }
     }
 #undef NRF_RD
