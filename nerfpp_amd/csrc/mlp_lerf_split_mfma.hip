@@ -134,7 +134,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     half8 fa[3][2];
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
     auto read_pair = [&](int kk_, int slot) {
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr + (uint32_t)kk_ * 2048u));
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr), "i"(kk_ * 2048), "i"(kk_ * 2048 + 1024));     // offsets in the instruction, not a v_add_u32 per pair
     };
     read_pair(0, 0);
     if (KS > 1) read_pair(1, 1);
@@ -520,10 +520,10 @@ struct GeoPF {
         const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(oper + lane);
 #pragma unroll
         for (int f = 0; f < GEO_FRAGS; f++)
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(bb[f][0]), "=&v"(bb[f][1]) : "v"(a + (uint32_t)f * 2048u));
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(bb[f][0]), "=&v"(bb[f][1]) : "v"(a), "i"(f * 2048), "i"(f * 2048 + 1024));
 #pragma unroll
         for (int s = 0; s < 8; s += 2)
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(xin[s][0]), "=&v"(xin[s + 1][0]) : "v"(a + (uint32_t)(2 * GEO_FRAGS + s) * 1024u));
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(xin[s][0]), "=&v"(xin[s + 1][0]) : "v"(a), "i"((2 * GEO_FRAGS + s) * 1024), "i"((2 * GEO_FRAGS + s) * 1024 + 1024));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the asm reads are opaque to the compiler: tie the registers to the wait
 #pragma unroll

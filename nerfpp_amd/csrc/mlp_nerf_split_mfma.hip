@@ -151,7 +151,8 @@ __device__ __forceinline__ void nerf_chunk_body_s(const CtxS &cx, const half8 *_
     half8 fa[3][2];
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
     auto read_pair = [&](int kk, int slot) {
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr + (uint32_t)kk * 2048u));
+        // the k-step's byte offset rides in the instruction (16-bit field; a chunk is < 64 KB) instead of a v_add_u32 per pair of reads (~990 per iteration)
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr), "i"(kk * 2048), "i"(kk * 2048 + 1024));
     };
     read_pair(0, 0);
     if (KS > 1) read_pair(1, 1);

@@ -111,7 +111,7 @@ __device__ __forceinline__ f32x16 tile(Ctx &cx, int layer, int mt, int next_ng, 
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
     f32x4 fa[3];
     // fragments two groups ahead through three register slots, counted waits
-#define NRF_RD(g_, slot_) asm volatile("ds_read_b128 %0, %1" : "=&v"(fa[slot_]) : "v"(waddr + (uint32_t)(g_) * 1024u))
+#define NRF_RD(g_, slot_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fa[slot_]) : "v"(waddr), "i"((g_) * 1024))          /* offset in the instruction, not a v_add_u32 per read */
     NRF_RD(0, 0);
     if (G > 1) NRF_RD(1, 1);
     f32x16 acc = zero;
@@ -190,7 +190,7 @@ __device__ __forceinline__ f32x16 tile16(Ctx &cx, int next_ng, BFn bfn)
     if (cx.next_group >= TOTAL_GROUPS) cx.next_group = 0;
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
     half8 fa[2][2];
-#define NRF_RD2(k_, slot_) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[slot_][0]), "=&v"(fa[slot_][1]) : "v"(waddr + (uint32_t)(k_) * 2048u))
+#define NRF_RD2(k_, slot_) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot_][0]), "=&v"(fa[slot_][1]) : "v"(waddr), "i"((k_) * 2048), "i"((k_) * 2048 + 1024))
     NRF_RD2(0, 0);
     f32x16 acc = zero;
 #pragma unroll
@@ -230,7 +230,7 @@ __device__ __forceinline__ void views_chunk(Ctx &cx, int next_ng, bool first, BF
         half8 fa[4][2];
 #pragma unroll
         for (int t = 0; t < 4; t++)
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(fa[t][0]), "=&v"(fa[t][1]) : "v"(waddr + (uint32_t)((t * K + k) * 2) * 1024u));
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[t][0]), "=&v"(fa[t][1]) : "v"(waddr), "i"((t * K + k) * 2048), "i"((t * K + k) * 2048 + 1024));
         half8 bh, bl;
         bfn(k, bh, bl);                                     // the conversion runs while the reads are in flight
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]));
