@@ -24,6 +24,9 @@ constexpr int HASH_LM_DEFAULT_VARIANT = 0;
 // 8 levels its layer-0 MFMA fragment holds; no feature buffer) and REJECTED -- at the 2-3 waves per SIMD the MLP's registers allow, the
 // gathers lose the memory-level parallelism the stand-alone kernel gets from 8 waves per SIMD: 30.9 ms per frame against 11.5 + 5.5.
 // ---------------------------------------------------------------------------------------------------
+#ifndef NRF_HASH_DENSE_A32
+#define NRF_HASH_DENSE_A32 1
+#endif
 struct PointPrep {
     float q[3];     // (clamp(x) - min) / (max - min), level independent (CuHashEmbedder.cu:44-46 before * mul)
     bool keep;
@@ -111,8 +114,23 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
         const uint32_t x0 = pos[0], y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
         const uint32_t tx0 = (x0 >> 2) * nby, ty0 = y0 >> 2, ty1 = y1 >> 2;
         const uint32_t ix0 = (x0 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
-        const uint4 q0 = dp[(((tx0 + ty0) * dz + z) << 4) | ix0 | iy0];      // corners (x..x+1, y0, z..z+1)
-        const uint4 q1 = dp[(((tx0 + ty1) * dz + z) << 4) | ix0 | iy1];      // corners (x..x+1, y1, z..z+1)
+        const uint32_t i0 = (((tx0 + ty0) * dz + z) << 4) | ix0 | iy0;       // corners (x..x+1, y0, z..z+1)
+        const uint32_t i1 = (((tx0 + ty1) * dz + z) << 4) | ix0 | iy1;       // corners (x..x+1, y1, z..z+1)
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t q0, q1;
+#if NRF_HASH_DENSE_A32
+        if ((uint64_t)nby * nby * dz < ((uint64_t)1 << 24)) {
+            // the level's image is below 4 GB (every level of 16..512; wave-uniform): the two loads take a 32-bit byte offset off a buffer resource of the level --
+            // one shift each instead of a 64-bit per-lane address (v_lshl_add_u64)
+            const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(dp), 0, -1, 0x00020000);
+            q0 = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(lr, i0 << 4, 0, 0));
+            q1 = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(lr, i1 << 4, 0, 0));
+        } else
+#endif
+        {
+            q0 = reinterpret_cast<const u32x4_t *>(dp)[i0];
+            q1 = reinterpret_cast<const u32x4_t *>(dp)[i1];
+        }
         // blend order k = 4dx + 2dy + dz; a quad holds (dx,dz) = (0,0),(0,1),(1,0),(1,1)
         const uint32_t wv[8] = {q0.x, q0.y, q1.x, q1.y, q0.z, q0.w, q1.z, q1.w};
         // both features of a corner go through the same multiply and the same add: float2 vector arithmetic lets the compiler use the

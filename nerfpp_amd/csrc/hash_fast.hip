@@ -255,6 +255,10 @@ __device__ __forceinline__ void hash_lm_body(const HashParams &hp, const PointSo
     __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t();
     if constexpr (GATHER != 0)
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(hp.table), 0, (int)(((size_t)hp.n_levels << hp.log2_t) * 4), 0x00020000);
+    // the feature planes as one buffer resource when they end below 4 GB (a chunk's always do; wave-uniform): a store is a 32-bit lane offset + the level's scalar offset
+    const bool store32 = NRF_HASH_DENSE_A32 && (uint64_t)hp.n_levels * (uint64_t)pstride * 4u < ((uint64_t)1 << 32);
+    __amdgpu_buffer_rsrc_t frs = __amdgpu_buffer_rsrc_t();
+    if (store32) frs = __builtin_amdgcn_make_buffer_rsrc(feats, 0, -1, 0x00020000);
     __half2 out[LPT][PPT];
 #pragma unroll
     for (int j = 0; j < LPT; j++)
@@ -265,7 +269,11 @@ __device__ __forceinline__ void hash_lm_body(const HashParams &hp, const PointSo
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             if (idx[q] < p) {
-                feats[(int64_t)(level + j) * pstride + idx[q]] = out[j][q];
+#if NRF_HASH_DENSE_A32
+                if (store32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, out[j][q]), frs, (uint32_t)idx[q] << 2, (uint32_t)(level + j) * (uint32_t)pstride * 4u, 0);
+                else
+#endif
+                    feats[(int64_t)(level + j) * pstride + idx[q]] = out[j][q];
                 if (level + j == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
             }
         }
