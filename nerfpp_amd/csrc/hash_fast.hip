@@ -61,6 +61,26 @@ __global__ void k_bake_dense_ngp(HashParams hp, int l, uint32_t dim, int64_t ent
     dst[i * 2 + 1] = uint4{c.x, c.y, d.x, d.y};
 }
 
+// a / d, correctly rounded, for operands and quotients in the normal range (here: coordinates of a scene box over cell sizes of 1e-3 .. 1): the reciprocal
+// refinement and the two quotient corrections of the compiler's own fp32 division, WITHOUT its range scaling and special-case fix-up (v_div_scale x 2,
+// v_div_fmas, v_div_fixup) -- those are the identity on such operands.  8 instructions instead of 11; six divisions per point and level.
+#ifndef NRF_NGP_FAST_DIV
+#define NRF_NGP_FAST_DIV 1
+#endif
+__device__ __forceinline__ float ngp_div(float a, float d)
+{
+#if NRF_NGP_FAST_DIV
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+    return q;
+#else
+    return a / d;
+#endif
+}
+
 __device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const float (&x)[3], const float (&xc)[3], int l, float (&acc)[2])
 {
     float w[3];
@@ -68,11 +88,11 @@ __device__ __forceinline__ void encode_level_ngp(const HashParams &hp, const flo
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float grid = hp.bias[l * 3 + a];          // (max - min) / res, divided once on the host (wave-uniform: a scalar load instead of a vector division)
-        const float fl = floorf((xc[a] - hp.bbox.mn[a]) / grid);
+        const float fl = floorf(ngp_div(xc[a] - hp.bbox.mn[a], grid));
         idx[a] = (uint32_t)(int32_t)fl;
         const float vmin = fl * grid + hp.bbox.mn[a];
         const float vmax = vmin + grid;
-        w[a] = (x[a] - vmin) / (vmax - vmin);
+        w[a] = ngp_div(x[a] - vmin, vmax - vmin);
     }
     float2 e[8];
     if (hp.dense_off[l] >= 0) {                 // wave-uniform
