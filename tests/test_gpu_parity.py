@@ -582,6 +582,57 @@ def test_hash_fast_path_fallbacks_bit_exact(api, O):
     e.set_dense_budget(1 << 34)
 
 
+def test_hash_baked_lookup_on_faces_lattice_points_and_outside(api):
+    """The baked-level lookup takes its cell index by a truncating conversion, its fraction by v_fract_f32 and its loads / stores through buffer resources
+    (hash_fast.h): against the generic hashed kernel on the inputs where those forms could differ -- coordinates ON the box faces (q = 0 and q = mul exactly),
+    points on the lattice of the coarsest and of the finest level (fraction exactly 0), points outside the box (clamped, keep mask false) and 10^6 random ones."""
+    import ctypes as C
+    lib = api.L.lib()
+    sc = api.S.make_hash_scene(mode="cu"); e = sc["embedder"]
+    n = 1_000_000
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    base = torch.rand((n, 3), device="cuda", generator=g) * 3.0 - 1.5
+    sets = {"random": base}
+    b = base.clone(); ax = torch.randint(0, 3, (n,), device="cuda", generator=g); sgn = torch.randint(0, 2, (n,), device="cuda", generator=g).float() * 3.0 - 1.5
+    b[torch.arange(n, device="cuda"), ax] = sgn; sets["one coordinate on a box face"] = b
+    sets["outside the box"] = base * 1.3
+    sets["level-0 lattice"] = torch.round((base + 1.5) / 3.0 * 16.0) / 16.0 * 3.0 - 1.5
+    sets["level-15 lattice"] = torch.round((base + 1.5) / 3.0 * 512.0) / 512.0 * 3.0 - 1.5
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for name, pts in sets.items():
+        pts = pts.contiguous()
+        x = torch.empty((16, n, 2), device="cuda", dtype=torch.float16); k = torch.empty((n,), device="cuda", dtype=torch.uint8)
+        api.L.check(lib.nrf_hash_encode_lm_f16(e._h, P(pts), C.c_int64(n), P(x), P(k), None))
+        emb, keep = e.forward(pts)                                              # generic hashed kernel, fp32 rows (the values are fp16 numbers)
+        ref = emb.reshape(-1, 16, 2).permute(1, 0, 2).to(torch.float16)
+        assert int((ref != x).sum()) == 0, name
+        assert int((keep.to(torch.uint8) != k).sum()) == 0, name
+
+
+def test_raw2weights_gather_equals_gathered_rows(api):
+    """nrf_raw2weights_gather (the LeRF fine pass composes sigma_le through the merge map) == nrf_raw2weights of the gathered rows, bit for bit."""
+    import ctypes as C
+    lib = api.L.lib()
+    n, s = 300, 96
+    rs = np.random.RandomState(11)
+    sig = dev((rs.rand(n * s).astype(np.float32) * 8.0) * (rs.rand(n * s) > 0.3))
+    src = dev(np.stack([rs.permutation(s) + i * s for i in range(n)]).astype(np.int32))
+    z = dev(np.sort(rs.rand(n, s).astype(np.float32) * 4.0 + 2.0, axis=1)); d = dev(rs.randn(n, 3).astype(np.float32))
+    P = lambda t: C.c_void_p(t.data_ptr())
+    outs = []
+    for mode in (0, 1):
+        w = torch.empty((n, s), device="cuda"); dep = torch.empty((n,), device="cuda"); dsp = torch.empty((n,), device="cuda"); acc = torch.empty((n,), device="cuda")
+        if mode == 0:
+            api.L.check(lib.nrf_raw2weights_gather(P(sig), 1, 0, P(src), P(z), P(d), 3, C.c_int64(n), s, P(w), P(dep), P(dsp), P(acc), None))
+        else:
+            g = sig[src.reshape(-1).long()].contiguous()
+            api.L.check(lib.nrf_raw2weights(P(g), 1, 0, P(z), P(d), 3, C.c_int64(n), s, P(w), P(dep), P(dsp), P(acc), None))
+        torch.cuda.synchronize()
+        outs.append([host(w), host(dep), host(dsp), host(acc)])
+    for a_, b_, nm in zip(outs[0], outs[1], ("weights", "depth", "disp", "acc")):
+        assert_exact(a_, b_, "raw2weights through the map == gathered rows: " + nm)
+
+
 # ------------------------------------------------------------------ LeRF (BASELINE config 4)
 def test_lerf_render_pass_vs_oracle(api, O, manifest):
     """LeRFRenderer::RenderRays minus the external Relevancy: CuHashEmbedder(F=8) -> LeRF head -> sigma_le weights ->
