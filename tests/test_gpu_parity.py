@@ -609,6 +609,34 @@ def test_hash_baked_lookup_on_faces_lattice_points_and_outside(api):
         assert int((keep.to(torch.uint8) != k).sum()) == 0, name
 
 
+def test_hash_encode_beside_matrix_core_kernels_on_another_stream(api):
+    """The encode's blend is inline asm (v_fma_mix_f32) fed by compiler-generated vector instructions.  A build in which those were PACKED fp32 instructions was bit-identical
+    on every single-stream check and wrong while matrix-core kernels ran on another stream (packed fp32 shares the matrix data path, its result latency
+    depends on other waves, and the compiler's hazard padding does not see the asm consumer).  The two-lane Chunk loop makes that the normal situation: the encode entry,
+    repeated while the split-precision MLP runs on a second stream, must reproduce its solo features every time."""
+    import ctypes as C
+    lib = api.L.lib()
+    sc = api.S.make_hash_scene(mode="cu"); e = sc["embedder"]
+    n = 2_000_000
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    pts = (torch.rand((n, 3), device="cuda", generator=g) * 3.0 - 1.5).contiguous()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ref = torch.empty((16, n, 2), device="cuda", dtype=torch.float16); k = torch.empty((n,), device="cuda", dtype=torch.uint8)
+    api.L.check(lib.nrf_hash_encode_lm_f16(e._h, P(pts), C.c_int64(n), P(ref), P(k), None)); torch.cuda.synchronize()
+    xin = torch.randn((1_000_000, 48), device="cuda") * 0.1
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(sa):
+        for _ in range(24): sc["mlp"].forward(xin, api.L.NRF_PREC_F16_SPLIT)
+    with torch.cuda.stream(sb):
+        for _ in range(10):
+            x = torch.empty((16, n, 2), device="cuda", dtype=torch.float16)
+            api.L.check(lib.nrf_hash_encode_lm_f16(e._h, P(pts), C.c_int64(n), P(x), P(k), C.c_void_p(sb.cuda_stream)))
+            outs.append(x)
+    torch.cuda.synchronize()
+    assert [int((o != ref).sum()) for o in outs] == [0] * 10
+
+
 def test_raw2weights_gather_equals_gathered_rows(api):
     """nrf_raw2weights_gather (the LeRF fine pass composes sigma_le through the merge map) == nrf_raw2weights of the gathered rows, bit for bit."""
     import ctypes as C
