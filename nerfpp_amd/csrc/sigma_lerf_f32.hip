@@ -150,7 +150,12 @@ k_lerf_sigma_f32(int64_t npts, const _Float16 *__restrict__ x_lm, int64_t pstrid
 #pragma unroll
                 for (int s = 0; s < 2; s++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) split_pair(t[8 * s + 2 * j], t[8 * s + 2 * j + 1], fh[s].u[j], fl[s].u[j]);
+                    for (int j = 0; j < 4; j++) {
+                        // through a compiler-visible vector instruction (identity on finite values): the asm of split_pair must never read a matrix result directly --
+                        // the compiler's hazard padding does not look into it (the other sigma kernels do the same)
+                        const float lim = -3.402823466e38f;
+                        split_pair(fmaxf(t[8 * s + 2 * j], lim), fmaxf(t[8 * s + 2 * j + 1], lim), fh[s].u[j], fl[s].u[j]);
+                    }
                 split_pair(hh == 0 ? g31 : 0.0f, 0.0f, fh[2].u[0], fl[2].u[0]);
 #pragma unroll
                 for (int j = 1; j < 4; j++) { fh[2].u[j] = 0; fl[2].u[j] = 0; }
