@@ -1850,6 +1850,16 @@ def test_chunk_loop_lanes_reproduce_the_single_stream_loop(api):
                 outs.append([host(res.Outputs.RGBMap), host(res.Outputs.DepthMap), host(res.Outputs.AccMap), host(res.Outputs.DispMap)])
             for x, y, nm in zip(outs[0], outs[1], ("rgb", "depth", "acc", "disp")):
                 assert_exact(y, x, "two lanes == one stream: %s, rows %d chunk %d" % (nm, rows, chunk))
+        # the classic model's kernels (weight-streaming split kernel, exact sigma kernel) beside each other on the two lanes
+        cl = api.S.make_classic_scene()
+        rpc = api.S.lego_render_params(cl["bbox"], chunk=16384, precision=api.L.NRF_PREC_F16_SPLIT)
+        co = []
+        for lanes in (1, 2, 2):
+            api.L.check(lib.nrf_set_render_lanes(lanes))
+            res = cl["renderer"].Render(800, 800, K, rpc, c2w=c2w, row0=380, rows=82)
+            co.append([host(res.Outputs.RGBMap), host(res.Outputs.DepthMap)])
+        for other in co[1:]:
+            assert_exact(other[0], co[0][0], "classic: two lanes == one stream, rgb"); assert_exact(other[1], co[0][1], "classic: two lanes == one stream, depth")
         # the caller's stream order holds across the fork / join: a side stream renders, then reduces the pixels on the same stream, no host sync in between
         rp = api.S.lego_render_params(sc["bbox"], chunk=40000, precision=api.L.NRF_PREC_F16_SPLIT)
         api.L.check(lib.nrf_set_render_lanes(2))
@@ -1883,6 +1893,14 @@ def test_lerf_render_pass_at_main_cpp_table_size(api, O):
     hit = accm > 1e-2
     assert hit.sum() > 500
     assert_close(np.linalg.norm(emb[hit], axis=1), np.ones(hit.sum()), rtol=1e-5, atol=0)
+    # the Chunk loop's two torch lanes (LeRFRenderer.Render) against the single-stream loop: same kernels on the same slices, a deterministic embedding
+    lanes_before = r.lanes
+    try:
+        r.lanes = 1 if lanes_before == 2 else 2
+        other = r.Render(800, 800, K, p, c2w=c2w, row0=398, rows=4)
+        assert torch.equal(other.Outputs.RenderedLangEmbedding, res.Outputs.RenderedLangEmbedding), "LeRF: two lanes == one stream, bit for bit"
+    finally:
+        r.lanes = lanes_before
     p2 = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=800, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
     res2 = r.Render(800, 800, K, p2, c2w=c2w, row0=398, rows=4)
     cosc = (host(res2.Outputs.RenderedLangEmbedding)[hit] * emb[hit]).sum(1)
