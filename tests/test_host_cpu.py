@@ -282,3 +282,16 @@ def test_bench_launcher_reports_failing_ranks_without_hanging():
     # contradictory flags are rejected by the parent before anything is started
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--collective", "cabi"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "cabi" in r.stderr
+
+
+def test_inline_asm_never_reads_a_matrix_packed_or_transcendental_result():
+    """tools/asm_input_lint.py over every kernel source: the compiler pads the hazards of its own instructions and does not look into inline asm, so an asm
+    instruction that reads what a matrix, packed-fp32 or transcendental instruction wrote is right alone and wrong beside other waves (round 3, DESIGN section 9:
+    the baked hash lookup with packed weight multiplies).  Compiles for gfx950 (no GPU needed), about a minute on 8 cores."""
+    import shutil, subprocess, sys
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_input_lint.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "hash_fast" in r.stdout and "mlp_small_mfma" in r.stdout
