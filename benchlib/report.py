@@ -1,0 +1,147 @@
+"""The ONE JSON line bench.py prints, and the side file that carries everything else.
+
+The driver keeps a bounded tail of stdout and parses the last line: round 3's 29-KB line did not survive it (BENCH_r03.json.parsed = null).  So the line
+is a fixed, flat set of keys, asserted < LINE_LIMIT bytes (tests/test_host_cpu.py builds it from canned measurements); the full record -- per-kernel
+event times of both passes, every sibling roofline, the secondary workloads with their own rooflines and oracle checks -- goes to bench_detail.json
+next to bench.py and to stderr."""
+import json
+import os
+import sys
+
+LINE_LIMIT = 4096
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+
+
+def _r(x, nd=4):
+    """Numbers as the line carries them: 4 significant decimals for fractions and milliseconds, integers where the value is one."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    if abs(x) >= 1e6 or x == int(x):
+        return int(round(x))
+    return round(x, nd)
+
+
+def _psnr(q):
+    return _r(q.get("psnr"), 2) if isinstance(q, dict) else None
+
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "units_per_launch", "flop_per_unit", "bytes_per_unit",
+             "mfma_issued_frac", "mfma_busy_frac_of_active_cycles")
+
+
+def compact_roofline(detail_roof, stats_csv=None):
+    """Top-level `roofline` of the line: the kernel that took the most time in the SINGLE-LANE pass (`isolated`: one kernel at a time on the GPU, so
+    units_per_launch x flop_per_unit / avg_launch_ms re-derives from the rocprofv3 kernel summary of the same pass), the hash encode as a sibling figure.
+    Without an isolated pass (N > 1 rehearsals, --no-isolated) the timed region's own events are used and `lanes` says so."""
+    src = detail_roof.get("isolated") or detail_roof.get("timed") or {}
+    lanes = 1 if detail_roof.get("isolated") else detail_roof.get("lanes_timed", 2)
+    names = list(src.keys())
+    if not names:
+        return None
+    dom = src[names[0]]
+    out = {k: _r(dom[k]) for k in ROOF_KEYS if dom.get(k) is not None}
+    out.setdefault("traffic", None)
+    if dom.get("traffic_source"):
+        out["traffic_source"] = dom["traffic_source"][:80]
+    out["lanes"] = lanes
+    if stats_csv:
+        out["kernel_stats"] = stats_csv
+    for sib in names[1:]:
+        s = src[sib]
+        out[sib] = {k: _r(s[k]) for k in ("kernel", "frac", "achieved", "unit", "avg_launch_ms", "launches", "units_per_launch", "hbm_frac", "traffic") if s.get(k) is not None}
+        if isinstance(out[sib].get("kernel"), str):
+            out[sib]["kernel"] = out[sib]["kernel"].split(" (")[0]
+    if isinstance(dom.get("colour_only"), dict):
+        c = dom["colour_only"]
+        out["colour_only"] = {k: _r(c[k]) for k in ("frac", "avg_launch_ms", "launches", "units_per_launch", "flop_per_unit") if c.get(k) is not None}
+    t = detail_roof.get("timed") or {}
+    if detail_roof.get("isolated") and t:
+        # the same kernels' launch times inside the two-lane timed region (they share the CUs there): context, not a roofline
+        out["timed_two_lane_avg_launch_ms"] = {n: _r(r.get("avg_launch_ms")) for n, r in t.items()}
+    return out
+
+
+def compact_also(rec):
+    """<= ~120 characters per entry: workload precision value ms psnr frac."""
+    if "error" in rec:
+        return {"workload": str(rec.get("workload"))[:28], "error": str(rec["error"])[:60]}
+    wl = str(rec.get("workload", "")).replace("_lego800_64+128", "")
+    if rec.get("encoder", "").startswith("HashEmbedder"):
+        wl += "_libtorch_twin"
+    if rec.get("scaling"):
+        wl = "scaling_" + rec["scaling"]
+    ms = rec.get("ms_per_step")
+    if ms is None and rec.get("s_per_frame") is not None:
+        ms = rec["s_per_frame"] * 1e3
+    q = rec.get("psnr_vs_oracle_db")
+    oc = rec.get("oracle_check")
+    out = {"workload": wl, "precision": rec.get("precision") or ("f16x3" if "train" in wl else None), "value": _r(rec.get("value")), "ms": _r(ms, 3)}
+    if rec.get("coarse_pass", "").startswith("whole network"):
+        out["workload"] += "_coarse_full"
+    if isinstance(q, dict):
+        out["psnr"] = _psnr(q)
+    elif isinstance(oc, dict):
+        out["cos_min"] = _r(oc.get("embedding_cos_min"), 7)
+        out["same_samples"] = _r(oc.get("fine_sample_set_bit_identical_rays"))
+    if isinstance(rec.get("roofline"), dict) and rec["roofline"].get("frac") is not None:
+        out["frac"] = _r(rec["roofline"]["frac"])
+    if rec.get("frames_per_step"):
+        out["frames_per_step"] = rec["frames_per_step"]
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def compact_line(detail, stats_csv=None):
+    """detail (the full record bench.py assembles) -> the dict that is printed as the one JSON line."""
+    cfg = detail["config"]
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _r(line["value"])
+    line["ms_per_step"] = _r(line["ms_per_step"])
+    line["config"] = {k: cfg[k] for k in ("workload", "baseline_config", "encoder", "frames_per_step", "rays_per_gpu_per_step", "chunk", "parallelism", "oracle_pin") if k in cfg}
+    line["roofline"] = compact_roofline(detail.get("roofline") or {}, stats_csv)
+    cb = detail.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": str(cb.get("sample", ""))[:160]}
+    line["psnr_vs_oracle_db"] = _psnr(detail.get("psnr_vs_oracle_db"))
+    pf = detail.get("parity_full_frame_vs_f32")
+    if isinstance(pf, dict):
+        line["full_frame_max_abs_err_vs_f32"] = pf.get("max_abs_err")
+    line["frame_sha256"] = detail.get("frame_sha256")
+    line["rays_per_s"] = _r(detail.get("rays_per_s"))
+    line["tile_rows"] = detail.get("tile_rows")
+    line["host_ms_per_tile"] = _r(detail.get("host_ms_per_tile"))
+    if detail.get("ranks_seen_by_rccl") is not None:
+        line["ranks_seen_by_rccl"] = detail["ranks_seen_by_rccl"]
+    if detail.get("collective_check"):
+        line["collective_check"] = str(detail["collective_check"])[:100]
+    if detail.get("also"):
+        line["also"] = [compact_also(r) for r in detail["also"]]
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def dumps_line(line):
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT:
+        # never lose the headline to its decorations: drop the optional parts, largest first
+        for k in ("also", "collective_check"):
+            if k in line and len(s) >= LINE_LIMIT:
+                line = {kk: vv for kk, vv in line.items() if kk != k}
+                line["dropped_for_size"] = line.get("dropped_for_size", []) + [k]
+                s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, len(s)
+    return s
+
+
+def emit(detail, stats_csv=None, path=DETAIL_PATH):
+    """Write the full record to the side file and to stderr, print the compact line (stdout, last line)."""
+    try:
+        with open(path, "w") as fh:
+            json.dump(detail, fh, indent=1)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+    print("[bench detail] " + json.dumps(detail), file=sys.stderr, flush=True)
+    print(dumps_line(compact_line(detail, stats_csv)), flush=True)

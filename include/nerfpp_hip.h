@@ -428,7 +428,9 @@ NRF_API int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_
 
 /* BatchifyRays (NeRFRenderer.h:465-525): the host loop over Chunk-sized slices of a packed ray batch, inside the library -- every output of `out`
  * is the whole batch's buffer ([n, ...]), slice i of the loop writes its rows in place (what the reference's torch::cat assembles afterwards), and
- * p->ray_base advances with the slice so the counter-based draws of the stochastic branches do not depend on Chunk.  Workspace: that of ONE chunk. */
+ * p->ray_base advances with the slice so the counter-based draws of the stochastic branches do not depend on Chunk.  Workspace: one chunk's per lane
+ * (nrf_set_render_lanes).  A renderer is bound to ONE device and ONE caller at a time: its lane streams and fork / join events are created on first use, follow the
+ * renderer to another device when a later call comes from there, and are shared by every call -- concurrent calls on one renderer from several host threads are not supported. */
 NRF_API size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p);
 NRF_API int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p,
                               const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
@@ -553,9 +555,10 @@ typedef struct nrf_comm nrf_comm;
  * (it is not destroyed by nrf_comm_destroy). */
 NRF_API int nrf_comm_unique_id(void *id_out);
 NRF_API int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out);
-/* ... with a bounded rendezvous: the communicator is initialised non-blocking and polled; after timeout_s seconds without all `world` ranks it is aborted and
- * NRF_ERR_HIP returned (a peer that never started, or an id of another launch).  timeout_s <= 0 waits for ever.  nrf_comm_create itself uses
- * NRF_COMM_TIMEOUT_S from the environment (default 300). */
+/* ... with a bounded rendezvous: the (ordinary, blocking) ncclCommInitRank runs on a helper thread bound to the caller's device and is waited for; after timeout_s
+ * seconds without all `world` ranks NRF_ERR_HIP is returned (a peer that never started, or an id of another launch) and the caller should exit.  timeout_s <= 0 waits for
+ * ever on the calling thread.  nrf_comm_create itself uses NRF_COMM_TIMEOUT_S from the environment (default 300; only a well-formed number is taken, 0 = wait for ever).
+ * A non-blocking communicator handed over with nrf_comm_wrap is supported too: nrf_allgather_tiles waits (bounded) until its group has been enqueued before it returns. */
 NRF_API int nrf_comm_create_timeout(const void *id, int world, int rank, double timeout_s, nrf_comm **out);
 NRF_API int nrf_comm_wrap(void *nccl_comm, nrf_comm **out);
 NRF_API void nrf_comm_destroy(nrf_comm *c);
@@ -574,8 +577,9 @@ NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int fra
 /* NRF_PROF_MLP_COLOUR: the NeRFSmall kernel's colour-net-only launch of a hierarchical render's fine pass (its S coarse depths; see nrf_render_params.coarse_mode) --
  * a different amount of work per point than NRF_PROF_MLP's whole-network launches, so it has its own slot. */
 enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAMPLE = 3, NRF_PROF_OTHER = 4, NRF_PROF_SIGMA = 5, NRF_PROF_MLP_COLOUR = 6, NRF_PROF_COUNT = 7 };
-/* The Chunk loop of nrf_batchify_rays / nrf_render_rows runs consecutive chunks on two internal streams (forked from and joined to the caller's stream) so that one
- * chunk's gather-bound kernels overlap another's matrix-bound ones; results do not depend on it.  lanes = 1 restores the single-stream loop (also: NRF_RENDER_LANES=1). */
+/* The Chunk loop of nrf_batchify_rays / nrf_render_rows runs consecutive chunks on `lanes` internal streams (default 2, at most 4; forked from and joined to the
+ * caller's stream) so that one chunk's gather-bound kernels overlap another's matrix-bound ones; results do not depend on it.  lanes = 1 restores the single-stream
+ * loop (also: NRF_RENDER_LANES=1..4).  Process-wide setting, read at every call; the workspace query and the call must see the same value. */
 NRF_API int nrf_set_render_lanes(int lanes);
 NRF_API int nrf_profile_enable(int on);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);

@@ -16,6 +16,8 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -39,10 +41,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    // optional (bounded rendezvous): a non-blocking communicator init that can be polled and aborted
-    decltype(&ncclCommInitRankConfig) CommInitRankConfig = nullptr;
+    // optional: the state of a non-blocking communicator a host may hand over (nrf_comm_wrap)
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
-    decltype(&ncclCommAbort) CommAbort = nullptr;
 };
 
 static Rccl g_rccl;
@@ -66,9 +66,7 @@ static void rccl_load()
     NRF_SYM(Broadcast, "ncclBroadcast"); NRF_SYM(GroupStart, "ncclGroupStart"); NRF_SYM(GroupEnd, "ncclGroupEnd");
     NRF_SYM(GetErrorString, "ncclGetErrorString");
 #undef NRF_SYM
-    r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(dlsym(h, "ncclCommInitRankConfig"));
     r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
-    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
     if (ok) g_rccl = r;
 }
 
@@ -130,28 +128,35 @@ int nrf_comm_create_timeout(const void *id, int world, int rank, double timeout_
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclComm_t c = nullptr;
-    if (timeout_s > 0.0 && R->CommInitRankConfig && R->CommGetAsyncError && R->CommAbort) {
-        // bounded rendezvous: non-blocking init, polled until every rank has arrived or the deadline passes (a peer that never starts -- or one that was
-        // handed a stale id -- would otherwise park this rank in ncclCommInitRank for ever); on timeout the half-built communicator is aborted
-        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-        cfg.blocking = 0;
-        ncclResult_t e = R->CommInitRankConfig(&c, world, uid, rank, &cfg);
-        if (e != ncclSuccess && e != ncclInProgress) { set_error("ncclCommInitRankConfig failed: %s", R->GetErrorString(e)); return NRF_ERR_HIP; }
-        const auto t0 = std::chrono::steady_clock::now();
-        ncclResult_t st = ncclInProgress;
-        for (;;) {
-            e = R->CommGetAsyncError(c, &st);
-            if (e != ncclSuccess) { set_error("ncclCommGetAsyncError failed: %s", R->GetErrorString(e)); (void)R->CommAbort(c); return NRF_ERR_HIP; }
-            if (st != ncclInProgress) break;
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-                (void)R->CommAbort(c);
-                set_error("nrf_comm_create: rank %d of %d waited %.0f s for its peers (a rank that never started, or a communicator id of another launch); aborted",
-                          rank, world, timeout_s);
-                return NRF_ERR_HIP;
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    if (timeout_s > 0.0) {
+        // Bounded rendezvous with a BLOCKING communicator: the plain ncclCommInitRank runs on a helper thread (bound to the caller's device) and this thread waits for it
+        // with a deadline -- a peer that never starts, or one that was handed a stale id, would otherwise park this rank in the rendezvous for ever.  The communicator
+        // itself stays an ordinary blocking one, so ncclGroupEnd / ncclCommDestroy return only once the work is enqueued (a non-blocking communicator answers
+        // ncclInProgress there at world > 1 and enqueues on a helper thread: events recorded after the call would then run ahead of the collective).
+        // On timeout the helper is left behind in its rendezvous (it owns its state; there is no handle to abort yet) and the caller is expected to exit non-zero.
+        struct InitJob {
+            std::mutex m; std::condition_variable cv;
+            bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr;
+            ncclUniqueId uid; int world = 1, rank = 0, dev = 0;
+        };
+        auto job = std::make_shared<InitJob>();
+        job->uid = uid; job->world = world; job->rank = rank;
+        if (hipGetDevice(&job->dev) != hipSuccess) { set_error("nrf_comm_create: no current HIP device"); return NRF_ERR_HIP; }
+        const auto init = R->CommInitRank;
+        std::thread([job, init]() {
+            ncclComm_t cc = nullptr;
+            ncclResult_t e = hipSetDevice(job->dev) == hipSuccess ? init(&cc, job->world, job->uid, job->rank) : ncclUnhandledCudaError;
+            { std::lock_guard<std::mutex> g(job->m); job->res = e; job->comm = cc; job->done = true; }
+            job->cv.notify_all();
+        }).detach();
+        std::unique_lock<std::mutex> lk(job->m);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; })) {
+            set_error("nrf_comm_create: rank %d of %d waited %.0f s for its peers (a rank that never started, or a communicator id of another launch); giving up",
+                      rank, world, timeout_s);
+            return NRF_ERR_HIP;
         }
-        if (st != ncclSuccess) { set_error("communicator init failed: %s", R->GetErrorString(st)); (void)R->CommAbort(c); return NRF_ERR_HIP; }
+        if (job->res != ncclSuccess) { set_error("ncclCommInitRank failed: %s", R->GetErrorString(job->res)); return NRF_ERR_HIP; }
+        c = job->comm;
     } else {
         NRF_NCCL(R, R->CommInitRank(&c, world, uid, rank));     // on the calling thread's current HIP device; blocks until all ranks arrive
     }
@@ -163,9 +168,15 @@ int nrf_comm_create_timeout(const void *id, int world, int rank, double timeout_
 
 int nrf_comm_create(const void *id, int world, int rank, nrf_comm **out)
 {
-    // default bound: NRF_COMM_TIMEOUT_S seconds (300; 0 = wait for ever, the plain blocking ncclCommInitRank)
+    // default bound: NRF_COMM_TIMEOUT_S seconds (300).  Only a well-formed number is taken; only an explicit 0 selects "wait for ever" (the plain blocking
+    // ncclCommInitRank on the calling thread) -- an empty or non-numeric value keeps the default instead of silently disabling the bound
     double t = 300.0;
-    if (const char *e = getenv("NRF_COMM_TIMEOUT_S")) t = atof(e);
+    if (const char *e = getenv("NRF_COMM_TIMEOUT_S")) {
+        char *end = nullptr;
+        const double v = strtod(e, &end);
+        while (end && (*end == ' ' || *end == '\t')) end++;
+        if (end != e && end && *end == '\0' && v >= 0.0 && v == v) t = v;
+    }
     return nrf_comm_create_timeout(id, world, rank, t, out);
 }
 
@@ -227,7 +238,18 @@ int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int
             }
         }
     }
-    const ncclResult_t end = R->GroupEnd();
+    ncclResult_t end = R->GroupEnd();
+    if (end == ncclInProgress && R->CommGetAsyncError) {
+        // a NON-BLOCKING communicator handed over through nrf_comm_wrap: the group is enqueued on RCCL's helper thread.  Nothing may be ordered behind this call on
+        // `stream` (an event, the caller's next kernel) before the enqueue has happened, so wait for it here, with a bound.
+        const auto t0 = std::chrono::steady_clock::now();
+        ncclResult_t q = R->CommGetAsyncError(c->comm, &end);
+        while (q == ncclSuccess && end == ncclInProgress && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            q = R->CommGetAsyncError(c->comm, &end);
+        }
+        if (q != ncclSuccess) end = q;
+    }
     if (first != ncclSuccess) { set_error("nrf_allgather_tiles: %s failed: %s", what, R->GetErrorString(first)); return NRF_ERR_HIP; }
     if (end != ncclSuccess) { set_error("nrf_allgather_tiles: ncclGroupEnd failed: %s", R->GetErrorString(end)); return NRF_ERR_HIP; }
     return NRF_OK;

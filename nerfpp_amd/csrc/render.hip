@@ -16,14 +16,25 @@
 #include <cstdlib>
 #include <mutex>
 
+constexpr int NRF_MAX_LANES = 4;
+
 struct nrf_renderer {
     nrf_renderer_desc desc;
     int in_ch = 0, in_views = 0;
-    // the two lanes of the Chunk loop (nrf_batchify_rays): auxiliary streams, created on first use on the device that is current then
+    // the lanes of the Chunk loop (nrf_batchify_rays): auxiliary streams and the fork / join events, created on first use on the device that is current then and
+    // re-created when a later call comes on another device.  A renderer serves one device and one caller at a time (include/nerfpp_hip.h, nrf_batchify_rays).
     mutable std::mutex lane_mu;
-    mutable hipStream_t lane[2] = {nullptr, nullptr};
+    mutable hipStream_t lane[NRF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipEvent_t lane_fork = nullptr, lane_done[NRF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable int lane_device = -1;
-    ~nrf_renderer() { for (auto &st : lane) if (st) (void)hipStreamDestroy(st); }
+    void drop_lanes() const
+    {
+        for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+        for (auto &e : lane_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (lane_fork) { (void)hipEventDestroy(lane_fork); lane_fork = nullptr; }
+        lane_device = -1;
+    }
+    ~nrf_renderer() { drop_lanes(); }
 };
 
 namespace nrf {
@@ -527,68 +538,76 @@ static nrf_render_outputs slice_outputs(const nrf_render_outputs &o, int64_t i, 
     return q;
 }
 
-// ---- the Chunk loop on two lanes ----
+// ---- the Chunk loop on lanes ----
 // Consecutive chunks are independent, and their kernels are bound by different things: the hash encode's fine levels by gather latency, the network kernels by the
-// matrix / vector issue of the SIMDs.  Issued on two streams, the chunks' kernels share the CUs (the NeRFSmall kernels hold 206-218 of a SIMD's 512 registers per wave,
-// two waves per SIMD: a wave of the 44-66-register encode fits beside them -- it did not in round 2, when those kernels held 255 and the same experiment gained nothing):
-// 24.8 -> 22.7 ms per frame (tools/scratch/overlap.py).  Chunk i runs on lane i % 2 with its own half of the workspace; the lanes fork from the caller's stream and join
-// it again, so the call is as asynchronous and as ordered as before, and the results do not depend on it (same kernels on the same slices).  A batch that is one chunk is
-// cut in two.  NRF_RENDER_LANES=1 (or nrf_set_render_lanes(1)) restores the single-stream loop.
+// matrix / vector issue of the SIMDs.  Issued on L streams, the chunks' kernels share the CUs (the NeRFSmall kernels hold 206-218 of a SIMD's 512 registers per wave,
+// two waves per SIMD: a wave of the 44-66-register encode fits beside them).  Chunk i runs on the lane that has been given the fewest rays so far, in its own slice of
+// the workspace; the lanes fork from the caller's stream and join it again, so the call is as asynchronous and as ordered as before, and the results do not depend on
+// it (same kernels on the same slices).  A batch that is one chunk is cut into L.  NRF_RENDER_LANES=1 (or nrf_set_render_lanes(1)) restores the single-stream loop.
 static std::atomic<int> g_render_lanes{0};          // 0: not decided yet (environment, default 2)
 static int render_lanes()
 {
     int v = g_render_lanes.load(std::memory_order_relaxed);
     if (v == 0) {
         const char *e = getenv("NRF_RENDER_LANES");
-        v = (e && atoi(e) == 1) ? 1 : 2;
+        v = e ? atoi(e) : 2;
+        if (v < 1 || v > NRF_MAX_LANES) v = 2;
         g_render_lanes.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 #ifndef NRF_LANE_STAGGER
-#define NRF_LANE_STAGGER 1
-#endif
-#ifndef NRF_LANE_STAGGER_PCT
-#define NRF_LANE_STAGGER_PCT 50          // lane 1's first chunk, in per cent of a chunk
+#define NRF_LANE_STAGGER 1               // lane k's first chunk is (L - k) / L of a chunk: the lanes run out of phase (0: full chunks from the start)
 #endif
 #ifndef NRF_LANE_BALANCE
-#define NRF_LANE_BALANCE 1               // the tail of the batch is cut so that both lanes end together (0: full chunks to the end)
+#define NRF_LANE_BALANCE 1               // the tail of the batch is cut so that all lanes end together (0: full chunks to the end)
 #endif
 constexpr int64_t LANE_MIN_RAYS = 32768;           // below this a batch stays on the caller's stream (a 16 384-ray training batch: 9.39 ms per step on one stream, 9.49 cut in two)
 
-// rays per chunk of the two-lane loop; 0: single-stream loop
-static int64_t lane_chunk(int64_t n, int chunk)
+// rays per chunk of the L-lane loop; 0: single-stream loop
+static int64_t lane_chunk(int64_t n, int chunk, int lanes)
 {
-    if (render_lanes() < 2 || n < LANE_MIN_RAYS) return 0;
+    if (lanes < 2 || n < LANE_MIN_RAYS) return 0;
     if (n > chunk) return chunk;
-    return ((n + 1) / 2 + 63) / 64 * 64;            // one chunk: two halves
+    return ((n + lanes - 1) / lanes + 63) / 64 * 64;            // one chunk: L parts
 }
 
 size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p)
 {
     if (!r || !p || chunk <= 0) return 0;
-    const int64_t lc = lane_chunk(n, chunk);
-    if (lc > 0 && lc < n) return 2 * align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256);
+    const int lanes = render_lanes();
+    const int64_t lc = lane_chunk(n, chunk, lanes);
+    if (lc > 0 && lc < n) return (size_t)lanes * align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256);
     return nrf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
 }
 
 int nrf_set_render_lanes(int lanes)
 {
-    NRF_CHECK_ARG(lanes == 1 || lanes == 2, "nrf_set_render_lanes: 1 (single stream) or 2");
+    NRF_CHECK_ARG(lanes >= 1 && lanes <= NRF_MAX_LANES, "nrf_set_render_lanes: 1 (single stream) .. %d", NRF_MAX_LANES);
     g_render_lanes.store(lanes, std::memory_order_relaxed);
     return NRF_OK;
 }
 
-static int lanes_of(const nrf_renderer *r, hipStream_t (&st)[2])
+static int lanes_of(const nrf_renderer *r, int lanes, hipStream_t *st, hipEvent_t *fork, hipEvent_t *done)
 {
     std::lock_guard<std::mutex> lk(r->lane_mu);
     int dev = 0;
     NRF_HIP(hipGetDevice(&dev));
-    if (r->lane[0] && r->lane_device != dev) { set_error("nrf_batchify_rays: the renderer's lanes live on device %d, the call came on device %d", r->lane_device, dev); return NRF_ERR_INVALID_ARG; }
-    for (int i = 0; i < 2; i++)
+    if (r->lane_device >= 0 && r->lane_device != dev) {
+        // the renderer is now used on another device: its lanes move with it (the old ones are drained and destroyed on their own device)
+        int cur = dev;
+        (void)hipSetDevice(r->lane_device);
+        r->drop_lanes();
+        NRF_HIP(hipSetDevice(cur));
+    }
+    for (int i = 0; i < lanes; i++) {
         if (!r->lane[i]) NRF_HIP(hipStreamCreateWithFlags(&r->lane[i], hipStreamNonBlocking));
+        if (!r->lane_done[i]) NRF_HIP(hipEventCreateWithFlags(&r->lane_done[i], hipEventDisableTiming));
+        st[i] = r->lane[i]; done[i] = r->lane_done[i];
+    }
+    if (!r->lane_fork) NRF_HIP(hipEventCreateWithFlags(&r->lane_fork, hipEventDisableTiming));
+    *fork = r->lane_fork;
     r->lane_device = dev;
-    st[0] = r->lane[0]; st[1] = r->lane[1];
     return NRF_OK;
 }
 
@@ -600,56 +619,56 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
     const int s = p->n_samples, sf = p->n_samples + p->n_importance, so = p->n_importance > 0 ? sf : s;
     const int c = r->desc.mlp->out_dims;
     nrf_render_params q = *p;
-    const int64_t lc = lane_chunk(n, chunk);
-    const size_t half = lc > 0 && lc < n ? align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256) : 0;
-    if (half > 0 && 2 * half <= workspace_bytes && d_workspace) {
-        // two lanes: fork from the caller's stream, chunk i on lane i % 2 in its own half of the workspace, join
-        hipStream_t st = as_stream(stream), lane[2];
-        NRF_TRY(lanes_of(r, lane));
-        hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
-        NRF_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    const int L = render_lanes();
+    const int64_t lc = lane_chunk(n, chunk, L);
+    const size_t part = lc > 0 && lc < n ? align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256) : 0;
+    if (part > 0 && (size_t)L * part <= workspace_bytes && d_workspace) {
+        // fork from the caller's stream, each chunk on the least-loaded lane in that lane's slice of the workspace, join
+        hipStream_t st = as_stream(stream), lane[NRF_MAX_LANES];
+        hipEvent_t fork = nullptr, done[NRF_MAX_LANES];
+        NRF_TRY(lanes_of(r, L, lane, &fork, done));
         int rc = NRF_OK;
-        if (hipEventRecord(fork, st) != hipSuccess || hipStreamWaitEvent(lane[0], fork, 0) != hipSuccess || hipStreamWaitEvent(lane[1], fork, 0) != hipSuccess) {
-            set_error("nrf_batchify_rays: forking the lanes failed"); rc = NRF_ERR_HIP;
-        }
-        // lane 1 starts with a half chunk: the lanes then run out of phase (one in its encode while the other is in its network) instead of doing the same thing at
-        // the same time, which is what makes them share the CUs well
-        // The next chunk goes to the lane that has been given fewer rays so far (strict alternation would leave lane 1, which started with half a chunk, a chunk and
-        // a half behind at the end of a five-chunk frame: the last quarter of the frame on one lane), and the last < 2 chunks are cut so that both lanes end together.
-        int64_t given[2] = {0, 0};
-        bool first1 = true;
+        if (hipEventRecord(fork, st) != hipSuccess) { set_error("nrf_batchify_rays: forking the lanes failed"); rc = NRF_ERR_HIP; }
+        for (int j = 0; j < L && rc == NRF_OK; j++)
+            if (hipStreamWaitEvent(lane[j], fork, 0) != hipSuccess) { set_error("nrf_batchify_rays: forking the lanes failed"); rc = NRF_ERR_HIP; }
+        // Lane k starts with (L - k) / L of a chunk: the lanes then run out of phase (one in its encode while another is in its network) instead of doing the same
+        // thing at the same time, which is what makes them share the CUs well.  The next chunk goes to the lane that has been given the fewest rays so far, and the
+        // last < L chunks are cut so that all lanes end together.
+        int64_t given[NRF_MAX_LANES] = {0, 0, 0, 0};
+        bool first[NRF_MAX_LANES] = {true, true, true, true};
         for (int64_t i = 0; i < n && rc == NRF_OK;) {                                                             // :476
-            const int k = given[1] < given[0] ? 1 : 0;
+            int k = 0;
+            for (int j = 1; j < L; j++) if (given[j] < given[k]) k = j;
             const int64_t rem = n - i;
             int64_t m = lc;
 #if NRF_LANE_STAGGER
-            if (k == 1 && first1) m = (lc * NRF_LANE_STAGGER_PCT / 100 + 63) / 64 * 64;
+            if (first[k]) m = (lc * (L - k) / L + 63) / 64 * 64;
 #endif
-            if (k == 1) first1 = false;
+            first[k] = false;
 #if NRF_LANE_BALANCE
-            if (rem < 2 * lc) {
-                m = ((rem + given[k ^ 1] - given[k]) / 2 + 63) / 64 * 64;       // lane k's share of the rest that evens the lanes out
+            if (rem < (int64_t)L * lc) {
+                int64_t total = rem;
+                for (int j = 0; j < L; j++) total += given[j];
+                m = (total / L - given[k] + 63) / 64 * 64;                       // lane k's share of the rest that evens the lanes out
                 if (m > lc) m = lc;
+                if (m < 1024) m = 1024;
                 if (rem - m < 1024 && rem <= lc) m = rem;                       // no crumbs
             }
 #endif
             if (m > rem) m = rem;
             q.ray_base = p->ray_base + i;
             const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
-            rc = nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * half, half, lane[k]);
+            rc = nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * part, part, lane[k]);
             given[k] += m;
             i += m;
         }
         // join on every path: whatever was launched is ordered before the caller's next operation
-        for (int j = 0; j < 2; j++) {
-            if (hipEventCreateWithFlags(&done[j], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[j], lane[j]) != hipSuccess ||
-                hipStreamWaitEvent(st, done[j], 0) != hipSuccess) {
+        for (int j = 0; j < L; j++) {
+            if (hipEventRecord(done[j], lane[j]) != hipSuccess || hipStreamWaitEvent(st, done[j], 0) != hipSuccess) {
                 if (rc == NRF_OK) { set_error("nrf_batchify_rays: joining the lanes failed"); rc = NRF_ERR_HIP; }
                 (void)hipStreamSynchronize(lane[j]);
             }
         }
-        (void)hipEventDestroy(fork);
-        for (int j = 0; j < 2; j++) if (done[j]) (void)hipEventDestroy(done[j]);
         return rc;
     }
     for (int64_t i = 0; i < n; i += chunk) {                                                                      // :476

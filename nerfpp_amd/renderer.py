@@ -255,10 +255,15 @@ class NeRFRenderer:
     @classmethod
     def _linspace(cls, steps, dev):
         """torch::linspace(0, 1, steps) on the device (NeRFRenderer.h:393, Sampler.h:21), ATen's own rounding; cached per (steps, device)."""
-        key = (int(steps), str(dev))
+        d = torch.device(dev)
+        if d.type == "cuda" and d.index is None:          # 'cuda' means the CURRENT device: key on the indexed device, or a later set_device would get the wrong card's buffer
+            d = torch.device("cuda", torch.cuda.current_device())
+        key = (int(steps), d)
         t = cls._lin_cache.get(key)
         if t is None:
-            t = cls._lin_cache[key] = torch.linspace(0.0, 1.0, int(steps), dtype=torch.float32).to(dev)
+            if len(cls._lin_cache) >= 64:
+                cls._lin_cache.clear()
+            t = cls._lin_cache[key] = torch.linspace(0.0, 1.0, int(steps), dtype=torch.float32).to(d)
         return t
 
     @staticmethod

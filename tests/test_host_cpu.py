@@ -284,6 +284,96 @@ def test_bench_launcher_reports_failing_ranks_without_hanging():
     assert r.returncode != 0 and "cabi" in r.stderr
 
 
+def _canned_bench_detail(world):
+    """A full bench record assembled from canned measurements (round 3's HIP-event totals) through the same functions bench.py calls on the GPU box."""
+    from benchlib import roofline as RF
+    from benchlib.costs import H, W, UNITS_PER_RAY
+    timed = {"hash": dict(ms=156.26, launches=120), "mlp": dict(ms=89.19, launches=60), "composite": dict(ms=59.88, launches=120), "sample": dict(ms=27.05, launches=60),
+             "other": dict(ms=0.0, launches=0), "sigma": dict(ms=56.47, launches=60), "mlp_colour": dict(ms=42.46, launches=60)}
+    single = {"hash": dict(ms=36.64, launches=50), "mlp": dict(ms=34.70, launches=25), "composite": dict(ms=9.1, launches=50), "sample": dict(ms=4.4, launches=25),
+              "other": dict(ms=0.0, launches=0), "sigma": dict(ms=24.47, launches=25), "mlp_colour": dict(ms=10.94, launches=25)}
+    units = H * W * UNITS_PER_RAY / world
+    roof = dict(timed=RF.kernel_rooflines(timed, "hash", "f16x3", "cu", units * 10), lanes_timed=2, kernel_ms_timed=timed)
+    if world == 1:
+        roof["isolated"] = RF.kernel_rooflines(single, "hash", "f16x3", "cu", units * 5)
+    long_text = "x" * 1500          # prose that once rode in the line (traffic_source, notes): must not reach it again
+    also = [dict(workload="hashnerf_lego800_64+128", baseline_config=2, precision="f16", value=12179889925.4, unit="ray-samples/s", ms_per_step=13.45, steps=10,
+                 kernel_ms=timed, roofline=dict(frac=0.3964, note=long_text), psnr_vs_oracle_db=dict(psnr=44.08, max_abs_err=0.116)),
+            dict(workload="classic_nerf_lego800_64+128", precision="f16x3", value=3.18e8, ms_per_step=514.4, coarse_pass="density branch in exact fp32 " + long_text,
+                 roofline=dict(frac=0.2086), psnr_vs_oracle_db=dict(psnr=141.16)),
+            dict(workload="classic_nerf_lego800_64+128", precision="f16x3", value=5.61e8, ms_per_step=291.9, coarse_pass="whole network in the timed arithmetic",
+                 roofline=dict(frac=0.2039), psnr_vs_oracle_db=dict(psnr=118.33)),
+            dict(workload="classic_nerf_lego800_64+128", precision="f16", value=1.5e9, ms_per_step=108.1, roofline=dict(frac=0.5653), psnr_vs_oracle_db=dict(psnr=58.4)),
+            dict(workload="hashnerf_lego800_64+128", encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3", value=5.83e9, ms_per_step=28.1,
+                 psnr_vs_oracle_db=dict(psnr=138.95)),
+            dict(workload="hashnerf_train_step", value=4.5e8, ms_per_step=9.31, arithmetic=long_text, cpu_reference=dict(sample=long_text)),
+            dict(workload="lerf_lego800_64+128", precision="f16x3", value=1.12e9, s_per_frame=0.1458, arithmetic=long_text, roofline=dict(frac=0.2857),
+                 oracle_check=dict(embedding_cos_min=0.99999988, fine_sample_set_bit_identical_rays=1.0)),
+            dict(workload="lerf_lego800_64+128", precision="f16", value=1.58e9, s_per_frame=0.1038, roofline=dict(frac=0.4867),
+                 oracle_check=dict(embedding_cos_min=0.99174, fine_sample_set_bit_identical_rays=0.0)),
+            dict(workload="lerf_lego800_64+128", error=long_text)]
+    if world > 1:
+        also = [dict(scaling="weak", frames_per_step=world, steps=5, ms_per_step=23.0, value=7.1e9 * world, unit="ray-samples/s", host_ms_per_tile=0.4, finite=True)]
+    return {"metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)", "value": 7302017868.09 * world, "unit": "ray-samples/s",
+            "n_gpus": world, "steps": 10, "warmup": 2, "ms_per_step": 22.4376 / world, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None, "dtype": "f16x3", "data": "synthetic",
+            "config": {"workload": "hashnerf_lego800_64+128", "baseline_config": 2, "encoder": "CuHashEmbedder L16 T2^19 F2 16..512 + CuSHEncoder deg4 + NeRFSmall 3x64/4x64",
+                       "oracle_pin": "restatement (CUDA-only encoders; reference-pinned twin in also)", "frames_per_step": 1, "rays_per_gpu_per_step": 640000 // world,
+                       "ray_samples_per_ray": 256, "chunk": 131072,
+                       "parallelism": f"row-tile x{world}" + (" + RCCL all_gather (torch.distributed)" if world > 1 else "")},
+            "executed_evaluations_per_ray": dict(hash_encode=192, fused_mlp=128, sigma_only=64, colour_net_only=64),
+            "rays_per_s": 28523507.3 * world, "s_per_frame": 0.0224 / world, "host_ms_per_tile": 0.4066, "tile_rows": 800 // world, "roofline": roof,
+            "ranks_seen_by_rccl": world if world > 1 else None,
+            "collective_check": ("nrf_allgather_tiles (C ABI, RCCL) == torch.distributed all_gather_into_tensor on every rank " + long_text) if world > 1 else None,
+            "cpu_baseline": dict(value=418719.8, unit="ray-samples/s", cores=32, kind="reference", thread_sweep={"8": 364710}, host_cpus=256, sample="18400 rays " + long_text),
+            "psnr_vs_oracle_db": dict(psnr=140.55, max_abs_err=7.2e-7), "parity_full_frame_vs_f32": dict(pixels=640000, max_abs_err=2.74e-6, psnr=140.06),
+            "frame_sha256": "dcaf99dc2ffe33542a3dbbdcf2b0fbcaf4ab6a2b313c8cd326bc029bcab65afb", "also": also}
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, capsys):
+    """The one JSON line the driver parses (round 3's grew to 29 KB and was lost: BENCH_r03.json.parsed = null): < 4 KB for the --gpus 1 and the --gpus N
+    shapes, round-trips through json, carries every key of the driver's contract plus a flat `roofline` and `cpu_baseline`; the top-level roofline is the
+    dominant kernel of the SINGLE-LANE pass and re-derives from its own fields; everything else lands in the side file."""
+    import json
+    from benchlib import report
+    detail = _canned_bench_detail(world)
+    report.emit(detail, stats_csv="profiles/round4/r4_single_lane_kernel_stats.csv", path=str(tmp_path / "bench_detail.json"))
+    cap = capsys.readouterr()
+    out_lines = cap.out.strip().splitlines()
+    assert len(out_lines) == 1, "ONE line on stdout"
+    s = out_lines[0]
+    assert len(s) < report.LINE_LIMIT == 4096, len(s)
+    line = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline", "psnr_vs_oracle_db", "frame_sha256"):
+        assert k in line, k
+    assert set(line["config"]) >= {"workload", "baseline_config", "encoder", "frames_per_step", "rays_per_gpu_per_step", "chunk", "parallelism"} and "model" not in line["config"]
+    assert line["n_gpus"] == world and line["scaling"] == ("weak" if world == 1 else "strong") and line["vs_baseline"] is None and line["dtype"] == "f16x3"
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 160
+    r = line["roofline"]
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "units_per_launch"} <= set(r)
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if world == 1:
+        # the isolated (single-lane) dominant kernel: NeRFSmall on the matrix cores; units x flop / launch time re-derives `achieved` (TFLOP/s)
+        assert r["lanes"] == 1 and r["kernel"].startswith("mlp_small") and r["bound"] == "mfma" and r["kernel_stats"].startswith("profiles/round4/")
+        assert abs(r["units_per_launch"] * r["flop_per_unit"] / (r["avg_launch_ms"] * 1e-3) / 1e12 - r["achieved"]) < 0.01 * r["achieved"]
+        assert 0.1 < r["frac"] < 0.25 and 0.4 < r["mfma_issued_frac"] < 0.8
+        assert r["hash"]["unit"] == "GB/s" and r["hash"]["frac"] > 1.0 and r["sigma"]["frac"] < 1.0      # hash: algorithmic bytes over the HBM peak (cache-served gathers)
+        assert len(line["also"]) == 9 and all(len(json.dumps(a)) <= 140 for a in line["also"])
+        assert [a["workload"] for a in line["also"]][:5] == ["hashnerf", "classic_nerf", "classic_nerf_coarse_full", "classic_nerf", "hashnerf_libtorch_twin"]
+    else:
+        assert r["lanes"] == 2 and line["ranks_seen_by_rccl"] == world and len(line["collective_check"]) <= 100 and line["also"][0]["workload"] == "scaling_weak"
+    assert "x" * 200 not in s, "prose stays in the side file"
+    side = json.load(open(tmp_path / "bench_detail.json"))
+    assert side["roofline"]["timed"]["hash"]["launches"] == 120 and side["also"] and "[bench detail] {" in cap.err
+    # a record that would still be too large loses its optional parts, never the headline
+    detail["also"] = [dict(workload="w%d" % i, precision="f16x3", value=1.0, ms_per_step=1.0, psnr_vs_oracle_db=dict(psnr=100.0), roofline=dict(frac=0.5)) for i in range(80)]
+    s2 = report.dumps_line(report.compact_line(detail))
+    l2 = json.loads(s2)
+    assert len(s2) < 4096 and "also" not in l2 and l2["dropped_for_size"] == ["also"] and l2["value"] == line["value"] and "cpu_baseline" in l2
+
+
 def test_inline_asm_never_reads_a_matrix_packed_or_transcendental_result():
     """tools/asm_input_lint.py over every kernel source: the compiler pads the hazards of its own instructions and does not look into inline asm, so an asm
     instruction that reads what a matrix, packed-fp32 or transcendental instruction wrote is right alone and wrong beside other waves (round 3, DESIGN section 9:
