@@ -165,7 +165,10 @@ def lerf_oracle_check(sc, res, nrays=256):
     eg = res.Outputs.RenderedLangEmbedding.cpu().numpy()[idx]
     cos = (eg * ref).sum(1)
     same = (zg == zf).all(1)
-    return dict(rays=int(idx.size), embedding_max_abs_err=float(np.abs(eg - ref).max()), embedding_rms_err=float(np.sqrt(((eg - ref).astype(np.float64) ** 2).mean())),
+    rel_err = None
+    if res.Outputs.Relevancy is not None and sc["renderer"].LerfPositives is not None:
+        rel_err = float(np.abs(res.Outputs.Relevancy.cpu().numpy()[idx] - O.relevancy(eg, sc["renderer"].LerfPositives, sc["renderer"].LerfNegatives)).max())
+    return dict(relevancy_max_abs_err_vs_oracle_on_gpu_embeddings=rel_err, rays=int(idx.size), embedding_max_abs_err=float(np.abs(eg - ref).max()), embedding_rms_err=float(np.sqrt(((eg - ref).astype(np.float64) ** 2).mean())),
                 fine_sample_set_bit_identical_rays=float(same.mean()), weights_max_abs_err_over_max=float(np.abs(wg - fin["weights"])[same].max() / fin["weights"].max()) if same.any() else None,
                 embedding_cos_min=float(cos.min()), embedding_cos_min_same_samples=float(cos[same].min()) if same.any() else None, embedding_cos_median=float(np.median(cos)),
                 against="CPU oracle, fp32 stage path end to end (its own coarse pass and fine sample set)")
@@ -181,7 +184,15 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
                            BoundingBox=sc["bbox"])
     r = sc["renderer"]
     r.set_precision(precision)
-    dt, kms, res = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1, lanes_hook=lambda k: setattr(r, "lanes", k))
+    # the pass ends where its users look: with prompts set, the frame includes Relevancy (LeRFRenderer.cpp:79).  Synthetic unit phrase embeddings: one positive, three canonical negatives
+    rng = np.random.RandomState(79)
+    pos = rng.randn(1, 768).astype(np.float32); pos /= np.linalg.norm(pos)
+    neg = rng.randn(3, 768).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)
+    r.SetLeRFPrompts(pos, neg)
+    r.keep_intermediates = False           # the timed frames write what LeRFRenderer::Render returns; the oracle check below renders once more with the depth sets kept
+    dt, kms, _ = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1, lanes_hook=lambda k: setattr(r, "lanes", k))
+    r.keep_intermediates = True
+    res = r.Render(H, W, K, p, c2w=c2w)
     n = H * W
     emb = res.Outputs.RenderedLangEmbedding
     hit = res.Outputs.AccMapLE > 1e-2
@@ -189,7 +200,8 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
     split = r.precision_name == "f16x3"
     exact = bool(split and r._exact_coarse_on())
     rec = dict(workload="lerf_lego800_64+128", baseline_config=5, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt, frames_timed=repeats, kernel_ms=kms,
-               fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()),
+               fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()), single_library_call=bool(r._single_call_ok(p)),
+               relevancy="rendered in the pass (1 positive, 3 negatives)" if res.Outputs.Relevancy is not None else None,
                rays_with_language_density=int(hit.sum()), embedding_norm_min_max=[float(nrm.min()), float(nrm.max())] if int(hit.sum()) else None,
                level_major_features=bool(getattr(r, "level_major", False)), precision=getattr(r, "precision_name", "f16"),
                coarse_pass="sigma_le in exact fp32 on the matrix cores (sigma_lerf_f32.hip): the fp32 path's fine sample set" if exact else "the timed arithmetic",

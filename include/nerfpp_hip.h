@@ -291,10 +291,26 @@ NRF_API int nrf_lerf_render_embedding_lm_gather(const nrf_mlp *m, const void *d_
                                                 int s, float *d_out, void *stream);
 
 /* RenderCLIPEmbedding (LeRFRenderer.h:45-54): out[n, embed_dim] = normalize(sum_s weights[n,s] * embeds[n,s,:embed_dim], eps 1e-8).
- * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]).  Relevancy(...) (LeRFRenderer.cpp:79) lives
- * in the external RuCLIP module and is not part of this library. */
+ * embeds rows are embed_stride floats apart (the raw LeRF output is [n,s,embed_dim+1]). */
 NRF_API int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed_dim, const float *d_weights, int64_t n, int s,
                                       float *d_out, void *stream);
+
+/* Relevancy(embeds, positives, negatives) (call sites LeRFRenderer.cpp:79, NeRFExecutor.h:824): [n, embed_dim] L2-normalised embeddings against
+ * [n_pos, embed_dim] positive and [n_neg, embed_dim] negative ("canonical") phrase embeddings -> d_out [n, 2] = (p_positive, p_negative) of the pairwise softmax
+ * (temperature 10) against the negative phrase the positive does worst against; column 0 is what the hosts consume (LeRFRenderer.h:18, NeRFExecutor.h:714).
+ * PARITY UNPINNED: the function's source is external (DeliriumV01D/RuCLIP, RuCLIPProcessor.h, no pinned version, absent from the reference tree) -- this is the
+ * published LERF relevancy score (Kerr et al. 2023, section 3.3; nerfstudio `get_relevancy`) that it mirrors, restated in oracle/nerf_oracle.c (orc_relevancy) and
+ * checked against that and against known answers.  positive_id selects the row of d_positives (the reference passes one positive phrase: 0). */
+NRF_API int nrf_lerf_relevancy(const float *d_embeds, int64_t n, int embed_dim, const float *d_positives, int n_pos, const float *d_negatives, int n_neg,
+                               int positive_id, float *d_out, void *stream);
+
+/* The relevancy image of RenderPath (NeRFExecutor.h:713-719): rel[..., 0].mul(255).to(kU8) -> cv::applyColorMap(COLORMAP_JET) -> d_bgr [n, 3] bytes in OpenCV's
+ * B, G, R order.  d_relevancy rows are rel_stride floats apart (2 for nrf_lerf_relevancy's output).  nrf_colormap_jet_u8 maps bytes that already are the image
+ * (the training-time preview, NeRFExecutor.h:825-831); nrf_colormap_jet_lut writes the 256 x 3 table to HOST memory.
+ * PARITY UNPINNED: OpenCV is not in this image; the table is restated from OpenCV's published colormap (oracle/nerf_oracle.c, orc_colormap_jet_lut, says how). */
+NRF_API int nrf_relevancy_image(const float *d_relevancy, int64_t n, int rel_stride, uint8_t *d_bgr, void *stream);
+NRF_API int nrf_colormap_jet_u8(const uint8_t *d_gray, int64_t n, uint8_t *d_bgr, void *stream);
+NRF_API int nrf_colormap_jet_lut(uint8_t *lut_host /*[256*3]*/);
 
 /* SamplePDF, deterministic branch (Sampler.h:6-43).  bins [n,nb], weights [n,nb-1], u [ns] device
  * (= linspace(0,1,ns)).  sum_vec: fp32 lanes of the host whose torch::sum order is reproduced for the
@@ -570,6 +586,51 @@ NRF_API int nrf_comm_rank(const nrf_comm *c);
 NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int h, int w, int c_channels, float *d_frames, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LeRF render pass as library calls           LeRFRenderer (LeRFRenderer.h:56-132, LeRFRenderer.cpp:85-330)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nrf_lerf_renderer_desc {
+    const nrf_hash *lang_embed;   /* LangEmbedFn: CuHashEmbedder L16 F8 (main.cpp:203-213) */
+    const nrf_mlp *lerf;          /* Lerf: nrf_mlp_lerf_create; arithmetic of the fused passes: nrf_lerf_set_precision */
+} nrf_lerf_renderer_desc;
+
+typedef struct nrf_lerf_outputs {     /* LeRFRendererOutputs (LeRFRenderer.h:9-18); NULL = not wanted */
+    float *d_embedding;        /* RenderedLangEmbedding [n, E] */
+    float *d_disp;             /* DispMapLE [n] */
+    float *d_acc;              /* AccMapLE [n] */
+    float *d_depth;            /* DepthMapLE [n] */
+    float *d_weights;          /* WeightsLE [n, n_samples + n_importance] */
+    float *d_relevancy;        /* Relevancy [n, 2] (needs nrf_lerf_set_prompts) */
+    /* intermediates for parity tests (optional) */
+    float *d_z_coarse;         /* [n, n_samples] */
+    float *d_weights_coarse;   /* [n, n_samples] */
+    float *d_z_fine;           /* [n, n_samples + n_importance] */
+} nrf_lerf_outputs;
+
+typedef struct nrf_lerf_renderer nrf_lerf_renderer;
+NRF_API int nrf_lerf_renderer_create(const nrf_lerf_renderer_desc *desc, nrf_lerf_renderer **out);
+NRF_API void nrf_lerf_renderer_destroy(nrf_lerf_renderer *r);
+/* LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [n_pos, E] / [n_neg, E] fp32 phrase embeddings (host or device), copied; 0 / 0 clears them.  Synchronises `stream`. */
+NRF_API int nrf_lerf_set_prompts(nrf_lerf_renderer *r, const float *positives, int n_pos, const float *negatives, int n_neg, int on_device, void *stream);
+
+/* LeRFRenderer::RenderRays (LeRFRenderer.cpp:85-187) over one chunk of packed rays [n, 8 | 11], hierarchical (n_importance > 0), deterministic (ThinRay, Perturb = 0:
+ * NRF_ERR_UNSUPPORTED otherwise), on the fused matrix-core path: every sample point is hash-encoded once and its density net evaluated once, raw_le [n, S, 769] is never
+ * formed.  Of `p`: n_samples, n_importance (multiples of 32 in sum), lindisp, sum_vec, coarse_mode (NRF_COARSE_AUTO: sigma_le of the coarse pass in exact fp32 when the head
+ * runs in NRF_PREC_F16_SPLIT, so that the fine sample set is the fp32 stage path's bit for bit; NRF_COARSE_FULL: the timed arithmetic).  d_t / d_u as nrf_render_rays. */
+NRF_API size_t nrf_lerf_render_rays_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, const nrf_render_params *p);
+NRF_API int nrf_lerf_render_rays(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
+                                 const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
+/* LeRFRenderer::BatchifyRays (LeRFRenderer.cpp:189-263): the Chunk loop inside the library, slices written in place, on the lanes of nrf_set_render_lanes /
+ * NRF_RENDER_LANES (one device and one caller at a time per renderer, as nrf_batchify_rays). */
+NRF_API size_t nrf_lerf_batchify_rays_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int chunk, const nrf_render_params *p);
+NRF_API int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p, const float *d_t,
+                                   const float *d_u, const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
+/* LeRFRenderer::Render for a pose (LeRFRenderer.cpp:265-330), restricted to the row tile of `v`: rays + the Chunk loop + (with prompts) the relevancy in ONE call,
+ * no synchronisation, no torch ops; out: buffers for the tile's rows*w rays; d_rays_out / d_near_far as nrf_render_rows. */
+NRF_API size_t nrf_lerf_render_rows_workspace_bytes(const nrf_lerf_renderer *r, const nrf_view *v, const nrf_render_params *p);
+NRF_API int nrf_lerf_render_rows(const nrf_lerf_renderer *r, const nrf_view *v, const nrf_render_params *p, const float *d_t, const float *d_u, const nrf_lerf_outputs *out,
+                                 float *d_rays_out, float *d_near_far, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)
  * ------------------------------------------------------------------------------------------- */
 /* When enabled, nrf_render_rays brackets its dominant kernels with HIP events on the caller's stream;
@@ -581,6 +642,7 @@ enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAM
  * caller's stream) so that one chunk's gather-bound kernels overlap another's matrix-bound ones; results do not depend on it.  lanes = 1 restores the single-stream
  * loop (also: NRF_RENDER_LANES=1..4).  Process-wide setting, read at every call; the workspace query and the call must see the same value. */
 NRF_API int nrf_set_render_lanes(int lanes);
+NRF_API int nrf_get_render_lanes(void);
 NRF_API int nrf_profile_enable(int on);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
 

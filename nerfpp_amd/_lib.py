@@ -51,6 +51,14 @@ class RenderOutputs(C.Structure):
                                           "d_z_coarse", "d_raw_coarse", "d_weights_coarse", "d_z_fine")]
 
 
+class LerfRendererDesc(C.Structure):
+    _fields_ = [("lang_embed", C.c_void_p), ("lerf", C.c_void_p)]
+
+
+class LerfOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("d_embedding", "d_disp", "d_acc", "d_depth", "d_weights", "d_relevancy", "d_z_coarse", "d_weights_coarse", "d_z_fine")]
+
+
 class View(C.Structure):          # nrf_view
     _fields_ = [("h", C.c_int), ("w", C.c_int), ("K", C.c_float * 9), ("c2w", C.c_float * 12), ("has_staticcam", C.c_int), ("c2w_staticcam", C.c_float * 12),
                 ("row0", C.c_int), ("rows", C.c_int), ("use_viewdirs", C.c_int), ("ndc", C.c_int), ("chunk", C.c_int), ("bbox", C.c_float * 6)]
@@ -77,7 +85,10 @@ SYMBOLS = [
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_create_timeout", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",
-    "nrf_profile_enable", "nrf_profile_read", "nrf_set_render_lanes",
+    "nrf_profile_enable", "nrf_profile_read", "nrf_set_render_lanes", "nrf_get_render_lanes",
+    "nrf_lerf_relevancy", "nrf_relevancy_image", "nrf_colormap_jet_u8", "nrf_colormap_jet_lut",
+    "nrf_lerf_renderer_create", "nrf_lerf_renderer_destroy", "nrf_lerf_set_prompts", "nrf_lerf_render_rays_workspace_bytes", "nrf_lerf_render_rays",
+    "nrf_lerf_batchify_rays_workspace_bytes", "nrf_lerf_batchify_rays", "nrf_lerf_render_rows_workspace_bytes", "nrf_lerf_render_rows",
 ]
 NRF_COMM_ID_BYTES = 128
 
@@ -105,6 +116,9 @@ def lib():
         L.nrf_render_rays_workspace_bytes.restype = C.c_size_t
         L.nrf_batchify_rays_workspace_bytes.restype = C.c_size_t
         L.nrf_render_rows_workspace_bytes.restype = C.c_size_t
+        L.nrf_lerf_render_rays_workspace_bytes.restype = C.c_size_t
+        L.nrf_lerf_batchify_rays_workspace_bytes.restype = C.c_size_t
+        L.nrf_lerf_render_rows_workspace_bytes.restype = C.c_size_t
         L.nrf_mlp_backward_workspace_bytes.restype = C.c_size_t
         L.nrf_mlp_backward_f16_workspace_bytes.restype = C.c_size_t
         L.nrf_hash_backward_binned_workspace_bytes.restype = C.c_size_t

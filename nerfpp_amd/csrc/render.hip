@@ -581,6 +581,8 @@ size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int c
     return nrf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
 }
 
+int nrf_get_render_lanes(void) { return render_lanes(); }
+
 int nrf_set_render_lanes(int lanes)
 {
     NRF_CHECK_ARG(lanes >= 1 && lanes <= NRF_MAX_LANES, "nrf_set_render_lanes: 1 (single stream) .. %d", NRF_MAX_LANES);

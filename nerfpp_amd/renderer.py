@@ -21,7 +21,7 @@ ATEN_SUM_VEC = 8   # fp32 lanes of ATen's CPU sum kernel on any AVX2+/AVX-512 x8
 
 def _host_f32(t, n):
     a = np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, np.float32).reshape(-1)
-    assert a.size == n
+    assert n is None or a.size == n
     return a
 
 
@@ -484,16 +484,13 @@ class LeRFRendererOutputs:            # LeRFRenderer.h:9-18
     AccMapLE: Optional[torch.Tensor] = None
     WeightsLE: Optional[torch.Tensor] = None
     DepthMapLE: Optional[torch.Tensor] = None
-    Relevancy: Optional[torch.Tensor] = None                # external RuCLIP `Relevancy(...)` (LeRFRenderer.cpp:79): NOT built
+    Relevancy: Optional[torch.Tensor] = None                # [N, 2] (LeRFRenderer.cpp:79; set when prompts are given -- parity unpinned, see Relevancy())
 
 
-@dataclass
-class LeRFRenderResult:               # LeRFRenderer.h:20-26
-    Outputs: LeRFRendererOutputs = field(default_factory=LeRFRendererOutputs)
-    Raw: Optional[torch.Tensor] = None
-    Near: float = 0.0
-    Far: float = 0.0
-    Extras: dict = field(default_factory=dict)
+class LeRFRenderResult(NeRFRenderResult):               # LeRFRenderer.h:20-26 (Near / Far read lazily from the device, as NeRFRenderResult)
+    def __init__(self):
+        super().__init__()
+        self.Outputs = LeRFRendererOutputs()
 
 
 def RenderCLIPEmbedding(embeds, weights):
@@ -510,10 +507,30 @@ def _clip_embedding(e, stride, dim, w):
     return out
 
 
+def Relevancy(embeds, positives, negatives, positive_id=0):
+    """Relevancy(embeds [N, E], positives [P, E], negatives [Q, E]) -> [N, 2] (call sites LeRFRenderer.cpp:79, NeRFExecutor.h:824).  The function's source is external
+    (DeliriumV01D/RuCLIP): this is the published LERF relevancy score it mirrors -- PARITY UNPINNED (include/nerfpp_hip.h, nrf_lerf_relevancy)."""
+    e = _dev_f32(embeds); pos = _dev_f32(positives).to(e.device); neg = _dev_f32(negatives).to(e.device)
+    out = torch.empty((e.shape[0], 2), device=e.device, dtype=torch.float32)
+    L.check(L.lib().nrf_lerf_relevancy(_ptr(e), C.c_int64(e.shape[0]), int(e.shape[1]), _ptr(pos), int(pos.shape[0]), _ptr(neg), int(neg.shape[0]), int(positive_id),
+                                       _ptr(out), _stream()))
+    return out
+
+
+def RelevancyImage(relevancy):
+    """The relevancy picture RenderPath writes (NeRFExecutor.h:713-719): rel[..., 0] * 255 -> u8 -> COLORMAP_JET, [..., 3] bytes in B, G, R order (parity unpinned)."""
+    r = _dev_f32(relevancy)
+    sh = r.shape[:-1]
+    n = int(np.prod(sh)) if len(sh) else 1
+    out = torch.empty((n, 3), device=r.device, dtype=torch.uint8)
+    L.check(L.lib().nrf_relevancy_image(_ptr(r), C.c_int64(n), int(r.shape[-1]), _ptr(out), _stream()))
+    return out.reshape(*sh, 3)
+
+
 class LeRFRenderer:
     """LeRFRenderer (LeRFRenderer.h:57-132, LeRFRenderer.cpp): CuHashEmbedder -> LeRF head -> sigma_le weights -> rendered CLIP
-    embedding.  Stage-composed over the C ABI (generic fp32 kernels); `Relevancy` needs the external RuCLIP text encoder and is
-    left to the caller."""
+    embedding -> relevancy.  The default configuration (fused matrix-core passes on level-major features) renders a pose or a ray batch with ONE library call
+    (nrf_lerf_render_rows / nrf_lerf_batchify_rays); every other configuration is stage-composed over the C ABI."""
 
     def __init__(self, lang_embed_fn, lerf, lerf_positives=None, lerf_negatives=None, point_chunk=1 << 16, fused=True, precision=L.NRF_PREC_F16_SPLIT):
         """precision: arithmetic of the fused matrix-core passes, L.NRF_PREC_F16_SPLIT (default: hi + lo fp16 operand pairs, fp32-grade like LeRFImpl::forward)
@@ -536,6 +553,118 @@ class LeRFRenderer:
             self.set_precision(precision)
         # level-major fp16 features straight into the matrix-core kernels' operand fragments (CuHashEmbedder, 16 levels x 8 features); False = fp32 rows
         self.level_major = self.fused and getattr(lang_embed_fn, "mode", None) == L.NRF_HASH_CU and lang_embed_fn.NLevels == 16 and lang_embed_fn.NFeaturesPerLevel == 8
+        # the pass as library calls (lerf_render.hip); single_call = False keeps the stage-composed host loop below (A/B tests)
+        self.single_call = True
+        self.keep_intermediates = True      # Extras: z_coarse / weights_coarse / z_fine of the whole batch (parity tests; a timing loop turns it off)
+        self._r = C.c_void_p()
+        self._ws = None
+        if self.level_major:
+            d = L.LerfRendererDesc(lang_embed_fn._h, lerf._m)
+            L.check(L.lib().nrf_lerf_renderer_create(C.byref(d), C.byref(self._r)))
+            if lerf_positives is not None and lerf_negatives is not None:
+                self.SetLeRFPrompts(lerf_positives, lerf_negatives)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_r", None):
+                L.lib().nrf_lerf_renderer_destroy(self._r)
+                self._r = None
+        except Exception:
+            pass
+
+    def GetLeRFPrompts(self):                        # LeRFRenderer.h:85
+        return self.LerfPositives, self.LerfNegatives
+
+    def SetLeRFPrompts(self, lerf_positives, lerf_negatives):
+        """LeRFRenderer.h:86: [P, E] / [Q, E] phrase embeddings (the text encoder is the host's)."""
+        self.LerfPositives, self.LerfNegatives = lerf_positives, lerf_negatives
+        if self._r:
+            if lerf_positives is None or lerf_negatives is None:
+                L.check(L.lib().nrf_lerf_set_prompts(self._r, None, 0, None, 0, 0, _stream()))
+            else:
+                pos = _host_f32(lerf_positives, None); neg = _host_f32(lerf_negatives, None)
+                E = self.Lerf.GetLangEmbedDim()
+                L.check(L.lib().nrf_lerf_set_prompts(self._r, pos.ctypes.data_as(C.c_void_p), pos.size // E, neg.ctypes.data_as(C.c_void_p), neg.size // E, 0, _stream()))
+
+    def _single_call_ok(self, p):
+        s, ni = int(p.NSamples), int(p.NImportance)
+        return bool(self.single_call and self._r and self.fused and self.level_major and self.reuse_features and self.hand_over_geo and self.compose_through_map
+                    and not p.ReturnRaw and ni > 0 and s % 32 == 0 and (s + ni) % 32 == 0 and p.ThinRay and p.Perturb == 0 and p.RawNoiseStd == 0)
+
+    def _render_single_call(self, h, w, k, p, rays, c2w, row0, rows):
+        """LeRFRenderer::Render as one C call: nrf_lerf_render_rows for a pose, nrf_lerf_batchify_rays for a ray batch."""
+        lib = L.lib()
+        s, ni = int(p.NSamples), int(p.NImportance)
+        sf, E = s + ni, self.Lerf.GetLangEmbedDim()
+        stride = 11 if p.UseViewdirs else 8
+        bb = _host_f32(p.BoundingBox, 6)
+        rp = L.RenderParams(s, ni, int(p.LinDisp), 0, self.precision, ATEN_SUM_VEC)
+        rp.coarse_mode = L.NRF_COARSE_AUTO if self.exact_coarse else L.NRF_COARSE_FULL
+        dev = torch.device("cuda", torch.cuda.current_device())
+        o = d = None
+        if c2w is not None:
+            rows = h - row0 if rows is None else rows
+            n = rows * w
+        else:
+            o = _dev_f32(rays[0]).reshape(-1, 3).contiguous(); d = _dev_f32(rays[1]).reshape(-1, 3).contiguous()
+            n, dev = o.shape[0], o.device
+        res = LeRFRenderResult()
+        want = bool(p.ReturnWeights)          # LeRFRenderer.cpp:180-185: without ReturnWeights the weights and the rendered embedding are dropped
+        f32 = dict(device=dev, dtype=torch.float32)
+        out = res.Outputs
+        out.DispMapLE = torch.empty((n,), **f32); out.AccMapLE = torch.empty((n,), **f32); out.DepthMapLE = torch.empty((n,), **f32)
+        ro = L.LerfOutputs()
+        ro.d_disp, ro.d_acc, ro.d_depth = _ptr(out.DispMapLE), _ptr(out.AccMapLE), _ptr(out.DepthMapLE)
+        if want:
+            out.WeightsLE = torch.empty((n, sf), **f32); out.RenderedLangEmbedding = torch.empty((n, E), **f32)
+            ro.d_weights, ro.d_embedding = _ptr(out.WeightsLE), _ptr(out.RenderedLangEmbedding)
+        if self.LerfPositives is not None and self.LerfNegatives is not None:
+            out.Relevancy = torch.empty((n, 2), **f32)
+            ro.d_relevancy = _ptr(out.Relevancy)
+        if p.KeepIntermediates or self.keep_intermediates:
+            res.Extras["z_fine"] = torch.empty((n, sf), **f32); res.Extras["z_coarse"] = torch.empty((n, s), **f32); res.Extras["weights_coarse"] = torch.empty((n, s), **f32)
+            ro.d_z_fine, ro.d_z_coarse, ro.d_weights_coarse = _ptr(res.Extras["z_fine"]), _ptr(res.Extras["z_coarse"]), _ptr(res.Extras["weights_coarse"])
+        rays_ = torch.empty((n, stride), **f32)
+        t, u = NeRFRenderer._linspace(s, dev), NeRFRenderer._linspace(ni, dev)
+
+        def workspace(nb):
+            if self._ws is None or self._ws.numel() < nb or self._ws.device != dev:
+                self._ws = None
+                self._ws = torch.empty((int(nb),), device=dev, dtype=torch.uint8)
+            return self._ws
+        lanes_global = int(lib.nrf_get_render_lanes())
+        if self.lanes != lanes_global:               # the lane count is a process-wide setting of the library: this renderer's own count for this call
+            L.check(lib.nrf_set_render_lanes(int(self.lanes)))
+        try:
+            self._issue_single_call(lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d)
+        finally:
+            if self.lanes != lanes_global:
+                L.check(lib.nrf_set_render_lanes(lanes_global))
+        res.Extras["rays_flat"] = rays_
+        return res
+
+    def _issue_single_call(self, lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d):
+        if c2w is not None:
+            v = L.View()
+            v.h, v.w, v.row0, v.rows = int(h), int(w), int(row0), int(rows)
+            v.K = (C.c_float * 9)(*_host_f32(k, 9).tolist())
+            v.c2w = (C.c_float * 12)(*_host_f32(torch.as_tensor(c2w)[:3, :4] if torch.is_tensor(c2w) else np.asarray(c2w)[:3, :4], 12).tolist())
+            v.use_viewdirs, v.ndc, v.chunk = int(bool(p.UseViewdirs)), 0, int(p.Chunk)
+            v.bbox = (C.c_float * 6)(*bb.tolist())
+            nf = torch.empty((2,), **f32)
+            ws = workspace(lib.nrf_lerf_render_rows_workspace_bytes(self._r, C.byref(v), C.byref(rp)))
+            L.check(lib.nrf_lerf_render_rows(self._r, C.byref(v), C.byref(rp), _ptr(t), _ptr(u), C.byref(ro), _ptr(rays_), _ptr(nf), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+            res._nf_dev = nf
+        else:
+            L.check(lib.nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))
+            ws = workspace(lib.nrf_lerf_batchify_rays_workspace_bytes(self._r, C.c_int64(n), int(p.Chunk), C.byref(rp)))
+            L.check(lib.nrf_lerf_batchify_rays(self._r, _ptr(rays_), stride, C.c_int64(n), int(p.Chunk), C.byref(rp), _ptr(t), _ptr(u), C.byref(ro), _ptr(ws),
+                                               C.c_size_t(ws.numel()), _stream()))
+            nr, fr = C.c_float(0), C.c_float(0)
+            L.check(lib.nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
+            res._nf = (nr.value, fr.value)
+        res.Extras["rays_flat"] = rays_
+        return res
 
     def set_precision(self, precision):
         L.check(L.lib().nrf_lerf_set_precision(self.Lerf._m, int(precision)))
@@ -729,6 +858,8 @@ class LeRFRenderer:
     def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, row0=0, rows=None):
         """LeRFRenderer.cpp:265-330."""
         p = render_params
+        if self._single_call_ok(p) and (c2w is not None or (rays[0] is not None and torch.as_tensor(rays[0]).numel() > 0)):
+            return self._render_single_call(h, w, k, p, rays, c2w, row0, rows)
         if c2w is not None:
             rays_o, rays_d, cone_angle = GetRays(h, w, k, c2w, row0=row0, rows=rows)
         else:
@@ -772,6 +903,8 @@ class LeRFRenderer:
             res.Extras[k_] = torch.cat([q.Extras[k_] for q in parts], 0)
         nr, fr = C.c_float(0), C.c_float(0)
         L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
-        res.Near, res.Far = nr.value, fr.value
+        res._nf = (nr.value, fr.value)
+        if self.LerfPositives is not None and self.LerfNegatives is not None and res.Outputs.RenderedLangEmbedding is not None:
+            res.Outputs.Relevancy = Relevancy(res.Outputs.RenderedLangEmbedding, self.LerfPositives, self.LerfNegatives)      # LeRFRenderer.cpp:79
         res.Extras["rays_flat"] = rays_
         return res

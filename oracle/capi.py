@@ -385,6 +385,27 @@ def to_u8(x):
     return out
 
 
+def relevancy(embeds, positives, negatives, positive_id=0):
+    """PARITY UNPINNED restatement of RuCLIP's Relevancy (LeRFRenderer.cpp:79): see nerf_oracle.c."""
+    e = _f(embeds); pos = _f(positives); neg = _f(negatives)
+    out = np.empty((e.shape[0], 2), np.float32)
+    lib().orc_relevancy(_p(e), C.c_int64(e.shape[0]), C.c_int(e.shape[1]), _p(pos), C.c_int(pos.shape[0]), _p(neg), C.c_int(neg.shape[0]), C.c_int(positive_id), _p(out))
+    return out
+
+
+def colormap_jet_lut():
+    lut = np.empty((256, 3), np.uint8)
+    lib().orc_colormap_jet_lut(lut.ctypes.data_as(C.c_void_p))
+    return lut
+
+
+def relevancy_image(rel):
+    rel = _f(rel)
+    out = np.empty((rel.shape[0], 3), np.uint8)
+    lib().orc_relevancy_image(_p(rel), C.c_int64(rel.shape[0]), C.c_int(rel.shape[1] if rel.ndim > 1 else 1), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def huber_loss(pred, target):
     pred = _f(pred); target = _f(target)
     loss = C.c_float(0); mse = C.c_float(0); grad = np.empty_like(pred)

@@ -1577,6 +1577,77 @@ ORC_API void orc_to_u8(const float *x, int64_t n, uint8_t *out)
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Relevancy (LeRFRenderer.cpp:79, NeRFExecutor.h:824) and the relevancy image (NeRFExecutor.h:713-719).
+ *
+ * PARITY UNPINNED.  `Relevancy(embeds, positives, negatives)` is defined in RuCLIPProcessor.h of the external module DeliriumV01D/RuCLIP
+ * (../RuCLIP/src, CMakeLists.Files.txt:8-10; no pinned version, absent from /root/reference), and cv::applyColorMap is OpenCV's (absent from this image).
+ * What is restated here is the PUBLISHED algorithm both derive from, anchored on the reference's call sites:
+ *   - LERF (Kerr et al., ICCV 2023, section 3.3 "relevancy score"; nerfstudio lerf `get_relevancy`, which RuCLIP's function mirrors statement for statement):
+ *       logits = embeds @ cat(positives, negatives)^T                       [N, P + Q]
+ *       sims   = stack(repeat(logits[:, positive_id], Q), logits[:, P:])    [N, Q, 2]
+ *       smx    = softmax(10 * sims, -1)                                     temperature 10
+ *       best   = argmin_q smx[:, q, 0]                                      the canonical phrase the positive loses most against (first on ties)
+ *       out    = smx[:, best, :]                                            [N, 2] = (p_positive, p_negative)
+ *     The call sites fix the shapes: embeds [N, 768] (L2-normalised rendered embedding), positives [1, 768], negatives [Q, 768] (NeRFExecutor.h:744-752: "[3, 768]"),
+ *     output [N, 2] of which column 0 is consumed (LeRFRenderer.h:18: "[num_rays, 2]", take the zeroth; NeRFExecutor.h:714, :825).
+ *   - COLORMAP_JET: OpenCV's table (see orc_colormap_jet_lut); cv::Mat channel order is B, G, R.  The input byte is `pos_probs.mul(255).to(torch::kU8)` (NeRFExecutor.h:715): truncation toward zero.
+ * ------------------------------------------------------------------------------------------------- */
+ORC_API void orc_relevancy(const float *embeds, int64_t n, int e, const float *pos, int p, const float *neg, int q, int positive_id, float *out)
+{
+    OMP_FOR
+    for (int64_t i = 0; i < n; i++) {
+        const float *x = embeds + i * (int64_t)e;
+        float lp = 0.0f;
+        for (int k = 0; k < e; k++) lp += x[k] * pos[(int64_t)positive_id * e + k];
+        float best0 = 0.0f, best1 = 0.0f;
+        for (int j = 0; j < q; j++) {
+            float ln = 0.0f;
+            for (int k = 0; k < e; k++) ln += x[k] * neg[(int64_t)j * e + k];
+            /* softmax over the pair (10 lp, 10 ln), max-subtracted as ATen's softmax does */
+            const float a = 10.0f * lp, b = 10.0f * ln, m = a > b ? a : b;
+            const float ea = expf(a - m), eb = expf(b - m), sum = ea + eb;
+            const float s0 = ea / sum, s1 = eb / sum;
+            if (j == 0 || s0 < best0) { best0 = s0; best1 = s1; }
+        }
+        out[i * 2 + 0] = best0; out[i * 2 + 1] = best1;
+        (void)p;
+    }
+}
+
+/* lut[256][3] in B, G, R order.  OpenCV's Jet table (modules/imgproc/src/colormap.cpp, 256 float entries per channel; first non-zero red entry 0.00588235294117645 =
+   4 * 96 / 255 - 1.5) is Octave's jet(256) evaluated at x = k / 255:
+       r = clamp(min(4x - 1.5, -4x + 4.5)),  g = clamp(min(4x - 0.5, -4x + 3.5)),  b = clamp(min(4x + 0.5, -4x + 2.5))       (clamp to [0, 1])
+   stored as float literals and converted with Mat::convertTo(CV_8U, 255.): the float product entry * 255.f, rounded to nearest (ties to even), saturated.
+   On the ramps entry * 255 = 4k - 382.5 etc. sits on a rounding tie before the float roundings, so without OpenCV at hand single entries may differ by one
+   count from its table: part of what "parity unpinned" covers for this function. */
+ORC_API void orc_colormap_jet_lut(uint8_t *lut)
+{
+    for (int k = 0; k < 256; k++) {
+        const double x = (double)k / 255.0;
+        const double c[3] = {fmin(4.0 * x - 1.5, -4.0 * x + 4.5), fmin(4.0 * x - 0.5, -4.0 * x + 3.5), fmin(4.0 * x + 0.5, -4.0 * x + 2.5)};   /* r, g, b */
+        for (int ch = 0; ch < 3; ch++) {
+            const float entry = (float)(c[ch] < 0.0 ? 0.0 : (c[ch] > 1.0 ? 1.0 : c[ch]));
+            const float scaled = entry * 255.0f;
+            long v = lrintf(scaled);
+            lut[k * 3 + (2 - ch)] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+/* rel[:, 0] * 255 -> u8 (truncation, saturated) -> JET, [n, 3] B, G, R   (NeRFExecutor.h:713-719) */
+ORC_API void orc_relevancy_image(const float *rel, int64_t n, int rel_stride, uint8_t *bgr)
+{
+    uint8_t lut[256 * 3];
+    orc_colormap_jet_lut(lut);
+    for (int64_t i = 0; i < n; i++) {
+        float v = rel[i * rel_stride] * 255.0f;
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        const int b = (int)(uint8_t)v;
+        bgr[i * 3 + 0] = lut[b * 3 + 0]; bgr[i * 3 + 1] = lut[b * 3 + 1]; bgr[i * 3 + 2] = lut[b * 3 + 2];
+    }
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -2458,3 +2458,96 @@ def test_classic_exact_coarse_sigma_pass_reproduces_the_parity_sample_set(api, O
     # plain fp16 precision may ask for the exact coarse pass too (NRF_COARSE_SIGMA_F32)
     e = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], precision=api.L.NRF_PREC_F16_MFMA, CoarseMode=api.L.NRF_COARSE_SIGMA_F32, **kw), c2w=c2w, row0=392, rows=2)
     assert_exact(host(e.Extras["z_fine"]), host(a.Extras["z_fine"])[:1600], "fp16 fine pass on the fp32 sample set")
+
+
+# ------------------------------------------------------------------ LeRF: Relevancy, the relevancy image, and the render pass as ONE library call (rows L2 / N4)
+def test_relevancy_and_jet_image_vs_oracle(api, O):
+    """nrf_lerf_relevancy / nrf_relevancy_image / nrf_colormap_jet_* against the oracle restatement (PARITY UNPINNED: RuCLIP's Relevancy and OpenCV's COLORMAP_JET are
+    external; see include/nerfpp_hip.h) at the call sites' shapes -- [N, 768] unit embeddings, one positive, Q in {1, 3, 5} negatives -- plus the known answers."""
+    import ctypes as C
+    rng = np.random.RandomState(713)
+    E = 768
+    for n, q in ((1, 3), (257, 3), (5000, 1), (1031, 5)):
+        x = rng.randn(n, E).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+        pos = rng.randn(2, E).astype(np.float32); pos /= np.linalg.norm(pos, axis=1, keepdims=True)
+        neg = rng.randn(q, E).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)
+        x[: min(n, q)] = neg[: min(n, q)]                                            # embeddings that ARE a canonical phrase: the positive loses against it
+        for pid in (0, 1):
+            got = host(api.R.Relevancy(dev(x), pos, neg, positive_id=pid))
+            ref = O.relevancy(x, pos, neg, positive_id=pid)
+            assert got.shape == (n, 2)
+            assert_close(got, ref, rtol=0, atol=3e-6, what=f"relevancy n={n} q={q} positive {pid}")        # 768-term fp32 dot products in another order, then exp
+            assert_close(got.sum(1), np.ones(n), rtol=0, atol=1e-6)
+        assert got[0, 0] < 1e-3
+    basis = np.linalg.qr(rng.randn(E, 5))[0].T.astype(np.float32)
+    r = host(api.R.Relevancy(dev(np.stack([basis[0], basis[2], basis[4]])), basis[:1], basis[1:4]))
+    assert_close(r[:, 0], [1 / (1 + np.exp(-10.0)), 1 / (1 + np.exp(10.0)), 0.5], rtol=0, atol=1e-6, what="known answers: the positive itself, a negative, orthogonal")
+    with pytest.raises(api.L.NrfError):
+        api.R.Relevancy(dev(basis[:2]), basis[:1], basis[1:1])                        # no negative phrase
+    # the colour map: table == oracle's, image == oracle's byte for byte, the byte -> colour entry too
+    lut = np.empty((256, 3), np.uint8)
+    api.L.check(api.L.lib().nrf_colormap_jet_lut(lut.ctypes.data_as(C.c_void_p)))
+    assert_exact(lut, O.colormap_jet_lut(), "COLORMAP_JET table")
+    rel = rng.rand(4099, 2).astype(np.float32); rel[:6, 0] = [0.0, 1.0, 0.5, 1.5, -0.3, 0.99999]
+    assert_exact(host(api.R.RelevancyImage(dev(rel))), O.relevancy_image(rel), "relevancy image")
+    assert api.R.RelevancyImage(dev(rel.reshape(4099, 1, 2))).shape == (4099, 1, 3)
+    g = torch.arange(0, 256, dtype=torch.uint8, device="cuda").repeat(3)
+    out = torch.empty((768, 3), dtype=torch.uint8, device="cuda")
+    api.L.check(api.L.lib().nrf_colormap_jet_u8(C.c_void_p(g.data_ptr()), C.c_int64(768), C.c_void_p(out.data_ptr()), None))
+    assert_exact(host(out)[256:512], lut, "nrf_colormap_jet_u8")
+
+
+def test_lerf_render_as_one_library_call_equals_the_stagewise_host_loop(api, O):
+    """nrf_lerf_render_rows / nrf_lerf_batchify_rays (LeRFRenderer::Render / BatchifyRays as C calls, lanes inside the library, no torch ops) against the same passes
+    composed stage by stage by the Python host (its own Chunk loop and torch.cat): depths, weights, maps and the rendered embedding identical bit for bit (split
+    precision: same kernels on the same slices, no atomics), for a pose tile and for an explicit ray batch, ragged chunks, 1 / 2 / 3 lanes; Relevancy filled in both."""
+    sc = api.S.make_lerf_scene()
+    r = sc["renderer"]
+    assert r.fused and r.level_major and r._r and r.precision_name == "f16x3"
+    rng = np.random.RandomState(86)
+    pos = rng.randn(1, 768).astype(np.float32); pos /= np.linalg.norm(pos)
+    neg = rng.randn(3, 768).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    p = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=1100, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    lanes0 = r.lanes
+    try:
+        r.SetLeRFPrompts(pos, neg)
+        assert r.GetLeRFPrompts()[1].shape == (3, 768)
+        r.single_call = False
+        ref = r.Render(800, 800, K, p, c2w=c2w, row0=396, rows=5)
+        r.single_call = True
+        for lanes in (1, 2, 3):
+            r.lanes = lanes
+            a = r.Render(800, 800, K, p, c2w=c2w, row0=396, rows=5)
+            assert api.L.lib().nrf_get_render_lanes() in (1, 2), "the library's process-wide lane count is restored after the call"
+            for f in ("WeightsLE", "DepthMapLE", "DispMapLE", "AccMapLE", "RenderedLangEmbedding", "Relevancy"):
+                assert_exact(host(getattr(a.Outputs, f)), host(getattr(ref.Outputs, f)), f"{f}, {lanes} lane(s)")
+            for f in ("z_fine", "z_coarse", "weights_coarse", "rays_flat"):
+                assert_exact(host(a.Extras[f]), host(ref.Extras[f]), f)
+            assert abs(a.Near - ref.Near) == 0 and abs(a.Far - ref.Far) == 0
+        r.lanes = 2
+        rel = host(a.Outputs.Relevancy)
+        assert rel.shape == (4000, 2) and np.isfinite(rel).all() and np.abs(rel.sum(1) - 1).max() < 1e-6
+        assert_close(rel, O.relevancy(host(a.Outputs.RenderedLangEmbedding), pos, neg), rtol=0, atol=3e-6, what="Relevancy of the rendered embeddings vs the oracle")
+        img = host(api.R.RelevancyImage(a.Outputs.Relevancy.reshape(5, 800, 2)))
+        assert img.shape == (5, 800, 3) and (img == O.relevancy_image(rel).reshape(5, 800, 3)).all()
+        # an explicit ray batch (the training-style call, LeRFRenderer.cpp:276-279): BatchifyRays in one call
+        o, d, cone = api.R.GetRays(800, 800, K, c2w, row0=396, rows=5)
+        b = r.Render(800, 800, K, p, rays=(o.reshape(-1, 3), d.reshape(-1, 3), cone))
+        for f in ("WeightsLE", "DepthMapLE", "AccMapLE", "RenderedLangEmbedding", "Relevancy"):
+            assert_exact(host(getattr(b.Outputs, f)), host(getattr(ref.Outputs, f)), f"{f}, ray batch")
+        assert b.Near == ref.Near and b.Far == ref.Far
+        # without ReturnWeights the weights and the embedding are dropped (LeRFRenderer.cpp:180-185); the relevancy is still rendered
+        p2 = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=True, ReturnWeights=False, ThinRay=True, BoundingBox=sc["bbox"])
+        c = r.Render(800, 800, K, p2, c2w=c2w, row0=396, rows=5)
+        assert c.Outputs.WeightsLE is None and c.Outputs.RenderedLangEmbedding is None
+        assert_exact(host(c.Outputs.Relevancy), host(ref.Outputs.Relevancy), "relevancy alone"); assert_exact(host(c.Outputs.DepthMapLE), host(ref.Outputs.DepthMapLE))
+        # the stochastic branches are not part of the render pass: refused, not silently ignored
+        p3 = api.R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=4096, Perturb=1.0, Ndc=False, UseViewdirs=True, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+        with pytest.raises(api.L.NrfError):
+            r.Render(800, 800, K, p3, c2w=c2w, row0=396, rows=1)
+        r.SetLeRFPrompts(None, None)
+        assert r.Render(800, 800, K, p, c2w=c2w, row0=396, rows=1).Outputs.Relevancy is None
+    finally:
+        r.lanes = lanes0; r.single_call = True
+        r.SetLeRFPrompts(None, None)

@@ -555,3 +555,49 @@ def test_oracle_ndc_with_viewdirs_and_staticcam_vs_reference(manifest):
     assert_close(rs[:, 8:], gs["rays_flat"][:, 8:], rtol=3e-7, atol=0)
     outs = O.render_rays(model, gs["rays_flat"], 64, 128, O.linspace(0, 1, 64), O.linspace(0, 1, 128), white_bkgr=True)
     assert_close(outs["rgb"], gs["out_rgb"].reshape(-1, 3), rtol=0, atol=1e-4)
+
+
+def test_relevancy_and_jet_known_answers():
+    """Relevancy (LeRFRenderer.cpp:79) and the relevancy image (NeRFExecutor.h:713-719) -- PARITY UNPINNED (sources external: RuCLIP, OpenCV): the restatement is held to
+    hand-computed answers of the published algorithm and to an independent numpy / torch statement of it at the call sites' shapes."""
+    from oracle import capi as O
+    E = 768
+    rng = np.random.RandomState(79)
+    basis = np.linalg.qr(rng.randn(E, 5))[0].T.astype(np.float32)            # 5 orthonormal phrase / embedding directions
+    pos, neg = basis[:1], basis[1:4]                                          # one positive, three canonical negatives: "[1, 768]", "[3, 768]" (NeRFExecutor.h:744-752)
+    # embedding == the positive phrase: logits (1, 0, 0, 0) -> every pair softmax(10 * (1, 0)) = sigmoid(10)
+    r = O.relevancy(pos, pos, neg)
+    assert r.shape == (1, 2) and abs(r[0, 0] - 1.0 / (1.0 + np.exp(-10.0))) < 1e-6 and abs(r.sum() - 1.0) < 1e-6
+    # embedding == a negative phrase: against THAT negative the positive loses, softmax(10 * (0, 1))[0] = sigmoid(-10) -- the min over negatives picks it
+    r = O.relevancy(neg[1:2], pos, neg)
+    assert abs(r[0, 0] - 1.0 / (1.0 + np.exp(10.0))) < 1e-9 and abs(r[0, 1] - 1.0 / (1.0 + np.exp(-10.0))) < 1e-6
+    # orthogonal to every phrase: all logits 0 -> 0.5 / 0.5
+    r = O.relevancy(basis[4:5], pos, neg)
+    assert np.allclose(r, 0.5, atol=1e-6)
+    # identical negatives tie: the first wins (argmin), the pair is the same either way
+    r = O.relevancy(0.6 * basis[:1] + 0.8 * basis[1:2], pos, np.stack([basis[1], basis[1]]))
+    assert abs(r[0, 0] - 1.0 / (1.0 + np.exp(-10.0 * (0.6 - 0.8)))) < 1e-6
+    # random unit embeddings against the independent torch statement of nerfstudio-lerf's get_relevancy (the function RuCLIP's mirrors)
+    x = rng.randn(257, E).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    ph_p = rng.randn(1, E).astype(np.float32); ph_p /= np.linalg.norm(ph_p); ph_n = rng.randn(3, E).astype(np.float32); ph_n /= np.linalg.norm(ph_n, axis=1, keepdims=True)
+    got = O.relevancy(x, ph_p, ph_n)
+    import torch
+    t = torch.from_numpy
+    out = torch.mm(t(x), torch.cat([t(ph_p), t(ph_n)]).T)
+    sims = torch.stack((out[:, :1].repeat(1, 3), out[:, 1:]), -1)
+    smx = torch.softmax(10 * sims, -1)
+    best = smx[..., 0].argmin(1)
+    ref = torch.gather(smx, 1, best[:, None, None].expand(-1, 3, 2))[:, 0, :].numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+    # COLORMAP_JET: the anchor colours of OpenCV's table (dark blue .. blue .. cyan .. green-ish centre .. yellow .. red .. dark red), B, G, R order; monotone ramps
+    lut = O.colormap_jet_lut()
+    assert lut.shape == (256, 3) and lut.dtype == np.uint8
+    assert lut[0].tolist() == [128, 0, 0] and lut[255].tolist() == [0, 0, 128] and lut[32].tolist() == [255, 0, 0] and lut[223].tolist() == [0, 0, 255]
+    assert lut[96].tolist()[:2] == [254, 255] and lut[159].tolist()[1:] == [255, 254] and lut[64].tolist() == [255, 128, 0] and lut[191].tolist() == [0, 128, 255]
+    assert abs(int(lut[127, 0]) - 130) <= 1 and lut[127, 1] == 255 and abs(int(lut[127, 2]) - 126) <= 1
+    d = np.diff(lut.astype(int), axis=0)
+    assert (np.abs(d) <= 4).all() and (d[:32, 0] >= 0).all() and (d[224:, 2] <= 0).all()            # 4 counts per step on the ramps, none elsewhere
+    # the image: rel[..., 0] * 255 truncated to a byte, then the table
+    rel = np.array([[0.0, 1.0], [0.5, 0.5], [0.999, 0.001], [1.0, 0.0], [1.7, 0.0], [-0.2, 0.0]], np.float32)
+    img = O.relevancy_image(rel)
+    assert img.tolist() == [lut[0].tolist(), lut[127].tolist(), lut[254].tolist(), lut[255].tolist(), lut[255].tolist(), lut[0].tolist()]
