@@ -173,6 +173,7 @@ NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float 
  * finest 512 take 4.4 GiB).  A training loop re-uploads the table every step and sets 0 (no bake); a renderer leaves the default.  Re-bakes immediately when a
  * table is present; synchronises `stream`. */
 NRF_API int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream);
+NRF_API int64_t nrf_hash_get_dense_budget(const nrf_hash *h);
 
 /* CuHashEmbedder mode: the per-level position scales mul_l (host arrays of n_levels floats).  The reference computes them ON THE DEVICE, per thread, as
  * exp2f((log2f(finest) - log2f(base)) * l / (L - 1) + log2f(base)) (CuHashEmbedder.cu:40); nrf_hash_create evaluates the same expression with the host's

@@ -16,7 +16,12 @@
 //                                                RawToOutputs (NeRFRenderer.h:96-158); Render is one library call per pose (nrf_render_rows);
 //                                                BatchifyRays (the host chunk loop) stays inherited for callers that use it directly.
 //                                                TNeRF is the reference's own NeRFSmall / NeRF module: its parameters are
-//                                                read in named_parameters() order (SyncWeights()).
+//                                                read in named_parameters() order (SyncWeights() once; later changes are
+//                                                picked up through ATen's version counters).  With grad mode on and
+//                                                parameters that require grad, Render is ONE autograd node (RenderFn): the
+//                                                reference's loop body -- Render, huber_loss, loss.backward(), Adam::step
+//                                                (NeRFExecutor.h:862-995) -- trains through the HIP path unchanged.
+//   HipHashEmbedderFunction                      the embedder's own autograd node (CuHashEmbedderFunction's counterpart)
 //
 // Compile inside the reference tree with -DNRFPP_WITH_REFERENCE (BaseEmbedder.h / NeRF.h / NeRFRenderer.h on the include
 // path): the classes then derive from the reference's own bases and slot into NeRFExecutor<...>.
@@ -36,6 +41,7 @@
 #include <vector>
 
 #include "nerfpp_hip.h"
+#include "nrf_rng.h"
 
 #ifdef NRFPP_WITH_REFERENCE
 #include "BaseEmbedder.h"
@@ -177,7 +183,8 @@ public:
 	void InitLevels() { for (size_t i = 0; i < LevelEmbeddings->size(); i++) for (auto p : LevelEmbeddings[i]->parameters()) torch::nn::init::uniform_(p, -0.0001, 0.0001); }
 
 	/// The executor calls Initialize() on a freshly built embedder (NeRFExecutor.h:570; HashEmbedder re-draws its tables there, CuHashEmbedder's is empty) -- and the
-	/// library needs the current table / primes pushed to it: both happen here.  After torch::load or an optimizer step call Sync().
+	/// library needs the current table / primes pushed to it: both happen here.  Later changes of the parameters (an optimizer step, torch::load, copy_) are noticed by
+	/// forward() itself through ATen's version counters (SyncIfChanged); after SetPrimes call Sync().
 	void Initialize() { if (Mode == NRF_HASH_NGP) InitLevels(); Sync(); }
 	void SetPrimes(torch::Tensor primes) { torch::NoGradGuard g; Primes.copy_(primes.view_as(Primes)); }
 	/// the table in the layout nrf_hash_set_table takes: CU [L * 2^T, F]; NGP the levels' weights concatenated
@@ -200,17 +207,101 @@ public:
 			check(nrf_hash_set_primes(Handle, p.data_ptr<int32_t>(), b.data()), "nrf_hash_set_primes");
 		}
 		c10::hip::getCurrentHIPStream().synchronize();
+		Synced = true; SyncedSignature = ParamSignature();
 	}
-	std::pair<torch::Tensor, torch::Tensor> forward(torch::Tensor x) override
+	/// The table as ONE tensor in nrf_hash_set_table's layout, still attached to the parameters: CU the `<name>_embeddings` parameter itself, NGP the levels'
+	/// weights concatenated (a differentiable torch::cat, so a gradient w.r.t. this tensor reaches every level's nn::Embedding weight).
+	torch::Tensor TableForGrad()
 	{
-		x = dev_f32(x).view({-1, 3});
-		auto out = torch::empty({x.size(0), GetOutputDims()}, x.options());
-		auto mask = torch::empty({x.size(0)}, x.options().dtype(torch::kUInt8));
-		check(nrf_hash_encode(Handle, x.data_ptr<float>(), x.size(0), out.data_ptr<float>(), mask.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
-		return std::make_pair(out, mask.to(torch::kBool));
+		if (Mode == NRF_HASH_CU) return Embeddings;
+		std::vector<torch::Tensor> lv;
+		for (size_t i = 0; i < LevelEmbeddings->size(); i++) lv.push_back(LevelEmbeddings[i]->as<torch::nn::Embedding>()->weight);
+		return torch::cat(lv, 0);
 	}
+	bool AnyRequiresGrad() { for (auto &p : this->parameters()) if (p.requires_grad()) return true; return false; }
+	/// changes whenever a parameter was written in place (optimizer step, copy_, torch::load) or replaced (->to(device)): ATen's version counters and the storage addresses
+	uint64_t ParamSignature()
+	{
+		uint64_t sig = 1469598103934665603ull;
+		for (auto &p : this->parameters()) { sig = (sig ^ (uint64_t)p._version()) * 1099511628211ull; sig = (sig ^ (uint64_t)(uintptr_t)p.data_ptr()) * 1099511628211ull; }
+		return sig;
+	}
+	/// Upload the table when the parameters changed since the last upload -- device to device on the current stream, no host synchronisation.  Called by every
+	/// forward, so a host that steps an optimizer over parameters() (NeRFExecutor::Train, NeRFExecutor.h:985) needs no extra call.
+	void SyncIfChanged()
+	{
+		const uint64_t sig = ParamSignature();
+		if (Synced && sig == SyncedSignature) return;
+		auto emb = dev_f32(Table().to(torch::kCUDA));
+		check(nrf_hash_set_table(Handle, emb.data_ptr<float>(), 1, current_stream()), "nrf_hash_set_table");
+		if (!Synced && Mode == NRF_HASH_CU) { auto p = Primes.to(torch::kCPU, torch::kInt32).contiguous(); auto b = host_floats(Biases); check(nrf_hash_set_primes(Handle, p.data_ptr<int32_t>(), b.data()), "nrf_hash_set_primes"); }
+		Synced = true; SyncedSignature = sig;
+	}
+	/// Training keeps the table moving: the baked dense pyramid of the render fast path (GBs, re-baked at every table upload) is switched off while gradients flow
+	/// and comes back with the first forward outside grad mode.
+	void SetTraining(bool on)
+	{
+		if (on == TrainingMode) return;
+		if (on) { DenseBudgetBefore = nrf_hash_get_dense_budget(Handle); check(nrf_hash_set_dense_budget(Handle, 0, current_stream()), "nrf_hash_set_dense_budget"); }
+		else check(nrf_hash_set_dense_budget(Handle, DenseBudgetBefore, current_stream()), "nrf_hash_set_dense_budget");
+		TrainingMode = on;
+	}
+	bool WantsGrad() { return torch::GradMode::is_enabled() && AnyRequiresGrad(); }
+
+	std::pair<torch::Tensor, torch::Tensor> forward(torch::Tensor x) override;
+private:
+	bool Synced = false, TrainingMode = false;
+	uint64_t SyncedSignature = 0;
+	int64_t DenseBudgetBefore = 0;
 };
 TORCH_MODULE(HipHashEmbedder);
+
+/// The autograd node of the embedder's forward: what CuHashEmbedderFunction is to CuHashEmbedderImpl::forward (CuHashEmbedder.cpp:85-103, CuHashEmbedder.cu:221-325).
+/// forward: nrf_hash_encode on the table as uploaded; backward: nrf_hash_backward (CuHashEmbedderBackwardKernel's gradient / nn::Embedding's index_add, fp32) w.r.t. the
+/// table tensor -- from where autograd carries it to `<name>_embeddings` / the per-level weights.  The query points get no gradient (as in the reference).
+struct HipHashEmbedderFunction : public torch::autograd::Function<HipHashEmbedderFunction> {
+	static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, torch::Tensor x, torch::Tensor table, int64_t handle)
+	{
+		auto *h = reinterpret_cast<nrf_hash *>(handle);
+		x = dev_f32(x.detach()).view({-1, 3});
+		auto out = torch::empty({x.size(0), (int64_t)nrf_hash_output_dims(h)}, x.options());
+		auto mask = torch::empty({x.size(0)}, x.options().dtype(torch::kUInt8));
+		check(nrf_hash_encode(h, x.data_ptr<float>(), x.size(0), out.data_ptr<float>(), mask.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
+		ctx->save_for_backward({x});
+		ctx->saved_data["handle"] = handle;
+		ctx->saved_data["table_sizes"] = table.sizes().vec();
+		auto keep = mask.to(torch::kBool);
+		ctx->mark_non_differentiable({keep});
+		return {out, keep};
+	}
+	static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+	{
+		auto *h = reinterpret_cast<nrf_hash *>(ctx->saved_data["handle"].toInt());
+		auto x = ctx->get_saved_variables()[0];
+		auto g_table = torch::zeros(ctx->saved_data["table_sizes"].toIntVector(), x.options());
+		if (grads[0].defined()) {
+			auto g = dev_f32(grads[0]);
+			check(nrf_hash_backward(h, x.data_ptr<float>(), x.size(0), g.data_ptr<float>(), g_table.data_ptr<float>(), current_stream()), "nrf_hash_backward");
+		}
+		return {torch::Tensor(), g_table, torch::Tensor()};
+	}
+};
+
+inline std::pair<torch::Tensor, torch::Tensor> HipHashEmbedderImpl::forward(torch::Tensor x)
+{
+	const bool grad = WantsGrad();
+	SetTraining(grad);
+	SyncIfChanged();
+	if (grad) {
+		auto r = HipHashEmbedderFunction::apply(x, TableForGrad(), (int64_t)reinterpret_cast<intptr_t>(Handle));
+		return std::make_pair(r[0], r[1]);
+	}
+	x = dev_f32(x).view({-1, 3});
+	auto out = torch::empty({x.size(0), GetOutputDims()}, x.options());
+	auto mask = torch::empty({x.size(0)}, x.options().dtype(torch::kUInt8));
+	check(nrf_hash_encode(Handle, x.data_ptr<float>(), x.size(0), out.data_ptr<float>(), mask.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
+	return std::make_pair(out, mask.to(torch::kBool));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Multi-GPU: one process per GPU, frames partitioned into contiguous row tiles (nrf_tile_partition), one RCCL all-gather per
@@ -302,9 +393,32 @@ struct MlpHandle {
 // HipLeRFPass holds everything that does not need the reference's headers (so it links and runs without LeRFRenderer.cpp, which pulls in the external
 // RuCLIP module for `Relevancy`); HipLeRFRenderer below subclasses the reference's LeRFRenderer onto it.
 // ---------------------------------------------------------------------------------------------------------------------
-struct LeRFPassOutputs {                 // LeRFRendererOutputs (LeRFRenderer.h:9-18) without Relevancy (external) -- same member names
-	torch::Tensor LangEmbedding, RenderedLangEmbedding, DispMapLE, AccMapLE, WeightsLE, DepthMapLE;
+struct LeRFPassOutputs {                 // LeRFRendererOutputs (LeRFRenderer.h:9-18) -- same member names.  Relevancy: [N, 2], defined when prompts are set
+	torch::Tensor LangEmbedding, RenderedLangEmbedding, DispMapLE, AccMapLE, WeightsLE, DepthMapLE, Relevancy;
 };
+
+/// Relevancy(embeds [N, E], positives [P, E], negatives [Q, E]) -> [N, 2] (call sites LeRFRenderer.cpp:79, NeRFExecutor.h:824).  The reference takes this function from
+/// the external RuCLIP module (RuCLIPProcessor.h); this is the published LERF relevancy score it mirrors -- PARITY UNPINNED (nerfpp_hip.h, nrf_lerf_relevancy).
+inline torch::Tensor Relevancy(torch::Tensor embeds, torch::Tensor positives, torch::Tensor negatives, int positive_id = 0)
+{
+	auto e = dev_f32(embeds);
+	auto pos = positives.to(e.device(), torch::kFloat32).reshape({-1, e.size(1)}).contiguous(), neg = negatives.to(e.device(), torch::kFloat32).reshape({-1, e.size(1)}).contiguous();
+	auto out = torch::empty({e.size(0), 2}, e.options());
+	check(nrf_lerf_relevancy(e.data_ptr<float>(), e.size(0), (int)e.size(1), pos.data_ptr<float>(), (int)pos.size(0), neg.data_ptr<float>(), (int)neg.size(0), positive_id,
+		out.data_ptr<float>(), current_stream()), "nrf_lerf_relevancy");
+	return out;
+}
+
+/// The relevancy picture of RenderPath (NeRFExecutor.h:713-719): rel[..., 0].mul(255).to(kU8) -> COLORMAP_JET, [..., 3] bytes in OpenCV's B, G, R order (parity unpinned)
+inline torch::Tensor RelevancyImage(torch::Tensor relevancy)
+{
+	auto r = dev_f32(relevancy);
+	auto sz = r.sizes().vec(); const int stride = (int)sz.back(); sz.back() = 3;
+	const int64_t n = r.numel() / stride;
+	auto out = torch::empty(sz, r.options().dtype(torch::kUInt8));
+	check(nrf_relevancy_image(r.data_ptr<float>(), n, stride, out.data_ptr<uint8_t>(), current_stream()), "nrf_relevancy_image");
+	return out;
+}
 
 /// nrf_mlp_small_desc of a LeRF module (LeRF.cpp:3-26) from its parameter shapes, named_parameters() order: sigma_le_net_0..L-1, le_net_0..L-1
 template <class TLeRF>
@@ -326,7 +440,62 @@ class HipLeRFPass {
 	nrf_mlp_small_desc Desc{};
 	int Precision;
 	bool Fused = false, LevelMajor = false;
+	nrf_lerf_renderer *Pass = nullptr;       // the render pass as library calls (nrf_lerf_render_rays / _batchify_rays / _render_rows), level-major fused configuration
+	torch::Tensor Workspace, Positives, Negatives;
+	std::vector<std::pair<int, torch::Tensor>> LinCache;
+	torch::Tensor linspace01(int steps, torch::Device dev)
+	{
+		for (auto &e : LinCache) if (e.first == steps && e.second.device() == dev) return e.second;
+		LinCache.emplace_back(steps, torch::linspace(0.f, 1.f, steps, torch::kFloat).to(dev));
+		return LinCache.back().second;
+	}
+	void *workspace(size_t bytes, torch::Device dev)
+	{
+		if (!Workspace.defined() || (size_t)Workspace.numel() < bytes || Workspace.device() != dev) Workspace = torch::empty({(int64_t)bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+		return Workspace.data_ptr();
+	}
+	bool SingleCallOk(int s, int ni) const { return SingleCall && Pass && Fused && LevelMajor && ReuseFeatures && HandOverGeo && ni > 0 && s % 32 == 0 && (s + ni) % 32 == 0; }
+	/// outputs of a single-call render over n rays; `o` receives the tensors, `ro` their addresses
+	void alloc_outputs(int64_t n, int sf, bool return_weights, torch::TensorOptions opt, LeRFPassOutputs &o, nrf_lerf_outputs &ro, torch::Tensor *z_fine)
+	{
+		o.DispMapLE = torch::empty({n}, opt); o.AccMapLE = torch::empty({n}, opt); o.DepthMapLE = torch::empty({n}, opt);
+		ro.d_disp = o.DispMapLE.data_ptr<float>(); ro.d_acc = o.AccMapLE.data_ptr<float>(); ro.d_depth = o.DepthMapLE.data_ptr<float>();
+		if (return_weights) {                                   // LeRFRenderer.cpp:180-185: without ReturnWeights the weights and the rendered embedding are dropped
+			o.WeightsLE = torch::empty({n, (int64_t)sf}, opt); o.RenderedLangEmbedding = torch::empty({n, (int64_t)GetLangEmbedDim()}, opt);
+			ro.d_weights = o.WeightsLE.data_ptr<float>(); ro.d_embedding = o.RenderedLangEmbedding.data_ptr<float>();
+		}
+		if (Positives.defined() && Negatives.defined()) { o.Relevancy = torch::empty({n, 2}, opt); ro.d_relevancy = o.Relevancy.data_ptr<float>(); }      // LeRFRenderer.cpp:79
+		if (z_fine) { *z_fine = torch::empty({n, (int64_t)sf}, opt); ro.d_z_fine = z_fine->data_ptr<float>(); }
+	}
+	nrf_render_params pass_params(int s, int ni, bool lin_disp) const
+	{
+		nrf_render_params p{};
+		p.n_samples = s; p.n_importance = ni; p.lindisp = lin_disp; p.precision = Precision; p.sum_vec = 8;
+		p.coarse_mode = ExactCoarse ? NRF_COARSE_AUTO : NRF_COARSE_FULL;
+		return p;
+	}
 public:
+	HipLeRFPass(const HipLeRFPass &) = delete;
+	HipLeRFPass &operator=(const HipLeRFPass &) = delete;
+	~HipLeRFPass() { nrf_lerf_renderer_destroy(Pass); }
+	bool SingleCall = true;             ///< the pass as library calls (false: stage-composed below, for A/B tests)
+
+	/// LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [P, E] positive and [Q, E] negative phrase embeddings from the host's text encoder; undefined tensors clear them.
+	/// With prompts set every render fills Relevancy.
+	void SetLeRFPrompts(torch::Tensor positives, torch::Tensor negatives)
+	{
+		Positives = positives; Negatives = negatives;
+		PushPrompts();
+	}
+	void PushPrompts()
+	{
+		if (!Pass) return;
+		if (!(Positives.defined() && Negatives.defined() && Positives.numel() && Negatives.numel())) { Positives = torch::Tensor(); Negatives = torch::Tensor(); check(nrf_lerf_set_prompts(Pass, nullptr, 0, nullptr, 0, 0, current_stream()), "nrf_lerf_set_prompts"); return; }
+		auto pos = host_floats(Positives), neg = host_floats(Negatives);
+		const int E = GetLangEmbedDim();
+		check(nrf_lerf_set_prompts(Pass, pos.data(), (int)pos.size() / E, neg.data(), (int)neg.size() / E, 0, current_stream()), "nrf_lerf_set_prompts");
+	}
+
 	/// precision of the fused matrix-core passes: NRF_PREC_F16_SPLIT (fp32-grade, as LeRFImpl::forward computes) or NRF_PREC_F16_MFMA
 	explicit HipLeRFPass(HipHashEmbedder lang_embed_fn, int precision = NRF_PREC_F16_SPLIT) : LangEmbedFn(lang_embed_fn), Precision(precision) {}
 
@@ -344,6 +513,12 @@ public:
 		Fused = nrf_lerf_mfma_available(m) != 0;
 		if (Fused) check(nrf_lerf_set_precision(m, Precision), "nrf_lerf_set_precision");
 		LevelMajor = Fused && LangEmbedFn->Mode == NRF_HASH_CU && LangEmbedFn->NLevels == 16 && LangEmbedFn->NFeaturesPerLevel == 8;
+		nrf_lerf_renderer_destroy(Pass); Pass = nullptr;
+		if (LevelMajor) {
+			nrf_lerf_renderer_desc rd{LangEmbedFn->GetHandle(), Mlp.m};
+			check(nrf_lerf_renderer_create(&rd, &Pass), "nrf_lerf_renderer_create");
+			PushPrompts();
+		}
 	}
 	template <class TLeRF> void SyncWeights(TLeRF &lerf) { SyncWeights(lerf_desc_of(lerf), parameter_blob(lerf)); }
 
@@ -499,6 +674,16 @@ public:
 		auto z = torch::empty({n, s}, opt);
 		check(nrf_z_vals(rays.data_ptr<float>(), stride, n, t.data_ptr<float>(), s, lin_disp, z.data_ptr<float>(), current_stream()), "nrf_z_vals");
 		auto rays_d = rays.index({Slice(), Slice(3, 6)}).contiguous();
+		if (SingleCallOk(s, ni) && n * (int64_t)(s + ni) < ((int64_t)1 << 31)) {
+			// the whole chunk as ONE library call (nrf_lerf_render_rays): no torch ops, Relevancy included when prompts are set
+			LeRFPassOutputs out; nrf_lerf_outputs ro{};
+			alloc_outputs(n, s + ni, return_weights, opt, out, ro, z_fine);
+			nrf_render_params p = pass_params(s, ni, lin_disp);
+			const size_t wsb = nrf_lerf_render_rays_workspace_bytes(Pass, n, &p);
+			check(nrf_lerf_render_rays(Pass, rays.data_ptr<float>(), stride, n, &p, linspace01(s, rays.device()).data_ptr<float>(), linspace01(ni, rays.device()).data_ptr<float>(), &ro,
+				workspace(wsb, rays.device()), wsb, current_stream()), "nrf_lerf_render_rays");
+			return out;
+		}
 		const bool fused = Fused && s % 32 == 0 && (ni == 0 || (s + ni) % 32 == 0);
 		auto stage = [&](torch::Tensor zz) {
 			auto pts = torch::empty({n, zz.size(1), 3}, opt);
@@ -507,6 +692,7 @@ public:
 		};
 		if (fused && LevelMajor && ReuseFeatures && ni > 0 && n * (int64_t)(s + ni) < ((int64_t)1 << 31)) {
 			LeRFPassOutputs out = FusedPassesReusing(rays, z, rays_d, ni, z_fine);
+			if (Positives.defined() && Negatives.defined()) out.Relevancy = Relevancy(out.RenderedLangEmbedding, Positives, Negatives);      // LeRFRenderer.cpp:79
 			if (!return_weights) { out.WeightsLE = torch::Tensor(); out.LangEmbedding = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }
 			return out;
 		}
@@ -518,6 +704,7 @@ public:
 			out = fused ? FusedPass(rays, zf, rays_d, true) : stage(zf);
 			if (z_fine) *z_fine = zf;
 		}
+		if (Positives.defined() && Negatives.defined() && out.RenderedLangEmbedding.defined()) out.Relevancy = Relevancy(out.RenderedLangEmbedding, Positives, Negatives);      // LeRFRenderer.cpp:79
 		if (!return_weights) { out.WeightsLE = torch::Tensor(); out.LangEmbedding = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }      // LeRFRenderer.cpp:180-185
 		return out;
 	}
@@ -531,6 +718,27 @@ public:
 		if (rows < 0) rows = h - row0;
 		const auto dev = torch::Device(torch::kCUDA, c10::hip::getCurrentHIPStream().device_index());
 		auto K = host_floats(k), M = host_floats(c2w.index({torch::indexing::Slice(torch::indexing::None, 3), torch::indexing::Slice(torch::indexing::None, 4)}));
+		if (SingleCallOk(n_samples, n_importance)) {
+			// LeRFRenderer::Render as ONE library call (nrf_lerf_render_rows): rays, AABB clipping, the Chunk loop on the library's lanes, Relevancy, the tile's Near / Far
+			nrf_view v{};
+			v.h = h; v.w = w; v.row0 = row0; v.rows = rows; v.use_viewdirs = use_viewdirs; v.ndc = 0; v.chunk = chunk;
+			for (int i = 0; i < 9; i++) v.K[i] = K[i];
+			for (int i = 0; i < 12; i++) v.c2w[i] = M[i];
+			auto bbv = host_floats(bounding_box);
+			TORCH_CHECK(bbv.size() == 6, "Render: bounding_box must hold [min xyz, max xyz]");
+			for (int i = 0; i < 6; i++) v.bbox[i] = bbv[i];
+			const auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
+			const int64_t nr = (int64_t)rows * w;
+			LeRFPassOutputs out; nrf_lerf_outputs ro{};
+			alloc_outputs(nr, n_samples + n_importance, return_weights, opt, out, ro, nullptr);
+			nrf_render_params p = pass_params(n_samples, n_importance, lin_disp);
+			auto nf = torch::empty({2}, opt);
+			const size_t wsb = nrf_lerf_render_rows_workspace_bytes(Pass, &v, &p);
+			check(nrf_lerf_render_rows(Pass, &v, &p, linspace01(n_samples, dev).data_ptr<float>(), linspace01(n_importance, dev).data_ptr<float>(), &ro, nullptr, nf.data_ptr<float>(),
+				workspace(wsb, dev), wsb, current_stream()), "nrf_lerf_render_rows");
+			if (near_out || far_out) { auto nfh = nf.cpu(); if (near_out) *near_out = nfh[0].item<float>(); if (far_out) *far_out = nfh[1].item<float>(); }
+			return out;
+		}
 		auto o = torch::empty({(int64_t)rows * w, 3}, torch::TensorOptions().dtype(torch::kFloat32).device(dev)), d = torch::empty_like(o);
 		check(nrf_get_rays(h, w, K.data(), M.data(), row0, rows, o.data_ptr<float>(), d.data_ptr<float>(), nullptr, current_stream()), "nrf_get_rays");
 		const int64_t n = o.size(0);
@@ -538,16 +746,18 @@ public:
 		auto bb = host_floats(bounding_box);
 		auto rays_ = torch::empty({n, stride}, o.options());
 		check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, use_viewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
-		std::vector<torch::Tensor> e, w_, dep, disp, acc;
+		std::vector<torch::Tensor> e, w_, dep, disp, acc, rel;
 		for (int64_t i = 0; i < n; i += chunk) {
 			auto part = RenderRays(rays_.index({torch::indexing::Slice(i, std::min<int64_t>(i + chunk, n))}), n_samples, lin_disp, n_importance, return_weights);
 			if (part.RenderedLangEmbedding.defined()) e.push_back(part.RenderedLangEmbedding);
 			if (part.WeightsLE.defined()) w_.push_back(part.WeightsLE);
+			if (part.Relevancy.defined()) rel.push_back(part.Relevancy);
 			dep.push_back(part.DepthMapLE); disp.push_back(part.DispMapLE); acc.push_back(part.AccMapLE);
 		}
 		LeRFPassOutputs out;
 		if (!e.empty()) out.RenderedLangEmbedding = torch::cat(e, 0);
 		if (!w_.empty()) out.WeightsLE = torch::cat(w_, 0);
+		if (!rel.empty()) out.Relevancy = torch::cat(rel, 0);
 		out.DepthMapLE = torch::cat(dep, 0); out.DispMapLE = torch::cat(disp, 0); out.AccMapLE = torch::cat(acc, 0);
 		float nr = 0.f, fr = 0.f;
 		check(nrf_near_far_range(rays_.data_ptr<float>(), n, stride, &nr, &fr, current_stream()), "nrf_near_far_range");
@@ -570,6 +780,10 @@ class HipNeRFRenderer : public NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> {
 	int Precision;
 	uint64_t Seed = 0;        ///seed of the counter-based draws of the stochastic branches (include/nrf_rng.h)
 	int64_t RayCursor = 0;    ///rays already rendered by the current Render() call: makes the draws independent of Chunk
+	nrf_mlp_small_desc Small{};   ///the NeRFSmall description given to SyncWeights (training path: nrf_mlp_backward is built for this family)
+	bool HasSmall = false;
+	uint64_t MlpSignature = 0;    ///ATen version counters + storage addresses of the network's parameters at the last upload
+	uint64_t TrainCalls = 0;      ///training renders so far: every one draws afresh from the counter RNG, as the reference does from torch's global generator
 
 	void *workspace(size_t bytes, torch::Device dev)
 	{
@@ -593,6 +807,9 @@ public:
 		if (small) { TORCH_CHECK((int64_t)blob.size() == nrf_mlp_small_param_count(small), "NeRFSmall parameter count mismatch"); check(nrf_mlp_small_create(small, blob.data(), 0, current_stream(), &m), "nrf_mlp_small_create"); }
 		else { TORCH_CHECK((int64_t)blob.size() == nrf_mlp_nerf_param_count(classic), "NeRF parameter count mismatch"); check(nrf_mlp_nerf_create(classic, blob.data(), 0, current_stream(), &m), "nrf_mlp_nerf_create"); }
 		Mlp.reset(m);
+		HasSmall = small != nullptr;
+		if (small) Small = *small;
+		MlpSignature = MlpSignatureOf();
 		nrf_renderer_destroy(Renderer); Renderer = nullptr;
 		nrf_renderer_desc d{};
 		if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) { this->EmbedFn->Sync(); d.hash = this->EmbedFn->GetHandle(); }
@@ -603,10 +820,164 @@ public:
 		check(nrf_renderer_create(&d, &Renderer), "nrf_renderer_create");
 	}
 
+	uint64_t MlpSignatureOf()
+	{
+		uint64_t sig = 1469598103934665603ull;
+		for (auto &p : this->NeRF->parameters()) { sig = (sig ^ (uint64_t)p._version()) * 1099511628211ull; sig = (sig ^ (uint64_t)(uintptr_t)p.data_ptr()) * 1099511628211ull; }
+		return sig;
+	}
+	/// the network's parameters as one blob in named_parameters() order (== the blob order of nerfpp_hip.h), still attached to them: a gradient w.r.t. this tensor
+	/// reaches every Linear weight through torch::cat's backward
+	torch::Tensor BlobForGrad()
+	{
+		std::vector<torch::Tensor> flat;
+		for (auto &p : this->NeRF->named_parameters()) flat.push_back(p.value().reshape({-1}));
+		return torch::cat(flat, 0);
+	}
+	/// Upload the network's parameters when they changed since the last upload (optimizer step, torch::load, copy_): the host never has to call SyncWeights again
+	/// after construction -- NeRFExecutor::Train steps its optimizer and renders test views without knowing about this class (NeRFExecutor.h:985, :1007-1042).
+	void SyncIfChanged()
+	{
+		TORCH_CHECK(Renderer != nullptr, "HipNeRFRenderer: call SyncWeights(small | classic description) once after construction");
+		const uint64_t sig = MlpSignatureOf();
+		if (sig != MlpSignature) {
+			torch::NoGradGuard ng;
+			torch::Tensor blob = BlobForGrad().to(torch::kFloat32).contiguous();
+			check(nrf_mlp_set_params(Mlp.m, blob.data_ptr<float>(), blob.is_cuda() ? 1 : 0, current_stream()), "nrf_mlp_set_params");
+			MlpSignature = sig;
+		}
+		if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) this->EmbedFn->SyncIfChanged();
+	}
+	bool WantsGrad()
+	{
+		if (!torch::GradMode::is_enabled()) return false;
+		for (auto &p : this->NeRF->parameters()) if (p.requires_grad()) return true;
+		if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) return this->EmbedFn->AnyRequiresGrad();
+		return false;
+	}
+
+	// ---- the training render: NeRFRenderer::Render on a ray batch as ONE autograd node (NeRFExecutor.h:876-923: Render -> huber_loss -> loss.backward()) ----
+	struct TrainState {           // what the backward needs besides the saved tensors
+		HipNeRFRenderer *self; int s; bool fine; bool white_bkgr; float noise_std, precond_alpha, cone_angle; bool has_cone; uint64_t seed; std::vector<float> bbox;
+	};
+	/// forward: rays_ [n, 8 | 11] -> {rgb, disp, acc, depth, weights | empty, raw}; gradients flow to `table` and `blob` from d loss / d rgb only (the fine pass:
+	/// z_samples are detached, NeRFRenderer.h:429; disparity / accumulation / depth / weights / raw are marked non-differentiable -- the reference's loss reads RGBMap, :882-887)
+	struct RenderFn : public torch::autograd::Function<RenderFn> {
+		static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, torch::Tensor rays_, torch::Tensor table, torch::Tensor blob, int64_t self_i, int64_t rp_i,
+			double cone_value)          // < 0: thin rays
+		{
+			torch::Tensor cone_angle; if (cone_value >= 0.0) cone_angle = torch::tensor((float)cone_value);
+			auto *self = reinterpret_cast<HipNeRFRenderer *>(self_i);
+			const NeRFRenderParams &rp = *reinterpret_cast<const NeRFRenderParams *>(rp_i);
+			const int64_t n = rays_.size(0); const int stride = (int)rays_.size(1);
+			const int s = rp.NSamples, ni = rp.NImportance, so = ni > 0 ? s + ni : s;
+			const auto opt = rays_.options();
+			auto rgb = torch::empty({n, 3}, opt), disp = torch::empty({n}, opt), acc = torch::empty({n}, opt), depth = torch::empty({n}, opt);
+			auto weights = rp.ReturnWeights ? torch::empty({n, (int64_t)so}, opt) : torch::Tensor();
+			auto raw = torch::empty({n, (int64_t)so, 4}, opt), z = torch::empty({n, (int64_t)so}, opt);
+			nrf_render_outputs ro{};
+			ro.d_rgb = rgb.data_ptr<float>(); ro.d_disp = disp.data_ptr<float>(); ro.d_acc = acc.data_ptr<float>(); ro.d_depth = depth.data_ptr<float>();
+			ro.d_weights = rp.ReturnWeights ? weights.data_ptr<float>() : nullptr;
+			ro.d_raw = raw.data_ptr<float>();
+			if (ni > 0) ro.d_z_fine = z.data_ptr<float>(); else ro.d_z_coarse = z.data_ptr<float>();
+			nrf_render_params p = self->make_params(rp, cone_angle, 0);
+			p.seed = self->Seed + 0x9E3779B97F4A7C15ull * self->TrainCalls++;
+			torch::Tensor t = self->linspace01(s, rays_.device());
+			torch::Tensor u; if (ni > 0) u = self->linspace01(ni, rays_.device());
+			if (n > 0) {
+				const size_t wsb = nrf_batchify_rays_workspace_bytes(self->Renderer, n, rp.Chunk, &p);
+				check(nrf_batchify_rays(self->Renderer, rays_.data_ptr<float>(), stride, n, rp.Chunk, &p, t.data_ptr<float>(), u.defined() ? u.data_ptr<float>() : nullptr, &ro,
+					self->workspace(wsb, rays_.device()), wsb, current_stream()), "nrf_batchify_rays");
+			}
+			ctx->save_for_backward({rays_, raw, z});
+			auto *st = new TrainState{self, so, ni > 0, (bool)rp.WhiteBkgr, rp.RawNoiseStd, ni > 0 ? rp.StochasticPreconditioningAlpha : 0.f, p.cone_angle, p.has_cone != 0, p.seed,
+				p.has_bbox ? std::vector<float>(p.bbox, p.bbox + 6) : std::vector<float>()};
+			ctx->saved_data["state"] = (int64_t)reinterpret_cast<intptr_t>(st);
+			ctx->saved_data["table_sizes"] = table.sizes().vec();
+			ctx->saved_data["blob_numel"] = blob.numel();
+			std::vector<torch::Tensor> nd{disp, acc, depth, raw};
+			if (weights.defined()) nd.push_back(weights);
+			ctx->mark_non_differentiable(nd);
+			return {rgb, disp, acc, depth, weights.defined() ? weights : torch::empty({0}, opt), raw};
+		}
+		static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+		{
+			std::unique_ptr<TrainState> st(reinterpret_cast<TrainState *>(ctx->saved_data["state"].toInt()));
+			ctx->saved_data["state"] = (int64_t)0;
+			auto saved = ctx->get_saved_variables();
+			auto [g_table, g_blob] = st->self->TrainBackward(*st, saved[0], saved[1], saved[2], grads[0], ctx->saved_data["table_sizes"].toIntVector(), ctx->saved_data["blob_numel"].toInt());
+			return {torch::Tensor(), g_table, g_blob, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+		}
+	};
+
+	torch::Tensor rng_fill(uint64_t seed, uint32_t stream, int64_t count, bool normal, torch::TensorOptions opt)
+	{
+		auto out = torch::empty({count}, opt);
+		check(nrf_rng_fill(seed, stream, 0, count, normal, out.data_ptr<float>(), current_stream()), "nrf_rng_fill");
+		return out;
+	}
+
+	/// d loss / d RGBMap -> (d loss / d table, d loss / d blob): RawToOutputs' backward (TruncExp's clamp included) -> the keep mask -> the network (fp32 layer-wise
+	/// kernels, pinned to the reference's autograd by golden `train_hash`) -> the hash grid.  The sample points of the forward are re-formed from the saved depths; the
+	/// draws of its stochastic branches (cone rays, preconditioning, raw noise) are regenerated from the same (seed, stream, index) of the counter RNG.
+	std::pair<torch::Tensor, torch::Tensor> TrainBackward(const TrainState &st, torch::Tensor rays, torch::Tensor raw, torch::Tensor z, torch::Tensor g_rgb_in,
+		std::vector<int64_t> table_sizes, int64_t blob_numel)
+	{
+		const int64_t n = rays.size(0); const int stride = (int)rays.size(1), s = st.s;
+		const auto opt = rays.options();
+		auto g_table = torch::zeros(table_sizes, opt), g_blob = torch::zeros({blob_numel}, opt);
+		if (n == 0 || !g_rgb_in.defined()) return {g_table, g_blob};
+		if constexpr (!std::is_same_v<TEmbedder, HipHashEmbedder>) { TORCH_CHECK(false, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration"); }
+		else {
+			auto g_rgb = dev_f32(g_rgb_in).reshape({n, 3});
+			auto g_raw = torch::empty_like(raw);
+			torch::Tensor noise;
+			if (st.noise_std > 0.f) noise = rng_fill(st.seed, st.fine ? NRF_RNG_NOISE_FINE : NRF_RNG_NOISE_COARSE, n * s, true, opt);
+			check(nrf_raw2outputs_backward_noise(raw.data_ptr<float>(), z.data_ptr<float>(), rays.data_ptr<float>() + 3, stride, n, s, 4, st.white_bkgr,
+				noise.defined() ? noise.data_ptr<float>() : nullptr, st.noise_std, g_rgb.data_ptr<float>(), g_raw.data_ptr<float>(), current_stream()), "nrf_raw2outputs_backward");
+			auto pts = torch::empty({n * s, 3}, opt);
+			check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
+			const float *bb = st.bbox.size() == 6 ? st.bbox.data() : nullptr;
+			if (st.precond_alpha > 0.f) {          // NeRFRenderer.h:433-443 (fine pass only)
+				TORCH_CHECK(bb, "stochastic preconditioning needs the bounding box");
+				torch::Tensor pn = rng_fill(st.seed, NRF_RNG_PRECOND, n * s * 3, true, opt);
+				auto out = torch::empty_like(pts);
+				check(nrf_precondition(pts.data_ptr<float>(), pn.data_ptr<float>(), st.precond_alpha, bb, n * s, out.data_ptr<float>(), current_stream()), "nrf_precondition");
+				pts = out;
+			}
+			if (st.has_cone) {                     // TangentScatter, NeRFRenderer.h:307-362
+				torch::Tensor ur = rng_fill(st.seed, st.fine ? NRF_RNG_R_FINE : NRF_RNG_R_COARSE, n * s, false, opt), ut = rng_fill(st.seed, st.fine ? NRF_RNG_THETA_FINE : NRF_RNG_THETA_COARSE, n * s, false, opt);
+				auto out = torch::empty_like(pts);
+				check(nrf_tangent_scatter(pts.data_ptr<float>(), rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, st.cone_angle, ur.data_ptr<float>(), ut.data_ptr<float>(), bb,
+					out.data_ptr<float>(), current_stream()), "nrf_tangent_scatter");
+				pts = out;
+			}
+			const nrf_hash *h = this->EmbedFn->GetHandle();
+			const int in_ch = this->EmbedFn->GetOutputDims();
+			auto emb = torch::empty({n * s, (int64_t)in_ch}, opt);
+			auto keep = torch::empty({n * s}, opt.dtype(torch::kUInt8));
+			check(nrf_hash_encode(h, pts.data_ptr<float>(), n * s, emb.data_ptr<float>(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
+			torch::Tensor x = emb;
+			if (stride == 11) {                    // UseViewdirs: the direction encoding of each ray, repeated for its samples (NeRFRenderer.h:179-181)
+				using torch::indexing::Slice;
+				torch::Tensor dirs = this->EmbeddirsFn->forward(rays.index({Slice(), Slice(8, 11)}).contiguous()).first;
+				x = torch::cat({emb, dirs.unsqueeze(1).expand({n, (int64_t)s, dirs.size(1)}).reshape({n * s, dirs.size(1)})}, 1).contiguous();
+			}
+			check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
+			auto g_x = torch::empty({n * s, (int64_t)in_ch}, opt);
+			const size_t wsb = nrf_mlp_backward_workspace_bytes(Mlp.m, n * s);
+			check(nrf_mlp_backward(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(), workspace(wsb, rays.device()), wsb,
+				current_stream()), "nrf_mlp_backward");
+			check(nrf_hash_backward_rays(h, pts.data_ptr<float>(), n, s, g_x.data_ptr<float>(), g_table.data_ptr<float>(), current_stream()), "nrf_hash_backward_rays");
+		}
+		return {g_table, g_blob};
+	}
+
 protected:
 	/// NeRFRenderer.h:164-194
 	torch::Tensor RunNetwork(torch::Tensor inputs, torch::Tensor view_dirs, TNeRF fn, TEmbedder embed_fn, TEmbedDirs embeddirs_fn) override
 	{
+		SyncIfChanged();
 		auto pts = dev_f32(inputs);
 		const int64_t n = pts.size(0); const int s = (int)pts.size(1);
 		torch::Tensor vd; if (view_dirs.defined() && view_dirs.numel()) vd = dev_f32(view_dirs);
@@ -773,7 +1144,23 @@ private:
 			else check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, render_params.UseViewdirs, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
 		}
 		NeRFRenderResult all_ret;
-		if (LibraryChunkLoop) {
+		const bool train = WantsGrad();
+		if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) this->EmbedFn->SetTraining(train);
+		SyncIfChanged();
+		if (train) {
+			// NeRFExecutor::Train's render (NeRFExecutor.h:876): one autograd node over the library's Chunk loop; loss.backward() then reaches the embedder's and the network's
+			// parameters exactly where the reference's autograd puts their gradients
+			TORCH_CHECK(HasSmall, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration (nrf_mlp_backward)");
+			if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) {
+				if (from_pose) check(nrf_view_rays(&v, rays_.data_ptr<float>(), nf.data_ptr<float>(), current_stream()), "nrf_view_rays");
+				auto outs = RenderFn::apply(rays_, this->EmbedFn->TableForGrad(), BlobForGrad(), (int64_t)reinterpret_cast<intptr_t>(this), (int64_t)reinterpret_cast<intptr_t>(&render_params),
+					(!render_params.ThinRay && cone_angle.defined() && cone_angle.numel()) ? (double)cone_angle.cpu().template item<float>() : -1.0);
+				auto &o = all_ret.Outputs;
+				o.RGBMap = outs[0]; o.DispMap = outs[1]; o.AccMap = outs[2]; o.DepthMap = outs[3];
+				if (render_params.ReturnWeights) o.Weights = outs[4];
+				if (render_params.ReturnRaw) all_ret.Raw = outs[5];
+			} else TORCH_CHECK(false, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration");
+		} else if (LibraryChunkLoop) {
 			auto &o = all_ret.Outputs;
 			o.RGBMap = torch::empty({n, 3}, opt); o.DispMap = torch::empty({n}, opt); o.AccMap = torch::empty({n}, opt); o.DepthMap = torch::empty({n}, opt);
 			if (render_params.ReturnWeights) o.Weights = torch::empty({n, (int64_t)so}, opt);
@@ -820,6 +1207,7 @@ public:
 		const float raw_noise_std = 0.f, const float stochastic_preconditioning_alpha = 0.f, torch::Tensor bounding_box = torch::Tensor(),
 		const bool return_weights = true) override
 	{
+		SyncIfChanged();
 		auto rays = dev_f32(ray_batch);
 		const int64_t n = rays.size(0); const int stride = (int)rays.size(1);
 		const int sf = n_samples + n_importance, so = n_importance > 0 ? sf : n_samples;
@@ -857,8 +1245,8 @@ public:
 // HipLeRFRenderer : LeRFRenderer (LeRFRenderer.h:56-132).  Needs the reference's LeRFRenderer.h on the include path and LeRFRenderer.cpp in the link (the
 // base class's vtable and its Render / BatchifyRays live there; that unit includes RuCLIPProcessor.h, LeRFRenderer.cpp:2, for `Relevancy`, :79 -- the external
 // RuCLIP module, which is why this class can only be COMPILED, not linked, where RuCLIP is absent).  The base keeps a null CuHashEmbedder: every path that would
-// touch it (RunLENetwork) is overridden.  Outputs.Relevancy is left undefined here; callers that want it apply RuCLIP's Relevancy(RenderedLangEmbedding,
-// positives, negatives) to the result, as LeRFRenderer.cpp:79 does.
+// touch it (RunLENetwork) is overridden.  Outputs.Relevancy is filled when prompts are set (SetLeRFPrompts): nrf_lerf_relevancy, the published LERF relevancy score that
+// RuCLIP's function mirrors -- parity unpinned (nerfpp_hip.h).
 // ---------------------------------------------------------------------------------------------------------------------
 #include "LeRFRenderer.h"
 
@@ -871,8 +1259,16 @@ class HipLeRFRenderer : public LeRFRenderer {
 	{
 		LeRFRendererOutputs o;
 		o.LangEmbedding = p.LangEmbedding; o.RenderedLangEmbedding = p.RenderedLangEmbedding; o.DispMapLE = p.DispMapLE; o.AccMapLE = p.AccMapLE;
-		o.WeightsLE = p.WeightsLE; o.DepthMapLE = p.DepthMapLE;
+		o.WeightsLE = p.WeightsLE; o.DepthMapLE = p.DepthMapLE; o.Relevancy = p.Relevancy;
 		return o;
+	}
+	/// the base keeps the prompts (SetLeRFPrompts is not virtual, LeRFRenderer.h:86): hand them to the pass when they changed
+	torch::Tensor SeenPos, SeenNeg;
+	void SyncPrompts()
+	{
+		if (LerfPositives.is_same(SeenPos) && LerfNegatives.is_same(SeenNeg)) return;
+		Pass.SetLeRFPrompts(LerfPositives, LerfNegatives);
+		SeenPos = LerfPositives; SeenNeg = LerfNegatives;
 	}
 protected:
 	torch::Tensor RunLENetwork(torch::Tensor inputs, LeRF lerf, CuHashEmbedder lang_embed_fn) override { return Pass.RunLENetwork(inputs); }
@@ -897,8 +1293,31 @@ public:
 		if (rng || return_raw)
 			return LeRFRenderer::RenderRays(ray_batch, cone_angle, n_samples, return_raw, lin_disp, perturb, n_importance, white_bkgr, raw_noise_std,
 				stochastic_preconditioning_alpha, bounding_box, return_weights);
+		SyncPrompts();
 		LeRFRenderResult res;
 		res.Outputs = to_ref(Pass.RenderRays(ray_batch, n_samples, lin_disp, n_importance, return_weights));
+		return res;
+	}
+
+	/// LeRFRenderer.cpp:265-330.  A deterministic pose render is ONE library call (nrf_lerf_render_rows: rays, the Chunk loop on the library's lanes, Relevancy,
+	/// Near / Far); everything else takes the inherited path, whose RenderRays calls land on the override above.
+	LeRFRenderResult Render(const int h, const int w, torch::Tensor k, const NeRFRenderParams &render_params,
+		std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays = {torch::Tensor(), torch::Tensor(), torch::Tensor()}, torch::Tensor c2w = torch::Tensor(),
+		torch::Tensor c2w_staticcam = torch::Tensor()) override
+	{
+		const NeRFRenderParams &p = render_params;
+		const bool rng = p.Perturb > 0.f || p.RawNoiseStd > 0.f || p.StochasticPreconditioningAlpha > 0.f || !p.ThinRay;
+		const bool pose = c2w.defined() && c2w.numel() != 0 && !(c2w_staticcam.defined() && c2w_staticcam.numel() != 0);
+		if (rng || p.ReturnRaw || p.Ndc || !pose || p.NImportance <= 0 || p.NSamples % 32 || (p.NSamples + p.NImportance) % 32)
+			return LeRFRenderer::Render(h, w, k, render_params, rays, c2w, c2w_staticcam);
+		SyncPrompts();
+		LeRFRenderResult res;
+		res.Outputs = to_ref(Pass.Render(h, w, k, p.BoundingBox, p.NSamples, p.NImportance, p.Chunk, c2w, p.UseViewdirs, p.LinDisp, p.ReturnWeights, &res.Near, &res.Far));
+		// LeRFRenderer.cpp:311-328: per-pixel maps reshaped to the frame
+		if (res.Outputs.RenderedLangEmbedding.defined()) res.Outputs.RenderedLangEmbedding = res.Outputs.RenderedLangEmbedding.reshape({h, w, -1});
+		if (res.Outputs.Relevancy.defined() && res.Outputs.Relevancy.numel() != 0) res.Outputs.Relevancy = res.Outputs.Relevancy.reshape({h, w, 2});
+		if (res.Outputs.DispMapLE.defined()) res.Outputs.DispMapLE = res.Outputs.DispMapLE.reshape({h, w});
+		if (res.Outputs.DepthMapLE.defined()) res.Outputs.DepthMapLE = res.Outputs.DepthMapLE.reshape({h, w});
 		return res;
 	}
 };

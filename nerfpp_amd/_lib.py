@@ -70,7 +70,7 @@ SYMBOLS = [
     "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_pack_rays_viewsrc", "nrf_view_rays", "nrf_near_far_range", "nrf_linspace", "nrf_z_vals", "nrf_points",
     "nrf_precrop_bounds", "nrf_rand_pixels", "nrf_ray_batch", "nrf_gather_pixels",
     "nrf_pe_encode", "nrf_sh_encode",
-    "nrf_hash_create", "nrf_hash_destroy", "nrf_hash_output_dims", "nrf_hash_table_elems", "nrf_hash_set_table", "nrf_hash_set_primes", "nrf_hash_set_dense_budget", "nrf_hash_get_level_scales", "nrf_hash_set_level_scales",
+    "nrf_hash_create", "nrf_hash_destroy", "nrf_hash_output_dims", "nrf_hash_table_elems", "nrf_hash_set_table", "nrf_hash_set_primes", "nrf_hash_set_dense_budget", "nrf_hash_get_dense_budget", "nrf_hash_get_level_scales", "nrf_hash_set_level_scales",
     "nrf_hash_encode",
     "nrf_mlp_small_param_count", "nrf_mlp_nerf_param_count", "nrf_mlp_small_create", "nrf_mlp_nerf_create", "nrf_mlp_destroy",
     "nrf_mlp_output_dims", "nrf_mlp_forward",
@@ -109,6 +109,7 @@ def lib():
         L.nrf_last_error.restype = C.c_char_p
         L.nrf_status_string.restype = C.c_char_p
         L.nrf_hash_table_elems.restype = C.c_int64
+        L.nrf_hash_get_dense_budget.restype = C.c_int64
         L.nrf_mlp_small_param_count.restype = C.c_int64
         L.nrf_mlp_nerf_param_count.restype = C.c_int64
         L.nrf_mlp_lerf_param_count.restype = C.c_int64

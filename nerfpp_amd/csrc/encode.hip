@@ -374,6 +374,8 @@ int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream)
     return hash_fast_prepare(h, h->dense_budget, as_stream(stream));
 }
 
+int64_t nrf_hash_get_dense_budget(const nrf_hash *h) { return h ? (int64_t)h->dense_budget : 0; }
+
 int nrf_hash_get_level_scales(const nrf_hash *h, float *scales_out)
 {
     NRF_CHECK_ARG(h && scales_out, "nrf_hash_get_level_scales: null pointer");

@@ -510,7 +510,12 @@ def _clip_embedding(e, stride, dim, w):
 def Relevancy(embeds, positives, negatives, positive_id=0):
     """Relevancy(embeds [N, E], positives [P, E], negatives [Q, E]) -> [N, 2] (call sites LeRFRenderer.cpp:79, NeRFExecutor.h:824).  The function's source is external
     (DeliriumV01D/RuCLIP): this is the published LERF relevancy score it mirrors -- PARITY UNPINNED (include/nerfpp_hip.h, nrf_lerf_relevancy)."""
-    e = _dev_f32(embeds); pos = _dev_f32(positives).to(e.device); neg = _dev_f32(negatives).to(e.device)
+    e = _dev_f32(embeds)
+
+    def phrases(x):           # the prompt embeddings come from the host's text encoder: a host array or a tensor on any device
+        x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        return x.to(device=e.device, dtype=torch.float32).reshape(-1, e.shape[1]).contiguous()
+    pos, neg = phrases(positives), phrases(negatives)
     out = torch.empty((e.shape[0], 2), device=e.device, dtype=torch.float32)
     L.check(L.lib().nrf_lerf_relevancy(_ptr(e), C.c_int64(e.shape[0]), int(e.shape[1]), _ptr(pos), int(pos.shape[0]), _ptr(neg), int(neg.shape[0]), int(positive_id),
                                        _ptr(out), _stream()))

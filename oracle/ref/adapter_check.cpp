@@ -59,8 +59,124 @@ static torch::Tensor orbit_pose(float theta_deg, float phi_deg, float radius)
 
 static void stage(const char *what) { if (getenv("NRF_ADAPTER_TRACE")) { fprintf(stderr, "[adapter_check] %s\n", what); fflush(stderr); } }
 
+// ---- `adapter_check train <dir>`: the reference's optimisation loop body (NeRFExecutor.h:862-995), statement for statement, on the HIP drop-in ----
+// Optimizer->zero_grad(); NeRFRenderer->Render(0, 0, Tensor(), params, {rays_o, rays_d, cone}); mse_loss; huber_loss; loss.backward(); Optimizer->step() -- with
+// HipNeRFRenderer<HipHashEmbedder(LibTorch twin), HipSHEncoder, NeRFSmall> in the place of the reference's renderer and torch::optim::Adam over the modules'
+// own parameters (NeRFExecutor.h:508-539).  Inputs (golden group train_hash: rays, target, initial parameters) are read from raw fp32 files in <dir>; the loss, the
+// rendered pixels, the step-1 gradients and the parameters after each of two steps are written back there, and tests/test_gpu_parity.py compares them with what the
+// reference's own CPU autograd produced (tests/golden/train_hash.npz).
+static torch::Tensor read_f32(const std::string &path, std::vector<int64_t> shape)
+{
+	int64_t n = 1; for (auto v : shape) n *= v;
+	auto t = torch::empty({n}, torch::kFloat32);
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f || fread(t.data_ptr<float>(), 4, (size_t)n, f) != (size_t)n) throw std::runtime_error("cannot read " + path);
+	fclose(f);
+	return t.view(shape);
+}
+
+static void write_f32(const std::string &path, torch::Tensor t)
+{
+	auto c = t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f || fwrite(c.data_ptr<float>(), 4, (size_t)c.numel(), f) != (size_t)c.numel()) throw std::runtime_error("cannot write " + path);
+	fclose(f);
+}
+
+static int run_train(const std::string &dir)
+{
+	if (!torch::cuda::is_available()) { printf("{\"train_ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
+	std::string note = "ok";
+	bool ok = false, standalone_embedder_grad_ok = false, inference_sees_updates = false;
+	float loss1 = 0.f, loss2 = 0.f;
+	try {
+		const int h = 8, w = 8, ns = 32, ni = 32;
+		auto bbox = read_f32(dir + "/bbox.f32", {6});
+		auto o = read_f32(dir + "/rays_o.f32", {h * w, 3}).cuda(), d = read_f32(dir + "/rays_d.f32", {h * w, 3}).cuda(), target = read_f32(dir + "/target.f32", {h * w, 3}).cuda();
+		nrfpp::HipHashEmbedder e("embedder", bbox, 4, 2, 12, 16, 128, NRF_HASH_NGP);
+		nrfpp::HipSHEncoder ed("embeddirs", 3, 4, NRF_SH_LIBTORCH);
+		NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 8, 16, "model");
+		m->to(torch::kCUDA);
+		{
+			torch::NoGradGuard ng;
+			for (auto &p : e->named_parameters()) p.value().copy_(read_f32(dir + "/init_" + p.key() + ".f32", p.value().sizes().vec()));
+			for (auto &p : m->named_parameters()) p.value().copy_(read_f32(dir + "/init_" + p.key() + ".f32", p.value().sizes().vec()));
+		}
+		e->Initialize();                                   // NGP mode would re-draw the tables (NeRFExecutor.h:570): put the golden's back
+		{
+			torch::NoGradGuard ng;
+			for (auto &p : e->named_parameters()) p.value().copy_(read_f32(dir + "/init_" + p.key() + ".f32", p.value().sizes().vec()));
+		}
+		nrfpp::HipNeRFRenderer<nrfpp::HipHashEmbedder, nrfpp::HipSHEncoder, NeRFSmall> renderer(e, ed, m, NRF_PREC_F32);
+		nrf_mlp_small_desc sd{8, 16, 3, 64, 15, 3, 64};
+		renderer.SyncWeights(&sd, nullptr);                // once, at construction; never again below
+		std::vector<torch::Tensor> grad_vars;              // NeRFExecutor.h:508-535: embedder first, then the model
+		for (auto &p : e->parameters()) grad_vars.push_back(p);
+		for (auto &p : m->parameters()) grad_vars.push_back(p);
+		const float lr = read_f32(dir + "/lr.f32", {1})[0].item<float>();
+		torch::optim::Adam opt(grad_vars, torch::optim::AdamOptions(lr).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));      // :539
+		NeRFRenderParams rp;
+		rp.NSamples = ns; rp.NImportance = ni; rp.Chunk = h * w; rp.ReturnRaw = true; rp.LinDisp = false; rp.Perturb = 0.f; rp.WhiteBkgr = false; rp.RawNoiseStd = 0.f;
+		rp.Ndc = false; rp.UseViewdirs = true; rp.ReturnWeights = true; rp.ThinRay = true; rp.RenderFactor = 0; rp.BoundingBox = bbox.cuda(); rp.StochasticPreconditioningAlpha = 0.f;
+		for (int step = 1; step <= 2; step++) {
+			const std::string st = dir + "/out_s" + std::to_string(step) + "_";
+			opt.zero_grad();                                                                                                // :866
+			auto res = renderer.Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()}, torch::Tensor(), torch::Tensor());   // :876
+			auto mse_loss = torch::mse_loss(res.Outputs.RGBMap, target.detach());                                           // :882
+			auto img_loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, target.detach());                         // :883
+			auto loss = img_loss;
+			loss.backward();                                                                                                // :923
+			write_f32(st + "loss.f32", loss.reshape({1})); write_f32(st + "mse.f32", mse_loss.reshape({1})); write_f32(st + "rgb.f32", res.Outputs.RGBMap);
+			(step == 1 ? loss1 : loss2) = loss.item<float>();
+			if (step == 1) {
+				for (auto &p : e->named_parameters()) write_f32(st + "grad_" + p.key() + ".f32", p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value()));
+				for (auto &p : m->named_parameters()) write_f32(st + "grad_" + p.key() + ".f32", p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value()));
+			}
+			opt.step();                                                                                                     // :985
+			for (auto &p : e->named_parameters()) write_f32(st + "param_" + p.key() + ".f32", p.value());
+			for (auto &p : m->named_parameters()) write_f32(st + "param_" + p.key() + ".f32", p.value());
+		}
+		// the test-time render that follows in the reference's loop (NoGradGuard, :1007-1042) must see the stepped parameters without any call into this repo's classes:
+		// it has to equal a render by a freshly built renderer given the same parameters
+		{
+			torch::NoGradGuard ng;
+			auto after = renderer.Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()}, torch::Tensor(), torch::Tensor());
+			nrfpp::HipHashEmbedder e2("embedder", bbox, 4, 2, 12, 16, 128, NRF_HASH_NGP);
+			auto pe = e->named_parameters(); auto pe2 = e2->named_parameters();
+			for (size_t i = 0; i < pe.size(); i++) pe2[i].value().copy_(pe[i].value());
+			e2->Sync();
+			nrfpp::HipNeRFRenderer<nrfpp::HipHashEmbedder, nrfpp::HipSHEncoder, NeRFSmall> fresh(e2, ed, m, NRF_PREC_F32);
+			fresh.SyncWeights(&sd, nullptr);
+			auto want = fresh.Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()}, torch::Tensor(), torch::Tensor());
+			inference_sees_updates = torch::equal(after.Outputs.RGBMap, want.Outputs.RGBMap) && !after.Outputs.RGBMap.requires_grad();
+		}
+		// the embedder on its own is an autograd function too (CuHashEmbedderFunction's counterpart): d sum(emb * c) / d table against the same gradient taken
+		// through the library's stage call
+		{
+			auto x = (torch::rand({777, 3}) * 2.8f - 1.4f).cuda();
+			auto c = torch::randn({777, 8}).cuda();
+			for (auto &p : e->parameters()) if (p.grad().defined()) p.grad().zero_();
+			auto [emb, keep] = e->forward(x);
+			(emb * c).sum().backward();
+			auto g_ref = torch::zeros({4 * 4096, 2}, x.options());
+			nrfpp::check(nrf_hash_backward(e->GetHandle(), x.data_ptr<float>(), 777, c.data_ptr<float>(), g_ref.data_ptr<float>(), nrfpp::current_stream()), "nrf_hash_backward");
+			std::vector<torch::Tensor> gl;
+			for (auto &p : e->parameters()) gl.push_back(p.grad());
+			auto g_got = torch::cat(gl, 0);
+			standalone_embedder_grad_ok = emb.requires_grad() && !keep.requires_grad() && g_got.abs().max().item<float>() > 0.f &&
+				(g_got - g_ref).abs().max().item<float>() <= 1e-6f * g_ref.abs().max().item<float>();      // float atomics: order-free up to rounding
+		}
+		ok = std::isfinite(loss1) && std::isfinite(loss2) && inference_sees_updates && standalone_embedder_grad_ok;
+	} catch (const std::exception &ex) { note = ex.what(); for (auto &ch : note) if (ch == '"' || ch == '\n') ch = ' '; note = note.substr(0, 400); }
+	printf("{\"train_ok\": %s, \"loss_step1\": %.9g, \"loss_step2\": %.9g, \"inference_after_steps_sees_updated_parameters\": %s, \"standalone_embedder_autograd_ok\": %s, \"note\": \"%s\"}\n",
+		ok ? "true" : "false", loss1, loss2, inference_sees_updates ? "true" : "false", standalone_embedder_grad_ok ? "true" : "false", note.c_str());
+	fflush(stdout);
+	return ok ? 0 : 1;
+}
+
 int main(int argc, const char **argv)
 {
+	if (argc > 2 && std::string(argv[1]) == "train") return run_train(argv[2]);
 	const int h = argc > 1 ? atoi(argv[1]) : 16, w = argc > 2 ? atoi(argv[2]) : 16;
 	if (!torch::cuda::is_available()) { printf("{\"ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
 	std::streambuf *cout_buf = std::cout.rdbuf();
@@ -257,7 +373,7 @@ int main(int argc, const char **argv)
 	// ---- LeRF render pass (BASELINE config 4): nrfpp::HipLeRFPass -- what HipLeRFRenderer : LeRFRenderer forwards to -- against the reference's own LeRF module
 	// (LeRF.cpp, LibTorch CPU) and RenderCLIPEmbedding (LeRFRenderer.h:45-54) on the same sample points.  The language hash grid is CUDA-only in the
 	// reference (CuHashEmbedder), so its features come from the HIP encoder on both sides.
-	bool lerf_ok = false, lerf_fused = false, lerf_reuse_same = false;
+	bool lerf_ok = false, lerf_fused = false, lerf_reuse_same = false, lerf_single_same = false, lerf_relevancy_ok = false;
 	double lerf_cos_min = 0.0, lerf_w_err = 1.0, lerf_f16_cos_min = 0.0;
 	std::string lerf_note = "ok";
 	try {
@@ -321,13 +437,36 @@ int main(int argc, const char **argv)
 		auto got16 = pass16.RenderRays(rays_, 64, false, 128, true);
 		auto cos16 = (got16.RenderedLangEmbedding.cpu() * emb_ref).sum(-1).index({hit});
 		lerf_f16_cos_min = cos16.numel() ? cos16.min().item<double>() : 0.0;
-		lerf_ok = lerf_fused && lerf_reuse_same && hit.sum().item<int64_t>() > (int64_t)h * w / 8 && lerf_cos_min > 1.0 - 2e-6 && lerf_w_err < 1e-5 && torch::isfinite(got.RenderedLangEmbedding).all().item<bool>();
+		// the pass as ONE library call (nrf_lerf_render_rays / nrf_lerf_render_rows, the default) against the stage-composed host loop: same kernels on the same slices; and
+		// Relevancy (LeRFRenderer.cpp:79; parity unpinned) filled by the call itself == the stage function applied to the rendered embedding
+		{
+			pass.SingleCall = false;
+			torch::Tensor zf3;
+			auto staged = pass.RenderRays(rays_, 64, false, 128, true, &zf3);
+			pass.SingleCall = true;
+			lerf_single_same = torch::equal(zf, zf3) && torch::equal(got.WeightsLE, staged.WeightsLE) && torch::equal(got.RenderedLangEmbedding, staged.RenderedLangEmbedding) &&
+				torch::equal(got.DepthMapLE, staged.DepthMapLE);
+			auto posp = torch::nn::functional::normalize(torch::randn({1, 768}), torch::nn::functional::NormalizeFuncOptions().dim(-1));
+			auto negp = torch::nn::functional::normalize(torch::randn({3, 768}), torch::nn::functional::NormalizeFuncOptions().dim(-1));
+			pass.SetLeRFPrompts(posp, negp);
+			float nr = 0.f, fr = 0.f;
+			auto frame = pass.Render(h, w, K, bbox, 64, 128, 100, c2w, true, false, true, &nr, &fr);          // pose render, ragged chunks, lanes inside the library
+			auto rel_stage = nrfpp::Relevancy(frame.RenderedLangEmbedding, posp, negp);
+			auto img = nrfpp::RelevancyImage(frame.Relevancy.reshape({h, w, 2}));
+			lerf_relevancy_ok = frame.Relevancy.defined() && frame.Relevancy.sizes() == std::vector<int64_t>({(int64_t)h * w, 2}) && torch::equal(frame.Relevancy, rel_stage) &&
+				(frame.Relevancy.sum(-1) - 1.f).abs().max().item<float>() < 1e-6f && torch::equal(frame.RenderedLangEmbedding, got.RenderedLangEmbedding) &&
+				img.sizes() == std::vector<int64_t>({h, w, 3}) && img.dtype() == torch::kUInt8 && nr > 0.f && fr > nr;
+			pass.SetLeRFPrompts(torch::Tensor(), torch::Tensor());
+			lerf_relevancy_ok = lerf_relevancy_ok && !pass.RenderRays(rays_, 64, false, 128, true).Relevancy.defined();
+		}
+		lerf_ok = lerf_fused && lerf_reuse_same && lerf_single_same && lerf_relevancy_ok && hit.sum().item<int64_t>() > (int64_t)h * w / 8 && lerf_cos_min > 1.0 - 2e-6 && lerf_w_err < 1e-5 &&
+			torch::isfinite(got.RenderedLangEmbedding).all().item<bool>();
 	} catch (const std::exception &ex) { lerf_note = ex.what(); for (auto &ch : lerf_note) if (ch == '"' || ch == '\n') ch = ' '; }
 	stage("LeRF section done");
 	ok = ok && lerf_ok;
 	std::cout.rdbuf(cout_buf);
-	printf("{\"lerf_pass_ok\": %s, \"lerf_fused\": %s, \"lerf_feature_reuse_equals_two_passes\": %s, \"lerf_split_cos_min_vs_reference_head\": %.9f, \"lerf_split_weights_max_abs_err\": %.3e, \"lerf_f16_cos_min\": %.6f, \"lerf_note\": \"%s\"}\n",
-		lerf_ok ? "true" : "false", lerf_fused ? "true" : "false", lerf_reuse_same ? "true" : "false", lerf_cos_min, lerf_w_err, lerf_f16_cos_min, lerf_note.c_str());
+	printf("{\"lerf_pass_ok\": %s, \"lerf_fused\": %s, \"lerf_single_library_call_equals_host_loop\": %s, \"lerf_relevancy_ok\": %s, \"lerf_feature_reuse_equals_two_passes\": %s, \"lerf_split_cos_min_vs_reference_head\": %.9f, \"lerf_split_weights_max_abs_err\": %.3e, \"lerf_f16_cos_min\": %.6f, \"lerf_note\": \"%s\"}\n",
+		lerf_ok ? "true" : "false", lerf_fused ? "true" : "false", lerf_single_same ? "true" : "false", lerf_relevancy_ok ? "true" : "false", lerf_reuse_same ? "true" : "false", lerf_cos_min, lerf_w_err, lerf_f16_cos_min, lerf_note.c_str());
 	printf("{\"module_state_ok\": %s, \"parameter_names_equal_reference\": %s, \"cu_from_scratch_primes_table_buffers_ok\": %s, \"zero_primes_rejected\": %s, \"torch_load_cu_fixture\": %s, "
 		"\"torch_load_ngp_fixture_forward_bit_exact\": %s, \"adapter_checkpoints_saved\": %s, \"chunk_loop_library_equals_reference_batchify\": %s, \"ndc_viewdirs_ok\": %s, "
 		"\"staticcam_ok\": %s, \"state_note\": \"%s\"}\n", (cu_scratch_ok && zero_primes_rejected) ? "true" : "false", names_equal ? "true" : "false", cu_scratch_ok ? "true" : "false",

@@ -483,6 +483,7 @@ def test_libtorch_adapter_drop_in_inside_reference_renderer(tmp_path):
     assert r["render_tile_equals_slice"] and r["render_sharded_world1_equals_render"], r     # multi-GPU surface: RenderTile / RenderSharded over a TileComm (world of one)
     lr = json.loads(lines[-3])                                                        # the LeRF pass: HipLeRFPass (what HipLeRFRenderer forwards to) vs the reference's LeRF module
     assert lr["lerf_pass_ok"] and lr["lerf_fused"], lr
+    assert lr["lerf_single_library_call_equals_host_loop"] and lr["lerf_relevancy_ok"], lr            # nrf_lerf_render_rays / _render_rows behind HipLeRFPass; Relevancy filled
     assert lr["lerf_split_cos_min_vs_reference_head"] > 1 - 2e-6 and lr["lerf_split_weights_max_abs_err"] < 1e-5, lr
     # module state of the drop-in
     assert ms["module_state_ok"] and ms["parameter_names_equal_reference"] and ms["cu_from_scratch_primes_table_buffers_ok"] and ms["zero_primes_rejected"], ms
@@ -2551,3 +2552,74 @@ def test_lerf_render_as_one_library_call_equals_the_stagewise_host_loop(api, O):
     finally:
         r.lanes = lanes0; r.single_call = True
         r.SetLeRFPrompts(None, None)
+
+
+def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manifest):
+    """The drop-in trains under the reference's own host code: oracle/_ref/adapter_check `train` executes the statements of NeRFExecutor::Train's loop body
+    (NeRFExecutor.h:862-995: Optimizer->zero_grad, NeRFRenderer->Render on a ray batch, mse_loss, huber_loss, loss.backward(), Optimizer->step()) with
+    HipNeRFRenderer<HipHashEmbedder, HipSHEncoder, NeRFSmall> in the renderer's place and torch::optim::Adam over the modules' own parameters -- Render is one autograd
+    node (nerfpp_torch.h, RenderFn), nothing of this repo is called between the steps.  Loss, pixels, the step-1 gradients of every parameter and the parameters after
+    two Adam steps against what the reference's CPU autograd produced (golden train_hash), at the tolerances of the stage-wise test above."""
+    import json, os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    g = load_golden("train_hash")
+    d = str(tmp_path)
+    for k in ("bbox", "rays_o", "rays_d", "target", "lr"):
+        np.ascontiguousarray(g[k], np.float32).tofile(os.path.join(d, k + ".f32"))
+    names = []
+    for ent in manifest["train_hash"]:          # (name, seed, amp, shape): the seeds the golden generator filled the reference's modules with
+        synth.blob_from_manifest([ent]).astype(np.float32).tofile(os.path.join(d, f"init_{ent[0]}.f32"))
+        names.append((ent[0], ent[3]))
+    assert len(names) == 10
+    out = subprocess.run([exe, "train", d], capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert out.returncode == 0 and r["train_ok"], (r, out.stderr[-1500:])
+    assert r["inference_after_steps_sees_updated_parameters"] and r["standalone_embedder_autograd_ok"], r
+    rd = lambda f, shape: np.fromfile(os.path.join(d, f), np.float32).reshape(shape)
+    lr = float(g["lr"][0])
+    # end to end the loss inherits the render's own distance to the reference's CPU render (a few fine samples in other CDF bins, 64 rays only): the bounds of
+    # test_trainer_two_steps_vs_reference, which runs the same chain through the Python host
+    assert abs(rd("out_s1_loss.f32", (1,))[0] - g["s1_loss"][0]) < 2e-4 and abs(rd("out_s1_mse.f32", (1,))[0] - g["s1_mse"][0]) < 4e-4
+    d1 = np.abs(rd("out_s1_rgb.f32", (64, 3)) - g["s1_rgb"])
+    assert np.median(d1) < 1e-5 and (d1 < 1e-4).mean() > 0.9, (np.median(d1), (d1 < 1e-4).mean())
+    # the gradients: (a) against the reference's autograd -- the rays whose fine sample set moved (above) contribute their whole difference, hence a norm-wise bound;
+    # (b) against the Python host's Trainer on the same HIP forward (the chain test_training_backward_stages_vs_reference_autograd pins stage by stage to the
+    # reference's autograd): the same kernels in the same order, so equal up to the order of the float atomics
+    from nerfpp_amd.train import Trainer
+    api_ = type("Api", (), dict(L=__import__("nerfpp_amd._lib", fromlist=["x"]), M=__import__("nerfpp_amd.modules", fromlist=["x"]), R=__import__("nerfpp_amd.renderer", fromlist=["x"])))
+    gg, table, blob, e, ed, m = _train_golden(api_, manifest)
+    tr = Trainer(e, ed, m, table, blob, learning_rate=lr)
+    rp = api_.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=64, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=g["bbox"],
+                                 Precision=api_.L.NRF_PREC_F32)
+    lm1, _ = tr.step(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["target"]), rp)
+    assert abs(host(lm1)[0] - rd("out_s1_loss.f32", (1,))[0]) < 1e-7, "same forward: same loss"
+    py = dict(zip([n for n, _ in names], np.split(np.concatenate([host(tr.g_table), host(tr.g_blob)]), np.cumsum([int(np.prod(sh)) for _, sh in names])[:-1])))
+    for name, shape in names:
+        ref = g[f"s1_grad_{name}"].astype(np.float64); got = rd(f"out_s1_grad_{name}.f32", ref.shape).astype(np.float64)
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert rel < 8e-2, (name, rel)
+        assert_close(got, py[name].reshape(ref.shape), rtol=1e-4, atol=1e-6 * np.abs(py[name]).max(), what=f"d loss / d {name}: C++ autograd node vs the Python Trainer's chain")
+    # the parameters after the two Adam steps.  Adam's first steps are ~lr * sign(g) (m / sqrt(v) = g / |g|, eps 1e-15): a weight whose gradient is rounding-level noise
+    # moves by +-lr either way, so against the reference's CPU run the comparison bounds the SHARE of such weights (as test_trainer_two_steps_vs_reference does; the hash
+    # table has many entries that only the moved rays touch) -- and against the Python host's Trainer stepping the same HIP chain it is tight
+    lm2, _ = tr.step(dev(g["rays_o"]), dev(g["rays_d"]), dev(g["target"]), rp)
+    py2 = dict(zip([n for n, _ in names], np.split(np.concatenate([host(tr.table), host(tr.blob)]), np.cumsum([int(np.prod(sh)) for _, sh in names])[:-1])))
+    for step in (1, 2):
+        for name, shape in names:
+            ref = g[f"s{step}_param_{name}"]
+            got = rd(f"out_s{step}_param_{name}.f32", ref.shape)
+            dd = np.abs(got - ref) / lr
+            table = "embeddings" in name
+            # (step 2 continues from this run's own step 1 -- the loop is the reference's, not a restart from its state -- and so carries step 1's sign noise)
+            assert dd.mean() < (0.08 if table else 0.03) * step and (dd > 0.05).mean() < ((0.2 if table else 0.05) if step == 1 else 0.35), (name, step, dd.mean(), (dd > 0.05).mean())
+            if step == 2:
+                dp = np.abs(got - py2[name].reshape(ref.shape)) / lr
+                assert (dp > 0.05).mean() < 0.05 and np.median(dp) < 1e-2, (name, (dp > 0.05).mean(), np.median(dp))       # float atomics in another order: the sign of a cancelling sum
+        assert abs(rd(f"out_s{step}_loss.f32", (1,))[0] - g[f"s{step}_loss"][0]) < 3e-4
+    assert abs(host(lm2)[0] - rd("out_s2_loss.f32", (1,))[0]) < 2e-5
+    assert r["loss_step2"] < r["loss_step1"]
