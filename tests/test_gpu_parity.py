@@ -2381,7 +2381,7 @@ def test_bench_launcher_two_ranks_share_the_gpu_and_reproduce_the_single_rank_fr
     gathered 800x800 frame must equal the single-rank frame bit for bit (sha256 of the pixel buffer, printed in both result lines)."""
     import json, os, subprocess, sys
     from conftest import ROOT
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-also"]
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-parity", "--no-also"]      # two warm-up steps: the first timed Render of two ranks SHARING a GPU must not carry one-time work
     env = dict(os.environ, NRF_BENCH_TIMEOUT="600")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -2621,5 +2621,35 @@ def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manife
                 dp = np.abs(got - py2[name].reshape(ref.shape)) / lr
                 assert (dp > 0.05).mean() < 0.05 and np.median(dp) < 1e-2, (name, (dp > 0.05).mean(), np.median(dp))       # float atomics in another order: the sign of a cancelling sum
         assert abs(rd(f"out_s{step}_loss.f32", (1,))[0] - g[f"s{step}_loss"][0]) < 3e-4
-    assert abs(host(lm2)[0] - rd("out_s2_loss.f32", (1,))[0]) < 2e-5
+    assert abs(host(lm2)[0] - rd("out_s2_loss.f32", (1,))[0]) < 2e-4          # two runs of the same chain: step 1 leaves a per-cent of the weights lr apart (sign of a cancelling atomic sum)
     assert r["loss_step2"] < r["loss_step1"]
+
+
+def test_two_real_rccl_ranks_gather_the_single_rank_frame(tmp_path):
+    """Config 4 on REAL RCCL, where the box has two GPUs (the driver's SCALE node; skipped on the one-GPU box, where two ranks can only share a device over gloo):
+    (a) tests/helpers/rccl_two_rank_worker.py under torch.distributed.run -- uneven row tiles through the ncclBroadcast group of nrf_allgather_tiles and even ones through
+    ncclAllGather, synchronous and overlapped, against torch.distributed's collective and against the full frame; nrf_comm_world == 2 on a communicator made by the
+    bounded (blocking) rendezvous;  (b) `bench.py --gpus 2 --collective cabi` on nccl: the gathered 800x800 frame's sha256 == the single-rank frame's."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), NRF_BENCH_TIMEOUT="600")
+    # a world of ONE through the same worker (every box): the bounded rendezvous' helper-thread ncclCommInitRank, both gather forms, real RCCL
+    w1 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_two_rank_worker.py")], capture_output=True, text=True, timeout=600,
+                        env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29552"))
+    l = [json.loads(x) for x in w1.stdout.splitlines() if x.startswith("{")]
+    assert w1.returncode == 0 and len(l) == 1 and l[0]["ok"] and l[0]["ranks_seen_by_rccl"] == 1, (w1.stdout[-1500:], w1.stderr[-1500:])
+    if torch.cuda.device_count() < 2:
+        pytest.skip("the two-rank part needs two GPUs (RCCL refuses two ranks on one device); the world-of-one part passed")
+    w = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29553",
+                        os.path.join(ROOT, "tests", "helpers", "rccl_two_rank_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    lines = [json.loads(x) for x in w.stdout.splitlines() if x.startswith("{")]
+    assert w.returncode == 0 and len(lines) == 2 and all(l["ok"] and l["ranks_seen_by_rccl"] == 2 for l in lines), (w.stdout[-2000:], w.stderr[-2000:])
+    assert any(f["rows"] == 3 for l in lines for f in l["frames"].values()) and any(f["rows"] == 2 for l in lines for f in l["frames"].values()), "uneven tiles: 3 + 2 rows of 5"
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-also", "--no-isolated"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--collective", "cabi"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1500:], two.stderr[-1500:])
+    l1 = json.loads([x for x in one.stdout.splitlines() if x.startswith("{")][-1]); l2 = json.loads([x for x in two.stdout.splitlines() if x.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["ranks_seen_by_rccl"] == 2 and l2["scaling"] == "strong" and l2["tile_rows"] == 400
+    assert l1["frame_sha256"] == l2["frame_sha256"] and "==" in l2["collective_check"], l2.get("collective_check")
+    assert len(two.stdout.splitlines()[-1]) < 4096
