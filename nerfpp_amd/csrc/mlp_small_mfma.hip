@@ -24,6 +24,8 @@
 // work of a kernel that was not MFMA-bound to begin with.  The doubled weight image (80 KB) is shared by 8 waves per workgroup.
 #include "mlp.h"
 
+#include <type_traits>
+
 namespace nrf {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -140,13 +142,15 @@ struct NoJob { __device__ __forceinline__ void operator()(int, int, int, int) co
 // The A fragments of the whole network lie in LDS in consumption order, so the fragment(s) of step i + 1 -- the next k-step, m-tile or
 // LAYER -- are simply the next 1 (2) KB: they are fetched at the top of step i and arrive while its products run.  `pre` carries them
 // from step to step and from layer to layer (fetched = false only for the very last step of the network).
-template <int MT, int KS, int NP, bool BLO, bool LAST = false, bool FINE = false, class Job = NoJob>
+template <int MT, int KS, int NP, bool BLO, bool LAST = false, bool FINE = false, int DROP = 0, class Job = NoJob>
 __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int lane, const half8 (&b)[PT][KS][NP], f32x16 (&acc)[PT][MT], half8 (&pre)[NP],
                                            Job job = Job())
 {
     // the first product of every accumulator takes the literal zero as its C operand (an inline constant of the MFMA encoding)
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int NG = (NP == 2 ? (BLO ? 3 : 2) : 1) * PT;          // matrix instructions per step
+    constexpr bool P_WL = NP == 2 && !(DROP & 1);                   // Wl . xh
+    constexpr bool P_XL = NP == 2 && BLO && !(DROP & 2);            // Wh . xl
+    constexpr int NG = (NP == 2 ? ((P_WL ? 1 : 0) + (P_XL ? 1 : 0) + 1) : 1) * PT;          // matrix instructions per step
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -166,14 +170,19 @@ __device__ __forceinline__ void gemm_layer(const half8 *__restrict__ frags, int 
             };
             if constexpr (NP == 2) {
                 // small terms first, the leading product last
+                bool first = ks == 0;
+                if constexpr (P_WL) {
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0); after(); }
-                if constexpr (BLO) {
+                    for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[pt][ks][0], first ? zero : acc[pt][mt], 0, 0, 0); after(); }
+                    first = false;
+                }
+                if constexpr (P_XL) {
 #pragma unroll
-                    for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], acc[pt][mt], 0, 0, 0); after(); }
+                    for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][1], first ? zero : acc[pt][mt], 0, 0, 0); after(); }
+                    first = false;
                 }
 #pragma unroll
-                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], acc[pt][mt], 0, 0, 0); after(); }
+                for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], first ? zero : acc[pt][mt], 0, 0, 0); after(); }
             } else {
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) { acc[pt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[pt][ks][0], ks == 0 ? zero : acc[pt][mt], 0, 0, 0); after(); }
@@ -240,6 +249,13 @@ struct SmallInput {
 #ifndef NRF_SMALL_FINE
 #define NRF_SMALL_FINE 1            // split mode: conversion work dealt out per matrix instruction (0: one block per step)
 #endif
+// Per-layer product budget of the split mode (tools/product_budget.py): layer ids 0..NL-1 = sigma net, NL.. = colour net.  Bit 2 id drops the
+// Wl.xh product of layer id (the weights' rounding residuals), bit 2 id + 1 drops Wh.xl (the activations' residuals -- their (lo) halves are then not formed either).
+// 0 (the shipped build): all three products everywhere.
+#ifndef NRF_SMALL_DROP_MASK
+#define NRF_SMALL_DROP_MASK 0
+#endif
+constexpr int small_drop_of(int id) { return (int)((((unsigned long long)NRF_SMALL_DROP_MASK) >> (2 * id)) & 3ull); }
 
 // LMLO: the level-major features come as (hi, lo) planes (fp32-valued features of the LibTorch HashEmbedder); without it they are exact
 // fp16 numbers (CuHashEmbedder rounds its output to fp16 itself, CuHashEmbedder.cu:95) and the layer-0 operand has no lo part.
@@ -432,7 +448,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         float qm[4];
         uint32_t qc[2];
-        auto conv_half = [&](int buf, int t, int i, int q, int part) {
+        auto conv_half = [&](int buf, int t, int i, int q, int part, bool need_lo) __attribute__((always_inline)) {
             (void)qm; (void)qc;
             if constexpr (SPLIT) {
                 const int pt = i >> 1, sh = i & 1;
@@ -463,6 +479,11 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                     for (int e = 0; e < 4; e++) qm[e] = fmaxf(acc2[pt][t][8 * sh + 4 * q + e], 0.0f);
                     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(qc[0]) : "v"(qm[0]), "v"(qm[1]));
                     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(qc[1]) : "v"(qm[2]), "v"(qm[3]));
+                } else if (!need_lo) {
+                    // (product budget builds) the consuming layer drops its Wh.xl product: the residuals are not formed
+                    u32x4 hv = __builtin_bit_cast(u32x4, bh[buf][pt][2 * t + sh][0]);
+                    hv[2 * q] = qc[0]; hv[2 * q + 1] = qc[1];
+                    bh[buf][pt][2 * t + sh][0] = __builtin_bit_cast(half8, hv);
                 } else {
                     uint32_t l0, l1;
                     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(qc[0]), "v"(qm[0]));
@@ -489,22 +510,31 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         // FINE (split mode): the items of a step are cut into half-quad units (4 per item) and dealt out over the step's ng matrix instructions, unit u after
         // instruction floor(u * ng / units); otherwise the step's items follow its last matrix instruction as one block.
         constexpr bool FINE = SPLIT && PIPE && (NRF_SMALL_FINE != 0) && V_KS == 1;      // the 64-wide direction encodings (SH degree 8) are at the register limit already
-        auto make_job = [&](int bi, bool conv_prev_tile1, bool conv_this_tile0, int ks_count) {
-            return [=, &conv_item, &conv_half](int mt, int ks, int g, int ng) {
+        // LoPrev / LoNext (std::bool_constant): does the layer that consumes the previous layer's tile 1 (= this layer) / this layer's tile 0 (= the next layer) use the
+        // (lo) halves?  Types, not values: every conv_half call site then carries a literal, and the register arrays stay registers (a run-time flag here sent them to scratch)
+        auto make_job = [&](int bi, bool conv_prev_tile1, bool conv_this_tile0, int ks_count, auto lo_prev_t, auto lo_next_t) __attribute__((always_inline)) {
+            return [=, &conv_item, &conv_half](int mt, int ks, int g, int ng) __attribute__((always_inline)) {
                 (void)conv_item; (void)conv_half;           // not referenced when PIPE is off for this instantiation
+                constexpr bool LoPrev = decltype(lo_prev_t)::value, LoNext = decltype(lo_next_t)::value;
                 if constexpr (PIPE) {
                     // items of this step: [i0, i1) of tile tt into buffer bb
                     int i0 = 0, i1 = 0, tt = 0, bb = bi;
-                    if (conv_prev_tile1 && mt == 0 && ks < 2) { i0 = 2 * ks; i1 = 2 * ks + 2; tt = 1; bb = bi; }
+                    bool is_prev = false;
+                    if (conv_prev_tile1 && mt == 0 && ks < 2) { i0 = 2 * ks; i1 = 2 * ks + 2; tt = 1; bb = bi; is_prev = true; }
                     if (conv_this_tile0 && mt == 1) {
                         const int per = (4 + ks_count - 1) / ks_count;
-                        i0 = ks * per; i1 = (ks + 1) * per < 4 ? (ks + 1) * per : 4; tt = 0; bb = bi ^ 1;
+                        i0 = ks * per; i1 = (ks + 1) * per < 4 ? (ks + 1) * per : 4; tt = 0; bb = bi ^ 1; is_prev = false;
                     }
                     if constexpr (FINE) {
                         const int units = (i1 - i0) * 4;
 #pragma unroll
-                        for (int u = 0; u < 16; u++)            // fixed bound: every index below must fold to a constant (register arrays)
-                            if (u < units && (u * ng) / units == g) conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1);
+                        for (int u = 0; u < 16; u++) {          // fixed bound: every index below must fold to a constant (register arrays)
+                            if (u < units && (u * ng) / units == g) {
+                                if constexpr (LoPrev && LoNext) conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1, true);
+                                else if (is_prev) { if constexpr (LoPrev) conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1, true); else conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1, false); }
+                                else { if constexpr (LoNext) conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1, true); else conv_half(bb, tt, i0 + (u >> 2), (u >> 1) & 1, u & 1, false); }
+                            }
+                        }
                     } else {
                         if (g == ng - 1) {
 #pragma unroll
@@ -533,15 +563,20 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         } else if constexpr (NL == 1) {
             gemm_layer<1, IN_KS, NP, IN_LO>(fr, lane, bx, sig, pre); fr += Plan::sigma_frags(0) * 64 * NP;
         } else {
-            gemm_layer<2, IN_KS, NP, IN_LO, false, FINE>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS)); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
+            gemm_layer<2, IN_KS, NP, IN_LO, false, FINE, small_drop_of(0)>(fr, lane, bx, acc2, pre, make_job(1, false, true, IN_KS, std::true_type{}, std::bool_constant<!(small_drop_of(1) & 2)>{})); fr += Plan::sigma_frags(0) * 64 * NP;     // tile 0 -> bh[0]
             prefetch_next();
             NRF_TSTAMP(0);
-#pragma unroll
-            for (int l = 1; l < NL; l++) {
+            static_assert(NL <= 3, "sigma net: at most three layers");
+            if constexpr (NL == 3) {
+                gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(1)>(fr, lane, bh[0], acc2, pre, make_job(0, true, true, 4, std::bool_constant<!(small_drop_of(1) & 2)>{}, std::bool_constant<!(small_drop_of(2) & 2)>{}));
+                fr += Plan::sigma_frags(1) * 64 * NP;
+                NRF_TSTAMP(1);
+            }
+            {
+                constexpr int l = NL - 1;
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
                 if constexpr (!PIPE) hidden_to_b(0);
-                if (l < NL - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
-                else gemm_layer<1, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4));
+                gemm_layer<1, 4, NP, SPLIT, false, FINE, small_drop_of(l)>(fr, lane, bh[bi], sig, pre, make_job(bi, true, false, 4, std::bool_constant<!(small_drop_of(l) & 2)>{}, std::true_type{}));
                 fr += Plan::sigma_frags(l) * 64 * NP;
                 NRF_TSTAMP(l);
             }
@@ -562,18 +597,28 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
         NRF_TSTAMP(3);
         f32x16 rgb[PT][1];
         if constexpr (NLC == 1) {
-            gemm_layer<1, V_KS + 1, NP, SPLIT, true>(fr, lane, bc, rgb, pre);
+            gemm_layer<1, V_KS + 1, NP, SPLIT, true, false, small_drop_of(NL)>(fr, lane, bc, rgb, pre);
             if constexpr (GEOIN) prefetch_next();
         } else {
-            gemm_layer<2, V_KS + 1, NP, SPLIT, false, FINE>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1)); fr += Plan::color_frags(0) * 64 * NP;
+            gemm_layer<2, V_KS + 1, NP, SPLIT, false, FINE, small_drop_of(NL)>(fr, lane, bc, acc2, pre, make_job(1, false, true, V_KS + 1, std::true_type{}, std::bool_constant<!(small_drop_of(NL + 1) & 2)>{})); fr += Plan::color_frags(0) * 64 * NP;
             if constexpr (GEOIN) prefetch_next();          // the colour-only kernel's operands of the next iteration, behind its first layer
             NRF_TSTAMP(4);
-#pragma unroll
-            for (int l = 1; l < NLC; l++) {
+            static_assert(NLC <= 4, "colour net: at most four layers");
+            if constexpr (NLC >= 3) {
+                gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(NL + 1)>(fr, lane, bh[0], acc2, pre, make_job(0, true, true, 4, std::bool_constant<!(small_drop_of(NL + 1) & 2)>{}, std::bool_constant<!(small_drop_of(NL + 2) & 2)>{}));
+                fr += Plan::color_frags(1) * 64 * NP;
+                NRF_TSTAMP(5);
+            }
+            if constexpr (NLC >= 4) {
+                gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(NL + 2)>(fr, lane, bh[PIPE ? 1 : 0], acc2, pre, make_job(PIPE ? 1 : 0, true, true, 4, std::bool_constant<!(small_drop_of(NL + 2) & 2)>{}, std::bool_constant<!(small_drop_of(NL + 3) & 2)>{}));
+                fr += Plan::color_frags(2) * 64 * NP;
+                NRF_TSTAMP(6);
+            }
+            {
+                constexpr int l = NLC - 1;
                 const int bi = PIPE ? ((l - 1) & 1) : 0;
                 if constexpr (!PIPE) hidden_to_b(0);
-                if (l < NLC - 1) gemm_layer<2, 4, NP, SPLIT, false, FINE>(fr, lane, bh[bi], acc2, pre, make_job(bi, true, true, 4));
-                else gemm_layer<1, 4, NP, SPLIT, true, FINE>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4));
+                gemm_layer<1, 4, NP, SPLIT, true, FINE, small_drop_of(NL + l)>(fr, lane, bh[bi], rgb, pre, make_job(bi, true, false, 4, std::bool_constant<!(small_drop_of(NL + l) & 2)>{}, std::true_type{}));
                 fr += Plan::color_frags(l) * 64 * NP;
                 NRF_TSTAMP(4 + l);
             }

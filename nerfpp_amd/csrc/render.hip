@@ -653,8 +653,8 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
                 for (int j = 0; j < L; j++) total += given[j];
                 m = (total / L - given[k] + 63) / 64 * 64;                       // lane k's share of the rest that evens the lanes out
                 if (m > lc) m = lc;
-                if (m < 1024) m = 1024;
-                if (rem - m < 1024 && rem <= lc) m = rem;                       // no crumbs
+                if (m < lc / 8) m = lc / 8;                                     // a lane already past its share: no slivers (a chunk has ~12 launches whatever its size)
+                if (rem - m < lc / 8 && rem <= lc) m = rem;                     // no crumbs
             }
 #endif
             if (m > rem) m = rem;

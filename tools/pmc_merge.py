@@ -13,7 +13,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (constants + kernel_source_hash; importing bench touches no GPU)
+from benchlib import costs as bench  # noqa: E402  (constants; touches no GPU)
+from benchlib import roofline as _rf  # noqa: E402
+bench.kernel_source_hash = _rf.kernel_source_hash
+bench.PMC_KERNEL_SOURCES = _rf.PMC_KERNEL_SOURCES
 
 hn, cl, clk, commit, out = sys.argv[1:6]
 res = {}
