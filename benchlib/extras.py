@@ -190,7 +190,8 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
     neg = rng.randn(3, 768).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)
     r.SetLeRFPrompts(pos, neg)
     r.keep_intermediates = False           # the timed frames write what LeRFRenderer::Render returns; the oracle check below renders once more with the depth sets kept
-    dt, kms, _ = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1, lanes_hook=lambda k: setattr(r, "lanes", k))
+    lanes0 = r.lanes                       # LeRF's own default is ONE lane: the frame time and the per-kernel pass below both run that way
+    dt, kms, _ = timed_frames(L, lambda: r.Render(H, W, K, p, c2w=c2w), repeats, warm=1, lanes_hook=lambda k: setattr(r, "lanes", min(k, lanes0)))
     r.keep_intermediates = True
     res = r.Render(H, W, K, p, c2w=c2w)
     n = H * W
@@ -200,7 +201,7 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
     split = r.precision_name == "f16x3"
     exact = bool(split and r._exact_coarse_on())
     rec = dict(workload="lerf_lego800_64+128", baseline_config=5, rays=n, value=n * UNITS_PER_RAY / dt, unit="ray-samples/s", s_per_frame=dt, frames_timed=repeats, kernel_ms=kms,
-               fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()), single_library_call=bool(r._single_call_ok(p)),
+               lanes=int(r.lanes), fused_matrix_core_path=bool(r.fused), finite=bool(torch.isfinite(emb).all()), single_library_call=bool(r._single_call_ok(p)),
                relevancy="rendered in the pass (1 positive, 3 negatives)" if res.Outputs.Relevancy is not None else None,
                rays_with_language_density=int(hit.sum()), embedding_norm_min_max=[float(nrm.min()), float(nrm.max())] if int(hit.sum()) else None,
                level_major_features=bool(getattr(r, "level_major", False)), precision=getattr(r, "precision_name", "f16"),

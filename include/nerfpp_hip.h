@@ -610,6 +610,8 @@ typedef struct nrf_lerf_outputs {     /* LeRFRendererOutputs (LeRFRenderer.h:9-1
 typedef struct nrf_lerf_renderer nrf_lerf_renderer;
 NRF_API int nrf_lerf_renderer_create(const nrf_lerf_renderer_desc *desc, nrf_lerf_renderer **out);
 NRF_API void nrf_lerf_renderer_destroy(nrf_lerf_renderer *r);
+/* Lanes of this renderer's Chunk loop, 1-4.  Default ONE: the LeRF kernels gain nothing from sharing the CUs (measured: 1 lane 140-143 ms per 800x800 frame, 2 lanes 146-147). */
+NRF_API int nrf_lerf_renderer_set_lanes(nrf_lerf_renderer *r, int lanes);
 /* LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [n_pos, E] / [n_neg, E] fp32 phrase embeddings (host or device), copied; 0 / 0 clears them.  Synchronises `stream`. */
 NRF_API int nrf_lerf_set_prompts(nrf_lerf_renderer *r, const float *positives, int n_pos, const float *negatives, int n_neg, int on_device, void *stream);
 
@@ -621,7 +623,7 @@ NRF_API size_t nrf_lerf_render_rays_workspace_bytes(const nrf_lerf_renderer *r, 
 NRF_API int nrf_lerf_render_rays(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
                                  const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
 /* LeRFRenderer::BatchifyRays (LeRFRenderer.cpp:189-263): the Chunk loop inside the library, slices written in place, on the lanes of nrf_set_render_lanes /
- * NRF_RENDER_LANES (one device and one caller at a time per renderer, as nrf_batchify_rays). */
+ * nrf_lerf_renderer_set_lanes (one device and one caller at a time per renderer, as nrf_batchify_rays). */
 NRF_API size_t nrf_lerf_batchify_rays_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int chunk, const nrf_render_params *p);
 NRF_API int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, int chunk, const nrf_render_params *p, const float *d_t,
                                    const float *d_u, const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream);
@@ -644,6 +646,8 @@ enum { NRF_PROF_HASH = 0, NRF_PROF_MLP = 1, NRF_PROF_COMPOSITE = 2, NRF_PROF_SAM
  * loop (also: NRF_RENDER_LANES=1..4).  Process-wide setting, read at every call; the workspace query and the call must see the same value. */
 NRF_API int nrf_set_render_lanes(int lanes);
 NRF_API int nrf_get_render_lanes(void);
+/* ... per renderer: 1-4 lanes for this renderer's calls whatever the process-wide setting; 0 returns it to that setting (two renderers of one process need not share it). */
+NRF_API int nrf_renderer_set_lanes(nrf_renderer *r, int lanes);
 NRF_API int nrf_profile_enable(int on);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
 

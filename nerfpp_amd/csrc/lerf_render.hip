@@ -37,6 +37,9 @@ struct nrf_lerf_renderer {
     // prompt embeddings on the device (SetLeRFPrompts, LeRFRenderer.h:86): [P, E] positives, [Q, E] negatives
     float *d_pos = nullptr, *d_neg = nullptr;
     int n_pos = 0, n_neg = 0;
+    // lanes of this renderer's Chunk loop.  ONE by default: the LeRF kernels gain nothing from sharing the CUs (800x800 frame, same call: 1 lane 140-143 ms, 2 lanes
+    // 146-147 ms at Chunk 32768; profiles/round4/r4g_lerf_lane_chunk_sweep.log) -- their sum is matrix-bound and the F = 8 encode is at the HBM roofline by itself
+    int lanes = 1;
     // lanes of the Chunk loop (as nrf_renderer's): created on first use, bound to one device and one caller at a time
     mutable std::mutex lane_mu;
     mutable hipStream_t lane[NRF_LERF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -165,8 +168,7 @@ static int jet_lut_device(const uint8_t **out, hipStream_t st)
     return NRF_OK;
 }
 
-extern "C" int nrf_get_render_lanes(void);
-static int lerf_lanes() { return nrf_get_render_lanes(); }
+static int lerf_lanes(const nrf_lerf_renderer *r) { return r->lanes < 1 ? 1 : (r->lanes > NRF_LERF_MAX_LANES ? NRF_LERF_MAX_LANES : r->lanes); }
 
 struct LerfPlan {
     int s, ni, sf, E;
@@ -321,6 +323,13 @@ int nrf_lerf_renderer_create(const nrf_lerf_renderer_desc *desc, nrf_lerf_render
 
 void nrf_lerf_renderer_destroy(nrf_lerf_renderer *r) { delete r; }
 
+int nrf_lerf_renderer_set_lanes(nrf_lerf_renderer *r, int lanes)
+{
+    NRF_CHECK_ARG(r && lanes >= 1 && lanes <= NRF_LERF_MAX_LANES, "nrf_lerf_renderer_set_lanes: 1 .. %d lanes", NRF_LERF_MAX_LANES);
+    r->lanes = lanes;
+    return NRF_OK;
+}
+
 int nrf_lerf_set_prompts(nrf_lerf_renderer *r, const float *positives, int n_pos, const float *negatives, int n_neg, int on_device, void *stream)
 {
     NRF_CHECK_ARG(r, "nrf_lerf_set_prompts: null renderer");
@@ -429,7 +438,7 @@ static int64_t lerf_lane_chunk(int64_t n, int chunk, int lanes)
 size_t nrf_lerf_batchify_rays_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int chunk, const nrf_render_params *p)
 {
     if (!r || !p || chunk <= 0 || n <= 0) return 0;
-    const int lanes = lerf_lanes();
+    const int lanes = lerf_lanes(r);
     const int64_t lc = lerf_lane_chunk(n, chunk, lanes);
     const size_t one = nrf_lerf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
     return lc > 0 ? (size_t)lanes * one : one;
@@ -442,7 +451,7 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
     NRF_CHECK_ARG(chunk > 0 && n >= 0, "nrf_lerf_batchify_rays: Chunk must be positive");
     LerfPlan pl;
     NRF_TRY(lerf_plan(r, p, &pl, "nrf_lerf_batchify_rays"));
-    const int L = lerf_lanes();
+    const int L = lerf_lanes(r);
     const int64_t lc = lerf_lane_chunk(n, chunk, L);
     const size_t part = lc > 0 ? nrf_lerf_render_rays_workspace_bytes(r, lc, p) : 0;
     if (part > 0 && (size_t)L * part <= workspace_bytes && d_workspace) {

@@ -27,6 +27,7 @@ struct nrf_renderer {
     mutable hipStream_t lane[NRF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t lane_fork = nullptr, lane_done[NRF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable int lane_device = -1;
+    int lanes = 0;                // this renderer's lane count; 0: the process-wide default (nrf_set_render_lanes / NRF_RENDER_LANES)
     void drop_lanes() const
     {
         for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
@@ -572,10 +573,19 @@ static int64_t lane_chunk(int64_t n, int chunk, int lanes)
     return ((n + lanes - 1) / lanes + 63) / 64 * 64;            // one chunk: L parts
 }
 
+static int lanes_for(const nrf_renderer *r) { return r->lanes > 0 ? r->lanes : render_lanes(); }
+
+int nrf_renderer_set_lanes(nrf_renderer *r, int lanes)
+{
+    NRF_CHECK_ARG(r && lanes >= 0 && lanes <= NRF_MAX_LANES, "nrf_renderer_set_lanes: 0 (the process-wide default) .. %d lanes", NRF_MAX_LANES);
+    r->lanes = lanes;
+    return NRF_OK;
+}
+
 size_t nrf_batchify_rays_workspace_bytes(const nrf_renderer *r, int64_t n, int chunk, const nrf_render_params *p)
 {
     if (!r || !p || chunk <= 0) return 0;
-    const int lanes = render_lanes();
+    const int lanes = lanes_for(r);
     const int64_t lc = lane_chunk(n, chunk, lanes);
     if (lc > 0 && lc < n) return (size_t)lanes * align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256);
     return nrf_render_rays_workspace_bytes(r, n < chunk ? n : (int64_t)chunk, p);
@@ -621,7 +631,7 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
     const int s = p->n_samples, sf = p->n_samples + p->n_importance, so = p->n_importance > 0 ? sf : s;
     const int c = r->desc.mlp->out_dims;
     nrf_render_params q = *p;
-    const int L = render_lanes();
+    const int L = lanes_for(r);
     const int64_t lc = lane_chunk(n, chunk, L);
     const size_t part = lc > 0 && lc < n ? align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256) : 0;
     if (part > 0 && (size_t)L * part <= workspace_bytes && d_workspace) {

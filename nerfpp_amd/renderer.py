@@ -552,7 +552,9 @@ class LeRFRenderer:
         self.compose_through_map = True     # reuse path: sigma_le of the sorted depths read through the merge map by the compositing kernel (False: gathered by torch first, A/B)
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
-        self.lanes = 1 if os.environ.get("NRF_RENDER_LANES", "2") == "1" else 2      # streams of Render's Chunk loop (see Render)
+        # streams of Render's Chunk loop.  ONE by default: the LeRF kernels gain nothing from sharing the CUs (800x800 frame, same call: 140-143 ms on one lane,
+        # 146-147 on two; profiles/round4/r4g_lerf_lane_chunk_sweep.log); NRF_LERF_LANES overrides
+        self.lanes = max(1, min(4, int(os.environ.get("NRF_LERF_LANES", "1"))))
         self._lane_streams = None
         if self.fused:
             self.set_precision(precision)
@@ -637,14 +639,8 @@ class LeRFRenderer:
                 self._ws = None
                 self._ws = torch.empty((int(nb),), device=dev, dtype=torch.uint8)
             return self._ws
-        lanes_global = int(lib.nrf_get_render_lanes())
-        if self.lanes != lanes_global:               # the lane count is a process-wide setting of the library: this renderer's own count for this call
-            L.check(lib.nrf_set_render_lanes(int(self.lanes)))
-        try:
-            self._issue_single_call(lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d)
-        finally:
-            if self.lanes != lanes_global:
-                L.check(lib.nrf_set_render_lanes(lanes_global))
+        L.check(lib.nrf_lerf_renderer_set_lanes(self._r, int(self.lanes)))          # this renderer's own lane count (default 1: see __init__)
+        self._issue_single_call(lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d)
         res.Extras["rays_flat"] = rays_
         return res
 

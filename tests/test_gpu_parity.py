@@ -2502,9 +2502,10 @@ def test_lerf_render_as_one_library_call_equals_the_stagewise_host_loop(api, O):
     """nrf_lerf_render_rows / nrf_lerf_batchify_rays (LeRFRenderer::Render / BatchifyRays as C calls, lanes inside the library, no torch ops) against the same passes
     composed stage by stage by the Python host (its own Chunk loop and torch.cat): depths, weights, maps and the rendered embedding identical bit for bit (split
     precision: same kernels on the same slices, no atomics), for a pose tile and for an explicit ray batch, ragged chunks, 1 / 2 / 3 lanes; Relevancy filled in both."""
+    import os
     sc = api.S.make_lerf_scene()
     r = sc["renderer"]
-    assert r.fused and r.level_major and r._r and r.precision_name == "f16x3"
+    assert r.fused and r.level_major and r._r and r.precision_name == "f16x3" and r.lanes == 1
     rng = np.random.RandomState(86)
     pos = rng.randn(1, 768).astype(np.float32); pos /= np.linalg.norm(pos)
     neg = rng.randn(3, 768).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)
@@ -2520,7 +2521,7 @@ def test_lerf_render_as_one_library_call_equals_the_stagewise_host_loop(api, O):
         for lanes in (1, 2, 3):
             r.lanes = lanes
             a = r.Render(800, 800, K, p, c2w=c2w, row0=396, rows=5)
-            assert api.L.lib().nrf_get_render_lanes() in (1, 2), "the library's process-wide lane count is restored after the call"
+            assert api.L.lib().nrf_get_render_lanes() == 2 or os.environ.get("NRF_RENDER_LANES"), "a renderer's own lane count leaves the process-wide setting alone"
             for f in ("WeightsLE", "DepthMapLE", "DispMapLE", "AccMapLE", "RenderedLangEmbedding", "Relevancy"):
                 assert_exact(host(getattr(a.Outputs, f)), host(getattr(ref.Outputs, f)), f"{f}, {lanes} lane(s)")
             for f in ("z_fine", "z_coarse", "weights_coarse", "rays_flat"):
