@@ -568,6 +568,7 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             NRF_TSTAMP(0);
             static_assert(NL <= 3, "sigma net: at most three layers");
             if constexpr (NL == 3) {
+                if constexpr (!PIPE) hidden_to_b(0);
                 gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(1)>(fr, lane, bh[0], acc2, pre, make_job(0, true, true, 4, std::bool_constant<!(small_drop_of(1) & 2)>{}, std::bool_constant<!(small_drop_of(2) & 2)>{}));
                 fr += Plan::sigma_frags(1) * 64 * NP;
                 NRF_TSTAMP(1);
@@ -605,11 +606,13 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
             NRF_TSTAMP(4);
             static_assert(NLC <= 4, "colour net: at most four layers");
             if constexpr (NLC >= 3) {
+                if constexpr (!PIPE) hidden_to_b(0);
                 gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(NL + 1)>(fr, lane, bh[0], acc2, pre, make_job(0, true, true, 4, std::bool_constant<!(small_drop_of(NL + 1) & 2)>{}, std::bool_constant<!(small_drop_of(NL + 2) & 2)>{}));
                 fr += Plan::color_frags(1) * 64 * NP;
                 NRF_TSTAMP(5);
             }
             if constexpr (NLC >= 4) {
+                if constexpr (!PIPE) hidden_to_b(0);
                 gemm_layer<2, 4, NP, SPLIT, false, FINE, small_drop_of(NL + 2)>(fr, lane, bh[PIPE ? 1 : 0], acc2, pre, make_job(PIPE ? 1 : 0, true, true, 4, std::bool_constant<!(small_drop_of(NL + 2) & 2)>{}, std::bool_constant<!(small_drop_of(NL + 3) & 2)>{}));
                 fr += Plan::color_frags(2) * 64 * NP;
                 NRF_TSTAMP(6);
