@@ -84,7 +84,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.backend == "nccl":           # bind the process group to this rank's device up front (no "guessing device ID" on heterogeneous rank -> GPU maps)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     from nerfpp_amd.dist import TileShard, TileComm
     if use_dist and args.backend != "nccl" and world > 1:
         # a rehearsal: the ranks SHARE one GPU.  Two processes with two lanes each is four streams' worth of kernels time-sliced between two contexts (102 ms per step

@@ -20,6 +20,16 @@
 namespace nrf {
 namespace lerf {
 
+#ifndef NRF_LERF_GRAM_ALO
+#define NRF_LERF_GRAM_ALO 0              // 1: the lo part of a enters the Gram product
+#endif
+#ifndef NRF_LERF_GRAM_GLO
+#define NRF_LERF_GRAM_GLO 0              // 1: the lo part of the Gram matrix enters it
+#endif
+#ifndef NRF_LERF_GRAM_HI_STREAM
+#define NRF_LERF_GRAM_HI_STREAM 1        // Gram layer without its lo part: only the hi fragments are streamed into LDS and read (0: both, as the image holds them)
+#endif
+
 constexpr int SNW = 4;                 // waves per workgroup: one per SIMD
 constexpr int SNBLK = 32 * SNW;
 constexpr int SMAXF = 32;              // fragments in the largest chunk: 16 k-steps x (hi, lo)
@@ -33,6 +43,11 @@ struct NetS {
     static constexpr int total_chunks() { return first_chunk(NL); }
     static constexpr int layer_of(int ci) { int l = L0; while (first_chunk(l + 1) <= ci) l++; return l; }
     static constexpr int chunk_frags(int ci) { return 2 * F::ks(layer_of(ci)); }
+    // The Gram layer (layer 3 of the 4-layer net) applies the hi fragments only (NRF_LERF_GRAM_GLO = 0): its chunks then stream and read HALF of what the image holds --
+    // fragment 2 i (hi of k-step i) into its usual slot, the lo slots left alone.  The weight stream's LDS-side write is what bounds kernel B (38 GB/s per CU taken in,
+    // matrix pipe busy 0.37-0.40), and the Gram chunks were a quarter of it.
+    static constexpr bool hi_only(int ci) { return NL == 4 && layer_of(ci) == 3 && !(NRF_LERF_GRAM_GLO) && (NRF_LERF_GRAM_HI_STREAM); }
+    static constexpr int dma_frags(int ci) { return hi_only(ci) ? F::ks(layer_of(ci)) : chunk_frags(ci); }
     static constexpr int image_off() { int n = 0; for (int i = 0; i < L0; i++) n += F::tiles(i) * 2 * F::ks(i); return n; }      // fragments of the skipped layers
     static constexpr int chunk_off(int ci) { int n = image_off(); for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
 };
@@ -44,17 +59,18 @@ template <class N, int CI, int Q>
 __device__ __forceinline__ void stage_piece(half8 *__restrict__ dst, const half8 *__restrict__ packed, int wave, int lane)
 {
     constexpr int ci = CI % N::total_chunks();
-    constexpr int nf = N::chunk_frags(ci);
+    constexpr int nf = N::dma_frags(ci);
+    constexpr int STEP = N::hi_only(ci) ? 2 : 1;          // hi-only chunks: every second fragment of the image, into its usual slot
     static_assert(nf % SNW == 0, "fragments per chunk must divide by the wave count");
     if constexpr (Q * SNW < nf) {
         constexpr int base = N::chunk_off(ci);
         // the fragment's address = SGPR base (its constant offset added on the scalar side, then made opaque) + lane * 16: the saddr form of the DMA.  With the offset
         // added after the opaque point the compiler forms a 64-bit per-lane address instead -- two v_lshl_add_u64 per DMA, ~1 070 per iteration of the classic kernel
-        const half8 *pk = packed + (size_t)wave * 64;
+        const half8 *pk = packed + (size_t)wave * (64 * STEP);
         asm volatile("" : "+s"(pk));                          // opaque: the addresses derived from it cannot be hoisted out of the persistent loop (533 SGPR pairs would spill)
-        pk += (size_t)(base + Q * SNW) * 64;
+        pk += (size_t)(base + STEP * Q * SNW) * 64;
         asm volatile("" : "+s"(pk));                          // the offset is added HERE, on the scalar side (s_add_u32 / s_addc_u32)
-        __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + (Q * SNW + wave) * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + STEP * (Q * SNW + wave) * 64), 16, 0, 0);
     }
 }
 
@@ -111,7 +127,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     constexpr int CI = N::first_chunk(L) + T;
     constexpr bool NATF = F::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
-    constexpr int NQ = N::chunk_frags((CI + 2) % N::total_chunks()) / SNW;
+    constexpr int NQ = N::dma_frags((CI + 2) % N::total_chunks()) / SNW;
     constexpr int EVERY = (KS / NQ) > 0 ? (KS / NQ) : 1;
     constexpr int LEAD = NQ > KS / EVERY ? NQ - KS / EVERY : 0;
     static_assert(NQ <= 8, "piece switch covers 8 pieces per wave");
@@ -133,8 +149,11 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     // the compiler the reads sit 32 pipe cycles before their use, or it waits for ALL outstanding reads)
     half8 fa[3][2];
     const uint32_t waddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(w + cx.lane);
+    constexpr bool HI = N::hi_only(CI);          // the lo fragments of this chunk were not streamed: they are not read either
+    static_assert(!HI || !WLO, "a hi-only chunk cannot apply the weights' lo part");
     auto read_pair = [&](int kk_, int slot) {
-        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr), "i"(kk_ * 2048), "i"(kk_ * 2048 + 1024));     // offsets in the instruction, not a v_add_u32 per pair
+        if constexpr (HI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fa[slot][0]) : "v"(waddr), "i"(kk_ * 2048));
+        else asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr), "i"(kk_ * 2048), "i"(kk_ * 2048 + 1024));     // offsets in the instruction, not a v_add_u32 per pair
     };
     read_pair(0, 0);
     if (KS > 1) read_pair(1, 1);
@@ -142,11 +161,17 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     for (int k = 0; k < KS; k++) {
         if (k + 2 < KS) {
             read_pair(k + 2, (k + 2) % 3);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
-        } else if (k + 1 < KS) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+            if constexpr (HI) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]));
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        } else if (k + 1 < KS) {
+            if constexpr (HI) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[k % 3][0]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        } else {
+            if constexpr (HI) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k % 3][0]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[k % 3][0]), "+v"(fa[k % 3][1]));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        const half8 ah = fa[k % 3][0], al = fa[k % 3][1];
+        const half8 ah = fa[k % 3][0], al = HI ? fa[k % 3][0] : fa[k % 3][1];
         const bool nat = NATF ? (k < KSN) : (k >= KSC);
         const int kk = NATF ? (nat ? k : k - KSN) : (nat ? k - KSC : k);
         const half8 bh = nat ? bn[nat ? kk : 0][0] : bc[nat ? 0 : kk][0];
@@ -323,13 +348,6 @@ struct ReduceS {
     }
 };
 
-#ifndef NRF_LERF_GRAM_ALO
-#define NRF_LERF_GRAM_ALO 0              // 1: the lo part of a enters the Gram product
-#endif
-#ifndef NRF_LERF_GRAM_GLO
-#define NRF_LERF_GRAM_GLO 0              // 1: the lo part of the Gram matrix enters it
-#endif
-
 // XLO: the input features carry a lo part (fp32 rows); level-major CuHashEmbedder features are exact fp16
 template <int NL, bool XLO>
 __global__ void __launch_bounds__(64 * SNW, 1)
@@ -340,8 +358,8 @@ k_lerf_split(int64_t npts, Args in, const half8 *__restrict__ packed)
     half8 *wbuf = reinterpret_cast<half8 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(0) / SNW>{});
-    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(1) / SNW>{});
+    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::dma_frags(0) / SNW>{});
+    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::dma_frags(1) / SNW>{});
     __syncthreads();
     int cur = 0;
     f32x16 accs[2];
@@ -542,8 +560,8 @@ k_lerf_split_geo(int64_t npts, Args in, const half8 *__restrict__ packed)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     half8 *oper = wbuf + 3 * SMAXF * 64 + wave * ((GEO_OPER_FRAGS + 1) * 64);
-    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(0) / SNW>{});
-    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::chunk_frags(1) / SNW>{});
+    stage_all<N, 0>(wbuf, packed, wave, lane, std::make_integer_sequence<int, N::dma_frags(0) / SNW>{});
+    stage_all<N, 1>(wbuf + SMAXF * 64, packed, wave, lane, std::make_integer_sequence<int, N::dma_frags(1) / SNW>{});
     __syncthreads();
     int cur = 0;
     f32x16 accs[2];
