@@ -21,7 +21,7 @@ from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecond
 
 class Trainer:
     def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
-                 tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32", grad_sync=None):
+                 tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32", grad_sync=None, train_dense_budget=256 << 20):
         if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
             raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
@@ -53,10 +53,12 @@ class Trainer:
         self.grad_sync = grad_sync          # callable(g_table, g_blob) reducing the gradients across data-parallel ranks in place, or None
         self._hws = None
         self._ws = None
-        # the baked dense pyramid of the render fast path would be re-baked (GBs, with a stream synchronisation) after every step's table upload:
-        # off for ANY hash embedder -- the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
+        # the baked dense pyramid of the render fast path is re-baked after every step's table upload: GBs at the render default -- so while training only the coarse
+        # levels that fit `train_dense_budget` stay baked (256 MB: re-baking them costs ~0.1 ms per step and their lookups are the 2-load fast path instead of 8 hashed
+        # corners: step 9.3 -> 8.5 ms, same bits; 0 / 16 / 64 / 1024 MB: 9.3 / 8.9 / 8.7 / 8.7 ms, profiles/round4/r4m_train_dense_budget.log).  For ANY hash embedder --
+        # the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
         self._dense_budget_before = getattr(embedder, "dense_budget", None)
-        embedder.set_dense_budget(0)
+        embedder.set_dense_budget(int(train_dense_budget))
         self._push_params()
 
     def close(self):
