@@ -203,12 +203,16 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
         NRF_HIP(hipFree(h->d_fast));
         h->d_fast = nullptr; h->fast_bytes = 0;
     }
+    bool fresh_image = false;
     if (nb > 0) {
-        if (h->fast_bytes < (size_t)total * entry_bytes) {
-            if (h->d_fast) NRF_HIP(hipFree(h->d_fast));
+        const size_t need = (size_t)total * entry_bytes;
+        // (re)allocate when the image grew -- or shrank to less than half (a training loop lowers the budget to a few coarse levels: the gigabytes go back)
+        if (h->fast_bytes < need || h->fast_bytes / 2 > need) {
+            if (h->d_fast) { NRF_HIP(hipStreamSynchronize(st)); NRF_HIP(hipFree(h->d_fast)); }
             h->d_fast = nullptr; h->fast_bytes = 0;
-            NRF_HIP(hipMalloc(&h->d_fast, (size_t)total * entry_bytes));
-            h->fast_bytes = (size_t)total * entry_bytes;
+            NRF_HIP(hipMalloc(&h->d_fast, need));
+            h->fast_bytes = need;
+            fresh_image = true;
         }
         hp.dense = h->d_fast;
         for (int l = 0; l < nb; l++) {
@@ -221,8 +225,10 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
             NRF_LAUNCH_CHECK();
         }
     }
-    if (nb > 0) NRF_HIP(hipStreamSynchronize(st));          // model-load time: the bake must be complete before launches from any other stream read it.
-                                                            // Nothing baked (budget 0: a training loop's per-step table upload): nothing to wait for
+    // A fresh image (model-load time, budget changes): the bake is complete before this returns, whatever stream reads it next.  A re-bake into the SAME image (the
+    // per-step table upload of a training loop) stays asynchronous on `st` like every other call: its readers are ordered behind it on that stream (the lanes of
+    // nrf_batchify_rays fork from it)
+    if (fresh_image) NRF_HIP(hipStreamSynchronize(st));
     h->fast_valid = true;
     h->dense_levels = nb;
     return NRF_OK;

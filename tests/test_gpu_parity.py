@@ -2194,8 +2194,8 @@ def test_lerf_fused_split_precision_vs_fp32_stage_path(api, O, manifest):
 
 # ------------------------------------------------------------------ training loop housekeeping: dense image off for every encoder, schedule, checkpoints
 def test_trainer_ngp_mode_schedule_and_checkpoint_round_trip(api, tmp_path):
-    """The reference's TV-loss training configuration (LibTorch HashEmbedder): the Trainer switches the baked dense pyramid off for ANY hash embedder (a re-bake per
-    step would move gigabytes), applies the executor's schedule (TV regulariser for the first half of the iterations, exponential lr decay, fresh draws per step,
+    """The reference's TV-loss training configuration (LibTorch HashEmbedder): the Trainer cuts the baked dense pyramid down to its coarse levels (256 MB) for ANY hash
+    embedder (a re-bake of the whole image per step would move gigabytes), applies the executor's schedule (TV regulariser for the first half of the iterations, exponential lr decay, fresh draws per step,
     the caller's params untouched), and its checkpoint -- written in the reference's formats, Adam state included -- restores a second Trainer that then takes
     bit-identical steps."""
     from nerfpp_amd.train import Trainer
@@ -2209,7 +2209,7 @@ def test_trainer_ngp_mode_schedule_and_checkpoint_round_trip(api, tmp_path):
     o = o.reshape(-1, 3); d = d.reshape(-1, 3)
     tgt = torch.rand((1024, 3), device="cuda") * 0.2 + 0.4
     tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-3, tv_loss_weight=1e-6)
-    assert free0 - torch.cuda.mem_get_info()[0] < baked - (4 << 30), "the dense image must be released (budget 0) for the LibTorch HashEmbedder too"
+    assert free0 - torch.cuda.mem_get_info()[0] < baked - (4 << 30), "the dense image must shrink to the training budget for the LibTorch HashEmbedder too"
     rp = api.R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=1024, Perturb=1.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
                                 BoundingBox=api.S.LEGO_BBOX, Precision=api.L.NRF_PREC_F32, Seed=5)
     n_iters, decay = 8, 0.002            # lr halves every 0.6 steps of "thousands": visible within a few steps
