@@ -500,8 +500,13 @@ NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, co
  * flags_out[0] != 0: the incoming gradient held an inf / NaN; flags_out[1] != 0: an accumulated parameter gradient is not finite.  Host array of 2; synchronises
  * `stream`.  A caller skips (or rescales) the optimizer step when either is set. */
 NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream);
-/* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images). */
+/* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images).
+ * NeRFSmall handles do it ON THE DEVICE in stream order (a gather + hi / lo split per image, no host round trip, nothing waits): work already issued on `stream`
+ * reads the old images, work issued after reads the new ones; other streams of the caller's are the caller's to order.  Other families (and NRF_MLP_HOST_REPACK=1)
+ * copy the blob to the host, repack there and synchronise `stream`. */
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
+/* Number of derived images nrf_mlp_set_params refreshes on the device for this handle (0: the host repack). */
+NRF_API int nrf_mlp_device_repack_images(const nrf_mlp *m);
 
 /* Backward of the hash grid w.r.t. its table: d_g_emb [p, L*F] -> d_g_table, fp32 in the table's own layout, ACCUMULATED into.
  * NRF_HASH_NGP: nn::Embedding's index_add of the trilinear weights (NeRF.cpp:279-298).  NRF_HASH_CU: CuHashEmbedderBackwardKernel

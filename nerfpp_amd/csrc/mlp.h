@@ -8,6 +8,18 @@ namespace nrf {
 
 enum { MLP_SMALL = 0, MLP_NERF = 1, MLP_LERF = 2 };
 
+// A derived weight image as a GATHER from the parameter blob: element e = convert(kind[e], params[src[e]]), 0 where src < 0.  Built once per handle by decoding
+// probe runs of the host packers and verified against the host-packed image (mlp.hip, build_weight_maps); nrf_mlp_set_params then refreshes every image on the
+// device, asynchronously -- an optimisation step no longer takes a host round trip.
+enum : uint8_t { WM_ZERO = 0, WM_F16_HI = 1, WM_F16_LO = 2, WM_F32 = 3 };
+struct WeightMap {
+    int32_t *d_src = nullptr;
+    uint8_t *d_kind = nullptr;
+    int64_t n = 0;
+    int elem = 2;              // bytes per element of the image: 2 (fp16, kinds HI / LO) or 4 (fp32)
+    void *d_out = nullptr;     // the image (owned by the handle's d_packed_* / layer fields)
+};
+
 struct LinearLayer {
     int in = 0, out = 0;
     float *d_wt = nullptr;      // W^T [in][out] fp32 (lane = output neuron reads coalesced)
@@ -37,6 +49,7 @@ struct nrf_mlp {
     float lerf_gram_scale = 1.0f;            // LeRF: the Gram matrix of the embedding layer is stored divided by this power of two (fp16 range), see mlp_lerf_mfma.hip
     void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
     size_t packed_bwd_bytes = 0;
+    std::vector<nrf::WeightMap> maps;        // NeRFSmall: every derived image as a gather from d_params (empty: nrf_mlp_set_params repacks on the host)
 };
 
 namespace nrf {
@@ -69,6 +82,10 @@ int mlp_nerf_forward_split_fused(const nrf_mlp *m, const float *pts, const float
 int launch_dirs_pe_split(const float *rays, int stride, int64_t n, __half *out_hi, __half *out_lo, hipStream_t st);
 int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &host_params);
+// the same images on the host (bytes), for the weight maps: false when the shape is outside the built family
+bool mlp_small_images_host(const nrf_mlp_small_desc &d, const std::vector<float> &hp, std::vector<uint8_t> &f16_img, std::vector<uint8_t> &split_img);
+bool mlp_small_bwd_image_host(const nrf_mlp *m, const std::vector<float> &hp, std::vector<uint8_t> &img);
+bool mlp_small_sigma_image_host(const nrf_mlp_small_desc &d, const std::vector<float> &hp, std::vector<uint8_t> &head_f32, std::vector<uint8_t> &tail_f16);
 size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p);
 int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p, float *g_params,
                                float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st);

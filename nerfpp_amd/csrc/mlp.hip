@@ -424,6 +424,148 @@ static int fetch_params(const float *params, int on_device, int64_t n, hipStream
     return NRF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// weight maps: every derived image of a NeRFSmall handle as a gather from the parameter blob (mlp.h)
+// ---------------------------------------------------------------------------------------------------
+// The host packers (mlp_small_mfma.hip, sigma_small_f32.hip, mlp_small_bwd_mfma.hip) stay the single statement of the fragment layouts.  They are run on four PROBE
+// blobs whose entries spell their own index: probes 0 / 1 carry the index in fp16-exact values 1 + a / 1024 (hi halves and fp32 copies read it back, lo halves are 0
+// there); probes 2 / 3 are 0.5 + b 2^-24, whose hi half is 0.5 and whose lo half is b 2^-24 exactly.  The decoded (source, kind) table is then checked against the
+// host-packed image of the REAL parameters byte for byte; any mismatch leaves the handle on the host repack.
+static const int WM_RADIX_HI = 1024, WM_RADIX_LO = 1023;
+
+static std::vector<float> weight_map_probe(int64_t n, int which)
+{
+    std::vector<float> v((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (which == 0) v[i] = 1.0f + (float)(i % WM_RADIX_HI) / 1024.0f;
+        else if (which == 1) v[i] = 1.0f + (float)(i / WM_RADIX_HI) / 1024.0f;
+        else if (which == 2) v[i] = 0.5f + (float)(i % WM_RADIX_LO + 1) * 0x1p-24f;
+        else v[i] = 0.5f + (float)(i / WM_RADIX_LO + 1) * 0x1p-24f;
+    }
+    return v;
+}
+
+static inline float wm_value(const uint8_t *img, int64_t e, int elem)
+{
+    if (elem == 4) { float f; memcpy(&f, img + 4 * e, 4); return f; }
+    _Float16 h; memcpy(&h, img + 2 * e, 2); return (float)h;
+}
+
+struct HostMap { std::vector<int32_t> src; std::vector<uint8_t> kind; int elem = 2; };
+
+static bool decode_weight_map(const std::vector<uint8_t> probe_img[4], int elem, int64_t n_params, HostMap &hm)
+{
+    const int64_t n = (int64_t)probe_img[0].size() / elem;
+    for (int q = 1; q < 4; q++) if ((int64_t)probe_img[q].size() != n * elem) return false;
+    hm.elem = elem; hm.src.assign((size_t)n, -1); hm.kind.assign((size_t)n, WM_ZERO);
+    for (int64_t e = 0; e < n; e++) {
+        const float a = wm_value(probe_img[0].data(), e, elem), b = wm_value(probe_img[1].data(), e, elem);
+        const float c = wm_value(probe_img[2].data(), e, elem), d = wm_value(probe_img[3].data(), e, elem);
+        int64_t i = -1; uint8_t k = WM_ZERO;
+        if (a != 0.0f) {
+            i = (int64_t)lrintf((b - 1.0f) * 1024.0f) * WM_RADIX_HI + lrintf((a - 1.0f) * 1024.0f);
+            k = elem == 4 ? WM_F32 : WM_F16_HI;
+        } else if (c != 0.0f) {
+            if (elem == 4) return false;
+            i = ((int64_t)lrintf(d * 0x1p24f) - 1) * WM_RADIX_LO + (lrintf(c * 0x1p24f) - 1);
+            k = WM_F16_LO;
+        }
+        if (k != WM_ZERO && (i < 0 || i >= n_params)) return false;
+        hm.src[(size_t)e] = (int32_t)i; hm.kind[(size_t)e] = k;
+    }
+    return true;
+}
+
+static bool weight_map_reproduces(const HostMap &hm, const std::vector<float> &hp, const std::vector<uint8_t> &img)
+{
+    const int64_t n = (int64_t)hm.src.size();
+    if ((int64_t)img.size() != n * hm.elem) return false;
+    for (int64_t e = 0; e < n; e++) {
+        const float v = hm.kind[(size_t)e] == WM_ZERO ? 0.0f : hp[(size_t)hm.src[(size_t)e]];
+        if (hm.elem == 4) {
+            if (memcmp(&v, img.data() + 4 * e, 4) != 0) return false;
+        } else {
+            _Float16 h = (_Float16)v;
+            if (hm.kind[(size_t)e] == WM_F16_LO) h = (_Float16)(v - (float)h);
+            if (hm.kind[(size_t)e] == WM_ZERO) h = (_Float16)0.0f;
+            if (memcmp(&h, img.data() + 2 * e, 2) != 0) return false;
+        }
+    }
+    return true;
+}
+
+static int upload_weight_map(nrf_mlp *m, const HostMap &hm, void *d_out)
+{
+    WeightMap wm;
+    wm.n = (int64_t)hm.src.size(); wm.elem = hm.elem; wm.d_out = d_out;
+    if (wm.n == 0) return NRF_OK;
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&wm.d_src), (size_t)wm.n * 4));
+    NRF_HIP(hipMemcpy(wm.d_src, hm.src.data(), (size_t)wm.n * 4, hipMemcpyHostToDevice));
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&wm.d_kind), (size_t)wm.n));
+    NRF_HIP(hipMemcpy(wm.d_kind, hm.kind.data(), (size_t)wm.n, hipMemcpyHostToDevice));
+    m->maps.push_back(wm);
+    return NRF_OK;
+}
+
+static void drop_weight_maps(nrf_mlp *m)
+{
+    for (auto &w : m->maps) { if (w.d_src) (void)hipFree(w.d_src); if (w.d_kind) (void)hipFree(w.d_kind); }
+    m->maps.clear();
+}
+
+// NeRFSmall, after the images exist: NRF_OK with m->maps filled, or with m->maps empty when a layout does not decode (the host repack then stays in charge)
+static int build_weight_maps(nrf_mlp *m, const std::vector<float> &hp)
+{
+    if (m->family != MLP_SMALL || m->n_params >= (int64_t)WM_RADIX_LO * WM_RADIX_LO) return NRF_OK;
+    for (auto &L : m->layers) if (L.d_bias) return NRF_OK;
+    if (const char *e = getenv("NRF_MLP_HOST_REPACK")) if (atoi(e) != 0) return NRF_OK;
+    const auto &d = m->small;
+    enum { I_F16, I_SPLIT, I_BWD, I_SIG_HEAD, I_SIG_TAIL, N_IMG };
+    auto images = [&](const std::vector<float> &p, std::vector<uint8_t> *out) {
+        const bool a = mlp_small_images_host(d, p, out[I_F16], out[I_SPLIT]);
+        const bool b = mlp_small_bwd_image_host(m, p, out[I_BWD]);
+        const bool c = mlp_small_sigma_image_host(d, p, out[I_SIG_HEAD], out[I_SIG_TAIL]);
+        if (!a) { out[I_F16].clear(); out[I_SPLIT].clear(); }
+        if (!b) out[I_BWD].clear();
+        if (!c) { out[I_SIG_HEAD].clear(); out[I_SIG_TAIL].clear(); }
+    };
+    std::vector<uint8_t> real[N_IMG], probe[4][N_IMG];
+    images(hp, real);
+    for (int q = 0; q < 4; q++) images(weight_map_probe(m->n_params, q), probe[q]);
+    const int elem[N_IMG] = { 2, 2, 2, 4, 2 };
+    void *dst[N_IMG] = { m->d_packed_f16, m->d_packed_split, m->d_packed_bwd, m->d_packed_sigma_f32,
+                         m->d_packed_sigma_f32 ? static_cast<char *>(m->d_packed_sigma_f32) + real[I_SIG_HEAD].size() : nullptr };
+    const size_t have[N_IMG] = { m->packed_f16_bytes, m->packed_split_bytes, m->packed_bwd_bytes, m->packed_sigma_f32_bytes, m->packed_sigma_f32_bytes };
+    for (int im = 0; im < N_IMG; im++) {
+        if (real[im].empty()) { if (dst[im] && im != I_SIG_TAIL && have[im]) { drop_weight_maps(m); return NRF_OK; } continue; }
+        const size_t want = (im == I_SIG_HEAD || im == I_SIG_TAIL) ? real[I_SIG_HEAD].size() + real[I_SIG_TAIL].size() : real[im].size();
+        const std::vector<uint8_t> four[4] = { probe[0][im], probe[1][im], probe[2][im], probe[3][im] };
+        HostMap hm;
+        if (!dst[im] || have[im] != want || !decode_weight_map(four, elem[im], m->n_params, hm) || !weight_map_reproduces(hm, hp, real[im])) { drop_weight_maps(m); return NRF_OK; }
+        NRF_TRY(upload_weight_map(m, hm, dst[im]));
+    }
+    for (auto &L : m->layers) {                       // W^T [in][out] of the generic fp32 forward / backward
+        HostMap hm; hm.elem = 4;
+        hm.src.resize((size_t)L.in * L.out); hm.kind.assign(hm.src.size(), WM_F32);
+        for (int o = 0; o < L.out; o++)
+            for (int k = 0; k < L.in; k++) hm.src[(size_t)k * L.out + o] = (int32_t)(L.w_off + (size_t)o * L.in + k);
+        NRF_TRY(upload_weight_map(m, hm, L.d_wt));
+    }
+    return NRF_OK;
+}
+
+__global__ void k_apply_weight_map(int64_t n, const int32_t *__restrict__ src, const uint8_t *__restrict__ kind, const float *__restrict__ params, void *__restrict__ out, int elem)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int k = kind[e];
+    const float v = k == WM_ZERO ? 0.0f : params[src[e]];
+    if (elem == 4) { static_cast<float *>(out)[e] = v; return; }
+    __half h = __float2half_rn(v);
+    if (k == WM_F16_LO) h = __float2half_rn(v - __half2float(h));
+    static_cast<__half *>(out)[e] = h;
+}
+
 }  // namespace nrf
 
 using namespace nrf;
@@ -468,6 +610,7 @@ int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int p
         s = add_layer(m, hp, off, (l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color, (l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color, false);
     if (s == NRF_OK) s = mlp_small_pack_f16(m, hp);
     if (s == NRF_OK) s = mlp_small_pack_sigma_f32(m, hp);
+    if (s == NRF_OK) s = build_weight_maps(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -540,6 +683,17 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
 {
     NRF_CHECK_ARG(m && params, "nrf_mlp_set_params: null pointer");
     hipStream_t st = as_stream(stream);
+    if (!m->maps.empty()) {
+        // NeRFSmall: blob and every derived image refreshed on the device, in stream order, nothing waits.  Work issued earlier on `stream` (and on the library's
+        // lanes, which are joined to it before a render call returns) still reads the old images and finishes first; another stream of the caller's must be ordered
+        // by the caller, as for any in-place update.
+        NRF_HIP(hipMemcpyAsync(m->d_params, params, (size_t)m->n_params * 4, params_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        for (auto &w : m->maps) {
+            k_apply_weight_map<<<dim3((unsigned)((w.n + 255) / 256)), dim3(256), 0, st>>>(w.n, w.d_src, w.d_kind, m->d_params, w.d_out, w.elem);
+            NRF_HIP(hipGetLastError());
+        }
+        return NRF_OK;
+    }
     std::vector<float> hp((size_t)m->n_params);
     if (params_on_device) {
         NRF_HIP(hipMemcpyAsync(hp.data(), params, hp.size() * 4, hipMemcpyDeviceToHost, st));
@@ -565,6 +719,8 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
     if (m->family == MLP_LERF) { NRF_TRY(mlp_lerf_pack_f16(m, hp)); return mlp_lerf_pack_sigma_f32(m, hp); }
     return NRF_OK;
 }
+
+int nrf_mlp_device_repack_images(const nrf_mlp *m) { return m ? (int)m->maps.size() : 0; }
 
 size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p) { return m ? mlp_backward_workspace_bytes(m, p) : 0; }
 
@@ -603,6 +759,7 @@ void nrf_mlp_destroy(nrf_mlp *m)
         if (L.d_wt) (void)hipFree(L.d_wt);
         if (L.d_bias) (void)hipFree(L.d_bias);
     }
+    drop_weight_maps(m);
     if (m->d_params) (void)hipFree(m->d_params);
     if (m->d_packed_f16) (void)hipFree(m->d_packed_f16);
     if (m->d_packed_split) (void)hipFree(m->d_packed_split);

@@ -450,15 +450,12 @@ LayerOffs layer_offsets(const nrf_mlp *m)
 }  // namespace
 
 // W^T fragments of every layer in the order the gradient chain consumes them
-int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
+bool mlp_small_bwd_image_host(const nrf_mlp *m, const std::vector<float> &hp, std::vector<uint8_t> &img)
 {
     const auto &d = m->small;
     bool ok = bwd_supported(d);
     for (auto &L : m->layers) if (L.d_bias) ok = false;
-    if (!ok) {
-        if (m->d_packed_bwd) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; m->packed_bwd_bytes = 0; }
-        return NRF_OK;
-    }
+    if (!ok) return false;
     const int G = d.geo_feat_dim;
     auto natural = [](int ks, int h, int j) { return 16 * ks + 8 * h + j; };
     auto chained = [](int ks, int h, int j) { return 32 * (ks >> 1) + prow(ks & 1, h, j); };
@@ -486,11 +483,22 @@ int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
         else if (l > 0) pk.layer(transposed(L), 64, 64, 2, 4, chained);
         else pk.layer(transposed(L), 32, 64, 1, 4, chained);
     }
-    const size_t bytes = pk.img.size() * sizeof(_Float16);
+    img.assign(reinterpret_cast<const uint8_t *>(pk.img.data()), reinterpret_cast<const uint8_t *>(pk.img.data() + pk.img.size()));
+    return true;
+}
+
+int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
+{
+    std::vector<uint8_t> img;
+    if (!mlp_small_bwd_image_host(m, hp, img)) {
+        if (m->d_packed_bwd) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; m->packed_bwd_bytes = 0; }
+        return NRF_OK;
+    }
+    const size_t bytes = img.size();
     if (m->d_packed_bwd && m->packed_bwd_bytes != bytes) { (void)hipFree(m->d_packed_bwd); m->d_packed_bwd = nullptr; }
-    if (!m->d_packed_bwd) NRF_HIP(hipMalloc(&m->d_packed_bwd, bytes));        // re-packed every optimisation step: overwritten in place
+    if (!m->d_packed_bwd) NRF_HIP(hipMalloc(&m->d_packed_bwd, bytes));        // host path of nrf_mlp_set_params: overwritten in place
     m->packed_bwd_bytes = bytes;
-    NRF_HIP(hipMemcpy(m->d_packed_bwd, pk.img.data(), bytes, hipMemcpyHostToDevice));
+    NRF_HIP(hipMemcpy(m->d_packed_bwd, img.data(), bytes, hipMemcpyHostToDevice));
     return NRF_OK;
 }
 

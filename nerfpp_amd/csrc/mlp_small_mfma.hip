@@ -753,25 +753,34 @@ static void pack_small(const nrf_mlp_small_desc &d, const std::vector<float> &hp
     }
 }
 
-int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+bool mlp_small_images_host(const nrf_mlp_small_desc &d, const std::vector<float> &hp, std::vector<uint8_t> &f16_img, std::vector<uint8_t> &split_img)
 {
-    const auto &d = m->small;
-    if (!small_mfma_supported(d)) return NRF_OK;      // the matrix-core precisions then report NRF_ERR_UNSUPPORTED at forward time
+    if (!small_mfma_supported(d)) return false;
     Packer pk, pk2;
     pk2.split = true;
     pack_small(d, hp, pk);
     pack_small(d, hp, pk2);
-    // re-pack after nrf_mlp_set_params (every optimisation step): same sizes, so the device images are overwritten in place
-    auto upload = [](void *&dst, size_t &have, const std::vector<_Float16> &img) -> int {
-        const size_t bytes = img.size() * sizeof(_Float16);
+    f16_img.assign(reinterpret_cast<const uint8_t *>(pk.img.data()), reinterpret_cast<const uint8_t *>(pk.img.data() + pk.img.size()));
+    split_img.assign(reinterpret_cast<const uint8_t *>(pk2.img.data()), reinterpret_cast<const uint8_t *>(pk2.img.data() + pk2.img.size()));
+    return true;
+}
+
+int mlp_small_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->small;
+    std::vector<uint8_t> a, b;
+    if (!mlp_small_images_host(d, hp, a, b)) return NRF_OK;      // the matrix-core precisions then report NRF_ERR_UNSUPPORTED at forward time
+    // re-pack after nrf_mlp_set_params (host path): same sizes, so the device images are overwritten in place
+    auto upload = [](void *&dst, size_t &have, const std::vector<uint8_t> &img) -> int {
+        const size_t bytes = img.size();
         if (dst && have != bytes) { (void)hipFree(dst); dst = nullptr; }
         if (!dst) NRF_HIP(hipMalloc(&dst, bytes));
         have = bytes;
         NRF_HIP(hipMemcpy(dst, img.data(), bytes, hipMemcpyHostToDevice));
         return NRF_OK;
     };
-    NRF_TRY(upload(m->d_packed_f16, m->packed_f16_bytes, pk.img));
-    NRF_TRY(upload(m->d_packed_split, m->packed_split_bytes, pk2.img));
+    NRF_TRY(upload(m->d_packed_f16, m->packed_f16_bytes, a));
+    NRF_TRY(upload(m->d_packed_split, m->packed_split_bytes, b));
     return mlp_small_pack_bwd(m, hp);
 }
 

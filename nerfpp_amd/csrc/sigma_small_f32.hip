@@ -230,10 +230,10 @@ static bool sigma_f32_supported(const nrf_mlp_small_desc &d)
     return d.input_ch == 32 && d.hidden_dim == 64 && (d.num_layers == 2 || d.num_layers == 3);
 }
 
-int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+// head: the fp32 fragments of the hidden layers + the sigma row; tail: the whole last layer as split fp16 fragments of the GEO product (stored behind the head)
+bool mlp_small_sigma_image_host(const nrf_mlp_small_desc &d, const std::vector<float> &hp, std::vector<uint8_t> &head_f32, std::vector<uint8_t> &tail_f16)
 {
-    const auto &d = m->small;
-    if (!sigma_f32_supported(d)) return NRF_OK;
+    if (!sigma_f32_supported(d)) return false;
     std::vector<float> img;
     size_t off = 0;
     for (int l = 0; l + 1 < d.num_layers; l++) {
@@ -251,28 +251,32 @@ int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     }
     for (int k = 0; k < d.hidden_dim; k++) img.push_back(hp[off + k]);       // row 0 (sigma) of the last sigma-net layer [1 + geo][hidden]
     // the whole last layer (rows 0 .. geo) as split fp16 fragments of the GEO product: k-step (t, u), lane (row i, half hh), element j = W[i][32t + 16u + 2j + hh]
-    {
-        const int rows = 1 + d.geo_feat_dim;
-        std::vector<_Float16> frag;
-        for (int ks = 0; ks < 4; ks++)
-            for (int part = 0; part < 2; part++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++) {
-                        const int i = lane & 31, k = 32 * (ks >> 1) + 16 * (ks & 1) + 2 * j + (lane >> 5);
-                        const float v = i < rows ? hp[off + (size_t)i * d.hidden_dim + k] : 0.0f;
-                        const _Float16 hv = (_Float16)v;
-                        frag.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
-                    }
-        const size_t nf = frag.size() * sizeof(_Float16) / sizeof(float);
-        const size_t at = img.size();
-        img.resize(at + nf);
-        std::memcpy(img.data() + at, frag.data(), nf * sizeof(float));
-    }
-    const size_t bytes = img.size() * sizeof(float);
+    const int rows = 1 + d.geo_feat_dim;
+    std::vector<_Float16> frag;
+    for (int ks = 0; ks < 4; ks++)
+        for (int part = 0; part < 2; part++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int i = lane & 31, k = 32 * (ks >> 1) + 16 * (ks & 1) + 2 * j + (lane >> 5);
+                    const float v = i < rows ? hp[off + (size_t)i * d.hidden_dim + k] : 0.0f;
+                    const _Float16 hv = (_Float16)v;
+                    frag.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
+                }
+    head_f32.assign(reinterpret_cast<const uint8_t *>(img.data()), reinterpret_cast<const uint8_t *>(img.data() + img.size()));
+    tail_f16.assign(reinterpret_cast<const uint8_t *>(frag.data()), reinterpret_cast<const uint8_t *>(frag.data() + frag.size()));
+    return true;
+}
+
+int mlp_small_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+{
+    std::vector<uint8_t> head, tail;
+    if (!mlp_small_sigma_image_host(m->small, hp, head, tail)) return NRF_OK;
+    const size_t bytes = head.size() + tail.size();
     if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
     if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));
     m->packed_sigma_f32_bytes = bytes;
-    NRF_HIP(hipMemcpy(m->d_packed_sigma_f32, img.data(), bytes, hipMemcpyHostToDevice));
+    NRF_HIP(hipMemcpy(m->d_packed_sigma_f32, head.data(), head.size(), hipMemcpyHostToDevice));
+    NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_sigma_f32) + head.size(), tail.data(), tail.size(), hipMemcpyHostToDevice));
     return NRF_OK;
 }
 

@@ -135,8 +135,7 @@ class _HashBase(BaseEmbedder):
         if torch.is_tensor(table) and table.is_cuda:
             t = table.contiguous().float().reshape(-1)
             assert t.numel() == self.table_elems()
-            L.check(L.lib().nrf_hash_set_table(self._h, _ptr(t), 1, _stream()))
-            torch.cuda.current_stream().synchronize()
+            L.check(L.lib().nrf_hash_set_table(self._h, _ptr(t), 1, _stream()))       # stream-ordered: the cast (and a re-bake into an existing image) queue behind `t`
         else:
             a = np.ascontiguousarray(table.detach().cpu().numpy() if torch.is_tensor(table) else table, np.float32).reshape(-1)
             assert a.size == self.table_elems()

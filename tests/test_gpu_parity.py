@@ -1085,6 +1085,48 @@ def test_mlp_backward_matrix_core_level_major_input(api):
     assert_close(host(gb), host(ga), rtol=1e-5, atol=1e-6 * float(ga.abs().max()), what="weight gradients (LDS float-atomic order only)")
 
 
+@pytest.mark.parametrize("nl,nlc", [(3, 4), (2, 3)])
+def test_mlp_set_params_on_the_device_equals_a_freshly_packed_handle(api, nl, nlc):
+    """nrf_mlp_set_params of a NeRFSmall handle refreshes the blob and every derived image (fp16 / split / sigma-fp32 + geo / backward fragments, transposed fp32
+    layers) ON THE DEVICE from gather maps decoded out of the host packers (mlp.hip build_weight_maps).  A handle created with blob A and moved to blob B must be
+    indistinguishable, bit for bit, from one created with B: all forward precisions, both backward chains, and a rendered frame (exact coarse sigma pass + geo
+    hand-over) after going A -> garbage -> A.  Reference: the optimizer step of NeRFExecutor::Train (NeRFExecutor.h:653-770) changes every weight each iteration."""
+    import ctypes as C
+    P = lambda t: C.c_void_p(t.data_ptr())
+    lib = api.L.lib()
+    a = api.S.make_hash_scene(mode="cu", log2_t=14, seed=77, num_layers=nl, num_layers_color=nlc)
+    b = api.S.make_hash_scene(mode="cu", log2_t=14, seed=78, num_layers=nl, num_layers_color=nlc)
+    ma, mb = a["mlp"], b["mlp"]
+    assert lib.nrf_mlp_device_repack_images(ma._m) >= 5 + nl + nlc, "the packers' layouts must decode into gather maps (else set_params silently takes the host path)"
+    rng = np.random.default_rng(5)
+    p = 1000
+    x = dev(rng.uniform(-1, 1, (p, 48)).astype(np.float32))
+    gr = dev((rng.standard_normal((p, 4)) * 1e-3).astype(np.float32))
+    K = api.S.lego_K(40, 40); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(a["bbox"], 16, 32, 4096, api.L.NRF_PREC_F16_SPLIT)
+    frame_a = host(a["renderer"].Render(40, 40, K, rp, c2w=c2w).Outputs.RGBMap)
+
+    blob_b = dev(b["mlp_blob"])
+    api.L.check(lib.nrf_mlp_set_params(ma._m, P(blob_b), 1, None))                      # device source
+    for prec, name in ((api.L.NRF_PREC_F32, "fp32"), (api.L.NRF_PREC_F16_MFMA, "fp16"), (api.L.NRF_PREC_F16_SPLIT, "split")):
+        assert_exact(host(ma.forward(x, prec)), host(mb.forward(x, prec)), f"forward {name}: updated handle == fresh handle")
+    for entry, wsb in ((lib.nrf_mlp_backward, lib.nrf_mlp_backward_workspace_bytes), (lib.nrf_mlp_backward_f16, lib.nrf_mlp_backward_f16_workspace_bytes)):
+        res = []
+        for m in (ma, mb):
+            nb = wsb(m._m, C.c_int64(p)); ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            g = torch.zeros(m.n_params, device="cuda"); gx = torch.zeros((p, 32), device="cuda")
+            api.L.check(entry(m._m, P(x), P(gr), C.c_int64(p), P(g), P(gx), P(ws), C.c_size_t(nb), None))
+            res.append((host(g), host(gx)))
+        assert np.abs(res[1][1]).max() > 0
+        assert_exact(res[0][1], res[1][1], "d loss / d features: updated handle == fresh handle")
+        assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-6 * np.abs(res[1][0]).max(), what="weight gradients (float-atomic order only)")
+
+    frame_b = host(a["renderer"].Render(40, 40, K, rp, c2w=c2w).Outputs.RGBMap)
+    assert np.abs(frame_b - frame_a).max() > 1e-3                                       # the frame really depends on the weights
+    api.L.check(lib.nrf_mlp_set_params(ma._m, C.c_void_p(a["mlp_blob"].ctypes.data), 0, None))      # host source
+    assert_exact(host(a["renderer"].Render(40, 40, K, rp, c2w=c2w).Outputs.RGBMap), frame_a, "frame after A -> B -> A")
+
+
 def test_mlp_backward_matrix_core_edges(api):
     """Boundary behaviour of nrf_mlp_backward_f16: empty batch, optional d_g_x, all-zero output gradient (loss scale of nothing), accumulation into a
     non-zero gradient blob, a workspace that is too small, a NeRFSmall shape outside the built family, more points than one 2^22-point pass."""
