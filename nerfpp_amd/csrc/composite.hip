@@ -78,24 +78,65 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
     using acc_t = typename std::conditional<FAST, float, double>::type;
     acc_t carry = 0;                                               // sum of log(1-alpha) over previous 64-sample blocks
     acc_t sr = 0, sg = 0, sb = 0, sw = 0, swz = 0;
+    // FAST, s <= 256 (the renderer's fine pass: 192 merged samples): the wave's inputs of ALL its 64-sample blocks are requested before the first is used -- merge-map
+    // entries, then the rows they name, the depths and their right neighbours.  Block by block the kernel was a chain of dependent loads per block (map -> row) with one
+    // ray per wave to hide it behind; the arithmetic and its order are unchanged.
+    constexpr int PRE = FAST ? 4 : 0;
+    const bool pre = FAST && s <= 64 * PRE && c == 4 && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0) && (!raw2 || (reinterpret_cast<uintptr_t>(raw2) & 15) == 0);
+    float4 pr4[PRE > 0 ? PRE : 1];
+    float pz[PRE > 0 ? PRE : 1], pzn[PRE > 0 ? PRE : 1];
+    if constexpr (FAST) {
+        if (pre) {
+            int64_t prow[PRE];
+#pragma unroll
+            for (int b = 0; b < PRE; b++) {
+                const int j = b * 64 + lane;
+                prow[b] = ray * s + (j < s ? j : s - 1);
+                if (src && b * 64 < s) prow[b] = src[prow[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < PRE; b++) {
+                if (b * 64 >= s) continue;                       // wave-uniform
+                const int j = b * 64 + lane, jc = j < s ? j : s - 1;
+                const float *r = raw + prow[b] * 4;
+                if (src) r = prow[b] < n_split ? raw + prow[b] * 4 : raw2 + (prow[b] - n_split) * 4;
+                pr4[b] = *reinterpret_cast<const float4 *>(r);
+                pz[b] = zr[jc];
+                pzn[b] = zr[jc + 1 < s ? jc + 1 : jc];
+            }
+        }
+    }
     for (int base = 0; base < s; base += 64) {
         const int j = base + lane;
         const bool live = j < s;
         float w = 0.0f, zj = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, lg = 0.0f;
         float alpha = 0.0f;
         if (live) {
-            const float *r = raw + (ray * s + j) * c;
-            if (src) {
-                const int64_t row = src[ray * s + j];
-                r = row < n_split ? raw + row * c : raw2 + (row - n_split) * c;
-            }
-            zj = zr[j];
-            float dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
-            dist = dist * nrm;                                      // :241
-            // c == 4 (rgb, sigma): one 16-byte load per sample instead of four dword loads
             float4 r4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            const bool vec = (c == 4) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
-            if (vec) r4 = *reinterpret_cast<const float4 *>(r);
+            bool vec;
+            const float *r = nullptr;
+            float dist;
+            if (FAST && pre) {
+                const int b = base >> 6;
+                // a compile-time index per block (the arrays stay in registers)
+                r4 = b == 0 ? pr4[0] : b == 1 ? pr4[PRE > 1 ? 1 : 0] : b == 2 ? pr4[PRE > 2 ? 2 : 0] : pr4[PRE > 3 ? 3 : 0];
+                zj = b == 0 ? pz[0] : b == 1 ? pz[PRE > 1 ? 1 : 0] : b == 2 ? pz[PRE > 2 ? 2 : 0] : pz[PRE > 3 ? 3 : 0];
+                const float zn = b == 0 ? pzn[0] : b == 1 ? pzn[PRE > 1 ? 1 : 0] : b == 2 ? pzn[PRE > 2 ? 2 : 0] : pzn[PRE > 3 ? 3 : 0];
+                dist = (j + 1 < s) ? (zn - zj) : 1e10f;
+                vec = true;
+            } else {
+                r = raw + (ray * s + j) * c;
+                if (src) {
+                    const int64_t row = src[ray * s + j];
+                    r = row < n_split ? raw + row * c : raw2 + (row - n_split) * c;
+                }
+                zj = zr[j];
+                dist = (j + 1 < s) ? (zr[j + 1] - zj) : 1e10f;   // NeRFRenderer.h:239-240
+                // c == 4 (rgb, sigma): one 16-byte load per sample instead of four dword loads
+                vec = (c == 4) && ((reinterpret_cast<uintptr_t>(raw) & 15) == 0);
+                if (vec) r4 = *reinterpret_cast<const float4 *>(r);
+            }
+            dist = dist * nrm;                                      // :241
             float sg = vec ? (sigma_ch == 3 ? r4.w : sigma_ch == 0 ? r4.x : sigma_ch == 1 ? r4.y : r4.z) : r[sigma_ch];
             if (nz.on)                                              // raw_noise_std > 0 (:251-252)
                 sg = sg + (nz.arr ? nz.arr[ray * s + j] : nrf_rng_normal(nz.g.seed, nz.stream, (uint64_t)((nz.g.ray_base + ray) * s + j))) * nz.std;
