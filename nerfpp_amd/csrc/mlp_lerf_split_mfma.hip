@@ -29,6 +29,16 @@ namespace lerf {
 #ifndef NRF_LERF_GRAM_HI_STREAM
 #define NRF_LERF_GRAM_HI_STREAM 1        // Gram layer without its lo part: only the hi fragments are streamed into LDS and read (0: both, as the image holds them)
 #endif
+#ifndef NRF_LERF_GRAM_TRI
+#define NRF_LERF_GRAM_TRI 1              // Gram layer as the upper block triangle of the symmetric matrix (the image holds it that way, see mlp_lerf_mfma.hip): neuron tile T
+#endif                                   // starts at k-step 2 T -- 72 instead of 128 k-steps per point tile; 0: all sixteen (the skipped blocks of the image are zero)
+
+#ifndef NRF_LERF_GRAM_ORDER
+#define NRF_LERF_GRAM_ORDER 1            // block-triangular Gram layer: neuron tiles in the order 0 7 1 6 2 5 3 4 (16, 2, 14, 4, ... k-steps), so any two consecutive chunks
+#endif                                   // hold 18 k-steps -- the weight stream runs two CHUNKS ahead, and behind tiles 6, 7 (4 + 2 k-steps) that was ~200 cycles
+#ifndef NRF_LERF_ABLATE
+#define NRF_LERF_ABLATE 0                // timing-only ablations of kernel B (results are garbage): 1 no weight stream, 2 no chunk barrier, 4 no conversions, 8 no Gram dot
+#endif                                   // products, 16 no ray sum, 32 no operand prefetch (tools/scratch/lerf_ablate.sh)
 
 constexpr int SNW = 4;                 // waves per workgroup: one per SIMD
 constexpr int SNBLK = 32 * SNW;
@@ -47,9 +57,20 @@ struct NetS {
     // fragment 2 i (hi of k-step i) into its usual slot, the lo slots left alone.  The weight stream's LDS-side write is what bounds kernel B (38 GB/s per CU taken in,
     // matrix pipe busy 0.37-0.40), and the Gram chunks were a quarter of it.
     static constexpr bool hi_only(int ci) { return NL == 4 && layer_of(ci) == 3 && !(NRF_LERF_GRAM_GLO) && (NRF_LERF_GRAM_HI_STREAM); }
-    static constexpr int dma_frags(int ci) { return hi_only(ci) ? F::ks(layer_of(ci)) : chunk_frags(ci); }
+    // Gram layer, block-triangular (NRF_LERF_GRAM_TRI): tile T of the layer multiplies k-steps 2 T .. 15 only; its stream starts at the multiple of four below (the
+    // pieces are dealt out four fragments -- one per wave -- at a time)
+    // neuron tile a chunk computes: its position in the layer, except in the block-triangular Gram layer (NRF_LERF_GRAM_ORDER)
+    static constexpr int tile_of(int ci)
+    {
+        const int c = ci - first_chunk(layer_of(ci));
+        if (NL == 4 && layer_of(ci) == 3 && (NRF_LERF_GRAM_TRI) && (NRF_LERF_GRAM_ORDER)) return (c & 1) ? 7 - (c >> 1) : (c >> 1);
+        return c;
+    }
+    static constexpr int k0(int ci) { return (NL == 4 && layer_of(ci) == 3 && (NRF_LERF_GRAM_TRI)) ? 2 * tile_of(ci) : 0; }
+    static constexpr int k0_dma(int ci) { return k0(ci) & ~3; }
+    static constexpr int dma_frags(int ci) { return (hi_only(ci) ? 1 : 2) * (F::ks(layer_of(ci)) - k0_dma(ci)); }
     static constexpr int image_off() { int n = 0; for (int i = 0; i < L0; i++) n += F::tiles(i) * 2 * F::ks(i); return n; }      // fragments of the skipped layers
-    static constexpr int chunk_off(int ci) { int n = image_off(); for (int i = 0; i < ci; i++) n += chunk_frags(i); return n; }
+    static constexpr int chunk_off(int ci) { int n = image_off(); for (int i = 0; i < first_chunk(layer_of(ci)); i++) n += chunk_frags(i); return n + tile_of(ci) * chunk_frags(ci); }
 };
 static_assert(NetS<4, 2>::total_chunks() == 16 && NetS<4, 2>::chunk_off(0) == 2 * (8 * 8 + 2 * 16), "kernel B from LE0 on");
 static_assert(NetS<2>::total_chunks() == 10 && NetS<4>::total_chunks() == 26, "chunk counts");
@@ -62,15 +83,16 @@ __device__ __forceinline__ void stage_piece(half8 *__restrict__ dst, const half8
     constexpr int nf = N::dma_frags(ci);
     constexpr int STEP = N::hi_only(ci) ? 2 : 1;          // hi-only chunks: every second fragment of the image, into its usual slot
     static_assert(nf % SNW == 0, "fragments per chunk must divide by the wave count");
-    if constexpr (Q * SNW < nf) {
+    if constexpr (Q * SNW < nf && !((NRF_LERF_ABLATE) & 1)) {
         constexpr int base = N::chunk_off(ci);
         // the fragment's address = SGPR base (its constant offset added on the scalar side, then made opaque) + lane * 16: the saddr form of the DMA.  With the offset
         // added after the opaque point the compiler forms a 64-bit per-lane address instead -- two v_lshl_add_u64 per DMA, ~1 070 per iteration of the classic kernel
         const half8 *pk = packed + (size_t)wave * (64 * STEP);
         asm volatile("" : "+s"(pk));                          // opaque: the addresses derived from it cannot be hoisted out of the persistent loop (533 SGPR pairs would spill)
-        pk += (size_t)(base + STEP * Q * SNW) * 64;
+        constexpr int F0 = 2 * N::k0_dma(ci);                 // first fragment of the chunk that travels (block-triangular Gram tiles skip their leading k-steps)
+        pk += (size_t)(base + F0 + STEP * Q * SNW) * 64;
         asm volatile("" : "+s"(pk));                          // the offset is added HERE, on the scalar side (s_add_u32 / s_addc_u32)
-        __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + STEP * (Q * SNW + wave) * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(pk + lane, (__attribute__((address_space(3))) void *)(dst + (F0 + STEP * (Q * SNW + wave)) * 64), 16, 0, 0);
     }
 }
 
@@ -127,9 +149,11 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     constexpr int CI = N::first_chunk(L) + T;
     constexpr bool NATF = F::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
+    constexpr int K0 = N::k0(CI);                 // first k-step of this chunk (block-triangular Gram tiles: 2 T)
+    constexpr int KRUN = KS - K0;
     constexpr int NQ = N::dma_frags((CI + 2) % N::total_chunks()) / SNW;
-    constexpr int EVERY = (KS / NQ) > 0 ? (KS / NQ) : 1;
-    constexpr int LEAD = NQ > KS / EVERY ? NQ - KS / EVERY : 0;
+    constexpr int EVERY = (KRUN / NQ) > 0 ? (KRUN / NQ) : 1;
+    constexpr int LEAD = NQ > KRUN / EVERY ? NQ - KRUN / EVERY : 0;
     static_assert(NQ <= 8, "piece switch covers 8 pieces per wave");
     stage_all<N, CI + 2>(dma_dst, cx.packed, cx.wave, cx.lane, std::make_integer_sequence<int, LEAD>{});
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -140,7 +164,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     constexpr int NT = F::tiles(L);
     constexpr bool DEFER = Hook::UNITS > 0;
     constexpr bool PEND = DEFER && T > 0;
-    static_assert(!DEFER || Hook::UNITS <= KS, "a deferred tile's units must fit the next tile's k-steps");
+    static_assert(!DEFER || Hook::UNITS <= KRUN, "a deferred tile's units must fit the next tile's k-steps");
     f32x16 &acc = cx.accs[T & 1];
     const f32x16 &prev = cx.accs[(T & 1) ^ 1];
     acc = zero;
@@ -155,10 +179,10 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         if constexpr (HI) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fa[slot][0]) : "v"(waddr), "i"(kk_ * 2048));
         else asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(fa[slot][0]), "=&v"(fa[slot][1]) : "v"(waddr), "i"(kk_ * 2048), "i"(kk_ * 2048 + 1024));     // offsets in the instruction, not a v_add_u32 per pair
     };
-    read_pair(0, 0);
-    if (KS > 1) read_pair(1, 1);
+    read_pair(K0, K0 % 3);
+    if (KRUN > 1) read_pair(K0 + 1, (K0 + 1) % 3);
 #pragma unroll
-    for (int k = 0; k < KS; k++) {
+    for (int k = K0; k < KS; k++) {
         if (k + 2 < KS) {
             read_pair(k + 2, (k + 2) % 3);
             if constexpr (HI) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[k % 3][0]));
@@ -181,9 +205,9 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        if constexpr (PEND) { if (k < Hook::UNITS) hook.unit(T - 1, prev, k); }
+        if constexpr (PEND) { if (k - K0 < Hook::UNITS) hook.unit(N::tile_of(CI - 1), prev, k - K0); }
         pf.template kstep<CI>(k);
-        if ((k % EVERY) == EVERY - 1 && q < NQ) {
+        if (((k - K0) % EVERY) == EVERY - 1 && q < NQ) {
             const int qq = q;
             switch (qq) {
 #define NRF_PIECE(Q) case Q: stage_piece<N, CI + 2, Q>(dma_dst, cx.packed, cx.wave, cx.lane); break;
@@ -201,9 +225,10 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         pf.template issue<CI>();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!DEFER || T == NT - 1) hook(T, acc);
+    if constexpr (!DEFER || T == NT - 1) hook(N::tile_of(CI), acc);
     __builtin_amdgcn_sched_barrier(0);          // the tile is consumed here (see mlp_lerf_mfma.hip)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NQ + EXTRA) : "memory");
+    if constexpr ((NRF_LERF_ABLATE) & 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((NRF_LERF_ABLATE) & 1) ? EXTRA : NQ + EXTRA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(((NRF_LERF_ABLATE) & 1) ? EXTRA : NQ + EXTRA) : "memory");
 }
 
 template <class N, int L, int T, bool BNLO, bool BCLO, bool WLO, int NN, int NC, class Hook, class PF>
@@ -240,6 +265,7 @@ struct ConvHookS {
     static constexpr int UNITS = 8;          // deferrable: unit u = values 8s + 2j, 8s + 2j + 1 (s = u >> 2, j = u & 3) -> words j of fragments 2 tile + s
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
+        if constexpr ((NRF_LERF_ABLATE) & 4) { asm volatile("" :: "v"(t[0])); return; }
         if (2 * tile + 1 < NOUT) {
             tile_to_frag2<RELU>(t, 0, bout[2 * tile][0], bout[2 * tile][1]);
             tile_to_frag2<RELU>(t, 1, bout[2 * tile + 1][0], bout[2 * tile + 1][1]);
@@ -248,6 +274,7 @@ struct ConvHookS {
     }
     __device__ __forceinline__ void unit(int tile, const f32x16 &t, int u)
     {
+        if constexpr ((NRF_LERF_ABLATE) & 4) { asm volatile("" :: "v"(t[0])); return; }
         if (2 * tile + 1 < NOUT) {
             const int s = u >> 2, j = u & 3;
             const float lim = RELU ? 0.0f : -3.402823466e38f;
@@ -317,6 +344,7 @@ struct DotHookS {
     }
     __device__ __forceinline__ void operator()(int tile, const f32x16 &t)
     {
+        if constexpr ((NRF_LERF_ABLATE) & 8) { ss += t[0]; return; }
 #pragma unroll
         for (int i = 0; i < 16; i++) ss = mix_dot(t[i], a[2 * tile + (i >> 3)], i & 7, ss);
         asm volatile("" : "+v"(ss));
@@ -476,7 +504,7 @@ struct GeoPF {
     int h;
     int64_t q1;                // tile t + 1: sample index of this lane (clamped to the launch)
     int par;                   // weight slot of the tile whose operands were issued last
-    static constexpr int count(int ci) { return ci == 0 ? 1 : ci == 4 ? GEO_OPER_FRAGS + 1 : 0; }
+    static constexpr int count(int ci) { return ((NRF_LERF_ABLATE) & 32) ? 0 : ci == 0 ? 1 : ci == 4 ? GEO_OPER_FRAGS + 1 : 0; }
     __device__ __forceinline__ float *wslot(int p) const { return reinterpret_cast<float *>(oper + GEO_OPER_FRAGS * 64) + p * 64; }
     __device__ __forceinline__ int32_t *cslot() const { return reinterpret_cast<int32_t *>(oper + GEO_OPER_FRAGS * 64) + 128; }
     // one DMA either way (the count is a constant): without a merge map the slot receives a dummy word and the column is the sample index
@@ -490,7 +518,8 @@ struct GeoPF {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(cslot() + lane)) : "memory");
         // per-lane part of the addresses (column, lane half) formed HERE, plane offsets uniform: nothing the compiler could precompute per lane and carry (or
         // spill) across the tile
-        const int64_t col = in.src ? (int64_t)c : q1;
+        int64_t col = in.src ? (int64_t)c : q1;
+        if constexpr ((NRF_LERF_ABLATE) & 64) col = col & 1023;          // timing only: every tile gathers the same cache-resident columns
         const half8 *gb = reinterpret_cast<const half8 *>(in.geo) + ((col << 1) + h);
         const __half *xb = in.x_lm + ((int64_t)h * in.pstride + col) * 8;
 #pragma unroll
@@ -506,6 +535,7 @@ struct GeoPF {
     template <int CI>
     __device__ __forceinline__ void issue()
     {
+        if constexpr ((NRF_LERF_ABLATE) & 32) return;
         if constexpr (CI == 0) load_col();
         else load_operands(lane_);
     }
@@ -621,6 +651,7 @@ k_lerf_split_geo(int64_t npts, Args in, const half8 *__restrict__ packed)
         // fragments 2t, 2t+1 of a hold, on each lane, the neurons of D-tile t's 16 registers.  The tile's share is added behind the next tile's LE0 (GeoPF::kstep),
         // except a ray's last one
         if (NRF_LERF_DEFER_SUM && jt + 1 < tpr) pf.f_prev = f;
+        else if constexpr ((NRF_LERF_ABLATE) & 16) vsum[0][0] += f;
         else {
             pf.f_prev = 0.0f;
 #pragma unroll

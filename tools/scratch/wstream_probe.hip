@@ -14,7 +14,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int FR = 32;                    // fragments per chunk (16 k-steps x (hi, lo)), 1 KB each
+#ifndef KSTEPS
+#define KSTEPS 16
+#endif
+#ifndef AHEAD
+#define AHEAD 2                           // chunks the stream runs ahead (ring of AHEAD + 1 buffers)
+#endif
+constexpr int KST = KSTEPS;               // k-steps per chunk (kernel A's sigma0 chunks: 8, two products each)
+constexpr int FR = 2 * KST;               // fragments per chunk (k-steps x (hi, lo)), 1 KB each
 constexpr int NW = 4;
 constexpr int PIECES = FR / NW;           // 8 per wave per chunk
 constexpr int CHUNKS_IN_IMAGE = 40;       // 1.25 MB image: L2-resident, as the kernels' weight images are
@@ -22,9 +29,10 @@ constexpr int CHUNKS_IN_IMAGE = 40;       // 1.25 MB image: L2-resident, as the 
 template <int MODE>
 __global__ void __launch_bounds__(64 * NW) k(const half8 *__restrict__ image, int chunks, float *out, long long *cycles)
 {
-    __shared__ half8 buf[3][FR * 64];
+    constexpr int RING = AHEAD + 1;
+    __shared__ half8 buf[RING][FR * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 3 * FR * 64; i += blockDim.x) (&buf[0][0])[i] = image[i];
+    for (int i = threadIdx.x; i < RING * FR * 64; i += blockDim.x) (&buf[0][0])[i] = image[i];
     __syncthreads();
     f32x16 acc;
     for (int j = 0; j < 16; j++) acc[j] = (float)(lane + j);
@@ -36,17 +44,17 @@ __global__ void __launch_bounds__(64 * NW) k(const half8 *__restrict__ image, in
     // chunk c computes from buf[c % 3]; chunk c + 2's pieces are issued during chunk c
     auto chunk = [&](int c, auto parity) {
         constexpr int PAR = decltype(parity)::value;
-        const half8 *w = buf[c % 3];
-        half8 *dst = buf[(c + 2) % 3];
-        half8 *dst1 = buf[(c + 1) % 3];
-        const half8 *src = image + (size_t)((c + 2) % CHUNKS_IN_IMAGE) * FR * 64;
+        const half8 *w = buf[c % RING];
+        half8 *dst = buf[(c + AHEAD) % RING];
+        half8 *dst1 = buf[(c + 1) % RING];
+        const half8 *src = image + (size_t)((c + AHEAD) % CHUNKS_IN_IMAGE) * FR * 64;
         // A fragments two k-steps ahead (as the kernels read them), so the LDS latency is not what a k-step waits for
-        half8 ah[18], al[18];
+        half8 ah[KST + 2], al[KST + 2];
         ah[0] = w[0 * 64 + lane]; al[0] = w[1 * 64 + lane];
         ah[1] = w[2 * 64 + lane]; al[1] = w[3 * 64 + lane];
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) {
-            if (ks + 2 < 16) { ah[ks + 2] = w[(2 * ks + 4) * 64 + lane]; al[ks + 2] = w[(2 * ks + 5) * 64 + lane]; }
+        for (int ks = 0; ks < KST; ks++) {
+            if (ks + 2 < KST) { ah[ks + 2] = w[(2 * ks + 4) * 64 + lane]; al[ks + 2] = w[(2 * ks + 5) * 64 + lane]; }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc, 0, 0, 0);
@@ -63,7 +71,7 @@ __global__ void __launch_bounds__(64 * NW) k(const half8 *__restrict__ image, in
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (AHEAD - 1)) : "memory");
         __syncthreads();
     };
     for (int c = 0; c + 1 < chunks; c += 2) {
@@ -94,7 +102,7 @@ static void run(const half8 *img, float *out, long long *cyc, int chunks, const 
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); }
     }
-    printf("mode %d  %-58s %8.3f ms   %7.0f clock64 ticks per chunk (48 matrix instructions = 1 536 pipe cycles)\n", MODE, what, best, (double)c / chunks);
+    printf("mode %d  %-58s %8.3f ms   %7.0f clock64 ticks per chunk (%d matrix instructions = %d pipe cycles; %d chunks ahead)\n", MODE, what, best, (double)c / chunks, 3 * KST, 96 * KST, AHEAD);
 }
 
 int main()
