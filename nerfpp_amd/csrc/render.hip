@@ -613,7 +613,16 @@ static int lanes_of(const nrf_renderer *r, int lanes, hipStream_t *st, hipEvent_
         NRF_HIP(hipSetDevice(cur));
     }
     for (int i = 0; i < lanes; i++) {
-        if (!r->lane[i]) NRF_HIP(hipStreamCreateWithFlags(&r->lane[i], hipStreamNonBlocking));
+        if (!r->lane[i]) {
+            // NRF_LANE_CU_MASK=1 (experiment, profiles/round4/r4z_*): lane i of L on its own 256 / L compute units (hipExtStreamCreateWithCUMask; a contiguous bit range)
+            static const int masked = [] { const char *e = getenv("NRF_LANE_CU_MASK"); return e ? atoi(e) : 0; }();
+            if (masked && lanes > 1) {
+                uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int per = 256 / lanes;
+                for (int b = i * per; b < (i + 1) * per; b++) bits[b >> 5] |= 1u << (b & 31);
+                NRF_HIP(hipExtStreamCreateWithCUMask(&r->lane[i], 8, bits));
+            } else NRF_HIP(hipStreamCreateWithFlags(&r->lane[i], hipStreamNonBlocking));
+        }
         if (!r->lane_done[i]) NRF_HIP(hipEventCreateWithFlags(&r->lane_done[i], hipEventDisableTiming));
         st[i] = r->lane[i]; done[i] = r->lane_done[i];
     }
