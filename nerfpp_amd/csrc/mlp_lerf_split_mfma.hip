@@ -150,6 +150,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
     constexpr bool NATF = F::nat_first(L);
     static_assert(KSN <= NN && KSC <= NC, "operand fragment arrays too small");
     constexpr int K0 = N::k0(CI);                 // first k-step of this chunk (block-triangular Gram tiles: 2 T)
+    constexpr int TILE = N::tile_of(CI), TILE_PREV = T > 0 ? N::tile_of(CI - 1) : 0;          // constants: as call arguments the compiler evaluated them at run time (and the hooks' fragment arrays went to scratch)
     constexpr int KRUN = KS - K0;
     constexpr int NQ = N::dma_frags((CI + 2) % N::total_chunks()) / SNW;
     constexpr int EVERY = (KRUN / NQ) > 0 ? (KRUN / NQ) : 1;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        if constexpr (PEND) { if (k - K0 < Hook::UNITS) hook.unit(N::tile_of(CI - 1), prev, k - K0); }
+        if constexpr (PEND) { if (k - K0 < Hook::UNITS) hook.unit(TILE_PREV, prev, k - K0); }
         pf.template kstep<CI>(k);
         if (((k - K0) % EVERY) == EVERY - 1 && q < NQ) {
             const int qq = q;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void chunk_body_s(const CtxS &cx, const half8 *__rest
         pf.template issue<CI>();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!DEFER || T == NT - 1) hook(N::tile_of(CI), acc);
+    if constexpr (!DEFER || T == NT - 1) hook(TILE, acc);
     __builtin_amdgcn_sched_barrier(0);          // the tile is consumed here (see mlp_lerf_mfma.hip)
     if constexpr ((NRF_LERF_ABLATE) & 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((NRF_LERF_ABLATE) & 1) ? EXTRA : NQ + EXTRA) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(((NRF_LERF_ABLATE) & 1) ? EXTRA : NQ + EXTRA) : "memory");
