@@ -100,7 +100,9 @@ def main():
         sc = scene.make_hash_scene(mode=args.hash_mode)
         if args.dense_mb >= 0 and args.hash_mode == "cu":
             sc["embedder"].set_dense_budget(int(args.dense_mb * (1 << 20)))
-        chunk = args.chunk or 131072
+        # 65 536 rays per RenderRays call: same-call A/B over 49 152 / 65 536 / 131 072 gives 21.3-21.6 / 21.4-21.7 / 21.8 ms per frame (profiles/round4/r4G_*), and every
+        # slow-box outlier of the round (frames of 45-130 ms on some boxes, r4d_lane_sweep_first_box.log, r4E_*) was at chunks of 98 304 rays and more
+        chunk = args.chunk or 65536
     else:
         sc = scene.make_classic_scene()
         chunk = args.chunk or 8192

@@ -68,7 +68,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                 scenes[wl] = scene.make_hash_scene(mode=args.hash_mode) if wl == "hash" else scene.make_classic_scene()
             sc = scenes[wl]
             prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[pname]
-            rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072 if wl == "hash" else 8192, prec)
+            rp = scene.lego_render_params(sc["bbox"], NS, NI, 65536 if wl == "hash" else 8192, prec)
             if coarse == "full":
                 rp.CoarseMode = L.NRF_COARSE_FULL
             n_fr = steps if not (wl == "classic" and pname == "f16x3") else max(3, steps // 2)
@@ -111,7 +111,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
         # pins the oracle) -- fp32 table, hi + lo fp16 feature planes
         try:
             sc = scene.make_hash_scene(mode="ngp")
-            rp = scene.lego_render_params(sc["bbox"], NS, NI, 131072, L.NRF_PREC_F16_SPLIT)
+            rp = scene.lego_render_params(sc["bbox"], NS, NI, 65536, L.NRF_PREC_F16_SPLIT)
             dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), steps)
             a2 = argparse.Namespace(**{**vars(args), "workload": "hash", "precision": "f16x3", "hash_mode": "ngp"})
             out.append(dict(workload="hashnerf_lego800_64+128", baseline_config=2, encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3",
