@@ -6,7 +6,7 @@ from nerfpp_amd import _lib as L, scene as S
 H = W = 800
 sc = S.make_hash_scene(mode="cu"); r = sc["renderer"]
 K = S.lego_K(H, W)
-rp = S.lego_render_params(sc["bbox"], 64, 128, 131072, L.NRF_PREC_F16_SPLIT)
+rp = S.lego_render_params(sc["bbox"], 64, 128, int(sys.argv[1]) if len(sys.argv) > 1 else 65536, L.NRF_PREC_F16_SPLIT)
 pose = S.pose_spherical(-180.0, -30.0, 4.0)
 base = None
 for n in (1, 2, 4, 8):
