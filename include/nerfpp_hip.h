@@ -456,7 +456,7 @@ NRF_API int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ra
  * Near / Far in ONE call -- what a rank of the row-tile sharding issues per frame; ~25 asynchronous launches, no synchronisation, no allocation.
  * out: buffers for the TILE's rows*w rays.  d_rays_out (optional): receives the packed rays [rows*w, 8|11] (else they live in the workspace).
  * d_near_far (optional): see nrf_view_rays.  p->ray_base is taken as the index of the FRAME's first ray; the tile adds row0 * w itself.
- * NRF_ERR_UNSUPPORTED: ndc together with cone rays (p->has_cone: NDCRays turns cone_angle into a per-ray tensor, RayUtils.h:76-81). */
+ * ndc together with cone rays (p->has_cone): NDCRays' factor on cone_angle is the NDC direction's norm over itself (RayUtils.h:73-81), exactly 1: p->cone_angle is used as is. */
 NRF_API size_t nrf_render_rows_workspace_bytes(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p);
 NRF_API int nrf_render_rows(const nrf_renderer *r, const nrf_view *v, const nrf_render_params *p, const float *d_t, const float *d_u,
                             const nrf_render_outputs *out, float *d_rays_out, float *d_near_far, void *d_workspace, size_t workspace_bytes, void *stream);

@@ -1131,7 +1131,7 @@ private:
 			sh = rays_d.sizes().vec();
 			auto vsrc = rays_d.reshape({-1, 3}).contiguous();                        // view directions: the un-warped rays_d (:549-561)
 			if (render_params.Ndc) {
-				TORCH_CHECK(render_params.ThinRay || !(cone_angle.defined() && cone_angle.numel()), "Render: Ndc with cone rays makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built");
+				// cone rays: the reference's scale factor is |d_ndc| / |d_ndc| = 1.0 exactly (RayUtils.h:73-81, rays_d already replaced): cone_angle keeps its value
 				auto oo = torch::empty_like(rays_o), od = torch::empty_like(rays_d);
 				check(nrf_ndc_rays(h, w, host_floats(k)[0], 1.f, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), rays_o.numel() / 3, oo.data_ptr<float>(), od.data_ptr<float>(),
 					current_stream()), "nrf_ndc_rays");

@@ -715,10 +715,9 @@ int nrf_render_rows(const nrf_renderer *r, const nrf_view *v, const nrf_render_p
 {
     NRF_CHECK_ARG(r && p && out, "nrf_render_rows: null pointer");
     NRF_TRY(nrf_view_check(v, "nrf_render_rows"));
-    if (v->ndc && p->has_cone) {
-        set_error("nrf_render_rows: Ndc with cone rays (ThinRay = false) makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built -- render with ThinRay");
-        return NRF_ERR_UNSUPPORTED;
-    }
+    // Ndc with cone rays (ThinRay = false): NDCRays multiplies cone_angle by |d_ndc| / |rays_d| AFTER rays_d has been replaced by d_ndc (RayUtils.h:73-81) -- the
+    // quotient of a finite non-zero number by itself, exactly 1.0 -- so every ray keeps the camera's cone_angle bit for bit, as a [.., 1] tensor there, as the scalar
+    // of p->cone_angle here
     const int64_t n = (int64_t)v->rows * v->w;
     if (n == 0) return nrf_view_rays(v, nullptr, d_near_far, stream);        // an empty tile: only Near / Far (= +inf / -inf) are defined
     const int stride = v->use_viewdirs ? 11 : 8;

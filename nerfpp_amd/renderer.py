@@ -41,7 +41,8 @@ def GetRays(h, w, k, c2w, device="cuda", row0=0, rows=None):
 
 
 def NDCRays(h, w, focal, near, rays_o, rays_d, cone_angle=None):
-    """RayUtils.h:49-83 (cone_angle rescaling only matters when ThinRay is false; not on the deterministic path)."""
+    """RayUtils.h:49-83.  cone_angle comes back unchanged: the reference multiplies it by |d_ndc| / |rays_d| after rays_d has become d_ndc (:73-81), i.e. by
+    exactly 1.0 per ray (its [.., 1] tensor holds the scalar's value everywhere)."""
     o = _dev_f32(rays_o); d = _dev_f32(rays_d)
     oo = torch.empty_like(o); od = torch.empty_like(d)
     L.check(L.lib().nrf_ndc_rays(h, w, C.c_float(focal), C.c_float(near), _ptr(o), _ptr(d), C.c_int64(o.numel() // 3), _ptr(oo), _ptr(od), _stream()))
@@ -389,8 +390,8 @@ class NeRFRenderer:
             dev = rays_d.device
             view_src = rays_d.reshape(-1, 3)
             if p.Ndc:
-                if not p.ThinRay and cone_angle is not None:
-                    raise L.NrfError("Ndc with cone rays (ThinRay = false) makes cone_angle a per-ray tensor (RayUtils.h:76-81); not built")
+                # cone rays: NDCRays' scale factor divides the new direction's norm by itself (RayUtils.h:73-81: rays_d is already the NDC direction there), exactly 1.0,
+                # so cone_angle keeps its value for every ray
                 kk = _host_f32(k, 9)
                 rays_o, rays_d, _ = NDCRays(h, w, float(kk[0]), 1.0, rays_o, rays_d, None)                       # :567
             o = rays_o.reshape(-1, 3).contiguous(); d = rays_d.reshape(-1, 3).contiguous()

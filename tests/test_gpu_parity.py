@@ -2389,6 +2389,35 @@ def test_render_ndc_with_viewdirs_vs_reference(api, manifest):
     assert (np.abs(host(rb.Outputs.RGBMap) - g["batch_rgb"]).max(axis=1) < 1e-4).mean() >= 0.95
 
 
+def test_render_ndc_with_cone_rays_vs_oracle(api, manifest):
+    """Ndc together with cone rays (ThinRay = false).  NDCRays multiplies cone_angle by |d_ndc| / |rays_d| AFTER rays_d has been replaced by d_ndc (RayUtils.h:73-81):
+    exactly 1.0, so every ray keeps the camera's cone_angle -- the render is the cone render of the NDC-warped rays.  Pose branch (one nrf_render_rows call) and
+    explicit ray batch, against the oracle on the same packed rays with the same counter-based draws, bit for bit; Chunk does not matter."""
+    from oracle import capi as O
+    g = load_golden("render_ndc")
+    r, _ = _golden_hash_scene(api, manifest)
+    def params(chunk):
+        p = _params(api, g["bbox"], chunk, Seed=77); p.Ndc = True
+        p.NSamples, p.NImportance, p.ThinRay, p.Perturb = 32, 48, False, 1.0
+        return p
+    a = r.Render(8, 8, g["k"], params(64), c2w=g["c2w"])
+    rays = host(a.Extras["rays_flat"])
+    assert_exact(rays[:, :8], g["rays_flat"][:, :8], "the NDC-warped rays of the golden")
+    o, d, cone = api.R.GetRays(8, 8, g["k"], g["c2w"])
+    table = synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" in x[0]])
+    blob = synth.blob_from_manifest([x for x in manifest["render_hash"] if "embeddings" not in x[0]])
+    st = dict(perturb=1.0, cone_angle=float(cone), seed=77, raw_noise_std=0.0, precond_alpha=0.0)
+    oc = O.render_rays(O.Model(0, blob, bbox=g["bbox"], table_f32=table), rays, 32, 48, O.linspace(0, 1, 32), None, white_bkgr=True, want_intermediates=True, stoch=st)
+    assert_exact(host(a.Extras["z_fine"]), oc["z_fine"], "fine sample set of the scattered NDC rays")
+    assert_exact(host(a.Outputs.RGBMap).reshape(-1, 3), oc["rgb"], "Ndc + cone: pixels == oracle bit for bit")
+    thin = params(64); thin.ThinRay = True
+    assert np.abs(host(r.Render(8, 8, g["k"], thin, c2w=g["c2w"]).Outputs.RGBMap) - host(a.Outputs.RGBMap)).max() > 1e-4, "the cone really scatters the samples"
+    assert_exact(host(r.Render(8, 8, g["k"], params(24), c2w=g["c2w"]).Outputs.RGBMap), host(a.Outputs.RGBMap), "independent of Chunk")
+    b = r.Render(8, 8, g["k"], params(64), rays=(o, d, cone))
+    assert_exact(host(b.Extras["rays_flat"]), rays, "ray-batch branch packs the same rows")
+    assert_exact(host(b.Outputs.RGBMap).reshape(-1, 3), host(a.Outputs.RGBMap).reshape(-1, 3), "ray-batch branch == pose branch")
+
+
 def test_render_c2w_staticcam_vs_reference(api, manifest):
     """c2w_staticcam (NeRFRenderer.h:554-558): the rays come from the static camera, the view directions from c2w."""
     g = load_golden("render_staticcam")
