@@ -664,6 +664,7 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
             int64_t m = lc;
 #if NRF_LANE_STAGGER
             if (first[k]) m = (lc * (L - k) / L + 63) / 64 * 64;
+            if (m > lc) m = lc;                                                 // a Chunk that is no multiple of 64: the rounding must not pass the lane's slice of the workspace
 #endif
             first[k] = false;
 #if NRF_LANE_BALANCE

@@ -1882,7 +1882,8 @@ def test_chunk_loop_lanes_reproduce_the_single_stream_loop(api):
     sc = api.S.make_hash_scene(mode="cu")
     K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
     lib = api.L.lib()
-    cases = [(300, 200, 40000), (300, 200, 65536), (300, 200, 131072), (300, 200, 1 << 20), (390, 20, 131072), (390, 21, 5000), (300, 37, 9999)]
+    cases = [(300, 200, 40000), (300, 200, 65536), (300, 200, 131072), (300, 200, 1 << 20), (390, 20, 131072), (390, 21, 5000), (300, 37, 9999),
+             (300, 200, 33001)]          # a Chunk that is no multiple of 64, several chunks per lane: a lane's first (staggered, rounded) chunk must stay within its workspace slice
     try:
         for row0, rows, chunk in cases:
             rp = api.S.lego_render_params(sc["bbox"], chunk=chunk, precision=api.L.NRF_PREC_F16_SPLIT)
