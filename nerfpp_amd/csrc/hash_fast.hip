@@ -161,6 +161,14 @@ k_hash_ngp_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fe
         lo[j] = __halves2half2(__float2half_rn(acc[0] - __half2float(h0)), __float2half_rn(acc[1] - __half2float(h1)));
         full[j] = float2{acc[0], acc[1]};
     }
+    // A point outside the box (keep == false) gets ZERO features.  Its sigma is forced to 0 downstream (NeRFRenderer.h:187-188), so its sample weighs exactly 0 and only
+    // the FINITENESS of its colour matters -- and this encoder extrapolates with weights from the unclamped point (NeRF.cpp:265-277): half a scene away from the box the
+    // finest levels' weights reach 1e5, the feature leaves the fp16 range (inf), the network returns NaN and 0 * NaN poisons the pixel of a ray that merely misses the
+    // box (found by tools/scratch/lane_fuzz.py; the reference's fp32 value there is finite and multiplied by a zero weight).  CuHashEmbedder clamps the point first.
+    if (!kp) {
+#pragma unroll
+        for (int j = 0; j < LPT; j++) { hi[j] = __halves2half2(__half(0.0f), __half(0.0f)); lo[j] = hi[j]; full[j] = float2{0.0f, 0.0f}; }
+    }
     if (i >= p) return;
 #pragma unroll
     for (int j = 0; j < LPT; j++) {

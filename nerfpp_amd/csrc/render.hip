@@ -85,6 +85,15 @@ __global__ void k_mask_sigma(int64_t p, int c, const uint8_t *__restrict__ keep,
     if (i < p && !keep[i]) raw[i * c + (c - 1)] = 0.0f;
 }
 
+// matrix-core precisions on HashEmbedder rows: a point outside the box gets zero features (see k_hash_ngp_lm: extrapolated features leave the fp16 range, sigma is masked anyway)
+__global__ void k_zero_unkept_rows(int64_t p, int width, int stride, const uint8_t *__restrict__ keep, float *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p * width) return;
+    const int64_t row = i / width;
+    if (!keep[row]) x[row * stride + (i - row * width)] = 0.0f;
+}
+
 // raw_f[i] = the network output of fine depth i: computed in the coarse pass (columns [0, n_coarse) of the merge map) or in the fine pass's evaluation of the new samples
 __global__ void k_gather_raw(int64_t p, const int32_t *__restrict__ src, const float4 *__restrict__ raw_coarse, const float4 *__restrict__ raw_new, int64_t n_coarse,
                              float4 *__restrict__ raw_f)
@@ -212,6 +221,10 @@ static int run_network(const nrf_renderer *r, const PointSource &ps, const float
     // embed_fn->forward(inputs_flat)                                            (NeRFRenderer.h:175)
     if (r->desc.hash) {
         NRF_TRY(launch_hash(r->desc.hash, ps, p, x, xd, keep, st));
+        if (prec != NRF_PREC_F32 && r->desc.hash->desc.mode == NRF_HASH_NGP) {
+            hipLaunchKernelGGL(k_zero_unkept_rows, dim3((unsigned)ceil_div(p * r->in_ch, 256)), dim3(256), 0, st, p, r->in_ch, xd, keep, x);
+            NRF_LAUNCH_CHECK();
+        }
     } else {
         const float *px = ps.pts;
         if (!px) {

@@ -1492,7 +1492,15 @@ def test_ngp_fast_path_vs_reference_render(api, manifest):
     ref32 = r.Render(8, 8, g["k"], _params(api, g["bbox"], 64, Precision=api.L.NRF_PREC_F32), c2w=g["c2w"])
     rgb = host(res.Outputs.RGBMap)
     scale = np.abs(g["coarse_raw"]).max()
-    assert_close(host(res.Extras["raw_coarse"]), host(ref32.Extras["raw_coarse"]), rtol=0, atol=3e-6 * scale, what="coarse raw: split fast path vs fp32 parity mode")
+    # samples outside the box: sigma is masked in both; the colour the fast path reports there is the network's on ZERO features (k_hash_ngp_lm: the extrapolated
+    # features of far-away points leave the fp16 range) -- weightless either way, compared inside the box only
+    rays = res.Extras["rays_flat"]; zc = res.Extras["z_coarse"]
+    _, keep = r.EmbedFn.forward((rays[:, None, 0:3] + rays[:, None, 3:6] * zc[..., None]).reshape(-1, 3))
+    keep = host(keep).reshape(zc.shape)
+    rc, rc32 = host(res.Extras["raw_coarse"]), host(ref32.Extras["raw_coarse"])
+    assert_close(rc[..., 3], rc32[..., 3], rtol=0, atol=3e-6 * scale, what="coarse sigma: split fast path vs fp32 parity mode (every sample)")
+    assert_close(rc[keep], rc32[keep], rtol=0, atol=3e-6 * scale, what="coarse raw inside the box: split fast path vs fp32 parity mode")
+    assert np.isfinite(rc).all()
     assert_close(rgb, g["out_rgb"], rtol=0, atol=1e-4, what="fast path pixels within 1e-4 of the reference's LibTorch CPU render")
     assert api.S.psnr(rgb, g["out_rgb"]) > 80
 
@@ -1507,6 +1515,8 @@ def check_default_split_fine_pass(api, sc, res, rays, what):
     n, s = zf.shape
     pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
     emb, keep = sc["embedder"].forward(pts)
+    if sc["embedder"].mode == api.L.NRF_HASH_NGP:
+        emb[~keep] = 0                  # HashEmbedder fast path: a point outside the box is encoded as zeros (k_hash_ngp_lm); CuHashEmbedder clamps the point instead
     dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
     x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
     ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)
@@ -1541,6 +1551,7 @@ def test_ngp_fast_path_features_equal_generic_encoder(api):
     pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * zf[..., None]).reshape(-1, 3)
     emb, keep = sc["embedder"].forward(pts)
     dirs, _ = sc["embeddirs"].forward(rays[:, 8:11].contiguous())
+    emb[~keep] = 0                                                       # the fast path encodes a point outside the box as zeros (k_hash_ngp_lm): its sigma is masked anyway
     x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
     ref = sc["mlp"].forward(x, api.L.NRF_PREC_F16_SPLIT)                 # fp32 rows -> the kernel splits them itself: same hi/lo operands
     ref[~keep, 3] = 0
@@ -1551,6 +1562,35 @@ def test_ngp_fast_path_features_equal_generic_encoder(api):
     check_default_split_fine_pass(api, sc, res2, rays, "HashEmbedder, default split render")
     f32 = sc["renderer"].Render(800, 800, K, api.S.lego_render_params(sc["bbox"], chunk=1000, precision=api.L.NRF_PREC_F32), c2w=c2w, row0=400, rows=2)
     assert api.S.psnr(host(res.Outputs.RGBMap), host(f32.Outputs.RGBMap)) > 85
+
+
+@pytest.mark.parametrize("mode", ["ngp", "cu"])
+def test_rays_that_miss_the_box_render_finite_background_in_every_precision(api, mode):
+    """A ray that misses the bounding box keeps a degenerate depth interval (far = near + 1e-6, RayUtils.h:87-126) OUTSIDE the box: every sample has keep == false, sigma is
+    forced to 0 (NeRFRenderer.h:187-188) and the pixel is the background.  HashEmbedder extrapolates such points with weights from the unclamped coordinate
+    (NeRF.cpp:265-277) -- 1e5 at the finest levels half a scene away -- which leaves the fp16 range: the matrix-core precisions once returned 0 * NaN there.  All
+    precisions: finite everywhere, the missing rays exactly white, everything else as close to NRF_PREC_F32 as the precision allows."""
+    sc = api.S.make_hash_scene(mode=mode, log2_t=16)
+    h, w = 120, 97
+    K = api.S.lego_K(h, w); c2w = api.S.pose_spherical(40.0, -25.0, 4.0)
+    outs = {}
+    for prec in (api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA, api.L.NRF_PREC_F16_SPLIT):
+        rp = api.S.lego_render_params(sc["bbox"], 64, 128, 4000, prec, ReturnWeights=True, ReturnRaw=(prec != api.L.NRF_PREC_F32), KeepIntermediates=True)
+        res = sc["renderer"].Render(h, w, K, rp, c2w=c2w)
+        rays = host(res.Extras["rays_flat"])
+        miss = (rays[:, 7] - rays[:, 6]) < 1e-5                         # near == far up to the 1e-6 floor
+        assert miss.sum() >= 3, "the pose is chosen so that a few rays miss the box"
+        rgb = host(res.Outputs.RGBMap).reshape(-1, 3)
+        for f in ("RGBMap", "DepthMap", "AccMap", "DispMap", "Weights"):
+            assert np.isfinite(host(getattr(res.Outputs, f))).all(), f"{f} finite, precision {prec}"
+        if res.Raw is not None:
+            assert np.isfinite(host(res.Raw)).all(), f"raw network outputs finite, precision {prec}"
+        assert_exact(rgb[miss], np.ones_like(rgb[miss]), f"missing rays are white background, precision {prec}")
+        assert_exact(host(res.Outputs.AccMap).reshape(-1)[miss], np.zeros(miss.sum(), np.float32), "... with zero opacity")
+        outs[prec] = rgb
+    # (with the intermediates kept the coarse pass of the split mode runs the whole network in split precision, not the exact sigma pass: a moved sample here and there)
+    assert api.S.psnr(outs[api.L.NRF_PREC_F16_SPLIT], outs[api.L.NRF_PREC_F32]) > 70
+    assert api.S.psnr(outs[api.L.NRF_PREC_F16_MFMA], outs[api.L.NRF_PREC_F32]) > 35
 
 
 def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
@@ -2348,9 +2388,6 @@ def test_render_rows_argument_errors(api):
     rp = api.S.lego_render_params(sc["bbox"], chunk=64)
     with pytest.raises(api.L.NrfError, match="outside image"):
         sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0), row0=4, rows=5)
-    rp = api.S.lego_render_params(sc["bbox"], chunk=64, Ndc=True, ThinRay=False)
-    with pytest.raises(api.L.NrfError, match="cone"):
-        sc["renderer"].Render(8, 8, api.S.lego_K(8, 8), rp, c2w=api.S.pose_spherical(0.0, -30.0, 4.0))
 
 
 def test_render_ndc_with_viewdirs_vs_reference(api, manifest):
