@@ -351,7 +351,12 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     b += align_up((size_t)n * s * c * 4, 256);            // raw_coarse
     b += align_up((size_t)n * sf * 4, 256);               // z_fine
     b += align_up((size_t)n * sf * c * 4, 256);           // raw_fine
-    b += network_ws_bytes(r, n * sf, p->precision) + 4096;
+    // the network's scratch: the generic row-major path of all S + N_importance depths, or the feature-reuse layout of the hash fast paths (reuse_layout), whichever is
+    // larger -- with few importance samples the HashEmbedder layout (two feature planes of every column + the fp32 plane of the S coarse ones) passes the first
+    const size_t reuse = align_up((size_t)n * sf * 16 * sizeof(__half2), 256) * 2 + align_up((size_t)n * s * 16 * sizeof(float2), 256) + align_up((size_t)n * sf, 256) +
+                         align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + 2048;
+    const size_t generic = network_ws_bytes(r, n * sf, p->precision);
+    b += (generic > reuse ? generic : reuse) + 4096;
     b += align_up((size_t)n * 64 * sizeof(__half), 256) * 2;  // per-ray direction features of the fast path (hi, lo)
     b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + 1024;   // feature reuse: merge map + new-sample depths
     b += align_up((size_t)n * sf * 4, 256) + align_up((size_t)n * (sf - s) * 4, 256) + align_up((size_t)n * (sf - s) * 16, 256);   // raw reuse: map, depths, outputs of the new samples

@@ -1593,6 +1593,22 @@ def test_rays_that_miss_the_box_render_finite_background_in_every_precision(api,
     assert api.S.psnr(outs[api.L.NRF_PREC_F16_MFMA], outs[api.L.NRF_PREC_F32]) > 35
 
 
+@pytest.mark.parametrize("mode", ["ngp", "cu"])
+def test_few_importance_samples_fit_the_workspace(api, mode):
+    """N_importance much smaller than N_samples (64 + 5): the feature-reuse layout of the hash fast paths (two feature planes per column + the fp32 plane of the coarse
+    columns with the HashEmbedder) is then larger than the generic network scratch the workspace formula was sized by -- nrf_render_rays answered NRF_ERR_WORKSPACE
+    (found by tools/scratch/render_fuzz.py).  Renders, chunk-invariant, close to NRF_PREC_F32."""
+    sc = api.S.make_hash_scene(mode=mode, log2_t=15)
+    K = api.S.lego_K(130, 44); c2w = api.S.pose_spherical(10.0, -30.0, 4.0)
+    outs = []
+    for chunk in (5564, 1000):
+        rp = api.S.lego_render_params(sc["bbox"], 64, 5, chunk, api.L.NRF_PREC_F16_SPLIT)
+        outs.append(host(sc["renderer"].Render(130, 44, K, rp, c2w=c2w).Outputs.RGBMap))
+    assert_exact(outs[1], outs[0], "independent of Chunk")
+    f32 = host(sc["renderer"].Render(130, 44, K, api.S.lego_render_params(sc["bbox"], 64, 5, 5564, api.L.NRF_PREC_F32), c2w=c2w).Outputs.RGBMap)
+    assert api.S.psnr(outs[0], f32) > 90
+
+
 def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
     """Default split render of the CuHashEmbedder scene (see check_default_split_fine_pass) -- ragged chunk sizes included."""
     sc = api.S.make_hash_scene(mode="cu")
