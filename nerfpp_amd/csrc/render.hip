@@ -490,6 +490,9 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     else NRF_TRY(network(ps, s, raw_c));                                                                           // :422
     nz.stream = NRF_RNG_NOISE_COARSE;
     if (ni == 0) {
+        // a caller that asked for both the coarse intermediates and Raw gets the same rows in both (raw_c is the coarse buffer then: Raw was left unwritten -- a training
+        // step with N_importance = 0 differentiated garbage; found by tools/scratch/train_fuzz.py)
+        if (out->d_raw && raw_c != out->d_raw) NRF_HIP(hipMemcpyAsync(out->d_raw, raw_c, (size_t)n * s * c * sizeof(float), hipMemcpyDeviceToDevice, st));
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
         return launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
                                   out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st, fastc);

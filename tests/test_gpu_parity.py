@@ -1244,6 +1244,37 @@ def test_trainer_two_steps_vs_reference(api, manifest):
     assert dt.mean() < 8e-3 and (dt > 0.05).mean() < 0.05, (dt.mean(), (dt > 0.05).mean())
 
 
+def test_raw_and_training_step_without_importance_sampling(api):
+    """N_importance = 0: the render's Raw is the coarse pass's raw (NeRFRenderer.h:421-423) -- also when the coarse intermediates are asked for in the same call (Raw was
+    left unwritten then, and a training step differentiated garbage: tools/scratch/train_fuzz.py).  The step's gradients are non-zero and agree between the float-atomic,
+    packed and binned table gradients and between the fp32 and matrix-core network backward."""
+    from nerfpp_amd.train import Trainer
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    sc = api.S.make_hash_scene(mode="cu", log2_t=14, table_amp=1e-2, sigma_scale=4.0)
+    rp = api.S.lego_render_params(sc["bbox"], 64, 0, 4096, api.L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates=True)
+    res = sc["renderer"].Render(800, 800, K, rp, c2w=c2w, row0=400, rows=2)
+    assert_exact(host(res.Raw), host(res.Extras["raw_coarse"]).reshape(host(res.Raw).shape), "Raw == the coarse raw when there is no fine pass")
+    assert np.abs(host(res.Raw)).max() > 0
+    o, d, _ = api.R.GetRays(800, 800, K, c2w)
+    idx = torch.arange(0, 1000, device="cuda") * 640
+    o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
+    tgt = torch.rand((1000, 3), generator=torch.Generator().manual_seed(3)).cuda()
+    p = api.R.NeRFRenderParams(NSamples=64, NImportance=0, Chunk=1000, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=api.S.LEGO_BBOX,
+                               Precision=api.L.NRF_PREC_F16_SPLIT)
+    grads = {}
+    for mb, hb in (("f32", "f32"), ("f32", "packed"), ("f32", "binned"), ("f16", "binned")):
+        s2 = api.S.make_hash_scene(mode="cu", log2_t=14, table_amp=1e-2, sigma_scale=4.0)
+        with Trainer(s2["embedder"], s2["embeddirs"], s2["mlp"], s2["table"], s2["mlp_blob"], mlp_backward=mb, hash_backward=hb) as tr:
+            tr.step(o, d, tgt, p)
+            grads[(mb, hb)] = (host(tr.g_table), host(tr.g_blob))
+    gt, gb = grads[("f32", "f32")]
+    assert np.abs(gt).max() > 0 and np.abs(gb).max() > 0
+    assert_exact(grads[("f32", "binned")][0], grads[("f32", "packed")][0], "binned == packed table gradient")
+    assert_close(grads[("f32", "packed")][0], gt, rtol=0, atol=2e-3 * np.abs(gt).max(), what="fixed-point table gradient vs float atomics")
+    assert_close(grads[("f32", "packed")][1], gb, rtol=1e-5, atol=1e-6 * np.abs(gb).max(), what="network gradient: same backward, same raw")
+    assert np.abs(grads[("f16", "binned")][1] - gb).max() < 5e-2 * np.abs(gb).max() and np.corrcoef(grads[("f16", "binned")][0], gt)[0, 1] > 0.99
+
+
 def test_trainer_learns_a_teacher_scene(api):
     """Fit a freshly initialised CuHash + NeRFSmall student to the renders of a teacher: the loss must fall steadily
     (CuHashEmbedder backward, fp32 accumulation; the render the loss is computed on runs on the matrix cores)."""
