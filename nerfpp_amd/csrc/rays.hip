@@ -335,8 +335,9 @@ extern "C" {
 
 int nrf_get_rays(int h, int w, const float *K, const float *c2w, int row0, int rows, float *d_o, float *d_d, float *cone_angle, void *stream)
 {
-    NRF_CHECK_ARG(K && c2w && d_o && d_d, "nrf_get_rays: null pointer");
+    NRF_CHECK_ARG(K && c2w, "nrf_get_rays: null pointer");
     NRF_CHECK_ARG(h > 0 && w > 0 && row0 >= 0 && rows >= 0 && row0 + rows <= h, "nrf_get_rays: rows [%d,%d) outside image of height %d", row0, row0 + rows, h);
+    NRF_CHECK_ARG((d_o && d_d) || rows == 0, "nrf_get_rays: null ray buffer");          // an empty tile (a rank of a world larger than the image is high) has no buffer
     const int64_t n = (int64_t)rows * w;
     if (cone_angle) {
         const float px = 1.0f / K[0], py = 1.0f / K[4];
