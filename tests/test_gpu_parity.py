@@ -1640,6 +1640,38 @@ def test_few_importance_samples_fit_the_workspace(api, mode):
     assert api.S.psnr(outs[0], f32) > 90
 
 
+def test_seeded_render_invariance_sweep(api):
+    """A seeded sweep in the manner of tools/scratch/render_fuzz.py / lane_fuzz.py (which found four defects in round 4): random frame sizes, sample counts, chunk sizes,
+    row tiles, lane counts, scenes and precisions -- a render does not depend on Chunk or on the number of lanes, a row tile equals the rows of the frame, everything is
+    finite (rays that miss the box included)."""
+    rng = np.random.default_rng(20261004)
+    lib = api.L.lib()
+    scenes = [api.S.make_hash_scene(mode="cu", log2_t=14), api.S.make_hash_scene(mode="ngp", log2_t=14), api.S.make_classic_scene()]
+    eq = lambda a, b: a.shape == b.shape and torch.equal(a.nan_to_num(nan=4321.0), b.nan_to_num(nan=4321.0))
+    try:
+        for case in range(18):
+            which = case % 3; sc = scenes[which]; r = sc["renderer"]
+            h, w = (int(rng.integers(12, 40)), int(rng.integers(12, 40))) if which == 2 else (int(rng.integers(100, 300)), int(rng.integers(100, 300)))
+            s = int(rng.choice([8, 17, 64])); ni = int(rng.choice([0, 5, 128]))
+            prec = int(rng.choice([api.L.NRF_PREC_F32, api.L.NRF_PREC_F16_MFMA, api.L.NRF_PREC_F16_SPLIT])) if which != 2 or case % 2 else api.L.NRF_PREC_F16_SPLIT
+            n = h * w
+            K = api.S.lego_K(h, w); c2w = api.S.pose_spherical(float(rng.uniform(-180, 180)), float(rng.uniform(-60, -5)), float(rng.uniform(3.0, 4.6)))
+            what = f"case {case}: scene {which} {h}x{w} s {s}+{ni} precision {prec}"
+            def render(chunk, lanes, **kw):
+                api.L.check(lib.nrf_set_render_lanes(lanes))
+                o = r.Render(h, w, K, api.S.lego_render_params(sc["bbox"], s, ni, chunk, prec, ReturnWeights=True), c2w=c2w, **kw).Outputs
+                return [o.RGBMap, o.DepthMap, o.AccMap, o.Weights]
+            full = render(n, 1)
+            assert all(bool(torch.isfinite(t).all()) for t in full), what + ": finite"
+            for chunk, lanes in ((int(rng.integers(max(1, n // 6), n)), 2), (33001, 3), (int(rng.integers(max(1, n // 6), n)), 4)):
+                assert all(eq(a, b) for a, b in zip(full, render(chunk, lanes))), what + f": chunk {chunk} on {lanes} lanes == one chunk on one stream"
+            row0 = int(rng.integers(0, h)); rows = int(rng.integers(1, h - row0 + 1))
+            t = render(int(rng.integers(max(1, n // 6), n)), 2, row0=row0, rows=rows)
+            assert all(eq(a.reshape(b[row0:row0 + rows].shape), b[row0:row0 + rows]) for a, b in zip(t, [f.reshape(h, w, -1) for f in full])), what + f": tile {row0}+{rows} == rows of the frame"
+    finally:
+        api.L.check(lib.nrf_set_render_lanes(2))
+
+
 def test_feature_reusing_fine_pass_equals_stagewise_cu(api):
     """Default split render of the CuHashEmbedder scene (see check_default_split_fine_pass) -- ragged chunk sizes included."""
     sc = api.S.make_hash_scene(mode="cu")
