@@ -3,6 +3,8 @@
   (b) the C oracle on the same seeded inputs.
 Bars: bit-exact for indices / integer outputs and for every stage made of + - * / floor / compare;
 float tolerance stated per test otherwise (pixels: 1e-4, BASELINE north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -2812,6 +2814,20 @@ def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manife
         assert abs(rd(f"out_s{step}_loss.f32", (1,))[0] - g[f"s{step}_loss"][0]) < 3e-4
     assert abs(host(lm2)[0] - rd("out_s2_loss.f32", (1,))[0]) < 2e-4          # two runs of the same chain: step 1 leaves a per-cent of the weights lr apart (sign of a cancelling atomic sum)
     assert r["loss_step2"] < r["loss_step1"]
+
+
+def test_c_abi_all_gather_at_world_sizes_above_one_with_threads_as_ranks():
+    """nrf_comm_create_timeout / nrf_allgather_tiles at world sizes 2-6 on ONE GPU: the ranks are threads of tests/helpers/comm_ranks_as_threads over
+    tests/helpers/mock_rccl.cpp, a stand-in for RCCL's entry points (group start / end, ncclAllGather, ncclBroadcast enqueued on the caller's stream) under RCCL's SONAME --
+    the real library refuses two ranks on one device, and no box of this pool has two.  Equal tiles, unequal ones (grouped broadcasts), ranks that own no rows, several
+    frames per step, two gathers back to back: every rank ends with every pixel of every frame.  (What stays unrehearsed is RCCL itself: test_two_real_rccl_ranks_...)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "helpers", "_build", "comm_ranks_as_threads")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(__file__), "helpers", "build_mock_rccl.sh")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(": ok") >= 9
 
 
 def test_two_real_rccl_ranks_gather_the_single_rank_frame(tmp_path):
