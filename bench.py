@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16", "f16x3", "f32"],
                     help="MLP arithmetic: f16 = matrix cores, fp16 operands; f16x3 = matrix cores, hi+lo fp16 operand pairs (fp32-grade); f32 = FMA chains "
                          "(== oracle bitwise).  Default: f16x3 (fp32-grade pixels; the reference computes in fp32)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the settling phase before the warmup steps (counter passes: tools/gpu_pmc*.sh count the frames of a run)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the single-lane pass behind roofline.isolated")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (other precision, classic workload) at N = 1")
     ap.add_argument("--hash-mode", default="cu", choices=["cu", "ngp"])
@@ -126,7 +127,7 @@ def main():
         row are within 10 % of the fastest one seen and at least `floor_s` of them have run (at most `budget_s`).  Some boxes of the pool start a process at a
         fraction of the clock -- the default frame at 97 instead of 22 ms per step for the first seconds of load (profiles/round4/r4E_*) -- and W = 1-2 warmup
         steps do not outlast that.  Every rank runs the same number of steps (the decision to stop is taken together)."""
-        if settled[0]:
+        if settled[0] or args.no_settle:
             return
         settled[0] = True
         t_begin = time.perf_counter(); best = float("inf"); good = 0
