@@ -8,16 +8,19 @@ from nerfpp_amd import _lib as L, scene as S, renderer as R
 from oracle import capi as O
 rng = np.random.default_rng(4242)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-def models():
+def models(seed=0):
     out = []
+    g = np.random.default_rng(seed)
     for mode in ("cu", "ngp"):
-        sc = S.make_hash_scene(mode=mode, log2_t=14); cfg = sc["cfg"]
+        sc = S.make_hash_scene(mode=mode, log2_t=int(g.choice([12, 14, 16])), base=int(g.choice([4, 16])), finest=int(g.choice([128, 512, 1024])), seed=5000 + seed); cfg = sc["cfg"]
+        sc["embedder"].set_dense_budget(int(g.choice([0, 4 << 20, 1 << 30])))
         if mode == "cu":
             ls = ((1 << cfg["log2_t"]) >> 4) << 4; Lv = cfg["n_levels"]
             m = O.Model(2, sc["mlp_blob"], bbox=sc["bbox"], table_f16=O.f32_to_f16(sc["table"]), primes=sc["primes"], local_idx=np.arange(Lv, dtype=np.int32) * ls,
-                        local_size=np.full(Lv, ls, np.int32), bias=np.zeros((Lv, 3), np.float32), mul=O.hash_cu_scales(Lv, cfg["base"], cfg["finest"]), log2_t=cfg["log2_t"])
+                        local_size=np.full(Lv, ls, np.int32), bias=np.zeros((Lv, 3), np.float32), mul=O.hash_cu_scales(Lv, cfg["base"], cfg["finest"]), log2_t=cfg["log2_t"],
+                        base=cfg["base"], finest=cfg["finest"])
         else:
-            m = O.Model(0, sc["mlp_blob"], bbox=sc["bbox"], table_f32=sc["table"], log2_t=cfg["log2_t"])
+            m = O.Model(0, sc["mlp_blob"], bbox=sc["bbox"], table_f32=sc["table"], log2_t=cfg["log2_t"], base=cfg["base"], finest=cfg["finest"])
         out.append((mode, sc, m))
     sc = S.make_classic_scene()
     out.append(("classic", sc, O.Model(1, sc["mlp_blob"], bbox=sc["bbox"])))
@@ -25,10 +28,11 @@ def models():
 ms = models()
 bad = 0
 for case in range(cases):
+    if case % 10 == 0 and case: ms = models(case)          # a new grid configuration (table size, resolutions, dense budget) every ten cases
     name, sc, model = ms[int(rng.integers(0, 3))]; r = sc["renderer"]
     h = int(rng.integers(3, 24)); w = int(rng.integers(3, 24))
     if name == "classic": h, w = min(h, 10), min(w, 12)
-    s = int(rng.choice([4, 8, 17, 32, 64, 65, 100]))          # nrf_fine_depths is built for 4..256 samples (refused loudly below); ni = int(rng.choice([0, 1, 5, 32, 63, 128]))
+    s = int(rng.choice([4, 8, 17, 32, 64, 65, 100])); ni = int(rng.choice([0, 1, 5, 32, 63, 128]))          # nrf_fine_depths is built for 4..256 samples (2 and 3 are refused loudly)
     if s + ni > 256: ni = 256 - s
     stoch = bool(rng.integers(0, 2)); white = bool(rng.integers(0, 2)); lindisp = bool(rng.integers(0, 4) == 0)
     seed = int(rng.integers(1, 1 << 40))
