@@ -391,7 +391,9 @@ int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int 
 int launch_fine_depths(const float *z, const float *weights, int64_t n, int s, const float *u, int64_t u_stride, const RngRef &g, int ns, int sum_vec,
                        float *zf, hipStream_t st, int32_t *src, float *z_new)
 {
-    NRF_CHECK_ARG(s >= 4 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [4,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
+    // s = 2: one bin edge and NO weight (weights[1:-1] is empty): the CDF is the single 0, every u lands past it and every sample is that edge (Sampler.h:28-40 on empty
+    // tensors); s = 3: two edges, one weight
+    NRF_CHECK_ARG(s >= 2 && s <= MAX_S && ns >= 1 && ns <= MAX_S, "nrf_fine_depths: n_samples %d / n_importance %d outside the built range [2,%d] / [1,%d]", s, ns, MAX_S, MAX_S);
     NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_fine_depths: sum_vec must be 0, 4, 8 or 16");
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_SAMPLE, st);

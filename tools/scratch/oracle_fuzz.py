@@ -32,7 +32,7 @@ for case in range(cases):
     name, sc, model = ms[int(rng.integers(0, 3))]; r = sc["renderer"]
     h = int(rng.integers(3, 24)); w = int(rng.integers(3, 24))
     if name == "classic": h, w = min(h, 10), min(w, 12)
-    s = int(rng.choice([4, 8, 17, 32, 64, 65, 100])); ni = int(rng.choice([0, 1, 5, 32, 63, 128]))          # nrf_fine_depths is built for 4..256 samples (2 and 3 are refused loudly)
+    s = int(rng.choice([2, 3, 4, 8, 17, 32, 64, 65, 100])); ni = int(rng.choice([0, 1, 5, 32, 63, 128]))
     if s + ni > 256: ni = 256 - s
     stoch = bool(rng.integers(0, 2)); white = bool(rng.integers(0, 2)); lindisp = bool(rng.integers(0, 4) == 0)
     seed = int(rng.integers(1, 1 << 40))

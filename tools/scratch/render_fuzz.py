@@ -14,7 +14,7 @@ for case in range(cases):
     name, sc = scenes[int(rng.integers(0, 3))]; r = sc["renderer"]
     h = int(rng.integers(9, 70)); w = int(rng.integers(9, 70))
     if name != "classic": h *= 2; w *= 2
-    s = int(rng.choice([8, 17, 32, 64, 100])); ni = int(rng.choice([0, 5, 32, 128, 150]))
+    s = int(rng.choice([2, 3, 8, 17, 32, 64, 100])); ni = int(rng.choice([0, 5, 32, 128, 150]))
     if s + ni > 256: ni = 256 - s
     prec = int(rng.choice([L.NRF_PREC_F32, L.NRF_PREC_F16_MFMA, L.NRF_PREC_F16_SPLIT]))
     stoch = bool(rng.integers(0, 3) == 0) and s >= 2
