@@ -450,8 +450,8 @@ int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed
 static int sample_pdf_entry(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int64_t u_stride, int ns, int sum_vec,
                             float *d_samples, int64_t *d_inds, void *stream)
 {
-    NRF_CHECK_ARG(d_bins && d_weights && d_u && d_samples && n >= 0, "nrf_sample_pdf: bad argument");
-    NRF_CHECK_ARG(nb >= 2 && nb <= MAX_S && ns >= 1 && ns <= 2 * MAX_S, "nrf_sample_pdf: nb %d / ns %d outside the built range (<= %d bins, <= %d samples)", nb, ns, MAX_S, 2 * MAX_S);
+    NRF_CHECK_ARG(d_bins && (d_weights || nb == 1) && d_u && d_samples && n >= 0, "nrf_sample_pdf: bad argument");      // one bin edge: no weight (an empty [n, 0] tensor has no storage)
+    NRF_CHECK_ARG(nb >= 1 && nb <= MAX_S && ns >= 1 && ns <= 2 * MAX_S, "nrf_sample_pdf: nb %d / ns %d outside the built range (<= %d bins, <= %d samples)", nb, ns, MAX_S, 2 * MAX_S);
     NRF_CHECK_ARG(sum_vec == 0 || sum_vec == 4 || sum_vec == 8 || sum_vec == 16, "nrf_sample_pdf: sum_vec must be 0, 4, 8 or 16");
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_SAMPLE, as_stream(stream));

@@ -31,7 +31,7 @@ def guard(name, detail, fn):
 bbox = np.asarray(S.LEGO_BBOX, np.float32)
 for i in range(N):
     # ---- SamplePDF
-    n = int(rng.choice([1, 3, 64, 257])); nb = int(rng.choice([2, 3, 5, 63, 64, 65, 191, 255])); ns = int(rng.choice([1, 2, 64, 128, 129, 256]))
+    n = int(rng.choice([1, 3, 64, 257])); nb = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 191, 255])); ns = int(rng.choice([1, 2, 64, 128, 129, 256]))
     bins = np.sort(rng.uniform(2, 6, (n, nb)).astype(np.float32), axis=1); wts = (rng.uniform(0, 1, (n, nb - 1)) ** 4).astype(np.float32)
     if rng.integers(0, 3) == 0: wts[rng.integers(0, n)] = 0
     def f():
@@ -80,7 +80,8 @@ for i in range(N):
         if deg <= 5:
             got, _ = M.SHEncoder("s", 3, deg).forward(dev(dirs)); check("SHEncoder", host(got), O.sh_libtorch(dirs, deg), f"p {len(dirs)} degree {deg}")
     guard("SH", f"degree {deg}", f)
-    Lv = int(rng.choice([2, 3, 5, 16]))          # one level divides by n_levels - 1 = 0 in the reference too (NeRF.cpp:214): refused loudly; F = int(rng.choice([1, 2, 4, 8])); T = int(rng.choice([10, 13, 16])); base = int(rng.choice([4, 16])); fin = int(rng.choice([32, 512, 1024]))
+    Lv = int(rng.choice([2, 3, 5, 16]))          # (one level: the reference's growth factor divides by n_levels - 1 = 0, NeRF.cpp:214; refused loudly here)
+    F = int(rng.choice([1, 2, 4, 8])); T = int(rng.choice([10, 13, 16])); base = int(rng.choice([4, 16])); fin = int(rng.choice([32, 512, 1024]))
     def f():
         if p == 0: return
         table = synth.synth_sym(int(rng.integers(1, 1000)), (Lv * (1 << T) * F,), np.float32(0.5))
