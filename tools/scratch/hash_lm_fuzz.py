@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S, modules as M, synth
 from oracle import capi as O
-rng = np.random.default_rng(60221023)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 60221023)          # second argument: another seed
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 lib = L.lib()
 P = lambda t: C.c_void_p(t.data_ptr())

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S
-rng = np.random.default_rng(20261004)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)          # second argument: another seed
 scenes = [S.make_hash_scene(mode="cu", log2_t=16), S.make_hash_scene(mode="ngp", log2_t=16), S.make_classic_scene()]
 lsc = S.make_lerf_scene(log2_t=14); lr = lsc["renderer"]
 lib = L.lib()

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S, renderer as R
-rng = np.random.default_rng(31337)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)          # second argument: another seed
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 sc = S.make_lerf_scene(log2_t=14); r = sc["renderer"]
 pr = np.random.RandomState(5); pos = pr.randn(1, 768).astype(np.float32); pos /= np.linalg.norm(pos); neg = pr.randn(3, 768).astype(np.float32); neg /= np.linalg.norm(neg, axis=1, keepdims=True)

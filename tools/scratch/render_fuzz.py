@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S, renderer as R
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)          # second argument: another seed
 scenes = [("cu", S.make_hash_scene(mode="cu", log2_t=15)), ("ngp", S.make_hash_scene(mode="ngp", log2_t=15)), ("classic", S.make_classic_scene())]
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S, renderer as R, modules as M, synth
 from oracle import capi as O
-rng = np.random.default_rng(2718)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2718)          # second argument: another seed
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 host = lambda t: t.detach().cpu().numpy()

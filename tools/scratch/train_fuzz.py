@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, torch
 from nerfpp_amd import _lib as L, scene as S, renderer as R
 from nerfpp_amd.train import Trainer
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)          # second argument: another seed
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 bad = 0
 for case in range(cases):
