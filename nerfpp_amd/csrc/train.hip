@@ -224,7 +224,11 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 // at one level, sums the eight corner contributions in registers while the voxel does not change and issues the atomics only when it
 // does.  Same addends as the per-point kernels, summed in a different order (fp32).
 constexpr int BWD_SEG = 16;
-constexpr int64_t PACKED_GROUP_PTS = 1 << 18;      // points per fixed-point pass of nrf_hash_backward_rays_packed
+// training step of 16 384 rays x 192 samples, same call, alternating builds (profiles/round4/r5a_*): 2^16 10.3 ms, 2^17 8.1-8.9, 2^18 7.84, 2^19 8.04, 2^20 8.6, 2^22 9.25
+#ifndef NRF_PACKED_GROUP_LOG2
+#define NRF_PACKED_GROUP_LOG2 18
+#endif
+constexpr int64_t PACKED_GROUP_PTS = (int64_t)1 << NRF_PACKED_GROUP_LOG2;      // points per fixed-point pass of nrf_hash_backward_rays_packed / _binned
 
 // Q (F == 2 only): both features of a table entry leave in ONE 64-bit integer atomic.  The L2 atomic units retire ~21-24 G operations/s
 // whatever the operand type (tools/scratch/atomic_bench.hip: fp32, f64, u32, u64 and packed-f16 adds all land there), so the table gradient
