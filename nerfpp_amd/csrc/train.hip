@@ -223,7 +223,11 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 // (importance sampling packs them densely) mostly sit in the same voxel of a level: one thread walks SEG consecutive samples of one ray
 // at one level, sums the eight corner contributions in registers while the voxel does not change and issues the atomics only when it
 // does.  Same addends as the per-point kernels, summed in a different order (fp32).
-constexpr int BWD_SEG = 16;
+// samples of a ray one thread walks; training step of 16 384 rays, same call (profiles/round4/r5b_*): 8: 8.0 ms, 12: 8.65, 16: 7.85, 24: 8.6, 32: 7.8, 48: 8.55
+#ifndef NRF_BWD_SEG
+#define NRF_BWD_SEG 16
+#endif
+constexpr int BWD_SEG = NRF_BWD_SEG;
 // training step of 16 384 rays x 192 samples, same call, alternating builds (profiles/round4/r5a_*): 2^16 10.3 ms, 2^17 8.1-8.9, 2^18 7.84, 2^19 8.04, 2^20 8.6, 2^22 9.25
 #ifndef NRF_PACKED_GROUP_LOG2
 #define NRF_PACKED_GROUP_LOG2 18
