@@ -250,7 +250,7 @@ constexpr int BIN_WORDS = 1 << BIN_SHIFT;
 constexpr int BIN_MAX_PER_LEVEL = 40;        // bins one level's words can touch: 2^19 / 2^14 = 32, + 1 for an unaligned base (+ margin)
 struct BinSink {
     uint32_t *wg_hist;       // [levels][workgroups][BIN_MAX_PER_LEVEL] records of a workgroup per bin (count pass writes, emit pass reads)
-    uint32_t *gcount;        // [nbins + 1] records per bin (count pass), then left as is
+    uint32_t *gcount;        // [nbins + 1] records per bin (count pass); zeroed again by k_bin_scan
     uint32_t *cursor;        // [nbins] next free record slot of a bin (scan initialises to the bin's start)
     uint4 *rec;              // records
 };
@@ -401,10 +401,18 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
 // and sum to one per point), whatever the hash collisions and however the samples cluster.  Accumulated in double.
 // HashEmbedder mode only: its interpolation weights are computed from the UNCLAMPED coordinate (NeRF.cpp:265-277), so a point outside the box
 // has weights beyond [0,1]; `pts` != NULL multiplies the point's mass by prod_a (1 + excess_a / finest cell size), a bound for every level.
+// blockIdx.y = pass (group of `group_pts` points; the launches of one pass at a time use gridDim.y = 1 and group_pts = p): its points, its row of `mass`.
 __global__ void __launch_bounds__(256) k_level_mass(int64_t p, int L, int F, const float *__restrict__ g, double *__restrict__ mass, const float *__restrict__ pts,
-                                                    Bbox bbox, float finest_res)
+                                                    Bbox bbox, float finest_res, int64_t group_pts)
 {
     __shared__ double red[4][NRF_MAX_LEVELS];
+    {
+        const int64_t first = (int64_t)blockIdx.y * group_pts;
+        g += first * (int64_t)(L * F);
+        if (pts) pts += first * 3;
+        mass += (int64_t)blockIdx.y * L;
+        p = (p - first) < group_pts ? (p - first) : group_pts;
+    }
     const int l = threadIdx.x % 16, sub = threadIdx.x / 16;          // 16 threads share a row: coalesced for the L = 16 default
     double m[(NRF_MAX_LEVELS + 15) / 16] = {};
     for (int64_t i = (int64_t)blockIdx.x * 16 + sub; i < p; i += (int64_t)gridDim.x * 16)
@@ -437,6 +445,7 @@ __global__ void __launch_bounds__(256) k_level_mass(int64_t p, int L, int F, con
 // times 1.01 for the fp16 rounding of the CuHashEmbedder addends.  The 2^30 leaves 2^30 units for the round-to-nearest of the individual addends.
 __global__ void k_qscale(int L, int overlap, const double *__restrict__ mass, float *__restrict__ qs)
 {
+    mass += (int64_t)blockIdx.x * L; qs += (int64_t)blockIdx.x * 2;          // one block per pass
     double b = 0.0;
     for (int l = 0; l < L; l++) {
         const double v = mass[l] + ((overlap && l + 1 < L) ? mass[l + 1] : 0.0);
@@ -465,7 +474,8 @@ __global__ void k_unpack_q(int64_t entries, unsigned long long *__restrict__ q, 
 }
 
 // start[b] = records of the bins before b (exclusive scan; start[nbins] = total), cursor[b] = start[b]
-__global__ void k_bin_scan(int nbins, const uint32_t *__restrict__ gcount, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor)
+// ... and leaves the counts zeroed for the next pass (nothing reads them after this)
+__global__ void k_bin_scan(int nbins, uint32_t *__restrict__ gcount, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t part[256];
     const int per = (nbins + 255) / 256, b0 = threadIdx.x * per;
@@ -476,7 +486,7 @@ __global__ void k_bin_scan(int nbins, const uint32_t *__restrict__ gcount, uint3
     if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 256; i++) { const uint32_t v = part[i]; part[i] = run; run += v; } start[nbins] = run; }
     __syncthreads();
     uint32_t run = part[threadIdx.x];
-    for (int i = b0; i < b0 + per && i < nbins; i++) { start[i] = run; cursor[i] = run; run += gcount[i]; }
+    for (int i = b0; i < b0 + per && i < nbins; i++) { start[i] = run; cursor[i] = run; run += gcount[i]; gcount[i] = 0u; }
 }
 
 // One workgroup per bin: its records summed in LDS (packed 64-bit words, integer addition: exact and order-free), then the two fixed-point fields of every touched
@@ -701,7 +711,7 @@ int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t
         const float *gp = d_g_emb + r0 * s * (int64_t)(L * 2), *pp = d_pts + r0 * s * 3;
         if (r0) NRF_HIP(hipMemsetAsync(mass, 0, 512, st));
         hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(ceil_div(p, 16) < 2048 ? ceil_div(p, 16) : 2048)), dim3(256), 0, st, p, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
-                           h->params.bbox, (float)h->desc.finest_resolution);
+                           h->params.bbox, (float)h->desc.finest_resolution, p);
         hipLaunchKernelGGL(k_qscale, dim3(1), dim3(1), 0, st, L, ngp ? 0 : 1, mass, qs);
         const int64_t threads = nr * ((s + BWD_SEG - 1) / BWD_SEG);
         dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
@@ -713,7 +723,8 @@ int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t
     return NRF_OK;
 }
 
-// workspace of the binned form: header (1 KB: mass, scale) | gcount [nbins + 1] | start [nbins + 1] | cursor [nbins] | wg_hist | records
+// workspace of the binned form: header (64 KB: mass [passes][L], scale [passes][2]) | gcount [nbins + 1] | start [nbins + 1] | cursor [nbins] | wg_hist | records
+constexpr size_t BIN_HDR = 65536;
 // n_rays < 0: the worst case (a whole group of 2^18 points per pass); otherwise the pass never holds more than n_rays rays and the record buffer is sized for that
 static void binned_layout(const nrf_hash *h, int s, int64_t n_rays, int64_t *nbins, int64_t *rays_per_group, int64_t *nwg, size_t *off_hist, size_t *off_rec, size_t *total)
 {
@@ -724,7 +735,7 @@ static void binned_layout(const nrf_hash *h, int s, int64_t n_rays, int64_t *nbi
     const int64_t held = (n_rays >= 0 && n_rays < *rays_per_group) ? (n_rays > 0 ? n_rays : 1) : *rays_per_group;      // rays a pass can hold at most
     const int64_t threads = held * ((s + BWD_SEG - 1) / BWD_SEG);
     *nwg = ceil_div(threads, (int64_t)256);
-    size_t o = 1024 + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
+    size_t o = BIN_HDR + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
     *off_hist = o;
     o += align_up((size_t)L * *nwg * BIN_MAX_PER_LEVEL * 4, 256);
     *off_rec = o;
@@ -763,10 +774,13 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     const int L = h->desc.n_levels;
     hipStream_t st = as_stream(stream);
     unsigned char *ws = reinterpret_cast<unsigned char *>(d_workspace);
+    // The level masses and scales of ALL passes come first, in two launches (a launch of 2^18 points is latency-bound: 30 us for 33 MB, thirteen of them per
+    // training step, plus the scale kernel and a memset per pass: profiles/round4/r5c_*); same per-pass sums, same scales, same table gradient bits.
+    const int64_t pass_cap = (int64_t)(BIN_HDR / ((size_t)L * 8 + 8));                          // passes whose masses and scales the header holds
     double *mass = reinterpret_cast<double *>(ws);
-    float *qs = reinterpret_cast<float *>(ws + 768);
+    float *qs = reinterpret_cast<float *>(ws + (size_t)pass_cap * L * 8);
     const size_t cnt_bytes = align_up((size_t)(nbins + 1) * 4, 256);
-    uint32_t *gcount = reinterpret_cast<uint32_t *>(ws + 1024), *start = reinterpret_cast<uint32_t *>(ws + 1024 + cnt_bytes), *cursor = reinterpret_cast<uint32_t *>(ws + 1024 + 2 * cnt_bytes);
+    uint32_t *gcount = reinterpret_cast<uint32_t *>(ws + BIN_HDR), *start = reinterpret_cast<uint32_t *>(ws + BIN_HDR + cnt_bytes), *cursor = reinterpret_cast<uint32_t *>(ws + BIN_HDR + 2 * cnt_bytes);
     BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<uint4 *>(ws + off_rec)};
     const int64_t entries = nrf_hash_table_elems(h) / 2;
     const bool ngp = h->desc.mode == NRF_HASH_NGP;
@@ -774,22 +788,31 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     const size_t lds = (size_t)BIN_WORDS * 8;
     if (attr_set.needed()) { NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set.done(); }
     // same groups and the same scale as the packed form: the integer fields are identical, so is the result
-    for (int64_t r0 = 0; r0 < n; r0 += rays_per_group) {
+    const int64_t group_pts = rays_per_group * s;
+    int64_t pass = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += rays_per_group, pass++) {
         const int64_t nr = (n - r0) < rays_per_group ? (n - r0) : rays_per_group;
-        const int64_t p = nr * s;
         const float *gp = d_g_emb + r0 * s * (int64_t)(L * 2), *pp = d_pts + r0 * s * 3;
-        NRF_HIP(hipMemsetAsync(ws, 0, 1024 + cnt_bytes, st));                        // mass, scale, bin counts
-        hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(ceil_div(p, 16) < 2048 ? ceil_div(p, 16) : 2048)), dim3(256), 0, st, p, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
-                           h->params.bbox, (float)h->desc.finest_resolution);
-        hipLaunchKernelGGL(k_qscale, dim3(1), dim3(1), 0, st, L, ngp ? 0 : 1, mass, qs);
+        if (pass % pass_cap == 0) {
+            // masses and scales of the next pass_cap passes (all of them unless the call holds more than ~450 x 2^18 points); the bin counts are zeroed once, k_bin_scan
+            // leaves them zeroed
+            const int64_t rays_left = n - r0, passes = ceil_div(rays_left, rays_per_group) < pass_cap ? ceil_div(rays_left, rays_per_group) : pass_cap;
+            const int64_t pts_here = (rays_left < passes * rays_per_group ? rays_left : passes * rays_per_group) * s;
+            NRF_HIP(hipMemsetAsync(ws, 0, pass == 0 ? BIN_HDR + cnt_bytes : BIN_HDR, st));
+            const int64_t blocks = ceil_div(group_pts < pts_here ? group_pts : pts_here, 16);
+            hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)passes), dim3(256), 0, st, pts_here, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
+                               h->params.bbox, (float)h->desc.finest_resolution, group_pts);
+            hipLaunchKernelGGL(k_qscale, dim3((unsigned)passes), dim3(1), 0, st, L, ngp ? 0 : 1, mass, qs);
+        }
+        const float *qsp = qs + (pass % pass_cap) * 2;
         const int64_t threads = nr * ((s + BWD_SEG - 1) / BWD_SEG);
         dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
-        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
-        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, (const uint32_t *)gcount, start, cursor);
-        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
-        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, (const float *)qs, sink);
-        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(BIN_THREADS), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, (const float *)qs, entries, d_g_table);
+        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
+        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, gcount, start, cursor);
+        if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
+        else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
+        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(BIN_THREADS), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, qsp, entries, d_g_table);
     }
     NRF_LAUNCH_CHECK();
     return NRF_OK;

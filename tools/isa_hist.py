@@ -25,6 +25,8 @@ if not os.path.exists(src):
 stem = os.path.splitext(os.path.basename(src))[0]
 # the per-file flags of the Makefile
 flags = ["-fno-honor-nans"] if stem in ("mlp_small_mfma", "sigma_small_f32", "sigma_lerf_f32", "sigma_nerf_f32", "mlp_nerf_split_mfma", "mlp_lerf_split_mfma") else []
+if stem == "mlp_small_bwd_mfma":
+    flags = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 with tempfile.TemporaryDirectory() as td:
     out = os.path.join(td, stem + ".s")
     cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fvisibility=hidden", "-I" + os.path.join(here, "..", "include"),
