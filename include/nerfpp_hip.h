@@ -487,8 +487,9 @@ NRF_API size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p);
 NRF_API int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
                              void *d_workspace, size_t workspace_bytes, void *stream);
 /* The same gradients on the matrix cores (fp16 operands, fp32 accumulation, power-of-two loss scaling chosen on the device from
- * max|g_out|): one fused kernel per 2^20 points, forward + gradient chain + weight gradients.  Built for in 32 / views 16 / 64-wide /
- * 2-3 sigma + 3-4 colour layers; NRF_ERR_UNSUPPORTED otherwise.  Same arguments as nrf_mlp_backward. */
+ * max|g_out|): one fused kernel per 2^22 points, forward + gradient chain + weight gradients.  Built for in 32 / views 16 / 64-wide /
+ * 2-3 sigma + 3-4 colour layers; NRF_ERR_UNSUPPORTED otherwise.  Same arguments as nrf_mlp_backward.  The workspace is a fixed ~25 MB (one slot of operand
+ * fragments per resident wave), whatever p. */
 NRF_API size_t nrf_mlp_backward_f16_workspace_bytes(const nrf_mlp *m, int64_t p);
 NRF_API int nrf_mlp_backward_f16(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
                                  void *d_workspace, size_t workspace_bytes, void *stream);

@@ -28,6 +28,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+#ifdef NRF_BWD_TRACE
+// diagnostic build only (tools/scratch/bwd_trace.py): cycle stamps of wave 0 of every workgroup, summed per section (names in the script)
+__device__ unsigned long long g_bwd_trace[256 * 16];
+#define NRF_BSTAMP(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define NRF_BSTAMP(i) do { } while (0)
+#endif
+
 constexpr int BW = 4;                   // waves per workgroup: one per SIMD, 512 registers each (the dW accumulators alone are 320)
 constexpr int BPT = 1;                  // 32-point tiles per wave (two would need 180 working registers on top of the 320 accumulators)
 constexpr int BW_BLOCK_PTS = 32 * BPT * BW;
@@ -86,15 +94,21 @@ template <int MT, int KS>
 __device__ __forceinline__ void gemm(const half8 *__restrict__ frags, int lane, const half8 (&b)[BPT][KS], f32x16 (&acc)[BPT][MT])
 {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the A fragment of the NEXT matrix instruction is read before this one is issued: with one wave per SIMD and a fence behind every instruction the LDS
+    // latency of a fragment read where it is used stands in front of each of the ~70 matrix instructions of the two chains (NRF_BWD_A_PREFETCH=0: as before)
+#ifndef NRF_BWD_A_PREFETCH
+#define NRF_BWD_A_PREFETCH 0            // measured: 1.70 against 1.64 ms per call with both this and the paired transposes (r5g_*): the LDS reads were never what the wave waits for
+#endif
+    half8 a_next = frags[lane];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
+    for (int i = 0; i < MT * KS; i++) {
+        const int mt = i / KS, ks = i % KS;
+        half8 a = a_next;
+        if (!NRF_BWD_A_PREFETCH) a = frags[i * 64 + lane];
+        else if (i + 1 < MT * KS) a_next = frags[(i + 1) * 64 + lane];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const half8 a = frags[(mt * KS + ks) * 64 + lane];
-#pragma unroll
-            for (int pt = 0; pt < BPT; pt++) acc[pt][mt] = mfma(a, b[pt][ks], ks == 0 ? zero : acc[pt][mt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int pt = 0; pt < BPT; pt++) acc[pt][mt] = mfma(a, b[pt][ks], ks == 0 ? zero : acc[pt][mt]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -198,11 +212,25 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
         t[0] = to_frag<false>(d, 0); t[1] = to_frag<false>(d, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // both 32-neuron groups' products are issued before the first conversion (two live D tiles): the second pair of matrix instructions runs while the first result lands
+#ifndef NRF_BWD_TRANSPOSE_PAIRS
+#define NRF_BWD_TRANSPOSE_PAIRS 0
+#endif
     auto transpose64 = [&](const half8 (&f)[BPT][4], half8 (&t)[2][BPT][2]) {
 #pragma unroll
-        for (int g = 0; g < 2; g++)
+        for (int pt = 0; pt < BPT; pt++) {
+            if (NRF_BWD_TRANSPOSE_PAIRS) {
+                f32x16 d0 = mfma(f[pt][0], sel0, zero), d1 = mfma(f[pt][2], sel0, zero);
+                d0 = mfma(f[pt][1], sel1, d0); d1 = mfma(f[pt][3], sel1, d1);
+                __builtin_amdgcn_sched_barrier(0);
+                t[0][pt][0] = to_frag<false>(d0, 0); t[0][pt][1] = to_frag<false>(d0, 1);
+                t[1][pt][0] = to_frag<false>(d1, 0); t[1][pt][1] = to_frag<false>(d1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
-            for (int pt = 0; pt < BPT; pt++) transpose(f[pt][2 * g], sel0, f[pt][2 * g + 1], sel1, t[g][pt]);
+                for (int g = 0; g < 2; g++) transpose(f[pt][2 * g], sel0, f[pt][2 * g + 1], sel1, t[g][pt]);
+            }
+        }
     };
 
     // weight-gradient accumulators of this wave, one 32x32 tile per (out group, in group); the hidden x hidden layers have four, the rest two
@@ -217,9 +245,57 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
     }
     a_c0[0] = a_c0[1] = a_s0[0] = a_s0[1] = a_cl[0] = a_cl[1] = a_sl[0] = a_sl[1] = zero;
     const int64_t nblocks = (npts + BW_BLOCK_PTS - 1) / BW_BLOCK_PTS;
+#ifdef NRF_BWD_TRACE
+    unsigned long long tr[16] = {}, tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+#endif
+    // One wave per SIMD and a dependent chain: whatever a pass loads where it needs it, it waits for in full (cycle stamps of -DNRF_BWD_TRACE builds,
+    // tools/scratch/bwd_trace.py, profiles/round4/r5g_*: of 33 k cycles per pass 6.4 k in front of the inputs, 1.9 k in front of the output gradients, ~13 k in front
+    // of the fragment reloads of the backward chain).  Most of that was HBM traffic of the fragment scratch, gone with the per-wave slot (below).  Requesting things
+    // ahead -- bit 1: the NEXT pass's inputs (level-major form) and output gradients while this pass computes; bit 2: each backward layer requests the fragments of
+    // the layer after it -- moves the waits without shortening the pass (r5j_*: training step 6.60-6.67 ms with 0, 1 or 2; the stamps show the cycles reappear at the
+    // g_x stores, behind which every later wait of the in-order counter queues), and 3 crashes this compiler: off.
+#ifndef NRF_BWD_PREFETCH
+#define NRF_BWD_PREFETCH 0
+#endif
+    half8 nx[BPT][IN_KS], nc[BPT];
+    float4 ng[BPT];
+    auto request_inputs = [&](int64_t b) {
+#pragma unroll
+        for (int pt = 0; pt < BPT; pt++) {
+            int64_t p = b * BW_BLOCK_PTS + wave * (32 * BPT) + pt * 32 + r;
+            if (p >= npts) p = npts - 1;
+#pragma unroll
+            for (int s = 0; s < IN_KS; s++) {
+                union { half8 v; __half2 q[4]; } u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) u.q[q] = lm.feats[(int64_t)(8 * s + 4 * h + q) * lm.pstride + p];      // features 16s + 8h + 2q, +1
+                nx[pt][s] = u.v;
+            }
+            const int64_t ray = (lm.p_base + p) / lm.s;
+            nc[pt] = *reinterpret_cast<const half8 *>(lm.dirs + ray * V + 8 * h);
+        }
+    };
+    auto request_gout = [&](int64_t b) {
+#pragma unroll
+        for (int pt = 0; pt < BPT; pt++) {
+            const int64_t p = b * BW_BLOCK_PTS + wave * (32 * BPT) + pt * 32 + r;
+            ng[pt] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (p < npts) ng[pt] = *reinterpret_cast<const float4 *>(g_out + p * gos);
+        }
+    };
+    if ((NRF_BWD_PREFETCH & 1) && (int64_t)blockIdx.x < nblocks) {
+        if (lm.feats) request_inputs(blockIdx.x);
+        request_gout(blockIdx.x);
+    }
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int64_t p0 = blk * BW_BLOCK_PTS + wave * (32 * BPT);
-        half8 *hs = scratch + ((p0 >> 5) * P::h_frags()) * 64;                  // this wave's tiles: [pt][fragment][lane]; wave-uniform pointer
+        const bool more = blk + gridDim.x < nblocks;
+        NRF_BSTAMP(15);
+        // this wave's fragments: [pt][fragment][lane]; wave-uniform pointer.  The SAME 24 KB every pass: a region per tile of the launch (2.4 GB for a training
+        // batch) made every fragment a line written back to HBM and, with 3 MB of them in flight per XCD, mostly re-read from there -- 4.8 GB per call, which is
+        // what the kernel's 1.6 ms were (profiles/round4/r5i_*); a wave's own slot is rewritten while it is still in the L2
+        half8 *hs = scratch + ((size_t)(blockIdx.x * BW + wave) * BPT * P::h_frags()) * 64;
         // the asm pins each fragment's base as an SGPR pair where it is used: left alone, the compiler precomputes one 64-bit VGPR address per
         // 4-KB window outside the persistent loop (20 register pairs) and spills them
         auto hstore = [&](int pt, int f, const half8 &v) { half8 *sp = hs + (pt * P::h_frags() + f) * 64; asm volatile("" : "+s"(sp)); sp[lane] = v; };
@@ -234,15 +310,10 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
                 int64_t p = p0 + pt * 32 + r;
                 if (p >= npts) p = npts - 1;
                 if (lm.feats) {
+                    if (!(NRF_BWD_PREFETCH & 1)) request_inputs(blk);
 #pragma unroll
-                    for (int s = 0; s < IN_KS; s++) {
-                        union { half8 v; __half2 q[4]; } u;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) u.q[q] = lm.feats[(int64_t)(8 * s + 4 * h + q) * lm.pstride + p];      // features 16s + 8h + 2q, +1
-                        bx[pt][s] = u.v; hstore(pt, P::h_sigma(0) + s, u.v);
-                    }
-                    const int64_t ray = (lm.p_base + p) / lm.s;
-                    bc[pt][0] = *reinterpret_cast<const half8 *>(lm.dirs + ray * V + 8 * h);
+                    for (int s = 0; s < IN_KS; s++) { bx[pt][s] = nx[pt][s]; hstore(pt, P::h_sigma(0) + s, bx[pt][s]); }
+                    bc[pt][0] = nc[pt];
                     hstore(pt, P::h_color(0), bc[pt][0]);
                     continue;
                 }
@@ -255,6 +326,8 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
                     else { bc[pt][0] = v; hstore(pt, P::h_color(0), v); }
                 }
             }
+            if ((NRF_BWD_PREFETCH & 1) && lm.feats && more) request_inputs(blk + gridDim.x);
+            NRF_BSTAMP(0);
             const half8 *fr = wf;
             gemm<2, IN_KS>(fr, lane, bx, acc2); fr += P::sigma_frags(0) * 64;
 #pragma unroll
@@ -282,18 +355,34 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
                 if (l < NLC - 1) { gemm<2, 4>(fr, lane, bh, acc2); fr += P::color_frags(l) * 64; }
             }
         }
+        NRF_BSTAMP(1);
         // ======================================= backward =======================================
         // bh = c_{NLC-1}, the input of the last colour layer, still in registers
+        // stage k of the backward chain reloads: k < NLC - 2: hidden colour layer NLC - 2 - k (4 fragments); NLC - 2: colour layer 0 (2); NLC - 1: last sigma layer (4);
+        // then the hidden sigma layers NL - 2 .. 1 (4 each); last: sigma layer 0 (2).  bn = the fragments requested for the next stage.
+        half8 bn[BPT][4];
+        auto request_stage = [&](int k) {
+#pragma unroll
+            for (int pt = 0; pt < BPT; pt++) {
+                if (k < NLC - 2) { for (int f = 0; f < 4; f++) bn[pt][f] = hload(pt, P::h_color(NLC - 2 - k) + f); }
+                else if (k == NLC - 2) { bn[pt][0] = hload(pt, P::h_color(0)); bn[pt][1] = hload(pt, P::h_color(0) + 1); }
+                else if (k == NLC - 1) { for (int f = 0; f < 4; f++) bn[pt][f] = hload(pt, P::h_sigma(NL - 1) + f); }
+                else if (k < NLC + NL - 2) { for (int f = 0; f < 4; f++) bn[pt][f] = hload(pt, P::h_sigma(NL - 2 - (k - NLC)) + f); }
+                else { bn[pt][0] = hload(pt, P::h_sigma(0)); bn[pt][1] = hload(pt, P::h_sigma(0) + 1); }
+            }
+        };
+        if (NRF_BWD_PREFETCH & 2) request_stage(0);
         half8 g1[BPT][1];
         float gsig[BPT];
+        if (!(NRF_BWD_PREFETCH & 1)) request_gout(blk);
 #pragma unroll
         for (int pt = 0; pt < BPT; pt++) {
-            const int64_t p = p0 + pt * 32 + r;
-            float4 g = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (p < npts) { const float *gr = g_out + p * gos; g = float4{gr[0], gr[1], gr[2], gr[3]}; }
+            const float4 g = ng[pt];
             g1[pt][0] = h == 0 ? half8{(_Float16)(g.x * S), (_Float16)(g.y * S), (_Float16)(g.z * S), 0, 0, 0, 0, 0} : hzero;
             gsig[pt] = g.w * S;
         }
+        if ((NRF_BWD_PREFETCH & 1) && more) request_gout(blk + gridDim.x);
+        NRF_BSTAMP(2);
         const half8 *br = wb;
         half8 gf[BPT][4];
         half8 gt[2][BPT][2], ht[2][BPT][2];
@@ -306,22 +395,33 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
             gemm<2, 1>(br, lane, g1, acc2); br += P::bwd_color_frags(NLC - 1) * 64;
             mask_to_frags(acc2, bh, gf);
         }
+        NRF_BSTAMP(3);
 #pragma unroll
         for (int l = NLC - 2; l >= 1; l--) {            // hidden colour layers c_l -> c_{l+1}
 #pragma unroll
             for (int pt = 0; pt < BPT; pt++)
 #pragma unroll
-                for (int f = 0; f < 4; f++) bh[pt][f] = hload(pt, P::h_color(l) + f);
+                for (int f = 0; f < 4; f++) bh[pt][f] = (NRF_BWD_PREFETCH & 2) ? bn[pt][f] : hload(pt, P::h_color(l) + f);
+            if (NRF_BWD_PREFETCH & 2) request_stage(NLC - 2 - l + 1);
+            NRF_BSTAMP(4);
             transpose64(bh, ht); transpose64(gf, gt);
+            NRF_BSTAMP(5);
             dw_update<2, 2>(gt, ht, a_c[l]);
+            NRF_BSTAMP(6);
             gemm<2, 4>(br, lane, gf, acc2); br += P::bwd_color_frags(l) * 64;
+            NRF_BSTAMP(7);
             mask_to_frags(acc2, bh, gf);
+            NRF_BSTAMP(8);
         }
         half8 g3[BPT][1];
         {   // colour layer 0: [views, geo] -> c_1; only the geo rows propagate; sigma's own gradient joins at row 0
             half8 ht1[1][BPT][2];
 #pragma unroll
-            for (int pt = 0; pt < BPT; pt++) transpose(hload(pt, P::h_color(0)), nat0, hload(pt, P::h_color(0) + 1), selgeo, ht1[0][pt]);
+            for (int pt = 0; pt < BPT; pt++) {
+                const half8 f0 = (NRF_BWD_PREFETCH & 2) ? bn[pt][0] : hload(pt, P::h_color(0)), f1 = (NRF_BWD_PREFETCH & 2) ? bn[pt][1] : hload(pt, P::h_color(0) + 1);
+                if ((NRF_BWD_PREFETCH & 2) && pt == BPT - 1) request_stage(NLC - 1);
+                transpose(f0, nat0, f1, selgeo, ht1[0][pt]);
+            }
             transpose64(gf, gt);
             dw_update<2, 1>(gt, ht1, a_c0);
             f32x16 a1[BPT][1];
@@ -332,11 +432,13 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
                 g3[pt][0] = to_frag<false>(a1[pt][0], 0);
             }
         }
+        NRF_BSTAMP(9);
         {   // sigma layer NL-1: h -> [sigma, geo]
 #pragma unroll
             for (int pt = 0; pt < BPT; pt++)
 #pragma unroll
-                for (int f = 0; f < 4; f++) bh[pt][f] = hload(pt, P::h_sigma(NL - 1) + f);
+                for (int f = 0; f < 4; f++) bh[pt][f] = (NRF_BWD_PREFETCH & 2) ? bn[pt][f] : hload(pt, P::h_sigma(NL - 1) + f);
+            if (NRF_BWD_PREFETCH & 2) request_stage(NLC);
             half8 gt1[1][BPT][2];
 #pragma unroll
             for (int pt = 0; pt < BPT; pt++) transpose1(g3[pt][0], sel0, gt1[0][pt]);
@@ -345,21 +447,27 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
             gemm<2, 1>(br, lane, g3, acc2); br += P::bwd_sigma_frags(NL - 1) * 64;
             mask_to_frags(acc2, bh, gf);
         }
+        NRF_BSTAMP(10);
 #pragma unroll
         for (int l = NL - 2; l >= 1; l--) {
 #pragma unroll
             for (int pt = 0; pt < BPT; pt++)
 #pragma unroll
-                for (int f = 0; f < 4; f++) bh[pt][f] = hload(pt, P::h_sigma(l) + f);
+                for (int f = 0; f < 4; f++) bh[pt][f] = (NRF_BWD_PREFETCH & 2) ? bn[pt][f] : hload(pt, P::h_sigma(l) + f);
+            if (NRF_BWD_PREFETCH & 2) request_stage(NLC + (NL - 2 - l) + 1);
             transpose64(bh, ht); transpose64(gf, gt);
             dw_update<2, 2>(gt, ht, a_s[l]);
             gemm<2, 4>(br, lane, gf, acc2); br += P::bwd_sigma_frags(l) * 64;
             mask_to_frags(acc2, bh, gf);
         }
+        NRF_BSTAMP(11);
         {   // sigma layer 0: x -> h_1; g_x leaves in fp32
             half8 ht1[1][BPT][2];
 #pragma unroll
-            for (int pt = 0; pt < BPT; pt++) transpose(hload(pt, P::h_sigma(0)), nat0, hload(pt, P::h_sigma(0) + 1), nat1, ht1[0][pt]);
+            for (int pt = 0; pt < BPT; pt++) {
+                const half8 f0 = (NRF_BWD_PREFETCH & 2) ? bn[pt][0] : hload(pt, P::h_sigma(0)), f1 = (NRF_BWD_PREFETCH & 2) ? bn[pt][1] : hload(pt, P::h_sigma(0) + 1);
+                transpose(f0, nat0, f1, nat1, ht1[0][pt]);
+            }
             transpose64(gf, gt);
             dw_update<2, 1>(gt, ht1, a_s0);
             if (g_x) {
@@ -377,7 +485,11 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
                 }
             }
         }
+        NRF_BSTAMP(12);
     }
+#ifdef NRF_BWD_TRACE
+    { NRF_BSTAMP(13); }
+#endif
     // ---- the wave's tiles -> LDS copy of the blob -> global (one float atomic per parameter and workgroup) ----
     {
         dw_flush<1, 2, 3, 64>(a_cl, dw + lo.c[NLC - 1], r, h);
@@ -394,7 +506,22 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
         const float v = dw[i];
         if (v != 0.0f) unsafeAtomicAdd(g_params + i, v * invS);
     }
+#ifdef NRF_BWD_TRACE
+    tr[14] = __builtin_readcyclecounter() - tstart;
+    if (threadIdx.x == 0) for (int i = 0; i < 16; i++) g_bwd_trace[(blockIdx.x & 255) * 16 + i] += tr[i];
+#endif
 }
+
+#ifdef NRF_BWD_TRACE
+}  // namespace
+extern "C" NRF_API int nrf_dbg_bwd_trace(unsigned long long *host_out, int reset)
+{
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd_trace), sizeof(unsigned long long) * 256 * 16) != hipSuccess) return NRF_ERR_HIP;
+    if (reset) { static unsigned long long z[256 * 16]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), z, sizeof(z)) != hipSuccess) return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+namespace {
+#endif
 
 __global__ void k_absmax(int64_t n, const float *__restrict__ g, uint32_t *__restrict__ out)
 {
@@ -502,15 +629,14 @@ int mlp_small_pack_bwd(nrf_mlp *m, const std::vector<float> &hp)
     return NRF_OK;
 }
 
-static const int64_t BWD_MFMA_CHUNK = 1 << 22;       // 3 GB of operand fragments per launch; every launch ends with one float atomic per parameter and workgroup
+static const int64_t BWD_MFMA_CHUNK = 1 << 22;       // points per launch; every launch ends with one float atomic per parameter and workgroup
 
 static size_t h_frags_of(const nrf_mlp_small_desc &d) { return 2 + 4 * (d.num_layers - 1) + 2 + 4 * (d.num_layers_color - 1); }
 
 size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p)
 {
-    const int64_t c = p < BWD_MFMA_CHUNK ? p : BWD_MFMA_CHUNK;
-    const int64_t tiles = ceil_div(c, (int64_t)BW_BLOCK_PTS) * (BW_BLOCK_PTS / 32);
-    return 256 + (size_t)tiles * h_frags_of(m->small) * 1024;
+    (void)p;                                       // one fragment slot per resident wave (256 persistent workgroups), whatever the batch
+    return 256 + (size_t)256 * (BW_BLOCK_PTS / 32) * h_frags_of(m->small) * 1024;
 }
 
 static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p,
