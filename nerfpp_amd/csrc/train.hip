@@ -248,11 +248,27 @@ constexpr int64_t PACKED_GROUP_PTS = (int64_t)1 << NRF_PACKED_GROUP_LOG2;      /
 constexpr int BIN_SHIFT = 14;
 constexpr int BIN_WORDS = 1 << BIN_SHIFT;
 constexpr int BIN_MAX_PER_LEVEL = 40;        // bins one level's words can touch: 2^19 / 2^14 = 32, + 1 for an unaligned base (+ margin)
+// A record = 8 bytes: the word's 14 bits inside its bin (the bin is where the record lies) and the two fixed-point addends as 25-bit two's-complement fields.  The
+// records of a pass are written once and read once through HBM (~16 M of them per 2^18 points): that traffic IS the time of the emit pass and of k_bin_accumulate
+// -- training step, same call: 16-byte records {word, q0, q1, pad} 6.55 ms, 12-byte 6.20, 8-byte 5.9 (profiles/round4/r5l_*, r5m_*).
+// An addend outside the field (|q| >= 2^24) goes to a side list as {word, q0, q1} instead: the scale bounds the sum of |q| over a level's records of a pass by 2^30
+// (k_qscale), so at most 64 records per level and field can be that large -- the list holds 128 per level and cannot overflow.
+typedef unsigned long long BinRec;
+struct BinOvf { uint32_t word; int32_t q0, q1; };
+constexpr int BIN_OVF_PER_LEVEL = 128;
+__device__ __forceinline__ bool bin_rec_fits(int32_t q0, int32_t q1) { return q0 >= -(1 << 24) && q0 < (1 << 24) && q1 >= -(1 << 24) && q1 < (1 << 24); }
+__device__ __forceinline__ BinRec bin_rec_pack(uint32_t word, int32_t q0, int32_t q1)
+{
+    return (BinRec)(word & (uint32_t)((1 << 14) - 1)) | ((BinRec)((uint32_t)q0 & 0x1ffffffu) << 14) | ((BinRec)((uint32_t)q1 & 0x1ffffffu) << 39);
+}
 struct BinSink {
     uint32_t *wg_hist;       // [levels][workgroups][BIN_MAX_PER_LEVEL] records of a workgroup per bin (count pass writes, emit pass reads)
     uint32_t *gcount;        // [nbins + 1] records per bin (count pass); zeroed again by k_bin_scan
     uint32_t *cursor;        // [nbins] next free record slot of a bin (scan initialises to the bin's start)
-    uint4 *rec;              // records
+    BinRec *rec;             // records
+    uint32_t *ovf_count;     // entries of the side list (k_bin_scan zeroes it between the count pass and the emit pass)
+    BinOvf *ovf;             // [BIN_OVF_PER_LEVEL * levels]
+    uint32_t ovf_cap;
 };
 
 template <int F, bool CU, bool Q, int MODE>
@@ -331,10 +347,15 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
                 } else if (q0 | q1) {
                     const uint32_t wbase = (uint32_t)((tl - g_table) / 2);                 // the level's first 64-bit word
                     const uint32_t word = wbase + row, b = (word >> BIN_SHIFT) - (wbase >> BIN_SHIFT);
-                    if constexpr (MODE == 1) atomicAdd(bin_cnt + b, 1u);
+                    if (!bin_rec_fits(q0, q1)) {                                             // (neither pass counts it)
+                        if constexpr (MODE == 2) {
+                            const uint32_t k2 = atomicAdd(sink.ovf_count, 1u);
+                            if (k2 < sink.ovf_cap) sink.ovf[k2] = BinOvf{word, q0, q1};
+                        }
+                    } else if constexpr (MODE == 1) atomicAdd(bin_cnt + b, 1u);
                     else {
                         const uint32_t rank = atomicAdd(bin_cnt + b, 1u);
-                        sink.rec[(size_t)bin_base[b] + rank] = make_uint4(word, (uint32_t)q0, (uint32_t)q1, 0u);
+                        sink.rec[(size_t)bin_base[b] + rank] = bin_rec_pack(word, q0, q1);
                     }
                 }
             } else {
@@ -475,8 +496,9 @@ __global__ void k_unpack_q(int64_t entries, unsigned long long *__restrict__ q, 
 
 // start[b] = records of the bins before b (exclusive scan; start[nbins] = total), cursor[b] = start[b]
 // ... and leaves the counts zeroed for the next pass (nothing reads them after this)
-__global__ void k_bin_scan(int nbins, uint32_t *__restrict__ gcount, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor)
+__global__ void k_bin_scan(int nbins, uint32_t *__restrict__ gcount, uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ ovf_count)
 {
+    if (threadIdx.x == 0) *ovf_count = 0u;             // the previous pass's side list has been consumed (stream order); the emit pass behind this fills it again
     __shared__ uint32_t part[256];
     const int per = (nbins + 255) / 256, b0 = threadIdx.x * per;
     uint32_t sum = 0;
@@ -492,21 +514,31 @@ __global__ void k_bin_scan(int nbins, uint32_t *__restrict__ gcount, uint32_t *_
 // One workgroup per bin: its records summed in LDS (packed 64-bit words, integer addition: exact and order-free), then the two fixed-point fields of every touched
 // word decoded and added to the fp32 gradient -- words of a bin belong to this workgroup alone, so the read-modify-write needs no atomic.
 constexpr int BIN_THREADS = 1024;          // one workgroup per CU (128 KB of LDS): sixteen waves, four record loads in flight per lane, to cover the loads' latency
-__global__ void __launch_bounds__(BIN_THREADS) k_bin_accumulate(const uint32_t *__restrict__ start, const uint4 *__restrict__ rec, const float *__restrict__ qs, int64_t entries,
-                                                                float *__restrict__ g_table)
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_accumulate(const uint32_t *__restrict__ start, const BinRec *__restrict__ rec, const float *__restrict__ qs, int64_t entries,
+                                                                float *__restrict__ g_table, const uint32_t *__restrict__ ovf_count, const BinOvf *__restrict__ ovf, uint32_t ovf_cap)
 {
     extern __shared__ unsigned long long bin_acc[];
     const uint32_t r0 = start[blockIdx.x], r1 = start[blockIdx.x + 1];
-    if (r0 == r1) return;
+    uint32_t novf = *ovf_count;
+    novf = novf < ovf_cap ? novf : ovf_cap;
+    if (r0 == r1 && novf == 0) return;
     for (int e = threadIdx.x; e < BIN_WORDS; e += BIN_THREADS) bin_acc[e] = 0ull;
     __syncthreads();
-    auto add = [&](const uint4 &r) { atomicAdd(bin_acc + (r.x & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)(((int64_t)(int32_t)r.z << 32) + (int64_t)(int32_t)r.y)); };
+    auto add = [&](const BinRec r) {
+        const int32_t q0 = (int32_t)((uint32_t)(r >> 14) << 7) >> 7;                      // bits 14..38, sign-extended
+        const int64_t q1 = (int64_t)r >> 39;                                              // bits 39..63
+        atomicAdd(bin_acc + ((uint32_t)r & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)((q1 << 32) + (int64_t)q0));
+    };
     uint32_t i = r0 + threadIdx.x;
     for (; i + 3u * BIN_THREADS < r1; i += 4u * BIN_THREADS) {
-        const uint4 a = rec[i], b = rec[i + BIN_THREADS], c = rec[i + 2u * BIN_THREADS], d = rec[i + 3u * BIN_THREADS];
+        const BinRec a = rec[i], b = rec[i + BIN_THREADS], c = rec[i + 2u * BIN_THREADS], d = rec[i + 3u * BIN_THREADS];
         add(a); add(b); add(c); add(d);
     }
     for (; i < r1; i += BIN_THREADS) add(rec[i]);
+    for (uint32_t k = threadIdx.x; k < novf; k += BIN_THREADS) {                          // the few addends beyond the 25-bit fields
+        const BinOvf o = ovf[k];
+        if ((o.word >> BIN_SHIFT) == blockIdx.x) atomicAdd(bin_acc + (o.word & (uint32_t)(BIN_WORDS - 1)), (unsigned long long)(((int64_t)o.q1 << 32) + (int64_t)o.q0));
+    }
     __syncthreads();
     const float inv = qs[1];
     for (int e = threadIdx.x; e < BIN_WORDS; e += BIN_THREADS) {
@@ -725,6 +757,7 @@ int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t
 
 // workspace of the binned form: header (64 KB: mass [passes][L], scale [passes][2]) | gcount [nbins + 1] | start [nbins + 1] | cursor [nbins] | wg_hist | records
 constexpr size_t BIN_HDR = 65536;
+constexpr size_t BIN_OVF_BYTES = 256 + ((size_t)BIN_OVF_PER_LEVEL * NRF_MAX_LEVELS * sizeof(BinOvf) + 255) / 256 * 256;      // counter | side list, behind the header
 // n_rays < 0: the worst case (a whole group of 2^18 points per pass); otherwise the pass never holds more than n_rays rays and the record buffer is sized for that
 static void binned_layout(const nrf_hash *h, int s, int64_t n_rays, int64_t *nbins, int64_t *rays_per_group, int64_t *nwg, size_t *off_hist, size_t *off_rec, size_t *total)
 {
@@ -735,11 +768,11 @@ static void binned_layout(const nrf_hash *h, int s, int64_t n_rays, int64_t *nbi
     const int64_t held = (n_rays >= 0 && n_rays < *rays_per_group) ? (n_rays > 0 ? n_rays : 1) : *rays_per_group;      // rays a pass can hold at most
     const int64_t threads = held * ((s + BWD_SEG - 1) / BWD_SEG);
     *nwg = ceil_div(threads, (int64_t)256);
-    size_t o = BIN_HDR + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
+    size_t o = BIN_HDR + BIN_OVF_BYTES + align_up((size_t)(*nbins + 1) * 4, 256) * 2 + align_up((size_t)*nbins * 4, 256);
     *off_hist = o;
     o += align_up((size_t)L * *nwg * BIN_MAX_PER_LEVEL * 4, 256);
     *off_rec = o;
-    o += (size_t)held * s * 8 * L * sizeof(uint4);                     // every sample may flush eight records per level
+    o += (size_t)held * s * 8 * L * sizeof(BinRec);                    // every sample may flush eight records per level
     *total = o;
 }
 
@@ -780,8 +813,10 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     double *mass = reinterpret_cast<double *>(ws);
     float *qs = reinterpret_cast<float *>(ws + (size_t)pass_cap * L * 8);
     const size_t cnt_bytes = align_up((size_t)(nbins + 1) * 4, 256);
-    uint32_t *gcount = reinterpret_cast<uint32_t *>(ws + BIN_HDR), *start = reinterpret_cast<uint32_t *>(ws + BIN_HDR + cnt_bytes), *cursor = reinterpret_cast<uint32_t *>(ws + BIN_HDR + 2 * cnt_bytes);
-    BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<uint4 *>(ws + off_rec)};
+    unsigned char *cb = ws + BIN_HDR + BIN_OVF_BYTES;
+    uint32_t *gcount = reinterpret_cast<uint32_t *>(cb), *start = reinterpret_cast<uint32_t *>(cb + cnt_bytes), *cursor = reinterpret_cast<uint32_t *>(cb + 2 * cnt_bytes);
+    BinSink sink{reinterpret_cast<uint32_t *>(ws + off_hist), gcount, cursor, reinterpret_cast<BinRec *>(ws + off_rec),
+                 reinterpret_cast<uint32_t *>(ws + BIN_HDR), reinterpret_cast<BinOvf *>(ws + BIN_HDR + 256), (uint32_t)(BIN_OVF_PER_LEVEL * L)};
     const int64_t entries = nrf_hash_table_elems(h) / 2;
     const bool ngp = h->desc.mode == NRF_HASH_NGP;
     static PerDeviceOnce attr_set;          // idempotent one-time setup per device (common.h)
@@ -798,7 +833,7 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
             // leaves them zeroed
             const int64_t rays_left = n - r0, passes = ceil_div(rays_left, rays_per_group) < pass_cap ? ceil_div(rays_left, rays_per_group) : pass_cap;
             const int64_t pts_here = (rays_left < passes * rays_per_group ? rays_left : passes * rays_per_group) * s;
-            NRF_HIP(hipMemsetAsync(ws, 0, pass == 0 ? BIN_HDR + cnt_bytes : BIN_HDR, st));
+            NRF_HIP(hipMemsetAsync(ws, 0, pass == 0 ? BIN_HDR + BIN_OVF_BYTES + cnt_bytes : BIN_HDR, st));
             const int64_t blocks = ceil_div(group_pts < pts_here ? group_pts : pts_here, 16);
             hipLaunchKernelGGL(k_level_mass, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)passes), dim3(256), 0, st, pts_here, L, 2, gp, mass, ngp ? pp : (const float *)nullptr,
                                h->params.bbox, (float)h->desc.finest_resolution, group_pts);
@@ -809,10 +844,11 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
         dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)L);
         if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
         else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 1>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, gcount, start, cursor);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(256), 0, st, (int)nbins, gcount, start, cursor, sink.ovf_count);
         if (ngp) hipLaunchKernelGGL((k_hash_bwd_ray<2, false, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
         else hipLaunchKernelGGL((k_hash_bwd_ray<2, true, true, 2>), grid, dim3(256), 0, st, h->params, pp, nr, s, gp, L * 2, d_g_table, qsp, sink);
-        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(BIN_THREADS), lds, st, (const uint32_t *)start, (const uint4 *)sink.rec, qsp, entries, d_g_table);
+        hipLaunchKernelGGL(k_bin_accumulate, dim3((unsigned)nbins), dim3(BIN_THREADS), lds, st, (const uint32_t *)start, (const BinRec *)sink.rec, qsp, entries, d_g_table, (const uint32_t *)sink.ovf_count,
+                           (const BinOvf *)sink.ovf, sink.ovf_cap);
     }
     NRF_LAUNCH_CHECK();
     return NRF_OK;

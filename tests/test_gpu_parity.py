@@ -1793,6 +1793,10 @@ def test_hash_backward_binned_equals_packed_bit_for_bit(api, mode, log2_t):
     pts[20:30] += np.float32(3.0 if mode == "cu" else 2e-3)
     g = (rng.standard_normal((n * s, 32)) * 1e-4).astype(np.float32)
     g[rng.random(n * s) < 0.1] = 0.0
+    # a few samples that dominate their pass (one in each of the three passes): their fixed-point addends exceed the 25-bit fields of the 8-byte records and
+    # travel through the side list
+    for row in (100, n * s // 2, n * s - 50):
+        g[row] = rng.choice([-1.0, 1.0], 32).astype(np.float32) * np.float32(20.0)
     dp, dg = dev(pts.reshape(-1, 3)), dev(g)
     lib = api.L.lib()
     base = (rng.standard_normal(e.table_elems()) * 1e-3).astype(np.float32)
@@ -1810,6 +1814,8 @@ def test_hash_backward_binned_equals_packed_bit_for_bit(api, mode, log2_t):
     a, b = host(gt_b), host(gt_q)
     assert np.abs(b - base).max() > 0
     assert_exact(a, b, f"{mode} T=2^{log2_t}: binned table gradient == packed-atomic table gradient")
+    side = int(host(wsb[65536:65540]).view(np.uint32)[0])       # entries of the LAST pass's side list (the workspace keeps the counter behind its 64-KB header)
+    assert 0 < side <= 128 * 16, f"{mode}: the dominating sample's addends went through the side list ({side} entries)"
     # a workspace sized for THIS batch (records for n rays instead of a whole 2^18-point pass) serves the same call
     lib.nrf_hash_backward_binned_workspace_bytes_for.restype = C.c_size_t
     nbf = lib.nrf_hash_backward_binned_workspace_bytes_for(e._h, C.c_int64(n), s)
