@@ -526,12 +526,12 @@ NRF_API int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_
 NRF_API size_t nrf_hash_backward_packed_workspace_bytes(const nrf_hash *h);
 NRF_API int nrf_hash_backward_rays_packed(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table,
                                           void *d_workspace, size_t workspace_bytes, void *stream);
-/* The same gradient with the contributions MERGED before they reach memory: records {word, fixed-point fields} are binned by ranges of 2^14 table words
+/* The same gradient with the contributions MERGED before they reach memory: 8-byte records {word in bin, two 25-bit fixed-point fields} are binned by ranges of 2^14 table words
  * (count pass, scan, emit pass), each bin is summed in one workgroup's LDS and added to d_g_table without atomics.  Same groups, same scale, integer sums:
  * the result equals nrf_hash_backward_rays_packed bit for bit.  log2_hashmap_size <= 19.  Workspace: nrf_hash_backward_binned_workspace_bytes(h, s)
- * (~0.5 GB at s = 192: 2^18 points x 8 corners x levels x 16 bytes), 256-byte aligned. */
+ * (~0.27 GB at s = 192: 2^18 points x 8 corners x levels x 8 bytes), 256-byte aligned. */
 NRF_API size_t nrf_hash_backward_binned_workspace_bytes(const nrf_hash *h, int s);
-/* ... for batches of at most n rays: the record buffer (16 B x 8 corners x levels per sample) is sized for min(n, one 2^18-point pass) instead of the whole pass */
+/* ... for batches of at most n rays: the record buffer (8 B x 8 corners x levels per sample) is sized for min(n, one 2^18-point pass) instead of the whole pass */
 NRF_API size_t nrf_hash_backward_binned_workspace_bytes_for(const nrf_hash *h, int64_t n, int s);
 NRF_API int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t n, int s, const float *d_g_emb, float *d_g_table,
                                           void *d_workspace, size_t workspace_bytes, void *stream);

@@ -229,6 +229,8 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 #endif
 constexpr int BWD_SEG = NRF_BWD_SEG;
 // training step of 16 384 rays x 192 samples, same call, alternating builds (profiles/round4/r5a_*): 2^16 10.3 ms, 2^17 8.1-8.9, 2^18 7.84, 2^19 8.04, 2^20 8.6, 2^22 9.25
+// ... and with the 8-byte records of the binned form (r5n_*): 2^17 6.4 ms, 2^18 5.93, 2^19 6.2, 2^20 6.75 -- a pass of 2^18 points emits ~130 MB of records, which the 256-MB
+// Infinity Cache still holds between the emit pass and k_bin_accumulate
 #ifndef NRF_PACKED_GROUP_LOG2
 #define NRF_PACKED_GROUP_LOG2 18
 #endif
