@@ -367,6 +367,8 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
             }
         }
     };
+    // (requesting the segment's 16 gradients and points up front instead of where they are used -- 5 registers per sample, the loop unrolled -- was slower: training step
+    // 6.33-6.45 against 6.04 ms, same call, profiles/round4/r5q_*)
     for (int j = j0; j < j1; j++) {
         const int64_t i = ray * s + j;
         float g[F];
