@@ -211,7 +211,7 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const uint32_t hx = (pos[0] + ((k >> 2) & 1)) * pa, hy = (pos[1] + ((k >> 1) & 1)) * pb, hz = (pos[2] + (k & 1)) * pc;
-        const uint32_t ps = (hx ^ hy ^ hz) % lsz;
+        const uint32_t ps = ((lsz & (lsz - 1u)) == 0u) ? ((hx ^ hy ^ hz) & (lsz - 1u)) : ((hx ^ hy ^ hz) % lsz);       // local_size is a power of two for T >= 4
         const float w = ((k & 4) ? a : 1.0f - a) * ((k & 2) ? b : 1.0f - b) * ((k & 1) ? c : 1.0f - c);
 #pragma unroll
         for (int f = 0; f < F; f++) unsafeAtomicAdd(tl + (size_t)ps * F + f, __half2float(__float2half_rn(g[f] * w)) * (1.0f / 128.0f));
@@ -334,13 +334,17 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
         tl = g_table + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
         hmask = (1u << hp.log2_t) - 1u;
     }
+    const bool lsz_pow2 = (lsz & (lsz - 1u)) == 0u;
     float qscale = 1.0f;
     if constexpr (Q) qscale = qscale_p[0];
     auto flush = [&]() {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t cx = cur[0] + ((k >> 2) & 1), cy = cur[1] + ((k >> 1) & 1), cz = cur[2] + (k & 1);
-            const uint32_t row = CU ? (((cx * pa) ^ (cy * pb) ^ (cz * pc)) % lsz) : ((cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask);
+            // `% local_size` (CuHashEmbedder.cu:70-77): local_size = (2^T >> 4) << 4 is a power of two for every T >= 4 (wave-uniform test, as cu_blend in encode.h):
+            // the general 32-bit modulo is ~30 vector instructions, eight times per flush
+            const uint32_t hv = (cx * pa) ^ (cy * pb) ^ (cz * pc);
+            const uint32_t row = CU ? (lsz_pow2 ? (hv & (lsz - 1u)) : (hv % lsz)) : ((cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask);
             if constexpr (Q) {
                 static_assert(!Q || F == 2, "packed atomics carry exactly two features");
                 const int32_t q0 = __float2int_rn(acc[k][0] * qscale), q1 = __float2int_rn(acc[k][F - 1] * qscale);
