@@ -50,8 +50,11 @@ def main():
                     help="torch.distributed backend; gloo lets N ranks SHARE one GPU (a rehearsal of the N > 1 code path on a one-GPU box: RCCL refuses two ranks on a device)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="strong (default at N > 1, BASELINE config 4): ONE frame per step split over the N ranks; weak: N frames per step, every GPU traces a whole frame's worth of rays")
-    ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
-                    help="the per-step all-gather: torch.distributed (RCCL through PyTorch) or nrf_allgather_tiles (RCCL behind the C ABI, what a C++ host calls)")
+    ap.add_argument("--collective", default=None, choices=["torch", "cabi"],
+                    help="the per-step all-gather: nrf_allgather_tiles (RCCL behind the C ABI, what a C++ host calls; default with --backend nccl, falls back to torch loudly if "
+                         "its communicator cannot be created) or torch.distributed (RCCL through PyTorch; the only one with --backend gloo)")
+    ap.add_argument("--lanes", default="auto", choices=["auto", "1", "2", "3", "4"],
+                    help="streams of the library's Chunk loop (nrf_set_render_lanes); auto: 1 against 2 measured before the warmup steps, the faster one is timed (NRF_RENDER_LANES pins it)")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
     ap.add_argument("--kernel-stats", default="profiles/round4/r4_single_lane_kernel_stats.csv",
                     help="named in roofline.kernel_stats: the committed rocprofv3 --kernel-trace --stats summary of the single-lane pass the roofline re-derives from")
@@ -61,6 +64,8 @@ def main():
         args.precision = "f16x3"
     if args.backend == "gloo" and args.collective == "cabi":
         sys.exit("--collective cabi is RCCL: one rank per GPU (--backend nccl)")
+    if args.collective is None:
+        args.collective = "cabi" if args.backend == "nccl" else "torch"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         from benchlib.launch import spawn_ranks
         sys.exit(spawn_ranks(args.gpus, os.path.abspath(__file__)))                 # plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
@@ -93,8 +98,7 @@ def main():
     if use_dist and args.backend != "nccl" and world > 1:
         # a rehearsal: the ranks SHARE one GPU.  Two processes with two lanes each is four streams' worth of kernels time-sliced between two contexts (102 ms per step
         # against 29 with one lane per process): one lane per process there
-        L.check(L.lib().nrf_set_render_lanes(1))
-        os.environ["NRF_RENDER_LANES"] = "1"
+        args.lanes = "1"
 
     prec = {"f16": L.NRF_PREC_F16_MFMA, "f16x3": L.NRF_PREC_F16_SPLIT, "f32": L.NRF_PREC_F32}[args.precision]
     if args.workload == "hash":
@@ -111,7 +115,27 @@ def main():
     rp = scene.lego_render_params(sc["bbox"], NS, NI, chunk, prec)
     K = scene.lego_K(H, W)
     shard = TileShard(H, W, rank, world, force_collective=args.force_dist)
-    comm = TileComm(rank, world) if (use_dist and args.collective == "cabi") else None
+    from benchlib.steps import FrameStepper
+    # the per-step all-gather: by default the one a C++ host calls -- nrf_allgather_tiles, RCCL behind the C ABI.  If its communicator cannot be created on ANY rank, all
+    # ranks fall back (in this process, loudly) to torch.distributed's RCCL; the line says which one was timed
+    comm = None
+    collective_note = None
+    if use_dist and args.collective == "cabi":
+        err = ""
+        try:
+            comm = TileComm(rank, world, timeout_s=120.0)
+        except Exception as e:
+            err = str(e)
+        ok = torch.tensor([0.0 if comm is None else 1.0], device="cuda")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() != 1.0:
+            print(f"[bench] rank {rank}: nrf_comm_create failed on some rank ({err or 'a peer'}): FALLING BACK to torch.distributed all_gather_into_tensor", file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm = None
+            args.collective = "torch"
+            collective_note = "cabi requested, nrf_comm_create failed: torch.distributed timed instead" + (f" ({err[:80]})" if err else "")
     import ctypes as C
     NPROF = len(L.NRF_PROF_NAMES)
 
@@ -121,6 +145,19 @@ def main():
         torch.cuda.synchronize()
 
     settled = [False]
+    from benchlib import timing
+    lib = L.lib()
+    dist_dev = "cuda" if args.backend == "nccl" else "cpu"
+
+    def agree_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], device=dist_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def set_lanes(n):
+        L.check(lib.nrf_set_render_lanes(int(n)))
 
     def settle(step, drain, budget_s=10.0, floor_s=1.5):
         """Before the first measurement of the process, outside every timed region and before the W warmup steps: whole steps, each synchronised, until three in a
@@ -140,86 +177,76 @@ def main():
             el = time.perf_counter() - t_begin
             stop = 1.0 if ((good >= 3 and el >= floor_s) or el >= budget_s) else 0.0
             if use_dist:
-                t = torch.tensor([stop], device="cuda" if args.backend == "nccl" else "cpu")
+                t = torch.tensor([stop], device=dist_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)          # all ranks stop together (each step holds a collective)
                 stop = float(t.item())                            # every rank's own clock passes the budget, so the minimum becomes 1 on all of them in the same iteration
             if stop:
                 break
 
-    def timed_run(scaling, steps, warmup, profile=False):
-        """W untimed + K timed steps of `scaling`; returns (seconds = max over ranks, frames of the last step, poses, host seconds this rank spent inside Render
-        calls, per-kernel HIP-event totals)."""
-        # frames of one step: poses on the reference's test orbit (pose_spherical(theta, -30, 4), theta step 9 degrees); strong scaling: one frame
-        nfr = 1 if scaling == "strong" else world
-        poses_ = [scene.pose_spherical(-180.0 + 9.0 * k, -30.0, 4.0) for k in range(nfr)]
-        host = [0.0]
+    def make_steps(scaling):
+        """The step of `scaling` (benchlib/steps.py) -> (step, drain, poses, the list of host seconds this rank spent inside each Render call, render_tiles)."""
+        # (overlap with RCCL only: gloo moves the tiles through the host on a helper thread and is slower issued that way -- 38.8 vs 29.4 ms per step in the 2-rank rehearsal)
+        fs = FrameStepper(renderer, rp, K, H, W, shard, scaling, world, comm=comm, overlap=args.backend == "nccl")
+        return fs.step, fs.drain, fs.poses, fs.host, fs.render_tiles
 
-        def render_tiles():
-            t_h = time.perf_counter()
-            tiles = [renderer.Render(H, W, K, rp, c2w=c2w, row0=shard.row0, rows=shard.rows).Outputs.RGBMap for c2w in poses_]   # one nrf_render_rows call each
-            host[0] += time.perf_counter() - t_h
-            return tiles
+    lanes_info = dict(requested=args.lanes, chosen=None, ms_per_step_by_lanes=None)
 
-        pending = [None]
-
-        def step():
-            # the all-gather of step k is issued asynchronously and completed (stream order, no host wait) at step k + 1: the next frame's kernels are not held behind
-            # a latency-bound collective -- what a renderer of consecutive frames does
-            # (RCCL only: gloo moves the tiles through the host on a helper thread and is slower issued that way -- 38.8 vs 29.4 ms per step in the 2-rank rehearsal)
-            tiles = render_tiles()
-            ov = args.backend == "nccl"
-            if comm is not None:
-                out, work = comm.all_gather_frames(torch.stack([t.reshape(shard.rows, W, 3) for t in tiles], 0), H, overlap=True)
-            elif ov:
-                out, work = shard.all_gather_frames(tiles, overlap=True)     # [frames, H, W, 3] on every rank; identity at N = 1
-            else:
-                out, work = shard.all_gather_frames(tiles), None
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = work
-            return out
-
-        def drain():
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
-
+    def timed_run(scaling, steps, warmup, pick_lanes=False):
+        """W untimed + K timed steps of `scaling`, the library's per-kernel event bracketing OFF (benchlib/timing.py refuses otherwise); returns (seconds = max over
+        ranks, frames of the last step, poses, host seconds this rank spent inside Render calls, render_tiles)."""
+        step, drain, poses_, host, render_tiles = make_steps(scaling)
         settle(step, drain)
+        if pick_lanes and lanes_info["chosen"] is None:
+            if args.lanes == "auto":
+                # 1 lane against 2, measured here: on some boxes the second lane costs more than it hides (round 4's driver box: the two-lane default was slower than one lane)
+                win, by = timing.choose_lanes(lib, set_lanes, step, drain, sync, agree_max)
+                lanes_info.update(chosen=win, ms_per_step_by_lanes={str(k): round(v, 3) for k, v in by.items()})
+            else:
+                set_lanes(int(args.lanes))
+                lanes_info.update(chosen=int(args.lanes))
         for _ in range(warmup):
             step()
         drain()
-        ms = (C.c_double * NPROF)(); cnt = (C.c_int64 * NPROF)()
-        if profile:
-            L.lib().nrf_profile_enable(1)
-            L.lib().nrf_profile_read(ms, cnt, 1)
-        host[0] = 0.0
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            frames_ = step()
-        drain()                                   # the last frame's collective, inside the timed region
-        sync()
-        dt = time.perf_counter() - t0
-        if profile:
-            L.lib().nrf_profile_read(ms, cnt, 1)
-            L.lib().nrf_profile_enable(0)
-        if use_dist:
-            t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, frames_, poses_, host[0], (ms, cnt), render_tiles
+        del host[:]
+        dt, frames_ = timing.timed_region(lib, step, drain, sync, steps)
+        return agree_max(dt), frames_, poses_, list(host), render_tiles
 
-    elapsed, frames, poses, host_s, (ms, cnt), render_tiles = timed_run(args.scaling, args.steps, args.warmup, profile=True)
+    def profiled_pass(scaling, steps, lanes):
+        """A short pass with the per-kernel event bracketing ON (never part of `value`): per-kernel HIP-event totals on the launch streams with `lanes` lanes."""
+        set_lanes(lanes)
+        step, drain, _, _, _ = make_steps(scaling)
+        step(); drain(); sync()
+        ms = (C.c_double * NPROF)(); cnt = (C.c_int64 * NPROF)()
+        lib.nrf_profile_enable(1)
+        lib.nrf_profile_read(ms, cnt, 1)
+        try:
+            sync(); t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            drain(); sync()
+            dt = time.perf_counter() - t0
+            lib.nrf_profile_read(ms, cnt, 1)
+        finally:
+            lib.nrf_profile_enable(0)
+            set_lanes(lanes_info["chosen"] or 2)
+        return dict(dt=agree_max(dt), ms=ms, cnt=cnt, steps=steps, lanes=lanes)
+
+    forced_env = os.environ.get("NRF_RENDER_LANES")
+    if forced_env and args.lanes == "auto":
+        args.lanes = forced_env                  # profiling scripts pin the lane count through the environment
+        lanes_info["requested"] = "env:" + forced_env
+    elapsed, frames, poses, host_s, render_tiles = timed_run(args.scaling, args.steps, args.warmup, pick_lanes=True)
+    lanes_timed = lanes_info["chosen"] or lib.nrf_get_render_lanes()
     nframes = len(poses)
     # at N > 1 the other scaling mode rides along in `also` (every rank takes part; fewer steps)
     other = None
     if world > 1 and not args.no_also:
         o_scaling = "weak" if args.scaling == "strong" else "strong"
         o_steps = max(2, args.steps // 2)
-        o_dt, o_frames, o_poses, o_host, _, _ = timed_run(o_scaling, o_steps, 1)
+        o_dt, o_frames, o_poses, o_host, _ = timed_run(o_scaling, o_steps, 1)
         other = dict(scaling=o_scaling, frames_per_step=len(o_poses), steps=o_steps, ms_per_step=o_dt / o_steps * 1e3,
                      value=len(o_poses) * H * W * UNITS_PER_RAY * o_steps / o_dt, unit="ray-samples/s",
-                     host_ms_per_tile=o_host / o_steps / len(o_poses) * 1e3, finite=bool(torch.isfinite(o_frames).all()))
+                     host_ms_per_tile=timing.median(o_host) * 1e3, finite=bool(torch.isfinite(o_frames).all()))
     # untimed cross-check of the other collective implementation on the same tiles (N > 1: the C-ABI all-gather a C++ host calls vs torch.distributed's).
     # It runs on a helper thread with a deadline so that nothing it does can cost the run its result line.
     collective_check = None
@@ -248,14 +275,14 @@ def main():
         collective_check = box.get("r", "nrf_allgather_tiles cross-check did not finish within 90 s")
         stuck = th.is_alive()                                        # a stuck collective: report what was timed and leave without tearing the group down
 
-    # rooflines of the kernels one at a time: a short single-lane pass (every rank takes part), see `roofline.isolated`
-    isolated = None
-    if not args.no_isolated and not stuck and os.environ.get("NRF_RENDER_LANES", "2") != "1":
-        L.check(L.lib().nrf_set_render_lanes(1))
+    # per-kernel times, never from the timed region: a short SINGLE-LANE pass with the event bracketing on (each kernel has the GPU to itself: `roofline`), and, when
+    # the timed region ran on more lanes, a short pass on that many (the same kernels sharing the CUs: context)
+    isolated = shared = None
+    if not args.no_isolated and not stuck:
         i_steps = max(3, min(5, args.steps))
-        i_dt, _, _, _, (i_ms, i_cnt), _ = timed_run(args.scaling, i_steps, 1, profile=True)
-        L.check(L.lib().nrf_set_render_lanes(2))
-        isolated = dict(dt=i_dt, ms=i_ms, cnt=i_cnt, steps=i_steps)
+        isolated = profiled_pass(args.scaling, i_steps, 1)
+        if lanes_timed > 1:
+            shared = profiled_pass(args.scaling, i_steps, lanes_timed)
     units_per_step = nframes * H * W * UNITS_PER_RAY          # over all ranks
     value = units_per_step * args.steps / elapsed
 
@@ -269,16 +296,22 @@ def main():
     if rank == 0:
         from benchlib import extras, roofline as RF
         units_rank = units_per_step / world                                                 # this rank's ray-samples per step
-        timed = RF.kernel_rooflines(RF.prof_table(ms, cnt, L.NRF_PROF_NAMES), args.workload, args.precision, args.hash_mode, units_rank * args.steps)
-        roof = dict(timed=timed, lanes_timed=int(os.environ.get("NRF_RENDER_LANES", "2")), kernel_ms_timed=RF.prof_table(ms, cnt, L.NRF_PROF_NAMES))
+        roof = dict(lanes_timed=lanes_timed, lanes=lanes_info, profile_events_in_timed_region=False)
+        if shared is not None:
+            # the kernels' launch times with the timed region's lane count (they share the CUs there), from a separate profiled pass
+            sprof = RF.prof_table(shared["ms"], shared["cnt"], L.NRF_PROF_NAMES)
+            roof["timed"] = RF.kernel_rooflines(sprof, args.workload, args.precision, args.hash_mode, units_rank * shared["steps"])
+            roof["kernel_ms_timed"] = sprof
+            roof["shared_pass_ms_per_step"] = shared["dt"] / shared["steps"] * 1e3
         if isolated is not None:
             # the same quantities with the Chunk loop on ONE stream (a short pass after the timed region): each kernel has the GPU to itself, so launch time is the
-            # kernel's own and the fractions are the kernels' -- in the timed region two chunks' kernels share the CUs.  THIS is the line's top-level roofline.
+            # kernel's own and the fractions are the kernels'.  THIS is the line's top-level roofline.
             iprof = RF.prof_table(isolated["ms"], isolated["cnt"], L.NRF_PROF_NAMES)
             roof["isolated"] = RF.kernel_rooflines(iprof, args.workload, args.precision, args.hash_mode, units_rank * isolated["steps"])
             roof["isolated_kernel_ms"] = iprof
             roof["isolated_steps"] = isolated["steps"]
             roof["isolated_ms_per_step"] = isolated["dt"] / isolated["steps"] * 1e3
+            roof["isolated_kernel_sum_ms_per_step"] = sum(v["ms"] for v in iprof.values()) / isolated["steps"]
         enc = ("CuHashEmbedder" if args.hash_mode == "cu" else "HashEmbedder") + " L16 T2^19 F2 16..512 + " + ("CuSHEncoder" if args.hash_mode == "cu" else "SHEncoder") + " deg4 + NeRFSmall 3x64/4x64"
         detail = {
             "metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)",
@@ -288,7 +321,8 @@ def main():
             "dtype": {"f16": "f16", "f16x3": "f16x3", "f32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("hashnerf_lego800_64+128" if args.workload == "hash" else "classic_nerf_lego800_64+128"),
-                       "baseline_config": (2 if args.workload == "hash" else 1),
+                       # 1-based, as BASELINE.md / SURVEY section 8 / DESIGN count them: 2 = classic 800x800 64+128, 3 = HashNeRF on one GPU, 4 = HashNeRF sharded over N GPUs, 5 = LeRF
+                       "baseline_config": ((4 if world > 1 else 3) if args.workload == "hash" else 2),
                        "encoder": enc if args.workload == "hash" else "PE(10)/PE(4) + NeRF 8x256 skip4 viewdirs",
                        # CuHashEmbedder / CuSHEncoder are CUDA-only units: their oracle is a line-by-line restatement pinned by known answers, not by a reference run
                        # (DESIGN.md section 2); the reference-pinned LibTorch twin of the same configuration rides in `also`
@@ -301,9 +335,12 @@ def main():
             "executed_evaluations_per_ray": dict(zip(("hash_encode", "fused_mlp", "sigma_only"), executed_per_ray(args.workload, args.precision, args.hash_mode)),
                                                  colour_net_only=colour_only_per_ray(args.workload, args.precision)),
             "rays_per_s": value / UNITS_PER_RAY, "s_per_frame": elapsed / args.steps / nframes * (world if args.scaling == "weak" else 1),
-            # wall time rank 0 spent INSIDE Render per tile (one nrf_render_rows call: ~25 asynchronous launches): the unsharded work that bounds strong scaling
-            "host_ms_per_tile": host_s / args.steps / nframes * 1e3, "tile_rows": shard.rows,
+            # wall time rank 0 spent INSIDE Render per tile (one nrf_render_rows call: ~110 asynchronous launches): the unsharded work that bounds strong scaling.
+            # MEDIAN over the timed region's calls: the launch work itself (0.4-0.5 ms on an idle queue, tools/scratch/host_time_probe.py).  The mean also holds the calls in
+            # which the host, frames ahead of the device, waits for queue space (the device is busy then: not a cost)
+            "host_ms_per_tile": timing.median(host_s) * 1e3, "host_ms_per_tile_mean": sum(host_s) / max(len(host_s), 1) * 1e3, "tile_rows": shard.rows,
             "roofline": roof, "ranks_seen_by_rccl": ranks_seen,
+            "collective": (("nrf_allgather_tiles (C ABI)" if comm is not None else "torch.distributed") + (": " + collective_note if collective_note else "")) if use_dist else None,
         }
         if other is not None:
             detail["also"] = [other]

@@ -27,6 +27,7 @@ def colour_only_per_ray(workload, precision):
 
 # algorithmic cost per ray-sample (SURVEY.md section 8d / BASELINE.md section 2)
 HASH_BYTES_PER_UNIT = 16 * 8 * 2 * 2 + 12 + 64      # table gathers + point in + fp16 features out (standalone encode kernel)
+HASH_GATHER_BYTES_PER_UNIT = 16 * 8 * 2 * 2         # the table gathers alone: 8 corners x F = 2 fp16 on each of 16 levels
 SMALL_FLOP_PER_UNIT = 35072
 SMALL_COLOUR_FLOP_PER_UNIT = 2 * ((16 + 15) * 64 + 64 * 64 + 64 * 64 + 64 * 3)      # the colour net alone (NeRF.cpp:383-406): 20 736
 SMALL_COLOUR_MFMA_FLOP_PER_UNIT = 72 * 32768 // 32                                   # its 72 of the split kernel's 116 matrix instructions per 32 points

@@ -34,7 +34,7 @@ def cpu_baseline(workload, seconds_target=12.0):
             probe = sweep[best_t]
             rows = int(max(6, min(96, 6 * seconds_target / max(probe["seconds"], 1e-3))))
             r = run(rows, best_t) if rows > 6 else probe
-            return dict(value=r["units_per_s"], unit="ray-samples/s", cores=r["threads"], kind="reference",
+            return dict(value=r["units_per_s"], unit="ray-samples/s", cores=ncpu, threads=r["threads"], kind="reference",
                         thread_sweep={str(t): round(v["units_per_s"]) for t, v in sweep.items()}, host_cpus=ncpu,
                         sample=f"{r['rays']} rays ({rows} rows of the {H}x{W} frame), {NS}+{NI}, Chunk 4096, reference LibTorch CPU "
                                f"{'Hash+SH+NeRFSmall' if fam == 'hash' else 'PE+NeRF 8x256'}, {r['seconds']:.1f} s, best of 8/16/32/64 threads")
@@ -62,5 +62,5 @@ def cpu_baseline(workload, seconds_target=12.0):
     rows = int(max(6, min(96, 6 * seconds_target / max(t, 1e-3))))
     if rows > 6:
         n, t = run(rows)
-    return dict(value=n * UNITS_PER_RAY / t, unit="ray-samples/s", cores=O.num_threads(), kind="port",
+    return dict(value=n * UNITS_PER_RAY / t, unit="ray-samples/s", cores=os.cpu_count() or O.num_threads(), threads=O.num_threads(), kind="port",
                 sample=f"{n} rays ({rows} rows of the {H}x{W} frame), {NS}+{NI} samples, C oracle with OpenMP, {t:.1f} s")

@@ -17,6 +17,7 @@ def timed_frames(L, render, frames, warm=2, lanes_hook=None):
     """warm untimed + `frames` timed calls of render() -> (seconds per frame, per-kernel HIP-event ms per frame and launches per frame)."""
     import ctypes as C
     import torch
+    assert not L.lib().nrf_profile_is_enabled(), "frame times are taken with the per-kernel event bracketing off"
     for _ in range(warm):
         render()
     torch.cuda.synchronize()
@@ -29,7 +30,8 @@ def timed_frames(L, render, frames, warm=2, lanes_hook=None):
     # above is the default two-lane Chunk loop's
     n = len(L.NRF_PROF_NAMES)
     ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
-    single = os.environ.get("NRF_RENDER_LANES", "2") != "1"
+    prev = L.lib().nrf_get_render_lanes()        # what bench.py measured to be the faster lane count on this box (the frame time above ran with it)
+    single = prev != 1
     if single:
         L.lib().nrf_set_render_lanes(1)
         if lanes_hook:
@@ -39,15 +41,17 @@ def timed_frames(L, render, frames, warm=2, lanes_hook=None):
     torch.cuda.synchronize()
     L.lib().nrf_profile_enable(1)
     L.lib().nrf_profile_read(ms, cnt, 1)
-    for _ in range(frames):
-        out = render()
-    torch.cuda.synchronize()
-    L.lib().nrf_profile_read(ms, cnt, 1)
-    if single:
-        L.lib().nrf_set_render_lanes(2)
-        if lanes_hook:
-            lanes_hook(2)
-    L.lib().nrf_profile_enable(0)
+    try:
+        for _ in range(frames):
+            out = render()
+        torch.cuda.synchronize()
+        L.lib().nrf_profile_read(ms, cnt, 1)
+    finally:
+        L.lib().nrf_profile_enable(0)
+        if single:
+            L.lib().nrf_set_render_lanes(prev)
+            if lanes_hook:
+                lanes_hook(prev)
     return dt, {nm: dict(ms_per_frame=ms[i] / frames, launches_per_frame=cnt[i] / frames) for i, nm in enumerate(L.NRF_PROF_NAMES)}, out
 
 
@@ -75,7 +79,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
             dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), n_fr)
             a2 = argparse.Namespace(**{**vars(args), "workload": wl, "precision": pname, "coarse_full": coarse == "full"})
             ex_hash, ex_mlp, ex_sigma = executed_per_ray(wl, pname, args.hash_mode, coarse_full=(coarse != "exact") if wl == "classic" else False)
-            rec = dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=2 if wl == "hash" else 1,
+            rec = dict(workload="hashnerf_lego800_64+128" if wl == "hash" else "classic_nerf_lego800_64+128", baseline_config=3 if wl == "hash" else 2,
                        precision=pname, value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=n_fr, kernel_ms=kms,
                        **({"coarse_pass": "density branch in exact fp32 on the matrix cores + colour branch on the exact h8 (sigma_nerf_f32.hip): the fp32 path's sample set, outputs reused by the fine pass" if coarse == "exact"
                            else "whole network in the timed arithmetic, outputs reused by the fine pass (NRF_COARSE_FULL)"} if coarse else {}),
@@ -101,7 +105,9 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
                 hk = kms["hash"]
                 rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode", unit="GB/s", peak=HBM_PEAK / 1e9,
                                                achieved=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / 1e9,
-                                               frac=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / HBM_PEAK)
+                                               frac=None,           # no counter pass for this secondary line: the fraction of the HBM peak is a counter figure (benchlib/roofline.py)
+                                               algorithmic_over_hbm_peak=H * W * ex_hash * HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / HBM_PEAK,
+                                               gather_frac_of_cache_ceiling=H * W * ex_hash * HASH_GATHER_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12) / GATHER_PEAK)
             rec["psnr_vs_oracle_db"] = quality_check(sc, sc["renderer"], rp, K, c2w, a2)
             out.append(rec)
         except Exception as e:
@@ -114,7 +120,7 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
             rp = scene.lego_render_params(sc["bbox"], NS, NI, 65536, L.NRF_PREC_F16_SPLIT)
             dt, kms, _ = timed_frames(L, lambda: sc["renderer"].Render(H, W, K, rp, c2w=c2w), steps)
             a2 = argparse.Namespace(**{**vars(args), "workload": "hash", "precision": "f16x3", "hash_mode": "ngp"})
-            out.append(dict(workload="hashnerf_lego800_64+128", baseline_config=2, encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3",
+            out.append(dict(workload="hashnerf_lego800_64+128", baseline_config=3, encoder="HashEmbedder + SHEncoder (LibTorch twin)", precision="f16x3",
                             value=H * W * UNITS_PER_RAY / dt, unit="ray-samples/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=kms,
                             psnr_vs_oracle_db=quality_check(sc, sc["renderer"], rp, K, c2w, a2)))
             del sc
@@ -229,7 +235,7 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
                                                        sk["launches_per_frame"], peak=F32_PEAK)
     if hk["launches_per_frame"]:
         b = units * LERF_HASH_BYTES_PER_UNIT / max(hk["ms_per_frame"] * 1e-3, 1e-12)
-        rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode F=8 (k_hash_cu, level-major fp16 out)", unit="GB/s", achieved=b / 1e9, peak=HBM_PEAK / 1e9, frac=b / HBM_PEAK,
+        rec["roofline"]["hash"] = dict(bound="hbm", kernel="hash_encode F=8 (k_hash_cu, level-major fp16 out)", unit="GB/s", achieved=b / 1e9, peak=HBM_PEAK / 1e9, frac=None, algorithmic_over_hbm_peak=b / HBM_PEAK,
                                        frac_of_infinity_cache_gather_rate=b / GATHER_PEAK, bytes_per_unit=LERF_HASH_BYTES_PER_UNIT, units_per_frame=units,
                                        note="the 134 MB hashed table is Infinity-Cache resident: the gather path's ceiling for such tables is 8.6 TB/s (MI355X_MICROARCH.md)")
     try:
@@ -282,7 +288,7 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
         try:
             outp = subprocess.run([drv, "bench_train", "1024", str(NS), str(NI), "4096", "1"], capture_output=True, text=True, timeout=600)
             r = json.loads(outp.stdout.strip().splitlines()[-1])
-            rec["cpu_reference"] = dict(rays_per_s=r["rays_per_s"], value=r["units_per_s"], unit="ray-samples/s", cores=r["threads"], kind="reference",
+            rec["cpu_reference"] = dict(rays_per_s=r["rays_per_s"], value=r["units_per_s"], unit="ray-samples/s", cores=os.cpu_count() or r["threads"], threads=r["threads"], kind="reference",
                                         sample=f"{r['rays']} rays per step, LibTorch CPU HashEmbedder+SHEncoder+NeRFSmall forward+backward+Adam, {r['seconds']:.1f} s per step")
         except Exception as e:
             rec["cpu_reference"] = f"unavailable: {e}"

@@ -52,7 +52,8 @@ def compact_roofline(detail_roof, stats_csv=None):
         out["kernel_stats"] = stats_csv
     for sib in names[1:]:
         s = src[sib]
-        out[sib] = {k: _r(s[k]) for k in ("kernel", "frac", "achieved", "unit", "avg_launch_ms", "launches", "units_per_launch", "hbm_frac", "traffic") if s.get(k) is not None}
+        out[sib] = {k: _r(s[k]) for k in ("kernel", "frac", "achieved", "unit", "avg_launch_ms", "launches", "units_per_launch", "traffic", "gather_frac_of_cache_ceiling",
+                                          "valu_issue_frac") if s.get(k) is not None}
         if isinstance(out[sib].get("kernel"), str):
             out[sib]["kernel"] = out[sib]["kernel"].split(" (")[0]
     if isinstance(dom.get("colour_only"), dict):
@@ -60,8 +61,10 @@ def compact_roofline(detail_roof, stats_csv=None):
         out["colour_only"] = {k: _r(c[k]) for k in ("frac", "avg_launch_ms", "launches", "units_per_launch", "flop_per_unit") if c.get(k) is not None}
     t = detail_roof.get("timed") or {}
     if detail_roof.get("isolated") and t:
-        # the same kernels' launch times inside the two-lane timed region (they share the CUs there): context, not a roofline
-        out["timed_two_lane_avg_launch_ms"] = {n: _r(r.get("avg_launch_ms")) for n, r in t.items()}
+        # the same kernels' launch times with the timed region's lane count (they share the CUs there; a separate profiled pass): context, not a roofline
+        out["shared_lanes_avg_launch_ms"] = {n: _r(r.get("avg_launch_ms")) for n, r in t.items()}
+    if detail_roof.get("isolated_kernel_sum_ms_per_step") is not None:
+        out["kernel_sum_ms_per_step"] = _r(detail_roof["isolated_kernel_sum_ms_per_step"])       # the single-lane pass: sum of the bracketed kernels' times per step
     return out
 
 
@@ -104,7 +107,9 @@ def compact_line(detail, stats_csv=None):
     line["roofline"] = compact_roofline(detail.get("roofline") or {}, stats_csv)
     cb = detail.get("cpu_baseline")
     if isinstance(cb, dict):
-        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": str(cb.get("sample", ""))[:160]}
+        # cores: the host cores of the box; threads: the LibTorch intra-op thread count that won the sweep and rendered the timed sample
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "threads": cb.get("threads", cb["cores"]), "kind": cb["kind"],
+                                "sample": str(cb.get("sample", ""))[:160]}
     line["psnr_vs_oracle_db"] = _psnr(detail.get("psnr_vs_oracle_db"))
     pf = detail.get("parity_full_frame_vs_f32")
     if isinstance(pf, dict):
@@ -113,8 +118,17 @@ def compact_line(detail, stats_csv=None):
     line["rays_per_s"] = _r(detail.get("rays_per_s"))
     line["tile_rows"] = detail.get("tile_rows")
     line["host_ms_per_tile"] = _r(detail.get("host_ms_per_tile"))
+    lanes = (detail.get("roofline") or {}).get("lanes")
+    if isinstance(lanes, dict):
+        # lanes of the library's Chunk loop in the timed region: measured 1 against 2 on this box before the warmup steps ("auto"), the faster one is timed
+        line["lanes_timed"] = lanes.get("chosen")
+        if lanes.get("ms_per_step_by_lanes"):
+            line["ms_per_step_by_lanes"] = lanes["ms_per_step_by_lanes"]
+    line["profile_events_in_timed_region"] = bool((detail.get("roofline") or {}).get("profile_events_in_timed_region", False))
     if detail.get("ranks_seen_by_rccl") is not None:
         line["ranks_seen_by_rccl"] = detail["ranks_seen_by_rccl"]
+    if detail.get("collective"):
+        line["collective"] = str(detail["collective"])[:120]
     if detail.get("collective_check"):
         line["collective_check"] = str(detail["collective_check"])[:100]
     if detail.get("also"):

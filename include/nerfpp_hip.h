@@ -566,6 +566,7 @@ NRF_API int nrf_render_view_dims(int h, int w, const float *K, float render_fact
  * read-only; per-tile pixels return to every rank with ONE RCCL collective per step over xGMI (north_star).  The reference
  * is single-GPU (no counterpart).  RCCL is resolved with dlopen at first use -- the copy already mapped into the process (LibTorch's)
  * if there is one -- so this library has no link-time RCCL dependency; without RCCL the nrf_comm_* calls return NRF_ERR_UNSUPPORTED.
+ * NRF_RCCL_LIBRARY=<path> in the environment names the copy to use instead (a host that maps several; the tests' threads-as-ranks stand-in).
  * ------------------------------------------------------------------------------------------- */
 /* Rank `rank` of `world` renders image rows [row0, row0 + rows): contiguous, the first h % world ranks one row taller.  Host only. */
 NRF_API int nrf_tile_partition(int h, int world, int rank, int *row0, int *rows);
@@ -655,6 +656,10 @@ NRF_API int nrf_get_render_lanes(void);
 /* ... per renderer: 1-4 lanes for this renderer's calls whatever the process-wide setting; 0 returns it to that setting (two renderers of one process need not share it). */
 NRF_API int nrf_renderer_set_lanes(nrf_renderer *r, int lanes);
 NRF_API int nrf_profile_enable(int on);
+/* 1 while the event bracketing is on.  A throughput measurement must run with it off: an event pair around every kernel of every lane costs host time per launch and
+ * separates the kernels on the device (bench.py asserts 0 before its timed region; the per-kernel times come from a separate pass).  Events are pooled: none is created on
+ * a launch path after the first profiled frame. */
+NRF_API int nrf_profile_is_enabled(void);
 NRF_API int nrf_profile_read(double *ms /*[NRF_PROF_COUNT]*/, int64_t *launches /*[NRF_PROF_COUNT]*/, int reset);
 
 #ifdef __cplusplus

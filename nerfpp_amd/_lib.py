@@ -85,7 +85,7 @@ SYMBOLS = [
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_create_timeout", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",
-    "nrf_profile_enable", "nrf_profile_read", "nrf_set_render_lanes", "nrf_get_render_lanes", "nrf_renderer_set_lanes", "nrf_lerf_renderer_set_lanes",
+    "nrf_profile_enable", "nrf_profile_is_enabled", "nrf_profile_read", "nrf_set_render_lanes", "nrf_get_render_lanes", "nrf_renderer_set_lanes", "nrf_lerf_renderer_set_lanes",
     "nrf_lerf_relevancy", "nrf_relevancy_image", "nrf_colormap_jet_u8", "nrf_colormap_jet_lut",
     "nrf_lerf_renderer_create", "nrf_lerf_renderer_destroy", "nrf_lerf_set_prompts", "nrf_lerf_render_rays_workspace_bytes", "nrf_lerf_render_rays",
     "nrf_lerf_batchify_rays_workspace_bytes", "nrf_lerf_batchify_rays", "nrf_lerf_render_rows_workspace_bytes", "nrf_lerf_render_rows",

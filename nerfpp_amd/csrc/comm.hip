@@ -53,6 +53,11 @@ static void rccl_load()
 {
     const char *names[] = {"librccl.so.1", "librccl.so"};
     void *h = nullptr;
+    // NRF_RCCL_LIBRARY: the host names the RCCL copy to use (a process that maps several; tests: the threads-as-ranks stand-in beside torch's own RCCL)
+    if (const char *forced = getenv("NRF_RCCL_LIBRARY")) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { snprintf(g_rccl_err, sizeof(g_rccl_err), "NRF_RCCL_LIBRARY=%s: %s", forced, dlerror()); return; }
+    }
     for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the host process already uses
     for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

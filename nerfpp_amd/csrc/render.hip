@@ -56,17 +56,35 @@ void set_error(const char *fmt, ...)
 // ---------------------------------------------------------------------------------------------------
 // profiling: HIP events around the dominant kernels, recorded on the caller's stream
 // ---------------------------------------------------------------------------------------------------
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;
 struct ProfRec { int slot; hipEvent_t e0, e1; };
 static std::vector<ProfRec> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;          // timing events are created once and recycled by nrf_profile_read: no hipEventCreate on a launch path
 static double g_prof_ms[NRF_PROF_COUNT];
 static int64_t g_prof_n[NRF_PROF_COUNT];
 
-ProfScope::ProfScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_), active(g_prof_on)
+static hipEvent_t prof_event()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+
+ProfScope::ProfScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_), active(g_prof_on.load(std::memory_order_relaxed))
 {
     if (!active) return;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { active = false; return; }
+    e0 = prof_event(); e1 = prof_event();
+    if (!e0 || !e1) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (e0) g_prof_pool.push_back(e0);
+        if (e1) g_prof_pool.push_back(e1);
+        active = false;
+        return;
+    }
     (void)hipEventRecord(e0, stream);
 }
 
@@ -272,10 +290,11 @@ const char *nrf_status_string(int status)
 
 int nrf_profile_enable(int on)
 {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_on.store(on != 0, std::memory_order_relaxed);
     return NRF_OK;
 }
+
+int nrf_profile_is_enabled(void) { return g_prof_on.load(std::memory_order_relaxed) ? 1 : 0; }
 
 int nrf_profile_read(double *ms, int64_t *launches, int reset)
 {
@@ -286,8 +305,8 @@ int nrf_profile_read(double *ms, int64_t *launches, int reset)
             g_prof_ms[rec.slot] += (double)t;
             g_prof_n[rec.slot] += 1;
         }
-        (void)hipEventDestroy(rec.e0);
-        (void)hipEventDestroy(rec.e1);
+        g_prof_pool.push_back(rec.e0);
+        g_prof_pool.push_back(rec.e1);
     }
     g_prof_pending.clear();
     for (int i = 0; i < NRF_PROF_COUNT; i++) {
@@ -698,6 +717,7 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
                 if (rem - m < lc / 8 && rem <= lc) m = rem;                     // no crumbs
             }
 #endif
+            if (m < 1) m = rem < lc ? rem : lc;                                 // Chunk < 8 on the lane path: lc / 8 == 0 must not leave an empty chunk (the loop would never advance)
             if (m > rem) m = rem;
             q.ray_base = p->ray_base + i;
             const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);

@@ -63,13 +63,24 @@ class TileComm:
     """The collective behind the C ABI (nrf_comm_* / nrf_allgather_tiles, include/nerfpp_hip.h): what the C++ / LibTorch host calls.  The RCCL unique id is
     created on rank 0 by the library and handed to the other ranks through torch.distributed (any backend; a file or a socket serves a host without it)."""
 
-    def __init__(self, rank=0, world=1, group=None, timeout_s=300.0):
-        """timeout_s bounds the communicator's own rendezvous (nrf_comm_create_timeout): a peer that never arrives raises instead of parking this rank for ever."""
-        self.rank, self.world = int(rank), int(world)
+    @staticmethod
+    def unique_id():
+        """A fresh RCCL unique id (nrf_comm_unique_id) as bytes: created by ONE rank and handed to the others by whatever channel the host has."""
         buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES)()
-        if self.rank == 0:
+        L.check(L.lib().nrf_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, rank=0, world=1, group=None, timeout_s=300.0, unique_id=None):
+        """timeout_s bounds the communicator's own rendezvous (nrf_comm_create_timeout): a peer that never arrives raises instead of parking this rank for ever.
+        unique_id: the id every rank was handed (TileComm.unique_id() on one of them); None: rank 0 creates it and torch.distributed broadcasts it."""
+        self.rank, self.world = int(rank), int(world)
+        self._c = None
+        buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES)()
+        if unique_id is not None:
+            buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        elif self.rank == 0:
             L.check(L.lib().nrf_comm_unique_id(buf))
-        if self.world > 1:
+        if self.world > 1 and unique_id is None:
             box = [bytes(buf)]
             dist.broadcast_object_list(box, src=0, group=group)
             buf = (C.c_ubyte * L.NRF_COMM_ID_BYTES).from_buffer_copy(box[0])

@@ -475,7 +475,7 @@ def RenderPath(renderer, render_poses, h, w, focal, k, rparams: NeRFRenderParams
 
 
 # ------------------------------------------------------------------------------------------------
-# LeRFRenderer.h / LeRFRenderer.cpp  (BASELINE config 4: language-embedded radiance field render pass)
+# LeRFRenderer.h / LeRFRenderer.cpp  (BASELINE config 5: language-embedded radiance field render pass)
 # ------------------------------------------------------------------------------------------------
 @dataclass
 class LeRFRendererOutputs:            # LeRFRenderer.h:9-18

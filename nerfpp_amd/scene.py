@@ -104,7 +104,7 @@ def synth_hash_table(n_levels, log2_t, n_feat, base_seed=5000, amp=0.5):
 
 def make_hash_scene(mode="cu", n_levels=16, n_feat=2, log2_t=19, base=16, finest=512, sh_degree=4, num_layers_color=4, seed=5000,
                     table_amp=0.5, sigma_scale=30.0, bbox=LEGO_BBOX, num_layers=3):
-    """HashNeRF (BASELINE config 2/3): hash grid + SH + NeRFSmall.  mode 'cu' = CuHashEmbedder + CuSHEncoder (the named
+    """HashNeRF (BASELINE config 3/4): hash grid + SH + NeRFSmall.  mode 'cu' = CuHashEmbedder + CuSHEncoder (the named
     plugin), 'ngp' = HashEmbedder + SHEncoder (the LibTorch CPU twin the oracle/_ref pins)."""
     table = synth_hash_table(n_levels, log2_t, n_feat, seed, table_amp)
     if mode == "cu":
@@ -128,7 +128,7 @@ def make_hash_scene(mode="cu", n_levels=16, n_feat=2, log2_t=19, base=16, finest
 
 
 def make_classic_scene(multires=10, multires_views=4, seed=7000, alpha_scale=40.0, bbox=LEGO_BBOX):
-    """Classic NeRF (BASELINE config 0/1): PE(10) + PE(4) + NeRF 8x256 with view directions."""
+    """Classic NeRF (BASELINE config 1/2): PE(10) + PE(4) + NeRF 8x256 with view directions."""
     emb = Embedder("embedder", multires); dirs = Embedder("embeddirs", multires_views)
     in_ch, in_views = emb.GetOutputDims(), dirs.GetOutputDims()
     params = synth_linear_stack(nerf_shapes(8, 256, in_ch, in_views, 4), seed, 1.4, 0.1, {"alpha_linear.weight": alpha_scale})
@@ -139,7 +139,7 @@ def make_classic_scene(multires=10, multires_views=4, seed=7000, alpha_scale=40.
 
 def make_lerf_scene(n_levels=16, n_feat=8, log2_t=19, base=16, finest=1024, num_layers=2, hidden=256, geo=32, embed=768, seed=311, table_amp=0.5,
                     sigma_scale=20.0, bbox=LEGO_BBOX):
-    """LeRF render pass (BASELINE config 4, the dimensions of main.cpp:203-213): CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768."""
+    """LeRF render pass (BASELINE config 5, the dimensions of main.cpp:203-213): CuHashEmbedder L16 F8 T2^19 16..1024 + LeRF 2x256 -> 768."""
     from .modules import LeRF
     from .renderer import LeRFRenderer
     from . import synth

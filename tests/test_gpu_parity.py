@@ -373,7 +373,7 @@ def test_render_hash_f16_mfma_pixels(api, manifest):
 
 # ------------------------------------------------------------------ full-size, size-independent properties
 def test_full_size_row_tile_properties(api, O):
-    """BASELINE config 2 shape: 800x800 camera, 64+128, HashNeRF (CuHash mode), one 16-row tile (12 800 rays, 3.3 M points).
+    """BASELINE config 3 shape (1-based, as BASELINE.md / SURVEY 8 count them): 800x800 camera, 64+128, HashNeRF (CuHash mode), one 16-row tile (12 800 rays, 3.3 M points).
     Properties: finite, acc in [0,1], rgb in [0,1+eps], depth within [near, far]; tile == slice-of-image by construction of
     the ray index; permuting rays permutes pixels (ray independence); a random 64-ray sample equals the oracle."""
     sc = api.S.make_hash_scene(mode="cu")
@@ -664,7 +664,7 @@ def test_raw2weights_gather_equals_gathered_rows(api):
         assert_exact(a_, b_, "raw2weights through the map == gathered rows: " + nm)
 
 
-# ------------------------------------------------------------------ LeRF (BASELINE config 4)
+# ------------------------------------------------------------------ LeRF (BASELINE config 5)
 def test_lerf_render_pass_vs_oracle(api, O, manifest):
     """LeRFRenderer::RenderRays minus the external Relevancy: CuHashEmbedder(F=8) -> LeRF head -> sigma_le weights ->
     RenderCLIPEmbedding, against the oracle composed stage by stage on the same rays."""
@@ -826,7 +826,7 @@ def test_mlp_small_split_precision_vs_oracle(api, O, manifest):
 
 
 def test_split_precision_render_matches_parity_mode(api, O):
-    """BASELINE config 2 shape, CuHash fast path in NRF_PREC_F16_SPLIT vs the bit-exact NRF_PREC_F32 mode on the adversarial scene.  The default coarse pass
+    """BASELINE config 3 shape, CuHash fast path in NRF_PREC_F16_SPLIT vs the bit-exact NRF_PREC_F32 mode on the adversarial scene.  The default coarse pass
     (sigma net in exact fp32) reproduces the parity mode's sample set, so EVERY pixel value is within 1e-4; with the whole network forced onto the coarse pass
     in split precision (NRF_COARSE_FULL, what round 1 timed) ~1e-6 weight differences move a few samples across CDF plateaus and only the statistical bound holds."""
     sc = api.S.make_hash_scene(mode="cu")
@@ -1960,7 +1960,7 @@ def test_allgather_tiles_c_abi_single_rank(api):
 
 
 def test_whole_frame_800x800_bench_configuration(api, O):
-    """The bench configuration itself (BASELINE config 2: CuHashEmbedder L16 T2^19 F2 + CuSHEncoder(4) + NeRFSmall, 640 000 rays, 64 + 128 samples,
+    """The bench configuration itself (BASELINE config 3: CuHashEmbedder L16 T2^19 F2 + CuSHEncoder(4) + NeRFSmall, 640 000 rays, 64 + 128 samples,
     Chunk 131 072, NRF_PREC_F16_SPLIT) rendered whole: properties over every pixel, the bit-exact NRF_PREC_F32 mode on the same frame as the yardstick
     (every pixel value within 1e-4), 1 024 random rays of the F32 frame equal to the CPU oracle bit for bit, and row tiles == slices of the frame."""
     sc = api.S.make_hash_scene(mode="cu")
@@ -2050,7 +2050,7 @@ def test_chunk_loop_lanes_reproduce_the_single_stream_loop(api):
 
 
 def test_lerf_render_pass_at_main_cpp_table_size(api, O):
-    """BASELINE config 4 at the reference's own sizes (main.cpp:203-213: CuHashEmbedder L16 F8 T2^19 16..1024, LeRF 2 x 256 -> 768) on a 4-row tile of the
+    """BASELINE config 5 at the reference's own sizes (main.cpp:203-213: CuHashEmbedder L16 F8 T2^19 16..1024, LeRF 2 x 256 -> 768) on a 4-row tile of the
     800x800 frame, 64 + 128 samples, fused matrix-core path: sigma_le and the rendered embedding of 48 sampled rays against the oracle composed stage by
     stage; unit norm, finite, Chunk-independent."""
     sc = api.S.make_lerf_scene()
@@ -2242,7 +2242,7 @@ def test_mlp_nerf_split_precision_vs_oracle_and_reference(api, O, manifest):
 
 
 def test_classic_split_render_vs_parity_mode_and_stagewise(api, O):
-    """BASELINE config 1 shape (PE(10)/PE(4) + NeRF 8x256, 800x800 camera, 64 + 128) on a 2-row tile: the fused split-precision path (points and PE formed in
+    """BASELINE config 2 shape (PE(10)/PE(4) + NeRF 8x256, 800x800 camera, 64 + 128) on a 2-row tile: the fused split-precision path (points and PE formed in
     the kernel, per-ray (hi, lo) direction rows) equals the stage-wise split path bit for bit, and its pixels are within 2e-4 of the bit-exact NRF_PREC_F32 render
     (>= 99 %; the coarse pass runs in split precision too, so a handful of fine samples may sit in another CDF bin), PSNR > 80 dB -- where the plain fp16 mode gives ~58."""
     sc = api.S.make_classic_scene()
@@ -2834,6 +2834,21 @@ def test_c_abi_all_gather_at_world_sizes_above_one_with_threads_as_ranks():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(": ok") >= 9
+
+
+def test_bench_step_with_the_c_abi_collective_at_world_two_threads_as_ranks():
+    """bench.py's OWN step function (benchlib/steps.py FrameStepper -- what `--collective cabi`, the N > 1 default, times) at world size 2 on one GPU: two threads as ranks,
+    TileComm = nrf_comm_create_timeout + nrf_allgather_tiles over tests/helpers/mock_rccl.cpp (named through NRF_RCCL_LIBRARY: torch maps the real RCCL, which refuses two
+    ranks on one device), the overlapped gather completing one step later -- strong scaling (one frame, two row tiles) and weak (two frames per step): every rank's gathered
+    frames == the single-rank render bit for bit."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, "tests", "helpers", "_build", "librccl.so.1")):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "helpers", "build_mock_rccl.sh")])
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "bench_step_threads_as_ranks.py")], capture_output=True, text=True, timeout=600)
+    lines = [json.loads(x) for x in w.stdout.splitlines() if x.startswith("{")]
+    assert w.returncode == 0 and len(lines) == 1 and lines[0]["ok"], (w.stdout[-2000:], w.stderr[-2000:])
+    assert all(r["ranks_seen_by_rccl"] == 2 and r["strong"] and r["weak"] for r in lines[0]["ranks"].values())
 
 
 def test_two_real_rccl_ranks_gather_the_single_rank_frame(tmp_path):

@@ -293,11 +293,13 @@ def _canned_bench_detail(world):
     single = {"hash": dict(ms=36.64, launches=50), "mlp": dict(ms=34.70, launches=25), "composite": dict(ms=9.1, launches=50), "sample": dict(ms=4.4, launches=25),
               "other": dict(ms=0.0, launches=0), "sigma": dict(ms=24.47, launches=25), "mlp_colour": dict(ms=10.94, launches=25)}
     units = H * W * UNITS_PER_RAY / world
-    roof = dict(timed=RF.kernel_rooflines(timed, "hash", "f16x3", "cu", units * 10), lanes_timed=2, kernel_ms_timed=timed)
+    roof = dict(timed=RF.kernel_rooflines(timed, "hash", "f16x3", "cu", units * 10), lanes_timed=2, kernel_ms_timed=timed, profile_events_in_timed_region=False,
+                lanes=dict(requested="auto", chosen=2, ms_per_step_by_lanes={"1": 23.435, "2": 22.003}))
     if world == 1:
         roof["isolated"] = RF.kernel_rooflines(single, "hash", "f16x3", "cu", units * 5)
+        roof["isolated_kernel_sum_ms_per_step"] = sum(v["ms"] for v in single.values()) / 5
     long_text = "x" * 1500          # prose that once rode in the line (traffic_source, notes): must not reach it again
-    also = [dict(workload="hashnerf_lego800_64+128", baseline_config=2, precision="f16", value=12179889925.4, unit="ray-samples/s", ms_per_step=13.45, steps=10,
+    also = [dict(workload="hashnerf_lego800_64+128", baseline_config=3, precision="f16", value=12179889925.4, unit="ray-samples/s", ms_per_step=13.45, steps=10,
                  kernel_ms=timed, roofline=dict(frac=0.3964, note=long_text), psnr_vs_oracle_db=dict(psnr=44.08, max_abs_err=0.116)),
             dict(workload="classic_nerf_lego800_64+128", precision="f16x3", value=3.18e8, ms_per_step=514.4, coarse_pass="density branch in exact fp32 " + long_text,
                  roofline=dict(frac=0.2086), psnr_vs_oracle_db=dict(psnr=141.16)),
@@ -317,15 +319,15 @@ def _canned_bench_detail(world):
     return {"metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)", "value": 7302017868.09 * world, "unit": "ray-samples/s",
             "n_gpus": world, "steps": 10, "warmup": 2, "ms_per_step": 22.4376 / world, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None, "dtype": "f16x3", "data": "synthetic",
-            "config": {"workload": "hashnerf_lego800_64+128", "baseline_config": 2, "encoder": "CuHashEmbedder L16 T2^19 F2 16..512 + CuSHEncoder deg4 + NeRFSmall 3x64/4x64",
+            "config": {"workload": "hashnerf_lego800_64+128", "baseline_config": 3, "encoder": "CuHashEmbedder L16 T2^19 F2 16..512 + CuSHEncoder deg4 + NeRFSmall 3x64/4x64",
                        "oracle_pin": "restatement (CUDA-only encoders; reference-pinned twin in also)", "frames_per_step": 1, "rays_per_gpu_per_step": 640000 // world,
                        "ray_samples_per_ray": 256, "chunk": 131072,
                        "parallelism": f"row-tile x{world}" + (" + RCCL all_gather (torch.distributed)" if world > 1 else "")},
             "executed_evaluations_per_ray": dict(hash_encode=192, fused_mlp=128, sigma_only=64, colour_net_only=64),
             "rays_per_s": 28523507.3 * world, "s_per_frame": 0.0224 / world, "host_ms_per_tile": 0.4066, "tile_rows": 800 // world, "roofline": roof,
-            "ranks_seen_by_rccl": world if world > 1 else None,
+            "ranks_seen_by_rccl": world if world > 1 else None, "collective": "nrf_allgather_tiles (C ABI)" if world > 1 else None, "host_ms_per_tile_mean": 5.25,
             "collective_check": ("nrf_allgather_tiles (C ABI, RCCL) == torch.distributed all_gather_into_tensor on every rank " + long_text) if world > 1 else None,
-            "cpu_baseline": dict(value=418719.8, unit="ray-samples/s", cores=32, kind="reference", thread_sweep={"8": 364710}, host_cpus=256, sample="18400 rays " + long_text),
+            "cpu_baseline": dict(value=418719.8, unit="ray-samples/s", cores=256, threads=32, kind="reference", thread_sweep={"8": 364710}, host_cpus=256, sample="18400 rays " + long_text),
             "psnr_vs_oracle_db": dict(psnr=140.55, max_abs_err=7.2e-7), "parity_full_frame_vs_f32": dict(pixels=640000, max_abs_err=2.74e-6, psnr=140.06),
             "frame_sha256": "dcaf99dc2ffe33542a3dbbdcf2b0fbcaf4ab6a2b313c8cd326bc029bcab65afb", "also": also}
 
@@ -350,7 +352,10 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
         assert k in line, k
     assert set(line["config"]) >= {"workload", "baseline_config", "encoder", "frames_per_step", "rays_per_gpu_per_step", "chunk", "parallelism"} and "model" not in line["config"]
     assert line["n_gpus"] == world and line["scaling"] == ("weak" if world == 1 else "strong") and line["vs_baseline"] is None and line["dtype"] == "f16x3"
-    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 160
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "threads", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 160
+    assert line["cpu_baseline"]["cores"] == 256 and line["cpu_baseline"]["threads"] == 32            # cores: the box's; threads: the count that won the sweep
+    assert line["profile_events_in_timed_region"] is False and line["lanes_timed"] == 2 and line["ms_per_step_by_lanes"] == {"1": 23.435, "2": 22.003}
+    assert line["config"]["baseline_config"] == 3                                                     # 1-based: config 3 = HashNeRF 800x800 on one GPU
     r = line["roofline"]
     assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "units_per_launch"} <= set(r)
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -359,11 +364,15 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
         assert r["lanes"] == 1 and r["kernel"].startswith("mlp_small") and r["bound"] == "mfma" and r["kernel_stats"].startswith("profiles/round4/")
         assert abs(r["units_per_launch"] * r["flop_per_unit"] / (r["avg_launch_ms"] * 1e-3) / 1e12 - r["achieved"]) < 0.01 * r["achieved"]
         assert 0.1 < r["frac"] < 0.25 and 0.4 < r["mfma_issued_frac"] < 0.8
-        assert r["hash"]["unit"] == "GB/s" and r["hash"]["frac"] > 1.0 and r["sigma"]["frac"] < 1.0      # hash: algorithmic bytes over the HBM peak (cache-served gathers)
+        # hash: no fraction above 1 any more -- frac is the COUNTER fraction of the HBM peak (absent while the kernel's sources differ from the profiled ones),
+        # the gathered bytes are priced against the cache-resident gather ceiling
+        assert r["hash"]["unit"] == "GB/s" and r["hash"].get("frac", 0.0) < 1.0 and 0.5 < r["hash"]["gather_frac_of_cache_ceiling"] < 1.5 and r["sigma"]["frac"] < 1.0
+        assert abs(r["kernel_sum_ms_per_step"] - 24.05) < 0.01
         assert len(line["also"]) == 9 and all(len(json.dumps(a)) <= 140 for a in line["also"])
         assert [a["workload"] for a in line["also"]][:5] == ["hashnerf", "classic_nerf", "classic_nerf_coarse_full", "classic_nerf", "hashnerf_libtorch_twin"]
     else:
         assert r["lanes"] == 2 and line["ranks_seen_by_rccl"] == world and len(line["collective_check"]) <= 100 and line["also"][0]["workload"] == "scaling_weak"
+        assert line["collective"].startswith("nrf_allgather_tiles")
     assert "x" * 200 not in s, "prose stays in the side file"
     side = json.load(open(tmp_path / "bench_detail.json"))
     assert side["roofline"]["timed"]["hash"]["launches"] == 120 and side["also"] and "[bench detail] {" in cap.err
@@ -372,6 +381,44 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
     s2 = report.dumps_line(report.compact_line(detail))
     l2 = json.loads(s2)
     assert len(s2) < 4096 and "also" not in l2 and l2["dropped_for_size"] == ["also"] and l2["value"] == line["value"] and "cpu_baseline" in l2
+
+
+def test_timed_region_refuses_to_run_with_the_per_kernel_event_bracketing_on():
+    """bench.py's headline is timed by benchlib/timing.py's timed_region, which asserts nrf_profile_is_enabled() == 0 before and after the K steps: round 4's driver-measured
+    30.1 ms per frame carried two timing events around every kernel of both lanes (the claimed 22 ms did not).  With the real library (loads without a GPU; the flag is host
+    state) the region runs with the bracketing off and raises with it on; bench.py's own timed path goes through it and no longer has a profile= switch."""
+    import re
+    from benchlib import timing
+    from nerfpp_amd import _lib as L
+    lib = L.lib()
+    assert lib.nrf_profile_is_enabled() == 0, "off by default"
+    calls = []
+    dt, out = timing.timed_region(lib, lambda: calls.append(1) or len(calls), lambda: calls.append("drain"), lambda: calls.append("sync"), 4)
+    assert calls == ["sync", 1, 1, 1, 1, "drain", "sync"] and out == 5 and dt >= 0.0, "exactly K steps, the drain inside, a sync on both sides"
+    lib.nrf_profile_enable(1)
+    try:
+        assert lib.nrf_profile_is_enabled() == 1
+        with pytest.raises(timing.ProfilingEnabledError):
+            timing.timed_region(lib, lambda: None, lambda: None, lambda: None, 1)
+    finally:
+        lib.nrf_profile_enable(0)
+    # a step that switches the bracketing on mid-region is caught as well
+    with pytest.raises(timing.ProfilingEnabledError):
+        try:
+            timing.timed_region(lib, lambda: lib.nrf_profile_enable(1), lambda: None, lambda: None, 1)
+        finally:
+            lib.nrf_profile_enable(0)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert "timing.timed_region(lib, step, drain, sync, steps)" in src and not re.search(r"timed_run\([^)]*profile\s*=", src), "the headline goes through timed_region; no profile= switch on it"
+    # the lane choice: interleaved blocks through the same refusing region, a tie goes to fewer lanes, the winner is left set
+    state = {"lanes": 0}
+    cost = {1: 0.004, 2: 0.003}
+    import time as _t
+    win, by = timing.choose_lanes(lib, lambda n: state.update(lanes=n), lambda: _t.sleep(cost[state["lanes"]]), lambda: None, lambda: None, lambda x: x, frames=3, rounds=2)
+    assert win == 2 and state["lanes"] == 2 and by[1] > by[2]
+    cost[2] = 0.006
+    win, _ = timing.choose_lanes(lib, lambda n: state.update(lanes=n), lambda: _t.sleep(cost[state["lanes"]]), lambda: None, lambda: None, lambda x: x, frames=3, rounds=1)
+    assert win == 1 and state["lanes"] == 1, "a second lane that does not pay is not used"
 
 
 def test_inline_asm_never_reads_a_matrix_packed_or_transcendental_result():
