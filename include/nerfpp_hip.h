@@ -160,7 +160,11 @@ NRF_API int64_t nrf_hash_table_elems(const nrf_hash *h);          /* L * 2^T * F
 
 /* Upload the embedding table from an fp32 array in the reference's parameter layout
  * (NGP: embeddings_0..L-1 concatenated, each [2^T, F], NeRF.cpp:255-258;  CU: `embedder_embeddings`
- * [L*2^T, F], CuHashEmbedder.cpp:24).  `src` may be host or device memory (src_on_device). */
+ * [L*2^T, F], CuHashEmbedder.cpp:24).  `src` may be host or device memory (src_on_device).
+ * STREAM ORDER: the upload, the fp32 -> fp16 cast of the CU mode and the re-bake of the dense image (see nrf_hash_set_dense_budget) are enqueued on `stream`
+ * and NOT waited for (a training loop calls this every step) -- except when the dense image is (re)allocated, which completes before the call returns.  Encode /
+ * render calls must therefore be issued on the SAME stream, or on one ordered behind it (an event recorded on `stream` after this call, or a synchronisation);
+ * a render on an unrelated stream races with the cast and the bake.  (nrf_batchify_rays' lanes fork from the caller's stream and are ordered behind it.) */
 NRF_API int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *stream);
 
 /* NRF_HASH_CU only: per-level primes [L*3] (buffer `embedder_primes`, CuHashEmbedder.cpp:51-52) and
@@ -171,7 +175,8 @@ NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float 
 /* The renderer's fast path reads a DENSE image of the grid's coarse levels (every lattice vertex's table entries copied next to each other, baked from the
  * table at upload; outputs identical to the hashed lookup): `budget_bytes` of it are built, coarse to fine, default 24 GiB of the 288 GB (all 16 levels at
  * finest 512 take 4.4 GiB).  A training loop re-uploads the table every step and sets 0 (no bake); a renderer leaves the default.  Re-bakes immediately when a
- * table is present; synchronises `stream`. */
+ * table is present.  STREAM ORDER as nrf_hash_set_table: when the image is (re)allocated or released the call completes the bake / drains `stream` before it
+ * returns; a re-bake into the existing image stays asynchronous on `stream`, and its readers must be ordered behind it there. */
 NRF_API int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream);
 NRF_API int64_t nrf_hash_get_dense_budget(const nrf_hash *h);
 

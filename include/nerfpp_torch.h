@@ -37,6 +37,8 @@
 #include <fstream>
 #include <stdexcept>
 #include <string>
+#include <mutex>
+#include <set>
 #include <thread>
 #include <vector>
 
@@ -66,6 +68,18 @@ inline void check(int status, const char *what)
 }
 
 inline void *current_stream() { return (void *)c10::hip::getCurrentHIPStream().stream(); }
+
+/// The renderers that exist: an autograd node of HipNeRFRenderer::Render refers to its renderer by address and may outlive it (a graph kept past the renderer's
+/// destruction); its backward asks here first and fails loudly instead of dereferencing a dangling pointer.
+class LiveRenderers {
+	std::mutex Mu;
+	std::set<const void *> Set;
+public:
+	void add(const void *p) { std::lock_guard<std::mutex> lk(Mu); Set.insert(p); }
+	void remove(const void *p) { std::lock_guard<std::mutex> lk(Mu); Set.erase(p); }
+	bool alive(const void *p) { std::lock_guard<std::mutex> lk(Mu); return Set.count(p) != 0; }
+};
+inline LiveRenderers &live_renderers() { static LiveRenderers r; return r; }
 
 inline torch::Tensor dev_f32(torch::Tensor t)
 {
@@ -795,8 +809,11 @@ class HipNeRFRenderer : public NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> {
 public:
 	/// small = {num_layers, hidden_dim, geo_feat_dim, num_layers_color, hidden_dim_color} of the NeRFSmall the executor built
 	/// (NeRFExecutor.h:479-493), or nerf = {depth, width, output_ch, skip, use_viewdirs} for the classic NeRF.
-	HipNeRFRenderer(TEmbedder embed_fn, TEmbedDirs embeddirs_fn, TNeRF nerf, int precision = NRF_PREC_F16_MFMA) : Base(embed_fn, embeddirs_fn, nerf), Precision(precision) {}
-	~HipNeRFRenderer() override { nrf_renderer_destroy(Renderer); }
+	HipNeRFRenderer(TEmbedder embed_fn, TEmbedDirs embeddirs_fn, TNeRF nerf, int precision = NRF_PREC_F16_MFMA) : Base(embed_fn, embeddirs_fn, nerf), Precision(precision)
+	{
+		nrfpp::live_renderers().add(this);
+	}
+	~HipNeRFRenderer() override { nrfpp::live_renderers().remove(this); nrf_renderer_destroy(Renderer); }
 
 	void SetPrecision(int precision) { Precision = precision; }
 	void SetSeed(uint64_t seed) { Seed = seed; }
@@ -892,9 +909,14 @@ public:
 					self->workspace(wsb, rays_.device()), wsb, current_stream()), "nrf_batchify_rays");
 			}
 			ctx->save_for_backward({rays_, raw, z});
-			auto *st = new TrainState{self, so, ni > 0, (bool)rp.WhiteBkgr, rp.RawNoiseStd, ni > 0 ? rp.StochasticPreconditioningAlpha : 0.f, p.cone_angle, p.has_cone != 0, p.seed,
-				p.has_bbox ? std::vector<float>(p.bbox, p.bbox + 6) : std::vector<float>()};
-			ctx->saved_data["state"] = (int64_t)reinterpret_cast<intptr_t>(st);
+			// the backward's state as plain values in the node itself (no heap object to leak when the graph is dropped without a backward, nothing consumed by a backward:
+			// retain_graph works); the renderer is looked up in the registry of live ones, so a backward after its destruction fails loudly instead of dereferencing it
+			ctx->saved_data["self"] = self_i;
+			ctx->saved_data["s"] = (int64_t)so; ctx->saved_data["fine"] = ni > 0; ctx->saved_data["white_bkgr"] = (bool)rp.WhiteBkgr;
+			ctx->saved_data["noise_std"] = (double)rp.RawNoiseStd; ctx->saved_data["precond_alpha"] = (double)(ni > 0 ? rp.StochasticPreconditioningAlpha : 0.f);
+			ctx->saved_data["cone_angle"] = (double)p.cone_angle; ctx->saved_data["has_cone"] = p.has_cone != 0;
+			ctx->saved_data["seed"] = (int64_t)p.seed;
+			ctx->saved_data["bbox"] = p.has_bbox ? std::vector<double>(p.bbox, p.bbox + 6) : std::vector<double>();
 			ctx->saved_data["table_sizes"] = table.sizes().vec();
 			ctx->saved_data["blob_numel"] = blob.numel();
 			std::vector<torch::Tensor> nd{disp, acc, depth, raw};
@@ -904,10 +926,15 @@ public:
 		}
 		static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
 		{
-			std::unique_ptr<TrainState> st(reinterpret_cast<TrainState *>(ctx->saved_data["state"].toInt()));
-			ctx->saved_data["state"] = (int64_t)0;
+			auto &sd = ctx->saved_data;
+			const int64_t self_i = sd["self"].toInt();
+			TORCH_CHECK(self_i != 0 && nrfpp::live_renderers().alive(reinterpret_cast<const void *>(self_i)),
+				"HipNeRFRenderer: backward through a Render() whose renderer has been destroyed");
+			TrainState st{reinterpret_cast<HipNeRFRenderer *>(self_i), (int)sd["s"].toInt(), sd["fine"].toBool(), sd["white_bkgr"].toBool(), (float)sd["noise_std"].toDouble(),
+				(float)sd["precond_alpha"].toDouble(), (float)sd["cone_angle"].toDouble(), sd["has_cone"].toBool(), (uint64_t)sd["seed"].toInt(), {}};
+			for (double v : sd["bbox"].toDoubleVector()) st.bbox.push_back((float)v);
 			auto saved = ctx->get_saved_variables();
-			auto [g_table, g_blob] = st->self->TrainBackward(*st, saved[0], saved[1], saved[2], grads[0], ctx->saved_data["table_sizes"].toIntVector(), ctx->saved_data["blob_numel"].toInt());
+			auto [g_table, g_blob] = st.self->TrainBackward(st, saved[0], saved[1], saved[2], grads[0], sd["table_sizes"].toIntVector(), sd["blob_numel"].toInt());
 			return {torch::Tensor(), g_table, g_blob, torch::Tensor(), torch::Tensor(), torch::Tensor()};
 		}
 	};

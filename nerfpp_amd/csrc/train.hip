@@ -357,6 +357,13 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
                         if constexpr (MODE == 2) {
                             const uint32_t k2 = atomicAdd(sink.ovf_count, 1u);
                             if (k2 < sink.ovf_cap) sink.ovf[k2] = BinOvf{word, q0, q1};
+                            else {
+                                // beyond the side list (k_qscale's bound makes this unreachable today: at most BIN_OVF_PER_LEVEL such addends per level and pass): never
+                                // dropped -- added to the fp32 gradient directly.  k_bin_accumulate's read-modify-write of this word runs after this kernel (stream order)
+                                float *gw = g_table + (size_t)word * 2;
+                                unsafeAtomicAdd(gw, (float)q0 * qscale_p[1]);
+                                unsafeAtomicAdd(gw + 1, (float)q1 * qscale_p[1]);
+                            }
                         }
                     } else if constexpr (MODE == 1) atomicAdd(bin_cnt + b, 1u);
                     else {

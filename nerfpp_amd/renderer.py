@@ -597,7 +597,8 @@ class LeRFRenderer:
     def _single_call_ok(self, p):
         s, ni = int(p.NSamples), int(p.NImportance)
         return bool(self.single_call and self._r and self.fused and self.level_major and self.reuse_features and self.hand_over_geo and self.compose_through_map
-                    and not p.ReturnRaw and ni > 0 and s % 32 == 0 and (s + ni) % 32 == 0 and p.ThinRay and p.Perturb == 0 and p.RawNoiseStd == 0)
+                    and not p.ReturnRaw and ni > 0 and s % 32 == 0 and (s + ni) % 32 == 0 and p.ThinRay and p.Perturb == 0 and p.RawNoiseStd == 0
+                    and not p.Ndc and p.StochasticPreconditioningAlpha == 0)            # as HipLeRFRenderer::Render (include/nerfpp_torch.h): both take the inherited path
 
     def _render_single_call(self, h, w, k, p, rays, c2w, row0, rows):
         """LeRFRenderer::Render as one C call: nrf_lerf_render_rows for a pose, nrf_lerf_batchify_rays for a ray batch."""

@@ -58,7 +58,10 @@ class Trainer:
         # corners: step 9.3 -> 8.5 ms, same bits; 0 / 16 / 64 / 1024 MB: 9.3 / 8.9 / 8.7 / 8.7 ms, profiles/round4/r4m_train_dense_budget.log).  For ANY hash embedder --
         # the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
         self._dense_budget_before = getattr(embedder, "dense_budget", None)
-        embedder.set_dense_budget(int(train_dense_budget))
+        # never MORE than the embedder already had: a host that built it with budget 0 (or a small one) keeps the levels it turned off -- as the C++ drop-in does
+        # (HipNeRFRenderer: min(previous budget, TrainDenseBudget))
+        prev = self._dense_budget_before
+        embedder.set_dense_budget(int(train_dense_budget) if prev is None else min(int(prev), int(train_dense_budget)))
         self._push_params()
 
     def close(self):

@@ -2021,6 +2021,16 @@ def test_chunk_loop_lanes_reproduce_the_single_stream_loop(api):
                 outs.append([host(res.Outputs.RGBMap), host(res.Outputs.DepthMap), host(res.Outputs.AccMap), host(res.Outputs.DispMap)])
             for x, y, nm in zip(outs[0], outs[1], ("rgb", "depth", "acc", "disp")):
                 assert_exact(y, x, "two lanes == one stream: %s, rows %d chunk %d" % (nm, rows, chunk))
+        # Chunk < 8 on the lane path with an odd ray count (round-4 advisor: the tail balance computed an EMPTY chunk there -- lc / 8 == 0 -- and the loop never advanced):
+        # 32 769 rays in chunks of 4 must come back, equal to the single-stream loop
+        o, d, _ = api.R.GetRays(800, 800, K, c2w, row0=380, rows=41)
+        o = o.reshape(-1, 3)[:32769].contiguous(); d = d.reshape(-1, 3)[:32769].contiguous()
+        rp4 = api.S.lego_render_params(sc["bbox"], chunk=4, precision=api.L.NRF_PREC_F16_SPLIT)
+        tiny = []
+        for lanes in (1, 2):
+            api.L.check(lib.nrf_set_render_lanes(lanes))
+            tiny.append(host(sc["renderer"].Render(800, 800, K, rp4, rays=(o, d, None)).Outputs.RGBMap))
+        assert_exact(tiny[1], tiny[0], "two lanes == one stream at Chunk 4, 32 769 rays")
         # the classic model's kernels (weight-streaming split kernel, exact sigma kernel) beside each other on the two lanes
         cl = api.S.make_classic_scene()
         rpc = api.S.lego_render_params(cl["bbox"], chunk=16384, precision=api.L.NRF_PREC_F16_SPLIT)
