@@ -646,6 +646,29 @@ NRF_API int nrf_lerf_render_rows(const nrf_lerf_renderer *r, const nrf_view *v, 
                                  float *d_rays_out, float *d_near_far, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N1, LeRF branch of the optimisation step (NeRFExecutor.h:955-982): lang_loss and its backward into LeRFImpl and the language grid
+ * ------------------------------------------------------------------------------------------- */
+/* lang_loss = huber_loss(pred, target, reduction none, delta).sum(-1).nanmean() (NeRFExecutor.h:970-974; delta 1.25 there): d_loss [1]; d_grad [n, e] = d loss / d pred
+ * (NULL: not wanted).  A row holding a NaN leaves the mean (count = the other rows); its gradient row is 0 except NaN at the NaN elements -- what LibTorch's backward
+ * leaves there (golden train_lerf_nan). */
+NRF_API int nrf_huber_rows_nanmean(const float *d_pred, const float *d_target, int64_t n, int e, float delta, float *d_loss, float *d_grad, void *stream);
+/* Backward of the FINE pass of LeRFRenderer::RenderRays (LeRFRenderer.cpp:141-172; the coarse pass carries none: z_samples are detached, :150) downstream of the language
+ * grid: d_emb [n*s, in] = lang_embed_fn->forward(pts) -> LeRFImpl::forward (LeRF.cpp:86-108) -> sigma_le[~keep] = 0 (LeRFRenderer.cpp:37-38) -> RawToLEOutputs' weights
+ * (:38-66; d_noise [n, s] / noise_std: the RawNoiseStd draws, NULL / 0 = none) -> RenderCLIPEmbedding (LeRFRenderer.h:45-54), given d_g_rendered [n, E] = d loss /
+ * d RenderedLangEmbedding.  fp32; the forward is recomputed here (every layer input kept, chunks of whole rays).  d_g_params: the head's blob layout, ACCUMULATED into;
+ * d_g_emb [n*s, in] written (NULL: not wanted); d_rendered [n, E] / d_weights [n, s]: the recomputed forward (NULL: not wanted).  d_dirs: rays_d, row stride d_stride. */
+NRF_API size_t nrf_lerf_head_backward_workspace_bytes(const nrf_mlp *lerf, int64_t n, int s);
+NRF_API int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_t *d_keep, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                                   const float *d_noise, float noise_std, const float *d_g_rendered, float *d_g_params, float *d_g_emb, float *d_rendered, float *d_weights,
+                                   void *d_workspace, size_t workspace_bytes, void *stream);
+/* ... with the language grid in front -- the backward of one LeRFRenderer::Render call on a ray batch in ONE library call: d_pts [n, s, 3] the fine pass's sample points
+ * (o + d z, after TangentScatter / preconditioning where those are on) -> nrf_hash_encode -> the head's backward -> nrf_hash_backward_rays (CuHashEmbedderBackwardKernel's
+ * gradient, CuHashEmbedder.cu:105-216).  d_g_lerf_params (head blob) and d_g_table (the grid's fp32 table layout) are ACCUMULATED into. */
+NRF_API size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int s);
+NRF_API int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise,
+                                     float noise_std, const float *d_g_rendered, float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)
  * ------------------------------------------------------------------------------------------- */
 /* When enabled, nrf_render_rays brackets its dominant kernels with HIP events on the caller's stream;

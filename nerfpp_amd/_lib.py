@@ -89,6 +89,7 @@ SYMBOLS = [
     "nrf_lerf_relevancy", "nrf_relevancy_image", "nrf_colormap_jet_u8", "nrf_colormap_jet_lut",
     "nrf_lerf_renderer_create", "nrf_lerf_renderer_destroy", "nrf_lerf_set_prompts", "nrf_lerf_render_rays_workspace_bytes", "nrf_lerf_render_rays",
     "nrf_lerf_batchify_rays_workspace_bytes", "nrf_lerf_batchify_rays", "nrf_lerf_render_rows_workspace_bytes", "nrf_lerf_render_rows",
+    "nrf_huber_rows_nanmean", "nrf_lerf_head_backward_workspace_bytes", "nrf_lerf_head_backward", "nrf_lerf_backward_points_workspace_bytes", "nrf_lerf_backward_points",
 ]
 NRF_COMM_ID_BYTES = 128
 
@@ -126,6 +127,8 @@ def lib():
         L.nrf_hash_backward_binned_workspace_bytes_for.restype = C.c_size_t
         L.nrf_lerf_geo_bytes.restype = C.c_size_t
         L.nrf_hash_backward_packed_workspace_bytes.restype = C.c_size_t
+        L.nrf_lerf_head_backward_workspace_bytes.restype = C.c_size_t
+        L.nrf_lerf_backward_points_workspace_bytes.restype = C.c_size_t
         _lib = L
     return _lib
 

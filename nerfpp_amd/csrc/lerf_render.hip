@@ -258,6 +258,10 @@ using namespace nrf;
 
 extern "C" int nrf_view_check(const nrf_view *v, const char *who);
 
+// the renderer's two modules, for lerf_train.hip (library-internal: not exported)
+extern "C" const nrf_hash *nrf_lerf_renderer_lang_embed(const nrf_lerf_renderer *r) { return r ? r->desc.lang_embed : nullptr; }
+extern "C" const nrf_mlp *nrf_lerf_renderer_head(const nrf_lerf_renderer *r) { return r ? r->desc.lerf : nullptr; }
+
 extern "C" {
 
 int nrf_lerf_relevancy(const float *d_embeds, int64_t n, int embed_dim, const float *d_positives, int n_pos, const float *d_negatives, int n_neg, int positive_id,

@@ -1,0 +1,378 @@
+// lerf_train.hip -- N1, the LeRF branch of the optimisation step (NeRFExecutor.h:955-982):
+//   lerf_render_result = LeRFRenderer->Render(ray batch)                                   :958-961
+//   lang_loss = huber_loss(RenderedLangEmbedding, target, reduction none, delta 1.25).sum(-1).nanmean()     :970-974        nrf_huber_rows_nanmean
+//   lang_loss.backward()  into LeRFImpl's two bias-free MLPs and the F = 8 language grid        :981            nrf_lerf_head_backward / nrf_lerf_backward_points
+// What carries gradient is the FINE pass (z_samples are detached, LeRFRenderer.cpp:150):
+//   pts -> CuHashEmbedder (language grid) -> LeRFImpl::forward (LeRF.cpp:86-108: sigma net in -> H.. -> 1 + geo; LE net cat[geo, in] -> H.. -> E; normalize eps 1e-8)
+//       -> sigma_le[~keep] = 0 (LeRFRenderer.cpp:37-38) -> RawToLEOutputs' weights (:38-66, TruncExp CustomOps.cpp:5-15) -> RenderCLIPEmbedding (LeRFRenderer.h:45-54).
+// fp32 throughout, from the generic layer kernels of mlp.hip (forward = the oracle's FMA chains; dW = TN products with one atomic add per element and workgroup): the
+// forward is RECOMPUTED here chunk by chunk with every layer input kept -- the render pass (fused matrix-core kernels) never forms raw_le [n, S, 769].
+// Pinned by LibTorch autograd over the compiled LeRF.cpp / RawToOutputs weights / the reference's inline RenderCLIPEmbedding: goldens train_lerf*.
+#include "encode.h"
+#include "mlp.h"
+#include "nrf_math.h"
+
+struct nrf_lerf_renderer;
+extern "C" const nrf_hash *nrf_lerf_renderer_lang_embed(const nrf_lerf_renderer *r);
+extern "C" const nrf_mlp *nrf_lerf_renderer_head(const nrf_lerf_renderer *r);
+
+namespace nrf {
+
+constexpr int64_t LT_CHUNK_PTS = 1 << 15;        // sample points per pass: 2 n_layers + 4 activation / gradient buffers of this many rows x the widest layer
+
+__device__ __forceinline__ double lt_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide sum of one double per thread (blockDim.x = 256: four waves); every thread gets the result
+__device__ __forceinline__ double lt_block_sum(double v, double *sh /*[4]*/)
+{
+    v = lt_wave_sum(v);
+    __syncthreads();                                 // sh may still be read from the previous use
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// huber(reduction none, delta) summed over a row; row_loss[i] (NaN for a row that holds a NaN)
+__global__ void k_huber_rows(int64_t n, int e, float delta, const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ row_loss)
+{
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int k = lane; k < e; k += 64) {
+        const float d = pred[i * e + k] - target[i * e + k];
+        const float z = fabsf(d);
+        acc += (z < delta) ? 0.5 * (double)z * (double)z : (double)delta * ((double)z - 0.5 * (double)delta);
+    }
+    acc = lt_wave_sum(acc);
+    if (lane == 0) row_loss[i] = (float)acc;
+}
+
+// nanmean over the rows: out[0] = loss, out[1] = 1 / (count of non-NaN rows)
+__global__ void k_nanmean(int64_t n, const float *__restrict__ row_loss, float *__restrict__ loss, float *__restrict__ inv_count)
+{
+    __shared__ double sh[4];
+    double acc = 0.0, cnt = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = row_loss[i];
+        if (v == v) { acc += (double)v; cnt += 1.0; }
+    }
+    acc = lt_block_sum(acc, sh);
+    cnt = lt_block_sum(cnt, sh);
+    if (threadIdx.x == 0) { *loss = (float)(acc / cnt); *inv_count = 1.0f / (float)cnt; }
+}
+
+// d loss / d pred: nansum hands a NaN row 0 instead of 1 / count; huber's own derivative multiplies it (NaN * 0 = NaN at a NaN element: what LibTorch leaves there)
+__global__ void k_huber_rows_grad(int64_t n, int e, float delta, const float *__restrict__ pred, const float *__restrict__ target, const float *__restrict__ row_loss,
+                                  const float *__restrict__ inv_count, float *__restrict__ grad)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * e) return;
+    const int64_t i = idx / e;
+    const float rl = row_loss[i];
+    const float go = (rl == rl) ? inv_count[0] : 0.0f;
+    const float d = pred[idx] - target[idx];
+    grad[idx] = (d < -delta) ? -delta * go : (d > delta ? delta * go : d * go);
+}
+
+// h [p, E] (row stride hs) -> le = h / max(||h||, 1e-8) IN PLACE, nrm[p] = ||h||        (LeRF.cpp:104; one wave per point)
+__global__ void k_lt_point_norm(int64_t p, int e, float *__restrict__ h, int hs, float *__restrict__ nrm)
+{
+    const int64_t pt = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (pt >= p) return;
+    const int lane = threadIdx.x & 63;
+    double ss = 0.0;
+    for (int k = lane; k < e; k += 64) { const float v = h[pt * hs + k]; ss += (double)v * (double)v; }
+    ss = lt_wave_sum(ss);
+    const float nr = (float)sqrt(ss);
+    const float c = fmaxf(nr, 1e-8f);
+    for (int k = lane; k < e; k += 64) h[pt * hs + k] = h[pt * hs + k] / c;
+    if (lane == 0) nrm[pt] = nr;
+}
+
+// One workgroup (256 threads) per ray: weights of the ray's s samples, RenderCLIPEmbedding forward and backward, the per-sample normalize backward (le -> g_h in place)
+// and the weights' backward -> g_sigma.  Dynamic LDS: 7 s + 2 e floats.
+//   sig33 [c, ss]: column 0 = sigma_le (unmasked: masked here with keep);   le / g_h [c, hs];   out: g33 [c, gs] column 0 = d loss / d sigma_le (0 where masked)
+__global__ void __launch_bounds__(256) k_lt_ray(int s, int e, const float *__restrict__ sig33, int ss, const uint8_t *__restrict__ keep, const float *__restrict__ z,
+                                                const float *__restrict__ dirs, int d_stride, const float *__restrict__ noise, float noise_std, float *__restrict__ le, int hs,
+                                                const float *__restrict__ nrm, const float *__restrict__ g_rendered, float *__restrict__ g33, int gs,
+                                                float *__restrict__ rendered, float *__restrict__ weights_out)
+{
+    extern __shared__ float lds[];
+    float *alpha = lds, *trans = lds + s, *xx = lds + 2 * s, *lt = lds + 3 * s, *wgt = lds + 4 * s, *gw = lds + 5 * s, *sg = lds + 6 * s;
+    float *v = lds + 7 * s, *gv = v + e;
+    __shared__ double sh[4];
+    const int64_t ray = blockIdx.x;
+    const int64_t p0 = ray * s;
+    const float *dv = dirs + ray * d_stride;
+    const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        float sr = (keep && !keep[p0 + j]) ? 0.0f : sig33[(p0 + j) * ss];
+        if (noise) sr = sr + noise[p0 + j] * noise_std;                    // RawNoiseStd > 0 (LeRFRenderer.cpp:50-51): the density that went through relu / alpha
+        sg[j] = sr;
+        float dist = (j + 1 < s) ? (z[p0 + j + 1] - z[p0 + j]) : 1e10f;
+        dist = dist * dn;
+        const float x = -(sr > 0.0f ? sr : 0.0f) * dist;
+        xx[j] = x;
+        alpha[j] = -nrf_expf(x) + 1.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                                // the log-space transmittance: a double running sum, each prefix rounded to fp32 (ATen's cumsum)
+        double logt = 0.0; float tprev = 0.0f;
+        for (int j = 0; j < s; j++) {
+            lt[j] = tprev; trans[j] = nrf_expf(tprev);
+            const float om = 1.0f - alpha[j];
+            logt += (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
+            tprev = (float)logt;
+            wgt[j] = alpha[j] * trans[j];
+        }
+    }
+    __syncthreads();
+    if (weights_out) for (int j = threadIdx.x; j < s; j += blockDim.x) weights_out[p0 + j] = wgt[j];
+    // v = sum_j w_j le_j ; ||v|| ; g . v
+    double vss = 0.0, gdot = 0.0;
+    for (int k = threadIdx.x; k < e; k += blockDim.x) {
+        double a = 0.0;
+        for (int j = 0; j < s; j++) a += (double)(wgt[j] * le[(p0 + j) * hs + k]);
+        const float vk = (float)a;
+        v[k] = vk;
+        vss += (double)vk * (double)vk;
+        gdot += (double)g_rendered[ray * e + k] * (double)vk;
+    }
+    vss = lt_block_sum(vss, sh);
+    gdot = lt_block_sum(gdot, sh);
+    const float vn = (float)sqrt(vss), vc = fmaxf(vn, 1e-8f);
+    const bool through_norm = vn >= 1e-8f && vn > 0.0f;                     // clamp_min passes the gradient to ||v|| only where it did not clamp
+    for (int k = threadIdx.x; k < e; k += blockDim.x) {
+        if (rendered) rendered[ray * e + k] = v[k] / vc;
+        float g = g_rendered[ray * e + k] / vc;
+        if (through_norm) g -= (float)(gdot / ((double)vc * (double)vc)) * (v[k] / vn);
+        gv[k] = g;
+    }
+    __syncthreads();
+    // per sample (a wave each): t = le . g_v = d loss / d w ; g_le = w g_v ; g_h = g_le / c - [||h|| >= eps] (g_le . h / c^2) h / ||h||, h = le c
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < s; j += 4) {
+        float *row = le + (p0 + j) * hs;
+        double t = 0.0;
+        for (int k = lane; k < e; k += 64) t += (double)row[k] * (double)gv[k];
+        t = lt_wave_sum(t);
+        const float nr = nrm[p0 + j], c = fmaxf(nr, 1e-8f), w = wgt[j];
+        const bool thr = nr >= 1e-8f && nr > 0.0f;
+        const float hdot_over_c2 = (float)((double)w * t * (double)c / ((double)c * (double)c));     // g_le . h / c^2 with h = le c
+        for (int k = lane; k < e; k += 64) {
+            float g = w * gv[k] / c;
+            if (thr) g -= hdot_over_c2 * (row[k] * c / nr);
+            row[k] = g;
+        }
+        if (lane == 0) gw[j] = (float)t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                                // weights backward (RawToLEOutputs :38-66, TruncExp::backward = grad * exp(clamp(x, -100, 5)))
+        double suffix = 0.0;
+        for (int j = s - 1; j >= 0; j--) {
+            float g_alpha = gw[j] * trans[j];
+            const float om = 1.0f - alpha[j];
+            if (om >= 1e-10f) g_alpha -= (float)suffix / om;
+            const float cl = lt[j] < -100.0f ? -100.0f : (lt[j] > 5.0f ? 5.0f : lt[j]);
+            suffix += (double)(gw[j] * alpha[j] * nrf_expf(cl));
+            const float cx = xx[j] < -100.0f ? -100.0f : (xx[j] > 5.0f ? 5.0f : xx[j]);
+            const float g_x = -g_alpha * nrf_expf(cx);
+            float dist = (j + 1 < s) ? (z[p0 + j + 1] - z[p0 + j]) : 1e10f;
+            dist = dist * dn;
+            float gsig = (sg[j] > 0.0f) ? -g_x * dist : 0.0f;
+            if (keep && !keep[p0 + j]) gsig = 0.0f;                        // index_put_ of a constant: no gradient to the masked sigma
+            g33[(p0 + j) * gs] = gsig;
+        }
+    }
+}
+
+// dst[pt][d_col + k] = src[pt][s_col + k] (+ add[pt][a_col + k]), k < ncols
+__global__ void k_lt_copy_cols(int64_t p, int ncols, const float *__restrict__ src, int s_stride, int s_col, const float *__restrict__ add, int a_stride, int a_col,
+                               float *__restrict__ dst, int d_stride, int d_col)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p * ncols) return;
+    const int64_t pt = idx / ncols; const int k = (int)(idx - pt * ncols);
+    float v = src[pt * s_stride + s_col + k];
+    if (add) v = v + add[pt * a_stride + a_col + k];
+    dst[pt * d_stride + d_col + k] = v;
+}
+
+static size_t head_ws_bytes(const nrf_mlp *m, int64_t n, int s)
+{
+    const int64_t rays = n < 1 ? 1 : (LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1);
+    const int64_t c = (n < rays ? (n < 1 ? 1 : n) : rays) * s;
+    const size_t buf = align_up((size_t)c * m->max_width * sizeof(float), 256);
+    return buf * (m->layers.size() + 4) + align_up((size_t)c * sizeof(float), 256) + 1024;
+}
+
+// one chunk of whole rays: c = rays * s points
+static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t *keep, const float *z, const float *dirs, int d_stride, const float *noise, float noise_std,
+                               int64_t rays, int s, const float *g_rendered, float *g_params, float *g_emb, float *rendered, float *weights, float *base, size_t buf,
+                               float *nrm, hipStream_t st)
+{
+    const auto &d = m->small;                    // MLP_LERF reuses: input_ch, num_layers, hidden_dim, geo_feat_dim; hidden_dim_color = embed dim (mlp.hip)
+    const int W = m->max_width, nl = d.num_layers, NL = 2 * nl, E = d.hidden_dim_color, in = d.input_ch, geo = d.geo_feat_dim;
+    const int64_t c = rays * s;
+    const Seg none{nullptr, 0, 0, 0};
+    std::vector<float *> H(NL);
+    for (int l = 0; l < NL; l++) H[l] = base + (size_t)l * buf;
+    float *G[4] = {base + (size_t)NL * buf, base + (size_t)(NL + 1) * buf, base + (size_t)(NL + 2) * buf, base + (size_t)(NL + 3) * buf};
+    // ---- forward, every layer output kept (post-ReLU for hidden layers)                            LeRF.cpp:86-102 ----
+    const Seg xin{emb, in, 0, in};
+    Seg cur = xin;
+    for (int l = 0; l < nl; l++) {
+        NRF_TRY(run_linear(c, cur, none, m->layers[l], l != nl - 1, H[l], W, 0, st));
+        cur = Seg{H[l], W, 0, m->layers[l].out};
+    }
+    const float *h33 = H[nl - 1];                                         // column 0 = sigma_le, 1.. = geo_feat_le
+    const Seg sgeo{h33, W, 1, geo};
+    for (int l = 0; l < nl; l++) {
+        NRF_TRY(run_linear(c, l == 0 ? sgeo : cur, l == 0 ? xin : none, m->layers[nl + l], l != nl - 1, H[nl + l], W, 0, st));
+        cur = Seg{H[nl + l], W, 0, m->layers[nl + l].out};
+    }
+    float *hle = H[NL - 1];                                               // h [c, E] -> le -> g_h, in place
+    hipLaunchKernelGGL(k_lt_point_norm, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, st, c, E, hle, W, nrm);
+    NRF_LAUNCH_CHECK();
+    // ---- per ray: weights, RenderCLIPEmbedding, their backward ----
+    float *g33 = G[0];
+    const size_t lds = ((size_t)7 * s + (size_t)2 * E) * sizeof(float);
+    hipLaunchKernelGGL(k_lt_ray, dim3((unsigned)rays), dim3(256), lds, st, s, E, h33, W, keep, z, dirs, d_stride, noise, noise_std, hle, W, (const float *)nrm, g_rendered, g33, W,
+                       rendered, weights);
+    NRF_LAUNCH_CHECK();
+    // ---- LE net backward (last layer first)                                                        LeRF.cpp:97-103 ----
+    Seg g{hle, W, 0, E};
+    int gi = 1;
+    for (int l = NL - 1; l >= nl; l--) {
+        const LinearLayer &L = m->layers[l];
+        if (l != NL - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
+        const bool first = (l == nl);
+        NRF_TRY(run_grad_w(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st));
+        float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
+        NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+        g = Seg{dst, W, 0, L.in};
+    }
+    // g = d / d cat[geo, in]: the sigma net's output gradient = (g_sigma [already in g33 column 0], g_geo)
+    const float *g_x0 = g.p;
+    hipLaunchKernelGGL(k_lt_copy_cols, dim3((unsigned)ceil_div(c * geo, 256)), dim3(256), 0, st, c, geo, g_x0, W, 0, (const float *)nullptr, 0, 0, g33, W, 1);
+    NRF_LAUNCH_CHECK();
+    g = Seg{g33, W, 0, 1 + geo};
+    // the gradient buffers still free: not g33 (G[0]), not the one holding g_x0
+    float *freeb[2]; int nf = 0;
+    for (int q = 1; q < 4 && nf < 2; q++) if (G[q] != g_x0) freeb[nf++] = G[q];
+    int fi = 0;
+    for (int l = nl - 1; l >= 0; l--) {
+        const LinearLayer &L = m->layers[l];
+        if (l != nl - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
+        NRF_TRY(run_grad_w(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
+        if (l == 0 && !g_emb) break;
+        float *dst = freeb[fi]; fi ^= 1;
+        NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+        g = Seg{dst, W, 0, L.in};
+    }
+    if (g_emb) {                                                           // d / d emb = through the sigma net + through the LE net's cat[geo, in]
+        hipLaunchKernelGGL(k_lt_copy_cols, dim3((unsigned)ceil_div(c * in, 256)), dim3(256), 0, st, c, in, g.p, g.stride, 0, g_x0, W, geo, g_emb, in, 0);
+        NRF_LAUNCH_CHECK();
+    }
+    return NRF_OK;
+}
+
+}  // namespace nrf
+
+using namespace nrf;
+
+extern "C" {
+
+int nrf_huber_rows_nanmean(const float *d_pred, const float *d_target, int64_t n, int e, float delta, float *d_loss, float *d_grad, void *stream)
+{
+    NRF_CHECK_ARG(d_pred && d_target && d_loss && n > 0 && e > 0 && delta > 0.0f, "nrf_huber_rows_nanmean: bad argument");
+    hipStream_t st = as_stream(stream);
+    float *tmp = nullptr;
+    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&tmp), (size_t)(n + 1) * sizeof(float), st));
+    int rc = NRF_OK;
+    hipLaunchKernelGGL(k_huber_rows, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, e, delta, d_pred, d_target, tmp);
+    hipLaunchKernelGGL(k_nanmean, dim3(1), dim3(256), 0, st, n, (const float *)tmp, d_loss, tmp + n);
+    if (d_grad) hipLaunchKernelGGL(k_huber_rows_grad, dim3((unsigned)ceil_div(n * e, 256)), dim3(256), 0, st, n, e, delta, d_pred, d_target, (const float *)tmp, (const float *)(tmp + n), d_grad);
+    if (hipGetLastError() != hipSuccess) { set_error("nrf_huber_rows_nanmean: launch failed"); rc = NRF_ERR_HIP; }
+    (void)hipFreeAsync(tmp, st);
+    return rc;
+}
+
+size_t nrf_lerf_head_backward_workspace_bytes(const nrf_mlp *lerf, int64_t n, int s)
+{
+    return (lerf && lerf->family == MLP_LERF && s >= 1) ? head_ws_bytes(lerf, n, s) : 0;
+}
+
+int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_t *d_keep, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s,
+                           const float *d_noise, float noise_std, const float *d_g_rendered, float *d_g_params, float *d_g_emb, float *d_rendered, float *d_weights,
+                           void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(lerf && d_emb && d_z && d_dirs && d_g_rendered && d_g_params && n >= 0 && s >= 1 && d_stride >= 3, "nrf_lerf_head_backward: bad argument");
+    if (lerf->family != MLP_LERF) { set_error("nrf_lerf_head_backward: the handle is not a LeRF head (nrf_mlp_lerf_create)"); return NRF_ERR_INVALID_ARG; }
+    const int E = lerf->small.hidden_dim_color;
+    if (((size_t)7 * s + (size_t)2 * E) * sizeof(float) > 60 * 1024) { set_error("nrf_lerf_head_backward: %d samples x %d embedding dims exceed the per-ray LDS image", s, E); return NRF_ERR_UNSUPPORTED; }
+    if (workspace_bytes < head_ws_bytes(lerf, n, s)) { set_error("nrf_lerf_head_backward: workspace %zu < %zu bytes", workspace_bytes, head_ws_bytes(lerf, n, s)); return NRF_ERR_WORKSPACE; }
+    if (n == 0) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t cmax = (n < rays_per ? n : rays_per) * s;
+    const size_t buf = align_up((size_t)cmax * lerf->max_width * sizeof(float), 256) / sizeof(float);
+    float *base = reinterpret_cast<float *>(d_workspace);
+    float *nrm = base + buf * (lerf->layers.size() + 4);
+    const int in = lerf->small.input_ch;
+    for (int64_t r0 = 0; r0 < n; r0 += rays_per) {
+        const int64_t rays = (n - r0) < rays_per ? (n - r0) : rays_per;
+        const int64_t p0 = r0 * s;
+        NRF_TRY(head_backward_chunk(lerf, d_emb + p0 * in, d_keep ? d_keep + p0 : nullptr, d_z + p0, d_dirs + r0 * d_stride, d_stride, d_noise ? d_noise + p0 : nullptr, noise_std,
+                                    rays, s, d_g_rendered + r0 * E, d_g_params, d_g_emb ? d_g_emb + p0 * in : nullptr, d_rendered ? d_rendered + r0 * E : nullptr,
+                                    d_weights ? d_weights + p0 : nullptr, base, buf, nrm, st));
+    }
+    return NRF_OK;
+}
+
+// ... with the language grid in front: pts [n, s, 3] -> nrf_hash_encode (fp32 rows) -> the head's backward -> nrf_hash_backward_rays, chunk by chunk of whole rays
+size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int s)
+{
+    if (!r || s < 1) return 0;
+    const nrf_mlp *m = nrf_lerf_renderer_head(r);
+    const nrf_hash *h = nrf_lerf_renderer_lang_embed(r);
+    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t c = (n < rays_per ? (n < 1 ? 1 : n) : rays_per) * s;
+    const int in = nrf_hash_output_dims(h);
+    return head_ws_bytes(m, n, s) + 2 * align_up((size_t)c * in * sizeof(float), 256) + align_up((size_t)c, 256) + 1024;
+}
+
+int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise,
+                             float noise_std, const float *d_g_rendered, float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && d_pts && d_z && d_dirs && d_g_rendered && d_g_lerf_params && d_g_table && n >= 0 && s >= 1, "nrf_lerf_backward_points: bad argument");
+    const nrf_mlp *m = nrf_lerf_renderer_head(r);
+    const nrf_hash *h = nrf_lerf_renderer_lang_embed(r);
+    const int in = nrf_hash_output_dims(h), E = m->small.hidden_dim_color;
+    if (in != m->small.input_ch) { set_error("nrf_lerf_backward_points: the grid yields %d features, the head expects %d", in, m->small.input_ch); return NRF_ERR_INVALID_ARG; }
+    if (workspace_bytes < nrf_lerf_backward_points_workspace_bytes(r, n, s)) { set_error("nrf_lerf_backward_points: workspace %zu < %zu bytes", workspace_bytes, nrf_lerf_backward_points_workspace_bytes(r, n, s)); return NRF_ERR_WORKSPACE; }
+    if (n == 0) return NRF_OK;
+    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t cmax = (n < rays_per ? n : rays_per) * s;
+    char *ws = static_cast<char *>(d_workspace);
+    const size_t hb = head_ws_bytes(m, n, s), eb = align_up((size_t)cmax * in * sizeof(float), 256);
+    float *emb = reinterpret_cast<float *>(ws + align_up(hb, 256)), *g_emb = reinterpret_cast<float *>(ws + align_up(hb, 256) + eb);
+    uint8_t *keep = reinterpret_cast<uint8_t *>(ws + align_up(hb, 256) + 2 * eb);
+    for (int64_t r0 = 0; r0 < n; r0 += rays_per) {
+        const int64_t rays = (n - r0) < rays_per ? (n - r0) : rays_per;
+        const int64_t p0 = r0 * s, c = rays * s;
+        NRF_TRY(nrf_hash_encode(h, d_pts + p0 * 3, c, emb, keep, stream));                                         // lang_embed_fn->forward (LeRFRenderer.cpp:34)
+        NRF_TRY(nrf_lerf_head_backward(m, emb, keep, d_z + p0, d_dirs + r0 * d_stride, d_stride, rays, s, d_noise ? d_noise + p0 : nullptr, noise_std, d_g_rendered + r0 * E,
+                                       d_g_lerf_params, g_emb, nullptr, nullptr, d_workspace, hb, stream));
+        NRF_TRY(nrf_hash_backward_rays(h, d_pts + p0 * 3, rays, s, g_emb, d_g_table, stream));                        // CuHashEmbedderBackwardKernel's gradient (CuHashEmbedder.cu:105-216)
+    }
+    return NRF_OK;
+}
+
+}  // extern "C"

@@ -27,6 +27,14 @@ struct LinearLayer {
     size_t w_off = 0;           // offset of W [out][in] in the parameter blob (floats)
 };
 
+// a column range of row-major fp32 rows: the operands of the generic fp32 layer kernels (mlp.hip)
+struct Seg {
+    const float *p;   // rows
+    int stride;       // floats between rows
+    int off;          // first column
+    int n;            // columns taken
+};
+
 }  // namespace nrf
 
 struct nrf_mlp {
@@ -60,6 +68,17 @@ size_t mlp_workspace_bytes(const nrf_mlp *m, int64_t p, int prec);
 // x: [p, x_stride] rows holding [input_ch | input_ch_views]; out: [p, out_stride]
 int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int prec, float *d_out, int out_stride,
                 void *d_ws, size_t ws_bytes, hipStream_t st);
+
+// the generic fp32 building blocks of mlp.hip (forward: an FMA chain per output in ascending k == the oracle; backward: dW by a TN product over the points with one
+// atomic add per element and workgroup, g_in by the same forward kernel on the blob's own [out][in] matrix), shared with lerf_train.hip / the classic backward:
+//   y[pt][y_off + o] = act(sum_k W[o][k] concat(a, b)[pt][k] + bias[o])
+int run_linear(int64_t npts, Seg a, Seg b, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
+//   dw[o][i] += sum_pt g[pt][o] concat(a, b)[pt][i]            (dw: the layer's [out][in] block of a parameter-gradient blob)
+int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
+//   y[pt][k] = sum_o g[pt][o] W[o][k]
+int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st);
+//   g[pt][k] = 0 where act[pt][k] <= 0
+int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act, int act_stride, hipStream_t st);
 
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);

@@ -9,13 +9,6 @@
 
 namespace nrf {
 
-struct Seg {
-    const float *p;   // rows
-    int stride;       // floats between rows
-    int off;          // first column
-    int n;            // columns taken
-};
-
 constexpr int LIN_TP = 16;   // points per block
 
 // y[pt][y_off + o] = act( sum_k W[o][k] * concat(a,b)[pt][k] + bias[o] ),  W given transposed ([in][out]).
@@ -93,7 +86,7 @@ __global__ void k_copy_col(int64_t npts, const float *__restrict__ x, int x_stri
     if (i < npts) y[i * y_stride + y_col] = x[i * x_stride + x_col];
 }
 
-static int run_linear(int64_t npts, Seg a, Seg b, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
+int run_linear(int64_t npts, Seg a, Seg b, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
 {
     const int in = a.n + b.n;
     if (in != L.in) { set_error("internal: linear layer expects %d inputs, got %d", L.in, in); return NRF_ERR_INVALID_ARG; }
@@ -246,6 +239,13 @@ __global__ void k_relu_mask(int64_t total, int n, float *__restrict__ g, int g_s
     if (!(act[pt * act_stride + k] > 0.0f)) g[pt * g_stride + k] = 0.0f;
 }
 
+int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act, int act_stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)ceil_div(npts * n, 256)), dim3(256), 0, st, npts * n, n, g, g_stride, act, act_stride);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
 constexpr int GW_PTS = 32;      // points staged per iteration
 // dW[o][i] += sum_pt g[pt][o] * concat(a, b)[pt][i]   (out, in <= 64 per launch tile; 256 threads, a 4x4 register tile each)
 __global__ void __launch_bounds__(256) k_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *__restrict__ dw)
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_grad_w(int64_t npts, Seg g, Seg a, Seg 
         }
 }
 
-static int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st)
+int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st)
 {
     const int64_t nb = ceil_div(npts, GW_PTS);
     dim3 grid((unsigned)(nb < 256 ? nb : 256), (unsigned)ceil_div(out, 64), (unsigned)ceil_div(in, 64));
@@ -297,7 +297,7 @@ static int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float 
 }
 
 // g_in[pt][k] = sum_o g[pt][o] * W[o][k]: k_linear with the blob matrix as its [in' = out][out' = in] operand
-static int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st)
+int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st)
 {
     const Seg none{nullptr, 0, 0, 0};
     const int threads = L.in >= 256 ? 256 : (int)ceil_div(L.in, 64) * 64;

@@ -302,3 +302,117 @@ class Trainer:
     @staticmethod
     def psnr(mse):
         return -10.0 * math.log(max(float(mse), 1e-30)) / math.log(10.0)       # NeRFExecutor.h:893
+
+
+# ------------------------------------------------------------------------------------------------
+# N1, LeRF branch of the optimisation step (NeRFExecutor.h:955-982)
+# ------------------------------------------------------------------------------------------------
+def HuberRowsNanmean(pred, target, delta=1.25, want_grad=True):
+    """lang_loss = huber_loss(pred, target, reduction none, delta).sum(-1).nanmean() (NeRFExecutor.h:970-974) -> (loss [1] on the device, d loss / d pred or None)."""
+    p = _dev_f32(pred); t = _dev_f32(target)
+    n, e = p.shape
+    loss = torch.empty((1,), device=p.device)
+    grad = torch.empty_like(p) if want_grad else None
+    L.check(L.lib().nrf_huber_rows_nanmean(_ptr(p), _ptr(t), C.c_int64(n), int(e), C.c_float(delta), _ptr(loss), _ptr(grad), _stream()))
+    return loss, grad
+
+
+def LeRFHeadBackward(lerf, emb, keep, z, rays_d, g_rendered, noise=None, noise_std=0.0, want_g_emb=True):
+    """Backward of the fine pass of LeRFRenderer::RenderRays downstream of the language grid (nrf_lerf_head_backward): emb [n*s, in], keep [n*s] bool / uint8 or None,
+    z [n, s], rays_d [n, 3], g_rendered [n, E] -> dict(g_params [blob], g_emb [n*s, in], rendered [n, E], weights [n, s]) (the recomputed fp32 forward rides along)."""
+    emb = _dev_f32(emb); z = _dev_f32(z); d = _dev_f32(rays_d).reshape(-1, 3).contiguous(); g = _dev_f32(g_rendered)
+    n, s = z.shape
+    E = lerf.GetLangEmbedDim()
+    k8 = None if keep is None else (keep if keep.dtype == torch.uint8 else keep.to(torch.uint8)).contiguous()
+    g_params = torch.zeros((lerf.n_params,), device=emb.device)
+    g_emb = torch.empty_like(emb) if want_g_emb else None
+    rendered = torch.empty((n, E), device=emb.device); weights = torch.empty((n, s), device=emb.device)
+    nz = None if noise is None else _dev_f32(noise)
+    nb = L.lib().nrf_lerf_head_backward_workspace_bytes(lerf._m, C.c_int64(n), int(s))
+    ws = torch.empty((int(nb),), device=emb.device, dtype=torch.uint8)
+    L.check(L.lib().nrf_lerf_head_backward(lerf._m, _ptr(emb), _ptr(k8), _ptr(z), _ptr(d), 3, C.c_int64(n), int(s), _ptr(nz), C.c_float(noise_std), _ptr(g), _ptr(g_params),
+                                           _ptr(g_emb), _ptr(rendered), _ptr(weights), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+    return dict(g_params=g_params, g_emb=g_emb, rendered=rendered, weights=weights)
+
+
+class LeRFTrainer:
+    """The LeRF half of NeRFExecutor::Train's loop body (NeRFExecutor.h:955-985): LeRFRenderer->Render on the ray batch -> lang_loss (huber, delta 1.25, row sums,
+    nanmean) -> lang_loss.backward() into the LeRF head and the language grid -> Adam (the executor's one optimizer, lr / betas (0.9, 0.99) / eps 1e-15, :539).
+    The render is the library's fused pass; the backward is ONE library call (nrf_lerf_backward_points: the language grid's encode, the head's recomputed fp32 forward and
+    backward, the grid's scatter).  PyTorch owns the buffers (fp32 master parameters, Adam moments) only."""
+
+    def __init__(self, renderer, lang_table, lerf_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15, delta=1.25):
+        from .renderer import LeRFRenderer
+        if not isinstance(renderer, LeRFRenderer) or not renderer._r:
+            raise L.NrfError("LeRFTrainer needs a LeRFRenderer on the library path (CuHashEmbedder L16 F8 language grid + a LeRF head of the built family)")
+        self.renderer, self.embedder, self.lerf = renderer, renderer.LangEmbedFn, renderer.Lerf
+        dev = "cuda"
+        as_dev = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32).reshape(-1) if not torch.is_tensor(a) else a.reshape(-1)).to(dev).contiguous()
+        self.table, self.blob = as_dev(lang_table), as_dev(lerf_blob)
+        assert self.table.numel() == self.embedder.table_elems() and self.blob.numel() == self.lerf.n_params
+        self.m_table, self.v_table = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
+        self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
+        self.lr, self.betas, self.eps, self.delta, self.t = float(learning_rate), betas, float(eps), float(delta), 0
+        self._ws = None
+        # while the table moves only the coarse levels that fit 256 MB stay baked (as Trainer), never more than the embedder had
+        self._dense_budget_before = getattr(self.embedder, "dense_budget", None)
+        if self._dense_budget_before is not None:
+            self.embedder.set_dense_budget(min(int(self._dense_budget_before), 256 << 20))
+        self._push_params()
+
+    def close(self):
+        if getattr(self, "_dense_budget_before", None) is not None:
+            self.embedder.set_dense_budget(self._dense_budget_before)
+            self._dense_budget_before = None
+
+    def _push_params(self):
+        self.embedder.set_table(self.table)
+        L.check(L.lib().nrf_mlp_set_params(self.lerf._m, _ptr(self.blob), 1, _stream()))
+
+    def backward(self, res, target, params, cone_angle=None):
+        """lang_loss and the gradients of one rendered batch (fills self.g_table / self.g_blob); returns the loss [1] on the device."""
+        lib = L.lib()
+        rays = res.Extras["rays_flat"]
+        n, stride = rays.shape
+        z = res.Extras["z_fine"]
+        s = z.shape[1]
+        rendered = res.Outputs.RenderedLangEmbedding.reshape(n, -1).contiguous()
+        loss, g = HuberRowsNanmean(rendered, target, self.delta)
+        pts = torch.empty((n * s, 3), device=rays.device)
+        L.check(lib.nrf_points(_ptr(rays), stride, _ptr(z), C.c_int64(n), s, _ptr(pts), _stream()))
+        p = params
+        seed = int(p.Seed)
+        if p.StochasticPreconditioningAlpha > 0:                                     # LeRFRenderer.cpp:155-164
+            pn = RngFill(seed, L.NRF_RNG_PRECOND, 0, n * s * 3, normal=True, device=rays.device)
+            pts = StochasticPrecondition(pts, pn, float(p.StochasticPreconditioningAlpha), p.BoundingBox)
+        if cone_angle is not None:                                                   # TangentScatter (:166)
+            ur = RngFill(seed, L.NRF_RNG_R_FINE, 0, n * s, device=rays.device); ut = RngFill(seed, L.NRF_RNG_THETA_FINE, 0, n * s, device=rays.device)
+            pts = TangentScatter(pts.reshape(n, s, 3), z, float(cone_angle), rays[:, 3:6].contiguous(), p.BoundingBox, ur, ut).reshape(n * s, 3)
+        noise_std = float(p.RawNoiseStd)
+        noise = RngFill(seed, L.NRF_RNG_NOISE_FINE, 0, n * s, normal=True, device=rays.device) if noise_std > 0 else None
+        self.g_blob.zero_(); self.g_table.zero_()
+        nb = lib.nrf_lerf_backward_points_workspace_bytes(self.renderer._r, C.c_int64(n), int(s))
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty((int(nb),), device="cuda", dtype=torch.uint8)
+        pts = pts.contiguous()
+        L.check(lib.nrf_lerf_backward_points(self.renderer._r, _ptr(pts), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), int(s), _ptr(noise), C.c_float(noise_std),
+                                             _ptr(g), _ptr(self.g_blob), _ptr(self.g_table), _ptr(self._ws), C.c_size_t(self._ws.numel()), _stream()))
+        self.last = dict(g_rendered=g, pts=pts)
+        return loss
+
+    def step(self, rays_o, rays_d, target_lang_embedding, render_params: NeRFRenderParams, cone_angle=None):
+        """Render; lang_loss; backward; Adam step on the language grid and the head (NeRFExecutor.h:955-985) -> (lang_loss [1] on the device, the render result)."""
+        p = copy.copy(render_params)
+        p.KeepIntermediates, p.ReturnWeights = True, True
+        p.Seed = (int(render_params.Seed) + 0x9E3779B97F4A7C15 * self.t) & ((1 << 64) - 1)
+        cone = None if p.ThinRay else cone_angle
+        res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))
+        loss = self.backward(res, target_lang_embedding, p, cone)
+        self.t += 1
+        b1, b2 = self.betas
+        for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):
+            L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                          C.c_float(self.eps), self.t, _stream()))
+        self._push_params()
+        return loss, res

@@ -413,6 +413,41 @@ def huber_loss(pred, target):
     return loss.value, mse.value, grad
 
 
+def huber_rows_nanmean(pred, target, delta=1.25):
+    """huber_loss(pred, target, reduction none, delta).sum(-1).nanmean() (NeRFExecutor.h:970-974) -> (loss, d loss / d pred)."""
+    pred = _f(pred); target = _f(target)
+    n, e = pred.shape
+    loss = C.c_float(0); grad = np.empty_like(pred)
+    lib().orc_huber_rows_nanmean(_p(pred), _p(target), C.c_int64(n), C.c_int(e), C.c_float(delta), C.byref(loss), _p(grad))
+    return loss.value, grad
+
+
+def lerf_param_count(in_ch, n_layers, hidden, geo, embed):
+    n, cd = 0, in_ch
+    for l in range(n_layers):
+        od = (1 + geo) if l == n_layers - 1 else hidden
+        n += cd * od; cd = od
+    cd = geo + in_ch
+    for l in range(n_layers):
+        od = embed if l == n_layers - 1 else hidden
+        n += cd * od; cd = od
+    return n
+
+
+def lerf_head_backward(params, emb, keep, z, d, g_rendered, in_ch=128, n_layers=2, hidden=256, geo=32, embed=768, noise=None, noise_std=0.0):
+    """Backward of the fine pass of LeRFRenderer::RenderRays downstream of the language grid (orc_lerf_head_backward) ->
+    dict(g_params [blob], g_emb [n*s, in], rendered [n, E], weights [n, s])."""
+    params = _f(params); emb = _f(emb); z = _f(z); d = _f(d); g_rendered = _f(g_rendered)
+    n, s = z.shape
+    k8 = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    g_params = np.zeros(lerf_param_count(in_ch, n_layers, hidden, geo, embed), np.float32)
+    assert params.size == g_params.size, (params.size, g_params.size)
+    g_emb = np.empty_like(emb); rendered = np.empty((n, embed), np.float32); weights = np.empty((n, s), np.float32)
+    lib().orc_lerf_head_backward(_p(params), _p(emb), _p(k8), _p(z), _p(d), C.c_int64(n), C.c_int(s), C.c_int(in_ch), C.c_int(n_layers), C.c_int(hidden), C.c_int(geo),
+                                 C.c_int(embed), _p(None if noise is None else _f(noise)), C.c_float(noise_std), _p(g_rendered), _p(g_params), _p(g_emb), _p(rendered), _p(weights))
+    return dict(g_params=g_params, g_emb=g_emb, rendered=rendered, weights=weights)
+
+
 def raw2outputs_backward(raw, z, d, g_rgb, white_bkgr=False):
     raw = _f(raw); z = _f(z); d = _f(d); g_rgb = _f(g_rgb)
     n, s, c = raw.shape

@@ -1429,6 +1429,197 @@ ORC_API void orc_mlp_small_backward(const float *params, const float *x, const f
     free(gacc);
 }
 
+/* N1, LeRF branch (NeRFExecutor.h:955-982): lang_loss = huber_loss(RenderedLangEmbedding, target, reduction none, delta).sum(-1).nanmean()  (:970-974).
+ * ATen: huber(reduction none) z = |d|: z < delta ? 0.5 z^2 : delta (z - 0.5 delta); nanmean = nansum / (count of non-NaN rows); the backward of nansum passes a ZERO
+ * to a NaN row, and huber's backward multiplies it by its own derivative -- NaN where the difference is NaN: such a ray's gradient row is 0 except NaN at the NaN
+ * elements (golden train_lerf_nan).  loss: 1 float; grad [n, e] = d loss / d pred. */
+ORC_API void orc_huber_rows_nanmean(const float *pred, const float *target, int64_t n, int e, float delta, float *loss, float *grad)
+{
+    double acc = 0.0;
+    int64_t cnt = 0;
+    unsigned char *isnan_row = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int64_t i = 0; i < n; i++) {
+        double row = 0.0;
+        for (int k = 0; k < e; k++) {
+            const float d = pred[i * e + k] - target[i * e + k];
+            const float z = fabsf(d);
+            row += (z < delta) ? 0.5 * (double)z * (double)z : (double)delta * ((double)z - 0.5 * (double)delta);
+        }
+        const float rowf = (float)row;
+        if (rowf != rowf) isnan_row[i] = 1; else { acc += (double)rowf; cnt++; }
+    }
+    if (loss) *loss = (float)(acc / (double)cnt);                       /* 0 / 0 = NaN when every row is NaN, as nanmean */
+    if (grad) {
+        const float norm = 1.0f / (float)cnt;
+        for (int64_t i = 0; i < n; i++) {
+            const float go = isnan_row[i] ? 0.0f : norm;
+            for (int k = 0; k < e; k++) {
+                const float d = pred[i * e + k] - target[i * e + k];
+                grad[i * e + k] = (d < -delta) ? -delta * go : (d > delta ? delta * go : d * go);        /* NaN d: the last branch, NaN * 0 = NaN */
+            }
+        }
+    }
+    free(isnan_row);
+}
+
+/* Backward of the FINE pass of LeRFRenderer::RenderRays downstream of the language grid, w.r.t. the LeRF head's parameters and the grid's features:
+ *   emb [n*s, in] -> LeRFImpl::forward (LeRF.cpp:86-108) -> sigma_le[~keep] = 0 (LeRFRenderer.cpp:37-38) -> RawToLEOutputs' weights (:38-66, = C1's) ->
+ *   RenderCLIPEmbedding (LeRFRenderer.h:45-54) -> rendered [n, E];  given g_rendered = d loss / d rendered.
+ * normalize(x, eps) = x / clamp_min(||x||, eps): its backward is g / c - [||x|| >= eps] (g . x / c^2) x / ||x||, c = max(||x||, eps).
+ * Weights backward as raw2outputs_backward_impl above with d loss / d w given directly (TruncExp::backward = grad * exp(clamp(x, -100, 5)), CustomOps.cpp:11-15).
+ * Accumulates into g_params (blob layout of orc_lerf; caller zeroes); writes g_emb [n*s, in] (may be NULL), rendered [n, E] and weights [n, s] (may be NULL). */
+ORC_API void orc_lerf_head_backward(const float *params, const float *emb, const unsigned char *keep, const float *z, const float *d, int64_t n, int s,
+                                    int in_ch, int n_layers, int hidden, int geo, int embed, const float *noise /*[n,s] or NULL: the RawNoiseStd draws (LeRFRenderer.cpp:50-51)*/,
+                                    float noise_std, const float *g_rendered, float *g_params, float *g_emb, float *rendered, float *weights_out)
+{
+    int64_t np_ = 0;
+    { int cd = in_ch; for (int l = 0; l < n_layers; l++) { int od = (l == n_layers - 1) ? (1 + geo) : hidden; np_ += (int64_t)cd * od; cd = od; }
+      cd = geo + in_ch; for (int l = 0; l < n_layers; l++) { int od = (l == n_layers - 1) ? embed : hidden; np_ += (int64_t)cd * od; cd = od; } }
+    double *gacc = (double *)calloc((size_t)np_, sizeof(double));
+    const int NL = 2 * n_layers;
+    const int maxw = (hidden > embed ? hidden : embed) > (geo + in_ch + 1) ? (hidden > embed ? hidden : embed) : (geo + in_ch + 1);
+    for (int64_t i = 0; i < n; i++) {                                     /* sequential over rays: deterministic double accumulation */
+        /* ---- forward of the ray's s samples, every layer input kept ---- */
+        float *act = (float *)calloc((size_t)s * (NL + 1) * maxw, sizeof(float));       /* act[j][l] = input of layer l (l = NL: the last layer's output h) */
+        float *le = (float *)malloc(sizeof(float) * (size_t)s * embed), *nrm = (float *)malloc(sizeof(float) * s), *sig = (float *)malloc(sizeof(float) * s);
+        const float *wl[32]; int dims[33];
+        for (int j = 0; j < s; j++) {
+            const float *xi = emb + (i * s + j) * in_ch;
+            float *A = act + (size_t)j * (NL + 1) * maxw;
+            const float *w = params;
+            memcpy(A, xi, sizeof(float) * in_ch); dims[0] = in_ch;
+            for (int l = 0; l < n_layers; l++) {
+                const int od = (l == n_layers - 1) ? (1 + geo) : hidden;
+                wl[l] = w;
+                linear(w, NULL, A + (size_t)l * maxw, dims[l], od, A + (size_t)(l + 1) * maxw, l != n_layers - 1);
+                w += (int64_t)dims[l] * od; dims[l + 1] = od;
+            }
+            /* act[n_layers] = (sigma, geo): the LE net's input replaces it in a separate slot: layer n_layers reads cat[geo, in] */
+            float *h33 = A + (size_t)n_layers * maxw;
+            sig[j] = (keep && !keep[i * s + j]) ? 0.0f : h33[0];
+            if (noise) sig[j] = sig[j] + noise[i * s + j] * noise_std;     /* the density that goes through relu / alpha */
+            float cin[4096];
+            for (int k = 0; k < geo; k++) cin[k] = h33[1 + k];
+            for (int k = 0; k < in_ch; k++) cin[geo + k] = xi[k];
+            float keep33[4096]; memcpy(keep33, h33, sizeof(float) * (1 + geo));
+            /* slots: [0..n_layers-1] inputs of the sigma layers; slot n_layers: cat[geo, in] (input of LE layer 0); h33 itself is not needed again (ReLU-free output) */
+            memcpy(h33, cin, sizeof(float) * (geo + in_ch));
+            int cd = geo + in_ch;
+            for (int l = 0; l < n_layers; l++) {
+                const int od = (l == n_layers - 1) ? embed : hidden;
+                wl[n_layers + l] = w;
+                linear(w, NULL, A + (size_t)(n_layers + l) * maxw, cd, od, A + (size_t)(n_layers + l + 1) * maxw, l != n_layers - 1);
+                w += (int64_t)cd * od; cd = od;
+            }
+            const float *h = A + (size_t)NL * maxw;
+            double ss = 0.0;
+            for (int k = 0; k < embed; k++) ss += (double)h[k] * (double)h[k];
+            nrm[j] = (float)sqrt(ss);
+            const float c = f_max(nrm[j], 1e-8f);
+            for (int k = 0; k < embed; k++) le[(size_t)j * embed + k] = h[k] / c;
+        }
+        /* ---- weights (as raw2outputs_impl) ---- */
+        const float *dv = d + i * 3;
+        const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        float *alpha = (float *)malloc(sizeof(float) * s), *trans = (float *)malloc(sizeof(float) * s), *x_ = (float *)malloc(sizeof(float) * s), *lt = (float *)malloc(sizeof(float) * s),
+              *wgt = (float *)malloc(sizeof(float) * s), *gw = (float *)malloc(sizeof(float) * s);
+        double logt = 0.0; float tprev = 0.0f;
+        for (int j = 0; j < s; j++) {
+            float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
+            dist = dist * dn;
+            const float sg = sig[j] > 0.0f ? sig[j] : 0.0f;
+            x_[j] = -sg * dist;
+            alpha[j] = -nrf_expf(x_[j]) + 1.0f;
+            lt[j] = tprev; trans[j] = nrf_expf(tprev);
+            const float om = 1.0f - alpha[j];
+            logt += (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
+            tprev = (float)logt;
+            wgt[j] = alpha[j] * trans[j];
+            if (weights_out) weights_out[i * s + j] = wgt[j];
+        }
+        /* ---- RenderCLIPEmbedding forward + backward ---- */
+        float *v = (float *)malloc(sizeof(float) * embed), *gv = (float *)malloc(sizeof(float) * embed);
+        double vss = 0.0;
+        for (int k = 0; k < embed; k++) { double a = 0.0; for (int j = 0; j < s; j++) a += (double)(wgt[j] * le[(size_t)j * embed + k]); v[k] = (float)a; vss += (double)v[k] * (double)v[k]; }
+        const float vn = (float)sqrt(vss), vc = f_max(vn, 1e-8f);
+        double gdot = 0.0;
+        for (int k = 0; k < embed; k++) { if (rendered) rendered[i * embed + k] = v[k] / vc; gdot += (double)g_rendered[i * embed + k] * (double)v[k]; }
+        for (int k = 0; k < embed; k++) {
+            float g = g_rendered[i * embed + k] / vc;
+            if (vn >= 1e-8f && vn > 0.0f) g -= (float)(gdot / ((double)vc * (double)vc)) * (v[k] / vn);
+            gv[k] = g;
+        }
+        /* per sample: g_w = le . g_v ; g_le = w g_v ; g_h = normalize backward */
+        float *gh = (float *)malloc(sizeof(float) * (size_t)s * embed);
+        for (int j = 0; j < s; j++) {
+            double t = 0.0;
+            for (int k = 0; k < embed; k++) t += (double)le[(size_t)j * embed + k] * (double)gv[k];
+            gw[j] = (float)t;
+            const float c = f_max(nrm[j], 1e-8f);
+            const float *h = act + (size_t)j * (NL + 1) * maxw + (size_t)NL * maxw;
+            double hdot = 0.0;                                             /* g_le . h = w (g_v . h) */
+            for (int k = 0; k < embed; k++) hdot += (double)(wgt[j] * gv[k]) * (double)h[k];
+            for (int k = 0; k < embed; k++) {
+                float g = wgt[j] * gv[k] / c;
+                if (nrm[j] >= 1e-8f && nrm[j] > 0.0f) g -= (float)(hdot / ((double)c * (double)c)) * (h[k] / nrm[j]);
+                gh[(size_t)j * embed + k] = g;
+            }
+        }
+        /* weights backward -> g_sigma */
+        float *gsig = (float *)malloc(sizeof(float) * s);
+        double suffix = 0.0;
+        for (int j = s - 1; j >= 0; j--) {
+            float g_alpha = gw[j] * trans[j];
+            const float om = 1.0f - alpha[j];
+            if (om >= 1e-10f) g_alpha -= (float)suffix / om;
+            const float cl = lt[j] < -100.0f ? -100.0f : (lt[j] > 5.0f ? 5.0f : lt[j]);
+            suffix += (double)(gw[j] * alpha[j] * nrf_expf(cl));
+            const float cx = x_[j] < -100.0f ? -100.0f : (x_[j] > 5.0f ? 5.0f : x_[j]);
+            const float g_x = -g_alpha * nrf_expf(cx);
+            float dist = (j + 1 < s) ? (z[i * s + j + 1] - z[i * s + j]) : 1e10f;
+            dist = dist * dn;
+            gsig[j] = (sig[j] > 0.0f) ? -g_x * dist : 0.0f;
+            if (keep && !keep[i * s + j]) gsig[j] = 0.0f;                 /* index_put_ of a constant: no gradient to the masked sigma */
+        }
+        /* ---- the two nets, per sample ---- */
+        for (int j = 0; j < s; j++) {
+            float *A = act + (size_t)j * (NL + 1) * maxw;
+            float g[4096], gin[4096];
+            memcpy(g, gh + (size_t)j * embed, sizeof(float) * embed);
+            int od = embed;
+            for (int l = NL - 1; l >= n_layers; l--) {                     /* LE net, last layer first */
+                const int id = (l == n_layers) ? (geo + in_ch) : hidden;
+                const float *in_l = A + (size_t)l * maxw, *out_l = A + (size_t)(l + 1) * maxw;
+                if (l != NL - 1) for (int o = 0; o < od; o++) if (!(out_l[o] > 0.0f)) g[o] = 0.0f;
+                double *ga = gacc + (wl[l] - params);
+                for (int o = 0; o < od; o++) for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)g[o] * (double)in_l[k];
+                for (int k = 0; k < id; k++) { float a = 0.0f; for (int o = 0; o < od; o++) a += wl[l][(int64_t)o * id + k] * g[o]; gin[k] = a; }
+                memcpy(g, gin, sizeof(float) * id); od = id;
+            }
+            float ge_a[4096];                                              /* d / d emb through the LE net's cat[geo, in] */
+            memcpy(ge_a, g + geo, sizeof(float) * in_ch);
+            float g33[4096];
+            g33[0] = gsig[j];
+            for (int k = 0; k < geo; k++) g33[1 + k] = g[k];
+            memcpy(g, g33, sizeof(float) * (1 + geo)); od = 1 + geo;
+            for (int l = n_layers - 1; l >= 0; l--) {
+                const int id = (l == 0) ? in_ch : hidden;
+                const float *in_l = A + (size_t)l * maxw, *out_l = A + (size_t)(l + 1) * maxw;
+                /* slot n_layers was overwritten with the LE input: the sigma net's last layer has no ReLU, so its output is not needed for a mask */
+                if (l != n_layers - 1) for (int o = 0; o < od; o++) if (!(out_l[o] > 0.0f)) g[o] = 0.0f;
+                double *ga = gacc + (wl[l] - params);
+                for (int o = 0; o < od; o++) for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)g[o] * (double)in_l[k];
+                for (int k = 0; k < id; k++) { float a = 0.0f; for (int o = 0; o < od; o++) a += wl[l][(int64_t)o * id + k] * g[o]; gin[k] = a; }
+                memcpy(g, gin, sizeof(float) * id); od = id;
+            }
+            if (g_emb) for (int k = 0; k < in_ch; k++) g_emb[(i * s + j) * in_ch + k] = g[k] + ge_a[k];
+        }
+        free(act); free(le); free(nrm); free(sig); free(alpha); free(trans); free(x_); free(lt); free(wgt); free(gw); free(v); free(gv); free(gh); free(gsig);
+    }
+    for (int64_t k = 0; k < np_; k++) g_params[k] += (float)gacc[k];
+    free(gacc);
+}
+
 /* Backward of HashEmbedderImpl::forward w.r.t. the embedding tables (NeRF.cpp:279-298 trilinear blend; nn::Embedding backward =
  * index_add of the row gradients).  g_emb [p, L*F]; g_table [L][2^T][F] accumulated (caller zeroes). */
 ORC_API void orc_hash_ngp_backward(const float *x, int64_t p, const float *bbox, int n_levels, int n_feat, int log2_t, int base, int finest,

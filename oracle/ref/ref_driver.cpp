@@ -19,6 +19,7 @@
 #include "Sampler.h"
 #include "CustomOps.h"
 #include "NeRFRenderer.h"   // filtered copy (OpenCV image helpers removed), see build_ref.sh
+#include "LeRFRenderer.h"   // for the inline RenderCLIPEmbedding (:45-54); LeRFRenderer.cpp itself needs RuCLIP and is not built
 
 #include "nrf_synth.h"
 
@@ -721,6 +722,76 @@ static void g_train()
 }
 
 // ----------------------------------------------------------------------------------------------
+// N1, LeRF branch of the optimisation step (NeRFExecutor.h:955-982): LeRFRenderer->Render on the ray batch ->
+// huber_loss(RenderedLangEmbedding, target, reduction none, delta 1.25).sum(-1).nanmean() -> lang_loss.backward().
+// What carries gradient is the FINE pass (z_samples are detached, LeRFRenderer.cpp:150): LeRFImpl::forward (compiled LeRF.cpp) on the language grid's
+// features, the sigma mask (LeRFRenderer.cpp:37-38), RawToLEOutputs' weights, RenderCLIPEmbedding (the reference's inline function, LeRFRenderer.h:45-54).
+// LeRFRenderer.cpp itself cannot be built here (it includes RuCLIP's header for Relevancy, which carries no gradient to the loss): its weights are the
+// expression of NeRFRenderer::RawToOutputs (NeRFRenderer.h:234-270 == LeRFRenderer.cpp:38-66, read side by side), so the COMPILED RawToOutputs runs on
+// [0, 0, 0, sigma_le] rows and its .Weights are used -- no arithmetic is restated.  The language grid is CuHashEmbedder (CUDA-only): its output is a leaf here
+// (`emb`), its own backward is pinned by the restatement (oracle/nerf_oracle.c).
+// ----------------------------------------------------------------------------------------------
+static void g_train_lerf()
+{
+	struct Cfg { const char *tag; int geo, layers, hidden, embed, in, n, s; int stride; };
+	// `small`: every gradient in full; `main`: main.cpp:203-213 dims, gradients of the big matrices as every `stride`-th element (fixture size)
+	for (const Cfg &c : {Cfg{"train_lerf", 8, 2, 32, 48, 16, 6, 24, 1}, Cfg{"train_lerf_main", 32, 2, 256, 768, 128, 4, 12, 61}, Cfg{"train_lerf_l3", 6, 3, 24, 40, 12, 5, 16, 1}})
+	{
+		const std::string tag = c.tag;
+		LeRF m(c.geo, c.layers, c.hidden, c.embed, c.in, "lang_model");
+		fill_module(tag, m, 8000u, 1.4f, 0.f);
+		const int n = c.n, S = c.s, E = c.embed;
+		auto emb = synth_tensor({n * S, c.in}, 83u, 0.5f).set_requires_grad(true);
+		auto keep = torch::ones({n * S}, torch::kBool);
+		keep.index_put_({3}, false); keep.index_put_({S + 1}, false); keep.index_put_({2 * S + S / 2}, false);
+		auto near = synth_tensor({n, 1}, 92u, 0.5f, 2.5f);
+		auto far = near + synth_tensor({n, 1}, 93u, 1.0f, 2.5f);
+		auto t = torch::linspace(0.f, 1.f, S, torch::kFloat);
+		auto z = (near * (1.f - t) + far * t + synth_tensor({n, S}, 95u, 0.02f)).contiguous();
+		z = std::get<0>(torch::sort(z, -1));                                  // a fine-pass depth set: sorted, unevenly spaced
+		auto d = synth_tensor({n, 3}, 94u, 40.0f);                             // long direction vectors: dists = dz * |d| put sigma_le * dists at O(1), rays span transparent .. opaque
+		auto target = torch::nn::functional::normalize(synth_tensor({n, E}, 96u, 1.0f), torch::nn::functional::NormalizeFuncOptions().dim(-1));
+		// RunLENetwork (LeRFRenderer.cpp:27-44) downstream of the embedder
+		auto outputs_flat = m->forward(emb);
+		outputs_flat.index_put_({~keep, -1}, 0);
+		auto raw = outputs_flat.view({n, S, E + 1});
+		Embedder e0("e", 2), ed0("ed", 2);
+		NeRF m0(2, 8, 15, 15, 4, std::set<int>{}, true, "model");
+		Spy<Embedder, Embedder, NeRF> spy(e0, ed0, m0);
+		auto raw4 = torch::cat({torch::zeros({n, S, 3}), raw.index({"...", Slice(E, E + 1)})}, -1);
+		auto weights = spy.OpenRawToOutputs(raw4, z, d, false).Weights;      // == RawToLEOutputs' WeightsLE (LeRFRenderer.cpp:38-66)
+		auto le = raw.index({"...", Slice(0, E)});
+		auto rendered = RenderCLIPEmbedding(le, weights.unsqueeze(-1));       // LeRFRenderer.h:45-54 (LeRFRenderer.cpp:74)
+		auto lang_loss = torch::nn::functional::huber_loss(rendered, target.detach(),
+			torch::nn::functional::HuberLossFuncOptions().reduction(torch::kNone).delta(1.25)).sum(-1).nanmean();       // NeRFExecutor.h:970-974
+		rendered.retain_grad(); weights.retain_grad();
+		lang_loss.backward();
+		save_npy(tag + ".emb", emb); save_npy(tag + ".keep", keep); save_npy(tag + ".z", z); save_npy(tag + ".d", d); save_npy(tag + ".target", target);
+		save_npy(tag + ".dims", torch::tensor({c.geo, c.layers, c.hidden, c.embed, c.in, n, S, c.stride}, torch::kInt32));
+		save_npy(tag + ".weights", weights); save_npy(tag + ".rendered", rendered); save_npy(tag + ".loss", lang_loss.detach().reshape({1}));
+		save_npy(tag + ".sigma_le", raw.index({"...", E}).contiguous());
+		save_npy(tag + ".grad_rendered", rendered.grad()); save_npy(tag + ".grad_weights", weights.grad());
+		save_npy(tag + ".grad_emb", emb.grad());
+		for (auto &p : m->named_parameters())
+		{
+			auto g = p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value());
+			if (c.stride > 1 && g.numel() > 20000) g = g.reshape({-1}).index({Slice(0, None, c.stride)}).contiguous();
+			save_npy(tag + ".grad_" + p.key(), g);
+		}
+	}
+	{
+		// what nanmean does with a ray whose target holds a NaN (a pixel without a CLIP embedding): that ray's term leaves the mean ...
+		const std::string tag = "train_lerf_nan";
+		auto pred = synth_tensor({5, 8}, 97u, 1.0f).set_requires_grad(true);
+		auto target = synth_tensor({5, 8}, 98u, 2.0f);
+		target.index_put_({2, 3}, std::numeric_limits<float>::quiet_NaN());
+		auto loss = torch::nn::functional::huber_loss(pred, target, torch::nn::functional::HuberLossFuncOptions().reduction(torch::kNone).delta(1.25)).sum(-1).nanmean();
+		loss.backward();
+		save_npy(tag + ".pred", pred); save_npy(tag + ".target", target); save_npy(tag + ".loss", loss.detach().reshape({1})); save_npy(tag + ".grad_pred", pred.grad());
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
 // bench: the reference CPU renderer timed on synthetic Lego-shaped rays (cpu_baseline kind "reference")
 // ----------------------------------------------------------------------------------------------
 static int run_bench(int argc, const char **argv)
@@ -945,6 +1016,7 @@ int main(int argc, const char **argv)
 	g_raw2out();
 	g_render();
 	g_train();
+	g_train_lerf();
 	g_tv();
 	g_manifest.close();
 	std::cout << "golden vectors written to " << g_outdir << std::endl;

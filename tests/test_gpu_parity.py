@@ -2832,6 +2832,116 @@ def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manife
     assert r["loss_step2"] < r["loss_step1"]
 
 
+# ------------------------------------------------------------------ N1, LeRF branch of the optimisation step (NeRFExecutor.h:955-982)
+def _lerf_golden_case(tag):
+    from nerfpp_amd.synth import load_manifest
+    from conftest import GOLDEN
+    man = load_manifest(os.path.join(GOLDEN, "manifest.txt"))
+    g = load_golden(tag)
+    geo, layers, hidden, embed, in_ch, n, s, stride = (int(v) for v in g["dims"])
+    blob = synth.blob_from_manifest(man[tag])
+    off, where = 0, {}
+    for name, _, _, shape in man[tag]:
+        where[name] = (off, shape); off += int(np.prod(shape))
+    return dict(geo=geo, n_layers=layers, hidden=hidden, embed=embed, in_ch=in_ch, n=n, s=s, stride=stride), blob, g, where
+
+
+@pytest.mark.parametrize("tag", ["train_lerf", "train_lerf_l3", "train_lerf_main"])
+def test_lerf_training_head_backward_vs_reference_autograd(api, O, tag):
+    """nrf_huber_rows_nanmean + nrf_lerf_head_backward (lerf_train.hip) against LibTorch autograd through the COMPILED LeRFImpl::forward, the compiled RawToOutputs' weights
+    (RawToLEOutputs' expression) and the reference's inline RenderCLIPEmbedding (goldens train_lerf*: two layers, three layers, main.cpp:203-213 dims): loss 2e-6 relative,
+    recomputed forward 1e-4, every gradient within 2e-4 of its tensor's largest entry of the REFERENCE's and within 2e-5 of the oracle's (float atomics in another order)."""
+    from nerfpp_amd import train as T
+    c, blob, g, where = _lerf_golden_case(tag)
+    lerf = api.M.LeRF(c["geo"], c["n_layers"], c["hidden"], c["embed"], c["in_ch"], "lang_model", params=blob)
+    loss, g_r = T.HuberRowsNanmean(dev(g["rendered"]), dev(g["target"]))
+    assert abs(float(host(loss)[0]) - float(g["loss"][0])) <= 2e-6 * abs(float(g["loss"][0]))
+    assert_close(host(g_r), g["grad_rendered"], rtol=1e-5, atol=1e-9, what="d lang_loss / d RenderedLangEmbedding")
+    r = T.LeRFHeadBackward(lerf, dev(g["emb"]), dev(g["keep"].astype(np.uint8)), dev(g["z"]), dev(g["d"]), dev(g["grad_rendered"]))
+    assert_close(host(r["weights"]), g["weights"], rtol=2e-5, atol=2e-7, what="WeightsLE of the recomputed forward")
+    assert_close(host(r["rendered"]), g["rendered"], rtol=1e-4, atol=2e-6, what="RenderedLangEmbedding of the recomputed forward")
+    ref = O.lerf_head_backward(blob, g["emb"], g["keep"], g["z"], g["d"], g["grad_rendered"], in_ch=c["in_ch"], n_layers=c["n_layers"], hidden=c["hidden"], geo=c["geo"], embed=c["embed"])
+    ge = g["grad_emb"]
+    assert_close(host(r["g_emb"]), ge, rtol=0, atol=2e-4 * float(np.abs(ge).max()), what="d loss / d language-grid features vs reference autograd")
+    assert_close(host(r["g_emb"]), ref["g_emb"], rtol=0, atol=2e-5 * float(np.abs(ge).max()), what="... vs oracle")
+    gp = host(r["g_params"])
+    for name, (off, shape) in where.items():
+        gold = g["grad_" + name].reshape(-1)
+        mine = gp[off:off + int(np.prod(shape))]
+        orc = ref["g_params"][off:off + int(np.prod(shape))]
+        assert_close(mine, orc, rtol=0, atol=2e-5 * float(np.abs(orc).max()), what=f"d loss / d {name} vs oracle")
+        if gold.size != mine.size:
+            mine = mine[::c["stride"]]
+        assert_close(mine, gold, rtol=0, atol=2e-4 * float(np.abs(gold).max()), what=f"d loss / d {name} vs reference autograd")
+    # the gradient buffer is ACCUMULATED into (a second call doubles it) and the chunking by whole rays does not change it beyond atomic order
+    # RawNoiseStd > 0: the draws enter sigma before relu / alpha (LeRFRenderer.cpp:50-51) -- against the oracle with the same draws
+    rng = np.random.RandomState(5)
+    noise = rng.randn(c["n"], c["s"]).astype(np.float32)
+    rn = T.LeRFHeadBackward(lerf, dev(g["emb"]), dev(g["keep"].astype(np.uint8)), dev(g["z"]), dev(g["d"]), dev(g["grad_rendered"]), noise=dev(noise), noise_std=0.3)
+    on = O.lerf_head_backward(blob, g["emb"], g["keep"], g["z"], g["d"], g["grad_rendered"], in_ch=c["in_ch"], n_layers=c["n_layers"], hidden=c["hidden"], geo=c["geo"], embed=c["embed"],
+                              noise=noise, noise_std=0.3)
+    assert_close(host(rn["weights"]), on["weights"], rtol=2e-5, atol=2e-7, what="weights with raw noise")
+    assert_close(host(rn["g_params"]), on["g_params"], rtol=0, atol=2e-5 * float(np.abs(on["g_params"]).max()), what="parameter gradients with raw noise")
+    assert np.abs(on["weights"] - ref["weights"]).max() > 1e-3, "the noise case differs from the plain one"
+
+
+def test_lerf_language_loss_nan_target_row_as_libtorch(api):
+    """A ray whose target holds a NaN leaves nanmean's mean; LibTorch's backward leaves NaN at exactly that element of the ray's gradient row, zeros in the rest of the row
+    (golden train_lerf_nan) -- reproduced, not repaired."""
+    from nerfpp_amd import train as T
+    g = load_golden("train_lerf_nan")
+    loss, grad = T.HuberRowsNanmean(dev(g["pred"]), dev(g["target"]))
+    assert abs(float(host(loss)[0]) - float(g["loss"][0])) <= 1e-6 * abs(float(g["loss"][0]))
+    got, ref = host(grad), g["grad_pred"]
+    assert (np.isnan(got) == np.isnan(ref)).all() and np.isnan(ref).sum() == 1
+    ok = ~np.isnan(ref)
+    assert_close(got[ok], ref[ok], rtol=1e-6, atol=0)
+    assert (got[2][~np.isnan(got[2])] == 0).all()
+
+
+def test_lerf_training_step_one_library_call_vs_oracle_and_descends(api, O):
+    """The LeRF half of the train loop body on the library path (LeRFTrainer: fused render -> nrf_huber_rows_nanmean -> nrf_lerf_backward_points -> nrf_adam_step), CuHashEmbedder
+    L16 F8 language grid (T = 2^14) + LeRF 2 x 256 -> 768 at main.cpp:203-213's head sizes, 96 rays x (32 + 32) samples: the table and head gradients of the ONE backward call
+    against the oracle composed stage by stage on the same fine depths (hash_cu -> lerf_head_backward -> hash_cu_backward); five Adam steps lower the loss."""
+    from nerfpp_amd import train as T
+    sc = api.S.make_lerf_scene(log2_t=14, sigma_scale=20.0)
+    r = sc["renderer"]
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = api.R.GetRays(800, 800, K, c2w, row0=400, rows=1)
+    o = o.reshape(-1, 3)[300:396].contiguous(); d = d.reshape(-1, 3)[300:396].contiguous()
+    n, s, ni = o.shape[0], 32, 32
+    p = api.R.NeRFRenderParams(NSamples=s, NImportance=ni, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    rng = np.random.RandomState(11)
+    tgt = rng.randn(n, 768).astype(np.float32); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+    tr = T.LeRFTrainer(r, sc["table"], sc["blob"], learning_rate=2e-3)
+    p1 = __import__("copy").copy(p); p1.KeepIntermediates = True
+    res = r.Render(0, 0, None, p1, rays=(o, d, None))
+    assert r._single_call_ok(p1), "the training render is the library's single call"
+    loss0 = tr.backward(res, dev(tgt), p1)
+    zf = host(res.Extras["z_fine"]); rays = host(res.Extras["rays_flat"])
+    Lv, F, Tt = 16, 8, 14
+    ls = ((1 << Tt) >> 4) << 4
+    li, lsz, bias, mul = np.arange(Lv, dtype=np.int32) * ls, np.full(Lv, ls, np.int32), np.zeros((Lv, 3), np.float32), O.hash_cu_scales(Lv, 16, 1024)
+    pts = O.points(rays[:, :3], rays[:, 3:6], zf).reshape(-1, 3)
+    emb, keep = O.hash_cu(pts, O.f32_to_f16(sc["table"]), sc["primes"], li, lsz, bias, sc["bbox"], mul, Lv, F)
+    fwd = O.lerf_head_backward(sc["blob"], emb, keep, zf, rays[:, 3:6], np.zeros((n, 768), np.float32))          # the oracle's fp32 forward on the same depths
+    rendered = host(res.Outputs.RenderedLangEmbedding).reshape(n, 768)
+    assert ((rendered * fwd["rendered"]).sum(1) > 1 - 2e-6).all(), "fused split-precision render vs the oracle's fp32 forward"
+    _, g_r = O.huber_rows_nanmean(rendered, tgt)
+    ref = O.lerf_head_backward(sc["blob"], emb, keep, zf, rays[:, 3:6], g_r)
+    assert_close(host(tr.g_blob), ref["g_params"], rtol=0, atol=3e-5 * float(np.abs(ref["g_params"]).max()), what="head gradients of nrf_lerf_backward_points vs oracle")
+    gt = O.hash_cu_backward(pts, sc["primes"], li, lsz, bias, sc["bbox"], mul, Lv, F, sc["table"].size, ref["g_emb"])
+    got_t = host(tr.g_table)
+    assert np.abs(gt).max() > 0 and (got_t != 0).sum() > 1000
+    assert_close(got_t, gt, rtol=0, atol=2e-3 * float(np.abs(gt).max()), what="language-grid gradient vs oracle (contributions rounded to fp16 after the x128 scaling, CuHashEmbedder.cu:105-216)")
+    losses = [float(host(loss0)[0])]
+    for _ in range(5):
+        l, _ = tr.step(o, d, dev(tgt), p)
+        losses.append(float(host(l)[0]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[1] < losses[0] * 1.0001, losses
+    tr.close()
+
+
 def test_c_abi_all_gather_at_world_sizes_above_one_with_threads_as_ranks():
     """nrf_comm_create_timeout / nrf_allgather_tiles at world sizes 2-6 on ONE GPU: the ranks are threads of tests/helpers/comm_ranks_as_threads over
     tests/helpers/mock_rccl.cpp, a stand-in for RCCL's entry points (group start / end, ncclAllGather, ncclBroadcast enqueued on the caller's stream) under RCCL's SONAME --

@@ -149,6 +149,63 @@ def test_lerf_head(manifest):
     assert_close(h[:, 0], g["y"][:, 768], rtol=1e-3, atol=2e-7)
 
 
+def lerf_golden_case(tag, manifest):
+    """A train_lerf* golden group -> (dims dict, parameter blob, golden arrays, {parameter name: (offset, shape)} in blob order)."""
+    g = load_golden(tag)
+    geo, layers, hidden, embed, in_ch, n, s, stride = (int(v) for v in g["dims"])
+    blob = synth.blob_from_manifest(manifest[tag])
+    off, where = 0, {}
+    for name, _, _, shape in manifest[tag]:
+        where[name] = (off, shape); off += int(np.prod(shape))
+    return dict(geo=geo, n_layers=layers, hidden=hidden, embed=embed, in_ch=in_ch, n=n, s=s, stride=stride), blob, g, where
+
+
+def check_lerf_param_grads(g_params, g, where, stride, rtol, atol, what):
+    """Every parameter gradient of a train_lerf* golden (the big matrices of the main.cpp-sized group are stored as every `stride`-th element)."""
+    for name, (off, shape) in where.items():
+        mine = g_params[off:off + int(np.prod(shape))]
+        ref = g["grad_" + name]
+        if ref.size != mine.size:
+            mine = mine[::stride]
+        assert_close(mine, ref.reshape(-1), rtol=rtol, atol=atol, what=f"{what}: d loss / d {name}")
+
+
+@pytest.mark.parametrize("tag", ["train_lerf", "train_lerf_l3", "train_lerf_main"])
+def test_lerf_training_branch_vs_reference_autograd(tag, manifest):
+    """N1, LeRF branch (NeRFExecutor.h:955-982).  Goldens: LibTorch autograd through the COMPILED LeRFImpl::forward, the compiled RawToOutputs' weights (the expression of
+    RawToLEOutputs) and the reference's inline RenderCLIPEmbedding, huber(delta 1.25).sum(-1).nanmean().  The oracle's restatement of the loss and of the whole backward
+    (orc_huber_rows_nanmean, orc_lerf_head_backward): forward values to 1e-5, every gradient to 2e-4 of its tensor's largest entry (MKL's sgemm order is not reproduced)."""
+    c, blob, g, where = lerf_golden_case(tag, manifest)
+    loss, g_r = O.huber_rows_nanmean(g["rendered"], g["target"])
+    assert abs(loss - float(g["loss"][0])) <= 2e-6 * abs(float(g["loss"][0]))
+    assert_close(g_r, g["grad_rendered"], rtol=1e-5, atol=1e-9, what="d loss / d rendered")
+    r = O.lerf_head_backward(blob, g["emb"], g["keep"], g["z"], g["d"], g["grad_rendered"], in_ch=c["in_ch"], n_layers=c["n_layers"], hidden=c["hidden"], geo=c["geo"],
+                             embed=c["embed"])
+    assert_close(r["weights"], g["weights"], rtol=2e-5, atol=2e-7, what="WeightsLE")
+    assert_close(r["rendered"], g["rendered"], rtol=1e-4, atol=2e-6, what="RenderedLangEmbedding")
+    ge = g["grad_emb"]
+    assert_close(r["g_emb"], ge, rtol=0, atol=2e-4 * float(np.abs(ge).max()), what="d loss / d embedded features")
+    for name, (off, shape) in where.items():
+        ref = g["grad_" + name]
+        mine = r["g_params"][off:off + int(np.prod(shape))]
+        if ref.size != mine.size:
+            mine = mine[::c["stride"]]
+        assert_close(mine, ref.reshape(-1), rtol=0, atol=2e-4 * float(np.abs(ref).max()), what=f"d loss / d {name}")
+
+
+def test_lerf_language_loss_with_a_nan_target_row():
+    """nanmean drops a ray whose target holds a NaN from the mean (count = the other rays) -- and LibTorch's backward leaves NaN at exactly the NaN elements of that
+    ray's gradient row (0 * NaN), zeros elsewhere in the row: golden train_lerf_nan; the restatement reproduces both."""
+    g = load_golden("train_lerf_nan")
+    loss, grad = O.huber_rows_nanmean(g["pred"], g["target"])
+    assert abs(loss - float(g["loss"][0])) <= 1e-6 * abs(float(g["loss"][0]))
+    ref = g["grad_pred"]
+    assert (np.isnan(grad) == np.isnan(ref)).all() and np.isnan(ref).sum() == 1
+    ok = ~np.isnan(ref)
+    assert_close(grad[ok], ref[ok], rtol=1e-6, atol=0)
+    assert (ref[2][~np.isnan(ref[2])] == 0).all() and (grad[2][~np.isnan(grad[2])] == 0).all()
+
+
 # ------------------------------------------------------------------------------------ compositing
 @pytest.mark.parametrize("S", [64, 192])
 @pytest.mark.parametrize("bg", ["black", "white"])
