@@ -131,6 +131,10 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
         out.append(train_step_measurement(args, scene, L))
     except Exception as e:
         out.append(dict(workload="hashnerf_train_step", error=str(e)))
+    try:
+        out.append(lerf_train_step_measurement(scene, L))
+    except Exception as e:
+        out.append(dict(workload="lerf_train_step", error=str(e)))
     for lp in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA):
         try:
             out.append(lerf_measurement(scene, L, K, c2w, lp))
@@ -243,6 +247,38 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
     except Exception as e:
         rec["oracle_check"] = f"unavailable: {e}"
     return rec
+
+
+def lerf_train_step_measurement(scene, L, n_rand=16384, steps=2):
+    """SURVEY section 8f row N1, LeRF branch (NeRFExecutor.h:955-985): LeRFRenderer->Render on the ray batch (the fused pass) -> lang_loss -> backward into the LeRF head and
+    the F = 8 language grid (ONE library call, fp32 layer kernels on the recomputed forward) -> Adam, at main.cpp:203-213 sizes and N_rand = 32*32*16 rays (main.cpp:232)."""
+    import torch
+    from nerfpp_amd import renderer as R
+    from nerfpp_amd.train import LeRFTrainer
+    sc = scene.make_lerf_scene()
+    K = scene.lego_K(H, W); c2w = scene.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(H, W, K, c2w)
+    idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
+    o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
+    tgt = torch.nn.functional.normalize(torch.randn((n_rand, 768), device="cuda"), dim=-1)
+    p = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=32768, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+    tr = LeRFTrainer(sc["renderer"], sc["table"], sc["blob"], learning_rate=5e-4)
+    try:
+        l0, _ = tr.step(o, d, tgt, p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = [float(l0.item())]
+        for _ in range(steps):
+            l, _ = tr.step(o, d, tgt, p)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        losses.append(float(l.item()))
+    finally:
+        tr.close()
+    return dict(workload="lerf_train_step", baseline_config=5, rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt, value=n_rand * UNITS_PER_RAY / dt,
+                unit="ray-samples/s", steps=steps, loss_first_last=losses,
+                arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated by fp32 layer kernels (no matrix cores yet), language-grid "
+                           "gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):

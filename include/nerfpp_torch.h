@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <mutex>
@@ -493,7 +494,7 @@ class HipLeRFPass {
 public:
 	HipLeRFPass(const HipLeRFPass &) = delete;
 	HipLeRFPass &operator=(const HipLeRFPass &) = delete;
-	~HipLeRFPass() { nrf_lerf_renderer_destroy(Pass); }
+	~HipLeRFPass() { live_renderers().remove(this); nrf_lerf_renderer_destroy(Pass); }
 	bool SingleCall = true;             ///< the pass as library calls (false: stage-composed below, for A/B tests)
 
 	/// LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [P, E] positive and [Q, E] negative phrase embeddings from the host's text encoder; undefined tensors clear them.
@@ -513,7 +514,7 @@ public:
 	}
 
 	/// precision of the fused matrix-core passes: NRF_PREC_F16_SPLIT (fp32-grade, as LeRFImpl::forward computes) or NRF_PREC_F16_MFMA
-	explicit HipLeRFPass(HipHashEmbedder lang_embed_fn, int precision = NRF_PREC_F16_SPLIT) : LangEmbedFn(lang_embed_fn), Precision(precision) {}
+	explicit HipLeRFPass(HipHashEmbedder lang_embed_fn, int precision = NRF_PREC_F16_SPLIT) : LangEmbedFn(lang_embed_fn), Precision(precision) { live_renderers().add(this); }
 
 	int GetLangEmbedDim() const { return Desc.hidden_dim_color; }
 	bool IsFused() const { return Fused; }
@@ -536,7 +537,144 @@ public:
 			PushPrompts();
 		}
 	}
-	template <class TLeRF> void SyncWeights(TLeRF &lerf) { SyncWeights(lerf_desc_of(lerf), parameter_blob(lerf)); }
+	template <class TLeRF> void SyncWeights(TLeRF &lerf)
+	{
+		SyncWeights(lerf_desc_of(lerf), parameter_blob(lerf));
+		// the module's parameters as one blob in named_parameters() order (== the head's blob layout), still attached to them: a gradient w.r.t. this tensor reaches every
+		// Linear weight through torch::cat's backward; and their version counters / storage addresses, so that an optimizer step is noticed without a call from the host
+		BlobForGradFn = [lerf]() mutable { std::vector<torch::Tensor> flat; for (auto &p : lerf->named_parameters()) flat.push_back(p.value().reshape({-1})); return torch::cat(flat, 0); };
+		HeadSignatureFn = [lerf]() mutable {
+			uint64_t sig = 1469598103934665603ull;
+			for (auto &p : lerf->parameters()) { sig = (sig ^ (uint64_t)p._version()) * 1099511628211ull; sig = (sig ^ (uint64_t)(uintptr_t)p.data_ptr()) * 1099511628211ull; }
+			return sig;
+		};
+		HeadRequiresGradFn = [lerf]() mutable { for (auto &p : lerf->parameters()) if (p.requires_grad()) return true; return false; };
+		HeadSignature = HeadSignatureFn();
+	}
+
+	// ---- the training render: LeRFRenderer::Render on a RAY BATCH as ONE autograd node (NeRFExecutor.h:955-982: Render -> huber(...).sum(-1).nanmean() -> lang_loss.backward()) ----
+	std::function<torch::Tensor()> BlobForGradFn;
+	std::function<uint64_t()> HeadSignatureFn;
+	std::function<bool()> HeadRequiresGradFn;
+	uint64_t HeadSignature = 0;
+	torch::Tensor LastFineDepths, LastRays;      ///< of the most recent training render: z_vals of the fine pass [n, S + N_importance] and the packed rays [n, 8 | 11]
+	bool WantsGrad() { return torch::GradMode::is_enabled() && ((HeadRequiresGradFn && HeadRequiresGradFn()) || LangEmbedFn->AnyRequiresGrad()); }
+	/// Upload the head's parameters / the language table when they changed since the last upload (an optimizer step over the module's own parameters, torch::load, copy_)
+	void SyncIfChanged()
+	{
+		if (HeadSignatureFn) {
+			const uint64_t sig = HeadSignatureFn();
+			if (sig != HeadSignature) {
+				torch::NoGradGuard ng;
+				auto blob = dev_f32(BlobForGradFn().to(torch::kCUDA));
+				check(nrf_mlp_set_params(Mlp.m, blob.data_ptr<float>(), 1, current_stream()), "nrf_mlp_set_params");
+				if (Fused) check(nrf_lerf_set_precision(Mlp.m, Precision), "nrf_lerf_set_precision");
+				HeadSignature = sig;
+			}
+		}
+		LangEmbedFn->SyncIfChanged();
+	}
+
+	/// forward: the library's Chunk loop over the packed rays (nrf_lerf_batchify_rays: the fused matrix-core passes, raw_le never formed) keeping the fine depths;
+	/// backward: ONE library call (nrf_lerf_backward_points: language-grid encode, the head's recomputed fp32 forward and backward, the grid's scatter) w.r.t. the language
+	/// table and the head's parameter blob.  Gradients flow from RenderedLangEmbedding only (what lang_loss reads, NeRFExecutor.h:970-974); z_samples are detached
+	/// (LeRFRenderer.cpp:150), so the coarse pass carries none.
+	struct LeRFRenderFn : public torch::autograd::Function<LeRFRenderFn> {
+		static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, torch::Tensor rays_, torch::Tensor table, torch::Tensor blob, int64_t self_i, int64_t s,
+			int64_t ni, int64_t chunk, bool lin_disp)
+		{
+			auto *self = reinterpret_cast<HipLeRFPass *>(self_i);
+			const int64_t n = rays_.size(0); const int stride = (int)rays_.size(1);
+			const auto opt = rays_.options();
+			LeRFPassOutputs out; nrf_lerf_outputs ro{}; torch::Tensor zf;
+			self->alloc_outputs(n, (int)(s + ni), true, opt, out, ro, &zf);
+			nrf_render_params p = self->pass_params((int)s, (int)ni, lin_disp);
+			if (n > 0) {
+				const size_t wsb = nrf_lerf_batchify_rays_workspace_bytes(self->Pass, n, (int)chunk, &p);
+				check(nrf_lerf_batchify_rays(self->Pass, rays_.data_ptr<float>(), stride, n, (int)chunk, &p, self->linspace01((int)s, rays_.device()).template data_ptr<float>(),
+					self->linspace01((int)ni, rays_.device()).template data_ptr<float>(), &ro, self->workspace(wsb, rays_.device()), wsb, current_stream()), "nrf_lerf_batchify_rays");
+			}
+			ctx->save_for_backward({rays_, zf});
+			ctx->saved_data["self"] = self_i;
+			ctx->saved_data["table_sizes"] = table.sizes().vec();
+			ctx->saved_data["blob_numel"] = blob.numel();
+			std::vector<torch::Tensor> nd{out.WeightsLE, out.DepthMapLE, out.DispMapLE, out.AccMapLE, zf};
+			if (out.Relevancy.defined()) nd.push_back(out.Relevancy);
+			ctx->mark_non_differentiable(nd);
+			return {out.RenderedLangEmbedding, out.WeightsLE, out.DepthMapLE, out.DispMapLE, out.AccMapLE, out.Relevancy.defined() ? out.Relevancy : torch::empty({0}, opt), zf};
+		}
+		static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx, torch::autograd::variable_list grads)
+		{
+			auto &sd = ctx->saved_data;
+			const int64_t self_i = sd["self"].toInt();
+			TORCH_CHECK(self_i != 0 && live_renderers().alive(reinterpret_cast<const void *>(self_i)), "HipLeRFPass: backward through a Render() whose pass has been destroyed");
+			auto *self = reinterpret_cast<HipLeRFPass *>(self_i);
+			auto saved = ctx->get_saved_variables();
+			auto rays = saved[0], z = saved[1];
+			const int64_t n = rays.size(0); const int stride = (int)rays.size(1), s = (int)z.size(1);
+			const auto opt = rays.options();
+			auto g_table = torch::zeros(sd["table_sizes"].toIntVector(), opt), g_blob = torch::zeros({sd["blob_numel"].toInt()}, opt);
+			if (n > 0 && grads[0].defined()) {
+				auto g = dev_f32(grads[0]).reshape({n, -1});
+				auto pts = torch::empty({n * s, 3}, opt);
+				check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
+				const size_t wsb = nrf_lerf_backward_points_workspace_bytes(self->Pass, n, s);
+				auto ws = torch::empty({(int64_t)wsb}, opt.dtype(torch::kUInt8));          // not the pass's render workspace: a backward may run while another render is being issued
+				check(nrf_lerf_backward_points(self->Pass, pts.data_ptr<float>(), z.data_ptr<float>(), rays.data_ptr<float>() + 3, stride, n, s, nullptr, 0.f, g.data_ptr<float>(),
+					g_blob.data_ptr<float>(), g_table.data_ptr<float>(), ws.data_ptr(), wsb, current_stream()), "nrf_lerf_backward_points");
+			}
+			return {torch::Tensor(), g_table, g_blob, torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+		}
+	};
+
+	/// LeRFRenderer::Render (LeRFRenderer.cpp:265-330) on an explicit ray batch, deterministic settings (ThinRay, Perturb = RawNoiseStd = StochasticPreconditioningAlpha = 0):
+	/// AABB clipping and packing, then the Chunk loop.  With grad mode on and parameters that require grad the result is differentiable (LeRFRenderFn); the head's and the
+	/// table's current values are picked up by themselves (SyncIfChanged).
+	LeRFPassOutputs RenderBatch(torch::Tensor rays_o, torch::Tensor rays_d, torch::Tensor bounding_box, const int n_samples, const int n_importance, const int chunk,
+		const bool lin_disp = false, const bool return_weights = true, float *near_out = nullptr, float *far_out = nullptr)
+	{
+		auto o = dev_f32(rays_o).reshape({-1, 3}).contiguous(), d = dev_f32(rays_d).reshape({-1, 3}).contiguous();
+		const int64_t n = o.size(0);
+		const int stride = 8;                                                   // LeRFRenderer::Render packs [o, d, near, far] only (LeRFRenderer.cpp:298)
+		auto bb = host_floats(bounding_box);
+		TORCH_CHECK(bb.size() == 6, "RenderBatch: bounding_box must hold [min xyz, max xyz]");
+		auto rays_ = torch::empty({n, stride}, o.options());
+		if (n > 0) check(nrf_pack_rays(o.data_ptr<float>(), d.data_ptr<float>(), bb.data(), n, 0, rays_.data_ptr<float>(), current_stream()), "nrf_pack_rays");
+		const bool train = WantsGrad();
+		LangEmbedFn->SetTraining(train);
+		SyncIfChanged();
+		LeRFPassOutputs out;
+		if (train) {
+			TORCH_CHECK(SingleCallOk(n_samples, n_importance) && BlobForGradFn, "training through HipLeRFPass needs the library path (CuHashEmbedder L16 F8 language grid, a head of the "
+				"built family, hierarchical sampling with sample counts in multiples of 32) and SyncWeights(lerf module)");
+			auto r = LeRFRenderFn::apply(rays_, LangEmbedFn->TableForGrad(), BlobForGradFn(), (int64_t)reinterpret_cast<intptr_t>(this), (int64_t)n_samples, (int64_t)n_importance,
+				(int64_t)chunk, lin_disp);
+			out.RenderedLangEmbedding = r[0]; out.WeightsLE = r[1]; out.DepthMapLE = r[2]; out.DispMapLE = r[3]; out.AccMapLE = r[4];
+			if (r[5].numel()) out.Relevancy = r[5];
+			LastFineDepths = r[6]; LastRays = rays_;
+			if (!return_weights) { out.WeightsLE = torch::Tensor(); out.RenderedLangEmbedding = torch::Tensor(); }      // LeRFRenderer.cpp:180-185
+		} else {
+			std::vector<torch::Tensor> e, w_, dep, disp, acc, rel;
+			for (int64_t i = 0; i < n; i += chunk) {
+				auto part = RenderRays(rays_.index({torch::indexing::Slice(i, std::min<int64_t>(i + chunk, n))}), n_samples, lin_disp, n_importance, return_weights);
+				if (part.RenderedLangEmbedding.defined()) e.push_back(part.RenderedLangEmbedding);
+				if (part.WeightsLE.defined()) w_.push_back(part.WeightsLE);
+				if (part.Relevancy.defined()) rel.push_back(part.Relevancy);
+				dep.push_back(part.DepthMapLE); disp.push_back(part.DispMapLE); acc.push_back(part.AccMapLE);
+			}
+			if (!e.empty()) out.RenderedLangEmbedding = torch::cat(e, 0);
+			if (!w_.empty()) out.WeightsLE = torch::cat(w_, 0);
+			if (!rel.empty()) out.Relevancy = torch::cat(rel, 0);
+			if (!dep.empty()) { out.DepthMapLE = torch::cat(dep, 0); out.DispMapLE = torch::cat(disp, 0); out.AccMapLE = torch::cat(acc, 0); }
+		}
+		if ((near_out || far_out) && n > 0) {
+			float nr = 0.f, fr = 0.f;
+			check(nrf_near_far_range(rays_.data_ptr<float>(), n, stride, &nr, &fr, current_stream()), "nrf_near_far_range");          // LeRFRenderer.cpp:327-328
+			if (near_out) *near_out = nr;
+			if (far_out) *far_out = fr;
+		}
+		return out;
+	}
 
 	/// LeRFRenderer::RunLENetwork (LeRFRenderer.cpp:5-25): [N,S,3] -> [N,S,E+1] in fp32, sigma_le zeroed where the embedder's keep_mask is false
 	torch::Tensor RunLENetwork(torch::Tensor inputs)
@@ -1337,6 +1475,22 @@ public:
 		const NeRFRenderParams &p = render_params;
 		const bool rng = p.Perturb > 0.f || p.RawNoiseStd > 0.f || p.StochasticPreconditioningAlpha > 0.f || !p.ThinRay;
 		const bool pose = c2w.defined() && c2w.numel() != 0 && !(c2w_staticcam.defined() && c2w_staticcam.numel() != 0);
+		const bool batch = !(c2w.defined() && c2w.numel() != 0) && std::get<0>(rays).defined() && std::get<0>(rays).numel() != 0;
+		if (!rng && batch && !p.ReturnRaw && !p.Ndc && p.NImportance > 0 && p.NSamples % 32 == 0 && (p.NSamples + p.NImportance) % 32 == 0) {
+			// the TRAINING render (NeRFExecutor.h:958-961: a ray batch): the library's Chunk loop; with grad mode on one autograd node whose backward reaches Lerf's
+			// parameters and the language grid's table (HipLeRFPass::LeRFRenderFn), so `lang_loss.backward()` (:981) works on the drop-in as on the reference
+			SyncPrompts();
+			LeRFRenderResult res;
+			auto sh = std::get<1>(rays).sizes().vec();
+			res.Outputs = to_ref(Pass.RenderBatch(std::get<0>(rays), std::get<1>(rays), p.BoundingBox, p.NSamples, p.NImportance, p.Chunk, p.LinDisp, p.ReturnWeights, &res.Near, &res.Far));
+			if (sh.size() > 2) {                                                  // LeRFRenderer.cpp:311-319
+				if (res.Outputs.DispMapLE.defined()) res.Outputs.DispMapLE = res.Outputs.DispMapLE.reshape({sh[0], sh[1]});
+				if (res.Outputs.DepthMapLE.defined()) res.Outputs.DepthMapLE = res.Outputs.DepthMapLE.reshape({sh[0], sh[1]});
+				if (res.Outputs.RenderedLangEmbedding.defined()) res.Outputs.RenderedLangEmbedding = res.Outputs.RenderedLangEmbedding.reshape({sh[0], sh[1], -1});
+				if (res.Outputs.Relevancy.defined() && res.Outputs.Relevancy.numel() != 0) res.Outputs.Relevancy = res.Outputs.Relevancy.reshape({sh[0], sh[1], 2});
+			}
+			return res;
+		}
 		if (rng || p.ReturnRaw || p.Ndc || !pose || p.NImportance <= 0 || p.NSamples % 32 || (p.NSamples + p.NImportance) % 32)
 			return LeRFRenderer::Render(h, w, k, render_params, rays, c2w, c2w_staticcam);
 		SyncPrompts();

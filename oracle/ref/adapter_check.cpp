@@ -21,6 +21,7 @@
 
 #include <cstdio>
 #include <iostream>
+#include <sstream>
 #include <unistd.h>
 
 using torch::indexing::Slice;
@@ -170,6 +171,166 @@ static int run_train(const std::string &dir)
 	} catch (const std::exception &ex) { note = ex.what(); for (auto &ch : note) if (ch == '"' || ch == '\n') ch = ' '; note = note.substr(0, 400); }
 	printf("{\"train_ok\": %s, \"loss_step1\": %.9g, \"loss_step2\": %.9g, \"inference_after_steps_sees_updated_parameters\": %s, \"standalone_embedder_autograd_ok\": %s, \"note\": \"%s\"}\n",
 		ok ? "true" : "false", loss1, loss2, inference_sees_updates ? "true" : "false", standalone_embedder_grad_ok ? "true" : "false", note.c_str());
+	fflush(stdout);
+	return ok ? 0 : 1;
+}
+
+// adapter_check train_lerf: the LeRF branch of NeRFExecutor::Train's loop body (NeRFExecutor.h:955-982) on the drop-in.
+//   * `LeRFRenderer` below is what nrfpp::HipLeRFRenderer::Render forwards a ray batch to (HipLeRFPass::RenderBatch) behind LeRFRenderer::Render's own signature -- the
+//     subclass itself cannot be linked here (its base class's unit includes RuCLIP's header); the statements between the markers are the reference's, verbatim.
+//   * the gradients that `lang_loss.backward()` leaves on the module's own parameters are compared with REFERENCE AUTOGRAD on the same fine depths: the compiled
+//     LeRFImpl::forward (LibTorch, on the GPU) on the language grid's features -> sigma mask -> the compiled RawToOutputs' weights (RawToLEOutputs' expression) -> the
+//     reference's inline RenderCLIPEmbedding -> the same loss.  (The language grid is CUDA-only in the reference: both sides use HipHashEmbedder's autograd function.)
+//   * three optimizer steps over the modules' own parameters lower the loss; the test-time render that follows sees the stepped parameters.
+using ClassicModel = NeRF;                 // (inside a NeRFRenderer subclass the name NeRF is the base's data member)
+using ClassicRendererBase = NeRFRenderer<Embedder, Embedder, ClassicModel>;
+struct OpenRawToOutputs : public ClassicRendererBase {
+	OpenRawToOutputs(Embedder e, Embedder d, ClassicModel m) : ClassicRendererBase(e, d, m) {}
+	NeRFRendererOutputs Open(torch::Tensor raw, torch::Tensor z, torch::Tensor d) { return ClassicRendererBase::RawToOutputs(raw, torch::Tensor(), z, d, 0.f, false); }
+};
+
+struct LeRFTrainRenderer {                 // LeRFRenderer::Render's signature (LeRFRenderer.h:125-132) in front of the pass HipLeRFRenderer forwards to
+	nrfpp::HipLeRFPass &Pass;
+	struct Result { nrfpp::LeRFPassOutputs Outputs; torch::Tensor Raw; float Near = 0.f, Far = 0.f; };
+	Result Render(const int h, const int w, torch::Tensor k, const NeRFRenderParams &p, std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> rays, torch::Tensor c2w, torch::Tensor c2w_staticcam)
+	{
+		Result r;
+		r.Outputs = Pass.RenderBatch(std::get<0>(rays), std::get<1>(rays), p.BoundingBox, p.NSamples, p.NImportance, p.Chunk, p.LinDisp, p.ReturnWeights, &r.Near, &r.Far);
+		return r;
+	}
+	LeRFTrainRenderer *operator->() { return this; }
+};
+
+static int run_train_lerf()
+{
+	if (!torch::cuda::is_available()) { printf("{\"train_lerf_ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
+	std::string note = "ok";
+	bool ok = false, inference_sees_updates = false, grads_ok = false;
+	float losses[4] = {0.f, 0.f, 0.f, 0.f};
+	double worst_rel = 0.0, table_rel = 0.0, rendered_cos_min = 0.0;
+	std::string worst_name;
+	try {
+		auto bbox = torch::tensor({-1.5f, -1.5f, -1.5f, 1.5f, 1.5f, 1.5f});
+		const int LL = 16, LF = 8, LT = 14, ns = 32, ni = 32, nrays = 160;
+		nrfpp::HipHashEmbedder le("lang_embedder", bbox, LL, LF, LT, 16, 256, NRF_HASH_CU);
+		{
+			torch::NoGradGuard ng;
+			fill_synth(le->Embeddings.data(), 311u, 0.5f);
+			std::vector<int32_t> pr;
+			for (int32_t c = 268435459; (int)pr.size() < 3 * LL; c += 2) { bool is_p = true; for (int32_t q = 3; (int64_t)q * q <= c; q += 2) if (c % q == 0) { is_p = false; break; } if (is_p) pr.push_back(c); }
+			le->SetPrimes(torch::from_blob(pr.data(), {LL, 1, 3}, torch::kInt32).clone());
+		}
+		le->Initialize();
+		LeRF lerf(32, 2, 256, 768, LL * LF, "lang_model");
+		{
+			torch::NoGradGuard ng;
+			int k = 0;
+			for (auto &p : lerf->named_parameters()) {
+				auto t = p.value();
+				float amp = 1.6f * std::sqrt(6.0f / float(t.size(0) + t.size(1)));
+				if (p.key().find("sigma_le_net_1") != std::string::npos) amp *= 20.0f;
+				fill_synth(t, 8000u + 1000u * (k++), amp);
+			}
+		}
+		lerf->to(torch::kCUDA);
+		nrfpp::HipLeRFPass pass(le, NRF_PREC_F16_SPLIT);
+		pass.SyncWeights(lerf);                              // once, at construction; never again below
+		LeRFTrainRenderer LeRFRenderer{pass};
+		// the batch (dataset.get_batch): rays of a Lego-shaped camera, target CLIP embeddings of unit norm
+		auto [ro, rd, cone] = GetRays(40, 40, lego_K(40, 40), orbit_pose(30.f, -30.f, 4.f));
+		auto idx = torch::arange(0, nrays, torch::kLong) * (1600 / nrays);
+		struct { struct { torch::Tensor rays_o, rays_d, cone_angle; } data; struct { torch::Tensor target_lang_embedding; } target; } batch;
+		batch.data.rays_o = ro.reshape({-1, 3}).index_select(0, idx).contiguous().cuda(); batch.data.rays_d = rd.reshape({-1, 3}).index_select(0, idx).contiguous().cuda();
+		batch.data.cone_angle = torch::Tensor();             // thin rays
+		torch::manual_seed(77);
+		batch.target.target_lang_embedding = torch::nn::functional::normalize(torch::randn({nrays, 768}), torch::nn::functional::NormalizeFuncOptions().dim(-1)).cuda();
+		std::vector<torch::Tensor> grad_vars;                // NeRFExecutor.h:508-535: the executor's one optimizer over every module's parameters
+		for (auto &p : le->parameters()) grad_vars.push_back(p);
+		for (auto &p : lerf->parameters()) grad_vars.push_back(p);
+		auto Optimizer = std::make_unique<torch::optim::Adam>(grad_vars, torch::optim::AdamOptions(2e-3).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));      // :539
+		auto render_params = std::make_unique<NeRFRenderParams>();
+		render_params->NSamples = ns; render_params->NImportance = ni; render_params->Chunk = 4096; render_params->ReturnRaw = false; render_params->LinDisp = false;
+		render_params->Perturb = 0.f; render_params->RawNoiseStd = 0.f; render_params->Ndc = false; render_params->UseViewdirs = false; render_params->ReturnWeights = true;
+		render_params->ThinRay = true; render_params->RenderFactor = 0; render_params->BoundingBox = bbox.cuda(); render_params->StochasticPreconditioningAlpha = 0.f;
+		torch::Tensor loss = torch::full({1}, 0.f).cuda();
+		std::streambuf *cout_buf = std::cout.rdbuf();
+		std::ostringstream sink;
+		for (int i = 1; i <= 3; i++) {
+			Optimizer->zero_grad();                                                                               // :866
+			std::cout.rdbuf(sink.rdbuf());                                                                        // the loop prints lang_loss (:980)
+			// ---- NeRFExecutor.h:958-981, verbatim ----
+			auto lerf_render_result = std::move(LeRFRenderer->Render(0, 0, torch::Tensor(),/*либо rays либо data.H, data.W, data.K,*/
+				*render_params, { batch.data.rays_o, batch.data.rays_d, batch.data.cone_angle }, torch::Tensor(), torch::Tensor()				/*либо rays либо pose c2w*/
+			));
+			torch::Tensor lang_loss;
+			lang_loss = torch::nn::functional::huber_loss(
+					lerf_render_result.Outputs.RenderedLangEmbedding.to(loss.device()),
+					batch.target.target_lang_embedding.detach().to(loss.device()),	//target clip embeddings provided by PyramidEmbedder for a given set of pixels
+					torch::nn::functional::HuberLossFuncOptions().reduction(torch::kNone).delta(1.25)
+				).sum(-1).nanmean();
+			std::cout<<"lang_loss: " << lang_loss << std::endl;
+			lang_loss.backward();
+			// ---- end of the reference's statements ----
+			std::cout.rdbuf(cout_buf);
+			losses[i] = lang_loss.item<float>();
+			if (i == 1) {
+				// reference autograd on the same fine depths
+				auto rays_ = pass.LastRays.detach(); auto zf = pass.LastFineDepths.detach();
+				std::vector<torch::Tensor> got;
+				for (auto &p : le->parameters()) got.push_back(p.grad().clone());
+				for (auto &p : lerf->parameters()) got.push_back(p.grad().clone());
+				Optimizer->zero_grad();
+				auto pts = rays_.index({Slice(), None, Slice(0, 3)}) + rays_.index({Slice(), None, Slice(3, 6)}) * zf.index({Slice(), Slice(), None});
+				auto [emb, keep] = le->forward(pts.reshape({-1, 3}));                          // HipHashEmbedderFunction (CuHashEmbedderFunction's counterpart)
+				auto outputs_flat = lerf->forward(emb);                                          // the compiled LeRFImpl::forward, LibTorch on the GPU
+				outputs_flat.index_put_({~keep, -1}, 0);                                         // LeRFRenderer.cpp:37-38
+				auto raw = outputs_flat.view({nrays, ns + ni, 769});
+				Embedder e0("e", 2), ed0("ed", 2);
+				NeRF m0(2, 8, 15, 15, 4, std::set<int>{}, true, "model");
+				OpenRawToOutputs open(e0, ed0, m0);
+				auto raw4 = torch::cat({torch::zeros({nrays, ns + ni, 3}, raw.options()), raw.index({"...", Slice(768, 769)})}, -1);
+				auto weights = open.Open(raw4, zf, rays_.index({Slice(), Slice(3, 6)})).Weights;  // == RawToLEOutputs' WeightsLE (LeRFRenderer.cpp:38-66)
+				auto rendered = RenderCLIPEmbedding(raw.index({"...", Slice(0, 768)}), weights.unsqueeze(-1));
+				auto ref_loss = torch::nn::functional::huber_loss(rendered, batch.target.target_lang_embedding.detach(),
+					torch::nn::functional::HuberLossFuncOptions().reduction(torch::kNone).delta(1.25)).sum(-1).nanmean();
+				ref_loss.backward();
+				auto hit = lerf_render_result.Outputs.AccMapLE.detach() > 1e-2f;                      // a ray that misses the box renders the zero vector on both sides
+				auto cosv = (rendered.detach() * lerf_render_result.Outputs.RenderedLangEmbedding.detach()).sum(-1).index({hit});
+				rendered_cos_min = cosv.numel() > nrays / 8 ? cosv.min().item<double>() : 0.0;
+				size_t gi = 0;
+				grads_ok = std::abs(ref_loss.item<float>() - losses[1]) <= 1e-5f * std::abs(losses[1]);
+				auto cmp = [&](const std::string &name, torch::Tensor want, double bar) {
+					auto a = got[gi++].to(torch::kFloat64), b = want.to(torch::kFloat64);
+					const double nb = b.norm().item<double>(), err = (a - b).norm().item<double>();
+					const double rel = err / (nb + 1e-30);
+					if (name.find("embeddings") != std::string::npos) table_rel = rel; else if (rel > worst_rel) { worst_rel = rel; worst_name = name; }
+					if (!(rel <= bar) || !torch::isfinite(a).all().item<bool>() || nb == 0.0) grads_ok = false;
+				};
+				for (auto &p : le->named_parameters()) cmp(p.key(), p.value().grad(), 2e-2);     // the grid's contributions are rounded to fp16 (x128) per call: ray-presummed here, per point there
+				for (auto &p : lerf->named_parameters()) cmp(p.key(), p.value().grad(), 2e-3);
+				// put the drop-in's own gradients back: the step below is the loop's
+				gi = 0;
+				for (auto &p : le->parameters()) p.mutable_grad() = got[gi++];
+				for (auto &p : lerf->parameters()) p.mutable_grad() = got[gi++];
+			}
+			Optimizer->step();                                                                                    // :985
+		}
+		{
+			torch::NoGradGuard ng;
+			auto after = LeRFRenderer->Render(0, 0, torch::Tensor(), *render_params, { batch.data.rays_o, batch.data.rays_d, batch.data.cone_angle }, torch::Tensor(), torch::Tensor());
+			nrfpp::HipHashEmbedder le2("lang_embedder", bbox, LL, LF, LT, 16, 256, NRF_HASH_CU);
+			le2->Embeddings.copy_(le->Embeddings); le2->SetPrimes(le->Primes); le2->Initialize();
+			nrfpp::HipLeRFPass fresh(le2, NRF_PREC_F16_SPLIT);
+			fresh.SyncWeights(lerf);
+			auto want = fresh.RenderBatch(batch.data.rays_o, batch.data.rays_d, bbox.cuda(), ns, ni, 4096);
+			inference_sees_updates = torch::equal(after.Outputs.RenderedLangEmbedding, want.RenderedLangEmbedding) && !after.Outputs.RenderedLangEmbedding.requires_grad();
+		}
+		ok = grads_ok && inference_sees_updates && std::isfinite(losses[3]) && losses[3] < losses[2] && losses[2] < losses[1] && rendered_cos_min > 1.0 - 2e-6;
+	} catch (const std::exception &ex) { note = ex.what(); for (auto &ch : note) if (ch == '"' || ch == '\n') ch = ' '; note = note.substr(0, 400); }
+	printf("{\"train_lerf_ok\": %s, \"lang_loss_steps\": [%.9g, %.9g, %.9g], \"gradients_vs_reference_autograd_ok\": %s, \"head_gradient_worst_rel_err\": %.3e, \"worst\": \"%s\", "
+		"\"language_table_gradient_rel_err\": %.3e, \"rendered_embedding_cos_min_vs_reference_forward\": %.9f, \"inference_after_steps_sees_updated_parameters\": %s, \"note\": \"%s\"}\n",
+		ok ? "true" : "false", losses[1], losses[2], losses[3], grads_ok ? "true" : "false", worst_rel, worst_name.c_str(), table_rel, rendered_cos_min,
+		inference_sees_updates ? "true" : "false", note.c_str());
 	fflush(stdout);
 	return ok ? 0 : 1;
 }
@@ -347,6 +508,7 @@ int main(int argc, const char **argv)
 	if (argc > 2 && std::string(argv[1]) == "trainfuzz") return run_trainfuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "fuzz") return run_fuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "train") return run_train(argv[2]);
+	if (argc > 1 && std::string(argv[1]) == "train_lerf") return run_train_lerf();
 	const int h = argc > 1 ? atoi(argv[1]) : 16, w = argc > 2 ? atoi(argv[2]) : 16;
 	if (!torch::cuda::is_available()) { printf("{\"ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
 	std::streambuf *cout_buf = std::cout.rdbuf();

@@ -2942,6 +2942,28 @@ def test_lerf_training_step_one_library_call_vs_oracle_and_descends(api, O):
     tr.close()
 
 
+def test_reference_lerf_train_loop_body_runs_through_the_hip_drop_in():
+    """The LeRF half of NeRFExecutor::Train's loop body (NeRFExecutor.h:955-982) on the drop-in: oracle/_ref/adapter_check `train_lerf` executes the reference's statements
+    verbatim -- LeRFRenderer->Render on the ray batch, huber_loss(..., reduction none, delta 1.25).sum(-1).nanmean(), lang_loss.backward(), Optimizer->step() -- with what
+    nrfpp::HipLeRFRenderer::Render forwards a ray batch to (HipLeRFPass::RenderBatch: ONE autograd node, LeRFRenderFn) in the renderer's place and torch::optim::Adam over
+    the modules' own parameters.  In the same binary the gradients left on those parameters are compared with REFERENCE AUTOGRAD on the same fine depths (the compiled
+    LeRFImpl::forward on the GPU, the compiled RawToOutputs' weights, the reference's inline RenderCLIPEmbedding): head 2e-3, language table 2e-2 norm-wise; the loss falls
+    over three steps and the test-time render afterwards sees the stepped parameters without any call into this repo's classes."""
+    import json, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, "train_lerf"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert out.returncode == 0 and r["train_lerf_ok"], (r, out.stderr[-1500:])
+    assert r["gradients_vs_reference_autograd_ok"] and r["inference_after_steps_sees_updated_parameters"], r
+    l = r["lang_loss_steps"]
+    assert l[2] < l[1] < l[0] and r["head_gradient_worst_rel_err"] < 2e-3 and r["language_table_gradient_rel_err"] < 2e-2 and r["rendered_embedding_cos_min_vs_reference_forward"] > 1 - 2e-6, r
+
+
 def test_c_abi_all_gather_at_world_sizes_above_one_with_threads_as_ranks():
     """nrf_comm_create_timeout / nrf_allgather_tiles at world sizes 2-6 on ONE GPU: the ranks are threads of tests/helpers/comm_ranks_as_threads over
     tests/helpers/mock_rccl.cpp, a stand-in for RCCL's entry points (group start / end, ncclAllGather, ncclBroadcast enqueued on the caller's stream) under RCCL's SONAME --
