@@ -175,6 +175,65 @@ __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const Poin
     return __halves2half2(__float2half_rn(acc[0]), __float2half_rn(acc[1]));
 }
 
+// ---- the baked lookup of SEVERAL levels as straight-line code (round 5) ----
+// encode_level above decides per level, at run time, between the baked image and the hashed table and between 32- and 64-bit addressing: two wave-uniform branches per
+// level, i.e. every level is its own basic block -- its two 16-byte loads are issued, ~20 weight instructions later they are waited for, and nothing of the next level
+// can start before.  A thread's levels ran one after the other and the only memory-level parallelism was the SIMD's other waves (2 loads x 8 waves in flight).  When the
+// HOST knows that every level of a launch is baked and below 4 GB (hash_fast_prepare's layout; the render path always), the kernel instance below has no such branches:
+// the loads of BATCH levels are issued back to back, then their blends follow -- BATCH x 2 loads per wave in flight, same arithmetic, same bits.
+struct DenseAddr { uint32_t o0, o1; };
+
+__device__ __forceinline__ void dense_level_issue(const HashParams &hp, const PointPrep &pp, int l, float q[3], uint32_t &off0, uint32_t &off1, __amdgpu_buffer_rsrc_t &lr)
+{
+    const float mul = hp.level_scale[l];
+    uint32_t pos[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { q[a] = pp.q[a] * mul; pos[a] = (uint32_t)q[a]; }
+    const uint32_t nby = (uint32_t)hp.dense_nby[l], dz = (uint32_t)hp.dense_nbz[l];
+    const uint32_t x0 = pos[0], y0 = pos[1], y1 = pos[1] + 1u, z = pos[2];
+    // tile indices stay below 2^24 (checked on the host with the 4 GB bound): the 24-bit multiply is a full-rate instruction, v_mul_lo_u32 is not
+    auto mul24 = [](uint32_t v, uint32_t s_uniform) {
+        uint32_t r;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(s_uniform), "v"(v));       // inputs: an integer shift / add result and a scalar: no matrix / packed / transcendental producer
+        return r;
+    };
+    const uint32_t tx0 = mul24(x0 >> 2, nby), ty0 = y0 >> 2, ty1 = y1 >> 2;
+    const uint32_t ix0 = (x0 & 3u) << 2, iy0 = y0 & 3u, iy1 = y1 & 3u;
+    const uint32_t i0 = ((mul24(tx0 + ty0, dz) + z) << 4) | ix0 | iy0;
+    const uint32_t i1 = ((mul24(tx0 + ty1, dz) + z) << 4) | ix0 | iy1;
+    off0 = i0 << 4; off1 = i1 << 4;
+    lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(reinterpret_cast<const uint4 *>(hp.dense) + hp.dense_off[l]), 0, -1, 0x00020000);
+}
+
+typedef uint32_t hf_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __half2 dense_level_blend(const float q[3], const hf_u32x4 q0, const hf_u32x4 q1)
+{
+    const float a = __builtin_amdgcn_fractf(q[0]), b = __builtin_amdgcn_fractf(q[1]), c = __builtin_amdgcn_fractf(q[2]);
+    const float oma = 1.0f - a, omb = 1.0f - b, omc = 1.0f - c;
+    const uint32_t wv[8] = {q0.x, q0.y, q1.x, q1.y, q0.z, q0.w, q1.z, q1.w};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float ws[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float wx = (k & 4) ? a : oma, wy = (k & 2) ? b : omb, wz = (k & 1) ? c : omc;
+        ws[k] = wx * wy * wz;
+    }
+    f32x2 pr[8];
+    const float negzero = -0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        float p0, p1;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p0) : "v"(wv[k]), "v"(ws[k]), "s"(negzero));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(wv[k]), "v"(ws[k]), "s"(negzero));
+        pr[k] = f32x2{p0, p1};
+    }
+    f32x2 s2 = pr[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) s2 = s2 + pr[k];
+    return __halves2half2(__float2half_rn(s2.x), __float2half_rn(s2.y));
+}
+
 template <int GATHER>
 __device__ __forceinline__ __half2 encode_level(const HashParams &hp, const PointPrep &pp, int l, __amdgpu_buffer_rsrc_t rsrc)
 {

@@ -274,7 +274,7 @@ __device__ __forceinline__ int64_t lane_tile_index(const PointSource &ps, int64_
 #endif
 }
 
-template <int PPT, int GATHER, int LPT>
+template <int PPT, int GATHER, int LPT, int DENSE = 0>
 __device__ __forceinline__ void hash_lm_body(const HashParams &hp, const PointSource &ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep,
                                              int level, int64_t tile)
 {
@@ -293,30 +293,68 @@ __device__ __forceinline__ void hash_lm_body(const HashParams &hp, const PointSo
     const bool store32 = NRF_HASH_DENSE_A32 && (uint64_t)hp.n_levels * (uint64_t)pstride * 4u < ((uint64_t)1 << 32);
     __amdgpu_buffer_rsrc_t frs = __amdgpu_buffer_rsrc_t();
     if (store32) frs = __builtin_amdgcn_make_buffer_rsrc(feats, 0, -1, 0x00020000);
-    __half2 out[LPT][PPT];
-#pragma unroll
-    for (int j = 0; j < LPT; j++)
-#pragma unroll
-        for (int q = 0; q < PPT; q++) out[j][q] = encode_level<GATHER>(hp, pp[q], level + j, rsrc);
-#pragma unroll
-    for (int j = 0; j < LPT; j++)
-#pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            if (idx[q] < p) {
+    auto store = [&](int j, int q, __half2 v) {
+        if (idx[q] < p) {
 #if NRF_HASH_DENSE_A32
-                if (store32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, out[j][q]), frs, (uint32_t)idx[q] << 2, (uint32_t)(level + j) * (uint32_t)pstride * 4u, 0);
-                else
+            if (store32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), frs, (uint32_t)idx[q] << 2, (uint32_t)(level + j) * (uint32_t)pstride * 4u, 0);
+            else
 #endif
-                    feats[(int64_t)(level + j) * pstride + idx[q]] = out[j][q];
-                if (level + j == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
-            }
+                feats[(int64_t)(level + j) * pstride + idx[q]] = v;
+            if (level + j == 0 && keep) keep[idx[q]] = pp[q].keep ? 1 : 0;
         }
+    };
+    if constexpr (DENSE > 0) {
+        // every level of this launch is baked and 32-bit addressable (decided on the host): BATCH = DENSE levels' loads in flight per thread, then their blends, then
+        // their stores -- a batch's quads, one level's weights / products and nothing of the other batches live in registers
+        constexpr int BATCH = DENSE < LPT ? DENSE : LPT;
+        static_assert(PPT == 1, "the straight-line baked instance takes one point per thread");
+#pragma unroll
+        for (int j0 = 0; j0 < LPT; j0 += BATCH) {
+            float qq[BATCH][3];
+            hf_u32x4 q0[BATCH], q1[BATCH];
+            __half2 o[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; b++) {
+                if (j0 + b < LPT) {
+                    uint32_t o0, o1; __amdgpu_buffer_rsrc_t lr;
+                    dense_level_issue(hp, pp[0], level + j0 + b, qq[b], o0, o1, lr);
+                    q0[b] = __builtin_bit_cast(hf_u32x4, __builtin_amdgcn_raw_buffer_load_b128(lr, o0, 0, 0));
+                    q1[b] = __builtin_bit_cast(hf_u32x4, __builtin_amdgcn_raw_buffer_load_b128(lr, o1, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; b++)
+                if (j0 + b < LPT) {
+                    o[b] = dense_level_blend(qq[b], q0[b], q1[b]);
+                    __builtin_amdgcn_sched_barrier(0);   // one level's 8 weights and 16 products at a time; and the next batch's loads stay behind this batch's blends
+                }
+#pragma unroll
+            for (int b = 0; b < BATCH; b++)
+                if (j0 + b < LPT) store(j0 + b, 0, o[b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        __half2 out[LPT][PPT];
+#pragma unroll
+        for (int j = 0; j < LPT; j++)
+#pragma unroll
+            for (int q = 0; q < PPT; q++) out[j][q] = encode_level<GATHER>(hp, pp[q], level + j, rsrc);
+#pragma unroll
+        for (int j = 0; j < LPT; j++)
+#pragma unroll
+            for (int q = 0; q < PPT; q++) store(j, q, out[j][q]);
+    }
 }
 
 // LPT levels per thread (blockIdx.y indexes groups of LPT levels): the coarse levels run at a fixed per-(point, level) instruction
 // cost (their lines are cached), a good part of which is forming the point and its box coordinates -- done once for LPT levels.
-template <int PPT, int GATHER, int LPT = 1>
-__global__ void __launch_bounds__(256)
+// the straight-line baked instances (DENSE > 0) keep DENSE levels' quads in registers: without a floor on the waves per SIMD the compiler hoists every load of the
+// thread to the front (214 registers for 12 levels: two waves per SIMD)
+#ifndef NRF_HASH_DENSE_WAVES
+#define NRF_HASH_DENSE_WAVES 8
+#endif
+template <int PPT, int GATHER, int LPT = 1, int DENSE = 0>
+__global__ void __launch_bounds__(256, (DENSE > 0 ? NRF_HASH_DENSE_WAVES : 1))
 k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ feats, int64_t pstride, uint8_t *__restrict__ keep, int lpg, int xcd_map,
              int level0)
 {
@@ -335,7 +373,7 @@ k_hash_cu_lm(HashParams hp, PointSource ps, int64_t p, __half2 *__restrict__ fea
         level = level0 + blockIdx.y * LPT;
         tile = blockIdx.x;
     }
-    hash_lm_body<PPT, GATHER, LPT>(hp, ps, p, feats, pstride, keep, level, tile);
+    hash_lm_body<PPT, GATHER, LPT, DENSE>(hp, ps, p, feats, pstride, keep, level, tile);
 }
 
 // per-ray direction features as fp16 rows [n, V] (the MLP kernel's colour-net operand): SH of the ray's view direction
@@ -441,11 +479,29 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
         for (int l = 0; l < lc && baked; l++) baked = hpar.dense_off[l] >= 0;
         const int clpt = (baked && (lc % NRF_HASH_COARSE_LPT) == 0) ? NRF_HASH_COARSE_LPT : 4;
         const int flpt = (baked && ((L - lc) % NRF_HASH_FINE_LPT) == 0) ? NRF_HASH_FINE_LPT : 1;
+        // every level baked AND its image below 4 GB with tile indices below 2^24 (all of 16..1024): the straight-line instances (hash_fast.h, dense_level_issue)
+#ifndef NRF_HASH_DENSE_BATCH_COARSE
+#define NRF_HASH_DENSE_BATCH_COARSE 3
+#endif
+#ifndef NRF_HASH_DENSE_BATCH_FINE
+#define NRF_HASH_DENSE_BATCH_FINE 2
+#endif
+        bool straight = baked && NRF_HASH_DENSE_A32 && NRF_HASH_DENSE_BATCH_COARSE > 0 && !(variant & 64);
+        for (int l = 0; l < L && straight; l++) {
+            const uint64_t nby = (uint64_t)hpar.dense_nby[l], dz = (uint64_t)hpar.dense_nbz[l];
+            straight = hpar.dense_off[l] >= 0 && nby * nby * dz < ((uint64_t)1 << 24) && hpar.bias[l * 3] == 0.0f && hpar.bias[l * 3 + 1] == 0.0f && hpar.bias[l * 3 + 2] == 0.0f;
+        }
         if (lc > 0) {
             if (clpt == 4) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 4>), dim3((unsigned)ntiles, (unsigned)(lc / 4)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
+            else if (straight) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_COARSE_LPT, NRF_HASH_DENSE_BATCH_COARSE>), dim3((unsigned)ntiles, (unsigned)(lc / NRF_HASH_COARSE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
             else hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_COARSE_LPT>), dim3((unsigned)ntiles, (unsigned)(lc / NRF_HASH_COARSE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, 0);
         }
         NRF_LAUNCH_CHECK();
+        if (straight && flpt == NRF_HASH_FINE_LPT) {
+            hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_FINE_LPT, NRF_HASH_DENSE_BATCH_FINE>), dim3((unsigned)ntiles, (unsigned)((L - lc) / NRF_HASH_FINE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
+            NRF_LAUNCH_CHECK();
+            return NRF_OK;
+        }
         // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
         // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
         if (flpt == 1) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
