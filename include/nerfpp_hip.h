@@ -486,8 +486,10 @@ NRF_API int nrf_raw2outputs_backward_noise(const float *d_raw, const float *d_z,
 /* d/d sigma = 0 where keep is false: the backward of `outputs_flat[~keep_mask, -1] = 0` (NeRFRenderer.h:187-188). */
 NRF_API int nrf_mask_sigma_grad(const uint8_t *d_keep, int64_t p, int c, float *d_g_raw, void *stream);
 
-/* Backward of the MLP (NeRFSmall family): x [p, in_dims] as given to nrf_mlp_forward, g_out [p, 4].  d_g_params (blob layout)
- * is ACCUMULATED into; d_g_x (optional) receives d loss / d x[:, :input_ch] as [p, input_ch]. */
+/* Backward of the MLP, fp32: NeRFSmallImpl::forward (NeRF.cpp:322-412) or -- round 5 -- the classic NeRFImpl::forward (NeRF.cpp:92-126: biases, the skip concat
+ * cat[input_pts, h], the view-direction head or output_linear).  x [p, in_dims] as given to nrf_mlp_forward, g_out [p, output dims] (4 with view directions).
+ * d_g_params (blob layout) is ACCUMULATED into; d_g_x (optional) receives d loss / d x[:, :input_ch] as [p, input_ch].  Pinned by LibTorch autograd through the compiled
+ * NeRF.cpp (goldens train_hash, mlp_nerf_bwd*, train_classic). */
 NRF_API size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p);
 NRF_API int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x,
                              void *d_workspace, size_t workspace_bytes, void *stream);

@@ -388,6 +388,159 @@ int mlp_small_backward(const nrf_mlp *m, const float *x, int xs, const float *g_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// N1 for the classic model: backward of NeRFImpl::forward (NeRF.cpp:92-126), fp32, from the same building blocks.  The layers have biases (d loss / d bias = the column
+// sums of the layer's output gradient); after layer `skip` the input is cat[input_pts, h] (:103-104); with view directions the head is alpha_linear(h), feature_linear(h)
+// (no ReLU), relu(views_linears_0(cat[feature, views])), rgb_linear (:108-120), without them output_linear(cat[h, input_pts]) (:121-124).
+// Pinned by LibTorch autograd through the compiled NeRF.cpp (goldens mlp_nerf_bwd*, train_classic).
+// ---------------------------------------------------------------------------------------------------
+// db[o] += sum_pt g[pt][o]
+__global__ void __launch_bounds__(256) k_grad_b(int64_t npts, Seg g, int out, float *__restrict__ db)
+{
+    const int o = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;                       // four point phases per block
+    float acc = 0.0f;
+    if (o < out)
+        for (int64_t pt = (int64_t)blockIdx.x * 4 + sub; pt < npts; pt += (int64_t)gridDim.x * 4) acc += g.p[pt * g.stride + g.off + o];
+    if (o < out && acc != 0.0f) unsafeAtomicAdd(db + o, acc);
+}
+
+static int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st)
+{
+    const int64_t nb = ceil_div(npts, 4);
+    hipLaunchKernelGGL(k_grad_b, dim3((unsigned)(nb < 128 ? nb : 128), (unsigned)ceil_div(out, 64)), dim3(256), 0, st, npts, g, out, db);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+// y[pt][k] = a[pt][a_off + k] (+ b[pt][b_off + k]), k < n
+__global__ void k_sum_cols(int64_t npts, int n, const float *__restrict__ a, int a_stride, int a_off, const float *__restrict__ b, int b_stride, int b_off, float *__restrict__ y,
+                           int y_stride)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npts * n) return;
+    const int64_t pt = e / n; const int k = (int)(e - pt * n);
+    float v = a[pt * a_stride + a_off + k];
+    if (b) v = v + b[pt * b_stride + b_off + k];
+    y[pt * y_stride + k] = v;
+}
+
+static int run_sum_cols(int64_t npts, int n, const float *a, int a_stride, int a_off, const float *b, int b_stride, int b_off, float *y, int y_stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sum_cols, dim3((unsigned)ceil_div(npts * n, 256)), dim3(256), 0, st, npts, n, a, a_stride, a_off, b, b_stride, b_off, y, y_stride);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+static size_t mlp_nerf_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
+{
+    const int64_t c = p < BWD_CHUNK ? p : BWD_CHUNK;
+    const int pad = m->nerf.input_ch > m->nerf.input_ch_views ? m->nerf.input_ch : m->nerf.input_ch_views;
+    return align_up((size_t)c * (m->max_width + pad) * sizeof(float), 256) * (m->nerf.depth + 7);
+}
+
+int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes,
+                      hipStream_t st)
+{
+    if (ws_bytes < mlp_nerf_backward_workspace_bytes(m, p)) { set_error("nrf_mlp_backward: workspace %zu < %zu bytes", ws_bytes, mlp_nerf_backward_workspace_bytes(m, p)); return NRF_ERR_WORKSPACE; }
+    const auto &d = m->nerf;
+    const int D = d.depth, Wd = d.width, in = d.input_ch, iv = d.input_ch_views;
+    const int W = m->max_width + (in > iv ? in : iv);       // row stride of every scratch buffer (the widest row: cat[input_pts, h] / cat[feature, views])
+    const size_t buf = align_up((size_t)(p < BWD_CHUNK ? p : BWD_CHUNK) * W * sizeof(float), 256) / sizeof(float);
+    float *base = reinterpret_cast<float *>(ws);
+    std::vector<float *> H(D);
+    for (int l = 0; l < D; l++) H[l] = base + (size_t)l * buf;
+    float *FEAT = base + (size_t)D * buf, *HV = base + (size_t)(D + 1) * buf;
+    float *G[5] = {base + (size_t)(D + 2) * buf, base + (size_t)(D + 3) * buf, base + (size_t)(D + 4) * buf, base + (size_t)(D + 5) * buf, base + (size_t)(D + 6) * buf};
+    const Seg none{nullptr, 0, 0, 0};
+    auto bias_of = [&](const LinearLayer &L) { return g_params + L.w_off + (size_t)L.in * L.out; };
+    for (int64_t p0 = 0; p0 < p; p0 += BWD_CHUNK) {
+        const int64_t c = (p - p0) < BWD_CHUNK ? (p - p0) : BWD_CHUNK;
+        const float *xc = x + p0 * xs, *gc = g_out + p0 * gos;
+        const Seg xin{xc, xs, 0, in};
+        // ---- forward, every layer output kept (NeRF.cpp:92-106) ----
+        Seg cur = xin;
+        bool cat_in = false;
+        for (int l = 0; l < D; l++) {
+            NRF_TRY(run_linear(c, cat_in ? xin : cur, cat_in ? cur : none, m->layers[l], 1, H[l], W, 0, st));
+            cur = Seg{H[l], W, 0, Wd};
+            cat_in = (l == d.skip);
+        }
+        const Seg hlast = cur;
+        float *gh = G[0];                                    // d loss / d (the last pts layer's post-ReLU output)
+        float *gx_acc = nullptr;                             // d loss / d input_pts collected on the way (G[4] when wanted)
+        auto add_gx = [&](const float *src, int src_stride, int src_off) -> int {
+            if (!g_x) return NRF_OK;
+            if (!gx_acc) { gx_acc = G[4]; return run_sum_cols(c, in, src, src_stride, src_off, nullptr, 0, 0, gx_acc, W, st); }
+            return run_sum_cols(c, in, src, src_stride, src_off, gx_acc, W, 0, gx_acc, W, st);
+        };
+        if (d.use_viewdirs) {
+            const LinearLayer &views = m->layers[D], &feat = m->layers[D + 1], &alpha = m->layers[D + 2], &rgb = m->layers[D + 3];
+            NRF_TRY(run_linear(c, hlast, none, feat, 0, FEAT, W, 0, st));                                              // feature (no ReLU)                 :110
+            const Seg sfeat{FEAT, W, 0, Wd}, sviews{xc, xs, in, iv};
+            NRF_TRY(run_linear(c, sfeat, sviews, views, 1, HV, W, 0, st));                                             // relu(views_linears_0(cat))         :111-117
+            const Seg g_rgb{gc, gos, 0, 3}, g_alpha{gc, gos, 3, 1};
+            // rgb_linear                                                                                              :118
+            NRF_TRY(run_grad_w(c, g_rgb, Seg{HV, W, 0, Wd / 2}, none, 3, Wd / 2, g_params + rgb.w_off, st));
+            NRF_TRY(run_grad_b(c, g_rgb, 3, bias_of(rgb), st));
+            NRF_TRY(run_backprop(c, g_rgb, m, rgb, G[1], W, st));
+            NRF_TRY(run_relu_mask(c, Wd / 2, G[1], W, HV, W, st));
+            const Seg g_hv{G[1], W, 0, Wd / 2};
+            // views_linears_0
+            NRF_TRY(run_grad_w(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, st));
+            NRF_TRY(run_grad_b(c, g_hv, Wd / 2, bias_of(views), st));
+            NRF_TRY(run_backprop(c, g_hv, m, views, G[2], W, st));                                                     // d / d cat[feature, views]
+            const Seg g_feat{G[2], W, 0, Wd};
+            // feature_linear and alpha_linear, both on h                                                              :108-110
+            NRF_TRY(run_grad_w(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, st));
+            NRF_TRY(run_grad_b(c, g_feat, Wd, bias_of(feat), st));
+            NRF_TRY(run_grad_w(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st));
+            NRF_TRY(run_grad_b(c, g_alpha, 1, bias_of(alpha), st));
+            NRF_TRY(run_backprop(c, g_feat, m, feat, G[1], W, st));
+            NRF_TRY(run_backprop(c, g_alpha, m, alpha, G[3], W, st));
+            NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, G[3], W, 0, gh, W, st));
+        } else {
+            const LinearLayer &outl = m->layers[D];                                                                    // output_linear(cat[h, input_pts])  :121-124
+            const Seg g_o{gc, gos, 0, outl.out};
+            NRF_TRY(run_grad_w(c, g_o, hlast, xin, outl.out, Wd + in, g_params + outl.w_off, st));
+            NRF_TRY(run_grad_b(c, g_o, outl.out, bias_of(outl), st));
+            NRF_TRY(run_backprop(c, g_o, m, outl, G[1], W, st));
+            NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, nullptr, 0, 0, gh, W, st));
+            NRF_TRY(add_gx(G[1], W, Wd));
+        }
+        // ---- pts_linears, last first ----
+        float *gcur = gh;
+        for (int l = D - 1; l >= 0; l--) {
+            const LinearLayer &L = m->layers[l];
+            NRF_TRY(run_relu_mask(c, Wd, gcur, W, H[l], W, st));
+            const Seg g{gcur, W, 0, Wd};
+            const bool cat = (l > 0) && (l - 1 == d.skip);                                                             // this layer's input is cat[input_pts, h_{l-1}]
+            const Seg a = (l == 0) ? xin : (cat ? xin : Seg{H[l - 1], W, 0, Wd});
+            const Seg b = cat ? Seg{H[l - 1], W, 0, Wd} : none;
+            NRF_TRY(run_grad_w(c, g, a, b, Wd, L.in, g_params + L.w_off, st));
+            NRF_TRY(run_grad_b(c, g, Wd, bias_of(L), st));
+            if (l == 0 && !g_x) break;
+            float *dst = (gcur == G[1]) ? G[2] : G[1];
+            NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+            if (l == 0) NRF_TRY(add_gx(dst, W, 0));
+            else if (cat) {
+                NRF_TRY(add_gx(dst, W, 0));
+                float *nxt = (dst == G[1]) ? G[2] : G[1];
+                // the h part of the gradient, moved to column 0 of another buffer (never in place: rows overlap)
+                nxt = (nxt == gcur) ? G[3] : nxt;
+                NRF_TRY(run_sum_cols(c, Wd, dst, W, in, nullptr, 0, 0, nxt, W, st));
+                gcur = nxt;
+                continue;
+            }
+            gcur = dst;
+        }
+        if (g_x) {
+            if (gx_acc) NRF_TRY(run_sum_cols(c, in, gx_acc, W, 0, nullptr, 0, 0, g_x + p0 * gxs, gxs, st));
+        }
+    }
+    return NRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // handle construction
 // ---------------------------------------------------------------------------------------------------
 static int add_layer(nrf_mlp *m, const std::vector<float> &hp, size_t &off, int in, int out, bool bias)
@@ -722,13 +875,19 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
 
 int nrf_mlp_device_repack_images(const nrf_mlp *m) { return m ? (int)m->maps.size() : 0; }
 
-size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p) { return m ? mlp_backward_workspace_bytes(m, p) : 0; }
+size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
+{
+    if (!m) return 0;
+    return m->family == MLP_NERF ? mlp_nerf_backward_workspace_bytes(m, p) : mlp_backward_workspace_bytes(m, p);
+}
 
 int nrf_mlp_backward(const nrf_mlp *m, const float *d_x, const float *d_g_out, int64_t p, float *d_g_params, float *d_g_x, void *d_workspace,
                      size_t workspace_bytes, void *stream)
 {
     NRF_CHECK_ARG(m && d_x && d_g_out && d_g_params && d_workspace && p >= 0, "nrf_mlp_backward: bad argument");
     if (p == 0) return NRF_OK;
+    if (m->family == MLP_NERF)          // NeRFImpl (NeRF.cpp:92-126); d_g_x [p, input_ch] = d loss / d input_pts
+        return mlp_nerf_backward(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->nerf.input_ch, d_workspace, workspace_bytes, as_stream(stream));
     return mlp_small_backward(m, d_x, m->in_dims, d_g_out, m->out_dims, p, d_g_params, d_g_x, m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
 }
 

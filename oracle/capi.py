@@ -173,6 +173,15 @@ def mlp_nerf(params, x, d=8, w=256, in_ch=63, in_views=27, out_ch=4, skip=4, use
     return out
 
 
+def mlp_nerf_backward(params, x, g_out, d=8, w=256, in_ch=63, in_views=27, out_ch=4, skip=4, use_viewdirs=True):
+    """Backward of NeRFImpl::forward (orc_mlp_nerf_backward) -> (g_params [blob], g_x [p, in_ch])."""
+    params = _f(params); x = _f(x); g_out = _f(g_out)
+    g_params = np.zeros_like(params); g_x = np.empty((x.shape[0], in_ch), np.float32)
+    lib().orc_mlp_nerf_backward(_p(params), _p(x), _p(g_out), C.c_int64(x.shape[0]), C.c_int(d), C.c_int(w), C.c_int(in_ch), C.c_int(in_views), C.c_int(out_ch), C.c_int(skip),
+                                C.c_int(int(use_viewdirs)), _p(g_params), _p(g_x))
+    return g_params, g_x
+
+
 def lerf(params, x, in_ch=128, n_layers=2, hidden=256, geo=32, embed=768):
     params = _f(params); x = _f(x)
     out = np.empty((x.shape[0], embed + 1), np.float32)

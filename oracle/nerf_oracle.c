@@ -1429,6 +1429,93 @@ ORC_API void orc_mlp_small_backward(const float *params, const float *x, const f
     free(gacc);
 }
 
+/* Backward of NeRFImpl::forward (NeRF.cpp:92-126: pts_linears with the skip concat cat[input_pts, h] after layer `skip`, biases everywhere; with view directions
+ * alpha_linear(h), feature_linear(h) (no ReLU), relu(views_linears_0(cat[feature, views])), rgb_linear; without: output_linear(cat[h, input_pts])).
+ * g_out [p, od] = d loss / d output (viewdirs: (rgb, alpha), od = 4).  Accumulates into g_params (blob layout of orc_mlp_nerf; caller zeroes); g_x [p, in_ch] =
+ * d loss / d input_pts (may be NULL; the positional encodings have no parameters).  Sequential over points, double accumulation. */
+ORC_API void orc_mlp_nerf_backward(const float *params, const float *x, const float *g_out, int64_t p, int d, int w, int in_ch, int in_views, int out_ch, int skip,
+                                   int use_viewdirs, float *g_params, float *g_x)
+{
+    const int64_t np_ = orc_mlp_nerf_param_count(d, w, in_ch, in_views, out_ch, skip, use_viewdirs);
+    double *gacc = (double *)calloc((size_t)np_, sizeof(double));
+    const int xd = in_ch + (use_viewdirs ? in_views : 0);
+    const int od = use_viewdirs ? 4 : out_ch;
+    const int maxw = w + in_ch + in_views + 8;
+    float *act = (float *)malloc(sizeof(float) * (size_t)(d + 1) * maxw);      /* act[l] = input of pts layer l; act[d] = h after the last one (cat form where it applies) */
+    for (int64_t i = 0; i < p; i++) {
+        const float *xi = x + i * xd;
+        const float *wl[64]; int dims[65];
+        const float *wp = params;
+        memcpy(act, xi, sizeof(float) * in_ch); dims[0] = in_ch;
+        for (int l = 0; l < d; l++) {
+            float *dst = act + (size_t)(l + 1) * maxw;
+            const int off = (l == skip) ? in_ch : 0;
+            wl[l] = wp;
+            linear(wp, wp + (int64_t)dims[l] * w, act + (size_t)l * maxw, dims[l], w, dst + off, 1);
+            wp += (int64_t)dims[l] * w + w;
+            if (off) memcpy(dst, xi, sizeof(float) * in_ch);
+            dims[l + 1] = w + off;
+        }
+        const float *hl = act + (size_t)d * maxw + (dims[d] - w);             /* the last layer's own w outputs (behind a cat, if the last layer is the skip layer) */
+        float gh[2048];                                                        /* d loss / d (that layer's w post-ReLU outputs) */
+        float gx_extra[1024]; memset(gx_extra, 0, sizeof(float) * in_ch);
+        if (use_viewdirs) {
+            const float *vw = wp; wp += (int64_t)(in_views + w) * (w / 2) + w / 2;
+            const float *fw = wp; wp += (int64_t)w * w + w;
+            const float *aw = wp; wp += w + 1;
+            const float *rw = wp;
+            float feat[2048], hv[1024];
+            linear(fw, fw + (int64_t)w * w, hl, w, w, feat, 0);
+            memcpy(feat + w, xi + in_ch, sizeof(float) * in_views);
+            linear(vw, vw + (int64_t)(in_views + w) * (w / 2), feat, w + in_views, w / 2, hv, 1);
+            const float *go = g_out + i * od;
+            /* rgb_linear */
+            float ghv[1024];
+            { double *ga = gacc + (rw - params);
+              for (int o = 0; o < 3; o++) { for (int k = 0; k < w / 2; k++) ga[(int64_t)o * (w / 2) + k] += (double)go[o] * (double)hv[k]; ga[(int64_t)3 * (w / 2) + o] += (double)go[o]; }
+              for (int k = 0; k < w / 2; k++) { float a = 0.0f; for (int o = 0; o < 3; o++) a += rw[(int64_t)o * (w / 2) + k] * go[o]; ghv[k] = (hv[k] > 0.0f) ? a : 0.0f; } }
+            /* views_linears_0 on cat[feature, views] */
+            float gfeat[2048];
+            { const int id = w + in_views; double *ga = gacc + (vw - params);
+              for (int o = 0; o < w / 2; o++) { for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)ghv[o] * (double)feat[k]; ga[(int64_t)(w / 2) * id + o] += (double)ghv[o]; }
+              for (int k = 0; k < w; k++) { float a = 0.0f; for (int o = 0; o < w / 2; o++) a += vw[(int64_t)o * id + k] * ghv[o]; gfeat[k] = a; } }
+            /* feature_linear (no ReLU) and alpha_linear, both on h */
+            { double *gf = gacc + (fw - params), *gal = gacc + (aw - params);
+              for (int o = 0; o < w; o++) { for (int k = 0; k < w; k++) gf[(int64_t)o * w + k] += (double)gfeat[o] * (double)hl[k]; gf[(int64_t)w * w + o] += (double)gfeat[o]; }
+              for (int k = 0; k < w; k++) gal[k] += (double)go[3] * (double)hl[k];
+              gal[w] += (double)go[3];
+              for (int k = 0; k < w; k++) { float a = 0.0f; for (int o = 0; o < w; o++) a += fw[(int64_t)o * w + k] * gfeat[o]; gh[k] = a + aw[k] * go[3]; } }
+        } else {
+            const float *ow = wp;
+            const float *go = g_out + i * od;
+            const int id = w + in_ch;
+            float hc[2048];
+            memcpy(hc, hl, sizeof(float) * w); memcpy(hc + w, xi, sizeof(float) * in_ch);
+            double *ga = gacc + (ow - params);
+            for (int o = 0; o < out_ch; o++) { for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)go[o] * (double)hc[k]; ga[(int64_t)out_ch * id + o] += (double)go[o]; }
+            for (int k = 0; k < w; k++) { float a = 0.0f; for (int o = 0; o < out_ch; o++) a += ow[(int64_t)o * id + k] * go[o]; gh[k] = a; }
+            for (int k = 0; k < in_ch; k++) { float a = 0.0f; for (int o = 0; o < out_ch; o++) a += ow[(int64_t)o * id + w + k] * go[o]; gx_extra[k] += a; }
+        }
+        /* pts_linears, last first; gh = gradient of layer l's w post-ReLU outputs */
+        for (int l = d - 1; l >= 0; l--) {
+            const int id = dims[l];
+            const float *in_l = act + (size_t)l * maxw;
+            const float *out_l = act + (size_t)(l + 1) * maxw + (dims[l + 1] - w);
+            float g[2048], gin[2048];
+            for (int o = 0; o < w; o++) g[o] = (out_l[o] > 0.0f) ? gh[o] : 0.0f;
+            double *ga = gacc + (wl[l] - params);
+            for (int o = 0; o < w; o++) { for (int k = 0; k < id; k++) ga[(int64_t)o * id + k] += (double)g[o] * (double)in_l[k]; ga[(int64_t)w * id + o] += (double)g[o]; }
+            for (int k = 0; k < id; k++) { float a = 0.0f; for (int o = 0; o < w; o++) a += wl[l][(int64_t)o * id + k] * g[o]; gin[k] = a; }
+            if (l == 0) { for (int k = 0; k < in_ch; k++) gx_extra[k] += gin[k]; }
+            else if (id == w + in_ch) { for (int k = 0; k < in_ch; k++) gx_extra[k] += gin[k]; memcpy(gh, gin + in_ch, sizeof(float) * w); }      /* input was cat[input_pts, h] */
+            else memcpy(gh, gin, sizeof(float) * w);
+        }
+        if (g_x) memcpy(g_x + i * in_ch, gx_extra, sizeof(float) * in_ch);
+    }
+    for (int64_t k = 0; k < np_; k++) g_params[k] += (float)gacc[k];
+    free(gacc); free(act);
+}
+
 /* N1, LeRF branch (NeRFExecutor.h:955-982): lang_loss = huber_loss(RenderedLangEmbedding, target, reduction none, delta).sum(-1).nanmean()  (:970-974).
  * ATen: huber(reduction none) z = |d|: z < delta ? 0.5 z^2 : delta (z - 0.5 delta); nanmean = nansum / (count of non-NaN rows); the backward of nansum passes a ZERO
  * to a NaN row, and huber's backward multiplies it by its own derivative -- NaN where the difference is NaN: such a ray's gradient row is 0 except NaN at the NaN

@@ -731,6 +731,77 @@ static void g_train()
 // [0, 0, 0, sigma_le] rows and its .Weights are used -- no arithmetic is restated.  The language grid is CuHashEmbedder (CUDA-only): its output is a leaf here
 // (`emb`), its own backward is pinned by the restatement (oracle/nerf_oracle.c).
 // ----------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------
+// N1 for the classic model: NeRFImpl (NeRF.cpp:41-126) is a legal TNeRF of the same train loop (NeRFExecutor.h:862-995).
+//   mlp_nerf_bwd*: autograd of the network alone, d sum(y * c) / d (parameters, input), three shapes (view directions + skip; no view directions; the 8 x 256 bench network,
+//                  big gradients stored as every 37th element)
+//   train_classic: two optimisation steps of the loop body on a small PE(10) / PE(4) network, as train_hash
+// ----------------------------------------------------------------------------------------------
+static void g_train_classic()
+{
+	struct Cfg { const char *tag; int d, w, in, views, out; int skip; bool vd; int n; int stride; };
+	for (const Cfg &c : {Cfg{"mlp_nerf_bwd", 4, 32, 15, 9, 5, 1, true, 40, 1}, Cfg{"mlp_nerf_bwd_noview", 4, 24, 15, 0, 4, 2, false, 32, 1}, Cfg{"mlp_nerf_bwd_full", 8, 256, 63, 27, 5, 4, true, 24, 37}})
+	{
+		const std::string tag = c.tag;
+		NeRF m(c.d, c.w, c.in, c.views, c.out, std::set<int>{c.skip}, c.vd, "model");
+		fill_module(tag, m, 7000u, 1.4f, 0.1f);
+		auto x = synth_tensor({c.n, c.in + c.views}, 71u, 1.0f).set_requires_grad(true);
+		auto y = m->forward(x);
+		auto cw = synth_tensor({c.n, y.size(1)}, 73u, 1.0f);
+		(y * cw).sum().backward();
+		save_npy(tag + ".dims", torch::tensor({c.d, c.w, c.in, c.views, c.out, c.skip, (int)c.vd, c.stride}, torch::kInt32));
+		save_npy(tag + ".x", x); save_npy(tag + ".y", y); save_npy(tag + ".g_out", cw);
+		save_npy(tag + ".grad_x", x.grad());
+		for (auto &p : m->named_parameters())
+		{
+			auto g = p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value());
+			if (c.stride > 1 && g.numel() > 20000) g = g.reshape({-1}).index({Slice(0, None, c.stride)}).contiguous();
+			save_npy(tag + ".grad_" + p.key(), g);
+		}
+	}
+	{
+		const std::string tag = "train_classic";
+		const int h = 8, w = 8, ns = 16, ni = 16;
+		auto k = lego_K(h, w);
+		k[0][0] = k[0][0] * 0.8f; k[1][1] = k[1][1] * 0.8f;
+		auto c2w = orbit_pose(-63.f, -30.f, 4.f);
+		Embedder e("embedder", 10), ed("embeddirs", 4);
+		NeRF m(4, 64, 63, 27, 5, std::set<int>{1}, true, "model");
+		fill_module(tag, m, 7000u, 1.4f, 0.1f, {{"alpha_linear.weight", 12.0f}});
+		auto [o, d, cone] = GetRays(h, w, k, c2w);
+		o = o.reshape({-1, 3}); d = d.reshape({-1, 3});
+		auto target = synth_tensor({h * w, 3}, 9100u, 0.5f, 0.5f);
+		save_npy(tag + ".rays_o", o); save_npy(tag + ".rays_d", d); save_npy(tag + ".target", target); save_npy(tag + ".bbox", lego_bbox());
+		std::vector<torch::Tensor> grad_vars;
+		for (auto &p : m->parameters()) grad_vars.push_back(p);
+		const float lr = 5e-3f;
+		torch::optim::Adam opt(grad_vars, torch::optim::AdamOptions(lr).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));		//NeRFExecutor.h:539
+		save_npy(tag + ".lr", torch::tensor({lr}));
+		auto rp = lego_params(ns, ni, h * w);
+		rp.WhiteBkgr = false;
+		for (int step = 1; step <= 2; step++)
+		{
+			const std::string st = tag + ".s" + std::to_string(step) + "_";
+			Spy<Embedder, Embedder, NeRF> spy(e, ed, m);
+			opt.zero_grad();
+			auto res = spy.Render(0, 0, torch::Tensor(), rp, {o, d, cone});
+			auto mse = torch::mse_loss(res.Outputs.RGBMap, target.detach());
+			auto loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, target.detach());		//:883
+			loss.backward();
+			save_npy(st + "loss", loss.detach().reshape({1})); save_npy(st + "mse", mse.detach().reshape({1}));
+			save_npy(st + "rgb", res.Outputs.RGBMap.detach());
+			if (step == 1)
+			{
+				save_npy(st + "fine_z", spy.r2o_z[1]); save_npy(st + "fine_raw", spy.r2o_raw[1]); save_npy(st + "fine_pts", spy.net_pts[1]);
+				save_npy(st + "grad_fine_raw", spy.raw_live[1].grad());
+				for (auto &p : m->named_parameters()) save_npy(st + "grad_" + p.key(), p.value().grad().defined() ? p.value().grad() : torch::zeros_like(p.value()));
+			}
+			opt.step();
+			for (auto &p : m->named_parameters()) save_npy(st + "param_" + p.key(), p.value().detach());
+		}
+	}
+}
+
 static void g_train_lerf()
 {
 	struct Cfg { const char *tag; int geo, layers, hidden, embed, in, n, s; int stride; };
@@ -1016,6 +1087,7 @@ int main(int argc, const char **argv)
 	g_raw2out();
 	g_render();
 	g_train();
+	g_train_classic();
 	g_train_lerf();
 	g_tv();
 	g_manifest.close();

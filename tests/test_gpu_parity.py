@@ -3,6 +3,7 @@
   (b) the C oracle on the same seeded inputs.
 Bars: bit-exact for indices / integer outputs and for every stage made of + - * / floor / compare;
 float tolerance stated per test otherwise (pixels: 1e-4, BASELINE north_star)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -134,6 +135,43 @@ def test_hash_cu_bit_exact_vs_oracle(api, O, cfg):
                            bbox, O.hash_cu_scales(Lv, base, fine), Lv, F)
     assert_exact(host(mask), rmask, "keep_mask"); assert_exact(host(emb), ref, "embedding (fp16-rounded)")
     assert (~rmask).sum() > 0
+
+
+@pytest.mark.parametrize("tag", ["hash_small", "hash_f8"])
+def test_cu_hash_kernel_reproduces_the_reference_pinned_hash_embedder_level_by_level(api, tag, manifest):
+    """GPU twin of tests/test_oracle_golden.py::test_cu_hash_restatement_reproduces_...: the HIP CuHashEmbedder path (nrf_hash_encode, NRF_HASH_CU) with the level scales
+    set to HashEmbedder's integer resolutions (nrf_hash_set_level_scales), primes (1, 2654435761, 805459861) and H1's level-l table placed where level l's view starts
+    (ELEMENT l * local_size: the overlap quirk forbids loading all levels at once) must reproduce the REFERENCE's golden embedding of level l up to H2's two fp16
+    roundings -- hash, corner order and trilinear weights of CuHashEmbedder.cu:66-100 against NeRF.cpp:230-298."""
+    from test_oracle_golden import cu_level_vs_ngp_golden, NGP_PRIMES_AS_INT32
+    g = load_golden(tag)
+    L, F, T, base, fine = (int(v) for v in g["cfg"])
+    e = api.M.CuHashEmbedder("embedder", g["bbox"], L, F, T, base, fine)
+    e.set_primes(np.tile(NGP_PRIMES_AS_INT32, L))
+    from oracle import capi as O
+    e.set_level_scales(O.hash_ngp_resolutions(L, base, fine))
+    ls = ((1 << T) >> 4) << 4
+    assert ls == 1 << T
+
+    def encode_level(l, table_l, res_l, T_, F_, x):
+        full = np.zeros(L * (1 << T) * F, np.float32)
+        full[l * ls:l * ls + table_l.size] = table_l.reshape(-1)
+        e.set_table(full)
+        emb, _ = e.forward(dev(x))
+        return host(emb)[:, l * F:(l + 1) * F]
+    assert cu_level_vs_ngp_golden(tag, manifest, encode_level) <= 1.0
+
+
+@pytest.mark.parametrize("deg", [6, 7, 8])
+def test_sh_cuda_variant_vs_an_independent_float64_recurrence(api, deg):
+    """GPU twin of the S1 anchor at the degrees the LibTorch twin does not reach: CuSHEncoder's HIP kernel against real spherical harmonics from the Legendre recurrence in
+    float64 (tests/test_oracle_golden.py::real_sh_f64) on unit vectors."""
+    from test_oracle_golden import real_sh_f64
+    g = load_golden("sh")
+    d = g["dirs"].astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    out, _ = api.M.CuSHEncoder("sh", 3, deg).forward(dev(d))
+    assert_close(host(out), real_sh_f64(d, deg), rtol=0, atol=1.5e-6 if deg <= 7 else 3e-6, what=f"CuSHEncoder kernel, degree {deg}")
 
 
 def test_hash_cu_known_answers(api):
@@ -2830,6 +2868,39 @@ def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manife
         assert abs(rd(f"out_s{step}_loss.f32", (1,))[0] - g[f"s{step}_loss"][0]) < 3e-4
     assert abs(host(lm2)[0] - rd("out_s2_loss.f32", (1,))[0]) < 2e-4          # two runs of the same chain: step 1 leaves a per-cent of the weights lr apart (sign of a cancelling atomic sum)
     assert r["loss_step2"] < r["loss_step1"]
+
+
+# ------------------------------------------------------------------ N1 for the classic model: backward of NeRFImpl::forward (NeRF.cpp:92-126)
+@pytest.mark.parametrize("tag", ["mlp_nerf_bwd", "mlp_nerf_bwd_noview", "mlp_nerf_bwd_full"])
+def test_classic_mlp_backward_vs_reference_autograd(api, O, tag, manifest):
+    """nrf_mlp_backward on the classic family (mlp.hip, mlp_nerf_backward: fp32 layer kernels, bias column sums, the skip concat, both heads) against LibTorch autograd through the
+    COMPILED NeRF.cpp -- a small network with view directions, one without (output_linear on cat[h, input_pts]), and the 8 x 256 bench network: every parameter gradient and
+    d / d input_pts within 2e-4 of its tensor's largest entry of the reference's, within 2e-5 of the oracle's."""
+    from test_oracle_golden import nerf_bwd_golden_case
+    kw, stride, blob, g, where = nerf_bwd_golden_case(tag, manifest)
+    m = api.M.NeRF(kw["d"], kw["w"], kw["in_ch"], kw["in_views"], kw["out_ch"], {kw["skip"]}, kw["use_viewdirs"], "model", params=blob)
+    od = 4 if kw["use_viewdirs"] else kw["out_ch"]
+    x = dev(g["x"]); go = dev(np.ascontiguousarray(g["g_out"][:, :od]))
+    n = x.shape[0]
+    g_params = torch.zeros((blob.size,), device="cuda"); g_x = torch.empty((n, kw["in_ch"]), device="cuda")
+    lib = api.L.lib()
+    nb = lib.nrf_mlp_backward_workspace_bytes(m._m, C.c_int64(n))
+    ws = torch.empty((int(nb),), device="cuda", dtype=torch.uint8)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    api.L.check(lib.nrf_mlp_backward(m._m, vp(x), vp(go), C.c_int64(n), vp(g_params), vp(g_x), vp(ws), C.c_size_t(int(nb)), None))
+    torch.cuda.synchronize()
+    ogp, ogx = O.mlp_nerf_backward(blob, g["x"], g["g_out"][:, :od], **kw)
+    ref_x = g["grad_x"][:, :kw["in_ch"]]
+    assert_close(host(g_x), ref_x, rtol=0, atol=2e-4 * float(np.abs(ref_x).max()), what="d / d input_pts vs reference autograd")
+    assert_close(host(g_x), ogx, rtol=0, atol=2e-5 * float(np.abs(ogx).max()), what="d / d input_pts vs oracle")
+    gp = host(g_params)
+    for name, (off, shape) in where.items():
+        cnt = int(np.prod(shape))
+        mine, orc, gold = gp[off:off + cnt], ogp[off:off + cnt], g["grad_" + name].reshape(-1)
+        assert_close(mine, orc, rtol=0, atol=2e-5 * float(np.abs(orc).max()) + 1e-9, what=f"d / d {name} vs oracle")
+        if gold.size != mine.size:
+            mine = mine[::stride]
+        assert_close(mine, gold, rtol=0, atol=2e-4 * float(np.abs(gold).max()) + 1e-9, what=f"d / d {name} vs reference autograd")
 
 
 # ------------------------------------------------------------------ N1, LeRF branch of the optimisation step (NeRFExecutor.h:955-982)

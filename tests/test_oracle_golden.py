@@ -118,6 +118,90 @@ def test_hash_ngp_bit_exact(tag, manifest):
     assert (~g["mask"]).sum() > 0, "fixture must contain out-of-box points"
 
 
+# ---- anchors for the restatement-pinned encoders (H2 CuHashEmbedder, S1 CuSHEncoder): they do not lift "parity unpinned", they make a restatement slip visible ----
+NGP_PRIMES_AS_INT32 = np.array([1, 2654435761, 805459861], np.uint32).view(np.int32)          # HashEmbedder's multipliers (NeRF.cpp:230-237) as CuHashEmbedder's per-level primes
+
+
+def cu_level_vs_ngp_golden(tag, manifest, encode_level):
+    """H2 against the REFERENCE-PINNED H1, level by level: with the level scale set to H1's integer resolution, primes (1, 2654435761, 805459861), local_size = 2^T and
+    zero bias, CuHashEmbedder's kernel (CuHashEmbedder.cu:27-101) addresses the same lattice with the same hash and blends the same 8 corners as HashEmbedderImpl::forward
+    (NeRF.cpp:230-298) -- so one level's view of its table, loaded with H1's level table, must reproduce the reference's golden embedding of that level up to the two
+    fp16 roundings H2 has and H1 has not (table entries and the output).  `encode_level(l, table_l [2^T, F], res_l, T, F, x) -> [p, F]` runs H2 for one level.
+    A swapped corner order, a wrong prime / axis pairing, weights of the wrong corner or a mis-scaled position all fail this by orders of magnitude."""
+    g = load_golden(tag)
+    L, F, T, base, fine = (int(v) for v in g["cfg"])
+    table = synth.blob_from_manifest(manifest[tag]).reshape(L, 1 << T, F)
+    res = O.hash_ngp_resolutions(L, base, fine)
+    keep = g["mask"].astype(bool)
+    x = g["x"][keep]
+    worst = 0.0
+    for l in range(L):
+        got = encode_level(l, table[l], float(res[l]), T, F, x)
+        ref = g["emb"][keep][:, l * F:(l + 1) * F]
+        tol = 3.0 * 2.0 ** -11 * float(np.abs(table[l]).max()) + 1e-7
+        err = float(np.abs(got - ref).max())
+        worst = max(worst, err / tol)
+        assert err <= tol, (tag, l, err, tol)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["hash_small", "hash_f8", "hash_full"])
+def test_cu_hash_restatement_reproduces_the_reference_pinned_hash_embedder_level_by_level(tag, manifest):
+    def encode_level(l, table_l, res_l, T, F, x):
+        out, _ = O.hash_cu(x, O.f32_to_f16(table_l.reshape(-1)), NGP_PRIMES_AS_INT32, np.zeros(1, np.int32), np.full(1, 1 << T, np.int32), np.zeros((1, 3), np.float32),
+                           load_golden(tag)["bbox"], np.array([res_l], np.float32), 1, F)
+        return out
+    assert cu_level_vs_ngp_golden(tag, manifest, encode_level) <= 1.0
+
+
+def real_sh_f64(dirs, degree):
+    """An INDEPENDENT statement of the basis CuSHEncoder tabulates as polynomials (CuSHEncoder.cu:15-104): real spherical harmonics from the associated Legendre
+    recurrence in float64 -- Y_l^m = sqrt(2) K_l^|m| P_l^|m|(z) {cos(m phi), m > 0; sin(|m| phi), m < 0}, Y_l^0 = K_l^0 P_l(z), P with the Condon-Shortley phase
+    ((-1)^m: Y_1^1 = -0.4886 x as there), K_l^m = sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!), output index l^2 + l + m."""
+    from math import factorial, pi, sqrt
+    d = np.asarray(dirs, np.float64)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    phi = np.arctan2(y, x)
+    st = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+    out = np.zeros((d.shape[0], degree * degree))
+    P = {}
+    for m in range(degree):
+        pmm = np.ones_like(z)
+        for k in range(1, m + 1):
+            pmm = pmm * (-(2 * k - 1)) * st                       # P_m^m = (-1)^m (2m-1)!! sin^m
+        P[(m, m)] = pmm
+        if m + 1 < degree:
+            P[(m + 1, m)] = z * (2 * m + 1) * pmm
+        for l in range(m + 2, degree):
+            P[(l, m)] = ((2 * l - 1) * z * P[(l - 1, m)] - (l + m - 1) * P[(l - 2, m)]) / (l - m)
+    for l in range(degree):
+        for m in range(-l, l + 1):
+            am = abs(m)
+            K = sqrt((2 * l + 1) / (4 * pi) * factorial(l - am) / factorial(l + am))
+            if m == 0:
+                v = K * P[(l, 0)]
+            elif m > 0:
+                v = sqrt(2.0) * K * np.cos(m * phi) * P[(l, am)]
+            else:
+                v = sqrt(2.0) * K * np.sin(am * phi) * P[(l, am)]
+            out[:, l * l + l + m] = v
+    return out
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_cu_restatement_vs_an_independent_float64_recurrence(deg):
+    """S1 at EVERY degree the kernel has (1..8; S2, the LibTorch twin, stops at 5): the restated polynomial table against real spherical harmonics computed from the
+    Legendre recurrence in float64 on unit vectors, <= 1.5e-6 absolute through degree 7 and <= 3e-6 at degree 8 (basis functions are O(1))."""
+    g = load_golden("sh")
+    d = g["dirs"].astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    got = O.sh_cu(d, deg)
+    ref = real_sh_f64(d, deg)
+    # degree 8's l = 7 band: degree-7 polynomials with coefficients up to ~50 evaluated in fp32 cancel to O(1) values: 3 of 2 560 entries reach 2.2e-6
+    assert_close(got, ref, rtol=0, atol=1.5e-6 if deg <= 7 else 3e-6, what=f"CuSHEncoder restatement, degree {deg}")
+
+
 # ------------------------------------------------------------------------------------------- MLPs
 @pytest.mark.parametrize("tag,kw", [
     ("mlp_small_c4", dict(in_ch=32, in_views=16, n_layers_c=4)),
@@ -147,6 +231,34 @@ def test_lerf_head(manifest):
     h = O.lerf_sigma_net(synth.blob_from_manifest(manifest["lerf"]), g["x"])
     assert h.shape == (g["x"].shape[0], 33) and (h[:, 0] == y[:, 768]).all()
     assert_close(h[:, 0], g["y"][:, 768], rtol=1e-3, atol=2e-7)
+
+
+def nerf_bwd_golden_case(tag, manifest):
+    g = load_golden(tag)
+    d, w, in_ch, views, out_ch, skip, vd, stride = (int(v) for v in g["dims"])
+    blob = synth.blob_from_manifest(manifest[tag])
+    off, where = 0, {}
+    for name, _, _, shape in manifest[tag]:
+        where[name] = (off, shape); off += int(np.prod(shape))
+    return dict(d=d, w=w, in_ch=in_ch, in_views=views, out_ch=out_ch, skip=skip, use_viewdirs=bool(vd)), stride, blob, g, where
+
+
+@pytest.mark.parametrize("tag", ["mlp_nerf_bwd", "mlp_nerf_bwd_noview", "mlp_nerf_bwd_full"])
+def test_classic_mlp_backward_vs_reference_autograd(tag, manifest):
+    """Backward of NeRFImpl::forward (NeRF.cpp:92-126: skip concat, biases, the view-direction branch / the output_linear branch): the oracle's restatement against
+    LibTorch autograd through the COMPILED NeRF.cpp -- d sum(y c) / d every parameter and d / d input_pts, within 2e-4 of each tensor's largest entry."""
+    kw, stride, blob, g, where = nerf_bwd_golden_case(tag, manifest)
+    y = O.mlp_nerf(blob, g["x"], **kw)
+    assert_close(y, g["y"], rtol=1e-4, atol=1e-5)
+    gp, gx = O.mlp_nerf_backward(blob, g["x"], g["g_out"][:, :y.shape[1]], **kw)
+    ref_x = g["grad_x"][:, :kw["in_ch"]]
+    assert_close(gx, ref_x, rtol=0, atol=2e-4 * float(np.abs(ref_x).max()), what="d / d input_pts")
+    for name, (off, shape) in where.items():
+        ref = g["grad_" + name].reshape(-1)
+        mine = gp[off:off + int(np.prod(shape))]
+        if ref.size != mine.size:
+            mine = mine[::stride]
+        assert_close(mine, ref, rtol=0, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, what=f"d / d {name}")
 
 
 def lerf_golden_case(tag, manifest):
