@@ -15,21 +15,28 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .modules import _HashBase, CuHashEmbedder, NeRFSmall, _ptr, _stream, _dev_f32
+from .modules import _HashBase, CuHashEmbedder, NeRF, NeRFSmall, _ptr, _stream, _dev_f32
 from .renderer import NeRFRenderer, NeRFRenderParams, RngFill, StochasticPrecondition, TangentScatter
 
 
 class Trainer:
     def __init__(self, embedder: _HashBase, embeddirs, mlp: NeRFSmall, table, mlp_blob, learning_rate=5e-4, betas=(0.9, 0.99), eps=1e-15,
                  tv_loss_weight=0.0, seed=0, mlp_backward="f32", hash_backward="f32", grad_sync=None, train_dense_budget=256 << 20):
-        if not isinstance(embedder, _HashBase) or not isinstance(mlp, NeRFSmall):
-            raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes (the reference's HashNeRF training configuration)")
+        # two configurations of the reference's train loop (NeRFExecutor.h:862-995): hash grid + NeRFSmall (main.cpp:220-221) and the classic PE(10) / PE(4) + NeRF 8x256
+        # (NeRFImpl is a legal TNeRF of the same loop; its embedders have no parameters: `table` is None / empty there)
+        self.has_table = isinstance(embedder, _HashBase)
+        if self.has_table != isinstance(mlp, NeRFSmall) or not (self.has_table or isinstance(mlp, NeRF)):
+            raise L.NrfError("Trainer is built for hash-grid + NeRFSmall scenes and for positional-encoding + NeRF (classic) scenes")
+        if not self.has_table and (mlp_backward != "f32" or hash_backward != "f32"):
+            raise L.NrfError("the classic model trains through the fp32 layer kernels (mlp_backward = hash_backward = 'f32')")
         self.embedder, self.embeddirs, self.mlp = embedder, embeddirs, mlp
         self.renderer = NeRFRenderer(embedder, embeddirs, mlp)
         dev = "cuda"
+        if not self.has_table:
+            table = np.zeros((0,), np.float32)
         self.table = torch.as_tensor(np.ascontiguousarray(table, np.float32).reshape(-1) if not torch.is_tensor(table) else table.reshape(-1)).to(dev).contiguous()
         self.blob = torch.as_tensor(np.ascontiguousarray(mlp_blob, np.float32).reshape(-1) if not torch.is_tensor(mlp_blob) else mlp_blob.reshape(-1)).to(dev).contiguous()
-        assert self.table.numel() == embedder.table_elems() and self.blob.numel() == mlp.n_params
+        assert self.table.numel() == (embedder.table_elems() if self.has_table else 0) and self.blob.numel() == mlp.n_params
         self.m_table, self.v_table = torch.zeros_like(self.table), torch.zeros_like(self.table)
         self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
         self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
@@ -57,7 +64,10 @@ class Trainer:
         # levels that fit `train_dense_budget` stay baked (256 MB: re-baking them costs ~0.1 ms per step and their lookups are the 2-load fast path instead of 8 hashed
         # corners: step 9.3 -> 8.5 ms, same bits; 0 / 16 / 64 / 1024 MB: 9.3 / 8.9 / 8.7 / 8.7 ms, profiles/round4/r4m_train_dense_budget.log).  For ANY hash embedder --
         # the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
-        self._dense_budget_before = getattr(embedder, "dense_budget", None)
+        self._dense_budget_before = getattr(embedder, "dense_budget", None) if self.has_table else None
+        if not self.has_table:
+            self._push_params()
+            return
         # never MORE than the embedder already had: a host that built it with budget 0 (or a small one) keeps the levels it turned off -- as the C++ drop-in does
         # (HipNeRFRenderer: min(previous budget, TrainDenseBudget))
         prev = self._dense_budget_before
@@ -78,7 +88,8 @@ class Trainer:
         self.close()
 
     def _push_params(self):
-        self.embedder.set_table(self.table)
+        if self.has_table:
+            self.embedder.set_table(self.table)
         L.check(L.lib().nrf_mlp_set_params(self.mlp._m, _ptr(self.blob), 1, _stream()))
 
     def _workspace(self, nbytes):
@@ -119,8 +130,18 @@ class Trainer:
             pts = TangentScatter(pts.reshape(n, s, 3), z, float(cone_angle), rays[:, 3:6].contiguous(), p.BoundingBox if p is not None else None, ur, ut).reshape(n * s, 3)
         dirs, _ = self.embeddirs.forward(rays[:, 8:11].contiguous())
         in_ch = self.embedder.GetOutputDims()
-        g_x = torch.empty((n * s, in_ch), device=rays.device)
         self.g_blob.zero_(); self.g_table.zero_()
+        if not self.has_table:
+            # classic model (NeRFRenderer.h:175-184 with Embedder / Embedder / NeRF): the encodings carry no parameters, so the chain ends at the network's own gradient
+            emb, _ = self.embedder.forward(pts)
+            x = torch.cat([emb, dirs[:, None, :].expand(n, s, dirs.shape[1]).reshape(n * s, -1)], 1).contiguous()
+            nb = lib.nrf_mlp_backward_workspace_bytes(self.mlp._m, C.c_int64(n * s))
+            ws = self._workspace(nb)
+            L.check(lib.nrf_mlp_backward(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), None, _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+            self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=None, x=x, pts=pts)
+            self.overflow = False
+            return loss_mse
+        g_x = torch.empty((n * s, in_ch), device=rays.device)
         lm = (self.mlp_backward == "f16" and isinstance(self.embedder, CuHashEmbedder) and self.embedder.NLevels == 16 and self.embedder.NFeaturesPerLevel == 2
               and dirs.shape[1] == 16)
         if lm:
@@ -180,7 +201,7 @@ class Trainer:
     def add_tv_loss(self):
         """loss += w * TotalVariationLoss(level) for every level (NeRF.h:255-300): accumulates into self.g_table and self.tv_loss."""
         e = self.embedder
-        if self.tv_loss_weight <= 0 or e.mode != L.NRF_HASH_NGP:
+        if self.tv_loss_weight <= 0 or not self.has_table or e.mode != L.NRF_HASH_NGP:
             return
         self.tv_loss.zero_()
         b = math.exp((math.log(e.FinestResolution) - math.log(e.BaseResolution)) / (e.NLevels - 1))          # NeRF.h:265
@@ -223,8 +244,9 @@ class Trainer:
         self.t += 1
         b1, b2 = self.betas
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):
-            L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
-                                          C.c_float(self.eps), self.t, _stream()))
+            if prm.numel():
+                L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                              C.c_float(self.eps), self.t, _stream()))
         self._push_params()
         if global_step is not None and lrate_decay:
             self.lr = self.learning_rate0 * math.pow(0.1, float(global_step) / (float(lrate_decay) * 1000.0))      # :992-996
@@ -233,6 +255,21 @@ class Trainer:
     # ---- checkpoint interchange (NeRFExecutor::SaveCheckpoint / the restore branch of Initialize, NeRFExecutor.h:1055-1070, :540-566) ----
     def _param_layout(self):
         """[(name, offset, shape)] of the embedder's and the model's parameters in the reference's optimizer order (embedder first, :508-535)."""
+        if not self.has_table:
+            # NeRFImpl's registration order (NeRF.cpp:76-91): pts_linears_i, views_linears_0, feature_linear, alpha_linear, rgb_linear | output_linear; weight then bias
+            d, off, mlp = self.mlp.desc, 0, []
+            def lin(name, o, i):
+                nonlocal off
+                mlp.append((f"model_{name}.weight", off, (o, i))); off += o * i
+                mlp.append((f"model_{name}.bias", off, (o,))); off += o
+            for l in range(d.depth):
+                lin(f"pts_linears_{l}", d.width, d.input_ch if l == 0 else (d.width + d.input_ch if l - 1 == d.skip else d.width))
+            if d.use_viewdirs:
+                lin("views_linears_0", d.width // 2, d.input_ch_views + d.width); lin("feature_linear", d.width, d.width); lin("alpha_linear", 1, d.width); lin("rgb_linear", 3, d.width // 2)
+            else:
+                lin("output_linear", d.output_ch, d.width + d.input_ch)
+            assert off == self.blob.numel()
+            return [], mlp
         e, out = self.embedder, []
         rows, F = 1 << e.Log2HashmapSize, e.NFeaturesPerLevel
         if e.mode == L.NRF_HASH_NGP:
@@ -257,7 +294,7 @@ class Trainer:
         emb, mlp = self._param_layout()
         cut = lambda t, off, shape: t[off:off + int(np.prod(shape))].reshape(shape).detach().cpu().numpy()
         bufs = None
-        if self.embedder.mode == L.NRF_HASH_CU:
+        if self.has_table and self.embedder.mode == L.NRF_HASH_CU:
             e = self.embedder
             ls = ((1 << e.Log2HashmapSize) >> 4) << 4
             bufs = OrderedDict([(f"{e.name}_primes", np.asarray(e.Primes, np.int32).reshape(e.NLevels, 1, 3)),
@@ -267,7 +304,8 @@ class Trainer:
             [(cut(self.m_table, o, sh), cut(self.v_table, o, sh)) for _, o, sh in emb] + [(cut(self.m_blob, o, sh), cut(self.v_blob, o, sh)) for _, o, sh in mlp]
         if moments is None:
             moments = [None] * (len(emb) + len(mlp))
-        CK.SaveCheckpoint(path, embedder=OrderedDict((n, cut(self.table, o, sh)) for n, o, sh in emb), embedder_buffers=bufs,
+        # (the positional encodings have no parameters: the reference writes an embedder_checkpoint.pt of an empty module there; restoring does not need it, :541-546)
+        CK.SaveCheckpoint(path, embedder=OrderedDict((n, cut(self.table, o, sh)) for n, o, sh in emb) if self.has_table else None, embedder_buffers=bufs,
                           model=OrderedDict((n, cut(self.blob, o, sh)) for n, o, sh in mlp), global_step=global_step,
                           optimizer=dict(moments=moments, step=self.t, lr=self.lr, betas=self.betas, eps=self.eps))
 

@@ -1284,6 +1284,47 @@ def test_trainer_two_steps_vs_reference(api, manifest):
     assert dt.mean() < 8e-3 and (dt > 0.05).mean() < 0.05, (dt.mean(), (dt > 0.05).mean())
 
 
+def test_trainer_two_steps_vs_reference_classic_model(api, manifest):
+    """The same loop body on the classic configuration -- Embedder(10) / Embedder(4) / NeRFImpl with a skip and the view-direction head (a legal TNeRF of NeRFExecutor::Train):
+    Trainer (fused render in NRF_PREC_F32 -> huber -> RawToOutputs backward -> nrf_mlp_backward on NeRFImpl -> Adam) against the reference's CPU autograd over the compiled
+    NeRF.cpp, golden train_classic: loss and mse of both steps, the step-1 gradient of every parameter, and the parameters after the steps at the sign-descent bounds of
+    test_trainer_two_steps_vs_reference."""
+    from nerfpp_amd.train import Trainer
+    g = load_golden("train_classic")
+    ent = manifest["train_classic"]
+    blob = synth.blob_from_manifest(ent)
+    e, ed = api.M.Embedder("embedder", 10), api.M.Embedder("embeddirs", 4)
+    m = api.M.NeRF(4, 64, 63, 27, 5, {1}, True, "model", params=blob)
+    lr = float(g["lr"][0])
+    tr = Trainer(e, ed, m, None, blob, learning_rate=lr)
+    rp = api.R.NeRFRenderParams(NSamples=16, NImportance=16, Chunk=64, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                                BoundingBox=g["bbox"], Precision=api.L.NRF_PREC_F32)
+    o, d, tgt = dev(g["rays_o"]), dev(g["rays_d"]), dev(g["target"])
+    names = [n for n, _, _, _ in ent]
+    lm1, _ = tr.step(o, d, tgt, rp)
+    assert abs(host(lm1)[0] - g["s1_loss"][0]) < 2e-4 and abs(host(lm1)[1] - g["s1_mse"][0]) < 4e-4, (host(lm1), g["s1_loss"], g["s1_mse"])
+    g1 = np.concatenate([g["s1_grad_" + n].reshape(-1) for n in names])
+    got = host(tr.g_blob)
+    # the few rays whose fine sample set differs from the CPU render's contribute their whole difference: a norm-wise bound
+    assert np.linalg.norm(got - g1) < 0.05 * np.linalg.norm(g1), (np.linalg.norm(got - g1), np.linalg.norm(g1))
+    ref1 = np.concatenate([g["s1_param_" + n].reshape(-1) for n in names])
+    d1 = np.abs(host(tr.blob) - ref1) / lr
+    assert d1.mean() < 0.03 and (d1 > 0.05).mean() < 0.04, (d1.mean(), (d1 > 0.05).mean())
+    # second step from the REFERENCE's state after step 1 (its parameters; moments rebuilt from its step-1 gradients)
+    tr.blob.copy_(dev(ref1))
+    tr.m_blob.copy_(dev(0.1 * g1)); tr.v_blob.copy_(dev(np.float32(0.01) * g1 * g1))
+    tr._push_params()
+    lm2, _ = tr.step(o, d, tgt, rp)
+    assert abs(host(lm2)[0] - g["s2_loss"][0]) < 2e-4, (host(lm2), g["s2_loss"])
+    ref2 = np.concatenate([g["s2_param_" + n].reshape(-1) for n in names])
+    d2 = np.abs(host(tr.blob) - ref2) / lr
+    assert d2.mean() < 8e-3 and (d2 > 0.05).mean() < 0.04, (d2.mean(), (d2 > 0.05).mean())
+    assert g["s2_loss"][0] < g["s1_loss"][0] and host(lm2)[0] < host(lm1)[0]
+    # the checkpoint layout of the classic model: the reference's parameter names in its registration order
+    _, lay = tr._param_layout()
+    assert [n for n, _, _ in lay] == names
+
+
 def test_raw_and_training_step_without_importance_sampling(api):
     """N_importance = 0: the render's Raw is the coarse pass's raw (NeRFRenderer.h:421-423) -- also when the coarse intermediates are asked for in the same call (Raw was
     left unwritten then, and a training step differentiated garbage: tools/scratch/train_fuzz.py).  The step's gradients are non-zero and agree between the float-atomic,
