@@ -1094,7 +1094,28 @@ public:
 		const auto opt = rays.options();
 		auto g_table = torch::zeros(table_sizes, opt), g_blob = torch::zeros({blob_numel}, opt);
 		if (n == 0 || !g_rgb_in.defined()) return {g_table, g_blob};
-		if constexpr (!std::is_same_v<TEmbedder, HipHashEmbedder>) { TORCH_CHECK(false, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration"); }
+		if constexpr (!std::is_same_v<TEmbedder, HipHashEmbedder>) {
+			// the classic configuration (HipEmbedder / HipEmbedder / NeRFImpl): the positional encodings carry no parameters, the chain ends at the network's gradient
+			// (nrf_mlp_backward on NeRFImpl: biases, skip concat, view-direction head -- pinned by the reference's autograd, goldens mlp_nerf_bwd*, train_classic)
+			TORCH_CHECK(st.precond_alpha == 0.f && !st.has_cone, "training the classic model through HipNeRFRenderer: thin rays without stochastic preconditioning");
+			auto g_rgb = dev_f32(g_rgb_in).reshape({n, 3});
+			auto g_raw = torch::empty_like(raw);
+			torch::Tensor noise;
+			if (st.noise_std > 0.f) noise = rng_fill(st.seed, st.fine ? NRF_RNG_NOISE_FINE : NRF_RNG_NOISE_COARSE, n * s, true, opt);
+			check(nrf_raw2outputs_backward_noise(raw.data_ptr<float>(), z.data_ptr<float>(), rays.data_ptr<float>() + 3, stride, n, s, 4, st.white_bkgr,
+				noise.defined() ? noise.data_ptr<float>() : nullptr, st.noise_std, g_rgb.data_ptr<float>(), g_raw.data_ptr<float>(), current_stream()), "nrf_raw2outputs_backward");
+			auto pts = torch::empty({n * s, 3}, opt);
+			check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
+			torch::Tensor x = this->EmbedFn->forward(pts).first;
+			if (stride == 11) {
+				using torch::indexing::Slice;
+				torch::Tensor dirs = this->EmbeddirsFn->forward(rays.index({Slice(), Slice(8, 11)}).contiguous()).first;
+				x = torch::cat({x, dirs.unsqueeze(1).expand({n, (int64_t)s, dirs.size(1)}).reshape({n * s, dirs.size(1)})}, 1).contiguous();
+			}
+			const size_t wsb = nrf_mlp_backward_workspace_bytes(Mlp.m, n * s);
+			check(nrf_mlp_backward(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), nullptr, workspace(wsb, rays.device()), wsb,
+				current_stream()), "nrf_mlp_backward");
+		}
 		else {
 			auto g_rgb = dev_f32(g_rgb_in).reshape({n, 3});
 			auto g_raw = torch::empty_like(raw);
@@ -1317,16 +1338,22 @@ private:
 		if (train) {
 			// NeRFExecutor::Train's render (NeRFExecutor.h:876): one autograd node over the library's Chunk loop; loss.backward() then reaches the embedder's and the network's
 			// parameters exactly where the reference's autograd puts their gradients
-			TORCH_CHECK(HasSmall, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration (nrf_mlp_backward)");
+			// two configurations train: hash grid + NeRFSmall (main.cpp:220-221) and the classic HipEmbedder / HipEmbedder / NeRFImpl (a legal TNeRF of the same loop)
+			torch::Tensor table_for_grad;
 			if constexpr (std::is_same_v<TEmbedder, HipHashEmbedder>) {
-				if (from_pose) check(nrf_view_rays(&v, rays_.data_ptr<float>(), nf.data_ptr<float>(), current_stream()), "nrf_view_rays");
-				auto outs = RenderFn::apply(rays_, this->EmbedFn->TableForGrad(), BlobForGrad(), (int64_t)reinterpret_cast<intptr_t>(this), (int64_t)reinterpret_cast<intptr_t>(&render_params),
-					(!render_params.ThinRay && cone_angle.defined() && cone_angle.numel()) ? (double)cone_angle.cpu().template item<float>() : -1.0);
-				auto &o = all_ret.Outputs;
-				o.RGBMap = outs[0]; o.DispMap = outs[1]; o.AccMap = outs[2]; o.DepthMap = outs[3];
-				if (render_params.ReturnWeights) o.Weights = outs[4];
-				if (render_params.ReturnRaw) all_ret.Raw = outs[5];
-			} else TORCH_CHECK(false, "training through HipNeRFRenderer is built for the hash-grid + NeRFSmall configuration");
+				TORCH_CHECK(HasSmall, "training a hash-grid scene through HipNeRFRenderer needs the NeRFSmall network (nrf_mlp_backward)");
+				table_for_grad = this->EmbedFn->TableForGrad();
+			} else {
+				TORCH_CHECK(!HasSmall, "training a positional-encoding scene through HipNeRFRenderer needs the classic NeRFImpl network");
+				table_for_grad = torch::empty({0}, opt);
+			}
+			if (from_pose) check(nrf_view_rays(&v, rays_.data_ptr<float>(), nf.data_ptr<float>(), current_stream()), "nrf_view_rays");
+			auto outs = RenderFn::apply(rays_, table_for_grad, BlobForGrad(), (int64_t)reinterpret_cast<intptr_t>(this), (int64_t)reinterpret_cast<intptr_t>(&render_params),
+				(!render_params.ThinRay && cone_angle.defined() && cone_angle.numel()) ? (double)cone_angle.cpu().template item<float>() : -1.0);
+			auto &o = all_ret.Outputs;
+			o.RGBMap = outs[0]; o.DispMap = outs[1]; o.AccMap = outs[2]; o.DepthMap = outs[3];
+			if (render_params.ReturnWeights) o.Weights = outs[4];
+			if (render_params.ReturnRaw) all_ret.Raw = outs[5];
 		} else if (LibraryChunkLoop) {
 			auto &o = all_ret.Outputs;
 			o.RGBMap = torch::empty({n, 3}, opt); o.DispMap = torch::empty({n}, opt); o.AccMap = torch::empty({n}, opt); o.DepthMap = torch::empty({n}, opt);

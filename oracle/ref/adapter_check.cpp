@@ -26,6 +26,8 @@
 
 using torch::indexing::Slice;
 using torch::indexing::None;
+using ClassicModel = NeRF;                 // (inside a NeRFRenderer subclass the name NeRF is the base's data member)
+using ClassicRendererBase = NeRFRenderer<Embedder, Embedder, ClassicModel>;
 
 static void fill_synth(torch::Tensor p, uint32_t seed, float amp)
 {
@@ -182,8 +184,6 @@ static int run_train(const std::string &dir)
 //     LeRFImpl::forward (LibTorch, on the GPU) on the language grid's features -> sigma mask -> the compiled RawToOutputs' weights (RawToLEOutputs' expression) -> the
 //     reference's inline RenderCLIPEmbedding -> the same loss.  (The language grid is CUDA-only in the reference: both sides use HipHashEmbedder's autograd function.)
 //   * three optimizer steps over the modules' own parameters lower the loss; the test-time render that follows sees the stepped parameters.
-using ClassicModel = NeRF;                 // (inside a NeRFRenderer subclass the name NeRF is the base's data member)
-using ClassicRendererBase = NeRFRenderer<Embedder, Embedder, ClassicModel>;
 struct OpenRawToOutputs : public ClassicRendererBase {
 	OpenRawToOutputs(Embedder e, Embedder d, ClassicModel m) : ClassicRendererBase(e, d, m) {}
 	NeRFRendererOutputs Open(torch::Tensor raw, torch::Tensor z, torch::Tensor d) { return ClassicRendererBase::RawToOutputs(raw, torch::Tensor(), z, d, 0.f, false); }
@@ -496,6 +496,66 @@ static int run_trainfuzz(int cases, uint64_t seed)
 		} catch (const std::exception &ex) { msg += std::string(" EXCEPTION ") + std::string(ex.what()).substr(0, 240); }
 		bad += !msg.empty();
 		printf("case %2d: n %d s %d+%d levels %d T %d colour layers %d:%s\n", c, n, s, ni, L, T, nlc, msg.empty() ? " ok" : msg.c_str());
+		fflush(stdout);
+	}
+	// the classic configuration through the same surface: Embedder / Embedder / NeRFImpl on LibTorch CPU against HipEmbedder / HipEmbedder / NeRFImpl (parameters on the GPU):
+	// loss and every parameter gradient of one training render (NeRFExecutor.h:876-923)
+	for (int c = 0; c < 3; c++) {
+		std::string msg;
+		const int n = rnd(8, 120), s = 16, ni = 16, depth = 3 + rnd(0, 2), width = 32 * rnd(1, 2), skip = rnd(0, depth - 2);
+		try {
+			torch::manual_seed(2000 + c);
+			auto bbox = torch::tensor({-1.5f, -1.5f, -1.5f, 1.5f, 1.5f, 1.5f});
+			Embedder e("embedder", 10), ed("embeddirs", 4);
+			ClassicModel m(depth, width, 63, 27, 5, std::set<int>{skip}, true, "model");
+			int k = 0;
+			for (auto &p : m->named_parameters()) {
+				auto t = p.value();
+				float amp = t.dim() == 2 ? 1.4f * std::sqrt(6.0f / float(t.size(0) + t.size(1))) : 0.1f;
+				if (p.key().find("alpha_linear.weight") != std::string::npos) amp *= 10.0f;
+				fill_synth(t, 70u + 1000u * (k++) + (uint32_t)c, amp);
+			}
+			nrfpp::HipEmbedder he("embedder", 10), hd("embeddirs", 4);
+			ClassicModel hm(depth, width, 63, 27, 5, std::set<int>{skip}, true, "model");
+			hm->to(torch::kCUDA);
+			{
+				torch::NoGradGuard ng;
+				auto mr = m->named_parameters(); auto mh = hm->named_parameters();
+				for (size_t i = 0; i < mr.size(); i++) mh[i].value().copy_(mr[i].value());
+			}
+			nrfpp::HipNeRFRenderer<nrfpp::HipEmbedder, nrfpp::HipEmbedder, ClassicModel> hip(he, hd, hm, NRF_PREC_F32);
+			nrf_mlp_nerf_desc cd{depth, width, 63, 27, 5, skip, 1};
+			hip.SyncWeights(nullptr, &cd);
+			NeRFRenderer<Embedder, Embedder, ClassicModel> ref(e, ed, m);
+			auto [ro, rd, cone] = GetRays(40, 40, lego_K(40, 40), orbit_pose((float)rnd(-180, 180), -30.f, 4.f));
+			auto idx = torch::randint(0, 1600, {n});
+			auto o = ro.reshape({-1, 3}).index_select(0, idx).contiguous(), d = rd.reshape({-1, 3}).index_select(0, idx).contiguous();
+			auto target = torch::rand({n, 3});
+			NeRFRenderParams rp;
+			rp.NSamples = s; rp.NImportance = ni; rp.Chunk = n; rp.ReturnRaw = true; rp.LinDisp = false; rp.Perturb = 0.f; rp.WhiteBkgr = rnd(0, 1) == 1; rp.RawNoiseStd = 0.f;
+			rp.Ndc = false; rp.UseViewdirs = true; rp.ReturnWeights = true; rp.ThinRay = true; rp.RenderFactor = 0; rp.BoundingBox = bbox; rp.StochasticPreconditioningAlpha = 0.f;
+			auto r_ref = ref.Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()}, torch::Tensor(), torch::Tensor());
+			auto l_ref = torch::nn::functional::huber_loss(r_ref.Outputs.RGBMap, target);
+			l_ref.backward();
+			auto rpg = rp; rpg.BoundingBox = bbox.cuda();
+			auto r_hip = hip.Render(0, 0, torch::Tensor(), rpg, {o.cuda(), d.cuda(), torch::Tensor()}, torch::Tensor(), torch::Tensor());
+			auto l_hip = torch::nn::functional::huber_loss(r_hip.Outputs.RGBMap, target.cuda());
+			l_hip.backward();
+			const float lr = l_ref.item<float>(), lh = l_hip.item<float>();
+			if (!(std::abs(lr - lh) <= 1e-2f * std::abs(lr) + 1e-7f)) { char t[96]; snprintf(t, sizeof t, " loss %.8g vs %.8g;", lh, lr); msg += t; }
+			auto mr = m->named_parameters(); auto mh = hm->named_parameters();
+			for (size_t i = 0; i < mr.size(); i++) {
+				auto gr = mr[i].value().grad(), gh = mh[i].value().grad();
+				if (!gr.defined()) gr = torch::zeros_like(mr[i].value());
+				if (!gh.defined()) { msg += " " + mr[i].key() + ": no gradient;"; continue; }
+				auto a = gh.cpu().to(torch::kFloat64), b = gr.to(torch::kFloat64);
+				const double nb = b.norm().item<double>(), err = (a - b).norm().item<double>();
+				if (!torch::isfinite(a).all().item<bool>()) msg += " " + mr[i].key() + ": non-finite;";
+				else if (err > 0.15 * nb + 1e-12) { char t[160]; snprintf(t, sizeof t, " %s: |dg| %.3e of |g| %.3e;", mr[i].key().c_str(), err, nb); msg += t; }
+			}
+		} catch (const std::exception &ex) { msg += std::string(" EXCEPTION ") + std::string(ex.what()).substr(0, 240); }
+		bad += !msg.empty();
+		printf("classic case %d: n %d s %d+%d depth %d width %d skip %d:%s\n", c, n, s, ni, depth, width, skip, msg.empty() ? " ok" : msg.c_str());
 		fflush(stdout);
 	}
 	printf("%s %d\n", bad ? "FAILED" : "all ok", bad);

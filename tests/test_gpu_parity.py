@@ -3054,6 +3054,21 @@ def test_lerf_training_step_one_library_call_vs_oracle_and_descends(api, O):
     tr.close()
 
 
+def test_drop_in_training_render_vs_reference_cpu_autograd_random_models():
+    """oracle/_ref/adapter_check `trainfuzz`: one training render + huber + backward through BOTH hosts -- the reference's NeRFRenderer on LibTorch CPU and the drop-in on the GPU --
+    on random batch sizes / sample counts / grid and network shapes (hash grid + NeRFSmall), and, round 5, on the CLASSIC configuration (Embedder / Embedder / NeRFImpl with a
+    random depth, width and skip layer against HipEmbedder / HipEmbedder / NeRFImpl): loss within 1 %, every parameter gradient within 15 % norm-wise (the rays whose fine
+    sample set moved contribute their whole difference)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, "trainfuzz", "4", "5"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2500:] + out.stderr[-1000:]
+    assert out.stdout.count("classic case") == 3 and out.stdout.count(": ok") >= 7, out.stdout[-2500:]
+
+
 def test_reference_lerf_train_loop_body_runs_through_the_hip_drop_in():
     """The LeRF half of NeRFExecutor::Train's loop body (NeRFExecutor.h:955-982) on the drop-in: oracle/_ref/adapter_check `train_lerf` executes the reference's statements
     verbatim -- LeRFRenderer->Render on the ray batch, huber_loss(..., reduction none, delta 1.25).sum(-1).nanmean(), lang_loss.backward(), Optimizer->step() -- with what
