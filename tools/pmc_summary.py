@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 --pmc counter CSVs written by tools/gpu_pmc.sh into one JSON of per-kernel averages per dispatch.
 
-usage: tools/pmc_summary.py gpurun_out/<tag> profiles/round1/<name>.json
+usage: tools/pmc_summary.py gpurun_out/<tag> docs/history/profiles/round1/<name>.json
 FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived metrics).  `hbm_bytes_per_launch` applies the gfx950 correction of
 MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B fabric read requests at 64 B -> x2 on the read side."""
 import collections
