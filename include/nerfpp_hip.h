@@ -215,6 +215,10 @@ typedef struct nrf_mlp_small_desc {      /* NeRFSmallImpl ctor (NeRF.cpp:322-360
     int input_ch, input_ch_views;
     int num_layers, hidden_dim, geo_feat_dim;
     int num_layers_color, hidden_dim_color;
+    /* the predicted-normals head (NeRF.cpp:343-347, :393-407; the executor builds it only when n_importance == 0 && use_pred_normal, NeRFExecutor.h:487): a third
+     * bias-free net on cat[sigma, geo_feat, input_pts] -> 3, appended to the output: [rgb, sigma, normal xyz] = 7 columns.  NRF_PREC_F32 only (the matrix-core
+     * precisions answer NRF_ERR_UNSUPPORTED for such a handle); RawToOutputs ignores the extra columns (NeRFRenderer.h:279).  Zero-initialised fields = no head. */
+    int use_pred_normal, num_layers_normals, hidden_dim_normals;
 } nrf_mlp_small_desc;
 
 typedef struct nrf_mlp_nerf_desc {       /* NeRFImpl ctor (NeRF.cpp:41-90) */

@@ -27,7 +27,8 @@ class HashDesc(C.Structure):
 
 class MlpSmallDesc(C.Structure):
     _fields_ = [("input_ch", C.c_int), ("input_ch_views", C.c_int), ("num_layers", C.c_int), ("hidden_dim", C.c_int),
-                ("geo_feat_dim", C.c_int), ("num_layers_color", C.c_int), ("hidden_dim_color", C.c_int)]
+                ("geo_feat_dim", C.c_int), ("num_layers_color", C.c_int), ("hidden_dim_color", C.c_int),
+                ("use_pred_normal", C.c_int), ("num_layers_normals", C.c_int), ("hidden_dim_normals", C.c_int)]
 
 
 class MlpNerfDesc(C.Structure):

@@ -138,6 +138,20 @@ static int forward_f32(const nrf_mlp *m, const float *x, int xs, int64_t p, floa
         // out = cat[colour, sigma] (NeRF.cpp:408)
         hipLaunchKernelGGL(k_copy_col, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, st, p, sig, W, 0, out, os, 3);
         NRF_LAUNCH_CHECK();
+        if (d.use_pred_normal) {
+            // predicted normals: cat[sigma, geo_feat, input_pts] -> ... -> 3, no final activation (NeRF.cpp:393-407); out = cat[colour, sigma, normals]
+            // `sig` (the sigma net's last output: column 0 = sigma, 1.. = geo) is one of A / B; the colour chain may have reused the other and C: two scratch rows remain
+            // free only if we are careful -- the head runs AFTER the colour net, out of buffers that no longer hold anything needed: every one except `sig`'s
+            float *nb[2] = {(sig == A) ? B : A, C};
+            Seg sg{sig, W, 0, 1 + d.geo_feat_dim};
+            Seg ncur = sg;
+            for (int l = 0; l < d.num_layers_normals; l++, li++) {
+                const bool last = (l == d.num_layers_normals - 1);
+                float *dst = last ? out : nb[l & 1];
+                NRF_TRY(run_linear(p, l == 0 ? sg : ncur, l == 0 ? Seg{x, xs, 0, d.input_ch} : none, m->layers[li], !last, dst, last ? os : W, last ? 4 : 0, st));
+                ncur = Seg{dst, last ? os : W, 0, m->layers[li].out};
+            }
+        }
         return NRF_OK;
     }
     if (m->family == MLP_NERF) {
@@ -322,7 +336,9 @@ int mlp_small_backward(const nrf_mlp *m, const float *x, int xs, const float *g_
     if (m->family != MLP_SMALL) { set_error("nrf_mlp_backward: built for the NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
     if (ws_bytes < mlp_backward_workspace_bytes(m, p)) { set_error("nrf_mlp_backward: workspace %zu < %zu bytes", ws_bytes, mlp_backward_workspace_bytes(m, p)); return NRF_ERR_WORKSPACE; }
     const auto &d = m->small;
-    const int W = m->max_width, nl = (int)m->layers.size();
+    // (a predicted-normals head, if the handle has one, sits behind these layers and receives no gradient: the training loss reads RGBMap only, NeRFExecutor.h:882-887,
+    // and nothing else reads the normals -- its parameters' gradient stays zero, as in the reference's autograd)
+    const int W = m->max_width, nl = d.num_layers + d.num_layers_color;
     const size_t buf = align_up((size_t)(p < BWD_CHUNK ? p : BWD_CHUNK) * W * sizeof(float), 256) / sizeof(float);
     float *base = reinterpret_cast<float *>(ws);
     std::vector<float *> H(nl);
@@ -732,6 +748,9 @@ int64_t nrf_mlp_small_param_count(const nrf_mlp_small_desc *d)
     for (int l = 0; l < d->num_layers; l++) n += (int64_t)((l == 0) ? d->input_ch : d->hidden_dim) * ((l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim);
     for (int l = 0; l < d->num_layers_color; l++)
         n += (int64_t)((l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color) * ((l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color);
+    if (d->use_pred_normal)                                               // NeRF.cpp:343-347
+        for (int l = 0; l < d->num_layers_normals; l++)
+            n += (int64_t)((l == 0) ? 1 + d->geo_feat_dim + d->input_ch : d->hidden_dim_normals) * ((l == d->num_layers_normals - 1) ? 3 : d->hidden_dim_normals);
     return n;
 }
 
@@ -752,8 +771,9 @@ int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int p
     NRF_CHECK_ARG(d->input_ch > 0 && d->input_ch_views >= 0 && d->num_layers >= 1 && d->hidden_dim > 0 && d->geo_feat_dim >= 0 &&
                   d->num_layers_color >= 1 && d->hidden_dim_color > 0, "nrf_mlp_small_create: bad dimensions");
     nrf_mlp *m = new nrf_mlp();
+    NRF_CHECK_ARG(!d->use_pred_normal || (d->num_layers_normals >= 1 && d->hidden_dim_normals > 0), "nrf_mlp_small_create: use_pred_normal needs num_layers_normals >= 1 and hidden_dim_normals > 0");
     m->family = MLP_SMALL; m->small = *d;
-    m->in_dims = d->input_ch + d->input_ch_views; m->out_dims = 4;
+    m->in_dims = d->input_ch + d->input_ch_views; m->out_dims = d->use_pred_normal ? 7 : 4;
     std::vector<float> hp;
     int s = fetch_params(params, params_on_device, nrf_mlp_small_param_count(d), as_stream(stream), hp, m);
     size_t off = 0;
@@ -761,9 +781,12 @@ int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int p
         s = add_layer(m, hp, off, (l == 0) ? d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? (1 + d->geo_feat_dim) : d->hidden_dim, false);
     for (int l = 0; l < d->num_layers_color && s == NRF_OK; l++)
         s = add_layer(m, hp, off, (l == 0) ? d->input_ch_views + d->geo_feat_dim : d->hidden_dim_color, (l == d->num_layers_color - 1) ? 3 : d->hidden_dim_color, false);
-    if (s == NRF_OK) s = mlp_small_pack_f16(m, hp);
-    if (s == NRF_OK) s = mlp_small_pack_sigma_f32(m, hp);
-    if (s == NRF_OK) s = build_weight_maps(m, hp);
+    for (int l = 0; d->use_pred_normal && l < d->num_layers_normals && s == NRF_OK; l++)
+        s = add_layer(m, hp, off, (l == 0) ? 1 + d->geo_feat_dim + d->input_ch : d->hidden_dim_normals, (l == d->num_layers_normals - 1) ? 3 : d->hidden_dim_normals, false);
+    // the matrix-core images describe the two-net model: a handle with the normals head keeps to the fp32 layer kernels
+    if (s == NRF_OK && !d->use_pred_normal) s = mlp_small_pack_f16(m, hp);
+    if (s == NRF_OK && !d->use_pred_normal) s = mlp_small_pack_sigma_f32(m, hp);
+    if (s == NRF_OK && !d->use_pred_normal) s = build_weight_maps(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -867,7 +890,7 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
         if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, hp.data() + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyHostToDevice, st));
     }
     NRF_HIP(hipStreamSynchronize(st));
-    if (m->family == MLP_SMALL) { NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }
+    if (m->family == MLP_SMALL) { if (m->small.use_pred_normal) return NRF_OK; NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }
     if (m->family == MLP_NERF) { NRF_TRY(mlp_nerf_pack_f16(m, hp)); return mlp_nerf_pack_sigma_f32(m, hp); }
     if (m->family == MLP_LERF) { NRF_TRY(mlp_lerf_pack_f16(m, hp)); return mlp_lerf_pack_sigma_f32(m, hp); }
     return NRF_OK;

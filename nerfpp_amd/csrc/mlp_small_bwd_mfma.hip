@@ -561,7 +561,7 @@ struct BPacker {
 
 bool bwd_supported(const nrf_mlp_small_desc &d)
 {
-    return d.input_ch == 32 && d.input_ch_views == V && d.hidden_dim == 64 && d.hidden_dim_color == 64 && d.geo_feat_dim == GEO &&
+    return !d.use_pred_normal && d.input_ch == 32 && d.input_ch_views == V && d.hidden_dim == 64 && d.hidden_dim_color == 64 && d.geo_feat_dim == GEO &&
            (d.num_layers == 2 || d.num_layers == 3) && (d.num_layers_color == 3 || d.num_layers_color == 4);
 }
 

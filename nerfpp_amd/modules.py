@@ -209,14 +209,13 @@ class BaseNeRF:
 
 
 class NeRFSmall(BaseNeRF):
-    """NeRFSmallImpl (NeRF.h:212-254, NeRF.cpp:322-412); use_pred_normal must be false on the render path
-    (NeRFExecutor.h:487 turns it off whenever n_importance > 0)."""
+    """NeRFSmallImpl (NeRF.h:212-254, NeRF.cpp:322-412).  use_pred_normal adds the predicted-normals head (NeRF.cpp:343-347, :393-407; the executor builds it only
+    when n_importance == 0, NeRFExecutor.h:487): output [rgb, sigma, normal xyz], NRF_PREC_F32 only."""
 
     def __init__(self, num_layers=3, hidden_dim=64, geo_feat_dim=15, num_layers_color=4, hidden_dim_color=64, use_pred_normal=False,
                  num_layers_normals=3, hidden_dim_normals=64, input_ch=3, input_ch_views=3, module_name="hashnerf", params=None):
-        if use_pred_normal:
-            raise L.NrfError("NeRFSmall(use_pred_normal=True) is a training-time branch (normals head); not on the render path")
-        self.desc = L.MlpSmallDesc(input_ch, input_ch_views, num_layers, hidden_dim, geo_feat_dim, num_layers_color, hidden_dim_color)
+        self.desc = L.MlpSmallDesc(input_ch, input_ch_views, num_layers, hidden_dim, geo_feat_dim, num_layers_color, hidden_dim_color,
+                                   int(bool(use_pred_normal)), int(num_layers_normals) if use_pred_normal else 0, int(hidden_dim_normals) if use_pred_normal else 0)
         self.n_params = L.lib().nrf_mlp_small_param_count(C.byref(self.desc))
         if params is not None:
             self.load(params)

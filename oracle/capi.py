@@ -162,6 +162,15 @@ def mlp_small(params, x, in_ch, in_views, n_layers=3, hidden=64, geo=15, n_layer
     return out
 
 
+def mlp_small_pred_normal(params, x, in_ch, in_views, n_layers=3, hidden=64, geo=15, n_layers_c=4, hidden_c=64, n_layers_n=3, hidden_n=64):
+    """NeRFSmallImpl::forward with the predicted-normals head (orc_mlp_small_pred_normal) -> [p, 7] = (rgb, sigma, normal)."""
+    params = _f(params); x = _f(x)
+    out = np.empty((x.shape[0], 7), np.float32)
+    lib().orc_mlp_small_pred_normal(_p(params), _p(x), C.c_int64(x.shape[0]), C.c_int(in_ch), C.c_int(in_views), C.c_int(n_layers), C.c_int(hidden), C.c_int(geo), C.c_int(n_layers_c),
+                                    C.c_int(hidden_c), C.c_int(n_layers_n), C.c_int(hidden_n), _p(out))
+    return out
+
+
 def mlp_nerf(params, x, d=8, w=256, in_ch=63, in_views=27, out_ch=4, skip=4, use_viewdirs=True):
     params = _f(params); x = _f(x)
     n = lib().orc_mlp_nerf_param_count(C.c_int(d), C.c_int(w), C.c_int(in_ch), C.c_int(in_views), C.c_int(out_ch), C.c_int(skip), C.c_int(int(use_viewdirs)))

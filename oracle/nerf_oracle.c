@@ -798,6 +798,34 @@ ORC_API void orc_mlp_small(const float *params, const float *x /*[p, in_ch+in_vi
     }
 }
 
+/* M2 with the predicted-normals head (NeRF.cpp:343-347, :393-407; built by the executor only when n_importance == 0 && use_pred_normal, NeRFExecutor.h:487):
+ *     a third bias-free net on cat[sigma, geo_feat, input_pts] -> Hn .. -> 3, no final activation; out = cat[colour, sigma, normals] [p, 7].
+ *     blob: sigma net, colour net, normals net (registration order, NeRF.cpp:349-359) */
+ORC_API void orc_mlp_small_pred_normal(const float *params, const float *x, int64_t p, int in_ch, int in_views, int n_layers, int hidden, int geo, int n_layers_c,
+                                       int hidden_c, int n_layers_n, int hidden_n, float *out /*[p,7]*/)
+{
+    int64_t off_n = 0;
+    { int cd = in_ch; for (int l = 0; l < n_layers; l++) { int od = (l == n_layers - 1) ? (1 + geo) : hidden; off_n += (int64_t)cd * od; cd = od; }
+      cd = in_views + geo; for (int l = 0; l < n_layers_c; l++) { int od = (l == n_layers_c - 1) ? 3 : hidden_c; off_n += (int64_t)cd * od; cd = od; } }
+    OMP_FOR
+    for (int64_t i = 0; i < p; i++) {
+        float a[1024], b2[1024], h33[512], cin[1024];
+        const float *xi = x + i * (in_ch + in_views);
+        float o4[4];
+        orc_mlp_small(params, xi, 1, in_ch, in_views, n_layers, hidden, geo, n_layers_c, hidden_c, o4);
+        /* the sigma net's output again (orc_mlp_small keeps it local): same chain, same bits */
+        { const float *w = params; const float *cur = xi; int cd = in_ch; float *bufs[2] = {a, b2};
+          for (int l = 0; l < n_layers; l++) { int od = (l == n_layers - 1) ? (1 + geo) : hidden; linear(w, NULL, cur, cd, od, bufs[l & 1], l != n_layers - 1); w += (int64_t)cd * od; cur = bufs[l & 1]; cd = od; }
+          memcpy(h33, cur, sizeof(float) * (1 + geo)); }
+        for (int k = 0; k < 1 + geo; k++) cin[k] = h33[k];                 /* cat[sigma.unsqueeze(-1), geo_feat, input_pts]  (NeRF.cpp:396) */
+        for (int k = 0; k < in_ch; k++) cin[1 + geo + k] = xi[k];
+        const float *w = params + off_n; const float *cur = cin; int cd = 1 + geo + in_ch; float *bufs[2] = {a, b2};
+        for (int l = 0; l < n_layers_n; l++) { int od = (l == n_layers_n - 1) ? 3 : hidden_n; linear(w, NULL, cur, cd, od, bufs[l & 1], l != n_layers_n - 1); w += (int64_t)cd * od; cur = bufs[l & 1]; cd = od; }
+        for (int k = 0; k < 4; k++) out[i * 7 + k] = o4[k];
+        for (int k = 0; k < 3; k++) out[i * 7 + 4 + k] = cur[k];
+    }
+}
+
 /* M1  NeRFImpl::forward                    NeRF.cpp:41-126
  *     D Linear(+bias)+ReLU; after layer index `skip` h = cat[input_pts, h] (NeRF.cpp:103-104);
  *     viewdirs: alpha = Linear(W,1)(h); feat = Linear(W,W)(h) (no ReLU); h = cat[feat, views];

@@ -371,6 +371,14 @@ static void g_mlp()
 		save_npy(tag + ".x", x); save_npy(tag + ".y", y);
 	}
 	{
+		// M2 with the predicted-normals head (use_pred_normal = true, NeRF.cpp:343-347, :393-407; selected by the executor when n_importance == 0, NeRFExecutor.h:487): [p, 7]
+		std::string tag = "mlp_small_pn";
+		NeRFSmall m(3, 64, 15, 3, 64, true, 3, 64, 32, 16, "model");
+		fill_module(tag, m, 6200u, 1.6f, 0.f);
+		auto x = synth_tensor({48, 48}, 63u, 1.0f);
+		save_npy(tag + ".x", x); save_npy(tag + ".y", m->forward(x));
+	}
+	{
 		// SH degree 8 direction input (main.cpp:188) -> 64-d views
 		std::string tag = "mlp_small_v64";
 		NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 32, 64, "model");

@@ -2911,6 +2911,40 @@ def test_reference_train_loop_body_runs_through_the_hip_drop_in(tmp_path, manife
     assert r["loss_step2"] < r["loss_step1"]
 
 
+def test_mlp_small_with_the_predicted_normals_head(api, O, manifest):
+    """NeRFSmall(use_pred_normal = true) (NeRF.cpp:343-347, :393-407; the executor builds it when n_importance == 0, NeRFExecutor.h:487): output [rgb, sigma, normal xyz] in
+    NRF_PREC_F32 == the oracle bit for bit and the compiled reference to 1e-4; the matrix-core precisions refuse such a handle loudly; a coarse-only render returns Raw with
+    7 columns (RawToOutputs ignores the last three, NeRFRenderer.h:279) -- and the reference's keep-mask quirk with this head is reproduced (see below)."""
+    g = load_golden("mlp_small_pn")
+    blob = synth.blob_from_manifest(manifest["mlp_small_pn"])
+    m = api.M.NeRFSmall(3, 64, 15, 3, 64, True, 3, 64, 32, 16, "model", params=blob)
+    assert m.GetOutputDims() == 7
+    y = host(m.forward(dev(g["x"]), precision=api.L.NRF_PREC_F32))
+    assert_exact(y, O.mlp_small_pred_normal(blob, g["x"], in_ch=32, in_views=16, n_layers_c=3), "NRF_PREC_F32 == oracle")
+    assert_close(y, g["y"], rtol=1e-4, atol=1e-5, what="vs the compiled reference")
+    with pytest.raises(api.L.NrfError):
+        m.forward(dev(g["x"]), precision=api.L.NRF_PREC_F16_SPLIT)
+    # through the renderer: CuHash-less scene with the LibTorch encoders, coarse only (the configuration the executor pairs with this head)
+    sc = api.S.make_hash_scene(mode="ngp", log2_t=14, seed=5000)
+    d = api.L.MlpSmallDesc(32, 16, 3, 64, 15, 4, 64, 1, 3, 64)
+    n_pn = int(api.L.lib().nrf_mlp_small_param_count(C.byref(d)))
+    blob2 = np.concatenate([sc["mlp_blob"], synth.synth_sym(91, (n_pn - sc["mlp_blob"].size,), np.float32(0.1))]).astype(np.float32)      # the scene's two nets + a normals net
+    m2 = api.M.NeRFSmall(3, 64, 15, 4, 64, True, 3, 64, 32, 16, "model", params=blob2)
+    r2 = api.R.NeRFRenderer(sc["embedder"], sc["embeddirs"], m2)
+    K = api.S.lego_K(16, 16); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    rp = api.S.lego_render_params(sc["bbox"], 64, 0, 128, api.L.NRF_PREC_F32, ReturnRaw=True)
+    a = r2.Render(16, 16, K, rp, c2w=c2w)
+    b = sc["renderer"].Render(16, 16, K, rp, c2w=c2w)
+    assert host(a.Raw).shape == (256, 64, 7) and host(b.Raw).shape == (256, 64, 4)
+    ra, rb = host(a.Raw), host(b.Raw)
+    assert_exact(ra[..., :3], rb[..., :3], "colour columns == the two-net model's")
+    # REFERENCE QUIRK reproduced: RunNetwork masks `outputs_flat[~keep_mask, -1]` (NeRFRenderer.h:187-188) -- with this head column -1 is the normal's z, not sigma: a point
+    # outside the box keeps its density and loses its normal's z.  So sigma differs from the two-net model exactly where that model masked it, and there the last column is 0
+    diff = ra[..., 3] != rb[..., 3]
+    assert diff.any() and (rb[..., 3][diff] == 0).all() and (ra[..., 6][diff] == 0).all() and (ra[..., 6][~diff] != 0).mean() > 0.99
+    assert np.abs(ra[..., 4:]).max() > 0 and np.isfinite(host(a.Outputs.RGBMap)).all()
+
+
 # ------------------------------------------------------------------ N1 for the classic model: backward of NeRFImpl::forward (NeRF.cpp:92-126)
 @pytest.mark.parametrize("tag", ["mlp_nerf_bwd", "mlp_nerf_bwd_noview", "mlp_nerf_bwd_full"])
 def test_classic_mlp_backward_vs_reference_autograd(api, O, tag, manifest):

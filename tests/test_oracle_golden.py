@@ -214,6 +214,14 @@ def test_mlp_small(tag, kw, manifest):
     assert_close(y, g["y"], rtol=1e-4, atol=1e-5)
 
 
+def test_mlp_small_with_the_predicted_normals_head(manifest):
+    """NeRFSmall(use_pred_normal = true): [rgb, sigma, normal] -- the third net on cat[sigma, geo_feat, input_pts] (NeRF.cpp:393-407) against the compiled reference."""
+    g = load_golden("mlp_small_pn")
+    y = O.mlp_small_pred_normal(synth.blob_from_manifest(manifest["mlp_small_pn"]), g["x"], in_ch=32, in_views=16, n_layers_c=3)
+    assert g["y"].shape == (48, 7)
+    assert_close(y, g["y"], rtol=1e-4, atol=1e-5)
+
+
 def test_mlp_nerf(manifest):
     g = load_golden("mlp_nerf")
     assert_close(O.mlp_nerf(synth.blob_from_manifest(manifest["mlp_nerf"]), g["x"], out_ch=5), g["y"], rtol=1e-4, atol=1e-5)
