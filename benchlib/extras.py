@@ -135,6 +135,10 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
         out.append(lerf_train_step_measurement(scene, L))
     except Exception as e:
         out.append(dict(workload="lerf_train_step", error=str(e)))
+    try:
+        out.append(classic_train_step_measurement(scene, L))
+    except Exception as e:
+        out.append(dict(workload="classic_train_step", error=str(e)))
     for lp in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA):
         try:
             out.append(lerf_measurement(scene, L, K, c2w, lp))
@@ -277,8 +281,35 @@ def lerf_train_step_measurement(scene, L, n_rand=16384, steps=2):
         tr.close()
     return dict(workload="lerf_train_step", baseline_config=5, rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt, value=n_rand * UNITS_PER_RAY / dt,
                 unit="ray-samples/s", steps=steps, loss_first_last=losses,
-                arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated by fp32 layer kernels (no matrix cores yet), language-grid "
-                           "gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
+                fp32_layer_products="rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels",
+                arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated in fp32 (layer products as library GEMMs on the fp32 matrix "
+                           "cores, weight gradients split over 32 point slices), language-grid gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
+
+
+def classic_train_step_measurement(scene, L, n_rand=4096, steps=3):
+    """N1 on the classic configuration (Embedder(10) / Embedder(4) / NeRFImpl 8x256, a legal TNeRF of NeRFExecutor::Train): render, huber, backward through RawToOutputs and
+    NeRFImpl (fp32 layer products: rocBLAS on the fp32 matrix cores where present), Adam -- 4 096 rays per step (a quarter of main.cpp:232's batch: the step is GEMM-bound and linear)."""
+    import torch
+    from nerfpp_amd import renderer as R
+    from nerfpp_amd.train import Trainer
+    sc = scene.make_classic_scene()
+    K = scene.lego_K(H, W); c2w = scene.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(H, W, K, c2w)
+    idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
+    o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
+    tgt = torch.rand((n_rand, 3), device="cuda")
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], None, sc["mlp_blob"], learning_rate=5e-4)
+    rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=scene.LEGO_BBOX,
+                            Precision=L.NRF_PREC_F16_SPLIT)
+    l0, _ = tr.step(o, d, tgt, rp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l, _ = tr.step(o, d, tgt, rp)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(workload="classic_train_step", baseline_config=2, rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt, value=n_rand * UNITS_PER_RAY / dt,
+                unit="ray-samples/s", steps=steps, loss_first_last=[float(l0[0]), float(l[0])], fp32_layer_products="rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels")
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):

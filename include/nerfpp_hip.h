@@ -689,6 +689,9 @@ NRF_API int nrf_set_render_lanes(int lanes);
 NRF_API int nrf_get_render_lanes(void);
 /* ... per renderer: 1-4 lanes for this renderer's calls whatever the process-wide setting; 0 returns it to that setting (two renderers of one process need not share it). */
 NRF_API int nrf_renderer_set_lanes(nrf_renderer *r, int lanes);
+/* 1 when the fp32 layer products of the training paths (classic and LeRF backward, NeRFSmall's fp32 backward) run as rocBLAS GEMMs on the fp32 matrix cores (the library is
+ * looked up with dlopen at first use, preferring the copy the process already maps), 0 when they run the hand-written FMA kernels (rocBLAS absent, or NRF_FP32_GEMM=0). */
+NRF_API int nrf_fp32_gemm_available(void);
 NRF_API int nrf_profile_enable(int on);
 /* 1 while the event bracketing is on.  A throughput measurement must run with it off: an event pair around every kernel of every lane costs host time per launch and
  * separates the kernels on the device (bench.py asserts 0 before its timed region; the per-kernel times come from a separate pass).  Events are pooled: none is created on

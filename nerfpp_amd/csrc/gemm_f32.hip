@@ -1,0 +1,177 @@
+// gemm_f32.hip -- the plain fp32 layer products of the TRAINING paths (the recomputed forward and the backward of the classic NeRFImpl and of the LeRF head; the fp32
+// backward of NeRFSmall) as library GEMMs: rocBLAS sgemm, which runs them on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Why a library here and hand-written kernels everywhere else: these are textbook row-major GEMMs with nothing to fuse (Y = X W^T, G_in = G W, dW += G^T X over 10^4..10^6
+// points), carry no bit-exactness requirement (a gradient is compared with autograd at 1e-4), and are not on the render path.  The parity mode's forward (NRF_PREC_F32 ==
+// the oracle's FMA chains bit for bit) never comes here: it keeps mlp.hip's k_linear.  rocBLAS is resolved with dlopen at first use -- the copy the process already maps
+// (LibTorch's) if there is one -- so libnerfpp_hip.so carries no link-time dependency on it; without it, or with NRF_FP32_GEMM=0, the hand-written fp32 kernels of mlp.hip run.
+#include "mlp.h"
+
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>
+
+#include <mutex>
+
+namespace nrf {
+
+struct RocBlas {
+    void *handle = nullptr;
+    decltype(&rocblas_create_handle) create = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocblas_sgemm) sgemm = nullptr;
+    decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
+    decltype(&rocblas_set_pointer_mode) set_pointer_mode = nullptr;
+    decltype(&rocblas_set_atomics_mode) set_atomics_mode = nullptr;
+};
+
+static RocBlas g_rb;
+static std::once_flag g_rb_once;
+static std::mutex g_rb_mu;
+static rocblas_handle g_rb_handle[64] = {};        // one per device
+
+static void rb_load()
+{
+    if (const char *e = getenv("NRF_FP32_GEMM")) if (atoi(e) == 0) return;
+    const char *names[] = {"librocblas.so.5", "librocblas.so"};
+    void *h = nullptr;
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);       // the copy the host process already uses
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    RocBlas r;
+    r.handle = h;
+    r.create = reinterpret_cast<decltype(r.create)>(dlsym(h, "rocblas_create_handle"));
+    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(h, "rocblas_set_stream"));
+    r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(h, "rocblas_sgemm"));
+    r.sgemm_sb = reinterpret_cast<decltype(r.sgemm_sb)>(dlsym(h, "rocblas_sgemm_strided_batched"));
+    r.set_pointer_mode = reinterpret_cast<decltype(r.set_pointer_mode)>(dlsym(h, "rocblas_set_pointer_mode"));
+    r.set_atomics_mode = reinterpret_cast<decltype(r.set_atomics_mode)>(dlsym(h, "rocblas_set_atomics_mode"));
+    if (r.create && r.set_stream && r.sgemm) g_rb = r;
+}
+
+// the device's handle bound to `st`, or nullptr (no rocBLAS: the callers fall back to the hand-written kernels)
+static rocblas_handle rb_handle(hipStream_t st)
+{
+    std::call_once(g_rb_once, rb_load);
+    if (!g_rb.handle) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_rb_mu);
+    if (!g_rb_handle[dev]) {
+        rocblas_handle h = nullptr;
+        if (g_rb.create(&h) != rocblas_status_success) return nullptr;
+        if (g_rb.set_pointer_mode) (void)g_rb.set_pointer_mode(h, rocblas_pointer_mode_host);
+        g_rb_handle[dev] = h;
+    }
+    if (g_rb.set_stream(g_rb_handle[dev], st) != rocblas_status_success) return nullptr;
+    return g_rb_handle[dev];
+}
+
+int fp32_gemm_available() { std::call_once(g_rb_once, rb_load); return g_rb.handle != nullptr; }
+
+// Row-major views: a row-major [rows][ld] array IS the column-major matrix (cols_of_the_view x rows) with leading dimension ld.
+// y[pt][y_off + o] (+)= sum_k seg[pt][k] W[o][w_col0 + k]          W: the blob's [out][in] block
+static bool gemm_fwd_seg(rocblas_handle h, int64_t npts, Seg x, const float *w_blob, int in, int w_col0, int out, float beta, float *y, int y_stride, int y_off)
+{
+    if (x.n == 0) return true;
+    const float alpha = 1.0f;
+    // Y_cm (out x pts, ld y_stride) = W_cm^T (W_cm = in x out, ld in; rows w_col0..) . X_cm (x.n x pts, ld x.stride)
+    return g_rb.sgemm(h, rocblas_operation_transpose, rocblas_operation_none, out, (rocblas_int)npts, x.n, &alpha, w_blob + w_col0, in, x.p + x.off, x.stride, &beta, y + y_off,
+                      y_stride) == rocblas_status_success;
+}
+
+__global__ void k_bias_relu(int64_t total, int out, float *__restrict__ y, int y_stride, int y_off, const float *__restrict__ bias, int relu)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int64_t pt = e / out; const int o = (int)(e - pt * out);
+    float v = y[pt * y_stride + y_off + o];
+    if (bias) v = v + bias[o];
+    if (relu) v = v < 0.0f ? 0.0f : v;
+    y[pt * y_stride + y_off + o] = v;
+}
+
+// Linear(+bias)(+ReLU) on cat[a, b]: the library product, then one elementwise pass where there is a bias or a ReLU.  Falls back to mlp.hip's kernel.
+int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
+{
+    rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
+    if (!h || npts > 0x7fffffff) return run_linear(npts, a, b, L, relu, y, y_stride, y_off, st);
+    const float *wb = m->d_params + L.w_off;
+    if (!gemm_fwd_seg(h, npts, a, wb, L.in, 0, L.out, 0.0f, y, y_stride, y_off) || !gemm_fwd_seg(h, npts, b, wb, L.in, a.n, L.out, 1.0f, y, y_stride, y_off)) {
+        set_error("rocblas_sgemm failed (forward layer %d -> %d over %lld points)", L.in, L.out, (long long)npts);
+        return NRF_ERR_HIP;
+    }
+    if (L.d_bias || relu) {
+        hipLaunchKernelGGL(k_bias_relu, dim3((unsigned)ceil_div(npts * L.out, 256)), dim3(256), 0, st, npts * L.out, L.out, y, y_stride, y_off, (const float *)L.d_bias, relu);
+        NRF_LAUNCH_CHECK();
+    }
+    return NRF_OK;
+}
+
+// dw[(o) * in + col0 + i] += sum_b part[b][o][i]
+__global__ void k_sum_partials(int batches, int out, int n, int in, int col0, const float *__restrict__ part, float *__restrict__ dw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= out * n) return;
+    float acc = 0.0f;
+    for (int bch = 0; bch < batches; bch++) acc += part[(size_t)bch * out * n + e];
+    const int o = e / n, i = e - o * n;
+    dw[(size_t)o * in + col0 + i] += acc;
+}
+
+// dw[o][i] += sum_pt g[pt][o] cat[a, b][pt][i]: accumulated by the GEMM itself (beta = 1), no atomics.  A weight gradient is a SMALL matrix (out x in) summed over very
+// MANY points: as one GEMM it is a handful of output tiles with a huge K (12 workgroups for 768 x 256: 29 TFLOP/s).  Above 16 k points the points are cut into 32 slices
+// computed as one strided-batched GEMM into partial matrices, which one small kernel then adds to dw.
+int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st)
+{
+    rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
+    if (!h || npts > 0x7fffffff) return run_grad_w(npts, g, a, b, out, in, dw, st);
+    const float one = 1.0f, zero = 0.0f;
+    constexpr int SLICES = 32;
+    const bool split = g_rb.sgemm_sb && npts >= 16384 && (int64_t)out * in <= 1024 * 1024;
+    float *part = nullptr;
+    if (split) {
+        const int nmax = a.n > b.n ? a.n : b.n;
+        if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)SLICES * out * nmax * sizeof(float), st) != hipSuccess) { set_error("run_grad_w_fast: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    }
+    auto seg = [&](Seg x, int col0) {
+        if (x.n == 0) return true;
+        if (split) {
+            const int64_t per = npts / SLICES, done = per * SLICES;
+            // part[b] (x.n x out, compact) = X_b (x.n x per) . G_b^T
+            if (g_rb.sgemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, x.n, out, (rocblas_int)per, &one, x.p + x.off, x.stride, (rocblas_stride)(per * x.stride), g.p + g.off,
+                              g.stride, (rocblas_stride)(per * g.stride), &zero, part, x.n, (rocblas_stride)((int64_t)out * x.n), SLICES) != rocblas_status_success) return false;
+            hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)ceil_div((int64_t)out * x.n, 256)), dim3(256), 0, st, SLICES, out, x.n, in, col0, (const float *)part, dw);
+            if (done == npts) return true;
+            return g_rb.sgemm(h, rocblas_operation_none, rocblas_operation_transpose, x.n, out, (rocblas_int)(npts - done), &one, x.p + done * x.stride + x.off, x.stride,
+                              g.p + done * g.stride + g.off, g.stride, &one, dw + col0, in) == rocblas_status_success;
+        }
+        // dW_cm (in x out, ld in; rows col0..) += X_cm (x.n x pts, ld x.stride) . G_cm^T (G_cm = out x pts, ld g.stride)
+        return g_rb.sgemm(h, rocblas_operation_none, rocblas_operation_transpose, x.n, out, (rocblas_int)npts, &one, x.p + x.off, x.stride, g.p + g.off, g.stride, &one, dw + col0,
+                          in) == rocblas_status_success;
+    };
+    const bool ok = seg(a, 0) && seg(b, a.n);
+    if (part) (void)hipFreeAsync(part, st);
+    if (!ok) { set_error("rocblas_sgemm failed (weight gradient %d x %d over %lld points)", out, in, (long long)npts); return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+
+// y[pt][k] = sum_o g[pt][o] W[o][k]
+int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st)
+{
+    rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
+    if (!h || npts > 0x7fffffff) return run_backprop(npts, g, m, L, y, y_stride, st);
+    const float one = 1.0f, zero = 0.0f;
+    // Y_cm (in x pts, ld y_stride) = W_cm (in x out, ld in) . G_cm (out x pts, ld g.stride)
+    if (g_rb.sgemm(h, rocblas_operation_none, rocblas_operation_none, L.in, (rocblas_int)npts, L.out, &one, m->d_params + L.w_off, L.in, g.p + g.off, g.stride, &zero, y, y_stride) !=
+        rocblas_status_success) {
+        set_error("rocblas_sgemm failed (backprop %d <- %d over %lld points)", L.in, L.out, (long long)npts);
+        return NRF_ERR_HIP;
+    }
+    return NRF_OK;
+}
+
+}  // namespace nrf
+
+// 1 when the training paths' fp32 layer products run as rocBLAS GEMMs on the fp32 matrix cores, 0 when they run mlp.hip's hand-written FMA kernels (rocBLAS absent or NRF_FP32_GEMM=0)
+extern "C" NRF_API int nrf_fp32_gemm_available(void) { return nrf::fp32_gemm_available(); }

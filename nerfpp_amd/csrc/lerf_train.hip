@@ -18,7 +18,9 @@ extern "C" const nrf_mlp *nrf_lerf_renderer_head(const nrf_lerf_renderer *r);
 
 namespace nrf {
 
-constexpr int64_t LT_CHUNK_PTS = 1 << 15;        // sample points per pass: 2 n_layers + 4 activation / gradient buffers of this many rows x the widest layer
+// sample points per pass: 2 n_layers + 4 activation / gradient buffers of this many rows x the widest layer (main.cpp sizes: 8 x 400 MB).  With 2^15 a pass was 170
+// rays = 170 workgroups of the per-ray kernel on 256 CUs, and every layer product a launch of a few tens of microseconds (profiles/round5/r5o_*)
+constexpr int64_t LT_CHUNK_PTS = 1 << 17;
 
 __device__ __forceinline__ double lt_wave_sum(double v)
 {
@@ -228,13 +230,13 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     const Seg xin{emb, in, 0, in};
     Seg cur = xin;
     for (int l = 0; l < nl; l++) {
-        NRF_TRY(run_linear(c, cur, none, m->layers[l], l != nl - 1, H[l], W, 0, st));
+        NRF_TRY(run_linear_fast(c, cur, none, m, m->layers[l], l != nl - 1, H[l], W, 0, st));
         cur = Seg{H[l], W, 0, m->layers[l].out};
     }
     const float *h33 = H[nl - 1];                                         // column 0 = sigma_le, 1.. = geo_feat_le
     const Seg sgeo{h33, W, 1, geo};
     for (int l = 0; l < nl; l++) {
-        NRF_TRY(run_linear(c, l == 0 ? sgeo : cur, l == 0 ? xin : none, m->layers[nl + l], l != nl - 1, H[nl + l], W, 0, st));
+        NRF_TRY(run_linear_fast(c, l == 0 ? sgeo : cur, l == 0 ? xin : none, m, m->layers[nl + l], l != nl - 1, H[nl + l], W, 0, st));
         cur = Seg{H[nl + l], W, 0, m->layers[nl + l].out};
     }
     float *hle = H[NL - 1];                                               // h [c, E] -> le -> g_h, in place
@@ -253,9 +255,9 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         const LinearLayer &L = m->layers[l];
         if (l != NL - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
-        NRF_TRY(run_grad_w(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st));
+        NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st));
         float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
-        NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
         g = Seg{dst, W, 0, L.in};
     }
     // g = d / d cat[geo, in]: the sigma net's output gradient = (g_sigma [already in g33 column 0], g_geo)
@@ -270,10 +272,10 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     for (int l = nl - 1; l >= 0; l--) {
         const LinearLayer &L = m->layers[l];
         if (l != nl - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
-        NRF_TRY(run_grad_w(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
+        NRF_TRY(run_grad_w_fast(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
         if (l == 0 && !g_emb) break;
         float *dst = freeb[fi]; fi ^= 1;
-        NRF_TRY(run_backprop(c, g, m, L, dst, W, st));
+        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
         g = Seg{dst, W, 0, L.in};
     }
     if (g_emb) {                                                           // d / d emb = through the sigma net + through the LE net's cat[geo, in]

@@ -80,6 +80,13 @@ int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, fl
 //   g[pt][k] = 0 where act[pt][k] <= 0
 int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act, int act_stride, hipStream_t st);
 
+// the same three products for the TRAINING paths (no bit-exactness requirement): rocBLAS sgemm on the fp32 matrix cores when the library is present, else the kernels above
+// (gemm_f32.hip); the weights are read from the handle's blob m->d_params
+int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
+int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
+int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st);
+int fp32_gemm_available();
+
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,

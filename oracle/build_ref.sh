@@ -67,11 +67,11 @@ echo "built $out/ref_driver"
 # reference CPU renderer.  Links the repo's own libnerfpp_hip.so (rpath relative to the binary) and LibTorch's HIP backend.
 hiplib="$here/../nerfpp_amd/lib/libnerfpp_hip.so"
 if [ -f "$hiplib" ]; then
-  if stale "$out/obj/adapter_check.o" "$here/ref/adapter_check.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_check.o" ]; then
+  if stale "$out/obj/adapter_check.o" "$here/ref/adapter_check.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_check.o" ] || [ "$here/../include/nerfpp_hip.h" -nt "$out/obj/adapter_check.o" ]; then
     $CXX $FLAGS $INC -c "$here/ref/adapter_check.cpp" -o "$out/obj/adapter_check.o"
   fi
   # the LeRFRenderer subclass: compile-only (its base class's unit needs the external RuCLIP module; see the file's header)
-  if stale "$out/obj/adapter_lerf_compile.o" "$here/ref/adapter_lerf_compile.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_lerf_compile.o" ]; then
+  if stale "$out/obj/adapter_lerf_compile.o" "$here/ref/adapter_lerf_compile.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_lerf_compile.o" ] || [ "$here/../include/nerfpp_hip.h" -nt "$out/obj/adapter_lerf_compile.o" ]; then
     $CXX $FLAGS $INC -c "$here/ref/adapter_lerf_compile.cpp" -o "$out/obj/adapter_lerf_compile.o"
     echo "compiled HipLeRFRenderer : LeRFRenderer against the reference header (not linkable without RuCLIP)"
   fi
