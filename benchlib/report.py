@@ -42,6 +42,11 @@ def compact_roofline(detail_roof, stats_csv=None):
     names = list(src.keys())
     if not names:
         return None
+    # dominant = most time; a kernel whose counter-based fraction is unavailable (hash encode while its sources differ from the profiled ones) yields the top slot to the next
+    priced = [n for n in names if src[n].get("frac") is not None]
+    if priced and priced[0] != names[0]:
+        names.remove(priced[0])
+        names.insert(0, priced[0])
     dom = src[names[0]]
     out = {k: _r(dom[k]) for k in ROOF_KEYS if dom.get(k) is not None}
     out.setdefault("traffic", None)
