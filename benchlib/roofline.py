@@ -62,7 +62,7 @@ def pmc_value(kernel, counter, per_point=False):
     """A raw counter of the committed PMC summary (summed over the profiled run's dispatches of `kernel`), optionally per point the kernel processed in that run."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        v = float(d[kernel][counter])
+        v = float(d[kernel][counter]) * float(d[kernel].get("launches", 1))          # the summary holds averages per logical launch
         return v / float(d[kernel]["points_in_run"]) if per_point else v
     except Exception:
         return None

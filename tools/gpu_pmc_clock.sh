@@ -11,7 +11,7 @@ for wl in "hash f16x3" "hash f16" "classic f16x3" "classic f16"; do
   set -- $wl
   for grp in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES"; do
     name=$(echo ${1}_${2}_$grp | tr ' ' '_' | cut -c1-48)
-    (timeout 600 rocprofv3 --pmc $grp --output-format csv -d $ROOTD/gpurun_out/${tag}_$name -- python3 $ROOTD/bench.py --workload $1 --precision $2 --steps 2 --warmup 1 --no-cpu-baseline --no-also --no-parity --no-settle 2>&1 | tail -3) > $ROOTD/gpurun_out/${tag}_$name.log 2>&1
+    (timeout 600 rocprofv3 --pmc $grp --output-format csv -d $ROOTD/gpurun_out/${tag}_$name -- python3 $ROOTD/bench.py --workload $1 --precision $2 --steps 2 --warmup 1 --no-cpu-baseline --no-also --no-parity --no-settle --no-isolated 2>&1 | tail -3) > $ROOTD/gpurun_out/${tag}_$name.log 2>&1
   done
 done
 cd $ROOTD

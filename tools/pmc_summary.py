@@ -15,6 +15,7 @@ res = {}
 for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}_*/*/*_counter_collection.csv"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     launches = collections.Counter()
+    instances = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         short = k.split("(")[0].replace("void ", "").strip()
@@ -25,14 +26,13 @@ for f in glob.glob(f"{tag}_*/runc/*_counter_collection.csv") + glob.glob(f"{tag}
         elif "k_mlp_nerf_split" in k: short = "mlp_nerf_split (k_mlp_nerf_split)"
         elif "k_mlp_nerf_mfma" in k: short = "mlp_nerf (k_mlp_nerf_mfma)"
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        # one logical hash-encode launch is TWO dispatches (four-levels-per-thread group + single-level group): count the latter
-        if short.startswith("hash_encode"):
-            if "ELi1ELi0ELi1E" in k or "<1, 0, 1>" in k: launches[(short, r["Counter_Name"])] += 1
-        else:
-            launches[(short, r["Counter_Name"])] += 1
+        # one logical hash-encode launch is one dispatch PER INSTANCE of the kernel (round 5: the 12-levels-per-thread group + the 2-levels-per-thread group of the
+        # four finest levels): dispatches / distinct instance names, settled below
+        launches[(short, r["Counter_Name"])] += 1
+        instances[short].add(k)
     for short, v in agg.items():
         for c, x in v.items():
-            n = max(launches[(short, c)], 1)
+            n = max(launches[(short, c)] // (len(instances[short]) if short.startswith("hash_encode") else 1), 1)
             res.setdefault(short, {})[c] = sum(x) / n
             res[short]["dispatches"] = len(x)
             res[short]["launches"] = n
