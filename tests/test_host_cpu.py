@@ -340,7 +340,7 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
     import json
     from benchlib import report
     detail = _canned_bench_detail(world)
-    report.emit(detail, stats_csv="profiles/round4/r4_single_lane_kernel_stats.csv", path=str(tmp_path / "bench_detail.json"))
+    report.emit(detail, stats_csv="profiles/round5/r5_single_lane_kernel_stats.csv", path=str(tmp_path / "bench_detail.json"))
     cap = capsys.readouterr()
     out_lines = cap.out.strip().splitlines()
     assert len(out_lines) == 1, "ONE line on stdout"
@@ -361,7 +361,7 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     if world == 1:
         # the isolated (single-lane) dominant kernel: NeRFSmall on the matrix cores; units x flop / launch time re-derives `achieved` (TFLOP/s)
-        assert r["lanes"] == 1 and r["kernel"].startswith("mlp_small") and r["bound"] == "mfma" and r["kernel_stats"].startswith("profiles/round4/")
+        assert r["lanes"] == 1 and r["kernel"].startswith("mlp_small") and r["bound"] == "mfma" and r["kernel_stats"].startswith("profiles/round5/")
         assert abs(r["units_per_launch"] * r["flop_per_unit"] / (r["avg_launch_ms"] * 1e-3) / 1e12 - r["achieved"]) < 0.01 * r["achieved"]
         assert 0.1 < r["frac"] < 0.25 and 0.4 < r["mfma_issued_frac"] < 0.8
         # hash: no fraction above 1 any more -- frac is the COUNTER fraction of the HBM peak (absent while the kernel's sources differ from the profiled ones),
