@@ -433,6 +433,91 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
     if (have) flush();
 }
 
+// The same walk with one LANE PER FEATURE (F = 4, 8: LeRF's language grid): F neighbouring lanes walk one ray segment together, each carrying its own feature's eight corner sums.
+// A flush is then eight atomic instructions whose lanes of a group add to F CONSECUTIVE floats of one table entry (a 16- / 32-byte segment of one line) instead of F x 8
+// instructions with every lane in a row of its own -- float atomics are priced by the segments an instruction touches (MI355X_MICROARCH.md, Global float atomics).  The sums are
+// the thread-per-segment walk's, term for term: the same samples are skipped (gradient zero in all F features: a group-wide test), cells change at the same samples.
+template <int F, bool CU>
+__global__ void __launch_bounds__(256) k_hash_bwd_ray_fl(HashParams hp, const float *__restrict__ pts, int64_t n, int s, const float *__restrict__ g_emb, int g_stride,
+                                                         float *__restrict__ g_table)
+{
+    static_assert(F == 4 || F == 8, "a group of F lanes inside one wavefront");
+    const int nseg = (s + BWD_SEG - 1) / BWD_SEG;
+    const int64_t tt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = tt / F;
+    const int f = (int)(tt - t * F);
+    const int l = blockIdx.y;
+    if (t >= n * nseg) return;                      // whole groups leave together (the thread count per level is a multiple of F)
+    const int64_t ray = t / nseg;
+    const int j0 = (int)(t - ray * nseg) * BWD_SEG;
+    const int j1 = (j0 + BWD_SEG < s) ? j0 + BWD_SEG : s;
+    const int gshift = (int)(threadIdx.x & 63) & ~(F - 1);       // the group's first lane inside its wavefront
+    float acc[8];
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    bool have = false;
+    const float scale = hp.level_scale[l];
+    float *tl;
+    uint32_t pa = 0, pb = 0, pc = 0, lsz = 1, hmask = 0;
+    if constexpr (CU) {
+        tl = g_table + hp.local_idx[l];
+        pa = hp.primes[l * 3 + 0]; pb = hp.primes[l * 3 + 1]; pc = hp.primes[l * 3 + 2]; lsz = hp.local_size[l];
+    } else {
+        tl = g_table + (int64_t)l * ((int64_t)1 << hp.log2_t) * F;
+        hmask = (1u << hp.log2_t) - 1u;
+    }
+    const bool lsz_pow2 = (lsz & (lsz - 1u)) == 0u;
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t cx = cur[0] + ((k >> 2) & 1), cy = cur[1] + ((k >> 1) & 1), cz = cur[2] + (k & 1);
+            const uint32_t hv = (cx * pa) ^ (cy * pb) ^ (cz * pc);
+            const uint32_t row = CU ? (lsz_pow2 ? (hv & (lsz - 1u)) : (hv % lsz)) : ((cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & hmask);
+            if (acc[k] != 0.0f) unsafeAtomicAdd(tl + (size_t)row * F + f, acc[k]);
+        }
+    };
+    for (int j = j0; j < j1; j++) {
+        const int64_t i = ray * s + j;
+        float g = g_emb[i * g_stride + l * F + f];
+        if constexpr (CU) g = __half2float(__float2half_rn(g * 128.0f));
+        const unsigned long long nz = __ballot(g != 0.0f);
+        if (((nz >> gshift) & ((1ull << F) - 1ull)) == 0ull) continue;
+        uint32_t pos[3];
+        float w[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float x = pts[i * 3 + a];
+            const float c = fmaxf(fminf(x, hp.bbox.mx[a]), hp.bbox.mn[a]);
+            if constexpr (CU) {
+                float q = (c - hp.bbox.mn[a]) / (hp.bbox.mx[a] - hp.bbox.mn[a]) * scale;
+                q = q + hp.bias[l * 3 + a];
+                const float fl = floorf(q);
+                pos[a] = (uint32_t)fl; w[a] = q - fl;
+            } else {
+                const float grid = (hp.bbox.mx[a] - hp.bbox.mn[a]) / scale;
+                const float fl = floorf((c - hp.bbox.mn[a]) / grid);
+                pos[a] = (uint32_t)(int32_t)fl;
+                const float vmin = fl * grid + hp.bbox.mn[a];
+                const float vmax = vmin + grid;
+                w[a] = (x - vmin) / (vmax - vmin);
+            }
+        }
+        if (!have || pos[0] != cur[0] || pos[1] != cur[1] || pos[2] != cur[2]) {
+            if (have) flush();
+            have = true;
+            cur[0] = pos[0]; cur[1] = pos[1]; cur[2] = pos[2];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float wx = ((k >> 2) & 1) ? w[0] : 1.0f - w[0], wy = ((k >> 1) & 1) ? w[1] : 1.0f - w[1], wz = (k & 1) ? w[2] : 1.0f - w[2];
+            if constexpr (CU) acc[k] += __half2float(__float2half_rn(g * (wx * wy * wz))) * (1.0f / 128.0f);
+            else acc[k] += ((g * wz) * wy) * wx;
+        }
+    }
+    if (have) flush();
+}
+
 // mass[l] = sum over the points of max_f |g[pt][l][f]|: no table entry of level l can receive more than that (corner weights are in [0,1]
 // and sum to one per point), whatever the hash collisions and however the samples cluster.  Accumulated in double.
 // HashEmbedder mode only: its interpolation weights are computed from the UNCLAMPED coordinate (NeRF.cpp:265-277), so a point outside the box
@@ -716,14 +801,23 @@ int nrf_hash_backward_rays(const nrf_hash *h, const float *d_pts, int64_t n, int
         if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL((k_hash_bwd_ray<FF, false>), grid, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table); \
         else hipLaunchKernelGGL((k_hash_bwd_ray<FF, true>), grid, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table);               \
     } while (0)
+    // F = 4, 8: a lane per feature (k_hash_bwd_ray_fl); NRF_HASH_BWD_FEATURE_LANES=0 keeps the thread-per-segment walk (A/B, tests)
+    static const bool feature_lanes = [] { const char *e = getenv("NRF_HASH_BWD_FEATURE_LANES"); return !(e && e[0] == '0'); }();
+#define NRF_BWD_FL(FF)                                                                                                                                  \
+    do {                                                                                                                                                \
+        dim3 gfl((unsigned)ceil_div(threads * FF, 256), (unsigned)L);                                                                                   \
+        if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL((k_hash_bwd_ray_fl<FF, false>), gfl, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table); \
+        else hipLaunchKernelGGL((k_hash_bwd_ray_fl<FF, true>), gfl, dim3(256), 0, st, h->params, d_pts, n, s, d_g_emb, L * F, d_g_table);               \
+    } while (0)
     switch (F) {
         case 1: NRF_BWD(1); break;
         case 2: NRF_BWD(2); break;
-        case 4: NRF_BWD(4); break;
-        case 8: NRF_BWD(8); break;
+        case 4: if (feature_lanes) NRF_BWD_FL(4); else NRF_BWD(4); break;
+        case 8: if (feature_lanes) NRF_BWD_FL(8); else NRF_BWD(8); break;
         default: set_error("nrf_hash_backward_rays: n_features %d not built (1, 2, 4, 8)", F); return NRF_ERR_UNSUPPORTED;
     }
 #undef NRF_BWD
+#undef NRF_BWD_FL
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

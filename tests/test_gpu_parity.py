@@ -1404,20 +1404,24 @@ def test_hash_cu_backward_vs_oracle(api, O, F, T):
     assert_close(host(gt), ref, rtol=2e-5, atol=1e-4 * np.abs(ref).max(), what="CuHash table gradient (fp32 atomics vs exact accumulation; a handful of entries differ by one fp16 ulp of a single contribution)")
 
 
+@pytest.mark.parametrize("n_feat", [2, 4, 8])
 @pytest.mark.parametrize("mode", ["ngp", "cu"])
-def test_hash_backward_ray_coherent_equals_per_point(api, mode):
-    """nrf_hash_backward_rays (voxel-run pre-summation along each ray) == nrf_hash_backward up to fp32 summation order."""
+def test_hash_backward_ray_coherent_equals_per_point(api, mode, n_feat):
+    """nrf_hash_backward_rays (voxel-run pre-summation along each ray) == nrf_hash_backward up to fp32 summation order.  F = 4, 8 (LeRF's language grid) walk with one lane per
+    feature (k_hash_bwd_ray_fl): rows whose gradient is zero in every feature are skipped by the whole group, rows with single zero features are not."""
     import ctypes as C
-    sc = api.S.make_hash_scene(mode=mode, log2_t=15)
+    sc = api.S.make_hash_scene(mode=mode, log2_t=15, n_feat=n_feat)
     e = sc["embedder"]
-    n, s = 700, 37                                                        # ragged: s not a multiple of the segment length
+    n, s = 701, 37                                                        # ragged: s not a multiple of the segment length, n * segments not a multiple of the workgroup
     K = api.S.lego_K(64, 64); c2w = api.S.pose_spherical(20.0, -30.0, 4.0)
     o, d, _ = api.R.GetRays(64, 64, K, c2w)
     o = o.reshape(-1, 3)[:n]; d = d.reshape(-1, 3)[:n]
     z = torch.sort(torch.rand((n, s), device="cuda") * 3.0 + 2.0, dim=1).values
     z[:, 5:20] = z[:, 5:6] + torch.linspace(0, 0.01, 15, device="cuda")   # a dense cluster, as importance sampling produces
     pts = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
-    g = (torch.randn((n * s, 32), device="cuda") * 1e-3).contiguous()
+    g = (torch.randn((n * s, 16 * n_feat), device="cuda") * 1e-3).contiguous()
+    g[::7] = 0.0                                                          # samples without gradient (masked / outside the box in a training step)
+    g[3::5, 1::n_feat] = 0.0                                              # single zero features inside live rows
     a = torch.zeros(e.table_elems(), device="cuda"); b = torch.zeros_like(a)
     P = lambda t: C.c_void_p(t.data_ptr())
     api.L.check(api.L.lib().nrf_hash_backward(e._h, P(pts), C.c_int64(n * s), P(g), P(a), None))
