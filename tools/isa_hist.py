@@ -48,9 +48,7 @@ for n, (i, name) in enumerate(starts):
         t = l.strip()
         if not l.startswith("\t") or t.startswith(".") or t.startswith(";"):
             continue
-        body.append(t.split()[0])
-        if t.startswith("s_endpgm"):
-            break
+        body.append(t.split()[0])          # to the end of the function: a kernel with early exits has several s_endpgm
     c = collections.Counter(body)
     grp = lambda pred: sum(v for k, v in c.items() if pred(k))
     print(name)
