@@ -415,7 +415,7 @@ int nrf_hash_encode_lm_f16_strided(const nrf_hash *h, const float *d_x, int64_t 
     ProfScope prof(NRF_PROF_HASH, st);
     // levels per thread: ONE.  This kernel's lookups are eight 16-byte gathers per level out of the hashed table (F = 8: 128 B per point and level); it lives on the number
     // of gathers in flight, and sharing the point preparation between levels costs more than it saves -- LeRF frame, same call, ms of hash encode: 1 per thread 40.4-41.1,
-    // 2: 43.8-43.9, 4: 50.2-50.3, 8: 59.5-59.6 (profiles/round3/r6h_lerf_hash_levels_per_thread_ab.log).  (The F = 2 fast path is the opposite case: hash_fast.hip.)
+    // 2: 43.8-43.9, 4: 50.2-50.3, 8: 59.5-59.6 (docs/history/profiles/round3/r6h_lerf_hash_levels_per_thread_ab.log).  (The F = 2 fast path is the opposite case: hash_fast.hip.)
 #ifndef NRF_HASH_LMF_LPT
 #define NRF_HASH_LMF_LPT 1
 #endif

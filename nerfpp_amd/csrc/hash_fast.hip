@@ -250,7 +250,7 @@ int hash_fast_prepare(nrf_hash *h, size_t budget_bytes, hipStream_t st)
 // lines per gather instruction at every level but the coarsest.  NRF_HASH_LANE_TILE = R > 1: a wave takes 64 / R consecutive samples of R consecutive rays --
 // neighbouring pixels at neighbouring depths, a handful of lines per gather -- while the features still go to column = point index (R runs of 256 / R bytes per
 // store instruction), so nothing downstream changes and the features are the same bits.  Measured on the bench frame, same call, ms of hash encode per frame
-// (profiles/round3/r4a_hash_lane_tile_ab.log): linear 8.54 / 8.20, R = 2: 8.39 / 8.05, R = 4: 8.14 / 8.19, R = 8: 8.81 / 8.44 (9.0 vs 8.7 in another call),
+// (docs/history/profiles/round3/r4a_hash_lane_tile_ab.log): linear 8.54 / 8.20, R = 2: 8.39 / 8.05, R = 4: 8.14 / 8.19, R = 8: 8.81 / 8.44 (9.0 vs 8.7 in another call),
 // R = 16: 10.8 -- the gather path does not pay for fewer distinct lines per instruction, the stores pay for more.  Even with the features stored at the thread's own
 // (linear) column -- a wrong image, but the cost a layout that followed the tiling would have -- R = 8 takes 8.8-9.1 against 8.4, R = 16 10.4, R = 64 15.8: a wave
 // that spans R rays loads R rays' origins and directions instead of one broadcast row.  Linear stays.
@@ -410,7 +410,7 @@ int launch_hash_ngp_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __ha
     const int lc = (L * 3 / 4) & ~3;
     // levels per thread of the coarse / fine launch (see launch_hash_lm).  This encoder's lookups are four 16-byte gathers per level out of an 8.7 GB fp32 image -- bench
     // frame of the LibTorch-twin scene, same call, ms of hash encode: 4 + 1 per thread 14.0-14.1, 12 + 2: 15.3, 6 + 2: 14.2, 4 + 2: 14.2, 2 + 1: 14.1
-    // (profiles/round3/r9e_ngp_levels_per_thread_ab.log; before the dense lookup's loads were repaired -- see encode_level_ngp -- every grouping took 23.6-24.1)
+    // (docs/history/profiles/round3/r9e_ngp_levels_per_thread_ab.log; before the dense lookup's loads were repaired -- see encode_level_ngp -- every grouping took 23.6-24.1)
 #ifndef NRF_NGP_COARSE_LPT
 #define NRF_NGP_COARSE_LPT 4
 #endif
@@ -462,11 +462,11 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
 #endif       // measured on 16 levels (ms per frame): 0 -> 11.8, 8 -> 11.4, 12 -> 11.1, 16 -> 11.9
         // Both launches as ONE (consecutive workgroups alternating between a four-coarse-levels kind and a one-fine-level kind, so that a CU holds vector-bound and
         // latency-bound waves together) was built and measured, same call: 8.71-8.74 ms per frame against 8.61-8.62 for the two launches
-        // (profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.  Again with the 12-level coarse kind and two 2-level fine kinds:
+        // (docs/history/profiles/round3/r5d_hash_mixed_launch_ab.log) -- the two kinds wait for the same gather path.  Again with the 12-level coarse kind and two 2-level fine kinds:
         // 7.78-7.79 against 7.65-7.68.
         // ... and the coarse levels ALL in one thread when there are twelve of them (16-level grids): the point and its box coordinates are formed once, and a coarse level
         // costs instructions, not gather latency.  Round 3, same call, ms of hash encode per frame: 4 per thread 8.34-8.42, 6: 7.88-8.11, 12: 7.79-7.86; 14 + 2: 7.95-8.01,
-        // 10 + 6: 7.89-7.96 (profiles/round3/r6g_hash_levels_per_thread_ab.log)
+        // 10 + 6: 7.89-7.96 (docs/history/profiles/round3/r6g_hash_levels_per_thread_ab.log)
 #ifndef NRF_HASH_COARSE_LPT
 #define NRF_HASH_COARSE_LPT 12
 #endif
@@ -474,7 +474,7 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
 #define NRF_HASH_FINE_LPT 2
 #endif
         // ... where those levels are baked.  With the hashed lookups (a training step uploads a new table every step and bakes nothing: 8 four-byte gathers per level into 8
-        // lines) the old grouping stays: training step 9.2-9.35 ms with 4 + 1 levels per thread against 9.83-9.87 with 12 + 2 (profiles/round3/r7c_train_step_hash_grouping_ab.log)
+        // lines) the old grouping stays: training step 9.2-9.35 ms with 4 + 1 levels per thread against 9.83-9.87 with 12 + 2 (docs/history/profiles/round3/r7c_train_step_hash_grouping_ab.log)
         bool baked = !(variant & 32);
         for (int l = 0; l < lc && baked; l++) baked = hpar.dense_off[l] >= 0;
         const int clpt = (baked && (lc % NRF_HASH_COARSE_LPT) == 0) ? NRF_HASH_COARSE_LPT : 4;
@@ -503,7 +503,7 @@ int launch_hash_lm(const nrf_hash *h, const PointSource &ps, int64_t p, __half2 
             return NRF_OK;
         }
         // the finest levels two per thread (round 3, same call, ms of hash encode per frame: one per thread 8.67-8.73, two 8.47-8.49; with only 8 or 4 levels in the
-        // four-per-thread launch 8.47 / 8.68; profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
+        // four-per-thread launch 8.47 / 8.68; docs/history/profiles/round3/r6e_hash_fine_levels_per_thread_ab.log)
         if (flpt == 1) hipLaunchKernelGGL((k_hash_cu_lm<1, 0, 1>), dim3((unsigned)ntiles, (unsigned)(L - lc)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         else hipLaunchKernelGGL((k_hash_cu_lm<1, 0, NRF_HASH_FINE_LPT>), dim3((unsigned)ntiles, (unsigned)((L - lc) / NRF_HASH_FINE_LPT)), dim3(256), 0, st, hpar, ps, p, feats, pstride, keep, lpg, 0, lc);
         NRF_LAUNCH_CHECK();

@@ -290,7 +290,7 @@ struct ConvHookS {
 };
 
 // Two ways of hiding kernel B's open vector work behind matrix instructions, both measured on the LeRF frame in one call against the build without them
-// (profiles/round3/r3u_lerf_defer_ab.log; 74.1-74.5 ms of LeRF passes per frame): DOT, the Gram tiles' dot products one per k-step behind the next tile --
+// (docs/history/profiles/round3/r3u_lerf_defer_ab.log; 74.1-74.5 ms of LeRF passes per frame): DOT, the Gram tiles' dot products one per k-step behind the next tile --
 // 74.1-75.3 ms, nothing; SUM, a tile's share of the ray's sum behind the next tile's LE0 -- 77.5-79.5 ms, slower (the conversions it interleaves with already
 // fill those k-steps).  The matrix pipe is this kernel's clock-limited resource; cycles freed beside it buy nothing.  Both off.
 #ifndef NRF_LERF_DEFER_DOT
@@ -644,7 +644,7 @@ k_lerf_split_geo(int64_t npts, Args in, const half8 *__restrict__ packed)
         // the split-precision sum of a and kernel C.  An fp16-grade norm (relative error ~1e-4: rounding of a and of G, no lo parts) perturbs the shares by as much
         // and the rendered unit embedding by < 1e-6 per component -- measured against the CPU oracle on 256 rays of the bench frame (max abs error, rms):
         //   three products (Gh.ah + Gl.ah + Gh.al) 3.6e-7 / 3.4e-8, 97.1 ms of LeRF passes per frame;  two (a's hi part) 7.6e-7 / 9.1e-8, 87.4 ms;
-        //   ONE (Gh.ah) 8.8e-7 / 1.2e-7, 77.5 ms -- the default.  cos >= 1 - 1.2e-7 in all three (profiles/round3/r3i_lerf_gram_products.log).
+        //   ONE (Gh.ah) 8.8e-7 / 1.2e-7, 77.5 ms -- the default.  cos >= 1 - 1.2e-7 in all three (docs/history/profiles/round3/r3i_lerf_gram_products.log).
         layer_s<N, 3, false, NRF_LERF_GRAM_ALO != 0, NRF_LERF_GRAM_GLO != 0>(cx, none, ba, ssq, pf);   // ||LE1(a)||^2 = a . (W^T W) a
         const float tot = fmaxf(ssq.ss + __shfl_xor(ssq.ss, 32), 0.0f) * in.gram_scale;
         const float wgt = rlive ? pf.weight(lane) : 0.0f;

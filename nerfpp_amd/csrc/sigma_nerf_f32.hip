@@ -6,7 +6,7 @@
 // values came out within 1e-4 of the fp32 render and the rest did not: a moved sample.  "Certified sampling" (re-evaluating only the rays whose u values come
 // within an error bound of a CDF edge) cannot close that gap: u_127 = 1.0 is compared with the CDF's top plateau, whose entries sit within 1e-7 of 1.0 on every
 // ray that saturates, so whether cdf_i <= 1.0 holds depends on the last bit of the weight sum -- nearly every ray would be flagged
-// (profiles/round3/r3c_classic_cdf_stats.log).  So the coarse sigma is evaluated in the parity arithmetic itself: v_mfma_f32_32x32x2_f32 is, bit for bit, the
+// (docs/history/profiles/round3/r3c_classic_cdf_stats.log).  So the coarse sigma is evaluated in the parity arithmetic itself: v_mfma_f32_32x32x2_f32 is, bit for bit, the
 // ascending-k fmaf chain of NRF_PREC_F32 / the oracle (sigma_small_f32.hip).  The colour branch (feature_linear, views_linears, rgb_linear: 17 % of the MACs) is
 // dead work for the coarse pass's own result -- but the fine pass re-evaluates the network at the S coarse depths unless the coarse pass leaves whole (rgb, sigma)
 // rows to reuse.  So the kernel's tail runs it on the exact h8 in SPLIT precision on the fp16 matrix instructions (240 of them per 32 points next to 7 680 fp32

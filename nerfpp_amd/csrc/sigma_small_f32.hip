@@ -29,12 +29,12 @@
 // 192 fp32 ones.  Natural row order: register q of lane half h of the result is row 8(q/4) + 4h + q%4, which IS element q of the colour net's geo operand fragment
 // (perm_row(0, h, q) in mlp_small_mfma.hip) -- split once more and stored as that fragment, planes [hi | lo][column][lane half] of 16 bytes.
 //
-// Tried and measured (round 3, profiles/round3/r3z_sigma_two_crews_ab.log): the packed fp32 FMA of the vector ALUs has the same peak rate as the fp32 matrix
+// Tried and measured (round 3, docs/history/profiles/round3/r3z_sigma_two_crews_ab.log): the packed fp32 FMA of the vector ALUs has the same peak rate as the fp32 matrix
 // instruction (157 TFLOP/s each) and the counters of this kernel show the matrix pipe busy 0.81 of the cycles with NO vector co-execution, so half of the waves
 // were given the same chains as v_pk_fma_f32 code (lane = point, weights broadcast from LDS, units of 64 points handed out by a ticket counter; both crews
 // bit-identical by construction, geo rows as exact fp32 chains).  Per frame, same call: all waves matrix 7.54 ms, all waves vector 8.7 ms, half and half 7.59 ms
 // -- the two formulations do not add up, they share what limits them -- against 4.8 ms for this file (whose geo rows cost 12 fp16 matrix instructions per 32
-// points instead of 512 packed FMAs per 64).  Not kept.  A registers-only probe settles why (tools/scratch/coexec_probe.hip, profiles/round3/
+// points instead of 512 packed FMAs per 64).  Not kept.  A registers-only probe settles why (tools/scratch/coexec_probe.hip, docs/history/profiles/round3/
 // r3z_fp32_mfma_vs_pk_fma_coexec_probe.log): four matrix waves alone 3.4 ms, four packed-FMA waves alone 4.7 ms, the eight together 8.2 ms -- on this chip the fp32
 // matrix instruction and the packed fp32 FMA execute on the same lanes; 157 TFLOP/s is the ceiling of their SUM.
 #include "mlp.h"
