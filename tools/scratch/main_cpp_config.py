@@ -12,6 +12,7 @@ for name, kw, ni in (("BASELINE config 3 (16..512, SH 4, colour 4x64, 64+128)", 
                      ("main.cpp grid only (16..1024, SH 4, colour 4x64, 64+128)", dict(finest=1024), 128)):
     if only and only not in name: continue
     sc = S.make_hash_scene(mode="cu", **kw)
+    if os.environ.get("NRF_DENSE_GB"): sc["embedder"].set_dense_budget(int(float(os.environ["NRF_DENSE_GB"]) * (1 << 30)))          # e.g. 40: the 17 GB finest level of the 16..1024 grid baked too
     rp = S.lego_render_params(sc["bbox"], 64, ni, 65536, L.NRF_PREC_F16_SPLIT)
     r = sc["renderer"]
     for _ in range(3): r.Render(H, W, K, rp, c2w=c2w)
