@@ -283,7 +283,8 @@ def lerf_train_step_measurement(scene, L, n_rand=16384, steps=2):
                 unit="ray-samples/s", steps=steps, loss_first_last=losses,
                 fp32_layer_products="rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels",
                 arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated in fp32 (layer products as library GEMMs on the fp32 matrix "
-                           "cores, weight gradients split over 32 point slices), language-grid gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
+                           "cores, weight gradients split over 32 point slices; the 256 -> 768 layer, normalize and RenderCLIPEmbedding in their Gram form: nothing 768-wide per sample), "
+                           "language-grid gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
 
 
 def classic_train_step_measurement(scene, L, n_rand=4096, steps=3):

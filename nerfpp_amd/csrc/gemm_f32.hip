@@ -171,6 +171,50 @@ int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &
     return NRF_OK;
 }
 
+// C[b][r][c] summed over b into C: dst[r * ldc + c] = beta * dst[..] + sum_b part[b][r][c]
+__global__ void k_sum_partials_rm(int batches, int rows, int cols, const float *__restrict__ part, float beta, float *__restrict__ dst, int ldc)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * cols) return;
+    float acc = 0.0f;
+    for (int b = 0; b < batches; b++) acc += part[(size_t)b * rows * cols + e];
+    const int r = e / cols, c = e - r * cols;
+    float *d = dst + (size_t)r * ldc + c;
+    *d = (beta == 0.0f ? 0.0f : beta * *d) + acc;
+}
+
+// A generic ROW-MAJOR product on the fp32 matrix cores (the Gram form of the LeRF training step, lerf_train.hip):  C [M x N] (ldc) = alpha op(A) op(B) + beta C,
+// A: transA ? [K x M] : [M x K] (lda), B: transB ? [N x K] : [K x N] (ldb).  A small C summed over a very long K (a 256 x 256 matrix over 10^5 points) is cut into 32
+// K-slices computed as one strided-batched GEMM and added by a small kernel, as run_grad_w_fast does.  Returns NRF_ERR_UNSUPPORTED without rocBLAS (the caller has a
+// path without it).
+int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc)
+{
+    rocblas_handle h = rb_handle(st);
+    if (!h || M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return NRF_ERR_UNSUPPORTED;
+    if (M == 0 || N == 0) return NRF_OK;
+    // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T, and a row-major array IS its transpose in column-major terms
+    const rocblas_operation o1 = transB ? rocblas_operation_transpose : rocblas_operation_none, o2 = transA ? rocblas_operation_transpose : rocblas_operation_none;
+    constexpr int SLICES = 32;
+    if (g_rb.sgemm_sb && K >= 16384 && M * N <= 1024 * 1024 && transA && !transB && (K % SLICES) == 0) {
+        // A: [K x M], B: [K x N]: slice b takes rows [b K / 32, (b + 1) K / 32) of both
+        float *part = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)SLICES * M * N * sizeof(float), st) != hipSuccess) { set_error("gemm_rm: hipMallocAsync failed"); return NRF_ERR_HIP; }
+        const float zero = 0.0f;
+        const int64_t per = K / SLICES;
+        const bool ok = g_rb.sgemm_sb(h, o1, o2, (rocblas_int)N, (rocblas_int)M, (rocblas_int)per, &alpha, B, ldb, (rocblas_stride)(per * ldb), A, lda, (rocblas_stride)(per * lda), &zero, part,
+                                      (rocblas_int)N, (rocblas_stride)(M * N), SLICES) == rocblas_status_success;
+        if (ok) hipLaunchKernelGGL(k_sum_partials_rm, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, SLICES, (int)M, (int)N, (const float *)part, beta, C, ldc);
+        (void)hipFreeAsync(part, st);
+        if (!ok) { set_error("rocblas_sgemm_strided_batched failed (%lld x %lld over %lld)", (long long)M, (long long)N, (long long)K); return NRF_ERR_HIP; }
+        return NRF_OK;
+    }
+    if (g_rb.sgemm(h, o1, o2, (rocblas_int)N, (rocblas_int)M, (rocblas_int)K, &alpha, B, ldb, A, lda, &beta, C, ldc) != rocblas_status_success) {
+        set_error("rocblas_sgemm failed (%lld x %lld x %lld)", (long long)M, (long long)N, (long long)K);
+        return NRF_ERR_HIP;
+    }
+    return NRF_OK;
+}
+
 }  // namespace nrf
 
 // 1 when the training paths' fp32 layer products run as rocBLAS GEMMs on the fp32 matrix cores, 0 when they run mlp.hip's hand-written FMA kernels (rocBLAS absent or NRF_FP32_GEMM=0)

@@ -5,12 +5,16 @@
 // What carries gradient is the FINE pass (z_samples are detached, LeRFRenderer.cpp:150):
 //   pts -> CuHashEmbedder (language grid) -> LeRFImpl::forward (LeRF.cpp:86-108: sigma net in -> H.. -> 1 + geo; LE net cat[geo, in] -> H.. -> E; normalize eps 1e-8)
 //       -> sigma_le[~keep] = 0 (LeRFRenderer.cpp:37-38) -> RawToLEOutputs' weights (:38-66, TruncExp CustomOps.cpp:5-15) -> RenderCLIPEmbedding (LeRFRenderer.h:45-54).
-// fp32 throughout, from the generic layer kernels of mlp.hip (forward = the oracle's FMA chains; dW = TN products with one atomic add per element and workgroup): the
-// forward is RECOMPUTED here chunk by chunk with every layer input kept -- the render pass (fused matrix-core kernels) never forms raw_le [n, S, 769].
+// fp32 throughout, from the generic layer kernels of mlp.hip (forward = the oracle's FMA chains; dW = TN products with one atomic add per element and workgroup) or, by
+// default, the library GEMMs of gemm_f32.hip: the forward is RECOMPUTED here chunk by chunk with every layer input kept -- the render pass (fused matrix-core kernels) never
+// forms raw_le [n, S, 769].  The LAST layer (256 -> 768 at main.cpp sizes), its normalize and RenderCLIPEmbedding run in their Gram form (k_ltg_ray_u below): 136 -> 77 ms
+// per step of 16 384 rays x 192 samples (profiles/round5/r5K_*, r5O_*).
 // Pinned by LibTorch autograd over the compiled LeRF.cpp / RawToOutputs weights / the reference's inline RenderCLIPEmbedding: goldens train_lerf*.
 #include "encode.h"
 #include "mlp.h"
 #include "nrf_math.h"
+
+#include <atomic>
 
 struct nrf_lerf_renderer;
 extern "C" const nrf_hash *nrf_lerf_renderer_lang_embed(const nrf_lerf_renderer *r);
@@ -20,7 +24,25 @@ namespace nrf {
 
 // sample points per pass: 2 n_layers + 4 activation / gradient buffers of this many rows x the widest layer (main.cpp sizes: 8 x 400 MB).  With 2^15 a pass was 170
 // rays = 170 workgroups of the per-ray kernel on 256 CUs, and every layer product a launch of a few tens of microseconds (profiles/round5/r5o_*)
-constexpr int64_t LT_CHUNK_PTS = 1 << 17;
+#ifndef NRF_LT_CHUNK_LOG2
+#define NRF_LT_CHUNK_LOG2 17
+#endif
+constexpr int64_t LT_CHUNK_PTS = (int64_t)1 << NRF_LT_CHUNK_LOG2;
+// With the last layer in its Gram form (below) nothing embedding-wide exists per sample: the activation rows are as wide as the widest OTHER layer (256 instead of 768 at
+// main.cpp sizes) and a pass takes 2^NRF_LT_GRAM_CHUNK_LOG2 points (fewer, larger launches: the step is ~1 000 launches at 2^17; profiles/round5/r5N_*, r5O_*)
+#ifndef NRF_LT_GRAM_CHUNK_LOG2
+#define NRF_LT_GRAM_CHUNK_LOG2 20
+#endif
+static bool lerf_train_gram(const nrf_mlp *m, int s);
+static int lt_width(const nrf_mlp *m, int s)
+{
+    if (!lerf_train_gram(m, s)) return m->max_width;
+    int w = 8;          // the per-sample scalars of the Gram form take 8 columns of a buffer
+    for (size_t l = 0; l + 1 < m->layers.size(); l++) { w = w > m->layers[l].in ? w : m->layers[l].in; w = w > m->layers[l].out ? w : m->layers[l].out; }
+    w = w > m->layers.back().in ? w : m->layers.back().in;
+    return w;
+}
+static int64_t lt_chunk_pts(const nrf_mlp *m, int s) { return lerf_train_gram(m, s) ? ((int64_t)1 << NRF_LT_GRAM_CHUNK_LOG2) : LT_CHUNK_PTS; }
 
 __device__ __forceinline__ double lt_wave_sum(double v)
 {
@@ -194,6 +216,165 @@ __global__ void __launch_bounds__(256) k_lt_ray(int s, int e, const float *__res
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// GRAM FORM of the head's last layer (round 5).  LE1 (W: E x H, bias-free, LeRF.cpp:21-24) followed by normalize and RenderCLIPEmbedding is linear up to per-sample
+// scalars, so -- as in the render pass (mlp_lerf_mfma.hip) -- nothing E-wide has to exist per SAMPLE.  With a_j the layer's input (H = 256), G = W^T W, s_j = G a_j:
+//   ||h_j||^2 = a_j . s_j        v = sum_j w_j le_j = W u,  u = sum_j (w_j / c_j) a_j  (per ray)        t_j = le_j . g_v = (a_j . q) / c_j,  q = W^T g_v  (per ray)
+//   g_a,j = W^T g_h,j = (w_j / c_j) q - beta_j s_j,    beta_j = [||h_j|| >= eps] w_j t_j / (c_j ||h_j||)
+//   dW = sum_j g_h,j a_j^T = sum_rays g_v u^T  -  W (A^T diag(beta) A)
+// Per sample: one H x H product (S = A G), two H-wide dot products and one H x H rank-1 share (A^T diag(beta) A); the E-wide products are per RAY.  The layer-wise path
+// above forms h, le and g_h as [points, E] arrays and runs three points x E x H products.  Same derivatives (tests: the autograd goldens train_lerf*).
+// Scratch per sample (pp, 8 floats): alpha, trans, lt, xx, sg, wgt, c, ||h||.
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int LTG_PP = 8;
+
+// per ray: the weights (as k_lt_ray), c_j and ||h_j|| from a_j . s_j, u = sum_j (w_j / c_j) a_j.  blockDim = 256; hd <= 256 features (one per thread)
+__global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *__restrict__ sig33, int ss, const uint8_t *__restrict__ keep, const float *__restrict__ z,
+                                                   const float *__restrict__ dirs, int d_stride, const float *__restrict__ noise, float noise_std, const float *__restrict__ a,
+                                                   int as, const float *__restrict__ sg_a, int sgs, float *__restrict__ pp, float *__restrict__ u, float *__restrict__ weights_out)
+{
+    extern __shared__ float lds[];
+    float *alpha = lds, *trans = lds + s, *xx = lds + 2 * s, *lt = lds + 3 * s, *wgt = lds + 4 * s, *sg = lds + 5 * s, *cj = lds + 6 * s;
+    const int64_t ray = blockIdx.x;
+    const int64_t p0 = ray * s;
+    const float *dv = dirs + ray * d_stride;
+    const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        float sr = (keep && !keep[p0 + j]) ? 0.0f : sig33[(p0 + j) * ss];
+        if (noise) sr = sr + noise[p0 + j] * noise_std;
+        sg[j] = sr;
+        float dist = (j + 1 < s) ? (z[p0 + j + 1] - z[p0 + j]) : 1e10f;
+        dist = dist * dn;
+        const float x = -(sr > 0.0f ? sr : 0.0f) * dist;
+        xx[j] = x;
+        alpha[j] = -nrf_expf(x) + 1.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double logt = 0.0; float tprev = 0.0f;
+        for (int j = 0; j < s; j++) {
+            lt[j] = tprev; trans[j] = nrf_expf(tprev);
+            const float om = 1.0f - alpha[j];
+            logt += (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
+            tprev = (float)logt;
+            wgt[j] = alpha[j] * trans[j];
+        }
+    }
+    // ||h_j|| (a wave per sample)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < s; j += 4) {
+        const float *ar = a + (p0 + j) * as, *sr = sg_a + (p0 + j) * sgs;
+        double q = 0.0;
+        for (int k = lane; k < hd; k += 64) q += (double)ar[k] * (double)sr[k];
+        q = lt_wave_sum(q);
+        const float nr = (float)sqrt(q > 0.0 ? q : 0.0);
+        if (lane == 0) { cj[j] = fmaxf(nr, 1e-8f); pp[(p0 + j) * LTG_PP + 7] = nr; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        float *o = pp + (p0 + j) * LTG_PP;
+        o[0] = alpha[j]; o[1] = trans[j]; o[2] = lt[j]; o[3] = xx[j]; o[4] = sg[j]; o[5] = wgt[j]; o[6] = cj[j];
+        if (weights_out) weights_out[p0 + j] = wgt[j];
+    }
+    if ((int)threadIdx.x < hd) {
+        double acc = 0.0;
+        for (int j = 0; j < s; j++) acc += (double)((wgt[j] / cj[j]) * a[(p0 + j) * as + threadIdx.x]);
+        u[ray * hd + threadIdx.x] = (float)acc;
+    }
+}
+
+// per ray: v = W u (given), rendered = v / max(||v||, eps), g_v = d loss / d v (RenderCLIPEmbedding's normalize backward, as k_lt_ray)
+__global__ void __launch_bounds__(256) k_ltg_ray_v(int e, const float *__restrict__ v, const float *__restrict__ g_rendered, float *__restrict__ gv, float *__restrict__ rendered)
+{
+    __shared__ double sh[4];
+    const int64_t ray = blockIdx.x;
+    double vss = 0.0, gdot = 0.0;
+    for (int k = threadIdx.x; k < e; k += blockDim.x) {
+        const float vk = v[ray * e + k];
+        vss += (double)vk * (double)vk;
+        gdot += (double)g_rendered[ray * e + k] * (double)vk;
+    }
+    vss = lt_block_sum(vss, sh);
+    gdot = lt_block_sum(gdot, sh);
+    const float vn = (float)sqrt(vss), vc = fmaxf(vn, 1e-8f);
+    const bool through_norm = vn >= 1e-8f && vn > 0.0f;
+    for (int k = threadIdx.x; k < e; k += blockDim.x) {
+        const float vk = v[ray * e + k];
+        if (rendered) rendered[ray * e + k] = vk / vc;
+        float g = g_rendered[ray * e + k] / vc;
+        if (through_norm) g -= (float)(gdot / ((double)vc * (double)vc)) * (vk / vn);
+        gv[ray * e + k] = g;
+    }
+}
+
+// per ray: t_j, beta_j; g_a,j = (w_j / c_j) q - beta_j s_j written OVER s_j; ba_j = beta_j a_j; the weights' backward -> g33 column 0 (as k_lt_ray's tail)
+__global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *__restrict__ q, const float *__restrict__ a, int as, float *__restrict__ sg_a, int sgs,
+                                                   float *__restrict__ ba, int bs, const float *__restrict__ pp, const uint8_t *__restrict__ keep, const float *__restrict__ z,
+                                                   const float *__restrict__ dirs, int d_stride, float *__restrict__ g33, int gs)
+{
+    extern __shared__ float lds[];
+    float *gw = lds, *qs = lds + s;
+    const int64_t ray = blockIdx.x;
+    const int64_t p0 = ray * s;
+    for (int k = threadIdx.x; k < hd; k += blockDim.x) qs[k] = q[ray * hd + k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < s; j += 4) {
+        const float *ar = a + (p0 + j) * as;
+        float *sr = sg_a + (p0 + j) * sgs, *br = ba + (p0 + j) * bs;
+        const float *o = pp + (p0 + j) * LTG_PP;
+        const float w = o[5], c = o[6], nr = o[7];
+        double d = 0.0;
+        for (int k = lane; k < hd; k += 64) d += (double)ar[k] * (double)qs[k];
+        d = lt_wave_sum(d);
+        const float t = (float)(d / (double)c);
+        const bool thr = nr >= 1e-8f && nr > 0.0f;
+        const float beta = thr ? (float)((double)w * (double)t / ((double)c * (double)nr)) : 0.0f;
+        const float wc = w / c;
+        for (int k = lane; k < hd; k += 64) {
+            const float av = ar[k];
+            sr[k] = wc * qs[k] - beta * sr[k];
+            br[k] = beta * av;
+        }
+        if (lane == 0) gw[j] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float *dv = dirs + ray * d_stride;
+        const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        double suffix = 0.0;
+        for (int j = s - 1; j >= 0; j--) {
+            const float *o = pp + (p0 + j) * LTG_PP;
+            const float alpha = o[0], trans = o[1], ltj = o[2], xj = o[3], sgj = o[4];
+            float g_alpha = gw[j] * trans;
+            const float om = 1.0f - alpha;
+            if (om >= 1e-10f) g_alpha -= (float)suffix / om;
+            const float cl = ltj < -100.0f ? -100.0f : (ltj > 5.0f ? 5.0f : ltj);
+            suffix += (double)(gw[j] * alpha * nrf_expf(cl));
+            const float cx = xj < -100.0f ? -100.0f : (xj > 5.0f ? 5.0f : xj);
+            const float g_x = -g_alpha * nrf_expf(cx);
+            float dist = (j + 1 < s) ? (z[p0 + j + 1] - z[p0 + j]) : 1e10f;
+            dist = dist * dn;
+            float gsig = (sgj > 0.0f) ? -g_x * dist : 0.0f;
+            if (keep && !keep[p0 + j]) gsig = 0.0f;
+            g33[(p0 + j) * gs] = gsig;
+        }
+    }
+}
+
+// NRF_LERF_TRAIN_GRAM=0 in the environment: the layer-wise last layer (A/B runs); the Gram form needs the library GEMMs and a head of the built proportions
+static std::atomic<int> g_lerf_train_gram{-1};          // -1: not decided yet (environment), 0 / 1
+static bool lerf_train_gram(const nrf_mlp *m, int s)
+{
+    int st = g_lerf_train_gram.load();
+    if (st < 0) { st = !(getenv("NRF_LERF_TRAIN_GRAM") && getenv("NRF_LERF_TRAIN_GRAM")[0] == '0'); g_lerf_train_gram.store(st); }
+    const bool on = st != 0;
+    const int hd = m->small.hidden_dim, E = m->small.hidden_dim_color;
+    (void)E;
+    return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(7 * s + hd) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
+}
+
 // dst[pt][d_col + k] = src[pt][s_col + k] (+ add[pt][a_col + k]), k < ncols
 __global__ void k_lt_copy_cols(int64_t p, int ncols, const float *__restrict__ src, int s_stride, int s_col, const float *__restrict__ add, int a_stride, int a_col,
                                float *__restrict__ dst, int d_stride, int d_col)
@@ -208,19 +389,21 @@ __global__ void k_lt_copy_cols(int64_t p, int ncols, const float *__restrict__ s
 
 static size_t head_ws_bytes(const nrf_mlp *m, int64_t n, int s)
 {
-    const int64_t rays = n < 1 ? 1 : (LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1);
+    const int64_t cp = lt_chunk_pts(m, s);
+    const int64_t rays = n < 1 ? 1 : (cp / s > 0 ? cp / s : 1);
     const int64_t c = (n < rays ? (n < 1 ? 1 : n) : rays) * s;
-    const size_t buf = align_up((size_t)c * m->max_width * sizeof(float), 256);
+    const size_t buf = align_up((size_t)c * lt_width(m, s) * sizeof(float), 256);
     return buf * (m->layers.size() + 4) + align_up((size_t)c * sizeof(float), 256) + 1024;
 }
 
 // one chunk of whole rays: c = rays * s points
 static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t *keep, const float *z, const float *dirs, int d_stride, const float *noise, float noise_std,
                                int64_t rays, int s, const float *g_rendered, float *g_params, float *g_emb, float *rendered, float *weights, float *base, size_t buf,
-                               float *nrm, hipStream_t st)
+                               float *nrm, const float *gram_in, hipStream_t st)
 {
+    const float *gram = gram_in;          // [hd x hd] Gram matrix, followed by this call's per-ray rows (nrf_lerf_head_backward)
     const auto &d = m->small;                    // MLP_LERF reuses: input_ch, num_layers, hidden_dim, geo_feat_dim; hidden_dim_color = embed dim (mlp.hip)
-    const int W = m->max_width, nl = d.num_layers, NL = 2 * nl, E = d.hidden_dim_color, in = d.input_ch, geo = d.geo_feat_dim;
+    const int W = gram ? lt_width(m, s) : m->max_width, nl = d.num_layers, NL = 2 * nl, E = d.hidden_dim_color, in = d.input_ch, geo = d.geo_feat_dim;
     const int64_t c = rays * s;
     const Seg none{nullptr, 0, 0, 0};
     std::vector<float *> H(NL);
@@ -235,23 +418,53 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     }
     const float *h33 = H[nl - 1];                                         // column 0 = sigma_le, 1.. = geo_feat_le
     const Seg sgeo{h33, W, 1, geo};
-    for (int l = 0; l < nl; l++) {
+    for (int l = 0; l < nl - (gram ? 1 : 0); l++) {          // Gram form: the last layer is never applied per sample
         NRF_TRY(run_linear_fast(c, l == 0 ? sgeo : cur, l == 0 ? xin : none, m, m->layers[nl + l], l != nl - 1, H[nl + l], W, 0, st));
         cur = Seg{H[nl + l], W, 0, m->layers[nl + l].out};
     }
     float *hle = H[NL - 1];                                               // h [c, E] -> le -> g_h, in place
+    float *g33 = G[0];
+    Seg g{hle, W, 0, E};
+    int gi = 1, l_top = NL - 1;
+    if (gram) {
+        // ---- last layer, normalize, RenderCLIPEmbedding and their backward in the layer's INPUT space (see k_ltg_ray_u) ----
+        const LinearLayer &L1 = m->layers[NL - 1];
+        const int hd = L1.in;
+        const float *wle = m->d_params + L1.w_off;                         // W [E][hd]
+        const float *a = H[NL - 2];                                        // [c, hd] (stride W): post-ReLU input of the last layer
+        float *sga = hle;                                                  // S = A G, then g_a in place: columns [0, hd) of the buffer h would have taken
+        float *ba = G[1];                                                  // beta_j a_j
+        float *pp = G[2];                                                  // per-sample scalars [c][8]
+        float *mm = const_cast<float *>(gram) + (size_t)hd * hd, *u = mm + (size_t)hd * hd, *v = u + (size_t)rays * hd, *gv = v + (size_t)rays * E, *q = gv + (size_t)rays * E;      // M [hd x hd]; per-ray rows
+        NRF_TRY(gemm_rm(st, false, false, c, hd, hd, 1.0f, a, W, gram, hd, 0.0f, sga, W));                                  // S = A G   (G symmetric)
+        hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)7 * s * sizeof(float), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
+                           (const float *)sga, W, pp, u, weights);
+        NRF_LAUNCH_CHECK();
+        NRF_TRY(gemm_rm(st, false, true, rays, E, hd, 1.0f, u, hd, wle, hd, 0.0f, v, E));                                  // V = U W^T
+        hipLaunchKernelGGL(k_ltg_ray_v, dim3((unsigned)rays), dim3(256), 0, st, E, (const float *)v, g_rendered, gv, rendered);
+        NRF_LAUNCH_CHECK();
+        NRF_TRY(gemm_rm(st, false, false, rays, hd, E, 1.0f, gv, E, wle, hd, 0.0f, q, hd));                                // Q = G_V W
+        hipLaunchKernelGGL(k_ltg_ray_g, dim3((unsigned)rays), dim3(256), (size_t)(s + hd) * sizeof(float), st, s, hd, (const float *)q, a, W, sga, W, ba, W, (const float *)pp, keep, z,
+                           dirs, d_stride, g33, W);
+        NRF_LAUNCH_CHECK();
+        float *dw = g_params + L1.w_off;                                   // [E][hd]
+        NRF_TRY(gemm_rm(st, true, false, E, hd, rays, 1.0f, gv, E, u, hd, 1.0f, dw, hd));                                  // dW += G_V^T U
+        NRF_TRY(gemm_rm(st, true, false, hd, hd, c, 1.0f, a, W, ba, W, 0.0f, mm, hd));                                     // M = A^T diag(beta) A
+        NRF_TRY(gemm_rm(st, false, false, E, hd, hd, -1.0f, wle, hd, mm, hd, 1.0f, dw, hd));                               // dW -= W M
+        g = Seg{sga, W, 0, hd};
+        l_top = NL - 2;
+        gi = 1;                                                            // G[1] (ba) is free again once M is formed: stream order
+    } else {
     hipLaunchKernelGGL(k_lt_point_norm, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, st, c, E, hle, W, nrm);
     NRF_LAUNCH_CHECK();
     // ---- per ray: weights, RenderCLIPEmbedding, their backward ----
-    float *g33 = G[0];
     const size_t lds = ((size_t)7 * s + (size_t)2 * E) * sizeof(float);
     hipLaunchKernelGGL(k_lt_ray, dim3((unsigned)rays), dim3(256), lds, st, s, E, h33, W, keep, z, dirs, d_stride, noise, noise_std, hle, W, (const float *)nrm, g_rendered, g33, W,
                        rendered, weights);
     NRF_LAUNCH_CHECK();
+    }
     // ---- LE net backward (last layer first)                                                        LeRF.cpp:97-103 ----
-    Seg g{hle, W, 0, E};
-    int gi = 1;
-    for (int l = NL - 1; l >= nl; l--) {
+    for (int l = l_top; l >= nl; l--) {
         const LinearLayer &L = m->layers[l];
         if (l != NL - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
@@ -322,20 +535,33 @@ int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_
     if (workspace_bytes < head_ws_bytes(lerf, n, s)) { set_error("nrf_lerf_head_backward: workspace %zu < %zu bytes", workspace_bytes, head_ws_bytes(lerf, n, s)); return NRF_ERR_WORKSPACE; }
     if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
-    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t cpts = lt_chunk_pts(lerf, s);
+    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
     const int64_t cmax = (n < rays_per ? n : rays_per) * s;
-    const size_t buf = align_up((size_t)cmax * lerf->max_width * sizeof(float), 256) / sizeof(float);
+    const size_t buf = align_up((size_t)cmax * lt_width(lerf, s) * sizeof(float), 256) / sizeof(float);
     float *base = reinterpret_cast<float *>(d_workspace);
     float *nrm = base + buf * (lerf->layers.size() + 4);
     const int in = lerf->small.input_ch;
-    for (int64_t r0 = 0; r0 < n; r0 += rays_per) {
+    // Gram form of the last layer: G = W^T W once per call (the weights change every step), stream-ordered scratch
+    float *gram = nullptr;
+    if (lerf_train_gram(lerf, s)) {
+        const LinearLayer &L1 = lerf->layers.back();
+        const int64_t rmax = n < rays_per ? n : rays_per;          // G, M, then the per-ray rows u, v, g_v, q of one chunk
+        NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&gram), ((size_t)2 * L1.in * L1.in + (size_t)rmax * (2 * L1.in + 2 * L1.out)) * sizeof(float), st));
+        const float *wle = lerf->d_params + L1.w_off;
+        const int rcg = gemm_rm(st, true, false, L1.in, L1.in, L1.out, 1.0f, wle, L1.in, wle, L1.in, 0.0f, gram, L1.in);
+        if (rcg != NRF_OK) { (void)hipFreeAsync(gram, st); return rcg; }
+    }
+    int rc = NRF_OK;
+    for (int64_t r0 = 0; r0 < n && rc == NRF_OK; r0 += rays_per) {
         const int64_t rays = (n - r0) < rays_per ? (n - r0) : rays_per;
         const int64_t p0 = r0 * s;
-        NRF_TRY(head_backward_chunk(lerf, d_emb + p0 * in, d_keep ? d_keep + p0 : nullptr, d_z + p0, d_dirs + r0 * d_stride, d_stride, d_noise ? d_noise + p0 : nullptr, noise_std,
-                                    rays, s, d_g_rendered + r0 * E, d_g_params, d_g_emb ? d_g_emb + p0 * in : nullptr, d_rendered ? d_rendered + r0 * E : nullptr,
-                                    d_weights ? d_weights + p0 : nullptr, base, buf, nrm, st));
+        rc = head_backward_chunk(lerf, d_emb + p0 * in, d_keep ? d_keep + p0 : nullptr, d_z + p0, d_dirs + r0 * d_stride, d_stride, d_noise ? d_noise + p0 : nullptr, noise_std,
+                                 rays, s, d_g_rendered + r0 * E, d_g_params, d_g_emb ? d_g_emb + p0 * in : nullptr, d_rendered ? d_rendered + r0 * E : nullptr,
+                                 d_weights ? d_weights + p0 : nullptr, base, buf, nrm, gram, st);
     }
-    return NRF_OK;
+    if (gram) (void)hipFreeAsync(gram, st);
+    return rc;
 }
 
 // ... with the language grid in front: pts [n, s, 3] -> nrf_hash_encode (fp32 rows) -> the head's backward -> nrf_hash_backward_rays, chunk by chunk of whole rays
@@ -344,7 +570,8 @@ size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int6
     if (!r || s < 1) return 0;
     const nrf_mlp *m = nrf_lerf_renderer_head(r);
     const nrf_hash *h = nrf_lerf_renderer_lang_embed(r);
-    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t cpts = lt_chunk_pts(m, s);
+    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
     const int64_t c = (n < rays_per ? (n < 1 ? 1 : n) : rays_per) * s;
     const int in = nrf_hash_output_dims(h);
     return head_ws_bytes(m, n, s) + 2 * align_up((size_t)c * in * sizeof(float), 256) + align_up((size_t)c, 256) + 1024;
@@ -360,7 +587,8 @@ int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, con
     if (in != m->small.input_ch) { set_error("nrf_lerf_backward_points: the grid yields %d features, the head expects %d", in, m->small.input_ch); return NRF_ERR_INVALID_ARG; }
     if (workspace_bytes < nrf_lerf_backward_points_workspace_bytes(r, n, s)) { set_error("nrf_lerf_backward_points: workspace %zu < %zu bytes", workspace_bytes, nrf_lerf_backward_points_workspace_bytes(r, n, s)); return NRF_ERR_WORKSPACE; }
     if (n == 0) return NRF_OK;
-    const int64_t rays_per = LT_CHUNK_PTS / s > 0 ? LT_CHUNK_PTS / s : 1;
+    const int64_t cpts = lt_chunk_pts(m, s);
+    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
     const int64_t cmax = (n < rays_per ? n : rays_per) * s;
     char *ws = static_cast<char *>(d_workspace);
     const size_t hb = head_ws_bytes(m, n, s), eb = align_up((size_t)cmax * in * sizeof(float), 256);
@@ -375,6 +603,15 @@ int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, con
         NRF_TRY(nrf_hash_backward_rays(h, d_pts + p0 * 3, rays, s, g_emb, d_g_table, stream));                        // CuHashEmbedderBackwardKernel's gradient (CuHashEmbedder.cu:105-216)
     }
     return NRF_OK;
+}
+
+// Debug / test entry (not part of the public header): the last layer of the head's backward in its Gram form (1, the default) or layer-wise (0); returns the previous setting
+NRF_API int nrf_dbg_lerf_train_gram(int on)
+{
+    int prev = g_lerf_train_gram.load();
+    if (prev < 0) prev = !(getenv("NRF_LERF_TRAIN_GRAM") && getenv("NRF_LERF_TRAIN_GRAM")[0] == '0');
+    g_lerf_train_gram.store(on ? 1 : 0);
+    return prev;
 }
 
 }  // extern "C"

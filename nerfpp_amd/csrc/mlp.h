@@ -86,6 +86,7 @@ int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLa
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st);
 int fp32_gemm_available();
+int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc);
 
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);

@@ -2996,11 +2996,23 @@ def _lerf_golden_case(tag):
     return dict(geo=geo, n_layers=layers, hidden=hidden, embed=embed, in_ch=in_ch, n=n, s=s, stride=stride), blob, g, where
 
 
+@pytest.fixture
+def lerf_gram_form(api, request):
+    """the head's last layer in its Gram form (1, the library's default) or layer-wise (0) for one test (nrf_dbg_lerf_train_gram, lerf_train.hip)"""
+    lib = api.L.lib()
+    lib.nrf_dbg_lerf_train_gram.restype = C.c_int
+    prev = lib.nrf_dbg_lerf_train_gram(int(request.param))
+    yield int(request.param)
+    lib.nrf_dbg_lerf_train_gram(prev)
+
+
+@pytest.mark.parametrize("lerf_gram_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("tag", ["train_lerf", "train_lerf_l3", "train_lerf_main"])
-def test_lerf_training_head_backward_vs_reference_autograd(api, O, tag):
+def test_lerf_training_head_backward_vs_reference_autograd(api, O, tag, lerf_gram_form):
     """nrf_huber_rows_nanmean + nrf_lerf_head_backward (lerf_train.hip) against LibTorch autograd through the COMPILED LeRFImpl::forward, the compiled RawToOutputs' weights
     (RawToLEOutputs' expression) and the reference's inline RenderCLIPEmbedding (goldens train_lerf*: two layers, three layers, main.cpp:203-213 dims): loss 2e-6 relative,
-    recomputed forward 1e-4, every gradient within 2e-4 of its tensor's largest entry of the REFERENCE's and within 2e-5 of the oracle's (float atomics in another order)."""
+    recomputed forward 1e-4, every gradient within 2e-4 of its tensor's largest entry of the REFERENCE's and within 2e-5 of the oracle's (float atomics in another order).
+    Both forms of the last layer: the Gram form (nothing embedding-wide per sample: the default) and the layer-wise one."""
     from nerfpp_amd import train as T
     c, blob, g, where = _lerf_golden_case(tag)
     lerf = api.M.LeRF(c["geo"], c["n_layers"], c["hidden"], c["embed"], c["in_ch"], "lang_model", params=blob)
