@@ -229,6 +229,23 @@ __global__ void __launch_bounds__(256) k_lt_ray(int s, int e, const float *__res
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 constexpr int LTG_PP = 8;
 
+// In-place EXCLUSIVE prefix sums of d[0 .. s) in double by one wave (call with the 64 lanes of wave 0 only; REVERSE: suffix sums, d[j] = sum_{i > j}).  Each lane takes
+// a contiguous run, the runs' totals go through a wave scan.  The per-ray weights need a running sum over the samples (ATen's cumsum accumulates in double): taken by
+// one thread it was 192 dependent software exp / log evaluations per ray -- most of these kernels' time.
+template <bool REVERSE>
+__device__ __forceinline__ void lt_excl_scan_wave0(double *d, int s, int lane)
+{
+    const int per = (s + 63) / 64;
+    auto at = [&](int i) { return REVERSE ? s - 1 - i : i; };
+    double run = 0.0;
+    for (int e = 0; e < per; e++) { const int i = lane * per + e; if (i < s) run += d[at(i)]; }
+    double incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    double acc = incl - run;
+    for (int e = 0; e < per; e++) { const int i = lane * per + e; if (i < s) { const double t = d[at(i)]; d[at(i)] = acc; acc += t; } }
+}
+
 // per ray: the weights (as k_lt_ray), c_j and ||h_j|| from a_j . s_j, u = sum_j (w_j / c_j) a_j.  blockDim = 256; hd <= 256 features (one per thread)
 __global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *__restrict__ sig33, int ss, const uint8_t *__restrict__ keep, const float *__restrict__ z,
                                                    const float *__restrict__ dirs, int d_stride, const float *__restrict__ noise, float noise_std, const float *__restrict__ a,
@@ -236,10 +253,12 @@ __global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *_
 {
     extern __shared__ float lds[];
     float *alpha = lds, *trans = lds + s, *xx = lds + 2 * s, *lt = lds + 3 * s, *wgt = lds + 4 * s, *sg = lds + 5 * s, *cj = lds + 6 * s;
+    double *dsum = reinterpret_cast<double *>(lds + 7 * s + (s & 1));          // [s] (8-byte aligned)
     const int64_t ray = blockIdx.x;
     const int64_t p0 = ray * s;
     const float *dv = dirs + ray * d_stride;
     const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int j = threadIdx.x; j < s; j += blockDim.x) {
         float sr = (keep && !keep[p0 + j]) ? 0.0f : sig33[(p0 + j) * ss];
         if (noise) sr = sr + noise[p0 + j] * noise_std;
@@ -248,21 +267,20 @@ __global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *_
         dist = dist * dn;
         const float x = -(sr > 0.0f ? sr : 0.0f) * dist;
         xx[j] = x;
-        alpha[j] = -nrf_expf(x) + 1.0f;
+        const float al = -nrf_expf(x) + 1.0f;
+        alpha[j] = al;
+        const float om = 1.0f - al;
+        dsum[j] = (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double logt = 0.0; float tprev = 0.0f;
-        for (int j = 0; j < s; j++) {
-            lt[j] = tprev; trans[j] = nrf_expf(tprev);
-            const float om = 1.0f - alpha[j];
-            logt += (double)nrf_logf(om > 1e-10f ? om : 1e-10f);
-            tprev = (float)logt;
-            wgt[j] = alpha[j] * trans[j];
-        }
+    if (wave == 0) lt_excl_scan_wave0<false>(dsum, s, lane);          // log-space transmittance: the double running sum, each prefix rounded to fp32 below
+    __syncthreads();
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        const float tprev = (float)dsum[j];
+        lt[j] = tprev; trans[j] = nrf_expf(tprev);
+        wgt[j] = alpha[j] * trans[j];
     }
     // ||h_j|| (a wave per sample)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int j = wave; j < s; j += 4) {
         const float *ar = a + (p0 + j) * as, *sr = sg_a + (p0 + j) * sgs;
         double q = 0.0;
@@ -315,6 +333,7 @@ __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *_
 {
     extern __shared__ float lds[];
     float *gw = lds, *qs = lds + s;
+    double *dsum = reinterpret_cast<double *>(lds + s + hd + ((s + hd) & 1));          // [s]
     const int64_t ray = blockIdx.x;
     const int64_t p0 = ray * s;
     for (int k = threadIdx.x; k < hd; k += blockDim.x) qs[k] = q[ray * hd + k];
@@ -340,18 +359,25 @@ __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *_
         if (lane == 0) gw[j] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // the weights' backward (RawToLEOutputs :38-66, TruncExp::backward = grad * exp(clamp(x, -100, 5))): per-sample terms in parallel, their suffix sums by one wave
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        const float *o = pp + (p0 + j) * LTG_PP;
+        const float ltj = o[2];
+        const float cl = ltj < -100.0f ? -100.0f : (ltj > 5.0f ? 5.0f : ltj);
+        dsum[j] = (double)(gw[j] * o[0] * nrf_expf(cl));
+    }
+    __syncthreads();
+    if (wave == 0) lt_excl_scan_wave0<true>(dsum, s, lane);
+    __syncthreads();
+    {
         const float *dv = dirs + ray * d_stride;
         const float dn = sqrtf(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
-        double suffix = 0.0;
-        for (int j = s - 1; j >= 0; j--) {
+        for (int j = threadIdx.x; j < s; j += blockDim.x) {
             const float *o = pp + (p0 + j) * LTG_PP;
-            const float alpha = o[0], trans = o[1], ltj = o[2], xj = o[3], sgj = o[4];
+            const float alpha = o[0], trans = o[1], xj = o[3], sgj = o[4];
             float g_alpha = gw[j] * trans;
             const float om = 1.0f - alpha;
-            if (om >= 1e-10f) g_alpha -= (float)suffix / om;
-            const float cl = ltj < -100.0f ? -100.0f : (ltj > 5.0f ? 5.0f : ltj);
-            suffix += (double)(gw[j] * alpha * nrf_expf(cl));
+            if (om >= 1e-10f) g_alpha -= (float)dsum[j] / om;
             const float cx = xj < -100.0f ? -100.0f : (xj > 5.0f ? 5.0f : xj);
             const float g_x = -g_alpha * nrf_expf(cx);
             float dist = (j + 1 < s) ? (z[p0 + j + 1] - z[p0 + j]) : 1e10f;
@@ -372,7 +398,7 @@ static bool lerf_train_gram(const nrf_mlp *m, int s)
     const bool on = st != 0;
     const int hd = m->small.hidden_dim, E = m->small.hidden_dim_color;
     (void)E;
-    return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(7 * s + hd) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
+    return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(9 * s + hd + 2) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
 }
 
 // dst[pt][d_col + k] = src[pt][s_col + k] (+ add[pt][a_col + k]), k < ncols
@@ -437,14 +463,14 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         float *pp = G[2];                                                  // per-sample scalars [c][8]
         float *mm = const_cast<float *>(gram) + (size_t)hd * hd, *u = mm + (size_t)hd * hd, *v = u + (size_t)rays * hd, *gv = v + (size_t)rays * E, *q = gv + (size_t)rays * E;      // M [hd x hd]; per-ray rows
         NRF_TRY(gemm_rm(st, false, false, c, hd, hd, 1.0f, a, W, gram, hd, 0.0f, sga, W));                                  // S = A G   (G symmetric)
-        hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)7 * s * sizeof(float), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
+        hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)(7 * s + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
                            (const float *)sga, W, pp, u, weights);
         NRF_LAUNCH_CHECK();
         NRF_TRY(gemm_rm(st, false, true, rays, E, hd, 1.0f, u, hd, wle, hd, 0.0f, v, E));                                  // V = U W^T
         hipLaunchKernelGGL(k_ltg_ray_v, dim3((unsigned)rays), dim3(256), 0, st, E, (const float *)v, g_rendered, gv, rendered);
         NRF_LAUNCH_CHECK();
         NRF_TRY(gemm_rm(st, false, false, rays, hd, E, 1.0f, gv, E, wle, hd, 0.0f, q, hd));                                // Q = G_V W
-        hipLaunchKernelGGL(k_ltg_ray_g, dim3((unsigned)rays), dim3(256), (size_t)(s + hd) * sizeof(float), st, s, hd, (const float *)q, a, W, sga, W, ba, W, (const float *)pp, keep, z,
+        hipLaunchKernelGGL(k_ltg_ray_g, dim3((unsigned)rays), dim3(256), (size_t)(s + hd + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, (const float *)q, a, W, sga, W, ba, W, (const float *)pp, keep, z,
                            dirs, d_stride, g33, W);
         NRF_LAUNCH_CHECK();
         float *dw = g_params + L1.w_off;                                   // [E][hd]

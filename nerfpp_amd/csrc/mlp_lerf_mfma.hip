@@ -19,7 +19,10 @@
 // Built for the reference's LeRF shape (main.cpp:203-213): in 16 x 8 = 128, hidden 256, 2 + 2 layers, geo 32, embedding 768.
 #include "mlp_lerf_net.h"
 
+#include <cmath>
+#include <thread>
 #include <utility>
+#include <vector>
 
 namespace nrf {
 namespace lerf {
@@ -329,13 +332,36 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         std::vector<double> wt((size_t)HID * EMB);                    // W^T [256][768]: contiguous dot products
         for (int o = 0; o < EMB; o++)
             for (int k = 0; k < HID; k++) wt[(size_t)k * EMB + o] = (double)w3[(size_t)o * HID + k];
-        for (int a = 0; a < HID; a++)
-            for (int b = a; b < HID; b++) {
-                double acc = 0.0;
-                const double *pa = wt.data() + (size_t)a * EMB, *pb = wt.data() + (size_t)b * EMB;
-                for (int o = 0; o < EMB; o++) acc += pa[o] * pb[o];
-                gram[(size_t)a * HID + b] = gram[(size_t)b * HID + a] = (float)acc;
+        // 256 x 257 / 2 dot products of 768 terms in double: the whole of a per-step parameter upload's host time while one thread did it (a LeRF training step re-packs
+        // every step: 21 ms of a 76 ms step, tools/scratch/lerf_train_phases.py).  Rows dealt out to up to 8 threads; four partial sums per dot product (same double
+        // precision, another association: the entries are rounded to fp32 and then to fp16 anyway)
+        auto rows = [&](int a0, int a1) {
+            for (int a = a0; a < a1; a++)
+                for (int b = a; b < HID; b++) {
+                    const double *pa = wt.data() + (size_t)a * EMB, *pb = wt.data() + (size_t)b * EMB;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int o = 0;
+                    for (; o + 4 <= EMB; o += 4) { s0 += pa[o] * pb[o]; s1 += pa[o + 1] * pb[o + 1]; s2 += pa[o + 2] * pb[o + 2]; s3 += pa[o + 3] * pb[o + 3]; }
+                    for (; o < EMB; o++) s0 += pa[o] * pb[o];
+                    gram[(size_t)a * HID + b] = gram[(size_t)b * HID + a] = (float)((s0 + s1) + (s2 + s3));
+                }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1);
+        if (nt == 1) rows(0, HID);
+        else {
+            // row a costs HID - a dot products: cut at equal areas of the triangle
+            std::vector<std::thread> th;
+            int a0 = 0;
+            for (int t = 0; t < nt; t++) {
+                const double frac = (double)(t + 1) / nt;
+                int a1 = t == nt - 1 ? HID : (int)(HID * (1.0 - sqrt(1.0 - frac)));
+                if (a1 < a0) a1 = a0;
+                th.emplace_back(rows, a0, a1);
+                a0 = a1;
             }
+            for (auto &x : th) x.join();
+        }
     }
     // fp16 range: entries of G are sums of 768 products and pass 65504 for weights of moderate size; G is stored divided by a power of two that brings
     // max|G| to <= 1024 (exact scaling; the kernels multiply a^T G a back), so neither the entries nor the fp16 rounding of large ones can overflow
@@ -357,32 +383,45 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
             if (ub < ta) gram[(size_t)a * HID + b] = 0.0f;
             else if (ub > ta) gram[(size_t)a * HID + b] *= 2.0f;
         }
+    // every fragment's (layer, tile, k-step), then the image values ONCE (fp16 image and the split image's (hi, lo) fragments both come from them), dealt out to threads:
+    // a per-step re-pack evaluated wval 1.1 M times on one thread
+    struct FragId { int L, tile, k; };
+    std::vector<FragId> frags;
+    frags.reserve(IMAGE_FRAGS);
     for (int L = 0; L < 5; L++)
         for (int tile = 0; tile < N::tiles(L); tile++)
-            for (int k = 0; k < N::ks(L); k++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(hp, gram, L, tile * 32 + (lane & 31), k, lane >> 5, j));
-    if (img.size() != (size_t)IMAGE_FRAGS * 512) { set_error("internal: LeRF weight image has %zu halves, expected %zu", img.size(), (size_t)IMAGE_FRAGS * 512); return NRF_ERR_INVALID_ARG; }
-    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }
+            for (int k = 0; k < N::ks(L); k++) frags.push_back(FragId{L, tile, k});
+    if ((int)frags.size() != IMAGE_FRAGS) { set_error("internal: LeRF weight image has %zu fragments, expected %d", frags.size(), IMAGE_FRAGS); return NRF_ERR_INVALID_ARG; }
+    img.resize((size_t)IMAGE_FRAGS * 512);
+    std::vector<_Float16> img2((size_t)IMAGE_FRAGS * 1024);
+    auto fill = [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++) {
+            const FragId id = frags[(size_t)f];
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const float v = wval(hp, gram, id.L, id.tile * 32 + (lane & 31), id.k, lane >> 5, j);
+                    const _Float16 hv = (_Float16)v;
+                    const size_t e = (size_t)lane * 8 + j;
+                    img[(size_t)f * 512 + e] = hv;
+                    img2[(size_t)(2 * f) * 512 + e] = hv;                                  // split image: every fragment followed by the fragment of the residuals w - f16(w)
+                    img2[(size_t)(2 * f + 1) * 512 + e] = (_Float16)(v - (float)hv);
+                }
+        }
+    };
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(fill, IMAGE_FRAGS * t / nt, IMAGE_FRAGS * (t + 1) / nt);
+        for (auto &x : th) x.join();
+    }
+    if (m->d_packed_f16 && m->packed_f16_bytes != img.size() * sizeof(_Float16)) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }
     m->packed_f16_bytes = img.size() * sizeof(_Float16);
-    NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
+    if (!m->d_packed_f16) NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));          // a re-pack of the same shape writes in place (the caller has synchronised: mlp.hip)
     NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), m->packed_f16_bytes, hipMemcpyHostToDevice));
-    // split-precision image (mlp_lerf_split_mfma.hip): every fragment followed by the fragment of the rounding residuals w - f16(w)
-    std::vector<_Float16> img2;
-    img2.reserve(img.size() * 2);
-    for (int L = 0; L < 5; L++)
-        for (int tile = 0; tile < N::tiles(L); tile++)
-            for (int k = 0; k < N::ks(L); k++)
-                for (int part = 0; part < 2; part++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int j = 0; j < 8; j++) {
-                            const float v = wval(hp, gram, L, tile * 32 + (lane & 31), k, lane >> 5, j);
-                            const _Float16 hv = (_Float16)v;
-                            img2.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
-                        }
-    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
+    if (m->d_packed_split && m->packed_split_bytes != img2.size() * sizeof(_Float16)) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
     m->packed_split_bytes = img2.size() * sizeof(_Float16);
-    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
+    if (!m->d_packed_split) NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_split, img2.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
     return NRF_OK;
 }
