@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 
+#include <functional>
 #include <vector>
 
 namespace nrf {
@@ -119,6 +120,11 @@ int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const 
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+// views_linears_0 o feature_linear of the classic network (no activation between them, NeRF.cpp:112-115), in double, rows over up to 8 host threads:
+// merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r]   (Wv rows are wv_stride floats apart)
+void nerf_merged_views_host(const float *wv, int wv_stride, const float *wf, const float *bf, const float *bv, int rows, int w, std::vector<float> &merged, std::vector<float> &merged_b);
+// f(i) for i in [0, n) on up to 8 host threads (the per-step re-pack of a training loop: nrf_mlp_set_params)
+void host_parallel_for(int n, const std::function<void(int, int)> &range_fn);
 // sigma_nerf_f32.hip: the classic network's density branch in exact fp32 on the matrix cores (coarse pass)
 int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);
 int mlp_nerf_sigma_f32_available(const nrf_mlp *m);

@@ -35,6 +35,9 @@
 //   9      : rgb_linear      [chained 8]          -> 1 tile (rows 0..2)         out = cat[rgb, alpha] (NeRF.cpp:119)
 #include "mlp_nerf_net.h"
 
+#include <functional>
+#include <thread>
+
 #include <utility>
 
 namespace nrf {
@@ -285,6 +288,36 @@ static bool nerf_mfma_supported(const nrf_mlp_nerf_desc &d)
     return d.depth == 8 && d.width == 256 && d.input_ch == 63 && d.input_ch_views == 27 && d.skip == 4 && d.use_viewdirs;
 }
 
+void host_parallel_for(int n, const std::function<void(int, int)> &range_fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = n < 2 ? 1 : (hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1));
+    if (nt == 1) { range_fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(range_fn, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+    for (auto &x : th) x.join();
+}
+
+void nerf_merged_views_host(const float *wv, int wv_stride, const float *wf, const float *bf, const float *bv, int rows, int w, std::vector<float> &merged, std::vector<float> &merged_b)
+{
+    merged.assign((size_t)rows * w, 0.0f); merged_b.assign((size_t)rows, 0.0f);
+    host_parallel_for(rows, [&](int r0, int r1) {
+        std::vector<double> acc((size_t)w);
+        for (int r = r0; r < r1; r++) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            double b = (double)bv[r];
+            for (int f = 0; f < w; f++) {
+                const double c = (double)wv[(size_t)r * wv_stride + f];
+                b += c * (double)bf[f];
+                const float *frow = wf + (size_t)f * w;
+                for (int k = 0; k < w; k++) acc[k] += c * (double)frow[k];
+            }
+            for (int k = 0; k < w; k++) merged[(size_t)r * w + k] = (float)acc[k];
+            merged_b[r] = (float)b;
+        }
+    });
+}
+
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 {
     const auto &d = m->nerf;
@@ -310,23 +343,8 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     auto chained = [](int k, int h, int j) { return 32 * (k >> 1) + nerf_perm_row(k & 1, h, j); };
     auto natural = [](int k, int h, int j) { return 16 * k + 8 * h + j; };
     // views_linears_0 o feature_linear: merged[r][k] = sum_f W_v[r][f] F[f][k], merged_b[r] = sum_f W_v[r][f] b_f[f] + b_v[r]   (double accumulation)
-    std::vector<float> merged((size_t)(W / 2) * W), merged_b(W / 2);
-    {
-        const float *wv = hp.data() + w_off[VIEWS], *wf = hp.data() + w_off[FEAT], *bf = hp.data() + b_off[FEAT], *bv = hp.data() + b_off[VIEWS];
-        std::vector<double> acc(W);
-        for (int r = 0; r < W / 2; r++) {
-            std::fill(acc.begin(), acc.end(), 0.0);
-            double b = (double)bv[r];
-            for (int f = 0; f < W; f++) {
-                const double c = (double)wv[(size_t)r * (V + W) + f];
-                b += c * (double)bf[f];
-                const float *frow = wf + (size_t)f * W;
-                for (int k = 0; k < W; k++) acc[k] += c * (double)frow[k];
-            }
-            for (int k = 0; k < W; k++) merged[(size_t)r * W + k] = (float)acc[k];
-            merged_b[r] = (float)b;
-        }
-    }
+    std::vector<float> merged, merged_b;
+    nerf_merged_views_host(hp.data() + w_off[VIEWS], V + W, hp.data() + w_off[FEAT], hp.data() + b_off[FEAT], hp.data() + b_off[VIEWS], W / 2, W, merged, merged_b);
     // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel-layer L (-> 0 if padding)
     auto wval = [&](int L, int row, int kstep, int h, int j) -> float {
         const int ksn = NerfNet::ks_nat(L), ksc = NerfNet::ks_ch(L);
@@ -346,40 +364,45 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         return row < 3 ? hp[w_off[RGB] + (size_t)row * (W / 2) + idx] : 0.0f;
     };
     for (int L = 0; L < NerfNet::NLAYER; L++) {
-        const int KS = NerfNet::ks(L);
-        for (int tile = 0; tile < NerfNet::tiles(L); tile++)
-            for (int k = 0; k < KS; k++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int j = 0; j < 8; j++) img.push_back((_Float16)wval(L, tile * 32 + (lane & 31), k, lane >> 5, j));
         float *bp = bias.data() + NerfNet::bias_off(L);
         if (L < 8) for (int i = 0; i < W; i++) bp[i] = hp[b_off[L] + i];
         else if (L == 8) { for (int i = 0; i < W / 2; i++) bp[i] = merged_b[i]; bp[W / 2] = hp[b_off[ALPHA]]; }
         else for (int i = 0; i < 3; i++) bp[i] = hp[b_off[RGB] + i];
     }
-    if (img.size() != (size_t)NerfNet::total_frags() * 512) { set_error("internal: classic NeRF weight image has %zu halves, expected %zu", img.size(), (size_t)NerfNet::total_frags() * 512); return NRF_ERR_INVALID_ARG; }
-    if (m->d_packed_f16) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // re-pack after nrf_mlp_set_params
-    m->packed_f16_bytes = img.size() * sizeof(_Float16) + bias.size() * sizeof(float);
-    NRF_HIP(hipMalloc(&m->d_packed_f16, m->packed_f16_bytes));
+    // every fragment's (layer, tile, k-step); the image values ONCE -- the fp16 image and the split image's (hi, lo) fragments both come from them -- on up to 8 threads
+    // (a training loop re-packs every step: this function and mlp_nerf_pack_sigma_f32 were 25 ms of an 85 ms classic step on one thread)
+    struct FragId { int L, tile, k; };
+    std::vector<FragId> frags;
+    for (int L = 0; L < NerfNet::NLAYER; L++)
+        for (int tile = 0; tile < NerfNet::tiles(L); tile++)
+            for (int k = 0; k < NerfNet::ks(L); k++) frags.push_back(FragId{L, tile, k});
+    const int NF = (int)frags.size();
+    if (NF != NerfNet::total_frags()) { set_error("internal: classic NeRF weight image has %d fragments, expected %d", NF, NerfNet::total_frags()); return NRF_ERR_INVALID_ARG; }
+    img.resize((size_t)NF * 512);
+    std::vector<_Float16> img2((size_t)NF * 1024);
+    host_parallel_for(NF, [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++) {
+            const FragId id = frags[(size_t)f];
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const float v = wval(id.L, id.tile * 32 + (lane & 31), id.k, lane >> 5, j);
+                    const _Float16 hv = (_Float16)v;
+                    const size_t e = (size_t)lane * 8 + j;
+                    img[(size_t)f * 512 + e] = hv;
+                    img2[(size_t)(2 * f) * 512 + e] = hv;                                  // NRF_PREC_F16_SPLIT image: every fragment followed by the fragment of the residuals w - f16(w)
+                    img2[(size_t)(2 * f + 1) * 512 + e] = (_Float16)(v - (float)hv);
+                }
+        }
+    });
+    const size_t b1 = img.size() * sizeof(_Float16) + bias.size() * sizeof(float), b2 = img2.size() * sizeof(_Float16) + bias.size() * sizeof(float);
+    if (m->d_packed_f16 && m->packed_f16_bytes != b1) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // a re-pack of the same shape writes in place (the caller has synchronised)
+    m->packed_f16_bytes = b1;
+    if (!m->d_packed_f16) NRF_HIP(hipMalloc(&m->d_packed_f16, b1));
     NRF_HIP(hipMemcpy(m->d_packed_f16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_f16) + img.size() * sizeof(_Float16), bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
-    // NRF_PREC_F16_SPLIT image (mlp_nerf_split_mfma.hip): every fragment followed by the fragment of the rounding residuals w - f16(w); same biases behind it
-    std::vector<_Float16> img2;
-    img2.reserve(img.size() * 2);
-    for (int L = 0; L < NerfNet::NLAYER; L++) {
-        const int KS = NerfNet::ks(L);
-        for (int tile = 0; tile < NerfNet::tiles(L); tile++)
-            for (int k = 0; k < KS; k++)
-                for (int part = 0; part < 2; part++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int j = 0; j < 8; j++) {
-                            const float v = wval(L, tile * 32 + (lane & 31), k, lane >> 5, j);
-                            const _Float16 hv = (_Float16)v;
-                            img2.push_back(part == 0 ? hv : (_Float16)(v - (float)hv));
-                        }
-    }
-    if (m->d_packed_split) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
-    m->packed_split_bytes = img2.size() * sizeof(_Float16) + bias.size() * sizeof(float);
-    NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
+    if (m->d_packed_split && m->packed_split_bytes != b2) { (void)hipFree(m->d_packed_split); m->d_packed_split = nullptr; }
+    m->packed_split_bytes = b2;
+    if (!m->d_packed_split) NRF_HIP(hipMalloc(&m->d_packed_split, b2));
     NRF_HIP(hipMemcpy(m->d_packed_split, img2.data(), img2.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     NRF_HIP(hipMemcpy(static_cast<char *>(m->d_packed_split) + img2.size() * sizeof(_Float16), bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     return NRF_OK;

@@ -421,22 +421,8 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     off += 256 + 1;
     const float *wr = hp.data() + off, *br = wr + (size_t)128 * 3;
     // views_linears_0 o feature_linear (no activation between them, NeRF.cpp:112-115): merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r], in double
-    std::vector<float> merged((size_t)128 * 256), merged_b(128);
-    {
-        std::vector<double> acc(256);
-        for (int r = 0; r < 128; r++) {
-            std::fill(acc.begin(), acc.end(), 0.0);
-            double b = (double)bv[r];
-            for (int f = 0; f < 256; f++) {
-                const double c = (double)wv[(size_t)r * (V + 256) + f];
-                b += c * (double)bf[f];
-                const float *frow = wf + (size_t)f * 256;
-                for (int k = 0; k < 256; k++) acc[k] += c * (double)frow[k];
-            }
-            for (int k = 0; k < 256; k++) merged[(size_t)r * 256 + k] = (float)acc[k];
-            merged_b[r] = (float)b;
-        }
-    }
+    std::vector<float> merged, merged_b;
+    nerf_merged_views_host(wv, V + 256, wf, bf, bv, 128, 256, merged, merged_b);
     // (hi, lo) fp16 fragments of the colour branch: per k-step the hi fragment then the fragment of the rounding residuals
     std::vector<_Float16> himg;
     himg.reserve((size_t)(4 * VIEW_GROUPS + VIEW_LAST_GROUPS + RGB_GROUPS) * 512);
