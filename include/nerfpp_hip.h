@@ -109,6 +109,9 @@ NRF_API int nrf_view_rays(const nrf_view *v, float *d_rays, float *d_near_far, v
 
 /* min(near), max(far) over a packed ray batch (NeRFRenderer.h:602-603); results to host, synchronises `stream`. */
 NRF_API int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *near_min, float *far_max, void *stream);
+/* ... the same into DEVICE memory (d_near_far [2] floats), in stream order, nothing waits: what a training loop wants (the reference's two .item() calls of
+ * NeRFRenderer.h:602-603 stall its host once per rendered batch; the values are only read when a frame is post-processed). */
+NRF_API int nrf_near_far_range_device(const float *d_rays, int64_t n, int ray_stride, float *d_near_far, void *stream);
 
 /* torch::linspace(start, end, steps) as ATen's CPU kernel rounds it (one fused rounding per
  * element) -- for hosts without torch; the LibTorch / PyTorch callers pass torch::linspace itself. */

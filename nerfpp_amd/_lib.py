@@ -68,7 +68,7 @@ class View(C.Structure):          # nrf_view
 # every symbol include/nerfpp_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "nrf_version", "nrf_last_error", "nrf_status_string",
-    "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_pack_rays_viewsrc", "nrf_view_rays", "nrf_near_far_range", "nrf_linspace", "nrf_z_vals", "nrf_points",
+    "nrf_get_rays", "nrf_ndc_rays", "nrf_aabb", "nrf_pack_rays", "nrf_pack_rays_viewsrc", "nrf_view_rays", "nrf_near_far_range", "nrf_near_far_range_device", "nrf_linspace", "nrf_z_vals", "nrf_points",
     "nrf_precrop_bounds", "nrf_rand_pixels", "nrf_ray_batch", "nrf_gather_pixels",
     "nrf_pe_encode", "nrf_sh_encode",
     "nrf_hash_create", "nrf_hash_destroy", "nrf_hash_output_dims", "nrf_hash_table_elems", "nrf_hash_set_table", "nrf_hash_set_primes", "nrf_hash_set_dense_budget", "nrf_hash_get_dense_budget", "nrf_hash_get_level_scales", "nrf_hash_set_level_scales",

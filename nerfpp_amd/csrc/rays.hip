@@ -462,6 +462,19 @@ int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *ne
     return NRF_OK;
 }
 
+int nrf_near_far_range_device(const float *d_rays, int64_t n, int ray_stride, float *d_near_far, void *stream)
+{
+    NRF_CHECK_ARG(d_rays && n > 0 && ray_stride >= 8 && d_near_far, "nrf_near_far_range_device: bad argument");
+    hipStream_t st = as_stream(stream);
+    int *enc = reinterpret_cast<int *>(d_near_far);          // the two order-encoded words live in the output itself until the decode (as nrf_view_rays)
+    hipLaunchKernelGGL(k_nf_init, dim3(1), dim3(1), 0, st, enc); NRF_LAUNCH_CHECK();
+    const unsigned grid = (unsigned)(ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024);
+    hipLaunchKernelGGL(k_near_far_range, dim3(grid), dim3(256), 0, st, n, ray_stride, d_rays, d_near_far);
+    NRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_nf_decode, dim3(1), dim3(1), 0, st, reinterpret_cast<const int *>(enc), d_near_far); NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
 int nrf_precrop_bounds(int h, int w, int iter, int precrop_iters, float precrop_frac, int *out)
 {
     NRF_CHECK_ARG(out && h > 0 && w > 0, "nrf_precrop_bounds: bad argument");

@@ -410,9 +410,8 @@ class NeRFRenderer:
                                           _ptr(self._linspace(ni, dev)) if ni > 0 else None, C.byref(ro), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
             nf = None
             if n > 0:
-                nr, fr = C.c_float(0), C.c_float(0)
-                L.check(lib.nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))   # :602-603
-                res._nf = (nr.value, fr.value)
+                nf = torch.empty((2,), device=dev, dtype=torch.float32)          # Near / Far stay on the device until someone reads them (a training loop never does):
+                L.check(lib.nrf_near_far_range_device(_ptr(rays_), C.c_int64(n), stride, _ptr(nf), _stream()))   # :602-603 without the reference's two host stalls
         out = res.Outputs
         out.RGBMap = out.RGBMap.reshape(sh)                                                               # :591-592
         if len(sh) > 2:
@@ -663,9 +662,9 @@ class LeRFRenderer:
             ws = workspace(lib.nrf_lerf_batchify_rays_workspace_bytes(self._r, C.c_int64(n), int(p.Chunk), C.byref(rp)))
             L.check(lib.nrf_lerf_batchify_rays(self._r, _ptr(rays_), stride, C.c_int64(n), int(p.Chunk), C.byref(rp), _ptr(t), _ptr(u), C.byref(ro), _ptr(ws),
                                                C.c_size_t(ws.numel()), _stream()))
-            nr, fr = C.c_float(0), C.c_float(0)
-            L.check(lib.nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
-            res._nf = (nr.value, fr.value)
+            nfd = torch.empty((2,), device=rays_.device, dtype=torch.float32)
+            L.check(lib.nrf_near_far_range_device(_ptr(rays_), C.c_int64(n), stride, _ptr(nfd), _stream()))
+            res._nf_dev = nfd
         res.Extras["rays_flat"] = rays_
         return res
 
@@ -904,9 +903,9 @@ class LeRFRenderer:
             setattr(res.Outputs, name, torch.cat(vals, 0) if vals else None)
         for k_ in (parts[0].Extras if parts else {}):
             res.Extras[k_] = torch.cat([q.Extras[k_] for q in parts], 0)
-        nr, fr = C.c_float(0), C.c_float(0)
-        L.check(L.lib().nrf_near_far_range(_ptr(rays_), C.c_int64(n), stride, C.byref(nr), C.byref(fr), _stream()))
-        res._nf = (nr.value, fr.value)
+        nfd = torch.empty((2,), device=rays_.device, dtype=torch.float32)
+        L.check(L.lib().nrf_near_far_range_device(_ptr(rays_), C.c_int64(n), stride, _ptr(nfd), _stream()))
+        res._nf_dev = nfd
         if self.LerfPositives is not None and self.LerfNegatives is not None and res.Outputs.RenderedLangEmbedding is not None:
             res.Outputs.Relevancy = Relevancy(res.Outputs.RenderedLangEmbedding, self.LerfPositives, self.LerfNegatives)      # LeRFRenderer.cpp:79
         res.Extras["rays_flat"] = rays_
