@@ -44,6 +44,8 @@ struct nrf_mlp {
     nrf_mlp_nerf_desc nerf{};
     int in_dims = 0, out_dims = 0;
     int max_width = 0;                       // widest activation row (for workspace sizing)
+    // classic network, host re-pack: views_linears_0 o feature_linear as computed by mlp_nerf_pack_f16, handed to mlp_nerf_pack_sigma_f32 of the same upload (then cleared)
+    std::vector<float> host_merged, host_merged_b;
     std::vector<nrf::LinearLayer> layers;    // in forward order (see mlp.hip for the per-family order)
     float *d_params = nullptr;               // the fp32 blob, checkpoint order, on device
     int64_t n_params = 0;

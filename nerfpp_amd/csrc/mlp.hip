@@ -414,16 +414,25 @@ __global__ void __launch_bounds__(256) k_grad_b(int64_t npts, Seg g, int out, fl
 {
     const int o = blockIdx.y * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;                       // four point phases per block
-    float acc = 0.0f;
-    if (o < out)
-        for (int64_t pt = (int64_t)blockIdx.x * 4 + sub; pt < npts; pt += (int64_t)gridDim.x * 4) acc += g.p[pt * g.stride + g.off + o];
+    // four rows in flight per thread (a classic training step spends 288 of these on 131 072 x 256 gradients: at one dependent load per thread they ran at 1.3 TB/s)
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (o < out) {
+        const int64_t step = (int64_t)gridDim.x * 4;
+        const float *p = g.p + g.off + o;
+        int64_t pt = (int64_t)blockIdx.x * 4 + sub;
+        for (; pt + 3 * step < npts; pt += 4 * step) {
+            a0 += p[pt * g.stride]; a1 += p[(pt + step) * g.stride]; a2 += p[(pt + 2 * step) * g.stride]; a3 += p[(pt + 3 * step) * g.stride];
+        }
+        for (; pt < npts; pt += step) a0 += p[pt * g.stride];
+    }
+    const float acc = (a0 + a1) + (a2 + a3);
     if (o < out && acc != 0.0f) unsafeAtomicAdd(db + o, acc);
 }
 
 static int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st)
 {
-    const int64_t nb = ceil_div(npts, 4);
-    hipLaunchKernelGGL(k_grad_b, dim3((unsigned)(nb < 128 ? nb : 128), (unsigned)ceil_div(out, 64)), dim3(256), 0, st, npts, g, out, db);
+    const int64_t nb = ceil_div(npts, 16);
+    hipLaunchKernelGGL(k_grad_b, dim3((unsigned)(nb < 512 ? (nb < 1 ? 1 : nb) : 512), (unsigned)ceil_div(out, 64)), dim3(256), 0, st, npts, g, out, db);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
@@ -723,6 +732,15 @@ static int build_weight_maps(nrf_mlp *m, const std::vector<float> &hp)
     return NRF_OK;
 }
 
+// wt[k][o] = w[o][k]   (W [out][in] of the parameter blob -> W^T [in][out])
+__global__ void k_transpose_wt(int in, int out, const float *__restrict__ w, float *__restrict__ wt)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)in * out) return;
+    const int k = (int)(e / out), o = (int)(e - (int64_t)k * out);
+    wt[e] = w[(size_t)o * in + k];
+}
+
 __global__ void k_apply_weight_map(int64_t n, const int32_t *__restrict__ src, const uint8_t *__restrict__ kind, const float *__restrict__ params, void *__restrict__ out, int elem)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -879,15 +897,13 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
         NRF_HIP(hipStreamSynchronize(st));             // the derived images are overwritten in place: nothing may still be reading them
     }
     NRF_HIP(hipMemcpyAsync(m->d_params, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
-    std::vector<std::vector<float>> wts(m->layers.size());          // alive until the one synchronisation below
-    for (size_t li = 0; li < m->layers.size(); li++) {
-        auto &L = m->layers[li];
-        auto &wt = wts[li];
-        wt.resize((size_t)L.in * L.out);
-        for (int o = 0; o < L.out; o++)
-            for (int k = 0; k < L.in; k++) wt[(size_t)k * L.out + o] = hp[L.w_off + (size_t)o * L.in + k];
-        NRF_HIP(hipMemcpyAsync(L.d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
-        if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, hp.data() + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyHostToDevice, st));
+    // W^T [in][out] and the bias of every layer (the generic fp32 kernels' operands) from the uploaded blob, on the device: a training loop comes here every step, and the
+    // host transposes + two small uploads per layer were most of what was left of this call (classic 8x256: 12 layers)
+    for (auto &L : m->layers) {
+        const int64_t ne = (int64_t)L.in * L.out;
+        k_transpose_wt<<<dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st>>>(L.in, L.out, m->d_params + L.w_off, L.d_wt);
+        NRF_HIP(hipGetLastError());
+        if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, m->d_params + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyDeviceToDevice, st));
     }
     NRF_HIP(hipStreamSynchronize(st));
     if (m->family == MLP_SMALL) { if (m->small.use_pred_normal) return NRF_OK; NRF_TRY(mlp_small_pack_f16(m, hp)); return mlp_small_pack_sigma_f32(m, hp); }

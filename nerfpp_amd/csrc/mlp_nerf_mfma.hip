@@ -345,6 +345,7 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     // views_linears_0 o feature_linear: merged[r][k] = sum_f W_v[r][f] F[f][k], merged_b[r] = sum_f W_v[r][f] b_f[f] + b_v[r]   (double accumulation)
     std::vector<float> merged, merged_b;
     nerf_merged_views_host(hp.data() + w_off[VIEWS], V + W, hp.data() + w_off[FEAT], hp.data() + b_off[FEAT], hp.data() + b_off[VIEWS], W / 2, W, merged, merged_b);
+    m->host_merged = merged; m->host_merged_b = merged_b;          // for mlp_nerf_pack_sigma_f32 of the same upload
     // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel-layer L (-> 0 if padding)
     auto wval = [&](int L, int row, int kstep, int h, int j) -> float {
         const int ksn = NerfNet::ks_nat(L), ksc = NerfNet::ks_ch(L);

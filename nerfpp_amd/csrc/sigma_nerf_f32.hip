@@ -393,23 +393,38 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     img.reserve((size_t)TOTAL_GROUPS * 256 + BIAS_FLOATS + ALPHA_FLOATS + VIEW_BIAS_FLOATS);
     std::vector<float> bias((size_t)BIAS_FLOATS, 0.0f);
     size_t off = 0;
+    // the fp32 fragments of the eight pts_linears, written by index on up to 8 host threads (a training loop re-packs every step): unit = (layer, row tile)
+    size_t layer_at[NL + 1], layer_off[NL];
+    layer_at[0] = 0;
     for (int l = 0; l < NL; l++) {
         const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
-        const float *w = hp.data() + off, *b = w + (size_t)in * 256;
-        // padded k -> column of W: layer 0: k < 63; layer 5: [input 0..62 | pad | h 0..255] -> columns [0..62 | - | 63..318]
-        auto col = [&](int k) { return l == 0 ? (k < 63 ? k : -1) : l == 5 ? (k < 63 ? k : k == 63 ? -1 : k - 1) : k; };
-        for (int mt = 0; mt < 8; mt++)
+        layer_off[l] = off; off += (size_t)in * 256 + 256;
+        layer_at[l + 1] = layer_at[l] + (size_t)8 * groups(l) * 256;
+    }
+    img.resize(layer_at[NL]);
+    host_parallel_for(NL * 8, [&](int u0, int u1) {
+        for (int u = u0; u < u1; u++) {
+            const int l = u >> 3, mt = u & 7;
+            const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
+            const float *w = hp.data() + layer_off[l];
+            // padded k -> column of W: layer 0: k < 63; layer 5: [input 0..62 | pad | h 0..255] -> columns [0..62 | - | 63..318]
+            auto col = [&](int k) { return l == 0 ? (k < 63 ? k : -1) : l == 5 ? (k < 63 ? k : k == 63 ? -1 : k - 1) : k; };
+            float *dst = img.data() + layer_at[l] + (size_t)mt * groups(l) * 256;
             for (int g = 0; g < groups(l); g++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int j = 0; j < 4; j++) {
                         const int row = 32 * mt + row_neuron(lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
                         const int c = col(k);
-                        img.push_back(c >= 0 ? w[(size_t)row * in + c] : 0.0f);
+                        *dst++ = c >= 0 ? w[(size_t)row * in + c] : 0.0f;
                     }
+        }
+    });
+    for (int l = 0; l < NL; l++) {
+        const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
+        const float *b = hp.data() + layer_off[l] + (size_t)in * 256;
         for (int mt = 0; mt < 8; mt++)
             for (int h = 0; h < 2; h++)
                 for (int q = 0; q < 16; q++) bias[((size_t)(l * 8 + mt) * 2 + h) * 16 + q] = b[32 * mt + 2 * q + h];
-        off += (size_t)in * 256 + 256;
     }
     // blob order after pts_linears: views_linears_0 (w, b), feature_linear (w, b), alpha_linear (w, b), rgb_linear (w, b)
     const int V = d.input_ch_views;                                  // 27
@@ -422,7 +437,9 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     const float *wr = hp.data() + off, *br = wr + (size_t)128 * 3;
     // views_linears_0 o feature_linear (no activation between them, NeRF.cpp:112-115): merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r], in double
     std::vector<float> merged, merged_b;
-    nerf_merged_views_host(wv, V + 256, wf, bf, bv, 128, 256, merged, merged_b);
+    if (m->host_merged.size() == (size_t)128 * 256 && m->host_merged_b.size() == 128) { merged.swap(m->host_merged); merged_b.swap(m->host_merged_b); }          // the same upload's product (mlp_nerf_pack_f16)
+    else nerf_merged_views_host(wv, V + 256, wf, bf, bv, 128, 256, merged, merged_b);
+    m->host_merged.clear(); m->host_merged_b.clear();
     // (hi, lo) fp16 fragments of the colour branch: per k-step the hi fragment then the fragment of the rounding residuals
     std::vector<_Float16> himg;
     himg.reserve((size_t)(4 * VIEW_GROUPS + VIEW_LAST_GROUPS + RGB_GROUPS) * 512);
