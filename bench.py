@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--lanes", default="auto", choices=["auto", "1", "2", "3", "4"],
                     help="streams of the library's Chunk loop (nrf_set_render_lanes); auto: 1 against 2 measured before the warmup steps, the faster one is timed (NRF_RENDER_LANES pins it)")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
-    ap.add_argument("--kernel-stats", default="profiles/round5/r5F_single_lane_kernel_stats.csv",
+    ap.add_argument("--kernel-stats", default="profiles/round5/r5Y_single_lane_kernel_stats.csv",
                     help="named in roofline.kernel_stats: the committed rocprofv3 --kernel-trace --stats summary of the single-lane pass the roofline re-derives from")
     args = ap.parse_args()
 
