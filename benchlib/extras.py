@@ -144,6 +144,33 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
             out.append(lerf_measurement(scene, L, K, c2w, lp))
         except Exception as e:
             out.append(dict(workload="lerf_lego800_64+128", error=str(e)))
+    out.extend(dropin_measurements())
+    return out
+
+
+DROPIN_RUNS = (("frame_hash", ()), ("frame_classic", ()), ("frame_lerf", ()), ("train_hash", ()), ("train_hash", ("0", "0", "hipadam")), ("train_classic", ()), ("train_lerf", ()))
+
+
+def dropin_measurements(runs=DROPIN_RUNS, timeout=300):
+    """What a C++ host of the reference gets: include/nerfpp_torch.h's adapters behind the reference's own virtual Render() and inside the statements of NeRFExecutor::Train's
+    loop body (NeRFExecutor.h:862-995: zero_grad, Render on the ray batch, huber_loss, backward, Adam::step), timed on that host's clock by the prebuilt harness
+    oracle/_ref/adapter_check bench (oracle/ref/adapter_bench.cpp) -- a child process, after and outside every timed region of this file.  Same scenes as the Python-mirror
+    lines above (frame: 800x800, 64+128; steps: 16 384 rays for hash / LeRF, 4 096 for the classic model), so `dropin_*` sits next to its mirror twin."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    out = []
+    if not os.path.exists(exe):
+        return [dict(workload="dropin", error="oracle/_ref/adapter_check not built (needs /root/reference at build time)")]
+    for what, extra in runs:
+        name = "dropin_" + what + ("_" + extra[2] if len(extra) > 2 else "")
+        try:
+            r = subprocess.run([exe, "bench", what, *extra], capture_output=True, text=True, timeout=timeout)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            if "error" in rec:
+                raise RuntimeError(rec["error"])
+            ms = rec.get("ms_per_frame", rec.get("ms_per_step"))
+            out.append(dict(workload=name, precision="f16x3", value=rec["value"], unit=rec["unit"], ms_per_step=ms, host="C++ / LibTorch (adapter_check bench)", detail=rec))
+        except Exception as e:
+            out.append(dict(workload=name, error=str(e)[:200]))
     return out
 
 

@@ -87,6 +87,9 @@ def compact_also(rec):
         ms = rec["s_per_frame"] * 1e3
     q = rec.get("psnr_vs_oracle_db")
     oc = rec.get("oracle_check")
+    if wl.startswith("dropin_"):
+        # the C++ / LibTorch host's line (oracle/_ref/adapter_check bench): its mirror twin above carries precision and quality
+        return {k: v for k, v in {"workload": wl, "value": _r(rec.get("value")), "ms": _r(ms, 3)}.items() if v is not None}
     out = {"workload": wl, "precision": rec.get("precision") or ("f16x3" if "train" in wl else None), "value": _r(rec.get("value")), "ms": _r(ms, 3)}
     if rec.get("coarse_pass", "").startswith("whole network"):
         out["workload"] += "_coarse_full"
@@ -144,6 +147,11 @@ def compact_line(detail, stats_csv=None):
 
 def dumps_line(line):
     s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT and isinstance(line.get("also"), list):
+        # first the decorations of the secondary entries (their full records are in the side file): workload + ms only
+        line = dict(line, also=[{k: a[k] for k in ("workload", "ms", "error") if k in a} for a in line["also"]])
+        line["dropped_for_size"] = ["also: workload + ms only"]
+        s = json.dumps(line, separators=(",", ":"))
     if len(s) >= LINE_LIMIT:
         # never lose the headline to its decorations: drop the optional parts, largest first
         for k in ("also", "collective_check"):

@@ -36,6 +36,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <mutex>
@@ -69,6 +70,30 @@ inline void check(int status, const char *what)
 }
 
 inline void *current_stream() { return (void *)c10::hip::getCurrentHIPStream().stream(); }
+
+/// Where a drop-in call spends its time (adapter_check bench): off by default -- one branch per scope.  When on, a scope drains the current stream on entry and on
+/// exit, so that its wall time is its own host AND device work; the sum of the scopes is then an upper bound of the unsynchronised call.
+struct PhaseClock {
+	bool On = false;
+	std::map<std::string, double> Ms;
+	std::map<std::string, int64_t> Calls;
+	void reset() { Ms.clear(); Calls.clear(); }
+};
+inline PhaseClock &phase_clock() { static PhaseClock c; return c; }
+class PhaseScope {
+	const char *Name;
+	std::chrono::steady_clock::time_point T0;
+	bool Live;
+public:
+	explicit PhaseScope(const char *name) : Name(name), Live(phase_clock().On) { if (Live) { c10::hip::getCurrentHIPStream().synchronize(); T0 = std::chrono::steady_clock::now(); } }
+	~PhaseScope()
+	{
+		if (!Live) return;
+		c10::hip::getCurrentHIPStream().synchronize();
+		phase_clock().Ms[Name] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count();
+		phase_clock().Calls[Name] += 1;
+	}
+};
 
 /// The renderers that exist: an autograd node of HipNeRFRenderer::Render refers to its renderer by address and may outlive it (a graph kept past the renderer's
 /// destruction); its backward asks here first and fails loudly instead of dereferencing a dangling pointer.
@@ -247,6 +272,7 @@ public:
 	{
 		const uint64_t sig = ParamSignature();
 		if (Synced && sig == SyncedSignature) return;
+		PhaseScope ps("hash.sync_table");
 		auto emb = dev_f32(Table().to(torch::kCUDA));
 		check(nrf_hash_set_table(Handle, emb.data_ptr<float>(), 1, current_stream()), "nrf_hash_set_table");
 		if (!Synced && Mode == NRF_HASH_CU) { auto p = Primes.to(torch::kCPU, torch::kInt32).contiguous(); auto b = host_floats(Biases); check(nrf_hash_set_primes(Handle, p.data_ptr<int32_t>(), b.data()), "nrf_hash_set_primes"); }
@@ -382,6 +408,51 @@ public:
 		auto out = torch::empty({tiles.size(0), (int64_t)h, tiles.size(2), tiles.size(3)}, tiles.options());
 		check(nrf_allgather_tiles(Comm, tiles.data_ptr<float>(), (int)tiles.size(0), h, (int)tiles.size(2), (int)tiles.size(3), out.data_ptr<float>(), current_stream()), "nrf_allgather_tiles");
 		return out;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// HipAdam : torch::optim::Adam -- the executor's optimizer (NeRFExecutor.h:539: `torch::optim::Adam(grad_vars, AdamOptions(lr).eps(1e-15).betas({0.9, 0.99}))`) with
+// its step as ONE kernel per parameter (nrf_adam_step: 4 reads + 3 writes per element) instead of LibTorch's chain of elementwise passes over the 64 MiB table.
+// Same update rule, same per-parameter state objects (torch::optim::AdamParamState: step, exp_avg, exp_avg_sq), so torch::save / torch::load of the optimizer
+// (optimizer_checkpoint.pt, NeRFExecutor.h:1055-1070) interchange with the reference's.  Options the kernel does not implement (weight_decay, amsgrad), parameters off the
+// GPU or not fp32 take torch::optim::Adam::step for the whole call.
+// ---------------------------------------------------------------------------------------------------------------------
+class HipAdam : public torch::optim::Adam {
+public:
+	using torch::optim::Adam::Adam;
+	torch::Tensor step(LossClosure closure = nullptr) override
+	{
+		for (auto &group : param_groups_) {
+			auto &o = static_cast<torch::optim::AdamOptions &>(group.options());
+			bool plain = o.weight_decay() == 0 && !o.amsgrad();
+			for (auto &p : group.params()) if (p.grad().defined() && !(p.is_cuda() && p.scalar_type() == torch::kFloat32 && p.is_contiguous() && !p.grad().is_sparse())) plain = false;
+			if (!plain) return torch::optim::Adam::step(closure);
+		}
+		torch::NoGradGuard ng;
+		torch::Tensor loss;
+		if (closure != nullptr) { at::AutoGradMode enable_grad(true); loss = closure(); }
+		for (auto &group : param_groups_) {
+			auto &o = static_cast<torch::optim::AdamOptions &>(group.options());
+			for (auto &p : group.params()) {
+				if (!p.grad().defined()) continue;
+				auto it = state_.find(p.unsafeGetTensorImpl());
+				if (it == state_.end()) {
+					auto st = std::make_unique<torch::optim::AdamParamState>();
+					st->step(0);
+					st->exp_avg(torch::zeros_like(p, torch::MemoryFormat::Preserve));
+					st->exp_avg_sq(torch::zeros_like(p, torch::MemoryFormat::Preserve));
+					it = state_.emplace(p.unsafeGetTensorImpl(), std::move(st)).first;
+				}
+				auto &st = static_cast<torch::optim::AdamParamState &>(*it->second);
+				st.step(st.step() + 1);
+				auto g = p.grad().to(torch::kFloat32).contiguous();
+				check(nrf_adam_step(p.data_ptr<float>(), g.data_ptr<float>(), st.exp_avg().data_ptr<float>(), st.exp_avg_sq().data_ptr<float>(), p.numel(), (float)o.lr(),
+					(float)std::get<0>(o.betas()), (float)std::get<1>(o.betas()), (float)o.eps(), (int)st.step(), current_stream()), "nrf_adam_step");
+				p.unsafeGetTensorImpl()->bump_version();          // written behind ATen's back: the drop-in's SyncIfChanged watches the version counters
+			}
+		}
+		return loss;
 	}
 };
 
@@ -938,6 +1009,7 @@ class HipNeRFRenderer : public NeRFRenderer<TEmbedder, TEmbedDirs, TNeRF> {
 	bool HasSmall = false;
 	uint64_t MlpSignature = 0;    ///ATen version counters + storage addresses of the network's parameters at the last upload
 	uint64_t TrainCalls = 0;      ///training renders so far: every one draws afresh from the counter RNG, as the reference does from torch's global generator
+	torch::Tensor TrainWorkspace, HashTrainWorkspace;   ///the fused backward's operand slots + overflow word, the binned scatter's records (kept apart from the render workspace)
 
 	void *workspace(size_t bytes, torch::Device dev)
 	{
@@ -954,6 +1026,11 @@ public:
 	~HipNeRFRenderer() override { nrfpp::live_renderers().remove(this); nrf_renderer_destroy(Renderer); }
 
 	void SetPrecision(int precision) { Precision = precision; }
+	/// arithmetic of the training backward: -1 (default) follows the render precision -- the fused fp16 matrix-core chain unless the renderer is in NRF_PREC_F32;
+	/// 0: always the fp32 layer kernels (the reference-pinned parity path); 1: the fp16 chain whenever the network is of the fused kernel's family
+	int TrainBackwardArithmetic = -1;
+	int64_t F16BackwardOverflows = 0;                   ///steps whose fp16 chain reported a non-finite value and were redone in fp32
+	bool WantsF16Backward() const { return TrainBackwardArithmetic == 1 || (TrainBackwardArithmetic == -1 && Precision != NRF_PREC_F32); }
 	void SetSeed(uint64_t seed) { Seed = seed; }
 
 	/// (Re)read the network's parameters and rebuild the device-side images; call after construction, load or an optimizer step.
@@ -998,6 +1075,7 @@ public:
 		TORCH_CHECK(Renderer != nullptr, "HipNeRFRenderer: call SyncWeights(small | classic description) once after construction");
 		const uint64_t sig = MlpSignatureOf();
 		if (sig != MlpSignature) {
+			PhaseScope ps("mlp.sync_params");
 			torch::NoGradGuard ng;
 			torch::Tensor blob = BlobForGrad().to(torch::kFloat32).contiguous();
 			check(nrf_mlp_set_params(Mlp.m, blob.data_ptr<float>(), blob.is_cuda() ? 1 : 0, current_stream()), "nrf_mlp_set_params");
@@ -1023,6 +1101,7 @@ public:
 		static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx, torch::Tensor rays_, torch::Tensor table, torch::Tensor blob, int64_t self_i, int64_t rp_i,
 			double cone_value)          // < 0: thin rays
 		{
+			PhaseScope ps("train.forward");
 			torch::Tensor cone_angle; if (cone_value >= 0.0) cone_angle = torch::tensor((float)cone_value);
 			auto *self = reinterpret_cast<HipNeRFRenderer *>(self_i);
 			const NeRFRenderParams &rp = *reinterpret_cast<const NeRFRenderParams *>(rp_i);
@@ -1090,6 +1169,7 @@ public:
 	std::pair<torch::Tensor, torch::Tensor> TrainBackward(const TrainState &st, torch::Tensor rays, torch::Tensor raw, torch::Tensor z, torch::Tensor g_rgb_in,
 		std::vector<int64_t> table_sizes, int64_t blob_numel)
 	{
+		PhaseScope ps("train.backward");
 		const int64_t n = rays.size(0); const int stride = (int)rays.size(1), s = st.s;
 		const auto opt = rays.options();
 		auto g_table = torch::zeros(table_sizes, opt), g_blob = torch::zeros({blob_numel}, opt);
@@ -1142,20 +1222,67 @@ public:
 			}
 			const nrf_hash *h = this->EmbedFn->GetHandle();
 			const int in_ch = this->EmbedFn->GetOutputDims();
-			auto emb = torch::empty({n * s, (int64_t)in_ch}, opt);
+			using torch::indexing::Slice;
+			torch::Tensor dirs;                    // UseViewdirs: the direction encoding of each ray (repeated for its samples, NeRFRenderer.h:179-181)
+			if (stride == 11) dirs = this->EmbeddirsFn->forward(rays.index({Slice(), Slice(8, 11)}).contiguous()).first;
 			auto keep = torch::empty({n * s}, opt.dtype(torch::kUInt8));
-			check(nrf_hash_encode(h, pts.data_ptr<float>(), n * s, emb.data_ptr<float>(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
-			torch::Tensor x = emb;
-			if (stride == 11) {                    // UseViewdirs: the direction encoding of each ray, repeated for its samples (NeRFRenderer.h:179-181)
-				using torch::indexing::Slice;
-				torch::Tensor dirs = this->EmbeddirsFn->forward(rays.index({Slice(), Slice(8, 11)}).contiguous()).first;
-				x = torch::cat({emb, dirs.unsqueeze(1).expand({n, (int64_t)s, dirs.size(1)}).reshape({n * s, dirs.size(1)})}, 1).contiguous();
-			}
-			check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
 			auto g_x = torch::empty({n * s, (int64_t)in_ch}, opt);
-			const size_t wsb = nrf_mlp_backward_workspace_bytes(Mlp.m, n * s);
-			check(nrf_mlp_backward(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(), workspace(wsb, rays.device()), wsb,
-				current_stream()), "nrf_mlp_backward");
+			torch::Tensor emb;
+			auto fp32_input = [&]() -> torch::Tensor {              // x [p, in_ch + dirs] fp32 rows, as RunNetwork forms them (:175-184)
+				if (!emb.defined()) {
+					emb = torch::empty({n * s, (int64_t)in_ch}, opt);
+					check(nrf_hash_encode(h, pts.data_ptr<float>(), n * s, emb.data_ptr<float>(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode");
+					check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
+				}
+				if (!dirs.defined()) return emb;
+				return torch::cat({emb, dirs.unsqueeze(1).expand({n, (int64_t)s, dirs.size(1)}).reshape({n * s, dirs.size(1)})}, 1).contiguous();
+			};
+			// The gradient chain of the network.  With the renderer in a matrix-core precision: ONE fused matrix-core kernel (fp16 operands, fp32 accumulation, loss scale chosen on
+			// the device from max |g_raw|; mlp_small_bwd_mfma.hip) fed, where the grid is the CuHashEmbedder L16 F2 one, from the level-major fp16 features of the render fast
+			// path -- what nerfpp_amd/train.py's Trainer(mlp_backward="f16", hash_backward="binned") issues.  Its overflow word is read back (one host synchronisation per step,
+			// as a loss scaler costs): a step whose fp16 chain met a non-finite value is redone by the fp32 layer kernels below instead of being skipped.  With the renderer in
+			// NRF_PREC_F32 (the parity mode): the fp32 layer kernels, pinned to the reference's autograd (golden train_hash).
+			bool f16_done = false;
+			if (WantsF16Backward()) {
+				PhaseScope pf("bwd.f16_chain");
+				const size_t wsb = nrf_mlp_backward_f16_workspace_bytes(Mlp.m, n * s);
+				if (!TrainWorkspace.defined() || (size_t)TrainWorkspace.numel() < wsb) TrainWorkspace = torch::empty({(int64_t)wsb}, opt.dtype(torch::kUInt8));
+				int rc;
+				const bool lm = this->EmbedFn->Mode == NRF_HASH_CU && this->EmbedFn->NLevels == 16 && this->EmbedFn->NFeaturesPerLevel == 2 && dirs.defined() && dirs.size(1) == 16;
+				if (lm) {
+					auto feats = torch::empty({16, n * s, 2}, opt.dtype(torch::kFloat16));
+					check(nrf_hash_encode_lm_f16(h, pts.data_ptr<float>(), n * s, feats.data_ptr(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16");
+					check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
+					auto dirs16 = dirs.to(torch::kFloat16).contiguous();
+					rc = nrf_mlp_backward_f16_lm(Mlp.m, feats.data_ptr(), dirs16.data_ptr(), s, g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(),
+						TrainWorkspace.data_ptr(), wsb, current_stream());
+				} else {
+					torch::Tensor x = fp32_input();
+					rc = nrf_mlp_backward_f16(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(), TrainWorkspace.data_ptr(), wsb,
+						current_stream());
+				}
+				if (rc == NRF_OK) {
+					uint32_t fl[2] = {0, 0};
+					check(nrf_mlp_backward_f16_flags(TrainWorkspace.data_ptr(), fl, current_stream()), "nrf_mlp_backward_f16_flags");
+					f16_done = !(fl[0] || fl[1]);
+					if (!f16_done) { F16BackwardOverflows++; g_blob.zero_(); }
+				} else if (rc != NRF_ERR_UNSUPPORTED) check(rc, "nrf_mlp_backward_f16");          // a network outside the fused kernel's family: the fp32 layer kernels
+			}
+			if (!f16_done) {
+				PhaseScope pf("bwd.f32_chain");
+				torch::Tensor x = fp32_input();
+				const size_t wsb = nrf_mlp_backward_workspace_bytes(Mlp.m, n * s);
+				check(nrf_mlp_backward(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(), workspace(wsb, rays.device()), wsb,
+					current_stream()), "nrf_mlp_backward");
+			}
+			PhaseScope ph("bwd.hash_scatter");
+			if (f16_done && this->EmbedFn->NFeaturesPerLevel == 2 && this->EmbedFn->Log2HashmapSize <= 19) {
+				// contributions merged per table range in LDS before they reach memory (equals the packed-atomic path bit for bit; resolution 2^-30 of a level's bound)
+				const size_t hwb = nrf_hash_backward_binned_workspace_bytes_for(h, n, s);
+				if (!HashTrainWorkspace.defined() || (size_t)HashTrainWorkspace.numel() < hwb) HashTrainWorkspace = torch::empty({(int64_t)hwb}, opt.dtype(torch::kUInt8));
+				check(nrf_hash_backward_rays_binned(h, pts.data_ptr<float>(), n, s, g_x.data_ptr<float>(), g_table.data_ptr<float>(), HashTrainWorkspace.data_ptr(), hwb, current_stream()),
+					"nrf_hash_backward_rays_binned");
+			} else
 			check(nrf_hash_backward_rays(h, pts.data_ptr<float>(), n, s, g_x.data_ptr<float>(), g_table.data_ptr<float>(), current_stream()), "nrf_hash_backward_rays");
 		}
 		return {g_table, g_blob};

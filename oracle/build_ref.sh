@@ -67,15 +67,21 @@ echo "built $out/ref_driver"
 # reference CPU renderer.  Links the repo's own libnerfpp_hip.so (rpath relative to the binary) and LibTorch's HIP backend.
 hiplib="$here/../nerfpp_amd/lib/libnerfpp_hip.so"
 if [ -f "$hiplib" ]; then
-  if stale "$out/obj/adapter_check.o" "$here/ref/adapter_check.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_check.o" ] || [ "$here/../include/nerfpp_hip.h" -nt "$out/obj/adapter_check.o" ]; then
-    $CXX $FLAGS $INC -c "$here/ref/adapter_check.cpp" -o "$out/obj/adapter_check.o"
-  fi
+  # adapter_check.cpp (the checks) and adapter_bench.cpp (`adapter_check bench ...`: the drop-in on the host's clock) share adapter_util.h; compiled side by side
+  for unit in adapter_check adapter_bench; do
+    if stale "$out/obj/$unit.o" "$here/ref/$unit.cpp" || [ "$here/ref/adapter_util.h" -nt "$out/obj/$unit.o" ] || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/$unit.o" ] || [ "$here/../include/nerfpp_hip.h" -nt "$out/obj/$unit.o" ]; then
+      rm -f "$out/obj/$unit.o"
+      $CXX $FLAGS $INC -I"$here/ref" -c "$here/ref/$unit.cpp" -o "$out/obj/$unit.o" &
+    fi
+  done
+  wait
+  for unit in adapter_check adapter_bench; do [ -f "$out/obj/$unit.o" ] || { echo "build_ref.sh: $unit.cpp did not compile" >&2; exit 1; }; done
   # the LeRFRenderer subclass: compile-only (its base class's unit needs the external RuCLIP module; see the file's header)
   if stale "$out/obj/adapter_lerf_compile.o" "$here/ref/adapter_lerf_compile.cpp" || [ "$here/../include/nerfpp_torch.h" -nt "$out/obj/adapter_lerf_compile.o" ] || [ "$here/../include/nerfpp_hip.h" -nt "$out/obj/adapter_lerf_compile.o" ]; then
     $CXX $FLAGS $INC -c "$here/ref/adapter_lerf_compile.cpp" -o "$out/obj/adapter_lerf_compile.o"
     echo "compiled HipLeRFRenderer : LeRFRenderer against the reference header (not linkable without RuCLIP)"
   fi
-  $CXX -o "$out/adapter_check" "$out/obj/adapter_check.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" "$out/obj/LeRF.o" $LIBS \
+  $CXX -o "$out/adapter_check" "$out/obj/adapter_check.o" "$out/obj/adapter_bench.o" "$out/obj/NeRF.o" "$out/obj/CustomOps.o" "$out/obj/LeRF.o" $LIBS \
       -Wl,--no-as-needed -ltorch_hip -lc10_hip -Wl,--as-needed -L"$here/../nerfpp_amd/lib" -lnerfpp_hip \
       -Wl,-rpath,'$ORIGIN/../../nerfpp_amd/lib' -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64
   echo "built $out/adapter_check"

@@ -13,9 +13,7 @@
 // (GetOutputDims / forward) of the hash and SH encoders against the reference modules.
 //
 // usage: adapter_check [h w]      prints one JSON line, exit code 0 iff every check passed
-#define NRFPP_WITH_REFERENCE
-#include "nerfpp_torch.h"
-#include "nrf_synth.h"
+#include "adapter_util.h"
 #include "LeRF.h"
 #include "LeRFRenderer.h"       // RenderCLIPEmbedding (inline, LeRFRenderer.h:45-54); the LeRFRenderer class itself is never instantiated here (its unit needs RuCLIP)
 
@@ -24,41 +22,7 @@
 #include <sstream>
 #include <unistd.h>
 
-using torch::indexing::Slice;
-using torch::indexing::None;
-using ClassicModel = NeRF;                 // (inside a NeRFRenderer subclass the name NeRF is the base's data member)
-using ClassicRendererBase = NeRFRenderer<Embedder, Embedder, ClassicModel>;
-
-static void fill_synth(torch::Tensor p, uint32_t seed, float amp)
-{
-	torch::NoGradGuard ng;
-	auto flat = torch::empty({p.numel()}, torch::kFloat32);
-	float *d = flat.data_ptr<float>();
-	for (int64_t i = 0; i < p.numel(); i++) d[i] = nrf_synth_sym(seed, (uint32_t)i, amp);
-	p.copy_(flat.view(p.sizes()));
-}
-
-static torch::Tensor lego_K(int h, int w)
-{
-	float focal = 0.5f * w / std::tan(0.5f * 0.6911112f);
-	float kdata[] = {focal, 0, 0.5f * w, 0, focal, 0.5f * h, 0, 0, 1};
-	return torch::from_blob(kdata, {3, 3}).clone();
-}
-
-static torch::Tensor orbit_pose(float theta_deg, float phi_deg, float radius)
-{
-	const float PI_ = std::acos(-1.0f);
-	float th = theta_deg / 180.f * PI_, ph = phi_deg / 180.f * PI_;
-	float t_[] = {1,0,0,0, 0,1,0,0, 0,0,1,radius, 0,0,0,1};
-	float rp[] = {1,0,0,0, 0,std::cos(ph),-std::sin(ph),0, 0,std::sin(ph),std::cos(ph),0, 0,0,0,1};
-	float rt[] = {std::cos(th),0,-std::sin(th),0, 0,1,0,0, std::sin(th),0,std::cos(th),0, 0,0,0,1};
-	float fl[] = {-1,0,0,0, 0,0,1,0, 0,1,0,0, 0,0,0,1};
-	auto c2w = torch::from_blob(t_, {4,4}).clone();
-	c2w = torch::matmul(torch::from_blob(rp, {4,4}).clone(), c2w);
-	c2w = torch::matmul(torch::from_blob(rt, {4,4}).clone(), c2w);
-	c2w = torch::matmul(torch::from_blob(fl, {4,4}).clone(), c2w);
-	return c2w.index({Slice(None, 3), Slice(None, 4)}).contiguous();
-}
+int run_bench(int argc, const char **argv);          // adapter_bench.cpp
 
 static void stage(const char *what) { if (getenv("NRF_ADAPTER_TRACE")) { fprintf(stderr, "[adapter_check] %s\n", what); fflush(stderr); } }
 
@@ -68,24 +32,6 @@ static void stage(const char *what) { if (getenv("NRF_ADAPTER_TRACE")) { fprintf
 // own parameters (NeRFExecutor.h:508-539).  Inputs (golden group train_hash: rays, target, initial parameters) are read from raw fp32 files in <dir>; the loss, the
 // rendered pixels, the step-1 gradients and the parameters after each of two steps are written back there, and tests/test_gpu_parity.py compares them with what the
 // reference's own CPU autograd produced (tests/golden/train_hash.npz).
-static torch::Tensor read_f32(const std::string &path, std::vector<int64_t> shape)
-{
-	int64_t n = 1; for (auto v : shape) n *= v;
-	auto t = torch::empty({n}, torch::kFloat32);
-	FILE *f = fopen(path.c_str(), "rb");
-	if (!f || fread(t.data_ptr<float>(), 4, (size_t)n, f) != (size_t)n) throw std::runtime_error("cannot read " + path);
-	fclose(f);
-	return t.view(shape);
-}
-
-static void write_f32(const std::string &path, torch::Tensor t)
-{
-	auto c = t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-	FILE *f = fopen(path.c_str(), "wb");
-	if (!f || fwrite(c.data_ptr<float>(), 4, (size_t)c.numel(), f) != (size_t)c.numel()) throw std::runtime_error("cannot write " + path);
-	fclose(f);
-}
-
 static int run_train(const std::string &dir)
 {
 	if (!torch::cuda::is_available()) { printf("{\"train_ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
@@ -427,10 +373,11 @@ static int run_trainfuzz(int cases, uint64_t seed)
 	if (!torch::cuda::is_available()) { printf("no GPU\n"); return 2; }
 	uint64_t st = seed * 0x9E3779B97F4A7C15ull + 777;
 	auto rnd = [&](int lo, int hi) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return lo + (int)(st % (uint64_t)(hi - lo + 1)); };
-	int bad = 0;
+	int bad = 0, f16_checked = 0;
 	const int svals[] = {8, 17, 32}, nvals[] = {5, 16, 32}, lvals[] = {2, 4, 8};
 	for (int c = 0; c < cases; c++) {
-		const int n = rnd(1, 200), s = svals[rnd(0, 2)], ni = nvals[rnd(0, 2)], L = lvals[rnd(0, 2)], T = rnd(10, 13), nlc = rnd(2, 4);
+		int n = rnd(1, 200), s = svals[rnd(0, 2)], ni = nvals[rnd(0, 2)], L = lvals[rnd(0, 2)], T = rnd(10, 13), nlc = rnd(2, 4);
+		if (c % 2 == 1) { L = 16; nlc = std::max(nlc, 3); }          // every other case is of the fused fp16 backward's family (in 32, 3-4 colour layers): it is checked below
 		std::string msg;
 		try {
 			torch::manual_seed(1000 + c);
@@ -492,6 +439,30 @@ static int run_trainfuzz(int cases, uint64_t seed)
 				for (size_t i = 0; i < pr.size(); i++) cmp(pr[i].key(), pr[i].value().grad(), ph[i].value().grad());
 				auto mr = m->named_parameters(); auto mh = hm->named_parameters();
 				for (size_t i = 0; i < mr.size(); i++) cmp(mr[i].key(), mr[i].value().grad(), mh[i].value().grad());
+			}
+			// the same step with the backward the drop-in takes when the renderer is in a matrix-core precision: the fused fp16 chain + the binned scatter
+			// (HipNeRFRenderer::WantsF16Backward); its gradients against the fp32 layer kernels' (which the block above holds to the reference's autograd)
+			if (L == 16 && nlc >= 3) {
+				std::vector<torch::Tensor> g32;
+				for (auto &p : he->parameters()) { g32.push_back(p.grad().clone()); p.mutable_grad() = torch::Tensor(); }
+				for (auto &p : hm->parameters()) { g32.push_back(p.grad().clone()); p.mutable_grad() = torch::Tensor(); }
+				hip.TrainBackwardArithmetic = 1;                  // same NRF_PREC_F32 forward (same sample set), the fp16 chain behind it
+				auto r16 = hip.Render(0, 0, torch::Tensor(), rpg, {o.cuda(), d.cuda(), torch::Tensor()}, torch::Tensor(), torch::Tensor());
+				torch::nn::functional::huber_loss(r16.Outputs.RGBMap, target.cuda()).backward();
+				size_t gi = 0;
+				double gt_err = 0.0, gt_ref = 0.0;
+				auto cmp16 = [&](const std::string &name, torch::Tensor g, bool table) {
+					auto a = g.to(torch::kFloat64), b = g32[gi++].to(torch::kFloat64);
+					if (!torch::isfinite(a).all().item<bool>()) { msg += " f16 chain " + name + ": non-finite;"; return; }
+					const double nb = b.norm().item<double>(), err = (a - b).norm().item<double>();
+					if (table) { gt_err += err * err; gt_ref += nb * nb; return; }                 // the grid: judged over all levels (a level that few points touch is all rounding)
+					if (err > 3e-2 * nb + 1e-9) { char t[160]; snprintf(t, sizeof t, " f16 chain %s: |dg| %.3e of |g| %.3e;", name.c_str(), err, nb); msg += t; }
+				};
+				for (auto &p : he->named_parameters()) cmp16(p.key(), p.value().grad(), true);
+				for (auto &p : hm->named_parameters()) cmp16(p.key(), p.value().grad(), false);
+				if (std::sqrt(gt_err) > 3e-2 * std::sqrt(gt_ref) + 1e-9) { char t[160]; snprintf(t, sizeof t, " f16 chain table: |dg| %.3e of |g| %.3e;", std::sqrt(gt_err), std::sqrt(gt_ref)); msg += t; }
+				if (hip.F16BackwardOverflows != 0) msg += " f16 chain overflowed on a benign batch;";
+				f16_checked++;
 			}
 		} catch (const std::exception &ex) { msg += std::string(" EXCEPTION ") + std::string(ex.what()).substr(0, 240); }
 		bad += !msg.empty();
@@ -558,6 +529,7 @@ static int run_trainfuzz(int cases, uint64_t seed)
 		printf("classic case %d: n %d s %d+%d depth %d width %d skip %d:%s\n", c, n, s, ni, depth, width, skip, msg.empty() ? " ok" : msg.c_str());
 		fflush(stdout);
 	}
+	printf("fused fp16 backward checked against the fp32 layer kernels in %d case(s)\n", f16_checked);
 	printf("%s %d\n", bad ? "FAILED" : "all ok", bad);
 	return bad ? 1 : 0;
 }
@@ -565,6 +537,7 @@ static int run_trainfuzz(int cases, uint64_t seed)
 
 int main(int argc, const char **argv)
 {
+	if (argc > 1 && std::string(argv[1]) == "bench") return run_bench(argc - 2, argv + 2);
 	if (argc > 2 && std::string(argv[1]) == "trainfuzz") return run_trainfuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "fuzz") return run_fuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "train") return run_train(argv[2]);

@@ -3117,6 +3117,60 @@ def test_drop_in_training_render_vs_reference_cpu_autograd_random_models():
     out = subprocess.run([exe, "trainfuzz", "4", "5"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2500:] + out.stderr[-1000:]
     assert out.stdout.count("classic case") == 3 and out.stdout.count(": ok") >= 7, out.stdout[-2500:]
+    # round 6: every other case is of the fused fp16 backward's family -- the chain the drop-in takes when its renderer is in a matrix-core precision is held to the fp32 layer
+    # kernels' gradients (3 % norm-wise per network tensor and over the grid), which the lines above hold to the reference's autograd
+    assert "fused fp16 backward checked against the fp32 layer kernels in 2 case(s)" in out.stdout, out.stdout[-2500:]
+
+
+def test_drop_in_frame_on_the_cpp_hosts_clock_equals_the_python_mirror_bit_for_bit(api, tmp_path):
+    """oracle/_ref/adapter_check `bench frame_hash`: HipNeRFRenderer::Render(800, 800, K, params, c2w) called through the reference's NeRFRenderer<>* virtual on bench.py's own
+    scene (same closed-form weights, include/nrf_synth.h) -- the dumped frame equals the Python mirror's frame of the same pose BIT FOR BIT (both hosts issue the same library
+    call), and the line carries the host-clock ms per frame for 1 and 2 lanes."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    scene, L = api.S, api.L
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, "bench", "frame_hash", "2", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["what"] == "dropin_frame" and rec["family"] == "hash" and set(rec["ms_per_frame_by_lanes"]) == {"1", "2"} and 0 < rec["ms_per_frame"] < 500, rec
+    assert abs(rec["value"] - 640000 * 256 / (rec["ms_per_frame"] * 1e-3)) < 1e-3 * rec["value"]
+    got = np.fromfile(str(tmp_path / "dropin_frame_hash_rgb.f32"), np.float32).reshape(800, 800, 3)
+    sc = scene.make_hash_scene(mode="cu")
+    rp = scene.lego_render_params(sc["bbox"], 64, 128, 65536, L.NRF_PREC_F16_SPLIT)
+    res = sc["renderer"].Render(800, 800, scene.lego_K(800, 800), rp, c2w=scene.pose_spherical(-180.0, -30.0, 4.0))
+    want = res.Outputs.RGBMap.reshape(800, 800, 3).cpu().numpy()
+    assert np.isfinite(got).all() and got.std() > 0.01
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+def test_drop_in_train_step_bench_takes_the_fused_backward_and_learns():
+    """oracle/_ref/adapter_check `bench train_hash`: the statements of NeRFExecutor::Train's loop body (NeRFExecutor.h:862-995) on the drop-in, timed on the host's clock, with
+    torch::optim::Adam (the reference's) and with nrfpp::HipAdam: the step runs the fused fp16 chain + the binned scatter (the phases say so), the loss falls, and both optimizers
+    follow the same trajectory (same update rule)."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    recs = {}
+    for opt in ("adam", "hipadam"):
+        out = subprocess.run([exe, "bench", "train_hash", "6", "4096", opt], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert rec["what"] == "dropin_train_step" and rec["optimizer"] == opt and rec["rays_per_step"] == 4096 and 0 < rec["ms_per_step"] < 500, rec
+        ph = rec["synchronised_phase_ms"]
+        assert "bwd.f16_chain" in ph and "bwd.hash_scatter" in ph and "bwd.f32_chain" not in ph, ph
+        assert set(rec["host_ms_per_statement"]) == {"zero_grad", "render", "loss", "backward", "optimizer_step"}
+        l0, l1 = rec["loss_first_last"]
+        assert np.isfinite(l1) and l1 < 0.8 * l0, rec["loss_first_last"]
+        recs[opt] = rec
+    # identical first loss (same scene, same batch); the settling phase runs a clock-dependent number of steps, so the last losses are only both lower
+    assert recs["adam"]["loss_first_last"][0] == recs["hipadam"]["loss_first_last"][0]
 
 
 def test_reference_lerf_train_loop_body_runs_through_the_hip_drop_in():

@@ -314,6 +314,10 @@ def _canned_bench_detail(world):
             dict(workload="lerf_lego800_64+128", precision="f16", value=1.58e9, s_per_frame=0.1038, roofline=dict(frac=0.4867),
                  oracle_check=dict(embedding_cos_min=0.99174, fine_sample_set_bit_identical_rays=0.0)),
             dict(workload="lerf_lego800_64+128", error=long_text)]
+    # the C++ / LibTorch host's own lines (benchlib/extras.py::dropin_measurements: oracle/_ref/adapter_check bench)
+    also += [dict(workload="dropin_" + w, precision="f16x3", value=v, unit="ray-samples/s", ms_per_step=ms, host="C++ / LibTorch (adapter_check bench)", detail=dict(note=long_text))
+             for w, v, ms in (("frame_hash", 7.5e9, 21.83), ("frame_classic", 3.2e8, 508.4), ("frame_lerf", 1.24e9, 132.0), ("train_hash", 6.8e8, 6.14),
+                              ("train_hash_hipadam", 7.2e8, 5.81), ("train_classic", 2.05e7, 51.0), ("train_lerf", 7.3e7, 57.1))]
     if world > 1:
         also = [dict(scaling="weak", frames_per_step=world, steps=5, ms_per_step=23.0, value=7.1e9 * world, unit="ray-samples/s", host_ms_per_tile=0.4, finite=True)]
     return {"metric": "ray-samples/sec (HIP volume-rendering path, Lego 800x800, N_samples=64+128)", "value": 7302017868.09 * world, "unit": "ray-samples/s",
@@ -368,7 +372,9 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
         # the gathered bytes are priced against the cache-resident gather ceiling
         assert r["hash"]["unit"] == "GB/s" and r["hash"].get("frac", 0.0) < 1.0 and 0.5 < r["hash"]["gather_frac_of_cache_ceiling"] < 1.5 and r["sigma"]["frac"] < 1.0
         assert abs(r["kernel_sum_ms_per_step"] - 24.05) < 0.01
-        assert len(line["also"]) == 9 and all(len(json.dumps(a)) <= 140 for a in line["also"])
+        assert len(line["also"]) == 16 and all(len(json.dumps(a)) <= 140 for a in line["also"])
+        assert [a["workload"] for a in line["also"]][9:] == ["dropin_frame_hash", "dropin_frame_classic", "dropin_frame_lerf", "dropin_train_hash", "dropin_train_hash_hipadam",
+                                                             "dropin_train_classic", "dropin_train_lerf"] and line["also"][9]["ms"] == 21.83
         assert [a["workload"] for a in line["also"]][:5] == ["hashnerf", "classic_nerf", "classic_nerf_coarse_full", "classic_nerf", "hashnerf_libtorch_twin"]
     else:
         assert r["lanes"] == 2 and line["ranks_seen_by_rccl"] == world and len(line["collective_check"]) <= 100 and line["also"][0]["workload"] == "scaling_weak"
@@ -380,7 +386,11 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
     detail["also"] = [dict(workload="w%d" % i, precision="f16x3", value=1.0, ms_per_step=1.0, psnr_vs_oracle_db=dict(psnr=100.0), roofline=dict(frac=0.5)) for i in range(80)]
     s2 = report.dumps_line(report.compact_line(detail))
     l2 = json.loads(s2)
-    assert len(s2) < 4096 and "also" not in l2 and l2["dropped_for_size"] == ["also"] and l2["value"] == line["value"] and "cpu_baseline" in l2
+    assert len(s2) < 4096 and "also" not in l2 and l2["dropped_for_size"] == ["also: workload + ms only", "also"] and l2["value"] == line["value"] and "cpu_baseline" in l2
+    # ... and a moderately oversized one keeps its entries, shortened
+    detail["also"] = [dict(workload="w%d" % i, precision="f16x3", value=123456789.0, ms_per_step=1.0, psnr_vs_oracle_db=dict(psnr=100.0), roofline=dict(frac=0.5)) for i in range(38)]
+    l3 = json.loads(report.dumps_line(report.compact_line(detail)))
+    assert len(l3["also"]) == 38 and set(l3["also"][0]) == {"workload", "ms"} and l3["dropped_for_size"] == ["also: workload + ms only"]
 
 
 def test_timed_region_refuses_to_run_with_the_per_kernel_event_bracketing_on():
