@@ -55,6 +55,10 @@ def main():
                          "its communicator cannot be created) or torch.distributed (RCCL through PyTorch; the only one with --backend gloo)")
     ap.add_argument("--lanes", default="auto", choices=["auto", "1", "2", "3", "4"],
                     help="streams of the library's Chunk loop (nrf_set_render_lanes); auto: 1 against 2 measured before the warmup steps, the faster one is timed (NRF_RENDER_LANES pins it)")
+    ap.add_argument("--overflow-policy", default="deferred", choices=["auto", "deferred", "ignore"],
+                    help="nrf_render_params.overflow_policy of the timed frames: deferred (default) keeps the frame calls asynchronous -- the chunks' non-finite words are read by the "
+                         "next call and, after the timed region, by nrf_renderer_nonfinite (reported as nonfinite_chunks); auto = one host read-back at the end of every frame call "
+                         "(+ an NRF_PREC_F32 re-render of flagged chunks), what a host that renders single frames gets by default")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
     ap.add_argument("--kernel-stats", default="profiles/round5/r5Y_single_lane_kernel_stats.csv",
                     help="named in roofline.kernel_stats: the committed rocprofv3 --kernel-trace --stats summary of the single-lane pass the roofline re-derives from")
@@ -113,6 +117,7 @@ def main():
         chunk = args.chunk or 8192
     renderer = sc["renderer"]
     rp = scene.lego_render_params(sc["bbox"], NS, NI, chunk, prec)
+    rp.OverflowPolicy = {"auto": L.NRF_OVERFLOW_AUTO, "deferred": L.NRF_OVERFLOW_DEFERRED, "ignore": L.NRF_OVERFLOW_IGNORE}[args.overflow_policy]
     K = scene.lego_K(H, W)
     shard = TileShard(H, W, rank, world, force_collective=args.force_dist)
     from benchlib.steps import FrameStepper
@@ -359,6 +364,11 @@ def main():
             except Exception as e:
                 detail["parity_full_frame_vs_f32"] = f"unavailable: {e}"
         assert frames.shape[0] == nframes and bool(torch.isfinite(frames).all())
+        # the non-finite words of every chunk rendered by this process (matrix-core precisions; include/nerfpp_hip.h, nrf_render_params.overflow_policy)
+        nf_flagged, nf_rerendered = renderer.nonfinite()
+        detail["overflow_policy"] = args.overflow_policy
+        detail["nonfinite_chunks"] = dict(flagged=nf_flagged, rerendered_in_f32=nf_rerendered)
+        assert nf_flagged == 0, "a timed frame produced non-finite network outputs"
         # the gathered frame of the first pose, hashed: equal strings at different N (or launchers) = the sharded render is the single-GPU render bit for bit
         import hashlib
         detail["frame_sha256"] = hashlib.sha256(frames[0].reshape(H, W, 3).contiguous().cpu().numpy().tobytes()).hexdigest()

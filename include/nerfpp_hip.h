@@ -37,7 +37,8 @@ enum {
     NRF_ERR_INVALID_ARG = 1,
     NRF_ERR_HIP = 2,          /* a HIP runtime call / kernel launch failed (no device, OOM, ...) */
     NRF_ERR_UNSUPPORTED = 3,  /* valid in the reference, not built here (message says what) */
-    NRF_ERR_WORKSPACE = 4     /* caller's workspace too small */
+    NRF_ERR_WORKSPACE = 4,    /* caller's workspace too small */
+    NRF_ERR_NONFINITE = 5     /* a matrix-core render produced inf / NaN network outputs (an fp16 operand left its range): see nrf_render_params.overflow_policy */
 };
 
 NRF_API int nrf_version(void);
@@ -420,7 +421,20 @@ typedef struct nrf_render_params {
     uint64_t seed;
     int64_t ray_base;         /* index of d_rays[0] within the whole image / ray batch */
     int coarse_mode;          /* NRF_COARSE_*: how the coarse pass is evaluated when n_importance > 0 (it only supplies SamplePDF's weights) */
+    int overflow_policy;      /* NRF_OVERFLOW_*: what happens when a matrix-core precision's network outputs are not finite (below) */
 } nrf_render_params;
+
+/* The matrix-core precisions carry operands in fp16 (NRF_PREC_F16_MFMA) or as fp16 (hi, lo) pairs (NRF_PREC_F16_SPLIT): an activation beyond 65 504 becomes an inf there.
+ * NeRFSmall's split image is range-scaled against that (nrf_mlp_set_input_rms_hint); whatever still overflows -- or any other family's network -- shows as inf / NaN network
+ * outputs, which the final compositing kernel of every chunk records in a per-chunk word of the renderer (4 FMAs per sample).  What the render entries do with it:
+ *   NRF_OVERFLOW_AUTO / _RERENDER  after the Chunk loop the words are read back (ONE host synchronisation at the end of nrf_render_rays / nrf_batchify_rays /
+ *                                  nrf_render_rows) and every flagged chunk is rendered again in NRF_PREC_F32 into the same outputs: the call's results are finite-input
+ *                                  correct whatever the weights.  The default.
+ *   NRF_OVERFLOW_ERROR             same read-back; a flagged chunk makes the call return NRF_ERR_NONFINITE (outputs of that chunk are not to be used).
+ *   NRF_OVERFLOW_DEFERRED          no synchronisation: the words are copied to the host asynchronously and looked at by the NEXT render call on this renderer, which then
+ *                                  returns NRF_ERR_NONFINITE before doing anything (or by nrf_renderer_nonfinite).  For pipelines that keep several frames in flight.
+ *   NRF_OVERFLOW_IGNORE            no detection at all (the compositing kernel skips the test). */
+enum { NRF_OVERFLOW_AUTO = 0, NRF_OVERFLOW_RERENDER = 1, NRF_OVERFLOW_ERROR = 2, NRF_OVERFLOW_DEFERRED = 3, NRF_OVERFLOW_IGNORE = 4 };
 
 typedef struct nrf_render_outputs {   /* NeRFRendererOutputs / NeRFRenderResult (NeRFRenderer.h:12-26); NULL = not wanted */
     float *d_rgb;             /* [n,3] */
@@ -441,6 +455,9 @@ typedef struct nrf_renderer nrf_renderer;
 
 NRF_API int nrf_renderer_create(const nrf_renderer_desc *desc, nrf_renderer **out);
 NRF_API void nrf_renderer_destroy(nrf_renderer *r);
+/* Totals since the renderer was created: chunks whose matrix-core render produced non-finite network outputs, and how many of them were rendered again in NRF_PREC_F32
+ * (NRF_OVERFLOW_RERENDER).  Completes a pending NRF_OVERFLOW_DEFERRED check first (waits for that call's work).  Either pointer may be NULL. */
+NRF_API int nrf_renderer_nonfinite(const nrf_renderer *r, int64_t *flagged_chunks, int64_t *rerendered_chunks);
 
 /* RunNetwork (NeRFRenderer.h:164-194): pts [n,s,3], viewdirs [n,3] (or NULL) -> raw [n,s,4]
  * with sigma forced to 0 where the embedder's keep_mask is false (:187-188). */
@@ -522,6 +539,18 @@ NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
 /* Number of derived images nrf_mlp_set_params refreshes on the device for this handle (0: the host repack). */
 NRF_API int nrf_mlp_device_repack_images(const nrf_mlp *m);
+/* NRF_PREC_F16_SPLIT, NeRFSmall (bias-free: NeRF.cpp:322-412): range safety.  ReLU is positively homogeneous, so the split-precision operand image holds 2^e_l W_l per
+ * layer and the kernels take the product of the scales out of (rgb, sigma) again -- exact in fp32 -- while every fp16 (hi, lo) pair the matrix cores read (weights, and the
+ * activations between layers) has two NORMAL halves whatever the magnitude of the checkpoint's weights: a model trained with xavier gain 0.1 (|W| ~ 0.01), a sigma head
+ * scaled by 100, weights x 2^-8 or x 2^6 all render as accurately as weights near 1.  The exponents are chosen on the device from the blob itself at create time and at
+ * every nrf_mlp_set_params (per-layer RMS row norms -> an RMS model of the activations, target RMS 8; mlp.hip, k_small_scales), in stream order.
+ * nrf_mlp_set_input_rms_hint: the expected RMS of the position features (default 0.25; a renderer built on a hash grid sets it from the table).
+ * nrf_mlp_get_split_scales: the exponents in force as powers of two -- group_scales_out[12] (sigma-net layers, colour layer 0's direction columns / geo columns, colour
+ * layers 1..), kernel_scales_out[8] ([0] 2^-S_sigma, [1] 2^-S_colour, [2] 2^S_hidden); synchronises `stream`.  All 1 for other families and with NRF_SPLIT_UNSCALED=1. */
+NRF_API int nrf_mlp_set_input_rms_hint(nrf_mlp *m, float rms, void *stream);
+/* on = 0: the split images from the blob as it is (all exponents 0) -- the representation of rounds 4-5, kept as an A/B switch and for tests of the non-finite word */
+NRF_API int nrf_mlp_set_split_scaling(nrf_mlp *m, int on, void *stream);
+NRF_API int nrf_mlp_get_split_scales(const nrf_mlp *m, float *group_scales_out, float *kernel_scales_out, void *stream);
 
 /* Backward of the hash grid w.r.t. its table: d_g_emb [p, L*F] -> d_g_table, fp32 in the table's own layout, ACCUMULATED into.
  * NRF_HASH_NGP: nn::Embedding's index_add of the trilinear weights (NeRF.cpp:279-298).  NRF_HASH_CU: CuHashEmbedderBackwardKernel
@@ -631,6 +660,10 @@ typedef struct nrf_lerf_outputs {     /* LeRFRendererOutputs (LeRFRenderer.h:9-1
 typedef struct nrf_lerf_renderer nrf_lerf_renderer;
 NRF_API int nrf_lerf_renderer_create(const nrf_lerf_renderer_desc *desc, nrf_lerf_renderer **out);
 NRF_API void nrf_lerf_renderer_destroy(nrf_lerf_renderer *r);
+/* The LeRF pass and nrf_render_params.overflow_policy: the compositing kernel of the fine pass looks at every sigma_le and the final normalise at every rendered embedding;
+ * the pass has no fp32 single-call twin to render a flagged chunk again with, so AUTO / RERENDER / ERROR all end a call with one read-back and answer a non-finite value with
+ * NRF_ERR_NONFINITE; DEFERRED reports at the next call (or here); IGNORE does not look.  flagged_calls: total since the renderer was created. */
+NRF_API int nrf_lerf_renderer_nonfinite(const nrf_lerf_renderer *r, int64_t *flagged_calls);
 /* Lanes of this renderer's Chunk loop, 1-4.  Default ONE: the LeRF kernels gain nothing from sharing the CUs (measured: 1 lane 140-143 ms per 800x800 frame, 2 lanes 146-147). */
 NRF_API int nrf_lerf_renderer_set_lanes(nrf_lerf_renderer *r, int lanes);
 /* LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [n_pos, E] / [n_neg, E] fp32 phrase embeddings (host or device), copied; 0 / 0 clears them.  Synchronises `stream`. */

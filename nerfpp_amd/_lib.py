@@ -18,6 +18,8 @@ NRF_DIRS_NONE, NRF_DIRS_PE, NRF_DIRS_SH_LIBTORCH, NRF_DIRS_SH_CUDA = 0, 1, 2, 3
  NRF_RNG_NOISE_FINE) = range(1, 10)       # include/nrf_rng.h
 NRF_PROF_NAMES = ("hash", "mlp", "composite", "sample", "other", "sigma", "mlp_colour")
 NRF_COARSE_AUTO, NRF_COARSE_FULL, NRF_COARSE_SIGMA_F32 = 0, 1, 2
+NRF_OVERFLOW_AUTO, NRF_OVERFLOW_RERENDER, NRF_OVERFLOW_ERROR, NRF_OVERFLOW_DEFERRED, NRF_OVERFLOW_IGNORE = 0, 1, 2, 3, 4
+NRF_ERR_NONFINITE = 5
 
 
 class HashDesc(C.Structure):
@@ -44,7 +46,7 @@ class RenderParams(C.Structure):
     _fields_ = [("n_samples", C.c_int), ("n_importance", C.c_int), ("lindisp", C.c_int), ("white_bkgr", C.c_int),
                 ("precision", C.c_int), ("sum_vec", C.c_int),
                 ("perturb", C.c_float), ("has_cone", C.c_int), ("cone_angle", C.c_float), ("raw_noise_std", C.c_float), ("precond_alpha", C.c_float),
-                ("has_bbox", C.c_int), ("bbox", C.c_float * 6), ("seed", C.c_uint64), ("ray_base", C.c_int64), ("coarse_mode", C.c_int)]
+                ("has_bbox", C.c_int), ("bbox", C.c_float * 6), ("seed", C.c_uint64), ("ray_base", C.c_int64), ("coarse_mode", C.c_int), ("overflow_policy", C.c_int)]
 
 
 class RenderOutputs(C.Structure):
@@ -82,7 +84,7 @@ SYMBOLS = [
     "nrf_renderer_create", "nrf_renderer_destroy", "nrf_run_network_workspace_bytes", "nrf_run_network",
     "nrf_render_rays_workspace_bytes", "nrf_render_rays", "nrf_batchify_rays_workspace_bytes", "nrf_batchify_rays", "nrf_render_rows_workspace_bytes", "nrf_render_rows",
     "nrf_normalize_depth", "nrf_to_u8",
-    "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_hash_encode_lm_f16_strided", "nrf_lerf_sigma_lm", "nrf_lerf_sigma_lm_strided", "nrf_lerf_render_embedding_lm", "nrf_lerf_render_embedding_lm_gather", "nrf_lerf_geo_bytes", "nrf_lerf_sigma_geo_lm_strided", "nrf_lerf_sigma_exact_available", "nrf_lerf_sigma_exact_lm_strided", "nrf_lerf_render_embedding_lm_geo", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_hash_backward_binned_workspace_bytes", "nrf_hash_backward_binned_workspace_bytes_for", "nrf_hash_backward_rays_binned", "nrf_mlp_set_params", "nrf_mlp_device_repack_images",
+    "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_hash_encode_lm_f16_strided", "nrf_lerf_sigma_lm", "nrf_lerf_sigma_lm_strided", "nrf_lerf_render_embedding_lm", "nrf_lerf_render_embedding_lm_gather", "nrf_lerf_geo_bytes", "nrf_lerf_sigma_geo_lm_strided", "nrf_lerf_sigma_exact_available", "nrf_lerf_sigma_exact_lm_strided", "nrf_lerf_render_embedding_lm_geo", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_hash_backward_binned_workspace_bytes", "nrf_hash_backward_binned_workspace_bytes_for", "nrf_hash_backward_rays_binned", "nrf_mlp_set_params", "nrf_mlp_device_repack_images", "nrf_mlp_set_input_rms_hint", "nrf_mlp_set_split_scaling", "nrf_mlp_get_split_scales", "nrf_renderer_nonfinite", "nrf_lerf_renderer_nonfinite",
     "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_create_timeout", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles",

@@ -64,8 +64,12 @@ template <bool FAST>
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK)
 k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ dirs,
               int d_stride, float *__restrict__ rgb, float *__restrict__ disp, float *__restrict__ acc, float *__restrict__ weights,
-              float *__restrict__ depth, SigmaNoise nz, const int32_t *__restrict__ src, const float *__restrict__ raw2, int64_t n_split)
+              float *__restrict__ depth, SigmaNoise nz, const int32_t *__restrict__ src, const float *__restrict__ raw2, int64_t n_split, uint32_t *__restrict__ flag)
 {
+    // flag (optional): *flag |= 1 when any network output this launch reads is an inf or a NaN -- the sign that a split-precision / fp16 activation left the fp16 range
+    // further up (mlp_small_mfma.hip; an inf that meets a ReLU or a zero weight can vanish, one that reaches an output layer cannot).  Four FMAs per sample: x * 0 + t
+    // is t for every finite x and NaN otherwise (relu(sigma) below would swallow a NaN sigma silently: NaN > 0 is false).
+    float bad_acc = 0.0f;
     // src: sample i's network output is row src[i] -- of raw when src[i] < n_split, else row src[i] - n_split of raw2 (the renderer's fine passes keep the outputs of the
     // coarse depths and of the new samples where they were computed: a ray's samples are two contiguous runs of rows, merged by depth)
     const int lane = threadIdx.x & 63;
@@ -137,6 +141,10 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
                 if (vec) r4 = *reinterpret_cast<const float4 *>(r);
             }
             dist = dist * nrm;                                      // :241
+            if (flag) {
+                if (vec) { bad_acc = __builtin_fmaf(r4.x, 0.0f, bad_acc); bad_acc = __builtin_fmaf(r4.y, 0.0f, bad_acc); bad_acc = __builtin_fmaf(r4.z, 0.0f, bad_acc); bad_acc = __builtin_fmaf(r4.w, 0.0f, bad_acc); }
+                else { bad_acc = __builtin_fmaf(r[sigma_ch], 0.0f, bad_acc); if (rgb) { bad_acc = __builtin_fmaf(r[0], 0.0f, bad_acc); bad_acc = __builtin_fmaf(r[1], 0.0f, bad_acc); bad_acc = __builtin_fmaf(r[2], 0.0f, bad_acc); } }
+            }
             float sg = vec ? (sigma_ch == 3 ? r4.w : sigma_ch == 0 ? r4.x : sigma_ch == 1 ? r4.y : r4.z) : r[sigma_ch];
             if (nz.on)                                              // raw_noise_std > 0 (:251-252)
                 sg = sg + (nz.arr ? nz.arr[ray * s + j] : nrf_rng_normal(nz.g.seed, nz.stream, (uint64_t)((nz.g.ray_base + ray) * s + j))) * nz.std;
@@ -163,6 +171,7 @@ k_raw2outputs(int64_t n, int s, int c, int sigma_ch, int white, const float *__r
         }
     }
     sr = wave_sum_t<acc_t>(sr); sg = wave_sum_t<acc_t>(sg); sb = wave_sum_t<acc_t>(sb); sw = wave_sum_t<acc_t>(sw); swz = wave_sum_t<acc_t>(swz);
+    if (flag) { if (__any(bad_acc != bad_acc) && lane == 0) atomicOr(flag, 1u); }
     if (lane == 0) {
         const float a = (float)sw;
         const float dep = (float)swz / (a > 1e-10f ? a : 1e-10f);  // :272
@@ -351,8 +360,10 @@ k_fine_depths(int64_t n, int s, int ns, int sum_vec, const float *__restrict__ z
 
 // RenderCLIPEmbedding (LeRFRenderer.h:45-54): out = normalize(sum_s w_s * e_s, eps 1e-8).  One workgroup per ray; thread = embedding
 // channel(s); the sum over samples and the squared norm accumulate in double (order-free, same definition as the oracle).
-__global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int dim, const float *__restrict__ e, const float *__restrict__ w, float *__restrict__ out)
+__global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int dim, const float *__restrict__ e, const float *__restrict__ w, float *__restrict__ out,
+                                                        uint32_t *__restrict__ flag)
 {
+    // flag (optional): *flag |= 1 when the weighted sum holds an inf or a NaN (its squared norm is then not finite): the LeRF pass's non-finite word
     __shared__ double red[4];
     const int64_t ray = blockIdx.x;
     const float *er = e + ray * (int64_t)s * stride;
@@ -369,20 +380,30 @@ __global__ void __launch_bounds__(256) k_clip_embedding(int s, int stride, int d
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
+    if (flag && threadIdx.x == 0 && !(red[0] + red[1] + red[2] + red[3] <= 1.7e308)) atomicOr(flag, 1u);
     const float nrm = fmaxf((float)sqrt(red[0] + red[1] + red[2] + red[3]), 1e-8f);
     for (int k = threadIdx.x; k < dim; k += 256) out[ray * dim + k] = out[ray * dim + k] / nrm;
 }
 
+int launch_clip_embedding(const float *embeds, int embed_stride, int embed_dim, const float *weights, int64_t n, int s, float *out, hipStream_t st, uint32_t *flag)
+{
+    if (n == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_clip_embedding, dim3((unsigned)n), dim3(256), 0, st, s, embed_stride, embed_dim, embeds, weights, out, flag);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
 int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
-                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast, const int32_t *src, const float *raw2, int64_t n_split)
+                       float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast, const int32_t *src, const float *raw2, int64_t n_split,
+                       uint32_t *flag)
 {
     if (src && !raw2) { raw2 = raw; n_split = 0; }          // one array of rows
     if (n == 0) return NRF_OK;
     ProfScope prof(NRF_PROF_COMPOSITE, st);
     if (fast) hipLaunchKernelGGL(k_raw2outputs<true>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split);
+                                 raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split, flag);
     else hipLaunchKernelGGL(k_raw2outputs<false>, dim3((unsigned)ceil_div(n, RAYS_PER_BLOCK)), dim3(64 * RAYS_PER_BLOCK), 0, st, n, s, c, sigma_ch, white,
-                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split);
+                       raw, z, dirs, d_stride, rgb, disp, acc, weights, depth, nz, src, raw2, n_split, flag);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
@@ -442,9 +463,7 @@ int nrf_render_clip_embedding(const float *d_embeds, int embed_stride, int embed
 {
     NRF_CHECK_ARG(d_embeds && d_weights && d_out && n >= 0 && s >= 1 && embed_dim >= 1 && embed_stride >= embed_dim, "nrf_render_clip_embedding: bad argument");
     if (n == 0) return NRF_OK;
-    hipLaunchKernelGGL(k_clip_embedding, dim3((unsigned)n), dim3(256), 0, as_stream(stream), s, embed_stride, embed_dim, d_embeds, d_weights, d_out);
-    NRF_LAUNCH_CHECK();
-    return NRF_OK;
+    return launch_clip_embedding(d_embeds, embed_stride, embed_dim, d_weights, n, s, d_out, as_stream(stream), nullptr);
 }
 
 static int sample_pdf_entry(const float *d_bins, const float *d_weights, int64_t n, int nb, const float *d_u, int64_t u_stride, int ns, int sum_vec,

@@ -38,6 +38,11 @@ struct nrf_hash {
     size_t fast_bytes = 0;
     bool fast_valid = false;
     int dense_levels = 0;
+    // RMS of the table's entries (device float, refreshed by every nrf_hash_set_table in its stream; a deterministic two-stage sum: the same table always gives the same
+    // bits) and a counter of the uploads: what a renderer's split-precision network scales its first layer by (mlp.h, k_small_scales)
+    float *d_table_rms = nullptr;
+    float *d_rms_part = nullptr;
+    uint64_t table_version = 0;
     size_t dense_budget = (size_t)24 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 4.4 GB at 16..512; at 16..1024 the finest level (35 GB) stays hashed -- HBM is 288 GB
 };
 

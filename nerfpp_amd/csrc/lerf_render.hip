@@ -24,6 +24,7 @@
 // and anchored on the reference's call sites; no reference run or fixture pins them.
 #include "common.h"
 #include "mlp.h"
+#include "stoch.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -45,6 +46,12 @@ struct nrf_lerf_renderer {
     mutable hipStream_t lane[NRF_LERF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable hipEvent_t lane_fork = nullptr, lane_done[NRF_LERF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable int lane_device = -1;
+    // the pass's non-finite word (nrf_render_params.overflow_policy): ONE per call -- the pass has no fp32 single-call twin to render a flagged chunk again with, so a
+    // flagged call is an error under every detecting policy; a pinned mirror and the event of a deferred copy
+    mutable uint32_t *d_flag = nullptr, *h_flag = nullptr;
+    mutable hipEvent_t flag_ev = nullptr;
+    mutable bool flag_pending = false;
+    mutable int64_t flagged_calls = 0;
     void drop_lanes() const
     {
         for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
@@ -55,6 +62,9 @@ struct nrf_lerf_renderer {
     ~nrf_lerf_renderer()
     {
         drop_lanes();
+        if (flag_ev) { (void)hipEventSynchronize(flag_ev); (void)hipEventDestroy(flag_ev); }
+        if (d_flag) (void)hipFree(d_flag);
+        if (h_flag) (void)hipHostFree(h_flag);
         if (d_pos) (void)hipFree(d_pos);
         if (d_neg) (void)hipFree(d_neg);
     }
@@ -364,8 +374,81 @@ size_t nrf_lerf_render_rays_workspace_bytes(const nrf_lerf_renderer *r, int64_t 
     return lerf_chunk_ws(pl, n);
 }
 
+static int lerf_render_rays_impl(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
+                                 const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream, uint32_t *d_flag);
+
+static inline bool lerf_detects(const nrf_render_params *p) { return p->overflow_policy != NRF_OVERFLOW_IGNORE; }
+
+static int lerf_flag_buffers(const nrf_lerf_renderer *r)
+{
+    if (r->d_flag) return NRF_OK;
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&r->d_flag), sizeof(uint32_t)));
+    NRF_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->h_flag), 2 * sizeof(uint32_t), hipHostMallocDefault));          // [0] synchronous read-back, [1] deferred copy
+    NRF_HIP(hipEventCreateWithFlags(&r->flag_ev, hipEventDisableTiming));
+    return NRF_OK;
+}
+
+static int lerf_take_deferred(const nrf_lerf_renderer *r, bool wait, const char *who)
+{
+    if (!r->flag_pending) return NRF_OK;
+    if (wait) NRF_HIP(hipEventSynchronize(r->flag_ev));
+    else if (hipEventQuery(r->flag_ev) != hipSuccess) return NRF_OK;
+    r->flag_pending = false;
+    if (!r->h_flag[1]) return NRF_OK;
+    r->flagged_calls++;
+    set_error("%s: an EARLIER LeRF render call (NRF_OVERFLOW_DEFERRED) produced non-finite language densities / embeddings: an fp16 operand of the fused passes left its range", who);
+    return NRF_ERR_NONFINITE;
+}
+
+// before a call's chunks are issued (clears the word) and after they have joined `st`
+static int lerf_flag_begin(const nrf_lerf_renderer *r, const nrf_render_params *p, hipStream_t st, const char *who)
+{
+    NRF_CHECK_ARG(p->overflow_policy >= NRF_OVERFLOW_AUTO && p->overflow_policy <= NRF_OVERFLOW_IGNORE, "%s: overflow_policy %d is not an NRF_OVERFLOW_* value", who, p->overflow_policy);
+    if (!lerf_detects(p)) return NRF_OK;
+    NRF_TRY(lerf_flag_buffers(r));
+    NRF_TRY(lerf_take_deferred(r, p->overflow_policy == NRF_OVERFLOW_DEFERRED, who));
+    NRF_HIP(hipMemsetAsync(r->d_flag, 0, sizeof(uint32_t), st));
+    return NRF_OK;
+}
+
+static int lerf_flag_end(const nrf_lerf_renderer *r, const nrf_render_params *p, hipStream_t st, const char *who)
+{
+    if (!lerf_detects(p)) return NRF_OK;
+    if (p->overflow_policy == NRF_OVERFLOW_DEFERRED) {
+        NRF_HIP(hipMemcpyAsync(r->h_flag + 1, r->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        NRF_HIP(hipEventRecord(r->flag_ev, st));
+        r->flag_pending = true;
+        return NRF_OK;
+    }
+    NRF_HIP(hipMemcpyAsync(r->h_flag, r->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NRF_HIP(hipStreamSynchronize(st));
+    if (!r->h_flag[0]) return NRF_OK;
+    r->flagged_calls++;
+    set_error("%s: non-finite language densities / embeddings: an fp16 operand of the fused LeRF passes left its range (weights / features of unusual magnitude).  The pass has "
+              "no fp32 single-call twin: render through the stage calls (nrf_mlp_forward NRF_PREC_F32 + nrf_raw2weights + nrf_render_clip_embedding)", who);
+    return NRF_ERR_NONFINITE;
+}
+
+int nrf_lerf_renderer_nonfinite(const nrf_lerf_renderer *r, int64_t *flagged_calls)
+{
+    NRF_CHECK_ARG(r, "nrf_lerf_renderer_nonfinite: null pointer");
+    const int rc = lerf_take_deferred(r, true, "nrf_lerf_renderer_nonfinite");
+    if (flagged_calls) *flagged_calls = r->flagged_calls;
+    return rc == NRF_ERR_NONFINITE ? NRF_OK : rc;
+}
+
 int nrf_lerf_render_rays(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
                          const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && p && out, "nrf_lerf_render_rays: null pointer");
+    if (n == 0) return lerf_render_rays_impl(r, d_rays, ray_stride, n, p, d_t, d_u, out, d_workspace, workspace_bytes, stream, nullptr);
+    NRF_TRY(lerf_flag_begin(r, p, as_stream(stream), "nrf_lerf_render_rays"));
+    NRF_TRY(lerf_render_rays_impl(r, d_rays, ray_stride, n, p, d_t, d_u, out, d_workspace, workspace_bytes, stream, lerf_detects(p) ? r->d_flag : nullptr));
+    return lerf_flag_end(r, p, as_stream(stream), "nrf_lerf_render_rays");
+}
+
+static int lerf_render_rays_impl(const nrf_lerf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
+                                 const nrf_lerf_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream, uint32_t *d_flag)
 {
     NRF_CHECK_ARG(r && p && out, "nrf_lerf_render_rays: null pointer");
     NRF_CHECK_ARG(n >= 0 && (ray_stride == 8 || ray_stride == 11), "nrf_lerf_render_rays: packed rays are [n, 8 | 11]");
@@ -419,14 +502,15 @@ int nrf_lerf_render_rays(const nrf_lerf_renderer *r, const float *d_rays, int ra
     if (pl.geo) NRF_TRY(nrf_lerf_sigma_geo_lm_strided(m, x_new, cols, keep + nc, nn, sig + nc, geo + (size_t)nc * 32, cols, stream));
     else NRF_TRY(nrf_lerf_sigma_lm_strided(m, x_new, cols, keep + nc, nn, sig + nc, stream));
     float *depth = out->d_depth ? out->d_depth : dda_f, *disp = out->d_disp ? out->d_disp : dda_f + n, *accm = out->d_acc ? out->d_acc : dda_f + 2 * n;
-    NRF_TRY(nrf_raw2weights_gather(sig, 1, 0, src, zf, dirs, ray_stride, n, sf, w_f, depth, disp, accm, stream));             // RawToLEOutputs, fine pass, through the merge map
+    // RawToLEOutputs, fine pass, through the merge map (nrf_raw2weights_gather + the pass's non-finite word: every sample's sigma_le is looked at here)
+    NRF_TRY(nrf::launch_raw2outputs(sig, zf, dirs, ray_stride, n, sf, 1, 0, 0, nullptr, disp, accm, w_f, depth, nrf::SigmaNoise{}, as_stream(stream), false, src, nullptr, 0, d_flag));
     if (out->d_embedding || out->d_relevancy) {
         if (pl.geo) NRF_TRY(nrf_lerf_render_embedding_lm_geo(m, x, cols, src, geo, cols, w_f, n, sf, acc, stream));
         else NRF_TRY(nrf_lerf_render_embedding_lm_gather(m, x, cols, src, w_f, n, sf, acc, stream));
         // the final normalise of RenderCLIPEmbedding (LeRFRenderer.h:53): one "sample" of weight 1 per ray
         NRF_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 0x3f800000, (size_t)n, as_stream(stream)));
         float *emb = out->d_embedding ? out->d_embedding : emb_ws;
-        NRF_TRY(nrf_render_clip_embedding(acc, E, E, ones, n, 1, emb, stream));
+        NRF_TRY(nrf::launch_clip_embedding(acc, E, E, ones, n, 1, emb, as_stream(stream), d_flag));
         if (out->d_relevancy)
             NRF_TRY(nrf_lerf_relevancy(emb, n, E, r->d_pos, r->n_pos, r->d_neg, r->n_neg, 0, out->d_relevancy, stream));     // LeRFRenderer.cpp:79 (one positive phrase)
     }
@@ -455,6 +539,8 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
     NRF_CHECK_ARG(chunk > 0 && n >= 0, "nrf_lerf_batchify_rays: Chunk must be positive");
     LerfPlan pl;
     NRF_TRY(lerf_plan(r, p, &pl, "nrf_lerf_batchify_rays"));
+    if (n > 0) NRF_TRY(lerf_flag_begin(r, p, as_stream(stream), "nrf_lerf_batchify_rays"));
+    uint32_t *const d_flag = (n > 0 && lerf_detects(p)) ? r->d_flag : nullptr;
     const int L = lerf_lanes(r);
     const int64_t lc = lerf_lane_chunk(n, chunk, L);
     const size_t part = lc > 0 ? nrf_lerf_render_rays_workspace_bytes(r, lc, p) : 0;
@@ -472,7 +558,7 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
         for (int64_t i = 0; i < n && rc == NRF_OK; i += lc, k = (k + 1) % L) {                                                // :206
             const int64_t mm = n - i < lc ? n - i : lc;
             const nrf_lerf_outputs o = slice(*out, i, pl.s, pl.sf, pl.E);
-            rc = nrf_lerf_render_rays(r, d_rays + i * ray_stride, ray_stride, mm, p, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * part, part, lane[k]);
+            rc = lerf_render_rays_impl(r, d_rays + i * ray_stride, ray_stride, mm, p, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * part, part, lane[k], d_flag);
         }
         for (int j = 0; j < L; j++) {
             if (hipEventRecord(done[j], lane[j]) != hipSuccess || hipStreamWaitEvent(st, done[j], 0) != hipSuccess) {
@@ -480,14 +566,14 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
                 (void)hipStreamSynchronize(lane[j]);
             }
         }
-        return rc;
+        return (rc == NRF_OK && n > 0) ? lerf_flag_end(r, p, st, "nrf_lerf_batchify_rays") : rc;
     }
     for (int64_t i = 0; i < n; i += chunk) {                                                                                  // :206
         const int64_t mm = n - i < chunk ? n - i : (int64_t)chunk;
         const nrf_lerf_outputs o = slice(*out, i, pl.s, pl.sf, pl.E);
-        NRF_TRY(nrf_lerf_render_rays(r, d_rays + i * ray_stride, ray_stride, mm, p, d_t, d_u, &o, d_workspace, workspace_bytes, stream));
+        NRF_TRY(lerf_render_rays_impl(r, d_rays + i * ray_stride, ray_stride, mm, p, d_t, d_u, &o, d_workspace, workspace_bytes, stream, d_flag));
     }
-    return NRF_OK;
+    return n > 0 ? lerf_flag_end(r, p, as_stream(stream), "nrf_lerf_batchify_rays") : NRF_OK;
 }
 
 size_t nrf_lerf_render_rows_workspace_bytes(const nrf_lerf_renderer *r, const nrf_view *v, const nrf_render_params *p)

@@ -19,7 +19,14 @@ struct WeightMap {
     int64_t n = 0;
     int elem = 2;              // bytes per element of the image: 2 (fp16, kinds HI / LO) or 4 (fp32)
     void *d_out = nullptr;     // the image (owned by the handle's d_packed_* / layer fields)
+    bool scaled = false;       // gathers from the handle's SCALED blob (d_params_scaled): the split-precision operand images
 };
+
+// NRF_PREC_F16_SPLIT range safety of the bias-free NeRFSmall: ReLU is positively homogeneous, so layer l may be computed with 2^e_l W_l and the product of the scales
+// taken out again at the end -- exact in fp32 (powers of two), while the fp16 (hi, lo) pairs the matrix cores read (weights split at pack time, activations split between
+// layers) sit where both halves are fp16 NORMALS whatever the magnitude of the checkpoint's weights.  Scale groups: sigma-net layer l -> group l; colour layer 0 has two
+// (its view-direction columns, and its geo columns, which also undo the sigma net's cumulative scale: the geo features arrive scaled); colour layer l >= 1 -> NL + 1 + l.
+enum { SMALL_MAX_GROUPS = 12, SMALL_SCALE_INV_SIGMA = 0, SMALL_SCALE_INV_RGB = 1, SMALL_SCALE_HIDDEN = 2, SMALL_SCALE_COUNT = 8 };
 
 struct LinearLayer {
     int in = 0, out = 0;
@@ -61,6 +68,15 @@ struct nrf_mlp {
     void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
     size_t packed_bwd_bytes = 0;
     std::vector<nrf::WeightMap> maps;        // NeRFSmall: every derived image as a gather from d_params (empty: nrf_mlp_set_params repacks on the host)
+    // range-safe split precision (see SMALL_MAX_GROUPS above): chosen ON THE DEVICE from the blob at every nrf_mlp_set_params (k_small_scales), in stream order
+    float *d_params_scaled = nullptr;        // blob[i] * gscale[group[i]]: what the split images (d_packed_split, the GEO tail of d_packed_sigma_f32) gather from
+    uint8_t *d_group = nullptr;              // scale group of blob element i
+    float *d_gscale = nullptr;               // [SMALL_MAX_GROUPS] powers of two
+    float *d_scales = nullptr;               // [SMALL_SCALE_COUNT] what the kernels read: 2^-S_sigma, 2^-S_colour, 2^S_hidden (all 1 while no scaling is in force)
+    float in_rms_hint = 0.25f;               // expected RMS of the position features; nrf_mlp_set_input_rms_hint
+    const float *d_in_rms_src = nullptr;     // ... or where to read it on the device: the RMS of the hash table a renderer pairs this network with (render.hip, ensure_scales)
+    uint64_t in_rms_seen = 0;                // table upload counter of that hash grid at the last rescale
+    bool split_scaling = true;               // false: the split images from the blob as it is (nrf_mlp_set_split_scaling; NRF_SPLIT_UNSCALED=1 makes that the default)
 };
 
 namespace nrf {
@@ -93,6 +109,7 @@ int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int6
 
 // matrix-core paths (separate translation units)
 int mlp_small_mfma_available(const nrf_mlp *m);
+int mlp_small_rescale(nrf_mlp *m, hipStream_t st);                    // mlp.hip: scales from the current blob -> d_gscale / d_scales / d_params_scaled (no-op without weight maps)
 int mlp_small_forward_mfma_lm(const nrf_mlp *m, const __half2 *feats, const __half2 *feats_lo, int64_t pstride, const __half *dirs, const __half *dirs_lo, int s,
                               const uint8_t *keep, int64_t p, float *out, hipStream_t st, const int32_t *src = nullptr);
 int mlp_small_color_from_geo_lm(const nrf_mlp *m, const void *geo, int64_t geo_stride, const float *sigma, const __half *dirs, const __half *dirs_lo, int s,

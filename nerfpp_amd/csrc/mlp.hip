@@ -724,6 +724,7 @@ static int build_weight_maps(nrf_mlp *m, const std::vector<float> &hp)
         HostMap hm;
         if (!dst[im] || have[im] != want || !decode_weight_map(four, elem[im], m->n_params, hm) || !weight_map_reproduces(hm, hp, real[im])) { drop_weight_maps(m); return NRF_OK; }
         NRF_TRY(upload_weight_map(m, hm, dst[im]));
+        m->maps.back().scaled = im == I_SPLIT || im == I_SIG_TAIL;      // the split-precision operands: gathered from the range-scaled blob (mlp_small_rescale)
     }
     for (auto &L : m->layers) {                       // W^T [in][out] of the generic fp32 forward / backward
         HostMap hm; hm.elem = 4;
@@ -754,6 +755,191 @@ __global__ void k_apply_weight_map(int64_t n, const int32_t *__restrict__ src, c
     __half h = __float2half_rn(v);
     if (k == WM_F16_LO) h = __float2half_rn(v - __half2float(h));
     static_cast<__half *>(out)[e] = h;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// range-safe split precision: the scale groups of a NeRFSmall blob (mlp.h, SMALL_MAX_GROUPS)
+// ---------------------------------------------------------------------------------------------------
+// One workgroup.  Per group: sum of squares and absolute maximum of its weights (strided partials combined in thread order: the same blob always gives the same scales),
+// then thread 0 walks the two nets with an RMS model of the activations -- a layer with RMS row norm r turns inputs of RMS a into pre-activations of RMS a r, a ReLU keeps
+// 1 / sqrt 2 of that -- and picks the CUMULATIVE power of two that puts every layer's output near RMS 8: 2^13 of head-room below the fp16 maximum, and every value down
+// to 1 / 64 of the RMS still has a normal (lo) half.  The weights follow: a group's own exponent is the difference of consecutive cumulative ones, capped so that its
+// largest scaled weight stays below 2^15.  Nothing here is exact arithmetic and nothing needs to be: ANY powers of two give the same fp32 result up to the (hi, lo)
+// roundings they are chosen to make harmless; an activation that still leaves the fp16 range is caught by the render path's non-finite word (render.hip).
+// Dead band: a layer whose weights and predicted activations already sit in the comfortable range keeps the exponent 0 -- a checkpoint of ordinary magnitudes renders
+// exactly as it did before there was any scaling; a layer outside the band is moved to the target.
+__global__ void __launch_bounds__(256) k_small_scales(nrf_mlp_small_desc d, const float *__restrict__ w, float in_rms_hint, const float *__restrict__ in_rms_src,
+                                                      float *__restrict__ gscale, float *__restrict__ scales)
+{
+    float in_rms = in_rms_hint;
+    if (in_rms_src) { const float v = *in_rms_src; if (v > 0.0f && isfinite(v)) in_rms = v; }
+    __shared__ float s_a[256], s_b[256];
+    __shared__ float g_sq[SMALL_MAX_GROUPS], g_mx[SMALL_MAX_GROUPS];
+    const int t = threadIdx.x;
+    const int NL = d.num_layers, NLC = d.num_layers_color, V = d.input_ch_views;
+    auto combine = [&](float v, bool is_max) -> float {          // every thread's v -> thread 0's result, in thread order
+        s_a[t] = v;
+        __syncthreads();
+        float r = 0.0f;
+        if (t == 0) for (int i = 0; i < 256; i++) r = is_max ? fmaxf(r, s_a[i]) : r + s_a[i];
+        __syncthreads();
+        return r;
+    };
+    (void)s_b;
+    size_t off = 0;
+    for (int L = 0; L < NL + NLC; L++) {
+        const bool col = L >= NL;
+        const int l = col ? L - NL : L;
+        const int in = col ? (l == 0 ? V + d.geo_feat_dim : d.hidden_dim_color) : (l == 0 ? d.input_ch : d.hidden_dim);
+        const int out = col ? (l == NLC - 1 ? 3 : d.hidden_dim_color) : (l == NL - 1 ? 1 + d.geo_feat_dim : d.hidden_dim);
+        float sq0 = 0.0f, mx0 = 0.0f, sq1 = 0.0f, mx1 = 0.0f;
+        for (int i = t; i < in * out; i += 256) {
+            const float v = w[off + i];
+            if (col && l == 0 && (i % in) >= V) { sq1 += v * v; mx1 = fmaxf(mx1, fabsf(v)); }
+            else { sq0 += v * v; mx0 = fmaxf(mx0, fabsf(v)); }
+        }
+        const int g = col ? (l == 0 ? NL : NL + 1 + l) : l;
+        const float a = combine(sq0, false), b = combine(mx0, true);
+        if (t == 0) { g_sq[g] = a; g_mx[g] = b; }
+        if (col && l == 0) {
+            const float a1 = combine(sq1, false), b1 = combine(mx1, true);
+            if (t == 0) { g_sq[NL + 1] = a1; g_mx[NL + 1] = b1; }
+        }
+        off += (size_t)in * out;
+    }
+    if (t != 0) return;
+    const float TARGET = 8.0f, RELU_KEEPS = 0.70710678f;
+    auto cap = [&](int e, int g, int shift) {                    // largest scaled weight of group g (exponent e + shift) below 2^15
+        if (!(g_mx[g] > 0.0f) || !isfinite(g_mx[g])) return e;
+        const int hi = 14 - ilogbf(g_mx[g]) - shift;
+        return e < hi ? e : hi;
+    };
+    auto want_cum = [&](float an, int fallback) {                // cumulative exponent that brings an activation RMS `an` to TARGET
+        if (!(an > 0.0f) || !isfinite(an)) return fallback;
+        const float e = roundf(log2f(TARGET / an));
+        return (int)fminf(fmaxf(e, -100.0f), 100.0f);
+    };
+    // exponent 0 is fine for group g (its weights enter the image times 2^shift) when the layer's output, at the cumulative scale 2^S it would then carry, has an RMS in
+    // [2^-4, 2^9] and the group's largest weight lies in [2^-4, 2^10]
+    auto comfortable = [&](float an, int S_, int g, int shift) {
+        if (!(an > 0.0f) || !isfinite(an) || !(g_mx[g] > 0.0f) || !isfinite(g_mx[g])) return false;
+        const float act = ldexpf(an, S_), wmax = ldexpf(g_mx[g], shift);
+        return act >= 0.0625f && act <= 512.0f && wmax >= 0.0625f && wmax <= 1024.0f;
+    };
+    // ... and a floor under the weights: an exponent chosen for the activations alone can leave a layer's weights tiny (a large input RMS in front of a small target: the
+    // last layer behind hidden layers that sit high in the band) -- then their (lo) halves are subnormal again.  The largest scaled weight of the group is kept at or
+    // above 2^-4 as long as the layer's output RMS stays below 2^11.
+    auto weight_floor = [&](int e, float an, int S_, int g, int shift) {
+        if (!(g_mx[g] > 0.0f) || !isfinite(g_mx[g]) || !(an > 0.0f) || !isfinite(an)) return e;
+        const int lo = -4 - ilogbf(g_mx[g]) - shift;
+        if (e >= lo) return e;
+        const int room = (int)floorf(log2f(2048.0f / an)) - S_;          // largest exponent that keeps the output RMS below 2^11
+        const int e2 = lo < room ? lo : room;
+        return e2 > e ? e2 : e;
+    };
+    int ge[SMALL_MAX_GROUPS];
+    for (int g = 0; g < SMALL_MAX_GROUPS; g++) ge[g] = 0;
+    float a = in_rms > 0.0f ? in_rms : 0.25f;
+    int S = 0, S_hidden = 0;
+    for (int l = 0; l < NL; l++) {
+        const int out = l == NL - 1 ? 1 + d.geo_feat_dim : d.hidden_dim;
+        const float an = a * sqrtf(g_sq[l] / (float)out) * (l < NL - 1 ? RELU_KEEPS : 1.0f);
+        int e = comfortable(an, S, l, 0) ? 0 : want_cum(an, S) - S;
+        e = weight_floor(e, an, S, l, 0);
+        e = cap(e, l, 0);
+        ge[l] = e; S += e; a = an;
+        if (l == NL - 2) S_hidden = S;
+    }
+    const int S_sigma = S;
+    int Sc = 0;
+    {
+        const int out = NLC == 1 ? 3 : d.hidden_dim_color;
+        const float zz = sqrtf(g_sq[NL] / (float)out * 0.25f + g_sq[NL + 1] / (float)out * a * a);          // view-direction features: RMS ~ 0.5
+        const float an = zz * (NLC > 1 ? RELU_KEEPS : 1.0f);
+        int e = (comfortable(an, 0, NL, 0) && comfortable(an, 0, NL + 1, -S_sigma)) ? 0 : want_cum(an, 0);
+        e = weight_floor(e, an, 0, NL, 0);
+        e = cap(e, NL, 0);
+        e = cap(e, NL + 1, -S_sigma);
+        ge[NL] = e; ge[NL + 1] = e - S_sigma; Sc = e; a = an;
+    }
+    for (int l = 1; l < NLC; l++) {
+        const int g = NL + 1 + l, out = l == NLC - 1 ? 3 : d.hidden_dim_color;
+        const float an = a * sqrtf(g_sq[g] / (float)out) * (l < NLC - 1 ? RELU_KEEPS : 1.0f);
+        int e = comfortable(an, Sc, g, 0) ? 0 : want_cum(an, Sc) - Sc;
+        e = weight_floor(e, an, Sc, g, 0);
+        e = cap(e, g, 0);
+        ge[g] = e; Sc += e; a = an;
+    }
+    bool sane = true;
+    for (int g = 0; g < NL + NLC + 1; g++) if (!isfinite(g_sq[g])) sane = false;
+    for (int g = 0; g < SMALL_MAX_GROUPS; g++) gscale[g] = sane ? ldexpf(1.0f, ge[g] < -120 ? -120 : (ge[g] > 120 ? 120 : ge[g])) : 1.0f;
+    for (int i = 0; i < SMALL_SCALE_COUNT; i++) scales[i] = 1.0f;
+    if (sane) {
+        scales[SMALL_SCALE_INV_SIGMA] = ldexpf(1.0f, -S_sigma);
+        scales[SMALL_SCALE_INV_RGB] = ldexpf(1.0f, -Sc);
+        scales[SMALL_SCALE_HIDDEN] = ldexpf(1.0f, S_hidden);
+    }
+}
+
+__global__ void k_scale_blob(int64_t n, const float *__restrict__ w, const uint8_t *__restrict__ group, const float *__restrict__ gscale, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[i] * gscale[group[i]];
+}
+
+// scales of the CURRENT blob, the scaled blob, and the images that gather from it -- all in stream order, nothing waits
+int mlp_small_rescale(nrf_mlp *m, hipStream_t st)
+{
+    if (!m || m->family != MLP_SMALL || m->maps.empty() || !m->d_group) return NRF_OK;
+    if (!m->split_scaling) {
+        const float ones[SMALL_MAX_GROUPS > SMALL_SCALE_COUNT ? SMALL_MAX_GROUPS : SMALL_SCALE_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        NRF_HIP(hipMemcpyAsync(m->d_params_scaled, m->d_params, (size_t)m->n_params * 4, hipMemcpyDeviceToDevice, st));
+        NRF_HIP(hipMemcpyAsync(m->d_gscale, ones, SMALL_MAX_GROUPS * sizeof(float), hipMemcpyHostToDevice, st));
+        NRF_HIP(hipMemcpyAsync(m->d_scales, ones, SMALL_SCALE_COUNT * sizeof(float), hipMemcpyHostToDevice, st));
+        NRF_HIP(hipStreamSynchronize(st));            // (`ones` is a stack array)
+    } else {
+        k_small_scales<<<dim3(1), dim3(256), 0, st>>>(m->small, m->d_params, m->in_rms_hint, m->d_in_rms_src, m->d_gscale, m->d_scales);
+        NRF_HIP(hipGetLastError());
+        k_scale_blob<<<dim3((unsigned)((m->n_params + 255) / 256)), dim3(256), 0, st>>>(m->n_params, m->d_params, m->d_group, m->d_gscale, m->d_params_scaled);
+        NRF_HIP(hipGetLastError());
+    }
+    for (auto &w : m->maps) {
+        if (!w.scaled) continue;
+        k_apply_weight_map<<<dim3((unsigned)((w.n + 255) / 256)), dim3(256), 0, st>>>(w.n, w.d_src, w.d_kind, m->d_params_scaled, w.d_out, w.elem);
+        NRF_HIP(hipGetLastError());
+    }
+    return NRF_OK;
+}
+
+// the scale machinery of a freshly built NeRFSmall handle: group table, buffers, identity scales (kernels read d_scales whether or not scaling is in force)
+static int small_scale_setup(nrf_mlp *m)
+{
+    const auto &d = m->small;
+    std::vector<float> ones(SMALL_MAX_GROUPS > SMALL_SCALE_COUNT ? SMALL_MAX_GROUPS : SMALL_SCALE_COUNT, 1.0f);
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_scales), SMALL_SCALE_COUNT * sizeof(float)));
+    NRF_HIP(hipMemcpy(m->d_scales, ones.data(), SMALL_SCALE_COUNT * sizeof(float), hipMemcpyHostToDevice));
+    if (m->maps.empty() || d.use_pred_normal || d.num_layers + d.num_layers_color + 1 > SMALL_MAX_GROUPS) return NRF_OK;
+    std::vector<uint8_t> group((size_t)m->n_params, 0);
+    size_t off = 0;
+    for (int l = 0; l < d.num_layers; l++) {
+        const size_t ne = (size_t)(l == 0 ? d.input_ch : d.hidden_dim) * (l == d.num_layers - 1 ? 1 + d.geo_feat_dim : d.hidden_dim);
+        for (size_t i = 0; i < ne; i++) group[off + i] = (uint8_t)l;
+        off += ne;
+    }
+    for (int l = 0; l < d.num_layers_color; l++) {
+        const int in = l == 0 ? d.input_ch_views + d.geo_feat_dim : d.hidden_dim_color, out = l == d.num_layers_color - 1 ? 3 : d.hidden_dim_color;
+        for (size_t i = 0; i < (size_t)in * out; i++)
+            group[off + i] = (uint8_t)(l == 0 ? ((int)(i % in) >= d.input_ch_views ? d.num_layers + 1 : d.num_layers) : d.num_layers + 1 + l);
+        off += (size_t)in * out;
+    }
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_group), group.size()));
+    NRF_HIP(hipMemcpy(m->d_group, group.data(), group.size(), hipMemcpyHostToDevice));
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_gscale), SMALL_MAX_GROUPS * sizeof(float)));
+    NRF_HIP(hipMemcpy(m->d_gscale, ones.data(), SMALL_MAX_GROUPS * sizeof(float), hipMemcpyHostToDevice));
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_params_scaled), (size_t)m->n_params * 4));
+    if (const char *e = getenv("NRF_SPLIT_UNSCALED")) m->split_scaling = atoi(e) == 0;          // A/B switch of the default
+    return NRF_OK;
 }
 
 }  // namespace nrf
@@ -808,6 +994,9 @@ int nrf_mlp_small_create(const nrf_mlp_small_desc *d, const float *params, int p
     if (s == NRF_OK && !d->use_pred_normal) s = mlp_small_pack_f16(m, hp);
     if (s == NRF_OK && !d->use_pred_normal) s = mlp_small_pack_sigma_f32(m, hp);
     if (s == NRF_OK && !d->use_pred_normal) s = build_weight_maps(m, hp);
+    if (s == NRF_OK) s = small_scale_setup(m);
+    if (s == NRF_OK) s = mlp_small_rescale(m, as_stream(stream));
+    if (s == NRF_OK) s = hipStreamSynchronize(as_stream(stream)) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -886,10 +1075,11 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
         // by the caller, as for any in-place update.
         NRF_HIP(hipMemcpyAsync(m->d_params, params, (size_t)m->n_params * 4, params_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         for (auto &w : m->maps) {
+            if (w.scaled && m->d_group) continue;          // the split-precision operands: below, from the range-scaled blob
             k_apply_weight_map<<<dim3((unsigned)((w.n + 255) / 256)), dim3(256), 0, st>>>(w.n, w.d_src, w.d_kind, m->d_params, w.d_out, w.elem);
             NRF_HIP(hipGetLastError());
         }
-        return NRF_OK;
+        return mlp_small_rescale(m, st);
     }
     std::vector<float> hp((size_t)m->n_params);
     if (params_on_device) {
@@ -916,6 +1106,33 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
 }
 
 int nrf_mlp_device_repack_images(const nrf_mlp *m) { return m ? (int)m->maps.size() : 0; }
+
+int nrf_mlp_set_input_rms_hint(nrf_mlp *m, float rms, void *stream)
+{
+    NRF_CHECK_ARG(m && rms > 0.0f && rms < 1e30f, "nrf_mlp_set_input_rms_hint: bad argument");
+    m->in_rms_hint = rms;
+    return mlp_small_rescale(m, as_stream(stream));
+}
+
+int nrf_mlp_set_split_scaling(nrf_mlp *m, int on, void *stream)
+{
+    NRF_CHECK_ARG(m, "nrf_mlp_set_split_scaling: null pointer");
+    m->split_scaling = on != 0;
+    return mlp_small_rescale(m, as_stream(stream));
+}
+
+int nrf_mlp_get_split_scales(const nrf_mlp *m, float *group_scales_out, float *kernel_scales_out, void *stream)
+{
+    NRF_CHECK_ARG(m && group_scales_out && kernel_scales_out, "nrf_mlp_get_split_scales: null pointer");
+    for (int i = 0; i < SMALL_MAX_GROUPS; i++) group_scales_out[i] = 1.0f;
+    for (int i = 0; i < SMALL_SCALE_COUNT; i++) kernel_scales_out[i] = 1.0f;
+    if (m->family != MLP_SMALL || !m->d_scales) return NRF_OK;
+    hipStream_t st = as_stream(stream);
+    if (m->d_gscale) NRF_HIP(hipMemcpyAsync(group_scales_out, m->d_gscale, SMALL_MAX_GROUPS * sizeof(float), hipMemcpyDeviceToHost, st));
+    NRF_HIP(hipMemcpyAsync(kernel_scales_out, m->d_scales, SMALL_SCALE_COUNT * sizeof(float), hipMemcpyDeviceToHost, st));
+    NRF_HIP(hipStreamSynchronize(st));
+    return NRF_OK;
+}
 
 size_t nrf_mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
 {
@@ -966,6 +1183,10 @@ void nrf_mlp_destroy(nrf_mlp *m)
     if (m->d_packed_split) (void)hipFree(m->d_packed_split);
     if (m->d_packed_bwd) (void)hipFree(m->d_packed_bwd);
     if (m->d_packed_sigma_f32) (void)hipFree(m->d_packed_sigma_f32);
+    if (m->d_params_scaled) (void)hipFree(m->d_params_scaled);
+    if (m->d_group) (void)hipFree(m->d_group);
+    if (m->d_gscale) (void)hipFree(m->d_gscale);
+    if (m->d_scales) (void)hipFree(m->d_scales);
     delete m;
 }
 

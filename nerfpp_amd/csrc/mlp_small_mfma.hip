@@ -229,6 +229,8 @@ struct SmallInput {
     const float *sigma;
     // point -> ray without a division: ray = (p * ray_mul) >> (31 + ray_shift) for p < 2^31 (ray_mul = ceil(2^(31 + L) / s), L = ceil(log2 s); set by the launchers)
     uint32_t ray_mul; int ray_shift;
+    // split mode: the powers of two that take the range scaling of the operand image out of the outputs again (mlp.h, SMALL_SCALE_*; all 1 while no scaling is in force)
+    const float *scales;
 };
 
 #ifndef NRF_SMALL_PIPE_SPLIT
@@ -278,6 +280,11 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t nblocks = (npts + BLOCK_PTS - 1) / BLOCK_PTS;
+    // split mode: the image holds 2^e_l W_l per layer (both fp16 halves of every weight normal, activations near RMS 8 whatever the checkpoint's magnitudes: mlp.h); the
+    // outputs carry the product of the scales, taken out in the epilogue -- powers of two, exact
+    float inv_sigma = 1.0f, inv_rgb = 1.0f;
+    if constexpr (SPLIT) { inv_sigma = in.scales[SMALL_SCALE_INV_SIGMA]; inv_rgb = in.scales[SMALL_SCALE_INV_RGB]; }
+    (void)inv_sigma; (void)inv_rgb;
 #if NRF_SMALL_STAGGER
     // SIMD partners (waves w and w + 4) run the same program and fall into lockstep -- both in their matrix phases, then both in their vector phases.
     // Waves 4-7 start a fraction of an iteration late (MI355X_MICROARCH.md, "two waves that run the SAME program: try a stagger").
@@ -633,10 +640,12 @@ k_mlp_small_mfma(int64_t npts, SmallInput in, const half8 *__restrict__ packed, 
                 const int64_t p = p0 + pt * 32 + r;
                 if (p < npts) {
                     float sg;
-                    if constexpr (GEOIN) sg = sgv[pt]; else sg = sig[pt][0][0];
+                    if constexpr (GEOIN) sg = sgv[pt]; else if constexpr (SPLIT) sg = sig[pt][0][0] * inv_sigma; else sg = sig[pt][0][0];
                     if constexpr (LM) { if (!kp[pt]) sg = 0.0f; }                                    // the embedder's keep mask (NeRFRenderer.h:187-188), fetched with the operands
-                    if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{rgb[pt][0][0], rgb[pt][0][1], rgb[pt][0][2], sg};
-                    else { float *o = out + p * out_stride; o[0] = rgb[pt][0][0]; o[1] = rgb[pt][0][1]; o[2] = rgb[pt][0][2]; o[3] = sg; }
+                    float c0 = rgb[pt][0][0], c1 = rgb[pt][0][1], c2 = rgb[pt][0][2];
+                    if constexpr (SPLIT) { c0 *= inv_rgb; c1 *= inv_rgb; c2 *= inv_rgb; }
+                    if (out_stride == 4) *reinterpret_cast<float4 *>(out + p * 4) = float4{c0, c1, c2, sg};
+                    else { float *o = out + p * out_stride; o[0] = c0; o[1] = c1; o[2] = c2; o[3] = sg; }
                 }
             }
         }
@@ -865,6 +874,7 @@ static int dispatch_small(const nrf_mlp *m, const SmallInput &in_, bool lm, bool
     const auto &d = m->small;
     SmallInput in = in_;
     in.ray_mul = 0; in.ray_shift = 0;
+    in.scales = m->d_scales;
     if (lm && in.s >= 1) {
         // ray = floor(p / s) for p < 2^31 as (p * M) >> (31 + L), L = ceil(log2 s), M = ceil(2^(31 + L) / s) < 2^32 (Granlund-Montgomery round-up); the kernel takes the
         // high word of the product and shifts by L - 1 (s = 1: ray = p, flagged by a negative shift)

@@ -28,6 +28,13 @@ struct nrf_renderer {
     mutable hipEvent_t lane_fork = nullptr, lane_done[NRF_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     mutable int lane_device = -1;
     int lanes = 0;                // this renderer's lane count; 0: the process-wide default (nrf_set_render_lanes / NRF_RENDER_LANES)
+    // non-finite words of the matrix-core precisions (nrf_render_params.overflow_policy): one per chunk of the current call on the device, a pinned host mirror for the
+    // synchronous policies and one for the deferred copy, and the event that says the deferred copy has landed
+    mutable uint32_t *d_flags = nullptr, *h_flags = nullptr, *h_deferred = nullptr;      // h_deferred: NRF_DEFERRED_RING x NRF_FLAG_SLOTS words
+    mutable hipEvent_t deferred_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable int deferred_slots[4] = {0, 0, 0, 0};      // > 0: a deferred copy of that many words is pending in ring entry i
+    mutable int deferred_head = 0;                     // ring entry the next deferred copy goes to (entries are filled and looked at in order)
+    mutable int64_t flagged_chunks = 0, rerendered_chunks = 0;
     void drop_lanes() const
     {
         for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
@@ -35,8 +42,17 @@ struct nrf_renderer {
         if (lane_fork) { (void)hipEventDestroy(lane_fork); lane_fork = nullptr; }
         lane_device = -1;
     }
-    ~nrf_renderer() { drop_lanes(); }
+    ~nrf_renderer()
+    {
+        drop_lanes();
+        for (auto &e : deferred_ev) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+        if (d_flags) (void)hipFree(d_flags);
+        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_deferred) (void)hipHostFree(h_deferred);
+    }
 };
+constexpr int NRF_FLAG_SLOTS = 4096;        // chunks of one call that have a word of their own (further chunks share them modulo this)
+constexpr int NRF_DEFERRED_RING = 4;        // NRF_OVERFLOW_DEFERRED: calls whose words may be in flight to the host at once (the host may run that many calls ahead)
 
 namespace nrf {
 
@@ -148,6 +164,19 @@ static size_t network_ws_bytes(const nrf_renderer *r, int64_t p, int prec)
 // The fast path (matrix-core precisions, a hash grid of either encoder with F = 2 and 16 levels, SH directions, NeRFSmall in the built
 // matrix-core family): level-major fp16 features -> MFMA MLP, no concatenated input.  CuHashEmbedder features are exact fp16 numbers;
 // HashEmbedder (LibTorch, fp32) features travel as hi + lo planes in the split-precision mode.
+// The split-precision image of a NeRFSmall network is scaled for the magnitude of its inputs (mlp.h, SMALL_MAX_GROUPS): a renderer on a hash grid points the network at
+// the grid's table RMS and has the scales re-derived whenever the table was uploaded since (a training loop: every step).  Called on the caller's stream BEFORE any
+// lane forks: the images are rewritten in that stream's order.  The handles are shared mutable state of one caller (nerfpp_hip.h, nrf_batchify_rays).
+static int ensure_scales(const nrf_renderer *r, hipStream_t st)
+{
+    const nrf_hash *h = r->desc.hash;
+    nrf_mlp *m = const_cast<nrf_mlp *>(r->desc.mlp);
+    if (!h || !m || m->family != MLP_SMALL || !m->d_group || !h->d_table_rms) return NRF_OK;
+    if (m->d_in_rms_src == h->d_table_rms && m->in_rms_seen == h->table_version) return NRF_OK;
+    m->d_in_rms_src = h->d_table_rms; m->in_rms_seen = h->table_version;
+    return mlp_small_rescale(m, st);
+}
+
 static bool fast_path(const nrf_renderer *r, int prec)
 {
     return (prec == NRF_PREC_F16_MFMA || prec == NRF_PREC_F16_SPLIT) && r->desc.hash && hash_fast_supported(r->desc.hash) && r->in_ch == 32 &&
@@ -284,6 +313,7 @@ const char *nrf_status_string(int status)
         case NRF_ERR_HIP: return "HIP runtime error";
         case NRF_ERR_UNSUPPORTED: return "unsupported configuration";
         case NRF_ERR_WORKSPACE: return "workspace too small";
+        case NRF_ERR_NONFINITE: return "non-finite network outputs in a matrix-core precision";
         default: return "unknown status";
     }
 }
@@ -385,8 +415,126 @@ size_t nrf_render_rays_workspace_bytes(const nrf_renderer *r, int64_t n, const n
     return b;
 }
 
+}  // extern "C"
+
+namespace nrf {
+
+static int flag_buffers(const nrf_renderer *r)
+{
+    if (r->d_flags) return NRF_OK;
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&r->d_flags), NRF_FLAG_SLOTS * sizeof(uint32_t)));
+    NRF_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->h_flags), NRF_FLAG_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+    NRF_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->h_deferred), (size_t)NRF_DEFERRED_RING * NRF_FLAG_SLOTS * sizeof(uint32_t), hipHostMallocDefault));
+    for (auto &e : r->deferred_ev) NRF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return NRF_OK;
+}
+
+// A pending NRF_OVERFLOW_DEFERRED copy: looked at when it has landed (wait = false: only then), reported ONCE
+// (oldest first; only_entry >= 0: that ring entry alone, which the caller is about to reuse)
+static int take_deferred(const nrf_renderer *r, bool wait, const char *who, int only_entry = -1)
+{
+    int bad = 0;
+    for (int k = 0; k < NRF_DEFERRED_RING; k++) {
+        const int e = only_entry >= 0 ? only_entry : (r->deferred_head + k) % NRF_DEFERRED_RING;      // head is the oldest entry once the ring has wrapped
+        if (r->deferred_slots[e] > 0) {
+            if (wait) NRF_HIP(hipEventSynchronize(r->deferred_ev[e]));
+            else if (hipEventQuery(r->deferred_ev[e]) != hipSuccess) break;                            // later entries were recorded later
+            for (int i = 0; i < r->deferred_slots[e]; i++) bad += r->h_deferred[(size_t)e * NRF_FLAG_SLOTS + i] != 0;
+            r->deferred_slots[e] = 0;
+        }
+        if (only_entry >= 0) break;
+    }
+    if (!bad) return NRF_OK;
+    r->flagged_chunks += bad;
+    set_error("%s: an EARLIER render call on this renderer (NRF_OVERFLOW_DEFERRED) produced non-finite network outputs in %d chunk(s): an fp16 operand of the matrix-core "
+              "precision left its range; render with NRF_OVERFLOW_RERENDER or NRF_PREC_F32", who, bad);
+    return NRF_ERR_NONFINITE;
+}
+
+static inline int policy_of(const nrf_render_params *p) { return p->overflow_policy == NRF_OVERFLOW_AUTO ? NRF_OVERFLOW_RERENDER : p->overflow_policy; }
+static inline bool detects(const nrf_render_params *p) { return p->precision != NRF_PREC_F32 && policy_of(p) != NRF_OVERFLOW_IGNORE; }
+
+static int render_rays_impl(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
+                            const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream, uint32_t *d_flag);
+
+// After `slots` chunk words were written on `st`: what the policy says.  chunk_of(i, &first, &count) names the rays of chunk i.
+template <class ChunkOf, class Rerender>
+static int settle_flags(const nrf_renderer *r, const nrf_render_params *p, int slots, hipStream_t st, const char *who, ChunkOf chunk_of, Rerender rerender)
+{
+    const int pol = policy_of(p);
+    if (pol == NRF_OVERFLOW_DEFERRED) {
+        const int e = r->deferred_head;
+        if (r->deferred_slots[e]) NRF_TRY(take_deferred(r, true, who, e));      // the ring is full: the copy of NRF_DEFERRED_RING calls ago (the host waits only when it runs that far ahead)
+        NRF_HIP(hipMemcpyAsync(r->h_deferred + (size_t)e * NRF_FLAG_SLOTS, r->d_flags, (size_t)slots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        NRF_HIP(hipEventRecord(r->deferred_ev[e], st));
+        r->deferred_slots[e] = slots;
+        r->deferred_head = (e + 1) % NRF_DEFERRED_RING;
+        return NRF_OK;
+    }
+    NRF_HIP(hipMemcpyAsync(r->h_flags, r->d_flags, (size_t)slots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NRF_HIP(hipStreamSynchronize(st));
+    int bad = 0;
+    for (int i = 0; i < slots; i++) bad += r->h_flags[i] != 0;
+    if (!bad) return NRF_OK;
+    r->flagged_chunks += bad;
+    if (pol == NRF_OVERFLOW_ERROR) {
+        set_error("%s: non-finite network outputs in %d of %d chunk(s): an fp16 operand of the matrix-core precision left its range (weights / features of unusual magnitude); "
+                  "render with NRF_OVERFLOW_RERENDER or NRF_PREC_F32", who, bad, slots);
+        return NRF_ERR_NONFINITE;
+    }
+    (void)chunk_of;
+    for (int i = 0; i < slots; i++) if (r->h_flags[i]) { NRF_TRY(rerender(i)); }
+    return NRF_OK;
+}
+
+// one chunk again in NRF_PREC_F32 into the same outputs (workspace: the caller's when it is large enough, else stream-ordered scratch)
+static int rerender_f32(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p, const float *d_t, const float *d_u,
+                        const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, hipStream_t st)
+{
+    nrf_render_params q = *p;
+    q.precision = NRF_PREC_F32;
+    const size_t need = nrf_render_rays_workspace_bytes(r, n, &q);
+    void *ws = d_workspace; size_t wsb = workspace_bytes; void *tmp = nullptr;
+    if (need > workspace_bytes) { NRF_HIP(hipMallocAsync(&tmp, need, st)); ws = tmp; wsb = need; }
+    const int rc = render_rays_impl(r, d_rays, ray_stride, n, &q, d_t, d_u, out, ws, wsb, st, nullptr);
+    if (tmp) (void)hipFreeAsync(tmp, st);
+    if (rc == NRF_OK) r->rerendered_chunks++;
+    return rc;
+}
+
+}  // namespace nrf
+
+extern "C" {
+
+int nrf_renderer_nonfinite(const nrf_renderer *r, int64_t *flagged_chunks, int64_t *rerendered_chunks)
+{
+    NRF_CHECK_ARG(r, "nrf_renderer_nonfinite: null pointer");
+    const int rc = take_deferred(r, true, "nrf_renderer_nonfinite");
+    if (flagged_chunks) *flagged_chunks = r->flagged_chunks;
+    if (rerendered_chunks) *rerendered_chunks = r->rerendered_chunks;
+    return rc == NRF_ERR_NONFINITE ? NRF_OK : rc;          // the counters ARE the report here
+}
+
 int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
                     const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(r && p && out, "nrf_render_rays: null pointer");
+    NRF_CHECK_ARG(p->overflow_policy >= NRF_OVERFLOW_AUTO && p->overflow_policy <= NRF_OVERFLOW_IGNORE, "nrf_render_rays: overflow_policy %d is not an NRF_OVERFLOW_* value", p->overflow_policy);
+    if (n == 0 || !detects(p)) return render_rays_impl(r, d_rays, ray_stride, n, p, d_t, d_u, out, d_workspace, workspace_bytes, stream, nullptr);
+    hipStream_t st = as_stream(stream);
+    NRF_TRY(flag_buffers(r));
+    NRF_TRY(take_deferred(r, false, "nrf_render_rays"));
+    NRF_HIP(hipMemsetAsync(r->d_flags, 0, sizeof(uint32_t), st));
+    NRF_TRY(render_rays_impl(r, d_rays, ray_stride, n, p, d_t, d_u, out, d_workspace, workspace_bytes, stream, r->d_flags));
+    return settle_flags(r, p, 1, st, "nrf_render_rays", [](int) {}, [&](int) { return rerender_f32(r, d_rays, ray_stride, n, p, d_t, d_u, out, d_workspace, workspace_bytes, st); });
+}
+
+}  // extern "C"
+
+namespace nrf {
+
+static int render_rays_impl(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
+                            const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream, uint32_t *d_flag)
 {
     NRF_CHECK_ARG(r && p && out, "nrf_render_rays: null pointer");
     if (n == 0) return NRF_OK;
@@ -404,6 +552,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         return NRF_ERR_WORKSPACE;
     }
     hipStream_t st = as_stream(stream);
+    if (p->precision == NRF_PREC_F16_SPLIT) NRF_TRY(ensure_scales(r, st));          // (a no-op inside a Chunk loop: nrf_batchify_rays did it before its lanes forked)
     const int s = p->n_samples, ni = p->n_importance, sf = s + ni;
     const int c = r->desc.mlp->out_dims;
     // the FINAL compositing of the matrix-core precisions uses hardware exp / log / rcp and fp32 scans (composite.hip); NRF_PREC_F32, and the coarse pass whose
@@ -514,7 +663,7 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
         if (out->d_raw && raw_c != out->d_raw) NRF_HIP(hipMemcpyAsync(out->d_raw, raw_c, (size_t)n * s * c * sizeof(float), hipMemcpyDeviceToDevice, st));
         // the reference leaves result.Outputs UNDEFINED in this case (:423 vs :448); the coarse maps are what a caller wants
         return launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                                  out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st, fastc);
+                                  out->d_weights ? out->d_weights : w_c, out->d_depth, nz, st, fastc, nullptr, nullptr, 0, d_flag);
     }
     NRF_TRY(launch_raw2outputs(raw_c, z_c, d_rays + 3, ray_stride, n, s, sigma_only ? 1 : c, sigma_only ? 0 : 3, p->white_bkgr, nullptr, nullptr, nullptr, w_c, nullptr, nz,
                                st, false));   // :423  always the exact arithmetic: these weights choose the fine samples
@@ -558,8 +707,12 @@ int nrf_render_rays(const nrf_renderer *r, const float *d_rays, int ray_stride, 
     } else NRF_TRY(network(psf, sf, raw_f));                                                                       // :447
     nz.stream = NRF_RNG_NOISE_FINE;
     return launch_raw2outputs(raw_final, z_f, d_rays + 3, ray_stride, n, sf, c, 3, p->white_bkgr, out->d_rgb, out->d_disp, out->d_acc,
-                              out->d_weights, out->d_depth, nz, st, fastc, src_final, raw2_final, split_final);     // :448
+                              out->d_weights, out->d_depth, nz, st, fastc, src_final, raw2_final, split_final, d_flag);     // :448
 }
+
+}  // namespace nrf
+
+extern "C" {
 
 
 // ---- BatchifyRays (NeRFRenderer.h:465-525) and the pose branch of Render (:530-605) as single calls ----
@@ -677,9 +830,35 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
 {
     NRF_CHECK_ARG(r && p && out, "nrf_batchify_rays: null pointer");
     NRF_CHECK_ARG(chunk > 0 && n >= 0, "nrf_batchify_rays: Chunk must be positive");
+    NRF_CHECK_ARG(p->overflow_policy >= NRF_OVERFLOW_AUTO && p->overflow_policy <= NRF_OVERFLOW_IGNORE, "nrf_batchify_rays: overflow_policy %d is not an NRF_OVERFLOW_* value", p->overflow_policy);
     const int s = p->n_samples, sf = p->n_samples + p->n_importance, so = p->n_importance > 0 ? sf : s;
     const int c = r->desc.mlp->out_dims;
     nrf_render_params q = *p;
+    // before any lane forks, on the caller's stream: the split image's range scales for the table as it is now, and the chunk words of this call cleared
+    if (p->precision == NRF_PREC_F16_SPLIT) NRF_TRY(ensure_scales(r, as_stream(stream)));
+    const bool det = n > 0 && detects(p);
+    if (det) {
+        NRF_TRY(flag_buffers(r));
+        NRF_TRY(take_deferred(r, false, "nrf_batchify_rays"));
+        NRF_HIP(hipMemsetAsync(r->d_flags, 0, NRF_FLAG_SLOTS * sizeof(uint32_t), as_stream(stream)));
+    }
+    struct ChunkRec { int64_t first, count; };
+    std::vector<ChunkRec> done_chunks;
+    auto flag_of = [&](size_t idx) -> uint32_t * { return det ? r->d_flags + (idx % NRF_FLAG_SLOTS) : nullptr; };
+    // the policy, once every chunk has been issued and the lanes have joined `stream` (nrf_render_params.overflow_policy)
+    auto settle = [&]() -> int {
+        if (!det || done_chunks.empty()) return NRF_OK;
+        const int slots = (int)(done_chunks.size() < (size_t)NRF_FLAG_SLOTS ? done_chunks.size() : (size_t)NRF_FLAG_SLOTS);
+        return settle_flags(r, p, slots, as_stream(stream), "nrf_batchify_rays", [](int) {}, [&](int slot) -> int {
+            for (size_t j = (size_t)slot; j < done_chunks.size(); j += NRF_FLAG_SLOTS) {
+                nrf_render_params q2 = *p;
+                q2.ray_base = p->ray_base + done_chunks[j].first;
+                const nrf_render_outputs o2 = slice_outputs(*out, done_chunks[j].first, s, so, sf, c);
+                NRF_TRY(rerender_f32(r, d_rays + done_chunks[j].first * ray_stride, ray_stride, done_chunks[j].count, &q2, d_t, d_u, &o2, d_workspace, workspace_bytes, as_stream(stream)));
+            }
+            return NRF_OK;
+        });
+    };
     const int L = lanes_for(r);
     const int64_t lc = lane_chunk(n, chunk, L);
     const size_t part = lc > 0 && lc < n ? align_up(nrf_render_rays_workspace_bytes(r, lc, p), 256) : 0;
@@ -721,7 +900,8 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
             if (m > rem) m = rem;
             q.ray_base = p->ray_base + i;
             const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
-            rc = nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * part, part, lane[k]);
+            rc = render_rays_impl(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, static_cast<char *>(d_workspace) + (size_t)k * part, part, lane[k], flag_of(done_chunks.size()));
+            done_chunks.push_back({i, m});
             given[k] += m;
             i += m;
         }
@@ -732,15 +912,16 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
                 (void)hipStreamSynchronize(lane[j]);
             }
         }
-        return rc;
+        return rc == NRF_OK ? settle() : rc;
     }
     for (int64_t i = 0; i < n; i += chunk) {                                                                      // :476
         const int64_t m = n - i < chunk ? n - i : (int64_t)chunk;
         q.ray_base = p->ray_base + i;
         const nrf_render_outputs o = slice_outputs(*out, i, s, so, sf, c);
-        NRF_TRY(nrf_render_rays(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, d_workspace, workspace_bytes, stream));
+        NRF_TRY(render_rays_impl(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, d_workspace, workspace_bytes, stream, flag_of(done_chunks.size())));
+        done_chunks.push_back({i, m});
     }
-    return NRF_OK;
+    return settle();
 }
 
 extern "C" int nrf_view_check(const nrf_view *v, const char *who);

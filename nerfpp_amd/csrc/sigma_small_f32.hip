@@ -60,6 +60,14 @@ __device__ __forceinline__ void sg_frag(const f32x16 &t, int q0, sg_half8 &hi, s
     for (int j = 0; j < 4; j++) sg_split_pair(fmaxf(t[q0 + 2 * j], -3.402823466e38f), fmaxf(t[q0 + 2 * j + 1], -3.402823466e38f), h.u[j], l.u[j]);
     hi = h.v; lo = l.v;
 }
+// ... of the values times a power of two (the range scale of the split-precision operands, mlp.h): the multiply is also the VALU result the asm may read
+__device__ __forceinline__ void sg_frag_scaled(const f32x16 &t, int q0, float scale, sg_half8 &hi, sg_half8 &lo)
+{
+    union { sg_half8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) sg_split_pair(t[q0 + 2 * j] * scale, t[q0 + 2 * j + 1] * scale, h.u[j], l.u[j]);
+    hi = h.v; lo = l.v;
+}
 
 constexpr int SIG_WAVES = 8;                     // 2 per SIMD: one's vector work (ReLU, swaps, the last layer) under the other's matrix chain
 constexpr int SIG_BLOCK_PTS = 64 * SIG_WAVES;    // two 32-point tiles per wave
@@ -107,7 +115,7 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[2][2])
 template <int NL, bool F32IN, bool GEO, bool A32>
 __global__ void __launch_bounds__(64 * SIG_WAVES)
 k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride, const uint8_t *__restrict__ keep, const float *__restrict__ image,
-                  float *__restrict__ sigma, sg_half8 *__restrict__ geo, int64_t geo_stride)
+                  float *__restrict__ sigma, sg_half8 *__restrict__ geo, int64_t geo_stride, const float *__restrict__ scales)
 {
     constexpr int W0_F4 = 2 * 4 * 64, W1_F4 = NL == 3 ? 2 * 8 * 64 : 0;
     __shared__ f32x4 wl[W0_F4 + W1_F4];
@@ -124,6 +132,9 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int64_t nblocks = (npts + SIG_BLOCK_PTS - 1) / SIG_BLOCK_PTS;
+    float hscale = 1.0f;
+    if constexpr (GEO) hscale = scales[SMALL_SCALE_HIDDEN];           // uniform: one scalar load
+    (void)hscale;
     // raw operand words of one block iteration: level ks of point (pt, r); lane half hh consumes feature hh
     // On this chip the fp32 matrix instruction runs on the vector ALUs' lanes (header), so every vector instruction of this kernel is time taken from the matrix pipe.
     // fp16 features: each lane half loads ITS 16-bit feature (a 2-byte load at byte offset 2 hh) instead of the packed word plus a shift and a select per value; and
@@ -187,6 +198,8 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
             return a;
         };
         // ---- GEO: rows 0..15 of the last layer for both point tiles, in split precision, stored as the colour net's operand fragment ----
+        // The exact hidden values enter the split product times 2^S_hidden and meet the last layer's weights times 2^e_last (the tail of the image is gathered from the
+        // range-scaled blob): the result is (sigma, geo_feat) x 2^S_sigma, which is what the colour net's scaled geo columns expect (mlp.h, SMALL_MAX_GROUPS)
         auto geo_out = [&](const f32x16 (&hl)[2][2]) {
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -197,7 +210,7 @@ k_sigma_small_f32(int64_t npts, const void *__restrict__ feats, int64_t pstride,
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         sg_half8 xh, xl;
-                        sg_frag(hl[pt][t], 8 * u, xh, xl);
+                        sg_frag_scaled(hl[pt][t], 8 * u, hscale, xh, xl);
                         const sg_half8 ah = wg[((2 * t + u) * 2 + 0) * 64 + lane], al = wg[((2 * t + u) * 2 + 1) * 64 + lane];
                         g = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, g, 0, 0, 0);
                         g = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, g, 0, 0, 0);
@@ -301,10 +314,10 @@ int mlp_small_sigma_f32_lm(const nrf_mlp *m, const void *feats, int f32_in, int6
     do {                                                                                                                                                             \
         constexpr bool A_ = !F_;                                                                                                                                     \
         if (A_ && a32) {                                                                                                                                             \
-            if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
-            else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
-        } else if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride); \
-        else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride);   \
+            if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride, m->d_scales); \
+            else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, A_>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride, m->d_scales); \
+        } else if (g) hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, true, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride, m->d_scales); \
+        else hipLaunchKernelGGL((k_sigma_small_f32<NL_, F_, false, false>), dim3(grid), dim3(64 * SIG_WAVES), 0, st, p, feats, pstride, keep, img, sigma, g, geo_stride, m->d_scales);   \
     } while (0)
     if (nl == 3) { if (f32_in) NRF_GO(3, true); else NRF_GO(3, false); }
     else { if (f32_in) NRF_GO(2, true); else NRF_GO(2, false); }

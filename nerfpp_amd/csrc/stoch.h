@@ -33,7 +33,8 @@ struct SigmaNoise {                        // RawNoiseStd > 0: sigma + normal*st
 
 int launch_raw2outputs(const float *raw, const float *z, const float *dirs, int d_stride, int64_t n, int s, int c, int sigma_ch, int white, float *rgb,
                        float *disp, float *acc, float *weights, float *depth, const SigmaNoise &nz, hipStream_t st, bool fast = false, const int32_t *src = nullptr,
-                       const float *raw2 = nullptr, int64_t n_split = 0);
+                       const float *raw2 = nullptr, int64_t n_split = 0, uint32_t *flag = nullptr);
+int launch_clip_embedding(const float *embeds, int embed_stride, int embed_dim, const float *weights, int64_t n, int s, float *out, hipStream_t st, uint32_t *flag = nullptr);
 int launch_fine_depths(const float *z, const float *weights, int64_t n, int s, const float *u, int64_t u_stride, const RngRef &g, int ns, int sum_vec,
                        float *zf, hipStream_t st, int32_t *src = nullptr, float *z_new = nullptr);
 int launch_jitter_z(const float *z, const float *t_rand, const RngRef &g, int64_t n, int s, float *out, hipStream_t st);

@@ -171,6 +171,10 @@ class NeRFRenderParams:               # NeRFRenderer.h:28-44 (same defaults)
     # not in the reference: how the coarse pass is evaluated when NImportance > 0 (L.NRF_COARSE_*, include/nerfpp_hip.h).  AUTO: with
     # NRF_PREC_F16_SPLIT on the HashNeRF fast path, sigma net only in exact fp32 on the matrix cores -> the fine sample set of NRF_PREC_F32
     CoarseMode: int = L.NRF_COARSE_AUTO
+    # not in the reference: what a matrix-core precision does when its network outputs are not finite (an fp16 operand left its range; L.NRF_OVERFLOW_*,
+    # include/nerfpp_hip.h).  AUTO: one host synchronisation at the end of the render call, flagged chunks rendered again in NRF_PREC_F32; DEFERRED: no
+    # synchronisation, the NEXT render call (or NeRFRenderer.nonfinite()) reports it
+    OverflowPolicy: int = L.NRF_OVERFLOW_AUTO
     # not in the reference (it draws from torch's global RNG): seed of the counter-based draws of the stochastic branches
     Seed: int = 0
 
@@ -215,6 +219,13 @@ class NeRFRenderer:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
             self._ws = torch.empty((int(nbytes),), device=device, dtype=torch.uint8)
         return self._ws
+
+    def nonfinite(self):
+        """(chunks whose matrix-core render produced non-finite network outputs, chunks rendered again in NRF_PREC_F32) since this renderer was built
+        (nrf_renderer_nonfinite: completes a pending OverflowPolicy DEFERRED check first)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().nrf_renderer_nonfinite(self._r, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- protected virtuals of the reference ----
     def RunNetwork(self, inputs, view_dirs, precision=L.NRF_PREC_F32):
@@ -269,7 +280,7 @@ class NeRFRenderer:
 
     @staticmethod
     def _params(n_samples, n_importance, cone_angle, lin_disp, perturb, white_bkgr, raw_noise_std, stochastic_preconditioning_alpha, bounding_box, precision,
-                seed, ray_base, coarse_mode):
+                seed, ray_base, coarse_mode, overflow_policy=L.NRF_OVERFLOW_AUTO):
         rp = L.RenderParams(int(n_samples), int(n_importance), int(lin_disp), int(white_bkgr), precision, ATEN_SUM_VEC)
         rp.perturb, rp.raw_noise_std, rp.precond_alpha = float(perturb), float(raw_noise_std), float(stochastic_preconditioning_alpha)
         if cone_angle is not None and (not torch.is_tensor(cone_angle) or cone_angle.numel()):
@@ -279,6 +290,7 @@ class NeRFRenderer:
             rp.bbox = (C.c_float * 6)(*_host_f32(bounding_box, 6).tolist())
         rp.seed, rp.ray_base = int(seed), int(ray_base)
         rp.coarse_mode = int(coarse_mode)
+        rp.overflow_policy = int(overflow_policy)
         return rp
 
     def _alloc_outputs(self, n, s, ni, dev, return_raw, return_weights, keep_intermediates):
@@ -347,7 +359,9 @@ class NeRFRenderer:
     def Render(self, h, w, k, render_params: NeRFRenderParams, rays=(None, None, None), c2w=None, c2w_staticcam=None, row0=0, rows=None, device="cuda"):
         """NeRFRenderer.h:530-605.  Either a pose (c2w, full image or the row tile [row0, row0+rows)) or an explicit ray batch.
         The pose branch is ONE library call (nrf_render_rows: ray generation, view directions, NDC, AABB, packing, the Chunk loop and the
-        tile's Near / Far); the ray-batch branch packs and then runs the Chunk loop in one call (nrf_batchify_rays).  Neither synchronises."""
+        tile's Near / Far); the ray-batch branch packs and then runs the Chunk loop in one call (nrf_batchify_rays).  In NRF_PREC_F32, and in the matrix-core
+        precisions with OverflowPolicy DEFERRED / IGNORE, neither synchronises; with the default policy a matrix-core render ends with one read-back of its
+        chunks' non-finite words (flagged chunks are rendered again in NRF_PREC_F32)."""
         p = render_params
         s, ni = int(p.NSamples), int(p.NImportance)
         stride = 11 if p.UseViewdirs else 8
@@ -373,7 +387,7 @@ class NeRFRenderer:
                 kk = _host_f32(k, 9)
                 cone_angle = float(np.float32((np.float32(1.0) / kk[0] + np.float32(1.0) / kk[4]) / np.float32(2.0)) * np.float32(1.1))
             rp = self._params(s, ni, cone_angle, p.LinDisp, p.Perturb, p.WhiteBkgr, p.RawNoiseStd, p.StochasticPreconditioningAlpha, p.BoundingBox, p.Precision,
-                              p.Seed, 0, p.CoarseMode)
+                              p.Seed, 0, p.CoarseMode, p.OverflowPolicy)
             res, ro = self._alloc_outputs(n, s, ni, dev, p.ReturnRaw, p.ReturnWeights, p.KeepIntermediates)
             rays_ = torch.empty((n, stride), device=dev, dtype=torch.float32)
             nf = torch.empty((2,), device=dev, dtype=torch.float32)
@@ -402,7 +416,7 @@ class NeRFRenderer:
             else:
                 L.check(lib.nrf_pack_rays(_ptr(o), _ptr(d), bb.ctypes.data_as(C.c_void_p), C.c_int64(n), int(p.UseViewdirs), _ptr(rays_), _stream()))   # :549-583
             rp = self._params(s, ni, None if p.ThinRay else cone_angle, p.LinDisp, p.Perturb, p.WhiteBkgr, p.RawNoiseStd, p.StochasticPreconditioningAlpha,
-                              p.BoundingBox, p.Precision, p.Seed, 0, p.CoarseMode)
+                              p.BoundingBox, p.Precision, p.Seed, 0, p.CoarseMode, p.OverflowPolicy)
             res, ro = self._alloc_outputs(n, s, ni, dev, p.ReturnRaw, p.ReturnWeights, p.KeepIntermediates)
             nb = lib.nrf_batchify_rays_workspace_bytes(self._r, C.c_int64(n), int(p.Chunk), C.byref(rp))
             ws = self._workspace(nb, dev)

@@ -3252,3 +3252,132 @@ def test_two_real_rccl_ranks_gather_the_single_rank_frame(tmp_path):
     assert l2["n_gpus"] == 2 and l2["ranks_seen_by_rccl"] == 2 and l2["scaling"] == "strong" and l2["tile_rows"] == 400
     assert l1["frame_sha256"] == l2["frame_sha256"] and "==" in l2["collective_check"], l2.get("collective_check")
     assert len(two.stdout.splitlines()[-1]) < 4096
+
+
+# ------------------------------------------------------------------------------------------- round 6: range-safe split precision + the non-finite word
+def _range_scene(api, mode="cu", table_amp=0.5, gain=1.6, scales=None, nlc=4):
+    """The bench's HashNeRF scene (nerfpp_amd/scene.py::make_hash_scene) with per-layer weight multipliers: {layer name: factor} on top of sigma_net_2 x 30."""
+    S, M = api.S, api.M
+    table = S.synth_hash_table(16, 19, 2, 5000, table_amp)
+    if mode == "cu":
+        emb = M.CuHashEmbedder("embedder", S.LEGO_BBOX, 16, 2, 19, 16, 512); emb.set_primes(np.array(S.CU_PRIMES[:48], np.int32)); dirs = M.CuSHEncoder("embeddirs", 3, 4)
+    else:
+        emb = M.HashEmbedder("embedder", S.LEGO_BBOX, 16, 2, 19, 16, 512); dirs = M.SHEncoder("embeddirs", 3, 4)
+    emb.set_table(table)
+    sc = {"sigma_net_2": 30.0}
+    for k, v in (scales or {}).items():
+        sc[k] = sc.get(k, 1.0) * v
+    params = S.synth_linear_stack(S.small_shapes(32, 16, 3, 64, 15, nlc, 64), 6000, gain, 0.0, sc)
+    blob = np.concatenate([a.reshape(-1) for _, a in params])
+    mlp = M.NeRFSmall(3, 64, 15, nlc, 64, False, 3, 64, 32, 16, "model", params=blob)
+    return dict(renderer=api.R.NeRFRenderer(emb, dirs, mlp), mlp=mlp, embedder=emb, bbox=S.LEGO_BBOX, blob=blob)
+
+
+def _split_vs_f32_rows(api, sc, rows=96, policy=None):
+    import copy
+    S, L = api.S, api.L
+    H = W = 800
+    K = S.lego_K(H, W); c2w = S.pose_spherical(-180.0, -30.0, 4.0)
+    rp = S.lego_render_params(sc["bbox"], 64, 128, 65536, L.NRF_PREC_F16_SPLIT)
+    if policy is not None:
+        rp.OverflowPolicy = policy
+    r0 = (H - rows) // 2
+    a = sc["renderer"].Render(H, W, K, rp, c2w=c2w, row0=r0, rows=rows).Outputs.RGBMap
+    rp32 = copy.copy(rp); rp32.Precision = L.NRF_PREC_F32; rp32.Chunk = 32768
+    b = sc["renderer"].Render(H, W, K, rp32, c2w=c2w, row0=r0, rows=rows).Outputs.RGBMap
+    return a, b
+
+
+_P2 = lambda e: 2.0 ** e
+RANGE_CASES = {
+    # the SAME function as the bench scene (the per-net products of the factors are 1): a checkpoint whose layers sit at very different magnitudes
+    "layers x 2^-8 / 2^+8 alternating": dict(scales={"sigma_net_0": _P2(-8), "sigma_net_1": _P2(8), "color_net_0": _P2(-8), "color_net_1": _P2(8), "color_net_2": _P2(-8), "color_net_3": _P2(8)}),
+    "hidden layers x 2^+6, heads x 2^-12 / 2^-18": dict(scales={"sigma_net_0": _P2(6), "sigma_net_1": _P2(6), "sigma_net_2": _P2(-12), "color_net_0": _P2(0), "color_net_1": _P2(6), "color_net_2": _P2(6),
+                                                                "color_net_3": _P2(-12)}),
+    "hidden activations beyond 65 504: first layers x 2^12, heads x 2^-24": dict(scales={"sigma_net_0": _P2(12), "sigma_net_1": _P2(12), "sigma_net_2": _P2(-24), "color_net_1": _P2(12), "color_net_2": _P2(12),
+                                                                                         "color_net_3": _P2(-24)}),
+    "hidden layers x 2^-10, heads x 2^+20 / 2^+30": dict(scales={"sigma_net_0": _P2(-10), "sigma_net_1": _P2(-10), "sigma_net_2": _P2(20), "color_net_0": _P2(-30), "color_net_1": _P2(-10), "color_net_2": _P2(-10),
+                                                                 "color_net_3": _P2(30)}),
+    # other functions: small-gain checkpoints, the reference's own table initialisation scale, every weight scaled down
+    "xavier gain 0.1 (|W| ~ 0.01, Trainable.h:33-53)": dict(gain=0.1, scales={"sigma_net_2": 3000.0, "color_net_3": 300.0}),
+    "table U 1e-4 (CuHashEmbedder.cpp:24)": dict(table_amp=1e-4, scales={"sigma_net_0": 3000.0}),
+    "all weights x 2^-8": dict(scales={**{f"sigma_net_{i}": _P2(-8) for i in range(3)}, **{f"color_net_{i}": _P2(-8) for i in range(4)}}),
+    "ngp twin, xavier gain 0.1": dict(mode="ngp", gain=0.1, scales={"sigma_net_2": 3000.0, "color_net_3": 300.0}),
+    "ngp twin, layers x 2^-8 / 2^+8 alternating": dict(mode="ngp", scales={"sigma_net_0": _P2(-8), "sigma_net_1": _P2(8), "color_net_0": _P2(-8), "color_net_1": _P2(8), "color_net_2": _P2(-8), "color_net_3": _P2(8)}),
+}
+
+
+@pytest.mark.parametrize("case", list(RANGE_CASES))
+def test_split_precision_is_range_safe(api, case):
+    """NRF_PREC_F16_SPLIT on checkpoints of unusual magnitude: the split-precision operand image is range-scaled per layer (ReLU is positively
+    homogeneous: powers of two, exact in fp32; mlp.hip k_small_scales), so weights of 0.01 or 2^12 render like weights near 1 -- every pixel of 96 rows of the 800x800
+    frame within 4e-6 of the library's own NRF_PREC_F32 mode (== the CPU oracle bit for bit), nothing flagged, nothing rendered again.  With the scaling switched off
+    (the representation of rounds 4-5) the same checkpoints lose digits or overflow: asserted for the cases where that is what the numbers say."""
+    L = api.L
+    sc = _range_scene(api, **RANGE_CASES[case])
+    a, b = _split_vs_f32_rows(api, sc)
+    assert bool(torch.isfinite(a).all())
+    err = float((a - b).abs().max())
+    assert err <= 4e-6, (case, err)
+    assert sc["renderer"].nonfinite() == (0, 0)
+    gs = (C.c_float * 12)(); ks = (C.c_float * 8)()
+    L.check(L.lib().nrf_mlp_get_split_scales(sc["mlp"]._m, gs, ks, None))
+    assert all(v > 0 and np.log2(v) == int(np.log2(v)) for v in list(gs) + list(ks)), "scales are powers of two"
+    assert any(v != 1.0 for v in gs), "this checkpoint needs scaling"
+    if "alternating" in case or "65 504" in case or "2^-10" in case:
+        L.check(L.lib().nrf_mlp_set_split_scaling(sc["mlp"]._m, 0, None))
+        a0, _ = _split_vs_f32_rows(api, sc, policy=L.NRF_OVERFLOW_IGNORE)
+        bad = (not bool(torch.isfinite(a0).all())) or float((a0 - b).abs().max()) > 1e-4
+        assert bad, "the unscaled split image is expected to lose this checkpoint"
+
+
+def test_range_scaling_leaves_ordinary_checkpoints_alone(api):
+    """Dead band: the bench scene (and its LibTorch twin) keep every exponent at 0 -- their frames are bit for bit the frames of round 5 (frame_sha256 of bench.py unchanged);
+    and the scales are a deterministic function of (blob, table): two handles of the same model agree, a table upload moves the first layer's exponent and only that."""
+    L = api.L
+    for mode in ("cu", "ngp"):
+        sc = _range_scene(api, mode=mode)
+        a, b = _split_vs_f32_rows(api, sc, rows=32)          # the first render binds the network to the grid's table RMS
+        gs = (C.c_float * 12)(); ks = (C.c_float * 8)()
+        L.check(L.lib().nrf_mlp_get_split_scales(sc["mlp"]._m, gs, ks, None))
+        assert list(gs) == [1.0] * 12 and list(ks)[:3] == [1.0] * 3, (mode, list(gs), list(ks))
+        assert float((a - b).abs().max()) <= 4e-6
+    # a table 2^12 times smaller: the first layer takes the difference, the rest of the network stays where it was
+    sc = _range_scene(api)
+    _split_vs_f32_rows(api, sc, rows=8)
+    sc["embedder"].set_table(api.S.synth_hash_table(16, 19, 2, 5000, 0.5 * 2.0 ** -12))
+    a, b = _split_vs_f32_rows(api, sc, rows=32)
+    gs = (C.c_float * 12)(); ks = (C.c_float * 8)()
+    L.check(L.lib().nrf_mlp_get_split_scales(sc["mlp"]._m, gs, ks, None))
+    assert gs[0] >= 2.0 ** 10 and list(gs)[1:3] == [1.0, 1.0], list(gs)
+    assert float((a - b).abs().max()) <= 4e-6
+
+
+def test_nonfinite_word_and_the_overflow_policies(api):
+    """nrf_render_params.overflow_policy on a checkpoint whose activations leave the fp16 range (range scaling switched off to provoke it: first layers x 2^12):
+    RERENDER (the default) returns the NRF_PREC_F32 frame bit for bit and counts the chunks it rendered again; ERROR raises NRF_ERR_NONFINITE; DEFERRED returns at once and the
+    NEXT call raises; IGNORE hands the garbage back silently (what every matrix-core render did before this round)."""
+    L = api.L
+    kw = RANGE_CASES["hidden activations beyond 65 504: first layers x 2^12, heads x 2^-24"]
+    sc = _range_scene(api, **kw)
+    L.check(L.lib().nrf_mlp_set_split_scaling(sc["mlp"]._m, 0, None))
+    a, b = _split_vs_f32_rows(api, sc, rows=40)                              # 32 000 rays: one chunk of 65 536
+    assert torch.equal(a, b), "flagged chunks are rendered again in NRF_PREC_F32: the parity mode's pixels"
+    flagged, again = sc["renderer"].nonfinite()
+    assert flagged >= 1 and again == flagged
+    with pytest.raises(L.NrfError, match="non-finite"):
+        _split_vs_f32_rows(api, sc, rows=40, policy=L.NRF_OVERFLOW_ERROR)
+    x, _ = _split_vs_f32_rows(api, sc, rows=40, policy=L.NRF_OVERFLOW_IGNORE)
+    assert not torch.equal(x, b)
+    before = sc["renderer"].nonfinite()[0]
+    S = api.S
+    rp = S.lego_render_params(sc["bbox"], 64, 128, 65536, L.NRF_PREC_F16_SPLIT); rp.OverflowPolicy = L.NRF_OVERFLOW_DEFERRED
+    sc["renderer"].Render(800, 800, S.lego_K(800, 800), rp, c2w=S.pose_spherical(-180.0, -30.0, 4.0), row0=380, rows=40)      # returns without waiting
+    torch.cuda.synchronize()
+    with pytest.raises(L.NrfError, match="EARLIER"):
+        sc["renderer"].Render(800, 800, S.lego_K(800, 800), rp, c2w=S.pose_spherical(-180.0, -30.0, 4.0), row0=380, rows=8)
+    assert sc["renderer"].nonfinite()[0] > before
+    # with the scaling back on the same checkpoint is fine under every policy
+    L.check(L.lib().nrf_mlp_set_split_scaling(sc["mlp"]._m, 1, None))
+    a, b = _split_vs_f32_rows(api, sc, rows=40, policy=L.NRF_OVERFLOW_ERROR)
+    assert float((a - b).abs().max()) <= 4e-6
