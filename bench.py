@@ -280,6 +280,25 @@ def main():
         collective_check = box.get("r", "nrf_allgather_tiles cross-check did not finish within 90 s")
         stuck = th.is_alive()                                        # a stuck collective: report what was timed and leave without tearing the group down
 
+    # data-parallel TRAINING step at N > 1 (every rank takes part; `also`): the gradient all-reduce behind the C ABI.  On a helper thread with a deadline, like the cross-check
+    dp_train = None
+    if use_dist and world > 1 and not args.no_also and not stuck:
+        import threading
+        box2 = {}
+
+        def dp_job():
+            try:
+                torch.cuda.set_device(local if args.backend == "nccl" else local % max(torch.cuda.device_count(), 1))
+                from benchlib import extras as _ex
+                box2["r"] = _ex.dp_train_step_measurement(L, scene, comm if args.backend == "nccl" else None, rank, world, sync, agree_max)
+            except Exception as e:
+                box2["r"] = dict(workload="hashnerf_train_step_dp", error=str(e)[:200])
+        th2 = threading.Thread(target=dp_job, daemon=True)
+        th2.start()
+        th2.join(timeout=180.0)
+        dp_train = box2.get("r", dict(workload="hashnerf_train_step_dp", error="did not finish within 180 s"))
+        stuck = stuck or th2.is_alive()
+
     # per-kernel times, never from the timed region: a short SINGLE-LANE pass with the event bracketing on (each kernel has the GPU to itself: `roofline`), and, when
     # the timed region ran on more lanes, a short pass on that many (the same kernels sharing the CUs: context)
     isolated = shared = None
@@ -349,6 +368,8 @@ def main():
         }
         if other is not None:
             detail["also"] = [other]
+        if dp_train is not None:
+            detail["also"] = detail.get("also", []) + [dp_train]
         if collective_check is not None:
             detail["collective_check"] = collective_check
         if cpu is not None:
@@ -367,6 +388,17 @@ def main():
         # the non-finite words of every chunk rendered by this process (matrix-core precisions; include/nerfpp_hip.h, nrf_render_params.overflow_policy)
         nf_flagged, nf_rerendered = renderer.nonfinite()
         detail["overflow_policy"] = args.overflow_policy
+        # device memory of the timed configuration on this rank (replicated per rank at N > 1): the hash table, the baked image of the render fast path, the Chunk loop's
+        # workspace, and the device's total in use (torch's pool, the library's own allocations, the runtime)
+        mem = {}
+        if args.workload == "hash":
+            tb, bb = C.c_int64(0), C.c_int64(0)
+            L.check(lib.nrf_hash_memory_bytes(sc["embedder"]._h, C.byref(tb), C.byref(bb)))
+            mem.update(hash_table=int(tb.value), baked_fast_path_image=int(bb.value))
+        mem["render_workspace"] = int(renderer._ws.numel()) if getattr(renderer, "_ws", None) is not None else 0
+        free_b, total_b = torch.cuda.mem_get_info()
+        mem["device_in_use"] = int(total_b - free_b)
+        detail["memory_bytes"] = mem
         detail["nonfinite_chunks"] = dict(flagged=nf_flagged, rerendered_in_f32=nf_rerendered)
         assert nf_flagged == 0, "a timed frame produced non-finite network outputs"
         # the gathered frame of the first pose, hashed: equal strings at different N (or launchers) = the sharded render is the single-GPU render bit for bit

@@ -390,6 +390,42 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
     return rec
 
 
+def dp_train_step_measurement(L, scene, comm, rank, world, sync, agree_max, n_rand=16384, steps=5):
+    """Data-parallel training at N > 1 (every rank calls this): one optimisation step of NeRFExecutor::Train per rank on ITS n_rand rays, the gradients averaged by
+    nrf_allreduce_grads behind the C ABI (CabiGradSync over the render path's communicator; torch.distributed's GradSync when that communicator does not exist), Adam on
+    every replica.  Weak scaling: value = world * n_rand rays per step.  Returns the record (rank 0 reports it)."""
+    import torch
+    from nerfpp_amd import renderer as R
+    from nerfpp_amd.dist import CabiGradSync, GradSync
+    from nerfpp_amd.train import Trainer
+    sc = scene.make_hash_scene(mode="cu", table_amp=1e-2, sigma_scale=4.0)
+    K = scene.lego_K(H, W); c2w = scene.pose_spherical(30.0 + 9.0 * rank, -30.0, 4.0)          # every rank its own view: its own ray batch
+    o, d, _ = R.GetRays(H, W, K, c2w)
+    idx = torch.arange(0, n_rand, device="cuda") * (H * W // n_rand)
+    o = o.reshape(-1, 3)[idx].contiguous(); d = d.reshape(-1, 3)[idx].contiguous()
+    torch.manual_seed(100 + rank)
+    tgt = torch.rand((n_rand, 3), device="cuda")
+    gs = CabiGradSync(comm) if comm is not None else GradSync(world)
+    rp = R.NeRFRenderParams(NSamples=NS, NImportance=NI, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True,
+                            BoundingBox=scene.LEGO_BBOX, Precision=L.NRF_PREC_F16_SPLIT)
+    with Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward="f16", hash_backward="binned", grad_sync=gs) as tr:
+        for _ in range(2):
+            tr.step(o, d, tgt, rp)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lm, _ = tr.step(o, d, tgt, rp)
+        sync()
+        dt = agree_max((time.perf_counter() - t0) / steps)
+        # replicas must agree: the checksum of the parameters, max - min over the ranks
+        chk = float(tr.blob.double().sum().item() + tr.table.double().sum().item())
+        spread = agree_max(chk) - (-agree_max(-chk))
+    return dict(workload="hashnerf_train_step_dp", n_gpus=world, rays_per_step=n_rand * world, samples="64+128", ms_per_step=dt * 1e3, value=n_rand * world * UNITS_PER_RAY / dt,
+                unit="ray-samples/s", steps=steps, batch="weak scaling: 16 384 rays per GPU per step", replicas_checksum_spread=spread,
+                gradient_exchange="nrf_allreduce_grads (C ABI: bucketed ncclAllReduce + scale, overflow agreement first)" if comm is not None else "torch.distributed all_reduce (GradSync)",
+                skipped_steps=int(getattr(tr, "skipped_steps", 0)))
+
+
 def full_frame_parity(sc, renderer, rp, K, c2w, args, scene, L):
     """The whole frame just timed against this library's own NRF_PREC_F32 mode (which equals the CPU oracle bit for bit -- tests/ and the 256-ray sample
     below) on identical weights and pose: every pixel value of the 800x800 frame (a 100-row band for the classic 8x256 network, whose fp32 path takes seconds per frame)."""

@@ -133,6 +133,8 @@ def compact_line(detail, stats_csv=None):
         if lanes.get("ms_per_step_by_lanes"):
             line["ms_per_step_by_lanes"] = lanes["ms_per_step_by_lanes"]
     line["profile_events_in_timed_region"] = bool((detail.get("roofline") or {}).get("profile_events_in_timed_region", False))
+    if isinstance(detail.get("memory_bytes"), dict):
+        line["memory_bytes"] = detail["memory_bytes"]
     if isinstance(detail.get("nonfinite_chunks"), dict):
         line["nonfinite_chunks"] = detail["nonfinite_chunks"].get("flagged")
         line["overflow_policy"] = detail.get("overflow_policy")

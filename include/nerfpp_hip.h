@@ -183,6 +183,9 @@ NRF_API int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float 
  * returns; a re-bake into the existing image stays asynchronous on `stream`, and its readers must be ordered behind it there. */
 NRF_API int nrf_hash_set_dense_budget(nrf_hash *h, int64_t budget_bytes, void *stream);
 NRF_API int64_t nrf_hash_get_dense_budget(const nrf_hash *h);
+/* Device memory the handle holds: the table in the mode's own type (fp16 CuHashEmbedder / fp32 HashEmbedder) and the baked image of the render fast path (dense coarse
+ * levels + the level-major copy of the hashed ones; 0 before the first upload).  Replicated on every rank of a sharded render. */
+NRF_API int nrf_hash_memory_bytes(const nrf_hash *h, int64_t *table_bytes, int64_t *baked_bytes);
 
 /* CuHashEmbedder mode: the per-level position scales mul_l (host arrays of n_levels floats).  The reference computes them ON THE DEVICE, per thread, as
  * exp2f((log2f(finest) - log2f(base)) * l / (L - 1) + log2f(base)) (CuHashEmbedder.cu:40); nrf_hash_create evaluates the same expression with the host's
@@ -635,6 +638,12 @@ NRF_API int nrf_comm_rank(const nrf_comm *c);
  * d_frames: [frames, h, w, c] on every rank.  One fused launch on `stream` (ncclAllGather per frame when h % world == 0, grouped
  * ncclBroadcast per tile otherwise); asynchronous like every other call.  d_tiles and d_frames must not overlap. */
 NRF_API int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int h, int w, int c_channels, float *d_frames, void *stream);
+/* The data-parallel TRAINING step's exchange (no reference counterpart: the reference trains on one device, NeRFExecutor.h:862-995): the n_grads fp32
+ * gradient buffers (hash table, network blob; counts[i] elements each) become their MEAN over the ranks, in place -- ncclAllReduce(sum) in slices of bucket_bytes
+ * (0: 32 MiB) as one group launch, then a multiply by 1 / world, all on `stream`.  overflow >= 0 first makes the fp16 backward's per-rank overflow report collective
+ * (all-reduce max of one word + one host read-back): *skip_out = 1 on every rank iff any rank passed a non-zero overflow, and no gradient is exchanged then (a peer's inf
+ * is never summed in; every replica skips the same optimizer step).  overflow < 0: no agreement, nothing synchronises (skip_out may be NULL).  World of one: identity. */
+NRF_API int nrf_allreduce_grads(const nrf_comm *c, float *const *d_grads, const int64_t *counts, int n_grads, int64_t bucket_bytes, int overflow, int *skip_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LeRF render pass as library calls           LeRFRenderer (LeRFRenderer.h:56-132, LeRFRenderer.cpp:85-330)

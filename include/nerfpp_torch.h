@@ -409,6 +409,25 @@ public:
 		check(nrf_allgather_tiles(Comm, tiles.data_ptr<float>(), (int)tiles.size(0), h, (int)tiles.size(2), (int)tiles.size(3), out.data_ptr<float>(), current_stream()), "nrf_allgather_tiles");
 		return out;
 	}
+	/// Data-parallel training (no reference counterpart): between `loss.backward()` and `Optimizer->step()` of NeRFExecutor::Train's loop body
+	/// (NeRFExecutor.h:923 / :985) every rank hands the gradients of its parameters over -- they become their mean over the ranks IN PLACE (nrf_allreduce_grads: bucketed
+	/// ncclAllReduce + one scale on the current stream), so all replicas take the same Adam step.  Parameters without a gradient are given a zero one first (all ranks must
+	/// pass the same buffers).  overflow: this rank's fp16-backward overflow report (HipNeRFRenderer redoes such a step in fp32 by itself: pass false); the return value is
+	/// the ranks' agreement -- true on every rank iff any rank passed true, and nothing was exchanged then (skip the optimizer step).
+	bool AllReduceGrads(std::vector<torch::Tensor> params, bool overflow = false, int64_t bucket_bytes = (int64_t)32 << 20) const
+	{
+		std::vector<float *> ptrs; std::vector<int64_t> counts; std::vector<torch::Tensor> keep;
+		for (auto &p : params) {
+			if (!p.defined() || p.numel() == 0) continue;
+			if (!p.grad().defined()) p.mutable_grad() = torch::zeros_like(p);
+			TORCH_CHECK(p.grad().is_cuda() && p.grad().scalar_type() == torch::kFloat32, "AllReduceGrads: gradients must be fp32 tensors on the GPU");
+			if (!p.grad().is_contiguous()) p.mutable_grad() = p.grad().contiguous();
+			keep.push_back(p.grad()); ptrs.push_back(keep.back().data_ptr<float>()); counts.push_back(keep.back().numel());
+		}
+		int skip = 0;
+		check(nrf_allreduce_grads(Comm, ptrs.data(), counts.data(), (int)ptrs.size(), bucket_bytes, overflow ? 1 : 0, &skip, current_stream()), "nrf_allreduce_grads");
+		return skip != 0;
+	}
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -25,6 +25,8 @@ struct nrf_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     bool owned = false;
+    // nrf_allreduce_grads: the overflow word the ranks agree on before any gradient is exchanged (device float + pinned mirror; created on first use)
+    mutable float *d_word = nullptr, *h_word = nullptr;
 };
 
 namespace nrf {
@@ -37,6 +39,7 @@ struct Rccl {
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -69,7 +72,7 @@ static void rccl_load()
     NRF_SYM(GetUniqueId, "ncclGetUniqueId"); NRF_SYM(CommInitRank, "ncclCommInitRank"); NRF_SYM(CommDestroy, "ncclCommDestroy");
     NRF_SYM(CommCount, "ncclCommCount"); NRF_SYM(CommUserRank, "ncclCommUserRank"); NRF_SYM(AllGather, "ncclAllGather");
     NRF_SYM(Broadcast, "ncclBroadcast"); NRF_SYM(GroupStart, "ncclGroupStart"); NRF_SYM(GroupEnd, "ncclGroupEnd");
-    NRF_SYM(GetErrorString, "ncclGetErrorString");
+    NRF_SYM(GetErrorString, "ncclGetErrorString"); NRF_SYM(AllReduce, "ncclAllReduce");
 #undef NRF_SYM
     r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
     if (ok) g_rccl = r;
@@ -90,6 +93,28 @@ static const Rccl *rccl()
             return NRF_ERR_HIP;                                                                          \
         }                                                                                                \
     } while (0)
+
+// ncclGroupEnd's answer, waited out when a NON-BLOCKING communicator (handed over through nrf_comm_wrap) says ncclInProgress: the group is enqueued on RCCL's helper
+// thread there, and nothing may be ordered behind the call on the stream (an event, the caller's next kernel) before the enqueue has happened -- bounded wait
+static ncclResult_t settle_group_end(const Rccl *R, const nrf_comm *c, ncclResult_t end)
+{
+    if (end == ncclInProgress && R->CommGetAsyncError) {
+        const auto t0 = std::chrono::steady_clock::now();
+        ncclResult_t q = R->CommGetAsyncError(c->comm, &end);
+        while (q == ncclSuccess && end == ncclInProgress && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            q = R->CommGetAsyncError(c->comm, &end);
+        }
+        if (q != ncclSuccess) end = q;
+    }
+    return end;
+}
+
+__global__ void k_scale_inplace(int64_t n, float f, float *__restrict__ p)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = p[i] * f;
+}
 
 static void partition(int h, int world, int rank, int *row0, int *rows)
 {
@@ -201,6 +226,8 @@ int nrf_comm_wrap(void *nccl_comm, nrf_comm **out)
 void nrf_comm_destroy(nrf_comm *c)
 {
     if (!c) return;
+    if (c->d_word) (void)hipFree(c->d_word);
+    if (c->h_word) (void)hipHostFree(c->h_word);
     if (c->owned && c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
@@ -243,20 +270,62 @@ int nrf_allgather_tiles(const nrf_comm *c, const float *d_tiles, int frames, int
             }
         }
     }
-    ncclResult_t end = R->GroupEnd();
-    if (end == ncclInProgress && R->CommGetAsyncError) {
-        // a NON-BLOCKING communicator handed over through nrf_comm_wrap: the group is enqueued on RCCL's helper thread.  Nothing may be ordered behind this call on
-        // `stream` (an event, the caller's next kernel) before the enqueue has happened, so wait for it here, with a bound.
-        const auto t0 = std::chrono::steady_clock::now();
-        ncclResult_t q = R->CommGetAsyncError(c->comm, &end);
-        while (q == ncclSuccess && end == ncclInProgress && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) {
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
-            q = R->CommGetAsyncError(c->comm, &end);
-        }
-        if (q != ncclSuccess) end = q;
-    }
+    const ncclResult_t end = settle_group_end(R, c, R->GroupEnd());
     if (first != ncclSuccess) { set_error("nrf_allgather_tiles: %s failed: %s", what, R->GetErrorString(first)); return NRF_ERR_HIP; }
     if (end != ncclSuccess) { set_error("nrf_allgather_tiles: ncclGroupEnd failed: %s", R->GetErrorString(end)); return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+
+// The data-parallel training step's exchange ("the only real collective"; 5, last row: 64 MiB of table gradient per step at L16 T2^19 F2).
+// Every rank has rendered and back-propagated ITS ray batch against the replicated model; the gradients become their mean over the ranks IN PLACE: one ncclAllReduce(sum)
+// per `bucket_bytes` slice (xGMI is point-to-point: a ring moves 2 (N - 1) / N of the payload over every link, several slices in flight keep the links busy while the
+// previous slice is reduced), all of one group launch, then one multiply by 1 / world per buffer -- on `stream`, nothing waits.
+// overflow >= 0 asks for the agreement FIRST: the fp16 backward's overflow report (nrf_mlp_backward_f16_flags) is per rank, the decision to skip the optimizer step must not
+// be -- a replica that steps while another skips, or that sums a peer's inf, ends with different parameters, moments and step counts.  The ranks all-reduce (max) one word
+// and read it back (one host synchronisation, as a loss scaler costs); *skip_out = 1 on EVERY rank iff any rank passed overflow != 0, and the gradients are then left untouched.
+int nrf_allreduce_grads(const nrf_comm *c, float *const *d_grads, const int64_t *counts, int n_grads, int64_t bucket_bytes, int overflow, int *skip_out, void *stream)
+{
+    NRF_CHECK_ARG(c && c->comm, "nrf_allreduce_grads: null communicator");
+    NRF_CHECK_ARG(n_grads >= 0 && (n_grads == 0 || (d_grads && counts)) && bucket_bytes >= 0, "nrf_allreduce_grads: bad argument");
+    NRF_CHECK_ARG(overflow < 0 || skip_out, "nrf_allreduce_grads: the overflow agreement needs skip_out");
+    for (int i = 0; i < n_grads; i++) NRF_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || d_grads[i]), "nrf_allreduce_grads: gradient %d: null buffer / negative count", i);
+    if (skip_out) *skip_out = 0;
+    if (c->world == 1) { if (skip_out) *skip_out = overflow > 0; return NRF_OK; }          // the mean over one rank
+    const Rccl *R = rccl();
+    if (!R) return NRF_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (overflow >= 0) {
+        if (!c->d_word) {
+            NRF_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_word), sizeof(float)));
+            NRF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_word), sizeof(float), hipHostMallocDefault));
+        }
+        *c->h_word = overflow ? 1.0f : 0.0f;
+        NRF_HIP(hipMemcpyAsync(c->d_word, c->h_word, sizeof(float), hipMemcpyHostToDevice, st));
+        NRF_NCCL(R, R->GroupStart());
+        const ncclResult_t e1 = R->AllReduce(c->d_word, c->d_word, 1, ncclFloat, ncclMax, c->comm, st);
+        const ncclResult_t e2 = settle_group_end(R, c, R->GroupEnd());
+        if (e1 != ncclSuccess || e2 != ncclSuccess) { set_error("nrf_allreduce_grads: the overflow agreement failed: %s", R->GetErrorString(e1 != ncclSuccess ? e1 : e2)); return NRF_ERR_HIP; }
+        NRF_HIP(hipMemcpyAsync(c->h_word, c->d_word, sizeof(float), hipMemcpyDeviceToHost, st));
+        NRF_HIP(hipStreamSynchronize(st));
+        if (*c->h_word > 0.0f) { *skip_out = 1; return NRF_OK; }
+    }
+    const int64_t bucket = bucket_bytes > 0 ? (bucket_bytes / 4 > 0 ? bucket_bytes / 4 : 1) : ((int64_t)32 << 20) / 4;          // elements; default 32 MiB
+    NRF_NCCL(R, R->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int i = 0; i < n_grads && first == ncclSuccess; i++)
+        for (int64_t off = 0; off < counts[i] && first == ncclSuccess; off += bucket) {
+            const int64_t m = counts[i] - off < bucket ? counts[i] - off : bucket;
+            first = R->AllReduce(d_grads[i] + off, d_grads[i] + off, (size_t)m, ncclFloat, ncclSum, c->comm, st);
+        }
+    const ncclResult_t end = settle_group_end(R, c, R->GroupEnd());          // closed on every path (a dangling group would swallow every later collective of this thread)
+    if (first != ncclSuccess) { set_error("nrf_allreduce_grads: ncclAllReduce failed: %s", R->GetErrorString(first)); return NRF_ERR_HIP; }
+    if (end != ncclSuccess) { set_error("nrf_allreduce_grads: ncclGroupEnd failed: %s", R->GetErrorString(end)); return NRF_ERR_HIP; }
+    const float inv = 1.0f / (float)c->world;
+    for (int i = 0; i < n_grads; i++) {
+        if (counts[i] == 0) continue;
+        hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)ceil_div(counts[i], 256)), dim3(256), 0, st, counts[i], inv, d_grads[i]);
+        NRF_LAUNCH_CHECK();
+    }
     return NRF_OK;
 }
 

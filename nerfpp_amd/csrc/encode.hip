@@ -336,6 +336,14 @@ void nrf_hash_destroy(nrf_hash *h)
     delete h;
 }
 
+int nrf_hash_memory_bytes(const nrf_hash *h, int64_t *table_bytes, int64_t *baked_bytes)
+{
+    NRF_CHECK_ARG(h, "nrf_hash_memory_bytes: null pointer");
+    if (table_bytes) *table_bytes = nrf_hash_table_elems(h) * (h->desc.mode == NRF_HASH_CU ? 2 : 4);
+    if (baked_bytes) *baked_bytes = (int64_t)h->fast_bytes;
+    return NRF_OK;
+}
+
 int nrf_hash_output_dims(const nrf_hash *h) { return h ? h->desc.n_levels * h->desc.n_features : 0; }
 int64_t nrf_hash_table_elems(const nrf_hash *h) { return h ? (int64_t)h->desc.n_levels * ((int64_t)1 << h->desc.log2_hashmap_size) * h->desc.n_features : 0; }
 

@@ -27,7 +27,10 @@ struct RocBlas {
 static RocBlas g_rb;
 static std::once_flag g_rb_once;
 static std::mutex g_rb_mu;
-static rocblas_handle g_rb_handle[64] = {};        // one per device
+// one handle per (host thread, device): a handle carries its stream (rocblas_set_stream), so two host threads that drive one GPU on their own streams -- data-parallel
+// replicas rehearsed as threads, a host that renders on one thread and trains on another -- must not share one (their products would be enqueued on each other's streams).
+// Handles live as long as the process (a host thread that ends leaves its handles behind: tens of them at most).
+static thread_local rocblas_handle g_rb_handle[64] = {};
 
 static void rb_load()
 {

@@ -118,6 +118,22 @@ class TileComm:
         ev.record(st)
         return out, TileComm._Pending(ev)
 
+    def all_reduce_grads(self, grads, overflow=None, bucket_bytes=32 << 20):
+        """nrf_allreduce_grads: the fp32 gradient tensors become their mean over the ranks IN PLACE (bucketed ncclAllReduce + one scale, on the current stream).
+        overflow: None -> no agreement, nothing synchronises, returns False; a bool -> the ranks first agree on it (one word, one read-back) and True comes back on EVERY
+        rank iff any rank passed True -- no gradient is exchanged then."""
+        gs = [g for g in grads if g is not None and g.numel()]
+        for g in gs:
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                raise L.NrfError("all_reduce_grads: gradients must be contiguous fp32 tensors on the GPU")
+        n = len(gs)
+        ptrs = (C.c_void_p * max(n, 1))(*[g.data_ptr() for g in gs])
+        counts = (C.c_int64 * max(n, 1))(*[g.numel() for g in gs])
+        skip = C.c_int(0)
+        L.check(L.lib().nrf_allreduce_grads(self._c, ptrs, counts, n, C.c_int64(int(bucket_bytes)), -1 if overflow is None else int(bool(overflow)), C.byref(skip),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return bool(skip.value)
+
     def close(self):
         if getattr(self, "_c", None):
             L.lib().nrf_comm_destroy(self._c)
@@ -173,4 +189,19 @@ class GradSync:
         inv = 1.0 / self.world
         for g in grads:
             g.mul_(inv)
+        return grads
+
+
+class CabiGradSync:
+    """GradSync's interface over the C ABI (nrf_allreduce_grads: what a C++ host calls through nrfpp::TileComm::AllReduceGrads): Trainer(grad_sync=CabiGradSync(comm)).
+    `comm` is a TileComm (one RCCL communicator per rank, shared with the render path's all-gather)."""
+
+    def __init__(self, comm, bucket_bytes=32 << 20):
+        self.comm, self.world, self.bucket_bytes = comm, int(comm.world), int(bucket_bytes)
+
+    def reduce_or_skip(self, overflow, *grads):
+        return self.comm.all_reduce_grads(grads, overflow=bool(overflow), bucket_bytes=self.bucket_bytes)
+
+    def __call__(self, *grads):
+        self.comm.all_reduce_grads(grads, overflow=None, bucket_bytes=self.bucket_bytes)
         return grads

@@ -17,9 +17,12 @@
 #include "adapter_util.h"
 #include "LeRF.h"
 
+#include <c10/hip/HIPGuard.h>
+
 #include <chrono>
 #include <iostream>
 #include <sstream>
+#include <unistd.h>
 
 using Clock = std::chrono::steady_clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
@@ -70,9 +73,9 @@ struct HashScene {
 	nrfpp::HipSHEncoder ed{nullptr};
 	NeRFSmall m{nullptr};
 	std::unique_ptr<HashRenderer> r;
-	HashScene(float table_amp, float sigma_scale, int precision)      // make_hash_scene(mode="cu", table_amp, sigma_scale)
+	HashScene(float table_amp, float sigma_scale, int precision, int log2_t = 19)      // make_hash_scene(mode="cu", table_amp, sigma_scale, log2_t)
 	{
-		const int L = 16, F = 2, T = 19;
+		const int L = 16, F = 2, T = log2_t;
 		e = nrfpp::HipHashEmbedder("embedder", bbox, L, F, T, 16, 512, NRF_HASH_CU);
 		{
 			torch::NoGradGuard ng;
@@ -394,6 +397,81 @@ static int bench_train_lerf(int steps, int64_t n_rand, const std::string &optimi
 	};
 	time_steps("lerf", "NeRFExecutor::Train's LeRF branch on HipLeRFPass::RenderBatch (HipLeRFRenderer::Render's ray-batch branch; f16x3 render)", body, steps, n_rand, optimizer, "");
 	return 0;
+}
+
+// ---- adapter_check train_dp: data-parallel training of the drop-in at world 2, the ranks being two THREADS of this process over the RCCL named by NRF_RCCL_LIBRARY
+// (tests: tests/helpers/mock_rccl.cpp -- RCCL itself refuses two ranks on one device).  Each rank: its own replica (modules, renderer, optimizer, stream) and its own
+// half of every ray batch; the loop body of NeRFExecutor::Train with ONE added statement between loss.backward() and Optimizer->step():
+// comm.AllReduceGrads(grad_vars) (nrfpp::TileComm -> nrf_allreduce_grads).  After the steps the replicas must hold the same parameters bit for bit; a third replica
+// trained WITHOUT the exchange on rank 0's half must not (the exchange happened).
+#include <thread>
+
+static int run_train_dp_impl(const std::string &optimizer)
+{
+	const int world = 2, steps = 3; const int64_t n = 1024;
+	auto [ro, rd] = ray_batch(world * n);
+	torch::manual_seed(11);
+	auto target = torch::rand({world * n, 3}).cuda();
+	char idp[128]; snprintf(idp, sizeof idp, "/tmp/nrf_train_dp_comm_%ld", (long)getpid());
+	const std::string id_path = idp;
+	std::vector<std::vector<torch::Tensor>> finals(world + 1);
+	std::vector<std::string> errors(world + 1);
+	auto rank_main = [&](int rank, bool exchange) {
+		try {
+			c10::hip::HIPStreamGuard sg(c10::hip::getStreamFromPool());
+			HashScene sc(1e-2f, 4.0f, NRF_PREC_F16_SPLIT, 14);
+			std::unique_ptr<nrfpp::TileComm> comm;
+			if (exchange) comm = std::make_unique<nrfpp::TileComm>(world, rank, id_path, 60.0, "train_dp");
+			std::vector<torch::Tensor> grad_vars;
+			for (auto &p : sc.e->parameters()) grad_vars.push_back(p);
+			for (auto &p : sc.m->parameters()) grad_vars.push_back(p);
+			auto Optimizer = make_optimizer(optimizer, grad_vars, 1e-2);
+			auto rp = lego_params(sc.bbox, (int)n, false, true, false);
+			auto o = ro.narrow(0, rank * n, n).contiguous(), d = rd.narrow(0, rank * n, n).contiguous(), tg = target.narrow(0, rank * n, n).contiguous();
+			for (int i = 0; i < steps; i++) {
+				Optimizer->zero_grad();
+				auto res = sc.r->Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()}, torch::Tensor(), torch::Tensor());
+				auto loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, tg.detach());
+				loss.backward();
+				if (comm) comm->AllReduceGrads(grad_vars);                   // the one added statement
+				Optimizer->step();
+			}
+			c10::hip::getCurrentHIPStream().synchronize();
+			for (auto &p : grad_vars) finals[exchange ? rank : world].push_back(p.detach().clone().cpu());
+		} catch (const std::exception &ex) { errors[exchange ? rank : world] = ex.what(); }
+	};
+	std::vector<std::thread> th;
+	for (int r = 0; r < world; r++) th.emplace_back(rank_main, r, true);
+	for (auto &t : th) t.join();
+	rank_main(0, false);
+	std::string note;
+	for (auto &e : errors) if (!e.empty()) { note += e.substr(0, 160) + "; "; }
+	for (auto &ch : note) if (ch == '"' || ch == '\n') ch = ' ';
+	bool same = note.empty() && finals[0].size() == finals[1].size() && !finals[0].empty(), differs_without = false;
+	double moved = 0.0;
+	if (note.empty()) {
+		for (size_t i = 0; same && i < finals[0].size(); i++) same = torch::equal(finals[0][i], finals[1][i]);
+		for (size_t i = 0; i < finals[0].size() && i < finals[world].size(); i++) if (!torch::equal(finals[0][i], finals[world][i])) differs_without = true;
+		moved = (finals[0].back() - finals[world].back()).abs().max().item<double>();
+	}
+	const bool ok = same && differs_without;
+	printf("{\"train_dp_ok\": %s, \"world\": %d, \"steps\": %d, \"rays_per_rank\": %lld, \"optimizer\": \"%s\", \"replicas_bit_identical\": %s, \"differs_from_a_replica_without_the_exchange\": %s, "
+		"\"last_layer_max_abs_diff_vs_unsynchronised\": %.3e, \"note\": \"%s\"}\n", ok ? "true" : "false", world, steps, (long long)n, optimizer.c_str(), same ? "true" : "false",
+		differs_without ? "true" : "false", moved, note.c_str());
+	fflush(stdout);
+	return ok ? 0 : 1;
+}
+
+int run_train_dp(int argc, const char **argv)
+{
+	if (!torch::cuda::is_available()) { printf("{\"train_dp_ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
+	std::streambuf *cout_buf = std::cout.rdbuf();
+	std::ostringstream quiet;
+	std::cout.rdbuf(quiet.rdbuf());
+	const int rc = run_train_dp_impl(argc > 0 ? argv[0] : "adam");
+	std::cout.rdbuf(cout_buf);
+	fflush(stdout);
+	_exit(rc);          // (a LibTorch-HIP process that has created communicators aborts in the runtimes' exit handlers: adapter_check.cpp, end of main)
 }
 
 int run_bench(int argc, const char **argv)

@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 int run_bench(int argc, const char **argv);          // adapter_bench.cpp
+int run_train_dp(int argc, const char **argv);       // adapter_bench.cpp
 
 static void stage(const char *what) { if (getenv("NRF_ADAPTER_TRACE")) { fprintf(stderr, "[adapter_check] %s\n", what); fflush(stderr); } }
 
@@ -538,6 +539,7 @@ static int run_trainfuzz(int cases, uint64_t seed)
 int main(int argc, const char **argv)
 {
 	if (argc > 1 && std::string(argv[1]) == "bench") return run_bench(argc - 2, argv + 2);
+	if (argc > 1 && std::string(argv[1]) == "train_dp") return run_train_dp(argc - 2, argv + 2);
 	if (argc > 2 && std::string(argv[1]) == "trainfuzz") return run_trainfuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "fuzz") return run_fuzz(atoi(argv[2]), argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
 	if (argc > 2 && std::string(argv[1]) == "train") return run_train(argv[2]);

@@ -2,7 +2,8 @@
 // threads of this process over tests/helpers/mock_rccl.cpp (linked in under RCCL's SONAME, so comm.hip's dlopen finds it instead of the real library, which refuses two
 // ranks on one device).  Per case: every rank fills its row tile of `frames` images with a pattern of (frame, row, column, channel), all ranks gather, every rank's
 // frames must equal the pattern everywhere -- equal tiles (one ncclAllGather per frame), unequal ones (grouped ncclBroadcasts), ranks that own no rows (h < world),
-// two gathers back to back on a stream with the tile rewritten in between.  Prints one line per case and "all ok" / "FAILED"; exit code 0 iff all pass.
+// two gathers back to back on a stream with the tile rewritten in between; then nrf_allreduce_grads at world 2..8: bucketed in-place mean of two gradient buffers against
+// host-formed values, twice in a row, and the overflow agreement (one rank reports, every rank skips, nothing is exchanged).  Prints one line per case and "all ok" / "FAILED"; exit code 0 iff all pass.
 #include "nerfpp_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -51,6 +52,54 @@ static bool rank_body(int world, int rank, const char *id, int frames, int h, in
     return ok;
 }
 
+// ---- nrf_allreduce_grads: two gradient buffers (a "table" and a "blob") become their mean over the ranks in place; expected values formed on the host in the mock's own
+// order (sum over ranks 0, 1, ... then x 1 / world: for world 2 that is (a + b) * 0.5f -- what the gloo GradSync of nerfpp_amd/dist.py computes, bit for bit).
+// `overflow_rank` >= 0: that rank reports an fp16 overflow -> every rank must come back with skip = 1 and its gradients untouched.
+static float gpat(int rank, int which, int64_t i) { return (float)((rank + 1) * (which ? 3 : 1)) * 0.25f + (float)(i % 1021) * 1e-3f - (float)((i * 7 + rank) % 13) * 0.0625f; }
+
+static bool allreduce_rank_body(int world, int rank, const char *id, int64_t n0, int64_t n1, int64_t bucket_bytes, int overflow_rank, std::atomic<int> &errors)
+{
+    HIPOK(hipSetDevice(0));
+    nrf_comm *c = nullptr;
+    if (nrf_comm_create_timeout(id, world, rank, 30.0, &c) != NRF_OK) { fprintf(stderr, "rank %d: %s\n", rank, nrf_last_error()); errors++; return false; }
+    hipStream_t st; HIPOK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int64_t counts[2] = {n0, n1};
+    float *d[2] = {nullptr, nullptr};
+    std::vector<float> h[2];
+    for (int w = 0; w < 2; w++) {
+        h[w].resize((size_t)counts[w]);
+        for (int64_t i = 0; i < counts[w]; i++) h[w][(size_t)i] = gpat(rank, w, i);
+        if (counts[w]) { HIPOK(hipMalloc(reinterpret_cast<void **>(&d[w]), (size_t)counts[w] * 4)); HIPOK(hipMemcpyAsync(d[w], h[w].data(), (size_t)counts[w] * 4, hipMemcpyHostToDevice, st)); }
+    }
+    bool ok = true;
+    for (int round = 0; round < 2 && ok; round++) {                 // round 1 reduces the already-averaged buffers again (all ranks hold the same values: the mean is themselves)
+        int skip = -1;
+        const int flag = overflow_rank < 0 ? (round == 0 ? -1 : 0) : (rank == overflow_rank ? 1 : 0);          // round 0 without the agreement (fully asynchronous), round 1 with
+        if (nrf_allreduce_grads(c, d, counts, 2, bucket_bytes, flag, &skip, st) != NRF_OK) { fprintf(stderr, "rank %d: %s\n", rank, nrf_last_error()); ok = false; break; }
+        std::vector<float> got[2];
+        for (int w = 0; w < 2; w++) { got[w].resize((size_t)counts[w]); if (counts[w]) HIPOK(hipMemcpyAsync(got[w].data(), d[w], (size_t)counts[w] * 4, hipMemcpyDeviceToHost, st)); }
+        HIPOK(hipStreamSynchronize(st));
+        if (overflow_rank >= 0) {
+            if (skip != 1) { fprintf(stderr, "rank %d: skip %d, want 1\n", rank, skip); ok = false; }
+            for (int w = 0; w < 2 && ok; w++) for (int64_t i = 0; i < counts[w]; i++) if (got[w][(size_t)i] != h[w][(size_t)i]) { fprintf(stderr, "rank %d: gradient touched although the step is skipped\n", rank); ok = false; break; }
+            continue;
+        }
+        if (skip != 0) { fprintf(stderr, "rank %d: skip %d, want 0\n", rank, skip); ok = false; }
+        for (int w = 0; w < 2 && ok; w++)
+            for (int64_t i = 0; i < counts[w]; i++) {
+                float want;
+                if (round == 0) { want = gpat(0, w, i); for (int q = 1; q < world; q++) want = want + gpat(q, w, i); want = want * (1.0f / (float)world); h[w][(size_t)i] = want; }
+                else { want = h[w][(size_t)i]; float a = want; for (int q = 1; q < world; q++) a = a + want; want = a * (1.0f / (float)world); h[w][(size_t)i] = want; }
+                if (got[w][(size_t)i] != want) { fprintf(stderr, "rank %d: buffer %d element %lld: %.9g, want %.9g (round %d)\n", rank, w, (long long)i, got[w][(size_t)i], want, round); ok = false; break; }
+            }
+    }
+    if (!ok) errors++;
+    for (int w = 0; w < 2; w++) if (d[w]) (void)hipFree(d[w]);
+    (void)hipStreamDestroy(st);
+    nrf_comm_destroy(c);
+    return ok;
+}
+
 int main()
 {
     struct Case { int world, frames, h, w, ch; };
@@ -64,6 +113,21 @@ int main()
         for (int r = 0; r < cs.world; r++) th.emplace_back([&, r] { rank_body(cs.world, r, id, cs.frames, cs.h, cs.w, cs.ch, errors); });
         for (auto &t : th) t.join();
         printf("world %d frames %d h %d w %d ch %d (%s tiles%s): %s\n", cs.world, cs.frames, cs.h, cs.w, cs.ch, cs.h % cs.world ? "unequal" : "equal", cs.h < cs.world ? ", some ranks own no rows" : "",
+               errors.load() ? "FAIL" : "ok");
+        fflush(stdout);
+        bad += errors.load() != 0;
+    }
+    struct RCase { int world; long long n0, n1, bucket; int overflow_rank; };
+    const RCase rcases[] = {{2, 1000003, 17, 1 << 20, -1}, {2, 4096, 1, 0, -1}, {3, 300001, 70000, 1 << 18, -1}, {4, 1 << 20, 18000, 1 << 20, -1}, {6, 12345, 0, 4096, -1}, {8, 100000, 5, 1 << 16, -1},
+                            {2, 5000, 7, 0, 1}, {5, 70001, 33, 1 << 16, 3}};
+    for (const RCase &rc : rcases) {
+        char id[NRF_COMM_ID_BYTES];
+        if (nrf_comm_unique_id(id) != NRF_OK) { fprintf(stderr, "%s\n", nrf_last_error()); return 2; }
+        std::atomic<int> errors{0};
+        std::vector<std::thread> th;
+        for (int r = 0; r < rc.world; r++) th.emplace_back([&, r] { allreduce_rank_body(rc.world, r, id, rc.n0, rc.n1, rc.bucket, rc.overflow_rank, errors); });
+        for (auto &t : th) t.join();
+        printf("allreduce_grads world %d counts %lld + %lld bucket %lld B%s: %s\n", rc.world, rc.n0, rc.n1, rc.bucket, rc.overflow_rank >= 0 ? " (one rank reports overflow: all skip)" : "",
                errors.load() ? "FAIL" : "ok");
         fflush(stdout);
         bad += errors.load() != 0;

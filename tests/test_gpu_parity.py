@@ -3207,6 +3207,9 @@ def test_c_abi_all_gather_at_world_sizes_above_one_with_threads_as_ranks():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and "all ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(": ok") >= 9
+    # round 6: nrf_allreduce_grads (the data-parallel training step's exchange) at world 2-8 over the same stand-in: bucketed in-place mean == host-formed values bit for bit
+    # (world 2: (a + b) * 0.5f, what the gloo GradSync computes), twice in a row, and the overflow agreement (one rank reports -> every rank skips, nothing exchanged)
+    assert out.stdout.count("allreduce_grads world") == 8 and out.stdout.count("all skip): ok") == 2, out.stdout[-2000:]
 
 
 def test_bench_step_with_the_c_abi_collective_at_world_two_threads_as_ranks():
@@ -3222,6 +3225,23 @@ def test_bench_step_with_the_c_abi_collective_at_world_two_threads_as_ranks():
     lines = [json.loads(x) for x in w.stdout.splitlines() if x.startswith("{")]
     assert w.returncode == 0 and len(lines) == 1 and lines[0]["ok"], (w.stdout[-2000:], w.stderr[-2000:])
     assert all(r["ranks_seen_by_rccl"] == 2 and r["strong"] and r["weak"] for r in lines[0]["ranks"].values())
+
+
+@pytest.mark.parametrize("h", [800, 801])
+def test_bench_step_at_world_eight_threads_as_ranks(h):
+    """The 8-GPU run the driver makes (BASELINE config 4), rehearsed on one GPU: bench.py's step function (FrameStepper) at world 8 -- eight threads as ranks over the mock RCCL,
+    each with its own replica -- for H = 800 (equal 100-row tiles: one ncclAllGather) and H = 801 (uneven tiles: the grouped broadcasts): every rank's gathered frame == the
+    single-rank render bit for bit, the tiles add up to the frame, every rank saw a world of 8 and reports its host time per tile."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, "tests", "helpers", "_build", "librccl.so.1")):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "helpers", "build_mock_rccl.sh")])
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "bench_step_threads_as_ranks.py"), "8", str(h), "64"], capture_output=True, text=True, timeout=900)
+    lines = [json.loads(x) for x in w.stdout.splitlines() if x.startswith("{")]
+    assert w.returncode == 0 and len(lines) == 1 and lines[0]["ok"], (w.stdout[-2000:], w.stderr[-2000:])
+    ranks = lines[0]["ranks"]
+    assert len(ranks) == 8 and all(r["ranks_seen_by_rccl"] == 8 and r["strong"] and r["host_ms_per_tile"] > 0 for r in ranks.values())
+    assert sorted(r["tile_rows"] for r in ranks.values()) == ([100] * 8 if h == 800 else [100] * 7 + [101])
 
 
 def test_two_real_rccl_ranks_gather_the_single_rank_frame(tmp_path):
@@ -3381,3 +3401,56 @@ def test_nonfinite_word_and_the_overflow_policies(api):
     L.check(L.lib().nrf_mlp_set_split_scaling(sc["mlp"]._m, 1, None))
     a, b = _split_vs_f32_rows(api, sc, rows=40, policy=L.NRF_OVERFLOW_ERROR)
     assert float((a - b).abs().max()) <= 4e-6
+
+
+@pytest.mark.parametrize("mlp_backward", ["f32", "f16"])
+def test_data_parallel_training_over_the_c_abi_all_reduce_threads_as_ranks(mlp_backward):
+    """Trainer(grad_sync=CabiGradSync(TileComm)) -- nrf_allreduce_grads behind the C ABI, the exchange a C++ host makes through nrfpp::TileComm::AllReduceGrads -- at world 2
+    on one GPU (threads as ranks over tests/helpers/mock_rccl.cpp): after four steps on disjoint halves of the ray batches the replicas hold the same parameters BIT FOR BIT,
+    and the first step's averaged gradient equals the gradient of one process that took the whole batch (1e-4 norm-wise in fp32; 3e-2 with the fp16 chain, whose loss scale
+    is per rank)."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, "tests", "helpers", "_build", "librccl.so.1")):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "helpers", "build_mock_rccl.sh")])
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "train_dp_threads_as_ranks.py"), mlp_backward], capture_output=True, text=True, timeout=600)
+    lines = [json.loads(x) for x in w.stdout.splitlines() if x.startswith("{")]
+    assert w.returncode == 0 and len(lines) == 1 and lines[0]["ok"], (lines, w.stderr[-1500:])
+    assert lines[0]["replicas_bit_identical"] and lines[0]["ranks_seen_by_rccl"] == 2
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "hipadam"])
+def test_drop_in_data_parallel_training_two_thread_ranks_end_with_identical_replicas(optimizer):
+    """oracle/_ref/adapter_check `train_dp`: NeRFExecutor::Train's loop body on the drop-in with ONE added statement -- nrfpp::TileComm::AllReduceGrads(grad_vars) between
+    loss.backward() and Optimizer->step() (nrf_allreduce_grads behind the C ABI) -- at world 2, the ranks being two threads over tests/helpers/mock_rccl.cpp (NRF_RCCL_LIBRARY).
+    Three steps on disjoint halves of the batches: the replicas' parameters are bit-identical, and differ from a replica trained without the exchange."""
+    import json, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check not built (needs /root/reference at build time)")
+    mock = os.path.join(ROOT, "tests", "helpers", "_build", "librccl.so.1")
+    if not os.path.exists(mock):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "helpers", "build_mock_rccl.sh")])
+    out = subprocess.run([exe, "train_dp", optimizer], capture_output=True, text=True, timeout=600, env=dict(os.environ, NRF_RCCL_LIBRARY=mock))
+    lines = [json.loads(x) for x in out.stdout.splitlines() if x.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1 and lines[0]["train_dp_ok"], (lines, out.stdout[-1500:], out.stderr[-1500:])
+    assert lines[0]["replicas_bit_identical"] and lines[0]["differs_from_a_replica_without_the_exchange"]
+
+
+def test_bench_two_rank_rehearsal_carries_the_data_parallel_training_step():
+    """`python bench.py --gpus 2 --backend gloo` WITH its `also` part (two ranks sharing this box's GPU): besides the other scaling mode every rank runs the data-parallel
+    training step (benchlib/extras.py::dp_train_step_measurement: a Trainer per rank on its own ray batch, gradients averaged before Adam -- torch.distributed here, the C-ABI
+    nrf_allreduce_grads with --backend nccl) and the line's `also` names it; the replicas' parameter checksums agree exactly after the steps."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, NRF_BENCH_TIMEOUT="900")
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
+                          "--no-isolated"], capture_output=True, text=True, timeout=1200, env=env)
+    assert two.returncode == 0, two.stderr[-2500:]
+    line = json.loads([x for x in two.stdout.splitlines() if x.startswith("{")][-1])
+    names = [a.get("workload") for a in line.get("also", [])]
+    assert "hashnerf_train_step_dp" in names and any(n.startswith("scaling_") for n in names), line.get("also")
+    side = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    dp = [a for a in side["also"] if a.get("workload") == "hashnerf_train_step_dp"][0]
+    assert "error" not in dp and dp["n_gpus"] == 2 and dp["rays_per_step"] == 32768 and dp["replicas_checksum_spread"] == 0.0 and dp["ms_per_step"] > 0, dp
