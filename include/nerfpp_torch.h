@@ -1611,12 +1611,19 @@ class HipLeRFRenderer : public LeRFRenderer {
 		SeenPos = LerfPositives; SeenNeg = LerfNegatives;
 	}
 protected:
-	torch::Tensor RunLENetwork(torch::Tensor inputs, LeRF lerf, CuHashEmbedder lang_embed_fn) override { return Pass.RunLENetwork(inputs); }
+	torch::Tensor RunLENetwork(torch::Tensor inputs, LeRF lerf, CuHashEmbedder lang_embed_fn) override { RunLENetworkCalls++; return Pass.RunLENetwork(inputs); }
 	LeRFRendererOutputs RawToLEOutputs(torch::Tensor raw_le, torch::Tensor z_vals_le, torch::Tensor rays_d, const int lang_embed_dim = 768, const float raw_noise_std = 0.f) override
 	{
-		return to_ref(Pass.RawToLEOutputs(raw_le, z_vals_le, rays_d, lang_embed_dim, raw_noise_std));
+		RawToLEOutputsCalls++;
+		SyncPrompts();
+		auto o = to_ref(Pass.RawToLEOutputs(raw_le, z_vals_le, rays_d, lang_embed_dim, raw_noise_std));
+		if (LerfPositives.defined() && LerfNegatives.defined() && LerfPositives.numel() && LerfNegatives.numel())          // LeRFRenderer.cpp:79
+			o.Relevancy = Relevancy(o.RenderedLangEmbedding, LerfPositives, LerfNegatives);
+		return o;
 	}
 public:
+	/// how often the inherited torch-op path (the RNG branches of LeRFRenderer::RenderRays) landed on the two overrides above
+	int64_t RunLENetworkCalls = 0, RawToLEOutputsCalls = 0;
 	HipLeRFRenderer(HipHashEmbedder lang_embed_fn, LeRF lerf, torch::Tensor lerf_positives = torch::Tensor(), torch::Tensor lerf_negatives = torch::Tensor(),
 		int precision = NRF_PREC_F16_SPLIT) : LeRFRenderer(CuHashEmbedder(nullptr), lerf, lerf_positives, lerf_negatives), Pass(lang_embed_fn, precision) { Pass.SyncWeights(Lerf); }
 
