@@ -132,6 +132,11 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
     except Exception as e:
         out.append(dict(workload="hashnerf_train_step", error=str(e)))
     try:
+        cpu_ref = next((r.get("cpu_reference") for r in out if isinstance(r, dict) and r.get("workload") == "hashnerf_train_step"), None)
+        out.append(train_run_measurement(scene, L, cpu_reference=cpu_ref))
+    except Exception as e:
+        out.append(dict(workload="hashnerf_train_run", error=str(e)))
+    try:
         out.append(lerf_train_step_measurement(scene, L))
     except Exception as e:
         out.append(dict(workload="lerf_train_step", error=str(e)))
@@ -387,6 +392,69 @@ def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="
                                         sample=f"{r['rays']} rays per step, LibTorch CPU HashEmbedder+SHEncoder+NeRFSmall forward+backward+Adam, {r['seconds']:.1f} s per step")
         except Exception as e:
             rec["cpu_reference"] = f"unavailable: {e}"
+    return rec
+
+
+def train_run_measurement(scene, L, iters=400, n_rand=16384, views=8, hw=400, cpu_reference=None):
+    """An END-TO-END training run as a measured workload: main.cpp's schedule -- 16 384 rays per iteration, 64 + 192 samples (main.cpp:189, 231-232), Adam
+    lr 1e-2 with the learning rate the reference's loop really has in force (constant: its decay statement updates a copy, golden train_curve), the density-noise schedule of
+    FillRenderParams (RawNoiseStd = max(0, 1 - i / (NIters / 8)), NeRFExecutor.h:411) -- of a freshly initialised student (table U 1e-4, CuHashEmbedder.cpp:24) on `views`
+    teacher-rendered hw x hw views of the bench scene.  Every iteration runs the ray-batch producer (NeRFDataset::get_batch: random pixels, rays, target gather; dataset.py)
+    and one Trainer.step (split-precision render, fused fp16 backward, binned scatter, Adam); the clock runs over all of it.  Quality: PSNR of a held-out view against the
+    teacher's render, before and after."""
+    import torch
+    from nerfpp_amd import renderer as R
+    from nerfpp_amd import dataset as D
+    from nerfpp_amd.train import Trainer
+    teacher = scene.make_hash_scene(mode="cu")
+    student = scene.make_hash_scene(mode="cu", seed=777, table_amp=1e-4, sigma_scale=1.0)
+    K = scene.lego_K(hw, hw)
+    rp_t = scene.lego_render_params(teacher["bbox"], NS, NI, 65536, L.NRF_PREC_F16_SPLIT, white_bkgr=False)
+    vs = []
+    for v in range(views + 1):                                   # the last one is held out
+        c2w = scene.pose_spherical(-180.0 + 360.0 * v / (views + 1), -30.0, 4.0)
+        img = teacher["renderer"].Render(hw, hw, K, rp_t, c2w=c2w).Outputs.RGBMap.reshape(hw, hw, 3).clone()
+        vs.append(D.View(hw, hw, K, c2w, img))
+    held = vs.pop()
+    ds = D.NeRFDataset(vs, n_rand, precorp_iters=0, seed=11)
+
+    def psnr_held():
+        rp_e = scene.lego_render_params(student["bbox"], NS, 192, 65536, L.NRF_PREC_F16_SPLIT, white_bkgr=False)
+        x = student["renderer"].Render(hw, hw, K, rp_e, c2w=held.Pose).Outputs.RGBMap.reshape(hw, hw, 3)
+        mse = float(((x - held.Image).double() ** 2).mean())
+        return -10.0 * float(np.log10(max(mse, 1e-30)))
+    rp = R.NeRFRenderParams(NSamples=64, NImportance=192, Chunk=n_rand, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=scene.LEGO_BBOX,
+                            Precision=L.NRF_PREC_F16_SPLIT)
+    with Trainer(student["embedder"], student["embeddirs"], student["mlp"], student["table"], student["mlp_blob"], learning_rate=1e-2, mlp_backward="f16", hash_backward="binned") as tr:
+        psnr0 = psnr_held()
+        losses = []
+
+        def one(i):
+            ds.SetCurrentIter(i)
+            b = ds.get_batch()
+            rp.RawNoiseStd = max(0.0, 1.0 - float(i) / (float(iters) / 8.0))                     # FillRenderParams, NeRFExecutor.h:411
+            lm, _ = tr.step(b["rays_o"], b["rays_d"], b["target_s"], rp)
+            return lm
+        for i in range(3):                                        # untimed: first-use allocations
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + iters):
+            losses.append(one(i))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        skipped = int(getattr(tr, "skipped_steps", 0))
+    # (leaving the `with` gives the student its full baked image back: the evaluation render below is the render fast path)
+    psnr1 = psnr_held()
+    l = [float(x[0]) for x in (losses[0], losses[len(losses) // 2], losses[-1])]
+    rec = dict(workload="hashnerf_train_run", iterations=iters, rays_per_iteration=n_rand, samples="64+192", views=views, view_size=[hw, hw], seconds=dt, ms_per_step=dt / iters * 1e3,
+               value=n_rand * 256 * iters / dt, unit="ray-samples/s (64 + 192 = 256 per ray)", rays_per_s=n_rand * iters / dt, iterations_per_s=iters / dt,
+               loss_first_mid_last=l, psnr_held_out_view_before_after_db=[psnr0, psnr1], skipped_steps=skipped,
+               includes="ray-batch producer (random pixels + rays + target gather) + render + huber + backward + Adam, every iteration",
+               schedule="main.cpp:189,231-232 (16 384 rays, 64 + 192), lr 1e-2 constant (the reference's decay loop updates a copy: golden train_curve), RawNoiseStd per FillRenderParams")
+    if isinstance(cpu_reference, dict) and cpu_reference.get("rays_per_s"):
+        rec["cpu_reference"] = dict(iterations_per_s=cpu_reference["rays_per_s"] / n_rand, rays_per_s=cpu_reference["rays_per_s"], kind="reference", cores=cpu_reference.get("cores"),
+                                    sample=cpu_reference.get("sample"))
     return rec
 
 

@@ -979,6 +979,104 @@ static int run_bench_train(int argc, const char **argv)
 }
 
 // ----------------------------------------------------------------------------------------------
+// train_curve: FIFTY optimisation steps of NeRFExecutor::Train's loop body (NeRFExecutor.h:862-996) on the reference's own modules and autograd -- HashEmbedder L16 F2 T2^12
+// (16..128) + SHEncoder(4) + NeRFSmall 3x64 / 3x64, torch::optim::Adam(lr 1e-2, betas (0.9, 0.99), eps 1e-15), the learning-rate decay of :992-996 -- fitting a student to
+// four 24 x 24 views rendered by a teacher of the same architecture (the reference's own Render, 32 + 32 samples).  Step i trains on 192 pixels of view i % 4:
+// pixel index (131 i + 29 j) % 576, j < 192 (a closed form: the test regenerates every batch from GetRays, which is bit-exact against golden `rays`).  Emitted: the teacher
+// images, the per-step huber loss and mse, the learning rate in force after every step next to the one :994 computes (they differ: see the loop), the first batch (rays,
+// targets) as a check of the batch rule.  The TotalVariationLoss term
+// (:896-913) is left out: its cube origins come from torch::randint on the global generator.
+// ----------------------------------------------------------------------------------------------
+static void g_train_curve()
+{
+	const std::string tag = "train_curve";
+	const int h = 24, w = 24, ns = 32, ni = 32, steps = 50, nrays = 192, nviews = 4;
+	auto k = lego_K(h, w);
+	auto bbox = lego_bbox();
+	const float thetas[nviews] = {-120.f, -30.f, 60.f, 150.f};
+	SHEncoder ed("embeddirs", 3, 4);
+	auto rp = lego_params(ns, ni, 4096);
+	rp.WhiteBkgr = false; rp.ReturnRaw = false;
+	// the teacher and its four views
+	std::vector<torch::Tensor> img, ro, rd;
+	{
+		torch::NoGradGuard ng;
+		HashEmbedder te("embedder", bbox, 16, 2, 12, 16, 128);
+		NeRFSmall tm(3, 64, 15, 3, 64, false, 3, 64, 32, 16, "model");
+		fill_module(tag + "_teacher", te, 5000u, 0.5f, 0.f);
+		fill_module(tag + "_teacher", tm, 6000u, 1.6f, 0.f, {{"sigma_net_2", 6.0f}});
+		NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> tr(te, ed, tm);
+		for (int v = 0; v < nviews; v++)
+		{
+			auto c2w = orbit_pose(thetas[v], -30.f, 4.f);
+			auto [o, d, cone] = GetRays(h, w, k, c2w);
+			auto res = tr.Render(h, w, k, rp, {torch::Tensor(), torch::Tensor(), torch::Tensor()}, c2w);
+			img.push_back(res.Outputs.RGBMap.reshape({-1, 3}).contiguous()); ro.push_back(o.reshape({-1, 3}).contiguous()); rd.push_back(d.reshape({-1, 3}).contiguous());
+		}
+	}
+	save_npy(tag + ".teacher_images", torch::stack(img, 0));
+	save_npy(tag + ".thetas", torch::from_blob(const_cast<float *>(thetas), {nviews}).clone());
+	save_npy(tag + ".dims", torch::tensor({h, w, ns, ni, steps, nrays, nviews}, torch::kInt32));
+	save_npy(tag + ".bbox", bbox);
+	// the student, trained twice: with LibTorch's default intra-op thread count and with ONE thread.  The two runs start from the same bits and see the same batches; they
+	// differ only in the order MKL / at::sum add things up -- the reference's own sensitivity to rounding (Adam with eps 1e-15 turns a rounding-level gradient into a whole
+	// step; a fine sample that changes CDF bin moves a pixel), which is the yardstick the HIP Trainer's curve is held to (tests: test_training_loss_curve_*)
+	const float LearningRate = 1e-2f, LRateDecay = 0.1f;		//decay_steps = 100
+	save_npy(tag + ".lr0_lrate_decay", torch::tensor({LearningRate, LRateDecay}));
+	const int default_threads = at::get_num_threads();
+	for (int run = 0; run < 2; run++)
+	{
+		at::set_num_threads(run == 0 ? default_threads : 1);
+		std::ofstream devnull("/dev/null");
+		if (run == 1) g_manifest.swap(devnull);			//the second student's fill_module lines would repeat the first's
+		HashEmbedder e("embedder", bbox, 16, 2, 12, 16, 128);
+		NeRFSmall m(3, 64, 15, 3, 64, false, 3, 64, 32, 16, "model");
+		fill_module(tag, e, 7770u, 1e-2f, 0.f);
+		fill_module(tag, m, 8880u, 1.6f, 0.f);
+		if (run == 1) g_manifest.swap(devnull);
+		std::vector<torch::Tensor> grad_vars;
+		for (auto &p : e->parameters()) grad_vars.push_back(p);
+		for (auto &p : m->parameters()) grad_vars.push_back(p);
+		torch::optim::Adam opt(grad_vars, torch::optim::AdamOptions(LearningRate).eps(1e-15).betas(std::make_tuple(0.9, 0.99)));		//NeRFExecutor.h:539
+		NeRFRenderer<HashEmbedder, SHEncoder, NeRFSmall> renderer(e, ed, m);
+		std::vector<float> losses, mses, lrs;
+		int global_step = 0;
+		for (int i = 0; i < steps; i++)
+		{
+			const int v = i % nviews;
+			std::vector<int64_t> idx(nrays);
+			for (int j = 0; j < nrays; j++) idx[j] = (131ll * i + 29ll * j) % (h * w);
+			auto it = torch::from_blob(idx.data(), {nrays}, torch::kLong).clone();
+			auto o = ro[v].index_select(0, it), d = rd[v].index_select(0, it), target = img[v].index_select(0, it);
+			if (i == 0 && run == 0) { save_npy(tag + ".s0_rays_o", o); save_npy(tag + ".s0_rays_d", d); save_npy(tag + ".s0_target", target); }
+			opt.zero_grad();																																														//:866
+			auto res = renderer.Render(0, 0, torch::Tensor(), rp, {o, d, torch::Tensor()});																						//:876
+			auto mse_loss = torch::mse_loss(res.Outputs.RGBMap, target.detach());																									//:882
+			auto img_loss = torch::nn::functional::huber_loss(res.Outputs.RGBMap, target.detach());																//:883
+			auto loss = img_loss;
+			loss.backward();																																																			//:923
+			opt.step();																																																						//:985
+			const int decay_steps = (int)(LRateDecay * 1000);																																			//:992-996
+			const float new_lrate = LearningRate * powf(0.1f, (float)global_step / decay_steps);
+			for (auto param_group : opt.param_groups())				//:995-996 VERBATIM, `auto` by value included: OptimizerParamGroup's copy constructor CLONES the options, so set_lr
+				param_group.options().set_lr(new_lrate);				//lands on the copy and the optimizer's learning rate never changes -- what the reference does is what the golden records
+			global_step++;
+			losses.push_back(loss.item<float>()); mses.push_back(mse_loss.item<float>());
+			lrs.push_back((float)static_cast<torch::optim::AdamOptions &>(opt.param_groups()[0].options()).lr()); lrs.push_back(new_lrate);
+		}
+		const std::string sfx = run == 0 ? "" : "_one_thread";
+		save_npy(tag + ".loss" + sfx, torch::from_blob(losses.data(), {steps}).clone());
+		save_npy(tag + ".mse" + sfx, torch::from_blob(mses.data(), {steps}).clone());
+		if (run == 0)
+		{
+			save_npy(tag + ".lr_in_force_and_lr_computed", torch::from_blob(lrs.data(), {steps, 2}).clone());		//[:, 0] the optimizer's lr after the step, [:, 1] the value :994 computed
+			save_npy(tag + ".threads", torch::tensor({default_threads, 1}, torch::kInt32));
+		}
+	}
+	at::set_num_threads(default_threads);
+}
+
+// ----------------------------------------------------------------------------------------------
 // N3: checkpoint interchange (NeRFExecutor::SaveCheckpoint / LoadCheckpoint, NeRFExecutor.h:540-566, :1055-1070).
 //   ckpt_save <dir> : torch::save the train_hash-sized HashEmbedder / NeRFSmall (+ start step) exactly as SaveCheckpoint does, plus a
 //                     module carrying CuHashEmbedder's registered names (CuHashEmbedder.cpp:24,73-76; the class itself needs CUDA)
@@ -1097,6 +1195,7 @@ int main(int argc, const char **argv)
 	g_train();
 	g_train_classic();
 	g_train_lerf();
+	g_train_curve();
 	g_tv();
 	g_manifest.close();
 	std::cout << "golden vectors written to " << g_outdir << std::endl;
