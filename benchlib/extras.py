@@ -137,11 +137,11 @@ def secondary_measurements(args, scene, L, K, c2w, sc_main, steps=10):
     except Exception as e:
         out.append(dict(workload="hashnerf_train_run", error=str(e)))
     try:
-        out.append(lerf_train_step_measurement(scene, L))
+        out.append(_with_train_gemm(L, lambda: lerf_train_step_measurement(scene, L)))
     except Exception as e:
         out.append(dict(workload="lerf_train_step", error=str(e)))
     try:
-        out.append(classic_train_step_measurement(scene, L))
+        out.append(_with_train_gemm(L, lambda: classic_train_step_measurement(scene, L)))
     except Exception as e:
         out.append(dict(workload="classic_train_step", error=str(e)))
     for lp in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA):
@@ -282,6 +282,21 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
         rec["oracle_check"] = lerf_oracle_check(sc, res)
     except Exception as e:
         rec["oracle_check"] = f"unavailable: {e}"
+    return rec
+
+
+def _with_train_gemm(L, fn):
+    """fn() under both arithmetics of the training paths' layer products: bf16x3 (the fast mode: the record's headline) and fp32 (the parity-grade default)."""
+    prev = L.lib().nrf_get_train_gemm()
+    try:
+        L.check(L.lib().nrf_set_train_gemm(1))
+        rec = fn()
+        rec["train_gemm"] = "bf16x3 split-precision matrix-core products, bias / ReLU / ReLU-mask fused (gemm_bf16x3.hip); weight-gradient products: rocBLAS sgemm"
+        L.check(L.lib().nrf_set_train_gemm(0))
+        r32 = fn()
+        rec["fp32_products"] = dict(ms_per_step=r32["ms_per_step"], loss_first_last=r32["loss_first_last"], what="rocBLAS sgemm + separate bias / ReLU / mask passes (the parity-grade default)")
+    finally:
+        L.check(L.lib().nrf_set_train_gemm(prev))
     return rec
 
 

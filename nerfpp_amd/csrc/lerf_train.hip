@@ -490,13 +490,17 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     NRF_LAUNCH_CHECK();
     }
     // ---- LE net backward (last layer first)                                                        LeRF.cpp:97-103 ----
+    // (bf16x3 products: the ReLU mask of the NEXT stage is applied by the back-propagation product's epilogue -- `premasked` -- instead of by a pass of its own)
+    const bool fuse = run_backprop_fuses_mask(c);
+    bool premasked = false;
     for (int l = l_top; l >= nl; l--) {
         const LinearLayer &L = m->layers[l];
-        if (l != NL - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
+        if (l != NL - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
         NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st));
         float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
-        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
+        premasked = fuse && !first;                          // dst = d / d H[l - 1], a ReLU output
+        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, premasked ? H[l - 1] : nullptr, W));
         g = Seg{dst, W, 0, L.in};
     }
     // g = d / d cat[geo, in]: the sigma net's output gradient = (g_sigma [already in g33 column 0], g_geo)
@@ -508,13 +512,15 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     float *freeb[2]; int nf = 0;
     for (int q = 1; q < 4 && nf < 2; q++) if (G[q] != g_x0) freeb[nf++] = G[q];
     int fi = 0;
+    premasked = false;
     for (int l = nl - 1; l >= 0; l--) {
         const LinearLayer &L = m->layers[l];
-        if (l != nl - 1) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
+        if (l != nl - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         NRF_TRY(run_grad_w_fast(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
         if (l == 0 && !g_emb) break;
         float *dst = freeb[fi]; fi ^= 1;
-        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
+        premasked = fuse && l >= 1;                          // dst = d / d H[l - 1]
+        NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, premasked ? H[l - 1] : nullptr, W));
         g = Seg{dst, W, 0, L.in};
     }
     if (g_emb) {                                                           // d / d emb = through the sigma net + through the LE net's cat[geo, in]

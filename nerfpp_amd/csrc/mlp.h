@@ -103,8 +103,13 @@ int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act,
 // (gemm_f32.hip); the weights are read from the handle's blob m->d_params
 int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
-int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st);
+// mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
+int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0);
+bool run_backprop_fuses_mask(int64_t npts);
 int fp32_gemm_available();
+// gemm_bf16x3.hip: the same two products (forward, back-propagation) as split-precision bf16 matrix-core GEMMs with the bias / ReLU / ReLU-mask epilogues fused
+int train_gemm_mode();               // 1: bf16x3 (default), 0: fp32 products (NRF_TRAIN_GEMM=f32, nrf_set_train_gemm(0))
+int gemm_nt_bf16x3(int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld, hipStream_t st);
 int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc);
 
 // matrix-core paths (separate translation units)

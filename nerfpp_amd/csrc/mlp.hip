@@ -463,7 +463,7 @@ static size_t mlp_nerf_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
 {
     const int64_t c = p < BWD_CHUNK ? p : BWD_CHUNK;
     const int pad = m->nerf.input_ch > m->nerf.input_ch_views ? m->nerf.input_ch : m->nerf.input_ch_views;
-    return align_up((size_t)c * (m->max_width + pad) * sizeof(float), 256) * (m->nerf.depth + 7);
+    return align_up((size_t)c * (size_t)((m->max_width + pad + 7) & ~7) * sizeof(float), 256) * (m->nerf.depth + 7);
 }
 
 int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes,
@@ -472,7 +472,9 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
     if (ws_bytes < mlp_nerf_backward_workspace_bytes(m, p)) { set_error("nrf_mlp_backward: workspace %zu < %zu bytes", ws_bytes, mlp_nerf_backward_workspace_bytes(m, p)); return NRF_ERR_WORKSPACE; }
     const auto &d = m->nerf;
     const int D = d.depth, Wd = d.width, in = d.input_ch, iv = d.input_ch_views;
-    const int W = m->max_width + (in > iv ? in : iv);       // row stride of every scratch buffer (the widest row: cat[input_pts, h] / cat[feature, views])
+    // row stride of every scratch buffer: the widest row (cat[input_pts, h] / cat[feature, views]), rounded up to 8 floats so that every row starts 32-byte aligned (the
+    // matrix-core products of gemm_bf16x3.hip load rows with 16-byte vectors)
+    const int W = (m->max_width + (in > iv ? in : iv) + 7) & ~7;
     const size_t buf = align_up((size_t)(p < BWD_CHUNK ? p : BWD_CHUNK) * W * sizeof(float), 256) / sizeof(float);
     float *base = reinterpret_cast<float *>(ws);
     std::vector<float *> H(D);
@@ -537,9 +539,12 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         }
         // ---- pts_linears, last first ----
         float *gcur = gh;
+        const bool fuse = run_backprop_fuses_mask(c);          // bf16x3 products: the next stage's ReLU mask in the back-propagation product's epilogue
+        bool premasked = false;
         for (int l = D - 1; l >= 0; l--) {
             const LinearLayer &L = m->layers[l];
-            NRF_TRY(run_relu_mask(c, Wd, gcur, W, H[l], W, st));
+            if (!premasked) NRF_TRY(run_relu_mask(c, Wd, gcur, W, H[l], W, st));
+            premasked = false;
             const Seg g{gcur, W, 0, Wd};
             const bool cat = (l > 0) && (l - 1 == d.skip);                                                             // this layer's input is cat[input_pts, h_{l-1}]
             const Seg a = (l == 0) ? xin : (cat ? xin : Seg{H[l - 1], W, 0, Wd});
@@ -548,7 +553,9 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_grad_b(c, g, Wd, bias_of(L), st));
             if (l == 0 && !g_x) break;
             float *dst = (gcur == G[1]) ? G[2] : G[1];
-            NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
+            const bool mask_next = fuse && l > 0 && !cat;          // dst = d / d H[l - 1] (with the skip concat the h part sits at a column offset: masked by its own pass)
+            NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, mask_next ? H[l - 1] : nullptr, W));
+            premasked = mask_next;
             if (l == 0) NRF_TRY(add_gx(dst, W, 0));
             else if (cat) {
                 NRF_TRY(add_gx(dst, W, 0));

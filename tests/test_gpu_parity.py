@@ -3556,3 +3556,64 @@ def test_end_to_end_training_run_measurement(api):
     l0, lm, l1 = rec["loss_first_mid_last"]
     p0, p1 = rec["psnr_held_out_view_before_after_db"]
     assert l1 < 0.5 * l0 and p1 > p0 + 8.0, rec
+
+
+# ------------------------------------------------------------------------------------------- round 6: bf16x3 split-precision training products
+@pytest.mark.parametrize("M,N,K", [(70000, 256, 256), (33000, 256, 160), (5000, 128, 283), (4097, 33, 256), (777, 70, 63), (300, 3, 128)])
+def test_gemm_nt_bf16x3_vs_float64(api, M, N, K):
+    """nrf_gemm_nt_bf16x3 (gemm_bf16x3.hip: every fp32 operand as hi + lo bf16, three matrix-core products per fp32 accumulator) against the float64 product: within 2e-5 of
+    the largest entry (measured 5e-6; torch's fp32 product 8e-7), bias + ReLU epilogue included; ragged M / N / K (row, column and K-tile tails), the whole-row kernel's
+    shapes (K in {128, 160, 256}, N > 128) and the generic one's."""
+    L = api.L
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)
+    a = torch.randn((M, K), device="cuda", generator=g); b = torch.randn((N, K), device="cuda", generator=g) * 0.1; bias = torch.randn((N,), device="cuda", generator=g)
+    c = torch.full((M, N), float("nan"), device="cuda")
+    L.check(L.lib().nrf_gemm_nt_bf16x3(C.c_void_p(a.data_ptr()), K, C.c_int64(M), K, C.c_void_p(b.data_ptr()), K, N, C.c_void_p(c.data_ptr()), N, C.c_void_p(bias.data_ptr()), 1, None))
+    want = torch.relu(a.double() @ b.double().t() + bias.double())
+    assert bool(torch.isfinite(c).all())
+    err = float((c.double() - want).abs().max() / want.abs().max())
+    assert err < 2e-5, err
+
+
+def test_classic_and_lerf_train_steps_in_bf16x3_mode_follow_the_fp32_chain(api):
+    """nrf_set_train_gemm(1): the classic NeRFImpl backward and the LeRF head backward with their forward / back-propagation products on the bf16 matrix cores (bias, ReLU and
+    the next stage's ReLU mask fused into the products' epilogues).  Against the SAME step with fp32 products (the default, which the goldens hold to the reference's
+    autograd): every parameter-gradient tensor within 3e-3 of its largest entry, the loss identical (the render is the same), nothing non-finite."""
+    L, S, R = api.L, api.S, api.R
+    from nerfpp_amd.train import Trainer, LeRFTrainer
+    K = S.lego_K(200, 200); c2w = S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(200, 200, K, c2w)
+    o = o.reshape(-1, 3)[::20][:1500].contiguous(); d = d.reshape(-1, 3)[::20][:1500].contiguous()
+    tgt = torch.rand((o.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    prev = L.lib().nrf_get_train_gemm()
+    try:
+        grads = {}
+        for mode in (0, 1):
+            L.check(L.lib().nrf_set_train_gemm(mode))
+            sc = S.make_classic_scene()
+            tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], None, sc["mlp_blob"], learning_rate=5e-4)
+            rp = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=2048, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX,
+                                    Precision=L.NRF_PREC_F32)
+            lm, _ = tr.step(o, d, tgt, rp)
+            grads[mode] = (tr.g_blob.clone(), float(host(lm)[0]))
+        g0, g1 = grads[0][0], grads[1][0]
+        assert grads[0][1] == grads[1][1] and bool(torch.isfinite(g1).all())
+        assert float((g1 - g0).abs().max() / g0.abs().max()) < 3e-3
+        assert float((g1 - g0).norm() / g0.norm()) < 1e-3
+        # LeRF head + language grid
+        lg = {}
+        tl = torch.nn.functional.normalize(torch.randn((o.shape[0], 768), device="cuda", generator=torch.Generator(device="cuda").manual_seed(6)), dim=-1)
+        for mode in (0, 1):
+            L.check(L.lib().nrf_set_train_gemm(mode))
+            sc = S.make_lerf_scene(log2_t=14)
+            p = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+            tr = LeRFTrainer(sc["renderer"], sc["table"], sc["blob"], learning_rate=1e-3)
+            l, _ = tr.step(o, d, tl, p)
+            lg[mode] = (tr.g_blob.clone(), tr.g_table.clone(), float(host(l)[0]))
+            tr.close()
+        assert lg[0][2] == lg[1][2]
+        for i in (0, 1):
+            a, b = lg[1][i], lg[0][i]
+            assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 2e-3, i
+    finally:
+        L.check(L.lib().nrf_set_train_gemm(prev))
