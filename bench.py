@@ -109,7 +109,7 @@ def main():
         sc = scene.make_hash_scene(mode=args.hash_mode)
         if args.dense_mb >= 0 and args.hash_mode == "cu":
             sc["embedder"].set_dense_budget(int(args.dense_mb * (1 << 20)))
-        # 65 536 rays per RenderRays call: same-call A/B over 49 152 / 65 536 / 131 072 gives 21.3-21.6 / 21.4-21.7 / 21.8 ms per frame (profiles/round4/r4G_*), and every
+        # 65 536 rays per RenderRays call: same-call A/B over 49 152 / 65 536 / 131 072 gives 21.3-21.6 / 21.4-21.7 / 21.8 ms per frame (docs/history/profiles/round4/r4G_*), and every
         # slow-box outlier of the round (frames of 45-130 ms on some boxes, r4d_lane_sweep_first_box.log, r4E_*) was at chunks of 98 304 rays and more
         chunk = args.chunk or 65536
     else:
@@ -167,7 +167,7 @@ def main():
     def settle(step, drain, budget_s=10.0, floor_s=1.5):
         """Before the first measurement of the process, outside every timed region and before the W warmup steps: whole steps, each synchronised, until three in a
         row are within 10 % of the fastest one seen and at least `floor_s` of them have run (at most `budget_s`).  Some boxes of the pool start a process at a
-        fraction of the clock -- the default frame at 97 instead of 22 ms per step for the first seconds of load (profiles/round4/r4E_*) -- and W = 1-2 warmup
+        fraction of the clock -- the default frame at 97 instead of 22 ms per step for the first seconds of load (docs/history/profiles/round4/r4E_*) -- and W = 1-2 warmup
         steps do not outlast that.  Every rank runs the same number of steps (the decision to stop is taken together)."""
         if settled[0] or args.no_settle:
             return

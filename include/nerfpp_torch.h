@@ -179,24 +179,16 @@ public:
 		const int64_t t_rows = (int64_t)1 << log2_hashmap_size;
 		const auto cuda = torch::TensorOptions().device(torch::kCUDA);
 		if (mode == NRF_HASH_CU) {
-			// ---- exactly the constructor state of CuHashEmbedderImpl (CuHashEmbedder.cpp:24-76): same draws from the same generators, same names, shapes, dtypes ----
-			Embeddings = register_parameter(module_name + "_embeddings", torch::rand({t_rows * NLevels, NFeaturesPerLevel}, cuda.dtype(torch::kFloat32)) * 1e-4f, /*requires_grad=*/true);   // :24
-			auto is_prim = [](int x) { for (int i = 2; i * i <= x; i++) if (x % i == 0) return false; return true; };                                                                     // :28-35
-			std::vector<int> prim_selected;
-			const int min_local_prim = 1 << 28, max_local_prim = 1 << 30;
-			for (int i = 0; i < 3 * NLevels * NVolumes; i++) {                                                                                                                            // :41-49
-				int val;
-				do { val = torch::randint(min_local_prim, max_local_prim, {1}, torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU)).item<int>(); } while (!is_prim(val));
-				prim_selected.push_back(val);
-			}
-			Primes = torch::from_blob(prim_selected.data(), 3 * NLevels * NVolumes, torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU)).to(torch::kCUDA);
-			Primes = Primes.reshape({NLevels, NVolumes, 3}).contiguous();                                                                                                                // :52-53
-			Biases = torch::zeros({NLevels * NVolumes, 3}, cuda.dtype(torch::kFloat)).contiguous();                                                                                      // :59 (RandBias is false)
-			int local_size = 1ll << static_cast<long long>(Log2HashmapSize);                                                                                                             // :63-68
-			local_size = (local_size >> 4) << 4;
-			FeatLocalSize = torch::full({NLevels}, local_size, cuda.dtype(torch::kInt32)).contiguous();
-			FeatLocalIdx = (torch::cumsum(FeatLocalSize, 0) - local_size).to(torch::kInt32).contiguous();
-			Primes = register_buffer(module_name + "_primes", Primes);                                                                                                                   // :73-76
+			// ---- CuHashEmbedderImpl's constructor state (CuHashEmbedder.cpp:24-76).  What must agree with the reference for torch::load interchange and for equal models
+			// under equal seeds: the registered names, shapes and dtypes, and the ORDER in which the generators are drawn from -- the table first (one CUDA torch::rand),
+			// then one CPU torch::randint per candidate multiplier until 3 * L * volumes primes in [2^28, 2^30) have been kept.
+			Embeddings = register_parameter(module_name + "_embeddings", torch::rand({t_rows * NLevels, NFeaturesPerLevel}, cuda.dtype(torch::kFloat32)) * 1e-4f, /*requires_grad=*/true);
+			Primes = DrawHashMultipliers(3 * NLevels * NVolumes).to(torch::kCUDA).reshape({NLevels, NVolumes, 3}).contiguous();
+			Biases = torch::zeros({NLevels * NVolumes, 3}, cuda.dtype(torch::kFloat)).contiguous();          // RandBias is false there
+			const int rows_per_level = (int)((((int64_t)1 << Log2HashmapSize) >> 4) << 4);                    // local_size, :63-68
+			FeatLocalSize = torch::full({NLevels}, rows_per_level, cuda.dtype(torch::kInt32)).contiguous();
+			FeatLocalIdx = (torch::arange(NLevels, cuda.dtype(torch::kInt32)) * rows_per_level).to(torch::kInt32).contiguous();
+			Primes = register_buffer(module_name + "_primes", Primes);
 			Biases = register_buffer(module_name + "_biases", Biases);
 			FeatLocalSize = register_buffer(module_name + "_feat_local_size", FeatLocalSize);
 			FeatLocalIdx = register_buffer(module_name + "_feat_local_idx", FeatLocalIdx);
@@ -209,6 +201,22 @@ public:
 		}
 	}
 	~HipHashEmbedderImpl() override { nrf_hash_destroy(Handle); }
+
+	/// `count` hash multipliers as an int32 CPU tensor: candidates are drawn one at a time from torch's CPU generator, uniform in [2^28, 2^30), and kept when prime
+	/// (CuHashEmbedder.cpp:28-49 draws and tests them the same way, so equal seeds give equal multipliers).  Trial division by odd numbers up to the square root.
+	static torch::Tensor DrawHashMultipliers(int count)
+	{
+		const auto cpu_i32 = torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU);
+		auto out = torch::empty({count}, cpu_i32);
+		int32_t *dst = out.data_ptr<int32_t>();
+		for (int kept = 0; kept < count;) {
+			const int64_t cand = torch::randint((int64_t)1 << 28, (int64_t)1 << 30, {1}, cpu_i32).item<int>();
+			bool composite = cand % 2 == 0;
+			for (int64_t q = 3; !composite && q * q <= cand; q += 2) composite = cand % q == 0;
+			if (!composite) dst[kept++] = (int32_t)cand;
+		}
+		return out;
+	}
 
 	const nrf_hash *GetHandle() const { return Handle; }
 	torch::Tensor GetBoundingBox() const { return BoundingBox; }

@@ -39,7 +39,7 @@ struct nrf_lerf_renderer {
     float *d_pos = nullptr, *d_neg = nullptr;
     int n_pos = 0, n_neg = 0;
     // lanes of this renderer's Chunk loop.  ONE by default: the LeRF kernels gain nothing from sharing the CUs (800x800 frame, same call: 1 lane 140-143 ms, 2 lanes
-    // 146-147 ms at Chunk 32768; profiles/round4/r4g_lerf_lane_chunk_sweep.log) -- their sum is matrix-bound and the F = 8 encode is at the HBM roofline by itself
+    // 146-147 ms at Chunk 32768; docs/history/profiles/round4/r4g_lerf_lane_chunk_sweep.log) -- their sum is matrix-bound and the F = 8 encode is at the HBM roofline by itself
     int lanes = 1;
     // lanes of the Chunk loop (as nrf_renderer's): created on first use, bound to one device and one caller at a time
     mutable std::mutex lane_mu;

@@ -250,7 +250,7 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
     const unsigned long long tstart = tprev;
 #endif
     // One wave per SIMD and a dependent chain: whatever a pass loads where it needs it, it waits for in full (cycle stamps of -DNRF_BWD_TRACE builds,
-    // tools/scratch/bwd_trace.py, profiles/round4/r5g_*: of 33 k cycles per pass 6.4 k in front of the inputs, 1.9 k in front of the output gradients, ~13 k in front
+    // tools/scratch/bwd_trace.py, docs/history/profiles/round4/r5g_*: of 33 k cycles per pass 6.4 k in front of the inputs, 1.9 k in front of the output gradients, ~13 k in front
     // of the fragment reloads of the backward chain).  Most of that was HBM traffic of the fragment scratch, gone with the per-wave slot (below).  Requesting things
     // ahead -- bit 1: the NEXT pass's inputs (level-major form) and output gradients while this pass computes; bit 2: each backward layer requests the fragments of
     // the layer after it -- moves the waits without shortening the pass (r5j_*: training step 6.60-6.67 ms with 0, 1 or 2; the stamps show the cycles reappear at the
@@ -294,7 +294,7 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
         NRF_BSTAMP(15);
         // this wave's fragments: [pt][fragment][lane]; wave-uniform pointer.  The SAME 24 KB every pass: a region per tile of the launch (2.4 GB for a training
         // batch) made every fragment a line written back to HBM and, with 3 MB of them in flight per XCD, mostly re-read from there -- 4.8 GB per call, which is
-        // what the kernel's 1.6 ms were (profiles/round4/r5i_*); a wave's own slot is rewritten while it is still in the L2
+        // what the kernel's 1.6 ms were (docs/history/profiles/round4/r5i_*); a wave's own slot is rewritten while it is still in the L2
         half8 *hs = scratch + ((size_t)(blockIdx.x * BW + wave) * BPT * P::h_frags()) * 64;
         // the asm pins each fragment's base as an SGPR pair where it is used: left alone, the compiler precomputes one 64-bit VGPR address per
         // 4-KB window outside the persistent loop (20 register pairs) and spills them

@@ -807,7 +807,7 @@ static int lanes_of(const nrf_renderer *r, int lanes, hipStream_t *st, hipEvent_
     }
     for (int i = 0; i < lanes; i++) {
         if (!r->lane[i]) {
-            // NRF_LANE_CU_MASK=1 (experiment, profiles/round4/r4z_*): lane i of L on its own 256 / L compute units (hipExtStreamCreateWithCUMask; a contiguous bit range)
+            // NRF_LANE_CU_MASK=1 (experiment, docs/history/profiles/round4/r4z_*): lane i of L on its own 256 / L compute units (hipExtStreamCreateWithCUMask; a contiguous bit range)
             static const int masked = [] { const char *e = getenv("NRF_LANE_CU_MASK"); return e ? atoi(e) : 0; }();
             if (masked && lanes > 1) {
                 uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -223,12 +223,12 @@ __global__ void k_hash_cu_bwd(HashParams hp, const float *__restrict__ pts, int6
 // (importance sampling packs them densely) mostly sit in the same voxel of a level: one thread walks SEG consecutive samples of one ray
 // at one level, sums the eight corner contributions in registers while the voxel does not change and issues the atomics only when it
 // does.  Same addends as the per-point kernels, summed in a different order (fp32).
-// samples of a ray one thread walks; training step of 16 384 rays, same call (profiles/round4/r5b_*): 8: 8.0 ms, 12: 8.65, 16: 7.85, 24: 8.6, 32: 7.8, 48: 8.55
+// samples of a ray one thread walks; training step of 16 384 rays, same call (docs/history/profiles/round4/r5b_*): 8: 8.0 ms, 12: 8.65, 16: 7.85, 24: 8.6, 32: 7.8, 48: 8.55
 #ifndef NRF_BWD_SEG
 #define NRF_BWD_SEG 16
 #endif
 constexpr int BWD_SEG = NRF_BWD_SEG;
-// training step of 16 384 rays x 192 samples, same call, alternating builds (profiles/round4/r5a_*): 2^16 10.3 ms, 2^17 8.1-8.9, 2^18 7.84, 2^19 8.04, 2^20 8.6, 2^22 9.25
+// training step of 16 384 rays x 192 samples, same call, alternating builds (docs/history/profiles/round4/r5a_*): 2^16 10.3 ms, 2^17 8.1-8.9, 2^18 7.84, 2^19 8.04, 2^20 8.6, 2^22 9.25
 // ... and with the 8-byte records of the binned form (r5n_*): 2^17 6.4 ms, 2^18 5.93, 2^19 6.2, 2^20 6.75 -- a pass of 2^18 points emits ~130 MB of records, which the 256-MB
 // Infinity Cache still holds between the emit pass and k_bin_accumulate
 #ifndef NRF_PACKED_GROUP_LOG2
@@ -252,7 +252,7 @@ constexpr int BIN_WORDS = 1 << BIN_SHIFT;
 constexpr int BIN_MAX_PER_LEVEL = 40;        // bins one level's words can touch: 2^19 / 2^14 = 32, + 1 for an unaligned base (+ margin)
 // A record = 8 bytes: the word's 14 bits inside its bin (the bin is where the record lies) and the two fixed-point addends as 25-bit two's-complement fields.  The
 // records of a pass are written once and read once through HBM (~16 M of them per 2^18 points): that traffic IS the time of the emit pass and of k_bin_accumulate
-// -- training step, same call: 16-byte records {word, q0, q1, pad} 6.55 ms, 12-byte 6.20, 8-byte 5.9 (profiles/round4/r5l_*, r5m_*).
+// -- training step, same call: 16-byte records {word, q0, q1, pad} 6.55 ms, 12-byte 6.20, 8-byte 5.9 (docs/history/profiles/round4/r5l_*, r5m_*).
 // An addend outside the field (|q| >= 2^24) goes to a side list as {word, q0, q1} instead: the scale bounds the sum of |q| over a level's records of a pass by 2^30
 // (k_qscale), so at most 64 records per level and field can be that large -- the list holds 128 per level and cannot overflow.
 typedef unsigned long long BinRec;
@@ -379,7 +379,7 @@ __device__ __forceinline__ void hash_bwd_walk(const HashParams &hp, const float 
         }
     };
     // (requesting the segment's 16 gradients and points up front instead of where they are used -- 5 registers per sample, the loop unrolled -- was slower: training step
-    // 6.33-6.45 against 6.04 ms, same call, profiles/round4/r5q_*)
+    // 6.33-6.45 against 6.04 ms, same call, docs/history/profiles/round4/r5q_*)
     for (int j = j0; j < j1; j++) {
         const int64_t i = ray * s + j;
         float g[F];
@@ -917,7 +917,7 @@ int nrf_hash_backward_rays_binned(const nrf_hash *h, const float *d_pts, int64_t
     hipStream_t st = as_stream(stream);
     unsigned char *ws = reinterpret_cast<unsigned char *>(d_workspace);
     // The level masses and scales of ALL passes come first, in two launches (a launch of 2^18 points is latency-bound: 30 us for 33 MB, thirteen of them per
-    // training step, plus the scale kernel and a memset per pass: profiles/round4/r5c_*); same per-pass sums, same scales, same table gradient bits.
+    // training step, plus the scale kernel and a memset per pass: docs/history/profiles/round4/r5c_*); same per-pass sums, same scales, same table gradient bits.
     const int64_t pass_cap = (int64_t)(BIN_HDR / ((size_t)L * 8 + 8));                          // passes whose masses and scales the header holds
     double *mass = reinterpret_cast<double *>(ws);
     float *qs = reinterpret_cast<float *>(ws + (size_t)pass_cap * L * 8);

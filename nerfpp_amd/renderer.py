@@ -567,7 +567,7 @@ class LeRFRenderer:
         self.reuse_features = True          # level-major fused path: encode every sample point once per render (False: the plain two-pass evaluation, for A/B tests)
         self.precision = int(precision)
         # streams of Render's Chunk loop.  ONE by default: the LeRF kernels gain nothing from sharing the CUs (800x800 frame, same call: 140-143 ms on one lane,
-        # 146-147 on two; profiles/round4/r4g_lerf_lane_chunk_sweep.log); NRF_LERF_LANES overrides
+        # 146-147 on two; docs/history/profiles/round4/r4g_lerf_lane_chunk_sweep.log); NRF_LERF_LANES overrides
         self.lanes = max(1, min(4, int(os.environ.get("NRF_LERF_LANES", "1"))))
         self._lane_streams = None
         if self.fused:

@@ -62,7 +62,7 @@ class Trainer:
         self._ws = None
         # the baked dense pyramid of the render fast path is re-baked after every step's table upload: GBs at the render default -- so while training only the coarse
         # levels that fit `train_dense_budget` stay baked (256 MB: re-baking them costs ~0.1 ms per step and their lookups are the 2-load fast path instead of 8 hashed
-        # corners: step 9.3 -> 8.5 ms, same bits; 0 / 16 / 64 / 1024 MB: 9.3 / 8.9 / 8.7 / 8.7 ms, profiles/round4/r4m_train_dense_budget.log).  For ANY hash embedder --
+        # corners: step 9.3 -> 8.5 ms, same bits; 0 / 16 / 64 / 1024 MB: 9.3 / 8.9 / 8.7 / 8.7 ms, docs/history/profiles/round4/r4m_train_dense_budget.log).  For ANY hash embedder --
         # the LibTorch HashEmbedder (the reference's TV-loss training configuration) included
         self._dense_budget_before = getattr(embedder, "dense_budget", None) if self.has_table else None
         if not self.has_table:

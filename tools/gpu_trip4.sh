@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 helper run on the GPU box: GPU tests + smoke + the driver's own bench command (compact line on stdout, full record in bench_detail.json) +
-# rocprofv3 kernel-trace summaries of the two-lane and the single-lane pass (copied into profiles/round4 afterwards).   usage: tools/gpu_trip4.sh <tag> [quick]
+# rocprofv3 kernel-trace summaries of the two-lane and the single-lane pass (copied into docs/history/profiles/round4 afterwards).   usage: tools/gpu_trip4.sh <tag> [quick]
 set -u
 tag=${1:-t}
 mkdir -p gpurun_out

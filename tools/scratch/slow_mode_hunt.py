@@ -1,4 +1,4 @@
-"""Some boxes of the pool render the default frame (2 lanes x 131 072-ray chunks) at 45-130 ms instead of 22 (profiles/round4/r4d_lane_sweep_first_box.log, r4E_*): this
+"""Some boxes of the pool render the default frame (2 lanes x 131 072-ray chunks) at 45-130 ms instead of 22 (docs/history/profiles/round4/r4d_lane_sweep_first_box.log, r4E_*): this
 probe, run first thing on a fresh box, times the frame at several chunk sizes in ONE process, with the per-kernel HIP-event times and the host time inside Render, so that a
 slow box tells what is slow (every kernel? the host?) and whether a smaller chunk escapes it.   usage (GPU box): python tools/scratch/slow_mode_hunt.py"""
 import ctypes as C, os, sys, time
