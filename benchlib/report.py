@@ -64,10 +64,7 @@ def compact_roofline(detail_roof, stats_csv=None):
     if isinstance(dom.get("colour_only"), dict):
         c = dom["colour_only"]
         out["colour_only"] = {k: _r(c[k]) for k in ("frac", "avg_launch_ms", "launches", "units_per_launch", "flop_per_unit") if c.get(k) is not None}
-    t = detail_roof.get("timed") or {}
-    if detail_roof.get("isolated") and t:
-        # the same kernels' launch times with the timed region's lane count (they share the CUs there; a separate profiled pass): context, not a roofline
-        out["shared_lanes_avg_launch_ms"] = {n: _r(r.get("avg_launch_ms")) for n, r in t.items()}
+    # (the same kernels' launch times with the timed region's lane count -- they share the CUs there -- are in the side file: roofline.timed)
     if detail_roof.get("isolated_kernel_sum_ms_per_step") is not None:
         out["kernel_sum_ms_per_step"] = _r(detail_roof["isolated_kernel_sum_ms_per_step"])       # the single-lane pass: sum of the bracketed kernels' times per step
     return out
@@ -89,8 +86,8 @@ def compact_also(rec):
     oc = rec.get("oracle_check")
     if wl.startswith("dropin_"):
         # the C++ / LibTorch host's line (oracle/_ref/adapter_check bench): its mirror twin above carries precision and quality
-        return {k: v for k, v in {"workload": wl, "value": _r(rec.get("value")), "ms": _r(ms, 3)}.items() if v is not None}
-    out = {"workload": wl, "precision": rec.get("precision") or ("f16x3" if "train" in wl else None), "value": _r(rec.get("value")), "ms": _r(ms, 3)}
+        return {k: v for k, v in {"workload": wl, "ms": _r(ms, 2)}.items() if v is not None}          # (value = rays x 256 / ms: in the side file)
+    out = {"workload": wl, "precision": rec.get("precision") or ("f16x3" if "train" in wl else None), "value": _r(rec.get("value")), "ms": _r(ms, 2)}
     if rec.get("coarse_pass", "").startswith("whole network"):
         out["workload"] += "_coarse_full"
     if isinstance(q, dict):
@@ -99,7 +96,7 @@ def compact_also(rec):
         out["cos_min"] = _r(oc.get("embedding_cos_min"), 7)
         out["same_samples"] = _r(oc.get("fine_sample_set_bit_identical_rays"))
     if isinstance(rec.get("roofline"), dict) and rec["roofline"].get("frac") is not None:
-        out["frac"] = _r(rec["roofline"]["frac"])
+        out["frac"] = _r(rec["roofline"]["frac"], 3)
     if rec.get("frames_per_step"):
         out["frames_per_step"] = rec["frames_per_step"]
     return {k: v for k, v in out.items() if v is not None}

@@ -31,8 +31,8 @@ struct nrf_renderer {
     // non-finite words of the matrix-core precisions (nrf_render_params.overflow_policy): one per chunk of the current call on the device, a pinned host mirror for the
     // synchronous policies and one for the deferred copy, and the event that says the deferred copy has landed
     mutable uint32_t *d_flags = nullptr, *h_flags = nullptr, *h_deferred = nullptr;      // h_deferred: NRF_DEFERRED_RING x NRF_FLAG_SLOTS words
-    mutable hipEvent_t deferred_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    mutable int deferred_slots[4] = {0, 0, 0, 0};      // > 0: a deferred copy of that many words is pending in ring entry i
+    mutable hipEvent_t deferred_ev[32] = {};
+    mutable int deferred_slots[32] = {};               // > 0: a deferred copy of that many words is pending in ring entry i
     mutable int deferred_head = 0;                     // ring entry the next deferred copy goes to (entries are filled and looked at in order)
     mutable int64_t flagged_chunks = 0, rerendered_chunks = 0;
     void drop_lanes() const
@@ -52,7 +52,8 @@ struct nrf_renderer {
     }
 };
 constexpr int NRF_FLAG_SLOTS = 4096;        // chunks of one call that have a word of their own (further chunks share them modulo this)
-constexpr int NRF_DEFERRED_RING = 4;        // NRF_OVERFLOW_DEFERRED: calls whose words may be in flight to the host at once (the host may run that many calls ahead)
+constexpr int NRF_DEFERRED_RING = 32;       // NRF_OVERFLOW_DEFERRED: calls whose words may be in flight to the host at once (the host may run that many calls ahead before a
+                                            // call waits for the oldest one's copy; 512 KB of pinned memory)
 
 namespace nrf {
 
