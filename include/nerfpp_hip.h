@@ -434,8 +434,9 @@ typedef struct nrf_render_params {
  *                                  nrf_render_rows) and every flagged chunk is rendered again in NRF_PREC_F32 into the same outputs: the call's results are finite-input
  *                                  correct whatever the weights.  The default.
  *   NRF_OVERFLOW_ERROR             same read-back; a flagged chunk makes the call return NRF_ERR_NONFINITE (outputs of that chunk are not to be used).
- *   NRF_OVERFLOW_DEFERRED          no synchronisation: the words are copied to the host asynchronously and looked at by the NEXT render call on this renderer, which then
- *                                  returns NRF_ERR_NONFINITE before doing anything (or by nrf_renderer_nonfinite).  For pipelines that keep several frames in flight.
+ *   NRF_OVERFLOW_DEFERRED          no synchronisation: the words are copied to pinned host memory behind the call's work and looked at by the first LATER render call on
+ *                                  this renderer that finds the copy complete, which then returns NRF_ERR_NONFINITE before doing anything (or by nrf_renderer_nonfinite).
+ *                                  Up to 32 calls' words may be in flight; the 33rd call waits for the oldest copy.  For pipelines that keep several frames in flight.
  *   NRF_OVERFLOW_IGNORE            no detection at all (the compositing kernel skips the test). */
 enum { NRF_OVERFLOW_AUTO = 0, NRF_OVERFLOW_RERENDER = 1, NRF_OVERFLOW_ERROR = 2, NRF_OVERFLOW_DEFERRED = 3, NRF_OVERFLOW_IGNORE = 4 };
 

@@ -1059,6 +1059,18 @@ public:
 	int64_t F16BackwardOverflows = 0;                   ///steps whose fp16 chain reported a non-finite value and were redone in fp32
 	bool WantsF16Backward() const { return TrainBackwardArithmetic == 1 || (TrainBackwardArithmetic == -1 && Precision != NRF_PREC_F32); }
 	void SetSeed(uint64_t seed) { Seed = seed; }
+	/// What a matrix-core render does when its network outputs hold a NaN / Inf (nrf_render_params.overflow_policy; no reference counterpart: NeRFRenderParams is the
+	/// reference's struct, so the policy is a property of the renderer).  NRF_OVERFLOW_AUTO (default): the chunk is rendered again in NRF_PREC_F32 before Render returns;
+	/// NRF_OVERFLOW_ERROR: Render throws (NRF_ERR_NONFINITE); NRF_OVERFLOW_DEFERRED: no wait in the frame loop, ask Nonfinite(); NRF_OVERFLOW_IGNORE.
+	int OverflowPolicy = NRF_OVERFLOW_AUTO;
+	void SetOverflowPolicy(int policy) { OverflowPolicy = policy; }
+	/// {chunks whose non-finite word was set, chunks rendered again in fp32} since the renderer was built (settles the deferred words that have arrived)
+	std::pair<int64_t, int64_t> Nonfinite() const
+	{
+		int64_t flagged = 0, redone = 0;
+		nrfpp::check(nrf_renderer_nonfinite(Renderer, &flagged, &redone), "nrf_renderer_nonfinite");
+		return {flagged, redone};
+	}
 
 	/// (Re)read the network's parameters and rebuild the device-side images; call after construction, load or an optimizer step.
 	void SyncWeights(const nrf_mlp_small_desc *small, const nrf_mlp_nerf_desc *classic)
@@ -1429,7 +1441,7 @@ private:
 		p.perturb = rp.Perturb; p.raw_noise_std = rp.RawNoiseStd; p.precond_alpha = rp.StochasticPreconditioningAlpha;
 		if (!rp.ThinRay && cone_angle.defined() && cone_angle.numel()) { p.has_cone = 1; p.cone_angle = cone_angle.cpu().template item<float>(); }
 		if (rp.BoundingBox.defined() && rp.BoundingBox.numel() == 6) { auto bb = host_floats(rp.BoundingBox); p.has_bbox = 1; for (int a = 0; a < 6; a++) p.bbox[a] = bb[a]; }
-		p.seed = Seed; p.ray_base = ray_base;
+		p.seed = Seed; p.ray_base = ray_base; p.overflow_policy = OverflowPolicy;
 		return p;
 	}
 
@@ -1572,7 +1584,7 @@ public:
 		p.perturb = perturb; p.raw_noise_std = raw_noise_std; p.precond_alpha = stochastic_preconditioning_alpha;
 		if (cone_angle.defined() && cone_angle.numel()) { p.has_cone = 1; p.cone_angle = cone_angle.cpu().template item<float>(); }
 		if (bounding_box.defined() && bounding_box.numel() == 6) { auto bb = host_floats(bounding_box); p.has_bbox = 1; for (int a = 0; a < 6; a++) p.bbox[a] = bb[a]; }
-		p.seed = Seed; p.ray_base = RayCursor; RayCursor += n;
+		p.seed = Seed; p.ray_base = RayCursor; RayCursor += n; p.overflow_policy = OverflowPolicy;
 		nrf_render_outputs o{};
 		o.d_rgb = res.Outputs.RGBMap.data_ptr<float>(); o.d_disp = res.Outputs.DispMap.data_ptr<float>(); o.d_acc = res.Outputs.AccMap.data_ptr<float>();
 		o.d_depth = res.Outputs.DepthMap.data_ptr<float>();
