@@ -286,15 +286,17 @@ def lerf_measurement(scene, L, K, c2w, precision, repeats=10):
 
 
 def _with_train_gemm(L, fn):
-    """fn() under both arithmetics of the training paths' layer products: bf16x3 (the fast mode: the record's headline) and fp32 (the parity-grade default)."""
+    """fn() under the library's default arithmetic of the training paths' layer products (by family: f16x3 split-precision matrix-core products for the classic and the
+    LeRF networks: the record's headline) and with fp32 products (rocBLAS sgemm) for comparison."""
     prev = L.lib().nrf_get_train_gemm()
     try:
-        L.check(L.lib().nrf_set_train_gemm(1))
+        L.check(L.lib().nrf_set_train_gemm(-1))
         rec = fn()
-        rec["train_gemm"] = "bf16x3 split-precision matrix-core products, bias / ReLU / ReLU-mask fused (gemm_bf16x3.hip); weight-gradient products: rocBLAS sgemm"
+        rec["train_gemm"] = ("f16x3: hi + lo fp16 of power-of-two scaled operands, three matrix-core products per accumulator, bias / ReLU / ReLU-mask fused "
+                             "(gemm_bf16x3.hip; the library's default for this family); weight-gradient products: see `weight_gradients`")
         L.check(L.lib().nrf_set_train_gemm(0))
         r32 = fn()
-        rec["fp32_products"] = dict(ms_per_step=r32["ms_per_step"], loss_first_last=r32["loss_first_last"], what="rocBLAS sgemm + separate bias / ReLU / mask passes (the parity-grade default)")
+        rec["fp32_products"] = dict(ms_per_step=r32["ms_per_step"], loss_first_last=r32["loss_first_last"], what="rocBLAS sgemm + separate bias / ReLU / mask passes (nrf_set_train_gemm(0))")
     finally:
         L.check(L.lib().nrf_set_train_gemm(prev))
     return rec

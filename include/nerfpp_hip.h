@@ -738,15 +738,21 @@ NRF_API int nrf_renderer_set_lanes(nrf_renderer *r, int lanes);
 /* 1 when the fp32 layer products of the training paths (classic and LeRF backward, NeRFSmall's fp32 backward) run as rocBLAS GEMMs on the fp32 matrix cores (the library is
  * looked up with dlopen at first use, preferring the copy the process already maps), 0 when they run the hand-written FMA kernels (rocBLAS absent, or NRF_FP32_GEMM=0). */
 NRF_API int nrf_fp32_gemm_available(void);
-/* Arithmetic of the forward / back-propagation products of the classic-NeRF and LeRF training steps: 0 (default) = fp32 products (rocBLAS sgemm where present, else
- * the FMA kernels): parity-grade gradients (2e-5 of the largest entry against the oracle).  1 = bf16x3 split precision on the bf16 matrix cores (every operand as
- * hi + lo bf16 -- fp32's exponent range, 16 significant bits -- three products per fp32 accumulator, bias / ReLU / ReLU-mask fused in the epilogue; gemm_bf16x3.hip):
- * the FAST mode (one product within 6e-6 of its largest entry; a whole chain's weight gradients within ~1e-3), what bench.py's classic / LeRF training lines time.
- * NRF_TRAIN_GEMM=bf16x3 in the environment selects 1 as the default.  Process-wide. */
-/* The product itself: C [m x n] (ldc) = A [m x k] (lda) . B [n x k]^T (ldb) (+ bias [n]) (ReLU), fp32 row-major in and out, bf16x3 arithmetic */
-NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
+/* Arithmetic of the forward / back-propagation products of the classic-NeRF and LeRF training steps (gemm_bf16x3.hip; NRF_TRAIN_GEMM=auto | f32 | bf16x3 | f16x3 in the
+ * environment selects the process-wide default):
+ *  -1  (default, "auto") by network family: 2 for the classic NeRF and the LeRF head, 0 for NeRFSmall's fp32 backward (the hash path's parity chain; its fast chain is
+ *      the fused fp16 backward, nrf_mlp_backward_f16).
+ *   0  fp32 products (rocBLAS sgemm where present, else the FMA kernels).
+ *   1  bf16x3: every operand as hi + lo bf16 (fp32's exponent range, 16 significant bits), three matrix-core products per fp32 accumulator, bias / ReLU / ReLU mask
+ *      fused in the epilogue.  One product within 6e-6 of its largest entry; a whole chain's weight gradients within ~1e-3 of the fp32 chain's.
+ *   2  f16x3: hi + lo fp16 (22 significant bits) of power-of-two scaled operands -- each row of A by its own largest entry, B by its largest entry, undone exactly in
+ *      the epilogue; one product is closer to the float64 product than sgemm's (5e-7 against 8e-7 of the largest entry at K = 256), a classic step's weight gradients
+ *      end 6e-5 (norm-wise) from the rocBLAS chain's -- rocBLAS and the FMA kernels are 2e-5 apart (ReLUs decided the other way by last-bit differences). */
 NRF_API int nrf_get_train_gemm(void);
-NRF_API int nrf_set_train_gemm(int bf16x3);
+NRF_API int nrf_set_train_gemm(int mode);
+/* The products themselves: C [m x n] (ldc) = A [m x k] (lda) . B [n x k]^T (ldb) (+ bias [n]) (ReLU), fp32 row-major in and out */
+NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
+NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
 NRF_API int nrf_profile_enable(int on);
 /* 1 while the event bracketing is on.  A throughput measurement must run with it off: an event pair around every kernel of every lane costs host time per launch and
  * separates the kernels on the device (bench.py asserts 0 before its timed region; the per-kernel times come from a separate pass).  Events are pooled: none is created on

@@ -25,9 +25,57 @@ namespace nrf {
 
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gb_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 gb_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gb_f16x4 __attribute__((ext_vector_type(4)));
 typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t gb_u32x4 __attribute__((ext_vector_type(4)));
+
+// The two split arithmetics of these kernels (same LDS image, same instruction count):
+//   F16 = false  hi + lo bf16 (16 significant bits, fp32's exponent range: nothing to scale)                                                -- mode 1, "bf16x3"
+//   F16 = true   hi + lo fp16 (22 significant bits) of POWER-OF-TWO SCALED operands: every row of A by its own largest entry (brought to [2^13, 2^14); the row's
+//                whole K is in registers before the first split), B by its largest entry (a small pre-pass, k_gb_absmax); the epilogue multiplies the two
+//                inverse powers back (exact).  An entry far below its row's maximum loses RELATIVE precision (fp16 subnormals: absolute step 2^-24 of the scaled
+//                row) but never more than 2^-38 of the row's maximum in absolute terms -- which is what a dot product feels.                  -- mode 2, "f16x3"
+template <bool F16> struct GbT;
+template <> struct GbT<false> {
+    typedef __bf16 e; typedef gb_bf16x8 v8; typedef gb_bf16x4 v4;
+    static __device__ __forceinline__ gb_f32x16 mfma(v8 a, v8 b, gb_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct GbT<true> {
+    typedef _Float16 e; typedef gb_f16x8 v8; typedef gb_f16x4 v4;
+    static __device__ __forceinline__ gb_f32x16 mfma(v8 a, v8 b, gb_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// power-of-two scale that brings a largest magnitude mx into [2^13, 2^14), and its inverse.  mx = 0 / subnormal / below 2^-114: scale 2^127, inverse flushed to 0 (the
+// products are 0 or below fp32's normal range anyway); inf / NaN rows keep their inf / NaN through the fp16 conversion, as an fp32 product would.
+__device__ __forceinline__ void gb_pow2_scale(float mx, float &scale, float &inv)
+{
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    e = e < 13 ? 13 : e;
+    scale = __uint_as_float((uint32_t)(267 - e) << 23);
+    inv = __uint_as_float((uint32_t)(e - 13) << 23);
+}
+__device__ __forceinline__ float gb_absmax4(const float4 &v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 constexpr int GB_BM = 128, GB_BK = 32;
+
+// the bit pattern of the largest |B[n][k]| (k < K) into *out (zeroed before the launch) with one atomic per workgroup: |x|'s bits order like the values
+__global__ void __launch_bounds__(256) k_gb_absmax(int N, int K, const float *__restrict__ b, int ldb, uint32_t *__restrict__ out)
+{
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float mx = 0.0f;
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+        const float *row = b + (size_t)n * ldb;
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(row[k]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 // WNW waves along n (64 columns each) x 2 waves along m: BN = 64 WNW, 128 WNW threads.  LDS per stage: A hi | A lo (8 KB each) | B hi | B lo (BN x 64 bytes each)
 template <int WNW> struct GbCfg {
     static constexpr int BN = 64 * WNW, THREADS = 128 * WNW;
@@ -40,13 +88,46 @@ template <int WNW> struct GbCfg {
 struct GemmNT {
     const float *a0; int lda0, k0;        // A columns [0, k0)
     const float *a1; int lda1, k1;        // A columns [k0, k0 + k1) (k1 == 0: none)
-    const float *b; int ldb;              // B [N][ldb]; column j of the product's K index is B[n][j]
     float *c; int ldc;
     int64_t M; int N;
     const float *bias; int relu;
     const float *mask; int mask_ld;       // optional [M][mask_ld]: C = mask > 0 ? C : 0
-    int va0, va1, vb0, vb1;               // widest aligned vector load of each operand segment: 4, 2 or 1 floats
+    int va0, va1;                         // widest aligned vector load of each A segment: 4, 2 or 1 floats
+    const uint32_t *bmax;                 // F16 arithmetic: bits of the largest |B| entry (k_gb_absmax)
+    const unsigned char *bimg;            // B already split (k_gb_split_b): [hi | lo][K tile][k-step][npad rows][16 elements], i.e. the kernels' LDS image tile by tile
+    int64_t bimg_half;                    // bytes of one half of it
+    int npad;                             // rows of the image (N rounded up to the workgroup's tile width)
 };
+
+// B -> its split image, ONCE per product instead of once per workgroup and K tile (the weights are the same for all 6 000 workgroups of a layer product: re-splitting
+// them was a quarter of the kernels' vector instructions).  Tile t < t0 covers columns [32 t, 32 t + 32) of segment 0 (zero beyond k0), tile t >= t0 columns
+// k0 + 32 (t - t0) ... of segment 1 -- the K loop's own tiling; rows >= N are zero.  One thread per (tile, k-step, row): 16 elements, two 32-byte stores.
+template <bool F16>
+__global__ void __launch_bounds__(256) k_gb_split_b(int N, int npad, int k0, int k1, const float *__restrict__ b, int ldb, const uint32_t *__restrict__ bmax, unsigned char *__restrict__ img,
+                                                    int64_t img_half)
+{
+    const int t0 = (k0 + GB_BK - 1) / GB_BK, t1 = (k1 + GB_BK - 1) / GB_BK;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)(t0 + t1) * 2 * npad) return;
+    const int n = (int)(idx % npad);
+    const int ks = (int)((idx / npad) & 1);
+    const int tile = (int)(idx / npad / 2);
+    const bool s1 = tile >= t0;
+    const int kb = (s1 ? tile - t0 : tile) * GB_BK + ks * 16, kend = s1 ? k1 : k0, col0 = s1 ? k0 : 0;
+    float scale = 1.0f, inv;
+    if (F16) gb_pow2_scale(__uint_as_float(bmax[0]), scale, inv);
+    typename GbT<F16>::e hi[16], lo[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        float x = (n < N && kb + j < kend) ? b[(size_t)n * ldb + col0 + kb + j] : 0.0f;
+        if (F16) x *= scale;
+        const typename GbT<F16>::e t = (typename GbT<F16>::e)x;
+        hi[j] = t; lo[j] = (typename GbT<F16>::e)(x - (float)t);
+    }
+    typename GbT<F16>::e *dh = reinterpret_cast<typename GbT<F16>::e *>(img) + idx * 16, *dl = reinterpret_cast<typename GbT<F16>::e *>(img + img_half) + idx * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { dh[j] = hi[j]; dl[j] = lo[j]; }
+}
 
 // NQ rows' quads (four consecutive k each) of one operand for one K tile.  Rows past the end are CLAMPED to the last row (valid memory; their products land in output
 // rows / columns that the epilogue does not store), so an interior tile -- every tile but the last one of a segment -- is NQ unconditional vector loads in one basic
@@ -85,23 +166,45 @@ __device__ __forceinline__ void gb_load_rows(const float *base, int ld, const in
     }
 }
 
-// x -> (hi, lo) bf16 pairs of four values, written as two 8-byte stores
-__device__ __forceinline__ void gb_split_store(const float4 &v, unsigned char *hi_img, unsigned char *lo_img, int byte_off)
+// x (times a power of two in the F16 arithmetic) -> (hi, lo) pairs of four values, written as two 8-byte stores
+template <bool F16>
+__device__ __forceinline__ void gb_split_store(const float4 &v, float scale, unsigned char *hi_img, unsigned char *lo_img, int byte_off)
 {
-    gb_bf16x4 h, l;
-    const float x[4] = {v.x, v.y, v.z, v.w};
+    typename GbT<F16>::v4 h, l;
+    float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const __bf16 t = (__bf16)x[j]; h[j] = t; l[j] = (__bf16)(x[j] - (float)t); }
-    *reinterpret_cast<gb_bf16x4 *>(hi_img + byte_off) = h;
-    *reinterpret_cast<gb_bf16x4 *>(lo_img + byte_off) = l;
+    for (int j = 0; j < 4; j++) {
+        if (F16) x[j] *= scale;
+        const typename GbT<F16>::e t = (typename GbT<F16>::e)x[j];
+        h[j] = t; l[j] = (typename GbT<F16>::e)(x[j] - (float)t);
+    }
+    *reinterpret_cast<typename GbT<F16>::v4 *>(hi_img + byte_off) = h;
+    *reinterpret_cast<typename GbT<F16>::v4 *>(lo_img + byte_off) = l;
+}
+
+// B tile of the workgroup's BN rows out of the split image: per [hi | lo] and k-step a contiguous BN x 32 bytes, which is also its LDS layout -- 16 bytes per thread
+// (THREADS x 16 = BN x 32), no arithmetic
+template <int BN>
+__device__ __forceinline__ void gb_load_b(const unsigned char *bimg, int64_t bimg_half, int npad, int tile, int n0, int t, gb_u32x4 (&rb)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        rb[c] = *reinterpret_cast<const gb_u32x4 *>(bimg + (c >> 1) * bimg_half + ((int64_t)(tile * 2 + (c & 1)) * npad + n0) * 32 + t * 16);
+}
+template <int BN>
+__device__ __forceinline__ void gb_store_b(unsigned char *b_base, int b_half, int t, const gb_u32x4 (&rb)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) *reinterpret_cast<gb_u32x4 *>(b_base + (c >> 1) * b_half + (c & 1) * BN * 32 + t * 16) = rb[c];
 }
 
 // XCD: consecutive workgroup ids are dealt out round-robin to the 8 XCDs (each with its own L2): the launch is re-indexed so that XCD x works through a CONTIGUOUS
 // eighth of the tiles -- the n-blocks of one m-block (which read the same A rows) and neighbouring m-blocks (which read the same B) then share an L2
-template <int WNW>
+template <int WNW, bool F16>
 __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT g)
 {
     using Cfg = GbCfg<WNW>;
+    using T8 = typename GbT<F16>::v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -121,27 +224,53 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
     const int t0 = (g.k0 + GB_BK - 1) / GB_BK, t1 = (g.k1 + GB_BK - 1) / GB_BK, T = t0 + t1;
     // two register sets: while tile t is multiplied out of LDS, tile t + 1's loads are landing and tile t + 2's are being issued (the kernel is latency-bound on its A
     // stream otherwise: one tile in flight per workgroup moved 1.9 TB/s, profiles/round6/r6m_gemm_probe.log)
-    float4 ra0[Cfg::QA], rb0[Cfg::QB], ra1[Cfg::QA], rb1[Cfg::QB];
-    int64_t arow[Cfg::QA], brow[Cfg::QB];
+    float4 ra0[Cfg::QA], ra1[Cfg::QA];
+    gb_u32x4 rb0[4], rb1[4];                                                // B: the image's four 16-byte pieces of this thread per K tile ([hi | lo] x [k-step])
+    int64_t arow[Cfg::QA];
 #pragma unroll
     for (int i = 0; i < Cfg::QA; i++) { const int64_t m = m0 + rq + Cfg::RSTEP * i; arow[i] = m < g.M ? m : g.M - 1; }
-#pragma unroll
-    for (int i = 0; i < Cfg::QB; i++) { const int n = n0 + rq + Cfg::RSTEP * i; brow[i] = n < g.N ? n : g.N - 1; }
-    auto load_tile = [&](int tile, float4 (&ra)[Cfg::QA], float4 (&rb)[Cfg::QB]) {
+    auto load_tile = [&](int tile, float4 (&ra)[Cfg::QA], gb_u32x4 (&rb)[4]) {
         const bool s1 = tile >= t0;
         const int tk = (s1 ? tile - t0 : tile) * GB_BK;                   // first column of the tile inside its segment
         const int kend = s1 ? g.k1 : g.k0;
         const bool full = tk + GB_BK <= kend;
         gb_load_rows<Cfg::QA>(s1 ? g.a1 : g.a0, s1 ? g.lda1 : g.lda0, arow, tk + 4 * kq, kend, full, s1 ? g.va1 : g.va0, ra);
-        gb_load_rows<Cfg::QB>(g.b + (s1 ? g.k0 : 0), g.ldb, brow, tk + 4 * kq, kend, full, s1 ? g.vb1 : g.vb0, rb);
+        gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb);
     };
-    auto store_tile = [&](int stage, const float4 (&ra)[Cfg::QA], const float4 (&rb)[Cfg::QB]) {
+    // F16: the rows' scales need every row's largest entry BEFORE the first split -- one extra pass over the workgroup's A rows (their second read, by the K loop, comes
+    // out of the caches); the inverse scales wait in LDS for the epilogue
+    float as[Cfg::QA], binv = 1.0f;
+    float *rinv = reinterpret_cast<float *>(gb_smem + 2 * Cfg::STAGE);
+#pragma unroll
+    for (int i = 0; i < Cfg::QA; i++) as[i] = 1.0f;
+    if (F16) {
+        { float bs; gb_pow2_scale(__uint_as_float(g.bmax[0]), bs, binv); }
+        float mx[Cfg::QA];
+#pragma unroll
+        for (int i = 0; i < Cfg::QA; i++) mx[i] = 0.0f;
+        for (int tile = 0; tile < T; tile++) {
+            const bool s1 = tile >= t0;
+            const int tk = (s1 ? tile - t0 : tile) * GB_BK;
+            const int kend = s1 ? g.k1 : g.k0;
+            gb_load_rows<Cfg::QA>(s1 ? g.a1 : g.a0, s1 ? g.lda1 : g.lda0, arow, tk + 4 * kq, kend, tk + GB_BK <= kend, s1 ? g.va1 : g.va0, ra0);
+#pragma unroll
+            for (int i = 0; i < Cfg::QA; i++) mx[i] = fmaxf(mx[i], gb_absmax4(ra0[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::QA; i++) {
+            float m = mx[i];
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));          // the row's eight threads (kq) are adjacent lanes
+            float inv;
+            gb_pow2_scale(m, as[i], inv);
+            if (kq == 0) rinv[rq + Cfg::RSTEP * i] = inv;
+        }
+    }
+    auto store_tile = [&](int stage, const float4 (&ra)[Cfg::QA], const gb_u32x4 (&rb)[4]) {
         unsigned char *base = gb_smem + stage * Cfg::STAGE;
         const int ks = kq >> 2;                                          // k-step of 16 inside the tile
 #pragma unroll
-        for (int i = 0; i < Cfg::QA; i++) gb_split_store(ra[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
-#pragma unroll
-        for (int i = 0; i < Cfg::QB; i++) gb_split_store(rb[i], base + 2 * Cfg::A_HALF, base + 2 * Cfg::A_HALF + Cfg::B_HALF, (ks * Cfg::BN + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+        for (int i = 0; i < Cfg::QA; i++) gb_split_store<F16>(ra[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+        gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
     };
     gb_f32x16 acc[2][2];
 #pragma unroll
@@ -154,24 +283,24 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
         const unsigned char *base = gb_smem + stage * Cfg::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            gb_bf16x8 ah[2], al[2], bh[2], bl[2];
+            T8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int offa = (ks * GB_BM + wm * 64 + i * 32 + r) * 32 + h * 16;
-                ah[i] = *reinterpret_cast<const gb_bf16x8 *>(base + offa);
-                al[i] = *reinterpret_cast<const gb_bf16x8 *>(base + Cfg::A_HALF + offa);
+                ah[i] = *reinterpret_cast<const T8 *>(base + offa);
+                al[i] = *reinterpret_cast<const T8 *>(base + Cfg::A_HALF + offa);
                 const int offb = (ks * Cfg::BN + wn * 64 + i * 32 + r) * 32 + h * 16;
-                bh[i] = *reinterpret_cast<const gb_bf16x8 *>(base + 2 * Cfg::A_HALF + offb);
-                bl[i] = *reinterpret_cast<const gb_bf16x8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
+                bh[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + offb);
+                bl[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     // small terms first, the leading product last
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = GbT<F16>::mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = GbT<F16>::mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = GbT<F16>::mfma(ah[i], bh[j], acc[i][j]);
                 }
         }
     };
@@ -203,9 +332,10 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int ml = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int64_t m = m0 + ml;
                 if (m >= g.M) continue;
-                float v = acc[i][j][q] + bias;
+                float v = (F16 ? acc[i][j][q] * rinv[ml] * binv : acc[i][j][q]) + bias;
                 if (g.relu) v = v > 0.0f ? v : 0.0f;
                 if (g.mask) v = g.mask[m * g.mask_ld + n] > 0.0f ? v : 0.0f;
                 g.c[m * g.ldc + n] = v;
@@ -213,14 +343,18 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
     }
 }
 
+constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
+constexpr int GB_ROWS_LDS = GB_ROWS_LDS_BASE + GB_BM * 4;                                                                                            // + the rows' inverse scales
+
 // The same product with the WHOLE A block of the workgroup (128 rows x K <= 256 columns: one contiguous 128 KB of a [M][K] array) requested in one burst at kernel
 // start: with K tiles of 32 requested one by one every row is visited eight times, 128 bytes at a time, microseconds apart -- DRAM pages are re-opened for each piece and
 // the A stream (what bounds this product: 64 flop per byte at N = K = 256) moved ~2 TB/s for this kernel and for rocBLAS's alike (profiles/round6/r6m_gemm_probe.log).
 // TK = K / 32 tiles live in 8 TK registers per thread; B (the weights, L2-resident) is streamed per tile as before.  One segment, K a multiple of 32, 16-byte aligned rows.
-template <int TK>
+template <int TK, bool F16>
 __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 {
     using Cfg = GbCfg<4>;
+    using T8 = typename GbT<F16>::v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -237,10 +371,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
     const int wm = wave / 4, wn = wave % 4;
     const int rq = t >> 3, kq = t & 7;
     float4 ra[TK][Cfg::QA];
-    float4 rb0[Cfg::QB], rb1[Cfg::QB];
-    int64_t brow[Cfg::QB];
-#pragma unroll
-    for (int i = 0; i < Cfg::QB; i++) { const int n = n0 + rq + Cfg::RSTEP * i; brow[i] = n < g.N ? n : g.N - 1; }
+    gb_u32x4 rb0[4], rb1[4];
     // the burst: row by row, all of its K (segment 0's tiles, then segment 1's: both are whole multiples of 32 columns here)
     const int t0 = g.k0 / GB_BK;
 #pragma unroll
@@ -253,14 +384,31 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         for (int tile = 0; tile < TK; tile++) ra[tile][i] = *reinterpret_cast<const float4 *>(tile < t0 ? rp0 + tile * GB_BK : rp1 + (tile - t0) * GB_BK);
     }
     // (B's columns run straight through both segments)
-    auto load_b = [&](int tile, float4 (&rb)[Cfg::QB]) { gb_load_rows<Cfg::QB>(g.b, g.ldb, brow, tile * GB_BK + 4 * kq, g.k0 + g.k1, true, g.vb0, rb); };
-    auto store_tile = [&](int stage, const float4 (&a)[Cfg::QA], const float4 (&rb)[Cfg::QB]) {
+    auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
+    // F16: the row's whole K sits in the eight threads (kq) of the row: its largest entry is 8 TK maxima and three lane exchanges away
+    float as[Cfg::QA], binv = 1.0f;
+    float *rinv = reinterpret_cast<float *>(gb_smem + GB_ROWS_LDS_BASE);
+#pragma unroll
+    for (int i = 0; i < Cfg::QA; i++) as[i] = 1.0f;
+    if (F16) {
+        { float bs; gb_pow2_scale(__uint_as_float(g.bmax[0]), bs, binv); }
+#pragma unroll
+        for (int i = 0; i < Cfg::QA; i++) {
+            float m = 0.0f;
+#pragma unroll
+            for (int tile = 0; tile < TK; tile++) m = fmaxf(m, gb_absmax4(ra[tile][i]));
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            float inv;
+            gb_pow2_scale(m, as[i], inv);
+            if (kq == 0) rinv[rq + Cfg::RSTEP * i] = inv;
+        }
+    }
+    auto store_tile = [&](int stage, const float4 (&a)[Cfg::QA], const gb_u32x4 (&rb)[4]) {
         unsigned char *base = gb_smem + stage * Cfg::STAGE;
         const int ks = kq >> 2;
 #pragma unroll
-        for (int i = 0; i < Cfg::QA; i++) gb_split_store(a[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
-#pragma unroll
-        for (int i = 0; i < Cfg::QB; i++) gb_split_store(rb[i], base + 2 * Cfg::A_HALF, base + 2 * Cfg::A_HALF + Cfg::B_HALF, (ks * Cfg::BN + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+        for (int i = 0; i < Cfg::QA; i++) gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+        gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
     };
     gb_f32x16 acc[2][2];
 #pragma unroll
@@ -273,23 +421,23 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         const unsigned char *base = gb_smem + stage * Cfg::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            gb_bf16x8 ah[2], al[2], bh[2], bl[2];
+            T8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int offa = (ks * GB_BM + wm * 64 + i * 32 + r) * 32 + h * 16;
-                ah[i] = *reinterpret_cast<const gb_bf16x8 *>(base + offa);
-                al[i] = *reinterpret_cast<const gb_bf16x8 *>(base + Cfg::A_HALF + offa);
+                ah[i] = *reinterpret_cast<const T8 *>(base + offa);
+                al[i] = *reinterpret_cast<const T8 *>(base + Cfg::A_HALF + offa);
                 const int offb = (ks * Cfg::BN + wn * 64 + i * 32 + r) * 32 + h * 16;
-                bh[i] = *reinterpret_cast<const gb_bf16x8 *>(base + 2 * Cfg::A_HALF + offb);
-                bl[i] = *reinterpret_cast<const gb_bf16x8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
+                bh[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + offb);
+                bl[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = GbT<F16>::mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = GbT<F16>::mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = GbT<F16>::mfma(ah[i], bh[j], acc[i][j]);
                 }
         }
     };
@@ -313,21 +461,20 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int nl = wn * 64 + j * 32 + r;
-        const int n = n0 + nl;
-        const float bias = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int ml = wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                float v = acc[i][j][q] + bias;
-                if (g.relu) v = v > 0.0f ? v : 0.0f;
-                ct[ml * CS + nl] = v;
-            }
+            for (int q = 0; q < 16; q++) ct[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + nl] = acc[i][j][q];
     }
     __syncthreads();
+    // (the inverse scales, the bias and the ReLU are applied here, once per row and four columns at a time, not per accumulator register)
     const int c4 = (t & 63) * 4, rw = t >> 6;                             // this thread's four columns; rows rw, rw + 8, ...
     const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0) && (!g.mask || (((g.mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.mask) & 15) == 0)));
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (g.bias) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < g.N) bias4[jj] = g.bias[n0 + c4 + jj];
+    }
 #pragma unroll 4
     for (int i = 0; i < GB_BM / 8; i++) {
         const int ml = rw + 8 * i;
@@ -335,6 +482,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         const int n = n0 + c4;
         if (m >= g.M || n >= g.N) continue;
         float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
+        if (F16) { const float rs = rinv[ml]; v.x = v.x * rs * binv; v.y = v.y * rs * binv; v.z = v.z * rs * binv; v.w = v.w * rs * binv; }          // (two steps: rs x binv alone may leave fp32's range)
+        v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
+        if (g.relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
         if (vec_ok && n + 4 <= g.N) {
             if (g.mask) {
                 const float4 k = *reinterpret_cast<const float4 *>(g.mask + m * g.mask_ld + n);
@@ -352,22 +502,40 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
     }
 }
 
-constexpr int GB_ROWS_LDS = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;          // the C tile (133 KB) or the two stages
 
-// -1: not decided (environment); 0 (the default): fp32 products -- rocBLAS sgemm / mlp.hip's FMA kernels: the parity-grade gradients the oracle-level tests hold to 2e-5;
-// 1: bf16x3 (NRF_TRAIN_GEMM=bf16x3, nrf_set_train_gemm(1)): the fast mode bench.py's classic / LeRF training lines use -- as the hash path's fused fp16 chain is
-// Trainer(mlp_backward="f16")'s, not its default
-static std::atomic<int> g_train_gemm{-1};
+// Arithmetic of the training paths' forward / back-propagation products.  -1 (the default, NRF_TRAIN_GEMM=auto): by network family -- f16x3 for the classic NeRF and the
+// LeRF head (whose 256-wide layers ARE the training step; their reference-autograd goldens hold in it), fp32 products for NeRFSmall's fp32 backward (the hash path's
+// parity chain: 4 096 points x 64-wide layers, where one ReLU decided the other way by a last-bit difference already shows against the golden; its fast chain is the fused
+// fp16 backward, not these products).  0 / 1 / 2 (NRF_TRAIN_GEMM=f32 | bf16x3 | f16x3, nrf_set_train_gemm): every family as said.
+//   0  fp32 products -- rocBLAS sgemm / mlp.hip's FMA kernels
+//   1  bf16x3: hi + lo bf16, 16 significant bits; a classic step's weight gradients end 2.5e-4 (norm-wise) from the fp32 chain's
+//   2  f16x3: hi + lo fp16 of power-of-two scaled operands, 22 significant bits: one product is closer to the float64 product than sgemm's (5e-7 vs 8e-7 of the largest
+//      entry); a classic step's weight gradients end 6e-5 from the rocBLAS chain's, where rocBLAS and the FMA kernels are 2e-5 apart (profiles/round6/r6o_*)
+#ifndef NRF_TRAIN_GEMM_DEFAULT
+#define NRF_TRAIN_GEMM_DEFAULT -1
+#endif
+static std::atomic<int> g_train_gemm{-2};
 int train_gemm_mode()
 {
     int m = g_train_gemm.load(std::memory_order_relaxed);
-    if (m >= 0) return m;
-    m = 0;
-    if (const char *e = getenv("NRF_TRAIN_GEMM")) { if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) m = 1; }
+    if (m >= -1) return m;
+    m = NRF_TRAIN_GEMM_DEFAULT;
+    if (const char *e = getenv("NRF_TRAIN_GEMM")) {
+        if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) m = 1;
+        else if (!strcmp(e, "f16x3") || !strcmp(e, "2")) m = 2;
+        else if (!strcmp(e, "f32") || !strcmp(e, "0")) m = 0;
+        else if (!strcmp(e, "auto") || !strcmp(e, "-1")) m = -1;
+    }
     g_train_gemm.store(m, std::memory_order_relaxed);
     return m;
 }
-void set_train_gemm_mode(int m) { g_train_gemm.store(m ? 1 : 0, std::memory_order_relaxed); }
+void set_train_gemm_mode(int m) { g_train_gemm.store(m < -1 ? -1 : (m > 2 ? 2 : m), std::memory_order_relaxed); }
+int train_gemm_for(const nrf_mlp *m)
+{
+    const int mode = train_gemm_mode();
+    if (mode >= 0) return mode;
+    return (m && m->family == MLP_SMALL) ? 0 : 2;
+}
 
 static int vec_class(const float *p, int ld, int col0)
 {
@@ -377,60 +545,83 @@ static int vec_class(const float *p, int ld, int col0)
     return 1;
 }
 
-// C = cat[a, b] . B^T (+ bias)(ReLU)(mask): B [N][ldb] holds the columns of segment a first, then segment b's
-int gemm_nt_bf16x3(int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld, hipStream_t st)
+template <bool F16>
+static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
+{
+    static const int force_wide = [] { const char *e = getenv("NRF_GEMM_WNW"); return e ? atoi(e) : 0; }();          // tuning: 2 / 4 forces the tile width
+    const bool wide = force_wide == 4 || (force_wide != 2 && g.N > 128);
+    const int bn = wide ? 256 : 128;
+    const int64_t blocks = ceil_div(g.M, GB_BM) * ceil_div((int64_t)g.N, (int64_t)bn);
+    if (blocks > 0x7fffffff) { set_error("gemm_nt_split: too many tiles"); return NRF_ERR_INVALID_ARG; }
+    constexpr int LDS2 = 2 * GbCfg<2>::STAGE + GB_BM * 4, LDS4 = 2 * GbCfg<4>::STAGE + GB_BM * 4;          // two stages + the rows' inverse scales
+    static bool attr_set = false;
+    if (!attr_set) {
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<4, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<4, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<5, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<8, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
+        attr_set = true;
+    }
+    // B: its largest entry (F16), then its split image -- two small launches over a cache-resident matrix, in stream order before the product
+    const int T = (g.k0 + GB_BK - 1) / GB_BK + (g.k1 + GB_BK - 1) / GB_BK;
+    g.npad = (int)ceil_div((int64_t)g.N, (int64_t)bn) * bn;
+    g.bimg_half = (int64_t)T * 2 * g.npad * 32;
+    unsigned char *ws = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)(2 * g.bimg_half + 16), st) != hipSuccess) { set_error("gemm_nt_split: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    uint32_t *bmax = reinterpret_cast<uint32_t *>(ws + 2 * g.bimg_half);
+    if (F16) {
+        (void)hipMemsetAsync(bmax, 0, sizeof(uint32_t), st);
+        hipLaunchKernelGGL(k_gb_absmax, dim3((unsigned)(g.N < 256 ? (g.N + 3) / 4 : 64)), dim3(256), 0, st, g.N, g.k0 + g.k1, B, ldb, bmax);
+    }
+    hipLaunchKernelGGL((k_gb_split_b<F16>), dim3((unsigned)ceil_div((int64_t)T * 2 * g.npad, (int64_t)256)), dim3(256), 0, st, g.N, g.npad, g.k0, g.k1, B, ldb, (const uint32_t *)bmax, ws,
+                       g.bimg_half);
+    g.bimg = ws; g.bmax = bmax;
+    static const bool no_rows = [] { const char *e = getenv("NRF_GEMM_ROWS"); return e && atoi(e) == 0; }();
+    const int ktot = g.k0 + g.k1;
+    const bool rows_ok = wide && !no_rows && g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot == 128 || ktot == 160 || ktot == 256);
+    if (rows_ok) {
+        if (ktot == 128) hipLaunchKernelGGL((k_gemm_nt_rows<4, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
+        else if (ktot == 160) hipLaunchKernelGGL((k_gemm_nt_rows<5, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
+        else hipLaunchKernelGGL((k_gemm_nt_rows<8, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
+    } else if (wide) hipLaunchKernelGGL((k_gemm_nt<4, F16>), dim3((unsigned)blocks), dim3(512), LDS4, st, g);
+    else hipLaunchKernelGGL((k_gemm_nt<2, F16>), dim3((unsigned)blocks), dim3(256), LDS2, st, g);
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(ws, st);
+    if (le != hipSuccess) { set_error("gemm_nt_split: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+
+// C = cat[a, b] . B^T (+ bias)(ReLU)(mask): B [N][ldb] holds the columns of segment a first, then segment b's.  arithmetic: 1 = bf16x3, 2 = f16x3 (scaled)
+int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
+                  hipStream_t st)
 {
     if (M <= 0 || N <= 0) return NRF_OK;
     GemmNT g{};
     g.a0 = a.p ? a.p + a.off : nullptr; g.lda0 = a.stride; g.k0 = a.p ? a.n : 0;
     g.a1 = (b.p && b.n > 0) ? b.p + b.off : nullptr; g.lda1 = b.stride; g.k1 = g.a1 ? b.n : 0;
     if (g.k0 == 0 && g.k1 > 0) { g.a0 = g.a1; g.lda0 = g.lda1; g.k0 = g.k1; g.a1 = nullptr; g.k1 = 0; }
-    g.b = B; g.ldb = ldb; g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld;
+    g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld;
     g.va0 = g.a0 ? vec_class(g.a0, g.lda0, 0) : 1;
     g.va1 = g.a1 ? vec_class(g.a1, g.lda1, 0) : 1;
-    g.vb0 = vec_class(B, ldb, 0);
-    g.vb1 = vec_class(B, ldb, g.k0);
-    static const int force_wide = [] { const char *e = getenv("NRF_GEMM_WNW"); return e ? atoi(e) : 0; }();          // tuning: 2 / 4 forces the tile width
-    const bool wide = force_wide == 4 || (force_wide != 2 && N > 128);
-    const int bn = wide ? 256 : 128;
-    const int64_t blocks = ceil_div(M, GB_BM) * ceil_div((int64_t)N, (int64_t)bn);
-    if (blocks > 0x7fffffff) { set_error("gemm_nt_bf16x3: too many tiles"); return NRF_ERR_INVALID_ARG; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GbCfg<2>::STAGE));
-        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GbCfg<4>::STAGE));
-        attr_set = true;
-    }
-    static const bool no_rows = [] { const char *e = getenv("NRF_GEMM_ROWS"); return e && atoi(e) == 0; }();
-    const int ktot = g.k0 + g.k1;
-    const bool rows_ok = wide && !no_rows && g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot == 128 || ktot == 160 || ktot == 256) &&
-                         (g.vb0 == 4 || g.vb0 == 2);
-    if (rows_ok) {
-        static bool attr2 = false;
-        if (!attr2) {
-            NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
-            NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<5>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
-            NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<8>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
-            attr2 = true;
-        }
-        if (ktot == 128) hipLaunchKernelGGL(k_gemm_nt_rows<4>, dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
-        else if (ktot == 160) hipLaunchKernelGGL(k_gemm_nt_rows<5>, dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
-        else hipLaunchKernelGGL(k_gemm_nt_rows<8>, dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
-    } else if (wide) hipLaunchKernelGGL(k_gemm_nt<4>, dim3((unsigned)blocks), dim3(512), 2 * GbCfg<4>::STAGE, st, g);
-    else hipLaunchKernelGGL(k_gemm_nt<2>, dim3((unsigned)blocks), dim3(256), 2 * GbCfg<2>::STAGE, st, g);
-    NRF_LAUNCH_CHECK();
-    return NRF_OK;
+    return arithmetic == 2 ? gemm_nt_launch<true>(g, B, ldb, st) : gemm_nt_launch<false>(g, B, ldb, st);
 }
 
 }  // namespace nrf
 
-// 1: the training paths' forward / back-propagation products run as bf16x3 split-precision matrix-core GEMMs; 0 (the default): as fp32 products (rocBLAS sgemm or mlp.hip's kernels)
+// -1: by network family (the default); 0: the training paths' forward / back-propagation products run as fp32 products (rocBLAS sgemm or mlp.hip's kernels); 1: as bf16x3,
+// 2: as f16x3 (scaled) split-precision matrix-core GEMMs (this file)
 extern "C" NRF_API int nrf_get_train_gemm(void) { return nrf::train_gemm_mode(); }
-extern "C" NRF_API int nrf_set_train_gemm(int bf16x3) { nrf::set_train_gemm_mode(bf16x3); return NRF_OK; }
+extern "C" NRF_API int nrf_set_train_gemm(int mode) { nrf::set_train_gemm_mode(mode); return NRF_OK; }
 
-// C [M x N] (ldc) = A [M x K] (lda) . B [N x K]^T (ldb) (+ bias [N]) (ReLU): the split-precision product as a stand-alone entry (tests, tools/scratch/gemm_probe.py)
+// C [M x N] (ldc) = A [M x K] (lda) . B [N x K]^T (ldb) (+ bias [N]) (ReLU): the split-precision products as stand-alone entries (tests, tools/scratch/gemm_probe.py)
 extern "C" NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream)
 {
     NRF_CHECK_ARG(d_a && d_b && d_c && m >= 0 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n, "nrf_gemm_nt_bf16x3: bad argument");
-    return nrf::gemm_nt_bf16x3(m, n, nrf::Seg{d_a, lda, 0, k}, nrf::Seg{nullptr, 0, 0, 0}, d_b, ldb, d_c, ldc, d_bias, relu, nullptr, 0, nrf::as_stream(stream));
+    return nrf::gemm_nt_split(1, m, n, nrf::Seg{d_a, lda, 0, k}, nrf::Seg{nullptr, 0, 0, 0}, d_b, ldb, d_c, ldc, d_bias, relu, nullptr, 0, nrf::as_stream(stream));
+}
+extern "C" NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream)
+{
+    NRF_CHECK_ARG(d_a && d_b && d_c && m >= 0 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n, "nrf_gemm_nt_f16x3: bad argument");
+    return nrf::gemm_nt_split(2, m, n, nrf::Seg{d_a, lda, 0, k}, nrf::Seg{nullptr, 0, 0, 0}, d_b, ldb, d_c, ldc, d_bias, relu, nullptr, 0, nrf::as_stream(stream));
 }

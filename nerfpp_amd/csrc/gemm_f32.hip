@@ -97,8 +97,8 @@ __global__ void k_bias_relu(int64_t total, int out, float *__restrict__ y, int y
 // Linear(+bias)(+ReLU) on cat[a, b]: the library product, then one elementwise pass where there is a bias or a ReLU.  Falls back to mlp.hip's kernel.
 int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
 {
-    if (npts >= 256 && train_gemm_mode() == 1)          // split-precision bf16 matrix-core product, bias + ReLU in its epilogue (gemm_bf16x3.hip)
-        return gemm_nt_bf16x3(npts, L.out, a, b, m->d_params + L.w_off, L.in, y + y_off, y_stride, L.d_bias, relu, nullptr, 0, st);
+    if (const int arith = npts >= 256 ? train_gemm_for(m) : 0)          // split-precision matrix-core product, bias + ReLU in its epilogue (gemm_bf16x3.hip)
+        return gemm_nt_split(arith, npts, L.out, a, b, m->d_params + L.w_off, L.in, y + y_off, y_stride, L.d_bias, relu, nullptr, 0, st);
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_linear(npts, a, b, L, relu, y, y_stride, y_off, st);
     const float *wb = m->d_params + L.w_off;
@@ -162,12 +162,12 @@ int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *d
 }
 
 // y[pt][k] = sum_o g[pt][o] W[o][k]
-bool run_backprop_fuses_mask(int64_t npts) { return npts >= 256 && train_gemm_mode() == 1; }
+bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts) { return npts >= 256 && train_gemm_for(m) != 0; }
 
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act, int mask_stride)
 {
-    if (npts >= 256 && train_gemm_mode() == 1)          // G . W with W^T [in][out] as the K-contiguous second operand (L.d_wt, refreshed by every nrf_mlp_set_params)
-        return gemm_nt_bf16x3(npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st);
+    if (const int arith = npts >= 256 ? train_gemm_for(m) : 0)          // G . W with W^T [in][out] as the K-contiguous second operand (L.d_wt, refreshed by every nrf_mlp_set_params)
+        return gemm_nt_split(arith, npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st);
     if (mask_act) { set_error("internal: run_backprop_fast: the fused ReLU mask exists in bf16x3 mode only"); return NRF_ERR_INVALID_ARG; }
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_backprop(npts, g, m, L, y, y_stride, st);

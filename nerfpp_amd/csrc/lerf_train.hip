@@ -491,7 +491,7 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     }
     // ---- LE net backward (last layer first)                                                        LeRF.cpp:97-103 ----
     // (bf16x3 products: the ReLU mask of the NEXT stage is applied by the back-propagation product's epilogue -- `premasked` -- instead of by a pass of its own)
-    const bool fuse = run_backprop_fuses_mask(c);
+    const bool fuse = run_backprop_fuses_mask(m, c);
     bool premasked = false;
     for (int l = l_top; l >= nl; l--) {
         const LinearLayer &L = m->layers[l];

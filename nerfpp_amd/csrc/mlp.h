@@ -105,11 +105,13 @@ int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLa
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
 // mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0);
-bool run_backprop_fuses_mask(int64_t npts);
+bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts);
 int fp32_gemm_available();
 // gemm_bf16x3.hip: the same two products (forward, back-propagation) as split-precision bf16 matrix-core GEMMs with the bias / ReLU / ReLU-mask epilogues fused
-int train_gemm_mode();               // 1: bf16x3 (default), 0: fp32 products (NRF_TRAIN_GEMM=f32, nrf_set_train_gemm(0))
-int gemm_nt_bf16x3(int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld, hipStream_t st);
+int train_gemm_mode();               // -1: by family (default); 0: fp32 products; 1: bf16x3; 2: f16x3 with power-of-two scaled operands (gemm_bf16x3.hip; NRF_TRAIN_GEMM, nrf_set_train_gemm)
+int train_gemm_for(const nrf_mlp *m);        // the arithmetic of this network's products: the explicit mode, or by family (NeRFSmall: fp32 products; classic, LeRF: f16x3)
+int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
+                  hipStream_t st);
 int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc);
 
 // matrix-core paths (separate translation units)

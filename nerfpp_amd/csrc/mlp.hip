@@ -539,7 +539,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         }
         // ---- pts_linears, last first ----
         float *gcur = gh;
-        const bool fuse = run_backprop_fuses_mask(c);          // bf16x3 products: the next stage's ReLU mask in the back-propagation product's epilogue
+        const bool fuse = run_backprop_fuses_mask(m, c);          // bf16x3 products: the next stage's ReLU mask in the back-propagation product's epilogue
         bool premasked = false;
         for (int l = D - 1; l >= 0; l--) {
             const LinearLayer &L = m->layers[l];

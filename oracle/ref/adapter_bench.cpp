@@ -24,6 +24,12 @@
 #include <sstream>
 #include <unistd.h>
 
+static const char *train_gemm_name()
+{
+	switch (nrf_get_train_gemm()) { case 0: return "f32"; case 1: return "bf16x3"; case 2: return "f16x3"; default: return "by family (classic, LeRF: f16x3; NeRFSmall fp32 backward: f32)"; }
+}
+
+
 using Clock = std::chrono::steady_clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 static void dev_sync() { c10::hip::getCurrentHIPStream().synchronize(); torch::cuda::synchronize(); }
@@ -272,7 +278,7 @@ static void time_steps(const char *family, const char *surface, Body body, int s
 	nrfpp::phase_clock().On = false;
 	printf("{\"what\": \"dropin_train_step\", \"family\": \"%s\", \"surface\": \"%s\", \"optimizer\": \"%s\", \"rays_per_step\": %lld, \"samples\": \"64+128\", \"steps\": %d, \"ms_per_step\": %.4f, "
 		"\"value\": %.6g, \"unit\": \"ray-samples/s\", \"train_gemm\": \"%s\", \"host_ms_per_statement\": %s, \"synchronised_phase_ms\": %s, \"loss_first_last\": [%.6g, %.6g]%s}\n", family, surface, optimizer.c_str(),
-		(long long)rays, steps, ms, (double)rays * 256.0 / (ms * 1e-3), nrf_get_train_gemm() ? "bf16x3" : "f32", json_map(sc.host, 1.0 / steps).c_str(), json_map(nrfpp::phase_clock().Ms, 1.0 / phase_steps).c_str(), loss_first,
+		(long long)rays, steps, ms, (double)rays * 256.0 / (ms * 1e-3), train_gemm_name(), json_map(sc.host, 1.0 / steps).c_str(), json_map(nrfpp::phase_clock().Ms, 1.0 / phase_steps).c_str(), loss_first,
 		loss_last, extra.c_str());
 	fflush(stdout);
 }
@@ -338,7 +344,6 @@ static int bench_train_hash(int steps, int64_t n_rand, const std::string &optimi
 
 static int bench_train_classic(int steps, int64_t n_rand, const std::string &optimizer)
 {
-	nrfpp::check(nrf_set_train_gemm(getenv("NRF_TRAIN_GEMM") ? nrf_get_train_gemm() : 1), "nrf_set_train_gemm");      // the fast mode (bf16x3 products) unless the environment says otherwise
 	ClassicScene sc(NRF_PREC_F16_SPLIT);
 	NeRFRenderer<nrfpp::HipEmbedder, nrfpp::HipEmbedder, ClassicModel> *base = sc.r.get();
 	nerf_train_steps("classic", "NeRFExecutor::Train's loop body on HipNeRFRenderer<HipEmbedder, HipEmbedder, NeRF 8x256> (f16x3 render)", base, sc.e, sc.m, sc.bbox, steps, n_rand, optimizer);
@@ -359,7 +364,6 @@ struct LeRFBenchRenderer {                 // LeRFRenderer::Render's signature (
 
 static int bench_train_lerf(int steps, int64_t n_rand, const std::string &optimizer)
 {
-	nrfpp::check(nrf_set_train_gemm(getenv("NRF_TRAIN_GEMM") ? nrf_get_train_gemm() : 1), "nrf_set_train_gemm");
 	LeRFScene sc;
 	LeRFBenchRenderer LeRFRenderer{*sc.pass};
 	struct { struct { torch::Tensor rays_o, rays_d, cone_angle; } data; struct { torch::Tensor target_lang_embedding; } target; } batch;

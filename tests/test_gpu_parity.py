@@ -3561,34 +3561,64 @@ def test_end_to_end_training_run_measurement(api):
 # ------------------------------------------------------------------------------------------- round 6: bf16x3 split-precision training products
 @pytest.mark.parametrize("M,N,K", [(70000, 256, 256), (33000, 256, 160), (5000, 128, 283), (4097, 33, 256), (777, 70, 63), (300, 3, 128)])
 def test_gemm_nt_bf16x3_vs_float64(api, M, N, K):
-    """nrf_gemm_nt_bf16x3 (gemm_bf16x3.hip: every fp32 operand as hi + lo bf16, three matrix-core products per fp32 accumulator) against the float64 product: within 2e-5 of
-    the largest entry (measured 5e-6; torch's fp32 product 8e-7), bias + ReLU epilogue included; ragged M / N / K (row, column and K-tile tails), the whole-row kernel's
-    shapes (K in {128, 160, 256}, N > 128) and the generic one's."""
+    """nrf_gemm_nt_bf16x3 / nrf_gemm_nt_f16x3 (gemm_bf16x3.hip: every fp32 operand as hi + lo bf16, or as hi + lo fp16 of power-of-two scaled rows; three matrix-core
+    products per fp32 accumulator) against the float64 product: within 2e-5 (bf16; measured 5e-6) / 2e-6 (fp16; measured 5e-7, torch's fp32 product 8e-7) of the largest
+    entry, bias + ReLU epilogue included; ragged M / N / K (row, column and K-tile tails), the whole-row kernel's shapes (K in {128, 160, 256}, N > 128) and the generic one's."""
     L = api.L
     g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)
     a = torch.randn((M, K), device="cuda", generator=g); b = torch.randn((N, K), device="cuda", generator=g) * 0.1; bias = torch.randn((N,), device="cuda", generator=g)
-    c = torch.full((M, N), float("nan"), device="cuda")
-    L.check(L.lib().nrf_gemm_nt_bf16x3(C.c_void_p(a.data_ptr()), K, C.c_int64(M), K, C.c_void_p(b.data_ptr()), K, N, C.c_void_p(c.data_ptr()), N, C.c_void_p(bias.data_ptr()), 1, None))
     want = torch.relu(a.double() @ b.double().t() + bias.double())
-    assert bool(torch.isfinite(c).all())
-    err = float((c.double() - want).abs().max() / want.abs().max())
-    assert err < 2e-5, err
+    for fn, bar in ((L.lib().nrf_gemm_nt_bf16x3, 2e-5), (L.lib().nrf_gemm_nt_f16x3, 2e-6)):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        L.check(fn(C.c_void_p(a.data_ptr()), K, C.c_int64(M), K, C.c_void_p(b.data_ptr()), K, N, C.c_void_p(c.data_ptr()), N, C.c_void_p(bias.data_ptr()), 1, None))
+        assert bool(torch.isfinite(c).all())
+        err = float((c.double() - want).abs().max() / want.abs().max())
+        assert err < bar, (err, bar)
 
 
-def test_classic_and_lerf_train_steps_in_bf16x3_mode_follow_the_fp32_chain(api):
-    """nrf_set_train_gemm(1): the classic NeRFImpl backward and the LeRF head backward with their forward / back-propagation products on the bf16 matrix cores (bias, ReLU and
-    the next stage's ReLU mask fused into the products' epilogues).  Against the SAME step with fp32 products (the default, which the goldens hold to the reference's
-    autograd): every parameter-gradient tensor within 3e-3 of its largest entry, the loss identical (the render is the same), nothing non-finite."""
+def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
+    """The scaled fp16 arithmetic where an unscaled fp16 pair fails (round 5's fp16x3 training GEMMs were removed for it): rows of A between 1e-12 and 1e+8 -- what a
+    back-propagated gradient looks like --, zero rows, a row of small entries with one huge one, weights x 1e-6 and x 1e+4, through the whole-row kernel (K = 256) and the
+    generic one (K = 200, two segments).  Error PER ROW relative to the row's largest result: below 4e-6 everywhere (measured 9e-7; torch's fp32 product 1.7e-6); the bf16
+    arithmetic (range-safe by construction) is held to 1e-4 on the same rows."""
+    L = api.L
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    M, N = 20000, 200
+    for K in (256, 200):
+        a = torch.randn((M, K), device="cuda", generator=g) * torch.pow(10.0, torch.rand((M, 1), device="cuda", generator=g) * 20 - 12)
+        a[::97] = 0.0
+        a[5::101, 3] *= 1e6
+        for wscale in (1.0, 1e-6, 1e4):
+            b = torch.randn((N, K), device="cuda", generator=g) * 0.1 * wscale
+            want = a.double() @ b.double().t()
+            rowmax = want.abs().amax(dim=1).clamp_min(1e-300)
+            for fn, bar in ((L.lib().nrf_gemm_nt_f16x3, 4e-6), (L.lib().nrf_gemm_nt_bf16x3, 1e-4)):
+                c = torch.full((M, N), float("nan"), device="cuda")
+                L.check(fn(C.c_void_p(a.data_ptr()), K, C.c_int64(M), K, C.c_void_p(b.data_ptr()), K, N, C.c_void_p(c.data_ptr()), N, None, 0, None))
+                assert bool(torch.isfinite(c).all())
+                assert bool((c[::97] == 0).all()), "zero rows stay zero"
+                err = float(((c.double() - want).abs().amax(dim=1) / rowmax).max())
+                assert err < bar, (K, wscale, err, bar)
+
+
+def test_classic_and_lerf_train_steps_in_the_split_gemm_modes_follow_the_fp32_chain(api):
+    """nrf_set_train_gemm(1 | 2): the classic NeRFImpl backward and the LeRF head backward with their forward / back-propagation products on the bf16 (1) / fp16 (2) matrix
+    cores (bias, ReLU and the next stage's ReLU mask fused into the products' epilogues).  Against the SAME step with fp32 products (mode 0, which the goldens hold to the
+    reference's autograd): the loss identical (the render is the same), nothing non-finite, every parameter-gradient tensor within 3e-3 of its largest entry in the bf16
+    arithmetic (16 significant bits; measured 1.1e-4, norm-wise 2.5e-4) and within 3e-4 in the scaled fp16 arithmetic (22 bits; measured 8.6e-5, norm-wise 6.3e-5).  The
+    yardstick for the latter: the same step with rocBLAS sgemm and with the hand-written fp32 FMA kernels -- two fp32 chains -- differs by 2.3e-5 / 1.9e-5
+    (tools/scratch/train_gemm_agreement.py, profiles/round6/r6o_train_gemm_agreement.log): ReLUs of near-zero pre-activations decided the other way."""
     L, S, R = api.L, api.S, api.R
     from nerfpp_amd.train import Trainer, LeRFTrainer
     K = S.lego_K(200, 200); c2w = S.pose_spherical(30.0, -30.0, 4.0)
     o, d, _ = R.GetRays(200, 200, K, c2w)
     o = o.reshape(-1, 3)[::20][:1500].contiguous(); d = d.reshape(-1, 3)[::20][:1500].contiguous()
     tgt = torch.rand((o.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    bars = {1: (3e-3, 1e-3, 2e-3), 2: (3e-4, 2e-4, 2e-4)}          # classic: max over max, norm-wise; LeRF: norm-wise
     prev = L.lib().nrf_get_train_gemm()
     try:
         grads = {}
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             L.check(L.lib().nrf_set_train_gemm(mode))
             sc = S.make_classic_scene()
             tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], None, sc["mlp_blob"], learning_rate=5e-4)
@@ -3596,14 +3626,17 @@ def test_classic_and_lerf_train_steps_in_bf16x3_mode_follow_the_fp32_chain(api):
                                     Precision=L.NRF_PREC_F32)
             lm, _ = tr.step(o, d, tgt, rp)
             grads[mode] = (tr.g_blob.clone(), float(host(lm)[0]))
-        g0, g1 = grads[0][0], grads[1][0]
-        assert grads[0][1] == grads[1][1] and bool(torch.isfinite(g1).all())
-        assert float((g1 - g0).abs().max() / g0.abs().max()) < 3e-3
-        assert float((g1 - g0).norm() / g0.norm()) < 1e-3
+        g0 = grads[0][0]
+        for mode in (1, 2):
+            g1 = grads[mode][0]
+            assert grads[0][1] == grads[mode][1] and bool(torch.isfinite(g1).all())
+            e_max, e_norm = float((g1 - g0).abs().max() / g0.abs().max()), float((g1 - g0).norm() / g0.norm())
+            print("classic step, train gemm mode %d vs fp32 products: max/max %.2e norm-wise %.2e" % (mode, e_max, e_norm))
+            assert e_max < bars[mode][0] and e_norm < bars[mode][1], (mode, e_max, e_norm)
         # LeRF head + language grid
         lg = {}
         tl = torch.nn.functional.normalize(torch.randn((o.shape[0], 768), device="cuda", generator=torch.Generator(device="cuda").manual_seed(6)), dim=-1)
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             L.check(L.lib().nrf_set_train_gemm(mode))
             sc = S.make_lerf_scene(log2_t=14)
             p = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
@@ -3611,9 +3644,12 @@ def test_classic_and_lerf_train_steps_in_bf16x3_mode_follow_the_fp32_chain(api):
             l, _ = tr.step(o, d, tl, p)
             lg[mode] = (tr.g_blob.clone(), tr.g_table.clone(), float(host(l)[0]))
             tr.close()
-        assert lg[0][2] == lg[1][2]
-        for i in (0, 1):
-            a, b = lg[1][i], lg[0][i]
-            assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 2e-3, i
+        for mode in (1, 2):
+            assert lg[0][2] == lg[mode][2]
+            for i in (0, 1):
+                a, b = lg[mode][i], lg[0][i]
+                e = float((a - b).norm() / b.norm())
+                print("LeRF step, train gemm mode %d vs fp32 products, tensor %d: norm-wise %.2e" % (mode, i, e))
+                assert bool(torch.isfinite(a).all()) and e < bars[mode][2], (mode, i, e)
     finally:
         L.check(L.lib().nrf_set_train_gemm(prev))
