@@ -752,6 +752,9 @@ NRF_API int nrf_get_train_gemm(void);
 NRF_API int nrf_set_train_gemm(int mode);
 /* The products themselves: C [m x n] (ldc) = A [m x k] (lda) . B [n x k]^T (ldb) (+ bias [n]) (ReLU), fp32 row-major in and out */
 NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
+/* dW [out x in] (ld in; columns col0 .. col0 + n) += G [p x out]^T (ldg) . X [p x n] (ldx), fp32 row-major: the weight-gradient product of a layer over p points
+ * (bf16x3 arithmetic -- a per-point scale cannot be undone in a sum over points; deterministic: slices of the points summed in a fixed order) */
+NRF_API int nrf_gemm_tn_bf16x3(const float *d_g, int ldg, int out, const float *d_x, int ldx, int n, int64_t p, float *d_dw, int in, int col0, void *stream);
 NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
 NRF_API int nrf_profile_enable(int on);
 /* 1 while the event bracketing is on.  A throughput measurement must run with it off: an event pair around every kernel of every lane costs host time per launch and

@@ -38,11 +38,12 @@ struct nrf_hash {
     size_t fast_bytes = 0;
     bool fast_valid = false;
     int dense_levels = 0;
-    // RMS of the table's entries (device float, refreshed by every nrf_hash_set_table in its stream; a deterministic two-stage sum: the same table always gives the same
-    // bits) and a counter of the uploads: what a renderer's split-precision network scales its first layer by (mlp.h, k_small_scales)
+    // RMS of the table's entries (device float; a deterministic two-stage sum: the same table always gives the same bits), re-derived on demand
+    // (hash_table_rms_update) when the table was uploaded since, and a counter of the uploads: what a renderer's split-precision network scales its first layer by
+    // (mlp.h, k_small_scales)
     float *d_table_rms = nullptr;
     float *d_rms_part = nullptr;
-    uint64_t table_version = 0;
+    uint64_t table_version = 0, rms_version = ~(uint64_t)0;
     size_t dense_budget = (size_t)24 << 30;   // bytes of dense image to bake (levels 0.. while they fit): 4.4 GB at 16..512; at 16..1024 the finest level (35 GB) stays hashed -- HBM is 288 GB
 };
 
@@ -51,6 +52,7 @@ namespace nrf {
 int launch_pe(const float *x, int x_stride, int64_t rows, int nfreq, int rep, float *out, int out_stride, hipStream_t st);
 int launch_sh(const float *dirs, int dir_stride, int64_t rows, int degree, int variant, int rep, float *out, int out_stride, hipStream_t st);
 int launch_hash(const nrf_hash *h, const PointSource &ps, int64_t p, float *out, int out_stride, uint8_t *keep, hipStream_t st);
+int hash_table_rms_update(nrf_hash *h, hipStream_t st);          // *h->d_table_rms brought up to date with the table (no-op when it is)
 
 // CuHashEmbedder.cu:70-100: 8 hashed corners, trilinear weights as three-factor products, fp32 sum of
 // products in the order 000,001,010,011,100,101,110,111 (bit 2 = x, bit 1 = y, bit 0 = z).

@@ -197,11 +197,12 @@ __global__ void k_hash_cu_lmf(HashParams hp, PointSource ps, int64_t p, __half *
 // RMS of `n` floats, deterministic: block b of RMS_BLOCKS sums elements b * 256 + t, + RMS_BLOCKS * 256, ... per thread, the block's 256 partials and then the blocks'
 // are added in index order
 constexpr int RMS_BLOCKS = 256;
-__global__ void __launch_bounds__(256) k_sumsq_partial(int64_t n, const float *__restrict__ in, float *__restrict__ part)
+template <typename T>
+__global__ void __launch_bounds__(256) k_sumsq_partial(int64_t n, const T *__restrict__ in, float *__restrict__ part)
 {
     __shared__ float s[256];
     float a = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RMS_BLOCKS * 256) { const float v = in[i]; a += v * v; }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)RMS_BLOCKS * 256) { const float v = (float)in[i]; a += v * v; }
     s[threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.x == 0) { float r = 0.0f; for (int i = 0; i < 256; i++) r += s[i]; part[blockIdx.x] = r; }
@@ -211,6 +212,22 @@ __global__ void k_rms_final(int64_t n, const float *__restrict__ part, float *__
     float r = 0.0f;
     for (int i = 0; i < RMS_BLOCKS; i++) r += part[i];
     *rms = sqrtf(r / (float)n);
+}
+
+// *d_table_rms = RMS of the table as the kernels see it (the fp16 table of the CuHashEmbedder mode, the fp32 one of the LibTorch twin), in `st`'s order; a no-op while the
+// table has not changed since the last call
+int hash_table_rms_update(nrf_hash *h, hipStream_t st)
+{
+    if (!h || !h->table_set || !h->d_table_rms) return NRF_OK;
+    if (h->rms_version == h->table_version) return NRF_OK;
+    const int64_t elems = nrf_hash_table_elems(h);
+    if (h->desc.mode == NRF_HASH_NGP) hipLaunchKernelGGL(k_sumsq_partial<float>, dim3(RMS_BLOCKS), dim3(256), 0, st, elems, reinterpret_cast<const float *>(h->d_table), h->d_rms_part);
+    else hipLaunchKernelGGL(k_sumsq_partial<__half>, dim3(RMS_BLOCKS), dim3(256), 0, st, elems, reinterpret_cast<const __half *>(h->d_table), h->d_rms_part);
+    NRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(1), 0, st, elems, h->d_rms_part, h->d_table_rms);
+    NRF_LAUNCH_CHECK();
+    h->rms_version = h->table_version;
+    return NRF_OK;
 }
 
 __global__ void k_f32_to_f16(int64_t n, const float *__restrict__ in, __half *__restrict__ out)
@@ -356,17 +373,8 @@ int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *s
         NRF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_table_rms), sizeof(float)));
         NRF_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_rms_part), RMS_BLOCKS * sizeof(float)));
     }
-    auto table_rms = [&](const float *d_f32) -> int {
-        hipLaunchKernelGGL(k_sumsq_partial, dim3(RMS_BLOCKS), dim3(256), 0, st, elems, d_f32, h->d_rms_part);
-        NRF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_rms_final, dim3(1), dim3(1), 0, st, elems, h->d_rms_part, h->d_table_rms);
-        NRF_LAUNCH_CHECK();
-        h->table_version++;
-        return NRF_OK;
-    };
     if (h->desc.mode == NRF_HASH_NGP) {
         NRF_HIP(hipMemcpyAsync(h->d_table, src, (size_t)elems * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        NRF_TRY(table_rms(reinterpret_cast<const float *>(h->d_table)));
     } else {
         // fp32 master -> fp16 once (the reference re-casts on every forward, CuHashEmbedder.cu:257)
         const float *d_src = src;
@@ -378,14 +386,15 @@ int nrf_hash_set_table(nrf_hash *h, const float *src, int src_on_device, void *s
         }
         hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, elems, d_src, reinterpret_cast<__half *>(h->d_table));
         NRF_LAUNCH_CHECK();
-        NRF_TRY(table_rms(d_src));
         if (tmp) { NRF_HIP(hipStreamSynchronize(st)); NRF_HIP(hipFree(tmp)); }
     }
     h->table_set = true;
     h->fast_valid = false;
+    h->table_version++;          // (the table's RMS is re-derived by hash_table_rms_update when a consumer asks: a LeRF language grid of 134 MB never does)
     if (hash_fast_supported(h)) NRF_TRY(hash_fast_prepare(h, h->dense_budget, st));
     return NRF_OK;
 }
+
 
 int nrf_hash_set_primes(nrf_hash *h, const int32_t *primes, const float *biases)
 {

@@ -198,6 +198,62 @@ __device__ __forceinline__ void gb_store_b(unsigned char *b_base, int b_half, in
     for (int c = 0; c < 4; c++) *reinterpret_cast<gb_u32x4 *>(b_base + (c >> 1) * b_half + (c & 1) * BN * 32 + t * 16) = rb[c];
 }
 
+// Epilogue of the 256-wide tiles through LDS: the workgroup's C block goes out as WHOLE ROWS (1 KB contiguous per wave instruction, the whole 128 x 256 block contiguous
+// when ldc == N) instead of 128-byte pieces of rows 1 KB apart (the same DRAM-page argument as for the A burst).  Row stride 260 floats: the two half-waves of an
+// accumulator register write rows 4 apart, 4 x 1040 bytes = 64 bytes off in the banks.  The inverse scales (F16), the bias, the ReLU and the mask are applied at the
+// write-out, once per row and four columns at a time, not per accumulator register.  All waves must be past their last LDS read of the K loop (a barrier) on entry.
+template <bool F16>
+__device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N,
+                                                 const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h)
+{
+    constexpr int CS = GbCfg<4>::BN + 4;
+    float *ct = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int nl = wn * 64 + j * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) ct[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + nl] = acc[i][j][q];
+    }
+    __syncthreads();
+    const int c4 = (t & 63) * 4, rw = t >> 6;                             // this thread's four columns; rows rw, rw + 8, ...
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!mask || (((mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < N) bias4[jj] = bias[n0 + c4 + jj];
+    }
+#pragma unroll 4
+    for (int i = 0; i < GB_BM / 8; i++) {
+        const int ml = rw + 8 * i;
+        const int64_t m = m0 + ml;
+        const int n = n0 + c4;
+        if (m >= M || n >= N) continue;
+        float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
+        if (F16) { const float rs = rinv[ml]; v.x = v.x * rs * binv; v.y = v.y * rs * binv; v.z = v.z * rs * binv; v.w = v.w * rs * binv; }          // (two steps: rs x binv alone may leave fp32's range)
+        v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
+        if (relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
+        if (vec_ok && n + 4 <= N) {
+            if (mask) {
+                const float4 k = *reinterpret_cast<const float4 *>(mask + m * mask_ld + n);
+                v.x = k.x > 0.0f ? v.x : 0.0f; v.y = k.y > 0.0f ? v.y : 0.0f; v.z = k.z > 0.0f ? v.z : 0.0f; v.w = k.w > 0.0f ? v.w : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(c + m * ldc + n) = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int jj = 0; jj < 4 && n + jj < N; jj++) {
+                float x = e[jj];
+                if (mask) x = mask[m * mask_ld + n + jj] > 0.0f ? x : 0.0f;
+                c[m * ldc + n + jj] = x;
+            }
+        }
+    }
+}
+
+constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
+constexpr int GB_ROWS_LDS = GB_ROWS_LDS_BASE + GB_BM * 4;                                                                                            // + the rows' inverse scales
+
 // XCD: consecutive workgroup ids are dealt out round-robin to the 8 XCDs (each with its own L2): the launch is re-indexed so that XCD x works through a CONTIGUOUS
 // eighth of the tiles -- the n-blocks of one m-block (which read the same A rows) and neighbouring m-blocks (which read the same B) then share an L2
 template <int WNW, bool F16>
@@ -240,7 +296,7 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
     // F16: the rows' scales need every row's largest entry BEFORE the first split -- one extra pass over the workgroup's A rows (their second read, by the K loop, comes
     // out of the caches); the inverse scales wait in LDS for the epilogue
     float as[Cfg::QA], binv = 1.0f;
-    float *rinv = reinterpret_cast<float *>(gb_smem + 2 * Cfg::STAGE);
+    float *rinv = reinterpret_cast<float *>(gb_smem + (WNW == 4 ? GB_ROWS_LDS_BASE : 2 * Cfg::STAGE));          // (the 256-wide tile stages its C block through LDS: past it)
 #pragma unroll
     for (int i = 0; i < Cfg::QA; i++) as[i] = 1.0f;
     if (F16) {
@@ -322,6 +378,10 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
         if (tile + 2 < T) store_tile(0, ra0, rb0);
         __syncthreads();
     }
+    if (WNW == 4) {          // whole rows through LDS, as the burst kernel's
+        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
+        return;
+    }
     // epilogue: register q of lane (r, h) of tile (i, j) is C[m0 + 64 wm + 32 i + (q & 3) + 8 (q >> 2) + 4 h][n0 + 64 wn + 32 j + r]
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -342,9 +402,6 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
             }
     }
 }
-
-constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
-constexpr int GB_ROWS_LDS = GB_ROWS_LDS_BASE + GB_BM * 4;                                                                                            // + the rows' inverse scales
 
 // The same product with the WHOLE A block of the workgroup (128 rows x K <= 256 columns: one contiguous 128 KB of a [M][K] array) requested in one burst at kernel
 // start: with K tiles of 32 requested one by one every row is visited eight times, 128 bytes at a time, microseconds apart -- DRAM pages are re-opened for each piece and
@@ -453,55 +510,235 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         if (tile + 1 < TK) { if (tile & 1) store_tile(0, ra[tile + 1 < TK ? tile + 1 : 0], rb0); else store_tile(1, ra[tile + 1 < TK ? tile + 1 : 0], rb1); }
         __syncthreads();
     }
-    // epilogue through LDS: the workgroup's C block goes out as WHOLE ROWS (1 KB contiguous per wave instruction, the whole 128 x 256 block contiguous when ldc == N) instead
-    // of 128-byte pieces of rows 1 KB apart (the same DRAM-page argument as for the A burst).  Row stride 260 floats: the two half-waves of an accumulator register write
-    // rows 4 apart, 4 x 1040 bytes = 64 bytes off in the banks.
-    constexpr int CS = Cfg::BN + 4;
-    float *ct = reinterpret_cast<float *>(gb_smem);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int nl = wn * 64 + j * 32 + r;
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) ct[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + nl] = acc[i][j][q];
-    }
-    __syncthreads();
-    // (the inverse scales, the bias and the ReLU are applied here, once per row and four columns at a time, not per accumulator register)
-    const int c4 = (t & 63) * 4, rw = t >> 6;                             // this thread's four columns; rows rw, rw + 8, ...
-    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0) && (!g.mask || (((g.mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.mask) & 15) == 0)));
-    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (g.bias) {
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < g.N) bias4[jj] = g.bias[n0 + c4 + jj];
-    }
-#pragma unroll 4
-    for (int i = 0; i < GB_BM / 8; i++) {
-        const int ml = rw + 8 * i;
-        const int64_t m = m0 + ml;
-        const int n = n0 + c4;
-        if (m >= g.M || n >= g.N) continue;
-        float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
-        if (F16) { const float rs = rinv[ml]; v.x = v.x * rs * binv; v.y = v.y * rs * binv; v.z = v.z * rs * binv; v.w = v.w * rs * binv; }          // (two steps: rs x binv alone may leave fp32's range)
-        v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
-        if (g.relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
-        if (vec_ok && n + 4 <= g.N) {
-            if (g.mask) {
-                const float4 k = *reinterpret_cast<const float4 *>(g.mask + m * g.mask_ld + n);
-                v.x = k.x > 0.0f ? v.x : 0.0f; v.y = k.y > 0.0f ? v.y : 0.0f; v.z = k.z > 0.0f ? v.z : 0.0f; v.w = k.w > 0.0f ? v.w : 0.0f;
-            }
-            *reinterpret_cast<float4 *>(g.c + m * g.ldc + n) = v;
-        } else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
-            for (int jj = 0; jj < 4 && n + jj < g.N; jj++) {
-                float x = e[jj];
-                if (g.mask) x = g.mask[m * g.mask_ld + n + jj] > 0.0f ? x : 0.0f;
-                g.c[m * g.ldc + n + jj] = x;
-            }
-        }
-    }
+    gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
 }
 
+
+static int vec_class(const float *p, int ld, int col0)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p + col0);
+    if ((a & 15) == 0 && (ld & 3) == 0) return 4;
+    if ((a & 7) == 0 && (ld & 1) == 0) return 2;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------------
+// The WEIGHT GRADIENT  dW [out x n] += G [P x out]^T . X [P x n]:  both operands are row-major over the POINTS, i.e. the contraction runs over their slow index -- a
+// "TN" product whose K is 10^5..10^6 and whose result is one small matrix.  (rocBLAS needs 32 strided-batch slices + a sum to fill the chip with it: 6-9 ms of a
+// training step.)  Here: 128 x 128 output tile per 256-thread workgroup (2 x 2 waves of 64 x 64) over one SLICE of the points; the slices' partial matrices are summed
+// by k_sum_partials in a fixed order (deterministic, no atomics).  K tile = 32 points:
+//   * a thread loads, for ONE operand (waves 0-1: G, waves 2-3: X), four consecutive columns of eight consecutive points (eight 16-byte loads; the 32 lanes of a
+//     half-wave cover 512 contiguous bytes of a point's row) -- that is four columns x eight k values = four 16-byte MFMA operand pieces after the split: the transpose
+//     happens in registers, four ds_write_b128 per half.
+//   * LDS image per operand and half: [k-step][position][16 elements] with position = (column & 3) * 32 + (column >> 2): one write instruction's 64 lanes (32 column
+//     quads x the two 8-point halves of a k-step) cover one contiguous KB, and a fragment read (32 positions) another: no bank conflicts either way.  MFMA tile t,
+//     row r is therefore column 4 r + t of the workgroup's 128.
+//   * arithmetic: bf16x3 (hi + lo bf16, fp32's exponent range: a column of G spans many orders of magnitude over the points, and a per-POINT scale cannot be undone in a
+//     sum over points).  16 significant bits in a LEAF product -- nothing is computed from dW inside the step -- measured 5e-6 of its largest entry.
+struct GemmTN {
+    const float *g; int ldg, out;         // G [P][ldg], columns [0, out)
+    const float *x; int ldx, n;           // X [P][ldx], columns [0, n)
+    int64_t P, slice_pts;                 // points (a multiple of 32), points per slice (a multiple of 32)
+    float *part;                          // [slices][out][n]
+    int vg, vx;                           // 4: rows 16-byte aligned and the column count a multiple of 4 (vector loads); 1: scalar loads
+    int nbo, nbi;                         // output tiles along out / n
+};
+
+constexpr int TN_T = 128;                                                 // tile edge
+constexpr int TN_OP = 2 * 2 * TN_T * 32;                                  // bytes of one operand's [hi | lo][k-step][position][16] image
+constexpr int TN_STAGE = 2 * TN_OP;
+
+template <bool VEC>          // VEC: both operands take 16-byte loads; otherwise both go element by element with clamped columns (unaligned segments, ragged widths)
+__global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t nb_all = gridDim.x, per = nb_all / 8;
+        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);           // XCD x works through a contiguous eighth: the tiles of one slice share an L2
+    }
+    const int tiles = a.nbo * a.nbi;
+    const int64_t slice = bid / tiles;
+    const int tl = (int)(bid - slice * tiles);
+    const int bo = tl / a.nbi, bi = tl - bo * a.nbi;
+    const int64_t p_begin = slice * a.slice_pts;
+    int64_t p_end = p_begin + a.slice_pts; if (p_end > a.P) p_end = a.P;
+    const int T = (int)((p_end - p_begin) / 32);
+    // staging map
+    const int opnd = t >> 7, unit = t & 127, cq = unit & 31, pg = unit >> 5;          // pg: which eight of the tile's 32 points; waves 0-1: G, 2-3: X
+    const float *src = opnd ? a.x : a.g;
+    const int ld = opnd ? a.ldx : a.ldg, ncols = opnd ? a.n : a.out;
+    int col = (opnd ? bi : bo) * TN_T + 4 * cq;
+    // columns past the operand's end are clamped to valid memory: what they produce lands in output rows / columns that are not stored
+    int cj[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) cj[j] = col + j < ncols ? col + j : ncols - 1;
+    if (VEC && col + 4 > ncols) col = ncols - 4;
+    float4 r0[8], r1[8];
+    auto load_tile = [&](int tile, float4 (&rr)[8]) {
+        const float *rp = src + (p_begin + (int64_t)tile * 32 + pg * 8) * ld;
+        if (VEC) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) rr[k] = *reinterpret_cast<const float4 *>(rp + (int64_t)k * ld + col);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float *q = rp + (int64_t)k * ld;
+                rr[k].x = q[cj[0]]; rr[k].y = q[cj[1]]; rr[k].z = q[cj[2]]; rr[k].w = q[cj[3]];
+            }
+        }
+    };
+    auto store_tile = [&](int stage, const float4 (&rr)[8]) {
+        unsigned char *base = gb_smem + stage * TN_STAGE + opnd * TN_OP;
+        const int ks = pg >> 1, hh = pg & 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            gb_bf16x8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float v = j == 0 ? rr[k].x : (j == 1 ? rr[k].y : (j == 2 ? rr[k].z : rr[k].w));
+                const __bf16 b = (__bf16)v;
+                hi[k] = b; lo[k] = (__bf16)(v - (float)b);
+            }
+            const int off = (ks * TN_T + j * 32 + cq) * 32 + hh * 16;
+            *reinterpret_cast<gb_bf16x8 *>(base + off) = hi;
+            *reinterpret_cast<gb_bf16x8 *>(base + TN_OP / 2 + off) = lo;
+        }
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    gb_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+    auto multiply = [&](int stage) {
+        const unsigned char *base = gb_smem + stage * TN_STAGE;
+#pragma unroll 1
+        for (int ks = 0; ks < 2; ks++) {
+            gb_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int offa = (ks * TN_T + (2 * wm + i) * 32 + r) * 32 + h * 16;
+                ah[i] = *reinterpret_cast<const gb_bf16x8 *>(base + offa);
+                al[i] = *reinterpret_cast<const gb_bf16x8 *>(base + TN_OP / 2 + offa);
+                const int offb = (ks * TN_T + (2 * wn + i) * 32 + r) * 32 + h * 16;
+                bh[i] = *reinterpret_cast<const gb_bf16x8 *>(base + TN_OP + offb);
+                bl[i] = *reinterpret_cast<const gb_bf16x8 *>(base + TN_OP + TN_OP / 2 + offb);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = GbT<false>::mfma(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = GbT<false>::mfma(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = GbT<false>::mfma(ah[i], bh[j], acc[i][j]);
+                }
+        }
+    };
+    if (T > 0) load_tile(0, r0);
+    if (T > 1) load_tile(1, r1);
+    if (T > 0) store_tile(0, r0);
+    __syncthreads();
+    for (int tile = 0; tile < T; tile += 2) {
+        if (tile + 2 < T) load_tile(tile + 2, r0);
+        multiply(0);
+        if (tile + 1 < T) store_tile(1, r1);
+        __syncthreads();
+        if (tile + 1 >= T) break;
+        if (tile + 3 < T) load_tile(tile + 3, r1);
+        multiply(1);
+        if (tile + 2 < T) store_tile(0, r0);
+        __syncthreads();
+    }
+    // register q of lane (r, h) of tile pair (i, j): G column o = 128 bo + 4 ((q & 3) + 8 (q >> 2) + 4 h) + (2 wm + i), X column c = 128 bi + 4 r + (2 wn + j)
+    float *dst = a.part + (size_t)slice * a.out * a.n;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = bi * TN_T + 4 * r + 2 * wn + j;
+            if (c >= a.n) continue;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int o = bo * TN_T + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + 2 * wm + i;
+                if (o < a.out) dst[(size_t)o * a.n + c] = acc[i][j][q];
+            }
+        }
+}
+
+__global__ void k_tn_sum(int slices, int out, int n, int in, int col0, const float *__restrict__ part, float *__restrict__ dw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= out * n) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= slices; b += 4) {
+        s0 += part[(size_t)b * out * n + e]; s1 += part[(size_t)(b + 1) * out * n + e]; s2 += part[(size_t)(b + 2) * out * n + e]; s3 += part[(size_t)(b + 3) * out * n + e];
+    }
+    for (; b < slices; b++) s0 += part[(size_t)b * out * n + e];
+    const int o = e / n, i = e - o * n;
+    dw[(size_t)o * in + col0 + i] += (s0 + s1) + (s2 + s3);
+}
+
+// the last P % 32 points (fp32 FMAs, one thread per dw entry)
+__global__ void k_tn_tail(int pts, int out, int n, const float *__restrict__ g, int ldg, const float *__restrict__ x, int ldx, int in, int col0, float *__restrict__ dw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= out * n) return;
+    const int o = e / n, i = e - o * n;
+    float acc = 0.0f;
+    for (int p = 0; p < pts; p++) acc = fmaf(g[(size_t)p * ldg + o], x[(size_t)p * ldx + i], acc);
+    dw[(size_t)o * in + col0 + i] += acc;
+}
+
+// dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
+int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
+{
+    if (P <= 0 || x.n <= 0 || out <= 0) return NRF_OK;
+    const int64_t P32 = P & ~(int64_t)31;
+    if (P32 < P) {
+        hipLaunchKernelGGL(k_tn_tail, dim3((unsigned)ceil_div((int64_t)out * x.n, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, x.n, g.p + g.off + P32 * g.stride, g.stride,
+                           x.p + x.off + P32 * x.stride, x.stride, in, col0, dw);
+        NRF_LAUNCH_CHECK();
+    }
+    if (P32 == 0) return NRF_OK;
+    GemmTN a{};
+    a.g = g.p + g.off; a.ldg = g.stride; a.out = out;
+    a.x = x.p + x.off; a.ldx = x.stride; a.n = x.n;
+    a.P = P32;
+    a.vg = (vec_class(a.g, a.ldg, 0) == 4 && (out & 3) == 0) ? 4 : 1;
+    a.vx = (vec_class(a.x, a.ldx, 0) == 4 && (x.n & 3) == 0) ? 4 : 1;
+    a.nbo = (out + TN_T - 1) / TN_T; a.nbi = (x.n + TN_T - 1) / TN_T;
+    const int tiles = a.nbo * a.nbi;
+    // slices: two rounds of the chip's 512 resident workgroups (each slice's partial matrix is written and read once more: 512 slices cost more in k_tn_sum than their
+    // balance bought), at least 8 K tiles (256 points) each
+    int64_t slices = (1024 + tiles - 1) / tiles;
+    const int64_t max_slices = (P32 / 32 + 7) / 8;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    a.slice_pts = ((P32 / 32 + slices - 1) / slices) * 32;
+    slices = (P32 + a.slice_pts - 1) / a.slice_pts;
+    float *part = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * out * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_bf16x3: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    a.part = part;
+    static bool attr = false;
+    if (!attr) {
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
+        NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_tn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
+        attr = true;
+    }
+    if (a.vg == 4 && a.vx == 4) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
+    else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
+    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * x.n, (int64_t)256)), dim3(256), 0, st, (int)slices, out, x.n, in, col0, (const float *)part, dw);
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(part, st);
+    if (le != hipSuccess) { set_error("gemm_tn_bf16x3: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
+    return NRF_OK;
+}
 
 // Arithmetic of the training paths' forward / back-propagation products.  -1 (the default, NRF_TRAIN_GEMM=auto): by network family -- f16x3 for the classic NeRF and the
 // LeRF head (whose 256-wide layers ARE the training step; their reference-autograd goldens hold in it), fp32 products for NeRFSmall's fp32 backward (the hash path's
@@ -537,13 +774,6 @@ int train_gemm_for(const nrf_mlp *m)
     return (m && m->family == MLP_SMALL) ? 0 : 2;
 }
 
-static int vec_class(const float *p, int ld, int col0)
-{
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p + col0);
-    if ((a & 15) == 0 && (ld & 3) == 0) return 4;
-    if ((a & 7) == 0 && (ld & 1) == 0) return 2;
-    return 1;
-}
 
 template <bool F16>
 static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
@@ -553,7 +783,7 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     const int bn = wide ? 256 : 128;
     const int64_t blocks = ceil_div(g.M, GB_BM) * ceil_div((int64_t)g.N, (int64_t)bn);
     if (blocks > 0x7fffffff) { set_error("gemm_nt_split: too many tiles"); return NRF_ERR_INVALID_ARG; }
-    constexpr int LDS2 = 2 * GbCfg<2>::STAGE + GB_BM * 4, LDS4 = 2 * GbCfg<4>::STAGE + GB_BM * 4;          // two stages + the rows' inverse scales
+    constexpr int LDS2 = 2 * GbCfg<2>::STAGE + GB_BM * 4, LDS4 = GB_ROWS_LDS;          // two stages + the rows' inverse scales; the 256-wide tile: its C block staged through LDS
     static bool attr_set = false;
     if (!attr_set) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
@@ -619,6 +849,12 @@ extern "C" NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, 
 {
     NRF_CHECK_ARG(d_a && d_b && d_c && m >= 0 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n, "nrf_gemm_nt_bf16x3: bad argument");
     return nrf::gemm_nt_split(1, m, n, nrf::Seg{d_a, lda, 0, k}, nrf::Seg{nullptr, 0, 0, 0}, d_b, ldb, d_c, ldc, d_bias, relu, nullptr, 0, nrf::as_stream(stream));
+}
+// dW [out x in] (ld in; columns col0 .. col0 + n) += G [p x out]^T (ldg) . X [p x n] (ldx): the weight-gradient product, bf16x3 arithmetic, deterministic
+extern "C" NRF_API int nrf_gemm_tn_bf16x3(const float *d_g, int ldg, int out, const float *d_x, int ldx, int n, int64_t p, float *d_dw, int in, int col0, void *stream)
+{
+    NRF_CHECK_ARG(d_g && d_x && d_dw && p >= 0 && out >= 1 && n >= 1 && ldg >= out && ldx >= n && col0 >= 0 && in >= col0 + n, "nrf_gemm_tn_bf16x3: bad argument");
+    return nrf::gemm_tn_bf16x3(p, nrf::Seg{d_g, ldg, 0, out}, nrf::Seg{d_x, ldx, 0, n}, out, in, col0, d_dw, nrf::as_stream(stream));
 }
 extern "C" NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream)
 {

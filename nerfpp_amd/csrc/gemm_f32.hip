@@ -127,8 +127,13 @@ __global__ void k_sum_partials(int batches, int out, int n, int in, int col0, co
 // dw[o][i] += sum_pt g[pt][o] cat[a, b][pt][i]: accumulated by the GEMM itself (beta = 1), no atomics.  A weight gradient is a SMALL matrix (out x in) summed over very
 // MANY points: as one GEMM it is a handful of output tiles with a huge K (12 workgroups for 768 x 256: 29 TFLOP/s).  Above 16 k points the points are cut into 32 slices
 // computed as one strided-batched GEMM into partial matrices, which one small kernel then adds to dw.
-int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st)
+int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith)
 {
+    if (arith != 0 && npts >= 4096 && out >= 32) {          // the split-precision modes: the hand-written bf16x3 TN product (gemm_bf16x3.hip), one call per column segment
+        if (a.n > 0) NRF_TRY(gemm_tn_bf16x3(npts, g, a, out, in, 0, dw, st));
+        if (b.n > 0) NRF_TRY(gemm_tn_bf16x3(npts, g, b, out, in, a.n, dw, st));
+        return NRF_OK;
+    }
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_grad_w(npts, g, a, b, out, in, dw, st);
     const float one = 1.0f, zero = 0.0f;

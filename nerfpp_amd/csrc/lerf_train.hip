@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256) k_ltg_ray_v(int e, const float *__restric
     }
 }
 
-// per ray: t_j, beta_j; g_a,j = (w_j / c_j) q - beta_j s_j written OVER s_j; ba_j = beta_j a_j; the weights' backward -> g33 column 0 (as k_lt_ray's tail)
+// per ray: t_j, beta_j; g_a,j = ((w_j / c_j) q - beta_j s_j) . [a_j > 0] written OVER s_j; ba_j = beta_j a_j; the weights' backward -> g33 column 0 (as k_lt_ray's tail)
 __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *__restrict__ q, const float *__restrict__ a, int as, float *__restrict__ sg_a, int sgs,
                                                    float *__restrict__ ba, int bs, const float *__restrict__ pp, const uint8_t *__restrict__ keep, const float *__restrict__ z,
                                                    const float *__restrict__ dirs, int d_stride, float *__restrict__ g33, int gs)
@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *_
         const float wc = w / c;
         for (int k = lane; k < hd; k += 64) {
             const float av = ar[k];
-            sr[k] = wc * qs[k] - beta * sr[k];
+            const float ga = wc * qs[k] - beta * sr[k];
+            sr[k] = av > 0.0f ? ga : 0.0f;          // a is a ReLU output: its mask here instead of in a pass of its own (what run_relu_mask would do before the next layer)
             br[k] = beta * av;
         }
         if (lane == 0) gw[j] = t;
@@ -452,6 +453,7 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     float *g33 = G[0];
     Seg g{hle, W, 0, E};
     int gi = 1, l_top = NL - 1;
+    bool gram_masked = false;
     if (gram) {
         // ---- last layer, normalize, RenderCLIPEmbedding and their backward in the layer's INPUT space (see k_ltg_ray_u) ----
         const LinearLayer &L1 = m->layers[NL - 1];
@@ -462,7 +464,9 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         float *ba = G[1];                                                  // beta_j a_j
         float *pp = G[2];                                                  // per-sample scalars [c][8]
         float *mm = const_cast<float *>(gram) + (size_t)hd * hd, *u = mm + (size_t)hd * hd, *v = u + (size_t)rays * hd, *gv = v + (size_t)rays * E, *q = gv + (size_t)rays * E;      // M [hd x hd]; per-ray rows
-        NRF_TRY(gemm_rm(st, false, false, c, hd, hd, 1.0f, a, W, gram, hd, 0.0f, sga, W));                                  // S = A G   (G symmetric)
+        const int arith = c >= 4096 ? train_gemm_for(m) : 0;               // the split-precision matrix-core products of gemm_bf16x3.hip instead of rocBLAS
+        if (arith) NRF_TRY(gemm_nt_split(arith, c, hd, Seg{a, W, 0, hd}, none, gram, hd, sga, W, nullptr, 0, nullptr, 0, st));           // S = A G = A G^T (G symmetric): an NT product
+        else NRF_TRY(gemm_rm(st, false, false, c, hd, hd, 1.0f, a, W, gram, hd, 0.0f, sga, W));                             // S = A G   (G symmetric)
         hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)(7 * s + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
                            (const float *)sga, W, pp, u, weights);
         NRF_LAUNCH_CHECK();
@@ -475,9 +479,13 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         NRF_LAUNCH_CHECK();
         float *dw = g_params + L1.w_off;                                   // [E][hd]
         NRF_TRY(gemm_rm(st, true, false, E, hd, rays, 1.0f, gv, E, u, hd, 1.0f, dw, hd));                                  // dW += G_V^T U
-        NRF_TRY(gemm_rm(st, true, false, hd, hd, c, 1.0f, a, W, ba, W, 0.0f, mm, hd));                                     // M = A^T diag(beta) A
+        if (arith) {                                                                                                       // M = A^T diag(beta) A: the weight-gradient product's shape
+            NRF_HIP(hipMemsetAsync(mm, 0, (size_t)hd * hd * sizeof(float), st));
+            NRF_TRY(gemm_tn_bf16x3(c, Seg{a, W, 0, hd}, Seg{ba, W, 0, hd}, hd, hd, 0, mm, st));
+        } else NRF_TRY(gemm_rm(st, true, false, hd, hd, c, 1.0f, a, W, ba, W, 0.0f, mm, hd));
         NRF_TRY(gemm_rm(st, false, false, E, hd, hd, -1.0f, wle, hd, mm, hd, 1.0f, dw, hd));                               // dW -= W M
         g = Seg{sga, W, 0, hd};
+        gram_masked = true;                                                // k_ltg_ray_g has applied H[NL - 2]'s ReLU mask to g_a
         l_top = NL - 2;
         gi = 1;                                                            // G[1] (ba) is free again once M is formed: stream order
     } else {
@@ -492,12 +500,12 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     // ---- LE net backward (last layer first)                                                        LeRF.cpp:97-103 ----
     // (bf16x3 products: the ReLU mask of the NEXT stage is applied by the back-propagation product's epilogue -- `premasked` -- instead of by a pass of its own)
     const bool fuse = run_backprop_fuses_mask(m, c);
-    bool premasked = false;
+    bool premasked = gram_masked;
     for (int l = l_top; l >= nl; l--) {
         const LinearLayer &L = m->layers[l];
         if (l != NL - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
-        NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st));
+        NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
         float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
         premasked = fuse && !first;                          // dst = d / d H[l - 1], a ReLU output
         NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, premasked ? H[l - 1] : nullptr, W));
@@ -516,7 +524,7 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     for (int l = nl - 1; l >= 0; l--) {
         const LinearLayer &L = m->layers[l];
         if (l != nl - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
-        NRF_TRY(run_grad_w_fast(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
+        NRF_TRY(run_grad_w_fast(c, g, l == 0 ? xin : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
         if (l == 0 && !g_emb) break;
         float *dst = freeb[fi]; fi ^= 1;
         premasked = fuse && l >= 1;                          // dst = d / d H[l - 1]

@@ -375,7 +375,7 @@ int mlp_small_backward(const nrf_mlp *m, const float *x, int xs, const float *g_
                 NRF_LAUNCH_CHECK();
             }
             const bool first = (l == sig_l + 1);
-            NRF_TRY(run_grad_w_fast(c, g, first ? cv : Seg{H[l - 1], W, 0, L.in}, first ? cg : none, L.out, L.in, g_params + L.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g, first ? cv : Seg{H[l - 1], W, 0, L.in}, first ? cg : none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
             float *dst = G[gi]; gi = (gi + 1) % 3;
             NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st));
             g = Seg{dst, W, 0, L.in};
@@ -395,7 +395,7 @@ int mlp_small_backward(const nrf_mlp *m, const float *x, int xs, const float *g_
                 hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)ceil_div(c * L.out, 256)), dim3(256), 0, st, c * L.out, L.out, const_cast<float *>(g.p), g.stride, H[l], W);
                 NRF_LAUNCH_CHECK();
             }
-            NRF_TRY(run_grad_w_fast(c, g, l == 0 ? Seg{xc, xs, 0, d.input_ch} : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g, l == 0 ? Seg{xc, xs, 0, d.input_ch} : Seg{H[l - 1], W, 0, L.in}, none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
             if (l == 0 && !g_x) break;
             float *dst = (l == 0) ? g_x + p0 * gxs : G[gi];
             gi = (gi + 1) % 3;
@@ -510,20 +510,20 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_linear_fast(c, sfeat, sviews, m, views, 1, HV, W, 0, st));                                             // relu(views_linears_0(cat))         :111-117
             const Seg g_rgb{gc, gos, 0, 3}, g_alpha{gc, gos, 3, 1};
             // rgb_linear                                                                                              :118
-            NRF_TRY(run_grad_w_fast(c, g_rgb, Seg{HV, W, 0, Wd / 2}, none, 3, Wd / 2, g_params + rgb.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g_rgb, Seg{HV, W, 0, Wd / 2}, none, 3, Wd / 2, g_params + rgb.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_rgb, 3, bias_of(rgb), st));
             NRF_TRY(run_backprop_fast(c, g_rgb, m, rgb, G[1], W, st));
             NRF_TRY(run_relu_mask(c, Wd / 2, G[1], W, HV, W, st));
             const Seg g_hv{G[1], W, 0, Wd / 2};
             // views_linears_0
-            NRF_TRY(run_grad_w_fast(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_hv, Wd / 2, bias_of(views), st));
             NRF_TRY(run_backprop_fast(c, g_hv, m, views, G[2], W, st));                                                     // d / d cat[feature, views]
             const Seg g_feat{G[2], W, 0, Wd};
             // feature_linear and alpha_linear, both on h                                                              :108-110
-            NRF_TRY(run_grad_w_fast(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_feat, Wd, bias_of(feat), st));
-            NRF_TRY(run_grad_w_fast(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_alpha, 1, bias_of(alpha), st));
             NRF_TRY(run_backprop_fast(c, g_feat, m, feat, G[1], W, st));
             NRF_TRY(run_backprop_fast(c, g_alpha, m, alpha, G[3], W, st));
@@ -531,7 +531,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         } else {
             const LinearLayer &outl = m->layers[D];                                                                    // output_linear(cat[h, input_pts])  :121-124
             const Seg g_o{gc, gos, 0, outl.out};
-            NRF_TRY(run_grad_w_fast(c, g_o, hlast, xin, outl.out, Wd + in, g_params + outl.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g_o, hlast, xin, outl.out, Wd + in, g_params + outl.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_o, outl.out, bias_of(outl), st));
             NRF_TRY(run_backprop_fast(c, g_o, m, outl, G[1], W, st));
             NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, nullptr, 0, 0, gh, W, st));
@@ -549,7 +549,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             const bool cat = (l > 0) && (l - 1 == d.skip);                                                             // this layer's input is cat[input_pts, h_{l-1}]
             const Seg a = (l == 0) ? xin : (cat ? xin : Seg{H[l - 1], W, 0, Wd});
             const Seg b = cat ? Seg{H[l - 1], W, 0, Wd} : none;
-            NRF_TRY(run_grad_w_fast(c, g, a, b, Wd, L.in, g_params + L.w_off, st));
+            NRF_TRY(run_grad_w_fast(c, g, a, b, Wd, L.in, g_params + L.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g, Wd, bias_of(L), st));
             if (l == 0 && !g_x) break;
             float *dst = (gcur == G[1]) ? G[2] : G[1];

@@ -174,6 +174,7 @@ static int ensure_scales(const nrf_renderer *r, hipStream_t st)
     nrf_mlp *m = const_cast<nrf_mlp *>(r->desc.mlp);
     if (!h || !m || m->family != MLP_SMALL || !m->d_group || !h->d_table_rms) return NRF_OK;
     if (m->d_in_rms_src == h->d_table_rms && m->in_rms_seen == h->table_version) return NRF_OK;
+    NRF_TRY(hash_table_rms_update(const_cast<nrf_hash *>(h), st));
     m->d_in_rms_src = h->d_table_rms; m->in_rms_seen = h->table_version;
     return mlp_small_rescale(m, st);
 }

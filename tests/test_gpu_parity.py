@@ -3601,6 +3601,36 @@ def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
                 assert err < bar, (K, wscale, err, bar)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,out,n,ldg,ldx,in_,col0", [(100000, 256, 256, 256, 256, 256, 0), (50001, 128, 283, 128, 283, 300, 17), (40000, 256, 63, 264, 63, 319, 256),
+                                                      (8192, 33, 143, 40, 144, 143, 0), (4100, 256, 128, 256, 128, 128, 0), (31, 64, 64, 64, 64, 64, 0)])
+def test_gemm_tn_bf16x3_vs_float64(api, P, out, n, ldg, ldx, in_, col0):
+    """nrf_gemm_tn_bf16x3 (gemm_bf16x3.hip: the weight-gradient product dW += G^T X, contraction over the points, bf16x3 arithmetic, slices of the points summed in a
+    fixed order) against the float64 product: within 2e-5 of the largest entry (measured 5e-6), added to what dW held, nothing written outside its columns; aligned and
+    unaligned rows (vector and element-wise load paths), ragged widths, a point count that is no multiple of 32 (tail kernel) and one below 32 (tail only);
+    two calls give the same bits (no atomics)."""
+    L = api.L
+    gen = torch.Generator(device="cuda"); gen.manual_seed(P + out + n)
+    G = torch.randn((P, ldg), device="cuda", generator=gen) * torch.pow(10.0, torch.rand((P, 1), device="cuda", generator=gen) * 6 - 6)          # gradient rows of any magnitude
+    X = torch.randn((P, ldx), device="cuda", generator=gen)
+    base = torch.randn((out, in_), device="cuda", generator=gen)
+    want = base.double().clone()
+    want[:, col0:col0 + n] += G[:, :out].double().t() @ X[:, :n].double()
+    outs = []
+    for _ in range(2):
+        dw = base.clone()
+        L.check(L.lib().nrf_gemm_tn_bf16x3(C.c_void_p(G.data_ptr()), ldg, out, C.c_void_p(X.data_ptr()), ldx, n, C.c_int64(P), C.c_void_p(dw.data_ptr()), in_, col0, None))
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]), "deterministic"
+    dw = outs[0]
+    assert bool(torch.isfinite(dw).all())
+    mask = torch.ones_like(base, dtype=torch.bool); mask[:, col0:col0 + n] = False
+    assert torch.equal(dw[mask], base[mask]), "columns outside [col0, col0 + n) untouched"
+    scale = (G[:, :out].double().t() @ X[:, :n].double()).abs().max()
+    err = float((dw.double() - want).abs().max() / scale)
+    assert err < 2e-5, err
+
+
 def test_classic_and_lerf_train_steps_in_the_split_gemm_modes_follow_the_fp32_chain(api):
     """nrf_set_train_gemm(1 | 2): the classic NeRFImpl backward and the LeRF head backward with their forward / back-propagation products on the bf16 (1) / fp16 (2) matrix
     cores (bias, ReLU and the next stage's ReLU mask fused into the products' epilogues).  Against the SAME step with fp32 products (mode 0, which the goldens hold to the

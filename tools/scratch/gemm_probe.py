@@ -47,3 +47,23 @@ for wscale in (1.0, 1e-6, 1e4):
         assert bool(torch.isfinite(c).all())
     res["fp32"] = float((((a @ b.t()).double() - want).abs().amax(dim=1) / rowmax).max())
     print(json.dumps(dict(case="rows 1e-12..1e+8, weights x %g" % wscale, worst_row_err_over_row_max=res)), flush=True)
+
+# the weight-gradient product dW = G^T X (contraction over the points): nrf_gemm_tn_bf16x3 against torch's fp32 product
+for (P, out, n) in [(786432, 256, 256), (786432, 256, 128), (786432, 128, 283), (786432, 768, 256)]:
+    G = torch.randn((P, out), device="cuda") * 1e-3; X = torch.randn((P, n), device="cuda")
+    dw = torch.zeros((out, n), device="cuda")
+    runs = {"tn_bf16x3": lambda: L.check(lib.nrf_gemm_tn_bf16x3(C.c_void_p(G.data_ptr()), out, out, C.c_void_p(X.data_ptr()), n, n, C.c_int64(P), C.c_void_p(dw.data_ptr()), n, 0, None)),
+            "torch_fp32": lambda: G.t() @ X}
+    res = {}
+    for name, f in runs.items():
+        f(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        res[name + "_us"] = round((time.perf_counter() - t0) / 5 * 1e6, 1)
+    dw.zero_(); runs["tn_bf16x3"](); torch.cuda.synchronize()
+    want = G.double().t() @ X.double()
+    res["max_err_over_max"] = {"tn_bf16x3": float((dw.double() - want).abs().max() / want.abs().max()), "fp32": float(((G.t() @ X).double() - want).abs().max() / want.abs().max())}
+    res["operand_GBps"] = round((P * (out + n) * 4) / (res["tn_bf16x3_us"] * 1e-6) / 1e9, 1)
+    print(json.dumps(dict(product="dW = G^T X", P=P, out=out, n=n, **res)), flush=True)
