@@ -538,8 +538,10 @@ NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, co
 NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream);
 /* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images).
  * NeRFSmall handles do it ON THE DEVICE in stream order (a gather + hi / lo split per image, no host round trip, nothing waits): work already issued on `stream`
- * reads the old images, work issued after reads the new ones; other streams of the caller's are the caller's to order.  Other families (and NRF_MLP_HOST_REPACK=1)
- * copy the blob to the host, repack there and synchronise `stream`. */
+ * reads the old images, work issued after reads the new ones; other streams of the caller's are the caller's to order.  The LeRF head of the built dimensions does it
+ * on the device too when `params` is a device pointer (its Gram matrix W^T W in double with the host packer's summation order, the images by the host packer's own layout
+ * function compiled for the device; checked byte for byte against the host packer when the handle is created) with ONE 4-byte read-back (the Gram matrix's
+ * power-of-two scale is a launch argument).  Other families (and NRF_MLP_HOST_REPACK=1) copy the blob to the host, repack there and synchronise `stream`. */
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
 /* Number of derived images nrf_mlp_set_params refreshes on the device for this handle (0: the host repack). */
 NRF_API int nrf_mlp_device_repack_images(const nrf_mlp *m);

@@ -538,8 +538,10 @@ static int vec_class(const float *p, int ld, int col0)
 struct GemmTN {
     const float *g; int ldg, out;         // G [P][ldg], columns [0, out)
     const float *x; int ldx, n;           // X [P][ldx], columns [0, n)
+    const float *x1; int ldx1, n1;        // an optional SECOND X segment (tiles bi >= nbi0): the same G tile is then read once from memory and once from the L2, not twice
+    int nbi0;                             // output tiles along n that belong to segment 0
     int64_t P, slice_pts;                 // points (a multiple of 32), points per slice (a multiple of 32)
-    float *part;                          // [slices][out][n]
+    float *part;                          // [slices][out][n + n1]
     int vg, vx;                           // 4: rows 16-byte aligned and the column count a multiple of 4 (vector loads); 1: scalar loads
     int nbo, nbi;                         // output tiles along out / n
 };
@@ -568,9 +570,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
     const int T = (int)((p_end - p_begin) / 32);
     // staging map
     const int opnd = t >> 7, unit = t & 127, cq = unit & 31, pg = unit >> 5;          // pg: which eight of the tile's 32 points; waves 0-1: G, 2-3: X
-    const float *src = opnd ? a.x : a.g;
-    const int ld = opnd ? a.ldx : a.ldg, ncols = opnd ? a.n : a.out;
-    int col = (opnd ? bi : bo) * TN_T + 4 * cq;
+    const bool seg1 = bi >= a.nbi0;
+    const int bil = seg1 ? bi - a.nbi0 : bi;
+    const float *src = opnd ? (seg1 ? a.x1 : a.x) : a.g;
+    const int ld = opnd ? (seg1 ? a.ldx1 : a.ldx) : a.ldg, ncols = opnd ? (seg1 ? a.n1 : a.n) : a.out;
+    int col = (opnd ? bil : bo) * TN_T + 4 * cq;
     // columns past the operand's end are clamped to valid memory: what they produce lands in output rows / columns that are not stored
     int cj[4];
 #pragma unroll
@@ -655,33 +659,40 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
         __syncthreads();
     }
     // register q of lane (r, h) of tile pair (i, j): G column o = 128 bo + 4 ((q & 3) + 8 (q >> 2) + 4 h) + (2 wm + i), X column c = 128 bi + 4 r + (2 wn + j)
-    float *dst = a.part + (size_t)slice * a.out * a.n;
+    const int nn = a.n + a.n1;
+    float *dst = a.part + (size_t)slice * a.out * nn;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int c = bi * TN_T + 4 * r + 2 * wn + j;
-            if (c >= a.n) continue;
+            const int cl = bil * TN_T + 4 * r + 2 * wn + j;
+            if (cl >= (seg1 ? a.n1 : a.n)) continue;
+            const int c = seg1 ? a.n + cl : cl;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int o = bo * TN_T + 4 * ((q & 3) + 8 * (q >> 2) + 4 * h) + 2 * wm + i;
-                if (o < a.out) dst[(size_t)o * a.n + c] = acc[i][j][q];
+                if (o < a.out) dst[(size_t)o * nn + c] = acc[i][j][q];
             }
         }
 }
 
-__global__ void k_tn_sum(int slices, int out, int n, int in, int col0, const float *__restrict__ part, float *__restrict__ dw)
+// dw += the slices' partial matrices, in slice order.  Columns [0, n0) of a partial row go to dw columns col0 ..; columns n0 + skip1 .. n0 + skip1 + keep1 to col1 ..
+// (the other columns of the second segment are computed but not wanted: an aligned read of [sigma | geo | padding] for the geo columns)
+__global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, int col1, int skip1, int keep1, const float *__restrict__ part, float *__restrict__ dw)
 {
+    const int nn = n0 + n1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= out * n) return;
+    if (e >= out * nn) return;
+    const int o = e / nn, i = e - o * nn;
+    if (i >= n0 && (i - n0 < skip1 || i - n0 >= skip1 + keep1)) return;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int b = 0;
     for (; b + 4 <= slices; b += 4) {
-        s0 += part[(size_t)b * out * n + e]; s1 += part[(size_t)(b + 1) * out * n + e]; s2 += part[(size_t)(b + 2) * out * n + e]; s3 += part[(size_t)(b + 3) * out * n + e];
+        s0 += part[(size_t)b * out * nn + e]; s1 += part[(size_t)(b + 1) * out * nn + e]; s2 += part[(size_t)(b + 2) * out * nn + e]; s3 += part[(size_t)(b + 3) * out * nn + e];
     }
-    for (; b < slices; b++) s0 += part[(size_t)b * out * n + e];
-    const int o = e / n, i = e - o * n;
-    dw[(size_t)o * in + col0 + i] += (s0 + s1) + (s2 + s3);
+    for (; b < slices; b++) s0 += part[(size_t)b * out * nn + e];
+    const int c = i < n0 ? col0 + i : col1 + (i - n0 - skip1);
+    dw[(size_t)o * in + c] += (s0 + s1) + (s2 + s3);
 }
 
 // the last P % 32 points (fp32 FMAs, one thread per dw entry)
@@ -695,25 +706,31 @@ __global__ void k_tn_tail(int pts, int out, int n, const float *__restrict__ g, 
     dw[(size_t)o * in + col0 + i] += acc;
 }
 
-// dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
-int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
+// dw [out][in] += g^T [x | x1] over P points: x's columns land at dw columns col0 .., x1's columns skip1 .. skip1 + keep1 at col1 .. (x1.n == 0: one segment; x1.n may be
+// rounded up past skip1 + keep1 for aligned 16-byte reads: the row must hold that many floats, what they contain does not matter)
+int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st)
 {
     if (P <= 0 || x.n <= 0 || out <= 0) return NRF_OK;
+    const bool two = x1.p && keep1 > 0 && x1.n >= skip1 + keep1;
     const int64_t P32 = P & ~(int64_t)31;
     if (P32 < P) {
-        hipLaunchKernelGGL(k_tn_tail, dim3((unsigned)ceil_div((int64_t)out * x.n, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, x.n, g.p + g.off + P32 * g.stride, g.stride,
-                           x.p + x.off + P32 * x.stride, x.stride, in, col0, dw);
+        const unsigned nb = (unsigned)ceil_div((int64_t)out * x.n, (int64_t)256);
+        hipLaunchKernelGGL(k_tn_tail, dim3(nb), dim3(256), 0, st, (int)(P - P32), out, x.n, g.p + g.off + P32 * g.stride, g.stride, x.p + x.off + P32 * x.stride, x.stride, in, col0, dw);
+        if (two)
+            hipLaunchKernelGGL(k_tn_tail, dim3((unsigned)ceil_div((int64_t)out * keep1, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, keep1,
+                               g.p + g.off + P32 * g.stride, g.stride, x1.p + x1.off + skip1 + P32 * x1.stride, x1.stride, in, col1, dw);
         NRF_LAUNCH_CHECK();
     }
     if (P32 == 0) return NRF_OK;
     GemmTN a{};
     a.g = g.p + g.off; a.ldg = g.stride; a.out = out;
     a.x = x.p + x.off; a.ldx = x.stride; a.n = x.n;
+    if (two) { a.x1 = x1.p + x1.off; a.ldx1 = x1.stride; a.n1 = x1.n; }
     a.P = P32;
     a.vg = (vec_class(a.g, a.ldg, 0) == 4 && (out & 3) == 0) ? 4 : 1;
-    a.vx = (vec_class(a.x, a.ldx, 0) == 4 && (x.n & 3) == 0) ? 4 : 1;
-    a.nbo = (out + TN_T - 1) / TN_T; a.nbi = (x.n + TN_T - 1) / TN_T;
-    const int tiles = a.nbo * a.nbi;
+    a.vx = (vec_class(a.x, a.ldx, 0) == 4 && (x.n & 3) == 0 && (!two || (vec_class(a.x1, a.ldx1, 0) == 4 && (x1.n & 3) == 0))) ? 4 : 1;
+    a.nbo = (out + TN_T - 1) / TN_T; a.nbi0 = (x.n + TN_T - 1) / TN_T; a.nbi = a.nbi0 + (two ? (x1.n + TN_T - 1) / TN_T : 0);
+    const int tiles = a.nbo * a.nbi, nn = a.n + a.n1;
     // slices: two rounds of the chip's 512 resident workgroups (each slice's partial matrix is written and read once more: 512 slices cost more in k_tn_sum than their
     // balance bought), at least 8 K tiles (256 points) each
     int64_t slices = (1024 + tiles - 1) / tiles;
@@ -723,7 +740,7 @@ int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw
     a.slice_pts = ((P32 / 32 + slices - 1) / slices) * 32;
     slices = (P32 + a.slice_pts - 1) / a.slice_pts;
     float *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * out * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_bf16x3: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * out * nn * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_bf16x3: hipMallocAsync failed"); return NRF_ERR_HIP; }
     a.part = part;
     static bool attr = false;
     if (!attr) {
@@ -733,11 +750,17 @@ int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw
     }
     if (a.vg == 4 && a.vx == 4) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
     else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
-    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * x.n, (int64_t)256)), dim3(256), 0, st, (int)slices, out, x.n, in, col0, (const float *)part, dw);
+    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw);
     const hipError_t le = hipGetLastError();
     (void)hipFreeAsync(part, st);
     if (le != hipSuccess) { set_error("gemm_tn_bf16x3: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
     return NRF_OK;
+}
+
+// dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
+int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
+{
+    return gemm_tn_bf16x3_2(P, g, x, col0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st);
 }
 
 // Arithmetic of the training paths' forward / back-propagation products.  -1 (the default, NRF_TRAIN_GEMM=auto): by network family -- f16x3 for the classic NeRF and the

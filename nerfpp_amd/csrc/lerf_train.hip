@@ -505,6 +505,11 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         const LinearLayer &L = m->layers[l];
         if (l != NL - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
+        if (first && c >= 4096 && train_gemm_for(m) != 0 && L.out >= 32 && W >= ((1 + geo + 3) & ~3))
+            // cat[geo, in]: both column segments in ONE pass over g (bf16x3 TN product); the geo columns as the aligned read [sigma | geo | up to 3 more floats of the row]
+            // whose first column and padding are dropped (W >= 1 + geo + 3: the row holds them, whatever they contain stays in the dropped columns)
+            NRF_TRY(gemm_tn_bf16x3_2(c, g, xin, geo, Seg{h33, W, 0, (1 + geo + 3) & ~3}, 0, 1, geo, L.out, L.in, g_params + L.w_off, st));
+        else
         NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
         float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
         premasked = fuse && !first;                          // dst = d / d H[l - 1], a ReLU output

@@ -64,6 +64,8 @@ struct nrf_mlp {
     void *d_packed_sigma_f32 = nullptr;      // fp32 MFMA fragments of the sigma net (sigma_small_f32.hip)
     size_t packed_sigma_f32_bytes = 0;
     int lerf_precision = NRF_PREC_F16_MFMA;  // arithmetic of the fused LeRF passes (nrf_lerf_set_precision)
+    float *d_lerf_gram = nullptr;            // LeRF device pack: the Gram matrix [256][256] (+ the bits of its largest entry behind it)
+    bool lerf_device_pack = false;           // the device packers reproduce the host packers' images byte for byte (checked at creation): nrf_mlp_set_params stays on the device
     float lerf_gram_scale = 1.0f;            // LeRF: the Gram matrix of the embedding layer is stored divided by this power of two (fp16 range), see mlp_lerf_mfma.hip
     void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
     size_t packed_bwd_bytes = 0;
@@ -104,11 +106,13 @@ int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act,
 int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith = 0);          // arith != 0 (train_gemm_for): gemm_tn_bf16x3
 int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);
+int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st);          // two X segments in one pass over G
 // mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0);
 bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts);
 int fp32_gemm_available();
 // gemm_bf16x3.hip: the same two products (forward, back-propagation) as split-precision bf16 matrix-core GEMMs with the bias / ReLU / ReLU-mask epilogues fused
+int host_pack_threads();            // threads of the host-side weight packers (a training loop re-packs every step): min(cores, 8), NRF_PACK_THREADS overrides
 int train_gemm_mode();               // -1: by family (default); 0: fp32 products; 1: bf16x3; 2: f16x3 with power-of-two scaled operands (gemm_bf16x3.hip; NRF_TRAIN_GEMM, nrf_set_train_gemm)
 int train_gemm_for(const nrf_mlp *m);        // the arithmetic of this network's products: the explicit mode, or by family (NeRFSmall: fp32 products; classic, LeRF: f16x3)
 int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
@@ -158,6 +162,8 @@ int mlp_nerf_sigma_f32_available(const nrf_mlp *m);
 int mlp_nerf_exact_coarse(const nrf_mlp *m, const float *pts, const float *rays, int ray_stride, const float *z, int s, const __half *dirs, const __half *dirs_lo, int64_t p,
                           float *raw, hipStream_t st);
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+int mlp_lerf_pack_f16_device(nrf_mlp *m, hipStream_t st);                              // the same images from m->d_params, on the device
+int mlp_lerf_pack_sigma_f32_device(nrf_mlp *m, hipStream_t st);                        // sigma_lerf_f32.hip
 int mlp_lerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &host_params);      // sigma_lerf_f32.hip
 
 }  // namespace nrf

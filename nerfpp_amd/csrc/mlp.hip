@@ -7,6 +7,8 @@
 // The matrix-core paths (NRF_PREC_F16_MFMA) are in mlp_small_mfma.hip / mlp_nerf_mfma.hip.
 #include "mlp.h"
 
+#include <thread>
+
 namespace nrf {
 
 constexpr int LIN_TP = 16;   // points per block
@@ -599,6 +601,16 @@ static int add_layer(nrf_mlp *m, const std::vector<float> &hp, size_t &off, int 
     return NRF_OK;
 }
 
+int host_pack_threads()
+{
+    static const int n = [] {
+        if (const char *e = getenv("NRF_PACK_THREADS")) { const int v = atoi(e); if (v >= 1) return v > 64 ? 64 : v; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1);          // (16 / 32 threads: no faster, profiles/round6/r6w_pack_threads.log)
+    }();
+    return n;
+}
+
 static int fetch_params(const float *params, int on_device, int64_t n, hipStream_t st, std::vector<float> &host, nrf_mlp *m)
 {
     host.resize((size_t)n);
@@ -1039,6 +1051,38 @@ int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int par
     return NRF_OK;
 }
 
+// The LeRF head's device packers (mlp_lerf_pack_f16_device, mlp_lerf_pack_sigma_f32_device) against the host packers' images, which the handle holds at this point:
+// the three images are read back, rebuilt on the device from m->d_params and read back again; equal byte for byte (and the same Gram scale) -> nrf_mlp_set_params keeps
+// this handle's parameter uploads on the device.  Anything else -> the host images are restored and the host packers stay in charge.  NRF_MLP_HOST_REPACK=1 skips it.
+static int lerf_device_pack_verify(nrf_mlp *m, hipStream_t st)
+{
+    m->lerf_device_pack = false;
+    if (const char *e = getenv("NRF_MLP_HOST_REPACK")) if (atoi(e) != 0) return NRF_OK;
+    if (!m->d_packed_f16 || !m->d_packed_split || !m->d_packed_sigma_f32) return NRF_OK;
+    void *dev[3] = { m->d_packed_f16, m->d_packed_split, m->d_packed_sigma_f32 };
+    const size_t bytes[3] = { m->packed_f16_bytes, m->packed_split_bytes, m->packed_sigma_f32_bytes };
+    std::vector<uint8_t> host[3], mine[3];
+    NRF_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 3; i++) { host[i].resize(bytes[i]); NRF_HIP(hipMemcpy(host[i].data(), dev[i], bytes[i], hipMemcpyDeviceToHost)); }
+    const float scale = m->lerf_gram_scale;
+    bool same = mlp_lerf_pack_f16_device(m, st) == NRF_OK && mlp_lerf_pack_sigma_f32_device(m, st) == NRF_OK;
+    if (same) {
+        NRF_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < 3 && same; i++) {
+            mine[i].resize(bytes[i]);
+            NRF_HIP(hipMemcpy(mine[i].data(), dev[i], bytes[i], hipMemcpyDeviceToHost));
+            same = memcmp(mine[i].data(), host[i].data(), bytes[i]) == 0;
+        }
+        same = same && m->lerf_gram_scale == scale;
+    }
+    if (!same) {
+        for (int i = 0; i < 3; i++) NRF_HIP(hipMemcpy(dev[i], host[i].data(), bytes[i], hipMemcpyHostToDevice));
+        m->lerf_gram_scale = scale;
+    }
+    m->lerf_device_pack = same;
+    return NRF_OK;
+}
+
 /* LeRFImpl ctor (LeRF.cpp:3-26): sigma net in->H..->1+geo, LE net (geo+in)->H..->embed, both `num_layers` deep, bias-free.
  * Described with nrf_mlp_small_desc: input_ch, num_layers, hidden_dim, geo_feat_dim, hidden_dim_color = lang_embed_dim. */
 NRF_API int64_t nrf_mlp_lerf_param_count(const nrf_mlp_small_desc *d)
@@ -1066,6 +1110,7 @@ NRF_API int nrf_mlp_lerf_create(const nrf_mlp_small_desc *d, const float *params
         s = add_layer(m, hp, off, (l == 0) ? d->geo_feat_dim + d->input_ch : d->hidden_dim, (l == d->num_layers - 1) ? d->hidden_dim_color : d->hidden_dim, false);
     if (s == NRF_OK) s = mlp_lerf_pack_f16(m, hp);
     if (s == NRF_OK) s = mlp_lerf_pack_sigma_f32(m, hp);
+    if (s == NRF_OK) s = lerf_device_pack_verify(m, as_stream(stream));
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -1087,6 +1132,17 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
             NRF_HIP(hipGetLastError());
         }
         return mlp_small_rescale(m, st);
+    }
+    if (m->family == MLP_LERF && m->lerf_device_pack && params_on_device) {
+        // the LeRF head: blob, transposed layers and the matrix-core images all on the device, in stream order (one 4-byte read-back inside: the Gram matrix's scale)
+        NRF_HIP(hipMemcpyAsync(m->d_params, params, (size_t)m->n_params * 4, hipMemcpyDeviceToDevice, st));
+        for (auto &L : m->layers) {
+            const int64_t ne = (int64_t)L.in * L.out;
+            k_transpose_wt<<<dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st>>>(L.in, L.out, m->d_params + L.w_off, L.d_wt);
+            NRF_HIP(hipGetLastError());
+        }
+        NRF_TRY(mlp_lerf_pack_f16_device(m, st));
+        return mlp_lerf_pack_sigma_f32_device(m, st);
     }
     std::vector<float> hp((size_t)m->n_params);
     if (params_on_device) {
@@ -1112,7 +1168,7 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
     return NRF_OK;
 }
 
-int nrf_mlp_device_repack_images(const nrf_mlp *m) { return m ? (int)m->maps.size() : 0; }
+int nrf_mlp_device_repack_images(const nrf_mlp *m) { return m ? (m->family == MLP_LERF ? (m->lerf_device_pack ? 3 : 0) : (int)m->maps.size()) : 0; }
 
 int nrf_mlp_set_input_rms_hint(nrf_mlp *m, float rms, void *stream)
 {
@@ -1190,6 +1246,7 @@ void nrf_mlp_destroy(nrf_mlp *m)
     if (m->d_packed_split) (void)hipFree(m->d_packed_split);
     if (m->d_packed_bwd) (void)hipFree(m->d_packed_bwd);
     if (m->d_packed_sigma_f32) (void)hipFree(m->d_packed_sigma_f32);
+    if (m->d_lerf_gram) (void)hipFree(m->d_lerf_gram);
     if (m->d_params_scaled) (void)hipFree(m->d_params_scaled);
     if (m->d_group) (void)hipFree(m->d_group);
     if (m->d_gscale) (void)hipFree(m->d_gscale);

@@ -291,23 +291,79 @@ k_lerf_embed(int64_t nrays, const float *__restrict__ asum, const half8 *__restr
     }
 }
 
-// value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L
-static float wval(const std::vector<float> &hp, const std::vector<float> &gram, int L, int row, int kstep, int h, int j)
+// value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel layer L (host packer and device packer: one statement of the layout)
+__host__ __device__ inline float lerf_wval(const float *hp, const float *gram, int L, int row, int kstep, int h, int j)
 {
     const size_t off0 = 0, off1 = off0 + (size_t)HID * IN, off2 = off1 + (size_t)(1 + GEO) * HID, off3 = off2 + (size_t)HID * (GEO + IN);
-    auto chained = [](int k, int hh, int jj) { return 32 * (k >> 1) + perm_row(k & 1, hh, jj); };
-    auto natural = [](int k, int hh, int jj) { return 16 * k + 8 * hh + jj; };
-    if (L == 0) return hp[off0 + (size_t)row * IN + natural(kstep, h, j)];
-    if (L == 1) return row < 1 + GEO ? hp[off1 + (size_t)row * HID + chained(kstep, h, j)] : 0.0f;
+    const int chained = 32 * (kstep >> 1) + perm_row(kstep & 1, h, j);
+    const int natural = 16 * kstep + 8 * h + j;
+    if (L == 0) return hp[off0 + (size_t)row * IN + natural];
+    if (L == 1) return row < 1 + GEO ? hp[off1 + (size_t)row * HID + chained] : 0.0f;
     if (L == 2) {
         if (kstep < 4) {                                   // the two sigma1 tiles: row 0 = sigma (no weight), rows 1..32 = geo
-            const int src = chained(kstep, h, j);
-            return (src >= 1 && src <= GEO) ? hp[off2 + (size_t)row * (GEO + IN) + (src - 1)] : 0.0f;
+            return (chained >= 1 && chained <= GEO) ? hp[off2 + (size_t)row * (GEO + IN) + (chained - 1)] : 0.0f;
         }
-        return hp[off2 + (size_t)row * (GEO + IN) + GEO + natural(kstep - 4, h, j)];
+        return hp[off2 + (size_t)row * (GEO + IN) + GEO + (16 * (kstep - 4) + 8 * h + j)];
     }
-    if (L == 3) return gram[(size_t)row * HID + chained(kstep, h, j)];
-    return hp[off3 + (size_t)row * HID + natural(kstep, h, j)];          // LE1 for kernel C: its operand comes from memory, natural order
+    if (L == 3) return gram[(size_t)row * HID + chained];
+    return hp[off3 + (size_t)row * HID + natural];          // LE1 for kernel C: its operand comes from memory, natural order
+}
+
+// fragment f of the image -> (layer, tile, k-step): layers in order, tiles of a layer in order, k-steps of a tile in order
+__host__ __device__ inline void lerf_frag_id(int f, int &L, int &tile, int &k)
+{
+    const int cnt[5] = {8 * 8, 2 * 16, 8 * 12, 8 * 16, 24 * 16}, ksl[5] = {8, 16, 12, 16, 16};
+    L = 0;
+    while (L < 4 && f >= cnt[L]) { f -= cnt[L]; L++; }
+    tile = f / ksl[L]; k = f - tile * ksl[L];
+}
+
+// ---- the same image built ON THE DEVICE from the parameter blob (a training loop uploads parameters every step: the host packer's 3 ms were GPU idle time) ----
+// G = W^T W of the embedding layer W [768][256], every entry with the host packer's four partial double sums in its order: the same bits
+__global__ void __launch_bounds__(256) k_lerf_gram_f64(const float *__restrict__ w3, float *__restrict__ gram, uint32_t *__restrict__ gmax_bits)
+{
+    const int a = blockIdx.x, b = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int o = 0; o + 4 <= EMB; o += 4) {
+        s0 += (double)w3[(size_t)o * HID + a] * (double)w3[(size_t)o * HID + b];
+        s1 += (double)w3[(size_t)(o + 1) * HID + a] * (double)w3[(size_t)(o + 1) * HID + b];
+        s2 += (double)w3[(size_t)(o + 2) * HID + a] * (double)w3[(size_t)(o + 2) * HID + b];
+        s3 += (double)w3[(size_t)(o + 3) * HID + a] * (double)w3[(size_t)(o + 3) * HID + b];
+    }
+    const float g = (float)((s0 + s1) + (s2 + s3));
+    gram[(size_t)a * HID + b] = g;
+    float mx = fabsf(g);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(gmax_bits, __float_as_uint(mx));
+}
+static_assert(EMB % 4 == 0, "the Gram kernel's four partial sums cover EMB exactly, as the host loop's main part does");
+
+// the fp16-range scale (an exact power of two) and the upper block triangle (G_TT, 2 G_TU, zeros below), in place
+__global__ void k_lerf_gram_finish(float *__restrict__ gram, int e)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= HID * HID) return;
+    const int a = idx / HID, b = idx - a * HID;
+    float g = gram[idx];
+    if (e != 0) g = ldexpf(g, -e);
+    const int ta = a / 32, ub = b / 32;
+    if (ub < ta) g = 0.0f;
+    else if (ub > ta) g *= 2.0f;
+    gram[idx] = g;
+}
+
+// one workgroup per fragment, one thread per element: the fp16 image and the split image's (hi, lo) fragment pair
+__global__ void __launch_bounds__(512) k_lerf_fill(const float *__restrict__ hp, const float *__restrict__ gram, _Float16 *__restrict__ img, _Float16 *__restrict__ img2)
+{
+    const int f = blockIdx.x, e = threadIdx.x, lane = e >> 3, j = e & 7;
+    int L, tile, k;
+    lerf_frag_id(f, L, tile, k);
+    const float v = lerf_wval(hp, gram, L, tile * 32 + (lane & 31), k, lane >> 5, j);
+    const _Float16 hv = (_Float16)v;
+    img[(size_t)f * 512 + e] = hv;
+    img2[(size_t)(2 * f) * 512 + e] = hv;
+    img2[(size_t)(2 * f + 1) * 512 + e] = (_Float16)(v - (float)hv);
 }
 
 }  // namespace lerf
@@ -346,8 +402,7 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
                     gram[(size_t)a * HID + b] = gram[(size_t)b * HID + a] = (float)((s0 + s1) + (s2 + s3));
                 }
         };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1);
+        const int nt = host_pack_threads();
         if (nt == 1) rows(0, HID);
         else {
             // row a costs HID - a dot products: cut at equal areas of the triangle
@@ -399,7 +454,7 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
             const FragId id = frags[(size_t)f];
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++) {
-                    const float v = wval(hp, gram, id.L, id.tile * 32 + (lane & 31), id.k, lane >> 5, j);
+                    const float v = lerf_wval(hp.data(), gram.data(), id.L, id.tile * 32 + (lane & 31), id.k, lane >> 5, j);
                     const _Float16 hv = (_Float16)v;
                     const size_t e = (size_t)lane * 8 + j;
                     img[(size_t)f * 512 + e] = hv;
@@ -409,8 +464,7 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         }
     };
     {
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1);
+        const int nt = host_pack_threads();
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++) th.emplace_back(fill, IMAGE_FRAGS * t / nt, IMAGE_FRAGS * (t + 1) / nt);
         for (auto &x : th) x.join();
@@ -423,6 +477,32 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     m->packed_split_bytes = img2.size() * sizeof(_Float16);
     if (!m->d_packed_split) NRF_HIP(hipMalloc(&m->d_packed_split, m->packed_split_bytes));
     NRF_HIP(hipMemcpy(m->d_packed_split, img2.data(), m->packed_split_bytes, hipMemcpyHostToDevice));
+    return NRF_OK;
+}
+
+// The images from m->d_params on the device, in `st`'s order; one 4-byte read-back (the Gram matrix's largest entry decides its power-of-two scale, which the
+// launchers pass by value).  Needs the image buffers of a first host pack.
+int mlp_lerf_pack_f16_device(nrf_mlp *m, hipStream_t st)
+{
+    if (!lerf_mfma_supported(m->small) || !m->d_packed_f16 || !m->d_packed_split || m->packed_f16_bytes != (size_t)IMAGE_FRAGS * 512 * sizeof(_Float16)) return NRF_ERR_UNSUPPORTED;
+    if (!m->d_lerf_gram) NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_lerf_gram), (size_t)HID * HID * sizeof(float) + 16));
+    uint32_t *gmax = reinterpret_cast<uint32_t *>(m->d_lerf_gram + (size_t)HID * HID);
+    const float *w3 = m->d_params + (size_t)HID * IN + (size_t)(1 + GEO) * HID + (size_t)HID * (GEO + IN);
+    NRF_HIP(hipMemsetAsync(gmax, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_lerf_gram_f64, dim3(HID), dim3(HID), 0, st, w3, m->d_lerf_gram, gmax);
+    NRF_LAUNCH_CHECK();
+    uint32_t bits = 0;
+    NRF_HIP(hipMemcpyAsync(&bits, gmax, sizeof(bits), hipMemcpyDeviceToHost, st));
+    NRF_HIP(hipStreamSynchronize(st));
+    float gm; memcpy(&gm, &bits, 4);
+    int e = 0;
+    if (gm > 1024.0f) (void)frexpf(gm / 1024.0f, &e);
+    m->lerf_gram_scale = ldexpf(1.0f, e);
+    hipLaunchKernelGGL(k_lerf_gram_finish, dim3(HID * HID / 256), dim3(256), 0, st, m->d_lerf_gram, e);
+    NRF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lerf_fill, dim3(IMAGE_FRAGS), dim3(512), 0, st, (const float *)m->d_params, (const float *)m->d_lerf_gram, reinterpret_cast<_Float16 *>(m->d_packed_f16),
+                       reinterpret_cast<_Float16 *>(m->d_packed_split));
+    NRF_LAUNCH_CHECK();
     return NRF_OK;
 }
 

@@ -290,8 +290,7 @@ static bool nerf_mfma_supported(const nrf_mlp_nerf_desc &d)
 
 void host_parallel_for(int n, const std::function<void(int, int)> &range_fn)
 {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = n < 2 ? 1 : (hw >= 8 ? 8 : (hw >= 2 ? (int)hw : 1));
+    const int nt = n < 2 ? 1 : host_pack_threads();
     if (nt == 1) { range_fn(0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++) th.emplace_back(range_fn, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));

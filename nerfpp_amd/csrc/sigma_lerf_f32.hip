@@ -209,6 +209,38 @@ int mlp_lerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     return NRF_OK;
 }
 
+// the same image from the parameter blob on the device (one thread per element; the index arithmetic of the host loops above)
+__global__ void k_lsig_fill(const float *__restrict__ hp, float *__restrict__ img)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int A = lsig::W0_F4 * 4, B = 256, Cn = lsig::W1G_F4 * 4;
+    if (idx >= A + B + Cn) return;
+    const float *w0 = hp, *w1 = hp + (size_t)lerf::HID * lerf::IN;
+    float v;
+    if (idx < A) {
+        const int j = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 15, mt = idx >> 12;
+        const int row = 32 * mt + lsig::row_neuron(lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+        v = w0[(size_t)row * lerf::IN + k];
+    } else if (idx < A + B) {
+        v = w1[idx - A];
+    } else {
+        const int r = idx - A - B, j = r & 3, lane = (r >> 2) & 63, g = r >> 8;
+        const int i = lane & 31, row = i == 0 ? 32 : i, k = 2 * (4 * g + j) + (lane >> 5);
+        v = w1[(size_t)row * lerf::HID + k];
+    }
+    img[idx] = v;
+}
+static_assert(lsig::W0_F4 * 4 == 8 * 16 * 64 * 4 && lsig::W1G_F4 * 4 == 64 * 64 * 4, "k_lsig_fill's index arithmetic");
+
+int mlp_lerf_pack_sigma_f32_device(nrf_mlp *m, hipStream_t st)
+{
+    const size_t n = (size_t)lsig::W0_F4 * 4 + 256 + (size_t)lsig::W1G_F4 * 4;
+    if (!lerf_sigma_f32_supported(m->small) || !m->d_packed_sigma_f32 || m->packed_sigma_f32_bytes != n * sizeof(float)) return NRF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_lsig_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)m->d_params, reinterpret_cast<float *>(m->d_packed_sigma_f32));
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
 }  // namespace nrf
 
 using namespace nrf;

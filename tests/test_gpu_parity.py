@@ -3602,6 +3602,35 @@ def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
 
 
 @pytest.mark.gpu
+def test_lerf_head_parameter_upload_stays_on_the_device_and_equals_the_host_pack(api):
+    """nrf_mlp_set_params on a LeRF head with a DEVICE pointer: the Gram matrix, the fp16 / split images and the exact-fp32 density image are rebuilt by device kernels
+    (mlp_lerf_pack_f16_device, mlp_lerf_pack_sigma_f32_device; round 6: the host packer's 3 ms were GPU idle time in every training step).  The handle says so
+    (nrf_mlp_device_repack_images == 3: its creation compared the device packers with the host packers byte for byte), and a pass rendered after such an upload equals,
+    bit for bit, the pass of a head CREATED from the same parameters (host packers) -- weights whose Gram matrix needs the fp16-range scale included."""
+    L, S, R = api.L, api.S, api.R
+    K = S.lego_K(64, 64); c2w = S.pose_spherical(40.0, -25.0, 4.0)
+    o, d, _ = R.GetRays(64, 64, K, c2w)
+    o = o.reshape(-1, 3)[::7].contiguous(); d = d.reshape(-1, 3)[::7].contiguous()
+    for gain in (1.0, 40.0):
+        sc = S.make_lerf_scene(log2_t=14)
+        assert L.lib().nrf_mlp_device_repack_images(sc["lerf"]._m) == 3
+        rng = np.random.default_rng(5)
+        blob2 = (sc["blob"] * (1.0 + 0.2 * rng.standard_normal(sc["blob"].shape))).astype(np.float32)
+        n3 = 768 * 256
+        blob2[-n3:] *= np.float32(gain)                                     # the embedding layer: gain 40 puts max |W^T W| beyond 1024 (the Gram image's scale != 1)
+        p = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"])
+        t2 = torch.as_tensor(blob2).cuda()
+        L.check(L.lib().nrf_mlp_set_params(sc["lerf"]._m, C.c_void_p(t2.data_ptr()), 1, None))
+        a = sc["renderer"].Render(0, 0, None, p, rays=(o, d, None))
+        from nerfpp_amd.modules import LeRF
+        from nerfpp_amd.renderer import LeRFRenderer
+        fresh = LeRFRenderer(sc["embedder"], LeRF(32, 2, 256, 768, 128, "lang_model", params=blob2))
+        b = fresh.Render(0, 0, None, p, rays=(o, d, None))
+        assert torch.equal(a.Outputs.RenderedLangEmbedding, b.Outputs.RenderedLangEmbedding) and torch.equal(a.Outputs.WeightsLE, b.Outputs.WeightsLE)
+        assert bool(torch.isfinite(a.Outputs.RenderedLangEmbedding).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("P,out,n,ldg,ldx,in_,col0", [(100000, 256, 256, 256, 256, 256, 0), (50001, 128, 283, 128, 283, 300, 17), (40000, 256, 63, 264, 63, 319, 256),
                                                       (8192, 33, 143, 40, 144, 143, 0), (4100, 256, 128, 256, 128, 128, 0), (31, 64, 64, 64, 64, 64, 0)])
 def test_gemm_tn_bf16x3_vs_float64(api, P, out, n, ldg, ldx, in_, col0):
