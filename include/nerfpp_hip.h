@@ -541,7 +541,10 @@ NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_
  * reads the old images, work issued after reads the new ones; other streams of the caller's are the caller's to order.  The LeRF head of the built dimensions does it
  * on the device too when `params` is a device pointer (its Gram matrix W^T W in double with the host packer's summation order, the images by the host packer's own layout
  * function compiled for the device; checked byte for byte against the host packer when the handle is created) with ONE 4-byte read-back (the Gram matrix's
- * power-of-two scale is a launch argument).  Other families (and NRF_MLP_HOST_REPACK=1) copy the blob to the host, repack there and synchronise `stream`. */
+ * power-of-two scale is a launch argument).  The classic 8 x 256 network does it on the device as NeRFSmall does (its three images are gathers of [blob | merged
+ * views layer]: the gather maps are decoded from the host packers run on probe blobs and verified against the host-packed images when the handle is created; the merged
+ * layer is re-derived by a device kernel with the host's double sums).  Anything else (and NRF_MLP_HOST_REPACK=1) copies the blob to the host, repacks there and
+ * synchronises `stream`. */
 NRF_API int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, void *stream);
 /* Number of derived images nrf_mlp_set_params refreshes on the device for this handle (0: the host repack). */
 NRF_API int nrf_mlp_device_repack_images(const nrf_mlp *m);

@@ -1,22 +1,29 @@
-// gemm_bf16x3.hip -- the layer products of the TRAINING paths on the bf16 matrix cores in split precision (round 6; replaces the rocBLAS sgemm calls of gemm_f32.hip
-// for the two products whose operands are K-contiguous: the recomputed forward  Y = cat[a, b] W^T (+ bias)(ReLU)  and the back-propagation  G_in = G W (. mask)).
+// gemm_bf16x3.hip -- the layer products of the TRAINING paths (classic NeRF backward, LeRF head backward) on the bf16 / fp16 matrix cores in split precision (round 6;
+// replaces the rocBLAS sgemm calls of gemm_f32.hip): the recomputed forward  Y = cat[a, b] W^T (+ bias)(ReLU), the back-propagation  G_in = G W (. mask)  -- both "NT"
+// products whose operands are K-contiguous (k_gemm_nt_rows, k_gemm_nt) -- and the weight gradient  dW += G^T X  (k_gemm_tn: the contraction runs over the points).
 //
-// Arithmetic.  Every fp32 operand x is carried as x = hi + lo, hi = bf16(x), lo = bf16(x - hi): 16 significant bits, and -- unlike the fp16 pairs of the render
-// path -- with fp32's own EXPONENT range, so no gradient or activation can leave it (round 5's fp16x3 training GEMMs were "not range-safe" and were removed; the render
-// path needed this round's range scaling for the same reason).  A product is three v_mfma_f32_32x32x16_bf16 into one fp32 accumulator: ah.bh + al.bh + ah.bl (the
-// dropped al.bl is 2^-16 relative).  The fp32 matrix instruction (v_mfma_f32_32x32x2_f32, what rocBLAS runs) retires 1/16 of the bf16 rate: three bf16 products cost
-// 3/16 of it.  One product is within 6e-6 of its largest entry (fp32: 8e-7); through a whole backward chain the weight gradients end within ~1e-3 of their largest entry
-// of the fp32 chain's.  That is a FAST mode (NRF_TRAIN_GEMM=bf16x3 / nrf_set_train_gemm(1)), as the fused fp16 chain is for the hash path; the default stays the
-// parity-grade fp32 products (rocBLAS sgemm or mlp.hip's FMA kernels) that the oracle-level gradient tests hold to 2e-5.
+// Arithmetic.  Every fp32 operand x is carried as x = hi + lo and a product is three matrix-core instructions into one fp32 accumulator: ah.bh + al.bh + ah.bl.
+//   bf16x3  hi = bf16(x), lo = bf16(x - hi): 16 significant bits with fp32's own EXPONENT range -- nothing can leave it.  One product within 6e-6 of its largest entry.
+//           Used for dW (a leaf of the step: nothing is computed from it, and a per-point scale could not be undone in a sum over points).
+//   f16x3   hi + lo fp16 (22 significant bits) of POWER-OF-TWO SCALED operands: every row of A by its own largest entry, B by its largest entry, undone exactly in the
+//           epilogue (round 5's unscaled fp16x3 products were "not range-safe" -- gradients of 1e-9 lie below fp16's normals -- and were removed).  One product within
+//           5e-7 of its largest entry (rocBLAS sgemm: 8e-7).  The default of the forward / back-propagation products for the classic and the LeRF networks.
+// The fp32 matrix instruction (v_mfma_f32_32x32x2_f32, what rocBLAS runs) retires 1/16 of the 16-bit rate: three products cost 3/16 of it.
 //
-// Kernel (k_gemm_nt): C [M x N] = A [M x K] . B [N x K]^T, row-major fp32 in memory, M = points (10^5..10^6), N, K <= a few hundred.  A may be the concatenation of TWO
-// column segments (the skip concat cat[input_pts, h] of NeRFImpl, cat[geo, x] of the LeRF head): the K loop walks segment 0 then segment 1, B's columns follow.
-//   * 128 x 128 output tile per 256-thread workgroup, 2 x 2 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers), K tiles of 32, two LDS stages (64 KB: two
-//     workgroups per CU), ONE barrier per K tile; the next tile's global loads are issued before the current tile's products and converted / written behind them.
-//   * LDS image per operand and half: [k-step of 16][row][16 bf16] -- a fragment read (lane = row r, half h -> 16 bytes at (ks, r, 8h)) of a 32-row tile covers 1 KB
-//     contiguously: conflict-free ds_read_b128; the staging writes (4 consecutive k of one row: 8 bytes per half) are contiguous across lanes too.
-//   * n-blocks of one m-block are adjacent in launch order: the second read of an A tile is an L2 hit.
-//   * epilogue in registers: + bias[n], ReLU, and the ReLU mask of the NEXT backward stage (C = act > 0 ? C : 0), which removes the k_bias_relu / k_relu_mask passes.
+// NT kernels: C [M x N] = A [M x K] . B [N x K]^T, row-major fp32 in memory, M = points (10^5..10^6), N, K <= a few hundred.  A may be the concatenation of TWO column
+// segments (the skip concat cat[input_pts, h] of NeRFImpl, cat[geo, x] of the LeRF head): the K loop walks segment 0 then segment 1, B's columns follow.
+//   * B (the weights: the same for all ~6 000 workgroups of a layer product) is split ONCE per product into the kernels' LDS image (k_gb_split_b; F16: after
+//     k_gb_absmax has found its largest entry) and copied tile by tile, 16 bytes per thread, no arithmetic.
+//   * k_gemm_nt_rows (K in {128, 160, 256}, 16-byte aligned rows, N > 128): 128 x 256 output tile per 512-thread workgroup; the workgroup's WHOLE A block (128 rows x K:
+//     contiguous 128 KB) is requested in one burst -- with K tiles of 32 requested one by one every row is visited eight times, 128 bytes at a time, microseconds apart,
+//     DRAM pages re-opened for each piece: ~2 TB/s, for rocBLAS alike -- and the C block leaves through LDS as whole rows for the same reason.  The row's largest entry
+//     (F16) is 8 TK maxima and three lane exchanges away.
+//   * k_gemm_nt (everything else: ragged K, unaligned segments, narrow N): K tiles of 32 through two LDS stages, two register sets in flight; F16 first scans the
+//     workgroup's rows for their largest entries (their second read comes out of the caches); the 256-wide tile shares the row-staged epilogue.
+//   * LDS image per operand and half: [k-step of 16][row][16 elements] -- a fragment read (lane = row r, half h -> 16 bytes at (ks, r, 8h)) of a 32-row tile covers 1 KB
+//     contiguously: conflict-free ds_read_b128.
+//   * epilogue: inverse scales, + bias[n], ReLU, and the ReLU mask of the NEXT backward stage (C = act > 0 ? C : 0), which removes the k_bias_relu / k_relu_mask passes.
+//   * workgroups of one XCD work through a contiguous eighth of the tiles (they share that XCD's L2).
 #include "mlp.h"
 
 #include <atomic>

@@ -151,6 +151,11 @@ int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const 
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);
+// the classic network's images as host vectors from (blob, merged views layer): what the packers upload and what mlp.hip's weight maps are decoded from
+bool nerf_f16_images_host(const nrf_mlp_nerf_desc &d, const float *hp, const float *merged, const float *merged_b, std::vector<_Float16> &img, std::vector<_Float16> &img2,
+                          std::vector<float> &bias);
+bool nerf_sigma_image_host(const nrf_mlp_nerf_desc &d, const float *hp, const float *merged, const float *merged_b, std::vector<float> &img, size_t &f16_at, size_t &f16_floats);
+size_t nerf_blob_offset_views();
 // views_linears_0 o feature_linear of the classic network (no activation between them, NeRF.cpp:112-115), in double, rows over up to 8 host threads:
 // merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r]   (Wv rows are wv_stride floats apart)
 void nerf_merged_views_host(const float *wv, int wv_stride, const float *wf, const float *bf, const float *bv, int rows, int w, std::vector<float> &merged, std::vector<float> &merged_b);

@@ -755,6 +755,105 @@ static int build_weight_maps(nrf_mlp *m, const std::vector<float> &hp)
     return NRF_OK;
 }
 
+// ---- classic NeRF (8 x 256): the same, with the merged views layer as a DERIVED block behind the blob ----
+// The packers' images are gathers of [blob | merged (views_linears_0 o feature_linear) | merged_b]; the merged block is a product, re-derived on the device by
+// k_nerf_merged_f64 with the host's double sums in the host's order (nerf_merged_views_host: f ascending, one accumulator per entry): the same bits.  The handle's
+// d_params buffer is re-allocated with room for the block behind the blob, so the maps' source indices run over one array.
+constexpr int NERF_MERGED_ROWS = 128, NERF_MERGED_W = 256, NERF_DERIVED = NERF_MERGED_ROWS * NERF_MERGED_W + NERF_MERGED_ROWS;
+
+__global__ void __launch_bounds__(256) k_nerf_merged_f64(const float *__restrict__ wv, int wv_stride, const float *__restrict__ wf, const float *__restrict__ bf,
+                                                         const float *__restrict__ bv, float *__restrict__ merged, float *__restrict__ merged_b)
+{
+    const int r = blockIdx.x, k = threadIdx.x;
+    double acc = 0.0;
+    for (int f = 0; f < NERF_MERGED_W; f++) acc += (double)wv[(size_t)r * wv_stride + f] * (double)wf[(size_t)f * NERF_MERGED_W + k];
+    merged[(size_t)r * NERF_MERGED_W + k] = (float)acc;
+    if (k == 0) {
+        double b = (double)bv[r];
+        for (int f = 0; f < NERF_MERGED_W; f++) b += (double)wv[(size_t)r * wv_stride + f] * (double)bf[f];
+        merged_b[r] = (float)b;
+    }
+}
+
+static int nerf_derive_on_device(const nrf_mlp *m, hipStream_t st)
+{
+    const auto &Lv = m->layers[8], &Lf = m->layers[9];          // views_linears_0, feature_linear (nrf_mlp_nerf_create's order)
+    const float *wv = m->d_params + Lv.w_off, *bv = wv + (size_t)Lv.in * Lv.out, *wf = m->d_params + Lf.w_off, *bf = wf + (size_t)Lf.in * Lf.out;
+    float *merged = m->d_params + m->n_params;
+    k_nerf_merged_f64<<<dim3(NERF_MERGED_ROWS), dim3(NERF_MERGED_W), 0, st>>>(wv, Lv.in, wf, bf, bv, merged, merged + (size_t)NERF_MERGED_ROWS * NERF_MERGED_W);
+    NRF_HIP(hipGetLastError());
+    return NRF_OK;
+}
+
+static std::vector<uint8_t> wm_bytes(const void *p, size_t n) { const uint8_t *b = static_cast<const uint8_t *>(p); return std::vector<uint8_t>(b, b + n); }
+
+// classic NeRF, after the images exist: NRF_OK with m->maps filled (and d_params re-homed with the derived block), or with m->maps empty (host repack stays in charge)
+static int build_weight_maps_nerf(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->nerf;
+    if (m->family != MLP_NERF || !m->d_packed_f16 || !m->d_packed_split || !m->d_packed_sigma_f32 || m->layers.size() != 12) return NRF_OK;
+    if (const char *e = getenv("NRF_MLP_HOST_REPACK")) if (atoi(e) != 0) return NRF_OK;
+    const int64_t n = m->n_params, next = n + NERF_DERIVED;
+    if (next >= (int64_t)WM_RADIX_LO * WM_RADIX_LO) return NRF_OK;
+    struct Images { std::vector<_Float16> img, img2; std::vector<float> bias, sig; size_t f16_at = 0, f16_floats = 0; bool ok = false; };
+    auto images = [&](const float *ext, Images &o) {
+        o.ok = nerf_f16_images_host(d, ext, ext + n, ext + n + (size_t)NERF_MERGED_ROWS * NERF_MERGED_W, o.img, o.img2, o.bias) &&
+               nerf_sigma_image_host(d, ext, ext + n, ext + n + (size_t)NERF_MERGED_ROWS * NERF_MERGED_W, o.sig, o.f16_at, o.f16_floats);
+    };
+    // the real extended blob: the host's merged block
+    std::vector<float> ext((size_t)next);
+    memcpy(ext.data(), hp.data(), (size_t)n * 4);
+    {
+        std::vector<float> merged, merged_b;
+        const size_t ov = m->layers[8].w_off, of = m->layers[9].w_off;
+        nerf_merged_views_host(hp.data() + ov, m->layers[8].in, hp.data() + of, hp.data() + of + (size_t)256 * 256, hp.data() + ov + (size_t)m->layers[8].in * 128, NERF_MERGED_ROWS, NERF_MERGED_W,
+                               merged, merged_b);
+        memcpy(ext.data() + n, merged.data(), merged.size() * 4);
+        memcpy(ext.data() + n + merged.size(), merged_b.data(), merged_b.size() * 4);
+    }
+    Images real, probe[4];
+    images(ext.data(), real);
+    if (!real.ok) return NRF_OK;
+    for (int q = 0; q < 4; q++) { const std::vector<float> pv = weight_map_probe(next, q); images(pv.data(), probe[q]); if (!probe[q].ok) return NRF_OK; }
+    // regions: (bytes of the real image, bytes of the four probes, element size, destination)
+    struct Region { std::vector<uint8_t> real, p[4]; int elem; void *dst; };
+    std::vector<Region> regs;
+    auto add = [&](auto bytes_of /* (const Images &) -> vector<uint8_t> */, int elem, void *dst) {
+        Region r; r.elem = elem; r.dst = dst; r.real = bytes_of(real);
+        for (int q = 0; q < 4; q++) r.p[q] = bytes_of(probe[q]);
+        regs.push_back(std::move(r));
+    };
+    char *f16 = static_cast<char *>(m->d_packed_f16), *spl = static_cast<char *>(m->d_packed_split), *sig = static_cast<char *>(m->d_packed_sigma_f32);
+    const size_t img_b = real.img.size() * 2, img2_b = real.img2.size() * 2, bias_b = real.bias.size() * 4;
+    if (m->packed_f16_bytes != img_b + bias_b || m->packed_split_bytes != img2_b + bias_b || m->packed_sigma_f32_bytes != real.sig.size() * 4) return NRF_OK;
+    add([](const Images &o) { return wm_bytes(o.img.data(), o.img.size() * 2); }, 2, f16);
+    add([](const Images &o) { return wm_bytes(o.bias.data(), o.bias.size() * 4); }, 4, f16 + img_b);
+    add([](const Images &o) { return wm_bytes(o.img2.data(), o.img2.size() * 2); }, 2, spl);
+    add([](const Images &o) { return wm_bytes(o.bias.data(), o.bias.size() * 4); }, 4, spl + img2_b);
+    const size_t a0 = real.f16_at, a1 = real.f16_at + real.f16_floats;
+    for (int q = 0; q < 4; q++) if (probe[q].f16_at != a0 || probe[q].f16_floats != real.f16_floats || probe[q].sig.size() != real.sig.size()) return NRF_OK;
+    add([&](const Images &o) { return wm_bytes(o.sig.data(), a0 * 4); }, 4, sig);
+    add([&](const Images &o) { return wm_bytes(o.sig.data() + a0, (a1 - a0) * 4); }, 2, sig + a0 * 4);
+    add([&](const Images &o) { return wm_bytes(o.sig.data() + a1, (o.sig.size() - a1) * 4); }, 4, sig + a1 * 4);
+    std::vector<HostMap> hms(regs.size());
+    for (size_t i = 0; i < regs.size(); i++) {
+        const std::vector<uint8_t> four[4] = { regs[i].p[0], regs[i].p[1], regs[i].p[2], regs[i].p[3] };
+        if (!decode_weight_map(four, regs[i].elem, next, hms[i]) || !weight_map_reproduces(hms[i], ext, regs[i].real)) return NRF_OK;
+    }
+    // re-home the blob with room for the derived block, derive it on the device and check it against the host's bits
+    float *big = nullptr;
+    NRF_HIP(hipMalloc(reinterpret_cast<void **>(&big), (size_t)next * 4));
+    NRF_HIP(hipMemcpy(big, m->d_params, (size_t)n * 4, hipMemcpyDeviceToDevice));
+    (void)hipFree(m->d_params);
+    m->d_params = big;
+    NRF_TRY(nerf_derive_on_device(m, nullptr));
+    std::vector<float> dev_derived((size_t)NERF_DERIVED);
+    NRF_HIP(hipMemcpy(dev_derived.data(), m->d_params + n, dev_derived.size() * 4, hipMemcpyDeviceToHost));
+    if (memcmp(dev_derived.data(), ext.data() + n, dev_derived.size() * 4) != 0) return NRF_OK;          // (maps stay empty: host repack)
+    for (size_t i = 0; i < regs.size(); i++) NRF_TRY(upload_weight_map(m, hms[i], regs[i].dst));
+    return NRF_OK;
+}
+
 // wt[k][o] = w[o][k]   (W [out][in] of the parameter blob -> W^T [in][out])
 __global__ void k_transpose_wt(int in, int out, const float *__restrict__ w, float *__restrict__ wt)
 {
@@ -1046,6 +1145,7 @@ int nrf_mlp_nerf_create(const nrf_mlp_nerf_desc *d, const float *params, int par
     if (w + d->input_ch_views > m->max_width) m->max_width = w + d->input_ch_views;
     if (s == NRF_OK) s = mlp_nerf_pack_f16(m, hp);
     if (s == NRF_OK) s = mlp_nerf_pack_sigma_f32(m, hp);
+    if (s == NRF_OK) s = build_weight_maps_nerf(m, hp);
     if (s != NRF_OK) { nrf_mlp_destroy(m); return s; }
     *out = m;
     return NRF_OK;
@@ -1126,6 +1226,16 @@ int nrf_mlp_set_params(nrf_mlp *m, const float *params, int params_on_device, vo
         // lanes, which are joined to it before a render call returns) still reads the old images and finishes first; another stream of the caller's must be ordered
         // by the caller, as for any in-place update.
         NRF_HIP(hipMemcpyAsync(m->d_params, params, (size_t)m->n_params * 4, params_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (m->family == MLP_NERF) {
+            // classic network: W^T and bias of every layer (the fp32 kernels' operands), then the merged views layer behind the blob: the maps below gather from both
+            for (auto &L : m->layers) {
+                const int64_t ne = (int64_t)L.in * L.out;
+                k_transpose_wt<<<dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st>>>(L.in, L.out, m->d_params + L.w_off, L.d_wt);
+                NRF_HIP(hipGetLastError());
+                if (L.d_bias) NRF_HIP(hipMemcpyAsync(L.d_bias, m->d_params + L.w_off + (size_t)L.in * L.out, (size_t)L.out * 4, hipMemcpyDeviceToDevice, st));
+            }
+            NRF_TRY(nerf_derive_on_device(m, st));
+        }
         for (auto &w : m->maps) {
             if (w.scaled && m->d_group) continue;          // the split-precision operands: below, from the range-scaled blob
             k_apply_weight_map<<<dim3((unsigned)((w.n + 255) / 256)), dim3(256), 0, st>>>(w.n, w.d_src, w.d_kind, m->d_params, w.d_out, w.elem);

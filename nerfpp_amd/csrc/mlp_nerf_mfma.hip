@@ -288,6 +288,9 @@ static bool nerf_mfma_supported(const nrf_mlp_nerf_desc &d)
     return d.depth == 8 && d.width == 256 && d.input_ch == 63 && d.input_ch_views == 27 && d.skip == 4 && d.use_viewdirs;
 }
 
+// blob offset (floats) of views_linears_0 in the built family (8 x 256, 63 inputs, skip 4): behind the eight pts_linears (NeRF.cpp:75-89 order)
+size_t nerf_blob_offset_views() { return (size_t)63 * 256 + 256 + (size_t)6 * (256 * 256 + 256) + (size_t)(256 + 63) * 256 + 256; }
+
 void host_parallel_for(int n, const std::function<void(int, int)> &range_fn)
 {
     const int nt = n < 2 ? 1 : host_pack_threads();
@@ -317,10 +320,13 @@ void nerf_merged_views_host(const float *wv, int wv_stride, const float *wf, con
     });
 }
 
-int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+// The fp16 image, the split image and the bias array of the classic network as host vectors, from the parameter blob `hp` and the merged views layer
+// (views_linears_0 o feature_linear: `merged` [128][256], `merged_b` [128], nerf_merged_views_host) -- every entry a copy (hi / lo half) of one entry of those three
+// arrays or zero, which is what lets mlp.hip decode the layout from probe blobs and rebuild the images on the device.  false: outside the built family.
+bool nerf_f16_images_host(const nrf_mlp_nerf_desc &d, const float *hp, const float *merged, const float *merged_b, std::vector<_Float16> &img, std::vector<_Float16> &img2,
+                          std::vector<float> &bias)
 {
-    const auto &d = m->nerf;
-    if (!nerf_mfma_supported(d)) return NRF_OK;
+    if (!nerf_mfma_supported(d)) return false;
     const int W = 256, IN = 63, V = 27;
     // blob offsets (NeRF.cpp:75-89 order)
     std::vector<size_t> w_off(12), b_off(12);
@@ -336,15 +342,10 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
     in_dim[ALPHA] = W; out_dim[ALPHA] = 1; w_off[ALPHA] = off; off += W; b_off[ALPHA] = off; off += 1;
     in_dim[RGB] = W / 2; out_dim[RGB] = 3; w_off[RGB] = off; off += (size_t)(W / 2) * 3; b_off[RGB] = off; off += 3;
 
-    std::vector<_Float16> img;
-    img.reserve((size_t)NerfNet::total_frags() * 512);
-    std::vector<float> bias(NBIAS, 0.0f);
+    img.clear(); img2.clear();
+    bias.assign(NBIAS, 0.0f);
     auto chained = [](int k, int h, int j) { return 32 * (k >> 1) + nerf_perm_row(k & 1, h, j); };
     auto natural = [](int k, int h, int j) { return 16 * k + 8 * h + j; };
-    // views_linears_0 o feature_linear: merged[r][k] = sum_f W_v[r][f] F[f][k], merged_b[r] = sum_f W_v[r][f] b_f[f] + b_v[r]   (double accumulation)
-    std::vector<float> merged, merged_b;
-    nerf_merged_views_host(hp.data() + w_off[VIEWS], V + W, hp.data() + w_off[FEAT], hp.data() + b_off[FEAT], hp.data() + b_off[VIEWS], W / 2, W, merged, merged_b);
-    m->host_merged = merged; m->host_merged_b = merged_b;          // for mlp_nerf_pack_sigma_f32 of the same upload
     // value of the weight that multiplies operand element (kstep, h, j) for output row `row` of kernel-layer L (-> 0 if padding)
     auto wval = [&](int L, int row, int kstep, int h, int j) -> float {
         const int ksn = NerfNet::ks_nat(L), ksc = NerfNet::ks_ch(L);
@@ -352,7 +353,7 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         const int kk = NerfNet::nat_first(L) ? (nat ? kstep : kstep - ksn) : (nat ? kstep - ksc : kstep);
         const int idx = nat ? natural(kk, h, j) : chained(kk, h, j);
         if (L < 8) {
-            const float *w = hp.data() + w_off[L];
+            const float *w = hp + w_off[L];
             if (L == 0) return (idx < IN) ? w[(size_t)row * IN + idx] : 0.0f;
             if (L == 5) return nat ? ((idx < IN) ? w[(size_t)row * (W + IN) + idx] : 0.0f) : w[(size_t)row * (W + IN) + IN + idx];
             return w[(size_t)row * W + idx];
@@ -377,9 +378,9 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
         for (int tile = 0; tile < NerfNet::tiles(L); tile++)
             for (int k = 0; k < NerfNet::ks(L); k++) frags.push_back(FragId{L, tile, k});
     const int NF = (int)frags.size();
-    if (NF != NerfNet::total_frags()) { set_error("internal: classic NeRF weight image has %d fragments, expected %d", NF, NerfNet::total_frags()); return NRF_ERR_INVALID_ARG; }
+    if (NF != NerfNet::total_frags()) { set_error("internal: classic NeRF weight image has %d fragments, expected %d", NF, NerfNet::total_frags()); return false; }
     img.resize((size_t)NF * 512);
-    std::vector<_Float16> img2((size_t)NF * 1024);
+    img2.resize((size_t)NF * 1024);
     host_parallel_for(NF, [&](int f0, int f1) {
         for (int f = f0; f < f1; f++) {
             const FragId id = frags[(size_t)f];
@@ -394,6 +395,22 @@ int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
                 }
         }
     });
+    return true;
+}
+
+int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->nerf;
+    if (!nerf_mfma_supported(d)) return NRF_OK;
+    const int W = 256, V = 27;
+    // views_linears_0 o feature_linear: merged[r][k] = sum_f W_v[r][f] F[f][k], merged_b[r] = sum_f W_v[r][f] b_f[f] + b_v[r]   (double accumulation)
+    const size_t o_views = nerf_blob_offset_views(), o_feat = o_views + (size_t)(V + W) * (W / 2) + W / 2;
+    std::vector<float> merged, merged_b;
+    nerf_merged_views_host(hp.data() + o_views, V + W, hp.data() + o_feat, hp.data() + o_feat + (size_t)W * W, hp.data() + o_views + (size_t)(V + W) * (W / 2), W / 2, W, merged, merged_b);
+    std::vector<_Float16> img, img2;
+    std::vector<float> bias;
+    if (!nerf_f16_images_host(d, hp.data(), merged.data(), merged_b.data(), img, img2, bias)) return NRF_ERR_INVALID_ARG;
+    m->host_merged = merged; m->host_merged_b = merged_b;          // for mlp_nerf_pack_sigma_f32 of the same upload
     const size_t b1 = img.size() * sizeof(_Float16) + bias.size() * sizeof(float), b2 = img2.size() * sizeof(_Float16) + bias.size() * sizeof(float);
     if (m->d_packed_f16 && m->packed_f16_bytes != b1) { (void)hipFree(m->d_packed_f16); m->d_packed_f16 = nullptr; }        // a re-pack of the same shape writes in place (the caller has synchronised)
     m->packed_f16_bytes = b1;

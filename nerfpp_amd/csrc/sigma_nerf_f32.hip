@@ -384,12 +384,13 @@ static bool sigma_nerf_f32_supported(const nrf_mlp_nerf_desc &d)
     return d.depth == 8 && d.width == 256 && d.input_ch == 63 && d.skip == 4 && d.use_viewdirs;
 }
 
-int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+// The exact-fp32 density image of the classic network as a host vector: fp32 fragments and biases with a block of fp16 (hi, lo) fragments in between (floats
+// [f16_at, f16_at + f16_floats) hold two fp16 values each).  As nerf_f16_images_host: every entry a copy (or fp16 hi / lo half) of one entry of hp / merged / merged_b.
+bool nerf_sigma_image_host(const nrf_mlp_nerf_desc &d, const float *hp, const float *merged, const float *merged_b, std::vector<float> &img, size_t &f16_at, size_t &f16_floats)
 {
-    const auto &d = m->nerf;
-    if (!sigma_nerf_f32_supported(d)) return NRF_OK;
+    if (!sigma_nerf_f32_supported(d)) return false;
     using namespace nsig;
-    std::vector<float> img;
+    img.clear();
     img.reserve((size_t)TOTAL_GROUPS * 256 + BIAS_FLOATS + ALPHA_FLOATS + VIEW_BIAS_FLOATS);
     std::vector<float> bias((size_t)BIAS_FLOATS, 0.0f);
     size_t off = 0;
@@ -406,7 +407,7 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
         for (int u = u0; u < u1; u++) {
             const int l = u >> 3, mt = u & 7;
             const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
-            const float *w = hp.data() + layer_off[l];
+            const float *w = hp + layer_off[l];
             // padded k -> column of W: layer 0: k < 63; layer 5: [input 0..62 | pad | h 0..255] -> columns [0..62 | - | 63..318]
             auto col = [&](int k) { return l == 0 ? (k < 63 ? k : -1) : l == 5 ? (k < 63 ? k : k == 63 ? -1 : k - 1) : k; };
             float *dst = img.data() + layer_at[l] + (size_t)mt * groups(l) * 256;
@@ -421,25 +422,19 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
     });
     for (int l = 0; l < NL; l++) {
         const int in = l == 0 ? 63 : l == 5 ? 63 + 256 : 256;
-        const float *b = hp.data() + layer_off[l] + (size_t)in * 256;
+        const float *b = hp + layer_off[l] + (size_t)in * 256;
         for (int mt = 0; mt < 8; mt++)
             for (int h = 0; h < 2; h++)
                 for (int q = 0; q < 16; q++) bias[((size_t)(l * 8 + mt) * 2 + h) * 16 + q] = b[32 * mt + 2 * q + h];
     }
     // blob order after pts_linears: views_linears_0 (w, b), feature_linear (w, b), alpha_linear (w, b), rgb_linear (w, b)
     const int V = d.input_ch_views;                                  // 27
-    const float *wv = hp.data() + off, *bv = wv + (size_t)(V + 256) * 128;
+    const float *wv = hp + off;
     off += (size_t)(V + 256) * 128 + 128;
-    const float *wf = hp.data() + off, *bf = wf + (size_t)256 * 256;
-    off += (size_t)256 * 256 + 256;
-    const float *aw = hp.data() + off;
+        off += (size_t)256 * 256 + 256;
+    const float *aw = hp + off;
     off += 256 + 1;
-    const float *wr = hp.data() + off, *br = wr + (size_t)128 * 3;
-    // views_linears_0 o feature_linear (no activation between them, NeRF.cpp:112-115): merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r], in double
-    std::vector<float> merged, merged_b;
-    if (m->host_merged.size() == (size_t)128 * 256 && m->host_merged_b.size() == 128) { merged.swap(m->host_merged); merged_b.swap(m->host_merged_b); }          // the same upload's product (mlp_nerf_pack_f16)
-    else nerf_merged_views_host(wv, V + 256, wf, bf, bv, 128, 256, merged, merged_b);
-    m->host_merged.clear(); m->host_merged_b.clear();
+    const float *wr = hp + off, *br = wr + (size_t)128 * 3;
     // (hi, lo) fp16 fragments of the colour branch: per k-step the hi fragment then the fragment of the rounding residuals
     std::vector<_Float16> himg;
     himg.reserve((size_t)(4 * VIEW_GROUPS + VIEW_LAST_GROUPS + RGB_GROUPS) * 512);
@@ -471,6 +466,7 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
         });
     {
         const size_t nf = himg.size() / 2, at = img.size();
+        f16_at = at; f16_floats = nf;
         img.resize(at + nf);
         memcpy(img.data() + at, himg.data(), nf * sizeof(float));
     }
@@ -483,6 +479,25 @@ int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
             for (int q = 0; q < 16; q++) img.push_back(merged_b[32 * t + 8 * (q >> 2) + 4 * h + (q & 3)]);
     for (int k = 0; k < 3; k++) img.push_back(br[k]);
     img.push_back(0.0f);
+    return true;
+}
+
+int mlp_nerf_pack_sigma_f32(nrf_mlp *m, const std::vector<float> &hp)
+{
+    const auto &d = m->nerf;
+    if (!sigma_nerf_f32_supported(d)) return NRF_OK;
+    // views_linears_0 o feature_linear (no activation between them, NeRF.cpp:112-115): merged[r][k] = sum_f Wv[r][f] Wf[f][k], merged_b[r] = sum_f Wv[r][f] bf[f] + bv[r], in double
+    std::vector<float> merged, merged_b;
+    if (m->host_merged.size() == (size_t)128 * 256 && m->host_merged_b.size() == 128) { merged.swap(m->host_merged); merged_b.swap(m->host_merged_b); }          // the same upload's product (mlp_nerf_pack_f16)
+    else {
+        const int V = d.input_ch_views;
+        const size_t o_views = nerf_blob_offset_views(), o_feat = o_views + (size_t)(V + 256) * 128 + 128;
+        nerf_merged_views_host(hp.data() + o_views, V + 256, hp.data() + o_feat, hp.data() + o_feat + (size_t)256 * 256, hp.data() + o_views + (size_t)(V + 256) * 128, 128, 256, merged, merged_b);
+    }
+    m->host_merged.clear(); m->host_merged_b.clear();
+    std::vector<float> img;
+    size_t f16_at = 0, f16_floats = 0;
+    if (!nerf_sigma_image_host(d, hp.data(), merged.data(), merged_b.data(), img, f16_at, f16_floats)) return NRF_ERR_INVALID_ARG;
     const size_t bytes = img.size() * sizeof(float);
     if (m->d_packed_sigma_f32 && m->packed_sigma_f32_bytes != bytes) { (void)hipFree(m->d_packed_sigma_f32); m->d_packed_sigma_f32 = nullptr; }
     if (!m->d_packed_sigma_f32) NRF_HIP(hipMalloc(&m->d_packed_sigma_f32, bytes));

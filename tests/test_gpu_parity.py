@@ -3602,6 +3602,34 @@ def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
 
 
 @pytest.mark.gpu
+def test_classic_network_parameter_upload_stays_on_the_device_and_equals_the_host_pack(api):
+    """nrf_mlp_set_params on the classic 8 x 256 network: its three matrix-core images (fp16, split, exact-fp32 density: seven regions of two element sizes) are gathers of
+    [blob | merged views layer]; the gather maps are DECODED from the host packers run on probe blobs and checked against the host-packed images byte for byte when the
+    handle is created (nrf_mlp_device_repack_images == 7), the merged layer is re-derived by a device kernel with the host's double sums.  A frame rendered after a device
+    upload equals, bit for bit and in every precision, the frame of a network CREATED from the same parameters (host packers)."""
+    L, S, R, M = api.L, api.S, api.R, api.M
+    K = S.lego_K(48, 48); c2w = S.pose_spherical(35.0, -20.0, 4.0)
+    sc = S.make_classic_scene()
+    assert L.lib().nrf_mlp_device_repack_images(sc["mlp"]._m) == 7
+    rng = np.random.default_rng(11)
+    blob2 = (sc["mlp_blob"] * (1.0 + 0.3 * rng.standard_normal(sc["mlp_blob"].shape))).astype(np.float32)
+    t2 = torch.as_tensor(blob2).cuda()
+    L.check(L.lib().nrf_mlp_set_params(sc["mlp"]._m, C.c_void_p(t2.data_ptr()), 1, None))
+    fresh_mlp = M.NeRF(8, 256, sc["embedder"].GetOutputDims(), sc["embeddirs"].GetOutputDims(), 5, (4,), True, "model", params=blob2)
+    fresh = R.NeRFRenderer(sc["embedder"], sc["embeddirs"], fresh_mlp)
+    for prec in (L.NRF_PREC_F16_SPLIT, L.NRF_PREC_F16_MFMA, L.NRF_PREC_F32):
+        p = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=2048, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX, Precision=prec)
+        a = sc["renderer"].Render(48, 48, K, p, c2w=c2w)
+        b = fresh.Render(48, 48, K, p, c2w=c2w)
+        assert torch.equal(a.Outputs.RGBMap, b.Outputs.RGBMap) and torch.equal(a.Outputs.DepthMap, b.Outputs.DepthMap), prec
+        assert bool(torch.isfinite(a.Outputs.RGBMap).all())
+    # ... and the host path (a host pointer) still gives the same images
+    L.check(L.lib().nrf_mlp_set_params(sc["mlp"]._m, blob2.ctypes.data_as(C.c_void_p), 0, None))
+    a = sc["renderer"].Render(48, 48, K, p, c2w=c2w)
+    assert torch.equal(a.Outputs.RGBMap, b.Outputs.RGBMap)
+
+
+@pytest.mark.gpu
 def test_lerf_head_parameter_upload_stays_on_the_device_and_equals_the_host_pack(api):
     """nrf_mlp_set_params on a LeRF head with a DEVICE pointer: the Gram matrix, the fp16 / split images and the exact-fp32 density image are rebuilt by device kernels
     (mlp_lerf_pack_f16_device, mlp_lerf_pack_sigma_f32_device; round 6: the host packer's 3 ms were GPU idle time in every training step).  The handle says so
