@@ -549,6 +549,7 @@ struct GemmTN {
     int nbi0;                             // output tiles along n that belong to segment 0
     int64_t P, slice_pts;                 // points (a multiple of 32), points per slice (a multiple of 32)
     float *part;                          // [slices][out][n + n1]
+    float *bpart;                         // optional [slices][out]: the slice's column sums of G (the layer's bias gradient), by the workgroups of X tile 0
     int vg, vx;                           // 4: rows 16-byte aligned and the column count a multiple of 4 (vector loads); 1: scalar loads
     int nbo, nbi;                         // output tiles along out / n
 };
@@ -588,6 +589,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
     for (int j = 0; j < 4; j++) cj[j] = col + j < ncols ? col + j : ncols - 1;
     if (VEC && col + 4 > ncols) col = ncols - 4;
     float4 r0[8], r1[8];
+    const bool bsum_on = a.bpart && opnd == 0 && bi == 0;          // (wave-uniform: waves 0-1 of the workgroups of X tile 0)
+    float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f, bs3 = 0.0f;          // this thread's four G columns, summed over its eight points of every K tile
     auto load_tile = [&](int tile, float4 (&rr)[8]) {
         const float *rp = src + (p_begin + (int64_t)tile * 32 + pg * 8) * ld;
         if (VEC) {
@@ -604,6 +607,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
     auto store_tile = [&](int stage, const float4 (&rr)[8]) {
         unsigned char *base = gb_smem + stage * TN_STAGE + opnd * TN_OP;
         const int ks = pg >> 1, hh = pg & 1;
+        if (bsum_on) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { bs0 += rr[k].x; bs1 += rr[k].y; bs2 += rr[k].z; bs3 += rr[k].w; }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             gb_bf16x8 hi, lo;
@@ -665,6 +672,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
         if (tile + 2 < T) store_tile(0, r0);
         __syncthreads();
     }
+    if (a.bpart && bi == 0) {
+        // the four point groups' sums of every column quad through LDS (the K loop's last barrier is behind us), added in group order
+        float *bl = reinterpret_cast<float *>(gb_smem);
+        if (opnd == 0) { bl[(pg * 32 + cq) * 4 + 0] = bs0; bl[(pg * 32 + cq) * 4 + 1] = bs1; bl[(pg * 32 + cq) * 4 + 2] = bs2; bl[(pg * 32 + cq) * 4 + 3] = bs3; }
+        __syncthreads();
+        if (t < TN_T) {
+            const int o = bo * TN_T + t;
+            if (o < a.out) a.bpart[(size_t)slice * a.out + o] = ((bl[t] + bl[128 + t]) + bl[256 + t]) + bl[384 + t];
+        }
+    }
     // register q of lane (r, h) of tile pair (i, j): G column o = 128 bo + 4 ((q & 3) + 8 (q >> 2) + 4 h) + (2 wm + i), X column c = 128 bi + 4 r + (2 wn + j)
     const int nn = a.n + a.n1;
     float *dst = a.part + (size_t)slice * a.out * nn;
@@ -685,10 +702,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
 
 // dw += the slices' partial matrices, in slice order.  Columns [0, n0) of a partial row go to dw columns col0 ..; columns n0 + skip1 .. n0 + skip1 + keep1 to col1 ..
 // (the other columns of the second segment are computed but not wanted: an aligned read of [sigma | geo | padding] for the geo columns)
-__global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, int col1, int skip1, int keep1, const float *__restrict__ part, float *__restrict__ dw)
+__global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, int col1, int skip1, int keep1, const float *__restrict__ part, float *__restrict__ dw,
+                         const float *__restrict__ bpart, float *__restrict__ db)
 {
     const int nn = n0 + n1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bpart && e < out) {          // db[o] += the slices' column sums of G, in slice order
+        float s = 0.0f;
+        for (int b = 0; b < slices; b++) s += bpart[(size_t)b * out + e];
+        db[e] += s;
+    }
     if (e >= out * nn) return;
     const int o = e / nn, i = e - o * nn;
     if (i >= n0 && (i - n0 < skip1 || i - n0 >= skip1 + keep1)) return;
@@ -713,9 +736,19 @@ __global__ void k_tn_tail(int pts, int out, int n, const float *__restrict__ g, 
     dw[(size_t)o * in + col0 + i] += acc;
 }
 
-// dw [out][in] += g^T [x | x1] over P points: x's columns land at dw columns col0 .., x1's columns skip1 .. skip1 + keep1 at col1 .. (x1.n == 0: one segment; x1.n may be
+// db[o] += sum over the last P % 32 points of g[p][o]
+__global__ void k_tn_tail_bias(int pts, int out, const float *__restrict__ g, int ldg, float *__restrict__ db)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= out) return;
+    float acc = 0.0f;
+    for (int p = 0; p < pts; p++) acc += g[(size_t)p * ldg + o];
+    db[o] += acc;
+}
+
+// dw [out][in] += g^T [x | x1] over P points (and, with db, db[o] += the column sums of g: the layer's bias gradient out of the same pass): x's columns land at dw columns col0 .., x1's columns skip1 .. skip1 + keep1 at col1 .. (x1.n == 0: one segment; x1.n may be
 // rounded up past skip1 + keep1 for aligned 16-byte reads: the row must hold that many floats, what they contain does not matter)
-int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st)
+int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db)
 {
     if (P <= 0 || x.n <= 0 || out <= 0) return NRF_OK;
     const bool two = x1.p && keep1 > 0 && x1.n >= skip1 + keep1;
@@ -726,6 +759,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
         if (two)
             hipLaunchKernelGGL(k_tn_tail, dim3((unsigned)ceil_div((int64_t)out * keep1, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, keep1,
                                g.p + g.off + P32 * g.stride, g.stride, x1.p + x1.off + skip1 + P32 * x1.stride, x1.stride, in, col1, dw);
+        if (db) hipLaunchKernelGGL(k_tn_tail_bias, dim3((unsigned)ceil_div((int64_t)out, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, g.p + g.off + P32 * g.stride, g.stride, db);
         NRF_LAUNCH_CHECK();
     }
     if (P32 == 0) return NRF_OK;
@@ -747,8 +781,12 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     a.slice_pts = ((P32 / 32 + slices - 1) / slices) * 32;
     slices = (P32 + a.slice_pts - 1) / a.slice_pts;
     float *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * out * nn * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_bf16x3: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    if (hipMallocAsync(reinterpret_cast<void **>(&part), ((size_t)slices * out * nn + (db ? (size_t)slices * out : 0)) * sizeof(float), st) != hipSuccess) {
+        set_error("gemm_tn_bf16x3: hipMallocAsync failed");
+        return NRF_ERR_HIP;
+    }
     a.part = part;
+    a.bpart = db ? part + (size_t)slices * out * nn : nullptr;
     static bool attr = false;
     if (!attr) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
@@ -757,7 +795,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     }
     if (a.vg == 4 && a.vx == 4) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
     else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
-    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw);
+    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw, (const float *)a.bpart, db);
     const hipError_t le = hipGetLastError();
     (void)hipFreeAsync(part, st);
     if (le != hipSuccess) { set_error("gemm_tn_bf16x3: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
@@ -767,7 +805,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
 // dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
 int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
 {
-    return gemm_tn_bf16x3_2(P, g, x, col0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st);
+    return gemm_tn_bf16x3_2(P, g, x, col0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st, nullptr);
 }
 
 // Arithmetic of the training paths' forward / back-propagation products.  -1 (the default, NRF_TRAIN_GEMM=auto): by network family -- f16x3 for the classic NeRF and the

@@ -444,21 +444,36 @@ static int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st)
 
 // y[pt][k] = a[pt][a_off + k] (+ b[pt][b_off + k]), k < n
 __global__ void k_sum_cols(int64_t npts, int n, const float *__restrict__ a, int a_stride, int a_off, const float *__restrict__ b, int b_stride, int b_off, float *__restrict__ y,
-                           int y_stride)
+                           int y_stride, const float *__restrict__ mask, int mask_stride)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= npts * n) return;
     const int64_t pt = e / n; const int k = (int)(e - pt * n);
     float v = a[pt * a_stride + a_off + k];
     if (b) v = v + b[pt * b_stride + b_off + k];
+    if (mask) v = mask[pt * mask_stride + k] > 0.0f ? v : 0.0f;          // the ReLU mask of the stage that consumes y (what run_relu_mask would do in a pass of its own)
     y[pt * y_stride + k] = v;
 }
 
-static int run_sum_cols(int64_t npts, int n, const float *a, int a_stride, int a_off, const float *b, int b_stride, int b_off, float *y, int y_stride, hipStream_t st)
+static int run_sum_cols(int64_t npts, int n, const float *a, int a_stride, int a_off, const float *b, int b_stride, int b_off, float *y, int y_stride, hipStream_t st,
+                        const float *mask = nullptr, int mask_stride = 0)
 {
-    hipLaunchKernelGGL(k_sum_cols, dim3((unsigned)ceil_div(npts * n, 256)), dim3(256), 0, st, npts, n, a, a_stride, a_off, b, b_stride, b_off, y, y_stride);
+    hipLaunchKernelGGL(k_sum_cols, dim3((unsigned)ceil_div(npts * n, 256)), dim3(256), 0, st, npts, n, a, a_stride, a_off, b, b_stride, b_off, y, y_stride, mask, mask_stride);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
+}
+
+// dW and db of one layer: the split-precision modes do both in the weight-gradient product's pass over g (gemm_tn_bf16x3_2 sums g's columns on its way through the
+// registers); otherwise the two kernels
+static int run_grad_wb_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, float *db, hipStream_t st, int arith)
+{
+    if (arith != 0 && npts >= 4096 && out >= 32 && a.n > 0) {
+        NRF_TRY(gemm_tn_bf16x3_2(npts, g, a, 0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st, db));
+        if (b.n > 0) NRF_TRY(gemm_tn_bf16x3(npts, g, b, out, in, a.n, dw, st));
+        return NRF_OK;
+    }
+    NRF_TRY(run_grad_w_fast(npts, g, a, b, out, in, dw, st, arith));
+    return run_grad_b(npts, g, out, db, st);
 }
 
 static size_t mlp_nerf_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
@@ -499,6 +514,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         }
         const Seg hlast = cur;
         float *gh = G[0];                                    // d loss / d (the last pts layer's post-ReLU output)
+        bool gh_masked = false;                              // ... already multiplied by that output's ReLU mask
         float *gx_acc = nullptr;                             // d loss / d input_pts collected on the way (G[4] when wanted)
         auto add_gx = [&](const float *src, int src_stride, int src_off) -> int {
             if (!g_x) return NRF_OK;
@@ -518,23 +534,21 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_relu_mask(c, Wd / 2, G[1], W, HV, W, st));
             const Seg g_hv{G[1], W, 0, Wd / 2};
             // views_linears_0
-            NRF_TRY(run_grad_w_fast(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, st, train_gemm_for(m)));
-            NRF_TRY(run_grad_b(c, g_hv, Wd / 2, bias_of(views), st));
+            NRF_TRY(run_grad_wb_fast(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, bias_of(views), st, train_gemm_for(m)));
             NRF_TRY(run_backprop_fast(c, g_hv, m, views, G[2], W, st));                                                     // d / d cat[feature, views]
             const Seg g_feat{G[2], W, 0, Wd};
             // feature_linear and alpha_linear, both on h                                                              :108-110
-            NRF_TRY(run_grad_w_fast(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, st, train_gemm_for(m)));
-            NRF_TRY(run_grad_b(c, g_feat, Wd, bias_of(feat), st));
+            NRF_TRY(run_grad_wb_fast(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, bias_of(feat), st, train_gemm_for(m)));
             NRF_TRY(run_grad_w_fast(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_alpha, 1, bias_of(alpha), st));
             NRF_TRY(run_backprop_fast(c, g_feat, m, feat, G[1], W, st));
             NRF_TRY(run_backprop_fast(c, g_alpha, m, alpha, G[3], W, st));
-            NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, G[3], W, 0, gh, W, st));
+            NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, G[3], W, 0, gh, W, st, H[D - 1], W));          // (+ h_{D-1}'s ReLU mask: the first pts_linears stage below finds it applied)
+            gh_masked = true;
         } else {
             const LinearLayer &outl = m->layers[D];                                                                    // output_linear(cat[h, input_pts])  :121-124
             const Seg g_o{gc, gos, 0, outl.out};
-            NRF_TRY(run_grad_w_fast(c, g_o, hlast, xin, outl.out, Wd + in, g_params + outl.w_off, st, train_gemm_for(m)));
-            NRF_TRY(run_grad_b(c, g_o, outl.out, bias_of(outl), st));
+            NRF_TRY(run_grad_wb_fast(c, g_o, hlast, xin, outl.out, Wd + in, g_params + outl.w_off, bias_of(outl), st, train_gemm_for(m)));
             NRF_TRY(run_backprop_fast(c, g_o, m, outl, G[1], W, st));
             NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, nullptr, 0, 0, gh, W, st));
             NRF_TRY(add_gx(G[1], W, Wd));
@@ -542,7 +556,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         // ---- pts_linears, last first ----
         float *gcur = gh;
         const bool fuse = run_backprop_fuses_mask(m, c);          // bf16x3 products: the next stage's ReLU mask in the back-propagation product's epilogue
-        bool premasked = false;
+        bool premasked = gh_masked;
         for (int l = D - 1; l >= 0; l--) {
             const LinearLayer &L = m->layers[l];
             if (!premasked) NRF_TRY(run_relu_mask(c, Wd, gcur, W, H[l], W, st));
@@ -551,8 +565,7 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             const bool cat = (l > 0) && (l - 1 == d.skip);                                                             // this layer's input is cat[input_pts, h_{l-1}]
             const Seg a = (l == 0) ? xin : (cat ? xin : Seg{H[l - 1], W, 0, Wd});
             const Seg b = cat ? Seg{H[l - 1], W, 0, Wd} : none;
-            NRF_TRY(run_grad_w_fast(c, g, a, b, Wd, L.in, g_params + L.w_off, st, train_gemm_for(m)));
-            NRF_TRY(run_grad_b(c, g, Wd, bias_of(L), st));
+            NRF_TRY(run_grad_wb_fast(c, g, a, b, Wd, L.in, g_params + L.w_off, bias_of(L), st, train_gemm_for(m)));
             if (l == 0 && !g_x) break;
             float *dst = (gcur == G[1]) ? G[2] : G[1];
             const bool mask_next = fuse && l > 0 && !cat;          // dst = d / d H[l - 1] (with the skip concat the h part sits at a column offset: masked by its own pass)
@@ -564,7 +577,8 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
                 float *nxt = (dst == G[1]) ? G[2] : G[1];
                 // the h part of the gradient, moved to column 0 of another buffer (never in place: rows overlap)
                 nxt = (nxt == gcur) ? G[3] : nxt;
-                NRF_TRY(run_sum_cols(c, Wd, dst, W, in, nullptr, 0, 0, nxt, W, st));
+                NRF_TRY(run_sum_cols(c, Wd, dst, W, in, nullptr, 0, 0, nxt, W, st, H[l - 1], W));          // (+ h_{l-1}'s ReLU mask)
+                premasked = true;
                 gcur = nxt;
                 continue;
             }
