@@ -702,16 +702,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
 
 // dw += the slices' partial matrices, in slice order.  Columns [0, n0) of a partial row go to dw columns col0 ..; columns n0 + skip1 .. n0 + skip1 + keep1 to col1 ..
 // (the other columns of the second segment are computed but not wanted: an aligned read of [sigma | geo | padding] for the geo columns)
-__global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, int col1, int skip1, int keep1, const float *__restrict__ part, float *__restrict__ dw,
-                         const float *__restrict__ bpart, float *__restrict__ db)
+__global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, int col1, int skip1, int keep1, const float *__restrict__ part, float *__restrict__ dw)
 {
     const int nn = n0 + n1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bpart && e < out) {          // db[o] += the slices' column sums of G, in slice order
-        float s = 0.0f;
-        for (int b = 0; b < slices; b++) s += bpart[(size_t)b * out + e];
-        db[e] += s;
-    }
     if (e >= out * nn) return;
     const int o = e / nn, i = e - o * nn;
     if (i >= n0 && (i - n0 < skip1 || i - n0 >= skip1 + keep1)) return;
@@ -723,6 +717,17 @@ __global__ void k_tn_sum(int slices, int out, int n0, int n1, int in, int col0, 
     for (; b < slices; b++) s0 += part[(size_t)b * out * nn + e];
     const int c = i < n0 ? col0 + i : col1 + (i - n0 - skip1);
     dw[(size_t)o * in + c] += (s0 + s1) + (s2 + s3);
+}
+
+// db[o] += the slices' column sums of G: one wave per column, lane l adds slices l, l + 64, ... and the lanes' sums are combined in a fixed butterfly (deterministic)
+__global__ void __launch_bounds__(64) k_tn_bias_sum(int slices, int out, const float *__restrict__ bpart, float *__restrict__ db)
+{
+    const int o = blockIdx.x, lane = threadIdx.x;
+    float s = 0.0f;
+    for (int b = lane; b < slices; b += 64) s += bpart[(size_t)b * out + o];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) db[o] += s;
 }
 
 // the last P % 32 points (fp32 FMAs, one thread per dw entry)
@@ -795,7 +800,8 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     }
     if (a.vg == 4 && a.vx == 4) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
     else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
-    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw, (const float *)a.bpart, db);
+    hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw);
+    if (db) hipLaunchKernelGGL(k_tn_bias_sum, dim3((unsigned)out), dim3(64), 0, st, (int)slices, out, (const float *)a.bpart, db);
     const hipError_t le = hipGetLastError();
     (void)hipFreeAsync(part, st);
     if (le != hipSuccess) { set_error("gemm_tn_bf16x3: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }

@@ -455,6 +455,18 @@ __global__ void k_sum_cols(int64_t npts, int n, const float *__restrict__ a, int
     y[pt * y_stride + k] = v;
 }
 
+// y[pt][k] = (a[pt][k] + s[pt] w[k]) . [mask[pt][k] > 0]: a sum whose second term is a rank-1 product (the back-propagation through a one-row layer)
+__global__ void k_sum_rank1(int64_t npts, int n, const float *__restrict__ a, int a_stride, const float *__restrict__ s, int s_stride, const float *__restrict__ w, float *__restrict__ y,
+                            int y_stride, const float *__restrict__ mask, int mask_stride)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npts * n) return;
+    const int64_t pt = e / n; const int k = (int)(e - pt * n);
+    float v = a[pt * a_stride + k] + s[pt * s_stride] * w[k];
+    if (mask) v = mask[pt * mask_stride + k] > 0.0f ? v : 0.0f;
+    y[pt * y_stride + k] = v;
+}
+
 static int run_sum_cols(int64_t npts, int n, const float *a, int a_stride, int a_off, const float *b, int b_stride, int b_off, float *y, int y_stride, hipStream_t st,
                         const float *mask = nullptr, int mask_stride = 0)
 {
@@ -542,8 +554,11 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_grad_w_fast(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_alpha, 1, bias_of(alpha), st));
             NRF_TRY(run_backprop_fast(c, g_feat, m, feat, G[1], W, st));
-            NRF_TRY(run_backprop_fast(c, g_alpha, m, alpha, G[3], W, st));
-            NRF_TRY(run_sum_cols(c, Wd, G[1], W, 0, G[3], W, 0, gh, W, st, H[D - 1], W));          // (+ h_{D-1}'s ReLU mask: the first pts_linears stage below finds it applied)
+            // d / d h through alpha_linear is the rank-1 product g_alpha (x) w_alpha: formed inside the sum (no [c, 256] array of its own), with h_{D-1}'s ReLU mask --
+            // the first pts_linears stage below finds it applied
+            hipLaunchKernelGGL(k_sum_rank1, dim3((unsigned)ceil_div(c * Wd, 256)), dim3(256), 0, st, c, Wd, (const float *)G[1], W, g_alpha.p + g_alpha.off, g_alpha.stride,
+                               (const float *)(m->d_params + alpha.w_off), gh, W, (const float *)H[D - 1], W);
+            NRF_LAUNCH_CHECK();
             gh_masked = true;
         } else {
             const LinearLayer &outl = m->layers[D];                                                                    // output_linear(cat[h, input_pts])  :121-124
