@@ -238,7 +238,8 @@ __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], u
         const int n = n0 + c4;
         if (m >= M || n >= N) continue;
         float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
-        if (F16) { const float rs = rinv[ml]; v.x = v.x * rs * binv; v.y = v.y * rs * binv; v.z = v.z * rs * binv; v.w = v.w * rs * binv; }          // (two steps: rs x binv alone may leave fp32's range)
+        // (rs x binv in one factor: the two inverse powers of two together leave fp32's normal range only where the product itself does)
+        if (F16) { const float rs = rinv[ml] * binv; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
         v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
         if (relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
         if (vec_ok && n + 4 <= N) {
@@ -423,101 +424,121 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nblocks_n = (g.N + Cfg::BN - 1) / Cfg::BN;
-    int64_t bid = blockIdx.x;
-    {
-        const int64_t nb_all = gridDim.x, per = nb_all / 8;
-        if (bid < per * 8) bid = (bid & 7) * per + (bid >> 3);
-    }
-    const int64_t mb = bid / nblocks_n;
-    const int nb = (int)(bid - mb * nblocks_n);
-    const int64_t m0 = mb * GB_BM;
-    const int n0 = nb * Cfg::BN;
+    const int64_t total = ((g.M + GB_BM - 1) / GB_BM) * nblocks_n;
     const int wm = wave / 4, wn = wave % 4;
     const int rq = t >> 3, kq = t & 7;
     float4 ra[TK][Cfg::QA];
     gb_u32x4 rb0[4], rb1[4];
-    // the burst: row by row, all of its K (segment 0's tiles, then segment 1's: both are whole multiples of 32 columns here)
     const int t0 = g.k0 / GB_BK;
-#pragma unroll
-    for (int i = 0; i < Cfg::QA; i++) {
-        const int64_t m = m0 + rq + Cfg::RSTEP * i;
-        const int64_t mc = m < g.M ? m : g.M - 1;
-        const float *rp0 = g.a0 + mc * g.lda0 + 4 * kq;
-        const float *rp1 = g.a1 ? g.a1 + mc * g.lda1 + 4 * kq : rp0;
-#pragma unroll
-        for (int tile = 0; tile < TK; tile++) ra[tile][i] = *reinterpret_cast<const float4 *>(tile < t0 ? rp0 + tile * GB_BK : rp1 + (tile - t0) * GB_BK);
-    }
-    // (B's columns run straight through both segments)
-    auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
-    // F16: the row's whole K sits in the eight threads (kq) of the row: its largest entry is 8 TK maxima and three lane exchanges away
-    float as[Cfg::QA], binv = 1.0f;
-    float *rinv = reinterpret_cast<float *>(gb_smem + GB_ROWS_LDS_BASE);
-#pragma unroll
-    for (int i = 0; i < Cfg::QA; i++) as[i] = 1.0f;
-    if (F16) {
-        { float bs; gb_pow2_scale(__uint_as_float(g.bmax[0]), bs, binv); }
+    // PERSISTENT: one workgroup per CU walks the output tiles bid, bid + gridDim.x, ...  With one tile per workgroup all 256 workgroups of a round read their A blocks,
+    // then all compute, then all write: 17 us of memory phases + 14 us of compute per round, one after the other (0.65 ms per 786 432 x 256 x 256).  Here the NEXT tile's
+    // A block is requested while the current one is multiplied -- into the very registers the current tile has just handed to LDS (tile k's four values per row are dead
+    // once store_tile(k) has split them), so the prefetch costs no register -- and the C block of the current tile leaves while the next one's loads are in flight.
+    // the A rows of an output tile as per-thread pointers (row rq + RSTEP i, columns 4 kq ..): computed once per output tile, the K tiles are immediate offsets
+    const float *ap0[Cfg::QA], *ap1[Cfg::QA];
+    auto point_a = [&](int64_t b) {
+        const int64_t m0b = (b / nblocks_n) * GB_BM;
 #pragma unroll
         for (int i = 0; i < Cfg::QA; i++) {
-            float m = 0.0f;
-#pragma unroll
-            for (int tile = 0; tile < TK; tile++) m = fmaxf(m, gb_absmax4(ra[tile][i]));
-            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
-            float inv;
-            gb_pow2_scale(m, as[i], inv);
-            if (kq == 0) rinv[rq + Cfg::RSTEP * i] = inv;
+            const int64_t m = m0b + rq + Cfg::RSTEP * i;
+            const int64_t mc = m < g.M ? m : g.M - 1;
+            ap0[i] = g.a0 + mc * g.lda0 + 4 * kq;
+            ap1[i] = g.a1 ? g.a1 + mc * g.lda1 + 4 * kq : ap0[i];
         }
-    }
-    auto store_tile = [&](int stage, const float4 (&a)[Cfg::QA], const gb_u32x4 (&rb)[4]) {
-        unsigned char *base = gb_smem + stage * Cfg::STAGE;
-        const int ks = kq >> 2;
-#pragma unroll
-        for (int i = 0; i < Cfg::QA; i++) gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
-        gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
     };
-    gb_f32x16 acc[2][2];
+    auto issue_a = [&](int tile) {          // K tile `tile` of the pointed-at rows -> ra[tile][*] (segment 0's K tiles, then segment 1's)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < Cfg::QA; i++) ra[tile][i] = *reinterpret_cast<const float4 *>(tile < t0 ? ap0[i] + tile * GB_BK : ap1[i] + (tile - t0) * GB_BK);
+    };
+    int64_t bid = blockIdx.x;
+    if (bid < total) {
+        point_a(bid);
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int tile = 0; tile < TK; tile++) issue_a(tile);
+    }
+    float *rinv = reinterpret_cast<float *>(gb_smem + GB_ROWS_LDS_BASE);
+    for (; bid < total; bid += gridDim.x) {
+        const int64_t mb = bid / nblocks_n;
+        const int nb = (int)(bid - mb * nblocks_n);
+        const int64_t m0 = mb * GB_BM;
+        const int n0 = nb * Cfg::BN;
+        const int64_t nbid = bid + gridDim.x;
+        const bool has_next = nbid < total;
+        if (has_next) point_a(nbid);
+        // (B's columns run straight through both segments)
+        auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
+        // F16: the row's whole K sits in the eight threads (kq) of the row: its largest entry is 8 TK maxima and three lane exchanges away
+        float as[Cfg::QA], binv = 1.0f;
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
-    auto multiply = [&](int stage) {
-        const unsigned char *base = gb_smem + stage * Cfg::STAGE;
+        for (int i = 0; i < Cfg::QA; i++) as[i] = 1.0f;
+        if (F16) {
+            { float bs; gb_pow2_scale(__uint_as_float(g.bmax[0]), bs, binv); }
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            T8 ah[2], al[2], bh[2], bl[2];
+            for (int i = 0; i < Cfg::QA; i++) {
+                float m = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int offa = (ks * GB_BM + wm * 64 + i * 32 + r) * 32 + h * 16;
-                ah[i] = *reinterpret_cast<const T8 *>(base + offa);
-                al[i] = *reinterpret_cast<const T8 *>(base + Cfg::A_HALF + offa);
-                const int offb = (ks * Cfg::BN + wn * 64 + i * 32 + r) * 32 + h * 16;
-                bh[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + offb);
-                bl[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
+                for (int tile = 0; tile < TK; tile++) m = fmaxf(m, gb_absmax4(ra[tile][i]));
+                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                float inv;
+                gb_pow2_scale(m, as[i], inv);
+                if (kq == 0) rinv[rq + Cfg::RSTEP * i] = inv;
             }
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    acc[i][j] = GbT<F16>::mfma(al[i], bh[j], acc[i][j]);
-                    acc[i][j] = GbT<F16>::mfma(ah[i], bl[j], acc[i][j]);
-                    acc[i][j] = GbT<F16>::mfma(ah[i], bh[j], acc[i][j]);
-                }
         }
-    };
-    load_b(0, rb0);
-    if (TK > 1) load_b(1, rb1);
-    store_tile(0, ra[0], rb0);
-    __syncthreads();
+        auto store_tile = [&](int stage, const float4 (&a)[Cfg::QA], const gb_u32x4 (&rb)[4]) {
+            unsigned char *base = gb_smem + stage * Cfg::STAGE;
+            const int ks = kq >> 2;
 #pragma unroll
-    for (int tile = 0; tile < TK; tile++) {
-        // B of tile + 2 into the set that tile's store has freed
-        if (tile + 2 < TK) { if (tile & 1) load_b(tile + 2, rb1); else load_b(tile + 2, rb0); }
-        multiply(tile & 1);
-        if (tile + 1 < TK) { if (tile & 1) store_tile(0, ra[tile + 1 < TK ? tile + 1 : 0], rb0); else store_tile(1, ra[tile + 1 < TK ? tile + 1 : 0], rb1); }
+            for (int i = 0; i < Cfg::QA; i++) gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+            gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
+        };
+        gb_f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+        auto multiply = [&](int stage) {
+            const unsigned char *base = gb_smem + stage * Cfg::STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                T8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int offa = (ks * GB_BM + wm * 64 + i * 32 + r) * 32 + h * 16;
+                    ah[i] = *reinterpret_cast<const T8 *>(base + offa);
+                    al[i] = *reinterpret_cast<const T8 *>(base + Cfg::A_HALF + offa);
+                    const int offb = (ks * Cfg::BN + wn * 64 + i * 32 + r) * 32 + h * 16;
+                    bh[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + offb);
+                    bl[i] = *reinterpret_cast<const T8 *>(base + 2 * Cfg::A_HALF + Cfg::B_HALF + offb);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        acc[i][j] = GbT<F16>::mfma(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = GbT<F16>::mfma(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = GbT<F16>::mfma(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+        };
+        load_b(0, rb0);
+        if (TK > 1) load_b(1, rb1);
+        store_tile(0, ra[0], rb0);
         __syncthreads();
+#pragma unroll
+        for (int tile = 0; tile < TK; tile++) {
+            // B of tile + 2 into the set that tile's store has freed
+            if (tile + 2 < TK) { if (tile & 1) load_b(tile + 2, rb1); else load_b(tile + 2, rb0); }
+            multiply(tile & 1);
+            if (tile + 1 < TK) { if (tile & 1) store_tile(0, ra[tile + 1 < TK ? tile + 1 : 0], rb0); else store_tile(1, ra[tile + 1 < TK ? tile + 1 : 0], rb1); }
+            // ra[tile] went to LDS one iteration ago (tile 0: before the loop): the next output tile's K tile `tile` into it
+            if (has_next) issue_a(tile);
+            __syncthreads();
+        }
+        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
+        __syncthreads();          // the C block staged in LDS is read out: the next tile's stages may overwrite it
     }
-    gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
 }
 
 
@@ -885,9 +906,12 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     const int ktot = g.k0 + g.k1;
     const bool rows_ok = wide && !no_rows && g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot == 128 || ktot == 160 || ktot == 256);
     if (rows_ok) {
-        if (ktot == 128) hipLaunchKernelGGL((k_gemm_nt_rows<4, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
-        else if (ktot == 160) hipLaunchKernelGGL((k_gemm_nt_rows<5, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
-        else hipLaunchKernelGGL((k_gemm_nt_rows<8, F16>), dim3((unsigned)blocks), dim3(512), GB_ROWS_LDS, st, g);
+        static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; return n; }();
+        static const int per_cu = [] { const char *e = getenv("NRF_GEMM_ROWS_PERSIST"); return e ? atoi(e) : 1; }();          // 0: one workgroup per output tile (A/B)
+        const unsigned pgrid = (unsigned)(per_cu > 0 && blocks > (int64_t)cus * per_cu ? (int64_t)cus * per_cu : blocks);          // persistent: one workgroup per CU (LDS: 133 KB)
+        if (ktot == 128) hipLaunchKernelGGL((k_gemm_nt_rows<4, F16>), dim3(pgrid), dim3(512), GB_ROWS_LDS, st, g);
+        else if (ktot == 160) hipLaunchKernelGGL((k_gemm_nt_rows<5, F16>), dim3(pgrid), dim3(512), GB_ROWS_LDS, st, g);
+        else hipLaunchKernelGGL((k_gemm_nt_rows<8, F16>), dim3(pgrid), dim3(512), GB_ROWS_LDS, st, g);
     } else if (wide) hipLaunchKernelGGL((k_gemm_nt<4, F16>), dim3((unsigned)blocks), dim3(512), LDS4, st, g);
     else hipLaunchKernelGGL((k_gemm_nt<2, F16>), dim3((unsigned)blocks), dim3(256), LDS2, st, g);
     const hipError_t le = hipGetLastError();
