@@ -874,7 +874,12 @@ template <bool F16>
 static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
 {
     static const int force_wide = [] { const char *e = getenv("NRF_GEMM_WNW"); return e ? atoi(e) : 0; }();          // tuning: 2 / 4 forces the tile width
-    const bool wide = force_wide == 4 || (force_wide != 2 && g.N > 128);
+    // a narrow product (N <= 128: the sigma head, the gradient w.r.t. a 128-wide input) whose A operand fits the whole-row kernel takes that kernel's 256-wide tile with
+    // the missing columns as zeros: its matrix work is wasted, its A stream is not (0.55 against 0.77 ms per 10^6 x 256 rows)
+    static const bool narrow_rows = [] { const char *e = getenv("NRF_GEMM_NARROW_ROWS"); return !e || atoi(e) != 0; }();
+    const int ktot0 = g.k0 + g.k1;
+    const bool rows_shape = g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot0 == 128 || ktot0 == 160 || ktot0 == 256);
+    const bool wide = force_wide == 4 || (force_wide != 2 && (g.N > 128 || (narrow_rows && rows_shape && g.M >= 65536)));
     const int bn = wide ? 256 : 128;
     const int64_t blocks = ceil_div(g.M, GB_BM) * ceil_div((int64_t)g.N, (int64_t)bn);
     if (blocks > 0x7fffffff) { set_error("gemm_nt_split: too many tiles"); return NRF_ERR_INVALID_ARG; }

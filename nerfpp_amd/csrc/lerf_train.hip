@@ -439,11 +439,14 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     // ---- forward, every layer output kept (post-ReLU for hidden layers)                            LeRF.cpp:86-102 ----
     const Seg xin{emb, in, 0, in};
     Seg cur = xin;
+    // the sigma net's output row [sigma | geo] is written 3 floats into its buffer row where that fits, so that the geo columns -- the LE net's first input segment --
+    // start on a 16-byte boundary: the LE net's first layer and its weight gradient then take the vector paths (whole-row kernel, K = geo + in = 160)
+    const int yo = (W >= 4 + geo && (W & 3) == 0) ? 3 : 0;
     for (int l = 0; l < nl; l++) {
-        NRF_TRY(run_linear_fast(c, cur, none, m, m->layers[l], l != nl - 1, H[l], W, 0, st));
+        NRF_TRY(run_linear_fast(c, cur, none, m, m->layers[l], l != nl - 1, H[l], W, l == nl - 1 ? yo : 0, st));
         cur = Seg{H[l], W, 0, m->layers[l].out};
     }
-    const float *h33 = H[nl - 1];                                         // column 0 = sigma_le, 1.. = geo_feat_le
+    const float *h33 = H[nl - 1] + yo;                                    // column 0 = sigma_le, 1.. = geo_feat_le
     const Seg sgeo{h33, W, 1, geo};
     for (int l = 0; l < nl - (gram ? 1 : 0); l++) {          // Gram form: the last layer is never applied per sample
         NRF_TRY(run_linear_fast(c, l == 0 ? sgeo : cur, l == 0 ? xin : none, m, m->layers[nl + l], l != nl - 1, H[nl + l], W, 0, st));
@@ -505,10 +508,12 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         const LinearLayer &L = m->layers[l];
         if (l != NL - 1 && !premasked) NRF_TRY(run_relu_mask(c, L.out, const_cast<float *>(g.p), g.stride, H[l], W, st));
         const bool first = (l == nl);
-        if (first && c >= 4096 && train_gemm_for(m) != 0 && L.out >= 32 && W >= ((1 + geo + 3) & ~3))
-            // cat[geo, in]: both column segments in ONE pass over g (bf16x3 TN product); the geo columns as the aligned read [sigma | geo | up to 3 more floats of the row]
-            // whose first column and padding are dropped (W >= 1 + geo + 3: the row holds them, whatever they contain stays in the dropped columns)
-            NRF_TRY(gemm_tn_bf16x3_2(c, g, xin, geo, Seg{h33, W, 0, (1 + geo + 3) & ~3}, 0, 1, geo, L.out, L.in, g_params + L.w_off, st));
+        if (first && c >= 4096 && train_gemm_for(m) != 0 && L.out >= 32 && W >= ((yo + 1 + geo + 3) & ~3)) {
+            // cat[geo, in]: both column segments in ONE pass over g (bf16x3 TN product).  The geo columns: as they are where they start on a 16-byte boundary (yo == 3);
+            // otherwise as the aligned read [sigma | geo | up to 3 more floats of the row] whose first column and padding are dropped in the slice sum
+            if (yo == 3 && (geo & 3) == 0) NRF_TRY(gemm_tn_bf16x3_2(c, g, xin, geo, sgeo, 0, 0, geo, L.out, L.in, g_params + L.w_off, st));
+            else NRF_TRY(gemm_tn_bf16x3_2(c, g, xin, geo, Seg{h33, W, 0, (1 + geo + 3) & ~3}, 0, 1, geo, L.out, L.in, g_params + L.w_off, st));
+        }
         else
         NRF_TRY(run_grad_w_fast(c, g, first ? sgeo : Seg{H[l - 1], W, 0, L.in}, first ? xin : none, L.out, L.in, g_params + L.w_off, st, train_gemm_for(m)));
         float *dst = G[gi]; gi = gi == 3 ? 1 : gi + 1;
