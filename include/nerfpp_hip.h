@@ -536,6 +536,11 @@ NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, co
  * flags_out[0] != 0: the incoming gradient held an inf / NaN; flags_out[1] != 0: an accumulated parameter gradient is not finite.  Host array of 2; synchronises
  * `stream`.  A caller skips (or rescales) the optimizer step when either is set. */
 NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream);
+/* The same two words without a host wait in the training step: _async copies them to h_flags2 (two uint32; pinned memory keeps the copy asynchronous) in `stream`'s order
+ * -- read them after the stream, or an event recorded behind the call, has passed; _device returns where they live on the device, for nrf_adam_step_guarded: the
+ * optimizer step is then skipped ON THE DEVICE when the chain overflowed, and the host learns of it one step later (nerfpp_amd/train.py). */
+NRF_API int nrf_mlp_backward_f16_flags_async(const void *d_workspace, uint32_t *h_flags2, void *stream);
+NRF_API const uint32_t *nrf_mlp_backward_f16_flags_device(const void *d_workspace);
 /* Replace the parameter blob (same layout) and refresh the derived operands (transposed layers, matrix-core images).
  * NeRFSmall handles do it ON THE DEVICE in stream order (a gather + hi / lo split per image, no host round trip, nothing waits): work already issued on `stream`
  * reads the old images, work issued after reads the new ones; other streams of the caller's are the caller's to order.  The LeRF head of the built dimensions does it
@@ -597,6 +602,9 @@ NRF_API int nrf_hash_tv_loss(const nrf_hash *h, const float *d_table, int level,
 /* torch::optim::Adam::step without weight decay / amsgrad; t = 1, 2, ... */
 NRF_API int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
                           void *stream);
+/* nrf_adam_step that updates NOTHING (parameters and moments alike) when any of the n_flags (<= 16) words at d_flags is non-zero at the time the kernel runs */
+NRF_API int nrf_adam_step_guarded(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t,
+                                  const uint32_t *d_flags, int n_flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image-space tail of NeRFExecutor::RenderPath (NeRFExecutor.h:690, :698-700; TorchTensorToCVMat, NeRFRenderer.h:58-68)

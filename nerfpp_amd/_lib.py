@@ -113,6 +113,7 @@ def lib():
         L.nrf_last_error.restype = C.c_char_p
         L.nrf_status_string.restype = C.c_char_p
         L.nrf_hash_table_elems.restype = C.c_int64
+        L.nrf_mlp_backward_f16_flags_device.restype = C.c_void_p
         L.nrf_hash_get_dense_budget.restype = C.c_int64
         L.nrf_mlp_small_param_count.restype = C.c_int64
         L.nrf_mlp_nerf_param_count.restype = C.c_int64

@@ -925,13 +925,18 @@ __global__ void __launch_bounds__(256) k_small_scales(nrf_mlp_small_desc d, cons
     __shared__ float g_sq[SMALL_MAX_GROUPS], g_mx[SMALL_MAX_GROUPS];
     const int t = threadIdx.x;
     const int NL = d.num_layers, NLC = d.num_layers_color, V = d.input_ch_views;
-    auto combine = [&](float v, bool is_max) -> float {          // every thread's v -> thread 0's result, in thread order
-        s_a[t] = v;
+    // every thread's v -> thread 0's result, in a FIXED order (a butterfly inside each wave, then the four waves' results in wave order): the same blob always gives
+    // the same scales.  (Thread 0 adding the 256 partials one by one -- sixteen times -- was 130 us of a 6 ms training step.)
+    auto combine = [&](float v, bool is_max) -> float {
+        float r = v;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const float x = __shfl_xor(r, o); r = is_max ? fmaxf(r, x) : r + x; }
+        if ((t & 63) == 0) s_a[t >> 6] = r;
         __syncthreads();
-        float r = 0.0f;
-        if (t == 0) for (int i = 0; i < 256; i++) r = is_max ? fmaxf(r, s_a[i]) : r + s_a[i];
+        float res = 0.0f;
+        if (t == 0) res = is_max ? fmaxf(fmaxf(s_a[0], s_a[1]), fmaxf(s_a[2], s_a[3])) : (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
         __syncthreads();
-        return r;
+        return res;
     };
     (void)s_b;
     size_t off = 0;
@@ -1407,6 +1412,16 @@ int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int precision
     NRF_HIP(hipFreeAsync(ws, st));
     return s;
 }
+
+// ... without waiting: the two words are copied into h_flags2 (two uint32, best pinned) in `stream`'s order; the caller reads them once the stream (or an event recorded
+// behind this call) has passed.  nrf_mlp_backward_f16_flags_device: where they live on the device (what nrf_adam_step_guarded takes).
+int nrf_mlp_backward_f16_flags_async(const void *d_workspace, uint32_t *h_flags2, void *stream)
+{
+    NRF_CHECK_ARG(d_workspace && h_flags2, "nrf_mlp_backward_f16_flags_async: null pointer");
+    NRF_HIP(hipMemcpyAsync(h_flags2, static_cast<const uint32_t *>(d_workspace) + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, as_stream(stream)));
+    return NRF_OK;
+}
+const uint32_t *nrf_mlp_backward_f16_flags_device(const void *d_workspace) { return d_workspace ? static_cast<const uint32_t *>(d_workspace) + 1 : nullptr; }
 
 int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream)
 {

@@ -688,10 +688,12 @@ __global__ void k_tv_loss(int n, int cube, int log2_t, int vx, int vy, int vz, f
 }
 
 __global__ void k_adam(int64_t n, float lr_over_bc1, float bc2_sqrt, float b1, float b2, float eps, float *__restrict__ p, const float *__restrict__ g,
-                       float *__restrict__ m, float *__restrict__ v)
+                       float *__restrict__ m, float *__restrict__ v, const uint32_t *__restrict__ flags, int n_flags)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // guarded step (nrf_adam_step_guarded): any non-zero word -- the fp16 backward's overflow report -- and nothing is updated, moments included
+    for (int f = 0; f < n_flags; f++) if (flags[f] != 0u) return;
     const float gi = g[i];
     const float mi = m[i] * b1 + gi * (1.0f - b1);
     const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
@@ -987,15 +989,21 @@ int nrf_hash_tv_loss(const nrf_hash *h, const float *d_table, int level, const i
     return NRF_OK;
 }
 
-int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t, void *stream)
+int nrf_adam_step_guarded(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t, const uint32_t *d_flags,
+                          int n_flags, void *stream)
 {
-    NRF_CHECK_ARG(d_p && d_g && d_m && d_v && n >= 0 && t >= 1, "nrf_adam_step: bad argument");
+    NRF_CHECK_ARG(d_p && d_g && d_m && d_v && n >= 0 && t >= 1 && n_flags >= 0 && n_flags <= 16 && (n_flags == 0 || d_flags), "nrf_adam_step: bad argument");
     if (n == 0) return NRF_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), n, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps,
-                       d_p, d_g, d_m, d_v);
+                       d_p, d_g, d_m, d_v, d_flags, n_flags);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
+}
+
+int nrf_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n, float lr, float beta1, float beta2, float eps, int t, void *stream)
+{
+    return nrf_adam_step_guarded(d_p, d_g, d_m, d_v, n, lr, beta1, beta2, eps, t, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -41,6 +41,7 @@ class Trainer:
         self.m_blob, self.v_blob = torch.zeros_like(self.blob), torch.zeros_like(self.blob)
         self.g_table, self.g_blob = torch.zeros_like(self.table), torch.zeros_like(self.blob)
         self.lr, self.betas, self.eps, self.t = float(learning_rate), betas, float(eps), 0
+        self._skipped, self._h_flags, self._flags_event, self._d_flags = 0, None, None, None          # deferred overflow words of a guarded step (_settle_flags)
         self.learning_rate0 = float(learning_rate)          # Params.LearningRate: the base of the exponential decay (NeRFExecutor.h:992-996)
         # TotalVariationLoss of the LibTorch HashEmbedder, weight 1e-6 in the reference for the first half of training (NeRFExecutor.h:896-913)
         self.tv_loss_weight, self.seed = float(tv_loss_weight), int(seed)
@@ -97,7 +98,7 @@ class Trainer:
             self._ws = torch.empty((int(nbytes),), device="cuda", dtype=torch.uint8)
         return self._ws
 
-    def backward(self, res, target, n_samples_out, white_bkgr, params=None, cone_angle=None):
+    def backward(self, res, target, n_samples_out, white_bkgr, params=None, cone_angle=None, defer_flags=False):
         """loss + gradients of one rendered batch (fills self.g_table / self.g_blob); returns device tensor [huber, mse].
         `params` (the NeRFRenderParams of the forward) tells which stochastic branches ran: their counter-based draws are regenerated here
         (same seed, stream and element index, include/nrf_rng.h), so the backward sees exactly the forward's sample points and densities."""
@@ -140,6 +141,7 @@ class Trainer:
             L.check(lib.nrf_mlp_backward(self.mlp._m, _ptr(x), _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), None, _ptr(ws), C.c_size_t(ws.numel()), _stream()))
             self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=None, x=x, pts=pts)
             self.overflow = False
+            self._d_flags = None
             return loss_mse
         g_x = torch.empty((n * s, in_ch), device=rays.device)
         lm = (self.mlp_backward == "f16" and isinstance(self.embedder, CuHashEmbedder) and self.embedder.NLevels == 16 and self.embedder.NFeaturesPerLevel == 2
@@ -179,13 +181,45 @@ class Trainer:
         else:
             L.check(lib.nrf_hash_backward_rays(self.embedder._h, _ptr(pts), C.c_int64(n), s, _ptr(g_x), _ptr(self.g_table), _stream()))
         self.last = dict(g_rgb=g_rgb, g_raw=g_raw, g_x=g_x, x=x, pts=pts)
-        # fp16 gradient chain: was anything in it, or anything it produced, not finite?  (nrf_mlp_backward_f16_flags; the caller skips the step then)
+        # fp16 gradient chain: was anything in it, or anything it produced, not finite?  (nrf_mlp_backward_f16_flags; the caller skips the step then.)  Without gradient
+        # exchange the host does not wait for the answer: the optimizer step is guarded ON THE DEVICE by the two words (nrf_adam_step_guarded) and the host reads them
+        # from pinned memory before the next step begins (_settle_flags) -- a wait in the middle of every step was 0.3 ms of GPU idle time in a 6 ms step.
         self.overflow = False
+        self._d_flags = None
         if self.mlp_backward == "f16":
-            fl = (C.c_uint32 * 2)()
-            L.check(lib.nrf_mlp_backward_f16_flags(_ptr(self._ws), fl, _stream()))
-            self.overflow = bool(fl[0] or fl[1])
+            if self.grad_sync is None and defer_flags:
+                if self._h_flags is None:
+                    self._h_flags = torch.zeros((2,), dtype=torch.int32).pin_memory()
+                L.check(lib.nrf_mlp_backward_f16_flags_async(_ptr(self._ws), C.c_void_p(self._h_flags.data_ptr()), _stream()))
+                self._flags_event = torch.cuda.Event(); self._flags_event.record(torch.cuda.current_stream())
+                self._d_flags = lib.nrf_mlp_backward_f16_flags_device(_ptr(self._ws))
+            else:
+                fl = (C.c_uint32 * 2)()
+                L.check(lib.nrf_mlp_backward_f16_flags(_ptr(self._ws), fl, _stream()))
+                self.overflow = bool(fl[0] or fl[1])
         return loss_mse
+
+    def _settle_flags(self):
+        """A guarded step whose overflow words have not been looked at yet: wait for their copy (issued behind that step's backward: long done when the next step
+        begins), and if the chain had overflowed -- the device skipped the update -- take the step count back."""
+        ev = getattr(self, "_flags_event", None)
+        if ev is None:
+            return
+        ev.synchronize()
+        self._flags_event = None
+        self.overflow = bool(int(self._h_flags[0]) or int(self._h_flags[1]))
+        if self.overflow:
+            self.t -= 1
+            self._skipped += 1
+
+    @property
+    def skipped_steps(self):
+        self._settle_flags()
+        return self._skipped
+
+    @skipped_steps.setter
+    def skipped_steps(self, v):
+        self._skipped = int(v)
 
     @staticmethod
     def _rng_u32(seed, stream, idx):
@@ -221,13 +255,14 @@ class Trainer:
         generator.  The caller's render_params object is not modified."""
         if not render_params.ThinRay and cone_angle is None:
             raise L.NrfError("Trainer.step: ThinRay = False needs the batch's cone_angle (GetRayBatch / GetRays)")
+        self._settle_flags()                               # (the previous step's overflow words: the step count below must be final)
         p = copy.copy(render_params)
         p.ReturnRaw, p.KeepIntermediates = True, True
         p.Seed = (int(render_params.Seed) + 0x9E3779B97F4A7C15 * self.t) & ((1 << 64) - 1)
         cone = None if p.ThinRay else cone_angle
         res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))
         s_out = p.NSamples + p.NImportance
-        loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone)
+        loss_mse = self.backward(res, target, s_out, p.WhiteBkgr, params=p, cone_angle=cone, defer_flags=True)
         if global_step is None or n_iters is None or global_step < n_iters / 2:
             self.add_tv_loss()
         # A non-finite gradient in the fp16 chain: no optimizer step (the moments would be poisoned for good).  With data-parallel replicas the flag is made
@@ -239,14 +274,15 @@ class Trainer:
             elif not skip:
                 self.grad_sync(self.g_table, self.g_blob)   # a plain callable: single-process hooks
         if skip:
-            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+            self._skipped += 1
             return loss_mse, res
-        self.t += 1
+        self.t += 1                                        # (a guarded step: taken back by _settle_flags if the device skipped the update)
         b1, b2 = self.betas
+        dfl, nfl = (C.c_void_p(self._d_flags), 2) if self._d_flags else (None, 0)
         for prm, g, m, v in ((self.table, self.g_table, self.m_table, self.v_table), (self.blob, self.g_blob, self.m_blob, self.v_blob)):
             if prm.numel():
-                L.check(L.lib().nrf_adam_step(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
-                                              C.c_float(self.eps), self.t, _stream()))
+                L.check(L.lib().nrf_adam_step_guarded(_ptr(prm), _ptr(g), _ptr(m), _ptr(v), C.c_int64(prm.numel()), C.c_float(self.lr), C.c_float(b1), C.c_float(b2),
+                                                      C.c_float(self.eps), self.t, dfl, nfl, _stream()))
         self._push_params()
         if global_step is not None and lrate_decay:
             self.lr = self.learning_rate0 * math.pow(0.1, float(global_step) / (float(lrate_decay) * 1000.0))      # :992-996
@@ -289,6 +325,7 @@ class Trainer:
     def SaveCheckpoint(self, path, global_step=0):
         """embedder_checkpoint.pt, model_checkpoint.pt, start_checkpoint.pt and optimizer_checkpoint.pt as the reference writes them: its executor restores
         from such a directory (all four must exist, :541-546), Adam moments and step included."""
+        self._settle_flags()
         from . import checkpoint as CK
         from collections import OrderedDict
         emb, mlp = self._param_layout()

@@ -3602,6 +3602,45 @@ def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
 
 
 @pytest.mark.gpu
+def test_training_step_with_an_overflowed_fp16_backward_is_skipped_on_the_device(api):
+    """Trainer.step with the fused fp16 backward no longer waits for the chain's overflow words in the middle of the step: the optimizer step is nrf_adam_step_guarded --
+    the kernel itself returns when either word is set -- and the host reads the words (copied to pinned memory behind the backward) before the NEXT step begins.  A batch
+    whose target holds a NaN (the incoming gradient is flagged): parameters and Adam moments keep their bits, the step count is taken back, skipped_steps counts it, and
+    the step after it is an ordinary one with the bias correction of step 2."""
+    L, S, R = api.L, api.S, api.R
+    from nerfpp_amd.train import Trainer
+    sc = S.make_hash_scene(mode="cu", log2_t=14, table_amp=1e-2, sigma_scale=4.0)
+    K = S.lego_K(100, 100); c2w = S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(100, 100, K, c2w)
+    o = o.reshape(-1, 3)[::5][:1024].contiguous(); d = d.reshape(-1, 3)[::5][:1024].contiguous()
+    tgt = torch.rand((o.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward="f16", hash_backward="binned")
+    rp = R.NeRFRenderParams(NSamples=32, NImportance=32, Chunk=1024, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX,
+                            Precision=L.NRF_PREC_F16_SPLIT)
+    tr.step(o, d, tgt, rp)
+    assert tr.skipped_steps == 0 and tr.t == 1
+    snap = [x.clone() for x in (tr.table, tr.blob, tr.m_table, tr.v_table, tr.m_blob, tr.v_blob)]
+    bad = tgt.clone(); bad[0, 0] = float("nan")          # (an inf would be clamped by the huber gradient: a NaN passes through)
+    tr.step(o, d, bad, rp)
+    assert tr.skipped_steps == 1 and tr.t == 1 and tr.overflow
+    for a, b in zip(snap, (tr.table, tr.blob, tr.m_table, tr.v_table, tr.m_blob, tr.v_blob)):
+        assert torch.equal(a, b), "a skipped step leaves parameters and moments untouched"
+    tr.step(o, d, tgt, rp)
+    assert tr.skipped_steps == 1 and tr.t == 2 and not torch.equal(snap[1], tr.blob) and bool(torch.isfinite(tr.blob).all()) and bool(torch.isfinite(tr.table).all())
+    # the same three batches with the host waiting for the words inside each step (a gradient hook switches the deferral off): the same bookkeeping, and parameters that
+    # moved by the same two Adam steps (|update| <= lr per step whatever the gradient's size -- eps is 1e-15 -- and the fp32 atomics of the backward make two runs differ
+    # in the last bits of the smallest gradients: no bit equality between ANY two runs)
+    sc2 = S.make_hash_scene(mode="cu", log2_t=14, table_amp=1e-2, sigma_scale=4.0)
+    tr2 = Trainer(sc2["embedder"], sc2["embeddirs"], sc2["mlp"], sc2["table"], sc2["mlp_blob"], learning_rate=5e-4, mlp_backward="f16", hash_backward="binned",
+                  grad_sync=lambda g_table, g_blob: None)
+    for t_ in (tgt, bad, tgt):
+        tr2.step(o, d, t_, rp)
+    assert tr2.skipped_steps == 1 and tr2.t == 2
+    assert float((tr2.blob - tr.blob).abs().max()) <= 2.2 * 5e-4 and float((tr2.table - tr.table).abs().max()) <= 2.2 * 5e-4
+    assert float((tr2.blob - tr.blob).abs().median()) < 1e-6
+
+
+@pytest.mark.gpu
 def test_classic_network_parameter_upload_stays_on_the_device_and_equals_the_host_pack(api):
     """nrf_mlp_set_params on the classic 8 x 256 network: its three matrix-core images (fp16, split, exact-fp32 density: seven regions of two element sizes) are gathers of
     [blob | merged views layer]; the gather maps are DECODED from the host packers run on probe blobs and checked against the host-packed images byte for byte when the
