@@ -302,6 +302,17 @@ def _with_train_gemm(L, fn):
     return rec
 
 
+def _layer_products_text(L):
+    """what the training paths' layer products run as under the library's current nrf_get_train_gemm() setting"""
+    mode = int(L.lib().nrf_get_train_gemm())
+    if mode in (-1, 2):
+        return ("f16x3 split-precision matrix-core products (hi + lo fp16 of power-of-two scaled rows; forward and back-propagation), bf16x3 weight gradients "
+                "(gemm_bf16x3.hip)" + (": the library's default for this family" if mode == -1 else ""))
+    if mode == 1:
+        return "bf16x3 split-precision matrix-core products (gemm_bf16x3.hip)"
+    return "rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels"
+
+
 def lerf_train_step_measurement(scene, L, n_rand=16384, steps=2):
     """SURVEY section 8f row N1, LeRF branch (NeRFExecutor.h:955-985): LeRFRenderer->Render on the ray batch (the fused pass) -> lang_loss -> backward into the LeRF head and
     the F = 8 language grid (ONE library call, fp32 layer kernels on the recomputed forward) -> Adam, at main.cpp:203-213 sizes and N_rand = 32*32*16 rays (main.cpp:232)."""
@@ -329,11 +340,11 @@ def lerf_train_step_measurement(scene, L, n_rand=16384, steps=2):
     finally:
         tr.close()
     return dict(workload="lerf_train_step", baseline_config=5, rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt, value=n_rand * UNITS_PER_RAY / dt,
-                unit="ray-samples/s", steps=steps, loss_first_last=losses,
-                fp32_layer_products="rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels",
-                arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated in fp32 (layer products as library GEMMs on the fp32 matrix "
-                           "cores, weight gradients split over 32 point slices; the 256 -> 768 layer, normalize and RenderCLIPEmbedding in their Gram form: nothing 768-wide per sample), "
-                           "language-grid gradient by float atomics after the ray-coherent pre-sum; Adam fp32")
+                unit="ray-samples/s", steps=steps, loss_first_last=losses, layer_products=_layer_products_text(L),
+                backward_workspace_bytes=int(tr._ws.numel()) if getattr(tr, "_ws", None) is not None else None,
+                arithmetic="render: split-f16 MFMA fused pass; backward: the head's forward recomputed and differentiated with fp32-grade layer products (see layer_products; "
+                           "the 256 -> 768 layer, normalize and RenderCLIPEmbedding in their Gram form: nothing 768-wide per sample), language-grid gradient by float atomics "
+                           "after the ray-coherent pre-sum; Adam fp32; the head's weight images rebuilt on the device at the parameter upload")
 
 
 def classic_train_step_measurement(scene, L, n_rand=4096, steps=3):
@@ -359,7 +370,8 @@ def classic_train_step_measurement(scene, L, n_rand=4096, steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return dict(workload="classic_train_step", baseline_config=2, rays_per_step=n_rand, samples="64+128", ms_per_step=dt * 1e3, rays_per_s=n_rand / dt, value=n_rand * UNITS_PER_RAY / dt,
-                unit="ray-samples/s", steps=steps, loss_first_last=[float(l0[0]), float(l[0])], fp32_layer_products="rocBLAS sgemm (fp32 matrix cores)" if L.lib().nrf_fp32_gemm_available() else "hand-written FMA kernels")
+                unit="ray-samples/s", steps=steps, loss_first_last=[float(l0[0]), float(l[0])], layer_products=_layer_products_text(L),
+                backward_workspace_bytes=int(tr._ws.numel()) if getattr(tr, "_ws", None) is not None else None)
 
 
 def train_step_measurement(args, scene, L, n_rand=16384, steps=5, mlp_backward="f16"):
