@@ -829,6 +829,57 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     return NRF_OK;
 }
 
+// The weight gradient of a THIN layer (out <= 4 rows per pass: the alpha and rgb heads): dW[o][i] += sum_p g[p][o] x[p][i] is a pass over X with a handful of
+// multipliers per row -- no matrix shape to speak of.  One thread per column of X, a slice of the points per workgroup (fp32 FMAs in point order), the slices' partial
+// rows summed by k_tn_sum in slice order: deterministic.  part: [slices][OUT][n].
+template <int OUT>
+__global__ void __launch_bounds__(256) k_dw_thin(int64_t P, int64_t slice_pts, int n, const float *__restrict__ g, int ldg, const float *__restrict__ x, int ldx, float *__restrict__ part)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int64_t slice = blockIdx.y;
+    const int64_t p0 = slice * slice_pts;
+    int64_t p1 = p0 + slice_pts; if (p1 > P) p1 = P;
+    float acc[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; o++) acc[o] = 0.0f;
+    if (i < n) {
+#pragma unroll 4
+        for (int64_t p = p0; p < p1; p++) {
+            const float xv = x[p * ldx + i];
+#pragma unroll
+            for (int o = 0; o < OUT; o++) acc[o] = fmaf(g[p * ldg + o], xv, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < OUT; o++) part[((size_t)slice * OUT + o) * n + i] = acc[o];
+    }
+}
+
+// dw [out][in] (columns col0 .. col0 + x.n) += g^T x for a layer of fewer than 32 rows, four rows per pass over X
+int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
+{
+    if (P <= 0 || x.n <= 0 || out <= 0) return NRF_OK;
+    int64_t slices = P / 1024; if (slices > 512) slices = 512; if (slices < 1) slices = 1;
+    const int64_t slice_pts = (P + slices - 1) / slices;
+    slices = (P + slice_pts - 1) / slice_pts;
+    float *part = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * 4 * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_thin: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    const dim3 grid((unsigned)ceil_div((int64_t)x.n, (int64_t)256), (unsigned)slices);
+    for (int o0 = 0; o0 < out; o0 += 4) {
+        const int oc = out - o0 < 4 ? out - o0 : 4;
+        const float *gp = g.p + g.off + o0, *xp = x.p + x.off;
+        if (oc == 1) hipLaunchKernelGGL(k_dw_thin<1>, grid, dim3(256), 0, st, P, slice_pts, x.n, gp, g.stride, xp, x.stride, part);
+        else if (oc == 2) hipLaunchKernelGGL(k_dw_thin<2>, grid, dim3(256), 0, st, P, slice_pts, x.n, gp, g.stride, xp, x.stride, part);
+        else if (oc == 3) hipLaunchKernelGGL(k_dw_thin<3>, grid, dim3(256), 0, st, P, slice_pts, x.n, gp, g.stride, xp, x.stride, part);
+        else hipLaunchKernelGGL(k_dw_thin<4>, grid, dim3(256), 0, st, P, slice_pts, x.n, gp, g.stride, xp, x.stride, part);
+        hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)oc * x.n, (int64_t)256)), dim3(256), 0, st, (int)slices, oc, x.n, 0, in, col0, 0, 0, 0, (const float *)part,
+                           dw + (size_t)o0 * in);
+    }
+    const hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(part, st);
+    if (le != hipSuccess) { set_error("gemm_tn_thin: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+
 // dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
 int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
 {

@@ -129,6 +129,11 @@ __global__ void k_sum_partials(int batches, int out, int n, int in, int col0, co
 // computed as one strided-batched GEMM into partial matrices, which one small kernel then adds to dw.
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith)
 {
+    if (arith != 0 && npts >= 4096 && out < 32) {           // a head of a few rows: a pass over x per four rows (gemm_tn_thin)
+        if (a.n > 0) NRF_TRY(gemm_tn_thin(npts, g, a, out, in, 0, dw, st));
+        if (b.n > 0) NRF_TRY(gemm_tn_thin(npts, g, b, out, in, a.n, dw, st));
+        return NRF_OK;
+    }
     if (arith != 0 && npts >= 4096 && out >= 32) {          // the split-precision modes: the hand-written bf16x3 TN product (gemm_bf16x3.hip), one call per column segment
         if (a.n > 0) NRF_TRY(gemm_tn_bf16x3(npts, g, a, out, in, 0, dw, st));
         if (b.n > 0) NRF_TRY(gemm_tn_bf16x3(npts, g, b, out, in, a.n, dw, st));

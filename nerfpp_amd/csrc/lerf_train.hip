@@ -43,6 +43,15 @@ static int lt_width(const nrf_mlp *m, int s)
     return w;
 }
 static int64_t lt_chunk_pts(const nrf_mlp *m, int s) { return lerf_train_gram(m, s) ? ((int64_t)1 << NRF_LT_GRAM_CHUNK_LOG2) : LT_CHUNK_PTS; }
+// rays per backward pass: n rays in passes of at most cpts / s rays, cut EVENLY (16 384 rays at 5 461 per pass are four passes of 4 096, not three full ones and a
+// one-ray tail whose products fall back to the small-shape paths)
+static int64_t lt_rays_per_pass(int64_t n, int64_t cpts, int s)
+{
+    const int64_t cap = cpts / s > 0 ? cpts / s : 1;
+    if (n <= cap) return n < 1 ? 1 : n;
+    const int64_t passes = (n + cap - 1) / cap;
+    return (n + passes - 1) / passes;
+}
 
 __device__ __forceinline__ double lt_wave_sum(double v)
 {
@@ -402,6 +411,17 @@ static bool lerf_train_gram(const nrf_mlp *m, int s)
     return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(9 * s + hd + 2) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
 }
 
+// dw [E][hd] -= W [E][hd] . M [hd][hd]   (the Gram form's last term: a product of two small matrices, one thread per entry, k ascending)
+__global__ void k_lt_sub_wm(int E, int hd, const float *__restrict__ w, const float *__restrict__ mm, float *__restrict__ dw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E * hd) return;
+    const int o = e / hd, j = e - o * hd;
+    float acc = 0.0f;
+    for (int k = 0; k < hd; k++) acc = fmaf(w[(size_t)o * hd + k], mm[(size_t)k * hd + j], acc);
+    dw[e] -= acc;
+}
+
 // dst[pt][d_col + k] = src[pt][s_col + k] (+ add[pt][a_col + k]), k < ncols
 __global__ void k_lt_copy_cols(int64_t p, int ncols, const float *__restrict__ src, int s_stride, int s_col, const float *__restrict__ add, int a_stride, int a_col,
                                float *__restrict__ dst, int d_stride, int d_col)
@@ -473,20 +493,27 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)(7 * s + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
                            (const float *)sga, W, pp, u, weights);
         NRF_LAUNCH_CHECK();
-        NRF_TRY(gemm_rm(st, false, true, rays, E, hd, 1.0f, u, hd, wle, hd, 0.0f, v, E));                                  // V = U W^T
+        const int arith_r = rays >= 256 ? arith : 0;                      // (the per-ray products: a few thousand rows)
+        if (arith_r) NRF_TRY(gemm_nt_split(arith_r, rays, E, Seg{u, hd, 0, hd}, none, wle, hd, v, E, nullptr, 0, nullptr, 0, st));          // V = U W^T
+        else NRF_TRY(gemm_rm(st, false, true, rays, E, hd, 1.0f, u, hd, wle, hd, 0.0f, v, E));                             // V = U W^T
         hipLaunchKernelGGL(k_ltg_ray_v, dim3((unsigned)rays), dim3(256), 0, st, E, (const float *)v, g_rendered, gv, rendered);
         NRF_LAUNCH_CHECK();
-        NRF_TRY(gemm_rm(st, false, false, rays, hd, E, 1.0f, gv, E, wle, hd, 0.0f, q, hd));                                // Q = G_V W
+        if (arith_r) NRF_TRY(gemm_nt_split(arith_r, rays, hd, Seg{gv, E, 0, E}, none, L1.d_wt, E, q, hd, nullptr, 0, nullptr, 0, st));     // Q = G_V W = G_V (W^T)^T: W^T [hd][E] is the layer's d_wt
+        else NRF_TRY(gemm_rm(st, false, false, rays, hd, E, 1.0f, gv, E, wle, hd, 0.0f, q, hd));                           // Q = G_V W
         hipLaunchKernelGGL(k_ltg_ray_g, dim3((unsigned)rays), dim3(256), (size_t)(s + hd + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, (const float *)q, a, W, sga, W, ba, W, (const float *)pp, keep, z,
                            dirs, d_stride, g33, W);
         NRF_LAUNCH_CHECK();
         float *dw = g_params + L1.w_off;                                   // [E][hd]
-        NRF_TRY(gemm_rm(st, true, false, E, hd, rays, 1.0f, gv, E, u, hd, 1.0f, dw, hd));                                  // dW += G_V^T U
+        if (arith_r) NRF_TRY(gemm_tn_bf16x3(rays, Seg{gv, E, 0, E}, Seg{u, hd, 0, hd}, E, hd, 0, dw, st));                  // dW += G_V^T U
+        else NRF_TRY(gemm_rm(st, true, false, E, hd, rays, 1.0f, gv, E, u, hd, 1.0f, dw, hd));                             // dW += G_V^T U
         if (arith) {                                                                                                       // M = A^T diag(beta) A: the weight-gradient product's shape
             NRF_HIP(hipMemsetAsync(mm, 0, (size_t)hd * hd * sizeof(float), st));
             NRF_TRY(gemm_tn_bf16x3(c, Seg{a, W, 0, hd}, Seg{ba, W, 0, hd}, hd, hd, 0, mm, st));
         } else NRF_TRY(gemm_rm(st, true, false, hd, hd, c, 1.0f, a, W, ba, W, 0.0f, mm, hd));
-        NRF_TRY(gemm_rm(st, false, false, E, hd, hd, -1.0f, wle, hd, mm, hd, 1.0f, dw, hd));                               // dW -= W M
+        if (arith) {                                                                                                       // dW -= W M: 768 x 256 x 256, fp32 FMAs
+            hipLaunchKernelGGL(k_lt_sub_wm, dim3((unsigned)ceil_div((int64_t)E * hd, (int64_t)256)), dim3(256), 0, st, E, hd, wle, (const float *)mm, dw);
+            NRF_LAUNCH_CHECK();
+        } else NRF_TRY(gemm_rm(st, false, false, E, hd, hd, -1.0f, wle, hd, mm, hd, 1.0f, dw, hd));                        // dW -= W M
         g = Seg{sga, W, 0, hd};
         gram_masked = true;                                                // k_ltg_ray_g has applied H[NL - 2]'s ReLU mask to g_a
         l_top = NL - 2;
@@ -586,7 +613,7 @@ int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_
     if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
     const int64_t cpts = lt_chunk_pts(lerf, s);
-    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
+    const int64_t rays_per = lt_rays_per_pass(n, cpts, s);
     const int64_t cmax = (n < rays_per ? n : rays_per) * s;
     const size_t buf = align_up((size_t)cmax * lt_width(lerf, s) * sizeof(float), 256) / sizeof(float);
     float *base = reinterpret_cast<float *>(d_workspace);
@@ -599,7 +626,11 @@ int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_
         const int64_t rmax = n < rays_per ? n : rays_per;          // G, M, then the per-ray rows u, v, g_v, q of one chunk
         NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&gram), ((size_t)2 * L1.in * L1.in + (size_t)rmax * (2 * L1.in + 2 * L1.out)) * sizeof(float), st));
         const float *wle = lerf->d_params + L1.w_off;
-        const int rcg = gemm_rm(st, true, false, L1.in, L1.in, L1.out, 1.0f, wle, L1.in, wle, L1.in, 0.0f, gram, L1.in);
+        int rcg;
+        if (lerf->lerf_gram_current && lerf->d_lerf_gram && L1.in == 256)
+            // the Gram matrix the device packer formed at the last parameter upload (double accumulation, unscaled copy behind the packed one): nothing to compute
+            rcg = hipMemcpyAsync(gram, lerf->d_lerf_gram + (size_t)L1.in * L1.in, (size_t)L1.in * L1.in * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
+        else rcg = gemm_rm(st, true, false, L1.in, L1.in, L1.out, 1.0f, wle, L1.in, wle, L1.in, 0.0f, gram, L1.in);
         if (rcg != NRF_OK) { (void)hipFreeAsync(gram, st); return rcg; }
     }
     int rc = NRF_OK;
@@ -621,7 +652,7 @@ size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int6
     const nrf_mlp *m = nrf_lerf_renderer_head(r);
     const nrf_hash *h = nrf_lerf_renderer_lang_embed(r);
     const int64_t cpts = lt_chunk_pts(m, s);
-    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
+    const int64_t rays_per = lt_rays_per_pass(n, cpts, s);
     const int64_t c = (n < rays_per ? (n < 1 ? 1 : n) : rays_per) * s;
     const int in = nrf_hash_output_dims(h);
     return head_ws_bytes(m, n, s) + 2 * align_up((size_t)c * in * sizeof(float), 256) + align_up((size_t)c, 256) + 1024;
@@ -638,7 +669,7 @@ int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, con
     if (workspace_bytes < nrf_lerf_backward_points_workspace_bytes(r, n, s)) { set_error("nrf_lerf_backward_points: workspace %zu < %zu bytes", workspace_bytes, nrf_lerf_backward_points_workspace_bytes(r, n, s)); return NRF_ERR_WORKSPACE; }
     if (n == 0) return NRF_OK;
     const int64_t cpts = lt_chunk_pts(m, s);
-    const int64_t rays_per = cpts / s > 0 ? cpts / s : 1;
+    const int64_t rays_per = lt_rays_per_pass(n, cpts, s);
     const int64_t cmax = (n < rays_per ? n : rays_per) * s;
     char *ws = static_cast<char *>(d_workspace);
     const size_t hb = head_ws_bytes(m, n, s), eb = align_up((size_t)cmax * in * sizeof(float), 256);

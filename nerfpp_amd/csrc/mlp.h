@@ -64,7 +64,8 @@ struct nrf_mlp {
     void *d_packed_sigma_f32 = nullptr;      // fp32 MFMA fragments of the sigma net (sigma_small_f32.hip)
     size_t packed_sigma_f32_bytes = 0;
     int lerf_precision = NRF_PREC_F16_MFMA;  // arithmetic of the fused LeRF passes (nrf_lerf_set_precision)
-    float *d_lerf_gram = nullptr;            // LeRF device pack: the Gram matrix [256][256] (+ the bits of its largest entry behind it)
+    float *d_lerf_gram = nullptr;            // LeRF device pack: the Gram matrix [256][256] in its packed form (scaled, block triangle), W^T W itself, the bits of its largest entry
+    bool lerf_gram_current = false;          // d_lerf_gram's W^T W belongs to the parameters now in d_params (set by the device packer, cleared by a host re-pack)
     bool lerf_device_pack = false;           // the device packers reproduce the host packers' images byte for byte (checked at creation): nrf_mlp_set_params stays on the device
     float lerf_gram_scale = 1.0f;            // LeRF: the Gram matrix of the embedding layer is stored divided by this power of two (fp16 range), see mlp_lerf_mfma.hip
     void *d_packed_bwd = nullptr;            // W^T fragments of the matrix-core backward (mlp_small_bwd_mfma.hip)
@@ -106,6 +107,7 @@ int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act,
 int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith = 0);          // arith != 0 (train_gemm_for): gemm_tn_bf16x3
 int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);
+int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);          // fewer than 32 rows: fp32 FMAs, four rows per pass over x
 int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db = nullptr);          // two X segments in one pass over G
 // mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0);

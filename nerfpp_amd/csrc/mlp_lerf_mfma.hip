@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(256) k_lerf_gram_f64(const float *__restrict__
     }
     const float g = (float)((s0 + s1) + (s2 + s3));
     gram[(size_t)a * HID + b] = g;
+    gram[(size_t)HID * HID + (size_t)a * HID + b] = g;          // the unscaled matrix, kept for the training backward's Gram form (lerf_train.hip)
     float mx = fabsf(g);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -377,6 +378,7 @@ static bool lerf_mfma_supported(const nrf_mlp_small_desc &d)
 
 int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 {
+    m->lerf_gram_current = false;          // (a host re-pack: the device-side W^T W, if any, belongs to older parameters)
     if (!lerf_mfma_supported(m->small)) return NRF_OK;
     std::vector<_Float16> img;
     img.reserve((size_t)IMAGE_FRAGS * 512);
@@ -485,8 +487,8 @@ int mlp_lerf_pack_f16(nrf_mlp *m, const std::vector<float> &hp)
 int mlp_lerf_pack_f16_device(nrf_mlp *m, hipStream_t st)
 {
     if (!lerf_mfma_supported(m->small) || !m->d_packed_f16 || !m->d_packed_split || m->packed_f16_bytes != (size_t)IMAGE_FRAGS * 512 * sizeof(_Float16)) return NRF_ERR_UNSUPPORTED;
-    if (!m->d_lerf_gram) NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_lerf_gram), (size_t)HID * HID * sizeof(float) + 16));
-    uint32_t *gmax = reinterpret_cast<uint32_t *>(m->d_lerf_gram + (size_t)HID * HID);
+    if (!m->d_lerf_gram) NRF_HIP(hipMalloc(reinterpret_cast<void **>(&m->d_lerf_gram), (size_t)2 * HID * HID * sizeof(float) + 16));          // [packed form | W^T W itself | max bits]
+    uint32_t *gmax = reinterpret_cast<uint32_t *>(m->d_lerf_gram + (size_t)2 * HID * HID);
     const float *w3 = m->d_params + (size_t)HID * IN + (size_t)(1 + GEO) * HID + (size_t)HID * (GEO + IN);
     NRF_HIP(hipMemsetAsync(gmax, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_lerf_gram_f64, dim3(HID), dim3(HID), 0, st, w3, m->d_lerf_gram, gmax);
@@ -503,6 +505,7 @@ int mlp_lerf_pack_f16_device(nrf_mlp *m, hipStream_t st)
     hipLaunchKernelGGL(k_lerf_fill, dim3(IMAGE_FRAGS), dim3(512), 0, st, (const float *)m->d_params, (const float *)m->d_lerf_gram, reinterpret_cast<_Float16 *>(m->d_packed_f16),
                        reinterpret_cast<_Float16 *>(m->d_packed_split));
     NRF_LAUNCH_CHECK();
+    m->lerf_gram_current = true;
     return NRF_OK;
 }
 
