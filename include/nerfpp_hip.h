@@ -768,6 +768,9 @@ NRF_API int nrf_gemm_nt_bf16x3(const float *d_a, int lda, int64_t m, int k, cons
 /* dW [out x in] (ld in; columns col0 .. col0 + n) += G [p x out]^T (ldg) . X [p x n] (ldx), fp32 row-major: the weight-gradient product of a layer over p points
  * (bf16x3 arithmetic -- a per-point scale cannot be undone in a sum over points; deterministic: slices of the points summed in a fixed order) */
 NRF_API int nrf_gemm_tn_bf16x3(const float *d_g, int ldg, int out, const float *d_x, int ldx, int n, int64_t p, float *d_dw, int in, int col0, void *stream);
+/* One layer's weight gradient as the split-precision training modes compute it, with its bias gradient: dW += G^T X as above (out >= 32) or, for a head of fewer rows,
+ * by fp32 FMAs four rows per pass over X; d_db (optional) [out] += the column sums of G, out of the same pass over G where out >= 32 */
+NRF_API int nrf_layer_grad_split(const float *d_g, int ldg, int out, const float *d_x, int ldx, int n, int64_t p, float *d_dw, int in, int col0, float *d_db, void *stream);
 NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream);
 NRF_API int nrf_profile_enable(int on);
 /* 1 while the event bracketing is on.  A throughput measurement must run with it off: an event pair around every kernel of every lane costs host time per launch and

@@ -1010,6 +1010,18 @@ extern "C" NRF_API int nrf_gemm_tn_bf16x3(const float *d_g, int ldg, int out, co
     NRF_CHECK_ARG(d_g && d_x && d_dw && p >= 0 && out >= 1 && n >= 1 && ldg >= out && ldx >= n && col0 >= 0 && in >= col0 + n, "nrf_gemm_tn_bf16x3: bad argument");
     return nrf::gemm_tn_bf16x3(p, nrf::Seg{d_g, ldg, 0, out}, nrf::Seg{d_x, ldx, 0, n}, out, in, col0, d_dw, nrf::as_stream(stream));
 }
+// The weight (and, with d_db, bias) gradient of one layer as the training paths' split-precision modes compute it: dW [out x in] (columns col0 .. col0 + n) += G^T X,
+// db [out] += the column sums of G -- gemm_tn_bf16x3_2 for 32 rows and more (the bias sums out of the same pass over G), gemm_tn_thin for a head of fewer rows
+extern "C" NRF_API int nrf_layer_grad_split(const float *d_g, int ldg, int out, const float *d_x, int ldx, int n, int64_t p, float *d_dw, int in, int col0, float *d_db, void *stream)
+{
+    NRF_CHECK_ARG(d_g && d_x && d_dw && p >= 0 && out >= 1 && n >= 1 && ldg >= out && ldx >= n && col0 >= 0 && in >= col0 + n, "nrf_layer_grad_split: bad argument");
+    const nrf::Seg g{d_g, ldg, 0, out}, x{d_x, ldx, 0, n};
+    hipStream_t st = nrf::as_stream(stream);
+    if (out >= 32) return nrf::gemm_tn_bf16x3_2(p, g, x, col0, nrf::Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, d_dw, st, d_db);
+    NRF_TRY(nrf::gemm_tn_thin(p, g, x, out, in, col0, d_dw, st));
+    if (d_db && p > 0) return nrf::run_grad_b(p, g, out, d_db, st);          // (a thin head's bias gradient: the pass the training paths run)
+    return NRF_OK;
+}
 extern "C" NRF_API int nrf_gemm_nt_f16x3(const float *d_a, int lda, int64_t m, int k, const float *d_b, int ldb, int n, float *d_c, int ldc, const float *d_bias, int relu, void *stream)
 {
     NRF_CHECK_ARG(d_a && d_b && d_c && m >= 0 && n >= 1 && k >= 1 && lda >= k && ldb >= k && ldc >= n, "nrf_gemm_nt_f16x3: bad argument");

@@ -97,6 +97,7 @@ int mlp_forward(const nrf_mlp *m, const float *d_x, int x_stride, int64_t p, int
 int run_linear(int64_t npts, Seg a, Seg b, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
 //   dw[o][i] += sum_pt g[pt][o] concat(a, b)[pt][i]            (dw: the layer's [out][in] block of a parameter-gradient blob)
 int run_grad_w(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st);
+int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st);          // db[o] += sum_pt g[pt][o]
 //   y[pt][k] = sum_o g[pt][o] W[o][k]
 int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st);
 //   g[pt][k] = 0 where act[pt][k] <= 0

@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) k_grad_b(int64_t npts, Seg g, int out, fl
     if (o < out && acc != 0.0f) unsafeAtomicAdd(db + o, acc);
 }
 
-static int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st)
+int run_grad_b(int64_t npts, Seg g, int out, float *db, hipStream_t st)
 {
     const int64_t nb = ceil_div(npts, 16);
     hipLaunchKernelGGL(k_grad_b, dim3((unsigned)(nb < 512 ? (nb < 1 ? 1 : nb) : 512), (unsigned)ceil_div(out, 64)), dim3(256), 0, st, npts, g, out, db);

@@ -3602,6 +3602,35 @@ def test_gemm_nt_f16x3_rows_of_any_magnitude(api):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,out,n,ldg,ldx", [(60000, 256, 256, 256, 264), (50001, 1, 256, 4, 256), (50001, 3, 128, 4, 128), (20000, 7, 63, 8, 63), (8200, 33, 96, 40, 96)])
+def test_layer_grad_split_weight_and_bias_gradients_vs_float64(api, P, out, n, ldg, ldx):
+    """nrf_layer_grad_split: a layer's weight AND bias gradient as the classic / LeRF backward compute them -- 32 rows and more: the bf16x3 TN product with the bias sums
+    taken out of the same pass over G; a head of fewer rows (alpha: 1, rgb: 3): fp32 FMAs four rows per pass over X.  Against float64: dW within 2e-5 of its largest entry
+    (thin heads: 2e-6, they are fp32 sums), db within 2e-6 of sum |g|; both ADDED to what the buffers held; dW deterministic."""
+    L = api.L
+    gen = torch.Generator(device="cuda"); gen.manual_seed(P + out + n)
+    G = torch.randn((P, ldg), device="cuda", generator=gen) * torch.pow(10.0, torch.rand((P, 1), device="cuda", generator=gen) * 4 - 4)
+    X = torch.randn((P, ldx), device="cuda", generator=gen)
+    dw0 = torch.randn((out, n), device="cuda", generator=gen); db0 = torch.randn((out,), device="cuda", generator=gen)
+    want_w = dw0.double() + G[:, :out].double().t() @ X[:, :n].double()
+    want_b = db0.double() + G[:, :out].double().sum(0)
+    res = []
+    for _ in range(2):
+        dw, db = dw0.clone(), db0.clone()
+        L.check(L.lib().nrf_layer_grad_split(C.c_void_p(G.data_ptr()), ldg, out, C.c_void_p(X.data_ptr()), ldx, n, C.c_int64(P), C.c_void_p(dw.data_ptr()), n, 0, C.c_void_p(db.data_ptr()), None))
+        res.append((dw, db))
+    assert torch.equal(res[0][0], res[1][0]), "deterministic"
+    if out >= 32:
+        assert torch.equal(res[0][1], res[1][1]), "the bias sums out of the TN pass are deterministic too (a thin head's go through k_grad_b's float atomics)"
+    dw, db = res[0]
+    scale_w = (G[:, :out].double().t() @ X[:, :n].double()).abs().max()
+    ew = float((dw.double() - want_w).abs().max() / scale_w)
+    eb = float(((db.double() - want_b).abs() / G[:, :out].double().abs().sum(0).clamp_min(1e-30)).max())
+    assert ew < (2e-5 if out >= 32 else 2e-6), ew
+    assert eb < 2e-6, eb
+
+
+@pytest.mark.gpu
 def test_training_step_with_an_overflowed_fp16_backward_is_skipped_on_the_device(api):
     """Trainer.step with the fused fp16 backward no longer waits for the chain's overflow words in the middle of the step: the optimizer step is nrf_adam_step_guarded --
     the kernel itself returns when either word is set -- and the host reads the words (copied to pinned memory behind the backward) before the NEXT step begins.  A batch
