@@ -813,11 +813,11 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     }
     a.part = part;
     a.bpart = db ? part + (size_t)slices * out * nn : nullptr;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;          // (the large dynamic LDS window is a per-device function attribute: common.h)
+    if (attr.needed()) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_tn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE));
-        attr = true;
+        attr.done();
     }
     if (a.vg == 4 && a.vx == 4) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
     else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)(slices * tiles)), dim3(256), 2 * TN_STAGE, st, a);
@@ -935,14 +935,14 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     const int64_t blocks = ceil_div(g.M, GB_BM) * ceil_div((int64_t)g.N, (int64_t)bn);
     if (blocks > 0x7fffffff) { set_error("gemm_nt_split: too many tiles"); return NRF_ERR_INVALID_ARG; }
     constexpr int LDS2 = 2 * GbCfg<2>::STAGE + GB_BM * 4, LDS4 = GB_ROWS_LDS;          // two stages + the rows' inverse scales; the 256-wide tile: its C block staged through LDS
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<2, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt<4, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<4, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<5, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
         NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_nt_rows<8, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_ROWS_LDS));
-        attr_set = true;
+        attr_set.done();
     }
     // B: its largest entry (F16), then its split image -- two small launches over a cache-resident matrix, in stream order before the product
     const int T = (g.k0 + GB_BK - 1) / GB_BK + (g.k1 + GB_BK - 1) / GB_BK;
@@ -962,7 +962,8 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     const int ktot = g.k0 + g.k1;
     const bool rows_ok = wide && !no_rows && g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot == 128 || ktot == 160 || ktot == 256);
     if (rows_ok) {
-        static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; return n; }();
+        int cus = 256;
+        { int dev = 0, n = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 1) cus = n; }
         static const int per_cu = [] { const char *e = getenv("NRF_GEMM_ROWS_PERSIST"); return e ? atoi(e) : 1; }();          // 0: one workgroup per output tile (A/B)
         const unsigned pgrid = (unsigned)(per_cu > 0 && blocks > (int64_t)cus * per_cu ? (int64_t)cus * per_cu : blocks);          // persistent: one workgroup per CU (LDS: 133 KB)
         if (ktot == 128) hipLaunchKernelGGL((k_gemm_nt_rows<4, F16>), dim3(pgrid), dim3(512), GB_ROWS_LDS, st, g);
