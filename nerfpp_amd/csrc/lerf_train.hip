@@ -8,7 +8,7 @@
 // fp32 throughout, from the generic layer kernels of mlp.hip (forward = the oracle's FMA chains; dW = TN products with one atomic add per element and workgroup) or, by
 // default, the library GEMMs of gemm_f32.hip: the forward is RECOMPUTED here chunk by chunk with every layer input kept -- the render pass (fused matrix-core kernels) never
 // forms raw_le [n, S, 769].  The LAST layer (256 -> 768 at main.cpp sizes), its normalize and RenderCLIPEmbedding run in their Gram form (k_ltg_ray_u below): 136 -> 77 ms
-// per step of 16 384 rays x 192 samples (profiles/round5/r5K_*, r5O_*).
+// per step of 16 384 rays x 192 samples (docs/history/profiles/round5/r5K_*, r5O_*).
 // Pinned by LibTorch autograd over the compiled LeRF.cpp / RawToOutputs weights / the reference's inline RenderCLIPEmbedding: goldens train_lerf*.
 #include "encode.h"
 #include "mlp.h"
@@ -23,13 +23,13 @@ extern "C" const nrf_mlp *nrf_lerf_renderer_head(const nrf_lerf_renderer *r);
 namespace nrf {
 
 // sample points per pass: 2 n_layers + 4 activation / gradient buffers of this many rows x the widest layer (main.cpp sizes: 8 x 400 MB).  With 2^15 a pass was 170
-// rays = 170 workgroups of the per-ray kernel on 256 CUs, and every layer product a launch of a few tens of microseconds (profiles/round5/r5o_*)
+// rays = 170 workgroups of the per-ray kernel on 256 CUs, and every layer product a launch of a few tens of microseconds (docs/history/profiles/round5/r5o_*)
 #ifndef NRF_LT_CHUNK_LOG2
 #define NRF_LT_CHUNK_LOG2 17
 #endif
 constexpr int64_t LT_CHUNK_PTS = (int64_t)1 << NRF_LT_CHUNK_LOG2;
 // With the last layer in its Gram form (below) nothing embedding-wide exists per sample: the activation rows are as wide as the widest OTHER layer (256 instead of 768 at
-// main.cpp sizes) and a pass takes 2^NRF_LT_GRAM_CHUNK_LOG2 points (fewer, larger launches: the step is ~1 000 launches at 2^17; profiles/round5/r5N_*, r5O_*)
+// main.cpp sizes) and a pass takes 2^NRF_LT_GRAM_CHUNK_LOG2 points (fewer, larger launches: the step is ~1 000 launches at 2^17; docs/history/profiles/round5/r5N_*, r5O_*)
 #ifndef NRF_LT_GRAM_CHUNK_LOG2
 #define NRF_LT_GRAM_CHUNK_LOG2 20
 #endif

@@ -327,7 +327,7 @@ int run_backprop(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, fl
 #ifndef NRF_BWD_CHUNK_LOG2
 #define NRF_BWD_CHUNK_LOG2 20
 #endif
-static const int64_t BWD_CHUNK = (int64_t)1 << NRF_BWD_CHUNK_LOG2;          // points per pass of the fp32 backward (bounds the scratch; profiles/round5/r5X_*)
+static const int64_t BWD_CHUNK = (int64_t)1 << NRF_BWD_CHUNK_LOG2;          // points per pass of the fp32 backward (bounds the scratch; docs/history/profiles/round5/r5X_*)
 
 size_t mlp_backward_workspace_bytes(const nrf_mlp *m, int64_t p)
 {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 helper run on the GPU box: [tests +] smoke + the driver's own bench command (compact line on stdout, full record in bench_detail.json) and optional
-# rocprofv3 kernel-trace summaries (copied into profiles/round5 afterwards).   usage: tools/gpu_trip5.sh <tag> [tests] [prof]
+# rocprofv3 kernel-trace summaries (copied into docs/history/profiles/round5 afterwards).   usage: tools/gpu_trip5.sh <tag> [tests] [prof]
 set -u
 tag=${1:-t}
 shift
