@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
 #pragma unroll
     for (int j = 0; j < 4; j++) cj[j] = col + j < ncols ? col + j : ncols - 1;
     if (VEC && col + 4 > ncols) col = ncols - 4;
-    float4 r0[8], r1[8];
+    float4 r0[8];
     const bool bsum_on = a.bpart && opnd == 0 && bi == 0;          // (wave-uniform: waves 0-1 of the workgroups of X tile 0)
     float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f, bs3 = 0.0f;          // this thread's four G columns, summed over its eight points of every K tile
     auto load_tile = [&](int tile, float4 (&rr)[8]) {
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
             for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
     auto multiply = [&](int stage) {
         const unsigned char *base = gb_smem + stage * TN_STAGE;
-#pragma unroll 1
+#pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             gb_bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -678,19 +678,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
                 }
         }
     };
-    if (T > 0) load_tile(0, r0);
-    if (T > 1) load_tile(1, r1);
-    if (T > 0) store_tile(0, r0);
+    // ONE register set: tile t + 1 is requested before tile t is multiplied, and split into the other LDS stage behind it; the CU's second workgroup covers what
+    // latency is left.  (Two sets with tiles t + 1, t + 2 in flight need 256 registers and spill -- or, with the k-step loop kept rolled to make room, the compiler
+    // ping-pongs the accumulators between two register sets: 575-630 us against 544 for the 786 432 x 256 x 256 product.)
+    if (T > 0) { load_tile(0, r0); store_tile(0, r0); }
     __syncthreads();
-    for (int tile = 0; tile < T; tile += 2) {
-        if (tile + 2 < T) load_tile(tile + 2, r0);
-        multiply(0);
-        if (tile + 1 < T) store_tile(1, r1);
-        __syncthreads();
-        if (tile + 1 >= T) break;
-        if (tile + 3 < T) load_tile(tile + 3, r1);
-        multiply(1);
-        if (tile + 2 < T) store_tile(0, r0);
+    for (int tile = 0; tile < T; tile++) {
+        if (tile + 1 < T) load_tile(tile + 1, r0);
+        multiply(tile & 1);
+        if (tile + 1 < T) store_tile((tile + 1) & 1, r0);
         __syncthreads();
     }
     if (a.bpart && bi == 0) {
