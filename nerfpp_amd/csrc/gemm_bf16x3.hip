@@ -542,6 +542,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 }
 
 
+// NRF_POISON=1 (debugging): every stream-ordered scratch buffer of this file is filled with NaN patterns before use -- a kernel that reads what it did not write shows
+static void gb_poison(void *p, size_t bytes, hipStream_t st)
+{
+    static const bool on = [] { const char *e = getenv("NRF_POISON"); return e && atoi(e) != 0; }();
+    if (on && p) (void)hipMemsetAsync(p, 0xff, bytes, st);
+}
+
 static int vec_class(const float *p, int ld, int col0)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p + col0);
@@ -807,6 +814,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
         set_error("gemm_tn_bf16x3: hipMallocAsync failed");
         return NRF_ERR_HIP;
     }
+    gb_poison(part, ((size_t)slices * out * nn + (db ? (size_t)slices * out : 0)) * sizeof(float), st);
     a.part = part;
     a.bpart = db ? part + (size_t)slices * out * nn : nullptr;
     static PerDeviceOnce attr;          // (the large dynamic LDS window is a per-device function attribute: common.h)
@@ -859,6 +867,7 @@ int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, 
     slices = (P + slice_pts - 1) / slice_pts;
     float *part = nullptr;
     if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * 4 * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_thin: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    gb_poison(part, (size_t)slices * 4 * x.n * sizeof(float), st);
     const dim3 grid((unsigned)ceil_div((int64_t)x.n, (int64_t)256), (unsigned)slices);
     for (int o0 = 0; o0 < out; o0 += 4) {
         const int oc = out - o0 < 4 ? out - o0 : 4;
@@ -946,6 +955,7 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     g.bimg_half = (int64_t)T * 2 * g.npad * 32;
     unsigned char *ws = nullptr;
     if (hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)(2 * g.bimg_half + 16), st) != hipSuccess) { set_error("gemm_nt_split: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    gb_poison(ws, (size_t)(2 * g.bimg_half + 16), st);
     uint32_t *bmax = reinterpret_cast<uint32_t *>(ws + 2 * g.bimg_half);
     if (F16) {
         (void)hipMemsetAsync(bmax, 0, sizeof(uint32_t), st);

@@ -262,7 +262,11 @@ static void time_steps(const char *family, const char *surface, Body body, int s
 {
 	StepClock warm;
 	float loss_first = body(warm).template item<float>();
-	settle([&] { body(warm); }, 1.0, 8.0);
+	// a FIXED number of warm-up steps (not the frame benches' time-based settle): every body() is an optimizer step, so the loss the timed steps end at -- and, with the
+	// random targets of the LeRF bench, whether the run has already reached the trivial optimum (all weights zero: rendered embedding 0, loss 0.5, degenerate
+	// gradients, 25 % slower steps) -- must not depend on how many steps fit into a second on this box
+	for (int i = 0; i < 8; i++) body(warm);
+	dev_sync();
 	StepClock sc;
 	torch::Tensor loss;
 	dev_sync(); const auto t0 = Clock::now();
