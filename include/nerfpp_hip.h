@@ -461,6 +461,13 @@ NRF_API int nrf_renderer_create(const nrf_renderer_desc *desc, nrf_renderer **ou
 NRF_API void nrf_renderer_destroy(nrf_renderer *r);
 /* Totals since the renderer was created: chunks whose matrix-core render produced non-finite network outputs, and how many of them were rendered again in NRF_PREC_F32
  * (NRF_OVERFLOW_RERENDER).  Completes a pending NRF_OVERFLOW_DEFERRED check first (waits for that call's work).  Either pointer may be NULL. */
+/* Where the most recent render call on this renderer left the hash features of its fine depths -- a SINGLE-chunk call (nrf_render_rays, or nrf_batchify_rays with
+ * Chunk >= n) of the feature-reusing fast path on a CuHashEmbedder grid: the level-major fp16 table [16][cols] (half2; coarse columns first, the new samples' behind
+ * them), the keep mask by column, and the merge map [n, sf] (sorted depth i of the batch -> its column).  They live in the caller's workspace: valid until the next
+ * render call on this renderer or any other use of that workspace.  NRF_ERR_UNSUPPORTED when the last call left none (serial is set either way).  For nrf_mlp_backward_f16_lm_src /
+ * nrf_mask_sigma_grad_src: a training step's backward reads the features its own forward render encoded instead of encoding the fine points again. */
+NRF_API int nrf_renderer_last_features(const nrf_renderer *r, const void **d_feats_lm, int64_t *cols, const uint8_t **d_keep_cols, const int32_t **d_src, int64_t *n, int *sf,
+                                       uint64_t *serial /* optional: a count of the chunks this renderer has rendered -- unchanged between two queries = no render in between */);
 NRF_API int nrf_renderer_nonfinite(const nrf_renderer *r, int64_t *flagged_chunks, int64_t *rerendered_chunks);
 
 /* RunNetwork (NeRFRenderer.h:164-194): pts [n,s,3], viewdirs [n,3] (or NULL) -> raw [n,s,4]
@@ -535,6 +542,11 @@ NRF_API int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, co
 /* Overflow report of the last nrf_mlp_backward_f16(_lm) that used `d_workspace` (the chain runs on fp16 operands behind a loss scale taken from max |g_out|):
  * flags_out[0] != 0: the incoming gradient held an inf / NaN; flags_out[1] != 0: an accumulated parameter gradient is not finite.  Host array of 2; synchronises
  * `stream`.  A caller skips (or rescales) the optimizer step when either is set. */
+/* nrf_mlp_backward_f16_lm with the features read through a column map: point q reads column d_src[q] of the level-major table [16][pstride] (what
+ * nrf_renderer_last_features hands over); nrf_mask_sigma_grad_src: nrf_mask_sigma_grad with the keep mask given by column the same way. */
+NRF_API int nrf_mlp_backward_f16_lm_src(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const void *d_dirs_f16, int s, const float *d_g_out, int64_t p,
+                                        float *d_g_params, float *d_g_x, void *d_workspace, size_t workspace_bytes, void *stream);
+NRF_API int nrf_mask_sigma_grad_src(const uint8_t *d_keep_cols, const int32_t *d_src, int64_t p, int c, float *d_g_raw, void *stream);
 NRF_API int nrf_mlp_backward_f16_flags(const void *d_workspace, uint32_t *flags_out, void *stream);
 /* The same two words without a host wait in the training step: _async copies them to h_flags2 (two uint32; pinned memory keeps the copy asynchronous) in `stream`'s order
  * -- read them after the stream, or an event recorded behind the call, has passed; _device returns where they live on the device, for nrf_adam_step_guarded: the

@@ -85,7 +85,7 @@ SYMBOLS = [
     "nrf_render_rays_workspace_bytes", "nrf_render_rays", "nrf_batchify_rays_workspace_bytes", "nrf_batchify_rays", "nrf_render_rows_workspace_bytes", "nrf_render_rows",
     "nrf_normalize_depth", "nrf_to_u8",
     "nrf_huber_loss", "nrf_raw2outputs_backward", "nrf_raw2outputs_backward_noise", "nrf_mask_sigma_grad", "nrf_mlp_backward_workspace_bytes", "nrf_mlp_backward", "nrf_mlp_backward_f16_workspace_bytes", "nrf_mlp_backward_f16", "nrf_mlp_backward_f16_lm", "nrf_mlp_backward_f16_flags", "nrf_hash_encode_lm_f16", "nrf_hash_encode_lm_f16_strided", "nrf_lerf_sigma_lm", "nrf_lerf_sigma_lm_strided", "nrf_lerf_render_embedding_lm", "nrf_lerf_render_embedding_lm_gather", "nrf_lerf_geo_bytes", "nrf_lerf_sigma_geo_lm_strided", "nrf_lerf_sigma_exact_available", "nrf_lerf_sigma_exact_lm_strided", "nrf_lerf_render_embedding_lm_geo", "nrf_hash_backward_packed_workspace_bytes", "nrf_hash_backward_rays_packed", "nrf_hash_backward_binned_workspace_bytes", "nrf_hash_backward_binned_workspace_bytes_for", "nrf_hash_backward_rays_binned", "nrf_mlp_set_params", "nrf_mlp_device_repack_images", "nrf_mlp_set_input_rms_hint", "nrf_mlp_set_split_scaling", "nrf_mlp_get_split_scales", "nrf_renderer_nonfinite", "nrf_hash_memory_bytes", "nrf_lerf_renderer_nonfinite",
-    "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step", "nrf_adam_step_guarded", "nrf_mlp_backward_f16_flags_async", "nrf_mlp_backward_f16_flags_device",
+    "nrf_hash_backward", "nrf_hash_backward_rays", "nrf_hash_tv_loss", "nrf_adam_step", "nrf_adam_step_guarded", "nrf_renderer_last_features", "nrf_mlp_backward_f16_lm_src", "nrf_mask_sigma_grad_src", "nrf_mlp_backward_f16_flags_async", "nrf_mlp_backward_f16_flags_device",
     "nrf_render_view_dims",
     "nrf_tile_partition", "nrf_comm_unique_id", "nrf_comm_create", "nrf_comm_create_timeout", "nrf_comm_wrap", "nrf_comm_destroy", "nrf_comm_world", "nrf_comm_rank", "nrf_allgather_tiles", "nrf_allreduce_grads",
     "nrf_profile_enable", "nrf_profile_is_enabled", "nrf_profile_read", "nrf_set_render_lanes", "nrf_get_render_lanes", "nrf_renderer_set_lanes", "nrf_lerf_renderer_set_lanes",

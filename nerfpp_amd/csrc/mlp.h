@@ -150,7 +150,7 @@ bool mlp_small_bwd_image_host(const nrf_mlp *m, const std::vector<float> &hp, st
 bool mlp_small_sigma_image_host(const nrf_mlp_small_desc &d, const std::vector<float> &hp, std::vector<uint8_t> &head_f32, std::vector<uint8_t> &tail_f16);
 size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p);
 int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p, float *g_params,
-                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st);
+                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st, int64_t lm_pstride = 0, const int32_t *lm_src = nullptr);
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st);
 int mlp_nerf_pack_f16(nrf_mlp *m, const std::vector<float> &host_params);

@@ -1377,6 +1377,18 @@ int nrf_mlp_backward_f16_lm(const nrf_mlp *m, const void *d_feats_lm, const void
                                       m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream));
 }
 
+// ... reading the features through a column map: point q -> column d_src[q] of a level-major table [16][pstride] (a renderer's feature-reusing fine pass keeps the
+// coarse columns and the new samples' columns apart: nrf_renderer_last_features)
+int nrf_mlp_backward_f16_lm_src(const nrf_mlp *m, const void *d_feats_lm, int64_t pstride, const int32_t *d_src, const void *d_dirs_f16, int s, const float *d_g_out, int64_t p,
+                                float *d_g_params, float *d_g_x, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(m && d_feats_lm && d_src && pstride >= 1 && d_dirs_f16 && d_g_out && d_g_params && d_workspace && p >= 0 && s >= 1, "nrf_mlp_backward_f16_lm_src: bad argument");
+    if (p == 0) return NRF_OK;
+    if (m->family != MLP_SMALL) { set_error("nrf_mlp_backward_f16_lm_src: built for the NeRFSmall family"); return NRF_ERR_UNSUPPORTED; }
+    return mlp_small_backward_mfma_lm(m, reinterpret_cast<const __half2 *>(d_feats_lm), reinterpret_cast<const __half *>(d_dirs_f16), s, d_g_out, m->out_dims, p, d_g_params, d_g_x,
+                                      m->small.input_ch, d_workspace, workspace_bytes, as_stream(stream), pstride, d_src);
+}
+
 void nrf_mlp_destroy(nrf_mlp *m)
 {
     if (!m) return;

@@ -75,7 +75,9 @@ struct LayerOffs { int s[4]; int c[4]; };       // offsets (floats) of every W i
 
 // Alternative input (feats != NULL): the level-major fp16 hash features of nrf_hash_encode_lm_f16 ([16 levels][pstride] half2, already offset to this launch's
 // first point) and per-RAY fp16 direction features [n][16]; point p of the launch belongs to ray (p_base + p) / s.  No [p, 48] fp32 row is ever formed.
-struct LmInput { const __half2 *feats; int64_t pstride; const __half *dirs; int s; int64_t p_base; };
+// `src` (optional): point q of the whole call reads feature COLUMN src[q] of a table that is then NOT offset per launch -- the merge map of a renderer's feature-reusing
+// fine pass (nrf_renderer_last_features): the training backward reads the features the forward render has just encoded instead of encoding the points again.
+struct LmInput { const __half2 *feats; int64_t pstride; const __half *dirs; int s; int64_t p_base; const int32_t *src; };
 
 __device__ __forceinline__ f32x16 mfma(const half8 &a, const half8 &b, const f32x16 &c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -265,11 +267,12 @@ k_small_bwd(int64_t npts, const float *__restrict__ x, int xs, const float *__re
         for (int pt = 0; pt < BPT; pt++) {
             int64_t p = b * BW_BLOCK_PTS + wave * (32 * BPT) + pt * 32 + r;
             if (p >= npts) p = npts - 1;
+            const int64_t col = lm.src ? (int64_t)lm.src[lm.p_base + p] : p;
 #pragma unroll
             for (int s = 0; s < IN_KS; s++) {
                 union { half8 v; __half2 q[4]; } u;
 #pragma unroll
-                for (int q = 0; q < 4; q++) u.q[q] = lm.feats[(int64_t)(8 * s + 4 * h + q) * lm.pstride + p];      // features 16s + 8h + 2q, +1
+                for (int q = 0; q < 4; q++) u.q[q] = lm.feats[(int64_t)(8 * s + 4 * h + q) * lm.pstride + col];      // features 16s + 8h + 2q, +1
                 nx[pt][s] = u.v;
             }
             const int64_t ray = (lm.p_base + p) / lm.s;
@@ -640,7 +643,7 @@ size_t mlp_small_backward_mfma_workspace_bytes(const nrf_mlp *m, int64_t p)
 }
 
 static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p,
-                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st);
+                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st, int64_t lm_pstride = 0, const int32_t *lm_src = nullptr);
 
 int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const float *g_out, int gos, int64_t p, float *g_params, float *g_x, int gxs, void *ws,
                             size_t ws_bytes, hipStream_t st)
@@ -650,14 +653,15 @@ int mlp_small_backward_mfma(const nrf_mlp *m, const float *x, int xs, const floa
 }
 
 int mlp_small_backward_mfma_lm(const nrf_mlp *m, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p, float *g_params,
-                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st)
+                               float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st, int64_t lm_pstride, const int32_t *lm_src)
 {
     if ((reinterpret_cast<uintptr_t>(feats_lm) & 3) || (reinterpret_cast<uintptr_t>(dirs) & 15) || s_per_ray < 1) { set_error("nrf_mlp_backward_f16_lm: bad feature / direction buffers"); return NRF_ERR_INVALID_ARG; }
-    return backward_mfma_impl(m, nullptr, 0, feats_lm, dirs, s_per_ray, g_out, gos, p, g_params, g_x, gxs, ws, ws_bytes, st);
+    if (lm_src && lm_pstride < 1) { set_error("nrf_mlp_backward_f16_lm_src: bad column stride"); return NRF_ERR_INVALID_ARG; }
+    return backward_mfma_impl(m, nullptr, 0, feats_lm, dirs, s_per_ray, g_out, gos, p, g_params, g_x, gxs, ws, ws_bytes, st, lm_pstride, lm_src);
 }
 
 static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __half2 *feats_lm, const __half *dirs, int s_per_ray, const float *g_out, int gos, int64_t p,
-                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st)
+                              float *g_params, float *g_x, int gxs, void *ws, size_t ws_bytes, hipStream_t st, int64_t lm_pstride, const int32_t *lm_src)
 {
     const auto &d = m->small;
     if (m->family != MLP_SMALL || !m->d_packed_bwd || !m->d_packed_f16) {
@@ -689,7 +693,7 @@ static int backward_mfma_impl(const nrf_mlp *m, const float *x, int xs, const __
                 set_error("internal: NeRFSmall backward image sizes do not match the kernel plan"); return NRF_ERR_UNSUPPORTED;                            \
             }                                                                                                                                             \
             NRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-            const LmInput lmi{feats_lm ? feats_lm + p0 : nullptr, p, dirs, s_per_ray, p0};                                                                   \
+            const LmInput lmi{feats_lm ? (lm_src ? feats_lm : feats_lm + p0) : nullptr, lm_src ? lm_pstride : p, dirs, s_per_ray, p0, lm_src};                  \
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * BW), lds, st, c, x ? x + p0 * xs : nullptr, xs, g_out + p0 * gos, gos, reinterpret_cast<const half8 *>(m->d_packed_f16), \
                                reinterpret_cast<const half8 *>(m->d_packed_bwd), scratch, g_params, g_x ? g_x + p0 * gxs : nullptr, gxs, absmax, (int)m->n_params, lo, lmi); \
                                                                                                      \

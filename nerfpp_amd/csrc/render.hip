@@ -35,6 +35,11 @@ struct nrf_renderer {
     mutable int deferred_slots[32] = {};               // > 0: a deferred copy of that many words is pending in ring entry i
     mutable int deferred_head = 0;                     // ring entry the next deferred copy goes to (entries are filled and looked at in order)
     mutable int64_t flagged_chunks = 0, rerendered_chunks = 0;
+    // where the most recent SINGLE-chunk render of the feature-reusing fast path (CuHashEmbedder mode) left its hash features in the caller's workspace: the level-major
+    // table, its column count, the keep mask by column and the merge map [n, sf] (nrf_renderer_last_features: the training backward reads them instead of encoding the
+    // fine points again).  Invalidated by every render call on entry.
+    mutable struct { const void *feats = nullptr; int64_t cols = 0; const uint8_t *keep = nullptr; const int32_t *src = nullptr; int64_t n = 0; int sf = 0; bool valid = false; } last_view;
+    mutable uint64_t chunk_serial = 0;                 // chunks rendered so far: a caller that saw serial k and still sees k knows that no render has touched the view since
     void drop_lanes() const
     {
         for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
@@ -538,6 +543,8 @@ namespace nrf {
 static int render_rays_impl(const nrf_renderer *r, const float *d_rays, int ray_stride, int64_t n, const nrf_render_params *p,
                             const float *d_t, const float *d_u, const nrf_render_outputs *out, void *d_workspace, size_t workspace_bytes, void *stream, uint32_t *d_flag)
 {
+    r->last_view.valid = false;          // (set again below by the feature-reusing fast path)
+    r->chunk_serial++;
     NRF_CHECK_ARG(r && p && out, "nrf_render_rays: null pointer");
     if (n == 0) return NRF_OK;
     NRF_CHECK_ARG(d_rays && d_t, "nrf_render_rays: null pointer");
@@ -695,6 +702,7 @@ static int render_rays_impl(const nrf_renderer *r, const float *d_rays, int ray_
         PointSource psn{nullptr, d_rays, rw.z_new, ray_stride, ni};
         if (ngp) NRF_TRY(launch_hash_ngp_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.feats_lo ? rw.feats_lo - rw.feats : 0, rw.keep + n * (int64_t)s, st));
         else NRF_TRY(launch_hash_lm(r->desc.hash, psn, n * (int64_t)ni, rw.feats + n * (int64_t)s, rw.cols, rw.keep + n * (int64_t)s, HASH_LM_DEFAULT_VARIANT, st));
+        if (!ngp) { r->last_view.feats = rw.feats; r->last_view.cols = rw.cols; r->last_view.keep = rw.keep; r->last_view.src = rw.src; r->last_view.n = n; r->last_view.sf = sf; r->last_view.valid = true; }
         if (geo_reuse) {
             const int64_t nc = n * (int64_t)s;
             NRF_TRY(mlp_small_color_from_geo_lm(r->desc.mlp, geo_planes, nc, raw_c, dirs16, dirs_lo, s, rw.keep, nc, raw_cols, st));
@@ -914,6 +922,7 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
                 (void)hipStreamSynchronize(lane[j]);
             }
         }
+        if (done_chunks.size() != 1) r->last_view.valid = false;          // the feature view describes ONE chunk's workspace: only a single-chunk call keeps it
         return rc == NRF_OK ? settle() : rc;
     }
     for (int64_t i = 0; i < n; i += chunk) {                                                                      // :476
@@ -923,7 +932,21 @@ int nrf_batchify_rays(const nrf_renderer *r, const float *d_rays, int ray_stride
         NRF_TRY(render_rays_impl(r, d_rays + i * ray_stride, ray_stride, m, &q, d_t, d_u, &o, d_workspace, workspace_bytes, stream, flag_of(done_chunks.size())));
         done_chunks.push_back({i, m});
     }
+    if (done_chunks.size() != 1) r->last_view.valid = false;
     return settle();
+}
+
+// The hash features the most recent render left in its workspace (a single-chunk render of the feature-reusing fast path, CuHashEmbedder grid): level-major fp16
+// [16][cols] half2, the keep mask by column, the merge map [n, sf] (sample i of the sorted depths -> column).  Valid until the next render call on this renderer or
+// any other use of that workspace.  NRF_ERR_UNSUPPORTED when the last call left none.
+extern "C" NRF_API int nrf_renderer_last_features(const nrf_renderer *r, const void **d_feats_lm, int64_t *cols, const uint8_t **d_keep_cols, const int32_t **d_src, int64_t *n, int *sf,
+                                                  uint64_t *serial)
+{
+    NRF_CHECK_ARG(r && d_feats_lm && cols && d_keep_cols && d_src && n && sf, "nrf_renderer_last_features: null pointer");
+    if (serial) *serial = r->chunk_serial;
+    if (!r->last_view.valid) { set_error("nrf_renderer_last_features: the last render call left no feature view (several chunks, another path, or none yet)"); return NRF_ERR_UNSUPPORTED; }
+    *d_feats_lm = r->last_view.feats; *cols = r->last_view.cols; *d_keep_cols = r->last_view.keep; *d_src = r->last_view.src; *n = r->last_view.n; *sf = r->last_view.sf;
+    return NRF_OK;
 }
 
 extern "C" int nrf_view_check(const nrf_view *v, const char *who);

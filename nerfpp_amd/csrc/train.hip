@@ -134,10 +134,10 @@ k_raw2outputs_bwd(int64_t n, int s, int c, int white, const float *__restrict__ 
 }
 
 // d loss / d sigma = 0 where the embedder's keep mask is false (raw[~keep, -1] = 0 is an in-place overwrite in the forward)
-__global__ void k_mask_grad(int64_t p, int c, const uint8_t *__restrict__ keep, float *__restrict__ g_raw)
+__global__ void k_mask_grad(int64_t p, int c, const uint8_t *__restrict__ keep, float *__restrict__ g_raw, const int32_t *__restrict__ src)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p && !keep[i]) g_raw[i * c + (c - 1)] = 0.0f;
+    if (i < p && !keep[src ? (int64_t)src[i] : i]) g_raw[i * c + (c - 1)] = 0.0f;          // src: the keep mask by feature COLUMN, point i's column = src[i]
 }
 
 // HashEmbedder (fp32 tables [L][2^T][F]): row gradient = g * wz * wy * wx in autograd's chain order
@@ -759,7 +759,16 @@ int nrf_mask_sigma_grad(const uint8_t *d_keep, int64_t p, int c, float *d_g_raw,
 {
     NRF_CHECK_ARG(d_keep && d_g_raw && p >= 0 && c >= 1, "nrf_mask_sigma_grad: bad argument");
     if (p == 0) return NRF_OK;
-    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, as_stream(stream), p, c, d_keep, d_g_raw);
+    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, as_stream(stream), p, c, d_keep, d_g_raw, (const int32_t *)nullptr);
+    NRF_LAUNCH_CHECK();
+    return NRF_OK;
+}
+
+int nrf_mask_sigma_grad_src(const uint8_t *d_keep_cols, const int32_t *d_src, int64_t p, int c, float *d_g_raw, void *stream)
+{
+    NRF_CHECK_ARG(d_keep_cols && d_src && d_g_raw && p >= 0 && c >= 1, "nrf_mask_sigma_grad_src: bad argument");
+    if (p == 0) return NRF_OK;
+    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)ceil_div(p, 256)), dim3(256), 0, as_stream(stream), p, c, d_keep_cols, d_g_raw, d_src);
     NRF_LAUNCH_CHECK();
     return NRF_OK;
 }

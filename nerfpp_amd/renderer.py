@@ -135,6 +135,7 @@ class NeRFRenderResult:               # NeRFRenderer.h:20-26
         self.Outputs = NeRFRendererOutputs()
         self.Raw = None
         self.Extras = {}          # intermediates exposed for stage-chained parity tests (not in the reference struct)
+        self.FeatureView = None   # NeRFRenderer.feature_view() of the render call that produced this result (ray-batch branch), or None
         self._nf = (0.0, 0.0)
         self._nf_dev = None
 
@@ -214,6 +215,18 @@ class NeRFRenderer:
             except Exception:       # interpreter shutdown: module globals may already be gone
                 pass
             self._r = None
+
+    def feature_view(self):
+        """nrf_renderer_last_features: where the most recent single-chunk render of the feature-reusing fast path left the hash features of its fine depths in this
+        renderer's workspace -- dict(feats, cols, keep, src: device addresses; n, sf; serial) or None.  Valid until the next render call on this renderer."""
+        if not getattr(self, "_r", None):
+            return None
+        fp, kp, sp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cols, nn, sf, ser = C.c_int64(), C.c_int64(), C.c_int(), C.c_uint64()
+        rc = L.lib().nrf_renderer_last_features(self._r, C.byref(fp), C.byref(cols), C.byref(kp), C.byref(sp), C.byref(nn), C.byref(sf), C.byref(ser))
+        if rc != 0:
+            return None
+        return dict(feats=fp.value, cols=int(cols.value), keep=kp.value, src=sp.value, n=int(nn.value), sf=int(sf.value), serial=int(ser.value))
 
     def _workspace(self, nbytes, device):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
@@ -362,6 +375,7 @@ class NeRFRenderer:
         tile's Near / Far); the ray-batch branch packs and then runs the Chunk loop in one call (nrf_batchify_rays).  In NRF_PREC_F32, and in the matrix-core
         precisions with OverflowPolicy DEFERRED / IGNORE, neither synchronises; with the default policy a matrix-core render ends with one read-back of its
         chunks' non-finite words (flagged chunks are rendered again in NRF_PREC_F32)."""
+        self._last_feature_view = None
         p = render_params
         s, ni = int(p.NSamples), int(p.NImportance)
         stride = 11 if p.UseViewdirs else 8
@@ -422,6 +436,7 @@ class NeRFRenderer:
             ws = self._workspace(nb, dev)
             L.check(lib.nrf_batchify_rays(self._r, _ptr(rays_), stride, C.c_int64(n), int(p.Chunk), C.byref(rp), _ptr(self._linspace(s, dev)),
                                           _ptr(self._linspace(ni, dev)) if ni > 0 else None, C.byref(ro), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+            self._last_feature_view = self.feature_view()          # (None unless this was a single-chunk render of the feature-reusing fast path)
             nf = None
             if n > 0:
                 nf = torch.empty((2,), device=dev, dtype=torch.float32)          # Near / Far stay on the device until someone reads them (a training loop never does):
@@ -431,6 +446,7 @@ class NeRFRenderer:
         if len(sh) > 2:
             out.DispMap = out.DispMap.reshape(sh[0], sh[1]); out.DepthMap = out.DepthMap.reshape(sh[0], sh[1])   # :594-600
         res._nf_dev = nf
+        res.FeatureView = getattr(self, "_last_feature_view", None)          # (not in Extras: those are tensors)
         res.Extras["rays_flat"] = rays_
         return res
 

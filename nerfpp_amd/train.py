@@ -148,16 +148,26 @@ class Trainer:
               and dirs.shape[1] == 16)
         if lm:
             # the fast path's own layout: level-major fp16 hash features + one fp16 direction row per ray; no [p, 48] fp32 input is formed
-            feats = torch.empty((16, n * s, 2), device=rays.device, dtype=torch.float16)
-            keep_u8 = torch.empty((n * s,), device=rays.device, dtype=torch.uint8)
-            ptsc = pts.contiguous()
-            L.check(lib.nrf_hash_encode_lm_f16(self.embedder._h, _ptr(ptsc), C.c_int64(n * s), _ptr(feats), _ptr(keep_u8), _stream()))
             dirs16 = dirs.to(torch.float16).contiguous()
-            L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
             nb = lib.nrf_mlp_backward_f16_workspace_bytes(self.mlp._m, C.c_int64(n * s))
             ws = self._workspace(nb)
-            L.check(lib.nrf_mlp_backward_f16_lm(self.mlp._m, _ptr(feats), _ptr(dirs16), s, _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws),
-                                                C.c_size_t(ws.numel()), _stream()))
+            # ... and where the forward render of THIS batch was the renderer's last call (a single-chunk render of the feature-reusing fast path), the features it
+            # encoded are still in its workspace -- coarse columns, new samples' columns, the merge map: the same points, the same kernel, the same bits -- and the
+            # fine points are not encoded a second time (0.6 ms of a 5.9 ms step)
+            view = self._render_features(res, n, s) if (fine and cone_angle is None and not (p is not None and p.StochasticPreconditioningAlpha > 0)) else None
+            if view is not None:
+                L.check(lib.nrf_mask_sigma_grad_src(C.c_void_p(view["keep"]), C.c_void_p(view["src"]), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
+                L.check(lib.nrf_mlp_backward_f16_lm_src(self.mlp._m, C.c_void_p(view["feats"]), C.c_int64(view["cols"]), C.c_void_p(view["src"]), _ptr(dirs16), s, _ptr(g_raw),
+                                                        C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws), C.c_size_t(ws.numel()), _stream()))
+            else:
+                feats = torch.empty((16, n * s, 2), device=rays.device, dtype=torch.float16)
+                keep_u8 = torch.empty((n * s,), device=rays.device, dtype=torch.uint8)
+                ptsc = pts.contiguous()
+                L.check(lib.nrf_hash_encode_lm_f16(self.embedder._h, _ptr(ptsc), C.c_int64(n * s), _ptr(feats), _ptr(keep_u8), _stream()))
+                L.check(lib.nrf_mask_sigma_grad(_ptr(keep_u8), C.c_int64(n * s), 4, _ptr(g_raw), _stream()))
+                L.check(lib.nrf_mlp_backward_f16_lm(self.mlp._m, _ptr(feats), _ptr(dirs16), s, _ptr(g_raw), C.c_int64(n * s), _ptr(self.g_blob), _ptr(g_x), _ptr(ws),
+                                                    C.c_size_t(ws.numel()), _stream()))
+            self.reused_render_features = view is not None
             x = None
         else:
             emb, keep = self.embedder.forward(pts)
@@ -198,6 +208,17 @@ class Trainer:
                 L.check(lib.nrf_mlp_backward_f16_flags(_ptr(self._ws), fl, _stream()))
                 self.overflow = bool(fl[0] or fl[1])
         return loss_mse
+
+    def _render_features(self, res, n, s):
+        """The renderer's feature view (NeRFRenderer.feature_view) if it still belongs to `res`: recorded on the result (FeatureView) by the Render call that produced it, and the
+        renderer has rendered nothing since (same chunk serial).  None otherwise, and with reuse_render_features = False."""
+        if not getattr(self, "reuse_render_features", True):
+            return None
+        mine = getattr(res, "FeatureView", None)
+        now = self.renderer.feature_view() if hasattr(self.renderer, "feature_view") else None
+        if not mine or not now or mine != now or now["n"] != n or now["sf"] != s:
+            return None
+        return now
 
     def _settle_flags(self):
         """A guarded step whose overflow words have not been looked at yet: wait for their copy (issued behind that step's backward: long done when the next step
@@ -257,7 +278,9 @@ class Trainer:
             raise L.NrfError("Trainer.step: ThinRay = False needs the batch's cone_angle (GetRayBatch / GetRays)")
         self._settle_flags()                               # (the previous step's overflow words: the step count below must be final)
         p = copy.copy(render_params)
-        p.ReturnRaw, p.KeepIntermediates = True, True
+        # the fine depths, not the coarse pass's raw rows: gradients flow through the fine pass only (NeRFRenderer.h:429), and without a raw_coarse output the render is the
+        # default path -- sigma net alone in the coarse pass, hash features kept per column for the fine pass -- whose features the backward then reads (feature_view)
+        p.ReturnRaw, p.KeepIntermediates = True, "depths"
         p.Seed = (int(render_params.Seed) + 0x9E3779B97F4A7C15 * self.t) & ((1 << 64) - 1)
         cone = None if p.ThinRay else cone_angle
         res = self.renderer.Render(0, 0, None, p, rays=(rays_o, rays_d, cone))

@@ -3631,6 +3631,45 @@ def test_layer_grad_split_weight_and_bias_gradients_vs_float64(api, P, out, n, l
 
 
 @pytest.mark.gpu
+def test_training_backward_reads_the_features_its_forward_render_encoded(api):
+    """The hash training step's backward needs the hash features of the fine depths; its forward render (a single-chunk render of the feature-reusing fast path) has just
+    encoded exactly those points -- coarse columns, the new samples' columns, the merge map.  nrf_renderer_last_features hands that view over and
+    nrf_mlp_backward_f16_lm_src / nrf_mask_sigma_grad_src read through the map: the same loss and the same gradients (to the last bits of the fused backward's atomic sums) as with a second encode of the points
+    (nrf_hash_encode_lm_f16); a render in between invalidates the view (the backward then encodes again); a multi-chunk render leaves none."""
+    L, S, R = api.L, api.S, api.R
+    from nerfpp_amd.train import Trainer
+    K = S.lego_K(100, 100); c2w = S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = R.GetRays(100, 100, K, c2w)
+    o = o.reshape(-1, 3)[::3][:3000].contiguous(); d = d.reshape(-1, 3)[::3][:3000].contiguous()
+    tgt = torch.rand((o.shape[0], 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    rp = R.NeRFRenderParams(NSamples=64, NImportance=128, Chunk=4096, Perturb=0.0, WhiteBkgr=False, Ndc=False, UseViewdirs=True, ThinRay=True, BoundingBox=S.LEGO_BBOX,
+                            Precision=L.NRF_PREC_F16_SPLIT, ReturnRaw=True, KeepIntermediates="depths")          # (what Trainer.step asks for)
+    grads = {}
+    # (the fused backward adds its workgroups' weight-gradient tiles with float atomics: two calls on the same inputs agree to the last bits of the sum, not bit for bit)
+    same = lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    for reuse in (True, False):
+        sc = S.make_hash_scene(mode="cu", log2_t=14, table_amp=1e-2, sigma_scale=4.0)
+        tr = Trainer(sc["embedder"], sc["embeddirs"], sc["mlp"], sc["table"], sc["mlp_blob"], learning_rate=5e-4, mlp_backward="f16", hash_backward="binned")
+        tr.reuse_render_features = reuse
+        res = tr.renderer.Render(0, 0, None, rp, rays=(o, d, None))
+        assert res.FeatureView is not None and res.FeatureView["n"] == o.shape[0] and res.FeatureView["sf"] == 192
+        lm = tr.backward(res, tgt, 192, False, params=rp)
+        assert tr.reused_render_features is reuse
+        grads[reuse] = (tr.g_blob.clone(), tr.g_table.clone(), host(lm).copy())
+        if reuse:
+            # a render in between: the view in `res` is stale, the backward falls back to encoding the points (same gradients again)
+            tr.renderer.Render(0, 0, None, rp, rays=(o[:100], d[:100], None))
+            tr.backward(res, tgt, 192, False, params=rp)
+            assert tr.reused_render_features is False and same(tr.g_blob, grads[True][0]) and same(tr.g_table, grads[True][1])
+            # two chunks: no view
+            rp2 = R.NeRFRenderParams(**{**rp.__dict__, "Chunk": 2048})
+            assert tr.renderer.Render(0, 0, None, rp2, rays=(o, d, None)).FeatureView is None
+    assert np.array_equal(grads[True][2], grads[False][2])
+    assert same(grads[True][0], grads[False][0]) and same(grads[True][1], grads[False][1])
+    assert float(grads[True][0].abs().max()) > 0 and float(grads[True][1].abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_training_step_with_an_overflowed_fp16_backward_is_skipped_on_the_device(api):
     """Trainer.step with the fused fp16 backward no longer waits for the chain's overflow words in the middle of the step: the optimizer step is nrf_adam_step_guarded --
     the kernel itself returns when either word is set -- and the host reads the words (copied to pinned memory behind the backward) before the NEXT step begins.  A batch
