@@ -1056,6 +1056,8 @@ public:
 	/// arithmetic of the training backward: -1 (default) follows the render precision -- the fused fp16 matrix-core chain unless the renderer is in NRF_PREC_F32;
 	/// 0: always the fp32 layer kernels (the reference-pinned parity path); 1: the fp16 chain whenever the network is of the fused kernel's family
 	int TrainBackwardArithmetic = -1;
+	bool ReuseRenderFeatures = true;                    ///the fused backward reads the hash features the forward render left in the workspace (nrf_renderer_last_features) when it can
+	bool ReusedRenderFeatures = false;                  ///... and whether the last backward did
 	int64_t F16BackwardOverflows = 0;                   ///steps whose fp16 chain reported a non-finite value and were redone in fp32
 	bool WantsF16Backward() const { return TrainBackwardArithmetic == 1 || (TrainBackwardArithmetic == -1 && Precision != NRF_PREC_F32); }
 	void SetSeed(uint64_t seed) { Seed = seed; }
@@ -1133,6 +1135,7 @@ public:
 	// ---- the training render: NeRFRenderer::Render on a ray batch as ONE autograd node (NeRFExecutor.h:876-923: Render -> huber_loss -> loss.backward()) ----
 	struct TrainState {           // what the backward needs besides the saved tensors
 		HipNeRFRenderer *self; int s; bool fine; bool white_bkgr; float noise_std, precond_alpha, cone_angle; bool has_cone; uint64_t seed; std::vector<float> bbox;
+		int64_t view_serial = -1;          // nrf_renderer_last_features' serial right after the forward's render (-1: it left no feature view)
 	};
 	/// forward: rays_ [n, 8 | 11] -> {rgb, disp, acc, depth, weights | empty, raw}; gradients flow to `table` and `blob` from d loss / d rgb only (the fine pass:
 	/// z_samples are detached, NeRFRenderer.h:429; disparity / accumulation / depth / weights / raw are marked non-differentiable -- the reference's loss reads RGBMap, :882-887)
@@ -1164,6 +1167,13 @@ public:
 				check(nrf_batchify_rays(self->Renderer, rays_.data_ptr<float>(), stride, n, rp.Chunk, &p, t.data_ptr<float>(), u.defined() ? u.data_ptr<float>() : nullptr, &ro,
 					self->workspace(wsb, rays_.device()), wsb, current_stream()), "nrf_batchify_rays");
 			}
+			{
+				// the hash features the render has just left in the workspace (a single-chunk render of the feature-reusing fast path): the backward reads them instead of
+				// encoding the fine points again, provided the renderer has rendered nothing in between (same serial)
+				const void *f = nullptr; const uint8_t *k = nullptr; const int32_t *sr = nullptr; int64_t cols = 0, vn = 0; int vsf = 0; uint64_t serial = 0;
+				const int rcv = n > 0 ? nrf_renderer_last_features(self->Renderer, &f, &cols, &k, &sr, &vn, &vsf, &serial) : NRF_ERR_UNSUPPORTED;
+				ctx->saved_data["view_serial"] = (rcv == NRF_OK && vn == n && vsf == so) ? (int64_t)serial : (int64_t)-1;
+			}
 			ctx->save_for_backward({rays_, raw, z});
 			// the backward's state as plain values in the node itself (no heap object to leak when the graph is dropped without a backward, nothing consumed by a backward:
 			// retain_graph works); the renderer is looked up in the registry of live ones, so a backward after its destruction fails loudly instead of dereferencing it
@@ -1187,7 +1197,7 @@ public:
 			TORCH_CHECK(self_i != 0 && nrfpp::live_renderers().alive(reinterpret_cast<const void *>(self_i)),
 				"HipNeRFRenderer: backward through a Render() whose renderer has been destroyed");
 			TrainState st{reinterpret_cast<HipNeRFRenderer *>(self_i), (int)sd["s"].toInt(), sd["fine"].toBool(), sd["white_bkgr"].toBool(), (float)sd["noise_std"].toDouble(),
-				(float)sd["precond_alpha"].toDouble(), (float)sd["cone_angle"].toDouble(), sd["has_cone"].toBool(), (uint64_t)sd["seed"].toInt(), {}};
+				(float)sd["precond_alpha"].toDouble(), (float)sd["cone_angle"].toDouble(), sd["has_cone"].toBool(), (uint64_t)sd["seed"].toInt(), {}, sd["view_serial"].toInt()};
 			for (double v : sd["bbox"].toDoubleVector()) st.bbox.push_back((float)v);
 			auto saved = ctx->get_saved_variables();
 			auto [g_table, g_blob] = st.self->TrainBackward(st, saved[0], saved[1], saved[2], grads[0], sd["table_sizes"].toIntVector(), sd["blob_numel"].toInt());
@@ -1289,12 +1299,23 @@ public:
 				int rc;
 				const bool lm = this->EmbedFn->Mode == NRF_HASH_CU && this->EmbedFn->NLevels == 16 && this->EmbedFn->NFeaturesPerLevel == 2 && dirs.defined() && dirs.size(1) == 16;
 				if (lm) {
-					auto feats = torch::empty({16, n * s, 2}, opt.dtype(torch::kFloat16));
-					check(nrf_hash_encode_lm_f16(h, pts.data_ptr<float>(), n * s, feats.data_ptr(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16");
-					check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
 					auto dirs16 = dirs.to(torch::kFloat16).contiguous();
-					rc = nrf_mlp_backward_f16_lm(Mlp.m, feats.data_ptr(), dirs16.data_ptr(), s, g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(),
-						TrainWorkspace.data_ptr(), wsb, current_stream());
+					// the forward render's own features where they are still in the workspace (TrainState::view_serial), else a second encode of the fine points
+					const void *vf = nullptr; const uint8_t *vk = nullptr; const int32_t *vs = nullptr; int64_t vcols = 0, vn = 0; int vsf = 0; uint64_t serial = 0;
+					const bool view = ReuseRenderFeatures && st.view_serial >= 0 && st.fine && !st.has_cone && st.precond_alpha == 0.f &&
+						nrf_renderer_last_features(Renderer, &vf, &vcols, &vk, &vs, &vn, &vsf, &serial) == NRF_OK && (int64_t)serial == st.view_serial && vn == n && vsf == s;
+					ReusedRenderFeatures = view;
+					if (view) {
+						check(nrf_mask_sigma_grad_src(vk, vs, n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad_src");
+						rc = nrf_mlp_backward_f16_lm_src(Mlp.m, vf, vcols, vs, dirs16.data_ptr(), s, g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(),
+							TrainWorkspace.data_ptr(), wsb, current_stream());
+					} else {
+						auto feats = torch::empty({16, n * s, 2}, opt.dtype(torch::kFloat16));
+						check(nrf_hash_encode_lm_f16(h, pts.data_ptr<float>(), n * s, feats.data_ptr(), keep.data_ptr<uint8_t>(), current_stream()), "nrf_hash_encode_lm_f16");
+						check(nrf_mask_sigma_grad(keep.data_ptr<uint8_t>(), n * s, 4, g_raw.data_ptr<float>(), current_stream()), "nrf_mask_sigma_grad");
+						rc = nrf_mlp_backward_f16_lm(Mlp.m, feats.data_ptr(), dirs16.data_ptr(), s, g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(),
+							TrainWorkspace.data_ptr(), wsb, current_stream());
+					}
 				} else {
 					torch::Tensor x = fp32_input();
 					rc = nrf_mlp_backward_f16(Mlp.m, x.data_ptr<float>(), g_raw.data_ptr<float>(), n * s, g_blob.data_ptr<float>(), g_x.data_ptr<float>(), TrainWorkspace.data_ptr(), wsb,
