@@ -3559,11 +3559,13 @@ def test_end_to_end_training_run_measurement(api):
 
 
 # ------------------------------------------------------------------------------------------- round 6: bf16x3 split-precision training products
-@pytest.mark.parametrize("M,N,K", [(70000, 256, 256), (33000, 256, 160), (5000, 128, 283), (4097, 33, 256), (777, 70, 63), (300, 3, 128)])
+@pytest.mark.parametrize("M,N,K", [(70000, 256, 256), (33000, 256, 160), (5000, 128, 283), (4097, 33, 256), (777, 70, 63), (300, 3, 128),
+                                   (5461, 768, 256), (70001, 33, 256), (66000, 128, 128), (40000, 256, 768)])
 def test_gemm_nt_bf16x3_vs_float64(api, M, N, K):
     """nrf_gemm_nt_bf16x3 / nrf_gemm_nt_f16x3 (gemm_bf16x3.hip: every fp32 operand as hi + lo bf16, or as hi + lo fp16 of power-of-two scaled rows; three matrix-core
     products per fp32 accumulator) against the float64 product: within 2e-5 (bf16; measured 5e-6) / 2e-6 (fp16; measured 5e-7, torch's fp32 product 8e-7) of the largest
-    entry, bias + ReLU epilogue included; ragged M / N / K (row, column and K-tile tails), the whole-row kernel's shapes (K in {128, 160, 256}, N > 128) and the generic one's."""
+    entry, bias + ReLU epilogue included; ragged M / N / K (row, column and K-tile tails), the whole-row (persistent) kernel's shapes (K in {128, 160, 256}; N > 128, three
+    column blocks at N = 768, and the narrow products N = 33 / 128 that take its 256-wide tile once M >= 65 536) and the generic one's (K = 768: 24 K tiles)."""
     L = api.L
     g = torch.Generator(device="cuda"); g.manual_seed(M + N + K)
     a = torch.randn((M, K), device="cuda", generator=g); b = torch.randn((N, K), device="cuda", generator=g) * 0.1; bias = torch.randn((N,), device="cuda", generator=g)
