@@ -209,9 +209,9 @@ __device__ __forceinline__ void gb_store_b(unsigned char *b_base, int b_half, in
 // when ldc == N) instead of 128-byte pieces of rows 1 KB apart (the same DRAM-page argument as for the A burst).  Row stride 260 floats: the two half-waves of an
 // accumulator register write rows 4 apart, 4 x 1040 bytes = 64 bytes off in the banks.  The inverse scales (F16), the bias, the ReLU and the mask are applied at the
 // write-out, once per row and four columns at a time, not per accumulator register.  All waves must be past their last LDS read of the K loop (a barrier) on entry.
-template <bool F16>
-__device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N,
-                                                 const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h)
+// accumulators (NI row tiles of 32 from row `row0` of the block x the wave's 64 columns) -> the C block's LDS image
+template <int NI>
+__device__ __forceinline__ void gb_stage_c(const gb_f32x16 (&acc)[NI][2], unsigned char *smem, int row0, int wn, int r, int h)
 {
     constexpr int CS = GbCfg<4>::BN + 4;
     float *ct = reinterpret_cast<float *>(smem);
@@ -219,12 +219,20 @@ __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], u
     for (int j = 0; j < 2; j++) {
         const int nl = wn * 64 + j * 32 + r;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) ct[(wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + nl] = acc[i][j][q];
+            for (int q = 0; q < 16; q++) ct[(row0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + nl] = acc[i][j][q];
     }
-    __syncthreads();
-    const int c4 = (t & 63) * 4, rw = t >> 6;                             // this thread's four columns; rows rw, rw + 8, ...
+}
+
+// the staged C block -> memory as whole rows, by `NW` waves (thread th of 64 NW): inverse scales, bias, ReLU, mask at the write-out
+template <bool F16, int NW, int BM = GB_BM>
+__device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N, const float *__restrict__ bias, int relu,
+                                             const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int th)
+{
+    constexpr int CS = GbCfg<4>::BN + 4;
+    const float *ct = reinterpret_cast<const float *>(smem);
+    const int c4 = (th & 63) * 4, rw = th >> 6;
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!mask || (((mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
     float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (bias) {
@@ -232,13 +240,12 @@ __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], u
         for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < N) bias4[jj] = bias[n0 + c4 + jj];
     }
 #pragma unroll 4
-    for (int i = 0; i < GB_BM / 8; i++) {
-        const int ml = rw + 8 * i;
+    for (int i = 0; i < BM / NW; i++) {
+        const int ml = rw + NW * i;
         const int64_t m = m0 + ml;
         const int n = n0 + c4;
         if (m >= M || n >= N) continue;
         float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
-        // (rs x binv in one factor: the two inverse powers of two together leave fp32's normal range only where the product itself does)
         if (F16) { const float rs = rinv[ml] * binv; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
         v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
         if (relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
@@ -257,6 +264,15 @@ __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], u
             }
         }
     }
+}
+
+template <bool F16>
+__device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N,
+                                                 const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h)
+{
+    gb_stage_c<2>(acc, smem, wm * 64, wn, r, h);
+    __syncthreads();
+    gb_readout_c<F16, 8>(smem, rinv, binv, c, ldc, M, N, bias, relu, mask, mask_ld, m0, n0, t);
 }
 
 constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
@@ -411,13 +427,28 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
     }
 }
 
+#ifdef NRF_GB_TRACE
+// diagnostic build only (tools/scratch/gemm_trace.py): clock stamps of waves 0 and 7 of every workgroup of k_gemm_nt_rows, summed per section
+__device__ unsigned long long g_gb_trace[256 * 2 * 16];
+#define NRF_GSTAMP(i) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr[i] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define NRF_GSTAMP(i) do { } while (0)
+#endif
+
 // The same product with the WHOLE A block of the workgroup (128 rows x K <= 256 columns: one contiguous 128 KB of a [M][K] array) requested in one burst at kernel
 // start: with K tiles of 32 requested one by one every row is visited eight times, 128 bytes at a time, microseconds apart -- DRAM pages are re-opened for each piece and
 // the A stream (what bounds this product: 64 flop per byte at N = K = 256) moved ~2 TB/s for this kernel and for rocBLAS's alike (profiles/round6/r6m_gemm_probe.log).
 // TK = K / 32 tiles live in 8 TK registers per thread; B (the weights, L2-resident) is streamed per tile as before.  One segment, K a multiple of 32, 16-byte aligned rows.
+// NRF_GB_ABL (diagnostic builds only, tools/scratch/gemm_ablate.sh; results are garbage): parts of this kernel left out to see what its time is made of.
+//   1 no multiply (fragment reads + matrix instructions)   2 no epilogue   4 epilogue staged in LDS but not written out   8 A not split / stored to LDS
+//   16 B tiles neither loaded nor stored   32 A not loaded   64 matrix instructions left out, fragment reads kept
+#ifndef NRF_GB_ABL
+#define NRF_GB_ABL 0
+#endif
 template <int TK, bool F16>
 __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 {
+    constexpr int ABL = NRF_GB_ABL;
     using Cfg = GbCfg<4>;
     using T8 = typename GbT<F16>::v8;
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_smem[];
@@ -436,8 +467,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
     // once store_tile(k) has split them), so the prefetch costs no register -- and the C block of the current tile leaves while the next one's loads are in flight.
     // the A rows of an output tile as per-thread pointers (row rq + RSTEP i, columns 4 kq ..): computed once per output tile, the K tiles are immediate offsets
     const float *ap0[Cfg::QA], *ap1[Cfg::QA];
-    auto point_a = [&](int64_t b) {
-        const int64_t m0b = (b / nblocks_n) * GB_BM;
+    auto point_a = [&](int64_t b) {          // (tile numbers fit 31 bits: a 32-bit division, not the 64-bit one's ~1 us per output tile)
+        const int64_t m0b = (int64_t)((uint32_t)b / (uint32_t)nblocks_n) * GB_BM;
 #pragma unroll
         for (int i = 0; i < Cfg::QA; i++) {
             const int64_t m = m0b + rq + Cfg::RSTEP * i;
@@ -448,7 +479,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
     };
     auto issue_a = [&](int tile) {          // K tile `tile` of the pointed-at rows -> ra[tile][*] (segment 0's K tiles, then segment 1's)
 #pragma unroll
-        for (int i = 0; i < Cfg::QA; i++) ra[tile][i] = *reinterpret_cast<const float4 *>(tile < t0 ? ap0[i] + tile * GB_BK : ap1[i] + (tile - t0) * GB_BK);
+        for (int i = 0; i < Cfg::QA; i++) {
+            if (ABL & 32) ra[tile][i] = float4{1.0f + tile, 2.0f, 3.0f + i, 4.0f};
+            else ra[tile][i] = *reinterpret_cast<const float4 *>(tile < t0 ? ap0[i] + tile * GB_BK : ap1[i] + (tile - t0) * GB_BK);
+        }
     };
     int64_t bid = blockIdx.x;
     if (bid < total) {
@@ -457,16 +491,22 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         for (int tile = 0; tile < TK; tile++) issue_a(tile);
     }
     float *rinv = reinterpret_cast<float *>(gb_smem + GB_ROWS_LDS_BASE);
+#ifdef NRF_GB_TRACE
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tstart = __builtin_readcyclecounter();
+    unsigned long long tprev = tstart;
+#endif
     for (; bid < total; bid += gridDim.x) {
-        const int64_t mb = bid / nblocks_n;
+        const int64_t mb = (int64_t)((uint32_t)bid / (uint32_t)nblocks_n);
         const int nb = (int)(bid - mb * nblocks_n);
         const int64_t m0 = mb * GB_BM;
         const int n0 = nb * Cfg::BN;
         const int64_t nbid = bid + gridDim.x;
         const bool has_next = nbid < total;
         if (has_next) point_a(nbid);
+        NRF_GSTAMP(0);
         // (B's columns run straight through both segments)
-        auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
+        auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { if (!(ABL & 16)) gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
         // F16: the row's whole K sits in the eight threads (kq) of the row: its largest entry is 8 TK maxima and three lane exchanges away
         float as[Cfg::QA], binv = 1.0f;
 #pragma unroll
@@ -488,8 +528,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
             unsigned char *base = gb_smem + stage * Cfg::STAGE;
             const int ks = kq >> 2;
 #pragma unroll
-            for (int i = 0; i < Cfg::QA; i++) gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
-            gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
+            for (int i = 0; i < Cfg::QA; i++) {
+                if (ABL & 8) { if (a[i].x == 12345.678f) base[t] = 1; }      // (keeps the loads alive)
+                else gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
+            }
+            if (!(ABL & 16)) gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
         };
         gb_f32x16 acc[2][2];
 #pragma unroll
@@ -499,6 +542,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
         auto multiply = [&](int stage) {
+            if (ABL & 1) return;
             const unsigned char *base = gb_smem + stage * Cfg::STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -516,29 +560,53 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
+                        if (ABL & 64) {                                     // fragment reads without the matrix instructions
+                            const gb_u32x4 x = __builtin_bit_cast(gb_u32x4, al[i]) ^ __builtin_bit_cast(gb_u32x4, bh[j]) ^ __builtin_bit_cast(gb_u32x4, ah[i]) ^ __builtin_bit_cast(gb_u32x4, bl[j]);
+                            acc[i][j][0] += __uint_as_float(x[0] ^ x[1] ^ x[2] ^ x[3]);
+                            continue;
+                        }
                         acc[i][j] = GbT<F16>::mfma(al[i], bh[j], acc[i][j]);
                         acc[i][j] = GbT<F16>::mfma(ah[i], bl[j], acc[i][j]);
                         acc[i][j] = GbT<F16>::mfma(ah[i], bh[j], acc[i][j]);
                     }
             }
         };
+        NRF_GSTAMP(1);                  // (F16: the row maxima = the wait for the whole A block)
         load_b(0, rb0);
         if (TK > 1) load_b(1, rb1);
         store_tile(0, ra[0], rb0);
+        NRF_GSTAMP(2);
         __syncthreads();
+        NRF_GSTAMP(3);
 #pragma unroll
         for (int tile = 0; tile < TK; tile++) {
             // B of tile + 2 into the set that tile's store has freed
             if (tile + 2 < TK) { if (tile & 1) load_b(tile + 2, rb1); else load_b(tile + 2, rb0); }
             multiply(tile & 1);
+            NRF_GSTAMP(4);
             if (tile + 1 < TK) { if (tile & 1) store_tile(0, ra[tile + 1 < TK ? tile + 1 : 0], rb0); else store_tile(1, ra[tile + 1 < TK ? tile + 1 : 0], rb1); }
             // ra[tile] went to LDS one iteration ago (tile 0: before the loop): the next output tile's K tile `tile` into it
             if (has_next) issue_a(tile);
+            NRF_GSTAMP(5);
             __syncthreads();
+            NRF_GSTAMP(3);
         }
-        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
+        if (ABL & 2) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 12345.678f) g.c[t] = 1.0f; }
+        else {
+            gb_stage_c<2>(acc, gb_smem, wm * 64, wn, r, h);
+            NRF_GSTAMP(6);
+            __syncthreads();
+            NRF_GSTAMP(7);
+            gb_readout_c<F16, 8>(gb_smem, rinv, binv, g.c, g.ldc, (ABL & 4) ? (int64_t)(g.N < 0) : g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t);
+            NRF_GSTAMP(8);
+        }
         __syncthreads();          // the C block staged in LDS is read out: the next tile's stages may overwrite it
+        NRF_GSTAMP(9);
     }
+#ifdef NRF_GB_TRACE
+    tr[15] = __builtin_readcyclecounter() - tstart;
+    if ((wave == 0 || wave == 7) && lane == 0) for (int i = 0; i < 16; i++) g_gb_trace[((blockIdx.x & 255) * 2 + (wave ? 1 : 0)) * 16 + i] += tr[i];
+#endif
 }
 
 
@@ -999,6 +1067,15 @@ int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B
 }
 
 }  // namespace nrf
+
+#ifdef NRF_GB_TRACE
+extern "C" NRF_API int nrf_dbg_gb_trace(unsigned long long *host_out, int reset)
+{
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nrf::g_gb_trace), sizeof(unsigned long long) * 256 * 2 * 16) != hipSuccess) return NRF_ERR_HIP;
+    if (reset) { static unsigned long long z[256 * 2 * 16]; if (hipMemcpyToSymbol(HIP_SYMBOL(nrf::g_gb_trace), z, sizeof(z)) != hipSuccess) return NRF_ERR_HIP; }
+    return NRF_OK;
+}
+#endif
 
 // -1: by network family (the default); 0: the training paths' forward / back-propagation products run as fp32 products (rocBLAS sgemm or mlp.hip's kernels); 1: as bf16x3,
 // 2: as f16x3 (scaled) split-precision matrix-core GEMMs (this file)
