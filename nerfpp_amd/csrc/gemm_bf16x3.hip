@@ -99,6 +99,7 @@ struct GemmNT {
     int64_t M; int N;
     const float *bias; int relu;
     const float *mask; int mask_ld;       // optional [M][mask_ld]: C = mask > 0 ? C : 0
+    const float *add; int add_ld;         // optional [M][add_ld]: C = (C after bias / ReLU / mask) + add  (a gradient that reaches the same tensor along a second path)
     int va0, va1;                         // widest aligned vector load of each A segment: 4, 2 or 1 floats
     const uint32_t *bmax;                 // F16 arithmetic: bits of the largest |B| entry (k_gb_absmax)
     const unsigned char *bimg;            // B already split (k_gb_split_b): [hi | lo][K tile][k-step][npad rows][16 elements], i.e. the kernels' LDS image tile by tile
@@ -228,12 +229,13 @@ __device__ __forceinline__ void gb_stage_c(const gb_f32x16 (&acc)[NI][2], unsign
 // the staged C block -> memory as whole rows, by `NW` waves (thread th of 64 NW): inverse scales, bias, ReLU, mask at the write-out
 template <bool F16, int NW, int BM = GB_BM>
 __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N, const float *__restrict__ bias, int relu,
-                                             const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int th)
+                                             const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int th, const float *__restrict__ add = nullptr, int add_ld = 0)
 {
     constexpr int CS = GbCfg<4>::BN + 4;
     const float *ct = reinterpret_cast<const float *>(smem);
     const int c4 = (th & 63) * 4, rw = th >> 6;
-    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!mask || (((mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!mask || (((mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0))) &&
+                        (!add || (((add_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(add) & 15) == 0)));
     float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (bias) {
 #pragma unroll
@@ -254,12 +256,14 @@ __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const fl
                 const float4 k = *reinterpret_cast<const float4 *>(mask + m * mask_ld + n);
                 v.x = k.x > 0.0f ? v.x : 0.0f; v.y = k.y > 0.0f ? v.y : 0.0f; v.z = k.z > 0.0f ? v.z : 0.0f; v.w = k.w > 0.0f ? v.w : 0.0f;
             }
+            if (add) { const float4 k = *reinterpret_cast<const float4 *>(add + m * add_ld + n); v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w; }
             *reinterpret_cast<float4 *>(c + m * ldc + n) = v;
         } else {
             const float e[4] = {v.x, v.y, v.z, v.w};
             for (int jj = 0; jj < 4 && n + jj < N; jj++) {
                 float x = e[jj];
                 if (mask) x = mask[m * mask_ld + n + jj] > 0.0f ? x : 0.0f;
+                if (add) x += add[m * add_ld + n + jj];
                 c[m * ldc + n + jj] = x;
             }
         }
@@ -268,11 +272,12 @@ __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const fl
 
 template <bool F16>
 __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N,
-                                                 const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h)
+                                                 const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h,
+                                                 const float *__restrict__ add = nullptr, int add_ld = 0)
 {
     gb_stage_c<2>(acc, smem, wm * 64, wn, r, h);
     __syncthreads();
-    gb_readout_c<F16, 8>(smem, rinv, binv, c, ldc, M, N, bias, relu, mask, mask_ld, m0, n0, t);
+    gb_readout_c<F16, 8>(smem, rinv, binv, c, ldc, M, N, bias, relu, mask, mask_ld, m0, n0, t, add, add_ld);
 }
 
 constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
@@ -403,7 +408,7 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
         __syncthreads();
     }
     if (WNW == 4) {          // whole rows through LDS, as the burst kernel's
-        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h);
+        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h, g.add, g.add_ld);
         return;
     }
     // epilogue: register q of lane (r, h) of tile (i, j) is C[m0 + 64 wm + 32 i + (q & 3) + 8 (q >> 2) + 4 h][n0 + 64 wn + 32 j + r]
@@ -422,6 +427,7 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
                 float v = (F16 ? acc[i][j][q] * rinv[ml] * binv : acc[i][j][q]) + bias;
                 if (g.relu) v = v > 0.0f ? v : 0.0f;
                 if (g.mask) v = g.mask[m * g.mask_ld + n] > 0.0f ? v : 0.0f;
+                if (g.add) v += g.add[m * g.add_ld + n];
                 g.c[m * g.ldc + n] = v;
             }
     }
@@ -597,7 +603,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
             NRF_GSTAMP(6);
             __syncthreads();
             NRF_GSTAMP(7);
-            gb_readout_c<F16, 8>(gb_smem, rinv, binv, g.c, g.ldc, (ABL & 4) ? (int64_t)(g.N < 0) : g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t);
+            gb_readout_c<F16, 8>(gb_smem, rinv, binv, g.c, g.ldc, (ABL & 4) ? (int64_t)(g.N < 0) : g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, g.add, g.add_ld);
             NRF_GSTAMP(8);
         }
         __syncthreads();          // the C block staged in LDS is read out: the next tile's stages may overwrite it
@@ -1053,14 +1059,14 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
 
 // C = cat[a, b] . B^T (+ bias)(ReLU)(mask): B [N][ldb] holds the columns of segment a first, then segment b's.  arithmetic: 1 = bf16x3, 2 = f16x3 (scaled)
 int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
-                  hipStream_t st)
+                  hipStream_t st, const float *add, int add_ld)
 {
     if (M <= 0 || N <= 0) return NRF_OK;
     GemmNT g{};
     g.a0 = a.p ? a.p + a.off : nullptr; g.lda0 = a.stride; g.k0 = a.p ? a.n : 0;
     g.a1 = (b.p && b.n > 0) ? b.p + b.off : nullptr; g.lda1 = b.stride; g.k1 = g.a1 ? b.n : 0;
     if (g.k0 == 0 && g.k1 > 0) { g.a0 = g.a1; g.lda0 = g.lda1; g.k0 = g.k1; g.a1 = nullptr; g.k1 = 0; }
-    g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld;
+    g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld; g.add = add; g.add_ld = add_ld;
     g.va0 = g.a0 ? vec_class(g.a0, g.lda0, 0) : 1;
     g.va1 = g.a1 ? vec_class(g.a1, g.lda1, 0) : 1;
     return arithmetic == 2 ? gemm_nt_launch<true>(g, B, ldb, st) : gemm_nt_launch<false>(g, B, ldb, st);

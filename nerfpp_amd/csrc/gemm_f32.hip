@@ -171,14 +171,81 @@ int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *d
     return NRF_OK;
 }
 
+// The back-propagation through a layer with FEW outputs (the LeRF sigma net's last layer: 33), y[p][n] = sum_{o < K} g[p][o] W[o][n] (. mask): as a matrix-core
+// product its K is one ragged tile and a half (0.68 ms per 786 432 points through the generic tile kernel, most of it clamped loads of columns that do not exist);
+// as plain fp32 FMAs it is 64 K per thread and 64-point tile, hidden behind the 1 KB row stores it exists to produce.  W [K][N] and the tile's g rows sit in LDS; a
+// wave owns rows (one instruction = one whole 1 KB row), a lane four columns; the g value of a (row, o) is an LDS broadcast.  Deterministic, exact fp32.
+__global__ void __launch_bounds__(256) k_backprop_thin(int64_t P, int K, int N, const float *__restrict__ g, int ldg, const float *__restrict__ W, float *__restrict__ y, int ldy,
+                                                       const float *__restrict__ mask, int ldm)
+{
+    extern __shared__ __attribute__((aligned(16))) float bt_smem[];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float *sw = bt_smem, *sg = bt_smem + (size_t)K * N;
+    const int t = threadIdx.x, c4 = (t & 63) * 4, pg = t >> 6;
+    for (int i = t; i < K * N; i += 256) sw[i] = W[i];
+    const int64_t tiles = (P + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * 64;
+        __syncthreads();                                                   // (first pass: W is in; later: the previous tile's g rows are read)
+        for (int i = t; i < 64 * K; i += 256) {
+            const int pr = i / K, k = i - pr * K;
+            const int64_t p = p0 + pr;
+            sg[i] = p < P ? g[p * ldg + k] : 0.0f;
+        }
+        __syncthreads();
+        for (int nb = 0; nb < N; nb += 256) {
+            const int n = nb + c4;
+            if (n >= N) continue;
+            f2 acc[16][2];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { acc[j][0] = f2{0.0f, 0.0f}; acc[j][1] = f2{0.0f, 0.0f}; }
+            for (int k = 0; k < K; k++) {
+                const float4 w = *reinterpret_cast<const float4 *>(sw + (size_t)k * N + n);
+                const f2 w0 = {w.x, w.y}, w1 = {w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float gv = sg[(pg + 4 * j) * K + k];
+                    const f2 g2 = {gv, gv};
+                    acc[j][0] = __builtin_elementwise_fma(g2, w0, acc[j][0]);
+                    acc[j][1] = __builtin_elementwise_fma(g2, w1, acc[j][1]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int64_t p = p0 + pg + 4 * j;
+                if (p >= P) continue;
+                float4 v = {acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
+                if (mask) {
+                    const float4 m = *reinterpret_cast<const float4 *>(mask + p * ldm + n);
+                    v.x = m.x > 0.0f ? v.x : 0.0f; v.y = m.y > 0.0f ? v.y : 0.0f; v.z = m.z > 0.0f ? v.z : 0.0f; v.w = m.w > 0.0f ? v.w : 0.0f;
+                }
+                *reinterpret_cast<float4 *>(y + p * ldy + n) = v;
+            }
+        }
+    }
+}
+
+static bool rows16(const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
+
 // y[pt][k] = sum_o g[pt][o] W[o][k]
 bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts) { return npts >= 256 && train_gemm_for(m) != 0; }
 
-int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act, int mask_stride)
+int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act, int mask_stride, const float *add,
+                      int add_stride)
 {
-    if (const int arith = npts >= 256 ? train_gemm_for(m) : 0)          // G . W with W^T [in][out] as the K-contiguous second operand (L.d_wt, refreshed by every nrf_mlp_set_params)
-        return gemm_nt_split(arith, npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st);
-    if (mask_act) { set_error("internal: run_backprop_fast: the fused ReLU mask exists in bf16x3 mode only"); return NRF_ERR_INVALID_ARG; }
+    const int arith = npts >= 256 ? train_gemm_for(m) : 0;
+    static const bool thin_on = [] { const char *e = getenv("NRF_BACKPROP_THIN"); return !e || atoi(e) != 0; }();          // 0: the tile kernel for every shape (A/B)
+    const size_t thin_lds = ((size_t)L.out * L.in + (size_t)64 * L.out) * sizeof(float);
+    if (arith && !add && thin_on && L.out <= 48 && (L.in & 3) == 0 && thin_lds <= 64 * 1024 && rows16(y, y_stride) && (!mask_act || rows16(mask_act, mask_stride))) {
+        const int64_t tiles = ceil_div(npts, (int64_t)64);
+        hipLaunchKernelGGL(k_backprop_thin, dim3((unsigned)(tiles < 768 ? tiles : 768)), dim3(256), thin_lds, st, npts, L.out, L.in, g.p + g.off, g.stride,
+                           (const float *)(m->d_params + L.w_off), y, y_stride, mask_act, mask_stride);
+        NRF_LAUNCH_CHECK();
+        return NRF_OK;
+    }
+    if (arith)          // G . W with W^T [in][out] as the K-contiguous second operand (L.d_wt, refreshed by every nrf_mlp_set_params)
+        return gemm_nt_split(arith, npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st, add, add_stride);
+    if (mask_act || add) { set_error("internal: run_backprop_fast: the fused ReLU mask exists in bf16x3 mode only"); return NRF_ERR_INVALID_ARG; }
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_backprop(npts, g, m, L, y, y_stride, st);
     const float one = 1.0f, zero = 0.0f;

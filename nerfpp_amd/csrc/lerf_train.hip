@@ -557,6 +557,7 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
     float *freeb[2]; int nf = 0;
     for (int q = 1; q < 4 && nf < 2; q++) if (G[q] != g_x0) freeb[nf++] = G[q];
     int fi = 0;
+    bool emb_done = false;
     premasked = false;
     for (int l = nl - 1; l >= 0; l--) {
         const LinearLayer &L = m->layers[l];
@@ -565,10 +566,16 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         if (l == 0 && !g_emb) break;
         float *dst = freeb[fi]; fi ^= 1;
         premasked = fuse && l >= 1;                          // dst = d / d H[l - 1]
+        if (l == 0 && fuse) {
+            // d / d emb = through the sigma net + through the LE net's cat[geo, in]: the second path's gradient is added by the product's write-out, straight into g_emb
+            NRF_TRY(run_backprop_fast(c, g, m, L, g_emb, in, st, nullptr, 0, g_x0 + geo, W));
+            emb_done = true;
+            break;
+        }
         NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, premasked ? H[l - 1] : nullptr, W));
         g = Seg{dst, W, 0, L.in};
     }
-    if (g_emb) {                                                           // d / d emb = through the sigma net + through the LE net's cat[geo, in]
+    if (g_emb && !emb_done) {                                              // (fp32 products: the sum as a pass of its own)
         hipLaunchKernelGGL(k_lt_copy_cols, dim3((unsigned)ceil_div(c * in, 256)), dim3(256), 0, st, c, in, g.p, g.stride, 0, g_x0, W, geo, g_emb, in, 0);
         NRF_LAUNCH_CHECK();
     }
