@@ -744,6 +744,16 @@ NRF_API int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, cons
 NRF_API size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int64_t n, int s);
 NRF_API int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise,
                                      float noise_std, const float *d_g_rendered, float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream);
+/* Where the most recent render call on this LeRF renderer left the language features of its fine depths (as nrf_renderer_last_features; a call that rendered exactly ONE
+ * chunk): the level-major fp16 table [16][cols][8] (coarse columns first, the new samples' behind them), the keep mask by column, the merge map [n, sf].  They live in the
+ * caller's workspace: valid until the next render call on this renderer or any other use of that workspace.  NRF_ERR_UNSUPPORTED when the last call left none (serial is set
+ * either way).  nrf_lerf_backward_points_src: nrf_lerf_backward_points whose head backward reads those rows through the map instead of encoding d_pts again (the points must be
+ * the ones that render encoded: thin rays, no preconditioning); d_pts still feeds the grid's gradient scatter. */
+NRF_API int nrf_lerf_renderer_last_features(const nrf_lerf_renderer *r, const void **d_feats_lm, int64_t *cols, const uint8_t **d_keep_cols, const int32_t **d_src, int64_t *n, int *sf,
+                                            uint64_t *serial /* optional */);
+NRF_API int nrf_lerf_backward_points_src(const nrf_lerf_renderer *r, const void *d_feats_lm, int64_t cols, const uint8_t *d_keep_cols, const int32_t *d_src, const float *d_pts,
+                                         const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise, float noise_std, const float *d_g_rendered,
+                                         float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)

@@ -594,6 +594,8 @@ public:
 	HipLeRFPass &operator=(const HipLeRFPass &) = delete;
 	~HipLeRFPass() { live_renderers().remove(this); nrf_lerf_renderer_destroy(Pass); }
 	bool SingleCall = true;             ///< the pass as library calls (false: stage-composed below, for A/B tests)
+	bool ReuseRenderFeatures = true;    ///< the training backward reads the language features its forward render left in the workspace (nrf_lerf_renderer_last_features) when it can
+	bool ReusedRenderFeatures = false;  ///< ... and whether the last backward did
 
 	/// LeRFRenderer::SetLeRFPrompts (LeRFRenderer.h:86): [P, E] positive and [Q, E] negative phrase embeddings from the host's text encoder; undefined tensors clear them.
 	/// With prompts set every render fills Relevancy.
@@ -694,6 +696,11 @@ public:
 			}
 			ctx->save_for_backward({rays_, zf});
 			ctx->saved_data["self"] = self_i;
+			{	// where this render left the language features of its fine depths (a one-chunk call): the backward reads them if no render has touched the workspace since
+				const void *f = nullptr; const uint8_t *k = nullptr; const int32_t *sr = nullptr; int64_t cols = 0, vn = 0; int vsf = 0; uint64_t serial = 0;
+				const int rcv = n > 0 ? nrf_lerf_renderer_last_features(self->Pass, &f, &cols, &k, &sr, &vn, &vsf, &serial) : NRF_ERR_UNSUPPORTED;
+				ctx->saved_data["view_serial"] = (rcv == NRF_OK && vn == n && vsf == (int)(s + ni)) ? (int64_t)serial : (int64_t)-1;
+			}
 			ctx->saved_data["table_sizes"] = table.sizes().vec();
 			ctx->saved_data["blob_numel"] = blob.numel();
 			std::vector<torch::Tensor> nd{out.WeightsLE, out.DepthMapLE, out.DispMapLE, out.AccMapLE, zf};
@@ -718,6 +725,15 @@ public:
 				check(nrf_points(rays.data_ptr<float>(), stride, z.data_ptr<float>(), n, s, pts.data_ptr<float>(), current_stream()), "nrf_points");
 				const size_t wsb = nrf_lerf_backward_points_workspace_bytes(self->Pass, n, s);
 				auto ws = torch::empty({(int64_t)wsb}, opt.dtype(torch::kUInt8));          // not the pass's render workspace: a backward may run while another render is being issued
+				const void *vf = nullptr; const uint8_t *vk = nullptr; const int32_t *vs = nullptr; int64_t vcols = 0, vn = 0; int vsf = 0; uint64_t serial = 0;
+				const int64_t want = sd["view_serial"].toInt();
+				const bool view = self->ReuseRenderFeatures && want >= 0 && nrf_lerf_renderer_last_features(self->Pass, &vf, &vcols, &vk, &vs, &vn, &vsf, &serial) == NRF_OK &&
+					(int64_t)serial == want && vn == n && vsf == s;
+				self->ReusedRenderFeatures = view;
+				if (view)
+					check(nrf_lerf_backward_points_src(self->Pass, vf, vcols, vk, vs, pts.data_ptr<float>(), z.data_ptr<float>(), rays.data_ptr<float>() + 3, stride, n, s, nullptr, 0.f,
+						g.data_ptr<float>(), g_blob.data_ptr<float>(), g_table.data_ptr<float>(), ws.data_ptr(), wsb, current_stream()), "nrf_lerf_backward_points_src");
+				else
 				check(nrf_lerf_backward_points(self->Pass, pts.data_ptr<float>(), z.data_ptr<float>(), rays.data_ptr<float>() + 3, stride, n, s, nullptr, 0.f, g.data_ptr<float>(),
 					g_blob.data_ptr<float>(), g_table.data_ptr<float>(), ws.data_ptr(), wsb, current_stream()), "nrf_lerf_backward_points");
 			}

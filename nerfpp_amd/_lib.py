@@ -93,6 +93,7 @@ SYMBOLS = [
     "nrf_lerf_renderer_create", "nrf_lerf_renderer_destroy", "nrf_lerf_set_prompts", "nrf_lerf_render_rays_workspace_bytes", "nrf_lerf_render_rays",
     "nrf_lerf_batchify_rays_workspace_bytes", "nrf_lerf_batchify_rays", "nrf_lerf_render_rows_workspace_bytes", "nrf_lerf_render_rows",
     "nrf_fp32_gemm_available", "nrf_get_train_gemm", "nrf_set_train_gemm", "nrf_gemm_nt_bf16x3", "nrf_gemm_nt_f16x3", "nrf_gemm_tn_bf16x3", "nrf_layer_grad_split", "nrf_huber_rows_nanmean", "nrf_lerf_head_backward_workspace_bytes", "nrf_lerf_head_backward", "nrf_lerf_backward_points_workspace_bytes", "nrf_lerf_backward_points",
+    "nrf_lerf_renderer_last_features", "nrf_lerf_backward_points_src",
 ]
 NRF_COMM_ID_BYTES = 128
 

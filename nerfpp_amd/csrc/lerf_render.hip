@@ -52,6 +52,10 @@ struct nrf_lerf_renderer {
     mutable hipEvent_t flag_ev = nullptr;
     mutable bool flag_pending = false;
     mutable int64_t flagged_calls = 0;
+    // where the last chunk left the language features of its fine depths (nrf_lerf_renderer_last_features; as nrf_renderer's last_view): the level-major fp16 table
+    // [16][cols][8], the keep mask by column, the merge map [n, sf] -- in the caller's workspace; valid after a call that rendered exactly ONE chunk
+    mutable struct { const void *feats = nullptr; int64_t cols = 0; const uint8_t *keep = nullptr; const int32_t *src = nullptr; int64_t n = 0; int sf = 0; bool valid = false; } last_view;
+    mutable uint64_t chunk_serial = 0;
     void drop_lanes() const
     {
         for (auto &st : lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
@@ -272,6 +276,16 @@ extern "C" int nrf_view_check(const nrf_view *v, const char *who);
 extern "C" const nrf_hash *nrf_lerf_renderer_lang_embed(const nrf_lerf_renderer *r) { return r ? r->desc.lang_embed : nullptr; }
 extern "C" const nrf_mlp *nrf_lerf_renderer_head(const nrf_lerf_renderer *r) { return r ? r->desc.lerf : nullptr; }
 
+extern "C" NRF_API int nrf_lerf_renderer_last_features(const nrf_lerf_renderer *r, const void **d_feats_lm, int64_t *cols, const uint8_t **d_keep_cols, const int32_t **d_src, int64_t *n, int *sf,
+                                                       uint64_t *serial)
+{
+    NRF_CHECK_ARG(r && d_feats_lm && cols && d_keep_cols && d_src && n && sf, "nrf_lerf_renderer_last_features: null pointer");
+    if (serial) *serial = r->chunk_serial;
+    if (!r->last_view.valid) { set_error("nrf_lerf_renderer_last_features: the last render call left no feature view (several chunks, or none yet)"); return NRF_ERR_UNSUPPORTED; }
+    *d_feats_lm = r->last_view.feats; *cols = r->last_view.cols; *d_keep_cols = r->last_view.keep; *d_src = r->last_view.src; *n = r->last_view.n; *sf = r->last_view.sf;
+    return NRF_OK;
+}
+
 extern "C" {
 
 int nrf_lerf_relevancy(const float *d_embeds, int64_t n, int embed_dim, const float *d_positives, int n_pos, const float *d_negatives, int n_neg, int positive_id,
@@ -454,6 +468,8 @@ static int lerf_render_rays_impl(const nrf_lerf_renderer *r, const float *d_rays
     NRF_CHECK_ARG(n >= 0 && (ray_stride == 8 || ray_stride == 11), "nrf_lerf_render_rays: packed rays are [n, 8 | 11]");
     LerfPlan pl;
     NRF_TRY(lerf_plan(r, p, &pl, "nrf_lerf_render_rays"));
+    r->last_view.valid = false;          // (set again at the end of the chunk)
+    r->chunk_serial++;
     if (n == 0) return NRF_OK;
     NRF_CHECK_ARG(d_rays && d_t && d_u && d_workspace, "nrf_lerf_render_rays: null pointer");
     NRF_CHECK_ARG(n * (int64_t)pl.sf < ((int64_t)1 << 31), "nrf_lerf_render_rays: %lld rays x %d samples exceed the 2^31 columns of one chunk; lower Chunk", (long long)n, pl.sf);
@@ -514,6 +530,7 @@ static int lerf_render_rays_impl(const nrf_lerf_renderer *r, const float *d_rays
         if (out->d_relevancy)
             NRF_TRY(nrf_lerf_relevancy(emb, n, E, r->d_pos, r->n_pos, r->d_neg, r->n_neg, 0, out->d_relevancy, stream));     // LeRFRenderer.cpp:79 (one positive phrase)
     }
+    r->last_view.feats = x; r->last_view.cols = cols; r->last_view.keep = keep; r->last_view.src = src; r->last_view.n = n; r->last_view.sf = sf; r->last_view.valid = true;
     return NRF_OK;
 }
 
@@ -566,6 +583,7 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
                 (void)hipStreamSynchronize(lane[j]);
             }
         }
+        if (n > lc) r->last_view.valid = false;          // the view describes ONE chunk's workspace
         return (rc == NRF_OK && n > 0) ? lerf_flag_end(r, p, st, "nrf_lerf_batchify_rays") : rc;
     }
     for (int64_t i = 0; i < n; i += chunk) {                                                                                  // :206
@@ -573,6 +591,7 @@ int nrf_lerf_batchify_rays(const nrf_lerf_renderer *r, const float *d_rays, int 
         const nrf_lerf_outputs o = slice(*out, i, pl.s, pl.sf, pl.E);
         NRF_TRY(lerf_render_rays_impl(r, d_rays + i * ray_stride, ray_stride, mm, p, d_t, d_u, &o, d_workspace, workspace_bytes, stream, d_flag));
     }
+    if (n > chunk) r->last_view.valid = false;          // the view describes ONE chunk's workspace
     return n > 0 ? lerf_flag_end(r, p, as_stream(stream), "nrf_lerf_batchify_rays") : NRF_OK;
 }
 

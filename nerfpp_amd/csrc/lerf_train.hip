@@ -434,6 +434,24 @@ __global__ void k_lt_copy_cols(int64_t p, int ncols, const float *__restrict__ s
     dst[pt * d_stride + d_col + k] = v;
 }
 
+// emb[q][8 l .. 8 l + 8) = the eight fp16 features of level l in column src[q] of the level-major table [16][cols] (16 bytes each) as fp32; keep[q] = keep_cols[src[q]].
+// One thread per (point, level): the 16 threads of a point write its 512-byte row piece by piece, the reads of a level follow the (mostly ascending) map.
+__global__ void k_lt_gather_feats(int64_t c, const uint4 *__restrict__ feats, int64_t cols, const int32_t *__restrict__ src, const uint8_t *__restrict__ keep_cols, float *__restrict__ emb,
+                                  uint8_t *__restrict__ keep)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c * 16) return;
+    const int64_t q = idx >> 4; const int l = (int)(idx & 15);
+    const int64_t col = src[q];
+    const uint4 v = feats[(int64_t)l * cols + col];
+    const __half2 *hp = reinterpret_cast<const __half2 *>(&v);
+    const float2 a = __half22float2(hp[0]), b = __half22float2(hp[1]), d = __half22float2(hp[2]), e = __half22float2(hp[3]);
+    float4 *o = reinterpret_cast<float4 *>(emb + q * 128 + l * 8);
+    o[0] = float4{a.x, a.y, b.x, b.y};
+    o[1] = float4{d.x, d.y, e.x, e.y};
+    if (l == 0) keep[q] = keep_cols[col];
+}
+
 static size_t head_ws_bytes(const nrf_mlp *m, int64_t n, int s)
 {
     const int64_t cp = lt_chunk_pts(m, s);
@@ -665,8 +683,29 @@ size_t nrf_lerf_backward_points_workspace_bytes(const nrf_lerf_renderer *r, int6
     return head_ws_bytes(m, n, s) + 2 * align_up((size_t)c * in * sizeof(float), 256) + align_up((size_t)c, 256) + 1024;
 }
 
+static int lerf_backward_points_impl(const nrf_lerf_renderer *r, const void *d_feats_lm, int64_t cols, const uint8_t *d_keep_cols, const int32_t *d_src, const float *d_pts, const float *d_z,
+                                     const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise, float noise_std, const float *d_g_rendered, float *d_g_lerf_params,
+                                     float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream);
+
 int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise,
                              float noise_std, const float *d_g_rendered, float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    return lerf_backward_points_impl(r, nullptr, 0, nullptr, nullptr, d_pts, d_z, d_dirs, d_stride, n, s, d_noise, noise_std, d_g_rendered, d_g_lerf_params, d_g_table, d_workspace,
+                                     workspace_bytes, stream);
+}
+
+int nrf_lerf_backward_points_src(const nrf_lerf_renderer *r, const void *d_feats_lm, int64_t cols, const uint8_t *d_keep_cols, const int32_t *d_src, const float *d_pts, const float *d_z,
+                                 const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise, float noise_std, const float *d_g_rendered, float *d_g_lerf_params,
+                                 float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    NRF_CHECK_ARG(d_feats_lm && d_keep_cols && d_src && cols >= n * (int64_t)s, "nrf_lerf_backward_points_src: the feature view (table, keep mask by column, merge map) is incomplete");
+    return lerf_backward_points_impl(r, d_feats_lm, cols, d_keep_cols, d_src, d_pts, d_z, d_dirs, d_stride, n, s, d_noise, noise_std, d_g_rendered, d_g_lerf_params, d_g_table, d_workspace,
+                                     workspace_bytes, stream);
+}
+
+static int lerf_backward_points_impl(const nrf_lerf_renderer *r, const void *d_feats_lm, int64_t cols, const uint8_t *d_keep_cols, const int32_t *d_src, const float *d_pts, const float *d_z,
+                                     const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise, float noise_std, const float *d_g_rendered, float *d_g_lerf_params,
+                                     float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     NRF_CHECK_ARG(r && d_pts && d_z && d_dirs && d_g_rendered && d_g_lerf_params && d_g_table && n >= 0 && s >= 1, "nrf_lerf_backward_points: bad argument");
     const nrf_mlp *m = nrf_lerf_renderer_head(r);
@@ -685,6 +724,12 @@ int nrf_lerf_backward_points(const nrf_lerf_renderer *r, const float *d_pts, con
     for (int64_t r0 = 0; r0 < n; r0 += rays_per) {
         const int64_t rays = (n - r0) < rays_per ? (n - r0) : rays_per;
         const int64_t p0 = r0 * s, c = rays * s;
+        if (d_feats_lm) {          // the rows the forward render has just encoded, read through its merge map (fp16 values, as nrf_hash_encode's rows hold)
+            if (in != 128) { set_error("nrf_lerf_backward_points_src: the feature view is the L16 F8 grid's"); return NRF_ERR_INVALID_ARG; }
+            hipLaunchKernelGGL(nrf::k_lt_gather_feats, dim3((unsigned)nrf::ceil_div(c * 16, (int64_t)256)), dim3(256), 0, nrf::as_stream(stream), c, static_cast<const uint4 *>(d_feats_lm), cols,
+                               d_src + p0, d_keep_cols, emb, keep);
+            NRF_LAUNCH_CHECK();
+        } else
         NRF_TRY(nrf_hash_encode(h, d_pts + p0 * 3, c, emb, keep, stream));                                         // lang_embed_fn->forward (LeRFRenderer.cpp:34)
         NRF_TRY(nrf_lerf_head_backward(m, emb, keep, d_z + p0, d_dirs + r0 * d_stride, d_stride, rays, s, d_noise ? d_noise + p0 : nullptr, noise_std, d_g_rendered + r0 * E,
                                        d_g_lerf_params, g_emb, nullptr, nullptr, d_workspace, hb, stream));

@@ -673,7 +673,20 @@ class LeRFRenderer:
         L.check(lib.nrf_lerf_renderer_set_lanes(self._r, int(self.lanes)))          # this renderer's own lane count (default 1: see __init__)
         self._issue_single_call(lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d)
         res.Extras["rays_flat"] = rays_
+        res.FeatureView = self.feature_view() if c2w is None else None          # (ray-batch branch; None unless this call rendered exactly one chunk)
         return res
+
+    def feature_view(self):
+        """nrf_lerf_renderer_last_features: where the most recent one-chunk render left the language features of its fine depths in this renderer's workspace --
+        dict(feats, cols, keep, src: device addresses; n, sf; serial) or None.  Valid until the next render call on this renderer (LeRFTrainer.backward reads it)."""
+        if not getattr(self, "_r", None):
+            return None
+        fp, kp, sp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cols, nn, sf, ser = C.c_int64(), C.c_int64(), C.c_int(), C.c_uint64()
+        rc = L.lib().nrf_lerf_renderer_last_features(self._r, C.byref(fp), C.byref(cols), C.byref(kp), C.byref(sp), C.byref(nn), C.byref(sf), C.byref(ser))
+        if rc != 0:
+            return None
+        return dict(feats=fp.value, cols=int(cols.value), keep=kp.value, src=sp.value, n=int(nn.value), sf=int(sf.value), serial=int(ser.value))
 
     def _issue_single_call(self, lib, h, w, k, p, c2w, row0, rows, bb, rp, ro, res, rays_, t, u, workspace, f32, stride, n, o, d):
         if c2w is not None:

@@ -494,8 +494,21 @@ class LeRFTrainer:
         if self._ws is None or self._ws.numel() < nb:
             self._ws = torch.empty((int(nb),), device="cuda", dtype=torch.uint8)
         pts = pts.contiguous()
-        L.check(lib.nrf_lerf_backward_points(self.renderer._r, _ptr(pts), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), int(s), _ptr(noise), C.c_float(noise_std),
-                                             _ptr(g), _ptr(self.g_blob), _ptr(self.g_table), _ptr(self._ws), C.c_size_t(self._ws.numel()), _stream()))
+        # the language features of exactly these points are what the forward render has just encoded (thin rays, no preconditioning: pts = o + d z_fine): read them through
+        # its merge map instead of encoding the points again -- if `res` is that renderer's LAST render (same chunk serial) and a one-chunk one (nrf_lerf_renderer_last_features)
+        view = None
+        if getattr(self, "reuse_render_features", True) and cone_angle is None and not p.StochasticPreconditioningAlpha > 0:
+            mine, now = getattr(res, "FeatureView", None), self.renderer.feature_view()
+            if mine is not None and now is not None and mine["serial"] == now["serial"] and now["n"] == n and now["sf"] == s:
+                view = now
+        self.reused_render_features = view is not None
+        if view is not None:
+            L.check(lib.nrf_lerf_backward_points_src(self.renderer._r, C.c_void_p(view["feats"]), C.c_int64(view["cols"]), C.c_void_p(view["keep"]), C.c_void_p(view["src"]), _ptr(pts),
+                                                     _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), int(s), _ptr(noise), C.c_float(noise_std), _ptr(g),
+                                                     _ptr(self.g_blob), _ptr(self.g_table), _ptr(self._ws), C.c_size_t(self._ws.numel()), _stream()))
+        else:
+            L.check(lib.nrf_lerf_backward_points(self.renderer._r, _ptr(pts), _ptr(z), C.c_void_p(rays.data_ptr() + 12), stride, C.c_int64(n), int(s), _ptr(noise),
+                                                 C.c_float(noise_std), _ptr(g), _ptr(self.g_blob), _ptr(self.g_table), _ptr(self._ws), C.c_size_t(self._ws.numel()), _stream()))
         self.last = dict(g_rendered=g, pts=pts)
         return loss
 

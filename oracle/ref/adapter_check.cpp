@@ -152,7 +152,7 @@ static int run_train_lerf()
 {
 	if (!torch::cuda::is_available()) { printf("{\"train_lerf_ok\": false, \"error\": \"no GPU\"}\n"); return 2; }
 	std::string note = "ok";
-	bool ok = false, inference_sees_updates = false, grads_ok = false;
+	bool ok = false, inference_sees_updates = false, grads_ok = false, reused_features = false;
 	float losses[4] = {0.f, 0.f, 0.f, 0.f};
 	double worst_rel = 0.0, table_rel = 0.0, rendered_cos_min = 0.0;
 	std::string worst_name;
@@ -221,6 +221,7 @@ static int run_train_lerf()
 			std::cout.rdbuf(cout_buf);
 			losses[i] = lang_loss.item<float>();
 			if (i == 1) {
+				reused_features = pass.ReusedRenderFeatures;          // the backward read the language features its forward render had left in the workspace
 				// reference autograd on the same fine depths
 				auto rays_ = pass.LastRays.detach(); auto zf = pass.LastFineDepths.detach();
 				std::vector<torch::Tensor> got;
@@ -275,9 +276,10 @@ static int run_train_lerf()
 		ok = grads_ok && inference_sees_updates && std::isfinite(losses[3]) && losses[3] < losses[2] && losses[2] < losses[1] && rendered_cos_min > 1.0 - 2e-6;
 	} catch (const std::exception &ex) { note = ex.what(); for (auto &ch : note) if (ch == '"' || ch == '\n') ch = ' '; note = note.substr(0, 400); }
 	printf("{\"train_lerf_ok\": %s, \"lang_loss_steps\": [%.9g, %.9g, %.9g], \"gradients_vs_reference_autograd_ok\": %s, \"head_gradient_worst_rel_err\": %.3e, \"worst\": \"%s\", "
-		"\"language_table_gradient_rel_err\": %.3e, \"rendered_embedding_cos_min_vs_reference_forward\": %.9f, \"inference_after_steps_sees_updated_parameters\": %s, \"note\": \"%s\"}\n",
+		"\"language_table_gradient_rel_err\": %.3e, \"rendered_embedding_cos_min_vs_reference_forward\": %.9f, \"inference_after_steps_sees_updated_parameters\": %s, "
+		"\"backward_read_the_forward_renders_features\": %s, \"note\": \"%s\"}\n",
 		ok ? "true" : "false", losses[1], losses[2], losses[3], grads_ok ? "true" : "false", worst_rel, worst_name.c_str(), table_rel, rendered_cos_min,
-		inference_sees_updates ? "true" : "false", note.c_str());
+		inference_sees_updates ? "true" : "false", reused_features ? "true" : "false", note.c_str());
 	fflush(stdout);
 	return ok ? 0 : 1;
 }

@@ -3104,6 +3104,45 @@ def test_lerf_training_step_one_library_call_vs_oracle_and_descends(api, O):
     tr.close()
 
 
+@pytest.mark.gpu
+def test_lerf_training_backward_reads_the_language_features_its_forward_render_encoded(api):
+    """The LeRF training step's backward needs the language grid's features at the fine depths; its forward render (a one-chunk library call) has just encoded exactly those
+    points -- coarse columns, the new samples' columns, the merge map.  nrf_lerf_renderer_last_features hands that view over and nrf_lerf_backward_points_src gathers the rows
+    through the map (fp16 values, as nrf_hash_encode's fp32 rows hold): the same loss, the same head and table gradients as with a second encode of the points; a render in
+    between invalidates the view; a two-chunk render leaves none."""
+    from nerfpp_amd import train as T
+    sc = api.S.make_lerf_scene(log2_t=14, sigma_scale=20.0)
+    r = sc["renderer"]
+    K = api.S.lego_K(800, 800); c2w = api.S.pose_spherical(30.0, -30.0, 4.0)
+    o, d, _ = api.R.GetRays(800, 800, K, c2w, row0=400, rows=1)
+    o = o.reshape(-1, 3)[200:584].contiguous(); d = d.reshape(-1, 3)[200:584].contiguous()
+    n, s, ni = o.shape[0], 32, 32
+    p = api.R.NeRFRenderParams(NSamples=s, NImportance=ni, Chunk=4096, Perturb=0.0, Ndc=False, UseViewdirs=False, ReturnWeights=True, ThinRay=True, BoundingBox=sc["bbox"],
+                               KeepIntermediates=True)
+    rng = np.random.RandomState(12)
+    tgt = rng.randn(n, 768).astype(np.float32); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+    tr = T.LeRFTrainer(r, sc["table"], sc["blob"], learning_rate=2e-3)
+    same = lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    got = {}
+    for reuse in (True, False):
+        tr.reuse_render_features = reuse
+        res = r.Render(0, 0, None, p, rays=(o, d, None))
+        assert res.FeatureView is not None and res.FeatureView["n"] == n and res.FeatureView["sf"] == s + ni and res.FeatureView["cols"] == n * (s + ni)
+        loss = tr.backward(res, dev(tgt), p)
+        assert tr.reused_render_features is reuse
+        got[reuse] = (tr.g_blob.clone(), tr.g_table.clone(), host(loss).copy())
+        if reuse:
+            r.Render(0, 0, None, p, rays=(o[:50], d[:50], None))          # a render in between: `res`'s view is stale, the backward encodes the points again
+            tr.backward(res, dev(tgt), p)
+            assert tr.reused_render_features is False and same(tr.g_blob, got[True][0]) and same(tr.g_table, got[True][1])
+            p2 = api.R.NeRFRenderParams(**{**p.__dict__, "Chunk": 128})
+            assert r.Render(0, 0, None, p2, rays=(o, d, None)).FeatureView is None
+    assert np.array_equal(got[True][2], got[False][2])
+    assert same(got[True][0], got[False][0]) and same(got[True][1], got[False][1])
+    assert float(got[True][0].abs().max()) > 0 and float(got[True][1].abs().max()) > 0
+    tr.close()
+
+
 def test_drop_in_training_render_vs_reference_cpu_autograd_random_models():
     """oracle/_ref/adapter_check `trainfuzz`: one training render + huber + backward through BOTH hosts -- the reference's NeRFRenderer on LibTorch CPU and the drop-in on the GPU --
     on random batch sizes / sample counts / grid and network shapes (hash grid + NeRFSmall), and, round 5, on the CLASSIC configuration (Embedder / Embedder / NeRFImpl with a
@@ -3191,6 +3230,7 @@ def test_reference_lerf_train_loop_body_runs_through_the_hip_drop_in():
     r = json.loads(lines[-1])
     assert out.returncode == 0 and r["train_lerf_ok"], (r, out.stderr[-1500:])
     assert r["gradients_vs_reference_autograd_ok"] and r["inference_after_steps_sees_updated_parameters"], r
+    assert r["backward_read_the_forward_renders_features"], r          # (round 6: nrf_lerf_backward_points_src -- the gradients held to the reference's autograd above are ITS gradients)
     l = r["lang_loss_steps"]
     assert l[2] < l[1] < l[0] and r["head_gradient_worst_rel_err"] < 2e-3 and r["language_table_gradient_rel_err"] < 2e-2 and r["rendered_embedding_cos_min_vs_reference_forward"] > 1 - 2e-6, r
 
