@@ -100,6 +100,13 @@ struct GemmNT {
     const float *bias; int relu;
     const float *mask; int mask_ld;       // optional [M][mask_ld]: C = mask > 0 ? C : 0
     const float *add; int add_ld;         // optional [M][add_ld]: C = (C after bias / ReLU / mask) + add  (a gradient that reaches the same tensor along a second path)
+    const float *r1s; int r1s_ld;         // optional rank-1 term BEFORE the ReLU / mask: C += r1s[m * r1s_ld] * r1w[n]  (the back-propagation through a one-row layer
+    const float *r1w;                     //  that reads the same input: g_alpha (x) w_alpha of NeRFImpl's alpha_linear)
+    // The ReLU mask as BITS (256-wide tiles, N <= 256): a forward product with ReLU leaves, per row, four 64-bit words -- bit `lane` of word j = (C[m][4 lane + j] > 0), the
+    // write-out's own thread layout -- and the back-propagation product that needs that mask reads those 32 bytes instead of the activation's 1 KB row (a third of its
+    // memory traffic).  Strides in 64-bit words.  bits_in replaces `mask` where the launch can use it (gemm_nt_bits_ok).
+    uint64_t *bits_out; int bits_out_ld;
+    const uint64_t *bits_in; int bits_in_ld;
     int va0, va1;                         // widest aligned vector load of each A segment: 4, 2 or 1 floats
     const uint32_t *bmax;                 // F16 arithmetic: bits of the largest |B| entry (k_gb_absmax)
     const unsigned char *bimg;            // B already split (k_gb_split_b): [hi | lo][K tile][k-step][npad rows][16 elements], i.e. the kernels' LDS image tile by tile
@@ -226,20 +233,39 @@ __device__ __forceinline__ void gb_stage_c(const gb_f32x16 (&acc)[NI][2], unsign
     }
 }
 
+// The mask words of the rows a wave will write out (rows rw + NW i, i < 16: four 64-bit words each) with ONE load per lane -- lane 4 i + j takes word j of row i -- issued
+// before the C block is staged, so that its latency is gone by the time the write-out loop wants the bits (a load per row INSIDE that loop cost the back-propagation
+// products 0.3 ms of 0.8: eight dependent round trips per output tile).
+template <int NW>
+__device__ __forceinline__ uint64_t gb_preload_bits(const uint64_t *__restrict__ bits_in, int bits_in_ld, int64_t M, int64_t m0, int th)
+{
+    if (!bits_in) return 0;
+    const int ln = th & 63, rw = th >> 6;
+    const int64_t m = m0 + rw + NW * (ln >> 2);
+    return m < M ? bits_in[m * bits_in_ld + (ln & 3)] : 0;
+}
+
 // the staged C block -> memory as whole rows, by `NW` waves (thread th of 64 NW): inverse scales, bias, ReLU, mask at the write-out
 template <bool F16, int NW, int BM = GB_BM>
 __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N, const float *__restrict__ bias, int relu,
-                                             const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int th, const float *__restrict__ add = nullptr, int add_ld = 0)
+                                             const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int th, const float *__restrict__ add = nullptr, int add_ld = 0,
+                                             const float *__restrict__ r1s = nullptr, int r1s_ld = 0, const float *__restrict__ r1w = nullptr, uint64_t *__restrict__ bits_out = nullptr,
+                                             int bits_out_ld = 0, const uint64_t *__restrict__ bits_in = nullptr, uint64_t pre = 0)
 {
+    static_assert(BM / NW <= 16, "a wave's rows' mask words must fit its 64 lanes");
     constexpr int CS = GbCfg<4>::BN + 4;
     const float *ct = reinterpret_cast<const float *>(smem);
     const int c4 = (th & 63) * 4, rw = th >> 6;
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && (!mask || (((mask_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0))) &&
                         (!add || (((add_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(add) & 15) == 0)));
-    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (bias) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < N) bias4[jj] = bias[n0 + c4 + jj];
+    }
+    if (r1s) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) if (n0 + c4 + jj < N) w4[jj] = r1w[n0 + c4 + jj];
     }
 #pragma unroll 4
     for (int i = 0; i < BM / NW; i++) {
@@ -250,7 +276,21 @@ __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const fl
         float4 v = *reinterpret_cast<const float4 *>(ct + ml * CS + c4);
         if (F16) { const float rs = rinv[ml] * binv; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
         v.x += bias4[0]; v.y += bias4[1]; v.z += bias4[2]; v.w += bias4[3];
+        if (r1s) { const float sv = r1s[m * r1s_ld]; v.x = v.x + sv * w4[0]; v.y = v.y + sv * w4[1]; v.z = v.z + sv * w4[2]; v.w = v.w + sv * w4[3]; }
         if (relu) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
+        if (bits_out) {          // (a wave = one row, a lane = four columns: four ballots are the row's mask; lanes of columns >= N are not here and leave zeros)
+            const uint64_t b0 = __ballot(v.x > 0.0f), b1 = __ballot(v.y > 0.0f), b2 = __ballot(v.z > 0.0f), b3 = __ballot(v.w > 0.0f);
+            const int ln = th & 63;
+            if (ln < 4) bits_out[m * bits_out_ld + ln] = ln == 0 ? b0 : ln == 1 ? b1 : ln == 2 ? b2 : b3;
+        }
+        if (bits_in) {          // row i's four words sit in lanes 4 i .. 4 i + 3 of `pre` (gb_preload_bits): a lane exchange, no load inside this loop
+            const int ln = th & 63;
+            uint64_t w[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+                w[jj] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(pre >> 32), 4 * i + jj) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pre, 4 * i + jj);
+            v.x = ((w[0] >> ln) & 1) ? v.x : 0.0f; v.y = ((w[1] >> ln) & 1) ? v.y : 0.0f; v.z = ((w[2] >> ln) & 1) ? v.z : 0.0f; v.w = ((w[3] >> ln) & 1) ? v.w : 0.0f;
+        }
         if (vec_ok && n + 4 <= N) {
             if (mask) {
                 const float4 k = *reinterpret_cast<const float4 *>(mask + m * mask_ld + n);
@@ -273,11 +313,14 @@ __device__ __forceinline__ void gb_readout_c(const unsigned char *smem, const fl
 template <bool F16>
 __device__ __forceinline__ void gb_epilogue_rows(const gb_f32x16 (&acc)[2][2], unsigned char *smem, const float *rinv, float binv, float *__restrict__ c, int ldc, int64_t M, int N,
                                                  const float *__restrict__ bias, int relu, const float *__restrict__ mask, int mask_ld, int64_t m0, int n0, int t, int wm, int wn, int r, int h,
-                                                 const float *__restrict__ add = nullptr, int add_ld = 0)
+                                                 const float *__restrict__ add = nullptr, int add_ld = 0, const float *__restrict__ r1s = nullptr, int r1s_ld = 0,
+                                                 const float *__restrict__ r1w = nullptr, uint64_t *__restrict__ bits_out = nullptr, int bits_out_ld = 0,
+                                                 const uint64_t *__restrict__ bits_in = nullptr, int bits_in_ld = 0)
 {
+    const uint64_t pre = gb_preload_bits<8>(bits_in, bits_in_ld, M, m0, t);
     gb_stage_c<2>(acc, smem, wm * 64, wn, r, h);
     __syncthreads();
-    gb_readout_c<F16, 8>(smem, rinv, binv, c, ldc, M, N, bias, relu, mask, mask_ld, m0, n0, t, add, add_ld);
+    gb_readout_c<F16, 8>(smem, rinv, binv, c, ldc, M, N, bias, relu, mask, mask_ld, m0, n0, t, add, add_ld, r1s, r1s_ld, r1w, bits_out, bits_out_ld, bits_in, pre);
 }
 
 constexpr int GB_ROWS_LDS_BASE = (GB_BM * (GbCfg<4>::BN + 4) * 4) > 2 * GbCfg<4>::STAGE ? (GB_BM * (GbCfg<4>::BN + 4) * 4) : 2 * GbCfg<4>::STAGE;     // the C tile (133 KB) or the two stages
@@ -408,7 +451,7 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
         __syncthreads();
     }
     if (WNW == 4) {          // whole rows through LDS, as the burst kernel's
-        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h, g.add, g.add_ld);
+        gb_epilogue_rows<F16>(acc, gb_smem, rinv, binv, g.c, g.ldc, g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, wm, wn, r, h, g.add, g.add_ld, g.r1s, g.r1s_ld, g.r1w, g.bits_out, g.bits_out_ld, g.bits_in, g.bits_in_ld);
         return;
     }
     // epilogue: register q of lane (r, h) of tile (i, j) is C[m0 + 64 wm + 32 i + (q & 3) + 8 (q >> 2) + 4 h][n0 + 64 wn + 32 j + r]
@@ -425,6 +468,7 @@ __global__ void __launch_bounds__(128 * WNW, WNW == 2 ? 2 : 1) k_gemm_nt(GemmNT 
                 const int64_t m = m0 + ml;
                 if (m >= g.M) continue;
                 float v = (F16 ? acc[i][j][q] * rinv[ml] * binv : acc[i][j][q]) + bias;
+                if (g.r1s) v = v + g.r1s[m * g.r1s_ld] * g.r1w[n];
                 if (g.relu) v = v > 0.0f ? v : 0.0f;
                 if (g.mask) v = g.mask[m * g.mask_ld + n] > 0.0f ? v : 0.0f;
                 if (g.add) v += g.add[m * g.add_ld + n];
@@ -599,11 +643,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         }
         if (ABL & 2) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 12345.678f) g.c[t] = 1.0f; }
         else {
+            const uint64_t pre = gb_preload_bits<8>(g.bits_in, g.bits_in_ld, g.M, m0, t);
             gb_stage_c<2>(acc, gb_smem, wm * 64, wn, r, h);
             NRF_GSTAMP(6);
             __syncthreads();
             NRF_GSTAMP(7);
-            gb_readout_c<F16, 8>(gb_smem, rinv, binv, g.c, g.ldc, (ABL & 4) ? (int64_t)(g.N < 0) : g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, g.add, g.add_ld);
+            gb_readout_c<F16, 8>(gb_smem, rinv, binv, g.c, g.ldc, (ABL & 4) ? (int64_t)(g.N < 0) : g.M, g.N, g.bias, g.relu, g.mask, g.mask_ld, m0, n0, t, g.add, g.add_ld, g.r1s, g.r1s_ld, g.r1w, g.bits_out, g.bits_out_ld, g.bits_in, pre);
             NRF_GSTAMP(8);
         }
         __syncthreads();          // the C block staged in LDS is read out: the next tile's stages may overwrite it
@@ -1011,6 +1056,10 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     const bool rows_shape = g.va0 == 4 && (g.k1 == 0 || g.va1 == 4) && (g.k0 % GB_BK) == 0 && (g.k1 % GB_BK) == 0 && (ktot0 == 128 || ktot0 == 160 || ktot0 == 256);
     const bool wide = force_wide == 4 || (force_wide != 2 && (g.N > 128 || (narrow_rows && rows_shape && g.M >= 65536)));
     const int bn = wide ? 256 : 128;
+    if (!(wide && g.N <= 256)) {
+        if (g.bits_out) { set_error("gemm_nt_split: mask bits asked of a product that cannot write them (gemm_nt_bits_ok)"); return NRF_ERR_INVALID_ARG; }
+        g.bits_in = nullptr;                          // (the float mask given beside them applies)
+    } else if (g.bits_in) g.mask = nullptr;
     const int64_t blocks = ceil_div(g.M, GB_BM) * ceil_div((int64_t)g.N, (int64_t)bn);
     if (blocks > 0x7fffffff) { set_error("gemm_nt_split: too many tiles"); return NRF_ERR_INVALID_ARG; }
     constexpr int LDS2 = 2 * GbCfg<2>::STAGE + GB_BM * 4, LDS4 = GB_ROWS_LDS;          // two stages + the rows' inverse scales; the 256-wide tile: its C block staged through LDS
@@ -1057,16 +1106,26 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     return NRF_OK;
 }
 
+// whether a product of N output columns runs on the 256-wide tiles with ONE column block -- the launches that can write / read ReLU masks as bits (GemmNT::bits_out / bits_in)
+bool gemm_nt_bits_ok(int64_t M, int N)
+{
+    static const int force_wide = [] { const char *e = getenv("NRF_GEMM_WNW"); return e ? atoi(e) : 0; }();
+    static const bool on = [] { const char *e = getenv("NRF_GEMM_MASK_BITS"); return !e || atoi(e) != 0; }();          // 0: float masks everywhere (A/B)
+    return on && force_wide != 2 && N > 128 && N <= 256 && (N & 3) == 0 && M > 0;
+}
+
 // C = cat[a, b] . B^T (+ bias)(ReLU)(mask): B [N][ldb] holds the columns of segment a first, then segment b's.  arithmetic: 1 = bf16x3, 2 = f16x3 (scaled)
 int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
-                  hipStream_t st, const float *add, int add_ld)
+                  hipStream_t st, const float *add, int add_ld, const float *r1s, int r1s_ld, const float *r1w, uint64_t *bits_out, int bits_out_ld, const uint64_t *bits_in,
+                  int bits_in_ld)
 {
     if (M <= 0 || N <= 0) return NRF_OK;
     GemmNT g{};
     g.a0 = a.p ? a.p + a.off : nullptr; g.lda0 = a.stride; g.k0 = a.p ? a.n : 0;
     g.a1 = (b.p && b.n > 0) ? b.p + b.off : nullptr; g.lda1 = b.stride; g.k1 = g.a1 ? b.n : 0;
     if (g.k0 == 0 && g.k1 > 0) { g.a0 = g.a1; g.lda0 = g.lda1; g.k0 = g.k1; g.a1 = nullptr; g.k1 = 0; }
-    g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld; g.add = add; g.add_ld = add_ld;
+    g.c = c; g.ldc = ldc; g.M = M; g.N = N; g.bias = bias; g.relu = relu; g.mask = mask; g.mask_ld = mask_ld; g.add = add; g.add_ld = add_ld; g.r1s = r1w ? r1s : nullptr; g.r1s_ld = r1s_ld; g.r1w = r1w;
+    g.bits_out = bits_out; g.bits_out_ld = bits_out_ld; g.bits_in = bits_in; g.bits_in_ld = bits_in_ld;
     g.va0 = g.a0 ? vec_class(g.a0, g.lda0, 0) : 1;
     g.va1 = g.a1 ? vec_class(g.a1, g.lda1, 0) : 1;
     return arithmetic == 2 ? gemm_nt_launch<true>(g, B, ldb, st) : gemm_nt_launch<false>(g, B, ldb, st);

@@ -95,10 +95,13 @@ __global__ void k_bias_relu(int64_t total, int out, float *__restrict__ y, int y
 }
 
 // Linear(+bias)(+ReLU) on cat[a, b]: the library product, then one elementwise pass where there is a bias or a ReLU.  Falls back to mlp.hip's kernel.
-int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st)
+int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st, uint64_t *relu_bits,
+                    int relu_bits_ld)
 {
     if (const int arith = npts >= 256 ? train_gemm_for(m) : 0)          // split-precision matrix-core product, bias + ReLU in its epilogue (gemm_bf16x3.hip)
-        return gemm_nt_split(arith, npts, L.out, a, b, m->d_params + L.w_off, L.in, y + y_off, y_stride, L.d_bias, relu, nullptr, 0, st);
+        return gemm_nt_split(arith, npts, L.out, a, b, m->d_params + L.w_off, L.in, y + y_off, y_stride, L.d_bias, relu, nullptr, 0, st, nullptr, 0, nullptr, 0, nullptr,
+                             relu ? relu_bits : nullptr, relu_bits_ld);
+    if (relu_bits) { set_error("internal: run_linear_fast: mask bits exist in the split-precision modes only"); return NRF_ERR_INVALID_ARG; }
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_linear(npts, a, b, L, relu, y, y_stride, y_off, st);
     const float *wb = m->d_params + L.w_off;
@@ -230,8 +233,10 @@ static bool rows16(const float *p, int ld) { return (reinterpret_cast<uintptr_t>
 // y[pt][k] = sum_o g[pt][o] W[o][k]
 bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts) { return npts >= 256 && train_gemm_for(m) != 0; }
 
+bool run_backprop_uses_mask_bits(const nrf_mlp *m, int64_t npts, int width) { return npts >= 256 && train_gemm_for(m) != 0 && gemm_nt_bits_ok(npts, width); }
+
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act, int mask_stride, const float *add,
-                      int add_stride)
+                      int add_stride, const uint64_t *mask_bits, int mask_bits_ld)
 {
     const int arith = npts >= 256 ? train_gemm_for(m) : 0;
     static const bool thin_on = [] { const char *e = getenv("NRF_BACKPROP_THIN"); return !e || atoi(e) != 0; }();          // 0: the tile kernel for every shape (A/B)
@@ -244,7 +249,8 @@ int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &
         return NRF_OK;
     }
     if (arith)          // G . W with W^T [in][out] as the K-contiguous second operand (L.d_wt, refreshed by every nrf_mlp_set_params)
-        return gemm_nt_split(arith, npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st, add, add_stride);
+        return gemm_nt_split(arith, npts, L.in, g, Seg{nullptr, 0, 0, 0}, L.d_wt, L.out, y, y_stride, nullptr, 0, mask_act, mask_stride, st, add, add_stride, nullptr, 0, nullptr,
+                             nullptr, 0, mask_bits, mask_bits_ld);
     if (mask_act || add) { set_error("internal: run_backprop_fast: the fused ReLU mask exists in bf16x3 mode only"); return NRF_ERR_INVALID_ARG; }
     rocblas_handle h = (npts >= 256) ? rb_handle(st) : nullptr;
     if (!h || npts > 0x7fffffff) return run_backprop(npts, g, m, L, y, y_stride, st);

@@ -105,22 +105,26 @@ int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act,
 
 // the same three products for the TRAINING paths (no bit-exactness requirement): rocBLAS sgemm on the fp32 matrix cores when the library is present, else the kernels above
 // (gemm_f32.hip); the weights are read from the handle's blob m->d_params
-int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st);
+int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st,
+                    uint64_t *relu_bits = nullptr, int relu_bits_ld = 0);          // relu_bits: where run_backprop_uses_mask_bits says so, the output's ReLU mask as bits too
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith = 0);          // arith != 0 (train_gemm_for): gemm_tn_bf16x3
 int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);
 int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);          // fewer than 32 rows: fp32 FMAs, four rows per pass over x
 int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db = nullptr);          // two X segments in one pass over G
 // mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0,
-                      const float *add = nullptr, int add_stride = 0);          // add (split-precision modes only, see run_backprop_fuses_mask): y = G W (. mask) + add
+                      const float *add = nullptr, int add_stride = 0, const uint64_t *mask_bits = nullptr, int mask_bits_ld = 0);          // add (split-precision modes only, see run_backprop_fuses_mask): y = G W (. mask) + add
 bool run_backprop_fuses_mask(const nrf_mlp *m, int64_t npts);
 int fp32_gemm_available();
 // gemm_bf16x3.hip: the same two products (forward, back-propagation) as split-precision bf16 matrix-core GEMMs with the bias / ReLU / ReLU-mask epilogues fused
 int host_pack_threads();            // threads of the host-side weight packers (a training loop re-packs every step): min(cores, 8), NRF_PACK_THREADS overrides
 int train_gemm_mode();               // -1: by family (default); 0: fp32 products; 1: bf16x3; 2: f16x3 with power-of-two scaled operands (gemm_bf16x3.hip; NRF_TRAIN_GEMM, nrf_set_train_gemm)
 int train_gemm_for(const nrf_mlp *m);        // the arithmetic of this network's products: the explicit mode, or by family (NeRFSmall: fp32 products; classic, LeRF: f16x3)
+bool run_backprop_uses_mask_bits(const nrf_mlp *m, int64_t npts, int width);          // a layer of `width` outputs whose forward product can leave its ReLU mask as bits (and whose consumers read them)
+bool gemm_nt_bits_ok(int64_t M, int N);          // ReLU masks as bits between a forward product and the back-propagation product that needs them (gemm_bf16x3.hip)
 int gemm_nt_split(int arithmetic, int64_t M, int N, Seg a, Seg b, const float *B, int ldb, float *c, int ldc, const float *bias, int relu, const float *mask, int mask_ld,
-                  hipStream_t st, const float *add = nullptr, int add_ld = 0);
+                  hipStream_t st, const float *add = nullptr, int add_ld = 0, const float *r1s = nullptr, int r1s_ld = 0, const float *r1w = nullptr,
+                  uint64_t *bits_out = nullptr, int bits_out_ld = 0, const uint64_t *bits_in = nullptr, int bits_in_ld = 0);
 int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int lda, const float *B, int ldb, float beta, float *C, int ldc);
 
 // matrix-core paths (separate translation units)

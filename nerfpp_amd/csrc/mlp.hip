@@ -519,8 +519,13 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
         // ---- forward, every layer output kept (NeRF.cpp:92-106) ----
         Seg cur = xin;
         bool cat_in = false;
+        // the hidden layers' ReLU masks as bits, 32 bytes per row in the row's own padding (columns [Wd, Wd + 8) of the W-wide buffers): written by the forward products, read
+        // by the back-propagation products in place of the 1 KB activation row
+        const bool bits = W - Wd >= 8 && run_backprop_uses_mask_bits(m, c, Wd);
+        auto bits_of = [&](float *h) { return bits ? reinterpret_cast<uint64_t *>(h + Wd) : nullptr; };
+        const int bits_ld = W / 2;
         for (int l = 0; l < D; l++) {
-            NRF_TRY(run_linear_fast(c, cat_in ? xin : cur, cat_in ? cur : none, m, m->layers[l], 1, H[l], W, 0, st));
+            NRF_TRY(run_linear_fast(c, cat_in ? xin : cur, cat_in ? cur : none, m, m->layers[l], 1, H[l], W, 0, st, bits_of(H[l]), bits_ld));
             cur = Seg{H[l], W, 0, Wd};
             cat_in = (l == d.skip);
         }
@@ -542,8 +547,11 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             // rgb_linear                                                                                              :118
             NRF_TRY(run_grad_w_fast(c, g_rgb, Seg{HV, W, 0, Wd / 2}, none, 3, Wd / 2, g_params + rgb.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_rgb, 3, bias_of(rgb), st));
-            NRF_TRY(run_backprop_fast(c, g_rgb, m, rgb, G[1], W, st));
-            NRF_TRY(run_relu_mask(c, Wd / 2, G[1], W, HV, W, st));
+            if (run_backprop_fuses_mask(m, c)) NRF_TRY(run_backprop_fast(c, g_rgb, m, rgb, G[1], W, st, HV, W));          // (+ the views layer's ReLU mask, in the product's write-out)
+            else {
+                NRF_TRY(run_backprop_fast(c, g_rgb, m, rgb, G[1], W, st));
+                NRF_TRY(run_relu_mask(c, Wd / 2, G[1], W, HV, W, st));
+            }
             const Seg g_hv{G[1], W, 0, Wd / 2};
             // views_linears_0
             NRF_TRY(run_grad_wb_fast(c, g_hv, sfeat, sviews, Wd / 2, Wd + iv, g_params + views.w_off, bias_of(views), st, train_gemm_for(m)));
@@ -553,12 +561,17 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_grad_wb_fast(c, g_feat, hlast, none, Wd, Wd, g_params + feat.w_off, bias_of(feat), st, train_gemm_for(m)));
             NRF_TRY(run_grad_w_fast(c, g_alpha, hlast, none, 1, Wd, g_params + alpha.w_off, st, train_gemm_for(m)));
             NRF_TRY(run_grad_b(c, g_alpha, 1, bias_of(alpha), st));
-            NRF_TRY(run_backprop_fast(c, g_feat, m, feat, G[1], W, st));
             // d / d h through alpha_linear is the rank-1 product g_alpha (x) w_alpha: formed inside the sum (no [c, 256] array of its own), with h_{D-1}'s ReLU mask --
-            // the first pts_linears stage below finds it applied
+            // the first pts_linears stage below finds it applied.  Split-precision modes: both in the write-out of the back-propagation product through feature_linear
+            if (const int arith = run_backprop_fuses_mask(m, c) ? train_gemm_for(m) : 0)
+                NRF_TRY(gemm_nt_split(arith, c, feat.in, g_feat, none, feat.d_wt, feat.out, gh, W, nullptr, 0, H[D - 1], W, st, nullptr, 0, g_alpha.p + g_alpha.off, g_alpha.stride,
+                                      m->d_params + alpha.w_off, nullptr, 0, bits_of(H[D - 1]), bits_ld));
+            else {
+            NRF_TRY(run_backprop_fast(c, g_feat, m, feat, G[1], W, st));
             hipLaunchKernelGGL(k_sum_rank1, dim3((unsigned)ceil_div(c * Wd, 256)), dim3(256), 0, st, c, Wd, (const float *)G[1], W, g_alpha.p + g_alpha.off, g_alpha.stride,
                                (const float *)(m->d_params + alpha.w_off), gh, W, (const float *)H[D - 1], W);
             NRF_LAUNCH_CHECK();
+            }
             gh_masked = true;
         } else {
             const LinearLayer &outl = m->layers[D];                                                                    // output_linear(cat[h, input_pts])  :121-124
@@ -583,8 +596,17 @@ int mlp_nerf_backward(const nrf_mlp *m, const float *x, int xs, const float *g_o
             NRF_TRY(run_grad_wb_fast(c, g, a, b, Wd, L.in, g_params + L.w_off, bias_of(L), st, train_gemm_for(m)));
             if (l == 0 && !g_x) break;
             float *dst = (gcur == G[1]) ? G[2] : G[1];
+            if (cat && fuse && !g_x) {
+                // the skip layer's input is cat[input_pts, h]: nobody asks for d / d input_pts, so only the h columns are formed -- rows [in, in + Wd) of W^T as a product of
+                // their own, which lands at column 0 with h_{l-1}'s ReLU mask applied by its write-out (the whole product + a masked copy of 256 of its 319 columns before)
+                NRF_TRY(gemm_nt_split(train_gemm_for(m), c, Wd, g, none, L.d_wt + (size_t)in * L.out, L.out, dst, W, nullptr, 0, H[l - 1], W, st, nullptr, 0, nullptr, 0, nullptr,
+                                      nullptr, 0, bits_of(H[l - 1]), bits_ld));
+                premasked = true;
+                gcur = dst;
+                continue;
+            }
             const bool mask_next = fuse && l > 0 && !cat;          // dst = d / d H[l - 1] (with the skip concat the h part sits at a column offset: masked by its own pass)
-            NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, mask_next ? H[l - 1] : nullptr, W));
+            NRF_TRY(run_backprop_fast(c, g, m, L, dst, W, st, mask_next ? H[l - 1] : nullptr, W, nullptr, 0, mask_next ? bits_of(H[l - 1]) : nullptr, bits_ld));
             premasked = mask_next;
             if (l == 0) NRF_TRY(add_gx(dst, W, 0));
             else if (cat) {
