@@ -755,6 +755,11 @@ NRF_API int nrf_lerf_backward_points_src(const nrf_lerf_renderer *r, const void 
                                          const float *d_z, const float *d_dirs, int d_stride, int64_t n, int s, const float *d_noise, float noise_std, const float *d_g_rendered,
                                          float *d_g_lerf_params, float *d_g_table, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The library's short-lived device buffers (a layer product's split operand image, slice sums, reduction cells) come from blocks it keeps per (device, stream) and reuses
+ * from call to call -- not from hipMallocAsync, whose pool proved unsafe inside a LibTorch host (scratch.hip).  nrf_scratch_trim gives the idle blocks back to the driver
+ * (waits for the streams they were last used on) and returns the bytes freed; optional. */
+NRF_API size_t nrf_scratch_trim(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Instrumentation (bench / tests)
  * ------------------------------------------------------------------------------------------- */

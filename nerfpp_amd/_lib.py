@@ -93,7 +93,7 @@ SYMBOLS = [
     "nrf_lerf_renderer_create", "nrf_lerf_renderer_destroy", "nrf_lerf_set_prompts", "nrf_lerf_render_rays_workspace_bytes", "nrf_lerf_render_rays",
     "nrf_lerf_batchify_rays_workspace_bytes", "nrf_lerf_batchify_rays", "nrf_lerf_render_rows_workspace_bytes", "nrf_lerf_render_rows",
     "nrf_fp32_gemm_available", "nrf_get_train_gemm", "nrf_set_train_gemm", "nrf_gemm_nt_bf16x3", "nrf_gemm_nt_f16x3", "nrf_gemm_tn_bf16x3", "nrf_layer_grad_split", "nrf_huber_rows_nanmean", "nrf_lerf_head_backward_workspace_bytes", "nrf_lerf_head_backward", "nrf_lerf_backward_points_workspace_bytes", "nrf_lerf_backward_points",
-    "nrf_lerf_renderer_last_features", "nrf_lerf_backward_points_src",
+    "nrf_lerf_renderer_last_features", "nrf_lerf_backward_points_src", "nrf_scratch_trim",
 ]
 NRF_COMM_ID_BYTES = 128
 
@@ -119,6 +119,7 @@ def lib():
         L.nrf_mlp_small_param_count.restype = C.c_int64
         L.nrf_mlp_nerf_param_count.restype = C.c_int64
         L.nrf_mlp_lerf_param_count.restype = C.c_int64
+        L.nrf_scratch_trim.restype = C.c_size_t
         L.nrf_run_network_workspace_bytes.restype = C.c_size_t
         L.nrf_render_rays_workspace_bytes.restype = C.c_size_t
         L.nrf_batchify_rays_workspace_bytes.restype = C.c_size_t

@@ -16,6 +16,10 @@
 namespace nrf {
 
 void set_error(const char *fmt, ...);
+// the library's own stream-ordered scratch (scratch.hip): a buffer for work enqueued on `st`; given back, it serves the next taker ON THAT STREAM.  Drop-in replacements of
+// hipMallocAsync / hipFreeAsync (same return type), which proved unsafe inside the LibTorch host
+hipError_t scratch_take(void **out, size_t bytes, hipStream_t st);
+hipError_t scratch_give(void *p, hipStream_t st);
 
 #define NRF_CHECK_ARG(cond, ...)                                   \
     do {                                                           \

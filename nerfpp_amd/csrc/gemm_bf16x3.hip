@@ -929,8 +929,8 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     a.slice_pts = ((P32 / 32 + slices - 1) / slices) * 32;
     slices = (P32 + a.slice_pts - 1) / a.slice_pts;
     float *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), ((size_t)slices * out * nn + (db ? (size_t)slices * out : 0)) * sizeof(float), st) != hipSuccess) {
-        set_error("gemm_tn_bf16x3: hipMallocAsync failed");
+    if (scratch_take(reinterpret_cast<void **>(&part), ((size_t)slices * out * nn + (db ? (size_t)slices * out : 0)) * sizeof(float), st) != hipSuccess) {
+        set_error("gemm_tn_bf16x3: scratch allocation failed");
         return NRF_ERR_HIP;
     }
     gb_poison(part, ((size_t)slices * out * nn + (db ? (size_t)slices * out : 0)) * sizeof(float), st);
@@ -947,7 +947,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     hipLaunchKernelGGL(k_tn_sum, dim3((unsigned)ceil_div((int64_t)out * nn, (int64_t)256)), dim3(256), 0, st, (int)slices, out, a.n, a.n1, in, col0, col1, two ? skip1 : 0, two ? keep1 : 0, (const float *)part, dw);
     if (db) hipLaunchKernelGGL(k_tn_bias_sum, dim3((unsigned)out), dim3(64), 0, st, (int)slices, out, (const float *)a.bpart, db);
     const hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(part, st);
+    (void)scratch_give(part, st);
     if (le != hipSuccess) { set_error("gemm_tn_bf16x3: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
     return NRF_OK;
 }
@@ -985,7 +985,7 @@ int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, 
     const int64_t slice_pts = (P + slices - 1) / slices;
     slices = (P + slice_pts - 1) / slice_pts;
     float *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * 4 * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_thin: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    if (scratch_take(reinterpret_cast<void **>(&part), (size_t)slices * 4 * x.n * sizeof(float), st) != hipSuccess) { set_error("gemm_tn_thin: scratch allocation failed"); return NRF_ERR_HIP; }
     gb_poison(part, (size_t)slices * 4 * x.n * sizeof(float), st);
     const dim3 grid((unsigned)ceil_div((int64_t)x.n, (int64_t)256), (unsigned)slices);
     for (int o0 = 0; o0 < out; o0 += 4) {
@@ -999,7 +999,7 @@ int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, 
                            dw + (size_t)o0 * in);
     }
     const hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(part, st);
+    (void)scratch_give(part, st);
     if (le != hipSuccess) { set_error("gemm_tn_thin: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
     return NRF_OK;
 }
@@ -1077,7 +1077,7 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     g.npad = (int)ceil_div((int64_t)g.N, (int64_t)bn) * bn;
     g.bimg_half = (int64_t)T * 2 * g.npad * 32;
     unsigned char *ws = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)(2 * g.bimg_half + 16), st) != hipSuccess) { set_error("gemm_nt_split: hipMallocAsync failed"); return NRF_ERR_HIP; }
+    if (scratch_take(reinterpret_cast<void **>(&ws), (size_t)(2 * g.bimg_half + 16), st) != hipSuccess) { set_error("gemm_nt_split: scratch allocation failed"); return NRF_ERR_HIP; }
     gb_poison(ws, (size_t)(2 * g.bimg_half + 16), st);
     uint32_t *bmax = reinterpret_cast<uint32_t *>(ws + 2 * g.bimg_half);
     if (F16) {
@@ -1101,7 +1101,7 @@ static int gemm_nt_launch(GemmNT &g, const float *B, int ldb, hipStream_t st)
     } else if (wide) hipLaunchKernelGGL((k_gemm_nt<4, F16>), dim3((unsigned)blocks), dim3(512), LDS4, st, g);
     else hipLaunchKernelGGL((k_gemm_nt<2, F16>), dim3((unsigned)blocks), dim3(256), LDS2, st, g);
     const hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(ws, st);
+    (void)scratch_give(ws, st);
     if (le != hipSuccess) { set_error("gemm_nt_split: launch failed: %s", hipGetErrorString(le)); return NRF_ERR_HIP; }
     return NRF_OK;
 }

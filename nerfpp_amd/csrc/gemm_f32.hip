@@ -150,7 +150,7 @@ int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *d
     float *part = nullptr;
     if (split) {
         const int nmax = a.n > b.n ? a.n : b.n;
-        if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)SLICES * out * nmax * sizeof(float), st) != hipSuccess) { set_error("run_grad_w_fast: hipMallocAsync failed"); return NRF_ERR_HIP; }
+        if (scratch_take(reinterpret_cast<void **>(&part), (size_t)SLICES * out * nmax * sizeof(float), st) != hipSuccess) { set_error("run_grad_w_fast: scratch allocation failed"); return NRF_ERR_HIP; }
     }
     auto seg = [&](Seg x, int col0) {
         if (x.n == 0) return true;
@@ -169,7 +169,7 @@ int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *d
                           in) == rocblas_status_success;
     };
     const bool ok = seg(a, 0) && seg(b, a.n);
-    if (part) (void)hipFreeAsync(part, st);
+    if (part) (void)scratch_give(part, st);
     if (!ok) { set_error("rocblas_sgemm failed (weight gradient %d x %d over %lld points)", out, in, (long long)npts); return NRF_ERR_HIP; }
     return NRF_OK;
 }
@@ -291,13 +291,13 @@ int gemm_rm(hipStream_t st, bool transA, bool transB, int64_t M, int64_t N, int6
     if (g_rb.sgemm_sb && K >= 16384 && M * N <= 1024 * 1024 && transA && !transB && (K % SLICES) == 0) {
         // A: [K x M], B: [K x N]: slice b takes rows [b K / 32, (b + 1) K / 32) of both
         float *part = nullptr;
-        if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)SLICES * M * N * sizeof(float), st) != hipSuccess) { set_error("gemm_rm: hipMallocAsync failed"); return NRF_ERR_HIP; }
+        if (scratch_take(reinterpret_cast<void **>(&part), (size_t)SLICES * M * N * sizeof(float), st) != hipSuccess) { set_error("gemm_rm: scratch allocation failed"); return NRF_ERR_HIP; }
         const float zero = 0.0f;
         const int64_t per = K / SLICES;
         const bool ok = g_rb.sgemm_sb(h, o1, o2, (rocblas_int)N, (rocblas_int)M, (rocblas_int)per, &alpha, B, ldb, (rocblas_stride)(per * ldb), A, lda, (rocblas_stride)(per * lda), &zero, part,
                                       (rocblas_int)N, (rocblas_stride)(M * N), SLICES) == rocblas_status_success;
         if (ok) hipLaunchKernelGGL(k_sum_partials_rm, dim3((unsigned)ceil_div(M * N, 256)), dim3(256), 0, st, SLICES, (int)M, (int)N, (const float *)part, beta, C, ldc);
-        (void)hipFreeAsync(part, st);
+        (void)scratch_give(part, st);
         if (!ok) { set_error("rocblas_sgemm_strided_batched failed (%lld x %lld over %lld)", (long long)M, (long long)N, (long long)K); return NRF_ERR_HIP; }
         return NRF_OK;
     }

@@ -611,13 +611,13 @@ int nrf_huber_rows_nanmean(const float *d_pred, const float *d_target, int64_t n
     NRF_CHECK_ARG(d_pred && d_target && d_loss && n > 0 && e > 0 && delta > 0.0f, "nrf_huber_rows_nanmean: bad argument");
     hipStream_t st = as_stream(stream);
     float *tmp = nullptr;
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&tmp), (size_t)(n + 1) * sizeof(float), st));
+    NRF_HIP(scratch_take(reinterpret_cast<void **>(&tmp), (size_t)(n + 1) * sizeof(float), st));
     int rc = NRF_OK;
     hipLaunchKernelGGL(k_huber_rows, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, e, delta, d_pred, d_target, tmp);
     hipLaunchKernelGGL(k_nanmean, dim3(1), dim3(256), 0, st, n, (const float *)tmp, d_loss, tmp + n);
     if (d_grad) hipLaunchKernelGGL(k_huber_rows_grad, dim3((unsigned)ceil_div(n * e, 256)), dim3(256), 0, st, n, e, delta, d_pred, d_target, (const float *)tmp, (const float *)(tmp + n), d_grad);
     if (hipGetLastError() != hipSuccess) { set_error("nrf_huber_rows_nanmean: launch failed"); rc = NRF_ERR_HIP; }
-    (void)hipFreeAsync(tmp, st);
+    (void)scratch_give(tmp, st);
     return rc;
 }
 
@@ -649,14 +649,14 @@ int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_
     if (lerf_train_gram(lerf, s)) {
         const LinearLayer &L1 = lerf->layers.back();
         const int64_t rmax = n < rays_per ? n : rays_per;          // G, M, then the per-ray rows u, v, g_v, q of one chunk
-        NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&gram), ((size_t)2 * L1.in * L1.in + (size_t)rmax * (2 * L1.in + 2 * L1.out)) * sizeof(float), st));
+        NRF_HIP(scratch_take(reinterpret_cast<void **>(&gram), ((size_t)2 * L1.in * L1.in + (size_t)rmax * (2 * L1.in + 2 * L1.out)) * sizeof(float), st));
         const float *wle = lerf->d_params + L1.w_off;
         int rcg;
         if (lerf->lerf_gram_current && lerf->d_lerf_gram && L1.in == 256)
             // the Gram matrix the device packer formed at the last parameter upload (double accumulation, unscaled copy behind the packed one): nothing to compute
             rcg = hipMemcpyAsync(gram, lerf->d_lerf_gram + (size_t)L1.in * L1.in, (size_t)L1.in * L1.in * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
         else rcg = gemm_rm(st, true, false, L1.in, L1.in, L1.out, 1.0f, wle, L1.in, wle, L1.in, 0.0f, gram, L1.in);
-        if (rcg != NRF_OK) { (void)hipFreeAsync(gram, st); return rcg; }
+        if (rcg != NRF_OK) { (void)scratch_give(gram, st); return rcg; }
     }
     int rc = NRF_OK;
     for (int64_t r0 = 0; r0 < n && rc == NRF_OK; r0 += rays_per) {
@@ -666,7 +666,7 @@ int nrf_lerf_head_backward(const nrf_mlp *lerf, const float *d_emb, const uint8_
                                  rays, s, d_g_rendered + r0 * E, d_g_params, d_g_emb ? d_g_emb + p0 * in : nullptr, d_rendered ? d_rendered + r0 * E : nullptr,
                                  d_weights ? d_weights + p0 : nullptr, base, buf, nrm, gram, st);
     }
-    if (gram) (void)hipFreeAsync(gram, st);
+    if (gram) (void)scratch_give(gram, st);
     return rc;
 }
 

@@ -1441,9 +1441,9 @@ int nrf_mlp_forward(const nrf_mlp *m, const float *d_x, int64_t p, int precision
     hipStream_t st = as_stream(stream);
     const size_t wsb = mlp_workspace_bytes(m, p, precision);
     void *ws = nullptr;
-    NRF_HIP(hipMallocAsync(&ws, wsb, st));          // stream-ordered scratch for the standalone entry point
+    NRF_HIP(scratch_take(&ws, wsb, st));          // stream-ordered scratch for the standalone entry point
     const int s = mlp_forward(m, d_x, m->in_dims, p, precision, d_out, m->out_dims, ws, wsb, st);
-    NRF_HIP(hipFreeAsync(ws, st));
+    NRF_HIP(scratch_give(ws, st));
     return s;
 }
 

@@ -527,7 +527,7 @@ static int lerf_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int 
 {
     float *asum = nullptr;
     const size_t bytes = (size_t)n * lerf::HID * sizeof(float);
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&asum), bytes, st));
+    NRF_HIP(scratch_take(reinterpret_cast<void **>(&asum), bytes, st));
     int rc = hipMemsetAsync(asum, 0, bytes, st) == hipSuccess ? NRF_OK : NRF_ERR_HIP;
     if (rc != NRF_OK) set_error("hipMemsetAsync failed");
     else {
@@ -540,7 +540,7 @@ static int lerf_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int 
             if (hipGetLastError() != hipSuccess) { set_error("k_lerf_embed launch failed"); rc = NRF_ERR_HIP; }
         }
     }
-    (void)hipFreeAsync(asum, st);
+    (void)scratch_give(asum, st);
     return rc;
 }
 

@@ -748,7 +748,7 @@ int lerf_split_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int s
 {
     float *asum = nullptr;
     const size_t bytes = (size_t)n * lerf::HID * sizeof(float);
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&asum), bytes, st));
+    NRF_HIP(scratch_take(reinterpret_cast<void **>(&asum), bytes, st));
     int rc = NRF_OK;              // every row of asum is stored by the wave that owns its ray: no zero fill
     if (rc == NRF_OK) {
         ProfScope prof(NRF_PROF_MLP, st);
@@ -760,7 +760,7 @@ int lerf_split_embedding_passes(const nrf_mlp *m, lerf::Args a, int64_t n, int s
             if (hipGetLastError() != hipSuccess) { set_error("k_lerf_embed_split launch failed"); rc = NRF_ERR_HIP; }
         }
     }
-    (void)hipFreeAsync(asum, st);          // stream-ordered: also on the error paths
+    (void)scratch_give(asum, st);          // stream-ordered: also on the error paths
     return rc;
 }
 

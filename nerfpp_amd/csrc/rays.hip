@@ -446,7 +446,7 @@ int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *ne
 {
     NRF_CHECK_ARG(d_rays && n > 0 && ray_stride >= 8 && near_min && far_max, "nrf_near_far_range: bad argument");
     int *d_out = nullptr;
-    NRF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_out), 2 * sizeof(int), as_stream(stream)));
+    NRF_HIP(scratch_take(reinterpret_cast<void **>(&d_out), 2 * sizeof(int), as_stream(stream)));
     const int init[2] = {0x7f800000 /* +inf */, (int)(0xff800000u ^ 0x7fffffffu) /* enc(-inf) */};
     NRF_HIP(hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, as_stream(stream)));
     const unsigned grid = (unsigned)(ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024);
@@ -455,7 +455,7 @@ int nrf_near_far_range(const float *d_rays, int64_t n, int ray_stride, float *ne
     int res[2];
     NRF_HIP(hipMemcpyAsync(res, d_out, sizeof(res), hipMemcpyDeviceToHost, as_stream(stream)));
     NRF_HIP(hipStreamSynchronize(as_stream(stream)));
-    NRF_HIP(hipFreeAsync(d_out, as_stream(stream)));
+    NRF_HIP(scratch_give(d_out, as_stream(stream)));
     auto dec = [](int v) { int b = v >= 0 ? v : (v ^ 0x7fffffff); float f; memcpy(&f, &b, 4); return f; };
     *near_min = dec(res[0]);
     *far_max = dec(res[1]);

@@ -502,9 +502,9 @@ static int rerender_f32(const nrf_renderer *r, const float *d_rays, int ray_stri
     q.precision = NRF_PREC_F32;
     const size_t need = nrf_render_rays_workspace_bytes(r, n, &q);
     void *ws = d_workspace; size_t wsb = workspace_bytes; void *tmp = nullptr;
-    if (need > workspace_bytes) { NRF_HIP(hipMallocAsync(&tmp, need, st)); ws = tmp; wsb = need; }
+    if (need > workspace_bytes) { NRF_HIP(scratch_take(&tmp, need, st)); ws = tmp; wsb = need; }
     const int rc = render_rays_impl(r, d_rays, ray_stride, n, &q, d_t, d_u, out, ws, wsb, st, nullptr);
-    if (tmp) (void)hipFreeAsync(tmp, st);
+    if (tmp) (void)scratch_give(tmp, st);
     if (rc == NRF_OK) r->rerendered_chunks++;
     return rc;
 }

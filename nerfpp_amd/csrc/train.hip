@@ -711,7 +711,7 @@ struct AsyncBuf {
     void *p = nullptr;
     hipStream_t st;
     explicit AsyncBuf(hipStream_t s) : st(s) {}
-    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+    ~AsyncBuf() { if (p) (void)scratch_give(p, st); }
     AsyncBuf(const AsyncBuf &) = delete;
     AsyncBuf &operator=(const AsyncBuf &) = delete;
 };
@@ -723,7 +723,7 @@ int nrf_huber_loss(const float *d_pred, const float *d_target, int64_t count, fl
     NRF_CHECK_ARG(d_pred && d_target && d_loss_mse && count > 0, "nrf_huber_loss: bad argument");
     hipStream_t st = as_stream(stream);
     AsyncBuf buf(st);
-    NRF_HIP(hipMallocAsync(&buf.p, 2 * sizeof(double), st));
+    NRF_HIP(scratch_take(&buf.p, 2 * sizeof(double), st));
     double *acc = static_cast<double *>(buf.p);
     NRF_HIP(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
     const unsigned grid = (unsigned)(ceil_div(count, 256) < 512 ? ceil_div(count, 256) : 512);
@@ -747,7 +747,7 @@ int nrf_raw2outputs_backward_noise(const float *d_raw, const float *d_z, const f
     if (n == 0) return NRF_OK;
     hipStream_t st = as_stream(stream);
     AsyncBuf buf(st);
-    NRF_HIP(hipMallocAsync(&buf.p, (size_t)n * s * sizeof(float), st));
+    NRF_HIP(scratch_take(&buf.p, (size_t)n * s * sizeof(float), st));
     float *lt = static_cast<float *>(buf.p);
     hipLaunchKernelGGL(k_raw2outputs_bwd, dim3((unsigned)ceil_div(n, BW_RAYS)), dim3(64 * BW_RAYS), 0, st, n, s, c, white_bkgr, d_raw, d_z, d_dirs, d_stride, d_g_rgb,
                        d_g_raw, lt, d_noise, noise_std);

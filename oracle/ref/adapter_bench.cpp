@@ -265,7 +265,10 @@ static void time_steps(const char *family, const char *surface, Body body, int s
 	// a FIXED number of warm-up steps (not the frame benches' time-based settle): every body() is an optimizer step, so the loss the timed steps end at -- and, with the
 	// random targets of the LeRF bench, whether the run has already reached the trivial optimum (all weights zero: rendered embedding 0, loss 0.5, degenerate
 	// gradients, 25 % slower steps) -- must not depend on how many steps fit into a second on this box
-	for (int i = 0; i < 8; i++) body(warm);
+	const bool show = getenv("NRF_BENCH_LOSSES") != nullptr;          // (debugging: the loss of every warm-up step on stderr)
+	if (show) fprintf(stderr, "loss %.6g", loss_first);
+	for (int i = 0; i < 8; i++) { auto l = body(warm); if (show) fprintf(stderr, " %.6g", l.template item<float>()); }
+	if (show) fprintf(stderr, "\n");
 	dev_sync();
 	StepClock sc;
 	torch::Tensor loss;
