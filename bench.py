@@ -60,7 +60,7 @@ def main():
                          "next call and, after the timed region, by nrf_renderer_nonfinite (reported as nonfinite_chunks); auto = one host read-back at the end of every frame call "
                          "(+ an NRF_PREC_F32 re-render of flagged chunks), what a host that renders single frames gets by default")
     ap.add_argument("--dense-mb", type=float, default=-1, help="override the baked dense-level budget of the hash fast path (MB)")
-    ap.add_argument("--kernel-stats", default="profiles/round6/r8k_single_lane_kernel_stats.csv",
+    ap.add_argument("--kernel-stats", default="profiles/round6/r8m_single_lane_kernel_stats.csv",
                     help="named in roofline.kernel_stats: the committed rocprofv3 --kernel-trace --stats summary of the single-lane pass the roofline re-derives from")
     args = ap.parse_args()
 

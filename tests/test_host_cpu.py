@@ -344,7 +344,7 @@ def test_bench_result_line_is_compact_complete_and_parseable(world, tmp_path, ca
     import json
     from benchlib import report
     detail = _canned_bench_detail(world)
-    report.emit(detail, stats_csv="profiles/round6/r8k_single_lane_kernel_stats.csv", path=str(tmp_path / "bench_detail.json"))
+    report.emit(detail, stats_csv="profiles/round6/r8m_single_lane_kernel_stats.csv", path=str(tmp_path / "bench_detail.json"))
     cap = capsys.readouterr()
     out_lines = cap.out.strip().splitlines()
     assert len(out_lines) == 1, "ONE line on stdout"
