@@ -699,6 +699,7 @@ struct GemmTN {
     float *bpart;                         // optional [slices][out]: the slice's column sums of G (the layer's bias gradient), by the workgroups of X tile 0
     int vg, vx;                           // 4: rows 16-byte aligned and the column count a multiple of 4 (vector loads); 1: scalar loads
     int nbo, nbi;                         // output tiles along out / n
+    const float *xscale; int xscale_ld;   // optional: segment 0's row p is multiplied by xscale[p * xscale_ld] on its way to LDS (dW = G^T diag(s) X without a scaled copy of X)
 };
 
 constexpr int TN_T = 128;                                                 // tile edge
@@ -736,10 +737,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
     for (int j = 0; j < 4; j++) cj[j] = col + j < ncols ? col + j : ncols - 1;
     if (VEC && col + 4 > ncols) col = ncols - 4;
     float4 r0[8];
+    float sc0[8];
+    const bool scaled = a.xscale && opnd == 1 && !seg1;            // (wave-uniform)
     const bool bsum_on = a.bpart && opnd == 0 && bi == 0;          // (wave-uniform: waves 0-1 of the workgroups of X tile 0)
     float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f, bs3 = 0.0f;          // this thread's four G columns, summed over its eight points of every K tile
     auto load_tile = [&](int tile, float4 (&rr)[8]) {
         const float *rp = src + (p_begin + (int64_t)tile * 32 + pg * 8) * ld;
+        if (scaled) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sc0[k] = a.xscale[(p_begin + (int64_t)tile * 32 + pg * 8 + k) * a.xscale_ld];
+        }
         if (VEC) {
 #pragma unroll
             for (int k = 0; k < 8; k++) rr[k] = *reinterpret_cast<const float4 *>(rp + (int64_t)k * ld + col);
@@ -763,7 +770,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(GemmTN a)
             gb_bf16x8 hi, lo;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const float v = j == 0 ? rr[k].x : (j == 1 ? rr[k].y : (j == 2 ? rr[k].z : rr[k].w));
+                float v = j == 0 ? rr[k].x : (j == 1 ? rr[k].y : (j == 2 ? rr[k].z : rr[k].w));
+                if (scaled) v = sc0[k] * v;
                 const __bf16 b = (__bf16)v;
                 hi[k] = b; lo[k] = (__bf16)(v - (float)b);
             }
@@ -874,13 +882,14 @@ __global__ void __launch_bounds__(64) k_tn_bias_sum(int slices, int out, const f
 }
 
 // the last P % 32 points (fp32 FMAs, one thread per dw entry)
-__global__ void k_tn_tail(int pts, int out, int n, const float *__restrict__ g, int ldg, const float *__restrict__ x, int ldx, int in, int col0, float *__restrict__ dw)
+__global__ void k_tn_tail(int pts, int out, int n, const float *__restrict__ g, int ldg, const float *__restrict__ x, int ldx, int in, int col0, float *__restrict__ dw,
+                          const float *__restrict__ xscale = nullptr, int xscale_ld = 0)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= out * n) return;
     const int o = e / n, i = e - o * n;
     float acc = 0.0f;
-    for (int p = 0; p < pts; p++) acc = fmaf(g[(size_t)p * ldg + o], x[(size_t)p * ldx + i], acc);
+    for (int p = 0; p < pts; p++) acc = fmaf(g[(size_t)p * ldg + o], xscale ? xscale[(size_t)p * xscale_ld] * x[(size_t)p * ldx + i] : x[(size_t)p * ldx + i], acc);
     dw[(size_t)o * in + col0 + i] += acc;
 }
 
@@ -896,14 +905,16 @@ __global__ void k_tn_tail_bias(int pts, int out, const float *__restrict__ g, in
 
 // dw [out][in] += g^T [x | x1] over P points (and, with db, db[o] += the column sums of g: the layer's bias gradient out of the same pass): x's columns land at dw columns col0 .., x1's columns skip1 .. skip1 + keep1 at col1 .. (x1.n == 0: one segment; x1.n may be
 // rounded up past skip1 + keep1 for aligned 16-byte reads: the row must hold that many floats, what they contain does not matter)
-int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db)
+int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db, const float *xscale,
+                     int xscale_ld)
 {
     if (P <= 0 || x.n <= 0 || out <= 0) return NRF_OK;
     const bool two = x1.p && keep1 > 0 && x1.n >= skip1 + keep1;
     const int64_t P32 = P & ~(int64_t)31;
     if (P32 < P) {
         const unsigned nb = (unsigned)ceil_div((int64_t)out * x.n, (int64_t)256);
-        hipLaunchKernelGGL(k_tn_tail, dim3(nb), dim3(256), 0, st, (int)(P - P32), out, x.n, g.p + g.off + P32 * g.stride, g.stride, x.p + x.off + P32 * x.stride, x.stride, in, col0, dw);
+        hipLaunchKernelGGL(k_tn_tail, dim3(nb), dim3(256), 0, st, (int)(P - P32), out, x.n, g.p + g.off + P32 * g.stride, g.stride, x.p + x.off + P32 * x.stride, x.stride, in, col0, dw,
+                           xscale ? xscale + P32 * xscale_ld : nullptr, xscale_ld);
         if (two)
             hipLaunchKernelGGL(k_tn_tail, dim3((unsigned)ceil_div((int64_t)out * keep1, (int64_t)256)), dim3(256), 0, st, (int)(P - P32), out, keep1,
                                g.p + g.off + P32 * g.stride, g.stride, x1.p + x1.off + skip1 + P32 * x1.stride, x1.stride, in, col1, dw);
@@ -916,6 +927,7 @@ int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int sk
     a.x = x.p + x.off; a.ldx = x.stride; a.n = x.n;
     if (two) { a.x1 = x1.p + x1.off; a.ldx1 = x1.stride; a.n1 = x1.n; }
     a.P = P32;
+    a.xscale = xscale; a.xscale_ld = xscale_ld;
     a.vg = (vec_class(a.g, a.ldg, 0) == 4 && (out & 3) == 0) ? 4 : 1;
     a.vx = (vec_class(a.x, a.ldx, 0) == 4 && (x.n & 3) == 0 && (!two || (vec_class(a.x1, a.ldx1, 0) == 4 && (x1.n & 3) == 0))) ? 4 : 1;
     a.nbo = (out + TN_T - 1) / TN_T; a.nbi0 = (x.n + TN_T - 1) / TN_T; a.nbi = a.nbi0 + (two ? (x1.n + TN_T - 1) / TN_T : 0);
@@ -1005,9 +1017,9 @@ int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, 
 }
 
 // dw [out][in] (columns col0 .. col0 + x.n) += g^T x over P points
-int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st)
+int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st, const float *xscale, int xscale_ld)
 {
-    return gemm_tn_bf16x3_2(P, g, x, col0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st, nullptr);
+    return gemm_tn_bf16x3_2(P, g, x, col0, Seg{nullptr, 0, 0, 0}, 0, 0, 0, out, in, dw, st, nullptr, xscale, xscale_ld);
 }
 
 // Arithmetic of the training paths' forward / back-propagation products.  -1 (the default, NRF_TRAIN_GEMM=auto): by network family -- f16x3 for the classic NeRF and the

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) k_ltg_ray_v(int e, const float *__restric
 // per ray: t_j, beta_j; g_a,j = ((w_j / c_j) q - beta_j s_j) . [a_j > 0] written OVER s_j; ba_j = beta_j a_j; the weights' backward -> g33 column 0 (as k_lt_ray's tail)
 __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *__restrict__ q, const float *__restrict__ a, int as, float *__restrict__ sg_a, int sgs,
                                                    float *__restrict__ ba, int bs, const float *__restrict__ pp, const uint8_t *__restrict__ keep, const float *__restrict__ z,
-                                                   const float *__restrict__ dirs, int d_stride, float *__restrict__ g33, int gs)
+                                                   const float *__restrict__ dirs, int d_stride, float *__restrict__ g33, int gs, int beta_only)
 {
     extern __shared__ float lds[];
     float *gw = lds, *qs = lds + s;
@@ -364,8 +364,9 @@ __global__ void __launch_bounds__(256) k_ltg_ray_g(int s, int hd, const float *_
             const float av = ar[k];
             const float ga = wc * qs[k] - beta * sr[k];
             sr[k] = av > 0.0f ? ga : 0.0f;          // a is a ReLU output: its mask here instead of in a pass of its own (what run_relu_mask would do before the next layer)
-            br[k] = beta * av;
+            if (!beta_only) br[k] = beta * av;
         }
+        if (beta_only && lane == 0) br[0] = beta;     // (the row beta_j a_j is formed by the weight-gradient product itself: its X operand is a, scaled per point)
         if (lane == 0) gw[j] = t;
     }
     __syncthreads();
@@ -519,14 +520,14 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         if (arith_r) NRF_TRY(gemm_nt_split(arith_r, rays, hd, Seg{gv, E, 0, E}, none, L1.d_wt, E, q, hd, nullptr, 0, nullptr, 0, st));     // Q = G_V W = G_V (W^T)^T: W^T [hd][E] is the layer's d_wt
         else NRF_TRY(gemm_rm(st, false, false, rays, hd, E, 1.0f, gv, E, wle, hd, 0.0f, q, hd));                           // Q = G_V W
         hipLaunchKernelGGL(k_ltg_ray_g, dim3((unsigned)rays), dim3(256), (size_t)(s + hd + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, (const float *)q, a, W, sga, W, ba, W, (const float *)pp, keep, z,
-                           dirs, d_stride, g33, W);
+                           dirs, d_stride, g33, W, arith ? 1 : 0);
         NRF_LAUNCH_CHECK();
         float *dw = g_params + L1.w_off;                                   // [E][hd]
         if (arith_r) NRF_TRY(gemm_tn_bf16x3(rays, Seg{gv, E, 0, E}, Seg{u, hd, 0, hd}, E, hd, 0, dw, st));                  // dW += G_V^T U
         else NRF_TRY(gemm_rm(st, true, false, E, hd, rays, 1.0f, gv, E, u, hd, 1.0f, dw, hd));                             // dW += G_V^T U
         if (arith) {                                                                                                       // M = A^T diag(beta) A: the weight-gradient product's shape
             NRF_HIP(hipMemsetAsync(mm, 0, (size_t)hd * hd * sizeof(float), st));
-            NRF_TRY(gemm_tn_bf16x3(c, Seg{a, W, 0, hd}, Seg{ba, W, 0, hd}, hd, hd, 0, mm, st));
+            NRF_TRY(gemm_tn_bf16x3(c, Seg{a, W, 0, hd}, Seg{a, W, 0, hd}, hd, hd, 0, mm, st, ba, W));          // X = diag(beta) A: beta_j sits in column 0 of ba's row j
         } else NRF_TRY(gemm_rm(st, true, false, hd, hd, c, 1.0f, a, W, ba, W, 0.0f, mm, hd));
         if (arith) {                                                                                                       // dW -= W M: 768 x 256 x 256, fp32 FMAs
             hipLaunchKernelGGL(k_lt_sub_wm, dim3((unsigned)ceil_div((int64_t)E * hd, (int64_t)256)), dim3(256), 0, st, E, hd, wle, (const float *)mm, dw);

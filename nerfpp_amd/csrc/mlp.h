@@ -108,9 +108,9 @@ int run_relu_mask(int64_t npts, int n, float *g, int g_stride, const float *act,
 int run_linear_fast(int64_t npts, Seg a, Seg b, const nrf_mlp *m, const LinearLayer &L, int relu, float *y, int y_stride, int y_off, hipStream_t st,
                     uint64_t *relu_bits = nullptr, int relu_bits_ld = 0);          // relu_bits: where run_backprop_uses_mask_bits says so, the output's ReLU mask as bits too
 int run_grad_w_fast(int64_t npts, Seg g, Seg a, Seg b, int out, int in, float *dw, hipStream_t st, int arith = 0);          // arith != 0 (train_gemm_for): gemm_tn_bf16x3
-int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);
+int gemm_tn_bf16x3(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st, const float *xscale = nullptr, int xscale_ld = 0);
 int gemm_tn_thin(int64_t P, Seg g, Seg x, int out, int in, int col0, float *dw, hipStream_t st);          // fewer than 32 rows: fp32 FMAs, four rows per pass over x
-int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db = nullptr);          // two X segments in one pass over G
+int gemm_tn_bf16x3_2(int64_t P, Seg g, Seg x, int col0, Seg x1, int col1, int skip1, int keep1, int out, int in, float *dw, hipStream_t st, float *db = nullptr, const float *xscale = nullptr, int xscale_ld = 0);          // two X segments in one pass over G
 // mask_act (optional, bf16x3 mode only -- callers test run_backprop_fuses_mask()): y = mask_act > 0 ? y : 0, the ReLU mask of the stage that consumes y
 int run_backprop_fast(int64_t npts, Seg g, const nrf_mlp *m, const LinearLayer &L, float *y, int y_stride, hipStream_t st, const float *mask_act = nullptr, int mask_stride = 0,
                       const float *add = nullptr, int add_stride = 0, const uint64_t *mask_bits = nullptr, int mask_bits_ld = 0);          // add (split-precision modes only, see run_backprop_fuses_mask): y = G W (. mask) + add
