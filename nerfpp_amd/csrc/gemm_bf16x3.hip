@@ -555,8 +555,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         const bool has_next = nbid < total;
         if (has_next) point_a(nbid);
         NRF_GSTAMP(0);
+        // A NARROW product on this 256-wide tile (N = 33: the LeRF sigma net's last layer; N = 128): the column groups of 64 past N do nothing -- their waves skip the
+        // fragment reads and matrix instructions, their B rows are neither loaded nor stored, their part of the C block is not staged (the write-out skips n >= N)
+        const int nact = g.N - n0 >= Cfg::BN ? Cfg::BN : ((g.N - n0 + 63) & ~63);          // columns of this tile that exist, rounded up to a wave's 64
+        const bool wave_on = wn * 64 < nact, b_on = (t >> 1) < nact;                        // (a thread's 16-byte B piece belongs to row t / 2 of a slab)
         // (B's columns run straight through both segments)
-        auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { if (!(ABL & 16)) gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
+        auto load_b = [&](int tile, gb_u32x4 (&rb)[4]) { if (!(ABL & 16) && b_on) gb_load_b<Cfg::BN>(g.bimg, g.bimg_half, g.npad, tile, n0, t, rb); };
         // F16: the row's whole K sits in the eight threads (kq) of the row: its largest entry is 8 TK maxima and three lane exchanges away
         float as[Cfg::QA], binv = 1.0f;
 #pragma unroll
@@ -582,7 +586,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
                 if (ABL & 8) { if (a[i].x == 12345.678f) base[t] = 1; }      // (keeps the loads alive)
                 else gb_split_store<F16>(a[i], as[i], base, base + Cfg::A_HALF, (ks * GB_BM + rq + Cfg::RSTEP * i) * 32 + (kq & 3) * 8);
             }
-            if (!(ABL & 16)) gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
+            if (!(ABL & 16) && b_on) gb_store_b<Cfg::BN>(base + 2 * Cfg::A_HALF, Cfg::B_HALF, t, rb);
         };
         gb_f32x16 acc[2][2];
 #pragma unroll
@@ -592,7 +596,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
         auto multiply = [&](int stage) {
-            if (ABL & 1) return;
+            if ((ABL & 1) || !wave_on) return;
             const unsigned char *base = gb_smem + stage * Cfg::STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -644,7 +648,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_nt_rows(GemmNT g)
         if (ABL & 2) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 12345.678f) g.c[t] = 1.0f; }
         else {
             const uint64_t pre = gb_preload_bits<8>(g.bits_in, g.bits_in_ld, g.M, m0, t);
-            gb_stage_c<2>(acc, gb_smem, wm * 64, wn, r, h);
+            if (wave_on) gb_stage_c<2>(acc, gb_smem, wm * 64, wn, r, h);
             NRF_GSTAMP(6);
             __syncthreads();
             NRF_GSTAMP(7);
