@@ -3161,6 +3161,29 @@ def test_drop_in_training_render_vs_reference_cpu_autograd_random_models():
     assert "fused fp16 backward checked against the fp32 layer kernels in 2 case(s)" in out.stdout, out.stdout[-2500:]
 
 
+def test_library_scratch_blocks_are_reused_and_can_be_given_back(api):
+    """scratch.hip: the library's short-lived device buffers come from blocks it keeps per (device, stream) -- a layer product leaves one behind, the same product again takes
+    it again (no growth), nrf_scratch_trim gives the idle blocks back (bytes > 0, then 0), and the product works as before afterwards."""
+    L = api.L
+    lib = L.lib()
+    M, N, K = 4096, 256, 256
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    a = torch.randn((M, K), device="cuda", generator=g); b = torch.randn((N, K), device="cuda", generator=g) * 0.1
+    c1 = torch.empty((M, N), device="cuda"); c2 = torch.empty((M, N), device="cuda")
+    call = lambda c: L.check(lib.nrf_gemm_nt_f16x3(C.c_void_p(a.data_ptr()), K, C.c_int64(M), K, C.c_void_p(b.data_ptr()), K, N, C.c_void_p(c.data_ptr()), N, None, 0, None))
+    torch.cuda.synchronize()
+    lib.nrf_scratch_trim()
+    call(c1); torch.cuda.synchronize()
+    first = lib.nrf_scratch_trim()
+    assert first > 0 and lib.nrf_scratch_trim() == 0
+    call(c1); call(c2); call(c2); torch.cuda.synchronize()
+    assert lib.nrf_scratch_trim() == first, "the same product three times over: one block, reused"
+    call(c2); torch.cuda.synchronize()
+    assert torch.equal(c1, c2)
+    want = a.double() @ b.double().t()
+    assert float((c2.double() - want).abs().max() / want.abs().max()) < 2e-6
+
+
 def test_drop_in_classic_training_in_the_split_precision_products_follows_the_fp32_products():
     """oracle/_ref/adapter_check `bench train_classic`: NeRFExecutor::Train's loop body on the drop-in, 13 optimizer steps of 4 096 rays, once with the library's default layer
     products (f16x3 split precision) and once with fp32 products (NRF_TRAIN_GEMM=f32): the last losses agree to 1e-3 (measured 1e-4).  Regression test of round 6's scratch
