@@ -289,15 +289,28 @@ __global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *_
         lt[j] = tprev; trans[j] = nrf_expf(tprev);
         wgt[j] = alpha[j] * trans[j];
     }
-    // ||h_j|| (a wave per sample)
+    __syncthreads();          // wgt[] of every sample is in LDS
+    // ||h_j|| (a wave per sample) and, from the row a_j the wave has just read, its term of u = sum_j (w_j / c_j) a_j: every wave sums its own samples (in double), the
+    // four waves' partial rows are added at the end -- a second pass over A, one thread per column and 192 dependent additions long, is gone
+    constexpr int UK = 4;          // columns per lane (hd <= 256)
+    double uacc[UK] = {0.0, 0.0, 0.0, 0.0};
     for (int j = wave; j < s; j += 4) {
         const float *ar = a + (p0 + j) * as, *sr = sg_a + (p0 + j) * sgs;
+        float av[UK];
         double q = 0.0;
-        for (int k = lane; k < hd; k += 64) q += (double)ar[k] * (double)sr[k];
+#pragma unroll
+        for (int i = 0; i < UK; i++) { const int k = lane + 64 * i; av[i] = k < hd ? ar[k] : 0.0f; if (k < hd) q += (double)av[i] * (double)sr[k]; }
         q = lt_wave_sum(q);
         const float nr = (float)sqrt(q > 0.0 ? q : 0.0);
-        if (lane == 0) { cj[j] = fmaxf(nr, 1e-8f); pp[(p0 + j) * LTG_PP + 7] = nr; }
+        const float c = fmaxf(nr, 1e-8f);
+        if (lane == 0) { cj[j] = c; pp[(p0 + j) * LTG_PP + 7] = nr; }
+        const float wc = wgt[j] / c;
+#pragma unroll
+        for (int i = 0; i < UK; i++) uacc[i] += (double)(wc * av[i]);
     }
+    double *upart = reinterpret_cast<double *>(lds + 7 * s + (s & 1)) + s;          // [4][hd] behind dsum (the launch reserves it)
+#pragma unroll
+    for (int i = 0; i < UK; i++) { const int k = lane + 64 * i; if (k < hd) upart[wave * hd + k] = uacc[i]; }
     __syncthreads();
     for (int j = threadIdx.x; j < s; j += blockDim.x) {
         float *o = pp + (p0 + j) * LTG_PP;
@@ -305,9 +318,8 @@ __global__ void __launch_bounds__(256) k_ltg_ray_u(int s, int hd, const float *_
         if (weights_out) weights_out[p0 + j] = wgt[j];
     }
     if ((int)threadIdx.x < hd) {
-        double acc = 0.0;
-        for (int j = 0; j < s; j++) acc += (double)((wgt[j] / cj[j]) * a[(p0 + j) * as + threadIdx.x]);
-        u[ray * hd + threadIdx.x] = (float)acc;
+        const int k = threadIdx.x;
+        u[ray * hd + k] = (float)(((upart[k] + upart[hd + k]) + upart[2 * hd + k]) + upart[3 * hd + k]);
     }
 }
 
@@ -409,7 +421,7 @@ static bool lerf_train_gram(const nrf_mlp *m, int s)
     const bool on = st != 0;
     const int hd = m->small.hidden_dim, E = m->small.hidden_dim_color;
     (void)E;
-    return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(9 * s + hd + 2) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
+    return on && fp32_gemm_available() && m->small.num_layers >= 2 && hd <= 256 && (size_t)(9 * s + 9 * hd + 2) * sizeof(float) <= 60 * 1024 && !m->layers.back().d_bias;
 }
 
 // dw [E][hd] -= W [E][hd] . M [hd][hd]   (the Gram form's last term: a product of two small matrices, one thread per entry, k ascending)
@@ -509,7 +521,7 @@ static int head_backward_chunk(const nrf_mlp *m, const float *emb, const uint8_t
         const int arith = c >= 4096 ? train_gemm_for(m) : 0;               // the split-precision matrix-core products of gemm_bf16x3.hip instead of rocBLAS
         if (arith) NRF_TRY(gemm_nt_split(arith, c, hd, Seg{a, W, 0, hd}, none, gram, hd, sga, W, nullptr, 0, nullptr, 0, st));           // S = A G = A G^T (G symmetric): an NT product
         else NRF_TRY(gemm_rm(st, false, false, c, hd, hd, 1.0f, a, W, gram, hd, 0.0f, sga, W));                             // S = A G   (G symmetric)
-        hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)(7 * s + 1) * sizeof(float) + (size_t)s * sizeof(double), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
+        hipLaunchKernelGGL(k_ltg_ray_u, dim3((unsigned)rays), dim3(256), (size_t)(7 * s + 1) * sizeof(float) + (size_t)(s + 4 * hd) * sizeof(double), st, s, hd, h33, W, keep, z, dirs, d_stride, noise, noise_std, a, W,
                            (const float *)sga, W, pp, u, weights);
         NRF_LAUNCH_CHECK();
         const int arith_r = rays >= 256 ? arith : 0;                      // (the per-ray products: a few thousand rows)
