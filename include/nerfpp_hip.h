@@ -757,7 +757,7 @@ NRF_API int nrf_lerf_backward_points_src(const nrf_lerf_renderer *r, const void 
 
 /* The library's short-lived device buffers (a layer product's split operand image, slice sums, reduction cells) come from blocks it keeps per (device, stream) and reuses
  * from call to call -- not from hipMallocAsync, whose pool proved unsafe inside a LibTorch host (scratch.hip).  nrf_scratch_trim gives the idle blocks back to the driver
- * (waits for the streams they were last used on) and returns the bytes freed; optional. */
+ * (after a hipDeviceSynchronize of their devices) and returns the bytes freed; optional. */
 NRF_API size_t nrf_scratch_trim(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -37,9 +37,11 @@ hipError_t scratch_take(void **out, size_t bytes, hipStream_t st)
     void *p = nullptr;
     e = hipMalloc(&p, size);
     if (e != hipSuccess) {
-        // out of memory: give the idle blocks of this device back and try once more
+        // out of memory: give the idle blocks of this device back and try once more.  (The device is drained as a whole: a block's stream may have been destroyed since
+        // -- its handle must not be touched again)
+        (void)hipDeviceSynchronize();
         for (size_t i = 0; i < g_blocks.size();) {
-            if (!g_blocks[i].busy && g_blocks[i].device == dev) { (void)hipStreamSynchronize(g_blocks[i].st); (void)hipFree(g_blocks[i].p); g_blocks.erase(g_blocks.begin() + (long)i); }
+            if (!g_blocks[i].busy && g_blocks[i].device == dev) { (void)hipFree(g_blocks[i].p); g_blocks.erase(g_blocks.begin() + (long)i); }
             else i++;
         }
         (void)hipGetLastError();
@@ -65,10 +67,11 @@ size_t scratch_trim()
     std::lock_guard<std::mutex> lk(g_mu);
     size_t freed = 0;
     int cur = 0; (void)hipGetDevice(&cur);
+    int synced = -1;
     for (size_t i = 0; i < g_blocks.size();) {
         if (!g_blocks[i].busy) {
             (void)hipSetDevice(g_blocks[i].device);
-            (void)hipStreamSynchronize(g_blocks[i].st);
+            if (synced != g_blocks[i].device) { (void)hipDeviceSynchronize(); synced = g_blocks[i].device; }          // (never the block's stream handle: it may be gone)
             (void)hipFree(g_blocks[i].p);
             freed += g_blocks[i].size;
             g_blocks.erase(g_blocks.begin() + (long)i);
@@ -80,6 +83,6 @@ size_t scratch_trim()
 
 }  // namespace nrf
 
-/* Gives the library's idle scratch blocks back to the driver (waits for the streams they were last used on); returns the bytes freed.  Optional: the blocks are reused
+/* Gives the library's idle scratch blocks back to the driver (drains the device first); returns the bytes freed.  Optional: the blocks are reused
  * from call to call and amount to the peak of one stream's short-lived buffers. */
 extern "C" NRF_API size_t nrf_scratch_trim(void) { return nrf::scratch_trim(); }
